@@ -1,0 +1,291 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of ``oracle/liboracle.so`` (the dependency-free C++ restatement of the reference's
+hot path, see the headers in this directory for the reference file:line each function follows) and
+of ``oracle/_ref/libref_math.so`` (the REAL ``/root/reference/base/Math.h`` compiled where it lies).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The product package ``panovlm_amd`` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+KIND_P2PLANE_METER = 0
+KIND_P2PLANE_ANGLE = 1
+KIND_P2LINE_METER = 2
+KIND_P2LINE_ANGLE = 3
+KIND_PLANE2PLANE_GLOBAL = 4
+KIND_PLANE_IOU = 5
+STRIDE = {0: 8, 1: 8, 2: 10, 3: 10, 4: 10, 5: 12}
+
+
+def build(force=False):
+    """Compile the oracle (and, when /root/reference exists, oracle/_ref)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
+            for f in os.listdir(_HERE) if f.endswith((".hpp", ".cpp"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return so
+
+
+class OrcScan(C.Structure):
+    _fields_ = [
+        ("id", C.c_int), ("valid", C.c_int),
+        ("R_wl", C.POINTER(C.c_double)), ("t_wl", C.POINTER(C.c_double)),
+        ("n_flat", C.c_int), ("flat_xyz", C.POINTER(C.c_float)), ("flat_tag", C.POINTER(C.c_float)),
+        ("n_less", C.c_int), ("less_xyz", C.POINTER(C.c_float)), ("less_tag", C.POINTER(C.c_float)),
+        ("n_corner", C.c_int), ("corner_xyz", C.POINTER(C.c_float)),
+        ("p2s_offsets", C.POINTER(C.c_int)), ("p2s_ids", C.POINTER(C.c_int)),
+        ("n_seg", C.c_int), ("seg_size", C.POINTER(C.c_int)), ("seg_coeffs", C.POINTER(C.c_double)),
+        ("end_points", C.POINTER(C.c_double)),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_fast_atan2_f.restype = C.c_float
+        _LIB.orc_fast_atan2_f.argtypes = [C.c_float, C.c_float]
+        _LIB.orc_fast_atan2_d.restype = C.c_double
+        _LIB.orc_fast_atan2_d.argtypes = [C.c_double, C.c_double]
+    return _LIB
+
+
+def ref_math():
+    """The real reference Math.h build, or None when oracle/_ref is absent."""
+    global _REF
+    if _REF is None:
+        p = os.path.join(_HERE, "_ref", "libref_math.so")
+        if not os.path.exists(p):
+            return None
+        _REF = C.CDLL(p)
+        _REF.ref_fast_atan2_f.restype = C.c_float
+        _REF.ref_fast_atan2_f.argtypes = [C.c_float, C.c_float]
+        _REF.ref_fast_atan2_d.restype = C.c_double
+        _REF.ref_fast_atan2_d.argtypes = [C.c_double, C.c_double]
+    return _REF
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def evaluate(kind, rec, ref_id, nei_id, aa, t, normalize=False, jac=True, threads=0):
+    """AutoDiff-style evaluation of n residual blocks.  rec: n x STRIDE[kind]; returns (r, J|None)."""
+    rec = _f64(rec); aa = _f64(aa); t = _f64(t)
+    ref_id = _i32(ref_id); nei_id = _i32(nei_id)
+    n = rec.shape[0]
+    assert rec.shape[1] == STRIDE[kind]
+    r = np.empty(n, np.float64)
+    J = np.empty((n, 12), np.float64) if jac else None
+    rc = lib().orc_eval(C.c_int(kind), C.c_int(1 if normalize else 0), C.c_long(n), _p(rec, C.c_double),
+                        C.c_int(rec.shape[1]), _p(ref_id, C.c_int), _p(nei_id, C.c_int), _p(aa, C.c_double),
+                        _p(t, C.c_double), _p(r, C.c_double), _p(J, C.c_double), C.c_int(threads))
+    assert rc == 0
+    return r, J
+
+
+def huber(a, s):
+    s = _f64(s)
+    rho = np.empty((s.shape[0], 3), np.float64)
+    lib().orc_huber(C.c_double(a), C.c_long(s.shape[0]), _p(s, C.c_double), _p(rho, C.c_double))
+    return rho
+
+
+def angle_axis_to_matrix(aa):
+    aa = _f64(aa); R = np.empty(9, np.float64)
+    lib().orc_angle_axis_to_matrix(_p(aa, C.c_double), _p(R, C.c_double))
+    return R.reshape(3, 3).T.copy()  # column-major -> numpy row-major
+
+
+def matrix_to_angle_axis(R):
+    Rc = _f64(np.asarray(R).T.reshape(-1)); aa = np.empty(3, np.float64)
+    lib().orc_matrix_to_angle_axis(_p(Rc, C.c_double), _p(aa, C.c_double))
+    return aa
+
+
+def form_plane_lsq(pts, tol):
+    pts = _f64(pts); plane = np.empty(4, np.float64)
+    ok = lib().orc_form_plane_lsq(_p(pts, C.c_double), C.c_int(pts.shape[0]), C.c_double(tol), _p(plane, C.c_double))
+    return bool(ok), plane
+
+
+def form_line_pca(pts, tol, dis_thr=0.0):
+    pts = _f64(pts); line = np.empty(6, np.float64)
+    ok = lib().orc_form_line_pca(_p(pts, C.c_double), C.c_int(pts.shape[0]), C.c_double(tol), C.c_double(dis_thr), _p(line, C.c_double))
+    return bool(ok), line
+
+
+def eig_sym3(S):
+    S = _f64(S); w = np.empty(3, np.float64); V = np.empty((3, 3), np.float64)
+    lib().orc_eig_sym3(_p(S, C.c_double), _p(w, C.c_double), _p(V, C.c_double))
+    return w, V
+
+
+def knn(tgt, q, k):
+    tgt = _f32(tgt); q = _f32(q)
+    idx = np.empty((q.shape[0], k), np.int32); sqd = np.empty((q.shape[0], k), np.float32)
+    bad = lib().orc_knn(_p(tgt, C.c_float), C.c_int(tgt.shape[0]), _p(q, C.c_float), C.c_int(q.shape[0]), C.c_int(k),
+                        _p(idx, C.c_int), _p(sqd, C.c_float))
+    assert bad == 0
+    return idx, sqd
+
+
+class ScanArrays:
+    """Keeps numpy buffers alive for an OrcScan."""
+
+    def __init__(self, scan):
+        """scan: dict with optional keys id, valid, R_wl(3x3), t_wl(3), flat_xyz, flat_tag, less_xyz,
+        less_tag, corner_xyz, p2s (list of lists), seg_size, seg_coeffs(Sx6), end_points(Sx6)."""
+        g = scan.get
+        self.R = _f64(g("R_wl", np.eye(3))).reshape(-1)
+        self.t = _f64(g("t_wl", np.zeros(3)))
+        self.flat = _f32(g("flat_xyz", np.zeros((0, 3)))); self.flat_tag = _f32(g("flat_tag", np.ones(len(self.flat))))
+        self.less = _f32(g("less_xyz", np.zeros((0, 3)))); self.less_tag = _f32(g("less_tag", np.ones(len(self.less))))
+        self.corner = _f32(g("corner_xyz", np.zeros((0, 3))))
+        p2s = g("p2s", None)
+        if p2s is None:
+            p2s = [[] for _ in range(len(self.corner))]
+        off = np.zeros(len(p2s) + 1, np.int32)
+        for i, l in enumerate(p2s):
+            off[i + 1] = off[i] + len(l)
+        self.p2s_off = off
+        self.p2s_ids = _i32([v for l in p2s for v in l]) if off[-1] > 0 else np.zeros(1, np.int32)
+        self.seg_size = _i32(g("seg_size", np.zeros(0)))
+        self.seg_coeffs = _f64(g("seg_coeffs", np.zeros((0, 6))))
+        self.end_points = _f64(g("end_points", np.zeros((len(self.seg_size), 6))))
+        s = OrcScan()
+        s.id = int(g("id", 0)); s.valid = int(g("valid", 1))
+        s.R_wl = _p(self.R, C.c_double); s.t_wl = _p(self.t, C.c_double)
+        s.n_flat = len(self.flat); s.flat_xyz = _p(self.flat, C.c_float); s.flat_tag = _p(self.flat_tag, C.c_float)
+        s.n_less = len(self.less); s.less_xyz = _p(self.less, C.c_float); s.less_tag = _p(self.less_tag, C.c_float)
+        s.n_corner = len(self.corner); s.corner_xyz = _p(self.corner, C.c_float)
+        s.p2s_offsets = _p(self.p2s_off, C.c_int); s.p2s_ids = _p(self.p2s_ids, C.c_int)
+        s.n_seg = len(self.seg_size); s.seg_size = _p(self.seg_size, C.c_int)
+        s.seg_coeffs = _p(self.seg_coeffs, C.c_double); s.end_points = _p(self.end_points, C.c_double)
+        self.c = s
+
+
+def assoc_point2plane(ref, nei, tol, thr, want_knn=False):
+    """ref/nei: scan dicts (world-frame float clouds).  Returns dict(point, plane, qidx, nn[, knn_all])."""
+    r = ScanArrays(ref); n = ScanArrays(nei)
+    cap = max(1, n.c.n_flat)
+    pt = np.empty((cap, 3)); pl = np.empty((cap, 4)); qi = np.empty(cap, np.int32); nn = np.empty((cap, 10), np.int32)
+    kall = np.empty((cap, 10), np.int32) if want_knn else None
+    m = lib().orc_assoc_point2plane(C.byref(r.c), C.byref(n.c), C.c_double(tol), C.c_float(thr), _p(pt, C.c_double),
+                                    _p(pl, C.c_double), _p(qi, C.c_int), _p(nn, C.c_int), _p(kall, C.c_int))
+    out = dict(point=pt[:m].copy(), plane=pl[:m].copy(), qidx=qi[:m].copy(), nn=nn[:m].copy())
+    if want_knn:
+        out["knn_all"] = kall
+    return out
+
+
+def assoc_point2line(ref, nei, thr):
+    r = ScanArrays(ref); n = ScanArrays(nei)
+    cap = max(1, n.c.n_corner)
+    pt = np.empty((cap, 3)); a = np.empty((cap, 3)); b = np.empty((cap, 3)); qi = np.empty(cap, np.int32)
+    m = lib().orc_assoc_point2line(C.byref(r.c), C.byref(n.c), C.c_float(thr), _p(pt, C.c_double), _p(a, C.c_double),
+                                   _p(b, C.c_double), _p(qi, C.c_int))
+    return dict(point=pt[:m].copy(), a=a[:m].copy(), b=b[:m].copy(), qidx=qi[:m].copy())
+
+
+def assoc_line2line(ref, nei, thr):
+    r = ScanArrays(ref); n = ScanArrays(nei)
+    ns, rs = max(1, n.c.n_seg), max(1, r.c.n_seg)
+    ni = np.empty(ns, np.int32); ri = np.empty(ns, np.int32); p1 = np.empty((ns, 3)); p2 = np.empty((ns, 3))
+    votes = np.zeros((ns, rs), np.int32)
+    m = lib().orc_assoc_line2line(C.byref(r.c), C.byref(n.c), C.c_float(thr), _p(ni, C.c_int), _p(ri, C.c_int),
+                                  _p(p1, C.c_double), _p(p2, C.c_double), _p(votes, C.c_int))
+    return dict(nei_idx=ni[:m].copy(), ref_idx=ri[:m].copy(), p1=p1[:m].copy(), p2=p2[:m].copy(),
+                votes=votes[:n.c.n_seg, :r.c.n_seg].copy())
+
+
+def find_neighbors(poses, valid, neighbor_size):
+    """poses: F x 12 ([R_wl row-major | t_wl]).  Returns list of lists."""
+    poses = _f64(poses); valid = _i32(valid)
+    F = poses.shape[0]
+    cap = F * (neighbor_size + 4) + F * 64 + 16
+    off = np.empty(F + 1, np.int32); ids = np.empty(cap, np.int32)
+    tot = lib().orc_find_neighbors(C.c_int(F), _p(poses, C.c_double), _p(valid, C.c_int), C.c_int(neighbor_size),
+                                   _p(off, C.c_int), _p(ids, C.c_int), C.c_int(cap))
+    assert tot >= 0
+    return [ids[off[i]:off[i + 1]].tolist() for i in range(F)]
+
+
+def fast_atan2_f(y, x):
+    return float(lib().orc_fast_atan2_f(C.c_float(y), C.c_float(x)))
+
+
+def fast_atan2_d(y, x):
+    return float(lib().orc_fast_atan2_d(C.c_double(y), C.c_double(x)))
+
+
+def cam_to_image(rows, cols, cam):
+    cam = np.ascontiguousarray(cam)
+    if cam.dtype == np.float32:
+        px = np.empty((cam.shape[0], 2), np.float32)
+        lib().orc_cam_to_image_f(C.c_int(rows), C.c_int(cols), C.c_long(cam.shape[0]), _p(cam, C.c_float), _p(px, C.c_float))
+    else:
+        cam = _f64(cam); px = np.empty((cam.shape[0], 2), np.float64)
+        lib().orc_cam_to_image_d(C.c_int(rows), C.c_int(cols), C.c_long(cam.shape[0]), _p(cam, C.c_double), _p(px, C.c_double))
+    return px
+
+
+def image_to_cam(rows, cols, px, r=1.0):
+    px = np.ascontiguousarray(px)
+    if px.dtype == np.float32:
+        cam = np.empty((px.shape[0], 3), np.float32)
+        lib().orc_image_to_cam_f(C.c_int(rows), C.c_int(cols), C.c_long(px.shape[0]), _p(px, C.c_float), C.c_float(r), _p(cam, C.c_float))
+    else:
+        px = _f64(px); cam = np.empty((px.shape[0], 3), np.float64)
+        lib().orc_image_to_cam_d(C.c_int(rows), C.c_int(cols), C.c_long(px.shape[0]), _p(px, C.c_double), C.c_double(r), _p(cam, C.c_double))
+    return cam
+
+
+def break_to_segments(rows, cols, start, end, length):
+    s = _f32(start); e = _f32(end)
+    out = np.empty(4096, np.float32)
+    n = lib().orc_break_to_segments(C.c_int(rows), C.c_int(cols), _p(s, C.c_float), _p(e, C.c_float), C.c_float(length),
+                                    _p(out, C.c_float), C.c_int(4096))
+    assert n >= 0
+    return out[:2 * n].reshape(n, 2).copy()
+
+
+def assoc_by_angle(rows, cols, lines, lidar_local, T_cl, multiple=True):
+    lines = _f32(lines); T = _f64(T_cl).reshape(-1)
+    l = ScanArrays(lidar_local)
+    cap = max(16, lines.shape[0] * max(1, l.c.n_seg))
+    ii = np.empty(cap, np.int32); li = np.empty(cap, np.int32); sc = np.empty(cap, np.float32)
+    st = np.empty((cap, 3)); en = np.empty((cap, 3))
+    votes = np.zeros((lines.shape[0], max(1, l.c.n_seg)), np.int32)
+    m = lib().orc_assoc_by_angle(C.c_int(rows), C.c_int(cols), _p(lines, C.c_float), C.c_int(lines.shape[0]), C.byref(l.c),
+                                 _p(T, C.c_double), C.c_int(1 if multiple else 0), C.c_int(cap), _p(ii, C.c_int),
+                                 _p(li, C.c_int), _p(sc, C.c_float), _p(st, C.c_double), _p(en, C.c_double), _p(votes, C.c_int))
+    assert m >= 0
+    return dict(image_line_id=ii[:m].copy(), lidar_line_id=li[:m].copy(), score=sc[:m].copy(), start=st[:m].copy(),
+                end=en[:m].copy(), votes=votes)

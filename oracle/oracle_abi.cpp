@@ -1,0 +1,204 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (C ABI for ctypes). Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load liboracle.so; the product (panovlm_amd/, libpvlm.so)
+// never does. Restated reference functions and their file:line citations live in the headers.
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "associate.hpp"
+#include "costfunction.hpp"
+#include "equirect.hpp"
+
+using namespace oracle;
+
+extern "C" {
+
+typedef struct {
+  int id, valid;
+  const double* R_wl;   // 9 row-major
+  const double* t_wl;   // 3
+  int n_flat; const float* flat_xyz; const float* flat_tag;
+  int n_less; const float* less_xyz; const float* less_tag;
+  int n_corner; const float* corner_xyz;
+  const int* p2s_offsets; const int* p2s_ids;  // CSR over corner points
+  int n_seg; const int* seg_size; const double* seg_coeffs; const double* end_points;
+} orc_scan;
+
+}
+
+static Scan to_scan(const orc_scan* s) {
+  Scan o;
+  o.id = s->id; o.valid = s->valid != 0;
+  if (s->R_wl) std::memcpy(o.R_wl, s->R_wl, 9 * sizeof(double));
+  if (s->t_wl) std::memcpy(o.t_wl, s->t_wl, 3 * sizeof(double));
+  if (s->n_flat) { o.surfFlat.assign(s->flat_xyz, s->flat_xyz + 3 * size_t(s->n_flat)); o.surfFlat_tag.assign(s->flat_tag, s->flat_tag + s->n_flat); }
+  if (s->n_less) { o.surfLessFlat.assign(s->less_xyz, s->less_xyz + 3 * size_t(s->n_less)); o.surfLessFlat_tag.assign(s->less_tag, s->less_tag + s->n_less); }
+  if (s->n_corner) {
+    o.cornerLessSharp.assign(s->corner_xyz, s->corner_xyz + 3 * size_t(s->n_corner));
+    o.point_to_segment.resize(s->n_corner);
+    if (s->p2s_offsets)
+      for (int i = 0; i < s->n_corner; ++i) o.point_to_segment[i].assign(s->p2s_ids + s->p2s_offsets[i], s->p2s_ids + s->p2s_offsets[i + 1]);
+  }
+  if (s->n_seg) {
+    o.segment_size.assign(s->seg_size, s->seg_size + s->n_seg);
+    o.segment_coeffs.assign(s->seg_coeffs, s->seg_coeffs + 6 * size_t(s->n_seg));
+    if (s->end_points) o.end_points.assign(s->end_points, s->end_points + 6 * size_t(s->n_seg));
+  }
+  return o;
+}
+
+extern "C" {
+
+int orc_num_threads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+// kinds and record layouts (row-major n x stride doubles):
+//  0 Point2Plane_Meter  [P_n(3) plane(4) w]                       stride 8
+//  1 Point2Plane_Angle  [P_n(3) plane(4) w]   flags&1 = normalize  stride 8
+//  2 Point2Line_Meter   [P_n(3) A(3) B(3) w]                      stride 10
+//  3 Point2Line_Angle   [P_n(3) A(3) B(3) w]  flags&1 = normalize  stride 10
+//  4 Plane2Plane_Global [plane_ref(3) a(3) b(3) w]                stride 10
+//  5 PlaneIOUResidual   [ref_plane(4) mid_nei(3) mid_ref(3) angle w]  stride 12
+// ref_id/nei_id index the pose tables aa/t (F x 3 each). J may be NULL. threads<=0 -> all.
+int orc_eval(int kind, int flags, long n, const double* rec, int stride, const int* ref_id, const int* nei_id,
+             const double* aa, const double* t, double* r, double* J, int threads) {
+  const bool normalize = (flags & 1) != 0;
+#ifdef _OPENMP
+  const int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nt)
+#endif
+  for (long i = 0; i < n; ++i) {
+    const double* c = rec + size_t(i) * stride;
+    const double* aar = aa + 3 * size_t(ref_id[i]); const double* tr = t + 3 * size_t(ref_id[i]);
+    const double* aan = aa + 3 * size_t(nei_id[i]); const double* tn = t + 3 * size_t(nei_id[i]);
+    double* Ji = J ? J + 12 * size_t(i) : nullptr;
+    switch (kind) {
+      case 0: { Point2Plane_Meter f; std::memcpy(f.curr_point, c, 24); std::memcpy(f.plane, c + 3, 32); f.weight = c[7]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
+      case 1: { Point2Plane_Angle f; std::memcpy(f.curr_point, c, 24); std::memcpy(f.plane, c + 3, 32); f.weight = c[7]; f.normalize_distance = normalize; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
+      case 2: { Point2Line_Meter f; std::memcpy(f.curr_point, c, 24); f.SetLine(c + 3, c + 6); f.weight = c[9]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
+      case 3: { Point2Line_Angle f; std::memcpy(f.curr_point, c, 24); f.SetLine(c + 3, c + 6); f.weight = c[9]; f.normalize_distance = normalize; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
+      case 4: { Plane2Plane_Global f; f.SetPlane(c); std::memcpy(f.point_a, c + 3, 24); std::memcpy(f.point_b, c + 6, 24); f.weight = c[9]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
+      case 5: { PlaneIOUResidual f; f.SetPlane(c); std::memcpy(f.middle_neighbor, c + 4, 24); std::memcpy(f.middle_ref, c + 7, 24); f.angle = c[10]; f.weight = c[11]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
+      default: break;
+    }
+  }
+  return (kind >= 0 && kind <= 5) ? 0 : -1;
+}
+
+void orc_huber(double a, long n, const double* s, double* rho3) {
+  for (long i = 0; i < n; ++i) HuberLossEvaluate(a, s[i], rho3 + 3 * i);
+}
+
+void orc_angle_axis_to_matrix(const double* aa, double* R_colmajor) { AngleAxisToRotationMatrix(aa, R_colmajor); }
+void orc_matrix_to_angle_axis(const double* R_colmajor, double* aa) { RotationMatrixToAngleAxis(R_colmajor, aa); }
+void orc_angle_axis_rotate_point(const double* aa, const double* p, double* o) { AngleAxisRotatePoint(aa, p, o); }
+
+int orc_form_plane_lsq(const double* pts, int n, double tol, double* plane) { return FormPlaneLSQ(pts, n, tol, plane) ? 1 : 0; }
+int orc_form_line_pca(const double* pts, int n, double tol, double dis_thr, double* line) { return FormLinePCA(pts, n, tol, dis_thr, line) ? 1 : 0; }
+void orc_eig_sym3(const double* S, double* w, double* V) { eig_sym3_jacobi(S, w, V); }
+
+// exact float32 k-NN of nq queries in nt targets (xyz interleaved); idx/sqd are nq x k.
+int orc_knn(const float* tgt, int nt, const float* q, int nq, int k, int* idx, float* sqd) {
+  if (k > 32) return -1;
+  int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+#endif
+  for (int i = 0; i < nq; ++i)
+    if (!KnnBrute(tgt, nt, q + 3 * i, k, idx + size_t(i) * k, sqd + size_t(i) * k)) bad++;
+  return bad;
+}
+
+// Returns M; fills out_point (M x 3), out_plane (M x 4), out_qidx (M), optional out_nn (M x 10),
+// optional knn_all (nq x 10). Capacity of the outputs must be >= nei.n_flat.
+int orc_assoc_point2plane(const orc_scan* ref, const orc_scan* nei, double tol, float thr, double* out_point,
+                          double* out_plane, int* out_qidx, int* out_nn, int* knn_all) {
+  Scan r = to_scan(ref), n = to_scan(nei);
+  std::vector<int> dump;
+  std::vector<Point2Plane> a = AssociatePoint2Plane(r, n, tol, thr, knn_all ? &dump : nullptr);
+  for (size_t i = 0; i < a.size(); ++i) {
+    std::memcpy(out_point + 3 * i, a[i].point, 24);
+    std::memcpy(out_plane + 4 * i, a[i].plane, 32);
+    out_qidx[i] = a[i].query_index;
+    if (out_nn) std::memcpy(out_nn + 10 * i, a[i].nn, 40);
+  }
+  if (knn_all) std::memcpy(knn_all, dump.data(), dump.size() * sizeof(int));
+  return int(a.size());
+}
+
+int orc_assoc_point2line(const orc_scan* ref, const orc_scan* nei, float thr, double* out_point, double* out_a, double* out_b, int* out_qidx) {
+  Scan r = to_scan(ref), n = to_scan(nei);
+  std::vector<Point2Line> a = AssociatePoint2Line(r, n, thr);
+  for (size_t i = 0; i < a.size(); ++i) {
+    std::memcpy(out_point + 3 * i, a[i].point, 24); std::memcpy(out_a + 3 * i, a[i].a, 24); std::memcpy(out_b + 3 * i, a[i].b, 24);
+    out_qidx[i] = a[i].query_index;
+  }
+  return int(a.size());
+}
+
+// votes: n_nei_seg x n_ref_seg (optional). Outputs sized >= n_nei_seg.
+int orc_assoc_line2line(const orc_scan* ref, const orc_scan* nei, float thr, int* out_nei_idx, int* out_ref_idx,
+                        double* out_p1, double* out_p2, int* votes) {
+  Scan r = to_scan(ref), n = to_scan(nei);
+  std::vector<int> v;
+  std::vector<Line2Line> a = AssociateLine2Line(r, n, thr, votes ? &v : nullptr);
+  for (size_t i = 0; i < a.size(); ++i) {
+    out_nei_idx[i] = a[i].neighbor_line_idx; out_ref_idx[i] = a[i].ref_line_idx;
+    std::memcpy(out_p1 + 3 * i, a[i].p1, 24); std::memcpy(out_p2 + 3 * i, a[i].p2, 24);
+  }
+  if (votes && !v.empty()) std::memcpy(votes, v.data(), v.size() * sizeof(int));
+  return int(a.size());
+}
+
+// poses: F x 12 doubles [R_wl row-major (9) | t_wl (3)], valid: F ints. out CSR: offsets F+1, ids (cap).
+int orc_find_neighbors(int F, const double* poses, const int* valid, int neighbor_size, int* offsets, int* ids, int cap) {
+  std::vector<Scan> l(F);
+  for (int i = 0; i < F; ++i) { l[i].id = i; l[i].valid = valid[i] != 0; std::memcpy(l[i].R_wl, poses + 12 * i, 72); std::memcpy(l[i].t_wl, poses + 12 * i + 9, 24); }
+  auto nb = FindNeighbors(l, neighbor_size);
+  int o = 0;
+  for (int i = 0; i < F; ++i) {
+    offsets[i] = o;
+    for (int v : nb[i]) { if (o >= cap) return -1; ids[o++] = v; }
+  }
+  offsets[F] = o;
+  return o;
+}
+
+float orc_fast_atan2_f(float y, float x) { return FastAtan2<float>(y, x); }
+double orc_fast_atan2_d(double y, double x) { return FastAtan2<double>(y, x); }
+
+void orc_cam_to_image_f(int rows, int cols, long n, const float* cam, float* px) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.CamToImage(cam + 3 * i, px + 2 * i); }
+void orc_cam_to_image_d(int rows, int cols, long n, const double* cam, double* px) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.CamToImage(cam + 3 * i, px + 2 * i); }
+void orc_image_to_cam_f(int rows, int cols, long n, const float* px, float r, float* cam) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.ImageToCam(px + 2 * i, r, cam + 3 * i); }
+void orc_image_to_cam_d(int rows, int cols, long n, const double* px, double r, double* cam) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.ImageToCam(px + 2 * i, r, cam + 3 * i); }
+int orc_break_to_segments(int rows, int cols, const float* start, const float* end, float len, float* out, int cap) {
+  Equirectangular eq(rows, cols);
+  std::vector<float> s = eq.BreakToSegments(start, end, len);
+  if (int(s.size()) > cap) return -int(s.size());
+  std::memcpy(out, s.data(), s.size() * sizeof(float));
+  return int(s.size() / 2);
+}
+
+// lidar: LOCAL-frame scan (corner_xyz, CSR, seg_size, end_points). Outputs sized >= cap pairs.
+int orc_assoc_by_angle(int rows, int cols, const float* lines, int n_lines, const orc_scan* lidar, const double* T_cl,
+                       int multiple, int cap, int* out_img_id, int* out_lidar_id, float* out_score, double* out_start,
+                       double* out_end, int* votes) {
+  Scan l = to_scan(lidar);
+  ByAngleDebug dbg;
+  auto pairs = AssociateByAngle(rows, cols, lines, n_lines, l, T_cl, multiple != 0, votes ? &dbg : nullptr);
+  if (int(pairs.size()) > cap) return -int(pairs.size());
+  for (size_t i = 0; i < pairs.size(); ++i) {
+    out_img_id[i] = pairs[i].image_line_id; out_lidar_id[i] = pairs[i].lidar_line_id; out_score[i] = pairs[i].angle;
+    std::memcpy(out_start + 3 * i, pairs[i].lidar_line_start, 24); std::memcpy(out_end + 3 * i, pairs[i].lidar_line_end, 24);
+  }
+  if (votes) std::memcpy(votes, dbg.votes.data(), dbg.votes.size() * sizeof(int));
+  return int(pairs.size());
+}
+
+}  // extern "C"
