@@ -1,0 +1,202 @@
+/*
+ * pvlm.h — C ABI of the MI355X-native association + residual/Jacobian engine (libpvlm.so).
+ *
+ * This is the drop-in boundary for ONE hot path of 3dv-casia/PanoVLM: the ICP-style inner loop
+ * (LiDAR<->LiDAR / camera<->LiDAR correspondence search + residual/Jacobian evaluation).  Every
+ * entry point names the reference interface it replaces (paths relative to the PanoVLM tree).
+ * Plain pointers and sizes only; no exceptions cross the boundary; every function returns a
+ * pvlm_status (0 = OK, negative = error, message via pvlm_last_error).
+ *
+ * Threading: one pvlm_ctx per GPU; a ctx is NOT thread-safe, different ctxs are independent.
+ * Memory: buffers passed in are caller-owned and only read during the call unless stated.
+ * Host pointers unless a parameter is prefixed d_ (device pointer, same GPU as the ctx).
+ */
+#ifndef PVLM_H_
+#define PVLM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pvlm_ctx pvlm_ctx;
+typedef struct pvlm_resset pvlm_resset;   /* a device-resident set of residual blocks of one functor */
+typedef struct pvlm_neq pvlm_neq;         /* block-sparse normal equations (per-pose 6x6 blocks)     */
+typedef struct pvlm_scan pvlm_scan;       /* device-resident feature clouds of one LiDAR scan        */
+
+typedef enum {
+  PVLM_OK = 0,
+  PVLM_ERR_ARG = -1,      /* bad argument (NULL, negative size, unknown enum)             */
+  PVLM_ERR_HIP = -2,      /* HIP runtime error (no device, launch failure, ...)           */
+  PVLM_ERR_NOMEM = -3,    /* host or device allocation failed                             */
+  PVLM_ERR_STATE = -4,    /* call order violated (e.g. evaluate before pvlm_set_poses)    */
+  PVLM_ERR_CAPACITY = -5  /* caller-provided output buffer too small                      */
+} pvlm_status;
+
+/* Residual functors — base/CostFunction.h.  All are 1 residual x 4 parameter blocks of 3
+ * (angleAxis_rw, t_rw, angleAxis_nw, t_nw), i.e. AutoDiffCostFunction<F,1,3,3,3,3>. */
+typedef enum {
+  PVLM_POINT2PLANE_METER = 0,   /* base/CostFunction.h:567-619 ; row = [P_n(3) plane(4)]            stride 7  */
+  PVLM_POINT2PLANE_ANGLE = 1,   /* base/CostFunction.h:630-729 ; row = [P_n(3) plane(4)]            stride 7  */
+  PVLM_POINT2LINE_METER = 2,    /* base/CostFunction.h:769-829 ; row = [P_n(3) A(3) B(3)]           stride 9  */
+  PVLM_POINT2LINE_ANGLE = 3,    /* base/CostFunction.h:836-934 ; row = [P_n(3) A(3) B(3)]           stride 9  */
+  PVLM_PLANE2PLANE_GLOBAL = 4,  /* base/CostFunction.h:350-425 ; row = [plane_ref(3) a(3) b(3) w]   stride 10 */
+  PVLM_PLANE_IOU = 5            /* base/CostFunction.h:433-507 ; row = [plane(4) mid_n(3) mid_r(3) angle w] stride 12 */
+} pvlm_functor;
+
+#define PVLM_FLAG_NORMALIZE_DISTANCE 1u /* `normalize_distance` of the *_Angle functors (Config.h:117) */
+
+typedef enum {
+  PVLM_LOSS_NONE = 0,  /* loss_function == nullptr (util/Optimization.cpp:304,417)         */
+  PVLM_LOSS_HUBER = 1  /* ceres::HuberLoss(a)       (util/Optimization.cpp:513-517)        */
+} pvlm_loss;
+
+/* ---- context ------------------------------------------------------------------------------ */
+pvlm_status pvlm_create(int device, pvlm_ctx** ctx);
+pvlm_status pvlm_destroy(pvlm_ctx* ctx);
+const char* pvlm_last_error(const pvlm_ctx* ctx);   /* valid until the next call on ctx */
+const char* pvlm_version(void);
+/* Launch on an externally owned hipStream_t (e.g. the caller's framework stream); NULL selects
+ * the context's own stream.  Kernels of one ctx are always issued on exactly one stream. */
+pvlm_status pvlm_set_stream(pvlm_ctx* ctx, void* hip_stream);
+pvlm_status pvlm_synchronize(pvlm_ctx* ctx);
+/* HIP-event timing on the ctx stream (bench.py measures kernel time with these). */
+pvlm_status pvlm_timer_start(pvlm_ctx* ctx);
+pvlm_status pvlm_timer_stop(pvlm_ctx* ctx, float* elapsed_ms);   /* records, synchronises, returns ms */
+pvlm_status pvlm_device_info(pvlm_ctx* ctx, int* cu_count, int64_t* hbm_bytes, char* name, int name_cap);
+/* Per-kernel timing of the dominant kernels: when enabled, every launch of the fused
+ * residual/Jacobian kernel (which=0), the materialise kernel (which=1) and the k-NN + plane-fit
+ * association kernel (which=2) is bracketed by HIP events on the ctx stream.  pvlm_profile_read
+ * synchronises and returns the accumulated milliseconds and launch count since the last
+ * pvlm_profile_enable(ctx, 1). */
+pvlm_status pvlm_profile_enable(pvlm_ctx* ctx, int on);
+pvlm_status pvlm_profile_read(pvlm_ctx* ctx, int which, double* total_ms, int64_t* launches);
+
+/* ---- parameter blocks ---------------------------------------------------------------------- *
+ * The pose table the residual blocks index: angleAxis_lw_list / t_lw_list of
+ * lidar_mapping/LidarOdometry.cpp:23-33 (and angleAxis_cw_list / t_cw_list of
+ * joint_optimization/CameraLidarOptimizer.cpp:387-548 appended behind them).  n x 3 each. */
+pvlm_status pvlm_set_poses(pvlm_ctx* ctx, int n, const double* angle_axis, const double* translation);
+pvlm_status pvlm_set_poses_dev(pvlm_ctx* ctx, int n, const double* d_angle_axis, const double* d_translation);
+
+/* ---- residual sets ---------------------------------------------------------------------------- *
+ * Replaces the per-correspondence `X::Create(...)` + `problem.AddResidualBlock(cost, loss, aa_r,
+ * t_r, aa_n, t_n)` loops of util/Optimization.cpp:538-557 (point-to-plane), :410-434
+ * (line-to-line), :583-602 (camera-LiDAR).  Residual blocks are grouped in `n_pairs` segments;
+ * segment p = rows [pair_offsets[p], pair_offsets[p+1]) all share the parameter blocks
+ * (pair_ref[p], pair_nei[p]) — exactly the (i, n_idx) loop nest of the reference.  `rows` is
+ * n x stride doubles with the per-functor row layout given at pvlm_functor.  `weight` is the
+ * scalar weight of kinds 0..3 (ignored by the *_Angle functors, as in the reference). */
+pvlm_status pvlm_resset_upload(pvlm_ctx* ctx, pvlm_functor kind, unsigned flags, double weight, int64_t n,
+                               int n_pairs, const int64_t* pair_offsets, const int* pair_ref, const int* pair_nei,
+                               const double* rows, int stride, pvlm_resset** out);
+pvlm_status pvlm_resset_destroy(pvlm_ctx* ctx, pvlm_resset* rs);
+pvlm_status pvlm_resset_info(const pvlm_resset* rs, int64_t* n, int* n_pairs, int* kind, unsigned* flags);
+/* Copies the segment table / rows back (rows in the upload layout); any pointer may be NULL. */
+pvlm_status pvlm_resset_download(pvlm_ctx* ctx, const pvlm_resset* rs, int64_t* pair_offsets, int* pair_ref,
+                                 int* pair_nei, double* rows);
+
+/* ceres::CostFunction::Evaluate for every block of the set at the poses of pvlm_set_poses:
+ * residuals[n] and jacobians[n x 12] = [d/daa_r | d/dt_r | d/daa_n | d/dt_n] (row-major per block,
+ * the layout AutoDiffCostFunction<F,1,3,3,3,3> hands to Ceres).  jacobians may be NULL (cost-only
+ * evaluation).  Values are the RAW residuals (no loss applied), as Evaluate returns them. */
+pvlm_status pvlm_eval(pvlm_ctx* ctx, const pvlm_resset* rs, double* residuals, double* jacobians);
+/* Same, outputs left in device memory (async on the ctx stream; no host copies). */
+pvlm_status pvlm_eval_dev(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_residuals, double* d_jacobians);
+
+/* Fused evaluation: residual + Jacobian in registers, loss-corrected (Ceres corrector for
+ * rho'' <= 0: scale r and J by sqrt(rho')) and contracted into per-pair normal-equation blocks
+ *   out[p] = [ H_rr(36) | H_rn(36) | H_nn(36) | g_r(6) | g_n(6) | cost(1) ]   (121 doubles, row-major)
+ * with H = J^T J, g = J^T r, cost = sum 1/2 rho(r^2) over the segment.  Deterministic. */
+#define PVLM_PAIR_BLOCK 121
+pvlm_status pvlm_eval_pair_blocks(pvlm_ctx* ctx, const pvlm_resset* rs, pvlm_loss loss, double loss_a, double* out);
+pvlm_status pvlm_eval_pair_blocks_dev(pvlm_ctx* ctx, const pvlm_resset* rs, pvlm_loss loss, double loss_a, double* d_out);
+
+/* ---- block-sparse normal equations ------------------------------------------------------------ *
+ * The Gauss-Newton system the outer trust-region solver needs (what Ceres assembles internally
+ * from the blocks of ceres::Problem; LidarOdometry.cpp:36-80).  Packed layout (doubles):
+ *   [ Hdiag n_poses x 36 | Hoff n_upairs x 36 | g n_poses x 6 | cost 1 ]
+ * Hoff[u] is the 6x6 block d2/dx_i dx_j for the unordered pose pair (upair_i[u] < upair_j[u]).
+ * One RCCL all-reduce(sum) of this buffer per LM iteration is the only multi-GPU exchange. */
+pvlm_status pvlm_neq_create(pvlm_ctx* ctx, int n_poses, int n_upairs, const int* upair_i, const int* upair_j,
+                            pvlm_neq** out);
+pvlm_status pvlm_neq_destroy(pvlm_ctx* ctx, pvlm_neq* neq);
+int64_t pvlm_neq_size(const pvlm_neq* neq); /* number of doubles in the packed buffer */
+/* packed (+)= contribution of one residual set.  d_packed is a device buffer of pvlm_neq_size()
+ * doubles (e.g. the tensor handed to the all-reduce); zero_first!=0 clears it before adding. */
+pvlm_status pvlm_neq_accumulate_dev(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset* rs, pvlm_loss loss,
+                                    double loss_a, int zero_first, double* d_packed);
+pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset* rs, pvlm_loss loss, double loss_a,
+                                int zero_first, double* packed_host_inout);
+
+/* ---- scans and LiDAR<->LiDAR association -------------------------------------------------------- *
+ * Input contract = the public members of sensors/Velodyne.h:80-91 during association: feature
+ * clouds in the WORLD frame as float32 (the float buffers pcl::transformPointCloud left behind,
+ * sensors/Velodyne.cpp:1773-1808), class tag = PointXYZI::intensity, pose (R_wl, t_wl) double. */
+typedef struct {
+  int id;                     /* Velodyne::id — index into the pose table                         */
+  const double* R_wl;         /* 9, row-major                                                     */
+  const double* t_wl;         /* 3                                                                */
+  int n_surf_flat;            const float* surf_flat_xyz;      const float* surf_flat_tag;       /* queries  (xyz interleaved) */
+  int n_surf_less_flat;       const float* surf_less_flat_xyz; const float* surf_less_flat_tag;  /* targets                     */
+  int n_corner;               const float* corner_xyz;         /* cornerLessSharp                 */
+  const int* p2s_offsets;     const int* p2s_ids;              /* point_to_segment as CSR (n_corner+1) */
+  int n_segments;             const int* segment_size;         /* edge_segmented[s].size()        */
+  const double* segment_coeffs; /* 6 per segment, LiDAR-local (point, unit direction)             */
+  const double* end_points;     /* 2x3 per segment, LiDAR-local                                   */
+} pvlm_scan_desc;
+
+pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* desc, pvlm_scan** out);
+pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* scan);
+
+/* Exact k-nearest-neighbour search of `queries` (nq x 3 float, world frame) in the scan's
+ * surfLessFlat cloud (which=0) or cornerLessSharp cloud (which=1): what
+ * pcl::KdTreeFLANN<PointXYZI>::nearestKSearch returns at LidarFeatureAssociate.cpp:575 / :496 —
+ * float32 squared distances accumulated as ((dx*dx)+dy*dy)+dz*dz, ascending, ties by index.
+ * Neighbours farther than `max_dist` are not searched: rows with fewer than k neighbours within
+ * max_dist get idx = -1 / sqd = +inf in the missing slots.  k <= 16. */
+pvlm_status pvlm_knn(pvlm_ctx* ctx, const pvlm_scan* scan, int which, const float* queries, int nq, int k,
+                     float max_dist, int32_t* idx, float* sqd);
+
+/* AssociatePoint2Plane(ref, nei, plane_tolerance, dist_threshold) of
+ * lidar_mapping/LidarFeatureAssociate.cpp:550-630 for a BATCH of ordered scan pairs
+ * (ref[p], nei[p]); the result is the residual set util/Optimization.cpp:506-562
+ * (AddLidarPointToPlaneResidual) would have added for those pairs, in the same order:
+ * segment p holds the accepted correspondences of pair p in query order.
+ * kind = PVLM_POINT2PLANE_ANGLE or _METER (config.angle_residual), flags/weight as for upload. */
+pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei,
+                                   double plane_tolerance, float dist_threshold, pvlm_functor kind, unsigned flags,
+                                   double weight, pvlm_resset** out);
+/* Optional debug readback of the last pvlm_assoc_point2plane call: query index and the 10
+ * neighbour indices of every accepted correspondence (n x 1, n x 10). */
+pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, int32_t* query_idx, int32_t* nn_idx);
+
+/* Vote matrix of AssociateLine2Line (lidar_mapping/LidarFeatureAssociate.cpp:457-473):
+ * votes[nei_seg][ref_seg] = number of nei cornerLessSharp points of that nei segment whose
+ * PointToLineDistance3D to the ref segment's world line is <= dist_threshold.
+ * votes is n_nei_segments x n_ref_segments, row-major, int32. */
+pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm_scan* nei, float dist_threshold,
+                                 int32_t* votes);
+
+/* ---- equirectangular camera model + camera<->LiDAR voting --------------------------------------- */
+/* Equirectangular::CamToImage<T> (sensors/Equirectangular.h:173-182, FastAtan2 variant) for n
+ * points; cam n x 3, pixels n x 2.  _f32 mirrors the cv::Point3f overloads, _f64 the Eigen ones. */
+pvlm_status pvlm_cam_to_image_f32(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* cam, float* pixels);
+pvlm_status pvlm_cam_to_image_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, const double* cam, double* pixels);
+/* Equirectangular::ImageToCam<T> (sensors/Equirectangular.h:149-170). */
+pvlm_status pvlm_image_to_cam_f32(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* pixels, float r, float* cam);
+pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, const double* pixels, double r, double* cam);
+
+/* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
+ * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2
+ * pixels, n_lines x 4 float) and every LiDAR corner point (LiDAR-local float xyz, transformed by
+ * T_cl as pcl::transformPointCloud does) apply the 15 m range test and the two 3-degree angle tests
+ * and count votes per LiDAR segment.  votes is n_lines x n_segments int32. */
+pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float* lines, int n_lines,
+                                 const pvlm_scan* lidar_local, const double* T_cl_rowmajor16, int32_t* votes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVLM_H_ */

@@ -1,0 +1,358 @@
+"""ctypes binding of include/pvlm.h.  Thin: argument marshalling and error translation only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+POINT2PLANE_METER, POINT2PLANE_ANGLE, POINT2LINE_METER, POINT2LINE_ANGLE, PLANE2PLANE_GLOBAL, PLANE_IOU = range(6)
+FLAG_NORMALIZE_DISTANCE = 1
+LOSS_NONE, LOSS_HUBER = 0, 1
+PAIR_BLOCK = 121
+STRIDE = {0: 7, 1: 7, 2: 9, 3: 9, 4: 10, 5: 12}
+
+# every symbol include/pvlm.h declares (tests/test_abi.py checks the header and the .so against it)
+ABI_SYMBOLS = [
+    "pvlm_create", "pvlm_destroy", "pvlm_last_error", "pvlm_version", "pvlm_set_stream", "pvlm_synchronize",
+    "pvlm_timer_start", "pvlm_timer_stop", "pvlm_device_info", "pvlm_profile_enable", "pvlm_profile_read", "pvlm_set_poses", "pvlm_set_poses_dev",
+    "pvlm_resset_upload", "pvlm_resset_destroy", "pvlm_resset_info", "pvlm_resset_download", "pvlm_eval",
+    "pvlm_eval_dev", "pvlm_eval_pair_blocks", "pvlm_eval_pair_blocks_dev", "pvlm_neq_create", "pvlm_neq_destroy",
+    "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_scan_upload", "pvlm_scan_destroy",
+    "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
+    "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
+    "pvlm_cam_lidar_votes",
+]
+
+
+class PvlmError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libpvlm.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Loads libpvlm.so.  Raises if it has not been built (python -m panovlm_amd.build): the HIP
+    extension IS the product, nothing else can stand in for it."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise PvlmError("libpvlm.so is missing (%s): build it with `python -m panovlm_amd.build` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    try:
+        # PyTorch ships its own libamdhip64 with the same SONAME; when it is in the process it must
+        # be loaded first so that one HIP runtime serves both.
+        import sys
+        if "torch" in sys.modules or os.environ.get("PVLM_PRELOAD_TORCH", "0") == "1":
+            import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(p)
+    lib.pvlm_last_error.restype = C.c_char_p
+    lib.pvlm_version.restype = C.c_char_p
+    lib.pvlm_neq_size.restype = C.c_int64
+    _LIB = lib
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        rc = self.lib.pvlm_create(C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            raise PvlmError("pvlm_create(device=%d) failed with status %d: no usable HIP device "
+                            "(this package has no CPU path)" % (device, rc))
+        self.device = device
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PvlmError("%s failed (%d): %s" % (what, rc, self.lib.pvlm_last_error(self._h).decode()))
+
+    def close(self):
+        if self._h:
+            self.lib.pvlm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.pvlm_set_stream(self._h, C.c_void_p(stream_handle or 0)), "pvlm_set_stream")
+
+    def synchronize(self):
+        self._check(self.lib.pvlm_synchronize(self._h), "pvlm_synchronize")
+
+    def timer_start(self):
+        self._check(self.lib.pvlm_timer_start(self._h), "pvlm_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(self.lib.pvlm_timer_stop(self._h, C.byref(ms)), "pvlm_timer_stop")
+        return float(ms.value)
+
+    def device_info(self):
+        cu = C.c_int(); hbm = C.c_int64(); name = C.create_string_buffer(64)
+        self._check(self.lib.pvlm_device_info(self._h, C.byref(cu), C.byref(hbm), name, C.c_int(64)), "pvlm_device_info")
+        return dict(cu_count=cu.value, hbm_bytes=hbm.value, arch=name.value.decode())
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.pvlm_profile_enable(self._h, C.c_int(1 if on else 0)), "pvlm_profile_enable")
+
+    def profile_read(self, which=0):
+        ms = C.c_double(); n = C.c_int64()
+        self._check(self.lib.pvlm_profile_read(self._h, C.c_int(which), C.byref(ms), C.byref(n)), "pvlm_profile_read")
+        return float(ms.value), int(n.value)
+
+    def set_poses(self, angle_axis, translation):
+        aa = _f64(angle_axis).reshape(-1, 3); t = _f64(translation).reshape(-1, 3)
+        assert aa.shape == t.shape
+        self._check(self.lib.pvlm_set_poses(self._h, C.c_int(aa.shape[0]), _p(aa, C.c_double), _p(t, C.c_double)), "pvlm_set_poses")
+
+    def set_poses_dev(self, n, d_aa_ptr, d_t_ptr):
+        self._check(self.lib.pvlm_set_poses_dev(self._h, C.c_int(n), C.c_void_p(d_aa_ptr), C.c_void_p(d_t_ptr)), "pvlm_set_poses_dev")
+
+    # --- equirectangular -------------------------------------------------------------------------
+    def cam_to_image(self, rows, cols, cam):
+        cam = np.ascontiguousarray(cam)
+        n = cam.shape[0]
+        if cam.dtype == np.float32:
+            px = np.empty((n, 2), np.float32)
+            self._check(self.lib.pvlm_cam_to_image_f32(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), _p(cam, C.c_float), _p(px, C.c_float)), "pvlm_cam_to_image_f32")
+        else:
+            cam = _f64(cam); px = np.empty((n, 2), np.float64)
+            self._check(self.lib.pvlm_cam_to_image_f64(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), _p(cam, C.c_double), _p(px, C.c_double)), "pvlm_cam_to_image_f64")
+        return px
+
+    def image_to_cam(self, rows, cols, px, r=1.0):
+        px = np.ascontiguousarray(px)
+        n = px.shape[0]
+        if px.dtype == np.float32:
+            cam = np.empty((n, 3), np.float32)
+            self._check(self.lib.pvlm_image_to_cam_f32(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), _p(px, C.c_float), C.c_float(r), _p(cam, C.c_float)), "pvlm_image_to_cam_f32")
+        else:
+            px = _f64(px); cam = np.empty((n, 3), np.float64)
+            self._check(self.lib.pvlm_image_to_cam_f64(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), _p(px, C.c_double), C.c_double(r), _p(cam, C.c_double)), "pvlm_image_to_cam_f64")
+        return cam
+
+    def cam_lidar_votes(self, rows, cols, lines, lidar_scan, T_cl):
+        lines = _f32(lines).reshape(-1, 4); T = _f64(T_cl).reshape(16)
+        votes = np.zeros((lines.shape[0], max(1, lidar_scan.n_segments)), np.int32)
+        self._check(self.lib.pvlm_cam_lidar_votes(self._h, C.c_int(rows), C.c_int(cols), _p(lines, C.c_float), C.c_int(lines.shape[0]),
+                                                  lidar_scan._h, _p(T, C.c_double), _p(votes, C.c_int32)), "pvlm_cam_lidar_votes")
+        return votes[:, :lidar_scan.n_segments]
+
+    # --- association -------------------------------------------------------------------------------
+    def knn(self, scan, queries, k, max_dist, which=0):
+        q = _f32(queries).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), np.int32); sqd = np.empty((q.shape[0], k), np.float32)
+        self._check(self.lib.pvlm_knn(self._h, scan._h, C.c_int(which), _p(q, C.c_float), C.c_int(q.shape[0]), C.c_int(k),
+                                      C.c_float(max_dist), _p(idx, C.c_int32), _p(sqd, C.c_float)), "pvlm_knn")
+        return idx, sqd
+
+    def assoc_point2plane(self, refs, neis, plane_tolerance, dist_threshold, kind=POINT2PLANE_ANGLE,
+                          flags=FLAG_NORMALIZE_DISTANCE, weight=1.0):
+        n = len(refs)
+        assert n == len(neis)
+        ra = (C.c_void_p * max(n, 1))(*[s._h for s in refs])
+        na = (C.c_void_p * max(n, 1))(*[s._h for s in neis])
+        h = C.c_void_p()
+        self._check(self.lib.pvlm_assoc_point2plane(self._h, C.c_int(n), ra, na, C.c_double(plane_tolerance), C.c_float(dist_threshold),
+                                                    C.c_int(kind), C.c_uint(flags), C.c_double(weight), C.byref(h)), "pvlm_assoc_point2plane")
+        return ResidualSet(self, h)
+
+    def line2line_votes(self, ref, nei, dist_threshold):
+        votes = np.zeros((max(1, nei.n_segments), max(1, ref.n_segments)), np.int32)
+        self._check(self.lib.pvlm_line2line_votes(self._h, ref._h, nei._h, C.c_float(dist_threshold), _p(votes, C.c_int32)), "pvlm_line2line_votes")
+        return votes[:nei.n_segments, :ref.n_segments]
+
+
+class ResidualSet:
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._h = handle
+        n = C.c_int64(); p = C.c_int(); k = C.c_int(); f = C.c_uint()
+        ctx._check(ctx.lib.pvlm_resset_info(self._h, C.byref(n), C.byref(p), C.byref(k), C.byref(f)), "pvlm_resset_info")
+        self.n, self.n_pairs, self.kind, self.flags = n.value, p.value, k.value, f.value
+
+    @classmethod
+    def upload(cls, ctx, kind, rows, pair_offsets, pair_ref, pair_nei, flags=0, weight=1.0):
+        rows = _f64(rows).reshape(-1, STRIDE[kind]) if np.size(rows) else np.zeros((0, STRIDE[kind]))
+        po = _i64(pair_offsets); pr = _i32(pair_ref); pn = _i32(pair_nei)
+        h = C.c_void_p()
+        ctx._check(ctx.lib.pvlm_resset_upload(ctx._h, C.c_int(kind), C.c_uint(flags), C.c_double(weight), C.c_int64(rows.shape[0]),
+                                              C.c_int(len(pr)), _p(po, C.c_int64), _p(pr, C.c_int), _p(pn, C.c_int),
+                                              _p(rows, C.c_double), C.c_int(STRIDE[kind]), C.byref(h)), "pvlm_resset_upload")
+        return cls(ctx, h)
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.pvlm_resset_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def download(self):
+        po = np.empty(self.n_pairs + 1, np.int64); pr = np.empty(max(self.n_pairs, 1), np.int32); pn = np.empty(max(self.n_pairs, 1), np.int32)
+        rows = np.empty((max(self.n, 1), STRIDE[self.kind]), np.float64)
+        self.ctx._check(self.ctx.lib.pvlm_resset_download(self.ctx._h, self._h, _p(po, C.c_int64), _p(pr, C.c_int), _p(pn, C.c_int),
+                                                          _p(rows, C.c_double)), "pvlm_resset_download")
+        return po, pr[:self.n_pairs], pn[:self.n_pairs], rows[:self.n]
+
+    def eval(self, jac=True):
+        r = np.empty(max(self.n, 1), np.float64)
+        J = np.empty((max(self.n, 1), 12), np.float64) if jac else None
+        self.ctx._check(self.ctx.lib.pvlm_eval(self.ctx._h, self._h, _p(r, C.c_double), _p(J, C.c_double)), "pvlm_eval")
+        return r[:self.n], (J[:self.n] if jac else None)
+
+    def eval_dev(self, d_r_ptr, d_J_ptr):
+        self.ctx._check(self.ctx.lib.pvlm_eval_dev(self.ctx._h, self._h, C.c_void_p(d_r_ptr), C.c_void_p(d_J_ptr or 0)), "pvlm_eval_dev")
+
+    def pair_blocks(self, loss=LOSS_NONE, loss_a=0.0):
+        out = np.empty((max(self.n_pairs, 1), PAIR_BLOCK), np.float64)
+        self.ctx._check(self.ctx.lib.pvlm_eval_pair_blocks(self.ctx._h, self._h, C.c_int(loss), C.c_double(loss_a), _p(out, C.c_double)),
+                        "pvlm_eval_pair_blocks")
+        return out[:self.n_pairs]
+
+    def pair_blocks_dev(self, d_out_ptr, loss=LOSS_NONE, loss_a=0.0):
+        self.ctx._check(self.ctx.lib.pvlm_eval_pair_blocks_dev(self.ctx._h, self._h, C.c_int(loss), C.c_double(loss_a), C.c_void_p(d_out_ptr)),
+                        "pvlm_eval_pair_blocks_dev")
+
+    def assoc_debug(self):
+        q = np.empty(max(self.n, 1), np.int32); nn = np.empty((max(self.n, 1), 10), np.int32)
+        self.ctx._check(self.ctx.lib.pvlm_assoc_point2plane_debug(self.ctx._h, self._h, _p(q, C.c_int32), _p(nn, C.c_int32)),
+                        "pvlm_assoc_point2plane_debug")
+        return q[:self.n], nn[:self.n]
+
+
+class NormalEq:
+    def __init__(self, ctx, n_poses, upair_i, upair_j):
+        self.ctx = ctx
+        ui = _i32(upair_i); uj = _i32(upair_j)
+        self._h = C.c_void_p()
+        ctx._check(ctx.lib.pvlm_neq_create(ctx._h, C.c_int(n_poses), C.c_int(len(ui)), _p(ui, C.c_int), _p(uj, C.c_int), C.byref(self._h)),
+                   "pvlm_neq_create")
+        self.n_poses, self.n_upairs = n_poses, len(ui)
+        self.size = int(ctx.lib.pvlm_neq_size(self._h))
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.pvlm_neq_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def accumulate(self, rs, loss=LOSS_NONE, loss_a=0.0, packed=None):
+        zero_first = packed is None
+        buf = np.zeros(self.size, np.float64) if packed is None else _f64(packed)
+        self.ctx._check(self.ctx.lib.pvlm_neq_accumulate(self.ctx._h, self._h, rs._h, C.c_int(loss), C.c_double(loss_a),
+                                                         C.c_int(1 if zero_first else 0), _p(buf, C.c_double)), "pvlm_neq_accumulate")
+        return buf
+
+    def accumulate_dev(self, rs, d_packed_ptr, loss=LOSS_NONE, loss_a=0.0, zero_first=True):
+        self.ctx._check(self.ctx.lib.pvlm_neq_accumulate_dev(self.ctx._h, self._h, rs._h, C.c_int(loss), C.c_double(loss_a),
+                                                             C.c_int(1 if zero_first else 0), C.c_void_p(d_packed_ptr)), "pvlm_neq_accumulate_dev")
+
+    def unpack(self, packed):
+        n, u = self.n_poses, self.n_upairs
+        Hd = packed[:n * 36].reshape(n, 6, 6); Ho = packed[n * 36:(n + u) * 36].reshape(u, 6, 6)
+        g = packed[(n + u) * 36:(n + u) * 36 + n * 6].reshape(n, 6)
+        return Hd, Ho, g, float(packed[-1])
+
+
+class ScanDesc(C.Structure):
+    _fields_ = [
+        ("id", C.c_int), ("R_wl", C.POINTER(C.c_double)), ("t_wl", C.POINTER(C.c_double)),
+        ("n_surf_flat", C.c_int), ("surf_flat_xyz", C.POINTER(C.c_float)), ("surf_flat_tag", C.POINTER(C.c_float)),
+        ("n_surf_less_flat", C.c_int), ("surf_less_flat_xyz", C.POINTER(C.c_float)), ("surf_less_flat_tag", C.POINTER(C.c_float)),
+        ("n_corner", C.c_int), ("corner_xyz", C.POINTER(C.c_float)),
+        ("p2s_offsets", C.POINTER(C.c_int)), ("p2s_ids", C.POINTER(C.c_int)),
+        ("n_segments", C.c_int), ("segment_size", C.POINTER(C.c_int)),
+        ("segment_coeffs", C.POINTER(C.c_double)), ("end_points", C.POINTER(C.c_double)),
+    ]
+
+
+class Scan:
+    """Device-resident feature clouds of one LiDAR scan (the sensors/Velodyne.h:80-91 contract).
+    `scan` is a dict: id, R_wl, t_wl, flat_xyz, flat_tag, less_xyz, less_tag, corner_xyz, p2s,
+    seg_size, seg_coeffs, end_points (all optional except the pose)."""
+
+    def __init__(self, ctx, scan):
+        g = scan.get
+        self.ctx = ctx
+        R = _f64(g("R_wl", np.eye(3))).reshape(9); t = _f64(g("t_wl", np.zeros(3)))
+        flat = _f32(g("flat_xyz", np.zeros((0, 3)))); flat_tag = _f32(g("flat_tag", np.ones(len(flat))))
+        less = _f32(g("less_xyz", np.zeros((0, 3)))); less_tag = _f32(g("less_tag", np.ones(len(less))))
+        corner = _f32(g("corner_xyz", np.zeros((0, 3))))
+        p2s = g("p2s", None)
+        if p2s is None:
+            p2s = [[] for _ in range(len(corner))]
+        off = np.zeros(len(p2s) + 1, np.int32)
+        for i, l in enumerate(p2s):
+            off[i + 1] = off[i] + len(l)
+        ids = _i32([v for l in p2s for v in l]) if off[-1] > 0 else np.zeros(1, np.int32)
+        seg_size = _i32(g("seg_size", np.zeros(0)))
+        seg_coeffs = _f64(g("seg_coeffs", np.zeros((len(seg_size), 6))))
+        end_points = _f64(g("end_points", np.zeros((len(seg_size), 6))))
+        d = ScanDesc()
+        d.id = int(g("id", 0)); d.R_wl = _p(R, C.c_double); d.t_wl = _p(t, C.c_double)
+        d.n_surf_flat = len(flat); d.surf_flat_xyz = _p(flat, C.c_float); d.surf_flat_tag = _p(flat_tag, C.c_float)
+        d.n_surf_less_flat = len(less); d.surf_less_flat_xyz = _p(less, C.c_float); d.surf_less_flat_tag = _p(less_tag, C.c_float)
+        d.n_corner = len(corner); d.corner_xyz = _p(corner, C.c_float)
+        d.p2s_offsets = _p(off, C.c_int); d.p2s_ids = _p(ids, C.c_int)
+        d.n_segments = len(seg_size); d.segment_size = _p(seg_size, C.c_int)
+        d.segment_coeffs = _p(seg_coeffs, C.c_double); d.end_points = _p(end_points, C.c_double)
+        self._h = C.c_void_p()
+        ctx._check(ctx.lib.pvlm_scan_upload(ctx._h, C.byref(d), C.byref(self._h)), "pvlm_scan_upload")
+        self.id = d.id
+        self.n_segments = len(seg_size)
+        self.n_flat, self.n_less, self.n_corner = len(flat), len(less), len(corner)
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.pvlm_scan_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,557 @@
+// K5 / K6 — residual + Jacobian evaluation kernels (materialise and fused normal-equation modes)
+// and the small pose / pair table + epilogue kernels around them.  gfx950 (wave64) only.
+//
+// Data layout in HBM: a residual set is SoA, `ncols` fp64 columns of n_dev rows; every pair
+// segment starts on an even row so each lane streams two consecutive rows with one 16-byte load
+// per column (1 KiB per wave instruction).  The per-pair constants (R_rn, t_rn, t_rw, J_l blocks)
+// are read through wave-uniform (scalar) loads.  Algorithmic HBM traffic per evaluation in fused
+// mode = 8*ncols bytes (56 B point-to-plane); materialise mode adds 8 + 96 B of stores.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "pvlm_functors.h"
+#include "pvlm_internal.h"
+
+using namespace pvlm_dev;
+
+// ---------------------------------------------------------------------------------------------
+// pose table: R_lw = exp([aa]x) with the same small-angle branch as ceres::AngleAxisToRotationMatrix
+// (theta^2 <= DBL_EPSILON -> first order), and the SO(3) left Jacobian J_l(aa).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pose_table(int n, const double* __restrict__ aa, const double* __restrict__ t, double* __restrict__ tab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = aa[3 * i], y = aa[3 * i + 1], z = aa[3 * i + 2];
+  const double th2 = x * x + y * y + z * z;
+  double* o = tab + (size_t)i * PVLM_POSE_TAB;
+  double R[9];
+  if (th2 > 2.220446049250313e-16) {
+    const double th = sqrt(th2);
+    const double wx = x / th, wy = y / th, wz = z / th;
+    const double c = cos(th), s = sin(th), k = 1.0 - c;
+    R[0] = c + wx * wx * k;      R[1] = wx * wy * k - wz * s; R[2] = wy * s + wx * wz * k;
+    R[3] = wz * s + wx * wy * k; R[4] = c + wy * wy * k;      R[5] = -wx * s + wy * wz * k;
+    R[6] = -wy * s + wx * wz * k; R[7] = wx * s + wy * wz * k; R[8] = c + wz * wz * k;
+  } else {
+    R[0] = 1; R[1] = -z; R[2] = y; R[3] = z; R[4] = 1; R[5] = -x; R[6] = -y; R[7] = x; R[8] = 1;
+  }
+  double A, B;  // J_l = I + A [w]x + B [w]x^2
+  if (th2 > 1e-6) {
+    const double th = sqrt(th2);
+    A = (1.0 - cos(th)) / th2;
+    B = (th - sin(th)) / (th2 * th);
+  } else {
+    A = 0.5 - th2 * (1.0 / 24.0) + th2 * th2 * (1.0 / 720.0);
+    B = (1.0 / 6.0) - th2 * (1.0 / 120.0) + th2 * th2 * (1.0 / 5040.0);
+  }
+  // [w]x^2 = w w^T - th2 I
+  const double J[9] = {1.0 + B * (x * x - th2), -A * z + B * x * y,       A * y + B * x * z,
+                       A * z + B * x * y,       1.0 + B * (y * y - th2), -A * x + B * y * z,
+                       -A * y + B * x * z,      A * x + B * y * z,        1.0 + B * (z * z - th2)};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { o[k] = R[k]; o[9 + k] = J[k]; }
+  o[18] = t[3 * i]; o[19] = t[3 * i + 1]; o[20] = t[3 * i + 2];
+}
+
+// pair table: R_rn = R_r R_n^T, t_rn = t_r - R_rn t_n, t_rw = t_r, Jl_r, M_n = -R_rn Jl_n
+__global__ void k_pair_table(int P, const int* __restrict__ ref, const int* __restrict__ nei, int n_poses,
+                             const double* __restrict__ pose, double* __restrict__ tab) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int ir = ref[p], in = nei[p];
+  double* o = tab + (size_t)p * PVLM_PAIR_TAB;
+  if (ir >= n_poses || in >= n_poses) {  // out-of-table ids poison the segment instead of faulting
+    for (int k = 0; k < PVLM_PAIR_TAB; ++k) o[k] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
+  const double* a = pose + (size_t)ir * PVLM_POSE_TAB;
+  const double* b = pose + (size_t)in * PVLM_POSE_TAB;
+  double R[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = a[i * 3] * b[j * 3] + a[i * 3 + 1] * b[j * 3 + 1] + a[i * 3 + 2] * b[j * 3 + 2];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[k] = R[k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o[9 + i] = a[18 + i] - (R[i * 3] * b[18] + R[i * 3 + 1] * b[19] + R[i * 3 + 2] * b[20]);
+    o[12 + i] = a[18 + i];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[15 + k] = a[9 + k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[24 + i * 3 + j] = -(R[i * 3] * b[9 + j] + R[i * 3 + 1] * b[9 + 3 + j] + R[i * 3 + 2] * b[9 + 6 + j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// materialise: r[n], J[n x 12] in compact (host) order.
+// ---------------------------------------------------------------------------------------------
+template <int KIND, bool NORM, int NCOLS>
+__global__ __launch_bounds__(256) void k_eval_materialise(const double* __restrict__ cols, int64_t n_dev,
+                                                          const int64_t* __restrict__ seg_start,
+                                                          const int64_t* __restrict__ out_start,
+                                                          const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
+                                                          int chunk_rows, const double* __restrict__ pair_tab, double weight,
+                                                          double* __restrict__ r_out, double* __restrict__ J_out) {
+  const int p = blk_pair[blockIdx.x];
+  const int64_t s0 = seg_start[p];
+  const int64_t o0 = out_start[p];
+  const int64_t len = out_start[p + 1] - o0;
+  const int64_t lo = (int64_t)blk_chunk[blockIdx.x] * chunk_rows;
+  const int64_t hi = min(len, lo + (int64_t)chunk_rows);
+  double T[PVLM_PAIR_TAB];
+#pragma unroll
+  for (int k = 0; k < PVLM_PAIR_TAB; ++k) T[k] = pair_tab[(size_t)p * PVLM_PAIR_TAB + k];
+  for (int64_t j = lo + 2 * (int64_t)threadIdx.x; j < hi; j += 512) {
+    double2 v[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (j + h >= hi) break;
+      double rec[NCOLS];
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
+      Wrench w;
+      eval_wrench<KIND, NORM>(rec, T, weight, w);
+      const int64_t o = o0 + j + h;
+      r_out[o] = w.r;
+      if (J_out) {
+        double* J = J_out + (size_t)o * 12;
+        const double* Jl = T + 15; const double* Mn = T + 24; const double* R = T;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          J[k] = w.c[0] * Jl[k] + w.c[1] * Jl[3 + k] + w.c[2] * Jl[6 + k];
+          J[3 + k] = w.g[k];
+          J[6 + k] = w.c[0] * Mn[k] + w.c[1] * Mn[3 + k] + w.c[2] * Mn[6 + k];
+          J[9 + k] = -(w.g[0] * R[k] + w.g[1] * R[3 + k] + w.g[2] * R[6 + k]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused: per block partial [S upper(21) | gv(6) | cost(1)],  S = sum rho' v v^T, gv = sum rho' v r,
+// cost = sum 1/2 rho(r^2).  v = [c ; g] (the wrench).  Deterministic: fixed tree inside the block,
+// chunks summed in order by k_pair_epilogue.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+template <int KIND, bool NORM, int NCOLS, int LOSS>
+__global__ __launch_bounds__(256) void k_eval_fused(const double* __restrict__ cols, int64_t n_dev,
+                                                    const int64_t* __restrict__ seg_start,
+                                                    const int64_t* __restrict__ out_start,
+                                                    const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
+                                                    int chunk_rows, const double* __restrict__ pair_tab, double weight,
+                                                    double loss_a, double* __restrict__ partials) {
+  const int p = blk_pair[blockIdx.x];
+  const int64_t s0 = seg_start[p];
+  const int64_t len = out_start[p + 1] - out_start[p];
+  const int64_t lo = (int64_t)blk_chunk[blockIdx.x] * chunk_rows;
+  const int64_t hi = min(len, lo + (int64_t)chunk_rows);
+  double T[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) T[k] = pair_tab[(size_t)p * PVLM_PAIR_TAB + k];
+  double acc[PVLM_PARTIAL];
+#pragma unroll
+  for (int k = 0; k < PVLM_PARTIAL; ++k) acc[k] = 0.0;
+  const double a2 = loss_a * loss_a;
+  for (int64_t j = lo + 2 * (int64_t)threadIdx.x; j < hi; j += 512) {
+    double2 v[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (j + h >= hi) break;
+      double rec[NCOLS];
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
+      Wrench w;
+      eval_wrench<KIND, NORM>(rec, T, weight, w);
+      const double s = w.r * w.r;
+      double rho1 = 1.0, half_rho = 0.5 * s;
+      if (LOSS == PVLM_LOSS_HUBER) {
+        // ceres::HuberLoss(a): s > a^2 -> rho = 2 a sqrt(s) - a^2, rho' = a / sqrt(s)
+        if (s > a2) {
+          const double rr = sqrt(s);
+          half_rho = 0.5 * (2.0 * loss_a * rr - a2);
+          rho1 = fmax(std::numeric_limits<double>::min(), loss_a / rr);
+        }
+      }
+      const double vv[6] = {w.c[0], w.c[1], w.c[2], w.g[0], w.g[1], w.g[2]};
+      int q = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double wa = rho1 * vv[a];
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[q++] += wa * vv[b];
+        acc[21 + a] += wa * w.r;
+      }
+      acc[27] += half_rho;
+    }
+  }
+  __shared__ double red[4][PVLM_PARTIAL];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < PVLM_PARTIAL; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < PVLM_PARTIAL)
+    partials[(size_t)blockIdx.x * PVLM_PARTIAL + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// one block (128 threads) per pair: sum chunk partials in order, expand S, apply
+// D_r = blockdiag(Jl_r, I), D_n = blockdiag(M_n, -R_rn) and write the 121-double pair block.
+__global__ __launch_bounds__(128) void k_pair_epilogue(int P, const int* __restrict__ pair_blk_start,
+                                                       const double* __restrict__ partials,
+                                                       const double* __restrict__ pair_tab, double* __restrict__ out) {
+  const int p = blockIdx.x;
+  __shared__ double S[6][6], gv[6], Dr[6][6], Dn[6][6], cost;
+  __shared__ double tot[PVLM_PARTIAL];
+  const int t = threadIdx.x;
+  if (t < PVLM_PARTIAL) {
+    double s = 0.0;
+    for (int b = pair_blk_start[p]; b < pair_blk_start[p + 1]; ++b) s += partials[(size_t)b * PVLM_PARTIAL + t];
+    tot[t] = s;
+  }
+  if (t < 36) {
+    const int i = t / 6, j = t % 6;
+    const double* T = pair_tab + (size_t)p * PVLM_PAIR_TAB;
+    double dr = 0.0, dn = 0.0;
+    if (i < 3 && j < 3) { dr = T[15 + i * 3 + j]; dn = T[24 + i * 3 + j]; }
+    else if (i >= 3 && j >= 3) { dr = (i == j) ? 1.0 : 0.0; dn = -T[(i - 3) * 3 + (j - 3)]; }
+    Dr[i][j] = dr; Dn[i][j] = dn;
+  }
+  __syncthreads();
+  if (t < 36) {
+    const int i = t / 6, j = t % 6;
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    S[i][j] = tot[a * 6 - a * (a - 1) / 2 + (b - a)];
+  }
+  if (t < 6) gv[t] = tot[21 + t];
+  if (t == 0) cost = tot[27];
+  __syncthreads();
+  double* o = out + (size_t)p * PVLM_PAIR_BLOCK;
+  if (t < 108) {
+    const int blk = t / 36, i = (t % 36) / 6, j = t % 6;
+    const double(*L)[6] = (blk == 2) ? Dn : Dr;   // left factor (transposed)
+    const double(*Rm)[6] = (blk == 0) ? Dr : Dn;  // right factor
+    double s = 0.0;
+    for (int a = 0; a < 6; ++a) {
+      double u = 0.0;
+      for (int b = 0; b < 6; ++b) u += S[a][b] * Rm[b][j];
+      s += L[a][i] * u;
+    }
+    o[t] = s;
+  } else if (t < 120) {
+    const int i = (t - 108) % 6;
+    const double(*L)[6] = (t < 114) ? Dr : Dn;
+    double s = 0.0;
+    for (int a = 0; a < 6; ++a) s += L[a][i] * gv[a];
+    o[t] = s;
+  } else if (t == 120) {
+    o[120] = cost;
+  }
+}
+
+// packed normal equations: deterministic gather over the CSR lists built at bind time.
+__global__ void k_neq_gather(int n_poses, int n_upairs, const int* __restrict__ diag_off, const int* __restrict__ diag_items,
+                             const int* __restrict__ off_off, const int* __restrict__ off_items,
+                             const double* __restrict__ pair_blocks, int P, int zero_first, double* __restrict__ packed) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  double* Hd = packed;
+  double* Ho = packed + (size_t)n_poses * 36;
+  double* g = Ho + (size_t)n_upairs * 36;
+  double* cost = g + (size_t)n_poses * 6;
+  if (b < n_poses) {
+    if (t < 42) {
+      double s = 0.0;
+      for (int k = diag_off[b]; k < diag_off[b + 1]; ++k) {
+        const int it = diag_items[k];
+        const double* pb = pair_blocks + (size_t)(it >> 1) * PVLM_PAIR_BLOCK;
+        const int role = it & 1;
+        s += (t < 36) ? pb[(role ? 72 : 0) + t] : pb[108 + (role ? 6 : 0) + (t - 36)];
+      }
+      double* dst = (t < 36) ? &Hd[(size_t)b * 36 + t] : &g[(size_t)b * 6 + (t - 36)];
+      *dst = zero_first ? s : (*dst + s);
+    }
+  } else if (b < n_poses + n_upairs) {
+    const int u = b - n_poses;
+    if (t < 36) {
+      const int i = t / 6, j = t % 6;
+      double s = 0.0;
+      for (int k = off_off[u]; k < off_off[u + 1]; ++k) {
+        const int it = off_items[k];
+        const double* pb = pair_blocks + (size_t)(it >> 1) * PVLM_PAIR_BLOCK + 36;  // H_rn
+        s += (it & 1) ? pb[j * 6 + i] : pb[t];
+      }
+      double* dst = &Ho[(size_t)u * 36 + t];
+      *dst = zero_first ? s : (*dst + s);
+    }
+  } else {
+    // cost: single block, fixed-order tree over pairs
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int p = t; p < P; p += 256) s += pair_blocks[(size_t)p * PVLM_PAIR_BLOCK + 120];
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+    if (t == 0) *cost = zero_first ? red[0] : (*cost + red[0]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static pvlm_status ensure_pose_cap(pvlm_ctx* ctx, int n) {
+  if (n <= ctx->cap_poses) return PVLM_OK;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(ctx->d_aa); hipFree(ctx->d_t); hipFree(ctx->d_pose_tab);
+  ctx->d_aa = ctx->d_t = ctx->d_pose_tab = nullptr;
+  ctx->cap_poses = 0;
+  pvlm_status st;
+  if ((st = pvlm_i_alloc(ctx, &ctx->d_aa, (size_t)n * 3))) return st;
+  if ((st = pvlm_i_alloc(ctx, &ctx->d_t, (size_t)n * 3))) return st;
+  if ((st = pvlm_i_alloc(ctx, &ctx->d_pose_tab, (size_t)n * PVLM_POSE_TAB))) return st;
+  ctx->cap_poses = n;
+  return PVLM_OK;
+}
+
+static pvlm_status pose_table_launch(pvlm_ctx* ctx, int n, const double* d_aa, const double* d_t) {
+  if (n > 0) {
+    hipLaunchKernelGGL(k_pose_table, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_aa, d_t, ctx->d_pose_tab);
+    PVLM_HIP(ctx, hipGetLastError());
+  }
+  ctx->n_poses = n;
+  ctx->poses_set = true;
+  ctx->pose_epoch++;
+  return PVLM_OK;
+}
+
+static pvlm_status ensure_pair_table(pvlm_ctx* ctx, const pvlm_resset* crs) {
+  pvlm_resset* rs = const_cast<pvlm_resset*>(crs);
+  if (!ctx->poses_set) { PVLM_SET_ERR(ctx, "pvlm_set_poses must be called before evaluation"); return PVLM_ERR_STATE; }
+  for (int p = 0; p < rs->n_pairs; ++p)
+    if (rs->h_ref[p] >= ctx->n_poses || rs->h_nei[p] >= ctx->n_poses) {
+      PVLM_SET_ERR(ctx, "segment %d references pose %d/%d but only %d poses are set", p, rs->h_ref[p], rs->h_nei[p], ctx->n_poses);
+      return PVLM_ERR_STATE;
+    }
+  if (rs->pair_tab_epoch == ctx->pose_epoch || rs->n_pairs == 0) return PVLM_OK;
+  hipLaunchKernelGGL(k_pair_table, dim3((rs->n_pairs + 63) / 64), dim3(64), 0, ctx->stream, rs->n_pairs, rs->d_ref, rs->d_nei,
+                     ctx->n_poses, ctx->d_pose_tab, rs->d_pair_tab);
+  PVLM_HIP(ctx, hipGetLastError());
+  rs->pair_tab_epoch = ctx->pose_epoch;
+  return PVLM_OK;
+}
+
+template <int KIND, bool NORM, int NCOLS>
+static void launch_materialise(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_r, double* d_J) {
+  hipLaunchKernelGGL((k_eval_materialise<KIND, NORM, NCOLS>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_cols, rs->n_dev,
+                     rs->d_seg_start, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_r, d_J);
+}
+
+template <int KIND, bool NORM, int NCOLS>
+static void launch_fused(pvlm_ctx* ctx, const pvlm_resset* rs, int loss, double a) {
+  if (loss == PVLM_LOSS_HUBER)
+    hipLaunchKernelGGL((k_eval_fused<KIND, NORM, NCOLS, PVLM_LOSS_HUBER>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_cols,
+                       rs->n_dev, rs->d_seg_start, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab,
+                       rs->weight, a, rs->d_partials);
+  else
+    hipLaunchKernelGGL((k_eval_fused<KIND, NORM, NCOLS, PVLM_LOSS_NONE>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_cols,
+                       rs->n_dev, rs->d_seg_start, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab,
+                       rs->weight, a, rs->d_partials);
+}
+
+#define PVLM_DISPATCH(FN, ...)                                                                         \
+  do {                                                                                                 \
+    const bool nz = (rs->flags & PVLM_FLAG_NORMALIZE_DISTANCE) != 0;                                   \
+    switch (rs->kind) {                                                                                \
+      case PVLM_POINT2PLANE_METER: FN<PVLM_POINT2PLANE_METER, false, 7>(__VA_ARGS__); break;           \
+      case PVLM_POINT2PLANE_ANGLE:                                                                     \
+        if (nz) FN<PVLM_POINT2PLANE_ANGLE, true, 7>(__VA_ARGS__);                                      \
+        else FN<PVLM_POINT2PLANE_ANGLE, false, 7>(__VA_ARGS__);                                        \
+        break;                                                                                         \
+      case PVLM_POINT2LINE_METER: FN<PVLM_POINT2LINE_METER, false, 9>(__VA_ARGS__); break;             \
+      case PVLM_POINT2LINE_ANGLE:                                                                      \
+        if (nz) FN<PVLM_POINT2LINE_ANGLE, true, 9>(__VA_ARGS__);                                       \
+        else FN<PVLM_POINT2LINE_ANGLE, false, 9>(__VA_ARGS__);                                         \
+        break;                                                                                         \
+      case PVLM_PLANE2PLANE_GLOBAL: FN<PVLM_PLANE2PLANE_GLOBAL, false, 10>(__VA_ARGS__); break;        \
+      case PVLM_PLANE_IOU: FN<PVLM_PLANE_IOU, false, 12>(__VA_ARGS__); break;                          \
+    }                                                                                                  \
+  } while (0)
+
+extern "C" {
+
+pvlm_status pvlm_set_poses(pvlm_ctx* ctx, int n, const double* aa, const double* t) {
+  if (!ctx || n < 0 || (n > 0 && (!aa || !t))) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ensure_pose_cap(ctx, n);
+  if (st) return st;
+  if (n > 0) {
+    PVLM_HIP(ctx, hipMemcpyAsync(ctx->d_aa, aa, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PVLM_HIP(ctx, hipMemcpyAsync(ctx->d_t, t, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable host memory: caller may reuse the buffers
+  }
+  return pose_table_launch(ctx, n, ctx->d_aa, ctx->d_t);
+}
+
+pvlm_status pvlm_set_poses_dev(pvlm_ctx* ctx, int n, const double* d_aa, const double* d_t) {
+  if (!ctx || n < 0 || (n > 0 && (!d_aa || !d_t))) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ensure_pose_cap(ctx, n);
+  if (st) return st;
+  return pose_table_launch(ctx, n, d_aa, d_t);
+}
+
+pvlm_status pvlm_eval_dev(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_r, double* d_J) {
+  if (!ctx || !rs || !d_r) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ensure_pair_table(ctx, rs);
+  if (st) return st;
+  if (rs->n_blocks == 0) return PVLM_OK;
+  {
+    pvlm_prof_scope prof(ctx, 1);
+    PVLM_DISPATCH(launch_materialise, ctx, rs, d_r, d_J);
+  }
+  PVLM_HIP(ctx, hipGetLastError());
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_eval(pvlm_ctx* ctx, const pvlm_resset* rs, double* r, double* J) {
+  if (!ctx || !rs || (rs->n > 0 && !r)) return PVLM_ERR_ARG;
+  if (rs->n == 0) return ensure_pair_table(ctx, rs);
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  double *d_r = nullptr, *d_J = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_r, (size_t)rs->n);
+  if (!st && J) st = pvlm_i_alloc(ctx, &d_J, (size_t)rs->n * 12);
+  if (!st) st = pvlm_eval_dev(ctx, rs, d_r, d_J);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(r, d_r, (size_t)rs->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && J) e = hipMemcpyAsync(J, d_J, (size_t)rs->n * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_eval copy-back: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_r); hipFree(d_J);
+  return st;
+}
+
+pvlm_status pvlm_eval_pair_blocks_dev(pvlm_ctx* ctx, const pvlm_resset* rs, pvlm_loss loss, double a, double* d_out) {
+  if (!ctx || !rs || !d_out || (loss != PVLM_LOSS_NONE && loss != PVLM_LOSS_HUBER)) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ensure_pair_table(ctx, rs);
+  if (st) return st;
+  if (rs->n_pairs == 0) return PVLM_OK;
+  if (rs->n_blocks > 0) {
+    pvlm_prof_scope prof(ctx, 0);
+    PVLM_DISPATCH(launch_fused, ctx, rs, (int)loss, a);
+    PVLM_HIP(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_pair_epilogue, dim3(rs->n_pairs), dim3(128), 0, ctx->stream, rs->n_pairs, rs->d_pair_blk_start, rs->d_partials,
+                     rs->d_pair_tab, d_out);
+  PVLM_HIP(ctx, hipGetLastError());
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_eval_pair_blocks(pvlm_ctx* ctx, const pvlm_resset* rs, pvlm_loss loss, double a, double* out) {
+  if (!ctx || !rs || (rs->n_pairs > 0 && !out)) return PVLM_ERR_ARG;
+  pvlm_status st = pvlm_eval_pair_blocks_dev(ctx, rs, loss, a, rs->d_pair_blocks);
+  if (st) return st;
+  if (rs->n_pairs > 0) {
+    PVLM_HIP(ctx, hipMemcpyAsync(out, rs->d_pair_blocks, (size_t)rs->n_pairs * PVLM_PAIR_BLOCK * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return PVLM_OK;
+}
+
+static pvlm_status neq_bind(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs) {
+  if (q->bound == rs) return PVLM_OK;
+  const int P = rs->n_pairs;
+  std::vector<std::vector<int>> diag(q->n_poses), off(q->n_upairs);
+  // unordered pair lookup
+  std::vector<std::pair<long long, int>> key(q->n_upairs);
+  for (int u = 0; u < q->n_upairs; ++u) key[u] = {(long long)q->ui[u] * q->n_poses + q->uj[u], u};
+  std::sort(key.begin(), key.end());
+  for (int p = 0; p < P; ++p) {
+    const int r = rs->h_ref[p], n = rs->h_nei[p];
+    if (r >= q->n_poses || n >= q->n_poses) { PVLM_SET_ERR(ctx, "segment %d pose id outside the normal-equation structure", p); return PVLM_ERR_ARG; }
+    if (r == n) { PVLM_SET_ERR(ctx, "segment %d has ref == nei", p); return PVLM_ERR_ARG; }
+    diag[r].push_back(p * 2 + 0);
+    diag[n].push_back(p * 2 + 1);
+    const int i = std::min(r, n), j = std::max(r, n);
+    const long long k = (long long)i * q->n_poses + j;
+    auto it = std::lower_bound(key.begin(), key.end(), std::make_pair(k, -1));
+    if (it == key.end() || it->first != k) { PVLM_SET_ERR(ctx, "pose pair (%d,%d) of segment %d missing from the upair list", i, j, p); return PVLM_ERR_ARG; }
+    off[it->second].push_back(p * 2 + (r < n ? 0 : 1));  // H_rn is d2/dx_r dx_n; transposed when r is the larger index
+  }
+  std::vector<int> doff(q->n_poses + 1, 0), ditems, ooff(q->n_upairs + 1, 0), oitems;
+  for (int i = 0; i < q->n_poses; ++i) { doff[i] = (int)ditems.size(); ditems.insert(ditems.end(), diag[i].begin(), diag[i].end()); }
+  doff[q->n_poses] = (int)ditems.size();
+  for (int u = 0; u < q->n_upairs; ++u) { ooff[u] = (int)oitems.size(); oitems.insert(oitems.end(), off[u].begin(), off[u].end()); }
+  ooff[q->n_upairs] = (int)oitems.size();
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(q->d_diag_off); hipFree(q->d_diag_items); hipFree(q->d_off_off); hipFree(q->d_off_items);
+  q->d_diag_off = q->d_diag_items = q->d_off_off = q->d_off_items = nullptr;
+  pvlm_status st;
+  if ((st = pvlm_i_alloc(ctx, &q->d_diag_off, doff.size()))) return st;
+  if ((st = pvlm_i_alloc(ctx, &q->d_diag_items, ditems.size()))) return st;
+  if ((st = pvlm_i_alloc(ctx, &q->d_off_off, ooff.size()))) return st;
+  if ((st = pvlm_i_alloc(ctx, &q->d_off_items, oitems.size()))) return st;
+  PVLM_HIP(ctx, hipMemcpy(q->d_diag_off, doff.data(), doff.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!ditems.empty()) PVLM_HIP(ctx, hipMemcpy(q->d_diag_items, ditems.data(), ditems.size() * sizeof(int), hipMemcpyHostToDevice));
+  PVLM_HIP(ctx, hipMemcpy(q->d_off_off, ooff.data(), ooff.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!oitems.empty()) PVLM_HIP(ctx, hipMemcpy(q->d_off_items, oitems.data(), oitems.size() * sizeof(int), hipMemcpyHostToDevice));
+  q->bound = rs;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_neq_accumulate_dev(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs, pvlm_loss loss, double a, int zero_first,
+                                    double* d_packed) {
+  if (!ctx || !q || !rs || !d_packed) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = neq_bind(ctx, q, rs);
+  if (st) return st;
+  st = pvlm_eval_pair_blocks_dev(ctx, rs, loss, a, rs->d_pair_blocks);
+  if (st) return st;
+  hipLaunchKernelGGL(k_neq_gather, dim3(q->n_poses + q->n_upairs + 1), dim3(256), 0, ctx->stream, q->n_poses, q->n_upairs, q->d_diag_off,
+                     q->d_diag_items, q->d_off_off, q->d_off_items, rs->d_pair_blocks, rs->n_pairs, zero_first, d_packed);
+  PVLM_HIP(ctx, hipGetLastError());
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs, pvlm_loss loss, double a, int zero_first, double* packed) {
+  if (!ctx || !q || !rs || !packed) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t nb = (size_t)pvlm_neq_size(q) * sizeof(double);
+  double* d = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d, (size_t)pvlm_neq_size(q));
+  if (st) return st;
+  hipError_t e = hipSuccess;
+  if (!zero_first) e = hipMemcpyAsync(d, packed, nb, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { hipFree(d); PVLM_SET_ERR(ctx, "neq upload: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  st = pvlm_neq_accumulate_dev(ctx, q, rs, loss, a, zero_first, d);
+  if (!st) {
+    e = hipMemcpyAsync(packed, d, nb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "neq download: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  return st;
+}
+
+}  // extern "C"

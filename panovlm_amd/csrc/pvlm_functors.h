@@ -1,0 +1,207 @@
+// Device-side closed-form residual + gradient of the six hot functors of base/CostFunction.h.
+//
+// Every functor of the reference evaluates   P_r = R(aa_rw) R(-aa_nw) (P_n - t_nw) + t_rw
+// (base/CostFunction.h:585-604 for the point functors, :369-403 / :466-486 for the two plane
+// functors, whose via-world chain is the same map) and then a scalar residual r(P_r).  With
+// g = dr/dP_r, m = P_r - t_rw and the left Jacobian J_l of SO(3) the AutoDiff row is
+//   d r/d aa_rw = (m x g)^T J_l(aa_rw)        d r/d t_rw = g^T
+//   d r/d aa_nw = (m x g)^T (-R_rn J_l(aa_nw))   d r/d t_nw = g^T (-R_rn)
+// so each functor only has to produce r and the "wrench" v = [c = sum m_k x g_k ; g = sum g_k]
+// (one term per transformed point).  Branches follow the VALUE of the residual exactly like
+// ceres::Jet does (abs'(x) = x<0 ? -1 : +1, clamped acos returns a constant, early-outs return 0).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pvlm_internal.h"
+
+namespace pvlm_dev {
+
+struct Wrench { double r; double c[3]; double g[3]; };
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// VectorAngle3D (base/Geometry.hpp:450-466), un-normalised form, with gradients wrt v1, v2.
+// Returns false when the clamped branches (constant result, zero gradient) were taken.
+__device__ __forceinline__ bool angle_between(const double* v1, const double* v2, double& r, double* g1, double* g2) {
+  const double d = dot3(v1, v2);
+  const double q1 = dot3(v1, v1), q2 = dot3(v2, v2);
+  const double n1 = sqrt(q1), n2 = sqrt(q2);
+  const double inv = 1.0 / (n1 * n2);
+  const double c = d * inv;
+  if (c >= 1.0) { r = 0.0; return false; }
+  if (c <= -1.0) { r = M_PI; return false; }
+  r = acos(c);
+  const double drdc = -1.0 / sqrt(1.0 - c * c);
+  const double k1 = c / q1, k2 = c / q2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    g1[k] = drdc * (v2[k] * inv - k1 * v1[k]);
+    g2[k] = drdc * (v1[k] * inv - k2 * v2[k]);
+  }
+  return true;
+}
+
+// Tail shared by Point2Plane_Angle / Point2Line_Angle (base/CostFunction.h:695-717, :899-920):
+// r = angle(P, Pp) or, with normalize_distance, the angle seen from the centre placed 1 m
+// before Pp on the ray O->Pp.  Outputs gradients wrt P (direct) and wrt Pp.
+template <bool NORM>
+__device__ __forceinline__ bool normalized_angle(const double* P, const double* Pp, double& r, double* gP, double* gPp) {
+  if (NORM) {
+    const double nu2 = dot3(Pp, Pp);
+    const double nu = sqrt(nu2);
+    const double ratio = (nu - 1.0) / nu;
+    double v1[3], v2[3], g1[3], g2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double ck = ratio * Pp[k]; v1[k] = Pp[k] - ck; v2[k] = P[k] - ck; }
+    if (!angle_between(v1, v2, r, g1, g2)) return false;
+    // c = ratio(Pp) * Pp, d ratio / d Pp = Pp / nu^3 ; cotangent of c is -(g1+g2)
+    double gc[3] = {-(g1[0] + g2[0]), -(g1[1] + g2[1]), -(g1[2] + g2[2])};
+    const double s = dot3(Pp, gc) / (nu2 * nu);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gP[k] = g2[k]; gPp[k] = g1[k] + ratio * gc[k] + s * Pp[k]; }
+    return true;
+  }
+  return angle_between(P, Pp, r, gP, gPp);
+}
+
+// ---- single-point functors: r and g = dr/dP_r -------------------------------------------------
+// rec = SoA row (see pvlm_ctx.hip for the column layout)
+template <int KIND, bool NORM>
+__device__ __forceinline__ void residual_grad(const double* P, const double* rec, double w, double& r, double* g) {
+  g[0] = g[1] = g[2] = 0.0;
+  r = 0.0;
+  if (KIND == PVLM_POINT2PLANE_METER) {
+    // base/CostFunction.h:606-607, Geometry.hpp:275-283 (normalized=true)
+    const double* n = rec + 3;
+    const double sd = n[0] * P[0] + n[1] * P[1] + n[2] * P[2] + n[3];
+    const double s = sd < 0.0 ? -w : w;
+    r = s * sd;
+    g[0] = s * n[0]; g[1] = s * n[1]; g[2] = s * n[2];
+  } else if (KIND == PVLM_POINT2PLANE_ANGLE) {
+    // base/CostFunction.h:679-717 (weight is NOT applied by the reference)
+    const double* n = rec + 3;
+    const double sd = n[0] * P[0] + n[1] * P[1] + n[2] * P[2] + n[3];
+    const double s = sd < 0.0 ? -1.0 : 1.0;
+    const double dis = s * sd;
+    if (dis < 1e-3) return;
+    double Pp[3] = {P[0] - dis * n[0], P[1] - dis * n[1], P[2] - dis * n[2]};
+    double sig = 1.0;
+    if (fabs(n[0] * Pp[0] + n[1] * Pp[1] + n[2] * Pp[2] + n[3]) > 1e-4) {
+      Pp[0] = P[0] + dis * n[0]; Pp[1] = P[1] + dis * n[1]; Pp[2] = P[2] + dis * n[2];
+      sig = -1.0;
+    }
+    double gP[3], gPp[3];
+    if (!normalized_angle<NORM>(P, Pp, r, gP, gPp)) return;
+    // Pp = P - sig*s*(n.P+d) n  ->  dPp/dP = I - sig*s n n^T
+    const double t = sig * s * dot3(n, gPp);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = gP[k] + gPp[k] - t * n[k];
+  } else if (KIND == PVLM_POINT2LINE_METER) {
+    // base/CostFunction.h:813-815, Geometry.hpp:198-211
+    const double* A = rec + 3; const double* d = rec + 6;
+    const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const double k = (d[0] * (P[0] - A[0]) + d[1] * (P[1] - A[1]) + d[2] * (P[2] - A[2])) / dd;
+    const double e[3] = {k * d[0] + A[0] - P[0], k * d[1] + A[1] - P[1], k * d[2] + A[2] - P[2]};
+    const double dist = sqrt(dot3(e, e));
+    r = w * dist;
+    // d dist/dP = (e/dist)^T (d d^T/dd - I)
+    const double q = dot3(d, e) / dd;
+    const double wi = w / dist;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) g[kk] = wi * (q * d[kk] - e[kk]);
+  } else if (KIND == PVLM_POINT2LINE_ANGLE) {
+    // base/CostFunction.h:881-920 (weight NOT applied)
+    const double* A = rec + 3; const double* d = rec + 6;
+    const double k = d[0] * (P[0] - A[0]) + d[1] * (P[1] - A[1]) + d[2] * (P[2] - A[2]);
+    const double Pp[3] = {k * d[0] + A[0], k * d[1] + A[1], k * d[2] + A[2]};
+    const double e[3] = {P[0] - Pp[0], P[1] - Pp[1], P[2] - Pp[2]};
+    const double dis = sqrt(dot3(e, e));
+    if (dis < 1e-3) return;
+    double gP[3], gPp[3];
+    if (!normalized_angle<NORM>(P, Pp, r, gP, gPp)) return;
+    const double t = dot3(d, gPp);  // dPp/dP = d d^T
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) g[kk] = gP[kk] + t * d[kk];
+  }
+}
+
+// Full wrench for any kind.  T = pair table row (R_rn[9] | t_rn[3] | t_rw[3] | ...).
+template <int KIND, bool NORM>
+__device__ __forceinline__ void eval_wrench(const double* rec, const double* T, double w, Wrench& out) {
+  const double* R = T; const double* trn = T + 9; const double* trw = T + 12;
+  auto chain = [&](const double* p, double* o) {
+    o[0] = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + trn[0];
+    o[1] = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + trn[1];
+    o[2] = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + trn[2];
+  };
+  if (KIND <= PVLM_POINT2LINE_ANGLE) {
+    double P[3];
+    chain(rec, P);
+    residual_grad<KIND, NORM>(P, rec, w, out.r, out.g);
+    const double m[3] = {P[0] - trw[0], P[1] - trw[1], P[2] - trw[2]};
+    cross3(m, out.g, out.c);
+  } else if (KIND == PVLM_PLANE2PLANE_GLOBAL) {
+    // base/CostFunction.h:405-412, Geometry.hpp:471-485 ; rec = [n_img(3) a(3) b(3) w]
+    const double* ni = rec; const double wk = rec[9];
+    double a[3], b[3], nrm[3];
+    chain(rec + 3, a);
+    chain(rec + 6, b);
+    cross3(a, b, nrm);
+    out.r = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { out.c[k] = 0.0; out.g[k] = 0.0; }
+    const double dp = dot3(ni, nrm);
+    const double s = dp < 0.0 ? -1.0 : 1.0;
+    const double q1 = dot3(ni, ni), q2 = dot3(nrm, nrm);
+    const double inv = 1.0 / (sqrt(q1) * sqrt(q2));
+    const double c = s * dp * inv;
+    if (c >= 1.0) return;
+    out.r = wk * acos(c);
+    const double drdc = -wk / sqrt(1.0 - c * c);
+    double gn[3], ga[3], gb[3], ca[3], cb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gn[k] = drdc * (s * ni[k] * inv - c * nrm[k] / q2);
+    cross3(b, gn, ga);   // d(a x b) . gn  wrt a
+    cross3(gn, a, gb);   // wrt b
+    const double ma[3] = {a[0] - trw[0], a[1] - trw[1], a[2] - trw[2]};
+    const double mb[3] = {b[0] - trw[0], b[1] - trw[1], b[2] - trw[2]};
+    cross3(ma, ga, ca);
+    cross3(mb, gb, cb);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { out.c[k] = ca[k] + cb[k]; out.g[k] = ga[k] + gb[k]; }
+  } else {  // PVLM_PLANE_IOU — base/CostFunction.h:488-497 ; rec = [plane(4) mid_n(3) mid_r(3) angle w]
+    const double* n = rec; const double* mr = rec + 7; const double ang = rec[10]; const double wk = rec[11];
+    double mc[3];
+    chain(rec + 4, mc);
+    out.r = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { out.c[k] = 0.0; out.g[k] = 0.0; }
+    const double sd = n[0] * mc[0] + n[1] * mc[1] + n[2] * mc[2] + n[3];
+    const double s = sd < 0.0 ? -1.0 : 1.0;
+    const double dis = s * sd;
+    double np[3] = {mc[0] - dis * n[0], mc[1] - dis * n[1], mc[2] - dis * n[2]};
+    double sig = 1.0;
+    if (fabs(n[0] * np[0] + n[1] * np[1] + n[2] * np[2] + n[3]) > 1e-4) {
+      np[0] = mc[0] + dis * n[0]; np[1] = mc[1] + dis * n[1]; np[2] = mc[2] + dis * n[2];
+      sig = -1.0;
+    }
+    double cur, g1[3], g2[3];
+    const bool smooth = angle_between(np, mr, cur, g1, g2);
+    if (cur < ang) return;
+    out.r = wk * (cur - ang);
+    if (!smooth) return;
+    const double t = sig * s * dot3(n, g1);
+    double g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = wk * (g1[k] - t * n[k]);
+    const double m[3] = {mc[0] - trw[0], mc[1] - trw[1], mc[2] - trw[2]};
+    cross3(m, g, out.c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out.g[k] = g[k];
+  }
+}
+
+}  // namespace pvlm_dev

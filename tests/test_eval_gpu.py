@@ -1,0 +1,121 @@
+"""GPU parity of the residual/Jacobian kernels (K5 materialise, K6 fused) against the CPU oracle,
+through the C ABI.  Tolerance: 1e-6 relative (BASELINE.json north_star); observed ~1e-12."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import panovlm_amd as pv
+    c = pv.Context(0)
+    yield c
+    c.close()
+
+
+CASES = [(0, False), (1, False), (1, True), (2, False), (3, False), (3, True), (4, False), (5, False)]
+
+
+def _build(rng, kind, F=7, P=23, max_count=300):
+    aa, t = synth.random_poses(rng, F)
+    ref, nei = synth.random_pairs(rng, F, P)
+    counts = rng.integers(0, max_count, size=P)
+    counts[0] = 0          # empty segment
+    counts[1] = 1          # odd, single-row segment
+    counts[2] = 1025       # spans several 512-row iterations, odd tail
+    rows, off = synth.random_resset(rng, kind, aa, t, ref, nei, counts)
+    return aa, t, ref, nei, rows, off
+
+
+@pytest.mark.parametrize("kind,normalize", CASES)
+def test_materialise_matches_oracle(ctx, oracle, kind, normalize):
+    import panovlm_amd as pv
+    rng = np.random.default_rng(100 + kind * 2 + int(normalize))
+    aa, t, ref, nei, rows, off = _build(rng, kind)
+    w = 1.7
+    rs = pv.ResidualSet.upload(ctx, kind, rows, off, ref, nei, flags=1 if normalize else 0, weight=w)
+    ctx.set_poses(aa, t)
+    r, J = rs.eval(jac=True)
+    rid, nid = synth.expand_ids(off, ref, nei)
+    ro, Jo = oracle.evaluate(kind, synth.oracle_rows(kind, rows, w), rid, nid, aa, t, normalize=normalize)
+    assert r.shape == ro.shape and J.shape == Jo.shape
+    assert np.all(np.abs(r - ro) <= RTOL * np.maximum(np.abs(ro), 1e-9) + 1e-15), np.abs(r - ro).max()
+    # zero residuals (early-outs / clamps) must agree exactly in position
+    assert np.array_equal(ro == 0, r == 0)
+    scale = np.maximum(np.abs(Jo).max(axis=1, keepdims=True), 1e-9)
+    assert np.all(np.abs(J - Jo) <= RTOL * scale), (np.abs(J - Jo) / scale).max()
+    # cost-only evaluation returns identical residuals
+    r2, J2 = rs.eval(jac=False)
+    assert J2 is None and np.array_equal(r, r2)
+    rs.close()
+
+
+@pytest.mark.parametrize("kind,normalize", CASES)
+@pytest.mark.parametrize("loss", [0, 1])
+def test_fused_pair_blocks_match_oracle(ctx, oracle, kind, normalize, loss):
+    import panovlm_amd as pv
+    rng = np.random.default_rng(200 + kind * 2 + int(normalize))
+    aa, t, ref, nei, rows, off = _build(rng, kind)
+    a = 2 * np.pi / 180 if kind in (1, 3, 4, 5) else 0.2
+    rs = pv.ResidualSet.upload(ctx, kind, rows, off, ref, nei, flags=1 if normalize else 0, weight=0.9)
+    ctx.set_poses(aa, t)
+    blocks = rs.pair_blocks(loss, a)
+    rid, nid = synth.expand_ids(off, ref, nei)
+    ro, Jo = oracle.evaluate(kind, synth.oracle_rows(kind, rows, 0.9), rid, nid, aa, t, normalize=normalize)
+    expect = synth.pair_blocks_from_jacobian(ro, Jo, off, loss, a)
+    scale = np.maximum(np.abs(expect).max(axis=1, keepdims=True), 1e-12)
+    assert np.all(np.abs(blocks - expect) <= RTOL * scale), (np.abs(blocks - expect) / scale).max()
+    # determinism: bit-identical on a second run
+    assert np.array_equal(blocks, rs.pair_blocks(loss, a))
+    rs.close()
+
+
+def test_normal_equations_packed(ctx, oracle):
+    import panovlm_amd as pv
+    rng = np.random.default_rng(7)
+    F, P = 9, 40
+    aa, t = synth.random_poses(rng, F)
+    ref, nei = synth.random_pairs(rng, F, P)
+    counts = rng.integers(1, 200, size=P)
+    rows, off = synth.random_resset(rng, 1, aa, t, ref, nei, counts)
+    rs = pv.ResidualSet.upload(ctx, 1, rows, off, ref, nei, flags=1)
+    ctx.set_poses(aa, t)
+    up = sorted({(min(a, b), max(a, b)) for a, b in zip(ref.tolist(), nei.tolist())})
+    neq = pv.NormalEq(ctx, F, [u[0] for u in up], [u[1] for u in up])
+    a = 2 * np.pi / 180
+    packed = neq.accumulate(rs, 1, a)
+    Hd, Ho, g, cost = neq.unpack(packed)
+    rid, nid = synth.expand_ids(off, ref, nei)
+    ro, Jo = oracle.evaluate(1, synth.oracle_rows(1, rows), rid, nid, aa, t, normalize=True)
+    w, half_rho = synth.huber_weights(ro, 1, a)
+    H = np.zeros((F * 6, F * 6)); gg = np.zeros(F * 6)
+    for i in range(len(ro)):
+        idx = np.concatenate([np.arange(6) + 6 * rid[i], np.arange(6) + 6 * nid[i]])
+        H[np.ix_(idx, idx)] += w[i] * np.outer(Jo[i], Jo[i])
+        gg[idx] += w[i] * Jo[i] * ro[i]
+    sc = np.abs(H).max()
+    for i in range(F):
+        assert np.allclose(Hd[i], H[6 * i:6 * i + 6, 6 * i:6 * i + 6], rtol=0, atol=1e-9 * sc)
+        assert np.allclose(g[i], gg[6 * i:6 * i + 6], rtol=0, atol=1e-9 * np.abs(gg).max())
+    for u, (i, j) in enumerate(up):
+        assert np.allclose(Ho[u], H[6 * i:6 * i + 6, 6 * j:6 * j + 6], rtol=0, atol=1e-9 * sc)
+    assert np.isclose(cost, half_rho.sum(), rtol=1e-10)
+    # accumulate a second time on top (+=)
+    packed2 = neq.accumulate(rs, 1, a, packed=packed.copy())
+    assert np.allclose(packed2, 2 * packed, rtol=1e-12)
+
+
+def test_errors_are_loud(ctx):
+    import panovlm_amd as pv
+    rows = np.zeros((2, 7)); rows[:, 3] = 1
+    rs = pv.ResidualSet.upload(ctx, 0, rows, [0, 2], [0], [5])
+    ctx.set_poses(np.zeros((2, 3)), np.zeros((2, 3)))
+    with pytest.raises(pv.PvlmError):
+        rs.eval()           # pose id 5 outside the table
+    with pytest.raises(pv.PvlmError):
+        pv.ResidualSet.upload(ctx, 0, rows, [0, 1], [0], [1])   # offsets do not span n
