@@ -43,7 +43,7 @@ def build(force=False, verbose=False):
         flags = list(common)
         # association kernels make accept/reject decisions that must be bit-identical to a
         # non-FMA x86-64 build of the reference: no contraction there.
-        if os.path.basename(src) in ("pvlm_assoc.hip", "pvlm_lines.hip", "pvlm_camera.hip"):
+        if os.path.basename(src) in ("pvlm_assoc.hip", "pvlm_lines.hip"):
             flags.append("-ffp-contract=off")
         cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
         if verbose:

@@ -1,0 +1,837 @@
+// K1 voxel-hash build, K2 exact k-NN, K3 plane fit + accept tests, ordered compaction:
+// the device side of AssociatePoint2Plane (lidar_mapping/LidarFeatureAssociate.cpp:550-630).
+// Compiled with -ffp-contract=off: distances (float32, FLANN L2_Simple order) and every
+// accept/reject decision (fp64) must match a non-FMA x86-64 build of the reference bit for bit.
+//
+// Data layout: a cloud is uploaded once per scan; its points are counting-sorted into cells of
+// a spatial hash (open addressing, 64-bit cell keys) as float4 (x, y, z, original index) so that
+// one 16-byte load fetches a candidate.  A query walks Chebyshev shells of cells around its own
+// cell and keeps a register-resident sorted top-k ordered by (distance, index); it stops as soon as
+// the k-th distance is provably inside the searched block, or the shell radius exceeds
+// dist_threshold.  Results are therefore the EXACT k nearest neighbours (ties by index).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "pvlm_internal.h"
+
+#define EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define CELL_BIAS (1 << 20)
+
+struct CloudView {
+  const float4* sorted;
+  const unsigned long long* keys;
+  const int* cell_start;
+  const int* cell_count;
+  const float* xyz;  // original order, interleaved
+  const float* tag;
+  int n, mask;
+  float ox, oy, oz, h, inv_h;
+};
+
+struct PairDesc {
+  CloudView ref;
+  const float* q_xyz;
+  const float* q_tag;
+  int nq;
+  double Rr[9], tr[3], Rn[9], tn[3];  // R_wl / t_wl of ref and nei
+  long long tmp_base;                 // first row of this pair in the batch temp arrays
+  int chunk_base;                     // first chunk counter of this pair
+};
+
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x;
+}
+__device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
+  return (unsigned long long)((ix + CELL_BIAS) & 0x1FFFFF) | ((unsigned long long)((iy + CELL_BIAS) & 0x1FFFFF) << 21) |
+         ((unsigned long long)((iz + CELL_BIAS) & 0x1FFFFF) << 42);
+}
+__device__ __forceinline__ int cell_of(float x, float o, float inv_h) {
+  float c = floorf((x - o) * inv_h);
+  c = fminf(fmaxf(c, -1000000.f), 1000000.f);
+  return (int)c;
+}
+
+// ---- K1 ---------------------------------------------------------------------------------------
+__global__ void k_hash_insert(int n, const float* __restrict__ xyz, float ox, float oy, float oz, float inv_h, int mask,
+                              unsigned long long* __restrict__ keys, int* __restrict__ count, int* __restrict__ slot_of) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = cell_key(cell_of(xyz[3 * i], ox, inv_h), cell_of(xyz[3 * i + 1], oy, inv_h), cell_of(xyz[3 * i + 2], oz, inv_h));
+  int s = (int)(mix64(key) & (unsigned long long)mask);
+  while (true) {
+    const unsigned long long prev = atomicCAS(&keys[s], EMPTY_KEY, key);
+    if (prev == EMPTY_KEY || prev == key) break;
+    s = (s + 1) & mask;
+  }
+  atomicAdd(&count[s], 1);
+  slot_of[i] = s;
+}
+
+// single-block exclusive scan of count[T] -> start[T]  (T <= 2^22)
+__global__ __launch_bounds__(1024) void k_scan_counts(int T, const int* __restrict__ count, int* __restrict__ start) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (T + 1023) / 1024;
+  const int lo = t * per, hi = min(T, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += count[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
+}
+
+// deterministic placement: the rank of point i inside its cell = number of points of the same
+// cell with a smaller index is not available cheaply, so points take slots by atomic cursor and
+// each cell is then sorted by original index (cells are small) — see k_sort_cells.
+__global__ void k_scatter(int n, const float* __restrict__ xyz, const int* __restrict__ slot_of, const int* __restrict__ start,
+                          int* __restrict__ cursor, float4* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = slot_of[i];
+  const int pos = start[s] + atomicAdd(&cursor[s], 1);
+  sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
+}
+
+__global__ void k_sort_cells(int T, const int* __restrict__ start, const int* __restrict__ count, float4* __restrict__ sorted) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= T) return;
+  const int c = count[s];
+  if (c < 2) return;
+  float4* a = sorted + start[s];
+  for (int i = 1; i < c; ++i) {  // insertion sort by original index
+    const float4 v = a[i];
+    const int vi = __float_as_int(v.w);
+    int j = i - 1;
+    while (j >= 0 && __float_as_int(a[j].w) > vi) { a[j + 1] = a[j]; --j; }
+    a[j + 1] = v;
+  }
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------
+template <int K>
+struct TopK {
+  float d[K];
+  int id[K];
+  int cnt;
+  __device__ __forceinline__ void init() {
+    cnt = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { d[k] = INFINITY; id[k] = -1; }
+  }
+  // ordered by (distance, index) ascending
+  __device__ __forceinline__ void push(float dist, int idx) {
+    if (!(dist < d[K - 1] || (dist == d[K - 1] && (unsigned)idx < (unsigned)id[K - 1]))) return;
+    d[K - 1] = dist; id[K - 1] = idx;
+#pragma unroll
+    for (int k = K - 1; k > 0; --k) {
+      const bool sw = d[k] < d[k - 1] || (d[k] == d[k - 1] && (unsigned)id[k] < (unsigned)id[k - 1]);
+      if (sw) { const float td = d[k]; d[k] = d[k - 1]; d[k - 1] = td; const int ti = id[k]; id[k] = id[k - 1]; id[k - 1] = ti; }
+    }
+    if (cnt < K) ++cnt;
+  }
+};
+
+template <int K>
+__device__ __forceinline__ void knn_search(const CloudView& cv, float qx, float qy, float qz, float max_dist, float thr2, TopK<K>& tk) {
+  tk.init();
+  if (cv.n <= 0) return;
+  const int cx = cell_of(qx, cv.ox, cv.inv_h), cy = cell_of(qy, cv.oy, cv.inv_h), cz = cell_of(qz, cv.oz, cv.inv_h);
+  const float fx = (qx - cv.ox) * cv.inv_h - (float)cx, fy = (qy - cv.oy) * cv.inv_h - (float)cy, fz = (qz - cv.oz) * cv.inv_h - (float)cz;
+  const float lo_min = fminf(fminf(fx, fy), fz), hi_min = fminf(fminf(1.f - fx, 1.f - fy), 1.f - fz);
+  const float inside = fminf(lo_min, hi_min);  // distance (in cells) from q to the nearest face of its own cell
+  const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
+  const int rmax = (int)ceilf(max_dist * 1.0001f * cv.inv_h);
+  for (int r = 0; r <= rmax; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      for (int dy = -r; dy <= r; ++dy) {
+        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+        const int step = face ? 1 : (r > 0 ? 2 * r : 1);
+        for (int dx = -r; dx <= r; dx += step) {
+          const unsigned long long key = cell_key(cx + dx, cy + dy, cz + dz);
+          int s = (int)(mix64(key) & (unsigned long long)cv.mask);
+          unsigned long long kk;
+          while ((kk = cv.keys[s]) != key && kk != EMPTY_KEY) s = (s + 1) & cv.mask;
+          if (kk != key) continue;
+          const int b = cv.cell_start[s], e = b + cv.cell_count[s];
+          for (int j = b; j < e; ++j) {
+            const float4 p = cv.sorted[j];
+            const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+            float d2 = 0.0f;
+            d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
+            if (d2 <= thr2) tk.push(d2, __float_as_int(p.w));
+          }
+        }
+      }
+    }
+    // every unsearched point lies outside the (2r+1)^3 block: farther than (inside + r) cells
+    const float bound = (inside + (float)r) * cv.h - slack;
+    if (tk.cnt == K && bound > 0.f && tk.d[K - 1] < bound * bound) break;
+    if ((float)r * cv.h >= max_dist * 1.0001f) break;  // everything within max_dist has been visited
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* __restrict__ q, int nq, float max_dist,
+                                                     int* __restrict__ idx, float* __restrict__ sqd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  TopK<K> tk;
+  const float thr2 = max_dist * max_dist;
+  knn_search<K>(cv, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_dist, thr2, tk);
+#pragma unroll
+  for (int k = 0; k < K; ++k) { idx[(size_t)i * K + k] = tk.id[k]; sqd[(size_t)i * K + k] = tk.d[k]; }
+}
+
+// ---- K3: fp64 fits (identical arithmetic to oracle/geometry.hpp, fully unrolled, static indexing) ----
+struct Fit10 {
+  // Householder QR with column pivoting on the 10x3 system A n = -1 (Eigen ColPivHouseholderQR
+  // restated, base/Geometry.hpp:345-373), then the tolerance test.  c0,c1,c2 = columns (destroyed).
+  static __device__ __forceinline__ void swap_cols(double* a, double* b) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { const double t = a[i]; a[i] = b[i]; b[i] = t; }
+  }
+  template <int KK>
+  static __device__ __forceinline__ void householder(double* ck, double* cj1, double* cj2, double* rhs_unused, double& tau) {
+    double tailSq = 0.0;
+#pragma unroll
+    for (int i = KK + 1; i < 10; ++i) tailSq += ck[i] * ck[i];
+    const double c0 = ck[KK];
+    double beta;
+    if (tailSq <= DBL_MIN) {
+      tau = 0.0; beta = c0;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) ck[i] = 0.0;
+    } else {
+      beta = sqrt(c0 * c0 + tailSq);
+      if (c0 >= 0.0) beta = -beta;
+      const double den = c0 - beta;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) ck[i] = ck[i] / den;
+      tau = (beta - c0) / beta;
+    }
+    ck[KK] = beta;
+    if (tau != 0.0) {
+      if (cj1) {
+        double tmp = 0.0;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * cj1[i];
+        tmp += cj1[KK];
+        cj1[KK] -= tau * tmp;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) cj1[i] -= tau * ck[i] * tmp;
+      }
+      if (cj2) {
+        double tmp = 0.0;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * cj2[i];
+        tmp += cj2[KK];
+        cj2[KK] -= tau * tmp;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) cj2[i] -= tau * ck[i] * tmp;
+      }
+    }
+  }
+  template <int KK>
+  static __device__ __forceinline__ void downdate(const double* cj, double& nU, double& nD, double thr) {
+    if (nU != 0.0) {
+      double temp = fabs(cj[KK]) / nU;
+      temp = (1.0 + temp) * (1.0 - temp);
+      temp = temp < 0.0 ? 0.0 : temp;
+      const double ratio = nU / nD;
+      const double temp2 = temp * ratio * ratio;
+      if (temp2 <= thr) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) s += cj[i] * cj[i];
+        nD = sqrt(s);
+        nU = nD;
+      } else {
+        nU *= sqrt(temp);
+      }
+    }
+  }
+  template <int KK>
+  static __device__ __forceinline__ void apply_rhs(const double* ck, double tau, double* b) {
+    if (tau != 0.0) {
+      double tmp = 0.0;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * b[i];
+      tmp += b[KK];
+      b[KK] -= tau * tmp;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) b[i] -= tau * ck[i] * tmp;
+    }
+  }
+
+  // pts: 10 x 3 (px[10], py[10], pz[10]).  Returns plane_ok; plane = (n, d).
+  static __device__ bool form_plane(const double* px, const double* py, const double* pz, double tol, double* plane) {
+    double c0[10], c1[10], c2[10], b[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c0[i] = px[i]; c1[i] = py[i]; c2[i] = pz[i]; b[i] = -1.0; }
+    const double eps = DBL_EPSILON;
+    double nU0, nU1, nU2, nD0, nD1, nD2;
+    {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) { s0 += c0[i] * c0[i]; s1 += c1[i] * c1[i]; s2 += c2[i] * c2[i]; }
+      nD0 = nU0 = sqrt(s0); nD1 = nU1 = sqrt(s1); nD2 = nU2 = sqrt(s2);
+    }
+    double maxn = nU0; if (nU1 > maxn) maxn = nU1; if (nU2 > maxn) maxn = nU2;
+    const double threshold_helper = (maxn * eps) * (maxn * eps) / 10.0;
+    const double ndt = sqrt(eps);
+    int nonzero = 3;
+    int p0 = 0, p1 = 1, p2 = 2;
+    double tau0, tau1, tau2;
+    // ---- k = 0
+    {
+      int big = 0; double bigv = nU0;
+      if (nU1 > bigv) { bigv = nU1; big = 1; }
+      if (nU2 > bigv) { bigv = nU2; big = 2; }
+      if (nonzero == 3 && bigv * bigv < threshold_helper * 10.0) nonzero = 0;
+      if (big == 1) { swap_cols(c0, c1); double t = nU0; nU0 = nU1; nU1 = t; t = nD0; nD0 = nD1; nD1 = t; int q = p0; p0 = p1; p1 = q; }
+      else if (big == 2) { swap_cols(c0, c2); double t = nU0; nU0 = nU2; nU2 = t; t = nD0; nD0 = nD2; nD2 = t; int q = p0; p0 = p2; p2 = q; }
+      householder<0>(c0, c1, c2, nullptr, tau0);
+      downdate<0>(c1, nU1, nD1, ndt);
+      downdate<0>(c2, nU2, nD2, ndt);
+    }
+    // ---- k = 1
+    {
+      int big = 1; double bigv = nU1;
+      if (nU2 > bigv) { bigv = nU2; big = 2; }
+      if (nonzero == 3 && bigv * bigv < threshold_helper * 9.0) nonzero = 1;
+      if (big == 2) { swap_cols(c1, c2); double t = nU1; nU1 = nU2; nU2 = t; t = nD1; nD1 = nD2; nD2 = t; int q = p1; p1 = p2; p2 = q; }
+      householder<1>(c1, c2, nullptr, nullptr, tau1);
+      downdate<1>(c2, nU2, nD2, ndt);
+    }
+    // ---- k = 2
+    {
+      const double bigv = nU2;
+      if (nonzero == 3 && bigv * bigv < threshold_helper * 8.0) nonzero = 2;
+      householder<2>(c2, nullptr, nullptr, nullptr, tau2);
+    }
+    if (nonzero > 0) apply_rhs<0>(c0, tau0, b);
+    if (nonzero > 1) apply_rhs<1>(c1, tau1, b);
+    if (nonzero > 2) apply_rhs<2>(c2, tau2, b);
+    // back substitution on the leading nonzero x nonzero triangle: R = [c0[0] c1[0] c2[0]; 0 c1[1] c2[1]; 0 0 c2[2]]
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (nonzero > 2) y2 = b[2] / c2[2];
+    if (nonzero > 1) { double s = b[1]; if (nonzero > 2) s -= c2[1] * y2; y1 = s / c1[1]; }
+    if (nonzero > 0) { double s = b[0]; if (nonzero > 1) s -= c1[0] * y1; if (nonzero > 2) s -= c2[0] * y2; y0 = s / c0[0]; }
+    double x[3] = {0.0, 0.0, 0.0};
+    if (nonzero > 0) { if (p0 == 0) x[0] = y0; else if (p0 == 1) x[1] = y0; else x[2] = y0; }
+    if (nonzero > 1) { if (p1 == 0) x[0] = y1; else if (p1 == 1) x[1] = y1; else x[2] = y1; }
+    if (nonzero > 2) { if (p2 == 0) x[0] = y2; else if (p2 == 1) x[1] = y2; else x[2] = y2; }
+    const double len = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const double d = 1.0 / len;
+    if (len * len > 0.0) { x[0] /= len; x[1] /= len; x[2] /= len; }
+    bool ok = true;
+    if (tol > 0) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const double dist = fabs((x[0] * px[i] + x[1] * py[i]) + x[2] * pz[i] + d);
+        if (dist > tol) ok = false;
+      }
+    }
+    plane[0] = ok ? x[0] : 0.0; plane[1] = ok ? x[1] : 0.0; plane[2] = ok ? x[2] : 0.0; plane[3] = ok ? d : 0.0;
+    return ok;
+  }
+
+  // FormLine(points, 3.0) is non-zero  <=>  largest eigenvalue > tol * middle eigenvalue of the
+  // scatter matrix (base/Geometry.hpp:220-260); cyclic Jacobi identical to oracle/geometry.hpp.
+  static __device__ bool is_line(const double* px, const double* py, const double* pz, double tol) {
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { cx = cx + px[i]; cy = cy + py[i]; cz = cz + pz[i]; }
+    cx = cx / 10.0; cy = cy / 10.0; cz = cz / 10.0;
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const double dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+      a00 = a00 + dx * dx; a01 = a01 + dx * dy; a02 = a02 + dx * dz;
+      a11 = a11 + dy * dy; a12 = a12 + dy * dz; a22 = a22 + dz * dz;
+    }
+    // the oracle accumulates the full 3x3 (S[r][c] += d[r]*d[c]); symmetric entries are bitwise equal
+    for (int sweep = 0; sweep < 12; ++sweep) {
+      const double off = a01 * a01 + a02 * a02 + a12 * a12;
+      if (off == 0.0) break;
+      // (p,q) = (0,1), r = 2
+      if (a01 != 0.0) {
+        const double theta = (a11 - a00) / (2.0 * a01);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        const double app = a00, aqq = a11, apq = a01;
+        a00 = app - t * apq; a11 = aqq + t * apq; a01 = 0.0;
+        const double arp = a02, arq = a12;
+        a02 = c * arp - s * arq; a12 = s * arp + c * arq;
+      }
+      // (p,q) = (0,2), r = 1
+      if (a02 != 0.0) {
+        const double theta = (a22 - a00) / (2.0 * a02);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        const double app = a00, aqq = a22, apq = a02;
+        a00 = app - t * apq; a22 = aqq + t * apq; a02 = 0.0;
+        const double arp = a01, arq = a12;
+        a01 = c * arp - s * arq; a12 = s * arp + c * arq;
+      }
+      // (p,q) = (1,2), r = 0
+      if (a12 != 0.0) {
+        const double theta = (a22 - a11) / (2.0 * a12);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        const double app = a11, aqq = a22, apq = a12;
+        a11 = app - t * apq; a22 = aqq + t * apq; a12 = 0.0;
+        const double arp = a01, arq = a02;
+        a01 = c * arp - s * arq; a02 = s * arp + c * arq;
+      }
+    }
+    // ascending sort of (a00, a11, a22)
+    double w0 = a00, w1 = a11, w2 = a22, t;
+    if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
+    if (w1 > w2) { t = w1; w1 = w2; w2 = t; }
+    if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
+    return w2 > tol * w1;
+  }
+};
+
+// World2Local: R_wl^T p - R_wl^T t  (sensors/Velodyne.cpp:1850-1853), R row-major
+__device__ __forceinline__ void world2local(const double* R, const double* t, double x, double y, double z, double* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a = (R[i] * x + R[3 + i] * y) + R[6 + i] * z;
+    const double b = (R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];
+    o[i] = a - b;
+  }
+}
+
+// grid: x = chunk of 256 queries, y = pair in batch.  Writes the k-NN indices, the candidate
+// record and the accept flag for every query; per-chunk accept counts for the compaction.
+__global__ __launch_bounds__(256) void k_assoc_p2plane(const PairDesc* __restrict__ pairs, float dist_threshold, double plane_tol,
+                                                       int* __restrict__ nn_tmp, double* __restrict__ rec_tmp,
+                                                       unsigned char* __restrict__ flag_tmp, int* __restrict__ chunk_count,
+                                                       long long tmp_rows) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= pd.nq) return;
+  bool accept = false;
+  if (q < pd.nq) {
+    const float qx = pd.q_xyz[3 * q], qy = pd.q_xyz[3 * q + 1], qz = pd.q_xyz[3 * q + 2];
+    const float thr2 = dist_threshold * dist_threshold;
+    TopK<10> tk;
+    knn_search<10>(pd.ref, qx, qy, qz, dist_threshold, thr2, tk);
+    const long long row = pd.tmp_base + q;
+    bool ok = (tk.cnt == 10);  // 10th neighbour within dist_threshold  (LidarFeatureAssociate.cpp:577)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) nn_tmp[row * 10 + k] = tk.id[k];
+    if (ok) {
+      const float qtag = pd.q_tag[q];
+      double px[10], py[10], pz[10];
+      int same = 0;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const int j = tk.id[k];
+        same += (pd.ref.tag[j] == qtag);
+        double l[3];
+        world2local(pd.Rr, pd.tr, (double)pd.ref.xyz[3 * j], (double)pd.ref.xyz[3 * j + 1], (double)pd.ref.xyz[3 * j + 2], l);
+        px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
+      }
+      ok = (same == 10);  // :583-591
+      if (ok) {
+        double plane[4];
+        const bool plane_ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+        const bool line = Fit10::is_line(px, py, pz, 3.0);
+        ok = plane_ok && !line;  // :592-596
+        if (ok) {
+          double pl[3];
+          world2local(pd.Rn, pd.tn, (double)qx, (double)qy, (double)qz, pl);
+          rec_tmp[0 * tmp_rows + row] = pl[0]; rec_tmp[1 * tmp_rows + row] = pl[1]; rec_tmp[2 * tmp_rows + row] = pl[2];
+          rec_tmp[3 * tmp_rows + row] = plane[0]; rec_tmp[4 * tmp_rows + row] = plane[1];
+          rec_tmp[5 * tmp_rows + row] = plane[2]; rec_tmp[6 * tmp_rows + row] = plane[3];
+        }
+      }
+    }
+    flag_tmp[row] = ok ? 1 : 0;
+    accept = ok;
+  }
+  const unsigned long long bal = __ballot(accept);
+  __shared__ int wc[4];
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_count[pd.chunk_base + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// ordered compaction: chunk (pair, c) writes its accepted rows at dst_base[chunk] + rank.
+__global__ __launch_bounds__(256) void k_compact(const PairDesc* __restrict__ pairs, const unsigned char* __restrict__ flag_tmp,
+                                                 const double* __restrict__ rec_tmp, const int* __restrict__ nn_tmp, long long tmp_rows,
+                                                 const long long* __restrict__ dst_dev_row, const long long* __restrict__ dst_out_row,
+                                                 double* __restrict__ cols, long long n_dev, int* __restrict__ qidx_out,
+                                                 int* __restrict__ nn_out) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  if (blockIdx.x * 256 >= pd.nq) return;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const long long row = pd.tmp_base + q;
+  const bool f = (q < pd.nq) && flag_tmp[row];
+  const unsigned long long bal = __ballot(f);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ int wc[4];
+  if (lane == 0) wc[wv] = __popcll(bal);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wv; ++w) base += wc[w];
+  const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+  if (f) {
+    const int ch = pd.chunk_base + blockIdx.x;
+    const long long d = dst_dev_row[ch] + rank;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) cols[(size_t)c * n_dev + d] = rec_tmp[(size_t)c * tmp_rows + row];
+    if (qidx_out) {
+      const long long o = dst_out_row[ch] + rank;
+      qidx_out[o] = q;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) nn_out[o * 10 + k] = nn_tmp[row * 10 + k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static void cloud_free(pvlm_cloud& c) {
+  hipFree(c.d_xyz); hipFree(c.d_tag); hipFree(c.d_keys); hipFree(c.d_cell_start); hipFree(c.d_cell_count); hipFree(c.d_sorted);
+  c = pvlm_cloud();
+}
+
+static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float* xyz, const float* tag, bool build_hash) {
+  c.n = n;
+  if (n <= 0) return PVLM_OK;
+  pvlm_status st;
+  if ((st = pvlm_i_alloc(ctx, &c.d_xyz, (size_t)n * 3))) return st;
+  PVLM_HIP(ctx, hipMemcpyAsync(c.d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  if (tag) {
+    if ((st = pvlm_i_alloc(ctx, &c.d_tag, (size_t)n))) return st;
+    PVLM_HIP(ctx, hipMemcpyAsync(c.d_tag, tag, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!build_hash) { PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream)); return PVLM_OK; }
+  // bounding box -> cell edge: surface-like clouds, aim at ~4 points per occupied cell
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) { const float v = xyz[3 * i + k]; if (v < mn[k]) mn[k] = v; if (v > mx[k]) mx[k] = v; }
+  float e[3];
+  for (int k = 0; k < 3; ++k) { if (!(mx[k] - mn[k] < 1e7f)) { PVLM_SET_ERR(ctx, "cloud contains non-finite coordinates"); return PVLM_ERR_ARG; } e[k] = std::max(mx[k] - mn[k], 0.05f); }
+  const float area = 2.f * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+  float h = std::sqrt(4.f * area / (float)n);
+  const char* env = getenv("PVLM_CELL");
+  if (env && atof(env) > 0) h = (float)atof(env);
+  h = std::min(std::max(h, 0.02f), 4.0f);
+  c.cell = h;
+  for (int k = 0; k < 3; ++k) c.origin[k] = mn[k] - h;
+  int T = 1024;
+  while (T < 2 * n) T <<= 1;
+  c.table_size = T;
+  int *d_slot = nullptr, *d_cursor = nullptr;
+  if ((st = pvlm_i_alloc(ctx, &c.d_keys, (size_t)T))) return st;
+  if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
+  if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
+  if ((st = pvlm_i_alloc(ctx, &c.d_sorted, (size_t)n))) return st;
+  if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
+  if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); return st; }
+  hipError_t e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
+  hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
+  hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+  const float inv_h = 1.0f / h;
+  hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h,
+                     T - 1, c.d_keys, c.d_cell_count, d_slot);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, T, c.d_cell_count, c.d_cell_start);
+  hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
+  hipLaunchKernelGGL(k_sort_cells, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, T, c.d_cell_start, c.d_cell_count, c.d_sorted);
+  hipError_t le = hipGetLastError();
+  hipError_t se = hipStreamSynchronize(ctx->stream);
+  hipFree(d_slot); hipFree(d_cursor);
+  if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-hash build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
+static CloudView view_of(const pvlm_cloud& c) {
+  CloudView v;
+  v.sorted = c.d_sorted; v.keys = c.d_keys; v.cell_start = c.d_cell_start; v.cell_count = c.d_cell_count;
+  v.xyz = c.d_xyz; v.tag = c.d_tag; v.n = c.n; v.mask = c.table_size - 1;
+  v.ox = c.origin[0]; v.oy = c.origin[1]; v.oz = c.origin[2]; v.h = c.cell; v.inv_h = c.cell > 0 ? 1.0f / c.cell : 0.f;
+  return v;
+}
+
+extern "C" {
+
+pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan** out) {
+  if (!ctx || !d || !out || !d->R_wl || !d->t_wl) return PVLM_ERR_ARG;
+  *out = nullptr;
+  if (d->n_surf_flat < 0 || d->n_surf_less_flat < 0 || d->n_corner < 0 || d->n_segments < 0 ||
+      (d->n_surf_flat > 0 && (!d->surf_flat_xyz || !d->surf_flat_tag)) ||
+      (d->n_surf_less_flat > 0 && (!d->surf_less_flat_xyz || !d->surf_less_flat_tag)) || (d->n_corner > 0 && !d->corner_xyz) ||
+      (d->n_segments > 0 && (!d->segment_size || !d->segment_coeffs))) {
+    PVLM_SET_ERR(ctx, "pvlm_scan_upload: inconsistent descriptor");
+    return PVLM_ERR_ARG;
+  }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_scan* s = new (std::nothrow) pvlm_scan();
+  if (!s) return PVLM_ERR_NOMEM;
+  s->id = d->id;
+  std::memcpy(s->R_wl, d->R_wl, sizeof(s->R_wl));
+  std::memcpy(s->t_wl, d->t_wl, sizeof(s->t_wl));
+  pvlm_status st = cloud_upload(ctx, s->flat, d->n_surf_flat, d->surf_flat_xyz, d->surf_flat_tag, false);
+  if (!st) st = cloud_upload(ctx, s->less, d->n_surf_less_flat, d->surf_less_flat_xyz, d->surf_less_flat_tag, true);
+  if (!st) st = cloud_upload(ctx, s->corner, d->n_corner, d->corner_xyz, nullptr, true);
+  if (!st && d->n_corner > 0 && d->p2s_offsets) {
+    s->h_p2s_off.assign(d->p2s_offsets, d->p2s_offsets + d->n_corner + 1);
+    const int tot = s->h_p2s_off.back();
+    if (tot > 0) s->h_p2s_ids.assign(d->p2s_ids, d->p2s_ids + tot);
+    for (int v : s->h_p2s_ids) if (v < 0 || v >= d->n_segments) { PVLM_SET_ERR(ctx, "point_to_segment id %d out of range", v); st = PVLM_ERR_ARG; break; }
+    if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
+    if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_ids, s->h_p2s_ids.size());
+    if (!st) {
+      hipError_t e = hipMemcpy(s->d_p2s_off, s->h_p2s_off.data(), s->h_p2s_off.size() * sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess && tot > 0) e = hipMemcpy(s->d_p2s_ids, s->h_p2s_ids.data(), s->h_p2s_ids.size() * sizeof(int), hipMemcpyHostToDevice);
+      if (e != hipSuccess) { PVLM_SET_ERR(ctx, "p2s upload: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    }
+  } else if (!st && d->n_corner > 0) {
+    s->h_p2s_off.assign(d->n_corner + 1, 0);
+    st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
+    if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_ids, 1);
+    if (!st && hipMemset(s->d_p2s_off, 0, s->h_p2s_off.size() * sizeof(int)) != hipSuccess) st = PVLM_ERR_HIP;
+  }
+  if (!st && d->n_segments > 0) {
+    s->n_segments = d->n_segments;
+    s->h_seg_size.assign(d->segment_size, d->segment_size + d->n_segments);
+    s->h_seg_coeffs.assign(d->segment_coeffs, d->segment_coeffs + 6 * (size_t)d->n_segments);
+    if (d->end_points) s->h_end_points.assign(d->end_points, d->end_points + 6 * (size_t)d->n_segments);
+  }
+  if (st) { pvlm_scan_destroy(ctx, s); return st; }
+  *out = s;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* s) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (!s) return PVLM_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  cloud_free(s->flat); cloud_free(s->less); cloud_free(s->corner);
+  hipFree(s->d_p2s_off); hipFree(s->d_p2s_ids);
+  delete s;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_knn(pvlm_ctx* ctx, const pvlm_scan* scan, int which, const float* queries, int nq, int k, float max_dist, int32_t* idx,
+                     float* sqd) {
+  if (!ctx || !scan || nq < 0 || (nq > 0 && (!queries || !idx || !sqd)) || (which != 0 && which != 1) || !(max_dist > 0)) return PVLM_ERR_ARG;
+  if (k != 5 && k != 10) { PVLM_SET_ERR(ctx, "pvlm_knn: k must be 5 or 10 (the values the reference uses)"); return PVLM_ERR_ARG; }
+  if (nq == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const pvlm_cloud& c = which == 0 ? scan->less : scan->corner;
+  float* d_q = nullptr; int* d_idx = nullptr; float* d_sqd = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_q, (size_t)nq * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_idx, (size_t)nq * k);
+  if (!st) st = pvlm_i_alloc(ctx, &d_sqd, (size_t)nq * k);
+  hipError_t e = hipSuccess;
+  if (!st) {
+    e = hipMemcpyAsync(d_q, queries, (size_t)nq * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      const CloudView cv = view_of(c);
+      if (k == 10) hipLaunchKernelGGL(k_knn_queries<10>, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, cv, d_q, nq, max_dist, d_idx, d_sqd);
+      else hipLaunchKernelGGL(k_knn_queries<5>, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, cv, d_q, nq, max_dist, d_idx, d_sqd);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(idx, d_idx, (size_t)nq * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sqd, d_sqd, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_knn: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_q); hipFree(d_idx); hipFree(d_sqd);
+  return st;
+}
+
+pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, double plane_tolerance,
+                                   float dist_threshold, pvlm_functor kind, unsigned flags, double weight, pvlm_resset** out) {
+  if (!ctx || !out || n_pairs < 0 || (n_pairs > 0 && (!ref || !nei))) return PVLM_ERR_ARG;
+  *out = nullptr;
+  if (kind != PVLM_POINT2PLANE_ANGLE && kind != PVLM_POINT2PLANE_METER) { PVLM_SET_ERR(ctx, "kind must be a point-to-plane functor"); return PVLM_ERR_ARG; }
+  if (!(dist_threshold > 0)) { PVLM_SET_ERR(ctx, "dist_threshold must be positive"); return PVLM_ERR_ARG; }
+  for (int p = 0; p < n_pairs; ++p) if (!ref[p] || !nei[p]) { PVLM_SET_ERR(ctx, "null scan in pair %d", p); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const bool keep_idx = (flags & 0x100u) != 0;
+
+  pvlm_resset* rs = new (std::nothrow) pvlm_resset();
+  if (!rs) return PVLM_ERR_NOMEM;
+  rs->kind = kind; rs->flags = flags & 0xFFu; rs->weight = weight; rs->n_pairs = n_pairs; rs->ncols = 7;
+  rs->h_ref.resize(n_pairs); rs->h_nei.resize(n_pairs);
+  for (int p = 0; p < n_pairs; ++p) { rs->h_ref[p] = ref[p]->id; rs->h_nei[p] = nei[p]->id; }
+
+  // ---- pass 1: k-NN + fits for all pairs, batched so the temp arrays stay below ~6 GB ----------
+  std::vector<PairDesc> descs(n_pairs);
+  std::vector<int> chunk_of_pair(n_pairs + 1, 0);
+  long long tot_q = 0;
+  int max_nq = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    PairDesc& d = descs[p];
+    d.ref = view_of(ref[p]->less);
+    d.q_xyz = nei[p]->flat.d_xyz; d.q_tag = nei[p]->flat.d_tag; d.nq = nei[p]->flat.n;
+    std::memcpy(d.Rr, ref[p]->R_wl, 72); std::memcpy(d.tr, ref[p]->t_wl, 24);
+    std::memcpy(d.Rn, nei[p]->R_wl, 72); std::memcpy(d.tn, nei[p]->t_wl, 24);
+    // a target cloud with fewer than 10 points can never satisfy the k = 10 search
+    if (d.ref.n < 10) d.nq = 0;
+    chunk_of_pair[p] = 0;
+    tot_q += d.nq;
+    max_nq = std::max(max_nq, d.nq);
+  }
+  const long long budget_rows = 64ll << 20;  // 64 M query rows per batch (~100 B each)
+  std::vector<int> counts_all;               // accepted per pair
+  std::vector<std::vector<int>> chunk_counts(n_pairs);
+  struct Batch { int p0, p1; long long rows; int chunks; double* d_rec; int* d_nn; unsigned char* d_flag; PairDesc* d_desc; };
+  std::vector<Batch> batches;
+  pvlm_status st = PVLM_OK;
+  auto free_batches = [&]() {
+    hipStreamSynchronize(ctx->stream);
+    for (Batch& b : batches) { hipFree(b.d_rec); hipFree(b.d_nn); hipFree(b.d_flag); hipFree(b.d_desc); }
+    batches.clear();
+  };
+#define FAIL(code) do { st = (code); free_batches(); pvlm_i_resset_free(ctx, rs); return st; } while (0)
+  {
+    int p = 0;
+    while (p < n_pairs) {
+      Batch b{p, p, 0, 0, nullptr, nullptr, nullptr, nullptr};
+      while (b.p1 < n_pairs && (b.p1 == b.p0 || b.rows + descs[b.p1].nq <= budget_rows)) {
+        descs[b.p1].tmp_base = b.rows;
+        descs[b.p1].chunk_base = b.chunks;
+        b.rows += descs[b.p1].nq;
+        b.chunks += (descs[b.p1].nq + 255) / 256;
+        ++b.p1;
+      }
+      batches.push_back(b);
+      p = b.p1;
+    }
+  }
+  // All batches keep their temp arrays until the compaction pass (their total is tot_q rows); when
+  // that would exceed the device budget the caller should split the pair list — checked here.
+  {
+    size_t free_b = 0, total_b = 0;
+    hipMemGetInfo(&free_b, &total_b);
+    const double need = (double)tot_q * (7 * 8 + 10 * 4 + 1) * 1.05 + (double)tot_q * 56.0;
+    if (need > 0.9 * (double)free_b) {
+      PVLM_SET_ERR(ctx, "pvlm_assoc_point2plane: %.1f GB of scratch+output needed, %.1f GB free; split the pair list", need / 1e9, free_b / 1e9);
+      FAIL(PVLM_ERR_NOMEM);
+    }
+  }
+  for (Batch& b : batches) {
+    const int nb = b.p1 - b.p0;
+    if ((st = pvlm_i_alloc(ctx, &b.d_rec, (size_t)std::max<long long>(b.rows, 1) * 7))) FAIL(st);
+    if ((st = pvlm_i_alloc(ctx, &b.d_nn, (size_t)std::max<long long>(b.rows, 1) * 10))) FAIL(st);
+    if ((st = pvlm_i_alloc(ctx, &b.d_flag, (size_t)std::max<long long>(b.rows, 1)))) FAIL(st);
+    if ((st = pvlm_i_alloc(ctx, &b.d_desc, (size_t)nb))) FAIL(st);
+    int* d_cc = nullptr;
+    if ((st = pvlm_i_alloc(ctx, &d_cc, (size_t)std::max(b.chunks, 1)))) FAIL(st);
+    std::vector<int> cc(std::max(b.chunks, 1), 0);
+    hipError_t e = hipMemcpyAsync(b.d_desc, &descs[b.p0], (size_t)nb * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cc, 0, (size_t)std::max(b.chunks, 1) * sizeof(int), ctx->stream);
+    int bmax = 0;
+    for (int p = b.p0; p < b.p1; ++p) bmax = std::max(bmax, descs[p].nq);
+    if (e == hipSuccess && bmax > 0) {
+      pvlm_prof_scope prof(ctx, 2);
+      hipLaunchKernelGGL(k_assoc_p2plane, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, dist_threshold, plane_tolerance,
+                         b.d_nn, b.d_rec, b.d_flag, d_cc, b.rows);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(cc.data(), d_cc, (size_t)std::max(b.chunks, 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_cc);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "association kernel: %s", hipGetErrorString(e)); FAIL(PVLM_ERR_HIP); }
+    for (int p = b.p0; p < b.p1; ++p) {
+      const int nc = (descs[p].nq + 255) / 256;
+      chunk_counts[p].assign(cc.begin() + descs[p].chunk_base, cc.begin() + descs[p].chunk_base + nc);
+    }
+  }
+  // ---- segment table ---------------------------------------------------------------------------
+  rs->h_out_start.assign(n_pairs + 1, 0);
+  rs->h_seg_start.assign(n_pairs + 1, 0);
+  for (int p = 0; p < n_pairs; ++p) {
+    long long m = 0;
+    for (int c : chunk_counts[p]) m += c;
+    rs->h_out_start[p + 1] = rs->h_out_start[p] + m;
+    rs->h_seg_start[p + 1] = rs->h_seg_start[p] + ((m + 1) & ~1ll);
+  }
+  rs->n = rs->h_out_start[n_pairs];
+  rs->n_dev = rs->h_seg_start[n_pairs];
+  if ((st = pvlm_i_alloc(ctx, &rs->d_cols, (size_t)std::max<int64_t>(rs->n_dev, 1) * 7))) FAIL(st);
+  if (hipMemsetAsync(rs->d_cols, 0, (size_t)std::max<int64_t>(rs->n_dev, 1) * 7 * sizeof(double), ctx->stream) != hipSuccess) FAIL(PVLM_ERR_HIP);
+  if (keep_idx) {
+    if ((st = pvlm_i_alloc(ctx, &rs->d_qidx, (size_t)std::max<int64_t>(rs->n, 1)))) FAIL(st);
+    if ((st = pvlm_i_alloc(ctx, &rs->d_nn, (size_t)std::max<int64_t>(rs->n, 1) * 10))) FAIL(st);
+  }
+  // ---- pass 2: ordered compaction ------------------------------------------------------------------
+  for (Batch& b : batches) {
+    const int nb = b.p1 - b.p0;
+    std::vector<long long> dst_dev(std::max(b.chunks, 1)), dst_out(std::max(b.chunks, 1));
+    int bmax = 0;
+    for (int p = b.p0; p < b.p1; ++p) {
+      long long dd = rs->h_seg_start[p], oo = rs->h_out_start[p];
+      for (size_t c = 0; c < chunk_counts[p].size(); ++c) {
+        dst_dev[descs[p].chunk_base + c] = dd; dst_out[descs[p].chunk_base + c] = oo;
+        dd += chunk_counts[p][c]; oo += chunk_counts[p][c];
+      }
+      bmax = std::max(bmax, descs[p].nq);
+    }
+    long long *d_dd = nullptr, *d_oo = nullptr;
+    if ((st = pvlm_i_alloc(ctx, &d_dd, dst_dev.size()))) FAIL(st);
+    if ((st = pvlm_i_alloc(ctx, &d_oo, dst_out.size()))) { hipFree(d_dd); FAIL(st); }
+    hipError_t e = hipMemcpyAsync(d_dd, dst_dev.data(), dst_dev.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_oo, dst_out.data(), dst_out.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && bmax > 0) {
+      hipLaunchKernelGGL(k_compact, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, b.d_flag, b.d_rec, b.d_nn, b.rows, d_dd, d_oo,
+                         rs->d_cols, (long long)rs->n_dev, rs->d_qidx, rs->d_nn);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_dd); hipFree(d_oo);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "compaction: %s", hipGetErrorString(e)); FAIL(PVLM_ERR_HIP); }
+  }
+  free_batches();
+#undef FAIL
+  // ---- device segment table + work list --------------------------------------------------------------
+  auto fail2 = [&](pvlm_status c) { pvlm_i_resset_free(ctx, rs); return c; };
+  if ((st = pvlm_i_alloc(ctx, &rs->d_seg_start, (size_t)n_pairs + 1))) return fail2(st);
+  if ((st = pvlm_i_alloc(ctx, &rs->d_out_start, (size_t)n_pairs + 1))) return fail2(st);
+  if ((st = pvlm_i_alloc(ctx, &rs->d_ref, (size_t)n_pairs))) return fail2(st);
+  if ((st = pvlm_i_alloc(ctx, &rs->d_nei, (size_t)n_pairs))) return fail2(st);
+  hipError_t e = hipMemcpy(rs->d_seg_start, rs->h_seg_start.data(), rs->h_seg_start.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(rs->d_out_start, rs->h_out_start.data(), rs->h_out_start.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_pairs) e = hipMemcpy(rs->d_ref, rs->h_ref.data(), (size_t)n_pairs * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess && n_pairs) e = hipMemcpy(rs->d_nei, rs->h_nei.data(), (size_t)n_pairs * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "segment table upload: %s", hipGetErrorString(e)); return fail2(PVLM_ERR_HIP); }
+  if ((st = pvlm_i_resset_finalize(ctx, rs))) return fail2(st);
+  *out = rs;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, int32_t* qidx, int32_t* nn) {
+  if (!ctx || !rs) return PVLM_ERR_ARG;
+  if (!rs->d_qidx) { PVLM_SET_ERR(ctx, "indices were not kept: pass flag 0x100 to pvlm_assoc_point2plane"); return PVLM_ERR_STATE; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (rs->n == 0) return PVLM_OK;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (qidx) PVLM_HIP(ctx, hipMemcpy(qidx, rs->d_qidx, (size_t)rs->n * sizeof(int), hipMemcpyDeviceToHost));
+  if (nn) PVLM_HIP(ctx, hipMemcpy(nn, rs->d_nn, (size_t)rs->n * 10 * sizeof(int), hipMemcpyDeviceToHost));
+  return PVLM_OK;
+}
+
+}  // extern "C"

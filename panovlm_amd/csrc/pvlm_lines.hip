@@ -1,0 +1,278 @@
+// K4 — vote matrix of AssociateLine2Line (lidar_mapping/LidarFeatureAssociate.cpp:457-473) and
+// K7/K8 — equirectangular projection (sensors/Equirectangular.h) and the point x image-line voting
+// loop of CameraLidarLineAssociate::AssociateByAngle (joint_optimization/
+// CameraLidarLineAssociate.cpp:394-426).  Compiled with -ffp-contract=off: every threshold test
+// must take the same branch as a non-FMA x86-64 build of the reference.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pvlm_internal.h"
+
+// ---- K4 -----------------------------------------------------------------------------------------
+// PointToLineDistance3D (base/Geometry.hpp:198-211), fp64, line = (point, direction).
+__device__ __forceinline__ double point_to_line(double px, double py, double pz, const double* l) {
+  const double x0 = l[0], y0 = l[1], z0 = l[2], nx = l[3], ny = l[4], nz = l[5];
+  const double k = (nx * (px - x0) + ny * (py - y0) + nz * (pz - z0)) / (nx * nx + ny * ny + nz * nz);
+  const double qx = k * nx + x0, qy = k * ny + y0, qz = k * nz + z0;
+  return sqrt((qx - px) * (qx - px) + (qy - py) * (qy - py) + (qz - pz) * (qz - pz));
+}
+
+__global__ __launch_bounds__(256) void k_line_votes(int n_pts, const float* __restrict__ xyz, const int* __restrict__ p2s_off,
+                                                    const int* __restrict__ p2s_ids, int n_ref_seg,
+                                                    const double* __restrict__ ref_lines_world, double thr, int* __restrict__ votes) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_pts * n_ref_seg) return;
+  const int i = g / n_ref_seg, s = g - i * n_ref_seg;
+  const double d = point_to_line((double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2], ref_lines_world + 6 * s);
+  if (d > thr) return;
+  for (int k = p2s_off[i]; k < p2s_off[i + 1]; ++k) atomicAdd(&votes[(size_t)p2s_ids[k] * n_ref_seg + s], 1);
+}
+
+// ---- K7 -----------------------------------------------------------------------------------------
+// FastAtan2 (base/Math.h:15-29).  For T = float the polynomial is evaluated in double (double
+// literals) and rounded to float on assignment, as are M_PI_2 - r and M_PI - r.
+template <typename T>
+__device__ __forceinline__ T fast_atan2(T y, T x) {
+  const T ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;  // std::abs
+  const T mn = ay < ax ? ay : ax, mxv = ax < ay ? ay : ax;  // std::min(ax, ay), std::max(ax, ay)
+  const T a = mn / (mxv + (T)DBL_EPSILON);
+  const T s = a * a;
+  T r = ((-0.04432655554792128 * s + 0.1555786518463281) * s - 0.3258083974640975) * s * a + 0.9997878412794807 * a;
+  if (ay > ax) r = 1.57079632679489661923 - r;
+  if (x < 0) r = 3.14159265358979323846 - r;
+  if (y < 0) r = -r;
+  return r;
+}
+
+template <typename T>
+__global__ void k_cam_to_image(int rows, int cols, long long n, const T* __restrict__ cam, T* __restrict__ px) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T x = cam[3 * i], y = cam[3 * i + 1], z = cam[3 * i + 2];
+  // CamToSphere: (FastAtan2(x, z), -FastAtan2(y, (T)sqrt(x*x + z*z)))   Equirectangular.h:50-51
+  const T lon = fast_atan2<T>(x, z);
+  const T lat = -fast_atan2<T>(y, (T)sqrt((double)(x * x + z * z)));
+  // SphereToImage: cols * (0.5 + lon / (2 pi)), rows * (0.5 - lat / pi)   :84-85
+  px[2 * i] = (T)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
+  px[2 * i + 1] = (T)(rows * (0.5 - lat / 3.14159265358979323846));
+}
+
+template <typename T>
+__global__ void k_image_to_cam(int rows, int cols, long long n, const T* __restrict__ px, T r, T* __restrict__ cam) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // ImageToSphere :102-103 ; SphereToCam :125-128 (float trig evaluated in double and rounded)
+  const T sx = (T)((2 * px[2 * i] / cols - 1) * 3.14159265358979323846);
+  const T sy = (T)((0.5 - px[2 * i + 1] / rows) * 3.14159265358979323846);
+  const T cy = (T)cos((double)sy);
+  cam[3 * i] = r * cy * (T)sin((double)sx);
+  cam[3 * i + 1] = -r * (T)sin((double)sy);
+  cam[3 * i + 2] = r * cy * (T)cos((double)sx);
+}
+
+// ---- K8 -----------------------------------------------------------------------------------------
+__device__ __forceinline__ double vangle(const double* a, const double* b) {  // VectorAngle3D, Geometry.hpp:450-466
+  double c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  const double n1 = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  const double n2 = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+  c = c / (n1 * n2);
+  if (c >= 1.0) return 0.0;
+  if (c <= -1.0) return 3.14159265358979323846;
+  return acos(c);
+}
+
+// line table row: [image_plane(4, normalised) | p4(3) | image_line_scope(1)]
+__global__ __launch_bounds__(256) void k_cam_lidar_votes(int n_pts, const float* __restrict__ xyz_local, const int* __restrict__ p2s_off,
+                                                         const int* __restrict__ p2s_ids, int n_lines, const double* __restrict__ line_tab,
+                                                         const double* __restrict__ T_cl, int n_seg, double angle_thr,
+                                                         int* __restrict__ votes) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)n_pts * n_lines) return;
+  const int li = (int)(g / n_pts), i = (int)(g - (long long)li * n_pts);
+  if (p2s_off[i] == p2s_off[i + 1]) return;
+  const float x = xyz_local[3 * i], y = xyz_local[3 * i + 1], z = xyz_local[3 * i + 2];
+  const float range = x * x + y * y + z * z;                         // :371-372 (float)
+  if (range > 15 * 15) return;                                       // :413
+  // pcl::transformPointCloud(float cloud, Matrix4d): float(m0*x + m1*y + m2*z + m3) in double
+  double p[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    p[r] = (double)(float)(T_cl[r * 4] * (double)x + T_cl[r * 4 + 1] * (double)y + T_cl[r * 4 + 2] * (double)z + T_cl[r * 4 + 3]);
+  const double* L = line_tab + 8 * li;
+  // ProjectPointToPlane(p, image_plane, normalized=true)   Geometry.hpp:301-316
+  const double dis = fabs(L[0] * p[0] + L[1] * p[1] + L[2] * p[2] + L[3]);
+  double pp[3] = {p[0] - dis * L[0], p[1] - dis * L[1], p[2] - dis * L[2]};
+  if (fabs(L[0] * pp[0] + L[1] * pp[1] + L[2] * pp[2] + L[3]) > 1e-4) {
+    pp[0] = p[0] + dis * L[0]; pp[1] = p[1] + dis * L[1]; pp[2] = p[2] + dis * L[2];
+  }
+  if (vangle(p, pp) >= angle_thr) return;                            // :419
+  if (vangle(L + 4, pp) >= L[7] + angle_thr) return;                 // :422
+  for (int k = p2s_off[i]; k < p2s_off[i + 1]; ++k) atomicAdd(&votes[(size_t)li * n_seg + p2s_ids[k]], 1);
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+namespace {
+template <typename T> struct HostEq {
+  int rows, cols;
+  void ImageToCam(const T* px, T r, T* cam) const {
+    T s[2];
+    s[0] = (2 * px[0] / cols - 1) * M_PI;
+    s[1] = (0.5 - px[1] / rows) * M_PI;
+    T cy = (T)std::cos((double)s[1]);
+    cam[0] = r * cy * (T)std::sin((double)s[0]);
+    cam[1] = -r * (T)std::sin((double)s[1]);
+    cam[2] = r * cy * (T)std::cos((double)s[0]);
+  }
+};
+inline double h_vangle(const double* a, const double* b) {
+  double c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  const double n1 = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  const double n2 = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+  c = c / (n1 * n2);
+  if (c >= 1.0) return 0.0;
+  if (c <= -1.0) return M_PI;
+  return std::acos(c);
+}
+}  // namespace
+
+template <typename T, typename K>
+static pvlm_status run_map(pvlm_ctx* ctx, long long n, const T* in, int in_w, T* out, int out_w, K launch) {
+  if (n == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  T *d_in = nullptr, *d_out = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_in, (size_t)n * in_w);
+  if (!st) st = pvlm_i_alloc(ctx, &d_out, (size_t)n * out_w);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(d_in, in, (size_t)n * in_w * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) { launch(d_in, d_out); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * out_w * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "equirect map: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_in); hipFree(d_out);
+  return st;
+}
+
+extern "C" {
+
+pvlm_status pvlm_cam_to_image_f32(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* cam, float* px) {
+  if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!cam || !px))) return PVLM_ERR_ARG;
+  return run_map<float>(ctx, n, cam, 3, px, 2, [&](float* di, float* dout) {
+    hipLaunchKernelGGL(k_cam_to_image<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, dout);
+  });
+}
+pvlm_status pvlm_cam_to_image_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, const double* cam, double* px) {
+  if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!cam || !px))) return PVLM_ERR_ARG;
+  return run_map<double>(ctx, n, cam, 3, px, 2, [&](double* di, double* dout) {
+    hipLaunchKernelGGL(k_cam_to_image<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, dout);
+  });
+}
+pvlm_status pvlm_image_to_cam_f32(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* px, float r, float* cam) {
+  if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!cam || !px))) return PVLM_ERR_ARG;
+  return run_map<float>(ctx, n, px, 2, cam, 3, [&](float* di, float* dout) {
+    hipLaunchKernelGGL(k_image_to_cam<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
+  });
+}
+pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, const double* px, double r, double* cam) {
+  if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!cam || !px))) return PVLM_ERR_ARG;
+  return run_map<double>(ctx, n, px, 2, cam, 3, [&](double* di, double* dout) {
+    hipLaunchKernelGGL(k_image_to_cam<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
+  });
+}
+
+pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm_scan* nei, float dist_threshold, int32_t* votes) {
+  if (!ctx || !ref || !nei || !votes) return PVLM_ERR_ARG;
+  const int nr = ref->n_segments, nn = nei->n_segments, nc = nei->corner.n;
+  if (nr == 0 || nn == 0) return PVLM_OK;
+  std::memset(votes, 0, (size_t)nr * nn * sizeof(int32_t));
+  if (nc == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  // TransformLines(ref.segment_coeffs, ref.GetPose())   LidarFeatureAssociate.cpp:219-236, :455
+  std::vector<double> lw((size_t)nr * 6);
+  for (int s = 0; s < nr; ++s) {
+    const double* c = &ref->h_seg_coeffs[6 * s];
+    const double* R = ref->R_wl; const double* t = ref->t_wl;
+    for (int i = 0; i < 3; ++i) {
+      lw[6 * s + i] = ((R[i * 3] * c[0] + R[i * 3 + 1] * c[1]) + R[i * 3 + 2] * c[2]) + t[i];
+      lw[6 * s + 3 + i] = (R[i * 3] * c[3] + R[i * 3 + 1] * c[4]) + R[i * 3 + 2] * c[5];
+    }
+  }
+  double* d_l = nullptr; int* d_v = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_l, lw.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)nr * nn);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(d_l, lw.data(), lw.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_v, 0, (size_t)nr * nn * sizeof(int), ctx->stream);
+    if (e == hipSuccess) {
+      const long long tot = (long long)nc * nr;
+      hipLaunchKernelGGL(k_line_votes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, nc, nei->corner.d_xyz, nei->d_p2s_off,
+                         nei->d_p2s_ids, nr, d_l, (double)dist_threshold, d_v);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(votes, d_v, (size_t)nr * nn * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "line votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_l); hipFree(d_v);
+  return st;
+}
+
+pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float* lines, int n_lines, const pvlm_scan* lidar,
+                                 const double* T_cl, int32_t* votes) {
+  if (!ctx || !lidar || !T_cl || n_lines < 0 || rows <= 0 || cols <= 0 || (n_lines > 0 && (!lines || !votes))) return PVLM_ERR_ARG;
+  const int ns = lidar->n_segments, np = lidar->corner.n;
+  if (n_lines == 0 || ns == 0) return PVLM_OK;
+  std::memset(votes, 0, (size_t)n_lines * ns * sizeof(int32_t));
+  if (np == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  // per-line constants (CameraLidarLineAssociate.cpp:396-406), host fp64
+  std::vector<double> tab((size_t)n_lines * 8);
+  HostEq<double> eq{rows, cols};
+  for (int li = 0; li < n_lines; ++li) {
+    const float* l = lines + 4 * li;
+    const double a[2] = {l[0], l[1]}, b[2] = {l[2], l[3]};
+    double p1[3], p2[3];
+    eq.ImageToCam(a, 1.0, p1);
+    eq.ImageToCam(b, 1.0, p2);
+    // FormPlane(p1, p2, 0): Geometry.hpp:328-336 with p3 = 0
+    const double p3[3] = {0, 0, 0};
+    double pa = ((p2[1] - p1[1]) * (p3[2] - p1[2]) - (p2[2] - p1[2]) * (p3[1] - p1[1]));
+    double pb = ((p2[2] - p1[2]) * (p3[0] - p1[0]) - (p2[0] - p1[0]) * (p3[2] - p1[2]));
+    double pc = ((p2[0] - p1[0]) * (p3[1] - p1[1]) - (p2[1] - p1[1]) * (p3[0] - p1[0]));
+    double pd = -(pa * p1[0] + pb * p1[1] + pc * p1[2]);
+    const double nn = std::sqrt(pa * pa + pb * pb + pc * pc + pd * pd);
+    if (nn * nn > 0.0) { pa /= nn; pb /= nn; pc /= nn; pd /= nn; }
+    double* t = &tab[8 * li];
+    t[0] = pa; t[1] = pb; t[2] = pc; t[3] = pd;
+    t[4] = (p1[0] + p2[0]) / 2.0; t[5] = (p1[1] + p2[1]) / 2.0; t[6] = (p1[2] + p2[2]) / 2.0;
+    t[7] = h_vangle(p1, t + 4);
+  }
+  double *d_tab = nullptr, *d_T = nullptr; int* d_v = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_tab, tab.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_T, 16);
+  if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)n_lines * ns);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_T, T_cl, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_v, 0, (size_t)n_lines * ns * sizeof(int), ctx->stream);
+    if (e == hipSuccess) {
+      const long long tot = (long long)np * n_lines;
+      const double thr = 3.0 / 180.0 * M_PI;
+      hipLaunchKernelGGL(k_cam_lidar_votes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, np, lidar->corner.d_xyz,
+                         lidar->d_p2s_off, lidar->d_p2s_ids, n_lines, d_tab, d_T, ns, thr, d_v);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(votes, d_v, (size_t)n_lines * ns * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "cam-lidar votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_tab); hipFree(d_T); hipFree(d_v);
+  return st;
+}
+
+}  // extern "C"

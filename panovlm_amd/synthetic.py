@@ -1,0 +1,138 @@
+"""Deterministic synthetic VLP-16 scans (BASELINE.md §2 / SURVEY.md §8d): workload generator
+shared by bench.py and the tests.  numpy only; not part of the compute path.
+
+Scene: a 8 x 3 x 12 m box room (x right, y down, z forward — the axis convention of
+sensors/Velodyne.cpp:125-132) with 6 interior boxes.  Scan k is ray-cast from the TRUE pose
+(0.1 m per step along z, bouncing between the end walls, 0.5 deg yaw per step) with 16 lasers
+(-15..+15 deg, 2 deg apart, sensors/Velodyne.cpp:176) x `cols` azimuth steps and sigma = 1 cm range
+noise.  The feature clouds handed to the association are the LOCAL float32 points moved to the world
+frame with the ESTIMATED pose (true pose perturbed by <= 2 cm / 0.5 deg), rounded to float32 per
+coordinate exactly like pcl::transformPointCloud(cloud, Matrix4d) does (sensors/Velodyne.cpp:1791).
+Every point is tagged POINT_NORMAL (=1) and is both a surfFlat query and a surfLessFlat target.
+"""
+import numpy as np
+
+SEED = 20240601
+ROOM_MIN = np.array([-4.0, -1.5, -6.0])
+ROOM_MAX = np.array([4.0, 1.5, 6.0])
+
+
+def _yaw(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def scene_boxes(seed=SEED):
+    rng = np.random.default_rng(seed)
+    boxes = []
+    for i in range(6):
+        side = -1.0 if i % 2 == 0 else 1.0
+        cx = side * rng.uniform(1.8, 3.2)
+        cz = -5.0 + 10.0 * (i + 0.5) / 6.0 + rng.uniform(-0.3, 0.3)
+        half = np.array([rng.uniform(0.3, 0.7), rng.uniform(0.4, 1.2), rng.uniform(0.3, 0.8)])
+        c = np.array([cx, 1.5 - half[1], cz])  # standing on the floor (y down)
+        boxes.append((c - half, c + half))
+    return boxes
+
+
+def true_pose(k):
+    """T_wl of frame k: 0.1 m steps along z bouncing in [-3.5, 3.5], yaw 0.5 deg per step."""
+    span = 70  # steps per leg
+    m = k % (2 * span)
+    z = -3.5 + 0.1 * (m if m <= span else 2 * span - m)
+    return _yaw(np.deg2rad(0.5) * k), np.array([0.0, 0.0, z])
+
+
+def estimated_pose(k, seed=SEED):
+    rng = np.random.default_rng(seed + 7919 * (k + 1))
+    R, t = true_pose(k)
+    if k == 0:
+        return R, t
+    d = rng.uniform(-np.deg2rad(0.5), np.deg2rad(0.5), size=3)
+    th = np.linalg.norm(d)
+    K = np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
+    dR = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+    return dR @ R, t + rng.uniform(-0.02, 0.02, size=3)
+
+
+def _ray_aabb(o, d, lo, hi):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        t1 = (lo - o) * inv
+        t2 = (hi - o) * inv
+    tn = np.minimum(t1, t2).max(axis=1)
+    tf = np.maximum(t1, t2).min(axis=1)
+    return tn, tf
+
+
+def raycast_local(k, cols=4096, rings=16, seed=SEED, noise=0.01):
+    """Local-frame float32 point cloud of scan k, ring-major (rings x cols, 3)."""
+    R, t = true_pose(k)
+    el = np.deg2rad(-15.0 + 2.0 * np.arange(rings))
+    az = 2 * np.pi * (np.arange(cols) + 0.5) / cols
+    ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+    dl = np.stack([ce * np.sin(az)[None, :], -se * np.ones_like(az)[None, :], ce * np.cos(az)[None, :]], axis=-1).reshape(-1, 3)
+    dw = dl @ R.T
+    o = t[None, :]
+    _, tf = _ray_aabb(o, dw, ROOM_MIN, ROOM_MAX)
+    rng_ = tf.copy()
+    for lo, hi in scene_boxes(seed):
+        tn, tf2 = _ray_aabb(o, dw, lo, hi)
+        hit = (tn > 0) & (tn <= tf2)
+        rng_ = np.where(hit & (tn < rng_), tn, rng_)
+    rng_ = rng_ + np.random.default_rng(seed + 104729 * (k + 1)).normal(size=rng_.shape) * noise
+    return (dl * rng_[:, None]).astype(np.float32)
+
+
+def to_world_f32(local_f32, R_wl, t_wl):
+    """pcl::transformPointCloud(float cloud, Matrix4d): per coordinate float(m0*x + m1*y + m2*z + m3)."""
+    p = local_f32.astype(np.float64)
+    out = np.empty_like(p)
+    for r in range(3):
+        out[:, r] = ((R_wl[r, 0] * p[:, 0] + R_wl[r, 1] * p[:, 1]) + R_wl[r, 2] * p[:, 2]) + t_wl[r]
+    return out.astype(np.float32)
+
+
+def make_scan(k, cols=4096, rings=16, seed=SEED, downsample_targets=0.0):
+    """Scan dict for panovlm_amd.Scan / the oracle.  downsample_targets > 0 voxel-subsamples the
+    surfLessFlat target cloud (first point per voxel), as the real extractor does at 0.2 m."""
+    local = raycast_local(k, cols, rings, seed)
+    R, t = estimated_pose(k, seed)
+    world = to_world_f32(local, R, t)
+    less = world
+    if downsample_targets > 0:
+        key = np.floor(local / downsample_targets).astype(np.int64)
+        _, first = np.unique(key, axis=0, return_index=True)
+        less = world[np.sort(first)]
+    return dict(id=k, R_wl=R, t_wl=t, flat_xyz=world, flat_tag=np.ones(len(world), np.float32),
+                less_xyz=less, less_tag=np.ones(len(less), np.float32), local_xyz=local)
+
+
+def pose_params(R_wl, t_wl):
+    """(angleAxis_lw, t_lw) parameter blocks of T_lw = T_wl^-1 (lidar_mapping/LidarOdometry.cpp:27-33)."""
+    R = R_wl.T
+    t = -R @ t_wl
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    if th < 1e-12:
+        aa = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    else:
+        aa = th / (2 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return aa, t
+
+
+def pair_list(F, nb):
+    """Ordered (ref, nei) pairs: every scan against its nb temporally nearest scans."""
+    ref, nei = [], []
+    half = nb // 2
+    for i in range(F):
+        cand = [i + d for d in range(-half, half + 1) if d != 0 and 0 <= i + d < F]
+        j = 1
+        while len(cand) < min(nb, F - 1):
+            for c in (i - half - j, i + half + j):
+                if 0 <= c < F and c not in cand and len(cand) < nb:
+                    cand.append(c)
+            j += 1
+        for c in cand:
+            ref.append(i); nei.append(c)
+    return np.array(ref, np.int32), np.array(nei, np.int32)

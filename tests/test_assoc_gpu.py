@@ -1,0 +1,145 @@
+"""GPU parity of the association kernels (voxel-hash k-NN, plane fit + accept tests, ordered
+compaction, line votes) against the CPU oracle through the C ABI.  Bar: correspondence indices
+bit-exact; fp64 records bit-exact too (same arithmetic, no FMA contraction in these kernels)."""
+import numpy as np
+import pytest
+
+from panovlm_amd import synthetic as sy
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+KEEP = 0x100
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import panovlm_amd as pv
+    c = pv.Context(0)
+    yield c
+    c.close()
+
+
+def _check_knn(ctx, oracle, tgt, q, k, max_dist):
+    import panovlm_amd as pv
+    scan = pv.Scan(ctx, dict(id=0, less_xyz=tgt, corner_xyz=tgt))
+    for which in (0, 1):
+        idx, sqd = ctx.knn(scan, q, k, max_dist, which=which)
+        oi, od = oracle.knn(tgt, q, k)
+        thr2 = np.float32(max_dist) * np.float32(max_dist)
+        valid = od <= thr2
+        exp_i = np.where(valid, oi, -1)
+        exp_d = np.where(valid, od, np.float32(np.inf))
+        assert np.array_equal(idx, exp_i), (np.argwhere(idx != exp_i)[:5], idx[idx != exp_i][:5], exp_i[idx != exp_i][:5])
+        assert np.array_equal(sqd, exp_d)
+    scan.close()
+
+
+def test_knn_random_cloud(ctx, oracle):
+    rng = np.random.default_rng(11)
+    tgt = (rng.normal(size=(5000, 3)) * 2).astype(np.float32)
+    q = (rng.normal(size=(3000, 3)) * 2.2).astype(np.float32)
+    _check_knn(ctx, oracle, tgt, q, 10, 1.0)
+    _check_knn(ctx, oracle, tgt, q, 5, 0.3)
+
+
+def test_knn_vlp_geometry_and_ties(ctx, oracle):
+    a = sy.make_scan(2, cols=1024)["flat_xyz"]
+    b = sy.make_scan(3, cols=1024)["flat_xyz"]
+    _check_knn(ctx, oracle, a, b, 10, 1.0)
+    # duplicated targets -> exact distance ties, resolved by ascending index on both sides
+    dup = np.concatenate([a[:2000], a[:2000]])
+    _check_knn(ctx, oracle, dup, b[:1500], 10, 1.0)
+    # queries identical to targets (distance 0)
+    _check_knn(ctx, oracle, a[:3000], a[:3000], 5, 0.5)
+
+
+def _compare_assoc(ctx, oracle, scans, pairs, tol, thr):
+    import panovlm_amd as pv
+    dev = {k: pv.Scan(ctx, s) for k, s in scans.items()}
+    rs = ctx.assoc_point2plane([dev[r] for r, _ in pairs], [dev[n] for _, n in pairs], tol, thr,
+                               kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE | KEEP)
+    off, ref, nei, rows = rs.download()
+    qidx, nn = rs.assoc_debug()
+    assert list(ref) == [scans[r]["id"] for r, _ in pairs] and list(nei) == [scans[n]["id"] for _, n in pairs]
+    total = 0
+    for p, (r, n) in enumerate(pairs):
+        o = oracle.assoc_point2plane(scans[r], scans[n], tol, thr)
+        s, e = off[p], off[p + 1]
+        assert e - s == len(o["qidx"]), (p, e - s, len(o["qidx"]))
+        assert np.array_equal(qidx[s:e], o["qidx"])
+        assert np.array_equal(nn[s:e], o["nn"])
+        assert np.array_equal(rows[s:e, 0:3], o["point"]), np.abs(rows[s:e, 0:3] - o["point"]).max()
+        assert np.array_equal(rows[s:e, 3:7], o["plane"]), np.abs(rows[s:e, 3:7] - o["plane"]).max()
+        total += e - s
+    assert rs.n == total
+    rs.close()
+    for d in dev.values():
+        d.close()
+    return total
+
+
+def test_point2plane_dense_synthetic(ctx, oracle):
+    scans = {k: sy.make_scan(k, cols=512) for k in (0, 1, 2)}
+    n = _compare_assoc(ctx, oracle, scans, [(0, 1), (1, 0), (1, 2), (2, 0)], 0.05, 1.0)
+    assert n > 1000
+    _compare_assoc(ctx, oracle, scans, [(0, 1), (2, 1)], 0.01, 1.0)   # Floor tolerance
+
+
+def test_point2plane_downsampled_targets_and_small_threshold(ctx, oracle):
+    scans = {k: sy.make_scan(k, cols=1024, downsample_targets=0.2) for k in (5, 6)}
+    n = _compare_assoc(ctx, oracle, scans, [(5, 6), (6, 5)], 0.05, 1.0)
+    assert n > 500
+    _compare_assoc(ctx, oracle, scans, [(5, 6)], 0.05, 0.35)        # many queries fail the 10th-neighbour test
+
+
+def test_point2plane_edge_cases(ctx, oracle):
+    rng = np.random.default_rng(3)
+    base = sy.make_scan(1, cols=256)
+    few = dict(base); few["id"] = 7; few["less_xyz"] = base["less_xyz"][:9]; few["less_tag"] = base["less_tag"][:9]   # < 10 targets
+    empty_q = dict(base); empty_q["id"] = 8; empty_q["flat_xyz"] = np.zeros((0, 3), np.float32); empty_q["flat_tag"] = np.zeros(0, np.float32)
+    mixed = dict(sy.make_scan(2, cols=256)); mixed["id"] = 9
+    tags = np.where(rng.uniform(size=len(mixed["less_xyz"])) < 0.2, 16.0, 1.0).astype(np.float32)  # POINT_GROUND sprinkled in
+    mixed["less_tag"] = tags
+    mixed["flat_tag"] = np.where(rng.uniform(size=len(mixed["flat_xyz"])) < 0.5, 16.0, 1.0).astype(np.float32)
+    far = dict(sy.make_scan(3, cols=256)); far["id"] = 10
+    far["flat_xyz"] = far["flat_xyz"] + np.float32(50.0)                    # queries far outside the target grid
+    scans = {1: base, 7: few, 8: empty_q, 9: mixed, 10: far}
+    _compare_assoc(ctx, oracle, scans, [(7, 1), (1, 8), (9, 1), (1, 9), (9, 9), (1, 10), (1, 1)], 0.05, 1.0)
+
+
+def test_point2plane_residual_set_is_evaluable(ctx, oracle):
+    """The association output feeds the evaluation kernels directly (device-resident hand-off)."""
+    import panovlm_amd as pv
+    scans = {k: sy.make_scan(k, cols=256) for k in (0, 1)}
+    dev = {k: pv.Scan(ctx, s) for k, s in scans.items()}
+    rs = ctx.assoc_point2plane([dev[0], dev[1]], [dev[1], dev[0]], 0.05, 1.0, kind=pv.POINT2PLANE_ANGLE, flags=1)
+    aa, t = zip(*[sy.pose_params(scans[k]["R_wl"], scans[k]["t_wl"]) for k in (0, 1)])
+    aa, t = np.array(aa), np.array(t)
+    ctx.set_poses(aa, t)
+    r, J = rs.eval()
+    off, ref, nei, rows = rs.download()
+    rid, nid = synth.expand_ids(off, ref, nei)
+    ro, Jo = oracle.evaluate(1, synth.oracle_rows(1, rows), rid, nid, aa, t, normalize=True)
+    assert np.allclose(r, ro, rtol=1e-6, atol=1e-12) and np.allclose(J, Jo, rtol=1e-6, atol=1e-9)
+    assert np.median(r[r > 0]) < 0.05   # radians: scans are ~cm-aligned
+    with pytest.raises(pv.PvlmError):
+        rs.assoc_debug()                # indices were not requested
+    rs.close()
+
+
+def test_line2line_votes(ctx, oracle):
+    import panovlm_amd as pv
+    rng = np.random.default_rng(21)
+    lines = synth.random_world_lines(rng, 14)
+    Ra, ta = sy.estimated_pose(3); Rb, tb = sy.estimated_pose(4)
+    a = synth.make_line_scan(rng, 3, Ra, ta, lines[:12])
+    b = synth.make_line_scan(rng, 4, Rb, tb, lines[2:])
+    da, db = pv.Scan(ctx, a), pv.Scan(ctx, b)
+    for thr in (0.3, 0.4, 0.05):
+        v = ctx.line2line_votes(da, db, thr)
+        o = oracle.assoc_line2line(a, b, thr)
+        assert v.shape == o["votes"].shape and np.array_equal(v, o["votes"])
+        v2 = ctx.line2line_votes(db, da, thr)
+        assert np.array_equal(v2, oracle.assoc_line2line(b, a, thr)["votes"])
+    assert v.sum() > 0
+    da.close(); db.close()

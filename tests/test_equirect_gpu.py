@@ -1,0 +1,66 @@
+"""GPU parity of the equirectangular model (K7) and the camera<->LiDAR voting loop (K8)."""
+import numpy as np
+import pytest
+
+from panovlm_amd import synthetic as sy
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import panovlm_amd as pv
+    c = pv.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("rows,cols", [(2880, 5760), (720, 1440)])
+def test_cam_to_image_bit_exact(ctx, oracle, rows, cols):
+    rng = np.random.default_rng(5)
+    cam = rng.normal(size=(20000, 3)) * np.array([3.0, 1.0, 3.0])
+    cam[:50, 0] = 0.0; cam[50:100, 2] = 0.0; cam[100:150, 1] = 0.0; cam[150:160] = 0.0   # axis / degenerate cases
+    cam[160:200] *= 1e-6
+    f32 = cam.astype(np.float32)
+    assert np.array_equal(ctx.cam_to_image(rows, cols, f32), oracle.cam_to_image(rows, cols, f32), equal_nan=True)
+    assert np.array_equal(ctx.cam_to_image(rows, cols, cam), oracle.cam_to_image(rows, cols, cam), equal_nan=True)
+
+
+@pytest.mark.parametrize("rows,cols", [(2880, 5760), (720, 1440)])
+def test_image_to_cam(ctx, oracle, rows, cols):
+    rng = np.random.default_rng(6)
+    px = rng.uniform([0, 0], [cols, rows], size=(20000, 2))
+    g = ctx.image_to_cam(rows, cols, px, 1.0); o = oracle.image_to_cam(rows, cols, px, 1.0)
+    assert np.abs(g - o).max() <= 4e-16          # device vs glibc sin/cos differ by <= 1 ulp
+    g32 = ctx.image_to_cam(rows, cols, px.astype(np.float32), 5.0); o32 = oracle.image_to_cam(rows, cols, px.astype(np.float32), 5.0)
+    assert np.abs(g32 - o32).max() <= 1e-6 and np.mean(g32 == o32) > 0.999
+    # round trip pixel -> ray -> pixel through the fast-atan2 model: ~0.3 deg accuracy (Math.h:9-10)
+    back = ctx.cam_to_image(rows, cols, g)
+    err = np.abs(back - px); err[:, 0] = np.minimum(err[:, 0], cols - err[:, 0])
+    assert err.max() < cols * 0.35 / 360 * 2
+
+
+def test_cam_lidar_votes(ctx, oracle):
+    import panovlm_amd as pv
+    rng = np.random.default_rng(8)
+    rows, cols = 2880, 5760
+    lines_w = synth.random_world_lines(rng, 10, extent=3.0)
+    R, t = np.eye(3), np.zeros(3)
+    scan = synth.make_line_scan(rng, 0, R, t, lines_w, pts_per_line=(20, 60), extra_pts=50)
+    local = dict(scan); local["corner_xyz"] = scan["corner_local"]
+    # camera ~ LiDAR with a small calibration offset
+    a = np.deg2rad(rng.uniform(-2, 2, size=3))
+    T = np.eye(4); T[:3, :3] = synth.rodrigues(a); T[:3, 3] = rng.uniform(-0.05, 0.05, size=3)
+    ends_cam = (scan["end_points"].reshape(-1, 3) @ T[:3, :3].T + T[:3, 3])
+    px = oracle.cam_to_image(rows, cols, ends_cam).reshape(-1, 4).astype(np.float32)
+    px += rng.normal(size=px.shape).astype(np.float32) * 2.0
+    extra = rng.uniform([0, 0, 0, 0], [cols, rows, cols, rows], size=(6, 4)).astype(np.float32)
+    lines = np.concatenate([px, extra])
+    dscan = pv.Scan(ctx, local)
+    v = ctx.cam_lidar_votes(rows, cols, lines, dscan, T)
+    o = oracle.assoc_by_angle(rows, cols, lines, local, T, multiple=True)
+    assert v.shape == o["votes"].shape
+    assert np.array_equal(v, o["votes"])
+    assert v.sum() > 50 and len(o["image_line_id"]) > 0
+    dscan.close()
