@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* 
   for (int k = 0; k < K; ++k) { idx[(size_t)i * K + k] = tk.id[k]; sqd[(size_t)i * K + k] = tk.d[k]; }
 }
 
-// ---- K3: fp64 fits (identical arithmetic to oracle/geometry.hpp, fully unrolled, static indexing) ----
+// ---- K3: fp64 fits (sequential-sum Householder/Jacobi arithmetic the parity tests pin, fully unrolled, static indexing) ----
 struct Fit10 {
   // Householder QR with column pivoting on the 10x3 system A n = -1 (Eigen ColPivHouseholderQR
   // restated, base/Geometry.hpp:345-373), then the tolerance test.  c0,c1,c2 = columns (destroyed).
@@ -348,7 +348,7 @@ struct Fit10 {
   }
 
   // FormLine(points, 3.0) is non-zero  <=>  largest eigenvalue > tol * middle eigenvalue of the
-  // scatter matrix (base/Geometry.hpp:220-260); cyclic Jacobi identical to oracle/geometry.hpp.
+  // scatter matrix (base/Geometry.hpp:220-260); cyclic Jacobi, fixed sweep order (0,1),(0,2),(1,2).
   static __device__ bool is_line(const double* px, const double* py, const double* pz, double tol) {
     double cx = 0.0, cy = 0.0, cz = 0.0;
 #pragma unroll
@@ -361,7 +361,7 @@ struct Fit10 {
       a00 = a00 + dx * dx; a01 = a01 + dx * dy; a02 = a02 + dx * dz;
       a11 = a11 + dy * dy; a12 = a12 + dy * dz; a22 = a22 + dz * dz;
     }
-    // the oracle accumulates the full 3x3 (S[r][c] += d[r]*d[c]); symmetric entries are bitwise equal
+    // only the upper triangle is accumulated: S[r][c] += d[r]*d[c] is symmetric bit for bit
     for (int sweep = 0; sweep < 12; ++sweep) {
       const double off = a01 * a01 + a02 * a02 + a12 * a12;
       if (off == 0.0) break;

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory (run from the repo root in the development
+container: `python tests/golden/make_golden.py`).
+
+  fast_atan2.npz   inputs + outputs of the REAL reference base/Math.h::FastAtan2 (float and double),
+                   produced by oracle/_ref/libref_math.so, i.e. compiled from /root/reference itself.
+  everything else  inputs + outputs of the CPU oracle (the restated reference algorithm; the reference
+                   has no tests / vectors of its own and cannot be built here — "parity unpinned").
+The fixtures are data only (numpy arrays): seeded inputs and expected outputs.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc  # noqa: E402
+from panovlm_amd import synthetic as sy  # noqa: E402
+from tests import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def fast_atan2():
+    ref = orc.ref_math()
+    assert ref is not None, "oracle/_ref/libref_math.so missing: run `make -C oracle` with /root/reference present"
+    rng = np.random.default_rng(1)
+    y = np.concatenate([rng.normal(size=3000) * 3, [0, 0, 1, -1, 0, 1e-30, -1e-30, 5, -5, 1, 1, -1, -1]])
+    x = np.concatenate([rng.normal(size=3000) * 3, [0, 1, 0, 0, -1, 1e-30, 1e-30, 5, 5, 1e-9, -1e-9, 1e-9, -1e-9]])
+    yf, xf = y.astype(np.float32), x.astype(np.float32)
+    of = np.empty_like(yf); od = np.empty_like(y)
+    ref.ref_fast_atan2_f_vec(C.c_long(len(yf)), yf.ctypes.data_as(C.POINTER(C.c_float)), xf.ctypes.data_as(C.POINTER(C.c_float)), of.ctypes.data_as(C.POINTER(C.c_float)))
+    ref.ref_fast_atan2_d_vec(C.c_long(len(y)), y.ctypes.data_as(C.POINTER(C.c_double)), x.ctypes.data_as(C.POINTER(C.c_double)), od.ctypes.data_as(C.POINTER(C.c_double)))
+    np.savez_compressed(os.path.join(OUT, "fast_atan2.npz"), y=y, x=x, out_f32=of, out_f64=od)
+
+
+def functors():
+    d = {}
+    for kind, normalize in [(0, False), (1, False), (1, True), (2, False), (3, False), (3, True), (4, False), (5, False)]:
+        rng = np.random.default_rng(1000 + kind * 2 + int(normalize))
+        F, P = 6, 16
+        aa, t = synth.random_poses(rng, F)
+        ref, nei = synth.random_pairs(rng, F, P)
+        counts = rng.integers(0, 24, size=P)
+        rows, off = synth.random_resset(rng, kind, aa, t, ref, nei, counts)
+        rid, nid = synth.expand_ids(off, ref, nei)
+        w = 1.3
+        r, J = orc.evaluate(kind, synth.oracle_rows(kind, rows, w), rid, nid, aa, t, normalize=normalize)
+        k = "k%d_n%d_" % (kind, int(normalize))
+        d.update({k + "aa": aa, k + "t": t, k + "ref": ref, k + "nei": nei, k + "off": off, k + "rows": rows, k + "r": r, k + "J": J})
+    d["weight"] = np.array(1.3)
+    np.savez_compressed(os.path.join(OUT, "functors.npz"), **d)
+
+
+def _scan_arrays(s, keys=("R_wl", "t_wl", "flat_xyz", "flat_tag", "less_xyz", "less_tag")):
+    return {k: np.asarray(s[k]) for k in keys}
+
+
+def assoc():
+    d = {}
+    scans = {k: sy.make_scan(k, cols=128) for k in (0, 1)}
+    scans[2] = sy.make_scan(2, cols=256, downsample_targets=0.2)
+    for k, s in scans.items():
+        for kk, v in _scan_arrays(s).items():
+            d["s%d_%s" % (k, kk)] = v
+    cases = [(0, 1, 0.05, 1.0), (1, 0, 0.01, 1.0), (2, 1, 0.05, 1.0), (1, 2, 0.05, 0.5)]
+    d["cases"] = np.array(cases)
+    for i, (r, n, tol, thr) in enumerate(cases):
+        o = orc.assoc_point2plane(scans[r], scans[n], tol, thr)
+        for kk in ("point", "plane", "qidx", "nn"):
+            d["c%d_%s" % (i, kk)] = o[kk]
+    np.savez_compressed(os.path.join(OUT, "assoc_point2plane.npz"), **d)
+
+
+def equirect():
+    rng = np.random.default_rng(5)
+    cam = rng.normal(size=(4000, 3)) * np.array([3.0, 1.0, 3.0])
+    cam[:20, 0] = 0; cam[20:40, 2] = 0; cam[40:60, 1] = 0
+    d = dict(cam=cam)
+    for rows, cols in [(2880, 5760), (720, 1440)]:
+        d["px_f32_%d" % rows] = orc.cam_to_image(rows, cols, cam.astype(np.float32))
+        d["px_f64_%d" % rows] = orc.cam_to_image(rows, cols, cam)
+        px = rng.uniform([0, 0], [cols, rows], size=(500, 2))
+        d["pix_%d" % rows] = px
+        d["cam_f64_%d" % rows] = orc.image_to_cam(rows, cols, px, 1.0)
+        d["seg_%d" % rows] = orc.break_to_segments(rows, cols, [100.0, 200.0], [cols - 150.0, rows - 300.0], 100.0)
+    np.savez_compressed(os.path.join(OUT, "equirect.npz"), **d)
+
+
+def _line_scan_arrays(s):
+    off = np.zeros(len(s["p2s"]) + 1, np.int32)
+    for i, l in enumerate(s["p2s"]):
+        off[i + 1] = off[i] + len(l)
+    ids = np.array([v for l in s["p2s"] for v in l], np.int32)
+    return dict(R_wl=s["R_wl"], t_wl=s["t_wl"], corner_xyz=s["corner_xyz"], corner_local=s["corner_local"], p2s_off=off, p2s_ids=ids,
+                seg_size=s["seg_size"], seg_coeffs=s["seg_coeffs"], end_points=s["end_points"])
+
+
+def lines():
+    rng = np.random.default_rng(21)
+    lw = synth.random_world_lines(rng, 10)
+    Ra, ta = sy.estimated_pose(3); Rb, tb = sy.estimated_pose(4)
+    a = synth.make_line_scan(rng, 3, Ra, ta, lw[:8], pts_per_line=(6, 20), extra_pts=10)
+    b = synth.make_line_scan(rng, 4, Rb, tb, lw[2:], pts_per_line=(6, 20), extra_pts=10)
+    d = {}
+    for name, s in (("a", a), ("b", b)):
+        for k, v in _line_scan_arrays(s).items():
+            d[name + "_" + k] = v
+    for thr in (0.3, 0.4):
+        o = orc.assoc_line2line(a, b, thr)
+        t = "t%02d_" % int(thr * 10)
+        d.update({t + "votes": o["votes"], t + "nei_idx": o["nei_idx"], t + "ref_idx": o["ref_idx"], t + "p1": o["p1"], t + "p2": o["p2"]})
+    # camera <-> LiDAR by angle
+    rows, cols = 2880, 5760
+    rng = np.random.default_rng(8)
+    lw = synth.random_world_lines(rng, 8, extent=3.0)
+    scan = synth.make_line_scan(rng, 0, np.eye(3), np.zeros(3), lw, pts_per_line=(20, 40), extra_pts=30)
+    local = dict(scan); local["corner_xyz"] = scan["corner_local"]
+    ang = np.deg2rad(rng.uniform(-2, 2, size=3))
+    T = np.eye(4); T[:3, :3] = synth.rodrigues(ang); T[:3, 3] = rng.uniform(-0.05, 0.05, size=3)
+    ends_cam = scan["end_points"].reshape(-1, 3) @ T[:3, :3].T + T[:3, 3]
+    px = orc.cam_to_image(rows, cols, ends_cam).reshape(-1, 4).astype(np.float32)
+    px += rng.normal(size=px.shape).astype(np.float32) * 2.0
+    img_lines = np.concatenate([px, rng.uniform([0, 0, 0, 0], [cols, rows, cols, rows], size=(4, 4)).astype(np.float32)])
+    for k, v in _line_scan_arrays(scan).items():
+        d["c_" + k] = v
+    d["c_T_cl"] = T; d["c_lines"] = img_lines
+    for mult in (1, 0):
+        o = orc.assoc_by_angle(rows, cols, img_lines, local, T, multiple=bool(mult))
+        m = "m%d_" % mult
+        d.update({m + "image_line_id": o["image_line_id"], m + "lidar_line_id": o["lidar_line_id"], m + "score": o["score"],
+                  m + "start": o["start"], m + "end": o["end"]})
+    d["c_votes"] = o["votes"]
+    np.savez_compressed(os.path.join(OUT, "lines.npz"), **d)
+
+
+def neighbors():
+    rng = np.random.default_rng(9)
+    F = 40
+    poses = np.zeros((F, 12)); valid = np.ones(F, np.int32)
+    for i in range(F):
+        R, t = sy.true_pose(i * 7)
+        poses[i, :9] = R.reshape(-1); poses[i, 9:] = t + rng.normal(size=3) * 0.01
+    poses[13, :9] = 0; poses[13, 9:] = np.inf; valid[13] = 0   # invalid pose sentinel (Velodyne.cpp:50-51)
+    nb = orc.find_neighbors(poses, valid, 6)
+    off = np.zeros(F + 1, np.int32)
+    for i, l in enumerate(nb):
+        off[i + 1] = off[i] + len(l)
+    np.savez_compressed(os.path.join(OUT, "neighbors.npz"), poses=poses, valid=valid, off=off, ids=np.array([v for l in nb for v in l], np.int32))
+
+
+if __name__ == "__main__":
+    orc.build()
+    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors()
+    tot = 0
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            sz = os.path.getsize(os.path.join(OUT, f)); tot += sz
+            print("%-26s %7d bytes" % (f, sz))
+    print("total", tot)

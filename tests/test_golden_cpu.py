@@ -1,0 +1,113 @@
+"""CPU suite: the oracle against the committed golden vectors, and the oracle's FastAtan2 against
+the REAL reference header (oracle/_ref, compiled from /root/reference/base/Math.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_fast_atan2_golden_is_the_real_reference(oracle):
+    g = load("fast_atan2.npz")
+    y, x = g["y"], g["x"]
+    of = np.array([oracle.fast_atan2_f(a, b) for a, b in zip(y.astype(np.float32), x.astype(np.float32))], np.float32)
+    od = np.array([oracle.fast_atan2_d(a, b) for a, b in zip(y, x)])
+    assert np.array_equal(of, g["out_f32"], equal_nan=True)
+    assert np.array_equal(od, g["out_f64"], equal_nan=True)
+    # accuracy claim of base/Math.h:9-10 (~0.3 degree) on non-degenerate inputs
+    m = (np.abs(x) + np.abs(y)) > 1e-6
+    assert np.abs(od[m] - np.arctan2(y[m], x[m])).max() < np.deg2rad(0.35)
+
+
+def test_ref_build_matches_oracle_bitwise(oracle):
+    ref = oracle.ref_math()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(77)
+    y = rng.normal(size=20000) * rng.choice([1e-3, 1, 100], size=20000)
+    x = rng.normal(size=20000) * rng.choice([1e-3, 1, 100], size=20000)
+    for a, b in zip(y[:4000], x[:4000]):
+        assert ref.ref_fast_atan2_d(a, b) == oracle.fast_atan2_d(a, b)
+        af, bf = np.float32(a), np.float32(b)
+        assert ref.ref_fast_atan2_f(C.c_float(af), C.c_float(bf)) == oracle.fast_atan2_f(af, bf)
+
+
+@pytest.mark.parametrize("kind,normalize", [(0, 0), (1, 0), (1, 1), (2, 0), (3, 0), (3, 1), (4, 0), (5, 0)])
+def test_functor_golden(oracle, kind, normalize):
+    g = load("functors.npz")
+    k = "k%d_n%d_" % (kind, normalize)
+    rid, nid = synth.expand_ids(g[k + "off"], g[k + "ref"], g[k + "nei"])
+    r, J = oracle.evaluate(kind, synth.oracle_rows(kind, g[k + "rows"], float(g["weight"])), rid, nid, g[k + "aa"], g[k + "t"], normalize=bool(normalize))
+    assert np.allclose(r, g[k + "r"], rtol=1e-12, atol=1e-15) and np.allclose(J, g[k + "J"], rtol=1e-11, atol=1e-13)
+
+
+def _scan(g, k):
+    return {kk: g["s%d_%s" % (k, kk)] for kk in ("R_wl", "t_wl", "flat_xyz", "flat_tag", "less_xyz", "less_tag")} | {"id": k}
+
+
+def test_assoc_point2plane_golden(oracle):
+    g = load("assoc_point2plane.npz")
+    for i, (r, n, tol, thr) in enumerate(g["cases"]):
+        o = oracle.assoc_point2plane(_scan(g, int(r)), _scan(g, int(n)), float(tol), float(thr))
+        assert np.array_equal(o["qidx"], g["c%d_qidx" % i]) and np.array_equal(o["nn"], g["c%d_nn" % i])
+        assert np.array_equal(o["point"], g["c%d_point" % i]) and np.array_equal(o["plane"], g["c%d_plane" % i])
+        assert len(o["qidx"]) > 50
+
+
+def test_equirect_golden(oracle):
+    g = load("equirect.npz")
+    for rows, cols in [(2880, 5760), (720, 1440)]:
+        assert np.array_equal(oracle.cam_to_image(rows, cols, g["cam"].astype(np.float32)), g["px_f32_%d" % rows], equal_nan=True)
+        assert np.array_equal(oracle.cam_to_image(rows, cols, g["cam"]), g["px_f64_%d" % rows], equal_nan=True)
+        assert np.allclose(oracle.image_to_cam(rows, cols, g["pix_%d" % rows], 1.0), g["cam_f64_%d" % rows], atol=1e-15)
+        seg = oracle.break_to_segments(rows, cols, [100.0, 200.0], [cols - 150.0, rows - 300.0], 100.0)
+        assert np.allclose(seg, g["seg_%d" % rows], atol=1e-3)
+        # the polyline wraps once around the image seam: left (x=0) and right (x=cols-1) appear
+        assert np.any(seg[:, 0] == 0) and np.any(seg[:, 0] == cols - 1)
+
+
+def line_scan(g, p, local=False):
+    off = g[p + "_p2s_off"]; ids = g[p + "_p2s_ids"]
+    return dict(R_wl=g[p + "_R_wl"], t_wl=g[p + "_t_wl"], corner_xyz=g[p + ("_corner_local" if local else "_corner_xyz")],
+                p2s=[ids[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)], seg_size=g[p + "_seg_size"],
+                seg_coeffs=g[p + "_seg_coeffs"], end_points=g[p + "_end_points"])
+
+
+def test_line2line_golden(oracle):
+    g = load("lines.npz")
+    a, b = line_scan(g, "a"), line_scan(g, "b")
+    for thr in (0.3, 0.4):
+        t = "t%02d_" % int(thr * 10)
+        o = oracle.assoc_line2line(a, b, thr)
+        assert np.array_equal(o["votes"], g[t + "votes"]) and np.array_equal(o["nei_idx"], g[t + "nei_idx"]) and np.array_equal(o["ref_idx"], g[t + "ref_idx"])
+        assert np.allclose(o["p1"], g[t + "p1"], atol=1e-14) and np.allclose(o["p2"], g[t + "p2"], atol=1e-14)
+        assert len(o["nei_idx"]) >= 4
+
+
+def test_by_angle_golden(oracle):
+    g = load("lines.npz")
+    scan = line_scan(g, "c", local=True)
+    for mult in (1, 0):
+        o = oracle.assoc_by_angle(2880, 5760, g["c_lines"], scan, g["c_T_cl"], multiple=bool(mult))
+        m = "m%d_" % mult
+        assert np.array_equal(o["image_line_id"], g[m + "image_line_id"]) and np.array_equal(o["lidar_line_id"], g[m + "lidar_line_id"])
+        assert np.allclose(o["score"], g[m + "score"], atol=1e-9) and np.allclose(o["start"], g[m + "start"], atol=1e-12)
+    assert np.array_equal(o["votes"], g["c_votes"])
+
+
+def test_find_neighbors_golden(oracle):
+    g = load("neighbors.npz")
+    nb = oracle.find_neighbors(g["poses"], g["valid"], 6)
+    off, ids = g["off"], g["ids"]
+    for i, l in enumerate(nb):
+        assert l == ids[off[i]:off[i + 1]].tolist()
+    assert all(i not in l for i, l in enumerate(nb) if g["valid"][i])   # self removed
+    assert nb[13] == [16, 15, 14, 13, 12, 11, 10]                       # invalid pose -> temporal window (LidarFeatureAssociate.cpp:103-107)

@@ -1,0 +1,75 @@
+"""HIP path against the committed golden vectors (through the C ABI)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+from tests.test_golden_cpu import _scan, line_scan, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import panovlm_amd as pv
+    c = pv.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("kind,normalize", [(0, 0), (1, 0), (1, 1), (2, 0), (3, 0), (3, 1), (4, 0), (5, 0)])
+def test_functor_golden(ctx, kind, normalize):
+    import panovlm_amd as pv
+    g = load("functors.npz")
+    k = "k%d_n%d_" % (kind, normalize)
+    rs = pv.ResidualSet.upload(ctx, kind, g[k + "rows"], g[k + "off"], g[k + "ref"], g[k + "nei"], flags=normalize, weight=float(g["weight"]))
+    ctx.set_poses(g[k + "aa"], g[k + "t"])
+    r, J = rs.eval()
+    ro, Jo = g[k + "r"], g[k + "J"]
+    tol = 1e-6 * np.maximum(np.abs(ro), 1e-9) + (8 * 2.2e-16 / np.maximum(np.abs(ro), 1e-7) if kind in (1, 3, 4, 5) else 0) + 1e-15
+    assert np.all(np.abs(r - ro) <= tol)
+    jt = 1e-6 + (8 * 2.2e-16 / np.maximum(ro * ro, 1e-14) if kind in (1, 3, 4, 5) else 0)
+    assert np.all(np.abs(J - Jo) <= (jt * np.ones_like(ro))[:, None] * np.maximum(np.abs(Jo).max(axis=1, keepdims=True), 1e-9))
+
+
+def test_assoc_point2plane_golden(ctx):
+    import panovlm_amd as pv
+    g = load("assoc_point2plane.npz")
+    dev = {k: pv.Scan(ctx, _scan(g, k)) for k in (0, 1, 2)}
+    for i, (r, n, tol, thr) in enumerate(g["cases"]):
+        rs = ctx.assoc_point2plane([dev[int(r)]], [dev[int(n)]], float(tol), float(thr), flags=0x101)
+        off, ref, nei, rows = rs.download()
+        qidx, nn = rs.assoc_debug()
+        assert np.array_equal(qidx, g["c%d_qidx" % i]) and np.array_equal(nn, g["c%d_nn" % i])
+        assert np.array_equal(rows[:, :3], g["c%d_point" % i]) and np.array_equal(rows[:, 3:], g["c%d_plane" % i])
+        rs.close()
+
+
+def test_equirect_golden(ctx):
+    g = load("equirect.npz")
+    for rows, cols in [(2880, 5760), (720, 1440)]:
+        assert np.array_equal(ctx.cam_to_image(rows, cols, g["cam"].astype(np.float32)), g["px_f32_%d" % rows], equal_nan=True)
+        assert np.array_equal(ctx.cam_to_image(rows, cols, g["cam"]), g["px_f64_%d" % rows], equal_nan=True)
+        assert np.allclose(ctx.image_to_cam(rows, cols, g["pix_%d" % rows], 1.0), g["cam_f64_%d" % rows], atol=1e-15)
+
+
+def test_fast_atan2_golden_through_projection(ctx):
+    """lon = FastAtan2(x, z): recover it from the u pixel coordinate and compare with the vectors of the
+    real reference header (u = cols * (0.5 + lon / 2pi) is monotone in lon)."""
+    g = load("fast_atan2.npz")
+    y, x = g["y"], g["x"]
+    cam = np.stack([y, np.zeros_like(y), x], axis=1)   # CamToSphere: lon = FastAtan2(point.x, point.z)
+    px = ctx.cam_to_image(2880, 5760, cam)
+    lon = (px[:, 0] / 5760 - 0.5) * 2 * np.pi
+    assert np.abs(lon - g["out_f64"]).max() < 1e-12
+
+
+def test_lines_golden(ctx):
+    import panovlm_amd as pv
+    g = load("lines.npz")
+    a, b = pv.Scan(ctx, line_scan(g, "a") | {"id": 3}), pv.Scan(ctx, line_scan(g, "b") | {"id": 4})
+    for thr in (0.3, 0.4):
+        assert np.array_equal(ctx.line2line_votes(a, b, thr), g["t%02d_votes" % int(thr * 10)])
+    c = pv.Scan(ctx, line_scan(g, "c", local=True))
+    assert np.array_equal(ctx.cam_lidar_votes(2880, 5760, g["c_lines"], c, g["c_T_cl"]), g["c_votes"])
