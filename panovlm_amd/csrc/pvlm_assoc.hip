@@ -91,9 +91,8 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int T, const int* __restri
   for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
 }
 
-// deterministic placement: the rank of point i inside its cell = number of points of the same
-// cell with a smaller index is not available cheaply, so points take slots by atomic cursor and
-// each cell is then sorted by original index (cells are small) — see k_sort_cells.
+// Points take their slot inside the cell by atomic cursor: the order inside a cell varies from run
+// to run, the k-NN result does not (top-k is ordered by (distance, original index)).
 __global__ void k_scatter(int n, const float* __restrict__ xyz, const int* __restrict__ slot_of, const int* __restrict__ start,
                           int* __restrict__ cursor, float4* __restrict__ sorted) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,21 +100,6 @@ __global__ void k_scatter(int n, const float* __restrict__ xyz, const int* __res
   const int s = slot_of[i];
   const int pos = start[s] + atomicAdd(&cursor[s], 1);
   sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
-}
-
-__global__ void k_sort_cells(int T, const int* __restrict__ start, const int* __restrict__ count, float4* __restrict__ sorted) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= T) return;
-  const int c = count[s];
-  if (c < 2) return;
-  float4* a = sorted + start[s];
-  for (int i = 1; i < c; ++i) {  // insertion sort by original index
-    const float4 v = a[i];
-    const int vi = __float_as_int(v.w);
-    int j = i - 1;
-    while (j >= 0 && __float_as_int(a[j].w) > vi) { a[j + 1] = a[j]; --j; }
-    a[j + 1] = v;
-  }
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------
@@ -555,7 +539,6 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
                      T - 1, c.d_keys, c.d_cell_count, d_slot);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, T, c.d_cell_count, c.d_cell_start);
   hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
-  hipLaunchKernelGGL(k_sort_cells, dim3((T + 255) / 256), dim3(256), 0, ctx->stream, T, c.d_cell_start, c.d_cell_count, c.d_sorted);
   hipError_t le = hipGetLastError();
   hipError_t se = hipStreamSynchronize(ctx->stream);
   hipFree(d_slot); hipFree(d_cursor);

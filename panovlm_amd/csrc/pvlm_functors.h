@@ -80,6 +80,34 @@ __device__ __forceinline__ void residual_grad(const double* P, const double* rec
     const double s = sd < 0.0 ? -w : w;
     r = s * sd;
     g[0] = s * n[0]; g[1] = s * n[1]; g[2] = s * n[2];
+  } else if (KIND == PVLM_POINT2PLANE_ANGLE && NORM) {
+    // base/CostFunction.h:679-715 with normalize_distance (the Room/Floor configuration), reduced
+    // algebraically.  Pp = P - sd n is the foot of P on the plane (both branches of the reference's
+    // sign test give this point), nu = |Pp|, the centre sits 1 m before Pp on the ray O->Pp, so
+    // vec1 = Pp/nu =: e (unit) and vec2 = e + sd n.  With u = Pp + d n (the in-plane part of Pp,
+    // |u| = q) and n.Pp = -d:   e.vec2 = 1 - sd d/nu =: x,   |e x vec2| = |sd| q/nu =: y,
+    // r = angle(vec1, vec2) = atan2(y, x) — the same angle the reference obtains from acos of the
+    // normalised dot product, without its cancellation near cos = 1.  r depends on P through
+    // (sd, nu) only: grad sd = n, grad nu = u/nu.
+    const double* n = rec + 3;
+    const double dd = n[3];
+    const double sd = n[0] * P[0] + n[1] * P[1] + n[2] * P[2] + dd;
+    const double s = sd < 0.0 ? -1.0 : 1.0;
+    const double dis = s * sd;
+    if (dis < 1e-3) return;
+    const double u[3] = {P[0] - (sd - dd) * n[0], P[1] - (sd - dd) * n[1], P[2] - (sd - dd) * n[2]};
+    const double q2 = dot3(u, u);
+    const double nu2 = q2 + dd * dd;
+    const double inv_nu = 1.0 / sqrt(nu2);
+    const double q = sqrt(q2);
+    const double x = 1.0 - sd * dd * inv_nu, y = dis * q * inv_nu;
+    const double invD = 1.0 / (x * x + y * y);
+    r = atan2(y, x);
+    const double fsd = (x * s * q + y * dd) * inv_nu * invD;
+    const double invq = q > 0.0 ? 1.0 / q : 0.0;
+    const double cu = (x * dis * dd * dd * invq - y * sd * dd) * (inv_nu * inv_nu * inv_nu) * invD;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = fsd * n[k] + cu * u[k];
   } else if (KIND == PVLM_POINT2PLANE_ANGLE) {
     // base/CostFunction.h:679-717 (weight is NOT applied by the reference)
     const double* n = rec + 3;

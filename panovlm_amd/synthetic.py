@@ -94,16 +94,20 @@ def to_world_f32(local_f32, R_wl, t_wl):
 
 
 def make_scan(k, cols=4096, rings=16, seed=SEED, downsample_targets=0.0):
-    """Scan dict for panovlm_amd.Scan / the oracle.  downsample_targets > 0 voxel-subsamples the
-    surfLessFlat target cloud (first point per voxel), as the real extractor does at 0.2 m."""
+    """Scan dict for panovlm_amd.Scan.  downsample_targets > 0 replaces the surfLessFlat target cloud
+    by its voxel-grid centroids, as the reference's extractor does at 0.2 m."""
     local = raycast_local(k, cols, rings, seed)
     R, t = estimated_pose(k, seed)
     world = to_world_f32(local, R, t)
     less = world
     if downsample_targets > 0:
-        key = np.floor(local / downsample_targets).astype(np.int64)
-        _, first = np.unique(key, axis=0, return_index=True)
-        less = world[np.sort(first)]
+        # pcl::VoxelGrid semantics: one centroid per occupied voxel (leaf 0.2 m in the extractor)
+        key = np.floor(local.astype(np.float64) / downsample_targets).astype(np.int64)
+        key = (key[:, 0] + 4096) * (8192 * 8192) + (key[:, 1] + 4096) * 8192 + (key[:, 2] + 4096)
+        uniq, inv = np.unique(key, return_inverse=True)
+        sums = np.zeros((len(uniq), 3)); np.add.at(sums, inv, local.astype(np.float64))
+        cnt = np.bincount(inv, minlength=len(uniq))[:, None]
+        less = to_world_f32((sums / cnt).astype(np.float32), R, t)
     return dict(id=k, R_wl=R, t_wl=t, flat_xyz=world, flat_tag=np.ones(len(world), np.float32),
                 less_xyz=less, less_tag=np.ones(len(less), np.float32), local_xyz=local)
 
