@@ -180,12 +180,12 @@ __global__ __launch_bounds__(256) void k_eval_fused(const double* __restrict__ c
       const double s = w.r * w.r;
       double rho1 = 1.0, half_rho = 0.5 * s;
       if (LOSS == PVLM_LOSS_HUBER) {
-        // ceres::HuberLoss(a): s > a^2 -> rho = 2 a sqrt(s) - a^2, rho' = a / sqrt(s)
-        if (s > a2) {
-          const double rr = sqrt(s);
-          half_rho = 0.5 * (2.0 * loss_a * rr - a2);
-          rho1 = fmax(std::numeric_limits<double>::min(), loss_a / rr);
-        }
+        // ceres::HuberLoss(a): s > a^2 -> rho = 2 a sqrt(s) - a^2, rho' = max(DBL_MIN, a / sqrt(s))
+        const double rr = fabs(w.r);
+        const bool out = s > a2;
+        const double inv = fast_rcp(out ? rr : 1.0);
+        rho1 = out ? fmax(std::numeric_limits<double>::min(), loss_a * inv) : 1.0;
+        half_rho = out ? fma(loss_a, rr, -0.5 * a2) : half_rho;
       }
       const double vv[6] = {w.c[0], w.c[1], w.c[2], w.g[0], w.g[1], w.g[2]};
       int q = 0;

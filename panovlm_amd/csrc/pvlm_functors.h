@@ -23,6 +23,54 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
   o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+
+// ---- fp64 helpers for the bandwidth-bound kernels ------------------------------------------------
+// The compiler's IEEE-exact fp64 division / sqrt expand to 12-18 instructions each (scaling,
+// fix-ups for denormals and specials).  The kernels only see well-scaled operands (metres,
+// radians), so the hardware estimate + two Newton steps (full double precision for normal
+// numbers) is used instead.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * r, 0.5 * r, 0.5);
+  r = fma(r, e, r);
+  e = fma(-x * r, 0.5 * r, 0.5);
+  return fma(r, e, r);
+}
+// atan2(y, x) for y >= 0: octant folding as in FastAtan2 (min/max), reduction at tan(pi/8) and a
+// degree-10 polynomial in t^2 (Chebyshev-node interpolant of atan(t)/t on [0, tan^2(pi/8)],
+// max relative error 2.2e-16 measured against mpmath).  Branch-free.
+__device__ __forceinline__ double atan2_pos(double y, double x) {
+  const double ax = fabs(x);
+  const double mn = fmin(y, ax), mx = fmax(y, ax);
+  const double a = mn * fast_rcp(mx);
+  const bool big = a > 0.41421356237309503;
+  const double red = (a - 1.0) * fast_rcp(a + 1.0);
+  const double t = big ? red : a;
+  const double u = t * t;
+  double p = 2.11272689568591313e-02;
+  p = fma(p, u, -4.34739031566048761e-02);
+  p = fma(p, u, 5.68812005923421543e-02);
+  p = fma(p, u, -6.64019012732186553e-02);
+  p = fma(p, u, 7.68994845277858746e-02);
+  p = fma(p, u, -9.09077271667437237e-02);
+  p = fma(p, u, 1.11111061650365134e-01);
+  p = fma(p, u, -1.42857141805968924e-01);
+  p = fma(p, u, 1.99999999988503901e-01);
+  p = fma(p, u, -3.33333333333284132e-01);
+  p = fma(p, u, 1.0);
+  double r = t * p;
+  r = big ? r + 0.78539816339744830962 : r;
+  r = (y > ax) ? 1.57079632679489661923 - r : r;
+  return (x < 0.0) ? 3.14159265358979323846 - r : r;
+}
+
 // VectorAngle3D (base/Geometry.hpp:450-466), un-normalised form, with gradients wrt v1, v2.
 // Returns false when the clamped branches (constant result, zero gradient) were taken.
 __device__ __forceinline__ bool angle_between(const double* v1, const double* v2, double& r, double* g1, double* g2) {
@@ -94,18 +142,19 @@ __device__ __forceinline__ void residual_grad(const double* P, const double* rec
     const double sd = n[0] * P[0] + n[1] * P[1] + n[2] * P[2] + dd;
     const double s = sd < 0.0 ? -1.0 : 1.0;
     const double dis = s * sd;
-    if (dis < 1e-3) return;
     const double u[3] = {P[0] - (sd - dd) * n[0], P[1] - (sd - dd) * n[1], P[2] - (sd - dd) * n[2]};
     const double q2 = dot3(u, u);
     const double nu2 = q2 + dd * dd;
-    const double inv_nu = 1.0 / sqrt(nu2);
-    const double q = sqrt(q2);
+    const double inv_nu = fast_rsqrt(nu2);
+    const double invq = q2 > 0.0 ? fast_rsqrt(q2) : 0.0;
+    const double q = q2 * invq;
     const double x = 1.0 - sd * dd * inv_nu, y = dis * q * inv_nu;
-    const double invD = 1.0 / (x * x + y * y);
-    r = atan2(y, x);
-    const double fsd = (x * s * q + y * dd) * inv_nu * invD;
-    const double invq = q > 0.0 ? 1.0 / q : 0.0;
-    const double cu = (x * dis * dd * dd * invq - y * sd * dd) * (inv_nu * inv_nu * inv_nu) * invD;
+    const double invD = fast_rcp(x * x + y * y);
+    const bool live = dis >= 1e-3;  // dis < 1e-3 -> residual 0, zero Jacobian (CostFunction.h:680-684)
+    r = live ? atan2_pos(y, x) : 0.0;
+    const double k0 = live ? inv_nu * invD : 0.0;
+    const double fsd = (x * s * q + y * dd) * k0;
+    const double cu = (x * dis * dd * dd * invq - y * sd * dd) * (inv_nu * inv_nu) * k0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] = fsd * n[k] + cu * u[k];
   } else if (KIND == PVLM_POINT2PLANE_ANGLE) {

@@ -1,0 +1,284 @@
+// pvlm_host.hpp — C++ host side above the C ABI (include/pvlm.h), mirroring PanoVLM's own
+// interfaces for the ICP hot path so that a PanoVLM maintainer (and the parity tests) can call it
+// with the names, argument meaning and error behaviour of the reference:
+//
+//   lidar_mapping/LidarFeatureAssociate.h:22-125   Point2Line / Line2Line / Point2Plane,
+//                                                  FindNeighbors, AssociatePoint2Plane, AssociateLine2Line
+//   base/CostFunction.h:350-934                    Point2Plane_{Meter,Angle}, Point2Line_{Meter,Angle},
+//                                                  Plane2Plane_Global, PlaneIOUResidual  (::Create)
+//   util/Optimization.h:39-158                     AddLidarPointToPlaneResidual, AddLidarLineToLineResidual2,
+//                                                  AddCameraLidarResidual, SetOptionsLidar
+//   lidar_mapping/LidarLineMatch.h, util/Tracks.h  LidarLineMatch::GenerateTracks (line tracks)
+//   lidar_mapping/LidarOdometry.h:40-81            LidarOdometry::RefinePose / EstimatePose
+//   joint_optimization/CameraLidarLineAssociate.h  CameraLidarLineAssociate::AssociateByAngle
+//   sensors/Velodyne.h:80-91,213-233               the Velodyne data contract + frame transforms
+//   sensors/Equirectangular.h                      Equirectangular (host, scalar)
+//
+// Eigen / PCL / Ceres are not dependencies: small POD types stand in for Eigen::Vector3d etc. and
+// the ceres:: classes the reference touches (CostFunction, LossFunction, Problem, Solver) are
+// re-declared in namespace pvlm::ceres_like with the same member names.  All heavy work goes
+// through libpvlm.so (HIP); nothing here computes a residual on the CPU.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pvlm.h"
+
+namespace pvlm {
+
+using Vector3d = std::array<double, 3>;
+using Vector4d = std::array<double, 4>;
+using Vector6d = std::array<double, 6>;
+using Matrix3d = std::array<double, 9>;   // row-major
+using Matrix4d = std::array<double, 16>;  // row-major
+
+struct PointXYZI { float x, y, z, intensity; };  // pcl::PointXYZI payload
+using PointCloud = std::vector<PointXYZI>;
+
+// sensors/Velodyne.h:57-66
+enum PointClassification { POINT_NORMAL = 0x01, POINT_LESS_SHARP = 0x02, POINT_SHARP = 0x04, POINT_FLAT = 0x08, POINT_GROUND = 0x10 };
+
+// base/Config.h:111-130 — the knobs the hot path reads (defaults = config/Room.txt:67-79)
+struct Config {
+  bool angle_residual = true;
+  bool point_to_line_residual = false;
+  bool line_to_line_residual = true;
+  bool point_to_plane_residual = true;
+  bool normalize_distance = true;
+  double point_to_line_dis_threshold = 0.3;
+  double point_to_plane_dis_threshold = 1.0;
+  double lidar_plane_tolerance = 0.05;
+  double lidar_weight = 1.0;
+  double camera_lidar_weight = 1.0;
+  int num_threads = 25;
+  int num_iteration_lidar = 7;
+};
+
+// The process-wide engine (one pvlm_ctx).  Throws std::runtime_error when no GPU / library.
+class Engine {
+ public:
+  static Engine& Default();
+  static void SetDevice(int device);  // before first use
+  pvlm_ctx* ctx() const { return ctx_; }
+  void Check(pvlm_status st, const char* what) const;
+  ~Engine();
+ private:
+  explicit Engine(int device);
+  pvlm_ctx* ctx_ = nullptr;
+};
+
+// ---- sensors/Velodyne.h data contract ---------------------------------------------------------------
+class Velodyne {
+ public:
+  int id = 0;
+  bool valid = true;
+  PointCloud cornerLessSharp, surfFlat, surfLessFlat;
+  std::vector<PointCloud> edge_segmented;
+  std::vector<std::set<int>> point_to_segment;
+  std::vector<Vector6d> segment_coeffs;  // LiDAR-local (point, unit direction)
+  std::vector<Vector3d> end_points;      // 2 per segment, LiDAR-local
+
+  Velodyne() { SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); SetTranslation({INFINITY, INFINITY, INFINITY}); }
+  void SetPose(const Matrix3d& R_wl, const Vector3d& t_wl) { R_wl_ = R_wl; t_wl_ = t_wl; InvalidateDevice(); }
+  void SetRotation(const Matrix3d& R_wl) { R_wl_ = R_wl; InvalidateDevice(); }
+  void SetTranslation(const Vector3d& t_wl) { t_wl_ = t_wl; InvalidateDevice(); }
+  const Matrix3d& GetRotation() const { return R_wl_; }
+  const Vector3d& GetTranslation() const { return t_wl_; }
+  Matrix4d GetPose() const;
+  bool IsPoseValid() const;                       // sensors/Velodyne.cpp:1894-1899
+  bool IsInWorldCoordinate() const { return world_; }
+  Vector3d World2Local(const Vector3d& p) const;  // sensors/Velodyne.cpp:1850-1853
+  Vector3d Local2World(const Vector3d& p) const;  // :1856-1859
+  void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
+  void Transform2Local();                         // :1810-1848
+
+  // device mirror of the clouds (uploaded lazily by the association entry points)
+  pvlm_scan* DeviceScan() const;
+  void InvalidateDevice() const;
+  ~Velodyne();
+  Velodyne(const Velodyne& o);
+  Velodyne& operator=(const Velodyne& o);
+
+ private:
+  Matrix3d R_wl_;
+  Vector3d t_wl_;
+  bool world_ = false;
+  mutable pvlm_scan* dev_ = nullptr;
+};
+
+// ---- lidar_mapping/LidarFeatureAssociate.h ------------------------------------------------------------
+struct Point2Plane { Vector3d point; Vector4d plane_coeff; };
+struct Point2Line { Vector3d point, line_point1, line_point2; };
+struct Line2Line { int neighbor_line_idx, ref_line_idx; Vector3d line_point1, line_point2; };
+
+std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars, const int neighbor_size);
+std::vector<std::vector<int>> FindNeighborsConsecutive(const std::vector<Velodyne>& lidars, const int neighbor_size);
+std::vector<Point2Plane> AssociatePoint2Plane(const Velodyne& ref_lidar, const Velodyne& nei_lidar, double plane_tolerance,
+                                              const float dist_threshold = 0.7f, bool visualization = false);
+std::vector<Line2Line> AssociateLine2Line(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const float dist_threshold = 0.7f,
+                                          bool visualization = false);
+std::vector<Vector6d> TransformLines(const std::vector<Vector6d>& line_coeffs, const Matrix4d& T);
+std::vector<Line2Line> FindAssociations(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const std::vector<Vector6d>& ref_world,
+                                        const std::vector<Vector6d>& nei_world, const std::vector<int>& line_matrix);
+
+// ---- util/Tracks.h + lidar_mapping/LidarLineMatch.h ----------------------------------------------------
+struct LineTrack {
+  uint32_t id = 0;
+  std::set<std::pair<uint32_t, uint32_t>> feature_pairs;  // {lidar id, line id}
+  bool IsInside(const std::pair<uint32_t, uint32_t>& p) const { return feature_pairs.count(p) > 0; }
+};
+class LidarLineMatch {
+ public:
+  explicit LidarLineMatch(const std::vector<Velodyne>& lidars) : lidars_(lidars) {}
+  void SetNeighborSize(int n) { neighbor_size_ = n; }
+  void SetMinTrackLength(int n) { min_track_length_ = n; }
+  bool GenerateTracks();
+  const std::vector<LineTrack>& GetTracks() const { return tracks_; }
+ private:
+  const std::vector<Velodyne>& lidars_;
+  int neighbor_size_ = 4, min_track_length_ = 3;
+  std::vector<LineTrack> tracks_;
+};
+
+// ---- the ceres:: surface the reference touches -----------------------------------------------------------
+namespace ceres_like {
+
+class CostFunction {
+ public:
+  virtual ~CostFunction() {}
+  // ceres::CostFunction::Evaluate: parameters = {aa_r, t_r, aa_n, t_n}; jacobians may be null, and each
+  // jacobians[i] may be null.  Evaluated on the GPU (one-row residual set) — API parity, not the fast path.
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const;
+  int kind = 0;
+  unsigned flags = 0;
+  double weight = 1.0;
+  std::vector<double> row;  // the ABI row of this block
+};
+class LossFunction { public: virtual ~LossFunction() {} virtual pvlm_loss kind() const = 0; virtual double a() const = 0; };
+class HuberLoss : public LossFunction {
+ public:
+  explicit HuberLoss(double a) : a_(a) {}
+  pvlm_loss kind() const override { return PVLM_LOSS_HUBER; }
+  double a() const override { return a_; }
+ private:
+  double a_;
+};
+
+class Problem {
+ public:
+  Problem();
+  ~Problem();
+  // Takes ownership of cost (and of loss, shared by many blocks like in Ceres).
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_r, double* t_r, double* aa_n, double* t_n);
+  // Device-resident hand-off: a residual set produced by the association kernels; segment p uses
+  // the parameter blocks (aa[ref_p], t[ref_p], aa[nei_p], t[nei_p]) of the given lists (ids = list index).
+  void AddResidualSet(pvlm_resset* set, LossFunction* loss, std::vector<Vector3d>* aa_list, std::vector<Vector3d>* t_list);
+  void SetParameterBlockConstant(double* block);
+  int NumResidualBlocks() const;
+  struct Impl;
+  Impl* impl() const { return impl_; }
+ private:
+  Problem(const Problem&) = delete;
+  Impl* impl_;
+};
+
+enum LinearSolverType { DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR };
+struct Solver {
+  struct Options {
+    bool minimizer_progress_to_stdout = false;
+    int num_threads = 1;
+    int max_num_iterations = 50;
+    int max_linear_solver_iterations = 500;
+    LinearSolverType linear_solver_type = DENSE_SCHUR;
+    // Ceres 2.0 trust-region defaults ([recalled])
+    double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16, min_trust_region_radius = 1e-32;
+    double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+  };
+  struct Summary {
+    double initial_cost = 0, final_cost = 0;
+    int num_successful_steps = 0, num_unsuccessful_steps = 0;
+    int num_residual_blocks = 0;
+    bool usable = false;
+    std::string message;
+    std::vector<double> cost_history;
+    bool IsSolutionUsable() const { return usable; }
+    std::string BriefReport() const;
+  };
+};
+void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary);
+
+}  // namespace ceres_like
+
+// ---- base/CostFunction.h functors: X::Create(...) ------------------------------------------------------
+struct Point2Plane_Meter { static ceres_like::CostFunction* Create(const Vector3d& curr_point, const Vector4d& plane, const double weight = 1); };
+struct Point2Plane_Angle { static ceres_like::CostFunction* Create(const Vector3d& curr_point, const Vector4d& plane, const bool normalize, const double weight = 1); };
+struct Point2Line_Meter { static ceres_like::CostFunction* Create(const Vector3d& curr_point, const Vector3d& last_point_a, const Vector3d& last_point_b, const double weight = 1); };
+struct Point2Line_Angle { static ceres_like::CostFunction* Create(const Vector3d& curr_point, const Vector3d& last_point_a, const Vector3d& last_point_b, const bool normalize, const double weight = 1); };
+struct Plane2Plane_Global { static ceres_like::CostFunction* Create(const Vector3d& plane_ref, const Vector3d& point_a, const Vector3d& point_b, const double w = 1.0); };
+struct PlaneIOUResidual { static ceres_like::CostFunction* Create(const Vector4d& ref_plane, const Vector3d& middle_neighbor, const Vector3d& middle_ref, const double angle, const double weight = 1.0); };
+
+// ---- util/Optimization.h ---------------------------------------------------------------------------------
+size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
+                                    std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
+                                    ceres_like::Problem& problem, double point_to_plane_dis_threshold, double plane_tolerance,
+                                    bool angle_residual, bool normalized_distance, double weight = 1.0);
+size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
+                                   std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
+                                   ceres_like::Problem& problem, const std::vector<LineTrack>& lidar_line_tracks,
+                                   double point_to_line_dis_threshold, bool angle_residual, bool normalized_distance, double weight = 1.0);
+ceres_like::Solver::Options SetOptionsLidar(const int num_threads, const int lidar_size);
+
+// ceres/rotation.h pieces the callers use (lidar_mapping/LidarOdometry.cpp:31,105)
+void RotationMatrixToAngleAxis(const Matrix3d& R, Vector3d* angle_axis);
+void AngleAxisToRotationMatrix(const Vector3d& angle_axis, Matrix3d* R);
+
+// ---- lidar_mapping/LidarOdometry.h --------------------------------------------------------------------------
+class LidarOdometry {
+ public:
+  LidarOdometry(const std::vector<Velodyne>& lidars, const Config& config) : lidars(lidars), config(config) {}
+  // EstimatePose(max_iteration): outer loop of LidarOdometry.cpp:116-187 WITHOUT the feature extraction
+  // (the scans handed in already carry their feature clouds — SURVEY.md §8 A0 / "next" row N3).
+  bool EstimatePose(const int max_iteration);
+  bool RefinePose(double& cost, int& steps, bool use_segment);
+  const std::vector<Velodyne>& GetLidarData() const { return lidars; }
+  std::vector<Matrix3d> GetGlobalRotation() const;
+  std::vector<Vector3d> GetGlobalTranslation() const;
+  // per-outer-iteration log (cost, successful steps, residual blocks) for tests
+  struct IterLog { double cost; int steps; int residual_blocks; };
+  std::vector<IterLog> log;
+ private:
+  std::vector<Velodyne> lidars;
+  Config config;
+};
+
+// ---- sensors/Equirectangular.h + joint_optimization/CameraLidarLineAssociate.h -------------------------------
+struct CameraLidarLinePair {
+  std::array<float, 4> image_line{{0, 0, 0, 0}};
+  Vector3d lidar_line_start{{0, 0, 0}}, lidar_line_end{{0, 0, 0}};
+  int image_line_id = -1, lidar_line_id = -1;
+  float angle = -1, weight = 1;
+};
+class CameraLidarLineAssociate {
+ public:
+  CameraLidarLineAssociate(int rows, int cols) : rows(rows), cols(cols) {}
+  // AssociateByAngle (CameraLidarLineAssociate.cpp:340-475): `lidar` carries LOCAL-frame corner points.
+  void AssociateByAngle(const std::vector<std::array<float, 4>>& lines, const Velodyne& lidar, const Matrix4d& T_cl,
+                        const bool multiple_association = true, const std::vector<bool>& image_line_mask = {},
+                        const std::vector<bool>& lidar_line_mask = {});
+  const std::vector<CameraLidarLinePair>& GetAssociatedPairs() const { return line_pairs; }
+ private:
+  void Filter(bool filter_by_angle, bool filter_by_length);
+  void UniqueLinePair(const std::vector<std::array<float, 4>>& lines, const std::vector<Vector3d>& lidar_lines_endpoint);
+  int rows, cols;
+  std::vector<CameraLidarLinePair> line_pairs;
+};
+
+}  // namespace pvlm
