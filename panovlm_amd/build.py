@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
     procs = []
     for src in sources():
         obj = os.path.join(bdir, os.path.basename(src) + ".o")
-        flags = list(common)
+        flags = list(common) + os.environ.get("PVLM_DEFINES", "").split()
         # association kernels make accept/reject decisions that must be bit-identical to a
         # non-FMA x86-64 build of the reference: no contraction there.
         if os.path.basename(src) in ("pvlm_assoc.hip", "pvlm_lines.hip"):

@@ -15,6 +15,13 @@
 
 using namespace pvlm_dev;
 
+#ifndef PVLM_PREFETCH
+#define PVLM_PREFETCH -1  // -1 = per-functor default, 0 / 1 force
+#endif
+#ifndef PVLM_FUSED_WAVES
+#define PVLM_FUSED_WAVES 2  // waves per SIMD the fused kernel must fit (no spilling at 3-4: measured 2x slower)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // pose table: R_lw = exp([aa]x) with the same small-angle branch as ceres::AngleAxisToRotationMatrix
 // (theta^2 <= DBL_EPSILON -> first order), and the SO(3) left Jacobian J_l(aa).
@@ -146,8 +153,35 @@ __device__ __forceinline__ double wave_sum(double x) {
   return x;
 }
 
+// one residual block: evaluate, robustify, accumulate  S += rho' v v^T, gv += rho' v r, cost += rho/2
 template <int KIND, bool NORM, int NCOLS, int LOSS>
-__global__ __launch_bounds__(256) void k_eval_fused(const double* __restrict__ cols, int64_t n_dev,
+__device__ __forceinline__ void accumulate_row(const double* rec, const double* T, double weight, double loss_a, double a2, double* acc) {
+  Wrench w;
+  eval_wrench<KIND, NORM>(rec, T, weight, w);
+  const double s = w.r * w.r;
+  double rho1 = 1.0, half_rho = 0.5 * s;
+  if (LOSS == PVLM_LOSS_HUBER) {
+    // ceres::HuberLoss(a): s > a^2 -> rho = 2 a sqrt(s) - a^2, rho' = max(DBL_MIN, a / sqrt(s))
+    const double rr = fabs(w.r);
+    const bool out = s > a2;
+    const double inv = fast_rcp(out ? rr : 1.0);
+    rho1 = out ? fmax(std::numeric_limits<double>::min(), loss_a * inv) : 1.0;
+    half_rho = out ? fma(loss_a, rr, -0.5 * a2) : half_rho;
+  }
+  const double vv[6] = {w.c[0], w.c[1], w.c[2], w.g[0], w.g[1], w.g[2]};
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double wa = rho1 * vv[a];
+#pragma unroll
+    for (int b = a; b < 6; ++b) acc[q++] += wa * vv[b];
+    acc[21 + a] += wa * w.r;
+  }
+  acc[27] += half_rho;
+}
+
+template <int KIND, bool NORM, int NCOLS, int LOSS>
+__global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const double* __restrict__ cols, int64_t n_dev,
                                                     const int64_t* __restrict__ seg_start,
                                                     const int64_t* __restrict__ out_start,
                                                     const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
@@ -165,38 +199,37 @@ __global__ __launch_bounds__(256) void k_eval_fused(const double* __restrict__ c
 #pragma unroll
   for (int k = 0; k < PVLM_PARTIAL; ++k) acc[k] = 0.0;
   const double a2 = loss_a * loss_a;
-  for (int64_t j = lo + 2 * (int64_t)threadIdx.x; j < hi; j += 512) {
-    double2 v[NCOLS];
+  // Each lane streams two consecutive rows per column with one 16-byte load.  The cheap (Meter)
+  // functors are latency-bound: their next tile is prefetched into registers while the current one
+  // is evaluated (+7 % on MI355X); the Angle functors are VALU-bound at 3 waves/SIMD and lose
+  // occupancy to the extra 28 VGPRs, so they load in place.
+  constexpr bool kPrefetch = PVLM_PREFETCH >= 0 ? (PVLM_PREFETCH != 0) : (KIND == PVLM_POINT2PLANE_METER || KIND == PVLM_POINT2LINE_METER);
+  int64_t j = lo + 2 * (int64_t)threadIdx.x;
+  double2 nx[NCOLS];
+  if (kPrefetch && j < hi) {
 #pragma unroll
-    for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+    for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+  }
+  for (; j < hi; j += 512) {
+    double2 v[NCOLS];
+    if (kPrefetch) {
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) v[c] = nx[c];
+      if (j + 512 < hi) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j + 512);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (j + h >= hi) break;
       double rec[NCOLS];
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
-      Wrench w;
-      eval_wrench<KIND, NORM>(rec, T, weight, w);
-      const double s = w.r * w.r;
-      double rho1 = 1.0, half_rho = 0.5 * s;
-      if (LOSS == PVLM_LOSS_HUBER) {
-        // ceres::HuberLoss(a): s > a^2 -> rho = 2 a sqrt(s) - a^2, rho' = max(DBL_MIN, a / sqrt(s))
-        const double rr = fabs(w.r);
-        const bool out = s > a2;
-        const double inv = fast_rcp(out ? rr : 1.0);
-        rho1 = out ? fmax(std::numeric_limits<double>::min(), loss_a * inv) : 1.0;
-        half_rho = out ? fma(loss_a, rr, -0.5 * a2) : half_rho;
-      }
-      const double vv[6] = {w.c[0], w.c[1], w.c[2], w.g[0], w.g[1], w.g[2]};
-      int q = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const double wa = rho1 * vv[a];
-#pragma unroll
-        for (int b = a; b < 6; ++b) acc[q++] += wa * vv[b];
-        acc[21 + a] += wa * w.r;
-      }
-      acc[27] += half_rho;
+      accumulate_row<KIND, NORM, NCOLS, LOSS>(rec, T, weight, loss_a, a2, acc);
     }
   }
   __shared__ double red[4][PVLM_PARTIAL];

@@ -27,32 +27,20 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 // ---- fp64 helpers for the bandwidth-bound kernels ------------------------------------------------
 // The compiler's IEEE-exact fp64 division / sqrt expand to 12-18 instructions each (scaling,
 // fix-ups for denormals and specials).  The kernels only see well-scaled operands (metres,
-// radians), so the hardware estimate + two Newton steps (full double precision for normal
-// numbers) is used instead.
+// radians), so the hardware estimate + ONE Newton step is used instead.  Measured on MI355X
+// (tools/micro/rcp_precision.hip): v_rcp_f64 4.6e-8, +1 step 2.2e-15; v_rsq_f64 5.2e-8, +1 step
+// 4.2e-15 max relative error — nine orders of magnitude inside the 1e-6 parity tolerance.
 __device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(r, fma(-x, r, 1.0), r);
 }
 __device__ __forceinline__ double fast_rsqrt(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  double e = fma(-x * r, 0.5 * r, 0.5);
-  r = fma(r, e, r);
-  e = fma(-x * r, 0.5 * r, 0.5);
-  return fma(r, e, r);
+  const double r = __builtin_amdgcn_rsq(x);
+  return fma(r, fma(-x * r, 0.5 * r, 0.5), r);
 }
-// atan2(y, x) for y >= 0: octant folding as in FastAtan2 (min/max), reduction at tan(pi/8) and a
-// degree-10 polynomial in t^2 (Chebyshev-node interpolant of atan(t)/t on [0, tan^2(pi/8)],
-// max relative error 2.2e-16 measured against mpmath).  Branch-free.
-__device__ __forceinline__ double atan2_pos(double y, double x) {
-  const double ax = fabs(x);
-  const double mn = fmin(y, ax), mx = fmax(y, ax);
-  const double a = mn * fast_rcp(mx);
-  const bool big = a > 0.41421356237309503;
-  const double red = (a - 1.0) * fast_rcp(a + 1.0);
-  const double t = big ? red : a;
+// atan(t) for |t| <= tan(pi/8): degree-10 polynomial in t^2 (Chebyshev-node interpolant of
+// atan(t)/t on [0, tan^2(pi/8)], max relative error 2.2e-16 measured against mpmath).
+__device__ __forceinline__ double atan_small(double t) {
   const double u = t * t;
   double p = 2.11272689568591313e-02;
   p = fma(p, u, -4.34739031566048761e-02);
@@ -65,7 +53,19 @@ __device__ __forceinline__ double atan2_pos(double y, double x) {
   p = fma(p, u, 1.99999999988503901e-01);
   p = fma(p, u, -3.33333333333284132e-01);
   p = fma(p, u, 1.0);
-  double r = t * p;
+  return t * p;
+}
+// atan2(y, x) for y >= 0.  When every lane of the wave has its angle below pi/8 (the normal ICP
+// regime) one reciprocal and the polynomial suffice; otherwise octant folding as in FastAtan2
+// (min/max) and the reduction atan(a) = pi/4 + atan((a-1)/(a+1)) are applied, branch-free.
+__device__ __forceinline__ double atan2_pos(double y, double x) {
+  if (__all(y <= 0.41421356237309503 * x)) return atan_small(y * fast_rcp(x));
+  const double ax = fabs(x);
+  const double mn = fmin(y, ax), mx = fmax(y, ax);
+  const double a = mn * fast_rcp(mx);
+  const bool big = a > 0.41421356237309503;
+  const double red = (a - 1.0) * fast_rcp(a + 1.0);
+  double r = atan_small(big ? red : a);
   r = big ? r + 0.78539816339744830962 : r;
   r = (y > ax) ? 1.57079632679489661923 - r : r;
   return (x < 0.0) ? 3.14159265358979323846 - r : r;
