@@ -113,31 +113,58 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* __restri
   double T[PVLM_PAIR_TAB];
 #pragma unroll
   for (int k = 0; k < PVLM_PAIR_TAB; ++k) T[k] = pair_tab[(size_t)p * PVLM_PAIR_TAB + k];
-  for (int64_t j = lo + 2 * (int64_t)threadIdx.x; j < hi; j += 512) {
-    double2 v[NCOLS];
+  // Jacobian rows are staged through LDS so that every store instruction of a wave writes one
+  // contiguous KiB (a lane's own 2 x 96 B would scatter 16-byte pieces over 64 cache lines).
+  // Tile of one wave-iteration: 128 rows x 12 doubles = 12 KiB, private to the wave.
+  __shared__ __attribute__((aligned(16))) double stage[4][128 * 12];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double* Jl = T + 15; const double* Mn = T + 24; const double* R = T;
+  const int64_t n_it = (hi - lo + 511) / 512;
+  for (int64_t it = 0; it < n_it; ++it) {
+    const int64_t j = lo + it * 512 + 2 * (int64_t)threadIdx.x;
+    if (j < hi) {
+      double2 v[NCOLS];
 #pragma unroll
-    for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (j + h >= hi) break;
-      double rec[NCOLS];
+      for (int h = 0; h < 2; ++h) {
+        if (j + h >= hi) break;
+        double rec[NCOLS];
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
-      Wrench w;
-      eval_wrench<KIND, NORM>(rec, T, weight, w);
-      const int64_t o = o0 + j + h;
-      r_out[o] = w.r;
-      if (J_out) {
-        double* J = J_out + (size_t)o * 12;
-        const double* Jl = T + 15; const double* Mn = T + 24; const double* R = T;
+        for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
+        Wrench w;
+        eval_wrench<KIND, NORM>(rec, T, weight, w);
+        r_out[o0 + j + h] = w.r;
+        if (J_out) {
+          double Jr[12];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          J[k] = w.c[0] * Jl[k] + w.c[1] * Jl[3 + k] + w.c[2] * Jl[6 + k];
-          J[3 + k] = w.g[k];
-          J[6 + k] = w.c[0] * Mn[k] + w.c[1] * Mn[3 + k] + w.c[2] * Mn[6 + k];
-          J[9 + k] = -(w.g[0] * R[k] + w.g[1] * R[3 + k] + w.g[2] * R[6 + k]);
+          for (int k = 0; k < 3; ++k) {
+            Jr[k] = w.c[0] * Jl[k] + w.c[1] * Jl[3 + k] + w.c[2] * Jl[6 + k];
+            Jr[3 + k] = w.g[k];
+            Jr[6 + k] = w.c[0] * Mn[k] + w.c[1] * Mn[3 + k] + w.c[2] * Mn[6 + k];
+            Jr[9 + k] = -(w.g[0] * R[k] + w.g[1] * R[3 + k] + w.g[2] * R[6 + k]);
+          }
+          double2* dst = reinterpret_cast<double2*>(&stage[wv][(2 * lane + h) * 12]);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) dst[k] = make_double2(Jr[2 * k], Jr[2 * k + 1]);
         }
       }
+    }
+    if (J_out) {
+      __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order; keep the compiler from reordering
+      const int64_t row0 = lo + it * 512 + (int64_t)wv * 128;         // first row of this wave's tile
+      const int64_t rows = min((int64_t)128, hi - row0);               // may be <= 0 for idle waves
+      if (rows > 0) {
+        double2* gdst = reinterpret_cast<double2*>(J_out + (size_t)(o0 + row0) * 12);
+        const double2* src = reinterpret_cast<const double2*>(&stage[wv][0]);
+        const int n2 = (int)rows * 6;                                   // double2 elements in the tile
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+          const int e = t * 64 + lane;
+          if (e < n2) gdst[e] = src[e];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
