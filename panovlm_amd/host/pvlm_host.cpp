@@ -1,0 +1,1167 @@
+// pvlm_host.cpp — implementation of the C++ host mirror (see pvlm_host.hpp for the reference
+// interfaces each piece stands in for).  Host logic only (neighbour lists, vote post-processing,
+// tracks, problem bookkeeping, the trust-region loop, the small linear solves); every residual,
+// Jacobian, distance and vote is produced by libpvlm.so on the GPU.
+#include "pvlm_host.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+
+namespace pvlm {
+
+// ================================================================================================
+// Engine
+// ================================================================================================
+static int g_device = 0;
+void Engine::SetDevice(int device) { g_device = device; }
+Engine::Engine(int device) {
+  pvlm_status st = pvlm_create(device, &ctx_);
+  if (st != PVLM_OK) throw std::runtime_error("pvlm_create failed (" + std::to_string((int)st) + "): no usable MI355X / HIP device; there is no CPU fallback");
+}
+Engine::~Engine() { if (ctx_) pvlm_destroy(ctx_); }
+Engine& Engine::Default() {
+  static Engine e(g_device);
+  return e;
+}
+void Engine::Check(pvlm_status st, const char* what) const {
+  if (st != PVLM_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string((int)st) + "): " + pvlm_last_error(ctx_));
+}
+
+// ================================================================================================
+// small dense helpers (row-major 3x3 / 4x4)
+// ================================================================================================
+static inline Vector3d MatVec(const Matrix3d& R, const Vector3d& p) {
+  return {(R[0] * p[0] + R[1] * p[1]) + R[2] * p[2], (R[3] * p[0] + R[4] * p[1]) + R[5] * p[2], (R[6] * p[0] + R[7] * p[1]) + R[8] * p[2]};
+}
+static inline Vector3d MatTVec(const Matrix3d& R, const Vector3d& p) {
+  return {(R[0] * p[0] + R[3] * p[1]) + R[6] * p[2], (R[1] * p[0] + R[4] * p[1]) + R[7] * p[2], (R[2] * p[0] + R[5] * p[1]) + R[8] * p[2]};
+}
+
+// ceres::RotationMatrixToAngleAxis / AngleAxisToRotationMatrix ([recalled] Ceres 2.0.0 rotation.h):
+// the callers hand Eigen column-major data; here R is row-major, element (r,c) = R[3r+c].
+void RotationMatrixToAngleAxis(const Matrix3d& R, Vector3d* aa) {
+  auto M = [&](int r, int c) { return R[3 * r + c]; };
+  double q[4];
+  const double trace = M(0, 0) + M(1, 1) + M(2, 2);
+  if (trace >= 0.0) {
+    double t = std::sqrt(trace + 1.0);
+    q[0] = 0.5 * t; t = 0.5 / t;
+    q[1] = (M(2, 1) - M(1, 2)) * t; q[2] = (M(0, 2) - M(2, 0)) * t; q[3] = (M(1, 0) - M(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (M(1, 1) > M(0, 0)) i = 1;
+    if (M(2, 2) > M(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+    q[i + 1] = 0.5 * t; t = 0.5 / t;
+    q[0] = (M(k, j) - M(j, k)) * t; q[j + 1] = (M(j, i) + M(i, j)) * t; q[k + 1] = (M(k, i) + M(i, k)) * t;
+  }
+  const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (s2 > 0.0) {
+    const double s = std::sqrt(s2);
+    const double two_theta = 2.0 * ((q[0] < 0.0) ? std::atan2(-s, -q[0]) : std::atan2(s, q[0]));
+    const double k = two_theta / s;
+    *aa = {q[1] * k, q[2] * k, q[3] * k};
+  } else {
+    *aa = {q[1] * 2.0, q[2] * 2.0, q[3] * 2.0};
+  }
+}
+void AngleAxisToRotationMatrix(const Vector3d& a, Matrix3d* Rout) {
+  Matrix3d& R = *Rout;
+  const double th2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+  if (th2 > std::numeric_limits<double>::epsilon()) {
+    const double th = std::sqrt(th2), wx = a[0] / th, wy = a[1] / th, wz = a[2] / th, c = std::cos(th), s = std::sin(th), k = 1.0 - c;
+    R = {c + wx * wx * k, wx * wy * k - wz * s, wy * s + wx * wz * k, wz * s + wx * wy * k, c + wy * wy * k, -wx * s + wy * wz * k,
+         -wy * s + wx * wz * k, wx * s + wy * wz * k, c + wz * wz * k};
+  } else {
+    R = {1, -a[2], a[1], a[2], 1, -a[0], -a[1], a[0], 1};
+  }
+}
+
+// ================================================================================================
+// Velodyne
+// ================================================================================================
+Matrix4d Velodyne::GetPose() const {
+  return {R_wl_[0], R_wl_[1], R_wl_[2], t_wl_[0], R_wl_[3], R_wl_[4], R_wl_[5], t_wl_[1], R_wl_[6], R_wl_[7], R_wl_[8], t_wl_[2], 0, 0, 0, 1};
+}
+bool Velodyne::IsPoseValid() const {
+  for (int k = 0; k < 3; ++k) if (std::isinf(t_wl_[k]) || std::isnan(t_wl_[k])) return false;
+  for (int k = 0; k < 9; ++k) if (std::fabs(R_wl_[k]) > 1e-12) return true;  // !R_wl.isZero()
+  return false;
+}
+Vector3d Velodyne::World2Local(const Vector3d& p) const {
+  const Vector3d a = MatTVec(R_wl_, p), b = MatTVec(R_wl_, t_wl_);
+  return {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+}
+Vector3d Velodyne::Local2World(const Vector3d& p) const {
+  const Vector3d a = MatVec(R_wl_, p);
+  return {a[0] + t_wl_[0], a[1] + t_wl_[1], a[2] + t_wl_[2]};
+}
+// pcl::transformPointCloud(cloud, cloud, Matrix4d): per coordinate float(m0*x + m1*y + m2*z + m3)
+static void TransformCloud(PointCloud& c, const Matrix3d& R, const Vector3d& t) {
+  for (PointXYZI& p : c) {
+    const double x = p.x, y = p.y, z = p.z;
+    p.x = static_cast<float>(R[0] * x + R[1] * y + R[2] * z + t[0]);
+    p.y = static_cast<float>(R[3] * x + R[4] * y + R[5] * z + t[1]);
+    p.z = static_cast<float>(R[6] * x + R[7] * y + R[8] * z + t[2]);
+  }
+}
+void Velodyne::Transform2LidarWorld() {
+  if (world_ || !IsPoseValid()) return;
+  TransformCloud(surfFlat, R_wl_, t_wl_); TransformCloud(surfLessFlat, R_wl_, t_wl_); TransformCloud(cornerLessSharp, R_wl_, t_wl_);
+  for (PointCloud& s : edge_segmented) TransformCloud(s, R_wl_, t_wl_);
+  world_ = true;
+  InvalidateDevice();
+}
+void Velodyne::Transform2Local() {
+  if (!world_ || !IsPoseValid()) return;
+  Matrix3d Rl = {R_wl_[0], R_wl_[3], R_wl_[6], R_wl_[1], R_wl_[4], R_wl_[7], R_wl_[2], R_wl_[5], R_wl_[8]};
+  const Vector3d rt = MatVec(Rl, t_wl_);
+  const Vector3d tl = {-rt[0], -rt[1], -rt[2]};
+  TransformCloud(surfFlat, Rl, tl); TransformCloud(surfLessFlat, Rl, tl); TransformCloud(cornerLessSharp, Rl, tl);
+  for (PointCloud& s : edge_segmented) TransformCloud(s, Rl, tl);
+  world_ = false;
+  InvalidateDevice();
+}
+void Velodyne::InvalidateDevice() const {
+  if (dev_) { pvlm_scan_destroy(Engine::Default().ctx(), dev_); dev_ = nullptr; }
+}
+Velodyne::~Velodyne() { if (dev_) pvlm_scan_destroy(Engine::Default().ctx(), dev_); }
+Velodyne::Velodyne(const Velodyne& o)
+    : id(o.id), valid(o.valid), cornerLessSharp(o.cornerLessSharp), surfFlat(o.surfFlat), surfLessFlat(o.surfLessFlat),
+      edge_segmented(o.edge_segmented), point_to_segment(o.point_to_segment), segment_coeffs(o.segment_coeffs), end_points(o.end_points),
+      R_wl_(o.R_wl_), t_wl_(o.t_wl_), world_(o.world_), dev_(nullptr) {}
+Velodyne& Velodyne::operator=(const Velodyne& o) {
+  if (this == &o) return *this;
+  InvalidateDevice();
+  id = o.id; valid = o.valid; cornerLessSharp = o.cornerLessSharp; surfFlat = o.surfFlat; surfLessFlat = o.surfLessFlat;
+  edge_segmented = o.edge_segmented; point_to_segment = o.point_to_segment; segment_coeffs = o.segment_coeffs; end_points = o.end_points;
+  R_wl_ = o.R_wl_; t_wl_ = o.t_wl_; world_ = o.world_;
+  return *this;
+}
+pvlm_scan* Velodyne::DeviceScan() const {
+  if (dev_) return dev_;
+  auto flat = [](const PointCloud& c, std::vector<float>& xyz, std::vector<float>& tag) {
+    xyz.resize(c.size() * 3); tag.resize(c.size());
+    for (size_t i = 0; i < c.size(); ++i) { xyz[3 * i] = c[i].x; xyz[3 * i + 1] = c[i].y; xyz[3 * i + 2] = c[i].z; tag[i] = c[i].intensity; }
+  };
+  std::vector<float> fx, ft, lx, lt, cx, ct;
+  flat(surfFlat, fx, ft); flat(surfLessFlat, lx, lt); flat(cornerLessSharp, cx, ct);
+  std::vector<int> off(cornerLessSharp.size() + 1, 0), ids, seg_size(edge_segmented.size());
+  for (size_t i = 0; i < cornerLessSharp.size(); ++i) {
+    if (i < point_to_segment.size()) for (int s : point_to_segment[i]) ids.push_back(s);
+    off[i + 1] = (int)ids.size();
+  }
+  for (size_t s = 0; s < edge_segmented.size(); ++s) seg_size[s] = (int)edge_segmented[s].size();
+  std::vector<double> coeffs(segment_coeffs.size() * 6), ends(edge_segmented.size() * 6, 0.0);
+  for (size_t s = 0; s < segment_coeffs.size(); ++s) std::memcpy(&coeffs[6 * s], segment_coeffs[s].data(), 48);
+  for (size_t s = 0; s < edge_segmented.size() && 2 * s + 1 < end_points.size(); ++s) {
+    std::memcpy(&ends[6 * s], end_points[2 * s].data(), 24); std::memcpy(&ends[6 * s + 3], end_points[2 * s + 1].data(), 24);
+  }
+  if (ids.empty()) ids.push_back(0);
+  pvlm_scan_desc d;
+  std::memset(&d, 0, sizeof(d));
+  d.id = id; d.R_wl = R_wl_.data(); d.t_wl = t_wl_.data();
+  d.n_surf_flat = (int)surfFlat.size(); d.surf_flat_xyz = fx.data(); d.surf_flat_tag = ft.data();
+  d.n_surf_less_flat = (int)surfLessFlat.size(); d.surf_less_flat_xyz = lx.data(); d.surf_less_flat_tag = lt.data();
+  d.n_corner = (int)cornerLessSharp.size(); d.corner_xyz = cx.data(); d.p2s_offsets = off.data(); d.p2s_ids = ids.data();
+  d.n_segments = (int)std::min(edge_segmented.size(), segment_coeffs.size()); d.segment_size = seg_size.data();
+  d.segment_coeffs = coeffs.data(); d.end_points = ends.data();
+  Engine& e = Engine::Default();
+  e.Check(pvlm_scan_upload(e.ctx(), &d, &dev_), "pvlm_scan_upload");
+  return dev_;
+}
+
+// ================================================================================================
+// FindNeighbors — lidar_mapping/LidarFeatureAssociate.cpp:19-111 (scan centres as float32
+// PointXYZI, exact k-NN / radius search as pcl::KdTreeFLANN returns them: ascending, L2_Simple)
+// ================================================================================================
+std::vector<std::vector<int>> FindNeighborsConsecutive(const std::vector<Velodyne>& lidars, const int neighbor_size) {
+  std::vector<std::vector<int>> all;
+  for (int i = 0; i < int(lidars.size()) - neighbor_size; i++) {
+    std::vector<int> nb;
+    for (int j = i + 1; j < (int)lidars.size() && j <= i + neighbor_size; j++) nb.push_back(j);
+    all.push_back(nb);
+  }
+  return all;
+}
+
+std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars, const int neighbor_size) {
+  std::vector<std::vector<int>> neighbors_all;
+  std::vector<std::array<float, 3>> center;
+  std::vector<int> owner;
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    const Vector3d& t = lidars[i].GetTranslation();
+    center.push_back({float(t[0]), float(t[1]), float(t[2])});
+    owner.push_back((int)i);
+  }
+  const int nc = (int)owner.size();
+  for (size_t i = 0; i < lidars.size(); i++) {
+    std::vector<int> neighbors;
+    if (lidars[i].IsPoseValid()) {
+      const Vector3d& t = lidars[i].GetTranslation();
+      const float q[3] = {float(t[0]), float(t[1]), float(t[2])};
+      std::vector<std::pair<float, int>> d(nc);
+      for (int j = 0; j < nc; ++j) {
+        const float dx = q[0] - center[j][0], dy = q[1] - center[j][1], dz = q[2] - center[j][2];
+        float s = 0.0f; s += dx * dx; s += dy * dy; s += dz * dz;
+        d[j] = {s, j};
+      }
+      std::stable_sort(d.begin(), d.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+      for (int j = 0; j < std::min(neighbor_size, nc); ++j) neighbors.push_back(d[j].second);
+      if (!neighbors.empty()) neighbors.erase(neighbors.begin());  // the first one is the scan itself
+      for (int& n : neighbors) n = owner[n];
+      std::set<int> nset(neighbors.begin(), neighbors.end());
+      int ni = (int)i - 1;
+      while (ni >= 0 && !lidars[ni].IsPoseValid()) ni--;
+      if (ni >= 0 && nset.count(ni) == 0) neighbors.push_back(ni);
+      ni = (int)i + 1;
+      while (ni < (int)lidars.size() && !lidars[ni].IsPoseValid()) ni++;
+      if (ni < (int)lidars.size() && nset.count(ni) == 0) neighbors.push_back(ni);
+      const float r2 = float(20.0 * 20.0);  // radiusSearch(20 m): FLANN keeps dist < r^2
+      const int loop_length = 200;
+      for (int j = 0; j < nc && d[j].first < r2; ++j) {
+        const int n_idx = owner[d[j].second];
+        int same_loop = 0;
+        for (int v : nset) {
+          if (std::abs(n_idx - v) <= loop_length) same_loop++;
+          if (same_loop >= 2) break;
+        }
+        if (same_loop < 2 && nset.count(n_idx) == 0) { neighbors.push_back(n_idx); nset.insert(n_idx); }
+      }
+    } else {
+      for (int j = -neighbor_size / 2; j <= neighbor_size / 2; j++) neighbors.push_back((int)i - j);
+    }
+    neighbors_all.push_back(neighbors);
+  }
+  return neighbors_all;
+}
+
+// ================================================================================================
+// association wrappers
+// ================================================================================================
+std::vector<Point2Plane> AssociatePoint2Plane(const Velodyne& ref, const Velodyne& nei, double plane_tolerance, const float dist_threshold, bool) {
+  std::vector<Point2Plane> out;
+  if (!ref.IsInWorldCoordinate() || !nei.IsInWorldCoordinate()) { fprintf(stderr, "lidar %d / %d is not in world coordinate\n", ref.id, nei.id); return out; }
+  Engine& e = Engine::Default();
+  pvlm_scan* r = ref.DeviceScan(); pvlm_scan* n = nei.DeviceScan();
+  pvlm_resset* rs = nullptr;
+  e.Check(pvlm_assoc_point2plane(e.ctx(), 1, &r, &n, plane_tolerance, dist_threshold, PVLM_POINT2PLANE_METER, 0, 1.0, &rs), "pvlm_assoc_point2plane");
+  int64_t m = 0;
+  pvlm_resset_info(rs, &m, nullptr, nullptr, nullptr);
+  std::vector<double> rows((size_t)std::max<int64_t>(m, 1) * 7);
+  e.Check(pvlm_resset_download(e.ctx(), rs, nullptr, nullptr, nullptr, rows.data()), "pvlm_resset_download");
+  pvlm_resset_destroy(e.ctx(), rs);
+  out.resize((size_t)m);
+  for (int64_t i = 0; i < m; ++i) {
+    out[i].point = {rows[7 * i], rows[7 * i + 1], rows[7 * i + 2]};
+    out[i].plane_coeff = {rows[7 * i + 3], rows[7 * i + 4], rows[7 * i + 5], rows[7 * i + 6]};
+  }
+  return out;
+}
+
+std::vector<Vector6d> TransformLines(const std::vector<Vector6d>& lc, const Matrix4d& T) {
+  std::vector<Vector6d> out(lc.size());
+  for (size_t s = 0; s < lc.size(); ++s) {
+    const Vector6d& c = lc[s];
+    for (int i = 0; i < 3; ++i) {
+      out[s][i] = ((T[4 * i] * c[0] + T[4 * i + 1] * c[1]) + T[4 * i + 2] * c[2]) + T[4 * i + 3];
+      out[s][3 + i] = (T[4 * i] * c[3] + T[4 * i + 1] * c[4]) + T[4 * i + 2] * c[5];
+    }
+  }
+  return out;
+}
+
+static inline double PointToLineDistance3D(const double* p, const double* l) {  // base/Geometry.hpp:198-211
+  const double k = (l[3] * (p[0] - l[0]) + l[4] * (p[1] - l[1]) + l[5] * (p[2] - l[2])) / (l[3] * l[3] + l[4] * l[4] + l[5] * l[5]);
+  const double q[3] = {k * l[3] + l[0], k * l[4] + l[1], k * l[5] + l[2]};
+  return std::sqrt((q[0] - p[0]) * (q[0] - p[0]) + (q[1] - p[1]) * (q[1] - p[1]) + (q[2] - p[2]) * (q[2] - p[2]));
+}
+static inline double PlaneAngle(const double* a, const double* b) {  // base/Geometry.hpp:471-485
+  double c = std::fabs(a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+  c = c / (std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]));
+  return c >= 1.0 ? 0.0 : std::acos(c);
+}
+
+static inline double PlaneAngleN(const double* a, const double* b) {  // PlaneAngle(..., normalized = true)
+  const double c = std::fabs(a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+  return c >= 1.0 ? 0.0 : std::acos(c);
+}
+
+// lidar_mapping/LidarFeatureAssociate.cpp:120-197; line_matrix row-major [nei segments x ref segments]
+std::vector<Line2Line> FindAssociations(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
+                                        const std::vector<Vector6d>& nei_world, const std::vector<int>& line_matrix) {
+  std::map<int, Line2Line> m;
+  const int nr = (int)ref.edge_segmented.size(), nn = (int)nei.edge_segmented.size();
+  for (int s = 0; s < nn && nr > 0; ++s) {
+    int max_col = 0, max_count = line_matrix[(size_t)s * nr];
+    for (int c = 1; c < nr; ++c) if (line_matrix[(size_t)s * nr + c] > max_count) { max_count = line_matrix[(size_t)s * nr + c]; max_col = c; }
+    if ((size_t)max_count < nei.edge_segmented[s].size() / 2) continue;
+    if (PlaneAngle(&ref_world[max_col][3], &nei_world[s][3]) * 180.0 / M_PI > 7) continue;
+    const Vector6d& loc = ref.segment_coeffs[max_col];
+    Line2Line a;
+    a.neighbor_line_idx = s; a.ref_line_idx = max_col;
+    for (int c = 0; c < 3; ++c) { a.line_point1[c] = 0.1 * loc[3 + c] + loc[c]; a.line_point2[c] = -0.1 * loc[3 + c] + loc[c]; }
+    auto it = m.find(max_col);
+    if (it == m.end()) m.insert({max_col, a});
+    else {
+      const double d1 = PointToLineDistance3D(nei_world[it->second.neighbor_line_idx].data(), ref_world[max_col].data());
+      const double d2 = PointToLineDistance3D(nei_world[s].data(), ref_world[max_col].data());
+      if (d2 < d1) it->second = a;
+    }
+  }
+  std::vector<Line2Line> out;
+  for (auto& kv : m) out.push_back(kv.second);
+  return out;
+}
+
+std::vector<Line2Line> AssociateLine2Line(const Velodyne& ref, const Velodyne& nei, const float dist_threshold, bool) {
+  std::vector<Line2Line> out;
+  if (!ref.IsInWorldCoordinate() || !nei.IsInWorldCoordinate()) { fprintf(stderr, "lidar %d / %d is not in world coordinate\n", ref.id, nei.id); return out; }
+  if (ref.edge_segmented.empty() || nei.edge_segmented.empty()) return out;  // CheckLidarSegment
+  const std::vector<Vector6d> nei_world = TransformLines(nei.segment_coeffs, nei.GetPose());
+  const std::vector<Vector6d> ref_world = TransformLines(ref.segment_coeffs, ref.GetPose());
+  std::vector<int> votes(ref.edge_segmented.size() * nei.edge_segmented.size(), 0);
+  Engine& e = Engine::Default();
+  e.Check(pvlm_line2line_votes(e.ctx(), ref.DeviceScan(), nei.DeviceScan(), dist_threshold, votes.data()), "pvlm_line2line_votes");
+  return FindAssociations(ref, nei, ref_world, nei_world, votes);
+}
+
+// ================================================================================================
+// tracks — util/Tracks.h:34-107 (UnionFind), util/Tracks.cpp:58-196 (TrackBuilder, allow_multiple_map)
+// ================================================================================================
+namespace {
+struct UnionFind {
+  std::vector<unsigned> parent, rank, size;
+  void Init(unsigned n) { size.assign(n, 1); parent.resize(n); std::iota(parent.begin(), parent.end(), 0u); rank.assign(n, 0); }
+  unsigned Find(unsigned i) { if (parent[i] != i) parent[i] = Find(parent[i]); return parent[i]; }
+  void Union(unsigned i, unsigned j) {
+    i = Find(i); j = Find(j);
+    if (i == j) return;
+    if (rank[i] < rank[j]) { parent[i] = j; size[j] += size[i]; }
+    else { parent[j] = i; size[i] += size[j]; if (rank[i] == rank[j]) ++rank[i]; }
+  }
+};
+}  // namespace
+
+bool LidarLineMatch::GenerateTracks() {
+  std::vector<std::pair<size_t, size_t>> pairs;
+  std::vector<std::set<std::pair<uint32_t, uint32_t>>> feature_each_pair;
+  const std::vector<std::vector<int>> neighbors = FindNeighbors(lidars_, neighbor_size_);
+  for (size_t i = 0; i < neighbors.size(); i++) {
+    if (!lidars_[i].IsPoseValid()) continue;
+    for (const int nei_id : neighbors[i]) {
+      if (nei_id < 0 || nei_id >= (int)lidars_.size()) continue;
+      const std::vector<Line2Line> ass = AssociateLine2Line(lidars_[nei_id], lidars_[i], 0.3f);
+      std::set<std::pair<uint32_t, uint32_t>> fp;
+      for (const Line2Line& a : ass) fp.insert({(uint32_t)a.neighbor_line_idx, (uint32_t)a.ref_line_idx});
+      feature_each_pair.push_back(fp);
+      pairs.push_back({i, (size_t)nei_id});
+    }
+  }
+  // TrackBuilder(true).Build
+  std::set<std::pair<uint32_t, uint32_t>> all;
+  for (size_t i = 0; i < pairs.size(); i++)
+    for (const auto& mth : feature_each_pair[i]) { all.emplace((uint32_t)pairs[i].first, mth.first); all.emplace((uint32_t)pairs[i].second, mth.second); }
+  std::map<std::pair<uint32_t, uint32_t>, uint32_t> f2i;
+  std::vector<std::pair<uint32_t, uint32_t>> i2f;
+  for (const auto& f : all) { f2i.emplace(f, (uint32_t)i2f.size()); i2f.push_back(f); }
+  UnionFind uf;
+  uf.Init((unsigned)i2f.size());
+  for (size_t i = 0; i < pairs.size(); i++)
+    for (const auto& mth : feature_each_pair[i])
+      uf.Union(f2i[{(uint32_t)pairs[i].first, mth.first}], f2i[{(uint32_t)pairs[i].second, mth.second}]);
+  // Filter(min_track_length): a track must span at least min_track_length different scans
+  std::map<uint32_t, std::set<uint32_t>> members;
+  std::set<uint32_t> bad;
+  for (uint32_t i = 0; i < i2f.size(); i++) members[uf.Find(i)].insert(i2f[i].first);
+  for (const auto& kv : members) if (kv.second.size() < (size_t)min_track_length_) bad.insert(kv.first);
+  for (unsigned& root : uf.parent)
+    if (bad.count(root) > 0) { uf.size[root] = 1; root = std::numeric_limits<uint32_t>::max(); }
+  // ExportTracks
+  std::map<uint32_t, size_t> t2i;
+  tracks_.clear();
+  for (uint32_t i = 0; i < i2f.size(); i++) {
+    const uint32_t tid = uf.parent[i];
+    if (tid != std::numeric_limits<uint32_t>::max() && uf.size[tid] > 1) {
+      auto it = t2i.find(tid);
+      if (it != t2i.end()) tracks_[it->second].feature_pairs.insert(i2f[i]);
+      else { t2i[tid] = tracks_.size(); LineTrack t; t.id = tid; t.feature_pairs.insert(i2f[i]); tracks_.push_back(t); }
+    }
+  }
+  for (size_t i = 0; i < tracks_.size(); i++) tracks_[i].id = (uint32_t)i;
+  return true;
+}
+
+// ================================================================================================
+// ceres-like problem / solver
+// ================================================================================================
+namespace ceres_like {
+
+static const int kStride[6] = {7, 7, 9, 9, 10, 12};
+
+bool CostFunction::Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+  Engine& e = Engine::Default();
+  double aa[6] = {parameters[0][0], parameters[0][1], parameters[0][2], parameters[2][0], parameters[2][1], parameters[2][2]};
+  double t[6] = {parameters[1][0], parameters[1][1], parameters[1][2], parameters[3][0], parameters[3][1], parameters[3][2]};
+  const int64_t off[2] = {0, 1};
+  const int ref = 0, nei = 1;
+  pvlm_resset* rs = nullptr;
+  if (pvlm_resset_upload(e.ctx(), (pvlm_functor)kind, flags, weight, 1, 1, off, &ref, &nei, row.data(), kStride[kind], &rs) != PVLM_OK) return false;
+  bool ok = pvlm_set_poses(e.ctx(), 2, aa, t) == PVLM_OK;
+  double J[12];
+  ok = ok && pvlm_eval(e.ctx(), rs, residuals, jacobians ? J : nullptr) == PVLM_OK;
+  pvlm_resset_destroy(e.ctx(), rs);
+  if (ok && jacobians)
+    for (int b = 0; b < 4; ++b)
+      if (jacobians[b]) for (int k = 0; k < 3; ++k) jacobians[b][k] = J[3 * b + k];
+  return ok && std::isfinite(residuals[0]);
+}
+
+struct Problem::Impl {
+  // parameter blocks: every double[3] the caller registered, in first-seen order
+  std::map<double*, int> block_id;
+  std::vector<double*> blocks;
+  std::vector<bool> constant;
+  // poses = (aa block, t block) pairs, in first-seen order
+  std::map<std::pair<int, int>, int> pose_id;
+  std::vector<std::pair<int, int>> poses;
+  // A group = one device residual set.  Host-built groups collect consecutive AddResidualBlock
+  // calls with identical (kind, flags, weight, loss); consecutive blocks with the same pose pair
+  // form a segment.  dev_* are the pose ids the device set uses (for sets handed in by the
+  // association kernels these are the caller's list indices), ref/nei the Problem pose ids.
+  struct Group {
+    int kind = 0; unsigned flags = 0; double weight = 1.0; LossFunction* loss = nullptr;
+    std::vector<double> rows; std::vector<int64_t> off; std::vector<int> ref, nei, dev_ref, dev_nei;
+    pvlm_resset* set = nullptr; bool external = false;
+    pvlm_neq* neq = nullptr; int dev_poses = 0;
+    std::vector<int> ui, uj;            // unordered dev-id pairs of the neq structure
+    std::vector<int> dev_to_pose;       // dev id -> Problem pose id (-1 unused)
+  };
+  std::vector<Group> groups;
+  std::vector<CostFunction*> owned_costs;
+  std::set<LossFunction*> owned_losses;
+  int num_blocks = 0;
+
+  int Block(double* p) {
+    auto it = block_id.find(p);
+    if (it != block_id.end()) return it->second;
+    const int id = (int)blocks.size();
+    block_id[p] = id; blocks.push_back(p); constant.push_back(false);
+    return id;
+  }
+  int Pose(double* aa, double* t) {
+    const std::pair<int, int> k(Block(aa), Block(t));
+    auto it = pose_id.find(k);
+    if (it != pose_id.end()) return it->second;
+    const int id = (int)poses.size();
+    pose_id[k] = id; poses.push_back(k);
+    return id;
+  }
+};
+
+Problem::Problem() : impl_(new Impl()) {}
+Problem::~Problem() {
+  Engine& e = Engine::Default();
+  for (auto& g : impl_->groups) { if (g.neq) pvlm_neq_destroy(e.ctx(), g.neq); if (g.set) pvlm_resset_destroy(e.ctx(), g.set); }
+  for (CostFunction* c : impl_->owned_costs) delete c;
+  for (LossFunction* l : impl_->owned_losses) delete l;
+  delete impl_;
+}
+int Problem::NumResidualBlocks() const { return impl_->num_blocks; }
+void Problem::SetParameterBlockConstant(double* block) { impl_->constant[impl_->Block(block)] = true; }
+
+void Problem::AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_r, double* t_r, double* aa_n, double* t_n) {
+  Impl& I = *impl_;
+  const int pr = I.Pose(aa_r, t_r), pn = I.Pose(aa_n, t_n);
+  if (loss) I.owned_losses.insert(loss);
+  I.owned_costs.push_back(cost);
+  if (I.groups.empty() || I.groups.back().external || I.groups.back().kind != cost->kind || I.groups.back().flags != cost->flags ||
+      I.groups.back().weight != cost->weight || I.groups.back().loss != loss) {
+    Impl::Group g; g.kind = cost->kind; g.flags = cost->flags; g.weight = cost->weight; g.loss = loss; g.off.push_back(0);
+    I.groups.push_back(g);
+  }
+  Impl::Group& g = I.groups.back();
+  if (g.ref.empty() || g.ref.back() != pr || g.nei.back() != pn) { g.ref.push_back(pr); g.nei.push_back(pn); g.off.push_back(g.off.back()); }
+  g.rows.insert(g.rows.end(), cost->row.begin(), cost->row.end());
+  g.off.back() += 1;
+  I.num_blocks++;
+}
+
+void Problem::AddResidualSet(pvlm_resset* set, LossFunction* loss, std::vector<Vector3d>* aa_list, std::vector<Vector3d>* t_list) {
+  Impl& I = *impl_;
+  if (loss) I.owned_losses.insert(loss);
+  int64_t n = 0; int P = 0, kind = 0; unsigned flags = 0;
+  pvlm_resset_info(set, &n, &P, &kind, &flags);
+  Impl::Group g; g.kind = kind; g.flags = flags; g.loss = loss; g.set = set; g.external = true;
+  g.off.resize((size_t)P + 1); g.dev_ref.resize((size_t)std::max(P, 1)); g.dev_nei.resize((size_t)std::max(P, 1));
+  Engine& e = Engine::Default();
+  e.Check(pvlm_resset_download(e.ctx(), set, g.off.data(), g.dev_ref.data(), g.dev_nei.data(), nullptr), "pvlm_resset_download");
+  g.dev_ref.resize(P); g.dev_nei.resize(P);
+  for (int p = 0; p < P; ++p) {
+    g.ref.push_back(I.Pose((*aa_list)[g.dev_ref[p]].data(), (*t_list)[g.dev_ref[p]].data()));
+    g.nei.push_back(I.Pose((*aa_list)[g.dev_nei[p]].data(), (*t_list)[g.dev_nei[p]].data()));
+  }
+  I.groups.push_back(g);
+  I.num_blocks += (int)n;
+}
+
+std::string Solver::Summary::BriefReport() const {
+  char b[256];
+  snprintf(b, sizeof(b), "pvlm LM: blocks %d, initial cost %.6e, final cost %.6e, successful %d, unsuccessful %d, %s", num_residual_blocks,
+           initial_cost, final_cost, num_successful_steps, num_unsuccessful_steps, message.c_str());
+  return b;
+}
+
+namespace {
+
+// Skyline (profile) Cholesky of a symmetric positive definite matrix given as dense row-major
+// lower triangle accessor.  Pose graphs of LiDAR odometry are block-banded (temporal neighbours)
+// plus a few loop closures, which the envelope captures.
+struct Skyline {
+  int n = 0;
+  std::vector<int> first;          // first stored column of each row
+  std::vector<size_t> start;       // offset of row i in val (entries first[i]..i)
+  std::vector<double> val;
+  double& at(int i, int j) { return val[start[i] + (size_t)(j - first[i])]; }
+  void Init(const std::vector<int>& f) {
+    n = (int)f.size(); first = f; start.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) start[i + 1] = start[i] + (size_t)(i - first[i] + 1);
+    val.assign(start[n], 0.0);
+  }
+  bool Factor() {
+    for (int i = 0; i < n; ++i) {
+      for (int j = first[i]; j <= i; ++j) {
+        double s = at(i, j);
+        const int k0 = std::max(first[i], first[j]);
+        for (int k = k0; k < j; ++k) s -= at(i, k) * at(j, k);
+        if (j < i) at(i, j) = s / at(j, j);
+        else { if (!(s > 0.0)) return false; at(i, i) = std::sqrt(s); }
+      }
+    }
+    return true;
+  }
+  void Solve(std::vector<double>& b) {
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = first[i]; k < i; ++k) s -= at(i, k) * b[k]; b[i] = s / at(i, i); }
+    for (int i = n - 1; i >= 0; --i) { b[i] /= at(i, i); for (int k = first[i]; k < i; ++k) b[k] -= at(i, k) * b[i]; }
+  }
+};
+
+struct Assembled {
+  double cost = 0;
+  std::vector<double> g;                       // n_free
+  std::map<std::pair<int, int>, std::array<double, 36>> H;  // block (pose a <= pose b) 6x6 row-major (d2/dx_a dx_b)
+};
+
+}  // namespace
+
+void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summary) {
+  Problem::Impl& I = *problem->impl();
+  Engine& e = Engine::Default();
+  *summary = Solver::Summary();
+  summary->num_residual_blocks = I.num_blocks;
+  const int NP = (int)I.poses.size();
+  if (I.num_blocks == 0 || NP == 0) { summary->message = "no residual blocks"; return; }
+
+  // ---- device sets + per-group normal-equation structures ---------------------------------------
+  for (auto& g : I.groups) {
+    const int P = (int)g.ref.size();
+    if (!g.set) {
+      g.dev_ref = g.ref; g.dev_nei = g.nei;
+      e.Check(pvlm_resset_upload(e.ctx(), (pvlm_functor)g.kind, g.flags, g.weight, g.off.back(), P, g.off.data(), g.dev_ref.data(), g.dev_nei.data(),
+                                 g.rows.data(), kStride[g.kind], &g.set), "pvlm_resset_upload");
+      std::vector<double>().swap(g.rows);
+    }
+    if (!g.neq) {
+      int mx = -1;
+      for (int p = 0; p < P; ++p) mx = std::max(mx, std::max(g.dev_ref[p], g.dev_nei[p]));
+      g.dev_poses = mx + 1;
+      g.dev_to_pose.assign(g.dev_poses, -1);
+      std::set<std::pair<int, int>> up;
+      for (int p = 0; p < P; ++p) {
+        g.dev_to_pose[g.dev_ref[p]] = g.ref[p]; g.dev_to_pose[g.dev_nei[p]] = g.nei[p];
+        up.insert({std::min(g.dev_ref[p], g.dev_nei[p]), std::max(g.dev_ref[p], g.dev_nei[p])});
+      }
+      for (auto& u : up) { g.ui.push_back(u.first); g.uj.push_back(u.second); }
+      e.Check(pvlm_neq_create(e.ctx(), g.dev_poses, (int)g.ui.size(), g.ui.data(), g.uj.data(), &g.neq), "pvlm_neq_create");
+    }
+  }
+
+  // ---- free-parameter layout -----------------------------------------------------------------------
+  std::vector<int> block_off(I.blocks.size(), -1);
+  int n_free = 0;
+  for (int p = 0; p < NP; ++p)
+    for (int b : {I.poses[p].first, I.poses[p].second})
+      if (!I.constant[b] && block_off[b] < 0) { block_off[b] = n_free; n_free += 3; }
+  if (n_free == 0) { summary->message = "all parameter blocks constant"; }
+
+  std::vector<double> x(3 * I.blocks.size());
+  auto load_x = [&]() { for (size_t b = 0; b < I.blocks.size(); ++b) for (int k = 0; k < 3; ++k) x[3 * b + k] = I.blocks[b][k]; };
+  auto store_x = [&](const std::vector<double>& v) { for (size_t b = 0; b < I.blocks.size(); ++b) for (int k = 0; k < 3; ++k) I.blocks[b][k] = v[3 * b + k]; };
+  load_x();
+
+  // evaluates cost (+ H, g when want_H) at parameter vector v
+  auto evaluate = [&](const std::vector<double>& v, bool want_H, Assembled& A) {
+    A.cost = 0; A.g.assign(n_free, 0.0); A.H.clear();
+    for (auto& g : I.groups) {
+      std::vector<double> aa((size_t)g.dev_poses * 3, 0.0), tt((size_t)g.dev_poses * 3, 0.0);
+      for (int d = 0; d < g.dev_poses; ++d) {
+        const int p = g.dev_to_pose[d];
+        if (p < 0) continue;
+        for (int k = 0; k < 3; ++k) { aa[3 * d + k] = v[3 * I.poses[p].first + k]; tt[3 * d + k] = v[3 * I.poses[p].second + k]; }
+      }
+      e.Check(pvlm_set_poses(e.ctx(), g.dev_poses, aa.data(), tt.data()), "pvlm_set_poses");
+      std::vector<double> packed((size_t)pvlm_neq_size(g.neq), 0.0);
+      e.Check(pvlm_neq_accumulate(e.ctx(), g.neq, g.set, g.loss ? g.loss->kind() : PVLM_LOSS_NONE, g.loss ? g.loss->a() : 0.0, 1, packed.data()),
+              "pvlm_neq_accumulate");
+      const int nd = g.dev_poses, nu = (int)g.ui.size();
+      A.cost += packed.back();
+      if (!want_H) continue;
+      const double* Hd = packed.data(); const double* Ho = Hd + (size_t)nd * 36; const double* gg = Ho + (size_t)nu * 36;
+      for (int d = 0; d < nd; ++d) {
+        const int p = g.dev_to_pose[d];
+        if (p < 0) continue;
+        auto& blk = A.H[{p, p}];
+        for (int k = 0; k < 36; ++k) blk[k] += Hd[(size_t)d * 36 + k];
+        for (int half = 0; half < 2; ++half) {
+          const int b = half ? I.poses[p].second : I.poses[p].first;
+          if (block_off[b] >= 0) for (int k = 0; k < 3; ++k) A.g[block_off[b] + k] += gg[(size_t)d * 6 + 3 * half + k];
+        }
+      }
+      for (int u = 0; u < nu; ++u) {
+        int pa = g.dev_to_pose[g.ui[u]], pb = g.dev_to_pose[g.uj[u]];
+        const double* src = Ho + (size_t)u * 36;  // d2/dx_ui dx_uj
+        if (pa <= pb) { auto& blk = A.H[{pa, pb}]; for (int k = 0; k < 36; ++k) blk[k] += src[k]; }
+        else { auto& blk = A.H[{pb, pa}]; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[r * 6 + c] += src[c * 6 + r]; }
+      }
+    }
+  };
+
+  Assembled A;
+  evaluate(x, true, A);
+  summary->initial_cost = summary->final_cost = A.cost;
+  summary->cost_history.push_back(A.cost);
+  summary->num_successful_steps = 1;  // iteration 0 counts as successful in Ceres' summary ([recalled])
+  summary->usable = std::isfinite(A.cost);
+  if (!summary->usable) { summary->message = "initial cost is not finite"; return; }
+  if (n_free == 0) return;
+
+  // scalar row/col index of (pose, half, k)
+  auto idx = [&](int pose, int r) { const int b = r < 3 ? I.poses[pose].first : I.poses[pose].second; return block_off[b] < 0 ? -1 : block_off[b] + (r % 3); };
+  // envelope
+  auto build_first = [&](const Assembled& As) {
+    std::vector<int> first(n_free);
+    for (int i = 0; i < n_free; ++i) first[i] = i;
+    for (auto& kv : As.H)
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+        const int i = idx(kv.first.first, r), j = idx(kv.first.second, c);
+        if (i < 0 || j < 0) continue;
+        const int hi = std::max(i, j), lo = std::min(i, j);
+        first[hi] = std::min(first[hi], lo);
+      }
+    // a 3-block's rows share the envelope start (keeps the profile monotone inside blocks)
+    return first;
+  };
+
+  // Jacobi scaling from the initial Jacobian: 1 / (1 + sqrt(diag(J^T J)))   (Ceres jacobi_scaling)
+  std::vector<double> scale(n_free, 1.0);
+  for (auto& kv : A.H) if (kv.first.first == kv.first.second)
+    for (int r = 0; r < 6; ++r) { const int i = idx(kv.first.first, r); if (i >= 0) scale[i] = 1.0 / (1.0 + std::sqrt(std::max(0.0, kv.second[r * 6 + r]))); }
+
+  double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+  double cost = A.cost;
+  int iter = 0;
+  auto gmax = [&](const Assembled& As) { double m = 0; for (double v : As.g) m = std::max(m, std::fabs(v)); return m; };
+  if (gmax(A) <= opt.gradient_tolerance) { summary->message = "gradient tolerance reached"; return; }
+  while (iter < opt.max_num_iterations) {
+    ++iter;
+    // scaled system  (D H D + diag(clamp(diag(D H D))) / radius) dy = -D g
+    Skyline S;
+    S.Init(build_first(A));
+    for (auto& kv : A.H)
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+        const int i = idx(kv.first.first, r), j = idx(kv.first.second, c);
+        if (i < 0 || j < 0) continue;
+        const double v = kv.second[r * 6 + c] * scale[i] * scale[j];
+        if (kv.first.first == kv.first.second) { if (i >= j) S.at(i, j) = v; }   // diagonal block: lower triangle once
+        else if (i >= j) S.at(i, j) += v; else S.at(j, i) += v;
+      }
+    std::vector<double> Hs_diag(n_free), rhs(n_free);
+    for (int i = 0; i < n_free; ++i) { Hs_diag[i] = S.at(i, i); rhs[i] = -A.g[i] * scale[i]; }
+    // keep an unfactored copy for the model cost
+    Skyline S0 = S;
+    for (int i = 0; i < n_free; ++i) S.at(i, i) += std::min(std::max(Hs_diag[i], opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
+    bool step_ok = S.Factor();
+    std::vector<double> dy = rhs;
+    double model_change = 0.0;
+    if (step_ok) {
+      S.Solve(dy);
+      // model_cost_change = -(g'.dy + 1/2 dy^T H' dy)
+      double gd = 0.0, dHd = 0.0;
+      for (int i = 0; i < n_free; ++i) gd += -rhs[i] * dy[i];
+      for (int i = 0; i < n_free; ++i) {
+        double s = 0.0;
+        for (int k = S0.first[i]; k < i; ++k) s += S0.at(i, k) * dy[k];
+        dHd += dy[i] * (2.0 * s + S0.at(i, i) * dy[i]);
+      }
+      model_change = -(gd + 0.5 * dHd);
+      step_ok = model_change > 0.0 && std::isfinite(model_change);
+    }
+    bool accepted = false;
+    double xn = 0.0, dn = 0.0;
+    if (step_ok) {
+      std::vector<double> cand = x;
+      for (size_t b = 0; b < I.blocks.size(); ++b)
+        if (block_off[b] >= 0) for (int k = 0; k < 3; ++k) { const double d = dy[block_off[b] + k] * scale[block_off[b] + k]; cand[3 * b + k] += d; dn += d * d; xn += x[3 * b + k] * x[3 * b + k]; }
+      Assembled C;
+      evaluate(cand, true, C);
+      const double rho = (cost - C.cost) / model_change;
+      if (opt.minimizer_progress_to_stdout)
+        printf("iter %2d cost %.8e -> %.8e  model %.3e rho %.3f radius %.3e\n", iter, cost, C.cost, model_change, rho, radius);
+      if (std::isfinite(C.cost) && rho > opt.min_relative_decrease) {
+        accepted = true;
+        const double cost_change = cost - C.cost;
+        x = cand; A = std::move(C);
+        const double f = 1.0 - std::pow(2.0 * rho - 1.0, 3);
+        radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, f));
+        decrease_factor = 2.0;
+        summary->num_successful_steps++;
+        summary->cost_history.push_back(A.cost);
+        const double prev = cost;
+        cost = A.cost;
+        if (std::fabs(cost_change) <= opt.function_tolerance * prev) { summary->message = "function tolerance reached"; break; }
+        if (gmax(A) <= opt.gradient_tolerance) { summary->message = "gradient tolerance reached"; break; }
+        if (std::sqrt(dn) <= opt.parameter_tolerance * (std::sqrt(xn) + opt.parameter_tolerance)) { summary->message = "parameter tolerance reached"; break; }
+      }
+    }
+    if (!accepted) {
+      summary->num_unsuccessful_steps++;
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+      if (radius < opt.min_trust_region_radius) { summary->message = "trust region collapsed"; break; }
+    }
+  }
+  if (summary->message.empty()) summary->message = "maximum number of iterations reached";
+  store_x(x);
+  summary->final_cost = cost;
+  summary->usable = std::isfinite(cost);
+}
+
+}  // namespace ceres_like
+
+// ================================================================================================
+// functor factories — base/CostFunction.h ::Create
+// ================================================================================================
+using ceres_like::CostFunction;
+static CostFunction* MakeCost(int kind, unsigned flags, double weight, std::initializer_list<double> row) {
+  CostFunction* c = new CostFunction();
+  c->kind = kind; c->flags = flags; c->weight = weight; c->row.assign(row.begin(), row.end());
+  return c;
+}
+CostFunction* Point2Plane_Meter::Create(const Vector3d& p, const Vector4d& pl, const double w) {
+  return MakeCost(PVLM_POINT2PLANE_METER, 0, w, {p[0], p[1], p[2], pl[0], pl[1], pl[2], pl[3]});
+}
+CostFunction* Point2Plane_Angle::Create(const Vector3d& p, const Vector4d& pl, const bool normalize, const double w) {
+  return MakeCost(PVLM_POINT2PLANE_ANGLE, normalize ? PVLM_FLAG_NORMALIZE_DISTANCE : 0, w, {p[0], p[1], p[2], pl[0], pl[1], pl[2], pl[3]});
+}
+CostFunction* Point2Line_Meter::Create(const Vector3d& p, const Vector3d& a, const Vector3d& b, const double w) {
+  return MakeCost(PVLM_POINT2LINE_METER, 0, w, {p[0], p[1], p[2], a[0], a[1], a[2], b[0], b[1], b[2]});
+}
+CostFunction* Point2Line_Angle::Create(const Vector3d& p, const Vector3d& a, const Vector3d& b, const bool normalize, const double w) {
+  return MakeCost(PVLM_POINT2LINE_ANGLE, normalize ? PVLM_FLAG_NORMALIZE_DISTANCE : 0, w, {p[0], p[1], p[2], a[0], a[1], a[2], b[0], b[1], b[2]});
+}
+CostFunction* Plane2Plane_Global::Create(const Vector3d& n, const Vector3d& a, const Vector3d& b, const double w) {
+  return MakeCost(PVLM_PLANE2PLANE_GLOBAL, 0, 1.0, {n[0], n[1], n[2], a[0], a[1], a[2], b[0], b[1], b[2], w});
+}
+CostFunction* PlaneIOUResidual::Create(const Vector4d& pl, const Vector3d& mn, const Vector3d& mr, const double angle, const double w) {
+  return MakeCost(PVLM_PLANE_IOU, 0, 1.0, {pl[0], pl[1], pl[2], pl[3], mn[0], mn[1], mn[2], mr[0], mr[1], mr[2], angle, w});
+}
+
+// ================================================================================================
+// util/Optimization.cpp adders
+// ================================================================================================
+size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
+                                    std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
+                                    double point_to_plane_dis_threshold, double plane_tolerance, bool angle_residual, bool normalized_distance,
+                                    double weight) {
+  // util/Optimization.cpp:513-517: one loss object shared by every block of this adder
+  ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
+  std::vector<pvlm_scan*> refs, neis;
+  std::vector<const Velodyne*> holders;
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;                 // :525-526
+    for (int n_idx : neighbors[i]) {
+      if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;  // :531-532
+      if (!lidars[n_idx].IsPoseValid()) continue;                                // :533-534
+      if (!lidars[i].IsInWorldCoordinate() || !lidars[n_idx].IsInWorldCoordinate()) continue;  // CheckLidarCoordinate -> empty result
+      refs.push_back(lidars[i].DeviceScan()); neis.push_back(lidars[n_idx].DeviceScan());
+    }
+  }
+  // parameter blocks are looked up by lidars[i].id (:527-528,:541-542); DeviceScan() carries that id
+  Engine& e = Engine::Default();
+  pvlm_resset* rs = nullptr;
+  e.Check(pvlm_assoc_point2plane(e.ctx(), (int)refs.size(), refs.data(), neis.data(), plane_tolerance, (float)point_to_plane_dis_threshold,
+                                 angle_residual ? PVLM_POINT2PLANE_ANGLE : PVLM_POINT2PLANE_METER,
+                                 normalized_distance ? PVLM_FLAG_NORMALIZE_DISTANCE : 0u, weight, &rs), "pvlm_assoc_point2plane");
+  int64_t n = 0;
+  pvlm_resset_info(rs, &n, nullptr, nullptr, nullptr);
+  if (n == 0) { pvlm_resset_destroy(e.ctx(), rs); delete loss; return 0; }
+  problem.AddResidualSet(rs, loss, &aa_list, &t_list);
+  return (size_t)n;
+}
+
+size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
+                                   std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
+                                   const std::vector<LineTrack>& tracks, double thr, bool angle_residual, bool normalized_distance, double weight) {
+  ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
+  bool loss_used = false;
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> lines_to_track;
+  for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) lines_to_track[pr].push_back(t.id);
+  size_t num = 0;
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    double* aa_r = aa_list[lidars[i].id].data(); double* t_r = t_list[lidars[i].id].data();
+    for (int n_idx : neighbors[i]) {
+      if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;
+      if (!lidars[n_idx].IsPoseValid() || !lidars[n_idx].valid) continue;
+      double* t_n = t_list[lidars[n_idx].id].data(); double* aa_n = aa_list[lidars[n_idx].id].data();
+      const std::vector<Line2Line> ass = AssociateLine2Line(lidars[i], lidars[n_idx], (float)thr);
+      for (const Line2Line& a : ass) {
+        auto it = lines_to_track.find({(uint32_t)i, (uint32_t)a.ref_line_idx});
+        if (it == lines_to_track.end()) continue;
+        bool valid = false;
+        for (uint32_t tid : it->second) if (tracks[tid].IsInside({(uint32_t)n_idx, (uint32_t)a.neighbor_line_idx})) { valid = true; break; }
+        if (!valid) continue;
+        for (const PointXYZI& p : lidars[n_idx].edge_segmented[a.neighbor_line_idx]) {
+          const Vector3d lp = lidars[n_idx].World2Local({(double)p.x, (double)p.y, (double)p.z});
+          if (angle_residual) {
+            // loss is nullptr for the angle variant (util/Optimization.cpp:417)
+            problem.AddResidualBlock(Point2Line_Angle::Create(lp, a.line_point1, a.line_point2, normalized_distance, weight), nullptr, aa_r, t_r, aa_n, t_n);
+          } else {
+            problem.AddResidualBlock(Point2Line_Meter::Create(lp, a.line_point1, a.line_point2, weight), loss, aa_r, t_r, aa_n, t_n);
+            loss_used = true;
+          }
+          num++;
+        }
+      }
+    }
+  }
+  if (!loss_used) delete loss;
+  return num;
+}
+
+ceres_like::Solver::Options SetOptionsLidar(const int num_threads, const int lidar_size) {
+  ceres_like::Solver::Options o;
+  o.minimizer_progress_to_stdout = false;
+  o.linear_solver_type = lidar_size <= 50 ? ceres_like::DENSE_SCHUR : (lidar_size <= 2000 ? ceres_like::SPARSE_SCHUR : ceres_like::ITERATIVE_SCHUR);
+  o.num_threads = num_threads;
+  o.max_num_iterations = 20;
+  o.max_linear_solver_iterations = 100;
+  return o;
+}
+
+// ================================================================================================
+// LidarOdometry — lidar_mapping/LidarOdometry.cpp:15-187
+// ================================================================================================
+bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
+  for (Velodyne& l : lidars) if (l.IsPoseValid() && !l.IsInWorldCoordinate()) l.Transform2LidarWorld();
+  std::vector<Vector3d> aa_list(lidars.size(), Vector3d{1, 1, 1}), t_list(lidars.size(), Vector3d{1, 1, 1});
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    const Matrix3d& R = lidars[i].GetRotation();
+    const Matrix3d R_lw = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+    RotationMatrixToAngleAxis(R_lw, &aa_list[i]);
+    const Vector3d rt = MatVec(R_lw, lidars[i].GetTranslation());
+    t_list[i] = {-rt[0], -rt[1], -rt[2]};
+  }
+  const std::vector<std::vector<int>> neighbors_all = FindNeighbors(lidars, 6);
+  ceres_like::Problem problem;
+  // (point_to_line_residual path: AssociatePoint2Line* variants are not on the Room/Floor path — SURVEY.md §3.2)
+  if (config.line_to_line_residual && use_segment) {
+    LidarLineMatch matcher(lidars);
+    matcher.SetNeighborSize(4);
+    matcher.SetMinTrackLength(3);
+    matcher.GenerateTracks();
+    AddLidarLineToLineResidual2(neighbors_all, lidars, aa_list, t_list, problem, matcher.GetTracks(), config.point_to_line_dis_threshold,
+                                config.angle_residual, config.normalize_distance);
+  }
+  if (config.point_to_plane_residual)
+    AddLidarPointToPlaneResidual(neighbors_all, lidars, aa_list, t_list, problem, config.point_to_plane_dis_threshold, config.lidar_plane_tolerance,
+                                 config.angle_residual, config.normalize_distance);
+  if (problem.NumResidualBlocks() == 0) { fprintf(stderr, "no residual\n"); return false; }
+  // gauge: first valid pose constant — only if it takes part in the problem (Ceres would abort otherwise)
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    problem.SetParameterBlockConstant(aa_list[i].data());
+    problem.SetParameterBlockConstant(t_list[i].data());
+    break;
+  }
+  ceres_like::Solver::Options options = SetOptionsLidar(config.num_threads, (int)lidars.size());
+  ceres_like::Solver::Summary summary;
+  ceres_like::Solve(options, &problem, &summary);
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].valid || !lidars[i].IsPoseValid()) continue;
+    lidars[i].Transform2Local();
+    Matrix3d R_lw;
+    AngleAxisToRotationMatrix(aa_list[i], &R_lw);
+    const Matrix3d R_wl = {R_lw[0], R_lw[3], R_lw[6], R_lw[1], R_lw[4], R_lw[7], R_lw[2], R_lw[5], R_lw[8]};
+    const Vector3d rt = MatVec(R_wl, t_list[i]);
+    lidars[i].SetRotation(R_wl);
+    lidars[i].SetTranslation({-rt[0], -rt[1], -rt[2]});
+  }
+  cost = summary.final_cost;
+  steps = summary.num_successful_steps;
+  log.push_back({cost, steps, problem.NumResidualBlocks()});
+  return summary.IsSolutionUsable();
+}
+
+bool LidarOdometry::EstimatePose(const int max_iteration) {
+  for (Velodyne& l : lidars) {
+    if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); continue; }
+    l.Transform2LidarWorld();
+  }
+  bool segmented = false;
+  for (Velodyne& l : lidars) { segmented = !l.edge_segmented.empty(); if (segmented) break; }
+  double curr_cost = 0, last_cost = 0;
+  int curr_step = INT16_MAX, last_step = INT16_MAX;
+  for (int iter = 0; iter < max_iteration; iter++) {
+    RefinePose(curr_cost, curr_step, segmented);
+    if (std::fabs(curr_cost - last_cost) / last_cost < 0.01) break;   // LidarOdometry.cpp:171-175
+    if (curr_step < 5 && last_step < 5) break;                        // :176-180
+    last_cost = curr_cost;
+    last_step = curr_step;
+  }
+  return true;
+}
+
+std::vector<Matrix3d> LidarOdometry::GetGlobalRotation() const { std::vector<Matrix3d> r; for (const Velodyne& l : lidars) r.push_back(l.GetRotation()); return r; }
+std::vector<Vector3d> LidarOdometry::GetGlobalTranslation() const { std::vector<Vector3d> t; for (const Velodyne& l : lidars) t.push_back(l.GetTranslation()); return t; }
+
+
+// ================================================================================================
+// Equirectangular (host, scalar) — sensors/Equirectangular.h:42-182, .cpp:20-65, base/Math.h:15-29
+// ================================================================================================
+namespace {
+template <typename T>
+inline T FastAtan2(const T& y, const T& x) {
+  T ax = std::abs(x), ay = std::abs(y);
+  T a = std::min(ax, ay) / (std::max(ax, ay) + (T)DBL_EPSILON);
+  T s = a * a;
+  T r = ((-0.04432655554792128 * s + 0.1555786518463281) * s - 0.3258083974640975) * s * a + 0.9997878412794807 * a;
+  if (ay > ax) r = M_PI_2 - r;
+  if (x < 0) r = M_PI - r;
+  if (y < 0) r = -r;
+  return r;
+}
+struct Equirect {
+  int cols, rows;
+  template <typename T> void ImageToCam(const T* px, T r, T* cam) const {
+    T sx = (2 * px[0] / cols - 1) * M_PI;
+    T sy = (0.5 - px[1] / rows) * M_PI;
+    T cy = (T)std::cos((double)sy);
+    cam[0] = r * cy * (T)std::sin((double)sx);
+    cam[1] = -r * (T)std::sin((double)sy);
+    cam[2] = r * cy * (T)std::cos((double)sx);
+  }
+  template <typename T> void CamToImage(const T* cam, T* px) const {
+    T lon = FastAtan2(cam[0], cam[2]);
+    T lat = -FastAtan2(cam[1], (T)std::sqrt(cam[0] * cam[0] + cam[2] * cam[2]));
+    px[0] = cols * (0.5 + lon / (2.0 * M_PI));
+    px[1] = rows * (0.5 - lat / M_PI);
+  }
+  std::vector<float> BreakToSegments(const float* start, const float* end, float seg_length) const {
+    float p1[3], p2[3];
+    ImageToCam(start, 5.0f, p1);
+    ImageToCam(end, 5.0f, p2);
+    const float sl[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    const float length = std::sqrt((start[0] - end[0]) * (start[0] - end[0]) + (start[1] - end[1]) * (start[1] - end[1]));
+    const int count = length / seg_length + 1;
+    std::vector<float> seg = {start[0], start[1]};
+    for (int i = 1; i < count; i++) {
+      const float f = i * 1.f / count;
+      const float p[3] = {p1[0] + f * sl[0], p1[1] + f * sl[1], p1[2] + f * sl[2]};
+      float pixel[2];
+      CamToImage(p, pixel);
+      const float lastx = seg[seg.size() - 2];
+      if (std::abs(pixel[0] - lastx) > 0.8 * cols) {
+        const float gq = p1[0] / (p1[0] - p2[0]);
+        const float q[3] = {p1[0] + gq * sl[0], p1[1] + gq * sl[1], p1[2] + gq * sl[2]};
+        float left[2];
+        CamToImage(q, left);
+        left[0] = 0;
+        const float right[2] = {float(cols - 1), left[1]};
+        if (pixel[0] > lastx) { seg.insert(seg.end(), {left[0], left[1], right[0], right[1]}); }
+        else { seg.insert(seg.end(), {right[0], right[1], left[0], left[1]}); }
+      }
+      seg.push_back(pixel[0]); seg.push_back(pixel[1]);
+    }
+    seg.push_back(end[0]); seg.push_back(end[1]);
+    return seg;
+  }
+};
+inline double VectorAngle3D(const double* a, const double* b) {
+  double c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  c = c / (std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]));
+  if (c >= 1.0) return 0.0;
+  if (c <= -1.0) return M_PI;
+  return std::acos(c);
+}
+inline void ProjectPointToPlane(const double* p, const double* pl, double* o) {  // normalized = true
+  const double dis = std::fabs(pl[0] * p[0] + pl[1] * p[1] + pl[2] * p[2] + pl[3]);
+  o[0] = p[0] - dis * pl[0]; o[1] = p[1] - dis * pl[1]; o[2] = p[2] - dis * pl[2];
+  if (std::fabs(pl[0] * o[0] + pl[1] * o[1] + pl[2] * o[2] + pl[3]) > 1e-4) { o[0] = p[0] + dis * pl[0]; o[1] = p[1] + dis * pl[1]; o[2] = p[2] + dis * pl[2]; }
+}
+inline void FormPlane0(const double* p1, const double* p2, double* out) {  // FormPlane(p1, p2, 0).normalize() as a 4-vector
+  const double p3[3] = {0, 0, 0};
+  double a = ((p2[1] - p1[1]) * (p3[2] - p1[2]) - (p2[2] - p1[2]) * (p3[1] - p1[1]));
+  double b = ((p2[2] - p1[2]) * (p3[0] - p1[0]) - (p2[0] - p1[0]) * (p3[2] - p1[2]));
+  double c = ((p2[0] - p1[0]) * (p3[1] - p1[1]) - (p2[1] - p1[1]) * (p3[0] - p1[0]));
+  double d = -(a * p1[0] + b * p1[1] + c * p1[2]);
+  const double n = std::sqrt(a * a + b * b + c * c + d * d);
+  if (n * n > 0.0) { a /= n; b /= n; c /= n; d /= n; }
+  out[0] = a; out[1] = b; out[2] = c; out[3] = d;
+}
+inline Vector3d Transform4(const Matrix4d& T, const Vector3d& p) {  // (T * p.homogeneous()).hnormalized()
+  double h[4];
+  for (int i = 0; i < 4; ++i) h[i] = ((T[4 * i] * p[0] + T[4 * i + 1] * p[1]) + T[4 * i + 2] * p[2]) + T[4 * i + 3] * 1.0;
+  return {h[0] / h[3], h[1] / h[3], h[2] / h[3]};
+}
+inline Matrix4d Inverse4(const Matrix4d& A) {
+  double m[4][8];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { m[i][j] = A[i * 4 + j]; m[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r) if (std::fabs(m[r][c]) > std::fabs(m[piv][c])) piv = r;
+    if (piv != c) for (int j = 0; j < 8; ++j) std::swap(m[c][j], m[piv][j]);
+    const double d = m[c][c];
+    for (int j = 0; j < 8; ++j) m[c][j] /= d;
+    for (int r = 0; r < 4; ++r) if (r != c) { const double f = m[r][c]; for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j]; }
+  }
+  Matrix4d o;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) o[i * 4 + j] = m[i][4 + j];
+  return o;
+}
+}  // namespace
+
+// ================================================================================================
+// CameraLidarLineAssociate — joint_optimization/CameraLidarLineAssociate.cpp:340-475, :628-715, :754-876
+// ================================================================================================
+void CameraLidarLineAssociate::AssociateByAngle(const std::vector<std::array<float, 4>>& lines, const Velodyne& lidar, const Matrix4d& T_cl,
+                                                const bool multiple_association, const std::vector<bool>& image_line_mask,
+                                                const std::vector<bool>& lidar_line_mask) {
+  const size_t n_seg = lidar.edge_segmented.size();
+  std::vector<bool> image_mask = image_line_mask.empty() ? std::vector<bool>(lines.size(), true) : image_line_mask;
+  std::vector<bool> lidar_mask = lidar_line_mask.empty() ? std::vector<bool>(n_seg, true) : lidar_line_mask;
+  line_pairs.clear();
+  std::vector<Vector3d> ends_cam;
+  std::vector<Vector4d> lidar_plane;
+  for (size_t i = 0; i < n_seg; i++) {
+    const Vector3d p1 = Transform4(T_cl, lidar.end_points[2 * i]), p2 = Transform4(T_cl, lidar.end_points[2 * i + 1]);
+    ends_cam.push_back(p1); ends_cam.push_back(p2);
+    Vector4d pl; FormPlane0(p1.data(), p2.data(), pl.data());
+    lidar_plane.push_back(pl);
+  }
+  // hot loop #3 (:394-426) on the GPU: votes[line][segment]
+  std::vector<int> votes(lines.size() * std::max<size_t>(n_seg, 1), 0);
+  Engine& e = Engine::Default();
+  if (!lines.empty() && n_seg > 0)
+    e.Check(pvlm_cam_lidar_votes(e.ctx(), rows, cols, &lines[0][0], (int)lines.size(), lidar.DeviceScan(), T_cl.data(), votes.data()), "pvlm_cam_lidar_votes");
+  const double angle_threshold = 3.0 / 180.0 * M_PI;
+  Equirect eq{cols, rows};
+  for (size_t li = 0; li < lines.size(); li++) {
+    if (!image_mask[li]) continue;
+    const std::array<float, 4>& l = lines[li];
+    const double a[2] = {l[0], l[1]}, b[2] = {l[2], l[3]};
+    double p1[3], p2[3], ip[4];
+    eq.ImageToCam(a, 1.0, p1); eq.ImageToCam(b, 1.0, p2);
+    FormPlane0(p1, p2, ip);
+    const double p4[3] = {(p1[0] + p2[0]) / 2.0, (p1[1] + p2[1]) / 2.0, (p1[2] + p2[2]) / 2.0};
+    const double scope = VectorAngle3D(p1, p4);
+    for (size_t s = 0; s < n_seg; ++s) {   // std::map iteration order = ascending segment id
+      const size_t cnt = (size_t)votes[li * n_seg + s];
+      if (cnt == 0) continue;
+      if (cnt < lidar.edge_segmented[s].size() / 2) continue;
+      if (!lidar_mask[s]) continue;
+      const double angle = PlaneAngleN(ip, lidar_plane[s].data());
+      if (angle > angle_threshold) continue;
+      const double mid[3] = {(ends_cam[2 * s][0] + ends_cam[2 * s + 1][0]) / 2.0, (ends_cam[2 * s][1] + ends_cam[2 * s + 1][1]) / 2.0,
+                             (ends_cam[2 * s][2] + ends_cam[2 * s + 1][2]) / 2.0};
+      double midp[3];
+      ProjectPointToPlane(mid, ip, midp);
+      if (VectorAngle3D(midp, p4) > scope) continue;
+      const float angle2 = (float)VectorAngle3D(mid, midp);
+      if (angle2 > angle_threshold / 2.0) continue;
+      CameraLidarLinePair lp;
+      lp.image_line = l; lp.lidar_line_start = ends_cam[2 * s]; lp.lidar_line_end = ends_cam[2 * s + 1];
+      lp.image_line_id = (int)li; lp.lidar_line_id = (int)s; lp.angle = (float)(angle + angle2);
+      line_pairs.push_back(lp);
+    }
+  }
+  Filter(false, true);
+  if (!multiple_association) UniqueLinePair(lines, ends_cam);
+  const Matrix4d T_lc = Inverse4(T_cl);
+  for (CameraLidarLinePair& lp : line_pairs) { lp.lidar_line_start = Transform4(T_lc, lp.lidar_line_start); lp.lidar_line_end = Transform4(T_lc, lp.lidar_line_end); }
+}
+
+void CameraLidarLineAssociate::Filter(bool filter_by_angle, bool filter_by_length) {
+  (void)filter_by_angle;  // AssociateByAngle calls Filter(false, true) only
+  const float min_len = 100, max_len = 2000;
+  std::vector<CameraLidarLinePair> good;
+  Equirect eq{cols, rows};
+  for (const CameraLidarLinePair& p : line_pairs) {
+    if (filter_by_length) {
+      const float a[3] = {(float)p.lidar_line_start[0], (float)p.lidar_line_start[1], (float)p.lidar_line_start[2]};
+      const float b[3] = {(float)p.lidar_line_end[0], (float)p.lidar_line_end[1], (float)p.lidar_line_end[2]};
+      float pa[2], pb[2];
+      eq.CamToImage(a, pa); eq.CamToImage(b, pb);
+      const std::vector<float> seg = eq.BreakToSegments(pa, pb, 100);
+      float len = 0;
+      const size_t n = seg.size() / 2;
+      for (size_t i = 0; i + 1 < n; i++) {
+        if (std::abs(seg[2 * i] - seg[2 * (i + 1)]) > 0.8 * cols) continue;
+        const float dx = seg[2 * i] - seg[2 * (i + 1)], dy = seg[2 * i + 1] - seg[2 * (i + 1) + 1];
+        len += std::sqrt(dx * dx + dy * dy);
+      }
+      if (len < min_len || len > max_len) continue;
+    }
+    good.push_back(p);
+  }
+  line_pairs.swap(good);
+}
+
+void CameraLidarLineAssociate::UniqueLinePair(const std::vector<std::array<float, 4>>& lines, const std::vector<Vector3d>& ends) {
+  struct PairScore { int idx; float score; };
+  std::map<int, PairScore> i2l, l2i;
+  for (const CameraLidarLinePair& pr : line_pairs) {
+    const int il = pr.image_line_id, ll = pr.lidar_line_id;
+    const float score = pr.angle;
+    auto a = i2l.find(il); auto b = l2i.find(ll);
+    const bool ha = a != i2l.end(), hb = b != l2i.end();
+    if (!ha && !hb) { i2l.insert({il, {ll, score}}); l2i.insert({ll, {il, score}}); }
+    else if (ha && !hb) { if (score < a->second.score) { l2i.erase(l2i.find(a->second.idx)); a->second = {ll, score}; l2i.insert({ll, {il, score}}); } }
+    else if (!ha && hb) { if (score < b->second.score) { i2l.erase(i2l.find(b->second.idx)); b->second = {il, score}; i2l.insert({il, {ll, score}}); } }
+    else {
+      const float sa = a->second.score, sb = b->second.score;
+      if (score < std::min(sa, sb)) {
+        i2l.erase(b->second.idx); l2i.erase(a->second.idx); i2l.erase(a); l2i.erase(b);
+        i2l.insert({il, {ll, score}}); l2i.insert({ll, {il, score}});
+      } else if (score > sa && score < sb) { i2l.erase(i2l.find(b->second.idx)); l2i.erase(b); }
+      else if (score < sa && score > sb) { l2i.erase(l2i.find(a->second.idx)); i2l.erase(a); }
+    }
+  }
+  line_pairs.clear();
+  for (auto& kv : i2l) {
+    CameraLidarLinePair lp;
+    lp.image_line = lines[kv.first]; lp.lidar_line_start = ends[2 * kv.second.idx]; lp.lidar_line_end = ends[2 * kv.second.idx + 1];
+    lp.image_line_id = kv.first; lp.lidar_line_id = kv.second.idx; lp.angle = kv.second.score;
+    line_pairs.push_back(lp);
+  }
+}
+
+}  // namespace pvlm

@@ -1,0 +1,148 @@
+// Test driver for the C++ host mirror (panovlm_amd/host): reads scans from a small binary file
+// written by tests/host_io.py, runs one entry point of the mirrored PanoVLM interface and prints
+// the result as text for pytest to compare with the CPU oracle.
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "../../panovlm_amd/host/pvlm_host.hpp"
+
+using namespace pvlm;
+
+template <typename T> static void rd(std::ifstream& f, T* p, size_t n) { f.read(reinterpret_cast<char*>(p), sizeof(T) * n); }
+
+static std::vector<Velodyne> LoadScans(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+  int32_t n = 0;
+  rd(f, &n, 1);
+  std::vector<Velodyne> out(n);
+  for (int s = 0; s < n; ++s) {
+    Velodyne& v = out[s];
+    int32_t hdr[3];
+    rd(f, hdr, 3);  // id, valid, world
+    v.id = hdr[0]; v.valid = hdr[1] != 0;
+    double R[9], t[3];
+    rd(f, R, 9); rd(f, t, 3);
+    Matrix3d Rm; Vector3d tm;
+    std::memcpy(Rm.data(), R, 72); std::memcpy(tm.data(), t, 24);
+    auto cloud = [&](PointCloud& c) {
+      int32_t m = 0; rd(f, &m, 1);
+      std::vector<float> b((size_t)m * 4);
+      rd(f, b.data(), b.size());
+      c.resize(m);
+      for (int i = 0; i < m; ++i) c[i] = {b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]};
+    };
+    cloud(v.surfFlat); cloud(v.surfLessFlat); cloud(v.cornerLessSharp);
+    int32_t nseg = 0; rd(f, &nseg, 1);
+    v.edge_segmented.resize(nseg); v.segment_coeffs.resize(nseg); v.end_points.resize(2 * (size_t)nseg);
+    for (int k = 0; k < nseg; ++k) {
+      cloud(v.edge_segmented[k]);
+      rd(f, v.segment_coeffs[k].data(), 6);
+      rd(f, v.end_points[2 * k].data(), 3); rd(f, v.end_points[2 * k + 1].data(), 3);
+    }
+    v.point_to_segment.resize(v.cornerLessSharp.size());
+    for (size_t i = 0; i < v.cornerLessSharp.size(); ++i) {
+      int32_t m = 0; rd(f, &m, 1);
+      for (int k = 0; k < m; ++k) { int32_t id; rd(f, &id, 1); v.point_to_segment[i].insert(id); }
+    }
+    v.SetPose(Rm, tm);
+    // clouds in the file are LOCAL; world flag asks for the transform
+    if (hdr[2]) v.Transform2LidarWorld();
+  }
+  return out;
+}
+
+static void PrintPoses(const std::vector<Velodyne>& l) {
+  for (const Velodyne& v : l) {
+    printf("pose %d", v.id);
+    for (double x : v.GetRotation()) printf(" %.17g", x);
+    for (double x : v.GetTranslation()) printf(" %.17g", x);
+    printf("\n");
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s <command> ...\n", argv[0]); return 2; }
+  const std::string cmd = argv[1];
+  try {
+    if (cmd == "neighbors") {
+      auto l = LoadScans(argv[2]);
+      auto nb = FindNeighbors(l, atoi(argv[3]));
+      for (size_t i = 0; i < nb.size(); ++i) { printf("nb %zu", i); for (int v : nb[i]) printf(" %d", v); printf("\n"); }
+    } else if (cmd == "p2plane") {
+      auto l = LoadScans(argv[2]);
+      auto a = AssociatePoint2Plane(l[atoi(argv[3])], l[atoi(argv[4])], atof(argv[5]), (float)atof(argv[6]));
+      for (auto& x : a) printf("a %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", x.point[0], x.point[1], x.point[2], x.plane_coeff[0], x.plane_coeff[1], x.plane_coeff[2], x.plane_coeff[3]);
+    } else if (cmd == "line2line") {
+      auto l = LoadScans(argv[2]);
+      auto a = AssociateLine2Line(l[atoi(argv[3])], l[atoi(argv[4])], (float)atof(argv[5]));
+      for (auto& x : a) printf("l %d %d %.17g %.17g %.17g %.17g %.17g %.17g\n", x.neighbor_line_idx, x.ref_line_idx, x.line_point1[0], x.line_point1[1], x.line_point1[2], x.line_point2[0], x.line_point2[1], x.line_point2[2]);
+    } else if (cmd == "tracks") {
+      auto l = LoadScans(argv[2]);
+      LidarLineMatch m(l);
+      m.SetNeighborSize(atoi(argv[3])); m.SetMinTrackLength(atoi(argv[4]));
+      m.GenerateTracks();
+      for (auto& t : m.GetTracks()) { printf("track %u", t.id); for (auto& p : t.feature_pairs) printf(" %u:%u", p.first, p.second); printf("\n"); }
+    } else if (cmd == "costfn") {
+      // costfn kind normalize weight row... | aa_r t_r aa_n t_n (12 numbers at the end)
+      const int kind = atoi(argv[2]); const bool norm = atoi(argv[3]) != 0; const double w = atof(argv[4]);
+      std::vector<double> v;
+      for (int i = 5; i < argc; ++i) v.push_back(atof(argv[i]));
+      const size_t nr = v.size() - 12;
+      ceres_like::CostFunction* c = nullptr;
+      auto V3 = [&](size_t o) { return Vector3d{v[o], v[o + 1], v[o + 2]}; };
+      if (kind == 0) c = Point2Plane_Meter::Create(V3(0), {v[3], v[4], v[5], v[6]}, w);
+      else if (kind == 1) c = Point2Plane_Angle::Create(V3(0), {v[3], v[4], v[5], v[6]}, norm, w);
+      else if (kind == 2) c = Point2Line_Meter::Create(V3(0), V3(3), V3(6), w);
+      else if (kind == 3) c = Point2Line_Angle::Create(V3(0), V3(3), V3(6), norm, w);
+      else if (kind == 4) c = Plane2Plane_Global::Create(V3(0), V3(3), V3(6), v[9]);
+      else c = PlaneIOUResidual::Create({v[0], v[1], v[2], v[3]}, V3(4), V3(7), v[10], v[11]);
+      const double* params[4] = {&v[nr], &v[nr + 3], &v[nr + 6], &v[nr + 9]};
+      double r, J0[3], J1[3], J2[3], J3[3];
+      double* J[4] = {J0, J1, nullptr, J3};  // one null block, like a constant parameter block
+      const bool ok = c->Evaluate(params, &r, J);
+      printf("ok %d r %.17g J", ok ? 1 : 0, r);
+      for (double* b : {J0, J1, J3}) for (int k = 0; k < 3; ++k) printf(" %.17g", b[k]);
+      printf("\n");
+      double r2;
+      c->Evaluate(params, &r2, nullptr);
+      printf("costonly %.17g\n", r2);
+      delete c;
+    } else if (cmd == "odometry") {
+      auto l = LoadScans(argv[2]);
+      Config cfg;
+      const int iters = atoi(argv[3]);
+      cfg.angle_residual = atoi(argv[4]) != 0; cfg.normalize_distance = atoi(argv[5]) != 0;
+      cfg.line_to_line_residual = atoi(argv[6]) != 0; cfg.point_to_plane_residual = atoi(argv[7]) != 0;
+      cfg.lidar_plane_tolerance = atof(argv[8]); cfg.point_to_plane_dis_threshold = atof(argv[9]); cfg.point_to_line_dis_threshold = atof(argv[10]);
+      LidarOdometry odo(l, cfg);
+      odo.EstimatePose(iters);
+      for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
+      PrintPoses(odo.GetLidarData());
+    } else if (cmd == "byangle") {
+      auto l = LoadScans(argv[2]);  // one LOCAL-frame scan
+      std::ifstream f(argv[3], std::ios::binary);
+      int32_t nl = 0; rd(f, &nl, 1);
+      std::vector<std::array<float, 4>> lines(nl);
+      for (auto& x : lines) rd(f, x.data(), 4);
+      Matrix4d T; rd(f, T.data(), 16);
+      CameraLidarLineAssociate a(atoi(argv[4]), atoi(argv[5]));
+      a.AssociateByAngle(lines, l[0], T, atoi(argv[6]) != 0);
+      for (auto& p : a.GetAssociatedPairs())
+        printf("pair %d %d %.9g %.17g %.17g %.17g %.17g %.17g %.17g\n", p.image_line_id, p.lidar_line_id, p.angle, p.lidar_line_start[0], p.lidar_line_start[1],
+               p.lidar_line_start[2], p.lidar_line_end[0], p.lidar_line_end[1], p.lidar_line_end[2]);
+    } else {
+      fprintf(stderr, "unknown command %s\n", cmd.c_str());
+      return 2;
+    }
+  } catch (const std::exception& e) {
+    fprintf(stderr, "error: %s\n", e.what());
+    return 3;
+  }
+  return 0;
+}

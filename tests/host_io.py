@@ -1,0 +1,54 @@
+"""Binary scan files for the C++ host-mirror test driver (tests/cpp/pvlm_host_driver.cpp)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def driver():
+    from panovlm_amd import build
+    build.build_host()
+    return build.HOST_DRIVER
+
+
+def _cloud(f, xyz, tag=None):
+    xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+    tag = np.ones(len(xyz), np.float32) if tag is None else np.asarray(tag, np.float32)
+    f.write(struct.pack("<i", len(xyz)))
+    f.write(np.concatenate([xyz, tag[:, None]], axis=1).astype(np.float32).tobytes())
+
+
+def write_scans(path, scans, world=True):
+    """scans: list of dicts with LOCAL-frame clouds: id, valid, R_wl, t_wl, flat_local(+flat_tag), less_local(+less_tag),
+    corner_local, p2s, seg_points (list of index arrays into corner_local), seg_coeffs, end_points."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(scans)))
+        for s in scans:
+            f.write(struct.pack("<iii", int(s.get("id", 0)), int(s.get("valid", 1)), 1 if world else 0))
+            f.write(np.asarray(s["R_wl"], np.float64).reshape(9).tobytes())
+            f.write(np.asarray(s["t_wl"], np.float64).reshape(3).tobytes())
+            _cloud(f, s.get("flat_local", np.zeros((0, 3))), s.get("flat_tag"))
+            _cloud(f, s.get("less_local", np.zeros((0, 3))), s.get("less_tag"))
+            corner = np.asarray(s.get("corner_local", np.zeros((0, 3))), np.float32).reshape(-1, 3)
+            _cloud(f, corner)
+            segs = s.get("seg_points", [])
+            f.write(struct.pack("<i", len(segs)))
+            for k, idx in enumerate(segs):
+                _cloud(f, corner[np.asarray(idx, int)])
+                f.write(np.asarray(s["seg_coeffs"][k], np.float64).tobytes())
+                f.write(np.asarray(s["end_points"][k], np.float64).tobytes())
+            p2s = s.get("p2s", [[] for _ in range(len(corner))])
+            for l in p2s:
+                f.write(struct.pack("<i", len(l)))
+                for v in sorted(l):
+                    f.write(struct.pack("<i", int(v)))
+
+
+def run(*args, timeout=600):
+    out = subprocess.run([driver()] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    if out.returncode != 0:
+        raise RuntimeError("driver failed (%d): %s" % (out.returncode, out.stderr[-2000:]))
+    return out.stdout.splitlines()

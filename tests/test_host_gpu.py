@@ -1,0 +1,165 @@
+"""The C++ host mirror (panovlm_amd/host, PanoVLM's own interface names) on the GPU against the CPU
+oracle: single cost functions, AssociatePoint2Plane / AssociateLine2Line, line tracks, FindNeighbors and
+the end-to-end LidarOdometry::EstimatePose loop against its CPU twin (tests/lm_twin.py)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from panovlm_amd import synthetic as sy
+from tests import host_io, lm_twin, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _vlp(k, cols):
+    s = sy.make_scan(k, cols=cols, downsample_targets=0.2)
+    R, t = s["R_wl"], s["t_wl"]
+    local = s["local_xyz"]
+    Rl, tl = lm_twin.inv_pose(R, t)
+    less_local = lm_twin.transform_f32(s["less_xyz"], Rl, tl)   # centroids back to the local frame
+    return dict(id=k, R_wl=R, t_wl=t, flat_local=local, flat_tag=np.ones(len(local), np.float32), less_local=less_local,
+                less_tag=np.ones(len(less_local), np.float32))
+
+
+@pytest.fixture(scope="module")
+def tmp():
+    with tempfile.TemporaryDirectory() as d:
+        yield d
+
+
+def test_single_cost_function_api(oracle):
+    rng = np.random.default_rng(3)
+    for kind, norm in [(0, 0), (1, 1), (2, 0), (3, 1), (4, 0), (5, 0)]:
+        aa, t = synth.random_poses(rng, 2)
+        rows, off = synth.random_resset(rng, kind, aa, t, np.array([0]), np.array([1]), [1], offsets_scale=(0.05,))
+        w = 1.25
+        params = np.concatenate([aa[0], t[0], aa[1], t[1]])
+        out = host_io.run("costfn", kind, norm, w, *["%.17g" % v for v in rows[0]], *["%.17g" % v for v in params])
+        vals = out[0].split()
+        ok, r = int(vals[1]), float(vals[3])
+        J = np.array([float(v) for v in vals[5:14]])
+        ro, Jo = oracle.evaluate(kind, synth.oracle_rows(kind, rows, w), [0], [1], aa, t, normalize=bool(norm))
+        assert ok == 1 and abs(r - ro[0]) <= 1e-6 * abs(ro[0]) + 1e-12
+        Jexp = np.concatenate([Jo[0, 0:3], Jo[0, 3:6], Jo[0, 9:12]])   # block 2 was passed as null
+        assert np.allclose(J, Jexp, rtol=1e-6, atol=1e-9)
+        assert abs(float(out[1].split()[1]) - r) == 0.0
+
+
+def test_find_neighbors_and_point2plane(oracle, tmp):
+    scans = [_vlp(k, 256) for k in range(5)]
+    path = os.path.join(tmp, "scans.bin")
+    host_io.write_scans(path, scans)
+    nb = [[int(v) for v in l.split()[2:]] for l in host_io.run("neighbors", path, 6)]
+    poses = np.array([np.concatenate([s["R_wl"].reshape(-1), s["t_wl"]]) for s in scans])
+    assert nb == oracle.find_neighbors(poses, np.ones(5, np.int32), 6)
+    world = [dict(id=s["id"], R_wl=s["R_wl"], t_wl=s["t_wl"], flat_xyz=lm_twin.transform_f32(s["flat_local"], s["R_wl"], s["t_wl"]), flat_tag=s["flat_tag"],
+                  less_xyz=lm_twin.transform_f32(s["less_local"], s["R_wl"], s["t_wl"]), less_tag=s["less_tag"]) for s in scans]
+    for r, n in [(0, 1), (3, 2)]:
+        got = np.array([[float(v) for v in l.split()[1:]] for l in host_io.run("p2plane", path, r, n, 0.05, 1.0)])
+        o = oracle.assoc_point2plane(world[r], world[n], 0.05, 1.0)
+        assert got.shape[0] == len(o["qidx"]) > 100
+        assert np.array_equal(got[:, :3], o["point"]) and np.array_equal(got[:, 3:], o["plane"])
+
+
+def _line_scans(rng, n):
+    lines = synth.random_world_lines(rng, 10)
+    out = []
+    for k in range(n):
+        R, t = sy.estimated_pose(k + 2)
+        s = synth.make_line_scan(rng, k, R, t, lines, pts_per_line=(10, 24), extra_pts=12, noise=0.005)
+        seg_points = [[i for i, l in enumerate(s["p2s"]) if sid in l] for sid in range(len(s["seg_size"]))]
+        out.append(dict(id=k, R_wl=R, t_wl=t, corner_local=s["corner_local"], p2s=s["p2s"], seg_points=seg_points,
+                        seg_coeffs=s["seg_coeffs"], end_points=s["end_points"], _oracle=s))
+    return out
+
+
+def test_line2line_and_tracks(oracle, tmp):
+    rng = np.random.default_rng(17)
+    scans = _line_scans(rng, 5)
+    path = os.path.join(tmp, "lines.bin")
+    host_io.write_scans(path, scans)
+    for r, n, thr in [(0, 1, 0.3), (2, 1, 0.3), (1, 3, 0.4)]:
+        got = [l.split()[1:] for l in host_io.run("line2line", path, r, n, thr)]
+        o = oracle.assoc_line2line(scans[r]["_oracle"], scans[n]["_oracle"], thr)
+        assert [int(g[0]) for g in got] == o["nei_idx"].tolist() and [int(g[1]) for g in got] == o["ref_idx"].tolist()
+        assert np.allclose(np.array([[float(v) for v in g[2:5]] for g in got]), o["p1"], atol=1e-13)
+        assert len(got) >= 5
+    # tracks: union-find over the pairwise associations (util/Tracks.cpp) -> python reimplementation here
+    tracks = [set(tuple(int(x) for x in p.split(":")) for p in l.split()[2:]) for l in host_io.run("tracks", path, 4, 3)]
+    poses = np.array([np.concatenate([s["R_wl"].reshape(-1), s["t_wl"]]) for s in scans])
+    nb = oracle.find_neighbors(poses, np.ones(5, np.int32), 4)
+    parent = {}
+
+    def find(a):
+        while parent.setdefault(a, a) != a:
+            parent[a] = parent[parent[a]]; a = parent[a]
+        return a
+    for i in range(5):
+        for j in nb[i]:
+            o = oracle.assoc_line2line(scans[j]["_oracle"], scans[i]["_oracle"], 0.3)
+            for a, b in zip(o["nei_idx"], o["ref_idx"]):
+                ra, rb = find((i, int(a))), find((j, int(b)))
+                if ra != rb:
+                    parent[ra] = rb
+    comps = {}
+    for node in list(parent):
+        comps.setdefault(find(node), set()).add(node)
+    expect = [c for c in comps.values() if len({n[0] for n in c}) >= 3 and len(c) > 1]
+    assert sorted(map(sorted, tracks)) == sorted(map(sorted, expect)) and len(tracks) >= 5
+
+
+def test_camera_lidar_by_angle(oracle, tmp):
+    rng = np.random.default_rng(8)
+    rows, cols = 2880, 5760
+    lw = synth.random_world_lines(rng, 9, extent=3.0)
+    s = synth.make_line_scan(rng, 0, np.eye(3), np.zeros(3), lw, pts_per_line=(20, 50), extra_pts=40)
+    seg_points = [[i for i, l in enumerate(s["p2s"]) if sid in l] for sid in range(len(s["seg_size"]))]
+    scan = dict(id=0, R_wl=np.eye(3), t_wl=np.zeros(3), corner_local=s["corner_local"], p2s=s["p2s"], seg_points=seg_points,
+                seg_coeffs=s["seg_coeffs"], end_points=s["end_points"])
+    path = os.path.join(tmp, "cam.bin")
+    host_io.write_scans(path, [scan], world=False)
+    ang = np.deg2rad(rng.uniform(-2, 2, size=3))
+    T = np.eye(4); T[:3, :3] = synth.rodrigues(ang); T[:3, 3] = rng.uniform(-0.05, 0.05, size=3)
+    ends_cam = s["end_points"].reshape(-1, 3) @ T[:3, :3].T + T[:3, 3]
+    px = oracle.cam_to_image(rows, cols, ends_cam).reshape(-1, 4).astype(np.float32)
+    px += rng.normal(size=px.shape).astype(np.float32) * 2.0
+    lines = np.concatenate([px, px[:3] + np.float32(6.0)])   # near-duplicates exercise UniqueLinePair
+    lpath = os.path.join(tmp, "lines_T.bin")
+    with open(lpath, "wb") as f:
+        f.write(np.int32(len(lines)).tobytes()); f.write(lines.astype(np.float32).tobytes()); f.write(T.astype(np.float64).tobytes())
+    local = dict(s); local["corner_xyz"] = s["corner_local"]
+    for mult in (1, 0):
+        got = [l.split()[1:] for l in host_io.run("byangle", path, lpath, rows, cols, mult)]
+        o = oracle.assoc_by_angle(rows, cols, lines, local, T, multiple=bool(mult))
+        assert [int(g[0]) for g in got] == o["image_line_id"].tolist() and [int(g[1]) for g in got] == o["lidar_line_id"].tolist()
+        assert np.allclose([float(g[2]) for g in got], o["score"], rtol=1e-6)
+        assert np.allclose(np.array([[float(v) for v in g[3:6]] for g in got]), o["start"], atol=1e-12)
+    assert len(got) >= 5
+
+
+def test_estimate_pose_matches_cpu_twin(oracle, tmp):
+    """LidarOdometry::EstimatePose (GPU association + GPU normal equations + host LM) vs the same loop on the
+    oracle: residual-block counts equal, costs and final poses within 1e-6 relative (north_star)."""
+    scans = [_vlp(k, 256) for k in range(4)]
+    path = os.path.join(tmp, "odo.bin")
+    host_io.write_scans(path, scans, world=False)
+    out = host_io.run("odometry", path, 3, 1, 1, 0, 1, 0.05, 1.0, 0.3)
+    iters = [l.split() for l in out if l.startswith("iter")]
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    cfg = dict(angle=True, normalize=True, tol=0.05, thr=1.0)
+    twin = [dict(s) for s in scans]
+    log = lm_twin.estimate_pose(oracle, twin, cfg, 3)
+    assert len(iters) == len(log)
+    for it, lg in zip(iters, log):
+        assert int(it[6]) == lg["blocks"]
+        assert abs(float(it[2]) - lg["final_cost"]) <= 1e-6 * lg["final_cost"]
+        assert int(it[4]) == lg["successful"]
+    for k, s in enumerate(twin):
+        R = poses[k][:9].reshape(3, 3); t = poses[k][9:]
+        assert np.abs(R - s["R_wl"]).max() <= 1e-6 and np.abs(t - s["t_wl"]).max() <= 1e-6 * max(1.0, np.abs(s["t_wl"]).max())
+    # the refinement actually moved the perturbed poses towards the truth
+    err0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, 4)])
+    err1 = np.mean([np.linalg.norm(poses[k][9:] - sy.true_pose(k)[1] - (poses[0][9:] - sy.true_pose(0)[1])) for k in range(1, 4)])
+    assert err1 < err0
