@@ -73,12 +73,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
 
+    from panovlm_amd import sharding
     from panovlm_amd import synthetic as sy
     F, nb = args.scans, args.neighbors
     ref_all, nei_all = sy.pair_list(F, nb)
-    lo, hi = (F * rank) // world, (F * (rank + 1)) // world
-    mine = (ref_all >= lo) & (ref_all < hi)
-    ref, nei = ref_all[mine], nei_all[mine]
+    ref, nei = sharding.shard_pairs(ref_all, nei_all, F, rank, world)   # block partition by reference scan
     needed = sorted(set(ref.tolist()) | set(nei.tolist()))
     t_gen = time.perf_counter()
     scans = generate_scans(needed, args.cols, 0.2 if args.targets == "voxel" else 0.0)       # before torch/HIP initialise (fork-safe)
@@ -113,8 +112,8 @@ def main():
 
     poses = [sy.pose_params(*sy.estimated_pose(k)) for k in range(F)]
     aa0 = np.array([p[0] for p in poses]); t0 = np.array([p[1] for p in poses])
-    up = sorted({(min(a, b), max(a, b)) for a, b in zip(ref_all.tolist(), nei_all.tolist())})
-    neq = pv.NormalEq(ctx, F, [u[0] for u in up], [u[1] for u in up])
+    ui, uj = sharding.unordered_pairs(ref_all, nei_all)                   # same block structure on every rank
+    neq = pv.NormalEq(ctx, F, ui, uj)
     packed = torch.zeros(neq.size, dtype=torch.float64, device=dev)
     d_aa = torch.from_numpy(np.ascontiguousarray(aa0)).to(dev)
     d_t = torch.from_numpy(np.ascontiguousarray(t0)).to(dev)

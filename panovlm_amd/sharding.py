@@ -1,0 +1,58 @@
+"""Frame sharding of the scan-pair list across ranks.
+
+The unit of independent work is one ordered scan pair (ref i, nei n).  Pairs are block-partitioned
+by REFERENCE scan so that the association of a rank only needs its own reference scans plus their
+neighbours; the only exchange is one all-reduce(sum) of the packed normal-equation buffer
+[Hdiag F x 36 | Hoff U x 36 | g F x 6 | cost] per LM iteration (include/pvlm.h, pvlm_neq_*).
+numpy only — used by bench.py on the GPU and by the gloo tests on the CPU."""
+import numpy as np
+
+
+def shard_range(F, rank, world):
+    return (F * rank) // world, (F * (rank + 1)) // world
+
+
+def shard_pairs(ref, nei, F, rank, world):
+    """Pairs whose reference scan lies in this rank's block, order preserved."""
+    lo, hi = shard_range(F, rank, world)
+    m = (ref >= lo) & (ref < hi)
+    return ref[m], nei[m]
+
+
+def unordered_pairs(ref, nei):
+    """Sorted unique (i < j) pose pairs: the off-diagonal block structure shared by every rank."""
+    a = np.minimum(ref, nei).astype(np.int64); b = np.maximum(ref, nei).astype(np.int64)
+    key = np.unique(a * (int(b.max()) + 1 if len(b) else 1) + b)
+    base = int(b.max()) + 1 if len(b) else 1
+    return (key // base).astype(np.int32), (key % base).astype(np.int32)
+
+
+def packed_size(F, U):
+    return F * 36 + U * 36 + F * 6 + 1
+
+
+def unpack(packed, F, U):
+    Hd = packed[:F * 36].reshape(F, 6, 6); Ho = packed[F * 36:(F + U) * 36].reshape(U, 6, 6)
+    g = packed[(F + U) * 36:(F + U) * 36 + F * 6].reshape(F, 6)
+    return Hd, Ho, g, float(packed[-1])
+
+
+def pack_from_pair_blocks(blocks, ref, nei, F, ui, uj):
+    """Host reference of the device gather (k_neq_gather): pair blocks (P x 121) -> packed buffer."""
+    U = len(ui)
+    out = np.zeros(packed_size(F, U))
+    Hd, Ho, g, _ = unpack(out, F, U)   # views
+    Hd = out[:F * 36].reshape(F, 6, 6); Ho = out[F * 36:(F + U) * 36].reshape(U, 6, 6); g = out[(F + U) * 36:-1].reshape(F, 6)
+    lut = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(ui, uj))}
+    for p in range(len(ref)):
+        r, n = int(ref[p]), int(nei[p])
+        b = blocks[p]
+        Hd[r] += b[0:36].reshape(6, 6); Hd[n] += b[72:108].reshape(6, 6)
+        g[r] += b[108:114]; g[n] += b[114:120]
+        Hrn = b[36:72].reshape(6, 6)
+        if r < n:
+            Ho[lut[(r, n)]] += Hrn
+        else:
+            Ho[lut[(n, r)]] += Hrn.T
+        out[-1] += b[120]
+    return out
