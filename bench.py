@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scans", type=int, default=256, help="number of scans F in the batch")
+    ap.add_argument("--scans", type=int, default=1024, help="number of scans F in the batch")
     ap.add_argument("--neighbors", type=int, default=8, help="ordered pairs per reference scan")
     ap.add_argument("--cols", type=int, default=4096, help="azimuth steps per ring (16 rings)")
     ap.add_argument("--functor", choices=["angle", "meter"], default="angle")
@@ -173,6 +173,20 @@ def main():
             mat = {"error": str(e)[:200]}
 
     if rank == 0:
+        # HBM traffic of the fused kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+        # this same command, summarised by tools/pmc_traffic.py into profiles/): used only when it was collected on
+        # exactly this workload (the synthetic batch is deterministic, so evals_per_launch identifies it).
+        traffic, traffic_src = None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+            try:
+                pm = json.load(open(f))
+                if pm.get("evals_per_launch") == n_local and world == 1:
+                    for k, v in pm["kernels"].items():
+                        if "k_eval_fused" in k:
+                            traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+            except Exception:
+                pass
         bytes_per_eval = 8 * 7  # 7 fp64 SoA columns (P_n, plane); pair ids live in the per-segment table
         k_avg_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = n_local * bytes_per_eval / k_avg_s / 1e9
@@ -196,7 +210,8 @@ def main():
                 "mode": "fused-normal-equations", "functor": args.functor, "targets": args.targets, "scans": F, "pairs": int(len(ref_all)),
                 "points_per_scan": 16 * args.cols, "residual_blocks": n_total, "robust_cost": cost},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": n_local * bytes_per_eval,
                          "kernel": "k_eval_fused", "kernel_avg_ms": kern_ms / max(kern_n, 1), "launches": kern_n,
                          "bytes_per_eval": bytes_per_eval, "evals_per_launch": n_local,
                          "M_evals_per_s_kernel": n_local / k_avg_s / 1e6,
