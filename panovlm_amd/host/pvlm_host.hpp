@@ -94,6 +94,7 @@ class Velodyne {
   Matrix4d GetPose() const;
   bool IsPoseValid() const;                       // sensors/Velodyne.cpp:1894-1899
   bool IsInWorldCoordinate() const { return world_; }
+  void MarkWorld(bool w = true) { world_ = w; InvalidateDevice(); }  // clouds already carry world-frame floats
   Vector3d World2Local(const Vector3d& p) const;  // sensors/Velodyne.cpp:1850-1853
   Vector3d Local2World(const Vector3d& p) const;  // :1856-1859
   void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
