@@ -217,7 +217,7 @@ def main():
                          "M_evals_per_s_kernel": n_local / k_avg_s / 1e6,
                          "ceiling_M_evals_per_s_64B": HBM_PEAK_GBPS * 1e9 / 64 / 1e6,
                          "ceiling_M_evals_per_s_56B": HBM_PEAK_GBPS * 1e9 / 56 / 1e6},
-            "association": {"kernel": "k_assoc_p2plane", "pairs": int(len(ref)), "queries": n_queries, "accepted": n_local,
+            "association": {"kernel": "k_knn_pairs + k_fit_pairs", "pairs": int(len(ref)), "queries": n_queries, "accepted": n_local,
                             "kernel_ms": assoc_ms, "launches": assoc_n, "wall_s": t_assoc,
                             "M_queries_per_s_kernel": n_queries / max(assoc_ms, 1e-9) / 1e3},
             "materialise": mat,

@@ -23,11 +23,12 @@
 struct CloudView {
   const float4* sorted;
   const unsigned long long* keys;
-  const int* cell_start;
+  const int* cell_start;   // hash: start of the slot's cell; dense: prefix offsets, ncells + 1 entries
   const int* cell_count;
   const float* xyz;  // original order, interleaved
   const float* tag;
   int n, mask;
+  int dense, nx, ny, nz;   // dense != 0: cells addressed directly as (iz*ny + iy)*nx + ix, no hashing
   float ox, oy, oz, h, inv_h;
 };
 
@@ -102,6 +103,18 @@ __global__ void k_scatter(int n, const float* __restrict__ xyz, const int* __res
   sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
 }
 
+// dense grid variant of K1: linear cell index, counts, scatter (the scan is k_scan_counts)
+__global__ void k_dense_count(int n, const float* __restrict__ xyz, float ox, float oy, float oz, float inv_h, int nx, int ny, int nz,
+                              int* __restrict__ count, int* __restrict__ cell_of_pt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ix = min(max(cell_of(xyz[3 * i], ox, inv_h), 0), nx - 1), iy = min(max(cell_of(xyz[3 * i + 1], oy, inv_h), 0), ny - 1),
+            iz = min(max(cell_of(xyz[3 * i + 2], oz, inv_h), 0), nz - 1);
+  const int c = (iz * ny + iy) * nx + ix;
+  cell_of_pt[i] = c;
+  atomicAdd(&count[c], 1);
+}
+
 // ---- K2 ---------------------------------------------------------------------------------------
 template <int K>
 struct TopK {
@@ -142,12 +155,26 @@ __device__ __forceinline__ void knn_search(const CloudView& cv, float qx, float 
         const bool face = (dz == -r || dz == r || dy == -r || dy == r);
         const int step = face ? 1 : (r > 0 ? 2 * r : 1);
         for (int dx = -r; dx <= r; dx += step) {
-          const unsigned long long key = cell_key(cx + dx, cy + dy, cz + dz);
-          int s = (int)(mix64(key) & (unsigned long long)cv.mask);
-          unsigned long long kk;
-          while ((kk = cv.keys[s]) != key && kk != EMPTY_KEY) s = (s + 1) & cv.mask;
-          if (kk != key) continue;
-          const int b = cv.cell_start[s], e = b + cv.cell_count[s];
+          int b, e;
+          if (cv.dense) {
+            // cells of one (z, y) row are contiguous in the sorted array: on the faces of the shell
+            // the whole x-run is one range (consumed at dx = -r), interior rows only have the two end cells
+            const int z = cz + dz, y = cy + dy;
+            if (z < 0 || z >= cv.nz || y < 0 || y >= cv.ny) break;
+            const int row = (z * cv.ny + y) * cv.nx;
+            int x0 = cx + dx, x1 = x0;
+            if (face) { x1 = cx + r; dx = r; }
+            x0 = max(x0, 0); x1 = min(x1, cv.nx - 1);
+            if (x0 > x1) continue;
+            b = cv.cell_start[row + x0]; e = cv.cell_start[row + x1 + 1];
+          } else {
+            const unsigned long long key = cell_key(cx + dx, cy + dy, cz + dz);
+            int s = (int)(mix64(key) & (unsigned long long)cv.mask);
+            unsigned long long kk;
+            while ((kk = cv.keys[s]) != key && kk != EMPTY_KEY) s = (s + 1) & cv.mask;
+            if (kk != key) continue;
+            b = cv.cell_start[s]; e = b + cv.cell_count[s];
+          }
           for (int j = b; j < e; ++j) {
             const float4 p = cv.sorted[j];
             const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
@@ -399,32 +426,43 @@ __device__ __forceinline__ void world2local(const double* R, const double* t, do
   }
 }
 
-// grid: x = chunk of 256 queries, y = pair in batch.  Writes the k-NN indices, the candidate
-// record and the accept flag for every query; per-chunk accept counts for the compaction.
-__global__ __launch_bounds__(256) void k_assoc_p2plane(const PairDesc* __restrict__ pairs, float dist_threshold, double plane_tol,
-                                                       int* __restrict__ nn_tmp, double* __restrict__ rec_tmp,
-                                                       unsigned char* __restrict__ flag_tmp, int* __restrict__ chunk_count,
-                                                       long long tmp_rows) {
+// K2 — grid: x = chunk of 256 queries, y = pair in batch.  Exact 10-NN of every query; slot 9 is -1
+// when fewer than 10 targets lie within dist_threshold (LidarFeatureAssociate.cpp:577).  Kept apart
+// from K3 so that the register-hungry fp64 fits do not set the occupancy of the search.
+__global__ __launch_bounds__(256) void k_knn_pairs(const PairDesc* __restrict__ pairs, float dist_threshold, int* __restrict__ nn_tmp) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= pd.nq) return;
+  const float qx = pd.q_xyz[3 * q], qy = pd.q_xyz[3 * q + 1], qz = pd.q_xyz[3 * q + 2];
+  TopK<10> tk;
+  knn_search<10>(pd.ref, qx, qy, qz, dist_threshold, dist_threshold * dist_threshold, tk);
+  int* d = nn_tmp + (pd.tmp_base + q) * 10;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) d[k] = tk.id[k];
+}
+
+// K3 — class test, 10x3 plane fit, collinearity test, candidate record, accept flag and the
+// per-chunk accept counts for the ordered compaction.
+__global__ __launch_bounds__(256) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp,
+                                                   double* __restrict__ rec_tmp, unsigned char* __restrict__ flag_tmp,
+                                                   int* __restrict__ chunk_count, long long tmp_rows) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= pd.nq) return;
   bool accept = false;
   if (q < pd.nq) {
-    const float qx = pd.q_xyz[3 * q], qy = pd.q_xyz[3 * q + 1], qz = pd.q_xyz[3 * q + 2];
-    const float thr2 = dist_threshold * dist_threshold;
-    TopK<10> tk;
-    knn_search<10>(pd.ref, qx, qy, qz, dist_threshold, thr2, tk);
     const long long row = pd.tmp_base + q;
-    bool ok = (tk.cnt == 10);  // 10th neighbour within dist_threshold  (LidarFeatureAssociate.cpp:577)
+    int id[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) nn_tmp[row * 10 + k] = tk.id[k];
+    for (int k = 0; k < 10; ++k) id[k] = nn_tmp[row * 10 + k];
+    bool ok = id[9] >= 0;
     if (ok) {
       const float qtag = pd.q_tag[q];
       double px[10], py[10], pz[10];
       int same = 0;
 #pragma unroll
       for (int k = 0; k < 10; ++k) {
-        const int j = tk.id[k];
+        const int j = id[k];
         same += (pd.ref.tag[j] == qtag);
         double l[3];
         world2local(pd.Rr, pd.tr, (double)pd.ref.xyz[3 * j], (double)pd.ref.xyz[3 * j + 1], (double)pd.ref.xyz[3 * j + 2], l);
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(256) void k_assoc_p2plane(const PairDesc* __restric
         ok = plane_ok && !line;  // :592-596
         if (ok) {
           double pl[3];
-          world2local(pd.Rn, pd.tn, (double)qx, (double)qy, (double)qz, pl);
+          world2local(pd.Rn, pd.tn, (double)pd.q_xyz[3 * q], (double)pd.q_xyz[3 * q + 1], (double)pd.q_xyz[3 * q + 2], pl);
           rec_tmp[0 * tmp_rows + row] = pl[0]; rec_tmp[1 * tmp_rows + row] = pl[1]; rec_tmp[2 * tmp_rows + row] = pl[2];
           rec_tmp[3 * tmp_rows + row] = plane[0]; rec_tmp[4 * tmp_rows + row] = plane[1];
           rec_tmp[5 * tmp_rows + row] = plane[2]; rec_tmp[6 * tmp_rows + row] = plane[3];
@@ -520,29 +558,53 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
   h = std::min(std::max(h, 0.02f), 4.0f);
   c.cell = h;
   for (int k = 0; k < 3; ++k) c.origin[k] = mn[k] - h;
-  int T = 1024;
-  while (T < 2 * n) T <<= 1;
-  c.table_size = T;
-  int *d_slot = nullptr, *d_cursor = nullptr;
-  if ((st = pvlm_i_alloc(ctx, &c.d_keys, (size_t)T))) return st;
-  if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
-  if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
-  if ((st = pvlm_i_alloc(ctx, &c.d_sorted, (size_t)n))) return st;
-  if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
-  if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); return st; }
-  hipError_t e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
-  hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
-  hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
   const float inv_h = 1.0f / h;
-  hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h,
-                     T - 1, c.d_keys, c.d_cell_count, d_slot);
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, T, c.d_cell_count, c.d_cell_start);
-  hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
-  hipError_t le = hipGetLastError();
-  hipError_t se = hipStreamSynchronize(ctx->stream);
+  long long dims[3];
+  for (int k = 0; k < 3; ++k) dims[k] = (long long)std::ceil((mx[k] - c.origin[k]) * inv_h) + 2;
+  const long long ncells = dims[0] * dims[1] * dims[2];
+  const bool dense = ncells <= std::max<long long>(64ll * n, 4096) && ncells <= (4ll << 20) && !getenv("PVLM_FORCE_HASH");
+  if ((st = pvlm_i_alloc(ctx, &c.d_sorted, (size_t)n))) return st;
+  int *d_slot = nullptr, *d_cursor = nullptr;
+  hipError_t le = hipSuccess, se = hipSuccess;
+  if (dense) {
+    c.dense = 1; c.nx = (int)dims[0]; c.ny = (int)dims[1]; c.nz = (int)dims[2];
+    c.table_size = (int)ncells + 1;
+    const int T = c.table_size;
+    if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
+    if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
+    if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
+    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); return st; }
+    hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
+    hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
+    if (e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+    hipLaunchKernelGGL(k_dense_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h, c.nx,
+                       c.ny, c.nz, c.d_cell_count, d_slot);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, T, c.d_cell_count, c.d_cell_start);
+    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
+    le = hipGetLastError();
+    se = hipStreamSynchronize(ctx->stream);
+  } else {
+    int T = 1024;
+    while (T < 2 * n) T <<= 1;
+    c.table_size = T;
+    if ((st = pvlm_i_alloc(ctx, &c.d_keys, (size_t)T))) return st;
+    if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
+    if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
+    if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
+    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); return st; }
+    hipError_t e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
+    hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
+    hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+    hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h,
+                       T - 1, c.d_keys, c.d_cell_count, d_slot);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, T, c.d_cell_count, c.d_cell_start);
+    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
+    le = hipGetLastError();
+    se = hipStreamSynchronize(ctx->stream);
+  }
   hipFree(d_slot); hipFree(d_cursor);
-  if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-hash build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
+  if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }
 
@@ -550,6 +612,7 @@ static CloudView view_of(const pvlm_cloud& c) {
   CloudView v;
   v.sorted = c.d_sorted; v.keys = c.d_keys; v.cell_start = c.d_cell_start; v.cell_count = c.d_cell_count;
   v.xyz = c.d_xyz; v.tag = c.d_tag; v.n = c.n; v.mask = c.table_size - 1;
+  v.dense = c.dense; v.nx = c.nx; v.ny = c.ny; v.nz = c.nz;
   v.ox = c.origin[0]; v.oy = c.origin[1]; v.oz = c.origin[2]; v.h = c.cell; v.inv_h = c.cell > 0 ? 1.0f / c.cell : 0.f;
   return v;
 }
@@ -731,8 +794,9 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     for (int p = b.p0; p < b.p1; ++p) bmax = std::max(bmax, descs[p].nq);
     if (e == hipSuccess && bmax > 0) {
       pvlm_prof_scope prof(ctx, 2);
-      hipLaunchKernelGGL(k_assoc_p2plane, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, dist_threshold, plane_tolerance,
-                         b.d_nn, b.d_rec, b.d_flag, d_cc, b.rows);
+      hipLaunchKernelGGL(k_knn_pairs, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, dist_threshold, b.d_nn);
+      hipLaunchKernelGGL(k_fit_pairs, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, plane_tolerance, b.d_nn, b.d_rec,
+                         b.d_flag, d_cc, b.rows);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(cc.data(), d_cc, (size_t)std::max(b.chunks, 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);

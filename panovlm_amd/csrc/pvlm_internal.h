@@ -97,7 +97,8 @@ struct pvlm_cloud {
   // voxel hash (built at upload): points sorted by cell
   float cell = 0.f;
   float origin[3] = {0, 0, 0};
-  int table_size = 0;            // power of two
+  int table_size = 0;            // hash: power-of-two slots; dense: ncells + 1
+  int dense = 0, nx = 0, ny = 0, nz = 0;  // dense grid when the bounding box is small enough
   unsigned long long* d_keys = nullptr;  // table_size, ~0 = empty
   int* d_cell_start = nullptr;   // table_size
   int* d_cell_count = nullptr;   // table_size
