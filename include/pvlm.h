@@ -57,9 +57,12 @@ pvlm_status pvlm_create(int device, pvlm_ctx** ctx);
 pvlm_status pvlm_destroy(pvlm_ctx* ctx);
 const char* pvlm_last_error(const pvlm_ctx* ctx);   /* valid until the next call on ctx */
 const char* pvlm_version(void);
-/* Launch on an externally owned hipStream_t (e.g. the caller's framework stream); NULL selects
- * the context's own stream.  Kernels of one ctx are always issued on exactly one stream. */
+/* Launch on an externally owned hipStream_t (e.g. the caller's framework stream).  The handle is
+ * used as given: NULL is HIP's default (null) stream, which is what a framework hands out for its
+ * default stream.  pvlm_use_own_stream returns to the context's private non-blocking stream (the
+ * state after pvlm_create).  Kernels of one ctx are always issued on exactly one stream. */
 pvlm_status pvlm_set_stream(pvlm_ctx* ctx, void* hip_stream);
+pvlm_status pvlm_use_own_stream(pvlm_ctx* ctx);
 pvlm_status pvlm_synchronize(pvlm_ctx* ctx);
 /* HIP-event timing on the ctx stream (bench.py measures kernel time with these). */
 pvlm_status pvlm_timer_start(pvlm_ctx* ctx);

@@ -14,7 +14,7 @@ STRIDE = {0: 7, 1: 7, 2: 9, 3: 9, 4: 10, 5: 12}
 
 # every symbol include/pvlm.h declares (tests/test_abi.py checks the header and the .so against it)
 ABI_SYMBOLS = [
-    "pvlm_create", "pvlm_destroy", "pvlm_last_error", "pvlm_version", "pvlm_set_stream", "pvlm_synchronize",
+    "pvlm_create", "pvlm_destroy", "pvlm_last_error", "pvlm_version", "pvlm_set_stream", "pvlm_use_own_stream", "pvlm_synchronize",
     "pvlm_timer_start", "pvlm_timer_stop", "pvlm_device_info", "pvlm_profile_enable", "pvlm_profile_read", "pvlm_set_poses", "pvlm_set_poses_dev",
     "pvlm_resset_upload", "pvlm_resset_destroy", "pvlm_resset_info", "pvlm_resset_download", "pvlm_eval",
     "pvlm_eval_dev", "pvlm_eval_pair_blocks", "pvlm_eval_pair_blocks_dev", "pvlm_neq_create", "pvlm_neq_destroy",
@@ -108,7 +108,11 @@ class Context:
             pass
 
     def set_stream(self, stream_handle):
+        """Issue all kernels on this hipStream_t (0 / None = HIP's default stream, e.g. torch's default stream)."""
         self._check(self.lib.pvlm_set_stream(self._h, C.c_void_p(stream_handle or 0)), "pvlm_set_stream")
+
+    def use_own_stream(self):
+        self._check(self.lib.pvlm_use_own_stream(self._h), "pvlm_use_own_stream")
 
     def synchronize(self):
         self._check(self.lib.pvlm_synchronize(self._h), "pvlm_synchronize")

@@ -81,7 +81,17 @@ const char* pvlm_last_error(const pvlm_ctx* ctx) { return ctx ? ctx->err.c_str()
 
 pvlm_status pvlm_set_stream(pvlm_ctx* ctx, void* s) {
   if (!ctx) return PVLM_ERR_ARG;
-  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing of ours may still be in flight on the old stream
+  ctx->stream = (hipStream_t)s;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_use_own_stream(pvlm_ctx* ctx) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = ctx->own_stream;
   return PVLM_OK;
 }
 

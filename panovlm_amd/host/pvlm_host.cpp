@@ -1050,6 +1050,45 @@ inline Matrix4d Inverse4(const Matrix4d& A) {
 }  // namespace
 
 // ================================================================================================
+// AddCameraLidarResidual — util/Optimization.cpp:564-607
+// ================================================================================================
+size_t AddCameraLidarResidual(int rows, int cols, const std::vector<bool>& frame_pose_valid, const std::vector<Velodyne>& lidars,
+                              std::vector<Vector3d>& aa_cw, std::vector<Vector3d>& t_cw, std::vector<Vector3d>& aa_lw, std::vector<Vector3d>& t_lw,
+                              const std::map<std::pair<size_t, size_t>, std::vector<CameraLidarLinePair>>& line_pairs,
+                              ceres_like::LossFunction* loss, ceres_like::Problem& problem, double weight) {
+  size_t num = 0;
+  Equirect eq{cols, rows};
+  for (const auto& kv : line_pairs) {
+    const size_t frame_id = kv.first.first, lidar_id = kv.first.second;
+    if (!lidars[lidar_id].IsPoseValid() || !frame_pose_valid[frame_id]) continue;
+    for (const CameraLidarLinePair& lp : kv.second) {
+      const double a[2] = {lp.image_line[0], lp.image_line[1]}, b[2] = {lp.image_line[2], lp.image_line[3]};
+      double p1[3], p2[3];
+      eq.ImageToCam(a, 1.0, p1); eq.ImageToCam(b, 1.0, p2);
+      // FormPlane(p1, p2, 0), NOT normalised here (the functor constructors normalise, CostFunction.h:361,459)
+      const double p3[3] = {0, 0, 0};
+      const double pa = ((p2[1] - p1[1]) * (p3[2] - p1[2]) - (p2[2] - p1[2]) * (p3[1] - p1[1]));
+      const double pb = ((p2[2] - p1[2]) * (p3[0] - p1[0]) - (p2[0] - p1[0]) * (p3[2] - p1[2]));
+      const double pc = ((p2[0] - p1[0]) * (p3[1] - p1[1]) - (p2[1] - p1[1]) * (p3[0] - p1[0]));
+      const double pd = -(pa * p1[0] + pb * p1[1] + pc * p1[2]);
+      // point order passed is (end, start)  (Optimization.cpp:592)
+      problem.AddResidualBlock(Plane2Plane_Global::Create({pa, pb, pc}, lp.lidar_line_end, lp.lidar_line_start, lp.weight * weight), loss,
+                               aa_cw[frame_id].data(), t_cw[frame_id].data(), aa_lw[lidar_id].data(), t_lw[lidar_id].data());
+      // full arc angle, VectorAngle3D(p1, p2, normalized = true)  (:596)
+      double c = p1[0] * p2[0] + p1[1] * p2[1] + p1[2] * p2[2];
+      const double angle = c >= 1.0 ? 0.0 : (c <= -1.0 ? M_PI : std::acos(c));
+      const Vector3d mid_l = {(lp.lidar_line_end[0] + lp.lidar_line_start[0]) / 2.0, (lp.lidar_line_end[1] + lp.lidar_line_start[1]) / 2.0,
+                              (lp.lidar_line_end[2] + lp.lidar_line_start[2]) / 2.0};
+      const Vector3d mid_i = {(p1[0] + p2[0]) / 2.0, (p1[1] + p2[1]) / 2.0, (p1[2] + p2[2]) / 2.0};
+      problem.AddResidualBlock(PlaneIOUResidual::Create({pa, pb, pc, pd}, mid_l, mid_i, angle, 2.0 * weight), loss, aa_cw[frame_id].data(),
+                               t_cw[frame_id].data(), aa_lw[lidar_id].data(), t_lw[lidar_id].data());
+      num += 2;
+    }
+  }
+  return num;
+}
+
+// ================================================================================================
 // CameraLidarLineAssociate — joint_optimization/CameraLidarLineAssociate.cpp:340-475, :628-715, :754-876
 // ================================================================================================
 void CameraLidarLineAssociate::AssociateByAngle(const std::vector<std::array<float, 4>>& lines, const Velodyne& lidar, const Matrix4d& T_cl,

@@ -235,6 +235,16 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
                                    std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
                                    ceres_like::Problem& problem, const std::vector<LineTrack>& lidar_line_tracks,
                                    double point_to_line_dis_threshold, bool angle_residual, bool normalized_distance, double weight = 1.0);
+// AddCameraLidarResidual (util/Optimization.cpp:564-607): two blocks per matched line pair —
+// Plane2Plane_Global (weight line_pair.weight * weight) and PlaneIOUResidual (weight 2 * weight) — on
+// (angleAxis_cw[frame], t_cw[frame], angleAxis_lw[lidar], t_lw[lidar]).  `frame_pose_valid[f]` stands for
+// frames[f].IsPoseValid(); rows/cols are the panorama size (frames[0].GetImageRows/Cols).
+struct CameraLidarLinePair;
+size_t AddCameraLidarResidual(int rows, int cols, const std::vector<bool>& frame_pose_valid, const std::vector<Velodyne>& lidars,
+                              std::vector<Vector3d>& angleAxis_cw_list, std::vector<Vector3d>& t_cw_list,
+                              std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
+                              const std::map<std::pair<size_t, size_t>, std::vector<CameraLidarLinePair>>& line_pairs,
+                              ceres_like::LossFunction* loss_function, ceres_like::Problem& problem, double weight);
 ceres_like::Solver::Options SetOptionsLidar(const int num_threads, const int lidar_size);
 
 // ceres/rotation.h pieces the callers use (lidar_mapping/LidarOdometry.cpp:31,105)

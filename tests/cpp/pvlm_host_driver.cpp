@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
       else if (kind == 4) c = Plane2Plane_Global::Create(V3(0), V3(3), V3(6), v[9]);
       else c = PlaneIOUResidual::Create({v[0], v[1], v[2], v[3]}, V3(4), V3(7), v[10], v[11]);
       const double* params[4] = {&v[nr], &v[nr + 3], &v[nr + 6], &v[nr + 9]};
-      double r, J0[3], J1[3], J2[3], J3[3];
+      double r, J0[3], J1[3], J3[3];
       double* J[4] = {J0, J1, nullptr, J3};  // one null block, like a constant parameter block
       const bool ok = c->Evaluate(params, &r, J);
       printf("ok %d r %.17g J", ok ? 1 : 0, r);
@@ -136,6 +136,40 @@ int main(int argc, char** argv) {
       for (auto& p : a.GetAssociatedPairs())
         printf("pair %d %d %.9g %.17g %.17g %.17g %.17g %.17g %.17g\n", p.image_line_id, p.lidar_line_id, p.angle, p.lidar_line_start[0], p.lidar_line_start[1],
                p.lidar_line_start[2], p.lidar_line_end[0], p.lidar_line_end[1], p.lidar_line_end[2]);
+    } else if (cmd == "camlidar") {
+      // camlidar <scan.bin> <lines_T.bin> rows cols weight huber_a iters : associate by angle, add the camera-LiDAR
+      // residual blocks (camera pose = identity, LiDAR pose T_lw = T_cl), solve for the LiDAR pose, print costs
+      auto l = LoadScans(argv[2]);
+      std::ifstream f(argv[3], std::ios::binary);
+      int32_t nl = 0; rd(f, &nl, 1);
+      std::vector<std::array<float, 4>> lines(nl);
+      for (auto& x : lines) rd(f, x.data(), 4);
+      Matrix4d T; rd(f, T.data(), 16);
+      const int rows = atoi(argv[4]), cols = atoi(argv[5]);
+      CameraLidarLineAssociate a(rows, cols);
+      a.AssociateByAngle(lines, l[0], T, true);
+      std::map<std::pair<size_t, size_t>, std::vector<CameraLidarLinePair>> lp;
+      lp[{0, 0}] = a.GetAssociatedPairs();
+      // world = camera frame: T_cw = I ; LiDAR: T_lw maps world->lidar = T_cl^-1, parameter = (aa_lw, t_lw)
+      Matrix3d Rcl = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+      Matrix3d Rlc = {Rcl[0], Rcl[3], Rcl[6], Rcl[1], Rcl[4], Rcl[7], Rcl[2], Rcl[5], Rcl[8]};
+      Vector3d tcl = {T[3], T[7], T[11]};
+      Vector3d tlc = {-(Rlc[0] * tcl[0] + Rlc[1] * tcl[1] + Rlc[2] * tcl[2]), -(Rlc[3] * tcl[0] + Rlc[4] * tcl[1] + Rlc[5] * tcl[2]),
+                      -(Rlc[6] * tcl[0] + Rlc[7] * tcl[1] + Rlc[8] * tcl[2])};
+      std::vector<Vector3d> aa_cw(1, Vector3d{0, 0, 0}), t_cw(1, Vector3d{0, 0, 0}), aa_lw(1), t_lw(1, tlc);
+      RotationMatrixToAngleAxis(Rlc, &aa_lw[0]);
+      l[0].SetPose(Rcl, tcl);
+      ceres_like::Problem problem;
+      const size_t nres = AddCameraLidarResidual(rows, cols, {true}, l, aa_cw, t_cw, aa_lw, t_lw, lp, new ceres_like::HuberLoss(atof(argv[7])), problem,
+                                                 atof(argv[6]));
+      problem.SetParameterBlockConstant(aa_cw[0].data());
+      problem.SetParameterBlockConstant(t_cw[0].data());
+      ceres_like::Solver::Options o;
+      o.max_num_iterations = atoi(argv[8]);
+      ceres_like::Solver::Summary sum;
+      ceres_like::Solve(o, &problem, &sum);
+      printf("blocks %zu initial %.17g final %.17g steps %d\n", nres, sum.initial_cost, sum.final_cost, sum.num_successful_steps);
+      printf("aa_lw %.17g %.17g %.17g t_lw %.17g %.17g %.17g\n", aa_lw[0][0], aa_lw[0][1], aa_lw[0][2], t_lw[0][0], t_lw[0][1], t_lw[0][2]);
     } else {
       fprintf(stderr, "unknown command %s\n", cmd.c_str());
       return 2;

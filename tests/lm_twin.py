@@ -182,3 +182,82 @@ def estimate_pose(oracle, scans, cfg, max_iteration):
             break
         last_cost, last_step = res["final_cost"], res["successful"]
     return log
+
+
+# ------------------------------------------------------------------------------------------------
+# line-to-line term: LidarLineMatch::GenerateTracks + AddLidarLineToLineResidual2 on the oracle
+# ------------------------------------------------------------------------------------------------
+def world_line_scan(s):
+    return dict(id=s["id"], R_wl=s["R_wl"], t_wl=s["t_wl"], corner_xyz=transform_f32(s["corner_cur"], s["R_wl"], s["t_wl"]), p2s=s["p2s"],
+                seg_size=np.array([len(x) for x in s["seg_points"]], np.int32), seg_coeffs=s["seg_coeffs"], end_points=s["end_points"])
+
+
+def line_tracks(oracle, world, nb, min_len):
+    parent = {}
+
+    def find(a):
+        while parent.setdefault(a, a) != a:
+            parent[a] = parent[parent[a]]; a = parent[a]
+        return a
+    for i in range(len(world)):
+        for j in nb[i]:
+            o = oracle.assoc_line2line(world[j], world[i], 0.3)
+            for a, b in zip(o["nei_idx"], o["ref_idx"]):
+                ra, rb = find((i, int(a))), find((j, int(b)))
+                if ra != rb:
+                    parent[ra] = rb
+    comps = {}
+    for node in list(parent):
+        comps.setdefault(find(node), set()).add(node)
+    return [c for c in comps.values() if len({n[0] for n in c}) >= min_len and len(c) > 1]
+
+
+def world2local(R, t, p):
+    out = np.empty(3)
+    for i in range(3):
+        a = (R[0, i] * p[0] + R[1, i] * p[1]) + R[2, i] * p[2]
+        b = (R[0, i] * t[0] + R[1, i] * t[1]) + R[2, i] * t[2]
+        out[i] = a - b
+    return out
+
+
+def refine_pose_lines(oracle, scans, thr=0.3, normalize=True):
+    F = len(scans)
+    world = [world_line_scan(s) for s in scans]
+    aa = np.zeros((F, 3)); t = np.zeros((F, 3))
+    for i, s in enumerate(scans):
+        Rl, tl = inv_pose(s["R_wl"], s["t_wl"])
+        aa[i] = oracle.matrix_to_angle_axis(Rl); t[i] = tl
+    poses = np.array([np.concatenate([s["R_wl"].reshape(-1), s["t_wl"]]) for s in scans])
+    nb6 = oracle.find_neighbors(poses, np.ones(F, np.int32), 6)
+    nb4 = oracle.find_neighbors(poses, np.ones(F, np.int32), 4)
+    tracks = line_tracks(oracle, world, nb4, 3)
+    member = {}
+    for k, tr in enumerate(tracks):
+        for node in tr:
+            member.setdefault(node, []).append(k)
+    rows, rid, nid = [], [], []
+    for i in range(F):
+        for n in nb6[i]:
+            if n < 0 or n == i or n >= F:
+                continue
+            o = oracle.assoc_line2line(world[i], world[n], thr)
+            for nl, rl, p1, p2 in zip(o["nei_idx"], o["ref_idx"], o["p1"], o["p2"]):
+                if (i, int(rl)) not in member:
+                    continue
+                if not any((n, int(nl)) in tracks[k] for k in member[(i, int(rl))]):
+                    continue
+                for ci in scans[n]["seg_points"][int(nl)]:
+                    lp = world2local(scans[n]["R_wl"], scans[n]["t_wl"], world[n]["corner_xyz"][ci].astype(np.float64))
+                    rows.append(np.concatenate([lp, p1, p2, [1.0]])); rid.append(i); nid.append(n)
+    group = dict(kind=3, normalize=normalize, rows=np.array(rows), rid=np.array(rid, np.int32), nid=np.array(nid, np.int32), loss=0, a=0.0)
+    res = solve(oracle, [group], aa, t, {0})
+    res["blocks"] = len(rows)
+    for i, s in enumerate(scans):
+        Rl, tl = inv_pose(s["R_wl"], s["t_wl"])
+        s["corner_cur"] = transform_f32(world[i]["corner_xyz"], Rl, tl)
+        R_lw = oracle.angle_axis_to_matrix(aa[i])
+        R_wl = R_lw.T.copy()
+        rt = np.array([(R_wl[r, 0] * t[i][0] + R_wl[r, 1] * t[i][1]) + R_wl[r, 2] * t[i][2] for r in range(3)])
+        s["R_wl"] = R_wl; s["t_wl"] = -rt
+    return res

@@ -163,3 +163,72 @@ def test_estimate_pose_matches_cpu_twin(oracle, tmp):
     err0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, 4)])
     err1 = np.mean([np.linalg.norm(poses[k][9:] - sy.true_pose(k)[1] - (poses[0][9:] - sy.true_pose(0)[1])) for k in range(1, 4)])
     assert err1 < err0
+
+
+def test_camera_lidar_residual_blocks(oracle, tmp):
+    """AddCameraLidarResidual (util/Optimization.cpp:564-607): Plane2Plane_Global + PlaneIOUResidual blocks built
+    from the by-angle association; initial robust cost against the oracle, then a short solve."""
+    rng = np.random.default_rng(12)
+    rows, cols = 2880, 5760
+    lw = synth.random_world_lines(rng, 9, extent=3.0)
+    s = synth.make_line_scan(rng, 0, np.eye(3), np.zeros(3), lw, pts_per_line=(20, 50), extra_pts=40)
+    seg_points = [[i for i, l in enumerate(s["p2s"]) if sid in l] for sid in range(len(s["seg_size"]))]
+    scan = dict(id=0, R_wl=np.eye(3), t_wl=np.zeros(3), corner_local=s["corner_local"], p2s=s["p2s"], seg_points=seg_points,
+                seg_coeffs=s["seg_coeffs"], end_points=s["end_points"])
+    path = os.path.join(tmp, "cam2.bin")
+    host_io.write_scans(path, [scan], world=False)
+    ang = np.deg2rad(rng.uniform(-2, 2, size=3))
+    T = np.eye(4); T[:3, :3] = synth.rodrigues(ang); T[:3, 3] = rng.uniform(-0.05, 0.05, size=3)
+    ends_cam = s["end_points"].reshape(-1, 3) @ T[:3, :3].T + T[:3, 3]
+    lines = oracle.cam_to_image(rows, cols, ends_cam).reshape(-1, 4).astype(np.float32)
+    lines += rng.normal(size=lines.shape).astype(np.float32) * 3.0
+    lpath = os.path.join(tmp, "lines_T2.bin")
+    with open(lpath, "wb") as f:
+        f.write(np.int32(len(lines)).tobytes()); f.write(lines.tobytes()); f.write(T.astype(np.float64).tobytes())
+    w, a = 1.5, 3 * np.pi / 180
+    out = host_io.run("camlidar", path, lpath, rows, cols, w, a, 8)
+    v = out[0].split()
+    blocks, initial, final = int(v[1]), float(v[3]), float(v[5])
+    # oracle side
+    local = dict(s); local["corner_xyz"] = s["corner_local"]
+    o = oracle.assoc_by_angle(rows, cols, lines, local, T, multiple=True)
+    assert blocks == 2 * len(o["image_line_id"]) > 8
+    Rlc = T[:3, :3].T; tlc = -Rlc @ T[:3, 3]
+    aa = np.stack([np.zeros(3), oracle.matrix_to_angle_axis(Rlc)]); t = np.stack([np.zeros(3), tlc])
+    r4, r5 = [], []
+    for k, li in enumerate(o["image_line_id"]):
+        px = lines[li].astype(np.float64)
+        p1 = oracle.image_to_cam(rows, cols, px[None, 0:2], 1.0)[0]; p2 = oracle.image_to_cam(rows, cols, px[None, 2:4], 1.0)[0]
+        pl = np.cross(p2 - p1, -p1); plane = np.concatenate([pl, [-(pl @ p1)]])
+        st, en = o["start"][k], o["end"][k]
+        r4.append(np.concatenate([plane[:3], en, st, [1.0 * w]]))
+        c = float(np.clip(p1 @ p2, -1, 1))
+        r5.append(np.concatenate([plane, (en + st) / 2, (p1 + p2) / 2, [np.arccos(c)], [2.0 * w]]))
+    n = len(r4)
+    ra, _ = oracle.evaluate(4, np.array(r4), [0] * n, [1] * n, aa, t, jac=False)
+    rb, _ = oracle.evaluate(5, np.array(r5), [0] * n, [1] * n, aa, t, jac=False)
+    cost = synth.huber_weights(np.concatenate([ra, rb]), 1, a)[1].sum()
+    assert abs(initial - cost) <= 1e-6 * cost
+    assert final <= initial * (1 + 1e-12) and np.isfinite(final)
+
+
+def test_line_to_line_refine_matches_cpu_twin(oracle, tmp):
+    """One RefinePose with only the line-to-line term (GenerateTracks + AddLidarLineToLineResidual2 + Solve) against
+    the oracle twin: same residual-block count, costs and poses within 1e-6."""
+    rng = np.random.default_rng(31)
+    scans = _line_scans(rng, 5)
+    path = os.path.join(tmp, "lodo.bin")
+    host_io.write_scans(path, scans, world=False)
+    out = host_io.run("odometry", path, 1, 1, 1, 1, 0, 0.05, 1.0, 0.3)
+    it = [l.split() for l in out if l.startswith("iter")][0]
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    twin = [dict(s) for s in scans]
+    for s in twin:
+        s["corner_cur"] = np.asarray(s["corner_local"], np.float32)
+    res = lm_twin.refine_pose_lines(oracle, twin, thr=0.3, normalize=True)
+    assert int(it[6]) == res["blocks"] > 200
+    assert abs(float(it[2]) - res["final_cost"]) <= 1e-6 * max(res["final_cost"], 1e-12)
+    assert int(it[4]) == res["successful"]
+    for k, s in enumerate(twin):
+        R = poses[k][:9].reshape(3, 3); t = poses[k][9:]
+        assert np.abs(R - s["R_wl"]).max() <= 1e-6 and np.abs(t - s["t_wl"]).max() <= 1e-6 * max(1.0, np.abs(s["t_wl"]).max())
