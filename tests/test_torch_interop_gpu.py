@@ -1,0 +1,50 @@
+"""Stream-ordered interop with PyTorch (what bench.py relies on): kernels issued on torch's current stream see
+tensors written just before and are seen by torch ops (and RCCL collectives) issued right after."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("use_side_stream", [False, True])
+def test_device_pointers_on_torch_stream(oracle, use_side_stream):
+    import torch
+    import panovlm_amd as pv
+    rng = np.random.default_rng(9)
+    F, P = 12, 60
+    aa, t = synth.random_poses(rng, F)
+    ref, nei = synth.random_pairs(rng, F, P)
+    rows, off = synth.random_resset(rng, 1, aa, t, ref, nei, rng.integers(200, 3000, size=P))
+    ctx = pv.Context(0)
+    rs = pv.ResidualSet.upload(ctx, 1, rows, off, ref, nei, flags=1)
+    up = sorted({(min(a, b), max(a, b)) for a, b in zip(ref.tolist(), nei.tolist())})
+    neq = pv.NormalEq(ctx, F, [u[0] for u in up], [u[1] for u in up])
+    ctx.set_poses(aa, t)
+    expect = neq.accumulate(rs, 1, 0.035)            # host-pointer path on the ctx's own stream
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev) if use_side_stream else torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        d_aa = torch.zeros((F, 3), dtype=torch.float64, device=dev)
+        d_t = torch.zeros((F, 3), dtype=torch.float64, device=dev)
+        packed = torch.full((neq.size,), float("nan"), dtype=torch.float64, device=dev)
+        for _ in range(3):
+            # torch writes the parameters, we consume them immediately, torch consumes our output immediately
+            d_aa.copy_(torch.from_numpy(aa), non_blocking=False); d_t.copy_(torch.from_numpy(t), non_blocking=False)
+            d_aa.mul_(1.0); d_t.add_(0.0)
+            ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
+            neq.accumulate_dev(rs, packed.data_ptr(), 1, 0.035, zero_first=True)
+            doubled = packed * 2.0
+        got = doubled.cpu().numpy() / 2.0
+    ctx.use_own_stream()
+    assert np.allclose(got, expect, rtol=1e-12, atol=1e-12 * np.abs(expect).max())
+    r = torch.empty(rs.n, dtype=torch.float64, device=dev); J = torch.empty((rs.n, 12), dtype=torch.float64, device=dev)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    rs.eval_dev(r.data_ptr(), J.data_ptr())
+    rh, Jh = r.cpu().numpy(), J.cpu().numpy()
+    ctx.use_own_stream()
+    r2, J2 = rs.eval()
+    assert np.array_equal(rh, r2) and np.array_equal(Jh, J2)
+    rs.close(); ctx.close()
