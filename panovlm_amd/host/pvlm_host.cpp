@@ -8,7 +8,10 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iomanip>
 #include <limits>
+#include <sstream>
 #include <numeric>
 #include <stdexcept>
 
@@ -80,6 +83,52 @@ void AngleAxisToRotationMatrix(const Vector3d& a, Matrix3d* Rout) {
          -wy * s + wx * wz * k, wx * s + wy * wz * k, c + wz * wz * k};
   } else {
     R = {1, -a[2], a[1], a[2], 1, -a[0], -a[1], a[0], 1};
+  }
+}
+
+// ================================================================================================
+// pose files — util/FileIO.cpp:11-79 (ReadPoseT), :168-191 (ExportPoseT)
+// ================================================================================================
+bool ReadPoseT(std::string file_path, bool with_invalid, std::vector<Matrix3d>& rotation_list, std::vector<Vector3d>& trans_list,
+               std::vector<std::string>& name_list) {
+  std::ifstream in(file_path);
+  if (!in.is_open()) { fprintf(stderr, "Fail to open %s\n", file_path.c_str()); return false; }
+  while (!in.eof()) {
+    Matrix3d R = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Vector3d t = {INFINITY, INFINITY, INFINITY};
+    std::string str;
+    std::getline(in, str);
+    std::vector<std::string> sub;
+    { std::stringstream ss(str); std::string tmp; while (std::getline(ss, tmp, ' ')) sub.push_back(tmp); }  // SplitString(str, ' ')
+    std::string curr_name;
+    bool pose_valid = true;
+    if (sub.size() == 13) { curr_name = sub[0]; sub.erase(sub.begin()); }
+    if (sub.size() == 12) {
+      for (const std::string& s : sub)
+        if (s.find("inf") != std::string::npos || s.find("nan") != std::string::npos) { pose_valid = false; break; }
+      if (pose_valid) {
+        double v[12];
+        for (int k = 0; k < 12; ++k) { std::stringstream ss(sub[k]); ss >> v[k]; }  // str2num<double>
+        R = {v[0], v[1], v[2], v[4], v[5], v[6], v[8], v[9], v[10]};
+        t = {v[3], v[7], v[11]};
+      }
+    }
+    if (pose_valid || (!pose_valid && with_invalid)) { rotation_list.push_back(R); trans_list.push_back(t); name_list.push_back(curr_name); }
+    if (in.peek() == EOF) break;
+  }
+  return true;
+}
+
+void ExportPoseT(const std::string file_path, const std::vector<Matrix3d>& rotation_list, const std::vector<Vector3d>& trans_list,
+                 const std::vector<std::string>& name_list, int precision) {
+  std::ofstream out(file_path);
+  if (!out.is_open()) { fprintf(stderr, "Fail to write %s\n", file_path.c_str()); return; }
+  out << std::setprecision(precision);
+  for (size_t i = 0; i < rotation_list.size() && i < trans_list.size(); i++) {
+    if (i < name_list.size()) out << name_list[i] << " ";
+    const Matrix3d& R = rotation_list[i]; const Vector3d& t = trans_list[i];
+    out << R[0] << " " << R[1] << " " << R[2] << " " << t[0] << " " << R[3] << " " << R[4] << " " << R[5] << " " << t[1] << " " << R[6] << " " << R[7]
+        << " " << R[8] << " " << t[2] << std::endl;
   }
 }
 

@@ -247,6 +247,16 @@ size_t AddCameraLidarResidual(int rows, int cols, const std::vector<bool>& frame
                               ceres_like::LossFunction* loss_function, ceres_like::Problem& problem, double weight);
 ceres_like::Solver::Options SetOptionsLidar(const int num_threads, const int lidar_size);
 
+// util/FileIO.cpp:11-79, :168-191 — pose text files: one row per pose, optional name + 12 numbers
+// (R row-major interleaved with t: r00 r01 r02 tx r10 r11 r12 ty r20 r21 r22 tz); rows containing
+// "inf"/"nan" are invalid poses (R = 0, t = inf) and are kept only when with_invalid is set.
+// ExportPoseT writes with the ostream default precision (6 significant digits) like the reference;
+// pass precision = 17 for a lossless file.
+bool ReadPoseT(std::string file_path, bool with_invalid, std::vector<Matrix3d>& rotation_list, std::vector<Vector3d>& trans_list,
+               std::vector<std::string>& name_list);
+void ExportPoseT(const std::string file_path, const std::vector<Matrix3d>& rotation_list, const std::vector<Vector3d>& trans_list,
+                 const std::vector<std::string>& name_list, int precision = 6);
+
 // ceres/rotation.h pieces the callers use (lidar_mapping/LidarOdometry.cpp:31,105)
 void RotationMatrixToAngleAxis(const Matrix3d& R, Vector3d* angle_axis);
 void AngleAxisToRotationMatrix(const Vector3d& angle_axis, Matrix3d* R);

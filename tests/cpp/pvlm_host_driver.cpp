@@ -136,6 +136,16 @@ int main(int argc, char** argv) {
       for (auto& p : a.GetAssociatedPairs())
         printf("pair %d %d %.9g %.17g %.17g %.17g %.17g %.17g %.17g\n", p.image_line_id, p.lidar_line_id, p.angle, p.lidar_line_start[0], p.lidar_line_start[1],
                p.lidar_line_start[2], p.lidar_line_end[0], p.lidar_line_end[1], p.lidar_line_end[2]);
+    } else if (cmd == "poseio") {
+      // poseio <in.txt> <out.txt> with_invalid precision
+      std::vector<Matrix3d> R; std::vector<Vector3d> t; std::vector<std::string> names;
+      if (!ReadPoseT(argv[2], atoi(argv[4]) != 0, R, t, names)) return 4;
+      ExportPoseT(argv[3], R, t, names, atoi(argv[5]));
+      printf("poses %zu\n", R.size());
+      for (size_t i = 0; i < R.size(); ++i) {
+        Velodyne v; v.SetPose(R[i], t[i]);
+        printf("p %zu name=%s valid=%d\n", i, names[i].c_str(), v.IsPoseValid() ? 1 : 0);
+      }
     } else if (cmd == "camlidar") {
       // camlidar <scan.bin> <lines_T.bin> rows cols weight huber_a iters : associate by angle, add the camera-LiDAR
       // residual blocks (camera pose = identity, LiDAR pose T_lw = T_cl), solve for the LiDAR pose, print costs
