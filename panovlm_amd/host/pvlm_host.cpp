@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <iomanip>
+#include <climits>
 #include <limits>
 #include <sstream>
 #include <numeric>
@@ -531,12 +532,19 @@ void Problem::AddResidualBlock(CostFunction* cost, LossFunction* loss, double* a
   const int pr = I.Pose(aa_r, t_r), pn = I.Pose(aa_n, t_n);
   if (loss) I.owned_losses.insert(loss);
   I.owned_costs.push_back(cost);
-  if (I.groups.empty() || I.groups.back().external || I.groups.back().kind != cost->kind || I.groups.back().flags != cost->flags ||
-      I.groups.back().weight != cost->weight || I.groups.back().loss != loss) {
+  // blocks are grouped by (functor, flags, weight, loss) regardless of the order they arrive in
+  // (AddCameraLidarResidual alternates two functors); inside a group the insertion order is kept.
+  int gi = -1;
+  for (int k = (int)I.groups.size() - 1; k >= 0; --k) {
+    const Impl::Group& c = I.groups[k];
+    if (!c.external && !c.set && c.kind == cost->kind && c.flags == cost->flags && c.weight == cost->weight && c.loss == loss) { gi = k; break; }
+  }
+  if (gi < 0) {
     Impl::Group g; g.kind = cost->kind; g.flags = cost->flags; g.weight = cost->weight; g.loss = loss; g.off.push_back(0);
     I.groups.push_back(g);
+    gi = (int)I.groups.size() - 1;
   }
-  Impl::Group& g = I.groups.back();
+  Impl::Group& g = I.groups[gi];
   if (g.ref.empty() || g.ref.back() != pr || g.nei.back() != pn) { g.ref.push_back(pr); g.nei.push_back(pn); g.off.push_back(g.off.back()); }
   g.rows.insert(g.rows.end(), cost->row.begin(), cost->row.end());
   g.off.back() += 1;
@@ -1250,6 +1258,142 @@ void CameraLidarLineAssociate::UniqueLinePair(const std::vector<std::array<float
     lp.image_line_id = kv.first; lp.lidar_line_id = kv.second.idx; lp.angle = kv.second.score;
     line_pairs.push_back(lp);
   }
+}
+
+
+// ================================================================================================
+// CameraLidarOptimizer (mapping mode) — joint_optimization/CameraLidarOptimizer.cpp:260-285, :331-548, :551-566
+// ================================================================================================
+static Matrix4d Mul4(const Matrix4d& A, const Matrix4d& B) {
+  Matrix4d C;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j]; C[4 * i + j] = s; }
+  return C;
+}
+
+std::vector<std::vector<int>> CameraLidarOptimizer::NeighborEachFrame(const int neighbor_size, const bool temporal) const {
+  std::vector<std::vector<int>> out(frames.size());
+  if (!temporal) throw std::runtime_error("NeighborEachFrame: only the temporal branch (the one JointOptimize uses) is mirrored");
+  for (int frame_id = 0; frame_id < (int)frames.size(); frame_id++) {
+    int start = std::max(0, frame_id - (neighbor_size / 2));
+    const int end = std::min((int)lidars.size(), start + neighbor_size);
+    start = std::max(0, end - neighbor_size);
+    for (int l = start; l < end; l++) out[frame_id].push_back(l);
+  }
+  return out;
+}
+
+CameraLidarOptimizer::LinePairs CameraLidarOptimizer::AssociateLineMulti(const int neighbor_size, const bool temporal) {
+  const std::vector<std::vector<int>> nb = NeighborEachFrame(neighbor_size, temporal);
+  LinePairs all;
+  for (size_t f = 0; f < frames.size(); f++) {
+    for (const int lid : nb[f]) {
+      const Velodyne& lidar = lidars[lid];
+      Matrix4d T_cl = T_cl_init;
+      if (frames[f].IsPoseValid() && lidar.IsPoseValid()) T_cl = Mul4(Inverse4(frames[f].GetPose()), lidar.GetPose());
+      CameraLidarLineAssociate associate(frames[f].rows, frames[f].cols);
+      if (!lidar.edge_segmented.empty()) associate.AssociateByAngle(frames[f].lines, lidar, T_cl, true);
+      all[{f, (size_t)lid}] = associate.GetAssociatedPairs();
+    }
+  }
+  return all;
+}
+
+int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const bool refine_camera_rotation, const bool refine_camera_trans,
+                                   const bool refine_lidar_rotation, const bool refine_lidar_trans, double& cost, int& steps) {
+  std::vector<Vector3d> aa_cw(frames.size(), Vector3d{0, 0, 0}), t_cw(frames.size(), Vector3d{0, 0, 0});
+  std::vector<Vector3d> aa_lw(lidars.size(), Vector3d{0, 0, 0}), t_lw(lidars.size(), Vector3d{0, 0, 0});
+  std::vector<bool> frame_valid(frames.size());
+  for (size_t i = 0; i < frames.size(); i++) {
+    frame_valid[i] = frames[i].IsPoseValid();
+    if (!frame_valid[i]) continue;
+    const Matrix3d& R = frames[i].R_wc;
+    const Matrix3d R_cw = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+    RotationMatrixToAngleAxis(R_cw, &aa_cw[i]);
+    const Vector3d rt = MatVec(R_cw, frames[i].t_wc);
+    t_cw[i] = {-rt[0], -rt[1], -rt[2]};
+  }
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    const Matrix3d& R = lidars[i].GetRotation();
+    const Matrix3d R_lw = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+    RotationMatrixToAngleAxis(R_lw, &aa_lw[i]);
+    const Vector3d rt = MatVec(R_lw, lidars[i].GetTranslation());
+    t_lw[i] = {-rt[0], -rt[1], -rt[2]};
+    lidars[i].Transform2LidarWorld();
+  }
+  ceres_like::Problem problem;
+  ceres_like::LossFunction* loss1 = new ceres_like::HuberLoss(3 * M_PI / 180.0);
+  const size_t n_cl = AddCameraLidarResidual(frames.empty() ? 0 : frames[0].rows, frames.empty() ? 0 : frames[0].cols, frame_valid, lidars, aa_cw, t_cw,
+                                             aa_lw, t_lw, line_pairs, loss1, problem, config.camera_lidar_weight);
+  if (n_cl == 0) delete loss1;
+  const std::vector<std::vector<int>> neighbors = FindNeighbors(lidars, 6);
+  if (config.line_to_line_residual) {
+    LidarLineMatch matcher(lidars);
+    matcher.SetNeighborSize(4);
+    matcher.SetMinTrackLength(3);
+    matcher.GenerateTracks();
+    AddLidarLineToLineResidual2(neighbors, lidars, aa_lw, t_lw, problem, matcher.GetTracks(), config.point_to_line_dis_threshold, config.angle_residual,
+                                config.normalize_distance);   // lidar_weight is NOT passed here (CameraLidarOptimizer.cpp:452-453)
+  }
+  if (config.point_to_plane_residual)
+    AddLidarPointToPlaneResidual(neighbors, lidars, aa_lw, t_lw, problem, config.point_to_plane_dis_threshold, config.lidar_plane_tolerance,
+                                 config.angle_residual, config.normalize_distance, config.lidar_weight);
+  for (size_t i = 0; i < frames.size(); i++)
+    if (frame_valid[i]) {
+      if (!refine_camera_rotation) problem.SetParameterBlockConstant(aa_cw[i].data());
+      if (!refine_camera_trans) problem.SetParameterBlockConstant(t_cw[i].data());
+    }
+  for (size_t i = 0; i < lidars.size(); i++)
+    if (lidars[i].IsPoseValid() && lidars[i].valid) {
+      if (!refine_lidar_rotation) problem.SetParameterBlockConstant(aa_lw[i].data());
+      if (!refine_lidar_trans) problem.SetParameterBlockConstant(t_lw[i].data());
+    }
+  if (!frames.empty()) { problem.SetParameterBlockConstant(aa_cw[0].data()); problem.SetParameterBlockConstant(t_cw[0].data()); }   // :490-491
+  last_blocks_ = problem.NumResidualBlocks();
+  ceres_like::Solver::Options options;   // SetOptionsSfM: Ceres defaults (50 iterations), sparse Schur
+  options.num_threads = config.num_threads;
+  ceres_like::Solver::Summary summary;
+  ceres_like::Solve(options, &problem, &summary);
+  if (!summary.IsSolutionUsable()) return 0;
+  for (size_t i = 0; i < frames.size(); i++) {
+    if (!frame_valid[i]) continue;
+    Matrix3d R_cw;
+    AngleAxisToRotationMatrix(aa_cw[i], &R_cw);
+    frames[i].R_wc = {R_cw[0], R_cw[3], R_cw[6], R_cw[1], R_cw[4], R_cw[7], R_cw[2], R_cw[5], R_cw[8]};
+    const Vector3d rt = MatVec(frames[i].R_wc, t_cw[i]);
+    frames[i].t_wc = {-rt[0], -rt[1], -rt[2]};
+  }
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid()) continue;
+    if (lidars[i].IsInWorldCoordinate()) lidars[i].Transform2Local();
+    Matrix3d R_lw;
+    AngleAxisToRotationMatrix(aa_lw[i], &R_lw);
+    const Matrix3d R_wl = {R_lw[0], R_lw[3], R_lw[6], R_lw[1], R_lw[4], R_lw[7], R_lw[2], R_lw[5], R_lw[8]};
+    const Vector3d rt = MatVec(R_wl, t_lw[i]);
+    lidars[i].SetPose(R_wl, {-rt[0], -rt[1], -rt[2]});
+  }
+  cost = summary.final_cost;
+  steps = summary.num_successful_steps;
+  return 1;
+}
+
+bool CameraLidarOptimizer::JointOptimize() {
+  double last_cost = 0, curr_cost = 0;
+  int last_step = INT32_MAX, curr_step = INT32_MAX;
+  LinePairs pairs = AssociateLineMulti(neighbor_size_joint, true);
+  for (int iter = 0; iter < num_iteration_joint; iter++) {
+    size_t npairs = 0;
+    for (auto& kv : pairs) npairs += kv.second.size();
+    Optimize(pairs, true, true, true, true, curr_cost, curr_step);
+    log.push_back({curr_cost, curr_step, last_blocks_, npairs});
+    pairs.clear();
+    pairs = AssociateLineMulti(neighbor_size_joint, true);
+    if (std::fabs(curr_cost - last_cost) / last_cost < 0.01) break;
+    if (curr_step < 5 && last_step < 5) break;
+    last_cost = curr_cost;
+    last_step = curr_step;
+  }
+  return true;
 }
 
 }  // namespace pvlm

@@ -302,4 +302,45 @@ class CameraLidarLineAssociate {
   std::vector<CameraLidarLinePair> line_pairs;
 };
 
+
+// ---- joint_optimization/CameraLidarOptimizer.h (mapping mode) --------------------------------------------------
+// sensors/Frame.h contract as far as the path needs it: image size, pose T_wc, the detected image lines
+// (image_lines_all[frame].GetLines()).
+struct Frame {
+  int id = 0, rows = 2880, cols = 5760;
+  Matrix3d R_wc{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  Vector3d t_wc{{0, 0, 0}};
+  bool pose_valid = true;
+  std::vector<std::array<float, 4>> lines;
+  bool IsPoseValid() const { return pose_valid; }
+  Matrix4d GetPose() const { return {R_wc[0], R_wc[1], R_wc[2], t_wc[0], R_wc[3], R_wc[4], R_wc[5], t_wc[1], R_wc[6], R_wc[7], R_wc[8], t_wc[2], 0, 0, 0, 1}; }
+};
+
+class CameraLidarOptimizer {
+ public:
+  using LinePairs = std::map<std::pair<size_t, size_t>, std::vector<CameraLidarLinePair>>;
+  // LiDAR scans are handed in in their LOCAL frame with feature clouds + segments (ExtractLidarLines, :151-175)
+  CameraLidarOptimizer(const Matrix4d& T_cl, const std::vector<Velodyne>& lidars, const std::vector<Frame>& frames, const Config& config,
+                       int neighbor_size_joint = 3, int num_iteration_joint = 5)
+      : T_cl_init(T_cl), lidars(lidars), frames(frames), config(config), neighbor_size_joint(neighbor_size_joint), num_iteration_joint(num_iteration_joint) {}
+  // JointOptimize(true), MAPPING mode loop of CameraLidarOptimizer.cpp:260-285.  The SfM reprojection term
+  // (AddCameraResidual, free 3-D points) is outside the hot path's scope and not added.
+  bool JointOptimize();
+  std::vector<std::vector<int>> NeighborEachFrame(const int neighbor_size, const bool temporal) const;   // :551-610 (temporal branch)
+  LinePairs AssociateLineMulti(const int neighbor_size, const bool temporal = true);                      // :331-384
+  int Optimize(const LinePairs& line_pairs, const bool refine_camera_rotation, const bool refine_camera_trans, const bool refine_lidar_rotation,
+               const bool refine_lidar_trans, double& cost, int& steps);                                   // :387-548
+  const std::vector<Velodyne>& GetLidars() const { return lidars; }
+  const std::vector<Frame>& GetFrames() const { return frames; }
+  struct IterLog { double cost; int steps; int residual_blocks; size_t line_pairs; };
+  std::vector<IterLog> log;
+ private:
+  Matrix4d T_cl_init;
+  std::vector<Velodyne> lidars;
+  std::vector<Frame> frames;
+  Config config;
+  int neighbor_size_joint, num_iteration_joint;
+  int last_blocks_ = 0;
+};
+
 }  // namespace pvlm

@@ -136,6 +136,35 @@ int main(int argc, char** argv) {
       for (auto& p : a.GetAssociatedPairs())
         printf("pair %d %d %.9g %.17g %.17g %.17g %.17g %.17g %.17g\n", p.image_line_id, p.lidar_line_id, p.angle, p.lidar_line_start[0], p.lidar_line_start[1],
                p.lidar_line_start[2], p.lidar_line_end[0], p.lidar_line_end[1], p.lidar_line_end[2]);
+    } else if (cmd == "joint") {
+      // joint <lidars.bin (LOCAL)> <frames.bin> neighbor_size iters l2l p2plane tol thr thr_line lidar_w cam_lidar_w
+      auto l = LoadScans(argv[2]);
+      std::ifstream f(argv[3], std::ios::binary);
+      Matrix4d T; rd(f, T.data(), 16);
+      int32_t nf = 0; rd(f, &nf, 1);
+      std::vector<Frame> frames(nf);
+      for (auto& fr : frames) {
+        int32_t h[4]; rd(f, h, 4);
+        fr.id = h[0]; fr.rows = h[1]; fr.cols = h[2]; fr.pose_valid = h[3] != 0;
+        rd(f, fr.R_wc.data(), 9); rd(f, fr.t_wc.data(), 3);
+        int32_t nl = 0; rd(f, &nl, 1);
+        fr.lines.resize(nl);
+        for (auto& x : fr.lines) rd(f, x.data(), 4);
+      }
+      Config cfg;
+      cfg.line_to_line_residual = atoi(argv[6]) != 0; cfg.point_to_plane_residual = atoi(argv[7]) != 0;
+      cfg.lidar_plane_tolerance = atof(argv[8]); cfg.point_to_plane_dis_threshold = atof(argv[9]); cfg.point_to_line_dis_threshold = atof(argv[10]);
+      cfg.lidar_weight = atof(argv[11]); cfg.camera_lidar_weight = atof(argv[12]);
+      CameraLidarOptimizer opt(T, l, frames, cfg, atoi(argv[4]), atoi(argv[5]));
+      opt.JointOptimize();
+      for (auto& it : opt.log) printf("iter cost %.17g steps %d blocks %d pairs %zu\n", it.cost, it.steps, it.residual_blocks, it.line_pairs);
+      PrintPoses(opt.GetLidars());
+      for (const Frame& fr : opt.GetFrames()) {
+        printf("frame %d", fr.id);
+        for (double x : fr.R_wc) printf(" %.17g", x);
+        for (double x : fr.t_wc) printf(" %.17g", x);
+        printf("\n");
+      }
     } else if (cmd == "poseio") {
       // poseio <in.txt> <out.txt> with_invalid precision
       std::vector<Matrix3d> R; std::vector<Vector3d> t; std::vector<std::string> names;

@@ -52,3 +52,17 @@ def run(*args, timeout=600):
     if out.returncode != 0:
         raise RuntimeError("driver failed (%d): %s" % (out.returncode, out.stderr[-2000:]))
     return out.stdout.splitlines()
+
+
+def write_frames(path, T_cl, frames):
+    """frames: list of dict(id, rows, cols, valid, R_wc, t_wc, lines (n x 4 float32))."""
+    with open(path, "wb") as f:
+        f.write(np.asarray(T_cl, np.float64).reshape(16).tobytes())
+        f.write(struct.pack("<i", len(frames)))
+        for fr in frames:
+            f.write(struct.pack("<iiii", int(fr["id"]), int(fr["rows"]), int(fr["cols"]), int(fr.get("valid", 1))))
+            f.write(np.asarray(fr["R_wc"], np.float64).reshape(9).tobytes())
+            f.write(np.asarray(fr["t_wc"], np.float64).reshape(3).tobytes())
+            lines = np.asarray(fr["lines"], np.float32).reshape(-1, 4)
+            f.write(struct.pack("<i", len(lines)))
+            f.write(lines.tobytes())

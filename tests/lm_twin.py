@@ -261,3 +261,109 @@ def refine_pose_lines(oracle, scans, thr=0.3, normalize=True):
         rt = np.array([(R_wl[r, 0] * t[i][0] + R_wl[r, 1] * t[i][1]) + R_wl[r, 2] * t[i][2] for r in range(3)])
         s["R_wl"] = R_wl; s["t_wl"] = -rt
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+# CameraLidarOptimizer (mapping mode, no SfM term): AssociateLineMulti + Optimize + JointOptimize
+# ------------------------------------------------------------------------------------------------
+def pose4(R, t):
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return T
+
+
+def associate_line_multi(oracle, lidars, frames, T_cl_init, neighbor_size):
+    out = {}
+    L = len(lidars)
+    for f, fr in enumerate(frames):
+        start = max(0, f - neighbor_size // 2); end = min(L, start + neighbor_size); start = max(0, end - neighbor_size)
+        for lid in range(start, end):
+            s = lidars[lid]
+            T_cl = np.linalg.inv(pose4(fr["R_wc"], fr["t_wc"])) @ pose4(s["R_wl"], s["t_wl"])
+            local = dict(corner_xyz=s["corner_cur"], p2s=s["p2s"], seg_size=np.array([len(x) for x in s["seg_points"]], np.int32),
+                         seg_coeffs=s["seg_coeffs"], end_points=s["end_points"])
+            out[(f, lid)] = (oracle.assoc_by_angle(fr["rows"], fr["cols"], fr["lines"], local, T_cl, multiple=True), fr["lines"])
+    return out
+
+
+def joint_optimize_step(oracle, lidars, frames, pairs, cfg):
+    Fc, L = len(frames), len(lidars)
+    aa = np.zeros((Fc + L, 3)); t = np.zeros((Fc + L, 3))
+    for i, fr in enumerate(frames):
+        Rl, tl = inv_pose(fr["R_wc"], fr["t_wc"]); aa[i] = oracle.matrix_to_angle_axis(Rl); t[i] = tl
+    for i, s in enumerate(lidars):
+        Rl, tl = inv_pose(s["R_wl"], s["t_wl"]); aa[Fc + i] = oracle.matrix_to_angle_axis(Rl); t[Fc + i] = tl
+    groups = []
+    r4, r5, rid, nid = [], [], [], []
+    w = cfg["camera_lidar_weight"]
+    for (f, lid), (o, lines) in sorted(pairs.items()):
+        fr = frames[f]
+        for k, li in enumerate(o["image_line_id"]):
+            px = np.asarray(lines[li], np.float64)
+            p1 = oracle.image_to_cam(fr["rows"], fr["cols"], px[None, 0:2], 1.0)[0]; p2 = oracle.image_to_cam(fr["rows"], fr["cols"], px[None, 2:4], 1.0)[0]
+            pl = np.cross(p2 - p1, -p1); plane = np.concatenate([pl, [-(pl @ p1)]])
+            st, en = o["start"][k], o["end"][k]
+            r4.append(np.concatenate([plane[:3], en, st, [1.0 * w]]))
+            c = float(np.clip(p1 @ p2, -1, 1))
+            r5.append(np.concatenate([plane, (en + st) / 2, (p1 + p2) / 2, [np.arccos(c)], [2.0 * w]]))
+            rid.append(f); nid.append(Fc + lid)
+    a3 = 3 * np.pi / 180
+    if r4:
+        groups.append(dict(kind=4, normalize=False, rows=np.array(r4), rid=np.array(rid, np.int32), nid=np.array(nid, np.int32), loss=1, a=a3))
+        groups.append(dict(kind=5, normalize=False, rows=np.array(r5), rid=np.array(rid, np.int32), nid=np.array(nid, np.int32), loss=1, a=a3))
+    blocks = 2 * len(r4)
+    # Optimize moves every valid scan to the world frame (Transform2LidarWorld) whatever terms are enabled
+    world = [dict(id=s["id"], R_wl=s["R_wl"], t_wl=s["t_wl"], flat_xyz=transform_f32(s["flat_cur"], s["R_wl"], s["t_wl"]), flat_tag=s["flat_tag"],
+                  less_xyz=transform_f32(s["less_cur"], s["R_wl"], s["t_wl"]), less_tag=s["less_tag"],
+                  corner_xyz=transform_f32(s["corner_cur"], s["R_wl"], s["t_wl"])) for s in lidars]
+    if cfg["p2plane"]:
+        poses = np.array([np.concatenate([s["R_wl"].reshape(-1), s["t_wl"]]) for s in lidars])
+        nb = oracle.find_neighbors(poses, np.ones(L, np.int32), 6)
+        rows, rr, nn = [], [], []
+        for i in range(L):
+            for n_idx in nb[i]:
+                if n_idx < 0 or n_idx == i or n_idx >= L:
+                    continue
+                o = oracle.assoc_point2plane(world[i], world[n_idx], cfg["tol"], cfg["thr"])
+                m = len(o["qidx"])
+                rows.append(np.concatenate([o["point"], o["plane"], np.full((m, 1), cfg["lidar_weight"])], axis=1))
+                rr += [Fc + i] * m; nn += [Fc + n_idx] * m
+        rows = np.concatenate(rows)
+        groups.append(dict(kind=1, normalize=True, rows=rows, rid=np.array(rr, np.int32), nid=np.array(nn, np.int32), loss=1, a=2 * np.pi / 180))
+        blocks += len(rows)
+    opt = Options(); opt.max_num_iterations = 50
+    res = solve(oracle, groups, aa, t, {0}, opt)
+    res["blocks"] = blocks
+    for i, fr in enumerate(frames):
+        R_cw = oracle.angle_axis_to_matrix(aa[i]); R_wc = R_cw.T.copy()
+        rt = np.array([(R_wc[r, 0] * t[i][0] + R_wc[r, 1] * t[i][1]) + R_wc[r, 2] * t[i][2] for r in range(3)])
+        fr["R_wc"] = R_wc; fr["t_wc"] = -rt
+    for i, s in enumerate(lidars):
+        Rl, tl = inv_pose(s["R_wl"], s["t_wl"])   # Transform2Local with the OLD pose: the float clouds round-trip
+        s["flat_cur"] = transform_f32(world[i]["flat_xyz"], Rl, tl); s["less_cur"] = transform_f32(world[i]["less_xyz"], Rl, tl)
+        s["corner_cur"] = transform_f32(world[i]["corner_xyz"], Rl, tl)
+        R_lw = oracle.angle_axis_to_matrix(aa[Fc + i]); R_wl = R_lw.T.copy()
+        rt = np.array([(R_wl[r, 0] * t[Fc + i][0] + R_wl[r, 1] * t[Fc + i][1]) + R_wl[r, 2] * t[Fc + i][2] for r in range(3)])
+        s["R_wl"] = R_wl; s["t_wl"] = -rt
+    return res
+
+
+def joint_optimize(oracle, lidars, frames, T_cl_init, cfg, neighbor_size, iters):
+    for s in lidars:
+        s["corner_cur"] = np.asarray(s["corner_local"], np.float32)
+        s["flat_cur"] = np.asarray(s.get("flat_local", np.zeros((0, 3))), np.float32); s["less_cur"] = np.asarray(s.get("less_local", np.zeros((0, 3))), np.float32)
+    log = []
+    last_cost, last_step = 0.0, 2 ** 31 - 1
+    pairs = associate_line_multi(oracle, lidars, frames, T_cl_init, neighbor_size)
+    for _ in range(iters):
+        npairs = sum(len(o["image_line_id"]) for o, _ in pairs.values())
+        res = joint_optimize_step(oracle, lidars, frames, pairs, cfg)
+        res["pairs"] = npairs
+        log.append(res)
+        pairs = associate_line_multi(oracle, lidars, frames, T_cl_init, neighbor_size)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if abs(res["final_cost"] - last_cost) / last_cost < 0.01:
+                break
+        if res["successful"] < 5 and last_step < 5:
+            break
+        last_cost, last_step = res["final_cost"], res["successful"]
+    return log

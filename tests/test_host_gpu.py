@@ -232,3 +232,58 @@ def test_line_to_line_refine_matches_cpu_twin(oracle, tmp):
     for k, s in enumerate(twin):
         R = poses[k][:9].reshape(3, 3); t = poses[k][9:]
         assert np.abs(R - s["R_wl"]).max() <= 1e-6 and np.abs(t - s["t_wl"]).max() <= 1e-6 * max(1.0, np.abs(s["t_wl"]).max())
+
+
+def _joint_scene(rng, n):
+    """n LiDAR scans (VLP plane clouds + line segments) and n panoramas looking at the same world lines."""
+    rows, cols = 2880, 5760
+    lw = synth.random_world_lines(rng, 10, extent=3.0)
+    a = np.deg2rad(np.array([1.0, -2.0, 0.5])); T_cl = np.eye(4); T_cl[:3, :3] = synth.rodrigues(a); T_cl[:3, 3] = [0.03, -0.02, 0.05]
+    lidars, frames = [], []
+    for k in range(n):
+        base = _vlp(k, 256)
+        ls = synth.make_line_scan(rng, k, base["R_wl"], base["t_wl"], lw, pts_per_line=(20, 40), extra_pts=20, noise=0.004, shared_frac=0.0)
+        seg_points = [[i for i, l in enumerate(ls["p2s"]) if sid in l] for sid in range(len(ls["seg_size"]))]
+        base.update(corner_local=ls["corner_local"], p2s=ls["p2s"], seg_points=seg_points, seg_coeffs=ls["seg_coeffs"], end_points=ls["end_points"])
+        lidars.append(base)
+        R_true, t_true = sy.true_pose(k)
+        T_wc = lm_twin.pose4(R_true, t_true) @ np.linalg.inv(T_cl)          # the camera sees the TRUE geometry
+        T_cw = np.linalg.inv(T_wc)
+        ends = np.array([np.concatenate([T_cw[:3, :3] @ p + T_cw[:3, 3], T_cw[:3, :3] @ q + T_cw[:3, 3]]) for p, q in lw]).reshape(-1, 3)
+        px = oracle_cam_to_image(rows, cols, ends).reshape(-1, 4).astype(np.float32) + rng.normal(size=(len(lw), 4)).astype(np.float32) * 1.5
+        # estimated camera pose = estimated LiDAR pose composed with the calibration (SetFramePose upstream)
+        T_wc_est = lm_twin.pose4(base["R_wl"], base["t_wl"]) @ np.linalg.inv(T_cl)
+        frames.append(dict(id=k, rows=rows, cols=cols, valid=1, R_wc=T_wc_est[:3, :3].copy(), t_wc=T_wc_est[:3, 3].copy(), lines=px))
+    return lidars, frames, T_cl
+
+
+def oracle_cam_to_image(rows, cols, pts):
+    from oracle import oracle as orc
+    return orc.cam_to_image(rows, cols, np.asarray(pts, np.float64))
+
+
+def test_joint_optimize_matches_cpu_twin(oracle, tmp):
+    """CameraLidarOptimizer::JointOptimize (mapping mode without the SfM term): AssociateLineMulti on the GPU voting
+    kernel, camera-LiDAR + LiDAR-LiDAR point-to-plane blocks, host LM — against the oracle twin."""
+    rng = np.random.default_rng(77)
+    lidars, frames, T_cl = _joint_scene(rng, 3)
+    lpath, fpath = os.path.join(tmp, "jl.bin"), os.path.join(tmp, "jf.bin")
+    host_io.write_scans(lpath, lidars, world=False)
+    host_io.write_frames(fpath, T_cl, frames)
+    out = host_io.run("joint", lpath, fpath, 3, 2, 0, 1, 0.05, 1.0, 0.3, 1.0, 2.0)
+    iters = [l.split() for l in out if l.startswith("iter")]
+    lposes = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    fposes = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("frame")}
+    tl = [dict(s) for s in lidars]; tf = [dict(f) for f in frames]
+    cfg = dict(p2plane=True, tol=0.05, thr=1.0, lidar_weight=1.0, camera_lidar_weight=2.0)
+    log = lm_twin.joint_optimize(oracle, tl, tf, T_cl, cfg, 3, 2)
+    assert len(iters) == len(log) >= 1
+    for it, lg in zip(iters, log):
+        assert int(it[8]) == lg["pairs"] > 10
+        assert int(it[6]) == lg["blocks"]
+        assert abs(float(it[2]) - lg["final_cost"]) <= 1e-6 * lg["final_cost"]
+        assert int(it[4]) == lg["successful"]
+    for k in range(3):
+        assert np.abs(lposes[k][:9].reshape(3, 3) - tl[k]["R_wl"]).max() <= 1e-6 and np.abs(lposes[k][9:] - tl[k]["t_wl"]).max() <= 1e-6
+        assert np.abs(fposes[k][:9].reshape(3, 3) - tf[k]["R_wc"]).max() <= 1e-6 and np.abs(fposes[k][9:] - tf[k]["t_wc"]).max() <= 1e-6
+    assert np.allclose(fposes[0][9:], frames[0]["t_wc"])    # camera 0 is the gauge
