@@ -72,24 +72,57 @@ __global__ void k_hash_insert(int n, const float* __restrict__ xyz, float ox, fl
   slot_of[i] = s;
 }
 
-// single-block exclusive scan of count[T] -> start[T]  (T <= 2^22)
-__global__ __launch_bounds__(1024) void k_scan_counts(int T, const int* __restrict__ count, int* __restrict__ start) {
+// exclusive scan of count[T] -> start[T] in three small launches (tile sums, scan of the tile sums by
+// one block, per-tile scan + offset): T reaches 4 M cells for dense grids, a single block walking it
+// serially cost 220 us per cloud.
+#define SCAN_TILE 2048
+__global__ __launch_bounds__(256) void k_scan_tile_sums(int T, const int* __restrict__ count, int* __restrict__ tile_sum) {
+  __shared__ int red[256];
+  const int base = blockIdx.x * SCAN_TILE;
+  int s = 0;
+  for (int i = threadIdx.x; i < SCAN_TILE; i += 256) if (base + i < T) s += count[base + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(1024) void k_scan_small(int n, int* __restrict__ v) {  // in-place exclusive scan, n <= 1024 * per
   __shared__ int part[1024];
   const int t = threadIdx.x;
-  const int per = (T + 1023) / 1024;
-  const int lo = t * per, hi = min(T, lo + per);
+  const int per = (n + 1023) / 1024;
+  const int lo = t * per, hi = min(n, lo + per);
   int s = 0;
-  for (int i = lo; i < hi; ++i) s += count[i];
+  for (int i = lo; i < hi; ++i) s += v[i];
   part[t] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    const int v = (t >= off) ? part[t - off] : 0;
+    const int x = (t >= off) ? part[t - off] : 0;
     __syncthreads();
-    part[t] += v;
+    part[t] += x;
     __syncthreads();
   }
   int run = part[t] - s;
-  for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
+  for (int i = lo; i < hi; ++i) { const int c = v[i]; v[i] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void k_scan_tiles(int T, const int* __restrict__ count, const int* __restrict__ tile_off, int* __restrict__ start) {
+  __shared__ int part[256];
+  const int base = blockIdx.x * SCAN_TILE, t = threadIdx.x;
+  const int per = SCAN_TILE / 256;
+  int loc[SCAN_TILE / 256];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < per; ++k) { const int i = base + t * per + k; loc[k] = i < T ? count[i] : 0; s += loc[k]; }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int x = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += x;
+    __syncthreads();
+  }
+  int run = tile_off[blockIdx.x] + part[t] - s;
+#pragma unroll
+  for (int k = 0; k < per; ++k) { const int i = base + t * per + k; if (i < T) start[i] = run; run += loc[k]; }
 }
 
 // Points take their slot inside the cell by atomic cursor: the order inside a cell varies from run
@@ -103,7 +136,7 @@ __global__ void k_scatter(int n, const float* __restrict__ xyz, const int* __res
   sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
 }
 
-// dense grid variant of K1: linear cell index, counts, scatter (the scan is k_scan_counts)
+// dense grid variant of K1: linear cell index, counts, scatter (the scan is launch_scan)
 __global__ void k_dense_count(int n, const float* __restrict__ xyz, float ox, float oy, float oz, float inv_h, int nx, int ny, int nz,
                               int* __restrict__ count, int* __restrict__ cell_of_pt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -529,6 +562,13 @@ __global__ __launch_bounds__(256) void k_compact(const PairDesc* __restrict__ pa
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static void launch_scan(pvlm_ctx* ctx, int T, const int* count, int* start, int* tiles) {
+  const int nt = (T + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(nt), dim3(256), 0, ctx->stream, T, count, tiles);
+  hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, nt, tiles);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(256), 0, ctx->stream, T, count, tiles, start);
+}
+
 static void cloud_free(pvlm_cloud& c) {
   hipFree(c.d_xyz); hipFree(c.d_tag); hipFree(c.d_keys); hipFree(c.d_cell_start); hipFree(c.d_cell_count); hipFree(c.d_sorted);
   c = pvlm_cloud();
@@ -564,7 +604,8 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
   const long long ncells = dims[0] * dims[1] * dims[2];
   const bool dense = ncells <= std::max<long long>(64ll * n, 4096) && ncells <= (4ll << 20) && !getenv("PVLM_FORCE_HASH");
   if ((st = pvlm_i_alloc(ctx, &c.d_sorted, (size_t)n))) return st;
-  int *d_slot = nullptr, *d_cursor = nullptr;
+  int *d_slot = nullptr, *d_cursor = nullptr, *d_tiles = nullptr;
+  if ((st = pvlm_i_alloc(ctx, &d_tiles, (size_t)((4ll << 20) / SCAN_TILE + 4096)))) return st;
   hipError_t le = hipSuccess, se = hipSuccess;
   if (dense) {
     c.dense = 1; c.nx = (int)dims[0]; c.ny = (int)dims[1]; c.nz = (int)dims[2];
@@ -573,13 +614,13 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
     if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
-    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); return st; }
+    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); hipFree(d_tiles); return st; }
     hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
     hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
     if (e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
     hipLaunchKernelGGL(k_dense_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h, c.nx,
                        c.ny, c.nz, c.d_cell_count, d_slot);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, T, c.d_cell_count, c.d_cell_start);
+    launch_scan(ctx, T, c.d_cell_count, c.d_cell_start, d_tiles);
     hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
     le = hipGetLastError();
     se = hipStreamSynchronize(ctx->stream);
@@ -591,19 +632,19 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
     if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
-    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); return st; }
+    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); hipFree(d_tiles); return st; }
     hipError_t e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
     hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
     hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
     hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h,
                        T - 1, c.d_keys, c.d_cell_count, d_slot);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, T, c.d_cell_count, c.d_cell_start);
+    launch_scan(ctx, T, c.d_cell_count, c.d_cell_start, d_tiles);
     hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
     le = hipGetLastError();
     se = hipStreamSynchronize(ctx->stream);
   }
-  hipFree(d_slot); hipFree(d_cursor);
+  hipFree(d_slot); hipFree(d_cursor); hipFree(d_tiles);
   if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }
