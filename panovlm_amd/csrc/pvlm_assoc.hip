@@ -149,27 +149,34 @@ __global__ void k_dense_count(int n, const float* __restrict__ xyz, float ox, fl
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------
+// Sorted top-K of (distance, index) pairs.  A squared distance is a non-negative float, whose bit
+// pattern orders like the value, so (float bits << 32 | index) is ONE 64-bit key that orders exactly
+// like the lexicographic (distance, index) pair the reference's sorted k-NN result implies: an
+// insertion step is a single u64 compare + select instead of a two-level comparison.
 template <int K>
 struct TopK {
-  float d[K];
-  int id[K];
+  unsigned long long key[K];
   int cnt;
   __device__ __forceinline__ void init() {
     cnt = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { d[k] = INFINITY; id[k] = -1; }
+    for (int k = 0; k < K; ++k) key[k] = 0x7F800000FFFFFFFFull;  // (+inf, idx -1)
   }
-  // ordered by (distance, index) ascending
   __device__ __forceinline__ void push(float dist, int idx) {
-    if (!(dist < d[K - 1] || (dist == d[K - 1] && (unsigned)idx < (unsigned)id[K - 1]))) return;
-    d[K - 1] = dist; id[K - 1] = idx;
+    const unsigned long long c = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx;
+    if (!(c < key[K - 1])) return;
+    key[K - 1] = c;
 #pragma unroll
     for (int k = K - 1; k > 0; --k) {
-      const bool sw = d[k] < d[k - 1] || (d[k] == d[k - 1] && (unsigned)id[k] < (unsigned)id[k - 1]);
-      if (sw) { const float td = d[k]; d[k] = d[k - 1]; d[k - 1] = td; const int ti = id[k]; id[k] = id[k - 1]; id[k - 1] = ti; }
+      const unsigned long long a = key[k - 1], b = key[k];
+      const bool sw = b < a;
+      key[k - 1] = sw ? b : a;
+      key[k] = sw ? a : b;
     }
     if (cnt < K) ++cnt;
   }
+  __device__ __forceinline__ float dist(int k) const { return __uint_as_float((unsigned)(key[k] >> 32)); }
+  __device__ __forceinline__ int index(int k) const { return (int)(unsigned)(key[k] & 0xFFFFFFFFull); }
 };
 
 template <int K>
@@ -220,8 +227,51 @@ __device__ __forceinline__ void knn_search(const CloudView& cv, float qx, float 
     }
     // every unsearched point lies outside the (2r+1)^3 block: farther than (inside + r) cells
     const float bound = (inside + (float)r) * cv.h - slack;
-    if (tk.cnt == K && bound > 0.f && tk.d[K - 1] < bound * bound) break;
+    if (tk.cnt == K && bound > 0.f && tk.dist(K - 1) < bound * bound) break;
     if ((float)r * cv.h >= max_dist * 1.0001f) break;  // everything within max_dist has been visited
+  }
+}
+
+// Same search on a dense grid whose sorted points and cell offsets have been staged in LDS by the
+// block (k_knn_pairs_lds): every cell lookup and candidate read is an LDS access.
+template <int K>
+__device__ __forceinline__ void knn_search_lds(const CloudView& cv, const float4* __restrict__ ls, const int* __restrict__ lc, float qx, float qy,
+                                               float qz, float max_dist, float thr2, TopK<K>& tk) {
+  tk.init();
+  const int cx = cell_of(qx, cv.ox, cv.inv_h), cy = cell_of(qy, cv.oy, cv.inv_h), cz = cell_of(qz, cv.oz, cv.inv_h);
+  const float fx = (qx - cv.ox) * cv.inv_h - (float)cx, fy = (qy - cv.oy) * cv.inv_h - (float)cy, fz = (qz - cv.oz) * cv.inv_h - (float)cz;
+  const float inside = fminf(fminf(fminf(fx, fy), fz), fminf(fminf(1.f - fx, 1.f - fy), 1.f - fz));
+  const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
+  const int rmax = (int)ceilf(max_dist * 1.0001f * cv.inv_h);
+  for (int r = 0; r <= rmax; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      const int z = cz + dz;
+      if (z < 0 || z >= cv.nz) continue;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= cv.ny) continue;
+        const int row = (z * cv.ny + y) * cv.nx;
+        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+        const int nseg = (face || r == 0) ? 1 : 2;
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+          int x0 = face ? cx - r : (sgi == 0 ? cx - r : cx + r);
+          int x1 = face ? cx + r : x0;
+          x0 = max(x0, 0); x1 = min(x1, cv.nx - 1);
+          if (x0 > x1) continue;
+          const int b = lc[row + x0], e = lc[row + x1 + 1];
+          for (int j = b; j < e; ++j) {
+            const float4 p = ls[j];
+            const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+            float d2 = 0.0f;
+            d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
+            if (d2 <= thr2) tk.push(d2, __float_as_int(p.w));
+          }
+        }
+      }
+    }
+    const float bound = (inside + (float)r) * cv.h - slack;
+    if (tk.cnt == K && bound > 0.f && tk.dist(K - 1) < bound * bound) break;
+    if ((float)r * cv.h >= max_dist * 1.0001f) break;
   }
 }
 
@@ -234,7 +284,7 @@ __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* 
   const float thr2 = max_dist * max_dist;
   knn_search<K>(cv, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_dist, thr2, tk);
 #pragma unroll
-  for (int k = 0; k < K; ++k) { idx[(size_t)i * K + k] = tk.id[k]; sqd[(size_t)i * K + k] = tk.d[k]; }
+  for (int k = 0; k < K; ++k) { idx[(size_t)i * K + k] = tk.index(k); sqd[(size_t)i * K + k] = tk.dist(k); }
 }
 
 // ---- K3: fp64 fits (sequential-sum Householder/Jacobi arithmetic the parity tests pin, fully unrolled, static indexing) ----
@@ -462,16 +512,43 @@ __device__ __forceinline__ void world2local(const double* R, const double* t, do
 // K2 — grid: x = chunk of 256 queries, y = pair in batch.  Exact 10-NN of every query; slot 9 is -1
 // when fewer than 10 targets lie within dist_threshold (LidarFeatureAssociate.cpp:577).  Kept apart
 // from K3 so that the register-hungry fp64 fits do not set the occupancy of the search.
-__global__ __launch_bounds__(256) void k_knn_pairs(const PairDesc* __restrict__ pairs, float dist_threshold, int* __restrict__ nn_tmp) {
+__global__ __launch_bounds__(256) void k_knn_pairs(const PairDesc* __restrict__ pairs, float dist_threshold, int* __restrict__ nn_tmp, long long tmp_rows) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= pd.nq) return;
   const float qx = pd.q_xyz[3 * q], qy = pd.q_xyz[3 * q + 1], qz = pd.q_xyz[3 * q + 2];
   TopK<10> tk;
   knn_search<10>(pd.ref, qx, qy, qz, dist_threshold, dist_threshold * dist_threshold, tk);
-  int* d = nn_tmp + (pd.tmp_base + q) * 10;
+  // neighbour table is column-major (slot k of every query contiguous): coalesced 256-byte stores per wave
 #pragma unroll
-  for (int k = 0; k < 10; ++k) d[k] = tk.id[k];
+  for (int k = 0; k < 10; ++k) nn_tmp[(size_t)k * tmp_rows + pd.tmp_base + q] = tk.index(k);
+}
+
+// K2, LDS-staged variant (opt-in, see the launch site): the whole target cloud of the pair (voxel-grid sorted float4 points + cell offsets,
+// <= 64 KiB: a 0.2 m voxel-downsampled scan is 40-60 KiB) is copied into LDS once per block of
+// KNN_LDS_QUERIES queries; the per-query walk over cells then never leaves the CU.
+#define KNN_LDS_THREADS 512
+#define KNN_LDS_QUERIES 2048
+__global__ __launch_bounds__(KNN_LDS_THREADS) void k_knn_pairs_lds(const PairDesc* __restrict__ pairs, float dist_threshold, int* __restrict__ nn_tmp,
+                                                                   long long tmp_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const PairDesc& pd = pairs[blockIdx.y];
+  const int q0 = blockIdx.x * KNN_LDS_QUERIES;
+  if (q0 >= pd.nq) return;
+  const CloudView& cv = pd.ref;
+  float4* ls = reinterpret_cast<float4*>(smem);
+  int* lc = reinterpret_cast<int*>(smem + (size_t)cv.n * sizeof(float4));
+  const int ncell1 = cv.nx * cv.ny * cv.nz + 1;
+  for (int i = threadIdx.x; i < cv.n; i += KNN_LDS_THREADS) ls[i] = cv.sorted[i];
+  for (int i = threadIdx.x; i < ncell1; i += KNN_LDS_THREADS) lc[i] = cv.cell_start[i];
+  __syncthreads();
+  const float thr2 = dist_threshold * dist_threshold;
+  for (int q = q0 + threadIdx.x; q < min(pd.nq, q0 + KNN_LDS_QUERIES); q += KNN_LDS_THREADS) {
+    TopK<10> tk;
+    knn_search_lds<10>(cv, ls, lc, pd.q_xyz[3 * q], pd.q_xyz[3 * q + 1], pd.q_xyz[3 * q + 2], dist_threshold, thr2, tk);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) nn_tmp[(size_t)k * tmp_rows + pd.tmp_base + q] = tk.index(k);
+  }
 }
 
 // K3 — class test, 10x3 plane fit, collinearity test, candidate record, accept flag and the
@@ -487,7 +564,7 @@ __global__ __launch_bounds__(256) void k_fit_pairs(const PairDesc* __restrict__ 
     const long long row = pd.tmp_base + q;
     int id[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) id[k] = nn_tmp[row * 10 + k];
+    for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
     bool ok = id[9] >= 0;
     if (ok) {
       const float qtag = pd.q_tag[q];
@@ -554,7 +631,7 @@ __global__ __launch_bounds__(256) void k_compact(const PairDesc* __restrict__ pa
       const long long o = dst_out_row[ch] + rank;
       qidx_out[o] = q;
 #pragma unroll
-      for (int k = 0; k < 10; ++k) nn_out[o * 10 + k] = nn_tmp[row * 10 + k];
+      for (int k = 0; k < 10; ++k) nn_out[o * 10 + k] = nn_tmp[(size_t)k * tmp_rows + row];
     }
   }
 }
@@ -835,7 +912,26 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     for (int p = b.p0; p < b.p1; ++p) bmax = std::max(bmax, descs[p].nq);
     if (e == hipSuccess && bmax > 0) {
       pvlm_prof_scope prof(ctx, 2);
-      hipLaunchKernelGGL(k_knn_pairs, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, dist_threshold, b.d_nn);
+      // LDS-staged search when every target cloud of the batch fits (dense grid, <= 64 KiB with its cell table)
+      size_t lds_need = 0;
+      // opt-in (PVLM_LDS_KNN=1): measured on MI355X it is not faster than the L1/L2-served search
+      // (35.0 vs 33.6 ms for 134 M queries against 2.6 k-point clouds) — the search is bound by top-k
+      // maintenance under SIMD divergence, not by memory latency — and it halves the occupancy.
+      bool lds_ok = getenv("PVLM_LDS_KNN") != nullptr;
+      for (int p = b.p0; p < b.p1 && lds_ok; ++p) {
+        const CloudView& v = descs[p].ref;
+        if (descs[p].nq == 0) continue;
+        if (!v.dense) { lds_ok = false; break; }
+        lds_need = std::max(lds_need, (size_t)v.n * sizeof(float4) + ((size_t)v.nx * v.ny * v.nz + 1) * sizeof(int));
+      }
+      if (getenv("PVLM_DEBUG")) fprintf(stderr, "[pvlm] knn batch pairs %d..%d: lds_ok=%d lds_need=%zu B\n", b.p0, b.p1, (int)lds_ok, lds_need);
+      if (lds_ok && lds_need > 64 * 1024 && lds_need <= 144 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_knn_pairs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      if (lds_ok && lds_need > 0 && lds_need <= 144 * 1024)
+        hipLaunchKernelGGL(k_knn_pairs_lds, dim3((bmax + KNN_LDS_QUERIES - 1) / KNN_LDS_QUERIES, nb), dim3(KNN_LDS_THREADS), (lds_need + 15) & ~(size_t)15,
+                           ctx->stream, b.d_desc, dist_threshold, b.d_nn, b.rows);
+      else
+        hipLaunchKernelGGL(k_knn_pairs, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, dist_threshold, b.d_nn, b.rows);
       hipLaunchKernelGGL(k_fit_pairs, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, plane_tolerance, b.d_nn, b.d_rec,
                          b.d_flag, d_cc, b.rows);
       e = hipGetLastError();
