@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scans", type=int, default=1024, help="number of scans F in the batch")
+    ap.add_argument("--scans", type=int, default=2048, help="number of scans F in the batch")
     ap.add_argument("--neighbors", type=int, default=8, help="ordered pairs per reference scan")
     ap.add_argument("--cols", type=int, default=4096, help="azimuth steps per ring (16 rings)")
     ap.add_argument("--functor", choices=["angle", "meter"], default="angle")
