@@ -211,12 +211,13 @@ class ResidualSet:
 
     @classmethod
     def upload(cls, ctx, kind, rows, pair_offsets, pair_ref, pair_nei, flags=0, weight=1.0):
-        rows = _f64(rows).reshape(-1, STRIDE[kind]) if np.size(rows) else np.zeros((0, STRIDE[kind]))
+        stride = STRIDE.get(kind, np.shape(rows)[-1] if np.ndim(rows) == 2 else 1)   # unknown kinds are rejected by the library
+        rows = _f64(rows).reshape(-1, stride) if np.size(rows) else np.zeros((0, stride))
         po = _i64(pair_offsets); pr = _i32(pair_ref); pn = _i32(pair_nei)
         h = C.c_void_p()
         ctx._check(ctx.lib.pvlm_resset_upload(ctx._h, C.c_int(kind), C.c_uint(flags), C.c_double(weight), C.c_int64(rows.shape[0]),
                                               C.c_int(len(pr)), _p(po, C.c_int64), _p(pr, C.c_int), _p(pn, C.c_int),
-                                              _p(rows, C.c_double), C.c_int(STRIDE[kind]), C.byref(h)), "pvlm_resset_upload")
+                                              _p(rows, C.c_double), C.c_int(stride), C.byref(h)), "pvlm_resset_upload")
         return cls(ctx, h)
 
     def close(self):
