@@ -133,6 +133,19 @@ pvlm_status pvlm_neq_accumulate_dev(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_res
 pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset* rs, pvlm_loss loss, double loss_a,
                                 int zero_first, double* packed_host_inout);
 
+/* ---- multi-GPU exchange (RCCL over xGMI) -------------------------------------------------------- *
+ * The reference is single-process (OpenMP only); sharding scan pairs across GPUs introduces exactly one
+ * exchange: all-reduce(sum) of the packed normal-equation buffer per LM iteration.
+ * One process per GPU.  Rank 0 obtains a 128-byte id (pvlm_comm_unique_id), the host's launcher carries
+ * it to the other ranks, every rank calls pvlm_comm_create (collective).  The all-reduce is enqueued on
+ * the ctx stream, in place, on a device buffer of `count` doubles (e.g. the d_packed of
+ * pvlm_neq_accumulate_dev).  RCCL is loaded lazily on the first pvlm_comm_* call. */
+typedef struct pvlm_comm pvlm_comm;
+pvlm_status pvlm_comm_unique_id(pvlm_ctx* ctx, unsigned char id_out[128]);
+pvlm_status pvlm_comm_create(pvlm_ctx* ctx, int world_size, int rank, const unsigned char id[128], pvlm_comm** out);
+pvlm_status pvlm_comm_destroy(pvlm_ctx* ctx, pvlm_comm* comm);
+pvlm_status pvlm_allreduce_sum_f64(pvlm_ctx* ctx, pvlm_comm* comm, double* d_buf, int64_t count);
+
 /* ---- scans and LiDAR<->LiDAR association -------------------------------------------------------- *
  * Input contract = the public members of sensors/Velodyne.h:80-91 during association: feature
  * clouds in the WORLD frame as float32 (the float buffers pcl::transformPointCloud left behind,

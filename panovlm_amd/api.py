@@ -18,7 +18,8 @@ ABI_SYMBOLS = [
     "pvlm_timer_start", "pvlm_timer_stop", "pvlm_device_info", "pvlm_profile_enable", "pvlm_profile_read", "pvlm_set_poses", "pvlm_set_poses_dev",
     "pvlm_resset_upload", "pvlm_resset_destroy", "pvlm_resset_info", "pvlm_resset_download", "pvlm_eval",
     "pvlm_eval_dev", "pvlm_eval_pair_blocks", "pvlm_eval_pair_blocks_dev", "pvlm_neq_create", "pvlm_neq_destroy",
-    "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_scan_upload", "pvlm_scan_destroy",
+    "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_comm_unique_id", "pvlm_comm_create",
+    "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_destroy",
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes",
@@ -301,6 +302,29 @@ class NormalEq:
         Hd = packed[:n * 36].reshape(n, 6, 6); Ho = packed[n * 36:(n + u) * 36].reshape(u, 6, 6)
         g = packed[(n + u) * 36:(n + u) * 36 + n * 6].reshape(n, 6)
         return Hd, Ho, g, float(packed[-1])
+
+
+class Comm:
+    """RCCL communicator of the C ABI (for hosts without their own collective layer)."""
+
+    def __init__(self, ctx, world_size, rank, unique_id=None):
+        self.ctx = ctx
+        if unique_id is None:
+            buf = (C.c_ubyte * 128)()
+            ctx._check(ctx.lib.pvlm_comm_unique_id(ctx._h, buf), "pvlm_comm_unique_id")
+            unique_id = bytes(buf)
+        self.unique_id = unique_id
+        self._h = C.c_void_p()
+        ctx._check(ctx.lib.pvlm_comm_create(ctx._h, C.c_int(world_size), C.c_int(rank), (C.c_ubyte * 128).from_buffer_copy(unique_id),
+                                            C.byref(self._h)), "pvlm_comm_create")
+
+    def allreduce_sum_f64(self, d_ptr, count):
+        self.ctx._check(self.ctx.lib.pvlm_allreduce_sum_f64(self.ctx._h, self._h, C.c_void_p(d_ptr), C.c_int64(count)), "pvlm_allreduce_sum_f64")
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.pvlm_comm_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
 
 
 class ScanDesc(C.Structure):

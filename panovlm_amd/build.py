@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on " + src)
         if verbose and out.strip():
             print(out)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return LIB
 

@@ -48,3 +48,21 @@ def test_device_pointers_on_torch_stream(oracle, use_side_stream):
     r2, J2 = rs.eval()
     assert np.array_equal(rh, r2) and np.array_equal(Jh, J2)
     rs.close(); ctx.close()
+
+
+def test_rccl_allreduce_through_the_abi_single_rank():
+    """pvlm_comm_* / pvlm_allreduce_sum_f64 (the C++ hosts' exchange) with world_size 1: RCCL loads lazily, the
+    communicator initialises and the in-place all-reduce of a packed buffer is the identity."""
+    import torch
+    import panovlm_amd as pv
+    ctx = pv.Context(0)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    comm = pv.Comm(ctx, 1, 0)
+    assert len(comm.unique_id) == 128
+    x = torch.arange(1000, dtype=torch.float64, device=dev) * 0.5
+    ref = x.clone()
+    comm.allreduce_sum_f64(x.data_ptr(), x.numel())
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    comm.close(); ctx.use_own_stream(); ctx.close()

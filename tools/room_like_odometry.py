@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Room-like end-to-end run of the mirrored LidarOdometry::EstimatePose on the GPU (BASELINE.json configs[0]/[3]
+shape: 16 x 1800 scans, <= 384 surfFlat queries per scan, 0.2 m voxel surfLessFlat targets, point-to-plane
+Angle residual, <= 7 outer iterations).  Reports wall time per stage of the C++ driver and the pose error
+before / after.  With --twin F' the first F' scans are also solved by the CPU oracle twin for a timing beside it.
+usage: python tools/room_like_odometry.py [--scans 64] [--iters 7] [--twin 0]"""
+import argparse, os, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from panovlm_amd import synthetic as sy
+from tests import host_io, lm_twin
+
+
+def room_scan(k, rng):
+    s = sy.make_scan(k, cols=1800, downsample_targets=0.2)
+    R, t = s["R_wl"], s["t_wl"]
+    Rl, tl = lm_twin.inv_pose(R, t)
+    less_local = lm_twin.transform_f32(s["less_xyz"], Rl, tl)
+    sel = np.sort(rng.choice(len(s["local_xyz"]), size=384, replace=False))   # 4 per sector x 6 sectors x 16 rings
+    flat = s["local_xyz"][sel]
+    return dict(id=k, R_wl=R, t_wl=t, flat_local=flat, flat_tag=np.ones(len(flat), np.float32), less_local=less_local,
+                less_tag=np.ones(len(less_local), np.float32))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scans", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=7)
+    ap.add_argument("--twin", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(1)
+    scans = [room_scan(k, rng) for k in range(a.scans)]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "room.bin")
+        host_io.write_scans(path, scans, world=False)
+        t0 = time.perf_counter()
+        out = host_io.run("odometry", path, a.iters, 1, 1, 0, 1, 0.05, 1.0, 0.3, timeout=3000)
+        wall = time.perf_counter() - t0
+    iters = [l for l in out if l.startswith("iter")]
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    e0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
+    e1 = np.mean([np.linalg.norm(poses[k][9:] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
+    print("GPU EstimatePose: %d scans, %d outer iterations, %.2f s wall (process start, upload, association, LM, write-back)" % (a.scans, len(iters), wall))
+    for l in iters:
+        print("  ", l)
+    print("mean translation error vs ground truth: %.4f m -> %.4f m" % (e0, e1))
+    if a.twin > 0:
+        from oracle import oracle as orc
+        tw = [dict(s) for s in scans[:a.twin]]
+        t0 = time.perf_counter()
+        log = lm_twin.estimate_pose(orc, tw, dict(angle=True, normalize=True, tol=0.05, thr=1.0), a.iters)
+        print("CPU oracle twin: %d scans, %d outer iterations, %.2f s" % (a.twin, len(log), time.perf_counter() - t0))
+
+
+if __name__ == "__main__":
+    main()
