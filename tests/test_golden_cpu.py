@@ -111,3 +111,22 @@ def test_find_neighbors_golden(oracle):
         assert l == ids[off[i]:off[i + 1]].tolist()
     assert all(i not in l for i, l in enumerate(nb) if g["valid"][i])   # self removed
     assert nb[13] == [16, 15, 14, 13, 12, 11, 10]                       # invalid pose -> temporal window (LidarFeatureAssociate.cpp:103-107)
+
+
+def test_refvec_container_round_trip(tmp_path):
+    """tools/refvec.py (re-pinning recipe against a real PanoVLM build): export -> read back == fixture inputs,
+    and `compare` accepts the fixtures' own expectations."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("refvec", os.path.join(root, "tools", "refvec.py"))
+    rv = importlib.util.module_from_spec(spec); spec.loader.exec_module(rv)
+    rv.export(str(tmp_path))
+    for fx in rv.FIXTURES:
+        z = np.load(os.path.join(rv.GOLDEN, fx + ".npz"))
+        b = rv.read_pvv(os.path.join(str(tmp_path), fx + ".in.pvv"))
+        for k, v in b.items():
+            assert np.array_equal(np.asarray(z[k], v.dtype).reshape(v.shape), v), (fx, k)
+        rv.write_pvv(os.path.join(str(tmp_path), fx + ".ref.pvv"),
+                     {k: z[k] for k in z.files if rv._is_output(fx, k) and not k.endswith(rv.INTERNAL)})
+    assert rv.compare(str(tmp_path)) == 0

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Re-pinning the oracle against a REAL PanoVLM build.
+
+The reference cannot be compiled in the development image (no Eigen/PCL/Ceres/OpenCV), so the golden
+fixtures under tests/golden/ come from the CPU oracle ("parity unpinned").  On a machine where PanoVLM
+builds, three steps re-pin them:
+
+    python tools/refvec.py export /tmp/pvv                       # fixtures' INPUTS -> flat .pvv files
+    ./dump_reference_vectors /tmp/pvv                            # tools/dump_reference_vectors.cpp, linked to PanoVLM
+    python tools/refvec.py compare /tmp/pvv                      # reference OUTPUTS vs the fixtures' expectations
+
+.pvv container: b"PVV1", u32 count, then per array: u32 name_len, name, u8 dtype (0 f32, 1 f64, 2 i32, 3 i64),
+u32 ndim, u64 dims[ndim], raw little-endian data (C order).
+"""
+import os
+import struct
+import sys
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+CODES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int32): 2, np.dtype(np.int64): 3}
+DTYPES = {v: k for k, v in CODES.items()}
+
+
+def write_pvv(path, arrays):
+    with open(path, "wb") as f:
+        f.write(b"PVV1" + struct.pack("<I", len(arrays)))
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a)
+            if a.dtype not in CODES:
+                a = a.astype(np.float64)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<BI", CODES[a.dtype], a.ndim))
+            f.write(struct.pack("<%dQ" % a.ndim, *a.shape))
+            f.write(a.tobytes())
+
+
+def read_pvv(path):
+    out = {}
+    with open(path, "rb") as f:
+        assert f.read(4) == b"PVV1"
+        (count,) = struct.unpack("<I", f.read(4))
+        for _ in range(count):
+            (nl,) = struct.unpack("<I", f.read(4))
+            name = f.read(nl).decode()
+            code, ndim = struct.unpack("<BI", f.read(5))
+            dims = struct.unpack("<%dQ" % ndim, f.read(8 * ndim))
+            dt = DTYPES[code]
+            n = int(np.prod(dims)) if ndim else 1
+            out[name] = np.frombuffer(f.read(n * dt.itemsize), dt).reshape(dims)
+    return out
+
+
+# which arrays of each fixture are EXPECTED OUTPUTS (everything else is input)
+def _is_output(fixture, key):
+    if fixture == "functors":
+        return key.endswith("_r") or key.endswith("_J")
+    if fixture == "assoc_point2plane":
+        return key.startswith("c") and key != "cases"
+    if fixture == "equirect":
+        return key.startswith(("px_", "cam_f64_", "seg_"))
+    if fixture == "lines":
+        return key.startswith(("t03_", "t04_", "m0_", "m1_")) or key == "c_votes"
+    if fixture == "neighbors":
+        return key in ("off", "ids")
+    if fixture == "fast_atan2":
+        return key.startswith("out_")
+    raise KeyError(fixture)
+
+
+# intermediate results the reference API does not expose (k-NN table, query indices, vote matrices)
+INTERNAL = ("_qidx", "_nn", "votes")
+FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2")
+
+
+def export(out_dir):
+    os.makedirs(out_dir, exist_ok=True)
+    for fx in FIXTURES:
+        z = np.load(os.path.join(GOLDEN, fx + ".npz"))
+        write_pvv(os.path.join(out_dir, fx + ".in.pvv"), {k: z[k] for k in z.files if not _is_output(fx, k)})
+        print("wrote", fx + ".in.pvv")
+
+
+def compare(out_dir):
+    bad = 0
+    for fx in FIXTURES:
+        path = os.path.join(out_dir, fx + ".ref.pvv")
+        if not os.path.exists(path):
+            print("%-20s MISSING (dump_reference_vectors did not write it)" % fx)
+            bad += 1
+            continue
+        ref = read_pvv(path)
+        z = np.load(os.path.join(GOLDEN, fx + ".npz"))
+        for k in z.files:
+            if not _is_output(fx, k):
+                continue
+            if k not in ref:
+                if k.endswith(INTERNAL):
+                    print("%-20s %-18s n/a (internal to the reference function, pinned through its outputs)" % (fx, k))
+                else:
+                    print("%-20s %-18s not produced" % (fx, k)); bad += 1
+                continue
+            exp, got = z[k], ref[k]
+            if exp.shape != got.shape:
+                print("%-20s %-18s SHAPE %s vs reference %s" % (fx, k, exp.shape, got.shape)); bad += 1
+                continue
+            if exp.dtype.kind in "iu" or exp.dtype == np.float32:
+                ok = np.array_equal(exp, got.astype(exp.dtype)); how = "bit-exact"
+            else:
+                # north_star tolerance: 1e-6 relative (values of O(1)); Jacobians of the angle functors are
+                # ill-conditioned as r -> 0, the GPU tests use the same conditioning-aware bound
+                ok = np.allclose(exp, got, rtol=1e-6, atol=1e-9); how = "1e-6"
+            print("%-20s %-18s %s %s" % (fx, k, how, "ok" if ok else "MISMATCH (max |d| %.3g)" % np.max(np.abs(exp.astype(np.float64) - got))))
+            bad += 0 if ok else 1
+    print("re-pin: %s" % ("ALL OUTPUTS AGREE with the reference build" if bad == 0 else "%d disagreement(s)" % bad))
+    return bad
+
+
+if __name__ == "__main__":
+    if len(sys.argv) != 3 or sys.argv[1] not in ("export", "compare"):
+        sys.exit(__doc__)
+    sys.exit(export(sys.argv[2]) if sys.argv[1] == "export" else compare(sys.argv[2]))
