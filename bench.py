@@ -254,7 +254,17 @@ def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds:
             break
+    # SURVEY.md §8(d) also asks for the single-thread figure: a 3 s slice of the same rows on 1 thread
+    n1 = min(n, 200_000); reps1 = 0
+    t1 = time.perf_counter()
+    while True:
+        orc.evaluate(kind, orows[:n1], rid[:n1], nid[:n1], aa, t, normalize=True, jac=True, threads=1)
+        reps1 += 1
+        dt1 = time.perf_counter() - t1
+        if dt1 >= min(3.0, args.cpu_seconds):
+            break
     return {"value": n * reps / dt / 1e6, "unit": "M evals/s", "cores": threads, "kind": "port",
+            "value_1thread": n1 * reps1 / dt1 / 1e6,
             "sample": "%d residual blocks of the first %d pairs x %d repetitions; r + 1x12 J by Jet<12> AutoDiff (restated "
                       "reference algorithm, g++ -O2), OpenMP %d threads, %.1f s" % (n, npairs, reps, threads, dt)}
 

@@ -133,6 +133,43 @@ pvlm_status pvlm_neq_accumulate_dev(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_res
 pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset* rs, pvlm_loss loss, double loss_a,
                                 int zero_first, double* packed_host_inout);
 
+/* ---- panoramic reprojection blocks with point elimination ---------------------------------------- *
+ * PanoramaReprojResidual_1Angle (base/CostFunction.h:218-247): r = w * angle(R(aa_cw) X + t_cw, bearing),
+ * three parameter blocks (aa_cw, t_cw, point_3d), added per track observation by AddCameraResidual
+ * (util/Optimization.cpp:172-222) inside CameraLidarOptimizer::Optimize (CameraLidarOptimizer.cpp:431-432),
+ * solved upstream by Ceres *_SCHUR (util/Optimization.cpp:608-634).  Here the 3-D points live on the GPU
+ * and are eliminated there: the host only sees the reduced 6x6 camera blocks.
+ *   observations are grouped by point: point p owns [point_offsets[p], point_offsets[p+1]);
+ *   cam_ids index the pose table of pvlm_set_poses (angleAxis_cw, t_cw);
+ *   bearings: n_obs x 3, any norm (normalised like the functor's constructor); points: n_points x 3.
+ * Packed output of pvlm_ba_reduce (pvlm_ba_packed_size doubles), F = n_cams, U = n_upairs (co-visible pairs,
+ * ui < uj, from pvlm_ba_structure):
+ *   [ S_diag F x 36 | S_off U x 36 (rows ui, cols uj) | g F x 6 | cost | U_diag F x 6 | gmax_points ]
+ * S, g = Schur complement of the point blocks damped as the LM driver damps every column:
+ *   V* = V + diag(clamp(V_kk s_k^2, min_diag, max_diag) / (radius s_k^2)),  s_k = 1/(1+sqrt(V_kk)) at the
+ *   first call (init_scale = 1; Ceres' Jacobi scaling), cameras are left undamped/unscaled for the caller;
+ * U_diag = diagonal of the camera blocks BEFORE elimination (for the caller's scaling and damping);
+ * gmax_points = max |gradient| over the point blocks; cost = sum rho(r^2)/2.
+ * pvlm_ba_step back-substitutes the points for the camera steps dcam (F x 6, zeros for constant blocks)
+ * into the candidate points and returns out3 = [model cost decrease of these blocks, |dX|^2, |X|^2];
+ * pvlm_ba_cost evaluates the cost at the current (candidate = 0) or candidate points with the poses of the
+ * last pvlm_set_poses; pvlm_ba_accept makes the candidate current.  pvlm_ba_eval materialises r and the
+ * 1x9 Jacobian rows [d/daa_cw | d/dt_cw | d/dX] (Ceres-feeding / parity mode). */
+typedef struct pvlm_baset pvlm_baset;
+pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int64_t* point_offsets, const int* cam_ids,
+                           const double* bearings, const double* points, double weight, pvlm_baset** out);
+pvlm_status pvlm_ba_destroy(pvlm_ctx* ctx, pvlm_baset* set);
+pvlm_status pvlm_ba_structure(const pvlm_baset* set, int* n_points, int64_t* n_obs, int* n_cams, int* n_upairs, int* ui, int* uj);
+int64_t pvlm_ba_packed_size(const pvlm_baset* set);
+pvlm_status pvlm_ba_get_points(pvlm_ctx* ctx, const pvlm_baset* set, int candidate, double* points);
+pvlm_status pvlm_ba_set_points(pvlm_ctx* ctx, pvlm_baset* set, const double* points);
+pvlm_status pvlm_ba_eval(pvlm_ctx* ctx, const pvlm_baset* set, double* r, double* J_or_null);
+pvlm_status pvlm_ba_reduce(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double loss_a, int init_scale, double radius,
+                           double min_diag, double max_diag, double* packed);
+pvlm_status pvlm_ba_step(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double loss_a, const double* dcam, double* out3);
+pvlm_status pvlm_ba_cost(pvlm_ctx* ctx, const pvlm_baset* set, pvlm_loss loss, double loss_a, int candidate, double* cost);
+pvlm_status pvlm_ba_accept(pvlm_ctx* ctx, pvlm_baset* set);
+
 /* ---- multi-GPU exchange (RCCL over xGMI) -------------------------------------------------------- *
  * The reference is single-process (OpenMP only); sharding scan pairs across GPUs introduces exactly one
  * exchange: all-reduce(sum) of the packed normal-equation buffer per LM iteration.

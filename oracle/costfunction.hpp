@@ -197,6 +197,44 @@ struct PlaneIOUResidual {
   }
 };
 
+// PanoramaReprojResidual_1Angle (base/CostFunction.h:218-247): angle between the keypoint's bearing and the
+// direction of the 3-D point in the camera frame; 3 parameter blocks (aa_cw, t_cw, point_3d).  Added by
+// AddCameraResidual (util/Optimization.cpp:172-222) with HuberLoss(4 deg).
+struct PanoramaReprojResidual_1Angle {
+  double point_sphere[3], weight;
+  // ctor: point_sphere.normalize() (:227-230; Eigen divides by the norm)
+  void SetBearing(const double* p) {
+    const double n = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    for (int k = 0; k < 3; ++k) point_sphere[k] = n > 0.0 ? p[k] / n : p[k];
+  }
+  template <typename T>
+  bool operator()(const T* aa_cw, const T* t_cw, const T* point_3d, T* residual) const {
+    T pc[3];
+    AngleAxisRotatePoint(aa_cw, point_3d, pc);
+    pc[0] += t_cw[0]; pc[1] += t_cw[1]; pc[2] += t_cw[2];
+    T norm = sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+    T dot = pc[0] * T(point_sphere[0]) + pc[1] * T(point_sphere[1]) + pc[2] * T(point_sphere[2]);
+    residual[0] = T(weight) * acos(dot / norm);
+    return true;
+  }
+};
+
+// AutoDiffCostFunction<PanoramaReprojResidual_1Angle,1,3,3,3>::Evaluate; J = 1x9 [d/daa_cw | d/dt_cw | d/dX]
+inline bool AutoDiffEvaluateReproj(const PanoramaReprojResidual_1Angle& f, const double* aa, const double* t, const double* X,
+                                   double* residual, double* J) {
+  if (!J) return f(aa, t, X, residual);
+  typedef Jet<9> JT;
+  JT p[3][3];
+  const double* src[3] = {aa, t, X};
+  for (int b = 0; b < 3; ++b)
+    for (int k = 0; k < 3; ++k) p[b][k] = JT(src[b][k], b * 3 + k);
+  JT r;
+  const bool ok = f(p[0], p[1], p[2], &r);
+  *residual = r.a;
+  for (int k = 0; k < 9; ++k) J[k] = r.v[k];
+  return ok;
+}
+
 // AutoDiffCostFunction<F,1,3,3,3,3>::Evaluate: params = {aa_rw, t_rw, aa_nw, t_nw};
 // J is the 1x12 row [d/daa_rw | d/dt_rw | d/daa_nw | d/dt_nw]; J may be null (cost only).
 template <typename F>

@@ -110,6 +110,19 @@ def evaluate(kind, rec, ref_id, nei_id, aa, t, normalize=False, jac=True, thread
     return r, J
 
 
+def evaluate_reproj(bearing, weight, cam_id, pt_id, aa, t, X, jac=True):
+    """PanoramaReprojResidual_1Angle blocks: returns (r, J n x 9 [aa_cw | t_cw | X]); bearing n x 3 (any norm)."""
+    bearing = _f64(bearing); aa = _f64(aa); t = _f64(t); X = _f64(X)
+    cam_id = _i32(cam_id); pt_id = _i32(pt_id)
+    n = bearing.shape[0]
+    r = np.empty(n, np.float64)
+    J = np.empty((n, 9), np.float64) if jac else None
+    rc = lib().orc_eval_reproj(C.c_long(n), _p(bearing, C.c_double), C.c_double(weight), _p(cam_id, C.c_int), _p(pt_id, C.c_int),
+                               _p(aa, C.c_double), _p(t, C.c_double), _p(X, C.c_double), _p(r, C.c_double), _p(J, C.c_double))
+    assert rc == 0
+    return r, J
+
+
 def huber(a, s):
     s = _f64(s)
     rho = np.empty((s.shape[0], 3), np.float64)

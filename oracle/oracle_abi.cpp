@@ -91,6 +91,20 @@ int orc_eval(int kind, int flags, long n, const double* rec, int stride, const i
   return (kind >= 0 && kind <= 5) ? 0 : -1;
 }
 
+// Reprojection blocks: observation i sees point pt_id[i] from camera cam_id[i] with the (un-normalised) bearing
+// bearing[3i..]; aa/t = camera pose tables (angleAxis_cw, t_cw), X = points (M x 3).  J: n x 9 or NULL.
+int orc_eval_reproj(long n, const double* bearing, double weight, const int* cam_id, const int* pt_id, const double* aa, const double* t,
+                    const double* X, double* r, double* J) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (long i = 0; i < n; ++i) {
+    PanoramaReprojResidual_1Angle f; f.SetBearing(bearing + 3 * size_t(i)); f.weight = weight;
+    AutoDiffEvaluateReproj(f, aa + 3 * size_t(cam_id[i]), t + 3 * size_t(cam_id[i]), X + 3 * size_t(pt_id[i]), r + i, J ? J + 9 * size_t(i) : nullptr);
+  }
+  return 0;
+}
+
 void orc_huber(double a, long n, const double* s, double* rho3) {
   for (long i = 0; i < n; ++i) HuberLossEvaluate(a, s[i], rho3 + 3 * i);
 }

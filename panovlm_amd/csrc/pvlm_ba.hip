@@ -1,0 +1,336 @@
+// Reprojection ("bundle") blocks of CameraLidarOptimizer::Optimize: PanoramaReprojResidual_1Angle
+// (base/CostFunction.h:218-247) added by AddCameraResidual (util/Optimization.cpp:172-222).  Three parameter
+// blocks per observation (aa_cw, t_cw, point_3d): the 3-D points are eliminated on the GPU (Schur complement,
+// what Ceres' *_SCHUR solvers do for this problem, util/Optimization.cpp:608-634) so that the host LM driver
+// only ever sees the 6x6 camera blocks in the same packed layout the LiDAR terms use.
+//
+// Layout in HBM: observations sorted by point (CSR), AoS 3-vectors (the set is 1e5..1e6 blocks — latency, not
+// bandwidth, bound); one thread per point for the 3x3 work, one thread per observation for its row of the
+// reduced system, fp64 hardware atomics into the packed buffer (summation order is not fixed: results are
+// reproducible to rounding, ~1e-16 relative, not bit for bit).  gfx950 only.
+#include <algorithm>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "pvlm_internal.h"
+
+#define PVLM_HD __host__ __device__
+#include "pvlm_ba_core.h"
+
+struct pvlm_baset {
+  int n_points = 0, n_cams = 0, n_upairs = 0;
+  int64_t n_obs = 0;
+  double weight = 1.0;
+  std::vector<int> ui, uj;
+  long long* d_pt_off = nullptr;
+  int* d_cam = nullptr;
+  int* d_obs_pt = nullptr;
+  double* d_s = nullptr;
+  double* d_X = nullptr;
+  double* d_Xc = nullptr;
+  double* d_scale = nullptr;
+  double* d_Vinv = nullptr;
+  double* d_gp = nullptr;
+  int* d_adj_off = nullptr;
+  int* d_adj_cam = nullptr;
+  int* d_adj_slot = nullptr;
+  double* d_packed = nullptr;   // packed_size doubles
+  double* d_dcam = nullptr;     // n_cams x 6
+  double* d_small = nullptr;    // 4 doubles of scalar results
+  bool scaled = false;          // Jacobi scaling of the point columns initialised
+  bool reduced = false;         // Vinv / gp valid for the current points
+  uint64_t reduced_epoch = ~0ull;
+  bool have_candidate = false;
+};
+
+static pvlm_ba::View make_view(const pvlm_baset* s, int loss, double a) {
+  pvlm_ba::View v;
+  v.n_points = s->n_points; v.n_cams = s->n_cams; v.n_upairs = s->n_upairs; v.n_obs = s->n_obs;
+  v.pt_off = s->d_pt_off; v.cam = s->d_cam; v.obs_pt = s->d_obs_pt; v.s = s->d_s; v.X = s->d_X; v.Xc = s->d_Xc;
+  v.scale = s->d_scale; v.Vinv = s->d_Vinv; v.gp = s->d_gp; v.adj_off = s->d_adj_off; v.adj_cam = s->d_adj_cam; v.adj_slot = s->d_adj_slot;
+  v.w = s->weight; v.loss = loss; v.a = a;
+  return v;
+}
+
+__device__ inline double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+__global__ void __launch_bounds__(128) k_ba_points(pvlm_ba::View v, const double* __restrict__ pose_tab, int init_scale, double radius, double min_diag, double max_diag,
+                            double* gmax) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < v.n_points) pvlm_ba::point_pass(v, pose_tab, p, init_scale, radius, min_diag, max_diag, gmax);
+}
+
+__global__ void __launch_bounds__(128) k_ba_obs(pvlm_ba::View v, const double* __restrict__ pose_tab, double* packed, double* cost) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0;
+  if (i < v.n_obs) c = pvlm_ba::obs_pass(v, pose_tab, i, packed);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c != 0.0) unsafeAtomicAdd(cost, c);
+}
+
+__global__ void __launch_bounds__(128) k_ba_step(pvlm_ba::View v, const double* __restrict__ pose_tab, const double* __restrict__ dcam, double* out3) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double o[3] = {0.0, 0.0, 0.0};
+  if (p < v.n_points) pvlm_ba::step_point(v, pose_tab, p, dcam, o);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double s = wave_sum(o[k]);
+    if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(&out3[k], s);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ba_cost(pvlm_ba::View v, const double* __restrict__ pose_tab, int candidate, double* cost) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0;
+  if (i < v.n_obs) c = pvlm_ba::cost_obs(v, pose_tab, i, candidate);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c != 0.0) unsafeAtomicAdd(cost, c);
+}
+
+// materialise r and the 1x9 Jacobian rows [aa_cw | t_cw | X] (Ceres-feeding / parity mode)
+__global__ void __launch_bounds__(256) k_ba_eval(pvlm_ba::View v, const double* __restrict__ pose_tab, double* __restrict__ r, double* __restrict__ J) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v.n_obs) return;
+  double rr, Jc[6], Jp[3];
+  pvlm_reproj::eval_obs(pose_tab + (size_t)v.cam[i] * PVLM_BA_POSE_TAB, v.X + 3 * (size_t)v.obs_pt[i], v.s + 3 * i, v.w, &rr, Jc, Jp);
+  r[i] = rr;
+  if (J) {
+    double* o = J + 9 * i;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = Jc[k];
+    o[6] = Jp[0]; o[7] = Jp[1]; o[8] = Jp[2];
+  }
+}
+
+static pvlm_status ba_free(pvlm_baset* s) {
+  hipFree(s->d_pt_off); hipFree(s->d_cam); hipFree(s->d_obs_pt); hipFree(s->d_s); hipFree(s->d_X); hipFree(s->d_Xc); hipFree(s->d_scale);
+  hipFree(s->d_Vinv); hipFree(s->d_gp); hipFree(s->d_adj_off); hipFree(s->d_adj_cam); hipFree(s->d_adj_slot); hipFree(s->d_packed);
+  hipFree(s->d_dcam); hipFree(s->d_small);
+  delete s;
+  return PVLM_OK;
+}
+
+static pvlm_status ba_ready(pvlm_ctx* ctx, const pvlm_baset* s) {
+  if (!ctx->poses_set) { PVLM_SET_ERR(ctx, "pvlm_set_poses (camera poses) must be called before the reprojection set is evaluated"); return PVLM_ERR_STATE; }
+  if (ctx->n_poses < s->n_cams) { PVLM_SET_ERR(ctx, "the reprojection set references camera %d but only %d poses are set", s->n_cams - 1, ctx->n_poses); return PVLM_ERR_STATE; }
+  return PVLM_OK;
+}
+
+template <typename T>
+static pvlm_status h2d(pvlm_ctx* ctx, T* dst, const T* src, size_t n) {
+  if (n) PVLM_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return PVLM_OK;
+}
+
+extern "C" {
+
+pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int64_t* point_offsets, const int* cam_ids, const double* bearings,
+                           const double* points, double weight, pvlm_baset** out) {
+  if (!ctx || !out || n_points < 0 || n_obs < 0 || (n_points > 0 && (!point_offsets || !points)) || (n_obs > 0 && (!cam_ids || !bearings)))
+    return PVLM_ERR_ARG;
+  *out = nullptr;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (n_points > 0 && (point_offsets[0] != 0 || point_offsets[n_points] != n_obs)) { PVLM_SET_ERR(ctx, "point_offsets must run from 0 to n_obs"); return PVLM_ERR_ARG; }
+  int n_cams = 0;
+  for (int64_t i = 0; i < n_obs; ++i) {
+    if (cam_ids[i] < 0) { PVLM_SET_ERR(ctx, "negative camera id at observation %lld", (long long)i); return PVLM_ERR_ARG; }
+    n_cams = std::max(n_cams, cam_ids[i] + 1);
+  }
+  std::vector<int> obs_pt((size_t)n_obs);
+  std::vector<long long> off((size_t)n_points + 1, 0);
+  std::set<std::pair<int, int>> up;
+  for (int p = 0; p < n_points; ++p) {
+    if (point_offsets[p + 1] < point_offsets[p]) { PVLM_SET_ERR(ctx, "point_offsets must be non-decreasing"); return PVLM_ERR_ARG; }
+    off[p] = point_offsets[p]; off[p + 1] = point_offsets[p + 1];
+    for (int64_t i = point_offsets[p]; i < point_offsets[p + 1]; ++i) {
+      obs_pt[(size_t)i] = p;
+      for (int64_t j = i + 1; j < point_offsets[p + 1]; ++j)
+        if (cam_ids[i] != cam_ids[j]) up.insert({std::min(cam_ids[i], cam_ids[j]), std::max(cam_ids[i], cam_ids[j])});
+    }
+  }
+  // unit bearings: point_sphere.normalize() of the functor's constructor (CostFunction.h:227-230)
+  std::vector<double> s((size_t)n_obs * 3);
+  for (int64_t i = 0; i < n_obs; ++i) {
+    const double* b = bearings + 3 * i;
+    const double n = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    for (int k = 0; k < 3; ++k) s[(size_t)i * 3 + k] = n > 0.0 ? b[k] / n : b[k];
+  }
+  pvlm_baset* bs = new pvlm_baset();
+  bs->n_points = n_points; bs->n_obs = n_obs; bs->n_cams = n_cams; bs->weight = weight;
+  std::vector<int> adj_off((size_t)n_cams + 1, 0), adj_cam, adj_slot;
+  for (auto& u : up) { bs->ui.push_back(u.first); bs->uj.push_back(u.second); }   // sorted by (ui, uj): CSR order
+  bs->n_upairs = (int)bs->ui.size();
+  for (int u = 0; u < bs->n_upairs; ++u) { adj_off[(size_t)bs->ui[u] + 1]++; adj_cam.push_back(bs->uj[u]); adj_slot.push_back(u); }
+  for (int c = 0; c < n_cams; ++c) adj_off[(size_t)c + 1] += adj_off[c];
+  const size_t psz = (size_t)pvlm_ba::packed_size(n_cams, bs->n_upairs);
+  pvlm_status st = PVLM_OK;
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_pt_off, (size_t)n_points + 1);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_cam, (size_t)n_obs);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_obs_pt, (size_t)n_obs);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_s, (size_t)n_obs * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_X, (size_t)n_points * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_Xc, (size_t)n_points * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_scale, (size_t)n_points * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_Vinv, (size_t)n_points * 6);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_gp, (size_t)n_points * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_adj_off, (size_t)n_cams + 1);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_adj_cam, adj_cam.size());
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_adj_slot, adj_slot.size());
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_packed, psz);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_dcam, (size_t)n_cams * 6);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_small, (size_t)4);
+  if (!st) st = h2d(ctx, bs->d_pt_off, off.data(), off.size());
+  if (!st) st = h2d(ctx, bs->d_cam, cam_ids, (size_t)n_obs);
+  if (!st) st = h2d(ctx, bs->d_obs_pt, obs_pt.data(), obs_pt.size());
+  if (!st) st = h2d(ctx, bs->d_s, s.data(), s.size());
+  if (!st) st = h2d(ctx, bs->d_X, points, (size_t)n_points * 3);
+  if (!st) st = h2d(ctx, bs->d_Xc, points, (size_t)n_points * 3);
+  if (!st) st = h2d(ctx, bs->d_adj_off, adj_off.data(), adj_off.size());
+  if (!st) st = h2d(ctx, bs->d_adj_cam, adj_cam.data(), adj_cam.size());
+  if (!st) st = h2d(ctx, bs->d_adj_slot, adj_slot.data(), adj_slot.size());
+  if (!st && hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "reprojection set upload failed"); st = PVLM_ERR_HIP; }
+  if (st) { ba_free(bs); return st; }
+  *out = bs;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_destroy(pvlm_ctx* ctx, pvlm_baset* set) {
+  if (!ctx || !set) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipStreamSynchronize(ctx->stream);
+  return ba_free(set);
+}
+
+pvlm_status pvlm_ba_structure(const pvlm_baset* set, int* n_points, int64_t* n_obs, int* n_cams, int* n_upairs, int* ui, int* uj) {
+  if (!set) return PVLM_ERR_ARG;
+  if (n_points) *n_points = set->n_points;
+  if (n_obs) *n_obs = set->n_obs;
+  if (n_cams) *n_cams = set->n_cams;
+  if (n_upairs) *n_upairs = set->n_upairs;
+  if (ui) std::copy(set->ui.begin(), set->ui.end(), ui);
+  if (uj) std::copy(set->uj.begin(), set->uj.end(), uj);
+  return PVLM_OK;
+}
+
+int64_t pvlm_ba_packed_size(const pvlm_baset* set) { return set ? (int64_t)pvlm_ba::packed_size(set->n_cams, set->n_upairs) : 0; }
+
+pvlm_status pvlm_ba_get_points(pvlm_ctx* ctx, const pvlm_baset* set, int candidate, double* points) {
+  if (!ctx || !set || !points) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (set->n_points) PVLM_HIP(ctx, hipMemcpyAsync(points, candidate ? set->d_Xc : set->d_X, (size_t)set->n_points * 24, hipMemcpyDeviceToHost, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_set_points(pvlm_ctx* ctx, pvlm_baset* set, const double* points) {
+  if (!ctx || !set || !points) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = h2d(ctx, set->d_X, points, (size_t)set->n_points * 3);
+  if (st) return st;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  set->reduced = false; set->have_candidate = false;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_eval(pvlm_ctx* ctx, const pvlm_baset* set, double* r, double* J) {
+  if (!ctx || !set || !r) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ba_ready(ctx, set);
+  if (st) return st;
+  if (set->n_obs == 0) return PVLM_OK;
+  double *d_r = nullptr, *d_J = nullptr;
+  if ((st = pvlm_i_alloc(ctx, &d_r, (size_t)set->n_obs))) return st;
+  if (J && (st = pvlm_i_alloc(ctx, &d_J, (size_t)set->n_obs * 9))) { hipFree(d_r); return st; }
+  const pvlm_ba::View v = make_view(set, 0, 0.0);
+  hipLaunchKernelGGL(k_ba_eval, dim3((unsigned)((set->n_obs + 255) / 256)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, d_r, d_J);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(r, d_r, (size_t)set->n_obs * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && J) e = hipMemcpyAsync(J, d_J, (size_t)set->n_obs * 72, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_r); hipFree(d_J);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_ba_eval: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_reduce(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double a, int init_scale, double radius, double min_diag,
+                           double max_diag, double* packed) {
+  if (!ctx || !set || !packed || !(radius > 0.0)) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ba_ready(ctx, set);
+  if (st) return st;
+  if (!init_scale && !set->scaled) { PVLM_SET_ERR(ctx, "pvlm_ba_reduce: the first call must initialise the point scaling (init_scale = 1)"); return PVLM_ERR_STATE; }
+  const size_t psz = (size_t)pvlm_ba::packed_size(set->n_cams, set->n_upairs);
+  PVLM_HIP(ctx, hipMemsetAsync(set->d_packed, 0, psz * 8, ctx->stream));
+  const pvlm_ba::View v = make_view(set, (int)loss, a);
+  double* d_cost = set->d_packed + (size_t)set->n_cams * 42 + (size_t)set->n_upairs * 36;
+  double* d_gmax = set->d_packed + psz - 1;
+  if (set->n_points) {
+    hipLaunchKernelGGL(k_ba_points, dim3((unsigned)((set->n_points + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, init_scale, radius,
+                       min_diag, max_diag, d_gmax);
+    PVLM_HIP(ctx, hipGetLastError());
+  }
+  if (set->n_obs) {
+    hipLaunchKernelGGL(k_ba_obs, dim3((unsigned)((set->n_obs + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_packed, d_cost);
+    PVLM_HIP(ctx, hipGetLastError());
+  }
+  PVLM_HIP(ctx, hipMemcpyAsync(packed, set->d_packed, psz * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (init_scale) set->scaled = true;
+  set->reduced = true; set->reduced_epoch = ctx->pose_epoch;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_step(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double a, const double* dcam, double* out3) {
+  if (!ctx || !set || !dcam || !out3) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ba_ready(ctx, set);
+  if (st) return st;
+  if (!set->reduced || set->reduced_epoch != ctx->pose_epoch) {
+    PVLM_SET_ERR(ctx, "pvlm_ba_step needs pvlm_ba_reduce at the same camera poses and points first");
+    return PVLM_ERR_STATE;
+  }
+  if ((st = h2d(ctx, set->d_dcam, dcam, (size_t)set->n_cams * 6))) return st;
+  PVLM_HIP(ctx, hipMemsetAsync(set->d_small, 0, 32, ctx->stream));
+  const pvlm_ba::View v = make_view(set, (int)loss, a);
+  if (set->n_points) {
+    hipLaunchKernelGGL(k_ba_step, dim3((unsigned)((set->n_points + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_dcam, set->d_small);
+    PVLM_HIP(ctx, hipGetLastError());
+  }
+  PVLM_HIP(ctx, hipMemcpyAsync(out3, set->d_small, 24, hipMemcpyDeviceToHost, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  set->have_candidate = true;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_cost(pvlm_ctx* ctx, const pvlm_baset* set, pvlm_loss loss, double a, int candidate, double* cost) {
+  if (!ctx || !set || !cost) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = ba_ready(ctx, set);
+  if (st) return st;
+  if (candidate && !set->have_candidate) { PVLM_SET_ERR(ctx, "pvlm_ba_cost(candidate): no candidate points (call pvlm_ba_step first)"); return PVLM_ERR_STATE; }
+  PVLM_HIP(ctx, hipMemsetAsync(set->d_small, 0, 32, ctx->stream));
+  const pvlm_ba::View v = make_view(set, (int)loss, a);
+  if (set->n_obs) {
+    hipLaunchKernelGGL(k_ba_cost, dim3((unsigned)((set->n_obs + 255) / 256)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, candidate, set->d_small);
+    PVLM_HIP(ctx, hipGetLastError());
+  }
+  PVLM_HIP(ctx, hipMemcpyAsync(cost, set->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_accept(pvlm_ctx* ctx, pvlm_baset* set) {
+  if (!ctx || !set) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (!set->have_candidate) { PVLM_SET_ERR(ctx, "pvlm_ba_accept: no candidate points"); return PVLM_ERR_STATE; }
+  std::swap(set->d_X, set->d_Xc);
+  set->reduced = false; set->have_candidate = false;
+  return PVLM_OK;
+}
+
+}  // extern "C"

@@ -147,3 +147,105 @@ def random_world_lines(rng, n, extent=4.0):
         d = rng.normal(size=3); d /= np.linalg.norm(d)
         out.append((a, a + d * rng.uniform(0.5, 3.0)))
     return out
+
+
+# ---- reprojection ("bundle") problems: PanoramaReprojResidual_1Angle blocks ---------------------------------
+def pose_table(aa, t):
+    """numpy restatement of the device pose table rows [R row-major | J_l(aa) row-major | t] (21 doubles)."""
+    aa = np.asarray(aa, np.float64); t = np.asarray(t, np.float64)
+    out = np.zeros((aa.shape[0], 21))
+    for i, w in enumerate(aa):
+        th2 = float(w @ w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if th2 > 2.220446049250313e-16:
+            th = np.sqrt(th2); k = K / th
+            R = np.eye(3) + np.sin(th) * k + (1 - np.cos(th)) * (k @ k)
+        else:
+            R = np.eye(3) + K
+        if th2 > 1e-6:
+            th = np.sqrt(th2); A = (1 - np.cos(th)) / th2; B = (th - np.sin(th)) / (th2 * th)
+        else:
+            A = 0.5 - th2 / 24 + th2 * th2 / 720; B = 1 / 6 - th2 / 120 + th2 * th2 / 5040
+        Jl = np.eye(3) + A * K + B * (K @ K)
+        out[i, :9] = R.reshape(-1); out[i, 9:18] = Jl.reshape(-1); out[i, 18:] = t[i]
+    return out
+
+
+def random_bundle(rng, n_cams=5, n_points=30, min_track=2, max_track=5, noise=2e-3, outliers=0.1, empty_points=1):
+    """Cameras looking at a cloud of points 2..6 m away; every point is seen by min..max_track cameras.
+    Returns dict(aa, t [camera poses cw], X [perturbed points], off, cam, bearing [noisy, un-normalised])."""
+    aa = rng.normal(size=(n_cams, 3)) * 0.3
+    t = rng.normal(size=(n_cams, 3)) * 0.5
+    Xt = rng.normal(size=(n_points, 3)) * 2.0 + np.array([0.0, 0.0, 1.0])
+    tab = pose_table(aa, t)
+    off = [0]; cam = []; bearing = []
+    for p in range(n_points):
+        k = 0 if p < empty_points else int(rng.integers(min_track, max_track + 1))
+        cs = rng.choice(n_cams, size=min(k, n_cams), replace=False)
+        if k > 2 and rng.uniform() < 0.2:
+            cs = np.concatenate([cs, cs[:1]])          # the same camera twice in one track
+        for c in cs:
+            pc = tab[c, :9].reshape(3, 3) @ Xt[p] + tab[c, 18:]
+            b = pc / np.linalg.norm(pc) + rng.normal(size=3) * (0.2 if rng.uniform() < outliers else noise)
+            cam.append(int(c)); bearing.append(b * rng.uniform(0.5, 2.0))
+        off.append(len(cam))
+    X = Xt + rng.normal(size=Xt.shape) * 0.05
+    return dict(aa=aa, t=t, X=X, off=np.array(off, np.int64), cam=np.array(cam, np.int32), bearing=np.array(bearing).reshape(-1, 3))
+
+
+def bundle_reference(r, J, off, cam, n_cams, loss, a, scale, radius, min_diag, max_diag):
+    """numpy Schur complement of the point blocks from materialised r, J (n x 9): returns dict with the dense
+    reduced camera system S (6F x 6F), g (6F), cost, Udiag (F x 6), the per-point Vinv, gp, scale, gmax."""
+    rho1, half = huber_weights(r, loss, a)
+    F = n_cams; M = len(off) - 1
+    U = np.zeros((6 * F, 6 * F)); gc = np.zeros(6 * F); Ud = np.zeros((F, 6))
+    S = np.zeros_like(U); g = np.zeros_like(gc)
+    Vinv = np.zeros((M, 3, 3)); gp = np.zeros((M, 3)); sc = np.zeros((M, 3)) if scale is None else np.array(scale, np.float64)
+    for i in range(len(r)):
+        c = cam[i]; Jc = J[i, :6]
+        U[6 * c:6 * c + 6, 6 * c:6 * c + 6] += rho1[i] * np.outer(Jc, Jc)
+        gc[6 * c:6 * c + 6] += rho1[i] * Jc * r[i]
+        Ud[c] += rho1[i] * Jc * Jc
+    S += U; g += gc
+    for p in range(M):
+        idx = np.arange(off[p], off[p + 1])
+        V = np.zeros((3, 3)); W = np.zeros((6 * F, 3))
+        for i in idx:
+            Jp = J[i, 6:]; c = cam[i]
+            V += rho1[i] * np.outer(Jp, Jp); gp[p] += rho1[i] * Jp * r[i]
+            W[6 * c:6 * c + 6] += rho1[i] * np.outer(J[i, :6], Jp)
+        if scale is None:
+            sc[p] = 1.0 / (1.0 + np.sqrt(np.diag(V)))
+        lam = np.clip(np.diag(V) * sc[p] ** 2, min_diag, max_diag) / (radius * sc[p] ** 2)
+        Vd = V + np.diag(lam)
+        Vinv[p] = np.linalg.inv(Vd)
+        S -= W @ Vinv[p] @ W.T
+        g -= W @ Vinv[p] @ gp[p]
+    return dict(S=S, g=g, cost=float(half.sum()), Udiag=Ud, Vinv=Vinv, gp=gp, scale=sc, gmax=float(np.abs(gp).max()) if M else 0.0)
+
+
+def bundle_unpack(packed, n_cams, ui, uj):
+    """packed buffer of pvlm_ba_reduce -> dense (S 6F x 6F symmetric, g 6F, cost, Udiag F x 6, gmax)."""
+    F = n_cams; U = len(ui)
+    Hd = packed[:F * 36].reshape(F, 6, 6); Ho = packed[F * 36:F * 36 + U * 36].reshape(U, 6, 6)
+    o = F * 36 + U * 36
+    g = packed[o:o + 6 * F].copy(); cost = float(packed[o + 6 * F]); Ud = packed[o + 6 * F + 1:o + 12 * F + 1].reshape(F, 6).copy()
+    S = np.zeros((6 * F, 6 * F))
+    for c in range(F):
+        S[6 * c:6 * c + 6, 6 * c:6 * c + 6] = Hd[c]
+    for u in range(U):
+        a, b = ui[u], uj[u]
+        S[6 * a:6 * a + 6, 6 * b:6 * b + 6] = Ho[u]; S[6 * b:6 * b + 6, 6 * a:6 * a + 6] = Ho[u].T
+    return S, g, cost, Ud, float(packed[-1])
+
+
+def covisible_pairs(off, cam):
+    up = set()
+    for p in range(len(off) - 1):
+        cs = cam[off[p]:off[p + 1]]
+        for i in range(len(cs)):
+            for j in range(i + 1, len(cs)):
+                if cs[i] != cs[j]:
+                    up.add((min(cs[i], cs[j]), max(cs[i], cs[j])))
+    up = sorted(up)
+    return np.array([u[0] for u in up], np.int32), np.array([u[1] for u in up], np.int32)
