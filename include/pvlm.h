@@ -144,17 +144,21 @@ pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset*
  *   bearings: n_obs x 3, any norm (normalised like the functor's constructor); points: n_points x 3.
  * Packed output of pvlm_ba_reduce (pvlm_ba_packed_size doubles), F = n_cams, U = n_upairs (co-visible pairs,
  * ui < uj, from pvlm_ba_structure):
- *   [ S_diag F x 36 | S_off U x 36 (rows ui, cols uj) | g F x 6 | cost | U_diag F x 6 | gmax_points ]
+ *   [ S_diag F x 36 | S_off U x 36 (rows ui, cols uj) | g F x 6 | cost | U_diag F x 6 | g_cam F x 6 | gmax_points ]
  * S, g = Schur complement of the point blocks damped as the LM driver damps every column:
  *   V* = V + diag(clamp(V_kk s_k^2, min_diag, max_diag) / (radius s_k^2)),  s_k = 1/(1+sqrt(V_kk)) at the
  *   first call (init_scale = 1; Ceres' Jacobi scaling), cameras are left undamped/unscaled for the caller;
- * U_diag = diagonal of the camera blocks BEFORE elimination (for the caller's scaling and damping);
+ * U_diag / g_cam = diagonal and gradient of the camera blocks BEFORE elimination (for the caller's scaling,
+ * damping and gradient test);
  * gmax_points = max |gradient| over the point blocks; cost = sum rho(r^2)/2.
  * pvlm_ba_step back-substitutes the points for the camera steps dcam (F x 6, zeros for constant blocks)
  * into the candidate points and returns out3 = [model cost decrease of these blocks, |dX|^2, |X|^2];
  * pvlm_ba_cost evaluates the cost at the current (candidate = 0) or candidate points with the poses of the
  * last pvlm_set_poses; pvlm_ba_accept makes the candidate current.  pvlm_ba_eval materialises r and the
- * 1x9 Jacobian rows [d/daa_cw | d/dt_cw | d/dX] (Ceres-feeding / parity mode). */
+ * 1x9 Jacobian rows [d/daa_cw | d/dt_cw | d/dX] (Ceres-feeding / parity mode).  pvlm_ba_set_constant marks
+ * points (mask[p] != 0) as constant parameter blocks (Problem::SetParameterBlockConstant, the
+ * refine_structure = false case of CameraLidarOptimizer.cpp:462-466): they are neither eliminated nor moved;
+ * mask = NULL frees all. */
 typedef struct pvlm_baset pvlm_baset;
 pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int64_t* point_offsets, const int* cam_ids,
                            const double* bearings, const double* points, double weight, pvlm_baset** out);
@@ -163,6 +167,7 @@ pvlm_status pvlm_ba_structure(const pvlm_baset* set, int* n_points, int64_t* n_o
 int64_t pvlm_ba_packed_size(const pvlm_baset* set);
 pvlm_status pvlm_ba_get_points(pvlm_ctx* ctx, const pvlm_baset* set, int candidate, double* points);
 pvlm_status pvlm_ba_set_points(pvlm_ctx* ctx, pvlm_baset* set, const double* points);
+pvlm_status pvlm_ba_set_constant(pvlm_ctx* ctx, pvlm_baset* set, const unsigned char* mask_or_null);
 pvlm_status pvlm_ba_eval(pvlm_ctx* ctx, const pvlm_baset* set, double* r, double* J_or_null);
 pvlm_status pvlm_ba_reduce(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double loss_a, int init_scale, double radius,
                            double min_diag, double max_diag, double* packed);

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes",
-    "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points",
+    "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
 
@@ -61,6 +61,7 @@ def load_library():
     lib.pvlm_last_error.restype = C.c_char_p
     lib.pvlm_version.restype = C.c_char_p
     lib.pvlm_neq_size.restype = C.c_int64
+    lib.pvlm_ba_packed_size.restype = C.c_int64
     _LIB = lib
     return lib
 
@@ -304,6 +305,77 @@ class NormalEq:
         Hd = packed[:n * 36].reshape(n, 6, 6); Ho = packed[n * 36:(n + u) * 36].reshape(u, 6, 6)
         g = packed[(n + u) * 36:(n + u) * 36 + n * 6].reshape(n, 6)
         return Hd, Ho, g, float(packed[-1])
+
+
+class BundleSet:
+    """Reprojection blocks (PanoramaReprojResidual_1Angle) with the 3-D points resident on the GPU and eliminated
+    there (pvlm_ba_* of include/pvlm.h).  Camera poses come from Context.set_poses (angleAxis_cw, t_cw)."""
+
+    def __init__(self, ctx, point_offsets, cam_ids, bearings, points, weight=1.0):
+        self.ctx = ctx
+        off = _i64(point_offsets); cam = _i32(cam_ids); b = _f64(bearings); X = _f64(points)
+        self._h = C.c_void_p()
+        ctx._check(ctx.lib.pvlm_ba_create(ctx._h, C.c_int(len(off) - 1), C.c_int64(len(cam)), _p(off, C.c_int64), _p(cam, C.c_int),
+                                          _p(b, C.c_double), _p(X, C.c_double), C.c_double(weight), C.byref(self._h)), "pvlm_ba_create")
+        npts = C.c_int(); nobs = C.c_int64(); ncam = C.c_int(); nup = C.c_int()
+        ctx.lib.pvlm_ba_structure(self._h, C.byref(npts), C.byref(nobs), C.byref(ncam), C.byref(nup), None, None)
+        self.n_points, self.n_obs, self.n_cams, self.n_upairs = npts.value, nobs.value, ncam.value, nup.value
+        self.ui = np.zeros(self.n_upairs, np.int32); self.uj = np.zeros(self.n_upairs, np.int32)
+        ctx.lib.pvlm_ba_structure(self._h, None, None, None, None, _p(self.ui, C.c_int), _p(self.uj, C.c_int))
+        self.size = int(ctx.lib.pvlm_ba_packed_size(self._h))
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.pvlm_ba_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def points(self, candidate=False):
+        X = np.zeros((self.n_points, 3), np.float64)
+        self.ctx._check(self.ctx.lib.pvlm_ba_get_points(self.ctx._h, self._h, C.c_int(1 if candidate else 0), _p(X, C.c_double)), "pvlm_ba_get_points")
+        return X
+
+    def set_points(self, X):
+        X = _f64(X)
+        assert X.shape == (self.n_points, 3)
+        self.ctx._check(self.ctx.lib.pvlm_ba_set_points(self.ctx._h, self._h, _p(X, C.c_double)), "pvlm_ba_set_points")
+
+    def set_constant(self, mask):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m is None or m.shape == (self.n_points,)
+        self.ctx._check(self.ctx.lib.pvlm_ba_set_constant(self.ctx._h, self._h, _p(m, C.c_ubyte)), "pvlm_ba_set_constant")
+
+    def evaluate(self, jac=True):
+        r = np.zeros(self.n_obs, np.float64)
+        J = np.zeros((self.n_obs, 9), np.float64) if jac else None
+        self.ctx._check(self.ctx.lib.pvlm_ba_eval(self.ctx._h, self._h, _p(r, C.c_double), _p(J, C.c_double)), "pvlm_ba_eval")
+        return r, J
+
+    def reduce(self, loss=LOSS_NONE, loss_a=0.0, init_scale=False, radius=1e4, min_diag=1e-6, max_diag=1e32):
+        packed = np.zeros(self.size, np.float64)
+        self.ctx._check(self.ctx.lib.pvlm_ba_reduce(self.ctx._h, self._h, C.c_int(loss), C.c_double(loss_a), C.c_int(1 if init_scale else 0),
+                                                    C.c_double(radius), C.c_double(min_diag), C.c_double(max_diag), _p(packed, C.c_double)), "pvlm_ba_reduce")
+        return packed
+
+    def step(self, dcam, loss=LOSS_NONE, loss_a=0.0):
+        d = _f64(dcam)
+        assert d.shape == (self.n_cams, 6)
+        out3 = np.zeros(3, np.float64)
+        self.ctx._check(self.ctx.lib.pvlm_ba_step(self.ctx._h, self._h, C.c_int(loss), C.c_double(loss_a), _p(d, C.c_double), _p(out3, C.c_double)), "pvlm_ba_step")
+        return out3
+
+    def cost(self, loss=LOSS_NONE, loss_a=0.0, candidate=False):
+        c = C.c_double()
+        self.ctx._check(self.ctx.lib.pvlm_ba_cost(self.ctx._h, self._h, C.c_int(loss), C.c_double(loss_a), C.c_int(1 if candidate else 0), C.byref(c)), "pvlm_ba_cost")
+        return c.value
+
+    def accept(self):
+        self.ctx._check(self.ctx.lib.pvlm_ba_accept(self.ctx._h, self._h), "pvlm_ba_accept")
 
 
 class Comm:

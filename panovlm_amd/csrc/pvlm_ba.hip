@@ -35,6 +35,7 @@ struct pvlm_baset {
   int* d_adj_off = nullptr;
   int* d_adj_cam = nullptr;
   int* d_adj_slot = nullptr;
+  unsigned char* d_frozen = nullptr;   // null = every point is free
   double* d_packed = nullptr;   // packed_size doubles
   double* d_dcam = nullptr;     // n_cams x 6
   double* d_small = nullptr;    // 4 doubles of scalar results
@@ -48,7 +49,7 @@ static pvlm_ba::View make_view(const pvlm_baset* s, int loss, double a) {
   pvlm_ba::View v;
   v.n_points = s->n_points; v.n_cams = s->n_cams; v.n_upairs = s->n_upairs; v.n_obs = s->n_obs;
   v.pt_off = s->d_pt_off; v.cam = s->d_cam; v.obs_pt = s->d_obs_pt; v.s = s->d_s; v.X = s->d_X; v.Xc = s->d_Xc;
-  v.scale = s->d_scale; v.Vinv = s->d_Vinv; v.gp = s->d_gp; v.adj_off = s->d_adj_off; v.adj_cam = s->d_adj_cam; v.adj_slot = s->d_adj_slot;
+  v.scale = s->d_scale; v.Vinv = s->d_Vinv; v.gp = s->d_gp; v.adj_off = s->d_adj_off; v.adj_cam = s->d_adj_cam; v.adj_slot = s->d_adj_slot; v.frozen = s->d_frozen;
   v.w = s->weight; v.loss = loss; v.a = a;
   return v;
 }
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(256) k_ba_eval(pvlm_ba::View v, const double* 
 static pvlm_status ba_free(pvlm_baset* s) {
   hipFree(s->d_pt_off); hipFree(s->d_cam); hipFree(s->d_obs_pt); hipFree(s->d_s); hipFree(s->d_X); hipFree(s->d_Xc); hipFree(s->d_scale);
   hipFree(s->d_Vinv); hipFree(s->d_gp); hipFree(s->d_adj_off); hipFree(s->d_adj_cam); hipFree(s->d_adj_slot); hipFree(s->d_packed);
-  hipFree(s->d_dcam); hipFree(s->d_small);
+  hipFree(s->d_dcam); hipFree(s->d_small); hipFree(s->d_frozen);
   delete s;
   return PVLM_OK;
 }
@@ -234,6 +235,21 @@ pvlm_status pvlm_ba_set_points(pvlm_ctx* ctx, pvlm_baset* set, const double* poi
   if (st) return st;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   set->reduced = false; set->have_candidate = false;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ba_set_constant(pvlm_ctx* ctx, pvlm_baset* set, const unsigned char* mask) {
+  if (!ctx || !set) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!mask) { hipFree(set->d_frozen); set->d_frozen = nullptr; }
+  else {
+    pvlm_status st;
+    if (!set->d_frozen && (st = pvlm_i_alloc(ctx, &set->d_frozen, (size_t)set->n_points))) return st;
+    if ((st = h2d(ctx, set->d_frozen, mask, (size_t)set->n_points))) return st;
+    PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  set->reduced = false;
   return PVLM_OK;
 }
 

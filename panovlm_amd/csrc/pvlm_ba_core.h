@@ -37,13 +37,15 @@ struct View {
   const int* adj_off;       // n_cams + 1 : CSR of co-visible cameras cj > ci
   const int* adj_cam;
   const int* adj_slot;      // index of the unordered pair (ci, cj) in the packed off-diagonal blocks
+  const unsigned char* frozen;  // n_points or null: 1 = constant parameter block (SetParameterBlockConstant)
   double w;                 // residual weight (config.camera_weight)
   int loss;                 // 0 none, 1 Huber
   double a;
 };
 
-// packed camera system (doubles): [Hdiag n_cams x 36 | Hoff n_upairs x 36 | g n_cams x 6 | cost | Udiag n_cams x 6 | gmax_points]
-PVLM_HD inline long long packed_size(int n_cams, int n_upairs) { return (long long)n_cams * 48 + (long long)n_upairs * 36 + 2; }
+// packed camera system (doubles):
+//   [Hdiag n_cams x 36 | Hoff n_upairs x 36 | g n_cams x 6 | cost | Udiag n_cams x 6 | gcam n_cams x 6 | gmax_points]
+PVLM_HD inline long long packed_size(int n_cams, int n_upairs) { return (long long)n_cams * 54 + (long long)n_upairs * 36 + 2; }
 
 struct Lin { double r, rho, rho1, Jc[6], Jp[3]; };
 
@@ -68,11 +70,12 @@ PVLM_HD inline void point_pass(const View& v, const double* pose_tab, int p, int
   if (init_scale) { sc[0] = 1.0 / (1.0 + sqrt(V[0])); sc[1] = 1.0 / (1.0 + sqrt(V[3])); sc[2] = 1.0 / (1.0 + sqrt(V[5])); }
   double Vd[6], inv[6];
   pvlm_reproj::damp3(V, sc, radius, min_diag, max_diag, Vd);
-  if (!pvlm_reproj::spd3_inverse(Vd, inv)) { for (int k = 0; k < 6; ++k) inv[k] = 0.0; }
+  const bool frozen = v.frozen && v.frozen[p];
+  if (frozen || !pvlm_reproj::spd3_inverse(Vd, inv)) { for (int k = 0; k < 6; ++k) inv[k] = 0.0; }   // Vinv = 0: not eliminated, does not move
   for (int k = 0; k < 6; ++k) v.Vinv[6 * (size_t)p + k] = inv[k];
   for (int k = 0; k < 3; ++k) v.gp[3 * (size_t)p + k] = g[k];
   const double m = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-  if (m > 0.0) PVLM_ATOMIC_MAXPOS(gmax, m);
+  if (m > 0.0 && !frozen) PVLM_ATOMIC_MAXPOS(gmax, m);
 }
 
 PVLM_HD inline int find_slot(const View& v, int ci, int cj) {  // cj > ci; -1 if the pair is not in the structure
@@ -99,6 +102,7 @@ PVLM_HD inline double obs_pass(const View& v, const double* pose_tab, long long 
   double* Ho = packed + (size_t)v.n_cams * 36;
   double* g = Ho + (size_t)v.n_upairs * 36 + (size_t)ci * 6;
   double* Ud = Ho + (size_t)v.n_upairs * 36 + (size_t)v.n_cams * 6 + 1 + (size_t)ci * 6;
+  double* gc = Ud + (size_t)v.n_cams * 6;
   // y = Vinv Jp_i ;  T_i = rho' Jc_i y^T  (rank one)
   double y[3]; pvlm_reproj::sym3_mul(Vi, li.Jp, y);
   const double* gp = v.gp + 3 * (size_t)p;
@@ -106,6 +110,7 @@ PVLM_HD inline double obs_pass(const View& v, const double* pose_tab, long long 
   for (int k = 0; k < 6; ++k) {
     PVLM_ATOMIC_ADD(&g[k], li.rho1 * li.Jc[k] * (li.r - ygp));
     PVLM_ATOMIC_ADD(&Ud[k], li.rho1 * li.Jc[k] * li.Jc[k]);
+    PVLM_ATOMIC_ADD(&gc[k], li.rho1 * li.Jc[k] * li.r);
   }
   for (long long j = v.pt_off[p]; j < v.pt_off[p + 1]; ++j) {
     const int cj = v.cam[j];
@@ -154,7 +159,7 @@ PVLM_HD inline void step_point(const View& v, const double* pose_tab, int p, con
   for (int k = 0; k < 3; ++k) v.Xc[3 * (size_t)p + k] = X[k] + dp[k];
   out3_local[0] = model;
   out3_local[1] = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
-  out3_local[2] = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+  out3_local[2] = (v.frozen && v.frozen[p]) ? 0.0 : X[0] * X[0] + X[1] * X[1] + X[2] * X[2];   // |x|^2 of the FREE parameters
 }
 
 // ---- cost only, one call per observation (candidate = 1: at Xc) ---------------------------------------------

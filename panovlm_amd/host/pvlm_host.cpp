@@ -458,6 +458,20 @@ static const int kStride[6] = {7, 7, 9, 9, 10, 12};
 
 bool CostFunction::Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
   Engine& e = Engine::Default();
+  if (kind == kReprojKind) {   // {aa_cw, t_cw, point_3d}: a one-observation reprojection set
+    const int64_t off[2] = {0, 1};
+    const int cam = 0;
+    pvlm_baset* bs = nullptr;
+    if (pvlm_ba_create(e.ctx(), 1, 1, off, &cam, row.data(), parameters[2], weight, &bs) != PVLM_OK) return false;
+    bool ok = pvlm_set_poses(e.ctx(), 1, parameters[0], parameters[1]) == PVLM_OK;
+    double J[9];
+    ok = ok && pvlm_ba_eval(e.ctx(), bs, residuals, jacobians ? J : nullptr) == PVLM_OK;
+    pvlm_ba_destroy(e.ctx(), bs);
+    if (ok && jacobians)
+      for (int b = 0; b < 3; ++b)
+        if (jacobians[b]) for (int k = 0; k < 3; ++k) jacobians[b][k] = J[3 * b + k];
+    return ok && std::isfinite(residuals[0]);
+  }
   double aa[6] = {parameters[0][0], parameters[0][1], parameters[0][2], parameters[2][0], parameters[2][1], parameters[2][2]};
   double t[6] = {parameters[1][0], parameters[1][1], parameters[1][2], parameters[3][0], parameters[3][1], parameters[3][2]};
   const int64_t off[2] = {0, 1};
@@ -495,6 +509,19 @@ struct Problem::Impl {
     std::vector<int> dev_to_pose;       // dev id -> Problem pose id (-1 unused)
   };
   std::vector<Group> groups;
+  // Reprojection blocks (camera pose + free 3-D point), one group per (weight, loss).  At Solve the observations
+  // are sorted by point and handed to the GPU (pvlm_baset); the point blocks are eliminated there.
+  struct Bundle {
+    double weight = 1.0; LossFunction* loss = nullptr;
+    std::vector<int> obs_pose, obs_point;      // Problem pose id / parameter-block id of the point, insertion order
+    std::vector<double> obs_bearing;           // 3 per observation (as handed to Create, un-normalised)
+    pvlm_baset* set = nullptr;
+    std::vector<int> point_blocks;             // device point index -> parameter-block id
+    std::vector<int> dev_to_pose;              // device camera id -> Problem pose id
+    std::vector<int> ui, uj;                   // co-visible device camera pairs (packed layout)
+  };
+  std::vector<Bundle> bundles;
+  std::vector<bool> is_point;                  // per parameter block
   std::vector<CostFunction*> owned_costs;
   std::set<LossFunction*> owned_losses;
   int num_blocks = 0;
@@ -503,7 +530,7 @@ struct Problem::Impl {
     auto it = block_id.find(p);
     if (it != block_id.end()) return it->second;
     const int id = (int)blocks.size();
-    block_id[p] = id; blocks.push_back(p); constant.push_back(false);
+    block_id[p] = id; blocks.push_back(p); constant.push_back(false); is_point.push_back(false);
     return id;
   }
   int Pose(double* aa, double* t) {
@@ -520,6 +547,7 @@ Problem::Problem() : impl_(new Impl()) {}
 Problem::~Problem() {
   Engine& e = Engine::Default();
   for (auto& g : impl_->groups) { if (g.neq) pvlm_neq_destroy(e.ctx(), g.neq); if (g.set) pvlm_resset_destroy(e.ctx(), g.set); }
+  for (auto& b : impl_->bundles) if (b.set) pvlm_ba_destroy(e.ctx(), b.set);
   for (CostFunction* c : impl_->owned_costs) delete c;
   for (LossFunction* l : impl_->owned_losses) delete l;
   delete impl_;
@@ -548,6 +576,24 @@ void Problem::AddResidualBlock(CostFunction* cost, LossFunction* loss, double* a
   if (g.ref.empty() || g.ref.back() != pr || g.nei.back() != pn) { g.ref.push_back(pr); g.nei.push_back(pn); g.off.push_back(g.off.back()); }
   g.rows.insert(g.rows.end(), cost->row.begin(), cost->row.end());
   g.off.back() += 1;
+  I.num_blocks++;
+}
+
+void Problem::AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_c, double* t_c, double* point_3d) {
+  Impl& I = *impl_;
+  if (cost->kind != kReprojKind) throw std::runtime_error("three-block AddResidualBlock expects PanoramaReprojResidual_1Angle");
+  const int pose = I.Pose(aa_c, t_c);
+  const int pb = I.Block(point_3d);
+  I.is_point[pb] = true;
+  if (loss) I.owned_losses.insert(loss);
+  I.owned_costs.push_back(cost);
+  int bi = -1;
+  for (int k = (int)I.bundles.size() - 1; k >= 0; --k)
+    if (!I.bundles[k].set && I.bundles[k].weight == cost->weight && I.bundles[k].loss == loss) { bi = k; break; }
+  if (bi < 0) { Impl::Bundle b; b.weight = cost->weight; b.loss = loss; I.bundles.push_back(b); bi = (int)I.bundles.size() - 1; }
+  Impl::Bundle& b = I.bundles[bi];
+  b.obs_pose.push_back(pose); b.obs_point.push_back(pb);
+  b.obs_bearing.insert(b.obs_bearing.end(), cost->row.begin(), cost->row.begin() + 3);
   I.num_blocks++;
 }
 
@@ -649,8 +695,49 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       e.Check(pvlm_neq_create(e.ctx(), g.dev_poses, (int)g.ui.size(), g.ui.data(), g.uj.data(), &g.neq), "pvlm_neq_create");
     }
   }
+  // ---- reprojection sets: observations sorted by point, points resident on the GPU ------------------
+  bool have_bundles = false;
+  for (auto& b : I.bundles) {
+    if (b.obs_pose.empty()) continue;
+    have_bundles = true;
+    if (b.set) continue;
+    std::map<int, int> pidx, cidx;
+    const size_t n = b.obs_pose.size();
+    std::vector<int> obs_dev_point(n);
+    for (size_t i = 0; i < n; ++i) {
+      auto it = pidx.find(b.obs_point[i]);
+      if (it == pidx.end()) { it = pidx.insert({b.obs_point[i], (int)b.point_blocks.size()}).first; b.point_blocks.push_back(b.obs_point[i]); }
+      obs_dev_point[i] = it->second;
+    }
+    const int M = (int)b.point_blocks.size();
+    std::vector<int64_t> off((size_t)M + 1, 0);
+    for (size_t i = 0; i < n; ++i) off[(size_t)obs_dev_point[i] + 1]++;
+    for (int p = 0; p < M; ++p) off[(size_t)p + 1] += off[p];
+    std::vector<int64_t> fill(off.begin(), off.end() - 1);
+    std::vector<int> cam(n); std::vector<double> bearing(3 * n), points((size_t)M * 3);
+    for (size_t i = 0; i < n; ++i) {   // stable: insertion order inside a point's track
+      const size_t dst = (size_t)fill[obs_dev_point[i]]++;
+      auto ic = cidx.find(b.obs_pose[i]);
+      if (ic == cidx.end()) { ic = cidx.insert({b.obs_pose[i], (int)b.dev_to_pose.size()}).first; b.dev_to_pose.push_back(b.obs_pose[i]); }
+      cam[dst] = ic->second;
+      for (int k = 0; k < 3; ++k) bearing[3 * dst + k] = b.obs_bearing[3 * i + k];
+    }
+    std::vector<unsigned char> frozen((size_t)M, 0); bool any_frozen = false;
+    for (int p = 0; p < M; ++p) {
+      for (int k = 0; k < 3; ++k) points[(size_t)p * 3 + k] = I.blocks[b.point_blocks[p]][k];
+      if (I.constant[b.point_blocks[p]]) { frozen[p] = 1; any_frozen = true; }
+    }
+    e.Check(pvlm_ba_create(e.ctx(), M, (int64_t)n, off.data(), cam.data(), bearing.data(), points.data(), b.weight, &b.set), "pvlm_ba_create");
+    if (any_frozen) e.Check(pvlm_ba_set_constant(e.ctx(), b.set, frozen.data()), "pvlm_ba_set_constant");
+    int nu = 0;
+    pvlm_ba_structure(b.set, nullptr, nullptr, nullptr, &nu, nullptr, nullptr);
+    b.ui.resize(nu); b.uj.resize(nu);
+    pvlm_ba_structure(b.set, nullptr, nullptr, nullptr, nullptr, b.ui.data(), b.uj.data());
+    std::vector<int>().swap(b.obs_pose); std::vector<int>().swap(b.obs_point); std::vector<double>().swap(b.obs_bearing);
+    b.obs_pose.push_back(-1);   // keeps "non-empty" for later Solve calls on the same Problem
+  }
 
-  // ---- free-parameter layout -----------------------------------------------------------------------
+  // ---- free-parameter layout (pose blocks; the point blocks never reach the host system) -------------
   std::vector<int> block_off(I.blocks.size(), -1);
   int n_free = 0;
   for (int p = 0; p < NP; ++p)
@@ -662,8 +749,10 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   auto load_x = [&]() { for (size_t b = 0; b < I.blocks.size(); ++b) for (int k = 0; k < 3; ++k) x[3 * b + k] = I.blocks[b][k]; };
   auto store_x = [&](const std::vector<double>& v) { for (size_t b = 0; b < I.blocks.size(); ++b) for (int k = 0; k < 3; ++k) I.blocks[b][k] = v[3 * b + k]; };
   load_x();
+  // scalar row/col index of (pose, half, k)
+  auto idx = [&](int pose, int r) { const int b = r < 3 ? I.poses[pose].first : I.poses[pose].second; return block_off[b] < 0 ? -1 : block_off[b] + (r % 3); };
 
-  // evaluates cost (+ H, g when want_H) at parameter vector v
+  // evaluates cost (+ H, g when want_H) of the four-block groups at parameter vector v
   auto evaluate = [&](const std::vector<double>& v, bool want_H, Assembled& A) {
     A.cost = 0; A.g.assign(n_free, 0.0); A.H.clear();
     for (auto& g : I.groups) {
@@ -700,100 +789,214 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     }
   };
 
+  // ---- reprojection sets: reduced camera system for a given trust-region radius ------------------------
+  struct Reduced {
+    double cost = 0, gmax_points = 0;
+    std::vector<double> g_red, g_cam, Udiag;                  // n_free each
+    std::map<std::pair<int, int>, std::array<double, 36>> H;  // Schur complement blocks (pose a <= pose b)
+  };
+  auto bundle_poses = [&](const Problem::Impl::Bundle& b, const std::vector<double>& v) {
+    const int nd = (int)b.dev_to_pose.size();
+    std::vector<double> aa((size_t)nd * 3), tt((size_t)nd * 3);
+    for (int d = 0; d < nd; ++d) {
+      const int p = b.dev_to_pose[d];
+      for (int k = 0; k < 3; ++k) { aa[3 * d + k] = v[3 * I.poses[p].first + k]; tt[3 * d + k] = v[3 * I.poses[p].second + k]; }
+    }
+    e.Check(pvlm_set_poses(e.ctx(), nd, aa.data(), tt.data()), "pvlm_set_poses");
+  };
+  auto bundle_reduce = [&](const std::vector<double>& v, double radius, bool init, Reduced& R) {
+    R = Reduced(); R.g_red.assign(n_free, 0.0); R.g_cam.assign(n_free, 0.0); R.Udiag.assign(n_free, 0.0);
+    for (auto& b : I.bundles) {
+      if (!b.set) continue;
+      bundle_poses(b, v);
+      std::vector<double> packed((size_t)pvlm_ba_packed_size(b.set), 0.0);
+      e.Check(pvlm_ba_reduce(e.ctx(), b.set, b.loss ? b.loss->kind() : PVLM_LOSS_NONE, b.loss ? b.loss->a() : 0.0, init ? 1 : 0, radius,
+                             opt.min_lm_diagonal, opt.max_lm_diagonal, packed.data()), "pvlm_ba_reduce");
+      const int nd = (int)b.dev_to_pose.size(), nu = (int)b.ui.size();
+      const double* Hd = packed.data(); const double* Ho = Hd + (size_t)nd * 36; const double* gg = Ho + (size_t)nu * 36;
+      const double* Ud = gg + (size_t)nd * 6 + 1; const double* gc = Ud + (size_t)nd * 6;
+      R.cost += gg[(size_t)nd * 6];
+      R.gmax_points = std::max(R.gmax_points, packed.back());
+      for (int d = 0; d < nd; ++d) {
+        const int p = b.dev_to_pose[d];
+        auto& blk = R.H[{p, p}];
+        for (int k = 0; k < 36; ++k) blk[k] += Hd[(size_t)d * 36 + k];
+        for (int r = 0; r < 6; ++r) {
+          const int i = idx(p, r);
+          if (i < 0) continue;
+          R.g_red[i] += gg[(size_t)d * 6 + r]; R.g_cam[i] += gc[(size_t)d * 6 + r]; R.Udiag[i] += Ud[(size_t)d * 6 + r];
+        }
+      }
+      for (int u = 0; u < nu; ++u) {
+        const int pa = b.dev_to_pose[b.ui[u]], pb = b.dev_to_pose[b.uj[u]];
+        const double* src = Ho + (size_t)u * 36;
+        if (pa <= pb) { auto& blk = R.H[{pa, pb}]; for (int k = 0; k < 36; ++k) blk[k] += src[k]; }
+        else { auto& blk = R.H[{pb, pa}]; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[r * 6 + c] += src[c * 6 + r]; }
+      }
+    }
+  };
+  // back-substitutes the points for the (unscaled) camera step; out3 += [model decrease, |dX|^2, |X|^2]
+  auto bundle_step = [&](const std::vector<double>& step, double* out3) {
+    for (auto& b : I.bundles) {
+      if (!b.set) continue;
+      const int nd = (int)b.dev_to_pose.size();
+      std::vector<double> dcam((size_t)nd * 6, 0.0);
+      for (int d = 0; d < nd; ++d)
+        for (int r = 0; r < 6; ++r) { const int i = idx(b.dev_to_pose[d], r); if (i >= 0) dcam[(size_t)d * 6 + r] = step[i]; }
+      double o[3];
+      e.Check(pvlm_ba_step(e.ctx(), b.set, b.loss ? b.loss->kind() : PVLM_LOSS_NONE, b.loss ? b.loss->a() : 0.0, dcam.data(), o), "pvlm_ba_step");
+      for (int k = 0; k < 3; ++k) out3[k] += o[k];
+    }
+  };
+  auto bundle_cost = [&](const std::vector<double>& v, bool candidate) {
+    double c = 0.0;
+    for (auto& b : I.bundles) {
+      if (!b.set) continue;
+      bundle_poses(b, v);
+      double ci = 0.0;
+      e.Check(pvlm_ba_cost(e.ctx(), b.set, b.loss ? b.loss->kind() : PVLM_LOSS_NONE, b.loss ? b.loss->a() : 0.0, candidate ? 1 : 0, &ci), "pvlm_ba_cost");
+      c += ci;
+    }
+    return c;
+  };
+  auto finish_points = [&]() {   // the refined structure goes back into the caller's point blocks
+    for (auto& b : I.bundles) {
+      if (!b.set) continue;
+      std::vector<double> X(b.point_blocks.size() * 3);
+      e.Check(pvlm_ba_get_points(e.ctx(), b.set, 0, X.data()), "pvlm_ba_get_points");
+      for (size_t p = 0; p < b.point_blocks.size(); ++p) for (int k = 0; k < 3; ++k) I.blocks[b.point_blocks[p]][k] = X[3 * p + k];
+    }
+  };
+
+  double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
   Assembled A;
   evaluate(x, true, A);
-  summary->initial_cost = summary->final_cost = A.cost;
-  summary->cost_history.push_back(A.cost);
+  Reduced R; R.g_red.assign(n_free, 0.0); R.g_cam.assign(n_free, 0.0); R.Udiag.assign(n_free, 0.0);
+  bool R_valid = true;
+  if (have_bundles) bundle_reduce(x, radius, true, R);
+  double cost = A.cost + R.cost;
+  summary->initial_cost = summary->final_cost = cost;
+  summary->cost_history.push_back(cost);
   summary->num_successful_steps = 1;  // iteration 0 counts as successful in Ceres' summary ([recalled])
-  summary->usable = std::isfinite(A.cost);
+  summary->usable = std::isfinite(cost);
   if (!summary->usable) { summary->message = "initial cost is not finite"; return; }
-  if (n_free == 0) return;
+  if (n_free == 0 && !have_bundles) return;
 
-  // scalar row/col index of (pose, half, k)
-  auto idx = [&](int pose, int r) { const int b = r < 3 ? I.poses[pose].first : I.poses[pose].second; return block_off[b] < 0 ? -1 : block_off[b] + (r % 3); };
-  // envelope
-  auto build_first = [&](const Assembled& As) {
+  // envelope of the camera/LiDAR system (four-block groups + Schur complement blocks)
+  auto build_first = [&](const Assembled& As, const Reduced& Rs) {
     std::vector<int> first(n_free);
     for (int i = 0; i < n_free; ++i) first[i] = i;
-    for (auto& kv : As.H)
+    auto add = [&](const std::pair<int, int>& key) {
       for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-        const int i = idx(kv.first.first, r), j = idx(kv.first.second, c);
+        const int i = idx(key.first, r), j = idx(key.second, c);
         if (i < 0 || j < 0) continue;
         const int hi = std::max(i, j), lo = std::min(i, j);
         first[hi] = std::min(first[hi], lo);
       }
-    // a 3-block's rows share the envelope start (keeps the profile monotone inside blocks)
+    };
+    for (auto& kv : As.H) add(kv.first);
+    for (auto& kv : Rs.H) add(kv.first);
     return first;
+  };
+  // diagonal of the FULL J^T J on the free pose columns (before any elimination)
+  auto full_diag = [&](const Assembled& As, const Reduced& Rs) {
+    std::vector<double> d(n_free, 0.0);
+    for (auto& kv : As.H) if (kv.first.first == kv.first.second)
+      for (int r = 0; r < 6; ++r) { const int i = idx(kv.first.first, r); if (i >= 0) d[i] = kv.second[r * 6 + r]; }
+    for (int i = 0; i < n_free; ++i) d[i] += Rs.Udiag[i];
+    return d;
   };
 
   // Jacobi scaling from the initial Jacobian: 1 / (1 + sqrt(diag(J^T J)))   (Ceres jacobi_scaling)
   std::vector<double> scale(n_free, 1.0);
-  for (auto& kv : A.H) if (kv.first.first == kv.first.second)
-    for (int r = 0; r < 6; ++r) { const int i = idx(kv.first.first, r); if (i >= 0) scale[i] = 1.0 / (1.0 + std::sqrt(std::max(0.0, kv.second[r * 6 + r]))); }
+  {
+    const std::vector<double> d0 = full_diag(A, R);
+    for (int i = 0; i < n_free; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(std::max(0.0, d0[i])));
+  }
 
-  double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
-  double cost = A.cost;
   int iter = 0;
-  auto gmax = [&](const Assembled& As) { double m = 0; for (double v : As.g) m = std::max(m, std::fabs(v)); return m; };
-  if (gmax(A) <= opt.gradient_tolerance) { summary->message = "gradient tolerance reached"; return; }
-  while (iter < opt.max_num_iterations) {
-    ++iter;
-    // scaled system  (D H D + diag(clamp(diag(D H D))) / radius) dy = -D g
-    Skyline S;
-    S.Init(build_first(A));
-    for (auto& kv : A.H)
+  auto gmax = [&](const Assembled& As, const Reduced& Rs) {
+    double m = Rs.gmax_points;
+    for (int i = 0; i < n_free; ++i) m = std::max(m, std::fabs(As.g[i] + Rs.g_cam[i]));
+    return m;
+  };
+  if (gmax(A, R) <= opt.gradient_tolerance) { summary->message = "gradient tolerance reached"; finish_points(); return; }
+  auto fill = [&](Skyline& S, const std::map<std::pair<int, int>, std::array<double, 36>>& H) {
+    for (auto& kv : H)
       for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
         const int i = idx(kv.first.first, r), j = idx(kv.first.second, c);
         if (i < 0 || j < 0) continue;
         const double v = kv.second[r * 6 + c] * scale[i] * scale[j];
-        if (kv.first.first == kv.first.second) { if (i >= j) S.at(i, j) = v; }   // diagonal block: lower triangle once
+        if (kv.first.first == kv.first.second) { if (i >= j) S.at(i, j) += v; }   // diagonal block: lower triangle once
         else if (i >= j) S.at(i, j) += v; else S.at(j, i) += v;
       }
-    std::vector<double> Hs_diag(n_free), rhs(n_free);
-    for (int i = 0; i < n_free; ++i) { Hs_diag[i] = S.at(i, i); rhs[i] = -A.g[i] * scale[i]; }
-    // keep an unfactored copy for the model cost
-    Skyline S0 = S;
-    for (int i = 0; i < n_free; ++i) S.at(i, i) += std::min(std::max(Hs_diag[i], opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
-    bool step_ok = S.Factor();
+  };
+  while (iter < opt.max_num_iterations) {
+    ++iter;
+    if (!R_valid) { bundle_reduce(x, radius, false, R); R_valid = true; }
+    // scaled system  (D (H + S_points) D + diag(clamp(diag(D J^T J D))) / radius) dy = -D g
+    Skyline S0;                      // four-block groups only: the Gauss-Newton model of those blocks
+    S0.Init(build_first(A, R));
+    fill(S0, A.H);
+    Skyline S = S0;
+    if (have_bundles) fill(S, R.H);
+    const std::vector<double> dfull = full_diag(A, R);
+    std::vector<double> rhs(n_free);
+    for (int i = 0; i < n_free; ++i) {
+      rhs[i] = -(A.g[i] + R.g_red[i]) * scale[i];
+      const double hs = dfull[i] * scale[i] * scale[i];
+      S.at(i, i) += std::min(std::max(hs, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
+    }
+    bool step_ok = n_free == 0 || S.Factor();
     std::vector<double> dy = rhs;
-    double model_change = 0.0;
+    double model_change = 0.0, dn = 0.0, xn = 0.0;
     if (step_ok) {
-      S.Solve(dy);
-      // model_cost_change = -(g'.dy + 1/2 dy^T H' dy)
+      if (n_free) S.Solve(dy);
+      // model_cost_change = -(g'.dy + 1/2 dy^T H' dy) over the four-block groups ...
       double gd = 0.0, dHd = 0.0;
-      for (int i = 0; i < n_free; ++i) gd += -rhs[i] * dy[i];
+      for (int i = 0; i < n_free; ++i) gd += (A.g[i] * scale[i]) * dy[i];
       for (int i = 0; i < n_free; ++i) {
         double s = 0.0;
         for (int k = S0.first[i]; k < i; ++k) s += S0.at(i, k) * dy[k];
         dHd += dy[i] * (2.0 * s + S0.at(i, i) * dy[i]);
       }
       model_change = -(gd + 0.5 * dHd);
+      // ... plus the reprojection blocks' own model decrease after back-substituting their points
+      if (have_bundles) {
+        std::vector<double> step(n_free);
+        for (int i = 0; i < n_free; ++i) step[i] = dy[i] * scale[i];
+        double o3[3] = {0, 0, 0};
+        bundle_step(step, o3);
+        model_change += o3[0]; dn += o3[1]; xn += o3[2];
+      }
       step_ok = model_change > 0.0 && std::isfinite(model_change);
     }
     bool accepted = false;
-    double xn = 0.0, dn = 0.0;
     if (step_ok) {
       std::vector<double> cand = x;
       for (size_t b = 0; b < I.blocks.size(); ++b)
         if (block_off[b] >= 0) for (int k = 0; k < 3; ++k) { const double d = dy[block_off[b] + k] * scale[block_off[b] + k]; cand[3 * b + k] += d; dn += d * d; xn += x[3 * b + k] * x[3 * b + k]; }
       Assembled C;
       evaluate(cand, true, C);
-      const double rho = (cost - C.cost) / model_change;
+      const double ccost = C.cost + (have_bundles ? bundle_cost(cand, true) : 0.0);
+      const double rho = (cost - ccost) / model_change;
       if (opt.minimizer_progress_to_stdout)
-        printf("iter %2d cost %.8e -> %.8e  model %.3e rho %.3f radius %.3e\n", iter, cost, C.cost, model_change, rho, radius);
-      if (std::isfinite(C.cost) && rho > opt.min_relative_decrease) {
+        printf("iter %2d cost %.8e -> %.8e  model %.3e rho %.3f radius %.3e\n", iter, cost, ccost, model_change, rho, radius);
+      if (std::isfinite(ccost) && rho > opt.min_relative_decrease) {
         accepted = true;
-        const double cost_change = cost - C.cost;
+        const double cost_change = cost - ccost;
         x = cand; A = std::move(C);
+        for (auto& b : I.bundles) if (b.set) e.Check(pvlm_ba_accept(e.ctx(), b.set), "pvlm_ba_accept");
         const double f = 1.0 - std::pow(2.0 * rho - 1.0, 3);
         radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, f));
         decrease_factor = 2.0;
+        if (have_bundles) { bundle_reduce(x, radius, false, R); R_valid = true; }   // gradient at the new point + next system
         summary->num_successful_steps++;
-        summary->cost_history.push_back(A.cost);
         const double prev = cost;
-        cost = A.cost;
+        cost = ccost;
+        summary->cost_history.push_back(cost);
         if (std::fabs(cost_change) <= opt.function_tolerance * prev) { summary->message = "function tolerance reached"; break; }
-        if (gmax(A) <= opt.gradient_tolerance) { summary->message = "gradient tolerance reached"; break; }
+        if (gmax(A, R) <= opt.gradient_tolerance) { summary->message = "gradient tolerance reached"; break; }
         if (std::sqrt(dn) <= opt.parameter_tolerance * (std::sqrt(xn) + opt.parameter_tolerance)) { summary->message = "parameter tolerance reached"; break; }
       }
     }
@@ -801,11 +1004,13 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       summary->num_unsuccessful_steps++;
       radius /= decrease_factor;
       decrease_factor *= 2.0;
+      R_valid = !have_bundles;
       if (radius < opt.min_trust_region_radius) { summary->message = "trust region collapsed"; break; }
     }
   }
   if (summary->message.empty()) summary->message = "maximum number of iterations reached";
   store_x(x);
+  finish_points();
   summary->final_cost = cost;
   summary->usable = std::isfinite(cost);
 }
@@ -835,6 +1040,11 @@ CostFunction* Point2Line_Angle::Create(const Vector3d& p, const Vector3d& a, con
 }
 CostFunction* Plane2Plane_Global::Create(const Vector3d& n, const Vector3d& a, const Vector3d& b, const double w) {
   return MakeCost(PVLM_PLANE2PLANE_GLOBAL, 0, 1.0, {n[0], n[1], n[2], a[0], a[1], a[2], b[0], b[1], b[2], w});
+}
+CostFunction* PanoramaReprojResidual_1Angle::Create(const Vector3d& pt, double w) {
+  CostFunction* c = MakeCost(kReprojKind, 0, w, {pt[0], pt[1], pt[2]});
+  c->num_blocks = 3;
+  return c;
 }
 CostFunction* PlaneIOUResidual::Create(const Vector4d& pl, const Vector3d& mn, const Vector3d& mr, const double angle, const double w) {
   return MakeCost(PVLM_PLANE_IOU, 0, 1.0, {pl[0], pl[1], pl[2], pl[3], mn[0], mn[1], mn[2], mr[0], mr[1], mr[2], angle, w});
@@ -911,6 +1121,16 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   }
   if (!loss_used) delete loss;
   return num;
+}
+
+ceres_like::Solver::Options SetOptionsSfM(const int num_threads) {
+  // util/Optimization.cpp:608-634: Ceres defaults (50 iterations, LM) with a *_SCHUR linear solver — the point
+  // blocks are eliminated, which is what Solve does for the reprojection sets on the GPU.
+  ceres_like::Solver::Options o;
+  o.minimizer_progress_to_stdout = false;
+  o.num_threads = num_threads;
+  o.linear_solver_type = ceres_like::SPARSE_SCHUR;
+  return o;
 }
 
 ceres_like::Solver::Options SetOptionsLidar(const int num_threads, const int lidar_size) {
@@ -1270,6 +1490,37 @@ static Matrix4d Mul4(const Matrix4d& A, const Matrix4d& B) {
   return C;
 }
 
+// ================================================================================================
+// AddCameraResidual — util/Optimization.cpp:172-222 (ANGLE_RESIDUAL_1)
+// ================================================================================================
+size_t AddCameraResidual(const std::vector<Frame>& frames, std::vector<Vector3d>& angleAxis_cw_list, std::vector<Vector3d>& t_cw_list,
+                         std::vector<PointTrack>& structure, ceres_like::Problem& problem, int residual_type, double weight) {
+  if (residual_type != ANGLE_RESIDUAL_1)
+    throw std::runtime_error("AddCameraResidual: only ANGLE_RESIDUAL_1 (the variant CameraLidarOptimizer::Optimize uses) is mirrored");
+  if (frames.empty() || structure.empty()) return 0;
+  const Equirect eq{frames[0].GetImageCols(), frames[0].GetImageRows()};           // :178
+  ceres_like::LossFunction* loss_function = new ceres_like::HuberLoss(4.0 * M_PI / 180.0);   // :180-181
+  size_t num_residual = 0;
+  for (size_t i = 0; i < structure.size(); i++) {
+    PointTrack& track = structure[i];
+    for (const std::pair<uint32_t, uint32_t>& pair : track.feature_pairs) {
+      const uint32_t frame_idx = pair.first;
+      if (!frames[frame_idx].IsPoseValid()) continue;                                // :192-193
+      // eq.ImageToCam(keypoint.pt) binds to ImageToCam(const cv::Point2i&): the float keypoint is converted with
+      // saturate_cast<int> (= cvRound, round-half-even), then un-projected in float with r = 1 (Equirectangular.h:153-161)
+      const std::array<float, 2>& kp = frames[frame_idx].keypoints[pair.second];
+      const float px[2] = {(float)(int)std::lrintf(kp[0]), (float)(int)std::lrintf(kp[1])};
+      float cam[3];
+      eq.ImageToCam(px, 1.f, cam);
+      ceres_like::CostFunction* cost_function = PanoramaReprojResidual_1Angle::Create({(double)cam[0], (double)cam[1], (double)cam[2]}, weight);
+      problem.AddResidualBlock(cost_function, loss_function, angleAxis_cw_list[frame_idx].data(), t_cw_list[frame_idx].data(), track.point_3d.data());
+      num_residual++;
+    }
+  }
+  if (num_residual == 0) delete loss_function;
+  return num_residual;
+}
+
 std::vector<std::vector<int>> CameraLidarOptimizer::NeighborEachFrame(const int neighbor_size, const bool temporal) const {
   std::vector<std::vector<int>> out(frames.size());
   if (!temporal) throw std::runtime_error("NeighborEachFrame: only the temporal branch (the one JointOptimize uses) is mirrored");
@@ -1298,8 +1549,9 @@ CameraLidarOptimizer::LinePairs CameraLidarOptimizer::AssociateLineMulti(const i
   return all;
 }
 
-int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const bool refine_camera_rotation, const bool refine_camera_trans,
-                                   const bool refine_lidar_rotation, const bool refine_lidar_trans, double& cost, int& steps) {
+int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, std::vector<PointTrack>& structure, const bool refine_camera_rotation,
+                                   const bool refine_camera_trans, const bool refine_lidar_rotation, const bool refine_lidar_trans,
+                                   const bool refine_structure, double& cost, int& steps) {
   std::vector<Vector3d> aa_cw(frames.size(), Vector3d{0, 0, 0}), t_cw(frames.size(), Vector3d{0, 0, 0});
   std::vector<Vector3d> aa_lw(lidars.size(), Vector3d{0, 0, 0}), t_lw(lidars.size(), Vector3d{0, 0, 0});
   std::vector<bool> frame_valid(frames.size());
@@ -1326,6 +1578,8 @@ int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const bool refin
   const size_t n_cl = AddCameraLidarResidual(frames.empty() ? 0 : frames[0].rows, frames.empty() ? 0 : frames[0].cols, frame_valid, lidars, aa_cw, t_cw,
                                              aa_lw, t_lw, line_pairs, loss1, problem, config.camera_lidar_weight);
   if (n_cl == 0) delete loss1;
+  // 3. camera-camera: reprojection of the triangulated tracks (CameraLidarOptimizer.cpp:431-432)
+  if (!structure.empty()) AddCameraResidual(frames, aa_cw, t_cw, structure, problem, RESIDUAL_TYPE::ANGLE_RESIDUAL_1, config.camera_weight);
   const std::vector<std::vector<int>> neighbors = FindNeighbors(lidars, 6);
   if (config.line_to_line_residual) {
     LidarLineMatch matcher(lidars);
@@ -1338,6 +1592,8 @@ int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const bool refin
   if (config.point_to_plane_residual)
     AddLidarPointToPlaneResidual(neighbors, lidars, aa_lw, t_lw, problem, config.point_to_plane_dis_threshold, config.lidar_plane_tolerance,
                                  config.angle_residual, config.normalize_distance, config.lidar_weight);
+  if (!refine_structure)                                                         // :462-466
+    for (PointTrack& track : structure) problem.SetParameterBlockConstant(track.point_3d.data());
   for (size_t i = 0; i < frames.size(); i++)
     if (frame_valid[i]) {
       if (!refine_camera_rotation) problem.SetParameterBlockConstant(aa_cw[i].data());
@@ -1350,8 +1606,7 @@ int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const bool refin
     }
   if (!frames.empty()) { problem.SetParameterBlockConstant(aa_cw[0].data()); problem.SetParameterBlockConstant(t_cw[0].data()); }   // :490-491
   last_blocks_ = problem.NumResidualBlocks();
-  ceres_like::Solver::Options options;   // SetOptionsSfM: Ceres defaults (50 iterations), sparse Schur
-  options.num_threads = config.num_threads;
+  ceres_like::Solver::Options options = SetOptionsSfM(config.num_threads);
   ceres_like::Solver::Summary summary;
   ceres_like::Solve(options, &problem, &summary);
   if (!summary.IsSolutionUsable()) return 0;
@@ -1384,7 +1639,7 @@ bool CameraLidarOptimizer::JointOptimize() {
   for (int iter = 0; iter < num_iteration_joint; iter++) {
     size_t npairs = 0;
     for (auto& kv : pairs) npairs += kv.second.size();
-    Optimize(pairs, true, true, true, true, curr_cost, curr_step);
+    Optimize(pairs, structure, true, true, true, true, true, curr_cost, curr_step);
     log.push_back({curr_cost, curr_step, last_blocks_, npairs});
     pairs.clear();
     pairs = AssociateLineMulti(neighbor_size_joint, true);

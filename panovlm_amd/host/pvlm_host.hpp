@@ -57,6 +57,7 @@ struct Config {
   double lidar_plane_tolerance = 0.05;
   double lidar_weight = 1.0;
   double camera_lidar_weight = 1.0;
+  double camera_weight = 1.0;
   int num_threads = 25;
   int num_iteration_lidar = 7;
 };
@@ -156,7 +157,9 @@ class CostFunction {
   virtual ~CostFunction() {}
   // ceres::CostFunction::Evaluate: parameters = {aa_r, t_r, aa_n, t_n}; jacobians may be null, and each
   // jacobians[i] may be null.  Evaluated on the GPU (one-row residual set) — API parity, not the fast path.
+  // The reprojection functor has THREE blocks {aa_cw, t_cw, point_3d} (num_blocks == 3).
   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const;
+  int num_blocks = 4;
   int kind = 0;
   unsigned flags = 0;
   double weight = 1.0;
@@ -178,6 +181,9 @@ class Problem {
   ~Problem();
   // Takes ownership of cost (and of loss, shared by many blocks like in Ceres).
   void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_r, double* t_r, double* aa_n, double* t_n);
+  // Three-block form of AddCameraResidual (util/Optimization.cpp:198-201): camera pose + a free 3-D point.
+  // The point blocks live on the GPU during Solve and are eliminated there (Schur complement).
+  void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_c, double* t_c, double* point_3d);
   // Device-resident hand-off: a residual set produced by the association kernels; segment p uses
   // the parameter blocks (aa[ref_p], t[ref_p], aa[nei_p], t[nei_p]) of the given lists (ids = list index).
   void AddResidualSet(pvlm_resset* set, LossFunction* loss, std::vector<Vector3d>* aa_list, std::vector<Vector3d>* t_list);
@@ -225,6 +231,9 @@ struct Point2Line_Meter { static ceres_like::CostFunction* Create(const Vector3d
 struct Point2Line_Angle { static ceres_like::CostFunction* Create(const Vector3d& curr_point, const Vector3d& last_point_a, const Vector3d& last_point_b, const bool normalize, const double weight = 1); };
 struct Plane2Plane_Global { static ceres_like::CostFunction* Create(const Vector3d& plane_ref, const Vector3d& point_a, const Vector3d& point_b, const double w = 1.0); };
 struct PlaneIOUResidual { static ceres_like::CostFunction* Create(const Vector4d& ref_plane, const Vector3d& middle_neighbor, const Vector3d& middle_ref, const double angle, const double weight = 1.0); };
+// base/CostFunction.h:218-247 — AutoDiffCostFunction<.,1,3,3,3> on (angleAxis_cw, t_cw, point_3d)
+struct PanoramaReprojResidual_1Angle { static ceres_like::CostFunction* Create(const Vector3d& pt, double weight = 1.0); };
+constexpr int kReprojKind = 100;   // CostFunction::kind of the three-block functor (not a pvlm_functor)
 
 // ---- util/Optimization.h ---------------------------------------------------------------------------------
 size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
@@ -246,6 +255,21 @@ size_t AddCameraLidarResidual(int rows, int cols, const std::vector<bool>& frame
                               const std::map<std::pair<size_t, size_t>, std::vector<CameraLidarLinePair>>& line_pairs,
                               ceres_like::LossFunction* loss_function, ceres_like::Problem& problem, double weight);
 ceres_like::Solver::Options SetOptionsLidar(const int num_threads, const int lidar_size);
+ceres_like::Solver::Options SetOptionsSfM(const int num_threads);                      // util/Optimization.cpp:608-634
+// util/Tracks.h:109-133 — a triangulated feature track: (frame index, keypoint index) pairs + the 3-D point
+struct PointTrack {
+  uint32_t id = 0xffffffffu;
+  std::set<std::pair<uint32_t, uint32_t>> feature_pairs;
+  Vector3d point_3d{{0, 0, 0}};
+};
+enum RESIDUAL_TYPE { ANGLE_RESIDUAL_1 = 0, ANGLE_RESIDUAL_2 = 1, PIXEL_RESIDUAL = 2 };
+struct Frame;
+// AddCameraResidual (util/Optimization.cpp:172-222), ANGLE_RESIDUAL_1 branch (the one Optimize uses,
+// CameraLidarOptimizer.cpp:431-432): one PanoramaReprojResidual_1Angle per (track, observation) whose frame has a
+// valid pose; bearing = eq.ImageToCam(keypoint.pt) — which resolves to the cv::Point2i overload, i.e. the keypoint
+// is rounded to the nearest pixel (cvRound) and un-projected in float; HuberLoss(4 deg).
+size_t AddCameraResidual(const std::vector<Frame>& frames, std::vector<Vector3d>& angleAxis_cw_list, std::vector<Vector3d>& t_cw_list,
+                         std::vector<PointTrack>& structure, ceres_like::Problem& problem, int residual_type, double weight);
 
 // util/FileIO.cpp:11-79, :168-191 — pose text files: one row per pose, optional name + 12 numbers
 // (R row-major interleaved with t: r00 r01 r02 tx r10 r11 r12 ty r20 r21 r22 tz); rows containing
@@ -312,7 +336,10 @@ struct Frame {
   Vector3d t_wc{{0, 0, 0}};
   bool pose_valid = true;
   std::vector<std::array<float, 4>> lines;
+  std::vector<std::array<float, 2>> keypoints;   // GetKeyPoints()[k].pt (SIFT keypoints, pixels)
   bool IsPoseValid() const { return pose_valid; }
+  int GetImageRows() const { return rows; }
+  int GetImageCols() const { return cols; }
   Matrix4d GetPose() const { return {R_wc[0], R_wc[1], R_wc[2], t_wc[0], R_wc[3], R_wc[4], R_wc[5], t_wc[1], R_wc[6], R_wc[7], R_wc[8], t_wc[2], 0, 0, 0, 1}; }
 };
 
@@ -324,12 +351,20 @@ class CameraLidarOptimizer {
                        int neighbor_size_joint = 3, int num_iteration_joint = 5)
       : T_cl_init(T_cl), lidars(lidars), frames(frames), config(config), neighbor_size_joint(neighbor_size_joint), num_iteration_joint(num_iteration_joint) {}
   // JointOptimize(true), MAPPING mode loop of CameraLidarOptimizer.cpp:260-285.  The SfM reprojection term
-  // (AddCameraResidual, free 3-D points) is outside the hot path's scope and not added.
+  // (AddCameraResidual, free 3-D points) is added when a structure has been set (SetStructure stands for
+  // ReadPointTracks(points.bin), :255); with an empty structure the problem has the LiDAR terms only.
   bool JointOptimize();
+  void SetStructure(const std::vector<PointTrack>& s) { structure = s; }
+  const std::vector<PointTrack>& GetStructure() const { return structure; }
   std::vector<std::vector<int>> NeighborEachFrame(const int neighbor_size, const bool temporal) const;   // :551-610 (temporal branch)
   LinePairs AssociateLineMulti(const int neighbor_size, const bool temporal = true);                      // :331-384
+  int Optimize(const LinePairs& line_pairs, std::vector<PointTrack>& structure, const bool refine_camera_rotation, const bool refine_camera_trans,
+               const bool refine_lidar_rotation, const bool refine_lidar_trans, const bool refine_structure, double& cost, int& steps);   // :387-548
   int Optimize(const LinePairs& line_pairs, const bool refine_camera_rotation, const bool refine_camera_trans, const bool refine_lidar_rotation,
-               const bool refine_lidar_trans, double& cost, int& steps);                                   // :387-548
+               const bool refine_lidar_trans, double& cost, int& steps) {                                  // no SfM term
+    std::vector<PointTrack> none;
+    return Optimize(line_pairs, none, refine_camera_rotation, refine_camera_trans, refine_lidar_rotation, refine_lidar_trans, true, cost, steps);
+  }
   const std::vector<Velodyne>& GetLidars() const { return lidars; }
   const std::vector<Frame>& GetFrames() const { return frames; }
   struct IterLog { double cost; int steps; int residual_blocks; size_t line_pairs; };
@@ -338,6 +373,7 @@ class CameraLidarOptimizer {
   Matrix4d T_cl_init;
   std::vector<Velodyne> lidars;
   std::vector<Frame> frames;
+  std::vector<PointTrack> structure;
   Config config;
   int neighbor_size_joint, num_iteration_joint;
   int last_blocks_ = 0;

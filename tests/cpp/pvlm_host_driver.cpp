@@ -57,6 +57,52 @@ static std::vector<Velodyne> LoadScans(const std::string& path) {
   return out;
 }
 
+// structure.bin (tests/host_io.py::write_structure): per-frame keypoints + triangulated tracks
+static std::vector<PointTrack> LoadStructure(const std::string& path, std::vector<Frame>& frames) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+  int32_t nf = 0; rd(f, &nf, 1);
+  if ((size_t)nf != frames.size()) { fprintf(stderr, "structure/frames mismatch\n"); exit(2); }
+  for (Frame& fr : frames) {
+    int32_t nk = 0; rd(f, &nk, 1);
+    fr.keypoints.resize(nk);
+    for (auto& k : fr.keypoints) rd(f, k.data(), 2);
+  }
+  int32_t nt = 0; rd(f, &nt, 1);
+  std::vector<PointTrack> tracks(nt);
+  for (int i = 0; i < nt; ++i) {
+    tracks[i].id = (uint32_t)i;
+    rd(f, tracks[i].point_3d.data(), 3);
+    int32_t no = 0; rd(f, &no, 1);
+    for (int k = 0; k < no; ++k) { uint32_t pr[2]; rd(f, pr, 2); tracks[i].feature_pairs.insert({pr[0], pr[1]}); }
+  }
+  return tracks;
+}
+
+static std::vector<Frame> LoadFrames(std::ifstream& f, Matrix4d* T) {
+  rd(f, T->data(), 16);
+  int32_t nf = 0; rd(f, &nf, 1);
+  std::vector<Frame> frames(nf);
+  for (auto& fr : frames) {
+    int32_t h[4]; rd(f, h, 4);
+    fr.id = h[0]; fr.rows = h[1]; fr.cols = h[2]; fr.pose_valid = h[3] != 0;
+    rd(f, fr.R_wc.data(), 9); rd(f, fr.t_wc.data(), 3);
+    int32_t nl = 0; rd(f, &nl, 1);
+    fr.lines.resize(nl);
+    for (auto& x : fr.lines) rd(f, x.data(), 4);
+  }
+  return frames;
+}
+
+static void PrintFrames(const std::vector<Frame>& frames) {
+  for (const Frame& fr : frames) {
+    printf("frame %d", fr.id);
+    for (double x : fr.R_wc) printf(" %.17g", x);
+    for (double x : fr.t_wc) printf(" %.17g", x);
+    printf("\n");
+  }
+}
+
 static void PrintPoses(const std::vector<Velodyne>& l) {
   for (const Velodyne& v : l) {
     printf("pose %d", v.id);
@@ -138,32 +184,60 @@ int main(int argc, char** argv) {
                p.lidar_line_start[2], p.lidar_line_end[0], p.lidar_line_end[1], p.lidar_line_end[2]);
     } else if (cmd == "joint") {
       // joint <lidars.bin (LOCAL)> <frames.bin> neighbor_size iters l2l p2plane tol thr thr_line lidar_w cam_lidar_w
+      // optional: camera_w structure.bin  (adds the SfM reprojection term, AddCameraResidual)
       auto l = LoadScans(argv[2]);
       std::ifstream f(argv[3], std::ios::binary);
-      Matrix4d T; rd(f, T.data(), 16);
-      int32_t nf = 0; rd(f, &nf, 1);
-      std::vector<Frame> frames(nf);
-      for (auto& fr : frames) {
-        int32_t h[4]; rd(f, h, 4);
-        fr.id = h[0]; fr.rows = h[1]; fr.cols = h[2]; fr.pose_valid = h[3] != 0;
-        rd(f, fr.R_wc.data(), 9); rd(f, fr.t_wc.data(), 3);
-        int32_t nl = 0; rd(f, &nl, 1);
-        fr.lines.resize(nl);
-        for (auto& x : fr.lines) rd(f, x.data(), 4);
-      }
+      Matrix4d T;
+      std::vector<Frame> frames = LoadFrames(f, &T);
       Config cfg;
       cfg.line_to_line_residual = atoi(argv[6]) != 0; cfg.point_to_plane_residual = atoi(argv[7]) != 0;
       cfg.lidar_plane_tolerance = atof(argv[8]); cfg.point_to_plane_dis_threshold = atof(argv[9]); cfg.point_to_line_dis_threshold = atof(argv[10]);
       cfg.lidar_weight = atof(argv[11]); cfg.camera_lidar_weight = atof(argv[12]);
+      std::vector<PointTrack> structure;
+      if (argc > 14) { cfg.camera_weight = atof(argv[13]); structure = LoadStructure(argv[14], frames); }
       CameraLidarOptimizer opt(T, l, frames, cfg, atoi(argv[4]), atoi(argv[5]));
+      opt.SetStructure(structure);
       opt.JointOptimize();
       for (auto& it : opt.log) printf("iter cost %.17g steps %d blocks %d pairs %zu\n", it.cost, it.steps, it.residual_blocks, it.line_pairs);
       PrintPoses(opt.GetLidars());
-      for (const Frame& fr : opt.GetFrames()) {
-        printf("frame %d", fr.id);
-        for (double x : fr.R_wc) printf(" %.17g", x);
-        for (double x : fr.t_wc) printf(" %.17g", x);
-        printf("\n");
+      PrintFrames(opt.GetFrames());
+      for (const PointTrack& t : opt.GetStructure()) printf("point %u %.17g %.17g %.17g\n", t.id, t.point_3d[0], t.point_3d[1], t.point_3d[2]);
+    } else if (cmd == "bundle") {
+      // bundle <frames.bin> <structure.bin> camera_w refine_structure max_iter : camera-only bundle adjustment
+      // (AddCameraResidual + SetOptionsSfM + Solve, camera 0 constant) on the GPU with point elimination
+      std::ifstream f(argv[2], std::ios::binary);
+      Matrix4d T;
+      std::vector<Frame> frames = LoadFrames(f, &T);
+      std::vector<PointTrack> structure = LoadStructure(argv[3], frames);
+      std::vector<Vector3d> aa(frames.size(), Vector3d{0, 0, 0}), tt(frames.size(), Vector3d{0, 0, 0});
+      for (size_t i = 0; i < frames.size(); ++i) {
+        if (!frames[i].IsPoseValid()) continue;
+        const Matrix3d& R = frames[i].R_wc;
+        const Matrix3d R_cw = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+        RotationMatrixToAngleAxis(R_cw, &aa[i]);
+        for (int r = 0; r < 3; ++r) tt[i][r] = -((R_cw[3 * r] * frames[i].t_wc[0] + R_cw[3 * r + 1] * frames[i].t_wc[1]) + R_cw[3 * r + 2] * frames[i].t_wc[2]);
+      }
+      ceres_like::Problem problem;
+      const size_t nres = AddCameraResidual(frames, aa, tt, structure, problem, RESIDUAL_TYPE::ANGLE_RESIDUAL_1, atof(argv[4]));
+      if (atoi(argv[5]) == 0) for (PointTrack& t : structure) problem.SetParameterBlockConstant(t.point_3d.data());
+      problem.SetParameterBlockConstant(aa[0].data()); problem.SetParameterBlockConstant(tt[0].data());
+      ceres_like::Solver::Options options = SetOptionsSfM(1);
+      options.max_num_iterations = atoi(argv[6]);
+      ceres_like::Solver::Summary summary;
+      ceres_like::Solve(options, &problem, &summary);
+      printf("summary blocks %zu initial %.17g final %.17g successful %d unsuccessful %d msg %s\n", nres, summary.initial_cost, summary.final_cost,
+             summary.num_successful_steps, summary.num_unsuccessful_steps, summary.message.c_str());
+      for (size_t i = 0; i < frames.size(); ++i)
+        printf("cam %zu %.17g %.17g %.17g %.17g %.17g %.17g\n", i, aa[i][0], aa[i][1], aa[i][2], tt[i][0], tt[i][1], tt[i][2]);
+      for (const PointTrack& t : structure) printf("point %u %.17g %.17g %.17g\n", t.id, t.point_3d[0], t.point_3d[1], t.point_3d[2]);
+      // API parity: the three-block functor evaluated alone
+      if (!structure.empty() && !structure[0].feature_pairs.empty()) {
+        ceres_like::CostFunction* c = PanoramaReprojResidual_1Angle::Create({0.3, -0.2, 1.0}, 1.5);
+        const double* params[3] = {aa[1].data(), tt[1].data(), structure[0].point_3d.data()};
+        double r = 0, j0[3], j1[3], j2[3]; double* jac[3] = {j0, j1, j2};
+        c->Evaluate(params, &r, jac);
+        printf("single %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", r, j0[0], j0[1], j0[2], j1[0], j1[1], j1[2], j2[0], j2[1], j2[2]);
+        delete c;
       }
     } else if (cmd == "poseio") {
       // poseio <in.txt> <out.txt> with_invalid precision

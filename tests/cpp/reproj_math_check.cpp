@@ -15,14 +15,14 @@ extern "C" {
 struct chk_view {
   int n_points, n_cams, n_upairs; long long n_obs;
   const long long* pt_off; const int* cam; const int* obs_pt; const double* s; const double* X; double* Xc; double* scale; double* Vinv; double* gp;
-  const int* adj_off; const int* adj_cam; const int* adj_slot; double w; int loss; double a;
+  const int* adj_off; const int* adj_cam; const int* adj_slot; const unsigned char* frozen; double w; int loss; double a;
 };
 
 static pvlm_ba::View to_view(const chk_view* c) {
   pvlm_ba::View v;
   v.n_points = c->n_points; v.n_cams = c->n_cams; v.n_upairs = c->n_upairs; v.n_obs = c->n_obs; v.pt_off = c->pt_off; v.cam = c->cam;
   v.obs_pt = c->obs_pt; v.s = c->s; v.X = c->X; v.Xc = c->Xc; v.scale = c->scale; v.Vinv = c->Vinv; v.gp = c->gp; v.adj_off = c->adj_off;
-  v.adj_cam = c->adj_cam; v.adj_slot = c->adj_slot; v.w = c->w; v.loss = c->loss; v.a = c->a;
+  v.adj_cam = c->adj_cam; v.adj_slot = c->adj_slot; v.frozen = c->frozen; v.w = c->w; v.loss = c->loss; v.a = c->a;
   return v;
 }
 

@@ -66,3 +66,18 @@ def write_frames(path, T_cl, frames):
             lines = np.asarray(fr["lines"], np.float32).reshape(-1, 4)
             f.write(struct.pack("<i", len(lines)))
             f.write(lines.tobytes())
+
+
+def write_structure(path, frames, tracks):
+    """frames: list of dict with "keypoints" (n x 2 float32 pixels); tracks: list of dict(point (3), obs [(frame, keypoint), ...])."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(frames)))
+        for fr in frames:
+            kp = np.asarray(fr.get("keypoints", np.zeros((0, 2))), np.float32).reshape(-1, 2)
+            f.write(struct.pack("<i", len(kp))); f.write(kp.tobytes())
+        f.write(struct.pack("<i", len(tracks)))
+        for t in tracks:
+            f.write(np.asarray(t["point"], np.float64).reshape(3).tobytes())
+            f.write(struct.pack("<i", len(t["obs"])))
+            for fi, ki in t["obs"]:
+                f.write(struct.pack("<II", int(fi), int(ki)))

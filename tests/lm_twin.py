@@ -31,17 +31,42 @@ class Options:
     max_lm_diagonal = 1e32
 
 
-def solve(oracle, groups, aa, t, const_poses, opt=Options()):
+def solve(oracle, groups, aa, t, const_poses, opt=Options(), bundle=None):
     """groups: list of dict(kind, normalize, rows (oracle layout incl. weight), rid, nid, loss (0/1), a).
-    aa, t: F x 3 arrays updated in place.  const_poses: set of pose ids held constant (both blocks)."""
+    aa, t: F x 3 arrays updated in place.  const_poses: set of pose ids held constant (both blocks).
+    bundle: optional dict(bearing n x 3, cam n (pose ids), pt n, X M x 3 (updated in place), w, loss, a,
+    frozen (bool)) — PanoramaReprojResidual_1Angle blocks; the twin solves the FULL damped system (pose +
+    point columns, dense), which is what eliminating the points and back-substituting computes."""
     F = aa.shape[0]
-    used = sorted(set(np.concatenate([np.concatenate([g["rid"], g["nid"]]) for g in groups]).tolist()))
+    ids = [np.concatenate([g["rid"], g["nid"]]) for g in groups]
+    if bundle is not None:
+        ids.append(np.asarray(bundle["cam"]))
+    used = sorted(set(np.concatenate(ids).tolist()))
     free = [p for p in used if p not in const_poses]
     col = {p: 6 * i for i, p in enumerate(free)}
-    n = 6 * len(free)
+    n_pose = 6 * len(free)
+    M = 0 if bundle is None else bundle["X"].shape[0]
+    pts_free = bundle is not None and not bundle.get("frozen", False)
+    n = n_pose + (3 * M if pts_free else 0)
+    X0 = None if bundle is None else bundle["X"].copy()
 
-    def evaluate(a_, t_):
+    def evaluate(a_, t_, X_=None):
         H = np.zeros((n, n)); g = np.zeros(n); cost = 0.0
+        if bundle is not None:
+            rb, Jb = oracle.evaluate_reproj(bundle["bearing"], bundle["w"], bundle["cam"], bundle["pt"], a_, t_, X_)
+            wb, hb = synth.huber_weights(rb, bundle["loss"], bundle["a"])
+            cost += hb.sum()
+            for i in range(len(rb)):
+                cols = []
+                c = col.get(int(bundle["cam"][i]), None)
+                if c is not None:
+                    cols.append((c, Jb[i, :6]))
+                if pts_free:
+                    cols.append((n_pose + 3 * int(bundle["pt"][i]), Jb[i, 6:]))
+                for (ci, Ji) in cols:
+                    g[ci:ci + len(Ji)] += wb[i] * Ji * rb[i]
+                    for (cj, Jj) in cols:
+                        H[ci:ci + len(Ji), cj:cj + len(Jj)] += wb[i] * np.outer(Ji, Jj)
         for gr in groups:
             r, J = oracle.evaluate(gr["kind"], gr["rows"], gr["rid"], gr["nid"], a_, t_, normalize=gr["normalize"])
             w, half = synth.huber_weights(r, gr["loss"], gr["a"])
@@ -67,8 +92,8 @@ def solve(oracle, groups, aa, t, const_poses, opt=Options()):
                         H[ci:ci + 6, cj:cj + 6] += Hp[oi:oi + 6, oj:oj + 6]
         return cost, H, g
 
-    x_aa, x_t = aa.copy(), t.copy()
-    cost, H, g = evaluate(x_aa, x_t)
+    x_aa, x_t, x_X = aa.copy(), t.copy(), X0
+    cost, H, g = evaluate(x_aa, x_t, x_X)
     out = dict(initial_cost=cost, successful=1, unsuccessful=0, message="")
     if n == 0:
         out["final_cost"] = cost
@@ -98,14 +123,17 @@ def solve(oracle, groups, aa, t, const_poses, opt=Options()):
             c_aa, c_t = x_aa.copy(), x_t.copy()
             for p in free:
                 c_aa[p] += step[col[p]:col[p] + 3]; c_t[p] += step[col[p] + 3:col[p] + 6]
-            c_cost, cH, cg = evaluate(c_aa, c_t)
+            c_X = x_X
+            if pts_free:
+                c_X = x_X + step[n_pose:].reshape(M, 3)
+            c_cost, cH, cg = evaluate(c_aa, c_t, c_X)
             rho = (cost - c_cost) / model
             if np.isfinite(c_cost) and rho > opt.min_relative_decrease:
                 accepted = True
-                xn = np.sqrt(sum((x_aa[p] ** 2).sum() + (x_t[p] ** 2).sum() for p in free))
+                xn = np.sqrt(sum((x_aa[p] ** 2).sum() + (x_t[p] ** 2).sum() for p in free) + ((x_X ** 2).sum() if pts_free else 0.0))
                 change = cost - c_cost
                 prev = cost
-                x_aa, x_t, cost, H, g = c_aa, c_t, c_cost, cH, cg
+                x_aa, x_t, x_X, cost, H, g = c_aa, c_t, c_X, c_cost, cH, cg
                 radius = min(opt.max_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
                 dec = 2.0
                 out["successful"] += 1
@@ -122,6 +150,8 @@ def solve(oracle, groups, aa, t, const_poses, opt=Options()):
             if radius < opt.min_radius:
                 out["message"] = "trust region collapsed"
     aa[:] = x_aa; t[:] = x_t
+    if bundle is not None:
+        bundle["X"][:] = x_X
     out["final_cost"] = cost
     return out
 
@@ -285,7 +315,48 @@ def associate_line_multi(oracle, lidars, frames, T_cl_init, neighbor_size):
     return out
 
 
-def joint_optimize_step(oracle, lidars, frames, pairs, cfg):
+# ------------------------------------------------------------------------------------------------
+# SfM reprojection term: AddCameraResidual (util/Optimization.cpp:172-222) on the oracle
+# ------------------------------------------------------------------------------------------------
+def reproj_blocks(oracle, frames, tracks, cam_offset=0):
+    """(cam ids, point ids, bearings) of the PanoramaReprojResidual_1Angle blocks: one per (track, observation)
+    in a frame with a valid pose; bearing = float ImageToCam of the keypoint ROUNDED to the nearest pixel
+    (the cv::Point2i overload the reference's call binds to)."""
+    cam, pt, bearing = [], [], []
+    for ti, tr in enumerate(tracks):
+        for (fi, ki) in sorted(set((int(a), int(b)) for a, b in tr["obs"])):
+            fr = frames[fi]
+            if not fr.get("valid", 1):
+                continue
+            px = np.rint(np.asarray(fr["keypoints"][ki], np.float32)).astype(np.float32)[None]
+            b = oracle.image_to_cam(fr["rows"], fr["cols"], px, 1.0)[0]
+            cam.append(cam_offset + fi); pt.append(ti); bearing.append(b.astype(np.float64))
+    return np.array(cam, np.int32), np.array(pt, np.int32), np.array(bearing, np.float64).reshape(-1, 3)
+
+
+def frame_params(oracle, frames):
+    aa = np.zeros((len(frames), 3)); t = np.zeros((len(frames), 3))
+    for i, fr in enumerate(frames):
+        if not fr.get("valid", 1):
+            continue
+        Rl, tl = inv_pose(np.asarray(fr["R_wc"], np.float64), np.asarray(fr["t_wc"], np.float64))
+        aa[i] = oracle.matrix_to_angle_axis(Rl); t[i] = tl
+    return aa, t
+
+
+def bundle_adjust(oracle, frames, tracks, weight, refine_structure=True, max_iter=50):
+    """Twin of the driver's `bundle` command: camera-only BA, camera 0 constant.  Returns (summary, aa, t, X)."""
+    aa, t = frame_params(oracle, frames)
+    cam, pt, bearing = reproj_blocks(oracle, frames, tracks)
+    X = np.array([tr["point"] for tr in tracks], np.float64)
+    opt = Options(); opt.max_num_iterations = max_iter
+    b = dict(bearing=bearing, cam=cam, pt=pt, X=X, w=weight, loss=1, a=4.0 * np.pi / 180.0, frozen=not refine_structure)
+    res = solve(oracle, [], aa, t, {0}, opt, bundle=b)
+    res["blocks"] = len(cam)
+    return res, aa, t, X
+
+
+def joint_optimize_step(oracle, lidars, frames, pairs, cfg, structure=None):
     Fc, L = len(frames), len(lidars)
     aa = np.zeros((Fc + L, 3)); t = np.zeros((Fc + L, 3))
     for i, fr in enumerate(frames):
@@ -331,7 +402,12 @@ def joint_optimize_step(oracle, lidars, frames, pairs, cfg):
         groups.append(dict(kind=1, normalize=True, rows=rows, rid=np.array(rr, np.int32), nid=np.array(nn, np.int32), loss=1, a=2 * np.pi / 180))
         blocks += len(rows)
     opt = Options(); opt.max_num_iterations = 50
-    res = solve(oracle, groups, aa, t, {0}, opt)
+    bundle = None
+    if structure is not None and len(structure["tracks"]):
+        cam, pt, bearing = reproj_blocks(oracle, frames, structure["tracks"])
+        bundle = dict(bearing=bearing, cam=cam, pt=pt, X=structure["X"], w=cfg.get("camera_weight", 1.0), loss=1, a=4.0 * np.pi / 180.0)
+        blocks += len(cam)
+    res = solve(oracle, groups, aa, t, {0}, opt, bundle=bundle)
     res["blocks"] = blocks
     for i, fr in enumerate(frames):
         R_cw = oracle.angle_axis_to_matrix(aa[i]); R_wc = R_cw.T.copy()
@@ -347,7 +423,8 @@ def joint_optimize_step(oracle, lidars, frames, pairs, cfg):
     return res
 
 
-def joint_optimize(oracle, lidars, frames, T_cl_init, cfg, neighbor_size, iters):
+def joint_optimize(oracle, lidars, frames, T_cl_init, cfg, neighbor_size, iters, structure=None):
+    """structure: optional dict(tracks=[dict(point, obs)], X=M x 3 array refined in place) — the SfM term."""
     for s in lidars:
         s["corner_cur"] = np.asarray(s["corner_local"], np.float32)
         s["flat_cur"] = np.asarray(s.get("flat_local", np.zeros((0, 3))), np.float32); s["less_cur"] = np.asarray(s.get("less_local", np.zeros((0, 3))), np.float32)
@@ -356,7 +433,7 @@ def joint_optimize(oracle, lidars, frames, T_cl_init, cfg, neighbor_size, iters)
     pairs = associate_line_multi(oracle, lidars, frames, T_cl_init, neighbor_size)
     for _ in range(iters):
         npairs = sum(len(o["image_line_id"]) for o, _ in pairs.values())
-        res = joint_optimize_step(oracle, lidars, frames, pairs, cfg)
+        res = joint_optimize_step(oracle, lidars, frames, pairs, cfg, structure)
         res["pairs"] = npairs
         log.append(res)
         pairs = associate_line_multi(oracle, lidars, frames, T_cl_init, neighbor_size)

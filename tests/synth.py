@@ -225,7 +225,8 @@ def bundle_reference(r, J, off, cam, n_cams, loss, a, scale, radius, min_diag, m
 
 
 def bundle_unpack(packed, n_cams, ui, uj):
-    """packed buffer of pvlm_ba_reduce -> dense (S 6F x 6F symmetric, g 6F, cost, Udiag F x 6, gmax)."""
+    """packed buffer of pvlm_ba_reduce -> dense (S 6F x 6F symmetric, g 6F, cost, Udiag F x 6, gmax); the
+    un-eliminated camera gradient is packed[-1 - 6F:-1]."""
     F = n_cams; U = len(ui)
     Hd = packed[:F * 36].reshape(F, 6, 6); Ho = packed[F * 36:F * 36 + U * 36].reshape(U, 6, 6)
     o = F * 36 + U * 36

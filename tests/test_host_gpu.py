@@ -287,3 +287,114 @@ def test_joint_optimize_matches_cpu_twin(oracle, tmp):
         assert np.abs(lposes[k][:9].reshape(3, 3) - tl[k]["R_wl"]).max() <= 1e-6 and np.abs(lposes[k][9:] - tl[k]["t_wl"]).max() <= 1e-6
         assert np.abs(fposes[k][:9].reshape(3, 3) - tf[k]["R_wc"]).max() <= 1e-6 and np.abs(fposes[k][9:] - tf[k]["t_wc"]).max() <= 1e-6
     assert np.allclose(fposes[0][9:], frames[0]["t_wc"])    # camera 0 is the gauge
+
+
+# ------------------------------------------------------------------------------------------------
+# SfM reprojection term (AddCameraResidual) with GPU point elimination
+# ------------------------------------------------------------------------------------------------
+def _add_tracks(rng, frames, true_poses, n_points, extent, px_noise=0.3, pt_noise=0.03, min_views=4, center=(0.0, 0.0, 0.5)):
+    """Keypoints = projections of random world points into the TRUE camera poses (+ pixel noise); tracks carry a
+    perturbed triangulation.  true_poses: list of (R_wc, t_wc).  The one-angle residual gives ONE equation per
+    observation, so a point needs >= 4 views to be well determined (fewer leave it to the LM damping)."""
+    Xt = rng.normal(size=(n_points, 3)) * np.asarray(extent)
+    lateral = np.maximum(np.hypot(Xt[:, 0], Xt[:, 1]), 1e-9)          # keep points off the (z) axis of motion: parallax
+    Xt[:, :2] *= np.maximum(1.0, 0.8 / lateral)[:, None]
+    Xt += np.asarray(center)
+    for fr in frames:
+        fr["keypoints"] = []
+    tracks = []
+    F = len(frames)
+    for p in range(n_points):
+        obs = []
+        for fi in sorted(rng.choice(F, size=int(rng.integers(min(min_views, F), F + 1)), replace=False)):
+            R, t = true_poses[fi]
+            pc = R.T @ (Xt[p] - t)
+            px = oracle_cam_to_image(frames[fi]["rows"], frames[fi]["cols"], pc[None])[0] + rng.normal(size=2) * px_noise
+            frames[fi]["keypoints"].append(px.astype(np.float32)); obs.append((int(fi), len(frames[fi]["keypoints"]) - 1))
+        tracks.append(dict(point=Xt[p] + rng.normal(size=3) * pt_noise, obs=obs))
+    return tracks, Xt
+
+
+def _bundle_scene(rng, F=5, M=80):
+    rows, cols = 2880, 5760
+    frames, true = [], []
+    for i in range(F):
+        R = synth.rodrigues(rng.normal(size=3) * 0.15); t = np.array([0.5 * i, 0.03 * i, 0.15 * i]) + rng.normal(size=3) * 0.03
+        true.append((R, t))
+        d = synth.rodrigues(rng.normal(size=3) * (0.004 if i else 0.0))
+        frames.append(dict(id=i, rows=rows, cols=cols, valid=1, R_wc=R @ d, t_wc=t + (rng.normal(size=3) * 0.02 if i else 0.0),
+                           lines=np.zeros((0, 4), np.float32)))
+    tracks, Xt = _add_tracks(rng, frames, true, M, (3.0, 1.0, 3.0))
+    return frames, tracks, Xt
+
+
+@pytest.mark.parametrize("refine_structure", [1, 0])
+def test_bundle_adjustment_matches_cpu_twin(oracle, tmp, refine_structure):
+    """AddCameraResidual + SetOptionsSfM + Solve: reprojection blocks linearised on the GPU, 3-D points eliminated
+    there (Schur), camera system solved on the host — against the twin's dense full-system LM on the oracle."""
+    rng = np.random.default_rng(91)
+    frames, tracks, _ = _bundle_scene(rng)
+    fpath, spath = os.path.join(tmp, "bf.bin"), os.path.join(tmp, "bs.bin")
+    host_io.write_frames(fpath, np.eye(4), frames)
+    host_io.write_structure(spath, frames, tracks)
+    max_iter = 12
+    out = host_io.run("bundle", fpath, spath, 1.5, refine_structure, max_iter)
+    summ = [l.split() for l in out if l.startswith("summary")][0]
+    cams = np.array([[float(v) for v in l.split()[2:]] for l in out if l.startswith("cam ")])
+    pts = np.array([[float(v) for v in l.split()[2:]] for l in out if l.startswith("point ")])
+    res, aa, t, X = lm_twin.bundle_adjust(oracle, [dict(f) for f in frames], tracks, 1.5, bool(refine_structure), max_iter)
+    assert int(summ[2]) == res["blocks"] == sum(len(tr["obs"]) for tr in tracks)
+    assert abs(float(summ[4]) - res["initial_cost"]) <= 1e-9 * res["initial_cost"]
+    assert res["final_cost"] < (0.2 if refine_structure else 0.8) * res["initial_cost"]   # the adjustment does something
+    assert abs(float(summ[6]) - res["final_cost"]) <= 1e-6 * res["final_cost"]
+    assert int(summ[8]) == res["successful"] and int(summ[10]) == res["unsuccessful"]
+    assert np.abs(cams[:, :3] - aa).max() <= 1e-6 and np.abs(cams[:, 3:] - t).max() <= 1e-6
+    assert np.abs(pts - X).max() <= 1e-6 * max(1.0, np.abs(X).max())
+    if not refine_structure:
+        assert np.array_equal(pts, np.array([tr["point"] for tr in tracks]))     # constant blocks are untouched
+    # camera 0 is the gauge
+    a0, t0 = lm_twin.frame_params(oracle, frames)
+    assert np.array_equal(cams[0, :3], a0[0]) and np.array_equal(cams[0, 3:], t0[0])
+    # the three-block functor alone (API parity): r and J against the oracle
+    single = np.array([float(v) for v in [l for l in out if l.startswith("single")][0].split()[1:]])
+    ro, Jo = oracle.evaluate_reproj(np.array([[0.3, -0.2, 1.0]]), 1.5, [0], [0], cams[1:2, :3], cams[1:2, 3:], pts[0:1])
+    assert abs(single[0] - ro[0]) <= 1e-6 * abs(ro[0]) and np.abs(single[1:] - Jo[0]).max() <= 1e-6 * np.abs(Jo[0]).max()
+
+
+def test_joint_optimize_with_sfm_term_matches_cpu_twin(oracle, tmp):
+    """CameraLidarOptimizer::JointOptimize with all three terms of Optimize (CameraLidarOptimizer.cpp:387-548):
+    camera-LiDAR line pairs, SfM reprojection with free 3-D points, LiDAR-LiDAR point-to-plane."""
+    rng = np.random.default_rng(78)
+    NS = 5
+    lidars, frames, T_cl = _joint_scene(rng, NS)
+    true = []
+    for k in range(NS):
+        R_true, t_true = sy.true_pose(k)
+        T_wc = lm_twin.pose4(R_true, t_true) @ np.linalg.inv(T_cl)
+        true.append((T_wc[:3, :3].copy(), T_wc[:3, 3].copy()))
+    tracks, _ = _add_tracks(rng, frames, true, 60, (1.0, 0.5, 0.8), center=(0.0, 0.0, -3.3))   # around the trajectory: parallax
+    lpath, fpath, spath = os.path.join(tmp, "sl.bin"), os.path.join(tmp, "sf.bin"), os.path.join(tmp, "ss.bin")
+    host_io.write_scans(lpath, lidars, world=False)
+    host_io.write_frames(fpath, T_cl, frames)
+    host_io.write_structure(spath, frames, tracks)
+    out = host_io.run("joint", lpath, fpath, 3, 2, 0, 1, 0.05, 1.0, 0.3, 1.0, 2.0, 1.5, spath)
+    iters = [l.split() for l in out if l.startswith("iter")]
+    lposes = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    fposes = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("frame")}
+    pts = np.array([[float(v) for v in l.split()[2:]] for l in out if l.startswith("point ")])
+    tl = [dict(s) for s in lidars]; tf = [dict(f) for f in frames]
+    structure = dict(tracks=tracks, X=np.array([tr["point"] for tr in tracks], np.float64))
+    cfg = dict(p2plane=True, tol=0.05, thr=1.0, lidar_weight=1.0, camera_lidar_weight=2.0, camera_weight=1.5)
+    log = lm_twin.joint_optimize(oracle, tl, tf, T_cl, cfg, 3, 2, structure)
+    assert len(iters) == len(log) >= 1
+    n_reproj = sum(len(tr["obs"]) for tr in tracks)
+    for it, lg in zip(iters, log):
+        assert int(it[8]) == lg["pairs"] > 10
+        assert int(it[6]) == lg["blocks"] > n_reproj
+        assert abs(float(it[2]) - lg["final_cost"]) <= 1e-6 * lg["final_cost"]
+        assert int(it[4]) == lg["successful"]
+    for k in range(NS):
+        assert np.abs(lposes[k][:9].reshape(3, 3) - tl[k]["R_wl"]).max() <= 1e-6 and np.abs(lposes[k][9:] - tl[k]["t_wl"]).max() <= 1e-6
+        assert np.abs(fposes[k][:9].reshape(3, 3) - tf[k]["R_wc"]).max() <= 1e-6 and np.abs(fposes[k][9:] - tf[k]["t_wc"]).max() <= 1e-6
+    assert pts.shape == structure["X"].shape and np.abs(pts - structure["X"]).max() <= 1e-6 * max(1.0, np.abs(structure["X"]).max())
+    assert np.abs(pts - np.array([tr["point"] for tr in tracks])).max() > 1e-4      # the structure was refined

@@ -17,7 +17,7 @@ class View(C.Structure):
     _fields_ = [("n_points", C.c_int), ("n_cams", C.c_int), ("n_upairs", C.c_int), ("n_obs", C.c_longlong),
                 ("pt_off", C.c_void_p), ("cam", C.c_void_p), ("obs_pt", C.c_void_p), ("s", C.c_void_p), ("X", C.c_void_p), ("Xc", C.c_void_p),
                 ("scale", C.c_void_p), ("Vinv", C.c_void_p), ("gp", C.c_void_p), ("adj_off", C.c_void_p), ("adj_cam", C.c_void_p),
-                ("adj_slot", C.c_void_p), ("w", C.c_double), ("loss", C.c_int), ("a", C.c_double)]
+                ("adj_slot", C.c_void_p), ("frozen", C.c_void_p), ("w", C.c_double), ("loss", C.c_int), ("a", C.c_double)]
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +51,7 @@ class Problem:
         self.keep["adj_slot"] = np.arange(len(self.ui), dtype=np.int32)
         k = self.keep
         self.view = View(self.M, self.F, len(self.ui), len(b["cam"]), *[k[n].ctypes.data for n in
-                         ("off", "cam", "obs_pt", "s", "X", "Xc", "scale", "Vinv", "gp", "adj_off", "adj_cam", "adj_slot")], w, loss, a)
+                         ("off", "cam", "obs_pt", "s", "X", "Xc", "scale", "Vinv", "gp", "adj_off", "adj_cam", "adj_slot")], None, w, loss, a)
         self.tab = np.ascontiguousarray(synth.pose_table(b["aa"], b["t"]))
 
 

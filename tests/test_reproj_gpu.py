@@ -1,0 +1,111 @@
+"""GPU parity of the reprojection ("bundle") kernels against the CPU oracle, through the C ABI (pvlm_ba_*):
+PanoramaReprojResidual_1Angle r / 1x9 J (base/CostFunction.h:218-247), the Schur complement of the 3-D points,
+back-substitution, candidate cost.  Tolerance 1e-6 relative (north_star); observed ~1e-12."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import panovlm_amd as pv
+    c = pv.Context(0)
+    yield c
+    c.close()
+
+
+def _set(ctx, b, w):
+    import panovlm_amd as pv
+    ctx.set_poses(b["aa"], b["t"])
+    return pv.BundleSet(ctx, b["off"], b["cam"], b["bearing"], b["X"], weight=w)
+
+
+def test_eval_matches_oracle(ctx, oracle):
+    rng = np.random.default_rng(3)
+    b = synth.random_bundle(rng, n_cams=9, n_points=700, max_track=7)
+    bs = _set(ctx, b, 1.3)
+    r, J = bs.evaluate()
+    pt = np.repeat(np.arange(len(b["off"]) - 1), np.diff(b["off"]))
+    ro, Jo = oracle.evaluate_reproj(b["bearing"], 1.3, b["cam"], pt, b["aa"], b["t"], b["X"])
+    assert np.all(np.abs(r - ro) <= 1e-6 * np.abs(ro) + 8 * 2.2e-16 / np.maximum(ro, 1e-7))
+    scale = np.abs(Jo).max(axis=1, keepdims=True)
+    assert np.all(np.abs(J - Jo) <= 1e-6 * scale + 1e-15 / np.maximum(ro, 1e-7)[:, None] ** 2)
+    ui, uj = synth.covisible_pairs(b["off"], b["cam"])
+    assert np.array_equal(ui, bs.ui) and np.array_equal(uj, bs.uj)
+    bs.close()
+
+
+@pytest.mark.parametrize("loss", [0, 1])
+def test_reduce_step_cost_match_oracle(ctx, oracle, loss):
+    import panovlm_amd as pv
+    rng = np.random.default_rng(50 + loss)
+    b = synth.random_bundle(rng, n_cams=7, n_points=300, max_track=6)
+    w, a = 1.7, 4.0 * np.pi / 180.0 * 0.2
+    bs = _set(ctx, b, w)
+    F = bs.n_cams
+    pt = np.repeat(np.arange(len(b["off"]) - 1), np.diff(b["off"]))
+    ro, Jo = oracle.evaluate_reproj(b["bearing"], w, b["cam"], pt, b["aa"], b["t"], b["X"])
+    radius, mn, mx = 1e4, 1e-6, 1e32
+    with pytest.raises(pv.PvlmError):
+        bs.reduce(loss, a, init_scale=False)                  # the scaling must be initialised first
+    packed = bs.reduce(loss, a, init_scale=True, radius=radius, min_diag=mn, max_diag=mx)
+    ref = synth.bundle_reference(ro, Jo, b["off"], b["cam"], F, loss, a, None, radius, mn, mx)
+    S, g, cost, Ud, gmax = synth.bundle_unpack(packed, F, bs.ui, bs.uj)
+    sc = np.abs(ref["S"]).max()
+    assert np.allclose(S, ref["S"], rtol=0, atol=1e-6 * sc), np.abs(S - ref["S"]).max() / sc
+    assert np.allclose(g, ref["g"], rtol=0, atol=1e-6 * np.abs(ref["g"]).max())
+    assert np.isclose(cost, ref["cost"], rtol=1e-9)
+    assert np.allclose(Ud, ref["Udiag"], rtol=1e-6) and np.isclose(gmax, ref["gmax"], rtol=1e-6)
+    # a smaller radius re-uses the stored point scaling
+    packed = bs.reduce(loss, a, init_scale=False, radius=10.0, min_diag=mn, max_diag=mx)
+    ref2 = synth.bundle_reference(ro, Jo, b["off"], b["cam"], F, loss, a, ref["scale"], 10.0, mn, mx)
+    S2, g2, _, _, _ = synth.bundle_unpack(packed, F, bs.ui, bs.uj)
+    assert np.allclose(S2, ref2["S"], rtol=0, atol=1e-6 * sc) and np.allclose(g2, ref2["g"], rtol=0, atol=1e-6 * np.abs(ref2["g"]).max())
+    # back-substitution
+    dcam = rng.normal(size=(F, 6)) * 1e-2
+    out3 = bs.step(dcam, loss, a)
+    rho1, _ = synth.huber_weights(ro, loss, a)
+    M = len(b["off"]) - 1
+    dX = np.zeros((M, 3)); model = 0.0
+    for p in range(M):
+        idx = np.arange(b["off"][p], b["off"][p + 1])
+        rhs = ref2["gp"][p].copy()
+        for i in idx:
+            rhs += rho1[i] * Jo[i, 6:] * (Jo[i, :6] @ dcam[b["cam"][i]])
+        dX[p] = -ref2["Vinv"][p] @ rhs
+        for i in idx:
+            d = Jo[i, :6] @ dcam[b["cam"][i]] + Jo[i, 6:] @ dX[p]
+            model -= rho1[i] * (ro[i] * d + 0.5 * d * d)
+    Xc = bs.points(candidate=True)
+    assert np.allclose(Xc, b["X"] + dX, rtol=0, atol=1e-6 * np.abs(dX).max())
+    assert np.isclose(out3[0], model, rtol=1e-6) and np.isclose(out3[1], (dX ** 2).sum(), rtol=1e-6) and np.isclose(out3[2], (b["X"] ** 2).sum(), rtol=1e-9)
+    # candidate cost with moved cameras, then accept
+    aa2 = b["aa"] + dcam[:, :3]; t2 = b["t"] + dcam[:, 3:]
+    ctx.set_poses(aa2, t2)
+    with pytest.raises(pv.PvlmError):
+        bs.step(dcam, loss, a)                                 # poses changed since the reduce
+    c1 = bs.cost(loss, a, candidate=True)
+    r1, _ = oracle.evaluate_reproj(b["bearing"], w, b["cam"], pt, aa2, t2, Xc, jac=False)
+    assert np.isclose(c1, synth.huber_weights(r1, loss, a)[1].sum(), rtol=1e-9)
+    bs.accept()
+    assert np.array_equal(bs.points(), Xc)
+    assert np.isclose(bs.cost(loss, a), c1, rtol=1e-12)
+    with pytest.raises(pv.PvlmError):
+        bs.accept()                                            # no candidate any more
+    bs.close()
+
+
+def test_empty_and_state_errors(ctx):
+    import panovlm_amd as pv
+    c2 = pv.Context(0)
+    bs = pv.BundleSet(c2, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros((0, 3)))
+    with pytest.raises(pv.PvlmError):
+        bs.cost()                                              # no poses set on this context
+    c2.set_poses(np.zeros((1, 3)), np.zeros((1, 3)))
+    assert bs.cost() == 0.0 and bs.size == 2
+    p = bs.reduce(init_scale=True)
+    assert np.all(p == 0)
+    bs.close(); c2.close()
