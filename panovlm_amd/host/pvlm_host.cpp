@@ -1609,6 +1609,7 @@ int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, std::vector<Poin
   ceres_like::Solver::Options options = SetOptionsSfM(config.num_threads);
   ceres_like::Solver::Summary summary;
   ceres_like::Solve(options, &problem, &summary);
+  last_history_ = summary.cost_history;
   if (!summary.IsSolutionUsable()) return 0;
   for (size_t i = 0; i < frames.size(); i++) {
     if (!frame_valid[i]) continue;
@@ -1640,7 +1641,7 @@ bool CameraLidarOptimizer::JointOptimize() {
     size_t npairs = 0;
     for (auto& kv : pairs) npairs += kv.second.size();
     Optimize(pairs, structure, true, true, true, true, true, curr_cost, curr_step);
-    log.push_back({curr_cost, curr_step, last_blocks_, npairs});
+    log.push_back({curr_cost, curr_step, last_blocks_, npairs, last_history_});
     pairs.clear();
     pairs = AssociateLineMulti(neighbor_size_joint, true);
     if (std::fabs(curr_cost - last_cost) / last_cost < 0.01) break;

@@ -367,7 +367,7 @@ class CameraLidarOptimizer {
   }
   const std::vector<Velodyne>& GetLidars() const { return lidars; }
   const std::vector<Frame>& GetFrames() const { return frames; }
-  struct IterLog { double cost; int steps; int residual_blocks; size_t line_pairs; };
+  struct IterLog { double cost; int steps; int residual_blocks; size_t line_pairs; std::vector<double> cost_history; };
   std::vector<IterLog> log;
  private:
   Matrix4d T_cl_init;
@@ -377,6 +377,7 @@ class CameraLidarOptimizer {
   Config config;
   int neighbor_size_joint, num_iteration_joint;
   int last_blocks_ = 0;
+  std::vector<double> last_history_;
 };
 
 }  // namespace pvlm

@@ -199,6 +199,7 @@ int main(int argc, char** argv) {
       opt.SetStructure(structure);
       opt.JointOptimize();
       for (auto& it : opt.log) printf("iter cost %.17g steps %d blocks %d pairs %zu\n", it.cost, it.steps, it.residual_blocks, it.line_pairs);
+      for (auto& it : opt.log) { printf("hist"); for (double c : it.cost_history) printf(" %.17g", c); printf("\n"); }
       PrintPoses(opt.GetLidars());
       PrintFrames(opt.GetFrames());
       for (const PointTrack& t : opt.GetStructure()) printf("point %u %.17g %.17g %.17g\n", t.id, t.point_3d[0], t.point_3d[1], t.point_3d[2]);

@@ -94,7 +94,7 @@ def solve(oracle, groups, aa, t, const_poses, opt=Options(), bundle=None):
 
     x_aa, x_t, x_X = aa.copy(), t.copy(), X0
     cost, H, g = evaluate(x_aa, x_t, x_X)
-    out = dict(initial_cost=cost, successful=1, unsuccessful=0, message="")
+    out = dict(initial_cost=cost, successful=1, unsuccessful=0, message="", history=[float(cost)])
     if n == 0:
         out["final_cost"] = cost
         return out
@@ -137,6 +137,7 @@ def solve(oracle, groups, aa, t, const_poses, opt=Options(), bundle=None):
                 radius = min(opt.max_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
                 dec = 2.0
                 out["successful"] += 1
+                out["history"].append(float(cost))
                 if abs(change) <= opt.function_tolerance * prev:
                     out["message"] = "function tolerance reached"
                 elif np.abs(g).max() <= opt.gradient_tolerance:
