@@ -237,6 +237,14 @@ pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, i
 pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm_scan* nei, float dist_threshold,
                                  int32_t* votes);
 
+/* Batched form — every (ref, nei) pair of an outer iteration in ONE launch and one copy back (the reference
+ * calls AssociateLine2Line twice per pair per outer iteration: LidarLineMatch.cpp:68, util/Optimization.cpp:379).
+ * The vote block of pair p starts at votes + vote_offsets[p] (n_nei_segments(p) x n_ref_segments(p), row-major);
+ * vote_offsets (n_pairs + 1) is an output.  votes == NULL only fills vote_offsets (sizing call);
+ * PVLM_ERR_CAPACITY if capacity (int32 elements) < vote_offsets[n_pairs]. */
+pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei,
+                                       float dist_threshold, int64_t* vote_offsets, int32_t* votes, int64_t capacity);
+
 /* ---- equirectangular camera model + camera<->LiDAR voting --------------------------------------- */
 /* Equirectangular::CamToImage<T> (sensors/Equirectangular.h:173-182, FastAtan2 variant) for n
  * points; cam n x 3, pixels n x 2.  _f32 mirrors the cv::Point3f overloads, _f64 the Eigen ones. */
@@ -253,6 +261,14 @@ pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, 
  * and count votes per LiDAR segment.  votes is n_lines x n_segments int32. */
 pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float* lines, int n_lines,
                                  const pvlm_scan* lidar_local, const double* T_cl_rowmajor16, int32_t* votes);
+
+/* Batched form — every (frame, LiDAR) pair of AssociateLineMulti (CameraLidarOptimizer.cpp:345-377, an omp loop
+ * over frames upstream) in one launch: pair p uses the image lines [line_offsets[p], line_offsets[p+1]) of
+ * `lines`, the scan lidar_local[p] and T_cl + 16 p; its votes (n_lines(p) x n_segments(p)) start at
+ * votes + vote_offsets[p].  Sizing / capacity rules as for pvlm_line2line_votes_batch. */
+pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets,
+                                       const float* lines, pvlm_scan* const* lidar_local, const double* T_cl_rowmajor16,
+                                       int64_t* vote_offsets, int32_t* votes, int64_t capacity);
 
 #ifdef __cplusplus
 }

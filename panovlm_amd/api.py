@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_destroy",
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
-    "pvlm_cam_lidar_votes",
+    "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -180,6 +180,22 @@ class Context:
                                                   lidar_scan._h, _p(T, C.c_double), _p(votes, C.c_int32)), "pvlm_cam_lidar_votes")
         return votes[:, :lidar_scan.n_segments]
 
+    def cam_lidar_votes_batch(self, rows, cols, lines_list, lidar_scans, T_cl_list):
+        """One launch for many (image lines, LiDAR-local scan, T_cl) triples; returns the list of vote matrices."""
+        n = len(lidar_scans)
+        assert len(lines_list) == n and len(T_cl_list) == n
+        ls = [_f32(l).reshape(-1, 4) for l in lines_list]
+        off = _i64(np.concatenate([[0], np.cumsum([len(l) for l in ls])]))
+        flat = _f32(np.concatenate(ls) if n and off[-1] else np.zeros((0, 4)))
+        T = _f64(np.array([np.asarray(t, np.float64).reshape(16) for t in T_cl_list]).reshape(-1))
+        hs = (C.c_void_p * max(n, 1))(*[s._h for s in lidar_scans])
+        voff = np.zeros(n + 1, np.int64)
+        args = (self._h, C.c_int(n), C.c_int(rows), C.c_int(cols), _p(off, C.c_int64), _p(flat, C.c_float), hs, _p(T, C.c_double), _p(voff, C.c_int64))
+        self._check(self.lib.pvlm_cam_lidar_votes_batch(*args, None, C.c_int64(0)), "pvlm_cam_lidar_votes_batch")
+        votes = np.zeros(max(int(voff[-1]), 1), np.int32)
+        self._check(self.lib.pvlm_cam_lidar_votes_batch(*args, _p(votes, C.c_int32), C.c_int64(len(votes))), "pvlm_cam_lidar_votes_batch")
+        return [votes[voff[p]:voff[p + 1]].reshape(len(ls[p]), lidar_scans[p].n_segments) for p in range(n)]
+
     # --- association -------------------------------------------------------------------------------
     def knn(self, scan, queries, k, max_dist, which=0):
         q = _f32(queries).reshape(-1, 3)
@@ -203,6 +219,20 @@ class Context:
         votes = np.zeros((max(1, nei.n_segments), max(1, ref.n_segments)), np.int32)
         self._check(self.lib.pvlm_line2line_votes(self._h, ref._h, nei._h, C.c_float(dist_threshold), _p(votes, C.c_int32)), "pvlm_line2line_votes")
         return votes[:nei.n_segments, :ref.n_segments]
+
+
+    def line2line_votes_batch(self, refs, neis, dist_threshold):
+        """One launch for many (ref, nei) pairs; returns the list of n_nei_seg x n_ref_seg vote matrices."""
+        n = len(refs)
+        assert len(neis) == n
+        hr = (C.c_void_p * max(n, 1))(*[s._h for s in refs]); hn = (C.c_void_p * max(n, 1))(*[s._h for s in neis])
+        voff = np.zeros(n + 1, np.int64)
+        self._check(self.lib.pvlm_line2line_votes_batch(self._h, C.c_int(n), hr, hn, C.c_float(dist_threshold), _p(voff, C.c_int64), None, C.c_int64(0)),
+                    "pvlm_line2line_votes_batch")
+        votes = np.zeros(max(int(voff[-1]), 1), np.int32)
+        self._check(self.lib.pvlm_line2line_votes_batch(self._h, C.c_int(n), hr, hn, C.c_float(dist_threshold), _p(voff, C.c_int64), _p(votes, C.c_int32),
+                                                        C.c_int64(len(votes))), "pvlm_line2line_votes_batch")
+        return [votes[voff[p]:voff[p + 1]].reshape(neis[p].n_segments, refs[p].n_segments) for p in range(n)]
 
 
 class ResidualSet:

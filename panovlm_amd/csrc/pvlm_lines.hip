@@ -30,6 +30,40 @@ __global__ __launch_bounds__(256) void k_line_votes(int n_pts, const float* __re
   for (int k = p2s_off[i]; k < p2s_off[i + 1]; ++k) atomicAdd(&votes[(size_t)p2s_ids[k] * n_ref_seg + s], 1);
 }
 
+// Batched form: one launch for every (ref, nei) pair of an outer iteration (the reference calls
+// AssociateLine2Line twice per pair per outer iteration, LidarLineMatch.cpp:68 and Optimization.cpp:379).
+// Work item = (pair, nei corner point, ref segment); the pair is found by bisection on the prefix of work sizes.
+struct pvlm_line_pair_desc {
+  const float* xyz; const int* p2s_off; const int* p2s_ids;
+  int n_pts, n_ref;
+  long long line_off;   // first world line of the pair's ref scan in `lines` (units of 6 doubles)
+  long long vote_off;   // first vote of the pair (n_nei_seg x n_ref_seg block)
+  long long work_off;   // prefix sum of n_pts * n_ref
+};
+
+__device__ __forceinline__ int find_pair(const long long* __restrict__ work_off, int n_pairs, long long g) {
+  int lo = 0, hi = n_pairs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (work_off[mid] <= g) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_line_votes_batch(int n_pairs, const pvlm_line_pair_desc* __restrict__ desc,
+                                                          const long long* __restrict__ work_off, long long total,
+                                                          const double* __restrict__ lines, double thr, int* __restrict__ votes) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const int p = find_pair(work_off, n_pairs, g);
+  const pvlm_line_pair_desc d = desc[p];
+  const long long l = g - d.work_off;
+  const int i = (int)(l / d.n_ref), s = (int)(l - (long long)i * d.n_ref);
+  const double dist = point_to_line((double)d.xyz[3 * i], (double)d.xyz[3 * i + 1], (double)d.xyz[3 * i + 2], lines + 6 * (d.line_off + s));
+  if (dist > thr) return;
+  for (int k = d.p2s_off[i]; k < d.p2s_off[i + 1]; ++k) atomicAdd(&votes[d.vote_off + (long long)d.p2s_ids[k] * d.n_ref + s], 1);
+}
+
 // ---- K7 -----------------------------------------------------------------------------------------
 // FastAtan2 (base/Math.h:15-29).  For T = float the polynomial is evaluated in double (double
 // literals) and rounded to float on assignment, as are M_PI_2 - r and M_PI - r.
@@ -112,6 +146,50 @@ __global__ __launch_bounds__(256) void k_cam_lidar_votes(int n_pts, const float*
   for (int k = p2s_off[i]; k < p2s_off[i + 1]; ++k) atomicAdd(&votes[(size_t)li * n_seg + p2s_ids[k]], 1);
 }
 
+// Batched form of K8: one launch for every (frame, LiDAR) pair of AssociateLineMulti
+// (joint_optimization/CameraLidarOptimizer.cpp:345-377).  Work item = (pair, image line, corner point).
+struct pvlm_cam_pair_desc {
+  const float* xyz; const int* p2s_off; const int* p2s_ids;
+  int n_pts, n_lines, n_seg;
+  long long tab_off;    // first line-table row of the pair (rows of 8 doubles)
+  long long vote_off;   // first vote of the pair (n_lines x n_seg block)
+  long long work_off;
+  double T[12];         // T_cl rows 0..2
+};
+
+__device__ __forceinline__ void cam_vote_one(const float* __restrict__ xyz_local, const int* __restrict__ p2s_off, const int* __restrict__ p2s_ids,
+                                             int i, int li, const double* __restrict__ L, const double* T_cl, int n_seg, double angle_thr,
+                                             int* __restrict__ votes) {
+  if (p2s_off[i] == p2s_off[i + 1]) return;
+  const float x = xyz_local[3 * i], y = xyz_local[3 * i + 1], z = xyz_local[3 * i + 2];
+  const float range = x * x + y * y + z * z;
+  if (range > 15 * 15) return;
+  double p[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    p[r] = (double)(float)(T_cl[r * 4] * (double)x + T_cl[r * 4 + 1] * (double)y + T_cl[r * 4 + 2] * (double)z + T_cl[r * 4 + 3]);
+  const double dis = fabs(L[0] * p[0] + L[1] * p[1] + L[2] * p[2] + L[3]);
+  double pp[3] = {p[0] - dis * L[0], p[1] - dis * L[1], p[2] - dis * L[2]};
+  if (fabs(L[0] * pp[0] + L[1] * pp[1] + L[2] * pp[2] + L[3]) > 1e-4) {
+    pp[0] = p[0] + dis * L[0]; pp[1] = p[1] + dis * L[1]; pp[2] = p[2] + dis * L[2];
+  }
+  if (vangle(p, pp) >= angle_thr) return;
+  if (vangle(L + 4, pp) >= L[7] + angle_thr) return;
+  for (int k = p2s_off[i]; k < p2s_off[i + 1]; ++k) atomicAdd(&votes[(size_t)li * n_seg + p2s_ids[k]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_cam_lidar_votes_batch(int n_pairs, const pvlm_cam_pair_desc* __restrict__ desc,
+                                                               const long long* __restrict__ work_off, long long total,
+                                                               const double* __restrict__ line_tab, double angle_thr, int* __restrict__ votes) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const int p = find_pair(work_off, n_pairs, g);
+  const pvlm_cam_pair_desc* d = desc + p;
+  const long long l = g - d->work_off;
+  const int li = (int)(l / d->n_pts), i = (int)(l - (long long)li * d->n_pts);
+  cam_vote_one(d->xyz, d->p2s_off, d->p2s_ids, i, li, line_tab + 8 * (d->tab_off + li), d->T, d->n_seg, angle_thr, votes + d->vote_off);
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 namespace {
 template <typename T> struct HostEq {
@@ -183,6 +261,132 @@ pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, 
   });
 }
 
+}  // extern "C"
+
+// TransformLines(ref.segment_coeffs, ref.GetPose())   LidarFeatureAssociate.cpp:219-236, :455
+static void world_lines(const pvlm_scan* ref, double* lw) {
+  const double* R = ref->R_wl; const double* t = ref->t_wl;
+  for (int s = 0; s < ref->n_segments; ++s) {
+    const double* c = &ref->h_seg_coeffs[6 * s];
+    for (int i = 0; i < 3; ++i) {
+      lw[6 * s + i] = ((R[i * 3] * c[0] + R[i * 3 + 1] * c[1]) + R[i * 3 + 2] * c[2]) + t[i];
+      lw[6 * s + 3 + i] = (R[i * 3] * c[3] + R[i * 3 + 1] * c[4]) + R[i * 3 + 2] * c[5];
+    }
+  }
+}
+
+// per-line constants of AssociateByAngle (CameraLidarLineAssociate.cpp:396-406), host fp64:
+// [image plane (4, normalised) | midpoint p4 (3) | half arc angle]
+static void line_table_row(int rows, int cols, const float* l, double* t) {
+  HostEq<double> eq{rows, cols};
+  const double a[2] = {l[0], l[1]}, b[2] = {l[2], l[3]};
+  double p1[3], p2[3];
+  eq.ImageToCam(a, 1.0, p1);
+  eq.ImageToCam(b, 1.0, p2);
+  const double p3[3] = {0, 0, 0};   // FormPlane(p1, p2, 0): Geometry.hpp:328-336
+  double pa = ((p2[1] - p1[1]) * (p3[2] - p1[2]) - (p2[2] - p1[2]) * (p3[1] - p1[1]));
+  double pb = ((p2[2] - p1[2]) * (p3[0] - p1[0]) - (p2[0] - p1[0]) * (p3[2] - p1[2]));
+  double pc = ((p2[0] - p1[0]) * (p3[1] - p1[1]) - (p2[1] - p1[1]) * (p3[0] - p1[0]));
+  double pd = -(pa * p1[0] + pb * p1[1] + pc * p1[2]);
+  const double nn = std::sqrt(pa * pa + pb * pb + pc * pc + pd * pd);
+  if (nn * nn > 0.0) { pa /= nn; pb /= nn; pc /= nn; pd /= nn; }
+  t[0] = pa; t[1] = pb; t[2] = pc; t[3] = pd;
+  t[4] = (p1[0] + p2[0]) / 2.0; t[5] = (p1[1] + p2[1]) / 2.0; t[6] = (p1[2] + p2[2]) / 2.0;
+  t[7] = h_vangle(p1, t + 4);
+}
+
+template <typename D>
+static pvlm_status run_vote_batch(pvlm_ctx* ctx, const std::vector<D>& desc, const std::vector<long long>& work_off, long long total_work,
+                                  const std::vector<double>& tab, long long n_votes, int32_t* votes, void (*launch)(pvlm_ctx*, int, const D*, const long long*, long long, const double*, int*)) {
+  D* d_desc = nullptr; long long* d_work = nullptr; double* d_tab = nullptr; int* d_v = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_desc, desc.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_work, work_off.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_tab, tab.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)n_votes);
+  if (!st) {
+    hipError_t e = hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(D), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_work, work_off.data(), work_off.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !tab.empty()) e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_v, 0, (size_t)n_votes * sizeof(int), ctx->stream);
+    if (e == hipSuccess && total_work > 0) { launch(ctx, (int)desc.size(), d_desc, d_work, total_work, d_tab, d_v); e = hipGetLastError(); }
+    if (e == hipSuccess && n_votes > 0) e = hipMemcpyAsync(votes, d_v, (size_t)n_votes * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "batched votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_desc); hipFree(d_work); hipFree(d_tab); hipFree(d_v);
+  return st;
+}
+
+extern "C" {
+
+pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, float dist_threshold,
+                                       int64_t* vote_offsets, int32_t* votes, int64_t capacity) {
+  if (!ctx || n_pairs < 0 || !vote_offsets || (n_pairs > 0 && (!ref || !nei))) return PVLM_ERR_ARG;
+  std::vector<pvlm_line_pair_desc> desc((size_t)n_pairs);
+  std::vector<long long> work_off((size_t)n_pairs + 1, 0);
+  std::vector<double> lines;
+  long long nv = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    if (!ref[p] || !nei[p]) return PVLM_ERR_ARG;
+    pvlm_line_pair_desc& d = desc[p];
+    d.xyz = nei[p]->corner.d_xyz; d.p2s_off = nei[p]->d_p2s_off; d.p2s_ids = nei[p]->d_p2s_ids;
+    d.n_pts = nei[p]->n_segments > 0 ? nei[p]->corner.n : 0; d.n_ref = ref[p]->n_segments;
+    d.line_off = (long long)lines.size() / 6; d.vote_off = nv; d.work_off = work_off[p];
+    lines.resize(lines.size() + (size_t)ref[p]->n_segments * 6);
+    world_lines(ref[p], lines.data() + (size_t)d.line_off * 6);
+    vote_offsets[p] = nv;
+    nv += (long long)nei[p]->n_segments * ref[p]->n_segments;
+    work_off[p + 1] = work_off[p] + (long long)d.n_pts * d.n_ref;
+  }
+  vote_offsets[n_pairs] = nv;
+  if (!votes) return PVLM_OK;                       // sizing call
+  if (capacity < nv) { PVLM_SET_ERR(ctx, "pvlm_line2line_votes_batch: %lld votes do not fit the capacity %lld", nv, (long long)capacity); return PVLM_ERR_CAPACITY; }
+  if (nv == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  static double s_thr;   // captured by the launcher below (plain function pointer)
+  s_thr = (double)dist_threshold;
+  return run_vote_batch<pvlm_line_pair_desc>(ctx, desc, work_off, work_off[n_pairs], lines, nv, votes,
+      [](pvlm_ctx* c, int np, const pvlm_line_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
+        hipLaunchKernelGGL(k_line_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl, s_thr, dv);
+      });
+}
+
+pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,
+                                       pvlm_scan* const* lidar_local, const double* T_cl, int64_t* vote_offsets, int32_t* votes, int64_t capacity) {
+  if (!ctx || n_pairs < 0 || !vote_offsets || rows <= 0 || cols <= 0 || (n_pairs > 0 && (!line_offsets || !lidar_local || !T_cl))) return PVLM_ERR_ARG;
+  std::vector<pvlm_cam_pair_desc> desc((size_t)n_pairs);
+  std::vector<long long> work_off((size_t)n_pairs + 1, 0);
+  long long nv = 0;
+  const long long n_lines_total = n_pairs > 0 ? line_offsets[n_pairs] : 0;
+  if (n_lines_total > 0 && !lines) return PVLM_ERR_ARG;
+  for (int p = 0; p < n_pairs; ++p) {
+    if (!lidar_local[p] || line_offsets[p + 1] < line_offsets[p]) return PVLM_ERR_ARG;
+    pvlm_cam_pair_desc& d = desc[p];
+    const pvlm_scan* l = lidar_local[p];
+    d.xyz = l->corner.d_xyz; d.p2s_off = l->d_p2s_off; d.p2s_ids = l->d_p2s_ids;
+    d.n_lines = (int)(line_offsets[p + 1] - line_offsets[p]); d.n_seg = l->n_segments;
+    d.n_pts = (d.n_seg > 0 && d.n_lines > 0) ? l->corner.n : 0;
+    d.tab_off = line_offsets[p]; d.vote_off = nv; d.work_off = work_off[p];
+    for (int k = 0; k < 12; ++k) d.T[k] = T_cl[(size_t)p * 16 + k];
+    vote_offsets[p] = nv;
+    nv += (long long)d.n_lines * d.n_seg;
+    work_off[p + 1] = work_off[p] + (long long)d.n_pts * d.n_lines;
+  }
+  vote_offsets[n_pairs] = nv;
+  if (!votes) return PVLM_OK;
+  if (capacity < nv) { PVLM_SET_ERR(ctx, "pvlm_cam_lidar_votes_batch: %lld votes do not fit the capacity %lld", nv, (long long)capacity); return PVLM_ERR_CAPACITY; }
+  if (nv == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  std::vector<double> tab((size_t)n_lines_total * 8);
+  for (long long li = 0; li < n_lines_total; ++li) line_table_row(rows, cols, lines + 4 * li, &tab[8 * (size_t)li]);
+  return run_vote_batch<pvlm_cam_pair_desc>(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes,
+      [](pvlm_ctx* c, int np, const pvlm_cam_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
+        hipLaunchKernelGGL(k_cam_lidar_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl,
+                           3.0 / 180.0 * M_PI, dv);
+      });
+}
+
 pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm_scan* nei, float dist_threshold, int32_t* votes) {
   if (!ctx || !ref || !nei || !votes) return PVLM_ERR_ARG;
   const int nr = ref->n_segments, nn = nei->n_segments, nc = nei->corner.n;
@@ -190,16 +394,8 @@ pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm
   std::memset(votes, 0, (size_t)nr * nn * sizeof(int32_t));
   if (nc == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  // TransformLines(ref.segment_coeffs, ref.GetPose())   LidarFeatureAssociate.cpp:219-236, :455
   std::vector<double> lw((size_t)nr * 6);
-  for (int s = 0; s < nr; ++s) {
-    const double* c = &ref->h_seg_coeffs[6 * s];
-    const double* R = ref->R_wl; const double* t = ref->t_wl;
-    for (int i = 0; i < 3; ++i) {
-      lw[6 * s + i] = ((R[i * 3] * c[0] + R[i * 3 + 1] * c[1]) + R[i * 3 + 2] * c[2]) + t[i];
-      lw[6 * s + 3 + i] = (R[i * 3] * c[3] + R[i * 3 + 1] * c[4]) + R[i * 3 + 2] * c[5];
-    }
-  }
+  world_lines(ref, lw.data());
   double* d_l = nullptr; int* d_v = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_l, lw.size());
   if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)nr * nn);
@@ -229,28 +425,8 @@ pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float*
   std::memset(votes, 0, (size_t)n_lines * ns * sizeof(int32_t));
   if (np == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  // per-line constants (CameraLidarLineAssociate.cpp:396-406), host fp64
   std::vector<double> tab((size_t)n_lines * 8);
-  HostEq<double> eq{rows, cols};
-  for (int li = 0; li < n_lines; ++li) {
-    const float* l = lines + 4 * li;
-    const double a[2] = {l[0], l[1]}, b[2] = {l[2], l[3]};
-    double p1[3], p2[3];
-    eq.ImageToCam(a, 1.0, p1);
-    eq.ImageToCam(b, 1.0, p2);
-    // FormPlane(p1, p2, 0): Geometry.hpp:328-336 with p3 = 0
-    const double p3[3] = {0, 0, 0};
-    double pa = ((p2[1] - p1[1]) * (p3[2] - p1[2]) - (p2[2] - p1[2]) * (p3[1] - p1[1]));
-    double pb = ((p2[2] - p1[2]) * (p3[0] - p1[0]) - (p2[0] - p1[0]) * (p3[2] - p1[2]));
-    double pc = ((p2[0] - p1[0]) * (p3[1] - p1[1]) - (p2[1] - p1[1]) * (p3[0] - p1[0]));
-    double pd = -(pa * p1[0] + pb * p1[1] + pc * p1[2]);
-    const double nn = std::sqrt(pa * pa + pb * pb + pc * pc + pd * pd);
-    if (nn * nn > 0.0) { pa /= nn; pb /= nn; pc /= nn; pd /= nn; }
-    double* t = &tab[8 * li];
-    t[0] = pa; t[1] = pb; t[2] = pc; t[3] = pd;
-    t[4] = (p1[0] + p2[0]) / 2.0; t[5] = (p1[1] + p2[1]) / 2.0; t[6] = (p1[2] + p2[2]) / 2.0;
-    t[7] = h_vangle(p1, t + 4);
-  }
+  for (int li = 0; li < n_lines; ++li) line_table_row(rows, cols, lines + 4 * li, &tab[8 * (size_t)li]);
   double *d_tab = nullptr, *d_T = nullptr; int* d_v = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_tab, tab.size());
   if (!st) st = pvlm_i_alloc(ctx, &d_T, 16);

@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -17,6 +19,16 @@
 #include <stdexcept>
 
 namespace pvlm {
+
+namespace {
+std::map<std::string, double>& Stages() { static std::map<std::string, double> m; return m; }
+struct StageTimer {
+  const char* name; std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
+  ~StageTimer() { Stages()[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+const std::map<std::string, double>& StageSeconds() { return Stages(); }
 
 // ================================================================================================
 // Engine
@@ -383,6 +395,40 @@ std::vector<Line2Line> AssociateLine2Line(const Velodyne& ref, const Velodyne& n
   return FindAssociations(ref, nei, ref_world, nei_world, votes);
 }
 
+// Every pair of an outer iteration in one GPU launch (pvlm_line2line_votes_batch); result[k] is what
+// AssociateLine2Line(*pairs[k].first, *pairs[k].second, dist_threshold) returns.
+std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<std::pair<const Velodyne*, const Velodyne*>>& pairs,
+                                                            const float dist_threshold) {
+  std::vector<std::vector<Line2Line>> out(pairs.size());
+  if (std::getenv("PVLM_HOST_NO_BATCH")) {   // measured variant: one launch + copies per pair, like the reference's call structure
+    for (size_t k = 0; k < pairs.size(); ++k) out[k] = AssociateLine2Line(*pairs[k].first, *pairs[k].second, dist_threshold);
+    return out;
+  }
+  std::vector<pvlm_scan*> refs, neis;
+  std::vector<size_t> which;
+  for (size_t k = 0; k < pairs.size(); ++k) {
+    const Velodyne& ref = *pairs[k].first; const Velodyne& nei = *pairs[k].second;
+    if (!ref.IsInWorldCoordinate() || !nei.IsInWorldCoordinate()) { fprintf(stderr, "lidar %d / %d is not in world coordinate\n", ref.id, nei.id); continue; }
+    if (ref.edge_segmented.empty() || nei.edge_segmented.empty()) continue;  // CheckLidarSegment
+    refs.push_back(ref.DeviceScan()); neis.push_back(nei.DeviceScan()); which.push_back(k);
+  }
+  if (which.empty()) return out;
+  Engine& e = Engine::Default();
+  std::vector<int64_t> voff(which.size() + 1, 0);
+  e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), nullptr, 0), "pvlm_line2line_votes_batch");
+  std::vector<int32_t> votes((size_t)std::max<int64_t>(voff.back(), 1), 0);
+  e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), votes.data(), (int64_t)votes.size()),
+          "pvlm_line2line_votes_batch");
+  for (size_t j = 0; j < which.size(); ++j) {
+    const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
+    const std::vector<Vector6d> nei_world = TransformLines(nei.segment_coeffs, nei.GetPose());
+    const std::vector<Vector6d> ref_world = TransformLines(ref.segment_coeffs, ref.GetPose());
+    const std::vector<int> v(votes.begin() + voff[j], votes.begin() + voff[j + 1]);
+    out[which[j]] = FindAssociations(ref, nei, ref_world, nei_world, v);
+  }
+  return out;
+}
+
 // ================================================================================================
 // tracks — util/Tracks.h:34-107 (UnionFind), util/Tracks.cpp:58-196 (TrackBuilder, allow_multiple_map)
 // ================================================================================================
@@ -401,19 +447,24 @@ struct UnionFind {
 }  // namespace
 
 bool LidarLineMatch::GenerateTracks() {
+  StageTimer stage_timer_("line tracks (associate + union-find)");
   std::vector<std::pair<size_t, size_t>> pairs;
   std::vector<std::set<std::pair<uint32_t, uint32_t>>> feature_each_pair;
   const std::vector<std::vector<int>> neighbors = FindNeighbors(lidars_, neighbor_size_);
+  std::vector<std::pair<const Velodyne*, const Velodyne*>> todo;   // the (ref, nei) arguments of AssociateLine2Line, :68
   for (size_t i = 0; i < neighbors.size(); i++) {
     if (!lidars_[i].IsPoseValid()) continue;
     for (const int nei_id : neighbors[i]) {
       if (nei_id < 0 || nei_id >= (int)lidars_.size()) continue;
-      const std::vector<Line2Line> ass = AssociateLine2Line(lidars_[nei_id], lidars_[i], 0.3f);
-      std::set<std::pair<uint32_t, uint32_t>> fp;
-      for (const Line2Line& a : ass) fp.insert({(uint32_t)a.neighbor_line_idx, (uint32_t)a.ref_line_idx});
-      feature_each_pair.push_back(fp);
+      todo.push_back({&lidars_[nei_id], &lidars_[i]});
       pairs.push_back({i, (size_t)nei_id});
     }
+  }
+  const std::vector<std::vector<Line2Line>> all_ass = AssociateLine2LineBatch(todo, 0.3f);   // one launch for the whole loop
+  for (const std::vector<Line2Line>& ass : all_ass) {
+    std::set<std::pair<uint32_t, uint32_t>> fp;
+    for (const Line2Line& a : ass) fp.insert({(uint32_t)a.neighbor_line_idx, (uint32_t)a.ref_line_idx});
+    feature_each_pair.push_back(fp);
   }
   // TrackBuilder(true).Build
   std::set<std::pair<uint32_t, uint32_t>> all;
@@ -665,6 +716,7 @@ struct Assembled {
 }  // namespace
 
 void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summary) {
+  StageTimer stage_timer_("solve (LM)");
   Problem::Impl& I = *problem->impl();
   Engine& e = Engine::Default();
   *summary = Solver::Summary();
@@ -1057,6 +1109,7 @@ size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbo
                                     std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
                                     double point_to_plane_dis_threshold, double plane_tolerance, bool angle_residual, bool normalized_distance,
                                     double weight) {
+  StageTimer stage_timer_("point-to-plane association");
   // util/Optimization.cpp:513-517: one loss object shared by every block of this adder
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
   std::vector<pvlm_scan*> refs, neis;
@@ -1086,11 +1139,24 @@ size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbo
 size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                    std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
                                    const std::vector<LineTrack>& tracks, double thr, bool angle_residual, bool normalized_distance, double weight) {
+  StageTimer stage_timer_("line-to-line association + blocks");
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
   bool loss_used = false;
   std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> lines_to_track;
   for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) lines_to_track[pr].push_back(t.id);
   size_t num = 0;
+  // all AssociateLine2Line(lidars[i], lidars[n_idx], thr) calls of the loop below (:379) in one GPU launch
+  std::vector<std::pair<const Velodyne*, const Velodyne*>> todo;
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    for (int n_idx : neighbors[i]) {
+      if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;
+      if (!lidars[n_idx].IsPoseValid() || !lidars[n_idx].valid) continue;
+      todo.push_back({&lidars[i], &lidars[n_idx]});
+    }
+  }
+  const std::vector<std::vector<Line2Line>> all_ass = AssociateLine2LineBatch(todo, (float)thr);
+  size_t next = 0;
   for (size_t i = 0; i < lidars.size(); i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
     double* aa_r = aa_list[lidars[i].id].data(); double* t_r = t_list[lidars[i].id].data();
@@ -1098,7 +1164,7 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
       if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;
       if (!lidars[n_idx].IsPoseValid() || !lidars[n_idx].valid) continue;
       double* t_n = t_list[lidars[n_idx].id].data(); double* aa_n = aa_list[lidars[n_idx].id].data();
-      const std::vector<Line2Line> ass = AssociateLine2Line(lidars[i], lidars[n_idx], (float)thr);
+      const std::vector<Line2Line>& ass = all_ass[next++];
       for (const Line2Line& a : ass) {
         auto it = lines_to_track.find({(uint32_t)i, (uint32_t)a.ref_line_idx});
         if (it == lines_to_track.end()) continue;
@@ -1371,6 +1437,18 @@ size_t AddCameraLidarResidual(int rows, int cols, const std::vector<bool>& frame
 void CameraLidarLineAssociate::AssociateByAngle(const std::vector<std::array<float, 4>>& lines, const Velodyne& lidar, const Matrix4d& T_cl,
                                                 const bool multiple_association, const std::vector<bool>& image_line_mask,
                                                 const std::vector<bool>& lidar_line_mask) {
+  // hot loop #3 (:394-426) on the GPU: votes[line][segment]
+  const size_t n_seg = lidar.edge_segmented.size();
+  std::vector<int> votes(lines.size() * std::max<size_t>(n_seg, 1), 0);
+  Engine& e = Engine::Default();
+  if (!lines.empty() && n_seg > 0)
+    e.Check(pvlm_cam_lidar_votes(e.ctx(), rows, cols, &lines[0][0], (int)lines.size(), lidar.DeviceScan(), T_cl.data(), votes.data()), "pvlm_cam_lidar_votes");
+  AssociateByAngleWithVotes(lines, lidar, T_cl, votes.data(), multiple_association, image_line_mask, lidar_line_mask);
+}
+
+void CameraLidarLineAssociate::AssociateByAngleWithVotes(const std::vector<std::array<float, 4>>& lines, const Velodyne& lidar, const Matrix4d& T_cl,
+                                                         const int* votes, const bool multiple_association, const std::vector<bool>& image_line_mask,
+                                                         const std::vector<bool>& lidar_line_mask) {
   const size_t n_seg = lidar.edge_segmented.size();
   std::vector<bool> image_mask = image_line_mask.empty() ? std::vector<bool>(lines.size(), true) : image_line_mask;
   std::vector<bool> lidar_mask = lidar_line_mask.empty() ? std::vector<bool>(n_seg, true) : lidar_line_mask;
@@ -1383,11 +1461,6 @@ void CameraLidarLineAssociate::AssociateByAngle(const std::vector<std::array<flo
     Vector4d pl; FormPlane0(p1.data(), p2.data(), pl.data());
     lidar_plane.push_back(pl);
   }
-  // hot loop #3 (:394-426) on the GPU: votes[line][segment]
-  std::vector<int> votes(lines.size() * std::max<size_t>(n_seg, 1), 0);
-  Engine& e = Engine::Default();
-  if (!lines.empty() && n_seg > 0)
-    e.Check(pvlm_cam_lidar_votes(e.ctx(), rows, cols, &lines[0][0], (int)lines.size(), lidar.DeviceScan(), T_cl.data(), votes.data()), "pvlm_cam_lidar_votes");
   const double angle_threshold = 3.0 / 180.0 * M_PI;
   Equirect eq{cols, rows};
   for (size_t li = 0; li < lines.size(); li++) {
@@ -1495,6 +1568,7 @@ static Matrix4d Mul4(const Matrix4d& A, const Matrix4d& B) {
 // ================================================================================================
 size_t AddCameraResidual(const std::vector<Frame>& frames, std::vector<Vector3d>& angleAxis_cw_list, std::vector<Vector3d>& t_cw_list,
                          std::vector<PointTrack>& structure, ceres_like::Problem& problem, int residual_type, double weight) {
+  StageTimer stage_timer_("reprojection blocks");
   if (residual_type != ANGLE_RESIDUAL_1)
     throw std::runtime_error("AddCameraResidual: only ANGLE_RESIDUAL_1 (the variant CameraLidarOptimizer::Optimize uses) is mirrored");
   if (frames.empty() || structure.empty()) return 0;
@@ -1534,17 +1608,53 @@ std::vector<std::vector<int>> CameraLidarOptimizer::NeighborEachFrame(const int 
 }
 
 CameraLidarOptimizer::LinePairs CameraLidarOptimizer::AssociateLineMulti(const int neighbor_size, const bool temporal) {
+  StageTimer stage_timer_("camera-LiDAR line association");
   const std::vector<std::vector<int>> nb = NeighborEachFrame(neighbor_size, temporal);
   LinePairs all;
+  // the voting loops of every (frame, LiDAR) pair in ONE launch (upstream: omp parallel for over frames, :345)
+  struct Job { size_t f; int lid; Matrix4d T_cl; };
+  std::vector<Job> jobs;
+  std::vector<pvlm_scan*> scans;
+  std::vector<int64_t> line_off(1, 0);
+  std::vector<float> lines_flat;
+  std::vector<double> T_flat;
   for (size_t f = 0; f < frames.size(); f++) {
     for (const int lid : nb[f]) {
       const Velodyne& lidar = lidars[lid];
       Matrix4d T_cl = T_cl_init;
       if (frames[f].IsPoseValid() && lidar.IsPoseValid()) T_cl = Mul4(Inverse4(frames[f].GetPose()), lidar.GetPose());
-      CameraLidarLineAssociate associate(frames[f].rows, frames[f].cols);
-      if (!lidar.edge_segmented.empty()) associate.AssociateByAngle(frames[f].lines, lidar, T_cl, true);
-      all[{f, (size_t)lid}] = associate.GetAssociatedPairs();
+      all[{f, (size_t)lid}] = {};
+      if (lidar.edge_segmented.empty() || frames[f].lines.empty()) continue;
+      jobs.push_back({f, lid, T_cl});
+      scans.push_back(lidar.DeviceScan());
+      for (const auto& l : frames[f].lines) lines_flat.insert(lines_flat.end(), l.begin(), l.end());
+      line_off.push_back((int64_t)lines_flat.size() / 4);
+      T_flat.insert(T_flat.end(), T_cl.begin(), T_cl.end());
     }
+  }
+  if (jobs.empty()) return all;
+  if (std::getenv("PVLM_HOST_NO_BATCH")) {   // measured variant: per-pair launches
+    for (const Job& j : jobs) {
+      CameraLidarLineAssociate associate(frames[j.f].rows, frames[j.f].cols);
+      associate.AssociateByAngle(frames[j.f].lines, lidars[j.lid], j.T_cl, true);
+      all[{j.f, (size_t)j.lid}] = associate.GetAssociatedPairs();
+    }
+    return all;
+  }
+  const int rows = frames[jobs[0].f].rows, cols = frames[jobs[0].f].cols;   // one image size per sequence, like AddCameraResidual assumes
+  Engine& e = Engine::Default();
+  std::vector<int64_t> voff(jobs.size() + 1, 0);
+  e.Check(pvlm_cam_lidar_votes_batch(e.ctx(), (int)jobs.size(), rows, cols, line_off.data(), lines_flat.data(), scans.data(), T_flat.data(), voff.data(),
+                                     nullptr, 0), "pvlm_cam_lidar_votes_batch");
+  std::vector<int32_t> votes((size_t)std::max<int64_t>(voff.back(), 1), 0);
+  e.Check(pvlm_cam_lidar_votes_batch(e.ctx(), (int)jobs.size(), rows, cols, line_off.data(), lines_flat.data(), scans.data(), T_flat.data(), voff.data(),
+                                     votes.data(), (int64_t)votes.size()), "pvlm_cam_lidar_votes_batch");
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    const Frame& fr = frames[jobs[j].f];
+    if (fr.rows != rows || fr.cols != cols) throw std::runtime_error("AssociateLineMulti: frames of different image size");
+    CameraLidarLineAssociate associate(fr.rows, fr.cols);
+    associate.AssociateByAngleWithVotes(fr.lines, lidars[jobs[j].lid], jobs[j].T_cl, votes.data() + voff[j], true);
+    all[{jobs[j].f, (size_t)jobs[j].lid}] = associate.GetAssociatedPairs();
   }
   return all;
 }

@@ -62,6 +62,10 @@ struct Config {
   int num_iteration_lidar = 7;
 };
 
+// Wall-clock seconds accumulated per stage of the mirrored call surface (association, track building, solve, ...)
+// since the process started — what tools/room_like_odometry.py prints beside the end-to-end time.
+const std::map<std::string, double>& StageSeconds();
+
 // The process-wide engine (one pvlm_ctx).  Throws std::runtime_error when no GPU / library.
 class Engine {
  public:
@@ -126,6 +130,10 @@ std::vector<Point2Plane> AssociatePoint2Plane(const Velodyne& ref_lidar, const V
                                               const float dist_threshold = 0.7f, bool visualization = false);
 std::vector<Line2Line> AssociateLine2Line(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const float dist_threshold = 0.7f,
                                           bool visualization = false);
+// Extension (not in PanoVLM): the AssociateLine2Line calls of a whole outer iteration in one GPU launch;
+// result[k] equals AssociateLine2Line(*pairs[k].first, *pairs[k].second, dist_threshold).
+std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<std::pair<const Velodyne*, const Velodyne*>>& pairs,
+                                                            const float dist_threshold = 0.7f);
 std::vector<Vector6d> TransformLines(const std::vector<Vector6d>& line_coeffs, const Matrix4d& T);
 std::vector<Line2Line> FindAssociations(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const std::vector<Vector6d>& ref_world,
                                         const std::vector<Vector6d>& nei_world, const std::vector<int>& line_matrix);
@@ -318,6 +326,11 @@ class CameraLidarLineAssociate {
   void AssociateByAngle(const std::vector<std::array<float, 4>>& lines, const Velodyne& lidar, const Matrix4d& T_cl,
                         const bool multiple_association = true, const std::vector<bool>& image_line_mask = {},
                         const std::vector<bool>& lidar_line_mask = {});
+  // Same with the vote matrix (n_lines x n_segments, from pvlm_cam_lidar_votes[_batch]) handed in — lets
+  // AssociateLineMulti run the voting loops of all (frame, LiDAR) pairs in one launch.
+  void AssociateByAngleWithVotes(const std::vector<std::array<float, 4>>& lines, const Velodyne& lidar, const Matrix4d& T_cl, const int* votes,
+                                 const bool multiple_association = true, const std::vector<bool>& image_line_mask = {},
+                                 const std::vector<bool>& lidar_line_mask = {});
   const std::vector<CameraLidarLinePair>& GetAssociatedPairs() const { return line_pairs; }
  private:
   void Filter(bool filter_by_angle, bool filter_by_length);

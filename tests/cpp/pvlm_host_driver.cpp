@@ -169,6 +169,7 @@ int main(int argc, char** argv) {
       LidarOdometry odo(l, cfg);
       odo.EstimatePose(iters);
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
+      for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());
       PrintPoses(odo.GetLidarData());
     } else if (cmd == "byangle") {
       auto l = LoadScans(argv[2]);  // one LOCAL-frame scan
@@ -199,6 +200,7 @@ int main(int argc, char** argv) {
       opt.SetStructure(structure);
       opt.JointOptimize();
       for (auto& it : opt.log) printf("iter cost %.17g steps %d blocks %d pairs %zu\n", it.cost, it.steps, it.residual_blocks, it.line_pairs);
+      for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());
       for (auto& it : opt.log) { printf("hist"); for (double c : it.cost_history) printf(" %.17g", c); printf("\n"); }
       PrintPoses(opt.GetLidars());
       PrintFrames(opt.GetFrames());

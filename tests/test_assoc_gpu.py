@@ -142,4 +142,12 @@ def test_line2line_votes(ctx, oracle):
         v2 = ctx.line2line_votes(db, da, thr)
         assert np.array_equal(v2, oracle.assoc_line2line(b, a, thr)["votes"])
     assert v.sum() > 0
-    da.close(); db.close()
+    # batched form (one launch for many pairs, incl. a scan without segments and a repeated pair) == pair by pair
+    empty = dict(a); empty.update(p2s=[[] for _ in a["p2s"]], seg_size=np.zeros(0, np.int32), seg_coeffs=np.zeros((0, 6)), end_points=np.zeros((0, 6)))
+    de = pv.Scan(ctx, empty)
+    refs, neis = [da, db, de, da, db], [db, da, da, de, da]
+    got = ctx.line2line_votes_batch(refs, neis, 0.3)
+    for r, n, g in zip(refs, neis, got):
+        assert g.shape == (n.n_segments, r.n_segments) and np.array_equal(g, ctx.line2line_votes(r, n, 0.3))
+    assert ctx.line2line_votes_batch([], [], 0.3) == []
+    da.close(); db.close(); de.close()

@@ -63,4 +63,12 @@ def test_cam_lidar_votes(ctx, oracle):
     assert v.shape == o["votes"].shape
     assert np.array_equal(v, o["votes"])
     assert v.sum() > 50 and len(o["image_line_id"]) > 0
+    # batched form: different line sets / calibrations per pair in one launch == pair by pair
+    T2 = T.copy(); T2[:3, 3] += 0.02
+    jobs = [(lines, T), (lines[:5], T2), (np.zeros((0, 4), np.float32), T), (lines[3:], T2)]
+    got = ctx.cam_lidar_votes_batch(rows, cols, [j[0] for j in jobs], [dscan] * len(jobs), [j[1] for j in jobs])
+    for (l, Tj), g in zip(jobs, got):
+        assert g.shape == (len(l), dscan.n_segments)
+        if len(l):
+            assert np.array_equal(g, ctx.cam_lidar_votes(rows, cols, l, dscan, Tj))
     dscan.close()

@@ -11,15 +11,33 @@ from panovlm_amd import synthetic as sy
 from tests import host_io, lm_twin
 
 
-def room_scan(k, rng):
+def room_edges():
+    """The 12 edges of the 8 x 3 x 12 m synthetic room (panovlm_amd/synthetic.py) + a few interior verticals:
+    the straight structures the reference's edge extractor would turn into line segments."""
+    x, y, z = 4.0, 1.5, 6.0
+    c = [np.array([sx * x, sy_ * y, sz * z]) for sx in (-1, 1) for sy_ in (-1, 1) for sz in (-1, 1)]
+    edges = [(a, b) for i, a in enumerate(c) for b in c[i + 1:] if np.count_nonzero(a != b) == 1]
+    for px, pz in ((-2.0, 1.0), (1.5, -2.5), (2.5, 3.0), (-1.0, -4.0)):
+        edges.append((np.array([px, -y, pz]), np.array([px, y, pz])))
+    return edges
+
+
+def room_scan(k, rng, lines=None):
     s = sy.make_scan(k, cols=1800, downsample_targets=0.2)
     R, t = s["R_wl"], s["t_wl"]
     Rl, tl = lm_twin.inv_pose(R, t)
     less_local = lm_twin.transform_f32(s["less_xyz"], Rl, tl)
     sel = np.sort(rng.choice(len(s["local_xyz"]), size=384, replace=False))   # 4 per sector x 6 sectors x 16 rings
     flat = s["local_xyz"][sel]
-    return dict(id=k, R_wl=R, t_wl=t, flat_local=flat, flat_tag=np.ones(len(flat), np.float32), less_local=less_local,
-                less_tag=np.ones(len(less_local), np.float32))
+    out = dict(id=k, R_wl=R, t_wl=t, flat_local=flat, flat_tag=np.ones(len(flat), np.float32), less_local=less_local,
+               less_tag=np.ones(len(less_local), np.float32))
+    if lines:
+        from tests import synth
+        Rt, tt = sy.true_pose(k)
+        ls = synth.make_line_scan(rng, k, Rt, tt, lines, pts_per_line=(30, 70), extra_pts=100, noise=0.01, shared_frac=0.0)   # sampled at the TRUE pose
+        out.update(corner_local=ls["corner_local"], p2s=ls["p2s"], seg_coeffs=ls["seg_coeffs"], end_points=ls["end_points"],
+                   seg_points=[[i for i, l in enumerate(ls["p2s"]) if sid in l] for sid in range(len(ls["seg_size"]))])
+    return out
 
 
 def main():
@@ -27,14 +45,16 @@ def main():
     ap.add_argument("--scans", type=int, default=64)
     ap.add_argument("--iters", type=int, default=7)
     ap.add_argument("--twin", type=int, default=0)
+    ap.add_argument("--lines", type=int, default=0, help="1: add line features (room edges) and the line-to-line term (Room config)")
     a = ap.parse_args()
     rng = np.random.default_rng(1)
-    scans = [room_scan(k, rng) for k in range(a.scans)]
+    edges = room_edges() if a.lines else None
+    scans = [room_scan(k, rng, edges) for k in range(a.scans)]
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "room.bin")
         host_io.write_scans(path, scans, world=False)
         t0 = time.perf_counter()
-        out = host_io.run("odometry", path, a.iters, 1, 1, 0, 1, 0.05, 1.0, 0.3, timeout=3000)
+        out = host_io.run("odometry", path, a.iters, 1, 1, 1 if a.lines else 0, 1, 0.05, 1.0, 0.3, timeout=3000)
         wall = time.perf_counter() - t0
     iters = [l for l in out if l.startswith("iter")]
     poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
@@ -43,6 +63,9 @@ def main():
     print("GPU EstimatePose: %d scans, %d outer iterations, %.2f s wall (process start, upload, association, LM, write-back)" % (a.scans, len(iters), wall))
     for l in iters:
         print("  ", l)
+    for l in out:
+        if l.startswith("stage"):
+            print("   stage %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:])))
     print("mean translation error vs ground truth: %.4f m -> %.4f m" % (e0, e1))
     if a.twin > 0:
         from oracle import oracle as orc
