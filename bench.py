@@ -172,6 +172,15 @@ def main():
         except Exception as e:  # reporting extra only
             mat = {"error": str(e)[:200]}
 
+    # 5.7K equirectangular panorama (5760 x 2880): whole-image CamToImage / ImageToCam maps (K7) and the
+    # camera<->LiDAR line-association voting loop (K8) for a Room-sized batch — reported beside the headline, never `value`
+    pano = None
+    if rank == 0:
+        try:
+            pano = panorama_block(ctx, pv, torch, dev)
+        except Exception as e:  # reporting extra only
+            pano = {"error": str(e)[:200]}
+
     if rank == 0:
         # HBM traffic of the fused kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command, summarised by tools/pmc_traffic.py into profiles/): used only when it was collected on
@@ -221,6 +230,7 @@ def main():
                             "kernel_ms": assoc_ms, "launches": assoc_n, "wall_s": t_assoc,
                             "M_queries_per_s_kernel": n_queries / max(assoc_ms, 1e-9) / 1e3},
             "materialise": mat,
+            "panorama": pano,
             "setup": {"scan_generation_s": t_gen, "scans_generated": len(needed)},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -229,6 +239,45 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def panorama_block(ctx, pv, torch, dev):
+    rows, cols = 2880, 5760
+    n = rows * cols
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    cam = torch.randn((n, 3), generator=g, device=dev, dtype=torch.float32) * 3.0
+    px = torch.empty((n, 2), device=dev, dtype=torch.float32)
+    out = {"rows": rows, "cols": cols, "pixels": n}
+    reps = 10
+    for name, fn, nbytes in (("cam_to_image_f32", lambda: ctx.cam_to_image_f32_dev(rows, cols, n, cam.data_ptr(), px.data_ptr()), 20),
+                             ("image_to_cam_f32", lambda: ctx.image_to_cam_f32_dev(rows, cols, n, px.data_ptr(), 1.0, cam.data_ptr()), 20)):
+        fn(); ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        out[name] = {"kernel_ms": ms, "G_points_per_s": n / ms / 1e6, "GBps": n * nbytes / ms / 1e6, "bytes_per_point": nbytes,
+                     "frac_of_hbm_peak": n * nbytes / ms / 1e6 / HBM_PEAK_GBPS}
+    # camera<->LiDAR voting: 454 frames x 3 neighbouring scans (Room, neighbor_size_joint = 3), 200 image lines per
+    # panorama, 1500 corner points in 40 segments per scan
+    rng = np.random.default_rng(11)
+    from panovlm_amd import synthetic as sy
+    lw = sy.random_world_lines(rng, 40, extent=4.0)
+    scan = sy.make_line_scan(rng, 0, np.eye(3), np.zeros(3), lw, pts_per_line=(30, 45), extra_pts=60)
+    local = dict(scan); local["corner_xyz"] = scan["corner_local"]
+    dscan = pv.Scan(ctx, local)
+    lines = rng.uniform([0, 0, 0, 0], [cols, rows, cols, rows], size=(200, 4)).astype(np.float32)
+    pairs = 454 * 3
+    T = np.eye(4)
+    t0 = time.perf_counter()
+    votes = ctx.cam_lidar_votes_batch(rows, cols, [lines] * pairs, [dscan] * pairs, [T] * pairs)
+    wall = time.perf_counter() - t0
+    tests_n = pairs * len(lines) * len(scan["corner_local"])
+    out["cam_lidar_votes"] = {"pairs": pairs, "image_lines": len(lines), "corner_points": int(len(scan["corner_local"])), "segments": int(dscan.n_segments),
+                              "point_line_tests": int(tests_n), "wall_s_incl_copies": wall, "G_tests_per_s_incl_copies": tests_n / wall / 1e9,
+                              "votes_cast": int(sum(int(v.sum()) for v in votes))}
+    dscan.close()
+    return out
 
 
 def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):

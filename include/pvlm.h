@@ -254,6 +254,10 @@ pvlm_status pvlm_cam_to_image_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, 
 pvlm_status pvlm_image_to_cam_f32(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* pixels, float r, float* cam);
 pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, const double* pixels, double r, double* cam);
 
+/* Same maps on device-resident buffers (async on the ctx stream, no copies) — whole-panorama use. */
+pvlm_status pvlm_cam_to_image_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* d_cam, float* d_pixels);
+pvlm_status pvlm_image_to_cam_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* d_pixels, float r, float* d_cam);
+
 /* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
  * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2
  * pixels, n_lines x 4 float) and every LiDAR corner point (LiDAR-local float xyz, transformed by

@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -179,6 +180,14 @@ class Context:
         self._check(self.lib.pvlm_cam_lidar_votes(self._h, C.c_int(rows), C.c_int(cols), _p(lines, C.c_float), C.c_int(lines.shape[0]),
                                                   lidar_scan._h, _p(T, C.c_double), _p(votes, C.c_int32)), "pvlm_cam_lidar_votes")
         return votes[:, :lidar_scan.n_segments]
+
+    def cam_to_image_f32_dev(self, rows, cols, n, d_cam_ptr, d_px_ptr):
+        self._check(self.lib.pvlm_cam_to_image_f32_dev(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), C.c_void_p(d_cam_ptr), C.c_void_p(d_px_ptr)),
+                    "pvlm_cam_to_image_f32_dev")
+
+    def image_to_cam_f32_dev(self, rows, cols, n, d_px_ptr, r, d_cam_ptr):
+        self._check(self.lib.pvlm_image_to_cam_f32_dev(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), C.c_void_p(d_px_ptr), C.c_float(r),
+                                                       C.c_void_p(d_cam_ptr)), "pvlm_image_to_cam_f32_dev")
 
     def cam_lidar_votes_batch(self, rows, cols, lines_list, lidar_scans, T_cl_list):
         """One launch for many (image lines, LiDAR-local scan, T_cl) triples; returns the list of vote matrices."""

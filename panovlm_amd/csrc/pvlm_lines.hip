@@ -261,6 +261,25 @@ pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, 
   });
 }
 
+// device-resident variants (async on the ctx stream, no copies): the panorama-sized maps of the MVS / depth-prior
+// consumers and of bench.py's panorama block
+pvlm_status pvlm_cam_to_image_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* d_cam, float* d_px) {
+  if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!d_cam || !d_px))) return PVLM_ERR_ARG;
+  if (n == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipLaunchKernelGGL(k_cam_to_image<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_cam, d_px);
+  PVLM_HIP(ctx, hipGetLastError());
+  return PVLM_OK;
+}
+pvlm_status pvlm_image_to_cam_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* d_px, float r, float* d_cam) {
+  if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!d_cam || !d_px))) return PVLM_ERR_ARG;
+  if (n == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipLaunchKernelGGL(k_image_to_cam<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_px, r, d_cam);
+  PVLM_HIP(ctx, hipGetLastError());
+  return PVLM_OK;
+}
+
 }  // extern "C"
 
 // TransformLines(ref.segment_coeffs, ref.GetPose())   LidarFeatureAssociate.cpp:219-236, :455

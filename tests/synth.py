@@ -106,47 +106,7 @@ def pair_blocks_from_jacobian(r, J, pair_offsets, loss, a):
 # ------------------------------------------------------------------------------------------------
 # segment-bearing scans (cornerLessSharp + edge_segmented + point_to_segment + segment_coeffs)
 # ------------------------------------------------------------------------------------------------
-def make_line_scan(rng, scan_id, R_wl, t_wl, lines_world, pts_per_line=(8, 40), noise=0.01, shared_frac=0.1, extra_pts=30):
-    """lines_world: list of (a, b) 3-D endpoints in the world frame.  Returns a scan dict whose
-    corner cloud samples those lines (+ a few unsegmented points); coefficients/end points are in
-    the LiDAR-local frame, the corner cloud in BOTH frames (corner_xyz = world float32 as during
-    LiDAR-LiDAR association, corner_local for camera-LiDAR association)."""
-    pts_local, p2s, seg_size, coeffs, ends = [], [], [], [], []
-    Rlw = R_wl.T
-    for s, (a, b) in enumerate(lines_world):
-        n = int(rng.integers(*pts_per_line))
-        u = np.sort(rng.uniform(0, 1, size=n))
-        pw = a[None, :] + u[:, None] * (b - a)[None, :] + rng.normal(size=(n, 3)) * noise
-        pl = (pw - t_wl) @ Rlw.T
-        al, bl = Rlw @ (a - t_wl), Rlw @ (b - t_wl)
-        d = (bl - al) / np.linalg.norm(bl - al)
-        first = len(pts_local)
-        for q in pl:
-            pts_local.append(q); p2s.append([s])
-        seg_size.append(n)
-        coeffs.append(np.concatenate([pl.mean(0), d]))
-        ends.append(np.concatenate([al, bl]))
-        # a few points shared with the previous segment (point_to_segment is a set of ids)
-        if s > 0 and rng.uniform() < shared_frac * 5:
-            k = first + int(rng.integers(0, n))
-            p2s[k] = sorted(set(p2s[k] + [s - 1]))
-            seg_size[s - 1] += 1
-    for _ in range(extra_pts):
-        pts_local.append(rng.normal(size=3) * 3); p2s.append([])
-    pts_local = np.array(pts_local, np.float32)
-    from panovlm_amd import synthetic as sy
-    world = sy.to_world_f32(pts_local, R_wl, t_wl)
-    return dict(id=scan_id, R_wl=R_wl, t_wl=t_wl, corner_xyz=world, corner_local=pts_local, p2s=p2s,
-                seg_size=np.array(seg_size, np.int32), seg_coeffs=np.array(coeffs), end_points=np.array(ends))
-
-
-def random_world_lines(rng, n, extent=4.0):
-    out = []
-    for _ in range(n):
-        a = rng.uniform(-extent, extent, size=3)
-        d = rng.normal(size=3); d /= np.linalg.norm(d)
-        out.append((a, a + d * rng.uniform(0.5, 3.0)))
-    return out
+from panovlm_amd.synthetic import make_line_scan, random_world_lines  # noqa: E402,F401  (shared with bench.py)
 
 
 # ---- reprojection ("bundle") problems: PanoramaReprojResidual_1Angle blocks ---------------------------------
