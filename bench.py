@@ -123,10 +123,13 @@ def main():
         dist.all_reduce(tot)
     n_total, q_total = int(tot[0].item()), int(tot[1].item())
 
-    def step():
+    def step_local():
         d_t.add_(1e-9)   # a fresh parameter point every step, as an LM iteration has
         ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
         neq.accumulate_dev(rs, packed.data_ptr(), pv.LOSS_HUBER, loss_a, zero_first=True)
+
+    def step():
+        step_local()
         if world > 1:
             dist.all_reduce(packed)
 
@@ -140,9 +143,9 @@ def main():
     # ~10 % below its steady state (measured: 89.7 -> 99.4 G eval/s at 101 M evals/launch).  Untimed pre-warm, then the
     # W warm-up steps of the contract.
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
+    while time.perf_counter() - t_pre < args.prewarm_seconds:   # local work only: the loop count differs between ranks
         for _ in range(8):
-            step()
+            step_local()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
