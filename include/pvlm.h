@@ -258,6 +258,14 @@ pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, 
 pvlm_status pvlm_cam_to_image_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* d_cam, float* d_pixels);
 pvlm_status pvlm_image_to_cam_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* d_pixels, float r, float* d_cam);
 
+/* ProjectLidar2PanoramaDepth (util/Visualization.h:407-441; the LiDAR-seeded depth prior of mvs/MVS.cpp:510-514):
+ * transforms the cloud (n x 3 float, LiDAR frame) by T_cl like pcl::transformPointCloud, projects with
+ * Equirectangular::CamToImage<float> and paints depth * 256 (uint16) over the window
+ * [floor(px) - size/2, ceil(px) + size/2]^2; points whose window leaves the image are skipped; where windows
+ * overlap the LAST point of the cloud wins, as in the reference's sequential loop.  depth: rows x cols uint16. */
+pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* xyz, const double* T_cl_rowmajor16,
+                                     unsigned size, uint16_t* depth);
+
 /* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
  * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2
  * pixels, n_lines x 4 float) and every LiDAR corner point (LiDAR-local float xyz, transformed by

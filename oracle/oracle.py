@@ -269,6 +269,15 @@ def cam_to_image(rows, cols, cam):
     return px
 
 
+def project_lidar_depth(rows, cols, xyz, T_cl, size=3):
+    """ProjectLidar2PanoramaDepth (util/Visualization.h:407-441): rows x cols uint16 image of depth * 256."""
+    xyz = _f32(xyz).reshape(-1, 3); T = _f64(T_cl).reshape(16)
+    out = np.zeros((rows, cols), np.uint16)
+    lib().orc_project_lidar_depth(C.c_int(rows), C.c_int(cols), C.c_long(xyz.shape[0]), _p(xyz, C.c_float), _p(T, C.c_double), C.c_ulong(size),
+                                  _p(out, C.c_ushort))
+    return out
+
+
 def image_to_cam(rows, cols, px, r=1.0):
     px = np.ascontiguousarray(px)
     if px.dtype == np.float32:

@@ -188,6 +188,31 @@ float orc_fast_atan2_f(float y, float x) { return FastAtan2<float>(y, x); }
 double orc_fast_atan2_d(double y, double x) { return FastAtan2<double>(y, x); }
 
 void orc_cam_to_image_f(int rows, int cols, long n, const float* cam, float* px) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.CamToImage(cam + 3 * i, px + 2 * i); }
+// ProjectLidar2PanoramaDepth (util/Visualization.h:407-441): sparse 16-bit depth image (depth * 256) of a LiDAR cloud
+// seen from the camera; every point paints a (size/2-padded) pixel window, later points overwrite earlier ones.
+// cloud: n x 3 float (LiDAR frame), T_cl row-major 4x4 double, out rows x cols uint16 (zero = no point).
+void orc_project_lidar_depth(int rows, int cols, long n, const float* xyz, const double* T_cl, unsigned long size, unsigned short* out) {
+  Equirectangular eq(rows, cols);
+  std::memset(out, 0, sizeof(unsigned short) * size_t(rows) * size_t(cols));
+  for (long i = 0; i < n; ++i) {
+    // pcl::transformPointCloud(float cloud, Matrix4d): computed in double, stored as float
+    float p[3];
+    for (int r = 0; r < 3; ++r)
+      p[r] = static_cast<float>(T_cl[4 * r] * double(xyz[3 * i]) + T_cl[4 * r + 1] * double(xyz[3 * i + 1]) + T_cl[4 * r + 2] * double(xyz[3 * i + 2]) + T_cl[4 * r + 3]);
+    float px[2];
+    eq.CamToImage(p, px);                                                  // eq.SphereToImage(eq.CamToSphere(point))
+    // cv::Point2i rb(ceil(pixel.x) + size / 2, ...): float + size_t evaluated in float, then truncated to int
+    const int rbx = int(std::ceil(px[0]) + float(size / 2)), rby = int(std::ceil(px[1]) + float(size / 2));
+    const int ltx = int(std::floor(px[0]) - float(size / 2)), lty = int(std::floor(px[1]) - float(size / 2));
+    if (!(rbx >= 0 && rby >= 0 && rbx + 1 <= cols && rby + 1 <= rows)) continue;   // eq.IsInside(cv::Point2i)
+    if (!(ltx >= 0 && lty >= 0 && ltx + 1 <= cols && lty + 1 <= rows)) continue;
+    const float depth = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    const unsigned short rel = static_cast<unsigned short>(depth * 256.0);
+    for (int u = lty; u <= rby; ++u)
+      for (int v = ltx; v <= rbx; ++v) out[size_t(u) * cols + v] = rel;
+  }
+}
+
 void orc_cam_to_image_d(int rows, int cols, long n, const double* cam, double* px) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.CamToImage(cam + 3 * i, px + 2 * i); }
 void orc_image_to_cam_f(int rows, int cols, long n, const float* px, float r, float* cam) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.ImageToCam(px + 2 * i, r, cam + 3 * i); }
 void orc_image_to_cam_d(int rows, int cols, long n, const double* px, double r, double* cam) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.ImageToCam(px + 2 * i, r, cam + 3 * i); }

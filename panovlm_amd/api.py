@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -188,6 +188,13 @@ class Context:
     def image_to_cam_f32_dev(self, rows, cols, n, d_px_ptr, r, d_cam_ptr):
         self._check(self.lib.pvlm_image_to_cam_f32_dev(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), C.c_void_p(d_px_ptr), C.c_float(r),
                                                        C.c_void_p(d_cam_ptr)), "pvlm_image_to_cam_f32_dev")
+
+    def project_lidar_depth(self, rows, cols, xyz, T_cl, size=3):
+        xyz = _f32(xyz).reshape(-1, 3); T = _f64(T_cl).reshape(16)
+        out = np.zeros((rows, cols), np.uint16)
+        self._check(self.lib.pvlm_project_lidar_depth(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(xyz.shape[0]), _p(xyz, C.c_float),
+                                                      _p(T, C.c_double), C.c_uint(size), _p(out, C.c_uint16)), "pvlm_project_lidar_depth")
+        return out
 
     def cam_lidar_votes_batch(self, rows, cols, lines_list, lidar_scans, T_cl_list):
         """One launch for many (image lines, LiDAR-local scan, T_cl) triples; returns the list of vote matrices."""

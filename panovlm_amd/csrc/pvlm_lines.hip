@@ -106,6 +106,38 @@ __global__ void k_image_to_cam(int rows, int cols, long long n, const T* __restr
   cam[3 * i + 2] = r * cy * (T)cos((double)sx);
 }
 
+// ---- LiDAR-seeded sparse depth image: ProjectLidar2PanoramaDepth (util/Visualization.h:407-441) ----------------
+// The reference paints the points in cloud order, so a pixel ends up with the depth of the LAST point whose window
+// covers it.  Pass 1: every point atomically maximises (point index << 16 | depth16) over its window — the winner is
+// exactly that last writer; pass 2 keeps the low 16 bits.
+__global__ __launch_bounds__(256) void k_depth_splat(int rows, int cols, long long n, const float* __restrict__ xyz, const double* __restrict__ T_cl,
+                                                     int half, unsigned long long* __restrict__ img) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  float p[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) p[r] = (float)(T_cl[4 * r] * (double)x + T_cl[4 * r + 1] * (double)y + T_cl[4 * r + 2] * (double)z + T_cl[4 * r + 3]);
+  const float lon = fast_atan2<float>(p[0], p[2]);
+  const float lat = -fast_atan2<float>(p[1], (float)sqrt((double)(p[0] * p[0] + p[2] * p[2])));
+  const float px = (float)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
+  const float py = (float)(rows * (0.5 - lat / 3.14159265358979323846));
+  const int rbx = (int)(ceilf(px) + (float)half), rby = (int)(ceilf(py) + (float)half);
+  const int ltx = (int)(floorf(px) - (float)half), lty = (int)(floorf(py) - (float)half);
+  if (!(rbx >= 0 && rby >= 0 && rbx + 1 <= cols && rby + 1 <= rows)) return;
+  if (!(ltx >= 0 && lty >= 0 && ltx + 1 <= cols && lty + 1 <= rows)) return;
+  const float depth = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  const unsigned short rel = (unsigned short)(unsigned int)((double)depth * 256.0);
+  const unsigned long long key = ((unsigned long long)(i + 1) << 16) | rel;
+  for (int u = lty; u <= rby; ++u)
+    for (int v = ltx; v <= rbx; ++v) atomicMax(&img[(size_t)u * cols + v], key);
+}
+
+__global__ void k_depth_finish(long long npix, const unsigned long long* __restrict__ img, unsigned short* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npix) out[i] = (unsigned short)(img[i] & 0xffffull);
+}
+
 // ---- K8 -----------------------------------------------------------------------------------------
 __device__ __forceinline__ double vangle(const double* a, const double* b) {  // VectorAngle3D, Geometry.hpp:450-466
   double c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
@@ -259,6 +291,37 @@ pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, 
   return run_map<double>(ctx, n, px, 2, cam, 3, [&](double* di, double* dout) {
     hipLaunchKernelGGL(k_image_to_cam<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
   });
+}
+
+pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* xyz, const double* T_cl, unsigned size,
+                                     uint16_t* depth) {
+  if (!ctx || n < 0 || rows <= 0 || cols <= 0 || !T_cl || !depth || (n > 0 && !xyz)) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t npix = (size_t)rows * cols;
+  float* d_xyz = nullptr; double* d_T = nullptr; unsigned long long* d_img = nullptr; unsigned short* d_out = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_xyz, (size_t)n * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_T, (size_t)16);
+  if (!st) st = pvlm_i_alloc(ctx, &d_img, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_out, npix);
+  if (!st) {
+    hipError_t e = hipMemsetAsync(d_img, 0, npix * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_T, T_cl, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n > 0) {
+      hipLaunchKernelGGL(k_depth_splat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_xyz, d_T, (int)(size / 2), d_img);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_depth_finish, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, (long long)npix, d_img, d_out);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(depth, d_out, npix * sizeof(unsigned short), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "project_lidar_depth: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_xyz); hipFree(d_T); hipFree(d_img); hipFree(d_out);
+  return st;
 }
 
 // device-resident variants (async on the ctx stream, no copies): the panorama-sized maps of the MVS / depth-prior

@@ -1563,6 +1563,15 @@ static Matrix4d Mul4(const Matrix4d& A, const Matrix4d& B) {
   return C;
 }
 
+std::vector<uint16_t> ProjectLidar2PanoramaDepth(const PointCloud& cloud, const int rows, const int cols, const Matrix4d& T_cl, const size_t size) {
+  std::vector<float> xyz(cloud.size() * 3);
+  for (size_t i = 0; i < cloud.size(); ++i) { xyz[3 * i] = cloud[i].x; xyz[3 * i + 1] = cloud[i].y; xyz[3 * i + 2] = cloud[i].z; }
+  std::vector<uint16_t> img((size_t)rows * cols, 0);
+  Engine& e = Engine::Default();
+  e.Check(pvlm_project_lidar_depth(e.ctx(), rows, cols, (int64_t)cloud.size(), xyz.data(), T_cl.data(), (unsigned)size, img.data()), "pvlm_project_lidar_depth");
+  return img;
+}
+
 // ================================================================================================
 // AddCameraResidual — util/Optimization.cpp:172-222 (ANGLE_RESIDUAL_1)
 // ================================================================================================

@@ -340,6 +340,10 @@ class CameraLidarLineAssociate {
 };
 
 
+// util/Visualization.h:407-441 — sparse LiDAR depth image (uint16 depth * 256, row-major rows x cols) seen from the
+// camera: the LiDAR-seeded depth prior of mvs/MVS.cpp:510-514.  `cloud` is in the LiDAR frame.
+std::vector<uint16_t> ProjectLidar2PanoramaDepth(const PointCloud& cloud, const int rows, const int cols, const Matrix4d& T_cl, const size_t size = 3);
+
 // ---- joint_optimization/CameraLidarOptimizer.h (mapping mode) --------------------------------------------------
 // sensors/Frame.h contract as far as the path needs it: image size, pose T_wc, the detected image lines
 // (image_lines_all[frame].GetLines()).

@@ -151,9 +151,31 @@ def neighbors():
     np.savez_compressed(os.path.join(OUT, "neighbors.npz"), poses=poses, valid=valid, off=off, ids=np.array([v for l in nb for v in l], np.int32))
 
 
+def reproj():
+    """PanoramaReprojResidual_1Angle blocks (base/CostFunction.h:218-247): r and the 1x9 Jacobian rows."""
+    rng = np.random.default_rng(31)
+    b = synth.random_bundle(rng, n_cams=5, n_points=40)
+    pt = np.repeat(np.arange(len(b["off"]) - 1), np.diff(b["off"])).astype(np.int32)
+    r, J = orc.evaluate_reproj(b["bearing"], 1.5, b["cam"], pt, b["aa"], b["t"], b["X"])
+    np.savez_compressed(os.path.join(OUT, "reproj.npz"), aa=b["aa"], t=b["t"], X=b["X"], off=b["off"], cam=b["cam"], pt=pt, bearing=b["bearing"],
+                        weight=np.array(1.5), r=r, J=J)
+
+
+def depth():
+    """ProjectLidar2PanoramaDepth (util/Visualization.h:407-441) of a small scan, window sizes 3 and 2."""
+    rng = np.random.default_rng(41)
+    s = sy.make_scan(5, cols=128)
+    xyz = np.concatenate([s["local_xyz"], s["local_xyz"][::5] * np.float32(1.02), rng.normal(size=(100, 3)).astype(np.float32) * np.float32([0.01, 3.0, 0.01])])
+    a = np.deg2rad([1.0, -2.0, 0.5]); T = np.eye(4); T[:3, :3] = synth.rodrigues(a); T[:3, 3] = [0.03, -0.02, 0.05]
+    d = dict(xyz=xyz, T_cl=T, rows=np.array(360), cols=np.array(720))
+    for size in (3, 2):
+        d["depth_size%d" % size] = orc.project_lidar_depth(360, 720, xyz, T, size)
+    np.savez_compressed(os.path.join(OUT, "depth.npz"), **d)
+
+
 if __name__ == "__main__":
     orc.build()
-    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors()
+    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth()
     tot = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -72,3 +72,23 @@ def test_cam_lidar_votes(ctx, oracle):
         if len(l):
             assert np.array_equal(g, ctx.cam_lidar_votes(rows, cols, l, dscan, Tj))
     dscan.close()
+
+
+@pytest.mark.parametrize("size", [3, 2, 0])
+def test_project_lidar_depth_matches_oracle(ctx, oracle, size):
+    """ProjectLidar2PanoramaDepth (util/Visualization.h:407-441): bit-exact uint16 image, including the
+    last-point-wins rule where windows overlap and the skipped windows at the image border."""
+    from panovlm_amd import synthetic as sy
+    rng = np.random.default_rng(12 + size)
+    rows, cols = 720, 1440
+    s = sy.make_scan(3, cols=512)
+    xyz = np.concatenate([s["local_xyz"], s["local_xyz"][::7] * np.float32(1.01),     # overlapping windows, different depths
+                          rng.normal(size=(500, 3)).astype(np.float32) * np.float32([0.01, 3.0, 0.01]),   # poles: windows leave the image
+                          np.float32([[0.0, 0.0, -2.0], [1e-4, 0.3, -2.0], [-1e-4, -0.3, -2.0]])])        # the +-pi seam
+    a = np.deg2rad([1.0, -2.0, 0.5]); T = np.eye(4); T[:3, :3] = synth.rodrigues(a); T[:3, 3] = [0.03, -0.02, 0.05]
+    got = ctx.project_lidar_depth(rows, cols, xyz, T, size)
+    ref = oracle.project_lidar_depth(rows, cols, xyz, T, size)
+    assert got.dtype == np.uint16 and got.shape == (rows, cols)
+    assert np.array_equal(got, ref)
+    assert 0.02 < (ref > 0).mean() < 0.9
+    assert np.array_equal(ctx.project_lidar_depth(rows, cols, np.zeros((0, 3), np.float32), T, size), np.zeros((rows, cols), np.uint16))

@@ -113,6 +113,19 @@ def test_find_neighbors_golden(oracle):
     assert nb[13] == [16, 15, 14, 13, 12, 11, 10]                       # invalid pose -> temporal window (LidarFeatureAssociate.cpp:103-107)
 
 
+def test_reproj_golden(oracle):
+    g = load("reproj.npz")
+    r, J = oracle.evaluate_reproj(g["bearing"], float(g["weight"]), g["cam"], g["pt"], g["aa"], g["t"], g["X"])
+    assert np.array_equal(r, g["r"]) and np.array_equal(J, g["J"])
+
+
+def test_depth_golden(oracle):
+    g = load("depth.npz")
+    for size in (3, 2):
+        img = oracle.project_lidar_depth(int(g["rows"]), int(g["cols"]), g["xyz"], g["T_cl"], size)
+        assert np.array_equal(img, g["depth_size%d" % size]) and (img > 0).mean() > 0.02
+
+
 def test_refvec_container_round_trip(tmp_path):
     """tools/refvec.py (re-pinning recipe against a real PanoVLM build): export -> read back == fixture inputs,
     and `compare` accepts the fixtures' own expectations."""

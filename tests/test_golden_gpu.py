@@ -73,3 +73,20 @@ def test_lines_golden(ctx):
         assert np.array_equal(ctx.line2line_votes(a, b, thr), g["t%02d_votes" % int(thr * 10)])
     c = pv.Scan(ctx, line_scan(g, "c", local=True))
     assert np.array_equal(ctx.cam_lidar_votes(2880, 5760, g["c_lines"], c, g["c_T_cl"]), g["c_votes"])
+
+
+def test_reproj_golden(ctx):
+    import panovlm_amd as pv
+    g = load("reproj.npz")
+    ctx.set_poses(g["aa"], g["t"])
+    bs = pv.BundleSet(ctx, g["off"], g["cam"], g["bearing"], g["X"], weight=float(g["weight"]))
+    r, J = bs.evaluate()
+    assert np.all(np.abs(r - g["r"]) <= 1e-6 * np.abs(g["r"]) + 8 * 2.2e-16 / np.maximum(g["r"], 1e-7))
+    assert np.all(np.abs(J - g["J"]) <= 1e-6 * np.abs(g["J"]).max(axis=1, keepdims=True) + 1e-15 / np.maximum(g["r"], 1e-7)[:, None] ** 2)
+    bs.close()
+
+
+def test_depth_golden(ctx):
+    g = load("depth.npz")
+    for size in (3, 2):
+        assert np.array_equal(ctx.project_lidar_depth(int(g["rows"]), int(g["cols"]), g["xyz"], g["T_cl"], size), g["depth_size%d" % size])

@@ -27,6 +27,7 @@
 #include "lidar_mapping/LidarFeatureAssociate.h"            // FindNeighbors, AssociatePoint2Plane, AssociateLine2Line
 #include "sensors/Equirectangular.h"
 #include "sensors/Velodyne.h"
+#include "util/Visualization.h"                             // ProjectLidar2PanoramaDepth
 
 namespace {
 
@@ -339,6 +340,48 @@ void DumpFastAtan2(const std::string& dir) {
   WriteBundle(dir + "/fast_atan2.ref.pvv", out);
 }
 
+// ---- PanoramaReprojResidual_1Angle (base/CostFunction.h:218-247) ---------------------------------------------
+void DumpReproj(const std::string& dir) {
+  const Bundle in = ReadBundle(dir + "/reproj.in.pvv");
+  if (in.empty()) return;
+  const Array &aa = in.at("aa"), &t = in.at("t"), &X = in.at("X"), &cam = in.at("cam"), &pt = in.at("pt"), &bearing = in.at("bearing");
+  const double weight = in.at("weight").as_double(0);
+  const size_t n = cam.count();
+  std::vector<double> r(n), J(n * 9);
+  for (size_t i = 0; i < n; ++i) {
+    ceres::CostFunction* cost = PanoramaReprojResidual_1Angle::Create(V3(bearing.f64() + 3 * i), weight);
+    const int c = (int)cam.as_double(i), p = (int)pt.as_double(i);
+    const double* params[3] = {aa.f64() + 3 * c, t.f64() + 3 * c, X.f64() + 3 * p};
+    double jb[3][3]; double* jac[3] = {jb[0], jb[1], jb[2]};
+    cost->Evaluate(params, &r[i], jac);
+    for (int b = 0; b < 3; ++b) for (int k = 0; k < 3; ++k) J[i * 9 + 3 * b + k] = jb[b][k];
+    delete cost;
+  }
+  Bundle out;
+  out["r"] = MakeArray(1, {n}, r);
+  out["J"] = MakeArray(1, {n, 9}, J);
+  WriteBundle(dir + "/reproj.ref.pvv", out);
+}
+
+// ---- ProjectLidar2PanoramaDepth (util/Visualization.h:407-441) -----------------------------------------------
+void DumpDepth(const std::string& dir) {
+  const Bundle in = ReadBundle(dir + "/depth.in.pvv");
+  if (in.empty()) return;
+  pcl::PointCloud<pcl::PointXYZI> cloud;
+  FillCloud(in.at("xyz"), nullptr, cloud);
+  Eigen::Matrix4d T;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T(i, j) = in.at("T_cl").f64()[4 * i + j];
+  const int rows = (int)in.at("rows").as_double(0), cols = (int)in.at("cols").as_double(0);
+  Bundle out;
+  for (size_t size : {size_t(3), size_t(2)}) {
+    const cv::Mat img = ProjectLidar2PanoramaDepth(cloud, rows, cols, T, size);
+    std::vector<int32_t> v((size_t)rows * cols);
+    for (int u = 0; u < rows; ++u) for (int w = 0; w < cols; ++w) v[(size_t)u * cols + w] = img.at<uint16_t>(u, w);
+    out["depth_size" + std::to_string(size)] = MakeArray(2, {(uint64_t)rows, (uint64_t)cols}, v);
+  }
+  WriteBundle(dir + "/depth.ref.pvv", out);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -351,5 +394,7 @@ int main(int argc, char** argv) {
   DumpNeighbors(dir);
   DumpPoint2Plane(dir);
   DumpLines(dir);
+  DumpReproj(dir);
+  DumpDepth(dir);
   return 0;
 }

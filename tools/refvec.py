@@ -29,7 +29,7 @@ def write_pvv(path, arrays):
         for name, a in arrays.items():
             a = np.ascontiguousarray(a)
             if a.dtype not in CODES:
-                a = a.astype(np.float64)
+                a = a.astype(np.int32 if a.dtype.kind in "iu" and a.dtype.itemsize < 4 else np.float64)
             nb = name.encode()
             f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<BI", CODES[a.dtype], a.ndim))
             f.write(struct.pack("<%dQ" % a.ndim, *a.shape))
@@ -66,12 +66,16 @@ def _is_output(fixture, key):
         return key in ("off", "ids")
     if fixture == "fast_atan2":
         return key.startswith("out_")
+    if fixture == "reproj":
+        return key in ("r", "J")
+    if fixture == "depth":
+        return key.startswith("depth_size")
     raise KeyError(fixture)
 
 
 # intermediate results the reference API does not expose (k-NN table, query indices, vote matrices)
 INTERNAL = ("_qidx", "_nn", "votes")
-FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2")
+FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth")
 
 
 def export(out_dir):
@@ -105,7 +109,9 @@ def compare(out_dir):
             if exp.shape != got.shape:
                 print("%-20s %-18s SHAPE %s vs reference %s" % (fx, k, exp.shape, got.shape)); bad += 1
                 continue
-            if exp.dtype.kind in "iu" or exp.dtype == np.float32:
+            if exp.dtype.kind in "iu" and exp.dtype.itemsize == 2:      # .pvv has no 16-bit type: images travel as int32
+                ok = np.array_equal(exp.astype(np.int32), got.astype(np.int32)); how = "bit-exact"
+            elif exp.dtype.kind in "iu" or exp.dtype == np.float32:
                 ok = np.array_equal(exp, got.astype(exp.dtype)); how = "bit-exact"
             else:
                 # north_star tolerance: 1e-6 relative (values of O(1)); Jacobians of the angle functors are
