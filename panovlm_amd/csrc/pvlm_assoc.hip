@@ -651,6 +651,17 @@ static void cloud_free(pvlm_cloud& c) {
   c = pvlm_cloud();
 }
 
+// build-time scratch, released on every exit path
+struct DevScratch {
+  std::vector<void*> ptrs;
+  ~DevScratch() { for (void* p : ptrs) hipFree(p); }
+  template <typename T> pvlm_status alloc(pvlm_ctx* ctx, T** p, size_t count) {
+    const pvlm_status st = pvlm_i_alloc(ctx, p, count);
+    if (!st) ptrs.push_back(*p);
+    return st;
+  }
+};
+
 static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float* xyz, const float* tag, bool build_hash) {
   c.n = n;
   if (n <= 0) return PVLM_OK;
@@ -682,7 +693,8 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
   const bool dense = ncells <= std::max<long long>(64ll * n, 4096) && ncells <= (4ll << 20) && !getenv("PVLM_FORCE_HASH");
   if ((st = pvlm_i_alloc(ctx, &c.d_sorted, (size_t)n))) return st;
   int *d_slot = nullptr, *d_cursor = nullptr, *d_tiles = nullptr;
-  if ((st = pvlm_i_alloc(ctx, &d_tiles, (size_t)((4ll << 20) / SCAN_TILE + 4096)))) return st;
+  DevScratch scratch;   // the members of `c` allocated so far are released by the caller (pvlm_scan_destroy path)
+  if ((st = scratch.alloc(ctx, &d_tiles, (size_t)((4ll << 20) / SCAN_TILE + 4096)))) return st;
   hipError_t le = hipSuccess, se = hipSuccess;
   if (dense) {
     c.dense = 1; c.nx = (int)dims[0]; c.ny = (int)dims[1]; c.nz = (int)dims[2];
@@ -690,11 +702,11 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
     const int T = c.table_size;
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
-    if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
-    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); hipFree(d_tiles); return st; }
+    if ((st = scratch.alloc(ctx, &d_slot, (size_t)n))) return st;
+    if ((st = scratch.alloc(ctx, &d_cursor, (size_t)T))) return st;
     hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
     hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
-    if (e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+    if (e2 != hipSuccess || e3 != hipSuccess) { PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
     hipLaunchKernelGGL(k_dense_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h, c.nx,
                        c.ny, c.nz, c.d_cell_count, d_slot);
     launch_scan(ctx, T, c.d_cell_count, c.d_cell_start, d_tiles);
@@ -708,12 +720,12 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
     if ((st = pvlm_i_alloc(ctx, &c.d_keys, (size_t)T))) return st;
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
     if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
-    if ((st = pvlm_i_alloc(ctx, &d_slot, (size_t)n))) return st;
-    if ((st = pvlm_i_alloc(ctx, &d_cursor, (size_t)T))) { hipFree(d_slot); hipFree(d_tiles); return st; }
+    if ((st = scratch.alloc(ctx, &d_slot, (size_t)n))) return st;
+    if ((st = scratch.alloc(ctx, &d_cursor, (size_t)T))) return st;
     hipError_t e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
     hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
     hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { hipFree(d_slot); hipFree(d_cursor); PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
     hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h,
                        T - 1, c.d_keys, c.d_cell_count, d_slot);
     launch_scan(ctx, T, c.d_cell_count, c.d_cell_start, d_tiles);
@@ -721,7 +733,6 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
     le = hipGetLastError();
     se = hipStreamSynchronize(ctx->stream);
   }
-  hipFree(d_slot); hipFree(d_cursor); hipFree(d_tiles);
   if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }

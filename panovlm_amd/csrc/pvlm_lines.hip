@@ -377,9 +377,9 @@ static void line_table_row(int rows, int cols, const float* l, double* t) {
   t[7] = h_vangle(p1, t + 4);
 }
 
-template <typename D>
+template <typename D, typename Launch>
 static pvlm_status run_vote_batch(pvlm_ctx* ctx, const std::vector<D>& desc, const std::vector<long long>& work_off, long long total_work,
-                                  const std::vector<double>& tab, long long n_votes, int32_t* votes, void (*launch)(pvlm_ctx*, int, const D*, const long long*, long long, const double*, int*)) {
+                                  const std::vector<double>& tab, long long n_votes, int32_t* votes, Launch launch) {
   D* d_desc = nullptr; long long* d_work = nullptr; double* d_tab = nullptr; int* d_v = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_desc, desc.size());
   if (!st) st = pvlm_i_alloc(ctx, &d_work, work_off.size());
@@ -426,11 +426,10 @@ pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* co
   if (capacity < nv) { PVLM_SET_ERR(ctx, "pvlm_line2line_votes_batch: %lld votes do not fit the capacity %lld", nv, (long long)capacity); return PVLM_ERR_CAPACITY; }
   if (nv == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  static double s_thr;   // captured by the launcher below (plain function pointer)
-  s_thr = (double)dist_threshold;
-  return run_vote_batch<pvlm_line_pair_desc>(ctx, desc, work_off, work_off[n_pairs], lines, nv, votes,
-      [](pvlm_ctx* c, int np, const pvlm_line_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
-        hipLaunchKernelGGL(k_line_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl, s_thr, dv);
+  const double thr = (double)dist_threshold;
+  return run_vote_batch(ctx, desc, work_off, work_off[n_pairs], lines, nv, votes,
+      [thr](pvlm_ctx* c, int np, const pvlm_line_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
+        hipLaunchKernelGGL(k_line_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl, thr, dv);
       });
 }
 
@@ -462,7 +461,7 @@ pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   std::vector<double> tab((size_t)n_lines_total * 8);
   for (long long li = 0; li < n_lines_total; ++li) line_table_row(rows, cols, lines + 4 * li, &tab[8 * (size_t)li]);
-  return run_vote_batch<pvlm_cam_pair_desc>(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes,
+  return run_vote_batch(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes,
       [](pvlm_ctx* c, int np, const pvlm_cam_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
         hipLaunchKernelGGL(k_cam_lidar_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl,
                            3.0 / 180.0 * M_PI, dv);
