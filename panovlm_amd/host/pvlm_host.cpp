@@ -176,6 +176,7 @@ static void TransformCloud(PointCloud& c, const Matrix3d& R, const Vector3d& t) 
 void Velodyne::Transform2LidarWorld() {
   if (world_ || !IsPoseValid()) return;
   TransformCloud(surfFlat, R_wl_, t_wl_); TransformCloud(surfLessFlat, R_wl_, t_wl_); TransformCloud(cornerLessSharp, R_wl_, t_wl_);
+  TransformCloud(cloud, R_wl_, t_wl_);
   for (PointCloud& s : edge_segmented) TransformCloud(s, R_wl_, t_wl_);
   world_ = true;
   InvalidateDevice();
@@ -186,6 +187,7 @@ void Velodyne::Transform2Local() {
   const Vector3d rt = MatVec(Rl, t_wl_);
   const Vector3d tl = {-rt[0], -rt[1], -rt[2]};
   TransformCloud(surfFlat, Rl, tl); TransformCloud(surfLessFlat, Rl, tl); TransformCloud(cornerLessSharp, Rl, tl);
+  TransformCloud(cloud, Rl, tl);
   for (PointCloud& s : edge_segmented) TransformCloud(s, Rl, tl);
   world_ = false;
   InvalidateDevice();
@@ -195,13 +197,13 @@ void Velodyne::InvalidateDevice() const {
 }
 Velodyne::~Velodyne() { if (dev_) pvlm_scan_destroy(Engine::Default().ctx(), dev_); }
 Velodyne::Velodyne(const Velodyne& o)
-    : id(o.id), valid(o.valid), cornerLessSharp(o.cornerLessSharp), surfFlat(o.surfFlat), surfLessFlat(o.surfLessFlat),
+    : id(o.id), valid(o.valid), name(o.name), cloud(o.cloud), cornerLessSharp(o.cornerLessSharp), surfFlat(o.surfFlat), surfLessFlat(o.surfLessFlat),
       edge_segmented(o.edge_segmented), point_to_segment(o.point_to_segment), segment_coeffs(o.segment_coeffs), end_points(o.end_points),
       R_wl_(o.R_wl_), t_wl_(o.t_wl_), world_(o.world_), dev_(nullptr) {}
 Velodyne& Velodyne::operator=(const Velodyne& o) {
   if (this == &o) return *this;
   InvalidateDevice();
-  id = o.id; valid = o.valid; cornerLessSharp = o.cornerLessSharp; surfFlat = o.surfFlat; surfLessFlat = o.surfLessFlat;
+  id = o.id; valid = o.valid; name = o.name; cloud = o.cloud; cornerLessSharp = o.cornerLessSharp; surfFlat = o.surfFlat; surfLessFlat = o.surfLessFlat;
   edge_segmented = o.edge_segmented; point_to_segment = o.point_to_segment; segment_coeffs = o.segment_coeffs; end_points = o.end_points;
   R_wl_ = o.R_wl_; t_wl_ = o.t_wl_; world_ = o.world_;
   return *this;
@@ -427,6 +429,147 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
     out[which[j]] = FindAssociations(ref, nei, ref_world, nei_world, v);
   }
   return out;
+}
+
+// ================================================================================================
+// LoadLidar — sensors/Velodyne.cpp:92-172 (+ the part of pcl::io::loadPCDFile a PointXYZI cloud needs)
+// ================================================================================================
+namespace {
+// LZF decompression (the codec of PCD "binary_compressed"): control byte < 32 = literal run of ctrl + 1 bytes; otherwise
+// a back reference of length (ctrl >> 5) + 2 (length 7 reads one extension byte) at offset ((ctrl & 31) << 8 | next) + 1.
+bool LzfDecompress(const unsigned char* in, size_t in_len, unsigned char* out, size_t out_len) {
+  size_t ip = 0, op = 0;
+  while (ip < in_len) {
+    unsigned ctrl = in[ip++];
+    if (ctrl < 32) {
+      const size_t run = ctrl + 1;
+      if (ip + run > in_len || op + run > out_len) return false;
+      std::memcpy(out + op, in + ip, run); ip += run; op += run;
+    } else {
+      size_t len = ctrl >> 5;
+      if (len == 7) { if (ip >= in_len) return false; len += in[ip++]; }
+      if (ip >= in_len) return false;
+      const size_t off = ((size_t)(ctrl & 0x1f) << 8) + in[ip++] + 1;
+      len += 2;
+      if (off > op || op + len > out_len) return false;
+      for (size_t k = 0; k < len; ++k, ++op) out[op] = out[op - off];   // may overlap: byte by byte
+    }
+  }
+  return op == out_len;
+}
+
+struct PcdField { std::string name; int size = 4; char type = 'F'; int count = 1; size_t offset = 0; };
+
+bool ReadPcd(const std::string& path, PointCloud& cloud) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::vector<PcdField> fields;
+  size_t points = 0, width = 0, height = 1;
+  std::string data_mode, line;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line.empty() || line[0] == '#') continue;
+    std::istringstream ls(line);
+    std::string key; ls >> key;
+    if (key == "FIELDS") { std::string n; while (ls >> n) { PcdField fd; fd.name = n; fields.push_back(fd); } }
+    else if (key == "SIZE") { for (PcdField& fd : fields) ls >> fd.size; }
+    else if (key == "TYPE") { for (PcdField& fd : fields) ls >> fd.type; }
+    else if (key == "COUNT") { for (PcdField& fd : fields) ls >> fd.count; }
+    else if (key == "WIDTH") ls >> width;
+    else if (key == "HEIGHT") ls >> height;
+    else if (key == "POINTS") ls >> points;
+    else if (key == "DATA") { ls >> data_mode; break; }
+  }
+  if (fields.empty() || data_mode.empty()) return false;
+  if (points == 0) points = width * height;
+  size_t stride = 0;
+  for (PcdField& fd : fields) { fd.offset = stride; stride += (size_t)fd.size * fd.count; }
+  int ix = -1, iy = -1, iz = -1, ii = -1;
+  for (size_t k = 0; k < fields.size(); ++k) {
+    if (fields[k].name == "x") ix = (int)k; else if (fields[k].name == "y") iy = (int)k; else if (fields[k].name == "z") iz = (int)k;
+    else if (fields[k].name == "intensity") ii = (int)k;
+  }
+  if (ix < 0 || iy < 0 || iz < 0) return false;
+  for (int k : {ix, iy, iz}) if (fields[k].type != 'F' || fields[k].size != 4) return false;   // PointXYZI: float32 coordinates
+  cloud.assign(points, PointXYZI{0, 0, 0, 0});
+  auto as_float = [](const PcdField& fd, const unsigned char* p) -> float {
+    if (fd.type == 'F' && fd.size == 4) { float v; std::memcpy(&v, p, 4); return v; }
+    if (fd.type == 'F' && fd.size == 8) { double v; std::memcpy(&v, p, 8); return (float)v; }
+    if (fd.type == 'U' && fd.size == 1) return (float)*p;
+    if (fd.type == 'U' && fd.size == 2) { uint16_t v; std::memcpy(&v, p, 2); return (float)v; }
+    if (fd.type == 'U' && fd.size == 4) { uint32_t v; std::memcpy(&v, p, 4); return (float)v; }
+    if (fd.type == 'I' && fd.size == 4) { int32_t v; std::memcpy(&v, p, 4); return (float)v; }
+    return 0.f;
+  };
+  if (data_mode == "ascii") {
+    for (size_t i = 0; i < points; ++i) {
+      if (!std::getline(f, line)) return false;
+      std::istringstream ls(line);
+      for (size_t k = 0; k < fields.size(); ++k)
+        for (int c = 0; c < fields[k].count; ++c) {
+          std::string tok; ls >> tok;
+          if (c > 0) continue;
+          float v = (tok == "nan" || tok == "-nan" || tok == "NaN") ? NAN : (float)std::strtod(tok.c_str(), nullptr);
+          if ((int)k == ix) cloud[i].x = v; else if ((int)k == iy) cloud[i].y = v; else if ((int)k == iz) cloud[i].z = v; else if ((int)k == ii) cloud[i].intensity = v;
+        }
+    }
+    return true;
+  }
+  std::vector<unsigned char> raw;
+  if (data_mode == "binary") {
+    raw.resize(points * stride);
+    f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)raw.size());
+    if ((size_t)f.gcount() != raw.size()) return false;
+    for (size_t i = 0; i < points; ++i) {
+      const unsigned char* p = raw.data() + i * stride;
+      cloud[i].x = as_float(fields[ix], p + fields[ix].offset); cloud[i].y = as_float(fields[iy], p + fields[iy].offset);
+      cloud[i].z = as_float(fields[iz], p + fields[iz].offset);
+      if (ii >= 0) cloud[i].intensity = as_float(fields[ii], p + fields[ii].offset);
+    }
+    return true;
+  }
+  if (data_mode == "binary_compressed") {
+    uint32_t csize = 0, usize = 0;
+    f.read(reinterpret_cast<char*>(&csize), 4); f.read(reinterpret_cast<char*>(&usize), 4);
+    if (!f || usize != points * stride) return false;
+    std::vector<unsigned char> comp(csize);
+    f.read(reinterpret_cast<char*>(comp.data()), csize);
+    if ((size_t)f.gcount() != csize) return false;
+    raw.resize(usize);
+    if (!LzfDecompress(comp.data(), csize, raw.data(), usize)) return false;
+    // the uncompressed block is field-major (all x, all y, ...)
+    size_t base = 0;
+    std::vector<size_t> fbase(fields.size());
+    for (size_t k = 0; k < fields.size(); ++k) { fbase[k] = base; base += (size_t)fields[k].size * fields[k].count * points; }
+    for (size_t i = 0; i < points; ++i) {
+      auto at = [&](int k) { return raw.data() + fbase[k] + i * (size_t)fields[k].size * fields[k].count; };
+      cloud[i].x = as_float(fields[ix], at(ix)); cloud[i].y = as_float(fields[iy], at(iy)); cloud[i].z = as_float(fields[iz], at(iz));
+      if (ii >= 0) cloud[i].intensity = as_float(fields[ii], at(ii));
+    }
+    return true;
+  }
+  return false;
+}
+}  // namespace
+
+bool Velodyne::LoadLidar(std::string file_path) {
+  if (file_path.empty()) file_path = name;
+  const std::string::size_type pos = file_path.rfind('.');
+  const std::string type = pos == std::string::npos ? "" : file_path.substr(pos);
+  if (type != ".pcd") { fprintf(stderr, "unknown point cloud format, only .pcd is mirrored (the reference also reads .ply)\n"); return false; }
+  PointCloud raw;
+  if (!ReadPcd(file_path, raw)) { fprintf(stderr, "Fail to load lidar data at %s\n", file_path.c_str()); return false; }
+  name = file_path;
+  cloud.clear();
+  for (const PointXYZI& p : raw) {
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;      // pcl::removeNaNFromPointCloud
+    const float dis = p.x * p.x + p.y * p.y + p.z * p.z;                                  // removeClosedPointCloud(0.5), float
+    if (dis < 0.5f * 0.5f) continue;
+    // T_cam_lidar (:127-132): X right, Y forward, Z up  ->  X right, Y down, Z forward
+    cloud.push_back({p.x, -p.z, p.y, p.intensity});
+  }
+  if (cloud.size() < 4000) { fprintf(stderr, "lidar %d is invalid, only %zu points in point cloud\n", id, cloud.size()); valid = false; }
+  return true;
 }
 
 // ================================================================================================

@@ -84,6 +84,8 @@ class Velodyne {
  public:
   int id = 0;
   bool valid = true;
+  std::string name;                               // file name of the raw scan
+  PointCloud cloud;                               // raw points as loaded (LoadLidar), camera-style axes
   PointCloud cornerLessSharp, surfFlat, surfLessFlat;
   std::vector<PointCloud> edge_segmented;
   std::vector<std::set<int>> point_to_segment;
@@ -102,6 +104,11 @@ class Velodyne {
   void MarkWorld(bool w = true) { world_ = w; InvalidateDevice(); }  // clouds already carry world-frame floats
   Vector3d World2Local(const Vector3d& p) const;  // sensors/Velodyne.cpp:1850-1853
   Vector3d Local2World(const Vector3d& p) const;  // :1856-1859
+  // LoadLidar (sensors/Velodyne.cpp:92-145): reads a .pcd file (the PCL formats: ascii, binary, binary_compressed; fields
+  // x y z [intensity], float32), drops non-finite points (pcl::removeNaNFromPointCloud), drops points closer than 0.5 m
+  // (removeClosedPointCloud, :148-172), swaps the axes to the camera convention (x, y, z) -> (x, -z, y) and marks the scan
+  // invalid when fewer than 4000 points remain.  Returns false when the file cannot be read (the reference logs and returns).
+  bool LoadLidar(std::string file_path = "");
   void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
   void Transform2Local();                         // :1810-1848
 

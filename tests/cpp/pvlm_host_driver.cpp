@@ -242,6 +242,12 @@ int main(int argc, char** argv) {
         printf("single %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", r, j0[0], j0[1], j0[2], j1[0], j1[1], j1[2], j2[0], j2[1], j2[2]);
         delete c;
       }
+    } else if (cmd == "loadpcd") {
+      // loadpcd <file.pcd> : Velodyne::LoadLidar — prints the count, valid flag and every point (hex floats)
+      Velodyne v; v.id = 7;
+      const bool ok = v.LoadLidar(argv[2]);
+      printf("loaded %d valid %d points %zu name %s\n", ok ? 1 : 0, v.valid ? 1 : 0, v.cloud.size(), v.name.c_str());
+      for (const PointXYZI& p : v.cloud) printf("p %a %a %a %a\n", p.x, p.y, p.z, p.intensity);
     } else if (cmd == "poseio") {
       // poseio <in.txt> <out.txt> with_invalid precision
       std::vector<Matrix3d> R; std::vector<Vector3d> t; std::vector<std::string> names;

@@ -53,3 +53,91 @@ def test_pose_file_roundtrip():
         assert out2[0] == "poses 5"
         first = open(dst6).readline().split()
         assert np.allclose([float(x) for x in first[1:]], rows[0][1], rtol=1e-5)
+
+
+def _lzf_compress(data):
+    """Small LZF encoder (the codec of PCD binary_compressed): greedy 3-byte hash matches, literal runs <= 32,
+    back references of length 3..264 at offsets <= 8192 — enough to exercise both token kinds of the decoder."""
+    out = bytearray(); lit = bytearray(); table = {}
+    i, n = 0, len(data)
+
+    def flush():
+        for k in range(0, len(lit), 32):
+            chunk = lit[k:k + 32]
+            out.append(len(chunk) - 1); out.extend(chunk)
+        lit.clear()
+    while i < n:
+        key = bytes(data[i:i + 3]); j = table.get(key, -1)
+        if len(key) == 3:
+            table[key] = i
+        if j >= 0 and 0 < i - j <= 8192:
+            length = 3
+            while i + length < n and length < 264 and data[j + length] == data[i + length]:
+                length += 1
+            flush()
+            off = i - j - 1; l = length - 2
+            if l < 7:
+                out.append((l << 5) | (off >> 8))
+            else:
+                out.append((7 << 5) | (off >> 8)); out.append(l - 7)
+            out.append(off & 0xff)
+            i += length
+        else:
+            lit.append(data[i]); i += 1
+    flush()
+    return bytes(out)
+
+
+def test_load_lidar_pcd_formats():
+    """Velodyne::LoadLidar (sensors/Velodyne.cpp:92-172): PCD ascii / binary / binary_compressed -> NaN removal,
+    0.5 m near-point removal (float), axis swap (x, y, z) -> (x, -z, y), < 4000 points = invalid scan."""
+    import struct
+    rng = np.random.default_rng(17)
+    n = 5000
+    pts = (rng.normal(size=(n, 3)) * 4).astype(np.float32)
+    inten = rng.uniform(0, 255, size=n).astype(np.float32)
+    inten[:2000] = 100.0                                                           # compressible run: back references in the LZF stream
+    pts[::97] = np.float32([np.nan, 1.0, 2.0]); pts[5::131, 2] = np.inf          # invalid returns
+    pts[3::53] = (rng.normal(size=(len(pts[3::53]), 3)) * 0.2).astype(np.float32)   # closer than 0.5 m
+    pts[7] = np.float32([0.3, 0.4, 0.0])                                           # exactly on the 0.5 m sphere: kept (dis < thr^2 is false)
+    finite = np.isfinite(pts).all(axis=1)
+    d2 = (pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1] + pts[:, 2] * pts[:, 2]).astype(np.float32)
+    keep = finite & ~(d2 < np.float32(0.25))
+    exp = np.stack([pts[keep, 0], -pts[keep, 2], pts[keep, 1], inten[keep]], axis=1)
+    assert 4000 < len(exp) < n and keep[7]
+    hdr = "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n" \
+          "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n"
+    rec = np.concatenate([pts, inten[:, None]], axis=1).astype(np.float32)
+
+    def parse(out):
+        head = out[0].split()
+        got = np.array([[float.fromhex(v) for v in l.split()[1:]] for l in out[1:] if l.startswith("p ")], np.float32).reshape(-1, 4)
+        return int(head[1]), int(head[3]), int(head[5]), got
+    with tempfile.TemporaryDirectory() as d:
+        files = {}
+        files["ascii"] = os.path.join(d, "a.pcd")
+        with open(files["ascii"], "w") as f:
+            f.write(hdr % (n, n, "ascii"))
+            for p, i in zip(pts, inten):
+                f.write(" ".join("nan" if np.isnan(v) else repr(float(v)) for v in p) + " " + repr(float(i)) + "\n")
+        files["binary"] = os.path.join(d, "b.pcd")
+        with open(files["binary"], "wb") as f:
+            f.write((hdr % (n, n, "binary")).encode()); f.write(rec.tobytes())
+        files["binary_compressed"] = os.path.join(d, "c.pcd")
+        soa = rec.T.copy().tobytes()                       # field-major block
+        comp = _lzf_compress(soa)
+        assert len(comp) < 0.95 * len(soa)                  # back references were emitted
+        with open(files["binary_compressed"], "wb") as f:
+            f.write((hdr % (n, n, "binary_compressed")).encode()); f.write(struct.pack("<II", len(comp), len(soa))); f.write(comp)
+        for mode, path in files.items():
+            ok, valid, count, got = parse(host_io.run("loadpcd", path))
+            assert ok == 1 and valid == 1 and count == len(exp), mode
+            assert np.array_equal(got, exp), mode     # ascii: repr() round-trips float32 values exactly through strtod
+        # fewer than 4000 points left -> invalid scan; a missing file -> not loaded
+        small = os.path.join(d, "s.pcd")
+        with open(small, "wb") as f:
+            f.write((hdr % (3000, 3000, "binary")).encode()); f.write(rec[:3000].tobytes())
+        ok, valid, count, _ = parse(host_io.run("loadpcd", small))
+        assert ok == 1 and valid == 0 and count == int(keep[:3000].sum())
+        ok, valid, count, _ = parse(host_io.run("loadpcd", os.path.join(d, "missing.pcd")))
+        assert ok == 0 and count == 0
