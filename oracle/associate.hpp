@@ -222,6 +222,86 @@ inline std::vector<Line2Line> AssociateLine2Line(const Scan& ref, const Scan& ne
   return FindAssociations(ref, nei, ref_world, nei_world, votes);
 }
 
+// LidarFeatureAssociate.cpp:238-317: every one of the 5 nearest ref corner points must lie on ONE ref segment; the
+// line end points are the segment's LOCAL coefficients +- 0.1 * direction (not transformed, as upstream).
+inline std::vector<Point2Line> AssociatePoint2LineSegmentKNN(const Scan& ref, const Scan& nei, float dist_threshold) {
+  std::vector<Point2Line> out;
+  if (ref.segment_size.empty() || nei.segment_size.empty()) return out;
+  const float sq_thr = dist_threshold * dist_threshold;
+  const int K = 5;
+  const int nt = int(ref.cornerLessSharp.size() / 3), nq = int(nei.cornerLessSharp.size() / 3);
+  for (int i = 0; i < nq; ++i) {
+    int idx[K]; float sqd[K];
+    const float* q = &nei.cornerLessSharp[3 * i];
+    if (!KnnBrute(ref.cornerLessSharp.data(), nt, q, K, idx, sqd)) continue;
+    if (sqd[K - 1] > sq_thr) continue;
+    std::map<size_t, size_t> seg_count;
+    for (int j = 0; j < K; ++j) for (int sid : ref.point_to_segment[idx[j]]) seg_count[size_t(sid)]++;
+    for (const auto& kv : seg_count) {
+      if (kv.second < size_t(K - 0)) continue;
+      const double* l = &ref.segment_coeffs[6 * kv.first];
+      Point2Line a;
+      for (int c = 0; c < 3; ++c) { a.a[c] = 0.1 * l[3 + c] + l[c]; a.b[c] = -0.1 * l[3 + c] + l[c]; }
+      const double qw[3] = {q[0], q[1], q[2]};
+      nei.World2Local(qw, a.point);
+      a.query_index = i;
+      out.push_back(a);
+    }
+  }
+  return out;
+}
+
+// LidarFeatureAssociate.cpp:319-383: nearest ref segment line (world) by point-to-line distance, brute force.
+inline std::vector<Point2Line> AssociatePoint2LineSegment(const Scan& ref, const Scan& nei, float dist_threshold) {
+  std::vector<Point2Line> out;
+  if (ref.segment_size.empty() || nei.segment_size.empty()) return out;
+  const std::vector<double> ref_world = TransformLines(ref.segment_coeffs, ref.R_wl, ref.t_wl);
+  const int nq = int(nei.cornerLessSharp.size() / 3), nr = int(ref.segment_size.size());
+  for (int i = 0; i < nq; ++i) {
+    const double p[3] = {nei.cornerLessSharp[3 * i], nei.cornerLessSharp[3 * i + 1], nei.cornerLessSharp[3 * i + 2]};
+    double min_distance = std::numeric_limits<double>::max();
+    int seg = -1;
+    for (int s = 0; s < nr; ++s) {
+      const double d = PointToLineDistance3D(p, &ref_world[6 * s]);
+      if (d < min_distance) { min_distance = d; seg = s; }
+    }
+    if (!(min_distance <= dist_threshold)) continue;
+    const double* l = &ref.segment_coeffs[6 * seg];
+    Point2Line a;
+    for (int c = 0; c < 3; ++c) { a.a[c] = 0.1 * l[3 + c] + l[c]; a.b[c] = -0.1 * l[3 + c] + l[c]; }
+    nei.World2Local(p, a.point);
+    a.query_index = i;
+    out.push_back(a);
+  }
+  return out;
+}
+
+// LidarFeatureAssociate.cpp:385-440: votes from the 5-NN's segments (>= 3 of the 5 on one ref segment), then FindAssociations.
+inline std::vector<Line2Line> AssociateLine2LineKNN(const Scan& ref, const Scan& nei, float dist_threshold, std::vector<int>* votes_out = nullptr) {
+  std::vector<Line2Line> out;
+  if (ref.segment_size.empty() || nei.segment_size.empty()) return out;
+  const float sq_thr = dist_threshold * dist_threshold;
+  const int K = 5;
+  const std::vector<double> nei_world = TransformLines(nei.segment_coeffs, nei.R_wl, nei.t_wl);
+  const std::vector<double> ref_world = TransformLines(ref.segment_coeffs, ref.R_wl, ref.t_wl);
+  const int nr = int(ref.segment_size.size()), nn = int(nei.segment_size.size());
+  std::vector<int> votes(size_t(nn) * nr, 0);
+  const int nt = int(ref.cornerLessSharp.size() / 3), nq = int(nei.cornerLessSharp.size() / 3);
+  for (int i = 0; i < nq; ++i) {
+    int idx[K]; float sqd[K];
+    if (!KnnBrute(ref.cornerLessSharp.data(), nt, &nei.cornerLessSharp[3 * i], K, idx, sqd)) continue;
+    if (sqd[K - 1] > sq_thr) continue;
+    std::map<size_t, size_t> seg_count;
+    for (int j = 0; j < K; ++j) for (int sid : ref.point_to_segment[idx[j]]) seg_count[size_t(sid)]++;
+    for (const auto& kv : seg_count) {
+      if (kv.second < size_t(K - 2)) continue;
+      for (int ns : nei.point_to_segment[i]) votes[size_t(ns) * nr + kv.first] += 1;
+    }
+  }
+  if (votes_out) *votes_out = votes;
+  return FindAssociations(ref, nei, ref_world, nei_world, votes);
+}
+
 // ---------------------------------------------------------------------------------------------
 // FindNeighbors — LidarFeatureAssociate.cpp:19-111 (exact k-NN / radius search over scan centres,
 // float32 centres as PointXYZI; FLANN radius search keeps dist < r^2 and returns ascending).

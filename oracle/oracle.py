@@ -218,21 +218,23 @@ def assoc_point2plane(ref, nei, tol, thr, want_knn=False):
     return out
 
 
-def assoc_point2line(ref, nei, thr):
+def assoc_point2line(ref, nei, thr, mode="knn"):
+    """mode "knn": AssociatePoint2Line, "segment_knn": AssociatePoint2LineSegmentKNN, "segment": AssociatePoint2LineSegment."""
     r = ScanArrays(ref); n = ScanArrays(nei)
-    cap = max(1, n.c.n_corner)
+    cap = max(1, n.c.n_corner * max(1, r.c.n_seg))
     pt = np.empty((cap, 3)); a = np.empty((cap, 3)); b = np.empty((cap, 3)); qi = np.empty(cap, np.int32)
-    m = lib().orc_assoc_point2line(C.byref(r.c), C.byref(n.c), C.c_float(thr), _p(pt, C.c_double), _p(a, C.c_double),
-                                   _p(b, C.c_double), _p(qi, C.c_int))
+    m = lib().orc_assoc_point2line(C.byref(r.c), C.byref(n.c), C.c_float(thr), C.c_int({"knn": 0, "segment_knn": 1, "segment": 2}[mode]),
+                                   _p(pt, C.c_double), _p(a, C.c_double), _p(b, C.c_double), _p(qi, C.c_int))
     return dict(point=pt[:m].copy(), a=a[:m].copy(), b=b[:m].copy(), qidx=qi[:m].copy())
 
 
-def assoc_line2line(ref, nei, thr):
+def assoc_line2line(ref, nei, thr, knn=False):
+    """knn=False: AssociateLine2Line (distance votes); knn=True: AssociateLine2LineKNN (5-NN segment votes)."""
     r = ScanArrays(ref); n = ScanArrays(nei)
     ns, rs = max(1, n.c.n_seg), max(1, r.c.n_seg)
     ni = np.empty(ns, np.int32); ri = np.empty(ns, np.int32); p1 = np.empty((ns, 3)); p2 = np.empty((ns, 3))
     votes = np.zeros((ns, rs), np.int32)
-    m = lib().orc_assoc_line2line(C.byref(r.c), C.byref(n.c), C.c_float(thr), _p(ni, C.c_int), _p(ri, C.c_int),
+    m = lib().orc_assoc_line2line(C.byref(r.c), C.byref(n.c), C.c_float(thr), C.c_int(1 if knn else 0), _p(ni, C.c_int), _p(ri, C.c_int),
                                   _p(p1, C.c_double), _p(p2, C.c_double), _p(votes, C.c_int))
     return dict(nei_idx=ni[:m].copy(), ref_idx=ri[:m].copy(), p1=p1[:m].copy(), p2=p2[:m].copy(),
                 votes=votes[:n.c.n_seg, :r.c.n_seg].copy())

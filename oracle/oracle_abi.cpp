@@ -146,9 +146,10 @@ int orc_assoc_point2plane(const orc_scan* ref, const orc_scan* nei, double tol, 
   return int(a.size());
 }
 
-int orc_assoc_point2line(const orc_scan* ref, const orc_scan* nei, float thr, double* out_point, double* out_a, double* out_b, int* out_qidx) {
+// mode 0: AssociatePoint2Line (5-NN + FormLine), 1: AssociatePoint2LineSegmentKNN, 2: AssociatePoint2LineSegment
+int orc_assoc_point2line(const orc_scan* ref, const orc_scan* nei, float thr, int mode, double* out_point, double* out_a, double* out_b, int* out_qidx) {
   Scan r = to_scan(ref), n = to_scan(nei);
-  std::vector<Point2Line> a = AssociatePoint2Line(r, n, thr);
+  std::vector<Point2Line> a = mode == 0 ? AssociatePoint2Line(r, n, thr) : (mode == 1 ? AssociatePoint2LineSegmentKNN(r, n, thr) : AssociatePoint2LineSegment(r, n, thr));
   for (size_t i = 0; i < a.size(); ++i) {
     std::memcpy(out_point + 3 * i, a[i].point, 24); std::memcpy(out_a + 3 * i, a[i].a, 24); std::memcpy(out_b + 3 * i, a[i].b, 24);
     out_qidx[i] = a[i].query_index;
@@ -157,11 +158,11 @@ int orc_assoc_point2line(const orc_scan* ref, const orc_scan* nei, float thr, do
 }
 
 // votes: n_nei_seg x n_ref_seg (optional). Outputs sized >= n_nei_seg.
-int orc_assoc_line2line(const orc_scan* ref, const orc_scan* nei, float thr, int* out_nei_idx, int* out_ref_idx,
+int orc_assoc_line2line(const orc_scan* ref, const orc_scan* nei, float thr, int knn, int* out_nei_idx, int* out_ref_idx,
                         double* out_p1, double* out_p2, int* votes) {
   Scan r = to_scan(ref), n = to_scan(nei);
   std::vector<int> v;
-  std::vector<Line2Line> a = AssociateLine2Line(r, n, thr, votes ? &v : nullptr);
+  std::vector<Line2Line> a = knn ? AssociateLine2LineKNN(r, n, thr, votes ? &v : nullptr) : AssociateLine2Line(r, n, thr, votes ? &v : nullptr);
   for (size_t i = 0; i < a.size(); ++i) {
     out_nei_idx[i] = a[i].neighbor_line_idx; out_ref_idx[i] = a[i].ref_line_idx;
     std::memcpy(out_p1 + 3 * i, a[i].p1, 24); std::memcpy(out_p2 + 3 * i, a[i].p2, 24);

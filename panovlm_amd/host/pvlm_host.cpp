@@ -397,6 +397,158 @@ std::vector<Line2Line> AssociateLine2Line(const Velodyne& ref, const Velodyne& n
   return FindAssociations(ref, nei, ref_world, nei_world, votes);
 }
 
+// ---- k-NN based variants: LidarFeatureAssociate.cpp:238-440, :478-548 ------------------------------------------
+namespace {
+// 5-NN of every nei corner point in ref.cornerLessSharp (world-frame floats), on the GPU: pcl::KdTreeFLANN::nearestKSearch
+// of :251-261 / :399-414 / :487-496.  idx/sqd are nq x 5; rows without 5 neighbours within the threshold carry +inf.
+constexpr int kLineK = 5;
+void CornerKnn(const Velodyne& ref, const Velodyne& nei, float dist_threshold, std::vector<int32_t>& idx, std::vector<float>& sqd) {
+  const size_t nq = nei.cornerLessSharp.size();
+  idx.assign(nq * kLineK, -1); sqd.assign(nq * kLineK, INFINITY);
+  if (nq == 0 || ref.cornerLessSharp.size() < (size_t)kLineK) return;
+  std::vector<float> q(nq * 3);
+  for (size_t i = 0; i < nq; ++i) { q[3 * i] = nei.cornerLessSharp[i].x; q[3 * i + 1] = nei.cornerLessSharp[i].y; q[3 * i + 2] = nei.cornerLessSharp[i].z; }
+  Engine& e = Engine::Default();
+  e.Check(pvlm_knn(e.ctx(), ref.DeviceScan(), 1, q.data(), (int)nq, kLineK, dist_threshold, idx.data(), sqd.data()), "pvlm_knn");
+}
+
+// principal axis test of FormLine (base/Geometry.hpp:220-260): scatter matrix of the points, cyclic Jacobi rotations;
+// a line when the largest eigenvalue exceeds tolerance x the middle one and every point is within dis_threshold of it.
+bool FormLine(const double* pts, int n, double tolerance, double dis_threshold, double* line) {
+  double c[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) c[k] = c[k] + pts[3 * i + k];
+  for (int k = 0; k < 3; ++k) c[k] = c[k] / double(n);
+  double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int i = 0; i < n; ++i) {
+    const double d[3] = {pts[3 * i] - c[0], pts[3 * i + 1] - c[1], pts[3 * i + 2] - c[2]};
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) A[r][k] = A[r][k] + d[r] * d[k];
+  }
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    if (A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2] == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[p][q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        const int r = 3 - p - q;
+        A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.0;
+        const double arp = A[r][p], arq = A[r][q];
+        A[r][p] = A[p][r] = cs * arp - sn * arq;
+        A[r][q] = A[q][r] = sn * arp + cs * arq;
+        for (int k = 0; k < 3; ++k) { const double vp = V[k][p], vq = V[k][q]; V[k][p] = cs * vp - sn * vq; V[k][q] = sn * vp + cs * vq; }
+      }
+  }
+  int order[3] = {0, 1, 2};
+  std::sort(order, order + 3, [&](int a, int b) { return A[a][a] < A[b][b]; });
+  for (int k = 0; k < 6; ++k) line[k] = 0.0;
+  if (!(A[order[2]][order[2]] > tolerance * A[order[1]][order[1]])) return false;
+  double dir[3] = {V[0][order[2]], V[1][order[2]], V[2][order[2]]};
+  const double len = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+  if (len * len > 0.0) for (double& v : dir) v /= len;
+  const double l[6] = {c[0], c[1], c[2], dir[0], dir[1], dir[2]};
+  if (dis_threshold > 0.0)
+    for (int i = 0; i < n; ++i) if (PointToLineDistance3D(pts + 3 * i, l) > dis_threshold) return false;
+  for (int k = 0; k < 6; ++k) line[k] = l[k];
+  return true;
+}
+
+bool WorldOk(const Velodyne& a, const Velodyne& b) {
+  if (a.IsInWorldCoordinate() && b.IsInWorldCoordinate()) return true;
+  fprintf(stderr, "lidar %d / %d is not in world coordinate\n", a.id, b.id);
+  return false;
+}
+}  // namespace
+
+std::vector<Point2Line> AssociatePoint2Line(const Velodyne& ref, const Velodyne& nei, const float dist_threshold, bool) {   // :478-548
+  std::vector<Point2Line> out;
+  if (!WorldOk(ref, nei)) return out;
+  const float sq_thr = dist_threshold * dist_threshold;
+  std::vector<int32_t> idx; std::vector<float> sqd;
+  CornerKnn(ref, nei, dist_threshold, idx, sqd);
+  for (size_t i = 0; i < nei.cornerLessSharp.size(); ++i) {
+    if (!(sqd[i * kLineK + kLineK - 1] <= sq_thr)) continue;                                   // :497-498
+    double pts[kLineK * 3];
+    for (int j = 0; j < kLineK; ++j) {
+      const PointXYZI& p = ref.cornerLessSharp[idx[i * kLineK + j]];
+      pts[3 * j] = p.x; pts[3 * j + 1] = p.y; pts[3 * j + 2] = p.z;
+    }
+    double line[6];
+    if (!FormLine(pts, kLineK, 10.0, 0.05, line)) continue;                                    // :506-509
+    Vector3d a, b;
+    for (int k = 0; k < 3; ++k) { a[k] = 0.1 * line[3 + k] + line[k]; b[k] = -0.1 * line[3 + k] + line[k]; }
+    const PointXYZI& q = nei.cornerLessSharp[i];
+    out.push_back({nei.World2Local({(double)q.x, (double)q.y, (double)q.z}), ref.World2Local(a), ref.World2Local(b)});
+  }
+  return out;
+}
+
+std::vector<Point2Line> AssociatePoint2LineSegmentKNN(const Velodyne& ref, const Velodyne& nei, const float dist_threshold, bool) {   // :238-317
+  std::vector<Point2Line> out;
+  if (!WorldOk(ref, nei) || ref.edge_segmented.empty() || nei.edge_segmented.empty()) return out;
+  const float sq_thr = dist_threshold * dist_threshold;
+  std::vector<int32_t> idx; std::vector<float> sqd;
+  CornerKnn(ref, nei, dist_threshold, idx, sqd);
+  for (size_t i = 0; i < nei.cornerLessSharp.size(); ++i) {
+    if (!(sqd[i * kLineK + kLineK - 1] <= sq_thr)) continue;
+    std::map<size_t, size_t> seg_count;
+    for (int j = 0; j < kLineK; ++j) for (int sid : ref.point_to_segment[idx[i * kLineK + j]]) seg_count[(size_t)sid]++;
+    for (const auto& kv : seg_count) {
+      if (kv.second < (size_t)kLineK) continue;                                                // all five neighbours on one segment
+      const Vector6d& l = ref.segment_coeffs[kv.first];                                        // LOCAL coefficients (:273-278)
+      Vector3d a, b;
+      for (int k = 0; k < 3; ++k) { a[k] = 0.1 * l[3 + k] + l[k]; b[k] = -0.1 * l[3 + k] + l[k]; }
+      const PointXYZI& q = nei.cornerLessSharp[i];
+      out.push_back({nei.World2Local({(double)q.x, (double)q.y, (double)q.z}), a, b});
+    }
+  }
+  return out;
+}
+
+std::vector<Point2Line> AssociatePoint2LineSegment(const Velodyne& ref, const Velodyne& nei, const float dist_threshold, bool) {   // :319-383
+  std::vector<Point2Line> out;
+  if (!WorldOk(ref, nei) || ref.edge_segmented.empty() || nei.edge_segmented.empty()) return out;
+  const std::vector<Vector6d> ref_world = TransformLines(ref.segment_coeffs, ref.GetPose());
+  for (const PointXYZI& q : nei.cornerLessSharp) {
+    const double p[3] = {(double)q.x, (double)q.y, (double)q.z};
+    double min_distance = std::numeric_limits<double>::max();
+    int seg = -1;
+    for (int s = 0; s < (int)ref_world.size(); ++s) {
+      const double d = PointToLineDistance3D(p, ref_world[s].data());
+      if (d < min_distance) { min_distance = d; seg = s; }
+    }
+    if (!(min_distance <= dist_threshold)) continue;
+    const Vector6d& l = ref.segment_coeffs[seg];
+    Vector3d a, b;
+    for (int k = 0; k < 3; ++k) { a[k] = 0.1 * l[3 + k] + l[k]; b[k] = -0.1 * l[3 + k] + l[k]; }
+    out.push_back({nei.World2Local({p[0], p[1], p[2]}), a, b});
+  }
+  return out;
+}
+
+std::vector<Line2Line> AssociateLine2LineKNN(const Velodyne& ref, const Velodyne& nei, const float dist_threshold, bool) {   // :385-440
+  std::vector<Line2Line> out;
+  if (!WorldOk(ref, nei) || ref.edge_segmented.empty() || nei.edge_segmented.empty()) return out;
+  const float sq_thr = dist_threshold * dist_threshold;
+  const std::vector<Vector6d> nei_world = TransformLines(nei.segment_coeffs, nei.GetPose());
+  const std::vector<Vector6d> ref_world = TransformLines(ref.segment_coeffs, ref.GetPose());
+  std::vector<int> votes(ref.edge_segmented.size() * nei.edge_segmented.size(), 0);
+  std::vector<int32_t> idx; std::vector<float> sqd;
+  CornerKnn(ref, nei, dist_threshold, idx, sqd);
+  for (size_t i = 0; i < nei.cornerLessSharp.size(); ++i) {
+    if (!(sqd[i * kLineK + kLineK - 1] <= sq_thr)) continue;
+    std::map<size_t, size_t> seg_count;
+    for (int j = 0; j < kLineK; ++j) for (int sid : ref.point_to_segment[idx[i * kLineK + j]]) seg_count[(size_t)sid]++;
+    for (const auto& kv : seg_count) {
+      if (kv.second < (size_t)(kLineK - 2)) continue;                                          // :424
+      for (int ns : nei.point_to_segment[i]) votes[(size_t)ns * ref.edge_segmented.size() + kv.first] += 1;
+    }
+  }
+  return FindAssociations(ref, nei, ref_world, nei_world, votes);
+}
+
 // Every pair of an outer iteration in one GPU launch (pvlm_line2line_votes_batch); result[k] is what
 // AssociateLine2Line(*pairs[k].first, *pairs[k].second, dist_threshold) returns.
 std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<std::pair<const Velodyne*, const Velodyne*>>& pairs,
@@ -1279,6 +1431,32 @@ size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbo
   return (size_t)n;
 }
 
+size_t AddLidarPointToLineResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
+                                   std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
+                                   double thr, bool use_segment, bool angle_residual, bool normalized_distance, double weight) {
+  ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);   // :449-453 (Huber for both variants here)
+  size_t num = 0;
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    double* aa_r = aa_list[lidars[i].id].data(); double* t_r = t_list[lidars[i].id].data();
+    for (int n_idx : neighbors[i]) {
+      if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;
+      if (!lidars[n_idx].IsPoseValid()) continue;
+      if (std::abs(n_idx - (int)i) > 1) continue;                                              // :475
+      double* t_n = t_list[lidars[n_idx].id].data(); double* aa_n = aa_list[lidars[n_idx].id].data();
+      const std::vector<Point2Line> ass = use_segment ? AssociatePoint2LineSegmentKNN(lidars[i], lidars[n_idx], (float)thr)
+                                                      : AssociatePoint2Line(lidars[i], lidars[n_idx], (float)thr);
+      for (const Point2Line& a : ass) {
+        if (angle_residual) problem.AddResidualBlock(Point2Line_Angle::Create(a.point, a.line_point1, a.line_point2, normalized_distance, weight), loss, aa_r, t_r, aa_n, t_n);
+        else problem.AddResidualBlock(Point2Line_Meter::Create(a.point, a.line_point1, a.line_point2, weight), loss, aa_r, t_r, aa_n, t_n);
+        num++;
+      }
+    }
+  }
+  if (num == 0) delete loss;
+  return num;
+}
+
 size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                    std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
                                    const std::vector<LineTrack>& tracks, double thr, bool angle_residual, bool normalized_distance, double weight) {
@@ -1368,7 +1546,9 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
   }
   const std::vector<std::vector<int>> neighbors_all = FindNeighbors(lidars, 6);
   ceres_like::Problem problem;
-  // (point_to_line_residual path: AssociatePoint2Line* variants are not on the Room/Floor path — SURVEY.md §3.2)
+  if (config.point_to_line_residual)                                                           // LidarOdometry.cpp:38-41
+    AddLidarPointToLineResidual(neighbors_all, lidars, aa_list, t_list, problem, config.point_to_line_dis_threshold, use_segment,
+                                config.angle_residual, config.normalize_distance);
   if (config.line_to_line_residual && use_segment) {
     LidarLineMatch matcher(lidars);
     matcher.SetNeighborSize(4);

@@ -137,6 +137,17 @@ std::vector<Point2Plane> AssociatePoint2Plane(const Velodyne& ref_lidar, const V
                                               const float dist_threshold = 0.7f, bool visualization = false);
 std::vector<Line2Line> AssociateLine2Line(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const float dist_threshold = 0.7f,
                                           bool visualization = false);
+// The k-NN based variants (lidar_mapping/LidarFeatureAssociate.cpp:238-440, :478-548; used when
+// config.point_to_line_residual is set — not by the Room/Floor configs).  The 5-NN search in ref.cornerLessSharp runs on
+// the GPU (pvlm_knn), the per-query 5-point PCA / segment counting on the host.
+std::vector<Point2Line> AssociatePoint2Line(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const float dist_threshold = 0.7f,
+                                            bool visualization = false);
+std::vector<Point2Line> AssociatePoint2LineSegmentKNN(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const float dist_threshold = 0.7f,
+                                                      bool visualization = false);
+std::vector<Point2Line> AssociatePoint2LineSegment(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const float dist_threshold = 0.7f,
+                                                   bool visualization = false);
+std::vector<Line2Line> AssociateLine2LineKNN(const Velodyne& ref_lidar, const Velodyne& nei_lidar, const float dist_threshold = 0.7f,
+                                             bool visualization = false);
 // Extension (not in PanoVLM): the AssociateLine2Line calls of a whole outer iteration in one GPU launch;
 // result[k] equals AssociateLine2Line(*pairs[k].first, *pairs[k].second, dist_threshold).
 std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<std::pair<const Velodyne*, const Velodyne*>>& pairs,
@@ -255,6 +266,11 @@ size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbo
                                     std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
                                     ceres_like::Problem& problem, double point_to_plane_dis_threshold, double plane_tolerance,
                                     bool angle_residual, bool normalized_distance, double weight = 1.0);
+// util/Optimization.cpp:443-504 — only pairs of consecutive scans (|n_idx - i| <= 1) get point-to-line blocks
+size_t AddLidarPointToLineResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
+                                   std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list, ceres_like::Problem& problem,
+                                   double point_to_line_dis_threshold, bool use_segment, bool angle_residual, bool normalized_distance,
+                                   double weight = 1.0);
 size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                    std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
                                    ceres_like::Problem& problem, const std::vector<LineTrack>& lidar_line_tracks,

@@ -128,6 +128,18 @@ int main(int argc, char** argv) {
       auto l = LoadScans(argv[2]);
       auto a = AssociateLine2Line(l[atoi(argv[3])], l[atoi(argv[4])], (float)atof(argv[5]));
       for (auto& x : a) printf("l %d %d %.17g %.17g %.17g %.17g %.17g %.17g\n", x.neighbor_line_idx, x.ref_line_idx, x.line_point1[0], x.line_point1[1], x.line_point1[2], x.line_point2[0], x.line_point2[1], x.line_point2[2]);
+    } else if (cmd == "p2line") {
+      // p2line <scans.bin> ref nei mode thr : mode 0 AssociatePoint2Line, 1 ...SegmentKNN, 2 ...Segment
+      auto l = LoadScans(argv[2]);
+      const Velodyne& r = l[atoi(argv[3])]; const Velodyne& n = l[atoi(argv[4])];
+      const int mode = atoi(argv[5]); const float thr = (float)atof(argv[6]);
+      const std::vector<Point2Line> a = mode == 0 ? AssociatePoint2Line(r, n, thr) : (mode == 1 ? AssociatePoint2LineSegmentKNN(r, n, thr) : AssociatePoint2LineSegment(r, n, thr));
+      for (auto& x : a) printf("a %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", x.point[0], x.point[1], x.point[2], x.line_point1[0], x.line_point1[1],
+                               x.line_point1[2], x.line_point2[0], x.line_point2[1], x.line_point2[2]);
+    } else if (cmd == "line2lineknn") {
+      auto l = LoadScans(argv[2]);
+      auto a = AssociateLine2LineKNN(l[atoi(argv[3])], l[atoi(argv[4])], (float)atof(argv[5]));
+      for (auto& x : a) printf("l %d %d %.17g %.17g %.17g %.17g %.17g %.17g\n", x.neighbor_line_idx, x.ref_line_idx, x.line_point1[0], x.line_point1[1], x.line_point1[2], x.line_point2[0], x.line_point2[1], x.line_point2[2]);
     } else if (cmd == "tracks") {
       auto l = LoadScans(argv[2]);
       LidarLineMatch m(l);

@@ -409,3 +409,31 @@ def test_joint_optimize_with_sfm_term_matches_cpu_twin(oracle, tmp):
     moved = np.abs(structure["X"] - np.array([tr["point"] for tr in tracks])).max()
     assert pts.shape == structure["X"].shape and np.abs(pts - structure["X"]).max() <= (1e-6 if same else 1e-2) * max(1.0, moved)
     assert moved > 1e-4      # the structure was refined
+
+
+def test_knn_based_line_association_variants(oracle, tmp):
+    """AssociatePoint2Line / ...SegmentKNN / ...Segment / AssociateLine2LineKNN (LidarFeatureAssociate.cpp:238-440,
+    :478-548): 5-NN in the ref corner cloud on the GPU (pvlm_knn), PCA / segment counting on the host."""
+    rng = np.random.default_rng(19)
+    scans = _line_scans(rng, 3)
+    path = os.path.join(tmp, "p2l.bin")
+    host_io.write_scans(path, scans)
+    for mode, name in ((0, "knn"), (1, "segment_knn"), (2, "segment")):
+        for r, n, thr in [(0, 1, 0.5), (1, 2, 0.3)]:
+            got = np.array([[float(v) for v in l.split()[1:]] for l in host_io.run("p2line", path, r, n, mode, thr)]).reshape(-1, 9)
+            o = oracle.assoc_point2line(scans[r]["_oracle"], scans[n]["_oracle"], thr, mode=name)
+            assert len(got) == len(o["point"]) > 10, (name, len(got), len(o["point"]))
+            assert np.allclose(got[:, :3], o["point"], rtol=0, atol=1e-12)
+            # the fitted direction's sign is the eigen solver's choice: (a, b) may come swapped
+            same = np.abs(got[:, 3:6] - o["a"]).max(axis=1) <= 1e-9
+            swapped = np.abs(got[:, 3:6] - o["b"]).max(axis=1) <= 1e-9
+            assert np.all(same | swapped)
+            assert np.all(np.where(same[:, None], np.abs(got[:, 6:9] - o["b"]), np.abs(got[:, 6:9] - o["a"])) <= 1e-9)
+            if mode:
+                assert same.all()          # segment coefficients are taken as they are
+    for r, n, thr in [(0, 1, 0.5), (2, 1, 0.4)]:
+        got = [l.split()[1:] for l in host_io.run("line2lineknn", path, r, n, thr)]
+        o = oracle.assoc_line2line(scans[r]["_oracle"], scans[n]["_oracle"], thr, knn=True)
+        assert [int(g[0]) for g in got] == o["nei_idx"].tolist() and [int(g[1]) for g in got] == o["ref_idx"].tolist()
+        assert np.allclose(np.array([[float(v) for v in g[2:5]] for g in got]).reshape(-1, 3), o["p1"], atol=1e-13)
+        assert len(got) >= 4
