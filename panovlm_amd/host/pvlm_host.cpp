@@ -925,6 +925,29 @@ void Problem::AddResidualBlock(CostFunction* cost, LossFunction* loss, double* a
   I.num_blocks++;
 }
 
+void Problem::AddResidualRows(int kind, unsigned flags, double weight, LossFunction* loss, double* aa_r, double* t_r, double* aa_n, double* t_n,
+                              const double* rows, size_t n) {
+  if (n == 0) return;
+  Impl& I = *impl_;
+  const int pr = I.Pose(aa_r, t_r), pn = I.Pose(aa_n, t_n);
+  if (loss) I.owned_losses.insert(loss);
+  int gi = -1;
+  for (int k = (int)I.groups.size() - 1; k >= 0; --k) {
+    const Impl::Group& c = I.groups[k];
+    if (!c.external && !c.set && c.kind == kind && c.flags == flags && c.weight == weight && c.loss == loss) { gi = k; break; }
+  }
+  if (gi < 0) {
+    Impl::Group g; g.kind = kind; g.flags = flags; g.weight = weight; g.loss = loss; g.off.push_back(0);
+    I.groups.push_back(g);
+    gi = (int)I.groups.size() - 1;
+  }
+  Impl::Group& g = I.groups[gi];
+  if (g.ref.empty() || g.ref.back() != pr || g.nei.back() != pn) { g.ref.push_back(pr); g.nei.push_back(pn); g.off.push_back(g.off.back()); }
+  g.rows.insert(g.rows.end(), rows, rows + n * (size_t)kStride[kind]);
+  g.off.back() += (int64_t)n;
+  I.num_blocks += (int)n;
+}
+
 void Problem::AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_c, double* t_c, double* point_3d) {
   Impl& I = *impl_;
   if (cost->kind != kReprojKind) throw std::runtime_error("three-block AddResidualBlock expects PanoramaReprojResidual_1Angle");
@@ -1101,6 +1124,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
 
   // evaluates cost (+ H, g when want_H) of the four-block groups at parameter vector v
   auto evaluate = [&](const std::vector<double>& v, bool want_H, Assembled& A) {
+    StageTimer stage_timer_eval_("solve: GPU linearisation + block assembly");
     A.cost = 0; A.g.assign(n_free, 0.0); A.H.clear();
     for (auto& g : I.groups) {
       std::vector<double> aa((size_t)g.dev_poses * 3, 0.0), tt((size_t)g.dev_poses * 3, 0.0);
@@ -1294,7 +1318,8 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       const double hs = dfull[i] * scale[i] * scale[i];
       S.at(i, i) += std::min(std::max(hs, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
     }
-    bool step_ok = n_free == 0 || S.Factor();
+    bool step_ok;
+    { StageTimer stage_timer_chol_("solve: host skyline Cholesky"); step_ok = n_free == 0 || S.Factor(); }
     std::vector<double> dy = rhs;
     double model_change = 0.0, dn = 0.0, xn = 0.0;
     if (step_ok) {
@@ -1478,6 +1503,7 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   }
   const std::vector<std::vector<Line2Line>> all_ass = AssociateLine2LineBatch(todo, (float)thr);
   size_t next = 0;
+  std::vector<double> row_buf;
   for (size_t i = 0; i < lidars.size(); i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
     double* aa_r = aa_list[lidars[i].id].data(); double* t_r = t_list[lidars[i].id].data();
@@ -1492,17 +1518,24 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
         bool valid = false;
         for (uint32_t tid : it->second) if (tracks[tid].IsInside({(uint32_t)n_idx, (uint32_t)a.neighbor_line_idx})) { valid = true; break; }
         if (!valid) continue;
-        for (const PointXYZI& p : lidars[n_idx].edge_segmented[a.neighbor_line_idx]) {
-          const Vector3d lp = lidars[n_idx].World2Local({(double)p.x, (double)p.y, (double)p.z});
-          if (angle_residual) {
-            // loss is nullptr for the angle variant (util/Optimization.cpp:417)
-            problem.AddResidualBlock(Point2Line_Angle::Create(lp, a.line_point1, a.line_point2, normalized_distance, weight), nullptr, aa_r, t_r, aa_n, t_n);
-          } else {
-            problem.AddResidualBlock(Point2Line_Meter::Create(lp, a.line_point1, a.line_point2, weight), loss, aa_r, t_r, aa_n, t_n);
-            loss_used = true;
-          }
-          num++;
+        // one block per point of the matched nei segment (:410-434) — added in bulk: same rows, same order as the
+        // X::Create + AddResidualBlock calls, without a heap object per block
+        const PointCloud& seg = lidars[n_idx].edge_segmented[a.neighbor_line_idx];
+        row_buf.resize(seg.size() * 9);
+        for (size_t k = 0; k < seg.size(); ++k) {
+          const Vector3d lp = lidars[n_idx].World2Local({(double)seg[k].x, (double)seg[k].y, (double)seg[k].z});
+          double* r = &row_buf[9 * k];
+          r[0] = lp[0]; r[1] = lp[1]; r[2] = lp[2];
+          for (int c = 0; c < 3; ++c) { r[3 + c] = a.line_point1[c]; r[6 + c] = a.line_point2[c]; }
         }
+        if (angle_residual)   // loss is nullptr for the angle variant (util/Optimization.cpp:417)
+          problem.AddResidualRows(PVLM_POINT2LINE_ANGLE, normalized_distance ? PVLM_FLAG_NORMALIZE_DISTANCE : 0u, weight, nullptr, aa_r, t_r, aa_n, t_n,
+                                  row_buf.data(), seg.size());
+        else {
+          problem.AddResidualRows(PVLM_POINT2LINE_METER, 0u, weight, loss, aa_r, t_r, aa_n, t_n, row_buf.data(), seg.size());
+          loss_used = loss_used || !seg.empty();
+        }
+        num += seg.size();
       }
     }
   }

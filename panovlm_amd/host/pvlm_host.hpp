@@ -207,6 +207,10 @@ class Problem {
   ~Problem();
   // Takes ownership of cost (and of loss, shared by many blocks like in Ceres).
   void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_r, double* t_r, double* aa_n, double* t_n);
+  // Bulk form (extension): n blocks of one functor on the same four parameter blocks, rows = n x stride in the ABI row
+  // layout of include/pvlm.h — what n X::Create + AddResidualBlock calls would add, without n heap objects.
+  void AddResidualRows(int kind, unsigned flags, double weight, LossFunction* loss, double* aa_r, double* t_r, double* aa_n, double* t_n,
+                       const double* rows, size_t n);
   // Three-block form of AddCameraResidual (util/Optimization.cpp:198-201): camera pose + a free 3-D point.
   // The point blocks live on the GPU during Solve and are eliminated there (Schur complement).
   void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_c, double* t_c, double* point_3d);
