@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -188,6 +188,23 @@ class Context:
     def image_to_cam_f32_dev(self, rows, cols, n, d_px_ptr, r, d_cam_ptr):
         self._check(self.lib.pvlm_image_to_cam_f32_dev(self._h, C.c_int(rows), C.c_int(cols), C.c_int64(n), C.c_void_p(d_px_ptr), C.c_float(r),
                                                        C.c_void_p(d_cam_ptr)), "pvlm_image_to_cam_f32_dev")
+
+    def spd_solve(self, A, B):
+        """Dense SPD solve on the GPU (rocSOLVER): returns (X, info)."""
+        A = _f64(A); n = A.shape[0]
+        B2 = np.asfortranarray(np.asarray(B, np.float64).reshape(n, -1))
+        info = C.c_int()
+        self._check(self.lib.pvlm_spd_solve(self._h, C.c_int(n), C.c_int(B2.shape[1]), _p(A, C.c_double),
+                                            B2.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info)), "pvlm_spd_solve")
+        return np.ascontiguousarray(B2).reshape(np.shape(B)), info.value
+
+    def spd_solve_blocks(self, n, row_idx, col_idx, mirror, blocks, scale, diag_add, rhs):
+        row_idx = _i32(row_idx).reshape(-1, 6); col_idx = _i32(col_idx).reshape(-1, 6); blocks = _f64(blocks).reshape(-1, 36); mirror = _i32(mirror)
+        x = _f64(rhs).copy(); info = C.c_int()
+        self._check(self.lib.pvlm_spd_solve_blocks(self._h, C.c_int(n), C.c_int(len(blocks)), _p(row_idx, C.c_int), _p(col_idx, C.c_int), _p(mirror, C.c_int),
+                                                   _p(blocks, C.c_double), _p(_f64(scale), C.c_double), _p(_f64(diag_add), C.c_double),
+                                                   _p(x, C.c_double), C.byref(info)), "pvlm_spd_solve_blocks")
+        return x, info.value
 
     def project_lidar_depth(self, rows, cols, xyz, T_cl, size=3):
         xyz = _f32(xyz).reshape(-1, 3); T = _f64(T_cl).reshape(16)

@@ -1302,35 +1302,80 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
         else if (i >= j) S.at(i, j) += v; else S.at(j, i) += v;
       }
   };
+  // Large reduced systems (Room / Floor sized joint problems: thousands of unknowns) are assembled, factorised and solved
+  // on the GPU (pvlm_spd_solve_blocks: rocSOLVER potrf); small ones by the host skyline Cholesky.
+  const char* gpu_min_env = std::getenv("PVLM_GPU_CHOLESKY_MIN");
+  const bool gpu_chol = n_free >= (gpu_min_env ? std::atoi(gpu_min_env) : 1500);
+  // v^T (D H D) v over a block list, without forming the matrix
+  auto quad_form = [&](const std::map<std::pair<int, int>, std::array<double, 36>>& H, const std::vector<double>& v) {
+    double q = 0.0;
+    for (auto& kv : H) {
+      double b = 0.0;
+      for (int r = 0; r < 6; ++r) {
+        const int i = idx(kv.first.first, r);
+        if (i < 0) continue;
+        double row = 0.0;
+        for (int c = 0; c < 6; ++c) { const int j = idx(kv.first.second, c); if (j >= 0) row += kv.second[r * 6 + c] * scale[j] * v[j]; }
+        b += scale[i] * v[i] * row;
+      }
+      q += kv.first.first == kv.first.second ? b : 2.0 * b;
+    }
+    return q;
+  };
   while (iter < opt.max_num_iterations) {
     ++iter;
     if (!R_valid) { bundle_reduce(x, radius, false, R); R_valid = true; }
     // scaled system  (D (H + S_points) D + diag(clamp(diag(D J^T J D))) / radius) dy = -D g
-    Skyline S0;                      // four-block groups only: the Gauss-Newton model of those blocks
-    S0.Init(build_first(A, R));
-    fill(S0, A.H);
-    Skyline S = S0;
-    if (have_bundles) fill(S, R.H);
     const std::vector<double> dfull = full_diag(A, R);
-    std::vector<double> rhs(n_free);
+    std::vector<double> rhs(n_free), damp(n_free);
     for (int i = 0; i < n_free; ++i) {
       rhs[i] = -(A.g[i] + R.g_red[i]) * scale[i];
       const double hs = dfull[i] * scale[i] * scale[i];
-      S.at(i, i) += std::min(std::max(hs, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
+      damp[i] = std::min(std::max(hs, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
     }
     bool step_ok;
-    { StageTimer stage_timer_chol_("solve: host skyline Cholesky"); step_ok = n_free == 0 || S.Factor(); }
     std::vector<double> dy = rhs;
     double model_change = 0.0, dn = 0.0, xn = 0.0;
+    Skyline S0;                      // four-block groups only: the Gauss-Newton model of those blocks
+    if (gpu_chol) {
+      StageTimer stage_timer_chol_("solve: GPU Cholesky (rocSOLVER)");
+      std::vector<int> rows, cols, mirror; std::vector<double> blocks;
+      auto push = [&](const std::map<std::pair<int, int>, std::array<double, 36>>& H) {
+        for (auto& kv : H) {
+          for (int r = 0; r < 6; ++r) { rows.push_back(idx(kv.first.first, r)); cols.push_back(idx(kv.first.second, r)); }
+          mirror.push_back(kv.first.first != kv.first.second ? 1 : 0);
+          blocks.insert(blocks.end(), kv.second.begin(), kv.second.end());
+        }
+      };
+      push(A.H);
+      if (have_bundles) push(R.H);
+      int info = 0;
+      e.Check(pvlm_spd_solve_blocks(e.ctx(), n_free, (int)mirror.size(), rows.data(), cols.data(), mirror.data(), blocks.data(), scale.data(), damp.data(),
+                                    dy.data(), &info), "pvlm_spd_solve_blocks");
+      step_ok = info == 0;
+    } else {
+      S0.Init(build_first(A, R));
+      fill(S0, A.H);
+      Skyline S = S0;
+      if (have_bundles) fill(S, R.H);
+      for (int i = 0; i < n_free; ++i) S.at(i, i) += damp[i];
+      { StageTimer stage_timer_chol_("solve: host skyline Cholesky"); step_ok = n_free == 0 || S.Factor(); }
+      if (step_ok && n_free) S.Solve(dy);
+    }
     if (step_ok) {
-      if (n_free) S.Solve(dy);
       // model_cost_change = -(g'.dy + 1/2 dy^T H' dy) over the four-block groups ...
       double gd = 0.0, dHd = 0.0;
       for (int i = 0; i < n_free; ++i) gd += (A.g[i] * scale[i]) * dy[i];
-      for (int i = 0; i < n_free; ++i) {
-        double s = 0.0;
-        for (int k = S0.first[i]; k < i; ++k) s += S0.at(i, k) * dy[k];
-        dHd += dy[i] * (2.0 * s + S0.at(i, i) * dy[i]);
+      if (gpu_chol) {
+        std::vector<double> unit(n_free);
+        for (int i = 0; i < n_free; ++i) unit[i] = dy[i];
+        dHd = quad_form(A.H, unit);
+      } else {
+        for (int i = 0; i < n_free; ++i) {
+          double s = 0.0;
+          for (int k = S0.first[i]; k < i; ++k) s += S0.at(i, k) * dy[k];
+          dHd += dy[i] * (2.0 * s + S0.at(i, i) * dy[i]);
+        }
       }
       model_change = -(gd + 0.5 * dHd);
       // ... plus the reprojection blocks' own model decrease after back-substituting their points

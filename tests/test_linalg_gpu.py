@@ -1,0 +1,93 @@
+"""GPU dense / block-sparse SPD solve of the LM driver (pvlm_spd_solve*, rocSOLVER potrf/potrs dlopen-ed by libpvlm.so)
+against numpy, and the host mirror's Solve with the GPU factorisation forced on against the CPU twin."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import host_io, lm_twin, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import panovlm_amd as pv
+    c = pv.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [7, 300, 1800])
+def test_dense_spd_solve(ctx, n):
+    rng = np.random.default_rng(n)
+    Q = rng.normal(size=(n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    B = rng.normal(size=(n, 3))
+    X, info = ctx.spd_solve(A, B)
+    assert info == 0
+    assert np.allclose(A @ X, B, rtol=0, atol=1e-9 * np.abs(B).max() * n)
+    assert np.allclose(X, np.linalg.solve(A, B), rtol=1e-9, atol=1e-12)
+    x1, info = ctx.spd_solve(A, B[:, 0])
+    assert info == 0 and np.allclose(x1, X[:, 0], rtol=1e-12, atol=1e-15)
+    # not positive definite: reported, not an error
+    A2 = A.copy(); A2[n // 2, n // 2] = -1.0
+    _, info = ctx.spd_solve(A2, B)
+    assert info == n // 2 + 1
+
+
+def test_block_sparse_assembly_and_solve(ctx):
+    """M = D (sum of 6x6 blocks) D + diag: pose-pair blocks mirrored, constant blocks (-1) dropped, repeated blocks summed."""
+    rng = np.random.default_rng(5)
+    P = 40                                   # poses; pose 0 fully constant, pose 1 has a constant rotation block
+    off = np.full((P, 6), -1, np.int64); n = 0
+    for p in range(P):
+        for half in range(2):
+            if p == 0 or (p == 1 and half == 0):
+                continue
+            off[p, 3 * half:3 * half + 3] = np.arange(n, n + 3); n += 3
+    rows, cols, mirror, blocks = [], [], [], []
+    H = np.zeros((n, n))
+    pairs = [(p, p) for p in range(P)] + [(p, q) for p in range(P) for q in range(p + 1, min(p + 4, P))] + [(2, 3), (5, 5)]   # two repeated
+    for (a, b) in pairs:
+        if a == b:
+            J = rng.normal(size=(9, 6)); blk = J.T @ J
+        else:
+            blk = rng.normal(size=(6, 6)) * 0.2
+        rows.append(off[a]); cols.append(off[b]); mirror.append(int(a != b)); blocks.append(blk.reshape(-1))
+        for r in range(6):
+            for c in range(6):
+                i, j = off[a, r], off[b, c]
+                if i < 0 or j < 0:
+                    continue
+                H[i, j] += blk[r, c]
+                if a != b:
+                    H[j, i] += blk[r, c]
+    scale = 1.0 / (1.0 + np.sqrt(np.maximum(np.diag(H), 0)))
+    diag = rng.uniform(0.5, 1.0, size=n) + 10.0
+    rhs = rng.normal(size=n)
+    M = H * scale[:, None] * scale[None, :] + np.diag(diag)
+    x, info = ctx.spd_solve_blocks(n, np.array(rows), np.array(cols), np.array(mirror), np.array(blocks), scale, diag, rhs)
+    assert info == 0
+    assert np.allclose(x, np.linalg.solve(M, rhs), rtol=1e-9, atol=1e-12)
+
+
+def test_solve_with_gpu_cholesky_matches_twin(oracle, tmp_path, monkeypatch):
+    """The bundle-adjustment solve (reprojection sets + Schur complement) with the reduced camera system factorised on
+    the GPU instead of the host skyline: same poses / points / step counts as the twin."""
+    from tests.test_host_gpu import _bundle_scene
+    monkeypatch.setenv("PVLM_GPU_CHOLESKY_MIN", "1")
+    rng = np.random.default_rng(91)
+    frames, tracks, _ = _bundle_scene(rng)
+    fpath, spath = os.path.join(str(tmp_path), "bf.bin"), os.path.join(str(tmp_path), "bs.bin")
+    host_io.write_frames(fpath, np.eye(4), frames)
+    host_io.write_structure(spath, frames, tracks)
+    out = host_io.run("bundle", fpath, spath, 1.5, 1, 12)
+    summ = [l.split() for l in out if l.startswith("summary")][0]
+    cams = np.array([[float(v) for v in l.split()[2:]] for l in out if l.startswith("cam ")])
+    pts = np.array([[float(v) for v in l.split()[2:]] for l in out if l.startswith("point ")])
+    res, aa, t, X = lm_twin.bundle_adjust(oracle, [dict(f) for f in frames], tracks, 1.5, True, 12)
+    assert abs(float(summ[6]) - res["final_cost"]) <= 1e-6 * res["final_cost"]
+    assert int(summ[8]) == res["successful"] and int(summ[10]) == res["unsuccessful"]
+    assert np.abs(cams[:, :3] - aa).max() <= 1e-6 and np.abs(cams[:, 3:] - t).max() <= 1e-6
+    assert np.abs(pts - X).max() <= 1e-6 * max(1.0, np.abs(X).max())
