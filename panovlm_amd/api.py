@@ -190,7 +190,8 @@ class Context:
                                                        C.c_void_p(d_cam_ptr)), "pvlm_image_to_cam_f32_dev")
 
     def spd_solve(self, A, B):
-        """Dense SPD solve on the GPU (rocSOLVER): returns (X, info)."""
+        """Dense SPD solve on the GPU (rocSOLVER): returns (X, info).  Note: in a process that imported torch the
+        rocBLAS that gets loaded is the wheel's bundled copy, whose first handle creation can take minutes on a fresh box."""
         A = _f64(A); n = A.shape[0]
         B2 = np.asfortranarray(np.asarray(B, np.float64).reshape(n, -1))
         info = C.c_int()

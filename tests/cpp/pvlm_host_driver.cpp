@@ -254,6 +254,32 @@ int main(int argc, char** argv) {
         printf("single %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", r, j0[0], j0[1], j0[2], j1[0], j1[1], j1[2], j2[0], j2[1], j2[2]);
         delete c;
       }
+    } else if (cmd == "spd") {
+      // spd <file> : [int32 n, nrhs | A n*n f64 | B n*nrhs f64 col-major] -> pvlm_spd_solve; prints info + X (hex doubles)
+      std::ifstream f(argv[2], std::ios::binary);
+      int32_t h[2]; rd(f, h, 2);
+      std::vector<double> A((size_t)h[0] * h[0]), B((size_t)h[0] * h[1]);
+      rd(f, A.data(), A.size()); rd(f, B.data(), B.size());
+      int info = -1;
+      Engine& e = Engine::Default();
+      e.Check(pvlm_spd_solve(e.ctx(), h[0], h[1], A.data(), B.data(), &info), "pvlm_spd_solve");
+      printf("info %d\n", info);
+      if (info == 0) for (double v : B) printf("x %a\n", v);
+    } else if (cmd == "spdblocks") {
+      // spdblocks <file> : [int32 n, nb | rows nb*6 i32 | cols nb*6 i32 | mirror nb i32 | blocks nb*36 f64 | scale n | diag n | rhs n]
+      std::ifstream f(argv[2], std::ios::binary);
+      int32_t h[2]; rd(f, h, 2);
+      const size_t n = h[0], nb = h[1];
+      std::vector<int32_t> rows(nb * 6), cols(nb * 6), mirror(nb);
+      std::vector<double> blocks(nb * 36), scale(n), diag(n), rhs(n);
+      rd(f, rows.data(), rows.size()); rd(f, cols.data(), cols.size()); rd(f, mirror.data(), mirror.size());
+      rd(f, blocks.data(), blocks.size()); rd(f, scale.data(), n); rd(f, diag.data(), n); rd(f, rhs.data(), n);
+      int info = -1;
+      Engine& e = Engine::Default();
+      e.Check(pvlm_spd_solve_blocks(e.ctx(), (int)n, (int)nb, rows.data(), cols.data(), mirror.data(), blocks.data(), scale.data(), diag.data(), rhs.data(), &info),
+              "pvlm_spd_solve_blocks");
+      printf("info %d\n", info);
+      if (info == 0) for (double v : rhs) printf("x %a\n", v);
     } else if (cmd == "loadpcd") {
       // loadpcd <file.pcd> : Velodyne::LoadLidar — prints the count, valid flag and every point (hex floats)
       Velodyne v; v.id = 7;
