@@ -175,11 +175,13 @@ pvlm_status pvlm_ba_step(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double 
 pvlm_status pvlm_ba_cost(pvlm_ctx* ctx, const pvlm_baset* set, pvlm_loss loss, double loss_a, int candidate, double* cost);
 pvlm_status pvlm_ba_accept(pvlm_ctx* ctx, pvlm_baset* set);
 
-/* ---- dense SPD solve for an LM driver (not hot path; rocSOLVER potrf/potrs, dlopen-ed at first use) --------- *
- * Solves A X = B for a symmetric positive definite n x n matrix (dense, host, full symmetric storage) and B = n x nrhs
- * (column-major, host, overwritten by X).  *info = 0 on success, k > 0 when the leading minor of order k is not
- * positive definite.  Upstream this step is inside ceres::Solve (SPARSE_SCHUR, util/Optimization.cpp:608-666); the
- * host mirror's stand-in LM driver uses it once the reduced pose system is too large for a host factorisation. */
+/* ---- dense SPD solve for an LM driver (not hot path) ------------------------------------------------------------ *
+ * Blocked fp64 Cholesky + triangular solves on the GPU (hand-written: 32-wide block columns, 64 x 64 register-tiled
+ * trailing updates).  Solves A X = B for a symmetric positive definite n x n matrix (dense, host, full symmetric storage)
+ * and B = n x nrhs (column-major, host, overwritten by X).  *info = 0 on success, k > 0 when the leading minor of order k
+ * is not positive definite (X is then undefined).  Upstream this step is inside ceres::Solve (SPARSE_SCHUR,
+ * util/Optimization.cpp:608-666); the host mirror's stand-in LM driver uses it once the reduced pose system is too large
+ * for a host factorisation (a Room-sized joint problem has 5442 unknowns). */
 pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, double* B, int* info);
 /* Block-sparse input: M = D (sum of the 6x6 blocks) D + diag(diag_add), D = diag(scale), assembled on the device, then
  * M x = rhs solved in place (rhs host, n doubles).  blocks: n_blocks x 36 row-major; row_idx / col_idx: n_blocks x 6

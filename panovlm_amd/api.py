@@ -190,8 +190,7 @@ class Context:
                                                        C.c_void_p(d_cam_ptr)), "pvlm_image_to_cam_f32_dev")
 
     def spd_solve(self, A, B):
-        """Dense SPD solve on the GPU (rocSOLVER): returns (X, info).  Note: in a process that imported torch the
-        rocBLAS that gets loaded is the wheel's bundled copy, whose first handle creation can take minutes on a fresh box."""
+        """Dense SPD solve on the GPU (blocked Cholesky kernels of libpvlm.so): returns (X, info)."""
         A = _f64(A); n = A.shape[0]
         B2 = np.asfortranarray(np.asarray(B, np.float64).reshape(n, -1))
         info = C.c_int()

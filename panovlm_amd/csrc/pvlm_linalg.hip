@@ -1,43 +1,189 @@
 // Dense symmetric positive definite solve on the GPU for the LM driver of the host mirror (the reduced pose system of a
 // Room/Floor-sized joint optimisation has 5e3..1e4 unknowns: a host Cholesky of it costs seconds per LM iteration and
-// dwarfs everything the hot path does).  This is NOT part of the hot path and not a hand-written kernel: it is the one
-// place where a vendor library is the right tool — rocSOLVER's potrf/potrs, dlopen-ed at first use like RCCL so that
-// libpvlm.so has no link-time dependency on it and hosts that never solve on the GPU never load it.
-// Upstream this step belongs to Ceres (SPARSE_SCHUR + SuiteSparse, util/Optimization.cpp:608-666).
-#include <dlfcn.h>
+// dwarfs everything the hot path does — measured 158 s of a 164 s JointOptimize at 454 frames).  Not part of the hot
+// path (upstream this step is inside ceres::Solve: SPARSE_SCHUR + SuiteSparse, util/Optimization.cpp:608-666), but it
+// has to exist for the mirrored call surface to be usable at Room scale.  Hand-written blocked Cholesky: rocSOLVER's
+// potrf was tried first and works, but the first rocblas_create_handle of a process pages the whole rocBLAS kernel
+// library in (measured 140..510 s on a cold box) — unacceptable inside a library call.
+#include <algorithm>
 
 #include "pvlm_internal.h"
 
-namespace {
-typedef void* rb_handle;
-typedef int (*fn_create)(rb_handle*);
-typedef int (*fn_destroy)(rb_handle);
-typedef int (*fn_set_stream)(rb_handle, hipStream_t);
-typedef int (*fn_potrf)(rb_handle, int, int, double*, int, int*);
-typedef int (*fn_potrs)(rb_handle, int, int, int, double*, int, double*, int);
-const int kFillLower = 122;   // rocblas_fill_lower (rocblas-types.h)
+// ---- blocked right-looking Cholesky, fp64, lower triangle of a row-major dense matrix ------------------------------
+// Step k (block column of NB = 32): (1) one workgroup factorises the diagonal block in LDS, (2) one thread per row below
+// solves its 32 panel entries against it, (3) the trailing lower triangle gets its rank-32 update in 64 x 64 tiles
+// (256 threads x 4 x 4 register tiles, both panel slices staged in LDS).  *info != 0 (set by a non-positive pivot, 1-based
+// like LAPACK) makes every later kernel of the sequence return at once.
+#define PVLM_CHOL_NB 32
 
-struct Solver {
-  void *hb = nullptr, *hs = nullptr;
-  fn_create create = nullptr; fn_destroy destroy = nullptr; fn_set_stream set_stream = nullptr; fn_potrf potrf = nullptr; fn_potrs potrs = nullptr;
-  rb_handle handle = nullptr;
-  bool Load(pvlm_ctx* ctx) {
-    if (handle) return true;
-    const char* blas[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
-    const char* solv[] = {"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so"};
-    for (const char* n : blas) { hb = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (hb) break; }
-    for (const char* n : solv) { hs = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (hs) break; }
-    if (!hb || !hs) { PVLM_SET_ERR(ctx, "rocBLAS / rocSOLVER not found: %s", dlerror()); return false; }
-    create = (fn_create)dlsym(hb, "rocblas_create_handle"); destroy = (fn_destroy)dlsym(hb, "rocblas_destroy_handle");
-    set_stream = (fn_set_stream)dlsym(hb, "rocblas_set_stream");
-    potrf = (fn_potrf)dlsym(hs, "rocsolver_dpotrf"); potrs = (fn_potrs)dlsym(hs, "rocsolver_dpotrs");
-    if (!create || !destroy || !set_stream || !potrf || !potrs) { PVLM_SET_ERR(ctx, "rocBLAS / rocSOLVER symbols missing"); return false; }
-    if (create(&handle) != 0 || !handle) { PVLM_SET_ERR(ctx, "rocblas_create_handle failed"); handle = nullptr; return false; }
-    return true;
+__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ M, int n, int k0, int kb, int* __restrict__ info) {
+  __shared__ double a[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ int fail;
+  if (*info != 0) return;
+  const int t = threadIdx.x;
+  if (t == 0) fail = 0;
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
+    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
+    a[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : 0.0;
   }
-};
-Solver g_solver;
-}  // namespace
+  __syncthreads();
+  for (int j = 0; j < kb; ++j) {
+    if (t == 0) { const double d = a[j][j]; if (!(d > 0.0)) fail = j + 1; else a[j][j] = sqrt(d); }
+    __syncthreads();
+    if (fail) break;
+    const double piv = a[j][j];
+    if (t > j && t < kb) a[t][j] /= piv;
+    __syncthreads();
+    for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
+      const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
+      if (c > j && c <= i && i < kb) a[i][c] -= a[i][j] * a[c][j];
+    }
+    __syncthreads();
+  }
+  if (fail) { if (t == 0) *info = k0 + fail; return; }
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
+    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
+    if (i < kb && j <= i) M[(size_t)(k0 + i) * n + k0 + j] = a[i][j];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, int n, int k0, int kb, const int* __restrict__ info) {
+  __shared__ double L[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  if (*info != 0) return;
+  for (int e = threadIdx.x; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
+    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
+    L[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int row = k0 + kb + blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  double x[PVLM_CHOL_NB];
+  double* r = M + (size_t)row * n + k0;
+#pragma unroll
+  for (int c = 0; c < PVLM_CHOL_NB; ++c) x[c] = c < kb ? r[c] : 0.0;
+#pragma unroll
+  for (int c = 0; c < PVLM_CHOL_NB; ++c) {
+    double s = x[c];
+#pragma unroll
+    for (int d = 0; d < c; ++d) s -= x[d] * L[c][d];
+    x[c] = s / L[c][c];
+  }
+#pragma unroll
+  for (int c = 0; c < PVLM_CHOL_NB; ++c) if (c < kb) r[c] = x[c];
+}
+
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info) {
+  __shared__ double As[64][PVLM_CHOL_NB + 1];
+  __shared__ double Bs[64][PVLM_CHOL_NB + 1];
+  if (*info != 0) return;
+  // linear block id -> (ti >= tj) of the lower triangle of the tile grid
+  int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long long)(ti + 1) * (ti + 2) / 2 <= (long long)blockIdx.x) ++ti;
+  while ((long long)ti * (ti + 1) / 2 > (long long)blockIdx.x) --ti;
+  const int tj = blockIdx.x - ti * (ti + 1) / 2;
+  if (ti >= tiles) return;
+  const int base = k0 + kb, r0 = base + ti * 64, c0 = base + tj * 64;
+  for (int e = threadIdx.x; e < 64 * PVLM_CHOL_NB; e += 256) {
+    const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
+    As[i][c] = (r0 + i < n && c < kb) ? M[(size_t)(r0 + i) * n + k0 + c] : 0.0;
+    Bs[i][c] = (c0 + i < n && c < kb) ? M[(size_t)(c0 + i) * n + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+  double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll 8
+  for (int c = 0; c < PVLM_CHOL_NB; ++c) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { av[q] = As[ty * 4 + q][c]; bv[q] = Bs[tx * 4 + q][c]; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[p][q] += av[p] * bv[q];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = r0 + ty * 4 + p;
+    if (row >= n) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = c0 + tx * 4 + q;
+      if (col <= row) M[(size_t)row * n + col] -= acc[p][q];
+    }
+  }
+}
+
+// ---- triangular solves with the factor (single right-hand side), blocked the same way -------------------------------
+__global__ __launch_bounds__(64) void k_tri_diag(const double* __restrict__ M, int n, int k0, int kb, double* __restrict__ b, int transposed,
+                                                 const int* __restrict__ info) {
+  __shared__ double L[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double y[PVLM_CHOL_NB];
+  if (*info != 0) return;
+  const int t = threadIdx.x;
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 64) {
+    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
+    L[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+  }
+  if (t < PVLM_CHOL_NB) y[t] = t < kb ? b[k0 + t] : 0.0;
+  __syncthreads();
+  if (t == 0) {
+    if (!transposed) {
+      for (int i = 0; i < kb; ++i) { double s = y[i]; for (int j = 0; j < i; ++j) s -= L[i][j] * y[j]; y[i] = s / L[i][i]; }
+    } else {
+      for (int i = kb - 1; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < kb; ++j) s -= L[j][i] * y[j]; y[i] = s / L[i][i]; }
+    }
+  }
+  __syncthreads();
+  if (t < kb) b[k0 + t] = y[t];
+}
+
+// forward: b[i] -= L[i, k0:k0+kb] . b[k0:k0+kb] for rows i >= k0 + kb
+__global__ __launch_bounds__(256) void k_fwd_update(const double* __restrict__ M, int n, int k0, int kb, double* __restrict__ b, const int* __restrict__ info) {
+  if (*info != 0) return;
+  const int i = k0 + kb + blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double* r = M + (size_t)i * n + k0;
+  double s = 0.0;
+  for (int c = 0; c < kb; ++c) s += r[c] * b[k0 + c];
+  b[i] -= s;
+}
+// backward: b[j] -= L[k0:k0+kb, j]^T . b[k0:k0+kb] for columns j < k0
+__global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ M, int n, int k0, int kb, double* __restrict__ b, const int* __restrict__ info) {
+  if (*info != 0) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= k0) return;
+  double s = 0.0;
+  for (int c = 0; c < kb; ++c) s += M[(size_t)(k0 + c) * n + j] * b[k0 + c];
+  b[j] -= s;
+}
+
+// factorises d_M (n x n row-major, lower triangle used and overwritten by L) and solves for nrhs right-hand sides stored
+// one after the other in d_B; all on ctx->stream.
+static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, int* d_info) {
+  hipStream_t s = ctx->stream;
+  for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
+    const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_info);
+    if (rem > 0) {
+      hipLaunchKernelGGL(k_chol_panel, dim3((rem + 255) / 256), dim3(256), 0, s, d_M, n, k0, kb, d_info);
+      const int tiles = (rem + 63) / 64;
+      hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
+    }
+  }
+  for (int r = 0; r < nrhs; ++r) {
+    double* b = d_B + (size_t)r * n;
+    for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
+      const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
+      hipLaunchKernelGGL(k_tri_diag, dim3(1), dim3(64), 0, s, d_M, n, k0, kb, b, 0, d_info);
+      if (rem > 0) hipLaunchKernelGGL(k_fwd_update, dim3((rem + 255) / 256), dim3(256), 0, s, d_M, n, k0, kb, b, d_info);
+    }
+    for (int k0 = ((n - 1) / PVLM_CHOL_NB) * PVLM_CHOL_NB; k0 >= 0; k0 -= PVLM_CHOL_NB) {
+      const int kb = std::min(PVLM_CHOL_NB, n - k0);
+      hipLaunchKernelGGL(k_tri_diag, dim3(1), dim3(64), 0, s, d_M, n, k0, kb, b, 1, d_info);
+      if (k0 > 0) hipLaunchKernelGGL(k_bwd_update, dim3((k0 + 255) / 256), dim3(256), 0, s, d_M, n, k0, kb, b, d_info);
+    }
+  }
+}
 
 // dense M (n x n, symmetric) += scatter of 6x6 blocks: entry (r, c) of block b goes to (row_idx[6b + r], col_idx[6b + c])
 // scaled by scale[i] * scale[j]; blocks flagged `mirror` (two different poses) are also added to the other triangle.
@@ -70,7 +216,6 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   *info_out = 0;
   if (n == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  if (!g_solver.Load(ctx)) return PVLM_ERR_STATE;
   double *d_M = nullptr, *d_blocks = nullptr, *d_scale = nullptr, *d_diag = nullptr, *d_rhs = nullptr; int *d_row = nullptr, *d_col = nullptr, *d_mir = nullptr, *d_info = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_M, (size_t)n * n);
   if (!st) st = pvlm_i_alloc(ctx, &d_blocks, (size_t)n_blocks * 36);
@@ -91,26 +236,22 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_diag, diag_add, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rhs, rhs, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
-    int rc = 0, info = 0;
+    int info = 0;
     if (e == hipSuccess) {
       if (n_blocks) hipLaunchKernelGGL(k_scatter_blocks, dim3((unsigned)(((long long)n_blocks * 36 + 255) / 256)), dim3(256), 0, s, n, n_blocks, d_row, d_col, d_mir, d_blocks, d_scale, d_M);
       hipLaunchKernelGGL(k_add_diag, dim3((n + 255) / 256), dim3(256), 0, s, n, d_diag, d_M);
       e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, sizeof(int), s);
     if (e == hipSuccess) {
-      rc = g_solver.set_stream(g_solver.handle, s);
-      if (rc == 0) rc = g_solver.potrf(g_solver.handle, kFillLower, n, d_M, n, d_info);
-      if (rc == 0) e = hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s);
-      if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(s);
-      if (rc == 0 && e == hipSuccess && info == 0) {
-        rc = g_solver.potrs(g_solver.handle, kFillLower, n, 1, d_M, n, d_rhs, n);
-        if (rc == 0) e = hipMemcpyAsync(rhs, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s);
-        if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(s);
-      }
+      chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_info);
+      e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(rhs, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     *info_out = info;
-    if (rc != 0) { PVLM_SET_ERR(ctx, "rocSOLVER potrf/potrs failed with rocblas_status %d", rc); st = PVLM_ERR_HIP; }
-    else if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
   hipFree(d_M); hipFree(d_blocks); hipFree(d_row); hipFree(d_col); hipFree(d_mir); hipFree(d_scale); hipFree(d_diag); hipFree(d_rhs); hipFree(d_info);
@@ -126,7 +267,6 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
   *info_out = 0;
   if (n == 0 || nrhs == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  if (!g_solver.Load(ctx)) return PVLM_ERR_STATE;
   double *d_A = nullptr, *d_B = nullptr; int* d_info = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_A, (size_t)n * n);
   if (!st) st = pvlm_i_alloc(ctx, &d_B, (size_t)n * nrhs);
@@ -134,21 +274,17 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
   if (!st) {
     hipError_t e = hipMemcpyAsync(d_A, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_B, B, (size_t)n * nrhs * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    int rc = 0, info = 0;
+    int info = 0;
+    if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream);
     if (e == hipSuccess) {
-      rc = g_solver.set_stream(g_solver.handle, ctx->stream);
-      if (rc == 0) rc = g_solver.potrf(g_solver.handle, kFillLower, n, d_A, n, d_info);
-      if (rc == 0) e = hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-      if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (rc == 0 && e == hipSuccess && info == 0) {
-        rc = g_solver.potrs(g_solver.handle, kFillLower, n, nrhs, d_A, n, d_B, n);
-        if (rc == 0) e = hipMemcpyAsync(B, d_B, (size_t)n * nrhs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      }
+      chol_factor_solve(ctx, n, d_A, d_B, nrhs, d_info);
+      e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(B, d_B, (size_t)n * nrhs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     *info_out = info;
-    if (rc != 0) { PVLM_SET_ERR(ctx, "rocSOLVER potrf/potrs failed with rocblas_status %d", rc); st = PVLM_ERR_HIP; }
-    else if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
   hipFree(d_A); hipFree(d_B); hipFree(d_info);

@@ -1303,7 +1303,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       }
   };
   // Large reduced systems (Room / Floor sized joint problems: thousands of unknowns) are assembled, factorised and solved
-  // on the GPU (pvlm_spd_solve_blocks: rocSOLVER potrf); small ones by the host skyline Cholesky.
+  // on the GPU (pvlm_spd_solve_blocks: blocked Cholesky kernels); small ones by the host skyline Cholesky.
   const char* gpu_min_env = std::getenv("PVLM_GPU_CHOLESKY_MIN");
   const bool gpu_chol = n_free >= (gpu_min_env ? std::atoi(gpu_min_env) : 1500);
   // v^T (D H D) v over a block list, without forming the matrix
@@ -1338,7 +1338,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     double model_change = 0.0, dn = 0.0, xn = 0.0;
     Skyline S0;                      // four-block groups only: the Gauss-Newton model of those blocks
     if (gpu_chol) {
-      StageTimer stage_timer_chol_("solve: GPU Cholesky (rocSOLVER)");
+      StageTimer stage_timer_chol_("solve: GPU Cholesky");
       std::vector<int> rows, cols, mirror; std::vector<double> blocks;
       auto push = [&](const std::map<std::pair<int, int>, std::array<double, 36>>& H) {
         for (auto& kv : H) {

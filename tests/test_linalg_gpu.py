@@ -1,5 +1,5 @@
-"""GPU dense / block-sparse SPD solve of the LM driver (pvlm_spd_solve*, rocSOLVER potrf/potrs dlopen-ed by libpvlm.so)
-against numpy, and the host mirror's Solve with the GPU factorisation forced on against the CPU twin."""
+"""GPU dense / block-sparse SPD solve of the LM driver (pvlm_spd_solve*: hand-written blocked Cholesky) against numpy,
+and the host mirror's Solve with the GPU factorisation forced on against the CPU twin."""
 import os
 
 import numpy as np
@@ -10,9 +10,7 @@ from tests import host_io, lm_twin, synth
 pytestmark = pytest.mark.gpu
 
 
-# The solves are driven through the C++ test driver, not the ctypes binding: in a Python process that has imported torch
-# the SONAME librocblas.so.5 resolves to the copy bundled in the torch wheel, whose first rocblas_create_handle pages in
-# its whole kernel library (measured 138 s on a fresh box); the C++ host — the real caller — gets the system library.
+# driven through the C++ test driver (the real caller of these entry points)
 def _run_spd(tmp_path, A, B):
     import struct
     n = A.shape[0]; B2 = np.asarray(B, np.float64).reshape(n, -1)
@@ -25,7 +23,7 @@ def _run_spd(tmp_path, A, B):
     return (x.reshape(B2.shape[1], n).T.reshape(np.shape(B)) if info == 0 else None), info
 
 
-@pytest.mark.parametrize("n", [7, 300, 1800])
+@pytest.mark.parametrize("n", [7, 32, 33, 300, 1800])
 def test_dense_spd_solve(tmp_path, n):
     rng = np.random.default_rng(n)
     Q = rng.normal(size=(n, n))
