@@ -47,29 +47,30 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ M, int n
   }
 }
 
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, int n, int k0, int kb, const int* __restrict__ info) {
+// one thread per row below the diagonal block: x L_kk^T = a  (forward substitution over the 32 panel entries).  The row
+// lives in LDS as xs[c][thread] (conflict-free, dynamic indexing without scratch) — a fully unrolled register version
+// needed 512 registers + scratch and mis-behaved.
+#define PVLM_PANEL_THREADS 128
+__global__ __launch_bounds__(PVLM_PANEL_THREADS) void k_chol_panel(double* __restrict__ M, int n, int k0, int kb, const int* __restrict__ info) {
   __shared__ double L[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double xs[PVLM_CHOL_NB][PVLM_PANEL_THREADS];
   if (*info != 0) return;
-  for (int e = threadIdx.x; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
+  const int t = threadIdx.x;
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += PVLM_PANEL_THREADS) {
     const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
     L[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
   }
+  const int row = k0 + kb + blockIdx.x * PVLM_PANEL_THREADS + t;
+  const bool live = row < n;
+  double* r = M + (size_t)(live ? row : 0) * n + k0;
+  for (int c = 0; c < kb; ++c) xs[c][t] = live ? r[c] : 0.0;
   __syncthreads();
-  const int row = k0 + kb + blockIdx.x * 256 + threadIdx.x;
-  if (row >= n) return;
-  double x[PVLM_CHOL_NB];
-  double* r = M + (size_t)row * n + k0;
-#pragma unroll
-  for (int c = 0; c < PVLM_CHOL_NB; ++c) x[c] = c < kb ? r[c] : 0.0;
-#pragma unroll
-  for (int c = 0; c < PVLM_CHOL_NB; ++c) {
-    double s = x[c];
-#pragma unroll
-    for (int d = 0; d < c; ++d) s -= x[d] * L[c][d];
-    x[c] = s / L[c][c];
+  for (int c = 0; c < kb; ++c) {
+    double s = xs[c][t];
+    for (int d = 0; d < c; ++d) s -= xs[d][t] * L[c][d];
+    xs[c][t] = s / L[c][c];
   }
-#pragma unroll
-  for (int c = 0; c < PVLM_CHOL_NB; ++c) if (c < kb) r[c] = x[c];
+  if (live) for (int c = 0; c < kb; ++c) r[c] = xs[c][t];
 }
 
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info) {
@@ -165,7 +166,7 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
     const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
     hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_info);
     if (rem > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3((rem + 255) / 256), dim3(256), 0, s, d_M, n, k0, kb, d_info);
+      hipLaunchKernelGGL(k_chol_panel, dim3((rem + PVLM_PANEL_THREADS - 1) / PVLM_PANEL_THREADS), dim3(PVLM_PANEL_THREADS), 0, s, d_M, n, k0, kb, d_info);
       const int tiles = (rem + 63) / 64;
       hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
     }
