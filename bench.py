@@ -324,8 +324,22 @@ def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):
         dt1 = time.perf_counter() - t1
         if dt1 >= min(3.0, args.cpu_seconds):
             break
+    # ... and the unoptimised build: the reference's CMakeLists.txt sets no -O flag, so its PCL + Ceres path runs at -O0
+    v_o0 = None
+    try:
+        n0 = min(n, 50_000); reps0 = 0
+        t2 = time.perf_counter()
+        while True:
+            orc.evaluate_unoptimised(kind, orows[:n0], rid[:n0], nid[:n0], aa, t, normalize=True, threads=1)
+            reps0 += 1
+            dt2 = time.perf_counter() - t2
+            if dt2 >= min(2.0, args.cpu_seconds):
+                break
+        v_o0 = n0 * reps0 / dt2 / 1e6
+    except Exception:
+        pass
     return {"value": n * reps / dt / 1e6, "unit": "M evals/s", "cores": threads, "kind": "port",
-            "value_1thread": n1 * reps1 / dt1 / 1e6,
+            "value_1thread": n1 * reps1 / dt1 / 1e6, "value_1thread_O0": v_o0,
             "sample": "%d residual blocks of the first %d pairs x %d repetitions; r + 1x12 J by Jet<12> AutoDiff (restated "
                       "reference algorithm, g++ -O2), OpenMP %d threads, %.1f s" % (n, npairs, reps, threads, dt)}
 

@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_O0 = None
 _REF = None
 
 KIND_P2PLANE_METER = 0
@@ -119,6 +120,22 @@ def evaluate_reproj(bearing, weight, cam_id, pt_id, aa, t, X, jac=True):
     J = np.empty((n, 9), np.float64) if jac else None
     rc = lib().orc_eval_reproj(C.c_long(n), _p(bearing, C.c_double), C.c_double(weight), _p(cam_id, C.c_int), _p(pt_id, C.c_int),
                                _p(aa, C.c_double), _p(t, C.c_double), _p(X, C.c_double), _p(r, C.c_double), _p(J, C.c_double))
+    assert rc == 0
+    return r, J
+
+
+def evaluate_unoptimised(kind, rec, ref_id, nei_id, aa, t, normalize=False, threads=1):
+    """Same as evaluate (r + J), run by the -O0 build of the oracle (liboracle_O0.so): the reference's CMakeLists sets no
+    optimisation flag.  Timing aid for bench.py's cpu_baseline only."""
+    global _LIB_O0
+    if _LIB_O0 is None:
+        build()
+        _LIB_O0 = C.CDLL(os.path.join(_HERE, "liboracle_O0.so"))
+    rec = _f64(rec); aa = _f64(aa); t = _f64(t); ref_id = _i32(ref_id); nei_id = _i32(nei_id)
+    n = rec.shape[0]
+    r = np.empty(n, np.float64); J = np.empty((n, 12), np.float64)
+    rc = _LIB_O0.orc_eval(C.c_int(kind), C.c_int(1 if normalize else 0), C.c_long(n), _p(rec, C.c_double), C.c_int(rec.shape[1]), _p(ref_id, C.c_int),
+                          _p(nei_id, C.c_int), _p(aa, C.c_double), _p(t, C.c_double), _p(r, C.c_double), _p(J, C.c_double), C.c_int(threads))
     assert rc == 0
     return r, J
 
