@@ -34,7 +34,8 @@ class PvlmError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libpvlm.so")
+    # PVLM_LIB selects another build of the same library (measured kernel variants); never a different implementation
+    return os.environ.get("PVLM_LIB") or os.path.join(_HERE, "libpvlm.so")
 
 
 _LIB = None

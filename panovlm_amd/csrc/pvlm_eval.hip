@@ -247,8 +247,13 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
         for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j + 512);
       }
     } else {
+#ifdef PVLM_EXP_SKIP   // timing experiment only (wrong results): how does the rate respond to fewer bytes per evaluation?
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)(c < NCOLS - PVLM_EXP_SKIP ? c : 0) * n_dev + s0 + j);
+#else
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+#endif
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
