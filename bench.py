@@ -147,6 +147,9 @@ def main():
         for _ in range(8):
             step_local()
         torch.cuda.synchronize()
+    if world > 1:      # communicator set-up (lazy in RCCL) must not land in a timed step even with --warmup 0
+        dist.all_reduce(packed)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
