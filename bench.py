@@ -72,6 +72,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # functional check of the multi-rank control flow on a ONE-GPU box (not a measurement): all ranks share GPU 0 and the
+    # exchange goes through gloo — PVLM_BENCH_SHARED_GPU=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    shared_gpu = os.environ.get("PVLM_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
 
     from panovlm_amd import sharding
@@ -89,7 +94,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     import panovlm_amd as pv
@@ -250,6 +258,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, pv, dscans, ref, nei, aa0, t0, kind, args)
+        # RCCL prints a version banner through C stdio; on a pipe that buffer is flushed at exit, i.e. AFTER Python's own
+        # output — push it out first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
