@@ -141,3 +141,27 @@ def test_load_lidar_pcd_formats():
         assert ok == 1 and valid == 0 and count == int(keep[:3000].sum())
         ok, valid, count, _ = parse(host_io.run("loadpcd", os.path.join(d, "missing.pcd")))
         assert ok == 0 and count == 0
+
+
+def test_point2line_segment_mirror_matches_oracle():
+    """AssociatePoint2LineSegment (LidarFeatureAssociate.cpp:319-383) is host-only (brute-force point-to-line distances):
+    the mirror against the oracle without a GPU."""
+    from oracle import oracle as orc
+    from panovlm_amd import synthetic as sy
+    rng = np.random.default_rng(23)
+    lines = sy.random_world_lines(rng, 10)
+    scans = []
+    for k in range(2):
+        R, t = sy.estimated_pose(k + 2)
+        s = sy.make_line_scan(rng, k, R, t, lines, pts_per_line=(10, 24), extra_pts=12, noise=0.005)
+        seg_points = [[i for i, l in enumerate(s["p2s"]) if sid in l] for sid in range(len(s["seg_size"]))]
+        scans.append(dict(id=k, R_wl=R, t_wl=t, corner_local=s["corner_local"], p2s=s["p2s"], seg_points=seg_points,
+                          seg_coeffs=s["seg_coeffs"], end_points=s["end_points"], _oracle=s))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "l.bin")
+        host_io.write_scans(path, scans)
+        got = np.array([[float(v) for v in l.split()[1:]] for l in host_io.run("p2line", path, 0, 1, 2, 0.3)]).reshape(-1, 9)
+    o = orc.assoc_point2line(scans[0]["_oracle"], scans[1]["_oracle"], 0.3, mode="segment")
+    assert len(got) == len(o["point"]) > 50
+    assert np.allclose(got[:, :3], o["point"], rtol=0, atol=1e-12) and np.allclose(got[:, 3:6], o["a"], rtol=0, atol=1e-12)
+    assert np.allclose(got[:, 6:9], o["b"], rtol=0, atol=1e-12)
