@@ -6,6 +6,7 @@
 // potrf was tried first and works, but the first rocblas_create_handle of a process pages the whole rocBLAS kernel
 // library in (measured 140..510 s on a cold box) — unacceptable inside a library call.
 #include <algorithm>
+#include <cstdlib>
 
 #include "pvlm_internal.h"
 
@@ -114,6 +115,50 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int
   }
 }
 
+// The same rank-32 trailing update on the matrix core: v_mfma_f64_16x16x4_f64 (the one GEMM-shaped kernel of this
+// library).  A 64 x 64 tile per workgroup, wave w owns the 16-row band [16w, 16w + 16) and all four 16-column tiles:
+// per k-step of 4 one A fragment (lane l: A[l & 15][k + (l >> 4)]) and four B fragments (B[k + (l >> 4)][l & 15] =
+// panel row of the column tile) from LDS, four MFMAs.  D layout of the f64 form: col = lane & 15,
+// row = (lane >> 4) + 4 * reg (cdna_hip_programming.md §3) — not the f32 map.
+typedef double pvlm_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info) {
+  __shared__ double As[64][PVLM_CHOL_NB + 1];
+  __shared__ double Bs[64][PVLM_CHOL_NB + 1];
+  if (*info != 0) return;
+  int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long long)(ti + 1) * (ti + 2) / 2 <= (long long)blockIdx.x) ++ti;
+  while ((long long)ti * (ti + 1) / 2 > (long long)blockIdx.x) --ti;
+  const int tj = blockIdx.x - ti * (ti + 1) / 2;
+  if (ti >= tiles) return;
+  const int base = k0 + kb, r0 = base + ti * 64, c0 = base + tj * 64;
+  for (int e = threadIdx.x; e < 64 * PVLM_CHOL_NB; e += 256) {
+    const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
+    As[i][c] = (r0 + i < n && c < kb) ? M[(size_t)(r0 + i) * n + k0 + c] : 0.0;
+    Bs[i][c] = (c0 + i < n && c < kb) ? M[(size_t)(c0 + i) * n + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  pvlm_d4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < PVLM_CHOL_NB; k += 4) {
+    const double a = As[16 * w + li][k + lk];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[16 * t + li][k + lk], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = c0 + 16 * t + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 16 * w + lk + 4 * r;
+      if (row < n && col <= row) M[(size_t)row * n + col] -= acc[t][r];
+    }
+  }
+}
+
 // ---- triangular solves with the factor (single right-hand side), blocked the same way -------------------------------
 __global__ __launch_bounds__(64) void k_tri_diag(const double* __restrict__ M, int n, int k0, int kb, double* __restrict__ b, int transposed,
                                                  const int* __restrict__ info) {
@@ -162,13 +207,15 @@ __global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ M
 // one after the other in d_B; all on ctx->stream.
 static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, int* d_info) {
   hipStream_t s = ctx->stream;
+  static const bool use_mfma = getenv("PVLM_CHOL_VALU") == nullptr;   // PVLM_CHOL_VALU=1: the register-tiled VALU update (measured variant)
   for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
     const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
     hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_info);
     if (rem > 0) {
       hipLaunchKernelGGL(k_chol_panel, dim3((rem + PVLM_PANEL_THREADS - 1) / PVLM_PANEL_THREADS), dim3(PVLM_PANEL_THREADS), 0, s, d_M, n, k0, kb, d_info);
       const int tiles = (rem + 63) / 64;
-      hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
+      if (use_mfma) hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
+      else hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
     }
   }
   for (int r = 0; r < nrhs; ++r) {
