@@ -68,7 +68,7 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   if (!ctx) return PVLM_ERR_ARG;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->d_aa); hipFree(ctx->d_t); hipFree(ctx->d_pose_tab);
+  hipFree(ctx->d_aa); hipFree(ctx->d_t); hipFree(ctx->d_pose_tab); hipFree(ctx->d_ws);
   hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
   for (int w = 0; w < 3; ++w) for (auto& pr : ctx->prof_pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);

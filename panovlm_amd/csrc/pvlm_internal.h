@@ -32,6 +32,9 @@ struct pvlm_ctx {
   double* d_aa = nullptr;
   double* d_t = nullptr;
   double* d_pose_tab = nullptr;
+  // grow-only device workspace of the dense solver (K10): a Room-sized system is 237 MB, allocating it per LM step costs ms
+  void* d_ws = nullptr;
+  size_t ws_bytes = 0;
   // per-kernel profiling (pvlm_profile_*): pending (start, stop) event pairs per kernel class
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[3];

@@ -251,6 +251,21 @@ __global__ void k_add_diag(int n, const double* __restrict__ d, double* __restri
   if (i < n) M[(size_t)i * n + i] += d[i];
 }
 
+// carve aligned pieces out of the context's grow-only workspace
+struct WsCarver {
+  char* base; size_t used = 0;
+  template <typename T> T* take(size_t count) { T* p = reinterpret_cast<T*>(base + used); used += (count * sizeof(T) + 255) & ~(size_t)255; return p; }
+};
+static pvlm_status ws_reserve(pvlm_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return PVLM_OK;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(ctx->d_ws); ctx->d_ws = nullptr; ctx->ws_bytes = 0;
+  PVLM_HIP(ctx, hipMalloc(&ctx->d_ws, bytes));
+  ctx->ws_bytes = bytes;
+  return PVLM_OK;
+}
+static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 extern "C" {
 
 // Block-sparse form for the LM driver: assembles M = D (sum of blocks) D + diag(diag_add) on the device (D = diag(scale)),
@@ -264,16 +279,14 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   *info_out = 0;
   if (n == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  double *d_M = nullptr, *d_blocks = nullptr, *d_scale = nullptr, *d_diag = nullptr, *d_rhs = nullptr; int *d_row = nullptr, *d_col = nullptr, *d_mir = nullptr, *d_info = nullptr;
-  pvlm_status st = pvlm_i_alloc(ctx, &d_M, (size_t)n * n);
-  if (!st) st = pvlm_i_alloc(ctx, &d_blocks, (size_t)n_blocks * 36);
-  if (!st) st = pvlm_i_alloc(ctx, &d_row, (size_t)n_blocks * 6);
-  if (!st) st = pvlm_i_alloc(ctx, &d_col, (size_t)n_blocks * 6);
-  if (!st) st = pvlm_i_alloc(ctx, &d_mir, (size_t)n_blocks);
-  if (!st) st = pvlm_i_alloc(ctx, &d_scale, (size_t)n);
-  if (!st) st = pvlm_i_alloc(ctx, &d_diag, (size_t)n);
-  if (!st) st = pvlm_i_alloc(ctx, &d_rhs, (size_t)n);
-  if (!st) st = pvlm_i_alloc(ctx, &d_info, (size_t)1);
+  const size_t need = pad256((size_t)n * n * 8) + pad256((size_t)n_blocks * 36 * 8) + 3 * pad256((size_t)n_blocks * 6 * 4) + 3 * pad256((size_t)n * 8) + 256;
+  pvlm_status st = ws_reserve(ctx, need);
+  if (st) return st;
+  WsCarver ws{static_cast<char*>(ctx->d_ws)};
+  double* d_M = ws.take<double>((size_t)n * n); double* d_blocks = ws.take<double>((size_t)n_blocks * 36);
+  int* d_row = ws.take<int>((size_t)n_blocks * 6); int* d_col = ws.take<int>((size_t)n_blocks * 6); int* d_mir = ws.take<int>((size_t)n_blocks * 6);
+  double* d_scale = ws.take<double>(n); double* d_diag = ws.take<double>(n); double* d_rhs = ws.take<double>(n);
+  int* d_info = ws.take<int>(1);
   if (!st) {
     hipStream_t s = ctx->stream;
     hipError_t e = hipMemsetAsync(d_M, 0, (size_t)n * n * sizeof(double), s);
@@ -302,7 +315,6 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_M); hipFree(d_blocks); hipFree(d_row); hipFree(d_col); hipFree(d_mir); hipFree(d_scale); hipFree(d_diag); hipFree(d_rhs); hipFree(d_info);
   return st;
 }
 
