@@ -11,14 +11,15 @@
 #include "pvlm_internal.h"
 
 // ---- blocked right-looking Cholesky, fp64, lower triangle of a row-major dense matrix ------------------------------
-// Step k (block column of NB = 32): (1) one workgroup factorises the diagonal block in LDS, (2) one thread per row below
-// solves its 32 panel entries against it, (3) the trailing lower triangle gets its rank-32 update in 64 x 64 tiles
-// (256 threads x 4 x 4 register tiles, both panel slices staged in LDS).  *info != 0 (set by a non-positive pivot, 1-based
+// Step k (block column of NB = 32): (1) one workgroup factorises the diagonal block in LDS and inverts it, (2) the panel
+// below is multiplied by that inverse, (3) the trailing lower triangle gets its rank-32 update in 64 x 64 tiles on the
+// f64 matrix core (both panel slices staged in LDS).  *info != 0 (set by a non-positive pivot, 1-based
 // like LAPACK) makes every later kernel of the sequence return at once.
 #define PVLM_CHOL_NB 32
 
-__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ M, int n, int k0, int kb, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ M, int n, int k0, int kb, double* __restrict__ Linv, int* __restrict__ info) {
   __shared__ double a[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
   __shared__ int fail;
   if (*info != 0) return;
   const int t = threadIdx.x;
@@ -42,36 +43,47 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ M, int n
     __syncthreads();
   }
   if (fail) { if (t == 0) *info = k0 + fail; return; }
+  // inverse of the factored block (lower triangular): thread c owns column c and only ever reads what it wrote itself.
+  // With it the panel solve and the triangular solves of this block column are plain (parallel) products.
+  if (t < PVLM_CHOL_NB) {
+    const int c = t;
+    for (int i = 0; i < PVLM_CHOL_NB; ++i) {
+      double x = 0.0;
+      if (c < kb && i < kb && i >= c) {
+        if (i == c) x = 1.0 / a[c][c];
+        else { double sacc = 0.0; for (int j = c; j < i; ++j) sacc += a[i][j] * inv[j][c]; x = -sacc / a[i][i]; }
+      }
+      inv[i][c] = x;
+    }
+  }
+  __syncthreads();
+  double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
   for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
     const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
     if (i < kb && j <= i) M[(size_t)(k0 + i) * n + k0 + j] = a[i][j];
+    Lk[e] = inv[i][j];
   }
 }
 
-// one thread per row below the diagonal block: x L_kk^T = a  (forward substitution over the 32 panel entries).  The row
-// lives in LDS as xs[c][thread] (conflict-free, dynamic indexing without scratch) — a fully unrolled register version
-// needed 512 registers + scratch and mis-behaved.
-#define PVLM_PANEL_THREADS 128
-__global__ __launch_bounds__(PVLM_PANEL_THREADS) void k_chol_panel(double* __restrict__ M, int n, int k0, int kb, const int* __restrict__ info) {
-  __shared__ double L[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
-  __shared__ double xs[PVLM_CHOL_NB][PVLM_PANEL_THREADS];
+// panel below the diagonal block: X = A L_kk^-T, i.e. X[row][c] = sum_{d <= c} A[row][d] Linv[c][d] — a small product,
+// 8 rows x 32 columns per workgroup, no dependency chain (the first version solved the triangular system per row:
+// 25 us per block column; a fully unrolled register version of that needed 512 registers + scratch and mis-behaved).
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, int n, int k0, int kb, const double* __restrict__ Linv,
+                                                    const int* __restrict__ info) {
+  __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double As[8][PVLM_CHOL_NB + 1];
   if (*info != 0) return;
   const int t = threadIdx.x;
-  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += PVLM_PANEL_THREADS) {
-    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
-    L[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
-  }
-  const int row = k0 + kb + blockIdx.x * PVLM_PANEL_THREADS + t;
-  const bool live = row < n;
-  double* r = M + (size_t)(live ? row : 0) * n + k0;
-  for (int c = 0; c < kb; ++c) xs[c][t] = live ? r[c] : 0.0;
+  const double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) inv[e / PVLM_CHOL_NB][e % PVLM_CHOL_NB] = Lk[e];
+  const int lr = t / PVLM_CHOL_NB, c = t % PVLM_CHOL_NB;
+  const int row = k0 + kb + blockIdx.x * 8 + lr;
+  const bool live = row < n && c < kb;
+  As[lr][c] = live ? M[(size_t)row * n + k0 + c] : 0.0;
   __syncthreads();
-  for (int c = 0; c < kb; ++c) {
-    double s = xs[c][t];
-    for (int d = 0; d < c; ++d) s -= xs[d][t] * L[c][d];
-    xs[c][t] = s / L[c][c];
-  }
-  if (live) for (int c = 0; c < kb; ++c) r[c] = xs[c][t];
+  double x = 0.0;
+  for (int d = 0; d <= c; ++d) x += As[lr][d] * inv[c][d];
+  if (live) M[(size_t)row * n + k0 + c] = x;
 }
 
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info) {
@@ -159,60 +171,69 @@ __global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M
   }
 }
 
-// ---- triangular solves with the factor (single right-hand side), blocked the same way -------------------------------
-__global__ __launch_bounds__(64) void k_tri_diag(const double* __restrict__ M, int n, int k0, int kb, double* __restrict__ b, int transposed,
-                                                 const int* __restrict__ info) {
-  __shared__ double L[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
-  __shared__ double y[PVLM_CHOL_NB];
+// ---- triangular solves with the factor (single right-hand side), one launch per block column ------------------------
+// forward step k: y_k = Linv_k b_k (every workgroup recomputes the 32-vector, workgroup 0 stores it in yv), then
+// b[i] -= L[i, k] . y_k for the rows below.  yv is a separate vector so that no workgroup reads what another one writes.
+__global__ __launch_bounds__(256) void k_fwd_step(const double* __restrict__ M, int n, int k0, int kb, const double* __restrict__ Linv,
+                                                  double* __restrict__ b, double* __restrict__ yv, const int* __restrict__ info) {
+  __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double v[PVLM_CHOL_NB], y[PVLM_CHOL_NB];
   if (*info != 0) return;
   const int t = threadIdx.x;
-  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 64) {
-    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
-    L[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-  }
-  if (t < PVLM_CHOL_NB) y[t] = t < kb ? b[k0 + t] : 0.0;
+  const double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) inv[e / PVLM_CHOL_NB][e % PVLM_CHOL_NB] = Lk[e];
+  if (t < PVLM_CHOL_NB) v[t] = t < kb ? b[k0 + t] : 0.0;
   __syncthreads();
-  if (t == 0) {
-    if (!transposed) {
-      for (int i = 0; i < kb; ++i) { double s = y[i]; for (int j = 0; j < i; ++j) s -= L[i][j] * y[j]; y[i] = s / L[i][i]; }
-    } else {
-      for (int i = kb - 1; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < kb; ++j) s -= L[j][i] * y[j]; y[i] = s / L[i][i]; }
-    }
+  if (t < PVLM_CHOL_NB) {
+    double sacc = 0.0;
+    for (int d = 0; d <= t; ++d) sacc += inv[t][d] * v[d];
+    y[t] = sacc;
+    if (blockIdx.x == 0 && t < kb) yv[k0 + t] = sacc;
   }
   __syncthreads();
-  if (t < kb) b[k0 + t] = y[t];
-}
-
-// forward: b[i] -= L[i, k0:k0+kb] . b[k0:k0+kb] for rows i >= k0 + kb
-__global__ __launch_bounds__(256) void k_fwd_update(const double* __restrict__ M, int n, int k0, int kb, double* __restrict__ b, const int* __restrict__ info) {
-  if (*info != 0) return;
-  const int i = k0 + kb + blockIdx.x * 256 + threadIdx.x;
+  const int i = k0 + kb + blockIdx.x * 256 + t;
   if (i >= n) return;
   const double* r = M + (size_t)i * n + k0;
-  double s = 0.0;
-  for (int c = 0; c < kb; ++c) s += r[c] * b[k0 + c];
-  b[i] -= s;
+  double sacc = 0.0;
+  for (int c = 0; c < kb; ++c) sacc += r[c] * y[c];
+  b[i] -= sacc;
 }
-// backward: b[j] -= L[k0:k0+kb, j]^T . b[k0:k0+kb] for columns j < k0
-__global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ M, int n, int k0, int kb, double* __restrict__ b, const int* __restrict__ info) {
+// backward step k: x_k = Linv_k^T yv_k (stored into b by workgroup 0), then yv[j] -= L[k, j]^T . x_k for the columns j < k0
+__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, int n, int k0, int kb, const double* __restrict__ Linv,
+                                                  double* __restrict__ b, double* __restrict__ yv, const int* __restrict__ info) {
+  __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double v[PVLM_CHOL_NB], x[PVLM_CHOL_NB];
   if (*info != 0) return;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int t = threadIdx.x;
+  const double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) inv[e / PVLM_CHOL_NB][e % PVLM_CHOL_NB] = Lk[e];
+  if (t < PVLM_CHOL_NB) v[t] = t < kb ? yv[k0 + t] : 0.0;
+  __syncthreads();
+  if (t < PVLM_CHOL_NB) {
+    double sacc = 0.0;
+    for (int d = t; d < PVLM_CHOL_NB; ++d) sacc += inv[d][t] * v[d];
+    x[t] = sacc;
+    if (blockIdx.x == 0 && t < kb) b[k0 + t] = sacc;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 256 + t;
   if (j >= k0) return;
-  double s = 0.0;
-  for (int c = 0; c < kb; ++c) s += M[(size_t)(k0 + c) * n + j] * b[k0 + c];
-  b[j] -= s;
+  double sacc = 0.0;
+  for (int c = 0; c < kb; ++c) sacc += M[(size_t)(k0 + c) * n + j] * x[c];
+  yv[j] -= sacc;
 }
 
 // factorises d_M (n x n row-major, lower triangle used and overwritten by L) and solves for nrhs right-hand sides stored
 // one after the other in d_B; all on ctx->stream.
-static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, int* d_info) {
+// d_Linv: ceil(n / 32) x 32 x 32 doubles (inverses of the diagonal blocks), d_y: n doubles (forward-solve result).
+static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, double* d_Linv, double* d_y, int* d_info) {
   hipStream_t s = ctx->stream;
   static const bool use_mfma = getenv("PVLM_CHOL_VALU") == nullptr;   // PVLM_CHOL_VALU=1: the register-tiled VALU update (measured variant)
   for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
     const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_info);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
     if (rem > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3((rem + PVLM_PANEL_THREADS - 1) / PVLM_PANEL_THREADS), dim3(PVLM_PANEL_THREADS), 0, s, d_M, n, k0, kb, d_info);
+      hipLaunchKernelGGL(k_chol_panel, dim3((rem + 7) / 8), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
       const int tiles = (rem + 63) / 64;
       if (use_mfma) hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
       else hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
@@ -222,13 +243,11 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
     double* b = d_B + (size_t)r * n;
     for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
       const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
-      hipLaunchKernelGGL(k_tri_diag, dim3(1), dim3(64), 0, s, d_M, n, k0, kb, b, 0, d_info);
-      if (rem > 0) hipLaunchKernelGGL(k_fwd_update, dim3((rem + 255) / 256), dim3(256), 0, s, d_M, n, k0, kb, b, d_info);
+      hipLaunchKernelGGL(k_fwd_step, dim3(std::max(1, (rem + 255) / 256)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, b, d_y, d_info);
     }
     for (int k0 = ((n - 1) / PVLM_CHOL_NB) * PVLM_CHOL_NB; k0 >= 0; k0 -= PVLM_CHOL_NB) {
       const int kb = std::min(PVLM_CHOL_NB, n - k0);
-      hipLaunchKernelGGL(k_tri_diag, dim3(1), dim3(64), 0, s, d_M, n, k0, kb, b, 1, d_info);
-      if (k0 > 0) hipLaunchKernelGGL(k_bwd_update, dim3((k0 + 255) / 256), dim3(256), 0, s, d_M, n, k0, kb, b, d_info);
+      hipLaunchKernelGGL(k_bwd_step, dim3(std::max(1, (k0 + 255) / 256)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, b, d_y, d_info);
     }
   }
 }
@@ -279,13 +298,16 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   *info_out = 0;
   if (n == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  const size_t need = pad256((size_t)n * n * 8) + pad256((size_t)n_blocks * 36 * 8) + 3 * pad256((size_t)n_blocks * 6 * 4) + 3 * pad256((size_t)n * 8) + 256;
+  const size_t linv_count = (size_t)((n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
+  const size_t need = pad256((size_t)n * n * 8) + pad256((size_t)n_blocks * 36 * 8) + 3 * pad256((size_t)n_blocks * 6 * 4) + 4 * pad256((size_t)n * 8) +
+                      pad256(linv_count * 8) + 256;
   pvlm_status st = ws_reserve(ctx, need);
   if (st) return st;
   WsCarver ws{static_cast<char*>(ctx->d_ws)};
   double* d_M = ws.take<double>((size_t)n * n); double* d_blocks = ws.take<double>((size_t)n_blocks * 36);
   int* d_row = ws.take<int>((size_t)n_blocks * 6); int* d_col = ws.take<int>((size_t)n_blocks * 6); int* d_mir = ws.take<int>((size_t)n_blocks * 6);
   double* d_scale = ws.take<double>(n); double* d_diag = ws.take<double>(n); double* d_rhs = ws.take<double>(n);
+  double* d_y = ws.take<double>(n); double* d_Linv = ws.take<double>(linv_count);
   int* d_info = ws.take<int>(1);
   if (!st) {
     hipStream_t s = ctx->stream;
@@ -305,7 +327,7 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     }
     if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, sizeof(int), s);
     if (e == hipSuccess) {
-      chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_info);
+      chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_Linv, d_y, d_info);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s);
@@ -327,9 +349,11 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
   *info_out = 0;
   if (n == 0 || nrhs == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  double *d_A = nullptr, *d_B = nullptr; int* d_info = nullptr;
+  double *d_A = nullptr, *d_B = nullptr, *d_Linv = nullptr, *d_y = nullptr; int* d_info = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_A, (size_t)n * n);
   if (!st) st = pvlm_i_alloc(ctx, &d_B, (size_t)n * nrhs);
+  if (!st) st = pvlm_i_alloc(ctx, &d_Linv, (size_t)((n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB);
+  if (!st) st = pvlm_i_alloc(ctx, &d_y, (size_t)n);
   if (!st) st = pvlm_i_alloc(ctx, &d_info, (size_t)1);
   if (!st) {
     hipError_t e = hipMemcpyAsync(d_A, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -337,7 +361,7 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
     int info = 0;
     if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream);
     if (e == hipSuccess) {
-      chol_factor_solve(ctx, n, d_A, d_B, nrhs, d_info);
+      chol_factor_solve(ctx, n, d_A, d_B, nrhs, d_Linv, d_y, d_info);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
@@ -347,7 +371,7 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_A); hipFree(d_B); hipFree(d_info);
+  hipFree(d_A); hipFree(d_B); hipFree(d_Linv); hipFree(d_y); hipFree(d_info);
   return st;
 }
 
