@@ -27,36 +27,29 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ M, int n
   for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
     const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
     a[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+    inv[i][j] = (i == j && i < kb) ? 1.0 : 0.0;
   }
   __syncthreads();
+  // right-looking factorisation of the block; the same eliminations applied to an identity give L^-1 on the way
+  // (Y = I; row j of Y is divided by the pivot, rows below get Y[i] -= L[i][j] Y[j]): no extra barriers.
   for (int j = 0; j < kb; ++j) {
     if (t == 0) { const double d = a[j][j]; if (!(d > 0.0)) fail = j + 1; else a[j][j] = sqrt(d); }
     __syncthreads();
     if (fail) break;
     const double piv = a[j][j];
     if (t > j && t < kb) a[t][j] /= piv;
+    if (t >= 64 && t - 64 <= j) inv[j][t - 64] /= piv;          // second wave: row j of the inverse (columns <= j)
     __syncthreads();
     for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
       const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
-      if (c > j && c <= i && i < kb) a[i][c] -= a[i][j] * a[c][j];
+      if (i > j && i < kb) {
+        if (c > j && c <= i) a[i][c] -= a[i][j] * a[c][j];
+        else if (c <= j) inv[i][c] -= a[i][j] * inv[j][c];
+      }
     }
     __syncthreads();
   }
   if (fail) { if (t == 0) *info = k0 + fail; return; }
-  // inverse of the factored block (lower triangular): thread c owns column c and only ever reads what it wrote itself.
-  // With it the panel solve and the triangular solves of this block column are plain (parallel) products.
-  if (t < PVLM_CHOL_NB) {
-    const int c = t;
-    for (int i = 0; i < PVLM_CHOL_NB; ++i) {
-      double x = 0.0;
-      if (c < kb && i < kb && i >= c) {
-        if (i == c) x = 1.0 / a[c][c];
-        else { double sacc = 0.0; for (int j = c; j < i; ++j) sacc += a[i][j] * inv[j][c]; x = -sacc / a[i][i]; }
-      }
-      inv[i][c] = x;
-    }
-  }
-  __syncthreads();
   double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
   for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
     const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;

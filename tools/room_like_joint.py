@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--keep", default="", help="write the scene files here and print the driver command (e.g. to run it under rocprofv3)")
     a = ap.parse_args()
     rng = np.random.default_rng(2)
     rows, cols = 2880, 5760
@@ -58,8 +59,12 @@ def main():
         tracks.append(dict(point=X[p] + rng.normal(size=3) * 0.03, obs=obs))
     n_obs = sum(len(t["obs"]) for t in tracks)
     with tempfile.TemporaryDirectory() as d:
+        if a.keep:
+            d = a.keep; os.makedirs(d, exist_ok=True)
         lp, fp, sp = (os.path.join(d, n) for n in ("l.bin", "f.bin", "s.bin"))
         host_io.write_scans(lp, lidars, world=False); host_io.write_frames(fp, T_cl, frames); host_io.write_structure(sp, frames, tracks)
+        if a.keep:
+            print("driver command:", host_io.driver(), "joint", lp, fp, 3, a.iters, 0, 1, 0.05, 1.0, 0.3, 0.01, 25.0, 1.0, sp)
         t0 = time.perf_counter()
         out = host_io.run("joint", lp, fp, 3, a.iters, 0, 1, 0.05, 1.0, 0.3, 0.01, 25.0, 1.0, sp, timeout=3000)   # Room weights (config/Room.txt:81-83)
         wall = time.perf_counter() - t0
