@@ -282,6 +282,17 @@ pvlm_status pvlm_image_to_cam_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t
 pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* xyz, const double* T_cl_rowmajor16,
                                      unsigned size, uint16_t* depth);
 
+/* Photometric scoring pass of the panoramic PatchMatch MVS: MVS::InitPatchMap + MVS::InitConfMap(use_geometry = false)
+ * (mvs/MVS.cpp:586-680) with the photometric term of ScorePixel (:774-923): for every pixel with depth > 0 the
+ * bilaterally weighted NCC of its (2 half_window + 1)^2 / step^2 window against each neighbour panorama through the
+ * plane-induced homography R_nr + t_nr n^T / d, averaged over the two best neighbours; conf = -1 (and depth / normal
+ * zeroed) where the reference patch is invalid, the plane faces away (d > 0) or no neighbour sees the window.
+ * ref_gray / nei_gray[b]: rows x cols uint8; R_nr: n x 9 row-major, t_nr: n x 3 (reference -> neighbour camera);
+ * depth (rows x cols), normal (rows x cols x 3, camera frame), conf (rows x cols): float32, in-out. n_neighbors <= 16. */
+pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                   const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal,
+                                   float* conf);
+
 /* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
  * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2
  * pixels, n_lines x 4 float) and every LiDAR corner point (LiDAR-local float xyz, transformed by

@@ -1,0 +1,149 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Never linked or imported by the product path.
+// CPU restatement of the photometric scoring pass of the reference's panoramic PatchMatch MVS:
+//   /root/reference/mvs/MVS.cpp:25-35    constants (ncc_window_size, num_texels, sigma_color, sigma_spatial, PreComputeI2C)
+//   /root/reference/mvs/MVS.cpp:637-680  FillPixelPatch (bilaterally weighted reference patch)
+//   /root/reference/mvs/MVS.cpp:586-618  InitConfMap (score of the current depth / normal hypothesis of every pixel)
+//   /root/reference/mvs/MVS.cpp:774-923  ScorePixel — photometric term (geometric_consistency = false, no close neighbours)
+//   /root/reference/mvs/MVS.cpp Sample   bilinear grey sample
+//   /root/reference/sensors/Equirectangular.cpp:12-19 PreComputeI2C (ImageToCam<float> of every integer pixel)
+// float32 arithmetic throughout, in the order of the cv::Matx / cv::Point3f operators the reference uses
+// ([recalled] OpenCV 3.4: Matx product = left-to-right sum over k starting from 0; Point3f::dot = x*x' + y*y' + z*z').
+// "parity unpinned" (no reference fixtures; OpenCV absent from this image).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "equirect.hpp"
+
+namespace oracle {
+
+struct MvsView {
+  int rows, cols, half_window, step;
+  const uint8_t* gray;   // rows x cols
+};
+
+struct PixelPatch { std::vector<float> texels0, weight; float sq0 = 0.f; bool ok = false; };
+
+inline int MvsNumTexels(int half_window, int step) {
+  const int w = 2 * half_window + 1, q = w / step + (step > 1 ? 1 : 0);
+  return q * q;
+}
+
+// MVS.cpp:637-680
+inline void FillPixelPatch(const MvsView& v, int px, int py, PixelPatch& patch) {
+  const int hw = v.half_window, n = MvsNumTexels(hw, v.step);
+  patch.texels0.assign(n, 0.f); patch.weight.assign(n, 0.f); patch.sq0 = 0.f; patch.ok = false;
+  // frame.IsInside(pt, hw, hw) with an integer point
+  if (!(px >= hw && py >= hw && px < v.cols - hw && py < v.rows - hw)) return;
+  const float sigma_color = -1.f / (2 * 0.2 * 0.2);                       // double expression rounded to float (:33)
+  const float sigma_spatial = -1.f / (2.f * hw * hw);
+  const uint8_t center = v.gray[(size_t)py * v.cols + px];
+  int k = 0;
+  for (int row = py - hw; row <= py + hw; row += v.step)
+    for (int col = px - hw; col <= px + hw; col += v.step) {
+      const uint8_t tex = v.gray[(size_t)row * v.cols + col];
+      float wColor = (tex - center) / 255.f;
+      wColor = wColor * wColor * sigma_color;
+      const float wSpatial = ((float)((col - px) * (col - px)) + (float)((row - py) * (row - py))) * sigma_spatial;
+      patch.weight[k] = std::exp(wColor + wSpatial);
+      patch.texels0[k] = tex;
+      k++;
+    }
+  float sum = 0.f;
+  for (int i = 0; i < n; ++i) sum += patch.weight[i];                      // std::accumulate(..., 0.f)
+  for (int i = 0; i < n; ++i) patch.weight[i] /= sum;
+  sum = 0;
+  for (int i = 0; i < n; ++i) sum += patch.weight[i] * patch.texels0[i];
+  for (int i = 0; i < n; ++i) patch.texels0[i] -= sum;
+  for (int i = 0; i < n; ++i) {
+    const float tmp = patch.texels0[i] * patch.weight[i];
+    patch.sq0 += patch.texels0[i] * tmp;
+    patch.texels0[i] = tmp;
+  }
+  patch.ok = !(patch.sq0 <= 1e-6);                                         // float compared with a double literal
+}
+
+// Sample(img_gray, pt): bilinear
+inline float MvsSample(const uint8_t* img, int cols, float x, float y) {
+  const int lx = (int)x, ly = (int)y;
+  const float fx = x - lx, fy = y - ly, x1 = 1.f - fx, y1 = 1.f - fy;
+  const uint8_t* p = img + (size_t)ly * cols + lx;
+  return (p[0] * x1 + p[1] * fx) * y1 + (p[cols] * x1 + p[cols + 1] * fx) * fy;
+}
+
+// ScorePixel, photometric term only.  unit = PreComputeI2C table (rows x cols x 3 float).  R_nr / t_nr: neighbour n at
+// R + 9 n / t + 3 n (row-major).  Returns the aggregated score (-1 = invalid).
+inline float ScorePixelPhotometric(const MvsView& ref, const float* unit, int px, int py, const float* normal, float depth, const PixelPatch& patch,
+                                   int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr) {
+  const Equirectangular eq(ref.rows, ref.cols);
+  const float* u0 = unit + 3 * ((size_t)py * ref.cols + px);
+  const float X0[3] = {u0[0] * depth, u0[1] * depth, u0[2] * depth};
+  const float d = X0[0] * normal[0] + X0[1] * normal[1] + X0[2] * normal[2];
+  if (d > 0) return -1;
+  const int hw = ref.half_window, w = 2 * hw + 1, n = MvsNumTexels(hw, ref.step);
+  std::vector<std::pair<float, int>> score_neighbor;
+  std::vector<float> texels1(n);
+  for (int nb = 0; nb < n_neighbors; ++nb) {
+    const float* R = R_nr + 9 * nb; const float* t = t_nr + 3 * nb;
+    // H = R_nr + (1.f / d) * t_nr * normal.t()
+    const float inv_d = 1.f / d;
+    float H[9];
+    for (int i = 0; i < 3; ++i) { const float ti = inv_d * t[i]; for (int j = 0; j < 3; ++j) H[3 * i + j] = R[3 * i + j] + ti * normal[j]; }
+    int k = 0; bool outside = false;
+    for (int i = 0; i < w && !outside; i += ref.step)
+      for (int j = 0; j < w; j += ref.step) {
+        const float* uv = unit + 3 * ((size_t)(py - hw + i) * ref.cols + (px - hw + j));
+        float X1[3];
+        for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += H[3 * r + c] * uv[c]; X1[r] = s; }   // Matx33f * Point3f
+        float x1[2];
+        eq.CamToImage(X1, x1);
+        if (!(x1[0] >= 1 && x1[1] >= 1 && x1[0] < ref.cols - 1 && x1[1] < ref.rows - 1)) { outside = true; break; }   // frame.IsInside(x1, 1, 1)
+        texels1[k++] = MvsSample(nei_gray[nb], ref.cols, x1[0], x1[1]);
+      }
+    if (outside) continue;                                                                                          // goto next_image
+    float sq1 = 0, sq01 = 0, sum = 0;
+    for (int i = 0; i < n; ++i) sum += texels1[i] * patch.weight[i];
+    for (int i = 0; i < n; ++i) texels1[i] -= sum;
+    for (int i = 0; i < n; ++i) sq1 += texels1[i] * texels1[i] * patch.weight[i];
+    const float nrm = patch.sq0 * sq1;
+    for (int i = 0; i < n; ++i) sq01 += patch.texels0[i] * texels1[i];
+    if (nrm <= 0.f) continue;
+    const float ncc = sq01 / std::sqrt(nrm);
+    score_neighbor.push_back({std::min(std::max(ncc, -1.f), 1.f), nb});
+  }
+  if (score_neighbor.empty()) return -1;
+  if (score_neighbor.size() == 1) return score_neighbor[0].first;
+  std::sort(score_neighbor.begin(), score_neighbor.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
+  float avg = 0; int count = 0;
+  for (const auto& p : score_neighbor) { if (count >= 2) break; avg += p.first; count++; }
+  return avg / count;
+}
+
+// InitPatchMap + InitConfMap(use_geometry = false): conf / depth / normal are in-out (rows x cols, rows x cols, rows x cols x 3)
+inline void InitConfMap(const MvsView& ref, int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr,
+                        float* depth, float* normal, float* conf) {
+  std::vector<float> unit((size_t)ref.rows * ref.cols * 3);
+  const Equirectangular eq(ref.rows, ref.cols);
+  for (int i = 0; i < ref.rows; ++i)
+    for (int j = 0; j < ref.cols; ++j) { const float px[2] = {(float)j, (float)i}; eq.ImageToCam(px, 1.f, &unit[3 * ((size_t)i * ref.cols + j)]); }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+  for (int row = 0; row < ref.rows; ++row) {
+    PixelPatch patch;
+    for (int col = 0; col < ref.cols; ++col) {
+      const size_t e = (size_t)row * ref.cols + col;
+      if (depth[e] <= 0) continue;
+      float c = -1;
+      FillPixelPatch(ref, col, row, patch);
+      if (patch.ok && patch.sq0 > 0) c = ScorePixelPhotometric(ref, unit.data(), col, row, normal + 3 * e, depth[e], patch, n_neighbors, nei_gray, R_nr, t_nr);
+      conf[e] = c;
+      if (c <= -1) { depth[e] = 0; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; }
+    }
+  }
+}
+
+}  // namespace oracle

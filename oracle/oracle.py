@@ -297,6 +297,30 @@ def project_lidar_depth(rows, cols, xyz, T_cl, size=3):
     return out
 
 
+def mvs_init_conf_map(ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_window=3, step=1, conf=None):
+    """InitPatchMap + InitConfMap(use_geometry=False) (mvs/MVS.cpp:586-680, :774-923).  Returns (conf, depth, normal) copies:
+    conf = score of every pixel with depth > 0 (-1 = invalid; depth / normal of those are zeroed), other pixels keep `conf`."""
+    ref = np.ascontiguousarray(ref_gray, np.uint8); rows, cols = ref.shape
+    neis = [np.ascontiguousarray(g, np.uint8) for g in nei_grays]
+    ptrs = (C.POINTER(C.c_ubyte) * max(len(neis), 1))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in neis])
+    R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
+    d = np.array(depth, np.float32, copy=True); nrm = np.array(normal, np.float32, copy=True)
+    c = np.zeros((rows, cols), np.float32) if conf is None else np.array(conf, np.float32, copy=True)
+    lib().orc_mvs_init_conf_map(C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte), C.c_int(len(neis)), ptrs,
+                                _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float))
+    return c, d, nrm
+
+
+def mvs_fill_patch(gray, px, py, half_window=3, step=1):
+    g = np.ascontiguousarray(gray, np.uint8); rows, cols = g.shape
+    w = 2 * half_window + 1; q = w // step + (1 if step > 1 else 0); n = q * q
+    weight = np.zeros(n, np.float32); tex = np.zeros(n, np.float32)
+    lib().orc_mvs_fill_patch.restype = C.c_float
+    sq0 = lib().orc_mvs_fill_patch(C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(g, C.c_ubyte), C.c_int(px), C.c_int(py),
+                                   _p(weight, C.c_float), _p(tex, C.c_float))
+    return weight, tex, float(sq0)
+
+
 def image_to_cam(rows, cols, px, r=1.0):
     px = np.ascontiguousarray(px)
     if px.dtype == np.float32:

@@ -9,6 +9,7 @@
 #include "associate.hpp"
 #include "costfunction.hpp"
 #include "equirect.hpp"
+#include "mvs.hpp"
 
 using namespace oracle;
 
@@ -212,6 +213,20 @@ void orc_project_lidar_depth(int rows, int cols, long n, const float* xyz, const
     for (int u = lty; u <= rby; ++u)
       for (int v = ltx; v <= rbx; ++v) out[size_t(u) * cols + v] = rel;
   }
+}
+
+// MVS photometric scoring pass (InitPatchMap + InitConfMap, mvs/MVS.cpp:586-680, :774-923): depth / normal / conf in-out.
+void orc_mvs_init_conf_map(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                           const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf) {
+  MvsView v{rows, cols, half_window, step, ref_gray};
+  InitConfMap(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf);
+}
+// one pixel's patch: weight / texels0 (num_texels each), returns sq0 (<= 1e-6 or outside = invalid -> -1)
+float orc_mvs_fill_patch(int rows, int cols, int half_window, int step, const unsigned char* gray, int px, int py, float* weight, float* texels0) {
+  MvsView v{rows, cols, half_window, step, gray};
+  PixelPatch p; FillPixelPatch(v, px, py, p);
+  for (size_t i = 0; i < p.weight.size(); ++i) { weight[i] = p.weight[i]; texels0[i] = p.texels0[i]; }
+  return p.ok ? p.sq0 : -1.f;
 }
 
 void orc_cam_to_image_d(int rows, int cols, long n, const double* cam, double* px) { Equirectangular eq(rows, cols); for (long i = 0; i < n; ++i) eq.CamToImage(cam + 3 * i, px + 2 * i); }

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -206,6 +206,19 @@ class Context:
                                                    _p(blocks, C.c_double), _p(_f64(scale), C.c_double), _p(_f64(diag_add), C.c_double),
                                                    _p(x, C.c_double), C.byref(info)), "pvlm_spd_solve_blocks")
         return x, info.value
+
+    def mvs_init_conf_map(self, ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_window=3, step=1, conf=None):
+        """MVS::InitPatchMap + InitConfMap(use_geometry=False) on the GPU: returns (conf, depth, normal) copies."""
+        ref = np.ascontiguousarray(ref_gray, np.uint8); rows, cols = ref.shape
+        neis = [np.ascontiguousarray(g, np.uint8) for g in nei_grays]
+        ptrs = (C.POINTER(C.c_ubyte) * max(len(neis), 1))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in neis])
+        R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
+        d = np.array(depth, np.float32, copy=True); nrm = np.array(normal, np.float32, copy=True)
+        c = np.zeros((rows, cols), np.float32) if conf is None else np.array(conf, np.float32, copy=True)
+        self._check(self.lib.pvlm_mvs_init_conf_map(self._h, C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte),
+                                                    C.c_int(len(neis)), ptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float),
+                                                    _p(c, C.c_float)), "pvlm_mvs_init_conf_map")
+        return c, d, nrm
 
     def project_lidar_depth(self, rows, cols, xyz, T_cl, size=3):
         xyz = _f32(xyz).reshape(-1, 3); T = _f64(T_cl).reshape(16)

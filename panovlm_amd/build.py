@@ -43,7 +43,7 @@ def build(force=False, verbose=False):
         flags = list(common) + os.environ.get("PVLM_DEFINES", "").split()
         # association kernels make accept/reject decisions that must be bit-identical to a
         # non-FMA x86-64 build of the reference: no contraction there.
-        if os.path.basename(src) in ("pvlm_assoc.hip", "pvlm_lines.hip"):
+        if os.path.basename(src) in ("pvlm_assoc.hip", "pvlm_lines.hip", "pvlm_mvs.hip"):
             flags.append("-ffp-contract=off")
         cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
         if verbose:

@@ -1,0 +1,168 @@
+// Photometric scoring pass of the reference's panoramic PatchMatch MVS: MVS::InitPatchMap + MVS::InitConfMap(use_geometry =
+// false) (mvs/MVS.cpp:586-636) = FillPixelPatch (:637-680) + the photometric term of ScorePixel (:774-923) for the current
+// depth / normal hypothesis of every pixel.  First kernel of SURVEY.md §8 N4's second part.
+//
+// One wave per reference pixel, one lane per texel of the NCC window (7 x 7 = 49 at the Room settings; larger windows
+// loop): the bilateral weights, the plane-induced homography H = R_nr + t_nr n^T / d, the equirectangular re-projection
+// (the same FastAtan2 arithmetic as K7) and the bilinear samples are per-lane work, the weighted means / variances are
+// wave reductions (tree order: float sums differ from the reference's sequential order by rounding, ~1e-7 relative).
+// Threshold decisions (d > 0, projection inside the image, sq0 <= 1e-6) use the reference's float arithmetic —
+// compiled with -ffp-contract=off.  Images stay in HBM as uint8; the PreComputeI2C table is built on the device.
+#include <vector>
+
+#include "pvlm_internal.h"
+
+#define PVLM_HD __host__ __device__
+#include "pvlm_mvs_core.h"
+
+#define PVLM_MVS_MAXM 4   // texels per lane: windows up to 256 texels
+
+__device__ inline float wave_sum_f(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return __shfl(x, 0, 64);
+}
+
+__global__ void k_mvs_unit_table(int rows, int cols, float* __restrict__ unit) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)rows * cols) return;
+  pvlm_mvs::unit_ray(rows, cols, (int)(e % cols), (int)(e / cols), unit + 3 * e);
+}
+
+struct pvlm_mvs_neighbours { const unsigned char* gray[16]; float R[16][9]; float t[16][3]; int n; };
+
+__global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
+                                                  const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* __restrict__ depth,
+                                                  float* __restrict__ normal, float* __restrict__ conf) {
+  const long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per pixel
+  const int lane = threadIdx.x & 63;
+  if (e >= (long long)rows * cols) return;
+  const float dep = depth[e];
+  if (dep <= 0) return;                                                   // InitConfMap :594-595
+  const int py = (int)(e / cols), px = (int)(e % cols);
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  float c = -1.f;
+  // ---- FillPixelPatch
+  const bool inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
+  float w[PVLM_MVS_MAXM], t0[PVLM_MVS_MAXM];
+  float sq0 = 0.f;
+  if (inside) {
+    float part = 0.f;
+#pragma unroll
+    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+      const int k = lane + 64 * m;
+      w[m] = 0.f; t0[m] = 0.f;
+      if (k < n) pvlm_mvs::patch_texel(ref_gray, cols, px, py, half_window, step, k, &w[m], &t0[m]);
+      part += w[m];
+    }
+    const float wsum = wave_sum_f(part);
+    part = 0.f;
+#pragma unroll
+    for (int m = 0; m < PVLM_MVS_MAXM; ++m) { w[m] /= wsum; part += w[m] * t0[m]; }
+    const float mean = wave_sum_f(part);
+    part = 0.f;
+#pragma unroll
+    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+      const int k = lane + 64 * m;
+      if (k < n) { t0[m] -= mean; const float tmp = t0[m] * w[m]; part += t0[m] * tmp; t0[m] = tmp; } else t0[m] = 0.f;
+    }
+    sq0 = wave_sum_f(part);
+  }
+  if (inside && !(sq0 <= 1e-6) && sq0 > 0) {
+    // ---- ScorePixel, photometric term
+    const float* u0 = unit + 3 * e;
+    const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
+    const float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+    const float d = X0[0] * nrm3[0] + X0[1] * nrm3[1] + X0[2] * nrm3[2];
+    if (!(d > 0)) {
+      float best1 = 0.f, best2 = 0.f; int count = 0;
+      for (int b = 0; b < nb.n; ++b) {
+        float H[9];
+        pvlm_mvs::homography(nb.R[b], nb.t[b], nrm3, d, H);
+        float t1[PVLM_MVS_MAXM];
+        bool ok = true;
+        float part = 0.f;
+#pragma unroll
+        for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+          const int k = lane + 64 * m;
+          t1[m] = 0.f;
+          if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b], rows, cols, H, px, py, half_window, step, k, &t1[m]) && ok;
+          part += t1[m] * w[m];
+        }
+        if (__any(!ok)) continue;                                          // goto next_image
+        const float sum = wave_sum_f(part);
+        float p1 = 0.f, p01 = 0.f;
+#pragma unroll
+        for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+          const int k = lane + 64 * m;
+          if (k < n) { t1[m] -= sum; p1 += t1[m] * t1[m] * w[m]; p01 += t0[m] * t1[m]; }
+        }
+        const float sq1 = wave_sum_f(p1), sq01 = wave_sum_f(p01);
+        const float nrm = sq0 * sq1;
+        if (nrm <= 0.f) continue;
+        float score = sq01 / sqrtf(nrm);
+        score = fminf(fmaxf(score, -1.f), 1.f);
+        if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+        ++count;
+      }
+      if (count == 1) c = best1;
+      else if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; c = avg / 2; }
+    }
+  }
+  if (lane == 0) {
+    conf[e] = c;
+    if (c <= -1) { depth[e] = 0; normal[3 * e] = 0; normal[3 * e + 1] = 0; normal[3 * e + 2] = 0; }
+  }
+}
+
+extern "C" {
+
+pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                   const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf) {
+  if (!ctx || rows <= 0 || cols <= 0 || half_window < 1 || step < 1 || !ref_gray || n_neighbors < 0 || n_neighbors > 16 || !depth || !normal || !conf ||
+      (n_neighbors > 0 && (!nei_gray || !R_nr || !t_nr)))
+    return PVLM_ERR_ARG;
+  if (pvlm_mvs::num_texels(half_window, step) > 64 * PVLM_MVS_MAXM) { PVLM_SET_ERR(ctx, "NCC window of %d texels exceeds %d", pvlm_mvs::num_texels(half_window, step), 64 * PVLM_MVS_MAXM); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t npix = (size_t)rows * cols;
+  unsigned char* d_img = nullptr; float *d_unit = nullptr, *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_img, npix * (size_t)(n_neighbors + 1));
+  if (!st) st = pvlm_i_alloc(ctx, &d_unit, npix * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_depth, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_normal, npix * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_conf, npix);
+  if (!st) {
+    hipStream_t s = ctx->stream;
+    pvlm_mvs_neighbours nb;
+    nb.n = n_neighbors;
+    hipError_t e = hipMemcpyAsync(d_img, ref_gray, npix, hipMemcpyHostToDevice, s);
+    for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
+      if (!nei_gray[b]) { e = hipErrorInvalidValue; break; }
+      e = hipMemcpyAsync(d_img + npix * (size_t)(b + 1), nei_gray[b], npix, hipMemcpyHostToDevice, s);
+      nb.gray[b] = d_img + npix * (size_t)(b + 1);
+      for (int k = 0; k < 9; ++k) nb.R[b][k] = R_nr[9 * b + k];
+      for (int k = 0; k < 3; ++k) nb.t[b][k] = t_nr[3 * b + k];
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_normal, normal, npix * 3 * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_conf, conf, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_unit);
+      {
+        pvlm_prof_scope prof(ctx, 1);   // timed with the "materialise" slot of pvlm_profile_* (bench / tools)
+        hipLaunchKernelGGL(k_mvs_conf, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf);
+      }
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(depth, d_depth, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(normal, d_normal, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(conf, d_conf, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_init_conf_map: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_img); hipFree(d_unit); hipFree(d_depth); hipFree(d_normal); hipFree(d_conf);
+  return st;
+}
+
+}  // extern "C"

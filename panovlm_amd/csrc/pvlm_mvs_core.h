@@ -1,0 +1,93 @@
+// Per-texel bodies of the panoramic MVS scoring kernel (photometric term of ScorePixel, mvs/MVS.cpp:774-923, with
+// FillPixelPatch :637-680 and the bilinear Sample).  Plain float arithmetic in the reference's order; host/device so
+// that tests/cpp/mvs_math_check.cpp can drive the same functions serially on a machine without a GPU.
+#pragma once
+#include <cfloat>
+#include <cmath>
+
+#ifndef PVLM_HD
+#define PVLM_HD __host__ __device__
+#endif
+
+namespace pvlm_mvs {
+
+// FastAtan2<float> (base/Math.h:15-29): polynomial evaluated in double (double literals), rounded to float on assignment
+PVLM_HD inline float fast_atan2f(float y, float x) {
+  const float ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
+  const float mn = ay < ax ? ay : ax, mx = ax < ay ? ay : ax;
+  const float a = mn / (mx + (float)DBL_EPSILON);
+  const float s = a * a;
+  float r = ((-0.04432655554792128 * s + 0.1555786518463281) * s - 0.3258083974640975) * s * a + 0.9997878412794807 * a;
+  if (ay > ax) r = 1.57079632679489661923 - r;
+  if (x < 0) r = 3.14159265358979323846 - r;
+  if (y < 0) r = -r;
+  return r;
+}
+
+// Equirectangular::CamToImage<float> (sensors/Equirectangular.h:50-51, :84-85)
+PVLM_HD inline void cam_to_image(int rows, int cols, const float* X, float* px) {
+  const float lon = fast_atan2f(X[0], X[2]);
+  const float lat = -fast_atan2f(X[1], (float)sqrt((double)(X[0] * X[0] + X[2] * X[2])));
+  px[0] = (float)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
+  px[1] = (float)(rows * (0.5 - lat / 3.14159265358979323846));
+}
+
+// Equirectangular::ImageToCam<float>(pixel, 1.f) of an integer pixel — the PreComputeI2C table (Equirectangular.cpp:12-19)
+PVLM_HD inline void unit_ray(int rows, int cols, int col, int row, float* cam) {
+  const float sx = (float)((2 * (float)col / cols - 1) * 3.14159265358979323846);
+  const float sy = (float)((0.5 - (float)row / rows) * 3.14159265358979323846);
+  const float cy = (float)cos((double)sy);
+  cam[0] = 1.f * cy * (float)sin((double)sx);
+  cam[1] = -1.f * (float)sin((double)sy);
+  cam[2] = 1.f * cy * (float)cos((double)sx);
+}
+
+PVLM_HD inline int num_texels(int half_window, int step) {
+  const int w = 2 * half_window + 1, q = w / step + (step > 1 ? 1 : 0);
+  return q * q;
+}
+// texel k of the window -> offsets (di, dj) from the top-left corner, as the reference's i / j loops visit them
+PVLM_HD inline void texel_offset(int half_window, int step, int k, int* di, int* dj) {
+  const int w = 2 * half_window + 1, q = w / step + (step > 1 ? 1 : 0);
+  *di = (k / q) * step; *dj = (k % q) * step;
+}
+
+// FillPixelPatch, per texel: un-normalised bilateral weight and the grey value
+PVLM_HD inline void patch_texel(const unsigned char* gray, int cols, int px, int py, int half_window, int step, int k, float* weight, float* texel) {
+  int di, dj; texel_offset(half_window, step, k, &di, &dj);
+  const int row = py - half_window + di, col = px - half_window + dj;
+  const float sigma_color = (float)(-1.f / (2 * 0.2 * 0.2));
+  const float sigma_spatial = -1.f / (2.f * half_window * half_window);
+  const unsigned char center = gray[(size_t)py * cols + px], tex = gray[(size_t)row * cols + col];
+  float wColor = (tex - center) / 255.f;
+  wColor = wColor * wColor * sigma_color;
+  const float wSpatial = ((float)((col - px) * (col - px)) + (float)((row - py) * (row - py))) * sigma_spatial;
+  *weight = expf(wColor + wSpatial);
+  *texel = tex;
+}
+
+// H = R_nr + (1.f / d) * t_nr * normal^T   (row-major 3x3)
+PVLM_HD inline void homography(const float* R, const float* t, const float* normal, float d, float* H) {
+  const float inv_d = 1.f / d;
+  for (int i = 0; i < 3; ++i) { const float ti = inv_d * t[i]; for (int j = 0; j < 3; ++j) H[3 * i + j] = R[3 * i + j] + ti * normal[j]; }
+}
+
+// one texel of the neighbour patch: project the reference texel's unit ray through H, test frame.IsInside(x1, 1, 1),
+// sample bilinearly.  Returns false when the projection leaves the image (the whole neighbour is then skipped).
+PVLM_HD inline bool neighbour_texel(const float* unit, const unsigned char* nei_gray, int rows, int cols, const float* H, int px, int py, int half_window,
+                                    int step, int k, float* value) {
+  int di, dj; texel_offset(half_window, step, k, &di, &dj);
+  const float* uv = unit + 3 * ((size_t)(py - half_window + di) * cols + (px - half_window + dj));
+  float X1[3];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += H[3 * r + c] * uv[c]; X1[r] = s; }
+  float x1[2];
+  cam_to_image(rows, cols, X1, x1);
+  if (!(x1[0] >= 1 && x1[1] >= 1 && x1[0] < cols - 1 && x1[1] < rows - 1)) return false;
+  const int lx = (int)x1[0], ly = (int)x1[1];
+  const float fx = x1[0] - lx, fy = x1[1] - ly, ax = 1.f - fx, ay = 1.f - fy;
+  const unsigned char* p = nei_gray + (size_t)ly * cols + lx;
+  *value = (p[0] * ax + p[1] * fx) * ay + (p[cols] * ax + p[cols + 1] * fx) * fy;
+  return true;
+}
+
+}  // namespace pvlm_mvs

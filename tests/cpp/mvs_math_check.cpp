@@ -1,0 +1,63 @@
+// Host-compiled check of the per-texel device bodies in panovlm_amd/csrc/pvlm_mvs_core.h: the same functions the HIP
+// kernel k_mvs_conf calls, composed serially (one "lane" after the other, plain left-to-right sums) so that the
+// per-texel arithmetic and the composition logic can be compared with the oracle on a machine without a GPU
+// (tests/test_mvs_cpu.py).  TEST INFRASTRUCTURE ONLY — libpvlm.so has no host path.
+#include <vector>
+
+#define PVLM_HD
+#include "../../panovlm_amd/csrc/pvlm_mvs_core.h"
+
+extern "C" void chk_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                             const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf) {
+  using namespace pvlm_mvs;
+  std::vector<float> unit((size_t)rows * cols * 3);
+  for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) unit_ray(rows, cols, c, r, &unit[3 * ((size_t)r * cols + c)]);
+  const int n = num_texels(half_window, step);
+  std::vector<float> w(n), t0(n), t1(n);
+  for (int py = 0; py < rows; ++py)
+    for (int px = 0; px < cols; ++px) {
+      const size_t e = (size_t)py * cols + px;
+      const float dep = depth[e];
+      if (dep <= 0) continue;
+      float c = -1.f, sq0 = 0.f;
+      const bool inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
+      if (inside) {
+        float wsum = 0.f;
+        for (int k = 0; k < n; ++k) { patch_texel(ref_gray, cols, px, py, half_window, step, k, &w[k], &t0[k]); wsum += w[k]; }
+        float mean = 0.f;
+        for (int k = 0; k < n; ++k) { w[k] /= wsum; mean += w[k] * t0[k]; }
+        for (int k = 0; k < n; ++k) { t0[k] -= mean; const float tmp = t0[k] * w[k]; sq0 += t0[k] * tmp; t0[k] = tmp; }
+      }
+      if (inside && !(sq0 <= 1e-6) && sq0 > 0) {
+        const float* u0 = &unit[3 * e];
+        const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
+        const float* nr = normal + 3 * e;
+        const float d = X0[0] * nr[0] + X0[1] * nr[1] + X0[2] * nr[2];
+        if (!(d > 0)) {
+          float best1 = 0.f, best2 = 0.f; int count = 0;
+          for (int b = 0; b < n_neighbors; ++b) {
+            float H[9];
+            homography(R_nr + 9 * b, t_nr + 3 * b, nr, d, H);
+            bool ok = true;
+            for (int k = 0; k < n && ok; ++k) ok = neighbour_texel(unit.data(), nei_gray[b], rows, cols, H, px, py, half_window, step, k, &t1[k]);
+            if (!ok) continue;
+            float sum = 0.f, sq1 = 0.f, sq01 = 0.f;
+            for (int k = 0; k < n; ++k) sum += t1[k] * w[k];
+            for (int k = 0; k < n; ++k) t1[k] -= sum;
+            for (int k = 0; k < n; ++k) sq1 += t1[k] * t1[k] * w[k];
+            for (int k = 0; k < n; ++k) sq01 += t0[k] * t1[k];
+            const float nrm = sq0 * sq1;
+            if (nrm <= 0.f) continue;
+            float score = sq01 / sqrtf(nrm);
+            score = fminf(fmaxf(score, -1.f), 1.f);
+            if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+            ++count;
+          }
+          if (count == 1) c = best1;
+          else if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; c = avg / 2; }
+        }
+      }
+      conf[e] = c;
+      if (c <= -1) { depth[e] = 0; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; }
+    }
+}

@@ -210,3 +210,36 @@ def covisible_pairs(off, cam):
                     up.add((min(cs[i], cs[j]), max(cs[i], cs[j])))
     up = sorted(up)
     return np.array([u[0] for u in up], np.int32), np.array([u[1] for u in up], np.int32)
+
+
+# ---- panoramic MVS scenes: a textured box room rendered as equirectangular grey images -------------------------------
+def _room_texture(P):
+    x, y, z = P[..., 0], P[..., 1], P[..., 2]
+    g = 128 + 45 * np.sin(3.1 * x + 1.3 * y) * np.cos(2.3 * z) + 35 * np.sin(6.7 * y + 2.1 * z + 0.5 * x) + 25 * np.cos(9.3 * x - 4.1 * z) * np.sin(5.9 * y)
+    return np.clip(g, 0, 255)
+
+
+def render_panorama(oracle, rows, cols, R_wc, t_wc, half=(4.0, 1.5, 6.0)):
+    """Grey equirectangular image of the inside of the box [-half, half] seen from the camera pose (R_wc, t_wc), with the
+    true depth (distance along the ray) and the surface normal in the camera frame, facing the camera."""
+    jj, ii = np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32))
+    px = np.stack([jj.reshape(-1), ii.reshape(-1)], axis=1)
+    dirs = oracle.image_to_cam(rows, cols, px, 1.0).astype(np.float64)                   # unit rays, camera frame
+    dw = dirs @ np.asarray(R_wc, np.float64).T
+    o = np.asarray(t_wc, np.float64)
+    h = np.asarray(half)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tpos = np.where(dw > 0, (h - o) / dw, np.where(dw < 0, (-h - o) / dw, np.inf))
+    axis = np.argmin(tpos, axis=1); t = tpos[np.arange(len(tpos)), axis]
+    P = o + dw * t[:, None]
+    n_w = np.zeros_like(P); n_w[np.arange(len(P)), axis] = -np.sign(dw[np.arange(len(P)), axis])
+    gray = np.rint(_room_texture(P)).astype(np.uint8).reshape(rows, cols)
+    normal = (n_w @ np.asarray(R_wc, np.float64)).astype(np.float32).reshape(rows, cols, 3)
+    return gray, t.astype(np.float32).reshape(rows, cols), normal
+
+
+def relative_pose(R_wr, t_wr, R_wn, t_wn):
+    """(R_nr, t_nr): X_n = R_nr X_r + t_nr — reference camera frame to neighbour camera frame (mvs NeighborInfo)."""
+    R = np.asarray(R_wn).T @ np.asarray(R_wr)
+    t = np.asarray(R_wn).T @ (np.asarray(t_wr) - np.asarray(t_wn))
+    return R.astype(np.float32), t.astype(np.float32)

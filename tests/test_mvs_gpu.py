@@ -1,0 +1,48 @@
+"""GPU parity of the panoramic MVS scoring pass (pvlm_mvs_init_conf_map: MVS::InitPatchMap + InitConfMap, mvs/MVS.cpp:586-680,
+:774-923) against the CPU oracle, through the C ABI.  float32: the kernel's wave-tree sums and device expf differ from the
+reference's sequential sums / libm by rounding, so scores are compared to 1e-4 absolute (observed ~1e-6); every validity
+decision (patch inside / textured, plane facing the camera, window projecting inside the neighbour) must be identical."""
+import numpy as np
+import pytest
+
+from tests.test_mvs_cpu import mvs_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import panovlm_amd as pv
+    c = pv.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("hw,step,rows,cols", [(3, 1, 180, 360), (5, 2, 96, 192), (11, 2, 96, 192)])
+def test_conf_map_matches_oracle(ctx, oracle, hw, step, rows, cols):
+    (gray, depth, normal), neis, Rn, tn = mvs_scene(oracle, rows, cols)
+    rng = np.random.default_rng(7)
+    depth = depth * rng.uniform(0.9, 1.1, size=depth.shape).astype(np.float32)
+    depth[5:9, 7:30] = 0
+    keep = np.full(depth.shape, 5.0, np.float32)
+    co, do, no = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, hw, step, conf=keep)
+    cg, dg, ng = ctx.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, hw, step, conf=keep)
+    assert np.array_equal(co == -1, cg == -1) and np.array_equal(co == 5.0, cg == 5.0)
+    assert np.array_equal(dg, do) and np.array_equal(ng, no)
+    valid = (co > -1) & (co != 5.0)
+    assert valid.mean() > 0.6
+    assert np.abs(cg[valid] - co[valid]).max() <= 1e-4, np.abs(cg[valid] - co[valid]).max()
+
+
+def test_conf_map_edge_cases(ctx, oracle):
+    import panovlm_amd as pv
+    (gray, depth, normal), neis, Rn, tn = mvs_scene(oracle, 64, 128)
+    # no neighbours: every pixel with depth gets -1 and loses its hypothesis
+    c, d, n = ctx.mvs_init_conf_map(gray, [], np.zeros((0, 9)), np.zeros((0, 3)), depth, normal)
+    assert np.all(c == -1) and np.all(d == 0) and np.all(n == 0)
+    # a flat (texture-less) reference image: sq0 <= 1e-6 everywhere
+    flat = np.full_like(gray, 100)
+    c, _, _ = ctx.mvs_init_conf_map(flat, neis, Rn, tn, depth, normal)
+    assert np.all(c == -1)
+    with pytest.raises(pv.PvlmError):
+        ctx.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, half_window=20, step=1)      # 41 x 41 texels > 256
