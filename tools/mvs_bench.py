@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Timing of the panoramic MVS scoring pass (pvlm_mvs_init_conf_map, kernel k_mvs_conf) at the Room MVS size (5.7K
+panorama at scale -2 = 1440 x 720, 7 x 7 NCC window, 4 neighbours) beside the CPU oracle (OpenMP) on the same inputs."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=720)
+    ap.add_argument("--cols", type=int, default=1440)
+    ap.add_argument("--neighbors", type=int, default=4)
+    ap.add_argument("--half-window", type=int, default=3)
+    ap.add_argument("--step", type=int, default=1)
+    a = ap.parse_args()
+    from oracle import oracle as orc     # scene rendering + the CPU leg (this is a measurement tool, not the product)
+    from tests import synth
+    import panovlm_amd as pv
+    n = a.neighbors + 1
+    poses = [(synth.rodrigues(np.array([0.02 * k, 0.2 * k - 0.3, 0.01])), np.array([0.3 * k - 0.5, 0.04 * k, 0.2 * k - 0.3])) for k in range(n)]
+    views = [synth.render_panorama(orc, a.rows, a.cols, R, t) for R, t in poses]
+    ref = n // 2
+    nei = [k for k in range(n) if k != ref]
+    Rn, tn = zip(*[synth.relative_pose(poses[ref][0], poses[ref][1], poses[k][0], poses[k][1]) for k in nei])
+    gray, depth, normal = views[ref]
+    neis = [views[k][0] for k in nei]
+    ctx = pv.Context(0)
+    ctx.mvs_init_conf_map(gray, neis, np.array(Rn), np.array(tn), depth, normal, a.half_window, a.step)
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        cg, _, _ = ctx.mvs_init_conf_map(gray, neis, np.array(Rn), np.array(tn), depth, normal, a.half_window, a.step)
+    wall = (time.perf_counter() - t0) / reps
+    ms, cnt = ctx.profile_read(1)
+    ctx.profile_enable(False)
+    t0 = time.perf_counter()
+    co, _, _ = orc.mvs_init_conf_map(gray, neis, np.array(Rn), np.array(tn), depth, normal, a.half_window, a.step)
+    cpu = time.perf_counter() - t0
+    w = 2 * a.half_window + 1; q = w // a.step + (1 if a.step > 1 else 0)
+    texels = a.rows * a.cols * q * q * a.neighbors
+    k_ms = ms / max(cnt, 1)
+    print(json.dumps(dict(rows=a.rows, cols=a.cols, neighbors=a.neighbors, window=[w, a.step], valid=float((cg > -1).mean()),
+                          max_abs_diff_vs_oracle=float(np.abs(cg - co)[(cg > -1) & (co > -1)].max()), kernel_ms=k_ms,
+                          M_pixels_per_s=a.rows * a.cols / k_ms / 1e3, G_texel_projections_per_s=texels / k_ms / 1e6,
+                          wall_ms_incl_copies=wall * 1e3, cpu_oracle_s=cpu, cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
+
+
+if __name__ == "__main__":
+    main()
