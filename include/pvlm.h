@@ -288,10 +288,13 @@ pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t 
  * plane-induced homography R_nr + t_nr n^T / d, averaged over the two best neighbours; conf = -1 (and depth / normal
  * zeroed) where the reference patch is invalid, the plane faces away (d > 0) or no neighbour sees the window.
  * ref_gray / nei_gray[b]: rows x cols uint8; R_nr: n x 9 row-major, t_nr: n x 3 (reference -> neighbour camera);
- * depth (rows x cols), normal (rows x cols x 3, camera frame), conf (rows x cols): float32, in-out. n_neighbors <= 16. */
+ * depth (rows x cols), normal (rows x cols x 3, camera frame), conf (rows x cols): float32, in-out. n_neighbors <= 16.
+ * nei_depth != NULL = InitConfMap(use_geometry = true): nei_depth[b] is neighbour b's photometric depth map
+ * (Frame::depth_filter) and every neighbour score gets the geometric-consistency adjustment of ScorePixel :857-893
+ * (forward / backward projection through that depth map, 0.2 x min(angle in degrees, 2) penalty). */
 pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
                                    const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal,
-                                   float* conf);
+                                   float* conf, const float* const* nei_depth_or_null);
 
 /* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
  * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <limits>
 #include <utility>
 #include <vector>
 
@@ -74,10 +75,58 @@ inline float MvsSample(const uint8_t* img, int cols, float x, float y) {
   return (p[0] * x1 + p[1] * fx) * y1 + (p[cols] * x1 + p[cols + 1] * fx) * fy;
 }
 
-// ScorePixel, photometric term only.  unit = PreComputeI2C table (rows x cols x 3 float).  R_nr / t_nr: neighbour n at
+// Sample(img, pt, functor) (mvs/MVS.cpp:1445-1467): bilinear sample of a float image that ignores the corners the functor
+// rejects (each rejected corner is replaced by its neighbours in a fixed preference order); +inf when all four fail.
+template <typename F>
+inline float MvsSampleDepth(const float* img, int cols, float x, float y, const F& ok) {
+  const int lx = (int)x, ly = (int)y;
+  const float fx = x - lx, fy = y - ly, x1 = 1.f - fx, y1 = 1.f - fy;
+  const float x0y0 = img[(size_t)ly * cols + lx], x1y0 = img[(size_t)ly * cols + lx + 1];
+  const float x0y1 = img[(size_t)(ly + 1) * cols + lx], x1y1 = img[(size_t)(ly + 1) * cols + lx + 1];
+  const bool b00 = ok(x0y0), b10 = ok(x1y0), b01 = ok(x0y1), b11 = ok(x1y1);
+  if (!b00 && !b10 && !b01 && !b11) return std::numeric_limits<float>::infinity();
+  return float(y1 * (x1 * (b00 ? x0y0 : (b10 ? x1y0 : (b01 ? x0y1 : x1y1))) + fx * (b10 ? x1y0 : (b00 ? x0y0 : (b11 ? x1y1 : x0y1)))) +
+               fy * (x1 * (b01 ? x0y1 : (b11 ? x1y1 : (b00 ? x0y0 : x1y0))) + fx * (b11 ? x1y1 : (b01 ? x0y1 : (b10 ? x1y0 : x0y0)))));
+}
+
+// geometric-consistency adjustment of one neighbour's score (ScorePixel :857-893): forward-project X0 into the neighbour,
+// read the neighbour's (photometric) depth there, back-project and penalise the angle between X0 and the returned point.
+inline float GeometricAdjust(float score, const Equirectangular& eq, const float* X0, const float* R, const float* t, const float* nei_depth) {
+  const float geometric_weight = 0.2; float consistency = 2;
+  float X1[3];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += R[3 * r + c] * X0[c]; X1[r] = s + t[r]; }
+  const float depth0 = (float)std::sqrt((double)X1[0] * X1[0] + (double)X1[1] * X1[1] + (double)X1[2] * X1[2]);   // cv::norm(Point3f) -> double
+  float x1[2];
+  eq.CamToImage(X1, x1);
+  score = 1 - score;
+  if (x1[0] >= 1 && x1[1] >= 1 && x1[0] < eq.cols - 1 && x1[1] < eq.rows - 1) {
+    const float depth1 = MvsSampleDepth(nei_depth, eq.cols, x1[0], x1[1], [depth0](const float& d) { return std::abs(depth0 - d) / depth0 < 0.03f; });
+    if (!std::isinf(depth1)) {
+      float cam[3];
+      eq.ImageToCam(x1, depth1, cam);
+      // R_rn = R_nr^T ; t_rn = (-R_rn) * t_nr ; X0_back = R_rn * cam + t_rn
+      float t_rn[3], Xb[3];
+      for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += (-R[3 * c + r]) * t[c]; t_rn[r] = s; }
+      for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += R[3 * c + r] * cam[c]; Xb[r] = s + t_rn[r]; }
+      // VectorAngle3D(X0, X0_back, false) in float, then * 180.0 / M_PI in double, stored as float
+      float cosang = X0[0] * Xb[0] + X0[1] * Xb[1] + X0[2] * Xb[2];
+      const float n1 = std::sqrt(X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2]), n2 = std::sqrt(Xb[0] * Xb[0] + Xb[1] * Xb[1] + Xb[2] * Xb[2]);
+      cosang /= (n1 * n2);
+      const float ang = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)M_PI : std::acos(cosang));
+      const float diff_angle = ang * 180.0 / M_PI;
+      consistency = std::min(diff_angle, consistency);
+    }
+  }
+  score += geometric_weight * consistency;
+  score = 1 - score;
+  return std::min(1.f, std::max(-1.f, score));
+}
+
+// ScorePixel, photometric term (+ the geometric-consistency term when nei_depth != nullptr).  unit = PreComputeI2C table (rows x cols x 3 float).  R_nr / t_nr: neighbour n at
 // R + 9 n / t + 3 n (row-major).  Returns the aggregated score (-1 = invalid).
 inline float ScorePixelPhotometric(const MvsView& ref, const float* unit, int px, int py, const float* normal, float depth, const PixelPatch& patch,
-                                   int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr) {
+                                   int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr,
+                                   const float* const* nei_depth = nullptr) {
   const Equirectangular eq(ref.rows, ref.cols);
   const float* u0 = unit + 3 * ((size_t)py * ref.cols + px);
   const float X0[3] = {u0[0] * depth, u0[1] * depth, u0[2] * depth};
@@ -112,7 +161,9 @@ inline float ScorePixelPhotometric(const MvsView& ref, const float* unit, int px
     for (int i = 0; i < n; ++i) sq01 += patch.texels0[i] * texels1[i];
     if (nrm <= 0.f) continue;
     const float ncc = sq01 / std::sqrt(nrm);
-    score_neighbor.push_back({std::min(std::max(ncc, -1.f), 1.f), nb});
+    float score = std::min(std::max(ncc, -1.f), 1.f);
+    if (nei_depth) score = GeometricAdjust(score, eq, X0, R, t, nei_depth[nb]);
+    score_neighbor.push_back({score, nb});
   }
   if (score_neighbor.empty()) return -1;
   if (score_neighbor.size() == 1) return score_neighbor[0].first;
@@ -122,9 +173,9 @@ inline float ScorePixelPhotometric(const MvsView& ref, const float* unit, int px
   return avg / count;
 }
 
-// InitPatchMap + InitConfMap(use_geometry = false): conf / depth / normal are in-out (rows x cols, rows x cols, rows x cols x 3)
+// InitPatchMap + InitConfMap(use_geometry = nei_depth != nullptr; nei_depth[b] = neighbour b's depth_filter): conf / depth / normal are in-out (rows x cols, rows x cols, rows x cols x 3)
 inline void InitConfMap(const MvsView& ref, int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr,
-                        float* depth, float* normal, float* conf) {
+                        float* depth, float* normal, float* conf, const float* const* nei_depth = nullptr) {
   std::vector<float> unit((size_t)ref.rows * ref.cols * 3);
   const Equirectangular eq(ref.rows, ref.cols);
   for (int i = 0; i < ref.rows; ++i)
@@ -139,7 +190,7 @@ inline void InitConfMap(const MvsView& ref, int n_neighbors, const uint8_t* cons
       if (depth[e] <= 0) continue;
       float c = -1;
       FillPixelPatch(ref, col, row, patch);
-      if (patch.ok && patch.sq0 > 0) c = ScorePixelPhotometric(ref, unit.data(), col, row, normal + 3 * e, depth[e], patch, n_neighbors, nei_gray, R_nr, t_nr);
+      if (patch.ok && patch.sq0 > 0) c = ScorePixelPhotometric(ref, unit.data(), col, row, normal + 3 * e, depth[e], patch, n_neighbors, nei_gray, R_nr, t_nr, nei_depth);
       conf[e] = c;
       if (c <= -1) { depth[e] = 0; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; }
     }

@@ -297,7 +297,7 @@ def project_lidar_depth(rows, cols, xyz, T_cl, size=3):
     return out
 
 
-def mvs_init_conf_map(ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_window=3, step=1, conf=None):
+def mvs_init_conf_map(ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_window=3, step=1, conf=None, nei_depths=None):
     """InitPatchMap + InitConfMap(use_geometry=False) (mvs/MVS.cpp:586-680, :774-923).  Returns (conf, depth, normal) copies:
     conf = score of every pixel with depth > 0 (-1 = invalid; depth / normal of those are zeroed), other pixels keep `conf`."""
     ref = np.ascontiguousarray(ref_gray, np.uint8); rows, cols = ref.shape
@@ -306,8 +306,12 @@ def mvs_init_conf_map(ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_windo
     R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
     d = np.array(depth, np.float32, copy=True); nrm = np.array(normal, np.float32, copy=True)
     c = np.zeros((rows, cols), np.float32) if conf is None else np.array(conf, np.float32, copy=True)
+    dptrs = None
+    if nei_depths is not None:      # use_geometry = true: the neighbours' photometric depth maps (depth_filter)
+        nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
+        dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
     lib().orc_mvs_init_conf_map(C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte), C.c_int(len(neis)), ptrs,
-                                _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float))
+                                _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float), dptrs)
     return c, d, nrm
 
 

@@ -217,9 +217,10 @@ void orc_project_lidar_depth(int rows, int cols, long n, const float* xyz, const
 
 // MVS photometric scoring pass (InitPatchMap + InitConfMap, mvs/MVS.cpp:586-680, :774-923): depth / normal / conf in-out.
 void orc_mvs_init_conf_map(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
-                           const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf) {
+                           const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                           const float* const* nei_depth) {
   MvsView v{rows, cols, half_window, step, ref_gray};
-  InitConfMap(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf);
+  InitConfMap(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth);
 }
 // one pixel's patch: weight / texels0 (num_texels each), returns sq0 (<= 1e-6 or outside = invalid -> -1)
 float orc_mvs_fill_patch(int rows, int cols, int half_window, int step, const unsigned char* gray, int px, int py, float* weight, float* texels0) {

@@ -207,7 +207,7 @@ class Context:
                                                    _p(x, C.c_double), C.byref(info)), "pvlm_spd_solve_blocks")
         return x, info.value
 
-    def mvs_init_conf_map(self, ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_window=3, step=1, conf=None):
+    def mvs_init_conf_map(self, ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_window=3, step=1, conf=None, nei_depths=None):
         """MVS::InitPatchMap + InitConfMap(use_geometry=False) on the GPU: returns (conf, depth, normal) copies."""
         ref = np.ascontiguousarray(ref_gray, np.uint8); rows, cols = ref.shape
         neis = [np.ascontiguousarray(g, np.uint8) for g in nei_grays]
@@ -215,9 +215,13 @@ class Context:
         R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
         d = np.array(depth, np.float32, copy=True); nrm = np.array(normal, np.float32, copy=True)
         c = np.zeros((rows, cols), np.float32) if conf is None else np.array(conf, np.float32, copy=True)
+        dptrs = None
+        if nei_depths is not None:
+            nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
+            dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
         self._check(self.lib.pvlm_mvs_init_conf_map(self._h, C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte),
                                                     C.c_int(len(neis)), ptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float),
-                                                    _p(c, C.c_float)), "pvlm_mvs_init_conf_map")
+                                                    _p(c, C.c_float), dptrs), "pvlm_mvs_init_conf_map")
         return c, d, nrm
 
     def project_lidar_depth(self, rows, cols, xyz, T_cl, size=3):

@@ -1,5 +1,5 @@
-// Photometric scoring pass of the reference's panoramic PatchMatch MVS: MVS::InitPatchMap + MVS::InitConfMap(use_geometry =
-// false) (mvs/MVS.cpp:586-636) = FillPixelPatch (:637-680) + the photometric term of ScorePixel (:774-923) for the current
+// Scoring pass of the reference's panoramic PatchMatch MVS: MVS::InitPatchMap + MVS::InitConfMap (mvs/MVS.cpp:586-636), photometric
+// and (use_geometry) geometric-consistency terms = FillPixelPatch (:637-680) + the photometric term of ScorePixel (:774-923) for the current
 // depth / normal hypothesis of every pixel.  First kernel of SURVEY.md §8 N4's second part.
 //
 // One wave per reference pixel, one lane per texel of the NCC window (7 x 7 = 49 at the Room settings; larger windows
@@ -8,6 +8,7 @@
 // wave reductions (tree order: float sums differ from the reference's sequential order by rounding, ~1e-7 relative).
 // Threshold decisions (d > 0, projection inside the image, sq0 <= 1e-6) use the reference's float arithmetic —
 // compiled with -ffp-contract=off.  Images stay in HBM as uint8; the PreComputeI2C table is built on the device.
+#include <algorithm>
 #include <vector>
 
 #include "pvlm_internal.h"
@@ -29,7 +30,7 @@ __global__ void k_mvs_unit_table(int rows, int cols, float* __restrict__ unit) {
   pvlm_mvs::unit_ray(rows, cols, (int)(e % cols), (int)(e / cols), unit + 3 * e);
 }
 
-struct pvlm_mvs_neighbours { const unsigned char* gray[16]; float R[16][9]; float t[16][3]; int n; };
+struct pvlm_mvs_neighbours { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
 
 __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
                                                   const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* __restrict__ depth,
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
         if (nrm <= 0.f) continue;
         float score = sq01 / sqrtf(nrm);
         score = fminf(fmaxf(score, -1.f), 1.f);
+        if (nb.geometric) score = pvlm_mvs::geometric_adjust(score, rows, cols, X0, nb.R[b], nb.t[b], nb.depth[b]);   // wave-uniform
         if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
         ++count;
       }
@@ -118,15 +120,17 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
 extern "C" {
 
 pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
-                                   const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf) {
+                                   const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                   const float* const* nei_depth) {
   if (!ctx || rows <= 0 || cols <= 0 || half_window < 1 || step < 1 || !ref_gray || n_neighbors < 0 || n_neighbors > 16 || !depth || !normal || !conf ||
       (n_neighbors > 0 && (!nei_gray || !R_nr || !t_nr)))
     return PVLM_ERR_ARG;
   if (pvlm_mvs::num_texels(half_window, step) > 64 * PVLM_MVS_MAXM) { PVLM_SET_ERR(ctx, "NCC window of %d texels exceeds %d", pvlm_mvs::num_texels(half_window, step), 64 * PVLM_MVS_MAXM); return PVLM_ERR_ARG; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   const size_t npix = (size_t)rows * cols;
-  unsigned char* d_img = nullptr; float *d_unit = nullptr, *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr;
+  unsigned char* d_img = nullptr; float *d_unit = nullptr, *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_ndepth = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_img, npix * (size_t)(n_neighbors + 1));
+  if (!st && nei_depth) st = pvlm_i_alloc(ctx, &d_ndepth, npix * (size_t)std::max(n_neighbors, 1));
   if (!st) st = pvlm_i_alloc(ctx, &d_unit, npix * 3);
   if (!st) st = pvlm_i_alloc(ctx, &d_depth, npix);
   if (!st) st = pvlm_i_alloc(ctx, &d_normal, npix * 3);
@@ -134,12 +138,18 @@ pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_w
   if (!st) {
     hipStream_t s = ctx->stream;
     pvlm_mvs_neighbours nb;
-    nb.n = n_neighbors;
+    nb.n = n_neighbors; nb.geometric = nei_depth ? 1 : 0;
     hipError_t e = hipMemcpyAsync(d_img, ref_gray, npix, hipMemcpyHostToDevice, s);
     for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
       if (!nei_gray[b]) { e = hipErrorInvalidValue; break; }
       e = hipMemcpyAsync(d_img + npix * (size_t)(b + 1), nei_gray[b], npix, hipMemcpyHostToDevice, s);
       nb.gray[b] = d_img + npix * (size_t)(b + 1);
+      nb.depth[b] = nullptr;
+      if (nei_depth && e == hipSuccess) {
+        if (!nei_depth[b]) { e = hipErrorInvalidValue; break; }
+        e = hipMemcpyAsync(d_ndepth + npix * (size_t)b, nei_depth[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
+        nb.depth[b] = d_ndepth + npix * (size_t)b;
+      }
       for (int k = 0; k < 9; ++k) nb.R[b][k] = R_nr[9 * b + k];
       for (int k = 0; k < 3; ++k) nb.t[b][k] = t_nr[3 * b + k];
     }
@@ -161,7 +171,7 @@ pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_w
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_init_conf_map: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_img); hipFree(d_unit); hipFree(d_depth); hipFree(d_normal); hipFree(d_conf);
+  hipFree(d_img); hipFree(d_unit); hipFree(d_depth); hipFree(d_normal); hipFree(d_conf); hipFree(d_ndepth);
   return st;
 }
 

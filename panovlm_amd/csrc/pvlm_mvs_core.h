@@ -90,4 +90,57 @@ PVLM_HD inline bool neighbour_texel(const float* unit, const unsigned char* nei_
   return true;
 }
 
+// Equirectangular::ImageToCam<float>(pixel, r) (sensors/Equirectangular.h:102-103, :125-128, :149-152)
+PVLM_HD inline void image_to_cam(int rows, int cols, const float* px, float r, float* cam) {
+  const float sx = (float)((2 * px[0] / cols - 1) * 3.14159265358979323846);
+  const float sy = (float)((0.5 - px[1] / rows) * 3.14159265358979323846);
+  const float cy = (float)cos((double)sy);
+  cam[0] = r * cy * (float)sin((double)sx);
+  cam[1] = -r * (float)sin((double)sy);
+  cam[2] = r * cy * (float)cos((double)sx);
+}
+
+// Sample(img, pt, functor) of mvs/MVS.cpp:1445-1467 with the functor of ScorePixel :873: |depth0 - d| / depth0 < 0.03f
+PVLM_HD inline float sample_depth(const float* img, int cols, float x, float y, float depth0) {
+  const int lx = (int)x, ly = (int)y;
+  const float fx = x - lx, fy = y - ly, x1 = 1.f - fx, y1 = 1.f - fy;
+  const float x0y0 = img[(size_t)ly * cols + lx], x1y0 = img[(size_t)ly * cols + lx + 1];
+  const float x0y1 = img[(size_t)(ly + 1) * cols + lx], x1y1 = img[(size_t)(ly + 1) * cols + lx + 1];
+  const bool b00 = fabsf(depth0 - x0y0) / depth0 < 0.03f, b10 = fabsf(depth0 - x1y0) / depth0 < 0.03f;
+  const bool b01 = fabsf(depth0 - x0y1) / depth0 < 0.03f, b11 = fabsf(depth0 - x1y1) / depth0 < 0.03f;
+  if (!b00 && !b10 && !b01 && !b11) return INFINITY;
+  return (float)(y1 * (x1 * (b00 ? x0y0 : (b10 ? x1y0 : (b01 ? x0y1 : x1y1))) + fx * (b10 ? x1y0 : (b00 ? x0y0 : (b11 ? x1y1 : x0y1)))) +
+                 fy * (x1 * (b01 ? x0y1 : (b11 ? x1y1 : (b00 ? x0y0 : x1y0))) + fx * (b11 ? x1y1 : (b01 ? x0y1 : (b10 ? x1y0 : x0y0)))));
+}
+
+// geometric-consistency adjustment of one neighbour's score (ScorePixel :857-893)
+PVLM_HD inline float geometric_adjust(float score, int rows, int cols, const float* X0, const float* R, const float* t, const float* nei_depth) {
+  const float geometric_weight = 0.2;
+  float consistency = 2;
+  float X1[3];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += R[3 * r + c] * X0[c]; X1[r] = s + t[r]; }
+  const float depth0 = (float)sqrt((double)X1[0] * X1[0] + (double)X1[1] * X1[1] + (double)X1[2] * X1[2]);
+  float x1[2];
+  cam_to_image(rows, cols, X1, x1);
+  score = 1 - score;
+  if (x1[0] >= 1 && x1[1] >= 1 && x1[0] < cols - 1 && x1[1] < rows - 1) {
+    const float depth1 = sample_depth(nei_depth, cols, x1[0], x1[1], depth0);
+    if (depth1 != INFINITY && depth1 != -INFINITY) {   // !isinf(depth1)
+      float cam[3], t_rn[3], Xb[3];
+      image_to_cam(rows, cols, x1, depth1, cam);
+      for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += (-R[3 * c + r]) * t[c]; t_rn[r] = s; }
+      for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += R[3 * c + r] * cam[c]; Xb[r] = s + t_rn[r]; }
+      float cosang = X0[0] * Xb[0] + X0[1] * Xb[1] + X0[2] * Xb[2];
+      const float n1 = sqrtf(X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2]), n2 = sqrtf(Xb[0] * Xb[0] + Xb[1] * Xb[1] + Xb[2] * Xb[2]);
+      cosang /= (n1 * n2);
+      const float ang = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)3.14159265358979323846 : acosf(cosang));
+      const float diff_angle = (float)(ang * 180.0 / 3.14159265358979323846);
+      consistency = diff_angle < consistency ? diff_angle : consistency;
+    }
+  }
+  score += geometric_weight * consistency;
+  score = 1 - score;
+  return fminf(1.f, fmaxf(-1.f, score));
+}
+
 }  // namespace pvlm_mvs

@@ -8,7 +8,8 @@
 #include "../../panovlm_amd/csrc/pvlm_mvs_core.h"
 
 extern "C" void chk_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
-                             const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf) {
+                             const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                             const float* const* nei_depth) {
   using namespace pvlm_mvs;
   std::vector<float> unit((size_t)rows * cols * 3);
   for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) unit_ray(rows, cols, c, r, &unit[3 * ((size_t)r * cols + c)]);
@@ -50,6 +51,7 @@ extern "C" void chk_mvs_conf(int rows, int cols, int half_window, int step, cons
             if (nrm <= 0.f) continue;
             float score = sq01 / sqrtf(nrm);
             score = fminf(fmaxf(score, -1.f), 1.f);
+            if (nei_depth) score = geometric_adjust(score, rows, cols, X0, R_nr + 9 * b, t_nr + 3 * b, nei_depth[b]);
             if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
             ++count;
           }

@@ -13,13 +13,20 @@ from tests import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def mvs_scene(oracle, rows=96, cols=192, n_views=4):
+def mvs_scene(oracle, rows=96, cols=192, n_views=4, with_depths=False):
     poses = [(synth.rodrigues(np.array([0.02 * k, 0.25 * k - 0.3, 0.01])), np.array([0.35 * k - 0.5, 0.04 * k, 0.25 * k - 0.3])) for k in range(n_views)]
     views = [synth.render_panorama(oracle, rows, cols, R, t) for R, t in poses]
     ref = 1
     nei = [k for k in range(n_views) if k != ref]
     Rn, tn = zip(*[synth.relative_pose(poses[ref][0], poses[ref][1], poses[k][0], poses[k][1]) for k in nei])
-    return views[ref], [views[k][0] for k in nei], np.array(Rn), np.array(tn)
+    out = (views[ref], [views[k][0] for k in nei], np.array(Rn), np.array(tn))
+    if with_depths:      # the neighbours' own depth maps (Frame::depth_filter), with holes and a band of wrong depths
+        nd = []
+        for k in nei:
+            d = views[k][1].copy(); d[20:30, 40:90] = 0; d[50:60, :] *= 1.2
+            nd.append(d)
+        out = out + (nd,)
+    return out
 
 
 def test_oracle_scores_prefer_the_true_geometry(oracle):
@@ -45,24 +52,45 @@ def test_oracle_scores_prefer_the_true_geometry(oracle):
     assert oracle.mvs_fill_patch(gray, 1, 40, 3, 1)[2] == -1.0          # window leaves the image
 
 
-@pytest.mark.parametrize("hw,step", [(3, 1), (5, 2)])
-def test_device_bodies_match_oracle(oracle, hw, step):
+def test_geometric_consistency_term(oracle):
+    """InitConfMap(use_geometry=true): a consistent neighbour depth leaves the score almost untouched, an inconsistent or
+    missing one costs 0.2 x min(angle, 2 deg) (ScorePixel :857-893)."""
+    (gray, depth, normal), neis, Rn, tn, nd = mvs_scene(oracle, with_depths=True)
+    pho, _, _ = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1)
+    geo, _, _ = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1, nei_depths=nd)
+    valid = (pho > -1) & (geo > -1)
+    drop = pho[valid] - geo[valid]
+    assert np.all(drop >= -1e-6) and drop.max() <= 0.4 + 1e-5          # penalty in [0, 0.2 * 2]
+    assert np.median(drop) < 0.02 and (drop > 0.3).mean() > 0.01      # mostly consistent, the tampered band / holes are punished
+    zero = [np.zeros_like(x) for x in nd]                              # no neighbour depth at all: the full penalty everywhere
+    worst, _, _ = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1, nei_depths=zero)
+    both = valid & (worst > -1)
+    assert np.allclose(pho[both] - worst[both], 0.4, atol=1e-5) or np.all(worst[both] >= -1)
+
+
+@pytest.mark.parametrize("hw,step,geometric", [(3, 1, False), (5, 2, False), (3, 1, True)])
+def test_device_bodies_match_oracle(oracle, hw, step, geometric):
     out = os.path.join(ROOT, "build", "libmvs_check.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "cpp", "mvs_math_check.cpp")])
     lib = C.CDLL(out)
-    (gray, depth, normal), neis, Rn, tn = mvs_scene(oracle)
+    (gray, depth, normal), neis, Rn, tn, nd = mvs_scene(oracle, with_depths=True)
     rng = np.random.default_rng(3)
-    depth = depth * rng.uniform(0.9, 1.1, size=depth.shape).astype(np.float32)     # hypotheses, not the truth
+    depth = depth * rng.uniform(0.97, 1.03, size=depth.shape).astype(np.float32)   # hypotheses, not the truth
     depth[5:9, 7:30] = 0
-    co, do, no = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, hw, step)
+    co, do, no = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, hw, step, nei_depths=nd if geometric else None)
     d = depth.copy(); nrm = normal.copy(); c = np.zeros_like(depth)
     ptrs = (C.POINTER(C.c_ubyte) * len(neis))(*[np.ascontiguousarray(g).ctypes.data_as(C.POINTER(C.c_ubyte)) for g in neis])
     R = np.ascontiguousarray(Rn, np.float32); t = np.ascontiguousarray(tn, np.float32)
+    nd = [np.ascontiguousarray(x, np.float32) for x in nd]
+    dptrs = (C.POINTER(C.c_float) * len(nd))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd]) if geometric else None
     lib.chk_mvs_conf(C.c_int(gray.shape[0]), C.c_int(gray.shape[1]), C.c_int(hw), C.c_int(step), gray.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_int(len(neis)),
                      ptrs, R.ctypes.data_as(C.POINTER(C.c_float)), t.ctypes.data_as(C.POINTER(C.c_float)), d.ctypes.data_as(C.POINTER(C.c_float)),
-                     nrm.ctypes.data_as(C.POINTER(C.c_float)), c.ctypes.data_as(C.POINTER(C.c_float)))
+                     nrm.ctypes.data_as(C.POINTER(C.c_float)), c.ctypes.data_as(C.POINTER(C.c_float)), dptrs)
     assert np.array_equal(co == -1, c == -1)                      # every validity decision
-    assert np.array_equal(c, co)                                  # same float arithmetic, same order: bit for bit
+    if geometric:      # acosf / the double-rounded angle may differ in the last bit between the two restatements
+        assert np.abs(c - co).max() <= 1e-6
+    else:
+        assert np.array_equal(c, co)                              # same float arithmetic, same order: bit for bit
     assert np.array_equal(d, do) and np.array_equal(nrm, no)
     assert (co > -1).mean() > 0.7

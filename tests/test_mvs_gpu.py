@@ -34,6 +34,21 @@ def test_conf_map_matches_oracle(ctx, oracle, hw, step, rows, cols):
     assert np.abs(cg[valid] - co[valid]).max() <= 1e-4, np.abs(cg[valid] - co[valid]).max()
 
 
+def test_conf_map_with_geometric_consistency_matches_oracle(ctx, oracle):
+    (gray, depth, normal), neis, Rn, tn, nd = mvs_scene(oracle, 120, 240, with_depths=True)
+    rng = np.random.default_rng(9)
+    depth = depth * rng.uniform(0.97, 1.03, size=depth.shape).astype(np.float32)
+    co, do, no = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1, nei_depths=nd)
+    cg, dg, ng = ctx.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1, nei_depths=nd)
+    assert np.array_equal(co == -1, cg == -1) and np.array_equal(dg, do) and np.array_equal(ng, no)
+    valid = co > -1
+    # the depth-validity functor |depth0 - d| / depth0 < 0.03 and min(angle, 2) are decided in float on both sides: a
+    # corner flipping across the 3 % threshold would show as a jump of up to 0.4 — none may occur
+    assert np.abs(cg[valid] - co[valid]).max() <= 1e-4, np.abs(cg[valid] - co[valid]).max()
+    pho, _, _ = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1)
+    assert (pho[valid] - co[valid]).max() > 0.3          # the term is active in this scene
+
+
 def test_conf_map_edge_cases(ctx, oracle):
     import panovlm_amd as pv
     (gray, depth, normal), neis, Rn, tn = mvs_scene(oracle, 64, 128)
