@@ -173,9 +173,24 @@ def depth():
     np.savez_compressed(os.path.join(OUT, "depth.npz"), **d)
 
 
+def mvs():
+    """MVS scoring pass (InitPatchMap + InitConfMap, mvs/MVS.cpp:586-680, :774-923) on a small rendered scene: photometric
+    and geometric-consistency confidences."""
+    from tests.test_mvs_cpu import mvs_scene
+    (gray, depth, normal), neis, Rn, tn, nd = mvs_scene(orc, 64, 128, with_depths=True)
+    rng = np.random.default_rng(51)
+    depth = depth * rng.uniform(0.97, 1.03, size=depth.shape).astype(np.float32)
+    d = dict(gray=gray, depth=depth, normal=normal, R_nr=Rn, t_nr=tn)
+    for k, (g, x) in enumerate(zip(neis, nd)):
+        d["nei%d_gray" % k] = g; d["nei%d_depth" % k] = x
+    d["conf_pho"], d["depth_pho"], _ = orc.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1)
+    d["conf_geo"], _, _ = orc.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1, nei_depths=nd)
+    np.savez_compressed(os.path.join(OUT, "mvs.npz"), **d)
+
+
 if __name__ == "__main__":
     orc.build()
-    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth()
+    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs()
     tot = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -126,6 +126,15 @@ def test_depth_golden(oracle):
         assert np.array_equal(img, g["depth_size%d" % size]) and (img > 0).mean() > 0.02
 
 
+def test_mvs_golden(oracle):
+    g = load("mvs.npz")
+    neis = [g["nei%d_gray" % k] for k in range(3)]; nd = [g["nei%d_depth" % k] for k in range(3)]
+    c, d, _ = oracle.mvs_init_conf_map(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth"], g["normal"], 3, 1)
+    assert np.array_equal(c, g["conf_pho"]) and np.array_equal(d, g["depth_pho"])
+    cg, _, _ = oracle.mvs_init_conf_map(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth"], g["normal"], 3, 1, nei_depths=nd)
+    assert np.array_equal(cg, g["conf_geo"]) and (c > -1).mean() > 0.6
+
+
 def test_refvec_container_round_trip(tmp_path):
     """tools/refvec.py (re-pinning recipe against a real PanoVLM build): export -> read back == fixture inputs,
     and `compare` accepts the fixtures' own expectations."""

@@ -90,3 +90,12 @@ def test_depth_golden(ctx):
     g = load("depth.npz")
     for size in (3, 2):
         assert np.array_equal(ctx.project_lidar_depth(int(g["rows"]), int(g["cols"]), g["xyz"], g["T_cl"], size), g["depth_size%d" % size])
+
+
+def test_mvs_golden(ctx):
+    g = load("mvs.npz")
+    neis = [g["nei%d_gray" % k] for k in range(3)]; nd = [g["nei%d_depth" % k] for k in range(3)]
+    for key, kw in (("conf_pho", {}), ("conf_geo", dict(nei_depths=nd))):
+        c, d, _ = ctx.mvs_init_conf_map(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth"], g["normal"], 3, 1, **kw)
+        assert np.array_equal(c == -1, g[key] == -1)
+        assert np.abs(c - g[key]).max() <= 1e-4

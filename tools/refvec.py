@@ -75,7 +75,8 @@ def _is_output(fixture, key):
 
 # intermediate results the reference API does not expose (k-NN table, query indices, vote matrices)
 INTERNAL = ("_qidx", "_nn", "votes")
-FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth")
+FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth")   # mvs.npz: the
+# reference entry point (MVS::InitConfMap) is a private member driven by the whole MVS object — not exported here
 
 
 def export(out_dir):
