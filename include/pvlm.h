@@ -296,6 +296,15 @@ pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_w
                                    const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal,
                                    float* conf, const float* const* nei_depth_or_null);
 
+/* Depth-map fusion filter: MVS::FilterDepthImage (mvs/MVS.cpp:1735-1790) with ProjectDepthConfToRef (:2011-2070, depth):
+ * every neighbour depth map is forward-projected into the reference view (4-pixel splat, nearest range wins); a reference
+ * depth survives when >= 2 neighbours agree within 0.8 x threshold at the pixel and >= 5 (neighbour, 4-neighbourhood)
+ * samples agree within 1.2 x threshold (or depth_constant marks it).  depth_filter / conf_filter (rows x cols float)
+ * are outputs, 0 where rejected; conf / conf_filter and depth_constant may be NULL. */
+pvlm_status pvlm_mvs_filter_depth(pvlm_ctx* ctx, int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr,
+                                  const float* depth, const float* conf_or_null, const unsigned char* depth_constant_or_null,
+                                  float depth_diff_threshold, float* depth_filter, float* conf_filter_or_null);
+
 /* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
  * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2
  * pixels, n_lines x 4 float) and every LiDAR corner point (LiDAR-local float xyz, transformed by

@@ -197,4 +197,73 @@ inline void InitConfMap(const MvsView& ref, int n_neighbors, const uint8_t* cons
   }
 }
 
+// ProjectDepthConfToRef, depth only (mvs/MVS.cpp:2011-2070): every neighbour pixel (zero-depth ones included, as upstream)
+// is moved to the reference camera and splat onto the four integer pixels around its projection; a pixel keeps the
+// smallest range it receives.  out: rows x cols, 0 = nothing projected.
+inline void ProjectDepthToRef(int rows, int cols, const float* unit, const float* nei_depth, const float* R_nr, const float* t_nr, float* out) {
+  const Equirectangular eq(rows, cols);
+  float R_rn[9], t_rn[3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_rn[3 * r + c] = R_nr[3 * c + r];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += (-R_rn[3 * r + c]) * t_nr[c]; t_rn[r] = s; }
+  std::fill(out, out + (size_t)rows * cols, 0.f);
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < cols; ++col) {
+      const size_t e = (size_t)row * cols + col;
+      const float pn[3] = {unit[3 * e] * nei_depth[e], unit[3 * e + 1] * nei_depth[e], unit[3 * e + 2] * nei_depth[e]};
+      float pr[3];
+      for (int r = 0; r < 3; ++r) { float sacc = 0; for (int c = 0; c < 3; ++c) sacc += R_rn[3 * r + c] * pn[c]; pr[r] = sacc + t_rn[r]; }
+      const float range = (float)std::sqrt((double)pr[0] * pr[0] + (double)pr[1] * pr[1] + (double)pr[2] * pr[2]);
+      float px[2];
+      eq.CamToImage(pr, px);
+      const int xs[2] = {(int)std::ceil(px[0]), (int)std::floor(px[0])}, ys[2] = {(int)std::ceil(px[1]), (int)std::floor(px[1])};
+      for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+          const int x = xs[a], y = ys[b];
+          if (!(x >= 0 && y >= 0 && x < cols && y < rows)) continue;
+          float& d = out[(size_t)y * cols + x];
+          if (d != 0 && d < range) continue;
+          d = range;
+        }
+    }
+}
+
+// FilterDepthImage (mvs/MVS.cpp:1735-1790): a depth survives when at least two neighbours agree with it within 0.8 x thr
+// at the pixel itself and at least five (neighbour, 4-neighbourhood) samples agree within 1.2 x thr (or the pixel is marked
+// depth_constant).  depth_filter / conf_filter: rows x cols outputs (0 elsewhere); conf / depth_constant may be null.
+inline void FilterDepthImage(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr,
+                             const float* depth, const float* conf, const unsigned char* depth_constant, float depth_diff_threshold,
+                             float* depth_filter, float* conf_filter) {
+  std::vector<float> unit((size_t)rows * cols * 3);
+  const Equirectangular eq(rows, cols);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) { const float px[2] = {(float)j, (float)i}; eq.ImageToCam(px, 1.f, &unit[3 * ((size_t)i * cols + j)]); }
+  std::vector<std::vector<float>> proj(n_neighbors, std::vector<float>((size_t)rows * cols));
+  for (int b = 0; b < n_neighbors; ++b) ProjectDepthToRef(rows, cols, unit.data(), nei_depth[b], R_nr + 9 * b, t_nr + 3 * b, proj[b].data());
+  const float loose = depth_diff_threshold * 1.2f, strict = depth_diff_threshold * 0.8f;
+  const int ox[4] = {-1, 1, 0, 0}, oy[4] = {0, 0, 1, -1};
+  std::fill(depth_filter, depth_filter + (size_t)rows * cols, 0.f);
+  if (conf_filter) std::fill(conf_filter, conf_filter + (size_t)rows * cols, 0.f);
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < cols; ++col) {
+      const size_t e = (size_t)row * cols + col;
+      const float d = depth[e];
+      if (d <= 0) continue;
+      int similar = 0;
+      for (int b = 0; b < n_neighbors; ++b) { const float dn = proj[b][e]; if (dn > 0 && std::abs((d - dn) / d) < strict) similar++; }
+      if (similar < 2) continue;
+      similar = 0;
+      for (int b = 0; b < n_neighbors; ++b)
+        for (int k = 0; k < 4; ++k) {
+          const int x = col + ox[k], y = row + oy[k];
+          if (!(x >= 0 && y >= 0 && x < cols && y < rows)) continue;
+          const float dn = proj[b][(size_t)y * cols + x];
+          if (dn > 0 && std::abs((d - dn) / d) < loose) similar++;
+        }
+      const bool keep_constant = depth_constant && depth_constant[e];
+      if (similar < 5 && !keep_constant) continue;
+      depth_filter[e] = d;
+      if (conf && conf_filter) conf_filter[e] = conf[e];
+    }
+}
+
 }  // namespace oracle

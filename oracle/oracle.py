@@ -315,6 +315,20 @@ def mvs_init_conf_map(ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_windo
     return c, d, nrm
 
 
+def mvs_filter_depth(nei_depths, R_nr, t_nr, depth, conf=None, depth_constant=None, thr=0.01):
+    """FilterDepthImage (mvs/MVS.cpp:1735-1790) with ProjectDepthConfToRef (:2011-2070): returns (depth_filter, conf_filter)."""
+    d = np.ascontiguousarray(depth, np.float32); rows, cols = d.shape
+    nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
+    dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
+    R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
+    cf = None if conf is None else np.ascontiguousarray(conf, np.float32)
+    dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
+    out_d = np.zeros((rows, cols), np.float32); out_c = np.zeros((rows, cols), np.float32)
+    lib().orc_mvs_filter_depth(C.c_int(rows), C.c_int(cols), C.c_int(len(nd)), dptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float),
+                               _p(cf, C.c_float), _p(dc, C.c_ubyte), C.c_float(thr), _p(out_d, C.c_float), _p(out_c, C.c_float))
+    return out_d, out_c
+
+
 def mvs_fill_patch(gray, px, py, half_window=3, step=1):
     g = np.ascontiguousarray(gray, np.uint8); rows, cols = g.shape
     w = 2 * half_window + 1; q = w // step + (1 if step > 1 else 0); n = q * q

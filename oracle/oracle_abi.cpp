@@ -222,6 +222,10 @@ void orc_mvs_init_conf_map(int rows, int cols, int half_window, int step, const 
   MvsView v{rows, cols, half_window, step, ref_gray};
   InitConfMap(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth);
 }
+void orc_mvs_filter_depth(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr, const float* depth,
+                          const float* conf, const unsigned char* depth_constant, float thr, float* depth_filter, float* conf_filter) {
+  FilterDepthImage(rows, cols, n_neighbors, nei_depth, R_nr, t_nr, depth, conf, depth_constant, thr, depth_filter, conf_filter);
+}
 // one pixel's patch: weight / texels0 (num_texels each), returns sq0 (<= 1e-6 or outside = invalid -> -1)
 float orc_mvs_fill_patch(int rows, int cols, int half_window, int step, const unsigned char* gray, int px, int py, float* weight, float* texels0) {
   MvsView v{rows, cols, half_window, step, gray};

@@ -117,7 +117,77 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
   }
 }
 
+// depth-map fusion filter (FilterDepthImage + ProjectDepthConfToRef)
+struct pvlm_mvs_pose { float R_rn[9]; float t_rn[3]; };
+__global__ void k_mvs_fill_u32(long long n, unsigned v, unsigned* __restrict__ p) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] = v;
+}
+__global__ void k_mvs_project(int rows, int cols, const float* __restrict__ unit, const float* __restrict__ nei_depth, pvlm_mvs_pose pose,
+                              unsigned* __restrict__ proj_bits) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (long long)rows * cols) pvlm_mvs::project_splat(rows, cols, unit, nei_depth, pose.R_rn, pose.t_rn, e, proj_bits);
+}
+__global__ void k_mvs_filter(int rows, int cols, int n_neighbors, const unsigned* __restrict__ proj_bits, const float* __restrict__ depth,
+                             const float* __restrict__ conf, const unsigned char* __restrict__ depth_constant, float thr,
+                             float* __restrict__ depth_filter, float* __restrict__ conf_filter) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (long long)rows * cols) pvlm_mvs::filter_pixel(rows, cols, n_neighbors, proj_bits, depth, conf, depth_constant, thr, e, depth_filter, conf_filter);
+}
+
 extern "C" {
+
+pvlm_status pvlm_mvs_filter_depth(pvlm_ctx* ctx, int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr,
+                                  const float* depth, const float* conf, const unsigned char* depth_constant, float depth_diff_threshold,
+                                  float* depth_filter, float* conf_filter) {
+  if (!ctx || rows <= 0 || cols <= 0 || n_neighbors < 0 || n_neighbors > 16 || !depth || !depth_filter || (n_neighbors > 0 && (!nei_depth || !R_nr || !t_nr)) ||
+      (conf && !conf_filter))
+    return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t npix = (size_t)rows * cols;
+  float *d_unit = nullptr, *d_nd = nullptr, *d_depth = nullptr, *d_conf = nullptr, *d_out = nullptr, *d_cout = nullptr;
+  unsigned* d_proj = nullptr; unsigned char* d_const = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_unit, npix * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_nd, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_proj, npix * (size_t)std::max(n_neighbors, 1));
+  if (!st) st = pvlm_i_alloc(ctx, &d_depth, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_out, npix);
+  if (!st && conf) st = pvlm_i_alloc(ctx, &d_conf, npix);
+  if (!st && conf) st = pvlm_i_alloc(ctx, &d_cout, npix);
+  if (!st && depth_constant) st = pvlm_i_alloc(ctx, &d_const, npix);
+  if (!st) {
+    hipStream_t s = ctx->stream;
+    const unsigned grid = (unsigned)((npix + 255) / 256);
+    hipLaunchKernelGGL(k_mvs_unit_table, dim3(grid), dim3(256), 0, s, rows, cols, d_unit);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && n_neighbors > 0) {
+      hipLaunchKernelGGL(k_mvs_fill_u32, dim3((unsigned)((npix * n_neighbors + 255) / 256)), dim3(256), 0, s, (long long)(npix * n_neighbors), 0x7f800000u, d_proj);
+      e = hipGetLastError();
+    }
+    for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
+      if (!nei_depth[b]) { e = hipErrorInvalidValue; break; }
+      e = hipMemcpyAsync(d_nd, nei_depth[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
+      pvlm_mvs_pose pose;
+      pvlm_mvs::inverse_pose(R_nr + 9 * b, t_nr + 3 * b, pose.R_rn, pose.t_rn);
+      if (e == hipSuccess) { hipLaunchKernelGGL(k_mvs_project, dim3(grid), dim3(256), 0, s, rows, cols, d_unit, d_nd, pose, d_proj + npix * (size_t)b); e = hipGetLastError(); }
+      if (e == hipSuccess) e = hipStreamSynchronize(s);   // d_nd is reused by the next neighbour; nei_depth[b] is pageable host memory
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && conf) e = hipMemcpyAsync(d_conf, conf, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && depth_constant) e = hipMemcpyAsync(d_const, depth_constant, npix, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_mvs_filter, dim3(grid), dim3(256), 0, s, rows, cols, n_neighbors, d_proj, d_depth, d_conf, d_const, depth_diff_threshold, d_out, d_cout);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(depth_filter, d_out, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && conf) e = hipMemcpyAsync(conf_filter, d_cout, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_filter_depth: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_unit); hipFree(d_nd); hipFree(d_proj); hipFree(d_depth); hipFree(d_conf); hipFree(d_out); hipFree(d_cout); hipFree(d_const);
+  return st;
+}
 
 pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
                                    const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,

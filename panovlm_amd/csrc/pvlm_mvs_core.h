@@ -143,4 +143,69 @@ PVLM_HD inline float geometric_adjust(float score, int rows, int cols, const flo
   return fminf(1.f, fmaxf(-1.f, score));
 }
 
+// ---- depth-map fusion filter: ProjectDepthConfToRef (mvs/MVS.cpp:2011-2070, depth only) + FilterDepthImage (:1735-1790) ----
+#ifndef PVLM_ATOMIC_MIN_U32
+#define PVLM_ATOMIC_MIN_U32(ptr, v) atomicMin((ptr), (v))
+#endif
+
+PVLM_HD inline unsigned float_bits(float f) { union { float f; unsigned u; } c; c.f = f; return c.u; }
+PVLM_HD inline float bits_float(unsigned u) { union { float f; unsigned u; } c; c.u = u; return c.f; }
+
+// R_rn = R_nr^T, t_rn = (-R_rn) t_nr
+PVLM_HD inline void inverse_pose(const float* R_nr, const float* t_nr, float* R_rn, float* t_rn) {
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_rn[3 * r + c] = R_nr[3 * c + r];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += (-R_rn[3 * r + c]) * t_nr[c]; t_rn[r] = s; }
+}
+
+// one neighbour pixel e: move it to the reference camera and splat its range onto the four integer pixels around the
+// projection; every target keeps the smallest range (the reference's "if (d != 0 && d < range) continue; d = range").
+// proj_bits: rows x cols float bit patterns initialised to +inf (0x7f800000) — ranges are >= 0, so unsigned order = float order.
+PVLM_HD inline void project_splat(int rows, int cols, const float* unit, const float* nei_depth, const float* R_rn, const float* t_rn, long long e,
+                                  unsigned* proj_bits) {
+  const float dn = nei_depth[e];
+  const float pn[3] = {unit[3 * e] * dn, unit[3 * e + 1] * dn, unit[3 * e + 2] * dn};
+  float pr[3];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += R_rn[3 * r + c] * pn[c]; pr[r] = s + t_rn[r]; }
+  const float range = (float)sqrt((double)pr[0] * pr[0] + (double)pr[1] * pr[1] + (double)pr[2] * pr[2]);
+  float px[2];
+  cam_to_image(rows, cols, pr, px);
+  const int xs[2] = {(int)ceilf(px[0]), (int)floorf(px[0])}, ys[2] = {(int)ceilf(px[1]), (int)floorf(px[1])};
+  const unsigned bits = float_bits(range);
+  for (int b = 0; b < 2; ++b)
+    for (int a = 0; a < 2; ++a) {
+      const int x = xs[a], y = ys[b];
+      if (!(x >= 0 && y >= 0 && x < cols && y < rows)) continue;
+      PVLM_ATOMIC_MIN_U32(&proj_bits[(size_t)y * cols + x], bits);
+    }
+}
+PVLM_HD inline float projected_depth(const unsigned* proj_bits, size_t e) { const unsigned b = proj_bits[e]; return b == 0x7f800000u ? 0.f : bits_float(b); }
+
+// FilterDepthImage for one reference pixel; proj_bits: n_neighbors images one after the other
+PVLM_HD inline void filter_pixel(int rows, int cols, int n_neighbors, const unsigned* proj_bits, const float* depth, const float* conf,
+                                 const unsigned char* depth_constant, float thr, long long e, float* depth_filter, float* conf_filter) {
+  const size_t npix = (size_t)rows * cols;
+  depth_filter[e] = 0.f;
+  if (conf_filter) conf_filter[e] = 0.f;
+  const float d = depth[e];
+  if (d <= 0) return;
+  const float loose = thr * 1.2f, strict = thr * 0.8f;
+  const int row = (int)(e / cols), col = (int)(e % cols);
+  int similar = 0;
+  for (int b = 0; b < n_neighbors; ++b) { const float dn = projected_depth(proj_bits + npix * b, e); if (dn > 0 && fabsf((d - dn) / d) < strict) similar++; }
+  if (similar < 2) return;
+  similar = 0;
+  const int ox[4] = {-1, 1, 0, 0}, oy[4] = {0, 0, 1, -1};
+  for (int b = 0; b < n_neighbors; ++b)
+    for (int k = 0; k < 4; ++k) {
+      const int x = col + ox[k], y = row + oy[k];
+      if (!(x >= 0 && y >= 0 && x < cols && y < rows)) continue;
+      const float dn = projected_depth(proj_bits + npix * b, (size_t)y * cols + x);
+      if (dn > 0 && fabsf((d - dn) / d) < loose) similar++;
+    }
+  const bool keep_constant = depth_constant && depth_constant[e];
+  if (similar < 5 && !keep_constant) return;
+  depth_filter[e] = d;
+  if (conf && conf_filter) conf_filter[e] = conf[e];
+}
+
 }  // namespace pvlm_mvs

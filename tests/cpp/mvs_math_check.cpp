@@ -5,6 +5,7 @@
 #include <vector>
 
 #define PVLM_HD
+#define PVLM_ATOMIC_MIN_U32(ptr, v) (*(ptr) = *(ptr) < (v) ? *(ptr) : (v))
 #include "../../panovlm_amd/csrc/pvlm_mvs_core.h"
 
 extern "C" void chk_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
@@ -62,4 +63,19 @@ extern "C" void chk_mvs_conf(int rows, int cols, int half_window, int step, cons
       conf[e] = c;
       if (c <= -1) { depth[e] = 0; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; }
     }
+}
+
+extern "C" void chk_mvs_filter(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr, const float* depth,
+                               const float* conf, const unsigned char* depth_constant, float thr, float* depth_filter, float* conf_filter) {
+  using namespace pvlm_mvs;
+  const size_t npix = (size_t)rows * cols;
+  std::vector<float> unit(npix * 3);
+  for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) unit_ray(rows, cols, c, r, &unit[3 * ((size_t)r * cols + c)]);
+  std::vector<unsigned> proj(npix * (size_t)(n_neighbors > 0 ? n_neighbors : 1), 0x7f800000u);
+  for (int b = 0; b < n_neighbors; ++b) {
+    float R_rn[9], t_rn[3];
+    inverse_pose(R_nr + 9 * b, t_nr + 3 * b, R_rn, t_rn);
+    for (size_t e = 0; e < npix; ++e) project_splat(rows, cols, unit.data(), nei_depth[b], R_rn, t_rn, (long long)e, proj.data() + npix * b);
+  }
+  for (size_t e = 0; e < npix; ++e) filter_pixel(rows, cols, n_neighbors, proj.data(), depth, conf, depth_constant, thr, (long long)e, depth_filter, conf_filter);
 }

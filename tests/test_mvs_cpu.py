@@ -94,3 +94,41 @@ def test_device_bodies_match_oracle(oracle, hw, step, geometric):
         assert np.array_equal(c, co)                              # same float arithmetic, same order: bit for bit
     assert np.array_equal(d, do) and np.array_equal(nrm, no)
     assert (co > -1).mean() > 0.7
+
+
+def _filter_scene(oracle, rows=96, cols=192):
+    poses = [(synth.rodrigues(np.array([0.02 * k, 0.25 * k - 0.3, 0.01])), np.array([0.35 * k - 0.5, 0.04 * k, 0.25 * k - 0.3])) for k in range(4)]
+    views = [synth.render_panorama(oracle, rows, cols, R, t) for R, t in poses]
+    ref, nei = 1, [0, 2, 3]
+    Rn, tn = zip(*[synth.relative_pose(poses[ref][0], poses[ref][1], poses[k][0], poses[k][1]) for k in nei])
+    depth = views[ref][1].copy()
+    depth[30:40, 50:80] *= 1.1          # a wrong patch: must be filtered out
+    depth[60:64, 100:140] = 0           # holes stay holes
+    nd = [views[k][1].copy() for k in nei]
+    nd[0][10:20, :] = 0                 # zero-depth neighbour pixels are splat too (at the epipole), as upstream
+    conf = np.random.default_rng(5).uniform(0.2, 1.0, size=depth.shape).astype(np.float32)
+    const = np.zeros(depth.shape, np.uint8); const[32:35, 55:60] = 1     # depth_constant pixels survive the second vote
+    return nd, np.array(Rn), np.array(tn), depth, conf, const
+
+
+def test_depth_filter_oracle_behaviour_and_device_bodies(oracle):
+    nd, Rn, tn, depth, conf, const = _filter_scene(oracle)
+    df, cf = oracle.mvs_filter_depth(nd, Rn, tn, depth, conf=conf, depth_constant=const, thr=0.01)
+    kept = df > 0
+    assert 0.15 < kept.mean() < 0.9
+    assert not kept[30:40, 50:80][const[30:40, 50:80] == 0].any() and not kept[60:64, 100:140].any()
+    assert np.array_equal(df[kept], depth[kept]) and np.array_equal(cf[kept], conf[kept]) and np.all(cf[~kept] == 0)
+    looser, _ = oracle.mvs_filter_depth(nd, Rn, tn, depth, thr=0.03)
+    assert (looser > 0).sum() > kept.sum()
+    # the device bodies, driven serially on the host: identical (same float arithmetic; the splat's minimum is order-free)
+    out = os.path.join(ROOT, "build", "libmvs_check.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "cpp", "mvs_math_check.cpp")])
+    lib = C.CDLL(out)
+    nd = [np.ascontiguousarray(x, np.float32) for x in nd]
+    dptrs = (C.POINTER(C.c_float) * len(nd))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
+    R = np.ascontiguousarray(Rn, np.float32); t = np.ascontiguousarray(tn, np.float32)
+    od = np.zeros_like(depth); oc = np.zeros_like(depth)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    lib.chk_mvs_filter(C.c_int(depth.shape[0]), C.c_int(depth.shape[1]), C.c_int(len(nd)), dptrs, fp(R), fp(t), fp(depth), fp(conf),
+                       const.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_float(0.01), fp(od), fp(oc))
+    assert np.array_equal(od, df) and np.array_equal(oc, cf)

@@ -61,3 +61,19 @@ def test_conf_map_edge_cases(ctx, oracle):
     assert np.all(c == -1)
     with pytest.raises(pv.PvlmError):
         ctx.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, half_window=20, step=1)      # 41 x 41 texels > 256
+
+
+def test_depth_filter_matches_oracle(ctx, oracle):
+    """pvlm_mvs_filter_depth (FilterDepthImage + ProjectDepthConfToRef): bit-exact — the forward splat keeps the minimum
+    range per pixel (order-free, atomicMin on the float bit pattern) and the votes are float comparisons."""
+    from tests.test_mvs_cpu import _filter_scene
+    for rows, cols in ((96, 192), (180, 360)):
+        nd, Rn, tn, depth, conf, const = _filter_scene(oracle, rows, cols)
+        for kw in (dict(conf=conf, depth_constant=const, thr=0.01), dict(thr=0.03)):
+            do, co = oracle.mvs_filter_depth(nd, Rn, tn, depth, **kw)
+            dg, cg = ctx.mvs_filter_depth(nd, Rn, tn, depth, **kw)
+            assert np.array_equal(dg, do) and np.array_equal(cg, co)
+            assert (do > 0).mean() > 0.1
+    # no neighbours: nothing survives
+    d0, _ = ctx.mvs_filter_depth([], np.zeros((0, 9)), np.zeros((0, 3)), depth)
+    assert np.all(d0 == 0)
