@@ -38,13 +38,25 @@ def main():
     t0 = time.perf_counter()
     co, _, _ = orc.mvs_init_conf_map(gray, neis, np.array(Rn), np.array(tn), depth, normal, a.half_window, a.step)
     cpu = time.perf_counter() - t0
+    # depth fusion filter (K12) on the same views: neighbours' true depth maps against the reference's
+    nd = [views[k][1] for k in nei]
+    ctx.mvs_filter_depth(nd, np.array(Rn), np.array(tn), depth, conf=cg, thr=0.01)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dfg, _ = ctx.mvs_filter_depth(nd, np.array(Rn), np.array(tn), depth, conf=cg, thr=0.01)
+    filt_wall = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    dfo, _ = orc.mvs_filter_depth(nd, np.array(Rn), np.array(tn), depth, conf=co, thr=0.01)
+    filt_cpu = time.perf_counter() - t0
     w = 2 * a.half_window + 1; q = w // a.step + (1 if a.step > 1 else 0)
     texels = a.rows * a.cols * q * q * a.neighbors
     k_ms = ms / max(cnt, 1)
     print(json.dumps(dict(rows=a.rows, cols=a.cols, neighbors=a.neighbors, window=[w, a.step], valid=float((cg > -1).mean()),
                           max_abs_diff_vs_oracle=float(np.abs(cg - co)[(cg > -1) & (co > -1)].max()), kernel_ms=k_ms,
                           M_pixels_per_s=a.rows * a.cols / k_ms / 1e3, G_texel_projections_per_s=texels / k_ms / 1e6,
-                          wall_ms_incl_copies=wall * 1e3, cpu_oracle_s=cpu, cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
+                          wall_ms_incl_copies=wall * 1e3, cpu_oracle_s=cpu,
+                          filter=dict(wall_ms_incl_copies=filt_wall * 1e3, kept=float((dfg > 0).mean()), identical_to_oracle=bool(np.array_equal(dfg, dfo)),
+                                      cpu_oracle_s_single_thread=filt_cpu), cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
 
 
 if __name__ == "__main__":
