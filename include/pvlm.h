@@ -305,6 +305,19 @@ pvlm_status pvlm_mvs_filter_depth(pvlm_ctx* ctx, int rows, int cols, int n_neigh
                                   const float* depth, const float* conf_or_null, const unsigned char* depth_constant_or_null,
                                   float depth_diff_threshold, float* depth_filter, float* conf_filter_or_null);
 
+/* The fusion filter the reference's MVS pipeline actually runs (mvs/MVS.cpp:194): MVS::FilterDepthImageRefine
+ * (mvs/MVS.cpp:1794-1890) with ProjectDepthConfToRef projecting depth and confidence (:2011-2070).  A reference depth is
+ * replaced by the confidence-weighted average of itself and the neighbour ranges that agree within 1.2 x threshold when
+ * >= 2 neighbours agree, the agreeing confidence exceeds the disagreeing one (occlusions / free-space violations) and
+ * the average lies in [min_depth, max_depth] (config.min_depth / max_depth, base/Config.h:65-66); conf_filter = positive -
+ * negative confidence.  depth_constant pixels that fail keep their depth with confidence 1.  nei_conf[b] = neighbour
+ * b's conf_map after ConvertNCC2Conf (:2343); conf (the reference frame's conf_map) is IN-OUT: zeroed where depth <= 0,
+ * as upstream.  depth_filter / conf_filter: rows x cols float outputs, 0 where rejected. */
+pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int n_neighbors, const float* const* nei_depth,
+                                         const float* const* nei_conf, const float* R_nr, const float* t_nr, const float* depth, float* conf,
+                                         const unsigned char* depth_constant_or_null, float depth_diff_threshold, float min_depth, float max_depth,
+                                         float* depth_filter, float* conf_filter);
+
 /* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
  * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2
  * pixels, n_lines x 4 float) and every LiDAR corner point (LiDAR-local float xyz, transformed by

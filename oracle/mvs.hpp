@@ -266,4 +266,98 @@ inline void FilterDepthImage(int rows, int cols, int n_neighbors, const float* c
     }
 }
 
+// ProjectDepthConfToRef with project_depth = project_conf = true (mvs/MVS.cpp:2011-2070): as ProjectDepthToRef, and every
+// write of a range also writes the source pixel's confidence, so a target pixel ends with the confidence of the last
+// (raster order) source pixel that passed the range test.
+inline void ProjectDepthConfToRef(int rows, int cols, const float* unit, const float* nei_depth, const float* nei_conf, const float* R_nr, const float* t_nr,
+                                  float* out_depth, float* out_conf) {
+  const Equirectangular eq(rows, cols);
+  float R_rn[9], t_rn[3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_rn[3 * r + c] = R_nr[3 * c + r];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += (-R_rn[3 * r + c]) * t_nr[c]; t_rn[r] = s; }
+  std::fill(out_depth, out_depth + (size_t)rows * cols, 0.f);
+  std::fill(out_conf, out_conf + (size_t)rows * cols, 0.f);
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < cols; ++col) {
+      const size_t e = (size_t)row * cols + col;
+      const float pn[3] = {unit[3 * e] * nei_depth[e], unit[3 * e + 1] * nei_depth[e], unit[3 * e + 2] * nei_depth[e]};
+      float pr[3];
+      for (int r = 0; r < 3; ++r) { float sacc = 0; for (int c = 0; c < 3; ++c) sacc += R_rn[3 * r + c] * pn[c]; pr[r] = sacc + t_rn[r]; }
+      const float range = (float)std::sqrt((double)pr[0] * pr[0] + (double)pr[1] * pr[1] + (double)pr[2] * pr[2]);
+      float px[2];
+      eq.CamToImage(pr, px);
+      const int xs[2] = {(int)std::ceil(px[0]), (int)std::floor(px[0])}, ys[2] = {(int)std::ceil(px[1]), (int)std::floor(px[1])};
+      for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+          const int x = xs[a], y = ys[b];
+          if (!(x >= 0 && y >= 0 && x < cols && y < rows)) continue;
+          float& d = out_depth[(size_t)y * cols + x];
+          if (d != 0 && d < range) continue;
+          d = range;
+          out_conf[(size_t)y * cols + x] = nei_conf[e];
+        }
+    }
+}
+
+// FilterDepthImageRefine (mvs/MVS.cpp:1794-1890) — the filter the pipeline runs (mvs/MVS.cpp:194).  Confidence-weighted
+// average of the agreeing depths; disagreeing neighbours subtract confidence (occlusion: the neighbour's projected
+// confidence; free-space violation: the neighbour's own confidence where the reference point lands in it).  conf is
+// IN-OUT (upstream zeroes frame.conf_map where depth <= 0); nei_conf[b] = neighbour b's conf_map (already through
+// ConvertNCC2Conf :2343).  min_depth / max_depth: config.min_depth / config.max_depth (base/Config.h:65-66).
+inline void FilterDepthImageRefine(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* const* nei_conf, const float* R_nr,
+                                   const float* t_nr, const float* depth, float* conf, const unsigned char* depth_constant, float depth_diff_threshold,
+                                   float min_depth, float max_depth, float* depth_filter, float* conf_filter) {
+  std::vector<float> unit((size_t)rows * cols * 3);
+  const Equirectangular eq(rows, cols);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) { const float px[2] = {(float)j, (float)i}; eq.ImageToCam(px, 1.f, &unit[3 * ((size_t)i * cols + j)]); }
+  std::vector<std::vector<float>> pd(n_neighbors, std::vector<float>((size_t)rows * cols)), pc(n_neighbors, std::vector<float>((size_t)rows * cols));
+  for (int b = 0; b < n_neighbors; ++b) ProjectDepthConfToRef(rows, cols, unit.data(), nei_depth[b], nei_conf[b], R_nr + 9 * b, t_nr + 3 * b, pd[b].data(), pc[b].data());
+  const float loose = depth_diff_threshold * 1.2f;
+  std::fill(depth_filter, depth_filter + (size_t)rows * cols, 0.f);
+  std::fill(conf_filter, conf_filter + (size_t)rows * cols, 0.f);
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < cols; ++col) {
+      const size_t e = (size_t)row * cols + col;
+      const float d = depth[e];
+      if (d <= 0) { conf[e] = 0; continue; }
+      float positive = conf[e], negative = 0, avg = d * positive;
+      int n_pos = 0, n_neg = 0;
+      bool bad = false;
+      for (int n = n_neighbors - 1; n >= 0; --n) {
+        const float dn = pd[n][e], cn = pc[n][e];
+        if (dn <= 0 && n_pos + n_neg + n < 2) { bad = true; break; }
+        if (std::abs((d - dn) / d) < loose) {
+          avg += dn * cn;
+          positive += cn;
+          n_pos += 1;
+        } else {
+          if (dn < d) negative += cn;
+          else {
+            const float X0[3] = {unit[3 * e] * d, unit[3 * e + 1] * d, unit[3 * e + 2] * d};
+            const float* R = R_nr + 9 * n; const float* t = t_nr + 3 * n;
+            float X1[3], x1[2];
+            for (int r = 0; r < 3; ++r) { float sacc = 0; for (int c = 0; c < 3; ++c) sacc += R[3 * r + c] * X0[c]; X1[r] = sacc + t[r]; }
+            eq.CamToImage(X1, x1);
+            const int xr = (int)std::round(x1[0]), yr = (int)std::round(x1[1]);
+            if (xr >= 0 && yr >= 0 && xr < cols && yr < rows) {
+              const float c = nei_conf[n][(size_t)yr * cols + xr];
+              negative += (c > 0 ? c : cn);
+            } else negative += cn;
+          }
+          n_neg += 1;
+        }
+      }
+      if (!bad) {
+        avg /= positive;
+        if (n_pos >= 2 && positive > negative && avg >= min_depth && avg <= max_depth) {
+          depth_filter[e] = avg;
+          conf_filter[e] = positive - negative;
+          continue;
+        }
+      }
+      if (depth_constant && depth_constant[e]) { depth_filter[e] = d; conf_filter[e] = 1.f; }
+    }
+}
+
 }  // namespace oracle

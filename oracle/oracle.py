@@ -329,6 +329,34 @@ def mvs_filter_depth(nei_depths, R_nr, t_nr, depth, conf=None, depth_constant=No
     return out_d, out_c
 
 
+def mvs_filter_depth_refine(nei_depths, nei_confs, R_nr, t_nr, depth, conf, depth_constant=None, thr=0.01, min_depth=0.1, max_depth=20.0):
+    """FilterDepthImageRefine (mvs/MVS.cpp:1794-1890): returns (depth_filter, conf_filter, conf) — conf is the reference
+    frame's conf_map after the call (zeroed where depth <= 0)."""
+    d = np.ascontiguousarray(depth, np.float32); rows, cols = d.shape
+    nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
+    nc = [np.ascontiguousarray(x, np.float32) for x in nei_confs]
+    dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
+    cptrs = (C.POINTER(C.c_float) * max(len(nc), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nc])
+    R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
+    cf = np.array(conf, np.float32, copy=True, order="C")
+    dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
+    out_d = np.zeros((rows, cols), np.float32); out_c = np.zeros((rows, cols), np.float32)
+    lib().orc_mvs_filter_depth_refine(C.c_int(rows), C.c_int(cols), C.c_int(len(nd)), dptrs, cptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float),
+                                      _p(cf, C.c_float), _p(dc, C.c_ubyte), C.c_float(thr), C.c_float(min_depth), C.c_float(max_depth),
+                                      _p(out_d, C.c_float), _p(out_c, C.c_float))
+    return out_d, out_c, cf
+
+
+def mvs_project_depth_conf(nei_depth, nei_conf, R_nr, t_nr):
+    """ProjectDepthConfToRef with depth + confidence (mvs/MVS.cpp:2011-2070): returns (depth_projected, conf_projected)."""
+    d = np.ascontiguousarray(nei_depth, np.float32); c = np.ascontiguousarray(nei_conf, np.float32); rows, cols = d.shape
+    R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
+    od = np.zeros((rows, cols), np.float32); oc = np.zeros((rows, cols), np.float32)
+    lib().orc_mvs_project_depth_conf(C.c_int(rows), C.c_int(cols), _p(d, C.c_float), _p(c, C.c_float), _p(R, C.c_float), _p(t, C.c_float),
+                                     _p(od, C.c_float), _p(oc, C.c_float))
+    return od, oc
+
+
 def mvs_fill_patch(gray, px, py, half_window=3, step=1):
     g = np.ascontiguousarray(gray, np.uint8); rows, cols = g.shape
     w = 2 * half_window + 1; q = w // step + (1 if step > 1 else 0); n = q * q

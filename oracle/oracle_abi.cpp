@@ -226,6 +226,20 @@ void orc_mvs_filter_depth(int rows, int cols, int n_neighbors, const float* cons
                           const float* conf, const unsigned char* depth_constant, float thr, float* depth_filter, float* conf_filter) {
   FilterDepthImage(rows, cols, n_neighbors, nei_depth, R_nr, t_nr, depth, conf, depth_constant, thr, depth_filter, conf_filter);
 }
+void orc_mvs_filter_depth_refine(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* const* nei_conf, const float* R_nr,
+                                 const float* t_nr, const float* depth, float* conf, const unsigned char* depth_constant, float thr, float min_depth,
+                                 float max_depth, float* depth_filter, float* conf_filter) {
+  FilterDepthImageRefine(rows, cols, n_neighbors, nei_depth, nei_conf, R_nr, t_nr, depth, conf, depth_constant, thr, min_depth, max_depth, depth_filter,
+                         conf_filter);
+}
+void orc_mvs_project_depth_conf(int rows, int cols, const float* nei_depth, const float* nei_conf, const float* R_nr, const float* t_nr, float* out_depth,
+                                float* out_conf) {
+  std::vector<float> unit((size_t)rows * cols * 3);
+  const Equirectangular eq(rows, cols);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) { const float px[2] = {(float)j, (float)i}; eq.ImageToCam(px, 1.f, &unit[3 * ((size_t)i * cols + j)]); }
+  ProjectDepthConfToRef(rows, cols, unit.data(), nei_depth, nei_conf, R_nr, t_nr, out_depth, out_conf);
+}
 // one pixel's patch: weight / texels0 (num_texels each), returns sq0 (<= 1e-6 or outside = invalid -> -1)
 float orc_mvs_fill_patch(int rows, int cols, int half_window, int step, const unsigned char* gray, int px, int py, float* weight, float* texels0) {
   MvsView v{rows, cols, half_window, step, gray};

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -237,6 +237,25 @@ class Context:
                                                    _p(d, C.c_float), _p(cf, C.c_float), _p(dc, C.c_ubyte), C.c_float(thr), _p(out_d, C.c_float),
                                                    _p(out_c, C.c_float) if cf is not None else None), "pvlm_mvs_filter_depth")
         return out_d, out_c
+
+    def mvs_filter_depth_refine(self, nei_depths, nei_confs, R_nr, t_nr, depth, conf, depth_constant=None, thr=0.01, min_depth=0.1, max_depth=20.0):
+        """MVS::FilterDepthImageRefine on the GPU: returns (depth_filter, conf_filter, conf) — conf = the reference frame's
+        conf_map after the call (zeroed where depth <= 0)."""
+        d = np.ascontiguousarray(depth, np.float32); rows, cols = d.shape
+        nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
+        nc = [np.ascontiguousarray(x, np.float32) for x in nei_confs]
+        assert len(nd) == len(nc)
+        dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
+        cptrs = (C.POINTER(C.c_float) * max(len(nc), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nc])
+        R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
+        cf = np.array(conf, np.float32, copy=True, order="C")
+        dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
+        out_d = np.zeros((rows, cols), np.float32); out_c = np.zeros((rows, cols), np.float32)
+        self._check(self.lib.pvlm_mvs_filter_depth_refine(self._h, C.c_int(rows), C.c_int(cols), C.c_int(len(nd)), dptrs, cptrs, _p(R, C.c_float),
+                                                          _p(t, C.c_float), _p(d, C.c_float), _p(cf, C.c_float), _p(dc, C.c_ubyte), C.c_float(thr),
+                                                          C.c_float(min_depth), C.c_float(max_depth), _p(out_d, C.c_float), _p(out_c, C.c_float)),
+                    "pvlm_mvs_filter_depth_refine")
+        return out_d, out_c, cf
 
     def project_lidar_depth(self, rows, cols, xyz, T_cl, size=3):
         xyz = _f32(xyz).reshape(-1, 3); T = _f64(T_cl).reshape(16)

@@ -135,6 +135,24 @@ __global__ void k_mvs_filter(int rows, int cols, int n_neighbors, const unsigned
   if (e < (long long)rows * cols) pvlm_mvs::filter_pixel(rows, cols, n_neighbors, proj_bits, depth, conf, depth_constant, thr, e, depth_filter, conf_filter);
 }
 
+// FilterDepthImageRefine: keyed splat (range, last raster-order source) + per-pixel confidence fusion
+__global__ void k_mvs_fill_u64(long long n, unsigned long long v, unsigned long long* __restrict__ p) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] = v;
+}
+__global__ void k_mvs_project_conf(int rows, int cols, const float* __restrict__ unit, const float* __restrict__ nei_depth, pvlm_mvs_pose pose,
+                                   unsigned long long* __restrict__ proj_key) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (long long)rows * cols) pvlm_mvs::project_splat_conf(rows, cols, unit, nei_depth, pose.R_rn, pose.t_rn, e, proj_key);
+}
+__global__ void k_mvs_refine(int rows, int cols, pvlm_mvs::RefineViews nv, const unsigned long long* __restrict__ proj_key, const float* __restrict__ unit,
+                             const float* __restrict__ depth, float* __restrict__ conf, const unsigned char* __restrict__ depth_constant, float thr,
+                             float min_depth, float max_depth, float* __restrict__ depth_filter, float* __restrict__ conf_filter) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (long long)rows * cols)
+    pvlm_mvs::refine_pixel(rows, cols, nv, proj_key, unit, depth, conf, depth_constant, thr, min_depth, max_depth, e, depth_filter, conf_filter);
+}
+
 extern "C" {
 
 pvlm_status pvlm_mvs_filter_depth(pvlm_ctx* ctx, int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr,
@@ -186,6 +204,71 @@ pvlm_status pvlm_mvs_filter_depth(pvlm_ctx* ctx, int rows, int cols, int n_neigh
   }
   hipStreamSynchronize(ctx->stream);
   hipFree(d_unit); hipFree(d_nd); hipFree(d_proj); hipFree(d_depth); hipFree(d_conf); hipFree(d_out); hipFree(d_cout); hipFree(d_const);
+  return st;
+}
+
+pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* const* nei_conf,
+                                         const float* R_nr, const float* t_nr, const float* depth, float* conf, const unsigned char* depth_constant,
+                                         float depth_diff_threshold, float min_depth, float max_depth, float* depth_filter, float* conf_filter) {
+  if (!ctx || rows <= 0 || cols <= 0 || n_neighbors < 0 || n_neighbors > 16 || !depth || !conf || !depth_filter || !conf_filter ||
+      (n_neighbors > 0 && (!nei_depth || !nei_conf || !R_nr || !t_nr)))
+    return PVLM_ERR_ARG;
+  const size_t npix = (size_t)rows * cols;
+  if (npix > 0xffffffffull) { PVLM_SET_ERR(ctx, "pvlm_mvs_filter_depth_refine: %zu pixels exceed the 32-bit source index of the splat key", npix); return PVLM_ERR_ARG; }
+  for (int b = 0; b < n_neighbors; ++b) if (!nei_depth[b] || !nei_conf[b]) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t nn = (size_t)std::max(n_neighbors, 1);
+  float *d_unit = nullptr, *d_nd = nullptr, *d_nc = nullptr, *d_depth = nullptr, *d_conf = nullptr, *d_out = nullptr, *d_cout = nullptr;
+  unsigned long long* d_key = nullptr; unsigned char* d_const = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_unit, npix * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_nd, npix * nn);
+  if (!st) st = pvlm_i_alloc(ctx, &d_nc, npix * nn);
+  if (!st) st = pvlm_i_alloc(ctx, &d_key, npix * nn);
+  if (!st) st = pvlm_i_alloc(ctx, &d_depth, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_conf, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_out, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_cout, npix);
+  if (!st && depth_constant) st = pvlm_i_alloc(ctx, &d_const, npix);
+  if (!st) {
+    hipStream_t s = ctx->stream;
+    const unsigned grid = (unsigned)((npix + 255) / 256);
+    hipLaunchKernelGGL(k_mvs_unit_table, dim3(grid), dim3(256), 0, s, rows, cols, d_unit);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && n_neighbors > 0) {
+      hipLaunchKernelGGL(k_mvs_fill_u64, dim3((unsigned)((npix * n_neighbors + 255) / 256)), dim3(256), 0, s, (long long)(npix * n_neighbors), ~0ull, d_key);
+      e = hipGetLastError();
+    }
+    pvlm_mvs::RefineViews nv;
+    nv.n = n_neighbors;
+    for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
+      e = hipMemcpyAsync(d_nd + npix * (size_t)b, nei_depth[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_nc + npix * (size_t)b, nei_conf[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
+      pvlm_mvs_pose pose;
+      pvlm_mvs::inverse_pose(R_nr + 9 * b, t_nr + 3 * b, pose.R_rn, pose.t_rn);
+      nv.conf[b] = d_nc + npix * (size_t)b;
+      for (int k = 0; k < 9; ++k) nv.R[b][k] = R_nr[9 * b + k];
+      for (int k = 0; k < 3; ++k) nv.t[b][k] = t_nr[3 * b + k];
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_mvs_project_conf, dim3(grid), dim3(256), 0, s, rows, cols, d_unit, d_nd + npix * (size_t)b, pose, d_key + npix * (size_t)b);
+        e = hipGetLastError();
+      }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_conf, conf, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && depth_constant) e = hipMemcpyAsync(d_const, depth_constant, npix, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_mvs_refine, dim3(grid), dim3(256), 0, s, rows, cols, nv, d_key, d_unit, d_depth, d_conf, d_const, depth_diff_threshold, min_depth,
+                         max_depth, d_out, d_cout);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(depth_filter, d_out, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(conf_filter, d_cout, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(conf, d_conf, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_filter_depth_refine: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_unit); hipFree(d_nd); hipFree(d_nc); hipFree(d_key); hipFree(d_depth); hipFree(d_conf); hipFree(d_out); hipFree(d_cout); hipFree(d_const);
   return st;
 }
 

@@ -208,4 +208,86 @@ PVLM_HD inline void filter_pixel(int rows, int cols, int n_neighbors, const unsi
   if (conf && conf_filter) conf_filter[e] = conf[e];
 }
 
+// ---- FilterDepthImageRefine (mvs/MVS.cpp:1794-1890) with ProjectDepthConfToRef projecting depth AND confidence ----
+// Sequentially (raster order) a target pixel ends with the smallest range it received and the confidence of the LAST
+// source pixel whose range equals that minimum (a write happens whenever !(d != 0 && d < range)).  Order-free form:
+// one 64-bit atomicMin of key = range_bits << 32 | (0xffffffff - source index); rows x cols keys initialised to ~0.
+#ifndef PVLM_ATOMIC_MIN_U64
+#define PVLM_ATOMIC_MIN_U64(ptr, v) atomicMin((ptr), (v))
+#endif
+PVLM_HD inline void project_splat_conf(int rows, int cols, const float* unit, const float* nei_depth, const float* R_rn, const float* t_rn, long long e,
+                                       unsigned long long* proj_key) {
+  const float dn = nei_depth[e];
+  const float pn[3] = {unit[3 * e] * dn, unit[3 * e + 1] * dn, unit[3 * e + 2] * dn};
+  float pr[3];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += R_rn[3 * r + c] * pn[c]; pr[r] = s + t_rn[r]; }
+  const float range = (float)sqrt((double)pr[0] * pr[0] + (double)pr[1] * pr[1] + (double)pr[2] * pr[2]);
+  float px[2];
+  cam_to_image(rows, cols, pr, px);
+  const int xs[2] = {(int)ceilf(px[0]), (int)floorf(px[0])}, ys[2] = {(int)ceilf(px[1]), (int)floorf(px[1])};
+  const unsigned long long key = ((unsigned long long)float_bits(range) << 32) | (unsigned long long)(0xffffffffu - (unsigned)e);
+  for (int b = 0; b < 2; ++b)
+    for (int a = 0; a < 2; ++a) {
+      const int x = xs[a], y = ys[b];
+      if (!(x >= 0 && y >= 0 && x < cols && y < rows)) continue;
+      PVLM_ATOMIC_MIN_U64(&proj_key[(size_t)y * cols + x], key);
+    }
+}
+PVLM_HD inline void projected_depth_conf(const unsigned long long* proj_key, const float* nei_conf, size_t e, float* d, float* c) {
+  const unsigned long long k = proj_key[e];
+  if (k == ~0ull) { *d = 0.f; *c = 0.f; return; }
+  *d = bits_float((unsigned)(k >> 32));
+  *c = nei_conf[0xffffffffu - (unsigned)(k & 0xffffffffull)];
+}
+
+struct RefineViews { const float* conf[16]; float R[16][9]; float t[16][3]; int n; };   // neighbour conf_map + T_nr
+
+// one reference pixel; proj_key: n images one after the other.  conf is in-out (zeroed where depth <= 0).
+PVLM_HD inline void refine_pixel(int rows, int cols, const RefineViews& nv, const unsigned long long* proj_key, const float* unit, const float* depth,
+                                 float* conf, const unsigned char* depth_constant, float thr, float min_depth, float max_depth, long long e,
+                                 float* depth_filter, float* conf_filter) {
+  const size_t npix = (size_t)rows * cols;
+  depth_filter[e] = 0.f;
+  conf_filter[e] = 0.f;
+  const float d = depth[e];
+  if (d <= 0) { conf[e] = 0.f; return; }
+  const float loose = thr * 1.2f;
+  float positive = conf[e], negative = 0.f, avg = d * positive;
+  int n_pos = 0, n_neg = 0;
+  bool bad = false;
+  for (int n = nv.n - 1; n >= 0; --n) {
+    float dn, cn;
+    projected_depth_conf(proj_key + npix * n, nv.conf[n], (size_t)e, &dn, &cn);
+    if (dn <= 0 && n_pos + n_neg + n < 2) { bad = true; break; }
+    if (fabsf((d - dn) / d) < loose) {
+      avg += dn * cn;
+      positive += cn;
+      n_pos += 1;
+    } else {
+      if (dn < d) negative += cn;           // occlusion
+      else {                                // free-space violation
+        const float X0[3] = {unit[3 * e] * d, unit[3 * e + 1] * d, unit[3 * e + 2] * d};
+        float X1[3], x1[2];
+        for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += nv.R[n][3 * r + c] * X0[c]; X1[r] = s + nv.t[n][r]; }
+        cam_to_image(rows, cols, X1, x1);
+        const int xr = (int)roundf(x1[0]), yr = (int)roundf(x1[1]);
+        if (xr >= 0 && yr >= 0 && xr < cols && yr < rows) {
+          const float c = nv.conf[n][(size_t)yr * cols + xr];
+          negative += (c > 0 ? c : cn);
+        } else negative += cn;
+      }
+      n_neg += 1;
+    }
+  }
+  if (!bad) {
+    avg /= positive;
+    if (n_pos >= 2 && positive > negative && avg >= min_depth && avg <= max_depth) {
+      depth_filter[e] = avg;
+      conf_filter[e] = positive - negative;
+      return;
+    }
+  }
+  if (depth_constant && depth_constant[e]) { depth_filter[e] = d; conf_filter[e] = 1.f; }
+}
+
 }  // namespace pvlm_mvs

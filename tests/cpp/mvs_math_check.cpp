@@ -6,6 +6,7 @@
 
 #define PVLM_HD
 #define PVLM_ATOMIC_MIN_U32(ptr, v) (*(ptr) = *(ptr) < (v) ? *(ptr) : (v))
+#define PVLM_ATOMIC_MIN_U64(ptr, v) (*(ptr) = *(ptr) < (v) ? *(ptr) : (v))
 #include "../../panovlm_amd/csrc/pvlm_mvs_core.h"
 
 extern "C" void chk_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
@@ -78,4 +79,28 @@ extern "C" void chk_mvs_filter(int rows, int cols, int n_neighbors, const float*
     for (size_t e = 0; e < npix; ++e) project_splat(rows, cols, unit.data(), nei_depth[b], R_rn, t_rn, (long long)e, proj.data() + npix * b);
   }
   for (size_t e = 0; e < npix; ++e) filter_pixel(rows, cols, n_neighbors, proj.data(), depth, conf, depth_constant, thr, (long long)e, depth_filter, conf_filter);
+}
+
+// FilterDepthImageRefine through the device bodies.  The source pixels are visited in REVERSE raster order on purpose:
+// the keyed minimum must reproduce the reference's sequential "last writer among the closest" whatever the order.
+extern "C" void chk_mvs_filter_refine(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* const* nei_conf, const float* R_nr,
+                                      const float* t_nr, const float* depth, float* conf, const unsigned char* depth_constant, float thr, float min_depth,
+                                      float max_depth, float* depth_filter, float* conf_filter) {
+  using namespace pvlm_mvs;
+  const size_t npix = (size_t)rows * cols;
+  std::vector<float> unit(npix * 3);
+  for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) unit_ray(rows, cols, c, r, &unit[3 * ((size_t)r * cols + c)]);
+  std::vector<unsigned long long> key(npix * (size_t)(n_neighbors > 0 ? n_neighbors : 1), ~0ull);
+  RefineViews nv;
+  nv.n = n_neighbors;
+  for (int b = 0; b < n_neighbors; ++b) {
+    float R_rn[9], t_rn[3];
+    inverse_pose(R_nr + 9 * b, t_nr + 3 * b, R_rn, t_rn);
+    for (size_t e = npix; e-- > 0;) project_splat_conf(rows, cols, unit.data(), nei_depth[b], R_rn, t_rn, (long long)e, key.data() + npix * b);
+    nv.conf[b] = nei_conf[b];
+    for (int k = 0; k < 9; ++k) nv.R[b][k] = R_nr[9 * b + k];
+    for (int k = 0; k < 3; ++k) nv.t[b][k] = t_nr[3 * b + k];
+  }
+  for (size_t e = 0; e < npix; ++e)
+    refine_pixel(rows, cols, nv, key.data(), unit.data(), depth, conf, depth_constant, thr, min_depth, max_depth, (long long)e, depth_filter, conf_filter);
 }

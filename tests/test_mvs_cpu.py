@@ -132,3 +132,72 @@ def test_depth_filter_oracle_behaviour_and_device_bodies(oracle):
     lib.chk_mvs_filter(C.c_int(depth.shape[0]), C.c_int(depth.shape[1]), C.c_int(len(nd)), dptrs, fp(R), fp(t), fp(depth), fp(conf),
                        const.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_float(0.01), fp(od), fp(oc))
     assert np.array_equal(od, df) and np.array_equal(oc, cf)
+
+
+def _refine_scene(oracle, rows=96, cols=192):
+    nd, Rn, tn, depth, conf, const = _filter_scene(oracle, rows, cols)
+    rng = np.random.default_rng(11)
+    nc = [rng.uniform(-0.3, 1.0, size=depth.shape).astype(np.float32).clip(0, None) for _ in nd]   # ConvertNCC2Conf: negatives are already 0
+    depth = depth * rng.uniform(0.995, 1.005, size=depth.shape).astype(np.float32)                  # estimates scatter around the surface
+    depth[20:26, 100:130] *= 0.7        # in front of what the neighbours see: free-space violation
+    depth[70:76, 20:60] *= 1.4          # behind it: occlusion
+    return nd, nc, Rn, tn, depth, conf, const
+
+
+def test_depth_conf_projection_keeps_last_closest_writer(oracle):
+    """ProjectDepthConfToRef with both outputs: range = the minimum, confidence = that of the last raster-order source
+    among those at the minimum range (checked with a numpy restatement of the sequential rule)."""
+    nd, nc, Rn, tn, *_ = _refine_scene(oracle, 48, 96)
+    pd, pc = oracle.mvs_project_depth_conf(nd[1], nc[1], Rn[1], tn[1])
+    only_d, _ = oracle.mvs_filter_depth([], np.zeros((0, 9)), np.zeros((0, 3)), nd[1])   # shapes only
+    assert pd.shape == only_d.shape
+    rows, cols = pd.shape
+    jj, ii = np.meshgrid(np.arange(cols), np.arange(rows))
+    unit = oracle.image_to_cam(rows, cols, np.stack([jj.ravel(), ii.ravel()], 1).astype(np.float32), 1.0)
+    R_rn = Rn[1].reshape(3, 3).T.astype(np.float32); t_rn = (-R_rn) @ tn[1].astype(np.float32)
+    pr = (unit * nd[1].reshape(-1, 1)) @ R_rn.T + t_rn
+    rng_ = np.linalg.norm(pr.astype(np.float64), axis=1).astype(np.float32)
+    px = oracle.cam_to_image(rows, cols, pr.astype(np.float32))
+    want_d = np.zeros(rows * cols, np.float32); want_c = np.zeros(rows * cols, np.float32)
+    for e in range(rows * cols):
+        for y in (int(np.ceil(px[e, 1])), int(np.floor(px[e, 1]))):
+            for x in (int(np.ceil(px[e, 0])), int(np.floor(px[e, 0]))):
+                if 0 <= x < cols and 0 <= y < rows:
+                    k = y * cols + x
+                    if want_d[k] != 0 and want_d[k] < rng_[e]:
+                        continue
+                    want_d[k] = rng_[e]; want_c[k] = nc[1].ravel()[e]
+    hit = want_d > 0
+    assert hit.mean() > 0.5
+    # the independent numpy transform may round a range differently in the last bit; the structure must agree
+    assert np.allclose(pd.ravel(), want_d, rtol=2e-6, atol=0) and (pc.ravel() == want_c).mean() > 0.995
+
+
+def test_depth_filter_refine_oracle_behaviour_and_device_bodies(oracle):
+    nd, nc, Rn, tn, depth, conf, const = _refine_scene(oracle)
+    df, cf, conf_after = oracle.mvs_filter_depth_refine(nd, nc, Rn, tn, depth, conf, depth_constant=const, thr=0.01, min_depth=0.1, max_depth=20.0)
+    kept = df > 0
+    assert 0.15 < kept.mean() < 0.95
+    assert np.all(conf_after[depth <= 0] == 0) and np.array_equal(conf_after[depth > 0], conf[depth > 0])
+    assert not kept[60:64, 100:140].any()                                   # holes stay holes
+    fused = kept & (const == 0)
+    assert np.abs(df[fused] / depth[fused] - 1).max() < 0.012               # an average of depths that agree within 1.2 %
+    assert (cf[fused] > 0).all()                                            # positive - negative, accepted only when positive wins
+    assert np.all(df[(const == 1) & ~fused & (depth > 0)] == depth[(const == 1) & ~fused & (depth > 0)])
+    for band in (np.s_[20:26, 100:130], np.s_[70:76, 20:60]):               # the displaced bands disagree with every neighbour
+        assert kept[band].mean() < 0.05
+    # a tight depth range rejects the averaged depth (IsInside(avg, min_depth, max_depth))
+    near, _, _ = oracle.mvs_filter_depth_refine(nd, nc, Rn, tn, depth, conf, thr=0.01, min_depth=0.1, max_depth=float(np.median(depth[depth > 0])))
+    assert 0 < (near > 0).sum() < (df[const == 0] > 0).sum()
+    # device bodies on the host (reverse-order splat): bit for bit
+    out = os.path.join(ROOT, "build", "libmvs_check.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "cpp", "mvs_math_check.cpp")])
+    lib = C.CDLL(out)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    nd = [np.ascontiguousarray(x, np.float32) for x in nd]; nc = [np.ascontiguousarray(x, np.float32) for x in nc]
+    dptrs = (C.POINTER(C.c_float) * len(nd))(*[fp(x) for x in nd]); cptrs = (C.POINTER(C.c_float) * len(nc))(*[fp(x) for x in nc])
+    R = np.ascontiguousarray(Rn, np.float32); t = np.ascontiguousarray(tn, np.float32)
+    od = np.zeros_like(depth); oc = np.zeros_like(depth); cc = conf.copy()
+    lib.chk_mvs_filter_refine(C.c_int(depth.shape[0]), C.c_int(depth.shape[1]), C.c_int(len(nd)), dptrs, cptrs, fp(R), fp(t), fp(depth), fp(cc),
+                              const.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_float(0.01), C.c_float(0.1), C.c_float(20.0), fp(od), fp(oc))
+    assert np.array_equal(od, df) and np.array_equal(oc, cf) and np.array_equal(cc, conf_after)

@@ -77,3 +77,21 @@ def test_depth_filter_matches_oracle(ctx, oracle):
     # no neighbours: nothing survives
     d0, _ = ctx.mvs_filter_depth([], np.zeros((0, 9)), np.zeros((0, 3)), depth)
     assert np.all(d0 == 0)
+
+
+def test_depth_filter_refine_matches_oracle(ctx, oracle):
+    """pvlm_mvs_filter_depth_refine (FilterDepthImageRefine + ProjectDepthConfToRef with confidences): bit-exact — the keyed
+    64-bit atomicMin reproduces the sequential "last writer among the closest", the per-pixel fusion is the reference's
+    float arithmetic (compiled with -ffp-contract=off)."""
+    from tests.test_mvs_cpu import _refine_scene
+    for rows, cols in ((96, 192), (180, 360)):
+        nd, nc, Rn, tn, depth, conf, const = _refine_scene(oracle, rows, cols)
+        for kw in (dict(depth_constant=const, thr=0.01), dict(thr=0.03, max_depth=float(np.median(depth[depth > 0])))):
+            do, co, ca = oracle.mvs_filter_depth_refine(nd, nc, Rn, tn, depth, conf, **kw)
+            dg, cg, cb = ctx.mvs_filter_depth_refine(nd, nc, Rn, tn, depth, conf, **kw)
+            assert np.array_equal(do, dg) and np.array_equal(co, cg) and np.array_equal(ca, cb)
+            assert 0.1 < (do > 0).mean() < 0.95
+    # no neighbours: nothing can be confirmed; only depth_constant pixels come through, with confidence 1
+    d0, c0, _ = ctx.mvs_filter_depth_refine([], [], np.zeros((0, 9)), np.zeros((0, 3)), depth, conf, depth_constant=const)
+    keep = (const == 1) & (depth > 0)
+    assert np.array_equal(d0[keep], depth[keep]) and np.all(c0[keep] == 1) and not d0[~keep].any()

@@ -48,6 +48,18 @@ def main():
     t0 = time.perf_counter()
     dfo, _ = orc.mvs_filter_depth(nd, np.array(Rn), np.array(tn), depth, conf=co, thr=0.01)
     filt_cpu = time.perf_counter() - t0
+    # the filter the pipeline runs (FilterDepthImageRefine): confidences of the scoring pass, negatives clamped (ConvertNCC2Conf)
+    nc = [np.clip(orc.mvs_init_conf_map(views[k][0], [gray], *[np.array(x)[None] for x in synth.relative_pose(poses[k][0], poses[k][1], poses[ref][0], poses[ref][1])],
+                                        views[k][1], views[k][2], a.half_window, a.step)[0], 0, None) for k in nei]
+    cref = np.clip(cg, 0, None)
+    ctx.mvs_filter_depth_refine(nd, nc, np.array(Rn), np.array(tn), depth, cref)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rdg, rcg, _ = ctx.mvs_filter_depth_refine(nd, nc, np.array(Rn), np.array(tn), depth, cref)
+    ref_wall = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    rdo, rco, _ = orc.mvs_filter_depth_refine(nd, nc, np.array(Rn), np.array(tn), depth, cref)
+    ref_cpu = time.perf_counter() - t0
     w = 2 * a.half_window + 1; q = w // a.step + (1 if a.step > 1 else 0)
     texels = a.rows * a.cols * q * q * a.neighbors
     k_ms = ms / max(cnt, 1)
@@ -56,7 +68,10 @@ def main():
                           M_pixels_per_s=a.rows * a.cols / k_ms / 1e3, G_texel_projections_per_s=texels / k_ms / 1e6,
                           wall_ms_incl_copies=wall * 1e3, cpu_oracle_s=cpu,
                           filter=dict(wall_ms_incl_copies=filt_wall * 1e3, kept=float((dfg > 0).mean()), identical_to_oracle=bool(np.array_equal(dfg, dfo)),
-                                      cpu_oracle_s_single_thread=filt_cpu), cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
+                                      cpu_oracle_s_single_thread=filt_cpu),
+                          filter_refine=dict(wall_ms_incl_copies=ref_wall * 1e3, kept=float((rdg > 0).mean()),
+                                             identical_to_oracle=bool(np.array_equal(rdg, rdo) and np.array_equal(rcg, rco)), cpu_oracle_s_single_thread=ref_cpu),
+                          cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
 
 
 if __name__ == "__main__":
