@@ -400,3 +400,47 @@ def assoc_by_angle(rows, cols, lines, lidar_local, T_cl, multiple=True):
     assert m >= 0
     return dict(image_line_id=ii[:m].copy(), lidar_line_id=li[:m].copy(), score=sc[:m].copy(), start=st[:m].copy(),
                 end=en[:m].copy(), votes=votes)
+
+
+class ScanFeatures:
+    """ReOrderVLP (+ ExtractFeatures, ADAPTIVE, planar branch) of oracle/features.hpp on one raw scan (n x 4 float32)."""
+
+    CLOUDS = {"cloud_scan": 0, "cornerSharp": 1, "cornerLessSharp": 2, "surfFlat": 3, "surfLessFlat": 4}
+
+    def __init__(self, cloud, n_scans=16, horizon=1800, max_curvature=1000.0, intersect_angle_threshold=5.0, segment=True, extract=True):
+        c = _f32(cloud).reshape(-1, 4)
+        L = lib()
+        L.orc_features_create.restype = C.c_void_p
+        L.orc_features_cloud.restype = C.c_long
+        h = C.c_void_p(L.orc_features_create(C.c_long(len(c)), _p(c, C.c_float), C.c_int(n_scans), C.c_int(horizon), C.c_float(max_curvature),
+                                             C.c_float(intersect_angle_threshold), C.c_int(1 if segment else 0), C.c_int(1 if extract else 0)))
+        try:
+            self.valid = bool(L.orc_features_valid(h))
+            for name, which in self.CLOUDS.items():
+                n = L.orc_features_cloud(h, C.c_int(which), None)
+                out = np.zeros((n, 4), np.float32)
+                L.orc_features_cloud(h, C.c_int(which), _p(out, C.c_float))
+                setattr(self, name, out)
+            n = len(self.cloud_scan)
+            self.rc = np.zeros((n, 2), np.int32)
+            have = extract and self.valid and n > 0
+            self.curvature = np.zeros(n if have else 0, np.float32)
+            self.state, self.sort_ind, self.left, self.right = (np.zeros(n if have else 0, np.int32) for _ in range(4))
+            self.scan_start = np.zeros(n_scans, np.int32); self.scan_end = np.zeros(n_scans, np.int32)
+            self.range_image = np.zeros((n_scans, horizon), np.float32)
+            self.image_to_point_idx = np.zeros((n_scans, horizon), np.int32)
+            L.orc_features_arrays(h, _p(self.rc, C.c_int), _p(self.curvature, C.c_float) if have else None, _p(self.state, C.c_int) if have else None,
+                                  _p(self.sort_ind, C.c_int) if have else None, _p(self.left, C.c_int) if have else None,
+                                  _p(self.right, C.c_int) if have else None, _p(self.scan_start, C.c_int), _p(self.scan_end, C.c_int),
+                                  _p(self.range_image, C.c_float), _p(self.image_to_point_idx, C.c_int))
+        finally:
+            L.orc_features_free(h)
+
+
+def voxel_grid(cloud, leaf):
+    c = _f32(cloud).reshape(-1, 4)
+    out = np.zeros((max(len(c), 1), 4), np.float32)
+    lib().orc_voxel_grid.restype = C.c_long
+    n = lib().orc_voxel_grid(C.c_long(len(c)), _p(c, C.c_float), C.c_float(leaf), _p(out, C.c_float))
+    return out[:n]
+

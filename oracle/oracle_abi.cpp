@@ -9,6 +9,7 @@
 #include "associate.hpp"
 #include "costfunction.hpp"
 #include "equirect.hpp"
+#include "features.hpp"
 #include "mvs.hpp"
 
 using namespace oracle;
@@ -273,6 +274,48 @@ int orc_assoc_by_angle(int rows, int cols, const float* lines, int n_lines, cons
   }
   if (votes) std::memcpy(votes, dbg.votes.data(), dbg.votes.size() * sizeof(int));
   return int(pairs.size());
+}
+
+
+// ---- LiDAR feature extraction, planar branch (features.hpp).  cloud: n x 4 float (x, y, z, intensity), LoadLidar's output.
+void* orc_features_create(long n, const float* cloud, int n_scans, int horizon, float max_curvature, float intersect_angle_threshold, int segment,
+                          int extract) {
+  std::vector<FPoint> c(n);
+  for (long i = 0; i < n; ++i) c[i] = FPoint{cloud[4 * i], cloud[4 * i + 1], cloud[4 * i + 2], cloud[4 * i + 3]};
+  ScanFeatures* f = new ScanFeatures();
+  ReOrderVLP(c, n_scans, horizon, *f);
+  if (extract) ExtractFeatures(*f, max_curvature, intersect_angle_threshold, segment != 0);
+  return f;
+}
+void orc_features_free(void* h) { delete static_cast<ScanFeatures*>(h); }
+int orc_features_valid(void* h) { return static_cast<ScanFeatures*>(h)->valid ? 1 : 0; }
+static const std::vector<FPoint>* feature_cloud(const ScanFeatures* f, int which) {
+  switch (which) { case 0: return &f->cloud_scan; case 1: return &f->cornerSharp; case 2: return &f->cornerLessSharp; case 3: return &f->surfFlat; case 4: return &f->surfLessFlat; }
+  return nullptr;
+}
+// which: 0 cloud_scan, 1 cornerSharp, 2 cornerLessSharp (before EdgeToLine), 3 surfFlat, 4 surfLessFlat
+long orc_features_cloud(void* h, int which, float* out) {
+  const std::vector<FPoint>* c = feature_cloud(static_cast<ScanFeatures*>(h), which);
+  if (!c) return -1;
+  if (out) for (size_t i = 0; i < c->size(); ++i) { out[4 * i] = (*c)[i].x; out[4 * i + 1] = (*c)[i].y; out[4 * i + 2] = (*c)[i].z; out[4 * i + 3] = (*c)[i].intensity; }
+  return (long)c->size();
+}
+// per-point arrays of cloud_scan (each n_scan_points long; null = skip); rc = (row, col) pairs; scan_start / scan_end: n_scans
+void orc_features_arrays(void* h, int* rc, float* curvature, int* state, int* sort_ind, int* left, int* right, int* scan_start, int* scan_end,
+                         float* range_image, int* image_to_point_idx) {
+  const ScanFeatures* f = static_cast<ScanFeatures*>(h);
+  const size_t n = f->cloud_scan.size();
+  if (rc) for (size_t i = 0; i < n; ++i) { rc[2 * i] = f->point_idx_to_image[i].first; rc[2 * i + 1] = f->point_idx_to_image[i].second; }
+  auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+  cp(curvature, f->curvature); cp(state, f->state); cp(sort_ind, f->sortInd); cp(left, f->left); cp(right, f->right);
+  cp(scan_start, f->scanStartInd); cp(scan_end, f->scanEndInd); cp(range_image, f->range_image); cp(image_to_point_idx, f->image_to_point_idx);
+}
+long orc_voxel_grid(long n, const float* cloud, float leaf, float* out) {
+  std::vector<FPoint> c(n);
+  for (long i = 0; i < n; ++i) c[i] = FPoint{cloud[4 * i], cloud[4 * i + 1], cloud[4 * i + 2], cloud[4 * i + 3]};
+  const std::vector<FPoint> o = VoxelGrid(c, leaf);
+  for (size_t i = 0; i < o.size(); ++i) { out[4 * i] = o[i].x; out[4 * i + 1] = o[i].y; out[4 * i + 2] = o[i].z; out[4 * i + 3] = o[i].intensity; }
+  return (long)o.size();
 }
 
 }  // extern "C"

@@ -1,0 +1,364 @@
+// LiDAR feature extraction in front of the hot path, planar branch — host side.
+//   Velodyne::ReOrderVLP       sensors/Velodyne.cpp:371-526
+//   Velodyne::Segmentation     sensors/Velodyne.cpp:1438-1586
+//   Velodyne::ExtractFeatures  sensors/Velodyne.cpp:531-760 (ADAPTIVE) -> ExtractEdgeFeatures2 :883-1000, ExtractPlaneFeatures2 :1098-1189
+// One scan is 28.8 k points and every stage is a dependency chain (the column state machine of the re-ordering, the
+// component labelling of the range image, greedy picks with non-maximum suppression along a ring), so this stays host
+// code, parallel over scans like lidar_mapping/LidarOdometry.cpp:131-147; the clouds it produces are what
+// Velodyne::DeviceScan uploads for the GPU association.  The arithmetic is the reference's float arithmetic
+// (`using namespace std` there: the float overloads of sqrt / atan / atan2 / acos / sin / cos), compiled with
+// -ffp-contract=off.  pcl::VoxelGrid and Eigen's 3-vector reductions are restated as documented in oracle/features.hpp.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <stdexcept>
+
+#include "pvlm_host.hpp"
+
+namespace pvlm {
+namespace {
+
+inline float Dist2(const PointXYZI& a, const PointXYZI& b) {   // base/Geometry.hpp:38-40
+  const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// sensors/Velodyne.cpp:170-211
+int RingOfElevation(float deg, int rings) {
+  int id = -1;
+  if (rings == 16) {
+    id = int((deg + 15) / 2 + 0.5);
+    if (id > 15 || id < 0) id = -1;
+  } else if (rings == 32) {
+    id = int((deg + 92.0 / 3.0) * 3.0 / 4.0);
+    if (id > 31 || id < 0) id = -1;
+  } else if (rings == 64) {
+    id = deg >= -8.83 ? int((2 - deg) * 3.0 + 0.5) : 32 + int((-8.83 - deg) * 2.0 + 0.5);
+    if (deg > 2 || deg < -24.33 || id > 50 || id < 0) id = -1;
+  }
+  return id;
+}
+
+inline double Azimuth(const PointXYZI& p) {   // atan2(float, float) in [0, 2 pi)
+  double a = std::atan2(p.x, p.z);
+  if (a < 0) a += 2 * M_PI;
+  return a;
+}
+
+// position of a ring in the VLP-16 firing sequence (the std::map of :407-414; a missing key reads as 0)
+inline int FiringSlot(int ring, int rings) { return (rings != 16 || ring < 0) ? 0 : (ring <= 7 ? 2 * ring : 2 * ring - 15); }
+
+// pcl::VoxelGrid<PointXYZI>, leaf x leaf x leaf, all fields averaged (see oracle/features.hpp for what is recalled)
+struct VoxelKey { unsigned cell, point; };
+inline bool operator<(const VoxelKey& a, const VoxelKey& b) { return a.cell < b.cell; }
+
+void VoxelGridAppend(const PointCloud& in, float leaf, float tag, PointCloud& out) {
+  if (in.empty()) return;
+  const float inv = 1.f / leaf;
+  float lo[3] = {in[0].x, in[0].y, in[0].z}, hi[3] = {in[0].x, in[0].y, in[0].z};
+  for (const PointXYZI& p : in) {
+    const float v[3] = {p.x, p.y, p.z};
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], v[k]); hi[k] = std::max(hi[k], v[k]); }
+  }
+  int64_t cells = 1;
+  for (int k = 0; k < 3; ++k) cells *= (int64_t)((hi[k] - lo[k]) * inv) + 1;
+  if (cells > (int64_t)INT32_MAX) {                                  // PCL: leaf too small for the extent -> input passed through
+    for (PointXYZI p : in) { p.intensity = tag; out.push_back(p); }
+    return;
+  }
+  int base[3], dim[3];
+  for (int k = 0; k < 3; ++k) { base[k] = (int)std::floor(lo[k] * inv); dim[k] = (int)std::floor(hi[k] * inv) - base[k] + 1; }
+  const int stride_y = dim[0], stride_z = dim[0] * dim[1];
+  std::vector<VoxelKey> keys;
+  keys.reserve(in.size());
+  for (unsigned i = 0; i < in.size(); ++i) {
+    const PointXYZI& p = in[i];
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    const int cx = (int)(std::floor(p.x * inv) - (float)base[0]);
+    const int cy = (int)(std::floor(p.y * inv) - (float)base[1]);
+    const int cz = (int)(std::floor(p.z * inv) - (float)base[2]);
+    keys.push_back(VoxelKey{(unsigned)(cx + cy * stride_y + cz * stride_z), i});
+  }
+  std::sort(keys.begin(), keys.end(), std::less<VoxelKey>());
+  size_t first = 0;
+  while (first < keys.size()) {
+    size_t last = first;
+    float sum[3] = {0, 0, 0};
+    while (last < keys.size() && keys[last].cell == keys[first].cell) {
+      const PointXYZI& p = in[keys[last].point];
+      sum[0] += p.x; sum[1] += p.y; sum[2] += p.z;
+      ++last;
+    }
+    const float n = (float)(last - first);
+    out.push_back(PointXYZI{sum[0] / n, sum[1] / n, sum[2] / n, tag});   // the caller overwrites intensity with the class tag (:1177-1178, :1186-1187)
+    first = last;
+  }
+}
+
+// union-find over range-image cells
+struct DisjointSets {
+  std::vector<int> parent;
+  explicit DisjointSets(size_t n) : parent(n) { std::iota(parent.begin(), parent.end(), 0); }
+  int Find(int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; }
+  void Union(int a, int b) { a = Find(a); b = Find(b); if (a != b) parent[std::max(a, b)] = std::min(a, b); }   // root = smallest cell = the BFS seed
+};
+
+}  // namespace
+
+void Velodyne::ReOrderVLP() {
+  if (!valid) return;
+  if (!cloud_scan.empty()) return;
+  RingLayout& L = layout_;
+  L = RingLayout();
+  L.image_to_point_idx.assign((size_t)N_SCANS * horizon_scans, -1);
+  L.scanStartInd.assign(N_SCANS, 0);
+  L.scanEndInd.assign(N_SCANS, 0);
+  if (N_SCANS != 16 && N_SCANS != 32 && N_SCANS != 64) { fprintf(stderr, "only support velodyne with 16, 32 or 64 scan line!\n"); return; }
+  L.range_image.assign((size_t)N_SCANS * horizon_scans, 0.f);
+  const int n = (int)cloud.size();
+  if (n == 0) return;
+  const double column_width = 2.0 * M_PI / horizon_scans;
+  const double first_azimuth = Azimuth(cloud[0]);
+  // pass 1 (sequential: the wrap detection and the column correction carry state from point to point): ring + column
+  std::vector<int> ring_of(n, -1), col_of(n, -1);
+  std::vector<int> ring_count(N_SCANS, 0);
+  bool wrapped = false;          // the sweep has passed the +z axis once (:416-417, :447-461)
+  double prev_azimuth = -1;
+  int shift = 0, prev_col = 0, prev_ring = -1;
+  for (int i = 0; i < n; ++i) {
+    const PointXYZI& p = cloud[i];
+    const float elevation = std::atan(-p.y / std::sqrt(p.x * p.x + p.z * p.z)) * 180 / M_PI;
+    const int ring = RingOfElevation(elevation, N_SCANS);
+    if (ring < 0) continue;
+    double azimuth = Azimuth(p);
+    if (azimuth < prev_azimuth && !wrapped) {
+      // believed only when the next N_SCANS returns all lie behind the previous azimuth as well
+      int behind = 0;
+      for (int j = i + 1; j < i + N_SCANS + 1 && j < n && behind < N_SCANS; ++j) behind += Azimuth(cloud[j]) < prev_azimuth ? 1 : 0;
+      wrapped = behind >= N_SCANS;
+    }
+    azimuth += 2 * M_PI * (wrapped ? 1 : 0);
+    int col = std::round((azimuth - first_azimuth) / column_width);
+    if (FiringSlot(ring, N_SCANS) < FiringSlot(prev_ring, N_SCANS)) {   // a new firing sequence started: same column as the last one?
+      shift = prev_col == col ? 1 : 0;
+      prev_col = col + shift;
+    }
+    prev_ring = ring;
+    col += shift;
+    while (col >= horizon_scans) col -= horizon_scans;
+    if (col < 0) continue;
+    ring_of[i] = ring; col_of[i] = col;
+    ring_count[ring]++;
+    L.range_image[(size_t)ring * horizon_scans + col] = std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+    prev_azimuth = azimuth;
+  }
+  // pass 2: stable counting sort by ring
+  std::vector<int> ring_begin(N_SCANS + 1, 0);
+  for (int r = 0; r < N_SCANS; ++r) ring_begin[r + 1] = ring_begin[r] + ring_count[r];
+  const int kept = ring_begin[N_SCANS];
+  cloud_scan.assign(kept, PointXYZI{0, 0, 0, 0});
+  L.point_idx_to_image.assign(kept, std::pair<int, int>(0, 0));
+  std::vector<int> cursor(ring_begin.begin(), ring_begin.end() - 1);
+  for (int i = 0; i < n; ++i) {
+    const int ring = ring_of[i];
+    if (ring < 0) continue;
+    const int dst = cursor[ring]++;
+    cloud_scan[dst] = PointXYZI{cloud[i].x, cloud[i].y, cloud[i].z, (float)ring};
+    L.point_idx_to_image[dst] = std::pair<int, int>(ring, col_of[i]);
+    L.image_to_point_idx[(size_t)ring * horizon_scans + col_of[i]] = dst;
+  }
+  for (int r = 0; r < N_SCANS; ++r) { L.scanStartInd[r] = ring_begin[r] + 5; L.scanEndInd[r] = ring_begin[r + 1] - 6; }
+}
+
+void Velodyne::Segmentation() {
+  RingLayout& L = layout_;
+  const int rows = N_SCANS, cols = horizon_scans;
+  const size_t cells = (size_t)rows * cols;
+  const float alpha_x = 0.2 / 180.0 * M_PI, alpha_y = 2.0 / 180.0 * M_PI, theta = 20.0 / 180.0 * M_PI;
+  const float sin_x = std::sin(alpha_x), cos_x = std::cos(alpha_x), sin_y = std::sin(alpha_y), cos_y = std::cos(alpha_y);
+  auto joined = [&](float a, float b, bool same_row) {
+    const float far = std::max(a, b), near = std::min(a, b);
+    const float angle = same_row ? std::atan2(near * sin_x, far - near * cos_x) : std::atan2(near * sin_y, far - near * cos_y);
+    return angle > theta;
+  };
+  // components of the symmetric "joined" relation between 4-neighbours (columns wrap around) = the BFS labels of :1463-1530
+  DisjointSets sets(cells);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const int here = r * cols + c;
+      const int right = r * cols + (c + 1 == cols ? 0 : c + 1);
+      if (right != here && joined(L.range_image[here], L.range_image[right], true)) sets.Union(here, right);
+      if (r + 1 < rows && joined(L.range_image[here], L.range_image[here + cols], false)) sets.Union(here, here + cols);
+    }
+  // per component: size and the rows that hold a cell OTHER than the seed (the BFS flags the row of every pushed cell;
+  // the seed — the first cell in raster order — is never pushed)
+  std::vector<int> size(cells, 0);
+  std::vector<uint64_t> row_mask(cells, 0);
+  for (size_t cell = 0; cell < cells; ++cell) {
+    const int root = sets.Find((int)cell);
+    size[root]++;
+    if ((int)cell != root) row_mask[root] |= 1ull << (cell / cols);
+  }
+  auto keep = [&](int root) {
+    if (size[root] >= 30) return true;
+    if (size[root] >= 5) return __builtin_popcountll(row_mask[root]) >= 3;
+    return false;
+  };
+  // drop the points of rejected components, ring order preserved
+  PointCloud kept;
+  kept.reserve(cloud_scan.size());
+  std::vector<std::pair<int, int>> kept_rc;
+  std::vector<int> cell_to_point(cells, -1);
+  std::vector<int> ring_count(rows, 0);
+  for (size_t i = 0; i < cloud_scan.size(); ++i) {
+    const std::pair<int, int> rc = L.point_idx_to_image[i];
+    const int cell = rc.first * cols + rc.second;
+    if (!keep(sets.Find(cell))) continue;
+    cell_to_point[cell] = (int)kept.size();
+    kept.push_back(cloud_scan[i]);
+    kept_rc.push_back(rc);
+    ring_count[(int)cloud_scan[i].intensity]++;
+  }
+  cloud_scan.swap(kept);
+  L.point_idx_to_image.swap(kept_rc);
+  L.image_to_point_idx.swap(cell_to_point);
+  int begin = 0;
+  for (int r = 0; r < rows; ++r) { L.scanStartInd[r] = begin + 5; begin += ring_count[r]; L.scanEndInd[r] = begin - 6; }
+}
+
+void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_threshold, int method, bool segment, ExtractionTrace* trace) {
+  if (!valid) return;
+  if (method != ADAPTIVE) throw std::invalid_argument("ExtractFeatures: only the ADAPTIVE method (config/Room.txt:32) is mirrored");
+  if (cloud_scan.empty()) { fprintf(stderr, "cloud_scan is empty, call Reorder first\n"); return; }
+  if (!cornerLessSharp.empty() || !surfLessFlat.empty()) return;
+  if (N_SCANS > 64) throw std::invalid_argument("ExtractFeatures: at most 64 rings");
+  const size_t before = cloud_scan.size();
+  if (segment) Segmentation();
+  if (cloud_scan.size() < before * 0.1) { fprintf(stderr, "LiDAR data %d has something wrong\n", id); valid = false; return; }
+  const RingLayout& L = layout_;
+  const int n = (int)cloud_scan.size();
+  const PointCloud& P = cloud_scan;
+  std::vector<float> curvature(n, -1.f), range(n);
+  std::vector<int> state(n, POINT_NORMAL), order(n), left(n, -1), right(n, -1);
+  std::iota(order.begin(), order.end(), 0);
+  for (int i = 0; i < n; ++i) range[i] = L.range_image[(size_t)L.point_idx_to_image[i].first * horizon_scans + L.point_idx_to_image[i].second];
+
+  // ---- curvature over a window grown until both ends are >= 8 cm away (:623-657).  Kept as upstream, including the
+  // right-hand walk that is guarded by the LEFT index and the window check that tests the left end twice; where
+  // upstream would read past the end of the cloud (undefined behaviour) the walk stops and the point gets no curvature.
+  for (int ring = 0; ring < N_SCANS; ++ring) {
+    const int lo = L.scanStartInd[ring], hi = L.scanEndInd[ring];
+    if ((size_t)(hi - lo) < (size_t)5) continue;
+    for (int i = lo; i <= hi; ++i) {
+      int a = i - 5, b = i + 5;
+      while (a >= lo && Dist2(P[a], P[i]) < 0.0064) --a;
+      while (a <= hi && b < n && Dist2(P[b], P[i]) < 0.0064) ++b;
+      const int half = std::max(i - a, b - i);
+      a = i - half; b = i + half;
+      if (a < lo - 5 || a > hi + 5 || b >= n) continue;
+      float acc = 0;
+      for (int k = a; k <= b; ++k) acc += range[k];
+      acc -= (b - a + 1) * range[i];
+      acc /= (b - a);
+      curvature[i] = std::abs(acc);
+      left[i] = a; right[i] = b;
+    }
+  }
+  // the six sectors of a ring (:707-723) — the same integer arithmetic everywhere below
+  auto sector = [&](int ring, int j, int* sp, int* ep) {
+    const int lo = L.scanStartInd[ring], span = L.scanEndInd[ring] - lo;
+    *sp = lo + span * j / 6;
+    *ep = lo + span * (j + 1) / 6 - 1;
+  };
+  auto usable = [&](int ring) { return L.scanEndInd[ring] - L.scanStartInd[ring] >= 6; };
+  {
+    const float* c = curvature.data();
+    for (int ring = 0; ring < N_SCANS; ++ring) {
+      if (!usable(ring)) continue;
+      for (int j = 0; j < 6; ++j) {
+        int sp, ep; sector(ring, j, &sp, &ep);
+        std::sort(order.begin() + sp, order.begin() + ep + 1, [c](int x, int y) { return c[x] < c[y]; });
+      }
+    }
+  }
+  // non-maximum suppression around a picked point (:969-986, :1140-1155)
+  auto suppress = [&](int ind, int ring) {
+    const int lo = L.scanStartInd[ring], hi = L.scanEndInd[ring];
+    for (int l = 1; ind + l <= hi; ++l) {
+      if (l <= 5 ? Dist2(P[ind + l], P[ind + l - 1]) > 0.05 : Dist2(P[ind + l], P[ind]) > 0.0036) break;
+      state[ind + l] |= POINT_DISABLE;
+    }
+    for (int l = 1; ind - l >= lo; ++l) {
+      if (l <= 5 ? Dist2(P[ind - l], P[ind - l + 1]) > 0.05 : Dist2(P[ind - l], P[ind]) > 0.0036) break;
+      state[ind - l] |= POINT_DISABLE;
+    }
+  };
+
+  // ---- ExtractEdgeFeatures2 (:883-1000): per sector, from the largest curvature down, at most 3 sharp + 27 less sharp
+  cornerSharp.clear(); cornerLessSharp.clear();
+  for (int ring = 0; ring < N_SCANS; ++ring) {
+    if (!usable(ring)) continue;
+    for (int j = 0; j < 6; ++j) {
+      int sp, ep; sector(ring, j, &sp, &ep);
+      int picked = 0;
+      for (int k = ep; k >= sp; --k) {
+        const int ind = order[k];
+        if (state[ind] != POINT_NORMAL) continue;
+        if (curvature[ind] > max_curvature || curvature[ind] < 0.1) continue;
+        // incidence angle between the beam and the local surface direction (left - right window ends), degrees
+        const PointXYZI &a = P[ind], &l = P[left[ind]], &r = P[right[ind]];
+        const float bx = l.x - r.x, by = l.y - r.y, bz = l.z - r.z;
+        const float along = a.x * bx + (a.y * by + a.z * bz);
+        const float blen = std::sqrt(bx * bx + (by * by + bz * bz));
+        float view_angle = std::acos(std::abs(along) / (range[ind] * blen));
+        view_angle *= (180.0 / M_PI);
+        if (view_angle < intersect_angle_threshold || view_angle > 180 - intersect_angle_threshold) continue;
+        ++picked;
+        if (picked > 30) break;
+        PointXYZI p = a;
+        p.intensity = ind;
+        if (picked <= 3) { state[ind] = POINT_SHARP; cornerSharp.push_back(p); }
+        else state[ind] = POINT_LESS_SHARP;
+        cornerLessSharp.push_back(p);
+        suppress(ind, ring);
+      }
+    }
+  }
+  // ---- ExtractPlaneFeatures2 (:1098-1189)
+  surfFlat.clear(); surfLessFlat.clear();
+  PointCloud ring_less_flat;
+  for (int ring = 0; ring < N_SCANS; ++ring) {
+    if (!usable(ring)) continue;
+    ring_less_flat.clear();
+    for (int j = 0; j < 6; ++j) {
+      int sp, ep; sector(ring, j, &sp, &ep);
+      int picked = 0;
+      for (int k = sp; k <= ep && picked < 4; ++k) {
+        const int ind = order[k];
+        if (state[ind] != POINT_NORMAL && state[ind] != POINT_GROUND) continue;
+        if (curvature[ind] > 0.02) continue;
+        PointXYZI p = P[ind];
+        p.intensity = state[ind];
+        surfFlat.push_back(p);
+        if (state[ind] == POINT_NORMAL) ring_less_flat.push_back(p);
+        state[ind] |= POINT_FLAT;
+        ++picked;
+        suppress(ind, ring);
+      }
+      for (int k = sp; k <= ep; ++k)      // note: k is a point index here, not a position in the sorted order (as upstream)
+        if ((state[k] & POINT_NORMAL) > 0 && (state[k] & POINT_DISABLE) == 0 && curvature[k] < 0.3) ring_less_flat.push_back(P[k]);
+    }
+    VoxelGridAppend(ring_less_flat, 0.2f, (float)POINT_NORMAL, surfLessFlat);
+  }
+  PointCloud ground;
+  for (int i = 0; i < n; ++i) if ((state[i] & POINT_GROUND) > 0) ground.push_back(P[i]);
+  VoxelGridAppend(ground, 0.2f, (float)POINT_GROUND, surfLessFlat);
+  InvalidateDevice();
+  if (trace) {
+    trace->curvature = std::move(curvature); trace->state = std::move(state); trace->sort_ind = std::move(order);
+    trace->left_neighbor = std::move(left); trace->right_neighbor = std::move(right);
+  }
+}
+
+}  // namespace pvlm

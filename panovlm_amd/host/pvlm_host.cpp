@@ -198,13 +198,15 @@ void Velodyne::InvalidateDevice() const {
 Velodyne::~Velodyne() { if (dev_) pvlm_scan_destroy(Engine::Default().ctx(), dev_); }
 Velodyne::Velodyne(const Velodyne& o)
     : id(o.id), valid(o.valid), name(o.name), cloud(o.cloud), cornerLessSharp(o.cornerLessSharp), surfFlat(o.surfFlat), surfLessFlat(o.surfLessFlat),
+      N_SCANS(o.N_SCANS), horizon_scans(o.horizon_scans), cloud_scan(o.cloud_scan), cornerSharp(o.cornerSharp),
       edge_segmented(o.edge_segmented), point_to_segment(o.point_to_segment), segment_coeffs(o.segment_coeffs), end_points(o.end_points),
-      R_wl_(o.R_wl_), t_wl_(o.t_wl_), world_(o.world_), dev_(nullptr) {}
+      R_wl_(o.R_wl_), t_wl_(o.t_wl_), world_(o.world_), layout_(o.layout_), dev_(nullptr) {}
 Velodyne& Velodyne::operator=(const Velodyne& o) {
   if (this == &o) return *this;
   InvalidateDevice();
   id = o.id; valid = o.valid; name = o.name; cloud = o.cloud; cornerLessSharp = o.cornerLessSharp; surfFlat = o.surfFlat; surfLessFlat = o.surfLessFlat;
   edge_segmented = o.edge_segmented; point_to_segment = o.point_to_segment; segment_coeffs = o.segment_coeffs; end_points = o.end_points;
+  N_SCANS = o.N_SCANS; horizon_scans = o.horizon_scans; cloud_scan = o.cloud_scan; cornerSharp = o.cornerSharp; layout_ = o.layout_;
   R_wl_ = o.R_wl_; t_wl_ = o.t_wl_; world_ = o.world_;
   return *this;
 }

@@ -43,7 +43,24 @@ struct PointXYZI { float x, y, z, intensity; };  // pcl::PointXYZI payload
 using PointCloud = std::vector<PointXYZI>;
 
 // sensors/Velodyne.h:57-66
-enum PointClassification { POINT_NORMAL = 0x01, POINT_LESS_SHARP = 0x02, POINT_SHARP = 0x04, POINT_FLAT = 0x08, POINT_GROUND = 0x10 };
+enum PointClassification { POINT_NORMAL = 0x01, POINT_LESS_SHARP = 0x02, POINT_SHARP = 0x04, POINT_FLAT = 0x08, POINT_GROUND = 0x10,
+                           POINT_DISABLE = 0x20, POINT_OCCLUDED = 0x40 };
+// sensors/Velodyne.h:50-55
+enum ExtractionMethod { LOAM = 1, DOUBLE_EXTRACTION = 2, ADAPTIVE = 3 };
+
+// Ring-ordered view of one scan, built by Velodyne::ReOrderVLP (private members of the reference's Velodyne,
+// sensors/Velodyne.h:97-120) and the per-point working arrays of ExtractFeatures (freed by the reference at the end of
+// the call; kept here when a trace is asked for, for the parity tests).
+struct RingLayout {
+  std::vector<float> range_image;                      // N_SCANS x horizon_scans, row-major; 0 = no return
+  std::vector<std::pair<int, int>> point_idx_to_image; // cloud_scan index -> (ring, column)
+  std::vector<int> image_to_point_idx;                 // (ring, column) -> cloud_scan index, -1 = empty
+  std::vector<int> scanStartInd, scanEndInd;           // per ring: first + 5, last - 5 (inclusive)
+};
+struct ExtractionTrace {
+  std::vector<float> curvature;
+  std::vector<int> state, sort_ind, left_neighbor, right_neighbor;
+};
 
 // base/Config.h:111-130 — the knobs the hot path reads (defaults = config/Room.txt:67-79)
 struct Config {
@@ -87,6 +104,10 @@ class Velodyne {
   std::string name;                               // file name of the raw scan
   PointCloud cloud;                               // raw points as loaded (LoadLidar), camera-style axes
   PointCloud cornerLessSharp, surfFlat, surfLessFlat;
+  int N_SCANS = 16;                               // sensors/Velodyne.h:72-73 (constructor arguments upstream)
+  int horizon_scans = 1800;
+  PointCloud cloud_scan;                          // ReOrderVLP: the scan ring by ring, intensity = ring id
+  PointCloud cornerSharp;
   std::vector<PointCloud> edge_segmented;
   std::vector<std::set<int>> point_to_segment;
   std::vector<Vector6d> segment_coeffs;  // LiDAR-local (point, unit direction)
@@ -109,6 +130,20 @@ class Velodyne {
   // (removeClosedPointCloud, :148-172), swaps the axes to the camera convention (x, y, z) -> (x, -z, y) and marks the scan
   // invalid when fewer than 4000 points remain.  Returns false when the file cannot be read (the reference logs and returns).
   bool LoadLidar(std::string file_path = "");
+  // ReOrderVLP (sensors/Velodyne.cpp:371-526): firing order -> ring order, range image, ring/column of every point.
+  void ReOrderVLP();
+  // ExtractFeatures (sensors/Velodyne.cpp:531-760), method ADAPTIVE only (config/Room.txt:32), PLANAR BRANCH: optional
+  // range-image Segmentation (:1438-1586), adaptive-window curvature (:623-657), per-sector sort (:707-723),
+  // ExtractEdgeFeatures2 (:883-1000) and ExtractPlaneFeatures2 (:1098-1189, surfLessFlat through the 0.2 m voxel grid).
+  // Fills cornerSharp / cornerLessSharp (intensity = index into cloud_scan) / surfFlat / surfLessFlat.  EdgeToLine
+  // (:1269-1324: line segments from the edge points) is NOT run — it fits lines with PCL's RANSAC, which cannot be
+  // restated bit for bit — so edge_segmented / segment_coeffs / end_points / point_to_segment stay empty and
+  // cornerLessSharp is the reference's cornerBeforeFilter.  Sequential per scan (a state machine, a BFS and greedy
+  // non-maximum suppression over 28.8 k points): host code, like upstream; run it under `omp parallel for` over scans
+  // as lidar_mapping/LidarOdometry.cpp:131-147 does.  Throws std::invalid_argument for another method.
+  void ExtractFeatures(float max_curvature = 50, float intersect_angle_threshold = 5, int method = ADAPTIVE, bool segment = true,
+                       ExtractionTrace* trace = nullptr);
+  const RingLayout& Layout() const { return layout_; }
   void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
   void Transform2Local();                         // :1810-1848
 
@@ -123,6 +158,8 @@ class Velodyne {
   Matrix3d R_wl_;
   Vector3d t_wl_;
   bool world_ = false;
+  RingLayout layout_;
+  void Segmentation();                            // sensors/Velodyne.cpp:1438-1586
   mutable pvlm_scan* dev_ = nullptr;
 };
 

@@ -84,6 +84,49 @@ def raycast_local(k, cols=4096, rings=16, seed=SEED, noise=0.01):
     return (dl * rng_[:, None]).astype(np.float32)
 
 
+VLP16_FIRING_ORDER = np.array([0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15])   # ring ids in firing order (sensors/Velodyne.cpp:407-414)
+
+
+def raw_vlp16_scan(k, cols=1800, seed=SEED, noise=0.01, skew=0.3, jitter=0.05, dropout=0.01, start_deg=37.0, clutter=0, elevation_noise=0.0,
+                   return_truth=False):
+    """Raw VLP-16 scan k as LoadLidar hands it to ReOrderVLP (sensors/Velodyne.cpp:92-145, :371-526): n x 4 float32
+    (x, y, z, intensity) in FIRING order — azimuth column by column, the 16 lasers of a column in the sensor's
+    interleaved order — camera-style axes (x right, y down, z forward), azimuth atan2(x, z) increasing from `start_deg`
+    through one full turn.  skew: azimuth progress inside one column (fraction of the column width), jitter: random
+    azimuth error per return (same unit), dropout: fraction of returns missing (no echo), clutter: number of small
+    (5-25 cm) boxes scattered through the room (the small segments Velodyne::Segmentation removes), elevation_noise:
+    sigma in degrees added to the beam elevation.  return_truth: also return the (ring, column) each return was fired at."""
+    R, t = true_pose(k)
+    rng = np.random.default_rng(seed + 15485863 * (k + 1))
+    small = []
+    for _ in range(clutter):
+        c = np.array([rng.uniform(-3.5, 3.5), rng.uniform(-1.2, 1.2), rng.uniform(-5.5, 5.5)])
+        h = rng.uniform(0.025, 0.125, size=3)
+        if np.linalg.norm(c - t) > 1.0:
+            small.append((c - h, c + h))
+    res = 2 * np.pi / cols
+    ring = np.tile(VLP16_FIRING_ORDER, cols)
+    col = np.repeat(np.arange(cols), 16)
+    fire = np.tile(np.arange(16), cols)
+    az = np.deg2rad(start_deg) + res * (col + skew * fire / 16.0 + jitter * rng.uniform(-1, 1, size=col.shape))
+    el = np.deg2rad(-15.0 + 2.0 * ring + elevation_noise * rng.normal(size=ring.shape))
+    dl = np.stack([np.cos(el) * np.sin(az), -np.sin(el), np.cos(el) * np.cos(az)], axis=-1)
+    dw = dl @ R.T
+    o = t[None, :]
+    _, tf = _ray_aabb(o, dw, ROOM_MIN, ROOM_MAX)
+    rng_ = tf.copy()
+    for lo, hi in scene_boxes(seed) + small:
+        tn, tf2 = _ray_aabb(o, dw, lo, hi)
+        hit = (tn > 0) & (tn <= tf2)
+        rng_ = np.where(hit & (tn < rng_), tn, rng_)
+    rng_ = rng_ + rng.normal(size=rng_.shape) * noise
+    keep = rng.uniform(size=rng_.shape) >= dropout
+    xyz = (dl * rng_[:, None]).astype(np.float32)[keep]
+    inten = rng.uniform(0, 100, size=len(xyz)).astype(np.float32)
+    raw = np.concatenate([xyz, inten[:, None]], axis=1)
+    return (raw, ring[keep], col[keep]) if return_truth else raw
+
+
 def to_world_f32(local_f32, R_wl, t_wl):
     """pcl::transformPointCloud(float cloud, Matrix4d): per coordinate float(m0*x + m1*y + m2*z + m3)."""
     p = local_f32.astype(np.float64)

@@ -286,6 +286,35 @@ int main(int argc, char** argv) {
       const bool ok = v.LoadLidar(argv[2]);
       printf("loaded %d valid %d points %zu name %s\n", ok ? 1 : 0, v.valid ? 1 : 0, v.cloud.size(), v.name.c_str());
       for (const PointXYZI& p : v.cloud) printf("p %a %a %a %a\n", p.x, p.y, p.z, p.intensity);
+    } else if (cmd == "features") {
+      // features <raw.bin> <out.bin> n_scans horizon max_curvature angle_threshold segment extract : ReOrderVLP (+ ExtractFeatures)
+      // raw.bin: int32 n, n x 4 float.  out.bin: int32 valid, then blocks [int32 count, payload]: cloud_scan, cornerSharp,
+      // cornerLessSharp, surfFlat, surfLessFlat (count x 4 float each); rc (count x 2 int32); scan_start, scan_end (n_scans int32);
+      // range_image (n_scans * horizon float); image_to_point_idx (same, int32); curvature (float), state, sort_ind, left, right (int32)
+      std::ifstream f(argv[2], std::ios::binary);
+      int32_t n = 0; rd(f, &n, 1);
+      Velodyne v; v.id = 3;
+      v.cloud.resize(n);
+      for (auto& p : v.cloud) rd(f, &p.x, 4);
+      v.N_SCANS = atoi(argv[4]); v.horizon_scans = atoi(argv[5]);
+      v.ReOrderVLP();
+      ExtractionTrace tr;
+      if (atoi(argv[9])) v.ExtractFeatures((float)atof(argv[6]), (float)atof(argv[7]), ADAPTIVE, atoi(argv[8]) != 0, &tr);
+      std::ofstream o(argv[3], std::ios::binary);
+      auto wr = [&](const void* p, size_t bytes) { o.write(static_cast<const char*>(p), (std::streamsize)bytes); };
+      auto block = [&](const void* p, size_t count, size_t elem) { const int32_t c = (int32_t)count; wr(&c, 4); if (count) wr(p, count * elem); };
+      const int32_t valid = v.valid ? 1 : 0; wr(&valid, 4);
+      for (const PointCloud* c : {&v.cloud_scan, &v.cornerSharp, &v.cornerLessSharp, &v.surfFlat, &v.surfLessFlat}) block(c->data(), c->size(), sizeof(PointXYZI));
+      const RingLayout& L = v.Layout();
+      std::vector<int32_t> rc;
+      for (const auto& x : L.point_idx_to_image) { rc.push_back(x.first); rc.push_back(x.second); }
+      block(rc.data(), rc.size() / 2, 8);
+      block(L.scanStartInd.data(), L.scanStartInd.size(), 4); block(L.scanEndInd.data(), L.scanEndInd.size(), 4);
+      block(L.range_image.data(), L.range_image.size(), 4); block(L.image_to_point_idx.data(), L.image_to_point_idx.size(), 4);
+      block(tr.curvature.data(), tr.curvature.size(), 4); block(tr.state.data(), tr.state.size(), 4); block(tr.sort_ind.data(), tr.sort_ind.size(), 4);
+      block(tr.left_neighbor.data(), tr.left_neighbor.size(), 4); block(tr.right_neighbor.data(), tr.right_neighbor.size(), 4);
+      printf("features valid %d scan %zu sharp %zu less_sharp %zu flat %zu less_flat %zu\n", valid, v.cloud_scan.size(), v.cornerSharp.size(),
+             v.cornerLessSharp.size(), v.surfFlat.size(), v.surfLessFlat.size());
     } else if (cmd == "poseio") {
       // poseio <in.txt> <out.txt> with_invalid precision
       std::vector<Matrix3d> R; std::vector<Vector3d> t; std::vector<std::string> names;

@@ -188,9 +188,22 @@ def mvs():
     np.savez_compressed(os.path.join(OUT, "mvs.npz"), **d)
 
 
+def features():
+    """LiDAR feature extraction, planar branch (sensors/Velodyne.cpp:371-526, :531-760, :883-1000, :1098-1189, :1438-1586) on a
+    small raw scan (16 rings x 240 columns, clutter, dropouts)."""
+    from panovlm_amd import synthetic as sy
+    raw = sy.raw_vlp16_scan(6, cols=240, clutter=25, dropout=0.05)
+    f = orc.ScanFeatures(raw, horizon=240)
+    d = dict(raw=raw, horizon=np.int32(240))
+    for name in ("cloud_scan", "cornerSharp", "cornerLessSharp", "surfFlat", "surfLessFlat", "rc", "scan_start", "scan_end", "range_image",
+                 "image_to_point_idx", "curvature", "state", "sort_ind", "left", "right"):
+        d[name] = getattr(f, name)
+    np.savez_compressed(os.path.join(OUT, "features.npz"), **d)
+
+
 if __name__ == "__main__":
     orc.build()
-    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs()
+    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs(); features()
     tot = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -81,3 +81,39 @@ def write_structure(path, frames, tracks):
             f.write(struct.pack("<i", len(t["obs"])))
             for fi, ki in t["obs"]:
                 f.write(struct.pack("<II", int(fi), int(ki)))
+
+
+def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_threshold=5.0, segment=True, extract=True):
+    """Velodyne::ReOrderVLP (+ ExtractFeatures) of the host mirror on one raw scan (n x 4 float32) through the test driver.
+    Returns a dict with the same fields as oracle.ScanFeatures."""
+    import tempfile
+    raw = np.ascontiguousarray(raw, np.float32).reshape(-1, 4)
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, "raw.bin"), os.path.join(d, "out.bin")
+        with open(src, "wb") as f:
+            f.write(struct.pack("<i", len(raw))); f.write(raw.tobytes())
+        log = run("features", src, dst, str(n_scans), str(horizon), repr(float(max_curvature)), repr(float(angle_threshold)), "1" if segment else "0",
+                  "1" if extract else "0")
+        buf = open(dst, "rb").read()
+    pos = [0]
+
+    def block(dtype, width=1):
+        n = struct.unpack_from("<i", buf, pos[0])[0]; pos[0] += 4
+        a = np.frombuffer(buf, dtype, n * width, pos[0]).copy(); pos[0] += a.nbytes
+        return a.reshape(n, width) if width > 1 else a
+
+    out = dict(log=log, valid=bool(struct.unpack_from("<i", buf, 0)[0]))
+    pos[0] = 4
+    for name in ("cloud_scan", "cornerSharp", "cornerLessSharp", "surfFlat", "surfLessFlat"):
+        out[name] = block(np.float32, 4)
+    out["rc"] = block(np.int32, 2)
+    out["scan_start"] = block(np.int32); out["scan_end"] = block(np.int32)
+    ri = block(np.float32)                                    # empty when the ring count is unsupported (upstream returns before sizing it)
+    out["range_image"] = (ri if len(ri) else np.zeros(n_scans * horizon, np.float32)).reshape(n_scans, horizon)
+    out["image_to_point_idx"] = block(np.int32).reshape(n_scans, horizon)
+    out["curvature"] = block(np.float32)
+    for name in ("state", "sort_ind", "left", "right"):
+        out[name] = block(np.int32)
+    assert pos[0] == len(buf)
+    return out
+
