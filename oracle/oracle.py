@@ -402,18 +402,23 @@ def assoc_by_angle(rows, cols, lines, lidar_local, T_cl, multiple=True):
                 end=en[:m].copy(), votes=votes)
 
 
+def _features_handle(cloud, n_scans=16, horizon=1800, max_curvature=1000.0, intersect_angle_threshold=5.0, segment=True, extract=True):
+    c = _f32(cloud).reshape(-1, 4)
+    L = lib()
+    L.orc_features_create.restype = C.c_void_p
+    return C.c_void_p(L.orc_features_create(C.c_long(len(c)), _p(c, C.c_float), C.c_int(n_scans), C.c_int(horizon), C.c_float(max_curvature),
+                                            C.c_float(intersect_angle_threshold), C.c_int(1 if segment else 0), C.c_int(1 if extract else 0)))
+
+
 class ScanFeatures:
     """ReOrderVLP (+ ExtractFeatures, ADAPTIVE, planar branch) of oracle/features.hpp on one raw scan (n x 4 float32)."""
 
     CLOUDS = {"cloud_scan": 0, "cornerSharp": 1, "cornerLessSharp": 2, "surfFlat": 3, "surfLessFlat": 4}
 
     def __init__(self, cloud, n_scans=16, horizon=1800, max_curvature=1000.0, intersect_angle_threshold=5.0, segment=True, extract=True):
-        c = _f32(cloud).reshape(-1, 4)
         L = lib()
-        L.orc_features_create.restype = C.c_void_p
         L.orc_features_cloud.restype = C.c_long
-        h = C.c_void_p(L.orc_features_create(C.c_long(len(c)), _p(c, C.c_float), C.c_int(n_scans), C.c_int(horizon), C.c_float(max_curvature),
-                                             C.c_float(intersect_angle_threshold), C.c_int(1 if segment else 0), C.c_int(1 if extract else 0)))
+        h = _features_handle(cloud, n_scans, horizon, max_curvature, intersect_angle_threshold, segment, extract)
         try:
             self.valid = bool(L.orc_features_valid(h))
             for name, which in self.CLOUDS.items():

@@ -76,7 +76,7 @@ def build_host(force=False):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     newest = max(os.path.getmtime(x) for x in (src, feat, hdr, LIB))
     if force or not os.path.exists(HOST_LIB) or os.path.getmtime(HOST_LIB) < newest:
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-ffp-contract=off", "-shared", src, feat, "-o", HOST_LIB, "-L" + HERE, "-lpvlm",
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-ffp-contract=off", "-shared", src, feat, "-o", HOST_LIB, "-L" + HERE, "-lpvlm", "-pthread",
                                "-Wl,-rpath,$ORIGIN"])
     if os.path.exists(drv) and (force or not os.path.exists(HOST_DRIVER) or os.path.getmtime(HOST_DRIVER) < max(os.path.getmtime(drv), os.path.getmtime(HOST_LIB))):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", drv, "-o", HOST_DRIVER, "-L" + HERE, "-lpvlm_host", "-lpvlm",

@@ -7,7 +7,11 @@
 // code, parallel over scans like lidar_mapping/LidarOdometry.cpp:131-147; the clouds it produces are what
 // Velodyne::DeviceScan uploads for the GPU association.  The arithmetic is the reference's float arithmetic
 // (`using namespace std` there: the float overloads of sqrt / atan / atan2 / acos / sin / cos), compiled with
-// -ffp-contract=off.  pcl::VoxelGrid and Eigen's 3-vector reductions are restated as documented in oracle/features.hpp.
+// -ffp-contract=off.  Two third-party behaviours are restated from memory [recalled — PCL is not in the image]:
+// pcl::VoxelGrid<PointXYZI>::applyFilter of PCL 1.10 (voxel index floor(x * inverse_leaf) - min_b, std::sort of
+// (voxel, point) pairs by voxel only, centroid summed in sorted order and divided by the count, output in ascending
+// voxel order) and Eigen 3.4's unvectorised 3-vector reductions (dot, squaredNorm: c0 + (c1 + c2)).  std::sort is
+// libstdc++'s, as in a reference build: with equal keys its order is deterministic for a given library only.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -49,7 +53,7 @@ inline double Azimuth(const PointXYZI& p) {   // atan2(float, float) in [0, 2 pi
 // position of a ring in the VLP-16 firing sequence (the std::map of :407-414; a missing key reads as 0)
 inline int FiringSlot(int ring, int rings) { return (rings != 16 || ring < 0) ? 0 : (ring <= 7 ? 2 * ring : 2 * ring - 15); }
 
-// pcl::VoxelGrid<PointXYZI>, leaf x leaf x leaf, all fields averaged (see oracle/features.hpp for what is recalled)
+// pcl::VoxelGrid<PointXYZI>, leaf x leaf x leaf, all fields averaged ([recalled], see the header of this file)
 struct VoxelKey { unsigned cell, point; };
 inline bool operator<(const VoxelKey& a, const VoxelKey& b) { return a.cell < b.cell; }
 

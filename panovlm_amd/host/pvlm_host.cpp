@@ -5,6 +5,7 @@
 #include "pvlm_host.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cstdio>
@@ -17,6 +18,7 @@
 #include <sstream>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 namespace pvlm {
 
@@ -1668,8 +1670,30 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
 }
 
 bool LidarOdometry::EstimatePose(const int max_iteration) {
+  // lidar_mapping/LidarOdometry.cpp:131-147: features are extracted once, scan-parallel (omp there, std::thread here).
+  // Scans that arrive with their feature clouds (or without raw points) are left alone; upstream's ReOrderVLP /
+  // ExtractFeatures return early for those as well (sensors/Velodyne.cpp:376-377, :542-543).
+  {
+    StageTimer stage_timer_features_("feature extraction (host, scan-parallel)");
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t i = next++; i < lidars.size(); i = next++) {
+        Velodyne& l = lidars[i];
+        if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); continue; }
+        if (!l.cloud.empty() && l.surfFlat.empty() && l.surfLessFlat.empty() && l.cornerLessSharp.empty() && !l.IsInWorldCoordinate()) {
+          l.ReOrderVLP();
+          l.ExtractFeatures(config.max_curvature, config.intersection_angle_threshold, config.extraction_method, config.lidar_segmentation);
+        }
+      }
+    };
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(config.num_threads, 1), lidars.size(), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  }
   for (Velodyne& l : lidars) {
-    if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); continue; }
+    if (!l.valid || !l.IsPoseValid()) continue;
     l.Transform2LidarWorld();
   }
   bool segmented = false;

@@ -77,6 +77,11 @@ struct Config {
   double camera_weight = 1.0;
   int num_threads = 25;
   int num_iteration_lidar = 7;
+  // feature extraction (base/Config.h:72-76; config/Room.txt:32-35 sets max_curvature = 1000)
+  int extraction_method = ADAPTIVE;
+  float max_curvature = 5;
+  float intersection_angle_threshold = 5;
+  bool lidar_segmentation = true;
 };
 
 // Wall-clock seconds accumulated per stage of the mirrored call surface (association, track building, solve, ...)

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -183,6 +184,64 @@ int main(int argc, char** argv) {
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
       for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());
       PrintPoses(odo.GetLidarData());
+    } else if (cmd == "rawodometry") {
+      // rawodometry <raw_scans.bin> iters angle normalize tol thr max_curvature angle_threshold segment : BASELINE config 0 plumbing —
+      // raw VLP-16 scans (firing order) -> ReOrderVLP -> ExtractFeatures -> LidarOdometry::EstimatePose with the
+      // point-to-plane term only.  raw_scans.bin: int32 count; per scan int32 id, R_wl (9 f64), t_wl (3 f64), int32 n, n x 4 f32.
+      std::ifstream f(argv[2], std::ios::binary);
+      if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+      int32_t ns = 0; rd(f, &ns, 1);
+      std::vector<Velodyne> l(ns);
+      for (Velodyne& v : l) {
+        int32_t id = 0, n = 0; rd(f, &id, 1);
+        Matrix3d R; Vector3d t; rd(f, R.data(), 9); rd(f, t.data(), 3);
+        rd(f, &n, 1);
+        v.id = id; v.SetPose(R, t);
+        v.cloud.resize(n);
+        for (auto& p : v.cloud) rd(f, &p.x, 4);
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (Velodyne& v : l) { v.ReOrderVLP(); v.ExtractFeatures((float)atof(argv[8]), (float)atof(argv[9]), ADAPTIVE, atoi(argv[10]) != 0); }
+      const double ext = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      for (const Velodyne& v : l) printf("features %d valid %d flat %zu less_flat %zu corner %zu\n", v.id, v.valid ? 1 : 0, v.surfFlat.size(), v.surfLessFlat.size(), v.cornerLessSharp.size());
+      printf("extract_seconds %.6f\n", ext);
+      Config cfg;
+      cfg.angle_residual = atoi(argv[4]) != 0; cfg.normalize_distance = atoi(argv[5]) != 0;
+      cfg.line_to_line_residual = false; cfg.point_to_plane_residual = true;
+      cfg.lidar_plane_tolerance = atof(argv[6]); cfg.point_to_plane_dis_threshold = atof(argv[7]);
+      LidarOdometry odo(l, cfg);
+      odo.EstimatePose(atoi(argv[3]));
+      for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
+      PrintPoses(odo.GetLidarData());
+    } else if (cmd == "featbench") {
+      // featbench <raw_scans.bin> reps segment : host seconds per scan of ReOrderVLP + ExtractFeatures (no GPU involved)
+      std::ifstream f(argv[2], std::ios::binary);
+      if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+      int32_t ns = 0; rd(f, &ns, 1);
+      std::vector<PointCloud> raw(ns);
+      for (PointCloud& c : raw) {
+        int32_t id = 0, n = 0; rd(f, &id, 1);
+        double skip[12]; rd(f, skip, 12);
+        rd(f, &n, 1);
+        c.resize(n);
+        for (auto& p : c) rd(f, &p.x, 4);
+      }
+      const int reps = atoi(argv[3]);
+      double reorder = 0, extract = 0; size_t flat = 0, less = 0, pts = 0;
+      for (int r = 0; r < reps; ++r)
+        for (const PointCloud& c : raw) {
+          Velodyne v; v.cloud = c;
+          const auto t0 = std::chrono::steady_clock::now();
+          v.ReOrderVLP();
+          const auto t1 = std::chrono::steady_clock::now();
+          v.ExtractFeatures(1000.f, 5.f, ADAPTIVE, atoi(argv[4]) != 0);
+          const auto t2 = std::chrono::steady_clock::now();
+          reorder += std::chrono::duration<double>(t1 - t0).count(); extract += std::chrono::duration<double>(t2 - t1).count();
+          flat += v.surfFlat.size(); less += v.surfLessFlat.size(); pts += c.size();
+        }
+      const double n = (double)reps * ns;
+      printf("featbench scans %d reps %d points_per_scan %.0f reorder_ms %.4f extract_ms %.4f flat %.1f less_flat %.1f\n", ns, reps, pts / n, 1e3 * reorder / n,
+             1e3 * extract / n, flat / n, less / n);
     } else if (cmd == "byangle") {
       auto l = LoadScans(argv[2]);  // one LOCAL-frame scan
       std::ifstream f(argv[3], std::ios::binary);

@@ -117,3 +117,14 @@ def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_
     assert pos[0] == len(buf)
     return out
 
+
+def write_raw_scans(path, scans):
+    """scans: list of dicts id, R_wl, t_wl, raw (n x 4 float32, firing order) for the driver's `rawodometry` command."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(scans)))
+        for s in scans:
+            raw = np.ascontiguousarray(s["raw"], np.float32).reshape(-1, 4)
+            f.write(struct.pack("<i", int(s["id"])))
+            f.write(np.asarray(s["R_wl"], np.float64).reshape(9).tobytes()); f.write(np.asarray(s["t_wl"], np.float64).reshape(3).tobytes())
+            f.write(struct.pack("<i", len(raw))); f.write(raw.tobytes())
+

@@ -437,3 +437,38 @@ def test_knn_based_line_association_variants(oracle, tmp):
         assert [int(g[0]) for g in got] == o["nei_idx"].tolist() and [int(g[1]) for g in got] == o["ref_idx"].tolist()
         assert np.allclose(np.array([[float(v) for v in g[2:5]] for g in got]).reshape(-1, 3), o["p1"], atol=1e-13)
         assert len(got) >= 4
+
+
+def test_raw_scans_to_refined_poses(oracle, tmp):
+    """BASELINE config 0 plumbing: raw VLP-16 scans in firing order (~29 k points) -> ReOrderVLP -> ExtractFeatures (host,
+    SURVEY.md §8 N3 planar branch) -> LidarOdometry::EstimatePose with the point-to-plane term (GPU association + normal
+    equations) against the same chain on the oracle: feature counts, residual-block counts, costs and poses."""
+    scans = []
+    for k in range(3):
+        R, t = sy.estimated_pose(k)
+        scans.append(dict(id=k, R_wl=R, t_wl=t, raw=sy.raw_vlp16_scan(k, clutter=30)))
+    path = os.path.join(tmp, "raw.bin")
+    host_io.write_raw_scans(path, scans)
+    out = host_io.run("rawodometry", path, 2, 1, 1, 0.05, 1.0, 1000.0, 5.0, 1)
+    feats = [l.split() for l in out if l.startswith("features")]
+    iters = [l.split() for l in out if l.startswith("iter")]
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    twin = []
+    for s, ft in zip(scans, feats):
+        f = oracle.ScanFeatures(s["raw"])
+        assert (int(ft[5]), int(ft[7]), int(ft[9])) == (len(f.surfFlat), len(f.surfLessFlat), len(f.cornerLessSharp))
+        assert 300 <= len(f.surfFlat) <= 384 and 2000 < len(f.surfLessFlat) < 8000                 # SURVEY.md §8: Nq <= 384, Nt = O(3-8 k)
+        twin.append(dict(id=s["id"], R_wl=s["R_wl"], t_wl=s["t_wl"], flat_local=f.surfFlat[:, :3], flat_tag=f.surfFlat[:, 3],
+                         less_local=f.surfLessFlat[:, :3], less_tag=f.surfLessFlat[:, 3]))
+    log = lm_twin.estimate_pose(oracle, twin, dict(angle=True, normalize=True, tol=0.05, thr=1.0), 2)
+    assert len(iters) == len(log)
+    for it, lg in zip(iters, log):
+        assert int(it[6]) == lg["blocks"] and lg["blocks"] > 500
+        assert abs(float(it[2]) - lg["final_cost"]) <= 1e-6 * lg["final_cost"]
+    for k, s in enumerate(twin):
+        R = poses[k][:9].reshape(3, 3); t = poses[k][9:]
+        assert np.abs(R - s["R_wl"]).max() <= 1e-6 and np.abs(t - s["t_wl"]).max() <= 1e-6 * max(1.0, np.abs(s["t_wl"]).max())
+    err0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, 3)])
+    err1 = np.mean([np.linalg.norm(poses[k][9:] - sy.true_pose(k)[1] - (poses[0][9:] - sy.true_pose(0)[1])) for k in range(1, 3)])
+    assert err1 < err0
+
