@@ -296,6 +296,21 @@ pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_w
                                    const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal,
                                    float* conf, const float* const* nei_depth_or_null);
 
+/* PatchMatch sweep: MVS::EstimateDepthMapSingle(ref, Propagate::CHECKER_BOARD, max_iter, conf_threshold, use_geometry)
+ * (mvs/MVS.cpp:682-720) = max_iter x PropagateCheckerBoard (:1098-1129; per pixel ProcessPixel :721-772: the four direct
+ * neighbours' hypotheses interpolated to the pixel and re-scored with the smoothness term, then PerturbDepthNormal3
+ * :1254-1320: up to 6 random + 6 refining perturbations), then hypotheses with conf < conf_threshold are dropped
+ * (depth 0, conf -1, normal 0; depth_constant pixels are kept).  depth / normal / conf are IN-OUT and must hold an
+ * initialised state (InitDepthNormal + pvlm_mvs_init_conf_map).  nei_depth != NULL = use_geometry; depth_constant may
+ * be NULL; min_depth / max_depth = config.min_depth / max_depth.
+ * RANDOM DRAWS: upstream all OpenMP threads pull from one cv::RNG seeded with time(NULL) (mvs/MVS.cpp:30), a data race
+ * that makes every run different; here draw k of pixel e in colour pass p is a hash of (seed, p, e, k) — the same
+ * arguments give the same maps. */
+pvlm_status pvlm_mvs_propagate(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                               const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                               const float* const* nei_depth_or_null, const unsigned char* depth_constant_or_null, float min_depth, float max_depth,
+                               unsigned long long seed, int max_iter, float conf_threshold);
+
 /* Depth-map fusion filter: MVS::FilterDepthImage (mvs/MVS.cpp:1735-1790) with ProjectDepthConfToRef (:2011-2070, depth):
  * every neighbour depth map is forward-projected into the reference view (4-pixel splat, nearest range wins); a reference
  * depth survives when >= 2 neighbours agree within 0.8 x threshold at the pixel and >= 5 (neighbour, 4-neighbourhood)

@@ -124,9 +124,11 @@ inline float GeometricAdjust(float score, const Equirectangular& eq, const float
 
 // ScorePixel, photometric term (+ the geometric-consistency term when nei_depth != nullptr).  unit = PreComputeI2C table (rows x cols x 3 float).  R_nr / t_nr: neighbour n at
 // R + 9 n / t + 3 n (row-major).  Returns the aggregated score (-1 = invalid).
+// plane (4) + close (n_close NeighborPixel records): the smoothness term of ScorePixel :843-857 (propagation only).
+struct NeighborPixel { float point[3]; float normal[3]; float depth; };   // mvs/MVS.h:59-64
 inline float ScorePixelPhotometric(const MvsView& ref, const float* unit, int px, int py, const float* normal, float depth, const PixelPatch& patch,
                                    int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr,
-                                   const float* const* nei_depth = nullptr) {
+                                   const float* const* nei_depth = nullptr, const float* plane = nullptr, const NeighborPixel* close = nullptr, int n_close = 0) {
   const Equirectangular eq(ref.rows, ref.cols);
   const float* u0 = unit + 3 * ((size_t)py * ref.cols + px);
   const float X0[3] = {u0[0] * depth, u0[1] * depth, u0[2] * depth};
@@ -162,6 +164,23 @@ inline float ScorePixelPhotometric(const MvsView& ref, const float* unit, int px
     if (nrm <= 0.f) continue;
     const float ncc = sq01 / std::sqrt(nrm);
     float score = std::min(std::max(ncc, -1.f), 1.f);
+    if (n_close > 0) {
+      // mvs/MVS.h:82-86
+      const float smoothBonus = 0.95f, smoothBonusDepth = 1.f - smoothBonus, smoothBonusNormal = (1.f - smoothBonus) * 0.96;
+      const float smoothSigmaDepth = -1.f / (2.f * 0.02f * 0.02f), smoothSigmaNormal = -1.f / (2.f * 0.22f * 0.22f);
+      score = 1 - score;
+      for (int q = 0; q < n_close; ++q) {
+        const NeighborPixel& c = close[q];
+        float diff_distance = std::abs(plane[0] * c.point[0] + plane[1] * c.point[1] + plane[2] * c.point[2] + plane[3]) / depth;   // PointToPlaneDistance(plane, point, true)
+        const float factorDepth = std::exp(diff_distance * diff_distance * smoothSigmaDepth);
+        const float cosang = normal[0] * c.normal[0] + normal[1] * c.normal[1] + normal[2] * c.normal[2];                            // VectorAngle3D(.., .., true)
+        float diff_angle = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)M_PI : std::acos(cosang));
+        const float factorNormal = std::exp(diff_angle * diff_angle * smoothSigmaNormal);
+        score *= (1.f - smoothBonusDepth * factorDepth) * (1.f - smoothBonusNormal * factorNormal);
+      }
+      score = 1 - score;
+      score = std::min(1.f, std::max(-1.f, score));
+    }
     if (nei_depth) score = GeometricAdjust(score, eq, X0, R, t, nei_depth[nb]);
     score_neighbor.push_back({score, nb});
   }
@@ -357,6 +376,229 @@ inline void FilterDepthImageRefine(int rows, int cols, int n_neighbors, const fl
         }
       }
       if (depth_constant && depth_constant[e]) { depth_filter[e] = d; conf_filter[e] = 1.f; }
+    }
+}
+
+
+// ---- PatchMatch sweep: EstimateDepthMapSingle with Propagate::CHECKER_BOARD (mvs/MVS.cpp:682-720), PropagateCheckerBoard
+// (:1098-1129), ProcessPixel (:721-772), PerturbDepthNormal3 (:1254-1320), InterpolatePixel (:1923-1935), CorrectNormal
+// (:1953-1971), PerturbNormal / PerturbDepth / GenerateRandomNormal (:1368-1431).
+// RANDOM DRAWS: upstream every thread of the `omp parallel for` pulls from ONE cv::RNG seeded with time(NULL)
+// (mvs/MVS.cpp:30) — a data race, no two runs agree.  Here draw k of pixel e in pass p is a hash of (seed, p, e, k); the
+// conversion to float is cv::RNG's (next() * 2^-32 in float; uniform(a, b) = that * (b - a) + a) [recalled, OpenCV 3.4].
+inline uint32_t MvsRandomU32(uint64_t seed, uint64_t pixel, uint32_t k) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (pixel + 1) + 0xD1B54A32D192ED03ull * (uint64_t)(k + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+inline uint64_t MvsPassSeed(uint64_t seed, int pass) { return seed * 0x2545F4914F6CDD1Dull + 0x632BE59BD9B4E019ull * (uint64_t)(pass + 1); }
+struct MvsRng {
+  uint64_t seed, pixel; uint32_t k = 0;
+  float next01() { return (float)MvsRandomU32(seed, pixel, k++) * 2.3283064365386962890625e-10f; }
+  float uniform(float a, float b) { return next01() * (b - a) + a; }
+};
+
+inline float MvsDot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }   // cv::Vec3f::dot / Point3f::dot
+
+// :1923-1935
+inline float InterpolatePixel(const float* unit, int cols, int px, int py, int nx, int ny, float depth, const float* normal, float min_depth, float max_depth) {
+  const float* view_ray = unit + 3 * ((size_t)py * cols + px);
+  const float* un = unit + 3 * ((size_t)ny * cols + nx);
+  const float X1[3] = {un[0] * depth, un[1] * depth, un[2] * depth};
+  const float dnorm = MvsDot3(view_ray, normal);
+  if (std::abs(dnorm) < 1e-6) return depth;
+  const float depth_new = MvsDot3(X1, normal) / dnorm;
+  if (depth_new >= min_depth && depth_new <= max_depth) return depth_new;
+  return depth;
+}
+
+// :1953-1971.  Eigen::AngleAxisf(rad, axis).toRotationMatrix() with the UN-normalised axis upstream passes [recalled, Eigen 3.4 AngleAxis.h]
+inline void CorrectNormal(const float* viewDir, float* normal) {
+  const float cosAngLen = MvsDot3(normal, viewDir);
+  if (cosAngLen >= 0) {
+    const float axis[3] = {normal[1] * viewDir[2] - normal[2] * viewDir[1], normal[2] * viewDir[0] - normal[0] * viewDir[2], normal[0] * viewDir[1] - normal[1] * viewDir[0]};
+    const float rad = std::min((std::acos(cosAngLen) - float(M_PI_2)) * 1.01f, -0.001f);
+    const float sn = std::sin(rad), c = std::cos(rad);
+    const float sin_axis[3] = {sn * axis[0], sn * axis[1], sn * axis[2]};
+    const float cos1_axis[3] = {(1.f - c) * axis[0], (1.f - c) * axis[1], (1.f - c) * axis[2]};
+    float R[9];
+    float tmp = cos1_axis[0] * axis[1];
+    R[1] = tmp - sin_axis[2]; R[3] = tmp + sin_axis[2];
+    tmp = cos1_axis[0] * axis[2];
+    R[2] = tmp + sin_axis[1]; R[6] = tmp - sin_axis[1];
+    tmp = cos1_axis[1] * axis[2];
+    R[5] = tmp - sin_axis[0]; R[7] = tmp + sin_axis[0];
+    R[0] = cos1_axis[0] * axis[0] + c; R[4] = cos1_axis[1] * axis[1] + c; R[8] = cos1_axis[2] * axis[2] + c;
+    const float x = R[0] * normal[0] + R[1] * normal[1] + R[2] * normal[2];
+    const float y = R[3] * normal[0] + R[4] * normal[1] + R[5] * normal[2];
+    const float z = R[6] * normal[0] + R[7] * normal[1] + R[8] * normal[2];
+    normal[0] = x; normal[1] = y; normal[2] = z;
+  }
+}
+
+// :1368-1396
+inline void PerturbNormal(MvsRng& rng, const float* normal, float perturbation, float* out) {
+  const float a1 = (rng.next01() - 0.5f) * perturbation;
+  const float a2 = (rng.next01() - 0.5f) * perturbation;
+  const float a3 = (rng.next01() - 0.5f) * perturbation;
+  const float sin_a1 = std::sin(a1), sin_a2 = std::sin(a2), sin_a3 = std::sin(a3);
+  const float cos_a1 = std::cos(a1), cos_a2 = std::cos(a2), cos_a3 = std::cos(a3);
+  float R[9];
+  R[0] = cos_a2 * cos_a3;
+  R[1] = -cos_a2 * sin_a3;
+  R[2] = sin_a2;
+  R[3] = cos_a1 * sin_a3 + cos_a3 * sin_a1 * sin_a2;
+  R[4] = cos_a1 * cos_a3 - sin_a1 * sin_a2 * sin_a3;
+  R[5] = -cos_a2 * sin_a1;
+  R[6] = sin_a1 * sin_a3 - cos_a1 * cos_a3 * sin_a2;
+  R[7] = cos_a3 * sin_a1 + cos_a1 * sin_a2 * sin_a3;
+  R[8] = cos_a1 * cos_a2;
+  out[0] = R[0] * normal[0] + R[1] * normal[1] + R[2] * normal[2];
+  out[1] = R[3] * normal[0] + R[4] * normal[1] + R[5] * normal[2];
+  out[2] = R[6] * normal[0] + R[7] * normal[1] + R[8] * normal[2];
+}
+// :1398-1403
+inline float PerturbDepth(MvsRng& rng, float depth, float perturbation) {
+  const float max_depth = (1 + perturbation) * depth, min_depth = (1 - perturbation) * depth;
+  return rng.uniform(0.f, 1.f) * (max_depth - min_depth) + min_depth;
+}
+// :1405-1431
+inline void GenerateRandomNormal(MvsRng& rng, const float* view_ray, float* normal) {
+  float v1 = 0.0f, v2 = 0.0f, s = 2.0f;
+  while (s >= 1.0f) {
+    v1 = 2.0f * rng.uniform(0.f, 1.f) - 1.0f;
+    v2 = 2.0f * rng.uniform(0.f, 1.f) - 1.0f;
+    s = v1 * v1 + v2 * v2;
+  }
+  const float s_norm = std::sqrt(1.0f - s);
+  normal[0] = 2.0f * v1 * s_norm; normal[1] = 2.0f * v2 * s_norm; normal[2] = 1.0f - 2.0f * s;
+  if (MvsDot3(normal, view_ray) > 0) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+}
+
+struct MvsSweep {
+  MvsView ref; const float* unit; int n_neighbors; const uint8_t* const* nei_gray; const float* R_nr; const float* t_nr;
+  const float* const* nei_depth;          // use_geometry when != nullptr
+  const unsigned char* depth_constant;    // may be nullptr
+  float min_depth, max_depth;
+  float *depth, *normal, *conf;
+};
+
+// PerturbDepthNormal3 :1254-1320 (perturb_normal = true, its default)
+inline bool PerturbDepthNormal3(const MvsSweep& S, MvsRng& rng, int px, int py, const PixelPatch& patch, const NeighborPixel* close, int n_close, bool perturb_depth) {
+  const size_t e = (size_t)py * S.ref.cols + px;
+  float* normal_origin = S.normal + 3 * e; float& depth_origin = S.depth[e]; float& conf_origin = S.conf[e];
+  const float* view_ray = S.unit + 3 * e;
+  const float scaleRanges[12] = {1.f, 0.5f, 0.25f, 0.125f, 0.0625f, 0.03125f, 0.015625f, 0.0078125f, 0.00390625f, 0.001953125f, 0.0009765625f, 0.00048828125f};
+  float thConfSmall(0.55 * 0.2f), thConfBig(0.55 * 0.4f), thConfRand(0.55 * 0.9f);
+  unsigned idxScaleRange(0);
+  if (1 - conf_origin <= thConfSmall) idxScaleRange = 2;
+  else if (1 - conf_origin <= thConfBig) idxScaleRange = 1;
+  else if (1 - conf_origin >= thConfRand) {
+    bool refine = false;
+    for (int iter = 0; iter < 6; iter++) {
+      float depth_random = perturb_depth ? rng.uniform(S.min_depth, S.max_depth) : depth_origin;
+      float normal_random[3];
+      GenerateRandomNormal(rng, view_ray, normal_random);
+      const float nconf = ScorePixelPhotometric(S.ref, S.unit, px, py, normal_random, depth_random, patch, S.n_neighbors, S.nei_gray, S.R_nr, S.t_nr, S.nei_depth);
+      if (nconf > conf_origin) {
+        conf_origin = nconf; depth_origin = depth_random;
+        normal_origin[0] = normal_random[0]; normal_origin[1] = normal_random[1]; normal_origin[2] = normal_random[2];
+        if (1 - nconf < thConfRand) { refine = true; break; }
+      }
+    }
+    if (!refine) return false;
+  }
+  float scaleRange(scaleRanges[idxScaleRange]);
+  float depthRange = depth_origin * 0.02;
+  float angleRange = 30.f / 180.f * M_PI;
+  for (int iter = 0; iter < 6; iter++) {
+    float depth_perturb = perturb_depth ? PerturbDepth(rng, depth_origin, scaleRange * depthRange) : depth_origin;
+    float normal_perturb[3];
+    PerturbNormal(rng, normal_origin, scaleRange * angleRange, normal_perturb);
+    if (MvsDot3(normal_perturb, view_ray) >= 0) continue;
+    const float X0[3] = {view_ray[0] * depth_perturb, view_ray[1] * depth_perturb, view_ray[2] * depth_perturb};
+    const float plane[4] = {normal_perturb[0], normal_perturb[1], normal_perturb[2], -MvsDot3(normal_perturb, X0)};
+    const float nconf = ScorePixelPhotometric(S.ref, S.unit, px, py, normal_perturb, depth_perturb, patch, S.n_neighbors, S.nei_gray, S.R_nr, S.t_nr, S.nei_depth, plane, close, n_close);
+    if (nconf > conf_origin) {
+      conf_origin = nconf; depth_origin = depth_perturb;
+      normal_origin[0] = normal_perturb[0]; normal_origin[1] = normal_perturb[1]; normal_origin[2] = normal_perturb[2];
+      idxScaleRange++;
+      scaleRange = scaleRanges[idxScaleRange];
+    }
+  }
+  return true;
+}
+
+// ProcessPixel :721-772 with the four direct neighbours PropagateCheckerBoard passes (:1113-1114)
+inline void ProcessPixel(const MvsSweep& S, MvsRng& rng, int px, int py, const PixelPatch& patch) {
+  const int rows = S.ref.rows, cols = S.ref.cols;
+  const size_t e = (size_t)py * cols + px;
+  const bool keep_depth_constant = S.depth_constant && S.depth_constant[e];
+  float& depth = S.depth[e]; float* normal = S.normal + 3 * e; float& conf = S.conf[e];
+  NeighborPixel close[4]; int n_close = 0;
+  const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
+  for (int q = 0; q < 4; ++q) {
+    if (!(cx[q] >= 0 && cy[q] >= 0 && cx[q] < cols && cy[q] < rows)) continue;
+    const size_t ne = (size_t)cy[q] * cols + cx[q];
+    const float d = S.depth[ne];
+    if (d <= 0) continue;
+    NeighborPixel& c = close[n_close++];
+    for (int k = 0; k < 3; ++k) { c.point[k] = S.unit[3 * ne + k] * d; c.normal[k] = S.normal[3 * ne + k]; }
+    c.depth = d;
+  }
+  const int nx[4] = {px - 1, px, px + 1, px}, ny[4] = {py, py - 1, py, py + 1};
+  const float* view_ray = S.unit + 3 * e;
+  for (int q = 0; q < 4; ++q) {
+    if (!(nx[q] >= 0 && ny[q] >= 0 && nx[q] < cols && ny[q] < rows)) continue;
+    const size_t ne = (size_t)ny[q] * cols + nx[q];
+    float depth_neighbor = S.depth[ne];
+    if (depth_neighbor <= 0) continue;
+    float normal_neighbor[3] = {S.normal[3 * ne], S.normal[3 * ne + 1], S.normal[3 * ne + 2]};
+    depth_neighbor = keep_depth_constant ? depth : InterpolatePixel(S.unit, cols, px, py, nx[q], ny[q], depth_neighbor, normal_neighbor, S.min_depth, S.max_depth);
+    CorrectNormal(view_ray, normal_neighbor);
+    const float X0[3] = {view_ray[0] * depth_neighbor, view_ray[1] * depth_neighbor, view_ray[2] * depth_neighbor};
+    const float plane[4] = {normal_neighbor[0], normal_neighbor[1], normal_neighbor[2], -MvsDot3(normal_neighbor, X0)};
+    const float newconf = ScorePixelPhotometric(S.ref, S.unit, px, py, normal_neighbor, depth_neighbor, patch, S.n_neighbors, S.nei_gray, S.R_nr, S.t_nr, S.nei_depth, plane, close, n_close);
+    if (conf < newconf) { conf = newconf; depth = depth_neighbor; normal[0] = normal_neighbor[0]; normal[1] = normal_neighbor[1]; normal[2] = normal_neighbor[2]; }
+  }
+  PerturbDepthNormal3(S, rng, px, py, patch, close, n_close, !keep_depth_constant);
+}
+
+// EstimateDepthMapSingle(ref, CHECKER_BOARD, max_iter, conf_threshold, use_geometry = nei_depth != nullptr) :682-720.
+// depth / normal / conf: in-out, already initialised (InitDepthNormal + InitConfMap).
+inline void EstimateDepthMapCheckerBoard(const MvsView& ref, int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr,
+                                         float* depth, float* normal, float* conf, const float* const* nei_depth, const unsigned char* depth_constant,
+                                         float min_depth, float max_depth, uint64_t seed, int max_iter, float conf_threshold) {
+  std::vector<float> unit((size_t)ref.rows * ref.cols * 3);
+  const Equirectangular eq(ref.rows, ref.cols);
+  for (int i = 0; i < ref.rows; ++i)
+    for (int j = 0; j < ref.cols; ++j) { const float px[2] = {(float)j, (float)i}; eq.ImageToCam(px, 1.f, &unit[3 * ((size_t)i * ref.cols + j)]); }
+  const MvsSweep S{ref, unit.data(), n_neighbors, nei_gray, R_nr, t_nr, nei_depth, depth_constant, min_depth, max_depth, depth, normal, conf};
+  for (int iter = 0; iter < max_iter; ++iter)
+    for (int offset = 0; offset <= 1; ++offset) {
+      const uint64_t pass_seed = MvsPassSeed(seed, 2 * iter + offset);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 2)
+#endif
+      for (int row = 0; row < ref.rows; ++row) {
+        PixelPatch patch;
+        for (int col = (row % 2 + offset) % 2; col < ref.cols; col += 2) {
+          const size_t e = (size_t)row * ref.cols + col;
+          if (depth[e] <= 0) continue;
+          FillPixelPatch(ref, col, row, patch);        // frame.patch_map[e] of InitPatchMap
+          if (patch.sq0 <= 1e-6) continue;
+          MvsRng rng{pass_seed, (uint64_t)e};
+          ProcessPixel(S, rng, col, row, patch);
+        }
+      }
+    }
+  for (int i = 0; i < ref.cols; ++i)
+    for (int j = 0; j < ref.rows; ++j) {
+      const size_t e = (size_t)j * ref.cols + i;
+      if (depth_constant && depth_constant[e]) continue;
+      if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; }
     }
 }
 

@@ -223,6 +223,15 @@ void orc_mvs_init_conf_map(int rows, int cols, int half_window, int step, const 
   MvsView v{rows, cols, half_window, step, ref_gray};
   InitConfMap(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth);
 }
+// PatchMatch: EstimateDepthMapSingle(CHECKER_BOARD) — mvs/MVS.cpp:682-772, :1098-1129, :1254-1431, :1923-1971
+void orc_mvs_propagate(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors, const unsigned char* const* nei_gray,
+                       const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf, const float* const* nei_depth,
+                       const unsigned char* depth_constant, float min_depth, float max_depth, unsigned long long seed, int max_iter, float conf_threshold) {
+  MvsView v{rows, cols, half_window, step, ref_gray};
+  EstimateDepthMapCheckerBoard(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth, seed, max_iter,
+                               conf_threshold);
+}
+unsigned orc_mvs_random_u32(unsigned long long seed, unsigned long long pixel, unsigned k) { return MvsRandomU32(seed, pixel, k); }
 void orc_mvs_filter_depth(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr, const float* depth,
                           const float* conf, const unsigned char* depth_constant, float thr, float* depth_filter, float* conf_filter) {
   FilterDepthImage(rows, cols, n_neighbors, nei_depth, R_nr, t_nr, depth, conf, depth_constant, thr, depth_filter, conf_filter);

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -223,6 +223,25 @@ class Context:
                                                     C.c_int(len(neis)), ptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float),
                                                     _p(c, C.c_float), dptrs), "pvlm_mvs_init_conf_map")
         return c, d, nrm
+
+    def mvs_propagate(self, ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_window=3, step=1, nei_depths=None, depth_constant=None, min_depth=0.1,
+                      max_depth=20.0, seed=1, max_iter=1, conf_threshold=-1.0):
+        """MVS::EstimateDepthMapSingle (checkerboard PatchMatch) on the GPU: returns (depth, normal, conf) copies."""
+        ref = np.ascontiguousarray(ref_gray, np.uint8); rows, cols = ref.shape
+        neis = [np.ascontiguousarray(g, np.uint8) for g in nei_grays]
+        ptrs = (C.POINTER(C.c_ubyte) * max(len(neis), 1))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in neis])
+        R = _f32(R_nr).reshape(-1); t = _f32(t_nr).reshape(-1)
+        d = np.array(depth, np.float32, copy=True); nrm = np.array(normal, np.float32, copy=True); c = np.array(conf, np.float32, copy=True)
+        dptrs = None
+        if nei_depths is not None:
+            nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
+            dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
+        dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
+        self._check(self.lib.pvlm_mvs_propagate(self._h, C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte), C.c_int(len(neis)),
+                                                ptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float), dptrs,
+                                                _p(dc, C.c_ubyte), C.c_float(min_depth), C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter),
+                                                C.c_float(conf_threshold)), "pvlm_mvs_propagate")
+        return d, nrm, c
 
     def mvs_filter_depth(self, nei_depths, R_nr, t_nr, depth, conf=None, depth_constant=None, thr=0.01):
         """MVS::FilterDepthImage on the GPU: returns (depth_filter, conf_filter)."""

@@ -32,6 +32,85 @@ __global__ void k_mvs_unit_table(int rows, int cols, float* __restrict__ unit) {
 
 struct pvlm_mvs_neighbours { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
 
+// ---- wave-level pieces shared by the scoring pass and the PatchMatch sweep (one wave per pixel, lane = texel) ----
+struct PatchRegs { float w[PVLM_MVS_MAXM], t0[PVLM_MVS_MAXM]; float sq0; bool inside; };
+
+// FillPixelPatch (mvs/MVS.cpp:637-680)
+__device__ inline void wave_fill_patch(const unsigned char* __restrict__ ref_gray, int rows, int cols, int px, int py, int half_window, int step, int n, int lane,
+                                       PatchRegs& P) {
+  P.inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
+  P.sq0 = 0.f;
+#pragma unroll
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) { P.w[m] = 0.f; P.t0[m] = 0.f; }
+  if (!P.inside) return;
+  float part = 0.f;
+#pragma unroll
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+    const int k = lane + 64 * m;
+    if (k < n) pvlm_mvs::patch_texel(ref_gray, cols, px, py, half_window, step, k, &P.w[m], &P.t0[m]);
+    part += P.w[m];
+  }
+  const float wsum = wave_sum_f(part);
+  part = 0.f;
+#pragma unroll
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) { P.w[m] /= wsum; part += P.w[m] * P.t0[m]; }
+  const float mean = wave_sum_f(part);
+  part = 0.f;
+#pragma unroll
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+    const int k = lane + 64 * m;
+    if (k < n) { P.t0[m] -= mean; const float tmp = P.t0[m] * P.w[m]; part += P.t0[m] * tmp; P.t0[m] = tmp; } else P.t0[m] = 0.f;
+  }
+  P.sq0 = wave_sum_f(part);
+}
+
+// ScorePixel (mvs/MVS.cpp:774-923) for one hypothesis (nrm3, dep) of pixel (px, py): photometric NCC per neighbour image,
+// optional smoothness factors (n_close > 0) and geometric-consistency adjustment (nb.geometric), best-two average.
+// Every lane returns the same value.
+__device__ inline float wave_score(int rows, int cols, int half_window, int step, int n, int lane, const float* __restrict__ unit,
+                                   const pvlm_mvs_neighbours& nb, int px, int py, const PatchRegs& P, const float* nrm3, float dep, const float* factors,
+                                   int n_close) {
+  const float* u0 = unit + 3 * ((size_t)py * cols + px);
+  const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
+  const float d = X0[0] * nrm3[0] + X0[1] * nrm3[1] + X0[2] * nrm3[2];
+  if (d > 0) return -1.f;
+  float best1 = 0.f, best2 = 0.f; int count = 0;
+  for (int b = 0; b < nb.n; ++b) {
+    float H[9];
+    pvlm_mvs::homography(nb.R[b], nb.t[b], nrm3, d, H);
+    float t1[PVLM_MVS_MAXM];
+    bool ok = true;
+    float part = 0.f;
+#pragma unroll
+    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+      const int k = lane + 64 * m;
+      t1[m] = 0.f;
+      if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b], rows, cols, H, px, py, half_window, step, k, &t1[m]) && ok;
+      part += t1[m] * P.w[m];
+    }
+    if (__any(!ok)) continue;                                          // goto next_image
+    const float sum = wave_sum_f(part);
+    float p1 = 0.f, p01 = 0.f;
+#pragma unroll
+    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+      const int k = lane + 64 * m;
+      if (k < n) { t1[m] -= sum; p1 += t1[m] * t1[m] * P.w[m]; p01 += P.t0[m] * t1[m]; }
+    }
+    const float sq1 = wave_sum_f(p1), sq01 = wave_sum_f(p01);
+    const float nrm = P.sq0 * sq1;
+    if (nrm <= 0.f) continue;
+    float score = sq01 / sqrtf(nrm);
+    score = fminf(fmaxf(score, -1.f), 1.f);
+    score = pvlm_mvs::smooth_score(score, factors, n_close);
+    if (nb.geometric) score = pvlm_mvs::geometric_adjust(score, rows, cols, X0, nb.R[b], nb.t[b], nb.depth[b]);   // wave-uniform
+    if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+    ++count;
+  }
+  if (count == 1) return best1;
+  if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; return avg / 2; }
+  return -1.f;
+}
+
 __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
                                                   const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* __restrict__ depth,
                                                   float* __restrict__ normal, float* __restrict__ conf) {
@@ -43,78 +122,60 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
   const int py = (int)(e / cols), px = (int)(e % cols);
   const int n = pvlm_mvs::num_texels(half_window, step);
   float c = -1.f;
-  // ---- FillPixelPatch
-  const bool inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
-  float w[PVLM_MVS_MAXM], t0[PVLM_MVS_MAXM];
-  float sq0 = 0.f;
-  if (inside) {
-    float part = 0.f;
-#pragma unroll
-    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
-      const int k = lane + 64 * m;
-      w[m] = 0.f; t0[m] = 0.f;
-      if (k < n) pvlm_mvs::patch_texel(ref_gray, cols, px, py, half_window, step, k, &w[m], &t0[m]);
-      part += w[m];
-    }
-    const float wsum = wave_sum_f(part);
-    part = 0.f;
-#pragma unroll
-    for (int m = 0; m < PVLM_MVS_MAXM; ++m) { w[m] /= wsum; part += w[m] * t0[m]; }
-    const float mean = wave_sum_f(part);
-    part = 0.f;
-#pragma unroll
-    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
-      const int k = lane + 64 * m;
-      if (k < n) { t0[m] -= mean; const float tmp = t0[m] * w[m]; part += t0[m] * tmp; t0[m] = tmp; } else t0[m] = 0.f;
-    }
-    sq0 = wave_sum_f(part);
-  }
-  if (inside && !(sq0 <= 1e-6) && sq0 > 0) {
-    // ---- ScorePixel, photometric term
-    const float* u0 = unit + 3 * e;
-    const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
+  PatchRegs P;
+  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, P);
+  if (P.inside && !(P.sq0 <= 1e-6) && P.sq0 > 0) {
     const float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
-    const float d = X0[0] * nrm3[0] + X0[1] * nrm3[1] + X0[2] * nrm3[2];
-    if (!(d > 0)) {
-      float best1 = 0.f, best2 = 0.f; int count = 0;
-      for (int b = 0; b < nb.n; ++b) {
-        float H[9];
-        pvlm_mvs::homography(nb.R[b], nb.t[b], nrm3, d, H);
-        float t1[PVLM_MVS_MAXM];
-        bool ok = true;
-        float part = 0.f;
-#pragma unroll
-        for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
-          const int k = lane + 64 * m;
-          t1[m] = 0.f;
-          if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b], rows, cols, H, px, py, half_window, step, k, &t1[m]) && ok;
-          part += t1[m] * w[m];
-        }
-        if (__any(!ok)) continue;                                          // goto next_image
-        const float sum = wave_sum_f(part);
-        float p1 = 0.f, p01 = 0.f;
-#pragma unroll
-        for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
-          const int k = lane + 64 * m;
-          if (k < n) { t1[m] -= sum; p1 += t1[m] * t1[m] * w[m]; p01 += t0[m] * t1[m]; }
-        }
-        const float sq1 = wave_sum_f(p1), sq01 = wave_sum_f(p01);
-        const float nrm = sq0 * sq1;
-        if (nrm <= 0.f) continue;
-        float score = sq01 / sqrtf(nrm);
-        score = fminf(fmaxf(score, -1.f), 1.f);
-        if (nb.geometric) score = pvlm_mvs::geometric_adjust(score, rows, cols, X0, nb.R[b], nb.t[b], nb.depth[b]);   // wave-uniform
-        if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
-        ++count;
-      }
-      if (count == 1) c = best1;
-      else if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; c = avg / 2; }
-    }
+    c = wave_score(rows, cols, half_window, step, n, lane, unit, nb, px, py, P, nrm3, dep, nullptr, 0);
   }
   if (lane == 0) {
     conf[e] = c;
     if (c <= -1) { depth[e] = 0; normal[3 * e] = 0; normal[3 * e + 1] = 0; normal[3 * e + 2] = 0; }
   }
+}
+
+// PatchMatch sweep, one colour of the checkerboard (PropagateCheckerBoard :1098-1129): pixels of colour `offset` read
+// the depth / normal of the other colour and update their own, so one launch is race-free.
+struct WaveScorer {
+  int rows, cols, half_window, step, n, lane, px, py;
+  const float* unit; const pvlm_mvs_neighbours* nb; const PatchRegs* P;
+  __device__ float operator()(const float* nrm3, float dep, const float* factors, int n_close) const {
+    return wave_score(rows, cols, half_window, step, n, lane, unit, *nb, px, py, *P, nrm3, dep, factors, n_close);
+  }
+};
+__global__ __launch_bounds__(256) void k_mvs_propagate(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
+                                                       const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth, float* normal, float* conf,
+                                                       const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth,
+                                                       unsigned long long pass_seed, int offset) {
+  const int half = (cols + 1) / 2;
+  const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per pixel of this colour
+  const int lane = threadIdx.x & 63;
+  if (wv >= (long long)rows * half) return;
+  const int py = (int)(wv / half);
+  const int px = ((py % 2 + offset) % 2) + 2 * (int)(wv % half);
+  if (px >= cols) return;
+  const long long e = (long long)py * cols + px;
+  float dep = depth[e];
+  if (dep <= 0) return;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  PatchRegs P;
+  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, P);
+  if (!P.inside || P.sq0 <= 1e-6) return;                                 // patch.sq0 <= 1e-6 (:1116-1117; patches outside the margin have sq0 = 0)
+  float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+  float c = conf[e];
+  pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+  pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
+  WaveScorer scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P};
+  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c);
+  if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+}
+// EstimateDepthMapSingle :698-714: hypotheses under the confidence threshold are dropped
+__global__ void k_mvs_threshold(long long npix, const unsigned char* __restrict__ depth_constant, float thr, float* __restrict__ depth, float* __restrict__ normal,
+                                float* __restrict__ conf) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npix) return;
+  if (depth_constant && depth_constant[e]) return;
+  if (conf[e] < thr) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = 0.f; normal[3 * e + 1] = 0.f; normal[3 * e + 2] = 0.f; }
 }
 
 // depth-map fusion filter (FilterDepthImage + ProjectDepthConfToRef)
@@ -272,18 +333,21 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
   return st;
 }
 
-pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
-                                   const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
-                                   const float* const* nei_depth) {
+// shared by the scoring pass (max_iter < 0) and the PatchMatch sweep: upload, launch, download
+static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                           const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                           const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth, unsigned long long seed,
+                           int max_iter, float conf_threshold) {
   if (!ctx || rows <= 0 || cols <= 0 || half_window < 1 || step < 1 || !ref_gray || n_neighbors < 0 || n_neighbors > 16 || !depth || !normal || !conf ||
       (n_neighbors > 0 && (!nei_gray || !R_nr || !t_nr)))
     return PVLM_ERR_ARG;
   if (pvlm_mvs::num_texels(half_window, step) > 64 * PVLM_MVS_MAXM) { PVLM_SET_ERR(ctx, "NCC window of %d texels exceeds %d", pvlm_mvs::num_texels(half_window, step), 64 * PVLM_MVS_MAXM); return PVLM_ERR_ARG; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   const size_t npix = (size_t)rows * cols;
-  unsigned char* d_img = nullptr; float *d_unit = nullptr, *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_ndepth = nullptr;
+  unsigned char *d_img = nullptr, *d_const = nullptr; float *d_unit = nullptr, *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_ndepth = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_img, npix * (size_t)(n_neighbors + 1));
   if (!st && nei_depth) st = pvlm_i_alloc(ctx, &d_ndepth, npix * (size_t)std::max(n_neighbors, 1));
+  if (!st && depth_constant) st = pvlm_i_alloc(ctx, &d_const, npix);
   if (!st) st = pvlm_i_alloc(ctx, &d_unit, npix * 3);
   if (!st) st = pvlm_i_alloc(ctx, &d_depth, npix);
   if (!st) st = pvlm_i_alloc(ctx, &d_normal, npix * 3);
@@ -309,11 +373,21 @@ pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_w
     if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth, npix * sizeof(float), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_normal, normal, npix * 3 * sizeof(float), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_conf, conf, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && depth_constant) e = hipMemcpyAsync(d_const, depth_constant, npix, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_unit);
-      {
+      if (max_iter < 0) {
         pvlm_prof_scope prof(ctx, 1);   // timed with the "materialise" slot of pvlm_profile_* (bench / tools)
         hipLaunchKernelGGL(k_mvs_conf, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf);
+      } else {
+        const size_t waves = (size_t)rows * (size_t)((cols + 1) / 2);
+        for (int iter = 0; iter < max_iter; ++iter)
+          for (int offset = 0; offset <= 1; ++offset) {
+            pvlm_prof_scope prof(ctx, 1);
+            hipLaunchKernelGGL(k_mvs_propagate, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal,
+                               d_conf, d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
+          }
+        hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (long long)npix, d_const, conf_threshold, d_depth, d_normal, d_conf);
       }
       e = hipGetLastError();
     }
@@ -321,11 +395,27 @@ pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_w
     if (e == hipSuccess) e = hipMemcpyAsync(normal, d_normal, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(conf, d_conf, npix * sizeof(float), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_init_conf_map: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "%s: %s", what, hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_img); hipFree(d_unit); hipFree(d_depth); hipFree(d_normal); hipFree(d_conf); hipFree(d_ndepth);
+  hipFree(d_img); hipFree(d_unit); hipFree(d_depth); hipFree(d_normal); hipFree(d_conf); hipFree(d_ndepth); hipFree(d_const);
   return st;
+}
+
+pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                   const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                   const float* const* nei_depth) {
+  return mvs_run(ctx, "pvlm_mvs_init_conf_map", rows, cols, half_window, step, ref_gray, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, nullptr,
+                 0.f, 0.f, 0ull, -1, 0.f);
+}
+
+pvlm_status pvlm_mvs_propagate(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                               const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                               const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                               unsigned long long seed, int max_iter, float conf_threshold) {
+  if (max_iter < 0) return PVLM_ERR_ARG;
+  return mvs_run(ctx, "pvlm_mvs_propagate", rows, cols, half_window, step, ref_gray, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth,
+                 depth_constant, min_depth, max_depth, seed, max_iter, conf_threshold);
 }
 
 }  // extern "C"

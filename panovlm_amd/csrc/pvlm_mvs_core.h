@@ -290,4 +290,213 @@ PVLM_HD inline void refine_pixel(int rows, int cols, const RefineViews& nv, cons
   if (depth_constant && depth_constant[e]) { depth_filter[e] = d; conf_filter[e] = 1.f; }
 }
 
+
+// ---- PatchMatch sweep: PropagateCheckerBoard (mvs/MVS.cpp:1098-1129) -> ProcessPixel (:721-772) -> PerturbDepthNormal3
+// (:1254-1320) with InterpolatePixel (:1923-1935), CorrectNormal (:1953-1971), PerturbNormal / PerturbDepth /
+// GenerateRandomNormal (:1368-1431) and the smoothness term of ScorePixel (:843-857).
+// Random draws: upstream shares one time-seeded cv::RNG between the threads of an `omp parallel for` (a data race, no
+// run repeats).  Here draw k of pixel e in pass p is a hash of (seed, p, e, k); float conversion as cv::RNG
+// (next() * 2^-32; uniform(a, b) = that * (b - a) + a).
+PVLM_HD inline unsigned random_u32(unsigned long long seed, unsigned long long pixel, unsigned k) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (pixel + 1) + 0xD1B54A32D192ED03ull * (unsigned long long)(k + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32);
+}
+PVLM_HD inline unsigned long long pass_seed(unsigned long long seed, int pass) {
+  return seed * 0x2545F4914F6CDD1Dull + 0x632BE59BD9B4E019ull * (unsigned long long)(pass + 1);
+}
+struct Rng {
+  unsigned long long seed, pixel; unsigned k;
+  PVLM_HD float next01() { return (float)random_u32(seed, pixel, k++) * 2.3283064365386962890625e-10f; }
+  PVLM_HD float uniform(float a, float b) { return next01() * (b - a) + a; }
+};
+
+PVLM_HD inline float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+PVLM_HD inline float interpolate_pixel(const float* view_ray, const float* unit_n, float depth, const float* normal, float min_depth, float max_depth) {
+  const float X1[3] = {unit_n[0] * depth, unit_n[1] * depth, unit_n[2] * depth};
+  const float dnorm = dot3(view_ray, normal);
+  if (fabsf(dnorm) < 1e-6) return depth;
+  const float depth_new = dot3(X1, normal) / dnorm;
+  if (depth_new >= min_depth && depth_new <= max_depth) return depth_new;
+  return depth;
+}
+
+// rotates a normal that looks away from the camera back to just past 90 degrees; Eigen::AngleAxisf(rad, axis) with the
+// un-normalised axis upstream passes (AngleAxis::toRotationMatrix written out)
+PVLM_HD inline void correct_normal(const float* viewDir, float* normal) {
+  const float cosAngLen = dot3(normal, viewDir);
+  if (cosAngLen >= 0) {
+    const float axis[3] = {normal[1] * viewDir[2] - normal[2] * viewDir[1], normal[2] * viewDir[0] - normal[0] * viewDir[2], normal[0] * viewDir[1] - normal[1] * viewDir[0]};
+    const float v = (acosf(cosAngLen) - (float)1.57079632679489661923) * 1.01f;
+    const float rad = (-0.001f < v) ? -0.001f : v;                       // std::min(v, -0.001f)
+    const float sn = sinf(rad), c = cosf(rad);
+    const float sin_axis[3] = {sn * axis[0], sn * axis[1], sn * axis[2]};
+    const float cos1_axis[3] = {(1.f - c) * axis[0], (1.f - c) * axis[1], (1.f - c) * axis[2]};
+    float R[9];
+    float tmp = cos1_axis[0] * axis[1];
+    R[1] = tmp - sin_axis[2]; R[3] = tmp + sin_axis[2];
+    tmp = cos1_axis[0] * axis[2];
+    R[2] = tmp + sin_axis[1]; R[6] = tmp - sin_axis[1];
+    tmp = cos1_axis[1] * axis[2];
+    R[5] = tmp - sin_axis[0]; R[7] = tmp + sin_axis[0];
+    R[0] = cos1_axis[0] * axis[0] + c; R[4] = cos1_axis[1] * axis[1] + c; R[8] = cos1_axis[2] * axis[2] + c;
+    const float x = R[0] * normal[0] + R[1] * normal[1] + R[2] * normal[2];
+    const float y = R[3] * normal[0] + R[4] * normal[1] + R[5] * normal[2];
+    const float z = R[6] * normal[0] + R[7] * normal[1] + R[8] * normal[2];
+    normal[0] = x; normal[1] = y; normal[2] = z;
+  }
+}
+
+PVLM_HD inline void perturb_normal(Rng& rng, const float* normal, float perturbation, float* out) {
+  const float a1 = (rng.next01() - 0.5f) * perturbation;
+  const float a2 = (rng.next01() - 0.5f) * perturbation;
+  const float a3 = (rng.next01() - 0.5f) * perturbation;
+  const float sin_a1 = sinf(a1), sin_a2 = sinf(a2), sin_a3 = sinf(a3);
+  const float cos_a1 = cosf(a1), cos_a2 = cosf(a2), cos_a3 = cosf(a3);
+  float R[9];
+  R[0] = cos_a2 * cos_a3;
+  R[1] = -cos_a2 * sin_a3;
+  R[2] = sin_a2;
+  R[3] = cos_a1 * sin_a3 + cos_a3 * sin_a1 * sin_a2;
+  R[4] = cos_a1 * cos_a3 - sin_a1 * sin_a2 * sin_a3;
+  R[5] = -cos_a2 * sin_a1;
+  R[6] = sin_a1 * sin_a3 - cos_a1 * cos_a3 * sin_a2;
+  R[7] = cos_a3 * sin_a1 + cos_a1 * sin_a2 * sin_a3;
+  R[8] = cos_a1 * cos_a2;
+  out[0] = R[0] * normal[0] + R[1] * normal[1] + R[2] * normal[2];
+  out[1] = R[3] * normal[0] + R[4] * normal[1] + R[5] * normal[2];
+  out[2] = R[6] * normal[0] + R[7] * normal[1] + R[8] * normal[2];
+}
+PVLM_HD inline float perturb_depth(Rng& rng, float depth, float perturbation) {
+  const float max_depth = (1 + perturbation) * depth, min_depth = (1 - perturbation) * depth;
+  return rng.uniform(0.f, 1.f) * (max_depth - min_depth) + min_depth;
+}
+PVLM_HD inline void generate_random_normal(Rng& rng, const float* view_ray, float* normal) {
+  float v1 = 0.0f, v2 = 0.0f, s = 2.0f;
+  while (s >= 1.0f) {
+    v1 = 2.0f * rng.uniform(0.f, 1.f) - 1.0f;
+    v2 = 2.0f * rng.uniform(0.f, 1.f) - 1.0f;
+    s = v1 * v1 + v2 * v2;
+  }
+  const float s_norm = sqrtf(1.0f - s);
+  normal[0] = 2.0f * v1 * s_norm; normal[1] = 2.0f * v2 * s_norm; normal[2] = 1.0f - 2.0f * s;
+  if (dot3(normal, view_ray) > 0) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+}
+
+struct ClosePixel { float point[3]; float normal[3]; float depth; };   // NeighborPixel, mvs/MVS.h:59-64
+
+// one close neighbour's factor of the smoothness term: (1 - bonusDepth * exp(dd^2 sigmaD)) * (1 - bonusNormal * exp(da^2 sigmaN))
+PVLM_HD inline float smooth_factor(const float* plane, const ClosePixel& c, const float* normal, float depth) {
+  const float smoothBonus = 0.95f, smoothBonusDepth = 1.f - smoothBonus, smoothBonusNormal = (float)((1.f - smoothBonus) * 0.96);
+  const float smoothSigmaDepth = -1.f / (2.f * 0.02f * 0.02f), smoothSigmaNormal = -1.f / (2.f * 0.22f * 0.22f);
+  const float diff_distance = fabsf(plane[0] * c.point[0] + plane[1] * c.point[1] + plane[2] * c.point[2] + plane[3]) / depth;
+  const float factorDepth = expf(diff_distance * diff_distance * smoothSigmaDepth);
+  const float cosang = normal[0] * c.normal[0] + normal[1] * c.normal[1] + normal[2] * c.normal[2];
+  const float diff_angle = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)3.14159265358979323846 : acosf(cosang));
+  const float factorNormal = expf(diff_angle * diff_angle * smoothSigmaNormal);
+  return (1.f - smoothBonusDepth * factorDepth) * (1.f - smoothBonusNormal * factorNormal);
+}
+// applied to one neighbour image's clamped NCC (ScorePixel :843-857)
+PVLM_HD inline float smooth_score(float score, const float* factors, int n_close) {
+  if (n_close <= 0) return score;
+  score = 1 - score;
+  for (int q = 0; q < n_close; ++q) score *= factors[q];
+  score = 1 - score;
+  return fminf(1.f, fmaxf(-1.f, score));
+}
+
+struct SweepArgs {
+  int rows, cols;
+  const float* unit;                       // PreComputeI2C table
+  const float* depth; const float* normal; // the maps (read: the other colour of the checkerboard)
+  const unsigned char* depth_constant;     // may be null
+  float min_depth, max_depth;
+};
+
+// ProcessPixel + PerturbDepthNormal3 for pixel (px, py).  score(normal, depth, factors, n_close) -> aggregated ScorePixel
+// value; factors = the smooth_factor of every close neighbour for that hypothesis (n_close = 0: no smoothness term).
+// depth / normal / conf: the pixel's own state, updated in place by the caller-visible references.
+template <class Scorer>
+PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, Scorer& score, float& depth, float* normal, float& conf) {
+  const int rows = A.rows, cols = A.cols;
+  const size_t e = (size_t)py * cols + px;
+  const bool keep_depth_constant = A.depth_constant && A.depth_constant[e];
+  const float* view_ray = A.unit + 3 * e;
+  ClosePixel close[4]; int n_close = 0;
+  {
+    const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
+    for (int q = 0; q < 4; ++q) {
+      if (!(cx[q] >= 0 && cy[q] >= 0 && cx[q] < cols && cy[q] < rows)) continue;
+      const size_t ne = (size_t)cy[q] * cols + cx[q];
+      const float d = A.depth[ne];
+      if (d <= 0) continue;
+      ClosePixel& c = close[n_close++];
+      for (int k = 0; k < 3; ++k) { c.point[k] = A.unit[3 * ne + k] * d; c.normal[k] = A.normal[3 * ne + k]; }
+      c.depth = d;
+    }
+  }
+  float factors[4];
+  // ---- propagation from the four direct neighbours (:749-771)
+  {
+    const int nx[4] = {px - 1, px, px + 1, px}, ny[4] = {py, py - 1, py, py + 1};
+    for (int q = 0; q < 4; ++q) {
+      if (!(nx[q] >= 0 && ny[q] >= 0 && nx[q] < cols && ny[q] < rows)) continue;
+      const size_t ne = (size_t)ny[q] * cols + nx[q];
+      float depth_neighbor = A.depth[ne];
+      if (depth_neighbor <= 0) continue;
+      float normal_neighbor[3] = {A.normal[3 * ne], A.normal[3 * ne + 1], A.normal[3 * ne + 2]};
+      depth_neighbor = keep_depth_constant ? depth : interpolate_pixel(view_ray, A.unit + 3 * ne, depth_neighbor, normal_neighbor, A.min_depth, A.max_depth);
+      correct_normal(view_ray, normal_neighbor);
+      const float X0[3] = {view_ray[0] * depth_neighbor, view_ray[1] * depth_neighbor, view_ray[2] * depth_neighbor};
+      const float plane[4] = {normal_neighbor[0], normal_neighbor[1], normal_neighbor[2], -dot3(normal_neighbor, X0)};
+      for (int c = 0; c < n_close; ++c) factors[c] = smooth_factor(plane, close[c], normal_neighbor, depth_neighbor);
+      const float newconf = score(normal_neighbor, depth_neighbor, factors, n_close);
+      if (conf < newconf) { conf = newconf; depth = depth_neighbor; normal[0] = normal_neighbor[0]; normal[1] = normal_neighbor[1]; normal[2] = normal_neighbor[2]; }
+    }
+  }
+  // ---- PerturbDepthNormal3 (perturb_depth = !keep_depth_constant, perturb_normal = true)
+  const bool perturb = !keep_depth_constant;
+  const float scaleRanges[12] = {1.f, 0.5f, 0.25f, 0.125f, 0.0625f, 0.03125f, 0.015625f, 0.0078125f, 0.00390625f, 0.001953125f, 0.0009765625f, 0.00048828125f};
+  const float thConfSmall = (float)(0.55 * 0.2f), thConfBig = (float)(0.55 * 0.4f), thConfRand = (float)(0.55 * 0.9f);
+  unsigned idxScaleRange = 0;
+  if (1 - conf <= thConfSmall) idxScaleRange = 2;
+  else if (1 - conf <= thConfBig) idxScaleRange = 1;
+  else if (1 - conf >= thConfRand) {
+    bool refine = false;
+    for (int iter = 0; iter < 6; iter++) {
+      const float depth_random = perturb ? rng.uniform(A.min_depth, A.max_depth) : depth;
+      float normal_random[3];
+      generate_random_normal(rng, view_ray, normal_random);
+      const float nconf = score(normal_random, depth_random, factors, 0);
+      if (nconf > conf) {
+        conf = nconf; depth = depth_random; normal[0] = normal_random[0]; normal[1] = normal_random[1]; normal[2] = normal_random[2];
+        if (1 - nconf < thConfRand) { refine = true; break; }
+      }
+    }
+    if (!refine) return;
+  }
+  float scaleRange = scaleRanges[idxScaleRange];
+  const float depthRange = (float)(depth * 0.02);
+  const float angleRange = (float)(30.f / 180.f * 3.14159265358979323846);
+  for (int iter = 0; iter < 6; iter++) {
+    const float depth_perturb = perturb ? perturb_depth(rng, depth, scaleRange * depthRange) : depth;
+    float normal_perturb[3];
+    perturb_normal(rng, normal, scaleRange * angleRange, normal_perturb);
+    if (dot3(normal_perturb, view_ray) >= 0) continue;
+    const float X0[3] = {view_ray[0] * depth_perturb, view_ray[1] * depth_perturb, view_ray[2] * depth_perturb};
+    const float plane[4] = {normal_perturb[0], normal_perturb[1], normal_perturb[2], -dot3(normal_perturb, X0)};
+    for (int c = 0; c < n_close; ++c) factors[c] = smooth_factor(plane, close[c], normal_perturb, depth_perturb);
+    const float nconf = score(normal_perturb, depth_perturb, factors, n_close);
+    if (nconf > conf) {
+      conf = nconf; depth = depth_perturb; normal[0] = normal_perturb[0]; normal[1] = normal_perturb[1]; normal[2] = normal_perturb[2];
+      idxScaleRange++;
+      scaleRange = scaleRanges[idxScaleRange];
+    }
+  }
+}
+
 }  // namespace pvlm_mvs
+

@@ -104,3 +104,95 @@ extern "C" void chk_mvs_filter_refine(int rows, int cols, int n_neighbors, const
   for (size_t e = 0; e < npix; ++e)
     refine_pixel(rows, cols, nv, key.data(), unit.data(), depth, conf, depth_constant, thr, min_depth, max_depth, (long long)e, depth_filter, conf_filter);
 }
+
+// ---- PatchMatch sweep through the device bodies (process_pixel and everything it calls), serial scorer ----
+namespace {
+struct SerialPatch { std::vector<float> w, t0; float sq0 = 0.f; bool inside = false; };
+void serial_fill_patch(const unsigned char* ref_gray, int rows, int cols, int px, int py, int half_window, int step, SerialPatch& P) {
+  using namespace pvlm_mvs;
+  const int n = num_texels(half_window, step);
+  P.w.assign(n, 0.f); P.t0.assign(n, 0.f); P.sq0 = 0.f;
+  P.inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
+  if (!P.inside) return;
+  float wsum = 0.f;
+  for (int k = 0; k < n; ++k) { patch_texel(ref_gray, cols, px, py, half_window, step, k, &P.w[k], &P.t0[k]); wsum += P.w[k]; }
+  float mean = 0.f;
+  for (int k = 0; k < n; ++k) { P.w[k] /= wsum; mean += P.w[k] * P.t0[k]; }
+  for (int k = 0; k < n; ++k) { P.t0[k] -= mean; const float tmp = P.t0[k] * P.w[k]; P.sq0 += P.t0[k] * tmp; P.t0[k] = tmp; }
+}
+struct SerialScorer {
+  int rows, cols, half_window, step, px, py, n_neighbors;
+  const float* unit; const unsigned char* const* nei_gray; const float* R_nr; const float* t_nr; const float* const* nei_depth; const SerialPatch* P;
+  float operator()(const float* nr, float dep, const float* factors, int n_close) const {
+    using namespace pvlm_mvs;
+    const int n = num_texels(half_window, step);
+    const float* u0 = unit + 3 * ((size_t)py * cols + px);
+    const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
+    const float d = X0[0] * nr[0] + X0[1] * nr[1] + X0[2] * nr[2];
+    if (d > 0) return -1.f;
+    std::vector<float> t1(n);
+    float best1 = 0.f, best2 = 0.f; int count = 0;
+    for (int b = 0; b < n_neighbors; ++b) {
+      float H[9];
+      homography(R_nr + 9 * b, t_nr + 3 * b, nr, d, H);
+      bool ok = true;
+      for (int k = 0; k < n && ok; ++k) ok = neighbour_texel(unit, nei_gray[b], rows, cols, H, px, py, half_window, step, k, &t1[k]);
+      if (!ok) continue;
+      float sum = 0.f, sq1 = 0.f, sq01 = 0.f;
+      for (int k = 0; k < n; ++k) sum += t1[k] * P->w[k];
+      for (int k = 0; k < n; ++k) t1[k] -= sum;
+      for (int k = 0; k < n; ++k) sq1 += t1[k] * t1[k] * P->w[k];
+      for (int k = 0; k < n; ++k) sq01 += P->t0[k] * t1[k];
+      const float nrm = P->sq0 * sq1;
+      if (nrm <= 0.f) continue;
+      float score = sq01 / sqrtf(nrm);
+      score = fminf(fmaxf(score, -1.f), 1.f);
+      score = smooth_score(score, factors, n_close);
+      if (nei_depth) score = geometric_adjust(score, rows, cols, X0, R_nr + 9 * b, t_nr + 3 * b, nei_depth[b]);
+      if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+      ++count;
+    }
+    if (count == 1) return best1;
+    if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; return avg / 2; }
+    return -1.f;
+  }
+};
+}  // namespace
+
+extern "C" void chk_mvs_propagate(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                  const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                  const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                  unsigned long long seed, int max_iter, float conf_threshold) {
+  using namespace pvlm_mvs;
+  const size_t npix = (size_t)rows * cols;
+  std::vector<float> unit(npix * 3);
+  for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) unit_ray(rows, cols, c, r, &unit[3 * ((size_t)r * cols + c)]);
+  SerialPatch P;
+  for (int iter = 0; iter < max_iter; ++iter)
+    for (int offset = 0; offset <= 1; ++offset) {
+      const unsigned long long ps = pass_seed(seed, 2 * iter + offset);
+      // the same wave -> pixel mapping as k_mvs_propagate, walked backwards: a colour pass must not depend on the order
+      const int half = (cols + 1) / 2;
+      for (long long wv = (long long)rows * half - 1; wv >= 0; --wv) {
+        const int py = (int)(wv / half), px = ((py % 2 + offset) % 2) + 2 * (int)(wv % half);
+        if (px >= cols) continue;
+        const size_t e = (size_t)py * cols + px;
+        float dep = depth[e];
+        if (dep <= 0) continue;
+        serial_fill_patch(ref_gray, rows, cols, px, py, half_window, step, P);
+        if (!P.inside || P.sq0 <= 1e-6) continue;
+        float nr[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+        float c = conf[e];
+        SweepArgs A{rows, cols, unit.data(), depth, normal, depth_constant, min_depth, max_depth};
+        Rng rng{ps, (unsigned long long)e, 0u};
+        SerialScorer scorer{rows, cols, half_window, step, px, py, n_neighbors, unit.data(), nei_gray, R_nr, t_nr, nei_depth, &P};
+        process_pixel(A, rng, px, py, scorer, dep, nr, c);
+        depth[e] = dep; normal[3 * e] = nr[0]; normal[3 * e + 1] = nr[1]; normal[3 * e + 2] = nr[2]; conf[e] = c;
+      }
+    }
+  for (size_t e = 0; e < npix; ++e) {
+    if (depth_constant && depth_constant[e]) continue;
+    if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0.f; }
+  }
+}
+extern "C" unsigned chk_mvs_random_u32(unsigned long long seed, unsigned long long pixel, unsigned k) { return pvlm_mvs::random_u32(seed, pixel, k); }

@@ -201,3 +201,62 @@ def test_depth_filter_refine_oracle_behaviour_and_device_bodies(oracle):
     lib.chk_mvs_filter_refine(C.c_int(depth.shape[0]), C.c_int(depth.shape[1]), C.c_int(len(nd)), dptrs, cptrs, fp(R), fp(t), fp(depth), fp(cc),
                               const.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_float(0.01), C.c_float(0.1), C.c_float(20.0), fp(od), fp(oc))
     assert np.array_equal(od, df) and np.array_equal(oc, cf) and np.array_equal(cc, conf_after)
+
+
+def sweep_scene(oracle, rows=96, cols=192):
+    """A perturbed initial state for the PatchMatch sweep: depths off by up to 10 %, normals tilted, scored by InitConfMap."""
+    (gray, depth, normal), neis, Rn, tn, nd = mvs_scene(oracle, rows, cols, with_depths=True)
+    rng = np.random.default_rng(7)
+    d0 = (depth * rng.uniform(0.9, 1.1, size=depth.shape)).astype(np.float32)
+    n0 = normal + 0.15 * rng.normal(size=normal.shape).astype(np.float32)
+    n0 = (n0 / np.linalg.norm(n0, axis=2, keepdims=True)).astype(np.float32)
+    c0, d1, n1 = oracle.mvs_init_conf_map(gray, neis, Rn, tn, d0, n0, 3, 1)
+    const = np.zeros(depth.shape, np.uint8); const[rows // 2 - 5:rows // 2 + 5, cols // 3:cols // 2] = 1
+    return dict(gray=gray, neis=neis, Rn=Rn, tn=tn, nd=nd, depth=d1, normal=n1, conf=c0, truth=depth, const=const)
+
+
+def test_patchmatch_sweep_oracle_behaviour_and_device_bodies(oracle):
+    """EstimateDepthMapSingle (checkerboard): the oracle converges towards the rendered geometry, never lowers a pixel's
+    score, honours depth_constant and the confidence threshold, and repeats for a seed; process_pixel and everything under
+    it (panovlm_amd/csrc/pvlm_mvs_core.h) compiled for the host gives the same maps bit for bit, pixels visited backwards."""
+    S = sweep_scene(oracle)
+    args = (S["gray"], S["neis"], S["Rn"], S["tn"], S["depth"], S["normal"], S["conf"])
+    valid = S["conf"] > -1
+    err = lambda d: np.median(np.abs(d[valid] / S["truth"][valid] - 1))
+    d1, n1, c1 = oracle.mvs_propagate(*args, max_iter=1, seed=5)
+    d3, n3, c3 = oracle.mvs_propagate(*args, max_iter=3, seed=5)
+    assert np.all(c1[valid] >= S["conf"][valid]) and np.all(c3[valid] >= c1[valid] - 0)          # a hypothesis is only ever replaced by a better one
+    assert err(S["depth"]) > 0.04 and err(d1) < 0.5 * err(S["depth"]) and err(d3) < 0.6 * err(d1)
+    assert np.array_equal(d1[~valid], S["depth"][~valid])                                          # pixels without a hypothesis are not touched
+    again = oracle.mvs_propagate(*args, max_iter=1, seed=5)
+    assert all(np.array_equal(a, b) for a, b in zip((d1, n1, c1), again))
+    other = oracle.mvs_propagate(*args, max_iter=1, seed=6)[0]
+    assert (other != d1)[valid].mean() > 0.5
+    dk, nk, ck = oracle.mvs_propagate(*args, max_iter=1, seed=5, depth_constant=S["const"], conf_threshold=0.97)
+    m = (S["const"] == 1) & valid
+    assert np.array_equal(dk[m], S["depth"][m]) and (nk[m] != S["normal"][m]).any()               # depth pinned, normal still refined
+    dropped = (ck == -1) & valid
+    assert dropped.any() and np.all(dk[dropped] == 0) and not dropped[m].any() and np.all(ck[valid & ~dropped & ~m] >= 0.97)
+    # random stream: uniform and independent enough for the purpose
+    oracle.lib().orc_mvs_random_u32.restype = C.c_uint
+    u = np.array([oracle.lib().orc_mvs_random_u32(C.c_ulonglong(3), C.c_ulonglong(p), C.c_uint(k)) for p in range(200) for k in range(20)], np.float64) / 2 ** 32
+    assert abs(u.mean() - 0.5) < 0.02 and abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 0.05
+    out = os.path.join(ROOT, "build", "libmvs_check.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "cpp", "mvs_math_check.cpp")])
+    lib = C.CDLL(out)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ptrs = (C.POINTER(C.c_ubyte) * len(S["neis"]))(*[np.ascontiguousarray(g).ctypes.data_as(C.POINTER(C.c_ubyte)) for g in S["neis"]])
+    R = np.ascontiguousarray(S["Rn"], np.float32); t = np.ascontiguousarray(S["tn"], np.float32)
+    nd = [np.ascontiguousarray(x, np.float32) for x in S["nd"]]
+    lib.chk_mvs_random_u32.restype = C.c_uint
+    assert lib.chk_mvs_random_u32(C.c_ulonglong(3), C.c_ulonglong(17), C.c_uint(4)) == oracle.lib().orc_mvs_random_u32(C.c_ulonglong(3), C.c_ulonglong(17), C.c_uint(4))
+    for geo, kw in ((False, dict(max_iter=1, seed=5)), (True, dict(max_iter=2, seed=9, conf_threshold=0.9, depth_constant=S["const"]))):
+        want = oracle.mvs_propagate(*args, nei_depths=S["nd"] if geo else None, **kw)
+        d = S["depth"].copy(); n = S["normal"].copy(); c = S["conf"].copy()
+        dptrs = (C.POINTER(C.c_float) * len(nd))(*[fp(x) for x in nd]) if geo else None
+        dc = kw.get("depth_constant")
+        lib.chk_mvs_propagate(C.c_int(d.shape[0]), C.c_int(d.shape[1]), C.c_int(3), C.c_int(1), S["gray"].ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_int(len(nd)), ptrs,
+                              fp(R), fp(t), fp(d), fp(n), fp(c), dptrs, dc.ctypes.data_as(C.POINTER(C.c_ubyte)) if dc is not None else None, C.c_float(0.1),
+                              C.c_float(20.0), C.c_ulonglong(kw["seed"]), C.c_int(kw["max_iter"]), C.c_float(kw.get("conf_threshold", -1.0)))
+        assert np.array_equal(d, want[0]) and np.array_equal(n, want[1]) and np.array_equal(c, want[2])
+

@@ -95,3 +95,40 @@ def test_depth_filter_refine_matches_oracle(ctx, oracle):
     d0, c0, _ = ctx.mvs_filter_depth_refine([], [], np.zeros((0, 9)), np.zeros((0, 3)), depth, conf, depth_constant=const)
     keep = (const == 1) & (depth > 0)
     assert np.array_equal(d0[keep], depth[keep]) and np.all(c0[keep] == 1) and not d0[~keep].any()
+
+
+def sweep_agreement(got, want, valid):
+    """Fraction of valid pixels on which two sweep results agree (depth 1e-4 relative, normal and conf 1e-4 absolute)."""
+    dg, ng, cg = got; do, no, co = want
+    same = (np.abs(dg - do) <= 1e-4 * np.maximum(np.abs(do), 1e-3)) & (np.abs(ng - no).max(axis=2) <= 1e-4) & (np.abs(cg - co) <= 1e-4)
+    return float(same[valid].mean())
+
+
+def test_patchmatch_sweep_matches_oracle(ctx, oracle):
+    """pvlm_mvs_propagate (k_mvs_propagate: one wave per pixel, process_pixel + wave-level ScorePixel) against the oracle.
+    The per-hypothesis scores differ at the 1e-6 level (wave-tree sums, device sinf / cosf / expf / acosf), so a pixel whose
+    two best candidates tie that closely may keep the other one and then draws different perturbations: the maps agree on
+    the great majority of pixels, and the sweeps are equally good where they differ."""
+    from tests.test_mvs_cpu import sweep_scene
+    S = sweep_scene(oracle)
+    args = (S["gray"], S["neis"], S["Rn"], S["tn"], S["depth"], S["normal"], S["conf"])
+    valid = S["conf"] > -1
+    err = lambda d: float(np.median(np.abs(d[valid] / S["truth"][valid] - 1)))
+    for kw in (dict(max_iter=1, seed=5), dict(max_iter=1, seed=9, nei_depths=S["nd"], depth_constant=S["const"], conf_threshold=0.9)):
+        want = oracle.mvs_propagate(*args, **kw)
+        got = ctx.mvs_propagate(*args, **kw)
+        agree = sweep_agreement(got, want, valid)
+        assert agree > 0.9, agree
+        assert np.array_equal(got[0] == 0, want[0] == 0) or np.mean((got[0] == 0) != (want[0] == 0)) < 0.01
+        assert abs(float(got[2][valid].mean()) - float(want[2][valid].mean())) < 2e-3
+        assert abs(err(got[0]) - err(want[0])) < 0.2 * err(want[0]) + 1e-4
+        if "conf_threshold" not in kw:
+            assert np.all(got[2][valid] >= S["conf"][valid])                                       # monotone, as on the CPU
+        m = (S["const"] == 1) & valid
+        if "depth_constant" in kw:
+            assert np.array_equal(got[0][m], S["depth"][m])
+        again = ctx.mvs_propagate(*args, **kw)
+        assert all(np.array_equal(a, b) for a, b in zip(got, again))                              # same arguments, same maps
+    d3 = ctx.mvs_propagate(*args, max_iter=3, seed=5)[0]
+    assert err(d3) < 0.3 * err(S["depth"])
+

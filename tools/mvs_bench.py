@@ -60,6 +60,24 @@ def main():
     t0 = time.perf_counter()
     rdo, rco, _ = orc.mvs_filter_depth_refine(nd, nc, np.array(Rn), np.array(tn), depth, cref)
     ref_cpu = time.perf_counter() - t0
+    # PatchMatch sweep (K13): one checkerboard iteration from a perturbed state, GPU beside the oracle (OpenMP)
+    prng = np.random.default_rng(7)
+    d0 = (depth * prng.uniform(0.9, 1.1, size=depth.shape)).astype(np.float32)
+    c0, d1, n1 = ctx.mvs_init_conf_map(gray, neis, np.array(Rn), np.array(tn), d0, normal, a.half_window, a.step)
+    sw = (gray, neis, np.array(Rn), np.array(tn), d1, n1, c0)
+    ctx.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5)
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    sg = ctx.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5)
+    sweep_wall = time.perf_counter() - t0
+    sweep_ms, sweep_cnt = ctx.profile_read(1)
+    ctx.profile_enable(False)
+    t0 = time.perf_counter()
+    so = orc.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5)
+    sweep_cpu = time.perf_counter() - t0
+    vs = c0 > -1
+    same = (np.abs(sg[0] - so[0]) <= 1e-4 * np.maximum(np.abs(so[0]), 1e-3)) & (np.abs(sg[1] - so[1]).max(axis=2) <= 1e-4) & (np.abs(sg[2] - so[2]) <= 1e-4)
+    rel = lambda d: float(np.median(np.abs(d[vs] / depth[vs] - 1)))
     w = 2 * a.half_window + 1; q = w // a.step + (1 if a.step > 1 else 0)
     texels = a.rows * a.cols * q * q * a.neighbors
     k_ms = ms / max(cnt, 1)
@@ -71,6 +89,9 @@ def main():
                                       cpu_oracle_s_single_thread=filt_cpu),
                           filter_refine=dict(wall_ms_incl_copies=ref_wall * 1e3, kept=float((rdg > 0).mean()),
                                              identical_to_oracle=bool(np.array_equal(rdg, rdo) and np.array_equal(rcg, rco)), cpu_oracle_s_single_thread=ref_cpu),
+                          sweep=dict(kernel_ms_per_colour_pass=sweep_ms / max(sweep_cnt, 1), colour_passes=int(sweep_cnt), wall_ms_one_iteration_incl_copies=sweep_wall * 1e3,
+                                     cpu_oracle_s=sweep_cpu, agree_with_oracle=float(same[vs].mean()), mean_conf_gpu=float(sg[2][vs].mean()), mean_conf_oracle=float(so[2][vs].mean()),
+                                     depth_err_before=rel(d1), depth_err_gpu=rel(sg[0]), depth_err_oracle=rel(so[0])),
                           cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
 
 
