@@ -185,6 +185,15 @@ def mvs():
         d["nei%d_gray" % k] = g; d["nei%d_depth" % k] = x
     d["conf_pho"], d["depth_pho"], _ = orc.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1)
     d["conf_geo"], _, _ = orc.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1, nei_depths=nd)
+    # one checkerboard PatchMatch iteration (EstimateDepthMapSingle, mvs/MVS.cpp:682-772, :1098-1129, :1254-1431) from the scored state
+    d["sweep_seed"] = np.uint64(5)
+    d["depth_sweep"], d["normal_sweep"], d["conf_sweep"] = orc.mvs_propagate(gray, neis, Rn, tn, d["depth_pho"], normal, d["conf_pho"], max_iter=1, seed=5)
+    # FilterDepthImageRefine (mvs/MVS.cpp:1794-1890) of the swept map against the neighbours' depth maps; confidences on a 1/16 grid
+    for k in range(len(nd)):
+        d["nei%d_conf" % k] = (np.round(rng.uniform(0, 1, size=depth.shape) * 16) / 16).astype(np.float32)
+    ref_conf = np.clip(d["conf_sweep"], 0, None)
+    d["depth_refine"], d["conf_refine"], d["conf_after_refine"] = orc.mvs_filter_depth_refine(nd, [d["nei%d_conf" % k] for k in range(len(nd))], Rn, tn,
+                                                                                               d["depth_sweep"], ref_conf, thr=0.02, min_depth=0.1, max_depth=20.0)
     np.savez_compressed(os.path.join(OUT, "mvs.npz"), **d)
 
 

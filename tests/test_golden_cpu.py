@@ -133,6 +133,12 @@ def test_mvs_golden(oracle):
     assert np.array_equal(c, g["conf_pho"]) and np.array_equal(d, g["depth_pho"])
     cg, _, _ = oracle.mvs_init_conf_map(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth"], g["normal"], 3, 1, nei_depths=nd)
     assert np.array_equal(cg, g["conf_geo"]) and (c > -1).mean() > 0.6
+    ds, ns, cs = oracle.mvs_propagate(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth_pho"], g["normal"], g["conf_pho"], max_iter=1, seed=int(g["sweep_seed"]))
+    assert np.array_equal(ds, g["depth_sweep"]) and np.array_equal(ns, g["normal_sweep"]) and np.array_equal(cs, g["conf_sweep"])
+    nc = [g["nei%d_conf" % k] for k in range(3)]
+    dr, cr, ca = oracle.mvs_filter_depth_refine(nd, nc, g["R_nr"], g["t_nr"], g["depth_sweep"], np.clip(g["conf_sweep"], 0, None), thr=0.02, min_depth=0.1, max_depth=20.0)
+    assert np.array_equal(dr, g["depth_refine"]) and np.array_equal(cr, g["conf_refine"]) and np.array_equal(ca, g["conf_after_refine"])
+    assert 0.05 < (dr > 0).mean() < 0.95
 
 
 def test_refvec_container_round_trip(tmp_path):

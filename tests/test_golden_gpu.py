@@ -99,3 +99,12 @@ def test_mvs_golden(ctx):
         c, d, _ = ctx.mvs_init_conf_map(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth"], g["normal"], 3, 1, **kw)
         assert np.array_equal(c == -1, g[key] == -1)
         assert np.abs(c - g[key]).max() <= 1e-4
+    # depth fusion of the golden swept map: bit-exact
+    nc = [g["nei%d_conf" % k] for k in range(3)]
+    dr, cr, ca = ctx.mvs_filter_depth_refine(nd, nc, g["R_nr"], g["t_nr"], g["depth_sweep"], np.clip(g["conf_sweep"], 0, None), thr=0.02, min_depth=0.1, max_depth=20.0)
+    assert np.array_equal(dr, g["depth_refine"]) and np.array_equal(cr, g["conf_refine"]) and np.array_equal(ca, g["conf_after_refine"])
+    # the PatchMatch iteration: the great majority of pixels land on the golden hypothesis (see test_mvs_gpu.py for why not all)
+    ds, ns, cs = ctx.mvs_propagate(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth_pho"], g["normal"], g["conf_pho"], max_iter=1, seed=int(g["sweep_seed"]))
+    valid = g["conf_pho"] > -1
+    same = (np.abs(ds - g["depth_sweep"]) <= 1e-4 * np.maximum(g["depth_sweep"], 1e-3)) & (np.abs(cs - g["conf_sweep"]) <= 1e-4)
+    assert same[valid].mean() > 0.9 and abs(float(cs[valid].mean()) - float(g["conf_sweep"][valid].mean())) < 2e-3
