@@ -188,3 +188,28 @@ def test_golden_scan(oracle):
     for name in FIELDS:
         assert np.array_equal(getattr(o, name), g[name], equal_nan=True), name
         assert np.array_equal(h[name], g[name], equal_nan=True), name
+
+
+def test_fuzz_unstructured_clouds(oracle):
+    """Clouds that do not look like a VLP-16 sweep at all (random order, several turns, backwards sweeps, duplicated
+    directions, out-of-band elevations): whatever path the re-ordering state machine takes, mirror and oracle agree."""
+    rng = np.random.default_rng(123)
+    for it in range(40):
+        mode = it % 5
+        n = int(rng.integers(50, 3000))
+        if mode == 0:
+            az = rng.uniform(0, 2 * np.pi, n); el = np.deg2rad(rng.uniform(-17, 17, n)); r = rng.uniform(0.5, 10, n)
+        elif mode == 1:
+            az = np.sort(rng.uniform(0, 2 * np.pi, n)); el = np.deg2rad(-15 + 2 * rng.integers(0, 16, n)); r = rng.uniform(0.5, 1.5, n)
+        elif mode == 2:
+            az = np.linspace(0, 5 * np.pi, n) + rng.normal(0, 0.01, n); el = np.deg2rad(-15 + 2 * (np.arange(n) % 16)); r = 3 + np.sin(az * 3)
+        elif mode == 3:
+            az = np.linspace(2 * np.pi, 0, n); el = np.deg2rad(-15 + 2 * (np.arange(n) % 16) + rng.normal(0, 0.7, n)); r = rng.uniform(1, 4, n)
+        else:
+            az = rng.choice(np.linspace(0, 2 * np.pi, 40), n); el = np.deg2rad(rng.choice([-15, -13, 1, 15, 40], n)); r = rng.choice([0.5, 1.0, 2.0], n)
+        xyz = np.stack([r * np.cos(el) * np.sin(az), -r * np.sin(el), r * np.cos(el) * np.cos(az)], 1).astype(np.float32)
+        raw = np.concatenate([xyz, np.zeros((n, 1), np.float32)], 1)
+        with np.errstate(all="ignore"):
+            o, g = _both(oracle, raw, cols=int(rng.choice([90, 360, 1800])), segment=bool(it % 2))
+        _assert_same(o, g)
+
