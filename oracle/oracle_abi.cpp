@@ -231,6 +231,22 @@ void orc_mvs_propagate(int rows, int cols, int half_window, int step, const unsi
   EstimateDepthMapCheckerBoard(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth, seed, max_iter,
                                conf_threshold);
 }
+// single PatchMatch helpers, for the unit tests of the restatement itself
+void orc_mvs_correct_normal(const float* view_dir, float* normal) { CorrectNormal(view_dir, normal); }
+float orc_mvs_interpolate_pixel(int rows, int cols, int px, int py, int nx, int ny, float depth, const float* normal, float min_depth, float max_depth) {
+  std::vector<float> unit((size_t)rows * cols * 3);
+  const Equirectangular eq(rows, cols);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) { const float p[2] = {(float)j, (float)i}; eq.ImageToCam(p, 1.f, &unit[3 * ((size_t)i * cols + j)]); }
+  return InterpolatePixel(unit.data(), cols, px, py, nx, ny, depth, normal, min_depth, max_depth);
+}
+unsigned orc_mvs_perturb_normal(unsigned long long seed, unsigned long long pixel, const float* normal, float perturbation, float* out) {
+  MvsRng rng{seed, pixel}; PerturbNormal(rng, normal, perturbation, out); return rng.k;
+}
+unsigned orc_mvs_random_normal(unsigned long long seed, unsigned long long pixel, const float* view_ray, float* out) {
+  MvsRng rng{seed, pixel}; GenerateRandomNormal(rng, view_ray, out); return rng.k;
+}
+float orc_mvs_perturb_depth(unsigned long long seed, unsigned long long pixel, float depth, float perturbation) { MvsRng rng{seed, pixel}; return PerturbDepth(rng, depth, perturbation); }
 unsigned orc_mvs_random_u32(unsigned long long seed, unsigned long long pixel, unsigned k) { return MvsRandomU32(seed, pixel, k); }
 void orc_mvs_filter_depth(int rows, int cols, int n_neighbors, const float* const* nei_depth, const float* R_nr, const float* t_nr, const float* depth,
                           const float* conf, const unsigned char* depth_constant, float thr, float* depth_filter, float* conf_filter) {

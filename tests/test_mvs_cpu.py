@@ -260,3 +260,60 @@ def test_patchmatch_sweep_oracle_behaviour_and_device_bodies(oracle):
                               C.c_float(20.0), C.c_ulonglong(kw["seed"]), C.c_int(kw["max_iter"]), C.c_float(kw.get("conf_threshold", -1.0)))
         assert np.array_equal(d, want[0]) and np.array_equal(n, want[1]) and np.array_equal(c, want[2])
 
+
+def test_patchmatch_helpers_against_numpy(oracle):
+    """The small pieces of the sweep, one by one, against what they are meant to compute."""
+    L = oracle.lib()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rng = np.random.default_rng(2)
+    # InterpolatePixel = intersection of the pixel's view ray with the neighbour's tangent plane
+    L.orc_mvs_interpolate_pixel.restype = C.c_float
+    rows, cols = 90, 180
+    unit = lambda x, y: oracle.image_to_cam(rows, cols, np.array([[x, y]], np.float32), 1.0)[0].astype(np.float64)
+    for _ in range(50):
+        px, py = int(rng.integers(1, cols - 1)), int(rng.integers(10, rows - 10))
+        nx, ny = px + int(rng.integers(-1, 2)), py + int(rng.integers(-1, 2))
+        n = -unit(px, py) + 0.3 * rng.normal(size=3); n /= np.linalg.norm(n)
+        d = float(rng.uniform(1, 8))
+        got = L.orc_mvs_interpolate_pixel(C.c_int(rows), C.c_int(cols), C.c_int(px), C.c_int(py), C.c_int(nx), C.c_int(ny), C.c_float(d),
+                                          fp(n.astype(np.float32)), C.c_float(0.1), C.c_float(20.0))
+        want = (unit(nx, ny) * d) @ n / (unit(px, py) @ n)
+        assert abs(got - (want if 0.1 <= want <= 20 else d)) < 1e-4 * d
+        assert abs((unit(px, py) * got - unit(nx, ny) * d) @ n) < 1e-4 * d or not (0.1 <= want <= 20)     # the new point lies on the plane
+    # CorrectNormal: a normal facing away from the camera comes back to just past 90 degrees; Eigen's AngleAxis formula in float64
+    for _ in range(50):
+        v = rng.normal(size=3); v /= np.linalg.norm(v)
+        n = v * rng.uniform(0.05, 1.0) + rng.normal(size=3) * 0.5; n /= np.linalg.norm(n)
+        if n @ v < 0:
+            n = -n
+        out = n.astype(np.float32).copy()
+        L.orc_mvs_correct_normal(fp(v.astype(np.float32)), fp(out))
+        a = np.cross(n, v); rad = min((np.arccos(n @ v) - np.pi / 2) * 1.01, -0.001)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.cos(rad) * np.eye(3) + (1 - np.cos(rad)) * np.outer(a, a) + np.sin(rad) * K                 # AngleAxis::toRotationMatrix, axis as given
+        assert np.abs(out - R @ n).max() < 1e-5
+        assert out @ v < n @ v                                                                             # turned towards the camera
+    facing = -np.array([0.0, 0.6, 0.8], np.float32); keep = facing.copy()
+    L.orc_mvs_correct_normal(fp(np.array([0.0, 0.6, 0.8], np.float32)), fp(keep))
+    assert np.array_equal(keep, facing)                                                                    # already facing the camera: untouched
+    # PerturbNormal: a rotation (norm kept) by at most ~ perturbation; three draws.  PerturbDepth: inside +- perturbation
+    L.orc_mvs_perturb_depth.restype = C.c_float
+    for k in range(50):
+        n = rng.normal(size=3); n = (n / np.linalg.norm(n)).astype(np.float32)
+        out = np.zeros(3, np.float32)
+        used = L.orc_mvs_perturb_normal(C.c_ulonglong(9), C.c_ulonglong(k), fp(n), C.c_float(0.3), fp(out))
+        assert used == 3 and abs(np.linalg.norm(out) - 1) < 1e-5
+        assert np.arccos(np.clip(out @ n, -1, 1)) <= 0.3 * np.sqrt(3) / 2 + 1e-3
+        d = L.orc_mvs_perturb_depth(C.c_ulonglong(9), C.c_ulonglong(k), C.c_float(4.0), C.c_float(0.02))
+        assert 4.0 * 0.98 - 1e-5 <= d <= 4.0 * 1.02 + 1e-5
+    # GenerateRandomNormal: unit, facing the camera, spread over the hemisphere; an even number of draws (rejection sampling)
+    v = np.array([0.0, 0.0, 1.0], np.float32)
+    ns = []
+    for k in range(400):
+        out = np.zeros(3, np.float32)
+        used = L.orc_mvs_random_normal(C.c_ulonglong(4), C.c_ulonglong(k), fp(v), fp(out))
+        assert used >= 2 and used % 2 == 0 and abs(np.linalg.norm(out) - 1) < 1e-5 and out @ v <= 0
+        ns.append(out)
+    ns = np.array(ns)
+    assert abs(ns[:, 2].mean() + 0.5) < 0.06 and np.abs(ns[:, :2].mean(0)).max() < 0.1                      # uniform on the hemisphere: E[n.v] = -1/2
+
