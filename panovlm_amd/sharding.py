@@ -56,3 +56,40 @@ def pack_from_pair_blocks(blocks, ref, nei, F, ui, uj):
             Ho[lut[(n, r)]] += Hrn.T
         out[-1] += b[120]
     return out
+
+
+# ---- per-view sharding of the MVS ("Config 5 (MVS) shards per reference view") ----
+def shard_views(n_views, rank, world, cost=None):
+    """Reference views of this rank.  Views are independent (mvs/MVS.cpp:93-117: one Initialize + EstimateDepthMapSingle
+    per reference view; neighbour images are only read), so there is no exchange: every rank keeps the grey images it
+    needs and writes its own depth maps.  Without `cost` a contiguous block; with per-view costs (e.g. pixels carrying a
+    depth prior) the longest-processing-time greedy assignment, identical on every rank."""
+    if cost is None:
+        lo, hi = shard_range(n_views, rank, world)
+        return list(range(lo, hi))
+    order = sorted(range(n_views), key=lambda v: (-float(cost[v]), v))
+    load = [0.0] * world; mine = []
+    for v in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += float(cost[v])
+        if r == rank:
+            mine.append(v)
+    return sorted(mine)
+
+
+def estimate_depth_maps(worker, views, neighbors, rank=0, world=1, half_window=3, step=1, pho_iters=3, conf_threshold=-0.7, min_depth=0.1, max_depth=20.0,
+                        seed=1, cost=None):
+    """The photometric pass of MVS::EstimateDepthMaps (mvs/MVS.cpp:93-117) for this rank's views: InitConfMap, then
+    EstimateDepthMapSingle(view, CHECKER_BOARD, pho_iters, conf_threshold, false).  worker: a panovlm_amd.Context (the two
+    calls run on its GPU).  views[v] = dict(gray, depth, normal) with an initialised depth / normal hypothesis;
+    neighbors[v] = list of (neighbour view, R_nr (3x3), t_nr (3)).  Returns {view: (depth, normal, conf)}."""
+    out = {}
+    for v in shard_views(len(views), rank, world, cost):
+        nb = neighbors[v]
+        grays = [views[n]["gray"] for n, _, _ in nb]
+        R = np.array([r for _, r, _ in nb], np.float32).reshape(-1, 9); t = np.array([x for _, _, x in nb], np.float32).reshape(-1, 3)
+        conf, depth, normal = worker.mvs_init_conf_map(views[v]["gray"], grays, R, t, views[v]["depth"], views[v]["normal"], half_window, step)
+        out[v] = worker.mvs_propagate(views[v]["gray"], grays, R, t, depth, normal, conf, half_window=half_window, step=step, min_depth=min_depth,
+                                      max_depth=max_depth, seed=seed + v, max_iter=pho_iters, conf_threshold=conf_threshold)
+    return out
+

@@ -97,3 +97,76 @@ def test_sharding_covers_every_pair_once():
         ui, uj = sh.unordered_pairs(ref, nei)
         assert np.all(ui < uj) and len(set(zip(ui.tolist(), uj.tolist()))) == len(ui)
         assert set(zip(ui.tolist(), uj.tolist())) == {(min(a, b), max(a, b)) for a, b in zip(ref.tolist(), nei.tolist())}
+
+
+# ---- MVS: per-view sharding, no exchange ----------------------------------------------------------------------
+def _mvs_views(oracle, n=4, rows=48, cols=96):
+    from tests import synth
+    poses = [(synth.rodrigues(np.array([0.02 * k, 0.25 * k - 0.3, 0.01])), np.array([0.35 * k - 0.5, 0.04 * k, 0.25 * k - 0.3])) for k in range(n)]
+    rng = np.random.default_rng(3)
+    views = []
+    for R, t in poses:
+        g, d, nrm = synth.render_panorama(oracle, rows, cols, R, t)
+        views.append(dict(gray=g, depth=(d * rng.uniform(0.93, 1.07, size=d.shape)).astype(np.float32), normal=nrm))
+    nb = [[(k,) + synth.relative_pose(poses[v][0], poses[v][1], poses[k][0], poses[k][1]) for k in range(n) if k != v] for v in range(n)]
+    return views, nb
+
+
+class _OracleWorker:
+    """Stands in for panovlm_amd.Context in the CPU test of the sharding logic (the GPU calls themselves are covered by
+    tests/test_mvs_gpu.py): same two methods, backed by the oracle."""
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def mvs_init_conf_map(self, *a, **k):
+        return self.o.mvs_init_conf_map(*a, **k)
+
+    def mvs_propagate(self, *a, **k):
+        return self.o.mvs_propagate(*a, **k)
+
+
+def _mvs_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from oracle import oracle
+    from panovlm_amd import sharding as sh
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    views, nb = _mvs_views(oracle)
+    mine = sh.estimate_depth_maps(_OracleWorker(oracle), views, nb, rank, world, pho_iters=1, seed=11)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {v: d[0] for v, d in mine.items()})     # collecting the results is the only communication
+    if rank == 0:
+        q.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_mvs_view_sharding_two_ranks(oracle):
+    import torch.multiprocessing as mp
+    from panovlm_amd import sharding as sh
+    for n, world in [(4, 2), (7, 3), (3, 8)]:
+        seen = sum((sh.shard_views(n, r, world) for r in range(world)), [])
+        assert sorted(seen) == list(range(n))
+        cost = [5, 1, 1, 1, 9, 2, 2][:n]
+        parts = [sh.shard_views(n, r, world, cost) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        loads = [sum(cost[v] for v in p) for p in parts]
+        assert max(loads) <= max(max(cost), -(-sum(cost) // world) + max(cost))          # LPT bound
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mvs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    views, nb = _mvs_views(oracle)
+    single = sh.estimate_depth_maps(_OracleWorker(oracle), views, nb, 0, 1, pho_iters=1, seed=11)
+    merged = {}
+    for part in gathered:
+        assert not (set(part) & set(merged))
+        merged.update(part)
+    assert sorted(merged) == [0, 1, 2, 3] and sorted(gathered[0]) == [0, 1] and sorted(gathered[1]) == [2, 3]
+    for v in range(4):
+        assert np.array_equal(merged[v], single[v][0])                                    # a view's result does not depend on who computed it
+
