@@ -72,6 +72,7 @@ inline int VerticalAngleToScanID(float vertical_angle, int max_scan) {
 inline void ReOrderVLP(const std::vector<FPoint>& cloud, int n_scans, int horizon, ScanFeatures& f) {
   f = ScanFeatures();
   f.n_scans = n_scans; f.horizon = horizon;
+  if (n_scans <= 0 || horizon <= 0) return;   // not a range image (upstream would divide by zero / never leave the column loop)
   f.image_to_point_idx.assign((size_t)n_scans * horizon, -1);
   f.scanStartInd.assign(n_scans, 0); f.scanEndInd.assign(n_scans, 0);
   if (n_scans != 16 && n_scans != 32 && n_scans != 64) return;

@@ -115,6 +115,7 @@ void Velodyne::ReOrderVLP() {
   if (!cloud_scan.empty()) return;
   RingLayout& L = layout_;
   L = RingLayout();
+  if (N_SCANS <= 0 || horizon_scans <= 0) { fprintf(stderr, "ReOrderVLP: %d rings x %d columns is not a range image\n", N_SCANS, horizon_scans); return; }
   L.image_to_point_idx.assign((size_t)N_SCANS * horizon_scans, -1);
   L.scanStartInd.assign(N_SCANS, 0);
   L.scanEndInd.assign(N_SCANS, 0);
