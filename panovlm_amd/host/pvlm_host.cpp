@@ -11,10 +11,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <iomanip>
 #include <climits>
 #include <limits>
+#include <mutex>
 #include <sstream>
 #include <numeric>
 #include <stdexcept>
@@ -1676,13 +1678,20 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
   {
     StageTimer stage_timer_features_("feature extraction (host, scan-parallel)");
     std::atomic<size_t> next{0};
+    std::mutex failure_lock;
+    std::exception_ptr failure;          // e.g. an extraction method that is not mirrored: rethrown on the calling thread
     auto work = [&]() {
       for (size_t i = next++; i < lidars.size(); i = next++) {
         Velodyne& l = lidars[i];
         if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); continue; }
         if (!l.cloud.empty() && l.surfFlat.empty() && l.surfLessFlat.empty() && l.cornerLessSharp.empty() && !l.IsInWorldCoordinate()) {
-          l.ReOrderVLP();
-          l.ExtractFeatures(config.max_curvature, config.intersection_angle_threshold, config.extraction_method, config.lidar_segmentation);
+          try {
+            l.ReOrderVLP();
+            l.ExtractFeatures(config.max_curvature, config.intersection_angle_threshold, config.extraction_method, config.lidar_segmentation);
+          } catch (...) {
+            std::lock_guard<std::mutex> g(failure_lock);
+            if (!failure) failure = std::current_exception();
+          }
         }
       }
     };
@@ -1691,6 +1700,7 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
     for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
     work();
     for (std::thread& t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
   }
   for (Velodyne& l : lidars) {
     if (!l.valid || !l.IsPoseValid()) continue;
