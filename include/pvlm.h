@@ -333,6 +333,30 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
                                          const unsigned char* depth_constant_or_null, float depth_diff_threshold, float min_depth, float max_depth,
                                          float* depth_filter, float* conf_filter);
 
+/* Resident view set: the maps of n_views equally sized views (grey image, depth, normal, conf, depth_filter, conf_filter —
+ * the cv::Mat members of sensors/Frame.h the MVS touches) stay in HBM across the calls, so that a view's scoring pass,
+ * sweeps and fusion filter — and its use as somebody's neighbour — cost no PCIe traffic.  Same kernels and results as
+ * the per-call entry points above.  `nei` holds view indices (each != ref); R_nr / t_nr as above.
+ *   pvlm_mvs_views_estimate      max_iter < 0: MVS::InitConfMap(ref, ., use_geometry); max_iter >= 0: MVS::EstimateDepthMapSingle
+ *                                (checkerboard).  use_geometry reads the neighbours' depth_filter (the photometric depth the reference
+ *                                keeps there, mvs/MVS.cpp:470-473): pvlm_mvs_views_snapshot_depth copies depth -> depth_filter of a view.
+ *   pvlm_mvs_views_filter_refine MVS::FilterDepthImageRefine(ref): writes depth_filter / conf_filter of ref, zeroes its conf where depth <= 0.
+ * estimate / filter_refine / snapshot_depth are asynchronous on the context's stream; upload / download synchronise.
+ * NULL pointers in upload / download skip that map. */
+typedef struct pvlm_mvs_views pvlm_mvs_views;
+pvlm_status pvlm_mvs_views_create(pvlm_ctx* ctx, int rows, int cols, int n_views, pvlm_mvs_views** out);
+pvlm_status pvlm_mvs_views_destroy(pvlm_ctx* ctx, pvlm_mvs_views* views);
+pvlm_status pvlm_mvs_views_upload(pvlm_ctx* ctx, pvlm_mvs_views* views, int view, const unsigned char* gray_or_null, const float* depth_or_null,
+                                  const float* normal_or_null, const float* conf_or_null);
+pvlm_status pvlm_mvs_views_download(pvlm_ctx* ctx, pvlm_mvs_views* views, int view, float* depth_or_null, float* normal_or_null, float* conf_or_null,
+                                    float* depth_filter_or_null, float* conf_filter_or_null);
+pvlm_status pvlm_mvs_views_snapshot_depth(pvlm_ctx* ctx, pvlm_mvs_views* views, int view);
+pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* views, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
+                                    int half_window, int step, int use_geometry, const unsigned char* depth_constant_or_null, float min_depth,
+                                    float max_depth, unsigned long long seed, int max_iter, float conf_threshold);
+pvlm_status pvlm_mvs_views_filter_refine(pvlm_ctx* ctx, pvlm_mvs_views* views, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
+                                         const unsigned char* depth_constant_or_null, float depth_diff_threshold, float min_depth, float max_depth);
+
 /* Hot loop #3 of CameraLidarLineAssociate::AssociateByAngle
  * (joint_optimization/CameraLidarLineAssociate.cpp:394-426): for every image line (x1,y1,x2,y2
  * pixels, n_lines x 4 float) and every LiDAR corner point (LiDAR-local float xyz, transformed by

@@ -23,7 +23,8 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate", "pvlm_mvs_views_create", "pvlm_mvs_views_destroy", "pvlm_mvs_views_upload", "pvlm_mvs_views_download",
+    "pvlm_mvs_views_snapshot_depth", "pvlm_mvs_views_estimate", "pvlm_mvs_views_filter_refine",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
 ]
@@ -336,6 +337,68 @@ class Context:
         self._check(self.lib.pvlm_line2line_votes_batch(self._h, C.c_int(n), hr, hn, C.c_float(dist_threshold), _p(voff, C.c_int64), _p(votes, C.c_int32),
                                                         C.c_int64(len(votes))), "pvlm_line2line_votes_batch")
         return [votes[voff[p]:voff[p + 1]].reshape(neis[p].n_segments, refs[p].n_segments) for p in range(n)]
+
+
+class MvsViews:
+    """Resident set of equally sized MVS views (pvlm_mvs_views_*): maps stay on the GPU between the scoring pass, the
+    PatchMatch sweeps and the fusion filter."""
+
+    def __init__(self, ctx, rows, cols, n_views):
+        self.ctx, self.rows, self.cols, self.n = ctx, rows, cols, n_views
+        self._h = C.c_void_p()
+        ctx._check(ctx.lib.pvlm_mvs_views_create(ctx._h, C.c_int(rows), C.c_int(cols), C.c_int(n_views), C.byref(self._h)), "pvlm_mvs_views_create")
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.pvlm_mvs_views_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, view, gray=None, depth=None, normal=None, conf=None):
+        g = None if gray is None else np.ascontiguousarray(gray, np.uint8)
+        d = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        n = None if normal is None else np.ascontiguousarray(normal, np.float32)
+        c = None if conf is None else np.ascontiguousarray(conf, np.float32)
+        for a, shape in ((g, (self.rows, self.cols)), (d, (self.rows, self.cols)), (n, (self.rows, self.cols, 3)), (c, (self.rows, self.cols))):
+            assert a is None or a.shape == shape
+        self.ctx._check(self.ctx.lib.pvlm_mvs_views_upload(self.ctx._h, self._h, C.c_int(view), _p(g, C.c_ubyte), _p(d, C.c_float), _p(n, C.c_float),
+                                                           _p(c, C.c_float)), "pvlm_mvs_views_upload")
+
+    def download(self, view, what=("depth", "normal", "conf", "depth_filter", "conf_filter")):
+        out = {k: np.zeros((self.rows, self.cols, 3) if k == "normal" else (self.rows, self.cols), np.float32) for k in what}
+        ptr = lambda k: _p(out[k], C.c_float) if k in out else None
+        self.ctx._check(self.ctx.lib.pvlm_mvs_views_download(self.ctx._h, self._h, C.c_int(view), ptr("depth"), ptr("normal"), ptr("conf"), ptr("depth_filter"),
+                                                             ptr("conf_filter")), "pvlm_mvs_views_download")
+        return out
+
+    def snapshot_depth(self, view):
+        self.ctx._check(self.ctx.lib.pvlm_mvs_views_snapshot_depth(self.ctx._h, self._h, C.c_int(view)), "pvlm_mvs_views_snapshot_depth")
+
+    def _nb(self, nei, R_nr, t_nr):
+        ids = _i32(np.asarray(nei, np.int32).reshape(-1))
+        return ids, _f32(R_nr).reshape(-1), _f32(t_nr).reshape(-1)
+
+    def estimate(self, ref, nei, R_nr, t_nr, half_window=3, step=1, use_geometry=False, depth_constant=None, min_depth=0.1, max_depth=20.0, seed=1, max_iter=-1,
+                 conf_threshold=-1.0):
+        """max_iter < 0: InitConfMap; otherwise EstimateDepthMapSingle (checkerboard) with max_iter iterations."""
+        ids, R, t = self._nb(nei, R_nr, t_nr)
+        dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
+        self.ctx._check(self.ctx.lib.pvlm_mvs_views_estimate(self.ctx._h, self._h, C.c_int(ref), C.c_int(len(ids)), _p(ids, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
+                                                             C.c_int(half_window), C.c_int(step), C.c_int(1 if use_geometry else 0), _p(dc, C.c_ubyte),
+                                                             C.c_float(min_depth), C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter),
+                                                             C.c_float(conf_threshold)), "pvlm_mvs_views_estimate")
+
+    def filter_refine(self, ref, nei, R_nr, t_nr, depth_constant=None, thr=0.01, min_depth=0.1, max_depth=20.0):
+        ids, R, t = self._nb(nei, R_nr, t_nr)
+        dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
+        self.ctx._check(self.ctx.lib.pvlm_mvs_views_filter_refine(self.ctx._h, self._h, C.c_int(ref), C.c_int(len(ids)), _p(ids, C.c_int), _p(R, C.c_float),
+                                                                  _p(t, C.c_float), _p(dc, C.c_ubyte), C.c_float(thr), C.c_float(min_depth),
+                                                                  C.c_float(max_depth)), "pvlm_mvs_views_filter_refine")
 
 
 class ResidualSet:

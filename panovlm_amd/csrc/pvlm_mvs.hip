@@ -418,4 +418,187 @@ pvlm_status pvlm_mvs_propagate(pvlm_ctx* ctx, int rows, int cols, int half_windo
                  depth_constant, min_depth, max_depth, seed, max_iter, conf_threshold);
 }
 
+
+// ---- resident view set: the same kernels with the maps kept in HBM between the scoring pass, the sweeps and the
+// fusion filter (the per-call entry points above move 30-50 MB over PCIe per call, which is most of their wall time) ----
+struct pvlm_mvs_views {
+  int rows = 0, cols = 0, n = 0;
+  size_t npix = 0;
+  unsigned char* d_gray = nullptr;                      // n x npix
+  float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_depth_filter = nullptr, *d_conf_filter = nullptr;   // n x npix (normal: x 3)
+  float* d_unit = nullptr;                              // npix x 3 (PreComputeI2C)
+  unsigned long long* d_key = nullptr;                  // 16 x npix splat keys (fusion filter scratch)
+  unsigned char* d_const = nullptr;                     // npix (depth_constant of the view being processed)
+};
+
+static bool views_ids_ok(const pvlm_mvs_views* v, int ref, int n_neighbors, const int* nei) {
+  if (!v || ref < 0 || ref >= v->n || n_neighbors < 0 || n_neighbors > 16 || (n_neighbors > 0 && !nei)) return false;
+  for (int b = 0; b < n_neighbors; ++b) if (nei[b] < 0 || nei[b] >= v->n || nei[b] == ref) return false;
+  return true;
+}
+
+pvlm_status pvlm_mvs_views_destroy(pvlm_ctx* ctx, pvlm_mvs_views* v) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (!v) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipStreamSynchronize(ctx->stream);
+  hipFree(v->d_gray); hipFree(v->d_depth); hipFree(v->d_normal); hipFree(v->d_conf); hipFree(v->d_depth_filter); hipFree(v->d_conf_filter);
+  hipFree(v->d_unit); hipFree(v->d_key); hipFree(v->d_const);
+  delete v;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_mvs_views_create(pvlm_ctx* ctx, int rows, int cols, int n_views, pvlm_mvs_views** out) {
+  if (!ctx || !out || rows <= 0 || cols <= 0 || n_views <= 0 || (size_t)rows * cols > 0xffffffffull) return PVLM_ERR_ARG;
+  *out = nullptr;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_mvs_views* v = new pvlm_mvs_views();
+  v->rows = rows; v->cols = cols; v->n = n_views; v->npix = (size_t)rows * cols;
+  const size_t all = v->npix * (size_t)n_views;
+  pvlm_status st = pvlm_i_alloc(ctx, &v->d_gray, all);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_depth, all);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_normal, all * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_conf, all);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_depth_filter, all);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_conf_filter, all);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_unit, v->npix * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_key, v->npix * 16);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_const, v->npix);
+  if (!st) {
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemsetAsync(v->d_gray, 0, all, s);
+    float* zero[5] = {v->d_depth, v->d_conf, v->d_depth_filter, v->d_conf_filter, v->d_normal};
+    for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipMemsetAsync(zero[k], 0, all * sizeof(float) * (k == 4 ? 3 : 1), s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, s, rows, cols, v->d_unit); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_create: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  if (st) { pvlm_mvs_views_destroy(ctx, v); return st; }
+  *out = v;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_mvs_views_upload(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, const unsigned char* gray, const float* depth, const float* normal,
+                                  const float* conf) {
+  if (!ctx || !v || view < 0 || view >= v->n) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipStream_t s = ctx->stream;
+  const size_t o = v->npix * (size_t)view;
+  hipError_t e = hipSuccess;
+  if (gray) e = hipMemcpyAsync(v->d_gray + o, gray, v->npix, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && depth) e = hipMemcpyAsync(v->d_depth + o, depth, v->npix * sizeof(float), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && normal) e = hipMemcpyAsync(v->d_normal + 3 * o, normal, v->npix * 3 * sizeof(float), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && conf) e = hipMemcpyAsync(v->d_conf + o, conf, v->npix * sizeof(float), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_upload: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_mvs_views_download(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, float* depth, float* normal, float* conf, float* depth_filter,
+                                    float* conf_filter) {
+  if (!ctx || !v || view < 0 || view >= v->n) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipStream_t s = ctx->stream;
+  const size_t o = v->npix * (size_t)view, bytes = v->npix * sizeof(float);
+  hipError_t e = hipSuccess;
+  if (depth) e = hipMemcpyAsync(depth, v->d_depth + o, bytes, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && normal) e = hipMemcpyAsync(normal, v->d_normal + 3 * o, 3 * bytes, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && conf) e = hipMemcpyAsync(conf, v->d_conf + o, bytes, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && depth_filter) e = hipMemcpyAsync(depth_filter, v->d_depth_filter + o, bytes, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && conf_filter) e = hipMemcpyAsync(conf_filter, v->d_conf_filter + o, bytes, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_download: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_mvs_views_snapshot_depth(pvlm_ctx* ctx, pvlm_mvs_views* v, int view) {
+  if (!ctx || !v || view < 0 || view >= v->n) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t o = v->npix * (size_t)view;
+  hipError_t e = hipMemcpyAsync(v->d_depth_filter + o, v->d_depth + o, v->npix * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_snapshot_depth: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
+static void views_neighbours(const pvlm_mvs_views* v, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr, bool geometry, pvlm_mvs_neighbours& nb) {
+  nb.n = n_neighbors; nb.geometric = geometry ? 1 : 0;
+  for (int b = 0; b < n_neighbors; ++b) {
+    nb.gray[b] = v->d_gray + v->npix * (size_t)nei[b];
+    nb.depth[b] = geometry ? v->d_depth_filter + v->npix * (size_t)nei[b] : nullptr;
+    for (int k = 0; k < 9; ++k) nb.R[b][k] = R_nr[9 * b + k];
+    for (int k = 0; k < 3; ++k) nb.t[b][k] = t_nr[3 * b + k];
+  }
+}
+
+// the scoring pass (max_iter < 0) or the PatchMatch sweep of view `ref` against resident neighbours; asynchronous on ctx->stream
+pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
+                                    int half_window, int step, int use_geometry, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                    unsigned long long seed, int max_iter, float conf_threshold) {
+  if (!ctx || !views_ids_ok(v, ref, n_neighbors, nei) || half_window < 1 || step < 1 || (n_neighbors > 0 && (!R_nr || !t_nr))) return PVLM_ERR_ARG;
+  if (pvlm_mvs::num_texels(half_window, step) > 64 * PVLM_MVS_MAXM) { PVLM_SET_ERR(ctx, "NCC window of %d texels exceeds %d", pvlm_mvs::num_texels(half_window, step), 64 * PVLM_MVS_MAXM); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipStream_t s = ctx->stream;
+  pvlm_mvs_neighbours nb;
+  views_neighbours(v, n_neighbors, nei, R_nr, t_nr, use_geometry != 0, nb);
+  const size_t o = v->npix * (size_t)ref;
+  hipError_t e = hipSuccess;
+  if (depth_constant) { e = hipMemcpyAsync(v->d_const, depth_constant, v->npix, hipMemcpyHostToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s); }
+  unsigned char* d_const = depth_constant ? v->d_const : nullptr;
+  if (e == hipSuccess) {
+    if (max_iter < 0) {
+      pvlm_prof_scope prof(ctx, 1);
+      hipLaunchKernelGGL(k_mvs_conf, dim3((unsigned)((v->npix + 3) / 4)), dim3(256), 0, s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o,
+                         v->d_normal + 3 * o, v->d_conf + o);
+    } else {
+      const size_t waves = (size_t)v->rows * (size_t)((v->cols + 1) / 2);
+      for (int iter = 0; iter < max_iter; ++iter)
+        for (int offset = 0; offset <= 1; ++offset) {
+          pvlm_prof_scope prof(ctx, 1);
+          hipLaunchKernelGGL(k_mvs_propagate, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb,
+                             v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o, d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
+        }
+      hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, s, (long long)v->npix, d_const, conf_threshold, v->d_depth + o,
+                         v->d_normal + 3 * o, v->d_conf + o);
+    }
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_estimate: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
+// FilterDepthImageRefine of view `ref`: reads depth / conf of the neighbours, writes depth_filter / conf_filter of ref and zeroes
+// conf of ref where depth <= 0 (in place, as upstream); asynchronous on ctx->stream
+pvlm_status pvlm_mvs_views_filter_refine(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
+                                         const unsigned char* depth_constant, float depth_diff_threshold, float min_depth, float max_depth) {
+  if (!ctx || !views_ids_ok(v, ref, n_neighbors, nei) || (n_neighbors > 0 && (!R_nr || !t_nr))) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipStream_t s = ctx->stream;
+  const size_t npix = v->npix, o = npix * (size_t)ref;
+  const unsigned grid = (unsigned)((npix + 255) / 256);
+  hipError_t e = hipSuccess;
+  if (depth_constant) { e = hipMemcpyAsync(v->d_const, depth_constant, npix, hipMemcpyHostToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s); }
+  if (e == hipSuccess && n_neighbors > 0) {
+    hipLaunchKernelGGL(k_mvs_fill_u64, dim3((unsigned)((npix * n_neighbors + 255) / 256)), dim3(256), 0, s, (long long)(npix * n_neighbors), ~0ull, v->d_key);
+    e = hipGetLastError();
+  }
+  pvlm_mvs::RefineViews nv;
+  nv.n = n_neighbors;
+  for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
+    pvlm_mvs_pose pose;
+    pvlm_mvs::inverse_pose(R_nr + 9 * b, t_nr + 3 * b, pose.R_rn, pose.t_rn);
+    nv.conf[b] = v->d_conf + npix * (size_t)nei[b];
+    for (int k = 0; k < 9; ++k) nv.R[b][k] = R_nr[9 * b + k];
+    for (int k = 0; k < 3; ++k) nv.t[b][k] = t_nr[3 * b + k];
+    hipLaunchKernelGGL(k_mvs_project_conf, dim3(grid), dim3(256), 0, s, v->rows, v->cols, v->d_unit, v->d_depth + npix * (size_t)nei[b], pose, v->d_key + npix * (size_t)b);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_mvs_refine, dim3(grid), dim3(256), 0, s, v->rows, v->cols, nv, v->d_key, v->d_unit, v->d_depth + o, v->d_conf + o,
+                       depth_constant ? v->d_const : nullptr, depth_diff_threshold, min_depth, max_depth, v->d_depth_filter + o, v->d_conf_filter + o);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_filter_refine: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
 }  // extern "C"

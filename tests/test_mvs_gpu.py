@@ -132,3 +132,57 @@ def test_patchmatch_sweep_matches_oracle(ctx, oracle):
     d3 = ctx.mvs_propagate(*args, max_iter=3, seed=5)[0]
     assert err(d3) < 0.3 * err(S["depth"])
 
+
+def test_resident_views_equal_the_per_call_entry_points(ctx, oracle):
+    """pvlm_mvs_views_*: the same kernels on maps that stay in HBM — every stage must equal the per-call API bit for bit
+    (scoring pass, sweep incl. geometric consistency / depth_constant / threshold, fusion filter with its in-place conf)."""
+    import time
+    from panovlm_amd.api import MvsViews
+    from tests.test_mvs_cpu import sweep_scene
+    S = sweep_scene(oracle)
+    rows, cols = S["depth"].shape
+    nei = [0, 2, 3]; ref = 1                                       # view ids of the scene: the reference is view 1
+    V = MvsViews(ctx, rows, cols, 4)
+    rng = np.random.default_rng(8)
+    nconf = [rng.uniform(0, 1, size=(rows, cols)).astype(np.float32) for _ in nei]
+    nnormal = np.zeros((rows, cols, 3), np.float32)
+    for k, b in enumerate(nei):                                    # neighbours: grey image, their own depth map and confidence
+        V.upload(b, gray=S["neis"][k], depth=S["nd"][k], normal=nnormal, conf=nconf[k])
+        V.snapshot_depth(b)                                        # depth_filter <- depth: what use_geometry reads
+    # ---- scoring pass (InitConfMap), photometric then geometric
+    d0 = (S["truth"] * np.random.default_rng(7).uniform(0.9, 1.1, size=S["truth"].shape)).astype(np.float32)
+    for geo in (False, True):
+        V.upload(ref, gray=S["gray"], depth=d0, normal=S["normal"], conf=np.zeros((rows, cols), np.float32))
+        V.estimate(ref, nei, S["Rn"], S["tn"], use_geometry=geo, max_iter=-1)
+        got = V.download(ref, ("depth", "normal", "conf"))
+        c, d, n = ctx.mvs_init_conf_map(S["gray"], S["neis"], S["Rn"], S["tn"], d0, S["normal"], 3, 1, nei_depths=S["nd"] if geo else None)
+        assert np.array_equal(got["conf"], c) and np.array_equal(got["depth"], d) and np.array_equal(got["normal"], n)
+    # ---- sweep
+    for kw in (dict(max_iter=2, seed=5), dict(max_iter=1, seed=9, use_geometry=True, depth_constant=S["const"], conf_threshold=0.9)):
+        V.upload(ref, depth=S["depth"], normal=S["normal"], conf=S["conf"])
+        V.estimate(ref, nei, S["Rn"], S["tn"], **kw)
+        got = V.download(ref, ("depth", "normal", "conf"))
+        pk = dict(kw); geo = pk.pop("use_geometry", False)
+        want = ctx.mvs_propagate(S["gray"], S["neis"], S["Rn"], S["tn"], S["depth"], S["normal"], S["conf"], nei_depths=S["nd"] if geo else None, **pk)
+        assert np.array_equal(got["depth"], want[0]) and np.array_equal(got["normal"], want[1]) and np.array_equal(got["conf"], want[2])
+    # ---- fusion filter on the swept state (still resident), with and without depth_constant
+    swept = V.download(ref, ("depth", "conf"))
+    cref = np.clip(swept["conf"], 0, None)
+    for kw in (dict(thr=0.02), dict(thr=0.01, depth_constant=S["const"], max_depth=float(np.median(swept["depth"][swept["depth"] > 0])))):
+        V.upload(ref, conf=cref)
+        V.filter_refine(ref, nei, S["Rn"], S["tn"], **kw)
+        got = V.download(ref, ("conf", "depth_filter", "conf_filter"))
+        dw, cw, ca = ctx.mvs_filter_depth_refine(S["nd"], nconf, S["Rn"], S["tn"], swept["depth"], cref, **kw)
+        assert np.array_equal(got["depth_filter"], dw) and np.array_equal(got["conf_filter"], cw) and np.array_equal(got["conf"], ca)
+        assert 0.02 < (dw > 0).mean() < 0.98
+    # ---- bad arguments are refused, not executed
+    import panovlm_amd as pv
+    for bad in (dict(ref=1, nei=[1, 2]), dict(ref=4, nei=[0]), dict(ref=0, nei=[7])):
+        with pytest.raises(pv.PvlmError):
+            V.estimate(bad["ref"], bad["nei"], S["Rn"][:len(bad["nei"])], S["tn"][:len(bad["nei"])])
+    # what residency buys at this size: wall time of one sweep iteration, maps in HBM vs the per-call entry point
+    t0 = time.perf_counter(); V.estimate(ref, nei, S["Rn"], S["tn"], max_iter=1, seed=3); V.download(ref, ("conf",)); t_res = time.perf_counter() - t0
+    t0 = time.perf_counter(); ctx.mvs_propagate(S["gray"], S["neis"], S["Rn"], S["tn"], S["depth"], S["normal"], S["conf"], max_iter=1, seed=3); t_call = time.perf_counter() - t0
+    print("resident %.2f ms, per call %.2f ms" % (t_res * 1e3, t_call * 1e3))
+    V.close()
+
