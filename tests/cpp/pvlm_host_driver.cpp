@@ -350,11 +350,16 @@ int main(int argc, char** argv) {
       // raw.bin: int32 n, n x 4 float.  out.bin: int32 valid, then blocks [int32 count, payload]: cloud_scan, cornerSharp,
       // cornerLessSharp, surfFlat, surfLessFlat (count x 4 float each); rc (count x 2 int32); scan_start, scan_end (n_scans int32);
       // range_image (n_scans * horizon float); image_to_point_idx (same, int32); curvature (float), state, sort_ind, left, right (int32)
-      std::ifstream f(argv[2], std::ios::binary);
-      int32_t n = 0; rd(f, &n, 1);
       Velodyne v; v.id = 3;
-      v.cloud.resize(n);
-      for (auto& p : v.cloud) rd(f, &p.x, 4);
+      const std::string in = argv[2];
+      if (in.size() > 4 && in.substr(in.size() - 4) == ".pcd") {          // the scan as it lies on disk: LoadLidar first
+        if (!v.LoadLidar(in)) return 4;
+      } else {
+        std::ifstream f(in, std::ios::binary);
+        int32_t n = 0; rd(f, &n, 1);
+        v.cloud.resize(n);
+        for (auto& p : v.cloud) rd(f, &p.x, 4);
+      }
       v.N_SCANS = atoi(argv[4]); v.horizon_scans = atoi(argv[5]);
       v.ReOrderVLP();
       ExtractionTrace tr;

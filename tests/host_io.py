@@ -87,11 +87,15 @@ def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_
     """Velodyne::ReOrderVLP (+ ExtractFeatures) of the host mirror on one raw scan (n x 4 float32) through the test driver.
     Returns a dict with the same fields as oracle.ScanFeatures."""
     import tempfile
-    raw = np.ascontiguousarray(raw, np.float32).reshape(-1, 4)
     with tempfile.TemporaryDirectory() as d:
-        src, dst = os.path.join(d, "raw.bin"), os.path.join(d, "out.bin")
-        with open(src, "wb") as f:
-            f.write(struct.pack("<i", len(raw))); f.write(raw.tobytes())
+        dst = os.path.join(d, "out.bin")
+        if isinstance(raw, str):                       # a .pcd file: the driver goes through Velodyne::LoadLidar
+            src = raw
+        else:
+            raw = np.ascontiguousarray(raw, np.float32).reshape(-1, 4)
+            src = os.path.join(d, "raw.bin")
+            with open(src, "wb") as f:
+                f.write(struct.pack("<i", len(raw))); f.write(raw.tobytes())
         log = run("features", src, dst, str(n_scans), str(horizon), repr(float(max_curvature)), repr(float(angle_threshold)), "1" if segment else "0",
                   "1" if extract else "0")
         buf = open(dst, "rb").read()

@@ -213,3 +213,22 @@ def test_fuzz_unstructured_clouds(oracle):
             o, g = _both(oracle, raw, cols=int(rng.choice([90, 360, 1800])), segment=bool(it % 2))
         _assert_same(o, g)
 
+
+def test_pcd_file_to_features(oracle, tmp_path):
+    """A scan as it lies on disk (binary .pcd, sensor axes x right / y forward / z up, with NaN returns and returns
+    closer than 0.5 m) -> Velodyne::LoadLidar -> ReOrderVLP -> ExtractFeatures, against the oracle fed with what LoadLidar
+    must produce (sensors/Velodyne.cpp:92-168: NaN and near points dropped, axes swapped to x, -z, y)."""
+    raw = sy.raw_vlp16_scan(13, clutter=20)
+    lidar = np.stack([raw[:, 0], raw[:, 2], -raw[:, 1], raw[:, 3]], axis=1).astype(np.float32)        # camera-style (x, y, z) = (x_l, -z_l, y_l)
+    rec = np.concatenate([lidar, np.float32([[np.nan, 1, 1, 0], [0.1, 0.2, 0.1, 5]])])              # one invalid, one too close
+    rec = np.concatenate([rec[:100], rec[-2:], rec[100:-2]]).astype(np.float32)
+    path = os.path.join(str(tmp_path), "scan.pcd")
+    hdr = "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n" \
+          "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n" % (len(rec), len(rec))
+    with open(path, "wb") as f:
+        f.write(hdr.encode()); f.write(rec.tobytes())
+    g = host_io.extract_features(path)
+    o = oracle.ScanFeatures(raw)
+    _assert_same(o, g)
+    assert len(g["surfFlat"]) == 384 and len(g["cloud_scan"]) > 20000
+
