@@ -649,6 +649,19 @@ bool ReadPcd(const std::string& path, PointCloud& cloud) {
   }
   if (ix < 0 || iy < 0 || iz < 0) return false;
   for (int k : {ix, iy, iz}) if (fields[k].type != 'F' || fields[k].size != 4) return false;   // PointXYZI: float32 coordinates
+  for (const PcdField& fd : fields) if (fd.size <= 0 || fd.size > 8 || fd.count <= 0 || fd.count > 4096) return false;
+  // a header must not make us allocate more than the file can hold (corrupt / hostile POINTS, WIDTH x HEIGHT)
+  const std::streampos body = f.tellg();
+  f.seekg(0, std::ios::end);
+  const size_t remaining = body < 0 ? 0 : (size_t)(f.tellg() - body);
+  f.seekg(body);
+  if (stride == 0) return false;
+  if (data_mode == "ascii" && points > remaining) return false;                         // >= 1 byte per point
+  else if (data_mode == "binary" && points > remaining / stride) return false;
+  else if (data_mode == "binary_compressed") {
+    if (remaining < 8 || points > 0xffffffffull / stride) return false;                 // the block length is a uint32
+    if (points * stride / 100 > remaining) return false;                                // LZF expands at most 264 bytes per 3
+  } else if (data_mode != "ascii" && data_mode != "binary") return false;
   cloud.assign(points, PointXYZI{0, 0, 0, 0});
   auto as_float = [](const PcdField& fd, const unsigned char* p) -> float {
     if (fd.type == 'F' && fd.size == 4) { float v; std::memcpy(&v, p, 4); return v; }
@@ -689,7 +702,7 @@ bool ReadPcd(const std::string& path, PointCloud& cloud) {
   if (data_mode == "binary_compressed") {
     uint32_t csize = 0, usize = 0;
     f.read(reinterpret_cast<char*>(&csize), 4); f.read(reinterpret_cast<char*>(&usize), 4);
-    if (!f || usize != points * stride) return false;
+    if (!f || usize != points * stride || remaining < 8 || csize > remaining - 8) return false;
     std::vector<unsigned char> comp(csize);
     f.read(reinterpret_cast<char*>(comp.data()), csize);
     if ((size_t)f.gcount() != csize) return false;

@@ -165,3 +165,43 @@ def test_point2line_segment_mirror_matches_oracle():
     assert len(got) == len(o["point"]) > 50
     assert np.allclose(got[:, :3], o["point"], rtol=0, atol=1e-12) and np.allclose(got[:, 3:6], o["a"], rtol=0, atol=1e-12)
     assert np.allclose(got[:, 6:9], o["b"], rtol=0, atol=1e-12)
+
+
+def test_pcd_reader_refuses_corrupt_files():
+    """Velodyne::LoadLidar on truncated / inconsistent / hostile .pcd files: refused quickly (the reference logs and returns
+    false, sensors/Velodyne.cpp:100-104), never a crash, a hang or an allocation the file cannot back."""
+    import struct
+    import subprocess
+    rng = np.random.default_rng(0)
+    n = 5000
+    pts = (rng.normal(size=(n, 4)) * 3).astype(np.float32)
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+           "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n")
+    good = (hdr % (n, n, "binary")).encode() + pts.tobytes()
+    bad = {
+        "truncated_body": good[:len(good) // 2], "truncated_header": good[:60],
+        "huge_points": (hdr % (n, 2 ** 31 - 1, "binary")).encode() + pts.tobytes(),
+        "negative_points": (hdr % (n, -5, "binary")).encode() + pts.tobytes(),
+        "bad_data_kw": (hdr % (n, n, "weird")).encode() + pts.tobytes(),
+        "compressed_garbage": (hdr % (n, n, "binary_compressed")).encode() + struct.pack("<II", 100, n * 16) + bytes(rng.integers(0, 256, 100, dtype=np.uint8)),
+        "compressed_sizes_lie": (hdr % (n, n, "binary_compressed")).encode() + struct.pack("<II", 2 ** 31, 2 ** 31) + b"abc",
+        "compressed_huge_points": (hdr % (n, 2 ** 28 - 1, "binary_compressed")).encode() + struct.pack("<II", 3, (2 ** 28 - 1) * 16) + b"abc",
+        "ascii_short_rows": (hdr % (n, n, "ascii")).encode() + b"1 2\n3 4 5 6\nfoo bar baz qux\n",
+        "ascii_huge_points": (hdr % (n, 2 ** 40, "ascii")).encode() + b"1 2 3 4\n",
+        "size8_coordinates": good.replace(b"SIZE 4 4 4 4", b"SIZE 8 8 8 8"), "size0_field": good.replace(b"SIZE 4 4 4 4", b"SIZE 4 4 4 0"),
+        "count_huge": good.replace(b"COUNT 1 1 1 1", b"COUNT 1 1 1 99999999"), "no_xyz": good.replace(b"FIELDS x y z intensity", b"FIELDS a b c d"),
+        "random_bytes": bytes(rng.integers(0, 256, 4096, dtype=np.uint8)), "empty": b"",
+    }
+    drv = host_io.driver()
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "good.pcd")
+        open(p, "wb").write(good)
+        out = subprocess.run([drv, "loadpcd", p], capture_output=True, timeout=30).stdout.decode().split("\n")[0].split()
+        assert out[1] == "1" and int(out[5]) > 4900
+        for name, data in bad.items():
+            p = os.path.join(d, name + ".pcd")
+            open(p, "wb").write(data)
+            r = subprocess.run([drv, "loadpcd", p], capture_output=True, timeout=30)
+            head = r.stdout.decode(errors="ignore").split("\n")[0].split()
+            assert r.returncode == 0 and head[:2] == ["loaded", "0"] and head[5] == "0", (name, r.returncode, head)
+
