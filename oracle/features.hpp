@@ -53,6 +53,7 @@ inline float PointDistanceSquare(const FPoint& a, const FPoint& b) { return FSqu
 
 // sensors/Velodyne.cpp:170-211
 inline int VerticalAngleToScanID(float vertical_angle, int max_scan) {
+  if (!(vertical_angle == vertical_angle)) return -1;   // NaN (point at the origin): int(NaN) is undefined upstream; on x86-64 it comes out negative = rejected
   int scanID = -1;
   if (max_scan == 16) {
     scanID = int((vertical_angle + 15) / 2 + 0.5);

@@ -30,6 +30,7 @@ inline float Dist2(const PointXYZI& a, const PointXYZI& b) {   // base/Geometry.
 
 // sensors/Velodyne.cpp:170-211
 int RingOfElevation(float deg, int rings) {
+  if (!(deg == deg)) return -1;   // a return at the sensor origin has no elevation (upstream converts the NaN to int: undefined, negative in practice)
   int id = -1;
   if (rings == 16) {
     id = int((deg + 15) / 2 + 0.5);
