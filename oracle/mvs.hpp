@@ -602,4 +602,56 @@ inline void EstimateDepthMapCheckerBoard(const MvsView& ref, int n_neighbors, co
     }
 }
 
+
+// MVS::SelectNeighborKNN (mvs/MVS.cpp:334-382).  valid[i], R_wc (9, row-major), t_wc (3) per frame.  Output: for every frame the
+// list of (neighbour id, R_nr float 9, t_nr float 3).  KdTreeFLANN::nearestKSearch restated as a brute-force sorted float32
+// search (ties by index); T_nr = T_wn^-1 * T_wr through the general 4x4 inverse like upstream (Gauss-Jordan with partial
+// pivoting here; Eigen uses a cofactor expansion [recalled] — both exact to ~1e-16 for a rigid transform).
+struct MvsNeighbor { int id; float R_nr[9]; float t_nr[3]; };
+inline void Inverse4(const double* A, double* out) {
+  double M[4][8];
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { M[r][c] = A[4 * r + c]; M[r][4 + c] = r == c ? 1.0 : 0.0; }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r) if (std::abs(M[r][col]) > std::abs(M[piv][col])) piv = r;
+    for (int c = 0; c < 8; ++c) std::swap(M[col][c], M[piv][c]);
+    const double inv = 1.0 / M[col][col];
+    for (int c = 0; c < 8; ++c) M[col][c] *= inv;
+    for (int r = 0; r < 4; ++r) if (r != col) { const double f = M[r][col]; for (int c = 0; c < 8; ++c) M[r][c] -= f * M[col][c]; }
+  }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = M[r][4 + c];
+}
+inline std::vector<std::vector<MvsNeighbor>> SelectNeighborKNN(int n, const int* valid, const double* R_wc, const double* t_wc, int neighbor_size, float sq_distance_threshold) {
+  std::vector<std::vector<MvsNeighbor>> neighbors(n);
+  std::vector<int> owner;
+  for (int i = 0; i < n; ++i) if (valid[i]) owner.push_back(i);
+  auto pose = [&](int i, double* T) {
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[4 * r + c] = R_wc[9 * i + 3 * r + c]; T[4 * r + 3] = t_wc[3 * i + r]; }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+  };
+  for (int ref = 0; ref < n; ++ref) {
+    if (!valid[ref]) continue;
+    const float q[3] = {(float)t_wc[3 * ref], (float)t_wc[3 * ref + 1], (float)t_wc[3 * ref + 2]};
+    std::vector<std::pair<float, int>> cand;
+    for (int j : owner) {
+      const float c[3] = {(float)t_wc[3 * j], (float)t_wc[3 * j + 1], (float)t_wc[3 * j + 2]};
+      float sq = 0; for (int m = 0; m < 3; ++m) { const float diff = q[m] - c[m]; sq += diff * diff; }
+      cand.push_back({sq, j});
+    }
+    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+    if ((int)cand.size() > neighbor_size * 3) cand.resize(neighbor_size * 3);
+    for (size_t i = 1; i < cand.size() && (int)neighbors[ref].size() < neighbor_size; ++i) {
+      if (cand[i].first < sq_distance_threshold) continue;
+      double Tn[16], Tr[16], Tni[16], T[16];
+      pose(cand[i].second, Tn); pose(ref, Tr);
+      Inverse4(Tn, Tni);
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { double acc = 0; for (int m = 0; m < 4; ++m) acc += Tni[4 * r + m] * Tr[4 * m + c]; T[4 * r + c] = acc; }
+      MvsNeighbor nb; nb.id = cand[i].second;
+      for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) nb.R_nr[3 * r + c] = (float)T[4 * r + c]; nb.t_nr[r] = (float)T[4 * r + 3]; }
+      neighbors[ref].push_back(nb);
+    }
+  }
+  return neighbors;
+}
+
 }  // namespace oracle

@@ -334,6 +334,16 @@ def mvs_propagate(ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_win
     return d, nrm, c
 
 
+def mvs_select_neighbors(valid, R_wc, t_wc, neighbor_size, sq_distance_threshold):
+    """MVS::SelectNeighborKNN (mvs/MVS.cpp:334-382): (ids n x k with -1 padding, R_nr n x k x 9 float32, t_nr n x k x 3 float32)."""
+    v = _i32(np.asarray(valid, np.int32)); n = len(v)
+    R = _f64(R_wc).reshape(-1); t = _f64(t_wc).reshape(-1)
+    ids = np.full((n, neighbor_size), -1, np.int32); oR = np.zeros((n, neighbor_size, 9), np.float32); ot = np.zeros((n, neighbor_size, 3), np.float32)
+    lib().orc_mvs_select_neighbors(C.c_int(n), _p(v, C.c_int), _p(R, C.c_double), _p(t, C.c_double), C.c_int(neighbor_size), C.c_float(sq_distance_threshold),
+                                   _p(ids, C.c_int), _p(oR, C.c_float), _p(ot, C.c_float))
+    return ids, oR, ot
+
+
 def mvs_filter_depth(nei_depths, R_nr, t_nr, depth, conf=None, depth_constant=None, thr=0.01):
     """FilterDepthImage (mvs/MVS.cpp:1735-1790) with ProjectDepthConfToRef (:2011-2070): returns (depth_filter, conf_filter)."""
     d = np.ascontiguousarray(depth, np.float32); rows, cols = d.shape

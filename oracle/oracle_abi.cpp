@@ -231,6 +231,17 @@ void orc_mvs_propagate(int rows, int cols, int half_window, int step, const unsi
   EstimateDepthMapCheckerBoard(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth, seed, max_iter,
                                conf_threshold);
 }
+// MVS::SelectNeighborKNN: out_id (n x neighbor_size, -1 = none), out_R (n x neighbor_size x 9), out_t (n x neighbor_size x 3)
+void orc_mvs_select_neighbors(int n, const int* valid, const double* R_wc, const double* t_wc, int neighbor_size, float sq_distance_threshold, int* out_id,
+                              float* out_R, float* out_t) {
+  const auto nb = SelectNeighborKNN(n, valid, R_wc, t_wc, neighbor_size, sq_distance_threshold);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < neighbor_size; ++k) {
+      const size_t o = (size_t)i * neighbor_size + k;
+      out_id[o] = k < (int)nb[i].size() ? nb[i][k].id : -1;
+      if (k < (int)nb[i].size()) { std::memcpy(out_R + 9 * o, nb[i][k].R_nr, 36); std::memcpy(out_t + 3 * o, nb[i][k].t_nr, 12); }
+    }
+}
 // single PatchMatch helpers, for the unit tests of the restatement itself
 void orc_mvs_correct_normal(const float* view_dir, float* normal) { CorrectNormal(view_dir, normal); }
 float orc_mvs_interpolate_pixel(int rows, int cols, int px, int py, int nx, int ny, float depth, const float* normal, float min_depth, float max_depth) {

@@ -1733,6 +1733,52 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
   return true;
 }
 
+// ================================================================================================
+// MVS::SelectNeighborKNN — mvs/MVS.cpp:334-382
+// ================================================================================================
+std::vector<std::vector<NeighborInfo>> SelectNeighborKNN(const std::vector<Frame>& frames, int neighbor_size, float sq_distance_threshold) {
+  std::vector<std::vector<NeighborInfo>> neighbors(frames.size());
+  std::vector<std::array<float, 3>> center;
+  std::vector<size_t> owner;
+  for (size_t i = 0; i < frames.size(); ++i) {
+    if (!frames[i].IsPoseValid()) continue;
+    center.push_back({(float)frames[i].t_wc[0], (float)frames[i].t_wc[1], (float)frames[i].t_wc[2]});
+    owner.push_back(i);
+  }
+  const int nc = (int)owner.size(), k = std::min(neighbor_size * 3, nc);
+  for (size_t ref = 0; ref < frames.size(); ++ref) {
+    if (!frames[ref].IsPoseValid()) continue;
+    const Frame& fr = frames[ref];
+    const float q[3] = {(float)fr.t_wc[0], (float)fr.t_wc[1], (float)fr.t_wc[2]};
+    std::vector<std::pair<float, int>> d(nc);
+    for (int j = 0; j < nc; ++j) {
+      const float dx = q[0] - center[j][0], dy = q[1] - center[j][1], dz = q[2] - center[j][2];
+      float sq = 0.0f; sq += dx * dx; sq += dy * dy; sq += dz * dz;
+      d[j] = {sq, j};
+    }
+    std::stable_sort(d.begin(), d.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+    for (int i = 1; i < k && (int)neighbors[ref].size() < neighbor_size; ++i) {    // i = 0: "the nearest one is always the view itself"
+      if (d[i].first < sq_distance_threshold) continue;                             // too close: the baseline would be too short
+      const Frame& fn = frames[owner[d[i].second]];
+      NeighborInfo info;
+      info.id = owner[d[i].second];
+      // T_nr = T_wn^-1 T_wr:  R_nr = R_wn^T R_wr,  t_nr = R_wn^T (t_wr - t_wn)
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+          double acc = 0;
+          for (int m = 0; m < 3; ++m) acc += fn.R_wc[3 * m + r] * fr.R_wc[3 * m + c];
+          info.R_nr[3 * r + c] = (float)acc;
+        }
+        double acc = 0;
+        for (int m = 0; m < 3; ++m) acc += fn.R_wc[3 * m + r] * (fr.t_wc[m] - fn.t_wc[m]);
+        info.t_nr[r] = (float)acc;
+      }
+      neighbors[ref].push_back(info);
+    }
+  }
+  return neighbors;
+}
+
 std::vector<Matrix3d> LidarOdometry::GetGlobalRotation() const { std::vector<Matrix3d> r; for (const Velodyne& l : lidars) r.push_back(l.GetRotation()); return r; }
 std::vector<Vector3d> LidarOdometry::GetGlobalTranslation() const { std::vector<Vector3d> t; for (const Velodyne& l : lidars) t.push_back(l.GetTranslation()); return t; }
 

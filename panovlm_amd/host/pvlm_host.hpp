@@ -429,6 +429,18 @@ struct Frame {
   Matrix4d GetPose() const { return {R_wc[0], R_wc[1], R_wc[2], t_wc[0], R_wc[3], R_wc[4], R_wc[5], t_wc[1], R_wc[6], R_wc[7], R_wc[8], t_wc[2], 0, 0, 0, 1}; }
 };
 
+// ---- mvs/MVS.h:45-57, mvs/MVS.cpp:334-382 — who the neighbours of a reference view are (the `nei` / R_nr / t_nr arguments of
+// pvlm_mvs_*).  SelectNeighborKNN: the 3 x neighbor_size nearest camera centres (float32, as pcl::KdTreeFLANN returns them),
+// the first hit skipped as "self", candidates closer than the squared distance threshold skipped, the first neighbor_size
+// kept; T_nr = T_wn^-1 T_wr in double, stored as float (cv::Matx33f / cv::Vec3f).  The rigid inverse is used where
+// upstream calls Eigen's general Matrix4d::inverse() — equal to ~1e-16 before the rounding to float.
+struct NeighborInfo {
+  size_t id = 0;
+  std::array<float, 9> R_nr{};   // reference -> neighbour, row-major
+  std::array<float, 3> t_nr{};
+};
+std::vector<std::vector<NeighborInfo>> SelectNeighborKNN(const std::vector<Frame>& frames, int neighbor_size, float sq_distance_threshold);
+
 class CameraLidarOptimizer {
  public:
   using LinePairs = std::map<std::pair<size_t, size_t>, std::vector<CameraLidarLinePair>>;

@@ -379,6 +379,20 @@ int main(int argc, char** argv) {
       block(tr.left_neighbor.data(), tr.left_neighbor.size(), 4); block(tr.right_neighbor.data(), tr.right_neighbor.size(), 4);
       printf("features valid %d scan %zu sharp %zu less_sharp %zu flat %zu less_flat %zu\n", valid, v.cloud_scan.size(), v.cornerSharp.size(),
              v.cornerLessSharp.size(), v.surfFlat.size(), v.surfLessFlat.size());
+    } else if (cmd == "mvsneighbors") {
+      // mvsneighbors <poses.bin> neighbor_size sq_distance_threshold : poses.bin = int32 n, per frame int32 valid, R_wc (9 f64), t_wc (3 f64)
+      std::ifstream f(argv[2], std::ios::binary);
+      int32_t n = 0; rd(f, &n, 1);
+      std::vector<Frame> frames(n);
+      for (int i = 0; i < n; ++i) { int32_t v = 0; rd(f, &v, 1); frames[i].id = i; frames[i].pose_valid = v != 0; rd(f, frames[i].R_wc.data(), 9); rd(f, frames[i].t_wc.data(), 3); }
+      const auto nb = SelectNeighborKNN(frames, atoi(argv[3]), (float)atof(argv[4]));
+      for (size_t i = 0; i < nb.size(); ++i)
+        for (const NeighborInfo& x : nb[i]) {
+          printf("nb %zu %zu", i, x.id);
+          for (float v : x.R_nr) printf(" %a", v);
+          for (float v : x.t_nr) printf(" %a", v);
+          printf("\n");
+        }
     } else if (cmd == "poseio") {
       // poseio <in.txt> <out.txt> with_invalid precision
       std::vector<Matrix3d> R; std::vector<Vector3d> t; std::vector<std::string> names;

@@ -205,3 +205,49 @@ def test_pcd_reader_refuses_corrupt_files():
             head = r.stdout.decode(errors="ignore").split("\n")[0].split()
             assert r.returncode == 0 and head[:2] == ["loaded", "0"] and head[5] == "0", (name, r.returncode, head)
 
+
+def test_mvs_select_neighbor_knn_mirror_matches_oracle():
+    """MVS::SelectNeighborKNN (mvs/MVS.cpp:334-382): host mirror (rigid inverse) against the oracle (general 4x4 inverse, as
+    upstream) — neighbour ids equal, R_nr / t_nr equal after the rounding to float except for last-bit flips — and against
+    numpy for the geometry (X_n = R_nr X_r + t_nr)."""
+    import struct
+    from oracle import oracle as orc
+    from tests import synth
+    rng = np.random.default_rng(17)
+    n = 40
+    R = np.array([synth.rodrigues(rng.normal(size=3) * 0.4) for _ in range(n)])
+    t = np.cumsum(rng.normal(size=(n, 3)) * 0.3, axis=0)
+    t[7] = t[6] + 1e-4                                      # closer than the threshold: skipped as a neighbour of each other
+    valid = np.ones(n, np.int32); valid[[3, 20]] = 0        # frames without a pose neither get nor become neighbours
+    for k, thr in ((4, 0.01), (8, 0.25), (30, 0.0)):
+        ids, oR, ot = orc.mvs_select_neighbors(valid, R, t, k, thr)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "poses.bin")
+            with open(path, "wb") as f:
+                f.write(struct.pack("<i", n))
+                for i in range(n):
+                    f.write(struct.pack("<i", int(valid[i]))); f.write(R[i].astype(np.float64).tobytes()); f.write(t[i].astype(np.float64).tobytes())
+            out = host_io.run("mvsneighbors", path, k, repr(thr))
+        got = {}
+        for l in out:
+            if l.startswith("nb "):
+                w = l.split()
+                got.setdefault(int(w[1]), []).append((int(w[2]), np.array([float.fromhex(x) for x in w[3:12]], np.float32), np.array([float.fromhex(x) for x in w[12:15]], np.float32)))
+        total = 0
+        for i in range(n):
+            want = [j for j in ids[i] if j >= 0]
+            assert [g[0] for g in got.get(i, [])] == want, (i, want)
+            if not valid[i]:
+                assert not want
+            assert i not in want and all(valid[j] for j in want) and len(want) <= k
+            for q, (j, Rg, tg) in enumerate(got.get(i, [])):
+                assert np.abs(Rg - oR[i, q]).max() <= 2e-7 and np.abs(tg - ot[i, q]).max() <= 1e-6 * max(1.0, np.abs(ot[i, q]).max())
+                Rn = R[j].T @ R[i]; tn = R[j].T @ (t[i] - t[j])
+                assert np.abs(Rg.reshape(3, 3) - Rn).max() < 1e-6 and np.abs(tg - tn).max() < 1e-5
+                d2 = np.float32(((t[i].astype(np.float32) - t[j].astype(np.float32)) ** 2).sum())
+                assert d2 >= np.float32(thr) * (1 - 1e-6)
+                total += 1
+        assert total > n
+        if thr == 0.01:
+            assert 7 not in [j for j in ids[6] if j >= 0] and 6 not in [j for j in ids[7] if j >= 0]
+
