@@ -242,6 +242,25 @@ void orc_mvs_select_neighbors(int n, const int* valid, const double* R_wc, const
       if (k < (int)nb[i].size()) { std::memcpy(out_R + 9 * o, nb[i][k].R_nr, 36); std::memcpy(out_t + 3 * o, nb[i][k].t_nr, 12); }
     }
 }
+// ScorePixel of one hypothesis (normal, depth) of pixel (px, py); close: n_close x 7 floats (point 3, normal 3, depth) = the smoothness term
+float orc_mvs_score_pixel(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors, const unsigned char* const* nei_gray,
+                          const float* R_nr, const float* t_nr, int px, int py, const float* normal, float depth, const float* const* nei_depth, int n_close,
+                          const float* close) {
+  MvsView v{rows, cols, half_window, step, ref_gray};
+  std::vector<float> unit((size_t)rows * cols * 3);
+  const Equirectangular eq(rows, cols);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) { const float p[2] = {(float)j, (float)i}; eq.ImageToCam(p, 1.f, &unit[3 * ((size_t)i * cols + j)]); }
+  PixelPatch patch;
+  FillPixelPatch(v, px, py, patch);
+  if (!patch.ok) return -2.f;
+  std::vector<NeighborPixel> cl(n_close);
+  for (int q = 0; q < n_close; ++q) { for (int k = 0; k < 3; ++k) { cl[q].point[k] = close[7 * q + k]; cl[q].normal[k] = close[7 * q + 3 + k]; } cl[q].depth = close[7 * q + 6]; }
+  const float* u0 = &unit[3 * ((size_t)py * cols + px)];
+  const float X0[3] = {u0[0] * depth, u0[1] * depth, u0[2] * depth};
+  const float plane[4] = {normal[0], normal[1], normal[2], -(normal[0] * X0[0] + normal[1] * X0[1] + normal[2] * X0[2])};
+  return ScorePixelPhotometric(v, unit.data(), px, py, normal, depth, patch, n_neighbors, nei_gray, R_nr, t_nr, nei_depth, plane, cl.data(), n_close);
+}
 // single PatchMatch helpers, for the unit tests of the restatement itself
 void orc_mvs_correct_normal(const float* view_dir, float* normal) { CorrectNormal(view_dir, normal); }
 float orc_mvs_interpolate_pixel(int rows, int cols, int px, int py, int nx, int ny, float depth, const float* normal, float min_depth, float max_depth) {
