@@ -426,3 +426,76 @@ def test_mvs_score_pixel_matches_numpy(oracle):
         diffs.append(abs(got - want)); checked += 1
     diffs = np.array(diffs)
     assert checked > 30 and np.median(diffs) < 1e-6 and diffs.max() < 1e-4, (checked, np.median(diffs), diffs.max())     # observed: 6e-8 / 2.4e-7
+
+
+def test_depth_fusion_filters_match_numpy(oracle):
+    """FilterDepthImage and FilterDepthImageRefine of the oracle (mvs/MVS.cpp:1735-1890) against a numpy restatement of
+    the per-pixel rules, on top of the oracle's own forward projection (checked separately in tests/test_mvs_cpu.py)."""
+    from tests.test_mvs_cpu import _refine_scene
+    nd, nc, Rn, tn, depth, conf, const = _refine_scene(oracle, 48, 96)
+    rows, cols = depth.shape
+    proj = [oracle.mvs_project_depth_conf(nd[b], nc[b], Rn[b], tn[b]) for b in range(len(nd))]
+    f32 = np.float32
+    thr = f32(0.01)
+    loose, strict = thr * f32(1.2), thr * f32(0.8)
+    # ---- FilterDepthImage: >= 2 neighbours agree at the pixel (strict), >= 5 (neighbour, 4-neighbourhood) samples agree (loose) or depth_constant
+    want = np.zeros_like(depth)
+    for r in range(rows):
+        for c in range(cols):
+            d = depth[r, c]
+            if d <= 0:
+                continue
+            if sum(1 for pd, _ in proj if pd[r, c] > 0 and abs((d - pd[r, c]) / d) < strict) < 2:
+                continue
+            votes = 0
+            for pd, _ in proj:
+                for dc, dr in ((-1, 0), (1, 0), (0, 1), (0, -1)):
+                    rr, cc = r + dr, c + dc
+                    if 0 <= rr < rows and 0 <= cc < cols and pd[rr, cc] > 0 and abs((d - pd[rr, cc]) / d) < loose:
+                        votes += 1
+            if votes >= 5 or const[r, c]:
+                want[r, c] = d
+    got, gotc = oracle.mvs_filter_depth(nd, Rn, tn, depth, conf=conf, depth_constant=const, thr=0.01)
+    assert np.array_equal(got, want) and np.array_equal(gotc, np.where(want > 0, conf, 0)) and 0.1 < (want > 0).mean() < 0.95
+    # ---- FilterDepthImageRefine
+    px = np.stack(np.meshgrid(np.arange(cols), np.arange(rows)), -1).reshape(-1, 2).astype(np.float32)
+    unit = oracle.image_to_cam(rows, cols, px, 1.0).reshape(rows, cols, 3)
+    min_d, max_d = f32(0.1), f32(3.0)
+    wd = np.zeros_like(depth); wc = np.zeros_like(depth); conf_after = conf.copy()
+    for r in range(rows):
+        for c in range(cols):
+            d = depth[r, c]
+            if d <= 0:
+                conf_after[r, c] = 0
+                continue
+            pos, neg, avg, npos, nneg, bad = conf[r, c], f32(0), d * conf[r, c], 0, 0, False
+            for n in range(len(proj) - 1, -1, -1):
+                dn, cn = proj[n][0][r, c], proj[n][1][r, c]
+                if dn <= 0 and npos + nneg + n < 2:
+                    bad = True
+                    break
+                if abs((d - dn) / d) < loose:
+                    avg = f32(avg + dn * cn); pos = f32(pos + cn); npos += 1
+                else:
+                    if dn < d:
+                        neg = f32(neg + cn)                                   # occlusion
+                    else:                                                     # free-space violation: the neighbour's own confidence where we land in it
+                        X1 = (Rn[n].reshape(3, 3).astype(f32) @ (unit[r, c] * d).astype(f32) + tn[n].astype(f32)).astype(f32)
+                        x1 = oracle.cam_to_image(rows, cols, X1[None, :])[0]
+                        xr, yr = int(np.floor(x1[0] + 0.5)), int(np.floor(x1[1] + 0.5))           # round half away from zero (positive values)
+                        cc = nc[n][yr, xr] if (0 <= xr < cols and 0 <= yr < rows) else f32(0)
+                        neg = f32(neg + (cc if cc > 0 else cn))
+                    nneg += 1
+            if not bad:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    avg = f32(avg / pos)
+                if npos >= 2 and pos > neg and min_d <= avg <= max_d:
+                    wd[r, c] = avg; wc[r, c] = f32(pos - neg)
+                    continue
+            if const[r, c]:
+                wd[r, c] = d; wc[r, c] = 1
+    gd, gc, ga = oracle.mvs_filter_depth_refine(nd, nc, Rn, tn, depth, conf, depth_constant=const, thr=0.01, min_depth=0.1, max_depth=3.0)
+    assert np.array_equal(ga, conf_after)
+    same = (np.abs(gd - wd) <= 1e-6 * np.maximum(wd, 1)) & (np.abs(gc - wc) <= 1e-5)
+    assert same.all() and np.array_equal(gd > 0, wd > 0)
+    assert 0.05 < (wd > 0).mean() < 0.95
