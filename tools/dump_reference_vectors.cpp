@@ -382,6 +382,36 @@ void DumpDepth(const std::string& dir) {
   WriteBundle(dir + "/depth.ref.pvv", out);
 }
 
+// ---- Velodyne::ReOrderVLP + ExtractFeatures, ADAPTIVE (sensors/Velodyne.cpp:371-526, :531-760) ----------------------
+// The fixture's `raw` is the cloud LoadLidar leaves in Velodyne::cloud (camera-style axes).  Public members only: the
+// ring-ordered cloud and the four feature clouds; cornerBeforeFilter is the edge cloud before EdgeToLine (what this
+// repo calls cornerLessSharp).  The per-point working arrays are private upstream and stay unpinned.
+void DumpFeatures(const std::string& dir) {
+  const Bundle in = ReadBundle(dir + "/features.in.pvv");
+  if (in.empty()) return;
+  const Array& raw = in.at("raw");
+  const int horizon = (int)in.at("horizon").as_double(0);
+  Velodyne v(16, 0, horizon);
+  for (size_t i = 0; i < raw.dims[0]; ++i) {
+    pcl::PointXYZI p; p.x = raw.f32()[4 * i]; p.y = raw.f32()[4 * i + 1]; p.z = raw.f32()[4 * i + 2]; p.intensity = raw.f32()[4 * i + 3];
+    v.cloud.push_back(p);
+  }
+  v.ReOrderVLP();
+  v.ExtractFeatures(1000.f, 5.f, ADAPTIVE, true);
+  auto flat = [](const pcl::PointCloud<pcl::PointXYZI>& c) {
+    std::vector<float> o;
+    for (const auto& p : c.points) { o.push_back(p.x); o.push_back(p.y); o.push_back(p.z); o.push_back(p.intensity); }
+    return o;
+  };
+  Bundle out;
+  out["cloud_scan"] = MakeArray(0, {v.cloud_scan.size(), 4}, flat(v.cloud_scan));
+  out["cornerSharp"] = MakeArray(0, {v.cornerSharp.size(), 4}, flat(v.cornerSharp));       // NB: upstream re-filters cornerSharp in EdgeToLine (:1312-1323)
+  out["cornerLessSharp"] = MakeArray(0, {v.cornerBeforeFilter.size(), 4}, flat(v.cornerBeforeFilter));
+  out["surfFlat"] = MakeArray(0, {v.surfFlat.size(), 4}, flat(v.surfFlat));
+  out["surfLessFlat"] = MakeArray(0, {v.surfLessFlat.size(), 4}, flat(v.surfLessFlat));
+  WriteBundle(dir + "/features.ref.pvv", out);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -396,5 +426,6 @@ int main(int argc, char** argv) {
   DumpLines(dir);
   DumpReproj(dir);
   DumpDepth(dir);
+  DumpFeatures(dir);
   return 0;
 }

@@ -70,12 +70,16 @@ def _is_output(fixture, key):
         return key in ("r", "J")
     if fixture == "depth":
         return key.startswith("depth_size")
+    if fixture == "features":
+        return key not in ("raw", "horizon")
     raise KeyError(fixture)
 
 
 # intermediate results the reference API does not expose (k-NN table, query indices, vote matrices)
-INTERNAL = ("_qidx", "_nn", "votes")
-FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth")   # mvs.npz: the
+INTERNAL = ("_qidx", "_nn", "votes",
+            # private working arrays of Velodyne (sensors/Velodyne.h:97-120); cornerSharp is re-filtered by EdgeToLine upstream
+            "rc", "scan_start", "scan_end", "range_image", "image_to_point_idx", "curvature", "state", "sort_ind", "left", "right", "cornerSharp")
+FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth", "features")   # mvs.npz: the
 # reference entry point (MVS::InitConfMap) is a private member driven by the whole MVS object — not exported here
 
 
