@@ -54,3 +54,14 @@ def test_context_creation_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(pv.PvlmError):
         pv.Context(0)
+
+
+def test_header_is_plain_c_and_cxx():
+    """include/pvlm.h is the drop-in boundary: it must compile as C99 (cgo / JNI / ctypes-style bindings) and as C++11,
+    warning-free, with nothing but the standard headers."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "pvlm.h")
+    for cmd in (["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", hdr],
+                ["g++", "-x", "c++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", hdr]):
+        r = subprocess.run(cmd, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
