@@ -68,6 +68,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steady-state pre-warm before the W warm-up steps (clock ramp)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as a captured HIP graph (pvlm_graph_*).  auto = off: measured on MI355X / ROCm 7.0 a replayed graph "
+                         "of the five kernels costs 28-33 us around the fused kernel against 22-26 us for five plain launches "
+                         "(per_rank_projection reports both), and eager launches let every launch of the dominant kernel inside the "
+                         "timed region be bracketed by HIP events (roofline.achieved)")
+    ap.add_argument("--no-projection", action="store_true", help="skip the per-rank projection block (scans/2, /4, /8 on this GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,21 +108,49 @@ def main():
 
     import panovlm_amd as pv
     ctx = pv.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one real (capturable) stream carries everything: the library's kernels, torch's few element-wise ops and the all-reduce
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    ctx.set_stream(side.cuda_stream)
 
     kind = pv.POINT2PLANE_ANGLE if args.functor == "angle" else pv.POINT2PLANE_METER
     loss_a = 2 * np.pi / 180 if args.functor == "angle" else 0.2     # util/Optimization.cpp:515-517
+    n_queries = int(sum(scans[int(n)]["flat_xyz"].shape[0] for n in nei))
+    n_targets = int(sum(scans[int(r)]["less_xyz"].shape[0] for r in ref))
+    # Working set reserved up front, like the scans are uploaded up front: hipMalloc maps pages at 40-70 ms per GB
+    # (tools/micro/alloc_cost.hip), the association's output alone is 56 B x accepted rows.  Upper bound: every query
+    # accepted + the two pipeline slots of scratch + the scans.
+    t_res = time.perf_counter()
+    shards_extra = 0.9 if (world == 1 and not args.no_projection and args.scans >= 64) else 0.0     # rank-0 shards of N = 2, 4, 8 live beside the batch
+    reserve_bytes = int(n_queries * 56 * (1.02 + shards_extra)) + 2 * min(n_queries, 16 << 20) * 100 + sum(
+        (len(s["flat_xyz"]) * 16 + len(s["less_xyz"]) * 48 + (4 << 20)) for s in scans.values()) + (1 << 30)
+    info = ctx.device_info()
+    reserve_bytes = min(reserve_bytes, int(info["hbm_bytes"] * 0.8))
+    ctx.reserve(reserve_bytes)
+    t_res = time.perf_counter() - t_res
     dscans = {k: pv.Scan(ctx, s) for k, s in scans.items()}
     ctx.synchronize()
-    ctx.profile_enable(True)
-    t_assoc = time.perf_counter()
-    rs = ctx.assoc_point2plane([dscans[int(r)] for r in ref], [dscans[int(n)] for n in nei], args.tolerance, 1.0,
-                               kind=kind, flags=pv.FLAG_NORMALIZE_DISTANCE, weight=1.0)
-    ctx.synchronize()
-    t_assoc = time.perf_counter() - t_assoc
-    assoc_ms, assoc_n = ctx.profile_read(2)
-    ctx.profile_enable(False)
-    n_queries = int(sum(scans[int(n)]["flat_xyz"].shape[0] for n in nei))
+
+    def associate(rr, nn_, tol, ds=dscans):
+        return ctx.assoc_point2plane([ds[int(r)] for r in rr], [ds[int(n)] for n in nn_], tol, 1.0, kind=kind, flags=pv.FLAG_NORMALIZE_DISTANCE, weight=1.0)
+
+    def timed_assoc(rr, nn_, tol, ds=dscans):
+        ctx.synchronize()
+        m0 = ctx.mem_info()
+        ctx.profile_enable(True)
+        t0 = time.perf_counter()
+        r_ = associate(rr, nn_, tol, ds)
+        ctx.synchronize()
+        wall = time.perf_counter() - t0
+        ms, launches = ctx.profile_read(2)
+        ctx.profile_enable(False)
+        return r_, wall, ms, launches, ctx.mem_info()["device_allocs"] - m0["device_allocs"]
+
+    rs, t_assoc_first, assoc_ms_first, _, allocs_first = timed_assoc(ref, nei, args.tolerance)
+    # the reference re-associates at every outer iteration (lidar_mapping/LidarOdometry.cpp:38-110): the steady state
+    # of the call is the SECOND and later ones, with the previous residual set given back first
+    rs.close()
+    rs, t_assoc, assoc_ms, assoc_n, allocs_steady = timed_assoc(ref, nei, args.tolerance)
     n_local = rs.n
 
     poses = [sy.pose_params(*sy.estimated_pose(k)) for k in range(F)]
@@ -131,15 +165,70 @@ def main():
         dist.all_reduce(tot)
     n_total, q_total = int(tot[0].item()), int(tot[1].item())
 
-    def step_local():
-        d_t.add_(1e-9)   # a fresh parameter point every step, as an LM iteration has
+    # ---- the step: k_pose_table -> k_pair_table -> k_eval_fused -> k_pair_epilogue -> k_neq_gather (-> all-reduce) ----
+    # Captured once as a HIP graph (pvlm_graph_*) and replayed: one submission per LM step instead of five launches
+    # (+ the collective).  For N > 1 the all-reduce goes through the library's own RCCL communicator on the SAME stream
+    # (pvlm_allreduce_sum_f64), inside the graph; PVLM_BENCH_COMM=torch keeps torch.distributed's eager all_reduce.
+    comm, comm_mode = None, "none"
+    if world > 1:
+        comm_mode = "torch"
+        if not shared_gpu and os.environ.get("PVLM_BENCH_COMM", "pvlm") == "pvlm":
+            try:
+                ids = [ctx.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                comm = pv.Comm(ctx, world, rank, ids[0])
+                comm_mode = "pvlm"
+            except Exception as e:  # keep the run alive on torch's communicator
+                sys.stderr.write("[bench] pvlm_comm unavailable (%s); using torch.distributed\n" % str(e)[:200])
+                comm = None
+
+    use_graph = args.graph == "on"
+
+    def make_step(rs_, neq_, packed_, with_comm, graphed=None):
+        graphed = use_graph if graphed is None else graphed
+
+        def local():
+            ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
+            neq_.accumulate_dev(rs_, packed_.data_ptr(), pv.LOSS_HUBER, loss_a, zero_first=True)
+            if with_comm and comm is not None:
+                comm.allreduce_sum_f64(packed_.data_ptr(), neq_.size)
+        graph = None
+        if graphed:
+            try:
+                local(); ctx.synchronize()          # first run binds / sizes everything: nothing left to allocate inside the capture
+                ctx.graph_begin()
+                try:
+                    local()
+                finally:
+                    graph = ctx.graph_end()
+            except Exception as e:
+                sys.stderr.write("[bench] graph capture failed (%s); eager launches\n" % str(e)[:200])
+                graph = None
+
+        def step():
+            d_t.add_(1e-9)   # a fresh parameter point every step, as an LM iteration has
+            if graph is not None:
+                graph.launch()
+            else:
+                local()
+            if with_comm and world > 1 and comm is None:
+                dist.all_reduce(packed_)
+        return step, graph
+
+    step, graph = make_step(rs, neq, packed, True)
+    if world > 1 and comm is not None:
+        # the captured collective must give what torch's eager one gives
+        step(); torch.cuda.synchronize()
+        a = packed.clone()
         ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
         neq.accumulate_dev(rs, packed.data_ptr(), pv.LOSS_HUBER, loss_a, zero_first=True)
-
-    def step():
-        step_local()
-        if world > 1:
-            dist.all_reduce(packed)
+        dist.all_reduce(packed); torch.cuda.synchronize()
+        ok = torch.tensor([1 if torch.allclose(a, packed, rtol=1e-9, atol=1e-9 * float(packed.abs().max())) else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            sys.stderr.write("[bench] pvlm_comm all-reduce disagrees with torch.distributed; using torch\n")
+            comm = None; comm_mode = "torch(fallback)"
+            step, graph = make_step(rs, neq, packed, True)
 
     def fence():
         torch.cuda.synchronize()
@@ -149,31 +238,57 @@ def main():
 
     # clocks: MI355X ramps memory/fabric clocks under sustained load; a 1 ms step measured after three warm-up steps runs
     # ~10 % below its steady state (measured: 89.7 -> 99.4 G eval/s at 101 M evals/launch).  Untimed pre-warm, then the
-    # W warm-up steps of the contract.
+    # W warm-up steps of the contract.  The pre-warm uses the same step (collective included: the loop count is fixed).
+    local_step, _ = (step, None) if world == 1 else make_step(rs, neq, torch.zeros_like(packed), False)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm_seconds:   # local work only: the loop count differs between ranks
         for _ in range(8):
-            step_local()
+            local_step()
         torch.cuda.synchronize()
-    if world > 1:      # communicator set-up (lazy in RCCL) must not land in a timed step even with --warmup 0
-        dist.all_reduce(packed)
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
         step()
     fence()
-    ctx.profile_enable(True)
+    # eager steps (N = 1): every launch of the fused kernel inside the timed region is bracketed by HIP events on the
+    # stream it runs on.  Graph replay (N > 1): events cannot be recorded inside a replayed graph, so the fused kernel is
+    # timed by an eager pass of the same K launches right after the timed region (same stream, data and clocks).
+    if graph is None:
+        ctx.profile_enable(True)
     t_wall = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t_wall
+    if graph is not None:
+        ctx.profile_enable(True)
+        for _ in range(args.steps):
+            d_t.add_(1e-9)
+            ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
+            neq.accumulate_dev(rs, packed.data_ptr(), pv.LOSS_HUBER, loss_a, zero_first=True)
     kern_ms, kern_n = ctx.profile_read(0)
     ctx.profile_enable(False)
+    if graph is not None:
+        step(); torch.cuda.synchronize()          # leave the reduced buffer of a full step behind
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     cost = float(packed[-1].item())
+
+    # ---- what one rank of an N-GPU run has to do, measured on this one GPU (no 8-GPU node is mine to launch) ----
+    projection = None
+    if rank == 0 and world == 1 and not args.no_projection and args.scans >= 64:
+        try:
+            projection = per_rank_projection(ctx, pv, torch, sharding, args, associate, make_step, ref_all, nei_all, F, ui, uj, dev,
+                                             dt / args.steps * 1e3, kern_ms / max(kern_n, 1), neq.size)
+        except Exception as e:  # reporting extra only
+            projection = {"error": str(e)[:200]}
+
+    extra_assoc = None
+    if rank == 0 and world == 1:
+        try:
+            extra_assoc = association_points(ctx, pv, torch, args, scans, dscans, ref, nei, associate, timed_assoc, make_step, F, ui, uj, dev)
+        except Exception as e:  # reporting extra only
+            extra_assoc = {"error": str(e)[:200]}
 
     # materialise mode (r + 1x12 J written to HBM: the Ceres-feeding path) — reported, never `value`
     mat = None
@@ -249,9 +364,11 @@ def main():
                          "M_evals_per_s_kernel": n_local / k_avg_s / 1e6,
                          "ceiling_M_evals_per_s_64B": HBM_PEAK_GBPS * 1e9 / 64 / 1e6,
                          "ceiling_M_evals_per_s_56B": HBM_PEAK_GBPS * 1e9 / 56 / 1e6},
-            "association": {"kernel": "k_knn_pairs + k_fit_pairs", "pairs": int(len(ref)), "queries": n_queries, "accepted": n_local,
-                            "kernel_ms": assoc_ms, "launches": assoc_n, "wall_s": t_assoc,
-                            "M_queries_per_s_kernel": n_queries / max(assoc_ms, 1e-9) / 1e3},
+            "association": association_block(n_queries, n_targets, n_local, int(len(ref)), assoc_ms, assoc_n, t_assoc, t_assoc_first, assoc_ms_first,
+                                             allocs_first, allocs_steady, t_res, reserve_bytes, ctx.mem_info(), extra_assoc),
+            "step": {"graph": graph is not None, "comm": comm_mode, "allreduce_doubles": int(neq.size) if world > 1 else 0,
+                     "kernels_per_step": 5, "ms_per_step_minus_fused_kernel": dt / args.steps * 1e3 - kern_ms / max(kern_n, 1)},
+            "per_rank_projection": projection,
             "materialise": mat,
             "panorama": pano,
             "setup": {"scan_generation_s": t_gen, "scans_generated": len(needed)},
@@ -269,6 +386,130 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def association_block(n_queries, n_targets, accepted, pairs, kernel_ms, launches, wall, wall_first, kernel_ms_first, allocs_first, allocs_steady,
+                      reserve_s, reserve_bytes, mem, extra):
+    """AssociatePoint2Plane for the whole batch (K2 k_knn_pairs + K3 k_fit_pairs + ordered compaction).  wall_s is the
+    steady-state call (second association of the same pairs, the first result given back first — what every outer
+    iteration after the first does); the first call and the up-front reservation of the working set are reported beside it."""
+    comp = (n_queries + n_targets) * 16            # SURVEY.md §8(d): (Nq + Nt) x 16 B per pair, the bytes any k-NN must touch once
+    out = {"kernel": "k_knn_pairs + k_fit_pairs", "pairs": pairs, "queries": n_queries, "accepted": accepted,
+           "kernel_ms": kernel_ms, "launches": launches, "wall_s": wall, "wall_over_kernel": wall / max(kernel_ms * 1e-3, 1e-12),
+           "M_queries_per_s_kernel": n_queries / max(kernel_ms, 1e-9) / 1e3, "M_queries_per_s_wall": n_queries / max(wall, 1e-12) / 1e6,
+           "hipMalloc_calls_in_call": allocs_steady,
+           "first_call": {"wall_s": wall_first, "kernel_ms": kernel_ms_first, "hipMalloc_calls": allocs_first},
+           "reserve": {"seconds": reserve_s, "bytes": reserve_bytes, "pool_reserved_bytes": mem["reserved"], "pool_peak_bytes": mem["peak"]},
+           "compulsory_bytes": comp, "compulsory_GBps_at_kernel_time": comp / max(kernel_ms, 1e-9) / 1e6,
+           "output_bytes": accepted * 56, "scratch_bytes_per_query": 97}
+    # counter evidence for K2 / K3 (separate rocprofv3 --pmc passes of this command, summarised by tools/pmc_assoc.py)
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_pmc_assoc*.json"))):
+        try:
+            pm = json.load(open(f))
+            if pm.get("queries") == n_queries:
+                out["pmc"] = {k: pm[k] for k in pm if k != "raw"}
+                out["pmc"]["source"] = os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    if extra:
+        out.update(extra)
+    return out
+
+
+def per_rank_projection(ctx, pv, torch, sharding, args, associate, make_step, ref_all, nei_all, F, ui, uj, dev, ms_full, k6_full_ms, neq_size):
+    """What rank 0 of an N-GPU run of THIS batch has to do per step, measured on this one GPU: its shard of the pair list
+    (block partition by reference scan), associated and evaluated exactly like the headline, the step replayed as a
+    HIP graph (as bench.py does for N > 1).  The all-reduce cannot be measured on one GPU: its size is reported, and the
+    projection is given without it and with a stated assumption for it."""
+    assumed_allreduce_us = {2: 40.0, 4: 60.0, 8: 80.0}     # [assumed, not measured] RCCL all-reduce of ~3 MB over xGMI
+    out = {"full_batch_ms_per_step": ms_full, "full_batch_fused_kernel_ms": k6_full_ms, "allreduce_bytes": int(neq_size) * 8,
+           "assumed_allreduce_us": assumed_allreduce_us, "ranks": {}}
+    for N in (2, 4, 8):
+        r, n = sharding.shard_pairs(ref_all, nei_all, F, 0, N)
+        rs_k = associate(r, n, args.tolerance)
+        neq_k = pv.NormalEq(ctx, F, ui, uj)
+        packed_k = torch.zeros(neq_size, dtype=torch.float64, device=dev)
+        res = {"pairs": int(len(r)), "evals": int(rs_k.n)}
+        for tag, graphed in (("graph", True), ("eager", False)):
+            step_k, g = make_step(rs_k, neq_k, packed_k, False, graphed=graphed)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.25:          # clock ramp at short steps
+                for _ in range(16):
+                    step_k()
+                torch.cuda.synchronize()
+            reps = 100
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step_k()
+            torch.cuda.synchronize()
+            res["ms_per_step_" + tag] = (time.perf_counter() - t0) / reps * 1e3
+            if g is not None:
+                g.close()
+            elif graphed:
+                res["graph_error"] = True
+        ctx.profile_enable(True)
+        step_k, _ = make_step(rs_k, neq_k, packed_k, False, graphed=False)
+        for _ in range(20):
+            step_k()
+        k_ms, k_n = ctx.profile_read(0)
+        ctx.profile_enable(False)
+        res["fused_kernel_ms"] = k_ms / max(k_n, 1)
+        res["around_fused_kernel_us_graph"] = (res["ms_per_step_graph"] - res["fused_kernel_ms"]) * 1e3
+        res["around_fused_kernel_us_eager"] = (res["ms_per_step_eager"] - res["fused_kernel_ms"]) * 1e3
+        res["projected_speedup_without_allreduce"] = ms_full / res["ms_per_step_graph"]
+        res["projected_speedup_with_assumed_allreduce"] = ms_full / (res["ms_per_step_graph"] + assumed_allreduce_us[N] * 1e-3)
+        out["ranks"][str(N)] = res
+        neq_k.close(); rs_k.close()
+    return out
+
+
+def association_points(ctx, pv, torch, args, scans, dscans, ref, nei, associate, timed_assoc, make_step, F, ui, uj, dev):
+    """Two more points SURVEY.md §8(d) asks for: raw targets (every one of the 65 536 points a surfLessFlat target, the
+    wording of BASELINE.md §2) and the Floor plane tolerance 0.01."""
+    out = {}
+    # --- raw targets: the first scans of the batch, re-uploaded with their full cloud as the target cloud
+    S = min(64, args.scans)
+    sel = [(int(r), int(n)) for r, n in zip(ref, nei) if r < S and n < S]
+    raw = {}
+    for k in range(S):
+        d = dict(scans[k]); d["less_xyz"] = scans[k]["flat_xyz"]; d["less_tag"] = scans[k]["flat_tag"]
+        raw[k] = pv.Scan(ctx, d)
+    rr = np.array([a for a, _ in sel]); nn_ = np.array([b for _, b in sel])
+    r0 = associate(rr, nn_, args.tolerance, raw); r0.close()                   # sizes the pool for this shape
+    rsr, wall, ms, launches, allocs = timed_assoc(rr, nn_, args.tolerance, raw)
+    nq = int(sum(len(scans[b]["flat_xyz"]) for _, b in sel)); nt = int(sum(len(scans[a]["flat_xyz"]) for a, _ in sel))
+    out["raw_targets"] = {"pairs": len(sel), "queries": nq, "targets_per_pair": int(len(scans[0]["flat_xyz"])), "accepted": int(rsr.n),
+                          "kernel_ms": ms, "wall_s": wall, "M_queries_per_s_kernel": nq / max(ms, 1e-9) / 1e3,
+                          "compulsory_bytes": (nq + nt) * 16, "compulsory_GBps_at_kernel_time": (nq + nt) * 16 / max(ms, 1e-9) / 1e6,
+                          "note": "10-NN of a query among raw VLP-16 returns lie on one ring: the reference's own collinearity test "
+                                  "(FormLine(points, 3.0)) rejects most queries"}
+    rsr.close()
+    for d in raw.values():
+        d.close()
+    # --- Floor: lidar_plane_tolerance 0.01 (config/Floor.txt) on the first 256 reference scans, association + fused step
+    keep = np.flatnonzero(ref < min(256, args.scans))
+    rf, nf = ref[keep], nei[keep]
+    r0 = associate(rf, nf, 0.01); r0.close()
+    rsf, wall, ms, launches, allocs = timed_assoc(rf, nf, 0.01)
+    nq = int(sum(len(scans[int(b)]["flat_xyz"]) for b in nf))
+    neq_f = pv.NormalEq(ctx, F, ui, uj)
+    packed_f = torch.zeros(neq_f.size, dtype=torch.float64, device=dev)
+    step_f, _ = make_step(rsf, neq_f, packed_f, False, graphed=False)
+    for _ in range(5):
+        step_f()
+    ctx.profile_enable(True)
+    for _ in range(10):
+        step_f()
+    k_ms, k_n = ctx.profile_read(0)
+    ctx.profile_enable(False)
+    out["floor_tolerance_0.01"] = {"pairs": int(len(rf)), "queries": nq, "accepted": int(rsf.n), "accept_ratio": rsf.n / max(nq, 1),
+                                   "assoc_kernel_ms": ms, "assoc_wall_s": wall, "M_queries_per_s_kernel": nq / max(ms, 1e-9) / 1e3,
+                                   "fused_kernel_ms": k_ms / max(k_n, 1), "M_evals_per_s_kernel": rsf.n / max(k_ms / max(k_n, 1), 1e-9) / 1e3,
+                                   "GBps": rsf.n * 56 / max(k_ms / max(k_n, 1), 1e-9) / 1e6}
+    neq_f.close(); rsf.close()
+    return out
 
 
 def panorama_block(ctx, pv, torch, dev):

@@ -68,6 +68,29 @@ pvlm_status pvlm_synchronize(pvlm_ctx* ctx);
 pvlm_status pvlm_timer_start(pvlm_ctx* ctx);
 pvlm_status pvlm_timer_stop(pvlm_ctx* ctx, float* elapsed_ms);   /* records, synchronises, returns ms */
 pvlm_status pvlm_device_info(pvlm_ctx* ctx, int* cu_count, int64_t* hbm_bytes, char* name, int name_cap);
+/* Device memory.  Every device buffer of a context comes from a caching sub-allocator owned by the context (hipMalloc
+ * maps pages at 40-70 ms per GB on MI355X; the reference's own loop re-associates every outer iteration,
+ * lidar_mapping/LidarOdometry.cpp:38-110, so scratch and outputs of similar size are needed again and again).
+ * pvlm_reserve makes sure ONE free range of `bytes` exists (a production host reserves its working set once, next to
+ * uploading the scans); pvlm_trim synchronises and returns every unused slab to the driver; pvlm_mem_info reports bytes
+ * held from the driver, bytes handed out, the high-water mark and the number of hipMalloc calls so far (a steady state
+ * adds none).  Any pointer may be NULL.  PVLM_NO_POOL=1 in the environment bypasses the pool (debugging). */
+pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes);
+pvlm_status pvlm_trim(pvlm_ctx* ctx);
+pvlm_status pvlm_mem_info(const pvlm_ctx* ctx, int64_t* reserved, int64_t* in_use, int64_t* peak, int64_t* device_allocs);
+/* HIP graph of a step: the calls issued between _begin and _end on this context (pvlm_set_poses_dev,
+ * pvlm_neq_accumulate_dev / pvlm_eval_pair_blocks_dev / pvlm_eval_dev, pvlm_allreduce_sum_f64 — the `_dev` forms, which
+ * neither allocate nor synchronise once they have run once with the same objects) are captured instead of executed;
+ * pvlm_graph_launch replays them as one submission on the context's stream with the CURRENT contents of the device
+ * buffers they were given (pose arrays, packed buffer).  One LM step is five small kernels around the fused one: replayed
+ * as a graph they cost one launch.  A call that would have to allocate or synchronise inside a capture fails with
+ * PVLM_ERR_STATE (run the step once eagerly first).  Needs a real stream (the context's own, or one given to
+ * pvlm_set_stream), not the legacy NULL stream. */
+typedef struct pvlm_graph pvlm_graph;
+pvlm_status pvlm_graph_begin(pvlm_ctx* ctx);
+pvlm_status pvlm_graph_end(pvlm_ctx* ctx, pvlm_graph** out);
+pvlm_status pvlm_graph_launch(pvlm_ctx* ctx, pvlm_graph* graph);
+pvlm_status pvlm_graph_destroy(pvlm_ctx* ctx, pvlm_graph* graph);
 /* Per-kernel timing of the dominant kernels: when enabled, every launch of the fused
  * residual/Jacobian kernel (which=0), the materialise kernel (which=1) and the k-NN + plane-fit
  * association kernel (which=2) is bracketed by HIP events on the ctx stream.  pvlm_profile_read

@@ -209,7 +209,7 @@ inline void InitConfMap(const MvsView& ref, int n_neighbors, const uint8_t* cons
       if (depth[e] <= 0) continue;
       float c = -1;
       FillPixelPatch(ref, col, row, patch);
-      if (patch.ok && patch.sq0 > 0) c = ScorePixelPhotometric(ref, unit.data(), col, row, normal + 3 * e, depth[e], patch, n_neighbors, nei_gray, R_nr, t_nr, nei_depth);
+      if (patch.sq0 > 0) c = ScorePixelPhotometric(   /* :602 — the 1e-6 verdict of FillPixelPatch is ignored by InitPatchMap :619-629 */ ref, unit.data(), col, row, normal + 3 * e, depth[e], patch, n_neighbors, nei_gray, R_nr, t_nr, nei_depth);
       conf[e] = c;
       if (c <= -1) { depth[e] = 0; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; }
     }

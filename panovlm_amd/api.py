@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "pvlm_mvs_views_snapshot_depth", "pvlm_mvs_views_estimate", "pvlm_mvs_views_filter_refine",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
+    "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
 ]
 
 
@@ -89,6 +90,27 @@ def _i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
 
 
+class Graph:
+    """A captured step (pvlm_graph_*): launch() replays it on the context's stream."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._h = ctx, handle
+
+    def launch(self):
+        self.ctx._check(self.ctx.lib.pvlm_graph_launch(self.ctx._h, self._h), "pvlm_graph_launch")
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.ctx.lib.pvlm_graph_destroy(self.ctx._h, self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     def __init__(self, device=0):
         self.lib = load_library()
@@ -123,6 +145,32 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.pvlm_synchronize(self._h), "pvlm_synchronize")
+
+    def reserve(self, nbytes):
+        """One free range of `nbytes` in the context's device pool (hipMalloc is 40-70 ms per GB: pay it at set-up)."""
+        self._check(self.lib.pvlm_reserve(self._h, C.c_int64(int(nbytes))), "pvlm_reserve")
+
+    def trim(self):
+        self._check(self.lib.pvlm_trim(self._h), "pvlm_trim")
+
+    def mem_info(self):
+        r, u, p, n = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.pvlm_mem_info(self._h, C.byref(r), C.byref(u), C.byref(p), C.byref(n)), "pvlm_mem_info")
+        return dict(reserved=r.value, in_use=u.value, peak=p.value, device_allocs=n.value)
+
+    def comm_unique_id(self):
+        """128-byte RCCL id (rank 0 creates it, the launcher carries it to the other ranks)."""
+        buf = (C.c_ubyte * 128)()
+        self._check(self.lib.pvlm_comm_unique_id(self._h, buf), "pvlm_comm_unique_id")
+        return bytes(buf)
+
+    def graph_begin(self):
+        self._check(self.lib.pvlm_graph_begin(self._h), "pvlm_graph_begin")
+
+    def graph_end(self):
+        g = C.c_void_p()
+        self._check(self.lib.pvlm_graph_end(self._h, C.byref(g)), "pvlm_graph_end")
+        return Graph(self, g)
 
     def timer_start(self):
         self._check(self.lib.pvlm_timer_start(self._h), "pvlm_timer_start")

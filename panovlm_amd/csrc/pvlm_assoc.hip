@@ -603,7 +603,8 @@ __global__ __launch_bounds__(256) void k_fit_pairs(const PairDesc* __restrict__ 
   if (threadIdx.x == 0) chunk_count[pd.chunk_base + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-// ordered compaction: chunk (pair, c) writes its accepted rows at dst_base[chunk] + rank.
+// ordered compaction: chunk (pair, c) writes its accepted rows at dst_dev_row[chunk] + rank of the batch's column
+// block (`cols`, column stride `n_dev` rows); qidx_out / nn_out (optional) are in the block's compact order.
 __global__ __launch_bounds__(256) void k_compact(const PairDesc* __restrict__ pairs, const unsigned char* __restrict__ flag_tmp,
                                                  const double* __restrict__ rec_tmp, const int* __restrict__ nn_tmp, long long tmp_rows,
                                                  const long long* __restrict__ dst_dev_row, const long long* __restrict__ dst_out_row,
@@ -646,25 +647,41 @@ static void launch_scan(pvlm_ctx* ctx, int T, const int* count, int* start, int*
   hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(256), 0, ctx->stream, T, count, tiles, start);
 }
 
-static void cloud_free(pvlm_cloud& c) {
-  hipFree(c.d_xyz); hipFree(c.d_tag); hipFree(c.d_keys); hipFree(c.d_cell_start); hipFree(c.d_cell_count); hipFree(c.d_sorted);
+static void cloud_free(pvlm_ctx* ctx, pvlm_cloud& c) {
+  pvlm_i_free(ctx, c.d_xyz); pvlm_i_free(ctx, c.d_tag); pvlm_i_free(ctx, c.d_keys); pvlm_i_free(ctx, c.d_cell_start); pvlm_i_free(ctx, c.d_cell_count);
+  pvlm_i_free(ctx, c.d_sorted);
   c = pvlm_cloud();
 }
 
 // build-time scratch, released on every exit path
 struct DevScratch {
+  pvlm_ctx* ctx;
   std::vector<void*> ptrs;
-  ~DevScratch() { for (void* p : ptrs) hipFree(p); }
-  template <typename T> pvlm_status alloc(pvlm_ctx* ctx, T** p, size_t count) {
+  explicit DevScratch(pvlm_ctx* c) : ctx(c) {}
+  ~DevScratch() { for (void* p : ptrs) pvlm_i_free(ctx, p); }
+  template <typename T> pvlm_status alloc(T** p, size_t count) {
     const pvlm_status st = pvlm_i_alloc(ctx, p, count);
     if (!st) ptrs.push_back(*p);
     return st;
   }
 };
 
+// largest cloud the voxel grid addresses with 32-bit cell tables (hashed table: 2 n slots rounded up to a power of two)
+#define PVLM_MAX_CLOUD_POINTS (256 << 20)
+
 static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float* xyz, const float* tag, bool build_hash) {
   c.n = n;
   if (n <= 0) return PVLM_OK;
+  if (n > PVLM_MAX_CLOUD_POINTS) { PVLM_SET_ERR(ctx, "cloud of %d points exceeds the supported maximum of %d", n, PVLM_MAX_CLOUD_POINTS); return PVLM_ERR_ARG; }
+  // bounding box (and the finiteness check: a NaN never updates a min / max, so every coordinate is tested)
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const float v = xyz[3 * i + k];
+      if (!std::isfinite(v)) { PVLM_SET_ERR(ctx, "cloud contains a non-finite coordinate (point %d)", i); return PVLM_ERR_ARG; }
+      if (v < mn[k]) mn[k] = v;
+      if (v > mx[k]) mx[k] = v;
+    }
   pvlm_status st;
   if ((st = pvlm_i_alloc(ctx, &c.d_xyz, (size_t)n * 3))) return st;
   PVLM_HIP(ctx, hipMemcpyAsync(c.d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -673,12 +690,9 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
     PVLM_HIP(ctx, hipMemcpyAsync(c.d_tag, tag, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   }
   if (!build_hash) { PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream)); return PVLM_OK; }
-  // bounding box -> cell edge: surface-like clouds, aim at ~4 points per occupied cell
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = 0; i < n; ++i)
-    for (int k = 0; k < 3; ++k) { const float v = xyz[3 * i + k]; if (v < mn[k]) mn[k] = v; if (v > mx[k]) mx[k] = v; }
+  // cell edge: surface-like clouds, aim at ~4 points per occupied cell
   float e[3];
-  for (int k = 0; k < 3; ++k) { if (!(mx[k] - mn[k] < 1e7f)) { PVLM_SET_ERR(ctx, "cloud contains non-finite coordinates"); return PVLM_ERR_ARG; } e[k] = std::max(mx[k] - mn[k], 0.05f); }
+  for (int k = 0; k < 3; ++k) { if (!(mx[k] - mn[k] < 1e7f)) { PVLM_SET_ERR(ctx, "cloud extent exceeds 1e7"); return PVLM_ERR_ARG; } e[k] = std::max(mx[k] - mn[k], 0.05f); }
   const float area = 2.f * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
   float h = std::sqrt(4.f * area / (float)n);
   const char* env = getenv("PVLM_CELL");
@@ -693,46 +707,39 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
   const bool dense = ncells <= std::max<long long>(64ll * n, 4096) && ncells <= (4ll << 20) && !getenv("PVLM_FORCE_HASH");
   if ((st = pvlm_i_alloc(ctx, &c.d_sorted, (size_t)n))) return st;
   int *d_slot = nullptr, *d_cursor = nullptr, *d_tiles = nullptr;
-  DevScratch scratch;   // the members of `c` allocated so far are released by the caller (pvlm_scan_destroy path)
-  if ((st = scratch.alloc(ctx, &d_tiles, (size_t)((4ll << 20) / SCAN_TILE + 4096)))) return st;
+  DevScratch scratch(ctx);   // the members of `c` allocated so far are released by the caller (pvlm_scan_destroy path)
+  long long T = 0;
+  if (dense) T = ncells + 1;
+  else { T = 1024; while (T < 2ll * n) T <<= 1; }
+  const size_t n_tiles = (size_t)((T + SCAN_TILE - 1) / SCAN_TILE);
+  // k_scan_small handles any tile count (n <= 1024 * per), the tile-sum buffer is sized from the actual table
+  if ((st = scratch.alloc(&d_tiles, n_tiles + 1))) return st;
   hipError_t le = hipSuccess, se = hipSuccess;
+  c.table_size = (int)T;
+  if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
+  if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
+  if ((st = scratch.alloc(&d_slot, (size_t)n))) return st;
+  if ((st = scratch.alloc(&d_cursor, (size_t)T))) return st;
+  hipError_t e1 = hipSuccess;
   if (dense) {
     c.dense = 1; c.nx = (int)dims[0]; c.ny = (int)dims[1]; c.nz = (int)dims[2];
-    c.table_size = (int)ncells + 1;
-    const int T = c.table_size;
-    if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
-    if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
-    if ((st = scratch.alloc(ctx, &d_slot, (size_t)n))) return st;
-    if ((st = scratch.alloc(ctx, &d_cursor, (size_t)T))) return st;
-    hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
-    hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
-    if (e2 != hipSuccess || e3 != hipSuccess) { PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+  } else {
+    if ((st = pvlm_i_alloc(ctx, &c.d_keys, (size_t)T))) return st;
+    e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
+  }
+  hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
+  hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+  if (dense)
     hipLaunchKernelGGL(k_dense_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h, c.nx,
                        c.ny, c.nz, c.d_cell_count, d_slot);
-    launch_scan(ctx, T, c.d_cell_count, c.d_cell_start, d_tiles);
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
-    le = hipGetLastError();
-    se = hipStreamSynchronize(ctx->stream);
-  } else {
-    int T = 1024;
-    while (T < 2 * n) T <<= 1;
-    c.table_size = T;
-    if ((st = pvlm_i_alloc(ctx, &c.d_keys, (size_t)T))) return st;
-    if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
-    if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
-    if ((st = scratch.alloc(ctx, &d_slot, (size_t)n))) return st;
-    if ((st = scratch.alloc(ctx, &d_cursor, (size_t)T))) return st;
-    hipError_t e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
-    hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
-    hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
+  else
     hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h,
-                       T - 1, c.d_keys, c.d_cell_count, d_slot);
-    launch_scan(ctx, T, c.d_cell_count, c.d_cell_start, d_tiles);
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
-    le = hipGetLastError();
-    se = hipStreamSynchronize(ctx->stream);
-  }
+                       (int)T - 1, c.d_keys, c.d_cell_count, d_slot);
+  launch_scan(ctx, (int)T, c.d_cell_count, c.d_cell_start, d_tiles);
+  hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
+  le = hipGetLastError();
+  se = hipStreamSynchronize(ctx->stream);
   if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }
@@ -744,6 +751,35 @@ static CloudView view_of(const pvlm_cloud& c) {
   v.dense = c.dense; v.nx = c.nx; v.ny = c.ny; v.nz = c.nz;
   v.ox = c.origin[0]; v.oy = c.origin[1]; v.oz = c.origin[2]; v.h = c.cell; v.inv_h = c.cell > 0 ? 1.0f / c.cell : 0.f;
   return v;
+}
+
+// (re)sizes the two pipeline slots of the association scratch; grow-only, so a steady state allocates nothing
+static pvlm_status assoc_ws_ensure(pvlm_ctx* ctx, long long rows, int chunks, int pairs) {
+  pvlm_assoc_ws& w = ctx->assoc_ws;
+  rows = std::max<long long>(rows, 1); chunks = std::max(chunks, 1); pairs = std::max(pairs, 1);
+  if (w.rows >= rows && w.chunks >= chunks && w.pairs >= pairs) return PVLM_OK;
+  rows = std::max(rows, w.rows); chunks = std::max(chunks, w.chunks); pairs = std::max(pairs, w.pairs);
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pvlm_i_assoc_ws_free(ctx);
+  pvlm_status st = PVLM_OK;
+  for (int s = 0; s < 2 && !st; ++s) {
+    if (!st) st = pvlm_i_alloc(ctx, &w.d_rec[s], (size_t)rows * 7);
+    if (!st) st = pvlm_i_alloc(ctx, &w.d_nn[s], (size_t)rows * 10);
+    if (!st) st = pvlm_i_alloc(ctx, &w.d_flag[s], (size_t)rows);
+    if (!st) st = pvlm_i_alloc(ctx, &w.d_cc[s], (size_t)chunks);
+    if (!st) st = pvlm_i_alloc(ctx, &w.d_dst[s], (size_t)chunks * 2);
+    if (!st) st = pvlm_i_alloc_bytes(ctx, &w.d_desc[s], (size_t)pairs * sizeof(PairDesc));
+    if (!st && (hipHostMalloc((void**)&w.h_cc[s], (size_t)chunks * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void**)&w.h_dst[s], (size_t)chunks * 2 * sizeof(long long), hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc(&w.h_desc[s], (size_t)pairs * sizeof(PairDesc), hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&w.ev[s], hipEventDisableTiming) != hipSuccess)) {
+      PVLM_SET_ERR(ctx, "association staging: pinned host allocation failed");
+      st = PVLM_ERR_NOMEM;
+    }
+  }
+  if (st) { pvlm_i_assoc_ws_free(ctx); return st; }
+  w.rows = rows; w.chunks = chunks; w.pairs = pairs; w.desc_bytes = (size_t)pairs * sizeof(PairDesc);
+  return PVLM_OK;
 }
 
 extern "C" {
@@ -774,16 +810,13 @@ pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan**
     for (int v : s->h_p2s_ids) if (v < 0 || v >= d->n_segments) { PVLM_SET_ERR(ctx, "point_to_segment id %d out of range", v); st = PVLM_ERR_ARG; break; }
     if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
     if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_ids, s->h_p2s_ids.size());
-    if (!st) {
-      hipError_t e = hipMemcpy(s->d_p2s_off, s->h_p2s_off.data(), s->h_p2s_off.size() * sizeof(int), hipMemcpyHostToDevice);
-      if (e == hipSuccess && tot > 0) e = hipMemcpy(s->d_p2s_ids, s->h_p2s_ids.data(), s->h_p2s_ids.size() * sizeof(int), hipMemcpyHostToDevice);
-      if (e != hipSuccess) { PVLM_SET_ERR(ctx, "p2s upload: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
-    }
+    if (!st) st = pvlm_i_h2d(ctx, s->d_p2s_off, s->h_p2s_off.data(), s->h_p2s_off.size() * sizeof(int));
+    if (!st && tot > 0) st = pvlm_i_h2d(ctx, s->d_p2s_ids, s->h_p2s_ids.data(), s->h_p2s_ids.size() * sizeof(int));
   } else if (!st && d->n_corner > 0) {
     s->h_p2s_off.assign(d->n_corner + 1, 0);
     st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
     if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_ids, 1);
-    if (!st && hipMemset(s->d_p2s_off, 0, s->h_p2s_off.size() * sizeof(int)) != hipSuccess) st = PVLM_ERR_HIP;
+    if (!st && hipMemsetAsync(s->d_p2s_off, 0, s->h_p2s_off.size() * sizeof(int), ctx->stream) != hipSuccess) st = PVLM_ERR_HIP;
   }
   if (!st && d->n_segments > 0) {
     s->n_segments = d->n_segments;
@@ -800,9 +833,8 @@ pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* s) {
   if (!ctx) return PVLM_ERR_ARG;
   if (!s) return PVLM_OK;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  cloud_free(s->flat); cloud_free(s->less); cloud_free(s->corner);
-  hipFree(s->d_p2s_off); hipFree(s->d_p2s_ids);
+  cloud_free(ctx, s->flat); cloud_free(ctx, s->less); cloud_free(ctx, s->corner);
+  pvlm_i_free(ctx, s->d_p2s_off); pvlm_i_free(ctx, s->d_p2s_ids);
   delete s;
   return PVLM_OK;
 }
@@ -833,10 +865,17 @@ pvlm_status pvlm_knn(pvlm_ctx* ctx, const pvlm_scan* scan, int which, const floa
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_knn: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_q); hipFree(d_idx); hipFree(d_sqd);
+  pvlm_i_free(ctx, d_q); pvlm_i_free(ctx, d_idx); pvlm_i_free(ctx, d_sqd);
   return st;
 }
 
+// The call is a two-slot software pipeline over batches of pairs (<= PVLM_ASSOC_BATCH_ROWS query rows, 16 M by
+// default = 1.6 GB of scratch per slot, whatever the size of the pair list):
+//   issue(b):  K2 + K3 of batch b into slot b & 1, accept counts -> pinned host memory, event
+//   finish(b): wait for the event (the GPU is already busy with batch b + 1), size the batch's column block
+//              exactly, take it from the context's pool, upload the destination rows, launch the ordered compaction
+// so the scratch is bounded, the output is exactly sized, nothing is allocated from the driver in a steady state
+// (re-association of every outer iteration reuses the pool) and the host never waits on an idle GPU.
 pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, double plane_tolerance,
                                    float dist_threshold, pvlm_functor kind, unsigned flags, double weight, pvlm_resset** out) {
   if (!ctx || !out || n_pairs < 0 || (n_pairs > 0 && (!ref || !nei))) return PVLM_ERR_ARG;
@@ -852,12 +891,11 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
   rs->kind = kind; rs->flags = flags & 0xFFu; rs->weight = weight; rs->n_pairs = n_pairs; rs->ncols = 7;
   rs->h_ref.resize(n_pairs); rs->h_nei.resize(n_pairs);
   for (int p = 0; p < n_pairs; ++p) { rs->h_ref[p] = ref[p]->id; rs->h_nei[p] = nei[p]->id; }
+  rs->h_out_start.assign(n_pairs + 1, 0);
+  rs->h_seg_start.assign(n_pairs + 1, 0);
+  rs->h_pair_block.assign(n_pairs, 0);
 
-  // ---- pass 1: k-NN + fits for all pairs, batched so the temp arrays stay below ~6 GB ----------
   std::vector<PairDesc> descs(n_pairs);
-  std::vector<int> chunk_of_pair(n_pairs + 1, 0);
-  long long tot_q = 0;
-  int max_nq = 0;
   for (int p = 0; p < n_pairs; ++p) {
     PairDesc& d = descs[p];
     d.ref = view_of(ref[p]->less);
@@ -866,166 +904,135 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     std::memcpy(d.Rn, nei[p]->R_wl, 72); std::memcpy(d.tn, nei[p]->t_wl, 24);
     // a target cloud with fewer than 10 points can never satisfy the k = 10 search
     if (d.ref.n < 10) d.nq = 0;
-    chunk_of_pair[p] = 0;
-    tot_q += d.nq;
-    max_nq = std::max(max_nq, d.nq);
   }
-  const long long budget_rows = 64ll << 20;  // 64 M query rows per batch (~100 B each)
-  std::vector<int> counts_all;               // accepted per pair
-  std::vector<std::vector<int>> chunk_counts(n_pairs);
-  struct Batch { int p0, p1; long long rows; int chunks; double* d_rec; int* d_nn; unsigned char* d_flag; PairDesc* d_desc; };
+  long long budget_rows = 16ll << 20;
+  if (const char* env = getenv("PVLM_ASSOC_BATCH_ROWS")) { const long long v = atoll(env); if (v > 0) budget_rows = v; }
+  struct Batch { int p0, p1; long long rows; int chunks; int bmax; };
   std::vector<Batch> batches;
-  pvlm_status st = PVLM_OK;
-  auto free_batches = [&]() {
-    hipStreamSynchronize(ctx->stream);
-    for (Batch& b : batches) { hipFree(b.d_rec); hipFree(b.d_nn); hipFree(b.d_flag); hipFree(b.d_desc); }
-    batches.clear();
-  };
-#define FAIL(code) do { st = (code); free_batches(); pvlm_i_resset_free(ctx, rs); return st; } while (0)
-  {
-    int p = 0;
-    while (p < n_pairs) {
-      Batch b{p, p, 0, 0, nullptr, nullptr, nullptr, nullptr};
-      while (b.p1 < n_pairs && (b.p1 == b.p0 || b.rows + descs[b.p1].nq <= budget_rows)) {
-        descs[b.p1].tmp_base = b.rows;
-        descs[b.p1].chunk_base = b.chunks;
-        b.rows += descs[b.p1].nq;
-        b.chunks += (descs[b.p1].nq + 255) / 256;
-        ++b.p1;
-      }
-      batches.push_back(b);
-      p = b.p1;
+  long long cap_rows = 0; int cap_chunks = 0, cap_pairs = 0;
+  for (int p = 0; p < n_pairs;) {
+    Batch b{p, p, 0, 0, 0};
+    while (b.p1 < n_pairs && (b.p1 == b.p0 || (b.rows + descs[b.p1].nq <= budget_rows && b.p1 - b.p0 < 32768))) {
+      descs[b.p1].tmp_base = b.rows;
+      descs[b.p1].chunk_base = b.chunks;
+      b.rows += descs[b.p1].nq;
+      b.chunks += (descs[b.p1].nq + 255) / 256;
+      b.bmax = std::max(b.bmax, descs[b.p1].nq);
+      ++b.p1;
     }
+    cap_rows = std::max(cap_rows, b.rows); cap_chunks = std::max(cap_chunks, b.chunks); cap_pairs = std::max(cap_pairs, b.p1 - b.p0);
+    batches.push_back(b);
+    p = b.p1;
   }
-  // All batches keep their temp arrays until the compaction pass (their total is tot_q rows); when
-  // that would exceed the device budget the caller should split the pair list — checked here.
-  {
-    size_t free_b = 0, total_b = 0;
-    hipMemGetInfo(&free_b, &total_b);
-    const double need = (double)tot_q * (7 * 8 + 10 * 4 + 1) * 1.05 + (double)tot_q * 56.0;
-    if (need > 0.9 * (double)free_b) {
-      PVLM_SET_ERR(ctx, "pvlm_assoc_point2plane: %.1f GB of scratch+output needed, %.1f GB free; split the pair list", need / 1e9, free_b / 1e9);
-      FAIL(PVLM_ERR_NOMEM);
-    }
-  }
-  for (Batch& b : batches) {
-    const int nb = b.p1 - b.p0;
-    if ((st = pvlm_i_alloc(ctx, &b.d_rec, (size_t)std::max<long long>(b.rows, 1) * 7))) FAIL(st);
-    if ((st = pvlm_i_alloc(ctx, &b.d_nn, (size_t)std::max<long long>(b.rows, 1) * 10))) FAIL(st);
-    if ((st = pvlm_i_alloc(ctx, &b.d_flag, (size_t)std::max<long long>(b.rows, 1)))) FAIL(st);
-    if ((st = pvlm_i_alloc(ctx, &b.d_desc, (size_t)nb))) FAIL(st);
-    int* d_cc = nullptr;
-    if ((st = pvlm_i_alloc(ctx, &d_cc, (size_t)std::max(b.chunks, 1)))) FAIL(st);
-    std::vector<int> cc(std::max(b.chunks, 1), 0);
-    hipError_t e = hipMemcpyAsync(b.d_desc, &descs[b.p0], (size_t)nb * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cc, 0, (size_t)std::max(b.chunks, 1) * sizeof(int), ctx->stream);
-    int bmax = 0;
-    for (int p = b.p0; p < b.p1; ++p) bmax = std::max(bmax, descs[p].nq);
-    if (e == hipSuccess && bmax > 0) {
+  pvlm_status st = assoc_ws_ensure(ctx, cap_rows, cap_chunks, cap_pairs);
+  if (st) { pvlm_i_resset_free(ctx, rs); return st; }
+  pvlm_assoc_ws& ws = ctx->assoc_ws;
+  const bool lds_env = getenv("PVLM_LDS_KNN") != nullptr;
+
+  auto issue = [&](int bi) -> pvlm_status {
+    const Batch& b = batches[bi];
+    const int s = bi & 1, nb = b.p1 - b.p0;
+    std::memcpy(ws.h_desc[s], &descs[b.p0], (size_t)nb * sizeof(PairDesc));
+    PVLM_HIP(ctx, hipMemcpyAsync(ws.d_desc[s], ws.h_desc[s], (size_t)nb * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
+    const PairDesc* d_desc = static_cast<const PairDesc*>(ws.d_desc[s]);
+    if (b.bmax > 0) {
       pvlm_prof_scope prof(ctx, 2);
-      // LDS-staged search when every target cloud of the batch fits (dense grid, <= 64 KiB with its cell table)
+      // LDS-staged search, opt-in (PVLM_LDS_KNN=1): measured on MI355X it is not faster than the L1/L2-served search
+      // (35.0 vs 33.6 ms for 134 M queries against 2.6 k-point clouds) — the search is bound by top-k maintenance
+      // under SIMD divergence, not by memory latency — and it halves the occupancy.
       size_t lds_need = 0;
-      // opt-in (PVLM_LDS_KNN=1): measured on MI355X it is not faster than the L1/L2-served search
-      // (35.0 vs 33.6 ms for 134 M queries against 2.6 k-point clouds) — the search is bound by top-k
-      // maintenance under SIMD divergence, not by memory latency — and it halves the occupancy.
-      bool lds_ok = getenv("PVLM_LDS_KNN") != nullptr;
+      bool lds_ok = lds_env;
       for (int p = b.p0; p < b.p1 && lds_ok; ++p) {
         const CloudView& v = descs[p].ref;
         if (descs[p].nq == 0) continue;
         if (!v.dense) { lds_ok = false; break; }
         lds_need = std::max(lds_need, (size_t)v.n * sizeof(float4) + ((size_t)v.nx * v.ny * v.nz + 1) * sizeof(int));
       }
-      if (getenv("PVLM_DEBUG")) fprintf(stderr, "[pvlm] knn batch pairs %d..%d: lds_ok=%d lds_need=%zu B\n", b.p0, b.p1, (int)lds_ok, lds_need);
       if (lds_ok && lds_need > 64 * 1024 && lds_need <= 144 * 1024)
         (void)hipFuncSetAttribute((const void*)k_knn_pairs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
       if (lds_ok && lds_need > 0 && lds_need <= 144 * 1024)
-        hipLaunchKernelGGL(k_knn_pairs_lds, dim3((bmax + KNN_LDS_QUERIES - 1) / KNN_LDS_QUERIES, nb), dim3(KNN_LDS_THREADS), (lds_need + 15) & ~(size_t)15,
-                           ctx->stream, b.d_desc, dist_threshold, b.d_nn, b.rows);
+        hipLaunchKernelGGL(k_knn_pairs_lds, dim3((b.bmax + KNN_LDS_QUERIES - 1) / KNN_LDS_QUERIES, nb), dim3(KNN_LDS_THREADS), (lds_need + 15) & ~(size_t)15,
+                           ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
       else
-        hipLaunchKernelGGL(k_knn_pairs, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, dist_threshold, b.d_nn, b.rows);
-      hipLaunchKernelGGL(k_fit_pairs, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, plane_tolerance, b.d_nn, b.d_rec,
-                         b.d_flag, d_cc, b.rows);
-      e = hipGetLastError();
+        hipLaunchKernelGGL(k_knn_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
+      hipLaunchKernelGGL(k_fit_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.d_rec[s],
+                         ws.d_flag[s], ws.d_cc[s], ws.rows);
+      PVLM_HIP(ctx, hipGetLastError());
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(cc.data(), d_cc, (size_t)std::max(b.chunks, 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(d_cc);
-    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "association kernel: %s", hipGetErrorString(e)); FAIL(PVLM_ERR_HIP); }
+    if (b.chunks > 0) PVLM_HIP(ctx, hipMemcpyAsync(ws.h_cc[s], ws.d_cc[s], (size_t)b.chunks * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PVLM_HIP(ctx, hipEventRecord(ws.ev[s], ctx->stream));
+    return PVLM_OK;
+  };
+  auto finish = [&](int bi) -> pvlm_status {
+    const Batch& b = batches[bi];
+    const int s = bi & 1, nb = b.p1 - b.p0;
+    PVLM_HIP(ctx, hipEventSynchronize(ws.ev[s]));
+    long long block_row = 0, block_n = 0;
     for (int p = b.p0; p < b.p1; ++p) {
       const int nc = (descs[p].nq + 255) / 256;
-      chunk_counts[p].assign(cc.begin() + descs[p].chunk_base, cc.begin() + descs[p].chunk_base + nc);
-    }
-  }
-  // ---- segment table ---------------------------------------------------------------------------
-  rs->h_out_start.assign(n_pairs + 1, 0);
-  rs->h_seg_start.assign(n_pairs + 1, 0);
-  for (int p = 0; p < n_pairs; ++p) {
-    long long m = 0;
-    for (int c : chunk_counts[p]) m += c;
-    rs->h_out_start[p + 1] = rs->h_out_start[p] + m;
-    rs->h_seg_start[p + 1] = rs->h_seg_start[p] + ((m + 1) & ~1ll);
-  }
-  rs->n = rs->h_out_start[n_pairs];
-  rs->n_dev = rs->h_seg_start[n_pairs];
-  if ((st = pvlm_i_alloc(ctx, &rs->d_cols, (size_t)std::max<int64_t>(rs->n_dev, 1) * 7))) FAIL(st);
-  if (hipMemsetAsync(rs->d_cols, 0, (size_t)std::max<int64_t>(rs->n_dev, 1) * 7 * sizeof(double), ctx->stream) != hipSuccess) FAIL(PVLM_ERR_HIP);
-  if (keep_idx) {
-    if ((st = pvlm_i_alloc(ctx, &rs->d_qidx, (size_t)std::max<int64_t>(rs->n, 1)))) FAIL(st);
-    if ((st = pvlm_i_alloc(ctx, &rs->d_nn, (size_t)std::max<int64_t>(rs->n, 1) * 10))) FAIL(st);
-  }
-  // ---- pass 2: ordered compaction ------------------------------------------------------------------
-  for (Batch& b : batches) {
-    const int nb = b.p1 - b.p0;
-    std::vector<long long> dst_dev(std::max(b.chunks, 1)), dst_out(std::max(b.chunks, 1));
-    int bmax = 0;
-    for (int p = b.p0; p < b.p1; ++p) {
-      long long dd = rs->h_seg_start[p], oo = rs->h_out_start[p];
-      for (size_t c = 0; c < chunk_counts[p].size(); ++c) {
-        dst_dev[descs[p].chunk_base + c] = dd; dst_out[descs[p].chunk_base + c] = oo;
-        dd += chunk_counts[p][c]; oo += chunk_counts[p][c];
+      rs->h_pair_block[p] = bi;
+      rs->h_seg_start[p] = block_row;
+      long long m = 0;
+      for (int c = 0; c < nc; ++c) {
+        const int ch = descs[p].chunk_base + c;
+        ws.h_dst[s][ch] = block_row + m;                 // row inside the block
+        ws.h_dst[s][b.chunks + ch] = block_n + m;        // compact row inside the block (debug arrays)
+        m += ws.h_cc[s][ch];
       }
-      bmax = std::max(bmax, descs[p].nq);
+      rs->h_out_start[p + 1] = rs->h_out_start[p] + m;
+      block_row += (m + 1) & ~1ll;
+      block_n += m;
     }
-    long long *d_dd = nullptr, *d_oo = nullptr;
-    if ((st = pvlm_i_alloc(ctx, &d_dd, dst_dev.size()))) FAIL(st);
-    if ((st = pvlm_i_alloc(ctx, &d_oo, dst_out.size()))) { hipFree(d_dd); FAIL(st); }
-    hipError_t e = hipMemcpyAsync(d_dd, dst_dev.data(), dst_dev.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_oo, dst_out.data(), dst_out.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && bmax > 0) {
-      hipLaunchKernelGGL(k_compact, dim3((bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, b.d_desc, b.d_flag, b.d_rec, b.d_nn, b.rows, d_dd, d_oo,
-                         rs->d_cols, (long long)rs->n_dev, rs->d_qidx, rs->d_nn);
-      e = hipGetLastError();
+    const long long R = std::max<long long>(block_row, 2);
+    double* d_block = nullptr;
+    pvlm_status sa = pvlm_i_alloc(ctx, &d_block, (size_t)R * 7);
+    if (sa) return sa;
+    rs->col_blocks.push_back(d_block); rs->block_rows.push_back(R); rs->block_n.push_back(block_n);
+    rs->n_dev += R;
+    int32_t *d_q = nullptr, *d_n = nullptr;
+    if (keep_idx) {
+      if ((sa = pvlm_i_alloc(ctx, &d_q, (size_t)std::max<long long>(block_n, 1)))) return sa;
+      rs->d_qidx.push_back(d_q);
+      if ((sa = pvlm_i_alloc(ctx, &d_n, (size_t)std::max<long long>(block_n, 1) * 10))) return sa;
+      rs->d_nn.push_back(d_n);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(d_dd); hipFree(d_oo);
-    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "compaction: %s", hipGetErrorString(e)); FAIL(PVLM_ERR_HIP); }
+    if (block_n > 0) {
+      PVLM_HIP(ctx, hipMemcpyAsync(ws.d_dst[s], ws.h_dst[s], (size_t)b.chunks * 2 * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_compact, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, static_cast<const PairDesc*>(ws.d_desc[s]), ws.d_flag[s],
+                         ws.d_rec[s], ws.d_nn[s], ws.rows, ws.d_dst[s], ws.d_dst[s] + b.chunks, d_block, R, d_q, d_n);
+      PVLM_HIP(ctx, hipGetLastError());
+    }
+    return PVLM_OK;
+  };
+  const int B = (int)batches.size();
+  for (int bi = 0; bi < B && !st; ++bi) {
+    st = issue(bi);
+    if (!st && bi >= 1) st = finish(bi - 1);
   }
-  free_batches();
-#undef FAIL
-  // ---- device segment table + work list --------------------------------------------------------------
-  auto fail2 = [&](pvlm_status c) { pvlm_i_resset_free(ctx, rs); return c; };
-  if ((st = pvlm_i_alloc(ctx, &rs->d_seg_start, (size_t)n_pairs + 1))) return fail2(st);
-  if ((st = pvlm_i_alloc(ctx, &rs->d_out_start, (size_t)n_pairs + 1))) return fail2(st);
-  if ((st = pvlm_i_alloc(ctx, &rs->d_ref, (size_t)n_pairs))) return fail2(st);
-  if ((st = pvlm_i_alloc(ctx, &rs->d_nei, (size_t)n_pairs))) return fail2(st);
-  hipError_t e = hipMemcpy(rs->d_seg_start, rs->h_seg_start.data(), rs->h_seg_start.size() * sizeof(int64_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(rs->d_out_start, rs->h_out_start.data(), rs->h_out_start.size() * sizeof(int64_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess && n_pairs) e = hipMemcpy(rs->d_ref, rs->h_ref.data(), (size_t)n_pairs * sizeof(int), hipMemcpyHostToDevice);
-  if (e == hipSuccess && n_pairs) e = hipMemcpy(rs->d_nei, rs->h_nei.data(), (size_t)n_pairs * sizeof(int), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "segment table upload: %s", hipGetErrorString(e)); return fail2(PVLM_ERR_HIP); }
-  if ((st = pvlm_i_resset_finalize(ctx, rs))) return fail2(st);
+  if (!st && B > 0) st = finish(B - 1);
+  if (!st) {
+    rs->n = rs->h_out_start[n_pairs];
+    st = pvlm_i_resset_finalize(ctx, rs);   // uploads the segment table + work list; the call's one full synchronisation
+  }
+  if (st) { hipStreamSynchronize(ctx->stream); pvlm_i_resset_free(ctx, rs); return st; }
   *out = rs;
   return PVLM_OK;
 }
 
 pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, int32_t* qidx, int32_t* nn) {
   if (!ctx || !rs) return PVLM_ERR_ARG;
-  if (!rs->d_qidx) { PVLM_SET_ERR(ctx, "indices were not kept: pass flag 0x100 to pvlm_assoc_point2plane"); return PVLM_ERR_STATE; }
+  if (rs->n > 0 && rs->d_qidx.empty()) { PVLM_SET_ERR(ctx, "indices were not kept: pass flag 0x100 to pvlm_assoc_point2plane"); return PVLM_ERR_STATE; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   if (rs->n == 0) return PVLM_OK;
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (qidx) PVLM_HIP(ctx, hipMemcpy(qidx, rs->d_qidx, (size_t)rs->n * sizeof(int), hipMemcpyDeviceToHost));
-  if (nn) PVLM_HIP(ctx, hipMemcpy(nn, rs->d_nn, (size_t)rs->n * 10 * sizeof(int), hipMemcpyDeviceToHost));
+  int64_t o = 0;
+  for (size_t b = 0; b < rs->d_qidx.size(); ++b) {
+    const int64_t m = rs->block_n[b];
+    pvlm_status st = PVLM_OK;
+    if (qidx && m) st = pvlm_i_d2h(ctx, qidx + o, rs->d_qidx[b], (size_t)m * sizeof(int));
+    if (!st && nn && m) st = pvlm_i_d2h(ctx, nn + o * 10, rs->d_nn[b], (size_t)m * 10 * sizeof(int));
+    if (st) return st;
+    o += m;
+  }
   return PVLM_OK;
 }
 

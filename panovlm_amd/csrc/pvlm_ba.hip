@@ -108,10 +108,10 @@ __global__ void __launch_bounds__(256) k_ba_eval(pvlm_ba::View v, const double* 
   }
 }
 
-static pvlm_status ba_free(pvlm_baset* s) {
-  hipFree(s->d_pt_off); hipFree(s->d_cam); hipFree(s->d_obs_pt); hipFree(s->d_s); hipFree(s->d_X); hipFree(s->d_Xc); hipFree(s->d_scale);
-  hipFree(s->d_Vinv); hipFree(s->d_gp); hipFree(s->d_adj_off); hipFree(s->d_adj_cam); hipFree(s->d_adj_slot); hipFree(s->d_packed);
-  hipFree(s->d_dcam); hipFree(s->d_small); hipFree(s->d_frozen);
+static pvlm_status ba_free(pvlm_ctx* ctx, pvlm_baset* s) {
+  pvlm_i_free(ctx, s->d_pt_off); pvlm_i_free(ctx, s->d_cam); pvlm_i_free(ctx, s->d_obs_pt); pvlm_i_free(ctx, s->d_s); pvlm_i_free(ctx, s->d_X); pvlm_i_free(ctx, s->d_Xc); pvlm_i_free(ctx, s->d_scale);
+  pvlm_i_free(ctx, s->d_Vinv); pvlm_i_free(ctx, s->d_gp); pvlm_i_free(ctx, s->d_adj_off); pvlm_i_free(ctx, s->d_adj_cam); pvlm_i_free(ctx, s->d_adj_slot); pvlm_i_free(ctx, s->d_packed);
+  pvlm_i_free(ctx, s->d_dcam); pvlm_i_free(ctx, s->d_small); pvlm_i_free(ctx, s->d_frozen);
   delete s;
   return PVLM_OK;
 }
@@ -195,7 +195,7 @@ pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int
   if (!st) st = h2d(ctx, bs->d_adj_cam, adj_cam.data(), adj_cam.size());
   if (!st) st = h2d(ctx, bs->d_adj_slot, adj_slot.data(), adj_slot.size());
   if (!st && hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "reprojection set upload failed"); st = PVLM_ERR_HIP; }
-  if (st) { ba_free(bs); return st; }
+  if (st) { ba_free(ctx, bs); return st; }
   *out = bs;
   return PVLM_OK;
 }
@@ -204,7 +204,7 @@ pvlm_status pvlm_ba_destroy(pvlm_ctx* ctx, pvlm_baset* set) {
   if (!ctx || !set) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   hipStreamSynchronize(ctx->stream);
-  return ba_free(set);
+  return ba_free(ctx, set);
 }
 
 pvlm_status pvlm_ba_structure(const pvlm_baset* set, int* n_points, int64_t* n_obs, int* n_cams, int* n_upairs, int* ui, int* uj) {
@@ -242,7 +242,7 @@ pvlm_status pvlm_ba_set_constant(pvlm_ctx* ctx, pvlm_baset* set, const unsigned 
   if (!ctx || !set) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (!mask) { hipFree(set->d_frozen); set->d_frozen = nullptr; }
+  if (!mask) { pvlm_i_free(ctx, set->d_frozen); set->d_frozen = nullptr; }
   else {
     pvlm_status st;
     if (!set->d_frozen && (st = pvlm_i_alloc(ctx, &set->d_frozen, (size_t)set->n_points))) return st;
@@ -261,14 +261,14 @@ pvlm_status pvlm_ba_eval(pvlm_ctx* ctx, const pvlm_baset* set, double* r, double
   if (set->n_obs == 0) return PVLM_OK;
   double *d_r = nullptr, *d_J = nullptr;
   if ((st = pvlm_i_alloc(ctx, &d_r, (size_t)set->n_obs))) return st;
-  if (J && (st = pvlm_i_alloc(ctx, &d_J, (size_t)set->n_obs * 9))) { hipFree(d_r); return st; }
+  if (J && (st = pvlm_i_alloc(ctx, &d_J, (size_t)set->n_obs * 9))) { pvlm_i_free(ctx, d_r); return st; }
   const pvlm_ba::View v = make_view(set, 0, 0.0);
   hipLaunchKernelGGL(k_ba_eval, dim3((unsigned)((set->n_obs + 255) / 256)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, d_r, d_J);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(r, d_r, (size_t)set->n_obs * 8, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && J) e = hipMemcpyAsync(J, d_J, (size_t)set->n_obs * 72, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  hipFree(d_r); hipFree(d_J);
+  pvlm_i_free(ctx, d_r); pvlm_i_free(ctx, d_J);
   if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_ba_eval: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }

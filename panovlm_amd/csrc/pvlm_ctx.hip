@@ -12,8 +12,133 @@ pvlm_status pvlm_i_bind(pvlm_ctx* ctx) {
   return PVLM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// device memory pool
+// ------------------------------------------------------------------------------------------------
+static const size_t kPoolAlign = 256;
+static const size_t kSlabGranule = 2u << 20;
+static const size_t kSmallSlab = 256u << 20;
+
+static size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
+
+static void pool_insert_free(pvlm_pool& P, char* base, size_t size, int slab) {
+  auto nx = P.free_ranges.lower_bound(base);
+  if (nx != P.free_ranges.end() && nx->second.slab == slab && base + size == nx->first) {   // merge with the next range
+    size += nx->second.size;
+    nx = P.free_ranges.erase(nx);
+  }
+  if (nx != P.free_ranges.begin()) {
+    auto pv = std::prev(nx);
+    if (pv->second.slab == slab && pv->first + pv->second.size == base) { pv->second.size += size; return; }
+  }
+  P.free_ranges.emplace(base, pvlm_pool::Range{size, slab});
+}
+
+static bool pool_add_slab(pvlm_ctx* ctx, size_t bytes) {
+  pvlm_pool& P = ctx->pool;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+  P.device_allocs++;
+  int id = -1;
+  for (size_t i = 0; i < P.slabs.size(); ++i) if (!P.slabs[i].base) { id = (int)i; break; }
+  if (id < 0) { id = (int)P.slabs.size(); P.slabs.push_back({nullptr, 0}); }
+  P.slabs[id] = {(char*)p, bytes};
+  P.reserved += bytes;
+  pool_insert_free(P, (char*)p, bytes, id);
+  return true;
+}
+
+void pvlm_i_pool_release(pvlm_ctx* ctx, bool all) {
+  pvlm_pool& P = ctx->pool;
+  (void)hipStreamSynchronize(ctx->stream);   // ranges freed stream-ordered may still be read by kernels in flight
+  for (size_t i = 0; i < P.slabs.size(); ++i) {
+    pvlm_pool::Slab& s = P.slabs[i];
+    if (!s.base) continue;
+    auto it = P.free_ranges.find(s.base);
+    const bool whole = it != P.free_ranges.end() && it->second.slab == (int)i && it->second.size == s.size;
+    if (!whole && !all) continue;
+    if (whole) P.free_ranges.erase(it);
+    else for (auto f = P.free_ranges.begin(); f != P.free_ranges.end();) f = (f->second.slab == (int)i) ? P.free_ranges.erase(f) : std::next(f);
+    (void)hipFree(s.base);
+    P.reserved -= s.size;
+    s = {nullptr, 0};
+  }
+  if (all) { P.live.clear(); P.in_use = 0; }
+}
+
+pvlm_status pvlm_i_alloc_bytes(pvlm_ctx* ctx, void** out, size_t bytes) {
+  *out = nullptr;
+  pvlm_pool& P = ctx->pool;
+  if (ctx->capturing) { PVLM_SET_ERR(ctx, "device allocation inside a graph capture (run the step once before pvlm_graph_begin)"); return PVLM_ERR_STATE; }
+  if (P.disabled) { PVLM_HIP(ctx, hipMalloc(out, bytes)); P.device_allocs++; return PVLM_OK; }
+  const size_t need = round_up(std::max<size_t>(bytes, 1), kPoolAlign);
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    auto best = P.free_ranges.end();
+    for (auto it = P.free_ranges.begin(); it != P.free_ranges.end(); ++it)
+      if (it->second.size >= need && (best == P.free_ranges.end() || it->second.size < best->second.size)) best = it;
+    if (best != P.free_ranges.end()) {
+      char* base = best->first;
+      const pvlm_pool::Range r = best->second;
+      P.free_ranges.erase(best);
+      if (r.size > need) P.free_ranges.emplace(base + need, pvlm_pool::Range{r.size - need, r.slab});
+      P.live.emplace(base, pvlm_pool::Range{need, r.slab});
+      P.in_use += need;
+      P.peak = std::max(P.peak, P.in_use);
+      *out = base;
+      return PVLM_OK;
+    }
+    // miss: small requests share 256 MB slabs; a large one gets its own slab with 1/8 headroom, so that the next
+    // outer iteration's slightly different size still fits the cached slab
+    size_t slab = need <= kSmallSlab / 2 ? kSmallSlab : round_up(need + need / 8, kSlabGranule);
+    if (attempt == 0 && need > kSmallSlab / 2) pvlm_i_pool_release(ctx, false);   // stale cached slabs could not serve it: give them back first
+    if (pool_add_slab(ctx, slab)) continue;
+    pvlm_i_pool_release(ctx, false);
+    if (pool_add_slab(ctx, round_up(need, kSlabGranule))) continue;
+    break;
+  }
+  PVLM_SET_ERR(ctx, "device allocation of %.3f GB failed (pool: %.3f GB reserved, %.3f GB in use)", bytes / 1e9, P.reserved / 1e9, P.in_use / 1e9);
+  return PVLM_ERR_NOMEM;
+}
+
+void pvlm_i_free(pvlm_ctx* ctx, const void* p) {
+  if (!p) return;
+  pvlm_pool& P = ctx->pool;
+  auto it = P.live.find(p);
+  if (it == P.live.end()) { (void)hipFree(const_cast<void*>(p)); return; }
+  const pvlm_pool::Range r = it->second;
+  P.live.erase(it);
+  P.in_use -= r.size;
+  pool_insert_free(P, (char*)const_cast<void*>(p), r.size, r.slab);
+}
+
+pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return PVLM_OK;
+  PVLM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
+}
+pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return PVLM_OK;
+  PVLM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
+}
+
+void pvlm_i_assoc_ws_free(pvlm_ctx* ctx) {
+  pvlm_assoc_ws& w = ctx->assoc_ws;
+  for (int s = 0; s < 2; ++s) {
+    pvlm_i_free(ctx, w.d_rec[s]); pvlm_i_free(ctx, w.d_nn[s]); pvlm_i_free(ctx, w.d_flag[s]); pvlm_i_free(ctx, w.d_cc[s]);
+    pvlm_i_free(ctx, w.d_dst[s]); pvlm_i_free(ctx, w.d_desc[s]);
+    if (w.h_cc[s]) (void)hipHostFree(w.h_cc[s]);
+    if (w.h_dst[s]) (void)hipHostFree(w.h_dst[s]);
+    if (w.h_desc[s]) (void)hipHostFree(w.h_desc[s]);
+    if (w.ev[s]) (void)hipEventDestroy(w.ev[s]);
+  }
+  w = pvlm_assoc_ws();
+}
+
 pvlm_prof_scope::pvlm_prof_scope(pvlm_ctx* c, int w) : ctx(c), which(w) {
-  if (!ctx->profiling) return;
+  if (!ctx->profiling || ctx->capturing) return;
   auto get = [&]() -> hipEvent_t {
     if (!ctx->prof_pool.empty()) { hipEvent_t e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -58,6 +183,7 @@ pvlm_status pvlm_create(int device, pvlm_ctx** out) {
     return PVLM_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  ctx->pool.disabled = getenv("PVLM_NO_POOL") != nullptr;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   *out = ctx;
@@ -68,7 +194,9 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   if (!ctx) return PVLM_ERR_ARG;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->d_aa); hipFree(ctx->d_t); hipFree(ctx->d_pose_tab); hipFree(ctx->d_ws);
+  pvlm_i_assoc_ws_free(ctx);
+  pvlm_i_free(ctx, ctx->d_aa); pvlm_i_free(ctx, ctx->d_t); pvlm_i_free(ctx, ctx->d_pose_tab); pvlm_i_free(ctx, ctx->d_ws); pvlm_i_free(ctx, ctx->d_neq_tmp);
+  pvlm_i_pool_release(ctx, true);   // objects the caller leaked (scans, residual sets) die with their slabs
   hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
   for (int w = 0; w < 3; ++w) for (auto& pr : ctx->prof_pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
@@ -99,6 +227,88 @@ pvlm_status pvlm_synchronize(pvlm_ctx* ctx) {
   if (!ctx) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (ctx->pool.disabled || bytes == 0) return PVLM_OK;
+  for (auto& f : ctx->pool.free_ranges) if ((int64_t)f.second.size >= bytes) return PVLM_OK;
+  if (!pool_add_slab(ctx, round_up((size_t)bytes, kSlabGranule))) {
+    PVLM_SET_ERR(ctx, "pvlm_reserve: hipMalloc of %.3f GB failed", bytes / 1e9);
+    return PVLM_ERR_NOMEM;
+  }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_trim(pvlm_ctx* ctx) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pvlm_i_assoc_ws_free(ctx);
+  pvlm_i_free(ctx, ctx->d_neq_tmp); ctx->d_neq_tmp = nullptr; ctx->neq_tmp_count = 0;
+  pvlm_i_pool_release(ctx, false);
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_mem_info(const pvlm_ctx* ctx, int64_t* reserved, int64_t* in_use, int64_t* peak, int64_t* device_allocs) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (reserved) *reserved = (int64_t)ctx->pool.reserved;
+  if (in_use) *in_use = (int64_t)ctx->pool.in_use;
+  if (peak) *peak = (int64_t)ctx->pool.peak;
+  if (device_allocs) *device_allocs = (int64_t)ctx->pool.device_allocs;
+  return PVLM_OK;
+}
+
+// ---- HIP graph of a step ------------------------------------------------------------------------
+struct pvlm_graph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+
+pvlm_status pvlm_graph_begin(pvlm_ctx* ctx) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (ctx->capturing) { PVLM_SET_ERR(ctx, "pvlm_graph_begin: a capture is already open"); return PVLM_ERR_STATE; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (ctx->stream == nullptr) { PVLM_SET_ERR(ctx, "pvlm_graph_begin: the legacy default stream cannot be captured; use pvlm_use_own_stream or a created stream"); return PVLM_ERR_STATE; }
+  hipStreamCaptureMode mode = hipStreamCaptureModeThreadLocal;
+  if (const char* e = getenv("PVLM_CAPTURE_MODE")) mode = e[0] == 'g' ? hipStreamCaptureModeGlobal : e[0] == 'r' ? hipStreamCaptureModeRelaxed : mode;
+  PVLM_HIP(ctx, hipStreamBeginCapture(ctx->stream, mode));
+  ctx->capturing = true;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_graph_end(pvlm_ctx* ctx, pvlm_graph** out) {
+  if (!ctx || !out) return PVLM_ERR_ARG;
+  *out = nullptr;
+  if (!ctx->capturing) { PVLM_SET_ERR(ctx, "pvlm_graph_end without pvlm_graph_begin"); return PVLM_ERR_STATE; }
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (e != hipSuccess || !g) { (void)hipGetLastError(); PVLM_SET_ERR(ctx, "hipStreamEndCapture: %s (a call inside the capture was not capturable)", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { hipGraphDestroy(g); PVLM_SET_ERR(ctx, "hipGraphInstantiate: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  pvlm_graph* pg = new (std::nothrow) pvlm_graph();
+  if (!pg) { hipGraphExecDestroy(x); hipGraphDestroy(g); return PVLM_ERR_NOMEM; }
+  pg->graph = g; pg->exec = x;
+  *out = pg;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_graph_launch(pvlm_ctx* ctx, pvlm_graph* g) {
+  if (!ctx || !g || !g->exec) return PVLM_ERR_ARG;
+  if (ctx->capturing) { PVLM_SET_ERR(ctx, "pvlm_graph_launch inside a capture"); return PVLM_ERR_STATE; }
+  PVLM_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_graph_destroy(pvlm_ctx* ctx, pvlm_graph* g) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (!g) return PVLM_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  delete g;
   return PVLM_OK;
 }
 
@@ -174,43 +384,66 @@ pvlm_status pvlm_resset_info(const pvlm_resset* rs, int64_t* n, int* n_pairs, in
 pvlm_status pvlm_i_resset_free(pvlm_ctx* ctx, pvlm_resset* rs) {
   if (!rs) return PVLM_OK;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  hipFree(rs->d_cols); hipFree(rs->d_seg_start); hipFree(rs->d_out_start); hipFree(rs->d_ref); hipFree(rs->d_nei);
-  hipFree(rs->d_blk_pair); hipFree(rs->d_blk_chunk); hipFree(rs->d_pair_blk_start); hipFree(rs->d_pair_tab);
-  hipFree(rs->d_partials); hipFree(rs->d_pair_blocks); hipFree(rs->d_qidx); hipFree(rs->d_nn);
+  // stream-ordered pool: kernels still reading the set are ahead of any later user of its memory on the same stream
+  for (double* b : rs->col_blocks) pvlm_i_free(ctx, b);
+  for (int32_t* b : rs->d_qidx) pvlm_i_free(ctx, b);
+  for (int32_t* b : rs->d_nn) pvlm_i_free(ctx, b);
+  pvlm_i_free(ctx, rs->d_pair_cols); pvlm_i_free(ctx, rs->d_pair_stride); pvlm_i_free(ctx, rs->d_out_start); pvlm_i_free(ctx, rs->d_ref);
+  pvlm_i_free(ctx, rs->d_nei); pvlm_i_free(ctx, rs->d_blk_pair); pvlm_i_free(ctx, rs->d_blk_chunk); pvlm_i_free(ctx, rs->d_pair_blk_start);
+  pvlm_i_free(ctx, rs->d_pair_tab); pvlm_i_free(ctx, rs->d_partials); pvlm_i_free(ctx, rs->d_pair_blocks);
   delete rs;
   return PVLM_OK;
 }
 
-// Needs: kind, n_pairs, h_seg_start, h_out_start, h_ref, h_nei filled; d_cols allocated & filled;
-// d_seg_start / d_out_start / d_ref / d_nei uploaded.  Builds the block work list and scratch.
+// Needs: kind, n_pairs, h_seg_start (row inside the block), h_pair_block, h_out_start, h_ref, h_nei filled; col_blocks /
+// block_rows allocated & filled (or being filled on the stream).  Uploads the segment table, builds the block work list
+// and the scratch.  One host synchronisation at the end (the staging vectors go out of scope).
 pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs) {
   const int P = rs->n_pairs;
+  rs->serial = ++ctx->resset_serial;
   int64_t total = rs->n_dev;
   int64_t chunk = ((total / 4096 + 511) / 512) * 512;
   chunk = std::max<int64_t>(512, std::min<int64_t>(16384, chunk));
   rs->chunk_rows = (int)chunk;
   std::vector<int> blk_pair, blk_chunk, pair_blk_start(P + 1, 0);
+  std::vector<const double*> pair_cols(std::max(P, 1), nullptr);
+  std::vector<int64_t> pair_stride(std::max(P, 1), 0);
   for (int p = 0; p < P; ++p) {
     pair_blk_start[p] = (int)blk_pair.size();
     const int64_t len = rs->h_out_start[p + 1] - rs->h_out_start[p];
     const int nch = (int)((len + chunk - 1) / chunk);
     for (int c = 0; c < nch; ++c) { blk_pair.push_back(p); blk_chunk.push_back(c); }
+    const int b = rs->h_pair_block[p];
+    pair_cols[p] = rs->col_blocks[b] + rs->h_seg_start[p];
+    pair_stride[p] = rs->block_rows[b];
   }
   pair_blk_start[P] = (int)blk_pair.size();
   rs->n_blocks = (int)blk_pair.size();
   pvlm_status st;
+  if ((st = pvlm_i_alloc(ctx, &rs->d_pair_cols, pair_cols.size()))) return st;
+  if ((st = pvlm_i_alloc(ctx, &rs->d_pair_stride, pair_stride.size()))) return st;
+  if ((st = pvlm_i_alloc(ctx, &rs->d_out_start, (size_t)P + 1))) return st;
+  if ((st = pvlm_i_alloc(ctx, &rs->d_ref, (size_t)P))) return st;
+  if ((st = pvlm_i_alloc(ctx, &rs->d_nei, (size_t)P))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_blk_pair, blk_pair.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_blk_chunk, blk_chunk.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_pair_blk_start, pair_blk_start.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_pair_tab, (size_t)std::max(P, 1) * PVLM_PAIR_TAB))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_partials, (size_t)std::max(rs->n_blocks, 1) * PVLM_PARTIAL))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_pair_blocks, (size_t)std::max(P, 1) * PVLM_PAIR_BLOCK))) return st;
-  if (rs->n_blocks) {
-    PVLM_HIP(ctx, hipMemcpyAsync(rs->d_blk_pair, blk_pair.data(), blk_pair.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    PVLM_HIP(ctx, hipMemcpyAsync(rs->d_blk_chunk, blk_chunk.data(), blk_chunk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  }
-  PVLM_HIP(ctx, hipMemcpyAsync(rs->d_pair_blk_start, pair_blk_start.data(), pair_blk_start.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  auto cp = [&](void* d, const void* h, size_t bytes) -> pvlm_status {
+    if (bytes == 0) return PVLM_OK;
+    PVLM_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PVLM_OK;
+  };
+  if ((st = cp(rs->d_pair_cols, pair_cols.data(), (size_t)P * sizeof(double*)))) return st;
+  if ((st = cp(rs->d_pair_stride, pair_stride.data(), (size_t)P * sizeof(int64_t)))) return st;
+  if ((st = cp(rs->d_out_start, rs->h_out_start.data(), rs->h_out_start.size() * sizeof(int64_t)))) return st;
+  if ((st = cp(rs->d_ref, rs->h_ref.data(), (size_t)P * sizeof(int)))) return st;
+  if ((st = cp(rs->d_nei, rs->h_nei.data(), (size_t)P * sizeof(int)))) return st;
+  if ((st = cp(rs->d_blk_pair, blk_pair.data(), blk_pair.size() * sizeof(int)))) return st;
+  if ((st = cp(rs->d_blk_chunk, blk_chunk.data(), blk_chunk.size() * sizeof(int)))) return st;
+  if ((st = cp(rs->d_pair_blk_start, pair_blk_start.data(), pair_blk_start.size() * sizeof(int)))) return st;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
   rs->pair_tab_epoch = ~0ull;
   return PVLM_OK;
@@ -247,6 +480,7 @@ pvlm_status pvlm_resset_upload(pvlm_ctx* ctx, pvlm_functor kind, unsigned flags,
   for (int p = 0; p < n_pairs; ++p) { rs->h_seg_start[p] = o; o += ((rs->h_out_start[p + 1] - rs->h_out_start[p]) + 1) & ~int64_t(1); }
   rs->h_seg_start[n_pairs] = o;
   rs->n_dev = o;
+  rs->h_pair_block.assign(n_pairs, 0);   // an uploaded set is one column block
 
   // host staging: SoA, padded; per-functor normalisations the reference does in its constructors
   std::vector<double> cols((size_t)ncols * std::max<int64_t>(rs->n_dev, 1), 0.0);
@@ -289,22 +523,11 @@ pvlm_status pvlm_resset_upload(pvlm_ctx* ctx, pvlm_functor kind, unsigned flags,
   }
   pvlm_status st = PVLM_OK;
 #define TRY(x) do { if ((st = (x)) != PVLM_OK) { pvlm_i_resset_free(ctx, rs); return st; } } while (0)
-  TRY(pvlm_i_alloc(ctx, &rs->d_cols, cols.size()));
-  TRY(pvlm_i_alloc(ctx, &rs->d_seg_start, (size_t)n_pairs + 1));
-  TRY(pvlm_i_alloc(ctx, &rs->d_out_start, (size_t)n_pairs + 1));
-  TRY(pvlm_i_alloc(ctx, &rs->d_ref, (size_t)n_pairs));
-  TRY(pvlm_i_alloc(ctx, &rs->d_nei, (size_t)n_pairs));
-  auto cp = [&](void* d, const void* h, size_t bytes) -> pvlm_status {
-    if (bytes == 0) return PVLM_OK;
-    PVLM_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return PVLM_OK;
-  };
-  TRY(cp(rs->d_cols, cols.data(), cols.size() * sizeof(double)));
-  TRY(cp(rs->d_seg_start, rs->h_seg_start.data(), rs->h_seg_start.size() * sizeof(int64_t)));
-  TRY(cp(rs->d_out_start, rs->h_out_start.data(), rs->h_out_start.size() * sizeof(int64_t)));
-  TRY(cp(rs->d_ref, rs->h_ref.data(), rs->h_ref.size() * sizeof(int)));
-  TRY(cp(rs->d_nei, rs->h_nei.data(), rs->h_nei.size() * sizeof(int)));
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { pvlm_i_resset_free(ctx, rs); return PVLM_ERR_HIP; }
+  double* d_block = nullptr;
+  TRY(pvlm_i_alloc(ctx, &d_block, cols.size()));
+  rs->col_blocks.push_back(d_block);
+  rs->block_rows.push_back(std::max<int64_t>(rs->n_dev, 1));
+  TRY(pvlm_i_h2d(ctx, d_block, cols.data(), cols.size() * sizeof(double)));
   TRY(pvlm_i_resset_finalize(ctx, rs));
 #undef TRY
   *out = rs;
@@ -323,20 +546,26 @@ pvlm_status pvlm_resset_download(pvlm_ctx* ctx, const pvlm_resset* rs, int64_t* 
   if (pair_ref && rs->n_pairs) std::memcpy(pair_ref, rs->h_ref.data(), rs->h_ref.size() * sizeof(int));
   if (pair_nei && rs->n_pairs) std::memcpy(pair_nei, rs->h_nei.data(), rs->h_nei.size() * sizeof(int));
   if (rows && rs->n > 0) {
-    std::vector<double> cols((size_t)rs->ncols * rs->n_dev);
-    PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PVLM_HIP(ctx, hipMemcpy(cols.data(), rs->d_cols, cols.size() * sizeof(double), hipMemcpyDeviceToHost));
     const int stride = pvlm_i_stride(rs->kind);
-    for (int p = 0; p < rs->n_pairs; ++p)
-      for (int64_t i = rs->h_out_start[p]; i < rs->h_out_start[p + 1]; ++i) {
-        const int64_t d = rs->h_seg_start[p] + (i - rs->h_out_start[p]);
-        double* r = rows + (size_t)i * stride;
-        for (int k = 0; k < rs->ncols; ++k) r[k] = cols[(size_t)k * rs->n_dev + d];
-        if (rs->kind == PVLM_POINT2LINE_METER || rs->kind == PVLM_POINT2LINE_ANGLE) {
-          // device keeps (A, unit direction); hand back B' = A - direction (same line)
-          for (int k = 0; k < 3; ++k) r[6 + k] = r[3 + k] - r[6 + k];
+    std::vector<double> cols;
+    for (size_t b = 0; b < rs->col_blocks.size(); ++b) {
+      const int64_t br = rs->block_rows[b];
+      cols.resize((size_t)rs->ncols * br);
+      pvlm_status st = pvlm_i_d2h(ctx, cols.data(), rs->col_blocks[b], cols.size() * sizeof(double));
+      if (st) return st;
+      for (int p = 0; p < rs->n_pairs; ++p) {
+        if (rs->h_pair_block[p] != (int)b) continue;
+        for (int64_t i = rs->h_out_start[p]; i < rs->h_out_start[p + 1]; ++i) {
+          const int64_t d = rs->h_seg_start[p] + (i - rs->h_out_start[p]);
+          double* r = rows + (size_t)i * stride;
+          for (int k = 0; k < rs->ncols; ++k) r[k] = cols[(size_t)k * br + d];
+          if (rs->kind == PVLM_POINT2LINE_METER || rs->kind == PVLM_POINT2LINE_ANGLE) {
+            // device keeps (A, unit direction); hand back B' = A - direction (same line)
+            for (int k = 0; k < 3; ++k) r[6 + k] = r[3 + k] - r[6 + k];
+          }
         }
       }
+    }
   }
   return PVLM_OK;
 }
@@ -361,8 +590,7 @@ pvlm_status pvlm_neq_destroy(pvlm_ctx* ctx, pvlm_neq* q) {
   if (!ctx) return PVLM_ERR_ARG;
   if (!q) return PVLM_OK;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  hipFree(q->d_diag_off); hipFree(q->d_diag_items); hipFree(q->d_off_off); hipFree(q->d_off_items);
+  pvlm_i_free(ctx, q->d_diag_off); pvlm_i_free(ctx, q->d_diag_items); pvlm_i_free(ctx, q->d_off_off); pvlm_i_free(ctx, q->d_off_items);
   delete q;
   return PVLM_OK;
 }

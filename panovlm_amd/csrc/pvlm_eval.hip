@@ -98,14 +98,15 @@ __global__ void k_pair_table(int P, const int* __restrict__ ref, const int* __re
 // materialise: r[n], J[n x 12] in compact (host) order.
 // ---------------------------------------------------------------------------------------------
 template <int KIND, bool NORM, int NCOLS>
-__global__ __launch_bounds__(256) void k_eval_materialise(const double* __restrict__ cols, int64_t n_dev,
-                                                          const int64_t* __restrict__ seg_start,
+__global__ __launch_bounds__(256) void k_eval_materialise(const double* const* __restrict__ pair_cols,
+                                                          const int64_t* __restrict__ pair_stride,
                                                           const int64_t* __restrict__ out_start,
                                                           const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
                                                           int chunk_rows, const double* __restrict__ pair_tab, double weight,
                                                           double* __restrict__ r_out, double* __restrict__ J_out) {
   const int p = blk_pair[blockIdx.x];
-  const int64_t s0 = seg_start[p];
+  const double* __restrict__ cols = pair_cols[p];   // first row of the pair's segment, column 0
+  const int64_t n_dev = pair_stride[p];             // column stride of the pair's block
   const int64_t o0 = out_start[p];
   const int64_t len = out_start[p + 1] - o0;
   const int64_t lo = (int64_t)blk_chunk[blockIdx.x] * chunk_rows;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* __restri
     if (j < hi) {
       double2 v[NCOLS];
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (j + h >= hi) break;
@@ -208,14 +209,15 @@ __device__ __forceinline__ void accumulate_row(const double* rec, const double* 
 }
 
 template <int KIND, bool NORM, int NCOLS, int LOSS>
-__global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const double* __restrict__ cols, int64_t n_dev,
-                                                    const int64_t* __restrict__ seg_start,
+__global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const double* const* __restrict__ pair_cols,
+                                                    const int64_t* __restrict__ pair_stride,
                                                     const int64_t* __restrict__ out_start,
                                                     const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
                                                     int chunk_rows, const double* __restrict__ pair_tab, double weight,
                                                     double loss_a, double* __restrict__ partials) {
   const int p = blk_pair[blockIdx.x];
-  const int64_t s0 = seg_start[p];
+  const double* __restrict__ cols = pair_cols[p];   // first row of the pair's segment, column 0
+  const int64_t n_dev = pair_stride[p];             // column stride of the pair's block
   const int64_t len = out_start[p + 1] - out_start[p];
   const int64_t lo = (int64_t)blk_chunk[blockIdx.x] * chunk_rows;
   const int64_t hi = min(len, lo + (int64_t)chunk_rows);
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
   double2 nx[NCOLS];
   if (kPrefetch && j < hi) {
 #pragma unroll
-    for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+    for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
   }
   for (; j < hi; j += 512) {
     double2 v[NCOLS];
@@ -244,15 +246,15 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
       for (int c = 0; c < NCOLS; ++c) v[c] = nx[c];
       if (j + 512 < hi) {
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j + 512);
+        for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j + 512);
       }
     } else {
 #ifdef PVLM_EXP_SKIP   // timing experiment only (wrong results): how does the rate respond to fewer bytes per evaluation?
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)(c < NCOLS - PVLM_EXP_SKIP ? c : 0) * n_dev + s0 + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)(c < NCOLS - PVLM_EXP_SKIP ? c : 0) * n_dev + j);
 #else
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + s0 + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
 #endif
     }
 #pragma unroll
@@ -382,8 +384,9 @@ __global__ void k_neq_gather(int n_poses, int n_upairs, const int* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 static pvlm_status ensure_pose_cap(pvlm_ctx* ctx, int n) {
   if (n <= ctx->cap_poses) return PVLM_OK;
+  if (ctx->capturing) { PVLM_SET_ERR(ctx, "pose table would grow inside a graph capture (run the step once before pvlm_graph_begin)"); return PVLM_ERR_STATE; }
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(ctx->d_aa); hipFree(ctx->d_t); hipFree(ctx->d_pose_tab);
+  pvlm_i_free(ctx, ctx->d_aa); pvlm_i_free(ctx, ctx->d_t); pvlm_i_free(ctx, ctx->d_pose_tab);
   ctx->d_aa = ctx->d_t = ctx->d_pose_tab = nullptr;
   ctx->cap_poses = 0;
   pvlm_status st;
@@ -423,19 +426,19 @@ static pvlm_status ensure_pair_table(pvlm_ctx* ctx, const pvlm_resset* crs) {
 
 template <int KIND, bool NORM, int NCOLS>
 static void launch_materialise(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_r, double* d_J) {
-  hipLaunchKernelGGL((k_eval_materialise<KIND, NORM, NCOLS>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_cols, rs->n_dev,
-                     rs->d_seg_start, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_r, d_J);
+  hipLaunchKernelGGL((k_eval_materialise<KIND, NORM, NCOLS>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride,
+                     rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_r, d_J);
 }
 
 template <int KIND, bool NORM, int NCOLS>
 static void launch_fused(pvlm_ctx* ctx, const pvlm_resset* rs, int loss, double a) {
   if (loss == PVLM_LOSS_HUBER)
-    hipLaunchKernelGGL((k_eval_fused<KIND, NORM, NCOLS, PVLM_LOSS_HUBER>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_cols,
-                       rs->n_dev, rs->d_seg_start, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab,
+    hipLaunchKernelGGL((k_eval_fused<KIND, NORM, NCOLS, PVLM_LOSS_HUBER>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_pair_cols,
+                       rs->d_pair_stride, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab,
                        rs->weight, a, rs->d_partials);
   else
-    hipLaunchKernelGGL((k_eval_fused<KIND, NORM, NCOLS, PVLM_LOSS_NONE>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_cols,
-                       rs->n_dev, rs->d_seg_start, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab,
+    hipLaunchKernelGGL((k_eval_fused<KIND, NORM, NCOLS, PVLM_LOSS_NONE>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_pair_cols,
+                       rs->d_pair_stride, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab,
                        rs->weight, a, rs->d_partials);
 }
 
@@ -510,7 +513,7 @@ pvlm_status pvlm_eval(pvlm_ctx* ctx, const pvlm_resset* rs, double* r, double* J
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_eval copy-back: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_r); hipFree(d_J);
+  pvlm_i_free(ctx, d_r); pvlm_i_free(ctx, d_J);
   return st;
 }
 
@@ -543,7 +546,9 @@ pvlm_status pvlm_eval_pair_blocks(pvlm_ctx* ctx, const pvlm_resset* rs, pvlm_los
 }
 
 static pvlm_status neq_bind(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs) {
-  if (q->bound == rs) return PVLM_OK;
+  if (q->bound == rs && q->bound_serial == rs->serial) return PVLM_OK;
+  if (ctx->capturing) { PVLM_SET_ERR(ctx, "normal equations not bound to this residual set yet (run the step once before pvlm_graph_begin)"); return PVLM_ERR_STATE; }
+  q->bound = nullptr;
   const int P = rs->n_pairs;
   std::vector<std::vector<int>> diag(q->n_poses), off(q->n_upairs);
   // unordered pair lookup
@@ -567,19 +572,20 @@ static pvlm_status neq_bind(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs) {
   doff[q->n_poses] = (int)ditems.size();
   for (int u = 0; u < q->n_upairs; ++u) { ooff[u] = (int)oitems.size(); oitems.insert(oitems.end(), off[u].begin(), off[u].end()); }
   ooff[q->n_upairs] = (int)oitems.size();
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(q->d_diag_off); hipFree(q->d_diag_items); hipFree(q->d_off_off); hipFree(q->d_off_items);
+  pvlm_i_free(ctx, q->d_diag_off); pvlm_i_free(ctx, q->d_diag_items); pvlm_i_free(ctx, q->d_off_off); pvlm_i_free(ctx, q->d_off_items);
   q->d_diag_off = q->d_diag_items = q->d_off_off = q->d_off_items = nullptr;
   pvlm_status st;
   if ((st = pvlm_i_alloc(ctx, &q->d_diag_off, doff.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &q->d_diag_items, ditems.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &q->d_off_off, ooff.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &q->d_off_items, oitems.size()))) return st;
-  PVLM_HIP(ctx, hipMemcpy(q->d_diag_off, doff.data(), doff.size() * sizeof(int), hipMemcpyHostToDevice));
-  if (!ditems.empty()) PVLM_HIP(ctx, hipMemcpy(q->d_diag_items, ditems.data(), ditems.size() * sizeof(int), hipMemcpyHostToDevice));
-  PVLM_HIP(ctx, hipMemcpy(q->d_off_off, ooff.data(), ooff.size() * sizeof(int), hipMemcpyHostToDevice));
-  if (!oitems.empty()) PVLM_HIP(ctx, hipMemcpy(q->d_off_items, oitems.data(), oitems.size() * sizeof(int), hipMemcpyHostToDevice));
+  PVLM_HIP(ctx, hipMemcpyAsync(q->d_diag_off, doff.data(), doff.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (!ditems.empty()) PVLM_HIP(ctx, hipMemcpyAsync(q->d_diag_items, ditems.data(), ditems.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  PVLM_HIP(ctx, hipMemcpyAsync(q->d_off_off, ooff.data(), ooff.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (!oitems.empty()) PVLM_HIP(ctx, hipMemcpyAsync(q->d_off_items, oitems.data(), oitems.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // pageable staging vectors go out of scope
   q->bound = rs;
+  q->bound_serial = rs->serial;
   return PVLM_OK;
 }
 
@@ -600,23 +606,22 @@ pvlm_status pvlm_neq_accumulate_dev(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resse
 pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs, pvlm_loss loss, double a, int zero_first, double* packed) {
   if (!ctx || !q || !rs || !packed) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  const size_t nb = (size_t)pvlm_neq_size(q) * sizeof(double);
-  double* d = nullptr;
-  pvlm_status st = pvlm_i_alloc(ctx, &d, (size_t)pvlm_neq_size(q));
-  if (st) return st;
-  hipError_t e = hipSuccess;
-  if (!zero_first) e = hipMemcpyAsync(d, packed, nb, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { hipFree(d); PVLM_SET_ERR(ctx, "neq upload: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
-  st = pvlm_neq_accumulate_dev(ctx, q, rs, loss, a, zero_first, d);
-  if (!st) {
-    e = hipMemcpyAsync(packed, d, nb, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "neq download: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  const size_t cnt = (size_t)pvlm_neq_size(q);
+  const size_t nb = cnt * sizeof(double);
+  // the device copy of the packed buffer lives as long as the context (an LM driver calls this every evaluation)
+  if (ctx->neq_tmp_count < cnt) {
+    pvlm_i_free(ctx, ctx->d_neq_tmp); ctx->d_neq_tmp = nullptr; ctx->neq_tmp_count = 0;
+    pvlm_status sa = pvlm_i_alloc(ctx, &ctx->d_neq_tmp, cnt);
+    if (sa) return sa;
+    ctx->neq_tmp_count = cnt;
   }
-  hipStreamSynchronize(ctx->stream);
-  hipFree(d);
-  return st;
+  double* d = ctx->d_neq_tmp;
+  if (!zero_first) PVLM_HIP(ctx, hipMemcpyAsync(d, packed, nb, hipMemcpyHostToDevice, ctx->stream));
+  pvlm_status st = pvlm_neq_accumulate_dev(ctx, q, rs, loss, a, zero_first, d);
+  if (st) return st;
+  PVLM_HIP(ctx, hipMemcpyAsync(packed, d, nb, hipMemcpyDeviceToHost, ctx->stream));
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
 }
 
 }  // extern "C"

@@ -4,7 +4,9 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pvlm.h"
@@ -18,8 +20,46 @@
 // Fused partial: [S upper triangle (21) | gv (6) | cost (1)]
 #define PVLM_PARTIAL 28
 
+// Device memory of a context comes from a caching sub-allocator: hipMalloc maps pages at 40-70 ms per GB on MI355X
+// (tools/micro/alloc_cost.hip: 16 GB 0.64 s, 48 GB 1.9-3.5 s), which made the association call 27x slower than
+// its kernels.  Slabs are obtained with hipMalloc (or reserved up front by pvlm_reserve), carved best-fit,
+// coalesced on free and kept until pvlm_trim / pvlm_destroy.  Reuse is stream-ordered: every access of the
+// library goes through the context's one stream, so a freed range may be handed out again immediately.
+struct pvlm_pool {
+  struct Range { size_t size; int slab; };
+  struct Slab { char* base; size_t size; };
+  std::vector<Slab> slabs;
+  std::map<char*, Range> free_ranges;             // address-ordered, coalesced inside a slab
+  std::unordered_map<const void*, Range> live;
+  size_t reserved = 0, in_use = 0, peak = 0;
+  uint64_t device_allocs = 0;                     // hipMalloc calls made (a steady state makes none)
+  bool disabled = false;                          // PVLM_NO_POOL=1: plain hipMalloc / hipFree
+};
+
+// scratch of pvlm_assoc_point2plane that survives the call (two pipeline slots + pinned host staging)
+struct pvlm_assoc_ws {
+  long long rows = 0; int chunks = 0, pairs = 0;  // capacity of one slot
+  double* d_rec[2] = {nullptr, nullptr};
+  int* d_nn[2] = {nullptr, nullptr};
+  unsigned char* d_flag[2] = {nullptr, nullptr};
+  int* d_cc[2] = {nullptr, nullptr};
+  long long* d_dst[2] = {nullptr, nullptr};       // 2 x chunks: device row, compact row
+  void* d_desc[2] = {nullptr, nullptr};
+  int* h_cc[2] = {nullptr, nullptr};              // pinned
+  long long* h_dst[2] = {nullptr, nullptr};       // pinned
+  void* h_desc[2] = {nullptr, nullptr};           // pinned
+  size_t desc_bytes = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
 struct pvlm_ctx {
   int device = 0;
+  pvlm_pool pool;
+  pvlm_assoc_ws assoc_ws;
+  uint64_t resset_serial = 0;  // every residual set gets a fresh serial (pvlm_neq caches its binding by it)
+  bool capturing = false;      // between pvlm_graph_begin and pvlm_graph_end: no allocation, no synchronisation
+  // persistent packed buffer of pvlm_neq_accumulate (host-pointer form)
+  double* d_neq_tmp = nullptr; size_t neq_tmp_count = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -55,11 +95,19 @@ struct pvlm_resset {
   unsigned flags = 0;
   double weight = 1.0;
   int64_t n = 0;       // residual blocks (compact / host order)
-  int64_t n_dev = 0;   // padded device rows (every segment starts at an even row)
+  int64_t n_dev = 0;   // padded device rows over all column blocks (every segment starts at an even row)
+  uint64_t serial = 0; // unique per set and context (see pvlm_ctx::resset_serial)
   int n_pairs = 0;
   int ncols = 0;       // SoA columns
-  double* d_cols = nullptr;       // ncols x n_dev, column-major (column c at d_cols + c*n_dev)
-  int64_t* d_seg_start = nullptr; // n_pairs+1, padded device row offsets (host-uploaded or device-built)
+  // Column storage: one or more blocks; block b is ncols x block_rows[b] doubles, column-major (column c at
+  // block + c*block_rows[b]).  A pair segment lives in exactly one block.  An uploaded set has one block; the
+  // association writes one block per batch of pairs, so that its scratch stays bounded and no pass over all
+  // pairs has to finish before the first correspondence is written.
+  std::vector<double*> col_blocks;
+  std::vector<int64_t> block_rows;          // even
+  std::vector<int> h_pair_block;            // n_pairs: block of the pair
+  const double** d_pair_cols = nullptr;     // n_pairs: address of the pair's first row in column 0
+  int64_t* d_pair_stride = nullptr;         // n_pairs: column stride (rows) of the pair's block
   int64_t* d_out_start = nullptr; // n_pairs+1, compact offsets
   int* d_ref = nullptr;
   int* d_nei = nullptr;
@@ -73,19 +121,22 @@ struct pvlm_resset {
   uint64_t pair_tab_epoch = ~0ull;
   double* d_partials = nullptr;     // n_blocks x PVLM_PARTIAL
   double* d_pair_blocks = nullptr;  // n_pairs x PVLM_PAIR_BLOCK (scratch for neq accumulate)
-  // host mirrors of the segment table
+  // host mirrors of the segment table (h_seg_start: first row of the pair INSIDE its block, n_pairs entries)
   std::vector<int64_t> h_seg_start, h_out_start;
   std::vector<int> h_ref, h_nei;
-  // optional association debug
-  int32_t* d_qidx = nullptr;  // n (compact)
-  int32_t* d_nn = nullptr;    // n x 10 (compact)
+  // optional association debug, per column block (compact order inside the block; blocks are in pair order)
+  std::vector<int32_t*> d_qidx;  // rows of the block
+  std::vector<int32_t*> d_nn;    // rows x 10
+  std::vector<int64_t> block_n;  // accepted rows of the block
 };
 
 struct pvlm_neq {
   int n_poses = 0, n_upairs = 0;
   std::vector<int> ui, uj;
-  // binding to a residual set (rebuilt when the set changes)
+  // binding to a residual set (rebuilt when the set changes).  Keyed by the set's serial, not only by its
+  // address: a set destroyed and re-created by a re-association routinely gets the old address back.
   const pvlm_resset* bound = nullptr;
+  uint64_t bound_serial = 0;
   int* d_diag_off = nullptr;   // n_poses+1 : CSR of (pair, role) incident to each pose
   int* d_diag_items = nullptr; // item = pair*2 + role (0 = pose is ref, 1 = pose is nei)
   int* d_off_off = nullptr;    // n_upairs+1
@@ -139,13 +190,19 @@ struct pvlm_scan {
 
 // helpers implemented in pvlm_ctx.hip
 pvlm_status pvlm_i_bind(pvlm_ctx* ctx);  // hipSetDevice(ctx->device)
+pvlm_status pvlm_i_alloc_bytes(pvlm_ctx* ctx, void** p, size_t bytes);   // from the context's pool
+void pvlm_i_free(pvlm_ctx* ctx, const void* p);                           // back to the pool (NULL ok; foreign pointers go to hipFree)
+void pvlm_i_pool_release(pvlm_ctx* ctx, bool all);                        // hipFree the fully free slabs (all: every slab, at destroy)
 template <typename T>
 inline pvlm_status pvlm_i_alloc(pvlm_ctx* ctx, T** p, size_t count) {
   *p = nullptr;
   if (count == 0) count = 1;
-  PVLM_HIP(ctx, hipMalloc((void**)p, count * sizeof(T)));
-  return PVLM_OK;
+  return pvlm_i_alloc_bytes(ctx, (void**)p, count * sizeof(T));
 }
+// host -> device through the context stream (pageable source: returns when the source may be reused)
+pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
+pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
+void pvlm_i_assoc_ws_free(pvlm_ctx* ctx);
 // builds work list + scratch for a resset whose segment table is final (h_* mirrors filled)
 pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs);
 pvlm_status pvlm_i_resset_free(pvlm_ctx* ctx, pvlm_resset* rs);

@@ -271,8 +271,9 @@ struct WsCarver {
 static pvlm_status ws_reserve(pvlm_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return PVLM_OK;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(ctx->d_ws); ctx->d_ws = nullptr; ctx->ws_bytes = 0;
-  PVLM_HIP(ctx, hipMalloc(&ctx->d_ws, bytes));
+  pvlm_i_free(ctx, ctx->d_ws); ctx->d_ws = nullptr; ctx->ws_bytes = 0;
+  pvlm_status st = pvlm_i_alloc_bytes(ctx, &ctx->d_ws, bytes);
+  if (st) return st;
   ctx->ws_bytes = bytes;
   return PVLM_OK;
 }
@@ -364,7 +365,7 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_A); hipFree(d_B); hipFree(d_Linv); hipFree(d_y); hipFree(d_info);
+  pvlm_i_free(ctx, d_A); pvlm_i_free(ctx, d_B); pvlm_i_free(ctx, d_Linv); pvlm_i_free(ctx, d_y); pvlm_i_free(ctx, d_info);
   return st;
 }
 

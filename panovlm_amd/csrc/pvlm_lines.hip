@@ -262,7 +262,7 @@ static pvlm_status run_map(pvlm_ctx* ctx, long long n, const T* in, int in_w, T*
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "equirect map: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_in); hipFree(d_out);
+  pvlm_i_free(ctx, d_in); pvlm_i_free(ctx, d_out);
   return st;
 }
 
@@ -320,7 +320,7 @@ pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t 
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "project_lidar_depth: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_xyz); hipFree(d_T); hipFree(d_img); hipFree(d_out);
+  pvlm_i_free(ctx, d_xyz); pvlm_i_free(ctx, d_T); pvlm_i_free(ctx, d_img); pvlm_i_free(ctx, d_out);
   return st;
 }
 
@@ -396,7 +396,7 @@ static pvlm_status run_vote_batch(pvlm_ctx* ctx, const std::vector<D>& desc, con
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "batched votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_desc); hipFree(d_work); hipFree(d_tab); hipFree(d_v);
+  pvlm_i_free(ctx, d_desc); pvlm_i_free(ctx, d_work); pvlm_i_free(ctx, d_tab); pvlm_i_free(ctx, d_v);
   return st;
 }
 
@@ -494,7 +494,7 @@ pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "line votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_l); hipFree(d_v);
+  pvlm_i_free(ctx, d_l); pvlm_i_free(ctx, d_v);
   return st;
 }
 
@@ -528,7 +528,7 @@ pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float*
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "cam-lidar votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_tab); hipFree(d_T); hipFree(d_v);
+  pvlm_i_free(ctx, d_tab); pvlm_i_free(ctx, d_T); pvlm_i_free(ctx, d_v);
   return st;
 }
 

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
   float c = -1.f;
   PatchRegs P;
   wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, P);
-  if (P.inside && !(P.sq0 <= 1e-6) && P.sq0 > 0) {
+  if (P.inside && P.sq0 > 0) {   // InitConfMap :602 tests sq0 > 0 only (InitPatchMap ignores FillPixelPatch's 1e-6 verdict; that gate is PropagateCheckerBoard's, :1116)
     const float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
     c = wave_score(rows, cols, half_window, step, n, lane, unit, nb, px, py, P, nrm3, dep, nullptr, 0);
   }
@@ -264,7 +264,7 @@ pvlm_status pvlm_mvs_filter_depth(pvlm_ctx* ctx, int rows, int cols, int n_neigh
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_filter_depth: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_unit); hipFree(d_nd); hipFree(d_proj); hipFree(d_depth); hipFree(d_conf); hipFree(d_out); hipFree(d_cout); hipFree(d_const);
+  pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_nd); pvlm_i_free(ctx, d_proj); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_out); pvlm_i_free(ctx, d_cout); pvlm_i_free(ctx, d_const);
   return st;
 }
 
@@ -329,7 +329,7 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_filter_depth_refine: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_unit); hipFree(d_nd); hipFree(d_nc); hipFree(d_key); hipFree(d_depth); hipFree(d_conf); hipFree(d_out); hipFree(d_cout); hipFree(d_const);
+  pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_nd); pvlm_i_free(ctx, d_nc); pvlm_i_free(ctx, d_key); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_out); pvlm_i_free(ctx, d_cout); pvlm_i_free(ctx, d_const);
   return st;
 }
 
@@ -398,7 +398,7 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "%s: %s", what, hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(d_img); hipFree(d_unit); hipFree(d_depth); hipFree(d_normal); hipFree(d_conf); hipFree(d_ndepth); hipFree(d_const);
+  pvlm_i_free(ctx, d_img); pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_normal); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_ndepth); pvlm_i_free(ctx, d_const);
   return st;
 }
 
@@ -442,8 +442,8 @@ pvlm_status pvlm_mvs_views_destroy(pvlm_ctx* ctx, pvlm_mvs_views* v) {
   if (!v) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   hipStreamSynchronize(ctx->stream);
-  hipFree(v->d_gray); hipFree(v->d_depth); hipFree(v->d_normal); hipFree(v->d_conf); hipFree(v->d_depth_filter); hipFree(v->d_conf_filter);
-  hipFree(v->d_unit); hipFree(v->d_key); hipFree(v->d_const);
+  pvlm_i_free(ctx, v->d_gray); pvlm_i_free(ctx, v->d_depth); pvlm_i_free(ctx, v->d_normal); pvlm_i_free(ctx, v->d_conf); pvlm_i_free(ctx, v->d_depth_filter); pvlm_i_free(ctx, v->d_conf_filter);
+  pvlm_i_free(ctx, v->d_unit); pvlm_i_free(ctx, v->d_key); pvlm_i_free(ctx, v->d_const);
   delete v;
   return PVLM_OK;
 }

@@ -1292,7 +1292,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   auto full_diag = [&](const Assembled& As, const Reduced& Rs) {
     std::vector<double> d(n_free, 0.0);
     for (auto& kv : As.H) if (kv.first.first == kv.first.second)
-      for (int r = 0; r < 6; ++r) { const int i = idx(kv.first.first, r); if (i >= 0) d[i] = kv.second[r * 6 + r]; }
+      for (int r = 0; r < 6; ++r) { const int i = idx(kv.first.first, r); if (i >= 0) d[i] += kv.second[r * 6 + r]; }   // += : two poses may share a parameter block
     for (int i = 0; i < n_free; ++i) d[i] += Rs.Udiag[i];
     return d;
   };

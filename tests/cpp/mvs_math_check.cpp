@@ -31,7 +31,7 @@ extern "C" void chk_mvs_conf(int rows, int cols, int half_window, int step, cons
         for (int k = 0; k < n; ++k) { w[k] /= wsum; mean += w[k] * t0[k]; }
         for (int k = 0; k < n; ++k) { t0[k] -= mean; const float tmp = t0[k] * w[k]; sq0 += t0[k] * tmp; t0[k] = tmp; }
       }
-      if (inside && !(sq0 <= 1e-6) && sq0 > 0) {
+      if (inside && sq0 > 0) {
         const float* u0 = &unit[3 * e];
         const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
         const float* nr = normal + 3 * e;

@@ -1,0 +1,241 @@
+"""Runtime around the kernels, on the GPU and through the C ABI: the context's device pool (a steady state makes no
+hipMalloc), the streamed association (any batch size gives the same residual set, bit for bit), the binding of
+pvlm_neq to a residual set that was destroyed and re-created, the HIP graph of an LM step, and the sharded path
+executed by HIP kernels: two ranks sharing GPU 0, each associating + accumulating its shard of the pair list,
+all-reduce, equal to the single-rank packed buffer (the loop that is sharded is
+util/Optimization.cpp:521-560)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+try:        # torch bundles its own HIP runtime: when both are in one process it has to be loaded before libpvlm.so
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
+from panovlm_amd import sharding as sh
+from panovlm_amd import synthetic as sy
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEEP = 0x100
+LOSS_A = 2 * np.pi / 180
+
+
+def _scans(F, cols=256):
+    return {k: sy.make_scan(k, cols=cols, downsample_targets=0.2) for k in range(F)}
+
+
+def _poses(F):
+    ps = [sy.pose_params(*sy.estimated_pose(k)) for k in range(F)]
+    return np.array([p[0] for p in ps]), np.array([p[1] for p in ps])
+
+
+def _associate(ctx, pv, dev, ref, nei, flags=0):
+    return ctx.assoc_point2plane([dev[int(r)] for r in ref], [dev[int(n)] for n in nei], 0.05, 1.0, kind=pv.POINT2PLANE_ANGLE,
+                                 flags=pv.FLAG_NORMALIZE_DISTANCE | flags)
+
+
+def test_pool_steady_state_and_streamed_batches_bit_exact():
+    import panovlm_amd as pv
+    F = 6
+    scans = _scans(F)
+    ref, nei = sy.pair_list(F, 4)
+    ctx = pv.Context(0)
+    dev = {k: pv.Scan(ctx, s) for k, s in scans.items()}
+    rs = _associate(ctx, pv, dev, ref, nei, KEEP)
+    off0, r0, n0, rows0 = rs.download()
+    q0, nn0 = rs.assoc_debug()
+    rs.close()
+    a0 = ctx.mem_info()
+    assert a0["reserved"] > 0 and a0["peak"] >= a0["in_use"]
+    # second and third call: same sizes -> served entirely by the pool
+    for _ in range(2):
+        rs = _associate(ctx, pv, dev, ref, nei, KEEP)
+        off1, r1, n1, rows1 = rs.download()
+        assert np.array_equal(off0, off1) and np.array_equal(rows0, rows1)
+        rs.close()
+    a1 = ctx.mem_info()
+    assert a1["device_allocs"] == a0["device_allocs"], (a0, a1)
+    assert a1["in_use"] == a0["in_use"]
+    for d in dev.values():
+        d.close()
+    ctx.trim()
+    assert ctx.mem_info()["in_use"] <= a0["in_use"]
+    ctx.close()
+    # tiny batches: every pair its own batch, odd / even pipeline slots, many column blocks
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "import panovlm_amd as pv\nfrom panovlm_amd import synthetic as sy\n"
+        "F = 6; scans = {k: sy.make_scan(k, cols=256, downsample_targets=0.2) for k in range(F)}\n"
+        "ref, nei = sy.pair_list(F, 4)\n"
+        "ctx = pv.Context(0); dev = {k: pv.Scan(ctx, s) for k, s in scans.items()}\n"
+        "rs = ctx.assoc_point2plane([dev[int(r)] for r in ref], [dev[int(n)] for n in nei], 0.05, 1.0, kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE | 0x100)\n"
+        "off, r, n, rows = rs.download(); q, nn = rs.assoc_debug()\n"
+        "aa = np.zeros((F, 3)); t = np.zeros((F, 3)); ctx.set_poses(aa, t)\n"
+        "res, J = rs.eval(jac=True); blocks = rs.pair_blocks(pv.LOSS_HUBER, 0.03)\n"
+        "np.savez(sys.argv[1], off=off, rows=rows, q=q, nn=nn, res=res, J=J, blocks=blocks)\n" % ROOT)
+    out = {}
+    for tag, rows_env in (("small", "5000"), ("default", None)):
+        env = dict(os.environ)
+        if rows_env:
+            env["PVLM_ASSOC_BATCH_ROWS"] = rows_env
+        path = "/tmp/pvlm_stream_%s_%d.npz" % (tag, os.getpid())
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+        out[tag] = dict(np.load(path))
+        os.remove(path)
+    assert np.array_equal(out["default"]["off"], off0) and np.array_equal(out["default"]["rows"], rows0)
+    assert np.array_equal(out["default"]["q"], q0) and np.array_equal(out["default"]["nn"], nn0)
+    for k in ("off", "rows", "q", "nn", "res", "J", "blocks"):
+        assert np.array_equal(out["small"][k], out["default"][k]), k
+
+
+def test_neq_rebinds_when_a_set_is_recreated_at_the_same_address():
+    """pvlm_neq cached its gather lists by the address of the residual set; a set destroyed and re-created
+    by a re-association usually gets the old address back."""
+    import panovlm_amd as pv
+    from tests import synth
+    rng = np.random.default_rng(5)
+    F = 7
+    aa, t = synth.random_poses(rng, F)
+    ctx = pv.Context(0)
+    ctx.set_poses(aa, t)
+    pairs_a = (np.array([0, 1, 2, 3], np.int32), np.array([1, 2, 3, 4], np.int32))
+    pairs_b = (np.array([4, 5, 6, 2], np.int32), np.array([5, 6, 4, 0], np.int32))   # same count, different structure
+    ui, uj = sh.unordered_pairs(np.concatenate([pairs_a[0], pairs_b[0]]), np.concatenate([pairs_a[1], pairs_b[1]]))
+    neq = pv.NormalEq(ctx, F, ui, uj)
+    got, want = [], []
+    for ref, nei in (pairs_a, pairs_b, pairs_a):
+        rows, off = synth.random_resset(rng, pv.POINT2PLANE_ANGLE, aa, t, ref, nei, np.full(len(ref), 40))
+        rs = pv.ResidualSet.upload(ctx, pv.POINT2PLANE_ANGLE, rows, off, ref, nei, flags=pv.FLAG_NORMALIZE_DISTANCE)
+        got.append(neq.accumulate(rs, pv.LOSS_HUBER, LOSS_A))
+        want.append(sh.pack_from_pair_blocks(rs.pair_blocks(pv.LOSS_HUBER, LOSS_A), ref, nei, F, ui, uj))
+        rs.close()     # the next upload has the same sizes: the allocator hands the same addresses out again
+    for g, w in zip(got, want):
+        assert np.allclose(g, w, rtol=1e-12, atol=1e-12 * np.abs(w).max())
+    assert not np.allclose(got[0], got[1])
+    neq.close()
+    ctx.close()
+
+
+def test_graph_of_a_step_equals_eager_steps():
+    import torch
+    import panovlm_amd as pv
+    F = 8
+    scans = _scans(F)
+    ref, nei = sy.pair_list(F, 4)
+    aa, t = _poses(F)
+    ui, uj = sh.unordered_pairs(ref, nei)
+    dev_t = torch.device("cuda", 0)
+    ctx = pv.Context(0)                       # own (capturable) stream
+    dev = {k: pv.Scan(ctx, s) for k, s in scans.items()}
+    rs = _associate(ctx, pv, dev, ref, nei)
+    neq = pv.NormalEq(ctx, F, ui, uj)
+    d_aa = torch.from_numpy(aa.copy()).to(dev_t); d_t = torch.from_numpy(t.copy()).to(dev_t)
+    packed = torch.zeros(neq.size, dtype=torch.float64, device=dev_t)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
+        neq.accumulate_dev(rs, packed.data_ptr(), pv.LOSS_HUBER, LOSS_A, zero_first=True)
+
+    step(); ctx.synchronize()
+    eager0 = packed.cpu().numpy().copy()
+    ctx.graph_begin()
+    step()
+    g = ctx.graph_end()
+    packed.zero_(); torch.cuda.synchronize()
+    g.launch(); ctx.synchronize()
+    assert np.array_equal(packed.cpu().numpy(), eager0)          # same kernels, same order: bit-identical
+    # new parameter point: the graph reads the pose arrays it was captured with
+    d_t.add_(0.01); d_aa.mul_(1.01); torch.cuda.synchronize()
+    g.launch(); ctx.synchronize()
+    replay = packed.cpu().numpy().copy()
+    step(); ctx.synchronize()
+    assert np.array_equal(packed.cpu().numpy(), replay)
+    assert not np.array_equal(replay, eager0)
+    # a capture that would have to allocate is refused, and the context stays usable
+    neq2 = pv.NormalEq(ctx, F, ui, uj)
+    ctx.graph_begin()
+    with pytest.raises(pv.PvlmError):
+        neq2.accumulate_dev(rs, packed.data_ptr(), pv.LOSS_HUBER, LOSS_A, zero_first=True)
+    try:
+        ctx.graph_end().close()
+    except pv.PvlmError:
+        pass
+    step(); ctx.synchronize()
+    assert np.array_equal(packed.cpu().numpy(), replay)
+    g.close(); neq.close(); neq2.close(); rs.close()
+    ctx.close()
+
+
+# ---- two ranks, one GPU: the sharded path on HIP kernels ------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _rank_packed(rank, world, F, cols):
+    """What one rank of bench.py does, with the exchange left to the caller: associate + accumulate its shard."""
+    import torch
+    import panovlm_amd as pv
+    ref_all, nei_all = sy.pair_list(F, 4)
+    ref, nei = sh.shard_pairs(ref_all, nei_all, F, rank, world)
+    needed = sorted(set(ref.tolist()) | set(nei.tolist()))
+    ctx = pv.Context(0)
+    dev = {k: pv.Scan(ctx, sy.make_scan(k, cols=cols, downsample_targets=0.2)) for k in needed}
+    rs = _associate(ctx, pv, dev, ref, nei)
+    aa, t = _poses(F)
+    ui, uj = sh.unordered_pairs(ref_all, nei_all)
+    neq = pv.NormalEq(ctx, F, ui, uj)
+    d = torch.device("cuda", 0)
+    d_aa = torch.from_numpy(aa).to(d); d_t = torch.from_numpy(t).to(d)
+    packed = torch.zeros(neq.size, dtype=torch.float64, device=d)
+    torch.cuda.synchronize()
+    ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
+    neq.accumulate_dev(rs, packed.data_ptr(), pv.LOSS_HUBER, LOSS_A, zero_first=True)
+    ctx.synchronize()
+    out = packed.cpu()
+    n = rs.n
+    neq.close(); rs.close(); ctx.close()
+    return out, n
+
+
+def _worker(rank, world, port, q, F, cols):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf, n = _rank_packed(rank, world, F, cols)
+    cnt = torch.tensor([n], dtype=torch.int64)
+    dist.all_reduce(buf)
+    dist.all_reduce(cnt)
+    dist.barrier()
+    if rank == 0:
+        q.put((buf.numpy(), int(cnt.item())))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_rank_normal_equations():
+    import torch.multiprocessing as mp
+    F, cols = 10, 256
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, q, F, cols)) for r in range(2)]
+    for p in procs:
+        p.start()
+    reduced, n2 = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single, n1 = _rank_packed(0, 1, F, cols)
+    single = single.numpy()
+    assert n1 == n2 and n1 > 1000
+    assert reduced.shape == single.shape
+    assert np.allclose(reduced, single, rtol=1e-12, atol=1e-12 * np.abs(single).max())
