@@ -407,9 +407,9 @@ def association_block(n_queries, n_targets, accepted, pairs, kernel_ms, launches
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_pmc_assoc*.json"))):
         try:
             pm = json.load(open(f))
-            if pm.get("queries") == n_queries:
-                out["pmc"] = {k: pm[k] for k in pm if k != "raw"}
-                out["pmc"]["source"] = os.path.relpath(f, ROOT)
+            # per-query figures: collected on the same generator at --scans 256 (134 M queries); they do not depend on the batch size
+            out["pmc"] = {"source": os.path.relpath(f, ROOT), "collected_on_queries": pm.get("queries"),
+                          "kernels": {k: {n: v for n, v in e.items() if n not in ("per_call", "dispatches_per_call")} for k, e in pm["kernels"].items()}}
         except Exception:
             pass
     if extra:
