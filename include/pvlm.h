@@ -226,6 +226,9 @@ pvlm_status pvlm_comm_unique_id(pvlm_ctx* ctx, unsigned char id_out[128]);
 pvlm_status pvlm_comm_create(pvlm_ctx* ctx, int world_size, int rank, const unsigned char id[128], pvlm_comm** out);
 pvlm_status pvlm_comm_destroy(pvlm_ctx* ctx, pvlm_comm* comm);
 pvlm_status pvlm_allreduce_sum_f64(pvlm_ctx* ctx, pvlm_comm* comm, double* d_buf, int64_t count);
+/* Same on a HOST buffer (staged through the context's device buffer, synchronous): for hosts whose LM driver keeps the
+ * summed system in host memory, like the mirrored one (panovlm_amd/host: Exchange / MakeRcclExchange). */
+pvlm_status pvlm_allreduce_sum_f64_host(pvlm_ctx* ctx, pvlm_comm* comm, double* buf, int64_t count);
 
 /* ---- scans and LiDAR<->LiDAR association -------------------------------------------------------- *
  * Input contract = the public members of sensors/Velodyne.h:80-91 during association: feature

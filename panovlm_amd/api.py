@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
+    "pvlm_allreduce_sum_f64_host",
 ]
 
 

@@ -918,6 +918,9 @@ Problem::~Problem() {
   delete impl_;
 }
 int Problem::NumResidualBlocks() const { return impl_->num_blocks; }
+void Problem::RegisterPoses(std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list) {
+  for (size_t i = 0; i < aa_list.size() && i < t_list.size(); ++i) impl_->Pose(aa_list[i].data(), t_list[i].data());
+}
 void Problem::SetParameterBlockConstant(double* block) { impl_->constant[impl_->Block(block)] = true; }
 
 void Problem::AddResidualBlock(CostFunction* cost, LossFunction* loss, double* aa_r, double* t_r, double* aa_n, double* t_n) {
@@ -1059,7 +1062,23 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   *summary = Solver::Summary();
   summary->num_residual_blocks = I.num_blocks;
   const int NP = (int)I.poses.size();
-  if (I.num_blocks == 0 || NP == 0) { summary->message = "no residual blocks"; return; }
+  const Exchange* xch = (opt.exchange && opt.exchange->active()) ? opt.exchange : nullptr;
+  // a rank of a sharded solve may own no residual block at all and still has to take part in every exchange
+  if ((!xch && I.num_blocks == 0) || NP == 0) { summary->message = "no residual blocks"; return; }
+  if (xch) for (auto& b : I.bundles) if (!b.obs_pose.empty()) throw std::runtime_error("sharded Solve: reprojection blocks are not sharded (camera terms run on one GPU)");
+  // concatenation of every rank's list through the one primitive an Exchange has
+  auto all_concat = [&](const std::vector<double>& mine) {
+    std::vector<double> cnt((size_t)xch->world, 0.0);
+    cnt[(size_t)xch->rank] = (double)mine.size();
+    xch->allreduce_sum(cnt.data(), cnt.size());
+    size_t total = 0, off = 0;
+    for (int r = 0; r < xch->world; ++r) { if (r == xch->rank) off = total; total += (size_t)cnt[(size_t)r]; }
+    std::vector<double> all(std::max<size_t>(total, 1), 0.0);
+    std::copy(mine.begin(), mine.end(), all.begin() + (std::ptrdiff_t)off);
+    xch->allreduce_sum(all.data(), all.size());
+    all.resize(total);
+    return all;
+  };
 
   // ---- device sets + per-group normal-equation structures ---------------------------------------
   for (auto& g : I.groups) {
@@ -1129,9 +1148,29 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   // ---- free-parameter layout (pose blocks; the point blocks never reach the host system) -------------
   std::vector<int> block_off(I.blocks.size(), -1);
   int n_free = 0;
+  // sharded solve: the poses were registered up front (RegisterPoses), so a rank also knows poses none of ITS blocks
+  // touch; a pose no rank touches is left out of the system, as if it had never been added
+  std::vector<char> touched(I.blocks.size(), xch ? 0 : 1);
+  std::vector<std::pair<int, int>> xkeys;          // sharded solve: sorted union of the ranks' 6x6 block keys (pose a <= pose b)
+  if (xch) {
+    std::vector<double> use(I.blocks.size(), 0.0), keys;
+    std::set<std::pair<int, int>> mine;
+    for (auto& g : I.groups)
+      for (size_t p = 0; p < g.ref.size(); ++p) {
+        for (int q : {g.ref[p], g.nei[p]}) { use[(size_t)I.poses[q].first] = 1.0; use[(size_t)I.poses[q].second] = 1.0; mine.insert({q, q}); }
+        mine.insert({std::min(g.ref[p], g.nei[p]), std::max(g.ref[p], g.nei[p])});
+      }
+    xch->allreduce_sum(use.data(), use.size());
+    for (size_t b = 0; b < use.size(); ++b) touched[b] = use[b] > 0.0;
+    for (auto& k : mine) { keys.push_back((double)k.first); keys.push_back((double)k.second); }
+    const std::vector<double> all = all_concat(keys);
+    std::set<std::pair<int, int>> uni;
+    for (size_t i = 0; i + 1 < all.size(); i += 2) uni.insert({(int)all[i], (int)all[i + 1]});
+    xkeys.assign(uni.begin(), uni.end());
+  }
   for (int p = 0; p < NP; ++p)
     for (int b : {I.poses[p].first, I.poses[p].second})
-      if (!I.constant[b] && block_off[b] < 0) { block_off[b] = n_free; n_free += 3; }
+      if (!I.constant[b] && touched[b] && block_off[b] < 0) { block_off[b] = n_free; n_free += 3; }
   if (n_free == 0) { summary->message = "all parameter blocks constant"; }
 
   std::vector<double> x(3 * I.blocks.size());
@@ -1175,6 +1214,30 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
         const double* src = Ho + (size_t)u * 36;  // d2/dx_ui dx_uj
         if (pa <= pb) { auto& blk = A.H[{pa, pb}]; for (int k = 0; k < 36; ++k) blk[k] += src[k]; }
         else { auto& blk = A.H[{pb, pa}]; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[r * 6 + c] += src[c * 6 + r]; }
+      }
+    }
+    if (xch) {
+      // the one exchange of an evaluation: [cost | g | blocks in key order], summed over the ranks;
+      // afterwards every rank holds the same Assembled, bit for bit
+      StageTimer stage_timer_x_("solve: exchange of the normal equations");
+      std::vector<double> buf(want_H ? 1 + (size_t)n_free + xkeys.size() * 36 : 1, 0.0);
+      buf[0] = A.cost;
+      if (want_H) {
+        std::copy(A.g.begin(), A.g.end(), buf.begin() + 1);
+        for (size_t k = 0; k < xkeys.size(); ++k) {
+          auto it = A.H.find(xkeys[k]);
+          if (it != A.H.end()) std::copy(it->second.begin(), it->second.end(), buf.begin() + 1 + n_free + (std::ptrdiff_t)k * 36);
+        }
+      }
+      xch->allreduce_sum(buf.data(), buf.size());
+      A.cost = buf[0];
+      if (want_H) {
+        std::copy(buf.begin() + 1, buf.begin() + 1 + n_free, A.g.begin());
+        A.H.clear();
+        for (size_t k = 0; k < xkeys.size(); ++k) {
+          auto& blk = A.H[xkeys[k]];
+          std::copy(buf.begin() + 1 + n_free + (std::ptrdiff_t)k * 36, buf.begin() + 1 + n_free + (std::ptrdiff_t)(k + 1) * 36, blk.begin());
+        }
       }
     }
   };
@@ -1492,13 +1555,14 @@ CostFunction* PlaneIOUResidual::Create(const Vector4d& pl, const Vector3d& mn, c
 size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                     std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
                                     double point_to_plane_dis_threshold, double plane_tolerance, bool angle_residual, bool normalized_distance,
-                                    double weight) {
+                                    double weight, const std::pair<size_t, size_t>* ref_range) {
   StageTimer stage_timer_("point-to-plane association");
   // util/Optimization.cpp:513-517: one loss object shared by every block of this adder
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
   std::vector<pvlm_scan*> refs, neis;
   std::vector<const Velodyne*> holders;
-  for (size_t i = 0; i < lidars.size(); i++) {
+  const size_t i_lo = ref_range ? ref_range->first : 0, i_hi = ref_range ? std::min(ref_range->second, lidars.size()) : lidars.size();
+  for (size_t i = i_lo; i < i_hi; i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;                 // :525-526
     for (int n_idx : neighbors[i]) {
       if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;  // :531-532
@@ -1522,10 +1586,12 @@ size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbo
 
 size_t AddLidarPointToLineResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                    std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
-                                   double thr, bool use_segment, bool angle_residual, bool normalized_distance, double weight) {
+                                   double thr, bool use_segment, bool angle_residual, bool normalized_distance, double weight,
+                                   const std::pair<size_t, size_t>* ref_range) {
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);   // :449-453 (Huber for both variants here)
   size_t num = 0;
-  for (size_t i = 0; i < lidars.size(); i++) {
+  const size_t i_lo = ref_range ? ref_range->first : 0, i_hi = ref_range ? std::min(ref_range->second, lidars.size()) : lidars.size();
+  for (size_t i = i_lo; i < i_hi; i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
     double* aa_r = aa_list[lidars[i].id].data(); double* t_r = t_list[lidars[i].id].data();
     for (int n_idx : neighbors[i]) {
@@ -1548,8 +1614,10 @@ size_t AddLidarPointToLineResidual(const std::vector<std::vector<int>>& neighbor
 
 size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                    std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list, ceres_like::Problem& problem,
-                                   const std::vector<LineTrack>& tracks, double thr, bool angle_residual, bool normalized_distance, double weight) {
+                                   const std::vector<LineTrack>& tracks, double thr, bool angle_residual, bool normalized_distance, double weight,
+                                   const std::pair<size_t, size_t>* ref_range) {
   StageTimer stage_timer_("line-to-line association + blocks");
+  const size_t i_lo = ref_range ? ref_range->first : 0, i_hi = ref_range ? std::min(ref_range->second, lidars.size()) : lidars.size();
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
   bool loss_used = false;
   std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> lines_to_track;
@@ -1557,7 +1625,7 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   size_t num = 0;
   // all AssociateLine2Line(lidars[i], lidars[n_idx], thr) calls of the loop below (:379) in one GPU launch
   std::vector<std::pair<const Velodyne*, const Velodyne*>> todo;
-  for (size_t i = 0; i < lidars.size(); i++) {
+  for (size_t i = i_lo; i < i_hi; i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
     for (int n_idx : neighbors[i]) {
       if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;
@@ -1568,7 +1636,7 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   const std::vector<std::vector<Line2Line>> all_ass = AssociateLine2LineBatch(todo, (float)thr);
   size_t next = 0;
   std::vector<double> row_buf;
-  for (size_t i = 0; i < lidars.size(); i++) {
+  for (size_t i = i_lo; i < i_hi; i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
     double* aa_r = aa_list[lidars[i].id].data(); double* t_r = t_list[lidars[i].id].data();
     for (int n_idx : neighbors[i]) {
@@ -1628,6 +1696,56 @@ ceres_like::Solver::Options SetOptionsLidar(const int num_threads, const int lid
 }
 
 // ================================================================================================
+// Exchange factories
+// ================================================================================================
+Exchange MakeRcclExchange(int world, int rank, const unsigned char id[128]) {
+  Engine& e = Engine::Default();
+  struct State {
+    pvlm_comm* comm = nullptr;
+    ~State() { if (comm) pvlm_comm_destroy(Engine::Default().ctx(), comm); }
+  };
+  auto st = std::make_shared<State>();
+  e.Check(pvlm_comm_create(e.ctx(), world, rank, id, &st->comm), "pvlm_comm_create");
+  Exchange x; x.world = world; x.rank = rank;
+  x.allreduce_sum = [st](double* buf, size_t count) {
+    Engine& en = Engine::Default();
+    en.Check(pvlm_allreduce_sum_f64_host(en.ctx(), st->comm, buf, (int64_t)count), "pvlm_allreduce_sum_f64_host");
+  };
+  return x;
+}
+
+Exchange MakeFileExchange(int world, int rank, const std::string& dir) {
+  auto seq = std::make_shared<long>(0);
+  Exchange x; x.world = world; x.rank = rank;
+  x.allreduce_sum = [world, rank, dir, seq](double* buf, size_t count) {
+    const long s = (*seq)++;
+    auto name = [&](long q, int r) { return dir + "/x" + std::to_string(q) + "_" + std::to_string(r) + ".bin"; };
+    {
+      const std::string tmp = name(s, rank) + ".tmp";
+      FILE* f = fopen(tmp.c_str(), "wb");
+      if (!f) throw std::runtime_error("file exchange: cannot write " + tmp);
+      const uint64_t n = count;
+      fwrite(&n, sizeof(n), 1, f); fwrite(buf, sizeof(double), count, f);
+      fclose(f);
+      if (rename(tmp.c_str(), name(s, rank).c_str()) != 0) throw std::runtime_error("file exchange: rename failed");
+    }
+    std::vector<double> sum(count, 0.0), part(count);
+    for (int r = 0; r < world; ++r) {             // rank order: the same sum, bit for bit, on every rank
+      FILE* f = nullptr;
+      for (int spin = 0; spin < 1200000 && !(f = fopen(name(s, r).c_str(), "rb")); ++spin) std::this_thread::sleep_for(std::chrono::microseconds(100));
+      if (!f) throw std::runtime_error("file exchange: rank " + std::to_string(r) + " never arrived at exchange " + std::to_string(s));
+      uint64_t n = 0;
+      if (fread(&n, sizeof(n), 1, f) != 1 || n != count || fread(part.data(), sizeof(double), count, f) != count) { fclose(f); throw std::runtime_error("file exchange: size mismatch between ranks"); }
+      fclose(f);
+      for (size_t i = 0; i < count; ++i) sum[i] += part[i];
+    }
+    std::copy(sum.begin(), sum.end(), buf);
+    if (s >= 2) remove(name(s - 2, rank).c_str());   // every rank has read exchange s-2 before it wrote s-1, and all of s-1 has been read here
+  };
+  return x;
+}
+
+// ================================================================================================
 // LidarOdometry — lidar_mapping/LidarOdometry.cpp:15-187
 // ================================================================================================
 bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
@@ -1643,21 +1761,28 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
   }
   const std::vector<std::vector<int>> neighbors_all = FindNeighbors(lidars, 6);
   ceres_like::Problem problem;
+  // sharded run: this rank adds the blocks of its reference scans only; pose ids are the list indices on every rank
+  const bool sharded = exchange_.active();
+  const std::pair<size_t, size_t> my_range = exchange_.Range(lidars.size());
+  const std::pair<size_t, size_t>* range = sharded ? &my_range : nullptr;
+  if (sharded) problem.RegisterPoses(aa_list, t_list);
   if (config.point_to_line_residual)                                                           // LidarOdometry.cpp:38-41
     AddLidarPointToLineResidual(neighbors_all, lidars, aa_list, t_list, problem, config.point_to_line_dis_threshold, use_segment,
-                                config.angle_residual, config.normalize_distance);
+                                config.angle_residual, config.normalize_distance, 1.0, range);
   if (config.line_to_line_residual && use_segment) {
     LidarLineMatch matcher(lidars);
     matcher.SetNeighborSize(4);
     matcher.SetMinTrackLength(3);
     matcher.GenerateTracks();
     AddLidarLineToLineResidual2(neighbors_all, lidars, aa_list, t_list, problem, matcher.GetTracks(), config.point_to_line_dis_threshold,
-                                config.angle_residual, config.normalize_distance);
+                                config.angle_residual, config.normalize_distance, 1.0, range);
   }
   if (config.point_to_plane_residual)
     AddLidarPointToPlaneResidual(neighbors_all, lidars, aa_list, t_list, problem, config.point_to_plane_dis_threshold, config.lidar_plane_tolerance,
-                                 config.angle_residual, config.normalize_distance);
-  if (problem.NumResidualBlocks() == 0) { fprintf(stderr, "no residual\n"); return false; }
+                                 config.angle_residual, config.normalize_distance, 1.0, range);
+  double total_blocks = (double)problem.NumResidualBlocks();
+  if (sharded) exchange_.allreduce_sum(&total_blocks, 1);        // the decision below must be the same on every rank
+  if (total_blocks == 0) { fprintf(stderr, "no residual\n"); return false; }
   // gauge: first valid pose constant — only if it takes part in the problem (Ceres would abort otherwise)
   for (size_t i = 0; i < lidars.size(); i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
@@ -1666,6 +1791,7 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
     break;
   }
   ceres_like::Solver::Options options = SetOptionsLidar(config.num_threads, (int)lidars.size());
+  if (sharded) options.exchange = &exchange_;
   ceres_like::Solver::Summary summary;
   ceres_like::Solve(options, &problem, &summary);
   for (size_t i = 0; i < lidars.size(); i++) {
@@ -1680,7 +1806,7 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
   }
   cost = summary.final_cost;
   steps = summary.num_successful_steps;
-  log.push_back({cost, steps, problem.NumResidualBlocks()});
+  log.push_back({cost, steps, (int)total_blocks});
   return summary.IsSolutionUsable();
 }
 

@@ -22,6 +22,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -260,6 +261,9 @@ class Problem {
   // the parameter blocks (aa[ref_p], t[ref_p], aa[nei_p], t[nei_p]) of the given lists (ids = list index).
   void AddResidualSet(pvlm_resset* set, LossFunction* loss, std::vector<Vector3d>* aa_list, std::vector<Vector3d>* t_list);
   void SetParameterBlockConstant(double* block);
+  // Registers every (angle-axis, translation) pair of the two lists as a pose, in list order, before any residual block
+  // is added: pose ids then equal list indices on every rank of a sharded solve (otherwise ids follow first use).
+  void RegisterPoses(std::vector<Vector3d>& aa_list, std::vector<Vector3d>& t_list);
   int NumResidualBlocks() const;
   struct Impl;
   Impl* impl() const { return impl_; }
@@ -268,9 +272,34 @@ class Problem {
   Impl* impl_;
 };
 
+}  // namespace ceres_like
+
+// ---- multi-GPU: how the ranks of a sharded solve add up their normal equations ------------
+// One process per GPU.  Every rank holds all scans and the full pose vector; a rank builds residual blocks only for its
+// block of REFERENCE scans (the `i` loop of util/Optimization.cpp:521-560 and :345-441), evaluates them on its GPU and
+// the ranks sum [cost | g | 6x6 blocks] once per evaluation.  Everything else of the LM iteration is replicated: the
+// summed system is bit-identical on every rank, so every rank takes the same decisions and no parameter broadcast is needed.
+// allreduce_sum: in place on a HOST buffer, must leave the same bits on every rank (RCCL's ring all-reduce does; the
+// file exchange sums in rank order).
+struct Exchange {
+  int world = 1, rank = 0;
+  std::function<void(double* buf, size_t count)> allreduce_sum;
+  bool active() const { return world > 1 && (bool)allreduce_sum; }
+  // block partition of n reference scans, the same rule as panovlm_amd/sharding.py
+  std::pair<size_t, size_t> Range(size_t n) const { return {n * (size_t)rank / (size_t)world, n * ((size_t)rank + 1) / (size_t)world}; }
+};
+// RCCL over xGMI through the C ABI (pvlm_comm_* on the engine's context): `id` = the 128 bytes rank 0 got from
+// pvlm_comm_unique_id, carried to the other ranks by the launcher.  Collective: every rank calls it.
+Exchange MakeRcclExchange(int world, int rank, const unsigned char id[128]);
+// Ranks on one host exchanging through a directory (functional tests on a one-GPU box; not a fast path).
+Exchange MakeFileExchange(int world, int rank, const std::string& dir);
+
+namespace ceres_like {
+
 enum LinearSolverType { DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR };
 struct Solver {
   struct Options {
+    const Exchange* exchange = nullptr;   // sharded solve: see Exchange (the Problem must have its poses registered with RegisterPoses)
     bool minimizer_progress_to_stdout = false;
     int num_threads = 1;
     int max_num_iterations = 50;
@@ -311,16 +340,18 @@ constexpr int kReprojKind = 100;   // CostFunction::kind of the three-block func
 size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                     std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
                                     ceres_like::Problem& problem, double point_to_plane_dis_threshold, double plane_tolerance,
-                                    bool angle_residual, bool normalized_distance, double weight = 1.0);
+                                    bool angle_residual, bool normalized_distance, double weight = 1.0,
+                                    const std::pair<size_t, size_t>* ref_range = nullptr /* sharded run: reference scans [first, second) only */);
 // util/Optimization.cpp:443-504 — only pairs of consecutive scans (|n_idx - i| <= 1) get point-to-line blocks
 size_t AddLidarPointToLineResidual(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                    std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list, ceres_like::Problem& problem,
                                    double point_to_line_dis_threshold, bool use_segment, bool angle_residual, bool normalized_distance,
-                                   double weight = 1.0);
+                                   double weight = 1.0, const std::pair<size_t, size_t>* ref_range = nullptr);
 size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbors, const std::vector<Velodyne>& lidars,
                                    std::vector<Vector3d>& angleAxis_lw_list, std::vector<Vector3d>& t_lw_list,
                                    ceres_like::Problem& problem, const std::vector<LineTrack>& lidar_line_tracks,
-                                   double point_to_line_dis_threshold, bool angle_residual, bool normalized_distance, double weight = 1.0);
+                                   double point_to_line_dis_threshold, bool angle_residual, bool normalized_distance, double weight = 1.0,
+                                   const std::pair<size_t, size_t>* ref_range = nullptr);
 // AddCameraLidarResidual (util/Optimization.cpp:564-607): two blocks per matched line pair —
 // Plane2Plane_Global (weight line_pair.weight * weight) and PlaneIOUResidual (weight 2 * weight) — on
 // (angleAxis_cw[frame], t_cw[frame], angleAxis_lw[lidar], t_lw[lidar]).  `frame_pose_valid[f]` stands for
@@ -376,9 +407,14 @@ class LidarOdometry {
   // per-outer-iteration log (cost, successful steps, residual blocks) for tests
   struct IterLog { double cost; int steps; int residual_blocks; };
   std::vector<IterLog> log;
+  // Sharded run (one process per GPU): set before EstimatePose / RefinePose on every rank.  Association and
+  // residual evaluation are done for the rank's block of reference scans only; poses, neighbour lists and line tracks are
+  // replicated.  residual_blocks in the log is then the sum over the ranks.
+  void SetExchange(const Exchange& e) { exchange_ = e; }
  private:
   std::vector<Velodyne> lidars;
   Config config;
+  Exchange exchange_;
 };
 
 // ---- sensors/Equirectangular.h + joint_optimization/CameraLidarLineAssociate.h -------------------------------

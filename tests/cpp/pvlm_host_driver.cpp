@@ -3,6 +3,7 @@
 // the result as text for pytest to compare with the CPU oracle.
 #include <cinttypes>
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
@@ -180,6 +181,30 @@ int main(int argc, char** argv) {
       cfg.line_to_line_residual = atoi(argv[6]) != 0; cfg.point_to_plane_residual = atoi(argv[7]) != 0;
       cfg.lidar_plane_tolerance = atof(argv[8]); cfg.point_to_plane_dis_threshold = atof(argv[9]); cfg.point_to_line_dis_threshold = atof(argv[10]);
       LidarOdometry odo(l, cfg);
+      // optional: world rank file:<dir> | rccl:<dir>   — one of `world` processes of a sharded run;
+      // rccl: rank 0 leaves the 128-byte communicator id in <dir>/rccl_id for the other ranks
+      if (argc > 13 && atoi(argv[11]) > 1) {
+        const int world = atoi(argv[11]), rank = atoi(argv[12]);
+        const std::string mode = argv[13];
+        const std::string dir = mode.substr(mode.find(':') + 1);
+        if (mode.rfind("file:", 0) == 0) odo.SetExchange(MakeFileExchange(world, rank, dir));
+        else {
+          unsigned char id[128];
+          const std::string path = dir + "/rccl_id";
+          if (rank == 0) {
+            Engine& e = Engine::Default();
+            e.Check(pvlm_comm_unique_id(e.ctx(), id), "pvlm_comm_unique_id");
+            FILE* f = fopen((path + ".tmp").c_str(), "wb"); fwrite(id, 1, 128, f); fclose(f);
+            rename((path + ".tmp").c_str(), path.c_str());
+          } else {
+            FILE* f = nullptr;
+            for (int spin = 0; spin < 600000 && !(f = fopen(path.c_str(), "rb")); ++spin) usleep(100);
+            if (!f || fread(id, 1, 128, f) != 128) { fprintf(stderr, "no communicator id\n"); return 2; }
+            fclose(f);
+          }
+          odo.SetExchange(MakeRcclExchange(world, rank, id));
+        }
+      }
       odo.EstimatePose(iters);
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
       for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());

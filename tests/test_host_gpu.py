@@ -63,11 +63,11 @@ def test_find_neighbors_and_point2plane(oracle, tmp):
         assert np.array_equal(got[:, :3], o["point"]) and np.array_equal(got[:, 3:], o["plane"])
 
 
-def _line_scans(rng, n):
+def _line_scans(rng, n, pose_offset=2):
     lines = synth.random_world_lines(rng, 10)
     out = []
     for k in range(n):
-        R, t = sy.estimated_pose(k + 2)
+        R, t = sy.estimated_pose(k + pose_offset)
         s = synth.make_line_scan(rng, k, R, t, lines, pts_per_line=(10, 24), extra_pts=12, noise=0.005)
         seg_points = [[i for i, l in enumerate(s["p2s"]) if sid in l] for sid in range(len(s["seg_size"]))]
         out.append(dict(id=k, R_wl=R, t_wl=t, corner_local=s["corner_local"], p2s=s["p2s"], seg_points=seg_points,
@@ -472,3 +472,49 @@ def test_raw_scans_to_refined_poses(oracle, tmp):
     err1 = np.mean([np.linalg.norm(poses[k][9:] - sy.true_pose(k)[1] - (poses[0][9:] - sy.true_pose(0)[1])) for k in range(1, 3)])
     assert err1 < err0
 
+
+
+def _parse_odometry(out):
+    iters = [l.split() for l in out if l.startswith("iter")]
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    return iters, poses
+
+
+def test_sharded_estimate_pose_two_ranks_on_one_gpu(tmp):
+    """LidarOdometry::EstimatePose sharded over two processes (Exchange, SURVEY.md §8 row E; the loop that is sharded is
+    util/Optimization.cpp:521-560 / :345-441): each rank associates and evaluates the blocks of its half of the
+    reference scans on the GPU, the ranks sum [cost | g | 6x6 blocks] once per evaluation, everything else is
+    replicated.  Both ranks must report the same log and poses, bit for bit, and agree with the one-process run
+    (same blocks; 1e-9: the order of the sums differs)."""
+    import subprocess
+    rng = np.random.default_rng(77)
+    # point-to-plane scans that also carry line segments: both sharded adders run
+    scans = [_vlp(k, 256) for k in range(6)]
+    lines = _line_scans(rng, 6, pose_offset=0)          # same estimated poses as the point-to-plane scans
+    for s, l in zip(scans, lines):
+        assert np.array_equal(s["R_wl"], l["R_wl"]) and np.array_equal(s["t_wl"], l["t_wl"])
+        for key in ("corner_local", "p2s", "seg_points", "seg_coeffs", "end_points"):
+            s[key] = l[key]
+    path = os.path.join(tmp, "shard.bin")
+    host_io.write_scans(path, scans, world=False)
+    args = ["odometry", path, 2, 1, 1, 1, 1, 0.05, 1.0, 0.3]
+    single = host_io.run(*args)
+    xdir = os.path.join(tmp, "xchg"); os.makedirs(xdir, exist_ok=True)
+    procs = [subprocess.Popen([host_io.driver()] + [str(a) for a in args] + ["2", str(r), "file:" + xdir], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(o.splitlines())
+    it0, po0 = _parse_odometry(outs[0]); it1, po1 = _parse_odometry(outs[1]); its, pos = _parse_odometry(single)
+    assert [l[:7] for l in it0] == [l[:7] for l in it1] and len(it0) == len(its) >= 1          # identical decisions on both ranks
+    for k in po0:
+        assert np.array_equal(po0[k], po1[k])
+    for a, b in zip(it0, its):
+        assert int(a[6]) == int(b[6]) > 1000 and int(a[4]) == int(b[4])
+        assert abs(float(a[2]) - float(b[2])) <= 1e-9 * float(b[2])
+    for k in pos:
+        assert np.abs(po0[k] - pos[k]).max() <= 1e-9 * max(1.0, np.abs(pos[k]).max())
+    # each rank really did only its share: the association stage of a rank saw half of the reference scans
+    assert any(l.startswith("stage") and "exchange of the normal equations" in l for l in outs[0])
