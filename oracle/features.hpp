@@ -16,9 +16,9 @@
 //   * Eigen 3.4 fixed-size 3-vector reductions (dot, squaredNorm) without vectorisation: c0 + (c1 + c2).
 // std::sort is libstdc++'s here as in a reference build; with equal keys (curvature ties, points of one voxel) its
 // order is deterministic for a given library but not specified by the language.
-// What is NOT restated: EdgeToLine / ExtractLineFeatures (sensors/LidarLineExtraction.cpp) — FuseLines fits every fused
-// group with pcl::SACSegmentation RANSAC (:150-160), whose sampling sequence lives inside PCL; cornerLessSharp is
-// therefore the cloud BEFORE that filter (the reference keeps it as cornerBeforeFilter, sensors/Velodyne.cpp:1271).
+// EdgeToLine / ExtractLineFeatures (sensors/LidarLineExtraction.cpp) live in oracle/lines.hpp; ExtractFeatures runs them
+// (between the edge and the planar picks, as upstream) when it is handed a LineFeatures object, otherwise cornerLessSharp
+// stays the cloud BEFORE that filter (the reference keeps it as cornerBeforeFilter, sensors/Velodyne.cpp:1271).
 // Two out-of-bounds reads of the reference (undefined behaviour there) are made safe, see "UB" below.
 #pragma once
 #include <algorithm>
@@ -46,6 +46,9 @@ struct ScanFeatures {
   std::vector<int> state, sortInd, left, right;
   std::vector<FPoint> cornerSharp, cornerLessSharp, surfFlat, surfLessFlat;
 };
+
+struct LineFeatures;                                        // oracle/lines.hpp
+inline void EdgeToLine(ScanFeatures& f, LineFeatures& L);   // oracle/lines.hpp (sensors/Velodyne.cpp:1269-1324)
 
 inline float FSquare(float a) { return a * a; }
 // base/Geometry.hpp:38-40
@@ -263,7 +266,7 @@ inline std::vector<FPoint> VoxelGrid(const std::vector<FPoint>& in, float leaf) 
 }
 
 // Velodyne::ExtractFeatures with method == ADAPTIVE (sensors/Velodyne.cpp:531-760), up to and including ExtractPlaneFeatures2
-inline void ExtractFeatures(ScanFeatures& f, float max_curvature, float intersect_angle_threshold, bool segment) {
+inline void ExtractFeatures(ScanFeatures& f, float max_curvature, float intersect_angle_threshold, bool segment, LineFeatures* lines = nullptr) {
   if (!f.valid || f.cloud_scan.empty()) return;
   int cloudSize = (int)f.cloud_scan.size();
   if (segment) Segmentation(f);
@@ -354,7 +357,8 @@ inline void ExtractFeatures(ScanFeatures& f, float max_curvature, float intersec
       }
     }
   }
-  // (EdgeToLine is not restated: it does not touch cloudState)
+  // EdgeToLine :752 — filters cornerLessSharp / cornerSharp down to the members of line segments; does not touch cloudState
+  if (lines) EdgeToLine(f, *lines);
   // ---- ExtractPlaneFeatures2 :1098-1189
   for (int i = 0; i < N_SCANS; i++) {
     if (f.scanEndInd[i] - f.scanStartInd[i] < 6) continue;

@@ -431,12 +431,13 @@ def assoc_by_angle(rows, cols, lines, lidar_local, T_cl, multiple=True):
                 end=en[:m].copy(), votes=votes)
 
 
-def _features_handle(cloud, n_scans=16, horizon=1800, max_curvature=1000.0, intersect_angle_threshold=5.0, segment=True, extract=True):
+def _features_handle(cloud, n_scans=16, horizon=1800, max_curvature=1000.0, intersect_angle_threshold=5.0, segment=True, extract=True, edge_to_line=False):
     c = _f32(cloud).reshape(-1, 4)
     L = lib()
     L.orc_features_create.restype = C.c_void_p
     return C.c_void_p(L.orc_features_create(C.c_long(len(c)), _p(c, C.c_float), C.c_int(n_scans), C.c_int(horizon), C.c_float(max_curvature),
-                                            C.c_float(intersect_angle_threshold), C.c_int(1 if segment else 0), C.c_int(1 if extract else 0)))
+                                            C.c_float(intersect_angle_threshold), C.c_int(1 if segment else 0),
+                                            C.c_int((1 if extract else 0) | (2 if (extract and edge_to_line) else 0))))
 
 
 class ScanFeatures:
@@ -444,10 +445,13 @@ class ScanFeatures:
 
     CLOUDS = {"cloud_scan": 0, "cornerSharp": 1, "cornerLessSharp": 2, "surfFlat": 3, "surfLessFlat": 4}
 
-    def __init__(self, cloud, n_scans=16, horizon=1800, max_curvature=1000.0, intersect_angle_threshold=5.0, segment=True, extract=True):
+    def __init__(self, cloud, n_scans=16, horizon=1800, max_curvature=1000.0, intersect_angle_threshold=5.0, segment=True, extract=True, edge_to_line=False):
+        """edge_to_line: also run Velodyne::EdgeToLine (oracle/lines.hpp): cornerSharp / cornerLessSharp are then the filtered clouds and
+        edge_segmented (list of n x 4 arrays), segment_coeffs (S x 6), end_points (S x 2 x 3), point_to_segment (list of lists),
+        cornerBeforeFilter are filled."""
         L = lib()
         L.orc_features_cloud.restype = C.c_long
-        h = _features_handle(cloud, n_scans, horizon, max_curvature, intersect_angle_threshold, segment, extract)
+        h = _features_handle(cloud, n_scans, horizon, max_curvature, intersect_angle_threshold, segment, extract, edge_to_line)
         try:
             self.valid = bool(L.orc_features_valid(h))
             for name, which in self.CLOUDS.items():
@@ -467,8 +471,28 @@ class ScanFeatures:
                                   _p(self.sort_ind, C.c_int) if have else None, _p(self.left, C.c_int) if have else None,
                                   _p(self.right, C.c_int) if have else None, _p(self.scan_start, C.c_int), _p(self.scan_end, C.c_int),
                                   _p(self.range_image, C.c_float), _p(self.image_to_point_idx, C.c_int))
+            if extract and edge_to_line:
+                ns, npt, nid, nb = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+                L.orc_lines_sizes(h, C.byref(ns), C.byref(npt), C.byref(nid), C.byref(nb))
+                so = np.zeros(ns.value + 1, np.int32); sp = np.zeros((max(npt.value, 1), 4), np.float32)
+                co = np.zeros((max(ns.value, 1), 6)); ep = np.zeros((max(ns.value, 1), 2, 3))
+                po = np.zeros(len(self.cornerLessSharp) + 1, np.int32); pi = np.zeros(max(nid.value, 1), np.int32)
+                bf = np.zeros((max(nb.value, 1), 4), np.float32)
+                L.orc_lines_get(h, _p(so, C.c_int), _p(sp, C.c_float), _p(co, C.c_double), _p(ep, C.c_double), _p(po, C.c_int), _p(pi, C.c_int), _p(bf, C.c_float))
+                self.edge_segmented = [sp[so[k]:so[k + 1]].copy() for k in range(ns.value)]
+                self.segment_coeffs = co[:ns.value]; self.end_points = ep[:ns.value]
+                self.point_to_segment = [pi[po[k]:po[k + 1]].tolist() for k in range(len(self.cornerLessSharp))]
+                self.cornerBeforeFilter = bf[:nb.value]
         finally:
             L.orc_features_free(h)
+
+
+def line_consensus(cloud_xyzi, threshold=0.02):
+    """The exhaustive 2-point maximum-consensus line that stands in for pcl::SACSegmentation in FuseLines (oracle/lines.hpp)."""
+    c = _f32(cloud_xyzi).reshape(-1, 4)
+    out = np.zeros(max(len(c), 1), np.int32)
+    n = lib().orc_line_consensus(C.c_int(len(c)), _p(c, C.c_float), C.c_double(threshold), _p(out, C.c_int))
+    return out[:n]
 
 
 def voxel_grid(cloud, leaf):

@@ -10,6 +10,7 @@
 #include "costfunction.hpp"
 #include "equirect.hpp"
 #include "features.hpp"
+#include "lines.hpp"
 #include "mvs.hpp"
 
 using namespace oracle;
@@ -332,23 +333,62 @@ int orc_assoc_by_angle(int rows, int cols, const float* lines, int n_lines, cons
 }
 
 
-// ---- LiDAR feature extraction, planar branch (features.hpp).  cloud: n x 4 float (x, y, z, intensity), LoadLidar's output.
+struct FeatHandle : ScanFeatures { LineFeatures lines; bool has_lines = false; };
+// ---- LiDAR feature extraction (features.hpp; line branch lines.hpp).  cloud: n x 4 float (x, y, z, intensity), LoadLidar's output.
 void* orc_features_create(long n, const float* cloud, int n_scans, int horizon, float max_curvature, float intersect_angle_threshold, int segment,
                           int extract) {
   std::vector<FPoint> c(n);
   for (long i = 0; i < n; ++i) c[i] = FPoint{cloud[4 * i], cloud[4 * i + 1], cloud[4 * i + 2], cloud[4 * i + 3]};
-  ScanFeatures* f = new ScanFeatures();
+  FeatHandle* f = new FeatHandle();
   ReOrderVLP(c, n_scans, horizon, *f);
-  if (extract) ExtractFeatures(*f, max_curvature, intersect_angle_threshold, segment != 0);
-  return f;
+  f->has_lines = (extract & 2) != 0;                       // extract: bit 0 = ExtractFeatures, bit 1 = with EdgeToLine (oracle/lines.hpp)
+  if (extract) ExtractFeatures(*f, max_curvature, intersect_angle_threshold, segment != 0, f->has_lines ? &f->lines : nullptr);
+  return static_cast<ScanFeatures*>(f);
 }
-void orc_features_free(void* h) { delete static_cast<ScanFeatures*>(h); }
+void orc_features_free(void* h) { delete static_cast<FeatHandle*>(static_cast<ScanFeatures*>(h)); }
+// line segments of EdgeToLine: sizes, then the arrays (null = skip).  seg_offsets: n_segments + 1; seg_points: total x 4 float
+// (intensity = index into cloud_scan); coeffs: n_segments x 6; end_points: n_segments x 2 x 3; p2s_offsets: n_corner + 1
+// (corner = the filtered cornerLessSharp), p2s_ids; before: the cloud before the filter (cornerBeforeFilter), n x 4
+void orc_lines_sizes(void* h, int* n_segments, int* n_seg_points, int* n_p2s_ids, int* n_before) {
+  const FeatHandle* f = static_cast<FeatHandle*>(static_cast<ScanFeatures*>(h));
+  int pts = 0, ids = 0;
+  for (auto& s : f->lines.edge_segmented) pts += (int)s.size();
+  for (auto& s : f->lines.point_to_segment) ids += (int)s.size();
+  *n_segments = (int)f->lines.edge_segmented.size(); *n_seg_points = pts; *n_p2s_ids = ids; *n_before = (int)f->lines.cornerBeforeFilter.size();
+}
+void orc_lines_get(void* h, int* seg_offsets, float* seg_points, double* coeffs, double* end_points, int* p2s_offsets, int* p2s_ids, float* before) {
+  const FeatHandle* f = static_cast<FeatHandle*>(static_cast<ScanFeatures*>(h));
+  const LineFeatures& L = f->lines;
+  int o = 0;
+  for (size_t s = 0; s < L.edge_segmented.size(); ++s) {
+    if (seg_offsets) seg_offsets[s] = o;
+    for (const FPoint& p : L.edge_segmented[s]) { if (seg_points) { seg_points[4 * o] = p.x; seg_points[4 * o + 1] = p.y; seg_points[4 * o + 2] = p.z; seg_points[4 * o + 3] = p.intensity; } ++o; }
+    if (coeffs) for (int k = 0; k < 6; ++k) coeffs[6 * s + k] = L.segment_coeffs[s][k];
+    if (end_points) for (int e = 0; e < 2; ++e) for (int k = 0; k < 3; ++k) end_points[6 * s + 3 * e + k] = L.end_points[2 * s + e][k];
+  }
+  if (seg_offsets) seg_offsets[L.edge_segmented.size()] = o;
+  o = 0;
+  for (size_t i = 0; i < L.point_to_segment.size(); ++i) {
+    if (p2s_offsets) p2s_offsets[i] = o;
+    for (int v : L.point_to_segment[i]) { if (p2s_ids) p2s_ids[o] = v; ++o; }
+  }
+  if (p2s_offsets) p2s_offsets[L.point_to_segment.size()] = o;
+  if (before) for (size_t i = 0; i < L.cornerBeforeFilter.size(); ++i) { const FPoint& p = L.cornerBeforeFilter[i]; before[4 * i] = p.x; before[4 * i + 1] = p.y; before[4 * i + 2] = p.z; before[4 * i + 3] = p.intensity; }
+}
+// the consensus step on its own (the redefinition of pcl::SACSegmentation in FuseLines): indices of the inliers, ascending
+int orc_line_consensus(int n, const float* cloud_xyzi, double threshold, int* inliers) {
+  std::vector<FPoint> c(n);
+  for (int i = 0; i < n; ++i) c[i] = FPoint{cloud_xyzi[4 * i], cloud_xyzi[4 * i + 1], cloud_xyzi[4 * i + 2], cloud_xyzi[4 * i + 3]};
+  const std::vector<int> in = LineConsensus(c, threshold);
+  for (size_t i = 0; i < in.size(); ++i) inliers[i] = in[i];
+  return (int)in.size();
+}
 int orc_features_valid(void* h) { return static_cast<ScanFeatures*>(h)->valid ? 1 : 0; }
 static const std::vector<FPoint>* feature_cloud(const ScanFeatures* f, int which) {
   switch (which) { case 0: return &f->cloud_scan; case 1: return &f->cornerSharp; case 2: return &f->cornerLessSharp; case 3: return &f->surfFlat; case 4: return &f->surfLessFlat; }
   return nullptr;
 }
-// which: 0 cloud_scan, 1 cornerSharp, 2 cornerLessSharp (before EdgeToLine), 3 surfFlat, 4 surfLessFlat
+// which: 0 cloud_scan, 1 cornerSharp, 2 cornerLessSharp (before EdgeToLine unless it was asked for), 3 surfFlat, 4 surfLessFlat
 long orc_features_cloud(void* h, int which, float* out) {
   const std::vector<FPoint>* c = feature_cloud(static_cast<ScanFeatures*>(h), which);
   if (!c) return -1;

@@ -71,12 +71,13 @@ def build_host(force=False):
     build(force=False)
     src = os.path.join(HERE, "host", "pvlm_host.cpp")
     feat = os.path.join(HERE, "host", "pvlm_features.cpp")   # float threshold decisions of the feature extractor: no FMA contraction
+    lines = os.path.join(HERE, "host", "pvlm_lines.cpp")     # line branch of the extractor (EdgeToLine)
     hdr = os.path.join(HERE, "host", "pvlm_host.hpp")
     drv = os.path.join(HERE, "..", "tests", "cpp", "pvlm_host_driver.cpp")
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    newest = max(os.path.getmtime(x) for x in (src, feat, hdr, LIB))
+    newest = max(os.path.getmtime(x) for x in (src, feat, lines, hdr, LIB))
     if force or not os.path.exists(HOST_LIB) or os.path.getmtime(HOST_LIB) < newest:
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-ffp-contract=off", "-shared", src, feat, "-o", HOST_LIB, "-L" + HERE, "-lpvlm", "-pthread",
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-ffp-contract=off", "-shared", src, feat, lines, "-o", HOST_LIB, "-L" + HERE, "-lpvlm", "-pthread",
                                "-Wl,-rpath,$ORIGIN"])
     if os.path.exists(drv) and (force or not os.path.exists(HOST_DRIVER) or os.path.getmtime(HOST_DRIVER) < max(os.path.getmtime(drv), os.path.getmtime(HOST_LIB))):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", drv, "-o", HOST_DRIVER, "-L" + HERE, "-lpvlm_host", "-lpvlm",

@@ -233,7 +233,7 @@ void Velodyne::Segmentation() {
   for (int r = 0; r < rows; ++r) { L.scanStartInd[r] = begin + 5; begin += ring_count[r]; L.scanEndInd[r] = begin - 6; }
 }
 
-void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_threshold, int method, bool segment, ExtractionTrace* trace) {
+void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_threshold, int method, bool segment, ExtractionTrace* trace, bool edge_to_line) {
   if (!valid) return;
   if (method != ADAPTIVE) throw std::invalid_argument("ExtractFeatures: only the ADAPTIVE method (config/Room.txt:32) is mirrored");
   if (cloud_scan.empty()) { fprintf(stderr, "cloud_scan is empty, call Reorder first\n"); return; }
@@ -331,6 +331,8 @@ void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_thresh
       }
     }
   }
+  // ---- EdgeToLine (:752, :1269-1324): line segments from the edge points; does not touch the per-point state
+  if (edge_to_line) EdgeToLine();
   // ---- ExtractPlaneFeatures2 (:1098-1189)
   surfFlat.clear(); surfLessFlat.clear();
   PointCloud ring_less_flat;

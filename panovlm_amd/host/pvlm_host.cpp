@@ -202,7 +202,7 @@ void Velodyne::InvalidateDevice() const {
 Velodyne::~Velodyne() { if (dev_) pvlm_scan_destroy(Engine::Default().ctx(), dev_); }
 Velodyne::Velodyne(const Velodyne& o)
     : id(o.id), valid(o.valid), name(o.name), cloud(o.cloud), cornerLessSharp(o.cornerLessSharp), surfFlat(o.surfFlat), surfLessFlat(o.surfLessFlat),
-      N_SCANS(o.N_SCANS), horizon_scans(o.horizon_scans), cloud_scan(o.cloud_scan), cornerSharp(o.cornerSharp),
+      N_SCANS(o.N_SCANS), horizon_scans(o.horizon_scans), cloud_scan(o.cloud_scan), cornerSharp(o.cornerSharp), cornerBeforeFilter(o.cornerBeforeFilter),
       edge_segmented(o.edge_segmented), point_to_segment(o.point_to_segment), segment_coeffs(o.segment_coeffs), end_points(o.end_points),
       R_wl_(o.R_wl_), t_wl_(o.t_wl_), world_(o.world_), layout_(o.layout_), dev_(nullptr) {}
 Velodyne& Velodyne::operator=(const Velodyne& o) {
@@ -210,7 +210,7 @@ Velodyne& Velodyne::operator=(const Velodyne& o) {
   InvalidateDevice();
   id = o.id; valid = o.valid; name = o.name; cloud = o.cloud; cornerLessSharp = o.cornerLessSharp; surfFlat = o.surfFlat; surfLessFlat = o.surfLessFlat;
   edge_segmented = o.edge_segmented; point_to_segment = o.point_to_segment; segment_coeffs = o.segment_coeffs; end_points = o.end_points;
-  N_SCANS = o.N_SCANS; horizon_scans = o.horizon_scans; cloud_scan = o.cloud_scan; cornerSharp = o.cornerSharp; layout_ = o.layout_;
+  N_SCANS = o.N_SCANS; horizon_scans = o.horizon_scans; cloud_scan = o.cloud_scan; cornerSharp = o.cornerSharp; cornerBeforeFilter = o.cornerBeforeFilter; layout_ = o.layout_;
   R_wl_ = o.R_wl_; t_wl_ = o.t_wl_; world_ = o.world_;
   return *this;
 }
@@ -467,6 +467,8 @@ bool WorldOk(const Velodyne& a, const Velodyne& b) {
   return false;
 }
 }  // namespace
+// public name of the PCA line test for the line branch of the feature extractor (host/pvlm_lines.cpp)
+bool FormLine3D(const double* pts, int n, double tolerance, double dis_threshold, double* line) { return FormLine(pts, n, tolerance, dis_threshold, line); }
 
 std::vector<Point2Line> AssociatePoint2Line(const Velodyne& ref, const Velodyne& nei, const float dist_threshold, bool) {   // :478-548
   std::vector<Point2Line> out;

@@ -114,6 +114,7 @@ class Velodyne {
   int horizon_scans = 1800;
   PointCloud cloud_scan;                          // ReOrderVLP: the scan ring by ring, intensity = ring id
   PointCloud cornerSharp;
+  PointCloud cornerBeforeFilter;                  // cornerLessSharp as ExtractEdgeFeatures2 left it (sensors/Velodyne.cpp:1271)
   std::vector<PointCloud> edge_segmented;
   std::vector<std::set<int>> point_to_segment;
   std::vector<Vector6d> segment_coeffs;  // LiDAR-local (point, unit direction)
@@ -141,14 +142,18 @@ class Velodyne {
   // ExtractFeatures (sensors/Velodyne.cpp:531-760), method ADAPTIVE only (config/Room.txt:32), PLANAR BRANCH: optional
   // range-image Segmentation (:1438-1586), adaptive-window curvature (:623-657), per-sector sort (:707-723),
   // ExtractEdgeFeatures2 (:883-1000) and ExtractPlaneFeatures2 (:1098-1189, surfLessFlat through the 0.2 m voxel grid).
-  // Fills cornerSharp / cornerLessSharp (intensity = index into cloud_scan) / surfFlat / surfLessFlat.  EdgeToLine
-  // (:1269-1324: line segments from the edge points) is NOT run — it fits lines with PCL's RANSAC, which cannot be
-  // restated bit for bit — so edge_segmented / segment_coeffs / end_points / point_to_segment stay empty and
-  // cornerLessSharp is the reference's cornerBeforeFilter.  Sequential per scan (a state machine, a BFS and greedy
+  // Fills cornerSharp / cornerLessSharp (intensity = index into cloud_scan) / surfFlat / surfLessFlat and, between the
+  // edge and the planar picks like upstream (:752), runs EdgeToLine unless edge_to_line is false (cornerLessSharp is then
+  // the reference's cornerBeforeFilter and no segments exist).  Sequential per scan (a state machine, a BFS and greedy
   // non-maximum suppression over 28.8 k points): host code, like upstream; run it under `omp parallel for` over scans
   // as lidar_mapping/LidarOdometry.cpp:131-147 does.  Throws std::invalid_argument for another method.
   void ExtractFeatures(float max_curvature = 50, float intersect_angle_threshold = 5, int method = ADAPTIVE, bool segment = true,
-                       ExtractionTrace* trace = nullptr);
+                       ExtractionTrace* trace = nullptr, bool edge_to_line = true);
+  // EdgeToLine (sensors/Velodyne.cpp:1269-1324) with ExtractLineFeatures (sensors/LidarLineExtraction.cpp:296-389): line
+  // segments grown from the edge points -> edge_segmented / segment_coeffs / end_points / point_to_segment, cornerLessSharp
+  // and cornerSharp filtered down to the members of segments.  Upstream's RANSAC line fit of a fused group
+  // (pcl::SACSegmentation, :150-160) is replaced by the exhaustive 2-point maximum-consensus line (host/pvlm_lines.cpp).
+  void EdgeToLine();
   const RingLayout& Layout() const { return layout_; }
   void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
   void Transform2Local();                         // :1810-1848
@@ -388,6 +393,10 @@ bool ReadPoseT(std::string file_path, bool with_invalid, std::vector<Matrix3d>& 
                std::vector<std::string>& name_list);
 void ExportPoseT(const std::string file_path, const std::vector<Matrix3d>& rotation_list, const std::vector<Vector3d>& trans_list,
                  const std::vector<std::string>& name_list, int precision = 6);
+
+// FormLine(points, tolerance, dis_threshold) of base/Geometry.hpp:220-260 on n x 3 doubles: false (and a zero line) when the
+// points do not form a line; line = (centroid, unit direction)
+bool FormLine3D(const double* pts, int n, double tolerance, double dis_threshold, double* line);
 
 // ceres/rotation.h pieces the callers use (lidar_mapping/LidarOdometry.cpp:31,105)
 void RotationMatrixToAngleAxis(const Matrix3d& R, Vector3d* angle_axis);

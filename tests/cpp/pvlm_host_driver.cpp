@@ -226,14 +226,16 @@ int main(int argc, char** argv) {
         for (auto& p : v.cloud) rd(f, &p.x, 4);
       }
       const auto t0 = std::chrono::steady_clock::now();
-      for (Velodyne& v : l) { v.ReOrderVLP(); v.ExtractFeatures((float)atof(argv[8]), (float)atof(argv[9]), ADAPTIVE, atoi(argv[10]) != 0); }
+      const bool with_lines = argc > 11 && atoi(argv[11]) != 0;       // optional: EdgeToLine + the line-to-line term
+      for (Velodyne& v : l) { v.ReOrderVLP(); v.ExtractFeatures((float)atof(argv[8]), (float)atof(argv[9]), ADAPTIVE, atoi(argv[10]) != 0, nullptr, with_lines); }
       const double ext = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      for (const Velodyne& v : l) printf("features %d valid %d flat %zu less_flat %zu corner %zu\n", v.id, v.valid ? 1 : 0, v.surfFlat.size(), v.surfLessFlat.size(), v.cornerLessSharp.size());
+      for (const Velodyne& v : l) printf("features %d valid %d flat %zu less_flat %zu corner %zu segments %zu\n", v.id, v.valid ? 1 : 0, v.surfFlat.size(), v.surfLessFlat.size(), v.cornerLessSharp.size(), v.edge_segmented.size());
       printf("extract_seconds %.6f\n", ext);
       Config cfg;
       cfg.angle_residual = atoi(argv[4]) != 0; cfg.normalize_distance = atoi(argv[5]) != 0;
-      cfg.line_to_line_residual = false; cfg.point_to_plane_residual = true;
+      cfg.line_to_line_residual = with_lines; cfg.point_to_plane_residual = true;
       cfg.lidar_plane_tolerance = atof(argv[6]); cfg.point_to_plane_dis_threshold = atof(argv[7]);
+      if (argc > 12) cfg.point_to_line_dis_threshold = atof(argv[12]);
       LidarOdometry odo(l, cfg);
       odo.EstimatePose(atoi(argv[3]));
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
@@ -388,7 +390,8 @@ int main(int argc, char** argv) {
       v.N_SCANS = atoi(argv[4]); v.horizon_scans = atoi(argv[5]);
       v.ReOrderVLP();
       ExtractionTrace tr;
-      if (atoi(argv[9])) v.ExtractFeatures((float)atof(argv[6]), (float)atof(argv[7]), ADAPTIVE, atoi(argv[8]) != 0, &tr);
+      const bool edge_to_line = argc > 10 && atoi(argv[10]) != 0;    // optional 9th argument: also run EdgeToLine (line blocks are appended to out.bin)
+      if (atoi(argv[9])) v.ExtractFeatures((float)atof(argv[6]), (float)atof(argv[7]), ADAPTIVE, atoi(argv[8]) != 0, &tr, edge_to_line);
       std::ofstream o(argv[3], std::ios::binary);
       auto wr = [&](const void* p, size_t bytes) { o.write(static_cast<const char*>(p), (std::streamsize)bytes); };
       auto block = [&](const void* p, size_t count, size_t elem) { const int32_t c = (int32_t)count; wr(&c, 4); if (count) wr(p, count * elem); };
@@ -402,8 +405,22 @@ int main(int argc, char** argv) {
       block(L.range_image.data(), L.range_image.size(), 4); block(L.image_to_point_idx.data(), L.image_to_point_idx.size(), 4);
       block(tr.curvature.data(), tr.curvature.size(), 4); block(tr.state.data(), tr.state.size(), 4); block(tr.sort_ind.data(), tr.sort_ind.size(), 4);
       block(tr.left_neighbor.data(), tr.left_neighbor.size(), 4); block(tr.right_neighbor.data(), tr.right_neighbor.size(), 4);
-      printf("features valid %d scan %zu sharp %zu less_sharp %zu flat %zu less_flat %zu\n", valid, v.cloud_scan.size(), v.cornerSharp.size(),
-             v.cornerLessSharp.size(), v.surfFlat.size(), v.surfLessFlat.size());
+      if (edge_to_line) {
+        // line blocks: cornerBeforeFilter; segment offsets (S + 1 int32) + all segment points (x 4 float); coeffs (S x 6 f64);
+        // end points (S x 6 f64); point_to_segment offsets (n_corner + 1 int32) + ids
+        block(v.cornerBeforeFilter.data(), v.cornerBeforeFilter.size(), sizeof(PointXYZI));
+        std::vector<int32_t> so(1, 0), po(1, 0), pid; PointCloud all;
+        for (const PointCloud& c : v.edge_segmented) { all.insert(all.end(), c.begin(), c.end()); so.push_back((int32_t)all.size()); }
+        block(so.data(), so.size(), 4); block(all.data(), all.size(), sizeof(PointXYZI));
+        std::vector<double> co, ep;
+        for (const Vector6d& c : v.segment_coeffs) co.insert(co.end(), c.begin(), c.end());
+        for (const Vector3d& e : v.end_points) ep.insert(ep.end(), e.begin(), e.end());
+        block(co.data(), co.size() / 6, 48); block(ep.data(), ep.size() / 6, 48);
+        for (const std::set<int>& l : v.point_to_segment) { pid.insert(pid.end(), l.begin(), l.end()); po.push_back((int32_t)pid.size()); }
+        block(po.data(), po.size(), 4); block(pid.data(), pid.size(), 4);
+      }
+      printf("features valid %d scan %zu sharp %zu less_sharp %zu flat %zu less_flat %zu segments %zu\n", valid, v.cloud_scan.size(), v.cornerSharp.size(),
+             v.cornerLessSharp.size(), v.surfFlat.size(), v.surfLessFlat.size(), v.edge_segmented.size());
     } else if (cmd == "mvsneighbors") {
       // mvsneighbors <poses.bin> neighbor_size sq_distance_threshold : poses.bin = int32 n, per frame int32 valid, R_wc (9 f64), t_wc (3 f64)
       std::ifstream f(argv[2], std::ios::binary);

@@ -210,9 +210,29 @@ def features():
     np.savez_compressed(os.path.join(OUT, "features.npz"), **d)
 
 
+def line_extraction():
+    """LiDAR feature extraction, LINE branch (Velodyne::EdgeToLine sensors/Velodyne.cpp:1269-1324, ExtractLineFeatures
+    sensors/LidarLineExtraction.cpp) on a raw 16 x 900 scan with clutter; the RANSAC of FuseLines is the exhaustive
+    2-point maximum consensus (oracle/lines.hpp)."""
+    from panovlm_amd import synthetic as sy
+    raw = sy.raw_vlp16_scan(4, cols=900, clutter=20, dropout=0.02)
+    f = orc.ScanFeatures(raw, horizon=900, edge_to_line=True)
+    so = np.cumsum([0] + [len(s) for s in f.edge_segmented]).astype(np.int32)
+    po = np.cumsum([0] + [len(l) for l in f.point_to_segment]).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "line_extraction.npz"), raw=raw, horizon=np.int32(900), cornerBeforeFilter=f.cornerBeforeFilter,
+                        cornerLessSharp=f.cornerLessSharp, cornerSharp=f.cornerSharp, surfFlat=f.surfFlat, surfLessFlat=f.surfLessFlat,
+                        seg_offsets=so, seg_points=np.concatenate(f.edge_segmented) if f.edge_segmented else np.zeros((0, 4), np.float32),
+                        segment_coeffs=f.segment_coeffs, end_points=f.end_points, p2s_offsets=po,
+                        p2s_ids=np.array([v for l in f.point_to_segment for v in l], np.int32))
+
+
 if __name__ == "__main__":
     orc.build()
-    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs(); features()
+    if len(sys.argv) > 1:          # regenerate only the named fixtures: python tests/golden/make_golden.py line_extraction
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs(); features(); line_extraction()
     tot = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -83,9 +83,9 @@ def write_structure(path, frames, tracks):
                 f.write(struct.pack("<II", int(fi), int(ki)))
 
 
-def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_threshold=5.0, segment=True, extract=True):
-    """Velodyne::ReOrderVLP (+ ExtractFeatures) of the host mirror on one raw scan (n x 4 float32) through the test driver.
-    Returns a dict with the same fields as oracle.ScanFeatures."""
+def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_threshold=5.0, segment=True, extract=True, edge_to_line=False):
+    """Velodyne::ReOrderVLP (+ ExtractFeatures, optionally with EdgeToLine) of the host mirror on one raw scan (n x 4 float32)
+    through the test driver.  Returns a dict with the same fields as oracle.ScanFeatures."""
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         dst = os.path.join(d, "out.bin")
@@ -97,7 +97,7 @@ def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_
             with open(src, "wb") as f:
                 f.write(struct.pack("<i", len(raw))); f.write(raw.tobytes())
         log = run("features", src, dst, str(n_scans), str(horizon), repr(float(max_curvature)), repr(float(angle_threshold)), "1" if segment else "0",
-                  "1" if extract else "0")
+                  "1" if extract else "0", "1" if edge_to_line else "0")
         buf = open(dst, "rb").read()
     pos = [0]
 
@@ -118,6 +118,14 @@ def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_
     out["curvature"] = block(np.float32)
     for name in ("state", "sort_ind", "left", "right"):
         out[name] = block(np.int32)
+    if edge_to_line and extract:
+        out["cornerBeforeFilter"] = block(np.float32, 4)
+        so = block(np.int32); pts = block(np.float32, 4)
+        out["edge_segmented"] = [pts[so[k]:so[k + 1]] for k in range(len(so) - 1)]
+        out["segment_coeffs"] = block(np.float64, 6)
+        out["end_points"] = block(np.float64, 6).reshape(-1, 2, 3)
+        po = block(np.int32); pid = block(np.int32)
+        out["point_to_segment"] = [pid[po[k]:po[k + 1]].tolist() for k in range(len(po) - 1)]
     assert pos[0] == len(buf)
     return out
 

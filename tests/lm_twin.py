@@ -294,6 +294,98 @@ def refine_pose_lines(oracle, scans, thr=0.3, normalize=True):
     return res
 
 
+def refine_pose_full(oracle, scans, cfg):
+    """One RefinePose with BOTH LiDAR terms, in the order lidar_mapping/LidarOdometry.cpp:38-56 adds them: line-to-line
+    (GenerateTracks + AddLidarLineToLineResidual2, no loss for the angle functor) then point-to-plane (Huber).  scans: dicts
+    with flat_cur / less_cur / corner_cur (LOCAL float clouds), flat_tag, less_tag, p2s, seg_points, seg_coeffs, end_points."""
+    F = len(scans)
+    wl = [world_line_scan(s) for s in scans]
+    wp = [dict(id=s["id"], R_wl=s["R_wl"], t_wl=s["t_wl"], flat_xyz=transform_f32(s["flat_cur"], s["R_wl"], s["t_wl"]), flat_tag=s["flat_tag"],
+               less_xyz=transform_f32(s["less_cur"], s["R_wl"], s["t_wl"]), less_tag=s["less_tag"]) for s in scans]
+    aa = np.zeros((F, 3)); t = np.zeros((F, 3))
+    for i, s in enumerate(scans):
+        Rl, tl = inv_pose(s["R_wl"], s["t_wl"])
+        aa[i] = oracle.matrix_to_angle_axis(Rl); t[i] = tl
+    poses = np.array([np.concatenate([s["R_wl"].reshape(-1), s["t_wl"]]) for s in scans])
+    nb6 = oracle.find_neighbors(poses, np.ones(F, np.int32), 6)
+    nb4 = oracle.find_neighbors(poses, np.ones(F, np.int32), 4)
+    groups = []
+    segmented = any(len(s["seg_points"]) > 0 for s in scans)
+    if cfg.get("lines", True) and segmented:
+        tracks = line_tracks(oracle, wl, nb4, 3)
+        member = {}
+        for k, tr in enumerate(tracks):
+            for node in tr:
+                member.setdefault(node, []).append(k)
+        rows, rid, nid = [], [], []
+        for i in range(F):
+            for n in nb6[i]:
+                if n < 0 or n == i or n >= F:
+                    continue
+                o = oracle.assoc_line2line(wl[i], wl[n], cfg.get("line_thr", 0.3))
+                for nl, rl, p1, p2 in zip(o["nei_idx"], o["ref_idx"], o["p1"], o["p2"]):
+                    if (i, int(rl)) not in member:
+                        continue
+                    if not any((n, int(nl)) in tracks[k] for k in member[(i, int(rl))]):
+                        continue
+                    for ci in scans[n]["seg_points"][int(nl)]:
+                        lp = world2local(scans[n]["R_wl"], scans[n]["t_wl"], wl[n]["corner_xyz"][ci].astype(np.float64))
+                        rows.append(np.concatenate([lp, p1, p2, [1.0]])); rid.append(i); nid.append(n)
+        if rows:
+            groups.append(dict(kind=3, normalize=cfg["normalize"], rows=np.array(rows), rid=np.array(rid, np.int32), nid=np.array(nid, np.int32), loss=0, a=0.0))
+    rows, rid, nid = [], [], []
+    for i in range(F):
+        for n_idx in nb6[i]:
+            if n_idx < 0 or n_idx == i or n_idx >= F:
+                continue
+            o = oracle.assoc_point2plane(wp[i], wp[n_idx], cfg["tol"], cfg["thr"])
+            m = len(o["qidx"])
+            rows.append(np.concatenate([o["point"], o["plane"], np.ones((m, 1))], axis=1))
+            rid += [i] * m; nid += [n_idx] * m
+    rows = np.concatenate(rows)
+    groups.append(dict(kind=1, normalize=cfg["normalize"], rows=rows, rid=np.array(rid, np.int32), nid=np.array(nid, np.int32), loss=1, a=2 * np.pi / 180))
+    res = solve(oracle, groups, aa, t, {0})
+    res["blocks"] = sum(len(g["rows"]) for g in groups)
+    res["line_blocks"] = len(groups[0]["rows"]) if len(groups) == 2 else 0
+    for i, s in enumerate(scans):
+        Rl, tl = inv_pose(s["R_wl"], s["t_wl"])
+        s["flat_cur"] = transform_f32(wp[i]["flat_xyz"], Rl, tl); s["less_cur"] = transform_f32(wp[i]["less_xyz"], Rl, tl)
+        s["corner_cur"] = transform_f32(wl[i]["corner_xyz"], Rl, tl)
+        R_lw = oracle.angle_axis_to_matrix(aa[i])
+        R_wl = R_lw.T.copy()
+        rt = np.array([(R_wl[r, 0] * t[i][0] + R_wl[r, 1] * t[i][1]) + R_wl[r, 2] * t[i][2] for r in range(3)])
+        s["R_wl"] = R_wl; s["t_wl"] = -rt
+    return res
+
+
+def estimate_pose_full(oracle, scans, cfg, max_iteration):
+    for s in scans:
+        s["flat_cur"] = np.asarray(s["flat_local"], np.float32); s["less_cur"] = np.asarray(s["less_local"], np.float32)
+        s["corner_cur"] = np.asarray(s["corner_local"], np.float32)
+    log = []
+    last_cost, last_step = 0.0, 32767
+    for _ in range(max_iteration):
+        res = refine_pose_full(oracle, scans, cfg)
+        log.append(res)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if abs(res["final_cost"] - last_cost) / last_cost < 0.01:
+                break
+        if res["successful"] < 5 and last_step < 5:
+            break
+        last_cost, last_step = res["final_cost"], res["successful"]
+    return log
+
+
+def twin_scan_from_features(sid, R_wl, t_wl, f):
+    """Scan dict of the twins above from an oracle.ScanFeatures(..., edge_to_line=True)."""
+    ids = [int(v) for v in f.cornerLessSharp[:, 3]]
+    where = {v: k for k, v in enumerate(ids)}
+    return dict(id=sid, R_wl=R_wl, t_wl=t_wl, flat_local=f.surfFlat[:, :3], flat_tag=f.surfFlat[:, 3], less_local=f.surfLessFlat[:, :3],
+                less_tag=f.surfLessFlat[:, 3], corner_local=f.cornerLessSharp[:, :3], p2s=f.point_to_segment,
+                seg_points=[[where[int(v)] for v in seg[:, 3]] for seg in f.edge_segmented], seg_coeffs=f.segment_coeffs,
+                end_points=f.end_points.reshape(-1, 6))
+
+
 # ------------------------------------------------------------------------------------------------
 # CameraLidarOptimizer (mapping mode, no SfM term): AssociateLineMulti + Optimize + JointOptimize
 # ------------------------------------------------------------------------------------------------

@@ -518,3 +518,33 @@ def test_sharded_estimate_pose_two_ranks_on_one_gpu(tmp):
         assert np.abs(po0[k] - pos[k]).max() <= 1e-9 * max(1.0, np.abs(pos[k]).max())
     # each rank really did only its share: the association stage of a rank saw half of the reference scans
     assert any(l.startswith("stage") and "exchange of the normal equations" in l for l in outs[0])
+
+
+def test_raw_scans_with_line_segments_to_refined_poses(oracle, tmp):
+    """SURVEY.md §8 N3, line branch: raw VLP-16 scans -> ReOrderVLP -> ExtractFeatures WITH EdgeToLine (host) -> segments ->
+    LidarLineMatch tracks + line-to-line blocks + point-to-plane blocks in LidarOdometry::EstimatePose (GPU votes,
+    association and normal equations) against the same chain on the oracle (oracle/lines.hpp feeds the twin)."""
+    scans = []
+    for k in range(4):
+        R, t = sy.estimated_pose(k)
+        scans.append(dict(id=k, R_wl=R, t_wl=t, raw=sy.raw_vlp16_scan(k, clutter=20)))
+    path = os.path.join(tmp, "raw_lines.bin")
+    host_io.write_raw_scans(path, scans)
+    out = host_io.run("rawodometry", path, 2, 1, 1, 0.05, 1.0, 1000.0, 5.0, 1, 1, 0.3)
+    feats = [l.split() for l in out if l.startswith("features")]
+    iters, poses = _parse_odometry(out)
+    twin = []
+    for s, ft in zip(scans, feats):
+        f = oracle.ScanFeatures(s["raw"], edge_to_line=True)
+        assert (int(ft[5]), int(ft[7]), int(ft[9]), int(ft[11])) == (len(f.surfFlat), len(f.surfLessFlat), len(f.cornerLessSharp), len(f.edge_segmented))
+        assert len(f.edge_segmented) >= 5
+        twin.append(lm_twin.twin_scan_from_features(s["id"], s["R_wl"], s["t_wl"], f))
+    log = lm_twin.estimate_pose_full(oracle, twin, dict(angle=True, normalize=True, tol=0.05, thr=1.0, line_thr=0.3), 2)
+    assert len(iters) == len(log)
+    for it, lg in zip(iters, log):
+        assert int(it[6]) == lg["blocks"] and lg["line_blocks"] > 50          # the line-to-line term is really in the problem
+        assert abs(float(it[2]) - lg["final_cost"]) <= 1e-6 * lg["final_cost"]
+        assert int(it[4]) == lg["successful"]
+    for k, s in enumerate(twin):
+        R = poses[k][:9].reshape(3, 3); t = poses[k][9:]
+        assert np.abs(R - s["R_wl"]).max() <= 1e-6 and np.abs(t - s["t_wl"]).max() <= 1e-6 * max(1.0, np.abs(s["t_wl"]).max())
