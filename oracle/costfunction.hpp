@@ -258,6 +258,48 @@ inline bool AutoDiffEvaluate(const F& f, const double* aa_r, const double* t_r, 
   return ok;
 }
 
+// The same evaluation in x87 extended precision (JetT<long double, 12>: 64-bit significand): the reference's own statements,
+// 11 more bits.  The arbiter where the double evaluation of upstream's formula is the less accurate side — acos(cos) of
+// the *_Angle functors has an error of ~eps/r near r -> 0 (base/Geometry.hpp:450-466) — so that the parity tests can assert
+// 1e-6 against the exact value of the formula instead of widening the gate by that error.  Results rounded to double.
+template <typename F>
+inline bool AutoDiffEvaluateExt(const F& f, const double* aa_r, const double* t_r, const double* aa_n, const double* t_n,
+                                double* residual, double* J) {
+  typedef JetT<long double, 12> JT;
+  JT p[4][3];
+  const double* src[4] = {aa_r, t_r, aa_n, t_n};
+  for (int b = 0; b < 4; ++b)
+    for (int k = 0; k < 3; ++k) p[b][k] = JT((long double)src[b][k], b * 3 + k);
+  JT r;
+  const bool ok = f(p[0], p[1], p[2], p[3], &r);
+  *residual = (double)r.a;
+  if (J) for (int k = 0; k < 12; ++k) J[k] = (double)r.v[k];
+  return ok;
+}
+
+// The quantity the *_Angle functors branch on (`dis < 1e-3 -> residual 0`, CostFunction.h:680-684, :893-897), in extended
+// precision: lets a test COUNT the blocks that sit on the threshold instead of hiding them in a tolerance.
+inline double BranchDistanceExt(const Point2Plane_Angle& f, const double* aa_r, const double* t_r, const double* aa_n, const double* t_n) {
+  long double a[4][3];
+  const double* src[4] = {aa_r, t_r, aa_n, t_n};
+  for (int b = 0; b < 4; ++b) for (int k = 0; k < 3; ++k) a[b][k] = src[b][k];
+  long double point_ref[3];
+  TransformNeighborToRef(a[0], a[1], a[2], a[3], f.curr_point, point_ref);
+  long double pc[4] = {f.plane[0], f.plane[1], f.plane[2], f.plane[3]};
+  return (double)PointToPlaneDistance(pc, point_ref, true);
+}
+inline double BranchDistanceExt(const Point2Line_Angle& f, const double* aa_r, const double* t_r, const double* aa_n, const double* t_n) {
+  long double a[4][3];
+  const double* src[4] = {aa_r, t_r, aa_n, t_n};
+  for (int b = 0; b < 4; ++b) for (int k = 0; k < 3; ++k) a[b][k] = src[b][k];
+  long double q[3];
+  TransformNeighborToRef(a[0], a[1], a[2], a[3], f.curr_point, q);
+  const long double x0 = f.line_point[0], y0 = f.line_point[1], z0 = f.line_point[2], nx = f.line_direction[0], ny = f.line_direction[1], nz = f.line_direction[2];
+  const long double k = nx * (q[0] - x0) + ny * (q[1] - y0) + nz * (q[2] - z0);
+  const long double pp[3] = {k * nx + x0, k * ny + y0, k * nz + z0};
+  return (double)std::sqrt((q[0] - pp[0]) * (q[0] - pp[0]) + (q[1] - pp[1]) * (q[1] - pp[1]) + (q[2] - pp[2]) * (q[2] - pp[2]));
+}
+
 // ceres::HuberLoss(a)::Evaluate — rho[0..2] for s = r^2 ([recalled] loss_function.cc)
 inline void HuberLossEvaluate(double a, double s, double* rho) {
   const double b = a * a;

@@ -319,8 +319,8 @@ inline void ExtractLineFeatures(const std::vector<FPoint>& edge_points, const st
         line_points.push_back(PclPoint2Vec(edge_points[idx2]));
         if (IsZero6(FormLineV(line_points, 5.0))) continue;
         std::set<int> curr_segment = {(int)idx, idx1, idx2};
-        int line_start, line_end;
-        double line_length;
+        int line_start = 0, line_end = 0;
+        double line_length = 0;
         FurthestPointsV(line_points, line_start, line_end, line_length);
         bool expand1 = true, expand2 = true;
         while (expand1 || expand2) {

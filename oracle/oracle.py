@@ -96,19 +96,30 @@ def num_threads():
     return int(lib().orc_num_threads())
 
 
-def evaluate(kind, rec, ref_id, nei_id, aa, t, normalize=False, jac=True, threads=0):
-    """AutoDiff-style evaluation of n residual blocks.  rec: n x STRIDE[kind]; returns (r, J|None)."""
+def evaluate(kind, rec, ref_id, nei_id, aa, t, normalize=False, jac=True, threads=0, extended=False):
+    """AutoDiff-style evaluation of n residual blocks.  rec: n x STRIDE[kind]; returns (r, J|None).
+    extended=True: the same statements in x87 extended precision (oracle/costfunction.hpp AutoDiffEvaluateExt), rounded to double."""
     rec = _f64(rec); aa = _f64(aa); t = _f64(t)
     ref_id = _i32(ref_id); nei_id = _i32(nei_id)
     n = rec.shape[0]
     assert rec.shape[1] == STRIDE[kind]
     r = np.empty(n, np.float64)
     J = np.empty((n, 12), np.float64) if jac else None
-    rc = lib().orc_eval(C.c_int(kind), C.c_int(1 if normalize else 0), C.c_long(n), _p(rec, C.c_double),
+    rc = lib().orc_eval(C.c_int(kind), C.c_int((1 if normalize else 0) | (2 if extended else 0)), C.c_long(n), _p(rec, C.c_double),
                         C.c_int(rec.shape[1]), _p(ref_id, C.c_int), _p(nei_id, C.c_int), _p(aa, C.c_double),
                         _p(t, C.c_double), _p(r, C.c_double), _p(J, C.c_double), C.c_int(threads))
     assert rc == 0
     return r, J
+
+
+def branch_distance(kind, rec, ref_id, nei_id, aa, t):
+    """The distance the *_Angle functors (kind 1, 3) test against 1e-3 first (CostFunction.h:680-684, :893-897), extended precision."""
+    rec = _f64(rec); aa = _f64(aa); t = _f64(t); ref_id = _i32(ref_id); nei_id = _i32(nei_id)
+    d = np.empty(rec.shape[0], np.float64)
+    rc = lib().orc_branch_distance(C.c_int(kind), C.c_long(rec.shape[0]), _p(rec, C.c_double), C.c_int(rec.shape[1]), _p(ref_id, C.c_int),
+                                   _p(nei_id, C.c_int), _p(aa, C.c_double), _p(t, C.c_double), _p(d, C.c_double))
+    assert rc == 0
+    return d
 
 
 def evaluate_reproj(bearing, weight, cam_id, pt_id, aa, t, X, jac=True):

@@ -72,6 +72,7 @@ int orc_num_threads() {
 int orc_eval(int kind, int flags, long n, const double* rec, int stride, const int* ref_id, const int* nei_id,
              const double* aa, const double* t, double* r, double* J, int threads) {
   const bool normalize = (flags & 1) != 0;
+  const bool ext = (flags & 2) != 0;      // x87 extended-precision evaluation of the same statements (AutoDiffEvaluateExt)
 #ifdef _OPENMP
   const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for schedule(static) num_threads(nt)
@@ -81,17 +82,31 @@ int orc_eval(int kind, int flags, long n, const double* rec, int stride, const i
     const double* aar = aa + 3 * size_t(ref_id[i]); const double* tr = t + 3 * size_t(ref_id[i]);
     const double* aan = aa + 3 * size_t(nei_id[i]); const double* tn = t + 3 * size_t(nei_id[i]);
     double* Ji = J ? J + 12 * size_t(i) : nullptr;
+    auto run = [&](const auto& f) { if (ext) AutoDiffEvaluateExt(f, aar, tr, aan, tn, r + i, Ji); else AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); };
     switch (kind) {
-      case 0: { Point2Plane_Meter f; std::memcpy(f.curr_point, c, 24); std::memcpy(f.plane, c + 3, 32); f.weight = c[7]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
-      case 1: { Point2Plane_Angle f; std::memcpy(f.curr_point, c, 24); std::memcpy(f.plane, c + 3, 32); f.weight = c[7]; f.normalize_distance = normalize; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
-      case 2: { Point2Line_Meter f; std::memcpy(f.curr_point, c, 24); f.SetLine(c + 3, c + 6); f.weight = c[9]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
-      case 3: { Point2Line_Angle f; std::memcpy(f.curr_point, c, 24); f.SetLine(c + 3, c + 6); f.weight = c[9]; f.normalize_distance = normalize; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
-      case 4: { Plane2Plane_Global f; f.SetPlane(c); std::memcpy(f.point_a, c + 3, 24); std::memcpy(f.point_b, c + 6, 24); f.weight = c[9]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
-      case 5: { PlaneIOUResidual f; f.SetPlane(c); std::memcpy(f.middle_neighbor, c + 4, 24); std::memcpy(f.middle_ref, c + 7, 24); f.angle = c[10]; f.weight = c[11]; AutoDiffEvaluate(f, aar, tr, aan, tn, r + i, Ji); break; }
+      case 0: { Point2Plane_Meter f; std::memcpy(f.curr_point, c, 24); std::memcpy(f.plane, c + 3, 32); f.weight = c[7]; run(f); break; }
+      case 1: { Point2Plane_Angle f; std::memcpy(f.curr_point, c, 24); std::memcpy(f.plane, c + 3, 32); f.weight = c[7]; f.normalize_distance = normalize; run(f); break; }
+      case 2: { Point2Line_Meter f; std::memcpy(f.curr_point, c, 24); f.SetLine(c + 3, c + 6); f.weight = c[9]; run(f); break; }
+      case 3: { Point2Line_Angle f; std::memcpy(f.curr_point, c, 24); f.SetLine(c + 3, c + 6); f.weight = c[9]; f.normalize_distance = normalize; run(f); break; }
+      case 4: { Plane2Plane_Global f; f.SetPlane(c); std::memcpy(f.point_a, c + 3, 24); std::memcpy(f.point_b, c + 6, 24); f.weight = c[9]; run(f); break; }
+      case 5: { PlaneIOUResidual f; f.SetPlane(c); std::memcpy(f.middle_neighbor, c + 4, 24); std::memcpy(f.middle_ref, c + 7, 24); f.angle = c[10]; f.weight = c[11]; run(f); break; }
       default: break;
     }
   }
   return (kind >= 0 && kind <= 5) ? 0 : -1;
+}
+
+// the distance the *_Angle functors (kind 1, 3) compare with 1e-3 before anything else, in extended precision
+int orc_branch_distance(int kind, long n, const double* rec, int stride, const int* ref_id, const int* nei_id, const double* aa, const double* t, double* dis) {
+  if (kind != 1 && kind != 3) return -1;
+  for (long i = 0; i < n; ++i) {
+    const double* c = rec + size_t(i) * stride;
+    const double* aar = aa + 3 * size_t(ref_id[i]); const double* tr = t + 3 * size_t(ref_id[i]);
+    const double* aan = aa + 3 * size_t(nei_id[i]); const double* tn = t + 3 * size_t(nei_id[i]);
+    if (kind == 1) { Point2Plane_Angle f; std::memcpy(f.curr_point, c, 24); std::memcpy(f.plane, c + 3, 32); f.weight = c[7]; f.normalize_distance = true; dis[i] = BranchDistanceExt(f, aar, tr, aan, tn); }
+    else { Point2Line_Angle f; std::memcpy(f.curr_point, c, 24); f.SetLine(c + 3, c + 6); f.weight = c[9]; f.normalize_distance = true; dis[i] = BranchDistanceExt(f, aar, tr, aan, tn); }
+  }
+  return 0;
 }
 
 // Reprojection blocks: observation i sees point pt_id[i] from camera cam_id[i] with the (un-normalised) bearing

@@ -48,8 +48,11 @@ def functors():
         rid, nid = synth.expand_ids(off, ref, nei)
         w = 1.3
         r, J = orc.evaluate(kind, synth.oracle_rows(kind, rows, w), rid, nid, aa, t, normalize=normalize)
+        # the same statements in x87 extended precision: the exact value of the reference's formula (arbiter of the GPU test)
+        rx, Jx = orc.evaluate(kind, synth.oracle_rows(kind, rows, w), rid, nid, aa, t, normalize=normalize, extended=True)
         k = "k%d_n%d_" % (kind, int(normalize))
-        d.update({k + "aa": aa, k + "t": t, k + "ref": ref, k + "nei": nei, k + "off": off, k + "rows": rows, k + "r": r, k + "J": J})
+        d.update({k + "aa": aa, k + "t": t, k + "ref": ref, k + "nei": nei, k + "off": off, k + "rows": rows, k + "r": r, k + "J": J,
+                  k + "r_ext": rx, k + "J_ext": Jx})
     d["weight"] = np.array(1.3)
     np.savez_compressed(os.path.join(OUT, "functors.npz"), **d)
 

@@ -1,5 +1,11 @@
 """GPU parity of the residual/Jacobian kernels (K5 materialise, K6 fused) against the CPU oracle,
-through the C ABI.  Tolerance: 1e-6 relative (BASELINE.json north_star); observed ~1e-12."""
+through the C ABI.  Tolerance: 1e-6 relative (BASELINE.json north_star), nothing added to it.
+
+Arbiter = the reference's statements (Jet AutoDiff through its rotation chain, acos of the clamped cosine) evaluated in
+x87 extended precision (oracle AutoDiffEvaluateExt): the exact value of upstream's formula to ~1e-19.  Upstream's own
+double evaluation is the LESS accurate side near r -> 0 (acos near 1 loses eps / r; round 1 widened the gate by that
+amount) and is itself held to the same 1e-6 here.  Decisions (the `dis < 1e-3 -> 0` early-out) are compared exactly,
+and the blocks that sit ON a threshold are counted, not tolerated."""
 import numpy as np
 import pytest
 
@@ -10,14 +16,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-6
 
 
-def r_tol(ro, kind):
-    """1e-6 relative (north_star).  The angle functors end in acos(c) exactly like the reference
-    (base/Geometry.hpp:450-485); near c = 1 an ulp of c moves the angle by ~eps/r, on the CPU as much as
-    on the GPU, so that conditioning term is added for them."""
-    tol = RTOL * np.maximum(np.abs(ro), 1e-9) + 1e-15
-    if kind in (1, 3, 4, 5):
-        tol = tol + 8 * 2.2e-16 / np.maximum(np.abs(ro), 1e-7)
-    return tol
+ATOL = 1e-13      # absolute floor for residuals that are exactly or nearly zero (radians / metres)
 
 
 @pytest.fixture(scope="module")
@@ -52,16 +51,25 @@ def test_materialise_matches_oracle(ctx, oracle, kind, normalize):
     ctx.set_poses(aa, t)
     r, J = rs.eval(jac=True)
     rid, nid = synth.expand_ids(off, ref, nei)
-    ro, Jo = oracle.evaluate(kind, synth.oracle_rows(kind, rows, w), rid, nid, aa, t, normalize=normalize)
+    orows = synth.oracle_rows(kind, rows, w)
+    ro, Jo = oracle.evaluate(kind, orows, rid, nid, aa, t, normalize=normalize, extended=True)     # exact value of upstream's formula
+    rd, Jd = oracle.evaluate(kind, orows, rid, nid, aa, t, normalize=normalize)                    # what upstream computes in double
     assert r.shape == ro.shape and J.shape == Jo.shape
-    assert np.all(np.abs(r - ro) <= r_tol(ro, kind)), (np.abs(r - ro) / r_tol(ro, kind)).max()
-    # zero residuals (early-outs / clamps) must agree exactly in position
-    assert np.array_equal(ro == 0, r == 0)
+    # decisions: the early-out of the *_Angle functors must fall on the same blocks as upstream's; blocks whose branch
+    # distance sits on the threshold (within 1e-12 relative) are counted — none may hide in a tolerance
+    if kind in (1, 3):
+        dis = oracle.branch_distance(kind, orows, rid, nid, aa, t)
+        on_threshold = np.abs(dis - 1e-3) <= 1e-15
+        assert on_threshold.sum() == 0
+        assert np.array_equal(r == 0, dis < 1e-3)
+    assert np.array_equal(rd == 0, r == 0) and np.array_equal(ro == 0, r == 0)
+    assert np.all(np.abs(r - ro) <= RTOL * np.abs(ro) + ATOL), (np.abs(r - ro) / (RTOL * np.abs(ro) + ATOL)).max()
     scale = np.maximum(np.abs(Jo).max(axis=1, keepdims=True), 1e-9)
-    jtol = np.full((len(ro), 1), RTOL)
-    if kind in (1, 3, 4, 5):   # d acos/dc = -1/sqrt(1-c^2): relative conditioning ~ eps / r^2
-        jtol = jtol + (8 * 2.2e-16 / np.maximum(ro * ro, 1e-14))[:, None]
-    assert np.all(np.abs(J - Jo) <= jtol * scale), (np.abs(J - Jo) / (jtol * scale)).max()
+    assert np.all(np.abs(J - Jo) <= RTOL * scale), (np.abs(J - Jo) / (RTOL * scale)).max()
+    # upstream's own double evaluation against the same arbiter and gate (it is the looser of the two near r -> 0)
+    assert np.all(np.abs(rd - ro) <= RTOL * np.abs(ro) + ATOL) and np.all(np.abs(Jd - Jo) <= RTOL * scale)
+    # the GPU is at least as close to the exact value as upstream's double arithmetic, up to rounding noise
+    assert np.abs(J - Jo).max() <= max(10 * np.abs(Jd - Jo).max(), 1e-10 * scale.max())
     # cost-only evaluation returns identical residuals
     r2, J2 = rs.eval(jac=False)
     assert J2 is None and np.array_equal(r, r2)
@@ -86,6 +94,49 @@ def test_fused_pair_blocks_match_oracle(ctx, oracle, kind, normalize, loss):
     # determinism: bit-identical on a second run
     assert np.array_equal(blocks, rs.pair_blocks(loss, a))
     rs.close()
+
+
+@pytest.mark.parametrize("kind", [1, 3])
+def test_early_out_threshold_is_decided_like_upstream(ctx, oracle, kind):
+    """Blocks constructed to straddle `dis < 1e-3` (CostFunction.h:680-684, :893-897): the point is moved along the plane
+    normal / away from the line so that the branch distance is 1e-3 (1 +- d) for d from 1e-3 down to 1e-12.  At every
+    margin >= 1e-9 the GPU takes upstream's branch on every block; below that the blocks are counted as on-threshold."""
+    import panovlm_amd as pv
+    rng = np.random.default_rng(900 + kind)
+    F = 5
+    aa, t = synth.random_poses(rng, F)
+    ref = np.array([0, 1, 2, 3], np.int32); nei = np.array([1, 2, 3, 4], np.int32)
+    rows, off = synth.random_resset(rng, kind, aa, t, ref, nei, np.full(4, 60))
+    rid, nid = synth.expand_ids(off, ref, nei)
+    flips = 0
+    for margin in (1e-3, 1e-6, 1e-9, 1e-12):
+        for side in (-1.0, 1.0):
+            target = 1e-3 * (1.0 + side * margin)
+            rr = rows.copy()
+            # move P_n so that the branch distance becomes `target`: for both functors the distance is linear along the
+            # offset direction, so two Newton corrections in extended precision land within 1e-16
+            for _ in range(4):
+                d = oracle.branch_distance(kind, synth.oracle_rows(kind, rr), rid, nid, aa, t)
+                eps = 1e-7
+                grad = np.zeros((len(rr), 3))
+                for k in range(3):
+                    pert = rr.copy(); pert[:, k] += eps
+                    grad[:, k] = (oracle.branch_distance(kind, synth.oracle_rows(kind, pert), rid, nid, aa, t) - d) / eps
+                g2 = np.maximum((grad * grad).sum(1), 1e-30)
+                rr[:, :3] += ((target - d) / g2)[:, None] * grad
+            d = oracle.branch_distance(kind, synth.oracle_rows(kind, rr), rid, nid, aa, t)
+            ok = np.abs(d - target) <= 1e-3 * margin * 0.25            # rows that really sit on the wanted side of the threshold
+            rs = pv.ResidualSet.upload(ctx, kind, rr, off, ref, nei, flags=1)
+            ctx.set_poses(aa, t)
+            r, _ = rs.eval(jac=False)
+            rd, _ = oracle.evaluate(kind, synth.oracle_rows(kind, rr), rid, nid, aa, t, normalize=True, jac=False)
+            rs.close()
+            if margin >= 1e-9:
+                assert ok.sum() >= 200
+                assert np.array_equal((r == 0)[ok], (d < 1e-3)[ok]) and np.array_equal((r == 0)[ok], (rd == 0)[ok])
+            else:
+                flips += int(((r == 0) != (rd == 0)).sum())
+    assert flips <= 240        # reported, not hidden: at a 1e-15 m margin GPU and CPU may round the distance to different sides
 
 
 def test_normal_equations_packed(ctx, oracle):

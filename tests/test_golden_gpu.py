@@ -26,11 +26,12 @@ def test_functor_golden(ctx, kind, normalize):
     rs = pv.ResidualSet.upload(ctx, kind, g[k + "rows"], g[k + "off"], g[k + "ref"], g[k + "nei"], flags=normalize, weight=float(g["weight"]))
     ctx.set_poses(g[k + "aa"], g[k + "t"])
     r, J = rs.eval()
-    ro, Jo = g[k + "r"], g[k + "J"]
-    tol = 1e-6 * np.maximum(np.abs(ro), 1e-9) + (8 * 2.2e-16 / np.maximum(np.abs(ro), 1e-7) if kind in (1, 3, 4, 5) else 0) + 1e-15
-    assert np.all(np.abs(r - ro) <= tol)
-    jt = 1e-6 + (8 * 2.2e-16 / np.maximum(ro * ro, 1e-14) if kind in (1, 3, 4, 5) else 0)
-    assert np.all(np.abs(J - Jo) <= (jt * np.ones_like(ro))[:, None] * np.maximum(np.abs(Jo).max(axis=1, keepdims=True), 1e-9))
+    # arbiter: the reference's statements evaluated in x87 extended precision (oracle/costfunction.hpp AutoDiffEvaluateExt) —
+    # plain 1e-6, no conditioning allowance; the double evaluation of the same formula is compared with the same gate
+    ro, Jo = g[k + "r_ext"], g[k + "J_ext"]
+    assert np.array_equal(r == 0, g[k + "r"] == 0)
+    assert np.all(np.abs(r - ro) <= 1e-6 * np.abs(ro) + 1e-13)
+    assert np.all(np.abs(J - Jo) <= 1e-6 * np.maximum(np.abs(Jo).max(axis=1, keepdims=True), 1e-9))
 
 
 def test_assoc_point2plane_golden(ctx):
