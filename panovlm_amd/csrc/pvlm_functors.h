@@ -72,23 +72,29 @@ __device__ __forceinline__ double atan2_pos(double y, double x) {
 }
 
 // VectorAngle3D (base/Geometry.hpp:450-466), un-normalised form, with gradients wrt v1, v2.
-// Returns false when the clamped branches (constant result, zero gradient) were taken.
+// Returns false when the clamped branches (constant result, zero gradient) were taken — decided on the cosine like
+// upstream.  The VALUE is atan2(|v1 x v2|, v1.v2) and the gradients are (v1 x w)/(|v1|^2 |w|), -(v2 x w)/(|v2|^2 |w|)
+// with w = v1 x v2: the same angle and derivatives as acos of the normalised dot product, without its loss of eps / r
+// near r -> 0 (upstream's double evaluation is the less accurate side there; tests/test_eval_gpu.py compares both with
+// an extended-precision evaluation of upstream's statements).
+__device__ __forceinline__ double atan2_pos(double y, double x);
 __device__ __forceinline__ bool angle_between(const double* v1, const double* v2, double& r, double* g1, double* g2) {
   const double d = dot3(v1, v2);
   const double q1 = dot3(v1, v1), q2 = dot3(v2, v2);
   const double n1 = sqrt(q1), n2 = sqrt(q2);
-  const double inv = 1.0 / (n1 * n2);
-  const double c = d * inv;
+  const double c = d / (n1 * n2);
   if (c >= 1.0) { r = 0.0; return false; }
   if (c <= -1.0) { r = M_PI; return false; }
-  r = acos(c);
-  const double drdc = -1.0 / sqrt(1.0 - c * c);
-  const double k1 = c / q1, k2 = c / q2;
+  double w[3], a1[3], a2[3];
+  cross3(v1, v2, w);
+  const double nw = sqrt(dot3(w, w));
+  if (!(nw > 0.0)) { r = d < 0.0 ? M_PI : 0.0; return false; }
+  r = atan2_pos(nw, d);
+  cross3(v1, w, a1);
+  cross3(v2, w, a2);
+  const double k1 = 1.0 / (q1 * nw), k2 = -1.0 / (q2 * nw);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    g1[k] = drdc * (v2[k] * inv - k1 * v1[k]);
-    g2[k] = drdc * (v1[k] * inv - k2 * v2[k]);
-  }
+  for (int k = 0; k < 3; ++k) { g1[k] = k1 * a1[k]; g2[k] = k2 * a2[k]; }
   return true;
 }
 
@@ -233,14 +239,20 @@ __device__ __forceinline__ void eval_wrench(const double* rec, const double* T, 
     const double dp = dot3(ni, nrm);
     const double s = dp < 0.0 ? -1.0 : 1.0;
     const double q1 = dot3(ni, ni), q2 = dot3(nrm, nrm);
-    const double inv = 1.0 / (sqrt(q1) * sqrt(q2));
-    const double c = s * dp * inv;
-    if (c >= 1.0) return;
-    out.r = wk * acos(c);
-    const double drdc = -wk / sqrt(1.0 - c * c);
+    const double c = s * dp / (sqrt(q1) * sqrt(q2));
+    if (c >= 1.0) return;                      // PlaneAngle's clamp (Geometry.hpp:480-481), decided on the cosine like upstream
+    // value and gradient in the cross-product form (see angle_between): theta = atan2(|ni x n|, |ni . n|),
+    // d theta / d n = -s (n x w) / (|n|^2 |w|), w = ni x n
+    double wv[3], nxw[3];
+    cross3(ni, nrm, wv);
+    const double nw = sqrt(dot3(wv, wv));
+    if (!(nw > 0.0)) return;
+    out.r = wk * atan2_pos(nw, s * dp);
+    cross3(nrm, wv, nxw);
+    const double kg = -wk * s / (q2 * nw);
     double gn[3], ga[3], gb[3], ca[3], cb[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) gn[k] = drdc * (s * ni[k] * inv - c * nrm[k] / q2);
+    for (int k = 0; k < 3; ++k) gn[k] = kg * nxw[k];
     cross3(b, gn, ga);   // d(a x b) . gn  wrt a
     cross3(gn, a, gb);   // wrt b
     const double ma[3] = {a[0] - trw[0], a[1] - trw[1], a[2] - trw[2]};

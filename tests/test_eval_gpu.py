@@ -66,8 +66,13 @@ def test_materialise_matches_oracle(ctx, oracle, kind, normalize):
     assert np.all(np.abs(r - ro) <= RTOL * np.abs(ro) + ATOL), (np.abs(r - ro) / (RTOL * np.abs(ro) + ATOL)).max()
     scale = np.maximum(np.abs(Jo).max(axis=1, keepdims=True), 1e-9)
     assert np.all(np.abs(J - Jo) <= RTOL * scale), (np.abs(J - Jo) / (RTOL * scale)).max()
-    # upstream's own double evaluation against the same arbiter and gate (it is the looser of the two near r -> 0)
-    assert np.all(np.abs(rd - ro) <= RTOL * np.abs(ro) + ATOL) and np.all(np.abs(Jd - Jo) <= RTOL * scale)
+    # upstream's own double evaluation against the same arbiter: it is the looser of the two near r -> 0 (acos of a
+    # cosine next to 1 loses eps / r, its derivative eps / r^2) and only passes with that conditioning term added —
+    # the allowance round 1 had put on the GPU comparison belongs here
+    cond = 8 * 2.2e-16 / np.maximum(np.abs(ro), 1e-300)
+    assert np.all(np.abs(rd - ro) <= RTOL * np.abs(ro) + ATOL + cond)
+    with np.errstate(over="ignore"):
+        assert np.all(np.abs(Jd - Jo) <= (RTOL + (cond / np.maximum(np.abs(ro), 1e-300))[:, None]) * scale)
     # the GPU is at least as close to the exact value as upstream's double arithmetic, up to rounding noise
     assert np.abs(J - Jo).max() <= max(10 * np.abs(Jd - Jo).max(), 1e-10 * scale.max())
     # cost-only evaluation returns identical residuals
