@@ -310,6 +310,14 @@ def main():
         except Exception as e:  # reporting extra only
             mat = {"error": str(e)[:200]}
 
+    # the Ceres-feeding boundary: r + J made HOST-visible (pinned memory, asynchronous copies) — PCIe-bound, reported, never `value`
+    pcie = None
+    if rank == 0 and world == 1:
+        try:
+            pcie = pcie_block(ctx, pv, associate, ref, nei, args)
+        except Exception as e:  # reporting extra only
+            pcie = {"error": str(e)[:200]}
+
     # 5.7K equirectangular panorama (5760 x 2880): whole-image CamToImage / ImageToCam maps (K7) and the
     # camera<->LiDAR line-association voting loop (K8) for a Room-sized batch — reported beside the headline, never `value`
     pano = None
@@ -370,6 +378,7 @@ def main():
                      "kernels_per_step": 5, "ms_per_step_minus_fused_kernel": dt / args.steps * 1e3 - kern_ms / max(kern_n, 1)},
             "per_rank_projection": projection,
             "materialise": mat,
+            "pcie": pcie,
             "panorama": pano,
             "setup": {"scan_generation_s": t_gen, "scans_generated": len(needed)},
         }
@@ -509,6 +518,41 @@ def association_points(ctx, pv, torch, args, scans, dscans, ref, nei, associate,
                                    "fused_kernel_ms": k_ms / max(k_n, 1), "M_evals_per_s_kernel": rsf.n / max(k_ms / max(k_n, 1), 1e-9) / 1e3,
                                    "GBps": rsf.n * 56 / max(k_ms / max(k_n, 1), 1e-9) / 1e6}
     neq_f.close(); rsf.close()
+    return out
+
+
+def pcie_block(ctx, pv, associate, ref, nei, args):
+    """Host-visible evaluation for a host-side solver (integration/pvlm_ceres.hpp): the blocks of the first 64 reference scans,
+    evaluated on the GPU and delivered into page-locked host memory.  Two encodings: the 1 x 12 Jacobian rows (104 B per
+    block) and wrench rows [r | c | g] + per-pair 3x3 tables (56 B per block, the row is formed on the host on demand)."""
+    keep = np.flatnonzero(ref < min(64, args.scans))
+    rs = associate(ref[keep], nei[keep], args.tolerance)
+    n, P = rs.n, rs.n_pairs
+    out = {"blocks": int(n), "pairs": int(P)}
+    t0 = time.perf_counter()
+    h_r = ctx.host_alloc(n * 8); h_J = ctx.host_alloc(n * 96); h_w = ctx.host_alloc(n * 56); h_t = ctx.host_alloc(max(P, 1) * 33 * 8)
+    out["pinned_alloc_s"] = time.perf_counter() - t0
+    for name, fn, nbytes in (("jacobian_rows", lambda: rs.eval_host_async(h_r, h_J), 104), ("wrench_rows", lambda: rs.eval_wrench_host_async(h_w, h_t), 56)):
+        fn(); ctx.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"bytes_per_block": nbytes, "seconds": dt, "M_evals_per_s_host_visible": n / dt / 1e6, "D2H_GBps": n * nbytes / dt / 1e9}
+    # the pageable path of round 1 (pvlm_eval into ordinary numpy arrays), on a slice
+    m = min(n, 2_000_000)
+    keep2 = np.flatnonzero(ref < 4)
+    rs2 = associate(ref[keep2], nei[keep2], args.tolerance)
+    t0 = time.perf_counter()
+    rs2.eval(jac=True)
+    dt = time.perf_counter() - t0
+    out["pageable_pvlm_eval"] = {"blocks": int(rs2.n), "M_evals_per_s_host_visible": rs2.n / dt / 1e6, "D2H_GBps": rs2.n * 104 / dt / 1e9}
+    out["link_GBps_measured"] = max(out["jacobian_rows"]["D2H_GBps"], out["wrench_rows"]["D2H_GBps"])   # the boxes of the pool differ (30 - 56 GB/s seen)
+    rs2.close(); rs.close()
+    for a in (h_r, h_J, h_w, h_t):
+        ctx.host_free(a)
     return out
 
 

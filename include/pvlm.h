@@ -131,6 +131,26 @@ pvlm_status pvlm_eval(pvlm_ctx* ctx, const pvlm_resset* rs, double* residuals, d
 /* Same, outputs left in device memory (async on the ctx stream; no host copies). */
 pvlm_status pvlm_eval_dev(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_residuals, double* d_jacobians);
 
+/* ---- host-visible evaluation: the Ceres-feeding boundary ------------------------------------------------------- *
+ * ceres::CostFunction::Evaluate reads host memory, so the last hop of this mode is a PCIe link (30 GB/s measured on the
+ * MI355X box, against 5 TB/s for the kernel): the API is built around that hop.
+ *   pvlm_host_alloc / _free     page-locked host memory (the copies run at link rate and asynchronously only into it;
+ *                               pageable destinations work but serialise).
+ *   pvlm_eval_host_async        residuals[n] and jacobians[n x 12] (NULL = cost only) as pvlm_eval, delivered
+ *                               asynchronously on the context's stream: 104 B per block.
+ *   pvlm_eval_wrench_host_async the same information in 56 B per block: wrench_rows[n x 7] = [r | c(3) | g(3)] plus the
+ *                               per-pair tables pair_tables[n_pairs x PVLM_PAIR_TABLE] = [R_rn(9) | t_rn(3) | t_rw(3) |
+ *                               J_l(aa_r)(9) | M_n(9)], from which the host forms the row on demand (36 multiply-adds):
+ *                                 d r/d aa_r = c^T J_l      d r/d t_r = g^T      d r/d aa_n = c^T M_n      d r/d t_n = -g^T R_rn
+ *                               (row-major 3x3 blocks; integration/pvlm_ceres.hpp does it inside Evaluate).
+ * Both go through a bounded device staging buffer (PVLM_STAGE_ROWS rows, 32 M by default) slice by slice; the results
+ * are complete after pvlm_synchronize.  Residuals are RAW (no loss), in the compact order of pvlm_resset_download. */
+#define PVLM_PAIR_TABLE 33
+pvlm_status pvlm_host_alloc(pvlm_ctx* ctx, int64_t bytes, void** out);
+pvlm_status pvlm_host_free(pvlm_ctx* ctx, void* p);
+pvlm_status pvlm_eval_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* residuals, double* jacobians_or_null);
+pvlm_status pvlm_eval_wrench_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* wrench_rows, double* pair_tables);
+
 /* Fused evaluation: residual + Jacobian in registers, loss-corrected (Ceres corrector for
  * rho'' <= 0: scale r and J by sqrt(rho')) and contracted into per-pair normal-equation blocks
  *   out[p] = [ H_rr(36) | H_rn(36) | H_nn(36) | g_r(6) | g_n(6) | cost(1) ]   (121 doubles, row-major)

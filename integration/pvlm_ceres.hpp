@@ -10,9 +10,17 @@
 //   3. evaluates all of them with one batched kernel launch per Ceres evaluation point through a
 //      ceres::EvaluationCallback (Problem::Options::evaluation_callback, Ceres >= 2.0).
 //
-// NOT compiled in this repository's image (no Ceres / Eigen / PCL there): it is written against the public Ceres 2.0
-// API and PanoVLM's own types, and is the file a PanoVLM maintainer adds next to util/Optimization.cpp.  It contains
-// no PanoVLM code.  Only include/pvlm.h (C ABI) is used from this repository.
+// Ceres itself is not in this repository's image: the file is written against the public Ceres 2.0 API and PanoVLM's own
+// types, and is what a PanoVLM maintainer adds next to util/Optimization.cpp.  It contains no PanoVLM code; only
+// include/pvlm.h (C ABI) is used from this repository.  CI compiles and RUNS it against an interface-only test double of
+// the few Ceres classes it touches (tests/cpp/ceres_double/ceres/ceres.h — labelled as such: it pins nothing about Ceres'
+// behaviour, it only proves that this file compiles and that the rows it hands out equal pvlm_eval's;
+// tests/test_host_gpu.py::test_ceres_adapter_rows).
+//
+// The boundary is a PCIe link (30 GB/s on the MI355X box): the batch is delivered as 56-byte wrench rows [r | c | g]
+// (pvlm_eval_wrench_host_async) into page-locked memory, asynchronously, and the 1 x 12 Jacobian row is formed from the
+// row and its pair's 3x3 tables inside Evaluate — 36 multiply-adds on the Ceres worker thread that asks for it —
+// instead of shipping 104 bytes per block.
 //
 // Usage inside LidarOdometry::RefinePose (lidar_mapping/LidarOdometry.cpp:36-80):
 //     pvlm::CeresBatch batch(ctx);                                  // before the ceres::Problem
@@ -35,38 +43,50 @@ namespace pvlm {
 class CeresBatch : public ceres::EvaluationCallback {
  public:
   explicit CeresBatch(pvlm_ctx* ctx) : ctx_(ctx) {}
-  ~CeresBatch() override { for (Set& s : sets_) pvlm_resset_destroy(ctx_, s.set); }
+  ~CeresBatch() override {
+    for (Set& s : sets_) { pvlm_host_free(ctx_, s.rows); pvlm_host_free(ctx_, s.tables); pvlm_resset_destroy(ctx_, s.set); }
+  }
+  CeresBatch(const CeresBatch&) = delete;
+  CeresBatch& operator=(const CeresBatch&) = delete;
 
   // The pose storage Ceres optimises in place: angleAxis_lw_list / t_lw_list (LidarOdometry.cpp:23-33), n x 3 each,
   // contiguous (eigen_vector<Eigen::Vector3d>::data()->data()).
   void SetPoseStorage(int n_poses, const double* angle_axis, const double* translation) { n_ = n_poses; aa_ = angle_axis; t_ = translation; }
 
-  // Takes ownership of a residual set produced by the association kernels; returns its index.
-  int AddSet(pvlm_resset* set) {
-    Set s; s.set = set;
-    pvlm_resset_info(set, &s.n, nullptr, nullptr, nullptr);
-    s.r.resize((size_t)s.n); s.J.resize((size_t)s.n * 12);
+  // Takes ownership of a residual set produced by the association kernels; `pair_of_row[i]` = segment of block i.
+  // Returns the set's index.
+  int AddSet(pvlm_resset* set, std::vector<int> pair_of_row) {
+    Set s; s.set = set; s.pair_of_row = std::move(pair_of_row);
+    pvlm_resset_info(set, &s.n, &s.n_pairs, nullptr, nullptr);
+    void* p = nullptr;
+    if (pvlm_host_alloc(ctx_, (int64_t)s.n * 7 * (int64_t)sizeof(double), &p) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
+    s.rows = static_cast<double*>(p);
+    if (pvlm_host_alloc(ctx_, (int64_t)s.n_pairs * PVLM_PAIR_TABLE * (int64_t)sizeof(double), &p) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
+    s.tables = static_cast<double*>(p);
     sets_.push_back(std::move(s));
     return (int)sets_.size() - 1;
   }
-  const double* residual(int set, int64_t row) const { return &sets_[set].r[(size_t)row]; }
-  const double* jacobian(int set, int64_t row) const { return &sets_[set].J[(size_t)row * 12]; }
+  // [r | c(3) | g(3)] of block `row`, and the table of its pair: [R_rn(9) | t_rn(3) | t_rw(3) | J_l(aa_r)(9) | M_n(9)]
+  const double* row(int set, int64_t row) const { return sets_[(size_t)set].rows + (size_t)row * 7; }
+  const double* table(int set, int64_t row) const { const Set& s = sets_[(size_t)set]; return s.tables + (size_t)s.pair_of_row[(size_t)row] * PVLM_PAIR_TABLE; }
 
-  // ceres::EvaluationCallback — called once before the residual blocks are evaluated at a (possibly new) point.
-  void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override {
-    if (!new_evaluation_point && (have_jacobians_ || !evaluate_jacobians)) return;
+  // ceres::EvaluationCallback — called once before the residual blocks are evaluated at a (possibly new) point.  The
+  // wrench rows serve cost-only and Jacobian evaluations alike, so a repeated call at the same point costs nothing.
+  void PrepareForEvaluation(bool /*evaluate_jacobians*/, bool new_evaluation_point) override {
+    if (!new_evaluation_point && valid_) return;
     if (pvlm_set_poses(ctx_, n_, aa_, t_) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
-    for (Set& s : sets_)   // ONE kernel launch per set for all of its residual blocks (K5, materialise mode)
-      if (pvlm_eval(ctx_, s.set, s.r.data(), evaluate_jacobians ? s.J.data() : nullptr) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
-    have_jacobians_ = evaluate_jacobians;
+    for (Set& s : sets_)   // ONE kernel per slice of a set, its copy queued right behind it; nothing waits until the end
+      if (pvlm_eval_wrench_host_async(ctx_, s.set, s.rows, s.tables) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
+    if (pvlm_synchronize(ctx_) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
+    valid_ = true;
   }
 
  private:
-  struct Set { pvlm_resset* set = nullptr; int64_t n = 0; std::vector<double> r, J; };
+  struct Set { pvlm_resset* set = nullptr; int64_t n = 0; int n_pairs = 0; double* rows = nullptr; double* tables = nullptr; std::vector<int> pair_of_row; };
   pvlm_ctx* ctx_;
   int n_ = 0; const double* aa_ = nullptr; const double* t_ = nullptr;
   std::vector<Set> sets_;
-  bool have_jacobians_ = false;
+  bool valid_ = false;
 };
 
 // Row i of a batched evaluation as a Ceres cost function: the same signature Ceres sees from
@@ -76,11 +96,16 @@ class CeresRow : public ceres::SizedCostFunction<1, 3, 3, 3, 3> {
  public:
   CeresRow(const CeresBatch* batch, int set, int64_t row) : batch_(batch), set_(set), row_(row) {}
   bool Evaluate(double const* const*, double* residuals, double** jacobians) const override {
-    residuals[0] = *batch_->residual(set_, row_);
+    const double* w = batch_->row(set_, row_);                 // [r | c | g]
+    residuals[0] = w[0];
     if (jacobians) {
-      const double* J = batch_->jacobian(set_, row_);   // [d/daa_r | d/dt_r | d/daa_n | d/dt_n]
-      for (int b = 0; b < 4; ++b)
-        if (jacobians[b]) { jacobians[b][0] = J[3 * b]; jacobians[b][1] = J[3 * b + 1]; jacobians[b][2] = J[3 * b + 2]; }
+      const double* T = batch_->table(set_, row_);
+      const double* c = w + 1; const double* g = w + 4;
+      const double* R = T; const double* Jl = T + 15; const double* Mn = T + 24;
+      if (jacobians[0]) for (int k = 0; k < 3; ++k) jacobians[0][k] = c[0] * Jl[k] + c[1] * Jl[3 + k] + c[2] * Jl[6 + k];     // d/d angleAxis_rw
+      if (jacobians[1]) for (int k = 0; k < 3; ++k) jacobians[1][k] = g[k];                                                    // d/d t_rw
+      if (jacobians[2]) for (int k = 0; k < 3; ++k) jacobians[2][k] = c[0] * Mn[k] + c[1] * Mn[3 + k] + c[2] * Mn[6 + k];     // d/d angleAxis_nw
+      if (jacobians[3]) for (int k = 0; k < 3; ++k) jacobians[3][k] = -(g[0] * R[k] + g[1] * R[3 + k] + g[2] * R[6 + k]);     // d/d t_nw
     }
     return std::isfinite(residuals[0]);
   }
@@ -119,7 +144,9 @@ size_t AddLidarPointToPlaneResidualGpu(CeresBatch& batch, pvlm_ctx* ctx, const s
   std::vector<int64_t> offsets((size_t)n_pairs + 1);
   std::vector<int> pair_ref((size_t)n_pairs), pair_nei((size_t)n_pairs);       // = lidars[.].id of each segment
   pvlm_resset_download(ctx, set, offsets.data(), pair_ref.data(), pair_nei.data(), nullptr);
-  const int set_id = batch.AddSet(set);
+  std::vector<int> pair_of_row((size_t)n);
+  for (int p = 0; p < n_pairs; ++p) for (int64_t row = offsets[p]; row < offsets[p + 1]; ++row) pair_of_row[(size_t)row] = p;
+  const int set_id = batch.AddSet(set, std::move(pair_of_row));
   batch.SetPoseStorage((int)angleAxis_lw_list.size(), angleAxis_lw_list.data()->data(), t_lw_list.data()->data());
   for (int p = 0; p < n_pairs; ++p)                                              // same order as the reference's push_back order
     for (int64_t row = offsets[p]; row < offsets[p + 1]; ++row)

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
-    "pvlm_allreduce_sum_f64_host",
+    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async",
 ]
 
 
@@ -164,6 +164,21 @@ class Context:
         buf = (C.c_ubyte * 128)()
         self._check(self.lib.pvlm_comm_unique_id(self._h, buf), "pvlm_comm_unique_id")
         return bytes(buf)
+
+    def host_alloc(self, nbytes):
+        """Page-locked host memory (pvlm_host_alloc) as a numpy float64 array; free with host_free(array)."""
+        p = C.c_void_p()
+        self._check(self.lib.pvlm_host_alloc(self._h, C.c_int64(int(nbytes)), C.byref(p)), "pvlm_host_alloc")
+        n = max(int(nbytes) // 8, 1)
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(n,))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, array):
+        p = getattr(self, "_pinned", {}).pop(array.ctypes.data, None)
+        if p is not None:
+            self._check(self.lib.pvlm_host_free(self._h, p), "pvlm_host_free")
 
     def graph_begin(self):
         self._check(self.lib.pvlm_graph_begin(self._h), "pvlm_graph_begin")
@@ -505,6 +520,15 @@ class ResidualSet:
     def pair_blocks_dev(self, d_out_ptr, loss=LOSS_NONE, loss_a=0.0):
         self.ctx._check(self.ctx.lib.pvlm_eval_pair_blocks_dev(self.ctx._h, self._h, C.c_int(loss), C.c_double(loss_a), C.c_void_p(d_out_ptr)),
                         "pvlm_eval_pair_blocks_dev")
+
+    def eval_host_async(self, r_host, J_host=None):
+        """pvlm_eval_host_async into (preferably pinned) host arrays; complete after ctx.synchronize()."""
+        self.ctx._check(self.ctx.lib.pvlm_eval_host_async(self.ctx._h, self._h, C.c_void_p(r_host.ctypes.data),
+                                                          C.c_void_p(J_host.ctypes.data if J_host is not None else 0)), "pvlm_eval_host_async")
+
+    def eval_wrench_host_async(self, w_host, tab_host):
+        self.ctx._check(self.ctx.lib.pvlm_eval_wrench_host_async(self.ctx._h, self._h, C.c_void_p(w_host.ctypes.data), C.c_void_p(tab_host.ctypes.data)),
+                        "pvlm_eval_wrench_host_async")
 
     def assoc_debug(self):
         q = np.empty(max(self.n, 1), np.int32); nn = np.empty((max(self.n, 1), 10), np.int32)

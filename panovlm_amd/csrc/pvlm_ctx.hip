@@ -390,7 +390,7 @@ pvlm_status pvlm_i_resset_free(pvlm_ctx* ctx, pvlm_resset* rs) {
   for (int32_t* b : rs->d_nn) pvlm_i_free(ctx, b);
   pvlm_i_free(ctx, rs->d_pair_cols); pvlm_i_free(ctx, rs->d_pair_stride); pvlm_i_free(ctx, rs->d_out_start); pvlm_i_free(ctx, rs->d_ref);
   pvlm_i_free(ctx, rs->d_nei); pvlm_i_free(ctx, rs->d_blk_pair); pvlm_i_free(ctx, rs->d_blk_chunk); pvlm_i_free(ctx, rs->d_pair_blk_start);
-  pvlm_i_free(ctx, rs->d_pair_tab); pvlm_i_free(ctx, rs->d_partials); pvlm_i_free(ctx, rs->d_pair_blocks);
+  pvlm_i_free(ctx, rs->d_pair_tab); pvlm_i_free(ctx, rs->d_partials); pvlm_i_free(ctx, rs->d_pair_blocks); pvlm_i_free(ctx, rs->d_stage);
   delete rs;
   return PVLM_OK;
 }
@@ -419,6 +419,7 @@ pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs) {
   }
   pair_blk_start[P] = (int)blk_pair.size();
   rs->n_blocks = (int)blk_pair.size();
+  rs->h_pair_blk_start = pair_blk_start;
   pvlm_status st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_pair_cols, pair_cols.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_pair_stride, pair_stride.size()))) return st;

@@ -103,13 +103,16 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* const* _
                                                           const int64_t* __restrict__ out_start,
                                                           const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
                                                           int chunk_rows, const double* __restrict__ pair_tab, double weight,
-                                                          double* __restrict__ r_out, double* __restrict__ J_out) {
-  const int p = blk_pair[blockIdx.x];
+                                                          double* __restrict__ r_out, double* __restrict__ J_out, int blk0, int64_t row0) {
+  // blk0 / row0: the launch covers work-list blocks [blk0, blk0 + gridDim.x) whose first compact row is row0; outputs are
+  // indexed relative to row0 (a bounded staging buffer filled slice by slice, pvlm_eval_host_async)
+  const int bi = blockIdx.x + blk0;
+  const int p = blk_pair[bi];
   const double* __restrict__ cols = pair_cols[p];   // first row of the pair's segment, column 0
   const int64_t n_dev = pair_stride[p];             // column stride of the pair's block
-  const int64_t o0 = out_start[p];
-  const int64_t len = out_start[p + 1] - o0;
-  const int64_t lo = (int64_t)blk_chunk[blockIdx.x] * chunk_rows;
+  const int64_t o0 = out_start[p] - row0;
+  const int64_t len = out_start[p + 1] - out_start[p];
+  const int64_t lo = (int64_t)blk_chunk[bi] * chunk_rows;
   const int64_t hi = min(len, lo + (int64_t)chunk_rows);
   double T[PVLM_PAIR_TAB];
 #pragma unroll
@@ -167,6 +170,65 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* const* _
       }
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wrench rows: [r | c(3) | g(3)] per block, compact order — everything a host needs to form the 1 x 12 Jacobian row with
+// the per-pair table (J = [c^T J_l(aa_r) | g^T | c^T M_n | -g^T R_rn]) in 56 B instead of 104 B: the Ceres-feeding
+// boundary is a PCIe link (30 GB/s measured), not HBM.  Rows staged through LDS so that every store instruction of a
+// wave writes contiguous memory.
+// ---------------------------------------------------------------------------------------------
+template <int KIND, bool NORM, int NCOLS>
+__global__ __launch_bounds__(256) void k_eval_wrench(const double* const* __restrict__ pair_cols, const int64_t* __restrict__ pair_stride,
+                                                     const int64_t* __restrict__ out_start, const int* __restrict__ blk_pair,
+                                                     const int* __restrict__ blk_chunk, int chunk_rows, const double* __restrict__ pair_tab,
+                                                     double weight, double* __restrict__ w_out, int blk0, int64_t row0) {
+  const int bi = blockIdx.x + blk0;
+  const int p = blk_pair[bi];
+  const double* __restrict__ cols = pair_cols[p];
+  const int64_t n_dev = pair_stride[p];
+  const int64_t o0 = out_start[p] - row0;
+  const int64_t len = out_start[p + 1] - out_start[p];
+  const int64_t lo = (int64_t)blk_chunk[bi] * chunk_rows;
+  const int64_t hi = min(len, lo + (int64_t)chunk_rows);
+  double T[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) T[k] = pair_tab[(size_t)p * PVLM_PAIR_TAB + k];
+  __shared__ double stage[4][128 * 7];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t n_it = (hi - lo + 511) / 512;
+  for (int64_t it = 0; it < n_it; ++it) {
+    const int64_t j = lo + it * 512 + 2 * (int64_t)threadIdx.x;
+    if (j < hi) {
+      double2 v[NCOLS];
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (j + h >= hi) break;
+        double rec[NCOLS];
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
+        Wrench w;
+        eval_wrench<KIND, NORM>(rec, T, weight, w);
+        double* dst = &stage[wv][(2 * lane + h) * 7];
+        dst[0] = w.r; dst[1] = w.c[0]; dst[2] = w.c[1]; dst[3] = w.c[2]; dst[4] = w.g[0]; dst[5] = w.g[1]; dst[6] = w.g[2];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int64_t r0 = lo + it * 512 + (int64_t)wv * 128;
+    const int64_t rows = min((int64_t)128, hi - r0);
+    if (rows > 0) {
+      double* g = w_out + (size_t)(o0 + r0) * 7;
+      const int n = (int)rows * 7;
+#pragma unroll
+      for (int t = 0; t < 14; ++t) {
+        const int e = t * 64 + lane;
+        if (e < n) g[e] = stage[wv][e];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -425,9 +487,15 @@ static pvlm_status ensure_pair_table(pvlm_ctx* ctx, const pvlm_resset* crs) {
 }
 
 template <int KIND, bool NORM, int NCOLS>
-static void launch_materialise(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_r, double* d_J) {
-  hipLaunchKernelGGL((k_eval_materialise<KIND, NORM, NCOLS>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride,
-                     rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_r, d_J);
+static void launch_materialise(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_r, double* d_J, int blk0 = 0, int nblk = -1, int64_t row0 = 0) {
+  hipLaunchKernelGGL((k_eval_materialise<KIND, NORM, NCOLS>), dim3(nblk < 0 ? rs->n_blocks : nblk), dim3(256), 0, ctx->stream, rs->d_pair_cols,
+                     rs->d_pair_stride, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_r, d_J,
+                     blk0, row0);
+}
+template <int KIND, bool NORM, int NCOLS>
+static void launch_wrench(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_w, int blk0, int nblk, int64_t row0) {
+  hipLaunchKernelGGL((k_eval_wrench<KIND, NORM, NCOLS>), dim3(nblk), dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride, rs->d_out_start,
+                     rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_w, blk0, row0);
 }
 
 template <int KIND, bool NORM, int NCOLS>
@@ -515,6 +583,86 @@ pvlm_status pvlm_eval(pvlm_ctx* ctx, const pvlm_resset* rs, double* r, double* J
   hipStreamSynchronize(ctx->stream);
   pvlm_i_free(ctx, d_r); pvlm_i_free(ctx, d_J);
   return st;
+}
+
+// Evaluation delivered to HOST memory, slice by slice through a bounded device staging buffer (PVLM_STAGE_ROWS rows,
+// 32 M by default): kernel over a run of whole pairs -> asynchronous copy of that slice; everything on the context stream.
+// mode 0: residuals[n] (+ jacobians[n x 12]); mode 1: wrench rows [n x 7] + the pair tables.
+static pvlm_status eval_to_host(pvlm_ctx* ctx, const pvlm_resset* crs, int mode, double* h_a, double* h_b) {
+  pvlm_resset* rs = const_cast<pvlm_resset*>(crs);
+  pvlm_status st = ensure_pair_table(ctx, rs);
+  if (st) return st;
+  if (mode == 1 && h_b && rs->n_pairs > 0)
+    PVLM_HIP(ctx, hipMemcpyAsync(h_b, rs->d_pair_tab, (size_t)rs->n_pairs * PVLM_PAIR_TAB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (rs->n == 0) return PVLM_OK;
+  int64_t stage_rows = 32ll << 20;
+  if (const char* e = getenv("PVLM_STAGE_ROWS")) { const long long v = atoll(e); if (v > 0) stage_rows = v; }
+  const int width = mode == 1 ? 7 : (h_b ? 13 : 1);
+  int64_t need = 0;      // the staging buffer holds the largest run of pairs that fits stage_rows (at least one pair)
+  for (int p = 0; p < rs->n_pairs;) {
+    int q = p; int64_t rows = 0;
+    while (q < rs->n_pairs && (q == p || rows + (rs->h_out_start[q + 1] - rs->h_out_start[q]) <= stage_rows)) { rows += rs->h_out_start[q + 1] - rs->h_out_start[q]; ++q; }
+    need = std::max(need, rows);
+    p = q;
+  }
+  if (rs->stage_doubles < (size_t)need * width) {
+    if (ctx->capturing) { PVLM_SET_ERR(ctx, "staging buffer would grow inside a graph capture"); return PVLM_ERR_STATE; }
+    pvlm_i_free(ctx, rs->d_stage); rs->d_stage = nullptr; rs->stage_doubles = 0;
+    if ((st = pvlm_i_alloc(ctx, &rs->d_stage, (size_t)need * width))) return st;
+    rs->stage_doubles = (size_t)need * width;
+  }
+  for (int p = 0; p < rs->n_pairs;) {
+    int q = p; int64_t rows = 0;
+    while (q < rs->n_pairs && (q == p || rows + (rs->h_out_start[q + 1] - rs->h_out_start[q]) <= stage_rows)) { rows += rs->h_out_start[q + 1] - rs->h_out_start[q]; ++q; }
+    const int blk0 = rs->h_pair_blk_start[p], nblk = rs->h_pair_blk_start[q] - blk0;
+    const int64_t row0 = rs->h_out_start[p];
+    if (nblk > 0) {
+      double* d_r = rs->d_stage;
+      double* d_J = rs->d_stage + rows;
+      {
+        pvlm_prof_scope prof(ctx, 1);
+        if (mode == 1) PVLM_DISPATCH(launch_wrench, ctx, rs, rs->d_stage, blk0, nblk, row0);
+        else PVLM_DISPATCH(launch_materialise, ctx, rs, d_r, h_b ? d_J : nullptr, blk0, nblk, row0);
+      }
+      PVLM_HIP(ctx, hipGetLastError());
+      if (mode == 1) PVLM_HIP(ctx, hipMemcpyAsync(h_a + (size_t)row0 * 7, rs->d_stage, (size_t)rows * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      else {
+        PVLM_HIP(ctx, hipMemcpyAsync(h_a + row0, d_r, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (h_b) PVLM_HIP(ctx, hipMemcpyAsync(h_b + (size_t)row0 * 12, d_J, (size_t)rows * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
+    p = q;
+  }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_eval_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* residuals, double* jacobians) {
+  if (!ctx || !rs || (rs->n > 0 && !residuals)) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  return eval_to_host(ctx, rs, 0, residuals, jacobians);
+}
+
+pvlm_status pvlm_eval_wrench_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* wrench_rows, double* pair_tables) {
+  if (!ctx || !rs || (rs->n > 0 && !wrench_rows) || (rs->n_pairs > 0 && !pair_tables)) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  return eval_to_host(ctx, rs, 1, wrench_rows, pair_tables);
+}
+
+pvlm_status pvlm_host_alloc(pvlm_ctx* ctx, int64_t bytes, void** out) {
+  if (!ctx || !out || bytes < 0) return PVLM_ERR_ARG;
+  *out = nullptr;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  PVLM_HIP(ctx, hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault));
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_host_free(pvlm_ctx* ctx, void* p) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (!p) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PVLM_HIP(ctx, hipHostFree(p));
+  return PVLM_OK;
 }
 
 pvlm_status pvlm_eval_pair_blocks_dev(pvlm_ctx* ctx, const pvlm_resset* rs, pvlm_loss loss, double a, double* d_out) {

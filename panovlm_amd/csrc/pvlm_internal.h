@@ -119,6 +119,9 @@ struct pvlm_resset {
   int* d_pair_blk_start = nullptr;  // n_pairs+1
   double* d_pair_tab = nullptr;     // n_pairs x PVLM_PAIR_TAB
   uint64_t pair_tab_epoch = ~0ull;
+  std::vector<int> h_pair_blk_start;  // host mirror of d_pair_blk_start
+  double* d_stage = nullptr;        // bounded staging buffer of the host-delivering evaluations (grow-only)
+  size_t stage_doubles = 0;
   double* d_partials = nullptr;     // n_blocks x PVLM_PARTIAL
   double* d_pair_blocks = nullptr;  // n_pairs x PVLM_PAIR_BLOCK (scratch for neq accumulate)
   // host mirrors of the segment table (h_seg_start: first row of the pair INSIDE its block, n_pairs entries)

@@ -12,6 +12,7 @@
 #include <string>
 
 #include "../../panovlm_amd/host/pvlm_host.hpp"
+#include "../../integration/pvlm_ceres.hpp"   // compiled against tests/cpp/ceres_double (an interface-only stand-in, see there)
 
 using namespace pvlm;
 
@@ -209,6 +210,47 @@ int main(int argc, char** argv) {
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
       for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());
       PrintPoses(odo.GetLidarData());
+    } else if (cmd == "ceresadapter") {
+      // ceresadapter <scans.bin> tol thr : integration/pvlm_ceres.hpp driven through the interface-only Ceres test double —
+      // AddLidarPointToPlaneResidualGpu builds one CeresRow per correspondence; one "Ceres evaluation" (callback + every
+      // block's Evaluate) is compared with pvlm_eval of the same residual set at the same poses.
+      auto l = LoadScans(argv[2]);
+      for (Velodyne& v : l) v.Transform2LidarWorld();
+      const auto nb = FindNeighbors(l, 6);
+      Engine& e = Engine::Default();
+      std::vector<pvlm_scan*> dev;
+      for (const Velodyne& v : l) dev.push_back(v.DeviceScan());
+      std::vector<Vector3d> aa(l.size()), tt(l.size());
+      for (size_t i = 0; i < l.size(); ++i) {
+        const Matrix3d& R = l[i].GetRotation();
+        const Matrix3d R_lw = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+        RotationMatrixToAngleAxis(R_lw, &aa[i]);
+        const Vector3d& t = l[i].GetTranslation();
+        for (int r = 0; r < 3; ++r) tt[i][r] = -(R_lw[3 * r] * t[0] + R_lw[3 * r + 1] * t[1] + R_lw[3 * r + 2] * t[2]);
+      }
+      CeresBatch batch(e.ctx());
+      ceres::Problem::Options po; po.evaluation_callback = &batch;
+      ceres::Problem problem(po);
+      const size_t n = AddLidarPointToPlaneResidualGpu(batch, e.ctx(), dev, nb, l, aa, tt, problem, atof(argv[4]), atof(argv[3]), true, true, 1.0);
+      std::vector<double> r, J, r2;
+      problem.EvaluateAll(true, true, &r, &J);
+      for (auto& v : tt) v[0] += 1e-3;                                       // Ceres moves the parameters in place ...
+      problem.EvaluateAll(false, true, &r2, nullptr);                         // ... and asks for the cost at the new point
+      // the same blocks straight through the ABI: re-associate (deterministic) and pvlm_eval at the first point
+      for (auto& v : tt) v[0] -= 1e-3;
+      std::vector<pvlm_scan*> ref, nei;
+      for (size_t i = 0; i < l.size(); i++) for (int k : nb[i]) { if (k < 0 || k == (int)i || k >= (int)l.size()) continue; ref.push_back(dev[i]); nei.push_back(dev[k]); }
+      pvlm_resset* rs = nullptr;
+      e.Check(pvlm_assoc_point2plane(e.ctx(), (int)ref.size(), ref.data(), nei.data(), atof(argv[3]), (float)atof(argv[4]), PVLM_POINT2PLANE_ANGLE, 1u, 1.0, &rs), "assoc");
+      int64_t m = 0; pvlm_resset_info(rs, &m, nullptr, nullptr, nullptr);
+      std::vector<double> rr((size_t)m), JJ((size_t)m * 12);
+      e.Check(pvlm_set_poses(e.ctx(), (int)l.size(), aa[0].data(), tt[0].data()), "poses");
+      e.Check(pvlm_eval(e.ctx(), rs, rr.data(), JJ.data()), "eval");
+      double dr = 0, dJ = 0, jmax = 0, moved = 0;
+      for (size_t i = 0; i < rr.size() && i < r.size(); ++i) { dr = std::max(dr, std::fabs(rr[i] - r[i])); moved = std::max(moved, std::fabs(r2[i] - r[i])); }
+      for (size_t i = 0; i < JJ.size() && i < J.size(); ++i) { dJ = std::max(dJ, std::fabs(JJ[i] - J[i])); jmax = std::max(jmax, std::fabs(JJ[i])); }
+      printf("blocks %zu direct %lld max_dr %.3e max_dJ %.3e J_max %.3e moved %.3e\n", n, (long long)m, dr, dJ, jmax, moved);
+      pvlm_resset_destroy(e.ctx(), rs);
     } else if (cmd == "rawodometry") {
       // rawodometry <raw_scans.bin> iters angle normalize tol thr max_curvature angle_threshold segment : BASELINE config 0 plumbing —
       // raw VLP-16 scans (firing order) -> ReOrderVLP -> ExtractFeatures -> LidarOdometry::EstimatePose with the

@@ -548,3 +548,50 @@ def test_raw_scans_with_line_segments_to_refined_poses(oracle, tmp):
     for k, s in enumerate(twin):
         R = poses[k][:9].reshape(3, 3); t = poses[k][9:]
         assert np.abs(R - s["R_wl"]).max() <= 1e-6 and np.abs(t - s["t_wl"]).max() <= 1e-6 * max(1.0, np.abs(s["t_wl"]).max())
+
+
+def test_ceres_adapter_rows(tmp):
+    """integration/pvlm_ceres.hpp (the reference-side binding that keeps Ceres as the outer solver), compiled against the
+    interface-only Ceres stand-in of tests/cpp/ceres_double and run on the GPU: the residual and the 1 x 12 Jacobian row
+    every CeresRow::Evaluate hands out (formed on the host from the 56-byte wrench row + its pair's tables, delivered
+    through pinned memory) equal pvlm_eval's materialised rows; a second evaluation at a moved point is really re-run."""
+    scans = [_vlp(k, 256) for k in range(4)]
+    path = os.path.join(tmp, "ceres.bin")
+    host_io.write_scans(path, scans, world=False)
+    out = host_io.run("ceresadapter", path, 0.05, 1.0)
+    f = [l.split() for l in out if l.startswith("blocks")][0]
+    n, direct, dr, dJ, jmax, moved = int(f[1]), int(f[3]), float(f[5]), float(f[7]), float(f[9]), float(f[11])
+    assert n == direct > 1000
+    assert dr == 0.0                                  # the residual is copied, not recomputed
+    assert dJ <= 1e-12 * jmax                         # the row is re-formed on the host: rounding only
+    assert moved > 1e-7                               # PrepareForEvaluation(new_evaluation_point = true) re-evaluated
+
+
+def test_host_visible_evaluation_matches_device_rows(oracle):
+    """pvlm_eval_host_async / pvlm_eval_wrench_host_async into pinned memory, sliced through a tiny staging buffer."""
+    import subprocess, sys
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "import panovlm_amd as pv\nfrom tests import synth\n"
+        "rng = np.random.default_rng(3); F, P = 6, 17\n"
+        "aa, t = synth.random_poses(rng, F); ref, nei = synth.random_pairs(rng, F, P)\n"
+        "rows, off = synth.random_resset(rng, 1, aa, t, ref, nei, rng.integers(0, 900, size=P))\n"
+        "ctx = pv.Context(0); rs = pv.ResidualSet.upload(ctx, 1, rows, off, ref, nei, flags=1); ctx.set_poses(aa, t)\n"
+        "r, J = rs.eval(jac=True); n = rs.n\n"
+        "hr = ctx.host_alloc(n * 8); hJ = ctx.host_alloc(n * 96); hw = ctx.host_alloc(n * 56); ht = ctx.host_alloc(P * 33 * 8)\n"
+        "rs.eval_host_async(hr, hJ); rs.eval_wrench_host_async(hw, ht); ctx.synchronize()\n"
+        "w = hw[:n * 7].reshape(n, 7); T = ht[:P * 33].reshape(P, 33)\n"
+        "pr = np.repeat(np.arange(P), np.diff(off))\n"
+        "c, g = w[:, 1:4], w[:, 4:7]; R = T[pr, 0:9].reshape(n, 3, 3); Jl = T[pr, 15:24].reshape(n, 3, 3); Mn = T[pr, 24:33].reshape(n, 3, 3)\n"
+        "Jw = np.concatenate([np.einsum('ni,nik->nk', c, Jl), g, np.einsum('ni,nik->nk', c, Mn), -np.einsum('ni,nik->nk', g, R)], axis=1)\n"
+        "ok = np.array_equal(hr[:n], r) and np.array_equal(hJ[:n * 12].reshape(n, 12), J) and np.array_equal(w[:, 0], r)\n"
+        "sc = np.abs(J).max(axis=1, keepdims=True); ok = ok and bool(np.all(np.abs(Jw - J) <= 1e-12 * sc))\n"
+        "hr2 = np.zeros(n); rs.eval_host_async(hr2, None); ctx.synchronize(); ok = ok and np.array_equal(hr2, r)\n"
+        "print('OK' if ok else 'MISMATCH', n)\n" % host_io.ROOT)
+    for stage in ("700", None):                       # 700 rows: every pair its own slice; default: one slice
+        env = dict(os.environ)
+        if stage:
+            env["PVLM_STAGE_ROWS"] = stage
+        o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        assert o.stdout.split()[0] == "OK" and int(o.stdout.split()[1]) > 1000, o.stdout
