@@ -265,6 +265,8 @@ typedef struct {
   int n_segments;             const int* segment_size;         /* edge_segmented[s].size()        */
   const double* segment_coeffs; /* 6 per segment, LiDAR-local (point, unit direction)             */
   const double* end_points;     /* 2x3 per segment, LiDAR-local                                   */
+  const float* seg_points_xyz;  /* optional: the points of edge_segmented[0], [1], ... one after the other (sum of
+                                   segment_size x 3 floats, WORLD frame like the clouds) — needed by pvlm_line2line_residuals */
 } pvlm_scan_desc;
 
 pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* desc, pvlm_scan** out);
@@ -306,6 +308,20 @@ pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm
  * PVLM_ERR_CAPACITY if capacity (int32 elements) < vote_offsets[n_pairs]. */
 pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei,
                                        float dist_threshold, int64_t* vote_offsets, int32_t* votes, int64_t capacity);
+
+/* Residual blocks of the line-to-line term, built on the device (the body of the innermost loops of
+ * AddLidarLineToLineResidual2, util/Optimization.cpp:404-434): match m says that segment match_nei_seg[m] of scan
+ * nei[match_pair[m]] was associated with segment match_ref_seg[m] of scan ref[match_pair[m]] (AssociateLine2Line +
+ * the line-track filter, decided by the caller).  Every point of the neighbour segment becomes one Point2Line block
+ *   [ World2Local_nei(point) | ref_local_point + 0.1 dir | ref_local_point - 0.1 dir ]      (Optimization.cpp:410-434)
+ * on the parameter blocks (ref, nei), in match order and, inside a match, in the order of edge_segmented[seg] — the
+ * order the reference's AddResidualBlock calls have.  Matches must be sorted by pair; consecutive matches of one pair form
+ * one segment of the result.  kind = PVLM_POINT2LINE_ANGLE / _METER.  Both scans must have been uploaded with
+ * seg_points_xyz.  Upstream this loop costs one heap-allocated AutoDiffCostFunction per POINT (600 k per outer iteration
+ * at Room scale); here the rows never exist on the host. */
+pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, int n_matches,
+                                     const int* match_pair, const int* match_nei_seg, const int* match_ref_seg, pvlm_functor kind,
+                                     unsigned flags, double weight, pvlm_resset** out);
 
 /* ---- equirectangular camera model + camera<->LiDAR voting --------------------------------------- */
 /* Equirectangular::CamToImage<T> (sensors/Equirectangular.h:173-182, FastAtan2 variant) for n

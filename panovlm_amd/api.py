@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
-    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async",
+    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_line2line_residuals",
 ]
 
 
@@ -679,6 +679,7 @@ class ScanDesc(C.Structure):
         ("p2s_offsets", C.POINTER(C.c_int)), ("p2s_ids", C.POINTER(C.c_int)),
         ("n_segments", C.c_int), ("segment_size", C.POINTER(C.c_int)),
         ("segment_coeffs", C.POINTER(C.c_double)), ("end_points", C.POINTER(C.c_double)),
+        ("seg_points_xyz", C.POINTER(C.c_float)),
     ]
 
 
@@ -712,6 +713,11 @@ class Scan:
         d.p2s_offsets = _p(off, C.c_int); d.p2s_ids = _p(ids, C.c_int)
         d.n_segments = len(seg_size); d.segment_size = _p(seg_size, C.c_int)
         d.segment_coeffs = _p(seg_coeffs, C.c_double); d.end_points = _p(end_points, C.c_double)
+        seg_xyz = g("seg_points_xyz", None)          # optional: the points of every segment, concatenated (world frame)
+        seg_xyz = _f32(seg_xyz).reshape(-1, 3) if seg_xyz is not None else None
+        if seg_xyz is not None:
+            assert len(seg_xyz) == int(seg_size.sum())
+        d.seg_points_xyz = _p(seg_xyz, C.c_float) if seg_xyz is not None and len(seg_xyz) else None
         self._h = C.c_void_p()
         ctx._check(ctx.lib.pvlm_scan_upload(ctx._h, C.byref(d), C.byref(self._h)), "pvlm_scan_upload")
         self.id = d.id

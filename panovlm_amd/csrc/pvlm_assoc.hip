@@ -689,7 +689,7 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
     if ((st = pvlm_i_alloc(ctx, &c.d_tag, (size_t)n))) return st;
     PVLM_HIP(ctx, hipMemcpyAsync(c.d_tag, tag, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   }
-  if (!build_hash) { PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream)); return PVLM_OK; }
+  if (!build_hash) return PVLM_OK;      // the caller (pvlm_scan_upload) synchronises once, after everything has been queued
   // cell edge: surface-like clouds, aim at ~4 points per occupied cell
   float e[3];
   for (int k = 0; k < 3; ++k) { if (!(mx[k] - mn[k] < 1e7f)) { PVLM_SET_ERR(ctx, "cloud extent exceeds 1e7"); return PVLM_ERR_ARG; } e[k] = std::max(mx[k] - mn[k], 0.05f); }
@@ -739,7 +739,7 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
   launch_scan(ctx, (int)T, c.d_cell_count, c.d_cell_start, d_tiles);
   hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
   le = hipGetLastError();
-  se = hipStreamSynchronize(ctx->stream);
+  // no synchronisation here: the scratch goes back to the pool stream-ordered, the caller waits once for the whole scan
   if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }
@@ -810,8 +810,12 @@ pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan**
     for (int v : s->h_p2s_ids) if (v < 0 || v >= d->n_segments) { PVLM_SET_ERR(ctx, "point_to_segment id %d out of range", v); st = PVLM_ERR_ARG; break; }
     if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
     if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_ids, s->h_p2s_ids.size());
-    if (!st) st = pvlm_i_h2d(ctx, s->d_p2s_off, s->h_p2s_off.data(), s->h_p2s_off.size() * sizeof(int));
-    if (!st && tot > 0) st = pvlm_i_h2d(ctx, s->d_p2s_ids, s->h_p2s_ids.data(), s->h_p2s_ids.size() * sizeof(int));
+    auto queue = [&](void* dst, const void* src, size_t bytes) {
+      if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: copy failed"); return PVLM_ERR_HIP; }
+      return PVLM_OK;
+    };
+    if (!st) st = queue(s->d_p2s_off, s->h_p2s_off.data(), s->h_p2s_off.size() * sizeof(int));
+    if (!st && tot > 0) st = queue(s->d_p2s_ids, s->h_p2s_ids.data(), s->h_p2s_ids.size() * sizeof(int));
   } else if (!st && d->n_corner > 0) {
     s->h_p2s_off.assign(d->n_corner + 1, 0);
     st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
@@ -823,7 +827,19 @@ pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan**
     s->h_seg_size.assign(d->segment_size, d->segment_size + d->n_segments);
     s->h_seg_coeffs.assign(d->segment_coeffs, d->segment_coeffs + 6 * (size_t)d->n_segments);
     if (d->end_points) s->h_end_points.assign(d->end_points, d->end_points + 6 * (size_t)d->n_segments);
+    if (d->seg_points_xyz) {
+      s->h_seg_pt_off.assign((size_t)d->n_segments + 1, 0);
+      for (int k = 0; k < d->n_segments; ++k) {
+        if (d->segment_size[k] < 0) { PVLM_SET_ERR(ctx, "negative segment size"); st = PVLM_ERR_ARG; break; }
+        s->h_seg_pt_off[(size_t)k + 1] = s->h_seg_pt_off[(size_t)k] + d->segment_size[k];
+      }
+      const size_t tot = (size_t)s->h_seg_pt_off.back();
+      if (!st) st = pvlm_i_alloc(ctx, &s->d_seg_xyz, std::max<size_t>(tot, 1) * 3);
+      if (!st && tot && hipMemcpyAsync(s->d_seg_xyz, d->seg_points_xyz, tot * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVLM_ERR_HIP;
+    }
   }
+  // ONE synchronisation per scan: every copy above reads caller-owned (pageable) memory that may be reused on return
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && !st) { PVLM_SET_ERR(ctx, "scan upload: device error"); st = PVLM_ERR_HIP; }
   if (st) { pvlm_scan_destroy(ctx, s); return st; }
   *out = s;
   return PVLM_OK;
@@ -834,7 +850,7 @@ pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* s) {
   if (!s) return PVLM_OK;
   hipSetDevice(ctx->device);
   cloud_free(ctx, s->flat); cloud_free(ctx, s->less); cloud_free(ctx, s->corner);
-  pvlm_i_free(ctx, s->d_p2s_off); pvlm_i_free(ctx, s->d_p2s_ids);
+  pvlm_i_free(ctx, s->d_p2s_off); pvlm_i_free(ctx, s->d_p2s_ids); pvlm_i_free(ctx, s->d_seg_xyz);
   delete s;
   return PVLM_OK;
 }

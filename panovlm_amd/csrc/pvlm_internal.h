@@ -173,6 +173,8 @@ struct pvlm_scan {
   std::vector<double> h_seg_coeffs, h_end_points;
   int* d_p2s_off = nullptr;
   int* d_p2s_ids = nullptr;
+  float* d_seg_xyz = nullptr;          // optional: points of every segment, one segment after the other (world frame)
+  std::vector<int> h_seg_pt_off;       // n_segments + 1 offsets into d_seg_xyz (points)
 };
 
 #define PVLM_SET_ERR(ctx, ...)                                   \

@@ -64,6 +64,37 @@ __global__ __launch_bounds__(256) void k_line_votes_batch(int n_pairs, const pvl
   for (int k = d.p2s_off[i]; k < d.p2s_off[i + 1]; ++k) atomicAdd(&votes[d.vote_off + (long long)d.p2s_ids[k] * d.n_ref + s], 1);
 }
 
+// ---- K4b: residual rows of the line-to-line term ---------------------------------------------------------------
+// One workgroup per match (a neighbour segment associated with a reference segment): thread i turns point i of the
+// neighbour segment into the SoA row [World2Local_nei(p) | A | unit(A - B)] of the Point2Line functors
+// (A, B = ref_local_point +- 0.1 dir, util/Optimization.cpp:410-434; the functor's constructor normalises A - B,
+// base/CostFunction.h:778-783 — done once per match on the host, in the arithmetic pvlm_resset_upload uses).
+struct pvlm_match_desc {
+  const float* pts;      // the neighbour segment's points (world frame)
+  int n_pts, pair;       // pair: index into the pair table (poses of the neighbour scan)
+  long long dst;         // first row of the match inside the column block
+  double line[6];        // A (3) | unit direction (3)
+};
+struct pvlm_match_pose { double R[9], t[3]; };   // R_wl, t_wl of the neighbour scan of a pair
+
+__global__ __launch_bounds__(64) void k_line_rows(const pvlm_match_desc* __restrict__ matches, const pvlm_match_pose* __restrict__ poses,
+                                                  double* __restrict__ cols, long long stride) {
+  const pvlm_match_desc m = matches[blockIdx.x];
+  const pvlm_match_pose& P = poses[m.pair];
+  for (int i = threadIdx.x; i < m.n_pts; i += 64) {
+    const double x = (double)m.pts[3 * i], y = (double)m.pts[3 * i + 1], z = (double)m.pts[3 * i + 2];
+    const long long d = m.dst + i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {     // World2Local: R_wl^T p - R_wl^T t   (sensors/Velodyne.cpp:1850-1853)
+      const double a = (P.R[k] * x + P.R[3 + k] * y) + P.R[6 + k] * z;
+      const double b = (P.R[k] * P.t[0] + P.R[3 + k] * P.t[1]) + P.R[6 + k] * P.t[2];
+      cols[(size_t)k * stride + d] = a - b;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cols[(size_t)(3 + k) * stride + d] = m.line[k];
+  }
+}
+
 // ---- K7 -----------------------------------------------------------------------------------------
 // FastAtan2 (base/Math.h:15-29).  For T = float the polynomial is evaluated in double (double
 // literals) and rounded to float on assignment, as are M_PI_2 - r and M_PI - r.
@@ -431,6 +462,89 @@ pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* co
       [thr](pvlm_ctx* c, int np, const pvlm_line_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
         hipLaunchKernelGGL(k_line_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl, thr, dv);
       });
+}
+
+pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, int n_matches, const int* match_pair,
+                                     const int* match_nei_seg, const int* match_ref_seg, pvlm_functor kind, unsigned flags, double weight,
+                                     pvlm_resset** out) {
+  if (!ctx || !out || n_pairs < 0 || n_matches < 0 || (n_pairs > 0 && (!ref || !nei)) || (n_matches > 0 && (!match_pair || !match_nei_seg || !match_ref_seg)))
+    return PVLM_ERR_ARG;
+  *out = nullptr;
+  if (kind != PVLM_POINT2LINE_ANGLE && kind != PVLM_POINT2LINE_METER) { PVLM_SET_ERR(ctx, "kind must be a point-to-line functor"); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_resset* rs = new (std::nothrow) pvlm_resset();
+  if (!rs) return PVLM_ERR_NOMEM;
+  rs->kind = kind; rs->flags = flags & 0xFFu; rs->weight = weight; rs->ncols = 9;
+  std::vector<pvlm_match_desc> md((size_t)n_matches);
+  std::vector<pvlm_match_pose> poses;
+  rs->h_out_start.assign(1, 0);
+  long long row = 0;
+  int last_pair = -1;
+  for (int m = 0; m < n_matches; ++m) {
+    const int p = match_pair[m];
+    if (p < 0 || p >= n_pairs || p < last_pair || !ref[p] || !nei[p]) { PVLM_SET_ERR(ctx, "match %d: pair index out of range or not sorted", m); pvlm_i_resset_free(ctx, rs); return PVLM_ERR_ARG; }
+    const pvlm_scan* R = ref[p]; const pvlm_scan* N = nei[p];
+    const int a = match_nei_seg[m], b = match_ref_seg[m];
+    if (a < 0 || a >= N->n_segments || b < 0 || b >= R->n_segments || !N->d_seg_xyz) {
+      PVLM_SET_ERR(ctx, "match %d: segment out of range, or the neighbour scan was uploaded without seg_points_xyz", m);
+      pvlm_i_resset_free(ctx, rs); return PVLM_ERR_ARG;
+    }
+    if (p != last_pair) {
+      if (last_pair >= 0) { rs->h_out_start.push_back(row); row = (row + 1) & ~1ll; }
+      rs->h_seg_start.push_back(row);
+      rs->h_ref.push_back(R->id); rs->h_nei.push_back(N->id);
+      pvlm_match_pose P; std::memcpy(P.R, N->R_wl, 72); std::memcpy(P.t, N->t_wl, 24);
+      poses.push_back(P);
+      last_pair = p;
+    }
+    pvlm_match_desc& d = md[(size_t)m];
+    d.pts = N->d_seg_xyz + 3 * (size_t)N->h_seg_pt_off[(size_t)a];
+    d.n_pts = N->h_seg_pt_off[(size_t)a + 1] - N->h_seg_pt_off[(size_t)a];
+    d.pair = (int)poses.size() - 1;
+    d.dst = row;
+    const double* loc = &R->h_seg_coeffs[6 * (size_t)b];
+    double A[3], B[3];
+    for (int c = 0; c < 3; ++c) { A[c] = 0.1 * loc[3 + c] + loc[c]; B[c] = -0.1 * loc[3 + c] + loc[c]; }   // Line2Line::line_point1 / 2
+    double dx = A[0] - B[0], dy = A[1] - B[1], dz = A[2] - B[2];                                           // ctor: (A - B).normalized()
+    const double n2 = dx * dx + dy * dy + dz * dz;
+    if (n2 > 0.0) { const double nn = std::sqrt(n2); dx /= nn; dy /= nn; dz /= nn; }
+    d.line[0] = A[0]; d.line[1] = A[1]; d.line[2] = A[2]; d.line[3] = dx; d.line[4] = dy; d.line[5] = dz;
+    row += d.n_pts;
+  }
+  // compact rows: the padding between segments is not counted
+  rs->n_pairs = (int)rs->h_ref.size();
+  if (rs->n_pairs > 0) rs->h_out_start.push_back(row);
+  {   // h_out_start was filled with device rows so far: turn it into compact offsets
+    long long compact = 0;
+    std::vector<int64_t> off((size_t)rs->n_pairs + 1, 0);
+    for (int p = 0; p < rs->n_pairs; ++p) { compact += rs->h_out_start[(size_t)p + 1] - rs->h_seg_start[(size_t)p]; off[(size_t)p + 1] = compact; }
+    rs->h_out_start = off;
+    rs->n = compact;
+  }
+  const long long R_rows = std::max<long long>((row + 1) & ~1ll, 2);
+  rs->n_dev = R_rows;
+  rs->h_pair_block.assign((size_t)rs->n_pairs, 0);
+  rs->h_seg_start.push_back(R_rows);
+  double* d_block = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_block, (size_t)R_rows * 9);
+  if (st) { pvlm_i_resset_free(ctx, rs); return st; }
+  rs->col_blocks.push_back(d_block); rs->block_rows.push_back(R_rows);
+  pvlm_match_desc* d_md = nullptr; pvlm_match_pose* d_po = nullptr;
+  if (n_matches > 0) {
+    st = pvlm_i_alloc(ctx, &d_md, md.size());
+    if (!st) st = pvlm_i_alloc(ctx, &d_po, poses.size());
+    if (!st) {
+      hipError_t e = hipMemcpyAsync(d_md, md.data(), md.size() * sizeof(pvlm_match_desc), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_po, poses.data(), poses.size() * sizeof(pvlm_match_pose), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) { hipLaunchKernelGGL(k_line_rows, dim3((unsigned)n_matches), dim3(64), 0, ctx->stream, d_md, d_po, d_block, R_rows); e = hipGetLastError(); }
+      if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_line2line_residuals: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    }
+  }
+  if (!st) st = pvlm_i_resset_finalize(ctx, rs);     // synchronises: the staging vectors above may go
+  pvlm_i_free(ctx, d_md); pvlm_i_free(ctx, d_po);
+  if (st) { hipStreamSynchronize(ctx->stream); pvlm_i_resset_free(ctx, rs); return st; }
+  *out = rs;
+  return PVLM_OK;
 }
 
 pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,

@@ -216,6 +216,7 @@ Velodyne& Velodyne::operator=(const Velodyne& o) {
 }
 pvlm_scan* Velodyne::DeviceScan() const {
   if (dev_) return dev_;
+  StageTimer stage_timer_("  (inside the stages below) scan upload: host SoA staging + pvlm_scan_upload");
   auto flat = [](const PointCloud& c, std::vector<float>& xyz, std::vector<float>& tag) {
     xyz.resize(c.size() * 3); tag.resize(c.size());
     for (size_t i = 0; i < c.size(); ++i) { xyz[3 * i] = c[i].x; xyz[3 * i + 1] = c[i].y; xyz[3 * i + 2] = c[i].z; tag[i] = c[i].intensity; }
@@ -242,6 +243,10 @@ pvlm_scan* Velodyne::DeviceScan() const {
   d.n_corner = (int)cornerLessSharp.size(); d.corner_xyz = cx.data(); d.p2s_offsets = off.data(); d.p2s_ids = ids.data();
   d.n_segments = (int)std::min(edge_segmented.size(), segment_coeffs.size()); d.segment_size = seg_size.data();
   d.segment_coeffs = coeffs.data(); d.end_points = ends.data();
+  std::vector<float> seg_xyz;       // the segments' own point lists (edge_segmented), for the device-built line-to-line blocks
+  for (int k = 0; k < d.n_segments; ++k) for (const PointXYZI& p : edge_segmented[(size_t)k]) { seg_xyz.push_back(p.x); seg_xyz.push_back(p.y); seg_xyz.push_back(p.z); }
+  if (seg_xyz.empty()) seg_xyz.push_back(0.f);
+  d.seg_points_xyz = seg_xyz.data();
   Engine& e = Engine::Default();
   e.Check(pvlm_scan_upload(e.ctx(), &d, &dev_), "pvlm_scan_upload");
   return dev_;
@@ -581,6 +586,7 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
   std::vector<int32_t> votes((size_t)std::max<int64_t>(voff.back(), 1), 0);
   e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), votes.data(), (int64_t)votes.size()),
           "pvlm_line2line_votes_batch");
+  StageTimer stage_timer_("  (inside) FindAssociations on the vote blocks (host)");
   for (size_t j = 0; j < which.size(); ++j) {
     const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
     const std::vector<Vector6d> nei_world = TransformLines(nei.segment_coeffs, nei.GetPose());
@@ -1083,6 +1089,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   };
 
   // ---- device sets + per-group normal-equation structures ---------------------------------------
+  StageTimer* stage_timer_setup_ = new StageTimer("solve: residual-set upload + structures");
   for (auto& g : I.groups) {
     const int P = (int)g.ref.size();
     if (!g.set) {
@@ -1105,6 +1112,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       e.Check(pvlm_neq_create(e.ctx(), g.dev_poses, (int)g.ui.size(), g.ui.data(), g.uj.data(), &g.neq), "pvlm_neq_create");
     }
   }
+  delete stage_timer_setup_;
   // ---- reprojection sets: observations sorted by point, points resident on the GPU ------------------
   bool have_bundles = false;
   for (auto& b : I.bundles) {
@@ -1621,7 +1629,6 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   StageTimer stage_timer_("line-to-line association + blocks");
   const size_t i_lo = ref_range ? ref_range->first : 0, i_hi = ref_range ? std::min(ref_range->second, lidars.size()) : lidars.size();
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
-  bool loss_used = false;
   std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> lines_to_track;
   for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) lines_to_track[pr].push_back(t.id);
   size_t num = 0;
@@ -1636,44 +1643,43 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
     }
   }
   const std::vector<std::vector<Line2Line>> all_ass = AssociateLine2LineBatch(todo, (float)thr);
+  // The association + track filter decide WHICH (neighbour segment, reference segment) pairs contribute (:379-400); the
+  // blocks themselves — one per point of the neighbour segment, :410-434 — are built on the GPU from the scans' segment
+  // point lists (pvlm_line2line_residuals): same rows in the same order as the X::Create + AddResidualBlock calls,
+  // without 600 k heap objects, a host SoA staging copy and a 180 MB upload per outer iteration at Room scale.
+  std::vector<pvlm_scan*> refs, neis;
+  std::vector<int> m_pair, m_nei, m_ref;
   size_t next = 0;
-  std::vector<double> row_buf;
   for (size_t i = i_lo; i < i_hi; i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
-    double* aa_r = aa_list[lidars[i].id].data(); double* t_r = t_list[lidars[i].id].data();
     for (int n_idx : neighbors[i]) {
       if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;
       if (!lidars[n_idx].IsPoseValid() || !lidars[n_idx].valid) continue;
-      double* t_n = t_list[lidars[n_idx].id].data(); double* aa_n = aa_list[lidars[n_idx].id].data();
       const std::vector<Line2Line>& ass = all_ass[next++];
+      bool pair_open = false;
       for (const Line2Line& a : ass) {
         auto it = lines_to_track.find({(uint32_t)i, (uint32_t)a.ref_line_idx});
         if (it == lines_to_track.end()) continue;
         bool valid = false;
         for (uint32_t tid : it->second) if (tracks[tid].IsInside({(uint32_t)n_idx, (uint32_t)a.neighbor_line_idx})) { valid = true; break; }
         if (!valid) continue;
-        // one block per point of the matched nei segment (:410-434) — added in bulk: same rows, same order as the
-        // X::Create + AddResidualBlock calls, without a heap object per block
-        const PointCloud& seg = lidars[n_idx].edge_segmented[a.neighbor_line_idx];
-        row_buf.resize(seg.size() * 9);
-        for (size_t k = 0; k < seg.size(); ++k) {
-          const Vector3d lp = lidars[n_idx].World2Local({(double)seg[k].x, (double)seg[k].y, (double)seg[k].z});
-          double* r = &row_buf[9 * k];
-          r[0] = lp[0]; r[1] = lp[1]; r[2] = lp[2];
-          for (int c = 0; c < 3; ++c) { r[3 + c] = a.line_point1[c]; r[6 + c] = a.line_point2[c]; }
-        }
-        if (angle_residual)   // loss is nullptr for the angle variant (util/Optimization.cpp:417)
-          problem.AddResidualRows(PVLM_POINT2LINE_ANGLE, normalized_distance ? PVLM_FLAG_NORMALIZE_DISTANCE : 0u, weight, nullptr, aa_r, t_r, aa_n, t_n,
-                                  row_buf.data(), seg.size());
-        else {
-          problem.AddResidualRows(PVLM_POINT2LINE_METER, 0u, weight, loss, aa_r, t_r, aa_n, t_n, row_buf.data(), seg.size());
-          loss_used = loss_used || !seg.empty();
-        }
-        num += seg.size();
+        const size_t pts = lidars[n_idx].edge_segmented[a.neighbor_line_idx].size();
+        if (pts == 0) continue;
+        if (!pair_open) { refs.push_back(lidars[i].DeviceScan()); neis.push_back(lidars[n_idx].DeviceScan()); pair_open = true; }
+        m_pair.push_back((int)refs.size() - 1); m_nei.push_back(a.neighbor_line_idx); m_ref.push_back(a.ref_line_idx);
+        num += pts;
       }
     }
   }
-  if (!loss_used) delete loss;
+  if (num == 0) { delete loss; return 0; }
+  Engine& e = Engine::Default();
+  pvlm_resset* rs = nullptr;
+  e.Check(pvlm_line2line_residuals(e.ctx(), (int)refs.size(), refs.data(), neis.data(), (int)m_pair.size(), m_pair.data(), m_nei.data(), m_ref.data(),
+                                   angle_residual ? PVLM_POINT2LINE_ANGLE : PVLM_POINT2LINE_METER,
+                                   (angle_residual && normalized_distance) ? PVLM_FLAG_NORMALIZE_DISTANCE : 0u, weight, &rs), "pvlm_line2line_residuals");
+  // loss is nullptr for the angle variant (util/Optimization.cpp:417), Huber for the metric one
+  if (angle_residual) { delete loss; loss = nullptr; }
+  problem.AddResidualSet(rs, loss, &aa_list, &t_list);
   return num;
 }
 
