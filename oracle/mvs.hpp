@@ -21,6 +21,18 @@
 
 namespace oracle {
 
+// std::exp / std::sin / std::cos / std::acos on FLOAT arguments (mvs/MVS.cpp has `using namespace std`): the reference
+// gets whatever its platform's libm returns for the float overloads — correctly rounded in glibc >= 2.40 (CORE-MATH), within
+// ~0.5-1 ulp of that in older glibc, i.e. platform-dependent in the last bit.  The restatement (and the product,
+// csrc/pvlm_mvs_core.h) fix the one libm-independent definition: the CORRECTLY ROUNDED float result, obtained as the double
+// function rounded to float (a double result within an ulp of the exact value rounds to the same float unless the exact
+// value lies within 2^-29 of a float rounding boundary).  With this — and the reference's sequential sums — the GPU path
+// and the oracle agree bit for bit on the scoring pass and the PatchMatch sweep (tests/test_mvs_gpu.py).
+inline float FExp(float x) { return (float)std::exp((double)x); }
+inline float FSin(float x) { return (float)std::sin((double)x); }
+inline float FCos(float x) { return (float)std::cos((double)x); }
+inline float FAcos(float x) { return (float)std::acos((double)x); }
+
 struct MvsView {
   int rows, cols, half_window, step;
   const uint8_t* gray;   // rows x cols
@@ -49,7 +61,7 @@ inline void FillPixelPatch(const MvsView& v, int px, int py, PixelPatch& patch) 
       float wColor = (tex - center) / 255.f;
       wColor = wColor * wColor * sigma_color;
       const float wSpatial = ((float)((col - px) * (col - px)) + (float)((row - py) * (row - py))) * sigma_spatial;
-      patch.weight[k] = std::exp(wColor + wSpatial);
+      patch.weight[k] = FExp(wColor + wSpatial);
       patch.texels0[k] = tex;
       k++;
     }
@@ -112,7 +124,7 @@ inline float GeometricAdjust(float score, const Equirectangular& eq, const float
       float cosang = X0[0] * Xb[0] + X0[1] * Xb[1] + X0[2] * Xb[2];
       const float n1 = std::sqrt(X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2]), n2 = std::sqrt(Xb[0] * Xb[0] + Xb[1] * Xb[1] + Xb[2] * Xb[2]);
       cosang /= (n1 * n2);
-      const float ang = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)M_PI : std::acos(cosang));
+      const float ang = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)M_PI : FAcos(cosang));
       const float diff_angle = ang * 180.0 / M_PI;
       consistency = std::min(diff_angle, consistency);
     }
@@ -172,10 +184,10 @@ inline float ScorePixelPhotometric(const MvsView& ref, const float* unit, int px
       for (int q = 0; q < n_close; ++q) {
         const NeighborPixel& c = close[q];
         float diff_distance = std::abs(plane[0] * c.point[0] + plane[1] * c.point[1] + plane[2] * c.point[2] + plane[3]) / depth;   // PointToPlaneDistance(plane, point, true)
-        const float factorDepth = std::exp(diff_distance * diff_distance * smoothSigmaDepth);
+        const float factorDepth = FExp(diff_distance * diff_distance * smoothSigmaDepth);
         const float cosang = normal[0] * c.normal[0] + normal[1] * c.normal[1] + normal[2] * c.normal[2];                            // VectorAngle3D(.., .., true)
-        float diff_angle = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)M_PI : std::acos(cosang));
-        const float factorNormal = std::exp(diff_angle * diff_angle * smoothSigmaNormal);
+        float diff_angle = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)M_PI : FAcos(cosang));
+        const float factorNormal = FExp(diff_angle * diff_angle * smoothSigmaNormal);
         score *= (1.f - smoothBonusDepth * factorDepth) * (1.f - smoothBonusNormal * factorNormal);
       }
       score = 1 - score;
@@ -419,8 +431,8 @@ inline void CorrectNormal(const float* viewDir, float* normal) {
   const float cosAngLen = MvsDot3(normal, viewDir);
   if (cosAngLen >= 0) {
     const float axis[3] = {normal[1] * viewDir[2] - normal[2] * viewDir[1], normal[2] * viewDir[0] - normal[0] * viewDir[2], normal[0] * viewDir[1] - normal[1] * viewDir[0]};
-    const float rad = std::min((std::acos(cosAngLen) - float(M_PI_2)) * 1.01f, -0.001f);
-    const float sn = std::sin(rad), c = std::cos(rad);
+    const float rad = std::min((FAcos(cosAngLen) - float(M_PI_2)) * 1.01f, -0.001f);
+    const float sn = FSin(rad), c = FCos(rad);
     const float sin_axis[3] = {sn * axis[0], sn * axis[1], sn * axis[2]};
     const float cos1_axis[3] = {(1.f - c) * axis[0], (1.f - c) * axis[1], (1.f - c) * axis[2]};
     float R[9];
@@ -443,8 +455,8 @@ inline void PerturbNormal(MvsRng& rng, const float* normal, float perturbation, 
   const float a1 = (rng.next01() - 0.5f) * perturbation;
   const float a2 = (rng.next01() - 0.5f) * perturbation;
   const float a3 = (rng.next01() - 0.5f) * perturbation;
-  const float sin_a1 = std::sin(a1), sin_a2 = std::sin(a2), sin_a3 = std::sin(a3);
-  const float cos_a1 = std::cos(a1), cos_a2 = std::cos(a2), cos_a3 = std::cos(a3);
+  const float sin_a1 = FSin(a1), sin_a2 = FSin(a2), sin_a3 = FSin(a3);
+  const float cos_a1 = FCos(a1), cos_a2 = FCos(a2), cos_a3 = FCos(a3);
   float R[9];
   R[0] = cos_a2 * cos_a3;
   R[1] = -cos_a2 * sin_a3;

@@ -124,17 +124,100 @@ __global__ void k_cam_to_image(int rows, int cols, long long n, const T* __restr
   px[2 * i + 1] = (T)(rows * (0.5 - lat / 3.14159265358979323846));
 }
 
-template <typename T>
+// sin and cos of a FLOAT argument, each the double-precision value rounded to float — what round 1 obtained from two calls
+// of the device library's double sin / cos (the reference calls std::sin / std::cos on floats).  The library routines carry
+// a full-range argument reduction and cost ~150 instructions each, which made ImageToCam<float> VALU-bound at 0.25 of the
+// HBM roof.  A float argument bounded by a few turns needs neither: one Cody-Waite step against pi/2 (the 33-bit head
+// leaves q * head exact for |q| < 2^20) and the fdlibm kernel polynomials (|error| < 2^-58 on [-pi/4, pi/4]) give a double
+// within 2 ulp of the exact value, i.e. the same float after rounding except when the exact value lies within ~2e-16
+// (relative) of a float rounding boundary.  tests/test_equirect_gpu.py compares the two paths on every pixel of a
+// 5760 x 2880 panorama and on sub-pixel positions; PVLM_EXACT_TRIG=1 selects the library path.
+__device__ __forceinline__ void sincos_f32_arg(float xf, float* s_out, float* c_out) {
+  const double x = (double)xf;
+  if (!(fabs(x) < 1.0e5)) { *s_out = (float)sin(x); *c_out = (float)cos(x); return; }
+  const double q = rint(x * 0.63661977236758134308);
+  double y = fma(-q, 1.57079632673412561417e+00, x);
+  y = fma(-q, 6.07710050650619224932e-11, y);
+  const double z = y * y;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sn = fma(y * z, ps, y);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int n = (int)(long long)q & 3;
+  const double sv = (n & 1) ? cs : sn, cv = (n & 1) ? sn : cs;
+  *s_out = (float)((n & 2) ? -sv : sv);
+  *c_out = (float)(((n + 1) & 2) ? -cv : cv);
+}
+
+// four points per lane, 16-byte vector accesses only (3 loads, 2 stores): the device-resident whole-panorama form
+__global__ __launch_bounds__(256) void k_cam_to_image_f32x4(int rows, int cols, long long n4, const float4* __restrict__ cam, float4* __restrict__ px) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = cam[3 * i], b = cam[3 * i + 1], c = cam[3 * i + 2];
+  const float p[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float x = p[3 * k], y = p[3 * k + 1], z = p[3 * k + 2];
+    const float lon = fast_atan2<float>(x, z);
+    const float lat = -fast_atan2<float>(y, (float)sqrt((double)(x * x + z * z)));
+    o[2 * k] = (float)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
+    o[2 * k + 1] = (float)(rows * (0.5 - lat / 3.14159265358979323846));
+  }
+  px[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
+  px[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+template <typename T, bool LIBRARY_TRIG>
 __global__ void k_image_to_cam(int rows, int cols, long long n, const T* __restrict__ px, T r, T* __restrict__ cam) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  // ImageToSphere :102-103 ; SphereToCam :125-128 (float trig evaluated in double and rounded)
+  // ImageToSphere :102-103 ; SphereToCam :125-128 (float trig = the double value rounded to float)
   const T sx = (T)((2 * px[2 * i] / cols - 1) * 3.14159265358979323846);
   const T sy = (T)((0.5 - px[2 * i + 1] / rows) * 3.14159265358979323846);
-  const T cy = (T)cos((double)sy);
-  cam[3 * i] = r * cy * (T)sin((double)sx);
-  cam[3 * i + 1] = -r * (T)sin((double)sy);
-  cam[3 * i + 2] = r * cy * (T)cos((double)sx);
+  T cy, sny, snx, csx;
+  if (sizeof(T) == 4 && !LIBRARY_TRIG) {
+    float a, b, c, d;
+    sincos_f32_arg((float)sy, &a, &b);
+    sincos_f32_arg((float)sx, &c, &d);
+    sny = (T)a; cy = (T)b; snx = (T)c; csx = (T)d;
+  } else {
+    cy = (T)cos((double)sy); sny = (T)sin((double)sy); snx = (T)sin((double)sx); csx = (T)cos((double)sx);
+  }
+  cam[3 * i] = r * cy * snx;
+  cam[3 * i + 1] = -r * sny;
+  cam[3 * i + 2] = r * cy * csx;
+}
+static bool exact_trig() { static const bool v = getenv("PVLM_EXACT_TRIG") != nullptr; return v; }
+
+// Whole-panorama form of the float map: four pixels per lane, every global access a 16-byte vector (2 loads, 3 stores)
+// instead of 8- and 12-byte pieces — the kernel is a 20 B/pixel stream once the trigonometry is cheap.
+__global__ __launch_bounds__(256) void k_image_to_cam_f32x4(int rows, int cols, long long n4, const float4* __restrict__ px, float r, float4* __restrict__ cam) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = px[2 * i], b = px[2 * i + 1];
+  const float u[4] = {a.x, a.z, b.x, b.z}, v[4] = {a.y, a.w, b.y, b.w};
+  float o[12];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float sx = (float)((2 * u[k] / cols - 1) * 3.14159265358979323846);
+    const float sy = (float)((0.5 - v[k] / rows) * 3.14159265358979323846);
+    float sny, cy, snx, csx;
+    sincos_f32_arg(sy, &sny, &cy);
+    sincos_f32_arg(sx, &snx, &csx);
+    o[3 * k] = r * cy * snx; o[3 * k + 1] = -r * sny; o[3 * k + 2] = r * cy * csx;
+  }
+  cam[3 * i] = make_float4(o[0], o[1], o[2], o[3]);
+  cam[3 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
+  cam[3 * i + 2] = make_float4(o[8], o[9], o[10], o[11]);
 }
 
 // ---- LiDAR-seeded sparse depth image: ProjectLidar2PanoramaDepth (util/Visualization.h:407-441) ----------------
@@ -314,13 +397,14 @@ pvlm_status pvlm_cam_to_image_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, 
 pvlm_status pvlm_image_to_cam_f32(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* px, float r, float* cam) {
   if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!cam || !px))) return PVLM_ERR_ARG;
   return run_map<float>(ctx, n, px, 2, cam, 3, [&](float* di, float* dout) {
-    hipLaunchKernelGGL(k_image_to_cam<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
+    if (exact_trig()) hipLaunchKernelGGL((k_image_to_cam<float, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
+    else hipLaunchKernelGGL((k_image_to_cam<float, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
   });
 }
 pvlm_status pvlm_image_to_cam_f64(pvlm_ctx* ctx, int rows, int cols, int64_t n, const double* px, double r, double* cam) {
   if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!cam || !px))) return PVLM_ERR_ARG;
   return run_map<double>(ctx, n, px, 2, cam, 3, [&](double* di, double* dout) {
-    hipLaunchKernelGGL(k_image_to_cam<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
+    hipLaunchKernelGGL((k_image_to_cam<double, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, di, r, dout);
   });
 }
 
@@ -361,7 +445,12 @@ pvlm_status pvlm_cam_to_image_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t
   if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!d_cam || !d_px))) return PVLM_ERR_ARG;
   if (n == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  hipLaunchKernelGGL(k_cam_to_image<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_cam, d_px);
+  if ((((uintptr_t)d_px | (uintptr_t)d_cam) & 15) == 0 && n >= 4) {
+    const long long n4 = n / 4, tail = n - 4 * n4;
+    hipLaunchKernelGGL(k_cam_to_image_f32x4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, n4, reinterpret_cast<const float4*>(d_cam),
+                       reinterpret_cast<float4*>(d_px));
+    if (tail) hipLaunchKernelGGL(k_cam_to_image<float>, dim3(1), dim3(64), 0, ctx->stream, rows, cols, tail, d_cam + 12 * n4, d_px + 8 * n4);
+  } else hipLaunchKernelGGL(k_cam_to_image<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_cam, d_px);
   PVLM_HIP(ctx, hipGetLastError());
   return PVLM_OK;
 }
@@ -369,7 +458,13 @@ pvlm_status pvlm_image_to_cam_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t
   if (!ctx || n < 0 || rows <= 0 || cols <= 0 || (n > 0 && (!d_cam || !d_px))) return PVLM_ERR_ARG;
   if (n == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  hipLaunchKernelGGL(k_image_to_cam<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_px, r, d_cam);
+  if (exact_trig()) hipLaunchKernelGGL((k_image_to_cam<float, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_px, r, d_cam);
+  else if ((((uintptr_t)d_px | (uintptr_t)d_cam) & 15) == 0 && n >= 4) {
+    const long long n4 = n / 4, tail = n - 4 * n4;
+    hipLaunchKernelGGL(k_image_to_cam_f32x4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, n4, reinterpret_cast<const float4*>(d_px), r,
+                       reinterpret_cast<float4*>(d_cam));
+    if (tail) hipLaunchKernelGGL((k_image_to_cam<float, false>), dim3(1), dim3(64), 0, ctx->stream, rows, cols, tail, d_px + 8 * n4, r, d_cam + 12 * n4);
+  } else hipLaunchKernelGGL((k_image_to_cam<float, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_px, r, d_cam);
   PVLM_HIP(ctx, hipGetLastError());
   return PVLM_OK;
 }

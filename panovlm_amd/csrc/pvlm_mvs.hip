@@ -5,7 +5,7 @@
 // One wave per reference pixel, one lane per texel of the NCC window (7 x 7 = 49 at the Room settings; larger windows
 // loop): the bilateral weights, the plane-induced homography H = R_nr + t_nr n^T / d, the equirectangular re-projection
 // (the same FastAtan2 arithmetic as K7) and the bilinear samples are per-lane work, the weighted means / variances are
-// wave reductions (tree order: float sums differ from the reference's sequential order by rounding, ~1e-7 relative).
+// summed in the reference's own sequential order (wave_seq_sum below).
 // Threshold decisions (d > 0, projection inside the image, sq0 <= 1e-6) use the reference's float arithmetic —
 // compiled with -ffp-contract=off.  Images stay in HBM as uint8; the PreComputeI2C table is built on the device.
 #include <algorithm>
@@ -18,10 +18,32 @@
 
 #define PVLM_MVS_MAXM 4   // texels per lane: windows up to 256 texels
 
-__device__ inline float wave_sum_f(float x) {
+// Sum of the n per-texel values v_k (texel k lives in lane k % 64, slot k / 64) IN INDEX ORDER: s = 0; s += v_0; s += v_1; ...
+// — exactly the reference's sequential float loops (mvs/MVS.cpp:659-673, :826-833).  A wave tree would be six steps instead
+// of n, but float addition does not associate: on texture-less windows sq0, sq1 and the normalisation nrm = sq0 * sq1 are sums of
+// rounding residues, and the reference's own tests `sq0 > 0` (:602), `nrm <= 0` (:835) then depend on the order of the
+// additions — measured at 5.7K, a tree order took the other branch on 0.4 % of the pixels.  Every lane reads texel i
+// with v_readlane (uniform index) and adds it: all lanes carry the same running sum, no shuffle, no LDS.
+__device__ inline float wave_seq_sum(const float (&v)[PVLM_MVS_MAXM], int n) {
+  float s = 0.f;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-  return __shfl(x, 0, 64);
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+    const int cnt = min(64, n - 64 * m);
+    for (int i = 0; i < cnt; ++i) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[m]), i));
+  }
+  return s;
+}
+__device__ inline void wave_seq_sum2(const float (&a)[PVLM_MVS_MAXM], const float (&b)[PVLM_MVS_MAXM], int n, float* sa, float* sb) {
+  float s = 0.f, t = 0.f;
+#pragma unroll
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+    const int cnt = min(64, n - 64 * m);
+    for (int i = 0; i < cnt; ++i) {
+      s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[m]), i));
+      t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[m]), i));
+    }
+  }
+  *sa = s; *sb = t;
 }
 
 __global__ void k_mvs_unit_table(int rows, int cols, float* __restrict__ unit) {
@@ -43,25 +65,22 @@ __device__ inline void wave_fill_patch(const unsigned char* __restrict__ ref_gra
 #pragma unroll
   for (int m = 0; m < PVLM_MVS_MAXM; ++m) { P.w[m] = 0.f; P.t0[m] = 0.f; }
   if (!P.inside) return;
-  float part = 0.f;
 #pragma unroll
   for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
     const int k = lane + 64 * m;
     if (k < n) pvlm_mvs::patch_texel(ref_gray, cols, px, py, half_window, step, k, &P.w[m], &P.t0[m]);
-    part += P.w[m];
   }
-  const float wsum = wave_sum_f(part);
-  part = 0.f;
+  const float wsum = wave_seq_sum(P.w, n);                    // accumulate(weight.begin(), weight.end(), 0.f)   :659
+  float prod[PVLM_MVS_MAXM];
 #pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) { P.w[m] /= wsum; part += P.w[m] * P.t0[m]; }
-  const float mean = wave_sum_f(part);
-  part = 0.f;
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) { P.w[m] /= wsum; prod[m] = P.w[m] * P.t0[m]; }
+  const float mean = wave_seq_sum(prod, n);                   // sum += weight[i] * texels0[i]                  :662-664
 #pragma unroll
   for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
     const int k = lane + 64 * m;
-    if (k < n) { P.t0[m] -= mean; const float tmp = P.t0[m] * P.w[m]; part += P.t0[m] * tmp; P.t0[m] = tmp; } else P.t0[m] = 0.f;
+    if (k < n) { P.t0[m] -= mean; const float tmp = P.t0[m] * P.w[m]; prod[m] = P.t0[m] * tmp; P.t0[m] = tmp; } else { P.t0[m] = 0.f; prod[m] = 0.f; }
   }
-  P.sq0 = wave_sum_f(part);
+  P.sq0 = wave_seq_sum(prod, n);                              // sq0 += texels0[i] * tmp                         :668-672
 }
 
 // ScorePixel (mvs/MVS.cpp:774-923) for one hypothesis (nrm3, dep) of pixel (px, py): photometric NCC per neighbour image,
@@ -78,25 +97,24 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
   for (int b = 0; b < nb.n; ++b) {
     float H[9];
     pvlm_mvs::homography(nb.R[b], nb.t[b], nrm3, d, H);
-    float t1[PVLM_MVS_MAXM];
+    float t1[PVLM_MVS_MAXM], pa[PVLM_MVS_MAXM], pb[PVLM_MVS_MAXM];
     bool ok = true;
-    float part = 0.f;
 #pragma unroll
     for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
       const int k = lane + 64 * m;
       t1[m] = 0.f;
       if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b], rows, cols, H, px, py, half_window, step, k, &t1[m]) && ok;
-      part += t1[m] * P.w[m];
+      pa[m] = t1[m] * P.w[m];
     }
     if (__any(!ok)) continue;                                          // goto next_image
-    const float sum = wave_sum_f(part);
-    float p1 = 0.f, p01 = 0.f;
+    const float sum = wave_seq_sum(pa, n);                             // sum += texels1[i] * weight[i]            :826-827
 #pragma unroll
     for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
       const int k = lane + 64 * m;
-      if (k < n) { t1[m] -= sum; p1 += t1[m] * t1[m] * P.w[m]; p01 += P.t0[m] * t1[m]; }
+      if (k < n) { t1[m] -= sum; pa[m] = t1[m] * t1[m] * P.w[m]; pb[m] = P.t0[m] * t1[m]; } else { pa[m] = 0.f; pb[m] = 0.f; }
     }
-    const float sq1 = wave_sum_f(p1), sq01 = wave_sum_f(p01);
+    float sq1, sq01;
+    wave_seq_sum2(pa, pb, n, &sq1, &sq01);                             // :830-831, :834-835
     const float nrm = P.sq0 * sq1;
     if (nrm <= 0.f) continue;
     float score = sq01 / sqrtf(nrm);

@@ -11,6 +11,14 @@
 
 namespace pvlm_mvs {
 
+// exp / sin / cos / acos of a FLOAT (the reference calls the std:: float overloads; their last bit depends on the libm
+// version): the correctly rounded float result, taken as the double function rounded to float — the same definition the
+// oracle uses (oracle/mvs.hpp), so that device, host-compiled check and oracle agree bit for bit.
+PVLM_HD inline float f_exp(float x) { return (float)exp((double)x); }
+PVLM_HD inline float f_sin(float x) { return (float)sin((double)x); }
+PVLM_HD inline float f_cos(float x) { return (float)cos((double)x); }
+PVLM_HD inline float f_acos(float x) { return (float)acos((double)x); }
+
 // FastAtan2<float> (base/Math.h:15-29): polynomial evaluated in double (double literals), rounded to float on assignment
 PVLM_HD inline float fast_atan2f(float y, float x) {
   const float ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
@@ -62,7 +70,7 @@ PVLM_HD inline void patch_texel(const unsigned char* gray, int cols, int px, int
   float wColor = (tex - center) / 255.f;
   wColor = wColor * wColor * sigma_color;
   const float wSpatial = ((float)((col - px) * (col - px)) + (float)((row - py) * (row - py))) * sigma_spatial;
-  *weight = expf(wColor + wSpatial);
+  *weight = f_exp(wColor + wSpatial);
   *texel = tex;
 }
 
@@ -133,7 +141,7 @@ PVLM_HD inline float geometric_adjust(float score, int rows, int cols, const flo
       float cosang = X0[0] * Xb[0] + X0[1] * Xb[1] + X0[2] * Xb[2];
       const float n1 = sqrtf(X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2]), n2 = sqrtf(Xb[0] * Xb[0] + Xb[1] * Xb[1] + Xb[2] * Xb[2]);
       cosang /= (n1 * n2);
-      const float ang = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)3.14159265358979323846 : acosf(cosang));
+      const float ang = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)3.14159265358979323846 : f_acos(cosang));
       const float diff_angle = (float)(ang * 180.0 / 3.14159265358979323846);
       consistency = diff_angle < consistency ? diff_angle : consistency;
     }
@@ -330,9 +338,9 @@ PVLM_HD inline void correct_normal(const float* viewDir, float* normal) {
   const float cosAngLen = dot3(normal, viewDir);
   if (cosAngLen >= 0) {
     const float axis[3] = {normal[1] * viewDir[2] - normal[2] * viewDir[1], normal[2] * viewDir[0] - normal[0] * viewDir[2], normal[0] * viewDir[1] - normal[1] * viewDir[0]};
-    const float v = (acosf(cosAngLen) - (float)1.57079632679489661923) * 1.01f;
+    const float v = (f_acos(cosAngLen) - (float)1.57079632679489661923) * 1.01f;
     const float rad = (-0.001f < v) ? -0.001f : v;                       // std::min(v, -0.001f)
-    const float sn = sinf(rad), c = cosf(rad);
+    const float sn = f_sin(rad), c = f_cos(rad);
     const float sin_axis[3] = {sn * axis[0], sn * axis[1], sn * axis[2]};
     const float cos1_axis[3] = {(1.f - c) * axis[0], (1.f - c) * axis[1], (1.f - c) * axis[2]};
     float R[9];
@@ -354,8 +362,8 @@ PVLM_HD inline void perturb_normal(Rng& rng, const float* normal, float perturba
   const float a1 = (rng.next01() - 0.5f) * perturbation;
   const float a2 = (rng.next01() - 0.5f) * perturbation;
   const float a3 = (rng.next01() - 0.5f) * perturbation;
-  const float sin_a1 = sinf(a1), sin_a2 = sinf(a2), sin_a3 = sinf(a3);
-  const float cos_a1 = cosf(a1), cos_a2 = cosf(a2), cos_a3 = cosf(a3);
+  const float sin_a1 = f_sin(a1), sin_a2 = f_sin(a2), sin_a3 = f_sin(a3);
+  const float cos_a1 = f_cos(a1), cos_a2 = f_cos(a2), cos_a3 = f_cos(a3);
   float R[9];
   R[0] = cos_a2 * cos_a3;
   R[1] = -cos_a2 * sin_a3;
@@ -393,10 +401,10 @@ PVLM_HD inline float smooth_factor(const float* plane, const ClosePixel& c, cons
   const float smoothBonus = 0.95f, smoothBonusDepth = 1.f - smoothBonus, smoothBonusNormal = (float)((1.f - smoothBonus) * 0.96);
   const float smoothSigmaDepth = -1.f / (2.f * 0.02f * 0.02f), smoothSigmaNormal = -1.f / (2.f * 0.22f * 0.22f);
   const float diff_distance = fabsf(plane[0] * c.point[0] + plane[1] * c.point[1] + plane[2] * c.point[2] + plane[3]) / depth;
-  const float factorDepth = expf(diff_distance * diff_distance * smoothSigmaDepth);
+  const float factorDepth = f_exp(diff_distance * diff_distance * smoothSigmaDepth);
   const float cosang = normal[0] * c.normal[0] + normal[1] * c.normal[1] + normal[2] * c.normal[2];
-  const float diff_angle = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)3.14159265358979323846 : acosf(cosang));
-  const float factorNormal = expf(diff_angle * diff_angle * smoothSigmaNormal);
+  const float diff_angle = cosang >= 1.f ? 0.f : (cosang <= -1.f ? (float)3.14159265358979323846 : f_acos(cosang));
+  const float factorNormal = f_exp(diff_angle * diff_angle * smoothSigmaNormal);
   return (1.f - smoothBonusDepth * factorDepth) * (1.f - smoothBonusNormal * factorNormal);
 }
 // applied to one neighbour image's clamped NCC (ScorePixel :843-857)

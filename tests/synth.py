@@ -213,13 +213,13 @@ def covisible_pairs(off, cam):
 
 
 # ---- panoramic MVS scenes: a textured box room rendered as equirectangular grey images -------------------------------
-def _room_texture(P):
-    x, y, z = P[..., 0], P[..., 1], P[..., 2]
+def _room_texture(P, frequency=1.0):
+    x, y, z = P[..., 0] * frequency, P[..., 1] * frequency, P[..., 2] * frequency
     g = 128 + 45 * np.sin(3.1 * x + 1.3 * y) * np.cos(2.3 * z) + 35 * np.sin(6.7 * y + 2.1 * z + 0.5 * x) + 25 * np.cos(9.3 * x - 4.1 * z) * np.sin(5.9 * y)
     return np.clip(g, 0, 255)
 
 
-def render_panorama(oracle, rows, cols, R_wc, t_wc, half=(4.0, 1.5, 6.0)):
+def render_panorama(oracle, rows, cols, R_wc, t_wc, half=(4.0, 1.5, 6.0), texture_frequency=1.0):
     """Grey equirectangular image of the inside of the box [-half, half] seen from the camera pose (R_wc, t_wc), with the
     true depth (distance along the ray) and the surface normal in the camera frame, facing the camera."""
     jj, ii = np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32))
@@ -233,7 +233,7 @@ def render_panorama(oracle, rows, cols, R_wc, t_wc, half=(4.0, 1.5, 6.0)):
     axis = np.argmin(tpos, axis=1); t = tpos[np.arange(len(tpos)), axis]
     P = o + dw * t[:, None]
     n_w = np.zeros_like(P); n_w[np.arange(len(P)), axis] = -np.sign(dw[np.arange(len(P)), axis])
-    gray = np.rint(_room_texture(P)).astype(np.uint8).reshape(rows, cols)
+    gray = np.rint(_room_texture(P, texture_frequency)).astype(np.uint8).reshape(rows, cols)   # frequency > 1: finer texture for large images
     normal = (n_w @ np.asarray(R_wc, np.float64)).astype(np.float32).reshape(rows, cols, 3)
     return gray, t.astype(np.float32).reshape(rows, cols), normal
 

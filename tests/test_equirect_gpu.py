@@ -41,6 +41,35 @@ def test_image_to_cam(ctx, oracle, rows, cols):
     assert err.max() < cols * 0.35 / 360 * 2
 
 
+def test_image_to_cam_f32_fast_trig_equals_library_trig_on_every_pixel_of_a_5p7k_panorama(ctx, oracle):
+    """Equirectangular::ImageToCam<float> (sensors/Equirectangular.h:149-170) on all 5760 x 2880 integer pixels and on 4 M
+    sub-pixel positions: the kernel's own sin/cos (one Cody-Waite step + fdlibm kernel polynomials in double, rounded to
+    float) gives the same floats as the device library's double sin / cos rounded to float (PVLM_EXACT_TRIG=1, the round-1
+    path), bit for bit, and both equal the oracle's (float)sin((double)x) on a sample."""
+    import os, subprocess, sys, tempfile
+    rows, cols = 2880, 5760
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    grid = np.stack([xx.ravel(), yy.ravel()], axis=1).astype(np.float32)
+    rng = np.random.default_rng(8)
+    sub = rng.uniform([-50, -50], [cols + 50, rows + 50], size=(4_000_000, 2)).astype(np.float32)     # incl. positions outside the image
+    px = np.concatenate([grid, sub])
+    fast = ctx.image_to_cam(rows, cols, px, 1.0)
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "px.npy"), px)
+        code = ("import numpy as np, sys; sys.path.insert(0, %r)\nimport panovlm_amd as pv\nctx = pv.Context(0)\n"
+                "px = np.load(sys.argv[1] + '/px.npy'); np.save(sys.argv[1] + '/exact.npy', ctx.image_to_cam(%d, %d, px, 1.0))\n"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), rows, cols))
+        env = dict(os.environ); env["PVLM_EXACT_TRIG"] = "1"
+        subprocess.run([sys.executable, "-c", code, d], check=True, env=env, timeout=900)
+        exact = np.load(os.path.join(d, "exact.npy"))
+    assert fast.dtype == np.float32 and fast.shape == exact.shape == (len(px), 3)
+    mism = np.flatnonzero((fast != exact).any(axis=1))
+    assert len(mism) == 0, (len(mism), px[mism[:5]], fast[mism[:5]], exact[mism[:5]])
+    idx = rng.choice(len(px), 200_000, replace=False)
+    o = oracle.image_to_cam(rows, cols, px[idx], 1.0)
+    assert np.mean((fast[idx] == o).all(axis=1)) > 0.9999 and np.abs(fast[idx] - o).max() <= 1.2e-7
+
+
 def test_cam_lidar_votes(ctx, oracle):
     import panovlm_amd as pv
     rng = np.random.default_rng(8)

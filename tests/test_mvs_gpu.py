@@ -1,7 +1,8 @@
-"""GPU parity of the panoramic MVS scoring pass (pvlm_mvs_init_conf_map: MVS::InitPatchMap + InitConfMap, mvs/MVS.cpp:586-680,
-:774-923) against the CPU oracle, through the C ABI.  float32: the kernel's wave-tree sums and device expf differ from the
-reference's sequential sums / libm by rounding, so scores are compared to 1e-4 absolute (observed ~1e-6); every validity
-decision (patch inside / textured, plane facing the camera, window projecting inside the neighbour) must be identical."""
+"""GPU parity of the panoramic MVS kernels (scoring pass pvlm_mvs_init_conf_map: MVS::InitPatchMap + InitConfMap,
+mvs/MVS.cpp:586-680, :774-923; checkerboard PatchMatch sweep; depth fusion filters) against the CPU oracle, through the
+C ABI.  BIT FOR BIT: the kernels add the NCC sums in the reference's sequential order (wave_seq_sum) and both sides use
+the correctly rounded float exp / sin / cos / acos, so scores, validity decisions, tie-breaks between hypotheses and the
+random perturbations drawn after them are identical."""
 import numpy as np
 import pytest
 
@@ -31,7 +32,7 @@ def test_conf_map_matches_oracle(ctx, oracle, hw, step, rows, cols):
     assert np.array_equal(dg, do) and np.array_equal(ng, no)
     valid = (co > -1) & (co != 5.0)
     assert valid.mean() > 0.6
-    assert np.abs(cg[valid] - co[valid]).max() <= 1e-4, np.abs(cg[valid] - co[valid]).max()
+    assert np.array_equal(cg, co), (int((cg != co).sum()), float(np.abs(cg[valid] - co[valid]).max()))      # bit for bit
 
 
 def test_conf_map_with_geometric_consistency_matches_oracle(ctx, oracle):
@@ -44,7 +45,7 @@ def test_conf_map_with_geometric_consistency_matches_oracle(ctx, oracle):
     valid = co > -1
     # the depth-validity functor |depth0 - d| / depth0 < 0.03 and min(angle, 2) are decided in float on both sides: a
     # corner flipping across the 3 % threshold would show as a jump of up to 0.4 — none may occur
-    assert np.abs(cg[valid] - co[valid]).max() <= 1e-4, np.abs(cg[valid] - co[valid]).max()
+    assert np.array_equal(cg, co), (int((cg != co).sum()), float(np.abs(cg[valid] - co[valid]).max()))
     pho, _, _ = oracle.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, 3, 1)
     assert (pho[valid] - co[valid]).max() > 0.3          # the term is active in this scene
 
@@ -55,10 +56,13 @@ def test_conf_map_edge_cases(ctx, oracle):
     # no neighbours: every pixel with depth gets -1 and loses its hypothesis
     c, d, n = ctx.mvs_init_conf_map(gray, [], np.zeros((0, 9)), np.zeros((0, 3)), depth, normal)
     assert np.all(c == -1) and np.all(d == 0) and np.all(n == 0)
-    # a flat (texture-less) reference image: sq0 <= 1e-6 everywhere
+    # a flat (texture-less) reference image: sq0 is a sum of rounding residues, zero or ~1e-10 depending on the window;
+    # InitConfMap tests `sq0 > 0` only (mvs/MVS.cpp:602), so the outcome is decided by the order of the float sums —
+    # the reference's sequential order on both sides: identical maps
     flat = np.full_like(gray, 100)
-    c, _, _ = ctx.mvs_init_conf_map(flat, neis, Rn, tn, depth, normal)
-    assert np.all(c == -1)
+    c, d, n = ctx.mvs_init_conf_map(flat, neis, Rn, tn, depth, normal)
+    co, do, no = oracle.mvs_init_conf_map(flat, neis, Rn, tn, depth, normal)
+    assert np.array_equal(c, co) and np.array_equal(d, do) and np.array_equal(n, no)
     with pytest.raises(pv.PvlmError):
         ctx.mvs_init_conf_map(gray, neis, Rn, tn, depth, normal, half_window=20, step=1)      # 41 x 41 texels > 256
 
@@ -105,10 +109,9 @@ def sweep_agreement(got, want, valid):
 
 
 def test_patchmatch_sweep_matches_oracle(ctx, oracle):
-    """pvlm_mvs_propagate (k_mvs_propagate: one wave per pixel, process_pixel + wave-level ScorePixel) against the oracle.
-    The per-hypothesis scores differ at the 1e-6 level (wave-tree sums, device sinf / cosf / expf / acosf), so a pixel whose
-    two best candidates tie that closely may keep the other one and then draws different perturbations: the maps agree on
-    the great majority of pixels, and the sweeps are equally good where they differ."""
+    """pvlm_mvs_propagate (k_mvs_propagate: one wave per pixel, process_pixel + wave-level ScorePixel) against the oracle:
+    depth, normal and confidence maps identical (round 1: 99 % of the pixels to 1e-4 — tree-order sums and the device's
+    float library functions made near-ties fall the other way)."""
     from tests.test_mvs_cpu import sweep_scene
     S = sweep_scene(oracle)
     args = (S["gray"], S["neis"], S["Rn"], S["tn"], S["depth"], S["normal"], S["conf"])
@@ -118,10 +121,8 @@ def test_patchmatch_sweep_matches_oracle(ctx, oracle):
         want = oracle.mvs_propagate(*args, **kw)
         got = ctx.mvs_propagate(*args, **kw)
         agree = sweep_agreement(got, want, valid)
-        assert agree > 0.9, agree
-        assert np.array_equal(got[0] == 0, want[0] == 0) or np.mean((got[0] == 0) != (want[0] == 0)) < 0.01
-        assert abs(float(got[2][valid].mean()) - float(want[2][valid].mean())) < 2e-3
-        assert abs(err(got[0]) - err(want[0])) < 0.2 * err(want[0]) + 1e-4
+        diff = [int((a != b).sum()) for a, b in zip(got, want)]
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), (agree, diff)          # depth, normal, conf: bit for bit
         if "conf_threshold" not in kw:
             assert np.all(got[2][valid] >= S["conf"][valid])                                       # monotone, as on the CPU
         m = (S["const"] == 1) & valid

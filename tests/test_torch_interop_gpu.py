@@ -66,3 +66,31 @@ def test_rccl_allreduce_through_the_abi_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(x, ref)
     comm.close(); ctx.use_own_stream(); ctx.close()
+
+
+def test_device_resident_panorama_maps_equal_the_host_pointer_entry_points():
+    """pvlm_cam_to_image_f32_dev / pvlm_image_to_cam_f32_dev (four points per lane, 16-byte accesses + a scalar tail) against the
+    host-pointer entry points (one point per lane): same floats, for sizes with every tail length and for an unaligned view."""
+    import torch
+    import panovlm_amd as pv
+    ctx = pv.Context(0)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    rows, cols = 2880, 5760
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    for n in (1, 3, 4, 5, 1000, 1001, 1002, 1003, 70001):
+        cam = (torch.randn((n + 1, 3), generator=g) * 3).float()
+        px = (torch.rand((n + 1, 2), generator=g) * torch.tensor([cols, rows])).float()
+        for off in (0, 1):                         # off = 1: the device view starts 12 / 8 bytes into the allocation -> scalar path
+            c_d = cam.to(dev)[off:off + n].contiguous() if off == 0 else cam.to(dev)[off:off + n]
+            p_d = px.to(dev)[off:off + n].contiguous() if off == 0 else px.to(dev)[off:off + n]
+            assert c_d.is_contiguous() and p_d.is_contiguous()
+            o_px = torch.empty((n, 2), device=dev); o_cam = torch.empty((n, 3), device=dev)
+            ctx.cam_to_image_f32_dev(rows, cols, n, c_d.data_ptr(), o_px.data_ptr())
+            ctx.image_to_cam_f32_dev(rows, cols, n, p_d.data_ptr(), 2.5, o_cam.data_ptr())
+            torch.cuda.synchronize()
+            want_px = ctx.cam_to_image(rows, cols, c_d.cpu().numpy())
+            want_cam = ctx.image_to_cam(rows, cols, p_d.cpu().numpy(), 2.5)
+            assert np.array_equal(o_px.cpu().numpy(), want_px, equal_nan=True), (n, off)
+            assert np.array_equal(o_cam.cpu().numpy(), want_cam), (n, off)
+    ctx.use_own_stream(); ctx.close()
