@@ -73,6 +73,7 @@ def main():
                          "of the five kernels costs 28-33 us around the fused kernel against 22-26 us for five plain launches "
                          "(per_rank_projection reports both), and eager launches let every launch of the dominant kernel inside the "
                          "timed region be bracketed by HIP events (roofline.achieved)")
+    ap.add_argument("--no-mvs", action="store_true", help="skip the panoramic MVS block (resident views at 1440 x 720 and 5760 x 2880)")
     ap.add_argument("--no-projection", action="store_true", help="skip the per-rank projection block (scans/2, /4, /8 on this GPU)")
     args = ap.parse_args()
 
@@ -327,6 +328,13 @@ def main():
         except Exception as e:  # reporting extra only
             pano = {"error": str(e)[:200]}
 
+    mvs = None
+    if rank == 0 and world == 1 and not args.no_mvs:
+        try:
+            mvs = mvs_block(ctx, pv)
+        except Exception as e:  # reporting extra only
+            mvs = {"error": str(e)[:200]}
+
     if rank == 0:
         # HBM traffic of the fused kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command, summarised by tools/pmc_traffic.py into profiles/): used only when it was collected on
@@ -380,6 +388,7 @@ def main():
             "materialise": mat,
             "pcie": pcie,
             "panorama": pano,
+            "mvs": mvs,
             "setup": {"scan_generation_s": t_gen, "scans_generated": len(needed)},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -553,6 +562,53 @@ def pcie_block(ctx, pv, associate, ref, nei, args):
     rs2.close(); rs.close()
     for a in (h_r, h_J, h_w, h_t):
         ctx.host_free(a)
+    return out
+
+
+def mvs_block(ctx, pv):
+    """BASELINE.json config 5: the panoramic PatchMatch kernels on views RESIDENT in HBM (pvlm_mvs_views_*), at the reference's
+    Room size (5.7K at scale -2 = 1440 x 720, config/Room.txt:87) and at the full 5.7K size.  Scene: a textured sphere of
+    radius 3 m seen from three camera centres 0.2 m apart (every window projects into every neighbour).  K11 = scoring pass
+    (InitConfMap), K13 = one checkerboard PatchMatch iteration (two colour passes), K12 = FilterDepthImageRefine.
+    The NCC sums run in the reference's sequential order and the kernels are VALU-bound, so their roof is instruction
+    issue, not HBM: the algorithmic HBM bytes (29 B per pixel and view touched) are reported next to the time."""
+    from panovlm_amd.api import MvsViews
+    out = {}
+    for rows, cols in ((720, 1440), (2880, 5760)):
+        yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+        lon = (2 * xx / cols - 1) * np.pi; lat = (0.5 - yy / rows) * np.pi
+        ray = np.stack([np.cos(lat) * np.sin(lon), -np.sin(lat), np.cos(lat) * np.cos(lon)], axis=-1).astype(np.float32)
+        gray = np.clip(128 + 50 * np.sin(40 * lon) * np.cos(37 * lat) + 40 * np.sin(91 * lat + 13 * lon), 0, 255).astype(np.uint8)
+        depth = np.full((rows, cols), 3.0, np.float32)
+        normal = (-ray).astype(np.float32)
+        V = MvsViews(ctx, rows, cols, 3)
+        for v in range(3):
+            V.upload(v, gray=gray, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
+            V.snapshot_depth(v)
+        Rn = np.stack([np.eye(3, dtype=np.float32)] * 2); tn = np.array([[0.2, 0, 0], [-0.2, 0.01, 0.05]], np.float32)
+        ref, nei = 0, [1, 2]
+        res = {"pixels": rows * cols, "neighbours": 2, "window": "7x7"}
+        for name, fn, reps in (("k11_scoring_pass", lambda: V.estimate(ref, nei, Rn, tn, max_iter=-1), 3),
+                               ("k13_patchmatch_iteration", lambda: V.estimate(ref, nei, Rn, tn, max_iter=1, seed=3), 2),
+                               ("k12_fusion_filter_refine", lambda: V.filter_refine(ref, nei, Rn, tn), 3)):
+            fn(); ctx.synchronize()
+            V.upload(ref, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
+            if name.startswith("k13"):
+                V.estimate(ref, nei, Rn, tn, max_iter=-1)
+            ctx.synchronize()
+            ctx.timer_start()
+            for _ in range(reps):
+                fn()
+            ms = ctx.timer_stop() / reps
+            texels = rows * cols * 49 * 2
+            res[name] = {"ms": ms, "M_pixels_per_s": rows * cols / ms / 1e3}
+            if name.startswith("k11"):
+                res[name]["G_texel_projections_per_s"] = texels / ms / 1e6
+            res[name]["algorithmic_hbm_bytes"] = rows * cols * 29 * 3
+            res[name]["frac_of_hbm_peak"] = rows * cols * 29 * 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        out["%dx%d" % (cols, rows)] = res
+        V.close()
+    out["bound"] = "VALU (sequential-order NCC sums + double-evaluated float exp / acos): HBM fraction is reported for completeness"
     return out
 
 

@@ -18,30 +18,29 @@
 
 #define PVLM_MVS_MAXM 4   // texels per lane: windows up to 256 texels
 
-// Sum of the n per-texel values v_k (texel k lives in lane k % 64, slot k / 64) IN INDEX ORDER: s = 0; s += v_0; s += v_1; ...
-// — exactly the reference's sequential float loops (mvs/MVS.cpp:659-673, :826-833).  A wave tree would be six steps instead
-// of n, but float addition does not associate: on texture-less windows sq0, sq1 and the normalisation nrm = sq0 * sq1 are sums of
-// rounding residues, and the reference's own tests `sq0 > 0` (:602), `nrm <= 0` (:835) then depend on the order of the
-// additions — measured at 5.7K, a tree order took the other branch on 0.4 % of the pixels.  Every lane reads texel i
-// with v_readlane (uniform index) and adds it: all lanes carry the same running sum, no shuffle, no LDS.
-__device__ inline float wave_seq_sum(const float (&v)[PVLM_MVS_MAXM], int n) {
-  float s = 0.f;
-#pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
-    const int cnt = min(64, n - 64 * m);
-    for (int i = 0; i < cnt; ++i) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[m]), i));
-  }
+// Sums of per-texel values IN INDEX ORDER: s = 0; s += v_0; s += v_1; ... — exactly the reference's sequential float loops
+// (mvs/MVS.cpp:659-673, :826-833).  A wave tree would be six steps instead of n, but float addition does not associate: on
+// texture-less windows sq0, sq1 and nrm = sq0 * sq1 are sums of rounding residues, and the reference's own tests
+// `sq0 > 0` (:602), `nrm <= 0` (:835) then depend on the order of the additions — measured at 5.7K, a tree order took the
+// other branch on 0.4 % of the pixels; near-ties between PatchMatch hypotheses fall the other way for the same reason.
+// Every lane parks its values in the wave's LDS strip (one float4 per texel = the same quantity for four neighbour images),
+// then all lanes walk the strip with broadcast 16-byte reads and add: four independent sequential chains per pass, every
+// lane ends with the same four sums.  (v_readlane chains, the first version, cost 2.5x the rest of the kernel.)
+#define PVLM_MVS_STRIP 256                     // texels per strip (= 64 * PVLM_MVS_MAXM)
+#define PVLM_MVS_LDS_PER_WAVE (3 * PVLM_MVS_STRIP)   // float4 elements: products A | products B1 | products B2
+__device__ inline float4 strip_seq_sum(const float4* __restrict__ strip, int n) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int i = 0; i < n; ++i) { const float4 q = strip[i]; s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w; }
   return s;
 }
-__device__ inline void wave_seq_sum2(const float (&a)[PVLM_MVS_MAXM], const float (&b)[PVLM_MVS_MAXM], int n, float* sa, float* sb) {
-  float s = 0.f, t = 0.f;
-#pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
-    const int cnt = min(64, n - 64 * m);
-    for (int i = 0; i < cnt; ++i) {
-      s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[m]), i));
-      t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[m]), i));
-    }
+__device__ inline void strip_seq_sum2(const float4* __restrict__ a, const float4* __restrict__ b, int n, float4* sa, float4* sb) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = s;
+#pragma unroll 8
+  for (int i = 0; i < n; ++i) {
+    const float4 q = a[i], r = b[i];
+    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
   }
   *sa = s; *sb = t;
 }
@@ -57,9 +56,9 @@ struct pvlm_mvs_neighbours { const unsigned char* gray[16]; const float* depth[1
 // ---- wave-level pieces shared by the scoring pass and the PatchMatch sweep (one wave per pixel, lane = texel) ----
 struct PatchRegs { float w[PVLM_MVS_MAXM], t0[PVLM_MVS_MAXM]; float sq0; bool inside; };
 
-// FillPixelPatch (mvs/MVS.cpp:637-680)
+// FillPixelPatch (mvs/MVS.cpp:637-680).  lds: the wave's strip (PVLM_MVS_LDS_PER_WAVE float4).
 __device__ inline void wave_fill_patch(const unsigned char* __restrict__ ref_gray, int rows, int cols, int px, int py, int half_window, int step, int n, int lane,
-                                       PatchRegs& P) {
+                                       float4* __restrict__ lds, PatchRegs& P) {
   P.inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
   P.sq0 = 0.f;
 #pragma unroll
@@ -68,19 +67,22 @@ __device__ inline void wave_fill_patch(const unsigned char* __restrict__ ref_gra
 #pragma unroll
   for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
     const int k = lane + 64 * m;
-    if (k < n) pvlm_mvs::patch_texel(ref_gray, cols, px, py, half_window, step, k, &P.w[m], &P.t0[m]);
+    if (k < n) { pvlm_mvs::patch_texel(ref_gray, cols, px, py, half_window, step, k, &P.w[m], &P.t0[m]); lds[k] = make_float4(P.w[m], 0.f, 0.f, 0.f); }
   }
-  const float wsum = wave_seq_sum(P.w, n);                    // accumulate(weight.begin(), weight.end(), 0.f)   :659
-  float prod[PVLM_MVS_MAXM];
-#pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) { P.w[m] /= wsum; prod[m] = P.w[m] * P.t0[m]; }
-  const float mean = wave_seq_sum(prod, n);                   // sum += weight[i] * texels0[i]                  :662-664
+  const float wsum = strip_seq_sum(lds, n).x;                 // accumulate(weight.begin(), weight.end(), 0.f)   :659
 #pragma unroll
   for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
     const int k = lane + 64 * m;
-    if (k < n) { P.t0[m] -= mean; const float tmp = P.t0[m] * P.w[m]; prod[m] = P.t0[m] * tmp; P.t0[m] = tmp; } else { P.t0[m] = 0.f; prod[m] = 0.f; }
+    P.w[m] /= wsum;
+    if (k < n) lds[k] = make_float4(P.w[m] * P.t0[m], 0.f, 0.f, 0.f);
   }
-  P.sq0 = wave_seq_sum(prod, n);                              // sq0 += texels0[i] * tmp                         :668-672
+  const float mean = strip_seq_sum(lds, n).x;                 // sum += weight[i] * texels0[i]                  :662-664
+#pragma unroll
+  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+    const int k = lane + 64 * m;
+    if (k < n) { P.t0[m] -= mean; const float tmp = P.t0[m] * P.w[m]; lds[k] = make_float4(P.t0[m] * tmp, 0.f, 0.f, 0.f); P.t0[m] = tmp; } else P.t0[m] = 0.f;
+  }
+  P.sq0 = strip_seq_sum(lds, n).x;                            // sq0 += texels0[i] * tmp                         :668-672
 }
 
 // ScorePixel (mvs/MVS.cpp:774-923) for one hypothesis (nrm3, dep) of pixel (px, py): photometric NCC per neighbour image,
@@ -88,41 +90,68 @@ __device__ inline void wave_fill_patch(const unsigned char* __restrict__ ref_gra
 // Every lane returns the same value.
 __device__ inline float wave_score(int rows, int cols, int half_window, int step, int n, int lane, const float* __restrict__ unit,
                                    const pvlm_mvs_neighbours& nb, int px, int py, const PatchRegs& P, const float* nrm3, float dep, const float* factors,
-                                   int n_close) {
+                                   int n_close, float4* __restrict__ lds) {
   const float* u0 = unit + 3 * ((size_t)py * cols + px);
   const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
   const float d = X0[0] * nrm3[0] + X0[1] * nrm3[1] + X0[2] * nrm3[2];
   if (d > 0) return -1.f;
   float best1 = 0.f, best2 = 0.f; int count = 0;
-  for (int b = 0; b < nb.n; ++b) {
-    float H[9];
-    pvlm_mvs::homography(nb.R[b], nb.t[b], nrm3, d, H);
-    float t1[PVLM_MVS_MAXM], pa[PVLM_MVS_MAXM], pb[PVLM_MVS_MAXM];
-    bool ok = true;
+  float4* sA = lds; float4* sB1 = lds + PVLM_MVS_STRIP; float4* sB2 = lds + 2 * PVLM_MVS_STRIP;
+  for (int b0 = 0; b0 < nb.n; b0 += 4) {                                 // four neighbour images per pass: one float4 per texel in LDS
+    float t1[4][PVLM_MVS_MAXM];
+    bool okj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bool ok = b0 + j < nb.n;
+      if (ok) {
+        float H[9];
+        pvlm_mvs::homography(nb.R[b0 + j], nb.t[b0 + j], nrm3, d, H);
+#pragma unroll
+        for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+          const int k = lane + 64 * m;
+          t1[j][m] = 0.f;
+          if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b0 + j], rows, cols, H, px, py, half_window, step, k, &t1[j][m]) && ok;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < PVLM_MVS_MAXM; ++m) t1[j][m] = 0.f;
+      }
+      okj[j] = !__any(!ok);                                              // goto next_image
+    }
+    if (!(okj[0] || okj[1] || okj[2] || okj[3])) continue;
 #pragma unroll
     for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
       const int k = lane + 64 * m;
-      t1[m] = 0.f;
-      if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b], rows, cols, H, px, py, half_window, step, k, &t1[m]) && ok;
-      pa[m] = t1[m] * P.w[m];
+      if (k < n) sA[k] = make_float4(t1[0][m] * P.w[m], t1[1][m] * P.w[m], t1[2][m] * P.w[m], t1[3][m] * P.w[m]);
     }
-    if (__any(!ok)) continue;                                          // goto next_image
-    const float sum = wave_seq_sum(pa, n);                             // sum += texels1[i] * weight[i]            :826-827
+    const float4 sum = strip_seq_sum(sA, n);                             // sum += texels1[i] * weight[i]            :826-827
+    const float sj[4] = {sum.x, sum.y, sum.z, sum.w};
 #pragma unroll
     for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
       const int k = lane + 64 * m;
-      if (k < n) { t1[m] -= sum; pa[m] = t1[m] * t1[m] * P.w[m]; pb[m] = P.t0[m] * t1[m]; } else { pa[m] = 0.f; pb[m] = 0.f; }
+      if (k < n) {
+        float p1[4], p01[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t1[j][m] -= sj[j]; p1[j] = t1[j][m] * t1[j][m] * P.w[m]; p01[j] = P.t0[m] * t1[j][m]; }
+        sB1[k] = make_float4(p1[0], p1[1], p1[2], p1[3]);
+        sB2[k] = make_float4(p01[0], p01[1], p01[2], p01[3]);
+      }
     }
-    float sq1, sq01;
-    wave_seq_sum2(pa, pb, n, &sq1, &sq01);                             // :830-831, :834-835
-    const float nrm = P.sq0 * sq1;
-    if (nrm <= 0.f) continue;
-    float score = sq01 / sqrtf(nrm);
-    score = fminf(fmaxf(score, -1.f), 1.f);
-    score = pvlm_mvs::smooth_score(score, factors, n_close);
-    if (nb.geometric) score = pvlm_mvs::geometric_adjust(score, rows, cols, X0, nb.R[b], nb.t[b], nb.depth[b]);   // wave-uniform
-    if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
-    ++count;
+    float4 q1, q01;
+    strip_seq_sum2(sB1, sB2, n, &q1, &q01);                              // :830-831, :834-835
+    const float sq1j[4] = {q1.x, q1.y, q1.z, q1.w}, sq01j[4] = {q01.x, q01.y, q01.z, q01.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                        // the neighbours in their own order, as the reference's loop visits them
+      if (!okj[j]) continue;
+      const float nrm = P.sq0 * sq1j[j];
+      if (nrm <= 0.f) continue;
+      float score = sq01j[j] / sqrtf(nrm);
+      score = fminf(fmaxf(score, -1.f), 1.f);
+      score = pvlm_mvs::smooth_score(score, factors, n_close);
+      if (nb.geometric) score = pvlm_mvs::geometric_adjust(score, rows, cols, X0, nb.R[b0 + j], nb.t[b0 + j], nb.depth[b0 + j]);   // wave-uniform
+      if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+      ++count;
+    }
   }
   if (count == 1) return best1;
   if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; return avg / 2; }
@@ -140,11 +169,13 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
   const int py = (int)(e / cols), px = (int)(e % cols);
   const int n = pvlm_mvs::num_texels(half_window, step);
   float c = -1.f;
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE];
+  float4* lds = strips[threadIdx.x >> 6];
   PatchRegs P;
-  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, P);
+  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
   if (P.inside && P.sq0 > 0) {   // InitConfMap :602 tests sq0 > 0 only (InitPatchMap ignores FillPixelPatch's 1e-6 verdict; that gate is PropagateCheckerBoard's, :1116)
     const float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
-    c = wave_score(rows, cols, half_window, step, n, lane, unit, nb, px, py, P, nrm3, dep, nullptr, 0);
+    c = wave_score(rows, cols, half_window, step, n, lane, unit, nb, px, py, P, nrm3, dep, nullptr, 0, lds);
   }
   if (lane == 0) {
     conf[e] = c;
@@ -156,9 +187,9 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
 // the depth / normal of the other colour and update their own, so one launch is race-free.
 struct WaveScorer {
   int rows, cols, half_window, step, n, lane, px, py;
-  const float* unit; const pvlm_mvs_neighbours* nb; const PatchRegs* P;
+  const float* unit; const pvlm_mvs_neighbours* nb; const PatchRegs* P; float4* lds;
   __device__ float operator()(const float* nrm3, float dep, const float* factors, int n_close) const {
-    return wave_score(rows, cols, half_window, step, n, lane, unit, *nb, px, py, *P, nrm3, dep, factors, n_close);
+    return wave_score(rows, cols, half_window, step, n, lane, unit, *nb, px, py, *P, nrm3, dep, factors, n_close, lds);
   }
 };
 __global__ __launch_bounds__(256) void k_mvs_propagate(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
@@ -176,14 +207,16 @@ __global__ __launch_bounds__(256) void k_mvs_propagate(int rows, int cols, int h
   float dep = depth[e];
   if (dep <= 0) return;
   const int n = pvlm_mvs::num_texels(half_window, step);
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE];
+  float4* lds = strips[threadIdx.x >> 6];
   PatchRegs P;
-  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, P);
+  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
   if (!P.inside || P.sq0 <= 1e-6) return;                                 // patch.sq0 <= 1e-6 (:1116-1117; patches outside the margin have sq0 = 0)
   float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
   float c = conf[e];
   pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
   pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
-  WaveScorer scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P};
+  WaveScorer scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
   pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c);
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
