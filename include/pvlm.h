@@ -344,6 +344,25 @@ pvlm_status pvlm_image_to_cam_f32_dev(pvlm_ctx* ctx, int rows, int cols, int64_t
 pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t n, const float* xyz, const double* T_cl_rowmajor16,
                                      unsigned size, uint16_t* depth);
 
+/* MVS::InitDepthNormal (mvs/MVS.cpp:496-584; config 5 "LiDAR-seeded depth priors"): the depth image of
+ * pvlm_project_lidar_depth (uint16, depth * 256; size 2 upstream, :512) seeds the depth map, every pixel without a LiDAR depth
+ * gets a uniform random depth in [min_depth, max_depth], keep_lidar_constant != 0 marks the seeded pixels in depth_constant
+ * (config.keep_lidar_constant, :561-565), `mask` (float, 1 = keep) zeroes excluded pixels (:571), and every kept pixel gets a
+ * random unit normal facing the camera (GenerateRandomNormal :1404-1431).  lidar_depth == NULL is the use_lidar = false branch
+ * (:566-569), mask == NULL keeps everything.  Random draws: upstream uses one cv::RNG seeded with time(NULL); here draw k of
+ * pixel e is a hash of (seed, e, k), as in pvlm_mvs_propagate — the same arguments give the same maps.
+ * depth: rows x cols, normal: rows x cols x 3 (outputs); depth_constant: rows x cols uint8, written only with a LiDAR image. */
+pvlm_status pvlm_mvs_init_depth_normal(pvlm_ctx* ctx, int rows, int cols, const uint16_t* lidar_depth_or_null, const float* mask_or_null, float min_depth,
+                                       float max_depth, int keep_lidar_constant, unsigned long long seed, float* depth, float* normal,
+                                       unsigned char* depth_constant_or_null);
+/* MVS::RemoveSmallSegments (mvs/MVS.cpp:1504-1577, called at the end of a view's estimation, :102 / :138): 4-connected regions of
+ * similar depth (relative difference < depth_diff_threshold, config 0.01) grown from seeds in column-major order; regions with fewer
+ * than min_segment pixels (config/Room.txt:92: 100) lose depth (0), normal (0) and confidence (-1) — pixels without depth are
+ * regions of size one and are reset as well.  In place on HOST arrays, executed on the host: the growth rule divides by the depth
+ * of the pixel a neighbour is reached from, so the result depends on the sequential seed order (see csrc/pvlm_mvs.hip). */
+pvlm_status pvlm_mvs_remove_small_segments(pvlm_ctx* ctx, int rows, int cols, float depth_diff_threshold, int min_segment, float* depth, float* normal,
+                                           float* conf, int64_t* removed_or_null);
+
 /* Photometric scoring pass of the panoramic PatchMatch MVS: MVS::InitPatchMap + MVS::InitConfMap(use_geometry = false)
  * (mvs/MVS.cpp:586-680) with the photometric term of ScorePixel (:774-923): for every pixel with depth > 0 the
  * bilaterally weighted NCC of its (2 half_window + 1)^2 / step^2 window against each neighbour panorama through the

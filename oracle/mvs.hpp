@@ -666,4 +666,77 @@ inline std::vector<std::vector<MvsNeighbor>> SelectNeighborKNN(int n, const int*
   return neighbors;
 }
 
+// MVS::InitDepthNormal (mvs/MVS.cpp:496-584), the branch the reference compiles (`#elif 1`, :511-514): the LiDAR depth image
+// of ProjectLidar2PanoramaDepth(cloud, rows, cols, T_cl, 2) (uint16, depth * 256) seeds the depth map, every other pixel
+// gets a uniform random depth (rng.fill(UNIFORM, max_depth, min_depth), :546), keep_lidar_constant marks the seeded pixels,
+// the mask zeroes excluded pixels, and every pixel the mask keeps gets GenerateRandomNormal.  lidar16 == nullptr is the
+// `use_lidar == false` branch (:566-569).  Random draws: counter based like the sweep (MvsRng; upstream: one time-seeded
+// cv::RNG) — draw 0 of pixel e is its random depth, the following draws its normal.
+inline void InitDepthNormal(int rows, int cols, const unsigned short* lidar16, const float* mask, float min_depth, float max_depth, bool keep_lidar_constant,
+                            uint64_t seed, float* depth, float* normal, unsigned char* depth_constant) {
+  const Equirectangular eq(rows, cols);
+  const uint64_t ps = MvsPassSeed(seed, -2);
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < cols; ++col) {
+      const size_t e = (size_t)row * cols + col;
+      MvsRng rng{ps, (uint64_t)e};
+      float d = lidar16 ? (float)lidar16[e] : 0.f;                       // convertTo(CV_32F)
+      d /= 256.f;
+      const float depth_random = rng.next01() * (min_depth - max_depth) + max_depth;   // uniform(a = max_depth, b = min_depth)
+      const float lidar_mask = d > 0 ? 0.f : 1.f;                        // cv::threshold(depth, 0, 1, THRESH_BINARY_INV)
+      d = d + depth_random * lidar_mask;                                 // cv::add(depth, random.mul(lidar_mask))
+      if (lidar16 && keep_lidar_constant && depth_constant) depth_constant[e] = (unsigned char)(1.f - lidar_mask);
+      const float m = mask ? mask[e] : 1.f;
+      depth[e] = d * m;                                                  // depth_map.mul(mask)
+      normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0.f;
+      if (m < 1) continue;
+      const float p[2] = {(float)col, (float)row};
+      float ray[3];
+      eq.ImageToCam(p, 1.f, ray);
+      GenerateRandomNormal(rng, ray, normal + 3 * e);
+    }
+}
+
+// MVS::RemoveSmallSegments (mvs/MVS.cpp:1504-1577): region growing over the 4-neighbourhood in COLUMN-major seed order; a
+// neighbour joins the region of the pixel it is reached from when its depth is positive and within depth_diff_threshold
+// (relative to the depth of the pixel it is reached FROM — the relation is not symmetric, so the seed order matters);
+// regions smaller than min_segment lose depth, normal and confidence.  Pixels without depth are regions of size one.
+inline int RemoveSmallSegments(int rows, int cols, float depth_diff_threshold, int min_segment, float* depth, float* normal, float* conf) {
+  std::vector<unsigned char> done((size_t)rows * cols, 0);
+  std::vector<int> seg_list((size_t)rows * cols);
+  int removed = 0;
+  for (int u = 0; u < cols; u++)
+    for (int v = 0; v < rows; v++) {
+      if (done[(size_t)v * cols + u]) continue;
+      seg_list[0] = v * cols + u;
+      unsigned seg_list_count = 1, seg_list_curr = 0;
+      while (seg_list_curr < seg_list_count) {
+        const int cur = seg_list[seg_list_curr];
+        const int cx = cur % cols, cy = cur / cols;
+        const int nx[4] = {cx - 1, cx + 1, cx, cx}, ny[4] = {cy, cy, cy - 1, cy + 1};
+        const float depth_curr = depth[cur];
+        for (int i = 0; i < 4; i++) {
+          if (!(nx[i] >= 0 && ny[i] >= 0 && nx[i] < cols && ny[i] < rows)) continue;       // frame.IsInside
+          const int nb = ny[i] * cols + nx[i];
+          if (!done[nb]) {
+            const float depth_neighbor = depth[nb];
+            if (depth_neighbor > 0 && std::abs((depth_curr - depth_neighbor) / depth_curr) < depth_diff_threshold) {
+              seg_list[seg_list_count++] = nb;
+              done[nb] = 1;
+            }
+          }
+        }
+        ++seg_list_curr;
+        done[cur] = 1;
+      }
+      if (seg_list_count < (unsigned)min_segment)
+        for (unsigned i = 0; i < seg_list_count; i++) {
+          const int e = seg_list[i];
+          depth[e] = 0; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; conf[e] = -1;
+          removed++;
+        }
+    }
+  return removed;
+}
+
 }  // namespace oracle

@@ -345,6 +345,25 @@ def mvs_propagate(ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_win
     return d, nrm, c
 
 
+def mvs_init_depth_normal(rows, cols, lidar_depth16=None, mask=None, min_depth=0.1, max_depth=20.0, keep_lidar_constant=True, seed=1):
+    """MVS::InitDepthNormal (mvs/MVS.cpp:496-584): returns (depth, normal, depth_constant uint8)."""
+    l16 = None if lidar_depth16 is None else np.ascontiguousarray(lidar_depth16, np.uint16)
+    m = None if mask is None else np.ascontiguousarray(mask, np.float32)
+    d = np.zeros((rows, cols), np.float32); n = np.zeros((rows, cols, 3), np.float32); c = np.zeros((rows, cols), np.uint8)
+    lib().orc_mvs_init_depth_normal(C.c_int(rows), C.c_int(cols), _p(l16, C.c_ushort), _p(m, C.c_float), C.c_float(min_depth), C.c_float(max_depth),
+                                    C.c_int(1 if keep_lidar_constant else 0), C.c_ulonglong(seed), _p(d, C.c_float), _p(n, C.c_float), _p(c, C.c_ubyte))
+    return d, n, c
+
+
+def mvs_remove_small_segments(depth, normal, conf, depth_diff_threshold=0.01, min_segment=100):
+    """MVS::RemoveSmallSegments (mvs/MVS.cpp:1504-1577): returns (depth, normal, conf, removed)."""
+    d = np.array(depth, np.float32, copy=True); n = np.array(normal, np.float32, copy=True); c = np.array(conf, np.float32, copy=True)
+    rows, cols = d.shape
+    k = lib().orc_mvs_remove_small_segments(C.c_int(rows), C.c_int(cols), C.c_float(depth_diff_threshold), C.c_int(min_segment), _p(d, C.c_float), _p(n, C.c_float),
+                                            _p(c, C.c_float))
+    return d, n, c, int(k)
+
+
 def mvs_select_neighbors(valid, R_wc, t_wc, neighbor_size, sq_distance_threshold):
     """MVS::SelectNeighborKNN (mvs/MVS.cpp:334-382): (ids n x k with -1 padding, R_nr n x k x 9 float32, t_nr n x k x 3 float32)."""
     v = _i32(np.asarray(valid, np.int32)); n = len(v)

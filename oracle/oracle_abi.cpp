@@ -247,6 +247,13 @@ void orc_mvs_propagate(int rows, int cols, int half_window, int step, const unsi
   EstimateDepthMapCheckerBoard(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth, seed, max_iter,
                                conf_threshold);
 }
+void orc_mvs_init_depth_normal(int rows, int cols, const unsigned short* lidar16, const float* mask, float min_depth, float max_depth, int keep_const,
+                               unsigned long long seed, float* depth, float* normal, unsigned char* depth_constant) {
+  InitDepthNormal(rows, cols, lidar16, mask, min_depth, max_depth, keep_const != 0, seed, depth, normal, depth_constant);
+}
+int orc_mvs_remove_small_segments(int rows, int cols, float thr, int min_segment, float* depth, float* normal, float* conf) {
+  return RemoveSmallSegments(rows, cols, thr, min_segment, depth, normal, conf);
+}
 // MVS::SelectNeighborKNN: out_id (n x neighbor_size, -1 = none), out_R (n x neighbor_size x 9), out_t (n x neighbor_size x 3)
 void orc_mvs_select_neighbors(int n, const int* valid, const double* R_wc, const double* t_wc, int neighbor_size, float sq_distance_threshold, int* out_id,
                               float* out_R, float* out_t) {

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
-    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_line2line_residuals",
+    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments",
 ]
 
 
@@ -288,6 +288,25 @@ class Context:
                                                     C.c_int(len(neis)), ptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float),
                                                     _p(c, C.c_float), dptrs), "pvlm_mvs_init_conf_map")
         return c, d, nrm
+
+    def mvs_init_depth_normal(self, rows, cols, lidar_depth16=None, mask=None, min_depth=0.1, max_depth=20.0, keep_lidar_constant=True, seed=1):
+        """MVS::InitDepthNormal on the GPU: returns (depth, normal, depth_constant uint8)."""
+        l16 = None if lidar_depth16 is None else np.ascontiguousarray(lidar_depth16, np.uint16)
+        m = None if mask is None else np.ascontiguousarray(mask, np.float32)
+        d = np.zeros((rows, cols), np.float32); n = np.zeros((rows, cols, 3), np.float32); c = np.zeros((rows, cols), np.uint8)
+        self._check(self.lib.pvlm_mvs_init_depth_normal(self._h, C.c_int(rows), C.c_int(cols), _p(l16, C.c_uint16), _p(m, C.c_float), C.c_float(min_depth),
+                                                        C.c_float(max_depth), C.c_int(1 if keep_lidar_constant else 0), C.c_ulonglong(seed), _p(d, C.c_float),
+                                                        _p(n, C.c_float), _p(c, C.c_ubyte)), "pvlm_mvs_init_depth_normal")
+        return d, n, c
+
+    def mvs_remove_small_segments(self, depth, normal, conf, depth_diff_threshold=0.01, min_segment=100):
+        """MVS::RemoveSmallSegments (host, sequential by construction): returns (depth, normal, conf, removed)."""
+        d = np.array(depth, np.float32, copy=True); n = np.array(normal, np.float32, copy=True); c = np.array(conf, np.float32, copy=True)
+        rows, cols = d.shape
+        k = C.c_int64()
+        self._check(self.lib.pvlm_mvs_remove_small_segments(self._h, C.c_int(rows), C.c_int(cols), C.c_float(depth_diff_threshold), C.c_int(min_segment),
+                                                            _p(d, C.c_float), _p(n, C.c_float), _p(c, C.c_float), C.byref(k)), "pvlm_mvs_remove_small_segments")
+        return d, n, c, int(k.value)
 
     def mvs_propagate(self, ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_window=3, step=1, nei_depths=None, depth_constant=None, min_depth=0.1,
                       max_depth=20.0, seed=1, max_iter=1, conf_threshold=-1.0):

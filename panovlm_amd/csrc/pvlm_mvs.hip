@@ -220,6 +220,32 @@ __global__ __launch_bounds__(256) void k_mvs_propagate(int rows, int cols, int h
   pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c);
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
+// MVS::InitDepthNormal (mvs/MVS.cpp:496-584, the `#elif 1` branch :511-514): LiDAR depth image (uint16, depth * 256) where it has a
+// value, a uniform random depth elsewhere, optional mask, a random normal facing the camera for every pixel the mask keeps.
+// Draw 0 of pixel e = its random depth, the following draws = GenerateRandomNormal (counter-based stream, as in the sweep).
+__global__ void k_mvs_init_depth_normal(int rows, int cols, const unsigned short* __restrict__ lidar16, const float* __restrict__ mask, float min_depth,
+                                        float max_depth, int keep_const, unsigned long long ps, float* __restrict__ depth, float* __restrict__ normal,
+                                        unsigned char* __restrict__ depth_constant) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)rows * cols) return;
+  pvlm_mvs::Rng rng{ps, (unsigned long long)e, 0u};
+  float d = lidar16 ? (float)lidar16[e] : 0.f;
+  d /= 256.f;
+  const float depth_random = rng.next01() * (min_depth - max_depth) + max_depth;      // rng.fill(UNIFORM, max_depth, min_depth)  :546
+  const float lidar_mask = d > 0 ? 0.f : 1.f;                                          // THRESH_BINARY_INV                         :552
+  d = d + depth_random * lidar_mask;
+  if (lidar16 && keep_const && depth_constant) depth_constant[e] = (unsigned char)(1.f - lidar_mask);
+  const float m = mask ? mask[e] : 1.f;
+  depth[e] = d * m;
+  float nrm[3] = {0.f, 0.f, 0.f};
+  if (!(m < 1)) {
+    float ray[3];
+    pvlm_mvs::unit_ray(rows, cols, (int)(e % cols), (int)(e / cols), ray);
+    pvlm_mvs::generate_random_normal(rng, ray, nrm);
+  }
+  normal[3 * e] = nrm[0]; normal[3 * e + 1] = nrm[1]; normal[3 * e + 2] = nrm[2];
+}
+
 // EstimateDepthMapSingle :698-714: hypotheses under the confidence threshold are dropped
 __global__ void k_mvs_threshold(long long npix, const unsigned char* __restrict__ depth_constant, float thr, float* __restrict__ depth, float* __restrict__ normal,
                                 float* __restrict__ conf) {
@@ -451,6 +477,83 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
   hipStreamSynchronize(ctx->stream);
   pvlm_i_free(ctx, d_img); pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_normal); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_ndepth); pvlm_i_free(ctx, d_const);
   return st;
+}
+
+pvlm_status pvlm_mvs_init_depth_normal(pvlm_ctx* ctx, int rows, int cols, const uint16_t* lidar_depth, const float* mask, float min_depth, float max_depth,
+                                       int keep_lidar_constant, unsigned long long seed, float* depth, float* normal, unsigned char* depth_constant) {
+  if (!ctx || rows <= 0 || cols <= 0 || !depth || !normal) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t npix = (size_t)rows * cols;
+  unsigned short* d_l = nullptr; float *d_m = nullptr, *d_d = nullptr, *d_n = nullptr; unsigned char* d_c = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_d, npix);
+  if (!st) st = pvlm_i_alloc(ctx, &d_n, npix * 3);
+  if (!st && lidar_depth) st = pvlm_i_alloc(ctx, &d_l, npix);
+  if (!st && mask) st = pvlm_i_alloc(ctx, &d_m, npix);
+  const bool want_const = lidar_depth && keep_lidar_constant && depth_constant;
+  if (!st && want_const) st = pvlm_i_alloc(ctx, &d_c, npix);
+  if (!st) {
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipSuccess;
+    if (lidar_depth) e = hipMemcpyAsync(d_l, lidar_depth, npix * sizeof(unsigned short), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && mask) e = hipMemcpyAsync(d_m, mask, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_mvs_init_depth_normal, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_l, d_m, min_depth, max_depth,
+                         keep_lidar_constant, pvlm_mvs::pass_seed(seed, -2), d_d, d_n, d_c);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(depth, d_d, npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(normal, d_n, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && want_const) e = hipMemcpyAsync(depth_constant, d_c, npix, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_init_depth_normal: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  hipStreamSynchronize(ctx->stream);
+  pvlm_i_free(ctx, d_l); pvlm_i_free(ctx, d_m); pvlm_i_free(ctx, d_d); pvlm_i_free(ctx, d_n); pvlm_i_free(ctx, d_c);
+  return st;
+}
+
+// MVS::RemoveSmallSegments (mvs/MVS.cpp:1504-1577).  HOST code on purpose: the region a pixel ends up in depends on the order in
+// which seeds are visited (column-major) because the similarity test divides by the depth of the pixel a neighbour is reached
+// FROM — a data-parallel labelling would merge regions the reference keeps apart.  One pass over the image with an explicit
+// frontier; 1440 x 720 takes a few milliseconds, once per view at the end of its estimation (:102, :138).
+pvlm_status pvlm_mvs_remove_small_segments(pvlm_ctx* ctx, int rows, int cols, float depth_diff_threshold, int min_segment, float* depth, float* normal,
+                                           float* conf, int64_t* removed) {
+  if (!ctx || rows <= 0 || cols <= 0 || !depth || !normal || !conf) return PVLM_ERR_ARG;
+  const size_t npix = (size_t)rows * cols;
+  std::vector<unsigned char> claimed(npix, 0);
+  std::vector<int> frontier(npix);
+  int64_t gone = 0;
+  const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
+  for (int u = 0; u < cols; ++u)
+    for (int v = 0; v < rows; ++v) {
+      const size_t seed = (size_t)v * cols + u;
+      if (claimed[seed]) continue;
+      size_t head = 0, tail = 0;
+      frontier[tail++] = (int)seed;
+      while (head < tail) {
+        const int cur = frontier[head++];
+        const int cx = cur % cols, cy = cur / cols;
+        const float here = depth[cur];
+        for (int k = 0; k < 4; ++k) {
+          const int x = cx + dx[k], y = cy + dy[k];
+          if (x < 0 || y < 0 || x >= cols || y >= rows) continue;
+          const size_t nb = (size_t)y * cols + x;
+          if (claimed[nb]) continue;
+          const float there = depth[nb];
+          if (there > 0 && std::fabs((here - there) / here) < depth_diff_threshold) { frontier[tail++] = (int)nb; claimed[nb] = 1; }
+        }
+        claimed[(size_t)cur] = 1;
+      }
+      if (tail < (size_t)min_segment) {
+        for (size_t i = 0; i < tail; ++i) {
+          const size_t e = (size_t)frontier[i];
+          depth[e] = 0.f; normal[3 * e] = 0.f; normal[3 * e + 1] = 0.f; normal[3 * e + 2] = 0.f; conf[e] = -1.f;
+        }
+        gone += (int64_t)tail;
+      }
+    }
+  if (removed) *removed = gone;
+  return PVLM_OK;
 }
 
 pvlm_status pvlm_mvs_init_conf_map(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,

@@ -187,3 +187,50 @@ def test_resident_views_equal_the_per_call_entry_points(ctx, oracle):
     print("resident %.2f ms, per call %.2f ms" % (t_res * 1e3, t_call * 1e3))
     V.close()
 
+
+
+def test_init_depth_normal_and_remove_small_segments_match_oracle(ctx, oracle):
+    """MVS::InitDepthNormal with the LiDAR depth prior (mvs/MVS.cpp:496-584; BASELINE config 5 "LiDAR-seeded depth priors") and
+    MVS::RemoveSmallSegments (:1504-1577): bit for bit against the oracle, then the pieces in the order the reference's driver
+    chains them (:436-470, :93-140): LiDAR prior -> InitDepthNormal -> InitConfMap -> sweep -> RemoveSmallSegments."""
+    from panovlm_amd import synthetic as sy
+    from tests.test_mvs_cpu import mvs_scene
+    rows, cols = 180, 360
+    cloud = np.concatenate([sy.make_scan(k, cols=512)["local_xyz"] for k in (0, 1)])
+    lidar16 = ctx.project_lidar_depth(rows, cols, cloud, np.eye(4), 2)
+    assert np.array_equal(lidar16, oracle.project_lidar_depth(rows, cols, cloud, np.eye(4), 2)) and 0.05 < (lidar16 > 0).mean() < 0.9
+    rng = np.random.default_rng(4)
+    mask = (rng.uniform(size=(rows, cols)) > 0.03).astype(np.float32)
+    for kw in (dict(lidar_depth16=lidar16, mask=mask, keep_lidar_constant=True, seed=7), dict(lidar_depth16=lidar16, keep_lidar_constant=False, seed=8),
+               dict(mask=mask, seed=9, min_depth=0.5, max_depth=12.0)):
+        dg, ng, cg = ctx.mvs_init_depth_normal(rows, cols, **kw)
+        do, no, co = oracle.mvs_init_depth_normal(rows, cols, **kw)
+        assert np.array_equal(dg, do) and np.array_equal(ng, no) and np.array_equal(cg, co)
+        kept = np.ones((rows, cols), bool) if kw.get("mask") is None else mask >= 1
+        assert np.all(dg[~kept] == 0) and np.all(ng[~kept] == 0)
+        assert np.allclose(np.linalg.norm(ng[kept], axis=1), 1, atol=1e-5) and dg[kept].min() >= kw.get("min_depth", 0.1) - 1e-6
+        if kw.get("lidar_depth16") is not None:
+            seeded = (lidar16 > 0) & kept
+            assert np.array_equal(dg[seeded], (lidar16[seeded].astype(np.float32) / np.float32(256)))
+            assert np.array_equal(cg == 1, lidar16 > 0) if kw["keep_lidar_constant"] else not cg.any()
+    # RemoveSmallSegments on a depth map with islands, holes and a smooth ramp
+    (gray, depth, normal), neis, Rn, tn = mvs_scene(oracle, rows, cols)
+    d = depth.copy()
+    d[rng.uniform(size=d.shape) < 0.08] = 0                        # holes
+    d[40:44, 50:58] *= 1.5; d[100:103, 200:204] *= 0.6             # islands smaller than min_segment at another depth
+    conf = rng.uniform(0, 1, size=d.shape).astype(np.float32)
+    for thr, mseg in ((0.01, 100), (0.05, 20), (0.002, 400)):
+        a = ctx.mvs_remove_small_segments(d, normal, conf, thr, mseg)
+        b = oracle.mvs_remove_small_segments(d, normal, conf, thr, mseg)
+        assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3] > 0
+        assert np.all(a[2][a[0] == 0] == -1) and np.all(a[1][a[0] == 0] == 0)
+    assert np.all(ctx.mvs_remove_small_segments(d, normal, conf, 0.01, 100)[0][40:44, 50:58] == 0)
+    # the driver's chain on the LiDAR-seeded state
+    d0, n0, c0 = ctx.mvs_init_depth_normal(rows, cols, lidar_depth16=lidar16, seed=3, max_depth=8.0)
+    cf, d1, n1 = ctx.mvs_init_conf_map(gray, neis, Rn, tn, d0, n0, 3, 1)
+    got = ctx.mvs_propagate(gray, neis, Rn, tn, d1, n1, cf, depth_constant=c0, max_iter=2, seed=3, max_depth=8.0)
+    want = oracle.mvs_propagate(gray, neis, Rn, tn, *oracle.mvs_init_conf_map(gray, neis, Rn, tn, d0, n0, 3, 1)[1:], oracle.mvs_init_conf_map(gray, neis, Rn, tn, d0, n0, 3, 1)[0],
+                                depth_constant=c0, max_iter=2, seed=3, max_depth=8.0)
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    fin = ctx.mvs_remove_small_segments(got[0], got[1], got[2], 0.01, 100)
+    assert np.array_equal(fin[0], oracle.mvs_remove_small_segments(want[0], want[1], want[2], 0.01, 100)[0])
