@@ -13,7 +13,7 @@ namespace pvlm_mvs {
 
 // exp / sin / cos / acos of a FLOAT (the reference calls the std:: float overloads; their last bit depends on the libm
 // version): the correctly rounded float result, taken as the double function rounded to float — the same definition the
-// oracle uses (oracle/mvs.hpp), so that device, host-compiled check and oracle agree bit for bit.
+// test oracle uses, so that device, host-compiled check and oracle agree bit for bit.
 PVLM_HD inline float f_exp(float x) { return (float)exp((double)x); }
 PVLM_HD inline float f_sin(float x) { return (float)sin((double)x); }
 PVLM_HD inline float f_cos(float x) { return (float)cos((double)x); }

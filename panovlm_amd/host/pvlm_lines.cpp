@@ -7,7 +7,7 @@
 // Host code, like upstream and like the planar branch next door (pvlm_features.cpp): a few hundred edge points per scan,
 // every step a dependency chain; scans are processed in parallel by LidarOdometry::EstimatePose.
 //
-// Own design, same results as the statement-by-statement restatement in oracle/lines.hpp (tests/test_lines_cpu.py compares
+// Own design, same results as the statement-by-statement restatement the test oracle holds (tests/test_lines_cpu.py compares
 // every output array): the 5 nearest neighbours of every edge point are computed once (upstream queries a kd-tree with a
 // point of the cloud every time), segment membership is a sorted vector + a stamp array instead of std::set<int>, groups
 // of segments are found by a plain reachability search.
