@@ -270,6 +270,12 @@ typedef struct {
 } pvlm_scan_desc;
 
 pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* desc, pvlm_scan** out);
+/* The same for `n_scans` scans at once (descs[k] -> out[k]; all or nothing): one staging copy, one device allocation
+ * shared by the batch (released when the last of its scans is destroyed) and one set of grid-build launches — what the
+ * loop over lidars of AddLidarPointToPlaneResidual / AddLidarLineToLineResidual2 (util/Optimization.cpp:521, :345) needs
+ * at every outer iteration of LidarOdometry::EstimatePose, when all 454 re-posed Room scans change at once
+ * (lidar_mapping/LidarOdometry.cpp:150-170).  pvlm_scan_upload is the n_scans = 1 case. */
+pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_desc* descs, pvlm_scan** out);
 pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* scan);
 
 /* Exact k-nearest-neighbour search of `queries` (nq x 3 float, world frame) in the scan's

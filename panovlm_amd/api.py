@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "pvlm_resset_upload", "pvlm_resset_destroy", "pvlm_resset_info", "pvlm_resset_download", "pvlm_eval",
     "pvlm_eval_dev", "pvlm_eval_pair_blocks", "pvlm_eval_pair_blocks_dev", "pvlm_neq_create", "pvlm_neq_destroy",
     "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_comm_unique_id", "pvlm_comm_create",
-    "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_destroy",
+    "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_upload_batch", "pvlm_scan_destroy",
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
@@ -707,9 +707,10 @@ class Scan:
     `scan` is a dict: id, R_wl, t_wl, flat_xyz, flat_tag, less_xyz, less_tag, corner_xyz, p2s,
     seg_size, seg_coeffs, end_points (all optional except the pose)."""
 
-    def __init__(self, ctx, scan):
+    @staticmethod
+    def _describe(scan):
+        """ScanDesc of a scan dict + the arrays it points into (to be kept alive across the call)."""
         g = scan.get
-        self.ctx = ctx
         R = _f64(g("R_wl", np.eye(3))).reshape(9); t = _f64(g("t_wl", np.zeros(3)))
         flat = _f32(g("flat_xyz", np.zeros((0, 3)))); flat_tag = _f32(g("flat_tag", np.ones(len(flat))))
         less = _f32(g("less_xyz", np.zeros((0, 3)))); less_tag = _f32(g("less_tag", np.ones(len(less))))
@@ -737,11 +738,39 @@ class Scan:
         if seg_xyz is not None:
             assert len(seg_xyz) == int(seg_size.sum())
         d.seg_points_xyz = _p(seg_xyz, C.c_float) if seg_xyz is not None and len(seg_xyz) else None
-        self._h = C.c_void_p()
-        ctx._check(ctx.lib.pvlm_scan_upload(ctx._h, C.byref(d), C.byref(self._h)), "pvlm_scan_upload")
+        keep = (R, t, flat, flat_tag, less, less_tag, corner, off, ids, seg_size, seg_coeffs, end_points, seg_xyz)
+        return d, keep
+
+    def _adopt(self, ctx, d, handle):
+        self.ctx = ctx
+        self._h = handle
         self.id = d.id
-        self.n_segments = len(seg_size)
-        self.n_flat, self.n_less, self.n_corner = len(flat), len(less), len(corner)
+        self.n_segments = d.n_segments
+        self.n_flat, self.n_less, self.n_corner = d.n_surf_flat, d.n_surf_less_flat, d.n_corner
+
+    def __init__(self, ctx, scan):
+        d, keep = self._describe(scan)
+        h = C.c_void_p()
+        self._h = None
+        ctx._check(ctx.lib.pvlm_scan_upload(ctx._h, C.byref(d), C.byref(h)), "pvlm_scan_upload")
+        self._adopt(ctx, d, h)
+
+    @classmethod
+    def upload_batch(cls, ctx, scans):
+        """pvlm_scan_upload_batch: every scan of `scans` (dicts) in one staging copy / one device slab / one grid build."""
+        pairs = [cls._describe(s) for s in scans]
+        n = len(pairs)
+        descs = (ScanDesc * max(n, 1))()
+        for k, (d, _) in enumerate(pairs):
+            descs[k] = d
+        handles = (C.c_void_p * max(n, 1))()
+        ctx._check(ctx.lib.pvlm_scan_upload_batch(ctx._h, n, descs, handles), "pvlm_scan_upload_batch")
+        out = []
+        for k, (d, _) in enumerate(pairs):
+            o = cls.__new__(cls)
+            o._adopt(ctx, d, C.c_void_p(handles[k]))
+            out.append(o)
+        return out
 
     def close(self):
         if self._h:

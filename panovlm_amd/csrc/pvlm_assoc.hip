@@ -57,21 +57,6 @@ __device__ __forceinline__ int cell_of(float x, float o, float inv_h) {
 }
 
 // ---- K1 ---------------------------------------------------------------------------------------
-__global__ void k_hash_insert(int n, const float* __restrict__ xyz, float ox, float oy, float oz, float inv_h, int mask,
-                              unsigned long long* __restrict__ keys, int* __restrict__ count, int* __restrict__ slot_of) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long key = cell_key(cell_of(xyz[3 * i], ox, inv_h), cell_of(xyz[3 * i + 1], oy, inv_h), cell_of(xyz[3 * i + 2], oz, inv_h));
-  int s = (int)(mix64(key) & (unsigned long long)mask);
-  while (true) {
-    const unsigned long long prev = atomicCAS(&keys[s], EMPTY_KEY, key);
-    if (prev == EMPTY_KEY || prev == key) break;
-    s = (s + 1) & mask;
-  }
-  atomicAdd(&count[s], 1);
-  slot_of[i] = s;
-}
-
 // exclusive scan of count[T] -> start[T] in three small launches (tile sums, scan of the tile sums by
 // one block, per-tile scan + offset): T reaches 4 M cells for dense grids, a single block walking it
 // serially cost 220 us per cloud.
@@ -125,27 +110,83 @@ __global__ __launch_bounds__(256) void k_scan_tiles(int T, const int* __restrict
   for (int k = 0; k < per; ++k) { const int i = base + t * per + k; if (i < T) start[i] = run; run += loc[k]; }
 }
 
-// Points take their slot inside the cell by atomic cursor: the order inside a cell varies from run
-// to run, the k-NN result does not (top-k is ordered by (distance, original index)).
-__global__ void k_scatter(int n, const float* __restrict__ xyz, const int* __restrict__ slot_of, const int* __restrict__ start,
-                          int* __restrict__ cursor, float4* __restrict__ sorted) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int s = slot_of[i];
-  const int pos = start[s] + atomicAdd(&cursor[s], 1);
-  sorted[pos] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(i));
+// ---- K1, batched: the grids of every cloud of an upload batch in three launches -------------------------------------
+// Hashed table: open addressing on 64-bit cell keys; dense table: linear cell index (iz*ny + iy)*nx + ix.  Points take
+// their slot inside the cell by atomic cursor: the order inside a cell varies from run to run, the k-NN result does not
+// (top-k is ordered by (distance, original index)).
+struct GridDesc {
+  const float* xyz; int n; int dense, nx, ny, nz; int T;
+  float ox, oy, oz, inv_h;
+  unsigned long long* keys; int* count; int* start; int* cursor; int* slot; float4* sorted;
+};
+struct GridBlock { int cloud, first; };   // 256 points of one cloud
+
+__global__ __launch_bounds__(256) void k_grid_count(const GridDesc* __restrict__ desc, const GridBlock* __restrict__ blocks) {
+  const GridBlock b = blocks[blockIdx.x];
+  const GridDesc& d = desc[b.cloud];
+  const int i = b.first + threadIdx.x;
+  if (i >= d.n) return;
+  const float x = d.xyz[3 * i], y = d.xyz[3 * i + 1], z = d.xyz[3 * i + 2];
+  if (d.dense) {
+    const int ix = min(max(cell_of(x, d.ox, d.inv_h), 0), d.nx - 1), iy = min(max(cell_of(y, d.oy, d.inv_h), 0), d.ny - 1),
+              iz = min(max(cell_of(z, d.oz, d.inv_h), 0), d.nz - 1);
+    const int c = (iz * d.ny + iy) * d.nx + ix;
+    d.slot[i] = c;
+    atomicAdd(&d.count[c], 1);
+  } else {
+    const unsigned long long key = cell_key(cell_of(x, d.ox, d.inv_h), cell_of(y, d.oy, d.inv_h), cell_of(z, d.oz, d.inv_h));
+    const int mask = d.T - 1;
+    int s = (int)(mix64(key) & (unsigned long long)mask);
+    while (true) {
+      const unsigned long long prev = atomicCAS(&d.keys[s], EMPTY_KEY, key);
+      if (prev == EMPTY_KEY || prev == key) break;
+      s = (s + 1) & mask;
+    }
+    atomicAdd(&d.count[s], 1);
+    d.slot[i] = s;
+  }
 }
 
-// dense grid variant of K1: linear cell index, counts, scatter (the scan is launch_scan)
-__global__ void k_dense_count(int n, const float* __restrict__ xyz, float ox, float oy, float oz, float inv_h, int nx, int ny, int nz,
-                              int* __restrict__ count, int* __restrict__ cell_of_pt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int ix = min(max(cell_of(xyz[3 * i], ox, inv_h), 0), nx - 1), iy = min(max(cell_of(xyz[3 * i + 1], oy, inv_h), 0), ny - 1),
-            iz = min(max(cell_of(xyz[3 * i + 2], oz, inv_h), 0), nz - 1);
-  const int c = (iz * ny + iy) * nx + ix;
-  cell_of_pt[i] = c;
-  atomicAdd(&count[c], 1);
+// exclusive scan of one cloud's cell counts by one workgroup (tables up to GRID_SCAN_MAX cells; larger ones go through
+// launch_scan): tiles of 4096 cells with a running carry
+#define GRID_SCAN_MAX (1 << 18)
+__global__ __launch_bounds__(1024) void k_grid_scan(const GridDesc* __restrict__ desc, const int* __restrict__ clouds) {
+  __shared__ int part[1024];
+  __shared__ int carry_s;
+  const GridDesc& d = desc[clouds[blockIdx.x]];
+  const int t = threadIdx.x, T = d.T;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < T; base += 4096) {
+    int loc[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = base + 4 * t + k; loc[k] = i < T ? d.count[i] : 0; sum += loc[k]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int x = (t >= off) ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += x;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    int run = carry + part[t] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = base + 4 * t + k; if (i < T) d.start[i] = run; run += loc[k]; }
+    __syncthreads();
+    if (t == 1023) carry_s = carry + part[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_grid_scatter(const GridDesc* __restrict__ desc, const GridBlock* __restrict__ blocks) {
+  const GridBlock b = blocks[blockIdx.x];
+  const GridDesc& d = desc[b.cloud];
+  const int i = b.first + threadIdx.x;
+  if (i >= d.n) return;
+  const int s = d.slot[i];
+  const int pos = d.start[s] + atomicAdd(&d.cursor[s], 1);
+  d.sorted[pos] = make_float4(d.xyz[3 * i], d.xyz[3 * i + 1], d.xyz[3 * i + 2], __int_as_float(i));
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------
@@ -647,12 +688,6 @@ static void launch_scan(pvlm_ctx* ctx, int T, const int* count, int* start, int*
   hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(256), 0, ctx->stream, T, count, tiles, start);
 }
 
-static void cloud_free(pvlm_ctx* ctx, pvlm_cloud& c) {
-  pvlm_i_free(ctx, c.d_xyz); pvlm_i_free(ctx, c.d_tag); pvlm_i_free(ctx, c.d_keys); pvlm_i_free(ctx, c.d_cell_start); pvlm_i_free(ctx, c.d_cell_count);
-  pvlm_i_free(ctx, c.d_sorted);
-  c = pvlm_cloud();
-}
-
 // build-time scratch, released on every exit path
 struct DevScratch {
   pvlm_ctx* ctx;
@@ -669,8 +704,22 @@ struct DevScratch {
 // largest cloud the voxel grid addresses with 32-bit cell tables (hashed table: 2 n slots rounded up to a power of two)
 #define PVLM_MAX_CLOUD_POINTS (256 << 20)
 
-static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float* xyz, const float* tag, bool build_hash) {
-  c.n = n;
+// ---- scan upload: ONE staging copy, ONE slab and ONE set of grid-build launches for a whole batch of scans -----------
+// (round 1 queued 7 pageable copies, 6 memsets and 10 kernels per scan and synchronised after each: 0.48 ms per scan,
+// 0.22 s of a Room-scale EstimatePose that re-uploads its 454 re-posed scans at every outer iteration)
+struct CloudPlan {
+  int n = 0;
+  const float* xyz = nullptr; const float* tag = nullptr;
+  bool grid = false;
+  float h = 0.f, origin[3] = {0, 0, 0};
+  int dense = 0, nx = 0, ny = 0, nz = 0;
+  long long T = 0;
+  // byte offsets: persistent slab (o_*) and build scratch (s_*)
+  size_t o_xyz = 0, o_tag = 0, o_count = 0, o_keys = 0, o_start = 0, o_sorted = 0, s_cursor = 0, s_slot = 0;
+};
+
+static pvlm_status cloud_plan(pvlm_ctx* ctx, CloudPlan& c, int n, const float* xyz, const float* tag, bool grid) {
+  c.n = n; c.xyz = xyz; c.tag = tag; c.grid = grid && n > 0;
   if (n <= 0) return PVLM_OK;
   if (n > PVLM_MAX_CLOUD_POINTS) { PVLM_SET_ERR(ctx, "cloud of %d points exceeds the supported maximum of %d", n, PVLM_MAX_CLOUD_POINTS); return PVLM_ERR_ARG; }
   // bounding box (and the finiteness check: a NaN never updates a min / max, so every coordinate is tested)
@@ -682,14 +731,7 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
       if (v < mn[k]) mn[k] = v;
       if (v > mx[k]) mx[k] = v;
     }
-  pvlm_status st;
-  if ((st = pvlm_i_alloc(ctx, &c.d_xyz, (size_t)n * 3))) return st;
-  PVLM_HIP(ctx, hipMemcpyAsync(c.d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  if (tag) {
-    if ((st = pvlm_i_alloc(ctx, &c.d_tag, (size_t)n))) return st;
-    PVLM_HIP(ctx, hipMemcpyAsync(c.d_tag, tag, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  }
-  if (!build_hash) return PVLM_OK;      // the caller (pvlm_scan_upload) synchronises once, after everything has been queued
+  if (!c.grid) return PVLM_OK;
   // cell edge: surface-like clouds, aim at ~4 points per occupied cell
   float e[3];
   for (int k = 0; k < 3; ++k) { if (!(mx[k] - mn[k] < 1e7f)) { PVLM_SET_ERR(ctx, "cloud extent exceeds 1e7"); return PVLM_ERR_ARG; } e[k] = std::max(mx[k] - mn[k], 0.05f); }
@@ -698,51 +740,25 @@ static pvlm_status cloud_upload(pvlm_ctx* ctx, pvlm_cloud& c, int n, const float
   const char* env = getenv("PVLM_CELL");
   if (env && atof(env) > 0) h = (float)atof(env);
   h = std::min(std::max(h, 0.02f), 4.0f);
-  c.cell = h;
+  c.h = h;
   for (int k = 0; k < 3; ++k) c.origin[k] = mn[k] - h;
   const float inv_h = 1.0f / h;
   long long dims[3];
   for (int k = 0; k < 3; ++k) dims[k] = (long long)std::ceil((mx[k] - c.origin[k]) * inv_h) + 2;
   const long long ncells = dims[0] * dims[1] * dims[2];
   const bool dense = ncells <= std::max<long long>(64ll * n, 4096) && ncells <= (4ll << 20) && !getenv("PVLM_FORCE_HASH");
-  if ((st = pvlm_i_alloc(ctx, &c.d_sorted, (size_t)n))) return st;
-  int *d_slot = nullptr, *d_cursor = nullptr, *d_tiles = nullptr;
-  DevScratch scratch(ctx);   // the members of `c` allocated so far are released by the caller (pvlm_scan_destroy path)
-  long long T = 0;
-  if (dense) T = ncells + 1;
-  else { T = 1024; while (T < 2ll * n) T <<= 1; }
-  const size_t n_tiles = (size_t)((T + SCAN_TILE - 1) / SCAN_TILE);
-  // k_scan_small handles any tile count (n <= 1024 * per), the tile-sum buffer is sized from the actual table
-  if ((st = scratch.alloc(&d_tiles, n_tiles + 1))) return st;
-  hipError_t le = hipSuccess, se = hipSuccess;
-  c.table_size = (int)T;
-  if ((st = pvlm_i_alloc(ctx, &c.d_cell_start, (size_t)T))) return st;
-  if ((st = pvlm_i_alloc(ctx, &c.d_cell_count, (size_t)T))) return st;
-  if ((st = scratch.alloc(&d_slot, (size_t)n))) return st;
-  if ((st = scratch.alloc(&d_cursor, (size_t)T))) return st;
-  hipError_t e1 = hipSuccess;
-  if (dense) {
-    c.dense = 1; c.nx = (int)dims[0]; c.ny = (int)dims[1]; c.nz = (int)dims[2];
-  } else {
-    if ((st = pvlm_i_alloc(ctx, &c.d_keys, (size_t)T))) return st;
-    e1 = hipMemsetAsync(c.d_keys, 0xFF, (size_t)T * sizeof(unsigned long long), ctx->stream);
-  }
-  hipError_t e2 = hipMemsetAsync(c.d_cell_count, 0, (size_t)T * sizeof(int), ctx->stream);
-  hipError_t e3 = hipMemsetAsync(d_cursor, 0, (size_t)T * sizeof(int), ctx->stream);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { PVLM_SET_ERR(ctx, "memset failed"); return PVLM_ERR_HIP; }
-  if (dense)
-    hipLaunchKernelGGL(k_dense_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h, c.nx,
-                       c.ny, c.nz, c.d_cell_count, d_slot);
-  else
-    hipLaunchKernelGGL(k_hash_insert, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, c.origin[0], c.origin[1], c.origin[2], inv_h,
-                       (int)T - 1, c.d_keys, c.d_cell_count, d_slot);
-  launch_scan(ctx, (int)T, c.d_cell_count, c.d_cell_start, d_tiles);
-  hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c.d_xyz, d_slot, c.d_cell_start, d_cursor, c.d_sorted);
-  le = hipGetLastError();
-  // no synchronisation here: the scratch goes back to the pool stream-ordered, the caller waits once for the whole scan
-  if (le != hipSuccess || se != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(le != hipSuccess ? le : se)); return PVLM_ERR_HIP; }
+  if (dense) { c.T = ncells + 1; c.dense = 1; c.nx = (int)dims[0]; c.ny = (int)dims[1]; c.nz = (int)dims[2]; }
+  else { c.T = 1024; while (c.T < 2ll * n) c.T <<= 1; }
   return PVLM_OK;
 }
+
+struct ScanPlan {
+  CloudPlan flat, less, corner;
+  size_t o_p2s_off = 0, o_p2s_ids = 0, o_seg_xyz = 0;
+  size_t n_p2s_ids = 0, n_seg_pts = 0;
+};
+
+static CloudView view_of(const pvlm_cloud& c);
 
 static CloudView view_of(const pvlm_cloud& c) {
   CloudView v;
@@ -784,64 +800,220 @@ static pvlm_status assoc_ws_ensure(pvlm_ctx* ctx, long long rows, int chunks, in
 
 extern "C" {
 
-pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan** out) {
-  if (!ctx || !d || !out || !d->R_wl || !d->t_wl) return PVLM_ERR_ARG;
-  *out = nullptr;
-  if (d->n_surf_flat < 0 || d->n_surf_less_flat < 0 || d->n_corner < 0 || d->n_segments < 0 ||
-      (d->n_surf_flat > 0 && (!d->surf_flat_xyz || !d->surf_flat_tag)) ||
-      (d->n_surf_less_flat > 0 && (!d->surf_less_flat_xyz || !d->surf_less_flat_tag)) || (d->n_corner > 0 && !d->corner_xyz) ||
-      (d->n_segments > 0 && (!d->segment_size || !d->segment_coeffs))) {
-    PVLM_SET_ERR(ctx, "pvlm_scan_upload: inconsistent descriptor");
-    return PVLM_ERR_ARG;
-  }
-  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  pvlm_scan* s = new (std::nothrow) pvlm_scan();
-  if (!s) return PVLM_ERR_NOMEM;
-  s->id = d->id;
-  std::memcpy(s->R_wl, d->R_wl, sizeof(s->R_wl));
-  std::memcpy(s->t_wl, d->t_wl, sizeof(s->t_wl));
-  pvlm_status st = cloud_upload(ctx, s->flat, d->n_surf_flat, d->surf_flat_xyz, d->surf_flat_tag, false);
-  if (!st) st = cloud_upload(ctx, s->less, d->n_surf_less_flat, d->surf_less_flat_xyz, d->surf_less_flat_tag, true);
-  if (!st) st = cloud_upload(ctx, s->corner, d->n_corner, d->corner_xyz, nullptr, true);
-  if (!st && d->n_corner > 0 && d->p2s_offsets) {
-    s->h_p2s_off.assign(d->p2s_offsets, d->p2s_offsets + d->n_corner + 1);
-    const int tot = s->h_p2s_off.back();
-    if (tot > 0) s->h_p2s_ids.assign(d->p2s_ids, d->p2s_ids + tot);
-    for (int v : s->h_p2s_ids) if (v < 0 || v >= d->n_segments) { PVLM_SET_ERR(ctx, "point_to_segment id %d out of range", v); st = PVLM_ERR_ARG; break; }
-    if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
-    if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_ids, s->h_p2s_ids.size());
-    auto queue = [&](void* dst, const void* src, size_t bytes) {
-      if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: copy failed"); return PVLM_ERR_HIP; }
-      return PVLM_OK;
-    };
-    if (!st) st = queue(s->d_p2s_off, s->h_p2s_off.data(), s->h_p2s_off.size() * sizeof(int));
-    if (!st && tot > 0) st = queue(s->d_p2s_ids, s->h_p2s_ids.data(), s->h_p2s_ids.size() * sizeof(int));
-  } else if (!st && d->n_corner > 0) {
-    s->h_p2s_off.assign(d->n_corner + 1, 0);
-    st = pvlm_i_alloc(ctx, &s->d_p2s_off, s->h_p2s_off.size());
-    if (!st) st = pvlm_i_alloc(ctx, &s->d_p2s_ids, 1);
-    if (!st && hipMemsetAsync(s->d_p2s_off, 0, s->h_p2s_off.size() * sizeof(int), ctx->stream) != hipSuccess) st = PVLM_ERR_HIP;
-  }
-  if (!st && d->n_segments > 0) {
-    s->n_segments = d->n_segments;
-    s->h_seg_size.assign(d->segment_size, d->segment_size + d->n_segments);
-    s->h_seg_coeffs.assign(d->segment_coeffs, d->segment_coeffs + 6 * (size_t)d->n_segments);
-    if (d->end_points) s->h_end_points.assign(d->end_points, d->end_points + 6 * (size_t)d->n_segments);
-    if (d->seg_points_xyz) {
-      s->h_seg_pt_off.assign((size_t)d->n_segments + 1, 0);
-      for (int k = 0; k < d->n_segments; ++k) {
-        if (d->segment_size[k] < 0) { PVLM_SET_ERR(ctx, "negative segment size"); st = PVLM_ERR_ARG; break; }
-        s->h_seg_pt_off[(size_t)k + 1] = s->h_seg_pt_off[(size_t)k] + d->segment_size[k];
-      }
-      const size_t tot = (size_t)s->h_seg_pt_off.back();
-      if (!st) st = pvlm_i_alloc(ctx, &s->d_seg_xyz, std::max<size_t>(tot, 1) * 3);
-      if (!st && tot && hipMemcpyAsync(s->d_seg_xyz, d->seg_points_xyz, tot * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = PVLM_ERR_HIP;
+pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan** out) { return pvlm_scan_upload_batch(ctx, 1, d, out); }
+
+pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_desc* descs, pvlm_scan** out) {
+  if (!ctx || n_scans < 0 || (n_scans > 0 && (!descs || !out))) return PVLM_ERR_ARG;
+  for (int k = 0; k < n_scans; ++k) out[k] = nullptr;
+  if (n_scans == 0) return PVLM_OK;
+  for (int k = 0; k < n_scans; ++k) {
+    const pvlm_scan_desc* d = &descs[k];
+    if (!d->R_wl || !d->t_wl || d->n_surf_flat < 0 || d->n_surf_less_flat < 0 || d->n_corner < 0 || d->n_segments < 0 ||
+        (d->n_surf_flat > 0 && (!d->surf_flat_xyz || !d->surf_flat_tag)) ||
+        (d->n_surf_less_flat > 0 && (!d->surf_less_flat_xyz || !d->surf_less_flat_tag)) || (d->n_corner > 0 && !d->corner_xyz) ||
+        (d->n_segments > 0 && (!d->segment_size || !d->segment_coeffs))) {
+      PVLM_SET_ERR(ctx, "pvlm_scan_upload: inconsistent descriptor (scan %d of the batch)", k);
+      return PVLM_ERR_ARG;
     }
   }
-  // ONE synchronisation per scan: every copy above reads caller-owned (pageable) memory that may be reused on return
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess && !st) { PVLM_SET_ERR(ctx, "scan upload: device error"); st = PVLM_ERR_HIP; }
-  if (st) { pvlm_scan_destroy(ctx, s); return st; }
-  *out = s;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_i_trace("scan_upload_batch: enter");
+  // ---- 1. plan: per-cloud grid parameters (host pass over the points: bounding box + finiteness), host-side tables
+  std::vector<ScanPlan> plan((size_t)n_scans);
+  std::vector<pvlm_scan*> scans((size_t)n_scans, nullptr);
+  auto fail = [&](pvlm_status st) { for (pvlm_scan* s : scans) delete s; return st; };
+  pvlm_status st = PVLM_OK;
+  for (int k = 0; k < n_scans && !st; ++k) {
+    const pvlm_scan_desc* d = &descs[k];
+    pvlm_scan* s = new (std::nothrow) pvlm_scan();
+    if (!s) return fail(PVLM_ERR_NOMEM);
+    scans[(size_t)k] = s;
+    s->id = d->id;
+    std::memcpy(s->R_wl, d->R_wl, sizeof(s->R_wl));
+    std::memcpy(s->t_wl, d->t_wl, sizeof(s->t_wl));
+    ScanPlan& P = plan[(size_t)k];
+    st = cloud_plan(ctx, P.flat, d->n_surf_flat, d->surf_flat_xyz, d->surf_flat_tag, false);
+    if (!st) st = cloud_plan(ctx, P.less, d->n_surf_less_flat, d->surf_less_flat_xyz, d->surf_less_flat_tag, true);
+    if (!st) st = cloud_plan(ctx, P.corner, d->n_corner, d->corner_xyz, nullptr, true);
+    if (st) break;
+    if (d->n_corner > 0) {
+      if (d->p2s_offsets) {
+        s->h_p2s_off.assign(d->p2s_offsets, d->p2s_offsets + d->n_corner + 1);
+        const int tot = s->h_p2s_off.back();
+        if (tot > 0) s->h_p2s_ids.assign(d->p2s_ids, d->p2s_ids + tot);
+        for (int v : s->h_p2s_ids) if (v < 0 || v >= d->n_segments) { PVLM_SET_ERR(ctx, "point_to_segment id %d out of range", v); st = PVLM_ERR_ARG; break; }
+      } else {
+        s->h_p2s_off.assign((size_t)d->n_corner + 1, 0);
+      }
+      P.n_p2s_ids = s->h_p2s_ids.size();
+    }
+    if (!st && d->n_segments > 0) {
+      s->n_segments = d->n_segments;
+      s->h_seg_size.assign(d->segment_size, d->segment_size + d->n_segments);
+      s->h_seg_coeffs.assign(d->segment_coeffs, d->segment_coeffs + 6 * (size_t)d->n_segments);
+      if (d->end_points) s->h_end_points.assign(d->end_points, d->end_points + 6 * (size_t)d->n_segments);
+      if (d->seg_points_xyz) {
+        s->h_seg_pt_off.assign((size_t)d->n_segments + 1, 0);
+        for (int q = 0; q < d->n_segments; ++q) {
+          if (d->segment_size[q] < 0) { PVLM_SET_ERR(ctx, "negative segment size"); st = PVLM_ERR_ARG; break; }
+          s->h_seg_pt_off[(size_t)q + 1] = s->h_seg_pt_off[(size_t)q] + d->segment_size[q];
+        }
+        P.n_seg_pts = (size_t)s->h_seg_pt_off.back();
+      }
+    }
+  }
+  if (st) return fail(st);
+  pvlm_i_trace("scan_upload_batch: plan (bbox, host tables)");
+  // ---- 2. layout.  Persistent slab: [uploaded arrays | build tables (descriptors, blocks) | cell counts (zeroed) |
+  //         hash keys (0xFF) | cell starts | sorted points];  scratch: [cursors (zeroed) | cell / slot of every point]
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t up = 0;
+  auto place = [&](size_t& off, size_t& cursor, size_t bytes) { off = cursor; cursor = align(cursor + bytes); };
+  int n_grids = 0; size_t n_blocks = 0;
+  auto each_cloud = [&](auto&& f) { for (ScanPlan& P : plan) { f(P.flat); f(P.less); f(P.corner); } };
+  each_cloud([&](CloudPlan& c) {
+    if (c.n <= 0) return;
+    place(c.o_xyz, up, (size_t)c.n * 12);
+    if (c.tag) place(c.o_tag, up, (size_t)c.n * 4);
+    if (c.grid) { ++n_grids; n_blocks += ((size_t)c.n + 255) / 256; }
+  });
+  for (int k = 0; k < n_scans; ++k) {
+    ScanPlan& P = plan[(size_t)k];
+    if (!scans[(size_t)k]->h_p2s_off.empty()) { place(P.o_p2s_off, up, scans[(size_t)k]->h_p2s_off.size() * 4); place(P.o_p2s_ids, up, std::max<size_t>(P.n_p2s_ids, 1) * 4); }
+    if (!scans[(size_t)k]->h_seg_pt_off.empty()) place(P.o_seg_xyz, up, std::max<size_t>(P.n_seg_pts, 1) * 12);
+  }
+  size_t o_desc = 0, o_blocks = 0, o_small = 0;
+  place(o_desc, up, std::max<size_t>((size_t)n_grids, 1) * sizeof(GridDesc));
+  place(o_blocks, up, std::max<size_t>(n_blocks, 1) * sizeof(GridBlock));
+  place(o_small, up, std::max<size_t>((size_t)n_grids, 1) * sizeof(int));
+  const size_t up_bytes = up;
+  size_t slab = up_bytes, scratch = 0;
+  const size_t o_count0 = slab;
+  each_cloud([&](CloudPlan& c) { if (c.grid) place(c.o_count, slab, (size_t)c.T * 4); });
+  const size_t count_bytes = slab - o_count0, o_keys0 = slab;
+  each_cloud([&](CloudPlan& c) { if (c.grid && !c.dense) place(c.o_keys, slab, (size_t)c.T * 8); });
+  const size_t keys_bytes = slab - o_keys0;
+  each_cloud([&](CloudPlan& c) { if (c.grid) { place(c.o_start, slab, (size_t)c.T * 4); place(c.o_sorted, slab, (size_t)c.n * 16); } });
+  each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_cursor, scratch, (size_t)c.T * 4); });
+  const size_t cursor_bytes = scratch;
+  each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_slot, scratch, (size_t)c.n * 4); });
+  // ---- 3. allocate: slab + scratch from the pool, the staging mirror of the uploaded front (pinned, grow-only)
+  char* d_slab = nullptr; char* d_scr = nullptr;
+  if ((st = pvlm_i_alloc_bytes(ctx, (void**)&d_slab, std::max<size_t>(slab, 256)))) return fail(st);
+  if ((st = pvlm_i_alloc_bytes(ctx, (void**)&d_scr, std::max<size_t>(scratch, 256)))) { pvlm_i_free(ctx, d_slab); return fail(st); }
+  auto bail = [&](pvlm_status e) { hipStreamSynchronize(ctx->stream); pvlm_i_free(ctx, d_slab); pvlm_i_free(ctx, d_scr); return fail(e); };
+  // staging window: the whole front when it fits, else PVLM_UPLOAD_STAGE_MB (default 64) at a time
+  size_t window = (size_t)64 << 20;
+  if (const char* env = getenv("PVLM_UPLOAD_STAGE_MB")) if (atof(env) > 0) window = (size_t)(atof(env) * 1048576.0);
+  window = align(std::max<size_t>(window, 4096));
+  const size_t need = std::min(up_bytes, window);
+  if (ctx->up_bytes < need) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(PVLM_ERR_HIP);
+    if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+    ctx->h_up = nullptr; ctx->up_bytes = 0;
+    const size_t want = std::min(need + need / 2, window);
+    if (hipHostMalloc(&ctx->h_up, want, hipHostMallocDefault) != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: %zu bytes of pinned staging unavailable", want); return bail(PVLM_ERR_NOMEM); }
+    ctx->up_bytes = want;
+  }
+  char* h = (char*)ctx->h_up;
+  pvlm_i_trace("scan_upload_batch: layout + allocations");
+  // ---- 4. the uploaded front as a list of (offset, source) segments, in ascending offset order
+  struct Seg { size_t off; const void* src; size_t bytes; };
+  std::vector<Seg> segs;
+  each_cloud([&](CloudPlan& c) {
+    if (c.n <= 0) return;
+    segs.push_back({c.o_xyz, c.xyz, (size_t)c.n * 12});
+    if (c.tag) segs.push_back({c.o_tag, c.tag, (size_t)c.n * 4});
+  });
+  for (int k = 0; k < n_scans; ++k) {
+    ScanPlan& P = plan[(size_t)k]; pvlm_scan* s = scans[(size_t)k];
+    if (!s->h_p2s_off.empty()) {
+      segs.push_back({P.o_p2s_off, s->h_p2s_off.data(), s->h_p2s_off.size() * 4});
+      if (P.n_p2s_ids) segs.push_back({P.o_p2s_ids, s->h_p2s_ids.data(), P.n_p2s_ids * 4});
+    }
+    if (!s->h_seg_pt_off.empty() && P.n_seg_pts) segs.push_back({P.o_seg_xyz, descs[k].seg_points_xyz, P.n_seg_pts * 12});
+  }
+  std::vector<GridDesc> hd((size_t)n_grids); std::vector<GridBlock> hb; std::vector<int> hs;
+  hb.reserve(n_blocks);
+  int g = 0;
+  std::vector<std::pair<int, const CloudPlan*>> big;       // tables too long for one workgroup: scanned by launch_scan
+  each_cloud([&](CloudPlan& c) {
+    if (!c.grid) return;
+    GridDesc& D = hd[(size_t)g];
+    D.xyz = (const float*)(d_slab + c.o_xyz); D.n = c.n; D.dense = c.dense; D.nx = c.nx; D.ny = c.ny; D.nz = c.nz; D.T = (int)c.T;
+    D.ox = c.origin[0]; D.oy = c.origin[1]; D.oz = c.origin[2]; D.inv_h = 1.0f / c.h;
+    D.keys = c.dense ? nullptr : (unsigned long long*)(d_slab + c.o_keys);
+    D.count = (int*)(d_slab + c.o_count); D.start = (int*)(d_slab + c.o_start); D.sorted = (float4*)(d_slab + c.o_sorted);
+    D.cursor = (int*)(d_scr + c.s_cursor); D.slot = (int*)(d_scr + c.s_slot);
+    for (int f = 0; f < c.n; f += 256) hb.push_back(GridBlock{g, f});
+    if (c.T <= GRID_SCAN_MAX) hs.push_back(g); else big.push_back({g, &c});
+    ++g;
+  });
+  const size_t nb = hb.size(); const int n_small = (int)hs.size();
+  if (n_grids) segs.push_back({o_desc, hd.data(), hd.size() * sizeof(GridDesc)});
+  if (nb) segs.push_back({o_blocks, hb.data(), nb * sizeof(GridBlock)});
+  if (n_small) segs.push_back({o_small, hs.data(), hs.size() * sizeof(int)});
+  // ---- 5. one copy, three memsets, three launches (+ the long tables), one synchronisation
+  hipError_t e = hipSuccess;
+  size_t first_seg = 0;
+  pvlm_i_trace("scan_upload_batch: segment + descriptor lists");
+  for (size_t lo = 0; lo < up_bytes && e == hipSuccess; lo += ctx->up_bytes) {
+    const size_t hi = std::min(up_bytes, lo + ctx->up_bytes);
+    if (lo > 0) e = hipStreamSynchronize(ctx->stream);            // the window is refilled: the previous copy must have left it
+    while (first_seg < segs.size() && segs[first_seg].off + segs[first_seg].bytes <= lo) ++first_seg;
+    for (size_t q = first_seg; q < segs.size() && segs[q].off < hi; ++q) {
+      const size_t a = std::max(segs[q].off, lo), b = std::min(segs[q].off + segs[q].bytes, hi);
+      if (b > a) std::memcpy(h + (a - lo), (const char*)segs[q].src + (a - segs[q].off), b - a);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_slab + lo, h, hi - lo, hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e == hipSuccess && count_bytes) e = hipMemsetAsync(d_slab + o_count0, 0, count_bytes, ctx->stream);
+  if (e == hipSuccess && keys_bytes) e = hipMemsetAsync(d_slab + o_keys0, 0xFF, keys_bytes, ctx->stream);
+  if (e == hipSuccess && cursor_bytes) e = hipMemsetAsync(d_scr, 0, cursor_bytes, ctx->stream);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: copy / memset failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
+  DevScratch tiles_scratch(ctx);
+  if (nb) {
+    const GridDesc* dd = (const GridDesc*)(d_slab + o_desc); const GridBlock* db = (const GridBlock*)(d_slab + o_blocks);
+    hipLaunchKernelGGL(k_grid_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dd, db);
+    if (n_small) hipLaunchKernelGGL(k_grid_scan, dim3((unsigned)n_small), dim3(1024), 0, ctx->stream, dd, (const int*)(d_slab + o_small));
+    for (const auto& bg : big) {
+      const CloudPlan& c = *bg.second;
+      int* d_tiles = nullptr;
+      if ((st = tiles_scratch.alloc(&d_tiles, (size_t)((c.T + SCAN_TILE - 1) / SCAN_TILE) + 1))) return bail(st);
+      launch_scan(ctx, (int)c.T, (const int*)(d_slab + c.o_count), (int*)(d_slab + c.o_start), d_tiles);
+    }
+    hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dd, db);
+    e = hipGetLastError();
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
+  }
+  pvlm_i_trace("scan_upload_batch: staged, copies + kernels queued");
+  // the staging buffer is reused by the next call and the scratch goes back to the pool: wait once for the whole batch
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: device error"); return bail(PVLM_ERR_HIP); }
+  pvlm_i_free(ctx, d_scr);
+  pvlm_i_trace("scan_upload_batch: synchronised");
+  // ---- 6. hand out the scans: views into the shared slab, released with the last of them
+  pvlm_scan_slab* sl = new (std::nothrow) pvlm_scan_slab();
+  if (!sl) { pvlm_i_free(ctx, d_slab); return fail(PVLM_ERR_NOMEM); }
+  sl->base = d_slab; sl->refs = n_scans;
+  auto bind = [&](pvlm_cloud& c, const CloudPlan& p) {
+    c.n = std::max(p.n, 0);
+    if (p.n <= 0) return;
+    c.d_xyz = (float*)(d_slab + p.o_xyz);
+    if (p.tag) c.d_tag = (float*)(d_slab + p.o_tag);
+    if (!p.grid) return;
+    c.cell = p.h; for (int q = 0; q < 3; ++q) c.origin[q] = p.origin[q];
+    c.table_size = (int)p.T; c.dense = p.dense; c.nx = p.nx; c.ny = p.ny; c.nz = p.nz;
+    c.d_keys = p.dense ? nullptr : (unsigned long long*)(d_slab + p.o_keys);
+    c.d_cell_start = (int*)(d_slab + p.o_start); c.d_cell_count = (int*)(d_slab + p.o_count); c.d_sorted = (float4*)(d_slab + p.o_sorted);
+  };
+  for (int k = 0; k < n_scans; ++k) {
+    pvlm_scan* s = scans[(size_t)k]; const ScanPlan& P = plan[(size_t)k];
+    s->slab = sl;
+    bind(s->flat, P.flat); bind(s->less, P.less); bind(s->corner, P.corner);
+    if (!s->h_p2s_off.empty()) { s->d_p2s_off = (int*)(d_slab + P.o_p2s_off); s->d_p2s_ids = (int*)(d_slab + P.o_p2s_ids); }
+    if (!s->h_seg_pt_off.empty()) s->d_seg_xyz = (float*)(d_slab + P.o_seg_xyz);
+    out[k] = s;
+  }
   return PVLM_OK;
 }
 
@@ -849,8 +1021,7 @@ pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* s) {
   if (!ctx) return PVLM_ERR_ARG;
   if (!s) return PVLM_OK;
   hipSetDevice(ctx->device);
-  cloud_free(ctx, s->flat); cloud_free(ctx, s->less); cloud_free(ctx, s->corner);
-  pvlm_i_free(ctx, s->d_p2s_off); pvlm_i_free(ctx, s->d_p2s_ids); pvlm_i_free(ctx, s->d_seg_xyz);
+  if (s->slab && --s->slab->refs == 0) { pvlm_i_free(ctx, s->slab->base); delete s->slab; }   // every array of the scan lives in the batch's slab
   delete s;
   return PVLM_OK;
 }
@@ -867,20 +1038,19 @@ pvlm_status pvlm_knn(pvlm_ctx* ctx, const pvlm_scan* scan, int which, const floa
   if (!st) st = pvlm_i_alloc(ctx, &d_idx, (size_t)nq * k);
   if (!st) st = pvlm_i_alloc(ctx, &d_sqd, (size_t)nq * k);
   hipError_t e = hipSuccess;
+  if (!st) st = pvlm_i_h2d_q(ctx, d_q, queries, (size_t)nq * 3 * sizeof(float));
   if (!st) {
-    e = hipMemcpyAsync(d_q, queries, (size_t)nq * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
+    {
       const CloudView cv = view_of(c);
       if (k == 10) hipLaunchKernelGGL(k_knn_queries<10>, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, cv, d_q, nq, max_dist, d_idx, d_sqd);
       else hipLaunchKernelGGL(k_knn_queries<5>, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, cv, d_q, nq, max_dist, d_idx, d_sqd);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(idx, d_idx, (size_t)nq * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(sqd, d_sqd, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_knn: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (!st) st = pvlm_i_d2h_q(ctx, idx, d_idx, (size_t)nq * k * sizeof(int));
+    if (!st) st = pvlm_i_d2h_q(ctx, sqd, d_sqd, (size_t)nq * k * sizeof(float));
   }
-  hipStreamSynchronize(ctx->stream);
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
   pvlm_i_free(ctx, d_q); pvlm_i_free(ctx, d_idx); pvlm_i_free(ctx, d_sqd);
   return st;
 }

@@ -6,6 +6,7 @@
 #include <new>
 
 #include "pvlm_internal.h"
+#include <chrono>
 
 pvlm_status pvlm_i_bind(pvlm_ctx* ctx) {
   PVLM_HIP(ctx, hipSetDevice(ctx->device));
@@ -111,17 +112,73 @@ void pvlm_i_free(pvlm_ctx* ctx, const void* p) {
   pool_insert_free(P, (char*)const_cast<void*>(p), r.size, r.slab);
 }
 
+static const size_t kStageBytes = (size_t)32 << 20;
+
+pvlm_status pvlm_i_sync(pvlm_ctx* ctx) {
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  pvlm_stage& a = ctx->stage;
+  if (e == hipSuccess) for (const pvlm_stage::Deferred& d : a.deferred) std::memcpy(d.dst, d.src, d.bytes);
+  a.deferred.clear();
+  a.cursor = 0;
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "stream synchronisation failed: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  return PVLM_OK;
+}
+
+static char* stage_take(pvlm_ctx* ctx, size_t bytes) {
+  pvlm_stage& a = ctx->stage;
+  if (!a.base) {
+    if (hipHostMalloc((void**)&a.base, kStageBytes, hipHostMallocDefault) != hipSuccess) { a.base = nullptr; return nullptr; }
+    a.size = kStageBytes;
+  }
+  bytes = (bytes + 63) & ~(size_t)63;
+  if (bytes > a.size) return nullptr;
+  if (a.cursor + bytes > a.size && pvlm_i_sync(ctx) != PVLM_OK) return nullptr;
+  char* p = a.base + a.cursor;
+  a.cursor += bytes;
+  return p;
+}
+
+pvlm_status pvlm_i_h2d_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  for (size_t done = 0; done < bytes;) {
+    const size_t n = std::min(bytes - done, kStageBytes / 2);
+    char* p = stage_take(ctx, n);
+    if (!p) {   // no pinned memory to be had: the runtime's own pageable path, synchronous
+      PVLM_HIP(ctx, hipMemcpyAsync((char*)dst + done, (const char*)src + done, bytes - done, hipMemcpyHostToDevice, ctx->stream));
+      PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return PVLM_OK;
+    }
+    std::memcpy(p, (const char*)src + done, n);
+    PVLM_HIP(ctx, hipMemcpyAsync((char*)dst + done, p, n, hipMemcpyHostToDevice, ctx->stream));
+    done += n;
+  }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_i_d2h_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  for (size_t done = 0; done < bytes;) {
+    const size_t n = std::min(bytes - done, kStageBytes / 2);
+    char* p = stage_take(ctx, n);
+    if (!p) {
+      PVLM_HIP(ctx, hipMemcpyAsync((char*)dst + done, (const char*)src + done, bytes - done, hipMemcpyDeviceToHost, ctx->stream));
+      PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return PVLM_OK;
+    }
+    PVLM_HIP(ctx, hipMemcpyAsync(p, (const char*)src + done, n, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->stage.deferred.push_back({(char*)dst + done, p, n});
+    done += n;
+  }
+  return PVLM_OK;
+}
+
 pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return PVLM_OK;
-  PVLM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PVLM_OK;
+  const pvlm_status st = pvlm_i_h2d_q(ctx, dst, src, bytes);
+  return st ? st : pvlm_i_sync(ctx);
 }
 pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return PVLM_OK;
-  PVLM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PVLM_OK;
+  const pvlm_status st = pvlm_i_d2h_q(ctx, dst, src, bytes);
+  return st ? st : pvlm_i_sync(ctx);
 }
 
 void pvlm_i_assoc_ws_free(pvlm_ctx* ctx) {
@@ -165,6 +222,18 @@ int pvlm_i_ncols(int kind) {
 }
 int pvlm_i_stride(int kind) { return pvlm_i_ncols(kind); }
 
+void pvlm_i_trace(const char* label) {
+  static const char* path = getenv("PVLM_TRACE");
+  if (!path) return;
+  static FILE* f = fopen(path, "a");
+  static auto last = std::chrono::steady_clock::now();
+  if (!f) return;
+  const auto now = std::chrono::steady_clock::now();
+  fprintf(f, "%-48s +%.3f ms\n", label, std::chrono::duration<double, std::milli>(now - last).count());
+  fflush(f);
+  last = now;
+}
+
 extern "C" {
 
 const char* pvlm_version(void) { return PVLM_VERSION_STR; }
@@ -195,6 +264,8 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   pvlm_i_assoc_ws_free(ctx);
+  if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+  if (ctx->stage.base) (void)hipHostFree(ctx->stage.base);
   pvlm_i_free(ctx, ctx->d_aa); pvlm_i_free(ctx, ctx->d_t); pvlm_i_free(ctx, ctx->d_pose_tab); pvlm_i_free(ctx, ctx->d_ws); pvlm_i_free(ctx, ctx->d_neq_tmp);
   pvlm_i_pool_release(ctx, true);   // objects the caller leaked (scans, residual sets) die with their slabs
   hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
@@ -433,9 +504,7 @@ pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs) {
   if ((st = pvlm_i_alloc(ctx, &rs->d_partials, (size_t)std::max(rs->n_blocks, 1) * PVLM_PARTIAL))) return st;
   if ((st = pvlm_i_alloc(ctx, &rs->d_pair_blocks, (size_t)std::max(P, 1) * PVLM_PAIR_BLOCK))) return st;
   auto cp = [&](void* d, const void* h, size_t bytes) -> pvlm_status {
-    if (bytes == 0) return PVLM_OK;
-    PVLM_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return PVLM_OK;
+    return bytes ? pvlm_i_h2d_q(ctx, d, h, bytes) : PVLM_OK;
   };
   if ((st = cp(rs->d_pair_cols, pair_cols.data(), (size_t)P * sizeof(double*)))) return st;
   if ((st = cp(rs->d_pair_stride, pair_stride.data(), (size_t)P * sizeof(int64_t)))) return st;
@@ -445,7 +514,7 @@ pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs) {
   if ((st = cp(rs->d_blk_pair, blk_pair.data(), blk_pair.size() * sizeof(int)))) return st;
   if ((st = cp(rs->d_blk_chunk, blk_chunk.data(), blk_chunk.size() * sizeof(int)))) return st;
   if ((st = cp(rs->d_pair_blk_start, pair_blk_start.data(), pair_blk_start.size() * sizeof(int)))) return st;
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  if ((st = pvlm_i_sync(ctx))) return st;            // one wait for everything the caller and this function queued
   rs->pair_tab_epoch = ~0ull;
   return PVLM_OK;
 }

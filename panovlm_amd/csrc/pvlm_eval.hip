@@ -537,9 +537,9 @@ pvlm_status pvlm_set_poses(pvlm_ctx* ctx, int n, const double* aa, const double*
   pvlm_status st = ensure_pose_cap(ctx, n);
   if (st) return st;
   if (n > 0) {
-    PVLM_HIP(ctx, hipMemcpyAsync(ctx->d_aa, aa, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    PVLM_HIP(ctx, hipMemcpyAsync(ctx->d_t, t, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable host memory: caller may reuse the buffers
+    // through the pinned arena: the caller may reuse aa / t at once, and nothing waits for the device here
+    if ((st = pvlm_i_h2d_q(ctx, ctx->d_aa, aa, (size_t)n * 3 * sizeof(double)))) return st;
+    if ((st = pvlm_i_h2d_q(ctx, ctx->d_t, t, (size_t)n * 3 * sizeof(double)))) return st;
   }
   return pose_table_launch(ctx, n, ctx->d_aa, ctx->d_t);
 }
@@ -687,8 +687,7 @@ pvlm_status pvlm_eval_pair_blocks(pvlm_ctx* ctx, const pvlm_resset* rs, pvlm_los
   pvlm_status st = pvlm_eval_pair_blocks_dev(ctx, rs, loss, a, rs->d_pair_blocks);
   if (st) return st;
   if (rs->n_pairs > 0) {
-    PVLM_HIP(ctx, hipMemcpyAsync(out, rs->d_pair_blocks, (size_t)rs->n_pairs * PVLM_PAIR_BLOCK * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((st = pvlm_i_d2h(ctx, out, rs->d_pair_blocks, (size_t)rs->n_pairs * PVLM_PAIR_BLOCK * sizeof(double)))) return st;
   }
   return PVLM_OK;
 }
@@ -727,11 +726,10 @@ static pvlm_status neq_bind(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs) {
   if ((st = pvlm_i_alloc(ctx, &q->d_diag_items, ditems.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &q->d_off_off, ooff.size()))) return st;
   if ((st = pvlm_i_alloc(ctx, &q->d_off_items, oitems.size()))) return st;
-  PVLM_HIP(ctx, hipMemcpyAsync(q->d_diag_off, doff.data(), doff.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  if (!ditems.empty()) PVLM_HIP(ctx, hipMemcpyAsync(q->d_diag_items, ditems.data(), ditems.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  PVLM_HIP(ctx, hipMemcpyAsync(q->d_off_off, ooff.data(), ooff.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  if (!oitems.empty()) PVLM_HIP(ctx, hipMemcpyAsync(q->d_off_items, oitems.data(), oitems.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // pageable staging vectors go out of scope
+  if ((st = pvlm_i_h2d_q(ctx, q->d_diag_off, doff.data(), doff.size() * sizeof(int)))) return st;
+  if (!ditems.empty() && (st = pvlm_i_h2d_q(ctx, q->d_diag_items, ditems.data(), ditems.size() * sizeof(int)))) return st;
+  if ((st = pvlm_i_h2d_q(ctx, q->d_off_off, ooff.data(), ooff.size() * sizeof(int)))) return st;
+  if (!oitems.empty() && (st = pvlm_i_h2d_q(ctx, q->d_off_items, oitems.data(), oitems.size() * sizeof(int)))) return st;
   q->bound = rs;
   q->bound_serial = rs->serial;
   return PVLM_OK;
@@ -764,12 +762,11 @@ pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* r
     ctx->neq_tmp_count = cnt;
   }
   double* d = ctx->d_neq_tmp;
-  if (!zero_first) PVLM_HIP(ctx, hipMemcpyAsync(d, packed, nb, hipMemcpyHostToDevice, ctx->stream));
-  pvlm_status st = pvlm_neq_accumulate_dev(ctx, q, rs, loss, a, zero_first, d);
+  pvlm_status st = PVLM_OK;
+  if (!zero_first && (st = pvlm_i_h2d_q(ctx, d, packed, nb))) return st;
+  st = pvlm_neq_accumulate_dev(ctx, q, rs, loss, a, zero_first, d);
   if (st) return st;
-  PVLM_HIP(ctx, hipMemcpyAsync(packed, d, nb, hipMemcpyDeviceToHost, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PVLM_OK;
+  return pvlm_i_d2h(ctx, packed, d, nb);
 }
 
 }  // extern "C"

@@ -52,6 +52,18 @@ struct pvlm_assoc_ws {
   hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
+// Pinned staging arena.  A copy between a caller's pageable buffer and the device makes the runtime lock and unlock the
+// caller's pages (measured: 10-20 ms for 3 MB); through the arena it is a host memcpy + a truly asynchronous DMA.
+// H2D: the bytes are copied into the arena when the copy is queued (the source may be reused at once).  D2H: the copy lands
+// in the arena and reaches the caller's buffer at the next pvlm_i_sync.  The arena rewinds at pvlm_i_sync; when it is full
+// it synchronises itself.
+struct pvlm_stage {
+  char* base = nullptr;
+  size_t size = 0, cursor = 0;
+  struct Deferred { void* dst; const void* src; size_t bytes; };
+  std::vector<Deferred> deferred;
+};
+
 struct pvlm_ctx {
   int device = 0;
   pvlm_pool pool;
@@ -60,6 +72,10 @@ struct pvlm_ctx {
   bool capturing = false;      // between pvlm_graph_begin and pvlm_graph_end: no allocation, no synchronisation
   // persistent packed buffer of pvlm_neq_accumulate (host-pointer form)
   double* d_neq_tmp = nullptr; size_t neq_tmp_count = 0;
+  // pinned staging of pvlm_scan_upload[_batch] (grow-only)
+  void* h_up = nullptr; size_t up_bytes = 0;
+  // pinned staging arena of every other host <-> device copy (pvlm_i_h2d_q / pvlm_i_d2h_q / pvlm_i_sync)
+  pvlm_stage stage;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -149,7 +165,7 @@ struct pvlm_neq {
 
 struct pvlm_cloud {
   int n = 0;
-  float* d_xyz = nullptr;   // SoA: x[n] y[n] z[n]  (original order)
+  float* d_xyz = nullptr;   // interleaved x y z, original order
   float* d_tag = nullptr;
   // voxel hash (built at upload): points sorted by cell
   float cell = 0.f;
@@ -163,8 +179,11 @@ struct pvlm_cloud {
   int* d_sorted_cell = nullptr;  // unused placeholder
 };
 
+struct pvlm_scan_slab { void* base = nullptr; int refs = 0; };   // one device allocation shared by the scans of an upload batch
+
 struct pvlm_scan {
   int id = 0;
+  pvlm_scan_slab* slab = nullptr;
   double R_wl[9];
   double t_wl[3];
   pvlm_cloud flat, less, corner;
@@ -193,6 +212,9 @@ struct pvlm_scan {
     }                                                                                              \
   } while (0)
 
+// PVLM_TRACE=<file>: appends "label +ms since the previous mark" lines — host-side wall clock between marks inside the
+// multi-step entry points (where does a call's time go when its kernels take microseconds?)
+void pvlm_i_trace(const char* label);
 // helpers implemented in pvlm_ctx.hip
 pvlm_status pvlm_i_bind(pvlm_ctx* ctx);  // hipSetDevice(ctx->device)
 pvlm_status pvlm_i_alloc_bytes(pvlm_ctx* ctx, void** p, size_t bytes);   // from the context's pool
@@ -204,6 +226,10 @@ inline pvlm_status pvlm_i_alloc(pvlm_ctx* ctx, T** p, size_t count) {
   if (count == 0) count = 1;
   return pvlm_i_alloc_bytes(ctx, (void**)p, count * sizeof(T));
 }
+// queued copies through the staging arena + the synchronisation that completes them (see pvlm_stage)
+pvlm_status pvlm_i_h2d_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
+pvlm_status pvlm_i_d2h_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
+pvlm_status pvlm_i_sync(pvlm_ctx* ctx);
 // host -> device through the context stream (pageable source: returns when the source may be reused)
 pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);

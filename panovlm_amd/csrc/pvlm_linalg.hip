@@ -306,31 +306,35 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   if (!st) {
     hipStream_t s = ctx->stream;
     hipError_t e = hipMemsetAsync(d_M, 0, (size_t)n * n * sizeof(double), s);
-    if (e == hipSuccess && n_blocks) e = hipMemcpyAsync(d_blocks, blocks, (size_t)n_blocks * 36 * sizeof(double), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && n_blocks) e = hipMemcpyAsync(d_row, row_idx, (size_t)n_blocks * 6 * sizeof(int), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && n_blocks) e = hipMemcpyAsync(d_col, col_idx, (size_t)n_blocks * 6 * sizeof(int), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && n_blocks) e = hipMemcpyAsync(d_mir, mirror, (size_t)n_blocks * sizeof(int), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_diag, diag_add, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rhs, rhs, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s);
+    // through the pinned arena (1.3 MB of blocks at Room scale, once per LM step: a pageable copy locks the caller's pages)
+    if (e == hipSuccess && n_blocks) {
+      st = pvlm_i_h2d_q(ctx, d_blocks, blocks, (size_t)n_blocks * 36 * sizeof(double));
+      if (!st) st = pvlm_i_h2d_q(ctx, d_row, row_idx, (size_t)n_blocks * 6 * sizeof(int));
+      if (!st) st = pvlm_i_h2d_q(ctx, d_col, col_idx, (size_t)n_blocks * 6 * sizeof(int));
+      if (!st) st = pvlm_i_h2d_q(ctx, d_mir, mirror, (size_t)n_blocks * sizeof(int));
+    }
+    if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_scale, scale, (size_t)n * sizeof(double));
+    if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_diag, diag_add, (size_t)n * sizeof(double));
+    if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_rhs, rhs, (size_t)n * sizeof(double));
     int info = 0;
-    if (e == hipSuccess) {
+    if (e == hipSuccess && !st) {
       if (n_blocks) hipLaunchKernelGGL(k_scatter_blocks, dim3((unsigned)(((long long)n_blocks * 36 + 255) / 256)), dim3(256), 0, s, n, n_blocks, d_row, d_col, d_mir, d_blocks, d_scale, d_M);
       hipLaunchKernelGGL(k_add_diag, dim3((n + 255) / 256), dim3(256), 0, s, n, d_diag, d_M);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, sizeof(int), s);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && !st) e = hipMemsetAsync(d_info, 0, sizeof(int), s);
+    if (e == hipSuccess && !st) {
       chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_Linv, d_y, d_info);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(rhs, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    *info_out = info;
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (!st) st = pvlm_i_d2h_q(ctx, &info, d_info, sizeof(int));
+    if (!st) st = pvlm_i_d2h_q(ctx, rhs, d_rhs, (size_t)n * sizeof(double));
+    { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+    *info_out = info;
+  } else {
+    hipStreamSynchronize(ctx->stream);
   }
-  hipStreamSynchronize(ctx->stream);
   return st;
 }
 

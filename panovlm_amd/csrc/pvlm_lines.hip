@@ -512,16 +512,15 @@ static pvlm_status run_vote_batch(pvlm_ctx* ctx, const std::vector<D>& desc, con
   if (!st) st = pvlm_i_alloc(ctx, &d_tab, tab.size());
   if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)n_votes);
   if (!st) {
-    hipError_t e = hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(D), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_work, work_off.data(), work_off.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && !tab.empty()) e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_v, 0, (size_t)n_votes * sizeof(int), ctx->stream);
-    if (e == hipSuccess && total_work > 0) { launch(ctx, (int)desc.size(), d_desc, d_work, total_work, d_tab, d_v); e = hipGetLastError(); }
-    if (e == hipSuccess && n_votes > 0) e = hipMemcpyAsync(votes, d_v, (size_t)n_votes * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    st = pvlm_i_h2d_q(ctx, d_desc, desc.data(), desc.size() * sizeof(D));
+    if (!st) st = pvlm_i_h2d_q(ctx, d_work, work_off.data(), work_off.size() * sizeof(long long));
+    if (!st && !tab.empty()) st = pvlm_i_h2d_q(ctx, d_tab, tab.data(), tab.size() * sizeof(double));
+    hipError_t e = st ? hipSuccess : hipMemsetAsync(d_v, 0, (size_t)n_votes * sizeof(int), ctx->stream);
+    if (!st && e == hipSuccess && total_work > 0) { launch(ctx, (int)desc.size(), d_desc, d_work, total_work, d_tab, d_v); e = hipGetLastError(); }
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "batched votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (!st && n_votes > 0) st = pvlm_i_d2h_q(ctx, votes, d_v, (size_t)n_votes * sizeof(int));
   }
-  hipStreamSynchronize(ctx->stream);
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
   pvlm_i_free(ctx, d_desc); pvlm_i_free(ctx, d_work); pvlm_i_free(ctx, d_tab); pvlm_i_free(ctx, d_v);
   return st;
 }
@@ -567,6 +566,7 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
   *out = nullptr;
   if (kind != PVLM_POINT2LINE_ANGLE && kind != PVLM_POINT2LINE_METER) { PVLM_SET_ERR(ctx, "kind must be a point-to-line functor"); return PVLM_ERR_ARG; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_i_trace("line2line_residuals: enter");
   pvlm_resset* rs = new (std::nothrow) pvlm_resset();
   if (!rs) return PVLM_ERR_NOMEM;
   rs->kind = kind; rs->flags = flags & 0xFFu; rs->weight = weight; rs->ncols = 9;
@@ -617,6 +617,7 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
     rs->n = compact;
   }
   const long long R_rows = std::max<long long>((row + 1) & ~1ll, 2);
+  pvlm_i_trace("line2line_residuals: match table built");
   rs->n_dev = R_rows;
   rs->h_pair_block.assign((size_t)rs->n_pairs, 0);
   rs->h_seg_start.push_back(R_rows);
@@ -629,13 +630,16 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
     st = pvlm_i_alloc(ctx, &d_md, md.size());
     if (!st) st = pvlm_i_alloc(ctx, &d_po, poses.size());
     if (!st) {
-      hipError_t e = hipMemcpyAsync(d_md, md.data(), md.size() * sizeof(pvlm_match_desc), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(d_po, poses.data(), poses.size() * sizeof(pvlm_match_pose), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) { hipLaunchKernelGGL(k_line_rows, dim3((unsigned)n_matches), dim3(64), 0, ctx->stream, d_md, d_po, d_block, R_rows); e = hipGetLastError(); }
+      st = pvlm_i_h2d_q(ctx, d_md, md.data(), md.size() * sizeof(pvlm_match_desc));
+      if (!st) st = pvlm_i_h2d_q(ctx, d_po, poses.data(), poses.size() * sizeof(pvlm_match_pose));
+      hipError_t e = hipSuccess;
+      if (!st) { hipLaunchKernelGGL(k_line_rows, dim3((unsigned)n_matches), dim3(64), 0, ctx->stream, d_md, d_po, d_block, R_rows); e = hipGetLastError(); }
       if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_line2line_residuals: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
     }
   }
+  pvlm_i_trace("line2line_residuals: copies + kernel queued");
   if (!st) st = pvlm_i_resset_finalize(ctx, rs);     // synchronises: the staging vectors above may go
+  pvlm_i_trace("line2line_residuals: finalize (sync)");
   pvlm_i_free(ctx, d_md); pvlm_i_free(ctx, d_po);
   if (st) { hipStreamSynchronize(ctx->stream); pvlm_i_resset_free(ctx, rs); return st; }
   *out = rs;

@@ -42,6 +42,10 @@ void Engine::SetDevice(int device) { g_device = device; }
 Engine::Engine(int device) {
   pvlm_status st = pvlm_create(device, &ctx_);
   if (st != PVLM_OK) throw std::runtime_error("pvlm_create failed (" + std::to_string((int)st) + "): no usable MI355X / HIP device; there is no CPU fallback");
+  // PVLM_HOST_RESERVE_MB: size the engine's device pool once, at start-up (hipMalloc of fresh memory costs 40-70 ms per GB
+  // on this driver — paid here instead of inside the first association / solve of the process)
+  if (const char* mb = std::getenv("PVLM_HOST_RESERVE_MB"))
+    if (std::atof(mb) > 0) Check(pvlm_reserve(ctx_, (size_t)(std::atof(mb) * 1048576.0)), "pvlm_reserve");
 }
 Engine::~Engine() { if (ctx_) pvlm_destroy(ctx_); }
 Engine& Engine::Default() {
@@ -214,42 +218,76 @@ Velodyne& Velodyne::operator=(const Velodyne& o) {
   R_wl_ = o.R_wl_; t_wl_ = o.t_wl_; world_ = o.world_;
   return *this;
 }
+// Host-side flattening of one scan's members into the arrays a pvlm_scan_desc points at.
+namespace {
+struct ScanStaging {
+  std::vector<float> fx, ft, lx, lt, cx, seg_xyz;
+  std::vector<int> off, ids, seg_size;
+  std::vector<double> coeffs, ends;
+  pvlm_scan_desc d;
+  void Fill(const Velodyne& v, const Matrix3d& R_wl, const Vector3d& t_wl) {
+    auto flat = [](const PointCloud& c, std::vector<float>& xyz, std::vector<float>* tag) {
+      xyz.resize(c.size() * 3); if (tag) tag->resize(c.size());
+      for (size_t i = 0; i < c.size(); ++i) { xyz[3 * i] = c[i].x; xyz[3 * i + 1] = c[i].y; xyz[3 * i + 2] = c[i].z; if (tag) (*tag)[i] = c[i].intensity; }
+    };
+    flat(v.surfFlat, fx, &ft); flat(v.surfLessFlat, lx, &lt); flat(v.cornerLessSharp, cx, nullptr);
+    off.assign(v.cornerLessSharp.size() + 1, 0); seg_size.resize(v.edge_segmented.size());
+    for (size_t i = 0; i < v.cornerLessSharp.size(); ++i) {
+      if (i < v.point_to_segment.size()) for (int s : v.point_to_segment[i]) ids.push_back(s);
+      off[i + 1] = (int)ids.size();
+    }
+    for (size_t s = 0; s < v.edge_segmented.size(); ++s) seg_size[s] = (int)v.edge_segmented[s].size();
+    coeffs.resize(v.segment_coeffs.size() * 6); ends.assign(v.edge_segmented.size() * 6, 0.0);
+    for (size_t s = 0; s < v.segment_coeffs.size(); ++s) std::memcpy(&coeffs[6 * s], v.segment_coeffs[s].data(), 48);
+    for (size_t s = 0; s < v.edge_segmented.size() && 2 * s + 1 < v.end_points.size(); ++s) {
+      std::memcpy(&ends[6 * s], v.end_points[2 * s].data(), 24); std::memcpy(&ends[6 * s + 3], v.end_points[2 * s + 1].data(), 24);
+    }
+    if (ids.empty()) ids.push_back(0);
+    std::memset(&d, 0, sizeof(d));
+    d.id = v.id; d.R_wl = R_wl.data(); d.t_wl = t_wl.data();
+    d.n_surf_flat = (int)v.surfFlat.size(); d.surf_flat_xyz = fx.data(); d.surf_flat_tag = ft.data();
+    d.n_surf_less_flat = (int)v.surfLessFlat.size(); d.surf_less_flat_xyz = lx.data(); d.surf_less_flat_tag = lt.data();
+    d.n_corner = (int)v.cornerLessSharp.size(); d.corner_xyz = cx.data(); d.p2s_offsets = off.data(); d.p2s_ids = ids.data();
+    d.n_segments = (int)std::min(v.edge_segmented.size(), v.segment_coeffs.size()); d.segment_size = seg_size.data();
+    d.segment_coeffs = coeffs.data(); d.end_points = ends.data();
+    // the segments' own point lists (edge_segmented), for the device-built line-to-line blocks
+    for (int k = 0; k < d.n_segments; ++k) for (const PointXYZI& p : v.edge_segmented[(size_t)k]) { seg_xyz.push_back(p.x); seg_xyz.push_back(p.y); seg_xyz.push_back(p.z); }
+    if (seg_xyz.empty()) seg_xyz.push_back(0.f);
+    d.seg_points_xyz = seg_xyz.data();
+  }
+};
+}  // namespace
+
 pvlm_scan* Velodyne::DeviceScan() const {
   if (dev_) return dev_;
   StageTimer stage_timer_("  (inside the stages below) scan upload: host SoA staging + pvlm_scan_upload");
-  auto flat = [](const PointCloud& c, std::vector<float>& xyz, std::vector<float>& tag) {
-    xyz.resize(c.size() * 3); tag.resize(c.size());
-    for (size_t i = 0; i < c.size(); ++i) { xyz[3 * i] = c[i].x; xyz[3 * i + 1] = c[i].y; xyz[3 * i + 2] = c[i].z; tag[i] = c[i].intensity; }
-  };
-  std::vector<float> fx, ft, lx, lt, cx, ct;
-  flat(surfFlat, fx, ft); flat(surfLessFlat, lx, lt); flat(cornerLessSharp, cx, ct);
-  std::vector<int> off(cornerLessSharp.size() + 1, 0), ids, seg_size(edge_segmented.size());
-  for (size_t i = 0; i < cornerLessSharp.size(); ++i) {
-    if (i < point_to_segment.size()) for (int s : point_to_segment[i]) ids.push_back(s);
-    off[i + 1] = (int)ids.size();
-  }
-  for (size_t s = 0; s < edge_segmented.size(); ++s) seg_size[s] = (int)edge_segmented[s].size();
-  std::vector<double> coeffs(segment_coeffs.size() * 6), ends(edge_segmented.size() * 6, 0.0);
-  for (size_t s = 0; s < segment_coeffs.size(); ++s) std::memcpy(&coeffs[6 * s], segment_coeffs[s].data(), 48);
-  for (size_t s = 0; s < edge_segmented.size() && 2 * s + 1 < end_points.size(); ++s) {
-    std::memcpy(&ends[6 * s], end_points[2 * s].data(), 24); std::memcpy(&ends[6 * s + 3], end_points[2 * s + 1].data(), 24);
-  }
-  if (ids.empty()) ids.push_back(0);
-  pvlm_scan_desc d;
-  std::memset(&d, 0, sizeof(d));
-  d.id = id; d.R_wl = R_wl_.data(); d.t_wl = t_wl_.data();
-  d.n_surf_flat = (int)surfFlat.size(); d.surf_flat_xyz = fx.data(); d.surf_flat_tag = ft.data();
-  d.n_surf_less_flat = (int)surfLessFlat.size(); d.surf_less_flat_xyz = lx.data(); d.surf_less_flat_tag = lt.data();
-  d.n_corner = (int)cornerLessSharp.size(); d.corner_xyz = cx.data(); d.p2s_offsets = off.data(); d.p2s_ids = ids.data();
-  d.n_segments = (int)std::min(edge_segmented.size(), segment_coeffs.size()); d.segment_size = seg_size.data();
-  d.segment_coeffs = coeffs.data(); d.end_points = ends.data();
-  std::vector<float> seg_xyz;       // the segments' own point lists (edge_segmented), for the device-built line-to-line blocks
-  for (int k = 0; k < d.n_segments; ++k) for (const PointXYZI& p : edge_segmented[(size_t)k]) { seg_xyz.push_back(p.x); seg_xyz.push_back(p.y); seg_xyz.push_back(p.z); }
-  if (seg_xyz.empty()) seg_xyz.push_back(0.f);
-  d.seg_points_xyz = seg_xyz.data();
+  ScanStaging st;
+  st.Fill(*this, R_wl_, t_wl_);
   Engine& e = Engine::Default();
-  e.Check(pvlm_scan_upload(e.ctx(), &d, &dev_), "pvlm_scan_upload");
+  e.Check(pvlm_scan_upload(e.ctx(), &st.d, &dev_), "pvlm_scan_upload");
   return dev_;
+}
+
+// Every scan of `scans` that has no device mirror yet, in ONE pvlm_scan_upload_batch (one staging copy, one slab, one
+// grid build): what the adders call before they walk their (scan, neighbour) pairs — at Room scale all 454 scans are
+// re-posed, hence re-uploaded, at every outer iteration of EstimatePose.
+void Velodyne::UploadBatch(const std::vector<const Velodyne*>& scans) {
+  std::vector<const Velodyne*> todo;
+  {
+    std::set<const Velodyne*> seen;
+    for (const Velodyne* v : scans) if (v && !v->dev_ && seen.insert(v).second) todo.push_back(v);
+  }
+  if (todo.empty()) return;
+  if (todo.size() == 1 || std::getenv("PVLM_HOST_NO_BATCH")) { for (const Velodyne* v : todo) v->DeviceScan(); return; }
+  StageTimer stage_timer_("  (inside the stages below) scan upload: host SoA staging + pvlm_scan_upload");
+  std::vector<ScanStaging> st(todo.size());
+  std::vector<pvlm_scan_desc> descs(todo.size());
+  for (size_t k = 0; k < todo.size(); ++k) { st[k].Fill(*todo[k], todo[k]->R_wl_, todo[k]->t_wl_); descs[k] = st[k].d; }
+  std::vector<pvlm_scan*> out(todo.size(), nullptr);
+  Engine& e = Engine::Default();
+  StageTimer stage_timer_abi_("  (inside the scan upload) pvlm_scan_upload_batch");
+  e.Check(pvlm_scan_upload_batch(e.ctx(), (int)todo.size(), descs.data(), out.data()), "pvlm_scan_upload_batch");
+  for (size_t k = 0; k < todo.size(); ++k) todo[k]->dev_ = out[k];
 }
 
 // ================================================================================================
@@ -267,6 +305,7 @@ std::vector<std::vector<int>> FindNeighborsConsecutive(const std::vector<Velodyn
 }
 
 std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars, const int neighbor_size) {
+  StageTimer stage_timer_("  (inside) FindNeighbors (host)");
   std::vector<std::vector<int>> neighbors_all;
   std::vector<std::array<float, 3>> center;
   std::vector<int> owner;
@@ -573,6 +612,14 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
   }
   std::vector<pvlm_scan*> refs, neis;
   std::vector<size_t> which;
+  {
+    std::vector<const Velodyne*> need;
+    for (const auto& pr : pairs)
+      if (pr.first->IsInWorldCoordinate() && pr.second->IsInWorldCoordinate() && !pr.first->edge_segmented.empty() && !pr.second->edge_segmented.empty()) {
+        need.push_back(pr.first); need.push_back(pr.second);
+      }
+    Velodyne::UploadBatch(need);
+  }
   for (size_t k = 0; k < pairs.size(); ++k) {
     const Velodyne& ref = *pairs[k].first; const Velodyne& nei = *pairs[k].second;
     if (!ref.IsInWorldCoordinate() || !nei.IsInWorldCoordinate()) { fprintf(stderr, "lidar %d / %d is not in world coordinate\n", ref.id, nei.id); continue; }
@@ -582,10 +629,14 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
   if (which.empty()) return out;
   Engine& e = Engine::Default();
   std::vector<int64_t> voff(which.size() + 1, 0);
-  e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), nullptr, 0), "pvlm_line2line_votes_batch");
-  std::vector<int32_t> votes((size_t)std::max<int64_t>(voff.back(), 1), 0);
-  e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), votes.data(), (int64_t)votes.size()),
-          "pvlm_line2line_votes_batch");
+  std::vector<int32_t> votes;
+  {
+    StageTimer stage_timer_votes_("  (inside) line votes of all pairs on the GPU (launch + copy back)");
+    e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), nullptr, 0), "pvlm_line2line_votes_batch");
+    votes.assign((size_t)std::max<int64_t>(voff.back(), 1), 0);
+    e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), votes.data(), (int64_t)votes.size()),
+            "pvlm_line2line_votes_batch");
+  }
   StageTimer stage_timer_("  (inside) FindAssociations on the vote blocks (host)");
   for (size_t j = 0; j < which.size(); ++j) {
     const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
@@ -789,6 +840,7 @@ bool LidarLineMatch::GenerateTracks() {
     feature_each_pair.push_back(fp);
   }
   // TrackBuilder(true).Build
+  StageTimer stage_timer_tb_("  (inside) TrackBuilder: union-find + filter + export (host)");
   std::set<std::pair<uint32_t, uint32_t>> all;
   for (size_t i = 0; i < pairs.size(); i++)
     for (const auto& mth : feature_each_pair[i]) { all.emplace((uint32_t)pairs[i].first, mth.first); all.emplace((uint32_t)pairs[i].second, mth.second); }
@@ -1572,14 +1624,18 @@ size_t AddLidarPointToPlaneResidual(const std::vector<std::vector<int>>& neighbo
   std::vector<pvlm_scan*> refs, neis;
   std::vector<const Velodyne*> holders;
   const size_t i_lo = ref_range ? ref_range->first : 0, i_hi = ref_range ? std::min(ref_range->second, lidars.size()) : lidars.size();
-  for (size_t i = i_lo; i < i_hi; i++) {
-    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;                 // :525-526
-    for (int n_idx : neighbors[i]) {
-      if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;  // :531-532
-      if (!lidars[n_idx].IsPoseValid()) continue;                                // :533-534
-      if (!lidars[i].IsInWorldCoordinate() || !lidars[n_idx].IsInWorldCoordinate()) continue;  // CheckLidarCoordinate -> empty result
-      refs.push_back(lidars[i].DeviceScan()); neis.push_back(lidars[n_idx].DeviceScan());
+  for (int pass = 0; pass < 2; ++pass) {       // pass 0: which scans take part (uploaded in one batch), pass 1: the pair list
+    for (size_t i = i_lo; i < i_hi; i++) {
+      if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;                 // :525-526
+      for (int n_idx : neighbors[i]) {
+        if (n_idx < 0 || n_idx == (int)i || n_idx >= (int)lidars.size()) continue;  // :531-532
+        if (!lidars[n_idx].IsPoseValid()) continue;                                // :533-534
+        if (!lidars[i].IsInWorldCoordinate() || !lidars[n_idx].IsInWorldCoordinate()) continue;  // CheckLidarCoordinate -> empty result
+        if (pass == 0) { holders.push_back(&lidars[i]); holders.push_back(&lidars[n_idx]); }
+        else { refs.push_back(lidars[i].DeviceScan()); neis.push_back(lidars[n_idx].DeviceScan()); }
+      }
     }
+    if (pass == 0) Velodyne::UploadBatch(holders);
   }
   // parameter blocks are looked up by lidars[i].id (:527-528,:541-542); DeviceScan() carries that id
   Engine& e = Engine::Default();
@@ -1630,7 +1686,10 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   const size_t i_lo = ref_range ? ref_range->first : 0, i_hi = ref_range ? std::min(ref_range->second, lidars.size()) : lidars.size();
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
   std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> lines_to_track;
-  for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) lines_to_track[pr].push_back(t.id);
+  {
+    StageTimer stage_timer_l2t_("  (inside) line-to-line: lines_to_track map (host)");
+    for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) lines_to_track[pr].push_back(t.id);
+  }
   size_t num = 0;
   // all AssociateLine2Line(lidars[i], lidars[n_idx], thr) calls of the loop below (:379) in one GPU launch
   std::vector<std::pair<const Velodyne*, const Velodyne*>> todo;
@@ -1650,6 +1709,7 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   std::vector<pvlm_scan*> refs, neis;
   std::vector<int> m_pair, m_nei, m_ref;
   size_t next = 0;
+  StageTimer* stage_timer_filter_ = new StageTimer("  (inside) line-to-line: track filter of the matches (host)");
   for (size_t i = i_lo; i < i_hi; i++) {
     if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
     for (int n_idx : neighbors[i]) {
@@ -1671,9 +1731,11 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
       }
     }
   }
+  delete stage_timer_filter_;
   if (num == 0) { delete loss; return 0; }
   Engine& e = Engine::Default();
   pvlm_resset* rs = nullptr;
+  StageTimer stage_timer_rows_("  (inside) line-to-line: blocks built on the GPU (pvlm_line2line_residuals)");
   e.Check(pvlm_line2line_residuals(e.ctx(), (int)refs.size(), refs.data(), neis.data(), (int)m_pair.size(), m_pair.data(), m_nei.data(), m_ref.data(),
                                    angle_residual ? PVLM_POINT2LINE_ANGLE : PVLM_POINT2LINE_METER,
                                    (angle_residual && normalized_distance) ? PVLM_FLAG_NORMALIZE_DISTANCE : 0u, weight, &rs), "pvlm_line2line_residuals");
@@ -2254,6 +2316,7 @@ CameraLidarOptimizer::LinePairs CameraLidarOptimizer::AssociateLineMulti(const i
   struct Job { size_t f; int lid; Matrix4d T_cl; };
   std::vector<Job> jobs;
   std::vector<pvlm_scan*> scans;
+  std::vector<const Velodyne*> scan_of_job;
   std::vector<int64_t> line_off(1, 0);
   std::vector<float> lines_flat;
   std::vector<double> T_flat;
@@ -2265,13 +2328,15 @@ CameraLidarOptimizer::LinePairs CameraLidarOptimizer::AssociateLineMulti(const i
       all[{f, (size_t)lid}] = {};
       if (lidar.edge_segmented.empty() || frames[f].lines.empty()) continue;
       jobs.push_back({f, lid, T_cl});
-      scans.push_back(lidar.DeviceScan());
+      scan_of_job.push_back(&lidar);
       for (const auto& l : frames[f].lines) lines_flat.insert(lines_flat.end(), l.begin(), l.end());
       line_off.push_back((int64_t)lines_flat.size() / 4);
       T_flat.insert(T_flat.end(), T_cl.begin(), T_cl.end());
     }
   }
   if (jobs.empty()) return all;
+  Velodyne::UploadBatch(scan_of_job);
+  for (const Velodyne* v : scan_of_job) scans.push_back(v->DeviceScan());
   if (std::getenv("PVLM_HOST_NO_BATCH")) {   // measured variant: per-pair launches
     for (const Job& j : jobs) {
       CameraLidarLineAssociate associate(frames[j.f].rows, frames[j.f].cols);

@@ -160,6 +160,7 @@ class Velodyne {
 
   // device mirror of the clouds (uploaded lazily by the association entry points)
   pvlm_scan* DeviceScan() const;
+  static void UploadBatch(const std::vector<const Velodyne*>& scans);   // all of them that are not resident yet, in one pvlm_scan_upload_batch
   void InvalidateDevice() const;
   ~Velodyne();
   Velodyne(const Velodyne& o);

@@ -151,3 +151,82 @@ def test_line2line_votes(ctx, oracle):
         assert g.shape == (n.n_segments, r.n_segments) and np.array_equal(g, ctx.line2line_votes(r, n, 0.3))
     assert ctx.line2line_votes_batch([], [], 0.3) == []
     da.close(); db.close(); de.close()
+
+
+def test_batched_scan_upload_equals_scan_by_scan(ctx, oracle):
+    """pvlm_scan_upload_batch (one staging copy, one slab, one grid build for all scans) hands out scans that behave exactly
+    like individually uploaded ones: k-NN in both target clouds, the association's residual set and the vote matrices are
+    bit-identical; scans of a batch can be destroyed in any order; a staging window smaller than the batch (several
+    copies) gives the same device contents."""
+    import os
+    import panovlm_amd as pv
+    rng = np.random.default_rng(31)
+    lines = synth.random_world_lines(rng, 12)
+    host = []
+    for k in range(7):
+        s = sy.make_scan(k, cols=512, downsample_targets=0.2 if k % 2 else 0.0)
+        R, t = sy.estimated_pose(k)
+        ls = synth.make_line_scan(rng, k, R, t, lines[k % 3:k % 3 + 8])
+        s.update(corner_xyz=ls["corner_xyz"], p2s=ls["p2s"], seg_size=ls["seg_size"], seg_coeffs=ls["seg_coeffs"], end_points=ls["end_points"])
+        host.append(s)
+    host[5] = dict(id=5, R_wl=host[5]["R_wl"], t_wl=host[5]["t_wl"])                      # a scan without any cloud
+    host[6]["less_xyz"] = (rng.normal(size=(3000, 3)) * [40, 40, 0.01]).astype(np.float32)  # flat and wide: hashed table
+    host[6]["less_tag"] = np.ones(3000, np.float32)
+    single = [pv.Scan(ctx, s) for s in host]
+
+    def compare(batch):
+        q = (rng.normal(size=(500, 3)) * 3).astype(np.float32)
+        for a, b, h in zip(single, batch, host):
+            assert (a.n_flat, a.n_less, a.n_corner, a.n_segments) == (b.n_flat, b.n_less, b.n_corner, b.n_segments)
+            for which, n in ((0, a.n_less), (1, a.n_corner)):
+                if n == 0:
+                    continue
+                ia, da = ctx.knn(a, q, 10, 2.0, which=which); ib, db = ctx.knn(b, q, 10, 2.0, which=which)
+                assert np.array_equal(ia, ib) and np.array_equal(da, db)
+        pairs = [(0, 1), (1, 0), (2, 3), (3, 4), (4, 6), (6, 2), (5, 1), (1, 5)]
+        ra = ctx.assoc_point2plane([single[r] for r, _ in pairs], [single[n] for _, n in pairs], 0.05, 1.0, kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE)
+        rb = ctx.assoc_point2plane([batch[r] for r, _ in pairs], [batch[n] for _, n in pairs], 0.05, 1.0, kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE)
+        xa, xb = ra.download(), rb.download()
+        assert ra.n == rb.n > 1000 and np.array_equal(xa[0], xb[0]) and np.array_equal(xa[1], xb[1])
+        ra.close(); rb.close()
+        va = ctx.line2line_votes_batch([single[0], single[2]], [single[1], single[3]], 0.4)
+        vb = ctx.line2line_votes_batch([batch[0], batch[2]], [batch[1], batch[3]], 0.4)
+        for x, y in zip(va, vb):
+            assert np.array_equal(x, y)
+        assert sum(int(x.sum()) for x in va) > 0
+
+    batch = pv.Scan.upload_batch(ctx, host)
+    assert len(batch) == len(host)
+    compare(batch)
+    # the slab lives until the last scan of the batch goes: destroy some, the others keep working
+    for k in (0, 3, 5):
+        batch[k].close()
+    i1, d1 = ctx.knn(batch[1], host[0]["flat_xyz"][:200], 10, 1.0)
+    i2, d2 = ctx.knn(single[1], host[0]["flat_xyz"][:200], 10, 1.0)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    for b in batch:
+        b.close()
+    # staging window of 64 KiB: the front of the slab goes over in many pieces
+    os.environ["PVLM_UPLOAD_STAGE_MB"] = "0.0625"
+    try:
+        c2 = pv.Context(0)                                # a fresh context: its staging buffer is sized by the small window
+        try:
+            small = pv.Scan.upload_batch(c2, host)
+            q = host[0]["flat_xyz"][:300]
+            for a, b in zip(single, small):
+                if a.n_less:
+                    ia, da = ctx.knn(a, q, 10, 1.0); ib, db = c2.knn(b, q, 10, 1.0)
+                    assert np.array_equal(ia, ib) and np.array_equal(da, db)
+            for b in small:
+                b.close()
+        finally:
+            c2.close()
+    finally:
+        del os.environ["PVLM_UPLOAD_STAGE_MB"]
+    assert pv.Scan.upload_batch(ctx, []) == []
+    # all or nothing: one bad scan (NaN) fails the whole batch loudly
+    bad = dict(host[1]); bad["less_xyz"] = host[1]["less_xyz"].copy(); bad["less_xyz"][7, 1] = np.nan
+    with pytest.raises(pv.PvlmError):
+        pv.Scan.upload_batch(ctx, [host[0], bad])
+    for a in single:
+        a.close()

@@ -7,7 +7,16 @@ import numpy as np
 import pytest
 import torch
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _float64_default():
+    """The transcription below builds its tensors without dtypes: float64 is the default for the duration of each test of THIS
+    module only (a module-level torch.set_default_dtype leaked into every module collected after it)."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 
 def rodrigues(aa):

@@ -79,13 +79,14 @@ def test_device_resident_panorama_maps_equal_the_host_pointer_entry_points():
     rows, cols = 2880, 5760
     g = torch.Generator(device="cpu"); g.manual_seed(3)
     for n in (1, 3, 4, 5, 1000, 1001, 1002, 1003, 70001):
-        cam = (torch.randn((n + 1, 3), generator=g) * 3).float()
-        px = (torch.rand((n + 1, 2), generator=g) * torch.tensor([cols, rows])).float()
+        cam = (torch.randn((n + 1, 3), generator=g, dtype=torch.float32) * 3)
+        px = (torch.rand((n + 1, 2), generator=g, dtype=torch.float32) * torch.tensor([cols, rows], dtype=torch.float32))
         for off in (0, 1):                         # off = 1: the device view starts 12 / 8 bytes into the allocation -> scalar path
             c_d = cam.to(dev)[off:off + n].contiguous() if off == 0 else cam.to(dev)[off:off + n]
             p_d = px.to(dev)[off:off + n].contiguous() if off == 0 else px.to(dev)[off:off + n]
             assert c_d.is_contiguous() and p_d.is_contiguous()
-            o_px = torch.empty((n, 2), device=dev); o_cam = torch.empty((n, 3), device=dev)
+            o_px = torch.empty((n, 2), device=dev, dtype=torch.float32); o_cam = torch.empty((n, 3), device=dev, dtype=torch.float32)
+            assert c_d.dtype == p_d.dtype == torch.float32
             ctx.cam_to_image_f32_dev(rows, cols, n, c_d.data_ptr(), o_px.data_ptr())
             ctx.image_to_cam_f32_dev(rows, cols, n, p_d.data_ptr(), 2.5, o_cam.data_ptr())
             torch.cuda.synchronize()

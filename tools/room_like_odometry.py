@@ -53,6 +53,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "room.bin")
         host_io.write_scans(path, scans, world=False)
+        os.environ.setdefault("PVLM_HOST_RESERVE_MB", "1536")       # the engine's pool, sized once at context creation
         t0 = time.perf_counter()
         out = host_io.run("odometry", path, a.iters, 1, 1, 1 if a.lines else 0, 1, 0.05, 1.0, 0.3, timeout=3000)
         wall = time.perf_counter() - t0
@@ -63,6 +64,9 @@ def main():
     print("GPU EstimatePose: %d scans, %d outer iterations, %.2f s wall (process start, upload, association, LM, write-back)" % (a.scans, len(iters), wall))
     for l in iters:
         print("  ", l)
+    for l in out:
+        if l.startswith("call"):
+            print("   call  %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:])))
     for l in out:
         if l.startswith("stage"):
             print("   stage %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:])))
