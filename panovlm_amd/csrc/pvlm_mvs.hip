@@ -5,7 +5,7 @@
 // One wave per reference pixel, one lane per texel of the NCC window (7 x 7 = 49 at the Room settings; larger windows
 // loop): the bilateral weights, the plane-induced homography H = R_nr + t_nr n^T / d, the equirectangular re-projection
 // (the same FastAtan2 arithmetic as K7) and the bilinear samples are per-lane work, the weighted means / variances are
-// summed in the reference's own sequential order (wave_seq_sum below).
+// summed in the reference's own sequential order (strip_seq_sum* below).
 // Threshold decisions (d > 0, projection inside the image, sq0 <= 1e-6) use the reference's float arithmetic —
 // compiled with -ffp-contract=off.  Images stay in HBM as uint8; the PreComputeI2C table is built on the device.
 #include <algorithm>
@@ -16,33 +16,52 @@
 #define PVLM_HD __host__ __device__
 #include "pvlm_mvs_core.h"
 
-#define PVLM_MVS_MAXM 4   // texels per lane: windows up to 256 texels
+#define PVLM_MVS_MAXM 4   // texels per lane: windows up to 256 texels.  Every wave-level piece below is a template on the
+                          // texels per lane M: M = 1 (windows up to 64 texels: the reference's 7 x 7 and 5 x 5) keeps one texel,
+                          // one weight and four neighbour samples per lane in registers and 3 KB of LDS per wave, M = 4 the rest
 
 // Sums of per-texel values IN INDEX ORDER: s = 0; s += v_0; s += v_1; ... — exactly the reference's sequential float loops
 // (mvs/MVS.cpp:659-673, :826-833).  A wave tree would be six steps instead of n, but float addition does not associate: on
 // texture-less windows sq0, sq1 and nrm = sq0 * sq1 are sums of rounding residues, and the reference's own tests
 // `sq0 > 0` (:602), `nrm <= 0` (:835) then depend on the order of the additions — measured at 5.7K, a tree order took the
 // other branch on 0.4 % of the pixels; near-ties between PatchMatch hypotheses fall the other way for the same reason.
-// Every lane parks its values in the wave's LDS strip (one float4 per texel = the same quantity for four neighbour images),
-// then all lanes walk the strip with broadcast 16-byte reads and add: four independent sequential chains per pass, every
-// lane ends with the same four sums.  (v_readlane chains, the first version, cost 2.5x the rest of the kernel.)
-#define PVLM_MVS_STRIP 256                     // texels per strip (= 64 * PVLM_MVS_MAXM)
-#define PVLM_MVS_LDS_PER_WAVE (3 * PVLM_MVS_STRIP)   // float4 elements: products A | products B1 | products B2
-__device__ inline float4 strip_seq_sum(const float4* __restrict__ strip, int n) {
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+// Every lane parks its values in the wave's LDS strip (one float4 per texel = the same quantity for four neighbour images);
+// then lane c walks COLUMN c of the strip — lanes 0-3 the four neighbours of one quantity, lanes 0-7 two quantities at
+// once — with one 4-byte LDS read and one add per texel, and the totals are handed to every lane with v_readlane.  History:
+// v_readlane chains over the registers cost 2.5x the rest of the kernel; all 64 lanes walking the strip with broadcast
+// 16-byte reads and adding all four columns (twelve dependent add chains per neighbour group, every lane redundantly)
+// took K11 from 2.75 to 5.2 ms; one chain per lane does the same additions in the same order in a sixth of the issue slots.
+#define PVLM_MVS_STRIP(M) (64 * (M))                       // texels per strip
+#define PVLM_MVS_LDS_PER_WAVE(M) (3 * PVLM_MVS_STRIP(M))   // float4 elements: products A | products B1 | products B2
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+// column 0 of the strip (one quantity, e.g. of the reference patch): every lane walks it, every lane ends with the sum
+__device__ inline float strip_seq_sum1(const float4* __restrict__ strip, int n) {
+  const float* f = reinterpret_cast<const float*>(strip);
+  __asm__ volatile("" ::: "memory");             // the strip was just written through another pointer type
+  float s = 0.f;
 #pragma unroll 8
-  for (int i = 0; i < n; ++i) { const float4 q = strip[i]; s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w; }
+  for (int i = 0; i < n; ++i) s += f[4 * i];
   return s;
 }
-__device__ inline void strip_seq_sum2(const float4* __restrict__ a, const float4* __restrict__ b, int n, float4* sa, float4* sb) {
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = s;
+// the four columns of one strip: lane c (mod 4) walks column c
+__device__ inline void strip_seq_sum4(const float4* __restrict__ strip, int n, int lane, float out[4]) {
+  const float* f = reinterpret_cast<const float*>(strip) + (lane & 3);
+  __asm__ volatile("" ::: "memory");
+  float s = 0.f;
 #pragma unroll 8
-  for (int i = 0; i < n; ++i) {
-    const float4 q = a[i], r = b[i];
-    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
-    t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
-  }
-  *sa = s; *sb = t;
+  for (int i = 0; i < n; ++i) s += f[4 * i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[j] = lane_bcast(s, j);
+}
+// the four columns of two strips (b follows a at a fixed distance): lane c (mod 8) walks column c & 3 of strip c >> 2
+__device__ inline void strip_seq_sum8(const float4* __restrict__ a, const float4* __restrict__ b, int n, int lane, float sa[4], float sb[4]) {
+  const float* f = reinterpret_cast<const float*>((lane & 4) ? b : a) + (lane & 3);
+  __asm__ volatile("" ::: "memory");
+  float s = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < n; ++i) s += f[4 * i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sa[j] = lane_bcast(s, j); sb[j] = lane_bcast(s, 4 + j); }
 }
 
 __global__ void k_mvs_unit_table(int rows, int cols, float* __restrict__ unit) {
@@ -54,51 +73,53 @@ __global__ void k_mvs_unit_table(int rows, int cols, float* __restrict__ unit) {
 struct pvlm_mvs_neighbours { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
 
 // ---- wave-level pieces shared by the scoring pass and the PatchMatch sweep (one wave per pixel, lane = texel) ----
-struct PatchRegs { float w[PVLM_MVS_MAXM], t0[PVLM_MVS_MAXM]; float sq0; bool inside; };
+template <int M> struct PatchRegs { float w[M], t0[M]; float sq0; bool inside; };
 
-// FillPixelPatch (mvs/MVS.cpp:637-680).  lds: the wave's strip (PVLM_MVS_LDS_PER_WAVE float4).
+// FillPixelPatch (mvs/MVS.cpp:637-680).  lds: the wave's strip (PVLM_MVS_LDS_PER_WAVE(M) float4).
+template <int M>
 __device__ inline void wave_fill_patch(const unsigned char* __restrict__ ref_gray, int rows, int cols, int px, int py, int half_window, int step, int n, int lane,
-                                       float4* __restrict__ lds, PatchRegs& P) {
+                                       float4* __restrict__ lds, PatchRegs<M>& P) {
   P.inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
   P.sq0 = 0.f;
 #pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) { P.w[m] = 0.f; P.t0[m] = 0.f; }
+  for (int m = 0; m < M; ++m) { P.w[m] = 0.f; P.t0[m] = 0.f; }
   if (!P.inside) return;
 #pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+  for (int m = 0; m < M; ++m) {
     const int k = lane + 64 * m;
     if (k < n) { pvlm_mvs::patch_texel(ref_gray, cols, px, py, half_window, step, k, &P.w[m], &P.t0[m]); lds[k] = make_float4(P.w[m], 0.f, 0.f, 0.f); }
   }
-  const float wsum = strip_seq_sum(lds, n).x;                 // accumulate(weight.begin(), weight.end(), 0.f)   :659
+  const float wsum = strip_seq_sum1(lds, n);                  // accumulate(weight.begin(), weight.end(), 0.f)   :659
 #pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+  for (int m = 0; m < M; ++m) {
     const int k = lane + 64 * m;
     P.w[m] /= wsum;
     if (k < n) lds[k] = make_float4(P.w[m] * P.t0[m], 0.f, 0.f, 0.f);
   }
-  const float mean = strip_seq_sum(lds, n).x;                 // sum += weight[i] * texels0[i]                  :662-664
+  const float mean = strip_seq_sum1(lds, n);                  // sum += weight[i] * texels0[i]                  :662-664
 #pragma unroll
-  for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+  for (int m = 0; m < M; ++m) {
     const int k = lane + 64 * m;
     if (k < n) { P.t0[m] -= mean; const float tmp = P.t0[m] * P.w[m]; lds[k] = make_float4(P.t0[m] * tmp, 0.f, 0.f, 0.f); P.t0[m] = tmp; } else P.t0[m] = 0.f;
   }
-  P.sq0 = strip_seq_sum(lds, n).x;                            // sq0 += texels0[i] * tmp                         :668-672
+  P.sq0 = strip_seq_sum1(lds, n);                             // sq0 += texels0[i] * tmp                         :668-672
 }
 
 // ScorePixel (mvs/MVS.cpp:774-923) for one hypothesis (nrm3, dep) of pixel (px, py): photometric NCC per neighbour image,
 // optional smoothness factors (n_close > 0) and geometric-consistency adjustment (nb.geometric), best-two average.
 // Every lane returns the same value.
+template <int M>
 __device__ inline float wave_score(int rows, int cols, int half_window, int step, int n, int lane, const float* __restrict__ unit,
-                                   const pvlm_mvs_neighbours& nb, int px, int py, const PatchRegs& P, const float* nrm3, float dep, const float* factors,
+                                   const pvlm_mvs_neighbours& nb, int px, int py, const PatchRegs<M>& P, const float* nrm3, float dep, const float* factors,
                                    int n_close, float4* __restrict__ lds) {
   const float* u0 = unit + 3 * ((size_t)py * cols + px);
   const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
   const float d = X0[0] * nrm3[0] + X0[1] * nrm3[1] + X0[2] * nrm3[2];
   if (d > 0) return -1.f;
   float best1 = 0.f, best2 = 0.f; int count = 0;
-  float4* sA = lds; float4* sB1 = lds + PVLM_MVS_STRIP; float4* sB2 = lds + 2 * PVLM_MVS_STRIP;
+  float4* sA = lds; float4* sB1 = lds + PVLM_MVS_STRIP(M); float4* sB2 = lds + 2 * PVLM_MVS_STRIP(M);
   for (int b0 = 0; b0 < nb.n; b0 += 4) {                                 // four neighbour images per pass: one float4 per texel in LDS
-    float t1[4][PVLM_MVS_MAXM];
+    float t1[4][M];
     bool okj[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -107,27 +128,27 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
         float H[9];
         pvlm_mvs::homography(nb.R[b0 + j], nb.t[b0 + j], nrm3, d, H);
 #pragma unroll
-        for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+        for (int m = 0; m < M; ++m) {
           const int k = lane + 64 * m;
           t1[j][m] = 0.f;
           if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b0 + j], rows, cols, H, px, py, half_window, step, k, &t1[j][m]) && ok;
         }
       } else {
 #pragma unroll
-        for (int m = 0; m < PVLM_MVS_MAXM; ++m) t1[j][m] = 0.f;
+        for (int m = 0; m < M; ++m) t1[j][m] = 0.f;
       }
       okj[j] = !__any(!ok);                                              // goto next_image
     }
     if (!(okj[0] || okj[1] || okj[2] || okj[3])) continue;
 #pragma unroll
-    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+    for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
       if (k < n) sA[k] = make_float4(t1[0][m] * P.w[m], t1[1][m] * P.w[m], t1[2][m] * P.w[m], t1[3][m] * P.w[m]);
     }
-    const float4 sum = strip_seq_sum(sA, n);                             // sum += texels1[i] * weight[i]            :826-827
-    const float sj[4] = {sum.x, sum.y, sum.z, sum.w};
+    float sj[4];
+    strip_seq_sum4(sA, n, lane, sj);                                     // sum += texels1[i] * weight[i]            :826-827
 #pragma unroll
-    for (int m = 0; m < PVLM_MVS_MAXM; ++m) {
+    for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
       if (k < n) {
         float p1[4], p01[4];
@@ -137,9 +158,8 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
         sB2[k] = make_float4(p01[0], p01[1], p01[2], p01[3]);
       }
     }
-    float4 q1, q01;
-    strip_seq_sum2(sB1, sB2, n, &q1, &q01);                              // :830-831, :834-835
-    const float sq1j[4] = {q1.x, q1.y, q1.z, q1.w}, sq01j[4] = {q01.x, q01.y, q01.z, q01.w};
+    float sq1j[4], sq01j[4];
+    strip_seq_sum8(sB1, sB2, n, lane, sq1j, sq01j);                      // :830-831, :834-835
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                                        // the neighbours in their own order, as the reference's loop visits them
       if (!okj[j]) continue;
@@ -158,6 +178,7 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
   return -1.f;
 }
 
+template <int M>
 __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
                                                   const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* __restrict__ depth,
                                                   float* __restrict__ normal, float* __restrict__ conf) {
@@ -169,13 +190,13 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
   const int py = (int)(e / cols), px = (int)(e % cols);
   const int n = pvlm_mvs::num_texels(half_window, step);
   float c = -1.f;
-  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE];
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
   float4* lds = strips[threadIdx.x >> 6];
-  PatchRegs P;
-  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
+  PatchRegs<M> P;
+  wave_fill_patch<M>(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
   if (P.inside && P.sq0 > 0) {   // InitConfMap :602 tests sq0 > 0 only (InitPatchMap ignores FillPixelPatch's 1e-6 verdict; that gate is PropagateCheckerBoard's, :1116)
     const float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
-    c = wave_score(rows, cols, half_window, step, n, lane, unit, nb, px, py, P, nrm3, dep, nullptr, 0, lds);
+    c = wave_score<M>(rows, cols, half_window, step, n, lane, unit, nb, px, py, P, nrm3, dep, nullptr, 0, lds);
   }
   if (lane == 0) {
     conf[e] = c;
@@ -185,13 +206,15 @@ __global__ __launch_bounds__(256) void k_mvs_conf(int rows, int cols, int half_w
 
 // PatchMatch sweep, one colour of the checkerboard (PropagateCheckerBoard :1098-1129): pixels of colour `offset` read
 // the depth / normal of the other colour and update their own, so one launch is race-free.
+template <int M>
 struct WaveScorer {
   int rows, cols, half_window, step, n, lane, px, py;
-  const float* unit; const pvlm_mvs_neighbours* nb; const PatchRegs* P; float4* lds;
+  const float* unit; const pvlm_mvs_neighbours* nb; const PatchRegs<M>* P; float4* lds;
   __device__ float operator()(const float* nrm3, float dep, const float* factors, int n_close) const {
-    return wave_score(rows, cols, half_window, step, n, lane, unit, *nb, px, py, *P, nrm3, dep, factors, n_close, lds);
+    return wave_score<M>(rows, cols, half_window, step, n, lane, unit, *nb, px, py, *P, nrm3, dep, factors, n_close, lds);
   }
 };
+template <int M>
 __global__ __launch_bounds__(256) void k_mvs_propagate(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
                                                        const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth, float* normal, float* conf,
                                                        const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth,
@@ -207,19 +230,38 @@ __global__ __launch_bounds__(256) void k_mvs_propagate(int rows, int cols, int h
   float dep = depth[e];
   if (dep <= 0) return;
   const int n = pvlm_mvs::num_texels(half_window, step);
-  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE];
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
   float4* lds = strips[threadIdx.x >> 6];
-  PatchRegs P;
-  wave_fill_patch(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
+  PatchRegs<M> P;
+  wave_fill_patch<M>(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
   if (!P.inside || P.sq0 <= 1e-6) return;                                 // patch.sq0 <= 1e-6 (:1116-1117; patches outside the margin have sq0 = 0)
   float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
   float c = conf[e];
   pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
   pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
-  WaveScorer scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
+  WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
   pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c);
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
+// launch helpers: M = 1 for windows of at most 64 texels (one texel per lane), M = PVLM_MVS_MAXM otherwise
+static void launch_mvs_conf(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
+                            const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf) {
+  const size_t npix = (size_t)rows * cols;
+  const dim3 grid((unsigned)((npix + 3) / 4)), block(256);
+  if (pvlm_mvs::num_texels(half_window, step) <= 64) hipLaunchKernelGGL(k_mvs_conf<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf);
+  else hipLaunchKernelGGL(k_mvs_conf<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf);
+}
+static void launch_mvs_propagate(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
+                                 const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, const unsigned char* depth_constant, float min_depth,
+                                 float max_depth, unsigned long long pass_seed, int offset) {
+  const size_t waves = (size_t)rows * (size_t)((cols + 1) / 2);
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (pvlm_mvs::num_texels(half_window, step) <= 64)
+    hipLaunchKernelGGL(k_mvs_propagate<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset);
+  else
+    hipLaunchKernelGGL(k_mvs_propagate<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset);
+}
+
 // MVS::InitDepthNormal (mvs/MVS.cpp:496-584, the `#elif 1` branch :511-514): LiDAR depth image (uint16, depth * 256) where it has a
 // value, a uniform random depth elsewhere, optional mask, a random normal facing the camera for every pixel the mask keeps.
 // Draw 0 of pixel e = its random depth, the following draws = GenerateRandomNormal (counter-based stream, as in the sweep).
@@ -455,14 +497,13 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
       hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_unit);
       if (max_iter < 0) {
         pvlm_prof_scope prof(ctx, 1);   // timed with the "materialise" slot of pvlm_profile_* (bench / tools)
-        hipLaunchKernelGGL(k_mvs_conf, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf);
+        launch_mvs_conf(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf);
       } else {
-        const size_t waves = (size_t)rows * (size_t)((cols + 1) / 2);
         for (int iter = 0; iter < max_iter; ++iter)
           for (int offset = 0; offset <= 1; ++offset) {
             pvlm_prof_scope prof(ctx, 1);
-            hipLaunchKernelGGL(k_mvs_propagate, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal,
-                               d_conf, d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
+            launch_mvs_propagate(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf, d_const, min_depth, max_depth,
+                                 pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
           }
         hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (long long)npix, d_const, conf_threshold, d_depth, d_normal, d_conf);
       }
@@ -701,15 +742,13 @@ pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, i
   if (e == hipSuccess) {
     if (max_iter < 0) {
       pvlm_prof_scope prof(ctx, 1);
-      hipLaunchKernelGGL(k_mvs_conf, dim3((unsigned)((v->npix + 3) / 4)), dim3(256), 0, s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o,
-                         v->d_normal + 3 * o, v->d_conf + o);
+      launch_mvs_conf(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o);
     } else {
-      const size_t waves = (size_t)v->rows * (size_t)((v->cols + 1) / 2);
       for (int iter = 0; iter < max_iter; ++iter)
         for (int offset = 0; offset <= 1; ++offset) {
           pvlm_prof_scope prof(ctx, 1);
-          hipLaunchKernelGGL(k_mvs_propagate, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb,
-                             v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o, d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
+          launch_mvs_propagate(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o, d_const,
+                               min_depth, max_depth, pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
         }
       hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, s, (long long)v->npix, d_const, conf_threshold, v->d_depth + o,
                          v->d_normal + 3 * o, v->d_conf + o);
