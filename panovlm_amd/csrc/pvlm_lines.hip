@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "pvlm_internal.h"
+#include "pvlm_exact_math.h"
 
 // ---- K4 -----------------------------------------------------------------------------------------
 // PointToLineDistance3D (base/Geometry.hpp:198-211), fp64, line = (point, direction).
@@ -117,11 +118,18 @@ __global__ void k_cam_to_image(int rows, int cols, long long n, const T* __restr
   if (i >= n) return;
   const T x = cam[3 * i], y = cam[3 * i + 1], z = cam[3 * i + 2];
   // CamToSphere: (FastAtan2(x, z), -FastAtan2(y, (T)sqrt(x*x + z*z)))   Equirectangular.h:50-51
-  const T lon = fast_atan2<T>(x, z);
-  const T lat = -fast_atan2<T>(y, (T)sqrt((double)(x * x + z * z)));
   // SphereToImage: cols * (0.5 + lon / (2 pi)), rows * (0.5 - lat / pi)   :84-85
-  px[2 * i] = (T)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
-  px[2 * i + 1] = (T)(rows * (0.5 - lat / 3.14159265358979323846));
+  if constexpr (sizeof(T) == 4) {     // float: same floats from cheaper sequences (pvlm_exact_math.h)
+    const float lon = fast_atan2<float>(x, z);
+    const float lat = -fast_atan2<float>(y, pvlm_exact::sqrt_via_double(x * x + z * z));
+    px[2 * i] = (float)(cols * (0.5 + pvlm_exact::div_two_pi(lon)));
+    px[2 * i + 1] = (float)(rows * (0.5 - pvlm_exact::div_pi(lat)));
+  } else {
+    const T lon = fast_atan2<T>(x, z);
+    const T lat = -fast_atan2<T>(y, (T)sqrt((double)(x * x + z * z)));
+    px[2 * i] = (T)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
+    px[2 * i + 1] = (T)(rows * (0.5 - lat / 3.14159265358979323846));
+  }
 }
 
 // sin and cos of a FLOAT argument, each the double-precision value rounded to float — what round 1 obtained from two calls
@@ -168,9 +176,9 @@ __global__ __launch_bounds__(256) void k_cam_to_image_f32x4(int rows, int cols, 
   for (int k = 0; k < 4; ++k) {
     const float x = p[3 * k], y = p[3 * k + 1], z = p[3 * k + 2];
     const float lon = fast_atan2<float>(x, z);
-    const float lat = -fast_atan2<float>(y, (float)sqrt((double)(x * x + z * z)));
-    o[2 * k] = (float)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
-    o[2 * k + 1] = (float)(rows * (0.5 - lat / 3.14159265358979323846));
+    const float lat = -fast_atan2<float>(y, pvlm_exact::sqrt_via_double(x * x + z * z));
+    o[2 * k] = (float)(cols * (0.5 + pvlm_exact::div_two_pi(lon)));
+    o[2 * k + 1] = (float)(rows * (0.5 - pvlm_exact::div_pi(lat)));
   }
   px[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
   px[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -233,9 +241,9 @@ __global__ __launch_bounds__(256) void k_depth_splat(int rows, int cols, long lo
 #pragma unroll
   for (int r = 0; r < 3; ++r) p[r] = (float)(T_cl[4 * r] * (double)x + T_cl[4 * r + 1] * (double)y + T_cl[4 * r + 2] * (double)z + T_cl[4 * r + 3]);
   const float lon = fast_atan2<float>(p[0], p[2]);
-  const float lat = -fast_atan2<float>(p[1], (float)sqrt((double)(p[0] * p[0] + p[2] * p[2])));
-  const float px = (float)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
-  const float py = (float)(rows * (0.5 - lat / 3.14159265358979323846));
+  const float lat = -fast_atan2<float>(p[1], pvlm_exact::sqrt_via_double(p[0] * p[0] + p[2] * p[2]));
+  const float px = (float)(cols * (0.5 + pvlm_exact::div_two_pi(lon)));
+  const float py = (float)(rows * (0.5 - pvlm_exact::div_pi(lat)));
   const int rbx = (int)(ceilf(px) + (float)half), rby = (int)(ceilf(py) + (float)half);
   const int ltx = (int)(floorf(px) - (float)half), lty = (int)(floorf(py) - (float)half);
   if (!(rbx >= 0 && rby >= 0 && rbx + 1 <= cols && rby + 1 <= rows)) return;

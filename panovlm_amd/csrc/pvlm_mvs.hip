@@ -214,8 +214,12 @@ struct WaveScorer {
     return wave_score<M>(rows, cols, half_window, step, n, lane, unit, *nb, px, py, *P, nrm3, dep, factors, n_close, lds);
   }
 };
+// M = 1: 169 VGPRs fall two registers short of three waves per SIMD; asking for three costs 2 spilled registers
+#ifndef PVLM_K13_WAVES
+#define PVLM_K13_WAVES 3
+#endif
 template <int M>
-__global__ __launch_bounds__(256) void k_mvs_propagate(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate(int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray,
                                                        const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth, float* normal, float* conf,
                                                        const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth,
                                                        unsigned long long pass_seed, int offset) {

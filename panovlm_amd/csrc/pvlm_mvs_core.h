@@ -2,6 +2,7 @@
 // FillPixelPatch :637-680 and the bilinear Sample).  Plain float arithmetic in the reference's order; host/device so
 // that tests/cpp/mvs_math_check.cpp can drive the same functions serially on a machine without a GPU.
 #pragma once
+#include "pvlm_exact_math.h"
 #include <cfloat>
 #include <cmath>
 
@@ -34,10 +35,12 @@ PVLM_HD inline float fast_atan2f(float y, float x) {
 
 // Equirectangular::CamToImage<float> (sensors/Equirectangular.h:50-51, :84-85)
 PVLM_HD inline void cam_to_image(int rows, int cols, const float* X, float* px) {
+  // the reference's statements are (float)sqrt((double)(..)), lon / (2.0 * pi), lat / pi in double: same floats, fewer
+  // instructions (pvlm_exact_math.h; the oracle keeps the statements as written)
   const float lon = fast_atan2f(X[0], X[2]);
-  const float lat = -fast_atan2f(X[1], (float)sqrt((double)(X[0] * X[0] + X[2] * X[2])));
-  px[0] = (float)(cols * (0.5 + lon / (2.0 * 3.14159265358979323846)));
-  px[1] = (float)(rows * (0.5 - lat / 3.14159265358979323846));
+  const float lat = -fast_atan2f(X[1], pvlm_exact::sqrt_via_double(X[0] * X[0] + X[2] * X[2]));
+  px[0] = (float)(cols * (0.5 + pvlm_exact::div_two_pi(lon)));
+  px[1] = (float)(rows * (0.5 - pvlm_exact::div_pi(lat)));
 }
 
 // Equirectangular::ImageToCam<float>(pixel, 1.f) of an integer pixel — the PreComputeI2C table (Equirectangular.cpp:12-19)

@@ -317,3 +317,14 @@ def test_patchmatch_helpers_against_numpy(oracle):
     ns = np.array(ns)
     assert abs(ns[:, 2].mean() + 0.5) < 0.06 and np.abs(ns[:, :2].mean(0)).max() < 0.1                      # uniform on the hemisphere: E[n.v] = -1/2
 
+
+
+def test_cheap_sequences_equal_the_reference_statements_for_every_float(tmp_path):
+    """panovlm_amd/csrc/pvlm_exact_math.h replaces x / pi, x / (2 pi) (double division of a promoted float) and
+    (float)sqrt((double)v) by cheaper sequences in the kernels; tests/cpp/exact_math_check.cpp walks all 2^32 float bit patterns
+    and counts the arguments for which the result differs from the reference's statement: none."""
+    exe = str(tmp_path / "exact_math_check")
+    subprocess.check_call(["g++", "-O2", "-march=native", "-fopenmp", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "cpp", "exact_math_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "division mismatches 0  sqrt mismatches 0" in out.stdout and "floats 4278190080" in out.stdout
