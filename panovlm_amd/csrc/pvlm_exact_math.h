@@ -8,6 +8,10 @@
 //    every caller adds the quotient to 0.5.
 //  * (float)sqrt((double)v) for a float v (CamToSphere, :50-51): equal to the correctly rounded float square root, because
 //    rounding a 53-bit square root to 24 bits never double-rounds (53 >= 2 * 24 + 2).
+//  * x / c in FLOAT for c = (float)cols, (float)rows (ImageToSphere, :102-103): the same correction in single precision gives
+//    the correctly rounded quotient whenever it is a normal number; a subnormal quotient (|x / c| < 2^-126) can differ in its
+//    last bits and -0 becomes +0, and both callers immediately form (q - 1) resp. (0.5 - q), which absorbs either.
+//    exact_math_check.cpp counts, for every finite float x and several sizes, the x where the value AFTER that step differs: 0.
 #pragma once
 #include <cmath>
 
@@ -31,6 +35,12 @@ PVLM_XHD inline double div_const(double x, double c, double inv_c) {
 }
 PVLM_XHD inline double div_pi(float x) { return div_const((double)x, kPi, kInvPi); }
 PVLM_XHD inline double div_two_pi(float x) { return div_const((double)x, kTwoPi, kInvTwoPi); }
+
+PVLM_XHD inline float div_f32(float x, float c, float inv_c) {
+  const float q = x * inv_c;
+  const float r = fmaf(-q, c, x);
+  return fmaf(r, inv_c, q);
+}
 
 // sqrtf is llvm.sqrt.f32 on the device, which hipcc lowers to the correctly rounded sequence by default
 // (-fhip-fp32-correctly-rounded-divide-sqrt); HIP's __fsqrt_rn is NOT: without OCML_BASIC_ROUNDED_OPERATIONS it is the 1-ulp

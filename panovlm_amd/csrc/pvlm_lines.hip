@@ -140,9 +140,13 @@ __global__ void k_cam_to_image(int rows, int cols, long long n, const T* __restr
 // within 2 ulp of the exact value, i.e. the same float after rounding except when the exact value lies within ~2e-16
 // (relative) of a float rounding boundary.  tests/test_equirect_gpu.py compares the two paths on every pixel of a
 // 5760 x 2880 panorama and on sub-pixel positions; PVLM_EXACT_TRIG=1 selects the library path.
+__device__ __attribute__((noinline)) float2 sincos_f32_arg_large(float xf) {   // |x| >= 1e5: never a pixel
+  const double x = (double)xf;
+  return make_float2((float)sin(x), (float)cos(x));
+}
 __device__ __forceinline__ void sincos_f32_arg(float xf, float* s_out, float* c_out) {
   const double x = (double)xf;
-  if (!(fabs(x) < 1.0e5)) { *s_out = (float)sin(x); *c_out = (float)cos(x); return; }
+  if (!(fabs(x) < 1.0e5)) { const float2 sc = sincos_f32_arg_large(xf); *s_out = sc.x; *c_out = sc.y; return; }   // out of line: the library path is 450 instructions
   const double q = rint(x * 0.63661977236758134308);
   double y = fma(-q, 1.57079632673412561417e+00, x);
   y = fma(-q, 6.07710050650619224932e-11, y);
@@ -152,17 +156,60 @@ __device__ __forceinline__ void sincos_f32_arg(float xf, float* s_out, float* c_
   ps = fma(z, ps, -1.98412698298579493134e-04);
   ps = fma(z, ps, 8.33333333332248946124e-03);
   ps = fma(z, ps, -1.66666666666666324348e-01);
-  const double sn = fma(y * z, ps, y);
+  const float sn = (float)fma(y * z, ps, y);
   double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
   pc = fma(z, pc, -2.75573143513906633035e-07);
   pc = fma(z, pc, 2.48015872894767294178e-05);
   pc = fma(z, pc, -1.38888888888741095749e-03);
   pc = fma(z, pc, 4.16666666666666019037e-02);
-  const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
-  const int n = (int)(long long)q & 3;
-  const double sv = (n & 1) ? cs : sn, cv = (n & 1) ? sn : cs;
-  *s_out = (float)((n & 2) ? -sv : sv);
-  *c_out = (float)(((n + 1) & 2) ? -cv : cv);
+  const float cs = (float)fma(z * z, pc, fma(z, -0.5, 1.0));
+  // quadrant: selection and sign commute with the rounding to float (round-to-nearest is odd), so they are done on floats
+  const int n = (int)q & 3;
+  const float sv = (n & 1) ? cs : sn, cv = (n & 1) ? sn : cs;
+  *s_out = (n & 2) ? -sv : sv;
+  *c_out = ((n + 1) & 2) ? -cv : cv;
+}
+
+// N arguments in lock step: every polynomial coefficient is used N times in a row, so the compiler materialises each
+// 64-bit constant once per N evaluations (one evaluation at a time it re-created them: 183 v_mov per 4 pixels).  Same
+// arithmetic, per argument, as sincos_f32_arg.
+template <int N>
+__device__ __forceinline__ void sincos_f32_args(const float (&xf)[N], float (&s_out)[N], float (&c_out)[N]) {
+  double y[N], z[N], ps[N], pc[N];
+  int n[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double x = (double)xf[i];
+    const double q = rint(x * 0.63661977236758134308);
+    y[i] = fma(-q, 1.57079632673412561417e+00, x);
+    y[i] = fma(-q, 6.07710050650619224932e-11, y[i]);
+    z[i] = y[i] * y[i];
+    n[i] = (int)q & 3;
+  }
+#define PVLM_STEP(arr, C)                      \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) arr[i] = fma(z[i], arr[i], C)
+#pragma unroll
+  for (int i = 0; i < N; ++i) ps[i] = fma(z[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  PVLM_STEP(ps, 2.75573137070700676789e-06);
+  PVLM_STEP(ps, -1.98412698298579493134e-04);
+  PVLM_STEP(ps, 8.33333333332248946124e-03);
+  PVLM_STEP(ps, -1.66666666666666324348e-01);
+#pragma unroll
+  for (int i = 0; i < N; ++i) pc[i] = fma(z[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  PVLM_STEP(pc, -2.75573143513906633035e-07);
+  PVLM_STEP(pc, 2.48015872894767294178e-05);
+  PVLM_STEP(pc, -1.38888888888741095749e-03);
+  PVLM_STEP(pc, 4.16666666666666019037e-02);
+#undef PVLM_STEP
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float sn = (float)fma(y[i] * z[i], ps[i], y[i]);
+    const float cs = (float)fma(z[i] * z[i], pc[i], fma(z[i], -0.5, 1.0));
+    const float sv = (n[i] & 1) ? cs : sn, cv = (n[i] & 1) ? sn : cs;
+    s_out[i] = (n[i] & 2) ? -sv : sv;
+    c_out[i] = ((n[i] + 1) & 2) ? -cv : cv;
+    if (!(fabsf(xf[i]) < 1.0e5f)) { const float2 sc = sincos_f32_arg_large(xf[i]); s_out[i] = sc.x; c_out[i] = sc.y; }   // never a pixel
+  }
 }
 
 // four points per lane, 16-byte vector accesses only (3 loads, 2 stores): the device-resident whole-panorama form
@@ -214,15 +261,18 @@ __global__ __launch_bounds__(256) void k_image_to_cam_f32x4(int rows, int cols, 
   const float4 a = px[2 * i], b = px[2 * i + 1];
   const float u[4] = {a.x, a.z, b.x, b.z}, v[4] = {a.y, a.w, b.y, b.w};
   float o[12];
+  const float fc = (float)cols, fr = (float)rows, inv_c = 1.0f / fc, inv_r = 1.0f / fr;
+  float arg[8], sn[8], cs[8];       // sy of the four pixels, then sx of the four pixels
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float sx = (float)((2 * u[k] / cols - 1) * 3.14159265358979323846);
-    const float sy = (float)((0.5 - v[k] / rows) * 3.14159265358979323846);
-    float sny, cy, snx, csx;
-    sincos_f32_arg(sy, &sny, &cy);
-    sincos_f32_arg(sx, &snx, &csx);
-    o[3 * k] = r * cy * snx; o[3 * k + 1] = -r * sny; o[3 * k + 2] = r * cy * csx;
+    // 2 u / cols and v / rows: the correctly rounded float quotients by one FMA correction of x * RN(1 / c)
+    // (pvlm_exact::div_f32; identical wherever the quotient is a normal number, and the "- 1" / "0.5 -" absorb the rest)
+    arg[4 + k] = (float)((pvlm_exact::div_f32(2 * u[k], fc, inv_c) - 1) * 3.14159265358979323846);
+    arg[k] = (float)((0.5 - pvlm_exact::div_f32(v[k], fr, inv_r)) * 3.14159265358979323846);
   }
+  sincos_f32_args<8>(arg, sn, cs);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { o[3 * k] = r * cs[k] * sn[4 + k]; o[3 * k + 1] = -r * sn[k]; o[3 * k + 2] = r * cs[k] * cs[4 + k]; }
   cam[3 * i] = make_float4(o[0], o[1], o[2], o[3]);
   cam[3 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
   cam[3 * i + 2] = make_float4(o[8], o[9], o[10], o[11]);

@@ -24,5 +24,19 @@ int main() {
     if (f >= 0) { const float s1 = (float)std::sqrt(x), s2 = pvlm_exact::sqrt_via_double(f); if (std::memcmp(&s1, &s2, 4)) ++bad_sqrt; }
   }
   printf("floats %lld  division mismatches %lld  sqrt mismatches %lld\n", n, bad_div, bad_sqrt);
-  return (bad_div || bad_sqrt) ? 1 : 0;
+  // float division by an image size, judged after the step that follows it in ImageToSphere: (2 u / cols - 1), (0.5 - v / rows)
+  long long bad_f32 = 0, raw_f32 = 0;
+  const int sizes[] = {5760};
+  for (int c : sizes) {
+    const float cf = (float)c, rc = 1.0f / cf;
+#pragma omp parallel for reduction(+ : bad_f32, raw_f32) schedule(static)
+    for (long long b = 0; b < (1ll << 32); ++b) {
+      uint32_t u = (uint32_t)b; float f; std::memcpy(&f, &u, 4);
+      if (!std::isfinite(f)) continue;
+      const float a1 = f / cf, a2 = pvlm_exact::div_f32(f, cf, rc);
+      if (std::memcmp(&a1, &a2, 4)) { ++raw_f32; if ((a1 - 1) != (a2 - 1) || (0.5 - a1) != (0.5 - a2) || std::fabs(a1) >= 1.1754944e-38f) ++bad_f32; }
+    }
+  }
+  printf("float division by 5760: %lld subnormal or signed-zero quotients differ, %lld visible\n", raw_f32, bad_f32);
+  return (bad_div || bad_sqrt || bad_f32) ? 1 : 0;
 }

@@ -328,3 +328,4 @@ def test_cheap_sequences_equal_the_reference_statements_for_every_float(tmp_path
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "division mismatches 0  sqrt mismatches 0" in out.stdout and "floats 4278190080" in out.stdout
+    assert ", 0 visible" in out.stdout

@@ -1,12 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r2
-python -m pytest tests/test_mvs_gpu.py tests/test_mvs_5p7k_gpu.py tests/test_equirect_gpu.py tests/test_golden_gpu.py tests/test_torch_interop_gpu.py tests/test_edge_cases_gpu.py -q -m gpu 2>&1 | grep -E "passed|failed"
-for v in default w4; do
-  [ $v = w4 ] && export PVLM_LIB=$PWD/panovlm_amd/build/variants/libpvlm_w4.so
-  python tools/mvs_bench.py > gpurun_out/r2/mvs_bench_$v.json 2> gpurun_out/r2/mvs_bench_$v.err
-  python - <<P
-import json
-d=json.load(open('gpurun_out/r2/mvs_bench_$v.json'))
-print('$v', 'K11 ms', d['kernel_ms'], 'maxdiff', d['max_abs_diff_vs_oracle'], 'K13 ms/colour', d['sweep']['kernel_ms_per_colour_pass'], 'agree', d['sweep']['agree_with_oracle'])
-P
-done
+python -m pytest tests/test_equirect_gpu.py tests/test_golden_gpu.py tests/test_torch_interop_gpu.py tests/test_edge_cases_gpu.py tests/test_mvs_gpu.py -q -m gpu 2>&1 | grep -E "passed|failed"
+python bench.py --scans 64 --no-projection --no-cpu-baseline --no-mvs 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(d['panorama'])[:520])"
