@@ -210,6 +210,28 @@ template <int M>
 struct WaveScorer {
   int rows, cols, half_window, step, n, lane, px, py;
   const float* unit; const pvlm_mvs_neighbours* nb; const PatchRegs<M>* P; float4* lds;
+  // close neighbour c's factor in lane c (mod 4): one evaluation of the two exp + one acos for the wave instead of four in a row
+  __device__ void smooth_factors(const float* plane, const pvlm_mvs::ClosePixel* close, int n_close, const float* normal, float depth, float* factors) const {
+    if (n_close <= 0) return;
+    const int c = lane & 3;
+    pvlm_mvs::ClosePixel mine = close[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (c == q) mine = close[q];                       // entries past n_close are zero-initialised and their factor is never read
+    const float f = pvlm_mvs::smooth_factor(plane, mine, normal, depth);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) factors[q] = lane_bcast(f, q);
+  }
+  // angle k in lane k (mod 4)
+  __device__ void sincos3(const float* a, float* sn, float* cs) const {
+    const int c = lane & 3;
+    float mine = a[0];
+    if (c == 1) mine = a[1];
+    if (c == 2) mine = a[2];
+    const float s = pvlm_mvs::f_sin(mine), co = pvlm_mvs::f_cos(mine);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { sn[k] = lane_bcast(s, k); cs[k] = lane_bcast(co, k); }
+  }
   __device__ float operator()(const float* nrm3, float dep, const float* factors, int n_close) const {
     return wave_score<M>(rows, cols, half_window, step, n, lane, unit, *nb, px, py, *P, nrm3, dep, factors, n_close, lds);
   }

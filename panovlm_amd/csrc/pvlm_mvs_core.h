@@ -361,12 +361,25 @@ PVLM_HD inline void correct_normal(const float* viewDir, float* normal) {
   }
 }
 
-PVLM_HD inline void perturb_normal(Rng& rng, const float* normal, float perturbation, float* out) {
+// The two pieces of wave-uniform transcendental arithmetic of a hypothesis — the smoothness factors of the (up to four) close
+// neighbours and the three sine / cosine pairs of a normal perturbation — go through the scorer object: on the host they are
+// the loops below; on the GPU, where a wave-uniform value costs a full wave instruction however few lanes need it, the wave
+// evaluates the four factors (resp. the three angles) in four (three) LANES at once and broadcasts them (WaveScorer in
+// pvlm_mvs.hip) — the same function on the same arguments, a quarter (third) of the instructions.
+struct SerialMath {
+  PVLM_HD void sincos3(const float* a, float* sn, float* cs) const { for (int k = 0; k < 3; ++k) { sn[k] = f_sin(a[k]); cs[k] = f_cos(a[k]); } }
+};
+
+template <class Math>
+PVLM_HD inline void perturb_normal(const Math& math, Rng& rng, const float* normal, float perturbation, float* out) {
   const float a1 = (rng.next01() - 0.5f) * perturbation;
   const float a2 = (rng.next01() - 0.5f) * perturbation;
   const float a3 = (rng.next01() - 0.5f) * perturbation;
-  const float sin_a1 = f_sin(a1), sin_a2 = f_sin(a2), sin_a3 = f_sin(a3);
-  const float cos_a1 = f_cos(a1), cos_a2 = f_cos(a2), cos_a3 = f_cos(a3);
+  const float ang[3] = {a1, a2, a3};
+  float sn3[3], cs3[3];
+  math.sincos3(ang, sn3, cs3);
+  const float sin_a1 = sn3[0], sin_a2 = sn3[1], sin_a3 = sn3[2];
+  const float cos_a1 = cs3[0], cos_a2 = cs3[1], cos_a3 = cs3[2];
   float R[9];
   R[0] = cos_a2 * cos_a3;
   R[1] = -cos_a2 * sin_a3;
@@ -410,6 +423,11 @@ PVLM_HD inline float smooth_factor(const float* plane, const ClosePixel& c, cons
   const float factorNormal = f_exp(diff_angle * diff_angle * smoothSigmaNormal);
   return (1.f - smoothBonusDepth * factorDepth) * (1.f - smoothBonusNormal * factorNormal);
 }
+struct SerialFactors {
+  PVLM_HD void smooth_factors(const float* plane, const ClosePixel* close, int n_close, const float* normal, float depth, float* factors) const {
+    for (int c = 0; c < n_close; ++c) factors[c] = smooth_factor(plane, close[c], normal, depth);
+  }
+};
 // applied to one neighbour image's clamped NCC (ScorePixel :843-857)
 PVLM_HD inline float smooth_score(float score, const float* factors, int n_close) {
   if (n_close <= 0) return score;
@@ -436,7 +454,7 @@ PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, 
   const size_t e = (size_t)py * cols + px;
   const bool keep_depth_constant = A.depth_constant && A.depth_constant[e];
   const float* view_ray = A.unit + 3 * e;
-  ClosePixel close[4]; int n_close = 0;
+  ClosePixel close[4] = {}; int n_close = 0;
   {
     const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
     for (int q = 0; q < 4; ++q) {
@@ -463,7 +481,7 @@ PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, 
       correct_normal(view_ray, normal_neighbor);
       const float X0[3] = {view_ray[0] * depth_neighbor, view_ray[1] * depth_neighbor, view_ray[2] * depth_neighbor};
       const float plane[4] = {normal_neighbor[0], normal_neighbor[1], normal_neighbor[2], -dot3(normal_neighbor, X0)};
-      for (int c = 0; c < n_close; ++c) factors[c] = smooth_factor(plane, close[c], normal_neighbor, depth_neighbor);
+      score.smooth_factors(plane, close, n_close, normal_neighbor, depth_neighbor, factors);
       const float newconf = score(normal_neighbor, depth_neighbor, factors, n_close);
       if (conf < newconf) { conf = newconf; depth = depth_neighbor; normal[0] = normal_neighbor[0]; normal[1] = normal_neighbor[1]; normal[2] = normal_neighbor[2]; }
     }
@@ -495,11 +513,11 @@ PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, 
   for (int iter = 0; iter < 6; iter++) {
     const float depth_perturb = perturb ? perturb_depth(rng, depth, scaleRange * depthRange) : depth;
     float normal_perturb[3];
-    perturb_normal(rng, normal, scaleRange * angleRange, normal_perturb);
+    perturb_normal(score, rng, normal, scaleRange * angleRange, normal_perturb);
     if (dot3(normal_perturb, view_ray) >= 0) continue;
     const float X0[3] = {view_ray[0] * depth_perturb, view_ray[1] * depth_perturb, view_ray[2] * depth_perturb};
     const float plane[4] = {normal_perturb[0], normal_perturb[1], normal_perturb[2], -dot3(normal_perturb, X0)};
-    for (int c = 0; c < n_close; ++c) factors[c] = smooth_factor(plane, close[c], normal_perturb, depth_perturb);
+    score.smooth_factors(plane, close, n_close, normal_perturb, depth_perturb, factors);
     const float nconf = score(normal_perturb, depth_perturb, factors, n_close);
     if (nconf > conf) {
       conf = nconf; depth = depth_perturb; normal[0] = normal_perturb[0]; normal[1] = normal_perturb[1]; normal[2] = normal_perturb[2];

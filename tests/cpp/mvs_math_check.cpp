@@ -120,7 +120,7 @@ void serial_fill_patch(const unsigned char* ref_gray, int rows, int cols, int px
   for (int k = 0; k < n; ++k) { P.w[k] /= wsum; mean += P.w[k] * P.t0[k]; }
   for (int k = 0; k < n; ++k) { P.t0[k] -= mean; const float tmp = P.t0[k] * P.w[k]; P.sq0 += P.t0[k] * tmp; P.t0[k] = tmp; }
 }
-struct SerialScorer {
+struct SerialScorer : pvlm_mvs::SerialMath, pvlm_mvs::SerialFactors {
   int rows, cols, half_window, step, px, py, n_neighbors;
   const float* unit; const unsigned char* const* nei_gray; const float* R_nr; const float* t_nr; const float* const* nei_depth; const SerialPatch* P;
   float operator()(const float* nr, float dep, const float* factors, int n_close) const {
@@ -185,7 +185,7 @@ extern "C" void chk_mvs_propagate(int rows, int cols, int half_window, int step,
         float c = conf[e];
         SweepArgs A{rows, cols, unit.data(), depth, normal, depth_constant, min_depth, max_depth};
         Rng rng{ps, (unsigned long long)e, 0u};
-        SerialScorer scorer{rows, cols, half_window, step, px, py, n_neighbors, unit.data(), nei_gray, R_nr, t_nr, nei_depth, &P};
+        SerialScorer scorer{{}, {}, rows, cols, half_window, step, px, py, n_neighbors, unit.data(), nei_gray, R_nr, t_nr, nei_depth, &P};
         process_pixel(A, rng, px, py, scorer, dep, nr, c);
         depth[e] = dep; normal[3 * e] = nr[0]; normal[3 * e + 1] = nr[1]; normal[3 * e + 2] = nr[2]; conf[e] = c;
       }
