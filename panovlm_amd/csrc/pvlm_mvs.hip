@@ -160,16 +160,44 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
     }
     float sq1j[4], sq01j[4];
     strip_seq_sum8(sB1, sB2, n, lane, sq1j, sq01j);                      // :830-831, :834-835
+    // NCC -> clamp -> smoothness -> (use_geometry) geometric-consistency adjustment of neighbour j in lane j (mod 4): the
+    // adjustment is ~600 wave-uniform instructions per neighbour (a projection, a depth sample, a back-projection with three
+    // double-evaluated sin / cos and an acos) — four lanes do the four neighbours of the pass in one go
+    const int jl = lane & 3;
+    float sq1 = sq1j[0], sq01 = sq01j[0]; bool okl = okj[0];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                                        // the neighbours in their own order, as the reference's loop visits them
-      if (!okj[j]) continue;
-      const float nrm = P.sq0 * sq1j[j];
-      if (nrm <= 0.f) continue;
-      float score = sq01j[j] / sqrtf(nrm);
+    for (int j = 1; j < 4; ++j)
+      if (jl == j) { sq1 = sq1j[j]; sq01 = sq01j[j]; okl = okj[j]; }
+    const float nrm = P.sq0 * sq1;
+    const bool valid = okl && !(nrm <= 0.f);                              // goto next_image / `if (nrm <= 0) continue`
+    float score = 0.f;
+    if (valid) {
+      score = sq01 / sqrtf(nrm);
       score = fminf(fmaxf(score, -1.f), 1.f);
       score = pvlm_mvs::smooth_score(score, factors, n_close);
-      if (nb.geometric) score = pvlm_mvs::geometric_adjust(score, rows, cols, X0, nb.R[b0 + j], nb.t[b0 + j], nb.depth[b0 + j]);   // wave-uniform
-      if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+      if (nb.geometric) {
+        float Rl[9], tl[3]; const float* dl = nb.depth[b0];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rl[k] = nb.R[b0][k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tl[k] = nb.t[b0][k];
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+          if (jl == j) {                                                 // b0 + j <= 15: inside the tables; a slot past nb.n is never `valid`
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rl[k] = nb.R[b0 + j][k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tl[k] = nb.t[b0 + j][k];
+            dl = nb.depth[b0 + j];
+          }
+        score = pvlm_mvs::geometric_adjust(score, rows, cols, X0, Rl, tl, dl);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                        // the neighbours in their own order, as the reference's loop visits them
+      if (!__builtin_amdgcn_readlane((int)valid, j)) continue;
+      const float sc = lane_bcast(score, j);
+      if (count == 0 || sc > best1) { best2 = best1; best1 = sc; } else if (count == 1 || sc > best2) best2 = sc;
       ++count;
     }
   }

@@ -75,6 +75,14 @@ def main():
     t0 = time.perf_counter()
     so = orc.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5)
     sweep_cpu = time.perf_counter() - t0
+    # the same iteration with the geometric-consistency term (use_geometry: the neighbours' depth maps; the call at mvs/MVS.cpp:137)
+    ctx.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5, nei_depths=nd)
+    ctx.profile_enable(True)
+    gg = ctx.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5, nei_depths=nd)
+    geo_ms, geo_cnt = ctx.profile_read(1)
+    ctx.profile_enable(False)
+    go = orc.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5, nei_depths=nd)
+    geo_same = bool(np.array_equal(gg[0], go[0]) and np.array_equal(gg[1], go[1]) and np.array_equal(gg[2], go[2]))
     vs = c0 > -1
     same = (np.abs(sg[0] - so[0]) <= 1e-4 * np.maximum(np.abs(so[0]), 1e-3)) & (np.abs(sg[1] - so[1]).max(axis=2) <= 1e-4) & (np.abs(sg[2] - so[2]) <= 1e-4)
     rel = lambda d: float(np.median(np.abs(d[vs] / depth[vs] - 1)))
@@ -92,6 +100,7 @@ def main():
                           sweep=dict(kernel_ms_per_colour_pass=sweep_ms / max(sweep_cnt, 1), colour_passes=int(sweep_cnt), wall_ms_one_iteration_incl_copies=sweep_wall * 1e3,
                                      cpu_oracle_s=sweep_cpu, agree_with_oracle=float(same[vs].mean()), mean_conf_gpu=float(sg[2][vs].mean()), mean_conf_oracle=float(so[2][vs].mean()),
                                      depth_err_before=rel(d1), depth_err_gpu=rel(sg[0]), depth_err_oracle=rel(so[0])),
+                          sweep_geometric=dict(kernel_ms_per_colour_pass=geo_ms / max(geo_cnt, 1), identical_to_oracle=geo_same),
                           cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
 
 
