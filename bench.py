@@ -608,7 +608,16 @@ def mvs_block(ctx, pv):
             res[name]["frac_of_hbm_peak"] = rows * cols * 29 * 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         out["%dx%d" % (cols, rows)] = res
         V.close()
-    out["bound"] = "VALU (sequential-order NCC sums + double-evaluated float exp / acos): HBM fraction is reported for completeness"
+    out["bound"] = "VALU: the kernels' roof is instruction issue, the HBM fraction is reported for completeness"
+    # SQ counters of the same kernels (tools/prof_r2_mvs_pmc.sh -> profiles/r2_pmc_mvs.json, separate --pmc pass of
+    # tools/mvs_bench.py): wave VALU instructions x 4 cycles / (1024 SIMDs x kernel time) = a lower bound of the VALU pipes' load
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_mvs.json")))
+        out["pmc"] = {"source": "profiles/r2_pmc_mvs.json",
+                      "kernels": {k: {f: v[f] for f in ("simd_valu_util_lower_bound", "valu_issue_frac", "wait_frac", "valu_insts_per_wave", "kernel_trace_ms") if f in v}
+                                  for k, v in pmc.items() if "k_mvs_conf" in k or "k_mvs_propagate" in k}}
+    except Exception:
+        out["pmc"] = None
     return out
 
 
