@@ -168,20 +168,39 @@ def main():
 
     # ---- the step: k_pose_table -> k_pair_table -> k_eval_fused -> k_pair_epilogue -> k_neq_gather (-> all-reduce) ----
     # Captured once as a HIP graph (pvlm_graph_*) and replayed: one submission per LM step instead of five launches
-    # (+ the collective).  For N > 1 the all-reduce goes through the library's own RCCL communicator on the SAME stream
-    # (pvlm_allreduce_sum_f64), inside the graph; PVLM_BENCH_COMM=torch keeps torch.distributed's eager all_reduce.
+    # (+ the collective) — optional (--graph on): a replayed graph measured SLOWER than the eager launches.
+    # Default: torch.distributed's communicator (backend "nccl" = RCCL), the path every multi-GPU PyTorch job exercises.
+    # PVLM_BENCH_COMM=pvlm routes the all-reduce through the library's own communicator (pvlm_comm_*, what the C++ hosts
+    # use) on the context stream instead; it is opt-in because no multi-GPU box was available to this repository's
+    # author to run it on (the 2-rank tests share one GPU, which RCCL refuses), and a collective that misbehaves hangs.
     comm, comm_mode = None, "none"
     if world > 1:
         comm_mode = "torch"
-        if not shared_gpu and os.environ.get("PVLM_BENCH_COMM", "pvlm") == "pvlm":
-            try:
-                ids = [ctx.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                comm = pv.Comm(ctx, world, rank, ids[0])
+        if not shared_gpu and os.environ.get("PVLM_BENCH_COMM", "torch") == "pvlm":
+            # every rank must take the same branch: the id travels even when rank 0 failed to make one, and the ranks agree on
+            # the outcome of the creation before anybody uses the communicator
+            ids = [None]
+            if rank == 0:
+                try:
+                    ids = [ctx.comm_unique_id()]
+                except Exception as e:
+                    sys.stderr.write("[bench] pvlm_comm_unique_id failed (%s)\n" % str(e)[:200])
+            dist.broadcast_object_list(ids, src=0)
+            made = 0
+            if ids[0] is not None:
+                try:
+                    comm = pv.Comm(ctx, world, rank, ids[0]); made = 1
+                except Exception as e:
+                    sys.stderr.write("[bench] pvlm_comm_create failed on rank %d (%s)\n" % (rank, str(e)[:200]))
+            flag = torch.tensor([made], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 comm_mode = "pvlm"
-            except Exception as e:  # keep the run alive on torch's communicator
-                sys.stderr.write("[bench] pvlm_comm unavailable (%s); using torch.distributed\n" % str(e)[:200])
+            else:
+                if comm is not None:
+                    comm.close()
                 comm = None
+                sys.stderr.write("[bench] pvlm_comm unavailable on some rank; using torch.distributed\n")
 
     use_graph = args.graph == "on"
 

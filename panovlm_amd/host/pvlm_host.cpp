@@ -327,7 +327,9 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
         float s = 0.0f; s += dx * dx; s += dy * dy; s += dz * dz;
         d[j] = {s, j};
       }
-      std::stable_sort(d.begin(), d.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+      // one sorted list serves both searches below: nearestKSearch (its first neighbor_size entries) and radiusSearch (its
+      // prefix within 20 m, also ascending) — ties in pcl's order = position
+      std::sort(d.begin(), d.end());
       for (int j = 0; j < std::min(neighbor_size, nc); ++j) neighbors.push_back(d[j].second);
       if (!neighbors.empty()) neighbors.erase(neighbors.begin());  // the first one is the scan itself
       for (int& n : neighbors) n = owner[n];
@@ -409,8 +411,14 @@ static inline double PlaneAngleN(const double* a, const double* b) {  // PlaneAn
 }
 
 // lidar_mapping/LidarFeatureAssociate.cpp:120-197; line_matrix row-major [nei segments x ref segments]
+static std::vector<Line2Line> FindAssociationsOn(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
+                                                 const std::vector<Vector6d>& nei_world, const int* line_matrix);
 std::vector<Line2Line> FindAssociations(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
                                         const std::vector<Vector6d>& nei_world, const std::vector<int>& line_matrix) {
+  return FindAssociationsOn(ref, nei, ref_world, nei_world, line_matrix.data());
+}
+static std::vector<Line2Line> FindAssociationsOn(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
+                                                 const std::vector<Vector6d>& nei_world, const int* line_matrix) {
   std::map<int, Line2Line> m;
   const int nr = (int)ref.edge_segmented.size(), nn = (int)nei.edge_segmented.size();
   for (int s = 0; s < nn && nr > 0; ++s) {
@@ -638,12 +646,15 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
             "pvlm_line2line_votes_batch");
   }
   StageTimer stage_timer_("  (inside) FindAssociations on the vote blocks (host)");
+  std::map<const Velodyne*, std::vector<Vector6d>> world;      // TransformLines(segment_coeffs, pose): once per scan of the batch, not per pair
+  auto world_of = [&](const Velodyne& v) -> const std::vector<Vector6d>& {
+    auto it = world.find(&v);
+    if (it == world.end()) it = world.emplace(&v, TransformLines(v.segment_coeffs, v.GetPose())).first;
+    return it->second;
+  };
   for (size_t j = 0; j < which.size(); ++j) {
     const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
-    const std::vector<Vector6d> nei_world = TransformLines(nei.segment_coeffs, nei.GetPose());
-    const std::vector<Vector6d> ref_world = TransformLines(ref.segment_coeffs, ref.GetPose());
-    const std::vector<int> v(votes.begin() + voff[j], votes.begin() + voff[j + 1]);
-    out[which[j]] = FindAssociations(ref, nei, ref_world, nei_world, v);
+    out[which[j]] = FindAssociationsOn(ref, nei, world_of(ref), world_of(nei), votes.data() + voff[j]);
   }
   return out;
 }
@@ -822,7 +833,6 @@ struct UnionFind {
 bool LidarLineMatch::GenerateTracks() {
   StageTimer stage_timer_("line tracks (associate + union-find)");
   std::vector<std::pair<size_t, size_t>> pairs;
-  std::vector<std::set<std::pair<uint32_t, uint32_t>>> feature_each_pair;
   const std::vector<std::vector<int>> neighbors = FindNeighbors(lidars_, neighbor_size_);
   std::vector<std::pair<const Velodyne*, const Velodyne*>> todo;   // the (ref, nei) arguments of AssociateLine2Line, :68
   for (size_t i = 0; i < neighbors.size(); i++) {
@@ -834,40 +844,48 @@ bool LidarLineMatch::GenerateTracks() {
     }
   }
   const std::vector<std::vector<Line2Line>> all_ass = AssociateLine2LineBatch(todo, 0.3f);   // one launch for the whole loop
-  for (const std::vector<Line2Line>& ass : all_ass) {
-    std::set<std::pair<uint32_t, uint32_t>> fp;
-    for (const Line2Line& a : ass) fp.insert({(uint32_t)a.neighbor_line_idx, (uint32_t)a.ref_line_idx});
-    feature_each_pair.push_back(fp);
+  // feature_each_pair: the (neighbour segment, reference segment) matches of every pair as a std::set orders them (sorted, unique)
+  typedef std::pair<uint32_t, uint32_t> Feature;      // (scan, segment)
+  std::vector<std::vector<Feature>> fpairs(all_ass.size());
+  for (size_t k = 0; k < all_ass.size(); ++k) {
+    std::vector<Feature>& fp = fpairs[k];
+    for (const Line2Line& a : all_ass[k]) fp.push_back({(uint32_t)a.neighbor_line_idx, (uint32_t)a.ref_line_idx});
+    std::sort(fp.begin(), fp.end()); fp.erase(std::unique(fp.begin(), fp.end()), fp.end());
   }
-  // TrackBuilder(true).Build
+  // TrackBuilder(true).Build — util/Tracks.cpp:58-196 with its std::set / std::map containers replaced by sorted vectors and
+  // dense tables: the same features in the same order (a set iterates in sorted order), the same unions in the same order
   StageTimer stage_timer_tb_("  (inside) TrackBuilder: union-find + filter + export (host)");
-  std::set<std::pair<uint32_t, uint32_t>> all;
+  std::vector<Feature> i2f;
   for (size_t i = 0; i < pairs.size(); i++)
-    for (const auto& mth : feature_each_pair[i]) { all.emplace((uint32_t)pairs[i].first, mth.first); all.emplace((uint32_t)pairs[i].second, mth.second); }
-  std::map<std::pair<uint32_t, uint32_t>, uint32_t> f2i;
-  std::vector<std::pair<uint32_t, uint32_t>> i2f;
-  for (const auto& f : all) { f2i.emplace(f, (uint32_t)i2f.size()); i2f.push_back(f); }
+    for (const Feature& mth : fpairs[i]) { i2f.push_back({(uint32_t)pairs[i].first, mth.first}); i2f.push_back({(uint32_t)pairs[i].second, mth.second}); }
+  std::sort(i2f.begin(), i2f.end()); i2f.erase(std::unique(i2f.begin(), i2f.end()), i2f.end());
+  auto f2i = [&](const Feature& f) { return (uint32_t)(std::lower_bound(i2f.begin(), i2f.end(), f) - i2f.begin()); };
   UnionFind uf;
   uf.Init((unsigned)i2f.size());
   for (size_t i = 0; i < pairs.size(); i++)
-    for (const auto& mth : feature_each_pair[i])
-      uf.Union(f2i[{(uint32_t)pairs[i].first, mth.first}], f2i[{(uint32_t)pairs[i].second, mth.second}]);
+    for (const Feature& mth : fpairs[i]) uf.Union(f2i({(uint32_t)pairs[i].first, mth.first}), f2i({(uint32_t)pairs[i].second, mth.second}));
   // Filter(min_track_length): a track must span at least min_track_length different scans
-  std::map<uint32_t, std::set<uint32_t>> members;
-  std::set<uint32_t> bad;
-  for (uint32_t i = 0; i < i2f.size(); i++) members[uf.Find(i)].insert(i2f[i].first);
-  for (const auto& kv : members) if (kv.second.size() < (size_t)min_track_length_) bad.insert(kv.first);
-  for (unsigned& root : uf.parent)
-    if (bad.count(root) > 0) { uf.size[root] = 1; root = std::numeric_limits<uint32_t>::max(); }
+  {
+    std::vector<std::pair<uint32_t, uint32_t>> root_scan(i2f.size());
+    for (uint32_t i = 0; i < i2f.size(); i++) root_scan[i] = {uf.Find(i), i2f[i].first};
+    std::sort(root_scan.begin(), root_scan.end()); root_scan.erase(std::unique(root_scan.begin(), root_scan.end()), root_scan.end());
+    std::vector<uint32_t> scans_of(i2f.size(), 0);
+    for (const auto& rs : root_scan) scans_of[rs.first]++;
+    std::vector<char> bad(i2f.size(), 0);
+    for (uint32_t r = 0; r < i2f.size(); r++) bad[r] = scans_of[r] > 0 && scans_of[r] < (uint32_t)min_track_length_;
+    // upstream walks the parent array once, testing each entry's CURRENT value (a root already invalidated no longer matches)
+    for (unsigned& root : uf.parent)
+      if (root != std::numeric_limits<uint32_t>::max() && bad[root]) { uf.size[root] = 1; root = std::numeric_limits<uint32_t>::max(); }
+  }
   // ExportTracks
-  std::map<uint32_t, size_t> t2i;
+  std::vector<int> t2i(i2f.size(), -1);
   tracks_.clear();
   for (uint32_t i = 0; i < i2f.size(); i++) {
     const uint32_t tid = uf.parent[i];
     if (tid != std::numeric_limits<uint32_t>::max() && uf.size[tid] > 1) {
-      auto it = t2i.find(tid);
-      if (it != t2i.end()) tracks_[it->second].feature_pairs.insert(i2f[i]);
-      else { t2i[tid] = tracks_.size(); LineTrack t; t.id = tid; t.feature_pairs.insert(i2f[i]); tracks_.push_back(t); }
+      if (t2i[tid] < 0) { t2i[tid] = (int)tracks_.size(); LineTrack t; t.id = tid; tracks_.push_back(t); }
+      std::set<Feature>& fs = tracks_[(size_t)t2i[tid]].feature_pairs;
+      fs.insert(fs.end(), i2f[i]);          // i2f is sorted: every insertion goes to the end
     }
   }
   for (size_t i = 0; i < tracks_.size(); i++) tracks_[i].id = (uint32_t)i;

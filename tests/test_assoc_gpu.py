@@ -230,3 +230,25 @@ def test_batched_scan_upload_equals_scan_by_scan(ctx, oracle):
         pv.Scan.upload_batch(ctx, [host[0], bad])
     for a in single:
         a.close()
+
+
+def test_knn_results_larger_than_the_staging_arena(ctx, oracle):
+    """Host<->device copies go through a 32 MB pinned arena in pieces of at most 16 MB; results are delivered to the caller's
+    buffers when the call synchronises.  900 k queries x 10 neighbours = 36 MB of indices + 36 MB of distances + an 11 MB
+    query upload: several wraps of the arena inside one call.  Checked against the oracle on a slice and against two half
+    calls everywhere."""
+    import panovlm_amd as pv
+    rng = np.random.default_rng(41)
+    tgt = (rng.normal(size=(4000, 3)) * 2).astype(np.float32)
+    q = (rng.normal(size=(900_000, 3)) * 2.1).astype(np.float32)
+    scan = pv.Scan(ctx, dict(id=0, less_xyz=tgt))
+    idx, sqd = ctx.knn(scan, q, 10, 1.0)
+    h = len(q) // 2
+    i1, d1 = ctx.knn(scan, q[:h], 10, 1.0); i2, d2 = ctx.knn(scan, q[h:], 10, 1.0)
+    assert np.array_equal(idx, np.concatenate([i1, i2])) and np.array_equal(sqd, np.concatenate([d1, d2]))
+    sel = slice(450_000 - 1500, 450_000 + 1500)                     # across the boundary of the copy pieces
+    oi, od = oracle.knn(tgt, q[sel], 10)
+    valid = od <= np.float32(1.0)
+    assert np.array_equal(idx[sel], np.where(valid, oi, -1)) and np.array_equal(sqd[sel], np.where(valid, od, np.float32(np.inf)))
+    assert (idx >= 0).mean() > 0.3
+    scan.close()

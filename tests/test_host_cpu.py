@@ -24,6 +24,31 @@ def test_find_neighbors_mirror_matches_golden():
     assert nb == [ids[off[i]:off[i + 1]].tolist() for i in range(len(poses))]
 
 
+def test_find_neighbors_loop_closures_match_oracle(oracle):
+    """FindNeighbors' second half (lidar_mapping/LidarFeatureAssociate.cpp:60-111): a 20 m radius search over ALL scan centres,
+    walked in ascending distance, adds the scans of an earlier pass through the same place (index gap > 200).  Trajectories that
+    come back to where they were — a figure of eight and a doubled circle, with invalid scans in between — against the oracle."""
+    rng = np.random.default_rng(5)
+    for F, shape in ((520, "circle"), (640, "eight")):
+        a = np.linspace(0, 2.3 * 2 * np.pi, F)                      # 2.3 turns: every place is visited two or three times
+        if shape == "circle":
+            c = np.stack([30 * np.cos(a), 30 * np.sin(a), 0.2 * np.sin(3 * a)], axis=1)
+        else:
+            c = np.stack([25 * np.sin(a), 18 * np.sin(2 * a), 0.1 * np.cos(a)], axis=1)
+        c += rng.normal(size=c.shape) * 0.05
+        valid = np.ones(F, np.int32); valid[rng.choice(F, 12, replace=False)] = 0
+        poses = np.zeros((F, 12)); poses[:, [0, 4, 8]] = 1.0; poses[:, 9:] = c
+        scans = [dict(id=i, valid=int(valid[i]), R_wl=np.eye(3), t_wl=c[i]) for i in range(F)]
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "n.bin")
+            host_io.write_scans(path, scans, world=False)
+            nb = [[int(v) for v in l.split()[2:]] for l in host_io.run("neighbors", path, 6)]
+        want = oracle.find_neighbors(poses, valid, 6)
+        assert nb == want
+        far = sum(1 for i, l in enumerate(want) for v in l if abs(v - i) > 200)
+        assert far > 100                                            # the loop-closure branch really fired
+
+
 def test_pose_file_roundtrip():
     rng = np.random.default_rng(4)
     with tempfile.TemporaryDirectory() as d:
