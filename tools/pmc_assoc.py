@@ -10,7 +10,8 @@ Per kernel (k_knn_pairs, k_fit_pairs, k_compact): counters summed over the dispa
                          instruction issued by the wave is one instruction of each of its queries)
   fetch bytes          = FETCH_SIZE KiB x 1024 (raw) and x 2 (the guide's correction for 16 B/lane streams; K2's
                          candidate loads are 16 B/lane but divergent, so the truth lies between the two)
-  compulsory ratio     = fetch bytes / ((Nq + Nt) x 16 B)."""
+  compulsory ratio     = fetch bytes / ((Nq + Nt) x 16 B)
+  simd_valu_util_lower_bound = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz): the roof of these kernels."""
 import collections
 import csv
 import glob
@@ -59,6 +60,10 @@ for k in sorted(agg):
         e["write_bytes"] = c["WRITE_SIZE"] * 1024; e["write_bytes_per_query"] = e["write_bytes"] / wl["queries"]
     if k in dur and dur[k]:
         e["kernel_trace_ms_per_call"] = sum(dur[k]) / calls
+        if "SQ_INSTS_VALU" in c:
+            # share of the chip's VALU issue capacity the kernel uses: a wave64 instruction occupies its SIMD16 for 4 cycles
+            # (fp64 and transcendental ones longer, so this is a LOWER bound), 1024 SIMDs at 2.4 GHz
+            e["simd_valu_util_lower_bound"] = c["SQ_INSTS_VALU"] * 4.0 / (1024 * e["kernel_trace_ms_per_call"] * 1e-3 * 2.4e9)
     res["kernels"][k] = e
 for k in sorted(dur):
     if k not in res["kernels"] and any(x in k for x in ("k_knn_pairs", "k_fit_pairs", "k_compact")):
