@@ -26,7 +26,9 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         drv = os.path.join(d, "driver_asan")
         subprocess.check_call(["g++"] + SAN + ["-ffp-contract=off", os.path.join(ROOT, "tests/cpp/pvlm_host_driver.cpp"), os.path.join(ROOT, "panovlm_amd/host/pvlm_host.cpp"),
-                               os.path.join(ROOT, "panovlm_amd/host/pvlm_features.cpp"), "-o", drv, "-L" + os.path.join(ROOT, "panovlm_amd"), "-lpvlm", "-pthread",
+                               os.path.join(ROOT, "panovlm_amd/host/pvlm_features.cpp"), os.path.join(ROOT, "panovlm_amd/host/pvlm_lines.cpp"),
+                               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests/cpp/ceres_double"),
+                               "-o", drv, "-L" + os.path.join(ROOT, "panovlm_amd"), "-lpvlm", "-pthread",
                                "-Wl,-rpath," + os.path.join(ROOT, "panovlm_amd")])
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
 
@@ -49,7 +51,7 @@ def main():
             with open(src, "wb") as f:
                 f.write(struct.pack("<i", len(c))); f.write(np.ascontiguousarray(c, np.float32).tobytes())
             for ns, hz, seg in ((16, 1800, 1), (16, 90, 0), (32, 360, 1), (64, 1800, 1)):
-                flagged += run("features", src, os.path.join(d, "o.bin"), ns, hz, 1000.0, 5.0, seg, 1)
+                flagged += run("features", src, os.path.join(d, "o.bin"), ns, hz, 1000.0, 5.0, seg, 1, 1)   # last 1: EdgeToLine too (the line branch)
         hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH %d\nHEIGHT 1\n"
                "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n")
         pts = (rng.normal(size=(5000, 4)) * 3).astype(np.float32)
