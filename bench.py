@@ -341,11 +341,35 @@ def main():
     # 5.7K equirectangular panorama (5760 x 2880): whole-image CamToImage / ImageToCam maps (K7) and the
     # camera<->LiDAR line-association voting loop (K8) for a Room-sized batch — reported beside the headline, never `value`
     pano = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         try:
             pano = panorama_block(ctx, pv, torch, dev)
         except Exception as e:  # reporting extra only
             pano = {"error": str(e)[:200]}
+    # N > 1: the image-space paths shard per view with no exchange at all (sharding.shard_views): every rank maps its own
+    # 5.7K panorama (K7) and runs the PatchMatch kernels on its own 5.7K view (K11, one K13 iteration); the job's rate is
+    # the sum of the ranks' rates.  Every rank takes part in the one all-reduce whatever happened to its measurement.
+    image_space = None
+    if world > 1:
+        local = [0.0, 0.0, 0.0, 0.0, 0.0]
+        try:
+            pb = panorama_block(ctx, pv, torch, dev, with_votes=False)
+            local[0] = pb["cam_to_image_f32"]["G_points_per_s"]; local[1] = pb["image_to_cam_f32"]["G_points_per_s"]
+            if not args.no_mvs:
+                mv = mvs_one_size(ctx, 2880, 5760, k13_reps=1)
+                local[2] = mv["k11_scoring_pass"]["M_pixels_per_s"]; local[3] = mv["k13_patchmatch_iteration"]["M_pixels_per_s"]
+            local[4] = 1.0
+        except Exception as e:  # reporting extra only
+            sys.stderr.write("[bench] rank %d: image-space block failed (%s)\n" % (rank, str(e)[:200]))
+        tsum = torch.tensor(local, dtype=torch.float64, device=dev)
+        dist.all_reduce(tsum)
+        if rank == 0:
+            v = tsum.tolist()
+            image_space = {"sharding": "one 5.7K view per rank, no exchange (weak scaling by construction)", "ranks_measured": int(round(v[4])),
+                           "cam_to_image_f32_G_points_per_s": v[0], "image_to_cam_f32_G_points_per_s": v[1],
+                           "cam_to_image_f32_frac_of_hbm_peak_per_gpu": v[0] * 20 / HBM_PEAK_GBPS / max(v[4], 1.0),
+                           "image_to_cam_f32_frac_of_hbm_peak_per_gpu": v[1] * 20 / HBM_PEAK_GBPS / max(v[4], 1.0),
+                           "mvs_k11_M_pixels_per_s": v[2], "mvs_k13_iteration_M_pixels_per_s": v[3], "rank0": {"cam_to_image_f32_G_points_per_s": local[0], "image_to_cam_f32_G_points_per_s": local[1]}}
 
     mvs = None
     if rank == 0 and world == 1 and not args.no_mvs:
@@ -408,6 +432,7 @@ def main():
             "pcie": pcie,
             "panorama": pano,
             "mvs": mvs,
+            "image_space_all_ranks": image_space,
             "setup": {"scan_generation_s": t_gen, "scans_generated": len(needed)},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -591,44 +616,11 @@ def mvs_block(ctx, pv):
     (InitConfMap), K13 = one checkerboard PatchMatch iteration (two colour passes), K12 = FilterDepthImageRefine.
     The NCC sums run in the reference's sequential order and the kernels are VALU-bound, so their roof is instruction
     issue, not HBM: the algorithmic HBM bytes (29 B per pixel and view touched) are reported next to the time."""
-    from panovlm_amd.api import MvsViews
     out = {}
     for rows, cols in ((720, 1440), (2880, 5760)):
-        yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
-        lon = (2 * xx / cols - 1) * np.pi; lat = (0.5 - yy / rows) * np.pi
-        ray = np.stack([np.cos(lat) * np.sin(lon), -np.sin(lat), np.cos(lat) * np.cos(lon)], axis=-1).astype(np.float32)
-        gray = np.clip(128 + 50 * np.sin(40 * lon) * np.cos(37 * lat) + 40 * np.sin(91 * lat + 13 * lon), 0, 255).astype(np.uint8)
-        depth = np.full((rows, cols), 3.0, np.float32)
-        normal = (-ray).astype(np.float32)
-        V = MvsViews(ctx, rows, cols, 3)
-        for v in range(3):
-            V.upload(v, gray=gray, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
-            V.snapshot_depth(v)
-        Rn = np.stack([np.eye(3, dtype=np.float32)] * 2); tn = np.array([[0.2, 0, 0], [-0.2, 0.01, 0.05]], np.float32)
-        ref, nei = 0, [1, 2]
-        res = {"pixels": rows * cols, "neighbours": 2, "window": "7x7"}
-        for name, fn, reps in (("k11_scoring_pass", lambda: V.estimate(ref, nei, Rn, tn, max_iter=-1), 3),
-                               ("k13_patchmatch_iteration", lambda: V.estimate(ref, nei, Rn, tn, max_iter=1, seed=3), 2),
-                               ("k12_fusion_filter_refine", lambda: V.filter_refine(ref, nei, Rn, tn), 3)):
-            fn(); ctx.synchronize()
-            V.upload(ref, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
-            if name.startswith("k13"):
-                V.estimate(ref, nei, Rn, tn, max_iter=-1)
-            ctx.synchronize()
-            ctx.timer_start()
-            for _ in range(reps):
-                fn()
-            ms = ctx.timer_stop() / reps
-            texels = rows * cols * 49 * 2
-            res[name] = {"ms": ms, "M_pixels_per_s": rows * cols / ms / 1e3}
-            if name.startswith("k11"):
-                res[name]["G_texel_projections_per_s"] = texels / ms / 1e6
-            res[name]["algorithmic_hbm_bytes"] = rows * cols * 29 * 3
-            res[name]["frac_of_hbm_peak"] = rows * cols * 29 * 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
-        out["%dx%d" % (cols, rows)] = res
-        V.close()
+        out["%dx%d" % (cols, rows)] = mvs_one_size(ctx, rows, cols)
     out["bound"] = "VALU: the kernels' roof is instruction issue, the HBM fraction is reported for completeness"
-    # SQ counters of the same kernels (tools/prof_r2_mvs_pmc.sh -> profiles/r2_pmc_mvs.json, separate --pmc pass of
+    # SQ counters of the same kernels (tools/prof_r2_final.sh -> profiles/r2_pmc_mvs.json, separate --pmc pass of
     # tools/mvs_bench.py): wave VALU instructions x 4 cycles / (1024 SIMDs x kernel time) = a lower bound of the VALU pipes' load
     try:
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_mvs.json")))
@@ -640,7 +632,45 @@ def mvs_block(ctx, pv):
     return out
 
 
-def panorama_block(ctx, pv, torch, dev):
+def mvs_one_size(ctx, rows, cols, k13_reps=2):
+    """One reference view against two resident neighbours at rows x cols: K11, one K13 iteration, K12 (see mvs_block)."""
+    from panovlm_amd.api import MvsViews
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    lon = (2 * xx / cols - 1) * np.pi; lat = (0.5 - yy / rows) * np.pi
+    ray = np.stack([np.cos(lat) * np.sin(lon), -np.sin(lat), np.cos(lat) * np.cos(lon)], axis=-1).astype(np.float32)
+    gray = np.clip(128 + 50 * np.sin(40 * lon) * np.cos(37 * lat) + 40 * np.sin(91 * lat + 13 * lon), 0, 255).astype(np.uint8)
+    depth = np.full((rows, cols), 3.0, np.float32)
+    normal = (-ray).astype(np.float32)
+    V = MvsViews(ctx, rows, cols, 3)
+    for v in range(3):
+        V.upload(v, gray=gray, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
+        V.snapshot_depth(v)
+    Rn = np.stack([np.eye(3, dtype=np.float32)] * 2); tn = np.array([[0.2, 0, 0], [-0.2, 0.01, 0.05]], np.float32)
+    ref, nei = 0, [1, 2]
+    res = {"pixels": rows * cols, "neighbours": 2, "window": "7x7"}
+    for name, fn, reps in (("k11_scoring_pass", lambda: V.estimate(ref, nei, Rn, tn, max_iter=-1), 3),
+                           ("k13_patchmatch_iteration", lambda: V.estimate(ref, nei, Rn, tn, max_iter=1, seed=3), k13_reps),
+                           ("k12_fusion_filter_refine", lambda: V.filter_refine(ref, nei, Rn, tn), 3)):
+        fn(); ctx.synchronize()
+        V.upload(ref, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
+        if name.startswith("k13"):
+            V.estimate(ref, nei, Rn, tn, max_iter=-1)
+        ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        texels = rows * cols * 49 * 2
+        res[name] = {"ms": ms, "M_pixels_per_s": rows * cols / ms / 1e3}
+        if name.startswith("k11"):
+            res[name]["G_texel_projections_per_s"] = texels / ms / 1e6
+        res[name]["algorithmic_hbm_bytes"] = rows * cols * 29 * 3
+        res[name]["frac_of_hbm_peak"] = rows * cols * 29 * 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    V.close()
+    return res
+
+
+def panorama_block(ctx, pv, torch, dev, with_votes=True):
     rows, cols = 2880, 5760
     n = rows * cols
     g = torch.Generator(device=dev); g.manual_seed(5)
@@ -657,6 +687,8 @@ def panorama_block(ctx, pv, torch, dev):
         ms = ctx.timer_stop() / reps
         out[name] = {"kernel_ms": ms, "G_points_per_s": n / ms / 1e6, "GBps": n * nbytes / ms / 1e6, "bytes_per_point": nbytes,
                      "frac_of_hbm_peak": n * nbytes / ms / 1e6 / HBM_PEAK_GBPS}
+    if not with_votes:
+        return out
     # camera<->LiDAR voting: 454 frames x 3 neighbouring scans (Room, neighbor_size_joint = 3), 200 image lines per
     # panorama, 1500 corner points in 40 segments per scan
     rng = np.random.default_rng(11)
