@@ -124,8 +124,7 @@ static pvlm_status ba_ready(pvlm_ctx* ctx, const pvlm_baset* s) {
 
 template <typename T>
 static pvlm_status h2d(pvlm_ctx* ctx, T* dst, const T* src, size_t n) {
-  if (n) PVLM_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-  return PVLM_OK;
+  return n ? pvlm_i_h2d_q(ctx, dst, src, n * sizeof(T)) : PVLM_OK;     // through the pinned staging arena
 }
 
 extern "C" {
@@ -223,9 +222,8 @@ int64_t pvlm_ba_packed_size(const pvlm_baset* set) { return set ? (int64_t)pvlm_
 pvlm_status pvlm_ba_get_points(pvlm_ctx* ctx, const pvlm_baset* set, int candidate, double* points) {
   if (!ctx || !set || !points) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  if (set->n_points) PVLM_HIP(ctx, hipMemcpyAsync(points, candidate ? set->d_Xc : set->d_X, (size_t)set->n_points * 24, hipMemcpyDeviceToHost, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PVLM_OK;
+  if (set->n_points) { const pvlm_status st = pvlm_i_d2h_q(ctx, points, candidate ? set->d_Xc : set->d_X, (size_t)set->n_points * 24); if (st) return st; }
+  return pvlm_i_sync(ctx);
 }
 
 pvlm_status pvlm_ba_set_points(pvlm_ctx* ctx, pvlm_baset* set, const double* points) {
@@ -265,12 +263,12 @@ pvlm_status pvlm_ba_eval(pvlm_ctx* ctx, const pvlm_baset* set, double* r, double
   const pvlm_ba::View v = make_view(set, 0, 0.0);
   hipLaunchKernelGGL(k_ba_eval, dim3((unsigned)((set->n_obs + 255) / 256)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, d_r, d_J);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(r, d_r, (size_t)set->n_obs * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && J) e = hipMemcpyAsync(J, d_J, (size_t)set->n_obs * 72, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_ba_eval: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  if (!st) st = pvlm_i_d2h_q(ctx, r, d_r, (size_t)set->n_obs * 8);
+  if (!st && J) st = pvlm_i_d2h_q(ctx, J, d_J, (size_t)set->n_obs * 72);
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
   pvlm_i_free(ctx, d_r); pvlm_i_free(ctx, d_J);
-  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_ba_eval: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
-  return PVLM_OK;
+  return st;
 }
 
 pvlm_status pvlm_ba_reduce(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double a, int init_scale, double radius, double min_diag,
@@ -294,8 +292,7 @@ pvlm_status pvlm_ba_reduce(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, doubl
     hipLaunchKernelGGL(k_ba_obs, dim3((unsigned)((set->n_obs + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_packed, d_cost);
     PVLM_HIP(ctx, hipGetLastError());
   }
-  PVLM_HIP(ctx, hipMemcpyAsync(packed, set->d_packed, psz * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((st = pvlm_i_d2h(ctx, packed, set->d_packed, psz * 8))) return st;      // 1.2 MB at Room scale, every LM step: pinned arena, not a pageable copy
   if (init_scale) set->scaled = true;
   set->reduced = true; set->reduced_epoch = ctx->pose_epoch;
   return PVLM_OK;
@@ -317,8 +314,7 @@ pvlm_status pvlm_ba_step(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double 
     hipLaunchKernelGGL(k_ba_step, dim3((unsigned)((set->n_points + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_dcam, set->d_small);
     PVLM_HIP(ctx, hipGetLastError());
   }
-  PVLM_HIP(ctx, hipMemcpyAsync(out3, set->d_small, 24, hipMemcpyDeviceToHost, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((st = pvlm_i_d2h(ctx, out3, set->d_small, 24))) return st;
   set->have_candidate = true;
   return PVLM_OK;
 }
@@ -335,9 +331,7 @@ pvlm_status pvlm_ba_cost(pvlm_ctx* ctx, const pvlm_baset* set, pvlm_loss loss, d
     hipLaunchKernelGGL(k_ba_cost, dim3((unsigned)((set->n_obs + 255) / 256)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, candidate, set->d_small);
     PVLM_HIP(ctx, hipGetLastError());
   }
-  PVLM_HIP(ctx, hipMemcpyAsync(cost, set->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PVLM_OK;
+  return pvlm_i_d2h(ctx, cost, set->d_small, 8);
 }
 
 pvlm_status pvlm_ba_accept(pvlm_ctx* ctx, pvlm_baset* set) {

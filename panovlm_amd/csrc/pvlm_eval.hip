@@ -574,13 +574,10 @@ pvlm_status pvlm_eval(pvlm_ctx* ctx, const pvlm_resset* rs, double* r, double* J
   pvlm_status st = pvlm_i_alloc(ctx, &d_r, (size_t)rs->n);
   if (!st && J) st = pvlm_i_alloc(ctx, &d_J, (size_t)rs->n * 12);
   if (!st) st = pvlm_eval_dev(ctx, rs, d_r, d_J);
-  if (!st) {
-    hipError_t e = hipMemcpyAsync(r, d_r, (size_t)rs->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && J) e = hipMemcpyAsync(J, d_J, (size_t)rs->n * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_eval copy-back: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
-  }
-  hipStreamSynchronize(ctx->stream);
+  // the caller's r / J are ordinary (pageable) arrays: staged through the pinned arena in 16 MB pieces
+  if (!st) st = pvlm_i_d2h_q(ctx, r, d_r, (size_t)rs->n * sizeof(double));
+  if (!st && J) st = pvlm_i_d2h_q(ctx, J, d_J, (size_t)rs->n * 12 * sizeof(double));
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
   pvlm_i_free(ctx, d_r); pvlm_i_free(ctx, d_J);
   return st;
 }

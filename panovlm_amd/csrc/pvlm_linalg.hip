@@ -79,7 +79,123 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, int 
   if (live) M[(size_t)row * n + k0 + c] = x;
 }
 
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info) {
+__device__ __forceinline__ double bcast_f64(double v, int src_lane) {     // v of lane src_lane (wave-uniform source) for every lane
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Diagonal block + panel in ONE launch (round 2): every workgroup of the panel factorises the 32 x 32 diagonal block itself —
+// redundantly, from the same input — and then multiplies its eight panel rows by the inverse it has just computed.  The
+// factorisation is a dependent chain (32 pivots) that takes as long in 600 workgroups side by side as in one, so the
+// separate k_chol_diag launch (24 us + a launch gap per block column, 171 block columns at n = 5442) disappears.  The chain
+// itself is run by ONE wave out of registers: lane i owns row i, pivots and column entries cross lanes by v_readlane, then
+// L^-1 column by column (lane c solves L x = e_c).  (A first version kept the block in LDS and paid two LDS round trips per
+// update element: 50 us per block column, slower than the two launches it replaced.)  Workgroup 0 stores the inverse for the triangular solves.  M's diagonal block keeps A's
+// values (nothing downstream reads L_kk: the update uses the panel, the solves use the inverses).
+// fwd_b != nullptr: the forward substitution of ONE right-hand side rides along — workgroup 0 also forms y_k = L_kk^-1 b_k
+// (b_k is final: every earlier block column's update has been applied), and the trailing-update launch of this block column
+// subtracts L[j, k] y_k from the rows below (k_chol_fwd_rows): the 171 k_fwd_step launches of round 1 disappear.
+__global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M, int n, int k0, int kb, double* __restrict__ Linv, int* __restrict__ info,
+                                                         int* __restrict__ fail_out, const double* __restrict__ fwd_b, double* __restrict__ fwd_y) {
+  __shared__ double a[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double As[8][PVLM_CHOL_NB + 1];
+  __shared__ int fail;
+  if (*info != 0) return;
+  const int t = threadIdx.x;
+  if (t == 0) fail = 0;
+  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
+    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
+    a[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+    inv[i][j] = 0.0;
+  }
+  const int lr = t / PVLM_CHOL_NB, c = t % PVLM_CHOL_NB;
+  const int row = k0 + kb + blockIdx.x * 8 + lr;
+  const bool live = row < n && c < kb;
+  As[lr][c] = live ? M[(size_t)row * n + k0 + c] : 0.0;
+  __syncthreads();
+  if (t < 64) {
+    // One wave, no LDS and no barrier inside the chain: lane i keeps ROW i of the block in registers (fully unrolled, so
+    // every register index is a compile-time constant); the pivot and the column entries l_cj a lane needs from another
+    // lane travel by v_readlane with a constant source lane.
+    const int i = t & (PVLM_CHOL_NB - 1);
+    double r[PVLM_CHOL_NB], x[PVLM_CHOL_NB];
+#pragma unroll
+    for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) { r[cc] = a[i][cc]; x[cc] = 0.0; }
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < PVLM_CHOL_NB; ++j) {
+      if (j < kb && !bad) {                                   // wave-uniform
+        const double d = bcast_f64(r[j], j);
+        if (!(d > 0.0)) bad = j + 1;
+        else {
+          const double sd = sqrt(d);
+          const double lij = r[j] / sd;                       // meaningful in the lanes below the pivot
+#pragma unroll
+          for (int cc = j + 1; cc < PVLM_CHOL_NB; ++cc) {
+            const double lcj = bcast_f64(lij, cc);
+            if (i > j && cc <= i) r[cc] -= lij * lcj;
+          }
+          if (i > j) r[j] = lij; else if (i == j) r[j] = sd;
+        }
+      }
+    }
+    if (bad) { if (t == 0) fail = bad; }
+    else {
+      // L^-1 column by column: lane c solves L x = e_c, x_q = -(sum_{k = c}^{q-1} l_qk x_k) / l_qq; l_qk lives in lane q
+#pragma unroll
+      for (int q = 0; q < PVLM_CHOL_NB; ++q) {
+        if (q < kb) {                                         // wave-uniform
+          double sacc = 0.0;
+#pragma unroll
+          for (int k = 0; k < q; ++k) {
+            const double lqk = bcast_f64(r[k], q);
+            if (k >= i) sacc += lqk * x[k];
+          }
+          const double lqq = bcast_f64(r[q], q);
+          x[q] = q == i ? 1.0 / lqq : (q > i ? -sacc / lqq : 0.0);
+        }
+      }
+      if (t < PVLM_CHOL_NB && i < kb) {
+#pragma unroll
+        for (int q = 0; q < PVLM_CHOL_NB; ++q) inv[q][i] = x[q];
+      }
+    }
+  }
+  __syncthreads();
+  if (fail) { if (t == 0 && blockIdx.x == 0) { *fail_out = k0 + fail; } return; }
+  if (blockIdx.x == 0) {
+    double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
+    for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) Lk[e] = inv[e / PVLM_CHOL_NB][e % PVLM_CHOL_NB];
+    if (fwd_b && t < kb) {
+      double sacc = 0.0;
+      for (int d = 0; d <= t; ++d) sacc += inv[t][d] * fwd_b[k0 + d];
+      fwd_y[k0 + t] = sacc;
+    }
+  }
+  double x = 0.0;
+  for (int d = 0; d <= c; ++d) x += As[lr][d] * inv[c][d];
+  if (live) M[(size_t)row * n + k0 + c] = x;
+}
+
+// b[i] -= L[i, k-block] . y_k for the rows below block column k (the second half of round 1's k_fwd_step), run by the
+// workgroups past the tile list of the trailing-update launches
+__device__ __forceinline__ void chol_fwd_rows(const double* __restrict__ M, int n, int k0, int kb, int chunk, double* __restrict__ b, const double* __restrict__ yv) {
+  __shared__ double y[PVLM_CHOL_NB];
+  const int t = threadIdx.x;
+  if (t < PVLM_CHOL_NB) y[t] = t < kb ? yv[k0 + t] : 0.0;
+  __syncthreads();
+  const int i = k0 + kb + chunk * 256 + t;
+  if (i >= n) return;
+  const double* r = M + (size_t)i * n + k0;
+  double sacc = 0.0;
+  for (int c = 0; c < kb; ++c) sacc += r[c] * y[c];
+  b[i] -= sacc;
+}
+
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info,
+                                                     int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y) {
+  if ((int)blockIdx.x >= n_tile_blocks) { if (*info == 0) chol_fwd_rows(M, n, k0, kb, (int)blockIdx.x - n_tile_blocks, fwd_b, fwd_y); return; }
   __shared__ double As[64][PVLM_CHOL_NB + 1];
   __shared__ double Bs[64][PVLM_CHOL_NB + 1];
   if (*info != 0) return;
@@ -126,10 +242,12 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int
 // panel row of the column tile) from LDS, four MFMAs.  D layout of the f64 form: col = lane & 15,
 // row = (lane >> 4) + 4 * reg (cdna_hip_programming.md §3) — not the f32 map.
 typedef double pvlm_d4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info) {
+__global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info,
+                                                          int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y) {
   __shared__ double As[64][PVLM_CHOL_NB + 1];
   __shared__ double Bs[64][PVLM_CHOL_NB + 1];
   if (*info != 0) return;
+  if ((int)blockIdx.x >= n_tile_blocks) { chol_fwd_rows(M, n, k0, kb, (int)blockIdx.x - n_tile_blocks, fwd_b, fwd_y); return; }
   int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
   while ((long long)(ti + 1) * (ti + 2) / 2 <= (long long)blockIdx.x) ++ti;
   while ((long long)ti * (ti + 1) / 2 > (long long)blockIdx.x) --ti;
@@ -222,22 +340,33 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
 static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, double* d_Linv, double* d_y, int* d_info) {
   hipStream_t s = ctx->stream;
   static const bool use_mfma = getenv("PVLM_CHOL_VALU") == nullptr;   // PVLM_CHOL_VALU=1: the register-tiled VALU update (measured variant)
+  static const bool fused = getenv("PVLM_CHOL_SPLIT") == nullptr;      // PVLM_CHOL_SPLIT=1: round 1's launch structure (k_chol_diag, k_chol_panel, k_fwd_step)
+  const bool ride = fused && nrhs >= 1;                                // the first right-hand side's forward substitution rides along
   for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
     const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
+    if (fused) {
+      // a failed pivot: every workgroup finds it itself (same arithmetic on the same block) and returns; workgroup 0 records it
+      // in *info, which the later launches test on entry
+      hipLaunchKernelGGL(k_chol_diag_panel, dim3(std::max(1, (rem + 7) / 8)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info, d_info,
+                         ride ? (const double*)d_B : nullptr, d_y);
+    } else {
+      hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
+      if (rem > 0) hipLaunchKernelGGL(k_chol_panel, dim3((rem + 7) / 8), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
+    }
     if (rem > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3((rem + 7) / 8), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
       const int tiles = (rem + 63) / 64;
-      if (use_mfma) hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
-      else hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((long long)tiles * (tiles + 1) / 2)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info);
+      const int tile_blocks = (int)((long long)tiles * (tiles + 1) / 2), fwd_blocks = ride ? (rem + 255) / 256 : 0;
+      if (use_mfma) hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y);
+      else hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y);
     }
   }
   for (int r = 0; r < nrhs; ++r) {
     double* b = d_B + (size_t)r * n;
-    for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
-      const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
-      hipLaunchKernelGGL(k_fwd_step, dim3(std::max(1, (rem + 255) / 256)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, b, d_y, d_info);
-    }
+    if (!(ride && r == 0))
+      for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
+        const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
+        hipLaunchKernelGGL(k_fwd_step, dim3(std::max(1, (rem + 255) / 256)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, b, d_y, d_info);
+      }
     for (int k0 = ((n - 1) / PVLM_CHOL_NB) * PVLM_CHOL_NB; k0 >= 0; k0 -= PVLM_CHOL_NB) {
       const int kb = std::min(PVLM_CHOL_NB, n - k0);
       hipLaunchKernelGGL(k_bwd_step, dim3(std::max(1, (k0 + 255) / 256)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, b, d_y, d_info);

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(64) void k_line_rows(const pvlm_match_desc* __restr
 // ---- K7 -----------------------------------------------------------------------------------------
 // FastAtan2 (base/Math.h:15-29).  For T = float the polynomial is evaluated in double (double
 // literals) and rounded to float on assignment, as are M_PI_2 - r and M_PI - r.
+// host <-> device copies through the context's pinned staging arena; downloads reach the caller's buffer at ln_sync
+static inline hipError_t ln_up(pvlm_ctx* ctx, void* d, const void* h, size_t bytes) { return pvlm_i_h2d_q(ctx, d, h, bytes) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t ln_down(pvlm_ctx* ctx, void* h, const void* d, size_t bytes) { return pvlm_i_d2h_q(ctx, h, d, bytes) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t ln_sync(pvlm_ctx* ctx) { return pvlm_i_sync(ctx) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
+
 template <typename T>
 __device__ __forceinline__ T fast_atan2(T y, T x) {
   const T ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;  // std::abs
@@ -427,13 +432,13 @@ static pvlm_status run_map(pvlm_ctx* ctx, long long n, const T* in, int in_w, T*
   pvlm_status st = pvlm_i_alloc(ctx, &d_in, (size_t)n * in_w);
   if (!st) st = pvlm_i_alloc(ctx, &d_out, (size_t)n * out_w);
   if (!st) {
-    hipError_t e = hipMemcpyAsync(d_in, in, (size_t)n * in_w * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = ln_up(ctx, d_in, in, (size_t)n * in_w * sizeof(T));
     if (e == hipSuccess) { launch(d_in, d_out); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * out_w * sizeof(T), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ln_down(ctx, out, d_out, (size_t)n * out_w * sizeof(T));
+    if (e == hipSuccess) e = ln_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "equirect map: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  ln_sync(ctx);
   pvlm_i_free(ctx, d_in); pvlm_i_free(ctx, d_out);
   return st;
 }
@@ -478,8 +483,8 @@ pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t 
   if (!st) st = pvlm_i_alloc(ctx, &d_out, npix);
   if (!st) {
     hipError_t e = hipMemsetAsync(d_img, 0, npix * sizeof(unsigned long long), ctx->stream);
-    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_T, T_cl, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n > 0) e = ln_up(ctx, d_xyz, xyz, (size_t)n * 3 * sizeof(float));
+    if (e == hipSuccess) e = ln_up(ctx, d_T, T_cl, 16 * sizeof(double));
     if (e == hipSuccess && n > 0) {
       hipLaunchKernelGGL(k_depth_splat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rows, cols, (long long)n, d_xyz, d_T, (int)(size / 2), d_img);
       e = hipGetLastError();
@@ -488,11 +493,11 @@ pvlm_status pvlm_project_lidar_depth(pvlm_ctx* ctx, int rows, int cols, int64_t 
       hipLaunchKernelGGL(k_depth_finish, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, (long long)npix, d_img, d_out);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(depth, d_out, npix * sizeof(unsigned short), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ln_down(ctx, depth, d_out, npix * sizeof(unsigned short));
+    if (e == hipSuccess) e = ln_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "project_lidar_depth: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  ln_sync(ctx);
   pvlm_i_free(ctx, d_xyz); pvlm_i_free(ctx, d_T); pvlm_i_free(ctx, d_img); pvlm_i_free(ctx, d_out);
   return st;
 }
@@ -699,7 +704,7 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
   if (!st) st = pvlm_i_resset_finalize(ctx, rs);     // synchronises: the staging vectors above may go
   pvlm_i_trace("line2line_residuals: finalize (sync)");
   pvlm_i_free(ctx, d_md); pvlm_i_free(ctx, d_po);
-  if (st) { hipStreamSynchronize(ctx->stream); pvlm_i_resset_free(ctx, rs); return st; }
+  if (st) { ln_sync(ctx); pvlm_i_resset_free(ctx, rs); return st; }
   *out = rs;
   return PVLM_OK;
 }
@@ -752,7 +757,7 @@ pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm
   pvlm_status st = pvlm_i_alloc(ctx, &d_l, lw.size());
   if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)nr * nn);
   if (!st) {
-    hipError_t e = hipMemcpyAsync(d_l, lw.data(), lw.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = ln_up(ctx, d_l, lw.data(), lw.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(d_v, 0, (size_t)nr * nn * sizeof(int), ctx->stream);
     if (e == hipSuccess) {
       const long long tot = (long long)nc * nr;
@@ -760,11 +765,11 @@ pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm
                          nei->d_p2s_ids, nr, d_l, (double)dist_threshold, d_v);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(votes, d_v, (size_t)nr * nn * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ln_down(ctx, votes, d_v, (size_t)nr * nn * sizeof(int));
+    if (e == hipSuccess) e = ln_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "line votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  ln_sync(ctx);
   pvlm_i_free(ctx, d_l); pvlm_i_free(ctx, d_v);
   return st;
 }
@@ -784,8 +789,8 @@ pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float*
   if (!st) st = pvlm_i_alloc(ctx, &d_T, 16);
   if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)n_lines * ns);
   if (!st) {
-    hipError_t e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_T, T_cl, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = ln_up(ctx, d_tab, tab.data(), tab.size() * sizeof(double));
+    if (e == hipSuccess) e = ln_up(ctx, d_T, T_cl, 16 * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(d_v, 0, (size_t)n_lines * ns * sizeof(int), ctx->stream);
     if (e == hipSuccess) {
       const long long tot = (long long)np * n_lines;
@@ -794,11 +799,11 @@ pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float*
                          lidar->d_p2s_off, lidar->d_p2s_ids, n_lines, d_tab, d_T, ns, thr, d_v);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(votes, d_v, (size_t)n_lines * ns * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ln_down(ctx, votes, d_v, (size_t)n_lines * ns * sizeof(int));
+    if (e == hipSuccess) e = ln_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "cam-lidar votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  ln_sync(ctx);
   pvlm_i_free(ctx, d_tab); pvlm_i_free(ctx, d_T); pvlm_i_free(ctx, d_v);
   return st;
 }

@@ -70,6 +70,12 @@ __global__ void k_mvs_unit_table(int rows, int cols, float* __restrict__ unit) {
   pvlm_mvs::unit_ray(rows, cols, (int)(e % cols), (int)(e / cols), unit + 3 * e);
 }
 
+// host <-> device copies of whole maps through the context's pinned staging arena (a pageable copy of a 5.7K map locks and
+// unlocks 66 MB of the caller's pages); downloads reach the caller's buffer at mvs_sync
+static inline hipError_t mvs_up(pvlm_ctx* ctx, void* d, const void* h, size_t bytes) { return pvlm_i_h2d_q(ctx, d, h, bytes) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t mvs_down(pvlm_ctx* ctx, void* h, const void* d, size_t bytes) { return pvlm_i_d2h_q(ctx, h, d, bytes) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t mvs_sync(pvlm_ctx* ctx) { return pvlm_i_sync(ctx) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
+
 struct pvlm_mvs_neighbours { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
 
 // ---- wave-level pieces shared by the scoring pass and the PatchMatch sweep (one wave per pixel, lane = texel) ----
@@ -418,25 +424,25 @@ pvlm_status pvlm_mvs_filter_depth(pvlm_ctx* ctx, int rows, int cols, int n_neigh
     }
     for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
       if (!nei_depth[b]) { e = hipErrorInvalidValue; break; }
-      e = hipMemcpyAsync(d_nd, nei_depth[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
+      e = mvs_up(ctx, d_nd, nei_depth[b], npix * sizeof(float));
       pvlm_mvs_pose pose;
       pvlm_mvs::inverse_pose(R_nr + 9 * b, t_nr + 3 * b, pose.R_rn, pose.t_rn);
       if (e == hipSuccess) { hipLaunchKernelGGL(k_mvs_project, dim3(grid), dim3(256), 0, s, rows, cols, d_unit, d_nd, pose, d_proj + npix * (size_t)b); e = hipGetLastError(); }
-      if (e == hipSuccess) e = hipStreamSynchronize(s);   // d_nd is reused by the next neighbour; nei_depth[b] is pageable host memory
+      if (e == hipSuccess) e = mvs_sync(ctx);   // d_nd is reused by the next neighbour; nei_depth[b] is pageable host memory
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth, npix * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && conf) e = hipMemcpyAsync(d_conf, conf, npix * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && depth_constant) e = hipMemcpyAsync(d_const, depth_constant, npix, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = mvs_up(ctx, d_depth, depth, npix * sizeof(float));
+    if (e == hipSuccess && conf) e = mvs_up(ctx, d_conf, conf, npix * sizeof(float));
+    if (e == hipSuccess && depth_constant) e = mvs_up(ctx, d_const, depth_constant, npix);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_mvs_filter, dim3(grid), dim3(256), 0, s, rows, cols, n_neighbors, d_proj, d_depth, d_conf, d_const, depth_diff_threshold, d_out, d_cout);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(depth_filter, d_out, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && conf) e = hipMemcpyAsync(conf_filter, d_cout, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = mvs_down(ctx, depth_filter, d_out, npix * sizeof(float));
+    if (e == hipSuccess && conf) e = mvs_down(ctx, conf_filter, d_cout, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_filter_depth: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  mvs_sync(ctx);
   pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_nd); pvlm_i_free(ctx, d_proj); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_out); pvlm_i_free(ctx, d_cout); pvlm_i_free(ctx, d_const);
   return st;
 }
@@ -475,8 +481,8 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
     pvlm_mvs::RefineViews nv;
     nv.n = n_neighbors;
     for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
-      e = hipMemcpyAsync(d_nd + npix * (size_t)b, nei_depth[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
-      if (e == hipSuccess) e = hipMemcpyAsync(d_nc + npix * (size_t)b, nei_conf[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
+      e = mvs_up(ctx, d_nd + npix * (size_t)b, nei_depth[b], npix * sizeof(float));
+      if (e == hipSuccess) e = mvs_up(ctx, d_nc + npix * (size_t)b, nei_conf[b], npix * sizeof(float));
       pvlm_mvs_pose pose;
       pvlm_mvs::inverse_pose(R_nr + 9 * b, t_nr + 3 * b, pose.R_rn, pose.t_rn);
       nv.conf[b] = d_nc + npix * (size_t)b;
@@ -487,21 +493,21 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
         e = hipGetLastError();
       }
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth, npix * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_conf, conf, npix * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && depth_constant) e = hipMemcpyAsync(d_const, depth_constant, npix, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = mvs_up(ctx, d_depth, depth, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_up(ctx, d_conf, conf, npix * sizeof(float));
+    if (e == hipSuccess && depth_constant) e = mvs_up(ctx, d_const, depth_constant, npix);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_mvs_refine, dim3(grid), dim3(256), 0, s, rows, cols, nv, d_key, d_unit, d_depth, d_conf, d_const, depth_diff_threshold, min_depth,
                          max_depth, d_out, d_cout);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(depth_filter, d_out, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(conf_filter, d_cout, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(conf, d_conf, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = mvs_down(ctx, depth_filter, d_out, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_down(ctx, conf_filter, d_cout, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_down(ctx, conf, d_conf, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_filter_depth_refine: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  mvs_sync(ctx);
   pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_nd); pvlm_i_free(ctx, d_nc); pvlm_i_free(ctx, d_key); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_out); pvlm_i_free(ctx, d_cout); pvlm_i_free(ctx, d_const);
   return st;
 }
@@ -529,24 +535,24 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
     hipStream_t s = ctx->stream;
     pvlm_mvs_neighbours nb;
     nb.n = n_neighbors; nb.geometric = nei_depth ? 1 : 0;
-    hipError_t e = hipMemcpyAsync(d_img, ref_gray, npix, hipMemcpyHostToDevice, s);
+    hipError_t e = mvs_up(ctx, d_img, ref_gray, npix);
     for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
       if (!nei_gray[b]) { e = hipErrorInvalidValue; break; }
-      e = hipMemcpyAsync(d_img + npix * (size_t)(b + 1), nei_gray[b], npix, hipMemcpyHostToDevice, s);
+      e = mvs_up(ctx, d_img + npix * (size_t)(b + 1), nei_gray[b], npix);
       nb.gray[b] = d_img + npix * (size_t)(b + 1);
       nb.depth[b] = nullptr;
       if (nei_depth && e == hipSuccess) {
         if (!nei_depth[b]) { e = hipErrorInvalidValue; break; }
-        e = hipMemcpyAsync(d_ndepth + npix * (size_t)b, nei_depth[b], npix * sizeof(float), hipMemcpyHostToDevice, s);
+        e = mvs_up(ctx, d_ndepth + npix * (size_t)b, nei_depth[b], npix * sizeof(float));
         nb.depth[b] = d_ndepth + npix * (size_t)b;
       }
       for (int k = 0; k < 9; ++k) nb.R[b][k] = R_nr[9 * b + k];
       for (int k = 0; k < 3; ++k) nb.t[b][k] = t_nr[3 * b + k];
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth, npix * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_normal, normal, npix * 3 * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_conf, conf, npix * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && depth_constant) e = hipMemcpyAsync(d_const, depth_constant, npix, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = mvs_up(ctx, d_depth, depth, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_up(ctx, d_normal, normal, npix * 3 * sizeof(float));
+    if (e == hipSuccess) e = mvs_up(ctx, d_conf, conf, npix * sizeof(float));
+    if (e == hipSuccess && depth_constant) e = mvs_up(ctx, d_const, depth_constant, npix);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_unit);
       if (max_iter < 0) {
@@ -563,13 +569,13 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
       }
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(depth, d_depth, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(normal, d_normal, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(conf, d_conf, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = mvs_down(ctx, depth, d_depth, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_down(ctx, normal, d_normal, npix * 3 * sizeof(float));
+    if (e == hipSuccess) e = mvs_down(ctx, conf, d_conf, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "%s: %s", what, hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  mvs_sync(ctx);
   pvlm_i_free(ctx, d_img); pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_normal); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_ndepth); pvlm_i_free(ctx, d_const);
   return st;
 }
@@ -589,20 +595,20 @@ pvlm_status pvlm_mvs_init_depth_normal(pvlm_ctx* ctx, int rows, int cols, const 
   if (!st) {
     hipStream_t s = ctx->stream;
     hipError_t e = hipSuccess;
-    if (lidar_depth) e = hipMemcpyAsync(d_l, lidar_depth, npix * sizeof(unsigned short), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && mask) e = hipMemcpyAsync(d_m, mask, npix * sizeof(float), hipMemcpyHostToDevice, s);
+    if (lidar_depth) e = mvs_up(ctx, d_l, lidar_depth, npix * sizeof(unsigned short));
+    if (e == hipSuccess && mask) e = mvs_up(ctx, d_m, mask, npix * sizeof(float));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_mvs_init_depth_normal, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_l, d_m, min_depth, max_depth,
                          keep_lidar_constant, pvlm_mvs::pass_seed(seed, -2), d_d, d_n, d_c);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(depth, d_d, npix * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(normal, d_n, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && want_const) e = hipMemcpyAsync(depth_constant, d_c, npix, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = mvs_down(ctx, depth, d_d, npix * sizeof(float));
+    if (e == hipSuccess) e = mvs_down(ctx, normal, d_n, npix * 3 * sizeof(float));
+    if (e == hipSuccess && want_const) e = mvs_down(ctx, depth_constant, d_c, npix);
+    if (e == hipSuccess) e = mvs_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_init_depth_normal: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
-  hipStreamSynchronize(ctx->stream);
+  mvs_sync(ctx);
   pvlm_i_free(ctx, d_l); pvlm_i_free(ctx, d_m); pvlm_i_free(ctx, d_d); pvlm_i_free(ctx, d_n); pvlm_i_free(ctx, d_c);
   return st;
 }
@@ -690,7 +696,7 @@ pvlm_status pvlm_mvs_views_destroy(pvlm_ctx* ctx, pvlm_mvs_views* v) {
   if (!ctx) return PVLM_ERR_ARG;
   if (!v) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  hipStreamSynchronize(ctx->stream);
+  mvs_sync(ctx);
   pvlm_i_free(ctx, v->d_gray); pvlm_i_free(ctx, v->d_depth); pvlm_i_free(ctx, v->d_normal); pvlm_i_free(ctx, v->d_conf); pvlm_i_free(ctx, v->d_depth_filter); pvlm_i_free(ctx, v->d_conf_filter);
   pvlm_i_free(ctx, v->d_unit); pvlm_i_free(ctx, v->d_key); pvlm_i_free(ctx, v->d_const);
   delete v;
@@ -719,7 +725,7 @@ pvlm_status pvlm_mvs_views_create(pvlm_ctx* ctx, int rows, int cols, int n_views
     float* zero[5] = {v->d_depth, v->d_conf, v->d_depth_filter, v->d_conf_filter, v->d_normal};
     for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipMemsetAsync(zero[k], 0, all * sizeof(float) * (k == 4 ? 3 : 1), s);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, s, rows, cols, v->d_unit); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = mvs_sync(ctx);
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_create: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   if (st) { pvlm_mvs_views_destroy(ctx, v); return st; }
@@ -734,11 +740,11 @@ pvlm_status pvlm_mvs_views_upload(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, co
   hipStream_t s = ctx->stream;
   const size_t o = v->npix * (size_t)view;
   hipError_t e = hipSuccess;
-  if (gray) e = hipMemcpyAsync(v->d_gray + o, gray, v->npix, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess && depth) e = hipMemcpyAsync(v->d_depth + o, depth, v->npix * sizeof(float), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess && normal) e = hipMemcpyAsync(v->d_normal + 3 * o, normal, v->npix * 3 * sizeof(float), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess && conf) e = hipMemcpyAsync(v->d_conf + o, conf, v->npix * sizeof(float), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (gray) e = mvs_up(ctx, v->d_gray + o, gray, v->npix);
+  if (e == hipSuccess && depth) e = mvs_up(ctx, v->d_depth + o, depth, v->npix * sizeof(float));
+  if (e == hipSuccess && normal) e = mvs_up(ctx, v->d_normal + 3 * o, normal, v->npix * 3 * sizeof(float));
+  if (e == hipSuccess && conf) e = mvs_up(ctx, v->d_conf + o, conf, v->npix * sizeof(float));
+  if (e == hipSuccess) e = mvs_sync(ctx);
   if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_upload: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }
@@ -750,12 +756,12 @@ pvlm_status pvlm_mvs_views_download(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, 
   hipStream_t s = ctx->stream;
   const size_t o = v->npix * (size_t)view, bytes = v->npix * sizeof(float);
   hipError_t e = hipSuccess;
-  if (depth) e = hipMemcpyAsync(depth, v->d_depth + o, bytes, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess && normal) e = hipMemcpyAsync(normal, v->d_normal + 3 * o, 3 * bytes, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess && conf) e = hipMemcpyAsync(conf, v->d_conf + o, bytes, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess && depth_filter) e = hipMemcpyAsync(depth_filter, v->d_depth_filter + o, bytes, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess && conf_filter) e = hipMemcpyAsync(conf_filter, v->d_conf_filter + o, bytes, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (depth) e = mvs_down(ctx, depth, v->d_depth + o, bytes);
+  if (e == hipSuccess && normal) e = mvs_down(ctx, normal, v->d_normal + 3 * o, 3 * bytes);
+  if (e == hipSuccess && conf) e = mvs_down(ctx, conf, v->d_conf + o, bytes);
+  if (e == hipSuccess && depth_filter) e = mvs_down(ctx, depth_filter, v->d_depth_filter + o, bytes);
+  if (e == hipSuccess && conf_filter) e = mvs_down(ctx, conf_filter, v->d_conf_filter + o, bytes);
+  if (e == hipSuccess) e = mvs_sync(ctx);
   if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_download: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }
@@ -791,7 +797,7 @@ pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, i
   views_neighbours(v, n_neighbors, nei, R_nr, t_nr, use_geometry != 0, nb);
   const size_t o = v->npix * (size_t)ref;
   hipError_t e = hipSuccess;
-  if (depth_constant) { e = hipMemcpyAsync(v->d_const, depth_constant, v->npix, hipMemcpyHostToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s); }
+  if (depth_constant) { e = mvs_up(ctx, v->d_const, depth_constant, v->npix); if (e == hipSuccess) e = mvs_sync(ctx); }
   unsigned char* d_const = depth_constant ? v->d_const : nullptr;
   if (e == hipSuccess) {
     if (max_iter < 0) {
@@ -823,7 +829,7 @@ pvlm_status pvlm_mvs_views_filter_refine(pvlm_ctx* ctx, pvlm_mvs_views* v, int r
   const size_t npix = v->npix, o = npix * (size_t)ref;
   const unsigned grid = (unsigned)((npix + 255) / 256);
   hipError_t e = hipSuccess;
-  if (depth_constant) { e = hipMemcpyAsync(v->d_const, depth_constant, npix, hipMemcpyHostToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s); }
+  if (depth_constant) { e = mvs_up(ctx, v->d_const, depth_constant, npix); if (e == hipSuccess) e = mvs_sync(ctx); }
   if (e == hipSuccess && n_neighbors > 0) {
     hipLaunchKernelGGL(k_mvs_fill_u64, dim3((unsigned)((npix * n_neighbors + 255) / 256)), dim3(256), 0, s, (long long)(npix * n_neighbors), ~0ull, v->d_key);
     e = hipGetLastError();

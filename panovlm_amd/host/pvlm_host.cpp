@@ -1338,6 +1338,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     e.Check(pvlm_set_poses(e.ctx(), nd, aa.data(), tt.data()), "pvlm_set_poses");
   };
   auto bundle_reduce = [&](const std::vector<double>& v, double radius, bool init, Reduced& R) {
+    StageTimer stage_timer_br_("solve: reprojection blocks reduced on the GPU + host scatter of the camera system");
     R = Reduced(); R.g_red.assign(n_free, 0.0); R.g_cam.assign(n_free, 0.0); R.Udiag.assign(n_free, 0.0);
     for (auto& b : I.bundles) {
       if (!b.set) continue;
@@ -1370,6 +1371,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   };
   // back-substitutes the points for the (unscaled) camera step; out3 += [model decrease, |dX|^2, |X|^2]
   auto bundle_step = [&](const std::vector<double>& step, double* out3) {
+    StageTimer stage_timer_bs_("solve: point back-substitution / candidate cost (GPU)");
     for (auto& b : I.bundles) {
       if (!b.set) continue;
       const int nd = (int)b.dev_to_pose.size();
@@ -1382,6 +1384,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     }
   };
   auto bundle_cost = [&](const std::vector<double>& v, bool candidate) {
+    StageTimer stage_timer_bc_("solve: point back-substitution / candidate cost (GPU)");
     double c = 0.0;
     for (auto& b : I.bundles) {
       if (!b.set) continue;
@@ -1501,6 +1504,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     Skyline S0;                      // four-block groups only: the Gauss-Newton model of those blocks
     if (gpu_chol) {
       StageTimer stage_timer_chol_("solve: GPU Cholesky");
+      StageTimer* stage_timer_push_ = new StageTimer("  (inside the GPU Cholesky stage) host block list");
       std::vector<int> rows, cols, mirror; std::vector<double> blocks;
       auto push = [&](const std::map<std::pair<int, int>, std::array<double, 36>>& H) {
         for (auto& kv : H) {
@@ -1511,6 +1515,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       };
       push(A.H);
       if (have_bundles) push(R.H);
+      delete stage_timer_push_;
       int info = 0;
       e.Check(pvlm_spd_solve_blocks(e.ctx(), n_free, (int)mirror.size(), rows.data(), cols.data(), mirror.data(), blocks.data(), scale.data(), damp.data(),
                                     dy.data(), &info), "pvlm_spd_solve_blocks");
