@@ -23,6 +23,7 @@ struct pvlm_baset {
   int64_t n_obs = 0;
   double weight = 1.0;
   std::vector<int> ui, uj;
+  std::vector<int2> h_cpl;          // staging of the couple lists during pvlm_ba_create
   long long* d_pt_off = nullptr;
   int* d_cam = nullptr;
   int* d_obs_pt = nullptr;
@@ -39,6 +40,10 @@ struct pvlm_baset {
   double* d_packed = nullptr;   // packed_size doubles
   double* d_dcam = nullptr;     // n_cams x 6
   double* d_small = nullptr;    // 4 doubles of scalar results
+  long long* d_cpl_off = nullptr;   // n_cams + n_upairs + 1: couples of block s (diagonal blocks first, then the pairs in (ui, uj) order)
+  int2* d_cpl = nullptr;            // (i, j) observation couples, block after block
+  double* d_cost_cam = nullptr;     // n_cams partial costs (summed in camera order: reproducible)
+  double* d_partials = nullptr;     // per-workgroup partial sums of k_ba_step (3 x) / k_ba_cost
   bool scaled = false;          // Jacobi scaling of the point columns initialised
   bool reduced = false;         // Vinv / gp valid for the current points
   uint64_t reduced_epoch = ~0ull;
@@ -74,23 +79,80 @@ __global__ void __launch_bounds__(128) k_ba_obs(pvlm_ba::View v, const double* _
   if ((threadIdx.x & 63) == 0 && c != 0.0) unsafeAtomicAdd(cost, c);
 }
 
-__global__ void __launch_bounds__(128) k_ba_step(pvlm_ba::View v, const double* __restrict__ pose_tab, const double* __restrict__ dcam, double* out3) {
+// Pass B, gather form: wave s sums the couples of block s (s < n_cams: diagonal block of camera s + its g / Udiag / gcam /
+// cost share; otherwise pair s - n_cams) — lane-strided partial sums, then a fixed shuffle tree: no atomics, bit-reproducible.
+__global__ void __launch_bounds__(256) k_ba_blocks(pvlm_ba::View v, const double* __restrict__ pose_tab, const long long* __restrict__ cpl_off,
+                                                   const int2* __restrict__ cpl, double* __restrict__ packed, double* __restrict__ cost_cam) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (s >= v.n_cams + v.n_upairs) return;
+  double acc[36], vec[19];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 19; ++k) vec[k] = 0.0;
+  for (long long q = cpl_off[s] + lane; q < cpl_off[s + 1]; q += 64) {
+    const int2 c = cpl[q];
+    pvlm_ba::couple_pass(v, pose_tab, c.x, c.y, acc, vec);
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+  const bool diag = s < v.n_cams;
+  if (diag) {
+#pragma unroll
+    for (int k = 0; k < 19; ++k)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) vec[k] += __shfl_xor(vec[k], off, 64);
+  }
+  if (lane != 0) return;
+  double* dst = diag ? packed + (size_t)s * 36 : packed + (size_t)v.n_cams * 36 + (size_t)(s - v.n_cams) * 36;
+#pragma unroll
+  for (int k = 0; k < 36; ++k) dst[k] = acc[k];
+  if (diag) {
+    double* g = packed + (size_t)v.n_cams * 36 + (size_t)v.n_upairs * 36 + (size_t)s * 6;
+    double* Ud = packed + (size_t)v.n_cams * 36 + (size_t)v.n_upairs * 36 + (size_t)v.n_cams * 6 + 1 + (size_t)s * 6;
+    double* gc = Ud + (size_t)v.n_cams * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { g[k] = vec[k]; Ud[k] = vec[6 + k]; gc[k] = vec[12 + k]; }
+    cost_cam[s] = vec[18];
+  }
+}
+__global__ void k_ba_cost_sum(int n_cams, const double* __restrict__ cost_cam, double* __restrict__ cost) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { double c = 0.0; for (int k = 0; k < n_cams; ++k) c += cost_cam[k]; *cost = c; }
+}
+
+// Scalar results (model decrease, step norms, cost) are summed reproducibly: per-workgroup partials (waves in order), then
+// one thread adds the partials in workgroup order (k_ba_sum_partials) — round 1 used one atomic per wave, whose order moved
+// the last bits of the cost and with them the LM driver's borderline decisions from run to run.
+__device__ inline void block_partial(double x, double* __restrict__ partial_out) {    // partial_out: this workgroup's slot
+  __shared__ double ws[4];
+  const double s = wave_sum(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (unsigned w = 0; w < (blockDim.x >> 6); ++w) t += ws[w]; *partial_out = t; }
+}
+__global__ void k_ba_sum_partials(int n_partials, int n_out, const double* __restrict__ partials, double* __restrict__ out) {
+  const int k = threadIdx.x;       // output k sums partials[k * n_partials ...]
+  if (k >= n_out || blockIdx.x != 0) return;
+  double t = 0.0;
+  for (int q = 0; q < n_partials; ++q) t += partials[(size_t)k * n_partials + q];
+  out[k] = t;
+}
+__global__ void __launch_bounds__(128) k_ba_step(pvlm_ba::View v, const double* __restrict__ pose_tab, const double* __restrict__ dcam, double* __restrict__ partials) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   double o[3] = {0.0, 0.0, 0.0};
   if (p < v.n_points) pvlm_ba::step_point(v, pose_tab, p, dcam, o);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double s = wave_sum(o[k]);
-    if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(&out3[k], s);
-  }
+  for (int k = 0; k < 3; ++k) block_partial(o[k], &partials[(size_t)k * gridDim.x + blockIdx.x]);
 }
 
-__global__ void __launch_bounds__(256) k_ba_cost(pvlm_ba::View v, const double* __restrict__ pose_tab, int candidate, double* cost) {
+__global__ void __launch_bounds__(256) k_ba_cost(pvlm_ba::View v, const double* __restrict__ pose_tab, int candidate, double* __restrict__ partials) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   double c = 0.0;
   if (i < v.n_obs) c = pvlm_ba::cost_obs(v, pose_tab, i, candidate);
-  c = wave_sum(c);
-  if ((threadIdx.x & 63) == 0 && c != 0.0) unsafeAtomicAdd(cost, c);
+  block_partial(c, &partials[blockIdx.x]);
 }
 
 // materialise r and the 1x9 Jacobian rows [aa_cw | t_cw | X] (Ceres-feeding / parity mode)
@@ -112,6 +174,7 @@ static pvlm_status ba_free(pvlm_ctx* ctx, pvlm_baset* s) {
   pvlm_i_free(ctx, s->d_pt_off); pvlm_i_free(ctx, s->d_cam); pvlm_i_free(ctx, s->d_obs_pt); pvlm_i_free(ctx, s->d_s); pvlm_i_free(ctx, s->d_X); pvlm_i_free(ctx, s->d_Xc); pvlm_i_free(ctx, s->d_scale);
   pvlm_i_free(ctx, s->d_Vinv); pvlm_i_free(ctx, s->d_gp); pvlm_i_free(ctx, s->d_adj_off); pvlm_i_free(ctx, s->d_adj_cam); pvlm_i_free(ctx, s->d_adj_slot); pvlm_i_free(ctx, s->d_packed);
   pvlm_i_free(ctx, s->d_dcam); pvlm_i_free(ctx, s->d_small); pvlm_i_free(ctx, s->d_frozen);
+  pvlm_i_free(ctx, s->d_cpl_off); pvlm_i_free(ctx, s->d_cpl); pvlm_i_free(ctx, s->d_cost_cam); pvlm_i_free(ctx, s->d_partials);
   delete s;
   return PVLM_OK;
 }
@@ -141,18 +204,23 @@ pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int
     if (cam_ids[i] < 0) { PVLM_SET_ERR(ctx, "negative camera id at observation %lld", (long long)i); return PVLM_ERR_ARG; }
     n_cams = std::max(n_cams, cam_ids[i] + 1);
   }
+  if (n_obs >= (1ll << 31)) { PVLM_SET_ERR(ctx, "more than 2^31 observations"); return PVLM_ERR_ARG; }
   std::vector<int> obs_pt((size_t)n_obs);
   std::vector<long long> off((size_t)n_points + 1, 0);
-  std::set<std::pair<int, int>> up;
+  // co-visible camera pairs as sorted unique 64-bit keys (ui << 32 | uj) — round 1 inserted 2 M couples into a std::set
+  std::vector<unsigned long long> keys;
   for (int p = 0; p < n_points; ++p) {
     if (point_offsets[p + 1] < point_offsets[p]) { PVLM_SET_ERR(ctx, "point_offsets must be non-decreasing"); return PVLM_ERR_ARG; }
     off[p] = point_offsets[p]; off[p + 1] = point_offsets[p + 1];
     for (int64_t i = point_offsets[p]; i < point_offsets[p + 1]; ++i) {
       obs_pt[(size_t)i] = p;
       for (int64_t j = i + 1; j < point_offsets[p + 1]; ++j)
-        if (cam_ids[i] != cam_ids[j]) up.insert({std::min(cam_ids[i], cam_ids[j]), std::max(cam_ids[i], cam_ids[j])});
+        if (cam_ids[i] != cam_ids[j])
+          keys.push_back(((unsigned long long)std::min(cam_ids[i], cam_ids[j]) << 32) | (unsigned)std::max(cam_ids[i], cam_ids[j]));
     }
   }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
   // unit bearings: point_sphere.normalize() of the functor's constructor (CostFunction.h:227-230)
   std::vector<double> s((size_t)n_obs * 3);
   for (int64_t i = 0; i < n_obs; ++i) {
@@ -163,10 +231,38 @@ pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int
   pvlm_baset* bs = new pvlm_baset();
   bs->n_points = n_points; bs->n_obs = n_obs; bs->n_cams = n_cams; bs->weight = weight;
   std::vector<int> adj_off((size_t)n_cams + 1, 0), adj_cam, adj_slot;
-  for (auto& u : up) { bs->ui.push_back(u.first); bs->uj.push_back(u.second); }   // sorted by (ui, uj): CSR order
+  for (unsigned long long k : keys) { bs->ui.push_back((int)(k >> 32)); bs->uj.push_back((int)(k & 0xFFFFFFFFu)); }   // sorted by (ui, uj): CSR order
   bs->n_upairs = (int)bs->ui.size();
   for (int u = 0; u < bs->n_upairs; ++u) { adj_off[(size_t)bs->ui[u] + 1]++; adj_cam.push_back(bs->uj[u]); adj_slot.push_back(u); }
   for (int c = 0; c < n_cams; ++c) adj_off[(size_t)c + 1] += adj_off[c];
+  // couples of every block: (i, j) with cam[i] < cam[j] for the pair blocks (the block of (ci, cj) is rows ci x columns cj),
+  // every ordered (i, j) with cam[i] == cam[j] — normally just (i, i) — for the diagonal blocks; counting sort by block
+  const int n_slots = n_cams + bs->n_upairs;
+  auto slot_of = [&](int ci, int cj) {          // ci < cj
+    const unsigned long long k = ((unsigned long long)ci << 32) | (unsigned)cj;
+    return n_cams + (int)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin());
+  };
+  std::vector<long long> cpl_off((size_t)n_slots + 1, 0);
+  {
+    std::vector<int> slot_seq;               // block of every couple, in visiting order (pass 0 finds it, pass 1 replays it)
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<long long> cursor;
+      if (pass == 1) {
+        for (int q = 0; q < n_slots; ++q) cpl_off[(size_t)q + 1] += cpl_off[q];
+        cursor.assign(cpl_off.begin(), cpl_off.end() - 1);
+        bs->h_cpl.resize((size_t)cpl_off[n_slots]);
+      }
+      size_t seq = 0;
+      for (int p = 0; p < n_points; ++p)
+        for (int64_t i = point_offsets[p]; i < point_offsets[p + 1]; ++i)
+          for (int64_t j = point_offsets[p]; j < point_offsets[p + 1]; ++j) {
+            const int ci = cam_ids[i], cj = cam_ids[j];
+            if (cj < ci) continue;
+            if (pass == 0) { const int q = ci == cj ? ci : slot_of(ci, cj); slot_seq.push_back(q); cpl_off[(size_t)q + 1]++; }
+            else bs->h_cpl[(size_t)cursor[slot_seq[seq++]]++] = make_int2((int)i, (int)j);
+          }
+    }
+  }
   const size_t psz = (size_t)pvlm_ba::packed_size(n_cams, bs->n_upairs);
   pvlm_status st = PVLM_OK;
   if (!st) st = pvlm_i_alloc(ctx, &bs->d_pt_off, (size_t)n_points + 1);
@@ -184,6 +280,12 @@ pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int
   if (!st) st = pvlm_i_alloc(ctx, &bs->d_packed, psz);
   if (!st) st = pvlm_i_alloc(ctx, &bs->d_dcam, (size_t)n_cams * 6);
   if (!st) st = pvlm_i_alloc(ctx, &bs->d_small, (size_t)4);
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_cpl_off, cpl_off.size());
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_cpl, std::max<size_t>(bs->h_cpl.size(), 1));
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_cost_cam, (size_t)std::max(n_cams, 1));
+  if (!st) st = pvlm_i_alloc(ctx, &bs->d_partials, std::max<size_t>(3 * (((size_t)n_points + 127) / 128), ((size_t)n_obs + 255) / 256) + 4);
+  if (!st) st = h2d(ctx, bs->d_cpl_off, cpl_off.data(), cpl_off.size());
+  if (!st) st = h2d(ctx, bs->d_cpl, bs->h_cpl.data(), bs->h_cpl.size());
   if (!st) st = h2d(ctx, bs->d_pt_off, off.data(), off.size());
   if (!st) st = h2d(ctx, bs->d_cam, cam_ids, (size_t)n_obs);
   if (!st) st = h2d(ctx, bs->d_obs_pt, obs_pt.data(), obs_pt.size());
@@ -194,6 +296,7 @@ pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int
   if (!st) st = h2d(ctx, bs->d_adj_cam, adj_cam.data(), adj_cam.size());
   if (!st) st = h2d(ctx, bs->d_adj_slot, adj_slot.data(), adj_slot.size());
   if (!st && hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "reprojection set upload failed"); st = PVLM_ERR_HIP; }
+  bs->h_cpl.clear(); bs->h_cpl.shrink_to_fit();
   if (st) { ba_free(ctx, bs); return st; }
   *out = bs;
   return PVLM_OK;
@@ -288,8 +391,16 @@ pvlm_status pvlm_ba_reduce(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, doubl
                        min_diag, max_diag, d_gmax);
     PVLM_HIP(ctx, hipGetLastError());
   }
-  if (set->n_obs) {
-    hipLaunchKernelGGL(k_ba_obs, dim3((unsigned)((set->n_obs + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_packed, d_cost);
+  {
+    static const bool scatter = getenv("PVLM_BA_ATOMICS") != nullptr;   // PVLM_BA_ATOMICS=1: round 1's scatter with fp64 atomics (k_ba_obs, measured variant)
+    if (scatter) {
+      if (set->n_obs) hipLaunchKernelGGL(k_ba_obs, dim3((unsigned)((set->n_obs + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_packed, d_cost);
+    } else {
+      const int n_slots = set->n_cams + set->n_upairs;
+      if (n_slots) hipLaunchKernelGGL(k_ba_blocks, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, set->d_cpl_off, set->d_cpl, set->d_packed,
+                                      set->d_cost_cam);
+      hipLaunchKernelGGL(k_ba_cost_sum, dim3(1), dim3(64), 0, ctx->stream, set->n_cams, set->d_cost_cam, d_cost);
+    }
     PVLM_HIP(ctx, hipGetLastError());
   }
   if ((st = pvlm_i_d2h(ctx, packed, set->d_packed, psz * 8))) return st;      // 1.2 MB at Room scale, every LM step: pinned arena, not a pageable copy
@@ -311,7 +422,9 @@ pvlm_status pvlm_ba_step(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, double 
   PVLM_HIP(ctx, hipMemsetAsync(set->d_small, 0, 32, ctx->stream));
   const pvlm_ba::View v = make_view(set, (int)loss, a);
   if (set->n_points) {
-    hipLaunchKernelGGL(k_ba_step, dim3((unsigned)((set->n_points + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_dcam, set->d_small);
+    const int nb = (set->n_points + 127) / 128;
+    hipLaunchKernelGGL(k_ba_step, dim3((unsigned)nb), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_dcam, set->d_partials);
+    hipLaunchKernelGGL(k_ba_sum_partials, dim3(1), dim3(64), 0, ctx->stream, nb, 3, set->d_partials, set->d_small);
     PVLM_HIP(ctx, hipGetLastError());
   }
   if ((st = pvlm_i_d2h(ctx, out3, set->d_small, 24))) return st;
@@ -328,7 +441,9 @@ pvlm_status pvlm_ba_cost(pvlm_ctx* ctx, const pvlm_baset* set, pvlm_loss loss, d
   PVLM_HIP(ctx, hipMemsetAsync(set->d_small, 0, 32, ctx->stream));
   const pvlm_ba::View v = make_view(set, (int)loss, a);
   if (set->n_obs) {
-    hipLaunchKernelGGL(k_ba_cost, dim3((unsigned)((set->n_obs + 255) / 256)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, candidate, set->d_small);
+    const int nb = (int)((set->n_obs + 255) / 256);
+    hipLaunchKernelGGL(k_ba_cost, dim3((unsigned)nb), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, candidate, set->d_partials);
+    hipLaunchKernelGGL(k_ba_sum_partials, dim3(1), dim3(64), 0, ctx->stream, nb, 1, set->d_partials, set->d_small);
     PVLM_HIP(ctx, hipGetLastError());
   }
   return pvlm_i_d2h(ctx, cost, set->d_small, 8);

@@ -131,6 +131,37 @@ PVLM_HD inline double obs_pass(const View& v, const double* pose_tab, long long 
   return 0.5 * li.rho;
 }
 
+// ---- pass B as a GATHER (round 2): one (i, j) couple of observations of the same point, cam[i] <= cam[j], contributes
+//   coef Jc_i Jc_j^T to the block of the camera pair (cam[i], cam[j]) — coef as in obs_pass — and, when j == i, the
+//   observation's share of g / Udiag / gcam / cost.  pvlm_ba.hip lists the couples of every block once (pvlm_ba_create) and
+//   one wave sums a block's couples in a fixed order: no atomics, and the same bits on every run.
+//   acc: 36 doubles (row-major 6 x 6, rows = camera of i), vec: g (6) | Udiag (6) | gcam (6) | cost (1), touched when j == i.
+PVLM_HD inline void couple_pass(const View& v, const double* pose_tab, long long i, long long j, double* acc, double* vec) {
+  const int p = v.obs_pt[i];
+  const double* X = v.X + 3 * (size_t)p;
+  const double* Vi = v.Vinv + 6 * (size_t)p;
+  Lin li, lj;
+  linearise(v, pose_tab, i, X, &li);
+  if (j == i) lj = li; else linearise(v, pose_tab, j, X, &lj);
+  double y[3]; pvlm_reproj::sym3_mul(Vi, li.Jp, y);
+  double coef = -li.rho1 * lj.rho1 * (y[0] * lj.Jp[0] + y[1] * lj.Jp[1] + y[2] * lj.Jp[2]);
+  if (j == i) coef += li.rho1;
+  for (int a = 0; a < 6; ++a) {
+    const double ca = coef * li.Jc[a];
+    for (int b = 0; b < 6; ++b) acc[a * 6 + b] += ca * lj.Jc[b];
+  }
+  if (j == i) {
+    const double* gp = v.gp + 3 * (size_t)p;
+    const double ygp = y[0] * gp[0] + y[1] * gp[1] + y[2] * gp[2];
+    for (int k = 0; k < 6; ++k) {
+      vec[k] += li.rho1 * li.Jc[k] * (li.r - ygp);
+      vec[6 + k] += li.rho1 * li.Jc[k] * li.Jc[k];
+      vec[12 + k] += li.rho1 * li.Jc[k] * li.r;
+    }
+    vec[18] += 0.5 * li.rho;
+  }
+}
+
 // ---- back-substitution, one call per point: dp = -Vinv (gp + sum_i rho' Jp_i (Jc_i . dc_i)); Xc = X + dp -----
 // dcam: n_cams x 6 camera steps (0 for constant blocks).  out3 += [model decrease, |dp|^2, |X|^2] where the model
 // decrease is -sum_i rho'_i (r_i d_i + d_i^2 / 2), d_i = Jc_i.dc_i + Jp_i.dp (Gauss-Newton model of these blocks).
