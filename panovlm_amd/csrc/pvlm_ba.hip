@@ -207,20 +207,33 @@ pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int
   if (n_obs >= (1ll << 31)) { PVLM_SET_ERR(ctx, "more than 2^31 observations"); return PVLM_ERR_ARG; }
   std::vector<int> obs_pt((size_t)n_obs);
   std::vector<long long> off((size_t)n_points + 1, 0);
-  // co-visible camera pairs as sorted unique 64-bit keys (ui << 32 | uj) — round 1 inserted 2 M couples into a std::set
+  // co-visible camera pairs as sorted unique 64-bit keys (ui << 32 | uj) — round 1 inserted 2 M couples into a std::set.
+  // Up to 4096 cameras the pairs are marked in an n_cams x n_cams table (later the pair -> block lookup); beyond, sorted keys.
   std::vector<unsigned long long> keys;
+  const bool table = n_cams <= 4096;
+  std::vector<int> pair_slot;                       // (ci, cj), ci < cj -> index of the pair, -1 = not co-visible
+  if (table) pair_slot.assign((size_t)n_cams * n_cams, -1);
   for (int p = 0; p < n_points; ++p) {
     if (point_offsets[p + 1] < point_offsets[p]) { PVLM_SET_ERR(ctx, "point_offsets must be non-decreasing"); return PVLM_ERR_ARG; }
     off[p] = point_offsets[p]; off[p + 1] = point_offsets[p + 1];
     for (int64_t i = point_offsets[p]; i < point_offsets[p + 1]; ++i) {
       obs_pt[(size_t)i] = p;
       for (int64_t j = i + 1; j < point_offsets[p + 1]; ++j)
-        if (cam_ids[i] != cam_ids[j])
-          keys.push_back(((unsigned long long)std::min(cam_ids[i], cam_ids[j]) << 32) | (unsigned)std::max(cam_ids[i], cam_ids[j]));
+        if (cam_ids[i] != cam_ids[j]) {
+          const int lo = std::min(cam_ids[i], cam_ids[j]), hi = std::max(cam_ids[i], cam_ids[j]);
+          if (table) pair_slot[(size_t)lo * n_cams + hi] = 0;
+          else keys.push_back(((unsigned long long)lo << 32) | (unsigned)hi);
+        }
     }
   }
-  std::sort(keys.begin(), keys.end());
-  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  if (table) {
+    for (int lo = 0; lo < n_cams; ++lo)
+      for (int hi = lo + 1; hi < n_cams; ++hi)
+        if (pair_slot[(size_t)lo * n_cams + hi] == 0) { pair_slot[(size_t)lo * n_cams + hi] = (int)keys.size(); keys.push_back(((unsigned long long)lo << 32) | (unsigned)hi); }
+  } else {
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  }
   // unit bearings: point_sphere.normalize() of the functor's constructor (CostFunction.h:227-230)
   std::vector<double> s((size_t)n_obs * 3);
   for (int64_t i = 0; i < n_obs; ++i) {
@@ -239,6 +252,7 @@ pvlm_status pvlm_ba_create(pvlm_ctx* ctx, int n_points, int64_t n_obs, const int
   // every ordered (i, j) with cam[i] == cam[j] — normally just (i, i) — for the diagonal blocks; counting sort by block
   const int n_slots = n_cams + bs->n_upairs;
   auto slot_of = [&](int ci, int cj) {          // ci < cj
+    if (table) return n_cams + pair_slot[(size_t)ci * n_cams + cj];
     const unsigned long long k = ((unsigned long long)ci << 32) | (unsigned)cj;
     return n_cams + (int)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin());
   };

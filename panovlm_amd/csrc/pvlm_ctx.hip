@@ -287,6 +287,8 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
   for (int w = 0; w < 3; ++w) for (auto& pr : ctx->prof_pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
+  if (ctx->aux_stream) { hipStreamSynchronize(ctx->aux_stream); hipStreamDestroy(ctx->aux_stream); }
+  for (hipEvent_t e : ctx->aux_ev) if (e) hipEventDestroy(e);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return PVLM_OK;

@@ -77,6 +77,8 @@ struct pvlm_ctx {
   // pinned staging arena of every other host <-> device copy (pvlm_i_h2d_q / pvlm_i_d2h_q / pvlm_i_sync)
   pvlm_stage stage;
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_stream = nullptr;   // second stream of the look-ahead Cholesky (K10), created on first use
+  hipEvent_t aux_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;

@@ -178,6 +178,21 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
   if (live) M[(size_t)row * n + k0 + c] = x;
 }
 
+// Which 64 x 64 tile (ti >= tj) of the trailing lower triangle a workgroup updates.  part 0: all tiles, linear id -> lower
+// triangle; part 1: the first tile column only (tj = 0: the columns the NEXT block column's factorisation needs);
+// part 2: the rest (tj >= 1) — parts 1 and 2 run on two streams (look-ahead, chol_factor_solve).
+__device__ __forceinline__ bool chol_tile_of(int id, int tiles, int part, int* ti_out, int* tj_out) {
+  if (part == 1) { if (id >= tiles) return false; *ti_out = id; *tj_out = 0; return true; }
+  const int shift = part == 2 ? 1 : 0, t = tiles - shift;
+  int ti = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+  while ((long long)(ti + 1) * (ti + 2) / 2 <= (long long)id) ++ti;
+  while ((long long)ti * (ti + 1) / 2 > (long long)id) --ti;
+  const int tj = id - ti * (ti + 1) / 2;
+  if (ti >= t) return false;
+  *ti_out = ti + shift; *tj_out = tj + shift;
+  return true;
+}
+
 // b[i] -= L[i, k-block] . y_k for the rows below block column k (the second half of round 1's k_fwd_step), run by the
 // workgroups past the tile list of the trailing-update launches
 __device__ __forceinline__ void chol_fwd_rows(const double* __restrict__ M, int n, int k0, int kb, int chunk, double* __restrict__ b, const double* __restrict__ yv) {
@@ -194,17 +209,14 @@ __device__ __forceinline__ void chol_fwd_rows(const double* __restrict__ M, int 
 }
 
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info,
-                                                     int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y) {
+                                                     int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y, int part) {
   if ((int)blockIdx.x >= n_tile_blocks) { if (*info == 0) chol_fwd_rows(M, n, k0, kb, (int)blockIdx.x - n_tile_blocks, fwd_b, fwd_y); return; }
   __shared__ double As[64][PVLM_CHOL_NB + 1];
   __shared__ double Bs[64][PVLM_CHOL_NB + 1];
   if (*info != 0) return;
   // linear block id -> (ti >= tj) of the lower triangle of the tile grid
-  int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-  while ((long long)(ti + 1) * (ti + 2) / 2 <= (long long)blockIdx.x) ++ti;
-  while ((long long)ti * (ti + 1) / 2 > (long long)blockIdx.x) --ti;
-  const int tj = blockIdx.x - ti * (ti + 1) / 2;
-  if (ti >= tiles) return;
+  int ti, tj;
+  if (!chol_tile_of((int)blockIdx.x, tiles, part, &ti, &tj)) return;
   const int base = k0 + kb, r0 = base + ti * 64, c0 = base + tj * 64;
   for (int e = threadIdx.x; e < 64 * PVLM_CHOL_NB; e += 256) {
     const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
@@ -243,16 +255,13 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int
 // row = (lane >> 4) + 4 * reg (cdna_hip_programming.md §3) — not the f32 map.
 typedef double pvlm_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info,
-                                                          int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y) {
+                                                          int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y, int part) {
   __shared__ double As[64][PVLM_CHOL_NB + 1];
   __shared__ double Bs[64][PVLM_CHOL_NB + 1];
   if (*info != 0) return;
   if ((int)blockIdx.x >= n_tile_blocks) { chol_fwd_rows(M, n, k0, kb, (int)blockIdx.x - n_tile_blocks, fwd_b, fwd_y); return; }
-  int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-  while ((long long)(ti + 1) * (ti + 2) / 2 <= (long long)blockIdx.x) ++ti;
-  while ((long long)ti * (ti + 1) / 2 > (long long)blockIdx.x) --ti;
-  const int tj = blockIdx.x - ti * (ti + 1) / 2;
-  if (ti >= tiles) return;
+  int ti, tj;
+  if (!chol_tile_of((int)blockIdx.x, tiles, part, &ti, &tj)) return;
   const int base = k0 + kb, r0 = base + ti * 64, c0 = base + tj * 64;
   for (int e = threadIdx.x; e < 64 * PVLM_CHOL_NB; e += 256) {
     const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
@@ -341,8 +350,29 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
   hipStream_t s = ctx->stream;
   static const bool use_mfma = getenv("PVLM_CHOL_VALU") == nullptr;   // PVLM_CHOL_VALU=1: the register-tiled VALU update (measured variant)
   static const bool fused = getenv("PVLM_CHOL_SPLIT") == nullptr;      // PVLM_CHOL_SPLIT=1: round 1's launch structure (k_chol_diag, k_chol_panel, k_fwd_step)
+  static const bool want_ahead = getenv("PVLM_CHOL_LOOKAHEAD") != nullptr;   // opt-in: measured SLOWER (below)
   const bool ride = fused && nrhs >= 1;                                // the first right-hand side's forward substitution rides along
-  for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB) {
+  // Look-ahead on a second stream (PVLM_CHOL_LOOKAHEAD=1; built, measured, not adopted: 5.45 ms against 4.56 ms at n = 2724 —
+  // two event records and two stream waits per block column cost more on this runtime than the 20 us of overlap they buy):
+  // block column k + 1 can be factorised as soon as the FIRST tile column of update k is done;
+  // the rest of update k (part 2) runs beside it.  Stream A (the context stream): F(k), U1(k) [first tile column + rhs rows];
+  // stream B: U2(k).  U2(k) waits for F(k) (it needs the panel); U1(k) waits for U2(k - 1) (they touch the same columns);
+  // everything else is ordered by the streams themselves.
+  bool ahead = fused && want_ahead && !ctx->capturing && n > 8 * PVLM_CHOL_NB;
+  if (ahead && !ctx->aux_stream) {
+    ahead = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int q = 0; q < 8 && ahead; ++q) ahead = hipEventCreateWithFlags(&ctx->aux_ev[q], hipEventDisableTiming) == hipSuccess;
+    if (!ahead) ctx->aux_stream = nullptr;
+  }
+  hipStream_t sb = ahead ? ctx->aux_stream : s;
+  if (ahead) { hipEventRecord(ctx->aux_ev[0], s); hipStreamWaitEvent(sb, ctx->aux_ev[0], 0); }
+  int step = 0, last_u2 = -1;
+  auto launch_update = [&](hipStream_t st, int k0, int kb, int tiles, int part, int tile_blocks, int fwd_blocks) {
+    if (tile_blocks + fwd_blocks <= 0) return;
+    if (use_mfma) hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part);
+    else hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part);
+  };
+  for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB, ++step) {
     const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
     if (fused) {
       // a failed pivot: every workgroup finds it itself (same arithmetic on the same block) and returns; workgroup 0 records it
@@ -355,11 +385,23 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
     }
     if (rem > 0) {
       const int tiles = (rem + 63) / 64;
-      const int tile_blocks = (int)((long long)tiles * (tiles + 1) / 2), fwd_blocks = ride ? (rem + 255) / 256 : 0;
-      if (use_mfma) hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y);
-      else hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, s, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y);
+      const int fwd_blocks = ride ? (rem + 255) / 256 : 0;
+      if (ahead && tiles >= 2) {
+        hipEvent_t ef = ctx->aux_ev[1 + (step & 1)], eu = ctx->aux_ev[3 + (step & 3)];
+        hipEventRecord(ef, s);                                   // F(k) done: the panel exists
+        hipStreamWaitEvent(sb, ef, 0);
+        launch_update(sb, k0, kb, tiles, 2, (int)((long long)(tiles - 1) * tiles / 2), 0);
+        hipEventRecord(eu, sb);
+        if (last_u2 >= 0) hipStreamWaitEvent(s, ctx->aux_ev[3 + (last_u2 & 3)], 0);    // U1(k) after U2(k - 1)
+        launch_update(s, k0, kb, tiles, 1, tiles, fwd_blocks);
+        last_u2 = step;
+      } else {
+        if (ahead && last_u2 >= 0) { hipStreamWaitEvent(s, ctx->aux_ev[3 + (last_u2 & 3)], 0); last_u2 = -1; }
+        launch_update(s, k0, kb, tiles, 0, (int)((long long)tiles * (tiles + 1) / 2), fwd_blocks);
+      }
     }
   }
+  if (ahead && last_u2 >= 0) hipStreamWaitEvent(s, ctx->aux_ev[3 + (last_u2 & 3)], 0);
   for (int r = 0; r < nrhs; ++r) {
     double* b = d_B + (size_t)r * n;
     if (!(ride && r == 0))
