@@ -98,6 +98,56 @@ def test_reduce_step_cost_match_oracle(ctx, oracle, loss):
     bs.close()
 
 
+def test_reduce_is_bit_reproducible_and_equals_the_atomic_scatter(oracle):
+    """pvlm_ba_reduce gathers every 6 x 6 block of the reduced camera system from its list of observation couples (one wave
+    per block, fixed summation order): two runs give identical bits — also for the scalar results of step / cost — and the
+    result equals round 1's atomic scatter (PVLM_BA_ATOMICS=1, read when the library is first used: a child process) to
+    rounding.  A track with two observations in the SAME camera exercises the (i, j != i) couples of a diagonal block."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import panovlm_amd as pv
+        from tests import synth
+        rng = np.random.default_rng(77)
+        b = synth.random_bundle(rng, n_cams=40, n_points=6000, max_track=9)
+        cam = b["cam"].copy(); off = b["off"]
+        for p in range(0, 200, 7):                      # repeat a camera inside some tracks
+            if off[p + 1] - off[p] >= 3: cam[off[p] + 2] = cam[off[p]]
+        ctx = pv.Context(0)
+        ctx.set_poses(b["aa"], b["t"])
+        outs = []
+        for rep in range(2):
+            bs = pv.BundleSet(ctx, off, cam, b["bearing"], b["X"], 1.3)
+            packed = bs.reduce(pv.LOSS_HUBER, 0.01, init_scale=True, radius=50.0)
+            o3 = bs.step(np.full((bs.n_cams, 6), 1e-3), pv.LOSS_HUBER, 0.01)
+            c = bs.cost(pv.LOSS_HUBER, 0.01, candidate=True)
+            outs.append(np.concatenate([packed, o3, [c]]))
+            bs.close()
+        assert np.array_equal(outs[0], outs[1]), "not reproducible"
+        np.save(sys.argv[1], outs[0])
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("gather", "atomics"):
+            env = dict(os.environ)
+            if mode == "atomics":
+                env["PVLM_BA_ATOMICS"] = "1"
+            path = os.path.join(d, mode + ".npy")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+            if mode == "gather":
+                assert r.returncode == 0, r.stderr[-1500:]          # the gather path is bitwise reproducible
+            else:
+                assert os.path.exists(path) or "not reproducible" in r.stderr, r.stderr[-1500:]
+            if os.path.exists(path):
+                res[mode] = np.load(path)
+    if "atomics" in res:
+        a, g = res["atomics"], res["gather"]
+        assert np.allclose(a, g, rtol=1e-10, atol=1e-10 * np.abs(g).max())
+    assert np.abs(res["gather"]).max() > 0
+
+
 def test_empty_and_state_errors(ctx):
     import panovlm_amd as pv
     c2 = pv.Context(0)
