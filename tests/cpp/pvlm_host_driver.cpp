@@ -303,21 +303,24 @@ int main(int argc, char** argv) {
         for (auto& p : c) rd(f, &p.x, 4);
       }
       const int reps = atoi(argv[3]);
-      double reorder = 0, extract = 0; size_t flat = 0, less = 0, pts = 0;
+      double reorder = 0, extract = 0, lines = 0; size_t flat = 0, less = 0, pts = 0, segs = 0, corner = 0;
       for (int r = 0; r < reps; ++r)
         for (const PointCloud& c : raw) {
           Velodyne v; v.cloud = c;
           const auto t0 = std::chrono::steady_clock::now();
           v.ReOrderVLP();
           const auto t1 = std::chrono::steady_clock::now();
-          v.ExtractFeatures(1000.f, 5.f, ADAPTIVE, atoi(argv[4]) != 0);
+          v.ExtractFeatures(1000.f, 5.f, ADAPTIVE, atoi(argv[4]) != 0, nullptr, false);     // planar branch + edge points
           const auto t2 = std::chrono::steady_clock::now();
+          v.EdgeToLine();                                                                   // line branch (sensors/Velodyne.cpp:1269-1324)
+          const auto t3 = std::chrono::steady_clock::now();
           reorder += std::chrono::duration<double>(t1 - t0).count(); extract += std::chrono::duration<double>(t2 - t1).count();
+          lines += std::chrono::duration<double>(t3 - t2).count(); segs += v.edge_segmented.size(); corner += v.cornerLessSharp.size();
           flat += v.surfFlat.size(); less += v.surfLessFlat.size(); pts += c.size();
         }
       const double n = (double)reps * ns;
-      printf("featbench scans %d reps %d points_per_scan %.0f reorder_ms %.4f extract_ms %.4f flat %.1f less_flat %.1f\n", ns, reps, pts / n, 1e3 * reorder / n,
-             1e3 * extract / n, flat / n, less / n);
+      printf("featbench scans %d reps %d points_per_scan %.0f reorder_ms %.4f extract_ms %.4f lines_ms %.4f flat %.1f less_flat %.1f segments %.1f corner %.1f\n", ns, reps,
+             pts / n, 1e3 * reorder / n, 1e3 * extract / n, 1e3 * lines / n, flat / n, less / n, segs / n, corner / n);
     } else if (cmd == "byangle") {
       auto l = LoadScans(argv[2]);  // one LOCAL-frame scan
       std::ifstream f(argv[3], std::ios::binary);

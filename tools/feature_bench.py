@@ -10,6 +10,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--clutter", type=int, default=30, help="boxes standing in the room: more edges, more line segments")
     a = ap.parse_args()
     from oracle import oracle as orc     # the CPU leg of a measurement tool, not the product
     from panovlm_amd import synthetic as sy
@@ -17,7 +18,7 @@ def main():
     scans = []
     for k in range(a.scans):
         R, t = sy.estimated_pose(k)
-        scans.append(dict(id=k, R_wl=R, t_wl=t, raw=sy.raw_vlp16_scan(k, clutter=30)))
+        scans.append(dict(id=k, R_wl=R, t_wl=t, raw=sy.raw_vlp16_scan(k, clutter=a.clutter)))
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "raw.bin")
         host_io.write_raw_scans(path, scans)
@@ -29,8 +30,9 @@ def main():
             orc.lib().orc_features_free(orc._features_handle(s["raw"]))
     oracle_ms = 1e3 * (time.perf_counter() - t0) / (a.reps * a.scans)
     print(json.dumps(dict(scans=a.scans, reps=a.reps, points_per_scan=host["points_per_scan"], host_reorder_ms=host["reorder_ms"], host_extract_ms=host["extract_ms"],
-                          host_ms_per_scan=host["reorder_ms"] + host["extract_ms"], oracle_ms_per_scan=oracle_ms, surf_flat=host["flat"], surf_less_flat=host["less_flat"],
-                          room_454_scans_one_thread_s=454e-3 * (host["reorder_ms"] + host["extract_ms"]))))
+                          host_lines_ms=host["lines_ms"], host_ms_per_scan=host["reorder_ms"] + host["extract_ms"] + host["lines_ms"], oracle_ms_per_scan=oracle_ms,
+                          surf_flat=host["flat"], surf_less_flat=host["less_flat"], line_segments=host["segments"], corner_points=host["corner"],
+                          room_454_scans_one_thread_s=454e-3 * (host["reorder_ms"] + host["extract_ms"] + host["lines_ms"]))))
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--keep", default="", help="write the scene files here and print the driver command (e.g. to run it under rocprofv3)")
+    ap.add_argument("--repeat", type=int, default=1, help="run the driver this many times on the same files and compare the results bit for bit")
     a = ap.parse_args()
     rng = np.random.default_rng(2)
     rows, cols = 2880, 5760
@@ -68,6 +69,10 @@ def main():
         t0 = time.perf_counter()
         out = host_io.run("joint", lp, fp, 3, a.iters, 0, 1, 0.05, 1.0, 0.3, 0.01, 25.0, 1.0, sp, timeout=3000)   # Room weights (config/Room.txt:81-83)
         wall = time.perf_counter() - t0
+        results = lambda o: [l for l in o if l.startswith(("iter", "pose", "fpose", "point"))]
+        same = all(results(host_io.run("joint", lp, fp, 3, a.iters, 0, 1, 0.05, 1.0, 0.3, 0.01, 25.0, 1.0, sp, timeout=3000)) == results(out) for _ in range(a.repeat - 1))
+        if a.repeat > 1:
+            print("reproducible over %d runs (costs, step counts, every pose and point): %s" % (a.repeat, same))
     print("GPU JointOptimize: %d frames + %d scans, %d tracks / %d observations, %.2f s wall" % (F, F, M, n_obs, wall))
     for l in out:
         if l.startswith("iter"):

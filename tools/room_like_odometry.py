@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--iters", type=int, default=7)
     ap.add_argument("--twin", type=int, default=0)
     ap.add_argument("--lines", type=int, default=0, help="1: add line features (room edges) and the line-to-line term (Room config)")
+    ap.add_argument("--repeat", type=int, default=1, help="run the driver this many times on the same file and compare the results bit for bit")
     a = ap.parse_args()
     rng = np.random.default_rng(1)
     edges = room_edges() if a.lines else None
@@ -57,6 +58,10 @@ def main():
         t0 = time.perf_counter()
         out = host_io.run("odometry", path, a.iters, 1, 1, 1 if a.lines else 0, 1, 0.05, 1.0, 0.3, timeout=3000)
         wall = time.perf_counter() - t0
+        results = lambda o: [l for l in o if l.startswith(("iter", "pose"))]
+        same = all(results(host_io.run("odometry", path, a.iters, 1, 1, 1 if a.lines else 0, 1, 0.05, 1.0, 0.3, timeout=3000)) == results(out) for _ in range(a.repeat - 1))
+        if a.repeat > 1:
+            print("reproducible over %d runs (costs, step counts, every pose): %s" % (a.repeat, same))
     iters = [l for l in out if l.startswith("iter")]
     poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
     e0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
