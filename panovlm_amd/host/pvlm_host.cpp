@@ -21,6 +21,7 @@
 #include <numeric>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 
 namespace pvlm {
 
@@ -933,11 +934,11 @@ bool CostFunction::Evaluate(double const* const* parameters, double* residuals, 
 
 struct Problem::Impl {
   // parameter blocks: every double[3] the caller registered, in first-seen order
-  std::map<double*, int> block_id;
+  std::unordered_map<double*, int> block_id;                 // only looked up, never iterated: ids are handed out in arrival order
   std::vector<double*> blocks;
   std::vector<bool> constant;
   // poses = (aa block, t block) pairs, in first-seen order
-  std::map<std::pair<int, int>, int> pose_id;
+  std::unordered_map<unsigned long long, int> pose_id;       // key: block id of aa << 32 | block id of t
   std::vector<std::pair<int, int>> poses;
   // A group = one device residual set.  Host-built groups collect consecutive AddResidualBlock
   // calls with identical (kind, flags, weight, loss); consecutive blocks with the same pose pair
@@ -978,10 +979,11 @@ struct Problem::Impl {
   }
   int Pose(double* aa, double* t) {
     const std::pair<int, int> k(Block(aa), Block(t));
-    auto it = pose_id.find(k);
+    const unsigned long long key = ((unsigned long long)(unsigned)k.first << 32) | (unsigned)k.second;
+    auto it = pose_id.find(key);
     if (it != pose_id.end()) return it->second;
     const int id = (int)poses.size();
-    pose_id[k] = id; poses.push_back(k);
+    pose_id[key] = id; poses.push_back(k);
     return id;
   }
 };
@@ -1189,7 +1191,8 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     if (b.obs_pose.empty()) continue;
     have_bundles = true;
     if (b.set) continue;
-    std::map<int, int> pidx, cidx;
+    StageTimer stage_timer_bundle_("solve: reprojection set creation (host grouping by point + pvlm_ba_create)");
+    std::unordered_map<int, int> pidx, cidx;      // ids are handed out in order of first appearance: the container's order plays no role
     const size_t n = b.obs_pose.size();
     std::vector<int> obs_dev_point(n);
     for (size_t i = 0; i < n; ++i) {
