@@ -251,4 +251,8 @@ def test_knn_results_larger_than_the_staging_arena(ctx, oracle):
     valid = od <= np.float32(1.0)
     assert np.array_equal(idx[sel], np.where(valid, oi, -1)) and np.array_equal(sqd[sel], np.where(valid, od, np.float32(np.inf)))
     assert (idx >= 0).mean() > 0.3
+    # a single read-back above 64 MB bypasses the arena (the runtime's own pageable path): 1.8 M queries x 10 x 4 B = 72 MB
+    big = np.concatenate([q, q])
+    ib, db = ctx.knn(scan, big, 10, 1.0)
+    assert np.array_equal(ib[:len(q)], idx) and np.array_equal(ib[len(q):], idx) and np.array_equal(db[:len(q)], sqd)
     scan.close()
