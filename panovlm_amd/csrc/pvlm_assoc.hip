@@ -739,6 +739,7 @@ static pvlm_status cloud_plan(pvlm_ctx* ctx, CloudPlan& c, int n, const float* x
   float h = std::sqrt(4.f * area / (float)n);
   const char* env = getenv("PVLM_CELL");
   if (env && atof(env) > 0) h = (float)atof(env);
+  if (const char* sc = getenv("PVLM_CELL_SCALE")) if (atof(sc) > 0) h *= (float)atof(sc);     // measured variants of the heuristic
   h = std::min(std::max(h, 0.02f), 4.0f);
   c.h = h;
   for (int k = 0; k < 3; ++k) c.origin[k] = mn[k] - h;
