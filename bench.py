@@ -614,7 +614,8 @@ def mvs_block(ctx, pv):
     """BASELINE.json config 5: the panoramic PatchMatch kernels on views RESIDENT in HBM (pvlm_mvs_views_*), at the reference's
     Room size (5.7K at scale -2 = 1440 x 720, config/Room.txt:87) and at the full 5.7K size.  Scene: a textured sphere of
     radius 3 m seen from three camera centres 0.2 m apart (every window projects into every neighbour).  K11 = scoring pass
-    (InitConfMap), K13 = one checkerboard PatchMatch iteration (two colour passes), K12 = FilterDepthImageRefine.
+    (InitConfMap), K13 = one checkerboard PatchMatch iteration (two colour passes), K13s = one iteration of the sequential sweep
+    the Room / Floor configs select (one launch per anti-diagonal), K12 = FilterDepthImageRefine.
     The NCC sums run in the reference's sequential order and the kernels are VALU-bound, so their roof is instruction
     issue, not HBM: the algorithmic HBM bytes (29 B per pixel and view touched) are reported next to the time."""
     out = {}
@@ -651,6 +652,7 @@ def mvs_one_size(ctx, rows, cols, k13_reps=2):
     res = {"pixels": rows * cols, "neighbours": 2, "window": "7x7"}
     for name, fn, reps in (("k11_scoring_pass", lambda: V.estimate(ref, nei, Rn, tn, max_iter=-1), 3),
                            ("k13_patchmatch_iteration", lambda: V.estimate(ref, nei, Rn, tn, max_iter=1, seed=3), k13_reps),
+                           ("k13s_sequential_iteration", lambda: V.estimate(ref, nei, Rn, tn, max_iter=1, seed=3, sequential=True), 1),
                            ("k12_fusion_filter_refine", lambda: V.filter_refine(ref, nei, Rn, tn), 3)):
         fn(); ctx.synchronize()
         V.upload(ref, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))

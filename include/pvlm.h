@@ -397,6 +397,16 @@ pvlm_status pvlm_mvs_propagate(pvlm_ctx* ctx, int rows, int cols, int half_windo
                                const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
                                const float* const* nei_depth_or_null, const unsigned char* depth_constant_or_null, float min_depth, float max_depth,
                                unsigned long long seed, int max_iter, float conf_threshold);
+/* The same with Propagate::SEQUENTIAL — the strategy config/Room.txt:90 and config/Floor.txt:88 select (propagate_strategy = 2):
+ * MVS::PropagateSequential (mvs/MVS.cpp:1057-1097) walks the image in raster order on even iterations (a pixel takes the
+ * hypotheses of its LEFT and UPPER neighbour, which the walk has just updated) and backwards on odd ones (right, lower); pixels
+ * with patch.sq0 <= 0 are skipped.  Here every anti-diagonal col + row = d is one launch, ascending (descending) d: a pixel
+ * reads only its four direct neighbours, so the pixels of a diagonal are independent and each sees exactly what the raster walk
+ * shows it — same maps as the sequential loop, bit for bit.  Draw k of pixel e in iteration i = hash(seed, i, e, k). */
+pvlm_status pvlm_mvs_propagate_sequential(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                          const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal,
+                                          float* conf, const float* const* nei_depth_or_null, const unsigned char* depth_constant_or_null,
+                                          float min_depth, float max_depth, unsigned long long seed, int max_iter, float conf_threshold);
 
 /* Depth-map fusion filter: MVS::FilterDepthImage (mvs/MVS.cpp:1735-1790) with ProjectDepthConfToRef (:2011-2070, depth):
  * every neighbour depth map is forward-projected into the reference view (4-pixel splat, nearest range wins); a reference
@@ -425,7 +435,7 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
  * sweeps and fusion filter — and its use as somebody's neighbour — cost no PCIe traffic.  Same kernels and results as
  * the per-call entry points above.  `nei` holds view indices (each != ref); R_nr / t_nr as above.
  *   pvlm_mvs_views_estimate      max_iter < 0: MVS::InitConfMap(ref, ., use_geometry); max_iter >= 0: MVS::EstimateDepthMapSingle
- *                                (checkerboard).  use_geometry reads the neighbours' depth_filter (the photometric depth the reference
+ *                                (checkerboard; pvlm_mvs_views_estimate_sequential: the sequential sweep).  use_geometry reads the neighbours' depth_filter (the photometric depth the reference
  *                                keeps there, mvs/MVS.cpp:470-473): pvlm_mvs_views_snapshot_depth copies depth -> depth_filter of a view.
  *   pvlm_mvs_views_filter_refine MVS::FilterDepthImageRefine(ref): writes depth_filter / conf_filter of ref, zeroes its conf where depth <= 0.
  * estimate / filter_refine / snapshot_depth are asynchronous on the context's stream; upload / download synchronise.
@@ -441,6 +451,10 @@ pvlm_status pvlm_mvs_views_snapshot_depth(pvlm_ctx* ctx, pvlm_mvs_views* views, 
 pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* views, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
                                     int half_window, int step, int use_geometry, const unsigned char* depth_constant_or_null, float min_depth,
                                     float max_depth, unsigned long long seed, int max_iter, float conf_threshold);
+/* EstimateDepthMapSingle with Propagate::SEQUENTIAL on a resident view (see pvlm_mvs_propagate_sequential); max_iter >= 0 */
+pvlm_status pvlm_mvs_views_estimate_sequential(pvlm_ctx* ctx, pvlm_mvs_views* views, int ref, int n_neighbors, const int* nei, const float* R_nr,
+                                               const float* t_nr, int half_window, int step, int use_geometry, const unsigned char* depth_constant_or_null,
+                                               float min_depth, float max_depth, unsigned long long seed, int max_iter, float conf_threshold);
 pvlm_status pvlm_mvs_views_filter_refine(pvlm_ctx* ctx, pvlm_mvs_views* views, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
                                          const unsigned char* depth_constant_or_null, float depth_diff_threshold, float min_depth, float max_depth);
 

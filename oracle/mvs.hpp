@@ -543,8 +543,9 @@ inline bool PerturbDepthNormal3(const MvsSweep& S, MvsRng& rng, int px, int py, 
   return true;
 }
 
-// ProcessPixel :721-772 with the four direct neighbours PropagateCheckerBoard passes (:1113-1114)
-inline void ProcessPixel(const MvsSweep& S, MvsRng& rng, int px, int py, const PixelPatch& patch) {
+// ProcessPixel :721-772; `neighbor`: the pixels whose hypotheses are propagated — the four direct neighbours PropagateCheckerBoard
+// passes (:1113-1114), or the two PropagateSequential passes (:1073, :1091)
+inline void ProcessPixel(const MvsSweep& S, MvsRng& rng, int px, int py, const PixelPatch& patch, int n_neighbor, const int* nx, const int* ny) {
   const int rows = S.ref.rows, cols = S.ref.cols;
   const size_t e = (size_t)py * cols + px;
   const bool keep_depth_constant = S.depth_constant && S.depth_constant[e];
@@ -560,9 +561,8 @@ inline void ProcessPixel(const MvsSweep& S, MvsRng& rng, int px, int py, const P
     for (int k = 0; k < 3; ++k) { c.point[k] = S.unit[3 * ne + k] * d; c.normal[k] = S.normal[3 * ne + k]; }
     c.depth = d;
   }
-  const int nx[4] = {px - 1, px, px + 1, px}, ny[4] = {py, py - 1, py, py + 1};
   const float* view_ray = S.unit + 3 * e;
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < n_neighbor; ++q) {
     if (!(nx[q] >= 0 && ny[q] >= 0 && nx[q] < cols && ny[q] < rows)) continue;
     const size_t ne = (size_t)ny[q] * cols + nx[q];
     float depth_neighbor = S.depth[ne];
@@ -602,7 +602,8 @@ inline void EstimateDepthMapCheckerBoard(const MvsView& ref, int n_neighbors, co
           FillPixelPatch(ref, col, row, patch);        // frame.patch_map[e] of InitPatchMap
           if (patch.sq0 <= 1e-6) continue;
           MvsRng rng{pass_seed, (uint64_t)e};
-          ProcessPixel(S, rng, col, row, patch);
+          const int nx[4] = {col - 1, col, col + 1, col}, ny[4] = {row, row - 1, row, row + 1};
+          ProcessPixel(S, rng, col, row, patch, 4, nx, ny);
         }
       }
     }
@@ -614,6 +615,44 @@ inline void EstimateDepthMapCheckerBoard(const MvsView& ref, int n_neighbors, co
     }
 }
 
+// EstimateDepthMapSingle(ref, SEQUENTIAL, max_iter, conf_threshold, use_geometry) :682-720 with PropagateSequential :1057-1097 — the
+// strategy config/Room.txt:90 / config/Floor.txt:88 select (propagate_strategy = 2).  Even iterations walk the image from the top
+// left in raster order and hand ProcessPixel the left and the upper neighbour; odd iterations walk back from the bottom right
+// with the right and the lower neighbour.  Strictly sequential, as upstream (there the parallelism is one image per thread).
+// Random draws of pixel e in iteration i: MvsRng{MvsPassSeed(seed, i), e} — the counter stream the checkerboard uses per colour pass.
+inline void EstimateDepthMapSequential(const MvsView& ref, int n_neighbors, const uint8_t* const* nei_gray, const float* R_nr, const float* t_nr,
+                                       float* depth, float* normal, float* conf, const float* const* nei_depth, const unsigned char* depth_constant,
+                                       float min_depth, float max_depth, uint64_t seed, int max_iter, float conf_threshold) {
+  std::vector<float> unit((size_t)ref.rows * ref.cols * 3);
+  const Equirectangular eq(ref.rows, ref.cols);
+  for (int i = 0; i < ref.rows; ++i)
+    for (int j = 0; j < ref.cols; ++j) { const float px[2] = {(float)j, (float)i}; eq.ImageToCam(px, 1.f, &unit[3 * ((size_t)i * ref.cols + j)]); }
+  const MvsSweep S{ref, unit.data(), n_neighbors, nei_gray, R_nr, t_nr, nei_depth, depth_constant, min_depth, max_depth, depth, normal, conf};
+  PixelPatch patch;
+  auto visit = [&](int col, int row, int dir, uint64_t pass_seed) {
+    const size_t e = (size_t)row * ref.cols + col;
+    if (depth[e] <= 0) return;                          // :1066, :1084
+    FillPixelPatch(ref, col, row, patch);               // frame.patch_map[e] of InitPatchMap
+    if (patch.sq0 <= 0) return;                         // :1069, :1087
+    MvsRng rng{pass_seed, (uint64_t)e};
+    const int nx[2] = {col + dir, col}, ny[2] = {row, row + dir};
+    ProcessPixel(S, rng, col, row, patch, 2, nx, ny);
+  };
+  for (int iter = 0; iter < max_iter; ++iter) {
+    const uint64_t pass_seed = MvsPassSeed(seed, iter);
+    if (iter % 2 == 0) {
+      for (int row = 0; row < ref.rows; ++row) for (int col = 0; col < ref.cols; ++col) visit(col, row, -1, pass_seed);
+    } else {
+      for (int row = ref.rows - 1; row >= 0; --row) for (int col = ref.cols - 1; col >= 0; --col) visit(col, row, +1, pass_seed);
+    }
+  }
+  for (int i = 0; i < ref.cols; ++i)
+    for (int j = 0; j < ref.rows; ++j) {
+      const size_t e = (size_t)j * ref.cols + i;
+      if (depth_constant && depth_constant[e]) continue;
+      if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0; }
+    }
+}
 
 // MVS::SelectNeighborKNN (mvs/MVS.cpp:334-382).  valid[i], R_wc (9, row-major), t_wc (3) per frame.  Output: for every frame the
 // list of (neighbour id, R_nr float 9, t_nr float 3).  KdTreeFLANN::nearestKSearch restated as a brute-force sorted float32

@@ -327,8 +327,9 @@ def mvs_init_conf_map(ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_windo
 
 
 def mvs_propagate(ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_window=3, step=1, nei_depths=None, depth_constant=None, min_depth=0.1,
-                  max_depth=20.0, seed=1, max_iter=1, conf_threshold=-1.0):
-    """EstimateDepthMapSingle(CHECKER_BOARD) (mvs/MVS.cpp:682-772, :1098-1129, :1254-1431): returns (depth, normal, conf) copies."""
+                  max_depth=20.0, seed=1, max_iter=1, conf_threshold=-1.0, sequential=False):
+    """EstimateDepthMapSingle(CHECKER_BOARD) (mvs/MVS.cpp:682-772, :1098-1129, :1254-1431), or with sequential=True
+    EstimateDepthMapSingle(SEQUENTIAL) (PropagateSequential :1057-1097, single-threaded): returns (depth, normal, conf) copies."""
     ref = np.ascontiguousarray(ref_gray, np.uint8); rows, cols = ref.shape
     neis = [np.ascontiguousarray(g, np.uint8) for g in nei_grays]
     ptrs = (C.POINTER(C.c_ubyte) * max(len(neis), 1))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in neis])
@@ -339,9 +340,10 @@ def mvs_propagate(ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_win
         nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
         dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
     dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
-    lib().orc_mvs_propagate(C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte), C.c_int(len(neis)), ptrs, _p(R, C.c_float),
-                            _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float), dptrs, _p(dc, C.c_ubyte), C.c_float(min_depth),
-                            C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter), C.c_float(conf_threshold))
+    fn = lib().orc_mvs_propagate_sequential if sequential else lib().orc_mvs_propagate
+    fn(C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte), C.c_int(len(neis)), ptrs, _p(R, C.c_float),
+       _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float), dptrs, _p(dc, C.c_ubyte), C.c_float(min_depth),
+       C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter), C.c_float(conf_threshold))
     return d, nrm, c
 
 

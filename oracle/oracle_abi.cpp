@@ -247,6 +247,14 @@ void orc_mvs_propagate(int rows, int cols, int half_window, int step, const unsi
   EstimateDepthMapCheckerBoard(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth, seed, max_iter,
                                conf_threshold);
 }
+// EstimateDepthMapSingle(SEQUENTIAL) — PropagateSequential mvs/MVS.cpp:1057-1097 (config/Room.txt:90 propagate_strategy = 2)
+void orc_mvs_propagate_sequential(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors, const unsigned char* const* nei_gray,
+                                  const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf, const float* const* nei_depth,
+                                  const unsigned char* depth_constant, float min_depth, float max_depth, unsigned long long seed, int max_iter, float conf_threshold) {
+  MvsView v{rows, cols, half_window, step, ref_gray};
+  EstimateDepthMapSequential(v, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth, seed, max_iter,
+                             conf_threshold);
+}
 void orc_mvs_init_depth_normal(int rows, int cols, const unsigned short* lidar16, const float* mask, float min_depth, float max_depth, int keep_const,
                                unsigned long long seed, float* depth, float* normal, unsigned char* depth_constant) {
   InitDepthNormal(rows, cols, lidar16, mask, min_depth, max_depth, keep_const != 0, seed, depth, normal, depth_constant);

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate", "pvlm_mvs_views_create", "pvlm_mvs_views_destroy", "pvlm_mvs_views_upload", "pvlm_mvs_views_download",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate", "pvlm_mvs_propagate_sequential", "pvlm_mvs_views_estimate_sequential", "pvlm_mvs_views_create", "pvlm_mvs_views_destroy", "pvlm_mvs_views_upload", "pvlm_mvs_views_download",
     "pvlm_mvs_views_snapshot_depth", "pvlm_mvs_views_estimate", "pvlm_mvs_views_filter_refine",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
@@ -309,8 +309,9 @@ class Context:
         return d, n, c, int(k.value)
 
     def mvs_propagate(self, ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_window=3, step=1, nei_depths=None, depth_constant=None, min_depth=0.1,
-                      max_depth=20.0, seed=1, max_iter=1, conf_threshold=-1.0):
-        """MVS::EstimateDepthMapSingle (checkerboard PatchMatch) on the GPU: returns (depth, normal, conf) copies."""
+                      max_depth=20.0, seed=1, max_iter=1, conf_threshold=-1.0, sequential=False):
+        """MVS::EstimateDepthMapSingle on the GPU — checkerboard PatchMatch, or (sequential=True) the raster-order sweep the Room /
+        Floor configs select, run anti-diagonal by anti-diagonal: returns (depth, normal, conf) copies."""
         ref = np.ascontiguousarray(ref_gray, np.uint8); rows, cols = ref.shape
         neis = [np.ascontiguousarray(g, np.uint8) for g in nei_grays]
         ptrs = (C.POINTER(C.c_ubyte) * max(len(neis), 1))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in neis])
@@ -321,10 +322,11 @@ class Context:
             nd = [np.ascontiguousarray(x, np.float32) for x in nei_depths]
             dptrs = (C.POINTER(C.c_float) * max(len(nd), 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in nd])
         dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
-        self._check(self.lib.pvlm_mvs_propagate(self._h, C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte), C.c_int(len(neis)),
-                                                ptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float), dptrs,
-                                                _p(dc, C.c_ubyte), C.c_float(min_depth), C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter),
-                                                C.c_float(conf_threshold)), "pvlm_mvs_propagate")
+        fn = self.lib.pvlm_mvs_propagate_sequential if sequential else self.lib.pvlm_mvs_propagate
+        self._check(fn(self._h, C.c_int(rows), C.c_int(cols), C.c_int(half_window), C.c_int(step), _p(ref, C.c_ubyte), C.c_int(len(neis)),
+                       ptrs, _p(R, C.c_float), _p(t, C.c_float), _p(d, C.c_float), _p(nrm, C.c_float), _p(c, C.c_float), dptrs,
+                       _p(dc, C.c_ubyte), C.c_float(min_depth), C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter),
+                       C.c_float(conf_threshold)), "pvlm_mvs_propagate_sequential" if sequential else "pvlm_mvs_propagate")
         return d, nrm, c
 
     def mvs_filter_depth(self, nei_depths, R_nr, t_nr, depth, conf=None, depth_constant=None, thr=0.01):
@@ -467,11 +469,12 @@ class MvsViews:
         return ids, _f32(R_nr).reshape(-1), _f32(t_nr).reshape(-1)
 
     def estimate(self, ref, nei, R_nr, t_nr, half_window=3, step=1, use_geometry=False, depth_constant=None, min_depth=0.1, max_depth=20.0, seed=1, max_iter=-1,
-                 conf_threshold=-1.0):
-        """max_iter < 0: InitConfMap; otherwise EstimateDepthMapSingle (checkerboard) with max_iter iterations."""
+                 conf_threshold=-1.0, sequential=False):
+        """max_iter < 0: InitConfMap; otherwise EstimateDepthMapSingle with max_iter iterations (checkerboard, or the sequential sweep)."""
         ids, R, t = self._nb(nei, R_nr, t_nr)
         dc = None if depth_constant is None else np.ascontiguousarray(depth_constant, np.uint8)
-        self.ctx._check(self.ctx.lib.pvlm_mvs_views_estimate(self.ctx._h, self._h, C.c_int(ref), C.c_int(len(ids)), _p(ids, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
+        fn = self.ctx.lib.pvlm_mvs_views_estimate_sequential if (sequential and max_iter >= 0) else self.ctx.lib.pvlm_mvs_views_estimate
+        self.ctx._check(fn(self.ctx._h, self._h, C.c_int(ref), C.c_int(len(ids)), _p(ids, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
                                                              C.c_int(half_window), C.c_int(step), C.c_int(1 if use_geometry else 0), _p(dc, C.c_ubyte),
                                                              C.c_float(min_depth), C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter),
                                                              C.c_float(conf_threshold)), "pvlm_mvs_views_estimate")

@@ -300,7 +300,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
   pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
   WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
-  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c);
+  const int pdx[4] = {-1, 0, 1, 0}, pdy[4] = {0, -1, 0, 1};
+  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 4, pdx, pdy);
+  if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+}
+
+// Sequential sweep (PropagateSequential :1057-1097, the strategy config/Room.txt and config/Floor.txt select: propagate_strategy = 2):
+// upstream walks the image in raster order (even iterations; odd ones backwards) and a pixel takes the hypotheses of its left and
+// upper neighbour, which that very walk has just updated.  A pixel only ever reads its four direct neighbours, so all pixels of an
+// anti-diagonal col + row = d are independent of each other and see exactly what the raster walk shows them: the neighbours on
+// d - 1 already updated, those on d + 1 not yet.  One launch per anti-diagonal (ascending d, or descending for the backward
+// walk), one wave per pixel: the same result as the sequential loop, bit for bit.
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_diag(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
+    float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int diag, int backward) {
+  const int r0 = max(0, diag - (cols - 1)), r1 = min(rows - 1, diag);
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int py = r0 + w;
+  if (py > r1) return;
+  const int px = diag - py;
+  const long long e = (long long)py * cols + px;
+  float dep = depth[e];
+  if (dep <= 0) return;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
+  float4* lds = strips[threadIdx.x >> 6];
+  PatchRegs<M> P;
+  wave_fill_patch<M>(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
+  if (!P.inside || P.sq0 <= 0) return;                                    // patch.sq0 <= 0 (:1069, :1087)
+  float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+  float c = conf[e];
+  pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+  pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
+  WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
+  const int sgn = backward ? 1 : -1;
+  const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};                          // (col - 1, row), (col, row - 1)  /  (col + 1, row), (col, row + 1)
+  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
 // launch helpers: M = 1 for windows of at most 64 texels (one texel per lane), M = PVLM_MVS_MAXM otherwise
@@ -320,6 +356,25 @@ static void launch_mvs_propagate(hipStream_t s, int rows, int cols, int half_win
     hipLaunchKernelGGL(k_mvs_propagate<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset);
   else
     hipLaunchKernelGGL(k_mvs_propagate<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset);
+}
+
+// one iteration of the sequential sweep: every anti-diagonal in walking order (iteration parity = direction, :1061, :1079)
+static void launch_mvs_propagate_sequential(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
+                                            const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, const unsigned char* depth_constant,
+                                            float min_depth, float max_depth, unsigned long long pass_seed, int iter) {
+  const int backward = iter % 2, n_diag = rows + cols - 1;
+  const bool small = pvlm_mvs::num_texels(half_window, step) <= 64;
+  for (int q = 0; q < n_diag; ++q) {
+    const int d = backward ? n_diag - 1 - q : q;
+    const int len = std::min(rows - 1, d) - std::max(0, d - (cols - 1)) + 1;
+    const dim3 grid((unsigned)((len + 3) / 4)), block(256);
+    if (small)
+      hipLaunchKernelGGL(k_mvs_propagate_diag<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth,
+                         pass_seed, d, backward);
+    else
+      hipLaunchKernelGGL(k_mvs_propagate_diag<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant,
+                         min_depth, max_depth, pass_seed, d, backward);
+  }
 }
 
 // MVS::InitDepthNormal (mvs/MVS.cpp:496-584, the `#elif 1` branch :511-514): LiDAR depth image (uint16, depth * 256) where it has a
@@ -516,7 +571,7 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
 static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
                            const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
                            const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth, unsigned long long seed,
-                           int max_iter, float conf_threshold) {
+                           int max_iter, float conf_threshold, int strategy = 1) {
   if (!ctx || rows <= 0 || cols <= 0 || half_window < 1 || step < 1 || !ref_gray || n_neighbors < 0 || n_neighbors > 16 || !depth || !normal || !conf ||
       (n_neighbors > 0 && (!nei_gray || !R_nr || !t_nr)))
     return PVLM_ERR_ARG;
@@ -558,6 +613,13 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
       if (max_iter < 0) {
         pvlm_prof_scope prof(ctx, 1);   // timed with the "materialise" slot of pvlm_profile_* (bench / tools)
         launch_mvs_conf(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf);
+      } else if (strategy == 2) {
+        for (int iter = 0; iter < max_iter; ++iter) {
+          pvlm_prof_scope prof(ctx, 1);                  // one profile interval per iteration (rows + cols - 1 launches)
+          launch_mvs_propagate_sequential(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf, d_const, min_depth, max_depth,
+                                          pvlm_mvs::pass_seed(seed, iter), iter);
+        }
+        hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (long long)npix, d_const, conf_threshold, d_depth, d_normal, d_conf);
       } else {
         for (int iter = 0; iter < max_iter; ++iter)
           for (int offset = 0; offset <= 1; ++offset) {
@@ -673,6 +735,15 @@ pvlm_status pvlm_mvs_propagate(pvlm_ctx* ctx, int rows, int cols, int half_windo
                  depth_constant, min_depth, max_depth, seed, max_iter, conf_threshold);
 }
 
+pvlm_status pvlm_mvs_propagate_sequential(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                          const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                          const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                          unsigned long long seed, int max_iter, float conf_threshold) {
+  if (max_iter < 0) return PVLM_ERR_ARG;
+  return mvs_run(ctx, "pvlm_mvs_propagate_sequential", rows, cols, half_window, step, ref_gray, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth,
+                 depth_constant, min_depth, max_depth, seed, max_iter, conf_threshold, 2);
+}
+
 
 // ---- resident view set: the same kernels with the maps kept in HBM between the scoring pass, the sweeps and the
 // fusion filter (the per-call entry points above move 30-50 MB over PCIe per call, which is most of their wall time) ----
@@ -786,9 +857,9 @@ static void views_neighbours(const pvlm_mvs_views* v, int n_neighbors, const int
 }
 
 // the scoring pass (max_iter < 0) or the PatchMatch sweep of view `ref` against resident neighbours; asynchronous on ctx->stream
-pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
-                                    int half_window, int step, int use_geometry, const unsigned char* depth_constant, float min_depth, float max_depth,
-                                    unsigned long long seed, int max_iter, float conf_threshold) {
+static pvlm_status views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
+                                  int half_window, int step, int use_geometry, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                  unsigned long long seed, int max_iter, float conf_threshold, int strategy) {
   if (!ctx || !views_ids_ok(v, ref, n_neighbors, nei) || half_window < 1 || step < 1 || (n_neighbors > 0 && (!R_nr || !t_nr))) return PVLM_ERR_ARG;
   if (pvlm_mvs::num_texels(half_window, step) > 64 * PVLM_MVS_MAXM) { PVLM_SET_ERR(ctx, "NCC window of %d texels exceeds %d", pvlm_mvs::num_texels(half_window, step), 64 * PVLM_MVS_MAXM); return PVLM_ERR_ARG; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
@@ -804,6 +875,13 @@ pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, i
       pvlm_prof_scope prof(ctx, 1);
       launch_mvs_conf(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o);
     } else {
+      if (strategy == 2) {
+        for (int iter = 0; iter < max_iter; ++iter) {
+          pvlm_prof_scope prof(ctx, 1);
+          launch_mvs_propagate_sequential(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o,
+                                          d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, iter), iter);
+        }
+      } else
       for (int iter = 0; iter < max_iter; ++iter)
         for (int offset = 0; offset <= 1; ++offset) {
           pvlm_prof_scope prof(ctx, 1);
@@ -817,6 +895,18 @@ pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, i
   }
   if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_estimate: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
   return PVLM_OK;
+}
+
+pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
+                                    int half_window, int step, int use_geometry, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                    unsigned long long seed, int max_iter, float conf_threshold) {
+  return views_estimate(ctx, v, ref, n_neighbors, nei, R_nr, t_nr, half_window, step, use_geometry, depth_constant, min_depth, max_depth, seed, max_iter, conf_threshold, 1);
+}
+pvlm_status pvlm_mvs_views_estimate_sequential(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
+                                               int half_window, int step, int use_geometry, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                               unsigned long long seed, int max_iter, float conf_threshold) {
+  if (max_iter < 0) return PVLM_ERR_ARG;
+  return views_estimate(ctx, v, ref, n_neighbors, nei, R_nr, t_nr, half_window, step, use_geometry, depth_constant, min_depth, max_depth, seed, max_iter, conf_threshold, 2);
 }
 
 // FilterDepthImageRefine of view `ref`: reads depth / conf of the neighbours, writes depth_filter / conf_filter of ref and zeroes

@@ -448,8 +448,11 @@ struct SweepArgs {
 // ProcessPixel + PerturbDepthNormal3 for pixel (px, py).  score(normal, depth, factors, n_close) -> aggregated ScorePixel
 // value; factors = the smooth_factor of every close neighbour for that hypothesis (n_close = 0: no smoothness term).
 // depth / normal / conf: the pixel's own state, updated in place by the caller-visible references.
+// n_prop / pdx / pdy: the pixels whose hypotheses are propagated, as the reference's sweeps pass them to ProcessPixel — the
+// four direct neighbours for the checkerboard (:1113-1114), (left, up) or (right, down) for the sequential sweep (:1073, :1091).
 template <class Scorer>
-PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, Scorer& score, float& depth, float* normal, float& conf) {
+PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, Scorer& score, float& depth, float* normal, float& conf,
+                                  int n_prop, const int* pdx, const int* pdy) {
   const int rows = A.rows, cols = A.cols;
   const size_t e = (size_t)py * cols + px;
   const bool keep_depth_constant = A.depth_constant && A.depth_constant[e];
@@ -470,10 +473,10 @@ PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, 
   float factors[4];
   // ---- propagation from the four direct neighbours (:749-771)
   {
-    const int nx[4] = {px - 1, px, px + 1, px}, ny[4] = {py, py - 1, py, py + 1};
-    for (int q = 0; q < 4; ++q) {
-      if (!(nx[q] >= 0 && ny[q] >= 0 && nx[q] < cols && ny[q] < rows)) continue;
-      const size_t ne = (size_t)ny[q] * cols + nx[q];
+    for (int q = 0; q < n_prop; ++q) {
+      const int nxq = px + pdx[q], nyq = py + pdy[q];
+      if (!(nxq >= 0 && nyq >= 0 && nxq < cols && nyq < rows)) continue;
+      const size_t ne = (size_t)nyq * cols + nxq;
       float depth_neighbor = A.depth[ne];
       if (depth_neighbor <= 0) continue;
       float normal_neighbor[3] = {A.normal[3 * ne], A.normal[3 * ne + 1], A.normal[3 * ne + 2]};

@@ -186,10 +186,54 @@ extern "C" void chk_mvs_propagate(int rows, int cols, int half_window, int step,
         SweepArgs A{rows, cols, unit.data(), depth, normal, depth_constant, min_depth, max_depth};
         Rng rng{ps, (unsigned long long)e, 0u};
         SerialScorer scorer{{}, {}, rows, cols, half_window, step, px, py, n_neighbors, unit.data(), nei_gray, R_nr, t_nr, nei_depth, &P};
-        process_pixel(A, rng, px, py, scorer, dep, nr, c);
+        const int pdx[4] = {-1, 0, 1, 0}, pdy[4] = {0, -1, 0, 1};
+        process_pixel(A, rng, px, py, scorer, dep, nr, c, 4, pdx, pdy);
         depth[e] = dep; normal[3 * e] = nr[0]; normal[3 * e + 1] = nr[1]; normal[3 * e + 2] = nr[2]; conf[e] = c;
       }
     }
+  for (size_t e = 0; e < npix; ++e) {
+    if (depth_constant && depth_constant[e]) continue;
+    if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0.f; }
+  }
+}
+
+// The sequential sweep through the device bodies, in the order k_mvs_propagate_diag gives the GPU: anti-diagonal after
+// anti-diagonal, and INSIDE a diagonal from the bottom row up (the launch makes no promise about the order of its waves) — not
+// the raster order of the oracle.  Equal maps prove what the kernel relies on: the pixels of a diagonal do not depend on each other.
+extern "C" void chk_mvs_propagate_sequential(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                             const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                             const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                             unsigned long long seed, int max_iter, float conf_threshold) {
+  using namespace pvlm_mvs;
+  const size_t npix = (size_t)rows * cols;
+  std::vector<float> unit(npix * 3);
+  for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) unit_ray(rows, cols, c, r, &unit[3 * ((size_t)r * cols + c)]);
+  SerialPatch P;
+  const int n_diag = rows + cols - 1;
+  for (int iter = 0; iter < max_iter; ++iter) {
+    const unsigned long long ps = pass_seed(seed, iter);
+    const int backward = iter % 2, sgn = backward ? 1 : -1;
+    for (int q = 0; q < n_diag; ++q) {
+      const int d = backward ? n_diag - 1 - q : q;
+      const int r0 = std::max(0, d - (cols - 1)), r1 = std::min(rows - 1, d);
+      for (int py = r1; py >= r0; --py) {
+        const int px = d - py;
+        const size_t e = (size_t)py * cols + px;
+        float dep = depth[e];
+        if (dep <= 0) continue;
+        serial_fill_patch(ref_gray, rows, cols, px, py, half_window, step, P);
+        if (!P.inside || P.sq0 <= 0) continue;
+        float nr[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+        float c = conf[e];
+        SweepArgs A{rows, cols, unit.data(), depth, normal, depth_constant, min_depth, max_depth};
+        Rng rng{ps, (unsigned long long)e, 0u};
+        SerialScorer scorer{{}, {}, rows, cols, half_window, step, px, py, n_neighbors, unit.data(), nei_gray, R_nr, t_nr, nei_depth, &P};
+        const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
+        process_pixel(A, rng, px, py, scorer, dep, nr, c, 2, pdx, pdy);
+        depth[e] = dep; normal[3 * e] = nr[0]; normal[3 * e + 1] = nr[1]; normal[3 * e + 2] = nr[2]; conf[e] = c;
+      }
+    }
+  }
   for (size_t e = 0; e < npix; ++e) {
     if (depth_constant && depth_constant[e]) continue;
     if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0.f; }

@@ -134,6 +134,41 @@ def test_patchmatch_sweep_matches_oracle(ctx, oracle):
     assert err(d3) < 0.3 * err(S["depth"])
 
 
+def test_sequential_sweep_matches_oracle(ctx, oracle):
+    """pvlm_mvs_propagate_sequential — Propagate::SEQUENTIAL, the strategy config/Room.txt:90 and config/Floor.txt:88 select
+    (MVS::PropagateSequential, mvs/MVS.cpp:1057-1097): the oracle walks the image pixel by pixel in raster order (back again on odd
+    iterations), the GPU runs one launch per anti-diagonal.  Depth, normal and confidence maps identical, photometric and with the
+    geometric term / depth_constant / threshold; also through the resident view set; and it is not the checkerboard sweep."""
+    from panovlm_amd.api import MvsViews
+    from tests.test_mvs_cpu import sweep_scene
+    S = sweep_scene(oracle)
+    args = (S["gray"], S["neis"], S["Rn"], S["tn"], S["depth"], S["normal"], S["conf"])
+    valid = S["conf"] > -1
+    err = lambda d: float(np.median(np.abs(d[valid] / S["truth"][valid] - 1)))
+    for kw in (dict(max_iter=3, seed=5), dict(max_iter=2, seed=9, nei_depths=S["nd"], depth_constant=S["const"], conf_threshold=0.9)):
+        want = oracle.mvs_propagate(*args, sequential=True, **kw)
+        got = ctx.mvs_propagate(*args, sequential=True, **kw)
+        diff = [int((a != b).sum()) for a, b in zip(got, want)]
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), diff
+        assert all(np.array_equal(a, b) for a, b in zip(got, ctx.mvs_propagate(*args, sequential=True, **kw)))
+        board = ctx.mvs_propagate(*args, **kw)
+        assert not np.array_equal(board[0], got[0])
+    swept = ctx.mvs_propagate(*args, sequential=True, max_iter=3, seed=5)
+    assert err(swept[0]) < 0.3 * err(S["depth"])
+    # resident views: the same launches on maps that stay in HBM
+    rows, cols = S["depth"].shape
+    V = MvsViews(ctx, rows, cols, 4)
+    nei = [0, 2, 3]; ref = 1
+    for k, b in enumerate(nei):
+        V.upload(b, gray=S["neis"][k], depth=S["nd"][k], normal=np.zeros((rows, cols, 3), np.float32), conf=np.zeros((rows, cols), np.float32))
+        V.snapshot_depth(b)
+    V.upload(ref, gray=S["gray"], depth=S["depth"], normal=S["normal"], conf=S["conf"])
+    V.estimate(ref, nei, S["Rn"], S["tn"], max_iter=3, seed=5, sequential=True)
+    got = V.download(ref, ("depth", "normal", "conf"))
+    assert np.array_equal(got["depth"], swept[0]) and np.array_equal(got["normal"], swept[1]) and np.array_equal(got["conf"], swept[2])
+    V.close()
+
+
 def test_resident_views_equal_the_per_call_entry_points(ctx, oracle):
     """pvlm_mvs_views_*: the same kernels on maps that stay in HBM — every stage must equal the per-call API bit for bit
     (scoring pass, sweep incl. geometric consistency / depth_constant / threshold, fusion filter with its in-place conf)."""

@@ -83,6 +83,13 @@ def main():
     ctx.profile_enable(False)
     go = orc.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5, nei_depths=nd)
     geo_same = bool(np.array_equal(gg[0], go[0]) and np.array_equal(gg[1], go[1]) and np.array_equal(gg[2], go[2]))
+    # the SEQUENTIAL sweep of the Room / Floor configs: one launch per anti-diagonal (rows + cols - 1 per iteration); the oracle's
+    # raster walk is single-threaded (minutes at this size), parity is pinned at 96 x 192 (tests/test_mvs_gpu.py)
+    ctx.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=1, seed=5, sequential=True)
+    ctx.profile_enable(True)
+    sq = ctx.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=2, seed=5, sequential=True)
+    seq_ms, seq_cnt = ctx.profile_read(1)
+    ctx.profile_enable(False)
     vs = c0 > -1
     same = (np.abs(sg[0] - so[0]) <= 1e-4 * np.maximum(np.abs(so[0]), 1e-3)) & (np.abs(sg[1] - so[1]).max(axis=2) <= 1e-4) & (np.abs(sg[2] - so[2]) <= 1e-4)
     rel = lambda d: float(np.median(np.abs(d[vs] / depth[vs] - 1)))
@@ -100,6 +107,8 @@ def main():
                           sweep=dict(kernel_ms_per_colour_pass=sweep_ms / max(sweep_cnt, 1), colour_passes=int(sweep_cnt), wall_ms_one_iteration_incl_copies=sweep_wall * 1e3,
                                      cpu_oracle_s=sweep_cpu, agree_with_oracle=float(same[vs].mean()), mean_conf_gpu=float(sg[2][vs].mean()), mean_conf_oracle=float(so[2][vs].mean()),
                                      depth_err_before=rel(d1), depth_err_gpu=rel(sg[0]), depth_err_oracle=rel(so[0])),
+                          sweep_sequential=dict(ms_per_iteration=seq_ms / max(seq_cnt, 1), launches_per_iteration=a.rows + a.cols - 1,
+                                                depth_err=rel(sq[0]), mean_conf=float(sq[2][vs].mean())),
                           sweep_geometric=dict(kernel_ms_per_colour_pass=geo_ms / max(geo_cnt, 1), identical_to_oracle=geo_same),
                           cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
 

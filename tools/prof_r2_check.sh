@@ -1,11 +1,5 @@
 #!/bin/bash
-for sc in 1.0 0.8 0.65 0.5 0.4 1.3; do
-  echo -n "cell scale $sc: "; PVLM_CELL_SCALE=$sc python tools/assoc_workload.py --scans 128 --calls 3 2>/dev/null | python -c "
+python -m pytest tests/test_mvs_gpu.py tests/test_mvs_5p7k_gpu.py -q -m gpu 2>&1 | grep -E "passed|failed|Error|assert" | head -8
+python tools/mvs_bench.py 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wall', [round(w*1e3,1) for w in d['wall_s']], 'accepted', d['accepted'])"
-done
-for sc in 1.0 0.65 0.5; do
-  echo -n "raw targets, cell scale $sc: "; PVLM_CELL_SCALE=$sc python tools/assoc_workload.py --scans 32 --calls 3 --targets raw 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wall', [round(w*1e3,1) for w in d['wall_s']], 'accepted', d['accepted'])"
-done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('K13 checkerboard ms/colour', d['sweep']['kernel_ms_per_colour_pass'], 'err', d['sweep']['depth_err_gpu'], 'seq', d['sweep_sequential'])"
