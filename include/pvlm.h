@@ -455,6 +455,15 @@ pvlm_status pvlm_mvs_views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* views, int re
 pvlm_status pvlm_mvs_views_estimate_sequential(pvlm_ctx* ctx, pvlm_mvs_views* views, int ref, int n_neighbors, const int* nei, const float* R_nr,
                                                const float* t_nr, int half_window, int step, int use_geometry, const unsigned char* depth_constant_or_null,
                                                float min_depth, float max_depth, unsigned long long seed, int max_iter, float conf_threshold);
+/* The same for n_jobs DISTINCT reference views in one go (one launch per anti-diagonal covers all of them): a single view's
+ * diagonal is too short to fill the GPU, and upstream runs this strategy with one image per thread for the same reason
+ * (mvs/MVS.cpp:87-93).  Job j: reference refs[j], its nei_counts[j] neighbours follow those of job j - 1 in nei / R_nr / t_nr,
+ * random stream seeds[j]; depth_constant: NULL or n_jobs pointers (NULL entries allowed).  Results = n_jobs calls of
+ * pvlm_mvs_views_estimate_sequential, bit for bit.  Synchronises before returning. */
+pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_views* views, int n_jobs, const int* refs, const int* nei_counts, const int* nei,
+                                                     const float* R_nr, const float* t_nr, int half_window, int step, int use_geometry,
+                                                     const unsigned char* const* depth_constant_or_null, float min_depth, float max_depth,
+                                                     const unsigned long long* seeds, int max_iter, float conf_threshold);
 pvlm_status pvlm_mvs_views_filter_refine(pvlm_ctx* ctx, pvlm_mvs_views* views, int ref, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr,
                                          const unsigned char* depth_constant_or_null, float depth_diff_threshold, float min_depth, float max_depth);
 

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
-    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate", "pvlm_mvs_propagate_sequential", "pvlm_mvs_views_estimate_sequential", "pvlm_mvs_views_create", "pvlm_mvs_views_destroy", "pvlm_mvs_views_upload", "pvlm_mvs_views_download",
+    "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate", "pvlm_mvs_propagate_sequential", "pvlm_mvs_views_estimate_sequential", "pvlm_mvs_views_estimate_sequential_batch", "pvlm_mvs_views_create", "pvlm_mvs_views_destroy", "pvlm_mvs_views_upload", "pvlm_mvs_views_download",
     "pvlm_mvs_views_snapshot_depth", "pvlm_mvs_views_estimate", "pvlm_mvs_views_filter_refine",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
@@ -478,6 +478,24 @@ class MvsViews:
                                                              C.c_int(half_window), C.c_int(step), C.c_int(1 if use_geometry else 0), _p(dc, C.c_ubyte),
                                                              C.c_float(min_depth), C.c_float(max_depth), C.c_ulonglong(seed), C.c_int(max_iter),
                                                              C.c_float(conf_threshold)), "pvlm_mvs_views_estimate")
+
+    def estimate_sequential_batch(self, jobs, half_window=3, step=1, use_geometry=False, min_depth=0.1, max_depth=20.0, max_iter=1, conf_threshold=-1.0):
+        """jobs: list of dicts (ref, nei, R_nr, t_nr, seed[, depth_constant]) with distinct refs: the sequential sweep of all of them, one
+        launch per anti-diagonal for the whole batch (pvlm_mvs_views_estimate_sequential_batch)."""
+        n = len(jobs)
+        refs = _i32([j["ref"] for j in jobs]); cnt = _i32([len(j["nei"]) for j in jobs])
+        ids = _i32([b for j in jobs for b in j["nei"]]) if int(cnt.sum()) else np.zeros(1, np.int32)
+        R = _f32(np.concatenate([np.asarray(j["R_nr"], np.float32).reshape(-1) for j in jobs])) if int(cnt.sum()) else np.zeros(9, np.float32)
+        t = _f32(np.concatenate([np.asarray(j["t_nr"], np.float32).reshape(-1) for j in jobs])) if int(cnt.sum()) else np.zeros(3, np.float32)
+        seeds = np.ascontiguousarray([int(j.get("seed", 1)) for j in jobs], np.uint64)
+        dcs = [None if j.get("depth_constant") is None else np.ascontiguousarray(j["depth_constant"], np.uint8) for j in jobs]
+        dptr = None
+        if any(d is not None for d in dcs):
+            dptr = (C.POINTER(C.c_ubyte) * max(n, 1))(*[None if d is None else d.ctypes.data_as(C.POINTER(C.c_ubyte)) for d in dcs])
+        self.ctx._check(self.ctx.lib.pvlm_mvs_views_estimate_sequential_batch(
+            self.ctx._h, self._h, C.c_int(n), _p(refs, C.c_int), _p(cnt, C.c_int), _p(ids, C.c_int), _p(R, C.c_float), _p(t, C.c_float), C.c_int(half_window), C.c_int(step),
+            C.c_int(1 if use_geometry else 0), dptr, C.c_float(min_depth), C.c_float(max_depth), seeds.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.c_int(max_iter),
+            C.c_float(conf_threshold)), "pvlm_mvs_views_estimate_sequential_batch")
 
     def filter_refine(self, ref, nei, R_nr, t_nr, depth_constant=None, thr=0.01, min_depth=0.1, max_depth=20.0):
         ids, R, t = self._nb(nei, R_nr, t_nr)

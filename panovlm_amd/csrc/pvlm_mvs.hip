@@ -339,6 +339,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
+// Several views per launch (grid.y = job): a single diagonal is at most min(rows, cols) waves — a third of the chip's SIMDs at
+// 1440 x 720, each running ONE wave with nothing to overlap its latencies — so the sequential sweep of one view is launch- and
+// latency-bound (134 ms per iteration against 29 ms for the checkerboard).  Upstream parallelises this strategy over IMAGES
+// (one view per OpenMP thread, mvs/MVS.cpp:87-93); so does this kernel: the views of a batch are independent (a view writes its
+// own depth / normal / conf and reads the others' grey image and, with use_geometry, their depth_filter snapshot).
+struct pvlm_mvs_job { pvlm_mvs_neighbours nb; size_t off; unsigned long long seed; const unsigned char* dconst; };
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_diag_batch(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ gray_base, const float* __restrict__ unit, const pvlm_mvs_job* __restrict__ jobs,
+    float* depth_base, float* normal_base, float* conf_base, float min_depth, float max_depth, int iter, int diag) {
+  const pvlm_mvs_job& J = jobs[blockIdx.y];
+  const int backward = iter & 1;
+  const int r0 = max(0, diag - (cols - 1)), r1 = min(rows - 1, diag);
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int py = r0 + w;
+  if (py > r1) return;
+  const int px = diag - py;
+  const long long e = (long long)py * cols + px;
+  float* depth = depth_base + J.off; float* normal = normal_base + 3 * J.off; float* conf = conf_base + J.off;
+  float dep = depth[e];
+  if (dep <= 0) return;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
+  float4* lds = strips[threadIdx.x >> 6];
+  PatchRegs<M> P;
+  wave_fill_patch<M>(gray_base + J.off, rows, cols, px, py, half_window, step, n, lane, lds, P);
+  if (!P.inside || P.sq0 <= 0) return;
+  float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+  float c = conf[e];
+  pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, J.dconst, min_depth, max_depth};
+  pvlm_mvs::Rng rng{pvlm_mvs::pass_seed(J.seed, iter), (unsigned long long)e, 0u};
+  WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &J.nb, &P, lds};
+  const int sgn = backward ? 1 : -1;
+  const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
+  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
+  if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+}
+
 // launch helpers: M = 1 for windows of at most 64 texels (one texel per lane), M = PVLM_MVS_MAXM otherwise
 static void launch_mvs_conf(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
                             const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf) {
@@ -907,6 +945,71 @@ pvlm_status pvlm_mvs_views_estimate_sequential(pvlm_ctx* ctx, pvlm_mvs_views* v,
                                                unsigned long long seed, int max_iter, float conf_threshold) {
   if (max_iter < 0) return PVLM_ERR_ARG;
   return views_estimate(ctx, v, ref, n_neighbors, nei, R_nr, t_nr, half_window, step, use_geometry, depth_constant, min_depth, max_depth, seed, max_iter, conf_threshold, 2);
+}
+
+// EstimateDepthMapSingle(SEQUENTIAL) of several views at once — the views of one call must be distinct; job j uses the nei_counts[j]
+// neighbours that follow those of job j - 1 in nei / R_nr / t_nr.  depth_constant: NULL, or n_jobs pointers (NULL entries allowed).
+pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_views* v, int n_jobs, const int* refs, const int* nei_counts, const int* nei,
+                                                     const float* R_nr, const float* t_nr, int half_window, int step, int use_geometry,
+                                                     const unsigned char* const* depth_constant, float min_depth, float max_depth,
+                                                     const unsigned long long* seeds, int max_iter, float conf_threshold) {
+  if (!ctx || !v || n_jobs < 0 || max_iter < 0 || half_window < 1 || step < 1 || (n_jobs > 0 && (!refs || !nei_counts || !seeds))) return PVLM_ERR_ARG;
+  if (n_jobs == 0) return PVLM_OK;
+  if (pvlm_mvs::num_texels(half_window, step) > 64 * PVLM_MVS_MAXM) { PVLM_SET_ERR(ctx, "NCC window of %d texels exceeds %d", pvlm_mvs::num_texels(half_window, step), 64 * PVLM_MVS_MAXM); return PVLM_ERR_ARG; }
+  std::vector<pvlm_mvs_job> jobs((size_t)n_jobs);
+  std::vector<char> seen((size_t)v->n, 0);
+  size_t at = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    if (!views_ids_ok(v, refs[j], nei_counts[j], nei ? nei + at : nullptr) || (nei_counts[j] > 0 && (!R_nr || !t_nr))) { PVLM_SET_ERR(ctx, "job %d: bad view ids", j); return PVLM_ERR_ARG; }
+    if (seen[(size_t)refs[j]]) { PVLM_SET_ERR(ctx, "view %d is the reference of two jobs of one batch", refs[j]); return PVLM_ERR_ARG; }
+    seen[(size_t)refs[j]] = 1;
+    views_neighbours(v, nei_counts[j], nei + at, R_nr + 9 * at, t_nr + 3 * at, use_geometry != 0, jobs[(size_t)j].nb);
+    jobs[(size_t)j].off = v->npix * (size_t)refs[j]; jobs[(size_t)j].seed = seeds[j]; jobs[(size_t)j].dconst = nullptr;
+    at += (size_t)nei_counts[j];
+  }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipStream_t s = ctx->stream;
+  pvlm_mvs_job* d_jobs = nullptr; unsigned char* d_cb = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_jobs, (size_t)n_jobs);
+  hipError_t e = hipSuccess;
+  if (!st && depth_constant) {
+    st = pvlm_i_alloc(ctx, &d_cb, (size_t)n_jobs * v->npix);
+    for (int j = 0; j < n_jobs && !st; ++j)
+      if (depth_constant[j]) {
+        if (mvs_up(ctx, d_cb + (size_t)j * v->npix, depth_constant[j], v->npix) != hipSuccess) st = PVLM_ERR_HIP;
+        jobs[(size_t)j].dconst = d_cb + (size_t)j * v->npix;
+      }
+  }
+  if (!st && mvs_up(ctx, d_jobs, jobs.data(), jobs.size() * sizeof(pvlm_mvs_job)) != hipSuccess) st = PVLM_ERR_HIP;
+  if (!st) {
+    const int n_diag = v->rows + v->cols - 1;
+    const bool small = pvlm_mvs::num_texels(half_window, step) <= 64;
+    for (int iter = 0; iter < max_iter; ++iter) {
+      pvlm_prof_scope prof(ctx, 1);
+      for (int q = 0; q < n_diag; ++q) {
+        const int d = (iter & 1) ? n_diag - 1 - q : q;
+        const int len = std::min(v->rows - 1, d) - std::max(0, d - (v->cols - 1)) + 1;
+        const dim3 grid((unsigned)((len + 3) / 4), (unsigned)n_jobs), block(256);
+        if (small)
+          hipLaunchKernelGGL(k_mvs_propagate_diag_batch<1>, grid, block, 0, s, v->rows, v->cols, half_window, step, v->d_gray, v->d_unit, d_jobs, v->d_depth, v->d_normal,
+                             v->d_conf, min_depth, max_depth, iter, d);
+        else
+          hipLaunchKernelGGL(k_mvs_propagate_diag_batch<PVLM_MVS_MAXM>, grid, block, 0, s, v->rows, v->cols, half_window, step, v->d_gray, v->d_unit, d_jobs, v->d_depth,
+                             v->d_normal, v->d_conf, min_depth, max_depth, iter, d);
+      }
+    }
+    for (int j = 0; j < n_jobs; ++j) {
+      const size_t o = jobs[(size_t)j].off;
+      hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, s, (long long)v->npix, jobs[(size_t)j].dconst, conf_threshold, v->d_depth + o,
+                         v->d_normal + 3 * o, v->d_conf + o);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_estimate_sequential_batch: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  // the job table and the depth_constant copies go back to the pool in stream order; the staged uploads must have left the arena
+  if (mvs_sync(ctx) != hipSuccess && !st) st = PVLM_ERR_HIP;
+  pvlm_i_free(ctx, d_jobs); pvlm_i_free(ctx, d_cb);
+  return st;
 }
 
 // FilterDepthImageRefine of view `ref`: reads depth / conf of the neighbours, writes depth_filter / conf_filter of ref and zeroes

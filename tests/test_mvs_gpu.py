@@ -166,6 +166,33 @@ def test_sequential_sweep_matches_oracle(ctx, oracle):
     V.estimate(ref, nei, S["Rn"], S["tn"], max_iter=3, seed=5, sequential=True)
     got = V.download(ref, ("depth", "normal", "conf"))
     assert np.array_equal(got["depth"], swept[0]) and np.array_equal(got["normal"], swept[1]) and np.array_equal(got["conf"], swept[2])
+    # several views per launch (pvlm_mvs_views_estimate_sequential_batch: upstream runs this strategy with one image per thread):
+    # two jobs with different references, neighbour lists, seeds and (for one) depth_constant == the two single calls
+    import panovlm_amd as pv
+    jobs = [dict(ref=1, nei=nei, R_nr=S["Rn"], t_nr=S["tn"], seed=5, depth_constant=S["const"]),
+            dict(ref=2, nei=[0, 3], R_nr=S["Rn"][:2], t_nr=S["tn"][:2], seed=11)]
+    init = {1: (S["depth"], S["normal"], S["conf"]), 2: (S["nd"][1], S["normal"], S["conf"])}
+    single = {}
+    for j in jobs:
+        d0, n0, c0 = init[j["ref"]]
+        V.upload(j["ref"], gray=S["gray"] if j["ref"] == 1 else S["neis"][1], depth=d0, normal=n0, conf=c0)
+    for geo in (False, True):
+        for j in jobs:
+            V.upload(j["ref"], depth=init[j["ref"]][0], normal=init[j["ref"]][1], conf=init[j["ref"]][2])
+        for j in jobs:
+            V.estimate(j["ref"], j["nei"], j["R_nr"], j["t_nr"], max_iter=2, seed=j["seed"], sequential=True, use_geometry=geo, depth_constant=j.get("depth_constant"),
+                       conf_threshold=0.5)
+            single[j["ref"]] = V.download(j["ref"], ("depth", "normal", "conf"))
+        for j in jobs:
+            V.upload(j["ref"], depth=init[j["ref"]][0], normal=init[j["ref"]][1], conf=init[j["ref"]][2])
+        V.estimate_sequential_batch(jobs, max_iter=2, use_geometry=geo, conf_threshold=0.5)
+        for j in jobs:
+            got = V.download(j["ref"], ("depth", "normal", "conf"))
+            for k in ("depth", "normal", "conf"):
+                assert np.array_equal(got[k], single[j["ref"]][k]), (geo, j["ref"], k)
+        assert not np.array_equal(single[1]["depth"], init[1][0]) and not np.array_equal(single[2]["depth"], init[2][0])
+    with pytest.raises(pv.PvlmError):
+        V.estimate_sequential_batch([jobs[0], jobs[0]])            # the same reference twice in one batch
     V.close()
 
 

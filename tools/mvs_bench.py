@@ -90,6 +90,25 @@ def main():
     sq = ctx.mvs_propagate(*sw, half_window=a.half_window, step=a.step, max_iter=2, seed=5, sequential=True)
     seq_ms, seq_cnt = ctx.profile_read(1)
     ctx.profile_enable(False)
+    # ... and eight views per launch through the resident view set (upstream: one image per thread for this strategy)
+    from panovlm_amd.api import MvsViews
+    B = 8
+    V = MvsViews(ctx, a.rows, a.cols, B + len(neis))
+    for k, g in enumerate(neis):
+        V.upload(B + k, gray=g, depth=nd[k], normal=np.zeros((a.rows, a.cols, 3), np.float32), conf=np.zeros((a.rows, a.cols), np.float32))
+    for k in range(B):
+        V.upload(k, gray=gray, depth=d1, normal=n1, conf=c0)
+    jobs = [dict(ref=k, nei=list(range(B, B + len(neis))), R_nr=np.array(Rn), t_nr=np.array(tn), seed=5 + k) for k in range(B)]
+    V.estimate_sequential_batch(jobs, half_window=a.half_window, step=a.step, max_iter=1)
+    for k in range(B):
+        V.upload(k, depth=d1, normal=n1, conf=c0)
+    ctx.profile_enable(True)
+    V.estimate_sequential_batch(jobs, half_window=a.half_window, step=a.step, max_iter=2)
+    bat_ms, bat_cnt = ctx.profile_read(1)
+    ctx.profile_enable(False)
+    bat0 = V.download(0, ("depth", "normal", "conf"))
+    batch_equals_single = bool(np.array_equal(bat0["depth"], sq[0]) and np.array_equal(bat0["conf"], sq[2]))
+    V.close()
     vs = c0 > -1
     same = (np.abs(sg[0] - so[0]) <= 1e-4 * np.maximum(np.abs(so[0]), 1e-3)) & (np.abs(sg[1] - so[1]).max(axis=2) <= 1e-4) & (np.abs(sg[2] - so[2]) <= 1e-4)
     rel = lambda d: float(np.median(np.abs(d[vs] / depth[vs] - 1)))
@@ -108,7 +127,9 @@ def main():
                                      cpu_oracle_s=sweep_cpu, agree_with_oracle=float(same[vs].mean()), mean_conf_gpu=float(sg[2][vs].mean()), mean_conf_oracle=float(so[2][vs].mean()),
                                      depth_err_before=rel(d1), depth_err_gpu=rel(sg[0]), depth_err_oracle=rel(so[0])),
                           sweep_sequential=dict(ms_per_iteration=seq_ms / max(seq_cnt, 1), launches_per_iteration=a.rows + a.cols - 1,
-                                                depth_err=rel(sq[0]), mean_conf=float(sq[2][vs].mean())),
+                                                depth_err=rel(sq[0]), mean_conf=float(sq[2][vs].mean()), batch_views=B,
+                                                batch_ms_per_iteration=bat_ms / max(bat_cnt, 1), batch_ms_per_view_iteration=bat_ms / max(bat_cnt, 1) / B,
+                                                batch_view0_equals_single_call=batch_equals_single),
                           sweep_geometric=dict(kernel_ms_per_colour_pass=geo_ms / max(geo_cnt, 1), identical_to_oracle=geo_same),
                           cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
 
