@@ -78,9 +78,9 @@ def shard_views(n_views, rank, world, cost=None):
 
 
 def estimate_depth_maps(worker, views, neighbors, rank=0, world=1, half_window=3, step=1, pho_iters=3, conf_threshold=-0.7, min_depth=0.1, max_depth=20.0,
-                        seed=1, cost=None):
+                        seed=1, cost=None, sequential=False):
     """The photometric pass of MVS::EstimateDepthMaps (mvs/MVS.cpp:93-117) for this rank's views: InitConfMap, then
-    EstimateDepthMapSingle(view, CHECKER_BOARD, pho_iters, conf_threshold, false).  worker: a panovlm_amd.Context (the two
+    EstimateDepthMapSingle(view, CHECKER_BOARD or — sequential=True, config propagate_strategy = 2 — SEQUENTIAL, pho_iters, conf_threshold, false).  worker: a panovlm_amd.Context (the two
     calls run on its GPU).  views[v] = dict(gray, depth, normal) with an initialised depth / normal hypothesis;
     neighbors[v] = list of (neighbour view, R_nr (3x3), t_nr (3)).  Returns {view: (depth, normal, conf)}."""
     out = {}
@@ -90,6 +90,6 @@ def estimate_depth_maps(worker, views, neighbors, rank=0, world=1, half_window=3
         R = np.array([r for _, r, _ in nb], np.float32).reshape(-1, 9); t = np.array([x for _, _, x in nb], np.float32).reshape(-1, 3)
         conf, depth, normal = worker.mvs_init_conf_map(views[v]["gray"], grays, R, t, views[v]["depth"], views[v]["normal"], half_window, step)
         out[v] = worker.mvs_propagate(views[v]["gray"], grays, R, t, depth, normal, conf, half_window=half_window, step=step, min_depth=min_depth,
-                                      max_depth=max_depth, seed=seed + v, max_iter=pho_iters, conf_threshold=conf_threshold)
+                                      max_depth=max_depth, seed=seed + v, max_iter=pho_iters, conf_threshold=conf_threshold, sequential=sequential)
     return out
 
