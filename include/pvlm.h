@@ -430,6 +430,19 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
                                          const unsigned char* depth_constant_or_null, float depth_diff_threshold, float min_depth, float max_depth,
                                          float* depth_filter, float* conf_filter);
 
+/* Depth map -> coloured world points: MVS::DepthImageToCloud (mvs/MVS.cpp:2073-2107; filter_sky = 1, normal_out = NULL) and
+ * MVS::DepthNormalToCloud (:2109-2142; filter_sky = 0, normal_out != NULL), the per-frame bodies of MVS::MergeDepthImages
+ * (:2144-2166; what MVS::FuseDepthMaps :224-227 saves as MVS-merge.pcd) and of the per-frame .pcd export.  A pixel with
+ * 0 < depth < 0.8 max_depth becomes TranslatePoint<float, double>(ImageToCam(col, row) * depth, T_wc) (base/Geometry.hpp:545-551)
+ * with its colour — unless filter_sky and BGR2HSV (util/Visualization.cpp:57-77) puts the colour in the reference's "sky blue"
+ * box (H 100..124, S 43..200, V 150..255) — and, with normal_out, the normal R_wc n.  Points come out in raster order, as
+ * the reference's loops push them.  bgr: rows x cols x 3 (cv::Vec3b order); T_wc: the frame pose, 3 x 4 or 4 x 4 row-major
+ * (12 doubles read); xyz / normal_out: capacity rows x cols x 3 float, rgb: rows x cols x 3 bytes (r, g, b); *n_points = points written.
+ * pvlm_mvs_views_depth_to_cloud (declared below) reads depth (or depth_filter) and normal of a resident view instead. */
+pvlm_status pvlm_mvs_depth_to_cloud(pvlm_ctx* ctx, int rows, int cols, const float* depth, const unsigned char* bgr, const float* normal_or_null,
+                                    const double* T_wc, float max_depth, int filter_sky, float* xyz, unsigned char* rgb, float* normal_out_or_null,
+                                    long long* n_points);
+
 /* Resident view set: the maps of n_views equally sized views (grey image, depth, normal, conf, depth_filter, conf_filter —
  * the cv::Mat members of sensors/Frame.h the MVS touches) stay in HBM across the calls, so that a view's scoring pass,
  * sweeps and fusion filter — and its use as somebody's neighbour — cost no PCIe traffic.  Same kernels and results as
@@ -443,6 +456,8 @@ pvlm_status pvlm_mvs_filter_depth_refine(pvlm_ctx* ctx, int rows, int cols, int 
 typedef struct pvlm_mvs_views pvlm_mvs_views;
 pvlm_status pvlm_mvs_views_create(pvlm_ctx* ctx, int rows, int cols, int n_views, pvlm_mvs_views** out);
 pvlm_status pvlm_mvs_views_destroy(pvlm_ctx* ctx, pvlm_mvs_views* views);
+pvlm_status pvlm_mvs_views_depth_to_cloud(pvlm_ctx* ctx, pvlm_mvs_views* views, int view, int use_filtered_depth, const unsigned char* bgr, const double* T_wc,
+                                          float max_depth, int filter_sky, float* xyz, unsigned char* rgb, float* normal_out_or_null, long long* n_points);
 pvlm_status pvlm_mvs_views_upload(pvlm_ctx* ctx, pvlm_mvs_views* views, int view, const unsigned char* gray_or_null, const float* depth_or_null,
                                   const float* normal_or_null, const float* conf_or_null);
 pvlm_status pvlm_mvs_views_download(pvlm_ctx* ctx, pvlm_mvs_views* views, int view, float* depth_or_null, float* normal_or_null, float* conf_or_null,

@@ -654,6 +654,53 @@ inline void EstimateDepthMapSequential(const MvsView& ref, int n_neighbors, cons
     }
 }
 
+// MVS::DepthImageToCloud (mvs/MVS.cpp:2073-2107), the per-frame body of MergeDepthImages (:2144-2166; FuseDepthMaps :224-227 saves
+// MergeDepthImages(2) as MVS-merge.pcd): every pixel with 0 < depth < 0.8 max_depth becomes the world point
+// TranslatePoint<float, double>(ImageToCam(col, row) * depth, T_wc) (base/Geometry.hpp:545-551) with the pixel's colour, unless the
+// colour is "sky blue" (BGR2HSV, util/Visualization.cpp:57-77: H in [100, 124], S in [43, 200], V in [150, 255]).
+// Raster order.  xyz: n x 3 float, rgb: n x 3 uint8 (r, g, b).  Returns n.
+inline void Bgr2Hsv(const unsigned char* bgr, float* hsv) {
+  const float r = bgr[2] / 255.f, g = bgr[1] / 255.f, b = bgr[0] / 255.f;
+  const float C_max = std::max(r, std::max(g, b)), C_min = std::min(r, std::min(g, b));
+  if (C_max == 0) { hsv[0] = hsv[1] = hsv[2] = 0; return; }
+  const float delta_C = C_max - C_min;
+  float h = 0.f;
+  if (C_max == r) h = 60.f * ((g - b) / delta_C + 6 * (g < b));
+  else if (C_max == g) h = 60.f * ((b - r) / delta_C + 2);
+  else if (C_max == b) h = 60.f * ((r - g) / delta_C + 4);
+  hsv[0] = h / 360.f; hsv[1] = delta_C / C_max; hsv[2] = C_max;
+}
+// normal / normal_out != null and filter_sky = false: MVS::DepthNormalToCloud (mvs/MVS.cpp:2109-2142), normal_world = R_wc * Vector3d(n).
+inline long long DepthImageToCloud(int rows, int cols, const float* depth, const unsigned char* bgr, const double* T_wc, float max_depth, float* xyz,
+                                   unsigned char* rgb, bool filter_sky = true, const float* normal = nullptr, float* normal_out = nullptr) {
+  const Equirectangular eq(rows, cols);
+  long long n = 0;
+  for (int row = 0; row < rows; ++row)
+    for (int col = 0; col < cols; ++col) {
+      const float d = depth[(size_t)row * cols + col];
+      if (d <= 0 || d >= max_depth * 0.8) continue;
+      const float px[2] = {(float)col, (float)row};
+      float ray[3];
+      eq.ImageToCam(px, 1.f, ray);
+      const float pc[3] = {ray[0] * d, ray[1] * d, ray[2] * d};
+      float pw[3];
+      for (int k = 0; k < 3; ++k) pw[k] = (float)(pc[0] * T_wc[4 * k] + pc[1] * T_wc[4 * k + 1] + pc[2] * T_wc[4 * k + 2] + T_wc[4 * k + 3]);
+      const unsigned char* c = bgr + 3 * ((size_t)row * cols + col);
+      float hsv[3];
+      Bgr2Hsv(c, hsv);
+      hsv[0] *= 180.f; hsv[1] *= 255.f; hsv[2] *= 255.f;
+      if (filter_sky && hsv[0] >= 100.f && hsv[0] <= 124.f && hsv[1] >= 43.f && hsv[1] <= 200.f && hsv[2] >= 150.f && hsv[2] <= 255.f) continue;
+      if (normal_out) {
+        const float* nc = normal + 3 * ((size_t)row * cols + col);
+        for (int k = 0; k < 3; ++k) normal_out[3 * n + k] = (float)(T_wc[4 * k] * (double)nc[0] + T_wc[4 * k + 1] * (double)nc[1] + T_wc[4 * k + 2] * (double)nc[2]);
+      }
+      xyz[3 * n] = pw[0]; xyz[3 * n + 1] = pw[1]; xyz[3 * n + 2] = pw[2];
+      rgb[3 * n] = c[2]; rgb[3 * n + 1] = c[1]; rgb[3 * n + 2] = c[0];
+      ++n;
+    }
+  return n;
+}
+
 // MVS::SelectNeighborKNN (mvs/MVS.cpp:334-382).  valid[i], R_wc (9, row-major), t_wc (3) per frame.  Output: for every frame the
 // list of (neighbour id, R_nr float 9, t_nr float 3).  KdTreeFLANN::nearestKSearch restated as a brute-force sorted float32
 // search (ties by index); T_nr = T_wn^-1 * T_wr through the general 4x4 inverse like upstream (Gauss-Jordan with partial

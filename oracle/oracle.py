@@ -347,6 +347,24 @@ def mvs_propagate(ref_gray, nei_grays, R_nr, t_nr, depth, normal, conf, half_win
     return d, nrm, c
 
 
+def mvs_depth_to_cloud(depth, bgr, T_wc, max_depth=20.0, filter_sky=True, normal=None):
+    """MVS::DepthImageToCloud (mvs/MVS.cpp:2073-2107) / DepthNormalToCloud (:2109-2142, normal given, filter_sky False):
+    returns (xyz n x 3 float32, rgb n x 3 uint8[, normal n x 3 float32]) in raster order."""
+    d = np.ascontiguousarray(depth, np.float32); rows, cols = d.shape
+    c = np.ascontiguousarray(bgr, np.uint8).reshape(rows, cols, 3)
+    T = np.ascontiguousarray(np.asarray(T_wc, np.float64).reshape(-1)[:12])
+    xyz = np.zeros((rows * cols, 3), np.float32); rgb = np.zeros((rows * cols, 3), np.uint8)
+    nin = None if normal is None else np.ascontiguousarray(normal, np.float32).reshape(rows, cols, 3)
+    nout = None if normal is None else np.zeros((rows * cols, 3), np.float32)
+    lib().orc_mvs_depth_to_cloud.restype = C.c_longlong
+    n = lib().orc_mvs_depth_to_cloud(C.c_int(rows), C.c_int(cols), _p(d, C.c_float), _p(c, C.c_ubyte), _p(T, C.c_double), C.c_float(max_depth), _p(xyz, C.c_float),
+                                     _p(rgb, C.c_ubyte), C.c_int(1 if filter_sky else 0), None if nin is None else _p(nin, C.c_float),
+                                     None if nout is None else _p(nout, C.c_float))
+    if normal is None:
+        return xyz[:n].copy(), rgb[:n].copy()
+    return xyz[:n].copy(), rgb[:n].copy(), nout[:n].copy()
+
+
 def mvs_init_depth_normal(rows, cols, lidar_depth16=None, mask=None, min_depth=0.1, max_depth=20.0, keep_lidar_constant=True, seed=1):
     """MVS::InitDepthNormal (mvs/MVS.cpp:496-584): returns (depth, normal, depth_constant uint8)."""
     l16 = None if lidar_depth16 is None else np.ascontiguousarray(lidar_depth16, np.uint16)

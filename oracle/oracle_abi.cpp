@@ -259,6 +259,10 @@ void orc_mvs_init_depth_normal(int rows, int cols, const unsigned short* lidar16
                                unsigned long long seed, float* depth, float* normal, unsigned char* depth_constant) {
   InitDepthNormal(rows, cols, lidar16, mask, min_depth, max_depth, keep_const != 0, seed, depth, normal, depth_constant);
 }
+long long orc_mvs_depth_to_cloud(int rows, int cols, const float* depth, const unsigned char* bgr, const double* T_wc, float max_depth, float* xyz,
+                                 unsigned char* rgb, int filter_sky, const float* normal, float* normal_out) {
+  return DepthImageToCloud(rows, cols, depth, bgr, T_wc, max_depth, xyz, rgb, filter_sky != 0, normal, normal_out);
+}
 int orc_mvs_remove_small_segments(int rows, int cols, float thr, int min_segment, float* depth, float* normal, float* conf) {
   return RemoveSmallSegments(rows, cols, thr, min_segment, depth, normal, conf);
 }

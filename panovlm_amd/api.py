@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
-    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments",
+    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
 ]
 
 
@@ -343,6 +343,23 @@ class Context:
                                                    _p(out_c, C.c_float) if cf is not None else None), "pvlm_mvs_filter_depth")
         return out_d, out_c
 
+    def mvs_depth_to_cloud(self, depth, bgr, T_wc, max_depth=20.0, filter_sky=True, normal=None):
+        """MVS::DepthImageToCloud (normal None) / DepthNormalToCloud (normal given; pass filter_sky=False for the reference's behaviour) on the GPU:
+        (xyz n x 3 float32, rgb n x 3 uint8[, normal n x 3 float32]) in raster order."""
+        d = np.ascontiguousarray(depth, np.float32); rows, cols = d.shape
+        c = np.ascontiguousarray(bgr, np.uint8); assert c.shape == (rows, cols, 3)
+        T = np.ascontiguousarray(np.asarray(T_wc, np.float64).reshape(-1)[:12])
+        nin = None if normal is None else np.ascontiguousarray(normal, np.float32)
+        assert nin is None or nin.shape == (rows, cols, 3)
+        xyz = np.empty((rows * cols, 3), np.float32); rgb = np.empty((rows * cols, 3), np.uint8)
+        nout = None if nin is None else np.empty((rows * cols, 3), np.float32)
+        n = C.c_longlong(0)
+        self._check(self.lib.pvlm_mvs_depth_to_cloud(self._h, C.c_int(rows), C.c_int(cols), _p(d, C.c_float), _p(c, C.c_ubyte), _p(nin, C.c_float), _p(T, C.c_double),
+                                                     C.c_float(max_depth), C.c_int(1 if filter_sky else 0), _p(xyz, C.c_float), _p(rgb, C.c_ubyte), _p(nout, C.c_float),
+                                                     C.byref(n)), "pvlm_mvs_depth_to_cloud")
+        k = n.value
+        return (xyz[:k].copy(), rgb[:k].copy()) if nout is None else (xyz[:k].copy(), rgb[:k].copy(), nout[:k].copy())
+
     def mvs_filter_depth_refine(self, nei_depths, nei_confs, R_nr, t_nr, depth, conf, depth_constant=None, thr=0.01, min_depth=0.1, max_depth=20.0):
         """MVS::FilterDepthImageRefine on the GPU: returns (depth_filter, conf_filter, conf) — conf = the reference frame's
         conf_map after the call (zeroed where depth <= 0)."""
@@ -496,6 +513,20 @@ class MvsViews:
             self.ctx._h, self._h, C.c_int(n), _p(refs, C.c_int), _p(cnt, C.c_int), _p(ids, C.c_int), _p(R, C.c_float), _p(t, C.c_float), C.c_int(half_window), C.c_int(step),
             C.c_int(1 if use_geometry else 0), dptr, C.c_float(min_depth), C.c_float(max_depth), seeds.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.c_int(max_iter),
             C.c_float(conf_threshold)), "pvlm_mvs_views_estimate_sequential_batch")
+
+    def depth_to_cloud(self, view, bgr, T_wc, max_depth=20.0, filter_sky=True, use_filtered_depth=True, with_normal=False):
+        """MVS::DepthImageToCloud / DepthNormalToCloud of a resident view (its depth_filter or depth map, its normal map)."""
+        c = np.ascontiguousarray(bgr, np.uint8); assert c.shape == (self.rows, self.cols, 3)
+        T = np.ascontiguousarray(np.asarray(T_wc, np.float64).reshape(-1)[:12])
+        npix = self.rows * self.cols
+        xyz = np.empty((npix, 3), np.float32); rgb = np.empty((npix, 3), np.uint8)
+        nout = np.empty((npix, 3), np.float32) if with_normal else None
+        n = C.c_longlong(0)
+        self.ctx._check(self.ctx.lib.pvlm_mvs_views_depth_to_cloud(self.ctx._h, self._h, C.c_int(view), C.c_int(1 if use_filtered_depth else 0), _p(c, C.c_ubyte),
+                                                                   _p(T, C.c_double), C.c_float(max_depth), C.c_int(1 if filter_sky else 0), _p(xyz, C.c_float),
+                                                                   _p(rgb, C.c_ubyte), _p(nout, C.c_float), C.byref(n)), "pvlm_mvs_views_depth_to_cloud")
+        k = n.value
+        return (xyz[:k].copy(), rgb[:k].copy()) if nout is None else (xyz[:k].copy(), rgb[:k].copy(), nout[:k].copy())
 
     def filter_refine(self, ref, nei, R_nr, t_nr, depth_constant=None, thr=0.01, min_depth=0.1, max_depth=20.0):
         ids, R, t = self._nb(nei, R_nr, t_nr)

@@ -785,6 +785,136 @@ pvlm_status pvlm_mvs_propagate_sequential(pvlm_ctx* ctx, int rows, int cols, int
 
 // ---- resident view set: the same kernels with the maps kept in HBM between the scoring pass, the sweeps and the
 // fusion filter (the per-call entry points above move 30-50 MB over PCIe per call, which is most of their wall time) ----
+// ---- MVS::DepthImageToCloud / DepthNormalToCloud (mvs/MVS.cpp:2073-2142): ordered stream compaction of a depth map into world points.
+// Three launches: kept pixels per 256-pixel block, an exclusive scan of the block counts by one workgroup, and the emit pass
+// (block base + rank of the lane among the kept lanes before it), so that the points come out in the reference's raster order.
+struct pvlm_cloud_pose { double T[12]; };
+
+__device__ __forceinline__ bool cloud_lane_keeps(long long e, long long npix, const float* depth, const unsigned char* bgr, float max_depth, int filter_sky) {
+  if (e >= npix) return false;
+  return pvlm_mvs::cloud_keeps(depth[e], max_depth, bgr + 3 * e, filter_sky != 0);
+}
+
+__global__ void __launch_bounds__(256) k_cloud_count(long long npix, const float* __restrict__ depth, const unsigned char* __restrict__ bgr, float max_depth,
+                                                     int filter_sky, unsigned* __restrict__ block_count) {
+  __shared__ unsigned wave_n[4];
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(cloud_lane_keeps(e, npix, depth, bgr, max_depth, filter_sky));
+  if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+}
+
+// exclusive scan in place; block_count[n_blocks] = total.  One workgroup of 1024 lanes, 1024 counts per round.
+__global__ void __launch_bounds__(1024) k_cloud_scan(unsigned n_blocks, unsigned* __restrict__ block_count) {
+  __shared__ unsigned long long wave_sum[16];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (unsigned base = 0; base < n_blocks; base += 1024) {
+    const unsigned i = base + threadIdx.x;
+    const unsigned long long v = i < n_blocks ? block_count[i] : 0;
+    unsigned long long inc = v;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wave_sum[w] = inc;
+    __syncthreads();
+    unsigned long long before = carry;
+    for (int k = 0; k < w; ++k) before += wave_sum[k];
+    if (i < n_blocks) block_count[i] = (unsigned)(before + inc - v);
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_count[n_blocks] = (unsigned)carry;
+}
+
+__global__ void __launch_bounds__(256) k_cloud_emit(int rows, int cols, const float* __restrict__ depth, const unsigned char* __restrict__ bgr,
+                                                    const float* __restrict__ normal, const float* __restrict__ unit, pvlm_cloud_pose pose, float max_depth,
+                                                    int filter_sky, const unsigned* __restrict__ block_base, float* __restrict__ xyz,
+                                                    unsigned char* __restrict__ rgb, float* __restrict__ normal_out) {
+  __shared__ unsigned wave_n[4];
+  const long long npix = (long long)rows * cols, e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool keep = cloud_lane_keeps(e, npix, depth, bgr, max_depth, filter_sky);
+  const unsigned long long m = __ballot(keep);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wave_n[w] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (!keep) return;
+  unsigned at = block_base[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+  for (int k = 0; k < w; ++k) at += wave_n[k];
+  float ray[3];
+  if (unit) { ray[0] = unit[3 * e]; ray[1] = unit[3 * e + 1]; ray[2] = unit[3 * e + 2]; }
+  else pvlm_mvs::unit_ray(rows, cols, (int)(e % cols), (int)(e / cols), ray);
+  float p[3];
+  pvlm_mvs::cloud_point(ray, depth[e], pose.T, p);
+  xyz[3 * (size_t)at] = p[0]; xyz[3 * (size_t)at + 1] = p[1]; xyz[3 * (size_t)at + 2] = p[2];
+  rgb[3 * (size_t)at] = bgr[3 * e + 2]; rgb[3 * (size_t)at + 1] = bgr[3 * e + 1]; rgb[3 * (size_t)at + 2] = bgr[3 * e];
+  if (normal_out) {
+    const float n[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+    pvlm_mvs::cloud_normal(n, pose.T, p);
+    normal_out[3 * (size_t)at] = p[0]; normal_out[3 * (size_t)at + 1] = p[1]; normal_out[3 * (size_t)at + 2] = p[2];
+  }
+}
+
+// depth / normal / unit: device maps (normal, unit may be null); bgr, outputs: host.  Synchronises.
+static pvlm_status depth_to_cloud(pvlm_ctx* ctx, const char* who, int rows, int cols, const float* d_depth, const float* d_normal, const float* d_unit,
+                                  const unsigned char* bgr, const double* T_wc, float max_depth, int filter_sky, float* xyz, unsigned char* rgb,
+                                  float* normal_out, long long* n_points) {
+  const size_t npix = (size_t)rows * cols;
+  const unsigned n_blocks = (unsigned)((npix + 255) / 256);
+  unsigned char *d_bgr = nullptr, *d_rgb = nullptr; unsigned* d_cnt = nullptr; float *d_xyz = nullptr, *d_nout = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_bgr, npix * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_cnt, (size_t)n_blocks + 1);
+  if (!st) st = pvlm_i_alloc(ctx, &d_xyz, npix * 3);
+  if (!st) st = pvlm_i_alloc(ctx, &d_rgb, npix * 3);
+  if (!st && normal_out) st = pvlm_i_alloc(ctx, &d_nout, npix * 3);
+  if (!st) {
+    hipStream_t s = ctx->stream;
+    pvlm_cloud_pose pose;
+    for (int k = 0; k < 12; ++k) pose.T[k] = T_wc[k];
+    hipError_t e = mvs_up(ctx, d_bgr, bgr, npix * 3);
+    if (e == hipSuccess) {
+      pvlm_prof_scope prof(ctx, 1);   // the three launches are one interval of the "materialise" slot (tools/mvs_bench.py)
+      hipLaunchKernelGGL(k_cloud_count, dim3(n_blocks), dim3(256), 0, s, (long long)npix, d_depth, d_bgr, max_depth, filter_sky, d_cnt);
+      hipLaunchKernelGGL(k_cloud_scan, dim3(1), dim3(1024), 0, s, n_blocks, d_cnt);
+      hipLaunchKernelGGL(k_cloud_emit, dim3(n_blocks), dim3(256), 0, s, rows, cols, d_depth, d_bgr, d_normal, d_unit, pose, max_depth, filter_sky, d_cnt, d_xyz, d_rgb, d_nout);
+      e = hipGetLastError();
+    }
+    unsigned total = 0;
+    if (e == hipSuccess) e = mvs_down(ctx, &total, d_cnt + n_blocks, sizeof(unsigned));
+    if (e == hipSuccess) e = mvs_sync(ctx);
+    if (e == hipSuccess && total > 0) {
+      e = mvs_down(ctx, xyz, d_xyz, (size_t)total * 3 * sizeof(float));
+      if (e == hipSuccess) e = mvs_down(ctx, rgb, d_rgb, (size_t)total * 3);
+      if (e == hipSuccess && normal_out) e = mvs_down(ctx, normal_out, d_nout, (size_t)total * 3 * sizeof(float));
+      if (e == hipSuccess) e = mvs_sync(ctx);
+    }
+    if (e == hipSuccess) *n_points = (long long)total;
+    else { PVLM_SET_ERR(ctx, "%s: %s", who, hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+  }
+  mvs_sync(ctx);
+  pvlm_i_free(ctx, d_bgr); pvlm_i_free(ctx, d_cnt); pvlm_i_free(ctx, d_xyz); pvlm_i_free(ctx, d_rgb); pvlm_i_free(ctx, d_nout);
+  return st;
+}
+
+pvlm_status pvlm_mvs_depth_to_cloud(pvlm_ctx* ctx, int rows, int cols, const float* depth, const unsigned char* bgr, const float* normal, const double* T_wc,
+                                    float max_depth, int filter_sky, float* xyz, unsigned char* rgb, float* normal_out, long long* n_points) {
+  if (!ctx || rows <= 0 || cols <= 0 || !depth || !bgr || !T_wc || !xyz || !rgb || !n_points || (normal_out && !normal)) return PVLM_ERR_ARG;
+  if ((size_t)rows * cols > 0xfffffff0ull) { PVLM_SET_ERR(ctx, "pvlm_mvs_depth_to_cloud: %d x %d pixels exceed the 32-bit point index", rows, cols); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t npix = (size_t)rows * cols;
+  float *d_depth = nullptr, *d_normal = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_depth, npix);
+  if (!st && normal_out) st = pvlm_i_alloc(ctx, &d_normal, npix * 3);
+  if (!st && mvs_up(ctx, d_depth, depth, npix * sizeof(float)) != hipSuccess) st = PVLM_ERR_HIP;
+  if (!st && normal_out && mvs_up(ctx, d_normal, normal, npix * 3 * sizeof(float)) != hipSuccess) st = PVLM_ERR_HIP;
+  if (!st) st = depth_to_cloud(ctx, "pvlm_mvs_depth_to_cloud", rows, cols, d_depth, d_normal, nullptr, bgr, T_wc, max_depth, filter_sky, xyz, rgb, normal_out, n_points);
+  mvs_sync(ctx);
+  pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_normal);
+  return st;
+}
+
 struct pvlm_mvs_views {
   int rows = 0, cols = 0, n = 0;
   size_t npix = 0;
@@ -799,6 +929,16 @@ static bool views_ids_ok(const pvlm_mvs_views* v, int ref, int n_neighbors, cons
   if (!v || ref < 0 || ref >= v->n || n_neighbors < 0 || n_neighbors > 16 || (n_neighbors > 0 && !nei)) return false;
   for (int b = 0; b < n_neighbors; ++b) if (nei[b] < 0 || nei[b] >= v->n || nei[b] == ref) return false;
   return true;
+}
+
+pvlm_status pvlm_mvs_views_depth_to_cloud(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, int use_filtered_depth, const unsigned char* bgr, const double* T_wc,
+                                          float max_depth, int filter_sky, float* xyz, unsigned char* rgb, float* normal_out, long long* n_points) {
+  if (!ctx || !v || view < 0 || view >= v->n || !bgr || !T_wc || !xyz || !rgb || !n_points) return PVLM_ERR_ARG;
+  if (v->npix > 0xfffffff0ull) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const float* d_depth = (use_filtered_depth ? v->d_depth_filter : v->d_depth) + (size_t)view * v->npix;
+  return depth_to_cloud(ctx, "pvlm_mvs_views_depth_to_cloud", v->rows, v->cols, d_depth, v->d_normal + (size_t)view * v->npix * 3, v->d_unit, bgr, T_wc, max_depth,
+                        filter_sky, xyz, rgb, normal_out, n_points);
 }
 
 pvlm_status pvlm_mvs_views_destroy(pvlm_ctx* ctx, pvlm_mvs_views* v) {

@@ -53,6 +53,35 @@ PVLM_HD inline void unit_ray(int rows, int cols, int col, int row, float* cam) {
   cam[2] = 1.f * cy * (float)cos((double)sx);
 }
 
+// BGR2HSV (util/Visualization.cpp:57-77) scaled as MVS::DepthImageToCloud does (mvs/MVS.cpp:2095-2099), and its "sky blue" box test
+PVLM_HD inline bool sky_colour(const unsigned char* bgr) {
+  const float r = bgr[2] / 255.f, g = bgr[1] / 255.f, b = bgr[0] / 255.f;
+  const float c_max = fmaxf(r, fmaxf(g, b)), c_min = fminf(r, fminf(g, b));
+  float h = 0.f, s = 0.f, v = 0.f;
+  if (c_max != 0.f) {
+    const float delta = c_max - c_min;
+    if (c_max == r) h = 60.f * ((g - b) / delta + (float)(6 * (g < b)));
+    else if (c_max == g) h = 60.f * ((b - r) / delta + 2.f);
+    else h = 60.f * ((r - g) / delta + 4.f);
+    h = h / 360.f; s = delta / c_max; v = c_max;
+  }
+  h *= 180.f; s *= 255.f; v *= 255.f;
+  return h >= 100.f && h <= 124.f && s >= 43.f && s <= 200.f && v >= 150.f && v <= 255.f;
+}
+// the pixel test of MVS::DepthImageToCloud / DepthNormalToCloud (mvs/MVS.cpp:2083-2085, :2120-2121, :2099)
+PVLM_HD inline bool cloud_keeps(float depth, float max_depth, const unsigned char* bgr, bool filter_sky) {
+  if (depth <= 0 || (double)depth >= (double)max_depth * 0.8) return false;
+  return !(filter_sky && sky_colour(bgr));
+}
+// TranslatePoint<float, double> (base/Geometry.hpp:545-551) of unit ray x depth; R_wc n for the normal (mvs/MVS.cpp:2133-2138)
+PVLM_HD inline void cloud_point(const float* ray, float depth, const double* T_wc, float* xyz) {
+  const float pc[3] = {ray[0] * depth, ray[1] * depth, ray[2] * depth};
+  for (int k = 0; k < 3; ++k) xyz[k] = (float)(pc[0] * T_wc[4 * k] + pc[1] * T_wc[4 * k + 1] + pc[2] * T_wc[4 * k + 2] + T_wc[4 * k + 3]);
+}
+PVLM_HD inline void cloud_normal(const float* n, const double* T_wc, float* out) {
+  for (int k = 0; k < 3; ++k) out[k] = (float)(T_wc[4 * k] * (double)n[0] + T_wc[4 * k + 1] * (double)n[1] + T_wc[4 * k + 2] * (double)n[2]);
+}
+
 PVLM_HD inline int num_texels(int half_window, int step) {
   const int w = 2 * half_window + 1, q = w / step + (step > 1 ? 1 : 0);
   return q * q;

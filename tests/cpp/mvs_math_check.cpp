@@ -239,4 +239,20 @@ extern "C" void chk_mvs_propagate_sequential(int rows, int cols, int half_window
     if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0.f; }
   }
 }
+// the per-pixel bodies of k_cloud_count / k_cloud_emit (pvlm_mvs.hip) run on the host in raster order
+extern "C" long long chk_mvs_depth_to_cloud(int rows, int cols, const float* depth, const unsigned char* bgr, const float* normal, const double* T_wc,
+                                            float max_depth, int filter_sky, float* xyz, unsigned char* rgb, float* normal_out) {
+  long long n = 0;
+  for (long long e = 0; e < (long long)rows * cols; ++e) {
+    if (!pvlm_mvs::cloud_keeps(depth[e], max_depth, bgr + 3 * e, filter_sky != 0)) continue;
+    float ray[3];
+    pvlm_mvs::unit_ray(rows, cols, (int)(e % cols), (int)(e / cols), ray);
+    pvlm_mvs::cloud_point(ray, depth[e], T_wc, xyz + 3 * n);
+    rgb[3 * n] = bgr[3 * e + 2]; rgb[3 * n + 1] = bgr[3 * e + 1]; rgb[3 * n + 2] = bgr[3 * e];
+    if (normal_out) pvlm_mvs::cloud_normal(normal + 3 * e, T_wc, normal_out + 3 * n);
+    ++n;
+  }
+  return n;
+}
+
 extern "C" unsigned chk_mvs_random_u32(unsigned long long seed, unsigned long long pixel, unsigned k) { return pvlm_mvs::random_u32(seed, pixel, k); }

@@ -243,3 +243,23 @@ def relative_pose(R_wr, t_wr, R_wn, t_wn):
     R = np.asarray(R_wn).T @ np.asarray(R_wr)
     t = np.asarray(R_wn).T @ (np.asarray(t_wr) - np.asarray(t_wn))
     return R.astype(np.float32), t.astype(np.float32)
+
+
+def cloud_scene(rng, rows, cols, max_depth=20.0):
+    """Inputs of MVS::DepthImageToCloud with every branch present: invalid / far depths, sky-coloured, grey (delta = 0: hue NaN) and black pixels,
+    colours on the edges of the sky box, a tilted pose."""
+    depth = rng.uniform(0.3, 0.9 * max_depth, size=(rows, cols)).astype(np.float32)
+    depth[rng.random((rows, cols)) < 0.15] = 0.0
+    depth[rng.random((rows, cols)) < 0.03] = -1.0
+    depth[0, :4] = np.float32(max_depth * 0.8) * np.array([1.0, 0.9999999, 1.0000001, 0.5], np.float32)
+    bgr = rng.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+    sky = rng.random((rows, cols)) < 0.3                                  # b > g > r, bright: hue 200..248 deg -> inside the box
+    bgr[sky] = np.stack([rng.integers(200, 256, sky.sum()), rng.integers(120, 200, sky.sum()), rng.integers(60, 120, sky.sum())], 1).astype(np.uint8)
+    grey = rng.random((rows, cols)) < 0.05
+    bgr[grey] = bgr[grey][:, :1]
+    bgr[rng.random((rows, cols)) < 0.02] = 0
+    # the inclusive edges of the box: V = 150 / 255, S = 43 / 255 ..., reached by exact byte triples
+    bgr[1, :6] = np.array([[150, 100, 75], [149, 100, 75], [255, 213, 212], [255, 212, 212], [255, 128, 55], [255, 128, 54]], np.uint8)
+    normal = rng.normal(size=(rows, cols, 3)); normal = (normal / np.linalg.norm(normal, axis=2, keepdims=True)).astype(np.float32)
+    T = np.eye(4); T[:3, :3] = rodrigues(np.array([0.3, -0.7, 0.2])); T[:3, 3] = [1.5, -0.25, 7.0]
+    return depth, bgr, normal, T

@@ -272,6 +272,62 @@ def test_patchmatch_sweep_oracle_behaviour_and_device_bodies(oracle):
         assert not np.array_equal(chk[0], want[0])                  # and it is a different sweep from the checkerboard
 
 
+def _hsv_numpy(bgr):
+    """BGR2HSV (util/Visualization.cpp:57-77) x (180, 255, 255), in float32 numpy."""
+    f = np.float32
+    c = bgr.astype(np.float32) / f(255)
+    b, g, r = c[..., 0], c[..., 1], c[..., 2]
+    cmax = np.maximum(r, np.maximum(g, b)); cmin = np.minimum(r, np.minimum(g, b)); delta = cmax - cmin
+    with np.errstate(invalid="ignore", divide="ignore"):
+        hr = f(60) * ((g - b) / delta + (f(6) * (g < b)).astype(np.float32))
+        hg = f(60) * ((b - r) / delta + f(2))
+        hb = f(60) * ((r - g) / delta + f(4))
+        h = np.where(cmax == r, hr, np.where(cmax == g, hg, hb)) / f(360)
+        s = delta / cmax
+    h = np.where(cmax == 0, f(0), h); s = np.where(cmax == 0, f(0), s)
+    return h * f(180), s * f(255), cmax * f(255)
+
+
+@pytest.mark.parametrize("with_normal", [False, True])
+def test_depth_to_cloud_oracle_against_numpy_and_device_bodies(oracle, with_normal):
+    """MVS::DepthImageToCloud / DepthNormalToCloud: the oracle against a vectorised numpy restatement, and the per-pixel bodies the HIP
+    kernels run (pvlm_mvs_core.h, compiled for the host) against the oracle, bit for bit."""
+    rows, cols, max_depth = 60, 120, 20.0
+    depth, bgr, normal, T = synth.cloud_scene(np.random.default_rng(12), rows, cols, max_depth)
+    res = oracle.mvs_depth_to_cloud(depth, bgr, T, max_depth, filter_sky=not with_normal, normal=normal if with_normal else None)
+    # numpy restatement
+    h, s, v = _hsv_numpy(bgr)
+    sky = (h >= 100) & (h <= 124) & (s >= 43) & (s <= 200) & (v >= 150) & (v <= 255)
+    keep = (depth > 0) & (depth.astype(np.float64) < np.float64(np.float32(max_depth)) * 0.8)
+    if not with_normal:
+        keep &= ~sky
+        assert 0.15 * sky.size < sky.sum() < 0.5 * sky.size
+    px = np.stack(np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32)), -1).reshape(-1, 2)
+    unit = oracle.image_to_cam(rows, cols, px, 1.0).reshape(rows, cols, 3)
+    pc = (unit * depth[..., None]).astype(np.float32)[keep].astype(np.float64)
+    want = (pc[:, 0:1] * T[:3, 0] + pc[:, 1:2] * T[:3, 1] + pc[:, 2:3] * T[:3, 2] + T[:3, 3]).astype(np.float32)
+    assert len(res[0]) == keep.sum() and 0.2 * keep.size < keep.sum() < keep.size
+    assert np.array_equal(res[0], want) and np.array_equal(res[1], bgr[keep][:, ::-1])
+    if with_normal:
+        nc = normal[keep].astype(np.float64)
+        assert np.array_equal(res[2], (T[:3, 0] * nc[:, 0:1] + T[:3, 1] * nc[:, 1:2] + T[:3, 2] * nc[:, 2:3]).astype(np.float32))
+    # device bodies on the host
+    out = os.path.join(ROOT, "build", "libmvs_check.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "cpp", "mvs_math_check.cpp")])
+    lib = C.CDLL(out)
+    lib.chk_mvs_depth_to_cloud.restype = C.c_longlong
+    xyz = np.zeros((rows * cols, 3), np.float32); rgb = np.zeros((rows * cols, 3), np.uint8); nout = np.zeros((rows * cols, 3), np.float32)
+    T12 = np.ascontiguousarray(T.reshape(-1)[:12])
+    n = lib.chk_mvs_depth_to_cloud(C.c_int(rows), C.c_int(cols), depth.ctypes.data_as(C.POINTER(C.c_float)), bgr.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                   normal.ctypes.data_as(C.POINTER(C.c_float)), T12.ctypes.data_as(C.POINTER(C.c_double)), C.c_float(max_depth),
+                                   C.c_int(0 if with_normal else 1), xyz.ctypes.data_as(C.POINTER(C.c_float)), rgb.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                   nout.ctypes.data_as(C.POINTER(C.c_float)) if with_normal else None)
+    assert n == len(res[0]) and np.array_equal(xyz[:n], res[0]) and np.array_equal(rgb[:n], res[1])
+    if with_normal:
+        assert np.array_equal(nout[:n], res[2])
+
+
 def test_patchmatch_helpers_against_numpy(oracle):
     """The small pieces of the sweep, one by one, against what they are meant to compute."""
     L = oracle.lib()

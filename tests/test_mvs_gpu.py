@@ -296,3 +296,48 @@ def test_init_depth_normal_and_remove_small_segments_match_oracle(ctx, oracle):
     assert all(np.array_equal(x, y) for x, y in zip(got, want))
     fin = ctx.mvs_remove_small_segments(got[0], got[1], got[2], 0.01, 100)
     assert np.array_equal(fin[0], oracle.mvs_remove_small_segments(want[0], want[1], want[2], 0.01, 100)[0])
+
+
+@pytest.mark.parametrize("rows,cols", [(60, 120), (37, 101), (720, 1440)])
+def test_depth_to_cloud_matches_oracle(ctx, oracle, rows, cols):
+    """pvlm_mvs_depth_to_cloud (MVS::DepthImageToCloud / DepthNormalToCloud, mvs/MVS.cpp:2073-2142): same points, colours, normals, in
+    the same (raster) order, bit for bit — 37 x 101 leaves a ragged last workgroup, 720 x 1440 takes four rounds of the block scan."""
+    from tests import synth
+    from panovlm_amd.api import MvsViews
+    depth, bgr, normal, T = synth.cloud_scene(np.random.default_rng(rows), rows, cols, 20.0)
+    want = oracle.mvs_depth_to_cloud(depth, bgr, T, 20.0)
+    got = ctx.mvs_depth_to_cloud(depth, bgr, T, 20.0)
+    assert len(want[0]) > 0.2 * rows * cols
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    wantn = oracle.mvs_depth_to_cloud(depth, bgr, T, 20.0, filter_sky=False, normal=normal)
+    gotn = ctx.mvs_depth_to_cloud(depth, bgr, T, 20.0, filter_sky=False, normal=normal)
+    assert len(wantn[0]) > len(want[0])
+    assert all(np.array_equal(a, b) for a, b in zip(gotn, wantn))
+    # 3 x 4 pose, a different max_depth
+    w2 = oracle.mvs_depth_to_cloud(depth, bgr, T[:3], 7.5); g2 = ctx.mvs_depth_to_cloud(depth, bgr, T[:3], 7.5)
+    assert 0 < len(w2[0]) < len(want[0]) and np.array_equal(g2[0], w2[0]) and np.array_equal(g2[1], w2[1])
+    # the resident view: depth_filter (uploaded as depth, then snapshot) and depth, unit rays from the view set's table
+    V = MvsViews(ctx, rows, cols, 2)
+    V.upload(1, gray=np.zeros((rows, cols), np.uint8), depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
+    gv = V.depth_to_cloud(1, bgr, T, 20.0, filter_sky=False, use_filtered_depth=False, with_normal=True)
+    assert all(np.array_equal(a, b) for a, b in zip(gv, wantn))
+    V.snapshot_depth(1)
+    gv = V.depth_to_cloud(1, bgr, T, 20.0)
+    assert np.array_equal(gv[0], want[0]) and np.array_equal(gv[1], want[1])
+    V.close()
+
+
+def test_depth_to_cloud_edge_cases(ctx, oracle):
+    rows, cols = 16, 48
+    bgr = np.full((rows, cols, 3), 90, np.uint8); T = np.eye(4)
+    none = ctx.mvs_depth_to_cloud(np.zeros((rows, cols), np.float32), bgr, T)
+    assert none[0].shape == (0, 3) and none[1].shape == (0, 3)
+    every = ctx.mvs_depth_to_cloud(np.full((rows, cols), 2.0, np.float32), bgr, T)
+    want = oracle.mvs_depth_to_cloud(np.full((rows, cols), 2.0, np.float32), bgr, T)
+    assert len(every[0]) == rows * cols and np.array_equal(every[0], want[0])
+    assert np.allclose(np.linalg.norm(every[0], axis=1), 2.0, atol=1e-5)
+    one = np.zeros((1, 1), np.float32) + 3
+    g = ctx.mvs_depth_to_cloud(one, np.zeros((1, 1, 3), np.uint8), T); w = oracle.mvs_depth_to_cloud(one, np.zeros((1, 1, 3), np.uint8), T)
+    assert len(g[0]) == 1 and np.array_equal(g[0], w[0])
+    with pytest.raises(Exception):
+        ctx.mvs_depth_to_cloud(np.zeros((0, 4), np.float32), np.zeros((0, 4, 3), np.uint8), T)

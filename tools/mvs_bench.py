@@ -109,6 +109,20 @@ def main():
     bat0 = V.download(0, ("depth", "normal", "conf"))
     batch_equals_single = bool(np.array_equal(bat0["depth"], sq[0]) and np.array_equal(bat0["conf"], sq[2]))
     V.close()
+    # depth map -> coloured world points (MVS::DepthImageToCloud, the body of MergeDepthImages): count + scan + emit
+    crng = np.random.default_rng(11)
+    bgr = np.repeat(gray[..., None], 3, axis=2); bgr[..., 0] = np.minimum(255, bgr[..., 0].astype(np.int32) + crng.integers(0, 90, size=gray.shape)).astype(np.uint8)
+    Twc = np.eye(4); Twc[:3, 3] = [0.5, 0.1, -2.0]
+    ctx.mvs_depth_to_cloud(depth, bgr, Twc, 20.0)
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    cl = ctx.mvs_depth_to_cloud(depth, bgr, Twc, 20.0)
+    cloud_wall = time.perf_counter() - t0
+    cloud_ms, cloud_cnt = ctx.profile_read(1)
+    ctx.profile_enable(False)
+    t0 = time.perf_counter()
+    clo = orc.mvs_depth_to_cloud(depth, bgr, Twc, 20.0)
+    cloud_cpu = time.perf_counter() - t0
     vs = c0 > -1
     same = (np.abs(sg[0] - so[0]) <= 1e-4 * np.maximum(np.abs(so[0]), 1e-3)) & (np.abs(sg[1] - so[1]).max(axis=2) <= 1e-4) & (np.abs(sg[2] - so[2]) <= 1e-4)
     rel = lambda d: float(np.median(np.abs(d[vs] / depth[vs] - 1)))
@@ -130,6 +144,8 @@ def main():
                                                 depth_err=rel(sq[0]), mean_conf=float(sq[2][vs].mean()), batch_views=B,
                                                 batch_ms_per_iteration=bat_ms / max(bat_cnt, 1), batch_ms_per_view_iteration=bat_ms / max(bat_cnt, 1) / B,
                                                 batch_view0_equals_single_call=batch_equals_single),
+                          depth_to_cloud=dict(kernels_ms=cloud_ms / max(cloud_cnt, 1), wall_ms_incl_copies=cloud_wall * 1e3, points=int(len(cl[0])),
+                                              identical_to_oracle=bool(np.array_equal(cl[0], clo[0]) and np.array_equal(cl[1], clo[1])), cpu_oracle_s_single_thread=cloud_cpu),
                           sweep_geometric=dict(kernel_ms_per_colour_pass=geo_ms / max(geo_cnt, 1), identical_to_oracle=geo_same),
                           cpu_threads=orc.num_threads(), speedup_kernel_vs_cpu=cpu / (k_ms * 1e-3))))
 
