@@ -412,6 +412,58 @@ void DumpFeatures(const std::string& dir) {
   WriteBundle(dir + "/features.ref.pvv", out);
 }
 
+// ---- the LINE branch: Velodyne::EdgeToLine (sensors/Velodyne.cpp:1269-1324) behind ExtractFeatures(ADAPTIVE) (:746-752) ----
+// ExtractLineFeatures (sensors/LidarLineExtraction.cpp:296-389) -> edge_segmented / segment_coeffs, FurthestPoints +
+// ProjectPoint2Line3D -> end_points, the de-duplicated cornerLessSharp with point_to_segment, the re-filtered cornerSharp.
+// All public members (sensors/Velodyne.h:88-91).  NB: FuseLines fits with pcl's SAC_RANSAC (:148-175), whose draws depend
+// on pcl's generator; this repo's oracle takes the exhaustive 2-point maximum consensus, so segment_coeffs / end_points
+// agree only where the consensus line is unique (tools/refvec.py compares them by direction and distance, not bit for bit).
+void DumpLineExtraction(const std::string& dir) {
+  const Bundle in = ReadBundle(dir + "/line_extraction.in.pvv");
+  if (in.empty()) return;
+  const Array& raw = in.at("raw");
+  const int horizon = (int)in.at("horizon").as_double(0);
+  Velodyne v(16, 0, horizon);
+  for (size_t i = 0; i < raw.dims[0]; ++i) {
+    pcl::PointXYZI p; p.x = raw.f32()[4 * i]; p.y = raw.f32()[4 * i + 1]; p.z = raw.f32()[4 * i + 2]; p.intensity = raw.f32()[4 * i + 3];
+    v.cloud.push_back(p);
+  }
+  v.ReOrderVLP();
+  v.ExtractFeatures(1000.f, 5.f, ADAPTIVE, true);
+  auto flat = [](const pcl::PointCloud<pcl::PointXYZI>& c) {
+    std::vector<float> o;
+    for (const auto& p : c.points) { o.push_back(p.x); o.push_back(p.y); o.push_back(p.z); o.push_back(p.intensity); }
+    return o;
+  };
+  Bundle out;
+  out["cornerBeforeFilter"] = MakeArray(0, {v.cornerBeforeFilter.size(), 4}, flat(v.cornerBeforeFilter));
+  out["cornerLessSharp"] = MakeArray(0, {v.cornerLessSharp.size(), 4}, flat(v.cornerLessSharp));
+  out["cornerSharp"] = MakeArray(0, {v.cornerSharp.size(), 4}, flat(v.cornerSharp));
+  out["surfFlat"] = MakeArray(0, {v.surfFlat.size(), 4}, flat(v.surfFlat));
+  out["surfLessFlat"] = MakeArray(0, {v.surfLessFlat.size(), 4}, flat(v.surfLessFlat));
+  std::vector<int32_t> seg_off = {0}, p2s_off = {0}, p2s_ids;
+  std::vector<float> seg_pts;
+  for (const auto& c : v.edge_segmented) {
+    const std::vector<float> f = flat(c);
+    seg_pts.insert(seg_pts.end(), f.begin(), f.end());
+    seg_off.push_back((int32_t)(seg_pts.size() / 4));
+  }
+  for (const std::set<int>& sset : v.point_to_segment) {
+    for (int id : sset) p2s_ids.push_back(id);                      // std::set: ascending, as the golden lists them
+    p2s_off.push_back((int32_t)p2s_ids.size());
+  }
+  std::vector<double> coeffs, ends;
+  for (const auto& c : v.segment_coeffs) for (int k = 0; k < 6; ++k) coeffs.push_back(c[k]);
+  for (const auto& e : v.end_points) for (int k = 0; k < 3; ++k) ends.push_back(e[k]);
+  out["seg_offsets"] = MakeArray(2, {seg_off.size()}, seg_off);
+  out["seg_points"] = MakeArray(0, {seg_pts.size() / 4, 4}, seg_pts);
+  out["segment_coeffs"] = MakeArray(1, {v.segment_coeffs.size(), 6}, coeffs);
+  out["end_points"] = MakeArray(1, {v.end_points.size() / 2, 2, 3}, ends);
+  out["p2s_offsets"] = MakeArray(2, {p2s_off.size()}, p2s_off);
+  out["p2s_ids"] = MakeArray(2, {p2s_ids.size()}, p2s_ids);
+  WriteBundle(dir + "/line_extraction.ref.pvv", out);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -427,5 +479,6 @@ int main(int argc, char** argv) {
   DumpReproj(dir);
   DumpDepth(dir);
   DumpFeatures(dir);
+  DumpLineExtraction(dir);
   return 0;
 }
