@@ -165,7 +165,7 @@ pvlm_status pvlm_i_h2d_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes
   return PVLM_OK;
 }
 
-pvlm_status pvlm_i_d2h_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+static pvlm_status d2h_queue(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes > kStageDirect) {
     PVLM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -184,6 +184,18 @@ pvlm_status pvlm_i_d2h_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes
     done += n;
   }
   return PVLM_OK;
+}
+
+// A failed queueing leaves no deferred copy behind: the caller returns its error without reaching pvlm_i_sync, and a later
+// synchronisation must not write into buffers that caller has released by then.
+pvlm_status pvlm_i_d2h_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  const pvlm_status st = d2h_queue(ctx, dst, src, bytes);
+  if (st) {
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->stage.deferred.clear();
+    ctx->stage.cursor = 0;
+  }
+  return st;
 }
 
 pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {

@@ -1002,7 +1002,6 @@ pvlm_status pvlm_mvs_views_download(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, 
                                     float* conf_filter) {
   if (!ctx || !v || view < 0 || view >= v->n) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  hipStream_t s = ctx->stream;
   const size_t o = v->npix * (size_t)view, bytes = v->npix * sizeof(float);
   hipError_t e = hipSuccess;
   if (depth) e = mvs_down(ctx, depth, v->d_depth + o, bytes);
@@ -1010,7 +1009,7 @@ pvlm_status pvlm_mvs_views_download(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, 
   if (e == hipSuccess && conf) e = mvs_down(ctx, conf, v->d_conf + o, bytes);
   if (e == hipSuccess && depth_filter) e = mvs_down(ctx, depth_filter, v->d_depth_filter + o, bytes);
   if (e == hipSuccess && conf_filter) e = mvs_down(ctx, conf_filter, v->d_conf_filter + o, bytes);
-  if (e == hipSuccess) e = mvs_sync(ctx);
+  { const hipError_t e2 = mvs_sync(ctx); if (e == hipSuccess) e = e2; }
   if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_mvs_views_download: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
   return PVLM_OK;
 }

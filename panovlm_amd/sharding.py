@@ -93,3 +93,19 @@ def estimate_depth_maps(worker, views, neighbors, rank=0, world=1, half_window=3
                                       max_depth=max_depth, seed=seed + v, max_iter=pho_iters, conf_threshold=conf_threshold, sequential=sequential)
     return out
 
+
+
+def merge_depth_images(worker, depths, bgrs, poses, skip=1, max_depth=20.0, rank=0, world=1):
+    """MVS::MergeDepthImages(skip) (mvs/MVS.cpp:2144-2166; FuseDepthMaps :224-227 calls it with skip = 2): the clouds of every skip-th frame
+    with a depth map (DepthImageToCloud, worker.mvs_depth_to_cloud) appended in frame order — upstream appends per OpenMP thread, i.e. in
+    frame order with one thread.  depths[i]: rows x cols float32 or None (an empty depth map: skipped), bgrs[i]: rows x cols x 3 uint8,
+    poses[i]: T_wc (3 x 4 or 4 x 4).  This rank takes a contiguous block of the selected frames: concatenating the ranks' results in rank
+    order gives the single-rank cloud, no exchange.  Returns (xyz n x 3 float32, rgb n x 3 uint8)."""
+    assert skip >= 1
+    chosen = [i for i in range(0, len(depths), skip) if depths[i] is not None]
+    lo, hi = shard_range(len(chosen), rank, world)
+    xyz, rgb = [np.zeros((0, 3), np.float32)], [np.zeros((0, 3), np.uint8)]
+    for i in chosen[lo:hi]:
+        p, c = worker.mvs_depth_to_cloud(depths[i], bgrs[i], poses[i], max_depth)[:2]
+        xyz.append(p); rgb.append(c)
+    return np.concatenate(xyz), np.concatenate(rgb)

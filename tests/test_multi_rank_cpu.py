@@ -124,6 +124,20 @@ class _OracleWorker:
     def mvs_propagate(self, *a, **k):
         return self.o.mvs_propagate(*a, **k)
 
+    def mvs_depth_to_cloud(self, *a, **k):
+        return self.o.mvs_depth_to_cloud(*a, **k)
+
+
+def _cloud_frames(n=7, rows=24, cols=48):
+    from tests import synth
+    rng = np.random.default_rng(5)
+    depths, bgrs, poses = [], [], []
+    for k in range(n):
+        d, c, _, T = synth.cloud_scene(rng, rows, cols)
+        T[:3, 3] += k
+        depths.append(None if k == 2 else d); bgrs.append(c); poses.append(T)      # frame 2 has no depth map: skipped, as upstream
+    return depths, bgrs, poses
+
 
 def _mvs_worker(rank, world, port, q):
     import torch.distributed as dist
@@ -132,8 +146,9 @@ def _mvs_worker(rank, world, port, q):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     views, nb = _mvs_views(oracle)
     mine = sh.estimate_depth_maps(_OracleWorker(oracle), views, nb, rank, world, pho_iters=1, seed=11)
+    cloud = sh.merge_depth_images(_OracleWorker(oracle), *_cloud_frames(), skip=2, rank=rank, world=world)
     gathered = [None] * world
-    dist.all_gather_object(gathered, {v: d[0] for v, d in mine.items()})     # collecting the results is the only communication
+    dist.all_gather_object(gathered, ({v: d[0] for v, d in mine.items()}, cloud))     # collecting the results is the only communication
     if rank == 0:
         q.put(gathered)
     dist.destroy_process_group()
@@ -162,6 +177,15 @@ def test_mvs_view_sharding_two_ranks(oracle):
         assert p.exitcode == 0
     views, nb = _mvs_views(oracle)
     single = sh.estimate_depth_maps(_OracleWorker(oracle), views, nb, 0, 1, pho_iters=1, seed=11)
+    # MergeDepthImages(2): frames 0, 4, 6 (2 has no depth map), rank 0 takes two of them; rank order = frame order
+    whole = sh.merge_depth_images(_OracleWorker(oracle), *_cloud_frames(), skip=2)
+    parts = [g[1] for g in gathered]
+    assert all(len(p[0]) > 0 for p in parts)
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), whole[0]) and np.array_equal(np.concatenate([p[1] for p in parts]), whole[1])
+    depths, bgrs, poses = _cloud_frames()
+    by_hand = [oracle.mvs_depth_to_cloud(depths[i], bgrs[i], poses[i], 20.0) for i in (0, 4, 6)]
+    assert np.array_equal(whole[0], np.concatenate([b[0] for b in by_hand]))
+    gathered = [g[0] for g in gathered]
     merged = {}
     for part in gathered:
         assert not (set(part) & set(merged))
