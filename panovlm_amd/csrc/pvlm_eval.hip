@@ -15,6 +15,54 @@
 
 using namespace pvlm_dev;
 
+// 16-byte load of two consecutive rows of a column.  The column base comes out of a pointer table in memory, so the compiler
+// cannot prove the address space and emits FLAT loads (aperture check, lgkmcnt + vmcnt); PVLM_GLOBAL_LOADS = 1 states that the
+// columns live in global memory.  PVLM_NT_LOADS = 1: non-temporal (the 45 GB of a launch are read exactly once; keeps them
+// out of the way of the pair table and the partials in L2 / MALL).  Measured on the benched kernel (tools/ab_eval_loads.sh,
+// profiles/r2_ab_eval_loads.txt): flat 7.61 ms, global 7.60 ms, flat + nt 7.52 ms, global + nt 7.50 ms per launch.
+#ifndef PVLM_NT_LOADS
+#define PVLM_NT_LOADS 1
+#endif
+#ifndef PVLM_GLOBAL_LOADS
+#define PVLM_GLOBAL_LOADS 1
+#endif
+typedef double pvlm_dbl2 __attribute__((ext_vector_type(2)));
+#if PVLM_GLOBAL_LOADS
+typedef const __attribute__((address_space(1))) pvlm_dbl2* pvlm_col_ptr;
+#else
+typedef const pvlm_dbl2* pvlm_col_ptr;
+#endif
+#ifndef PVLM_NT_LOADS_MATERIALISE   // the same hint in the kernels that also WRITE rows (k_eval_materialise, k_eval_wrench)
+#define PVLM_NT_LOADS_MATERIALISE 0
+#endif
+template <bool NT>
+__device__ __forceinline__ double2 stream_load2(const double* p) {
+  pvlm_col_ptr q = (pvlm_col_ptr)(p);
+  const pvlm_dbl2 v = NT ? __builtin_nontemporal_load(q) : *q;
+  return make_double2(v.x, v.y);
+}
+// ... and the stores of the materialising kernels (r, the 1 x 12 rows, the wrench rows).  Non-temporal STORES were measured and lose:
+// k_eval_materialise 4.80 TB/s against 5.04 TB/s with ordinary stores (profiles/r2_ab_eval_loads.txt) — off.
+#ifndef PVLM_NT_STORES
+#define PVLM_NT_STORES 0
+#endif
+__device__ __forceinline__ void stream_store2(double2* p, double2 v) {
+#if PVLM_NT_STORES
+  pvlm_dbl2 w; w.x = v.x; w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<pvlm_dbl2*>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void stream_store1(double* p, double v) {
+#if PVLM_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
+
 #ifndef PVLM_PREFETCH
 #define PVLM_PREFETCH -1  // -1 = per-functor default, 0 / 1 force
 #endif
@@ -129,7 +177,7 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* const* _
     if (j < hi) {
       double2 v[NCOLS];
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS_MATERIALISE != 0>(cols + (size_t)c * n_dev + j);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (j + h >= hi) break;
@@ -138,7 +186,7 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* const* _
         for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
         Wrench w;
         eval_wrench<KIND, NORM>(rec, T, weight, w);
-        r_out[o0 + j + h] = w.r;
+        stream_store1(r_out + o0 + j + h, w.r);
         if (J_out) {
           double Jr[12];
 #pragma unroll
@@ -165,7 +213,7 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* const* _
 #pragma unroll
         for (int t = 0; t < 12; ++t) {
           const int e = t * 64 + lane;
-          if (e < n2) gdst[e] = src[e];
+          if (e < n2) stream_store2(gdst + e, src[e]);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -203,7 +251,7 @@ __global__ __launch_bounds__(256) void k_eval_wrench(const double* const* __rest
     if (j < hi) {
       double2 v[NCOLS];
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS_MATERIALISE != 0>(cols + (size_t)c * n_dev + j);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (j + h >= hi) break;
@@ -225,7 +273,7 @@ __global__ __launch_bounds__(256) void k_eval_wrench(const double* const* __rest
 #pragma unroll
       for (int t = 0; t < 14; ++t) {
         const int e = t * 64 + lane;
-        if (e < n) g[e] = stage[wv][e];
+        if (e < n) stream_store1(g + e, stage[wv][e]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -299,7 +347,7 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
   double2 nx[NCOLS];
   if (kPrefetch && j < hi) {
 #pragma unroll
-    for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
+    for (int c = 0; c < NCOLS; ++c) nx[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j);
   }
   for (; j < hi; j += 512) {
     double2 v[NCOLS];
@@ -308,7 +356,7 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
       for (int c = 0; c < NCOLS; ++c) v[c] = nx[c];
       if (j + 512 < hi) {
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) nx[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j + 512);
+        for (int c = 0; c < NCOLS; ++c) nx[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j + 512);
       }
     } else {
 #ifdef PVLM_EXP_SKIP   // timing experiment only (wrong results): how does the rate respond to fewer bytes per evaluation?
@@ -316,7 +364,7 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
       for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)(c < NCOLS - PVLM_EXP_SKIP ? c : 0) * n_dev + j);
 #else
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)c * n_dev + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j);
 #endif
     }
 #pragma unroll

@@ -217,11 +217,34 @@ __device__ __forceinline__ void sincos_f32_args(const float (&xf)[N], float (&s_
   }
 }
 
+// streaming accesses of the whole-panorama maps.  PVLM_NT_MAPS = 1 makes them non-temporal: measured and rejected — CamToImage drops
+// from 0.66 to 0.555 of the HBM peak, ImageToCam does not move (profiles/r2_ab_eval_loads.txt).
+#ifndef PVLM_NT_MAPS
+#define PVLM_NT_MAPS 0
+#endif
+typedef float pvlm_flt4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 map_load4(const float4* p) {
+#if PVLM_NT_MAPS
+  const pvlm_flt4 v = __builtin_nontemporal_load((const __attribute__((address_space(1))) pvlm_flt4*)(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void map_store4(float4* p, float4 v) {
+#if PVLM_NT_MAPS
+  pvlm_flt4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, (__attribute__((address_space(1))) pvlm_flt4*)(p));
+#else
+  *p = v;
+#endif
+}
+
 // four points per lane, 16-byte vector accesses only (3 loads, 2 stores): the device-resident whole-panorama form
 __global__ __launch_bounds__(256) void k_cam_to_image_f32x4(int rows, int cols, long long n4, const float4* __restrict__ cam, float4* __restrict__ px) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const float4 a = cam[3 * i], b = cam[3 * i + 1], c = cam[3 * i + 2];
+  const float4 a = map_load4(cam + 3 * i), b = map_load4(cam + 3 * i + 1), c = map_load4(cam + 3 * i + 2);
   const float p[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
   float o[8];
 #pragma unroll
@@ -232,8 +255,8 @@ __global__ __launch_bounds__(256) void k_cam_to_image_f32x4(int rows, int cols, 
     o[2 * k] = (float)(cols * (0.5 + pvlm_exact::div_two_pi(lon)));
     o[2 * k + 1] = (float)(rows * (0.5 - pvlm_exact::div_pi(lat)));
   }
-  px[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
-  px[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
+  map_store4(px + 2 * i, make_float4(o[0], o[1], o[2], o[3]));
+  map_store4(px + 2 * i + 1, make_float4(o[4], o[5], o[6], o[7]));
 }
 
 template <typename T, bool LIBRARY_TRIG>
@@ -263,7 +286,7 @@ static bool exact_trig() { static const bool v = getenv("PVLM_EXACT_TRIG") != nu
 __global__ __launch_bounds__(256) void k_image_to_cam_f32x4(int rows, int cols, long long n4, const float4* __restrict__ px, float r, float4* __restrict__ cam) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const float4 a = px[2 * i], b = px[2 * i + 1];
+  const float4 a = map_load4(px + 2 * i), b = map_load4(px + 2 * i + 1);
   const float u[4] = {a.x, a.z, b.x, b.z}, v[4] = {a.y, a.w, b.y, b.w};
   float o[12];
   const float fc = (float)cols, fr = (float)rows, inv_c = 1.0f / fc, inv_r = 1.0f / fr;
@@ -278,9 +301,9 @@ __global__ __launch_bounds__(256) void k_image_to_cam_f32x4(int rows, int cols, 
   sincos_f32_args<8>(arg, sn, cs);
 #pragma unroll
   for (int k = 0; k < 4; ++k) { o[3 * k] = r * cs[k] * sn[4 + k]; o[3 * k + 1] = -r * sn[k]; o[3 * k + 2] = r * cs[k] * cs[4 + k]; }
-  cam[3 * i] = make_float4(o[0], o[1], o[2], o[3]);
-  cam[3 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
-  cam[3 * i + 2] = make_float4(o[8], o[9], o[10], o[11]);
+  map_store4(cam + 3 * i, make_float4(o[0], o[1], o[2], o[3]));
+  map_store4(cam + 3 * i + 1, make_float4(o[4], o[5], o[6], o[7]));
+  map_store4(cam + 3 * i + 2, make_float4(o[8], o[9], o[10], o[11]));
 }
 
 // ---- LiDAR-seeded sparse depth image: ProjectLidar2PanoramaDepth (util/Visualization.h:407-441) ----------------
