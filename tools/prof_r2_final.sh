@@ -4,8 +4,13 @@ set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2f; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed" > $O/gpu_tests.txt; cat $O/gpu_tests.txt
-# MVS counters first: bench.py quotes them
+# counters first: bench.py quotes them
 cd /tmp && export TMPDIR=/tmp
+# HBM read traffic of the fused kernel (FETCH_SIZE in its own pass; the WRITE_SIZE pass hung on this pool in round 2 and is skipped)
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/bench_fetch -- python $R/bench.py --no-cpu-baseline --no-mvs --no-projection --steps 10 > $O/bench_fetch.log 2>&1
+grep '^{' $O/bench_fetch.log | tail -1 > $O/bench_fetch.json
+cd $R && python tools/pmc_traffic.py $O/bench_fetch - $O/bench_fetch.json $O/r2_pmc_traffic_default.json > /dev/null && cp $O/r2_pmc_traffic_default.json $R/profiles/r2_pmc_traffic_default.json   # bench.py quotes it
+cd /tmp
 W="python $R/tools/mvs_bench.py"
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/mvs_trace -- $W > $O/mvs_trace.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $O/mvs_pmc -- $W > $O/mvs_pmc.log 2>&1
