@@ -1167,10 +1167,10 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
         m += ws.h_cc[s][ch];
       }
       rs->h_out_start[p + 1] = rs->h_out_start[p] + m;
-      block_row += (m + 1) & ~1ll;
+      block_row += pvlm_i_seg_rows(m);
       block_n += m;
     }
-    const long long R = std::max<long long>(block_row, 2);
+    const long long R = std::max<long long>(block_row, 16);
     double* d_block = nullptr;
     pvlm_status sa = pvlm_i_alloc(ctx, &d_block, (size_t)R * 7);
     if (sa) return sa;

@@ -577,7 +577,7 @@ pvlm_status pvlm_resset_upload(pvlm_ctx* ctx, pvlm_functor kind, unsigned flags,
   rs->h_nei.assign(pair_nei, pair_nei + n_pairs);
   rs->h_seg_start.resize(n_pairs + 1);
   int64_t o = 0;
-  for (int p = 0; p < n_pairs; ++p) { rs->h_seg_start[p] = o; o += ((rs->h_out_start[p + 1] - rs->h_out_start[p]) + 1) & ~int64_t(1); }
+  for (int p = 0; p < n_pairs; ++p) { rs->h_seg_start[p] = o; o += pvlm_i_seg_rows(rs->h_out_start[p + 1] - rs->h_out_start[p]); }
   rs->h_seg_start[n_pairs] = o;
   rs->n_dev = o;
   rs->h_pair_block.assign(n_pairs, 0);   // an uploaded set is one column block

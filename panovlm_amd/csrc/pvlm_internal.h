@@ -219,6 +219,11 @@ struct pvlm_scan {
 void pvlm_i_trace(const char* label);
 // helpers implemented in pvlm_ctx.hip
 pvlm_status pvlm_i_bind(pvlm_ctx* ctx);  // hipSetDevice(ctx->device)
+// Rows a pair's segment occupies inside a column block: a multiple of 16 rows = 128 B, so that every column of every pair starts on
+// a cache line (the pool hands out 256-B aligned blocks and the column stride is a sum of padded segments).  With segments padded
+// to 2 rows only (round 1) seven of eight pairs started inside a line: every 1 KiB wave access of k_eval_fused touched 9 lines
+// instead of 8 (FETCH_SIZE 1.07 x the algorithmic bytes once the loads are non-temporal, profiles/r2_pmc_traffic_default.json).
+inline int64_t pvlm_i_seg_rows(int64_t rows) { return (rows + 15) & ~int64_t(15); }
 pvlm_status pvlm_i_alloc_bytes(pvlm_ctx* ctx, void** p, size_t bytes);   // from the context's pool
 void pvlm_i_free(pvlm_ctx* ctx, const void* p);                           // back to the pool (NULL ok; foreign pointers go to hipFree)
 void pvlm_i_pool_release(pvlm_ctx* ctx, bool all);                        // hipFree the fully free slabs (all: every slab, at destroy)

@@ -671,7 +671,7 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
       pvlm_i_resset_free(ctx, rs); return PVLM_ERR_ARG;
     }
     if (p != last_pair) {
-      if (last_pair >= 0) { rs->h_out_start.push_back(row); row = (row + 1) & ~1ll; }
+      if (last_pair >= 0) { rs->h_out_start.push_back(row); row = pvlm_i_seg_rows(row); }
       rs->h_seg_start.push_back(row);
       rs->h_ref.push_back(R->id); rs->h_nei.push_back(N->id);
       pvlm_match_pose P; std::memcpy(P.R, N->R_wl, 72); std::memcpy(P.t, N->t_wl, 24);
@@ -702,7 +702,7 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
     rs->h_out_start = off;
     rs->n = compact;
   }
-  const long long R_rows = std::max<long long>((row + 1) & ~1ll, 2);
+  const long long R_rows = std::max<long long>(pvlm_i_seg_rows(row), 16);
   pvlm_i_trace("line2line_residuals: match table built");
   rs->n_dev = R_rows;
   rs->h_pair_block.assign((size_t)rs->n_pairs, 0);

@@ -12,9 +12,16 @@ bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
 def load(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(list)
+    grid = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k].append(float(r["Counter_Value"])); grid[k].append(int(r["Grid_Size"]))
+    # the bench command also launches these kernels on smaller sets (association points, projection): keep the dispatches of the
+    # largest grid = the benchmark's workload (evals_per_launch)
+    for k in agg:
+        g = max(grid[k])
+        agg[k] = [v for v, gs in zip(agg[k], grid[k]) if gs == g]
     return agg
 
 

@@ -79,6 +79,13 @@ def _is_output(fixture, key):
 INTERNAL = ("_qidx", "_nn", "votes",
             # private working arrays of Velodyne (sensors/Velodyne.h:97-120); cornerSharp is re-filtered by EdgeToLine upstream
             "rc", "scan_start", "scan_end", "range_image", "image_to_point_idx", "curvature", "state", "sort_ind", "left", "right", "cornerSharp")
+
+
+def is_internal(fixture, key):
+    """Golden arrays the reference API does not expose.  In line_extraction cornerSharp is the public, re-filtered cloud."""
+    return key.endswith(INTERNAL) and fixture != "line_extraction"
+
+
 FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth", "features", "line_extraction")   # mvs.npz: the
 # reference entry point (MVS::InitConfMap) is a private member driven by the whole MVS object — not exported here
 
@@ -105,7 +112,7 @@ def compare(out_dir):
             if not _is_output(fx, k):
                 continue
             if k not in ref:
-                if k.endswith(INTERNAL) and fx != "line_extraction":   # there cornerSharp is the public, re-filtered cloud
+                if is_internal(fx, k):
                     print("%-20s %-18s n/a (internal to the reference function, pinned through its outputs)" % (fx, k))
                 else:
                     print("%-20s %-18s not produced" % (fx, k)); bad += 1
