@@ -24,7 +24,6 @@ cd $R && python tools/trace_groups.py $(find $O/bench_trace -name "*kernel_trace
 cp $(find $O/bench_trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats_default.csv
 python tools/room_like_odometry.py --scans 454 --iters 3 --lines 1 > /dev/null 2>&1
 python tools/room_like_odometry.py --scans 454 --iters 3 --lines 1 > $O/room_like_lines454.txt 2>&1
-python tools/room_like_odometry.py --scans 128 --iters 3 --lines 1 > $O/room_like_lines128.txt 2>&1
 python tools/room_like_joint.py --frames 454 --points 150000 > $O/room_like_joint454.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 du -sh $O
