@@ -840,7 +840,10 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
     if (d->n_corner > 0) {
       if (d->p2s_offsets) {
         s->h_p2s_off.assign(d->p2s_offsets, d->p2s_offsets + d->n_corner + 1);
+        bool monotone = s->h_p2s_off.front() == 0;
+        for (int q = 0; q < d->n_corner && monotone; ++q) monotone = s->h_p2s_off[(size_t)q] <= s->h_p2s_off[(size_t)q + 1];
         const int tot = s->h_p2s_off.back();
+        if (!monotone || (tot > 0 && !d->p2s_ids)) { PVLM_SET_ERR(ctx, "point_to_segment offsets must start at 0 and not decrease; p2s_ids must be given (scan %d of the batch)", k); st = PVLM_ERR_ARG; break; }
         if (tot > 0) s->h_p2s_ids.assign(d->p2s_ids, d->p2s_ids + tot);
         for (int v : s->h_p2s_ids) if (v < 0 || v >= d->n_segments) { PVLM_SET_ERR(ctx, "point_to_segment id %d out of range", v); st = PVLM_ERR_ARG; break; }
       } else {

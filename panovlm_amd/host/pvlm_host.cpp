@@ -232,7 +232,7 @@ struct ScanStaging {
       for (size_t i = 0; i < c.size(); ++i) { xyz[3 * i] = c[i].x; xyz[3 * i + 1] = c[i].y; xyz[3 * i + 2] = c[i].z; if (tag) (*tag)[i] = c[i].intensity; }
     };
     flat(v.surfFlat, fx, &ft); flat(v.surfLessFlat, lx, &lt); flat(v.cornerLessSharp, cx, nullptr);
-    off.assign(v.cornerLessSharp.size() + 1, 0); seg_size.resize(v.edge_segmented.size());
+    off.assign(v.cornerLessSharp.size() + 1, 0); ids.clear(); seg_size.resize(v.edge_segmented.size());
     for (size_t i = 0; i < v.cornerLessSharp.size(); ++i) {
       if (i < v.point_to_segment.size()) for (int s : v.point_to_segment[i]) ids.push_back(s);
       off[i + 1] = (int)ids.size();
