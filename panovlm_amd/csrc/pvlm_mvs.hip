@@ -986,7 +986,6 @@ pvlm_status pvlm_mvs_views_upload(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, co
                                   const float* conf) {
   if (!ctx || !v || view < 0 || view >= v->n) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  hipStream_t s = ctx->stream;
   const size_t o = v->npix * (size_t)view;
   hipError_t e = hipSuccess;
   if (gray) e = mvs_up(ctx, v->d_gray + o, gray, v->npix);
