@@ -200,6 +200,20 @@ def mvs():
     np.savez_compressed(os.path.join(OUT, "mvs.npz"), **d)
 
 
+def mvs_cloud():
+    """MVS::DepthImageToCloud / DepthNormalToCloud (mvs/MVS.cpp:2073-2142) of a 40 x 80 depth map with every branch present (invalid and far
+    depths, sky-coloured, grey and black pixels); and one SEQUENTIAL PatchMatch iteration (PropagateSequential, :1057-1097) from the scored
+    state of the mvs.npz scene (its inputs are read from that fixture)."""
+    depth, bgr, normal, T = synth.cloud_scene(np.random.default_rng(61), 40, 80, 20.0)
+    g = np.load(os.path.join(OUT, "mvs.npz"))
+    neis = [g["nei%d_gray" % k] for k in range(3)]
+    ds, ns, cs = orc.mvs_propagate(g["gray"], neis, g["R_nr"], g["t_nr"], g["depth_pho"], g["normal"], g["conf_pho"], max_iter=1, seed=int(g["sweep_seed"]), sequential=True)
+    xyz, rgb = orc.mvs_depth_to_cloud(depth, bgr, T, 20.0)
+    xyz_n, rgb_n, nrm_n = orc.mvs_depth_to_cloud(depth, bgr, T, 20.0, filter_sky=False, normal=normal)
+    np.savez_compressed(os.path.join(OUT, "mvs_cloud.npz"), depth=depth, bgr=bgr, normal=normal, T_wc=T, max_depth=np.float32(20.0), xyz=xyz, rgb=rgb,
+                        xyz_all=xyz_n, rgb_all=rgb_n, normal_all=nrm_n, depth_seq=ds, normal_seq=ns, conf_seq=cs)
+
+
 def features():
     """LiDAR feature extraction, planar branch (sensors/Velodyne.cpp:371-526, :531-760, :883-1000, :1098-1189, :1438-1586) on a
     small raw scan (16 rings x 240 columns, clutter, dropouts)."""
@@ -235,7 +249,7 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
         sys.exit(0)
-    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs(); features(); line_extraction()
+    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs(); mvs_cloud(); features(); line_extraction()
     tot = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

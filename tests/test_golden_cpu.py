@@ -141,6 +141,20 @@ def test_mvs_golden(oracle):
     assert 0.05 < (dr > 0).mean() < 0.95
 
 
+def test_mvs_cloud_golden(oracle):
+    """tests/golden/mvs_cloud.npz: DepthImageToCloud / DepthNormalToCloud and one sequential PatchMatch iteration (make_golden.py mvs_cloud)."""
+    g = np.load(os.path.join(G, "mvs_cloud.npz"))
+    xyz, rgb = oracle.mvs_depth_to_cloud(g["depth"], g["bgr"], g["T_wc"], float(g["max_depth"]))
+    assert np.array_equal(xyz, g["xyz"]) and np.array_equal(rgb, g["rgb"]) and 0.3 * g["depth"].size < len(xyz) < 0.8 * g["depth"].size
+    a, b, c = oracle.mvs_depth_to_cloud(g["depth"], g["bgr"], g["T_wc"], float(g["max_depth"]), filter_sky=False, normal=g["normal"])
+    assert np.array_equal(a, g["xyz_all"]) and np.array_equal(b, g["rgb_all"]) and np.array_equal(c, g["normal_all"]) and len(a) > len(xyz)
+    m = np.load(os.path.join(G, "mvs.npz"))
+    neis = [m["nei%d_gray" % k] for k in range(3)]
+    ds, ns, cs = oracle.mvs_propagate(m["gray"], neis, m["R_nr"], m["t_nr"], m["depth_pho"], m["normal"], m["conf_pho"], max_iter=1, seed=int(m["sweep_seed"]), sequential=True)
+    assert np.array_equal(ds, g["depth_seq"]) and np.array_equal(ns, g["normal_seq"]) and np.array_equal(cs, g["conf_seq"])
+    assert not np.array_equal(ds, m["depth_sweep"])          # a different sweep from the checkerboard one of mvs.npz
+
+
 def test_refvec_container_round_trip(tmp_path):
     """tools/refvec.py (re-pinning recipe against a real PanoVLM build): export -> read back == fixture inputs,
     and `compare` accepts the fixtures' own expectations."""
