@@ -62,6 +62,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(tag, defines):
+    """A measured variant of the library: build/var/libpvlm_<tag>.so with extra -D switches (e.g. ["-DPVLM_NT_LOADS=0"]), selected at
+    run time through PVLM_LIB (tools/ab_eval_loads.sh).  Only the sources that mention one of the switches are recompiled; the other
+    objects are those of the in-tree build.  python -m panovlm_amd.build --variant temporal -DPVLM_NT_LOADS=0"""
+    build(force=False)
+    vdir = os.path.join(HERE, "..", "build", "var")
+    os.makedirs(vdir, exist_ok=True)
+    names = [d[2:].split("=")[0] for d in defines if d.startswith("-D")]
+    objs = []
+    for src in sources():
+        base = os.path.basename(src)
+        obj = os.path.join(HERE, "build", base + ".o")
+        if any(n in open(src).read() for n in names):
+            obj = os.path.join(vdir, base + "." + tag + ".o")
+            flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-Wno-unused-result"] + list(defines)
+            if base in ("pvlm_assoc.hip", "pvlm_lines.hip", "pvlm_mvs.hip"):
+                flags.append("-ffp-contract=off")
+            subprocess.check_call([_hipcc()] + flags + ["-c", src, "-o", obj])
+        objs.append(obj)
+    out = os.path.join(vdir, "libpvlm_%s.so" % tag)
+    subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+    return out
+
+
 HOST_LIB = os.path.join(HERE, "libpvlm_host.so")
 HOST_DRIVER = os.path.join(HERE, "build", "pvlm_host_driver")
 
@@ -91,5 +115,9 @@ def build_host(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
-    print(build_host(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        k = sys.argv.index("--variant")
+        print(build_variant(sys.argv[k + 1], [a for a in sys.argv[k + 2:] if a.startswith("-D")]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))
+        print(build_host(force="--force" in sys.argv))

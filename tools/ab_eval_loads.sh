@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B of streaming-access variants of the residual / map kernels.  Variant libraries (build/var/libpvlm_<tag>.so, built by hand with
-# -DPVLM_GLOBAL_LOADS / -DPVLM_NT_LOADS / -DPVLM_NT_STORES / -DPVLM_NT_MAPS) are selected through PVLM_LIB; "base" = the in-tree library.
+# A/B of streaming-access variants of the residual / map kernels.  Variant libraries (build/var/libpvlm_<tag>.so, built here, without a GPU, by
+#   python -m panovlm_amd.build --variant temporal -DPVLM_NT_LOADS=0        (likewise -DPVLM_GLOBAL_LOADS / -DPVLM_NT_STORES / -DPVLM_NT_MAPS / ...)
+# are selected through PVLM_LIB; "base" = the in-tree library.
 # Prints per variant: value, roofline.frac, fused kernel ms, materialise GB/s, CamToImage / ImageToCam fraction of the HBM peak, wrench rows M/s.
 mkdir -p gpurun_out/r2
 for v in ${VARIANTS:-base nost base nost}; do
