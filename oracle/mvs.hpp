@@ -701,6 +701,129 @@ inline long long DepthImageToCloud(int rows, int cols, const float* depth, const
   return n;
 }
 
+// MVS::FuseDepthImages(use_filtered_depth = true) (mvs/MVS.cpp:2168-2334; the second half of FuseDepthMaps :229-230, MVS-fuse.pcd): the
+// confidence-weighted fusion "from openMVS".  Frames are visited by decreasing neighbour count (std::sort, :2189); a pixel with a valid
+// depth that nobody has claimed claims the pixels it projects to in its neighbours when their depths agree (relative difference <
+// depth_diff_threshold), averages position and colour with weights ConfToWeight (:2337-2340), and becomes a cloud point when >= 2 neighbour
+// pixels agreed; otherwise its claims are withdrawn.  Neighbour depths in front of which the point lies (|X1| < n_depth) are zeroed in
+// the neighbour's map once the point is accepted.  A literal restatement, upstream's state machine included:
+//   * view_project / invalid_depth live OUTSIDE the frame loop and are cleared at the end of a pixel's body — which the early `continue`s
+//     (invalid depth, claimed pixel, and the sky-colour rejection :2316) skip, so their contents carry over to the next processed pixel;
+//   * every frame starts with neighbours + 1 references on its depth map, one is dropped per visit as reference or neighbour (:2322-2331),
+//     at zero the map is released; a released map is read again from the depth file when the frame is needed as somebody's NEIGHBOUR or
+//     is itself the reference's id in the read loop (:2209-2215; the file holds the UNFILTERED estimate, and the zeroing is lost), but a
+//     reference whose map is gone is skipped (:2205-2206, the test precedes the read loop);
+//   * the colour test runs on the rounded colour (cv::Vec3b(color): saturate_cast), the stored colour is truncated (static_cast<uchar>).
+// depth_filter[i] (may be null = empty) is the working map and is MODIFIED; depth_saved[i] (may be null) is what ReadFrameDepth would load;
+// present_after / maps_after (n, n x rows x cols; optional): which frames hold a depth_filter map after the call, and its contents.
+// conf[i] = the <id>_filter.bin confidence; bgr[i] the colour image; T_wc[i] 16 doubles.  nei_off (n + 1) / nei / R_nr (9 each) / t_nr (3 each).
+struct FusedPoint { float x, y, z; unsigned char r, g, b; };
+inline float ConfToWeight(float conf, float depth) { return 1.f / (std::max(1.f - conf, 0.03f) * (depth * depth)); }
+inline std::vector<FusedPoint> FuseDepthImages(int n, int rows, int cols, float* const* depth_filter, const float* const* depth_saved, const float* const* conf,
+                                               const unsigned char* const* bgr, const double* T_wc, const int* frame_id, const int* nei_off, const int* nei,
+                                               const float* R_nr, const float* t_nr, float max_depth, float depth_diff_threshold,
+                                               int* present_after = nullptr, float* maps_after = nullptr) {
+  const Equirectangular eq(rows, cols);
+  const size_t npix = (size_t)rows * cols;
+  std::vector<float> unit(3 * npix);                                                      // PreComputeI2C
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < cols; ++j) { const float px[2] = {(float)j, (float)i}; eq.ImageToCam(px, 1.f, &unit[3 * ((size_t)i * cols + j)]); }
+  std::vector<FusedPoint> cloud;
+  std::vector<std::vector<uint16_t>> occupied(n, std::vector<uint16_t>(npix, 65535));
+  std::vector<float*> map(n);                                                             // frames[i].depth_filter.data, null = empty
+  std::vector<std::vector<float>> reloaded(n);
+  for (int i = 0; i < n; ++i) map[i] = depth_filter[i];
+  std::vector<std::pair<int, int>> idx_connections;
+  std::vector<int> depth_count(n);
+  for (int i = 0; i < n; ++i) { idx_connections.push_back({i, nei_off[i + 1] - nei_off[i]}); depth_count[i] = nei_off[i + 1] - nei_off[i] + 1; }
+  std::sort(idx_connections.begin(), idx_connections.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
+  std::vector<std::pair<size_t, std::pair<int, int>>> view_project, invalid_depth;       // (frame, (x, y))
+  auto translate = [](const float* p, const double* T, float* o) {                      // TranslatePoint<float, double>
+    for (int k = 0; k < 3; ++k) o[k] = (float)(p[0] * T[4 * k] + p[1] * T[4 * k + 1] + p[2] * T[4 * k + 2] + T[4 * k + 3]);
+  };
+  for (const std::pair<int, int>& pc : idx_connections) {
+    const int ref_idx = pc.first;
+    std::vector<int> ids = {ref_idx};
+    for (int b = nei_off[ref_idx]; b < nei_off[ref_idx + 1]; ++b) ids.push_back(nei[b]);
+    if (map[ref_idx] != nullptr) {
+      for (int id : ids)                                                                  // :2209-2215
+        if (map[id] == nullptr && depth_saved[id] != nullptr) { reloaded[id].assign(depth_saved[id], depth_saved[id] + npix); map[id] = reloaded[id].data(); }
+      const float* ref_depth_map = map[ref_idx];
+      for (int row = 0; row < rows; row++)
+        for (int col = 0; col < cols; col++) {
+          const size_t e = (size_t)row * cols + col;
+          const float depth = ref_depth_map[e];
+          if (depth <= 0 || depth >= max_depth * 0.8) continue;
+          uint16_t& occupied_id = occupied[ref_idx][e];
+          if (occupied_id != 65535) continue;
+          occupied_id = (uint16_t)frame_id[ref_idx];
+          float color[3] = {(float)bgr[ref_idx][3 * e], (float)bgr[ref_idx][3 * e + 1], (float)bgr[ref_idx][3 * e + 2]};
+          float confidence = ConfToWeight(conf[ref_idx][e], depth);
+          const float X0[3] = {unit[3 * e] * depth, unit[3 * e + 1] * depth, unit[3 * e + 2] * depth};
+          float X[3];
+          translate(X0, T_wc + 16 * (size_t)ref_idx, X);
+          for (int k = 0; k < 3; ++k) { X[k] = X[k] * confidence; color[k] = color[k] * confidence; }
+          for (int b = nei_off[ref_idx]; b < nei_off[ref_idx + 1]; ++b) {
+            const size_t n_idx = (size_t)nei[b];
+            if (map[n_idx] == nullptr) continue;
+            const float* R = R_nr + 9 * (size_t)b; const float* t = t_nr + 3 * (size_t)b;
+            float X1[3];
+            for (int r = 0; r < 3; ++r) { float sacc = 0; for (int c = 0; c < 3; ++c) sacc += R[3 * r + c] * X0[c]; X1[r] = sacc + t[r]; }   // cv::Matx33f * Point3f + Point3f
+            float x1[2];
+            eq.CamToImage(X1, x1);
+            const int px = (int)std::round(x1[0]), py = (int)std::round(x1[1]);
+            if (!(px >= 0 && py >= 0 && px < cols && py < rows)) continue;
+            const size_t ne = (size_t)py * cols + px;
+            const float n_depth = map[n_idx][ne];
+            if (n_depth <= 0) continue;
+            uint16_t& n_occupied_id = occupied[n_idx][ne];
+            if (n_occupied_id != 65535) continue;
+            if (std::abs((depth - n_depth) / depth) < depth_diff_threshold) {
+              view_project.push_back({n_idx, {px, py}});
+              const float n_confidence = ConfToWeight(conf[n_idx][ne], n_depth);
+              const float n_point[3] = {unit[3 * ne] * n_depth, unit[3 * ne + 1] * n_depth, unit[3 * ne + 2] * n_depth};
+              float Xn[3];
+              translate(n_point, T_wc + 16 * n_idx, Xn);
+              for (int k = 0; k < 3; ++k) { X[k] += Xn[k] * n_confidence; color[k] += (float)bgr[n_idx][3 * ne + k] * n_confidence; }
+              confidence += n_confidence;
+              n_occupied_id = occupied_id;
+            }
+            if (std::sqrt((double)X1[0] * X1[0] + (double)X1[1] * X1[1] + (double)X1[2] * X1[2]) < n_depth) invalid_depth.push_back({n_idx, {px, py}});   // cv::norm(Point3f)
+          }
+          if (view_project.size() < 2) {
+            for (const auto& p : view_project) occupied[p.first][(size_t)p.second.second * cols + p.second.first] = 65535;
+            occupied_id = 65535;
+          } else {
+            const float nrm = 1.f / confidence;
+            const float point_world[3] = {X[0] * nrm, X[1] * nrm, X[2] * nrm};
+            for (int k = 0; k < 3; ++k) color[k] = color[k] * nrm;
+            FusedPoint p;
+            p.x = point_world[0]; p.y = point_world[1]; p.z = point_world[2];
+            p.r = (unsigned char)color[2]; p.g = (unsigned char)color[1]; p.b = (unsigned char)color[0];
+            for (const auto& q : invalid_depth)
+              if (map[q.first] != nullptr) map[q.first][(size_t)q.second.second * cols + q.second.first] = 0;
+            unsigned char rounded[3];                                                     // cv::Vec3b(color): saturate_cast<uchar>(float) = clamp(cvRound)
+            for (int k = 0; k < 3; ++k) { const long v = std::lrint(color[k]); rounded[k] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); }
+            float hsv[3];
+            Bgr2Hsv(rounded, hsv);
+            hsv[0] *= 180.f; hsv[1] *= 255.f; hsv[2] *= 255.f;
+            if (hsv[0] >= 100 && hsv[0] <= 124 && hsv[1] >= 43 && hsv[1] <= 200 && hsv[2] >= 150 && hsv[2] <= 255) continue;   // NB: skips the clears below
+            cloud.push_back(p);
+          }
+          invalid_depth.clear();
+          view_project.clear();
+        }
+    }
+    for (int id : ids)                                                                    // next_image: :2322-2331
+      if (--depth_count[id] <= 0) map[id] = nullptr;                                      // depth_filter.release()
+  }
+  for (int i = 0; i < n && present_after; ++i) {                                          // the frames' depth_filter members after the call
+    present_after[i] = map[i] != nullptr;
+    if (map[i] && maps_after) std::copy(map[i], map[i] + npix, maps_after + (size_t)i * npix);
+  }
+  return cloud;
+}
+
 // MVS::SelectNeighborKNN (mvs/MVS.cpp:334-382).  valid[i], R_wc (9, row-major), t_wc (3) per frame.  Output: for every frame the
 // list of (neighbour id, R_nr float 9, t_nr float 3).  KdTreeFLANN::nearestKSearch restated as a brute-force sorted float32
 // search (ties by index); T_nr = T_wn^-1 * T_wr through the general 4x4 inverse like upstream (Gauss-Jordan with partial

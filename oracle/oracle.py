@@ -365,6 +365,36 @@ def mvs_depth_to_cloud(depth, bgr, T_wc, max_depth=20.0, filter_sky=True, normal
     return xyz[:n].copy(), rgb[:n].copy(), nout[:n].copy()
 
 
+def mvs_fuse_depth_images(depth_filter, depth_saved, conf, bgr, T_wc, neighbors, max_depth=20.0, thr=0.01, frame_id=None):
+    """MVS::FuseDepthImages (mvs/MVS.cpp:2168-2334).  depth_filter / depth_saved: lists of rows x cols float32 maps or None (empty Mat / no
+    file); conf, bgr: lists of maps; T_wc: n x 4 x 4; neighbors[i] = list of (id, R_nr 3x3, t_nr 3).  Returns (xyz, rgb, depth maps after the
+    call — None where released)."""
+    n = len(conf); rows, cols = np.shape(conf[0])
+    work = [None if d is None else np.array(d, np.float32, order="C", copy=True) for d in depth_filter]
+    saved = [None if d is None else np.ascontiguousarray(d, np.float32) for d in depth_saved]
+    cf = [np.ascontiguousarray(c, np.float32) for c in conf]; cl = [np.ascontiguousarray(c, np.uint8).reshape(rows, cols, 3) for c in bgr]
+    fp = lambda arrs, t: (C.POINTER(t) * n)(*[None if a is None else a.ctypes.data_as(C.POINTER(t)) for a in arrs])
+    T = _f64(T_wc).reshape(n, 16)
+    off = np.zeros(n + 1, np.int32); ids = []; R = []; t = []
+    for i, nb in enumerate(neighbors):
+        for (j, Rn, tn) in nb:
+            ids.append(j); R.append(np.asarray(Rn, np.float32).reshape(9)); t.append(np.asarray(tn, np.float32).reshape(3))
+        off[i + 1] = len(ids)
+    ids = np.array(ids if ids else [0], np.int32)
+    R = np.ascontiguousarray(np.array(R, np.float32).reshape(-1)) if R else np.zeros(9, np.float32)
+    t = np.ascontiguousarray(np.array(t, np.float32).reshape(-1)) if t else np.zeros(3, np.float32)
+    fid = np.arange(n, dtype=np.int32) if frame_id is None else np.ascontiguousarray(frame_id, np.int32)
+    cap = n * rows * cols
+    xyz = np.zeros((cap, 3), np.float32); rgb = np.zeros((cap, 3), np.uint8)
+    present = np.zeros(n, np.int32); after = np.zeros((n, rows, cols), np.float32)
+    lib().orc_mvs_fuse_depth_images.restype = C.c_longlong
+    m = lib().orc_mvs_fuse_depth_images(C.c_int(n), C.c_int(rows), C.c_int(cols), fp(work, C.c_float), fp(saved, C.c_float), fp(cf, C.c_float), fp(cl, C.c_ubyte),
+                                        _p(T, C.c_double), _p(fid, C.c_int), _p(off, C.c_int), _p(ids, C.c_int), _p(R, C.c_float), _p(t, C.c_float),
+                                        C.c_float(max_depth), C.c_float(thr), _p(xyz, C.c_float), _p(rgb, C.c_ubyte), C.c_longlong(cap), _p(present, C.c_int),
+                                        _p(after, C.c_float))
+    return xyz[:m].copy(), rgb[:m].copy(), [after[i].copy() if present[i] else None for i in range(n)]
+
+
 def mvs_init_depth_normal(rows, cols, lidar_depth16=None, mask=None, min_depth=0.1, max_depth=20.0, keep_lidar_constant=True, seed=1):
     """MVS::InitDepthNormal (mvs/MVS.cpp:496-584): returns (depth, normal, depth_constant uint8)."""
     l16 = None if lidar_depth16 is None else np.ascontiguousarray(lidar_depth16, np.uint16)

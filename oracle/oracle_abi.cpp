@@ -263,6 +263,19 @@ long long orc_mvs_depth_to_cloud(int rows, int cols, const float* depth, const u
                                  unsigned char* rgb, int filter_sky, const float* normal, float* normal_out) {
   return DepthImageToCloud(rows, cols, depth, bgr, T_wc, max_depth, xyz, rgb, filter_sky != 0, normal, normal_out);
 }
+long long orc_mvs_fuse_depth_images(int n, int rows, int cols, float* const* depth_filter, const float* const* depth_saved, const float* const* conf,
+                                    const unsigned char* const* bgr, const double* T_wc, const int* frame_id, const int* nei_off, const int* nei, const float* R_nr,
+                                    const float* t_nr, float max_depth, float depth_diff_threshold, float* xyz, unsigned char* rgb, long long capacity,
+                                    int* present_after, float* maps_after) {
+  const std::vector<FusedPoint> cloud = FuseDepthImages(n, rows, cols, depth_filter, depth_saved, conf, bgr, T_wc, frame_id, nei_off, nei, R_nr, t_nr, max_depth,
+                                                        depth_diff_threshold, present_after, maps_after);
+  const long long m = std::min<long long>((long long)cloud.size(), capacity);
+  for (long long i = 0; i < m; ++i) {
+    xyz[3 * i] = cloud[i].x; xyz[3 * i + 1] = cloud[i].y; xyz[3 * i + 2] = cloud[i].z;
+    rgb[3 * i] = cloud[i].r; rgb[3 * i + 1] = cloud[i].g; rgb[3 * i + 2] = cloud[i].b;
+  }
+  return (long long)cloud.size();
+}
 int orc_mvs_remove_small_segments(int rows, int cols, float thr, int min_segment, float* depth, float* normal, float* conf) {
   return RemoveSmallSegments(rows, cols, thr, min_segment, depth, normal, conf);
 }

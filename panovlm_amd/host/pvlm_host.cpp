@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cfloat>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -2490,6 +2491,131 @@ bool CameraLidarOptimizer::JointOptimize() {
     last_step = curr_step;
   }
   return true;
+}
+
+// ================================================================================================
+// MVS::FuseDepthImages — mvs/MVS.cpp:2168-2334 (ConfToWeight :2337-2340, BGR2HSV util/Visualization.cpp:57-77)
+// ================================================================================================
+namespace {
+struct FuseState {
+  int rows, cols;
+  std::vector<DepthFrame>& frames;
+  std::vector<char> loaded;                       // depth_filter present (not released)
+  std::vector<int> references;                    // frame_depth_filter_count
+  std::vector<std::vector<uint16_t>> owner;       // `occupied`: 65535 = free
+  std::vector<float> ray;                         // PreComputeI2C
+  bool Has(size_t f) const { return loaded[f] != 0; }
+  void Read(size_t f) {                           // ReadFrameDepth(<id>_geo|_pho.bin, frames[f], true)
+    if (frames[f].depth_file.empty()) return;
+    frames[f].depth_filter = frames[f].depth_file;
+    loaded[f] = 1;
+  }
+  void Drop(size_t f) { if (--references[f] <= 0) { frames[f].depth_filter.clear(); loaded[f] = 0; } }
+};
+inline float WeightOfConf(float conf, float depth) { return 1.f / (std::max(1.f - conf, 0.03f) * (depth * depth)); }
+inline void ToWorld(const float* p, const Matrix4d& T, float* o) {          // TranslatePoint<float, double>, base/Geometry.hpp:545-551
+  for (int k = 0; k < 3; ++k) o[k] = (float)(p[0] * T[4 * k] + p[1] * T[4 * k + 1] + p[2] * T[4 * k + 2] + T[4 * k + 3]);
+}
+inline bool SkyBlue(const float* bgr_f) {                                    // on cv::Vec3b(color): saturate_cast = clamp(cvRound)
+  unsigned char c[3];
+  for (int k = 0; k < 3; ++k) { const long v = std::lrint(bgr_f[k]); c[k] = (unsigned char)std::min(255l, std::max(0l, v)); }
+  const float r = c[2] / 255.f, g = c[1] / 255.f, b = c[0] / 255.f;
+  const float hi = std::max(r, std::max(g, b)), lo = std::min(r, std::min(g, b));
+  float h = 0, s = 0, v = 0;
+  if (hi != 0) {
+    const float d = hi - lo;
+    if (hi == r) h = 60.f * ((g - b) / d + 6 * (g < b));
+    else if (hi == g) h = 60.f * ((b - r) / d + 2);
+    else h = 60.f * ((r - g) / d + 4);
+    h = h / 360.f; s = d / hi; v = hi;
+  }
+  h *= 180.f; s *= 255.f; v *= 255.f;
+  return h >= 100 && h <= 124 && s >= 43 && s <= 200 && v >= 150 && v <= 255;
+}
+}  // namespace
+
+std::vector<PointXYZRGB> FuseDepthImages(int rows, int cols, std::vector<DepthFrame>& frames, const std::vector<std::vector<NeighborInfo>>& neighbors, float max_depth,
+                                         float depth_diff_threshold) {
+  const size_t n = frames.size(), npix = (size_t)rows * cols;
+  if (neighbors.size() != n) throw std::invalid_argument("FuseDepthImages: one neighbour list per frame");
+  for (const DepthFrame& f : frames)
+    if ((!f.depth_filter.empty() && f.depth_filter.size() != npix) || (!f.depth_file.empty() && f.depth_file.size() != npix) || f.conf.size() != npix || f.bgr.size() != 3 * npix)
+      throw std::invalid_argument("FuseDepthImages: map sizes");
+  for (const auto& l : neighbors) for (const NeighborInfo& x : l) if (x.id >= n) throw std::invalid_argument("FuseDepthImages: neighbour id");
+  FuseState S{rows, cols, frames, std::vector<char>(n, 0), std::vector<int>(n, 0), {}, std::vector<float>(3 * npix)};
+  S.owner.assign(n, std::vector<uint16_t>(npix, UINT16_MAX));
+  const Equirect eq{cols, rows};
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) { const float px[2] = {(float)x, (float)y}; eq.ImageToCam(px, 1.f, &S.ray[3 * ((size_t)y * cols + x)]); }
+  std::vector<std::pair<int, int>> order;                                       // idx_connections (:2181-2189)
+  for (size_t i = 0; i < n; ++i) { S.loaded[i] = !frames[i].depth_filter.empty(); S.references[i] = (int)neighbors[i].size() + 1; order.push_back({(int)i, (int)neighbors[i].size()}); }
+  std::sort(order.begin(), order.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second > b.second; });
+  struct Claim { size_t frame; int x, y; };
+  std::vector<Claim> agreed, in_front;                                          // view_project, invalid_depth: declared outside the frame loop upstream
+  std::vector<PointXYZRGB> cloud;
+  for (const std::pair<int, int>& oc : order) {
+    const size_t ref = (size_t)oc.first;
+    const std::vector<NeighborInfo>& nb = neighbors[ref];
+    if (S.Has(ref)) {                                                           // :2205-2206 — before the read loop
+      for (const NeighborInfo& x : nb) if (!S.Has(x.id)) S.Read(x.id);          // :2209-2215
+      DepthFrame& F = frames[ref];
+      for (size_t e = 0; e < npix; ++e) {
+        const float depth = F.depth_filter[e];
+        if (depth <= 0 || depth >= max_depth * 0.8) continue;
+        uint16_t& mine = S.owner[ref][e];
+        if (mine != UINT16_MAX) continue;
+        mine = (uint16_t)F.id;
+        float weight = WeightOfConf(F.conf[e], depth);
+        const float X0[3] = {S.ray[3 * e] * depth, S.ray[3 * e + 1] * depth, S.ray[3 * e + 2] * depth};
+        float X[3], colour[3];
+        ToWorld(X0, F.T_wc, X);
+        for (int k = 0; k < 3; ++k) { X[k] = X[k] * weight; colour[k] = (float)F.bgr[3 * e + k] * weight; }
+        for (const NeighborInfo& x : nb) {
+          if (!S.Has(x.id)) continue;
+          DepthFrame& N = frames[x.id];
+          float X1[3], uv[2];
+          for (int r = 0; r < 3; ++r) { float acc = 0; for (int c = 0; c < 3; ++c) acc += x.R_nr[3 * r + c] * X0[c]; X1[r] = acc + x.t_nr[r]; }
+          eq.CamToImage(X1, uv);
+          const int u = (int)std::round(uv[0]), v = (int)std::round(uv[1]);
+          if (u < 0 || v < 0 || u >= cols || v >= rows) continue;
+          const size_t ne = (size_t)v * cols + u;
+          const float n_depth = N.depth_filter[ne];
+          if (n_depth <= 0) continue;
+          uint16_t& theirs = S.owner[x.id][ne];
+          if (theirs != UINT16_MAX) continue;
+          if (std::abs((depth - n_depth) / depth) < depth_diff_threshold) {
+            agreed.push_back({x.id, u, v});
+            const float w = WeightOfConf(N.conf[ne], n_depth);
+            const float P[3] = {S.ray[3 * ne] * n_depth, S.ray[3 * ne + 1] * n_depth, S.ray[3 * ne + 2] * n_depth};
+            float Pw[3];
+            ToWorld(P, N.T_wc, Pw);
+            for (int k = 0; k < 3; ++k) { X[k] += Pw[k] * w; colour[k] += (float)N.bgr[3 * ne + k] * w; }
+            weight += w;
+            theirs = mine;
+          }
+          if (std::sqrt((double)X1[0] * X1[0] + (double)X1[1] * X1[1] + (double)X1[2] * X1[2]) < n_depth) in_front.push_back({x.id, u, v});
+        }
+        if (agreed.size() < 2) {
+          for (const Claim& c : agreed) S.owner[c.frame][(size_t)c.y * cols + c.x] = UINT16_MAX;
+          mine = UINT16_MAX;
+        } else {
+          const float inv = 1.f / weight;
+          PointXYZRGB p;
+          p.x = X[0] * inv; p.y = X[1] * inv; p.z = X[2] * inv;
+          for (int k = 0; k < 3; ++k) colour[k] = colour[k] * inv;
+          p.r = (unsigned char)colour[2]; p.g = (unsigned char)colour[1]; p.b = (unsigned char)colour[0];
+          for (const Claim& c : in_front) if (S.Has(c.frame)) frames[c.frame].depth_filter[(size_t)c.y * cols + c.x] = 0;
+          if (SkyBlue(colour)) continue;                                        // :2316 — leaves both lists filled for the next pixel
+          cloud.push_back(p);
+        }
+        in_front.clear();
+        agreed.clear();
+      }
+    }
+    S.Drop(ref);                                                                // next_image (:2322-2331)
+    for (const NeighborInfo& x : nb) S.Drop(x.id);
+  }
+  return cloud;
 }
 
 }  // namespace pvlm

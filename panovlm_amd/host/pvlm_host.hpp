@@ -487,6 +487,25 @@ struct NeighborInfo {
 };
 std::vector<std::vector<NeighborInfo>> SelectNeighborKNN(const std::vector<Frame>& frames, int neighbor_size, float sq_distance_threshold);
 
+// ---- mvs/MVS.cpp:2168-2334 — MVS::FuseDepthImages(use_filtered_depth = true), the second half of MVS::FuseDepthMaps (:224-231; the first
+// half, MergeDepthImages, is a loop over pvlm_mvs_depth_to_cloud).  The greedy confidence-weighted fusion walks frames by decreasing
+// neighbour count and pixels in raster order; a pixel's fate depends on every claim made before it, so this is host code here as
+// upstream.  DepthFrame holds the cv::Mat members of sensors/Frame.h the function touches.  Upstream's bookkeeping is kept: a depth map
+// is released after (neighbours + 1) visits and read again from the depth FILE when needed as a neighbour (depth_file: the unfiltered
+// estimate <id>_geo.bin / _pho.bin; empty = no file), a reference whose map is gone is skipped, the claim lists survive the `continue`
+// of the sky-colour test.  depth_filter maps are modified (depths in front of which an accepted point lies are zeroed).
+struct DepthFrame {
+  int id = 0;
+  std::vector<float> depth_filter;       // rows x cols, empty = cv::Mat::empty()
+  std::vector<float> depth_file;         // rows x cols or empty
+  std::vector<float> conf;               // rows x cols: <id>_filter.bin
+  std::vector<unsigned char> bgr;        // rows x cols x 3
+  Matrix4d T_wc{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+};
+struct PointXYZRGB { float x, y, z; unsigned char r, g, b; };
+std::vector<PointXYZRGB> FuseDepthImages(int rows, int cols, std::vector<DepthFrame>& frames, const std::vector<std::vector<NeighborInfo>>& neighbors, float max_depth,
+                                         float depth_diff_threshold);
+
 class CameraLidarOptimizer {
  public:
   using LinePairs = std::map<std::pair<size_t, size_t>, std::vector<CameraLidarLinePair>>;

@@ -487,6 +487,38 @@ int main(int argc, char** argv) {
           for (float v : x.t_nr) printf(" %a", v);
           printf("\n");
         }
+    } else if (cmd == "fusedepth") {
+      // fusedepth <in.bin> <out.bin> max_depth depth_diff_threshold : MVS::FuseDepthImages (host code, no GPU).  in.bin: int32 n, rows, cols;
+      // per frame: int32 id, int32 has_filter [+ map], int32 has_file [+ map], conf map, bgr bytes, T_wc (16 f64), int32 neighbours,
+      // per neighbour int32 id + R_nr (9 f32) + t_nr (3 f32).  out.bin: int64 m, m x 3 f32, m x 3 u8, per frame int32 present [+ map]
+      std::ifstream f(argv[2], std::ios::binary);
+      int32_t n = 0, rows = 0, cols = 0; rd(f, &n, 1); rd(f, &rows, 1); rd(f, &cols, 1);
+      const size_t npix = (size_t)rows * cols;
+      std::vector<DepthFrame> frames(n);
+      std::vector<std::vector<NeighborInfo>> nb(n);
+      for (int i = 0; i < n; ++i) {
+        DepthFrame& F = frames[i];
+        int32_t v = 0; rd(f, &v, 1); F.id = v;
+        rd(f, &v, 1); if (v) { F.depth_filter.resize(npix); rd(f, F.depth_filter.data(), npix); }
+        rd(f, &v, 1); if (v) { F.depth_file.resize(npix); rd(f, F.depth_file.data(), npix); }
+        F.conf.resize(npix); rd(f, F.conf.data(), npix);
+        F.bgr.resize(3 * npix); rd(f, F.bgr.data(), 3 * npix);
+        rd(f, F.T_wc.data(), 16);
+        rd(f, &v, 1); nb[i].resize(v);
+        for (NeighborInfo& x : nb[i]) { int32_t id = 0; rd(f, &id, 1); x.id = (size_t)id; rd(f, x.R_nr.data(), 9); rd(f, x.t_nr.data(), 3); }
+      }
+      const std::vector<PointXYZRGB> cloud = FuseDepthImages(rows, cols, frames, nb, (float)atof(argv[4]), (float)atof(argv[5]));
+      std::ofstream o(argv[3], std::ios::binary);
+      const int64_t m = (int64_t)cloud.size();
+      o.write((const char*)&m, 8);
+      for (const PointXYZRGB& p : cloud) { const float q[3] = {p.x, p.y, p.z}; o.write((const char*)q, 12); }
+      for (const PointXYZRGB& p : cloud) { const unsigned char q[3] = {p.r, p.g, p.b}; o.write((const char*)q, 3); }
+      for (const DepthFrame& F : frames) {
+        const int32_t present = F.depth_filter.empty() ? 0 : 1;
+        o.write((const char*)&present, 4);
+        if (present) o.write((const char*)F.depth_filter.data(), (std::streamsize)(npix * 4));
+      }
+      printf("fused %lld\n", (long long)m);
     } else if (cmd == "poseio") {
       // poseio <in.txt> <out.txt> with_invalid precision
       std::vector<Matrix3d> R; std::vector<Vector3d> t; std::vector<std::string> names;

@@ -140,3 +140,38 @@ def write_raw_scans(path, scans):
             f.write(np.asarray(s["R_wl"], np.float64).reshape(9).tobytes()); f.write(np.asarray(s["t_wl"], np.float64).reshape(3).tobytes())
             f.write(struct.pack("<i", len(raw))); f.write(raw.tobytes())
 
+
+
+def fuse_depth_images(depth_filter, depth_file, conf, bgr, T_wc, neighbors, max_depth=20.0, thr=0.01, frame_id=None):
+    """Host mirror pvlm::FuseDepthImages through the driver (`fusedepth`): same arguments and return value as oracle.mvs_fuse_depth_images."""
+    import tempfile
+    n = len(conf); rows, cols = np.shape(conf[0])
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(src, "wb") as f:
+            f.write(struct.pack("<iii", n, rows, cols))
+            for i in range(n):
+                f.write(struct.pack("<i", i if frame_id is None else int(frame_id[i])))
+                for m in (depth_filter[i], depth_file[i]):
+                    f.write(struct.pack("<i", 0 if m is None else 1))
+                    if m is not None:
+                        f.write(np.ascontiguousarray(m, np.float32).tobytes())
+                f.write(np.ascontiguousarray(conf[i], np.float32).tobytes())
+                f.write(np.ascontiguousarray(bgr[i], np.uint8).tobytes())
+                f.write(np.asarray(T_wc[i], np.float64).reshape(16).tobytes())
+                f.write(struct.pack("<i", len(neighbors[i])))
+                for (j, R, t) in neighbors[i]:
+                    f.write(struct.pack("<i", int(j))); f.write(np.asarray(R, np.float32).reshape(9).tobytes()); f.write(np.asarray(t, np.float32).reshape(3).tobytes())
+        run("fusedepth", src, dst, repr(float(max_depth)), repr(float(thr)))
+        raw = open(dst, "rb").read()
+    m = struct.unpack_from("<q", raw, 0)[0]; at = 8
+    xyz = np.frombuffer(raw, np.float32, 3 * m, at).reshape(m, 3).copy(); at += 12 * m
+    rgb = np.frombuffer(raw, np.uint8, 3 * m, at).reshape(m, 3).copy(); at += 3 * m
+    maps = []
+    for i in range(n):
+        present = struct.unpack_from("<i", raw, at)[0]; at += 4
+        if present:
+            maps.append(np.frombuffer(raw, np.float32, rows * cols, at).reshape(rows, cols).copy()); at += 4 * rows * cols
+        else:
+            maps.append(None)
+    return xyz, rgb, maps

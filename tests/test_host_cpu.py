@@ -276,3 +276,108 @@ def test_mvs_select_neighbor_knn_mirror_matches_oracle():
         if thr == 0.01:
             assert 7 not in [j for j in ids[6] if j >= 0] and 6 not in [j for j in ids[7] if j >= 0]
 
+
+
+def _fusion_scene(n=5, rows=40, cols=80, seed=3, noise=0.002, baseline=1.0):
+    """n panoramas of the synthetic room with their true depth maps (+ a little noise), confidences, colour images and poses."""
+    from oracle import oracle as orc
+    from tests import synth
+    rng = np.random.default_rng(seed)
+    poses = [(synth.rodrigues(np.array([0.03 * k, 0.3 * k - 0.5, 0.02])), baseline * np.array([0.5 * k - 1.0, 0.05 * k, 0.4 * k - 0.8])) for k in range(n)]
+    depth, bgr, conf, T = [], [], [], []
+    for R, t in poses:
+        g, d, _ = synth.render_panorama(orc, rows, cols, R, t)
+        depth.append((d * rng.uniform(1 - noise, 1 + noise, size=d.shape)).astype(np.float32))
+        c = np.stack([g, (g.astype(np.int32) * 3 // 4).astype(np.uint8), (g.astype(np.int32) // 2).astype(np.uint8)], -1)       # b > g > r: bluish, mostly dark
+        bgr.append(np.ascontiguousarray(c)); conf.append(rng.uniform(0.2, 1.0, size=d.shape).astype(np.float32))
+        M = np.eye(4); M[:3, :3] = R; M[:3, 3] = t; T.append(M)
+    nb = [[(k,) + synth.relative_pose(poses[v][0], poses[v][1], poses[k][0], poses[k][1]) for k in range(n) if k != v] for v in range(n)]
+    return depth, bgr, conf, T, nb
+
+
+def test_fuse_depth_images_oracle_properties():
+    """MVS::FuseDepthImages (mvs/MVS.cpp:2168-2334), the oracle's restatement on views of the synthetic room: fused points lie on the room's
+    surfaces, a pixel is used at most once, nothing is fused without agreement, and the accepted points zero the depths they stand in front of."""
+    from oracle import oracle as orc
+    # upstream compares the reference's range with the NEIGHBOUR's range at the projected pixel (:2262), i.e. it asks both cameras to be
+    # equally far from the point: short baselines, so that most pixels pass
+    depth, bgr, conf, T, nb = _fusion_scene(baseline=0.1)
+    n, (rows, cols) = len(depth), depth[0].shape
+    xyz, rgb, after = orc.mvs_fuse_depth_images(depth, [None] * n, conf, bgr, T, nb, max_depth=20.0, thr=0.02)
+    valid = sum(int(((d > 0) & (d < 16.0)).sum()) for d in depth)
+    assert 0.1 * valid < len(xyz) < 0.34 * valid                     # every point consumed >= 3 pixels (its own + >= 2 neighbours')
+    half = np.array([4.0, 1.5, 6.0])
+    off = np.abs(np.abs(xyz) - half).min(axis=1)                     # distance to the nearest wall plane
+    assert np.median(off) < 0.02 and np.quantile(off, 0.99) < 0.25 and np.all(np.abs(xyz) < half + 0.3)
+    assert rgb.max() > 60 and np.all(rgb[:, 2] >= rgb[:, 0])         # colours are weighted means of the bluish images (r <= b)
+    none, _, _ = orc.mvs_fuse_depth_images(depth, [None] * n, conf, bgr, T, nb, max_depth=20.0, thr=0.0)
+    assert len(none) == 0                                            # |d - d'| / d < 0 never holds: no agreement, every claim withdrawn
+    lonely, _, _ = orc.mvs_fuse_depth_images(depth, [None] * n, conf, bgr, T, [[] for _ in range(n)], thr=0.02)
+    assert len(lonely) == 0
+    # a frame with one neighbour only can never collect two agreeing views
+    one = [[nb[v][0]] for v in range(n)]
+    assert len(orc.mvs_fuse_depth_images(depth, [None] * n, conf, bgr, T, one, thr=0.02)[0]) == 0
+    # an occluder in front of the scene in view 1 (too-small depths): the points of the other views stand behind it -> those depths are zeroed
+    d2 = [d.copy() for d in depth]; d2[1][10:20, 30:50] *= 0.5
+    _, _, after2 = orc.mvs_fuse_depth_images(d2, [None] * n, conf, bgr, T, nb, thr=0.02)
+    assert all(a is None for a in after2)                            # symmetric lists: neighbours + 1 visits each, every map released at the end
+    # ... visible on a frame that is nobody's neighbour: it keeps its last reference until it has been the reference itself, but is
+    # visited last (fewest neighbours) — give it none and it is never a neighbour nor has neighbours: its map is released untouched.
+    lists = [[x for x in nb[v] if x[0] != 1] for v in range(n)]; lists[1] = []
+    ref_only = orc.mvs_fuse_depth_images(d2, [None] * n, conf, bgr, T, lists, thr=0.02)
+    assert len(ref_only[0]) > 0 and all(a is None for a in ref_only[2])
+    # frame 1 (the occluder) keeps references: 4 neighbours of its own, but a neighbour of frames 0 and 2 only -> its map survives, with the
+    # occluding depths zeroed by the points of 0 and 2 that stand behind them (cv::norm(X1) < n_depth is false there; the occluder's depths are
+    # SMALLER than |X1|... so it is the scene BEHIND a too-far depth that is cleared: make the patch too far instead)
+    d3 = [d.copy() for d in depth]; d3[1][10:20, 30:50] *= 1.5
+    lists = [[x for x in nb[v] if x[0] != 1 or v in (0, 2)] for v in range(n)]
+    kept = orc.mvs_fuse_depth_images(d3, [None] * n, conf, bgr, T, lists, thr=0.02)[2]
+    assert kept[1] is not None and all(kept[k] is None for k in (0, 2, 3, 4))
+    patch = np.zeros((rows, cols), bool); patch[10:20, 30:50] = True
+    cleared = (kept[1] == 0) & (d3[1] > 0)
+    # (no margin in the test: on consistent surfaces noise and pixel rounding put about half of the projected points in front, too)
+    assert cleared[patch].mean() > cleared[~patch].mean() + 0.15 and 0 < cleared[~patch].mean() < 0.4 and np.array_equal(kept[1][~cleared], d3[1][~cleared])
+    # max_depth: pixels at >= 0.8 max_depth do not start points
+    far, _, _ = orc.mvs_fuse_depth_images(depth, [None] * n, conf, bgr, T, nb, max_depth=5.0, thr=0.02)
+    assert 0 < len(far) < len(xyz)
+
+
+def test_fuse_depth_images_host_mirror_equals_oracle():
+    """pvlm::FuseDepthImages (host code, as upstream) against the oracle, bit for bit, on inputs that drive upstream's state machine: sky-coloured
+    fused points (the `continue` that skips the list clears), asymmetric neighbour lists (maps released early, read again from the depth file,
+    references skipped), invalid depths, an occluder."""
+    from oracle import oracle as orc
+    from tests import host_io
+    depth, bgr, conf, T, nb = _fusion_scene(n=6, seed=9, baseline=0.15)
+    n, (rows, cols) = len(depth), depth[0].shape
+    rng = np.random.default_rng(1)
+    for k in range(n):
+        depth[k][rng.random((rows, cols)) < 0.05] = 0.0
+        sky = rng.random((rows, cols)) < 0.25
+        bgr[k][sky] = np.stack([rng.integers(200, 256, sky.sum()), rng.integers(120, 200, sky.sum()), rng.integers(60, 120, sky.sum())], 1).astype(np.uint8)
+    depth[2][5:15, 20:40] *= 0.6
+    files = [(d * rng.uniform(0.99, 1.01, size=d.shape)).astype(np.float32) for d in depth]
+    files[4] = None                                                  # no depth file for frame 4: once released it stays empty
+    # asymmetric lists: 0 and 1 are everybody's neighbours (released and re-read), 5 is nobody's; frame 3 arrives without a filtered map
+    lists = [[x for x in nb[v] if x[0] in (0, 1, (v + 1) % n, (v + 2) % n)] for v in range(n)]
+    lists[5] = [x for x in nb[5] if x[0] in (0, 1, 2, 3)]
+    filt = list(depth); filt[3] = None
+    for kw in (dict(thr=0.02), dict(thr=0.05, max_depth=9.0)):
+        want = orc.mvs_fuse_depth_images(filt, files, conf, bgr, T, lists, frame_id=np.arange(n) + 7, **kw)
+        got = host_io.fuse_depth_images(filt, files, conf, bgr, T, lists, frame_id=np.arange(n) + 7, **kw)
+        assert len(want[0]) > 200
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        for a, b in zip(got[2], want[2]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+    # the scene does reach those paths: without the depth files the released maps stay empty (fewer points), and the result is not the
+    # sky-free result minus the sky points (the lists that survive the `continue` admit points the clean run rejects)
+    assert len(orc.mvs_fuse_depth_images(filt, [None] * n, conf, bgr, T, lists, thr=0.02)[0]) < 0.7 * len(orc.mvs_fuse_depth_images(filt, files, conf, bgr, T, lists, thr=0.02)[0])
+    plain = [np.stack([b[..., 0], b[..., 0] * 0 + 90, b[..., 0] * 0 + 90], -1).astype(np.uint8) for b in bgr]      # no sky-coloured pixel anywhere
+    with_sky = {tuple(p) for p in orc.mvs_fuse_depth_images(filt, files, conf, bgr, T, lists, thr=0.02)[0].tolist()}
+    without = {tuple(p) for p in orc.mvs_fuse_depth_images(filt, files, conf, plain, T, lists, thr=0.02)[0].tolist()}
+    assert len(with_sky - without) > 20
+    # the symmetric, well-behaved case as well
+    depth, bgr, conf, T, nb = _fusion_scene(baseline=0.1)
+    want = orc.mvs_fuse_depth_images(depth, [None] * 5, conf, bgr, T, nb, thr=0.02)
+    got = host_io.fuse_depth_images(depth, [None] * 5, conf, bgr, T, nb, thr=0.02)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
