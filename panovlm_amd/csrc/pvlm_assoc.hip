@@ -16,22 +16,13 @@
 #include <new>
 
 #include "pvlm_internal.h"
+#include "pvlm_assoc_core.h"
 
-#define EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
-#define CELL_BIAS (1 << 20)
+using namespace pvlm_assoc;
 
-struct CloudView {
-  const float4* sorted;
-  const unsigned long long* keys;
-  const int* cell_start;   // hash: start of the slot's cell; dense: prefix offsets, ncells + 1 entries
-  const int* cell_count;
-  const float* xyz;  // original order, interleaved
-  const float* tag;
-  int n, mask;
-  int dense, nx, ny, nz;   // dense != 0: cells addressed directly as (iz*ny + iy)*nx + ix, no hashing
-  float ox, oy, oz, h, inv_h;
-};
+#define EMPTY_KEY PVLM_EMPTY_KEY
 
+// one descriptor per ordered scan pair of an association batch
 struct PairDesc {
   CloudView ref;
   const float* q_xyz;
@@ -41,20 +32,6 @@ struct PairDesc {
   long long tmp_base;                 // first row of this pair in the batch temp arrays
   int chunk_base;                     // first chunk counter of this pair
 };
-
-__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
-  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
-  return x;
-}
-__device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
-  return (unsigned long long)((ix + CELL_BIAS) & 0x1FFFFF) | ((unsigned long long)((iy + CELL_BIAS) & 0x1FFFFF) << 21) |
-         ((unsigned long long)((iz + CELL_BIAS) & 0x1FFFFF) << 42);
-}
-__device__ __forceinline__ int cell_of(float x, float o, float inv_h) {
-  float c = floorf((x - o) * inv_h);
-  c = fminf(fmaxf(c, -1000000.f), 1000000.f);
-  return (int)c;
-}
 
 // ---- K1 ---------------------------------------------------------------------------------------
 // exclusive scan of count[T] -> start[T] in three small launches (tile sums, scan of the tile sums by
@@ -189,133 +166,7 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const GridDesc* __restrict
   d.sorted[pos] = make_float4(d.xyz[3 * i], d.xyz[3 * i + 1], d.xyz[3 * i + 2], __int_as_float(i));
 }
 
-// ---- K2 ---------------------------------------------------------------------------------------
-// Sorted top-K of (distance, index) pairs.  A squared distance is a non-negative float, whose bit
-// pattern orders like the value, so (float bits << 32 | index) is ONE 64-bit key that orders exactly
-// like the lexicographic (distance, index) pair the reference's sorted k-NN result implies: an
-// insertion step is a single u64 compare + select instead of a two-level comparison.
-template <int K>
-struct TopK {
-  unsigned long long key[K];
-  int cnt;
-  __device__ __forceinline__ void init() {
-    cnt = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) key[k] = 0x7F800000FFFFFFFFull;  // (+inf, idx -1)
-  }
-  __device__ __forceinline__ void push(float dist, int idx) {
-    const unsigned long long c = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx;
-    if (!(c < key[K - 1])) return;
-    key[K - 1] = c;
-#pragma unroll
-    for (int k = K - 1; k > 0; --k) {
-      const unsigned long long a = key[k - 1], b = key[k];
-      const bool sw = b < a;
-      key[k - 1] = sw ? b : a;
-      key[k] = sw ? a : b;
-    }
-    if (cnt < K) ++cnt;
-  }
-  __device__ __forceinline__ float dist(int k) const { return __uint_as_float((unsigned)(key[k] >> 32)); }
-  __device__ __forceinline__ int index(int k) const { return (int)(unsigned)(key[k] & 0xFFFFFFFFull); }
-};
-
-template <int K>
-__device__ __forceinline__ void knn_search(const CloudView& cv, float qx, float qy, float qz, float max_dist, float thr2, TopK<K>& tk) {
-  tk.init();
-  if (cv.n <= 0) return;
-  const int cx = cell_of(qx, cv.ox, cv.inv_h), cy = cell_of(qy, cv.oy, cv.inv_h), cz = cell_of(qz, cv.oz, cv.inv_h);
-  const float fx = (qx - cv.ox) * cv.inv_h - (float)cx, fy = (qy - cv.oy) * cv.inv_h - (float)cy, fz = (qz - cv.oz) * cv.inv_h - (float)cz;
-  const float lo_min = fminf(fminf(fx, fy), fz), hi_min = fminf(fminf(1.f - fx, 1.f - fy), 1.f - fz);
-  const float inside = fminf(lo_min, hi_min);  // distance (in cells) from q to the nearest face of its own cell
-  const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
-  const int rmax = (int)ceilf(max_dist * 1.0001f * cv.inv_h);
-  for (int r = 0; r <= rmax; ++r) {
-    for (int dz = -r; dz <= r; ++dz) {
-      for (int dy = -r; dy <= r; ++dy) {
-        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-        const int step = face ? 1 : (r > 0 ? 2 * r : 1);
-        for (int dx = -r; dx <= r; dx += step) {
-          int b, e;
-          if (cv.dense) {
-            // cells of one (z, y) row are contiguous in the sorted array: on the faces of the shell
-            // the whole x-run is one range (consumed at dx = -r), interior rows only have the two end cells
-            const int z = cz + dz, y = cy + dy;
-            if (z < 0 || z >= cv.nz || y < 0 || y >= cv.ny) break;
-            const int row = (z * cv.ny + y) * cv.nx;
-            int x0 = cx + dx, x1 = x0;
-            if (face) { x1 = cx + r; dx = r; }
-            x0 = max(x0, 0); x1 = min(x1, cv.nx - 1);
-            if (x0 > x1) continue;
-            b = cv.cell_start[row + x0]; e = cv.cell_start[row + x1 + 1];
-          } else {
-            const unsigned long long key = cell_key(cx + dx, cy + dy, cz + dz);
-            int s = (int)(mix64(key) & (unsigned long long)cv.mask);
-            unsigned long long kk;
-            while ((kk = cv.keys[s]) != key && kk != EMPTY_KEY) s = (s + 1) & cv.mask;
-            if (kk != key) continue;
-            b = cv.cell_start[s]; e = b + cv.cell_count[s];
-          }
-          for (int j = b; j < e; ++j) {
-            const float4 p = cv.sorted[j];
-            const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
-            float d2 = 0.0f;
-            d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
-            if (d2 <= thr2) tk.push(d2, __float_as_int(p.w));
-          }
-        }
-      }
-    }
-    // every unsearched point lies outside the (2r+1)^3 block: farther than (inside + r) cells
-    const float bound = (inside + (float)r) * cv.h - slack;
-    if (tk.cnt == K && bound > 0.f && tk.dist(K - 1) < bound * bound) break;
-    if ((float)r * cv.h >= max_dist * 1.0001f) break;  // everything within max_dist has been visited
-  }
-}
-
-// Same search on a dense grid whose sorted points and cell offsets have been staged in LDS by the
-// block (k_knn_pairs_lds): every cell lookup and candidate read is an LDS access.
-template <int K>
-__device__ __forceinline__ void knn_search_lds(const CloudView& cv, const float4* __restrict__ ls, const int* __restrict__ lc, float qx, float qy,
-                                               float qz, float max_dist, float thr2, TopK<K>& tk) {
-  tk.init();
-  const int cx = cell_of(qx, cv.ox, cv.inv_h), cy = cell_of(qy, cv.oy, cv.inv_h), cz = cell_of(qz, cv.oz, cv.inv_h);
-  const float fx = (qx - cv.ox) * cv.inv_h - (float)cx, fy = (qy - cv.oy) * cv.inv_h - (float)cy, fz = (qz - cv.oz) * cv.inv_h - (float)cz;
-  const float inside = fminf(fminf(fminf(fx, fy), fz), fminf(fminf(1.f - fx, 1.f - fy), 1.f - fz));
-  const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
-  const int rmax = (int)ceilf(max_dist * 1.0001f * cv.inv_h);
-  for (int r = 0; r <= rmax; ++r) {
-    for (int dz = -r; dz <= r; ++dz) {
-      const int z = cz + dz;
-      if (z < 0 || z >= cv.nz) continue;
-      for (int dy = -r; dy <= r; ++dy) {
-        const int y = cy + dy;
-        if (y < 0 || y >= cv.ny) continue;
-        const int row = (z * cv.ny + y) * cv.nx;
-        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-        const int nseg = (face || r == 0) ? 1 : 2;
-        for (int sgi = 0; sgi < nseg; ++sgi) {
-          int x0 = face ? cx - r : (sgi == 0 ? cx - r : cx + r);
-          int x1 = face ? cx + r : x0;
-          x0 = max(x0, 0); x1 = min(x1, cv.nx - 1);
-          if (x0 > x1) continue;
-          const int b = lc[row + x0], e = lc[row + x1 + 1];
-          for (int j = b; j < e; ++j) {
-            const float4 p = ls[j];
-            const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
-            float d2 = 0.0f;
-            d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
-            if (d2 <= thr2) tk.push(d2, __float_as_int(p.w));
-          }
-        }
-      }
-    }
-    const float bound = (inside + (float)r) * cv.h - slack;
-    if (tk.cnt == K && bound > 0.f && tk.dist(K - 1) < bound * bound) break;
-    if ((float)r * cv.h >= max_dist * 1.0001f) break;
-  }
-}
-
+// ---- K2 / K3: per-query bodies in pvlm_assoc_core.h (TopK, knn_search, Fit10, world2local) --------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* __restrict__ q, int nq, float max_dist,
                                                      int* __restrict__ idx, float* __restrict__ sqd) {
@@ -326,228 +177,6 @@ __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* 
   knn_search<K>(cv, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_dist, thr2, tk);
 #pragma unroll
   for (int k = 0; k < K; ++k) { idx[(size_t)i * K + k] = tk.index(k); sqd[(size_t)i * K + k] = tk.dist(k); }
-}
-
-// ---- K3: fp64 fits (sequential-sum Householder/Jacobi arithmetic the parity tests pin, fully unrolled, static indexing) ----
-struct Fit10 {
-  // Householder QR with column pivoting on the 10x3 system A n = -1 (Eigen ColPivHouseholderQR
-  // restated, base/Geometry.hpp:345-373), then the tolerance test.  c0,c1,c2 = columns (destroyed).
-  static __device__ __forceinline__ void swap_cols(double* a, double* b) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { const double t = a[i]; a[i] = b[i]; b[i] = t; }
-  }
-  template <int KK>
-  static __device__ __forceinline__ void householder(double* ck, double* cj1, double* cj2, double* rhs_unused, double& tau) {
-    double tailSq = 0.0;
-#pragma unroll
-    for (int i = KK + 1; i < 10; ++i) tailSq += ck[i] * ck[i];
-    const double c0 = ck[KK];
-    double beta;
-    if (tailSq <= DBL_MIN) {
-      tau = 0.0; beta = c0;
-#pragma unroll
-      for (int i = KK + 1; i < 10; ++i) ck[i] = 0.0;
-    } else {
-      beta = sqrt(c0 * c0 + tailSq);
-      if (c0 >= 0.0) beta = -beta;
-      const double den = c0 - beta;
-#pragma unroll
-      for (int i = KK + 1; i < 10; ++i) ck[i] = ck[i] / den;
-      tau = (beta - c0) / beta;
-    }
-    ck[KK] = beta;
-    if (tau != 0.0) {
-      if (cj1) {
-        double tmp = 0.0;
-#pragma unroll
-        for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * cj1[i];
-        tmp += cj1[KK];
-        cj1[KK] -= tau * tmp;
-#pragma unroll
-        for (int i = KK + 1; i < 10; ++i) cj1[i] -= tau * ck[i] * tmp;
-      }
-      if (cj2) {
-        double tmp = 0.0;
-#pragma unroll
-        for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * cj2[i];
-        tmp += cj2[KK];
-        cj2[KK] -= tau * tmp;
-#pragma unroll
-        for (int i = KK + 1; i < 10; ++i) cj2[i] -= tau * ck[i] * tmp;
-      }
-    }
-  }
-  template <int KK>
-  static __device__ __forceinline__ void downdate(const double* cj, double& nU, double& nD, double thr) {
-    if (nU != 0.0) {
-      double temp = fabs(cj[KK]) / nU;
-      temp = (1.0 + temp) * (1.0 - temp);
-      temp = temp < 0.0 ? 0.0 : temp;
-      const double ratio = nU / nD;
-      const double temp2 = temp * ratio * ratio;
-      if (temp2 <= thr) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = KK + 1; i < 10; ++i) s += cj[i] * cj[i];
-        nD = sqrt(s);
-        nU = nD;
-      } else {
-        nU *= sqrt(temp);
-      }
-    }
-  }
-  template <int KK>
-  static __device__ __forceinline__ void apply_rhs(const double* ck, double tau, double* b) {
-    if (tau != 0.0) {
-      double tmp = 0.0;
-#pragma unroll
-      for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * b[i];
-      tmp += b[KK];
-      b[KK] -= tau * tmp;
-#pragma unroll
-      for (int i = KK + 1; i < 10; ++i) b[i] -= tau * ck[i] * tmp;
-    }
-  }
-
-  // pts: 10 x 3 (px[10], py[10], pz[10]).  Returns plane_ok; plane = (n, d).
-  static __device__ bool form_plane(const double* px, const double* py, const double* pz, double tol, double* plane) {
-    double c0[10], c1[10], c2[10], b[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { c0[i] = px[i]; c1[i] = py[i]; c2[i] = pz[i]; b[i] = -1.0; }
-    const double eps = DBL_EPSILON;
-    double nU0, nU1, nU2, nD0, nD1, nD2;
-    {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) { s0 += c0[i] * c0[i]; s1 += c1[i] * c1[i]; s2 += c2[i] * c2[i]; }
-      nD0 = nU0 = sqrt(s0); nD1 = nU1 = sqrt(s1); nD2 = nU2 = sqrt(s2);
-    }
-    double maxn = nU0; if (nU1 > maxn) maxn = nU1; if (nU2 > maxn) maxn = nU2;
-    const double threshold_helper = (maxn * eps) * (maxn * eps) / 10.0;
-    const double ndt = sqrt(eps);
-    int nonzero = 3;
-    int p0 = 0, p1 = 1, p2 = 2;
-    double tau0, tau1, tau2;
-    // ---- k = 0
-    {
-      int big = 0; double bigv = nU0;
-      if (nU1 > bigv) { bigv = nU1; big = 1; }
-      if (nU2 > bigv) { bigv = nU2; big = 2; }
-      if (nonzero == 3 && bigv * bigv < threshold_helper * 10.0) nonzero = 0;
-      if (big == 1) { swap_cols(c0, c1); double t = nU0; nU0 = nU1; nU1 = t; t = nD0; nD0 = nD1; nD1 = t; int q = p0; p0 = p1; p1 = q; }
-      else if (big == 2) { swap_cols(c0, c2); double t = nU0; nU0 = nU2; nU2 = t; t = nD0; nD0 = nD2; nD2 = t; int q = p0; p0 = p2; p2 = q; }
-      householder<0>(c0, c1, c2, nullptr, tau0);
-      downdate<0>(c1, nU1, nD1, ndt);
-      downdate<0>(c2, nU2, nD2, ndt);
-    }
-    // ---- k = 1
-    {
-      int big = 1; double bigv = nU1;
-      if (nU2 > bigv) { bigv = nU2; big = 2; }
-      if (nonzero == 3 && bigv * bigv < threshold_helper * 9.0) nonzero = 1;
-      if (big == 2) { swap_cols(c1, c2); double t = nU1; nU1 = nU2; nU2 = t; t = nD1; nD1 = nD2; nD2 = t; int q = p1; p1 = p2; p2 = q; }
-      householder<1>(c1, c2, nullptr, nullptr, tau1);
-      downdate<1>(c2, nU2, nD2, ndt);
-    }
-    // ---- k = 2
-    {
-      const double bigv = nU2;
-      if (nonzero == 3 && bigv * bigv < threshold_helper * 8.0) nonzero = 2;
-      householder<2>(c2, nullptr, nullptr, nullptr, tau2);
-    }
-    if (nonzero > 0) apply_rhs<0>(c0, tau0, b);
-    if (nonzero > 1) apply_rhs<1>(c1, tau1, b);
-    if (nonzero > 2) apply_rhs<2>(c2, tau2, b);
-    // back substitution on the leading nonzero x nonzero triangle: R = [c0[0] c1[0] c2[0]; 0 c1[1] c2[1]; 0 0 c2[2]]
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    if (nonzero > 2) y2 = b[2] / c2[2];
-    if (nonzero > 1) { double s = b[1]; if (nonzero > 2) s -= c2[1] * y2; y1 = s / c1[1]; }
-    if (nonzero > 0) { double s = b[0]; if (nonzero > 1) s -= c1[0] * y1; if (nonzero > 2) s -= c2[0] * y2; y0 = s / c0[0]; }
-    double x[3] = {0.0, 0.0, 0.0};
-    if (nonzero > 0) { if (p0 == 0) x[0] = y0; else if (p0 == 1) x[1] = y0; else x[2] = y0; }
-    if (nonzero > 1) { if (p1 == 0) x[0] = y1; else if (p1 == 1) x[1] = y1; else x[2] = y1; }
-    if (nonzero > 2) { if (p2 == 0) x[0] = y2; else if (p2 == 1) x[1] = y2; else x[2] = y2; }
-    const double len = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    const double d = 1.0 / len;
-    if (len * len > 0.0) { x[0] /= len; x[1] /= len; x[2] /= len; }
-    bool ok = true;
-    if (tol > 0) {
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        const double dist = fabs((x[0] * px[i] + x[1] * py[i]) + x[2] * pz[i] + d);
-        if (dist > tol) ok = false;
-      }
-    }
-    plane[0] = ok ? x[0] : 0.0; plane[1] = ok ? x[1] : 0.0; plane[2] = ok ? x[2] : 0.0; plane[3] = ok ? d : 0.0;
-    return ok;
-  }
-
-  // FormLine(points, 3.0) is non-zero  <=>  largest eigenvalue > tol * middle eigenvalue of the
-  // scatter matrix (base/Geometry.hpp:220-260); cyclic Jacobi, fixed sweep order (0,1),(0,2),(1,2).
-  static __device__ bool is_line(const double* px, const double* py, const double* pz, double tol) {
-    double cx = 0.0, cy = 0.0, cz = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { cx = cx + px[i]; cy = cy + py[i]; cz = cz + pz[i]; }
-    cx = cx / 10.0; cy = cy / 10.0; cz = cz / 10.0;
-    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const double dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
-      a00 = a00 + dx * dx; a01 = a01 + dx * dy; a02 = a02 + dx * dz;
-      a11 = a11 + dy * dy; a12 = a12 + dy * dz; a22 = a22 + dz * dz;
-    }
-    // only the upper triangle is accumulated: S[r][c] += d[r]*d[c] is symmetric bit for bit
-    for (int sweep = 0; sweep < 12; ++sweep) {
-      const double off = a01 * a01 + a02 * a02 + a12 * a12;
-      if (off == 0.0) break;
-      // (p,q) = (0,1), r = 2
-      if (a01 != 0.0) {
-        const double theta = (a11 - a00) / (2.0 * a01);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        const double app = a00, aqq = a11, apq = a01;
-        a00 = app - t * apq; a11 = aqq + t * apq; a01 = 0.0;
-        const double arp = a02, arq = a12;
-        a02 = c * arp - s * arq; a12 = s * arp + c * arq;
-      }
-      // (p,q) = (0,2), r = 1
-      if (a02 != 0.0) {
-        const double theta = (a22 - a00) / (2.0 * a02);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        const double app = a00, aqq = a22, apq = a02;
-        a00 = app - t * apq; a22 = aqq + t * apq; a02 = 0.0;
-        const double arp = a01, arq = a12;
-        a01 = c * arp - s * arq; a12 = s * arp + c * arq;
-      }
-      // (p,q) = (1,2), r = 0
-      if (a12 != 0.0) {
-        const double theta = (a22 - a11) / (2.0 * a12);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        const double app = a11, aqq = a22, apq = a12;
-        a11 = app - t * apq; a22 = aqq + t * apq; a12 = 0.0;
-        const double arp = a01, arq = a02;
-        a01 = c * arp - s * arq; a02 = s * arp + c * arq;
-      }
-    }
-    // ascending sort of (a00, a11, a22)
-    double w0 = a00, w1 = a11, w2 = a22, t;
-    if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
-    if (w1 > w2) { t = w1; w1 = w2; w2 = t; }
-    if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
-    return w2 > tol * w1;
-  }
-};
-
-// World2Local: R_wl^T p - R_wl^T t  (sensors/Velodyne.cpp:1850-1853), R row-major
-__device__ __forceinline__ void world2local(const double* R, const double* t, double x, double y, double z, double* o) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double a = (R[i] * x + R[3 + i] * y) + R[6 + i] * z;
-    const double b = (R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];
-    o[i] = a - b;
-  }
 }
 
 // K2 — grid: x = chunk of 256 queries, y = pair in batch.  Exact 10-NN of every query; slot 9 is -1
@@ -563,33 +192,6 @@ __global__ __launch_bounds__(256) void k_knn_pairs(const PairDesc* __restrict__ 
   // neighbour table is column-major (slot k of every query contiguous): coalesced 256-byte stores per wave
 #pragma unroll
   for (int k = 0; k < 10; ++k) nn_tmp[(size_t)k * tmp_rows + pd.tmp_base + q] = tk.index(k);
-}
-
-// K2, LDS-staged variant (opt-in, see the launch site): the whole target cloud of the pair (voxel-grid sorted float4 points + cell offsets,
-// <= 64 KiB: a 0.2 m voxel-downsampled scan is 40-60 KiB) is copied into LDS once per block of
-// KNN_LDS_QUERIES queries; the per-query walk over cells then never leaves the CU.
-#define KNN_LDS_THREADS 512
-#define KNN_LDS_QUERIES 2048
-__global__ __launch_bounds__(KNN_LDS_THREADS) void k_knn_pairs_lds(const PairDesc* __restrict__ pairs, float dist_threshold, int* __restrict__ nn_tmp,
-                                                                   long long tmp_rows) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const PairDesc& pd = pairs[blockIdx.y];
-  const int q0 = blockIdx.x * KNN_LDS_QUERIES;
-  if (q0 >= pd.nq) return;
-  const CloudView& cv = pd.ref;
-  float4* ls = reinterpret_cast<float4*>(smem);
-  int* lc = reinterpret_cast<int*>(smem + (size_t)cv.n * sizeof(float4));
-  const int ncell1 = cv.nx * cv.ny * cv.nz + 1;
-  for (int i = threadIdx.x; i < cv.n; i += KNN_LDS_THREADS) ls[i] = cv.sorted[i];
-  for (int i = threadIdx.x; i < ncell1; i += KNN_LDS_THREADS) lc[i] = cv.cell_start[i];
-  __syncthreads();
-  const float thr2 = dist_threshold * dist_threshold;
-  for (int q = q0 + threadIdx.x; q < min(pd.nq, q0 + KNN_LDS_QUERIES); q += KNN_LDS_THREADS) {
-    TopK<10> tk;
-    knn_search_lds<10>(cv, ls, lc, pd.q_xyz[3 * q], pd.q_xyz[3 * q + 1], pd.q_xyz[3 * q + 2], dist_threshold, thr2, tk);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) nn_tmp[(size_t)k * tmp_rows + pd.tmp_base + q] = tk.index(k);
-  }
 }
 
 // K3 — class test, 10x3 plane fit, collinearity test, candidate record, accept flag and the
@@ -622,9 +224,10 @@ __global__ __launch_bounds__(256) void k_fit_pairs(const PairDesc* __restrict__ 
       ok = (same == 10);  // :583-591
       if (ok) {
         double plane[4];
-        const bool plane_ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
-        const bool line = Fit10::is_line(px, py, pz, 3.0);
-        ok = plane_ok && !line;  // :592-596
+        // :592-596 accepts when the plane fits AND the ten points are not collinear: the eigen test only runs for the lanes
+        // whose plane fit passed (the decision is the same, a wave whose lanes all failed skips the Jacobi sweeps)
+        ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+        if (ok) ok = !Fit10::is_line(px, py, pz, 3.0);
         if (ok) {
           double pl[3];
           world2local(pd.Rn, pd.tn, (double)pd.q_xyz[3 * q], (double)pd.q_xyz[3 * q + 1], (double)pd.q_xyz[3 * q + 2], pl);
@@ -763,7 +366,7 @@ static CloudView view_of(const pvlm_cloud& c);
 
 static CloudView view_of(const pvlm_cloud& c) {
   CloudView v;
-  v.sorted = c.d_sorted; v.keys = c.d_keys; v.cell_start = c.d_cell_start; v.cell_count = c.d_cell_count;
+  v.sorted = reinterpret_cast<const Point4*>(c.d_sorted); v.keys = c.d_keys; v.cell_start = c.d_cell_start; v.cell_count = c.d_cell_count;
   v.xyz = c.d_xyz; v.tag = c.d_tag; v.n = c.n; v.mask = c.table_size - 1;
   v.dense = c.dense; v.nx = c.nx; v.ny = c.ny; v.nz = c.nz;
   v.ox = c.origin[0]; v.oy = c.origin[1]; v.oz = c.origin[2]; v.h = c.cell; v.inv_h = c.cell > 0 ? 1.0f / c.cell : 0.f;
@@ -776,7 +379,7 @@ static pvlm_status assoc_ws_ensure(pvlm_ctx* ctx, long long rows, int chunks, in
   rows = std::max<long long>(rows, 1); chunks = std::max(chunks, 1); pairs = std::max(pairs, 1);
   if (w.rows >= rows && w.chunks >= chunks && w.pairs >= pairs) return PVLM_OK;
   rows = std::max(rows, w.rows); chunks = std::max(chunks, w.chunks); pairs = std::max(pairs, w.pairs);
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PVLM_TRY_SYNC(ctx);
   pvlm_i_assoc_ws_free(ctx);
   pvlm_status st = PVLM_OK;
   for (int s = 0; s < 2 && !st; ++s) {
@@ -1117,7 +720,6 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
   pvlm_status st = assoc_ws_ensure(ctx, cap_rows, cap_chunks, cap_pairs);
   if (st) { pvlm_i_resset_free(ctx, rs); return st; }
   pvlm_assoc_ws& ws = ctx->assoc_ws;
-  const bool lds_env = getenv("PVLM_LDS_KNN") != nullptr;
 
   auto issue = [&](int bi) -> pvlm_status {
     const Batch& b = batches[bi];
@@ -1127,24 +729,9 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     const PairDesc* d_desc = static_cast<const PairDesc*>(ws.d_desc[s]);
     if (b.bmax > 0) {
       pvlm_prof_scope prof(ctx, 2);
-      // LDS-staged search, opt-in (PVLM_LDS_KNN=1): measured on MI355X it is not faster than the L1/L2-served search
-      // (35.0 vs 33.6 ms for 134 M queries against 2.6 k-point clouds) — the search is bound by top-k maintenance
-      // under SIMD divergence, not by memory latency — and it halves the occupancy.
-      size_t lds_need = 0;
-      bool lds_ok = lds_env;
-      for (int p = b.p0; p < b.p1 && lds_ok; ++p) {
-        const CloudView& v = descs[p].ref;
-        if (descs[p].nq == 0) continue;
-        if (!v.dense) { lds_ok = false; break; }
-        lds_need = std::max(lds_need, (size_t)v.n * sizeof(float4) + ((size_t)v.nx * v.ny * v.nz + 1) * sizeof(int));
-      }
-      if (lds_ok && lds_need > 64 * 1024 && lds_need <= 144 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_knn_pairs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-      if (lds_ok && lds_need > 0 && lds_need <= 144 * 1024)
-        hipLaunchKernelGGL(k_knn_pairs_lds, dim3((b.bmax + KNN_LDS_QUERIES - 1) / KNN_LDS_QUERIES, nb), dim3(KNN_LDS_THREADS), (lds_need + 15) & ~(size_t)15,
-                           ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
-      else
-        hipLaunchKernelGGL(k_knn_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
+      // (an LDS-staged variant of the search was built and measured in round 2: 35.0 vs 33.6 ms for 134 M queries — the
+      // search is bound by instruction issue, not by memory latency; numbers in DESIGN.md, code removed in round 3)
+      hipLaunchKernelGGL(k_knn_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
       hipLaunchKernelGGL(k_fit_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.d_rec[s],
                          ws.d_flag[s], ws.d_cc[s], ws.rows);
       PVLM_HIP(ctx, hipGetLastError());

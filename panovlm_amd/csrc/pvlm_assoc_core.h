@@ -1,0 +1,457 @@
+// Per-query bodies of the association kernels (K2 exact k-NN in the voxel grid, K3 plane fit + collinearity test):
+// the device side of AssociatePoint2Plane (lidar_mapping/LidarFeatureAssociate.cpp:550-630).  Host/device so that
+// tests/cpp/assoc_core_check.cpp can drive the very same functions serially on a machine without a GPU
+// (tests/test_assoc_core_cpu.py: search == brute force, fits == the oracle's decisions).  libpvlm.so has no host path.
+//
+// Arithmetic contract: distances are float32 in flann::L2_Simple order, every accept / reject decision is fp64 in the
+// reference's operation order; the including translation unit is compiled with -ffp-contract=off.
+#pragma once
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#ifndef PVLM_HD
+#define PVLM_HD __host__ __device__ __forceinline__
+#define PVLM_ASSOC_DEVICE 1
+#endif
+
+#ifndef PVLM_ASSOC_STATS_CANDIDATE   // counting hooks of the host-compiled check (tests/cpp/assoc_core_check.cpp)
+#define PVLM_ASSOC_STATS_CANDIDATE() ((void)0)
+#define PVLM_ASSOC_STATS_ROW() ((void)0)
+#endif
+
+namespace pvlm_assoc {
+
+#define PVLM_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define PVLM_CELL_BIAS (1 << 20)
+
+struct Point4 { float x, y, z, w; };   // (x, y, z, original index as float bits): one 16-byte load per candidate
+
+struct CloudView {
+  const Point4* sorted;
+  const unsigned long long* keys;
+  const int* cell_start;   // hash: start of the slot's cell; dense: prefix offsets, ncells + 1 entries
+  const int* cell_count;
+  const float* xyz;  // original order, interleaved
+  const float* tag;
+  int n, mask;
+  int dense, nx, ny, nz;   // dense != 0: cells addressed directly as (iz*ny + iy)*nx + ix, no hashing
+  float ox, oy, oz, h, inv_h;
+};
+
+PVLM_HD unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x;
+}
+PVLM_HD unsigned long long cell_key(int ix, int iy, int iz) {
+  return (unsigned long long)((ix + PVLM_CELL_BIAS) & 0x1FFFFF) | ((unsigned long long)((iy + PVLM_CELL_BIAS) & 0x1FFFFF) << 21) |
+         ((unsigned long long)((iz + PVLM_CELL_BIAS) & 0x1FFFFF) << 42);
+}
+PVLM_HD int cell_of(float x, float o, float inv_h) {
+  float c = floorf((x - o) * inv_h);
+  c = fminf(fmaxf(c, -1000000.f), 1000000.f);
+  return (int)c;
+}
+PVLM_HD unsigned f2u(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+PVLM_HD float u2f(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+
+// ---- sorted top-K of (distance, index) ---------------------------------------------------------------------------------
+// A squared distance is a non-negative float, whose bit pattern orders like its value, so (float bits << 32 | index) is
+// ONE 64-bit key ordered exactly like the lexicographic (distance, index) pair the reference's sorted k-NN result
+// implies.  Round 2 inserted with a compare-and-swap chain on u64 (v_cmp_lt_u64 + four v_cndmask per slot, 45
+// instructions whenever ANY lane of the wave inserts).  Now the key lives in a register pair as the bit pattern of a
+// POSITIVE NORMAL DOUBLE — positive doubles order like their bit patterns too — and an insertion into the sorted list is
+//     key'[k] = min(key[k], max(key[k-1], c)),   key'[0] = min(key[0], c)
+// i.e. 2K - 1 v_min_f64 / v_max_f64, branch-free, whatever the other lanes do.  KEY_BIAS lifts the exponent field by one
+// so that a distance of exactly 0 (key high word 0) is a normal number and no denormal ever reaches the min / max units.
+#define PVLM_KEY_BIAS 0x00100000u
+#define PVLM_KEY_INF_HI (0x7F800000u + PVLM_KEY_BIAS)      // (+inf, index -1): an empty slot
+#define PVLM_KEY_REJECT_HI (0x7F800001u + PVLM_KEY_BIAS)   // above every slot: never enters the list
+
+#if defined(PVLM_ASSOC_DEVICE) && defined(__HIP_DEVICE_COMPILE__)
+typedef double topk_key;
+__device__ __forceinline__ topk_key key_make(unsigned hi, unsigned lo) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ unsigned key_hi(topk_key k) { return (unsigned)__double2hiint(k); }
+__device__ __forceinline__ unsigned key_lo(topk_key k) { return (unsigned)__double2loint(k); }
+// inline asm: fmin() / fmax() would be preceded by a canonicalising v_max_f64 x, x of operands the compiler cannot prove quiet
+__device__ __forceinline__ topk_key key_min(topk_key a, topk_key b) { topk_key r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ topk_key key_max(topk_key a, topk_key b) { topk_key r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+typedef unsigned long long topk_key;
+PVLM_HD topk_key key_make(unsigned hi, unsigned lo) { return ((unsigned long long)hi << 32) | lo; }
+PVLM_HD unsigned key_hi(topk_key k) { return (unsigned)(k >> 32); }
+PVLM_HD unsigned key_lo(topk_key k) { return (unsigned)(k & 0xFFFFFFFFull); }
+PVLM_HD topk_key key_min(topk_key a, topk_key b) { return a < b ? a : b; }
+PVLM_HD topk_key key_max(topk_key a, topk_key b) { return a < b ? b : a; }
+#endif
+
+template <int K>
+struct TopK {
+  topk_key key[K];
+  PVLM_HD void init() {
+#pragma unroll
+    for (int k = 0; k < K; ++k) key[k] = key_make(PVLM_KEY_INF_HI, 0xFFFFFFFFu);
+  }
+  // candidate (d2, idx); `take` false (beyond the distance threshold, NaN) turns it into a key above every slot
+  PVLM_HD void push(float d2, int idx, bool take) {
+    const topk_key c = key_make(take ? f2u(d2) + PVLM_KEY_BIAS : PVLM_KEY_REJECT_HI, (unsigned)idx);
+#pragma unroll
+    for (int k = K - 1; k > 0; --k) key[k] = key_min(key[k], key_max(key[k - 1], c));
+    key[0] = key_min(key[0], c);
+  }
+  PVLM_HD bool full() const { return key_hi(key[K - 1]) < PVLM_KEY_INF_HI; }
+  PVLM_HD float dist(int k) const { return u2f(key_hi(key[k]) - PVLM_KEY_BIAS); }      // +inf for an empty slot
+  PVLM_HD int index(int k) const { return (int)key_lo(key[k]); }                         // -1 for an empty slot
+};
+
+// ---- K2: exact k-NN of one query ------------------------------------------------------------------------------------------
+// Chebyshev shells of cells around the query's cell, as in round 2, but every (z, y) row of a shell is first tested against
+// the CURRENT k-th distance (or dist_threshold while the list is not full): a row whose nearest possible point is farther is
+// skipped, and the x-run of a surviving row is clipped to the cells the remaining budget can reach.  A skipped cell only
+// holds points with d2 > the k-th distance, which can never enter the list (a tie enters only at EQUAL distance), so the
+// result is still the exact, tie-broken k-NN; the slack covers the float rounding of the points' cell assignment.
+template <int K, class Visit>
+PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float max_dist, float thr2, TopK<K>& tk, Visit&& visit) {
+  tk.init();
+  if (cv.n <= 0) return;
+  const int cx = cell_of(qx, cv.ox, cv.inv_h), cy = cell_of(qy, cv.oy, cv.inv_h), cz = cell_of(qz, cv.oz, cv.inv_h);
+  const float fx = (qx - cv.ox) * cv.inv_h - (float)cx, fy = (qy - cv.oy) * cv.inv_h - (float)cy, fz = (qz - cv.oz) * cv.inv_h - (float)cz;
+  const float lo_min = fminf(fminf(fx, fy), fz), hi_min = fminf(fminf(1.f - fx, 1.f - fy), 1.f - fz);
+  const float inside = fminf(lo_min, hi_min);  // distance (in cells) from q to the nearest face of its own cell
+  const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
+  const int rmax = (int)ceilf(max_dist * 1.0001f * cv.inv_h);
+  for (int r = 0; r <= rmax; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      const int z = cz + dz;
+      if (cv.dense && (z < 0 || z >= cv.nz)) continue;
+      const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);   // gap to the row's slab, in cells
+      const float gzm = fmaxf(gz * cv.h - slack, 0.f);
+      for (int dy = -r; dy <= r; ++dy) {
+        const int y = cy + dy;
+        if (cv.dense && (y < 0 || y >= cv.ny)) continue;
+        const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
+        const float gym = fmaxf(gy * cv.h - slack, 0.f);
+        const float lb = gym * gym + gzm * gzm;                       // <= d2 of every point of the row
+        const float budget = fminf(thr2, tk.dist(K - 1)) * 1.00001f;   // dist(K-1) = +inf while the list is not full
+        if (lb > budget) continue;
+        const float reach = (sqrtf(budget - lb) + slack) * cv.inv_h;  // cells the budget still reaches along x
+        const int xa = cx + (int)floorf(fx - reach), xb = cx + (int)floorf(fx + reach);
+        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+        // a face row of the shell is one x-run; an interior row only owns its two end cells (one call site for both:
+        // the candidate loop is inlined once)
+        for (int part = 0; part < 2; ++part) {
+          int x0, x1;
+          if (face) {
+            if (part) break;
+            x0 = xa > cx - r ? xa : cx - r; x1 = xb < cx + r ? xb : cx + r;
+          } else {
+            x0 = x1 = part ? cx + r : cx - r;
+            if (x0 < xa || x0 > xb) continue;
+          }
+          if (x0 <= x1) { PVLM_ASSOC_STATS_ROW(); visit(z, y, x0, x1); }
+        }
+      }
+    }
+    // every unsearched point lies outside the (2r+1)^3 block: farther than (inside + r) cells
+    const float bound = (inside + (float)r) * cv.h - slack;
+    if (tk.full() && bound > 0.f && tk.dist(K - 1) < bound * bound) break;
+    if ((float)r * cv.h >= max_dist * 1.0001f) break;  // everything within max_dist has been visited
+  }
+}
+
+template <int K>
+PVLM_HD void knn_scan_run(const CloudView& cv, int b, int e, float qx, float qy, float qz, float thr2, TopK<K>& tk) {
+  if (b >= e) return;
+  // the next candidate is in flight while the current one goes through the insertion network (the redundant last load
+  // re-reads candidate e - 1)
+  Point4 p = cv.sorted[b];
+  for (int j = b; j < e; ++j) {
+    const Point4 nxt = cv.sorted[j + 1 < e ? j + 1 : j];
+    const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+    float d2 = 0.0f;
+    d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
+    tk.push(d2, (int)f2u(p.w), d2 <= thr2);
+    PVLM_ASSOC_STATS_CANDIDATE();
+    p = nxt;
+  }
+}
+
+template <int K, bool DENSE>
+PVLM_HD void knn_search_grid(const CloudView& cv, float qx, float qy, float qz, float max_dist, float thr2, TopK<K>& tk) {
+  knn_rows<K>(cv, qx, qy, qz, max_dist, thr2, tk, [&](int z, int y, int x0, int x1) {
+    if (DENSE) {
+      // the cells of one (z, y) row are contiguous in the sorted array: the whole x-run is one range
+      x0 = x0 > 0 ? x0 : 0; x1 = x1 < cv.nx - 1 ? x1 : cv.nx - 1;
+      if (x0 > x1) return;
+      const int row = (z * cv.ny + y) * cv.nx;
+      knn_scan_run<K>(cv, cv.cell_start[row + x0], cv.cell_start[row + x1 + 1], qx, qy, qz, thr2, tk);
+    } else {
+      for (int x = x0; x <= x1; ++x) {
+        const unsigned long long key = cell_key(x, y, z);
+        int s = (int)(mix64(key) & (unsigned long long)cv.mask);
+        unsigned long long kk;
+        while ((kk = cv.keys[s]) != key && kk != PVLM_EMPTY_KEY) s = (s + 1) & cv.mask;
+        if (kk != key) continue;
+        const int b = cv.cell_start[s];
+        knn_scan_run<K>(cv, b, b + cv.cell_count[s], qx, qy, qz, thr2, tk);
+      }
+    }
+  });
+}
+
+template <int K>
+PVLM_HD void knn_search(const CloudView& cv, float qx, float qy, float qz, float max_dist, float thr2, TopK<K>& tk) {
+  if (cv.dense) knn_search_grid<K, true>(cv, qx, qy, qz, max_dist, thr2, tk);
+  else knn_search_grid<K, false>(cv, qx, qy, qz, max_dist, thr2, tk);
+}
+
+// ---- K3: fp64 fits (sequential-sum Householder / Jacobi arithmetic the parity tests pin, fully unrolled, static indexing) ----
+struct Fit10 {
+  // Householder QR with column pivoting on the 10x3 system A n = -1 (Eigen ColPivHouseholderQR
+  // restated, base/Geometry.hpp:345-373), then the tolerance test.  c0,c1,c2 = columns (destroyed).
+  static PVLM_HD void swap_cols(double* a, double* b) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { const double t = a[i]; a[i] = b[i]; b[i] = t; }
+  }
+  template <int KK>
+  static PVLM_HD void householder(double* ck, double* cj1, double* cj2, double& tau) {
+    double tailSq = 0.0;
+#pragma unroll
+    for (int i = KK + 1; i < 10; ++i) tailSq += ck[i] * ck[i];
+    const double c0 = ck[KK];
+    double beta;
+    if (tailSq <= DBL_MIN) {
+      tau = 0.0; beta = c0;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) ck[i] = 0.0;
+    } else {
+      beta = sqrt(c0 * c0 + tailSq);
+      if (c0 >= 0.0) beta = -beta;
+      const double den = c0 - beta;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) ck[i] = ck[i] / den;
+      tau = (beta - c0) / beta;
+    }
+    ck[KK] = beta;
+    if (tau != 0.0) {
+      if (cj1) {
+        double tmp = 0.0;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * cj1[i];
+        tmp += cj1[KK];
+        cj1[KK] -= tau * tmp;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) cj1[i] -= tau * ck[i] * tmp;
+      }
+      if (cj2) {
+        double tmp = 0.0;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * cj2[i];
+        tmp += cj2[KK];
+        cj2[KK] -= tau * tmp;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) cj2[i] -= tau * ck[i] * tmp;
+      }
+    }
+  }
+  template <int KK>
+  static PVLM_HD void downdate(const double* cj, double& nU, double& nD, double thr) {
+    if (nU != 0.0) {
+      double temp = fabs(cj[KK]) / nU;
+      temp = (1.0 + temp) * (1.0 - temp);
+      temp = temp < 0.0 ? 0.0 : temp;
+      const double ratio = nU / nD;
+      const double temp2 = temp * ratio * ratio;
+      if (temp2 <= thr) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = KK + 1; i < 10; ++i) s += cj[i] * cj[i];
+        nD = sqrt(s);
+        nU = nD;
+      } else {
+        nU *= sqrt(temp);
+      }
+    }
+  }
+  template <int KK>
+  static PVLM_HD void apply_rhs(const double* ck, double tau, double* b) {
+    if (tau != 0.0) {
+      double tmp = 0.0;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) tmp += ck[i] * b[i];
+      tmp += b[KK];
+      b[KK] -= tau * tmp;
+#pragma unroll
+      for (int i = KK + 1; i < 10; ++i) b[i] -= tau * ck[i] * tmp;
+    }
+  }
+
+  // pts: 10 x 3 (px[10], py[10], pz[10]).  Returns plane_ok; plane = (n, d).
+  static PVLM_HD bool form_plane(const double* px, const double* py, const double* pz, double tol, double* plane) {
+    double c0[10], c1[10], c2[10], b[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c0[i] = px[i]; c1[i] = py[i]; c2[i] = pz[i]; b[i] = -1.0; }
+    const double eps = DBL_EPSILON;
+    double nU0, nU1, nU2, nD0, nD1, nD2;
+    {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) { s0 += c0[i] * c0[i]; s1 += c1[i] * c1[i]; s2 += c2[i] * c2[i]; }
+      nD0 = nU0 = sqrt(s0); nD1 = nU1 = sqrt(s1); nD2 = nU2 = sqrt(s2);
+    }
+    double maxn = nU0; if (nU1 > maxn) maxn = nU1; if (nU2 > maxn) maxn = nU2;
+    const double threshold_helper = (maxn * eps) * (maxn * eps) / 10.0;
+    const double ndt = sqrt(eps);
+    int nonzero = 3;
+    int p0 = 0, p1 = 1, p2 = 2;
+    double tau0, tau1, tau2;
+    // ---- k = 0
+    {
+      int big = 0; double bigv = nU0;
+      if (nU1 > bigv) { bigv = nU1; big = 1; }
+      if (nU2 > bigv) { bigv = nU2; big = 2; }
+      if (nonzero == 3 && bigv * bigv < threshold_helper * 10.0) nonzero = 0;
+      if (big == 1) { swap_cols(c0, c1); double t = nU0; nU0 = nU1; nU1 = t; t = nD0; nD0 = nD1; nD1 = t; int q = p0; p0 = p1; p1 = q; }
+      else if (big == 2) { swap_cols(c0, c2); double t = nU0; nU0 = nU2; nU2 = t; t = nD0; nD0 = nD2; nD2 = t; int q = p0; p0 = p2; p2 = q; }
+      householder<0>(c0, c1, c2, tau0);
+      downdate<0>(c1, nU1, nD1, ndt);
+      downdate<0>(c2, nU2, nD2, ndt);
+    }
+    // ---- k = 1
+    {
+      int big = 1; double bigv = nU1;
+      if (nU2 > bigv) { bigv = nU2; big = 2; }
+      if (nonzero == 3 && bigv * bigv < threshold_helper * 9.0) nonzero = 1;
+      if (big == 2) { swap_cols(c1, c2); double t = nU1; nU1 = nU2; nU2 = t; t = nD1; nD1 = nD2; nD2 = t; int q = p1; p1 = p2; p2 = q; }
+      householder<1>(c1, c2, nullptr, tau1);
+      downdate<1>(c2, nU2, nD2, ndt);
+    }
+    // ---- k = 2
+    {
+      const double bigv = nU2;
+      if (nonzero == 3 && bigv * bigv < threshold_helper * 8.0) nonzero = 2;
+      householder<2>(c2, nullptr, nullptr, tau2);
+    }
+    if (nonzero > 0) apply_rhs<0>(c0, tau0, b);
+    if (nonzero > 1) apply_rhs<1>(c1, tau1, b);
+    if (nonzero > 2) apply_rhs<2>(c2, tau2, b);
+    // back substitution on the leading nonzero x nonzero triangle: R = [c0[0] c1[0] c2[0]; 0 c1[1] c2[1]; 0 0 c2[2]]
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (nonzero > 2) y2 = b[2] / c2[2];
+    if (nonzero > 1) { double s = b[1]; if (nonzero > 2) s -= c2[1] * y2; y1 = s / c1[1]; }
+    if (nonzero > 0) { double s = b[0]; if (nonzero > 1) s -= c1[0] * y1; if (nonzero > 2) s -= c2[0] * y2; y0 = s / c0[0]; }
+    double x[3] = {0.0, 0.0, 0.0};
+    if (nonzero > 0) { if (p0 == 0) x[0] = y0; else if (p0 == 1) x[1] = y0; else x[2] = y0; }
+    if (nonzero > 1) { if (p1 == 0) x[0] = y1; else if (p1 == 1) x[1] = y1; else x[2] = y1; }
+    if (nonzero > 2) { if (p2 == 0) x[0] = y2; else if (p2 == 1) x[1] = y2; else x[2] = y2; }
+    const double len = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const double d = 1.0 / len;
+    if (len * len > 0.0) { x[0] /= len; x[1] /= len; x[2] /= len; }
+    bool ok = true;
+    if (tol > 0) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const double dist = fabs((x[0] * px[i] + x[1] * py[i]) + x[2] * pz[i] + d);
+        if (dist > tol) ok = false;
+      }
+    }
+    plane[0] = ok ? x[0] : 0.0; plane[1] = ok ? x[1] : 0.0; plane[2] = ok ? x[2] : 0.0; plane[3] = ok ? d : 0.0;
+    return ok;
+  }
+
+  // FormLine(points, 3.0) is non-zero  <=>  largest eigenvalue > tol * middle eigenvalue of the
+  // scatter matrix (base/Geometry.hpp:220-260); cyclic Jacobi, fixed sweep order (0,1),(0,2),(1,2) — the oracle's
+  // eig_sym3_jacobi, which sweeps until the off-diagonal part is EXACTLY zero (8-10 sweeps of three rotations with two
+  // divisions and two square roots each: the larger half of round 2's K3).
+  //
+  // Certified early exit.  Only the DECISION w2 > tol * w1 of the converged sweep is needed.  Before each sweep the
+  // current diagonal d (sorted) and the off-diagonal Frobenius norm E = sqrt(2 (a01^2 + a02^2 + a12^2)) bracket the exact
+  // eigenvalues of the current matrix: |lambda_i - d_i| <= E (Weyl).  The remaining sweeps are orthogonal similarity
+  // transforms carried out in fp64, so what the converged loop returns differs from lambda_i by no more than its
+  // accumulated rounding, < 1e-13 |lambda|_max for at most 36 rotations; `guard` below is 1e-11 of the largest diagonal
+  // entry.  When the brackets already decide the comparison the loop stops — the answer is the one the full loop would
+  // give — otherwise it sweeps on, down to the oracle's own termination.  Typical: decided after 2-3 sweeps.
+  static PVLM_HD bool is_line(const double* px, const double* py, const double* pz, double tol, int* sweeps_done = nullptr) {
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { cx = cx + px[i]; cy = cy + py[i]; cz = cz + pz[i]; }
+    cx = cx / 10.0; cy = cy / 10.0; cz = cz / 10.0;
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const double dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+      a00 = a00 + dx * dx; a01 = a01 + dx * dy; a02 = a02 + dx * dz;
+      a11 = a11 + dy * dy; a12 = a12 + dy * dz; a22 = a22 + dz * dz;
+    }
+    // only the upper triangle is accumulated: S[r][c] += d[r]*d[c] is symmetric bit for bit
+    for (int sweep = 0; sweep < 12; ++sweep) {
+      const double off = a01 * a01 + a02 * a02 + a12 * a12;
+      if (off == 0.0) break;
+      if (sweeps_done) *sweeps_done = sweep;
+      {
+        double w0 = a00, w1 = a11, w2 = a22, t;
+        if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
+        if (w1 > w2) { t = w1; w1 = w2; w2 = t; }
+        if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
+        const double amax = fmax(fabs(w2), fabs(w0));
+        const double E = sqrt(2.0 * off) * (1.0 + 1e-9) + 1e-11 * amax;   // Weyl radius + rounding of the remaining sweeps
+        // (w2 - E) > tol (w1 + E)  =>  certainly a line;   (w2 + E) < tol (w1 - E)  =>  certainly not
+        const double guard = 1e-11 * amax * (1.0 + fabs(tol));
+        if (E == E && amax < 1e300) {    // finite
+          if ((w2 - E) - tol * (w1 + E) > guard) return true;
+          if (tol * (w1 - E) - (w2 + E) > guard) return false;
+        }
+      }
+      // (p,q) = (0,1), r = 2
+      if (a01 != 0.0) {
+        const double theta = (a11 - a00) / (2.0 * a01);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        const double app = a00, aqq = a11, apq = a01;
+        a00 = app - t * apq; a11 = aqq + t * apq; a01 = 0.0;
+        const double arp = a02, arq = a12;
+        a02 = c * arp - s * arq; a12 = s * arp + c * arq;
+      }
+      // (p,q) = (0,2), r = 1
+      if (a02 != 0.0) {
+        const double theta = (a22 - a00) / (2.0 * a02);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        const double app = a00, aqq = a22, apq = a02;
+        a00 = app - t * apq; a22 = aqq + t * apq; a02 = 0.0;
+        const double arp = a01, arq = a12;
+        a01 = c * arp - s * arq; a12 = s * arp + c * arq;
+      }
+      // (p,q) = (1,2), r = 0
+      if (a12 != 0.0) {
+        const double theta = (a22 - a11) / (2.0 * a12);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        const double app = a11, aqq = a22, apq = a12;
+        a11 = app - t * apq; a22 = aqq + t * apq; a12 = 0.0;
+        const double arp = a01, arq = a02;
+        a01 = c * arp - s * arq; a02 = s * arp + c * arq;
+      }
+      if (sweeps_done) *sweeps_done = sweep + 1;
+    }
+    // ascending sort of (a00, a11, a22)
+    double w0 = a00, w1 = a11, w2 = a22, t;
+    if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
+    if (w1 > w2) { t = w1; w1 = w2; w2 = t; }
+    if (w0 > w1) { t = w0; w0 = w1; w1 = t; }
+    return w2 > tol * w1;
+  }
+};
+
+// World2Local: R_wl^T p - R_wl^T t  (sensors/Velodyne.cpp:1850-1853), R row-major
+PVLM_HD void world2local(const double* R, const double* t, double x, double y, double z, double* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a = (R[i] * x + R[3 + i] * y) + R[6 + i] * z;
+    const double b = (R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];
+    o[i] = a - b;
+  }
+}
+
+}  // namespace pvlm_assoc

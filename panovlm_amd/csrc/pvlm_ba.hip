@@ -348,7 +348,7 @@ pvlm_status pvlm_ba_set_points(pvlm_ctx* ctx, pvlm_baset* set, const double* poi
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   pvlm_status st = h2d(ctx, set->d_X, points, (size_t)set->n_points * 3);
   if (st) return st;
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PVLM_TRY_SYNC(ctx);
   set->reduced = false; set->have_candidate = false;
   return PVLM_OK;
 }
@@ -356,13 +356,13 @@ pvlm_status pvlm_ba_set_points(pvlm_ctx* ctx, pvlm_baset* set, const double* poi
 pvlm_status pvlm_ba_set_constant(pvlm_ctx* ctx, pvlm_baset* set, const unsigned char* mask) {
   if (!ctx || !set) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PVLM_TRY_SYNC(ctx);
   if (!mask) { pvlm_i_free(ctx, set->d_frozen); set->d_frozen = nullptr; }
   else {
     pvlm_status st;
     if (!set->d_frozen && (st = pvlm_i_alloc(ctx, &set->d_frozen, (size_t)set->n_points))) return st;
     if ((st = h2d(ctx, set->d_frozen, mask, (size_t)set->n_points))) return st;
-    PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PVLM_TRY_SYNC(ctx);
   }
   set->reduced = false;
   return PVLM_OK;

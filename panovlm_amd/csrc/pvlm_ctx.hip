@@ -105,7 +105,14 @@ void pvlm_i_free(pvlm_ctx* ctx, const void* p) {
   if (!p) return;
   pvlm_pool& P = ctx->pool;
   auto it = P.live.find(p);
-  if (it == P.live.end()) { (void)hipFree(const_cast<void*>(p)); return; }
+  if (it == P.live.end()) {
+    // PVLM_NO_POOL=1: every block is a plain hipMalloc.  With the pool on there are no foreign pointers: an unknown one is a double
+    // free or an interior pointer — diagnosed, never handed to hipFree (its range may belong to another object by now)
+    if (P.disabled) { (void)hipFree(const_cast<void*>(p)); return; }
+    PVLM_SET_ERR(ctx, "pvlm_i_free: %p is not a live block of this context's pool (double free or interior pointer)", p);
+    fprintf(stderr, "[pvlm] %s\n", ctx->err.c_str());
+    return;
+  }
   const pvlm_pool::Range r = it->second;
   P.live.erase(it);
   P.in_use -= r.size;
@@ -114,7 +121,22 @@ void pvlm_i_free(pvlm_ctx* ctx, const void* p) {
 
 static const size_t kStageBytes = (size_t)32 << 20;
 
+// Inside a graph capture (pvlm_graph_begin .. pvlm_graph_end) only the _dev entry points may run: a staged copy would be captured as
+// a memcpy node reading the recycled pinned arena (every replay would upload whatever bytes the arena holds by then), and a
+// synchronisation invalidates the capture.  The three staging helpers refuse instead.
+static pvlm_status refuse_in_capture(pvlm_ctx* ctx, const char* what) {
+  PVLM_SET_ERR(ctx, "%s inside a graph capture: only the device-pointer (_dev) entry points may be captured", what);
+  return PVLM_ERR_STATE;
+}
+
+pvlm_status pvlm_i_stream_sync(pvlm_ctx* ctx) {
+  if (ctx->capturing) return refuse_in_capture(ctx, "host synchronisation");
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
+}
+
 pvlm_status pvlm_i_sync(pvlm_ctx* ctx) {
+  if (ctx->capturing) return refuse_in_capture(ctx, "host synchronisation");
   const hipError_t e = hipStreamSynchronize(ctx->stream);
   pvlm_stage& a = ctx->stage;
   if (e == hipSuccess) for (const pvlm_stage::Deferred& d : a.deferred) std::memcpy(d.dst, d.src, d.bytes);
@@ -145,6 +167,7 @@ static char* stage_take(pvlm_ctx* ctx, size_t bytes) {
 static const size_t kStageDirect = (size_t)64 << 20;
 
 pvlm_status pvlm_i_h2d_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (ctx->capturing) return refuse_in_capture(ctx, "host-to-device copy");
   if (bytes > kStageDirect) {
     PVLM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));     // pageable source: the caller may reuse it on return
@@ -166,6 +189,7 @@ pvlm_status pvlm_i_h2d_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes
 }
 
 static pvlm_status d2h_queue(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (ctx->capturing) return refuse_in_capture(ctx, "device-to-host copy");
   if (bytes > kStageDirect) {
     PVLM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -189,6 +213,7 @@ static pvlm_status d2h_queue(pvlm_ctx* ctx, void* dst, const void* src, size_t b
 // A failed queueing leaves no deferred copy behind: the caller returns its error without reaching pvlm_i_sync, and a later
 // synchronisation must not write into buffers that caller has released by then.
 pvlm_status pvlm_i_d2h_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (ctx->capturing) return refuse_in_capture(ctx, "device-to-host copy");
   const pvlm_status st = d2h_queue(ctx, dst, src, bytes);
   if (st) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -327,8 +352,7 @@ pvlm_status pvlm_use_own_stream(pvlm_ctx* ctx) {
 pvlm_status pvlm_synchronize(pvlm_ctx* ctx) {
   if (!ctx) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return PVLM_OK;
+  return pvlm_i_stream_sync(ctx);   // PVLM_ERR_STATE inside a capture
 }
 
 pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes) {

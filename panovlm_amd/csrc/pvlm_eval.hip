@@ -495,7 +495,7 @@ __global__ void k_neq_gather(int n_poses, int n_upairs, const int* __restrict__ 
 static pvlm_status ensure_pose_cap(pvlm_ctx* ctx, int n) {
   if (n <= ctx->cap_poses) return PVLM_OK;
   if (ctx->capturing) { PVLM_SET_ERR(ctx, "pose table would grow inside a graph capture (run the step once before pvlm_graph_begin)"); return PVLM_ERR_STATE; }
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PVLM_TRY_SYNC(ctx);
   pvlm_i_free(ctx, ctx->d_aa); pvlm_i_free(ctx, ctx->d_t); pvlm_i_free(ctx, ctx->d_pose_tab);
   ctx->d_aa = ctx->d_t = ctx->d_pose_tab = nullptr;
   ctx->cap_poses = 0;
@@ -705,7 +705,7 @@ pvlm_status pvlm_host_free(pvlm_ctx* ctx, void* p) {
   if (!ctx) return PVLM_ERR_ARG;
   if (!p) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PVLM_TRY_SYNC(ctx);
   PVLM_HIP(ctx, hipHostFree(p));
   return PVLM_OK;
 }

@@ -237,6 +237,10 @@ inline pvlm_status pvlm_i_alloc(pvlm_ctx* ctx, T** p, size_t count) {
 pvlm_status pvlm_i_h2d_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 pvlm_status pvlm_i_d2h_q(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 pvlm_status pvlm_i_sync(pvlm_ctx* ctx);
+// plain stream synchronisation of an entry point that is not capturable: PVLM_ERR_STATE inside a graph capture (a synchronisation
+// would invalidate the capture), otherwise hipStreamSynchronize
+pvlm_status pvlm_i_stream_sync(pvlm_ctx* ctx);
+#define PVLM_TRY_SYNC(ctx) do { const pvlm_status _s = pvlm_i_stream_sync(ctx); if (_s) return _s; } while (0)
 // host -> device through the context stream (pageable source: returns when the source may be reused)
 pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);

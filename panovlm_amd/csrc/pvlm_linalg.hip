@@ -441,7 +441,7 @@ struct WsCarver {
 };
 static pvlm_status ws_reserve(pvlm_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return PVLM_OK;
-  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PVLM_TRY_SYNC(ctx);
   pvlm_i_free(ctx, ctx->d_ws); ctx->d_ws = nullptr; ctx->ws_bytes = 0;
   pvlm_status st = pvlm_i_alloc_bytes(ctx, &ctx->d_ws, bytes);
   if (st) return st;

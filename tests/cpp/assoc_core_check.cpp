@@ -1,0 +1,137 @@
+// Host-compiled check of the per-query device bodies in panovlm_amd/csrc/pvlm_assoc_core.h (K2 exact k-NN in the voxel
+// grid with row pruning, K3 plane fit + certified collinearity test): the same functions k_knn_pairs / k_fit_pairs call,
+// driven serially over a grid built here the way pvlm_scan_upload_batch builds it (cell edge heuristic, dense table when
+// the bounding box allows, hashed table otherwise), so that the search can be compared with brute force and the fits with
+// the oracle on a machine without a GPU (tests/test_assoc_core_cpu.py).  TEST INFRASTRUCTURE ONLY — libpvlm.so has no
+// host path.  Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#define PVLM_HD inline
+static long long g_candidates = 0, g_rows_visited = 0;
+#define PVLM_ASSOC_STATS_CANDIDATE() (++g_candidates)
+#define PVLM_ASSOC_STATS_ROW() (++g_rows_visited)
+#include "../../panovlm_amd/csrc/pvlm_assoc_core.h"
+
+using namespace pvlm_assoc;
+
+namespace {
+struct Grid {
+  std::vector<Point4> sorted;
+  std::vector<unsigned long long> keys;
+  std::vector<int> start, count;
+  CloudView view;
+};
+
+// cloud_plan + k_grid_count / k_grid_scan / k_grid_scatter of csrc/pvlm_assoc.hip, serial
+void build_grid(const float* xyz, int n, float cell_override, int force_hash, Grid& g) {
+  float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], xyz[3 * i + k]); mx[k] = std::max(mx[k], xyz[3 * i + k]); }
+  float e[3];
+  for (int k = 0; k < 3; ++k) e[k] = std::max(mx[k] - mn[k], 0.05f);
+  const float area = 2.f * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+  float h = std::sqrt(4.f * area / (float)std::max(n, 1));
+  if (cell_override > 0) h = cell_override;
+  h = std::min(std::max(h, 0.02f), 4.0f);
+  float origin[3];
+  for (int k = 0; k < 3; ++k) origin[k] = mn[k] - h;
+  const float inv_h = 1.0f / h;
+  long long dims[3];
+  for (int k = 0; k < 3; ++k) dims[k] = (long long)std::ceil((mx[k] - origin[k]) * inv_h) + 2;
+  const long long ncells = dims[0] * dims[1] * dims[2];
+  const bool dense = ncells <= std::max<long long>(64ll * n, 4096) && ncells <= (4ll << 20) && !force_hash;
+  CloudView& v = g.view;
+  v = CloudView();
+  v.n = n; v.xyz = xyz; v.tag = nullptr; v.ox = origin[0]; v.oy = origin[1]; v.oz = origin[2]; v.h = h; v.inv_h = inv_h;
+  v.dense = dense ? 1 : 0; v.nx = (int)dims[0]; v.ny = (int)dims[1]; v.nz = (int)dims[2];
+  std::vector<int> slot((size_t)n);
+  long long T;
+  if (dense) {
+    T = ncells + 1;
+    g.count.assign((size_t)T, 0); g.start.assign((size_t)T, 0);
+    for (int i = 0; i < n; ++i) {
+      const int ix = std::min(std::max(cell_of(xyz[3 * i], v.ox, inv_h), 0), v.nx - 1), iy = std::min(std::max(cell_of(xyz[3 * i + 1], v.oy, inv_h), 0), v.ny - 1),
+                iz = std::min(std::max(cell_of(xyz[3 * i + 2], v.oz, inv_h), 0), v.nz - 1);
+      slot[(size_t)i] = (iz * v.ny + iy) * v.nx + ix;
+      ++g.count[(size_t)slot[(size_t)i]];
+    }
+    v.mask = 0;
+  } else {
+    T = 1024; while (T < 2ll * n) T <<= 1;
+    g.keys.assign((size_t)T, PVLM_EMPTY_KEY); g.count.assign((size_t)T, 0); g.start.assign((size_t)T, 0);
+    const int mask = (int)T - 1;
+    for (int i = 0; i < n; ++i) {
+      const unsigned long long key = cell_key(cell_of(xyz[3 * i], v.ox, inv_h), cell_of(xyz[3 * i + 1], v.oy, inv_h), cell_of(xyz[3 * i + 2], v.oz, inv_h));
+      int s = (int)(mix64(key) & (unsigned long long)mask);
+      while (g.keys[(size_t)s] != PVLM_EMPTY_KEY && g.keys[(size_t)s] != key) s = (s + 1) & mask;
+      g.keys[(size_t)s] = key;
+      slot[(size_t)i] = s; ++g.count[(size_t)s];
+    }
+    v.mask = mask;
+  }
+  int run = 0;
+  for (long long c = 0; c < T; ++c) { g.start[(size_t)c] = run; run += g.count[(size_t)c]; }
+  std::vector<int> cursor((size_t)T, 0);
+  g.sorted.resize((size_t)std::max(n, 1));
+  // reverse insertion order inside a cell on purpose: the device's order is arbitrary (atomic cursor), the result must not depend on it
+  for (int i = n - 1; i >= 0; --i) {
+    const int s = slot[(size_t)i];
+    Point4 p; p.x = xyz[3 * i]; p.y = xyz[3 * i + 1]; p.z = xyz[3 * i + 2]; p.w = u2f((unsigned)i);
+    g.sorted[(size_t)(g.start[(size_t)s] + cursor[(size_t)s]++)] = p;
+  }
+  v.sorted = g.sorted.data(); v.keys = g.keys.empty() ? nullptr : g.keys.data(); v.cell_start = g.start.data(); v.cell_count = g.count.data();
+}
+}  // namespace
+
+extern "C" {
+
+// k = 5 or 10.  stats[0] = candidates scanned, stats[1] = (z, y) rows visited, stats[2] = 1 when the grid is dense
+int chk_knn(const float* tgt, int n, const float* q, int nq, int k, float max_dist, float cell_override, int force_hash, int* idx, float* sqd, long long* stats) {
+  Grid g;
+  build_grid(tgt, n, cell_override, force_hash, g);
+  g_candidates = 0; g_rows_visited = 0;
+  const float thr2 = max_dist * max_dist;
+  for (int i = 0; i < nq; ++i) {
+    if (k == 10) {
+      TopK<10> tk;
+      knn_search<10>(g.view, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_dist, thr2, tk);
+      for (int j = 0; j < 10; ++j) { idx[(size_t)i * 10 + j] = tk.index(j); sqd[(size_t)i * 10 + j] = tk.dist(j); }
+    } else if (k == 5) {
+      TopK<5> tk;
+      knn_search<5>(g.view, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_dist, thr2, tk);
+      for (int j = 0; j < 5; ++j) { idx[(size_t)i * 5 + j] = tk.index(j); sqd[(size_t)i * 5 + j] = tk.dist(j); }
+    } else {
+      return -1;
+    }
+  }
+  if (stats) { stats[0] = g_candidates; stats[1] = g_rows_visited; stats[2] = g.view.dense; }
+  return 0;
+}
+
+// pts: m x 10 x 3 (row-major).  plane_ok[m], plane[m x 4], line[m]: the two decisions of K3 for every 10-point set
+void chk_fit(const double* pts, int m, double plane_tol, double line_tol, int* plane_ok, double* plane, int* line) {
+  for (int s = 0; s < m; ++s) {
+    double px[10], py[10], pz[10];
+    for (int i = 0; i < 10; ++i) { px[i] = pts[(size_t)s * 30 + 3 * i]; py[i] = pts[(size_t)s * 30 + 3 * i + 1]; pz[i] = pts[(size_t)s * 30 + 3 * i + 2]; }
+    plane_ok[s] = Fit10::form_plane(px, py, pz, plane_tol, plane + 4 * (size_t)s) ? 1 : 0;
+    line[s] = Fit10::is_line(px, py, pz, line_tol) ? 1 : 0;
+  }
+}
+
+// how many Jacobi sweeps the certified test ran before deciding (statistics for DESIGN.md), -1 = ran to the oracle's termination
+long long chk_line_sweeps(const double* pts, int m, double line_tol, int* hist13) {
+  long long total = 0;
+  for (int k = 0; k < 13; ++k) hist13[k] = 0;
+  for (int s = 0; s < m; ++s) {
+    double px[10], py[10], pz[10];
+    for (int i = 0; i < 10; ++i) { px[i] = pts[(size_t)s * 30 + 3 * i]; py[i] = pts[(size_t)s * 30 + 3 * i + 1]; pz[i] = pts[(size_t)s * 30 + 3 * i + 2]; }
+    int sweeps = 0;
+    Fit10::is_line(px, py, pz, line_tol, &sweeps);
+    ++hist13[std::min(sweeps, 12)];
+    total += sweeps;
+  }
+  return total;
+}
+
+}  // extern "C"

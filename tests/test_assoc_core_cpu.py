@@ -1,0 +1,184 @@
+"""The per-query bodies of the association kernels (csrc/pvlm_assoc_core.h), compiled for the host by
+tests/cpp/assoc_core_check.cpp and driven serially: the pruned voxel-grid search must return the exact, tie-broken
+k-NN of the oracle's brute force (indices AND float32 distances, bit for bit), and the plane fit / certified
+collinearity test must take the oracle's decisions.  No GPU: this is where a change of the search or of the fits is
+validated before it is measured."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from panovlm_amd import synthetic as sy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def chk(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("assoc_core") / "assoc_core_check.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out,
+                           os.path.join(ROOT, "tests", "cpp", "assoc_core_check.cpp")])
+    lib = ctypes.CDLL(out)
+    lib.chk_knn.restype = ctypes.c_int
+    lib.chk_line_sweeps.restype = ctypes.c_longlong
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def knn(lib, tgt, q, k, max_dist, cell=0.0, force_hash=0):
+    tgt = np.ascontiguousarray(tgt, np.float32); q = np.ascontiguousarray(q, np.float32)
+    idx = np.empty((len(q), k), np.int32); sqd = np.empty((len(q), k), np.float32); stats = np.zeros(3, np.int64)
+    rc = lib.chk_knn(_p(tgt, ctypes.c_float), len(tgt), _p(q, ctypes.c_float), len(q), k, ctypes.c_float(max_dist), ctypes.c_float(cell), force_hash,
+                     _p(idx, ctypes.c_int), _p(sqd, ctypes.c_float), _p(stats, ctypes.c_longlong))
+    assert rc == 0
+    return idx, sqd, stats
+
+
+def check(lib, oracle, tgt, q, k, max_dist, **kw):
+    idx, sqd, stats = knn(lib, tgt, q, k, max_dist, **kw)
+    oi, od = oracle.knn(tgt, q, k)
+    thr2 = np.float32(max_dist) * np.float32(max_dist)
+    valid = od <= thr2
+    exp_i = np.where(valid, oi, -1)
+    exp_d = np.where(valid, od, np.float32(np.inf))
+    bad = np.argwhere(idx != exp_i)
+    assert len(bad) == 0, (bad[:5], idx[idx != exp_i][:5], exp_i[idx != exp_i][:5], kw)
+    assert np.array_equal(sqd, exp_d)
+    return stats
+
+
+def test_search_equals_brute_force_random_cloud(chk, oracle):
+    rng = np.random.default_rng(11)
+    tgt = (rng.normal(size=(5000, 3)) * 2).astype(np.float32)
+    q = (rng.normal(size=(1500, 3)) * 2.2).astype(np.float32)
+    for kw in ({}, {"force_hash": 1}, {"cell": 0.11}, {"cell": 0.9}, {"cell": 3.0}, {"cell": 0.35, "force_hash": 1}):
+        check(chk, oracle, tgt, q, 10, 1.0, **kw)
+        check(chk, oracle, tgt, q, 5, 0.3, **kw)
+    # a threshold larger than the cloud, queries far outside the grid
+    check(chk, oracle, tgt, q * 4, 10, 30.0, cell=1.5)
+    check(chk, oracle, tgt[:300], q * 3, 5, 2.0)
+
+
+def test_search_vlp_geometry_ties_and_zero_distances(chk, oracle):
+    a = sy.make_scan(2, cols=512)["flat_xyz"]
+    b = sy.make_scan(3, cols=512)["flat_xyz"]
+    s = check(chk, oracle, a, b[::3], 10, 1.0)
+    assert s[2] == 1                                  # the dense table is what the bench clouds use
+    check(chk, oracle, a, b[::3], 10, 1.0, force_hash=1)
+    dup = np.concatenate([a[:2000], a[:2000]])         # exact distance ties, resolved by ascending index
+    check(chk, oracle, dup, b[:800], 10, 1.0)
+    check(chk, oracle, dup, b[:800], 10, 1.0, force_hash=1)
+    check(chk, oracle, a[:3000], a[:3000:2], 5, 0.5)   # queries identical to targets (distance 0)
+    check(chk, oracle, a[:3000], a[:3000:2], 10, 0.05)  # most lists stay incomplete
+
+
+def test_search_voxel_targets_prunes_and_stays_exact(chk, oracle):
+    """The bench's shape: every point of a scan queries the 0.2 m voxel centroids of another scan.  The pruned search scans
+    fewer candidates than the full shells would (the figure DESIGN.md quotes comes from here)."""
+    t = sy.make_scan(5, cols=1024, downsample_targets=0.2)
+    s = sy.make_scan(6, cols=1024, downsample_targets=0.2)
+    q = s["flat_xyz"][::5]
+    stats = check(chk, oracle, t["less_xyz"], q, 10, 1.0)
+    per_query = stats[0] / len(q)
+    print("candidates per query %.1f, rows per query %.1f, targets %d" % (per_query, stats[1] / len(q), len(t["less_xyz"])))
+    assert per_query < 60          # round 2's full shells: ~60 at this density; measured here ~35
+
+
+def test_search_degenerate_clouds(chk, oracle):
+    rng = np.random.default_rng(3)
+    line = np.zeros((400, 3), np.float32); line[:, 0] = np.linspace(-5, 5, 400)
+    plane = np.zeros((900, 3), np.float32); plane[:, :2] = rng.uniform(-3, 3, size=(900, 2))
+    point = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (40, 1))
+    q = rng.uniform(-4, 4, size=(300, 3)).astype(np.float32)
+    for tgt in (line, plane, point, plane[:9], plane[:1]):
+        for kw in ({}, {"force_hash": 1}):
+            if len(tgt) >= 10:
+                check(chk, oracle, tgt, q, 10, 1.5, **kw)
+            if len(tgt) >= 5:
+                check(chk, oracle, tgt, q, 5, 6.0, **kw)
+
+
+def _fits(lib, pts, plane_tol, line_tol):
+    pts = np.ascontiguousarray(pts, np.float64)
+    m = len(pts)
+    ok = np.empty(m, np.int32); plane = np.empty((m, 4)); line = np.empty(m, np.int32)
+    lib.chk_fit(_p(pts, ctypes.c_double), m, ctypes.c_double(plane_tol), ctypes.c_double(line_tol), _p(ok, ctypes.c_int), _p(plane, ctypes.c_double), _p(line, ctypes.c_int))
+    return ok.astype(bool), plane, line.astype(bool)
+
+
+def _point_sets(rng, m):
+    """10-point neighbourhoods from clean planes to clean lines, with everything in between (the decision w2 > 3 w1 has to be
+    taken on a continuum of eigenvalue ratios) and degenerate sets."""
+    sets = []
+    for _ in range(m):
+        kind = rng.integers(0, 6)
+        c = rng.uniform(-20, 20, size=3)
+        B = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        if kind == 0:      # planar patch, isotropic
+            s = np.array([rng.uniform(0.05, 0.5), rng.uniform(0.05, 0.5), rng.uniform(0, 0.01)])
+        elif kind == 1:    # elongated patch: ratio of the two large eigenvalues around the threshold 3 (std ratio sqrt 3)
+            a = rng.uniform(0.05, 0.5); s = np.array([a, a / np.sqrt(3.0) * rng.uniform(0.8, 1.25), rng.uniform(0, 0.01)])
+        elif kind == 2:    # line
+            s = np.array([rng.uniform(0.1, 1.0), rng.uniform(0, 0.005), rng.uniform(0, 0.005)])
+        elif kind == 3:    # blob
+            s = rng.uniform(0.05, 0.5, size=3)
+        elif kind == 4:    # two equal eigenvalues (the slow case of Jacobi)
+            a = rng.uniform(0.05, 0.5); s = np.array([a, a, a * rng.uniform(0, 1)])
+        else:              # exactly coplanar / collinear lattices
+            g = rng.integers(-3, 4, size=(10, 3)).astype(np.float64)
+            g[:, 2] = 0
+            if rng.integers(0, 2):
+                g[:, 1] = 0
+            sets.append(g * 0.125 + np.round(c))
+            continue
+        sets.append(c + (rng.normal(size=(10, 3)) * s) @ B.T)
+    return np.array(sets)
+
+
+def test_fits_take_the_oracles_decisions(chk, oracle):
+    rng = np.random.default_rng(21)
+    pts = _point_sets(rng, 6000)
+    for plane_tol in (0.05, 0.01):
+        ok, plane, line = _fits(chk, pts, plane_tol, 3.0)
+        for s in range(len(pts)):
+            o_ok, o_plane = oracle.form_plane_lsq(pts[s], plane_tol)
+            o_line = oracle.form_line_pca(pts[s], 3.0)[0]
+            assert bool(o_ok) == bool(ok[s]), s
+            if o_ok:
+                assert np.array_equal(np.asarray(o_plane), plane[s]), s          # same arithmetic: bit for bit
+            assert bool(o_line) == bool(line[s]), (s, pts[s])
+    assert 0.1 < line.mean() < 0.9 and 0.1 < ok.mean() < 0.9                   # both branches of both tests were exercised
+
+
+def test_certified_line_test_near_the_threshold(chk, oracle):
+    """Sets whose eigenvalue ratio sits within 1e-9 ... 1e-15 of the threshold: the certified early exit must hand these to the
+    full sweep and still agree with the oracle."""
+    rng = np.random.default_rng(8)
+    sets = []
+    for k in range(1500):
+        # ten points symmetric about the origin: the scatter matrix is diagonal in the chosen basis with exactly known entries
+        a = rng.uniform(0.1, 1.0)
+        eps = 10.0 ** rng.uniform(-15, -6) * rng.choice([-1, 1])
+        b = a / np.sqrt(3.0) * (1 + eps)
+        base = np.array([[a, 0, 0], [-a, 0, 0], [0, b, 0], [0, -b, 0], [0, 0, 0.01], [0, 0, -0.01], [a, 0, 0], [-a, 0, 0], [0, b, 0], [0, -b, 0]])
+        B = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        sets.append(base @ B.T + rng.uniform(-5, 5, size=3))
+    pts = np.array(sets)
+    _, _, line = _fits(chk, pts, 0.05, 3.0)
+    exp = np.array([bool(oracle.form_line_pca(p, 3.0)[0]) for p in pts])
+    assert np.array_equal(line, exp)
+    assert 0.2 < exp.mean() < 0.8
+
+
+def test_certified_line_test_saves_sweeps(chk):
+    rng = np.random.default_rng(5)
+    pts = np.ascontiguousarray(_point_sets(rng, 4000))
+    hist = np.zeros(13, np.int32)
+    total = chk.chk_line_sweeps(_p(pts, ctypes.c_double), len(pts), ctypes.c_double(3.0), _p(hist, ctypes.c_int))
+    print("Jacobi sweeps per set: %.2f, histogram %s" % (total / len(pts), hist.tolist()))
+    assert total / len(pts) < 4.0          # the uncertified loop runs 6-10 sweeps to an exactly zero off-diagonal part

@@ -169,6 +169,21 @@ def test_graph_of_a_step_equals_eager_steps():
         pass
     step(); ctx.synchronize()
     assert np.array_equal(packed.cpu().numpy(), replay)
+    # host-pointer entry points are not capturable (a staged copy would replay whatever the pinned arena holds by then; a
+    # synchronisation invalidates the capture): refused with PVLM_ERR_STATE, the capture itself survives and replays correctly
+    ctx.graph_begin()
+    with pytest.raises(pv.PvlmError):
+        ctx.set_poses(aa, t)
+    with pytest.raises(pv.PvlmError):
+        rs.eval(jac=False)
+    with pytest.raises(pv.PvlmError):
+        ctx.synchronize()
+    step()
+    g2 = ctx.graph_end()
+    packed.zero_(); torch.cuda.synchronize()
+    g2.launch(); ctx.synchronize()
+    assert np.array_equal(packed.cpu().numpy(), replay)
+    g2.close()
     g.close(); neq.close(); neq2.close(); rs.close()
     ctx.close()
 
