@@ -64,23 +64,34 @@ def build(force=False, verbose=False):
 
 def build_variant(tag, defines):
     """A measured variant of the library: build/var/libpvlm_<tag>.so with extra -D switches (e.g. ["-DPVLM_NT_LOADS=0"]), selected at
-    run time through PVLM_LIB (tools/ab_eval_loads.sh).  Only the sources that mention one of the switches are recompiled; the other
-    objects are those of the in-tree build.  python -m panovlm_amd.build --variant temporal -DPVLM_NT_LOADS=0"""
+    run time through PVLM_LIB (tools/ab_eval_loads.sh).  A source is recompiled when it, or any header under csrc/, mentions one of
+    the switches (a switch consumed in a header reaches every source that may include it); the other objects are those of the
+    in-tree build.  Same flags as the in-tree build (PVLM_DEFINES included).  A switch nobody mentions is an error: the variant
+    would silently equal the baseline.  python -m panovlm_amd.build --variant temporal -DPVLM_NT_LOADS=0"""
     build(force=False)
     vdir = os.path.join(HERE, "..", "build", "var")
     os.makedirs(vdir, exist_ok=True)
     names = [d[2:].split("=")[0] for d in defines if d.startswith("-D")]
+    headers = {f: open(os.path.join(CSRC, f)).read() for f in os.listdir(CSRC) if f.endswith(".h")}
+    in_header = [n for n in names if any(n in t for t in headers.values())]
+    mentioned = set(in_header)
     objs = []
     for src in sources():
         base = os.path.basename(src)
         obj = os.path.join(HERE, "build", base + ".o")
-        if any(n in open(src).read() for n in names):
+        text = open(src).read()
+        mentioned.update(n for n in names if n in text)
+        if any(n in text for n in names) or in_header:
             obj = os.path.join(vdir, base + "." + tag + ".o")
-            flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-Wno-unused-result"] + list(defines)
+            flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+            flags += os.environ.get("PVLM_DEFINES", "").split() + list(defines)
             if base in ("pvlm_assoc.hip", "pvlm_lines.hip", "pvlm_mvs.hip"):
                 flags.append("-ffp-contract=off")
             subprocess.check_call([_hipcc()] + flags + ["-c", src, "-o", obj])
         objs.append(obj)
+    missing = [n for n in names if n not in mentioned]
+    if missing:
+        raise RuntimeError("no source or header under csrc/ mentions %s: the variant would equal the baseline" % ", ".join(missing))
     out = os.path.join(vdir, "libpvlm_%s.so" % tag)
     subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     return out

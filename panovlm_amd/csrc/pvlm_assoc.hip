@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_scan_tiles(int T, const int* __restrict
 // (top-k is ordered by (distance, original index)).
 struct GridDesc {
   const float* xyz; int n; int dense, nx, ny, nz; int T;
-  float ox, oy, oz, inv_h;
+  float ox, oy, oz, inv_h, inv_hx;   // inv_hx: dense tables are xf times finer along x (nx counts the fine cells)
   unsigned long long* keys; int* count; int* start; int* cursor; int* slot; float4* sorted;
 };
 struct GridBlock { int cloud, first; };   // 256 points of one cloud
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_grid_count(const GridDesc* __restrict__
   if (i >= d.n) return;
   const float x = d.xyz[3 * i], y = d.xyz[3 * i + 1], z = d.xyz[3 * i + 2];
   if (d.dense) {
-    const int ix = min(max(cell_of(x, d.ox, d.inv_h), 0), d.nx - 1), iy = min(max(cell_of(y, d.oy, d.inv_h), 0), d.ny - 1),
+    const int ix = min(max(cell_of(x, d.ox, d.inv_hx), 0), d.nx - 1), iy = min(max(cell_of(y, d.oy, d.inv_h), 0), d.ny - 1),
               iz = min(max(cell_of(z, d.oz, d.inv_h), 0), d.nz - 1);
     const int c = (iz * d.ny + iy) * d.nx + ix;
     d.slot[i] = c;
@@ -179,10 +179,18 @@ __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* 
   for (int k = 0; k < K; ++k) { idx[(size_t)i * K + k] = tk.index(k); sqd[(size_t)i * K + k] = tk.dist(k); }
 }
 
+// Occupancy targets (waves per SIMD) of the two kernels: A/B-measured with panovlm_amd.build --variant (profiles/r3_assoc_variants.txt)
+#ifndef PVLM_K2_WAVES
+#define PVLM_K2_WAVES 6     // 80 VGPRs (2 spilled dwords outside the candidate loop); unconstrained: 82 VGPRs = 5 waves
+#endif
+#ifndef PVLM_K3_WAVES
+#define PVLM_K3_WAVES 2     // 195 VGPRs; 3 waves = 168 VGPRs + 15 spilled doubles
+#endif
+
 // K2 — grid: x = chunk of 256 queries, y = pair in batch.  Exact 10-NN of every query; slot 9 is -1
 // when fewer than 10 targets lie within dist_threshold (LidarFeatureAssociate.cpp:577).  Kept apart
 // from K3 so that the register-hungry fp64 fits do not set the occupancy of the search.
-__global__ __launch_bounds__(256) void k_knn_pairs(const PairDesc* __restrict__ pairs, float dist_threshold, int* __restrict__ nn_tmp, long long tmp_rows) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K2_WAVES, 8))) void k_knn_pairs(const PairDesc* __restrict__ pairs, float dist_threshold, int* __restrict__ nn_tmp, long long tmp_rows) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= pd.nq) return;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void k_knn_pairs(const PairDesc* __restrict__ 
 
 // K3 — class test, 10x3 plane fit, collinearity test, candidate record, accept flag and the
 // per-chunk accept counts for the ordered compaction.
-__global__ __launch_bounds__(256) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAVES, 8))) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp,
                                                    double* __restrict__ rec_tmp, unsigned char* __restrict__ flag_tmp,
                                                    int* __restrict__ chunk_count, long long tmp_rows) {
   const PairDesc& pd = pairs[blockIdx.y];
@@ -315,7 +323,7 @@ struct CloudPlan {
   const float* xyz = nullptr; const float* tag = nullptr;
   bool grid = false;
   float h = 0.f, origin[3] = {0, 0, 0};
-  int dense = 0, nx = 0, ny = 0, nz = 0;
+  int dense = 0, nx = 0, ny = 0, nz = 0, xf = 1;
   long long T = 0;
   // byte offsets: persistent slab (o_*) and build scratch (s_*)
   size_t o_xyz = 0, o_tag = 0, o_count = 0, o_keys = 0, o_start = 0, o_sorted = 0, s_cursor = 0, s_slot = 0;
@@ -351,8 +359,15 @@ static pvlm_status cloud_plan(pvlm_ctx* ctx, CloudPlan& c, int n, const float* x
   for (int k = 0; k < 3; ++k) dims[k] = (long long)std::ceil((mx[k] - c.origin[k]) * inv_h) + 2;
   const long long ncells = dims[0] * dims[1] * dims[2];
   const bool dense = ncells <= std::max<long long>(64ll * n, 4096) && ncells <= (4ll << 20) && !getenv("PVLM_FORCE_HASH");
-  if (dense) { c.T = ncells + 1; c.dense = 1; c.nx = (int)dims[0]; c.ny = (int)dims[1]; c.nz = (int)dims[2]; }
-  else { c.T = 1024; while (c.T < 2ll * n) c.T <<= 1; }
+  if (dense) {
+    // cells xf times finer along x, the direction in which a row is one contiguous run (pvlm_assoc_core.h): as fine as the
+    // table limits allow, 4 by default (PVLM_CELL_XF)
+    int xf = 4;
+    if (const char* e = getenv("PVLM_CELL_XF")) xf = std::min(std::max(atoi(e), 1), 16);
+    while (xf > 1 && !(ncells * xf <= std::max<long long>(64ll * n, 4096) && ncells * xf <= (4ll << 20))) --xf;
+    c.xf = xf;
+    c.T = ncells * xf + 1; c.dense = 1; c.nx = (int)dims[0] * xf; c.ny = (int)dims[1]; c.nz = (int)dims[2];
+  } else { c.T = 1024; while (c.T < 2ll * n) c.T <<= 1; }
   return PVLM_OK;
 }
 
@@ -368,7 +383,7 @@ static CloudView view_of(const pvlm_cloud& c) {
   CloudView v;
   v.sorted = reinterpret_cast<const Point4*>(c.d_sorted); v.keys = c.d_keys; v.cell_start = c.d_cell_start; v.cell_count = c.d_cell_count;
   v.xyz = c.d_xyz; v.tag = c.d_tag; v.n = c.n; v.mask = c.table_size - 1;
-  v.dense = c.dense; v.nx = c.nx; v.ny = c.ny; v.nz = c.nz;
+  v.dense = c.dense; v.nx = c.nx; v.ny = c.ny; v.nz = c.nz; v.xf = c.dense ? std::max(c.xf, 1) : 1;
   v.ox = c.origin[0]; v.oy = c.origin[1]; v.oz = c.origin[2]; v.h = c.cell; v.inv_h = c.cell > 0 ? 1.0f / c.cell : 0.f;
   return v;
 }
@@ -548,7 +563,7 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
     if (!c.grid) return;
     GridDesc& D = hd[(size_t)g];
     D.xyz = (const float*)(d_slab + c.o_xyz); D.n = c.n; D.dense = c.dense; D.nx = c.nx; D.ny = c.ny; D.nz = c.nz; D.T = (int)c.T;
-    D.ox = c.origin[0]; D.oy = c.origin[1]; D.oz = c.origin[2]; D.inv_h = 1.0f / c.h;
+    D.ox = c.origin[0]; D.oy = c.origin[1]; D.oz = c.origin[2]; D.inv_h = 1.0f / c.h; D.inv_hx = D.inv_h * (float)c.xf;
     D.keys = c.dense ? nullptr : (unsigned long long*)(d_slab + c.o_keys);
     D.count = (int*)(d_slab + c.o_count); D.start = (int*)(d_slab + c.o_start); D.sorted = (float4*)(d_slab + c.o_sorted);
     D.cursor = (int*)(d_scr + c.s_cursor); D.slot = (int*)(d_scr + c.s_slot);
@@ -609,7 +624,7 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
     if (p.tag) c.d_tag = (float*)(d_slab + p.o_tag);
     if (!p.grid) return;
     c.cell = p.h; for (int q = 0; q < 3; ++q) c.origin[q] = p.origin[q];
-    c.table_size = (int)p.T; c.dense = p.dense; c.nx = p.nx; c.ny = p.ny; c.nz = p.nz;
+    c.table_size = (int)p.T; c.dense = p.dense; c.nx = p.nx; c.ny = p.ny; c.nz = p.nz; c.xf = p.xf;
     c.d_keys = p.dense ? nullptr : (unsigned long long*)(d_slab + p.o_keys);
     c.d_cell_start = (int*)(d_slab + p.o_start); c.d_cell_count = (int*)(d_slab + p.o_count); c.d_sorted = (float4*)(d_slab + p.o_sorted);
   };

@@ -37,6 +37,7 @@ struct CloudView {
   const float* tag;
   int n, mask;
   int dense, nx, ny, nz;   // dense != 0: cells addressed directly as (iz*ny + iy)*nx + ix, no hashing
+  int xf;                  // dense tables: cells are xf times finer along x (nx counts the FINE cells of a row); hashed tables: 1
   float ox, oy, oz, h, inv_h;
 };
 
@@ -111,12 +112,19 @@ struct TopK {
 // skipped, and the x-run of a surviving row is clipped to the cells the remaining budget can reach.  A skipped cell only
 // holds points with d2 > the k-th distance, which can never enter the list (a tie enters only at EQUAL distance), so the
 // result is still the exact, tie-broken k-NN; the slack covers the float rounding of the points' cell assignment.
+// Dense tables are `xf` times finer along x than along y / z: the cells of a (z, y) row stay one contiguous run of the sorted
+// array, so the finer x resolution costs no extra row — it only lets the clip cut a run to (almost) exactly the interval the
+// budget reaches.  Shells, gaps and the termination bound work on the coarse cells; visit() receives FINE x indices.
 template <int K, class Visit>
 PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float max_dist, float thr2, TopK<K>& tk, Visit&& visit) {
   tk.init();
   if (cv.n <= 0) return;
-  const int cx = cell_of(qx, cv.ox, cv.inv_h), cy = cell_of(qy, cv.oy, cv.inv_h), cz = cell_of(qz, cv.oz, cv.inv_h);
-  const float fx = (qx - cv.ox) * cv.inv_h - (float)cx, fy = (qy - cv.oy) * cv.inv_h - (float)cy, fz = (qz - cv.oz) * cv.inv_h - (float)cz;
+  const int xf = cv.xf;
+  const float ux = (qx - cv.ox) * cv.inv_h;                                   // x of the query in coarse cells
+  const int cxf = cell_of(qx, cv.ox, cv.inv_h * (float)xf);                   // its fine cell, as the grid build computes it
+  const int cx = cxf >= 0 ? cxf / xf : -((-cxf + xf - 1) / xf);               // coarse cell = floor(fine / xf)
+  const int cy = cell_of(qy, cv.oy, cv.inv_h), cz = cell_of(qz, cv.oz, cv.inv_h);
+  const float fx = ux - (float)cx, fy = (qy - cv.oy) * cv.inv_h - (float)cy, fz = (qz - cv.oz) * cv.inv_h - (float)cz;
   const float lo_min = fminf(fminf(fx, fy), fz), hi_min = fminf(fminf(1.f - fx, 1.f - fy), 1.f - fz);
   const float inside = fminf(lo_min, hi_min);  // distance (in cells) from q to the nearest face of its own cell
   const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
@@ -135,20 +143,20 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
         const float lb = gym * gym + gzm * gzm;                       // <= d2 of every point of the row
         const float budget = fminf(thr2, tk.dist(K - 1)) * 1.00001f;   // dist(K-1) = +inf while the list is not full
         if (lb > budget) continue;
-        const float reach = (sqrtf(budget - lb) + slack) * cv.inv_h;  // cells the budget still reaches along x
-        const int xa = cx + (int)floorf(fx - reach), xb = cx + (int)floorf(fx + reach);
+        const float reach = (sqrtf(budget - lb) + slack) * cv.inv_h;  // (coarse) cells the budget still reaches along x
+        const int xa = (int)floorf((ux - reach) * (float)xf), xb = (int)floorf((ux + reach) * (float)xf);   // fine cells
         const bool face = (dz == -r || dz == r || dy == -r || dy == r);
         // a face row of the shell is one x-run; an interior row only owns its two end cells (one call site for both:
         // the candidate loop is inlined once)
         for (int part = 0; part < 2; ++part) {
-          int x0, x1;
+          int x0, x1;   // fine cells
           if (face) {
             if (part) break;
-            x0 = xa > cx - r ? xa : cx - r; x1 = xb < cx + r ? xb : cx + r;
+            x0 = (cx - r) * xf; x1 = (cx + r + 1) * xf - 1;
           } else {
-            x0 = x1 = part ? cx + r : cx - r;
-            if (x0 < xa || x0 > xb) continue;
+            x0 = (part ? cx + r : cx - r) * xf; x1 = x0 + xf - 1;
           }
+          x0 = x0 > xa ? x0 : xa; x1 = x1 < xb ? x1 : xb;
           if (x0 <= x1) { PVLM_ASSOC_STATS_ROW(); visit(z, y, x0, x1); }
         }
       }
@@ -360,19 +368,62 @@ struct Fit10 {
     return ok;
   }
 
+  // Closed-form screen of the collinearity decision.  The eigenvalues of the symmetric 3x3 scatter matrix by the trigonometric
+  // solution of its characteristic cubic (Smith 1961): q = tr/3, p^2 = |A - qI|_F^2 / 6, r = det(A - qI) / (2 p^3),
+  // phi = acos(r) / 3 in [0, pi/3],  l3 = q + 2 p cos(phi),  l1 = q + 2 p cos(phi + 2 pi/3),  l2 = 3 q - l1 - l3.
+  // acos by the degree-7 minimax form sqrt(1 - x) P(x) (Abramowitz & Stegun 4.4.46, |error| <= 2e-8), cos / sin of phi by
+  // their Taylor polynomials up to x^12 / x^13 (remainder < 3e-11 on [0, pi/3]); the rounding of r is amplified by acos near
+  // |r| = 1 to at most sqrt(2 * 1e-15) / 3 = 1.5e-8 in phi.  Every eigenvalue is therefore within 2 p (3e-8) <= 6e-8 l3 of
+  // the exact one (measured against LAPACK over 10^6 matrices in tests/test_assoc_core_cpu.py: <= 2e-8 l3), while the converged
+  // Jacobi loop of the reference restatement is within 1e-13.  The screen answers only when l3 - tol l2 clears a guard of
+  // 1e-5 (l3 + tol |l2|) — 160 times its error — and returns -1 otherwise: then, and only then, the exact loop runs.
+  static PVLM_HD int line_screen(double a00, double a01, double a02, double a11, double a12, double a22, double tol, double* eig = nullptr) {
+    const double q = ((a00 + a11) + a22) * (1.0 / 3.0);
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p1 = (a01 * a01 + a02 * a02) + a12 * a12;
+    const double p2 = ((b00 * b00 + b11 * b11) + b22 * b22) + 2.0 * p1;
+    if (!(p2 > 1e-24 * (q * q) && p2 > 1e-280 && p2 < 1e280)) return -1;   // (nearly) a multiple of the identity, or not finite
+    const double p = sqrt(p2 * (1.0 / 6.0));
+    const double det = (b00 * (b11 * b22 - a12 * a12) - a01 * (a01 * b22 - a12 * a02)) + a02 * (a01 * a12 - b11 * a02);
+    double r = det / (2.0 * ((p * p) * p));
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double x = fabs(r);
+    double P = -0.0012624911;
+    P = P * x + 0.0066700901; P = P * x - 0.0170881256; P = P * x + 0.0308918810; P = P * x - 0.0501743046;
+    P = P * x + 0.0889789874; P = P * x - 0.2145988016; P = P * x + 1.5707963050;
+    double ac = sqrt(1.0 - x) * P;                                  // acos(|r|)
+    if (r < 0.0) ac = 3.14159265358979323846 - ac;
+    const double phi = ac * (1.0 / 3.0), z = phi * phi;
+    double c = 1.0 / 479001600.0;
+    c = c * z - 1.0 / 3628800.0; c = c * z + 1.0 / 40320.0; c = c * z - 1.0 / 720.0; c = c * z + 1.0 / 24.0; c = c * z - 0.5; c = c * z + 1.0;
+    double sn = 1.0 / 6227020800.0;
+    sn = sn * z - 1.0 / 39916800.0; sn = sn * z + 1.0 / 362880.0; sn = sn * z - 1.0 / 5040.0; sn = sn * z + 1.0 / 120.0; sn = sn * z - 1.0 / 6.0; sn = sn * z + 1.0;
+    sn = sn * phi;
+    const double l3 = q + 2.0 * p * c;
+    const double l1 = q + 2.0 * p * (-0.5 * c - 0.86602540378443864676 * sn);
+    const double l2 = (3.0 * q - l1) - l3;
+    if (eig) { eig[0] = l1; eig[1] = l2; eig[2] = l3; }
+    const double margin = l3 - tol * l2, guard = 1e-5 * (fabs(l3) + fabs(tol * l2));
+    if (margin > guard) return 1;
+    if (margin < -guard) return 0;
+    return -1;
+  }
+
   // FormLine(points, 3.0) is non-zero  <=>  largest eigenvalue > tol * middle eigenvalue of the
   // scatter matrix (base/Geometry.hpp:220-260); cyclic Jacobi, fixed sweep order (0,1),(0,2),(1,2) — the oracle's
   // eig_sym3_jacobi, which sweeps until the off-diagonal part is EXACTLY zero (8-10 sweeps of three rotations with two
-  // divisions and two square roots each: the larger half of round 2's K3).
+  // divisions and two square roots each: the larger half of round 2's K3).  Only the DECISION w2 > tol * w1 of the
+  // converged sweep is needed: line_screen() above gives it for all but a ~1e-5 band around the threshold; inside the band
+  // the loop below runs, itself with a certified exit:
   //
-  // Certified early exit.  Only the DECISION w2 > tol * w1 of the converged sweep is needed.  Before each sweep the
+  // Certified early exit.  Before each sweep the
   // current diagonal d (sorted) and the off-diagonal Frobenius norm E = sqrt(2 (a01^2 + a02^2 + a12^2)) bracket the exact
   // eigenvalues of the current matrix: |lambda_i - d_i| <= E (Weyl).  The remaining sweeps are orthogonal similarity
   // transforms carried out in fp64, so what the converged loop returns differs from lambda_i by no more than its
   // accumulated rounding, < 1e-13 |lambda|_max for at most 36 rotations; `guard` below is 1e-11 of the largest diagonal
   // entry.  When the brackets already decide the comparison the loop stops — the answer is the one the full loop would
-  // give — otherwise it sweeps on, down to the oracle's own termination.  Typical: decided after 2-3 sweeps.
-  static PVLM_HD bool is_line(const double* px, const double* py, const double* pz, double tol, int* sweeps_done = nullptr) {
+  // give — otherwise it sweeps on, down to the oracle's own termination.
+  static PVLM_HD bool is_line(const double* px, const double* py, const double* pz, double tol, int* sweeps_done = nullptr, bool screen = true) {
     double cx = 0.0, cy = 0.0, cz = 0.0;
 #pragma unroll
     for (int i = 0; i < 10; ++i) { cx = cx + px[i]; cy = cy + py[i]; cz = cz + pz[i]; }
@@ -385,6 +436,10 @@ struct Fit10 {
       a11 = a11 + dy * dy; a12 = a12 + dy * dz; a22 = a22 + dz * dz;
     }
     // only the upper triangle is accumulated: S[r][c] += d[r]*d[c] is symmetric bit for bit
+    if (screen) {
+      const int fast = line_screen(a00, a01, a02, a11, a12, a22, tol);
+      if (fast >= 0) { if (sweeps_done) *sweeps_done = 0; return fast != 0; }
+    }
     for (int sweep = 0; sweep < 12; ++sweep) {
       const double off = a01 * a01 + a02 * a02 + a12 * a12;
       if (off == 0.0) break;

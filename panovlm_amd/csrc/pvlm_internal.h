@@ -173,7 +173,8 @@ struct pvlm_cloud {
   float cell = 0.f;
   float origin[3] = {0, 0, 0};
   int table_size = 0;            // hash: power-of-two slots; dense: ncells + 1
-  int dense = 0, nx = 0, ny = 0, nz = 0;  // dense grid when the bounding box is small enough
+  int dense = 0, nx = 0, ny = 0, nz = 0;  // dense grid when the bounding box is small enough (nx: fine cells, see xf)
+  int xf = 1;                             // dense grid: cells are xf times finer along x
   unsigned long long* d_keys = nullptr;  // table_size, ~0 = empty
   int* d_cell_start = nullptr;   // table_size
   int* d_cell_count = nullptr;   // table_size

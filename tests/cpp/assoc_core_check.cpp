@@ -25,7 +25,7 @@ struct Grid {
 };
 
 // cloud_plan + k_grid_count / k_grid_scan / k_grid_scatter of csrc/pvlm_assoc.hip, serial
-void build_grid(const float* xyz, int n, float cell_override, int force_hash, Grid& g) {
+void build_grid(const float* xyz, int n, float cell_override, int force_hash, int xf_want, Grid& g) {
   float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
   for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], xyz[3 * i + k]); mx[k] = std::max(mx[k], xyz[3 * i + k]); }
   float e[3];
@@ -44,14 +44,19 @@ void build_grid(const float* xyz, int n, float cell_override, int force_hash, Gr
   CloudView& v = g.view;
   v = CloudView();
   v.n = n; v.xyz = xyz; v.tag = nullptr; v.ox = origin[0]; v.oy = origin[1]; v.oz = origin[2]; v.h = h; v.inv_h = inv_h;
-  v.dense = dense ? 1 : 0; v.nx = (int)dims[0]; v.ny = (int)dims[1]; v.nz = (int)dims[2];
+  int xf = 1;
+  if (dense) {
+    xf = std::min(std::max(xf_want, 1), 16);
+    while (xf > 1 && !(ncells * xf <= std::max<long long>(64ll * n, 4096) && ncells * xf <= (4ll << 20))) --xf;
+  }
+  v.dense = dense ? 1 : 0; v.nx = (int)dims[0] * xf; v.ny = (int)dims[1]; v.nz = (int)dims[2]; v.xf = xf;
   std::vector<int> slot((size_t)n);
   long long T;
   if (dense) {
-    T = ncells + 1;
+    T = ncells * xf + 1;
     g.count.assign((size_t)T, 0); g.start.assign((size_t)T, 0);
     for (int i = 0; i < n; ++i) {
-      const int ix = std::min(std::max(cell_of(xyz[3 * i], v.ox, inv_h), 0), v.nx - 1), iy = std::min(std::max(cell_of(xyz[3 * i + 1], v.oy, inv_h), 0), v.ny - 1),
+      const int ix = std::min(std::max(cell_of(xyz[3 * i], v.ox, inv_h * (float)xf), 0), v.nx - 1), iy = std::min(std::max(cell_of(xyz[3 * i + 1], v.oy, inv_h), 0), v.ny - 1),
                 iz = std::min(std::max(cell_of(xyz[3 * i + 2], v.oz, inv_h), 0), v.nz - 1);
       slot[(size_t)i] = (iz * v.ny + iy) * v.nx + ix;
       ++g.count[(size_t)slot[(size_t)i]];
@@ -86,10 +91,10 @@ void build_grid(const float* xyz, int n, float cell_override, int force_hash, Gr
 
 extern "C" {
 
-// k = 5 or 10.  stats[0] = candidates scanned, stats[1] = (z, y) rows visited, stats[2] = 1 when the grid is dense
-int chk_knn(const float* tgt, int n, const float* q, int nq, int k, float max_dist, float cell_override, int force_hash, int* idx, float* sqd, long long* stats) {
+// k = 5 or 10; xf = refinement of the dense table along x (the library default is 4).  stats[0] = candidates scanned, stats[1] = (z, y) rows visited, stats[2] = 1 when the grid is dense
+int chk_knn(const float* tgt, int n, const float* q, int nq, int k, float max_dist, float cell_override, int force_hash, int xf, int* idx, float* sqd, long long* stats) {
   Grid g;
-  build_grid(tgt, n, cell_override, force_hash, g);
+  build_grid(tgt, n, cell_override, force_hash, xf, g);
   g_candidates = 0; g_rows_visited = 0;
   const float thr2 = max_dist * max_dist;
   for (int i = 0; i < nq; ++i) {
@@ -119,15 +124,21 @@ void chk_fit(const double* pts, int m, double plane_tol, double line_tol, int* p
   }
 }
 
+// the closed-form screen alone on m symmetric matrices (a00 a01 a02 a11 a12 a22): decision (-1 = left to the exact loop) and the
+// eigenvalues it computed — accuracy and fall-back rate for the test
+void chk_line_screen(const double* A, int m, double tol, int* decision, double* eig) {
+  for (int s = 0; s < m; ++s) decision[s] = Fit10::line_screen(A[6 * s], A[6 * s + 1], A[6 * s + 2], A[6 * s + 3], A[6 * s + 4], A[6 * s + 5], tol, eig + 3 * (size_t)s);
+}
+
 // how many Jacobi sweeps the certified test ran before deciding (statistics for DESIGN.md), -1 = ran to the oracle's termination
-long long chk_line_sweeps(const double* pts, int m, double line_tol, int* hist13) {
+long long chk_line_sweeps(const double* pts, int m, double line_tol, int screen, int* hist13) {
   long long total = 0;
   for (int k = 0; k < 13; ++k) hist13[k] = 0;
   for (int s = 0; s < m; ++s) {
     double px[10], py[10], pz[10];
     for (int i = 0; i < 10; ++i) { px[i] = pts[(size_t)s * 30 + 3 * i]; py[i] = pts[(size_t)s * 30 + 3 * i + 1]; pz[i] = pts[(size_t)s * 30 + 3 * i + 2]; }
     int sweeps = 0;
-    Fit10::is_line(px, py, pz, line_tol, &sweeps);
+    Fit10::is_line(px, py, pz, line_tol, &sweeps, screen != 0);
     ++hist13[std::min(sweeps, 12)];
     total += sweeps;
   }

@@ -30,10 +30,10 @@ def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def knn(lib, tgt, q, k, max_dist, cell=0.0, force_hash=0):
+def knn(lib, tgt, q, k, max_dist, cell=0.0, force_hash=0, xf=4):
     tgt = np.ascontiguousarray(tgt, np.float32); q = np.ascontiguousarray(q, np.float32)
     idx = np.empty((len(q), k), np.int32); sqd = np.empty((len(q), k), np.float32); stats = np.zeros(3, np.int64)
-    rc = lib.chk_knn(_p(tgt, ctypes.c_float), len(tgt), _p(q, ctypes.c_float), len(q), k, ctypes.c_float(max_dist), ctypes.c_float(cell), force_hash,
+    rc = lib.chk_knn(_p(tgt, ctypes.c_float), len(tgt), _p(q, ctypes.c_float), len(q), k, ctypes.c_float(max_dist), ctypes.c_float(cell), force_hash, xf,
                      _p(idx, ctypes.c_int), _p(sqd, ctypes.c_float), _p(stats, ctypes.c_longlong))
     assert rc == 0
     return idx, sqd, stats
@@ -56,7 +56,7 @@ def test_search_equals_brute_force_random_cloud(chk, oracle):
     rng = np.random.default_rng(11)
     tgt = (rng.normal(size=(5000, 3)) * 2).astype(np.float32)
     q = (rng.normal(size=(1500, 3)) * 2.2).astype(np.float32)
-    for kw in ({}, {"force_hash": 1}, {"cell": 0.11}, {"cell": 0.9}, {"cell": 3.0}, {"cell": 0.35, "force_hash": 1}):
+    for kw in ({}, {"force_hash": 1}, {"cell": 0.11}, {"cell": 0.9}, {"cell": 3.0}, {"cell": 0.35, "force_hash": 1}, {"xf": 1}, {"xf": 3, "cell": 0.5}, {"xf": 16, "cell": 1.1}):
         check(chk, oracle, tgt, q, 10, 1.0, **kw)
         check(chk, oracle, tgt, q, 5, 0.3, **kw)
     # a threshold larger than the cloud, queries far outside the grid
@@ -68,6 +68,8 @@ def test_search_vlp_geometry_ties_and_zero_distances(chk, oracle):
     a = sy.make_scan(2, cols=512)["flat_xyz"]
     b = sy.make_scan(3, cols=512)["flat_xyz"]
     s = check(chk, oracle, a, b[::3], 10, 1.0)
+    check(chk, oracle, a, b[::3], 10, 1.0, xf=1)
+    check(chk, oracle, a, b[::3], 10, 1.0, xf=7)
     assert s[2] == 1                                  # the dense table is what the bench clouds use
     check(chk, oracle, a, b[::3], 10, 1.0, force_hash=1)
     dup = np.concatenate([a[:2000], a[:2000]])         # exact distance ties, resolved by ascending index
@@ -83,10 +85,12 @@ def test_search_voxel_targets_prunes_and_stays_exact(chk, oracle):
     t = sy.make_scan(5, cols=1024, downsample_targets=0.2)
     s = sy.make_scan(6, cols=1024, downsample_targets=0.2)
     q = s["flat_xyz"][::5]
+    coarse = check(chk, oracle, t["less_xyz"], q, 10, 1.0, xf=1)
     stats = check(chk, oracle, t["less_xyz"], q, 10, 1.0)
+    print("x-refinement 1: candidates per query %.1f" % (coarse[0] / len(q)))
     per_query = stats[0] / len(q)
     print("candidates per query %.1f, rows per query %.1f, targets %d" % (per_query, stats[1] / len(q), len(t["less_xyz"])))
-    assert per_query < 60          # round 2's full shells: ~60 at this density; measured here ~35
+    assert per_query < 45          # full shells (round 2): ~90; row pruning: ~50; x-refined cells: ~35
 
 
 def test_search_degenerate_clouds(chk, oracle):
@@ -95,8 +99,8 @@ def test_search_degenerate_clouds(chk, oracle):
     plane = np.zeros((900, 3), np.float32); plane[:, :2] = rng.uniform(-3, 3, size=(900, 2))
     point = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (40, 1))
     q = rng.uniform(-4, 4, size=(300, 3)).astype(np.float32)
-    for tgt in (line, plane, point, plane[:9], plane[:1]):
-        for kw in ({}, {"force_hash": 1}):
+    for tgt in (line, plane, point, plane[:9], plane[:1], line[:, [1, 0, 2]], line[:, [2, 1, 0]], plane[:, [2, 0, 1]]):
+        for kw in ({}, {"force_hash": 1}, {"xf": 1}):
             if len(tgt) >= 10:
                 check(chk, oracle, tgt, q, 10, 1.5, **kw)
             if len(tgt) >= 5:
@@ -179,6 +183,36 @@ def test_certified_line_test_saves_sweeps(chk):
     rng = np.random.default_rng(5)
     pts = np.ascontiguousarray(_point_sets(rng, 4000))
     hist = np.zeros(13, np.int32)
-    total = chk.chk_line_sweeps(_p(pts, ctypes.c_double), len(pts), ctypes.c_double(3.0), _p(hist, ctypes.c_int))
-    print("Jacobi sweeps per set: %.2f, histogram %s" % (total / len(pts), hist.tolist()))
+    total = chk.chk_line_sweeps(_p(pts, ctypes.c_double), len(pts), ctypes.c_double(3.0), 0, _p(hist, ctypes.c_int))
+    print("exact loop with the certified exit, Jacobi sweeps per set: %.2f, histogram %s" % (total / len(pts), hist.tolist()))
     assert total / len(pts) < 4.0          # the uncertified loop runs 6-10 sweeps to an exactly zero off-diagonal part
+    total = chk.chk_line_sweeps(_p(pts, ctypes.c_double), len(pts), ctypes.c_double(3.0), 1, _p(hist, ctypes.c_int))
+    print("with the closed-form screen in front: %.4f sweeps per set, histogram %s" % (total / len(pts), hist.tolist()))
+    assert hist[0] >= 0.99 * len(pts)
+
+
+def test_closed_form_screen_accuracy_and_fallback_band(chk):
+    """The screen's eigenvalues against LAPACK on scatter-like matrices of every conditioning, and its decisions: wrong never, undecided
+    only inside the guard band."""
+    rng = np.random.default_rng(17)
+    m = 300000
+    lam = np.sort(np.abs(rng.normal(size=(m, 3))) * 10.0 ** rng.uniform(-6, 2, size=(m, 1)), axis=1)
+    lam[: m // 4, 0] *= 10.0 ** rng.uniform(-12, 0, size=m // 4)            # planar patches: one tiny eigenvalue
+    lam[m // 4: m // 2, 1] = lam[m // 4: m // 2, 0] * (1 + 10.0 ** rng.uniform(-12, -1, size=m // 4))   # nearly equal pairs
+    lam[m // 2: 5 * m // 8, 1] = lam[m // 2: 5 * m // 8, 2] / 3.0 * (1 + rng.choice([-1, 1], size=m // 8) * 10.0 ** rng.uniform(-9, -2, size=m // 8))   # around the threshold
+    lam = np.sort(lam, axis=1)
+    Q = np.linalg.qr(rng.normal(size=(m, 3, 3)))[0]
+    A = np.einsum("mij,mj,mkj->mik", Q, lam, Q)
+    A = 0.5 * (A + A.transpose(0, 2, 1))
+    packed = np.ascontiguousarray(np.stack([A[:, 0, 0], A[:, 0, 1], A[:, 0, 2], A[:, 1, 1], A[:, 1, 2], A[:, 2, 2]], axis=1))
+    dec = np.empty(m, np.int32); eig = np.zeros((m, 3))
+    chk.chk_line_screen(_p(packed, ctypes.c_double), m, ctypes.c_double(3.0), _p(dec, ctypes.c_int), _p(eig, ctypes.c_double))
+    w = np.linalg.eigvalsh(A)
+    err = np.abs(eig - w).max(axis=1) / w[:, 2]
+    print("screen: max eigenvalue error %.2e of the largest eigenvalue; undecided %.4f %%" % (err.max(), 100.0 * (dec < 0).mean()))
+    assert err.max() < 1e-7                                                 # the bound in the header: 6e-8
+    margin = (w[:, 2] - 3.0 * w[:, 1]) / (w[:, 2] + 3.0 * w[:, 1])
+    decided = dec >= 0
+    assert np.array_equal(dec[decided] == 1, margin[decided] > 0)          # never wrong
+    assert np.all(np.abs(margin[~decided]) < 1.1e-5)                        # undecided only inside the guard band ...
+    assert np.all(decided[np.abs(margin) > 1.1e-5])                         # ... and always decided outside it
