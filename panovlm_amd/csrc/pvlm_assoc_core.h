@@ -54,6 +54,13 @@ PVLM_HD int cell_of(float x, float o, float inv_h) {
   c = fminf(fmaxf(c, -1000000.f), 1000000.f);
   return (int)c;
 }
+// square root for the pruning reach only (never for a distance that is compared or returned): the raw hardware estimate,
+// the caller adds a relative margin; sqrtf() expands to 20 instructions of denormal scaling and last-bit correction
+#if defined(PVLM_ASSOC_DEVICE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float sqrt_reach(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+PVLM_HD float sqrt_reach(float x) { return sqrtf(x); }
+#endif
 PVLM_HD unsigned f2u(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 PVLM_HD float u2f(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 
@@ -143,7 +150,7 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
         const float lb = gym * gym + gzm * gzm;                       // <= d2 of every point of the row
         const float budget = fminf(thr2, tk.dist(K - 1)) * 1.00001f;   // dist(K-1) = +inf while the list is not full
         if (lb > budget) continue;
-        const float reach = (sqrtf(budget - lb) + slack) * cv.inv_h;  // (coarse) cells the budget still reaches along x
+        const float reach = (sqrt_reach(budget - lb) * 1.0001f + slack) * cv.inv_h;  // (coarse) cells the budget still reaches along x
         const int xa = (int)floorf((ux - reach) * (float)xf), xb = (int)floorf((ux + reach) * (float)xf);   // fine cells
         const bool face = (dz == -r || dz == r || dy == -r || dy == r);
         // a face row of the shell is one x-run; an interior row only owns its two end cells (one call site for both:

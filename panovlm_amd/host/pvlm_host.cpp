@@ -1145,8 +1145,20 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   const int NP = (int)I.poses.size();
   const Exchange* xch = (opt.exchange && opt.exchange->active()) ? opt.exchange : nullptr;
   // a rank of a sharded solve may own no residual block at all and still has to take part in every exchange
-  if ((!xch && I.num_blocks == 0) || NP == 0) { summary->message = "no residual blocks"; return; }
-  if (xch) for (auto& b : I.bundles) if (!b.obs_pose.empty()) throw std::runtime_error("sharded Solve: reprojection blocks are not sharded (camera terms run on one GPU)");
+  if (!xch && (I.num_blocks == 0 || NP == 0)) { summary->message = "no residual blocks"; return; }
+  if (xch) {
+    // Entry into a sharded Solve is collective: a rank that cannot take part (no registered poses, reprojection blocks — which are
+    // not sharded) must not leave its peers waiting in the first all-reduce.  Every rank contributes its own verdict to one
+    // exchange and all of them leave together, with the same message.
+    bool has_bundle = false;
+    for (auto& b : I.bundles) if (!b.obs_pose.empty()) has_bundle = true;
+    double verdict[3] = {NP == 0 ? 1.0 : 0.0, has_bundle ? 1.0 : 0.0, (double)NP};
+    double agreed[3] = {verdict[0], verdict[1], verdict[2]};
+    xch->allreduce_sum(agreed, 3);
+    if (agreed[0] > 0) throw std::runtime_error("sharded Solve: " + std::to_string((int)agreed[0]) + " rank(s) entered without registered poses (Problem::RegisterPoses must run on every rank)");
+    if (agreed[1] > 0) throw std::runtime_error("sharded Solve: reprojection blocks are not sharded (camera terms run on one GPU)");
+    if (agreed[2] != (double)NP * xch->world) throw std::runtime_error("sharded Solve: the ranks registered different numbers of poses");
+  }
   // concatenation of every rank's list through the one primitive an Exchange has
   auto all_concat = [&](const std::vector<double>& mine) {
     std::vector<double> cnt((size_t)xch->world, 0.0);
@@ -1811,6 +1823,23 @@ Exchange MakeRcclExchange(int world, int rank, const unsigned char id[128]) {
   return x;
 }
 
+std::pair<size_t, size_t> Exchange::BalancedRange(const std::vector<double>& weight, int of_rank) const {
+  const size_t n = weight.size();
+  const size_t rk = (size_t)(of_rank < 0 ? rank : of_rank), W = (size_t)std::max(world, 1);
+  double total = 0;
+  for (double w : weight) total += w;
+  if (!(total > 0)) return {n * rk / W, n * (rk + 1) / W};
+  auto boundary = [&](size_t r) -> size_t {
+    if (r == 0) return 0;
+    if (r >= W) return n;
+    const double want = total * (double)r / (double)W;
+    double acc = 0;
+    for (size_t i = 0; i < n; ++i) { if (acc >= want) return i; acc += weight[i]; }
+    return n;
+  };
+  return {boundary(rk), boundary(rk + 1)};
+}
+
 Exchange MakeFileExchange(int world, int rank, const std::string& dir) {
   auto seq = std::make_shared<long>(0);
   Exchange x; x.world = world; x.rank = rank;
@@ -1860,7 +1889,19 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
   ceres_like::Problem problem;
   // sharded run: this rank adds the blocks of its reference scans only; pose ids are the list indices on every rank
   const bool sharded = exchange_.active();
-  const std::pair<size_t, size_t> my_range = exchange_.Range(lidars.size());
+  // contiguous ranges of reference scans with equal association work: weight(i) = queries of i's pairs (+ the corner points of
+  // the line term).  The lists are replicated, so every rank derives the same partition.
+  std::vector<double> shard_weight(lidars.size(), 0.0);
+  if (sharded)
+    for (size_t i = 0; i < lidars.size(); i++) {
+      if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+      for (int k : neighbors_all[i]) {
+        if (k < 0 || k == (int)i || k >= (int)lidars.size() || !lidars[(size_t)k].valid || !lidars[(size_t)k].IsPoseValid()) continue;
+        if (config.point_to_plane_residual) shard_weight[i] += (double)lidars[(size_t)k].surfFlat.size();
+        if (config.line_to_line_residual && use_segment) shard_weight[i] += (double)lidars[(size_t)k].cornerLessSharp.size();
+      }
+    }
+  const std::pair<size_t, size_t> my_range = sharded ? exchange_.BalancedRange(shard_weight) : std::pair<size_t, size_t>{0, lidars.size()};
   const std::pair<size_t, size_t>* range = sharded ? &my_range : nullptr;
   if (sharded) problem.RegisterPoses(aa_list, t_list);
   if (config.point_to_line_residual)                                                           // LidarOdometry.cpp:38-41
@@ -1878,6 +1919,14 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
     AddLidarPointToPlaneResidual(neighbors_all, lidars, aa_list, t_list, problem, config.point_to_plane_dis_threshold, config.lidar_plane_tolerance,
                                  config.angle_residual, config.normalize_distance, 1.0, range);
   double total_blocks = (double)problem.NumResidualBlocks();
+  if (sharded) {
+    ShardLog sl{my_range.first, my_range.second, std::vector<double>((size_t)exchange_.world, 0.0), (int)problem.NumResidualBlocks()};
+    for (int r = 0; r < exchange_.world; ++r) {
+      const auto rg = exchange_.BalancedRange(shard_weight, r);
+      for (size_t i = rg.first; i < rg.second; ++i) sl.queries_per_rank[(size_t)r] += shard_weight[i];
+    }
+    shard_log.push_back(sl);
+  }
   if (sharded) exchange_.allreduce_sum(&total_blocks, 1);        // the decision below must be the same on every rank
   if (total_blocks == 0) { fprintf(stderr, "no residual\n"); return false; }
   // gauge: first valid pose constant — only if it takes part in the problem (Ceres would abort otherwise)
@@ -1913,13 +1962,17 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
   // ExtractFeatures return early for those as well (sensors/Velodyne.cpp:376-377, :542-543).
   {
     StageTimer stage_timer_features_("feature extraction (host, scan-parallel)");
+    // invalid scans first, on the calling thread: SetRotation / SetTranslation give the scan's device copy back to the engine's
+    // context (InvalidateDevice -> pvlm_scan_destroy), whose pool is not thread-safe — never from the workers below
+    for (Velodyne& l : lidars)
+      if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); }
     std::atomic<size_t> next{0};
     std::mutex failure_lock;
     std::exception_ptr failure;          // e.g. an extraction method that is not mirrored: rethrown on the calling thread
     auto work = [&]() {
       for (size_t i = next++; i < lidars.size(); i = next++) {
         Velodyne& l = lidars[i];
-        if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); continue; }
+        if (!l.valid || !l.IsPoseValid()) continue;        // reset above, on the calling thread
         if (!l.cloud.empty() && l.surfFlat.empty() && l.surfLessFlat.empty() && l.cornerLessSharp.empty() && !l.IsInWorldCoordinate()) {
           try {
             l.ReOrderVLP();

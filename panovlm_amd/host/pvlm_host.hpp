@@ -293,6 +293,11 @@ struct Exchange {
   bool active() const { return world > 1 && (bool)allreduce_sum; }
   // block partition of n reference scans, the same rule as panovlm_amd/sharding.py
   std::pair<size_t, size_t> Range(size_t n) const { return {n * (size_t)rank / (size_t)world, n * ((size_t)rank + 1) / (size_t)world}; }
+  // contiguous ranges of (nearly) equal summed weight: boundary r is the first scan whose weight prefix reaches r / world of the
+  // total.  With weight(i) = sum of the query counts of i's neighbour scans this is SURVEY.md §8 E's "rebalancing by sum Nq":
+  // temporal neighbour lists give every scan the same weight, loop-closure pairs make some scans heavier.  Every rank computes
+  // the same boundaries from the same (replicated) weights.  All-zero weights: Range(n).
+  std::pair<size_t, size_t> BalancedRange(const std::vector<double>& weight, int of_rank = -1) const;
 };
 // RCCL over xGMI through the C ABI (pvlm_comm_* on the engine's context): `id` = the 128 bytes rank 0 got from
 // pvlm_comm_unique_id, carried to the other ranks by the launcher.  Collective: every rank calls it.
@@ -417,6 +422,10 @@ class LidarOdometry {
   // per-outer-iteration log (cost, successful steps, residual blocks) for tests
   struct IterLog { double cost; int steps; int residual_blocks; };
   std::vector<IterLog> log;
+  // sharded runs, per outer iteration: this rank's range of reference scans, the association queries (sum Nq over the pairs of
+  // a rank's reference scans) of EVERY rank — computed from the replicated neighbour lists — and this rank's own residual blocks
+  struct ShardLog { size_t first, last; std::vector<double> queries_per_rank; int local_blocks; };
+  std::vector<ShardLog> shard_log;
   // Sharded run (one process per GPU): set before EstimatePose / RefinePose on every rank.  Association and
   // residual evaluation are done for the rank's block of reference scans only; poses, neighbour lists and line tracks are
   // replicated.  residual_blocks in the log is then the sum over the ranks.

@@ -31,7 +31,7 @@ void build_grid(const float* xyz, int n, float cell_override, int force_hash, in
   float e[3];
   for (int k = 0; k < 3; ++k) e[k] = std::max(mx[k] - mn[k], 0.05f);
   const float area = 2.f * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
-  float h = std::sqrt(4.f * area / (float)std::max(n, 1));
+  float h = 0.65f * std::sqrt(4.f * area / (float)std::max(n, 1));
   if (cell_override > 0) h = cell_override;
   h = std::min(std::max(h, 0.02f), 4.0f);
   float origin[3];

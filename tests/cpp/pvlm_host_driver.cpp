@@ -213,6 +213,11 @@ int main(int argc, char** argv) {
       odo.EstimatePose(iters);
       const auto t_end = std::chrono::steady_clock::now();
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
+      for (auto& sl : odo.shard_log) {   // sharded runs: the partition of this outer iteration and the work behind it
+        printf("shard refs %zu %zu local_blocks %d queries_per_rank", sl.first, sl.last, sl.local_blocks);
+        for (double q : sl.queries_per_rank) printf(" %.0f", q);
+        printf("\n");
+      }
       printf("call %.6f context creation (once per process)\n", std::chrono::duration<double>(t_call - t_ctx).count());
       printf("call %.6f LidarOdometry::EstimatePose\n", std::chrono::duration<double>(t_end - t_call).count());
       for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());
@@ -288,6 +293,11 @@ int main(int argc, char** argv) {
       LidarOdometry odo(l, cfg);
       odo.EstimatePose(atoi(argv[3]));
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
+      for (auto& sl : odo.shard_log) {   // sharded runs: the partition of this outer iteration and the work behind it
+        printf("shard refs %zu %zu local_blocks %d queries_per_rank", sl.first, sl.last, sl.local_blocks);
+        for (double q : sl.queries_per_rank) printf(" %.0f", q);
+        printf("\n");
+      }
       PrintPoses(odo.GetLidarData());
     } else if (cmd == "featbench") {
       // featbench <raw_scans.bin> reps segment : host seconds per scan of ReOrderVLP + ExtractFeatures (no GPU involved)

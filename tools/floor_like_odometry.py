@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 4 on ONE GPU: the mirrored LidarOdometry::EstimatePose at the reference's Floor size (config/Floor.txt:
+1593 scans, lidar_plane_tolerance 0.01, point-to-plane + line-to-line Angle terms) run as 1 process and as a sharded job of
+N processes — each rank with its own context on the same GPU, the packed normal equations summed through a directory
+(pvlm::MakeFileExchange; RCCL refuses several ranks on one device).  What is sharded is the loop of
+util/Optimization.cpp:521-560 / :345-441 under lidar_mapping/LidarOdometry.cpp:116-187: every rank associates and evaluates
+the pairs of its contiguous range of reference scans (ranges of equal summed query count, Exchange::BalancedRange).
+
+Prints, per world size: the outer-iteration log of rank 0, whether every rank reported the same bits, the largest pose
+difference against the one-process run, the partition (reference range, association queries, residual blocks per rank)
+and the call's wall time.  usage: python tools/floor_like_odometry.py [--scans 1593] [--ranks 2,8] [--iters 2]"""
+import argparse, os, subprocess, sys, tempfile, time
+import multiprocessing as mp
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from panovlm_amd import synthetic as sy
+from tests import host_io
+from tools.room_like_odometry import room_edges, room_scan
+
+
+def _scan(args):
+    k, lines = args
+    return room_scan(k, np.random.default_rng(1000 + k), room_edges() if lines else None)
+
+
+def parse(out):
+    iters = [l.split() for l in out if l.startswith("iter")]
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
+    shards = [l.split() for l in out if l.startswith("shard")]
+    call = [float(l.split()[1]) for l in out if l.startswith("call") and "EstimatePose" in l]
+    return iters, poses, shards, (call[0] if call else float("nan"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scans", type=int, default=1593)
+    ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--ranks", default="2,8")
+    ap.add_argument("--tolerance", type=float, default=0.01, help="lidar_plane_tolerance (config/Floor.txt)")
+    ap.add_argument("--lines", type=int, default=1)
+    a = ap.parse_args()
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(min(64, os.cpu_count() or 8)) as pool:
+        scans = pool.map(_scan, [(k, a.lines) for k in range(a.scans)], chunksize=4)
+    print("generated %d scans in %.1f s" % (a.scans, time.perf_counter() - t0))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "floor.bin")
+        host_io.write_scans(path, scans, world=False)
+        args = ["odometry", path, a.iters, 1, 1, 1 if a.lines else 0, 1, a.tolerance, 1.0, 0.3]
+        os.environ.setdefault("PVLM_HOST_RESERVE_MB", "1536")
+        t0 = time.perf_counter()
+        single = host_io.run(*args, timeout=3000)
+        wall1 = time.perf_counter() - t0
+        its, pos, _, call1 = parse(single)
+        print("world 1: %.2f s process wall, EstimatePose call %.3f s" % (wall1, call1))
+        for l in its:
+            print("   ", " ".join(l))
+        e0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
+        e1 = np.mean([np.linalg.norm(pos[k][9:] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
+        print("mean translation error vs ground truth: %.4f m -> %.4f m" % (e0, e1))
+        ok_all = True
+        for world in [int(w) for w in a.ranks.split(",") if w]:
+            xdir = os.path.join(d, "xchg%d" % world); os.makedirs(xdir, exist_ok=True)
+            env = dict(os.environ, PVLM_HOST_RESERVE_MB=str(max(256, 1536 // world)))       # per-rank pool: 1/N of the one-process reservation
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([host_io.driver()] + [str(x) for x in args] + [str(world), str(r), "file:" + xdir], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env) for r in range(world)]
+            outs = []
+            for p in procs:
+                o, e = p.communicate(timeout=3000)
+                if p.returncode != 0:
+                    print("rank failed:", e[-1500:]); sys.exit(1)
+                outs.append(o.splitlines())
+            wall = time.perf_counter() - t0
+            parsed = [parse(o) for o in outs]
+            it0, po0, sh0, call0 = parsed[0]
+            same = all([l[:7] for l in p[0]] == [l[:7] for l in it0] and all(np.array_equal(p[1][k], po0[k]) for k in po0) for p in parsed[1:])
+            steps_equal = len(it0) == len(its) and all(int(x[4]) == int(y[4]) and int(x[6]) == int(y[6]) for x, y in zip(it0, its))
+            cost_rel = max(abs(float(x[2]) - float(y[2])) / float(y[2]) for x, y in zip(it0, its)) if steps_equal else float("nan")
+            dpose = max(np.abs(po0[k] - pos[k]).max() / max(1.0, np.abs(pos[k]).max()) for k in pos)
+            print("world %d: %.2f s wall for the %d processes, EstimatePose call %.3f s (rank 0)" % (world, wall, world, call0))
+            print("   every rank reports the same log and poses, bit for bit: %s" % same)
+            print("   step and block counts equal to the one-process run: %s, largest relative cost difference %.3e, largest relative pose difference %.3e" % (steps_equal, cost_rel, dpose))
+            # partition of the first outer iteration: reference range + residual blocks from every rank's own line, queries from rank 0's table
+            q = [float(v) for v in sh0[0][sh0[0].index("queries_per_rank") + 1:]]
+            blocks = [int(p[2][0][5]) for p in parsed]
+            for r, p in enumerate(parsed):
+                print("   rank %d: reference scans [%s, %s)  association queries %.0f  residual blocks %d" % (r, p[2][0][2], p[2][0][3], q[r], blocks[r]))
+            print("   load balance (max / mean): queries %.3f, residual blocks %.3f" % (max(q) / (sum(q) / world), max(blocks) / (sum(blocks) / world)))
+            ok_all = ok_all and same and steps_equal and dpose <= 1e-9
+        print("sharded runs equal to the one-process run (1e-9, identical step counts): %s" % ok_all)
+
+
+if __name__ == "__main__":
+    main()
