@@ -51,6 +51,36 @@ def generate_scans(ids, cols, voxel):
     return dict(zip(ids, out))
 
 
+class Watchdog:
+    """A collective that never returns would cost the only multi-GPU record this project can get: every phase of a multi-rank
+    run that can block on another rank (rendezvous, first collectives, the timed region) runs under a deadline.  When it expires
+    the process says which phase hung and exits with code 3 (os._exit: a rank stuck inside a collective cannot unwind)."""
+
+    def __init__(self, rank):
+        self.rank, self.timer, self.phase = rank, None, ""
+
+    def arm(self, phase, seconds):
+        import threading
+        self.disarm()
+        self.phase = phase
+
+        def fire():
+            sys.stderr.write("[bench] rank %d: WATCHDOG — '%s' did not finish within %d s; aborting the run\n" % (self.rank, phase, seconds))
+            sys.stderr.flush()
+            if self.rank == 0:
+                print(json.dumps({"metric": "M residual+Jacobian evals/sec (point-to-plane, 64k pts/scan)", "value": None, "unit": "M evals/s",
+                                  "error": "watchdog: '%s' hung for %d s" % (phase, seconds)}), flush=True)
+            os._exit(3)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +105,8 @@ def main():
                          "timed region be bracketed by HIP events (roofline.achieved)")
     ap.add_argument("--no-mvs", action="store_true", help="skip the panoramic MVS block (resident views at 1440 x 720 and 5760 x 2880)")
     ap.add_argument("--no-projection", action="store_true", help="skip the per-rank projection block (scans/2, /4, /8 on this GPU)")
+    ap.add_argument("--collective-timeout", type=float, default=float(os.environ.get("PVLM_BENCH_COLLECTIVE_TIMEOUT", "240")),
+                    help="N > 1: seconds any phase that waits for other ranks may take before the watchdog aborts the run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,12 +131,18 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
+    dog = Watchdog(rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL across processes)
+        dog.arm("rendezvous (init_process_group)", args.collective_timeout)
+        to = datetime.timedelta(seconds=args.collective_timeout)
         if shared_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=to)
+        dog.disarm()
     dev = torch.device("cuda", local_rank)
 
     import panovlm_amd as pv
@@ -163,7 +201,11 @@ def main():
     d_t = torch.from_numpy(np.ascontiguousarray(t0)).to(dev)
     tot = torch.tensor([n_local, n_queries], dtype=torch.int64, device=dev)
     if world > 1:
+        # the first collective of the run: set-up times differ between ranks (scan generation, association), so the deadline is generous
+        dog.arm("first all-reduce (block counts)", max(args.collective_timeout, 600.0))
         dist.all_reduce(tot)
+        torch.cuda.synchronize()
+        dog.disarm()
     n_total, q_total = int(tot[0].item()), int(tot[1].item())
 
     # ---- the step: k_pose_table -> k_pair_table -> k_eval_fused -> k_pair_epilogue -> k_neq_gather (-> all-reduce) ----
@@ -265,6 +307,8 @@ def main():
         for _ in range(8):
             local_step()
         torch.cuda.synchronize()
+    if world > 1:
+        dog.arm("warm-up + timed steps (all-reduce of %d doubles per step)" % neq.size, max(args.collective_timeout, 60.0 + 2.0 * (args.steps + args.warmup)))
     for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
         step()
     fence()
@@ -293,6 +337,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     cost = float(packed[-1].item())
+    dog.disarm()
+    # N > 1: the all-reduce of the packed blocks alone (barrier-bracketed, max over ranks) and the per-rank load table
+    allreduce_us, rank_table = None, None
+    if world > 1:
+        dog.arm("all-reduce timing", args.collective_timeout)
+        scratch = torch.zeros_like(packed)
+        reps = 50
+
+        def one():
+            if comm is not None:
+                comm.allreduce_sum_f64(scratch.data_ptr(), neq.size)
+            else:
+                dist.all_reduce(scratch)
+        for _ in range(5):
+            one()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one()
+        fence()
+        ar = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device=dev)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        allreduce_us = float(ar.item())
+        table = torch.zeros((world, 4), dtype=torch.float64, device=dev)
+        table[rank, 0] = len(ref); table[rank, 1] = n_queries; table[rank, 2] = n_local; table[rank, 3] = kern_ms / max(kern_n, 1)
+        dist.all_reduce(table)
+        rank_table = [{"rank": r, "pairs": int(v[0]), "queries": int(v[1]), "evals": int(v[2]), "fused_kernel_ms": v[3]} for r, v in enumerate(table.tolist())]
+        dog.disarm()
 
     # ---- what one rank of an N-GPU run has to do, measured on this one GPU (no 8-GPU node is mine to launch) ----
     projection = None
@@ -351,6 +423,7 @@ def main():
     # the sum of the ranks' rates.  Every rank takes part in the one all-reduce whatever happened to its measurement.
     image_space = None
     if world > 1:
+        dog.arm("image-space block (per-view shards, one all-reduce of the rates)", max(args.collective_timeout, 600.0))
         local = [0.0, 0.0, 0.0, 0.0, 0.0]
         try:
             pb = panorama_block(ctx, pv, torch, dev, with_votes=False)
@@ -363,6 +436,7 @@ def main():
             sys.stderr.write("[bench] rank %d: image-space block failed (%s)\n" % (rank, str(e)[:200]))
         tsum = torch.tensor(local, dtype=torch.float64, device=dev)
         dist.all_reduce(tsum)
+        dog.disarm()
         if rank == 0:
             v = tsum.tolist()
             image_space = {"sharding": "one 5.7K view per rank, no exchange (weak scaling by construction)", "ranks_measured": int(round(v[4])),
@@ -382,7 +456,7 @@ def main():
         # HBM traffic of the fused kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command, summarised by tools/pmc_traffic.py into profiles/): used only when it was collected on
         # exactly this workload (the synthetic batch is deterministic, so evals_per_launch identifies it).
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stamp = None, None, None
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
             try:
@@ -391,6 +465,9 @@ def main():
                     for k, v in pm["kernels"].items():
                         if "k_eval_fused" in k:
                             traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                            traffic_stamp = {"collected_at_commit": pm.get("commit"), "collected_on": pm.get("date"),
+                                             "note": "counter passes of THIS command, collected in a separate rocprofv3 --pmc run (counters cannot be read inside "
+                                                     "a timed run); it is that run's traffic, cited here because the synthetic batch is deterministic"}
             except Exception:
                 pass
         bytes_per_eval = 8 * 7  # 7 fp64 SoA columns (P_n, plane); pair ids live in the per-segment table
@@ -416,16 +493,22 @@ def main():
                 "mode": "fused-normal-equations", "functor": args.functor, "targets": args.targets, "scans": F, "pairs": int(len(ref_all)),
                 "points_per_scan": 16 * args.cols, "residual_blocks": n_total, "robust_cost": cost},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "traffic_provenance": traffic_stamp,
                          "algorithmic_bytes_per_launch": n_local * bytes_per_eval,
                          "kernel": "k_eval_fused", "kernel_avg_ms": kern_ms / max(kern_n, 1), "launches": kern_n,
                          "bytes_per_eval": bytes_per_eval, "evals_per_launch": n_local,
                          "M_evals_per_s_kernel": n_local / k_avg_s / 1e6,
+                         "frac_of_64B_ceiling": (n_local / k_avg_s) / (HBM_PEAK_GBPS * 1e9 / 64),
                          "ceiling_M_evals_per_s_64B": HBM_PEAK_GBPS * 1e9 / 64 / 1e6,
                          "ceiling_M_evals_per_s_56B": HBM_PEAK_GBPS * 1e9 / 56 / 1e6},
             "association": association_block(n_queries, n_targets, n_local, int(len(ref)), assoc_ms, assoc_n, t_assoc, t_assoc_first, assoc_ms_first,
                                              allocs_first, allocs_steady, t_res, reserve_bytes, ctx.mem_info(), extra_assoc),
             "step": {"graph": graph is not None, "comm": comm_mode, "allreduce_doubles": int(neq.size) if world > 1 else 0,
+                     "comm_backend": None if world == 1 else ("gloo (PVLM_BENCH_SHARED_GPU: all ranks on one GPU, functional check, not a measurement)" if shared_gpu
+                                                             else ("RCCL through torch.distributed (backend nccl)" if comm is None else "RCCL through pvlm_comm_*")),
+                     "rccl_ranks": 0 if (world == 1 or shared_gpu) else world, "allreduce_us": allreduce_us,
+                     "allreduce_us_note": None if world == 1 else "all-reduce of the packed blocks alone, %d doubles, 50 repetitions, barrier-bracketed, max over ranks" % neq.size,
+                     "per_rank": rank_table, "collective_timeout_s": args.collective_timeout if world > 1 else None,
                      "kernels_per_step": 5, "ms_per_step_minus_fused_kernel": dt / args.steps * 1e3 - kern_ms / max(kern_n, 1)},
             "per_rank_projection": projection,
             "materialise": mat,
@@ -446,7 +529,9 @@ def main():
             pass
         print(json.dumps(out), flush=True)
     if world > 1:
+        dog.arm("final barrier", args.collective_timeout)
         dist.barrier()
+        dog.disarm()
         dist.destroy_process_group()
 
 
@@ -466,7 +551,7 @@ def association_block(n_queries, n_targets, accepted, pairs, kernel_ms, launches
            "output_bytes": accepted * 56, "scratch_bytes_per_query": 97}
     # counter evidence for K2 / K3 (separate rocprofv3 --pmc passes of this command, summarised by tools/pmc_assoc.py)
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_pmc_assoc*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_assoc*.json"))):      # the latest round's summary wins
         try:
             pm = json.load(open(f))
             # per-query figures: collected on the same generator at --scans 256 (134 M queries); they do not depend on the batch size
@@ -531,11 +616,13 @@ def association_points(ctx, pv, torch, args, scans, dscans, ref, nei, associate,
     """Two more points SURVEY.md §8(d) asks for: raw targets (every one of the 65 536 points a surfLessFlat target, the
     wording of BASELINE.md §2) and the Floor plane tolerance 0.01."""
     out = {}
-    # --- raw targets: the first scans of the batch, re-uploaded with their full cloud as the target cloud
-    S = min(64, args.scans)
+    # --- raw targets, the WHOLE batch (BASELINE.md §2's literal wording: every one of the 65 536 points of a scan is also a
+    # surfLessFlat target): all scans re-uploaded with their full cloud as the target cloud, all pairs associated, and the
+    # fused step run on what the reference's own accept tests let through
+    S = args.scans
     sel = [(int(r), int(n)) for r, n in zip(ref, nei) if r < S and n < S]
     raw = {}
-    for k in range(S):
+    for k in sorted(set(a for a, _ in sel) | set(b for _, b in sel)):
         d = dict(scans[k]); d["less_xyz"] = scans[k]["flat_xyz"]; d["less_tag"] = scans[k]["flat_tag"]
         raw[k] = pv.Scan(ctx, d)
     rr = np.array([a for a, _ in sel]); nn_ = np.array([b for _, b in sel])
@@ -547,7 +634,28 @@ def association_points(ctx, pv, torch, args, scans, dscans, ref, nei, associate,
                           "compulsory_bytes": (nq + nt) * 16, "compulsory_GBps_at_kernel_time": (nq + nt) * 16 / max(ms, 1e-9) / 1e6,
                           "note": "10-NN of a query among raw VLP-16 returns lie on one ring: the reference's own collinearity test "
                                   "(FormLine(points, 3.0)) rejects most queries"}
-    rsr.close()
+    neq_r = pv.NormalEq(ctx, F, ui, uj)
+    packed_r = torch.zeros(neq_r.size, dtype=torch.float64, device=dev)
+    step_r, _ = make_step(rsr, neq_r, packed_r, False, graphed=False)
+    for _ in range(5):
+        step_r()
+    torch.cuda.synchronize()
+    reps = 20
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step_r()
+    torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) / reps * 1e3
+    k_ms, k_n = ctx.profile_read(0)
+    ctx.profile_enable(False)
+    k_avg = k_ms / max(k_n, 1)
+    out["raw_targets"]["fused"] = {"what": "the fused step (r + 1x12 J -> per-pose blocks) on the blocks of the literal BASELINE.md §2 workload: %d pairs, raw 65 536-point "
+                                           "targets" % len(sel), "evals": int(rsr.n), "fused_kernel_ms": k_avg, "ms_per_step": step_ms,
+                                   "M_evals_per_s_kernel": rsr.n / max(k_avg, 1e-9) / 1e3, "M_evals_per_s_step": rsr.n / max(step_ms, 1e-9) / 1e3,
+                                   "GBps_kernel": rsr.n * 56 / max(k_avg, 1e-9) / 1e6, "frac_of_hbm_peak": rsr.n * 56 / max(k_avg, 1e-9) / 1e6 / HBM_PEAK_GBPS,
+                                   "evals_per_pair": rsr.n / max(len(sel), 1)}
+    neq_r.close(); rsr.close()
     for d in raw.values():
         d.close()
     # --- Floor: lidar_plane_tolerance 0.01 (config/Floor.txt) on the first 256 reference scans, association + fused step
@@ -625,8 +733,10 @@ def mvs_block(ctx, pv):
     # SQ counters of the same kernels (tools/prof_r2_final.sh -> profiles/r2_pmc_mvs.json, separate --pmc pass of
     # tools/mvs_bench.py): wave VALU instructions x 4 cycles / (1024 SIMDs x kernel time) = a lower bound of the VALU pipes' load
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_mvs.json")))
-        out["pmc"] = {"source": "profiles/r2_pmc_mvs.json",
+        import glob
+        src = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_mvs.json")))[-1]
+        pmc = json.load(open(src))
+        out["pmc"] = {"source": "profiles/" + os.path.basename(src),
                       "kernels": {k: {f: v[f] for f in ("simd_valu_util_lower_bound", "valu_issue_frac", "wait_frac", "valu_insts_per_wave", "kernel_trace_ms") if f in v}
                                   for k, v in pmc.items() if "k_mvs_conf" in k or "k_mvs_propagate" in k}}
     except Exception:

@@ -27,7 +27,9 @@ def load(d, counter):
 
 fe = load(fetch_dir, "FETCH_SIZE")
 wr = load(write_dir, "WRITE_SIZE") if write_dir != "-" else {}
-res = {"bench_command": "python bench.py --no-cpu-baseline (default workload)", "evals_per_launch": bench["roofline"]["evals_per_launch"],
+import os, datetime
+res = {"bench_command": "python bench.py --no-cpu-baseline (default workload)",
+       "commit": os.environ.get("PVLM_COMMIT"), "date": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"), "evals_per_launch": bench["roofline"]["evals_per_launch"],
        "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950: FETCH_SIZE counts 64 B per 128 B request on 16 B/lane streams); write bytes = WRITE_SIZE x 1024",
        "writes": "WRITE_SIZE pass" if write_dir != "-" else "not collected (reads only; round 1 measured 12.7 MB of writes per k_eval_fused launch against 45.7 GB of reads)",
        "kernels": {}}
