@@ -64,24 +64,34 @@ class Problem {
   explicit Problem(const Options& o) : options_(o) {}
   ~Problem() { for (auto& b : blocks_) if (costs_.insert(b.cost).second) delete b.cost; for (LossFunction* l : losses_) delete l; }
   void* AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, double* x1, double* x2, double* x3) {
-    blocks_.push_back(Block{cost, loss, {x0, x1, x2, x3}});
+    blocks_.push_back(Block{cost, loss, {x0, x1, x2, x3}, 4});
+    if (loss) losses_.insert(loss);
+    return &blocks_.back();
+  }
+  void* AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, double* x1, double* x2) {
+    blocks_.push_back(Block{cost, loss, {x0, x1, x2, nullptr}, 3});
     if (loss) losses_.insert(loss);
     return &blocks_.back();
   }
   int NumResidualBlocks() const { return (int)blocks_.size(); }
-  // test-double only: what one Ceres evaluation does — the callback once, then every block (residuals + 1 x 12 rows)
+  // test-double only: what one Ceres evaluation does — the callback once, then every block (residual + one Jacobian row of up
+  // to 12 entries, 3 per parameter block, at J[12 i ...]; a three-block cost fills the first 9)
   void EvaluateAll(bool jacobians, bool new_point, std::vector<double>* r, std::vector<double>* J) {
     if (options_.evaluation_callback) options_.evaluation_callback->PrepareForEvaluation(jacobians, new_point);
     r->assign(blocks_.size(), 0.0);
     if (J) J->assign(blocks_.size() * 12, 0.0);
     for (size_t i = 0; i < blocks_.size(); ++i) {
       double* jac[4] = {nullptr, nullptr, nullptr, nullptr};
-      if (jacobians && J) for (int b = 0; b < 4; ++b) jac[b] = J->data() + 12 * i + 3 * b;
+      if (jacobians && J) for (int b = 0; b < blocks_[i].n; ++b) jac[b] = J->data() + 12 * i + 3 * b;
       blocks_[i].cost->Evaluate(blocks_[i].x, &(*r)[i], jacobians && J ? jac : nullptr);
     }
   }
+  // the loss a block was added with (nullptr = none) and its parameter blocks: what the adapter tests check against the reference's calls
+  const LossFunction* loss_of(size_t i) const { return blocks_[i].loss; }
+  double* const* parameters_of(size_t i) const { return blocks_[i].x; }
+  int num_parameter_blocks_of(size_t i) const { return blocks_[i].n; }
  private:
-  struct Block { CostFunction* cost; LossFunction* loss; double* x[4]; };
+  struct Block { CostFunction* cost; LossFunction* loss; double* x[4]; int n; };
   Options options_;
   std::vector<Block> blocks_;
   std::set<CostFunction*> costs_;

@@ -263,6 +263,136 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < JJ.size() && i < J.size(); ++i) { dJ = std::max(dJ, std::fabs(JJ[i] - J[i])); jmax = std::max(jmax, std::fabs(JJ[i])); }
       printf("blocks %zu direct %lld max_dr %.3e max_dJ %.3e J_max %.3e moved %.3e\n", n, (long long)m, dr, dJ, jmax, moved);
       pvlm_resset_destroy(e.ctx(), rs);
+    } else if (cmd == "ceresjoint") {
+      // ceresjoint <lidars.bin (LOCAL)> <frames.bin> <structure.bin> neighbor_size tol thr thr_line : the problem of
+      // CameraLidarOptimizer::Optimize (joint_optimization/CameraLidarOptimizer.cpp:387-498) built ENTIRELY through
+      // integration/pvlm_ceres.hpp — all four adders on one CeresBatch, against the interface-only Ceres test double — then one
+      // "Ceres evaluation" (callback + every block's Evaluate) compared row by row with pvlm_eval / pvlm_ba_eval of the same sets,
+      // and the block counts with the host mirror's own adders.
+      auto l = LoadScans(argv[2]);
+      std::ifstream f(argv[3], std::ios::binary);
+      Matrix4d T;
+      std::vector<Frame> frames = LoadFrames(f, &T);
+      std::vector<PointTrack> structure = LoadStructure(argv[4], frames);
+      Config cfg;
+      cfg.lidar_plane_tolerance = atof(argv[6]); cfg.point_to_plane_dis_threshold = atof(argv[7]); cfg.point_to_line_dis_threshold = atof(argv[8]);
+      CameraLidarOptimizer opt(T, l, frames, cfg, atoi(argv[5]), 1);
+      const CameraLidarOptimizer::LinePairs pairs = opt.AssociateLineMulti(atoi(argv[5]), true);
+      // pose lists and world-frame clouds, as Optimize prepares them (:394-417)
+      std::vector<Vector3d> aa_cw(frames.size(), Vector3d{0, 0, 0}), t_cw(frames.size(), Vector3d{0, 0, 0});
+      std::vector<Vector3d> aa_lw(l.size(), Vector3d{0, 0, 0}), t_lw(l.size(), Vector3d{0, 0, 0});
+      auto inv_pose = [](const Matrix3d& R, const Vector3d& t, Vector3d* aa, Vector3d* tt) {
+        const Matrix3d Rt = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]};
+        RotationMatrixToAngleAxis(Rt, aa);
+        for (int r = 0; r < 3; ++r) (*tt)[r] = -((Rt[3 * r] * t[0] + Rt[3 * r + 1] * t[1]) + Rt[3 * r + 2] * t[2]);
+      };
+      for (size_t i = 0; i < frames.size(); ++i) if (frames[i].IsPoseValid()) inv_pose(frames[i].R_wc, frames[i].t_wc, &aa_cw[i], &t_cw[i]);
+      for (size_t i = 0; i < l.size(); ++i) if (l[i].IsPoseValid() && l[i].valid) { inv_pose(l[i].GetRotation(), l[i].GetTranslation(), &aa_lw[i], &t_lw[i]); l[i].Transform2LidarWorld(); }
+      const auto nb = FindNeighbors(l, 6);
+      LidarLineMatch matcher(l);
+      matcher.SetNeighborSize(4); matcher.SetMinTrackLength(3); matcher.GenerateTracks();
+      Engine& e = Engine::Default();
+      std::vector<pvlm_scan*> dev;
+      for (const Velodyne& v : l) dev.push_back(v.DeviceScan());
+      const int rows = frames[0].GetImageRows(), cols = frames[0].GetImageCols();
+      // the PanoVLM-side lines of the two camera adders (Equirectangular::ImageToCam, FormPlane, VectorAngle3D), restated for the test
+      auto image_to_cam_d = [&](double px, double py, double* cam) {
+        const double sx = (2 * px / cols - 1) * M_PI, sy = (0.5 - py / rows) * M_PI, cy = std::cos(sy);
+        cam[0] = cy * std::sin(sx); cam[1] = -std::sin(sy); cam[2] = cy * std::cos(sx);
+      };
+      auto make_rows = [&](const CameraLidarLinePair& lp, double weight, double* p2p, double* iou) {
+        double p1[3], p2[3];
+        image_to_cam_d(lp.image_line[0], lp.image_line[1], p1); image_to_cam_d(lp.image_line[2], lp.image_line[3], p2);
+        const double pa = ((p2[1] - p1[1]) * (0 - p1[2]) - (p2[2] - p1[2]) * (0 - p1[1])), pb = ((p2[2] - p1[2]) * (0 - p1[0]) - (p2[0] - p1[0]) * (0 - p1[2])),
+                     pc = ((p2[0] - p1[0]) * (0 - p1[1]) - (p2[1] - p1[1]) * (0 - p1[0]));
+        const double pd = -(pa * p1[0] + pb * p1[1] + pc * p1[2]);
+        const double c = p1[0] * p2[0] + p1[1] * p2[1] + p1[2] * p2[2];
+        const double angle = c >= 1.0 ? 0.0 : (c <= -1.0 ? M_PI : std::acos(c));
+        const double r_p2p[10] = {pa, pb, pc, lp.lidar_line_end[0], lp.lidar_line_end[1], lp.lidar_line_end[2], lp.lidar_line_start[0], lp.lidar_line_start[1],
+                                  lp.lidar_line_start[2], lp.weight * weight};
+        const double r_iou[12] = {pa, pb, pc, pd, (lp.lidar_line_end[0] + lp.lidar_line_start[0]) / 2.0, (lp.lidar_line_end[1] + lp.lidar_line_start[1]) / 2.0,
+                                  (lp.lidar_line_end[2] + lp.lidar_line_start[2]) / 2.0, (p1[0] + p2[0]) / 2.0, (p1[1] + p2[1]) / 2.0, (p1[2] + p2[2]) / 2.0, angle, 2.0 * weight};
+        std::copy(r_p2p, r_p2p + 10, p2p); std::copy(r_iou, r_iou + 12, iou);
+      };
+      auto bearing = [&](size_t frame_idx, size_t kp_idx, double* out) {          // ImageToCam(cv::Point2i) in float, see AddCameraResidual of the mirror
+        const std::array<float, 2>& kp = frames[frame_idx].keypoints[kp_idx];
+        const float px = (float)(int)std::lrintf(kp[0]), py = (float)(int)std::lrintf(kp[1]);
+        const float sx = (2 * px / cols - 1) * M_PI, sy = (0.5 - py / rows) * M_PI, cy = (float)std::cos((double)sy);
+        out[0] = (double)(1.f * cy * (float)std::sin((double)sx)); out[1] = (double)(-1.f * (float)std::sin((double)sy)); out[2] = (double)(1.f * cy * (float)std::cos((double)sx));
+      };
+      auto associate = [&](size_t i, size_t n_idx) {
+        std::vector<std::pair<int, int>> out;
+        for (const Line2Line& a : AssociateLine2Line(l[i], l[n_idx], (float)cfg.point_to_line_dis_threshold)) out.push_back({a.ref_line_idx, a.neighbor_line_idx});
+        return out;
+      };
+      CeresBatch batch(e.ctx());
+      ceres::Problem::Options po; po.evaluation_callback = &batch;
+      ceres::Problem problem(po);
+      batch.SetPoseStorage((int)aa_lw.size(), aa_lw.data()->data(), t_lw.data()->data());
+      const int cam_base = batch.AddPoseArray((int)aa_cw.size(), aa_cw.data()->data(), t_cw.data()->data());
+      ceres::LossFunction* loss1 = new ceres::HuberLoss(3 * M_PI / 180.0);
+      const size_t n_cl = AddCameraLidarResidualGpu(batch, e.ctx(), frames, l, aa_cw, t_cw, aa_lw, t_lw, pairs, loss1, problem, cfg.camera_lidar_weight, cam_base, make_rows);
+      const size_t n_cam = AddCameraResidualGpu(batch, e.ctx(), frames, aa_cw, t_cw, structure, problem, cfg.camera_weight, cam_base, bearing);
+      const size_t n_l2l = AddLidarLineToLineResidual2Gpu(batch, e.ctx(), dev, nb, l, aa_lw, t_lw, problem, matcher.GetTracks(), associate, cfg.angle_residual, cfg.normalize_distance, 1.0);
+      const size_t n_p2p = AddLidarPointToPlaneResidualGpu(batch, e.ctx(), dev, nb, l, aa_lw, t_lw, problem, cfg.point_to_plane_dis_threshold, cfg.lidar_plane_tolerance,
+                                                           cfg.angle_residual, cfg.normalize_distance, cfg.lidar_weight);
+      // the host mirror's own adders on its stand-in problem: the same block counts
+      size_t m_cl, m_cam, m_l2l, m_p2p;
+      {
+        std::vector<bool> fv(frames.size());
+        for (size_t i = 0; i < frames.size(); ++i) fv[i] = frames[i].IsPoseValid();
+        ceres_like::Problem mp;
+        m_cl = AddCameraLidarResidual(rows, cols, fv, l, aa_cw, t_cw, aa_lw, t_lw, pairs, new ceres_like::HuberLoss(3 * M_PI / 180.0), mp, cfg.camera_lidar_weight);
+        m_cam = AddCameraResidual(frames, aa_cw, t_cw, structure, mp, RESIDUAL_TYPE::ANGLE_RESIDUAL_1, cfg.camera_weight);
+        m_l2l = AddLidarLineToLineResidual2(nb, l, aa_lw, t_lw, mp, matcher.GetTracks(), cfg.point_to_line_dis_threshold, cfg.angle_residual, cfg.normalize_distance);
+        m_p2p = AddLidarPointToPlaneResidual(nb, l, aa_lw, t_lw, mp, cfg.point_to_plane_dis_threshold, cfg.lidar_plane_tolerance, cfg.angle_residual, cfg.normalize_distance,
+                                             cfg.lidar_weight);
+      }
+      printf("counts adapter %zu %zu %zu %zu mirror %zu %zu %zu %zu problem %d\n", n_cl, n_cam, n_l2l, n_p2p, m_cl, m_cam, m_l2l, m_p2p, problem.NumResidualBlocks());
+      std::vector<double> r, J;
+      problem.EvaluateAll(true, true, &r, &J);
+      // direct evaluation of the very same sets through the ABI.  Pose table = [LiDAR poses | camera poses], as the batch sets it.
+      std::vector<double> aa_all, t_all;
+      for (auto& v : aa_lw) aa_all.insert(aa_all.end(), v.begin(), v.end());
+      for (auto& v : aa_cw) aa_all.insert(aa_all.end(), v.begin(), v.end());
+      for (auto& v : t_lw) t_all.insert(t_all.end(), v.begin(), v.end());
+      for (auto& v : t_cw) t_all.insert(t_all.end(), v.begin(), v.end());
+      e.Check(pvlm_set_poses(e.ctx(), (int)(aa_all.size() / 3), aa_all.data(), t_all.data()), "poses");
+      auto direct = [&](int set, std::vector<double>& rr, std::vector<double>& JJ) {
+        int64_t m = 0; pvlm_resset_info(batch.set(set), &m, nullptr, nullptr, nullptr);
+        rr.assign((size_t)m, 0.0); JJ.assign((size_t)m * 12, 0.0);
+        e.Check(pvlm_eval(e.ctx(), batch.set(set), rr.data(), JJ.data()), "eval");
+      };
+      double dr = 0, dJ = 0, jmax = 0; size_t checked = 0; int loss_errors = 0;
+      auto cmp = [&](size_t block, const double* rr, const double* JJ, int nj) {
+        dr = std::max(dr, std::fabs(r[block] - rr[0]));
+        for (int k = 0; k < nj; ++k) { dJ = std::max(dJ, std::fabs(J[12 * block + k] - JJ[k])); jmax = std::max(jmax, std::fabs(JJ[k])); }
+        ++checked;
+      };
+      std::vector<double> ra, Ja, rb, Jb;
+      size_t at = 0;
+      direct(0, ra, Ja); direct(1, rb, Jb);                                        // sets 0 / 1: Plane2Plane_Global / PlaneIOU, interleaved in the problem
+      for (size_t k = 0; k < n_cl / 2; ++k) {
+        cmp(at, &ra[k], &Ja[12 * k], 12); if (problem.loss_of(at) != loss1) ++loss_errors; ++at;
+        cmp(at, &rb[k], &Jb[12 * k], 12); if (problem.loss_of(at) != loss1) ++loss_errors; ++at;
+      }
+      {
+        std::vector<double> rr(n_cam), JJ(n_cam * 9);
+        e.Check(pvlm_ba_eval(e.ctx(), batch.bundle(0), rr.data(), JJ.data()), "ba_eval");
+        for (size_t k = 0; k < n_cam; ++k) { cmp(at, &rr[k], &JJ[9 * k], 9); if (problem.num_parameter_blocks_of(at) != 3 || !problem.loss_of(at)) ++loss_errors; ++at; }
+      }
+      direct(2, ra, Ja);
+      for (size_t k = 0; k < n_l2l; ++k) { cmp(at, &ra[k], &Ja[12 * k], 12); if (problem.loss_of(at) != nullptr) ++loss_errors; ++at; }   // nullptr loss for the angle variant (:417)
+      direct(3, ra, Ja);
+      for (size_t k = 0; k < n_p2p; ++k) { cmp(at, &ra[k], &Ja[12 * k], 12); if (!problem.loss_of(at)) ++loss_errors; ++at; }
+      // a moved point re-evaluates everything (points included)
+      std::vector<double> r2;
+      for (auto& v : t_cw) v[1] += 1e-3;
+      for (PointTrack& t : structure) t.point_3d[0] += 1e-3;
+      problem.EvaluateAll(false, true, &r2, nullptr);
+      double moved = 0; for (size_t i = 0; i < r.size(); ++i) moved = std::max(moved, std::fabs(r2[i] - r[i]));
+      printf("rows checked %zu of %d max_dr %.3e max_dJ %.3e J_max %.3e loss_errors %d moved %.3e sets %d\n", checked, problem.NumResidualBlocks(), dr, dJ, jmax, loss_errors, moved,
+             batch.num_sets());
     } else if (cmd == "rawodometry") {
       // rawodometry <raw_scans.bin> iters angle normalize tol thr max_curvature angle_threshold segment : BASELINE config 0 plumbing —
       // raw VLP-16 scans (firing order) -> ReOrderVLP -> ExtractFeatures -> LidarOdometry::EstimatePose with the

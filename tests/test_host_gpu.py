@@ -570,6 +570,41 @@ def test_ceres_adapter_rows(tmp):
     assert moved > 1e-7                               # PrepareForEvaluation(new_evaluation_point = true) re-evaluated
 
 
+
+def test_ceres_adapter_full_optimize_problem(tmp):
+    """integration/pvlm_ceres.hpp, all FOUR adders of CameraLidarOptimizer::Optimize (AddCameraLidarResidualGpu: Plane2Plane_Global +
+    PlaneIOU, AddCameraResidualGpu: three-block reprojection rows from pvlm_ba_eval, AddLidarLineToLineResidual2Gpu: device-built
+    Point2Line rows with a nullptr loss, AddLidarPointToPlaneResidualGpu) on ONE CeresBatch against the interface-only Ceres
+    stand-in: block counts equal to the host mirror's adders, every row of one "Ceres evaluation" equal to pvlm_eval /
+    pvlm_ba_eval of the same sets (1e-13 of the row's scale), the losses the reference passes, and a re-evaluation after the
+    parameters — points included — moved."""
+    rng = np.random.default_rng(78)
+    NS = 5
+    lidars, frames, T_cl = _joint_scene(rng, NS)
+    true = []
+    for k in range(NS):
+        R_true, t_true = sy.true_pose(k)
+        T_wc = lm_twin.pose4(R_true, t_true) @ np.linalg.inv(T_cl)
+        true.append((T_wc[:3, :3].copy(), T_wc[:3, 3].copy()))
+    tracks, _ = _add_tracks(rng, frames, true, 60, (1.0, 0.5, 0.8), center=(0.0, 0.0, -3.3))
+    lpath, fpath, spath = os.path.join(tmp, "cl.bin"), os.path.join(tmp, "cf.bin"), os.path.join(tmp, "cs.bin")
+    host_io.write_scans(lpath, lidars, world=False)
+    host_io.write_frames(fpath, T_cl, frames)
+    host_io.write_structure(spath, frames, tracks)
+    out = host_io.run("ceresjoint", lpath, fpath, spath, 3, 0.05, 1.0, 0.3)
+    c = [l.split() for l in out if l.startswith("counts")][0]
+    adapter = [int(v) for v in c[2:6]]; mirror = [int(v) for v in c[7:11]]; total = int(c[12])
+    assert adapter == mirror and total == sum(adapter), (adapter, mirror, total)
+    n_cl, n_cam, n_l2l, n_p2p = adapter
+    assert n_cl >= 20 and n_cam == sum(len(tr["obs"]) for tr in tracks) and n_l2l > 100 and n_p2p > 1000
+    r = [l.split() for l in out if l.startswith("rows")][0]
+    checked, of, dr, dJ, jmax, loss_errors, moved, sets = int(r[2]), int(r[4]), float(r[6]), float(r[8]), float(r[10]), int(r[12]), float(r[14]), int(r[16])
+    assert checked == of == total and sets == 4
+    assert dr == 0.0                                  # residuals are copied, not recomputed
+    assert dJ <= 1e-13 * jmax                         # four-block rows are re-formed on the host from the wrench rows: rounding only
+    assert loss_errors == 0                           # Huber(3 deg) camera-LiDAR, Huber(4 deg) reprojection, nullptr line-to-line (Angle), Huber point-to-plane
+    assert moved > 1e-7
+
 def test_host_visible_evaluation_matches_device_rows(oracle):
     """pvlm_eval_host_async / pvlm_eval_wrench_host_async into pinned memory, sliced through a tiny staging buffer."""
     import subprocess, sys
