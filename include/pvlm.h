@@ -175,6 +175,13 @@ pvlm_status pvlm_neq_accumulate_dev(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_res
                                     double loss_a, int zero_first, double* d_packed);
 pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset* rs, pvlm_loss loss, double loss_a,
                                 int zero_first, double* packed_host_inout);
+/* The same contribution, queued: the set is linearised into the structure's OWN device buffer (kept with the handle) and its copy
+ * into `packed` (host, pvlm_neq_size() doubles) is queued behind it — nothing is allocated after the first call and nothing
+ * waits.  An LM driver calls it once per residual set of its problem (pvlm_set_poses in that set's pose numbering first) and then
+ * pvlm_synchronize ONCE: every `packed` is complete when that returns.  One submission and one synchronisation per
+ * linearisation, whatever the number of residual sets (lidar_mapping/LidarOdometry.cpp:36-80 evaluates point-to-plane and
+ * line-to-line blocks in the same ceres::Solve). */
+pvlm_status pvlm_neq_accumulate_async(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset* rs, pvlm_loss loss, double loss_a, double* packed);
 
 /* ---- panoramic reprojection blocks with point elimination ---------------------------------------- *
  * PanoramaReprojResidual_1Angle (base/CostFunction.h:218-247): r = w * angle(R(aa_cw) X + t_cw, bearing),

@@ -352,7 +352,7 @@ pvlm_status pvlm_use_own_stream(pvlm_ctx* ctx) {
 pvlm_status pvlm_synchronize(pvlm_ctx* ctx) {
   if (!ctx) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  return pvlm_i_stream_sync(ctx);   // PVLM_ERR_STATE inside a capture
+  return pvlm_i_sync(ctx);   // PVLM_ERR_STATE inside a capture; completes the queued device-to-host copies (pvlm_neq_accumulate_async)
 }
 
 pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes) {
@@ -715,6 +715,9 @@ pvlm_status pvlm_neq_destroy(pvlm_ctx* ctx, pvlm_neq* q) {
   if (!q) return PVLM_OK;
   hipSetDevice(ctx->device);
   pvlm_i_free(ctx, q->d_diag_off); pvlm_i_free(ctx, q->d_diag_items); pvlm_i_free(ctx, q->d_off_off); pvlm_i_free(ctx, q->d_off_items);
+  // a queued copy out of d_packed (pvlm_neq_accumulate_async) may still be in flight: the block goes back to the pool, whose reuse
+  // is ordered by the same stream, so the copy reads it before any later writer touches it
+  pvlm_i_free(ctx, q->d_packed);
   delete q;
   return PVLM_OK;
 }

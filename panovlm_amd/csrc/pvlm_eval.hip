@@ -814,4 +814,17 @@ pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* r
   return pvlm_i_d2h(ctx, packed, d, nb);
 }
 
+pvlm_status pvlm_neq_accumulate_async(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_resset* rs, pvlm_loss loss, double a, double* packed) {
+  if (!ctx || !q || !rs || !packed) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t cnt = (size_t)pvlm_neq_size(q);
+  if (!q->d_packed) {
+    const pvlm_status sa = pvlm_i_alloc(ctx, &q->d_packed, cnt);
+    if (sa) return sa;
+  }
+  const pvlm_status st = pvlm_neq_accumulate_dev(ctx, q, rs, loss, a, 1, q->d_packed);
+  if (st) return st;
+  return pvlm_i_d2h_q(ctx, packed, q->d_packed, cnt * sizeof(double));   // complete at the next pvlm_synchronize
+}
+
 }  // extern "C"

@@ -163,6 +163,7 @@ struct pvlm_neq {
   int* d_off_off = nullptr;    // n_upairs+1
   int* d_off_items = nullptr;  // item = pair*2 + transposed
   int64_t n_diag_items = 0, n_off_items = 0;
+  double* d_packed = nullptr;  // the structure's own packed buffer (pvlm_neq_accumulate_async), allocated on first use
 };
 
 struct pvlm_cloud {

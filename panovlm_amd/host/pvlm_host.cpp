@@ -28,13 +28,15 @@ namespace pvlm {
 
 namespace {
 std::map<std::string, double>& Stages() { static std::map<std::string, double> m; return m; }
+std::map<std::string, long>& StageCallCounts() { static std::map<std::string, long> m; return m; }
 struct StageTimer {
   const char* name; std::chrono::steady_clock::time_point t0;
   explicit StageTimer(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
-  ~StageTimer() { Stages()[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  ~StageTimer() { Stages()[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++StageCallCounts()[name]; }
 };
 }  // namespace
 const std::map<std::string, double>& StageSeconds() { return Stages(); }
+const std::map<std::string, long>& StageCalls() { return StageCallCounts(); }
 
 // ================================================================================================
 // Engine
@@ -1128,11 +1130,24 @@ struct Skyline {
   }
 };
 
+// Gauss-Newton blocks of the four-block groups at one point.  The block STRUCTURE is fixed for a whole Solve (the sorted key
+// list is built once and shared); an evaluation only refills the numbers: H[36 k ...] = block keys[k] = (pose a <= pose b),
+// 6x6 row-major d2/dx_a dx_b.  (Round 2 rebuilt a std::map of 36-double nodes at every evaluation: 1.6 ms per LM step at Room scale.)
+using BlockKeys = std::vector<std::pair<int, int>>;
 struct Assembled {
   double cost = 0;
   std::vector<double> g;                       // n_free
-  std::map<std::pair<int, int>, std::array<double, 36>> H;  // block (pose a <= pose b) 6x6 row-major (d2/dx_a dx_b)
+  std::shared_ptr<const BlockKeys> keys;
+  std::vector<double> H;                       // 36 per key
 };
+// one iteration protocol for the flat table and for the std::map the reprojection path still uses
+template <typename F> inline void ForEachBlock(const Assembled& A, F&& f) {
+  if (!A.keys) return;
+  for (size_t k = 0; k < A.keys->size(); ++k) f((*A.keys)[k], A.H.data() + 36 * k);
+}
+template <typename F> inline void ForEachBlock(const std::map<std::pair<int, int>, std::array<double, 36>>& H, F&& f) {
+  for (auto& kv : H) f(kv.first, kv.second.data());
+}
 
 }  // namespace
 
@@ -1276,29 +1291,93 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   // scalar row/col index of (pose, half, k)
   auto idx = [&](int pose, int r) { const int b = r < 3 ? I.poses[pose].first : I.poses[pose].second; return block_off[b] < 0 ? -1 : block_off[b] + (r % 3); };
 
-  // evaluates cost (+ H, g when want_H) of the four-block groups at parameter vector v
-  auto evaluate = [&](const std::vector<double>& v, bool want_H, Assembled& A) {
-    StageTimer stage_timer_eval_("solve: GPU linearisation + block assembly");
-    A.cost = 0; A.g.assign(n_free, 0.0); A.H.clear();
+  // ---- fixed block structure of the four-block groups + per-group scatter maps (built once per Solve) -----------------
+  auto keys = std::make_shared<BlockKeys>();
+  if (xch) *keys = xkeys;                       // sharded: the union over the ranks, so that the exchanged buffer IS the table
+  else {
+    std::set<std::pair<int, int>> ks;
     for (auto& g : I.groups) {
-      std::vector<double> aa((size_t)g.dev_poses * 3, 0.0), tt((size_t)g.dev_poses * 3, 0.0);
+      for (int d = 0; d < g.dev_poses; ++d) if (g.dev_to_pose[d] >= 0) ks.insert({g.dev_to_pose[d], g.dev_to_pose[d]});
+      for (size_t u = 0; u < g.ui.size(); ++u) { const int pa = g.dev_to_pose[g.ui[u]], pb = g.dev_to_pose[g.uj[u]]; ks.insert({std::min(pa, pb), std::max(pa, pb)}); }
+    }
+    keys->assign(ks.begin(), ks.end());
+  }
+  auto slot_of = [&](int a, int b) {
+    const auto it = std::lower_bound(keys->begin(), keys->end(), std::make_pair(a, b));
+    if (it == keys->end() || *it != std::make_pair(a, b)) throw std::runtime_error("Solve: block key missing from the structure");
+    return (int)(it - keys->begin());
+  };
+  // Pinned landing buffers of the groups' packed normal equations + where every block of a group goes in the flat table.
+  // Released on every exit path (Solve has several).
+  struct GroupIO {
+    double* packed = nullptr; size_t count = 0;
+    std::vector<int> diag_slot, off_slot; std::vector<char> off_transposed;
+    std::vector<double> aa, tt;
+  };
+  struct GroupIOHolder {
+    std::vector<GroupIO> io; pvlm_ctx* ctx;
+    explicit GroupIOHolder(pvlm_ctx* c) : ctx(c) {}
+    ~GroupIOHolder() { pvlm_synchronize(ctx); for (GroupIO& x : io) if (x.packed) pvlm_host_free(ctx, x.packed); }
+  } gio(e.ctx());
+  gio.io.resize(I.groups.size());
+  for (size_t gi = 0; gi < I.groups.size(); ++gi) {
+    auto& g = I.groups[gi]; GroupIO& x = gio.io[gi];
+    x.count = (size_t)pvlm_neq_size(g.neq);
+    void* p = nullptr;
+    e.Check(pvlm_host_alloc(e.ctx(), (int64_t)(x.count * sizeof(double)), &p), "pvlm_host_alloc");
+    x.packed = static_cast<double*>(p);
+    x.diag_slot.assign((size_t)g.dev_poses, -1);
+    for (int d = 0; d < g.dev_poses; ++d) if (g.dev_to_pose[d] >= 0) x.diag_slot[(size_t)d] = slot_of(g.dev_to_pose[d], g.dev_to_pose[d]);
+    x.off_slot.resize(g.ui.size()); x.off_transposed.resize(g.ui.size());
+    for (size_t u = 0; u < g.ui.size(); ++u) {
+      const int pa = g.dev_to_pose[g.ui[u]], pb = g.dev_to_pose[g.uj[u]];
+      x.off_slot[u] = slot_of(std::min(pa, pb), std::max(pa, pb)); x.off_transposed[u] = pa > pb;
+    }
+    x.aa.assign((size_t)g.dev_poses * 3, 0.0); x.tt.assign((size_t)g.dev_poses * 3, 0.0);
+  }
+
+  // evaluates cost (+ H, g when want_H) of the four-block groups at parameter vector v: ONE submission for all groups (per group:
+  // its pose table, pair table, fused kernel, epilogue, gather, queued copy into its pinned buffer), ONE synchronisation, then the
+  // groups' blocks are added into the flat table through the precomputed slots — same order of additions as ever
+  long evaluations = 0;
+  auto evaluate = [&](const std::vector<double>& v, bool want_H, Assembled& A) {
+    // the first linearisation of a Solve binds the structures to the residual sets (CSR upload), sizes the per-structure buffers
+    // and, once per process, loads the kernels' code objects: timed apart from the steady LM steps
+    StageTimer stage_timer_eval_(evaluations++ == 0 ? "solve: first linearisation of a Solve (structures bound, buffers sized, code objects loaded)"
+                                                    : "solve: GPU linearisation + block assembly");
+    static const bool eval_trace = std::getenv("PVLM_HOST_EVAL_TRACE") != nullptr;   // per-call phase times on stderr (profiling tools)
+    const auto tr0 = std::chrono::steady_clock::now();
+    A.cost = 0; A.g.assign(n_free, 0.0); A.keys = keys;
+    if (want_H) A.H.assign(36 * keys->size(), 0.0); else A.H.clear();
+    const auto tr1 = std::chrono::steady_clock::now();
+    StageTimer* stage_timer_sub_ = new StageTimer("  (inside the linearisation) submission: pose tables + kernels + copies queued");
+    for (size_t gi = 0; gi < I.groups.size(); ++gi) {
+      auto& g = I.groups[gi]; GroupIO& x = gio.io[gi];
       for (int d = 0; d < g.dev_poses; ++d) {
         const int p = g.dev_to_pose[d];
         if (p < 0) continue;
-        for (int k = 0; k < 3; ++k) { aa[3 * d + k] = v[3 * I.poses[p].first + k]; tt[3 * d + k] = v[3 * I.poses[p].second + k]; }
+        for (int k = 0; k < 3; ++k) { x.aa[3 * d + k] = v[3 * I.poses[p].first + k]; x.tt[3 * d + k] = v[3 * I.poses[p].second + k]; }
       }
-      e.Check(pvlm_set_poses(e.ctx(), g.dev_poses, aa.data(), tt.data()), "pvlm_set_poses");
-      std::vector<double> packed((size_t)pvlm_neq_size(g.neq), 0.0);
-      e.Check(pvlm_neq_accumulate(e.ctx(), g.neq, g.set, g.loss ? g.loss->kind() : PVLM_LOSS_NONE, g.loss ? g.loss->a() : 0.0, 1, packed.data()),
-              "pvlm_neq_accumulate");
+      e.Check(pvlm_set_poses(e.ctx(), g.dev_poses, x.aa.data(), x.tt.data()), "pvlm_set_poses");
+      e.Check(pvlm_neq_accumulate_async(e.ctx(), g.neq, g.set, g.loss ? g.loss->kind() : PVLM_LOSS_NONE, g.loss ? g.loss->a() : 0.0, x.packed),
+              "pvlm_neq_accumulate_async");
+    }
+    delete stage_timer_sub_;
+    const auto tr2 = std::chrono::steady_clock::now();
+    { StageTimer stage_timer_wait_("  (inside the linearisation) the one synchronisation"); e.Check(pvlm_synchronize(e.ctx()), "pvlm_synchronize"); }
+    const auto tr3 = std::chrono::steady_clock::now();
+    StageTimer stage_timer_merge_("  (inside the linearisation) host: groups' blocks into the flat table");
+    for (size_t gi = 0; gi < I.groups.size(); ++gi) {
+      auto& g = I.groups[gi]; const GroupIO& x = gio.io[gi];
+      const double* packed = x.packed;
       const int nd = g.dev_poses, nu = (int)g.ui.size();
-      A.cost += packed.back();
+      A.cost += packed[x.count - 1];
       if (!want_H) continue;
-      const double* Hd = packed.data(); const double* Ho = Hd + (size_t)nd * 36; const double* gg = Ho + (size_t)nu * 36;
+      const double* Hd = packed; const double* Ho = Hd + (size_t)nd * 36; const double* gg = Ho + (size_t)nu * 36;
       for (int d = 0; d < nd; ++d) {
         const int p = g.dev_to_pose[d];
         if (p < 0) continue;
-        auto& blk = A.H[{p, p}];
+        double* blk = A.H.data() + 36 * (size_t)x.diag_slot[(size_t)d];
         for (int k = 0; k < 36; ++k) blk[k] += Hd[(size_t)d * 36 + k];
         for (int half = 0; half < 2; ++half) {
           const int b = half ? I.poses[p].second : I.poses[p].first;
@@ -1306,35 +1385,28 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
         }
       }
       for (int u = 0; u < nu; ++u) {
-        int pa = g.dev_to_pose[g.ui[u]], pb = g.dev_to_pose[g.uj[u]];
         const double* src = Ho + (size_t)u * 36;  // d2/dx_ui dx_uj
-        if (pa <= pb) { auto& blk = A.H[{pa, pb}]; for (int k = 0; k < 36; ++k) blk[k] += src[k]; }
-        else { auto& blk = A.H[{pb, pa}]; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[r * 6 + c] += src[c * 6 + r]; }
+        double* blk = A.H.data() + 36 * (size_t)x.off_slot[(size_t)u];
+        if (!x.off_transposed[(size_t)u]) for (int k = 0; k < 36; ++k) blk[k] += src[k];
+        else for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[r * 6 + c] += src[c * 6 + r];
       }
+    }
+    if (eval_trace) {
+      const auto tr4 = std::chrono::steady_clock::now();
+      auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      fprintf(stderr, "[eval %ld] zero %.0f us, submission %.0f us, synchronisation %.0f us, merge %.0f us (%zu groups, %zu keys)\n", evaluations, us(tr0, tr1), us(tr1, tr2),
+              us(tr2, tr3), us(tr3, tr4), I.groups.size(), keys->size());
     }
     if (xch) {
       // the one exchange of an evaluation: [cost | g | blocks in key order], summed over the ranks;
       // afterwards every rank holds the same Assembled, bit for bit
       StageTimer stage_timer_x_("solve: exchange of the normal equations");
-      std::vector<double> buf(want_H ? 1 + (size_t)n_free + xkeys.size() * 36 : 1, 0.0);
+      std::vector<double> buf(want_H ? 1 + (size_t)n_free + A.H.size() : 1, 0.0);
       buf[0] = A.cost;
-      if (want_H) {
-        std::copy(A.g.begin(), A.g.end(), buf.begin() + 1);
-        for (size_t k = 0; k < xkeys.size(); ++k) {
-          auto it = A.H.find(xkeys[k]);
-          if (it != A.H.end()) std::copy(it->second.begin(), it->second.end(), buf.begin() + 1 + n_free + (std::ptrdiff_t)k * 36);
-        }
-      }
+      if (want_H) { std::copy(A.g.begin(), A.g.end(), buf.begin() + 1); std::copy(A.H.begin(), A.H.end(), buf.begin() + 1 + n_free); }
       xch->allreduce_sum(buf.data(), buf.size());
       A.cost = buf[0];
-      if (want_H) {
-        std::copy(buf.begin() + 1, buf.begin() + 1 + n_free, A.g.begin());
-        A.H.clear();
-        for (size_t k = 0; k < xkeys.size(); ++k) {
-          auto& blk = A.H[xkeys[k]];
-          std::copy(buf.begin() + 1 + n_free + (std::ptrdiff_t)k * 36, buf.begin() + 1 + n_free + (std::ptrdiff_t)(k + 1) * 36, blk.begin());
-        }
-      }
+      if (want_H) { std::copy(buf.begin() + 1, buf.begin() + 1 + n_free, A.g.begin()); std::copy(buf.begin() + 1 + n_free, buf.end(), A.H.begin()); }
     }
   };
 
@@ -1446,15 +1518,17 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
         first[hi] = std::min(first[hi], lo);
       }
     };
-    for (auto& kv : As.H) add(kv.first);
-    for (auto& kv : Rs.H) add(kv.first);
+    ForEachBlock(As, [&](const std::pair<int, int>& key, const double*) { add(key); });
+    ForEachBlock(Rs.H, [&](const std::pair<int, int>& key, const double*) { add(key); });
     return first;
   };
   // diagonal of the FULL J^T J on the free pose columns (before any elimination)
   auto full_diag = [&](const Assembled& As, const Reduced& Rs) {
     std::vector<double> d(n_free, 0.0);
-    for (auto& kv : As.H) if (kv.first.first == kv.first.second)
-      for (int r = 0; r < 6; ++r) { const int i = idx(kv.first.first, r); if (i >= 0) d[i] += kv.second[r * 6 + r]; }   // += : two poses may share a parameter block
+    ForEachBlock(As, [&](const std::pair<int, int>& key, const double* blk) {
+      if (key.first != key.second) return;
+      for (int r = 0; r < 6; ++r) { const int i = idx(key.first, r); if (i >= 0) d[i] += blk[r * 6 + r]; }   // += : two poses may share a parameter block
+    });
     for (int i = 0; i < n_free; ++i) d[i] += Rs.Udiag[i];
     return d;
   };
@@ -1473,34 +1547,35 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     return m;
   };
   if (gmax(A, R) <= opt.gradient_tolerance) { summary->message = "gradient tolerance reached"; finish_points(); return; }
-  auto fill = [&](Skyline& S, const std::map<std::pair<int, int>, std::array<double, 36>>& H) {
-    for (auto& kv : H)
+  auto fill = [&](Skyline& S, const auto& H) {
+    ForEachBlock(H, [&](const std::pair<int, int>& key, const double* blk) {
       for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-        const int i = idx(kv.first.first, r), j = idx(kv.first.second, c);
+        const int i = idx(key.first, r), j = idx(key.second, c);
         if (i < 0 || j < 0) continue;
-        const double v = kv.second[r * 6 + c] * scale[i] * scale[j];
-        if (kv.first.first == kv.first.second) { if (i >= j) S.at(i, j) += v; }   // diagonal block: lower triangle once
+        const double v = blk[r * 6 + c] * scale[i] * scale[j];
+        if (key.first == key.second) { if (i >= j) S.at(i, j) += v; }   // diagonal block: lower triangle once
         else if (i >= j) S.at(i, j) += v; else S.at(j, i) += v;
       }
+    });
   };
   // Large reduced systems (Room / Floor sized joint problems: thousands of unknowns) are assembled, factorised and solved
   // on the GPU (pvlm_spd_solve_blocks: blocked Cholesky kernels); small ones by the host skyline Cholesky.
   const char* gpu_min_env = std::getenv("PVLM_GPU_CHOLESKY_MIN");
   const bool gpu_chol = n_free >= (gpu_min_env ? std::atoi(gpu_min_env) : 1500);
   // v^T (D H D) v over a block list, without forming the matrix
-  auto quad_form = [&](const std::map<std::pair<int, int>, std::array<double, 36>>& H, const std::vector<double>& v) {
+  auto quad_form = [&](const auto& H, const std::vector<double>& v) {
     double q = 0.0;
-    for (auto& kv : H) {
+    ForEachBlock(H, [&](const std::pair<int, int>& key, const double* blk) {
       double b = 0.0;
       for (int r = 0; r < 6; ++r) {
-        const int i = idx(kv.first.first, r);
+        const int i = idx(key.first, r);
         if (i < 0) continue;
         double row = 0.0;
-        for (int c = 0; c < 6; ++c) { const int j = idx(kv.first.second, c); if (j >= 0) row += kv.second[r * 6 + c] * scale[j] * v[j]; }
+        for (int c = 0; c < 6; ++c) { const int j = idx(key.second, c); if (j >= 0) row += blk[r * 6 + c] * scale[j] * v[j]; }
         b += scale[i] * v[i] * row;
       }
-      q += kv.first.first == kv.first.second ? b : 2.0 * b;
-    }
+      q += key.first == key.second ? b : 2.0 * b;
+    });
     return q;
   };
   while (iter < opt.max_num_iterations) {
@@ -1522,14 +1597,14 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       StageTimer stage_timer_chol_("solve: GPU Cholesky");
       StageTimer* stage_timer_push_ = new StageTimer("  (inside the GPU Cholesky stage) host block list");
       std::vector<int> rows, cols, mirror; std::vector<double> blocks;
-      auto push = [&](const std::map<std::pair<int, int>, std::array<double, 36>>& H) {
-        for (auto& kv : H) {
-          for (int r = 0; r < 6; ++r) { rows.push_back(idx(kv.first.first, r)); cols.push_back(idx(kv.first.second, r)); }
-          mirror.push_back(kv.first.first != kv.first.second ? 1 : 0);
-          blocks.insert(blocks.end(), kv.second.begin(), kv.second.end());
-        }
+      auto push = [&](const auto& H) {
+        ForEachBlock(H, [&](const std::pair<int, int>& key, const double* blk) {
+          for (int r = 0; r < 6; ++r) { rows.push_back(idx(key.first, r)); cols.push_back(idx(key.second, r)); }
+          mirror.push_back(key.first != key.second ? 1 : 0);
+          blocks.insert(blocks.end(), blk, blk + 36);
+        });
       };
-      push(A.H);
+      push(A);
       if (have_bundles) push(R.H);
       delete stage_timer_push_;
       int info = 0;
@@ -1538,7 +1613,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       step_ok = info == 0;
     } else {
       S0.Init(build_first(A, R));
-      fill(S0, A.H);
+      fill(S0, A);
       Skyline S = S0;
       if (have_bundles) fill(S, R.H);
       for (int i = 0; i < n_free; ++i) S.at(i, i) += damp[i];
@@ -1552,7 +1627,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       if (gpu_chol) {
         std::vector<double> unit(n_free);
         for (int i = 0; i < n_free; ++i) unit[i] = dy[i];
-        dHd = quad_form(A.H, unit);
+        dHd = quad_form(A, unit);
       } else {
         for (int i = 0; i < n_free; ++i) {
           double s = 0.0;

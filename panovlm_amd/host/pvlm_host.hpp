@@ -88,6 +88,7 @@ struct Config {
 // Wall-clock seconds accumulated per stage of the mirrored call surface (association, track building, solve, ...)
 // since the process started — what tools/room_like_odometry.py prints beside the end-to-end time.
 const std::map<std::string, double>& StageSeconds();
+const std::map<std::string, long>& StageCalls();       // how many times each stage ran
 
 // The process-wide engine (one pvlm_ctx).  Throws std::runtime_error when no GPU / library.
 class Engine {

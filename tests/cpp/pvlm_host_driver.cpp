@@ -220,7 +220,7 @@ int main(int argc, char** argv) {
       }
       printf("call %.6f context creation (once per process)\n", std::chrono::duration<double>(t_call - t_ctx).count());
       printf("call %.6f LidarOdometry::EstimatePose\n", std::chrono::duration<double>(t_end - t_call).count());
-      for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());
+      for (auto& kv : StageSeconds()) printf("stage %.6f %s [%ld calls]\n", kv.second, kv.first.c_str(), StageCalls().at(kv.first));
       PrintPoses(odo.GetLidarData());
     } else if (cmd == "ceresadapter") {
       // ceresadapter <scans.bin> tol thr : integration/pvlm_ceres.hpp driven through the interface-only Ceres test double —
@@ -490,7 +490,7 @@ int main(int argc, char** argv) {
       opt.SetStructure(structure);
       opt.JointOptimize();
       for (auto& it : opt.log) printf("iter cost %.17g steps %d blocks %d pairs %zu\n", it.cost, it.steps, it.residual_blocks, it.line_pairs);
-      for (auto& kv : StageSeconds()) printf("stage %.6f %s\n", kv.second, kv.first.c_str());
+      for (auto& kv : StageSeconds()) printf("stage %.6f %s [%ld calls]\n", kv.second, kv.first.c_str(), StageCalls().at(kv.first));
       for (auto& it : opt.log) { printf("hist"); for (double c : it.cost_history) printf(" %.17g", c); printf("\n"); }
       PrintPoses(opt.GetLidars());
       PrintFrames(opt.GetFrames());

@@ -48,9 +48,14 @@ def write_scans(path, scans, world=True):
 
 
 def run(*args, timeout=600):
-    out = subprocess.run([driver()] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    # PVLM_DRIVER_PREFIX: a command the driver is run under, e.g. "rocprofv3 --kernel-trace --stats -d DIR --" (profiling tools only)
+    prefix = os.environ.get("PVLM_DRIVER_PREFIX", "").split()
+    out = subprocess.run(prefix + [driver()] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
     if out.returncode != 0:
         raise RuntimeError("driver failed (%d): %s" % (out.returncode, out.stderr[-2000:]))
+    if os.environ.get("PVLM_HOST_EVAL_TRACE"):
+        import sys
+        sys.stderr.write(out.stderr)
     return out.stdout.splitlines()
 
 

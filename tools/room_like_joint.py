@@ -18,6 +18,16 @@ def cam_to_image(rows, cols, p):
     return np.stack([cols * (0.5 + lon / (2 * np.pi)), rows * (0.5 - lat / np.pi)], axis=1)
 
 
+def _stage_line(l):
+    """'stage <seconds> <label> [<n> calls]' of the driver -> seconds, label, ms per call"""
+    import re
+    m = re.match(r"stage (\S+) (.*) \[(\d+) calls\]$", l)
+    if not m:
+        return "   stage %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:]))
+    sec, label, n = float(m.group(1)), m.group(2), int(m.group(3))
+    return "   stage %8.3f s  %s  [%d calls, %.3f ms each]" % (sec, label, n, sec / max(n, 1) * 1e3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
@@ -78,7 +88,7 @@ def main():
         if l.startswith("iter"):
             print("  ", l)
         if l.startswith("stage"):
-            print("   stage %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:])))
+            print(_stage_line(l))
     poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}
     e0 = np.mean([np.linalg.norm(lidars[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, F)])
     e1 = np.mean([np.linalg.norm(poses[k][9:] - sy.true_pose(k)[1]) for k in range(1, F)])

@@ -40,6 +40,16 @@ def room_scan(k, rng, lines=None):
     return out
 
 
+def _stage_line(l):
+    """'stage <seconds> <label> [<n> calls]' of the driver -> seconds, label, ms per call"""
+    import re
+    m = re.match(r"stage (\S+) (.*) \[(\d+) calls\]$", l)
+    if not m:
+        return "   stage %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:]))
+    sec, label, n = float(m.group(1)), m.group(2), int(m.group(3))
+    return "   stage %8.3f s  %s  [%d calls, %.3f ms each]" % (sec, label, n, sec / max(n, 1) * 1e3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=64)
@@ -74,7 +84,7 @@ def main():
             print("   call  %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:])))
     for l in out:
         if l.startswith("stage"):
-            print("   stage %8.3f s  %s" % (float(l.split()[1]), " ".join(l.split()[2:])))
+            print(_stage_line(l))
     print("mean translation error vs ground truth: %.4f m -> %.4f m" % (e0, e1))
     if a.twin > 0:
         from oracle import oracle as orc
