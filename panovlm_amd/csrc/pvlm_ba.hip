@@ -71,6 +71,14 @@ __global__ void __launch_bounds__(128) k_ba_points(pvlm_ba::View v, const double
   if (p < v.n_points) pvlm_ba::point_pass(v, pose_tab, p, init_scale, radius, min_diag, max_diag, gmax);
 }
 
+// Round 1's scatter of every observation's rank-one blocks with fp64 atomics: 9.1 ms against 0.64 ms for the gather below at Room
+// scale, and not bit-reproducible (profiles/r1_bundle_bench.json).  Kept out of the default library; a library
+// built with -DPVLM_MEASURED_VARIANTS=1 (python -m panovlm_amd.build --variant measured -DPVLM_MEASURED_VARIANTS=1) selects it
+// with PVLM_BA_ATOMICS=1.
+#ifndef PVLM_MEASURED_VARIANTS
+#define PVLM_MEASURED_VARIANTS 0
+#endif
+#if PVLM_MEASURED_VARIANTS
 __global__ void __launch_bounds__(128) k_ba_obs(pvlm_ba::View v, const double* __restrict__ pose_tab, double* packed, double* cost) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   double c = 0.0;
@@ -78,6 +86,7 @@ __global__ void __launch_bounds__(128) k_ba_obs(pvlm_ba::View v, const double* _
   c = wave_sum(c);
   if ((threadIdx.x & 63) == 0 && c != 0.0) unsafeAtomicAdd(cost, c);
 }
+#endif
 
 // Pass B, gather form: wave s sums the couples of block s (s < n_cams: diagonal block of camera s + its g / Udiag / gcam /
 // cost share; otherwise pair s - n_cams) — lane-strided partial sums, then a fixed shuffle tree: no atomics, bit-reproducible.
@@ -406,10 +415,13 @@ pvlm_status pvlm_ba_reduce(pvlm_ctx* ctx, pvlm_baset* set, pvlm_loss loss, doubl
     PVLM_HIP(ctx, hipGetLastError());
   }
   {
-    static const bool scatter = getenv("PVLM_BA_ATOMICS") != nullptr;   // PVLM_BA_ATOMICS=1: round 1's scatter with fp64 atomics (k_ba_obs, measured variant)
+#if PVLM_MEASURED_VARIANTS
+    static const bool scatter = getenv("PVLM_BA_ATOMICS") != nullptr;   // round 1's scatter with fp64 atomics (k_ba_obs)
     if (scatter) {
       if (set->n_obs) hipLaunchKernelGGL(k_ba_obs, dim3((unsigned)((set->n_obs + 127) / 128)), dim3(128), 0, ctx->stream, v, ctx->d_pose_tab, set->d_packed, d_cost);
-    } else {
+    } else
+#endif
+    {
       const int n_slots = set->n_cams + set->n_upairs;
       if (n_slots) hipLaunchKernelGGL(k_ba_blocks, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, ctx->stream, v, ctx->d_pose_tab, set->d_cpl_off, set->d_cpl, set->d_packed,
                                       set->d_cost_cam);

@@ -17,6 +17,14 @@
 // like LAPACK) makes every later kernel of the sequence return at once.
 #define PVLM_CHOL_NB 32
 
+// Measured variants that lost (round 1's separate diagonal / panel launches, the register-tiled VALU trailing update, the two-stream
+// look-ahead) are compiled only into a library built with -DPVLM_MEASURED_VARIANTS=1 (python -m panovlm_amd.build --variant measured
+// -DPVLM_MEASURED_VARIANTS=1), where PVLM_CHOL_SPLIT / PVLM_CHOL_VALU / PVLM_CHOL_LOOKAHEAD select them; their numbers are in
+// profiles/r1_chol_bench.jsonl and DESIGN.md §3 K10.
+#ifndef PVLM_MEASURED_VARIANTS
+#define PVLM_MEASURED_VARIANTS 0
+#endif
+#if PVLM_MEASURED_VARIANTS
 __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ M, int n, int k0, int kb, double* __restrict__ Linv, int* __restrict__ info) {
   __shared__ double a[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
   __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
@@ -78,6 +86,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, int 
   for (int d = 0; d <= c; ++d) x += As[lr][d] * inv[c][d];
   if (live) M[(size_t)row * n + k0 + c] = x;
 }
+#endif  // PVLM_MEASURED_VARIANTS
 
 __device__ __forceinline__ double bcast_f64(double v, int src_lane) {     // v of lane src_lane (wave-uniform source) for every lane
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -208,6 +217,7 @@ __device__ __forceinline__ void chol_fwd_rows(const double* __restrict__ M, int 
   b[i] -= sacc;
 }
 
+#if PVLM_MEASURED_VARIANTS
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info,
                                                      int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y, int part) {
   if ((int)blockIdx.x >= n_tile_blocks) { if (*info == 0) chol_fwd_rows(M, n, k0, kb, (int)blockIdx.x - n_tile_blocks, fwd_b, fwd_y); return; }
@@ -247,6 +257,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int
     }
   }
 }
+
+#endif  // PVLM_MEASURED_VARIANTS
 
 // The same rank-32 trailing update on the matrix core: v_mfma_f64_16x16x4_f64 (the one GEMM-shaped kernel of this
 // library).  A 64 x 64 tile per workgroup, wave w owns the 16-row band [16w, 16w + 16) and all four 16-column tiles:
@@ -348,9 +360,13 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
 // d_Linv: ceil(n / 32) x 32 x 32 doubles (inverses of the diagonal blocks), d_y: n doubles (forward-solve result).
 static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, double* d_Linv, double* d_y, int* d_info) {
   hipStream_t s = ctx->stream;
+#if PVLM_MEASURED_VARIANTS
   static const bool use_mfma = getenv("PVLM_CHOL_VALU") == nullptr;   // PVLM_CHOL_VALU=1: the register-tiled VALU update (measured variant)
   static const bool fused = getenv("PVLM_CHOL_SPLIT") == nullptr;      // PVLM_CHOL_SPLIT=1: round 1's launch structure (k_chol_diag, k_chol_panel, k_fwd_step)
   static const bool want_ahead = getenv("PVLM_CHOL_LOOKAHEAD") != nullptr;   // opt-in: measured SLOWER (below)
+#else
+  const bool fused = true, want_ahead = false;                        // the default library: fused diagonal + panel launch, MFMA-f64 update, one stream
+#endif
   const bool ride = fused && nrhs >= 1;                                // the first right-hand side's forward substitution rides along
   // Look-ahead on a second stream (PVLM_CHOL_LOOKAHEAD=1; built, measured, not adopted: 5.45 ms against 4.56 ms at n = 2724 —
   // two event records and two stream waits per block column cost more on this runtime than the 20 us of overlap they buy):
@@ -369,8 +385,10 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
   int step = 0, last_u2 = -1;
   auto launch_update = [&](hipStream_t st, int k0, int kb, int tiles, int part, int tile_blocks, int fwd_blocks) {
     if (tile_blocks + fwd_blocks <= 0) return;
-    if (use_mfma) hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part);
-    else hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part);
+#if PVLM_MEASURED_VARIANTS
+    if (!use_mfma) { hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part); return; }
+#endif
+    hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part);
   };
   for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB, ++step) {
     const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
@@ -379,10 +397,13 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
       // in *info, which the later launches test on entry
       hipLaunchKernelGGL(k_chol_diag_panel, dim3(std::max(1, (rem + 7) / 8)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info, d_info,
                          ride ? (const double*)d_B : nullptr, d_y);
-    } else {
+    }
+#if PVLM_MEASURED_VARIANTS
+    else {
       hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
       if (rem > 0) hipLaunchKernelGGL(k_chol_panel, dim3((rem + 7) / 8), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info);
     }
+#endif
     if (rem > 0) {
       const int tiles = (rem + 63) / 64;
       const int fwd_blocks = ride ? (rem + 255) / 256 : 0;

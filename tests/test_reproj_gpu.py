@@ -101,8 +101,10 @@ def test_reduce_step_cost_match_oracle(ctx, oracle, loss):
 def test_reduce_is_bit_reproducible_and_equals_the_atomic_scatter(oracle):
     """pvlm_ba_reduce gathers every 6 x 6 block of the reduced camera system from its list of observation couples (one wave
     per block, fixed summation order): two runs give identical bits — also for the scalar results of step / cost — and the
-    result equals round 1's atomic scatter (PVLM_BA_ATOMICS=1, read when the library is first used: a child process) to
-    rounding.  A track with two observations in the SAME camera exercises the (i, j != i) couples of a diagonal block."""
+    result equals round 1's atomic scatter to rounding.  The scatter kernel is no longer in the default library (round 3: the
+    losing variants are compiled out); the comparison runs when a library built with -DPVLM_MEASURED_VARIANTS=1 is present
+    (python -m panovlm_amd.build --variant measured -DPVLM_MEASURED_VARIANTS=1 -> build/var/libpvlm_measured.so), in a child
+    process with PVLM_LIB pointing at it and PVLM_BA_ATOMICS=1.  A track with two observations in the SAME camera exercises the (i, j != i) couples of a diagonal block."""
     import subprocess, sys, os, textwrap
     code = textwrap.dedent("""
         import sys, numpy as np
@@ -130,10 +132,13 @@ def test_reduce_is_bit_reproducible_and_equals_the_atomic_scatter(oracle):
     import tempfile
     res = {}
     with tempfile.TemporaryDirectory() as d:
+        measured = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "var", "libpvlm_measured.so")
         for mode in ("gather", "atomics"):
             env = dict(os.environ)
             if mode == "atomics":
-                env["PVLM_BA_ATOMICS"] = "1"
+                if not os.path.exists(measured):
+                    continue
+                env["PVLM_BA_ATOMICS"] = "1"; env["PVLM_LIB"] = measured
             path = os.path.join(d, mode + ".npy")
             r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
             if mode == "gather":

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Wall time of pvlm_spd_solve_blocks (K10: device assembly + blocked Cholesky + triangular solves) on a Room-sized
 reduced pose system: P poses (6 unknowns each), pose 0 constant, every pose coupled to its next `band` poses.
-PVLM_CHOL_VALU=1 selects the VALU trailing update instead of the MFMA-f64 one.  Checks the residual of the solution."""
+PVLM_CHOL_VALU=1 selects the VALU trailing update instead of the MFMA-f64 one — only in a library built with
+-DPVLM_MEASURED_VARIANTS=1 (PVLM_LIB=build/var/libpvlm_measured.so); the default library has the MFMA update only.  Checks the residual of the solution."""
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
