@@ -389,6 +389,58 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// The same evaluation with a WAVE as the unit of work (work-list entry = (pair, chunk) per wave, four independent waves per
+// workgroup): for residual sets made of many short segments — Room / Floor odometry: thousands of scan pairs of a few hundred
+// blocks each — where a 256-thread workgroup per segment leaves most lanes idle and pays a 28-value cross-wave reduction through
+// LDS + a barrier per segment.  A wave streams 128 rows per iteration and reduces with shuffles only.  Selected per residual set
+// at finalize (pvlm_resset::wave_units: mean segment < 4096 rows); the headline's long segments keep k_eval_fused.
+template <int KIND, bool NORM, int NCOLS, int LOSS>
+__global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused_wave(const double* const* __restrict__ pair_cols,
+                                                    const int64_t* __restrict__ pair_stride,
+                                                    const int64_t* __restrict__ out_start,
+                                                    const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
+                                                    int chunk_rows, int n_units, const double* __restrict__ pair_tab, double weight,
+                                                    double loss_a, double* __restrict__ partials) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (unit >= n_units) return;
+  const int p = blk_pair[unit];
+  const double* __restrict__ cols = pair_cols[p];
+  const int64_t n_dev = pair_stride[p];
+  const int64_t len = out_start[p + 1] - out_start[p];
+  const int64_t lo = (int64_t)blk_chunk[unit] * chunk_rows;
+  const int64_t hi = min(len, lo + (int64_t)chunk_rows);
+  double T[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) T[k] = pair_tab[(size_t)p * PVLM_PAIR_TAB + k];
+  double acc[PVLM_PARTIAL];
+#pragma unroll
+  for (int k = 0; k < PVLM_PARTIAL; ++k) acc[k] = 0.0;
+  const double a2 = loss_a * loss_a;
+  for (int64_t j = lo + 2 * (int64_t)lane; j < hi; j += 128) {
+    double2 v[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (j + h >= hi) break;
+      double rec[NCOLS];
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
+      accumulate_row<KIND, NORM, NCOLS, LOSS>(rec, T, weight, loss_a, a2, acc);
+    }
+  }
+  // fixed shuffle tree; lane k keeps total k, so that the 28 results leave in one coalesced store
+  double mine = 0.0;
+#pragma unroll
+  for (int k = 0; k < PVLM_PARTIAL; ++k) {
+    double s = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == k) mine = s;
+  }
+  if (lane < PVLM_PARTIAL) partials[(size_t)unit * PVLM_PARTIAL + lane] = mine;
+}
+
 // one block (128 threads) per pair: sum chunk partials in order, expand S, apply
 // D_r = blockdiag(Jl_r, I), D_n = blockdiag(M_n, -R_rn) and write the 121-double pair block.
 __global__ __launch_bounds__(128) void k_pair_epilogue(int P, const int* __restrict__ pair_blk_start,
@@ -548,6 +600,16 @@ static void launch_wrench(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_w, int
 
 template <int KIND, bool NORM, int NCOLS>
 static void launch_fused(pvlm_ctx* ctx, const pvlm_resset* rs, int loss, double a) {
+  if (rs->wave_units) {          // many short segments: one wave per (pair, chunk)
+    const dim3 grid((unsigned)((rs->n_blocks + 3) / 4));
+    if (loss == PVLM_LOSS_HUBER)
+      hipLaunchKernelGGL((k_eval_fused_wave<KIND, NORM, NCOLS, PVLM_LOSS_HUBER>), grid, dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride, rs->d_out_start,
+                         rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->n_blocks, rs->d_pair_tab, rs->weight, a, rs->d_partials);
+    else
+      hipLaunchKernelGGL((k_eval_fused_wave<KIND, NORM, NCOLS, PVLM_LOSS_NONE>), grid, dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride, rs->d_out_start,
+                         rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->n_blocks, rs->d_pair_tab, rs->weight, a, rs->d_partials);
+    return;
+  }
   if (loss == PVLM_LOSS_HUBER)
     hipLaunchKernelGGL((k_eval_fused<KIND, NORM, NCOLS, PVLM_LOSS_HUBER>), dim3(rs->n_blocks), dim3(256), 0, ctx->stream, rs->d_pair_cols,
                        rs->d_pair_stride, rs->d_out_start, rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab,

@@ -132,6 +132,7 @@ struct pvlm_resset {
   // block work list: block b handles rows [chunk*chunk_rows, ...) of pair blk_pair[b]
   int n_blocks = 0;
   int chunk_rows = 0;
+  bool wave_units = false;   // the fused kernel takes one work-list entry per WAVE (short segments), see pvlm_i_resset_finalize
   int* d_blk_pair = nullptr;
   int* d_blk_chunk = nullptr;
   int* d_pair_blk_start = nullptr;  // n_pairs+1

@@ -339,6 +339,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
+// MEASURED VARIANT, not in the default library (built with -DPVLM_MEASURED_VARIANTS=1, selected with PVLM_MVS_SPEC=1).  Round 3 built
+// it to shorten the per-pixel chain of a single view's sequential sweep and measured NO gain
+// (profiles/r3_mvs_spec_ab.txt, 1440 x 720, 4 neighbours): 156.9 ms per iteration against 152.9 ms for the wave-per-pixel kernel;
+// per launch 72 us against 70 us on full 720-pixel diagonals, 38 us against 50 us on diagonals shorter than 50 pixels.  Why: a
+// pixel costs a fixed ~20 us (patch statistics, close neighbours, dependent global loads) plus ~4-5 us per CHAINED scoring; the
+// speculation cuts the chain from 8 scorings to 3, but every one of the four waves repeats the fixed part, so a full diagonal is
+// 2880 waves of (fixed + 3 scorings) on 1024 SIMDs — throughput-bound at about the time one wave per SIMD needs for its whole chain.
+// The exactness argument (process_pixel_spec == process_pixel, any batch width) stays tested on the CPU (tests/test_mvs_cpu.py).
+#ifndef PVLM_MEASURED_VARIANTS
+#define PVLM_MEASURED_VARIANTS 0
+#endif
+#if PVLM_MEASURED_VARIANTS
+// The same anti-diagonal with FOUR waves per pixel (one workgroup = one pixel): a single view's diagonal is at most
+// min(rows, cols) pixels, i.e. with a wave per pixel a sixth of the chip's wave slots, each running a chain of 8-14 dependent
+// scorings of ~1300 instructions.  pvlm_mvs::process_pixel_spec scores the independent hypotheses of a pixel side by side — the two
+// propagated ones; batches of four consecutive refinements built as if none of them were accepted — one per wave, exchanges the four
+// confidences through LDS and resolves them in order: the same result as the chain, bit for bit, in 1 + ~3 dependent scorings.
+template <int M>
+struct BlockBatch {
+  WaveScorer<M>* scorer; int wave, lane; pvlm_mvs::Hypothesis* xchg; int phase;
+  __device__ int width() const { return 4; }
+  template <class Build>
+  __device__ void run(int n, const float* view_ray, const pvlm_mvs::ClosePixel* close, int n_close, Build&& build, pvlm_mvs::Hypothesis* out) {
+    pvlm_mvs::Hypothesis mine;
+    mine.normal[0] = mine.normal[1] = mine.normal[2] = 0.f; mine.depth = 0.f; mine.conf = -1.f; mine.valid = 0;
+    if (wave < n) {
+      build(wave, mine);
+      if (mine.valid) mine.conf = pvlm_mvs::score_hypothesis(*scorer, view_ray, close, n_close, mine);
+      if (lane == 0) xchg[phase * 4 + wave] = mine;
+    }
+    __syncthreads();
+    // two exchange buffers: a wave that runs ahead writes batch t + 1 into the other half and then waits at ITS barrier, which the
+    // slowest wave only reaches after it has read batch t
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (w < n) out[w] = xchg[phase * 4 + w];
+    phase ^= 1;
+  }
+  __device__ WaveScorer<M>& single() { return *scorer; }
+};
+
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_diag_spec(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
+    float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int diag, int backward) {
+  const int r0 = max(0, diag - (cols - 1));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int py = r0 + (int)blockIdx.x;                                    // one workgroup per pixel of the diagonal
+  const int px = diag - py;
+  const long long e = (long long)py * cols + px;
+  float dep = depth[e];
+  if (dep <= 0) return;                                                   // every exit before the first batch is taken by the four waves alike
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
+  __shared__ pvlm_mvs::Hypothesis xchg[8];
+  float4* lds = strips[wave];
+  PatchRegs<M> P;
+  wave_fill_patch<M>(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
+  if (!P.inside || P.sq0 <= 0) return;                                    // patch.sq0 <= 0 (:1069, :1087)
+  float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+  float c = conf[e];
+  pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+  pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
+  WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
+  BlockBatch<M> batch{&scorer, wave, lane, xchg, 0};
+  const int sgn = backward ? 1 : -1;
+  const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
+  pvlm_mvs::process_pixel_spec(A, rng, px, py, batch, dep, nrm3, c, 2, pdx, pdy);
+  // the pixel's neighbours on this diagonal are other workgroups' pixels and nobody reads (px, py) before the next launch
+  if (threadIdx.x == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+}
+#endif  // PVLM_MEASURED_VARIANTS
+
 // Several views per launch (grid.y = job): a single diagonal is at most min(rows, cols) waves — a third of the chip's SIMDs at
 // 1440 x 720, each running ONE wave with nothing to overlap its latencies — so the sequential sweep of one view is launch- and
 // latency-bound (134 ms per iteration against 29 ms for the checkerboard).  Upstream parallelises this strategy over IMAGES
@@ -402,10 +474,26 @@ static void launch_mvs_propagate_sequential(hipStream_t s, int rows, int cols, i
                                             float min_depth, float max_depth, unsigned long long pass_seed, int iter) {
   const int backward = iter % 2, n_diag = rows + cols - 1;
   const bool small = pvlm_mvs::num_texels(half_window, step) <= 64;
+#if PVLM_MEASURED_VARIANTS
+  static const bool spec = getenv("PVLM_MVS_SPEC") && atoi(getenv("PVLM_MVS_SPEC")) != 0;   // four waves per pixel (measured: no gain, see above)
+#else
+  const bool spec = false;
+#endif
   for (int q = 0; q < n_diag; ++q) {
     const int d = backward ? n_diag - 1 - q : q;
     const int len = std::min(rows - 1, d) - std::max(0, d - (cols - 1)) + 1;
-    const dim3 grid((unsigned)((len + 3) / 4)), block(256);
+    const dim3 grid((unsigned)(spec ? len : (len + 3) / 4)), block(256);
+#if PVLM_MEASURED_VARIANTS
+    if (spec) {
+      if (small)
+        hipLaunchKernelGGL(k_mvs_propagate_diag_spec<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth,
+                           max_depth, pass_seed, d, backward);
+      else
+        hipLaunchKernelGGL(k_mvs_propagate_diag_spec<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant,
+                           min_depth, max_depth, pass_seed, d, backward);
+      continue;
+    }
+#endif
     if (small)
       hipLaunchKernelGGL(k_mvs_propagate_diag<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth,
                          pass_seed, d, backward);

@@ -559,5 +559,139 @@ PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, 
   }
 }
 
-}  // namespace pvlm_mvs
+// ---- ProcessPixel with the independent hypotheses of a pixel scored side by side ------------------------------------------------
+// The score of a hypothesis does not depend on the pixel's current confidence, only the DECISIONS do.  So
+//   * the propagated hypotheses (the walk's two already-updated neighbours) can be scored together and then accepted or not one
+//     after the other, exactly as the sequential loop would;
+//   * the six refinements of PerturbDepthNormal3 chain only through acceptances: iteration i perturbs the state left by the last
+//     ACCEPTED iteration before it, with draws whose position in the pixel's counter-based random stream is fixed (4 draws per
+//     iteration, 3 when the depth is kept).  A batch of W consecutive iterations is therefore built from the current state as if
+//     none of them were accepted, scored together, and resolved in order: everything up to and including the first accepted one
+//     is what the sequential loop would have done; the rest of the batch is discarded and the next batch starts behind it.
+// Same results as process_pixel, bit for bit (tests/test_mvs_cpu.py drives both through the serial scorer); the chain of dependent
+// scorings drops from 2 + 6 to 1 + (6 / expected batch progress).  On the GPU a batch is the W waves of a workgroup
+// (k_mvs_propagate_diag_spec: a single view's anti-diagonal is at most min(rows, cols) pixels — a sixth of the chip's wave slots with
+// one wave per pixel).  The random phase (1 - conf >= thConfRand, rejection-sampled normals: a variable number of draws) stays
+// a chain; every executor of the batch runs it redundantly.
+struct Hypothesis { float normal[3]; float depth; float conf; int valid; };
 
+// hypothesis -> its score (plane through the point, smoothness factors of the close neighbours, ScorePixel)
+template <class Scorer>
+PVLM_HD inline float score_hypothesis(Scorer& score, const float* view_ray, const ClosePixel* close, int n_close, const Hypothesis& h) {
+  const float X0[3] = {view_ray[0] * h.depth, view_ray[1] * h.depth, view_ray[2] * h.depth};
+  const float plane[4] = {h.normal[0], h.normal[1], h.normal[2], -dot3(h.normal, X0)};
+  float factors[4];
+  score.smooth_factors(plane, close, n_close, h.normal, h.depth, factors);
+  return score(h.normal, h.depth, factors, n_close);
+}
+
+// Batch runner of the host check: the W "waves" one after the other.  build(w, h) fills hypothesis w of the batch (valid = 0: not scored).
+template <class Scorer>
+struct SerialBatch {
+  Scorer* score; int W;
+  PVLM_HD int width() const { return W; }
+  template <class Build>
+  PVLM_HD void run(int n, const float* view_ray, const ClosePixel* close, int n_close, Build&& build, Hypothesis* out) {
+    for (int w = 0; w < n; ++w) {
+      build(w, out[w]);
+      out[w].conf = out[w].valid ? score_hypothesis(*score, view_ray, close, n_close, out[w]) : -1.f;
+    }
+  }
+  PVLM_HD Scorer& single() { return *score; }
+};
+
+template <class Batch>
+PVLM_HD inline void process_pixel_spec(const SweepArgs& A, Rng& rng, int px, int py, Batch& batch, float& depth, float* normal, float& conf,
+                                       int n_prop, const int* pdx, const int* pdy) {
+  const int rows = A.rows, cols = A.cols;
+  const size_t e = (size_t)py * cols + px;
+  const bool keep_depth_constant = A.depth_constant && A.depth_constant[e];
+  const float* view_ray = A.unit + 3 * e;
+  ClosePixel close[4] = {}; int n_close = 0;
+  {
+    const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
+    for (int q = 0; q < 4; ++q) {
+      if (!(cx[q] >= 0 && cy[q] >= 0 && cx[q] < cols && cy[q] < rows)) continue;
+      const size_t ne = (size_t)cy[q] * cols + cx[q];
+      const float d = A.depth[ne];
+      if (d <= 0) continue;
+      ClosePixel& c = close[n_close++];
+      for (int k = 0; k < 3; ++k) { c.point[k] = A.unit[3 * ne + k] * d; c.normal[k] = A.normal[3 * ne + k]; }
+      c.depth = d;
+    }
+  }
+  const int W = batch.width();
+  Hypothesis hyp[4];
+  // ---- propagation (:749-771): the hypotheses do not depend on each other's outcome
+  for (int base = 0; base < n_prop; base += W) {
+    const int n = n_prop - base < W ? n_prop - base : W;
+    const float depth_now = depth;
+    batch.run(n, view_ray, close, n_close, [&](int w, Hypothesis& h) {
+      h.valid = 0;
+      const int q = base + w;
+      const int nxq = px + pdx[q], nyq = py + pdy[q];
+      if (!(nxq >= 0 && nyq >= 0 && nxq < cols && nyq < rows)) return;
+      const size_t ne = (size_t)nyq * cols + nxq;
+      float depth_neighbor = A.depth[ne];
+      if (depth_neighbor <= 0) return;
+      float normal_neighbor[3] = {A.normal[3 * ne], A.normal[3 * ne + 1], A.normal[3 * ne + 2]};
+      // keep_depth_constant: the pixel's own depth, which no acceptance changes (an accepted neighbour hands over that same depth)
+      depth_neighbor = keep_depth_constant ? depth_now : interpolate_pixel(view_ray, A.unit + 3 * ne, depth_neighbor, normal_neighbor, A.min_depth, A.max_depth);
+      correct_normal(view_ray, normal_neighbor);
+      h.normal[0] = normal_neighbor[0]; h.normal[1] = normal_neighbor[1]; h.normal[2] = normal_neighbor[2]; h.depth = depth_neighbor; h.valid = 1;
+    }, hyp);
+    for (int w = 0; w < n; ++w)
+      if (hyp[w].valid && conf < hyp[w].conf) { conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2]; }
+  }
+  // ---- PerturbDepthNormal3
+  const bool perturb = !keep_depth_constant;
+  const float scaleRanges[12] = {1.f, 0.5f, 0.25f, 0.125f, 0.0625f, 0.03125f, 0.015625f, 0.0078125f, 0.00390625f, 0.001953125f, 0.0009765625f, 0.00048828125f};
+  const float thConfSmall = (float)(0.55 * 0.2f), thConfBig = (float)(0.55 * 0.4f), thConfRand = (float)(0.55 * 0.9f);
+  unsigned idxScaleRange = 0;
+  if (1 - conf <= thConfSmall) idxScaleRange = 2;
+  else if (1 - conf <= thConfBig) idxScaleRange = 1;
+  else if (1 - conf >= thConfRand) {
+    bool refine = false;
+    float factors[4];
+    for (int iter = 0; iter < 6; iter++) {
+      const float depth_random = perturb ? rng.uniform(A.min_depth, A.max_depth) : depth;
+      float normal_random[3];
+      generate_random_normal(rng, view_ray, normal_random);
+      const float nconf = batch.single()(normal_random, depth_random, factors, 0);
+      if (nconf > conf) {
+        conf = nconf; depth = depth_random; normal[0] = normal_random[0]; normal[1] = normal_random[1]; normal[2] = normal_random[2];
+        if (1 - nconf < thConfRand) { refine = true; break; }
+      }
+    }
+    if (!refine) return;
+  }
+  const float angleRange = (float)(30.f / 180.f * 3.14159265358979323846);
+  const unsigned draws = perturb ? 4u : 3u;                 // per refinement iteration: perturb_depth (1, when the depth moves) + perturb_normal (3)
+  // the depth range is taken once, before the loop, from the depth at that point — like upstream (:1291) — not per batch
+  const float depthRange = (float)(depth * 0.02);
+  for (int base = 0; base < 6;) {
+    const int n = 6 - base < W ? 6 - base : W;
+    const float scaleRange = scaleRanges[idxScaleRange];
+    const float depth_now = depth;
+    const float normal_now[3] = {normal[0], normal[1], normal[2]};
+    const unsigned k0 = rng.k;
+    batch.run(n, view_ray, close, n_close, [&](int w, Hypothesis& h) {
+      Rng r = rng; r.k = k0 + draws * (unsigned)w;          // iteration base + w, as if base .. base + w - 1 were all rejected
+      h.depth = perturb ? perturb_depth(r, depth_now, scaleRange * depthRange) : depth_now;
+      perturb_normal(batch.single(), r, normal_now, scaleRange * angleRange, h.normal);
+      h.valid = dot3(h.normal, view_ray) >= 0 ? 0 : 1;     // `continue` (:1303-1304): the draws are spent, nothing is scored
+    }, hyp);
+    int taken = n;
+    for (int w = 0; w < n; ++w)
+      if (hyp[w].valid && hyp[w].conf > conf) {
+        conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2];
+        idxScaleRange++;
+        taken = w + 1;
+        break;
+      }
+    rng.k = k0 + draws * (unsigned)taken;
+    base += taken;
+  }
+}
+
+}  // namespace pvlm_mvs

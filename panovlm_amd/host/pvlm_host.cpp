@@ -320,7 +320,10 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
     owner.push_back((int)i);
   }
   const int nc = (int)owner.size();
-  for (size_t i = 0; i < lidars.size(); i++) {
+  // every scan's list is independent of the others: scan-parallel (at Floor size — 1593 scans, all inside the 20 m radius of the
+  // synthetic room — the serial loop was 0.1 s per call, four calls per EstimatePose)
+  neighbors_all.assign(lidars.size(), std::vector<int>());
+  auto one = [&](size_t i) {
     std::vector<int> neighbors;
     if (lidars[i].IsPoseValid()) {
       const Vector3d& t = lidars[i].GetTranslation();
@@ -358,8 +361,15 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
     } else {
       for (int j = -neighbor_size / 2; j <= neighbor_size / 2; j++) neighbors.push_back((int)i - j);
     }
-    neighbors_all.push_back(neighbors);
-  }
+    neighbors_all[i].swap(neighbors);
+  };
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, lidars.size() / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  std::atomic<size_t> next{0};
+  auto work = [&]() { for (size_t i = next++; i < lidars.size(); i = next++) one(i); };
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
   return neighbors_all;
 }
 

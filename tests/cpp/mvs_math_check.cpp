@@ -200,10 +200,10 @@ extern "C" void chk_mvs_propagate(int rows, int cols, int half_window, int step,
 // The sequential sweep through the device bodies, in the order k_mvs_propagate_diag gives the GPU: anti-diagonal after
 // anti-diagonal, and INSIDE a diagonal from the bottom row up (the launch makes no promise about the order of its waves) — not
 // the raster order of the oracle.  Equal maps prove what the kernel relies on: the pixels of a diagonal do not depend on each other.
-extern "C" void chk_mvs_propagate_sequential(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
-                                             const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
-                                             const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
-                                             unsigned long long seed, int max_iter, float conf_threshold) {
+static void propagate_sequential_impl(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                      const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                      const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                      unsigned long long seed, int max_iter, float conf_threshold, int spec_width) {
   using namespace pvlm_mvs;
   const size_t npix = (size_t)rows * cols;
   std::vector<float> unit(npix * 3);
@@ -229,7 +229,12 @@ extern "C" void chk_mvs_propagate_sequential(int rows, int cols, int half_window
         Rng rng{ps, (unsigned long long)e, 0u};
         SerialScorer scorer{{}, {}, rows, cols, half_window, step, px, py, n_neighbors, unit.data(), nei_gray, R_nr, t_nr, nei_depth, &P};
         const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
-        process_pixel(A, rng, px, py, scorer, dep, nr, c, 2, pdx, pdy);
+        if (spec_width > 0) {          // the speculative batches of k_mvs_propagate_diag_spec, the "waves" of a batch one after the other
+          SerialBatch<SerialScorer> batch{&scorer, spec_width};
+          process_pixel_spec(A, rng, px, py, batch, dep, nr, c, 2, pdx, pdy);
+        } else {
+          process_pixel(A, rng, px, py, scorer, dep, nr, c, 2, pdx, pdy);
+        }
         depth[e] = dep; normal[3 * e] = nr[0]; normal[3 * e + 1] = nr[1]; normal[3 * e + 2] = nr[2]; conf[e] = c;
       }
     }
@@ -238,6 +243,21 @@ extern "C" void chk_mvs_propagate_sequential(int rows, int cols, int half_window
     if (depth_constant && depth_constant[e]) continue;
     if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0.f; }
   }
+}
+extern "C" void chk_mvs_propagate_sequential(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                             const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                             const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                             unsigned long long seed, int max_iter, float conf_threshold) {
+  propagate_sequential_impl(rows, cols, half_window, step, ref_gray, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth,
+                            seed, max_iter, conf_threshold, 0);
+}
+// the same sweep through process_pixel_spec: batches of `width` hypotheses scored side by side (width = 4 on the GPU)
+extern "C" void chk_mvs_propagate_sequential_spec(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                                  const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                                  const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                                  unsigned long long seed, int max_iter, float conf_threshold, int width) {
+  propagate_sequential_impl(rows, cols, half_window, step, ref_gray, n_neighbors, nei_gray, R_nr, t_nr, depth, normal, conf, nei_depth, depth_constant, min_depth, max_depth,
+                            seed, max_iter, conf_threshold, width);
 }
 // the per-pixel bodies of k_cloud_count / k_cloud_emit (pvlm_mvs.hip) run on the host in raster order
 extern "C" long long chk_mvs_depth_to_cloud(int rows, int cols, const float* depth, const unsigned char* bgr, const float* normal, const double* T_wc,

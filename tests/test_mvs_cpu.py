@@ -268,6 +268,16 @@ def test_patchmatch_sweep_oracle_behaviour_and_device_bodies(oracle):
                                          ptrs, fp(R), fp(t), fp(d), fp(n), fp(c), dptrs, dc.ctypes.data_as(C.POINTER(C.c_ubyte)) if dc is not None else None,
                                          C.c_float(0.1), C.c_float(20.0), C.c_ulonglong(kw["seed"]), C.c_int(3), C.c_float(kw.get("conf_threshold", -1.0)))
         assert np.array_equal(d, want[0]) and np.array_equal(n, want[1]) and np.array_equal(c, want[2])
+        # ... and through process_pixel_spec, the form k_mvs_propagate_diag_spec runs: the independent hypotheses of a pixel (the two
+        # propagated ones; batches of W consecutive refinements built as if none were accepted) scored side by side and resolved in
+        # order — the same maps for every batch width
+        for width in (1, 2, 3, 4):
+            d = S["depth"].copy(); n = S["normal"].copy(); c = S["conf"].copy()
+            lib.chk_mvs_propagate_sequential_spec(C.c_int(d.shape[0]), C.c_int(d.shape[1]), C.c_int(3), C.c_int(1), S["gray"].ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                                  C.c_int(len(nd)), ptrs, fp(R), fp(t), fp(d), fp(n), fp(c), dptrs,
+                                                  dc.ctypes.data_as(C.POINTER(C.c_ubyte)) if dc is not None else None, C.c_float(0.1), C.c_float(20.0),
+                                                  C.c_ulonglong(kw["seed"]), C.c_int(3), C.c_float(kw.get("conf_threshold", -1.0)), C.c_int(width))
+            assert np.array_equal(d, want[0]) and np.array_equal(n, want[1]) and np.array_equal(c, want[2]), width
         chk = oracle.mvs_propagate(*args, nei_depths=S["nd"] if geo else None, **kw3)
         assert not np.array_equal(chk[0], want[0])                  # and it is a different sweep from the checkerboard
 

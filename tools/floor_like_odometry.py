@@ -55,6 +55,10 @@ def main():
         print("world 1: %.2f s process wall, EstimatePose call %.3f s" % (wall1, call1))
         for l in its:
             print("   ", " ".join(l))
+        from tools.room_like_odometry import _stage_line
+        for l in single:
+            if l.startswith("stage"):
+                print(_stage_line(l))
         e0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
         e1 = np.mean([np.linalg.norm(pos[k][9:] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
         print("mean translation error vs ground truth: %.4f m -> %.4f m" % (e0, e1))
