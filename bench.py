@@ -463,7 +463,7 @@ def main():
                 pm = json.load(open(f))
                 if pm.get("evals_per_launch") == n_local and world == 1:
                     for k, v in pm["kernels"].items():
-                        if "k_eval_fused" in k:
+                        if "k_eval_fused<" in k:       # the headline's kernel (the wave-per-segment form runs on the short-segment side workloads)
                             traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
                             traffic_stamp = {"collected_at_commit": pm.get("commit"), "collected_on": pm.get("date"),
                                              "note": "counter passes of THIS command, collected in a separate rocprofv3 --pmc run (counters cannot be read inside "

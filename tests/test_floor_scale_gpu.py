@@ -24,7 +24,7 @@ def test_estimate_pose_at_floor_scale_sharded_over_2_and_8_ranks():
     assert "sharded runs equal to the one-process run (1e-9, identical step counts): True" in out, out[-3000:]
     assert out.count("every rank reports the same log and poses, bit for bit: True") == 2
     iters = [l.split() for l in out.splitlines() if l.strip().startswith("iter")]
-    assert len(iters) >= 3 and all(int(l[6]) > 500_000 for l in iters)          # Floor tolerance: > 0.5 M residual blocks per outer iteration
+    assert len(iters) >= 2 and all(int(l[6]) > 500_000 for l in iters)          # the one-process log; Floor tolerance: > 0.5 M residual blocks per outer iteration
     m = re.search(r"mean translation error vs ground truth: ([0-9.]+) m -> ([0-9.]+) m", out)
     assert m and float(m.group(2)) < 0.5 * float(m.group(1))
     bal = [(float(a), float(b)) for a, b in re.findall(r"load balance \(max / mean\): queries ([0-9.]+), residual blocks ([0-9.]+)", out)]
