@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "pvlm_timer_start", "pvlm_timer_stop", "pvlm_device_info", "pvlm_profile_enable", "pvlm_profile_read", "pvlm_set_poses", "pvlm_set_poses_dev",
     "pvlm_resset_upload", "pvlm_resset_destroy", "pvlm_resset_info", "pvlm_resset_download", "pvlm_eval",
     "pvlm_eval_dev", "pvlm_eval_pair_blocks", "pvlm_eval_pair_blocks_dev", "pvlm_neq_create", "pvlm_neq_destroy",
-    "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_comm_unique_id", "pvlm_comm_create",
+    "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_neq_accumulate_async", "pvlm_comm_unique_id", "pvlm_comm_create",
     "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_upload_batch", "pvlm_scan_destroy",
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
@@ -639,6 +639,14 @@ class NormalEq:
     def accumulate_dev(self, rs, d_packed_ptr, loss=LOSS_NONE, loss_a=0.0, zero_first=True):
         self.ctx._check(self.ctx.lib.pvlm_neq_accumulate_dev(self.ctx._h, self._h, rs._h, C.c_int(loss), C.c_double(loss_a),
                                                              C.c_int(1 if zero_first else 0), C.c_void_p(d_packed_ptr)), "pvlm_neq_accumulate_dev")
+
+    def accumulate_async(self, rs, packed, loss=LOSS_NONE, loss_a=0.0):
+        """Queues the linearisation of `rs` into this structure's own device buffer and its copy into `packed` (float64 array of
+        `size` elements that must stay alive); complete after ctx.synchronize().  One call per residual set of a problem, one
+        synchronisation for all of them."""
+        assert packed.dtype == np.float64 and packed.flags["C_CONTIGUOUS"] and packed.size == self.size
+        self.ctx._check(self.ctx.lib.pvlm_neq_accumulate_async(self.ctx._h, self._h, rs._h, C.c_int(loss), C.c_double(loss_a),
+                                                               packed.ctypes.data_as(C.POINTER(C.c_double))), "pvlm_neq_accumulate_async")
 
     def unpack(self, packed):
         n, u = self.n_poses, self.n_upairs

@@ -136,15 +136,19 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
   const float inside = fminf(lo_min, hi_min);  // distance (in cells) from q to the nearest face of its own cell
   const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
   const int rmax = (int)ceilf(max_dist * 1.0001f * cv.inv_h);
+  // dense tables: the (dz, dy) loops only run over rows that exist (a line- or plane-shaped cloud has a table a few cells thick: with the
+  // loops over the full shell a query with fewer than K points in reach walked O(rmax^3) empty rows), and the search stops once the
+  // searched block covers the whole table
+  const int ncx = cv.dense ? cv.nx / xf : 0;
   for (int r = 0; r <= rmax; ++r) {
-    for (int dz = -r; dz <= r; ++dz) {
+    const int dz_lo = cv.dense ? (-r > -cz ? -r : -cz) : -r, dz_hi = cv.dense ? (r < cv.nz - 1 - cz ? r : cv.nz - 1 - cz) : r;
+    const int dy_lo = cv.dense ? (-r > -cy ? -r : -cy) : -r, dy_hi = cv.dense ? (r < cv.ny - 1 - cy ? r : cv.ny - 1 - cy) : r;
+    for (int dz = dz_lo; dz <= dz_hi; ++dz) {
       const int z = cz + dz;
-      if (cv.dense && (z < 0 || z >= cv.nz)) continue;
       const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);   // gap to the row's slab, in cells
       const float gzm = fmaxf(gz * cv.h - slack, 0.f);
-      for (int dy = -r; dy <= r; ++dy) {
+      for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int y = cy + dy;
-        if (cv.dense && (y < 0 || y >= cv.ny)) continue;
         const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
         const float gym = fmaxf(gy * cv.h - slack, 0.f);
         const float lb = gym * gym + gzm * gzm;                       // <= d2 of every point of the row
@@ -172,6 +176,7 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
     const float bound = (inside + (float)r) * cv.h - slack;
     if (tk.full() && bound > 0.f && tk.dist(K - 1) < bound * bound) break;
     if ((float)r * cv.h >= max_dist * 1.0001f) break;  // everything within max_dist has been visited
+    if (cv.dense && cx - r <= 0 && cx + r >= ncx - 1 && cy - r <= 0 && cy + r >= cv.ny - 1 && cz - r <= 0 && cz + r >= cv.nz - 1) break;   // ... or the whole table
   }
 }
 

@@ -100,7 +100,7 @@ def test_search_degenerate_clouds(chk, oracle):
     point = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (40, 1))
     q = rng.uniform(-4, 4, size=(300, 3)).astype(np.float32)
     for tgt in (line, plane, point, plane[:9], plane[:1], line[:, [1, 0, 2]], line[:, [2, 1, 0]], plane[:, [2, 0, 1]]):
-        for kw in ({}, {"force_hash": 1}, {"xf": 1}):
+        for kw in ({}, {"force_hash": 1, "cell": 0.4}, {"xf": 1}):     # hashed tables have no extent to clip the shells to: a usable cell edge
             if len(tgt) >= 10:
                 check(chk, oracle, tgt, q, 10, 1.5, **kw)
             if len(tgt) >= 5:

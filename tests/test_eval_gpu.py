@@ -177,6 +177,19 @@ def test_normal_equations_packed(ctx, oracle):
     # accumulate a second time on top (+=)
     packed2 = neq.accumulate(rs, 1, a, packed=packed.copy())
     assert np.allclose(packed2, 2 * packed, rtol=1e-12)
+    # the queued form: two structures, two sets, ONE synchronisation — each landing buffer equals the synchronous call bit for bit
+    # (what an LM driver does with the point-to-plane and the line-to-line blocks of one problem); both evaluation forms of the
+    # fused kernel (workgroup- and wave-per-chunk, chosen by segment length) are behind it
+    rows_b, off_b = synth.random_resset(rng, 1, aa, t, ref, nei, rng.integers(3000, 9000, size=P))
+    rs_b = pv.ResidualSet.upload(ctx, 1, rows_b, off_b, ref, nei, flags=1)
+    neq_b = pv.NormalEq(ctx, F, [u[0] for u in up], [u[1] for u in up])
+    want_a, want_b = neq.accumulate(rs, 1, a), neq_b.accumulate(rs_b, 1, a)
+    got_a = np.full(neq.size, np.nan); got_b = np.full(neq_b.size, np.nan)
+    neq.accumulate_async(rs, got_a, 1, a)
+    neq_b.accumulate_async(rs_b, got_b, 1, a)
+    ctx.synchronize()
+    assert np.array_equal(got_a, want_a) and np.array_equal(got_b, want_b) and not np.array_equal(got_a, got_b)
+    neq_b.close(); rs_b.close()
 
 
 def test_errors_are_loud(ctx):
