@@ -122,6 +122,8 @@ class Velodyne {
   std::vector<Vector3d> end_points;      // 2 per segment, LiDAR-local
 
   Velodyne() { SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); SetTranslation({INFINITY, INFINITY, INFINITY}); }
+  // The pose setters and MarkWorld give the scan's device copy back to the engine's context (InvalidateDevice ->
+  // pvlm_scan_destroy), whose pool is not thread-safe: call them from the thread that owns the engine, never from workers.
   void SetPose(const Matrix3d& R_wl, const Vector3d& t_wl) { R_wl_ = R_wl; t_wl_ = t_wl; InvalidateDevice(); }
   void SetRotation(const Matrix3d& R_wl) { R_wl_ = R_wl; InvalidateDevice(); }
   void SetTranslation(const Vector3d& t_wl) { t_wl_ = t_wl; InvalidateDevice(); }

@@ -263,6 +263,17 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < JJ.size() && i < J.size(); ++i) { dJ = std::max(dJ, std::fabs(JJ[i] - J[i])); jmax = std::max(jmax, std::fabs(JJ[i])); }
       printf("blocks %zu direct %lld max_dr %.3e max_dJ %.3e J_max %.3e moved %.3e\n", n, (long long)m, dr, dJ, jmax, moved);
       pvlm_resset_destroy(e.ctx(), rs);
+    } else if (cmd == "balance") {
+      // balance <world> w0 w1 ... : Exchange::BalancedRange of every rank for the given per-scan weights (no GPU)
+      const int world = atoi(argv[2]);
+      std::vector<double> w;
+      for (int k = 3; k < argc; ++k) w.push_back(atof(argv[k]));
+      for (int r = 0; r < world; ++r) {
+        Exchange x; x.world = world; x.rank = r;
+        const auto own = x.BalancedRange(w);
+        const auto asked = Exchange{world, 0, nullptr}.BalancedRange(w, r);
+        printf("range %d %zu %zu %zu %zu\n", r, own.first, own.second, asked.first, asked.second);
+      }
     } else if (cmd == "ceresjoint") {
       // ceresjoint <lidars.bin (LOCAL)> <frames.bin> <structure.bin> neighbor_size tol thr thr_line : the problem of
       // CameraLidarOptimizer::Optimize (joint_optimization/CameraLidarOptimizer.cpp:387-498) built ENTIRELY through

@@ -381,3 +381,23 @@ def test_fuse_depth_images_host_mirror_equals_oracle():
     want = orc.mvs_fuse_depth_images(depth, [None] * 5, conf, bgr, T, nb, thr=0.02)
     got = host_io.fuse_depth_images(depth, [None] * 5, conf, bgr, T, nb, thr=0.02)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_balanced_ranges_of_a_sharded_run():
+    """Exchange::BalancedRange (SURVEY.md §8 row E's rebalancing by sum Nq): contiguous, disjoint, covering ranges whose summed weights
+    differ by at most one scan's weight; every rank computes the same boundaries; zero weights fall back to the block partition."""
+    rng = np.random.default_rng(4)
+    for world, w in ((2, [5, 1, 1, 1, 1, 1]), (3, rng.integers(1, 50, size=40).tolist()), (8, [7] * 100 + [70] * 5 + [7] * 60), (4, [0] * 10), (8, [3, 3]),
+                     (5, [0, 0, 9, 0, 0, 0, 1])):
+        out = host_io.run("balance", world, *w)
+        rg = [[int(v) for v in l.split()[1:]] for l in out if l.startswith("range")]
+        assert len(rg) == world
+        assert all(r[1:3] == r[3:5] for r in rg)                     # own range == the range any other rank computes for it
+        assert rg[0][1] == 0 and rg[-1][2] == len(w) and all(rg[k][2] == rg[k + 1][1] for k in range(world - 1))
+        assert all(r[1] <= r[2] for r in rg)
+        tot = float(sum(w))
+        if tot > 0:
+            sums = [sum(w[r[1]:r[2]]) for r in rg]
+            assert max(sums) <= tot / world + max(w)                 # no rank carries more than its share plus one scan
+        else:
+            assert [r[1:3] for r in rg] == [[len(w) * k // world, len(w) * (k + 1) // world] for k in range(world)]
