@@ -122,6 +122,11 @@ pvlm_status pvlm_resset_info(const pvlm_resset* rs, int64_t* n, int* n_pairs, in
 /* Copies the segment table / rows back (rows in the upload layout); any pointer may be NULL. */
 pvlm_status pvlm_resset_download(pvlm_ctx* ctx, const pvlm_resset* rs, int64_t* pair_offsets, int* pair_ref,
                                  int* pair_nei, double* rows);
+/* Replaces the pose ids of the set's segments (pair_ref / pair_nei, n_pairs each).  A set produced by the association carries the ids
+ * of the scans it was built from (lidars[i].id, util/Optimization.cpp:527-528); a problem that mixes such sets with uploaded ones
+ * (camera poses + LiDAR poses, joint_optimization/CameraLidarOptimizer.cpp:394-417) renumbers them once into ONE pose table, so that a
+ * single pvlm_set_poses and a single packed buffer serve every set.  Queued on the context stream; no synchronisation. */
+pvlm_status pvlm_resset_set_pose_ids(pvlm_ctx* ctx, pvlm_resset* rs, const int* pair_ref, const int* pair_nei);
 
 /* ceres::CostFunction::Evaluate for every block of the set at the poses of pvlm_set_poses:
  * residuals[n] and jacobians[n x 12] = [d/daa_r | d/dt_r | d/daa_n | d/dt_n] (row-major per block,
@@ -182,6 +187,12 @@ pvlm_status pvlm_neq_accumulate(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset*
  * linearisation, whatever the number of residual sets (lidar_mapping/LidarOdometry.cpp:36-80 evaluates point-to-plane and
  * line-to-line blocks in the same ceres::Solve). */
 pvlm_status pvlm_neq_accumulate_async(pvlm_ctx* ctx, pvlm_neq* neq, const pvlm_resset* rs, pvlm_loss loss, double loss_a, double* packed);
+/* A whole problem in ONE packed buffer: the n residual sets are linearised one after the other and SUMMED on the device into the
+ * buffer of neq[0] (all n structures must have been created with the same n_poses and pair list, and the sets must share one pose
+ * numbering — pvlm_resset_set_pose_ids below); one copy into `packed` (host, pvlm_neq_size(neq[0]) doubles) is queued behind them and
+ * is complete after the next pvlm_synchronize.  Nothing is allocated after the first call, nothing waits. */
+pvlm_status pvlm_neq_accumulate_sets(pvlm_ctx* ctx, int n, pvlm_neq* const* neq, const pvlm_resset* const* rs, const pvlm_loss* loss,
+                                     const double* loss_a, double* packed);
 
 /* ---- panoramic reprojection blocks with point elimination ---------------------------------------- *
  * PanoramaReprojResidual_1Angle (base/CostFunction.h:218-247): r = w * angle(R(aa_cw) X + t_cw, bearing),

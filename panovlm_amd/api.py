@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "pvlm_timer_start", "pvlm_timer_stop", "pvlm_device_info", "pvlm_profile_enable", "pvlm_profile_read", "pvlm_set_poses", "pvlm_set_poses_dev",
     "pvlm_resset_upload", "pvlm_resset_destroy", "pvlm_resset_info", "pvlm_resset_download", "pvlm_eval",
     "pvlm_eval_dev", "pvlm_eval_pair_blocks", "pvlm_eval_pair_blocks_dev", "pvlm_neq_create", "pvlm_neq_destroy",
-    "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_neq_accumulate_async", "pvlm_comm_unique_id", "pvlm_comm_create",
+    "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_neq_accumulate_async", "pvlm_neq_accumulate_sets", "pvlm_resset_set_pose_ids", "pvlm_comm_unique_id", "pvlm_comm_create",
     "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_upload_batch", "pvlm_scan_destroy",
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",

@@ -495,6 +495,21 @@ pvlm_status pvlm_profile_read(pvlm_ctx* ctx, int which, double* total_ms, int64_
 // ------------------------------------------------------------------------------------------------
 // residual sets
 // ------------------------------------------------------------------------------------------------
+pvlm_status pvlm_resset_set_pose_ids(pvlm_ctx* ctx, pvlm_resset* rs, const int* pair_ref, const int* pair_nei) {
+  if (!ctx || !rs || (rs->n_pairs > 0 && (!pair_ref || !pair_nei))) return PVLM_ERR_ARG;
+  for (int p = 0; p < rs->n_pairs; ++p)
+    if (pair_ref[p] < 0 || pair_nei[p] < 0) { PVLM_SET_ERR(ctx, "pvlm_resset_set_pose_ids: negative pose id in segment %d", p); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (rs->n_pairs == 0) return PVLM_OK;
+  rs->h_ref.assign(pair_ref, pair_ref + rs->n_pairs);
+  rs->h_nei.assign(pair_nei, pair_nei + rs->n_pairs);
+  pvlm_status st = pvlm_i_h2d_q(ctx, rs->d_ref, rs->h_ref.data(), (size_t)rs->n_pairs * sizeof(int));
+  if (!st) st = pvlm_i_h2d_q(ctx, rs->d_nei, rs->h_nei.data(), (size_t)rs->n_pairs * sizeof(int));
+  rs->pair_tab_epoch = ~0ull;                  // the pair table is rebuilt from the new ids at the next evaluation
+  rs->serial = ++ctx->resset_serial;           // ... and every pvlm_neq bound to the set binds again
+  return st;
+}
+
 pvlm_status pvlm_resset_info(const pvlm_resset* rs, int64_t* n, int* n_pairs, int* kind, unsigned* flags) {
   if (!rs) return PVLM_ERR_ARG;
   if (n) *n = rs->n;

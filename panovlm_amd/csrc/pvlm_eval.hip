@@ -889,4 +889,28 @@ pvlm_status pvlm_neq_accumulate_async(pvlm_ctx* ctx, pvlm_neq* q, const pvlm_res
   return pvlm_i_d2h_q(ctx, packed, q->d_packed, cnt * sizeof(double));   // complete at the next pvlm_synchronize
 }
 
+pvlm_status pvlm_neq_accumulate_sets(pvlm_ctx* ctx, int n, pvlm_neq* const* neq, const pvlm_resset* const* rs, const pvlm_loss* loss,
+                                     const double* loss_a, double* packed) {
+  if (!ctx || n <= 0 || !neq || !rs || !loss || !loss_a || !packed) return PVLM_ERR_ARG;
+  for (int k = 0; k < n; ++k) {
+    if (!neq[k] || !rs[k]) return PVLM_ERR_ARG;
+    if (neq[k]->n_poses != neq[0]->n_poses || neq[k]->n_upairs != neq[0]->n_upairs || neq[k]->ui != neq[0]->ui || neq[k]->uj != neq[0]->uj) {
+      PVLM_SET_ERR(ctx, "pvlm_neq_accumulate_sets: structure %d differs from structure 0 (same n_poses and pair list required)", k);
+      return PVLM_ERR_ARG;
+    }
+  }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_neq* q0 = neq[0];
+  const size_t cnt = (size_t)pvlm_neq_size(q0);
+  if (!q0->d_packed) {
+    const pvlm_status sa = pvlm_i_alloc(ctx, &q0->d_packed, cnt);
+    if (sa) return sa;
+  }
+  for (int k = 0; k < n; ++k) {
+    const pvlm_status st = pvlm_neq_accumulate_dev(ctx, neq[k], rs[k], loss[k], loss_a[k], k == 0 ? 1 : 0, q0->d_packed);
+    if (st) return st;
+  }
+  return pvlm_i_d2h_q(ctx, packed, q0->d_packed, cnt * sizeof(double));   // complete at the next pvlm_synchronize
+}
+
 }  // extern "C"

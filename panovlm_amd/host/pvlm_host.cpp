@@ -1198,28 +1198,35 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     return all;
   };
 
-  // ---- device sets + per-group normal-equation structures ---------------------------------------
+  // ---- device sets, ONE pose numbering and ONE normal-equation structure for all four-block groups --------------
+  // Every group's segments are renumbered to the Problem's pose ids (a set that came from the association carries the caller's list
+  // indices: pvlm_resset_set_pose_ids, once), so that a linearisation needs one pose table and the groups' blocks are summed on the
+  // device into one packed buffer [diag NP x 36 | off U x 36 | g NP x 6 | cost] over the union (ui < uj) of their pose pairs.
   StageTimer* stage_timer_setup_ = new StageTimer("solve: residual-set upload + structures");
-  for (auto& g : I.groups) {
-    const int P = (int)g.ref.size();
-    if (!g.set) {
-      g.dev_ref = g.ref; g.dev_nei = g.nei;
-      e.Check(pvlm_resset_upload(e.ctx(), (pvlm_functor)g.kind, g.flags, g.weight, g.off.back(), P, g.off.data(), g.dev_ref.data(), g.dev_nei.data(),
-                                 g.rows.data(), kStride[g.kind], &g.set), "pvlm_resset_upload");
-      std::vector<double>().swap(g.rows);
-    }
-    if (!g.neq) {
-      int mx = -1;
-      for (int p = 0; p < P; ++p) mx = std::max(mx, std::max(g.dev_ref[p], g.dev_nei[p]));
-      g.dev_poses = mx + 1;
-      g.dev_to_pose.assign(g.dev_poses, -1);
-      std::set<std::pair<int, int>> up;
-      for (int p = 0; p < P; ++p) {
-        g.dev_to_pose[g.dev_ref[p]] = g.ref[p]; g.dev_to_pose[g.dev_nei[p]] = g.nei[p];
-        up.insert({std::min(g.dev_ref[p], g.dev_nei[p]), std::max(g.dev_ref[p], g.dev_nei[p])});
+  std::vector<int> gui, guj;
+  {
+    std::set<std::pair<int, int>> up;
+    for (auto& g : I.groups) {
+      const int P = (int)g.ref.size();
+      if (!g.set) {
+        g.dev_ref = g.ref; g.dev_nei = g.nei;
+        e.Check(pvlm_resset_upload(e.ctx(), (pvlm_functor)g.kind, g.flags, g.weight, g.off.back(), P, g.off.data(), g.dev_ref.data(), g.dev_nei.data(),
+                                   g.rows.data(), kStride[g.kind], &g.set), "pvlm_resset_upload");
+        std::vector<double>().swap(g.rows);
+      } else if (g.dev_ref != g.ref || g.dev_nei != g.nei) {
+        e.Check(pvlm_resset_set_pose_ids(e.ctx(), g.set, g.ref.data(), g.nei.data()), "pvlm_resset_set_pose_ids");
+        g.dev_ref = g.ref; g.dev_nei = g.nei;
       }
-      for (auto& u : up) { g.ui.push_back(u.first); g.uj.push_back(u.second); }
-      e.Check(pvlm_neq_create(e.ctx(), g.dev_poses, (int)g.ui.size(), g.ui.data(), g.uj.data(), &g.neq), "pvlm_neq_create");
+      for (int p = 0; p < P; ++p) up.insert({std::min(g.ref[p], g.nei[p]), std::max(g.ref[p], g.nei[p])});
+    }
+    for (auto& u : up) { gui.push_back(u.first); guj.push_back(u.second); }
+    for (auto& g : I.groups) {
+      if (g.neq && g.dev_poses == NP && g.ui == gui && g.uj == guj) continue;      // a second Solve on an unchanged Problem
+      if (g.neq) { pvlm_neq_destroy(e.ctx(), g.neq); g.neq = nullptr; }
+      g.dev_poses = NP; g.ui = gui; g.uj = guj;
+      g.dev_to_pose.resize((size_t)NP);
+      for (int p = 0; p < NP; ++p) g.dev_to_pose[(size_t)p] = p;
+      e.Check(pvlm_neq_create(e.ctx(), NP, (int)gui.size(), gui.data(), guj.data(), &g.neq), "pvlm_neq_create");
     }
   }
   delete stage_timer_setup_;
@@ -1301,54 +1308,54 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   // scalar row/col index of (pose, half, k)
   auto idx = [&](int pose, int r) { const int b = r < 3 ? I.poses[pose].first : I.poses[pose].second; return block_off[b] < 0 ? -1 : block_off[b] + (r % 3); };
 
-  // ---- fixed block structure of the four-block groups + per-group scatter maps (built once per Solve) -----------------
+  // ---- fixed block structure of the four-block groups (built once per Solve) ----------------------------------------
+  // Unsharded: the key list IS the packed layout — the NP diagonal blocks, then the U pair blocks — so an evaluation's table is a plain
+  // copy of the buffer the GPU filled.  Sharded: the sorted union over the ranks (the exchanged buffer is then the table), filled
+  // through a slot map.
+  const int n_groups = (int)I.groups.size();
+  const int U = (int)gui.size();
   auto keys = std::make_shared<BlockKeys>();
-  if (xch) *keys = xkeys;                       // sharded: the union over the ranks, so that the exchanged buffer IS the table
-  else {
-    std::set<std::pair<int, int>> ks;
-    for (auto& g : I.groups) {
-      for (int d = 0; d < g.dev_poses; ++d) if (g.dev_to_pose[d] >= 0) ks.insert({g.dev_to_pose[d], g.dev_to_pose[d]});
-      for (size_t u = 0; u < g.ui.size(); ++u) { const int pa = g.dev_to_pose[g.ui[u]], pb = g.dev_to_pose[g.uj[u]]; ks.insert({std::min(pa, pb), std::max(pa, pb)}); }
-    }
-    keys->assign(ks.begin(), ks.end());
+  std::vector<int> slot_of_packed;              // sharded: packed block (diag p | pair u) -> position in the key list
+  if (xch) {
+    *keys = xkeys;
+    auto slot_of = [&](int a, int b) {
+      const auto it = std::lower_bound(keys->begin(), keys->end(), std::make_pair(a, b));
+      if (it == keys->end() || *it != std::make_pair(a, b)) throw std::runtime_error("Solve: block key missing from the structure");
+      return (int)(it - keys->begin());
+    };
+    std::vector<char> used((size_t)NP, 0);
+    for (auto& g : I.groups) for (size_t p = 0; p < g.ref.size(); ++p) { used[(size_t)g.ref[p]] = 1; used[(size_t)g.nei[p]] = 1; }
+    slot_of_packed.assign((size_t)NP + (size_t)U, -1);
+    for (int p = 0; p < NP; ++p) if (used[(size_t)p]) slot_of_packed[(size_t)p] = slot_of(p, p);
+    for (int u = 0; u < U; ++u) slot_of_packed[(size_t)NP + (size_t)u] = slot_of(gui[(size_t)u], guj[(size_t)u]);
+  } else {
+    keys->reserve((size_t)NP + (size_t)U);
+    for (int p = 0; p < NP; ++p) keys->push_back({p, p});
+    for (int u = 0; u < U; ++u) keys->push_back({gui[(size_t)u], guj[(size_t)u]});
   }
-  auto slot_of = [&](int a, int b) {
-    const auto it = std::lower_bound(keys->begin(), keys->end(), std::make_pair(a, b));
-    if (it == keys->end() || *it != std::make_pair(a, b)) throw std::runtime_error("Solve: block key missing from the structure");
-    return (int)(it - keys->begin());
-  };
-  // Pinned landing buffers of the groups' packed normal equations + where every block of a group goes in the flat table.
-  // Released on every exit path (Solve has several).
-  struct GroupIO {
-    double* packed = nullptr; size_t count = 0;
-    std::vector<int> diag_slot, off_slot; std::vector<char> off_transposed;
+  // pinned landing buffer of the packed normal equations; released on every exit path (Solve has several)
+  struct PackedIO {
+    double* packed = nullptr; size_t count = 0; pvlm_ctx* ctx;
     std::vector<double> aa, tt;
-  };
-  struct GroupIOHolder {
-    std::vector<GroupIO> io; pvlm_ctx* ctx;
-    explicit GroupIOHolder(pvlm_ctx* c) : ctx(c) {}
-    ~GroupIOHolder() { pvlm_synchronize(ctx); for (GroupIO& x : io) if (x.packed) pvlm_host_free(ctx, x.packed); }
-  } gio(e.ctx());
-  gio.io.resize(I.groups.size());
-  for (size_t gi = 0; gi < I.groups.size(); ++gi) {
-    auto& g = I.groups[gi]; GroupIO& x = gio.io[gi];
-    x.count = (size_t)pvlm_neq_size(g.neq);
+    std::vector<pvlm_neq*> neq; std::vector<const pvlm_resset*> sets; std::vector<pvlm_loss> loss; std::vector<double> loss_a;
+    explicit PackedIO(pvlm_ctx* c) : ctx(c) {}
+    ~PackedIO() { pvlm_synchronize(ctx); if (packed) pvlm_host_free(ctx, packed); }
+  } io(e.ctx());
+  if (n_groups > 0) {
+    io.count = (size_t)pvlm_neq_size(I.groups[0].neq);
     void* p = nullptr;
-    e.Check(pvlm_host_alloc(e.ctx(), (int64_t)(x.count * sizeof(double)), &p), "pvlm_host_alloc");
-    x.packed = static_cast<double*>(p);
-    x.diag_slot.assign((size_t)g.dev_poses, -1);
-    for (int d = 0; d < g.dev_poses; ++d) if (g.dev_to_pose[d] >= 0) x.diag_slot[(size_t)d] = slot_of(g.dev_to_pose[d], g.dev_to_pose[d]);
-    x.off_slot.resize(g.ui.size()); x.off_transposed.resize(g.ui.size());
-    for (size_t u = 0; u < g.ui.size(); ++u) {
-      const int pa = g.dev_to_pose[g.ui[u]], pb = g.dev_to_pose[g.uj[u]];
-      x.off_slot[u] = slot_of(std::min(pa, pb), std::max(pa, pb)); x.off_transposed[u] = pa > pb;
+    e.Check(pvlm_host_alloc(e.ctx(), (int64_t)(io.count * sizeof(double)), &p), "pvlm_host_alloc");
+    io.packed = static_cast<double*>(p);
+    for (auto& g : I.groups) {
+      io.neq.push_back(g.neq); io.sets.push_back(g.set);
+      io.loss.push_back(g.loss ? (pvlm_loss)g.loss->kind() : PVLM_LOSS_NONE); io.loss_a.push_back(g.loss ? g.loss->a() : 0.0);
     }
-    x.aa.assign((size_t)g.dev_poses * 3, 0.0); x.tt.assign((size_t)g.dev_poses * 3, 0.0);
   }
+  io.aa.assign((size_t)NP * 3, 0.0); io.tt.assign((size_t)NP * 3, 0.0);
 
-  // evaluates cost (+ H, g when want_H) of the four-block groups at parameter vector v: ONE submission for all groups (per group:
-  // its pose table, pair table, fused kernel, epilogue, gather, queued copy into its pinned buffer), ONE synchronisation, then the
-  // groups' blocks are added into the flat table through the precomputed slots — same order of additions as ever
+  // evaluates cost (+ H, g when want_H) of the four-block groups at parameter vector v: ONE pose table, ONE submission for all groups
+  // (per group: pair table, fused kernel, epilogue, gather ADDING into the shared packed buffer), one queued copy, ONE synchronisation.
+  // The groups' blocks are summed in group order, as the host used to add them.
   long evaluations = 0;
   auto evaluate = [&](const std::vector<double>& v, bool want_H, Assembled& A) {
     // the first linearisation of a Solve binds the structures to the residual sets (CSR upload), sizes the per-structure buffers
@@ -1357,55 +1364,39 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
                                                     : "solve: GPU linearisation + block assembly");
     static const bool eval_trace = std::getenv("PVLM_HOST_EVAL_TRACE") != nullptr;   // per-call phase times on stderr (profiling tools)
     const auto tr0 = std::chrono::steady_clock::now();
-    A.cost = 0; A.g.assign(n_free, 0.0); A.keys = keys;
-    if (want_H) A.H.assign(36 * keys->size(), 0.0); else A.H.clear();
-    const auto tr1 = std::chrono::steady_clock::now();
-    StageTimer* stage_timer_sub_ = new StageTimer("  (inside the linearisation) submission: pose tables + kernels + copies queued");
-    for (size_t gi = 0; gi < I.groups.size(); ++gi) {
-      auto& g = I.groups[gi]; GroupIO& x = gio.io[gi];
-      for (int d = 0; d < g.dev_poses; ++d) {
-        const int p = g.dev_to_pose[d];
-        if (p < 0) continue;
-        for (int k = 0; k < 3; ++k) { x.aa[3 * d + k] = v[3 * I.poses[p].first + k]; x.tt[3 * d + k] = v[3 * I.poses[p].second + k]; }
-      }
-      e.Check(pvlm_set_poses(e.ctx(), g.dev_poses, x.aa.data(), x.tt.data()), "pvlm_set_poses");
-      e.Check(pvlm_neq_accumulate_async(e.ctx(), g.neq, g.set, g.loss ? g.loss->kind() : PVLM_LOSS_NONE, g.loss ? g.loss->a() : 0.0, x.packed),
-              "pvlm_neq_accumulate_async");
+    A.cost = 0; A.g.assign(n_free, 0.0); A.keys = keys; A.H.clear();
+    if (n_groups > 0) {
+      for (int p = 0; p < NP; ++p)
+        for (int k = 0; k < 3; ++k) { io.aa[3 * (size_t)p + k] = v[3 * I.poses[p].first + k]; io.tt[3 * (size_t)p + k] = v[3 * I.poses[p].second + k]; }
+      e.Check(pvlm_set_poses(e.ctx(), NP, io.aa.data(), io.tt.data()), "pvlm_set_poses");
+      e.Check(pvlm_neq_accumulate_sets(e.ctx(), n_groups, io.neq.data(), io.sets.data(), io.loss.data(), io.loss_a.data(), io.packed), "pvlm_neq_accumulate_sets");
     }
-    delete stage_timer_sub_;
+    const auto tr1 = std::chrono::steady_clock::now();
+    if (n_groups > 0) e.Check(pvlm_synchronize(e.ctx()), "pvlm_synchronize");
     const auto tr2 = std::chrono::steady_clock::now();
-    { StageTimer stage_timer_wait_("  (inside the linearisation) the one synchronisation"); e.Check(pvlm_synchronize(e.ctx()), "pvlm_synchronize"); }
-    const auto tr3 = std::chrono::steady_clock::now();
-    StageTimer stage_timer_merge_("  (inside the linearisation) host: groups' blocks into the flat table");
-    for (size_t gi = 0; gi < I.groups.size(); ++gi) {
-      auto& g = I.groups[gi]; const GroupIO& x = gio.io[gi];
-      const double* packed = x.packed;
-      const int nd = g.dev_poses, nu = (int)g.ui.size();
-      A.cost += packed[x.count - 1];
-      if (!want_H) continue;
-      const double* Hd = packed; const double* Ho = Hd + (size_t)nd * 36; const double* gg = Ho + (size_t)nu * 36;
-      for (int d = 0; d < nd; ++d) {
-        const int p = g.dev_to_pose[d];
-        if (p < 0) continue;
-        double* blk = A.H.data() + 36 * (size_t)x.diag_slot[(size_t)d];
-        for (int k = 0; k < 36; ++k) blk[k] += Hd[(size_t)d * 36 + k];
-        for (int half = 0; half < 2; ++half) {
-          const int b = half ? I.poses[p].second : I.poses[p].first;
-          if (block_off[b] >= 0) for (int k = 0; k < 3; ++k) A.g[block_off[b] + k] += gg[(size_t)d * 6 + 3 * half + k];
+    if (n_groups > 0) {
+      const double* packed = io.packed;
+      A.cost = packed[io.count - 1];
+      if (want_H) {
+        const double* gg = packed + ((size_t)NP + (size_t)U) * 36;
+        for (int p = 0; p < NP; ++p)
+          for (int half = 0; half < 2; ++half) {
+            const int b = half ? I.poses[p].second : I.poses[p].first;
+            if (block_off[b] >= 0) for (int k = 0; k < 3; ++k) A.g[block_off[b] + k] += gg[(size_t)p * 6 + 3 * half + k];
+          }
+        if (!xch) A.H.assign(packed, packed + ((size_t)NP + (size_t)U) * 36);
+        else {
+          A.H.assign(36 * keys->size(), 0.0);
+          for (size_t q = 0; q < slot_of_packed.size(); ++q)
+            if (slot_of_packed[q] >= 0) std::copy(packed + 36 * q, packed + 36 * (q + 1), A.H.begin() + 36 * (std::ptrdiff_t)slot_of_packed[q]);
         }
       }
-      for (int u = 0; u < nu; ++u) {
-        const double* src = Ho + (size_t)u * 36;  // d2/dx_ui dx_uj
-        double* blk = A.H.data() + 36 * (size_t)x.off_slot[(size_t)u];
-        if (!x.off_transposed[(size_t)u]) for (int k = 0; k < 36; ++k) blk[k] += src[k];
-        else for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[r * 6 + c] += src[c * 6 + r];
-      }
-    }
+    } else if (want_H) A.H.assign(36 * keys->size(), 0.0);
     if (eval_trace) {
-      const auto tr4 = std::chrono::steady_clock::now();
+      const auto tr3 = std::chrono::steady_clock::now();
       auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-      fprintf(stderr, "[eval %ld] zero %.0f us, submission %.0f us, synchronisation %.0f us, merge %.0f us (%zu groups, %zu keys)\n", evaluations, us(tr0, tr1), us(tr1, tr2),
-              us(tr2, tr3), us(tr3, tr4), I.groups.size(), keys->size());
+      fprintf(stderr, "[eval %ld] submission %.0f us, synchronisation %.0f us, table %.0f us (%d groups, %zu keys)\n", evaluations, us(tr0, tr1), us(tr1, tr2), us(tr2, tr3),
+              n_groups, keys->size());
     }
     if (xch) {
       // the one exchange of an evaluation: [cost | g | blocks in key order], summed over the ranks;
