@@ -573,6 +573,12 @@ class ResidualSet:
                                                           _p(rows, C.c_double)), "pvlm_resset_download")
         return po, pr[:self.n_pairs], pn[:self.n_pairs], rows[:self.n]
 
+    def set_pose_ids(self, pair_ref, pair_nei):
+        """Renumbers the segments' poses (one pose table for every set of a problem)."""
+        pr = _i32(pair_ref); pn = _i32(pair_nei)
+        assert len(pr) == self.n_pairs and len(pn) == self.n_pairs
+        self.ctx._check(self.ctx.lib.pvlm_resset_set_pose_ids(self.ctx._h, self._h, _p(pr, C.c_int), _p(pn, C.c_int)), "pvlm_resset_set_pose_ids")
+
     def eval(self, jac=True):
         r = np.empty(max(self.n, 1), np.float64)
         J = np.empty((max(self.n, 1), 12), np.float64) if jac else None
@@ -647,6 +653,16 @@ class NormalEq:
         assert packed.dtype == np.float64 and packed.flags["C_CONTIGUOUS"] and packed.size == self.size
         self.ctx._check(self.ctx.lib.pvlm_neq_accumulate_async(self.ctx._h, self._h, rs._h, C.c_int(loss), C.c_double(loss_a),
                                                                packed.ctypes.data_as(C.POINTER(C.c_double))), "pvlm_neq_accumulate_async")
+
+    @staticmethod
+    def accumulate_sets(ctx, neqs, sets, losses, loss_as, packed):
+        """All sets linearised and summed on the device into neqs[0]'s buffer (identical structures), one queued copy into `packed`;
+        complete after ctx.synchronize()."""
+        n = len(neqs)
+        assert packed.dtype == np.float64 and packed.flags["C_CONTIGUOUS"] and packed.size == neqs[0].size
+        qa = (C.c_void_p * n)(*[q._h for q in neqs]); ra = (C.c_void_p * n)(*[r._h for r in sets])
+        la = (C.c_int * n)(*[int(l) for l in losses]); aa = (C.c_double * n)(*[float(a) for a in loss_as])
+        ctx._check(ctx.lib.pvlm_neq_accumulate_sets(ctx._h, C.c_int(n), qa, ra, la, aa, packed.ctypes.data_as(C.POINTER(C.c_double))), "pvlm_neq_accumulate_sets")
 
     def unpack(self, packed):
         n, u = self.n_poses, self.n_upairs

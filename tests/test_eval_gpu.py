@@ -189,7 +189,24 @@ def test_normal_equations_packed(ctx, oracle):
     neq_b.accumulate_async(rs_b, got_b, 1, a)
     ctx.synchronize()
     assert np.array_equal(got_a, want_a) and np.array_equal(got_b, want_b) and not np.array_equal(got_a, got_b)
-    neq_b.close(); rs_b.close()
+    # ... and the summed form: a set uploaded in ANOTHER pose numbering (ids shifted by 3) is renumbered into the common one
+    # (pvlm_resset_set_pose_ids) and both sets are added on the device into one buffer = the sum of the two synchronous results
+    rs_c = pv.ResidualSet.upload(ctx, 1, rows_b, off_b, ref + 3, nei + 3, flags=1)
+    rs_c.set_pose_ids(ref, nei)
+    po, pr, pn, _ = rs_c.download()
+    assert np.array_equal(pr, ref) and np.array_equal(pn, nei)
+    neq_c = pv.NormalEq(ctx, F, [u[0] for u in up], [u[1] for u in up])
+    summed = np.full(neq.size, np.nan)
+    pv.NormalEq.accumulate_sets(ctx, [neq, neq_c], [rs, rs_c], [1, 1], [a, a], summed)
+    ctx.synchronize()
+    assert np.array_equal(summed, want_a + want_b)          # one addition per entry, the same one the host would make
+    with pytest.raises(pv.PvlmError):                       # different structures cannot share a buffer
+        other = pv.NormalEq(ctx, F + 1, [u[0] for u in up], [u[1] for u in up])
+        try:
+            pv.NormalEq.accumulate_sets(ctx, [neq, other], [rs, rs_c], [1, 1], [a, a], summed)
+        finally:
+            other.close()
+    neq_c.close(); rs_c.close(); neq_b.close(); rs_b.close()
 
 
 def test_errors_are_loud(ctx):
