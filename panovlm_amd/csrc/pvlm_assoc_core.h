@@ -61,6 +61,25 @@ __device__ __forceinline__ float sqrt_reach(float x) { return __builtin_amdgcn_s
 #else
 PVLM_HD float sqrt_reach(float x) { return sqrtf(x); }
 #endif
+// min and max of an int over the ACTIVE lanes of the wave, the same value in every lane (host: the value itself).  A shuffle butterfly
+// when the whole wave is active — inactive lanes do not forward partial results, so with a partial mask the butterfly is wrong —
+// otherwise one v_readlane per active lane.  Called once per query wave, before any lane has left the search.
+#if defined(PVLM_ASSOC_DEVICE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void wave_minmax_i(int v, int* mn, int* mx) {
+  const unsigned long long act = __ballot(1);
+  int lo = v, hi = v;
+  if (act == ~0ull) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+  } else {
+    lo = 0x7fffffff; hi = -0x7fffffff - 1;
+    for (unsigned long long m = act; m; m &= m - 1) { const int x = __builtin_amdgcn_readlane(v, __builtin_ctzll(m)); lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
+  }
+  *mn = __builtin_amdgcn_readfirstlane(lo); *mx = __builtin_amdgcn_readfirstlane(hi);
+}
+#else
+PVLM_HD void wave_minmax_i(int v, int* mn, int* mx) { *mn = v; *mx = v; }
+#endif
 PVLM_HD unsigned f2u(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 PVLM_HD float u2f(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 
@@ -136,19 +155,27 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
   const float inside = fminf(lo_min, hi_min);  // distance (in cells) from q to the nearest face of its own cell
   const float slack = 1e-3f * cv.h + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 1.f);
   const int rmax = (int)ceilf(max_dist * 1.0001f * cv.inv_h);
-  // dense tables: the (dz, dy) loops only run over rows that exist (a line- or plane-shaped cloud has a table a few cells thick: with the
-  // loops over the full shell a query with fewer than K points in reach walked O(rmax^3) empty rows), and the search stops once the
-  // searched block covers the whole table
+  // Dense tables: the (dz, dy) loops only run over rows that exist in SOME lane's table range (a line- or plane-shaped cloud has a table
+  // a few cells thick: with the loops over the full shell a query with fewer than K points in reach walked O(rmax^3) empty rows), and the
+  // search stops once the searched block covers the whole table.  The bounds come from the wave's min / max cell (reduced once, at
+  // entry), so that the loop counters stay scalar: per-lane bounds cost K2 5 % in divergent loop control.
   const int ncx = cv.dense ? cv.nx / xf : 0;
+  int cz_min = 0, cz_max = 0, cy_min = 0, cy_max = 0;        // over the wave: the clipped loop bounds below stay scalar
+  if (cv.dense) { wave_minmax_i(cz, &cz_min, &cz_max); wave_minmax_i(cy, &cy_min, &cy_max); }
   for (int r = 0; r <= rmax; ++r) {
-    const int dz_lo = cv.dense ? (-r > -cz ? -r : -cz) : -r, dz_hi = cv.dense ? (r < cv.nz - 1 - cz ? r : cv.nz - 1 - cz) : r;
-    const int dy_lo = cv.dense ? (-r > -cy ? -r : -cy) : -r, dy_hi = cv.dense ? (r < cv.ny - 1 - cy ? r : cv.ny - 1 - cy) : r;
+    int dz_lo = -r, dz_hi = r, dy_lo = -r, dy_hi = r;
+    if (cv.dense) {                                            // rows of SOME lane's table range; the per-lane range test below remains
+      dz_lo = -cz_max > dz_lo ? -cz_max : dz_lo; dz_hi = cv.nz - 1 - cz_min < dz_hi ? cv.nz - 1 - cz_min : dz_hi;
+      dy_lo = -cy_max > dy_lo ? -cy_max : dy_lo; dy_hi = cv.ny - 1 - cy_min < dy_hi ? cv.ny - 1 - cy_min : dy_hi;
+    }
     for (int dz = dz_lo; dz <= dz_hi; ++dz) {
       const int z = cz + dz;
+      if (cv.dense && (z < 0 || z >= cv.nz)) continue;
       const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);   // gap to the row's slab, in cells
       const float gzm = fmaxf(gz * cv.h - slack, 0.f);
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int y = cy + dy;
+        if (cv.dense && (y < 0 || y >= cv.ny)) continue;
         const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
         const float gym = fmaxf(gy * cv.h - slack, 0.f);
         const float lb = gym * gym + gzm * gzm;                       // <= d2 of every point of the row
