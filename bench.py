@@ -637,10 +637,10 @@ def association_points(ctx, pv, torch, args, scans, dscans, ref, nei, associate,
     neq_r = pv.NormalEq(ctx, F, ui, uj)
     packed_r = torch.zeros(neq_r.size, dtype=torch.float64, device=dev)
     step_r, _ = make_step(rsr, neq_r, packed_r, False, graphed=False)
-    for _ in range(5):
+    for _ in range(20):
         step_r()
     torch.cuda.synchronize()
-    reps = 20
+    reps = 100
     ctx.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(reps):

@@ -318,6 +318,28 @@ __device__ __forceinline__ void accumulate_row(const double* rec, const double* 
   acc[27] += half_rho;
 }
 
+// Sums of N <= 32 per-lane values over the wave with a fixed tree: at offset 32 every lane keeps one half of the values and trades
+// the other half with its partner (16 exchanges), at 16 a quarter, ... — after offset 2 a lane holds one value, its index = lane >> 1,
+// and the last exchange adds the two partial sums.  The order of the additions is the same on every run.
+template <int N>
+__device__ __forceinline__ double wave_transpose_sum(const double (&a)[N], int lane) {
+  static_assert(N <= 32, "at most 32 values");
+  double v[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) v[k] = k < N ? a[k] : 0.0;
+#pragma unroll
+  for (int half = 16; half >= 1; half >>= 1) {             // exchange distance 2 * half lanes
+    const bool up = (lane & (2 * half)) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const double keep = up ? v[half + k] : v[k];
+      const double send = up ? v[k] : v[half + k];
+      v[k] = keep + __shfl_xor(send, 2 * half, 64);
+    }
+  }
+  return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
 template <int KIND, bool NORM, int NCOLS, int LOSS>
 __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const double* const* __restrict__ pair_cols,
                                                     const int64_t* __restrict__ pair_stride,
@@ -378,10 +400,9 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
   }
   __shared__ double red[4][PVLM_PARTIAL];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < PVLM_PARTIAL; ++k) {
-    const double s = wave_sum(acc[k]);
-    if (lane == 0) red[wv][k] = s;
+  {
+    const double s = wave_transpose_sum<PVLM_PARTIAL>(acc, lane);       // lane 2k: total k of this wave
+    if (!(lane & 1) && (lane >> 1) < PVLM_PARTIAL) red[wv][lane >> 1] = s;
   }
   __syncthreads();
   if (threadIdx.x < PVLM_PARTIAL)
@@ -429,16 +450,9 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused_wave(const
       accumulate_row<KIND, NORM, NCOLS, LOSS>(rec, T, weight, loss_a, a2, acc);
     }
   }
-  // fixed shuffle tree; lane k keeps total k, so that the 28 results leave in one coalesced store
-  double mine = 0.0;
-#pragma unroll
-  for (int k = 0; k < PVLM_PARTIAL; ++k) {
-    double s = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == k) mine = s;
-  }
-  if (lane < PVLM_PARTIAL) partials[(size_t)unit * PVLM_PARTIAL + lane] = mine;
+  // the 28 totals in one transposing butterfly (32 exchanges instead of 28 x 6): lanes 2k and 2k + 1 end with total k
+  const double mine = wave_transpose_sum<PVLM_PARTIAL>(acc, lane);
+  if (!(lane & 1) && (lane >> 1) < PVLM_PARTIAL) partials[(size_t)unit * PVLM_PARTIAL + (lane >> 1)] = mine;
 }
 
 // one block (128 threads) per pair: sum chunk partials in order, expand S, apply
