@@ -40,18 +40,30 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 // atan(t) for |t| <= tan(pi/8): degree-10 polynomial in t^2 (Chebyshev-node interpolant of
 // atan(t)/t on [0, tan^2(pi/8)], max relative error 2.2e-16 measured against mpmath).
+// A Horner step p * u + c costs ONE v_fma_f64 when the coefficient sits in a scalar register pair; written as fma(p, u, literal) the
+// compiler keeps the ten literals in VGPRs and pays a 64-bit move per step to feed the two-address v_fmac_f64 (ISA of round 3:
+// 20 of the ~330 VALU instructions of a two-row iteration) — hence the operand constraint below.  Same instruction, same bits.
+__device__ __forceinline__ double fma_sconst(double p, double u, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(u), "s"(c));
+  return d;
+#else
+  return fma(p, u, c);
+#endif
+}
 __device__ __forceinline__ double atan_small(double t) {
   const double u = t * t;
   double p = 2.11272689568591313e-02;
-  p = fma(p, u, -4.34739031566048761e-02);
-  p = fma(p, u, 5.68812005923421543e-02);
-  p = fma(p, u, -6.64019012732186553e-02);
-  p = fma(p, u, 7.68994845277858746e-02);
-  p = fma(p, u, -9.09077271667437237e-02);
-  p = fma(p, u, 1.11111061650365134e-01);
-  p = fma(p, u, -1.42857141805968924e-01);
-  p = fma(p, u, 1.99999999988503901e-01);
-  p = fma(p, u, -3.33333333333284132e-01);
+  p = fma_sconst(p, u, -4.34739031566048761e-02);
+  p = fma_sconst(p, u, 5.68812005923421543e-02);
+  p = fma_sconst(p, u, -6.64019012732186553e-02);
+  p = fma_sconst(p, u, 7.68994845277858746e-02);
+  p = fma_sconst(p, u, -9.09077271667437237e-02);
+  p = fma_sconst(p, u, 1.11111061650365134e-01);
+  p = fma_sconst(p, u, -1.42857141805968924e-01);
+  p = fma_sconst(p, u, 1.99999999988503901e-01);
+  p = fma_sconst(p, u, -3.33333333333284132e-01);
   p = fma(p, u, 1.0);
   return t * p;
 }
