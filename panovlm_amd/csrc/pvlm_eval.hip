@@ -35,6 +35,10 @@ typedef const pvlm_dbl2* pvlm_col_ptr;
 #ifndef PVLM_NT_LOADS_MATERIALISE   // the same hint in the kernels that also WRITE rows (k_eval_materialise, k_eval_wrench)
 #define PVLM_NT_LOADS_MATERIALISE 0
 #endif
+// base + a 32-bit BYTE offset: the form the backend matches to `global_load ... v_off, s[base]` when the base is wave-uniform
+__device__ __forceinline__ const double* at_byte(const double* base, unsigned bytes) {
+  return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + bytes);
+}
 template <bool NT>
 __device__ __forceinline__ double2 stream_load2(const double* p) {
   pvlm_col_ptr q = (pvlm_col_ptr)(p);
@@ -68,6 +72,12 @@ __device__ __forceinline__ void stream_store1(double* p, double v) {
 #endif
 #ifndef PVLM_FUSED_WAVES
 #define PVLM_FUSED_WAVES 2  // waves per SIMD the fused kernel must fit (no spilling at 3-4: measured 2x slower)
+#endif
+#ifndef PVLM_FUSED_WAVES_7COL      // ... the block-per-chunk kernel of the 7-column (point-to-plane) functors: 128 VGPRs without scratch since the
+#define PVLM_FUSED_WAVES_7COL 4    // saddr loads + scalar polynomial coefficients of round 3; 118.2 vs 117.2 G eval/s at 3 waves (profiles/r3_eval_diet_ab.txt)
+#endif
+#ifndef PVLM_FUSED_WAVES_WAVEFORM  // ... and the wave-per-(pair, chunk) kernel: 168 VGPRs fit three waves; left to itself the allocator takes 178 (two waves, -10 %)
+#define PVLM_FUSED_WAVES_WAVEFORM 3
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -341,7 +351,7 @@ __device__ __forceinline__ double wave_transpose_sum(const double (&a)[N], int l
 }
 
 template <int KIND, bool NORM, int NCOLS, int LOSS>
-__global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const double* const* __restrict__ pair_cols,
+__global__ __launch_bounds__(256, (NCOLS == 7 ? PVLM_FUSED_WAVES_7COL : PVLM_FUSED_WAVES)) void k_eval_fused(const double* const* __restrict__ pair_cols,
                                                     const int64_t* __restrict__ pair_stride,
                                                     const int64_t* __restrict__ out_start,
                                                     const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
@@ -365,33 +375,39 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
   // is evaluated (+7 % on MI355X); the Angle functors are VALU-bound at 3 waves/SIMD and lose
   // occupancy to the extra 28 VGPRs, so they load in place.
   constexpr bool kPrefetch = PVLM_PREFETCH >= 0 ? (PVLM_PREFETCH != 0) : (KIND == PVLM_POINT2PLANE_METER || KIND == PVLM_POINT2LINE_METER);
-  int64_t j = lo + 2 * (int64_t)threadIdx.x;
-  double2 nx[NCOLS];
-  if (kPrefetch && j < hi) {
+  // addresses = a wave-uniform column base (scalar registers) + one 32-bit row offset shared by the columns: the loads take the
+  // saddr + voffset form and an iteration advances ONE register instead of a 64-bit pointer per column
+  const double* colb[NCOLS];
 #pragma unroll
-    for (int c = 0; c < NCOLS; ++c) nx[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j);
+  for (int c = 0; c < NCOLS; ++c) colb[c] = cols + (size_t)c * n_dev + lo;
+  const unsigned span = hi > lo ? (unsigned)(hi - lo) : 0u;
+  unsigned j = 2u * threadIdx.x;
+  double2 nx[NCOLS];
+  if (kPrefetch && j < span) {
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) nx[c] = stream_load2<PVLM_NT_LOADS != 0>(at_byte(colb[c], 8u * j));
   }
-  for (; j < hi; j += 512) {
+  for (; j < span; j += 512) {
     double2 v[NCOLS];
     if (kPrefetch) {
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) v[c] = nx[c];
-      if (j + 512 < hi) {
+      if (j + 512 < span) {
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) nx[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j + 512);
+        for (int c = 0; c < NCOLS; ++c) nx[c] = stream_load2<PVLM_NT_LOADS != 0>(at_byte(colb[c], 8u * (j + 512)));
       }
     } else {
 #ifdef PVLM_EXP_SKIP   // timing experiment only (wrong results): how does the rate respond to fewer bytes per evaluation?
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(cols + (size_t)(c < NCOLS - PVLM_EXP_SKIP ? c : 0) * n_dev + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = *reinterpret_cast<const double2*>(colb[c < NCOLS - PVLM_EXP_SKIP ? c : 0] + j);
 #else
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j);
+      for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS != 0>(at_byte(colb[c], 8u * j));
 #endif
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (j + h >= hi) break;
+      if (j + h >= span) break;
       double rec[NCOLS];
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
@@ -416,13 +432,15 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused(const doub
 // LDS + a barrier per segment.  A wave streams 128 rows per iteration and reduces with shuffles only.  Selected per residual set
 // at finalize (pvlm_resset::wave_units: mean segment < 4096 rows); the headline's long segments keep k_eval_fused.
 template <int KIND, bool NORM, int NCOLS, int LOSS>
-__global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused_wave(const double* const* __restrict__ pair_cols,
+__global__ __launch_bounds__(256, PVLM_FUSED_WAVES_WAVEFORM) void k_eval_fused_wave(const double* const* __restrict__ pair_cols,
                                                     const int64_t* __restrict__ pair_stride,
                                                     const int64_t* __restrict__ out_start,
                                                     const int* __restrict__ blk_pair, const int* __restrict__ blk_chunk,
                                                     int chunk_rows, int n_units, const double* __restrict__ pair_tab, double weight,
                                                     double loss_a, double* __restrict__ partials) {
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // the unit is the same for the 64 lanes: said explicitly, the pair's pointers, bounds and the 15 pose constants are scalar loads
+  // into scalar registers (30 VGPRs less) instead of 64 identical vector loads
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (unit >= n_units) return;
   const int p = blk_pair[unit];
   const double* __restrict__ cols = pair_cols[p];
@@ -437,13 +455,17 @@ __global__ __launch_bounds__(256, PVLM_FUSED_WAVES) void k_eval_fused_wave(const
 #pragma unroll
   for (int k = 0; k < PVLM_PARTIAL; ++k) acc[k] = 0.0;
   const double a2 = loss_a * loss_a;
-  for (int64_t j = lo + 2 * (int64_t)lane; j < hi; j += 128) {
+  const double* colb[NCOLS];       // uniform column bases + one 32-bit row offset, as in k_eval_fused
+#pragma unroll
+  for (int c = 0; c < NCOLS; ++c) colb[c] = cols + (size_t)c * n_dev + lo;
+  const unsigned span = hi > lo ? (unsigned)(hi - lo) : 0u;
+  for (unsigned j = 2u * lane; j < span; j += 128) {
     double2 v[NCOLS];
 #pragma unroll
-    for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS != 0>(cols + (size_t)c * n_dev + j);
+    for (int c = 0; c < NCOLS; ++c) v[c] = stream_load2<PVLM_NT_LOADS != 0>(at_byte(colb[c], 8u * j));
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (j + h >= hi) break;
+      if (j + h >= span) break;
       double rec[NCOLS];
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
