@@ -305,6 +305,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
 
+// The same colour pass with one pixel per THREAD (pvlm_mvs::ColumnScorer): the reference's own per-pixel program — window texel after
+// texel, sums in index order — run by 64 pixels side by side.  Against the wave-per-pixel kernel above: all 64 lanes carry texels
+// (there 49 of 64 on a 7 x 7 window), nothing wave-uniform is evaluated 64 times (homographies, perturbation trigonometry, the
+// smoothness factors, the decision logic of process_pixel), and the index-ordered sums are a register add per texel instead of an
+// LDS strip walked by one lane.  The neighbour texels of the image being scored are a column of the workgroup's LDS table ([k][lane]:
+// bank-conflict free, 12.5 KB per wave at 7 x 7, i.e. three waves per SIMD); the patch weights a column of `wtab` ([k][pixel of the
+// pass], n x rows x ceil(cols / 2) floats of scratch).  Windows of at most 64 texels.
+#ifndef PVLM_K13L_WAVES
+#define PVLM_K13L_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WAVES, 4))) void k_mvs_propagate_lane(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
+    float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int offset,
+    float* __restrict__ wtab) {
+  extern __shared__ float lane_tab[];                                      // [n][64]
+  const int half = (cols + 1) / 2;
+  const long long wv = (long long)blockIdx.x * 64 + threadIdx.x;           // the wave kernel's pixel numbering: thread <-> pixel of this colour
+  if (wv >= (long long)rows * half) return;
+  const int py = (int)(wv / half);
+  const int px = ((py % 2 + offset) % 2) + 2 * (int)(wv % half);
+  if (px >= cols) return;
+  const long long e = (long long)py * cols + px;
+  float dep = depth[e];
+  if (dep <= 0) return;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)rows * half, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
+  pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
+  if (!P.inside || P.sq0 <= 1e-6) return;                                 // patch.sq0 <= 1e-6 (:1116-1117)
+  float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+  float c = conf[e];
+  pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+  pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
+  pvlm_mvs::ColumnScorer<pvlm_mvs_neighbours> scorer{{}, {}, rows, cols, half_window, step, n, px, py, unit, ref_gray, &nb, P};
+  const int pdx[4] = {-1, 0, 1, 0}, pdy[4] = {0, -1, 0, 1};
+  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 4, pdx, pdy);
+  depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c;
+}
+
 // Sequential sweep (PropagateSequential :1057-1097, the strategy config/Room.txt and config/Floor.txt select: propagate_strategy = 2):
 // upstream walks the image in raster order (even iterations; odd ones backwards) and a pixel takes the hypotheses of its left and
 // upper neighbour, which that very walk has just updated.  A pixel only ever reads its four direct neighbours, so all pixels of an
@@ -457,12 +495,29 @@ static void launch_mvs_conf(hipStream_t s, int rows, int cols, int half_window, 
   if (pvlm_mvs::num_texels(half_window, step) <= 64) hipLaunchKernelGGL(k_mvs_conf<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf);
   else hipLaunchKernelGGL(k_mvs_conf<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf);
 }
+// The colour pass takes the thread-per-pixel form when the caller hands it the weight table (mvs_lane_table: windows of at most 64
+// texels, PVLM_MVS_LANE=0 switches back for A/B runs): 8.9 against 14.6 ms per pass at 1440 x 720 x 4 neighbours, 9.8 against 19.5 ms with the
+// geometric term (profiles/r3_mvs_lane_ab.txt).
+static bool mvs_lane_form(int n_tex) {
+  static const bool off = getenv("PVLM_MVS_LANE") && atoi(getenv("PVLM_MVS_LANE")) == 0;
+  return !off && n_tex <= 64;
+}
+static size_t mvs_lane_table_floats(int rows, int cols, int half_window, int step) {
+  const int n_tex = pvlm_mvs::num_texels(half_window, step);
+  return mvs_lane_form(n_tex) ? (size_t)n_tex * (size_t)rows * (size_t)((cols + 1) / 2) : 0;
+}
 static void launch_mvs_propagate(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
                                  const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, const unsigned char* depth_constant, float min_depth,
-                                 float max_depth, unsigned long long pass_seed, int offset) {
+                                 float max_depth, unsigned long long pass_seed, int offset, float* wtab) {
   const size_t waves = (size_t)rows * (size_t)((cols + 1) / 2);
+  const int n_tex = pvlm_mvs::num_texels(half_window, step);
+  if (wtab && n_tex <= 64) {
+    hipLaunchKernelGGL(k_mvs_propagate_lane, dim3((unsigned)((waves + 63) / 64)), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step, img, unit, nb,
+                       depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset, wtab);
+    return;
+  }
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  if (pvlm_mvs::num_texels(half_window, step) <= 64)
+  if (n_tex <= 64)
     hipLaunchKernelGGL(k_mvs_propagate<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset);
   else
     hipLaunchKernelGGL(k_mvs_propagate<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset);
@@ -747,12 +802,16 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
         }
         hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (long long)npix, d_const, conf_threshold, d_depth, d_normal, d_conf);
       } else {
+        float* d_wtab = nullptr;                       // patch weights of the thread-per-pixel form, [texel][pixel of the colour]
+        const size_t wtab_floats = mvs_lane_table_floats(rows, cols, half_window, step);
+        if (wtab_floats && pvlm_i_alloc(ctx, &d_wtab, wtab_floats)) d_wtab = nullptr;    // no room: the wave-per-pixel form needs none
         for (int iter = 0; iter < max_iter; ++iter)
           for (int offset = 0; offset <= 1; ++offset) {
             pvlm_prof_scope prof(ctx, 1);
             launch_mvs_propagate(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf, d_const, min_depth, max_depth,
-                                 pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
+                                 pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset, d_wtab);
           }
+        pvlm_i_free(ctx, d_wtab);                        // stream-ordered: behind the launches above
         hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (long long)npix, d_const, conf_threshold, d_depth, d_normal, d_conf);
       }
       e = hipGetLastError();
@@ -1145,13 +1204,18 @@ static pvlm_status views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int
           launch_mvs_propagate_sequential(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o,
                                           d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, iter), iter);
         }
-      } else
-      for (int iter = 0; iter < max_iter; ++iter)
-        for (int offset = 0; offset <= 1; ++offset) {
-          pvlm_prof_scope prof(ctx, 1);
-          launch_mvs_propagate(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o, d_const,
-                               min_depth, max_depth, pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset);
-        }
+      } else {
+        float* d_wtab = nullptr;
+        const size_t wtab_floats = mvs_lane_table_floats(v->rows, v->cols, half_window, step);
+        if (wtab_floats && pvlm_i_alloc(ctx, &d_wtab, wtab_floats)) d_wtab = nullptr;
+        for (int iter = 0; iter < max_iter; ++iter)
+          for (int offset = 0; offset <= 1; ++offset) {
+            pvlm_prof_scope prof(ctx, 1);
+            launch_mvs_propagate(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o, d_const,
+                                 min_depth, max_depth, pvlm_mvs::pass_seed(seed, 2 * iter + offset), offset, d_wtab);
+          }
+        pvlm_i_free(ctx, d_wtab);
+      }
       hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, s, (long long)v->npix, d_const, conf_threshold, v->d_depth + o,
                          v->d_normal + 3 * o, v->d_conf + o);
     }

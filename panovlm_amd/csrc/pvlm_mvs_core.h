@@ -694,4 +694,129 @@ PVLM_HD inline void process_pixel_spec(const SweepArgs& A, Rng& rng, int px, int
   }
 }
 
+// ---- one pixel per THREAD ------------------------------------------------------------------------------------------------------
+// FillPixelPatch + ScorePixel as the reference runs them: one pixel, its window texel after texel, the sums in index order.  The
+// per-pixel arrays are COLUMNS of tables shared by many pixels — element k of a column at [k * stride]:
+//   w   the normalised bilateral weights: a table in global memory (k_mvs_propagate_lane: [texel][pixel of the pass], written by the
+//       thread that reads it, coalesced), because it is the one array that lives for the whole pixel;
+//   t1  the current neighbour image's texels: the workgroup's LDS ([texel][lane], 12.5 KB per wave at 7 x 7);
+//   the weighted centred reference texel (t0 - mean) * w is recomputed from the grey byte, the mean and w: the same two operations
+//   FillPixelPatch performs (:668-672), so the same float.
+// On the GPU this is 64 pixels per wave: no lane idles on a 49-texel window, no wave-uniform value is computed 64 times, no
+// cross-lane sums.  On the host (tests/cpp/mvs_math_check.cpp) the strides are 1.
+struct ColumnPatch { float* w; size_t w_stride; float* t1; int t1_stride; float mean, sq0; bool inside; };
+
+PVLM_HD inline float ref_texel(const unsigned char* gray, int cols, int px, int py, int half_window, int step, int k) {
+  int di, dj; texel_offset(half_window, step, k, &di, &dj);
+  return (float)gray[(size_t)(py - half_window + di) * cols + (px - half_window + dj)];
+}
+
+PVLM_HD inline void fill_patch_column(const unsigned char* ref_gray, int rows, int cols, int px, int py, int half_window, int step, int n, ColumnPatch& P) {
+  P.sq0 = 0.f; P.mean = 0.f;
+  P.inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
+  if (!P.inside) return;
+  const size_t st = P.w_stride;
+  float wsum = 0.f;
+  for (int k = 0; k < n; ++k) { float w, t; patch_texel(ref_gray, cols, px, py, half_window, step, k, &w, &t); P.w[k * st] = w; wsum += w; }            // :659
+  float mean = 0.f;
+  for (int k = 0; k < n; ++k) { const float w = P.w[k * st] / wsum; P.w[k * st] = w; mean += w * ref_texel(ref_gray, cols, px, py, half_window, step, k); }   // :662-664
+  float sq0 = 0.f;
+  for (int k = 0; k < n; ++k) { const float t = ref_texel(ref_gray, cols, px, py, half_window, step, k) - mean; const float tmp = t * P.w[k * st]; sq0 += t * tmp; }   // :668-672
+  P.mean = mean; P.sq0 = sq0;
+}
+
+// neighbour_texel in two halves, so that the four byte loads of texel k + 1 can be in flight while texel k is consumed:
+// the projection (where the tap lands, the bilinear fractions) and the interpolation of the four grey values.
+struct TexelTap { size_t at; float fx, fy; bool ok; };
+PVLM_HD inline TexelTap texel_tap(const float* uv, int rows, int cols, const float* H) {
+  float X1[3];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += H[3 * r + c] * uv[c]; X1[r] = s; }
+  float x1[2];
+  cam_to_image(rows, cols, X1, x1);
+  TexelTap t;
+  t.ok = x1[0] >= 1 && x1[1] >= 1 && x1[0] < cols - 1 && x1[1] < rows - 1;                  // frame.IsInside(x1, 1, 1)
+  const int lx = t.ok ? (int)x1[0] : 0, ly = t.ok ? (int)x1[1] : 0;                          // a tap outside the image reads pixel (0, 0) and is not used
+  t.fx = x1[0] - lx; t.fy = x1[1] - ly;
+  t.at = (size_t)ly * cols + lx;
+  return t;
+}
+struct TexelBytes { unsigned char p00, p01, p10, p11; };
+PVLM_HD inline TexelBytes tap_bytes(const unsigned char* gray, int cols, const TexelTap& t) {
+  const unsigned char* p = gray + t.at;
+  return TexelBytes{p[0], p[1], p[cols], p[cols + 1]};
+}
+PVLM_HD inline float tap_value(const TexelTap& t, const TexelBytes& b) {
+  const float ax = 1.f - t.fx, ay = 1.f - t.fy;
+  return (b.p00 * ax + b.p01 * t.fx) * ay + (b.p10 * ax + b.p11 * t.fx) * t.fy;
+}
+PVLM_HD inline const float* texel_ray(const float* unit, int cols, int px, int py, int half_window, int step, int k) {
+  int di, dj; texel_offset(half_window, step, k, &di, &dj);
+  return unit + 3 * ((size_t)(py - half_window + di) * cols + (px - half_window + dj));
+}
+
+// Views: gray[], depth[], R[][9], t[][3], n, geometric (pvlm_mvs_neighbours on the GPU)
+template <class Views>
+struct ColumnScorer : SerialMath, SerialFactors {
+  int rows, cols, half_window, step, n, px, py;
+  const float* unit; const unsigned char* ref_gray; const Views* nb; ColumnPatch P;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PVLM_MVS_NOINLINE_SCORER)
+  __attribute__((noinline))          // process_pixel scores at three places: one copy of the 49-texel loops, not three
+#endif
+  PVLM_HD float operator()(const float* nr, float dep, const float* factors, int n_close) const {
+    const float* u0 = unit + 3 * ((size_t)py * cols + px);
+    const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
+    const float d = X0[0] * nr[0] + X0[1] * nr[1] + X0[2] * nr[2];
+    if (d > 0) return -1.f;
+    const size_t ws = P.w_stride; const int ts = P.t1_stride;
+    float best1 = 0.f, best2 = 0.f; int count = 0;
+    for (int b = 0; b < nb->n; ++b) {
+      float H[9];
+      homography(nb->R[b], nb->t[b], nr, d, H);
+      const unsigned char* gray = nb->gray[b];
+      // software pipeline over the window: the ray of texel k + 2, the taps of texel k + 1 and the weight of texel k + 1 are loaded
+      // while texel k is interpolated — one thread has nothing else to hide its load latency with
+      float uv[3];
+      { const float* r = texel_ray(unit, cols, px, py, half_window, step, 0); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
+      TexelTap cur = texel_tap(uv, rows, cols, H);
+      TexelBytes cb = tap_bytes(gray, cols, cur);
+      float wk = P.w[0];
+      if (n > 1) { const float* r = texel_ray(unit, cols, px, py, half_window, step, 1); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
+      bool ok = true;
+      float sum = 0.f;
+      for (int k = 0; k < n; ++k) {
+        TexelTap nxt = cur; TexelBytes nbts = cb; float wn = wk;
+        if (k + 1 < n) {
+          nxt = texel_tap(uv, rows, cols, H);
+          nbts = tap_bytes(gray, cols, nxt);
+          wn = P.w[(size_t)(k + 1) * ws];
+          if (k + 2 < n) { const float* r = texel_ray(unit, cols, px, py, half_window, step, k + 2); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
+        }
+        ok = ok && cur.ok;                                                            // a texel outside the neighbour image drops the image (`goto next_image`)
+        const float v = tap_value(cur, cb);
+        P.t1[k * ts] = v;
+        sum += v * wk;                                                                // :826-827
+        cur = nxt; cb = nbts; wk = wn;
+      }
+      if (!ok) continue;
+      float sq1 = 0.f, sq01 = 0.f;                                                    // two sums, each in index order (:830-831, :834-835)
+      for (int k = 0; k < n; ++k) {
+        const float w = P.w[k * ws], t = P.t1[k * ts] - sum;
+        sq1 += t * t * w;
+        sq01 += (ref_texel(ref_gray, cols, px, py, half_window, step, k) - P.mean) * w * t;
+      }
+      const float nrm = P.sq0 * sq1;
+      if (nrm <= 0.f) continue;
+      float score = sq01 / sqrtf(nrm);
+      score = fminf(fmaxf(score, -1.f), 1.f);
+      score = smooth_score(score, factors, n_close);
+      if (nb->geometric) score = geometric_adjust(score, rows, cols, X0, nb->R[b], nb->t[b], nb->depth[b]);
+      if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+      ++count;
+    }
+    if (count == 1) return best1;
+    if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; return avg / 2; }
+    return -1.f;
+  }
+};
+
 }  // namespace pvlm_mvs

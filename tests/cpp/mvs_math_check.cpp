@@ -197,6 +197,58 @@ extern "C" void chk_mvs_propagate(int rows, int cols, int half_window, int step,
   }
 }
 
+// The checkerboard sweep through the THREAD-per-pixel bodies (pvlm_mvs::fill_patch_column + ColumnScorer, the program of
+// k_mvs_propagate_lane): weight table and texel column with the strides the kernel uses ([texel][pixel of the pass], [texel][64]),
+// pixels visited backwards.
+namespace {
+struct HostViews { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
+}
+extern "C" void chk_mvs_propagate_column(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
+                                         const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
+                                         const float* const* nei_depth, const unsigned char* depth_constant, float min_depth, float max_depth,
+                                         unsigned long long seed, int max_iter, float conf_threshold) {
+  using namespace pvlm_mvs;
+  const size_t npix = (size_t)rows * cols;
+  std::vector<float> unit(npix * 3);
+  for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) unit_ray(rows, cols, c, r, &unit[3 * ((size_t)r * cols + c)]);
+  HostViews nb{};
+  nb.n = n_neighbors; nb.geometric = nei_depth != nullptr;
+  for (int b = 0; b < n_neighbors; ++b) {
+    nb.gray[b] = nei_gray[b]; nb.depth[b] = nei_depth ? nei_depth[b] : nullptr;
+    for (int k = 0; k < 9; ++k) nb.R[b][k] = R_nr[9 * b + k];
+    for (int k = 0; k < 3; ++k) nb.t[b][k] = t_nr[3 * b + k];
+  }
+  const int n = num_texels(half_window, step), half = (cols + 1) / 2;
+  const size_t in_pass = (size_t)rows * half;
+  std::vector<float> wtab((size_t)n * in_pass), t1((size_t)n * 64);
+  for (int iter = 0; iter < max_iter; ++iter)
+    for (int offset = 0; offset <= 1; ++offset) {
+      const unsigned long long ps = pass_seed(seed, 2 * iter + offset);
+      for (long long wv = (long long)in_pass - 1; wv >= 0; --wv) {
+        const int py = (int)(wv / half), px = ((py % 2 + offset) % 2) + 2 * (int)(wv % half);
+        if (px >= cols) continue;
+        const size_t e = (size_t)py * cols + px;
+        float dep = depth[e];
+        if (dep <= 0) continue;
+        ColumnPatch P{wtab.data() + wv, in_pass, t1.data() + (wv % 64), 64, 0.f, 0.f, false};
+        fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
+        if (!P.inside || P.sq0 <= 1e-6) continue;
+        float nr[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+        float c = conf[e];
+        SweepArgs A{rows, cols, unit.data(), depth, normal, depth_constant, min_depth, max_depth};
+        Rng rng{ps, (unsigned long long)e, 0u};
+        ColumnScorer<HostViews> scorer{{}, {}, rows, cols, half_window, step, n, px, py, unit.data(), ref_gray, &nb, P};
+        const int pdx[4] = {-1, 0, 1, 0}, pdy[4] = {0, -1, 0, 1};
+        process_pixel(A, rng, px, py, scorer, dep, nr, c, 4, pdx, pdy);
+        depth[e] = dep; normal[3 * e] = nr[0]; normal[3 * e + 1] = nr[1]; normal[3 * e + 2] = nr[2]; conf[e] = c;
+      }
+    }
+  for (size_t e = 0; e < npix; ++e) {
+    if (depth_constant && depth_constant[e]) continue;
+    if (conf[e] < conf_threshold) { depth[e] = 0.f; conf[e] = -1.f; normal[3 * e] = normal[3 * e + 1] = normal[3 * e + 2] = 0.f; }
+  }
+}
+
 // The sequential sweep through the device bodies, in the order k_mvs_propagate_diag gives the GPU: anti-diagonal after
 // anti-diagonal, and INSIDE a diagonal from the bottom row up (the launch makes no promise about the order of its waves) — not
 // the raster order of the oracle.  Equal maps prove what the kernel relies on: the pixels of a diagonal do not depend on each other.

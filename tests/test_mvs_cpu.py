@@ -259,6 +259,12 @@ def test_patchmatch_sweep_oracle_behaviour_and_device_bodies(oracle):
                               fp(R), fp(t), fp(d), fp(n), fp(c), dptrs, dc.ctypes.data_as(C.POINTER(C.c_ubyte)) if dc is not None else None, C.c_float(0.1),
                               C.c_float(20.0), C.c_ulonglong(kw["seed"]), C.c_int(kw["max_iter"]), C.c_float(kw.get("conf_threshold", -1.0)))
         assert np.array_equal(d, want[0]) and np.array_equal(n, want[1]) and np.array_equal(c, want[2])
+        # the thread-per-pixel bodies (fill_patch_column + ColumnScorer: the program of k_mvs_propagate_lane) — the same maps
+        d = S["depth"].copy(); n = S["normal"].copy(); c = S["conf"].copy()
+        lib.chk_mvs_propagate_column(C.c_int(d.shape[0]), C.c_int(d.shape[1]), C.c_int(3), C.c_int(1), S["gray"].ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_int(len(nd)), ptrs,
+                                     fp(R), fp(t), fp(d), fp(n), fp(c), dptrs, dc.ctypes.data_as(C.POINTER(C.c_ubyte)) if dc is not None else None, C.c_float(0.1),
+                                     C.c_float(20.0), C.c_ulonglong(kw["seed"]), C.c_int(kw["max_iter"]), C.c_float(kw.get("conf_threshold", -1.0)))
+        assert np.array_equal(d, want[0]) and np.array_equal(n, want[1]) and np.array_equal(c, want[2])
         # the SEQUENTIAL sweep (the Room / Floor strategy): the oracle walks in raster order, the device bodies go anti-diagonal
         # by anti-diagonal, bottom row first inside a diagonal — the kernel's launch structure.  Three iterations: forward, back, forward.
         kw3 = dict(kw); kw3["max_iter"] = 3
