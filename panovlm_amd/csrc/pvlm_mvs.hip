@@ -318,19 +318,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WAVES, 4))) void k_mvs_propagate_lane(
     int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
     float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int offset,
-    float* __restrict__ wtab) {
+    float* __restrict__ wtab, int row0, int band_rows) {
   extern __shared__ float lane_tab[];                                      // [n][64]
   const int half = (cols + 1) / 2;
-  const long long wv = (long long)blockIdx.x * 64 + threadIdx.x;           // the wave kernel's pixel numbering: thread <-> pixel of this colour
-  if (wv >= (long long)rows * half) return;
-  const int py = (int)(wv / half);
+  const long long wv = (long long)blockIdx.x * 64 + threadIdx.x;           // thread <-> pixel of this colour inside the band of rows [row0, row0 + band_rows)
+  if (wv >= (long long)band_rows * half) return;
+  const int py = row0 + (int)(wv / half);
   const int px = ((py % 2 + offset) % 2) + 2 * (int)(wv % half);
   if (px >= cols) return;
   const long long e = (long long)py * cols + px;
   float dep = depth[e];
   if (dep <= 0) return;
   const int n = pvlm_mvs::num_texels(half_window, step);
-  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)rows * half, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
+  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)band_rows * half, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
   pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
   if (!P.inside || P.sq0 <= 1e-6) return;                                 // patch.sq0 <= 1e-6 (:1116-1117)
   float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
@@ -341,6 +341,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WA
   const int pdx[4] = {-1, 0, 1, 0}, pdy[4] = {0, -1, 0, 1};
   pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 4, pdx, pdy);
   depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c;
+}
+// ... and the scoring pass (InitConfMap, k_mvs_conf) in the same form: every pixel of the band, one ScorePixel each
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WAVES, 4))) void k_mvs_conf_lane(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb,
+    float* __restrict__ depth, float* __restrict__ normal, float* __restrict__ conf, float* __restrict__ wtab, int row0, int band_rows) {
+  extern __shared__ float lane_tab[];
+  const long long wv = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (wv >= (long long)band_rows * cols) return;
+  const long long e = (long long)row0 * cols + wv;
+  const float dep = depth[e];
+  if (dep <= 0) return;                                                   // InitConfMap :594-595
+  const int py = (int)(e / cols), px = (int)(e % cols);
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)band_rows * cols, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
+  pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
+  float c = -1.f;
+  if (P.inside && P.sq0 > 0) {                                            // :602 tests sq0 > 0 only
+    const float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+    pvlm_mvs::ColumnScorer<pvlm_mvs_neighbours> scorer{{}, {}, rows, cols, half_window, step, n, px, py, unit, ref_gray, &nb, P};
+    c = scorer(nrm3, dep, nullptr, 0);
+  }
+  conf[e] = c;
+  if (c <= -1) { depth[e] = 0; normal[3 * e] = 0; normal[3 * e + 1] = 0; normal[3 * e + 2] = 0; }
 }
 
 // Sequential sweep (PropagateSequential :1057-1097, the strategy config/Room.txt and config/Floor.txt select: propagate_strategy = 2):
@@ -488,9 +511,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
 }
 
 // launch helpers: M = 1 for windows of at most 64 texels (one texel per lane), M = PVLM_MVS_MAXM otherwise
+static bool mvs_lane_form(int n_tex);
+static void launch_mvs_conf_lane(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
+                                 const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, float* wtab);
 static void launch_mvs_conf(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
-                            const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf) {
+                            const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, float* wtab) {
   const size_t npix = (size_t)rows * cols;
+  if (wtab && pvlm_mvs::num_texels(half_window, step) <= 64) { launch_mvs_conf_lane(s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, wtab); return; }
   const dim3 grid((unsigned)((npix + 3) / 4)), block(256);
   if (pvlm_mvs::num_texels(half_window, step) <= 64) hipLaunchKernelGGL(k_mvs_conf<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf);
   else hipLaunchKernelGGL(k_mvs_conf<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf);
@@ -502,18 +529,40 @@ static bool mvs_lane_form(int n_tex) {
   static const bool off = getenv("PVLM_MVS_LANE") && atoi(getenv("PVLM_MVS_LANE")) == 0;
   return !off && n_tex <= 64;
 }
-static size_t mvs_lane_table_floats(int rows, int cols, int half_window, int step) {
+// The weight table serves a BAND of image rows at a time (one launch per band, in stream order), so that its size does not grow with
+// the image: at most PVLM_MVS_LANE_TABLE_MB (128) — the whole 1440 x 720 pass in one band, 13 bands per pass at 5760 x 2880.
+struct LaneBands { int band_rows; size_t floats; };
+static LaneBands mvs_lane_bands(int rows, int per_row_pixels, int half_window, int step) {
   const int n_tex = pvlm_mvs::num_texels(half_window, step);
-  return mvs_lane_form(n_tex) ? (size_t)n_tex * (size_t)rows * (size_t)((cols + 1) / 2) : 0;
+  if (!mvs_lane_form(n_tex)) return {0, 0};
+  static const size_t cap_mb = getenv("PVLM_MVS_LANE_TABLE_MB") ? (size_t)std::max(1, atoi(getenv("PVLM_MVS_LANE_TABLE_MB"))) : 128;
+  const size_t per_row = (size_t)n_tex * per_row_pixels;                  // floats per image row
+  const int band = (int)std::max<size_t>(1, std::min<size_t>((size_t)rows, (cap_mb << 18) / std::max<size_t>(per_row, 1)));
+  return {band, per_row * band};
+}
+static void launch_mvs_conf_lane(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
+                                 const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, float* wtab) {
+  const int n_tex = pvlm_mvs::num_texels(half_window, step);
+  const int band = mvs_lane_bands(rows, cols, half_window, step).band_rows;
+  for (int row0 = 0; row0 < rows; row0 += band) {
+    const int br = std::min(band, rows - row0);
+    hipLaunchKernelGGL(k_mvs_conf_lane, dim3((unsigned)(((size_t)br * cols + 63) / 64)), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step, img, unit,
+                       nb, depth, normal, conf, wtab, row0, br);
+  }
 }
 static void launch_mvs_propagate(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
                                  const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, const unsigned char* depth_constant, float min_depth,
                                  float max_depth, unsigned long long pass_seed, int offset, float* wtab) {
-  const size_t waves = (size_t)rows * (size_t)((cols + 1) / 2);
+  const int half = (cols + 1) / 2;
+  const size_t waves = (size_t)rows * (size_t)half;
   const int n_tex = pvlm_mvs::num_texels(half_window, step);
   if (wtab && n_tex <= 64) {
-    hipLaunchKernelGGL(k_mvs_propagate_lane, dim3((unsigned)((waves + 63) / 64)), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step, img, unit, nb,
-                       depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset, wtab);
+    const int band = mvs_lane_bands(rows, half, half_window, step).band_rows;
+    for (int row0 = 0; row0 < rows; row0 += band) {                       // a colour's pixels do not read each other: the bands are independent
+      const int br = std::min(band, rows - row0);
+      hipLaunchKernelGGL(k_mvs_propagate_lane, dim3((unsigned)(((size_t)br * half + 63) / 64)), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step,
+                         img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset, wtab, row0, br);
+    }
     return;
   }
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
@@ -792,8 +841,14 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_unit);
       if (max_iter < 0) {
-        pvlm_prof_scope prof(ctx, 1);   // timed with the "materialise" slot of pvlm_profile_* (bench / tools)
-        launch_mvs_conf(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf);
+        float* d_wtab = nullptr;
+        const size_t wtab_floats = mvs_lane_bands(rows, cols, half_window, step).floats;
+        if (wtab_floats && pvlm_i_alloc(ctx, &d_wtab, wtab_floats)) d_wtab = nullptr;
+        {
+          pvlm_prof_scope prof(ctx, 1);   // timed with the "materialise" slot of pvlm_profile_* (bench / tools)
+          launch_mvs_conf(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf, d_wtab);
+        }
+        pvlm_i_free(ctx, d_wtab);
       } else if (strategy == 2) {
         for (int iter = 0; iter < max_iter; ++iter) {
           pvlm_prof_scope prof(ctx, 1);                  // one profile interval per iteration (rows + cols - 1 launches)
@@ -802,8 +857,8 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
         }
         hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (long long)npix, d_const, conf_threshold, d_depth, d_normal, d_conf);
       } else {
-        float* d_wtab = nullptr;                       // patch weights of the thread-per-pixel form, [texel][pixel of the colour]
-        const size_t wtab_floats = mvs_lane_table_floats(rows, cols, half_window, step);
+        float* d_wtab = nullptr;                       // patch weights of the thread-per-pixel form, [texel][pixel of the colour in a band of rows]
+        const size_t wtab_floats = mvs_lane_bands(rows, (cols + 1) / 2, half_window, step).floats;
         if (wtab_floats && pvlm_i_alloc(ctx, &d_wtab, wtab_floats)) d_wtab = nullptr;    // no room: the wave-per-pixel form needs none
         for (int iter = 0; iter < max_iter; ++iter)
           for (int offset = 0; offset <= 1; ++offset) {
@@ -1195,8 +1250,14 @@ static pvlm_status views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int
   unsigned char* d_const = depth_constant ? v->d_const : nullptr;
   if (e == hipSuccess) {
     if (max_iter < 0) {
-      pvlm_prof_scope prof(ctx, 1);
-      launch_mvs_conf(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o);
+      float* d_wtab = nullptr;
+      const size_t wtab_floats = mvs_lane_bands(v->rows, v->cols, half_window, step).floats;
+      if (wtab_floats && pvlm_i_alloc(ctx, &d_wtab, wtab_floats)) d_wtab = nullptr;
+      {
+        pvlm_prof_scope prof(ctx, 1);
+        launch_mvs_conf(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o, d_wtab);
+      }
+      pvlm_i_free(ctx, d_wtab);
     } else {
       if (strategy == 2) {
         for (int iter = 0; iter < max_iter; ++iter) {
@@ -1206,7 +1267,7 @@ static pvlm_status views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int
         }
       } else {
         float* d_wtab = nullptr;
-        const size_t wtab_floats = mvs_lane_table_floats(v->rows, v->cols, half_window, step);
+        const size_t wtab_floats = mvs_lane_bands(v->rows, (v->cols + 1) / 2, half_window, step).floats;
         if (wtab_floats && pvlm_i_alloc(ctx, &d_wtab, wtab_floats)) d_wtab = nullptr;
         for (int iter = 0; iter < max_iter; ++iter)
           for (int offset = 0; offset <= 1; ++offset) {
