@@ -510,6 +510,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
 
+// MEASURED VARIANT, not in the default library (-DPVLM_MEASURED_VARIANTS=1, used from PVLM_MVS_LANE_BATCH_MIN pixels per diagonal):
+// the anti-diagonal of many views with one pixel per THREAD (see k_mvs_propagate_lane), workgroup = 64 pixels of one job's diagonal.
+// Bit-identical (tests/test_mvs_gpu.py with PVLM_MVS_LANE_BATCH_MIN=1) and NOT faster at any batch size measured, 1440 x 720 x 4
+// neighbours, ms per view and iteration (tools/mvs_batch_bench.py, profiles/r3_mvs_lane_ab.txt): one wave per pixel 37.1 / 27.8 / 26.1 /
+// 25.4 / 24.6 for 8 / 32 / 64 / 128 / 320 views; thread per pixel on the long diagonals 43.2 (64 views), 30.6 (128), 26.1 (320).  Why the
+// colour pass gains 1.65x and this does not: a thread runs the whole ~400 k-instruction program of its pixel (1.6 ms alone on a SIMD),
+// and a diagonal of V views is only V x 720 / 64 such waves per launch — 3 840 for 320 views against 3 072 resident slots: one and a
+// quarter rounds, the second almost empty; the colour pass launches 8 100.  It would take > 500 resident views to fill two rounds.
+#if PVLM_MEASURED_VARIANTS
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WAVES, 4))) void k_mvs_propagate_diag_batch_lane(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ gray_base, const float* __restrict__ unit, const pvlm_mvs_job* __restrict__ jobs,
+    float* depth_base, float* normal_base, float* conf_base, float min_depth, float max_depth, int iter, int diag, int groups_per_job, float* __restrict__ wtab) {
+  extern __shared__ float lane_tab[];
+  const int job = blockIdx.x / groups_per_job, w = (blockIdx.x % groups_per_job) * 64 + threadIdx.x;
+  const pvlm_mvs_job& J = jobs[job];
+  const int backward = iter & 1;
+  const int r0 = max(0, diag - (cols - 1)), r1 = min(rows - 1, diag);
+  const int py = r0 + w;
+  if (py > r1) return;
+  const int px = diag - py;
+  const long long e = (long long)py * cols + px;
+  float* depth = depth_base + J.off; float* normal = normal_base + 3 * J.off; float* conf = conf_base + J.off;
+  float dep = depth[e];
+  if (dep <= 0) return;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  const unsigned char* ref_gray = gray_base + J.off;
+  pvlm_mvs::ColumnPatch P{wtab + (size_t)blockIdx.x * 64 + threadIdx.x, (size_t)gridDim.x * 64, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
+  pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
+  if (!P.inside || P.sq0 <= 0) return;                                    // patch.sq0 <= 0 (:1069, :1087)
+  float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+  float c = conf[e];
+  pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, J.dconst, min_depth, max_depth};
+  pvlm_mvs::Rng rng{pvlm_mvs::pass_seed(J.seed, iter), (unsigned long long)e, 0u};
+  pvlm_mvs::ColumnScorer<pvlm_mvs_neighbours> scorer{{}, {}, rows, cols, half_window, step, n, px, py, unit, ref_gray, &J.nb, P};
+  const int sgn = backward ? 1 : -1;
+  const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
+  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
+  depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c;
+}
+#endif
+
 // launch helpers: M = 1 for windows of at most 64 texels (one texel per lane), M = PVLM_MVS_MAXM otherwise
 static bool mvs_lane_form(int n_tex);
 static void launch_mvs_conf_lane(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
@@ -1332,14 +1373,31 @@ pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_vie
       }
   }
   if (!st && mvs_up(ctx, d_jobs, jobs.data(), jobs.size() * sizeof(pvlm_mvs_job)) != hipSuccess) st = PVLM_ERR_HIP;
+  // Per anti-diagonal: one wave per pixel (k_mvs_propagate_diag_batch); the thread-per-pixel form of a diagonal is a measured variant (above).
+  const int n_tex = pvlm_mvs::num_texels(half_window, step);
+  float* d_wtab = nullptr;
+#if PVLM_MEASURED_VARIANTS
+  static const long long lane_min = getenv("PVLM_MVS_LANE_BATCH_MIN") ? atoll(getenv("PVLM_MVS_LANE_BATCH_MIN")) : (1ll << 40);
+  const int longest = std::min(v->rows, v->cols);
+  if (!st && mvs_lane_form(n_tex) && (long long)n_jobs * longest >= lane_min)
+    if (pvlm_i_alloc(ctx, &d_wtab, (size_t)n_tex * (size_t)n_jobs * (size_t)((longest + 63) / 64) * 64)) d_wtab = nullptr;
+#endif
   if (!st) {
     const int n_diag = v->rows + v->cols - 1;
-    const bool small = pvlm_mvs::num_texels(half_window, step) <= 64;
+    const bool small = n_tex <= 64;
     for (int iter = 0; iter < max_iter; ++iter) {
       pvlm_prof_scope prof(ctx, 1);
       for (int q = 0; q < n_diag; ++q) {
         const int d = (iter & 1) ? n_diag - 1 - q : q;
         const int len = std::min(v->rows - 1, d) - std::max(0, d - (v->cols - 1)) + 1;
+#if PVLM_MEASURED_VARIANTS
+        if (d_wtab && (long long)n_jobs * len >= lane_min) {
+          const int groups = (len + 63) / 64;
+          hipLaunchKernelGGL(k_mvs_propagate_diag_batch_lane, dim3((unsigned)(groups * n_jobs)), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, v->rows, v->cols, half_window,
+                             step, v->d_gray, v->d_unit, d_jobs, v->d_depth, v->d_normal, v->d_conf, min_depth, max_depth, iter, d, groups, d_wtab);
+          continue;
+        }
+#endif
         const dim3 grid((unsigned)((len + 3) / 4), (unsigned)n_jobs), block(256);
         if (small)
           hipLaunchKernelGGL(k_mvs_propagate_diag_batch<1>, grid, block, 0, s, v->rows, v->cols, half_window, step, v->d_gray, v->d_unit, d_jobs, v->d_depth, v->d_normal,
@@ -1359,7 +1417,7 @@ pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_vie
   }
   // the job table and the depth_constant copies go back to the pool in stream order; the staged uploads must have left the arena
   if (mvs_sync(ctx) != hipSuccess && !st) st = PVLM_ERR_HIP;
-  pvlm_i_free(ctx, d_jobs); pvlm_i_free(ctx, d_cb);
+  pvlm_i_free(ctx, d_jobs); pvlm_i_free(ctx, d_cb); pvlm_i_free(ctx, d_wtab);
   return st;
 }
 
