@@ -799,6 +799,9 @@ struct ColumnScorer : SerialMath, SerialFactors {
       }
       if (!ok) continue;
       float sq1 = 0.f, sq01 = 0.f;                                                    // two sums, each in index order (:830-831, :834-835)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 7                                                                      // the three loads of seven texels in flight together
+#endif
       for (int k = 0; k < n; ++k) {
         const float w = P.w[k * ws], t = P.t1[k * ts] - sum;
         sq1 += t * t * w;
