@@ -722,15 +722,16 @@ def mvs_block(ctx, pv):
     """BASELINE.json config 5: the panoramic PatchMatch kernels on views RESIDENT in HBM (pvlm_mvs_views_*), at the reference's
     Room size (5.7K at scale -2 = 1440 x 720, config/Room.txt:87) and at the full 5.7K size.  Scene: a textured sphere of
     radius 3 m seen from three camera centres 0.2 m apart (every window projects into every neighbour).  K11 = scoring pass
-    (InitConfMap), K13 = one checkerboard PatchMatch iteration (two colour passes), K13s = one iteration of the sequential sweep
-    the Room / Floor configs select (one launch per anti-diagonal), K12 = FilterDepthImageRefine.
+    (InitConfMap) and K13 = one checkerboard PatchMatch iteration (two colour passes), both with one pixel per thread since round 3;
+    K13s = one iteration of the sequential sweep the Room / Floor configs select (one launch per anti-diagonal, one wave per pixel),
+    K12 = FilterDepthImageRefine.
     The NCC sums run in the reference's sequential order and the kernels are VALU-bound, so their roof is instruction
     issue, not HBM: the algorithmic HBM bytes (29 B per pixel and view touched) are reported next to the time."""
     out = {}
     for rows, cols in ((720, 1440), (2880, 5760)):
         out["%dx%d" % (cols, rows)] = mvs_one_size(ctx, rows, cols)
     out["bound"] = "VALU: the kernels' roof is instruction issue, the HBM fraction is reported for completeness"
-    # SQ counters of the same kernels (tools/prof_r2_final.sh -> profiles/r2_pmc_mvs.json, separate --pmc pass of
+    # SQ counters of the same kernels (tools/prof_r3_final.sh -> profiles/r3_pmc_mvs.json, separate --pmc pass of
     # tools/mvs_bench.py): wave VALU instructions x 4 cycles / (1024 SIMDs x kernel time) = a lower bound of the VALU pipes' load
     try:
         import glob

@@ -26,6 +26,14 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_tra
 grep '^{' $O/bench_under_rocprof.log | tail -1 > $O/r3_bench_under_rocprof.json
 cd $R && python tools/trace_groups.py $(find $O/bench_trace -name "*kernel_trace.csv" | head -1) $O/r3_kernel_groups_default.csv > /dev/null
 cp $(find $O/bench_trace -name "*kernel_stats.csv" | head -1) $O/r3_kernel_stats_default.csv
+# MVS: the bench tool + SQ counters of the image-space kernels (thread-per-pixel colour pass / scoring pass, wave-per-pixel diagonals)
+timeout 600 python tools/mvs_bench.py 2> $O/mvs_bench.err | tail -1 > $O/r3_mvs_bench.json
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/mvs_trace -- python $R/tools/mvs_bench.py > $O/mvs_trace.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $O/mvs_pmc -- python $R/tools/mvs_bench.py > $O/mvs_pmc.log 2>&1
+cd $R && python tools/pmc_kernels.py $O/r3_pmc_mvs.json '{"k_mvs_conf": 1036800, "k_mvs_propagate_lane": 518400, "k_mvs_propagate<": 518400}' $O/mvs_trace $O/mvs_pmc k_mvs_conf k_mvs_propagate k_mvs_refine k_mvs_project > /dev/null
+cp $O/r3_pmc_mvs.json $R/profiles/r3_pmc_mvs.json
+find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 python tools/room_like_odometry.py --scans 454 --iters 3 --lines 1 --repeat 2 > $O/r3_room_like_lines454.txt 2>&1
 python tools/room_like_joint.py --frames 454 --points 150000 > $O/r3_room_like_joint454.txt 2>&1
 python tools/floor_like_odometry.py --scans 1593 --ranks 2,8 --iters 2 > $O/r3_floor_like_1593.txt 2>&1
