@@ -551,6 +551,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WA
 }
 #endif
 
+// The anti-diagonal of many views with FOUR threads per pixel, one neighbour image each (pvlm_mvs::QuadScorer): a workgroup is 64 pixels of
+// one job's diagonal.  Between the wave per pixel (every uniform value computed 64 times, 49 of 64 lanes busy, LDS strip walks for the
+// ordered sums) and the thread per pixel (a 400 k-instruction program per thread: too few, too long waves on a diagonal — the measured
+// variant above) — a quarter of that program per thread, four times the waves, the per-image NCC sums still a register add per texel.
+// Chosen per diagonal by launch threshold (pvlm_mvs_views_estimate_sequential_batch); same maps as the other forms, bit for bit.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WAVES, 4))) void k_mvs_propagate_diag_batch_quad(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ gray_base, const float* __restrict__ unit, const pvlm_mvs_job* __restrict__ jobs,
+    float* depth_base, float* normal_base, float* conf_base, float min_depth, float max_depth, int iter, int diag, int groups_per_job, float* __restrict__ wtab) {
+  extern __shared__ float lane_tab[];                                      // [n][256]: one texel column per thread
+  const int job = blockIdx.x / groups_per_job, w = (blockIdx.x % groups_per_job) * 64 + (threadIdx.x >> 2);
+  const pvlm_mvs_job& J = jobs[job];
+  const int backward = iter & 1;
+  const int r0 = max(0, diag - (cols - 1)), r1 = min(rows - 1, diag);
+  const int py = r0 + w;
+  if (py > r1) return;                                                    // whole quads leave together: a pixel's four threads take every branch alike
+  const int px = diag - py;
+  const long long e = (long long)py * cols + px;
+  float* depth = depth_base + J.off; float* normal = normal_base + 3 * J.off; float* conf = conf_base + J.off;
+  float dep = depth[e];
+  if (dep <= 0) return;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  const unsigned char* ref_gray = gray_base + J.off;
+  // the pixel's weight column: its four threads compute and store the same values
+  pvlm_mvs::ColumnPatch P{wtab + (size_t)blockIdx.x * 64 + (threadIdx.x >> 2), (size_t)gridDim.x * 64, lane_tab + threadIdx.x, 256, 0.f, 0.f, false};
+  pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
+  if (!P.inside || P.sq0 <= 0) return;                                    // patch.sq0 <= 0 (:1069, :1087)
+  float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+  float c = conf[e];
+  pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, J.dconst, min_depth, max_depth};
+  pvlm_mvs::Rng rng{pvlm_mvs::pass_seed(J.seed, iter), (unsigned long long)e, 0u};
+  pvlm_mvs::QuadScorer<pvlm_mvs_neighbours> scorer{{{}, {}, rows, cols, half_window, step, n, px, py, unit, ref_gray, &J.nb, P}};
+  const int sgn = backward ? 1 : -1;
+  const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
+  pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
+  if ((threadIdx.x & 3) == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+}
+
 // launch helpers: M = 1 for windows of at most 64 texels (one texel per lane), M = PVLM_MVS_MAXM otherwise
 static bool mvs_lane_form(int n_tex);
 static void launch_mvs_conf_lane(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
@@ -1376,6 +1413,12 @@ pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_vie
   // Per anti-diagonal: one wave per pixel (k_mvs_propagate_diag_batch); the thread-per-pixel form of a diagonal is a measured variant (above).
   const int n_tex = pvlm_mvs::num_texels(half_window, step);
   float* d_wtab = nullptr;
+  // four threads per pixel from PVLM_MVS_QUAD_MIN pixels per diagonal over all jobs (0 = never); below that, one wave per pixel
+  static const long long quad_min = getenv("PVLM_MVS_QUAD_MIN") ? atoll(getenv("PVLM_MVS_QUAD_MIN")) : 16384;
+  const int longest_diag = std::min(v->rows, v->cols);
+  float* d_qtab = nullptr;
+  if (!st && quad_min > 0 && mvs_lane_form(n_tex) && (long long)n_jobs * longest_diag >= quad_min)
+    if (pvlm_i_alloc(ctx, &d_qtab, (size_t)n_tex * (size_t)n_jobs * (size_t)((longest_diag + 63) / 64) * 64)) d_qtab = nullptr;
 #if PVLM_MEASURED_VARIANTS
   static const long long lane_min = getenv("PVLM_MVS_LANE_BATCH_MIN") ? atoll(getenv("PVLM_MVS_LANE_BATCH_MIN")) : (1ll << 40);
   const int longest = std::min(v->rows, v->cols);
@@ -1390,6 +1433,12 @@ pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_vie
       for (int q = 0; q < n_diag; ++q) {
         const int d = (iter & 1) ? n_diag - 1 - q : q;
         const int len = std::min(v->rows - 1, d) - std::max(0, d - (v->cols - 1)) + 1;
+        if (d_qtab && (long long)n_jobs * len >= quad_min) {
+          const int groups = (len + 63) / 64;
+          hipLaunchKernelGGL(k_mvs_propagate_diag_batch_quad, dim3((unsigned)(groups * n_jobs)), dim3(256), (size_t)n_tex * 256 * sizeof(float), s, v->rows, v->cols, half_window,
+                             step, v->d_gray, v->d_unit, d_jobs, v->d_depth, v->d_normal, v->d_conf, min_depth, max_depth, iter, d, groups, d_qtab);
+          continue;
+        }
 #if PVLM_MEASURED_VARIANTS
         if (d_wtab && (long long)n_jobs * len >= lane_min) {
           const int groups = (len + 63) / 64;
@@ -1417,7 +1466,7 @@ pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_vie
   }
   // the job table and the depth_constant copies go back to the pool in stream order; the staged uploads must have left the arena
   if (mvs_sync(ctx) != hipSuccess && !st) st = PVLM_ERR_HIP;
-  pvlm_i_free(ctx, d_jobs); pvlm_i_free(ctx, d_cb); pvlm_i_free(ctx, d_wtab);
+  pvlm_i_free(ctx, d_jobs); pvlm_i_free(ctx, d_cb); pvlm_i_free(ctx, d_wtab); pvlm_i_free(ctx, d_qtab);
   return st;
 }
 

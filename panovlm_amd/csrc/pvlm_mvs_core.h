@@ -759,60 +759,64 @@ template <class Views>
 struct ColumnScorer : SerialMath, SerialFactors {
   int rows, cols, half_window, step, n, px, py;
   const float* unit; const unsigned char* ref_gray; const Views* nb; ColumnPatch P;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PVLM_MVS_NOINLINE_SCORER)
-  __attribute__((noinline))          // process_pixel scores at three places: one copy of the 49-texel loops, not three
+  // the body of ScorePixel's loop for neighbour image b: false = the image does not count (`goto next_image`, `if (nrm <= 0) continue`)
+  PVLM_HD bool score_view(int b, const float* nr, float d, const float* X0, const float* factors, int n_close, float* out) const {
+    const size_t ws = P.w_stride; const int ts = P.t1_stride;
+    float H[9];
+    homography(nb->R[b], nb->t[b], nr, d, H);
+    const unsigned char* gray = nb->gray[b];
+    // software pipeline over the window: the ray of texel k + 2, the taps of texel k + 1 and the weight of texel k + 1 are loaded
+    // while texel k is interpolated — one thread has nothing else to hide its load latency with
+    float uv[3];
+    { const float* r = texel_ray(unit, cols, px, py, half_window, step, 0); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
+    TexelTap cur = texel_tap(uv, rows, cols, H);
+    TexelBytes cb = tap_bytes(gray, cols, cur);
+    float wk = P.w[0];
+    if (n > 1) { const float* r = texel_ray(unit, cols, px, py, half_window, step, 1); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
+    bool ok = true;
+    float sum = 0.f;
+    for (int k = 0; k < n; ++k) {
+      TexelTap nxt = cur; TexelBytes nbts = cb; float wn = wk;
+      if (k + 1 < n) {
+        nxt = texel_tap(uv, rows, cols, H);
+        nbts = tap_bytes(gray, cols, nxt);
+        wn = P.w[(size_t)(k + 1) * ws];
+        if (k + 2 < n) { const float* r = texel_ray(unit, cols, px, py, half_window, step, k + 2); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
+      }
+      ok = ok && cur.ok;                                                              // a texel outside the neighbour image drops the image (`goto next_image`)
+      const float v = tap_value(cur, cb);
+      P.t1[k * ts] = v;
+      sum += v * wk;                                                                  // :826-827
+      cur = nxt; cb = nbts; wk = wn;
+    }
+    if (!ok) return false;
+    float sq1 = 0.f, sq01 = 0.f;                                                      // two sums, each in index order (:830-831, :834-835)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 7                                                                      // the three loads of seven texels in flight together
 #endif
+    for (int k = 0; k < n; ++k) {
+      const float w = P.w[k * ws], t = P.t1[k * ts] - sum;
+      sq1 += t * t * w;
+      sq01 += (ref_texel(ref_gray, cols, px, py, half_window, step, k) - P.mean) * w * t;
+    }
+    const float nrm = P.sq0 * sq1;
+    if (nrm <= 0.f) return false;
+    float score = sq01 / sqrtf(nrm);
+    score = fminf(fmaxf(score, -1.f), 1.f);
+    score = smooth_score(score, factors, n_close);
+    if (nb->geometric) score = geometric_adjust(score, rows, cols, X0, nb->R[b], nb->t[b], nb->depth[b]);
+    *out = score;
+    return true;
+  }
   PVLM_HD float operator()(const float* nr, float dep, const float* factors, int n_close) const {
     const float* u0 = unit + 3 * ((size_t)py * cols + px);
     const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
     const float d = X0[0] * nr[0] + X0[1] * nr[1] + X0[2] * nr[2];
     if (d > 0) return -1.f;
-    const size_t ws = P.w_stride; const int ts = P.t1_stride;
     float best1 = 0.f, best2 = 0.f; int count = 0;
     for (int b = 0; b < nb->n; ++b) {
-      float H[9];
-      homography(nb->R[b], nb->t[b], nr, d, H);
-      const unsigned char* gray = nb->gray[b];
-      // software pipeline over the window: the ray of texel k + 2, the taps of texel k + 1 and the weight of texel k + 1 are loaded
-      // while texel k is interpolated — one thread has nothing else to hide its load latency with
-      float uv[3];
-      { const float* r = texel_ray(unit, cols, px, py, half_window, step, 0); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
-      TexelTap cur = texel_tap(uv, rows, cols, H);
-      TexelBytes cb = tap_bytes(gray, cols, cur);
-      float wk = P.w[0];
-      if (n > 1) { const float* r = texel_ray(unit, cols, px, py, half_window, step, 1); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
-      bool ok = true;
-      float sum = 0.f;
-      for (int k = 0; k < n; ++k) {
-        TexelTap nxt = cur; TexelBytes nbts = cb; float wn = wk;
-        if (k + 1 < n) {
-          nxt = texel_tap(uv, rows, cols, H);
-          nbts = tap_bytes(gray, cols, nxt);
-          wn = P.w[(size_t)(k + 1) * ws];
-          if (k + 2 < n) { const float* r = texel_ray(unit, cols, px, py, half_window, step, k + 2); uv[0] = r[0]; uv[1] = r[1]; uv[2] = r[2]; }
-        }
-        ok = ok && cur.ok;                                                            // a texel outside the neighbour image drops the image (`goto next_image`)
-        const float v = tap_value(cur, cb);
-        P.t1[k * ts] = v;
-        sum += v * wk;                                                                // :826-827
-        cur = nxt; cb = nbts; wk = wn;
-      }
-      if (!ok) continue;
-      float sq1 = 0.f, sq01 = 0.f;                                                    // two sums, each in index order (:830-831, :834-835)
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 7                                                                      // the three loads of seven texels in flight together
-#endif
-      for (int k = 0; k < n; ++k) {
-        const float w = P.w[k * ws], t = P.t1[k * ts] - sum;
-        sq1 += t * t * w;
-        sq01 += (ref_texel(ref_gray, cols, px, py, half_window, step, k) - P.mean) * w * t;
-      }
-      const float nrm = P.sq0 * sq1;
-      if (nrm <= 0.f) continue;
-      float score = sq01 / sqrtf(nrm);
-      score = fminf(fmaxf(score, -1.f), 1.f);
-      score = smooth_score(score, factors, n_close);
-      if (nb->geometric) score = geometric_adjust(score, rows, cols, X0, nb->R[b], nb->t[b], nb->depth[b]);
+      float score;
+      if (!score_view(b, nr, d, X0, factors, n_close, &score)) continue;
       if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
       ++count;
     }
@@ -821,5 +825,37 @@ struct ColumnScorer : SerialMath, SerialFactors {
     return -1.f;
   }
 };
+
+#if defined(__HIPCC__)
+// Four threads per pixel, one neighbour image each (image b in thread b mod 4 of the pixel's quad): the per-image bodies run side by
+// side and their outcomes are visited in image order, as the reference's loop visits them — the same best-two average in all four
+// threads.  Everything else of process_pixel is done by the four threads alike.  Device only (quad shuffles).
+template <class Views>
+struct QuadScorer : ColumnScorer<Views> {
+  __device__ float operator()(const float* nr, float dep, const float* factors, int n_close) const {
+    const float* u0 = this->unit + 3 * ((size_t)this->py * this->cols + this->px);
+    const float X0[3] = {u0[0] * dep, u0[1] * dep, u0[2] * dep};
+    const float d = X0[0] * nr[0] + X0[1] * nr[1] + X0[2] * nr[2];
+    if (d > 0) return -1.f;
+    const int lane = (int)(threadIdx.x & 63), q = lane & 3, base = lane & ~3;
+    float best1 = 0.f, best2 = 0.f; int count = 0;
+    for (int b0 = 0; b0 < this->nb->n; b0 += 4) {
+      float mine = 0.f; int valid = 0;
+      if (b0 + q < this->nb->n) valid = this->score_view(b0 + q, nr, d, X0, factors, n_close, &mine) ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vj = __shfl(valid, base + j, 64);
+        const float score = __shfl(mine, base + j, 64);
+        if (!vj) continue;
+        if (count == 0 || score > best1) { best2 = best1; best1 = score; } else if (count == 1 || score > best2) best2 = score;
+        ++count;
+      }
+    }
+    if (count == 1) return best1;
+    if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; return avg / 2; }
+    return -1.f;
+  }
+};
+#endif
 
 }  // namespace pvlm_mvs

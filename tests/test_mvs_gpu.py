@@ -3,6 +3,9 @@ mvs/MVS.cpp:586-680, :774-923; checkerboard PatchMatch sweep; depth fusion filte
 C ABI.  BIT FOR BIT: the kernels add the NCC sums in the reference's sequential order (wave_seq_sum) and both sides use
 the correctly rounded float exp / sin / cos / acos, so scores, validity decisions, tie-breaks between hypotheses and the
 random perturbations drawn after them are identical."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -194,6 +197,19 @@ def test_sequential_sweep_matches_oracle(ctx, oracle):
     with pytest.raises(pv.PvlmError):
         V.estimate_sequential_batch([jobs[0], jobs[0]])            # the same reference twice in one batch
     V.close()
+
+
+def test_other_launch_forms_give_the_same_maps():
+    """The image-space kernels have several launch forms chosen by size: one pixel per thread (scoring pass, colour pass) or one wave
+    per pixel, and for a batched anti-diagonal one wave per pixel or four threads per pixel from PVLM_MVS_QUAD_MIN pixels per
+    diagonal.  The switches are read once per process, so the oracle comparisons of this file are re-run in child processes with
+    the non-default forms forced: every form must give the oracle's maps bit for bit."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    for env in ({"PVLM_MVS_QUAD_MIN": "1"}, {"PVLM_MVS_LANE": "0"}, {"PVLM_MVS_LANE_TABLE_MB": "4"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "sweep_matches_oracle or conf_map_matches_oracle or sequential", "-p", "no:cacheprovider"],
+                           env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, (env, r.stdout[-1500:])
 
 
 def test_resident_views_equal_the_per_call_entry_points(ctx, oracle):
