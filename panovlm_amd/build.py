@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on " + src)
         if verbose and out.strip():
             print(out)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
     subprocess.check_call(cmd)
     return LIB
 

@@ -10,10 +10,12 @@
 // the k-th distance is provably inside the searched block, or the shell radius exceeds
 // dist_threshold.  Results are therefore the EXACT k nearest neighbours (ties by index).
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "pvlm_internal.h"
 #include "pvlm_assoc_core.h"
@@ -329,19 +331,28 @@ struct CloudPlan {
   size_t o_xyz = 0, o_tag = 0, o_count = 0, o_keys = 0, o_start = 0, o_sorted = 0, s_cursor = 0, s_slot = 0;
 };
 
-static pvlm_status cloud_plan(pvlm_ctx* ctx, CloudPlan& c, int n, const float* xyz, const float* tag, bool grid) {
-  c.n = n; c.xyz = xyz; c.tag = tag; c.grid = grid && n > 0;
-  if (n <= 0) return PVLM_OK;
-  if (n > PVLM_MAX_CLOUD_POINTS) { PVLM_SET_ERR(ctx, "cloud of %d points exceeds the supported maximum of %d", n, PVLM_MAX_CLOUD_POINTS); return PVLM_ERR_ARG; }
-  // bounding box (and the finiteness check: a NaN never updates a min / max, so every coordinate is tested)
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+// bounding box of a cloud and its first non-finite point (a NaN never updates a min / max, so every coordinate is tested): the one pass
+// over the points that planning needs — taken for all clouds of a batch side by side (pvlm_scan_upload_batch), reported serially
+struct CloudBox { float mn[3], mx[3]; int bad_point; };
+static void cloud_box(int n, const float* xyz, CloudBox& b) {
+  for (int k = 0; k < 3; ++k) { b.mn[k] = FLT_MAX; b.mx[k] = -FLT_MAX; }
+  b.bad_point = -1;
   for (int i = 0; i < n; ++i)
     for (int k = 0; k < 3; ++k) {
       const float v = xyz[3 * i + k];
-      if (!std::isfinite(v)) { PVLM_SET_ERR(ctx, "cloud contains a non-finite coordinate (point %d)", i); return PVLM_ERR_ARG; }
-      if (v < mn[k]) mn[k] = v;
-      if (v > mx[k]) mx[k] = v;
+      if (!std::isfinite(v)) { b.bad_point = i; return; }
+      if (v < b.mn[k]) b.mn[k] = v;
+      if (v > b.mx[k]) b.mx[k] = v;
     }
+}
+static pvlm_status cloud_plan(pvlm_ctx* ctx, CloudPlan& c, int n, const float* xyz, const float* tag, bool grid, const CloudBox* box = nullptr) {
+  c.n = n; c.xyz = xyz; c.tag = tag; c.grid = grid && n > 0;
+  if (n <= 0) return PVLM_OK;
+  if (n > PVLM_MAX_CLOUD_POINTS) { PVLM_SET_ERR(ctx, "cloud of %d points exceeds the supported maximum of %d", n, PVLM_MAX_CLOUD_POINTS); return PVLM_ERR_ARG; }
+  CloudBox own;
+  if (!box) { cloud_box(n, xyz, own); box = &own; }
+  if (box->bad_point >= 0) { PVLM_SET_ERR(ctx, "cloud contains a non-finite coordinate (point %d)", box->bad_point); return PVLM_ERR_ARG; }
+  const float* mn = box->mn; const float* mx = box->mx;
   if (!c.grid) return PVLM_OK;
   // cell edge: surface-like clouds, aim at ~4 points per occupied cell
   float e[3];
@@ -444,6 +455,24 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
   std::vector<pvlm_scan*> scans((size_t)n_scans, nullptr);
   auto fail = [&](pvlm_status st) { for (pvlm_scan* s : scans) delete s; return st; };
   pvlm_status st = PVLM_OK;
+  // the pass over every point (bounding boxes, finiteness): scan-parallel for a batch (with the threaded staging copy below: 39 -> 25 ms per
+  // call for the 1593 scans of Floor)
+  std::vector<CloudBox> boxes((size_t)n_scans * 3);
+  {
+    auto box_of = [&](int k) {
+      const pvlm_scan_desc* d = &descs[k];
+      if (d->n_surf_flat > 0 && d->n_surf_flat <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_surf_flat, d->surf_flat_xyz, boxes[(size_t)k * 3]);
+      if (d->n_surf_less_flat > 0 && d->n_surf_less_flat <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_surf_less_flat, d->surf_less_flat_xyz, boxes[(size_t)k * 3 + 1]);
+      if (d->n_corner > 0 && d->n_corner <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_corner, d->corner_xyz, boxes[(size_t)k * 3 + 2]);
+    };
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)n_scans / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int k = next++; k < n_scans; k = next++) box_of(k); };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  }
   for (int k = 0; k < n_scans && !st; ++k) {
     const pvlm_scan_desc* d = &descs[k];
     pvlm_scan* s = new (std::nothrow) pvlm_scan();
@@ -453,9 +482,9 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
     std::memcpy(s->R_wl, d->R_wl, sizeof(s->R_wl));
     std::memcpy(s->t_wl, d->t_wl, sizeof(s->t_wl));
     ScanPlan& P = plan[(size_t)k];
-    st = cloud_plan(ctx, P.flat, d->n_surf_flat, d->surf_flat_xyz, d->surf_flat_tag, false);
-    if (!st) st = cloud_plan(ctx, P.less, d->n_surf_less_flat, d->surf_less_flat_xyz, d->surf_less_flat_tag, true);
-    if (!st) st = cloud_plan(ctx, P.corner, d->n_corner, d->corner_xyz, nullptr, true);
+    st = cloud_plan(ctx, P.flat, d->n_surf_flat, d->surf_flat_xyz, d->surf_flat_tag, false, &boxes[(size_t)k * 3]);
+    if (!st) st = cloud_plan(ctx, P.less, d->n_surf_less_flat, d->surf_less_flat_xyz, d->surf_less_flat_tag, true, &boxes[(size_t)k * 3 + 1]);
+    if (!st) st = cloud_plan(ctx, P.corner, d->n_corner, d->corner_xyz, nullptr, true, &boxes[(size_t)k * 3 + 2]);
     if (st) break;
     if (d->n_corner > 0) {
       if (d->p2s_offsets) {
@@ -585,9 +614,20 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
     const size_t hi = std::min(up_bytes, lo + ctx->up_bytes);
     if (lo > 0) e = hipStreamSynchronize(ctx->stream);            // the window is refilled: the previous copy must have left it
     while (first_seg < segs.size() && segs[first_seg].off + segs[first_seg].bytes <= lo) ++first_seg;
-    for (size_t q = first_seg; q < segs.size() && segs[q].off < hi; ++q) {
+    size_t last_seg = first_seg;
+    while (last_seg < segs.size() && segs[last_seg].off < hi) ++last_seg;
+    auto stage = [&](size_t q) {
       const size_t a = std::max(segs[q].off, lo), b = std::min(segs[q].off + segs[q].bytes, hi);
       if (b > a) std::memcpy(h + (a - lo), (const char*)segs[q].src + (a - segs[q].off), b - a);
+    };
+    {   // the segments land in disjoint ranges of the pinned window: copied side by side (one core moves ~10 GB/s, the window is up to 64 MB)
+      const size_t n_threads = (hi - lo) < ((size_t)8 << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)8, (last_seg - first_seg) / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+      std::atomic<size_t> next{first_seg};
+      auto work = [&]() { for (size_t q = next++; q < last_seg; q = next++) stage(q); };
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+      work();
+      for (std::thread& t : pool) t.join();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(d_slab + lo, h, hi - lo, hipMemcpyHostToDevice, ctx->stream);
   }

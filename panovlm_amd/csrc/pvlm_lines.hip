@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "pvlm_internal.h"
@@ -619,15 +620,23 @@ pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* co
   std::vector<pvlm_line_pair_desc> desc((size_t)n_pairs);
   std::vector<long long> work_off((size_t)n_pairs + 1, 0);
   std::vector<double> lines;
+  std::unordered_map<const pvlm_scan*, long long> line_off_of;       // a reference scan's world lines once per call, not once per pair
   long long nv = 0;
   for (int p = 0; p < n_pairs; ++p) {
     if (!ref[p] || !nei[p]) return PVLM_ERR_ARG;
     pvlm_line_pair_desc& d = desc[p];
     d.xyz = nei[p]->corner.d_xyz; d.p2s_off = nei[p]->d_p2s_off; d.p2s_ids = nei[p]->d_p2s_ids;
     d.n_pts = nei[p]->n_segments > 0 ? nei[p]->corner.n : 0; d.n_ref = ref[p]->n_segments;
-    d.line_off = (long long)lines.size() / 6; d.vote_off = nv; d.work_off = work_off[p];
-    lines.resize(lines.size() + (size_t)ref[p]->n_segments * 6);
-    world_lines(ref[p], lines.data() + (size_t)d.line_off * 6);
+    d.vote_off = nv; d.work_off = work_off[p];
+    if (votes) {                                                    // the sizing call needs no lines
+      auto it = line_off_of.find(ref[p]);
+      if (it == line_off_of.end()) {
+        it = line_off_of.emplace(ref[p], (long long)lines.size() / 6).first;
+        lines.resize(lines.size() + (size_t)ref[p]->n_segments * 6);
+        world_lines(ref[p], lines.data() + (size_t)it->second * 6);
+      }
+      d.line_off = it->second;
+    }
     vote_offsets[p] = nv;
     nv += (long long)nei[p]->n_segments * ref[p]->n_segments;
     work_off[p + 1] = work_off[p] + (long long)d.n_pts * d.n_ref;

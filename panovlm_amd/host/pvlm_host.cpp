@@ -286,7 +286,15 @@ void Velodyne::UploadBatch(const std::vector<const Velodyne*>& scans) {
   StageTimer stage_timer_("  (inside the stages below) scan upload: host SoA staging + pvlm_scan_upload");
   std::vector<ScanStaging> st(todo.size());
   std::vector<pvlm_scan_desc> descs(todo.size());
-  for (size_t k = 0; k < todo.size(); ++k) { st[k].Fill(*todo[k], todo[k]->R_wl_, todo[k]->t_wl_); descs[k] = st[k].d; }
+  {   // the flattening is per scan and independent: scan-parallel, like FindNeighbors
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, todo.size() / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t k = next++; k < todo.size(); k = next++) { st[k].Fill(*todo[k], todo[k]->R_wl_, todo[k]->t_wl_); descs[k] = st[k].d; } };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  }
   std::vector<pvlm_scan*> out(todo.size(), nullptr);
   Engine& e = Engine::Default();
   StageTimer stage_timer_abi_("  (inside the scan upload) pvlm_scan_upload_batch");
@@ -661,15 +669,22 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
   }
   StageTimer stage_timer_("  (inside) FindAssociations on the vote blocks (host)");
   std::map<const Velodyne*, std::vector<Vector6d>> world;      // TransformLines(segment_coeffs, pose): once per scan of the batch, not per pair
-  auto world_of = [&](const Velodyne& v) -> const std::vector<Vector6d>& {
-    auto it = world.find(&v);
-    if (it == world.end()) it = world.emplace(&v, TransformLines(v.segment_coeffs, v.GetPose())).first;
-    return it->second;
+  for (size_t j = 0; j < which.size(); ++j)
+    for (const Velodyne* v : {pairs[which[j]].first, pairs[which[j]].second})
+      if (!world.count(v)) world.emplace(v, TransformLines(v->segment_coeffs, v->GetPose()));
+  // the pairs are independent (read-only scans and vote blocks, one output slot each): pair-parallel
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, which.size() / 256 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t j = next++; j < which.size(); j = next++) {
+      const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
+      out[which[j]] = FindAssociationsOn(ref, nei, world.find(&ref)->second, world.find(&nei)->second, votes.data() + voff[j]);
+    }
   };
-  for (size_t j = 0; j < which.size(); ++j) {
-    const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
-    out[which[j]] = FindAssociationsOn(ref, nei, world_of(ref), world_of(nei), votes.data() + voff[j]);
-  }
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
   return out;
 }
 
@@ -869,22 +884,40 @@ bool LidarLineMatch::GenerateTracks() {
   // TrackBuilder(true).Build — util/Tracks.cpp:58-196 with its std::set / std::map containers replaced by sorted vectors and
   // dense tables: the same features in the same order (a set iterates in sorted order), the same unions in the same order
   StageTimer stage_timer_tb_("  (inside) TrackBuilder: union-find + filter + export (host)");
-  std::vector<Feature> i2f;
+  // Feature (scan, segment) -> index in the SORTED set of all features that occur (upstream: a std::set filled from every match, then
+  // numbered in iteration order).  A dense table over (scan, segment) gives the same numbering without sorting 2 x matches features and
+  // without a binary search per union: mark what occurs, number the marks in table order = (scan, segment) order.
+  std::vector<uint32_t> seg_base(lidars_.size() + 1, 0);
+  {
+    std::vector<uint32_t> seg_count(lidars_.size(), 0);
+    for (size_t s = 0; s < lidars_.size(); ++s) seg_count[s] = (uint32_t)lidars_[s].edge_segmented.size();
+    for (size_t i = 0; i < pairs.size(); i++)
+      for (const Feature& mth : fpairs[i]) {
+        seg_count[pairs[i].first] = std::max(seg_count[pairs[i].first], mth.first + 1);
+        seg_count[pairs[i].second] = std::max(seg_count[pairs[i].second], mth.second + 1);
+      }
+    for (size_t s = 0; s < lidars_.size(); ++s) seg_base[s + 1] = seg_base[s] + seg_count[s];
+  }
+  std::vector<uint32_t> rank(seg_base.back(), 0);
   for (size_t i = 0; i < pairs.size(); i++)
-    for (const Feature& mth : fpairs[i]) { i2f.push_back({(uint32_t)pairs[i].first, mth.first}); i2f.push_back({(uint32_t)pairs[i].second, mth.second}); }
-  std::sort(i2f.begin(), i2f.end()); i2f.erase(std::unique(i2f.begin(), i2f.end()), i2f.end());
-  auto f2i = [&](const Feature& f) { return (uint32_t)(std::lower_bound(i2f.begin(), i2f.end(), f) - i2f.begin()); };
+    for (const Feature& mth : fpairs[i]) { rank[seg_base[pairs[i].first] + mth.first] = 1; rank[seg_base[pairs[i].second] + mth.second] = 1; }
+  std::vector<Feature> i2f;
+  for (size_t sc = 0; sc < lidars_.size(); ++sc)
+    for (uint32_t cell = seg_base[sc]; cell < seg_base[sc + 1]; ++cell)
+      if (rank[cell]) { rank[cell] = (uint32_t)i2f.size(); i2f.push_back({(uint32_t)sc, cell - seg_base[sc]}); }
+  auto f2i = [&](const Feature& f) { return rank[seg_base[f.first] + f.second]; };
   UnionFind uf;
   uf.Init((unsigned)i2f.size());
   for (size_t i = 0; i < pairs.size(); i++)
     for (const Feature& mth : fpairs[i]) uf.Union(f2i({(uint32_t)pairs[i].first, mth.first}), f2i({(uint32_t)pairs[i].second, mth.second}));
   // Filter(min_track_length): a track must span at least min_track_length different scans
   {
-    std::vector<std::pair<uint32_t, uint32_t>> root_scan(i2f.size());
-    for (uint32_t i = 0; i < i2f.size(); i++) root_scan[i] = {uf.Find(i), i2f[i].first};
-    std::sort(root_scan.begin(), root_scan.end()); root_scan.erase(std::unique(root_scan.begin(), root_scan.end()), root_scan.end());
-    std::vector<uint32_t> scans_of(i2f.size(), 0);
-    for (const auto& rs : root_scan) scans_of[rs.first]++;
+    // distinct scans per root: the features come in scan order, so a root sees each of its scans in one run
+    std::vector<uint32_t> scans_of(i2f.size(), 0), last_scan(i2f.size(), std::numeric_limits<uint32_t>::max());
+    for (uint32_t i = 0; i < i2f.size(); i++) {
+      const uint32_t root = uf.Find(i);
+      if (last_scan[root] != i2f[i].first) { last_scan[root] = i2f[i].first; scans_of[root]++; }
+    }
     std::vector<char> bad(i2f.size(), 0);
     for (uint32_t r = 0; r < i2f.size(); r++) bad[r] = scans_of[r] > 0 && scans_of[r] < (uint32_t)min_track_length_;
     // upstream walks the parent array once, testing each entry's CURRENT value (a root already invalidated no longer matches)
