@@ -318,22 +318,6 @@ std::vector<std::vector<int>> FindNeighborsConsecutive(const std::vector<Velodyn
 
 std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars, const int neighbor_size) {
   StageTimer stage_timer_("  (inside) FindNeighbors (host)");
-  // The lists are a function of the scan centres (as floats), the two validity flags and neighbor_size — nothing else is read below.
-  // An outer iteration of EstimatePose asks for them twice with the same poses (GenerateTracks, then the residual adders): the last
-  // answer is kept with its exact inputs and handed out again when they compare equal.
-  struct Key { float c[3]; int flags; };
-  std::vector<Key> key(lidars.size());
-  for (size_t i = 0; i < lidars.size(); i++) {
-    const Vector3d& t = lidars[i].GetTranslation();
-    key[i] = Key{{float(t[0]), float(t[1]), float(t[2])}, (lidars[i].IsPoseValid() ? 1 : 0) | (lidars[i].valid ? 2 : 0)};
-  }
-  static std::mutex memo_mu;
-  static std::vector<Key> memo_key; static int memo_size = -1; static std::vector<std::vector<int>> memo_result;
-  {
-    std::lock_guard<std::mutex> lock(memo_mu);
-    if (memo_size == neighbor_size && memo_key.size() == key.size() && (key.empty() || std::memcmp(memo_key.data(), key.data(), key.size() * sizeof(Key)) == 0))
-      return memo_result;
-  }
   std::vector<std::vector<int>> neighbors_all;
   std::vector<std::array<float, 3>> center;
   std::vector<int> owner;
@@ -394,10 +378,6 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
   for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
   work();
   for (std::thread& t : pool) t.join();
-  {
-    std::lock_guard<std::mutex> lock(memo_mu);
-    memo_key.swap(key); memo_size = neighbor_size; memo_result = neighbors_all;
-  }
   return neighbors_all;
 }
 
