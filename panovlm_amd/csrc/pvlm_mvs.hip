@@ -1414,7 +1414,7 @@ pvlm_status pvlm_mvs_views_estimate_sequential_batch(pvlm_ctx* ctx, pvlm_mvs_vie
   const int n_tex = pvlm_mvs::num_texels(half_window, step);
   float* d_wtab = nullptr;
   // four threads per pixel from PVLM_MVS_QUAD_MIN pixels per diagonal over all jobs (0 = never); below that, one wave per pixel
-  static const long long quad_min = getenv("PVLM_MVS_QUAD_MIN") ? atoll(getenv("PVLM_MVS_QUAD_MIN")) : 16384;
+  static const long long quad_min = getenv("PVLM_MVS_QUAD_MIN") ? atoll(getenv("PVLM_MVS_QUAD_MIN")) : 32768;
   const int longest_diag = std::min(v->rows, v->cols);
   float* d_qtab = nullptr;
   if (!st && quad_min > 0 && mvs_lane_form(n_tex) && (long long)n_jobs * longest_diag >= quad_min)
