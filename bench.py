@@ -730,6 +730,10 @@ def mvs_block(ctx, pv):
     out = {}
     for rows, cols in ((720, 1440), (2880, 5760)):
         out["%dx%d" % (cols, rows)] = mvs_one_size(ctx, rows, cols)
+    try:
+        out["k13s_sequential_batch_1440x720"] = mvs_batch_point(ctx)
+    except Exception as e:                                   # e.g. a small pool reservation: the per-view numbers above stand on their own
+        out["k13s_sequential_batch_1440x720"] = {"error": str(e)[:200]}
     out["bound"] = "VALU: the kernels' roof is instruction issue, the HBM fraction is reported for completeness"
     # SQ counters of the same kernels (tools/prof_r3_final.sh -> profiles/r3_pmc_mvs.json, separate --pmc pass of
     # tools/mvs_bench.py): wave VALU instructions x 4 cycles / (1024 SIMDs x kernel time) = a lower bound of the VALU pipes' load
@@ -782,6 +786,33 @@ def mvs_one_size(ctx, rows, cols, k13_reps=2):
         res[name]["frac_of_hbm_peak"] = rows * cols * 29 * 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
     V.close()
     return res
+
+
+def mvs_batch_point(ctx, rows=720, cols=1440, views=64):
+    """The sweep the Room / Floor configs select (sequential), as a pipeline over many frames runs it: `views` resident reference views per
+    launch (pvlm_mvs_views_estimate_sequential_batch; upstream: one image per OpenMP thread), two neighbours each — ms per view and
+    iteration.  From 32 768 pixels per anti-diagonal the launch uses four threads per pixel, below that one wave per pixel."""
+    from panovlm_amd.api import MvsViews
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    lon = (2 * xx / cols - 1) * np.pi; lat = (0.5 - yy / rows) * np.pi
+    ray = np.stack([np.cos(lat) * np.sin(lon), -np.sin(lat), np.cos(lat) * np.cos(lon)], axis=-1).astype(np.float32)
+    gray = np.clip(128 + 50 * np.sin(40 * lon) * np.cos(37 * lat) + 40 * np.sin(91 * lat + 13 * lon), 0, 255).astype(np.uint8)
+    depth = np.full((rows, cols), 3.0, np.float32)
+    normal = (-ray).astype(np.float32)
+    V = MvsViews(ctx, rows, cols, views + 2)
+    for v in range(views + 2):
+        V.upload(v, gray=gray, depth=depth, normal=normal, conf=np.zeros((rows, cols), np.float32))
+    Rn = np.stack([np.eye(3, dtype=np.float32)] * 2); tn = np.array([[0.2, 0, 0], [-0.2, 0.01, 0.05]], np.float32)
+    jobs = [dict(ref=k, nei=[views, views + 1], R_nr=Rn, t_nr=tn, seed=3 + k) for k in range(views)]
+    for k in range(views):
+        V.estimate(k, [views, views + 1], Rn, tn, max_iter=-1)
+    ctx.synchronize()
+    ctx.timer_start()
+    V.estimate_sequential_batch(jobs, max_iter=1)
+    ms = ctx.timer_stop()
+    V.close()
+    return {"rows": rows, "cols": cols, "views_per_launch": views, "neighbours": 2, "ms_per_iteration": ms, "ms_per_view_and_iteration": ms / views,
+            "M_pixels_per_s": views * rows * cols / ms / 1e3}
 
 
 def panorama_block(ctx, pv, torch, dev, with_votes=True):
