@@ -7,6 +7,7 @@
 //   /root/reference/base/CostFunction.h:836-934  Point2Line_Angle
 //   /root/reference/base/CostFunction.h:350-425  Plane2Plane_Global
 //   /root/reference/base/CostFunction.h:433-507  PlaneIOUResidual
+//   /root/reference/base/CostFunction.h:294-348  Plane2Plane_Relative, :509-565 PlaneRelativeIOUResidual (calibration mode)
 // plus ceres::HuberLoss + the Ceres corrector ([recalled] Ceres 2.0.0 loss_function.cc,
 // corrector.cc; call sites util/Optimization.cpp:513-517,336-340).
 // "parity unpinned": the reference ships no tests for these; cross-checked here against an
@@ -197,6 +198,55 @@ struct PlaneIOUResidual {
   }
 };
 
+// Plane2Plane_Relative (base/CostFunction.h:294-348) and PlaneRelativeIOUResidual (:509-565): the calibration-mode functors of
+// CameraLidarOptimizer::Optimize(line_pairs, T_cl) (joint_optimization/CameraLidarOptimizer.cpp:32-87) — ONE pose (aa_cl, t_cl).
+struct Plane2Plane_Relative {
+  double plane_ref[3], point_a[3], point_b[3], weight;
+  void SetPlane(const double* p) {                                  // ctor: plane_ref.normalize() (:306)
+    const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    const double n = std::sqrt(n2);
+    for (int k = 0; k < 3; ++k) plane_ref[k] = n2 > 0.0 ? p[k] / n : p[k];
+  }
+  template <typename T>
+  bool operator()(const T* aa_cl, const T* t_cl, T* residual) const {
+    T pa0[3] = {T(point_a[0]), T(point_a[1]), T(point_a[2])}, pa[3];
+    AngleAxisRotatePoint(aa_cl, pa0, pa);
+    pa[0] += t_cl[0]; pa[1] += t_cl[1]; pa[2] += t_cl[2];
+    T pb0[3] = {T(point_b[0]), T(point_b[1]), T(point_b[2])}, pb[3];
+    AngleAxisRotatePoint(aa_cl, pb0, pb);
+    pb[0] += t_cl[0]; pb[1] += t_cl[1]; pb[2] += t_cl[2];
+    T a = pa[1] * pb[2] - pa[2] * pb[1];
+    T b = pa[2] * pb[0] - pa[0] * pb[2];
+    T c = pa[0] * pb[1] - pa[1] * pb[0];
+    T lidar_line_plane[3] = {a, b, c};
+    T img_plane_norm[3] = {T(plane_ref[0]), T(plane_ref[1]), T(plane_ref[2])};
+    residual[0] = T(weight) * PlaneAngle<T>(img_plane_norm, lidar_line_plane) * T(180.0) / T(M_PI);
+    return true;
+  }
+};
+
+struct PlaneRelativeIOUResidual {
+  double ref_plane[4], middle_neighbor[3], middle_ref[3], angle, weight;
+  void SetPlane(const double* p) {                                  // ctor: ref_plane = plane / |plane.xyz| (:523)
+    const double n = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    for (int k = 0; k < 4; ++k) ref_plane[k] = p[k] / n;
+  }
+  template <typename T>
+  bool operator()(const T* aa_cl, const T* t_cl, T* residual) const {
+    T pn[3] = {T(middle_neighbor[0]), T(middle_neighbor[1]), T(middle_neighbor[2])}, mt[3];
+    AngleAxisRotatePoint(aa_cl, pn, mt);
+    mt[0] += t_cl[0]; mt[1] += t_cl[1]; mt[2] += t_cl[2];
+    T pc[4] = {T(ref_plane[0]), T(ref_plane[1]), T(ref_plane[2]), T(ref_plane[3])};
+    T rp[3] = {T(middle_ref[0]), T(middle_ref[1]), T(middle_ref[2])};
+    T np[3];
+    ProjectPointToPlane(mt, pc, np, true);
+    T curr = VectorAngle3D(np, rp);
+    if (curr < T(angle)) residual[0] = T(0.0);
+    else residual[0] = T(weight) * (curr - T(angle));
+    return true;
+  }
+};
+
 // PanoramaReprojResidual_1Angle (base/CostFunction.h:218-247): angle between the keypoint's bearing and the
 // direction of the 3-D point in the camera frame; 3 parameter blocks (aa_cw, t_cw, point_3d).  Added by
 // AddCameraResidual (util/Optimization.cpp:172-222) with HuberLoss(4 deg).
@@ -232,6 +282,22 @@ inline bool AutoDiffEvaluateReproj(const PanoramaReprojResidual_1Angle& f, const
   const bool ok = f(p[0], p[1], p[2], &r);
   *residual = r.a;
   for (int k = 0; k < 9; ++k) J[k] = r.v[k];
+  return ok;
+}
+
+// AutoDiffCostFunction<F,1,3,3>::Evaluate (the calibration-mode functors): params = {aa_cl, t_cl}; J = 1x6 [d/daa_cl | d/dt_cl]
+template <typename F>
+inline bool AutoDiffEvaluateRelative(const F& f, const double* aa, const double* t, double* residual, double* J) {
+  if (!J) return f(aa, t, residual);
+  typedef Jet<6> JT;
+  JT p[2][3];
+  const double* src[2] = {aa, t};
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 3; ++k) p[b][k] = JT(src[b][k], b * 3 + k);
+  JT r;
+  const bool ok = f(p[0], p[1], &r);
+  *residual = r.a;
+  for (int k = 0; k < 6; ++k) J[k] = r.v[k];
   return ok;
 }
 

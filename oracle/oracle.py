@@ -112,6 +112,20 @@ def evaluate(kind, rec, ref_id, nei_id, aa, t, normalize=False, jac=True, thread
     return r, J
 
 
+def evaluate_relative(kind, rec, aa_cl, t_cl, jac=True):
+    """The calibration-mode functors of CameraLidarOptimizer::Optimize(line_pairs, T_cl): kind 4 = Plane2Plane_Relative (residual in
+    degrees), 5 = PlaneRelativeIOUResidual; one pose (aa_cl, t_cl); records as for evaluate().  Returns (r, J n x 6 | None)."""
+    rec = _f64(rec); aa_cl = _f64(aa_cl); t_cl = _f64(t_cl)
+    n = rec.shape[0]
+    assert rec.shape[1] == STRIDE[kind]
+    r = np.empty(n, np.float64)
+    J = np.empty((n, 6), np.float64) if jac else None
+    rc = lib().orc_eval_relative(C.c_int(kind), C.c_long(n), _p(rec, C.c_double), C.c_int(rec.shape[1]), _p(aa_cl, C.c_double), _p(t_cl, C.c_double),
+                                 _p(r, C.c_double), _p(J, C.c_double))
+    assert rc == 0
+    return r, J
+
+
 def branch_distance(kind, rec, ref_id, nei_id, aa, t):
     """The distance the *_Angle functors (kind 1, 3) test against 1e-3 first (CostFunction.h:680-684, :893-897), extended precision."""
     rec = _f64(rec); aa = _f64(aa); t = _f64(t); ref_id = _i32(ref_id); nei_id = _i32(nei_id)

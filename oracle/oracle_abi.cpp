@@ -96,6 +96,18 @@ int orc_eval(int kind, int flags, long n, const double* rec, int stride, const i
   return (kind >= 0 && kind <= 5) ? 0 : -1;
 }
 
+// Calibration-mode functors (one pose): kind 4 = Plane2Plane_Relative, 5 = PlaneRelativeIOUResidual, records as for orc_eval.  J: n x 6 or NULL.
+int orc_eval_relative(int kind, long n, const double* rec, int stride, const double* aa_cl, const double* t_cl, double* r, double* J) {
+  for (long i = 0; i < n; ++i) {
+    const double* c = rec + size_t(i) * stride;
+    double* Ji = J ? J + 6 * size_t(i) : nullptr;
+    if (kind == 4) { Plane2Plane_Relative f; f.SetPlane(c); std::memcpy(f.point_a, c + 3, 24); std::memcpy(f.point_b, c + 6, 24); f.weight = c[9]; AutoDiffEvaluateRelative(f, aa_cl, t_cl, r + i, Ji); }
+    else if (kind == 5) { PlaneRelativeIOUResidual f; f.SetPlane(c); std::memcpy(f.middle_neighbor, c + 4, 24); std::memcpy(f.middle_ref, c + 7, 24); f.angle = c[10]; f.weight = c[11]; AutoDiffEvaluateRelative(f, aa_cl, t_cl, r + i, Ji); }
+    else return -1;
+  }
+  return 0;
+}
+
 // the distance the *_Angle functors (kind 1, 3) compare with 1e-3 before anything else, in extended precision
 int orc_branch_distance(int kind, long n, const double* rec, int stride, const int* ref_id, const int* nei_id, const double* aa, const double* t, double* dis) {
   if (kind != 1 && kind != 3) return -1;

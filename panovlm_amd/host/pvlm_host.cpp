@@ -2552,6 +2552,66 @@ CameraLidarOptimizer::LinePairs CameraLidarOptimizer::AssociateLineMulti(const i
   return all;
 }
 
+// Calibration mode (CameraLidarOptimizer.cpp:32-87).  The two functors of this mode, Plane2Plane_Relative (base/CostFunction.h:294-348) and
+// PlaneRelativeIOUResidual (:509-565), map a LiDAR point with ONE pose, P_c = R(aa_cl) P_l + t_cl.  That is the chain of Plane2Plane_Global /
+// PlaneIOUResidual — P_c = R(aa_cw) (R(-aa_lw) (P_l - t_lw)) + t_cw — with the LiDAR pose at the identity, where it is exact: ceres'
+// AngleAxisRotatePoint takes its first-order branch for a zero rotation and returns the point unchanged.  So the blocks are kinds 4 and 5 of
+// the GPU evaluation with (aa_cw, t_cw) = (aa_cl, t_cl) free and a constant identity for the second pose; the derivative with respect to
+// (aa_cl, t_cl) is the first half of the row.  Plane2Plane_Relative returns weight * angle * 180 / pi: folded into the block weight.
+int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const Matrix4d& T_cl, double* final_cost, int* successful_steps, int* residual_blocks) {
+  ceres_like::Problem problem;
+  ceres_like::LossFunction* loss_function = new ceres_like::HuberLoss(2.0 * M_PI / 180.0);                 // :36
+  const Matrix3d R = {T_cl[0], T_cl[1], T_cl[2], T_cl[4], T_cl[5], T_cl[6], T_cl[8], T_cl[9], T_cl[10]};
+  Vector3d angle_axis, t = {T_cl[3], T_cl[7], T_cl[11]};
+  RotationMatrixToAngleAxis(R, &angle_axis);
+  Vector3d aa_id = {0, 0, 0}, t_id = {0, 0, 0};
+  if (frames.empty()) { delete loss_function; T_cl_optimized = T_cl; return 1; }
+  const Equirect eq{frames[0].cols, frames[0].rows};                                                       // :41
+  size_t blocks = 0;
+  for (const auto& kv : line_pairs)
+    for (const CameraLidarLinePair& pair : kv.second) {
+      // ImageToCam(cv::Point2f, float(5.0)) -> cv::Point3f; the plane through p1, p2 and the centre in FLOAT arithmetic, then widened (:51-57)
+      const float a2[2] = {pair.image_line[0], pair.image_line[1]}, b2[2] = {pair.image_line[2], pair.image_line[3]};
+      float p1[3], p2[3];
+      eq.ImageToCam(a2, 5.0f, p1); eq.ImageToCam(b2, 5.0f, p2);
+      const float p3[3] = {0.f, 0.f, 0.f};
+      const double a = ((p2[1] - p1[1]) * (p3[2] - p1[2]) - (p2[2] - p1[2]) * (p3[1] - p1[1]));
+      const double b = ((p2[2] - p1[2]) * (p3[0] - p1[0]) - (p2[0] - p1[0]) * (p3[2] - p1[2]));
+      const double c = ((p2[0] - p1[0]) * (p3[1] - p1[1]) - (p2[1] - p1[1]) * (p3[0] - p1[0]));
+      problem.AddResidualBlock(Plane2Plane_Global::Create({a, b, c}, pair.lidar_line_end, pair.lidar_line_start, 1.0 * 180.0 / M_PI), loss_function,
+                               angle_axis.data(), t.data(), aa_id.data(), t_id.data());                     // :59-60
+      // PlaneRelativeIOUResidual(plane, middle, p1, p2, 2): angle = VectorAngle3D(p1, p2) / 2.f and the midpoint, both in float (:521-527);
+      // VectorAngle3D<float> (base/Geometry.hpp:432-448) with the float overloads of sqrt / acos [recalled: <cmath> in scope]
+      float cos_angle = (p1[0] * p2[0] + p1[1] * p2[1]) + p1[2] * p2[2];
+      const float norm1 = std::sqrt((p1[0] * p1[0] + p1[1] * p1[1]) + p1[2] * p1[2]), norm2 = std::sqrt((p2[0] * p2[0] + p2[1] * p2[1]) + p2[2] * p2[2]);
+      cos_angle /= (norm1 * norm2);
+      const float full = cos_angle >= 1.f ? 0.f : (cos_angle <= -1.f ? (float)M_PI : std::acos(cos_angle));
+      const float half_arc = full / 2.f;
+      const Vector3d mid_i = {(double)((p1[0] + p2[0]) / 2.f), (double)((p1[1] + p2[1]) / 2.f), (double)((p1[2] + p2[2]) / 2.f)};
+      const Vector3d mid_l = {(pair.lidar_line_start[0] + pair.lidar_line_end[0]) / 2.0, (pair.lidar_line_start[1] + pair.lidar_line_end[1]) / 2.0,
+                              (pair.lidar_line_start[2] + pair.lidar_line_end[2]) / 2.0};
+      problem.AddResidualBlock(PlaneIOUResidual::Create({a, b, c, 0.0}, mid_l, mid_i, (double)half_arc, 2.0), nullptr, angle_axis.data(), t.data(),
+                               aa_id.data(), t_id.data());                                                   // :62-64
+      blocks += 2;
+    }
+  if (blocks == 0) { delete loss_function; T_cl_optimized = T_cl; if (residual_blocks) *residual_blocks = 0; return 1; }
+  problem.SetParameterBlockConstant(aa_id.data());
+  problem.SetParameterBlockConstant(t_id.data());
+  ceres_like::Solver::Options options;                                                                     // :71-77
+  options.max_num_iterations = 50;
+  options.linear_solver_type = ceres_like::SPARSE_SCHUR;
+  options.num_threads = 10;
+  ceres_like::Solver::Summary summary;
+  ceres_like::Solve(options, &problem, &summary);
+  Matrix3d Ro;
+  AngleAxisToRotationMatrix(angle_axis, &Ro);                                                              // :83-86
+  T_cl_optimized = {Ro[0], Ro[1], Ro[2], t[0], Ro[3], Ro[4], Ro[5], t[1], Ro[6], Ro[7], Ro[8], t[2], 0, 0, 0, 1};
+  if (final_cost) *final_cost = summary.final_cost;
+  if (successful_steps) *successful_steps = summary.num_successful_steps;
+  if (residual_blocks) *residual_blocks = (int)blocks;
+  return 1;
+}
+
 int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, std::vector<PointTrack>& structure, const bool refine_camera_rotation,
                                    const bool refine_camera_trans, const bool refine_lidar_rotation, const bool refine_lidar_trans,
                                    const bool refine_structure, double& cost, int& steps) {

@@ -540,12 +540,18 @@ class CameraLidarOptimizer {
     std::vector<PointTrack> none;
     return Optimize(line_pairs, none, refine_camera_rotation, refine_camera_trans, refine_lidar_rotation, refine_lidar_trans, true, cost, steps);
   }
+  // Calibration mode, CameraLidarOptimizer.cpp:32-87: ONE unknown, the camera <- LiDAR transform, refined on the associated line pairs
+  // with Plane2Plane_Relative (residual in DEGREES, Huber 2 deg expressed in radians as upstream has it) and PlaneRelativeIOUResidual
+  // (weight 2, half of the image line's arc, no loss).  Returns 1 like upstream; the result is GetOptimizedTcl().
+  int Optimize(const LinePairs& line_pairs, const Matrix4d& T_cl, double* final_cost = nullptr, int* successful_steps = nullptr, int* residual_blocks = nullptr);
+  const Matrix4d& GetOptimizedTcl() const { return T_cl_optimized; }
   const std::vector<Velodyne>& GetLidars() const { return lidars; }
   const std::vector<Frame>& GetFrames() const { return frames; }
   struct IterLog { double cost; int steps; int residual_blocks; size_t line_pairs; std::vector<double> cost_history; };
   std::vector<IterLog> log;
  private:
   Matrix4d T_cl_init;
+  Matrix4d T_cl_optimized = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::vector<Velodyne> lidars;
   std::vector<Frame> frames;
   std::vector<PointTrack> structure;

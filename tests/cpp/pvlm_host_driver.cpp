@@ -714,6 +714,29 @@ int main(int argc, char** argv) {
       ceres_like::Solve(o, &problem, &sum);
       printf("blocks %zu initial %.17g final %.17g steps %d\n", nres, sum.initial_cost, sum.final_cost, sum.num_successful_steps);
       printf("aa_lw %.17g %.17g %.17g t_lw %.17g %.17g %.17g\n", aa_lw[0][0], aa_lw[0][1], aa_lw[0][2], t_lw[0][0], t_lw[0][1], t_lw[0][2]);
+    } else if (cmd == "calib") {
+      // calib <pairs.bin> rows cols : CameraLidarOptimizer::Optimize(line_pairs, T_cl), calibration mode.  File: int32 n, then per pair
+      // float image_line[4], double lidar_line_start[3], double lidar_line_end[3]; then double T_cl[16] (row-major)
+      std::ifstream f(argv[2], std::ios::binary);
+      int32_t n = 0; rd(f, &n, 1);
+      CameraLidarOptimizer::LinePairs lp;
+      for (int k = 0; k < n; ++k) {
+        CameraLidarLinePair q;
+        rd(f, q.image_line.data(), 4); rd(f, q.lidar_line_start.data(), 3); rd(f, q.lidar_line_end.data(), 3);
+        lp[{(size_t)(k / 8), 0}].push_back(q);                       // several frames against one LiDAR, as the caller's map has them
+      }
+      Matrix4d T; rd(f, T.data(), 16);
+      std::vector<Frame> frames(1);
+      frames[0].rows = atoi(argv[3]); frames[0].cols = atoi(argv[4]);
+      Config cfg;
+      CameraLidarOptimizer opt(T, std::vector<Velodyne>(), frames, cfg);
+      double cost = 0; int steps = 0, blocks = 0;
+      opt.Optimize(lp, T, &cost, &steps, &blocks);
+      const Matrix4d& To = opt.GetOptimizedTcl();
+      printf("blocks %d final %.17g steps %d\n", blocks, cost, steps);
+      printf("T");
+      for (int k = 0; k < 16; ++k) printf(" %.17g", To[k]);
+      printf("\n");
     } else {
       fprintf(stderr, "unknown command %s\n", cmd.c_str());
       return 2;

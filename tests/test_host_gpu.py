@@ -212,6 +212,82 @@ def test_camera_lidar_residual_blocks(oracle, tmp):
     assert final <= initial * (1 + 1e-12) and np.isfinite(final)
 
 
+def _image_to_cam_f32(rows, cols, px, r):
+    """Equirectangular::ImageToCam<float> (sensors/Equirectangular.h:102-103, :125-128) statement by statement in float32."""
+    f = np.float32
+    x, y = f(px[0]), f(px[1])
+    sx = f(np.float64(f(f(f(2) * x) / f(cols)) - f(1)) * np.pi)
+    sy = f((0.5 - np.float64(f(y / f(rows)))) * np.pi)
+    cy = f(np.cos(np.float64(sy)))
+    return np.array([f(f(r) * cy) * f(np.sin(np.float64(sx))), f(-f(r)) * f(np.sin(np.float64(sy))), f(f(r) * cy) * f(np.cos(np.float64(sx)))], np.float32)
+
+
+def test_calibration_mode_optimize_matches_cpu_twin(oracle, tmp):
+    """CameraLidarOptimizer::Optimize(line_pairs, T_cl), calibration mode (joint_optimization/CameraLidarOptimizer.cpp:32-87): one
+    unknown transform, Plane2Plane_Relative (degrees, Huber) + PlaneRelativeIOUResidual (weight 2, half arc, no loss) per associated
+    line pair.  The host mirror evaluates them on the GPU as kinds 4 / 5 with an identity second pose; the twin runs the restated
+    trust-region policy on the oracle's Jet evaluation of the same blocks.  Same block count, step count, cost and transform; and the
+    transform moves towards the one the pairs were generated with."""
+    rng = np.random.default_rng(44)
+    rows, cols = 2880, 5760
+    n = 60
+    R_true = synth.rodrigues(np.array([0.02, -0.03, 0.015])); t_true = np.array([0.05, -0.02, 0.08])
+    mid = rng.normal(size=(n, 3)); mid *= (rng.uniform(2.0, 6.0, size=(n, 1)) / np.linalg.norm(mid, axis=1, keepdims=True))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    half = rng.uniform(0.3, 1.2, size=(n, 1))
+    start, end = mid - half * d, mid + half * d
+    ends_cam = np.stack([start @ R_true.T + t_true, end @ R_true.T + t_true], axis=1).reshape(-1, 3)
+    lines = oracle.cam_to_image(rows, cols, ends_cam).reshape(-1, 4).astype(np.float32)
+    lines += rng.normal(size=lines.shape).astype(np.float32) * 1.5
+    keep = np.abs(lines[:, 0] - lines[:, 2]) < 0.5 * cols                       # no wrap-around lines
+    lines, start, end = lines[keep], start[keep], end[keep]
+    n = len(lines)
+    T0 = np.eye(4); T0[:3, :3] = synth.rodrigues(np.array([0.05, -0.01, -0.02])); T0[:3, 3] = t_true + np.array([0.06, 0.04, -0.05])
+    path = os.path.join(tmp, "calib.bin")
+    with open(path, "wb") as f:
+        f.write(np.int32(n).tobytes())
+        for k in range(n):
+            f.write(lines[k].tobytes()); f.write(start[k].astype(np.float64).tobytes()); f.write(end[k].astype(np.float64).tobytes())
+        f.write(T0.astype(np.float64).tobytes())
+    out = host_io.run("calib", path, rows, cols)
+    v = out[0].split()
+    blocks, final, steps = int(v[1]), float(v[3]), int(v[5])
+    T = np.array([float(x) for x in out[1].split()[1:]]).reshape(4, 4)
+    assert blocks == 2 * n
+    # the twin: rows as the reference's statements build them (float points, float plane, float half arc), kinds 4 / 5, poses {T_cl, identity}
+    r4, r5 = [], []
+    for k in range(n):
+        p1 = _image_to_cam_f32(rows, cols, lines[k, 0:2], 5.0); p2 = _image_to_cam_f32(rows, cols, lines[k, 2:4], 5.0)
+        f32 = np.float32; z = f32(0)
+        a = f32(f32(p2[1] - p1[1]) * f32(z - p1[2])) - f32(f32(p2[2] - p1[2]) * f32(z - p1[1]))
+        b = f32(f32(p2[2] - p1[2]) * f32(z - p1[0])) - f32(f32(p2[0] - p1[0]) * f32(z - p1[2]))
+        c = f32(f32(p2[0] - p1[0]) * f32(z - p1[1])) - f32(f32(p2[1] - p1[1]) * f32(z - p1[0]))
+        plane = np.array([a, b, c], np.float64)
+        r4.append(np.concatenate([plane, end[k], start[k], [180.0 / np.pi]]))
+        cosang = f32(f32(f32(p1[0] * p2[0]) + f32(p1[1] * p2[1])) + f32(p1[2] * p2[2]))
+        n1 = np.sqrt(f32(f32(f32(p1[0] * p1[0]) + f32(p1[1] * p1[1])) + f32(p1[2] * p1[2])), dtype=np.float32)
+        n2 = np.sqrt(f32(f32(f32(p2[0] * p2[0]) + f32(p2[1] * p2[1])) + f32(p2[2] * p2[2])), dtype=np.float32)
+        cosang = f32(cosang / f32(n1 * n2))
+        full = f32(0) if cosang >= 1 else (f32(np.pi) if cosang <= -1 else np.arccos(cosang, dtype=np.float32))
+        mid_i = np.array([f32(f32(p1[q] + p2[q]) / f32(2)) for q in range(3)], np.float64)
+        r5.append(np.concatenate([plane, [0.0], (start[k] + end[k]) / 2.0, mid_i, [np.float64(f32(full / f32(2)))], [2.0]]))
+    aa = np.stack([oracle.matrix_to_angle_axis(T0[:3, :3]), np.zeros(3)]); t = np.stack([T0[:3, 3].copy(), np.zeros(3)])
+    ids0 = np.zeros(n, np.int32); ids1 = np.ones(n, np.int32)
+    groups = [dict(kind=4, normalize=False, rows=np.array(r4), rid=ids0, nid=ids1, loss=1, a=2.0 * np.pi / 180.0),
+              dict(kind=5, normalize=False, rows=np.array(r5), rid=ids0, nid=ids1, loss=0, a=0.0)]
+    opt = lm_twin.Options(); opt.max_num_iterations = 50
+    res = lm_twin.solve(oracle, groups, aa, t, {1}, opt)
+    Rt = synth.rodrigues(aa[0])
+    assert steps == res["successful"] and abs(final - res["final_cost"]) <= 1e-6 * res["final_cost"]
+    assert np.abs(T[:3, :3] - Rt).max() <= 1e-6 and np.abs(T[:3, 3] - t[0]).max() <= 1e-6
+    assert np.array_equal(T[3], [0, 0, 0, 1])
+    # towards the truth: rotation and translation errors shrink
+    ang = lambda R: np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+    assert ang(T[:3, :3] @ R_true.T) < 0.3 * ang(T0[:3, :3] @ R_true.T)
+    assert np.linalg.norm(T[:3, 3] - t_true) < 0.5 * np.linalg.norm(T0[:3, 3] - t_true)
+    assert res["final_cost"] < 0.2 * res["initial_cost"]
+
+
 def test_line_to_line_refine_matches_cpu_twin(oracle, tmp):
     """One RefinePose with only the line-to-line term (GenerateTracks + AddLidarLineToLineResidual2 + Solve) against
     the oracle twin: same residual-block count, costs and poses within 1e-6."""

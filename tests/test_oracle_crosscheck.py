@@ -232,6 +232,31 @@ def test_knn_matches_ckdtree(oracle):
     assert np.array_equal(manual.astype(np.float32), sqd)
 
 
+def test_calibration_functors_are_the_global_ones_at_an_identity_pose(oracle):
+    """Plane2Plane_Relative / PlaneRelativeIOUResidual (base/CostFunction.h:294-348, :509-565: ONE pose, the calibration mode of
+    CameraLidarOptimizer::Optimize) against Plane2Plane_Global / PlaneIOUResidual with the second pose at the identity — the form
+    in which the product evaluates them (kinds 4 and 5, the first six columns of the Jacobian row): the IOU term is the same to
+    the last bit, the plane term differs only by where the constant 180 / pi is multiplied in."""
+    rng = np.random.default_rng(17)
+    n = 400
+    aa = rng.normal(size=3) * 0.4; t = rng.normal(size=3)
+    A = np.stack([aa, np.zeros(3)]); T = np.stack([t, np.zeros(3)])
+    r4 = np.concatenate([rng.normal(size=(n, 3)), rng.normal(size=(n, 3)) * 3, rng.normal(size=(n, 3)) * 3, np.full((n, 1), 1.3)], axis=1)
+    rr, Jr = oracle.evaluate_relative(4, r4, aa, t)
+    g4 = r4.copy(); g4[:, 9] = 1.3 * 180.0 / np.pi
+    rg, Jg = oracle.evaluate(4, g4, [0] * n, [1] * n, A, T)
+    assert np.abs(rr - rg).max() <= 1e-14 * np.abs(rr).max() and np.abs(Jr - Jg[:, :6]).max() <= 1e-14 * np.abs(Jr).max()
+    assert rr.min() >= 0 and rr.max() > 10                                    # degrees
+    r5 = np.concatenate([rng.normal(size=(n, 3)), np.zeros((n, 1)), rng.normal(size=(n, 3)) * 3, rng.normal(size=(n, 3)), rng.uniform(0, 1.5, size=(n, 1)),
+                         np.full((n, 1), 2.0)], axis=1)
+    rr, Jr = oracle.evaluate_relative(5, r5, aa, t)
+    rg, Jg = oracle.evaluate(5, r5, [0] * n, [1] * n, A, T)
+    assert np.array_equal(rr, rg) and np.array_equal(Jr, Jg[:, :6])
+    assert 0.1 < (rr > 0).mean() < 0.9                                        # both sides of the half-arc threshold
+    # cost-only path
+    assert np.abs(oracle.evaluate_relative(5, r5, aa, t, jac=False)[0] - rr).max() <= 1e-13
+
+
 def test_reproj_functor_matches_torch_autograd(oracle):
     """PanoramaReprojResidual_1Angle (base/CostFunction.h:218-247): the oracle's Jet<9> AutoDiff against torch.float64
     autograd through an independent Rodrigues implementation."""
