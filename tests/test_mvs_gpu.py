@@ -199,6 +199,33 @@ def test_sequential_sweep_matches_oracle(ctx, oracle):
     V.close()
 
 
+def test_sequential_batch_with_six_neighbours_matches_oracle(ctx, oracle):
+    """More neighbour images than the four a quad of threads takes in one round (QuadScorer visits them in groups of four, the last
+    group partly filled) and than the float4 strips of the wave form hold: two jobs of the batched sequential sweep against the
+    oracle's raster walk.  Re-run with the four-threads-per-pixel form forced by test_other_launch_forms_give_the_same_maps."""
+    from panovlm_amd.api import MvsViews
+    rows, cols = 64, 128
+    (gray, depth, normal), neis, Rn, tn = mvs_scene(oracle, rows, cols, n_views=7)
+    rng = np.random.default_rng(3)
+    d0 = (depth * rng.uniform(0.92, 1.08, size=depth.shape)).astype(np.float32)
+    c0, d1, n1 = oracle.mvs_init_conf_map(gray, neis, Rn, tn, d0, normal, 3, 1)
+    want = [oracle.mvs_propagate(gray, neis, Rn, tn, d1, n1, c0, max_iter=2, seed=sd, sequential=True, conf_threshold=0.3) for sd in (9, 10)]
+    V = MvsViews(ctx, rows, cols, len(neis) + 2)
+    zero3 = np.zeros((rows, cols, 3), np.float32); zero1 = np.zeros((rows, cols), np.float32)
+    for k, g in enumerate(neis):
+        V.upload(k, gray=g, depth=zero1, normal=zero3, conf=zero1)
+    refs = [len(neis), len(neis) + 1]
+    for r in refs:
+        V.upload(r, gray=gray, depth=d1, normal=n1, conf=c0)
+    jobs = [dict(ref=r, nei=list(range(len(neis))), R_nr=Rn, t_nr=tn, seed=sd) for r, sd in zip(refs, (9, 10))]
+    V.estimate_sequential_batch(jobs, max_iter=2, conf_threshold=0.3)
+    for r, w in zip(refs, want):
+        got = V.download(r, ("depth", "normal", "conf"))
+        assert np.array_equal(got["depth"], w[0]) and np.array_equal(got["normal"], w[1]) and np.array_equal(got["conf"], w[2])
+    assert not np.array_equal(want[0][0], want[1][0])
+    V.close()
+
+
 def test_other_launch_forms_give_the_same_maps():
     """The image-space kernels have several launch forms chosen by size: one pixel per thread (scoring pass, colour pass) or one wave
     per pixel, and for a batched anti-diagonal one wave per pixel or four threads per pixel from PVLM_MVS_QUAD_MIN pixels per
