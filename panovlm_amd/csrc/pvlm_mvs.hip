@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
 // smoothness factors, the decision logic of process_pixel), and the index-ordered sums are a register add per texel instead of an
 // LDS strip walked by one lane.  The neighbour texels of the image being scored are a column of the workgroup's LDS table ([k][lane]:
 // bank-conflict free, 12.5 KB per wave at 7 x 7, i.e. three waves per SIMD); the patch weights a column of `wtab` ([k][pixel of the
-// pass], n x rows x ceil(cols / 2) floats of scratch).  Windows of at most 64 texels.
+// band of rows this launch serves], n x band_rows x ceil(cols / 2) floats of scratch, mvs_lane_bands).  Windows of at most 64 texels.
 #ifndef PVLM_K13L_WAVES
 #define PVLM_K13L_WAVES 3
 #endif
