@@ -7,7 +7,9 @@
  * Plain pointers and sizes only; no exceptions cross the boundary; every function returns a
  * pvlm_status (0 = OK, negative = error, message via pvlm_last_error).
  *
- * Threading: one pvlm_ctx per GPU; a ctx is NOT thread-safe, different ctxs are independent.
+ * Threading: one pvlm_ctx per GPU; a ctx is NOT thread-safe, different ctxs are independent.  A call may use a few short-lived host
+ * threads of its own for host-side passes over its inputs (pvlm_scan_upload_batch: bounding boxes and the staging copy of a large batch);
+ * they are joined before the call returns.
  * Memory: buffers passed in are caller-owned and only read during the call unless stated.
  * Host pointers unless a parameter is prefixed d_ (device pointer, same GPU as the ctx).
  */
