@@ -321,16 +321,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WA
     float* __restrict__ wtab, int row0, int band_rows) {
   extern __shared__ float lane_tab[];                                      // [n][64]
   const int half = (cols + 1) / 2;
-  const long long wv = (long long)blockIdx.x * 64 + threadIdx.x;           // thread <-> pixel of this colour inside the band of rows [row0, row0 + band_rows)
-  if (wv >= (long long)band_rows * half) return;
-  const int py = row0 + (int)(wv / half);
-  const int px = ((py % 2 + offset) % 2) + 2 * (int)(wv % half);
+  // a workgroup is an 8 x 8 TILE of pixels of this colour (16 image columns x 8 rows) inside the band of rows [row0, row0 + band_rows):
+  // the 64 windows overlap — a third of the cache lines a 64-pixel run along one row touches
+  const int tiles_x = (half + 7) / 8;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  const int ry = ty * 8 + (int)(threadIdx.x >> 3), hx = tx * 8 + (int)(threadIdx.x & 7);
+  if (ry >= band_rows || hx >= half) return;
+  const long long wv = (long long)blockIdx.x * 64 + threadIdx.x;           // this thread's column of the weight table
+  const int py = row0 + ry;
+  const int px = ((py % 2 + offset) % 2) + 2 * hx;
   if (px >= cols) return;
   const long long e = (long long)py * cols + px;
   float dep = depth[e];
   if (dep <= 0) return;
   const int n = pvlm_mvs::num_texels(half_window, step);
-  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)band_rows * half, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
+  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)gridDim.x * 64, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
   pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
   if (!P.inside || P.sq0 <= 1e-6) return;                                 // patch.sq0 <= 1e-6 (:1116-1117)
   float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
@@ -347,14 +352,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_WA
     int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb,
     float* __restrict__ depth, float* __restrict__ normal, float* __restrict__ conf, float* __restrict__ wtab, int row0, int band_rows) {
   extern __shared__ float lane_tab[];
+  const int tiles_x = (cols + 7) / 8;                                      // 8 x 8 pixel tiles, as in k_mvs_propagate_lane
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  const int ry = ty * 8 + (int)(threadIdx.x >> 3), px = tx * 8 + (int)(threadIdx.x & 7);
+  if (ry >= band_rows || px >= cols) return;
   const long long wv = (long long)blockIdx.x * 64 + threadIdx.x;
-  if (wv >= (long long)band_rows * cols) return;
-  const long long e = (long long)row0 * cols + wv;
+  const int py = row0 + ry;
+  const long long e = (long long)py * cols + px;
   const float dep = depth[e];
   if (dep <= 0) return;                                                   // InitConfMap :594-595
-  const int py = (int)(e / cols), px = (int)(e % cols);
   const int n = pvlm_mvs::num_texels(half_window, step);
-  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)band_rows * cols, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
+  pvlm_mvs::ColumnPatch P{wtab + wv, (size_t)gridDim.x * 64, lane_tab + threadIdx.x, 64, 0.f, 0.f, false};
   pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
   float c = -1.f;
   if (P.inside && P.sq0 > 0) {                                            // :602 tests sq0 > 0 only
@@ -614,8 +622,8 @@ static LaneBands mvs_lane_bands(int rows, int per_row_pixels, int half_window, i
   const int n_tex = pvlm_mvs::num_texels(half_window, step);
   if (!mvs_lane_form(n_tex)) return {0, 0};
   static const size_t cap_mb = getenv("PVLM_MVS_LANE_TABLE_MB") ? (size_t)std::max(1, atoi(getenv("PVLM_MVS_LANE_TABLE_MB"))) : 128;
-  const size_t per_row = (size_t)n_tex * per_row_pixels;                  // floats per image row
-  const int band = (int)std::max<size_t>(1, std::min<size_t>((size_t)rows, (cap_mb << 18) / std::max<size_t>(per_row, 1)));
+  const size_t per_row = (size_t)n_tex * (((size_t)per_row_pixels + 7) / 8 * 8);   // floats per image row, in whole 8 x 8 tiles
+  int band = (int)std::max<size_t>(8, std::min<size_t>(((size_t)rows + 7) / 8 * 8, (cap_mb << 18) / std::max<size_t>(per_row, 1) / 8 * 8));
   return {band, per_row * band};
 }
 static void launch_mvs_conf_lane(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
@@ -624,7 +632,7 @@ static void launch_mvs_conf_lane(hipStream_t s, int rows, int cols, int half_win
   const int band = mvs_lane_bands(rows, cols, half_window, step).band_rows;
   for (int row0 = 0; row0 < rows; row0 += band) {
     const int br = std::min(band, rows - row0);
-    hipLaunchKernelGGL(k_mvs_conf_lane, dim3((unsigned)(((size_t)br * cols + 63) / 64)), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step, img, unit,
+    hipLaunchKernelGGL(k_mvs_conf_lane, dim3((unsigned)(((cols + 7) / 8) * ((br + 7) / 8))), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step, img, unit,
                        nb, depth, normal, conf, wtab, row0, br);
   }
 }
@@ -638,7 +646,7 @@ static void launch_mvs_propagate(hipStream_t s, int rows, int cols, int half_win
     const int band = mvs_lane_bands(rows, half, half_window, step).band_rows;
     for (int row0 = 0; row0 < rows; row0 += band) {                       // a colour's pixels do not read each other: the bands are independent
       const int br = std::min(band, rows - row0);
-      hipLaunchKernelGGL(k_mvs_propagate_lane, dim3((unsigned)(((size_t)br * half + 63) / 64)), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step,
+      hipLaunchKernelGGL(k_mvs_propagate_lane, dim3((unsigned)(((half + 7) / 8) * ((br + 7) / 8))), dim3(64), (size_t)n_tex * 64 * sizeof(float), s, rows, cols, half_window, step,
                          img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset, wtab, row0, br);
     }
     return;
