@@ -518,6 +518,53 @@ pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int
                                        const float* lines, pvlm_scan* const* lidar_local, const double* T_cl_rowmajor16,
                                        int64_t* vote_offsets, int32_t* votes, int64_t capacity);
 
+/* ---- LiDAR feature extraction, range-image stages ------------------------------------------------------- *
+ * The per-point / per-ring stages in front of the association, for a BATCH of raw scans in one go (the reference runs them scan by
+ * scan under `omp parallel for`, lidar_mapping/LidarOdometry.cpp:131-147):
+ *   Velodyne::ReOrderVLP      sensors/Velodyne.cpp:371-526    firing order -> ring order; range image; (ring, column) of every point
+ *   Velodyne::Segmentation    sensors/Velodyne.cpp:1438-1586  range-image labelling; points of small components dropped (segment != 0)
+ *   adaptive-window curvature sensors/Velodyne.cpp:623-657    the first loop of Velodyne::ExtractFeatures (method ADAPTIVE)
+ * What they produce — cloud_scan, point_idx_to_image, image_to_point_idx, range_image, scanStartInd / scanEndInd, cloudCurvature,
+ * left_neighbor / right_neighbor, cloudDistance (sensors/Velodyne.h:97-120 and the locals of ExtractFeatures) — is what the
+ * sort-dependent picks (ExtractEdgeFeatures2 :883-1000, ExtractPlaneFeatures2 :1098-1189) read.
+ * xyzi: the scan as LoadLidar left it (sensors/Velodyne.cpp:92-145; camera-style axes, float x y z intensity), point i at
+ * xyzi + i * stride_floats (pcl::PointXYZI: stride 8; packed: 4).  Non-finite coordinates are an error (LoadLidar removed them).
+ * Decisions that go through the float libm of the reference's host (atan / atan2 with `using namespace std`) are certified on
+ * the device in fp64 interval form; the few points / edges that cannot be certified are decided by the libm of THIS host
+ * inside the call (resolved_points / resolved_edges count them; replayed = 1 when a scan's +z crossing needed every point). */
+typedef struct pvlm_ring_batch pvlm_ring_batch;
+typedef struct pvlm_raw_scan {
+  const float* xyzi;
+  int n;
+  int stride_floats;
+} pvlm_raw_scan;
+typedef struct pvlm_ring_result {
+  int n_raw;                        /* points handed in                                                                          */
+  int n_reordered;                  /* cloud_scan.size() after ReOrderVLP                                                        */
+  int n_kept;                       /* cloud_scan.size() after Segmentation (== n_reordered when segment == 0)                   */
+  int resolved_points, resolved_edges, replayed;
+  const int* ring_count_reordered;  /* 64 entries: points per ring after ReOrderVLP                                              */
+  const int* ring_count;            /* 64 entries: points per ring of the kept cloud: scanStartInd[r] = sum_{q<r} + 5,
+                                       scanEndInd[r] = sum_{q<=r} - 6 (:520-522, :1575-1580)                                      */
+  /* the kept cloud, n_kept entries each, valid until pvlm_ring_batch_destroy (pinned host memory owned by the batch):           */
+  const int* source;                /* index of the point in the raw scan: cloud_scan[i] = (raw xyz, intensity = ring)           */
+  const int* ring_col;              /* point_idx_to_image[i] as (ring << 16) | column                                            */
+  const float* curvature;           /* cloudCurvature[i]; -1 where upstream leaves it unset                                      */
+  const int* half_window;           /* left_neighbor[i] = i - half_window[i], right_neighbor[i] = i + half_window[i]; -1 = unset  */
+  const float* range;               /* cloudDistance[i] = range_image(point_idx_to_image[i])  (:566-569)                         */
+} pvlm_ring_result;
+pvlm_status pvlm_ring_extract_batch(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* scans, int n_rings, int horizon_scans, int segment,
+                                    pvlm_ring_batch** out);
+pvlm_status pvlm_ring_batch_scan(const pvlm_ring_batch* batch, int scan, pvlm_ring_result* result);
+/* The device-resident arrays of one scan (tests, visualisation).  state 0: after ReOrderVLP, 1: after Segmentation.  cloud_xyzi: n x 4
+ * (intensity = ring), ring_col_pairs: n x 2, range_image / image_to_point: n_rings x horizon_scans (0 / -1 = empty).  NULL = skip. */
+pvlm_status pvlm_ring_batch_fetch(pvlm_ctx* ctx, const pvlm_ring_batch* batch, int scan, int state, float* cloud_xyzi, int* ring_col_pairs,
+                                  float* range_image, int* image_to_point);
+/* HIP-event milliseconds of the last run: [0] upload  [1] K16 ring/azimuth + host libm  [2] K17 columns (+ replays)  [3] K18 scatter
+ * [4] K19 edges + host libm  [5] K20 components  [6] K21 compaction + K22 curvature  [7] download. */
+pvlm_status pvlm_ring_batch_timing(const pvlm_ring_batch* batch, double* ms8);
+pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* batch);
+
 #ifdef __cplusplus
 }
 #endif

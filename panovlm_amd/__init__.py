@@ -6,9 +6,9 @@ There is NO CPU fallback: importing the bindings without the built library, or c
 context without a GPU, raises.
 """
 from .api import (  # noqa: F401
-    Context, ResidualSet, NormalEq, BundleSet, Scan, Comm, PvlmError, lib_path, load_library,
+    Context, ResidualSet, NormalEq, BundleSet, Scan, Comm, RingBatch, PvlmError, lib_path, load_library,
     POINT2PLANE_METER, POINT2PLANE_ANGLE, POINT2LINE_METER, POINT2LINE_ANGLE, PLANE2PLANE_GLOBAL, PLANE_IOU,
     FLAG_NORMALIZE_DISTANCE, LOSS_NONE, LOSS_HUBER, PAIR_BLOCK, STRIDE, ABI_SYMBOLS,
 )
 
-__all__ = ["Context", "ResidualSet", "NormalEq", "BundleSet", "Scan", "PvlmError", "lib_path", "load_library"]
+__all__ = ["Context", "ResidualSet", "NormalEq", "BundleSet", "Scan", "RingBatch", "PvlmError", "lib_path", "load_library"]

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
+    "pvlm_ring_extract_batch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -858,3 +859,76 @@ class Scan:
             self.close()
         except Exception:
             pass
+
+
+class RawScanDesc(C.Structure):
+    _fields_ = [("xyzi", C.POINTER(C.c_float)), ("n", C.c_int), ("stride_floats", C.c_int)]
+
+
+class RingResultDesc(C.Structure):
+    _fields_ = [("n_raw", C.c_int), ("n_reordered", C.c_int), ("n_kept", C.c_int), ("resolved_points", C.c_int), ("resolved_edges", C.c_int), ("replayed", C.c_int),
+                ("ring_count_reordered", C.POINTER(C.c_int)), ("ring_count", C.POINTER(C.c_int)), ("source", C.POINTER(C.c_int)), ("ring_col", C.POINTER(C.c_int)),
+                ("curvature", C.POINTER(C.c_float)), ("half_window", C.POINTER(C.c_int)), ("range", C.POINTER(C.c_float))]
+
+
+class RingBatch:
+    """pvlm_ring_extract_batch: ReOrderVLP + Segmentation + adaptive curvature of a batch of raw scans (n x 4 float32 each) on the GPU."""
+
+    def __init__(self, ctx, raw_scans, n_rings=16, horizon=1800, segment=True):
+        self.ctx = ctx
+        self._raw = [_f32(r).reshape(-1, 4) for r in raw_scans]
+        self.n_rings, self.horizon = n_rings, horizon
+        descs = (RawScanDesc * max(len(self._raw), 1))()
+        for k, r in enumerate(self._raw):
+            descs[k].xyzi = _p(r, C.c_float); descs[k].n = len(r); descs[k].stride_floats = 4
+        self._h = C.c_void_p()
+        ctx._check(ctx.lib.pvlm_ring_extract_batch(ctx._h, C.c_int(len(self._raw)), descs, C.c_int(n_rings), C.c_int(horizon), C.c_int(1 if segment else 0),
+                                                   C.byref(self._h)), "pvlm_ring_extract_batch")
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.ctx.lib.pvlm_ring_batch_destroy(self.ctx._h, self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def timing(self):
+        ms = np.zeros(8)
+        self.ctx._check(self.ctx.lib.pvlm_ring_batch_timing(self._h, _p(ms, C.c_double)), "pvlm_ring_batch_timing")
+        return dict(zip(("upload", "classify", "columns", "scatter", "edges", "components", "compact_curvature", "download"), ms.tolist()))
+
+    def result(self, scan):
+        """The kept cloud of one scan as numpy copies (the picks of the host read these arrays in place)."""
+        r = RingResultDesc()
+        self.ctx._check(self.ctx.lib.pvlm_ring_batch_scan(self._h, C.c_int(scan), C.byref(r)), "pvlm_ring_batch_scan")
+        m = r.n_kept
+        arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n > 0 else np.zeros(0, dt)
+        out = dict(n_raw=r.n_raw, n_reordered=r.n_reordered, n_kept=m, resolved_points=r.resolved_points, resolved_edges=r.resolved_edges, replayed=r.replayed,
+                   ring_count_reordered=arr(r.ring_count_reordered, 64, np.int32), ring_count=arr(r.ring_count, 64, np.int32), source=arr(r.source, m, np.int32),
+                   ring_col=arr(r.ring_col, m, np.int32), curvature=arr(r.curvature, m, np.float32), half_window=arr(r.half_window, m, np.int32),
+                   range=arr(r.range, m, np.float32))
+        return out
+
+    def fetch(self, scan, state):
+        """Device-resident arrays of one scan: state 0 after ReOrderVLP, 1 after Segmentation."""
+        res = self.result(scan)
+        n = res["n_kept"] if state else res["n_reordered"]
+        cloud = np.zeros((max(n, 1), 4), np.float32); rc = np.zeros((max(n, 1), 2), np.int32)
+        image = np.zeros((self.n_rings, self.horizon), np.float32); i2p = np.zeros((self.n_rings, self.horizon), np.int32)
+        self.ctx._check(self.ctx.lib.pvlm_ring_batch_fetch(self.ctx._h, self._h, C.c_int(scan), C.c_int(state), _p(cloud, C.c_float), _p(rc, C.c_int), _p(image, C.c_float),
+                                                           _p(i2p, C.c_int)), "pvlm_ring_batch_fetch")
+        return cloud[:n], rc[:n], image, i2p
+
+    def arrays(self, scan):
+        """Everything tests/ring_cases.assert_matches_oracle compares, for one scan."""
+        res = self.result(scan)
+        c0, rc0, image, i2p0 = self.fetch(scan, 0)
+        c1, rc1, _, i2p1 = self.fetch(scan, 1)
+        return dict(n_reordered=res["n_reordered"], n_kept=res["n_kept"], cloud_reordered=c0, rc_reordered=rc0, range_image=image, image_to_point_reordered=i2p0,
+                    ring_count_reordered=res["ring_count_reordered"], cloud_kept=c1, rc_kept=rc1, image_to_point_kept=i2p1, ring_count=res["ring_count"],
+                    curvature=res["curvature"], half_window=res["half_window"], range=res["range"], source=res["source"], ring_col=res["ring_col"],
+                    resolved_points=res["resolved_points"], resolved_edges=res["resolved_edges"], replayed=res["replayed"])

@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpvlm.so")
 ARCH = "gfx950"
+# sources whose float / double decisions must equal a non-FMA x86-64 build of the reference bit for bit
+NO_CONTRACT = ("pvlm_assoc.hip", "pvlm_lines.hip", "pvlm_mvs.hip", "pvlm_ring.hip")
 
 
 def _hipcc():
@@ -43,7 +45,7 @@ def build(force=False, verbose=False):
         flags = list(common) + os.environ.get("PVLM_DEFINES", "").split()
         # association kernels make accept/reject decisions that must be bit-identical to a
         # non-FMA x86-64 build of the reference: no contraction there.
-        if os.path.basename(src) in ("pvlm_assoc.hip", "pvlm_lines.hip", "pvlm_mvs.hip"):
+        if os.path.basename(src) in NO_CONTRACT:
             flags.append("-ffp-contract=off")
         # the candidate loop of the k-NN search: SLP packs two of its three float subtractions / multiplications into v_pk ops and pays
         # three register moves to assemble the operands — measured 2 % slower than the scalar form (23.6 vs 23.15 ms per 134 M queries)
@@ -89,7 +91,7 @@ def build_variant(tag, defines):
             obj = os.path.join(vdir, base + "." + tag + ".o")
             flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
             flags += os.environ.get("PVLM_DEFINES", "").split() + list(defines)
-            if base in ("pvlm_assoc.hip", "pvlm_lines.hip", "pvlm_mvs.hip"):
+            if base in NO_CONTRACT:
                 flags.append("-ffp-contract=off")
             if base == "pvlm_assoc.hip":
                 flags.append("-fno-slp-vectorize")
@@ -99,7 +101,7 @@ def build_variant(tag, defines):
     if missing:
         raise RuntimeError("no source or header under csrc/ mentions %s: the variant would equal the baseline" % ", ".join(missing))
     out = os.path.join(vdir, "libpvlm_%s.so" % tag)
-    subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+    subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-pthread"])
     return out
 
 

@@ -1,0 +1,635 @@
+// K16-K23 — the range-image stages of the LiDAR feature extractor for a BATCH of raw scans:
+//   Velodyne::ReOrderVLP        sensors/Velodyne.cpp:371-526    firing order -> ring order, range image, (ring, column) of every point
+//   Velodyne::Segmentation      sensors/Velodyne.cpp:1438-1586  range-image labelling, small components removed
+//   adaptive-window curvature   sensors/Velodyne.cpp:623-657    (ExtractFeatures, method ADAPTIVE)
+// One launch per stage covers every scan of the batch (454 scans of Room, 1593 of Floor); everything between the raw
+// points and the per-point curvature stays in HBM.  The sort-dependent picks (ExtractEdgeFeatures2 / ExtractPlaneFeatures2,
+// pcl::VoxelGrid) stay on the host (host/pvlm_features.cpp) and read the arrays this file downloads.
+// Compiled with -ffp-contract=off: every float expression below is the reference's, operation for operation.
+//
+// libm decisions.  Three decisions of the reference go through FLOAT libm calls of the host it was built on
+// (`using namespace std`, sensors/Velodyne.cpp:7): atan (elevation -> ring), atan2 (azimuth -> column, the +z crossing)
+// and atan2 again (the segmentation angle).  Their last bit belongs to that host's libm, not to IEEE-754.  The kernels
+// therefore compute the TRUE value in fp64, take the interval of floats within kUlps of it — every libm result lies
+// inside (glibc documents <= 2 ulp for atanf / atan2f) — and carry the DECISION (ring, column, joined / not joined) through
+// the reference's own arithmetic for the interval: when both ends agree the decision is certified, whatever the libm.
+// The few points or edges whose interval straddles a decision boundary (~1e-4 of the points, ~0 edges) are listed, and the
+// entry point asks the host's own libm for exactly those (std::atan2 / std::atan on the same floats, what a reference
+// build on this machine would call) before the dependent stage runs.  Comparisons between two azimuths (the +z-crossing
+// test, :447-461) are interval comparisons; a scan whose crossing cannot be certified gets exact azimuths for all its
+// points from the host and is replayed.  No decision is ever taken from an uncertified device value.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "pvlm_internal.h"
+#include "pvlm_ring_core.h"
+
+using namespace pvlm_ring;
+
+namespace {
+
+struct PtBlock { int scan, first; };   // 256 points of one scan
+
+// ---- K16: per raw point — ring and azimuth with their certificates -----------------------------------------------------
+// az[i] = the float nearest to the true atan2(x, z); ring[i] = the ring every float within kUlps of the true atan() gives, or the
+// point is listed; likewise the column (for both states of the +z crossing).  exact[i] = 0.
+__global__ __launch_bounds__(256) void k_ring_classify(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, int rings, int horizon,
+                                                       const float4* __restrict__ raw, float* __restrict__ az, signed char* __restrict__ ring,
+                                                       unsigned char* __restrict__ exact, int* __restrict__ n_listed, int* __restrict__ listed) {
+  const PtBlock b = blocks[blockIdx.x];
+  const RingScan sc = scans[b.scan];
+  const int i = b.first + threadIdx.x;
+  if (i >= sc.n) return;
+  const float4 p = raw[sc.pt0 + i];
+  float f; int r;
+  const bool list = classify_point(sc, rings, horizon, p.x, p.y, p.z, &f, &r);
+  az[sc.pt0 + i] = f;
+  ring[sc.pt0 + i] = (signed char)r;
+  exact[sc.pt0 + i] = 0;
+  if (list) listed[atomicAdd(n_listed, 1)] = (int)(sc.pt0 + i);
+}
+
+struct PointPatch { int at; float az; int ring; };
+__global__ void k_ring_patch(int n, const PointPatch* __restrict__ patch, float* __restrict__ az, signed char* __restrict__ ring, unsigned char* __restrict__ exact) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const PointPatch p = patch[k];
+  az[p.at] = p.az; ring[p.at] = (signed char)p.ring; exact[p.at] = 1;
+}
+
+// ---- K17: the column state machine of :431-507, one lane per scan ---------------------------------------------------------
+// The loop carries five scalars from point to point (crossed, last azimuth, column offset, last column, last ring): it is
+// replayed as written, one scan per lane, over the per-point values K16 prepared; the heavy arithmetic is all in K16.
+// colpos[i] = (column or -1, position of the point inside its ring).  status: (-1, .) = done, (i, last) = the +z crossing could not be
+// certified at point i against the azimuth of point `last` (see columns_scan).
+__global__ __launch_bounds__(64) void k_ring_columns(const RingScan* __restrict__ scans, const int* __restrict__ todo, int n_todo, int rings, int horizon,
+                                                     const float* __restrict__ az, const signed char* __restrict__ ring, const unsigned char* __restrict__ exact,
+                                                     int2* __restrict__ colpos, int* __restrict__ ring_count, int2* __restrict__ status) {
+  __shared__ int cnt[kMaxRings * 64];
+  const int lane = threadIdx.x;
+  const int t = blockIdx.x * 64 + lane;
+  for (int r = 0; r < rings; ++r) cnt[r * 64 + lane] = 0;
+  if (t >= n_todo) return;
+  const int s = todo ? todo[t] : t;
+  const RingScan sc = scans[s];
+  int last = -1;
+  const int stuck = columns_scan(sc, rings, horizon, az + sc.pt0, ring + sc.pt0, exact + sc.pt0, reinterpret_cast<int*>(colpos + sc.pt0),
+                                 [&](int r) -> int& { return cnt[r * 64 + lane]; }, &last);
+  status[s] = make_int2(stuck, last);
+  for (int r = 0; r < kMaxRings; ++r) ring_count[(size_t)s * kMaxRings + r] = r < rings ? cnt[r * 64 + lane] : 0;
+}
+
+// ---- K18: ring-ordered cloud, (ring, column) of every point, range image ---------------------------------------------------
+// Several returns can land in one cell; the reference's loops leave the LAST one (in cloud order) in range_image and in
+// image_to_point_idx (:497-499, :513-517): atomicMax over the raw index picks it, the second pass writes it.
+__global__ __launch_bounds__(256) void k_ring_scatter(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, int horizon,
+                                                      const float4* __restrict__ raw, const signed char* __restrict__ ring, const int2* __restrict__ colpos,
+                                                      const int* __restrict__ ring_count, float4* __restrict__ cloud_scan, int* __restrict__ source,
+                                                      int2* __restrict__ rc, int* __restrict__ winner) {
+  __shared__ int begin[kMaxRings];
+  const PtBlock b = blocks[blockIdx.x];
+  const RingScan sc = scans[b.scan];
+  if (threadIdx.x == 0) { int run = 0; for (int r = 0; r < kMaxRings; ++r) { begin[r] = run; run += ring_count[(size_t)b.scan * kMaxRings + r]; } }
+  __syncthreads();
+  const int i = b.first + threadIdx.x;
+  if (i >= sc.n) return;
+  const int2 cp = colpos[sc.pt0 + i];
+  if (cp.x < 0) return;
+  const int r = ring[sc.pt0 + i];
+  const int dst = begin[r] + cp.y;
+  const float4 p = raw[sc.pt0 + i];
+  cloud_scan[sc.pt0 + dst] = make_float4(p.x, p.y, p.z, (float)r);
+  source[sc.pt0 + dst] = i;
+  rc[sc.pt0 + dst] = make_int2(r, cp.x);
+  atomicMax(&winner[sc.cell0 + (long long)r * horizon + cp.x], i);
+}
+__global__ __launch_bounds__(256) void k_ring_cells(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, int horizon,
+                                                    const float4* __restrict__ raw, const signed char* __restrict__ ring, const int2* __restrict__ colpos,
+                                                    const int* __restrict__ ring_count, const int* __restrict__ winner, float* __restrict__ range_image,
+                                                    int* __restrict__ image_to_point) {
+  __shared__ int begin[kMaxRings];
+  const PtBlock b = blocks[blockIdx.x];
+  const RingScan sc = scans[b.scan];
+  if (threadIdx.x == 0) { int run = 0; for (int r = 0; r < kMaxRings; ++r) { begin[r] = run; run += ring_count[(size_t)b.scan * kMaxRings + r]; } }
+  __syncthreads();
+  const int i = b.first + threadIdx.x;
+  if (i >= sc.n) return;
+  const int2 cp = colpos[sc.pt0 + i];
+  if (cp.x < 0) return;
+  const int r = ring[sc.pt0 + i];
+  const long long cell = sc.cell0 + (long long)r * horizon + cp.x;
+  if (winner[cell] != i) return;
+  const float4 p = raw[sc.pt0 + i];
+  range_image[cell] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+  image_to_point[cell] = begin[r] + cp.y;
+}
+
+// ---- K19: the "joined" relation between 4-neighbours of the range image (:1500-1512), certified ------------------------------
+struct EdgeQuery { long long cell; int bit; float y, x; };   // undecided edge: the host evaluates atan2f(y, x) > theta
+__global__ __launch_bounds__(256) void k_seg_edges(const RingScan* __restrict__ scans, int rings, int horizon, const float* __restrict__ range_image,
+                                                   float sin_x, float cos_x, float sin_y, float cos_y, float theta, unsigned char* __restrict__ edges,
+                                                   int* __restrict__ n_queries, EdgeQuery* __restrict__ queries, int query_cap) {
+  const RingScan sc = scans[blockIdx.y];
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= rings * horizon) return;
+  const int r = cell / horizon, c = cell - r * horizon;
+  const float* R = range_image + sc.cell0;
+  const float here = R[cell];
+  unsigned char bits = 0;
+  auto test = [&](int other, int bit, float s, float cs) {
+    float y = 0.f, x = 0.f;
+    const int j = joined_certified(here, R[other], s, cs, theta, &y, &x);
+    if (j > 0) bits |= (unsigned char)bit;
+    else if (j < 0) {
+      const int k = atomicAdd(n_queries, 1);
+      if (k < query_cap) queries[k] = EdgeQuery{sc.cell0 + cell, bit, y, x};
+    }
+  };
+  const int right = r * horizon + (c + 1 == horizon ? 0 : c + 1);
+  if (right != cell) test(right, 1, sin_x, cos_x);
+  if (r + 1 < rings) test(cell + horizon, 2, sin_y, cos_y);
+  edges[sc.cell0 + cell] = bits;
+}
+struct EdgePatch { long long cell; int bit; };
+__global__ void k_seg_patch(int n, const EdgePatch* __restrict__ patch, unsigned char* __restrict__ edges) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) atomicOr((unsigned int*)(edges + (patch[k].cell & ~3ll)), (unsigned)patch[k].bit << (8 * (int)(patch[k].cell & 3)));
+}
+
+// ---- K20: connected components of the joined relation = the BFS labels of :1463-1530 ------------------------------------------
+// Lock-free union-find in HBM (hook the larger root under the smaller by atomicMin: the root of a component is its smallest
+// cell = the seed the reference's raster-order BFS starts from).  Then per component: size and the rows holding a cell other
+// than the seed (lineCountFlag marks pushed cells only; the seed is popped, never pushed, :1473-1476, :1518).
+__device__ inline int uf_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int uf_find(const int* parent, int x) {
+  int r = x;
+  for (int q = uf_load(parent + r); q != r; q = uf_load(parent + r)) r = q;
+  return r;
+}
+__device__ inline void uf_union(int* parent, int a, int b) {
+  while (true) {
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(parent + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+__global__ __launch_bounds__(256) void k_seg_init(const RingScan* __restrict__ scans, int cells, int* __restrict__ parent, int* __restrict__ comp_size,
+                                                  unsigned long long* __restrict__ row_mask, int* __restrict__ image_to_point2) {
+  const RingScan sc = scans[blockIdx.y];
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= cells) return;
+  parent[sc.cell0 + cell] = cell; comp_size[sc.cell0 + cell] = 0; row_mask[sc.cell0 + cell] = 0ull; image_to_point2[sc.cell0 + cell] = -1;
+}
+__global__ __launch_bounds__(256) void k_seg_union(const RingScan* __restrict__ scans, int rings, int horizon, const unsigned char* __restrict__ edges,
+                                                   int* __restrict__ parent) {
+  const RingScan sc = scans[blockIdx.y];
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= rings * horizon) return;
+  const unsigned char bits = edges[sc.cell0 + cell];
+  if (!bits) return;
+  const int r = cell / horizon, c = cell - r * horizon;
+  int* P = parent + sc.cell0;
+  if (bits & 1) uf_union(P, cell, r * horizon + (c + 1 == horizon ? 0 : c + 1));
+  if (bits & 2) uf_union(P, cell, cell + horizon);
+}
+__global__ __launch_bounds__(256) void k_seg_stats(const RingScan* __restrict__ scans, int rings, int horizon, const int* __restrict__ parent,
+                                                   int* __restrict__ root_of, int* __restrict__ comp_size, unsigned long long* __restrict__ row_mask) {
+  const RingScan sc = scans[blockIdx.y];
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= rings * horizon) return;
+  const int root = uf_find(parent + sc.cell0, cell);
+  root_of[sc.cell0 + cell] = root;
+  atomicAdd(comp_size + sc.cell0 + root, 1);
+  if (cell != root) atomicOr(row_mask + sc.cell0 + root, 1ull << (cell / horizon));
+}
+
+// ---- K21: drop the points of rejected components, ring order kept (:1547-1580); one workgroup per scan -----------------------
+// segment == 0: nothing is dropped (the curvature stage reads the same arrays either way).
+__global__ __launch_bounds__(1024) void k_seg_compact(const RingScan* __restrict__ scans, int rings, int horizon, int segment, const int* __restrict__ ring_count,
+                                                      const float4* __restrict__ cloud_scan, const int* __restrict__ source, const int2* __restrict__ rc,
+                                                      const float* __restrict__ range_image, const int* __restrict__ root_of, const int* __restrict__ comp_size,
+                                                      const unsigned long long* __restrict__ row_mask, float4* __restrict__ cloud2, int* __restrict__ source2,
+                                                      int* __restrict__ ring_col2, float* __restrict__ range2, int* __restrict__ image_to_point2,
+                                                      int* __restrict__ ring_count2, int* __restrict__ counts) {
+  __shared__ int part[1024];
+  __shared__ int carry_s;
+  __shared__ int kept_ring[kMaxRings];
+  const int s = blockIdx.x, t = threadIdx.x;
+  const RingScan sc = scans[s];
+  int n = 0;
+  for (int r = 0; r < rings; ++r) n += ring_count[(size_t)s * kMaxRings + r];
+  if (t == 0) carry_s = 0;
+  if (t < kMaxRings) kept_ring[t] = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 4096) {
+    int keep[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + 4 * t + k;
+      keep[k] = 0;
+      if (i < n) {
+        keep[k] = 1;
+        if (segment) {
+          const int2 q = rc[sc.pt0 + i];
+          const long long root = sc.cell0 + root_of[sc.cell0 + (long long)q.x * horizon + q.y];
+          const int size = comp_size[root];
+          keep[k] = keep_component(size, __popcll(row_mask[root])) ? 1 : 0;
+        }
+      }
+      sum += keep[k];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int x = (t >= off) ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += x;
+      __syncthreads();
+    }
+    int run = carry_s + part[t] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + 4 * t + k;
+      if (i < n && keep[k]) {
+        const float4 p = cloud_scan[sc.pt0 + i];
+        const int2 q = rc[sc.pt0 + i];
+        const long long cell = sc.cell0 + (long long)q.x * horizon + q.y;
+        cloud2[sc.pt0 + run] = p;
+        source2[sc.pt0 + run] = source[sc.pt0 + i];
+        ring_col2[sc.pt0 + run] = (q.x << 16) | q.y;
+        range2[sc.pt0 + run] = range_image[cell];
+        atomicMax(image_to_point2 + cell, run);                     // several points of one cell: the last one stays (:1556)
+        atomicAdd(&kept_ring[q.x], 1);
+        ++run;
+      }
+    }
+    __syncthreads();
+    if (t == 1023) carry_s += part[1023];
+    __syncthreads();
+  }
+  if (t < kMaxRings) ring_count2[(size_t)s * kMaxRings + t] = t < rings ? kept_ring[t] : 0;
+  if (t == 0) { counts[2 * s] = n; counts[2 * s + 1] = carry_s; }
+}
+
+// ---- K22: adaptive-window curvature (:623-657), one thread per kept point ------------------------------------------------------
+// Kept as upstream, including the right-hand walk guarded by the LEFT index and the window test that looks at the left end
+// twice; where upstream would read past the end of the cloud (undefined behaviour) the walk stops and the point has no curvature.
+__global__ __launch_bounds__(256) void k_curvature(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, const int* __restrict__ ring_count2,
+                                                   const int* __restrict__ counts, const float4* __restrict__ cloud2, const float* __restrict__ range2,
+                                                   float* __restrict__ curvature, int* __restrict__ half_window) {
+  __shared__ int begin[kMaxRings + 1];
+  const PtBlock b = blocks[blockIdx.x];
+  const RingScan sc = scans[b.scan];
+  const int n = counts[2 * b.scan + 1];
+  if (b.first >= n) return;
+  if (threadIdx.x == 0) { int run = 0; for (int r = 0; r < kMaxRings; ++r) { begin[r] = run; run += ring_count2[(size_t)b.scan * kMaxRings + r]; } begin[kMaxRings] = run; }
+  __syncthreads();
+  const int i = b.first + threadIdx.x;
+  if (i >= n) return;
+  const Point* P = reinterpret_cast<const Point*>(cloud2 + sc.pt0);
+  const int ring = (int)P[i].w;
+  float curv; int half;
+  curvature_point(P, range2 + sc.pt0, n, begin[ring] + 5, begin[ring + 1] - 6, i, &curv, &half);
+  curvature[sc.pt0 + i] = curv; half_window[sc.pt0 + i] = half;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------
+struct pvlm_ring_batch {
+  pvlm_ctx* ctx = nullptr;
+  int n_scans = 0, rings = 0, horizon = 0, segment = 0;
+  long long total_points = 0, total_cells = 0;
+  std::vector<RingScan> scans;
+  std::vector<int> counts;            // 2 per scan: reordered, kept
+  std::vector<int> ring_count, ring_count2;   // kMaxRings per scan
+  std::vector<int> resolved_points, resolved_edges, replayed;
+  // device (pool)
+  RingScan* d_scans = nullptr;
+  float4* d_cloud_scan = nullptr; int2* d_rc = nullptr; float* d_range_image = nullptr; int* d_image_to_point = nullptr;
+  float4* d_cloud2 = nullptr; int* d_image_to_point2 = nullptr;
+  // pinned host results: kept state, 5 arrays of total_points
+  char* h_results = nullptr;
+  const int* h_source = nullptr; const int* h_ring_col = nullptr; const float* h_curvature = nullptr; const int* h_half = nullptr; const float* h_range = nullptr;
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+extern "C" pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* b);
+
+// scratch of one run, back to the pool on every exit path
+struct RingScratch {
+  pvlm_ctx* ctx; std::vector<void*> p;
+  ~RingScratch() { for (void* q : p) pvlm_i_free(ctx, q); }
+  template <typename T> pvlm_status get(T** d, size_t count) { const pvlm_status st = pvlm_i_alloc(ctx, d, count); if (!st) p.push_back(*d); return st; }
+};
+
+static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, long long total) {
+  B->ctx = ctx; B->n_scans = n_scans; B->rings = n_rings; B->horizon = horizon; B->segment = segment ? 1 : 0;
+  const int cells = n_rings * horizon;
+  B->total_points = total; B->total_cells = (long long)n_scans * cells;
+  B->scans.resize((size_t)n_scans); B->counts.assign((size_t)n_scans * 2, 0);
+  B->ring_count.assign((size_t)n_scans * kMaxRings, 0); B->ring_count2.assign((size_t)n_scans * kMaxRings, 0);
+  B->resolved_points.assign((size_t)n_scans, 0); B->resolved_edges.assign((size_t)n_scans, 0); B->replayed.assign((size_t)n_scans, 0);
+  std::vector<PtBlock> blocks;
+  {
+    long long pt0 = 0;
+    for (int s = 0; s < n_scans; ++s) {
+      RingScan& sc = B->scans[(size_t)s];
+      sc.pt0 = pt0; sc.cell0 = (long long)s * cells; sc.n = raw_scans[s].n; sc.pad = 0; sc.start_ori = 0;
+      if (sc.n > 0) sc.start_ori = ori_of_atan2(std::atan2(raw_scans[s].xyzi[0], raw_scans[s].xyzi[2]));   // float overload, :397-399
+      for (int f = 0; f < sc.n; f += 256) blocks.push_back(PtBlock{s, f});
+      pt0 += sc.n;
+    }
+  }
+  if (n_scans == 0 || total == 0) return PVLM_OK;
+  // ---- device memory: everything from the context's pool; the scratch goes back at the end of the call
+  RingScratch tmp{ctx, {}};
+  const size_t NP = (size_t)total, NC = (size_t)B->total_cells;
+  float4* d_raw = nullptr; float* d_az = nullptr; signed char* d_ring = nullptr; unsigned char* d_exact = nullptr; int* d_listed = nullptr; int* d_counter = nullptr;
+  int2* d_colpos = nullptr; int* d_ring_count = nullptr; int2* d_status = nullptr; PtBlock* d_blocks = nullptr; int* d_source = nullptr; int* d_winner = nullptr;
+  unsigned char* d_edges = nullptr; EdgeQuery* d_queries = nullptr; int* d_parent = nullptr; int* d_root = nullptr; int* d_comp_size = nullptr;
+  unsigned long long* d_row_mask = nullptr; int* d_source2 = nullptr; int* d_ring_col2 = nullptr; float* d_range2 = nullptr; int* d_ring_count2 = nullptr;
+  int* d_counts = nullptr; float* d_curv = nullptr; int* d_half = nullptr;
+  const int query_cap = 1 << 16;
+  pvlm_status st = PVLM_OK;
+#define RING_GET(ptr, count) if (!st) st = tmp.get(&ptr, count)
+#define RING_KEEP(ptr, count) if (!st) st = pvlm_i_alloc(ctx, &ptr, count)
+  RING_KEEP(B->d_scans, (size_t)n_scans); RING_KEEP(B->d_cloud_scan, NP); RING_KEEP(B->d_rc, NP); RING_KEEP(B->d_range_image, NC);
+  RING_KEEP(B->d_image_to_point, NC); RING_KEEP(B->d_cloud2, NP); RING_KEEP(B->d_image_to_point2, NC);
+  RING_GET(d_raw, NP); RING_GET(d_az, NP); RING_GET(d_ring, NP); RING_GET(d_exact, NP); RING_GET(d_listed, NP); RING_GET(d_counter, 4);
+  RING_GET(d_colpos, NP); RING_GET(d_ring_count, (size_t)n_scans * kMaxRings); RING_GET(d_status, (size_t)n_scans); RING_GET(d_blocks, blocks.size());
+  RING_GET(d_source, NP); RING_GET(d_winner, NC); RING_GET(d_edges, NC + 4); RING_GET(d_queries, (size_t)query_cap); RING_GET(d_parent, NC);
+  RING_GET(d_root, NC); RING_GET(d_comp_size, NC); RING_GET(d_row_mask, NC); RING_GET(d_source2, NP); RING_GET(d_ring_col2, NP); RING_GET(d_range2, NP);
+  RING_GET(d_ring_count2, (size_t)n_scans * kMaxRings); RING_GET(d_counts, (size_t)n_scans * 2); RING_GET(d_curv, NP); RING_GET(d_half, NP);
+#undef RING_GET
+#undef RING_KEEP
+  if (st) return (st);
+  // ---- pinned buffer: raw points on the way up (16 B / point), the five result arrays on the way down (20 B / point)
+  const size_t pinned = NP * 20 + 256;
+  if (hipHostMalloc((void**)&B->h_results, pinned, hipHostMallocDefault) != hipSuccess) { B->h_results = nullptr; PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %zu bytes of pinned memory unavailable", pinned); return (PVLM_ERR_NOMEM); }
+  hipStream_t S = ctx->stream;
+  hipEvent_t ev[9];
+  for (hipEvent_t& e : ev) if (hipEventCreate(&e) != hipSuccess) { PVLM_SET_ERR(ctx, "hipEventCreate failed"); return (PVLM_ERR_HIP); }
+  struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int k = 0; k < 9; ++k) (void)hipEventDestroy(e[k]); } } evg{ev};
+  {   // staging copy, scan-parallel (a scan's points are contiguous when stride_floats == 4)
+    float4* h = (float4*)B->h_results;
+    std::atomic<int> next{0};
+    std::atomic<long long> bad{-1};
+    auto work = [&]() {
+      for (int s = next++; s < n_scans; s = next++) {
+        const pvlm_raw_scan& r = raw_scans[s];
+        float4* d = h + B->scans[(size_t)s].pt0;
+        if (r.stride_floats == 4) std::memcpy(d, r.xyzi, (size_t)r.n * 16);
+        else for (int i = 0; i < r.n; ++i) { const float* p = r.xyzi + (size_t)i * r.stride_floats; d[i] = make_float4(p[0], p[1], p[2], p[3]); }
+        for (int i = 0; i < r.n; ++i)
+          if (!std::isfinite(d[i].x) || !std::isfinite(d[i].y) || !std::isfinite(d[i].z)) { bad = B->scans[(size_t)s].pt0 + i; break; }
+      }
+    };
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)n_scans / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    std::vector<std::thread> pool;
+    try { for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work); } catch (...) {}   // fewer workers: the calling thread does the rest
+    try { work(); } catch (...) { for (std::thread& t : pool) t.join(); throw; }
+    for (std::thread& t : pool) t.join();
+    if (bad >= 0) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: non-finite coordinate (point %lld of the batch)", (long long)bad); return PVLM_ERR_ARG; }
+  }
+  (void)hipEventRecord(ev[0], S);
+  PVLM_HIP(ctx, hipMemcpyAsync(d_raw, B->h_results, NP * 16, hipMemcpyHostToDevice, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(B->d_scans, B->scans.data(), (size_t)n_scans * sizeof(RingScan), hipMemcpyHostToDevice, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(PtBlock), hipMemcpyHostToDevice, S));
+  PVLM_HIP(ctx, hipMemsetAsync(d_counter, 0, 4 * sizeof(int), S));
+  PVLM_HIP(ctx, hipMemsetAsync(d_winner, 0xFF, NC * sizeof(int), S));
+  PVLM_HIP(ctx, hipMemsetAsync(B->d_range_image, 0, NC * sizeof(float), S));
+  PVLM_HIP(ctx, hipMemsetAsync(B->d_image_to_point, 0xFF, NC * sizeof(int), S));
+  (void)hipEventRecord(ev[1], S);
+  // ---- K16 + the host's libm for the listed points
+  hipLaunchKernelGGL(k_ring_classify, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, n_rings, horizon, d_raw, d_az, d_ring, d_exact, d_counter, d_listed);
+  int h_counter[4] = {0, 0, 0, 0};
+  PVLM_HIP(ctx, hipMemcpyAsync(h_counter, d_counter, sizeof(int), hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipStreamSynchronize(S));      // also: the staging buffer is free again
+  auto scan_of = [&](long long at) { int lo = 0, hi = n_scans - 1; while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (B->scans[(size_t)mid].pt0 <= at) lo = mid; else hi = mid - 1; } return lo; };
+  auto exact_of = [&](long long at, PointPatch* pp) {
+    const int s = scan_of(at);
+    const pvlm_raw_scan& r = raw_scans[s];
+    const float* p = r.xyzi + (size_t)(at - B->scans[(size_t)s].pt0) * r.stride_floats;
+    const float q = -p[1] / std::sqrt(p[0] * p[0] + p[2] * p[2]);
+    pp->at = (int)at; pp->az = std::atan2(p[0], p[2]); pp->ring = q == q ? ring_of_atan(std::atan(q), n_rings) : -1;
+    return s;
+  };
+  std::vector<PointPatch> patches;
+  PointPatch* d_patch = nullptr;
+  auto send_patches = [&]() -> pvlm_status {
+    if (patches.empty()) return PVLM_OK;
+    pvlm_i_free(ctx, d_patch); d_patch = nullptr;
+    pvlm_status s2 = pvlm_i_alloc(ctx, &d_patch, patches.size());
+    if (s2) return s2;
+    PVLM_HIP(ctx, hipMemcpyAsync(d_patch, patches.data(), patches.size() * sizeof(PointPatch), hipMemcpyHostToDevice, S));
+    hipLaunchKernelGGL(k_ring_patch, dim3((unsigned)((patches.size() + 255) / 256)), dim3(256), 0, S, (int)patches.size(), d_patch, d_az, d_ring, d_exact);
+    PVLM_HIP(ctx, hipStreamSynchronize(S));     // `patches` is pageable
+    return PVLM_OK;
+  };
+  if (h_counter[0] > 0) {
+    std::vector<int> listed((size_t)h_counter[0]);
+    PVLM_HIP(ctx, hipMemcpy(listed.data(), d_listed, listed.size() * sizeof(int), hipMemcpyDeviceToHost));
+    patches.resize(listed.size());
+    for (size_t k = 0; k < listed.size(); ++k) B->resolved_points[(size_t)exact_of(listed[k], &patches[k])]++;
+    if ((st = send_patches())) { pvlm_i_free(ctx, d_patch); return (st); }
+  }
+  (void)hipEventRecord(ev[2], S);
+  // ---- K17; a scan whose +z crossing stays undecided gets the host's azimuths for the points of that comparison and is replayed
+  hipLaunchKernelGGL(k_ring_columns, dim3((unsigned)((n_scans + 63) / 64)), dim3(64), 0, S, B->d_scans, (const int*)nullptr, n_scans, n_rings, horizon, d_az, d_ring, d_exact,
+                     d_colpos, d_ring_count, d_status);
+  std::vector<int2> status((size_t)n_scans, make_int2(-1, -1));
+  PVLM_HIP(ctx, hipMemcpyAsync(status.data(), d_status, (size_t)n_scans * sizeof(int2), hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipStreamSynchronize(S));
+  for (int round = 0;; ++round) {
+    std::vector<int> again;
+    for (int s = 0; s < n_scans; ++s) if (status[(size_t)s].x >= 0) again.push_back(s);
+    if (again.empty()) break;
+    patches.clear();
+    for (int s : again) {
+      const RingScan& sc = B->scans[(size_t)s];
+      B->replayed[(size_t)s]++;
+      const int at = status[(size_t)s].x, last = status[(size_t)s].y;
+      // after 64 rounds (never seen): the whole scan from the host libm, which cannot be undecided
+      const int lo = round < 64 ? at : 0, hi = round < 64 ? std::min(sc.n, at + n_rings + 1) : sc.n;
+      PointPatch pp;
+      if (round < 64 && last >= 0) { exact_of(sc.pt0 + last, &pp); patches.push_back(pp); }
+      for (int i = lo; i < hi; ++i) { exact_of(sc.pt0 + i, &pp); patches.push_back(pp); }
+    }
+    if ((st = send_patches())) { pvlm_i_free(ctx, d_patch); return (st); }
+    int* d_again = nullptr;
+    if ((st = pvlm_i_alloc(ctx, &d_again, again.size()))) { pvlm_i_free(ctx, d_patch); return (st); }
+    hipError_t e = hipMemcpyAsync(d_again, again.data(), again.size() * sizeof(int), hipMemcpyHostToDevice, S);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_ring_columns, dim3((unsigned)((again.size() + 63) / 64)), dim3(64), 0, S, B->d_scans, (const int*)d_again, (int)again.size(), n_rings, horizon, d_az,
+                         d_ring, d_exact, d_colpos, d_ring_count, d_status);
+      e = hipMemcpyAsync(status.data(), d_status, (size_t)n_scans * sizeof(int2), hipMemcpyDeviceToHost, S);
+      if (e == hipSuccess) e = hipStreamSynchronize(S);
+    }
+    pvlm_i_free(ctx, d_again);
+    if (e != hipSuccess) { pvlm_i_free(ctx, d_patch); PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: replay failed: %s", hipGetErrorString(e)); return (PVLM_ERR_HIP); }
+  }
+  pvlm_i_free(ctx, d_patch); d_patch = nullptr;
+  (void)hipEventRecord(ev[3], S);
+  // ---- K18
+  hipLaunchKernelGGL(k_ring_scatter, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, horizon, d_raw, d_ring, d_colpos, d_ring_count, B->d_cloud_scan, d_source,
+                     B->d_rc, d_winner);
+  hipLaunchKernelGGL(k_ring_cells, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, horizon, d_raw, d_ring, d_colpos, d_ring_count, d_winner, B->d_range_image,
+                     B->d_image_to_point);
+  (void)hipEventRecord(ev[4], S);
+  // ---- K19 / K20: segmentation
+  const dim3 cell_grid((unsigned)((cells + 255) / 256), (unsigned)n_scans);
+  if (B->segment) {
+    // the constants of :1459-1462 and their sin / cos (:1510), float libm of the host
+    const float alpha_x = 0.2 / 180.0 * M_PI, alpha_y = 2.0 / 180.0 * M_PI, theta = 20.0 / 180.0 * M_PI;
+    const float sin_x = std::sin(alpha_x), cos_x = std::cos(alpha_x), sin_y = std::sin(alpha_y), cos_y = std::cos(alpha_y);
+    hipLaunchKernelGGL(k_seg_edges, cell_grid, dim3(256), 0, S, B->d_scans, n_rings, horizon, B->d_range_image, sin_x, cos_x, sin_y, cos_y, theta, d_edges, d_counter + 1, d_queries, query_cap);
+    hipLaunchKernelGGL(k_seg_init, cell_grid, dim3(256), 0, S, B->d_scans, cells, d_parent, d_comp_size, d_row_mask, B->d_image_to_point2);
+    PVLM_HIP(ctx, hipMemcpyAsync(h_counter + 1, d_counter + 1, sizeof(int), hipMemcpyDeviceToHost, S));
+    PVLM_HIP(ctx, hipStreamSynchronize(S));
+    if (h_counter[1] > query_cap) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %d undecided segmentation edges (capacity %d)", h_counter[1], query_cap); return (PVLM_ERR_CAPACITY); }
+    if (h_counter[1] > 0) {
+      std::vector<EdgeQuery> q((size_t)h_counter[1]);
+      PVLM_HIP(ctx, hipMemcpy(q.data(), d_queries, q.size() * sizeof(EdgeQuery), hipMemcpyDeviceToHost));
+      std::vector<EdgePatch> ep;
+      for (const EdgeQuery& e : q) {
+        B->resolved_edges[(size_t)(e.cell / cells)]++;
+        if (std::atan2(e.y, e.x) > theta) ep.push_back(EdgePatch{e.cell, e.bit});
+      }
+      if (!ep.empty()) {
+        EdgePatch* d_ep = nullptr;
+        if ((st = pvlm_i_alloc(ctx, &d_ep, ep.size()))) return (st);
+        hipError_t e = hipMemcpyAsync(d_ep, ep.data(), ep.size() * sizeof(EdgePatch), hipMemcpyHostToDevice, S);
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_seg_patch, dim3((unsigned)((ep.size() + 255) / 256)), dim3(256), 0, S, (int)ep.size(), d_ep, d_edges); e = hipStreamSynchronize(S); }
+        pvlm_i_free(ctx, d_ep);
+        if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: edge patch failed: %s", hipGetErrorString(e)); return (PVLM_ERR_HIP); }
+      }
+    }
+    (void)hipEventRecord(ev[5], S);
+    hipLaunchKernelGGL(k_seg_union, cell_grid, dim3(256), 0, S, B->d_scans, n_rings, horizon, d_edges, d_parent);
+    hipLaunchKernelGGL(k_seg_stats, cell_grid, dim3(256), 0, S, B->d_scans, n_rings, horizon, d_parent, d_root, d_comp_size, d_row_mask);
+  } else {
+    PVLM_HIP(ctx, hipMemsetAsync(B->d_image_to_point2, 0xFF, NC * sizeof(int), S));
+    (void)hipEventRecord(ev[5], S);
+  }
+  (void)hipEventRecord(ev[6], S);
+  // ---- K21 / K22
+  hipLaunchKernelGGL(k_seg_compact, dim3((unsigned)n_scans), dim3(1024), 0, S, B->d_scans, n_rings, horizon, B->segment, d_ring_count, B->d_cloud_scan, d_source, B->d_rc,
+                     B->d_range_image, d_root, d_comp_size, d_row_mask, B->d_cloud2, d_source2, d_ring_col2, d_range2, B->d_image_to_point2, d_ring_count2, d_counts);
+  hipLaunchKernelGGL(k_curvature, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, d_ring_count2, d_counts, B->d_cloud2, d_range2, d_curv, d_half);
+  (void)hipEventRecord(ev[7], S);
+  // ---- results
+  char* h = B->h_results;
+  B->h_source = (const int*)h; B->h_ring_col = (const int*)(h + NP * 4); B->h_curvature = (const float*)(h + NP * 8); B->h_half = (const int*)(h + NP * 12);
+  B->h_range = (const float*)(h + NP * 16);
+  PVLM_HIP(ctx, hipMemcpyAsync(h, d_source2, NP * 4, hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 4, d_ring_col2, NP * 4, hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 8, d_curv, NP * 4, hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 12, d_half, NP * 4, hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16, d_range2, NP * 4, hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(B->counts.data(), d_counts, (size_t)n_scans * 2 * sizeof(int), hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(B->ring_count.data(), d_ring_count, (size_t)n_scans * kMaxRings * sizeof(int), hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(B->ring_count2.data(), d_ring_count2, (size_t)n_scans * kMaxRings * sizeof(int), hipMemcpyDeviceToHost, S));
+  (void)hipEventRecord(ev[8], S);
+  PVLM_HIP(ctx, hipStreamSynchronize(S));
+  for (int k = 0; k < 8; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, ev[k], ev[k + 1]) == hipSuccess) B->ms[k] = ms; }
+  return PVLM_OK;
+}
+
+extern "C" {
+
+pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* b) {
+  if (!b) return PVLM_OK;
+  if (!ctx) ctx = b->ctx;
+  if (ctx) {
+    (void)pvlm_i_bind(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
+    pvlm_i_free(ctx, b->d_scans); pvlm_i_free(ctx, b->d_cloud_scan); pvlm_i_free(ctx, b->d_rc); pvlm_i_free(ctx, b->d_range_image);
+    pvlm_i_free(ctx, b->d_image_to_point); pvlm_i_free(ctx, b->d_cloud2); pvlm_i_free(ctx, b->d_image_to_point2);
+  }
+  if (b->h_results) (void)hipHostFree(b->h_results);
+  delete b;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ring_extract_batch(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, pvlm_ring_batch** out) {
+  if (!ctx || !out || n_scans < 0 || (n_scans > 0 && !raw_scans)) return PVLM_ERR_ARG;
+  *out = nullptr;
+  if ((n_rings != 16 && n_rings != 32 && n_rings != 64) || horizon <= 0 || horizon > 65535) {
+    PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %d rings x %d columns is not a supported range image (16 / 32 / 64 rings, 1..65535 columns)", n_rings, horizon);
+    return PVLM_ERR_ARG;
+  }
+  long long total = 0;
+  for (int s = 0; s < n_scans; ++s) {
+    if (raw_scans[s].n < 0 || (raw_scans[s].n > 0 && !raw_scans[s].xyzi) || raw_scans[s].stride_floats < 4) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: bad descriptor (scan %d)", s); return PVLM_ERR_ARG; }
+    total += raw_scans[s].n;
+  }
+  if (total >= (1ll << 31) || (long long)n_scans * n_rings * horizon >= (1ll << 31)) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: batch too large (split it)"); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (ctx->capturing) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch inside a graph capture"); return PVLM_ERR_STATE; }
+  pvlm_ring_batch* B = new (std::nothrow) pvlm_ring_batch();
+  if (!B) return PVLM_ERR_NOMEM;
+  pvlm_status st = PVLM_ERR_HIP;
+  try {
+    st = ring_run(ctx, B, n_scans, raw_scans, n_rings, horizon, segment, total);
+  } catch (const std::bad_alloc&) {
+    PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: out of host memory");
+    st = PVLM_ERR_NOMEM;
+  } catch (...) {
+    PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: unexpected host exception");
+    st = PVLM_ERR_HIP;
+  }
+  if (st) { (void)hipStreamSynchronize(ctx->stream); pvlm_ring_batch_destroy(ctx, B); return st; }
+  *out = B;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ring_batch_scan(const pvlm_ring_batch* b, int scan, pvlm_ring_result* r) {
+  if (!b || !r || scan < 0 || scan >= b->n_scans) return PVLM_ERR_ARG;
+  const RingScan& sc = b->scans[(size_t)scan];
+  std::memset(r, 0, sizeof(*r));
+  r->n_raw = sc.n;
+  r->n_reordered = b->counts[(size_t)scan * 2]; r->n_kept = b->counts[(size_t)scan * 2 + 1];
+  r->resolved_points = b->resolved_points[(size_t)scan]; r->resolved_edges = b->resolved_edges[(size_t)scan]; r->replayed = b->replayed[(size_t)scan];
+  r->ring_count_reordered = b->ring_count.data() + (size_t)scan * kMaxRings;
+  r->ring_count = b->ring_count2.data() + (size_t)scan * kMaxRings;
+  if (b->h_source) {
+    r->source = b->h_source + sc.pt0; r->ring_col = b->h_ring_col + sc.pt0; r->curvature = b->h_curvature + sc.pt0; r->half_window = b->h_half + sc.pt0;
+    r->range = b->h_range + sc.pt0;
+  }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ring_batch_timing(const pvlm_ring_batch* b, double* ms8) {
+  if (!b || !ms8) return PVLM_ERR_ARG;
+  for (int k = 0; k < 8; ++k) ms8[k] = b->ms[k];
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ring_batch_fetch(pvlm_ctx* ctx, const pvlm_ring_batch* b, int scan, int state, float* cloud_xyzi, int* ring_col_pairs, float* range_image,
+                                  int* image_to_point) {
+  if (!ctx || !b || scan < 0 || scan >= b->n_scans || (state != 0 && state != 1)) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const RingScan& sc = b->scans[(size_t)scan];
+  const int n = b->counts[(size_t)scan * 2 + state];
+  const size_t cells = (size_t)b->rings * b->horizon;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (cloud_xyzi && n > 0) PVLM_HIP(ctx, hipMemcpy(cloud_xyzi, (state ? b->d_cloud2 : b->d_cloud_scan) + sc.pt0, (size_t)n * 16, hipMemcpyDeviceToHost));
+  if (ring_col_pairs && n > 0) {
+    if (state == 0) PVLM_HIP(ctx, hipMemcpy(ring_col_pairs, b->d_rc + sc.pt0, (size_t)n * 8, hipMemcpyDeviceToHost));
+    else for (int i = 0; i < n; ++i) { const int v = b->h_ring_col[sc.pt0 + i]; ring_col_pairs[2 * i] = v >> 16; ring_col_pairs[2 * i + 1] = v & 0xFFFF; }
+  }
+  if (range_image) PVLM_HIP(ctx, hipMemcpy(range_image, b->d_range_image + sc.cell0, cells * 4, hipMemcpyDeviceToHost));
+  if (image_to_point) PVLM_HIP(ctx, hipMemcpy(image_to_point, (state ? b->d_image_to_point2 : b->d_image_to_point) + sc.cell0, cells * 4, hipMemcpyDeviceToHost));
+  return PVLM_OK;
+}
+
+}  // extern "C"
