@@ -74,6 +74,8 @@ struct pvlm_ctx {
   double* d_neq_tmp = nullptr; size_t neq_tmp_count = 0;
   // pinned staging of pvlm_scan_upload[_batch] (grow-only)
   void* h_up = nullptr; size_t up_bytes = 0;
+  // pinned buffer a destroyed pvlm_ring_batch leaves behind for the next one (hipHostMalloc of a Room batch's 260 MB: 51 ms)
+  void* h_ring = nullptr; size_t ring_bytes = 0;
   // pinned staging arena of every other host <-> device copy (pvlm_i_h2d_q / pvlm_i_d2h_q / pvlm_i_sync)
   pvlm_stage stage;
   hipStream_t own_stream = nullptr;

@@ -36,11 +36,11 @@ namespace {
 struct PtBlock { int scan, first; };   // 256 points of one scan
 
 // ---- K16: per raw point — ring and azimuth with their certificates -----------------------------------------------------
-// az[i] = the float nearest to the true atan2(x, z); ring[i] = the ring every float within kUlps of the true atan() gives, or the
-// point is listed; likewise the column (for both states of the +z crossing).  exact[i] = 0.
+// rec = (the float nearest to the true atan2(x, z), the ring every float within kUlps of the true atan() gives), or the point is listed;
+// likewise the column (for both states of the +z crossing).  Stored in the chunk-transposed order K17 walks (chunk_slot).
 __global__ __launch_bounds__(256) void k_ring_classify(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, int rings, int horizon,
-                                                       const float4* __restrict__ raw, float* __restrict__ az, signed char* __restrict__ ring,
-                                                       unsigned char* __restrict__ exact, int* __restrict__ n_listed, int* __restrict__ listed) {
+                                                       const float4* __restrict__ raw, PointRec* __restrict__ rec, int* __restrict__ n_listed,
+                                                       int* __restrict__ listed) {
   const PtBlock b = blocks[blockIdx.x];
   const RingScan sc = scans[b.scan];
   const int i = b.first + threadIdx.x;
@@ -48,47 +48,44 @@ __global__ __launch_bounds__(256) void k_ring_classify(const RingScan* __restric
   const float4 p = raw[sc.pt0 + i];
   float f; int r;
   const bool list = classify_point(sc, rings, horizon, p.x, p.y, p.z, &f, &r);
-  az[sc.pt0 + i] = f;
-  ring[sc.pt0 + i] = (signed char)r;
-  exact[sc.pt0 + i] = 0;
+  rec[sc.slot0 + chunk_slot(i, chunk_of(sc.n, kColumnThreads), kColumnThreads)] = make_rec(f, r, false);
   if (list) listed[atomicAdd(n_listed, 1)] = (int)(sc.pt0 + i);
 }
 
-struct PointPatch { int at; float az; int ring; };
-__global__ void k_ring_patch(int n, const PointPatch* __restrict__ patch, float* __restrict__ az, signed char* __restrict__ ring, unsigned char* __restrict__ exact) {
+struct PointPatch { long long slot; float az; int ring; };
+__global__ void k_ring_patch(int n, const PointPatch* __restrict__ patch, PointRec* __restrict__ rec) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const PointPatch p = patch[k];
-  az[p.at] = p.az; ring[p.at] = (signed char)p.ring; exact[p.at] = 1;
+  rec[p.slot] = make_rec(p.az, p.ring, true);
 }
 
-// ---- K17: the column state machine of :431-507, one lane per scan ---------------------------------------------------------
-// The loop carries five scalars from point to point (crossed, last azimuth, column offset, last column, last ring): it is
-// replayed as written, one scan per lane, over the per-point values K16 prepared; the heavy arithmetic is all in K16.
+// ---- K17: the column state machine of :431-507, one workgroup per scan ----------------------------------------------------------
+// columns_block (pvlm_ring_core.h): the loop's five carried scalars decompose into block-wide prefix scans (offset functions,
+// last accepted point, per-ring counts); with one lane per scan — the loop replayed as written — a Room batch took 48 ms.
 // colpos[i] = (column or -1, position of the point inside its ring).  status: (-1, .) = done, (i, last) = the +z crossing could not be
-// certified at point i against the azimuth of point `last` (see columns_scan).
-__global__ __launch_bounds__(64) void k_ring_columns(const RingScan* __restrict__ scans, const int* __restrict__ todo, int n_todo, int rings, int horizon,
-                                                     const float* __restrict__ az, const signed char* __restrict__ ring, const unsigned char* __restrict__ exact,
-                                                     int2* __restrict__ colpos, int* __restrict__ ring_count, int2* __restrict__ status) {
-  __shared__ int cnt[kMaxRings * 64];
-  const int lane = threadIdx.x;
-  const int t = blockIdx.x * 64 + lane;
-  for (int r = 0; r < rings; ++r) cnt[r * 64 + lane] = 0;
-  if (t >= n_todo) return;
-  const int s = todo ? todo[t] : t;
+// certified at point i against the azimuth of point `last`.
+struct BlockExec {
+  __device__ int threads() const { return (int)blockDim.x; }
+  template <class F> __device__ void phase(F&& f) { f((int)threadIdx.x); __syncthreads(); }
+};
+__global__ __launch_bounds__(1024) void k_ring_columns(const RingScan* __restrict__ scans, const int* __restrict__ todo, int rings, int horizon,
+                                                       const PointRec* __restrict__ rec, int2* __restrict__ colpos, int* __restrict__ ring_count,
+                                                       int2* __restrict__ status) {
+  __shared__ int scratch[kColumnsScratch * 1024];     // 88 KB: one workgroup per CU
+  const int s = todo ? todo[blockIdx.x] : (int)blockIdx.x;
   const RingScan sc = scans[s];
+  BlockExec ex;
   int last = -1;
-  const int stuck = columns_scan(sc, rings, horizon, az + sc.pt0, ring + sc.pt0, exact + sc.pt0, reinterpret_cast<int*>(colpos + sc.pt0),
-                                 [&](int r) -> int& { return cnt[r * 64 + lane]; }, &last);
-  status[s] = make_int2(stuck, last);
-  for (int r = 0; r < kMaxRings; ++r) ring_count[(size_t)s * kMaxRings + r] = r < rings ? cnt[r * 64 + lane] : 0;
+  const int stuck = columns_block(ex, sc, rings, horizon, rec + sc.slot0, reinterpret_cast<int*>(colpos + sc.slot0), ring_count + (size_t)s * kMaxRings, &last, scratch);
+  if (threadIdx.x == 0) status[s] = make_int2(stuck, last);
 }
 
 // ---- K18: ring-ordered cloud, (ring, column) of every point, range image ---------------------------------------------------
 // Several returns can land in one cell; the reference's loops leave the LAST one (in cloud order) in range_image and in
 // image_to_point_idx (:497-499, :513-517): atomicMax over the raw index picks it, the second pass writes it.
 __global__ __launch_bounds__(256) void k_ring_scatter(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, int horizon,
-                                                      const float4* __restrict__ raw, const signed char* __restrict__ ring, const int2* __restrict__ colpos,
+                                                      const float4* __restrict__ raw, const PointRec* __restrict__ rec, const int2* __restrict__ colpos,
                                                       const int* __restrict__ ring_count, float4* __restrict__ cloud_scan, int* __restrict__ source,
                                                       int2* __restrict__ rc, int* __restrict__ winner) {
   __shared__ int begin[kMaxRings];
@@ -98,9 +95,10 @@ __global__ __launch_bounds__(256) void k_ring_scatter(const RingScan* __restrict
   __syncthreads();
   const int i = b.first + threadIdx.x;
   if (i >= sc.n) return;
-  const int2 cp = colpos[sc.pt0 + i];
+  const long long at = sc.slot0 + chunk_slot(i, chunk_of(sc.n, kColumnThreads), kColumnThreads);
+  const int2 cp = colpos[at];
   if (cp.x < 0) return;
-  const int r = ring[sc.pt0 + i];
+  const int r = rec_ring(rec[at]);
   const int dst = begin[r] + cp.y;
   const float4 p = raw[sc.pt0 + i];
   cloud_scan[sc.pt0 + dst] = make_float4(p.x, p.y, p.z, (float)r);
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(256) void k_ring_scatter(const RingScan* __restrict
   atomicMax(&winner[sc.cell0 + (long long)r * horizon + cp.x], i);
 }
 __global__ __launch_bounds__(256) void k_ring_cells(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, int horizon,
-                                                    const float4* __restrict__ raw, const signed char* __restrict__ ring, const int2* __restrict__ colpos,
+                                                    const float4* __restrict__ raw, const PointRec* __restrict__ rec, const int2* __restrict__ colpos,
                                                     const int* __restrict__ ring_count, const int* __restrict__ winner, float* __restrict__ range_image,
                                                     int* __restrict__ image_to_point) {
   __shared__ int begin[kMaxRings];
@@ -119,9 +117,10 @@ __global__ __launch_bounds__(256) void k_ring_cells(const RingScan* __restrict__
   __syncthreads();
   const int i = b.first + threadIdx.x;
   if (i >= sc.n) return;
-  const int2 cp = colpos[sc.pt0 + i];
+  const long long at = sc.slot0 + chunk_slot(i, chunk_of(sc.n, kColumnThreads), kColumnThreads);
+  const int2 cp = colpos[at];
   if (cp.x < 0) return;
-  const int r = ring[sc.pt0 + i];
+  const int r = rec_ring(rec[at]);
   const long long cell = sc.cell0 + (long long)r * horizon + cp.x;
   if (winner[cell] != i) return;
   const float4 p = raw[sc.pt0 + i];
@@ -162,13 +161,21 @@ __global__ void k_seg_patch(int n, const EdgePatch* __restrict__ patch, unsigned
 }
 
 // ---- K20: connected components of the joined relation = the BFS labels of :1463-1530 ------------------------------------------
-// Lock-free union-find in HBM (hook the larger root under the smaller by atomicMin: the root of a component is its smallest
-// cell = the seed the reference's raster-order BFS starts from).  Then per component: size and the rows holding a cell other
-// than the seed (lineCountFlag marks pushed cells only; the seed is popped, never pushed, :1473-1476, :1518).
+// The horizontal part of the relation is a set of RUNS along a ring: k_seg_init finds the start of every cell's run with one
+// max-scan per row and makes it the cell's parent (a tree of depth 1), so that the lock-free union-find in HBM only has the
+// vertical edges and the wrap-around edge of each row left (hook the larger root under the smaller by atomicMin: the root of a
+// component is its smallest cell = the seed the reference's raster-order BFS starts from).  Unioning the horizontal edges cell by
+// cell instead built chains as long as a row before any find could shorten them (5.3 ms per Room batch).  Then per component:
+// size and the rows holding a cell other than the seed (lineCountFlag marks pushed cells only; the seed is popped, never pushed,
+// :1473-1476, :1518), with one atomic per run of equal roots inside a wave instead of one per cell.
 __device__ inline int uf_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline int uf_find(const int* parent, int x) {
+__device__ inline int uf_find(int* parent, int x) {
   int r = x;
-  for (int q = uf_load(parent + r); q != r; q = uf_load(parent + r)) r = q;
+  for (int q = uf_load(parent + r); q != r;) {
+    const int g = uf_load(parent + q);
+    if (g != q) __hip_atomic_store(parent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving: an ancestor stays an ancestor
+    r = q; q = g;
+  }
   return r;
 }
 __device__ inline void uf_union(int* parent, int a, int b) {
@@ -181,12 +188,36 @@ __device__ inline void uf_union(int* parent, int a, int b) {
     a = old;
   }
 }
-__global__ __launch_bounds__(256) void k_seg_init(const RingScan* __restrict__ scans, int cells, int* __restrict__ parent, int* __restrict__ comp_size,
-                                                  unsigned long long* __restrict__ row_mask, int* __restrict__ image_to_point2) {
+// grid (rings, scans): parent = start of the cell's run inside the row (runs do not wrap here), the per-cell accumulators cleared
+__global__ __launch_bounds__(256) void k_seg_init(const RingScan* __restrict__ scans, int horizon, const unsigned char* __restrict__ edges, int* __restrict__ parent,
+                                                  int* __restrict__ comp_size, unsigned long long* __restrict__ row_mask, int* __restrict__ image_to_point2) {
+  __shared__ int part[256];
+  __shared__ int carry_s;
   const RingScan sc = scans[blockIdx.y];
-  const int cell = blockIdx.x * 256 + threadIdx.x;
-  if (cell >= cells) return;
-  parent[sc.cell0 + cell] = cell; comp_size[sc.cell0 + cell] = 0; row_mask[sc.cell0 + cell] = 0ull; image_to_point2[sc.cell0 + cell] = -1;
+  const int r = blockIdx.x, t = threadIdx.x;
+  const long long row0 = sc.cell0 + (long long)r * horizon;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < horizon; base += 256) {
+    const int c = base + t;
+    // a run starts at column 0 and wherever the cell on the left is not joined to this one
+    int v = (c < horizon && (c == 0 || !(edges[row0 + c - 1] & 1))) ? c : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int x = t >= off ? part[t - off] : 0;
+      __syncthreads();
+      part[t] = max(part[t], x);
+      __syncthreads();
+    }
+    const int start = max(part[t], carry_s);
+    if (c < horizon) {
+      parent[row0 + c] = r * horizon + start; comp_size[row0 + c] = 0; row_mask[row0 + c] = 0ull; image_to_point2[row0 + c] = -1;
+    }
+    __syncthreads();
+    if (t == 255) carry_s = start;
+    __syncthreads();
+  }
 }
 __global__ __launch_bounds__(256) void k_seg_union(const RingScan* __restrict__ scans, int rings, int horizon, const unsigned char* __restrict__ edges,
                                                    int* __restrict__ parent) {
@@ -197,18 +228,29 @@ __global__ __launch_bounds__(256) void k_seg_union(const RingScan* __restrict__ 
   if (!bits) return;
   const int r = cell / horizon, c = cell - r * horizon;
   int* P = parent + sc.cell0;
-  if (bits & 1) uf_union(P, cell, r * horizon + (c + 1 == horizon ? 0 : c + 1));
+  if ((bits & 1) && c + 1 == horizon) uf_union(P, cell, r * horizon);      // the one horizontal edge the runs do not cover: last column -> first
   if (bits & 2) uf_union(P, cell, cell + horizon);
 }
-__global__ __launch_bounds__(256) void k_seg_stats(const RingScan* __restrict__ scans, int rings, int horizon, const int* __restrict__ parent,
+__global__ __launch_bounds__(256) void k_seg_stats(const RingScan* __restrict__ scans, int rings, int horizon, int* __restrict__ parent,
                                                    int* __restrict__ root_of, int* __restrict__ comp_size, unsigned long long* __restrict__ row_mask) {
   const RingScan sc = scans[blockIdx.y];
   const int cell = blockIdx.x * 256 + threadIdx.x;
-  if (cell >= rings * horizon) return;
-  const int root = uf_find(parent + sc.cell0, cell);
-  root_of[sc.cell0 + cell] = root;
-  atomicAdd(comp_size + sc.cell0 + root, 1);
-  if (cell != root) atomicOr(row_mask + sc.cell0 + root, 1ull << (cell / horizon));
+  const bool live = cell < rings * horizon;
+  int root = -1 - (int)threadIdx.x, row = 0;          // dead lanes: distinct negative values, never equal to a neighbour's root
+  if (live) { root = uf_find(parent + sc.cell0, cell); root_of[sc.cell0 + cell] = root; row = cell / horizon; }
+  // consecutive lanes are consecutive cells: one atomicAdd per run of equal roots, one atomicOr per (run, row) of non-seed cells
+  const int lane = threadIdx.x & 63;
+  const int prev_root = __shfl_up(root, 1, 64), prev_row = __shfl_up(row, 1, 64);
+  const bool head = lane == 0 || prev_root != root;
+  const unsigned long long heads = __ballot(head);
+  if (live && head) {
+    const unsigned long long later = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int len = later ? __builtin_ctzll(later) + 1 : 64 - lane;
+    atomicAdd(comp_size + sc.cell0 + root, len);
+  }
+  const bool counts = live && cell != root;
+  const int prev_counts = __shfl_up(counts ? 1 : 0, 1, 64);
+  if (counts && (head || prev_row != row || !prev_counts)) atomicOr(row_mask + sc.cell0 + root, 1ull << row);
 }
 
 // ---- K21: drop the points of rejected components, ring order kept (:1547-1580); one workgroup per scan -----------------------
@@ -307,7 +349,7 @@ __global__ __launch_bounds__(256) void k_curvature(const RingScan* __restrict__ 
 struct pvlm_ring_batch {
   pvlm_ctx* ctx = nullptr;
   int n_scans = 0, rings = 0, horizon = 0, segment = 0;
-  long long total_points = 0, total_cells = 0;
+  long long total_points = 0, total_cells = 0, total_slots = 0;
   std::vector<RingScan> scans;
   std::vector<int> counts;            // 2 per scan: reordered, kept
   std::vector<int> ring_count, ring_count2;   // kMaxRings per scan
@@ -317,7 +359,7 @@ struct pvlm_ring_batch {
   float4* d_cloud_scan = nullptr; int2* d_rc = nullptr; float* d_range_image = nullptr; int* d_image_to_point = nullptr;
   float4* d_cloud2 = nullptr; int* d_image_to_point2 = nullptr;
   // pinned host results: kept state, 5 arrays of total_points
-  char* h_results = nullptr;
+  char* h_results = nullptr; size_t results_bytes = 0;
   const int* h_source = nullptr; const int* h_ring_col = nullptr; const float* h_curvature = nullptr; const int* h_half = nullptr; const float* h_range = nullptr;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -344,6 +386,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     for (int s = 0; s < n_scans; ++s) {
       RingScan& sc = B->scans[(size_t)s];
       sc.pt0 = pt0; sc.cell0 = (long long)s * cells; sc.n = raw_scans[s].n; sc.pad = 0; sc.start_ori = 0;
+      sc.slot0 = B->total_slots; B->total_slots += chunk_slots(sc.n, kColumnThreads);
       if (sc.n > 0) sc.start_ori = ori_of_atan2(std::atan2(raw_scans[s].xyzi[0], raw_scans[s].xyzi[2]));   // float overload, :397-399
       for (int f = 0; f < sc.n; f += 256) blocks.push_back(PtBlock{s, f});
       pt0 += sc.n;
@@ -352,8 +395,8 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   if (n_scans == 0 || total == 0) return PVLM_OK;
   // ---- device memory: everything from the context's pool; the scratch goes back at the end of the call
   RingScratch tmp{ctx, {}};
-  const size_t NP = (size_t)total, NC = (size_t)B->total_cells;
-  float4* d_raw = nullptr; float* d_az = nullptr; signed char* d_ring = nullptr; unsigned char* d_exact = nullptr; int* d_listed = nullptr; int* d_counter = nullptr;
+  const size_t NP = (size_t)total, NC = (size_t)B->total_cells, NS = (size_t)B->total_slots;
+  float4* d_raw = nullptr; PointRec* d_rec = nullptr; int* d_listed = nullptr; int* d_counter = nullptr;
   int2* d_colpos = nullptr; int* d_ring_count = nullptr; int2* d_status = nullptr; PtBlock* d_blocks = nullptr; int* d_source = nullptr; int* d_winner = nullptr;
   unsigned char* d_edges = nullptr; EdgeQuery* d_queries = nullptr; int* d_parent = nullptr; int* d_root = nullptr; int* d_comp_size = nullptr;
   unsigned long long* d_row_mask = nullptr; int* d_source2 = nullptr; int* d_ring_col2 = nullptr; float* d_range2 = nullptr; int* d_ring_count2 = nullptr;
@@ -364,17 +407,24 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
 #define RING_KEEP(ptr, count) if (!st) st = pvlm_i_alloc(ctx, &ptr, count)
   RING_KEEP(B->d_scans, (size_t)n_scans); RING_KEEP(B->d_cloud_scan, NP); RING_KEEP(B->d_rc, NP); RING_KEEP(B->d_range_image, NC);
   RING_KEEP(B->d_image_to_point, NC); RING_KEEP(B->d_cloud2, NP); RING_KEEP(B->d_image_to_point2, NC);
-  RING_GET(d_raw, NP); RING_GET(d_az, NP); RING_GET(d_ring, NP); RING_GET(d_exact, NP); RING_GET(d_listed, NP); RING_GET(d_counter, 4);
-  RING_GET(d_colpos, NP); RING_GET(d_ring_count, (size_t)n_scans * kMaxRings); RING_GET(d_status, (size_t)n_scans); RING_GET(d_blocks, blocks.size());
+  RING_GET(d_raw, NP); RING_GET(d_rec, NS); RING_GET(d_listed, NP); RING_GET(d_counter, 4);
+  RING_GET(d_colpos, NS); RING_GET(d_ring_count, (size_t)n_scans * kMaxRings); RING_GET(d_status, (size_t)n_scans); RING_GET(d_blocks, blocks.size());
   RING_GET(d_source, NP); RING_GET(d_winner, NC); RING_GET(d_edges, NC + 4); RING_GET(d_queries, (size_t)query_cap); RING_GET(d_parent, NC);
   RING_GET(d_root, NC); RING_GET(d_comp_size, NC); RING_GET(d_row_mask, NC); RING_GET(d_source2, NP); RING_GET(d_ring_col2, NP); RING_GET(d_range2, NP);
   RING_GET(d_ring_count2, (size_t)n_scans * kMaxRings); RING_GET(d_counts, (size_t)n_scans * 2); RING_GET(d_curv, NP); RING_GET(d_half, NP);
 #undef RING_GET
 #undef RING_KEEP
   if (st) return (st);
+  pvlm_i_trace("ring: device memory");
   // ---- pinned buffer: raw points on the way up (16 B / point), the five result arrays on the way down (20 B / point)
   const size_t pinned = NP * 20 + 256;
-  if (hipHostMalloc((void**)&B->h_results, pinned, hipHostMallocDefault) != hipSuccess) { B->h_results = nullptr; PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %zu bytes of pinned memory unavailable", pinned); return (PVLM_ERR_NOMEM); }
+  if (ctx->h_ring && ctx->ring_bytes >= pinned) {
+    B->h_results = (char*)ctx->h_ring; B->results_bytes = ctx->ring_bytes;
+    ctx->h_ring = nullptr; ctx->ring_bytes = 0;
+  } else if (hipHostMalloc((void**)&B->h_results, pinned, hipHostMallocDefault) == hipSuccess) {
+    B->results_bytes = pinned;
+  } else { B->h_results = nullptr; PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %zu bytes of pinned memory unavailable", pinned); return (PVLM_ERR_NOMEM); }
+  pvlm_i_trace("ring: pinned buffer");
   hipStream_t S = ctx->stream;
   hipEvent_t ev[9];
   for (hipEvent_t& e : ev) if (hipEventCreate(&e) != hipSuccess) { PVLM_SET_ERR(ctx, "hipEventCreate failed"); return (PVLM_ERR_HIP); }
@@ -400,6 +450,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     for (std::thread& t : pool) t.join();
     if (bad >= 0) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: non-finite coordinate (point %lld of the batch)", (long long)bad); return PVLM_ERR_ARG; }
   }
+  pvlm_i_trace("ring: staging copy");
   (void)hipEventRecord(ev[0], S);
   PVLM_HIP(ctx, hipMemcpyAsync(d_raw, B->h_results, NP * 16, hipMemcpyHostToDevice, S));
   PVLM_HIP(ctx, hipMemcpyAsync(B->d_scans, B->scans.data(), (size_t)n_scans * sizeof(RingScan), hipMemcpyHostToDevice, S));
@@ -410,7 +461,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   PVLM_HIP(ctx, hipMemsetAsync(B->d_image_to_point, 0xFF, NC * sizeof(int), S));
   (void)hipEventRecord(ev[1], S);
   // ---- K16 + the host's libm for the listed points
-  hipLaunchKernelGGL(k_ring_classify, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, n_rings, horizon, d_raw, d_az, d_ring, d_exact, d_counter, d_listed);
+  hipLaunchKernelGGL(k_ring_classify, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, n_rings, horizon, d_raw, d_rec, d_counter, d_listed);
   int h_counter[4] = {0, 0, 0, 0};
   PVLM_HIP(ctx, hipMemcpyAsync(h_counter, d_counter, sizeof(int), hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipStreamSynchronize(S));      // also: the staging buffer is free again
@@ -420,7 +471,9 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     const pvlm_raw_scan& r = raw_scans[s];
     const float* p = r.xyzi + (size_t)(at - B->scans[(size_t)s].pt0) * r.stride_floats;
     const float q = -p[1] / std::sqrt(p[0] * p[0] + p[2] * p[2]);
-    pp->at = (int)at; pp->az = std::atan2(p[0], p[2]); pp->ring = q == q ? ring_of_atan(std::atan(q), n_rings) : -1;
+    const RingScan& sc = B->scans[(size_t)s];
+    pp->slot = sc.slot0 + chunk_slot((int)(at - sc.pt0), chunk_of(sc.n, kColumnThreads), kColumnThreads);
+    pp->az = std::atan2(p[0], p[2]); pp->ring = q == q ? ring_of_atan(std::atan(q), n_rings) : -1;
     return s;
   };
   std::vector<PointPatch> patches;
@@ -431,7 +484,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     pvlm_status s2 = pvlm_i_alloc(ctx, &d_patch, patches.size());
     if (s2) return s2;
     PVLM_HIP(ctx, hipMemcpyAsync(d_patch, patches.data(), patches.size() * sizeof(PointPatch), hipMemcpyHostToDevice, S));
-    hipLaunchKernelGGL(k_ring_patch, dim3((unsigned)((patches.size() + 255) / 256)), dim3(256), 0, S, (int)patches.size(), d_patch, d_az, d_ring, d_exact);
+    hipLaunchKernelGGL(k_ring_patch, dim3((unsigned)((patches.size() + 255) / 256)), dim3(256), 0, S, (int)patches.size(), d_patch, d_rec);
     PVLM_HIP(ctx, hipStreamSynchronize(S));     // `patches` is pageable
     return PVLM_OK;
   };
@@ -442,10 +495,11 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     for (size_t k = 0; k < listed.size(); ++k) B->resolved_points[(size_t)exact_of(listed[k], &patches[k])]++;
     if ((st = send_patches())) { pvlm_i_free(ctx, d_patch); return (st); }
   }
+  pvlm_i_trace("ring: upload + K16 + listed points");
   (void)hipEventRecord(ev[2], S);
   // ---- K17; a scan whose +z crossing stays undecided gets the host's azimuths for the points of that comparison and is replayed
-  hipLaunchKernelGGL(k_ring_columns, dim3((unsigned)((n_scans + 63) / 64)), dim3(64), 0, S, B->d_scans, (const int*)nullptr, n_scans, n_rings, horizon, d_az, d_ring, d_exact,
-                     d_colpos, d_ring_count, d_status);
+  hipLaunchKernelGGL(k_ring_columns, dim3((unsigned)n_scans), dim3(1024), 0, S, B->d_scans, (const int*)nullptr, n_rings, horizon, d_rec, d_colpos,
+                     d_ring_count, d_status);
   std::vector<int2> status((size_t)n_scans, make_int2(-1, -1));
   PVLM_HIP(ctx, hipMemcpyAsync(status.data(), d_status, (size_t)n_scans * sizeof(int2), hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipStreamSynchronize(S));
@@ -469,8 +523,8 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     if ((st = pvlm_i_alloc(ctx, &d_again, again.size()))) { pvlm_i_free(ctx, d_patch); return (st); }
     hipError_t e = hipMemcpyAsync(d_again, again.data(), again.size() * sizeof(int), hipMemcpyHostToDevice, S);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_ring_columns, dim3((unsigned)((again.size() + 63) / 64)), dim3(64), 0, S, B->d_scans, (const int*)d_again, (int)again.size(), n_rings, horizon, d_az,
-                         d_ring, d_exact, d_colpos, d_ring_count, d_status);
+      hipLaunchKernelGGL(k_ring_columns, dim3((unsigned)again.size()), dim3(1024), 0, S, B->d_scans, (const int*)d_again, n_rings, horizon, d_rec, d_colpos,
+                         d_ring_count, d_status);
       e = hipMemcpyAsync(status.data(), d_status, (size_t)n_scans * sizeof(int2), hipMemcpyDeviceToHost, S);
       if (e == hipSuccess) e = hipStreamSynchronize(S);
     }
@@ -478,11 +532,12 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     if (e != hipSuccess) { pvlm_i_free(ctx, d_patch); PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: replay failed: %s", hipGetErrorString(e)); return (PVLM_ERR_HIP); }
   }
   pvlm_i_free(ctx, d_patch); d_patch = nullptr;
+  pvlm_i_trace("ring: K17");
   (void)hipEventRecord(ev[3], S);
   // ---- K18
-  hipLaunchKernelGGL(k_ring_scatter, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, horizon, d_raw, d_ring, d_colpos, d_ring_count, B->d_cloud_scan, d_source,
+  hipLaunchKernelGGL(k_ring_scatter, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, horizon, d_raw, d_rec, d_colpos, d_ring_count, B->d_cloud_scan, d_source,
                      B->d_rc, d_winner);
-  hipLaunchKernelGGL(k_ring_cells, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, horizon, d_raw, d_ring, d_colpos, d_ring_count, d_winner, B->d_range_image,
+  hipLaunchKernelGGL(k_ring_cells, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, horizon, d_raw, d_rec, d_colpos, d_ring_count, d_winner, B->d_range_image,
                      B->d_image_to_point);
   (void)hipEventRecord(ev[4], S);
   // ---- K19 / K20: segmentation
@@ -492,7 +547,6 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     const float alpha_x = 0.2 / 180.0 * M_PI, alpha_y = 2.0 / 180.0 * M_PI, theta = 20.0 / 180.0 * M_PI;
     const float sin_x = std::sin(alpha_x), cos_x = std::cos(alpha_x), sin_y = std::sin(alpha_y), cos_y = std::cos(alpha_y);
     hipLaunchKernelGGL(k_seg_edges, cell_grid, dim3(256), 0, S, B->d_scans, n_rings, horizon, B->d_range_image, sin_x, cos_x, sin_y, cos_y, theta, d_edges, d_counter + 1, d_queries, query_cap);
-    hipLaunchKernelGGL(k_seg_init, cell_grid, dim3(256), 0, S, B->d_scans, cells, d_parent, d_comp_size, d_row_mask, B->d_image_to_point2);
     PVLM_HIP(ctx, hipMemcpyAsync(h_counter + 1, d_counter + 1, sizeof(int), hipMemcpyDeviceToHost, S));
     PVLM_HIP(ctx, hipStreamSynchronize(S));
     if (h_counter[1] > query_cap) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %d undecided segmentation edges (capacity %d)", h_counter[1], query_cap); return (PVLM_ERR_CAPACITY); }
@@ -514,6 +568,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
       }
     }
     (void)hipEventRecord(ev[5], S);
+    hipLaunchKernelGGL(k_seg_init, dim3((unsigned)n_rings, (unsigned)n_scans), dim3(256), 0, S, B->d_scans, horizon, d_edges, d_parent, d_comp_size, d_row_mask, B->d_image_to_point2);
     hipLaunchKernelGGL(k_seg_union, cell_grid, dim3(256), 0, S, B->d_scans, n_rings, horizon, d_edges, d_parent);
     hipLaunchKernelGGL(k_seg_stats, cell_grid, dim3(256), 0, S, B->d_scans, n_rings, horizon, d_parent, d_root, d_comp_size, d_row_mask);
   } else {
@@ -540,6 +595,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   PVLM_HIP(ctx, hipMemcpyAsync(B->ring_count2.data(), d_ring_count2, (size_t)n_scans * kMaxRings * sizeof(int), hipMemcpyDeviceToHost, S));
   (void)hipEventRecord(ev[8], S);
   PVLM_HIP(ctx, hipStreamSynchronize(S));
+  pvlm_i_trace("ring: segmentation, curvature, download");
   for (int k = 0; k < 8; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, ev[k], ev[k + 1]) == hipSuccess) B->ms[k] = ms; }
   return PVLM_OK;
 }
@@ -555,7 +611,14 @@ pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* b) {
     pvlm_i_free(ctx, b->d_scans); pvlm_i_free(ctx, b->d_cloud_scan); pvlm_i_free(ctx, b->d_rc); pvlm_i_free(ctx, b->d_range_image);
     pvlm_i_free(ctx, b->d_image_to_point); pvlm_i_free(ctx, b->d_cloud2); pvlm_i_free(ctx, b->d_image_to_point2);
   }
-  if (b->h_results) (void)hipHostFree(b->h_results);
+  if (b->h_results) {
+    if (ctx && b->results_bytes > ctx->ring_bytes) {      // the larger buffer stays with the context for the next batch
+      if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+      ctx->h_ring = b->h_results; ctx->ring_bytes = b->results_bytes;
+    } else {
+      (void)hipHostFree(b->h_results);
+    }
+  }
   delete b;
   return PVLM_OK;
 }

@@ -15,8 +15,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <atomic>
+#include <chrono>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 #include "pvlm_host.hpp"
 
@@ -100,6 +104,12 @@ void VoxelGridAppend(const PointCloud& in, float leaf, float tag, PointCloud& ou
     first = last;
   }
 }
+
+struct StageTimer {   // wall clock of a host stage into pvlm::StageSeconds()
+  const char* name; std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
+  ~StageTimer() { AddStageSeconds(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+};
 
 // union-find over range-image cells
 struct DisjointSets {
@@ -246,8 +256,7 @@ void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_thresh
   const int n = (int)cloud_scan.size();
   const PointCloud& P = cloud_scan;
   std::vector<float> curvature(n, -1.f), range(n);
-  std::vector<int> state(n, POINT_NORMAL), order(n), left(n, -1), right(n, -1);
-  std::iota(order.begin(), order.end(), 0);
+  std::vector<int> left(n, -1), right(n, -1);
   for (int i = 0; i < n; ++i) range[i] = L.range_image[(size_t)L.point_idx_to_image[i].first * horizon_scans + L.point_idx_to_image[i].second];
 
   // ---- curvature over a window grown until both ends are >= 8 cm away (:623-657).  Kept as upstream, including the
@@ -271,6 +280,16 @@ void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_thresh
       left[i] = a; right[i] = b;
     }
   }
+  PickFeatures(max_curvature, intersect_angle_threshold, curvature, range, left, right, trace, edge_to_line);
+}
+
+void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold, std::vector<float>& curvature, const std::vector<float>& range, std::vector<int>& left,
+                            std::vector<int>& right, ExtractionTrace* trace, bool edge_to_line) {
+  const RingLayout& L = layout_;
+  const int n = (int)cloud_scan.size();
+  const PointCloud& P = cloud_scan;
+  std::vector<int> state(n, POINT_NORMAL), order(n);
+  std::iota(order.begin(), order.end(), 0);
   // the six sectors of a ring (:707-723) — the same integer arithmetic everywhere below
   auto sector = [&](int ring, int j, int* sp, int* ep) {
     const int lo = L.scanStartInd[ring], span = L.scanEndInd[ring] - lo;
@@ -367,6 +386,85 @@ void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_thresh
     trace->curvature = std::move(curvature); trace->state = std::move(state); trace->sort_ind = std::move(order);
     trace->left_neighbor = std::move(left); trace->right_neighbor = std::move(right);
   }
+}
+
+// ---- the batch form: range-image stages on the GPU, picks on the host ---------------------------------------------------------
+void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float max_curvature, float intersect_angle_threshold, int method, bool segment, bool edge_to_line,
+                                    int num_threads, std::vector<ExtractionTrace>* traces) {
+  if (method != ADAPTIVE) throw std::invalid_argument("ExtractFeatures: only the ADAPTIVE method (config/Room.txt:32) is mirrored");
+  if (traces) traces->assign(scans.size(), ExtractionTrace());
+  std::vector<size_t> todo;
+  for (size_t k = 0; k < scans.size(); ++k) {
+    Velodyne* v = scans[k];
+    if (!v || !v->valid || !v->cloud_scan.empty() || v->cloud.empty()) continue;                  // ReOrderVLP returns early (:373-377)
+    if (!v->cornerLessSharp.empty() || !v->surfLessFlat.empty()) continue;                         // ExtractFeatures would (:542-543)
+    todo.push_back(k);
+  }
+  if (todo.empty()) return;
+  const int rings = scans[todo[0]]->N_SCANS, horizon = scans[todo[0]]->horizon_scans;
+  if (rings > 64) throw std::invalid_argument("ExtractFeatures: at most 64 rings");
+  for (size_t k : todo) if (scans[k]->N_SCANS != rings || scans[k]->horizon_scans != horizon) throw std::invalid_argument("ExtractFeaturesBatch: the scans of a call share one range-image shape");
+  std::vector<pvlm_raw_scan> raw(todo.size());
+  for (size_t j = 0; j < todo.size(); ++j) { const PointCloud& c = scans[todo[j]]->cloud; raw[j] = pvlm_raw_scan{&c[0].x, (int)c.size(), (int)(sizeof(PointXYZI) / sizeof(float))}; }
+  Engine& e = Engine::Default();
+  pvlm_ring_batch* batch = nullptr;
+  {
+    StageTimer stage_timer_("  (inside feature extraction) range-image stages of all scans on the GPU (pvlm_ring_extract_batch)");
+    e.Check(pvlm_ring_extract_batch(e.ctx(), (int)todo.size(), raw.data(), rings, horizon, segment ? 1 : 0, &batch), "pvlm_ring_extract_batch");
+  }
+  struct Release { pvlm_ctx* c; pvlm_ring_batch* b; ~Release() { pvlm_ring_batch_destroy(c, b); } } release{e.ctx(), batch};
+  if (traces) {                                   // the two images: device-resident, fetched for the parity tests only
+    for (size_t j = 0; j < todo.size(); ++j) {
+      RingLayout& L = scans[todo[j]]->layout_;
+      L.range_image.assign((size_t)rings * horizon, 0.f); L.image_to_point_idx.assign((size_t)rings * horizon, -1);
+      e.Check(pvlm_ring_batch_fetch(e.ctx(), batch, (int)j, 1, nullptr, nullptr, L.range_image.data(), L.image_to_point_idx.data()), "pvlm_ring_batch_fetch");
+    }
+  }
+  StageTimer stage_timer_picks_("  (inside feature extraction) picks, EdgeToLine, voxel grid (host, scan-parallel)");
+  std::atomic<size_t> next{0};
+  std::mutex failure_lock;
+  std::exception_ptr failure;
+  auto work = [&]() {
+    for (size_t j = next++; j < todo.size(); j = next++) {
+      try {
+        Velodyne& v = *scans[todo[j]];
+        pvlm_ring_result r;
+        if (pvlm_ring_batch_scan(batch, (int)j, &r) != PVLM_OK) throw std::runtime_error("pvlm_ring_batch_scan failed");
+        RingLayout& L = v.layout_;
+        const std::vector<float> keep_image = std::move(L.range_image); const std::vector<int> keep_index = std::move(L.image_to_point_idx);
+        L = RingLayout();
+        L.range_image = keep_image; L.image_to_point_idx = keep_index;
+        L.scanStartInd.assign(rings, 0); L.scanEndInd.assign(rings, 0);
+        // < 10 % of the re-ordered points survive the segmentation: the scan is dropped (:551-556); the cloud is left as Segmentation left it
+        const int n = r.n_kept;
+        v.cloud_scan.resize((size_t)n);
+        L.point_idx_to_image.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+          const PointXYZI& p = v.cloud[(size_t)r.source[i]];
+          const int ring = r.ring_col[i] >> 16;
+          v.cloud_scan[(size_t)i] = PointXYZI{p.x, p.y, p.z, (float)ring};
+          L.point_idx_to_image[(size_t)i] = std::pair<int, int>(ring, r.ring_col[i] & 0xFFFF);
+        }
+        int begin = 0;
+        for (int q = 0; q < rings; ++q) { L.scanStartInd[q] = begin + 5; begin += r.ring_count[q]; L.scanEndInd[q] = begin - 6; }
+        if (n < r.n_reordered * 0.1) { fprintf(stderr, "LiDAR data %d has something wrong\n", v.id); v.valid = false; continue; }
+        if (n == 0) continue;
+        std::vector<float> curvature(r.curvature, r.curvature + n), range(r.range, r.range + n);
+        std::vector<int> left((size_t)n), right((size_t)n);
+        for (int i = 0; i < n; ++i) { const int h = r.half_window[i]; left[(size_t)i] = h < 0 ? -1 : i - h; right[(size_t)i] = h < 0 ? -1 : i + h; }
+        v.PickFeatures(max_curvature, intersect_angle_threshold, curvature, range, left, right, traces ? &(*traces)[todo[j]] : nullptr, edge_to_line);
+      } catch (...) {
+        std::lock_guard<std::mutex> g(failure_lock);
+        if (!failure) failure = std::current_exception();
+      }
+    }
+  };
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(num_threads, 1), todo.size(), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  std::vector<std::thread> pool;
+  try { for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work); } catch (...) {}      // fewer workers: the calling thread does the rest
+  work();
+  for (std::thread& t : pool) t.join();
+  if (failure) std::rethrow_exception(failure);
 }
 
 }  // namespace pvlm

@@ -35,6 +35,7 @@ struct StageTimer {
   ~StageTimer() { Stages()[name] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++StageCallCounts()[name]; }
 };
 }  // namespace
+void AddStageSeconds(const char* name, double seconds) { Stages()[name] += seconds; ++StageCallCounts()[name]; }
 const std::map<std::string, double>& StageSeconds() { return Stages(); }
 const std::map<std::string, long>& StageCalls() { return StageCallCounts(); }
 
@@ -2070,35 +2071,42 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
   // Scans that arrive with their feature clouds (or without raw points) are left alone; upstream's ReOrderVLP /
   // ExtractFeatures return early for those as well (sensors/Velodyne.cpp:376-377, :542-543).
   {
-    StageTimer stage_timer_features_("feature extraction (host, scan-parallel)");
+    StageTimer stage_timer_features_("feature extraction (range-image stages on the GPU, picks on the host)");
     // invalid scans first, on the calling thread: SetRotation / SetTranslation give the scan's device copy back to the engine's
     // context (InvalidateDevice -> pvlm_scan_destroy), whose pool is not thread-safe — never from the workers below
     for (Velodyne& l : lidars)
       if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); }
-    std::atomic<size_t> next{0};
-    std::mutex failure_lock;
-    std::exception_ptr failure;          // e.g. an extraction method that is not mirrored: rethrown on the calling thread
-    auto work = [&]() {
-      for (size_t i = next++; i < lidars.size(); i = next++) {
-        Velodyne& l = lidars[i];
-        if (!l.valid || !l.IsPoseValid()) continue;        // reset above, on the calling thread
-        if (!l.cloud.empty() && l.surfFlat.empty() && l.surfLessFlat.empty() && l.cornerLessSharp.empty() && !l.IsInWorldCoordinate()) {
+    // the scans that still need their features: range-image stages of all of them in one GPU batch, picks on config.num_threads
+    // host threads (Velodyne::ExtractFeaturesBatch).  PVLM_HOST_FEATURES=1: everything on the host, scan by scan, as upstream does.
+    std::vector<Velodyne*> need;
+    for (Velodyne& l : lidars) {
+      if (!l.valid || !l.IsPoseValid()) continue;            // reset above
+      if (!l.cloud.empty() && l.surfFlat.empty() && l.surfLessFlat.empty() && l.cornerLessSharp.empty() && !l.IsInWorldCoordinate()) need.push_back(&l);
+    }
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(config.num_threads, 1), std::max<size_t>(need.size(), 1), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    if (!need.empty() && !std::getenv("PVLM_HOST_FEATURES")) {
+      Velodyne::ExtractFeaturesBatch(need, config.max_curvature, config.intersection_angle_threshold, config.extraction_method, config.lidar_segmentation, true, (int)n_threads);
+    } else if (!need.empty()) {
+      std::atomic<size_t> next{0};
+      std::mutex failure_lock;
+      std::exception_ptr failure;          // e.g. an extraction method that is not mirrored: rethrown on the calling thread
+      auto work = [&]() {
+        for (size_t i = next++; i < need.size(); i = next++) {
           try {
-            l.ReOrderVLP();
-            l.ExtractFeatures(config.max_curvature, config.intersection_angle_threshold, config.extraction_method, config.lidar_segmentation);
+            need[i]->ReOrderVLP();
+            need[i]->ExtractFeatures(config.max_curvature, config.intersection_angle_threshold, config.extraction_method, config.lidar_segmentation);
           } catch (...) {
             std::lock_guard<std::mutex> g(failure_lock);
             if (!failure) failure = std::current_exception();
           }
         }
-      }
-    };
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(config.num_threads, 1), lidars.size(), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (std::thread& t : pool) t.join();
-    if (failure) std::rethrow_exception(failure);
+      };
+      std::vector<std::thread> pool;
+      try { for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work); } catch (...) {}
+      work();
+      for (std::thread& t : pool) t.join();
+      if (failure) std::rethrow_exception(failure);
+    }
   }
   for (Velodyne& l : lidars) {
     if (!l.valid || !l.IsPoseValid()) continue;

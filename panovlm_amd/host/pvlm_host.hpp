@@ -87,6 +87,7 @@ struct Config {
 
 // Wall-clock seconds accumulated per stage of the mirrored call surface (association, track building, solve, ...)
 // since the process started — what tools/room_like_odometry.py prints beside the end-to-end time.
+void AddStageSeconds(const char* name, double seconds);   // wall-clock accounting of the host stages (see StageSeconds)
 const std::map<std::string, double>& StageSeconds();
 const std::map<std::string, long>& StageCalls();       // how many times each stage ran
 
@@ -157,6 +158,16 @@ class Velodyne {
   // and cornerSharp filtered down to the members of segments.  Upstream's RANSAC line fit of a fused group
   // (pcl::SACSegmentation, :150-160) is replaced by the exhaustive 2-point maximum-consensus line (host/pvlm_lines.cpp).
   void EdgeToLine();
+  // ReOrderVLP + ExtractFeatures for MANY scans: the per-point / per-ring stages (ring and column of every return, range image,
+  // Segmentation, adaptive-window curvature — sensors/Velodyne.cpp:371-526, :1438-1586, :623-657) run on the GPU for the whole
+  // batch (pvlm_ring_extract_batch, one launch per stage), the sort-dependent picks (ExtractEdgeFeatures2 / EdgeToLine /
+  // ExtractPlaneFeatures2 with pcl::VoxelGrid) on `num_threads` host threads from the arrays the device returns.  Every scan ends
+  // up exactly as ReOrderVLP() + ExtractFeatures(...) leave it (tests/test_host_gpu.py), except that Layout().range_image and
+  // .image_to_point_idx are only filled when traces are asked for (nothing downstream reads them).  Scans that ReOrderVLP /
+  // ExtractFeatures would leave alone (invalid, already re-ordered, no points) are skipped; all scans of a call share N_SCANS and
+  // horizon_scans of the first.  Call from the thread that owns the engine.
+  static void ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float max_curvature = 50, float intersect_angle_threshold = 5, int method = ADAPTIVE,
+                                   bool segment = true, bool edge_to_line = true, int num_threads = 1, std::vector<ExtractionTrace>* traces = nullptr);
   const RingLayout& Layout() const { return layout_; }
   void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
   void Transform2Local();                         // :1810-1848
@@ -175,6 +186,9 @@ class Velodyne {
   bool world_ = false;
   RingLayout layout_;
   void Segmentation();                            // sensors/Velodyne.cpp:1438-1586
+  // the second half of ExtractFeatures (:707-753, ExtractEdgeFeatures2, EdgeToLine, ExtractPlaneFeatures2) from the per-point arrays
+  void PickFeatures(float max_curvature, float intersect_angle_threshold, std::vector<float>& curvature, const std::vector<float>& range, std::vector<int>& left,
+                    std::vector<int>& right, ExtractionTrace* trace, bool edge_to_line);
   mutable pvlm_scan* dev_ = nullptr;
 };
 

@@ -472,6 +472,32 @@ int main(int argc, char** argv) {
       const double n = (double)reps * ns;
       printf("featbench scans %d reps %d points_per_scan %.0f reorder_ms %.4f extract_ms %.4f lines_ms %.4f flat %.1f less_flat %.1f segments %.1f corner %.1f\n", ns, reps,
              pts / n, 1e3 * reorder / n, 1e3 * extract / n, 1e3 * lines / n, flat / n, less / n, segs / n, corner / n);
+    } else if (cmd == "featbench_gpu") {
+      // featbench_gpu <raw_scans.bin> reps segment threads : wall seconds of Velodyne::ExtractFeaturesBatch over all scans of the file
+      std::ifstream f(argv[2], std::ios::binary);
+      if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+      int32_t ns = 0; rd(f, &ns, 1);
+      std::vector<PointCloud> raw(ns);
+      for (PointCloud& c : raw) {
+        int32_t id = 0, n = 0; rd(f, &id, 1);
+        double skip[12]; rd(f, skip, 12);
+        rd(f, &n, 1);
+        c.resize(n);
+        for (auto& p : c) rd(f, &p.x, 4);
+      }
+      const int reps = atoi(argv[3]), threads = argc > 5 ? atoi(argv[5]) : 16;
+      for (int r = 0; r < reps; ++r) {
+        std::vector<Velodyne> scans(ns);
+        std::vector<Velodyne*> ptr;
+        for (int k = 0; k < ns; ++k) { scans[k].id = k; scans[k].cloud = raw[k]; ptr.push_back(&scans[k]); }
+        const auto t0 = std::chrono::steady_clock::now();
+        Velodyne::ExtractFeaturesBatch(ptr, 1000.f, 5.f, ADAPTIVE, atoi(argv[4]) != 0, true, threads);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        size_t flat = 0, less = 0, segs = 0, corner = 0, pts = 0;
+        for (const Velodyne& v : scans) { flat += v.surfFlat.size(); less += v.surfLessFlat.size(); segs += v.edge_segmented.size(); corner += v.cornerLessSharp.size(); pts += v.cloud.size(); }
+        printf("featbench_gpu scans %d threads %d wall_ms %.3f ms_per_scan %.4f points_per_scan %.0f flat %.1f less_flat %.1f segments %.1f corner %.1f\n", ns, threads, 1e3 * sec,
+               1e3 * sec / ns, (double)pts / ns, (double)flat / ns, (double)less / ns, (double)segs / ns, (double)corner / ns);
+      }
     } else if (cmd == "byangle") {
       auto l = LoadScans(argv[2]);  // one LOCAL-frame scan
       std::ifstream f(argv[3], std::ios::binary);
@@ -591,10 +617,17 @@ int main(int argc, char** argv) {
         for (auto& p : v.cloud) rd(f, &p.x, 4);
       }
       v.N_SCANS = atoi(argv[4]); v.horizon_scans = atoi(argv[5]);
-      v.ReOrderVLP();
       ExtractionTrace tr;
       const bool edge_to_line = argc > 10 && atoi(argv[10]) != 0;    // optional 9th argument: also run EdgeToLine (line blocks are appended to out.bin)
-      if (atoi(argv[9])) v.ExtractFeatures((float)atof(argv[6]), (float)atof(argv[7]), ADAPTIVE, atoi(argv[8]) != 0, &tr, edge_to_line);
+      const bool on_gpu = argc > 11 && atoi(argv[11]) != 0;          // optional 10th: the batch form (range-image stages on the GPU), extract must be 1
+      if (on_gpu) {
+        std::vector<ExtractionTrace> traces;
+        Velodyne::ExtractFeaturesBatch({&v}, (float)atof(argv[6]), (float)atof(argv[7]), ADAPTIVE, atoi(argv[8]) != 0, edge_to_line, 2, &traces);
+        tr = std::move(traces[0]);
+      } else {
+        v.ReOrderVLP();
+        if (atoi(argv[9])) v.ExtractFeatures((float)atof(argv[6]), (float)atof(argv[7]), ADAPTIVE, atoi(argv[8]) != 0, &tr, edge_to_line);
+      }
       std::ofstream o(argv[3], std::ios::binary);
       auto wr = [&](const void* p, size_t bytes) { o.write(static_cast<const char*>(p), (std::streamsize)bytes); };
       auto block = [&](const void* p, size_t count, size_t elem) { const int32_t c = (int32_t)count; wr(&c, 4); if (count) wr(p, count * elem); };

@@ -16,12 +16,22 @@
 
 using namespace pvlm_ring;
 
+namespace {
+// the workgroup of columns_block, serial: a phase is a loop over the threads
+struct SerialExec {
+  int T;
+  int threads() const { return T; }
+  template <class F> void phase(F&& f) { for (int t = 0; t < T; ++t) f(t); }
+};
+}  // namespace
+
 extern "C" {
 
 // xyzi: n x 4.  ulps_override > 0 replaces kUlps' role of "how far the libm may be off" only through force_list (see below).
 // stats: [0] listed points, [1] undecided edges, [2] replayed, [3] n_reordered, [4] n_kept.
 // force: bit 0 = list every point, bit 1 = every azimuth exact before the state machine (all decisions from the host libm).
-int chk_ring(const float* xyzi, int n, int rings, int horizon, int segment, int force,
+// threads > 0: the workgroup form of the column machine (columns_block) with that many threads; 0: the one-lane loop (columns_scan)
+int chk_ring(const float* xyzi, int n, int rings, int horizon, int segment, int force, int threads,
              float* cloud_reordered, int* rc_reordered, float* range_image, int* img2pt_reordered, int* ring_count,
              float* cloud_kept, int* rc_kept, int* img2pt_kept, int* ring_count2, float* curvature, int* half_window, float* range, long long* stats) {
   const int cells = rings * horizon;
@@ -32,19 +42,23 @@ int chk_ring(const float* xyzi, int n, int rings, int horizon, int segment, int 
   std::fill(ring_count, ring_count + kMaxRings, 0);
   std::fill(ring_count2, ring_count2 + kMaxRings, 0);
   if (n <= 0) return 0;
-  RingScan sc{0, 0, n, 0, 0.0};
+  RingScan sc{0, 0, n, 0, 0, 0.0};
   sc.start_ori = ori_of_atan2(std::atan2(xyzi[0], xyzi[2]));
-  std::vector<float> az(n); std::vector<signed char> ring(n); std::vector<unsigned char> exact(n, 0);
+  // natural order (rec) for the one-lane loop; chunk-transposed (rec_t, colpos_t) for the workgroup form — both kept in step
+  const int T = threads > 0 ? threads : 1, L = chunk_of(n, T);
+  std::vector<PointRec> rec(n), rec_t((size_t)chunk_slots(n, T));
+  std::vector<signed char> ring(n);
+  auto put = [&](int i, float az, int r, bool exact) { rec[i] = make_rec(az, r, exact); rec_t[(size_t)chunk_slot(i, L, T)] = rec[i]; ring[i] = (signed char)r; };
   auto make_exact = [&](int i) {
     const float* p = xyzi + 4 * (size_t)i;
     const float q = -p[1] / std::sqrt(p[0] * p[0] + p[2] * p[2]);
-    az[i] = std::atan2(p[0], p[2]); ring[i] = (signed char)(q == q ? ring_of_atan(std::atan(q), rings) : -1); exact[i] = 1;
+    put(i, std::atan2(p[0], p[2]), q == q ? ring_of_atan(std::atan(q), rings) : -1, true);
   };
   // K16
   for (int i = 0; i < n; ++i) {
     float f; int r;
     const bool list = classify_point(sc, rings, horizon, xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2], &f, &r);
-    az[i] = f; ring[i] = (signed char)r;
+    put(i, f, r, false);
     if (list || (force & 1)) { make_exact(i); ++stats[0]; }
   }
   // K17 (+ replays: the points of an undecided crossing test from the host libm, as pvlm_ring_extract_batch does)
@@ -54,7 +68,16 @@ int chk_ring(const float* xyzi, int n, int rings, int horizon, int segment, int 
   for (int round = 0;; ++round) {
     std::fill(cnt.begin(), cnt.end(), 0);
     int last = -1;
-    const int stuck = columns_scan(sc, rings, horizon, az.data(), ring.data(), exact.data(), colpos.data(), [&](int r) -> int& { return cnt[r]; }, &last);
+    int stuck;
+    if (threads > 0) {
+      SerialExec ex{threads};
+      std::vector<int> scratch(kColumnsScratch * (size_t)threads);
+      std::vector<int> colpos_t(2 * (size_t)chunk_slots(n, T));
+      stuck = columns_block(ex, sc, rings, horizon, rec_t.data(), colpos_t.data(), cnt.data(), &last, scratch.data());
+      if (stuck < 0) for (int i = 0; i < n; ++i) { const size_t a = (size_t)chunk_slot(i, L, T); colpos[2 * i] = colpos_t[2 * a]; colpos[2 * i + 1] = colpos_t[2 * a + 1]; }
+    } else {
+      stuck = columns_scan(sc, rings, horizon, rec.data(), colpos.data(), [&](int r) -> int& { return cnt[r]; }, &last);
+    }
     if (stuck < 0) break;
     if (round > 64) return -2;
     ++stats[2];

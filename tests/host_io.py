@@ -88,9 +88,10 @@ def write_structure(path, frames, tracks):
                 f.write(struct.pack("<II", int(fi), int(ki)))
 
 
-def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_threshold=5.0, segment=True, extract=True, edge_to_line=False):
+def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_threshold=5.0, segment=True, extract=True, edge_to_line=False, on_gpu=False):
     """Velodyne::ReOrderVLP (+ ExtractFeatures, optionally with EdgeToLine) of the host mirror on one raw scan (n x 4 float32)
-    through the test driver.  Returns a dict with the same fields as oracle.ScanFeatures."""
+    through the test driver.  on_gpu: Velodyne::ExtractFeaturesBatch instead (range-image stages on the GPU, picks on the host).
+    Returns a dict with the same fields as oracle.ScanFeatures."""
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         dst = os.path.join(d, "out.bin")
@@ -102,7 +103,7 @@ def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_
             with open(src, "wb") as f:
                 f.write(struct.pack("<i", len(raw))); f.write(raw.tobytes())
         log = run("features", src, dst, str(n_scans), str(horizon), repr(float(max_curvature)), repr(float(angle_threshold)), "1" if segment else "0",
-                  "1" if extract else "0", "1" if edge_to_line else "0")
+                  "1" if extract else "0", "1" if edge_to_line else "0", "1" if on_gpu else "0")
         buf = open(dst, "rb").read()
     pos = [0]
 

@@ -709,3 +709,33 @@ def test_host_visible_evaluation_matches_device_rows(oracle):
         o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert o.returncode == 0, o.stderr[-2000:]
         assert o.stdout.split()[0] == "OK" and int(o.stdout.split()[1]) > 1000, o.stdout
+
+
+@pytest.mark.parametrize("case", [dict(k=3), dict(k=2, clutter=150, dropout=0.3), dict(k=4, jitter=0.6, skew=0.9), dict(k=5, start_deg=359.0, elevation_noise=0.6),
+                                  dict(k=7, start_deg=180.0, dropout=0.9), dict(k=8, segment=False, max_curvature=5.0, angle_threshold=10.0),
+                                  dict(k=9, cols=4096, clutter=40)],
+                         ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_feature_extraction_with_gpu_stages_matches_oracle(oracle, case):
+    """Velodyne::ExtractFeaturesBatch — ring / column order, range image, Segmentation and curvature from the GPU
+    (pvlm_ring_extract_batch), picks + EdgeToLine + voxel grid on the host — leaves a scan exactly as the oracle's
+    ReOrderVLP + ExtractFeatures do: every cloud, every per-point array, the line segments."""
+    c = dict(case); k = c.pop("k")
+    ext = {n: c.pop(n) for n in ("segment", "max_curvature", "angle_threshold") if n in c}
+    cols = c.get("cols", 1800)
+    raw = sy.raw_vlp16_scan(k, **c)
+    o = oracle.ScanFeatures(raw, horizon=cols, max_curvature=ext.get("max_curvature", 1000.0), intersect_angle_threshold=ext.get("angle_threshold", 5.0),
+                            segment=ext.get("segment", True), edge_to_line=True)
+    g = host_io.extract_features(raw, horizon=cols, edge_to_line=True, on_gpu=True, **ext)
+    assert o.valid == g["valid"]
+    names = ("cloud_scan", "rc", "scan_start", "scan_end") if not o.valid else \
+        ("cloud_scan", "cornerSharp", "cornerLessSharp", "surfFlat", "surfLessFlat", "rc", "scan_start", "scan_end", "range_image", "image_to_point_idx", "curvature",
+         "state", "sort_ind", "left", "right")
+    for name in names:
+        a, b = getattr(o, name), g[name]
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), name
+    if o.valid:
+        assert len(o.edge_segmented) == len(g["edge_segmented"])
+        for a, b in zip(o.edge_segmented, g["edge_segmented"]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(o.segment_coeffs, g["segment_coeffs"], equal_nan=True) and np.array_equal(o.end_points, g["end_points"], equal_nan=True)
+        assert o.point_to_segment == g["point_to_segment"] and np.array_equal(o.cornerBeforeFilter, g["cornerBeforeFilter"])

@@ -27,7 +27,7 @@ def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def run(lib, raw, n_scans, horizon, segment, force=0):
+def run(lib, raw, n_scans, horizon, segment, force=0, threads=0):
     raw = np.ascontiguousarray(raw, np.float32)
     n = len(raw); cells = n_scans * horizon
     f32 = lambda *s: np.zeros(s, np.float32)
@@ -37,7 +37,7 @@ def run(lib, raw, n_scans, horizon, segment, force=0):
              curvature=f32(max(n, 1)), half_window=i32(max(n, 1)), range=f32(max(n, 1)))
     stats = np.zeros(5, np.int64)
     c_f, c_i = ctypes.c_float, ctypes.c_int
-    rcode = lib.chk_ring(_p(raw, c_f), n, n_scans, horizon, int(segment), force, _p(g["cloud_reordered"], c_f), _p(g["rc_reordered"], c_i), _p(g["range_image"], c_f),
+    rcode = lib.chk_ring(_p(raw, c_f), n, n_scans, horizon, int(segment), force, threads, _p(g["cloud_reordered"], c_f), _p(g["rc_reordered"], c_i), _p(g["range_image"], c_f),
                          _p(g["image_to_point_reordered"], c_i), _p(g["ring_count_reordered"], c_i), _p(g["cloud_kept"], c_f), _p(g["rc_kept"], c_i),
                          _p(g["image_to_point_kept"], c_i), _p(g["ring_count"], c_i), _p(g["curvature"], c_f), _p(g["half_window"], c_i), _p(g["range"], c_f),
                          _p(stats, ctypes.c_longlong))
@@ -57,6 +57,20 @@ def test_device_bodies_match_oracle(chk, oracle, case):
     if case.get("jitter", 0.05) < 0.5 and "start_deg" not in case:
         assert g["listed"] <= max(20, 2e-3 * len(raw))
     assert g["undecided_edges"] <= 4
+
+
+@pytest.mark.parametrize("threads", [1, 7, 64, 1024])
+def test_workgroup_form_of_the_column_machine(chk, oracle, threads):
+    """columns_block (chunks + block scans, what the kernel runs) == the sequential loop == the oracle, for every chunking."""
+    for case in rc.CASES:
+        raw, n_scans, horizon, segment = rc.raw_of(case)
+        g = run(chk, raw, n_scans, horizon, segment, threads=threads)
+        rc.assert_matches_oracle(oracle, raw, n_scans, horizon, segment, g)
+        s = run(chk, raw, n_scans, horizon, segment)
+        assert g["replayed"] == s["replayed"] and g["listed"] == s["listed"]
+    raw = rc.raw_of(dict(k=9, cols=180))[0]
+    for sub in (raw[:1], raw[:5], raw[:40], raw[::7]):
+        rc.assert_matches_oracle(oracle, sub, 16, 180, True, run(chk, sub, 16, 180, True, threads=threads))
 
 
 @pytest.mark.parametrize("force", [1, 2, 3])
