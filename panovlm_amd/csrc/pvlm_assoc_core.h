@@ -20,6 +20,10 @@
 #define PVLM_ASSOC_STATS_CANDIDATE() ((void)0)
 #define PVLM_ASSOC_STATS_ROW() ((void)0)
 #endif
+#ifndef PVLM_ASSOC_STATS_ITER
+#define PVLM_ASSOC_STATS_ITER(r, dz, dy, part) ((void)0)
+#define PVLM_ASSOC_STATS_RUN(len, pass) ((void)0)
+#endif
 
 namespace pvlm_assoc {
 
@@ -113,23 +117,36 @@ PVLM_HD topk_key key_min(topk_key a, topk_key b) { return a < b ? a : b; }
 PVLM_HD topk_key key_max(topk_key a, topk_key b) { return a < b ? b : a; }
 #endif
 
+// The distance threshold lives in the list itself: an empty slot holds the key (threshold bits + 1, index 0) — the smallest key of a
+// distance ABOVE the threshold — so a candidate beyond the threshold can never displace it (equal at best: no change) and the
+// candidate loop needs no threshold test of its own (round 3: v_cmp_le + v_cndmask per candidate).  Empty slots read back as
+// (index -1, distance +inf).
 template <int K>
 struct TopK {
   topk_key key[K];
-  PVLM_HD void init() {
+  unsigned empty_hi;                                                              // high word of an empty slot
+  PVLM_HD void init(float thr2) {
+    empty_hi = (thr2 < 3.0e38f ? f2u(thr2) + 1u : 0x7F800000u) + PVLM_KEY_BIAS;      // thr2 = +inf (or NaN): nothing is beyond it
 #pragma unroll
-    for (int k = 0; k < K; ++k) key[k] = key_make(PVLM_KEY_INF_HI, 0xFFFFFFFFu);
+    for (int k = 0; k < K; ++k) key[k] = key_make(empty_hi, 0u);
   }
-  // candidate (d2, idx); `take` false (beyond the distance threshold, NaN) turns it into a key above every slot
-  PVLM_HD void push(float d2, int idx, bool take) {
-    const topk_key c = key_make(take ? f2u(d2) + PVLM_KEY_BIAS : PVLM_KEY_REJECT_HI, (unsigned)idx);
+  // candidate (d2, idx), d2 a non-negative float (finite or +inf; the clouds are finite)
+  PVLM_HD void push(float d2, int idx) {
+    const topk_key c = key_make(f2u(d2) + PVLM_KEY_BIAS, (unsigned)idx);
+#ifdef PVLM_K2_NONET   // timing experiment only (wrong results): what the insertion network costs
+    key[0] = key_min(key[0], c);
+#else
 #pragma unroll
     for (int k = K - 1; k > 0; --k) key[k] = key_min(key[k], key_max(key[k - 1], c));
     key[0] = key_min(key[0], c);
+#endif
   }
-  PVLM_HD bool full() const { return key_hi(key[K - 1]) < PVLM_KEY_INF_HI; }
-  PVLM_HD float dist(int k) const { return u2f(key_hi(key[k]) - PVLM_KEY_BIAS); }      // +inf for an empty slot
-  PVLM_HD int index(int k) const { return (int)key_lo(key[k]); }                         // -1 for an empty slot
+  PVLM_HD bool full() const { return key_hi(key[K - 1]) < empty_hi; }
+  PVLM_HD bool would_enter(float d2, int idx) const { return key_make(f2u(d2) + PVLM_KEY_BIAS, (unsigned)idx) < key[K - 1]; }
+  // the pruning bound: the k-th distance, or (just above) the threshold while the list is not full
+  PVLM_HD float kth_or_threshold() const { return u2f(key_hi(key[K - 1]) - PVLM_KEY_BIAS); }
+  PVLM_HD float dist(int k) const { const unsigned h = key_hi(key[k]); return h < empty_hi ? u2f(h - PVLM_KEY_BIAS) : u2f(0x7F800000u); }
+  PVLM_HD int index(int k) const { return key_hi(key[k]) < empty_hi ? (int)key_lo(key[k]) : -1; }
 };
 
 // ---- K2: exact k-NN of one query ------------------------------------------------------------------------------------------
@@ -143,7 +160,7 @@ struct TopK {
 // budget reaches.  Shells, gaps and the termination bound work on the coarse cells; visit() receives FINE x indices.
 template <int K, class Visit>
 PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float max_dist, float thr2, TopK<K>& tk, Visit&& visit) {
-  tk.init();
+  tk.init(thr2);
   if (cv.n <= 0) return;
   const int xf = cv.xf;
   const float ux = (qx - cv.ox) * cv.inv_h;                                   // x of the query in coarse cells
@@ -162,6 +179,12 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
   const int ncx = cv.dense ? cv.nx / xf : 0;
   int cz_min = 0, cz_max = 0, cy_min = 0, cy_max = 0;        // over the wave: the clipped loop bounds below stay scalar
   if (cv.dense) { wave_minmax_i(cz, &cz_min, &cz_max); wave_minmax_i(cy, &cy_min, &cy_max); }
+  // Pruning arithmetic (never a distance that is compared or returned): fused multiply-adds, and the per-row bound as two FMAs off
+  // per-query constants — gap(d) h - slack = |d| h + (d > 0 ? -f h - slack : (f - 1) h - slack).  The budget (k-th distance, or the
+  // threshold while the list is not full) only changes when a row was scanned: it is refreshed there, not in every row test
+  // (round 3: 15 VALU instructions per skipped row, 45 row tests per query).
+  const float ypos = fmaf(-fy, cv.h, -slack), yneg = fmaf(fy - 1.f, cv.h, -slack), zpos = fmaf(-fz, cv.h, -slack), zneg = fmaf(fz - 1.f, cv.h, -slack);
+  float budget = tk.kth_or_threshold() * 1.00001f;
   for (int r = 0; r <= rmax; ++r) {
     int dz_lo = -r, dz_hi = r, dy_lo = -r, dy_hi = r;
     if (cv.dense) {                                            // rows of SOME lane's table range; the per-lane range test below remains
@@ -171,17 +194,15 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
     for (int dz = dz_lo; dz <= dz_hi; ++dz) {
       const int z = cz + dz;
       if (cv.dense && (z < 0 || z >= cv.nz)) continue;
-      const float gz = dz > 0 ? (float)dz - fz : (dz < 0 ? fz - (float)(dz + 1) : 0.f);   // gap to the row's slab, in cells
-      const float gzm = fmaxf(gz * cv.h - slack, 0.f);
+      const float gzm = dz == 0 ? 0.f : fmaxf(fmaf((float)(dz > 0 ? dz : -dz), cv.h, dz > 0 ? zpos : zneg), 0.f);   // gap to the row's slab minus the slack
+      const float gz2 = gzm * gzm;
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int y = cy + dy;
         if (cv.dense && (y < 0 || y >= cv.ny)) continue;
-        const float gy = dy > 0 ? (float)dy - fy : (dy < 0 ? fy - (float)(dy + 1) : 0.f);
-        const float gym = fmaxf(gy * cv.h - slack, 0.f);
-        const float lb = gym * gym + gzm * gzm;                       // <= d2 of every point of the row
-        const float budget = fminf(thr2, tk.dist(K - 1)) * 1.00001f;   // dist(K-1) = +inf while the list is not full
+        const float gym = dy == 0 ? 0.f : fmaxf(fmaf((float)(dy > 0 ? dy : -dy), cv.h, dy > 0 ? ypos : yneg), 0.f);
+        const float lb = fmaf(gym, gym, gz2);                         // <= d2 of every point of the row
         if (lb > budget) continue;
-        const float reach = (sqrt_reach(budget - lb) * 1.0001f + slack) * cv.inv_h;  // (coarse) cells the budget still reaches along x
+        const float reach = fmaf(sqrt_reach(budget - lb), 1.0001f, slack) * cv.inv_h;  // (coarse) cells the budget still reaches along x
         const int xa = (int)floorf((ux - reach) * (float)xf), xb = (int)floorf((ux + reach) * (float)xf);   // fine cells
         const bool face = (dz == -r || dz == r || dy == -r || dy == r);
         // a face row of the shell is one x-run; an interior row only owns its two end cells (one call site for both:
@@ -195,33 +216,50 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
             x0 = (part ? cx + r : cx - r) * xf; x1 = x0 + xf - 1;
           }
           x0 = x0 > xa ? x0 : xa; x1 = x1 < xb ? x1 : xb;
-          if (x0 <= x1) { PVLM_ASSOC_STATS_ROW(); visit(z, y, x0, x1); }
+          if (x0 <= x1) { PVLM_ASSOC_STATS_ROW(); PVLM_ASSOC_STATS_ITER(r, dz, dy, part); visit(z, y, x0, x1); budget = tk.kth_or_threshold() * 1.00001f; }
         }
       }
     }
     // every unsearched point lies outside the (2r+1)^3 block: farther than (inside + r) cells
     const float bound = (inside + (float)r) * cv.h - slack;
-    if (tk.full() && bound > 0.f && tk.dist(K - 1) < bound * bound) break;
+    if (tk.full() && bound > 0.f && tk.kth_or_threshold() < bound * bound) break;
     if ((float)r * cv.h >= max_dist * 1.0001f) break;  // everything within max_dist has been visited
     if (cv.dense && cx - r <= 0 && cx + r >= ncx - 1 && cy - r <= 0 && cy + r >= cv.ny - 1 && cz - r <= 0 && cz + r >= cv.nz - 1) break;   // ... or the whole table
   }
 }
 
+// Candidates of one run [b, e) of the sorted array.  The loads of PVLM_K2_BATCH consecutive candidates are issued together before
+// the first of them goes through the insertion network (the compiler schedules a one-candidate loop as load - wait - use: the wave
+// then sits out one memory latency per candidate; a run is 3.3 candidates long on average, so four loads in flight cover most runs
+// with ONE latency).  Slots past the end of the run re-read its last candidate and are turned into +inf keys.
+#ifndef PVLM_K2_BATCH
+#define PVLM_K2_BATCH 1   // measured (profiles/r4_assoc_variants.txt): 1 / 2 / 4 / 8 -> 1327 / 1367 / 1466 / 2436 us per dispatch: the padded slots cost more network work than the latency they hide
+#endif
 template <int K>
 PVLM_HD void knn_scan_run(const CloudView& cv, int b, int e, float qx, float qy, float qz, float thr2, TopK<K>& tk) {
+  (void)thr2;
   if (b >= e) return;
-  // the next candidate is in flight while the current one goes through the insertion network (the redundant last load
-  // re-reads candidate e - 1)
-  Point4 p = cv.sorted[b];
-  for (int j = b; j < e; ++j) {
-    const Point4 nxt = cv.sorted[j + 1 < e ? j + 1 : j];
-    const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
-    float d2 = 0.0f;
-    d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
-    tk.push(d2, (int)f2u(p.w), d2 <= thr2);
-    PVLM_ASSOC_STATS_CANDIDATE();
-    p = nxt;
+  const Point4* s = cv.sorted;
+  const int last = e - 1;
+  int stat_pass = 0; (void)stat_pass;
+  for (int j = b; j < e; j += PVLM_K2_BATCH) {
+    Point4 p[PVLM_K2_BATCH];
+#pragma unroll
+    for (int k = 0; k < PVLM_K2_BATCH; ++k) p[k] = s[k == 0 ? j : (j + k < last ? j + k : last)];
+#pragma unroll
+    for (int k = 0; k < PVLM_K2_BATCH; ++k) {
+      const float ddx = qx - p[k].x, ddy = qy - p[k].y, ddz = qz - p[k].z;
+      float d2 = 0.0f;
+      d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
+      if (k > 0) d2 = j + k < e ? d2 : u2f(0x7F800000u);  // past the end: never enters the list
+#ifdef PVLM_ASSOC_STATS_COUNT_PASS
+      if ((k == 0 || j + k < e) && tk.would_enter(d2, (int)f2u(p[k].w))) ++stat_pass;
+#endif
+      tk.push(d2, (int)f2u(p[k].w));
+      if (k == 0 || j + k < e) PVLM_ASSOC_STATS_CANDIDATE();
+    }
   }
+  PVLM_ASSOC_STATS_RUN(e - b, stat_pass);
 }
 
 template <int K, bool DENSE>

@@ -12,6 +12,13 @@
 static long long g_candidates = 0, g_rows_visited = 0;
 #define PVLM_ASSOC_STATS_CANDIDATE() (++g_candidates)
 #define PVLM_ASSOC_STATS_ROW() (++g_rows_visited)
+// lockstep statistics (chk_knn_lockstep): one record per scanned run = (row-loop iteration id, run length, candidates that beat the k-th key)
+struct RunRecord { int iter, len, pass; };
+static std::vector<RunRecord>* g_runs = nullptr;
+static int g_iter_id = 0;
+#define PVLM_ASSOC_STATS_COUNT_PASS 1
+#define PVLM_ASSOC_STATS_ITER(r, dz, dy, part) (g_iter_id = (((r) * 64 + (dz) + 32) * 64 + (dy) + 32) * 2 + (part))
+#define PVLM_ASSOC_STATS_RUN(len, pass) do { if (g_runs) g_runs->push_back(RunRecord{g_iter_id, (len), (pass)}); } while (0)
 #include "../../panovlm_amd/csrc/pvlm_assoc_core.h"
 
 using namespace pvlm_assoc;
@@ -112,6 +119,27 @@ int chk_knn(const float* tgt, int n, const float* q, int nq, int k, float max_di
   }
   if (stats) { stats[0] = g_candidates; stats[1] = g_rows_visited; stats[2] = g.view.dense; }
   return 0;
+}
+
+// Divergence statistics of the search as a wave runs it: the queries of a wave (64 consecutive ones) walk the same (r, dz, dy) loop,
+// each scanning its own run; a wave pays max-over-lanes per iteration.  Per query: out_n[i] records starting at out_off[i] in rec (iter, len, pass).
+long long chk_knn_lockstep(const float* tgt, int n, const float* q, int nq, float max_dist, int* rec, long long cap, long long* out_off) {
+  Grid g;
+  build_grid(tgt, n, 0.f, 0, 4, g);
+  std::vector<RunRecord> runs;
+  g_runs = &runs;
+  const float thr2 = max_dist * max_dist;
+  long long total = 0;
+  for (int i = 0; i < nq; ++i) {
+    runs.clear();
+    TopK<10> tk;
+    knn_search<10>(g.view, q[3 * i], q[3 * i + 1], q[3 * i + 2], max_dist, thr2, tk);
+    out_off[i] = total;
+    for (const RunRecord& r : runs) { if (total < cap) { rec[3 * total] = r.iter; rec[3 * total + 1] = r.len; rec[3 * total + 2] = r.pass; } ++total; }
+  }
+  out_off[nq] = total;
+  g_runs = nullptr;
+  return total;
 }
 
 // pts: m x 10 x 3 (row-major).  plane_ok[m], plane[m x 4], line[m]: the two decisions of K3 for every 10-point set
