@@ -81,6 +81,40 @@ class Watchdog:
             self.timer = None
 
 
+def visible_gpus():
+    """GPUs this process may use, counted without initialising HIP in it (the ranks are still to be forked): rocm-smi-free, through
+    a child interpreter."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def launch_ranks(n, shared_gpu):
+    """Re-executes this script as n ranks under torch.distributed.run on 127.0.0.1 (free port) and returns its exit code."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if not shared_gpu and have < n:
+        sys.stderr.write("bench.py: --gpus %d needs %d GPUs, this node shows %d (PVLM_BENCH_SHARED_GPU=1 runs the %d ranks on one GPU as a functional check)\n"
+                         % (n, n, have, n))
+        return 2
+    if shared_gpu and have < 1:
+        sys.stderr.write("bench.py: no GPU visible\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,11 +146,21 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # functional check of the multi-rank control flow on a ONE-GPU box (not a measurement): all ranks share GPU 0 and the
-    # exchange goes through gloo — PVLM_BENCH_SHARED_GPU=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    # exchange goes through gloo — PVLM_BENCH_SHARED_GPU=1 python bench.py --gpus 2
     shared_gpu = os.environ.get("PVLM_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
-    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher of its own N ranks (one per GPU, RCCL) —
+        # the same command line torch.distributed.run would be given by hand
+        sys.exit(launch_ranks(args.gpus, shared_gpu))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d, or run `python bench.py --gpus %d` and let it spawn its ranks\n"
+                         % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
 
     from panovlm_amd import sharding
     from panovlm_amd import synthetic as sy
@@ -569,7 +613,9 @@ def per_rank_projection(ctx, pv, torch, sharding, args, associate, make_step, re
     (block partition by reference scan), associated and evaluated exactly like the headline, the step replayed as a
     HIP graph (as bench.py does for N > 1).  The all-reduce cannot be measured on one GPU: its size is reported, and the
     projection is given without it and with a stated assumption for it."""
-    assumed_allreduce_us = {2: 40.0, 4: 60.0, 8: 80.0}     # [assumed, not measured] RCCL all-reduce of ~3 MB over xGMI
+    # [assumed, not measured: this block only runs at N = 1, where there is nothing to all-reduce with; a run with N > 1 reports the measured
+    # figure as extra.allreduce_us] RCCL all-reduce of ~3 MB over xGMI
+    assumed_allreduce_us = {2: 40.0, 4: 60.0, 8: 80.0}
     out = {"full_batch_ms_per_step": ms_full, "full_batch_fused_kernel_ms": k6_full_ms, "allreduce_bytes": int(neq_size) * 8,
            "assumed_allreduce_us": assumed_allreduce_us, "ranks": {}}
     for N in (2, 4, 8):
