@@ -253,6 +253,11 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
  * with mirror = 0.  Repeated blocks add up. */
 pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror, const double* blocks,
                                   const double* scale, const double* diag_add, double* rhs, int* info);
+/* How the last pvlm_spd_solve_blocks structure of this context is factorised: *tile_sparse = 1 when the dense kernels skip the
+ * structurally zero 64-row tiles (ordering of the pose graph by minimum degree + elimination-tree postorder; the reference selects
+ * SPARSE_SCHUR for 50 < lidars <= 2000, util/Optimization.cpp:641-658), *update_fraction = its tile updates / those of the dense
+ * factorisation.  Systems under 1500 unknowns, or whose fraction exceeds 0.6, keep the natural order and the dense kernels. */
+pvlm_status pvlm_spd_plan_info(const pvlm_ctx* ctx, int* tile_sparse, double* update_fraction);
 
 /* ---- multi-GPU exchange (RCCL over xGMI) -------------------------------------------------------- *
  * The reference is single-process (OpenMP only); sharding scan pairs across GPUs introduces exactly one

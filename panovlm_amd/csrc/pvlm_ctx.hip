@@ -319,6 +319,7 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   pvlm_i_assoc_ws_free(ctx);
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);
   if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+  pvlm_i_spd_plan_release(ctx);
   if (ctx->stage.base) (void)hipHostFree(ctx->stage.base);
   pvlm_i_free(ctx, ctx->d_aa); pvlm_i_free(ctx, ctx->d_t); pvlm_i_free(ctx, ctx->d_pose_tab); pvlm_i_free(ctx, ctx->d_ws); pvlm_i_free(ctx, ctx->d_neq_tmp);
   pvlm_i_pool_release(ctx, true);   // objects the caller leaked (scans, residual sets) die with their slabs

@@ -95,6 +95,7 @@ struct pvlm_ctx {
   // grow-only device workspace of the dense solver (K10): a Room-sized system is 237 MB, allocating it per LM step costs ms
   void* d_ws = nullptr;
   size_t ws_bytes = 0;
+  void* spd_plan = nullptr;           // tile-sparse plan of the last pvlm_spd_solve_blocks structure (csrc/pvlm_linalg.hip), freed by pvlm_i_spd_plan_release
   // per-kernel profiling (pvlm_profile_*): pending (start, stop) event pairs per kernel class
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[3];
@@ -250,6 +251,7 @@ pvlm_status pvlm_i_stream_sync(pvlm_ctx* ctx);
 pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 void pvlm_i_assoc_ws_free(pvlm_ctx* ctx);
+void pvlm_i_spd_plan_release(pvlm_ctx* ctx);
 // builds work list + scratch for a resset whose segment table is final (h_* mirrors filled)
 pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs);
 pvlm_status pvlm_i_resset_free(pvlm_ctx* ctx, pvlm_resset* rs);

@@ -7,6 +7,9 @@
 // library in (measured 140..510 s on a cold box) — unacceptable inside a library call.
 #include <algorithm>
 #include <cstdlib>
+#include <iterator>
+#include <new>
+#include <vector>
 
 #include "pvlm_internal.h"
 
@@ -104,8 +107,11 @@ __device__ __forceinline__ double bcast_f64(double v, int src_lane) {     // v o
 // fwd_b != nullptr: the forward substitution of ONE right-hand side rides along — workgroup 0 also forms y_k = L_kk^-1 b_k
 // (b_k is final: every earlier block column's update has been applied), and the trailing-update launch of this block column
 // subtracts L[j, k] y_k from the rows below (k_chol_fwd_rows): the 171 k_fwd_step launches of round 1 disappear.
+// row_tiles != nullptr (the tile-sparse factorisation below): workgroup g handles rows 8 (g & 7) .. + 8 of the 64-row tile
+// row_tiles[g >> 3] — only the tiles that hold a nonzero of this block column — instead of the g-th group of 8 rows below the block.
 __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M, int n, int k0, int kb, double* __restrict__ Linv, int* __restrict__ info,
-                                                         int* __restrict__ fail_out, const double* __restrict__ fwd_b, double* __restrict__ fwd_y) {
+                                                         int* __restrict__ fail_out, const double* __restrict__ fwd_b, double* __restrict__ fwd_y,
+                                                         const int* __restrict__ row_tiles, int n_row_tiles) {
   __shared__ double a[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
   __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
   __shared__ double As[8][PVLM_CHOL_NB + 1];
@@ -119,8 +125,9 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
     inv[i][j] = 0.0;
   }
   const int lr = t / PVLM_CHOL_NB, c = t % PVLM_CHOL_NB;
-  const int row = k0 + kb + blockIdx.x * 8 + lr;
-  const bool live = row < n && c < kb;
+  int row = k0 + kb + blockIdx.x * 8 + lr;
+  if (row_tiles) row = (int)(blockIdx.x >> 3) < n_row_tiles ? row_tiles[blockIdx.x >> 3] * 64 + (int)(blockIdx.x & 7) * 8 + lr : n;
+  const bool live = row >= k0 + kb && row < n && c < kb;
   As[lr][c] = live ? M[(size_t)row * n + k0 + c] : 0.0;
   __syncthreads();
   if (t < 64) {
@@ -266,19 +273,24 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, int
 // panel row of the column tile) from LDS, four MFMAs.  D layout of the f64 form: col = lane & 15,
 // row = (lane >> 4) + 4 * reg (cdna_hip_programming.md §3) — not the f32 map.
 typedef double pvlm_d4 __attribute__((ext_vector_type(4)));
+// pairs != nullptr (tile-sparse factorisation): workgroup g updates the tile pairs[g] = (ti, tj) in ABSOLUTE 64-row tiles of the
+// matrix — only the pairs whose two row tiles hold a nonzero of this block column; rows / columns above `base` are masked.
 __global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M, int n, int k0, int kb, int tiles, const int* __restrict__ info,
-                                                          int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y, int part) {
+                                                          int n_tile_blocks, double* __restrict__ fwd_b, const double* __restrict__ fwd_y, int part,
+                                                          const int2* __restrict__ pairs) {
   __shared__ double As[64][PVLM_CHOL_NB + 1];
   __shared__ double Bs[64][PVLM_CHOL_NB + 1];
   if (*info != 0) return;
   if ((int)blockIdx.x >= n_tile_blocks) { chol_fwd_rows(M, n, k0, kb, (int)blockIdx.x - n_tile_blocks, fwd_b, fwd_y); return; }
   int ti, tj;
-  if (!chol_tile_of((int)blockIdx.x, tiles, part, &ti, &tj)) return;
-  const int base = k0 + kb, r0 = base + ti * 64, c0 = base + tj * 64;
+  const int base = k0 + kb;
+  int r0, c0;
+  if (pairs) { const int2 pr = pairs[blockIdx.x]; r0 = pr.x * 64; c0 = pr.y * 64; }
+  else { if (!chol_tile_of((int)blockIdx.x, tiles, part, &ti, &tj)) return; r0 = base + ti * 64; c0 = base + tj * 64; }
   for (int e = threadIdx.x; e < 64 * PVLM_CHOL_NB; e += 256) {
     const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
-    As[i][c] = (r0 + i < n && c < kb) ? M[(size_t)(r0 + i) * n + k0 + c] : 0.0;
-    Bs[i][c] = (c0 + i < n && c < kb) ? M[(size_t)(c0 + i) * n + k0 + c] : 0.0;
+    As[i][c] = (r0 + i >= base && r0 + i < n && c < kb) ? M[(size_t)(r0 + i) * n + k0 + c] : 0.0;
+    Bs[i][c] = (c0 + i >= base && c0 + i < n && c < kb) ? M[(size_t)(c0 + i) * n + k0 + c] : 0.0;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r0 + 16 * w + lk + 4 * r;
-      if (row < n && col <= row) M[(size_t)row * n + col] -= acc[t][r];
+      if (row < n && col <= row && col >= base) M[(size_t)row * n + col] -= acc[t][r];
     }
   }
 }
@@ -358,7 +370,13 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
 // factorises d_M (n x n row-major, lower triangle used and overwritten by L) and solves for nrhs right-hand sides stored
 // one after the other in d_B; all on ctx->stream.
 // d_Linv: ceil(n / 32) x 32 x 32 doubles (inverses of the diagonal blocks), d_y: n doubles (forward-solve result).
-static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, double* d_Linv, double* d_y, int* d_info) {
+// Tile-sparse form (plan != nullptr): block column k only touches the 64-row tiles that hold one of its nonzeros — lists made by the
+// symbolic factorisation of SpdPlan, below — instead of every row below it.
+struct SpdTileLists {
+  const int* d_row_tiles; const int2* d_pairs;          // concatenated over the block columns
+  const int* row_off; const int* pair_off;              // host: steps + 1 offsets
+};
+static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, int nrhs, double* d_Linv, double* d_y, int* d_info, const SpdTileLists* plan = nullptr) {
   hipStream_t s = ctx->stream;
 #if PVLM_MEASURED_VARIANTS
   static const bool use_mfma = getenv("PVLM_CHOL_VALU") == nullptr;   // PVLM_CHOL_VALU=1: the register-tiled VALU update (measured variant)
@@ -388,15 +406,26 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
 #if PVLM_MEASURED_VARIANTS
     if (!use_mfma) { hipLaunchKernelGGL(k_chol_update, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part); return; }
 #endif
-    hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part);
+    hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(tile_blocks + fwd_blocks)), dim3(256), 0, st, d_M, n, k0, kb, tiles, d_info, tile_blocks, d_B, d_y, part,
+                       (const int2*)nullptr);
   };
   for (int k0 = 0; k0 < n; k0 += PVLM_CHOL_NB, ++step) {
     const int kb = std::min(PVLM_CHOL_NB, n - k0), rem = n - k0 - kb;
+    if (plan) {
+      const int nrt = plan->row_off[step + 1] - plan->row_off[step], npr = plan->pair_off[step + 1] - plan->pair_off[step];
+      hipLaunchKernelGGL(k_chol_diag_panel, dim3((unsigned)std::max(1, nrt * 8)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info, d_info,
+                         ride ? (const double*)d_B : nullptr, d_y, plan->d_row_tiles + plan->row_off[step], nrt);
+      const int fwd_blocks = (ride && rem > 0) ? (rem + 255) / 256 : 0;
+      if (npr + fwd_blocks > 0)
+        hipLaunchKernelGGL(k_chol_update_mfma, dim3((unsigned)(npr + fwd_blocks)), dim3(256), 0, s, d_M, n, k0, kb, 0, d_info, npr, d_B, d_y, 0,
+                           plan->d_pairs + plan->pair_off[step]);
+      continue;
+    }
     if (fused) {
       // a failed pivot: every workgroup finds it itself (same arithmetic on the same block) and returns; workgroup 0 records it
       // in *info, which the later launches test on entry
       hipLaunchKernelGGL(k_chol_diag_panel, dim3(std::max(1, (rem + 7) / 8)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, d_info, d_info,
-                         ride ? (const double*)d_B : nullptr, d_y);
+                         ride ? (const double*)d_B : nullptr, d_y, (const int*)nullptr, 0);
     }
 #if PVLM_MEASURED_VARIANTS
     else {
@@ -471,6 +500,177 @@ static pvlm_status ws_reserve(pvlm_ctx* ctx, size_t bytes) {
 }
 static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// ---- tile-sparse plan of pvlm_spd_solve_blocks ------------------------------------------------------------------------------------
+// The reduced pose system of a Floor-sized run (1593 scans, 9558 unknowns) is block-sparse: 15 neighbours per scan.  Factorised as a
+// dense matrix it cost 39.6 ms per LM step and 46 % of the whole EstimatePose call (profiles/r3_floor_like_1593.txt); the reference
+// selects SPARSE_SCHUR there (util/Optimization.cpp:641-658).  The plan keeps the dense kernels and their 64 x 64 / 32-column tiling
+// and makes them skip what is structurally zero:
+//   1. nodes = groups of unknowns that always appear together (the 6 parameters of a pose); minimum-degree ordering of the node graph,
+//      then the postorder of its elimination tree, so that nodes with the same structure sit next to each other (minimum degree alone
+//      scatters them: 93 % of the tile updates of the dense factorisation remain; with the postorder 21 %);
+//   2. symbolic factorisation at the granularity the kernels work at — which 64-row tiles hold a nonzero of which 32-column block
+//      column, fill included;
+//   3. per block column the list of its row tiles (panel) and of the tile pairs its rank-32 update touches.
+// Unknowns are permuted on the host (indices, scale, damping, right-hand side); the device sees an ordinary symmetric system.
+// One plan is cached per context, keyed by a hash of the index lists: the LM steps of a Solve share their structure.
+struct SpdPlan {
+  unsigned long long key = 0;
+  int n = 0;
+  bool sparse = false;
+  std::vector<int> new_of_old;                 // permutation of the unknowns
+  std::vector<int> row_off, pair_off;          // steps + 1
+  int* d_row_tiles = nullptr; int2* d_pairs = nullptr;
+  double update_fraction = 1.0;                // tile updates / tile updates of the dense factorisation
+};
+
+static unsigned long long spd_hash(int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](const int* p, size_t count) { for (size_t i = 0; i < count; ++i) { h ^= (unsigned)p[i]; h *= 1099511628211ull; } };
+  mix(&n, 1); mix(&n_blocks, 1); mix(row_idx, (size_t)n_blocks * 6); mix(col_idx, (size_t)n_blocks * 6); mix(mirror, (size_t)n_blocks);
+  return h;
+}
+
+static void spd_plan_free(pvlm_ctx* ctx, SpdPlan* p) {
+  if (!p) return;
+  pvlm_i_free(ctx, p->d_row_tiles); pvlm_i_free(ctx, p->d_pairs);
+  delete p;
+}
+void pvlm_i_spd_plan_release(pvlm_ctx* ctx) { spd_plan_free(ctx, static_cast<SpdPlan*>(ctx->spd_plan)); ctx->spd_plan = nullptr; }
+
+static pvlm_status spd_plan_build(pvlm_ctx* ctx, int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror, SpdPlan* P) {
+  P->n = n; P->sparse = false;
+  P->new_of_old.resize((size_t)n);
+  for (int i = 0; i < n; ++i) P->new_of_old[(size_t)i] = i;
+  static const int min_n = getenv("PVLM_SPD_SPARSE_MIN") ? atoi(getenv("PVLM_SPD_SPARSE_MIN")) : 1500;
+  if (n < min_n || n_blocks == 0) return PVLM_OK;
+  // ---- nodes: unknowns that share a block side
+  std::vector<int> uf((size_t)n);
+  for (int i = 0; i < n; ++i) uf[(size_t)i] = i;
+  auto find = [&](int a) { while (uf[(size_t)a] != a) { uf[(size_t)a] = uf[(size_t)uf[(size_t)a]]; a = uf[(size_t)a]; } return a; };
+  auto side = [&](const int* idx) { int first = -1; for (int r = 0; r < 6; ++r) { const int i = idx[r]; if (i < 0 || i >= n) continue; if (first < 0) first = find(i); else { const int q = find(i); if (q != first) uf[(size_t)std::max(q, first)] = std::min(q, first), first = std::min(q, first); } } return first; };
+  for (int b = 0; b < n_blocks; ++b) { side(row_idx + 6 * b); side(col_idx + 6 * b); }
+  std::vector<int> node_of((size_t)n, -1);
+  std::vector<std::vector<int>> members;
+  for (int i = 0; i < n; ++i) { const int r = find(i); if (node_of[(size_t)r] < 0) { node_of[(size_t)r] = (int)members.size(); members.emplace_back(); } node_of[(size_t)i] = node_of[(size_t)r]; members[(size_t)node_of[(size_t)i]].push_back(i); }
+  const int N = (int)members.size();
+  std::vector<std::vector<int>> adj((size_t)N);
+  for (int b = 0; b < n_blocks; ++b) {
+    int a = -1, c = -1;
+    for (int r = 0; r < 6 && a < 0; ++r) if (row_idx[6 * b + r] >= 0 && row_idx[6 * b + r] < n) a = node_of[(size_t)row_idx[6 * b + r]];
+    for (int r = 0; r < 6 && c < 0; ++r) if (col_idx[6 * b + r] >= 0 && col_idx[6 * b + r] < n) c = node_of[(size_t)col_idx[6 * b + r]];
+    if (a >= 0 && c >= 0 && a != c) { adj[(size_t)a].push_back(c); adj[(size_t)c].push_back(a); }
+  }
+  for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  // ---- minimum degree: the elimination game on bitset rows (N is a few thousand: eliminating a node ORs its row into its neighbours',
+  // 25 words each at Floor size; sorted-list merges took 70 ms per plan there, this takes 3)
+  if (N > 16384) { for (int i = 0; i < n; ++i) P->new_of_old[(size_t)i] = i; return PVLM_OK; }
+  std::vector<int> order; order.reserve((size_t)N);
+  {
+    const int W = (N + 63) / 64;
+    std::vector<unsigned long long> bits((size_t)N * W, 0ull);
+    std::vector<int> degree((size_t)N, 0);
+    for (int v = 0; v < N; ++v) { for (int a : adj[(size_t)v]) bits[(size_t)v * W + (a >> 6)] |= 1ull << (a & 63); degree[(size_t)v] = (int)adj[(size_t)v].size(); }
+    std::vector<char> gone((size_t)N, 0);
+    std::vector<int> nb;
+    for (int step = 0; step < N; ++step) {
+      int best = -1, deg = 0x7fffffff;
+      for (int v = 0; v < N; ++v) if (!gone[(size_t)v] && degree[(size_t)v] < deg) { deg = degree[(size_t)v]; best = v; }
+      gone[(size_t)best] = 1; order.push_back(best);
+      const unsigned long long* rb = &bits[(size_t)best * W];
+      nb.clear();
+      for (int w = 0; w < W; ++w) for (unsigned long long m = rb[w]; m; m &= m - 1) nb.push_back(w * 64 + __builtin_ctzll(m));
+      for (int a : nb) {
+        unsigned long long* ra = &bits[(size_t)a * W];
+        int d = 0;
+        for (int w = 0; w < W; ++w) { ra[w] |= rb[w]; }
+        ra[a >> 6] &= ~(1ull << (a & 63)); ra[best >> 6] &= ~(1ull << (best & 63));
+        for (int w = 0; w < W; ++w) d += __builtin_popcountll(ra[w]);
+        degree[(size_t)a] = d;
+      }
+    }
+  }
+  // ---- elimination tree of the permuted graph + postorder
+  {
+    std::vector<int> pos((size_t)N);
+    for (int k = 0; k < N; ++k) pos[(size_t)order[(size_t)k]] = k;
+    std::vector<int> parent((size_t)N, -1), anc((size_t)N, -1);
+    for (int i = 0; i < N; ++i)
+      for (int w : adj[(size_t)order[(size_t)i]]) {
+        int j = pos[(size_t)w];
+        while (j != -1 && j < i) { const int nxt = anc[(size_t)j]; anc[(size_t)j] = i; if (nxt == -1) parent[(size_t)j] = i; j = nxt; }
+      }
+    std::vector<std::vector<int>> child((size_t)N);
+    std::vector<int> roots;
+    for (int v = 0; v < N; ++v) { if (parent[(size_t)v] >= 0) child[(size_t)parent[(size_t)v]].push_back(v); else roots.push_back(v); }
+    std::vector<int> post; post.reserve((size_t)N);
+    std::vector<std::pair<int, size_t>> stack;
+    for (int r : roots) {
+      stack.push_back({r, 0});
+      while (!stack.empty()) {
+        auto& top = stack.back();
+        if (top.second < child[(size_t)top.first].size()) { const int c = child[(size_t)top.first][top.second++]; stack.push_back({c, 0}); }
+        else { post.push_back(top.first); stack.pop_back(); }
+      }
+    }
+    std::vector<int> reordered((size_t)N);
+    for (int k = 0; k < N; ++k) reordered[(size_t)k] = order[(size_t)post[(size_t)k]];
+    order.swap(reordered);
+  }
+  {
+    int next = 0;
+    for (int v : order) for (int i : members[(size_t)v]) P->new_of_old[(size_t)i] = next++;
+  }
+  // ---- symbolic factorisation on (64-row tile) x (32-column block column) cells
+  const int C = (n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB, T = (n + 63) / 64;
+  std::vector<unsigned char> nz((size_t)T * C, 0);
+  for (int b = 0; b < n_blocks; ++b)
+    for (int r = 0; r < 6; ++r) {
+      const int io = row_idx[6 * b + r];
+      if (io < 0 || io >= n) continue;
+      const int i = P->new_of_old[(size_t)io];
+      for (int c = 0; c < 6; ++c) {
+        const int jo = col_idx[6 * b + c];
+        if (jo < 0 || jo >= n) continue;
+        const int j = P->new_of_old[(size_t)jo];
+        const int lo = std::min(i, j), hi = std::max(i, j);
+        nz[(size_t)(hi / 64) * C + lo / PVLM_CHOL_NB] = 1;
+      }
+    }
+  std::vector<int> row_tiles; std::vector<int2> pairs;
+  P->row_off.assign(1, 0); P->pair_off.assign(1, 0);
+  long long dense_pairs = 0;
+  std::vector<int> R;
+  for (int k = 0; k < C; ++k) {
+    const int base = std::min(n, (k + 1) * PVLM_CHOL_NB);
+    const int t0 = base / 64;
+    R.clear();
+    for (int t = t0; t < T; ++t) if (nz[(size_t)t * C + k] && (t + 1) * 64 > base) R.push_back(t);
+    for (int t : R) row_tiles.push_back(t);
+    for (size_t a = 0; a < R.size(); ++a)
+      for (size_t c = 0; c <= a; ++c) {
+        pairs.push_back(make_int2(R[a], R[c]));
+        for (int col = 2 * R[c]; col <= 2 * R[c] + 1; ++col) if (col > k && col < C) nz[(size_t)R[a] * C + col] = 1;
+      }
+    P->row_off.push_back((int)row_tiles.size()); P->pair_off.push_back((int)pairs.size());
+    const long long dt = (n - base + 63) / 64;
+    dense_pairs += dt * (dt + 1) / 2;
+  }
+  P->update_fraction = dense_pairs ? (double)pairs.size() / (double)dense_pairs : 1.0;
+  static const double max_fraction = getenv("PVLM_SPD_SPARSE_FRACTION") ? atof(getenv("PVLM_SPD_SPARSE_FRACTION")) : 0.6;
+  if (P->update_fraction > max_fraction) {     // not sparse enough to pay for the irregular tile lists: natural order, dense kernels
+    for (int i = 0; i < n; ++i) P->new_of_old[(size_t)i] = i;
+    return PVLM_OK;
+  }
+  pvlm_status st = pvlm_i_alloc(ctx, &P->d_row_tiles, std::max<size_t>(row_tiles.size(), 1));
+  if (!st) st = pvlm_i_alloc(ctx, &P->d_pairs, std::max<size_t>(pairs.size(), 1));
+  if (!st && !row_tiles.empty()) st = pvlm_i_h2d_q(ctx, P->d_row_tiles, row_tiles.data(), row_tiles.size() * sizeof(int));
+  if (!st && !pairs.empty()) st = pvlm_i_h2d_q(ctx, P->d_pairs, pairs.data(), pairs.size() * sizeof(int2));
+  if (!st) st = pvlm_i_sync(ctx);
+  if (st) return st;
+  P->sparse = true;
+  return PVLM_OK;
+}
+
 extern "C" {
 
 // Block-sparse form for the LM driver: assembles M = D (sum of blocks) D + diag(diag_add) on the device (D = diag(scale)),
@@ -484,6 +684,37 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   *info_out = 0;
   if (n == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  // the plan of this structure (ordering + tile lists), built once and reused while the index lists stay the same
+  SpdPlan* plan = static_cast<SpdPlan*>(ctx->spd_plan);
+  std::vector<int> prow, pcol;
+  std::vector<double> pscale, pdiag, prhs;
+  try {
+    const unsigned long long key = spd_hash(n, n_blocks, row_idx, col_idx, mirror);
+    if (!plan || plan->key != key || plan->n != n) {
+      PVLM_TRY_SYNC(ctx);
+      pvlm_i_trace("spd solve: before the plan");
+      pvlm_i_spd_plan_release(ctx);
+      plan = new SpdPlan();
+      plan->key = key;
+      ctx->spd_plan = plan;
+      const pvlm_status pst = spd_plan_build(ctx, n, n_blocks, row_idx, col_idx, mirror, plan);
+      if (pst) { pvlm_i_spd_plan_release(ctx); return pst; }
+      if (getenv("PVLM_TRACE")) { char msg[96]; snprintf(msg, sizeof msg, "spd plan built: %s, update fraction %.3f, n %d, blocks %d", plan->sparse ? "tile-sparse" : "dense", plan->update_fraction, n, n_blocks); pvlm_i_trace(msg); }
+    }
+    if (plan->sparse) {
+      const std::vector<int>& nw = plan->new_of_old;
+      prow.resize((size_t)n_blocks * 6); pcol.resize((size_t)n_blocks * 6);
+      for (size_t k = 0; k < prow.size(); ++k) { prow[k] = row_idx[k] >= 0 && row_idx[k] < n ? nw[(size_t)row_idx[k]] : -1; pcol[k] = col_idx[k] >= 0 && col_idx[k] < n ? nw[(size_t)col_idx[k]] : -1; }
+      pscale.resize((size_t)n); pdiag.resize((size_t)n); prhs.resize((size_t)n);
+      for (int i = 0; i < n; ++i) { const size_t q = (size_t)nw[(size_t)i]; pscale[q] = scale[i]; pdiag[q] = diag_add[i]; prhs[q] = rhs[i]; }
+      row_idx = prow.data(); col_idx = pcol.data(); scale = pscale.data(); diag_add = pdiag.data();
+    }
+  } catch (const std::bad_alloc&) {
+    PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: out of host memory");
+    return PVLM_ERR_NOMEM;
+  }
+  double* rhs_io = plan->sparse ? prhs.data() : rhs;
+  SpdTileLists lists{plan->d_row_tiles, plan->d_pairs, plan->row_off.data(), plan->pair_off.data()};
   const size_t linv_count = (size_t)((n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
   const size_t need = pad256((size_t)n * n * 8) + pad256((size_t)n_blocks * 36 * 8) + 3 * pad256((size_t)n_blocks * 6 * 4) + 4 * pad256((size_t)n * 8) +
                       pad256(linv_count * 8) + 256;
@@ -507,7 +738,7 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     }
     if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_scale, scale, (size_t)n * sizeof(double));
     if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_diag, diag_add, (size_t)n * sizeof(double));
-    if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_rhs, rhs, (size_t)n * sizeof(double));
+    if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_rhs, rhs_io, (size_t)n * sizeof(double));
     int info = 0;
     if (e == hipSuccess && !st) {
       if (n_blocks) hipLaunchKernelGGL(k_scatter_blocks, dim3((unsigned)(((long long)n_blocks * 36 + 255) / 256)), dim3(256), 0, s, n, n_blocks, d_row, d_col, d_mir, d_blocks, d_scale, d_M);
@@ -516,18 +747,28 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     }
     if (e == hipSuccess && !st) e = hipMemsetAsync(d_info, 0, sizeof(int), s);
     if (e == hipSuccess && !st) {
-      chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_Linv, d_y, d_info);
+      chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_Linv, d_y, d_info, plan->sparse ? &lists : nullptr);
       e = hipGetLastError();
     }
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
     if (!st) st = pvlm_i_d2h_q(ctx, &info, d_info, sizeof(int));
-    if (!st) st = pvlm_i_d2h_q(ctx, rhs, d_rhs, (size_t)n * sizeof(double));
+    if (!st) st = pvlm_i_d2h_q(ctx, rhs_io, d_rhs, (size_t)n * sizeof(double));
     { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+    pvlm_i_trace("spd solve: factorised and solved");
+    if (!st && plan->sparse) for (int i = 0; i < n; ++i) rhs[i] = prhs[(size_t)plan->new_of_old[(size_t)i]];
     *info_out = info;
   } else {
     hipStreamSynchronize(ctx->stream);
   }
   return st;
+}
+
+pvlm_status pvlm_spd_plan_info(const pvlm_ctx* ctx, int* tile_sparse, double* update_fraction) {
+  if (!ctx) return PVLM_ERR_ARG;
+  const SpdPlan* p = static_cast<const SpdPlan*>(ctx->spd_plan);
+  if (tile_sparse) *tile_sparse = p && p->sparse ? 1 : 0;
+  if (update_fraction) *update_fraction = p ? p->update_fraction : 1.0;
+  return PVLM_OK;
 }
 
 // Solves A X = B for symmetric positive definite A (n x n, dense, both triangles or at least the lower one of the

@@ -591,9 +591,20 @@ int main(int argc, char** argv) {
       rd(f, blocks.data(), blocks.size()); rd(f, scale.data(), n); rd(f, diag.data(), n); rd(f, rhs.data(), n);
       int info = -1;
       Engine& e = Engine::Default();
-      e.Check(pvlm_spd_solve_blocks(e.ctx(), (int)n, (int)nb, rows.data(), cols.data(), mirror.data(), blocks.data(), scale.data(), diag.data(), rhs.data(), &info),
-              "pvlm_spd_solve_blocks");
+      const int repeat = argc > 3 ? std::max(1, atoi(argv[3])) : 1;       // optional: solve the same system again (the cached plan is reused)
+      const std::vector<double> rhs0 = rhs;
+      double ms = 0;
+      for (int r = 0; r < repeat; ++r) {
+        rhs = rhs0;
+        const auto t0 = std::chrono::steady_clock::now();
+        e.Check(pvlm_spd_solve_blocks(e.ctx(), (int)n, (int)nb, rows.data(), cols.data(), mirror.data(), blocks.data(), scale.data(), diag.data(), rhs.data(), &info),
+                "pvlm_spd_solve_blocks");
+        ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      }
       printf("info %d\n", info);
+      int sparse = 0; double fraction = 1.0;
+      pvlm_spd_plan_info(e.ctx(), &sparse, &fraction);
+      printf("plan %s fraction %.4f last_solve_ms %.3f\n", sparse ? "tile-sparse" : "dense", fraction, ms);
       if (info == 0) for (double v : rhs) printf("x %a\n", v);
     } else if (cmd == "loadpcd") {
       // loadpcd <file.pcd> : Velodyne::LoadLidar — prints the count, valid flag and every point (hex floats)

@@ -39,47 +39,84 @@ def test_dense_spd_solve(tmp_path, n):
     assert info == n // 2 + 1
 
 
-def test_block_sparse_assembly_and_solve(tmp_path):
-    """M = D (sum of 6x6 blocks) D + diag: pose-pair blocks mirrored, constant blocks (-1) dropped, repeated blocks summed."""
-    import struct
-    rng = np.random.default_rng(5)
-    P = 40                                   # poses; pose 0 fully constant, pose 1 has a constant rotation block
+def _block_system(rng, P, pairs, constant=()):
+    """Poses with 6 unknowns each (those in `constant`: (pose, half) pairs are fixed), one 6x6 block per (a, b) of `pairs`."""
     off = np.full((P, 6), -1, np.int64); n = 0
     for p in range(P):
         for half in range(2):
-            if p == 0 or (p == 1 and half == 0):
+            if (p, half) in constant:
                 continue
             off[p, 3 * half:3 * half + 3] = np.arange(n, n + 3); n += 3
     rows, cols, mirror, blocks = [], [], [], []
     H = np.zeros((n, n))
-    pairs = [(p, p) for p in range(P)] + [(p, q) for p in range(P) for q in range(p + 1, min(p + 4, P))] + [(2, 3), (5, 5)]   # two repeated
     for (a, b) in pairs:
         if a == b:
             J = rng.normal(size=(9, 6)); blk = J.T @ J
         else:
             blk = rng.normal(size=(6, 6)) * 0.2
         rows.append(off[a]); cols.append(off[b]); mirror.append(int(a != b)); blocks.append(blk.reshape(-1))
-        for r in range(6):
-            for c in range(6):
-                i, j = off[a, r], off[b, c]
-                if i < 0 or j < 0:
-                    continue
-                H[i, j] += blk[r, c]
-                if a != b:
-                    H[j, i] += blk[r, c]
+        ia, ib = off[a], off[b]
+        va, vb = ia >= 0, ib >= 0
+        H[np.ix_(ia[va], ib[vb])] += blk[np.ix_(va, vb)]
+        if a != b:
+            H[np.ix_(ib[vb], ia[va])] += blk[np.ix_(va, vb)].T
     scale = 1.0 / (1.0 + np.sqrt(np.maximum(np.diag(H), 0)))
     diag = rng.uniform(0.5, 1.0, size=n) + 10.0
     rhs = rng.normal(size=n)
     M = H * scale[:, None] * scale[None, :] + np.diag(diag)
+    return n, rows, cols, mirror, blocks, scale, diag, rhs, M
+
+
+def _solve_blocks(tmp_path, n, rows, cols, mirror, blocks, scale, diag, rhs, repeat=1):
+    import struct
     path = os.path.join(str(tmp_path), "blk.bin")
     with open(path, "wb") as f:
         f.write(struct.pack("<ii", n, len(blocks)))
         f.write(np.array(rows, np.int32).tobytes()); f.write(np.array(cols, np.int32).tobytes()); f.write(np.array(mirror, np.int32).tobytes())
         f.write(np.array(blocks, np.float64).tobytes()); f.write(scale.tobytes()); f.write(diag.tobytes()); f.write(rhs.tobytes())
-    out = host_io.run("spdblocks", path)
-    assert int(out[0].split()[1]) == 0
-    x = np.array([float.fromhex(l.split()[1]) for l in out[1:]])
+    out = host_io.run("spdblocks", path, repeat)
+    info = int(out[0].split()[1])
+    x = np.array([float.fromhex(l.split()[1]) for l in out if l.startswith("x ")])
+    return info, x, out
+
+
+def test_block_sparse_assembly_and_solve(tmp_path):
+    """M = D (sum of 6x6 blocks) D + diag: pose-pair blocks mirrored, constant blocks (-1) dropped, repeated blocks summed."""
+    rng = np.random.default_rng(5)
+    P = 40                                   # poses; pose 0 fully constant, pose 1 has a constant rotation block
+    pairs = [(p, p) for p in range(P)] + [(p, q) for p in range(P) for q in range(p + 1, min(p + 4, P))] + [(2, 3), (5, 5)]   # two repeated
+    n, rows, cols, mirror, blocks, scale, diag, rhs, M = _block_system(rng, P, pairs, constant={(0, 0), (0, 1), (1, 0)})
+    info, x, _ = _solve_blocks(tmp_path, n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert info == 0
     assert np.allclose(x, np.linalg.solve(M, rhs), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("P,links", [(300, "chain"), (400, "loops"), (260, "dense")])
+def test_tile_sparse_factorisation(tmp_path, monkeypatch, P, links):
+    """The tile-sparse plan of pvlm_spd_solve_blocks (minimum-degree + elimination-tree postorder of the pose graph, symbolic
+    factorisation on 64-row x 32-column cells, per block column only the tiles that hold a nonzero): same solution as a dense
+    solve — for a temporal chain, for a chain with long loop closures (fill-in), and for a graph too dense to pay (dense kernels)."""
+    monkeypatch.setenv("PVLM_SPD_SPARSE_MIN", "0")
+    rng = np.random.default_rng(P)
+    pairs = [(p, p) for p in range(P)] + [(p, q) for p in range(P) for q in range(p + 1, min(p + 3, P))]
+    if links == "loops":
+        pairs += [(int(a), int(b)) for a, b in zip(rng.integers(0, P, 150), rng.integers(0, P, 150)) if a < b]
+    if links == "dense":
+        pairs += [(p, q) for p in range(P) for q in range(p + 1, P) if rng.uniform() < 0.3]
+    n, rows, cols, mirror, blocks, scale, diag, rhs, M = _block_system(rng, P, pairs, constant={(0, 0), (0, 1), (7, 1)})
+    info, x, out = _solve_blocks(tmp_path, n, rows, cols, mirror, blocks, scale, diag, rhs, repeat=2)      # the second solve reuses the cached plan
+    want = np.linalg.solve(M, rhs)
+    assert info == 0
+    assert np.allclose(x, want, rtol=1e-9, atol=1e-12)
+    plan = [l for l in out if l.startswith("plan")][0].split()
+    print(" ".join(plan))
+    assert (plan[1] == "tile-sparse") == (links != "dense")
+    if links == "chain":
+        assert float(plan[3]) < 0.15        # fraction of the dense factorisation's tile updates
+    # not positive definite -> reported through info, as the dense path does
+    diag2 = diag.copy(); diag2[n // 2] = -1e6
+    info, _, _ = _solve_blocks(tmp_path, n, rows, cols, mirror, blocks, scale, diag2, rhs)
+    assert info != 0
 
 
 def test_solve_with_gpu_cholesky_matches_twin(oracle, tmp_path, monkeypatch):
