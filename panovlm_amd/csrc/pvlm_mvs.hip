@@ -408,19 +408,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
   if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
 }
-// MEASURED VARIANT, not in the default library (built with -DPVLM_MEASURED_VARIANTS=1, selected with PVLM_MVS_SPEC=1).  Round 3 built
-// it to shorten the per-pixel chain of a single view's sequential sweep (VERDICT round 2, item 5) and measured NO gain
-// (profiles/r3_mvs_spec_ab.txt, 1440 x 720, 4 neighbours): 156.9 ms per iteration against 152.9 ms for the wave-per-pixel kernel;
-// per launch 72 us against 70 us on full 720-pixel diagonals, 38 us against 50 us on diagonals shorter than 50 pixels.  Why: a
-// pixel costs a fixed ~20 us (patch statistics, close neighbours, dependent global loads) plus ~4-5 us per CHAINED scoring; the
-// speculation cuts the chain from 8 scorings to 3, but every one of the four waves repeats the fixed part, so a full diagonal is
-// 2880 waves of (fixed + 3 scorings) on 1024 SIMDs — throughput-bound at about the time one wave per SIMD needs for its whole chain.
-// The exactness argument (process_pixel_spec == process_pixel, any batch width) stays tested on the CPU (tests/test_mvs_cpu.py).
-#ifndef PVLM_MEASURED_VARIANTS
-#define PVLM_MEASURED_VARIANTS 0
+// K13p — the same sweep as ONE persistent launch per iteration, ordered by data flow instead of by diagonal.
+// Round 3 launched one kernel per anti-diagonal (2159 at 1440 x 720, 8639 at 5760 x 2880): every diagonal waited for its slowest pixel
+// and for a launch, and every pixel paid its ~20 us of state-independent preparation (patch statistics, texel products) inside that
+// window.  A pixel only needs its two predecessors (left / up of the walk) to be FINAL; everything of the preparation depends on the
+// reference image alone.  Here a wave draws pixels from a ticket counter in walking order (diagonal after diagonal — so the wave that
+// owns a predecessor drew it earlier and is running: no deadlock whatever the number of resident waves), prepares the pixel, THEN waits
+// for the two per-pixel "done" stamps (acquire), runs the dependent chain, stores and stamps its own pixel (release).  The critical path
+// per diagonal is the chain of dependent scorings only; preparation and launch latency are off it.  Neighbours on the NEXT diagonal are
+// read before they change for the same reason as before: they wait for this pixel's stamp.  Results: those of the diagonal launches, bit for bit.
+__device__ __forceinline__ void mvs_walk_pixel(long long t, int rows, int cols, int* wx, int* wy) {     // ticket -> pixel in the walk's own frame
+  const long long m = rows < cols ? rows : cols, mx = rows < cols ? cols : rows, npix = (long long)rows * cols;
+  const long long ta = m * (m - 1) / 2, tb = ta + (mx - m + 1) * m;
+  auto tri = [](long long u, long long* d, long long* k) {                  // u-th element of 1 + 2 + 3 + ...: row d, position k
+    long long q = (long long)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
+    while ((q + 1) * (q + 2) / 2 <= u) ++q;
+    while (q * (q + 1) / 2 > u) --q;
+    *d = q; *k = u - q * (q + 1) / 2;
+  };
+  long long d, k;
+  if (t < ta) tri(t, &d, &k);
+  else if (t < tb) { const long long u = t - ta; d = m - 1 + u / m; k = u % m; }
+  else { long long dd, kk; tri(npix - 1 - t, &dd, &kk); d = (long long)rows + cols - 2 - dd; k = dd - kk; }
+  const long long r0 = d - (cols - 1) > 0 ? d - (cols - 1) : 0;
+  *wy = (int)(r0 + k); *wx = (int)(d - (r0 + k));
+}
+#ifndef PVLM_MVS_FLOW_SLEEP
+#define PVLM_MVS_FLOW_SLEEP 8     // x 64 cycles between two polls of a stamp
 #endif
-#if PVLM_MEASURED_VARIANTS
-// The same anti-diagonal with FOUR waves per pixel (one workgroup = one pixel): a single view's diagonal is at most
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_flow(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
+    float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int backward,
+    unsigned long long* ticket, int* done, int epoch) {
+  const int lane = threadIdx.x & 63;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
+  float4* lds = strips[threadIdx.x >> 6];
+  const long long npix = (long long)rows * cols;
+  const int sgn = backward ? 1 : -1;
+  while (true) {
+    unsigned long long t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1ull);
+    t = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    if ((long long)t >= npix) return;
+    int wx, wy;
+    mvs_walk_pixel((long long)t, rows, cols, &wx, &wy);
+    const int px = backward ? cols - 1 - wx : wx, py = backward ? rows - 1 - wy : wy;
+    const long long e = (long long)py * cols + px;
+    // ---- preparation: nothing here reads what the sweep writes (the pixel's own state is only written by this wave)
+    float dep = depth[e];
+    bool live = dep > 0;
+    PatchRegs<M> P;
+    if (live) {
+      wave_fill_patch<M>(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
+      live = P.inside && P.sq0 > 0;                                         // patch.sq0 <= 0 (:1069, :1087)
+    }
+    if (live) {
+      float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+      float c = conf[e];
+      // ---- the two predecessors of the walk must be final
+      const int lx = px + sgn, uy = py + sgn;
+      // polled with relaxed loads (an acquire load invalidates the CU's whole L1 at every poll: with thousands of waiting waves the
+      // working ones lost their cached texels all the time — first version: 3.4 s per iteration); ONE acquire fence once both are in
+      if (lane == 0) {
+        if (lx >= 0 && lx < cols) while (__hip_atomic_load(done + e + sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
+        if (uy >= 0 && uy < rows) while (__hip_atomic_load(done + e + (long long)sgn * cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // every lane reads the neighbours' state below
+      pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+      pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
+      WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
+      const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
+      pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
+      if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+    }
+    // a pixel the sweep skips keeps its state: its successors may read it at once
+    if (lane == 0) __hip_atomic_store(done + e, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Four waves per pixel (one workgroup = one pixel): a single view's diagonal is at most
 // min(rows, cols) pixels, i.e. with a wave per pixel a sixth of the chip's wave slots, each running a chain of 8-14 dependent
 // scorings of ~1300 instructions.  pvlm_mvs::process_pixel_spec scores the independent hypotheses of a pixel side by side — the two
 // propagated ones; batches of four consecutive refinements built as if none of them were accepted — one per wave, exchanges the four
@@ -448,6 +516,75 @@ struct BlockBatch {
   __device__ WaveScorer<M>& single() { return *scorer; }
 };
 
+// K13q — the data-flow sweep with FOUR waves per pixel (one workgroup = one pixel).  Once the preparation is off the critical path
+// (K13p) what is left per pixel is the chain of 8-14 dependent scorings; pvlm_mvs::process_pixel_spec scores the independent hypotheses
+// of a pixel side by side — one per wave, confidences exchanged through LDS and resolved in order: the same result as the chain, bit
+// for bit, in 1 + ~3 dependent scorings (tests/test_mvs_cpu.py).  Round 3 measured this form with one launch per diagonal and found
+// no gain, because all four waves repeated the preparation INSIDE the diagonal's window; here they do it while they wait.
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_flow_spec(
+    int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
+    float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int backward,
+    unsigned long long* ticket, int* done, int epoch) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = pvlm_mvs::num_texels(half_window, step);
+  __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
+  __shared__ pvlm_mvs::Hypothesis xchg[8];
+  __shared__ unsigned long long drawn;
+  float4* lds = strips[wave];
+  const long long npix = (long long)rows * cols;
+  const int sgn = backward ? 1 : -1;
+  while (true) {
+    if (threadIdx.x == 0) drawn = atomicAdd(ticket, 1ull);
+    __syncthreads();
+    const unsigned long long t = drawn;
+    if ((long long)t >= npix) return;                                       // the whole workgroup alike
+    int wx, wy;
+    mvs_walk_pixel((long long)t, rows, cols, &wx, &wy);
+    const int px = backward ? cols - 1 - wx : wx, py = backward ? rows - 1 - wy : wy;
+    const long long e = (long long)py * cols + px;
+    float dep = depth[e];
+    bool live = dep > 0;
+    PatchRegs<M> P;
+    if (live) {
+      wave_fill_patch<M>(ref_gray, rows, cols, px, py, half_window, step, n, lane, lds, P);
+      live = P.inside && P.sq0 > 0;
+    }
+    if (live) {
+      float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
+      float c = conf[e];
+      const int lx = px + sgn, uy = py + sgn;
+      if (threadIdx.x == 0) {
+        if (lx >= 0 && lx < cols) while (__hip_atomic_load(done + e + sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
+        if (uy >= 0 && uy < rows) while (__hip_atomic_load(done + e + (long long)sgn * cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+      pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
+      WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
+      BlockBatch<M> batch{&scorer, wave, lane, xchg, 0};
+      const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
+      pvlm_mvs::process_pixel_spec(A, rng, px, py, batch, dep, nrm3, c, 2, pdx, pdy);
+      if (threadIdx.x == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(done + e, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                                          // `drawn` and the exchange buffers are reused by the next pixel
+  }
+}
+
+// MEASURED VARIANT, not in the default library (built with -DPVLM_MEASURED_VARIANTS=1, selected with PVLM_MVS_SPEC=1).  Round 3 built
+// it to shorten the per-pixel chain of a single view's sequential sweep (VERDICT round 2, item 5) and measured NO gain
+// (profiles/r3_mvs_spec_ab.txt, 1440 x 720, 4 neighbours): 156.9 ms per iteration against 152.9 ms for the wave-per-pixel kernel;
+// per launch 72 us against 70 us on full 720-pixel diagonals, 38 us against 50 us on diagonals shorter than 50 pixels.  Why: a
+// pixel costs a fixed ~20 us (patch statistics, close neighbours, dependent global loads) plus ~4-5 us per CHAINED scoring; the
+// speculation cuts the chain from 8 scorings to 3, but every one of the four waves repeats the fixed part, so a full diagonal is
+// 2880 waves of (fixed + 3 scorings) on 1024 SIMDs — throughput-bound at about the time one wave per SIMD needs for its whole chain.
+// The exactness argument (process_pixel_spec == process_pixel, any batch width) stays tested on the CPU (tests/test_mvs_cpu.py).
+#ifndef PVLM_MEASURED_VARIANTS
+#define PVLM_MEASURED_VARIANTS 0
+#endif
+#if PVLM_MEASURED_VARIANTS
 template <int M>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_diag_spec(
     int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
@@ -658,12 +795,35 @@ static void launch_mvs_propagate(hipStream_t s, int rows, int cols, int half_win
     hipLaunchKernelGGL(k_mvs_propagate<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth, pass_seed, offset);
 }
 
-// one iteration of the sequential sweep: every anti-diagonal in walking order (iteration parity = direction, :1061, :1079)
+// one iteration of the sequential sweep (iteration parity = direction, :1061, :1079): one persistent launch (k_mvs_propagate_flow) when
+// the caller provides the ticket counter + per-pixel stamps (flow != nullptr; stamps of iteration `iter` = iter + 1, the caller zeroes
+// them once), otherwise — PVLM_MVS_FLOW=0, or no memory for the stamps — every anti-diagonal in walking order
+struct MvsFlow { unsigned long long* ticket; int* done; int blocks; bool spec; };
 static void launch_mvs_propagate_sequential(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
                                             const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, const unsigned char* depth_constant,
-                                            float min_depth, float max_depth, unsigned long long pass_seed, int iter) {
+                                            float min_depth, float max_depth, unsigned long long pass_seed, int iter, const MvsFlow* flow = nullptr) {
   const int backward = iter % 2, n_diag = rows + cols - 1;
   const bool small = pvlm_mvs::num_texels(half_window, step) <= 64;
+  if (flow) {
+    (void)hipMemsetAsync(flow->ticket, 0, sizeof(unsigned long long), s);
+    const dim3 grid((unsigned)flow->blocks), block(256);
+    if (flow->spec) {
+      if (small)
+        hipLaunchKernelGGL(k_mvs_propagate_flow_spec<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth,
+                           pass_seed, backward, flow->ticket, flow->done, iter + 1);
+      else
+        hipLaunchKernelGGL(k_mvs_propagate_flow_spec<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant,
+                           min_depth, max_depth, pass_seed, backward, flow->ticket, flow->done, iter + 1);
+      return;
+    }
+    if (small)
+      hipLaunchKernelGGL(k_mvs_propagate_flow<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth,
+                         pass_seed, backward, flow->ticket, flow->done, iter + 1);
+    else
+      hipLaunchKernelGGL(k_mvs_propagate_flow<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth,
+                         max_depth, pass_seed, backward, flow->ticket, flow->done, iter + 1);
+    return;
+  }
 #if PVLM_MEASURED_VARIANTS
   static const bool spec = getenv("PVLM_MVS_SPEC") && atoi(getenv("PVLM_MVS_SPEC")) != 0;   // four waves per pixel (measured: no gain, see above)
 #else
@@ -692,6 +852,39 @@ static void launch_mvs_propagate_sequential(hipStream_t s, int rows, int cols, i
                          min_depth, max_depth, pass_seed, d, backward);
   }
 }
+
+#ifndef PVLM_MVS_FLOW_MAX_DIAG
+#define PVLM_MVS_FLOW_MAX_DIAG 1024   // longest anti-diagonal (pixels) up to which the data-flow launch is used
+#endif
+// scratch of the persistent sweep: ticket counter + one stamp per pixel (zeroed here), grid = what the chip keeps resident
+static bool mvs_flow_begin(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, MvsFlow* f) {
+  // PVLM_MVS_FLOW: 0 = one launch per anti-diagonal, 1 = persistent data-flow launch with a wave per pixel (K13p), 2 = with four waves per
+  // pixel (K13q).  Unset: by size — measured per iteration (profiles/r4_mvs_seq_forms.txt), 1440 x 720: 137.7 / 133.8 / 117.5 ms for
+  // 0 / 1 / 2; 5760 x 2880: 822 / 875 / 1462 ms (a 2880-pixel diagonal fills the chip with one wave per pixel; four per pixel oversubscribe it)
+  static const int forced = getenv("PVLM_MVS_FLOW") ? atoi(getenv("PVLM_MVS_FLOW")) : -1;
+  const int mode = forced >= 0 ? forced : (std::min(rows, cols) <= PVLM_MVS_FLOW_MAX_DIAG ? 2 : 0);
+  f->ticket = nullptr; f->done = nullptr; f->blocks = 0; f->spec = mode == 2;
+  if (mode == 0) return false;
+  const size_t npix = (size_t)rows * cols;
+  if (pvlm_i_alloc(ctx, &f->ticket, (size_t)1)) { f->ticket = nullptr; return false; }
+  if (pvlm_i_alloc(ctx, &f->done, npix)) { pvlm_i_free(ctx, f->ticket); f->ticket = nullptr; f->done = nullptr; return false; }
+  (void)hipMemsetAsync(f->done, 0, npix * sizeof(int), ctx->stream);
+  int per_cu = 0;
+  const bool small = pvlm_mvs::num_texels(half_window, step) <= 64;
+  hipError_t e;
+  if (f->spec) e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mvs_propagate_flow_spec<1>, 256, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mvs_propagate_flow_spec<PVLM_MVS_MAXM>, 256, 0);
+  else e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mvs_propagate_flow<1>, 256, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mvs_propagate_flow<PVLM_MVS_MAXM>, 256, 0);
+  if (e != hipSuccess || per_cu < 1) per_cu = 1;
+  f->blocks = std::max(1, ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu;
+  // more waves than ~2.5 anti-diagonals hold pixels only wait: one diagonal in its dependent chain, the next ones preparing
+  static const double depth_diags = getenv("PVLM_MVS_FLOW_DIAGS") ? atof(getenv("PVLM_MVS_FLOW_DIAGS")) : 2.5;
+  const int useful = (int)(depth_diags * std::min(rows, cols) / (f->spec ? 1.0 : 4.0)) + 1;
+  f->blocks = std::max(1, std::min(f->blocks, useful));
+  return true;
+}
+static void mvs_flow_end(pvlm_ctx* ctx, MvsFlow* f) { pvlm_i_free(ctx, f->ticket); pvlm_i_free(ctx, f->done); f->ticket = nullptr; f->done = nullptr; }
 
 // MVS::InitDepthNormal (mvs/MVS.cpp:496-584, the `#elif 1` branch :511-514): LiDAR depth image (uint16, depth * 256) where it has a
 // value, a uniform random depth elsewhere, optional mask, a random normal facing the camera for every pixel the mask keeps.
@@ -936,11 +1129,14 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
         }
         pvlm_i_free(ctx, d_wtab);
       } else if (strategy == 2) {
+        MvsFlow flow;
+        const bool have_flow = mvs_flow_begin(ctx, rows, cols, half_window, step, &flow);
         for (int iter = 0; iter < max_iter; ++iter) {
-          pvlm_prof_scope prof(ctx, 1);                  // one profile interval per iteration (rows + cols - 1 launches)
+          pvlm_prof_scope prof(ctx, 1);                  // one profile interval per iteration (one persistent launch, or rows + cols - 1 launches)
           launch_mvs_propagate_sequential(s, rows, cols, half_window, step, d_img, d_unit, nb, d_depth, d_normal, d_conf, d_const, min_depth, max_depth,
-                                          pvlm_mvs::pass_seed(seed, iter), iter);
+                                          pvlm_mvs::pass_seed(seed, iter), iter, have_flow ? &flow : nullptr);
         }
+        mvs_flow_end(ctx, &flow);
         hipLaunchKernelGGL(k_mvs_threshold, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (long long)npix, d_const, conf_threshold, d_depth, d_normal, d_conf);
       } else {
         float* d_wtab = nullptr;                       // patch weights of the thread-per-pixel form, [texel][pixel of the colour in a band of rows]
@@ -1346,11 +1542,14 @@ static pvlm_status views_estimate(pvlm_ctx* ctx, pvlm_mvs_views* v, int ref, int
       pvlm_i_free(ctx, d_wtab);
     } else {
       if (strategy == 2) {
+        MvsFlow flow;
+        const bool have_flow = mvs_flow_begin(ctx, v->rows, v->cols, half_window, step, &flow);
         for (int iter = 0; iter < max_iter; ++iter) {
           pvlm_prof_scope prof(ctx, 1);
           launch_mvs_propagate_sequential(s, v->rows, v->cols, half_window, step, v->d_gray + o, v->d_unit, nb, v->d_depth + o, v->d_normal + 3 * o, v->d_conf + o,
-                                          d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, iter), iter);
+                                          d_const, min_depth, max_depth, pvlm_mvs::pass_seed(seed, iter), iter, have_flow ? &flow : nullptr);
         }
+        mvs_flow_end(ctx, &flow);
       } else {
         float* d_wtab = nullptr;
         const size_t wtab_floats = mvs_lane_bands(v->rows, (v->cols + 1) / 2, half_window, step).floats;

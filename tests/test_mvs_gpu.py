@@ -233,7 +233,7 @@ def test_other_launch_forms_give_the_same_maps():
     the non-default forms forced: every form must give the oracle's maps bit for bit."""
     import subprocess
     here = os.path.abspath(__file__)
-    for env in ({"PVLM_MVS_QUAD_MIN": "1"}, {"PVLM_MVS_LANE": "0"}, {"PVLM_MVS_LANE_TABLE_MB": "4"}):
+    for env in ({"PVLM_MVS_QUAD_MIN": "1"}, {"PVLM_MVS_LANE": "0"}, {"PVLM_MVS_LANE_TABLE_MB": "4"}, {"PVLM_MVS_FLOW": "0"}, {"PVLM_MVS_FLOW": "1"}):   # FLOW 0: one launch per anti-diagonal, 1: data-flow launch, a wave per pixel (default at these sizes: 2)
         r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "sweep_matches_oracle or conf_map_matches_oracle or sequential", "-p", "no:cacheprovider"],
                            env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, (env, r.stdout[-1500:])
