@@ -95,7 +95,7 @@ pvlm_status pvlm_graph_launch(pvlm_ctx* ctx, pvlm_graph* graph);
 pvlm_status pvlm_graph_destroy(pvlm_ctx* ctx, pvlm_graph* graph);
 /* Per-kernel timing of the dominant kernels: when enabled, every launch of the fused
  * residual/Jacobian kernel (which=0), the materialise kernel (which=1) and the k-NN + plane-fit
- * association kernel (which=2) is bracketed by HIP events on the ctx stream.  pvlm_profile_read
+ * association kernel (which=2) and of the batched camera-LiDAR vote kernel (which=3) is bracketed by HIP events on the ctx stream.  pvlm_profile_read
  * synchronises and returns the accumulated milliseconds and launch count since the last
  * pvlm_profile_enable(ctx, 1). */
 pvlm_status pvlm_profile_enable(pvlm_ctx* ctx, int on);

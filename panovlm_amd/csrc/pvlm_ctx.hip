@@ -324,7 +324,7 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   pvlm_i_free(ctx, ctx->d_aa); pvlm_i_free(ctx, ctx->d_t); pvlm_i_free(ctx, ctx->d_pose_tab); pvlm_i_free(ctx, ctx->d_ws); pvlm_i_free(ctx, ctx->d_neq_tmp);
   pvlm_i_pool_release(ctx, true);   // objects the caller leaked (scans, residual sets) die with their slabs
   hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
-  for (int w = 0; w < 3; ++w) for (auto& pr : ctx->prof_pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (int w = 0; w < 4; ++w) for (auto& pr : ctx->prof_pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
   if (ctx->aux_stream) { hipStreamSynchronize(ctx->aux_stream); hipStreamDestroy(ctx->aux_stream); }
   for (hipEvent_t e : ctx->aux_ev) if (e) hipEventDestroy(e);
@@ -469,7 +469,7 @@ pvlm_status pvlm_profile_enable(pvlm_ctx* ctx, int on) {
   if (!ctx) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int w = 0; w < 3; ++w) {
+  for (int w = 0; w < 4; ++w) {
     for (auto& pr : ctx->prof_pending[w]) { ctx->prof_pool.push_back(pr.first); ctx->prof_pool.push_back(pr.second); }
     ctx->prof_pending[w].clear();
     ctx->prof_ms[w] = 0; ctx->prof_n[w] = 0;
@@ -479,7 +479,7 @@ pvlm_status pvlm_profile_enable(pvlm_ctx* ctx, int on) {
 }
 
 pvlm_status pvlm_profile_read(pvlm_ctx* ctx, int which, double* total_ms, int64_t* launches) {
-  if (!ctx || which < 0 || which > 2) return PVLM_ERR_ARG;
+  if (!ctx || which < 0 || which > 3) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (auto& pr : ctx->prof_pending[which]) {

@@ -98,10 +98,10 @@ struct pvlm_ctx {
   void* spd_plan = nullptr;           // tile-sparse plan of the last pvlm_spd_solve_blocks structure (csrc/pvlm_linalg.hip), freed by pvlm_i_spd_plan_release
   // per-kernel profiling (pvlm_profile_*): pending (start, stop) event pairs per kernel class
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[3];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[4];
   std::vector<hipEvent_t> prof_pool;
-  double prof_ms[3] = {0, 0, 0};
-  int64_t prof_n[3] = {0, 0, 0};
+  double prof_ms[4] = {0, 0, 0, 0};
+  int64_t prof_n[4] = {0, 0, 0, 0};
 };
 
 // RAII bracket: records events around a kernel launch when profiling is on.

@@ -771,6 +771,7 @@ pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int
   for (long long li = 0; li < n_lines_total; ++li) line_table_row(rows, cols, lines + 4 * li, &tab[8 * (size_t)li]);
   return run_vote_batch(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes,
       [](pvlm_ctx* c, int np, const pvlm_cam_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
+        pvlm_prof_scope prof(c, 3);
         hipLaunchKernelGGL(k_cam_lidar_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl,
                            3.0 / 180.0 * M_PI, dv);
       });
