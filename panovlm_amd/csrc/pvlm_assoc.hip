@@ -18,6 +18,7 @@
 #include <thread>
 
 #include "pvlm_internal.h"
+#include "pvlm_workers.h"
 #include "pvlm_assoc_core.h"
 
 using namespace pvlm_assoc;
@@ -436,7 +437,23 @@ extern "C" {
 
 pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan** out) { return pvlm_scan_upload_batch(ctx, 1, d, out); }
 
+static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm_scan_desc* descs, pvlm_scan** out);
+// no exception crosses the C ABI: a worker's or a container's std::bad_alloc / std::system_error becomes a status
 pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_desc* descs, pvlm_scan** out) {
+  try {
+    return scan_upload_batch_impl(ctx, n_scans, descs, out);
+  } catch (const std::bad_alloc&) {
+    if (ctx) { (void)hipStreamSynchronize(ctx->stream); PVLM_SET_ERR(ctx, "pvlm_scan_upload_batch: out of host memory"); }
+    return PVLM_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    if (ctx) { (void)hipStreamSynchronize(ctx->stream); PVLM_SET_ERR(ctx, "pvlm_scan_upload_batch: %s", e.what()); }
+    return PVLM_ERR_HIP;
+  } catch (...) {
+    if (ctx) { (void)hipStreamSynchronize(ctx->stream); PVLM_SET_ERR(ctx, "pvlm_scan_upload_batch: unexpected host exception"); }
+    return PVLM_ERR_HIP;
+  }
+}
+static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm_scan_desc* descs, pvlm_scan** out) {
   if (!ctx || n_scans < 0 || (n_scans > 0 && (!descs || !out))) return PVLM_ERR_ARG;
   for (int k = 0; k < n_scans; ++k) out[k] = nullptr;
   if (n_scans == 0) return PVLM_OK;
@@ -470,10 +487,7 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)n_scans / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     std::atomic<int> next{0};
     auto work = [&]() { for (int k = next++; k < n_scans; k = next++) box_of(k); };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (std::thread& t : pool) t.join();
+    pvlm_run_workers(n_threads, work);
   }
   for (int k = 0; k < n_scans && !st; ++k) {
     const pvlm_scan_desc* d = &descs[k];
@@ -626,10 +640,7 @@ pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_d
       const size_t n_threads = (hi - lo) < ((size_t)8 << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)8, (last_seg - first_seg) / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
       std::atomic<size_t> next{first_seg};
       auto work = [&]() { for (size_t q = next++; q < last_seg; q = next++) stage(q); };
-      std::vector<std::thread> pool;
-      for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
-      work();
-      for (std::thread& t : pool) t.join();
+      pvlm_run_workers(n_threads, work);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(d_slab + lo, h, hi - lo, hipMemcpyHostToDevice, ctx->stream);
   }

@@ -108,7 +108,8 @@ void pvlm_i_free(pvlm_ctx* ctx, const void* p) {
   if (it == P.live.end()) {
     // PVLM_NO_POOL=1: every block is a plain hipMalloc.  With the pool on there are no foreign pointers: an unknown one is a double
     // free or an interior pointer — diagnosed, never handed to hipFree (its range may belong to another object by now)
-    if (P.disabled) { (void)hipFree(const_cast<void*>(p)); return; }
+    // no pool: the stream-ordered reuse argument does not apply to hipFree — wait for the work that may still read the buffer
+    if (P.disabled) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(const_cast<void*>(p)); return; }
     PVLM_SET_ERR(ctx, "pvlm_i_free: %p is not a live block of this context's pool (double free or interior pointer)", p);
     fprintf(stderr, "[pvlm] %s\n", ctx->err.c_str());
     return;
@@ -507,7 +508,8 @@ pvlm_status pvlm_resset_set_pose_ids(pvlm_ctx* ctx, pvlm_resset* rs, const int* 
   rs->h_nei.assign(pair_nei, pair_nei + rs->n_pairs);
   pvlm_status st = pvlm_i_h2d_q(ctx, rs->d_ref, rs->h_ref.data(), (size_t)rs->n_pairs * sizeof(int));
   if (!st) st = pvlm_i_h2d_q(ctx, rs->d_nei, rs->h_nei.data(), (size_t)rs->n_pairs * sizeof(int));
-  rs->pair_tab_epoch = ~0ull;                  // the pair table is rebuilt from the new ids at the next evaluation
+  rs->pair_tab_epoch = ~0ull;                  // the pair table is rebuilt from the new ids at the next evaluation (ensure_pair_table,
+                                               // csrc/pvlm_eval.hip: every path that reads the pose table checks the ids against n_poses there)
   rs->serial = ++ctx->resset_serial;           // ... and every pvlm_neq bound to the set binds again
   return st;
 }

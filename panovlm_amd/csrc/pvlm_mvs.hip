@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K13L_W
   const unsigned char* ref_gray = gray_base + J.off;
   // the pixel's weight column: its four threads compute and store the same values
   pvlm_mvs::ColumnPatch P{wtab + (size_t)blockIdx.x * 64 + (threadIdx.x >> 2), (size_t)gridDim.x * 64, lane_tab + threadIdx.x, 256, 0.f, 0.f, false};
-  pvlm_mvs::fill_patch_column(ref_gray, rows, cols, px, py, half_window, step, n, P);
+  pvlm_mvs::fill_patch_column<true>(ref_gray, rows, cols, px, py, half_window, step, n, P);     // shared column: only final values are stored
   if (!P.inside || P.sq0 <= 0) return;                                    // patch.sq0 <= 0 (:1069, :1087)
   float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
   float c = conf[e];

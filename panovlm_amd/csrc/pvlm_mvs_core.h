@@ -711,15 +711,25 @@ PVLM_HD inline float ref_texel(const unsigned char* gray, int cols, int px, int 
   return (float)gray[(size_t)(py - half_window + di) * cols + (px - half_window + dj)];
 }
 
+// SHARED: several threads fill the SAME column with the same values (the four threads of a pixel in k_mvs_propagate_diag_batch_quad).
+// The one-owner form parks the raw weight in the column and normalises it in place — a read-modify-write that four unsynchronised
+// threads may not do on one address; the shared form sums the weights first and stores only the final value (stores of equal values:
+// idempotent), at the price of evaluating the 49 weights twice.  Same arithmetic, same bits.
+template <bool SHARED = false>
 PVLM_HD inline void fill_patch_column(const unsigned char* ref_gray, int rows, int cols, int px, int py, int half_window, int step, int n, ColumnPatch& P) {
   P.sq0 = 0.f; P.mean = 0.f;
   P.inside = px >= half_window && py >= half_window && px < cols - half_window && py < rows - half_window;
   if (!P.inside) return;
   const size_t st = P.w_stride;
   float wsum = 0.f;
-  for (int k = 0; k < n; ++k) { float w, t; patch_texel(ref_gray, cols, px, py, half_window, step, k, &w, &t); P.w[k * st] = w; wsum += w; }            // :659
   float mean = 0.f;
+  if (SHARED) {
+    for (int k = 0; k < n; ++k) { float w, t; patch_texel(ref_gray, cols, px, py, half_window, step, k, &w, &t); wsum += w; }                             // :659
+    for (int k = 0; k < n; ++k) { float w, t; patch_texel(ref_gray, cols, px, py, half_window, step, k, &w, &t); w = w / wsum; P.w[k * st] = w; mean += w * ref_texel(ref_gray, cols, px, py, half_window, step, k); }
+  } else {
+  for (int k = 0; k < n; ++k) { float w, t; patch_texel(ref_gray, cols, px, py, half_window, step, k, &w, &t); P.w[k * st] = w; wsum += w; }            // :659
   for (int k = 0; k < n; ++k) { const float w = P.w[k * st] / wsum; P.w[k * st] = w; mean += w * ref_texel(ref_gray, cols, px, py, half_window, step, k); }   // :662-664
+  }
   float sq0 = 0.f;
   for (int k = 0; k < n; ++k) { const float t = ref_texel(ref_gray, cols, px, py, half_window, step, k) - mean; const float tmp = t * P.w[k * st]; sq0 += t * tmp; }   // :668-672
   P.mean = mean; P.sq0 = sq0;

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "pvlm_internal.h"
+#include "pvlm_workers.h"
 #include "pvlm_ring_core.h"
 
 using namespace pvlm_ring;
@@ -444,10 +445,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
       }
     };
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)n_scans / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
-    std::vector<std::thread> pool;
-    try { for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work); } catch (...) {}   // fewer workers: the calling thread does the rest
-    try { work(); } catch (...) { for (std::thread& t : pool) t.join(); throw; }
-    for (std::thread& t : pool) t.join();
+    pvlm_run_workers(n_threads, work);
     if (bad >= 0) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: non-finite coordinate (point %lld of the batch)", (long long)bad); return PVLM_ERR_ARG; }
   }
   pvlm_i_trace("ring: staging copy");

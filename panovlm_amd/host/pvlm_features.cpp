@@ -23,6 +23,7 @@
 #include <thread>
 
 #include "pvlm_host.hpp"
+#include "../csrc/pvlm_workers.h"
 
 namespace pvlm {
 namespace {
@@ -460,10 +461,7 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     }
   };
   const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(num_threads, 1), todo.size(), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
-  std::vector<std::thread> pool;
-  try { for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work); } catch (...) {}      // fewer workers: the calling thread does the rest
-  work();
-  for (std::thread& t : pool) t.join();
+  pvlm_run_workers(n_threads, work);
   if (failure) std::rethrow_exception(failure);
 }
 

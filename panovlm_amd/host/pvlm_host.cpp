@@ -3,6 +3,7 @@
 // tracks, problem bookkeeping, the trust-region loop, the small linear solves); every residual,
 // Jacobian, distance and vote is produced by libpvlm.so on the GPU.
 #include "pvlm_host.hpp"
+#include "../csrc/pvlm_workers.h"
 
 #include <algorithm>
 #include <atomic>
@@ -291,10 +292,7 @@ void Velodyne::UploadBatch(const std::vector<const Velodyne*>& scans) {
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, todo.size() / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     std::atomic<size_t> next{0};
     auto work = [&]() { for (size_t k = next++; k < todo.size(); k = next++) { st[k].Fill(*todo[k], todo[k]->R_wl_, todo[k]->t_wl_); descs[k] = st[k].d; } };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    work();
-    for (std::thread& t : pool) t.join();
+    pvlm_run_workers(n_threads, work);
   }
   std::vector<pvlm_scan*> out(todo.size(), nullptr);
   Engine& e = Engine::Default();
@@ -375,10 +373,7 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
   const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, lidars.size() / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   std::atomic<size_t> next{0};
   auto work = [&]() { for (size_t i = next++; i < lidars.size(); i = next++) one(i); };
-  std::vector<std::thread> pool;
-  for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
-  work();
-  for (std::thread& t : pool) t.join();
+  pvlm_run_workers(n_threads, work);
   return neighbors_all;
 }
 
@@ -682,10 +677,7 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
       out[which[j]] = FindAssociationsOn(ref, nei, world.find(&ref)->second, world.find(&nei)->second, votes.data() + voff[j]);
     }
   };
-  std::vector<std::thread> pool;
-  for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
-  work();
-  for (std::thread& t : pool) t.join();
+  pvlm_run_workers(n_threads, work);
   return out;
 }
 
@@ -1211,12 +1203,14 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     // exchange and all of them leave together, with the same message.
     bool has_bundle = false;
     for (auto& b : I.bundles) if (!b.obs_pose.empty()) has_bundle = true;
-    double verdict[3] = {NP == 0 ? 1.0 : 0.0, has_bundle ? 1.0 : 0.0, (double)NP};
-    double agreed[3] = {verdict[0], verdict[1], verdict[2]};
-    xch->allreduce_sum(agreed, 3);
+    // sum and sum of squares of the pose counts: world * sum(NP^2) == sum(NP)^2 holds exactly when all counts are equal (Cauchy-Schwarz),
+    // and every rank evaluates the same reduced numbers — a test against the local NP alone let the rank whose count equals the mean
+    // pass while its peers threw, and hang in the next exchange
+    double agreed[4] = {NP == 0 ? 1.0 : 0.0, has_bundle ? 1.0 : 0.0, (double)NP, (double)NP * (double)NP};
+    xch->allreduce_sum(agreed, 4);
     if (agreed[0] > 0) throw std::runtime_error("sharded Solve: " + std::to_string((int)agreed[0]) + " rank(s) entered without registered poses (Problem::RegisterPoses must run on every rank)");
     if (agreed[1] > 0) throw std::runtime_error("sharded Solve: reprojection blocks are not sharded (camera terms run on one GPU)");
-    if (agreed[2] != (double)NP * xch->world) throw std::runtime_error("sharded Solve: the ranks registered different numbers of poses");
+    if ((double)xch->world * agreed[3] != agreed[2] * agreed[2]) throw std::runtime_error("sharded Solve: the ranks registered different numbers of poses");
   }
   // concatenation of every rank's list through the one primitive an Exchange has
   auto all_concat = [&](const std::vector<double>& mine) {
@@ -2101,10 +2095,7 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
           }
         }
       };
-      std::vector<std::thread> pool;
-      try { for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work); } catch (...) {}
-      work();
-      for (std::thread& t : pool) t.join();
+      pvlm_run_workers(n_threads, work);
       if (failure) std::rethrow_exception(failure);
     }
   }
@@ -2565,7 +2556,9 @@ CameraLidarOptimizer::LinePairs CameraLidarOptimizer::AssociateLineMulti(const i
 // PlaneIOUResidual — P_c = R(aa_cw) (R(-aa_lw) (P_l - t_lw)) + t_cw — with the LiDAR pose at the identity, where it is exact: ceres'
 // AngleAxisRotatePoint takes its first-order branch for a zero rotation and returns the point unchanged.  So the blocks are kinds 4 and 5 of
 // the GPU evaluation with (aa_cw, t_cw) = (aa_cl, t_cl) free and a constant identity for the second pose; the derivative with respect to
-// (aa_cl, t_cl) is the first half of the row.  Plane2Plane_Relative returns weight * angle * 180 / pi: folded into the block weight.
+// (aa_cl, t_cl) is the first half of the row.  Plane2Plane_Relative returns weight * angle * 180 / pi: folded into the block weight,
+// i.e. (weight * 180 / pi) * angle — mathematically the same, up to 1 ulp away from upstream's left-to-right product (the twin test
+// compares at 1e-6).
 int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const Matrix4d& T_cl, double* final_cost, int* successful_steps, int* residual_blocks) {
   ceres_like::Problem problem;
   ceres_like::LossFunction* loss_function = new ceres_like::HuberLoss(2.0 * M_PI / 180.0);                 // :36
@@ -2602,7 +2595,13 @@ int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, const Matrix4d& 
                                aa_id.data(), t_id.data());                                                   // :62-64
       blocks += 2;
     }
-  if (blocks == 0) { delete loss_function; T_cl_optimized = T_cl; if (residual_blocks) *residual_blocks = 0; return 1; }
+  if (blocks == 0) {
+    delete loss_function; T_cl_optimized = T_cl;
+    if (residual_blocks) *residual_blocks = 0;
+    if (final_cost) *final_cost = 0.0;                  // nothing to solve: the callers read these unconditionally
+    if (successful_steps) *successful_steps = 0;
+    return 1;
+  }
   problem.SetParameterBlockConstant(aa_id.data());
   problem.SetParameterBlockConstant(t_id.data());
   ceres_like::Solver::Options options;                                                                     // :71-77
