@@ -749,9 +749,10 @@ def pcie_block(ctx, pv, associate, ref, nei, args):
     n, P = rs.n, rs.n_pairs
     out = {"blocks": int(n), "pairs": int(P)}
     t0 = time.perf_counter()
-    h_r = ctx.host_alloc(n * 8); h_J = ctx.host_alloc(n * 96); h_w = ctx.host_alloc(n * 56); h_t = ctx.host_alloc(max(P, 1) * 33 * 8)
+    h_r = ctx.host_alloc(n * 8); h_J = ctx.host_alloc(n * 96); h_w = ctx.host_alloc(n * 56); h_t = ctx.host_alloc(max(P, 1) * 33 * 8); h_f = ctx.host_alloc(n * 32)
     out["pinned_alloc_s"] = time.perf_counter() - t0
-    for name, fn, nbytes in (("jacobian_rows", lambda: rs.eval_host_async(h_r, h_J), 104), ("wrench_rows", lambda: rs.eval_wrench_host_async(h_w, h_t), 56)):
+    for name, fn, nbytes in (("jacobian_rows", lambda: rs.eval_host_async(h_r, h_J), 104), ("wrench_rows", lambda: rs.eval_wrench_host_async(h_w, h_t), 56),
+                             ("force_rows", lambda: rs.eval_force_host_async(h_f, h_t), 32)):
         fn(); ctx.synchronize()
         reps = 3
         t0 = time.perf_counter()
@@ -771,7 +772,8 @@ def pcie_block(ctx, pv, associate, ref, nei, args):
     out["pageable_pvlm_eval"] = {"blocks": int(rs2.n), "M_evals_per_s_host_visible": rs2.n / dt / 1e6, "D2H_GBps": rs2.n * 104 / dt / 1e9}
     out["link_GBps_measured"] = max(out["jacobian_rows"]["D2H_GBps"], out["wrench_rows"]["D2H_GBps"])   # the boxes of the pool differ (30 - 56 GB/s seen)
     rs2.close(); rs.close()
-    for a in (h_r, h_J, h_w, h_t):
+    out["what_the_adapter_uses"] = "force_rows [r | g] for the point functors (integration/pvlm_ceres.hpp: the moment is rebuilt from the block's point in Evaluate), wrench_rows for plane / IOU blocks"
+    for a in (h_r, h_J, h_w, h_t, h_f):
         ctx.host_free(a)
     return out
 

@@ -150,13 +150,18 @@ pvlm_status pvlm_eval_dev(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_residu
  *                               J_l(aa_r)(9) | M_n(9)], from which the host forms the row on demand (36 multiply-adds):
  *                                 d r/d aa_r = c^T J_l      d r/d t_r = g^T      d r/d aa_n = c^T M_n      d r/d t_n = -g^T R_rn
  *                               (row-major 3x3 blocks; integration/pvlm_ceres.hpp does it inside Evaluate).
- * Both go through a bounded device staging buffer (PVLM_STAGE_ROWS rows, 32 M by default) slice by slice; the results
+ *   pvlm_eval_force_host_async  kinds 0..3 (the point functors), 32 B per block: force_rows[n x 4] = [r | g(3)].  The moment is
+ *                               c = (R_rn P_n + t_rn - t_rw) x g with P_n = the first three entries of the block's row (the host holds them:
+ *                               pvlm_resset_download) and R_rn, t_rn, t_rw from the pair table — 15 more multiply-adds in Evaluate for
+ *                               43 % fewer bytes over the link, which is the roof of this mode.
+ * All three go through a bounded device staging buffer (PVLM_STAGE_ROWS rows, 32 M by default) slice by slice; the results
  * are complete after pvlm_synchronize.  Residuals are RAW (no loss), in the compact order of pvlm_resset_download. */
 #define PVLM_PAIR_TABLE 33
 pvlm_status pvlm_host_alloc(pvlm_ctx* ctx, int64_t bytes, void** out);
 pvlm_status pvlm_host_free(pvlm_ctx* ctx, void* p);
 pvlm_status pvlm_eval_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* residuals, double* jacobians_or_null);
 pvlm_status pvlm_eval_wrench_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* wrench_rows, double* pair_tables);
+pvlm_status pvlm_eval_force_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* force_rows, double* pair_tables);
 
 /* Fused evaluation: residual + Jacobian in registers, loss-corrected (Ceres corrector for
  * rho'' <= 0: scale r and J by sqrt(rho')) and contracted into per-pair normal-equation blocks

@@ -22,9 +22,12 @@
 // behaviour, it only proves that this file compiles and that the rows it hands out equal pvlm_eval's;
 // tests/test_host_gpu.py::test_ceres_adapter_rows).
 //
-// The boundary is a PCIe link (55 GB/s measured on the MI355X box, bench.py -> "pcie"): the batch is delivered as 56-byte wrench rows [r | c | g]
-// (pvlm_eval_wrench_host_async) into page-locked memory, asynchronously, and the 1 x 12 Jacobian row is formed from the
-// row and its pair's 3x3 tables inside Evaluate — 36 multiply-adds on the Ceres worker thread that asks for it —
+// The boundary is a PCIe link (55 GB/s measured on the MI355X box, bench.py -> "pcie"): the link is the roof of this mode, so the batch
+// is delivered in as few bytes as carry the information, into page-locked memory, asynchronously.  Point functors (point-to-plane,
+// point-to-line): 32-byte force rows [r | g] (pvlm_eval_force_host_async); the moment c = (R_rn P_n + t_rn - t_rw) x g is rebuilt
+// inside Evaluate from the block's point, which the batch holds on the host (downloaded once, when the set is added).  Plane / IOU
+// blocks of the camera-LiDAR term: 56-byte wrench rows [r | c | g] (pvlm_eval_wrench_host_async).  The 1 x 12 Jacobian row is
+// formed from the row and its pair's 3x3 tables inside Evaluate — ~50 multiply-adds on the Ceres worker thread that asks for it —
 // instead of shipping 104 bytes per block.
 //
 // Usage inside LidarOdometry::RefinePose (lidar_mapping/LidarOdometry.cpp:36-80):
@@ -79,17 +82,29 @@ class CeresBatch : public ceres::EvaluationCallback {
   // Returns the set's index.
   int AddSet(pvlm_resset* set, std::vector<int> pair_of_row) {
     Set s; s.set = set; s.pair_of_row = std::move(pair_of_row);
-    pvlm_resset_info(set, &s.n, &s.n_pairs, nullptr, nullptr);
+    int kind = 0;
+    pvlm_resset_info(set, &s.n, &s.n_pairs, &kind, nullptr);
+    s.width = kind <= PVLM_POINT2LINE_ANGLE ? 4 : 7;
+    if (s.width == 4 && s.n > 0) {                 // the points of the blocks: the first three entries of every row, once
+      const int stride = kind <= PVLM_POINT2PLANE_ANGLE ? 7 : 9;
+      std::vector<double> rows((size_t)s.n * stride);
+      if (pvlm_resset_download(ctx_, set, nullptr, nullptr, nullptr, rows.data()) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
+      s.points.resize((size_t)s.n * 3);
+      for (int64_t i = 0; i < s.n; ++i) for (int k = 0; k < 3; ++k) s.points[(size_t)i * 3 + k] = rows[(size_t)i * stride + k];
+    }
     void* p = nullptr;
-    if (pvlm_host_alloc(ctx_, (int64_t)s.n * 7 * (int64_t)sizeof(double), &p) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
+    if (pvlm_host_alloc(ctx_, (int64_t)s.n * s.width * (int64_t)sizeof(double), &p) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
     s.rows = static_cast<double*>(p);
     if (pvlm_host_alloc(ctx_, (int64_t)s.n_pairs * PVLM_PAIR_TABLE * (int64_t)sizeof(double), &p) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
     s.tables = static_cast<double*>(p);
     sets_.push_back(std::move(s));
     return (int)sets_.size() - 1;
   }
-  // [r | c(3) | g(3)] of block `row`, and the table of its pair: [R_rn(9) | t_rn(3) | t_rw(3) | J_l(aa_r)(9) | M_n(9)]
-  const double* row(int set, int64_t row) const { return sets_[(size_t)set].rows + (size_t)row * 7; }
+  // [r | c(3) | g(3)] (width 7) or [r | g(3)] (width 4, point functors: the point of the block is point(set, row)) of block `row`,
+  // and the table of its pair: [R_rn(9) | t_rn(3) | t_rw(3) | J_l(aa_r)(9) | M_n(9)]
+  const double* row(int set, int64_t row) const { const Set& s = sets_[(size_t)set]; return s.rows + (size_t)row * s.width; }
+  int row_width(int set) const { return sets_[(size_t)set].width; }
+  const double* point(int set, int64_t row) const { return sets_[(size_t)set].points.data() + (size_t)row * 3; }
   const double* table(int set, int64_t row) const { const Set& s = sets_[(size_t)set]; return s.tables + (size_t)s.pair_of_row[(size_t)row] * PVLM_PAIR_TABLE; }
   pvlm_resset* set(int set) const { return sets_[(size_t)set].set; }
   int num_sets() const { return (int)sets_.size(); }
@@ -125,7 +140,8 @@ class CeresBatch : public ceres::EvaluationCallback {
     }
     if (pvlm_set_poses(ctx_, n, aa, t) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
     for (Set& s : sets_)   // ONE kernel per slice of a set, its copy queued right behind it; nothing waits until the end
-      if (pvlm_eval_wrench_host_async(ctx_, s.set, s.rows, s.tables) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
+      if ((s.width == 4 ? pvlm_eval_force_host_async(ctx_, s.set, s.rows, s.tables) : pvlm_eval_wrench_host_async(ctx_, s.set, s.rows, s.tables)) != PVLM_OK)
+        throw std::runtime_error(pvlm_last_error(ctx_));
     if (pvlm_synchronize(ctx_) != PVLM_OK) throw std::runtime_error(pvlm_last_error(ctx_));
     for (Bundle& b : bundles_) {   // the points are Ceres parameter blocks too: their current values travel with every evaluation
       for (size_t p = 0; p < b.points.size(); ++p) for (int k = 0; k < 3; ++k) b.X[3 * p + k] = b.points[p][k];
@@ -136,7 +152,8 @@ class CeresBatch : public ceres::EvaluationCallback {
   }
 
  private:
-  struct Set { pvlm_resset* set = nullptr; int64_t n = 0; int n_pairs = 0; double* rows = nullptr; double* tables = nullptr; std::vector<int> pair_of_row; };
+  struct Set { pvlm_resset* set = nullptr; int64_t n = 0; int n_pairs = 0; int width = 7; double* rows = nullptr; double* tables = nullptr; std::vector<int> pair_of_row;
+               std::vector<double> points; };
   struct Bundle { pvlm_baset* set = nullptr; int64_t n_obs = 0; std::vector<const double*> points; std::vector<double> r, J, X; };
   struct PoseArray { int n = 0; const double* aa = nullptr; const double* t = nullptr; int base = 0; };
   void Rebase() {
@@ -160,12 +177,22 @@ class CeresRow : public ceres::SizedCostFunction<1, 3, 3, 3, 3> {
  public:
   CeresRow(const CeresBatch* batch, int set, int64_t row) : batch_(batch), set_(set), row_(row) {}
   bool Evaluate(double const* const*, double* residuals, double** jacobians) const override {
-    const double* w = batch_->row(set_, row_);                 // [r | c | g]
+    const double* w = batch_->row(set_, row_);                 // [r | c | g], or [r | g] for the point functors
     residuals[0] = w[0];
     if (jacobians) {
       const double* T = batch_->table(set_, row_);
-      const double* c = w + 1; const double* g = w + 4;
       const double* R = T; const double* Jl = T + 15; const double* Mn = T + 24;
+      double moment[3];
+      const double* c = w + 1; const double* g = w + 4;
+      if (batch_->row_width(set_) == 4) {
+        // c = (P_r - t_rw) x g,  P_r = R_rn P_n + t_rn  (csrc/pvlm_functors.h eval_wrench, the same operations in the same order)
+        g = w + 1;
+        const double* P = batch_->point(set_, row_); const double* trn = T + 9; const double* trw = T + 12;
+        const double m[3] = {R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + trn[0] - trw[0], R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + trn[1] - trw[1],
+                             R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + trn[2] - trw[2]};
+        moment[0] = m[1] * g[2] - m[2] * g[1]; moment[1] = m[2] * g[0] - m[0] * g[2]; moment[2] = m[0] * g[1] - m[1] * g[0];
+        c = moment;
+      }
       if (jacobians[0]) for (int k = 0; k < 3; ++k) jacobians[0][k] = c[0] * Jl[k] + c[1] * Jl[3 + k] + c[2] * Jl[6 + k];     // d/d angleAxis_rw
       if (jacobians[1]) for (int k = 0; k < 3; ++k) jacobians[1][k] = g[k];                                                    // d/d t_rw
       if (jacobians[2]) for (int k = 0; k < 3; ++k) jacobians[2][k] = c[0] * Mn[k] + c[1] * Mn[3 + k] + c[2] * Mn[6 + k];     // d/d angleAxis_nw

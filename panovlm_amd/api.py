@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
-    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
+    "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
     "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
@@ -607,6 +607,10 @@ class ResidualSet:
     def eval_wrench_host_async(self, w_host, tab_host):
         self.ctx._check(self.ctx.lib.pvlm_eval_wrench_host_async(self.ctx._h, self._h, C.c_void_p(w_host.ctypes.data), C.c_void_p(tab_host.ctypes.data)),
                         "pvlm_eval_wrench_host_async")
+
+    def eval_force_host_async(self, f_host, tab_host):
+        """[r | g(3)] rows (32 B per block, point functors) + pair tables into page-locked arrays (Context.host_alloc); complete after synchronize()."""
+        self.ctx._check(self.ctx.lib.pvlm_eval_force_host_async(self.ctx._h, self._h, _p(f_host, C.c_double), _p(tab_host, C.c_double)), "pvlm_eval_force_host_async")
 
     def assoc_debug(self):
         q = np.empty(max(self.n, 1), np.int32); nn = np.empty((max(self.n, 1), 10), np.int32)

@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void k_eval_materialise(const double* const* _
 // boundary is a PCIe link (30 GB/s measured), not HBM.  Rows staged through LDS so that every store instruction of a
 // wave writes contiguous memory.
 // ---------------------------------------------------------------------------------------------
-template <int KIND, bool NORM, int NCOLS>
+// W = 7: [r | c | g].  W = 4 (point functors only): [r | g] — the moment c = (P_r - t_rw) x g is rebuilt by the host from the point it
+// already holds and the pair table, so that 32 B instead of 56 B cross the PCIe link per block (pvlm_eval_force_host_async).
+template <int KIND, bool NORM, int NCOLS, int W>
 __global__ __launch_bounds__(256) void k_eval_wrench(const double* const* __restrict__ pair_cols, const int64_t* __restrict__ pair_stride,
                                                      const int64_t* __restrict__ out_start, const int* __restrict__ blk_pair,
                                                      const int* __restrict__ blk_chunk, int chunk_rows, const double* __restrict__ pair_tab,
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void k_eval_wrench(const double* const* __rest
   double T[15];
 #pragma unroll
   for (int k = 0; k < 15; ++k) T[k] = pair_tab[(size_t)p * PVLM_PAIR_TAB + k];
-  __shared__ double stage[4][128 * 7];
+  __shared__ double stage[4][128 * W];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t n_it = (hi - lo + 511) / 512;
   for (int64_t it = 0; it < n_it; ++it) {
@@ -270,18 +272,19 @@ __global__ __launch_bounds__(256) void k_eval_wrench(const double* const* __rest
         for (int c = 0; c < NCOLS; ++c) rec[c] = h ? v[c].y : v[c].x;
         Wrench w;
         eval_wrench<KIND, NORM>(rec, T, weight, w);
-        double* dst = &stage[wv][(2 * lane + h) * 7];
-        dst[0] = w.r; dst[1] = w.c[0]; dst[2] = w.c[1]; dst[3] = w.c[2]; dst[4] = w.g[0]; dst[5] = w.g[1]; dst[6] = w.g[2];
+        double* dst = &stage[wv][(2 * lane + h) * W];
+        if (W == 7) { dst[0] = w.r; dst[1] = w.c[0]; dst[2] = w.c[1]; dst[3] = w.c[2]; dst[4] = w.g[0]; dst[5] = w.g[1]; dst[6] = w.g[2]; }
+        else { dst[0] = w.r; dst[1] = w.g[0]; dst[2] = w.g[1]; dst[3] = w.g[2]; }
       }
     }
     __builtin_amdgcn_wave_barrier();
     const int64_t r0 = lo + it * 512 + (int64_t)wv * 128;
     const int64_t rows = min((int64_t)128, hi - r0);
     if (rows > 0) {
-      double* g = w_out + (size_t)(o0 + r0) * 7;
-      const int n = (int)rows * 7;
+      double* g = w_out + (size_t)(o0 + r0) * W;
+      const int n = (int)rows * W;
 #pragma unroll
-      for (int t = 0; t < 14; ++t) {
+      for (int t = 0; t < 2 * W; ++t) {
         const int e = t * 64 + lane;
         if (e < n) stream_store1(g + e, stage[wv][e]);
       }
@@ -629,9 +632,13 @@ static void launch_materialise(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_r
                      blk0, row0);
 }
 template <int KIND, bool NORM, int NCOLS>
-static void launch_wrench(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_w, int blk0, int nblk, int64_t row0) {
-  hipLaunchKernelGGL((k_eval_wrench<KIND, NORM, NCOLS>), dim3(nblk), dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride, rs->d_out_start,
-                     rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_w, blk0, row0);
+static void launch_wrench(pvlm_ctx* ctx, const pvlm_resset* rs, double* d_w, int blk0, int nblk, int64_t row0, bool force_only) {
+  if (force_only)
+    hipLaunchKernelGGL((k_eval_wrench<KIND, NORM, NCOLS, 4>), dim3(nblk), dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride, rs->d_out_start,
+                       rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_w, blk0, row0);
+  else
+    hipLaunchKernelGGL((k_eval_wrench<KIND, NORM, NCOLS, 7>), dim3(nblk), dim3(256), 0, ctx->stream, rs->d_pair_cols, rs->d_pair_stride, rs->d_out_start,
+                       rs->d_blk_pair, rs->d_blk_chunk, rs->chunk_rows, rs->d_pair_tab, rs->weight, d_w, blk0, row0);
 }
 
 template <int KIND, bool NORM, int NCOLS>
@@ -730,17 +737,17 @@ pvlm_status pvlm_eval(pvlm_ctx* ctx, const pvlm_resset* rs, double* r, double* J
 
 // Evaluation delivered to HOST memory, slice by slice through a bounded device staging buffer (PVLM_STAGE_ROWS rows,
 // 32 M by default): kernel over a run of whole pairs -> asynchronous copy of that slice; everything on the context stream.
-// mode 0: residuals[n] (+ jacobians[n x 12]); mode 1: wrench rows [n x 7] + the pair tables.
+// mode 0: residuals[n] (+ jacobians[n x 12]); mode 1: wrench rows [n x 7] + the pair tables; mode 2: force rows [n x 4] + the pair tables.
 static pvlm_status eval_to_host(pvlm_ctx* ctx, const pvlm_resset* crs, int mode, double* h_a, double* h_b) {
   pvlm_resset* rs = const_cast<pvlm_resset*>(crs);
   pvlm_status st = ensure_pair_table(ctx, rs);
   if (st) return st;
-  if (mode == 1 && h_b && rs->n_pairs > 0)
+  if (mode >= 1 && h_b && rs->n_pairs > 0)
     PVLM_HIP(ctx, hipMemcpyAsync(h_b, rs->d_pair_tab, (size_t)rs->n_pairs * PVLM_PAIR_TAB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (rs->n == 0) return PVLM_OK;
   int64_t stage_rows = 32ll << 20;
   if (const char* e = getenv("PVLM_STAGE_ROWS")) { const long long v = atoll(e); if (v > 0) stage_rows = v; }
-  const int width = mode == 1 ? 7 : (h_b ? 13 : 1);
+  const int width = mode == 1 ? 7 : (mode == 2 ? 4 : (h_b ? 13 : 1));
   int64_t need = 0;      // the staging buffer holds the largest run of pairs that fits stage_rows (at least one pair)
   for (int p = 0; p < rs->n_pairs;) {
     int q = p; int64_t rows = 0;
@@ -764,11 +771,11 @@ static pvlm_status eval_to_host(pvlm_ctx* ctx, const pvlm_resset* crs, int mode,
       double* d_J = rs->d_stage + rows;
       {
         pvlm_prof_scope prof(ctx, 1);
-        if (mode == 1) PVLM_DISPATCH(launch_wrench, ctx, rs, rs->d_stage, blk0, nblk, row0);
+        if (mode >= 1) PVLM_DISPATCH(launch_wrench, ctx, rs, rs->d_stage, blk0, nblk, row0, mode == 2);
         else PVLM_DISPATCH(launch_materialise, ctx, rs, d_r, h_b ? d_J : nullptr, blk0, nblk, row0);
       }
       PVLM_HIP(ctx, hipGetLastError());
-      if (mode == 1) PVLM_HIP(ctx, hipMemcpyAsync(h_a + (size_t)row0 * 7, rs->d_stage, (size_t)rows * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      if (mode >= 1) PVLM_HIP(ctx, hipMemcpyAsync(h_a + (size_t)row0 * width, rs->d_stage, (size_t)rows * width * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       else {
         PVLM_HIP(ctx, hipMemcpyAsync(h_a + row0, d_r, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (h_b) PVLM_HIP(ctx, hipMemcpyAsync(h_b + (size_t)row0 * 12, d_J, (size_t)rows * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -789,6 +796,13 @@ pvlm_status pvlm_eval_wrench_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, do
   if (!ctx || !rs || (rs->n > 0 && !wrench_rows) || (rs->n_pairs > 0 && !pair_tables)) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   return eval_to_host(ctx, rs, 1, wrench_rows, pair_tables);
+}
+
+pvlm_status pvlm_eval_force_host_async(pvlm_ctx* ctx, const pvlm_resset* rs, double* force_rows, double* pair_tables) {
+  if (!ctx || !rs || (rs->n > 0 && !force_rows) || (rs->n_pairs > 0 && !pair_tables)) return PVLM_ERR_ARG;
+  if (rs->kind > PVLM_POINT2LINE_ANGLE) { PVLM_SET_ERR(ctx, "pvlm_eval_force_host_async: point functors only (kinds 0..3): the moment of a plane / IOU block is not (P_r - t_rw) x g"); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  return eval_to_host(ctx, rs, 2, force_rows, pair_tables);
 }
 
 pvlm_status pvlm_host_alloc(pvlm_ctx* ctx, int64_t bytes, void** out) {

@@ -682,7 +682,7 @@ def test_ceres_adapter_full_optimize_problem(tmp):
     assert moved > 1e-7
 
 def test_host_visible_evaluation_matches_device_rows(oracle):
-    """pvlm_eval_host_async / pvlm_eval_wrench_host_async into pinned memory, sliced through a tiny staging buffer."""
+    """pvlm_eval_host_async / pvlm_eval_wrench_host_async / pvlm_eval_force_host_async into pinned memory, sliced through a tiny staging buffer."""
     import subprocess, sys
     code = (
         "import numpy as np, sys; sys.path.insert(0, %r)\n"
@@ -701,6 +701,10 @@ def test_host_visible_evaluation_matches_device_rows(oracle):
         "ok = np.array_equal(hr[:n], r) and np.array_equal(hJ[:n * 12].reshape(n, 12), J) and np.array_equal(w[:, 0], r)\n"
         "sc = np.abs(J).max(axis=1, keepdims=True); ok = ok and bool(np.all(np.abs(Jw - J) <= 1e-12 * sc))\n"
         "hr2 = np.zeros(n); rs.eval_host_async(hr2, None); ctx.synchronize(); ok = ok and np.array_equal(hr2, r)\n"
+        "hf = ctx.host_alloc(n * 32); ht2 = ctx.host_alloc(P * 33 * 8); rs.eval_force_host_async(hf, ht2); ctx.synchronize()\n"       # [r | g]: 32 B per block
+        "f = hf[:n * 4].reshape(n, 4); ok = ok and np.array_equal(f[:, 0], r) and np.array_equal(f[:, 1:4], g) and np.array_equal(ht2[:P * 33], ht[:P * 33])\n"
+        "Pn = rows[:, 0:3]; Pr = np.einsum('nik,nk->ni', R, Pn) + T[pr, 9:12]; c2 = np.cross(Pr - T[pr, 12:15], g)\n"               # the moment the host rebuilds
+        "ok = ok and bool(np.all(np.abs(c2 - c) <= 1e-12 * np.maximum(np.abs(c).max(axis=1, keepdims=True), 1e-300)))\n"
         "print('OK' if ok else 'MISMATCH', n)\n" % host_io.ROOT)
     for stage in ("700", None):                       # 700 rows: every pair its own slice; default: one slice
         env = dict(os.environ)
