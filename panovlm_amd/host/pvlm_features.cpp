@@ -2,9 +2,9 @@
 //   Velodyne::ReOrderVLP       sensors/Velodyne.cpp:371-526
 //   Velodyne::Segmentation     sensors/Velodyne.cpp:1438-1586
 //   Velodyne::ExtractFeatures  sensors/Velodyne.cpp:531-760 (ADAPTIVE) -> ExtractEdgeFeatures2 :883-1000, ExtractPlaneFeatures2 :1098-1189
-// One scan is 28.8 k points and every stage is a dependency chain (the column state machine of the re-ordering, the
-// component labelling of the range image, greedy picks with non-maximum suppression along a ring), so this stays host
-// code, parallel over scans like lidar_mapping/LidarOdometry.cpp:131-147; the clouds it produces are what
+// Scan-by-scan host forms of every stage (one scan is 28.8 k points; the column state machine of the re-ordering, the
+// component labelling of the range image, greedy picks with non-maximum suppression along a ring).  The per-point / per-ring
+// stages also exist as batched HIP kernels (csrc/pvlm_ring.hip): ExtractFeaturesBatch at the end of this file runs those and keeps only the sort-dependent picks here; the clouds are what
 // Velodyne::DeviceScan uploads for the GPU association.  The arithmetic is the reference's float arithmetic
 // (`using namespace std` there: the float overloads of sqrt / atan / atan2 / acos / sin / cos), compiled with
 // -ffp-contract=off.  Two third-party behaviours are restated from memory [recalled — PCL is not in the image]:
