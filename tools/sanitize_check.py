@@ -95,6 +95,29 @@ def bodies():
                 want = oracle.mvs_propagate(S["gray"], S["neis"], S["Rn"], S["tn"], S["depth"], S["normal"], S["conf"], nei_depths=S["nd"] if geo else None,
                                             depth_constant=S["const"], seed=3, max_iter=1, conf_threshold=0.5)
                 print("device bodies %dx%d geometric=%s equal to the oracle: %s" % (rows, cols, geo, np.array_equal(dd, want[0]) and np.array_equal(c, want[2])))
+        # the range-image bodies (csrc/pvlm_ring_core.h) through their host-compiled driver: stress, scaled, tiny, empty and hostile clouds,
+        # the one-lane loop and the workgroup form
+        so = os.path.join(d, "libring_check_asan.so")
+        subprocess.check_call(["g++"] + SAN + ["-ffp-contract=off", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests/cpp/ring_core_check.cpp")],
+                              env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
+        lib = C.CDLL(so); lib.chk_ring.restype = C.c_int
+        from panovlm_amd import synthetic as sy
+        from tests.test_ring_core_cpu import run as ring_run
+        from tests import ring_cases
+        rng = np.random.default_rng(2)
+        dense = sy.raw_vlp16_scan(4); dense[:, :3] *= 0.02
+        wild = (rng.normal(size=(4000, 4)) * 5).astype(np.float32); wild[::40, :3] = 0
+        ok = True
+        for name, raw, rings, hz in (("vlp", sy.raw_vlp16_scan(3, clutter=40), 16, 1800), ("dense", dense, 16, 1800), ("wild", wild, 32, 360), ("wild64", wild, 64, 90),
+                                     ("tiny", sy.raw_vlp16_scan(9, cols=180)[:40], 16, 180), ("one", sy.raw_vlp16_scan(9, cols=180)[:1], 16, 180)):
+            for threads in (0, 64):
+                for seg in (True, False):
+                    g = ring_run(lib, raw, rings, hz, seg, threads=threads)
+                    try:
+                        ring_cases.assert_matches_oracle(oracle, raw, rings, hz, seg, g)
+                    except AssertionError:
+                        ok = False; print("ring bodies differ from the oracle:", name, threads, seg)
+        print("range-image device bodies under the sanitizers equal to the oracle: %s" % ok)
     return 0
 
 
