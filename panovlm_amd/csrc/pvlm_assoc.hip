@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* 
 
 // Occupancy targets (waves per SIMD) of the two kernels: A/B-measured with panovlm_amd.build --variant (profiles/r3_assoc_variants.txt)
 #ifndef PVLM_K2_WAVES
-#define PVLM_K2_WAVES 6     // 80 VGPRs (2 spilled dwords outside the candidate loop); unconstrained: 82 VGPRs = 5 waves
+#define PVLM_K2_WAVES 8     // round 4, after the row-logic diet (76 VGPRs unconstrained): 6 / 7 / 8 waves -> 1313 / 1229 / 1188 us per dispatch (voxel), 6377 / 5974 / 5684 (raw):
+                            // the search waits on dependent loads (cell table -> candidates), more resident waves hide more of it than the few spilled registers cost
 #endif
 #ifndef PVLM_K3_WAVES
 #define PVLM_K3_WAVES 2     // 195 VGPRs; 3 waves = 168 VGPRs + 15 spilled doubles
@@ -238,7 +239,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
         // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
         // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
         // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
-        // A wave whose lanes are all collinear never enters the QR.
+        // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
+        // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw — on 65 536-point targets K3 waits for its gathers at two
+        // waves per SIMD, not for the QR; profiles/r4_assoc_variants.txt.)
         ok = !Fit10::is_line(px, py, pz, 3.0);
         if (ok) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
         if (ok) {
