@@ -187,6 +187,11 @@ __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* 
 #define PVLM_K2_WAVES 8     // round 4, after the row-logic diet (76 VGPRs unconstrained): 6 / 7 / 8 waves -> 1313 / 1229 / 1188 us per dispatch (voxel), 6377 / 5974 / 5684 (raw):
                             // the search waits on dependent loads (cell table -> candidates), more resident waves hide more of it than the few spilled registers cost
 #endif
+#ifdef PVLM_K3_GLOBAL_LOADS        // measured variant (lost: 1273 vs 1245 us voxel, 1238 vs 1225 us raw; 223 instead of 195 VGPRs): K3's gathers as global saddr loads
+#define K3_LOADF(base, i) load_float(base, i)
+#else
+#define K3_LOADF(base, i) ((base)[i])
+#endif
 #ifndef PVLM_K3_WAVES
 #define PVLM_K3_WAVES 2     // 195 VGPRs; 3 waves = 168 VGPRs + 15 spilled doubles
 #endif
@@ -228,9 +233,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
 #pragma unroll
       for (int k = 0; k < 10; ++k) {
         const int j = id[k];
-        same += (pd.ref.tag[j] == qtag);
+        same += (K3_LOADF(pd.ref.tag, j) == qtag);
         double l[3];
-        world2local(pd.Rr, pd.tr, (double)pd.ref.xyz[3 * j], (double)pd.ref.xyz[3 * j + 1], (double)pd.ref.xyz[3 * j + 2], l);
+        world2local(pd.Rr, pd.tr, (double)K3_LOADF(pd.ref.xyz, 3 * j), (double)K3_LOADF(pd.ref.xyz, 3 * j + 1), (double)K3_LOADF(pd.ref.xyz, 3 * j + 2), l);
         px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
       }
       ok = (same == 10);  // :583-591

@@ -87,6 +87,29 @@ PVLM_HD void wave_minmax_i(int v, int* mn, int* mx) { *mn = v; *mx = v; }
 PVLM_HD unsigned f2u(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 PVLM_HD float u2f(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 
+// Table loads of the search.  The pointers come out of a descriptor in memory, so the compiler cannot prove their address space and emits
+// FLAT loads through 64-bit VGPR pointers (aperture check, vmcnt + lgkmcnt, three VALU instructions of address arithmetic per load).
+// On the device they are stated to be global memory addressed as wave-uniform base + 32-bit BYTE offset: `global_load ... v_off, s[base]`
+// — no pointer pairs in VGPRs (a cloud is at most 2^28 points: 16 B x index fits 32 bits).
+#if defined(PVLM_ASSOC_DEVICE) && defined(__HIP_DEVICE_COMPILE__) && !defined(PVLM_K2_FLAT_LOADS)
+typedef float pvlm_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Point4 load_point(const Point4* base, int j) {
+  const pvlm_f4 v = *(const __attribute__((address_space(1))) pvlm_f4*)((const __attribute__((address_space(1))) char*)(const char*)base + ((unsigned)j << 4));
+  Point4 p; p.x = v.x; p.y = v.y; p.z = v.z; p.w = v.w;
+  return p;
+}
+__device__ __forceinline__ int load_int(const int* base, int i) {
+  return *(const __attribute__((address_space(1))) int*)((const __attribute__((address_space(1))) char*)(const char*)base + ((unsigned)i << 2));
+}
+__device__ __forceinline__ float load_float(const float* base, int i) {
+  return *(const __attribute__((address_space(1))) float*)((const __attribute__((address_space(1))) char*)(const char*)base + ((unsigned)i << 2));
+}
+#else
+PVLM_HD Point4 load_point(const Point4* base, int j) { return base[j]; }
+PVLM_HD int load_int(const int* base, int i) { return base[i]; }
+PVLM_HD float load_float(const float* base, int i) { return base[i]; }
+#endif
+
 // ---- sorted top-K of (distance, index) ---------------------------------------------------------------------------------
 // A squared distance is a non-negative float, whose bit pattern orders like its value, so (float bits << 32 | index) is
 // ONE 64-bit key ordered exactly like the lexicographic (distance, index) pair the reference's sorted k-NN result
@@ -245,7 +268,7 @@ PVLM_HD void knn_scan_run(const CloudView& cv, int b, int e, float qx, float qy,
   for (int j = b; j < e; j += PVLM_K2_BATCH) {
     Point4 p[PVLM_K2_BATCH];
 #pragma unroll
-    for (int k = 0; k < PVLM_K2_BATCH; ++k) p[k] = s[k == 0 ? j : (j + k < last ? j + k : last)];
+    for (int k = 0; k < PVLM_K2_BATCH; ++k) p[k] = load_point(s, k == 0 ? j : (j + k < last ? j + k : last));
 #pragma unroll
     for (int k = 0; k < PVLM_K2_BATCH; ++k) {
       const float ddx = qx - p[k].x, ddy = qy - p[k].y, ddz = qz - p[k].z;
@@ -270,7 +293,7 @@ PVLM_HD void knn_search_grid(const CloudView& cv, float qx, float qy, float qz, 
       x0 = x0 > 0 ? x0 : 0; x1 = x1 < cv.nx - 1 ? x1 : cv.nx - 1;
       if (x0 > x1) return;
       const int row = (z * cv.ny + y) * cv.nx;
-      knn_scan_run<K>(cv, cv.cell_start[row + x0], cv.cell_start[row + x1 + 1], qx, qy, qz, thr2, tk);
+      knn_scan_run<K>(cv, load_int(cv.cell_start, row + x0), load_int(cv.cell_start, row + x1 + 1), qx, qy, qz, thr2, tk);
     } else {
       for (int x = x0; x <= x1; ++x) {
         const unsigned long long key = cell_key(x, y, z);
@@ -278,8 +301,8 @@ PVLM_HD void knn_search_grid(const CloudView& cv, float qx, float qy, float qz, 
         unsigned long long kk;
         while ((kk = cv.keys[s]) != key && kk != PVLM_EMPTY_KEY) s = (s + 1) & cv.mask;
         if (kk != key) continue;
-        const int b = cv.cell_start[s];
-        knn_scan_run<K>(cv, b, b + cv.cell_count[s], qx, qy, qz, thr2, tk);
+        const int b = load_int(cv.cell_start, s);
+        knn_scan_run<K>(cv, b, b + load_int(cv.cell_count, s), qx, qy, qz, thr2, tk);
       }
     }
   });
