@@ -570,7 +570,7 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   const size_t count_bytes = slab - o_count0, o_keys0 = slab;
   each_cloud([&](CloudPlan& c) { if (c.grid && !c.dense) place(c.o_keys, slab, (size_t)c.T * 8); });
   const size_t keys_bytes = slab - o_keys0;
-  each_cloud([&](CloudPlan& c) { if (c.grid) { place(c.o_start, slab, (size_t)c.T * 4); place(c.o_sorted, slab, (size_t)c.n * 16); } });
+  each_cloud([&](CloudPlan& c) { if (c.grid) { place(c.o_start, slab, (size_t)c.T * 4); place(c.o_sorted, slab, ((size_t)c.n + 1) * 16); } });   // + 1: the search may read (never use) one record past a run
   each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_cursor, scratch, (size_t)c.T * 4); });
   const size_t cursor_bytes = scratch;
   each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_slot, scratch, (size_t)c.n * 4); });

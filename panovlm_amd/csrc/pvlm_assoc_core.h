@@ -263,6 +263,21 @@ PVLM_HD void knn_scan_run(const CloudView& cv, int b, int e, float qx, float qy,
   (void)thr2;
   if (b >= e) return;
   const Point4* s = cv.sorted;
+#if PVLM_K2_BATCH == 1 && defined(PVLM_K2_PREFETCH)
+  // software pipeline: record j + 1 is requested before record j goes through the insertion network (the array has one spare record behind
+  // its last point, so the request needs no bound test — its result is simply not used after the last iteration)
+  Point4 cur = load_point(s, b);
+  for (int j = b; j < e; ++j) {
+    const Point4 nxt = load_point(s, j + 1);
+    const float ddx = qx - cur.x, ddy = qy - cur.y, ddz = qz - cur.z;
+    float d2 = 0.0f;
+    d2 += ddx * ddx; d2 += ddy * ddy; d2 += ddz * ddz;  // flann::L2_Simple order
+    tk.push(d2, (int)f2u(cur.w));
+    PVLM_ASSOC_STATS_CANDIDATE();
+    cur = nxt;
+  }
+  PVLM_ASSOC_STATS_RUN(e - b, 0);
+#else
   const int last = e - 1;
   int stat_pass = 0; (void)stat_pass;
   for (int j = b; j < e; j += PVLM_K2_BATCH) {
@@ -283,6 +298,7 @@ PVLM_HD void knn_scan_run(const CloudView& cv, int b, int e, float qx, float qy,
     }
   }
   PVLM_ASSOC_STATS_RUN(e - b, stat_pass);
+#endif
 }
 
 template <int K, bool DENSE>
