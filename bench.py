@@ -795,7 +795,7 @@ def mvs_block(ctx, pv):
     except Exception as e:                                   # e.g. a small pool reservation: the per-view numbers above stand on their own
         out["k13s_sequential_batch_1440x720"] = {"error": str(e)[:200]}
     out["bound"] = "VALU: the kernels' roof is instruction issue, the HBM fraction is reported for completeness"
-    # SQ counters of the same kernels (tools/prof_r3_final.sh -> profiles/r3_pmc_mvs.json, separate --pmc pass of
+    # SQ counters of the same kernels (tools/prof_r4_final.sh -> profiles/r4_pmc_mvs.json, separate --pmc pass of
     # tools/mvs_bench.py): wave VALU instructions x 4 cycles / (1024 SIMDs x kernel time) = a lower bound of the VALU pipes' load
     try:
         import glob

@@ -13,7 +13,7 @@ out, units = sys.argv[1], json.loads(sys.argv[2])
 trace_dir, pmc_dir = sys.argv[3], sys.argv[4]
 want = sys.argv[5:]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); ndisp = collections.Counter(); dur = collections.defaultdict(list)
-name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "")
+name = lambda r: r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 for f in glob.glob(pmc_dir + "/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
