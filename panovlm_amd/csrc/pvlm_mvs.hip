@@ -14,6 +14,13 @@
 #include "pvlm_internal.h"
 
 #define PVLM_HD __host__ __device__
+#ifndef PVLM_MVS_FLOW_CLOCK
+#define PVLM_MVS_FLOW_CLOCK 0      // measured variant: see FLOW_CLOCK_* below
+#endif
+#if PVLM_MVS_FLOW_CLOCK
+__device__ unsigned long long g_flow_clock[24];
+#define PVLM_MVS_SPEC_STAT(i) do { if (threadIdx.x == 0) atomicAdd(&g_flow_clock[16 + (i)], 1ull); } while (0)
+#endif
 #include "pvlm_mvs_core.h"
 
 #define PVLM_MVS_MAXM 4   // texels per lane: windows up to 256 texels.  Every wave-level piece below is a template on the
@@ -78,6 +85,17 @@ static inline hipError_t mvs_sync(pvlm_ctx* ctx) { return pvlm_i_sync(ctx) == PV
 
 struct pvlm_mvs_neighbours { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
 
+// MEASURED VARIANT (-DPVLM_MVS_FLOW_CLOCK=1): where a pixel of K13q spends its time, summed over all workgroups by thread 0 with the
+// 100 MHz wall clock: [0] ticket + walk + patch preparation, [1] waiting for the two stamps, [2] the dependent chain, [3] store + stamp,
+// [4] pixels, [5] batch rounds; inside the chain: [8] close neighbours (fence -> first batch), [9] hypothesis build, [10] score_hypothesis,
+// [11] barrier + exchange, and inside wave_score [12] homographies + neighbour texels, [13] strip sums, [14] NCC + geometric adjustment; printed by mvs_flow_end.
+#if PVLM_MVS_FLOW_CLOCK
+#define FLOW_CLOCK_NOW() wall_clock64()
+#define FLOW_CLOCK_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_flow_clock[i], (unsigned long long)(v)); } while (0)
+#else
+#define FLOW_CLOCK_NOW() 0ull
+#define FLOW_CLOCK_ADD(i, v) do { (void)(v); } while (0)
+#endif
 // ---- wave-level pieces shared by the scoring pass and the PatchMatch sweep (one wave per pixel, lane = texel) ----
 template <int M> struct PatchRegs { float w[M], t0[M]; float sq0; bool inside; };
 
@@ -127,6 +145,7 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
   for (int b0 = 0; b0 < nb.n; b0 += 4) {                                 // four neighbour images per pass: one float4 per texel in LDS
     float t1[4][M];
     bool okj[4];
+    const unsigned long long wk0 = FLOW_CLOCK_NOW();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bool ok = b0 + j < nb.n;
@@ -146,6 +165,7 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
       okj[j] = !__any(!ok);                                              // goto next_image
     }
     if (!(okj[0] || okj[1] || okj[2] || okj[3])) continue;
+    const unsigned long long wk1 = FLOW_CLOCK_NOW();
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
@@ -166,6 +186,7 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
     }
     float sq1j[4], sq01j[4];
     strip_seq_sum8(sB1, sB2, n, lane, sq1j, sq01j);                      // :830-831, :834-835
+    const unsigned long long wk2 = FLOW_CLOCK_NOW();
     // NCC -> clamp -> smoothness -> (use_geometry) geometric-consistency adjustment of neighbour j in lane j (mod 4): the
     // adjustment is ~600 wave-uniform instructions per neighbour (a projection, a depth sample, a back-projection with three
     // double-evaluated sin / cos and an acos) — four lanes do the four neighbours of the pass in one go
@@ -206,6 +227,7 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
       if (count == 0 || sc > best1) { best2 = best1; best1 = sc; } else if (count == 1 || sc > best2) best2 = sc;
       ++count;
     }
+    FLOW_CLOCK_ADD(12, wk1 - wk0); FLOW_CLOCK_ADD(13, wk2 - wk1); FLOW_CLOCK_ADD(14, FLOW_CLOCK_NOW() - wk2);
   }
   if (count == 1) return best1;
   if (count >= 2) { float avg = 0.f; avg += best1; avg += best2; return avg / 2; }
@@ -410,13 +432,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
 }
 // K13p — the same sweep as ONE persistent launch per iteration, ordered by data flow instead of by diagonal.
 // Round 3 launched one kernel per anti-diagonal (2159 at 1440 x 720, 8639 at 5760 x 2880): every diagonal waited for its slowest pixel
-// and for a launch, and every pixel paid its ~20 us of state-independent preparation (patch statistics, texel products) inside that
-// window.  A pixel only needs its two predecessors (left / up of the walk) to be FINAL; everything of the preparation depends on the
-// reference image alone.  Here a wave draws pixels from a ticket counter in walking order (diagonal after diagonal — so the wave that
-// owns a predecessor drew it earlier and is running: no deadlock whatever the number of resident waves), prepares the pixel, THEN waits
-// for the two per-pixel "done" stamps (acquire), runs the dependent chain, stores and stamps its own pixel (release).  The critical path
-// per diagonal is the chain of dependent scorings only; preparation and launch latency are off it.  Neighbours on the NEXT diagonal are
-// read before they change for the same reason as before: they wait for this pixel's stamp.  Results: those of the diagonal launches, bit for bit.
+// and for a launch, and every pixel paid its state-independent preparation (patch statistics, texel products) inside that window.
+// A pixel only needs its two predecessors (left / up of the walk) to be FINAL; everything of the preparation depends on the reference
+// image alone.  Here a wave draws pixels from a ticket counter in walking order (diagonal after diagonal — so the wave that owns a
+// predecessor drew it earlier and is running: no deadlock whatever the number of resident waves), prepares the pixel, THEN waits for the
+// state of its two predecessors, runs the dependent chain and publishes its own.  The critical path per diagonal is the chain of dependent
+// scorings only; preparation and launch latency are off it.  Neighbours on the NEXT diagonal are read before they change: they wait for
+// this pixel.  Results: those of the diagonal launches, bit for bit.  The hand-off itself is described at k_mvs_propagate_flow_spec below:
+// four 8-byte {value, epoch} cells per pixel, agent-scope atomics on both sides, no fence.
 __device__ __forceinline__ void mvs_walk_pixel(long long t, int rows, int cols, int* wx, int* wy) {     // ticket -> pixel in the walk's own frame
   const long long m = rows < cols ? rows : cols, mx = rows < cols ? cols : rows, npix = (long long)rows * cols;
   const long long ta = m * (m - 1) / 2, tb = ta + (mx - m + 1) * m;
@@ -436,11 +459,43 @@ __device__ __forceinline__ void mvs_walk_pixel(long long t, int rows, int cols, 
 #ifndef PVLM_MVS_FLOW_SLEEP
 #define PVLM_MVS_FLOW_SLEEP 8     // x 64 cycles between two polls of a stamp
 #endif
+// the four {value, epoch} cells of a pixel: depth, normal x / y / z
+__device__ __forceinline__ unsigned long long mvs_cell(int epoch, float f) { return ((unsigned long long)(unsigned)epoch << 32) | pvlm_mvs::float_bits(f); }
+// State of the four direct neighbours for the pixel of this wave (all 64 lanes call it; every lane returns the whole Around): lane 4 q + k
+// fetches value k of slot q — from the cells, polled until they carry this iteration's epoch, for the two predecessors of the walk; from
+// the maps for the other two (and nothing for a slot outside the image).
+__device__ inline void mvs_wave_around(int rows, int cols, int px, int py, int sgn, int lane, const float* depth, const float* normal, const unsigned long long* cell,
+                                       int epoch, pvlm_mvs::Around& ar) {
+  const int q = (lane >> 2) & 3, k = lane & 3;
+  const int cx = px + (q == 0 ? -1 : (q == 3 ? 1 : 0)), cy = py + (q == 1 ? -1 : (q == 2 ? 1 : 0));
+  const bool in = cx >= 0 && cy >= 0 && cx < cols && cy < rows;
+  const bool pred = q == pvlm_mvs::around_slot(sgn, 0) || q == pvlm_mvs::around_slot(0, sgn);
+  const long long ne = in ? (long long)cy * cols + cx : 0;
+  float f = 0.f;
+  if (lane < 16 && in && !pred) f = k == 0 ? depth[ne] : normal[3 * ne + k - 1];
+  const bool need = lane < 16 && in && pred;
+  bool have = !need;
+  while (true) {
+    if (!have) {
+      const unsigned long long v = __hip_atomic_load(cell + 4 * ne + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      have = (int)(v >> 32) == epoch;
+      f = pvlm_mvs::bits_float((unsigned)v);
+    }
+    if (__all(have)) break;
+    __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    ar.inside[s] = __builtin_amdgcn_readlane((int)in, 4 * s);
+    ar.depth[s] = lane_bcast(f, 4 * s);
+    ar.normal[s][0] = lane_bcast(f, 4 * s + 1); ar.normal[s][1] = lane_bcast(f, 4 * s + 2); ar.normal[s][2] = lane_bcast(f, 4 * s + 3);
+  }
+}
 template <int M>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_flow(
     int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
     float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int backward,
-    unsigned long long* ticket, int* done, int epoch) {
+    unsigned long long* ticket, unsigned long long* cell, int epoch) {
   const int lane = threadIdx.x & 63;
   const int n = pvlm_mvs::num_texels(half_window, step);
   __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
@@ -458,6 +513,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
     const long long e = (long long)py * cols + px;
     // ---- preparation: nothing here reads what the sweep writes (the pixel's own state is only written by this wave)
     float dep = depth[e];
+    float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
     bool live = dep > 0;
     PatchRegs<M> P;
     if (live) {
@@ -465,26 +521,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
       live = P.inside && P.sq0 > 0;                                         // patch.sq0 <= 0 (:1069, :1087)
     }
     if (live) {
-      float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
       float c = conf[e];
-      // ---- the two predecessors of the walk must be final
-      const int lx = px + sgn, uy = py + sgn;
-      // polled with relaxed loads (an acquire load invalidates the CU's whole L1 at every poll: with thousands of waiting waves the
-      // working ones lost their cached texels all the time — first version: 3.4 s per iteration); ONE acquire fence once both are in
-      if (lane == 0) {
-        if (lx >= 0 && lx < cols) while (__hip_atomic_load(done + e + sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
-        if (uy >= 0 && uy < rows) while (__hip_atomic_load(done + e + (long long)sgn * cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // every lane reads the neighbours' state below
+      pvlm_mvs::Around ar;
+      mvs_wave_around(rows, cols, px, py, sgn, lane, depth, normal, cell, epoch, ar);   // waits for the two predecessors of the walk
       pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
       pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
       WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
+      pvlm_mvs::SerialBatch<WaveScorer<M>> batch{&scorer, 1};                 // one hypothesis after the other: process_pixel's chain
       const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
-      pvlm_mvs::process_pixel(A, rng, px, py, scorer, dep, nrm3, c, 2, pdx, pdy);
+      pvlm_mvs::process_pixel_around(A, rng, px, py, batch, ar, dep, nrm3, c, 2, pdx, pdy);
+      if (lane < 4) __hip_atomic_store(cell + 4 * e + lane, mvs_cell(epoch, lane == 0 ? dep : nrm3[lane - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+    } else if (lane < 4) {
+      // a pixel the sweep skips keeps its state: its successors may read it at once
+      __hip_atomic_store(cell + 4 * e + lane, mvs_cell(epoch, lane == 0 ? dep : nrm3[lane - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // a pixel the sweep skips keeps its state: its successors may read it at once
-    if (lane == 0) __hip_atomic_store(done + e, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -495,18 +546,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
 // confidences through LDS and resolves them in order: the same result as the chain, bit for bit, in 1 + ~3 dependent scorings.
 template <int M>
 struct BlockBatch {
-  WaveScorer<M>* scorer; int wave, lane; pvlm_mvs::Hypothesis* xchg; int phase;
+  WaveScorer<M>* scorer; int wave, lane; pvlm_mvs::Hypothesis* xchg; int phase; unsigned long long since;
   __device__ int width() const { return 4; }
   template <class Build>
   __device__ void run(int n, const float* view_ray, const pvlm_mvs::ClosePixel* close, int n_close, Build&& build, pvlm_mvs::Hypothesis* out) {
     pvlm_mvs::Hypothesis mine;
+    FLOW_CLOCK_ADD(5, 1);
+    const unsigned long long bk0 = FLOW_CLOCK_NOW();
+    if (since) { FLOW_CLOCK_ADD(8, bk0 - since); since = 0; }
+    unsigned long long bk1 = bk0, bk2 = bk0;
     mine.normal[0] = mine.normal[1] = mine.normal[2] = 0.f; mine.depth = 0.f; mine.conf = -1.f; mine.valid = 0;
     if (wave < n) {
       build(wave, mine);
+      bk1 = FLOW_CLOCK_NOW();
       if (mine.valid) mine.conf = pvlm_mvs::score_hypothesis(*scorer, view_ray, close, n_close, mine);
       if (lane == 0) xchg[phase * 4 + wave] = mine;
+      bk2 = FLOW_CLOCK_NOW();
     }
     __syncthreads();
+    FLOW_CLOCK_ADD(9, bk1 - bk0); FLOW_CLOCK_ADD(10, bk2 - bk1); FLOW_CLOCK_ADD(11, FLOW_CLOCK_NOW() - bk2);
     // two exchange buffers: a wave that runs ahead writes batch t + 1 into the other half and then waits at ITS barrier, which the
     // slowest wave only reaches after it has read batch t
 #pragma unroll
@@ -517,24 +575,35 @@ struct BlockBatch {
 };
 
 // K13q — the data-flow sweep with FOUR waves per pixel (one workgroup = one pixel).  Once the preparation is off the critical path
-// (K13p) what is left per pixel is the chain of 8-14 dependent scorings; pvlm_mvs::process_pixel_spec scores the independent hypotheses
+// (K13p) what is left per pixel is the chain of 8-14 dependent scorings; pvlm_mvs::process_pixel_around scores the independent hypotheses
 // of a pixel side by side — one per wave, confidences exchanged through LDS and resolved in order: the same result as the chain, bit
-// for bit, in 1 + ~3 dependent scorings (tests/test_mvs_cpu.py).  Round 3 measured this form with one launch per diagonal and found
-// no gain, because all four waves repeated the preparation INSIDE the diagonal's window; here they do it while they wait.
+// for bit, in 1 + ~2 dependent batches (tests/test_mvs_cpu.py).
+//
+// Hand-off between pixels.  The first form (K13p's: plain stores -> agent release -> stamp; poll -> agent acquire -> plain loads) cost
+// every pixel an L2 write-back, an L1 invalidate of its CU (three workgroups share one: every texel and unit-ray line re-fetched from
+// L2 all the time) and ~8 dependent L2 round trips for the neighbours' state behind the fence.  A pixel needs exactly 16 bytes from each
+// of its two predecessors — depth + normal — so they travel as four 8-byte cells {value, epoch} per pixel, written with agent-scope
+// atomic stores (write-through) and polled with agent-scope atomic loads by eight lanes at once: a cell is complete or absent, there is
+// nothing to order and nothing to fence (MI355X_MICROARCH.md, "8-B agent atomics both sides").  The maps themselves are written with plain
+// stores as before — this launch reads them only where the sweep has not been yet (the other two neighbours, read BEFORE the wait) — and
+// are whole when the kernel ends.
 template <int M>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PVLM_K13_WAVES : 2))) void k_mvs_propagate_flow_spec(
     int rows, int cols, int half_window, int step, const unsigned char* __restrict__ ref_gray, const float* __restrict__ unit, pvlm_mvs_neighbours nb, float* depth,
     float* normal, float* conf, const unsigned char* __restrict__ depth_constant, float min_depth, float max_depth, unsigned long long pass_seed, int backward,
-    unsigned long long* ticket, int* done, int epoch) {
+    unsigned long long* ticket, unsigned long long* cell, int epoch) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = pvlm_mvs::num_texels(half_window, step);
   __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
   __shared__ pvlm_mvs::Hypothesis xchg[8];
+  __shared__ pvlm_mvs::Around around;
   __shared__ unsigned long long drawn;
   float4* lds = strips[wave];
   const long long npix = (long long)rows * cols;
   const int sgn = backward ? 1 : -1;
+  const int slot_h = pvlm_mvs::around_slot(sgn, 0), slot_v = pvlm_mvs::around_slot(0, sgn);   // the walk's two predecessors
   while (true) {
+    const unsigned long long ck0 = FLOW_CLOCK_NOW();
     if (threadIdx.x == 0) drawn = atomicAdd(ticket, 1ull);
     __syncthreads();
     const unsigned long long t = drawn;
@@ -544,6 +613,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
     const int px = backward ? cols - 1 - wx : wx, py = backward ? rows - 1 - wy : wy;
     const long long e = (long long)py * cols + px;
     float dep = depth[e];
+    float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
     bool live = dep > 0;
     PatchRegs<M> P;
     if (live) {
@@ -551,25 +621,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
       live = P.inside && P.sq0 > 0;
     }
     if (live) {
-      float nrm3[3] = {normal[3 * e], normal[3 * e + 1], normal[3 * e + 2]};
       float c = conf[e];
-      const int lx = px + sgn, uy = py + sgn;
-      if (threadIdx.x == 0) {
-        if (lx >= 0 && lx < cols) while (__hip_atomic_load(done + e + sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
-        if (uy >= 0 && uy < rows) while (__hip_atomic_load(done + e + (long long)sgn * cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
+      // the two neighbours the walk has not reached yet: their state cannot change before this pixel is published
+      if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        const int cx = px + (q == 0 ? -1 : (q == 3 ? 1 : 0)), cy = py + (q == 1 ? -1 : (q == 2 ? 1 : 0));
+        const bool in = cx >= 0 && cy >= 0 && cx < cols && cy < rows;
+        around.inside[q] = in;
+        if (q != slot_h && q != slot_v) {
+          const long long ne = in ? (long long)cy * cols + cx : e;
+          around.depth[q] = in ? depth[ne] : 0.f;
+          around.normal[q][0] = normal[3 * ne]; around.normal[q][1] = normal[3 * ne + 1]; around.normal[q][2] = normal[3 * ne + 2];
+        }
+      }
+      const unsigned long long ck1 = FLOW_CLOCK_NOW();
+      // lanes 0-3: the four cells of the horizontal predecessor, lanes 4-7: of the vertical one
+      if (wave == 0) {
+        const int p = lane >> 2, k = lane & 3;
+        const int qx = px + (p ? 0 : sgn), qy = py + (p ? sgn : 0);
+        const bool need = lane < 8 && qx >= 0 && qx < cols && qy >= 0 && qy < rows;
+        const unsigned long long* src = cell + 4 * ((long long)qy * cols + qx) + k;
+        unsigned long long v = 0;
+        bool have = !need;
+        while (true) {
+          if (!have) { v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); have = (int)(v >> 32) == epoch; }
+          if (__all(have)) break;
+          __builtin_amdgcn_s_sleep(PVLM_MVS_FLOW_SLEEP);
+        }
+        if (need) {
+          const float f = pvlm_mvs::bits_float((unsigned)v);
+          const int slot = p ? slot_v : slot_h;
+          if (k == 0) around.depth[slot] = f; else around.normal[slot][k - 1] = f;
+        }
       }
       __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const unsigned long long ck2 = FLOW_CLOCK_NOW();
       pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
       pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
       WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
-      BlockBatch<M> batch{&scorer, wave, lane, xchg, 0};
+      BlockBatch<M> batch{&scorer, wave, lane, xchg, 0, ck2};
       const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
-      pvlm_mvs::process_pixel_spec(A, rng, px, py, batch, dep, nrm3, c, 2, pdx, pdy);
+      pvlm_mvs::process_pixel_around(A, rng, px, py, batch, around, dep, nrm3, c, 2, pdx, pdy);
+      const unsigned long long ck3 = FLOW_CLOCK_NOW();
+      if (threadIdx.x < 4) {
+        const float f = threadIdx.x == 0 ? dep : nrm3[threadIdx.x - 1];
+        __hip_atomic_store(cell + 4 * e + threadIdx.x, mvs_cell(epoch, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (threadIdx.x == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
+      FLOW_CLOCK_ADD(0, ck1 - ck0); FLOW_CLOCK_ADD(1, ck2 - ck1); FLOW_CLOCK_ADD(2, ck3 - ck2); FLOW_CLOCK_ADD(3, FLOW_CLOCK_NOW() - ck3); FLOW_CLOCK_ADD(4, 1);
+    } else if (threadIdx.x < 4) {
+      // a pixel the sweep skips keeps its state: its successors may read it at once
+      const float f = threadIdx.x == 0 ? dep : nrm3[threadIdx.x - 1];
+      __hip_atomic_store(cell + 4 * e + threadIdx.x, mvs_cell(epoch, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(done + e, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();                                                          // `drawn` and the exchange buffers are reused by the next pixel
+    __syncthreads();                                                          // `drawn`, `around` and the exchange buffers are reused by the next pixel
   }
 }
 
@@ -608,7 +713,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
   pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
   WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
-  BlockBatch<M> batch{&scorer, wave, lane, xchg, 0};
+  BlockBatch<M> batch{&scorer, wave, lane, xchg, 0, 0ull};
   const int sgn = backward ? 1 : -1;
   const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
   pvlm_mvs::process_pixel_spec(A, rng, px, py, batch, dep, nrm3, c, 2, pdx, pdy);
@@ -798,7 +903,7 @@ static void launch_mvs_propagate(hipStream_t s, int rows, int cols, int half_win
 // one iteration of the sequential sweep (iteration parity = direction, :1061, :1079): one persistent launch (k_mvs_propagate_flow) when
 // the caller provides the ticket counter + per-pixel stamps (flow != nullptr; stamps of iteration `iter` = iter + 1, the caller zeroes
 // them once), otherwise — PVLM_MVS_FLOW=0, or no memory for the stamps — every anti-diagonal in walking order
-struct MvsFlow { unsigned long long* ticket; int* done; int blocks; bool spec; };
+struct MvsFlow { unsigned long long* ticket; unsigned long long* cell; int blocks; bool spec; };
 static void launch_mvs_propagate_sequential(hipStream_t s, int rows, int cols, int half_window, int step, const unsigned char* img, const float* unit,
                                             const pvlm_mvs_neighbours& nb, float* depth, float* normal, float* conf, const unsigned char* depth_constant,
                                             float min_depth, float max_depth, unsigned long long pass_seed, int iter, const MvsFlow* flow = nullptr) {
@@ -810,18 +915,18 @@ static void launch_mvs_propagate_sequential(hipStream_t s, int rows, int cols, i
     if (flow->spec) {
       if (small)
         hipLaunchKernelGGL(k_mvs_propagate_flow_spec<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth,
-                           pass_seed, backward, flow->ticket, flow->done, iter + 1);
+                           pass_seed, backward, flow->ticket, flow->cell, iter + 1);
       else
         hipLaunchKernelGGL(k_mvs_propagate_flow_spec<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant,
-                           min_depth, max_depth, pass_seed, backward, flow->ticket, flow->done, iter + 1);
+                           min_depth, max_depth, pass_seed, backward, flow->ticket, flow->cell, iter + 1);
       return;
     }
     if (small)
       hipLaunchKernelGGL(k_mvs_propagate_flow<1>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth, max_depth,
-                         pass_seed, backward, flow->ticket, flow->done, iter + 1);
+                         pass_seed, backward, flow->ticket, flow->cell, iter + 1);
     else
       hipLaunchKernelGGL(k_mvs_propagate_flow<PVLM_MVS_MAXM>, grid, block, 0, s, rows, cols, half_window, step, img, unit, nb, depth, normal, conf, depth_constant, min_depth,
-                         max_depth, pass_seed, backward, flow->ticket, flow->done, iter + 1);
+                         max_depth, pass_seed, backward, flow->ticket, flow->cell, iter + 1);
     return;
   }
 #if PVLM_MEASURED_VARIANTS
@@ -854,21 +959,22 @@ static void launch_mvs_propagate_sequential(hipStream_t s, int rows, int cols, i
 }
 
 #ifndef PVLM_MVS_FLOW_MAX_DIAG
-#define PVLM_MVS_FLOW_MAX_DIAG 1024   // longest anti-diagonal (pixels) up to which the data-flow launch is used
+#define PVLM_MVS_FLOW_MAX_DIAG 1024   // longest anti-diagonal (pixels) up to which a pixel gets a workgroup of four waves (K13q); beyond: one wave (K13p)
 #endif
-// scratch of the persistent sweep: ticket counter + one stamp per pixel (zeroed here), grid = what the chip keeps resident
+// scratch of the persistent sweep: ticket counter + four hand-off cells per pixel (zeroed here), grid = what the chip keeps resident
 static bool mvs_flow_begin(pvlm_ctx* ctx, int rows, int cols, int half_window, int step, MvsFlow* f) {
   // PVLM_MVS_FLOW: 0 = one launch per anti-diagonal, 1 = persistent data-flow launch with a wave per pixel (K13p), 2 = with four waves per
-  // pixel (K13q).  Unset: by size — measured per iteration (profiles/r4_mvs_seq_forms.txt), 1440 x 720: 137.7 / 133.8 / 117.5 ms for
-  // 0 / 1 / 2; 5760 x 2880: 822 / 875 / 1462 ms (a 2880-pixel diagonal fills the chip with one wave per pixel; four per pixel oversubscribe it)
+  // pixel (K13q).  Unset: by size — four waves per pixel while an anti-diagonal of workgroups fits the chip (768 resident workgroups), one
+  // wave per pixel beyond.  Measured per iteration, 4 neighbours (profiles/r4_mvs_seq_forms.txt): 1440 x 720: 127.6 / 119.4 / 82.4 ms for
+  // 0 / 1 / 2; 5760 x 2880: 697 / 607 / 879 ms.
   static const int forced = getenv("PVLM_MVS_FLOW") ? atoi(getenv("PVLM_MVS_FLOW")) : -1;
-  const int mode = forced >= 0 ? forced : (std::min(rows, cols) <= PVLM_MVS_FLOW_MAX_DIAG ? 2 : 0);
-  f->ticket = nullptr; f->done = nullptr; f->blocks = 0; f->spec = mode == 2;
+  const int mode = forced >= 0 ? forced : (std::min(rows, cols) <= PVLM_MVS_FLOW_MAX_DIAG ? 2 : 1);
+  f->ticket = nullptr; f->cell = nullptr; f->blocks = 0; f->spec = mode == 2;
   if (mode == 0) return false;
   const size_t npix = (size_t)rows * cols;
   if (pvlm_i_alloc(ctx, &f->ticket, (size_t)1)) { f->ticket = nullptr; return false; }
-  if (pvlm_i_alloc(ctx, &f->done, npix)) { pvlm_i_free(ctx, f->ticket); f->ticket = nullptr; f->done = nullptr; return false; }
-  (void)hipMemsetAsync(f->done, 0, npix * sizeof(int), ctx->stream);
+  if (pvlm_i_alloc(ctx, &f->cell, 4 * npix)) { pvlm_i_free(ctx, f->ticket); f->ticket = nullptr; f->cell = nullptr; return false; }   // four {value, epoch} cells per pixel
+  (void)hipMemsetAsync(f->cell, 0, 4 * npix * sizeof(unsigned long long), ctx->stream);
   int per_cu = 0;
   const bool small = pvlm_mvs::num_texels(half_window, step) <= 64;
   hipError_t e;
@@ -884,7 +990,22 @@ static bool mvs_flow_begin(pvlm_ctx* ctx, int rows, int cols, int half_window, i
   f->blocks = std::max(1, std::min(f->blocks, useful));
   return true;
 }
-static void mvs_flow_end(pvlm_ctx* ctx, MvsFlow* f) { pvlm_i_free(ctx, f->ticket); pvlm_i_free(ctx, f->done); f->ticket = nullptr; f->done = nullptr; }
+static void mvs_flow_end(pvlm_ctx* ctx, MvsFlow* f) {
+#if PVLM_MVS_FLOW_CLOCK
+  if (f->ticket) {
+    unsigned long long h[24] = {}, z[24] = {};
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_flow_clock), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_flow_clock), z, sizeof z);
+    const double px = (double)std::max<unsigned long long>(h[4], 1);
+    fprintf(stderr, "[flow clock] pixels %llu | us per pixel: prepare %.2f  wait %.2f  chain %.2f  publish %.2f | batch rounds per pixel %.2f | blocks %d\n", h[4],
+            h[0] * 0.01 / px, h[1] * 0.01 / px, h[2] * 0.01 / px, h[3] * 0.01 / px, (double)h[5] / px, f->blocks);
+    fprintf(stderr, "[flow clock]   chain, us per pixel (wave 0): close neighbours %.2f  build %.2f  score %.2f  barrier + exchange %.2f | inside score: texels %.2f  strip sums %.2f  ncc + geometry %.2f\n",
+            h[8] * 0.01 / px, h[9] * 0.01 / px, h[10] * 0.01 / px, h[11] * 0.01 / px, h[12] * 0.01 / px, h[13] * 0.01 / px, h[14] * 0.01 / px);
+    fprintf(stderr, "[flow clock]   per pixel: propagated hypotheses accepted %.3f  random phase entered %.3f  refinements accepted %.3f\n", h[16] / px, h[17] / px, h[19] / px);
+  }
+#endif
+  pvlm_i_free(ctx, f->ticket); pvlm_i_free(ctx, f->cell); f->ticket = nullptr; f->cell = nullptr; }
 
 // MVS::InitDepthNormal (mvs/MVS.cpp:496-584, the `#elif 1` branch :511-514): LiDAR depth image (uint16, depth * 256) where it has a
 // value, a uniform random depth elsewhere, optional mask, a random normal facing the camera for every pixel the mask keeps.

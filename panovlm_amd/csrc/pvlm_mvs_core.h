@@ -15,10 +15,18 @@ namespace pvlm_mvs {
 // exp / sin / cos / acos of a FLOAT (the reference calls the std:: float overloads; their last bit depends on the libm
 // version): the correctly rounded float result, taken as the double function rounded to float — the same definition the
 // test oracle uses, so that device, host-compiled check and oracle agree bit for bit.
-PVLM_HD inline float f_exp(float x) { return (float)exp((double)x); }
-PVLM_HD inline float f_sin(float x) { return (float)sin((double)x); }
-PVLM_HD inline float f_cos(float x) { return (float)cos((double)x); }
-PVLM_HD inline float f_acos(float x) { return (float)acos((double)x); }
+// On the device each is ONE out-of-line function: inlined, the double-precision routines (1-4 KB each) were repeated at every call
+// site and k_mvs_propagate_flow_spec<1> came to 70 KB of code — more than the 64 KB instruction cache two CUs share.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PVLM_MVS_MATH __attribute__((noinline))
+#else
+#define PVLM_MVS_MATH
+#endif
+PVLM_HD inline PVLM_MVS_MATH float f_exp(float x) { return (float)exp((double)x); }
+PVLM_HD inline float f_exp_inline(float x) { return (float)exp((double)x); }   // FillPixelPatch: once per texel, one call site per kernel
+PVLM_HD inline PVLM_MVS_MATH float f_sin(float x) { return (float)sin((double)x); }
+PVLM_HD inline PVLM_MVS_MATH float f_cos(float x) { return (float)cos((double)x); }
+PVLM_HD inline PVLM_MVS_MATH float f_acos(float x) { return (float)acos((double)x); }
 
 // FastAtan2<float> (base/Math.h:15-29): polynomial evaluated in double (double literals), rounded to float on assignment
 PVLM_HD inline float fast_atan2f(float y, float x) {
@@ -102,7 +110,7 @@ PVLM_HD inline void patch_texel(const unsigned char* gray, int cols, int px, int
   float wColor = (tex - center) / 255.f;
   wColor = wColor * wColor * sigma_color;
   const float wSpatial = ((float)((col - px) * (col - px)) + (float)((row - py) * (row - py))) * sigma_spatial;
-  *weight = f_exp(wColor + wSpatial);
+  *weight = f_exp_inline(wColor + wSpatial);
   *texel = tex;
 }
 
@@ -134,10 +142,10 @@ PVLM_HD inline bool neighbour_texel(const float* unit, const unsigned char* nei_
 PVLM_HD inline void image_to_cam(int rows, int cols, const float* px, float r, float* cam) {
   const float sx = (float)((2 * px[0] / cols - 1) * 3.14159265358979323846);
   const float sy = (float)((0.5 - px[1] / rows) * 3.14159265358979323846);
-  const float cy = (float)cos((double)sy);
-  cam[0] = r * cy * (float)sin((double)sx);
-  cam[1] = -r * (float)sin((double)sy);
-  cam[2] = r * cy * (float)cos((double)sx);
+  const float cy = f_cos(sy);
+  cam[0] = r * cy * f_sin(sx);
+  cam[1] = -r * f_sin(sy);
+  cam[2] = r * cy * f_cos(sx);
 }
 
 // Sample(img, pt, functor) of mvs/MVS.cpp:1445-1467 with the functor of ScorePixel :873: |depth0 - d| / depth0 < 0.03f
@@ -574,6 +582,9 @@ PVLM_HD inline void process_pixel(const SweepArgs& A, Rng& rng, int px, int py, 
 // one wave per pixel).  The random phase (1 - conf >= thConfRand, rejection-sampled normals: a variable number of draws) stays
 // a chain; every executor of the batch runs it redundantly.
 struct Hypothesis { float normal[3]; float depth; float conf; int valid; };
+#ifndef PVLM_MVS_SPEC_STAT
+#define PVLM_MVS_SPEC_STAT(i) do { } while (0)   // measured variant of pvlm_mvs.hip (-DPVLM_MVS_FLOW_CLOCK=1): outcomes per pixel
+#endif
 
 // hypothesis -> its score (plane through the point, smoothness factors of the close neighbours, ScorePixel)
 template <class Scorer>
@@ -600,25 +611,40 @@ struct SerialBatch {
   PVLM_HD Scorer& single() { return *score; }
 };
 
+// State of the four direct neighbours of a pixel — slot 0 (x - 1, y), 1 (x, y - 1), 2 (x, y + 1), 3 (x + 1, y), the order ProcessPixel
+// collects its close pixels in — as the sweep shows it to this pixel.  gather_around reads it from the maps; the data-flow kernels
+// (pvlm_mvs.hip, K13r) receive the two slots the walk has just updated from the workgroup that computed them instead.
+struct Around { float depth[4]; float normal[4][3]; int inside[4]; };
+PVLM_HD inline int around_slot(int dx, int dy) { return dx < 0 ? 0 : (dy < 0 ? 1 : (dy > 0 ? 2 : 3)); }
+PVLM_HD inline void gather_around(const SweepArgs& A, int px, int py, Around& ar) {
+  const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
+  for (int q = 0; q < 4; ++q) {
+    ar.inside[q] = cx[q] >= 0 && cy[q] >= 0 && cx[q] < A.cols && cy[q] < A.rows;
+    ar.depth[q] = 0.f; ar.normal[q][0] = ar.normal[q][1] = ar.normal[q][2] = 0.f;
+    if (!ar.inside[q]) continue;
+    const size_t ne = (size_t)cy[q] * A.cols + cx[q];
+    ar.depth[q] = A.depth[ne];
+    for (int k = 0; k < 3; ++k) ar.normal[q][k] = A.normal[3 * ne + k];
+  }
+}
+
 template <class Batch>
-PVLM_HD inline void process_pixel_spec(const SweepArgs& A, Rng& rng, int px, int py, Batch& batch, float& depth, float* normal, float& conf,
-                                       int n_prop, const int* pdx, const int* pdy) {
-  const int rows = A.rows, cols = A.cols;
+PVLM_HD inline void process_pixel_around(const SweepArgs& A, Rng& rng, int px, int py, Batch& batch, const Around& ar, float& depth, float* normal, float& conf,
+                                         int n_prop, const int* pdx, const int* pdy) {
+  const int cols = A.cols;
   const size_t e = (size_t)py * cols + px;
   const bool keep_depth_constant = A.depth_constant && A.depth_constant[e];
   const float* view_ray = A.unit + 3 * e;
+  const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
   ClosePixel close[4] = {}; int n_close = 0;
-  {
-    const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
-    for (int q = 0; q < 4; ++q) {
-      if (!(cx[q] >= 0 && cy[q] >= 0 && cx[q] < cols && cy[q] < rows)) continue;
-      const size_t ne = (size_t)cy[q] * cols + cx[q];
-      const float d = A.depth[ne];
-      if (d <= 0) continue;
-      ClosePixel& c = close[n_close++];
-      for (int k = 0; k < 3; ++k) { c.point[k] = A.unit[3 * ne + k] * d; c.normal[k] = A.normal[3 * ne + k]; }
-      c.depth = d;
-    }
+  for (int q = 0; q < 4; ++q) {
+    if (!ar.inside[q]) continue;
+    const float d = ar.depth[q];
+    if (d <= 0) continue;
+    const size_t ne = (size_t)cy[q] * cols + cx[q];
+    ClosePixel& c = close[n_close++];
+    for (int k = 0; k < 3; ++k) { c.point[k] = A.unit[3 * ne + k] * d; c.normal[k] = ar.normal[q][k]; }
+    c.depth = d;
   }
   const int W = batch.width();
   Hypothesis hyp[4];
@@ -629,19 +655,19 @@ PVLM_HD inline void process_pixel_spec(const SweepArgs& A, Rng& rng, int px, int
     batch.run(n, view_ray, close, n_close, [&](int w, Hypothesis& h) {
       h.valid = 0;
       const int q = base + w;
-      const int nxq = px + pdx[q], nyq = py + pdy[q];
-      if (!(nxq >= 0 && nyq >= 0 && nxq < cols && nyq < rows)) return;
-      const size_t ne = (size_t)nyq * cols + nxq;
-      float depth_neighbor = A.depth[ne];
+      const int slot = around_slot(pdx[q], pdy[q]);
+      if (!ar.inside[slot]) return;
+      const size_t ne = (size_t)(py + pdy[q]) * cols + (px + pdx[q]);
+      float depth_neighbor = ar.depth[slot];
       if (depth_neighbor <= 0) return;
-      float normal_neighbor[3] = {A.normal[3 * ne], A.normal[3 * ne + 1], A.normal[3 * ne + 2]};
+      float normal_neighbor[3] = {ar.normal[slot][0], ar.normal[slot][1], ar.normal[slot][2]};
       // keep_depth_constant: the pixel's own depth, which no acceptance changes (an accepted neighbour hands over that same depth)
       depth_neighbor = keep_depth_constant ? depth_now : interpolate_pixel(view_ray, A.unit + 3 * ne, depth_neighbor, normal_neighbor, A.min_depth, A.max_depth);
       correct_normal(view_ray, normal_neighbor);
       h.normal[0] = normal_neighbor[0]; h.normal[1] = normal_neighbor[1]; h.normal[2] = normal_neighbor[2]; h.depth = depth_neighbor; h.valid = 1;
     }, hyp);
     for (int w = 0; w < n; ++w)
-      if (hyp[w].valid && conf < hyp[w].conf) { conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2]; }
+      if (hyp[w].valid && conf < hyp[w].conf) { conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2]; PVLM_MVS_SPEC_STAT(0); }
   }
   // ---- PerturbDepthNormal3
   const bool perturb = !keep_depth_constant;
@@ -651,6 +677,7 @@ PVLM_HD inline void process_pixel_spec(const SweepArgs& A, Rng& rng, int px, int
   if (1 - conf <= thConfSmall) idxScaleRange = 2;
   else if (1 - conf <= thConfBig) idxScaleRange = 1;
   else if (1 - conf >= thConfRand) {
+    PVLM_MVS_SPEC_STAT(1);
     bool refine = false;
     float factors[4];
     for (int iter = 0; iter < 6; iter++) {
@@ -687,11 +714,20 @@ PVLM_HD inline void process_pixel_spec(const SweepArgs& A, Rng& rng, int px, int
         conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2];
         idxScaleRange++;
         taken = w + 1;
+        PVLM_MVS_SPEC_STAT(3);
         break;
       }
     rng.k = k0 + draws * (unsigned)taken;
     base += taken;
   }
+}
+
+template <class Batch>
+PVLM_HD inline void process_pixel_spec(const SweepArgs& A, Rng& rng, int px, int py, Batch& batch, float& depth, float* normal, float& conf,
+                                       int n_prop, const int* pdx, const int* pdy) {
+  Around ar;
+  gather_around(A, px, py, ar);
+  process_pixel_around(A, rng, px, py, batch, ar, depth, normal, conf, n_prop, pdx, pdy);
 }
 
 // ---- one pixel per THREAD ------------------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=720); ap.add_argument("--cols", type=int, default=1440)
     ap.add_argument("--neighbors", type=int, default=4); ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--checkerboard", action="store_true", help="time the checkerboard sweep (PropagateCheckerBoard) instead")
     a = ap.parse_args()
     from oracle import oracle as orc     # scene rendering only
     from tests import synth
@@ -25,15 +26,15 @@ def main():
     d0 = (depth * np.random.default_rng(7).uniform(0.9, 1.1, size=depth.shape)).astype(np.float32)
     c0, d1, n1 = ctx.mvs_init_conf_map(gray, neis, np.array(Rn), np.array(tn), d0, normal, 3, 1)
     sw = (gray, neis, np.array(Rn), np.array(tn), d1, n1, c0)
-    ctx.mvs_propagate(*sw, half_window=3, step=1, max_iter=1, seed=5, sequential=True)
+    ctx.mvs_propagate(*sw, half_window=3, step=1, max_iter=1, seed=5, sequential=not a.checkerboard)
     ctx.profile_enable(True)
     t0 = time.perf_counter()
-    sq = ctx.mvs_propagate(*sw, half_window=3, step=1, max_iter=a.iters, seed=5, sequential=True)
+    sq = ctx.mvs_propagate(*sw, half_window=3, step=1, max_iter=a.iters, seed=5, sequential=not a.checkerboard)
     wall = time.perf_counter() - t0
-    ms, cnt = ctx.profile_read(1)
+    ms, cnt = ctx.profile_read(1)          # checkerboard: one interval per colour pass
     ctx.profile_enable(False)
     h = hashlib.sha256(); [h.update(np.ascontiguousarray(x).tobytes()) for x in sq[:3]]
-    print(json.dumps(dict(rows=a.rows, cols=a.cols, flow=os.environ.get("PVLM_MVS_FLOW", "1"), sleep=os.environ.get("PVLM_LIB", "base"), ms_per_iteration=ms / max(cnt, 1),
+    print(json.dumps(dict(sweep="checkerboard" if a.checkerboard else "sequential", rows=a.rows, cols=a.cols, flow=os.environ.get("PVLM_MVS_FLOW", "1"), sleep=os.environ.get("PVLM_LIB", "base"), ms_per_iteration=ms / max(cnt, 1),
                           iterations=int(cnt), wall_ms=wall * 1e3, sha256=h.hexdigest()[:16], diags=os.environ.get("PVLM_MVS_FLOW_DIAGS", "2.5"))))
 
 
