@@ -171,6 +171,9 @@ class Velodyne {
   const RingLayout& Layout() const { return layout_; }
   void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
   void Transform2Local();                         // :1810-1848
+  // Every scan of the list to the world (local) frame — the loops of LidarOdometry.cpp:148-152 and :120-130 over all scans: the device
+  // copies are given back on the calling thread (the engine's pool is not thread-safe), the clouds transformed scan-parallel.
+  static void TransformBatch(const std::vector<Velodyne*>& scans, bool to_world, int num_threads);
 
   // device mirror of the clouds (uploaded lazily by the association entry points)
   pvlm_scan* DeviceScan() const;
