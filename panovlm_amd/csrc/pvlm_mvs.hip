@@ -201,7 +201,7 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
     if (valid) {
       score = sq01 / sqrtf(nrm);
       score = fminf(fmaxf(score, -1.f), 1.f);
-      score = pvlm_mvs::smooth_score(score, factors, n_close);
+      score = pvlm_mvs::smooth_score_static(score, factors, n_close);
       if (nb.geometric) {
         float Rl[9], tl[3]; const float* dl = nb.depth[b0];
 #pragma unroll
@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   const int lane = threadIdx.x & 63;
   const int n = pvlm_mvs::num_texels(half_window, step);
   __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
+  __shared__ pvlm_mvs::ClosePixel close_s[4][4];
   float4* lds = strips[threadIdx.x >> 6];
   const long long npix = (long long)rows * cols;
   const int sgn = backward ? 1 : -1;
@@ -525,11 +526,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
       pvlm_mvs::Around ar;
       mvs_wave_around(rows, cols, px, py, sgn, lane, depth, normal, cell, epoch, ar);   // waits for the two predecessors of the walk
       pvlm_mvs::SweepArgs A{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+      // the close pixels in the wave's LDS slot (see k_mvs_propagate_flow_spec)
+      pvlm_mvs::ClosePixel* close_w = close_s[threadIdx.x >> 6];
+      int n_close;
+      {
+        pvlm_mvs::ClosePixel cl[4];
+        n_close = pvlm_mvs::build_close(A, px, py, ar, cl);
+        if (lane < 4) {
+          pvlm_mvs::ClosePixel mine = cl[0];
+#pragma unroll
+          for (int q = 1; q < 4; ++q) if (lane == q) mine = cl[q];
+          close_w[lane] = mine;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
       pvlm_mvs::Rng rng{pass_seed, (unsigned long long)e, 0u};
       WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
       pvlm_mvs::SerialBatch<WaveScorer<M>> batch{&scorer, 1};                 // one hypothesis after the other: process_pixel's chain
       const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
-      pvlm_mvs::process_pixel_around(A, rng, px, py, batch, ar, dep, nrm3, c, 2, pdx, pdy);
+      pvlm_mvs::process_pixel_close(A, rng, px, py, batch, ar, close_w, n_close, dep, nrm3, c, 2, pdx, pdy);
+      __builtin_amdgcn_wave_barrier();                                         // the slot is rewritten for the wave's next pixel
       if (lane < 4) __hip_atomic_store(cell + 4 * e + lane, mvs_cell(epoch, lane == 0 ? dep : nrm3[lane - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lane == 0) { depth[e] = dep; normal[3 * e] = nrm3[0]; normal[3 * e + 1] = nrm3[1]; normal[3 * e + 2] = nrm3[2]; conf[e] = c; }
     } else if (lane < 4) {
@@ -597,6 +613,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
   __shared__ float4 strips[4][PVLM_MVS_LDS_PER_WAVE(M)];
   __shared__ pvlm_mvs::Hypothesis xchg[8];
   __shared__ pvlm_mvs::Around around;
+  __shared__ pvlm_mvs::ClosePixel close_s[4];
+  __shared__ int n_close_s;
   __shared__ unsigned long long drawn;
   float4* lds = strips[wave];
   const long long npix = (long long)rows * cols;
@@ -653,6 +671,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
           const int slot = p ? slot_v : slot_h;
           if (k == 0) around.depth[slot] = f; else around.normal[slot][k - 1] = f;
         }
+        // the close pixels of this pixel, once, in LDS: every scoring of every wave reads all of them (a per-thread array would sit in
+        // scratch memory: 18 stores + 6 loads per scoring behind the wait)
+        __builtin_amdgcn_wave_barrier();                                       // LDS operations of one wave execute in order
+        pvlm_mvs::SweepArgs A0{rows, cols, unit, depth, normal, depth_constant, min_depth, max_depth};
+        pvlm_mvs::ClosePixel cl[4];
+        const int nc = pvlm_mvs::build_close(A0, px, py, around, cl);
+        if (lane < 4) {
+          pvlm_mvs::ClosePixel mine = cl[0];
+#pragma unroll
+          for (int q = 1; q < 4; ++q) if (lane == q) mine = cl[q];
+          close_s[lane] = mine;
+        }
+        if (lane == 0) n_close_s = nc;
       }
       __syncthreads();
       const unsigned long long ck2 = FLOW_CLOCK_NOW();
@@ -661,7 +692,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M == 1 ? PV
       WaveScorer<M> scorer{rows, cols, half_window, step, n, lane, px, py, unit, &nb, &P, lds};
       BlockBatch<M> batch{&scorer, wave, lane, xchg, 0, ck2};
       const int pdx[2] = {sgn, 0}, pdy[2] = {0, sgn};
-      pvlm_mvs::process_pixel_around(A, rng, px, py, batch, around, dep, nrm3, c, 2, pdx, pdy);
+      pvlm_mvs::process_pixel_close(A, rng, px, py, batch, around, close_s, n_close_s, dep, nrm3, c, 2, pdx, pdy);
       const unsigned long long ck3 = FLOW_CLOCK_NOW();
       if (threadIdx.x < 4) {
         const float f = threadIdx.x == 0 ? dep : nrm3[threadIdx.x - 1];

@@ -473,6 +473,16 @@ PVLM_HD inline float smooth_score(float score, const float* factors, int n_close
   score = 1 - score;
   return fminf(1.f, fmaxf(-1.f, score));
 }
+// the same with compile-time indices (n_close <= 4): for callers that hold the factors in registers (the wave-per-pixel scorer; the
+// thread-per-pixel kernels are at their register budget and keep the loop above)
+PVLM_HD inline float smooth_score_static(float score, const float* factors, int n_close) {
+  if (n_close <= 0) return score;
+  score = 1 - score;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) if (q < n_close) score *= factors[q];
+  score = 1 - score;
+  return fminf(1.f, fmaxf(-1.f, score));
+}
 
 struct SweepArgs {
   int rows, cols;
@@ -628,24 +638,38 @@ PVLM_HD inline void gather_around(const SweepArgs& A, int px, int py, Around& ar
   }
 }
 
+// The close pixels of ProcessPixel (:735-747) from an Around: the direct neighbours that hold a hypothesis, compacted in slot order.
+// Written with compile-time indices only (the s-th entry is selected, not addressed): an array indexed by a running count would live
+// in scratch memory on the GPU, and every scoring reads all of it.
+PVLM_HD inline int build_close(const SweepArgs& A, int px, int py, const Around& ar, ClosePixel* close) {
+  const int cols = A.cols;
+  const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
+  int n_close = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { close[s].depth = 0.f; for (int k = 0; k < 3; ++k) { close[s].point[k] = 0.f; close[s].normal[k] = 0.f; } }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float d = ar.depth[q];
+    const bool take = ar.inside[q] && d > 0;
+    const size_t ne = take ? (size_t)cy[q] * cols + cx[q] : (size_t)py * cols + px;
+    ClosePixel c;
+    for (int k = 0; k < 3; ++k) { c.point[k] = A.unit[3 * ne + k] * d; c.normal[k] = ar.normal[q][k]; }
+    c.depth = d;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (take && s == n_close) close[s] = c;
+    n_close += take ? 1 : 0;
+  }
+  return n_close;
+}
+
 template <class Batch>
-PVLM_HD inline void process_pixel_around(const SweepArgs& A, Rng& rng, int px, int py, Batch& batch, const Around& ar, float& depth, float* normal, float& conf,
-                                         int n_prop, const int* pdx, const int* pdy) {
+PVLM_HD inline void process_pixel_close(const SweepArgs& A, Rng& rng, int px, int py, Batch& batch, const Around& ar, const ClosePixel* close, int n_close,
+                                        float& depth, float* normal, float& conf, int n_prop, const int* pdx, const int* pdy) {
   const int cols = A.cols;
   const size_t e = (size_t)py * cols + px;
   const bool keep_depth_constant = A.depth_constant && A.depth_constant[e];
   const float* view_ray = A.unit + 3 * e;
-  const int cx[4] = {px - 1, px, px, px + 1}, cy[4] = {py, py - 1, py + 1, py};
-  ClosePixel close[4] = {}; int n_close = 0;
-  for (int q = 0; q < 4; ++q) {
-    if (!ar.inside[q]) continue;
-    const float d = ar.depth[q];
-    if (d <= 0) continue;
-    const size_t ne = (size_t)cy[q] * cols + cx[q];
-    ClosePixel& c = close[n_close++];
-    for (int k = 0; k < 3; ++k) { c.point[k] = A.unit[3 * ne + k] * d; c.normal[k] = ar.normal[q][k]; }
-    c.depth = d;
-  }
   const int W = batch.width();
   Hypothesis hyp[4];
   // ---- propagation (:749-771): the hypotheses do not depend on each other's outcome
@@ -666,8 +690,9 @@ PVLM_HD inline void process_pixel_around(const SweepArgs& A, Rng& rng, int px, i
       correct_normal(view_ray, normal_neighbor);
       h.normal[0] = normal_neighbor[0]; h.normal[1] = normal_neighbor[1]; h.normal[2] = normal_neighbor[2]; h.depth = depth_neighbor; h.valid = 1;
     }, hyp);
-    for (int w = 0; w < n; ++w)
-      if (hyp[w].valid && conf < hyp[w].conf) { conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2]; PVLM_MVS_SPEC_STAT(0); }
+#pragma unroll
+    for (int w = 0; w < 4; ++w)                              // w < n <= 4: compile-time indices keep hyp[] in registers
+      if (w < n && hyp[w].valid && conf < hyp[w].conf) { conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2]; PVLM_MVS_SPEC_STAT(0); }
   }
   // ---- PerturbDepthNormal3
   const bool perturb = !keep_depth_constant;
@@ -709,17 +734,27 @@ PVLM_HD inline void process_pixel_around(const SweepArgs& A, Rng& rng, int px, i
       h.valid = dot3(h.normal, view_ray) >= 0 ? 0 : 1;     // `continue` (:1303-1304): the draws are spent, nothing is scored
     }, hyp);
     int taken = n;
-    for (int w = 0; w < n; ++w)
-      if (hyp[w].valid && hyp[w].conf > conf) {
+    bool accepted = false;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)                              // the first accepted one ends the batch
+      if (!accepted && w < n && hyp[w].valid && hyp[w].conf > conf) {
         conf = hyp[w].conf; depth = hyp[w].depth; normal[0] = hyp[w].normal[0]; normal[1] = hyp[w].normal[1]; normal[2] = hyp[w].normal[2];
         idxScaleRange++;
         taken = w + 1;
+        accepted = true;
         PVLM_MVS_SPEC_STAT(3);
-        break;
       }
     rng.k = k0 + draws * (unsigned)taken;
     base += taken;
   }
+}
+
+template <class Batch>
+PVLM_HD inline void process_pixel_around(const SweepArgs& A, Rng& rng, int px, int py, Batch& batch, const Around& ar, float& depth, float* normal, float& conf,
+                                         int n_prop, const int* pdx, const int* pdy) {
+  ClosePixel close[4];
+  const int n_close = build_close(A, px, py, ar, close);
+  process_pixel_close(A, rng, px, py, batch, ar, close, n_close, depth, normal, conf, n_prop, pdx, pdy);
 }
 
 template <class Batch>
