@@ -53,7 +53,7 @@ find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_col
 python tools/spd_floor_bench.py > $O/r4_spd_floor.txt 2>&1; python tools/spd_floor_bench.py --scans 454 >> $O/r4_spd_floor.txt 2>&1
 python tools/room_like_odometry.py --scans 454 --iters 3 --lines 1 --repeat 2 > $O/r4_room_like_lines454.txt 2>&1
 python tools/room_like_joint.py --frames 454 --points 150000 > $O/r4_room_like_joint454.txt 2>&1
-python tools/floor_like_odometry.py --scans 1593 --ranks 2,8 --iters 2 > $O/r4_floor_like_1593.txt 2>&1
+python tools/floor_like_odometry.py --scans 1593 --ranks 2,8 --iters 2 --repeat 5 > $O/r4_floor_like_1593.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 du -sh $O
 head -c 400 $O/r4_bench_default.json
