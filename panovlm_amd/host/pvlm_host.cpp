@@ -683,11 +683,13 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
   if (which.empty()) return out;
   Engine& e = Engine::Default();
   std::vector<int64_t> voff(which.size() + 1, 0);
-  std::vector<int32_t> votes;
+  // kept between calls (every element of a vote block is written by the call: no clearing): a fresh 50 MB vector per call is 11 k page
+  // faults and a memset before the copy back even starts
+  static std::vector<int32_t> votes;
   {
     StageTimer stage_timer_votes_("  (inside) line votes of all pairs on the GPU (launch + copy back)");
     e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), nullptr, 0), "pvlm_line2line_votes_batch");
-    votes.assign((size_t)std::max<int64_t>(voff.back(), 1), 0);
+    if (votes.size() < (size_t)std::max<int64_t>(voff.back(), 1)) votes.resize((size_t)std::max<int64_t>(voff.back(), 1));
     e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), votes.data(), (int64_t)votes.size()),
             "pvlm_line2line_votes_batch");
   }
