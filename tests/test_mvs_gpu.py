@@ -239,6 +239,23 @@ def test_other_launch_forms_give_the_same_maps():
         assert r.returncode == 0, (env, r.stdout[-1500:])
 
 
+def test_data_flow_sweep_on_odd_shapes():
+    """The persistent data-flow launches of the sequential sweep (K13p / K13q: ticket order over the anti-diagonals, per-pixel hand-off
+    cells) against one launch per anti-diagonal on shapes the oracle scenes do not have: taller than wide, odd sizes, barely larger than
+    the window, and three iterations (forward, backward, forward).  The form is read once per process: child processes, one per form;
+    the maps must agree bit for bit (sha256 of depth | normal | conf)."""
+    import json, subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mvs_seq_bench.py")
+    for rows, cols in ((40, 24), (17, 33), (9, 64), (64, 201)):
+        sums = {}
+        for form in ("0", "1", "2"):
+            r = subprocess.run([sys.executable, tool, "--rows", str(rows), "--cols", str(cols), "--iters", "3", "--neighbors", "2"],
+                               env=dict(os.environ, PVLM_MVS_FLOW=form), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            assert r.returncode == 0, (rows, cols, form, r.stderr[-800:])
+            sums[form] = json.loads(r.stdout.strip().splitlines()[-1])["sha256"]
+        assert sums["0"] == sums["1"] == sums["2"], (rows, cols, sums)
+
+
 def test_resident_views_equal_the_per_call_entry_points(ctx, oracle):
     """pvlm_mvs_views_*: the same kernels on maps that stay in HBM — every stage must equal the per-call API bit for bit
     (scoring pass, sweep incl. geometric consistency / depth_constant / threshold, fusion filter with its in-place conf)."""
