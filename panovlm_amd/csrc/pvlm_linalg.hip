@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, int 
 }
 #endif  // PVLM_MEASURED_VARIANTS
 
+// MEASURED VARIANT (-DPVLM_CHOL_CLOCK=1): where workgroup 0 of k_chol_diag_panel spends its time, 100 MHz wall clock, summed over the launches
+// of a solve and printed by chol_factor_solve: [0] entry -> block + rows in LDS, [1] the 32-pivot chain + inverse, [2] stores + panel rows, [3] launches.
+#ifndef PVLM_CHOL_CLOCK
+#define PVLM_CHOL_CLOCK 0
+#endif
+#if PVLM_CHOL_CLOCK
+__device__ unsigned long long g_chol_clock[4];
+#define CHOL_NOW() wall_clock64()
+#define CHOL_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_chol_clock[i], (unsigned long long)(v)); } while (0)
+#else
+#define CHOL_NOW() 0ull
+#define CHOL_ADD(i, v) do { (void)(v); } while (0)
+#endif
 __device__ __forceinline__ double bcast_f64(double v, int src_lane) {     // v of lane src_lane (wave-uniform source) for every lane
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double(hi, lo);
@@ -118,6 +131,7 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
   __shared__ double As[8][PVLM_CHOL_NB + 1];
   __shared__ int fail;
   if (*info != 0) return;
+  const unsigned long long ck0 = CHOL_NOW();
   const int t = threadIdx.x;
   if (t == 0) fail = 0;
   for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
@@ -131,6 +145,7 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
   const bool live = row >= k0 + kb && row < n && c < kb;
   As[lr][c] = live ? M[(size_t)row * n + k0 + c] : 0.0;
   __syncthreads();
+  const unsigned long long ck1 = CHOL_NOW();
   if (t < 64) {
     // One wave, no LDS and no barrier inside the chain: lane i keeps ROW i of the block in registers (fully unrolled, so
     // every register index is a compile-time constant); the pivot and the column entries l_cj a lane needs from another
@@ -140,20 +155,32 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
 #pragma unroll
     for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) { r[cc] = a[i][cc]; x[cc] = 0.0; }
     int bad = 0;
+    double rdiag[PVLM_CHOL_NB];                               // 1 / l_jj (wave-uniform), reused by the inverse below
+#pragma unroll
+    for (int j = 0; j < PVLM_CHOL_NB; ++j) rdiag[j] = 0.0;
 #pragma unroll
     for (int j = 0; j < PVLM_CHOL_NB; ++j) {
       if (j < kb && !bad) {                                   // wave-uniform
         const double d = bcast_f64(r[j], j);
         if (!(d > 0.0)) bad = j + 1;
         else {
-          const double sd = sqrt(d);
-          const double lij = r[j] / sd;                       // meaningful in the lanes below the pivot
+          // 1 / sqrt(d) by v_rsq_f64 + three Newton steps (12 dependent instructions) instead of sqrt and a division per pivot (~45, a fifth
+          // of the chain's time: the chain is ONE wave's dependent instructions, 23.6 us per block column measured with -DPVLM_CHOL_CLOCK=1);
+          // l_jj = d y, l_ij = a_ij y: last-bit differences against sqrt-and-divide, as any other summation order gives
+          double y = __builtin_amdgcn_rsq(d);
+          y = y * (1.5 - 0.5 * d * y * y);
+          y = y * (1.5 - 0.5 * d * y * y);
+          y = y * (1.5 - 0.5 * d * y * y);
+          rdiag[j] = y;
+          const double sd = d * y;
+          const double lij = r[j] * y;                        // meaningful in the lanes below the pivot
 #pragma unroll
           for (int cc = j + 1; cc < PVLM_CHOL_NB; ++cc) {
             const double lcj = bcast_f64(lij, cc);
-            if (i > j && cc <= i) r[cc] -= lij * lcj;
-          }
-          if (i > j) r[j] = lij; else if (i == j) r[j] = sd;
+            r[cc] -= lij * lcj;       // every lane, no mask: entries above the diagonal (cc > i, and all of the lanes i <= j) turn into
+          }                           // values nobody reads — a per-step exec mask cost more than the update itself (50 cycles per step)
+          r[j] = lij;                 // lane j: d y = l_jj; lanes above the pivot: unused
+          (void)sd;
         }
       }
     }
@@ -167,10 +194,10 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
 #pragma unroll
           for (int k = 0; k < q; ++k) {
             const double lqk = bcast_f64(r[k], q);
-            if (k >= i) sacc += lqk * x[k];
+            sacc += lqk * x[k];       // x[k] = 0 for k < i: no mask needed
           }
-          const double lqq = bcast_f64(r[q], q);
-          x[q] = q == i ? 1.0 / lqq : (q > i ? -sacc / lqq : 0.0);
+          const double rq = rdiag[q];
+          x[q] = q == i ? rq : (q > i ? -sacc * rq : 0.0);
         }
       }
       if (t < PVLM_CHOL_NB && i < kb) {
@@ -180,6 +207,7 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
     }
   }
   __syncthreads();
+  const unsigned long long ck2 = CHOL_NOW();
   if (fail) { if (t == 0 && blockIdx.x == 0) { *fail_out = k0 + fail; } return; }
   if (blockIdx.x == 0) {
     double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
@@ -193,6 +221,7 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
   double x = 0.0;
   for (int d = 0; d <= c; ++d) x += As[lr][d] * inv[c][d];
   if (live) M[(size_t)row * n + k0 + c] = x;
+  CHOL_ADD(0, ck1 - ck0); CHOL_ADD(1, ck2 - ck1); CHOL_ADD(2, CHOL_NOW() - ck2); CHOL_ADD(3, 1);
 }
 
 // Which 64 x 64 tile (ti >= tj) of the trailing lower triangle a workgroup updates.  part 0: all tiles, linear id -> lower
@@ -465,6 +494,16 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
       hipLaunchKernelGGL(k_bwd_step, dim3(std::max(1, (k0 + 255) / 256)), dim3(256), 0, s, d_M, n, k0, kb, d_Linv, b, d_y, d_info);
     }
   }
+#if PVLM_CHOL_CLOCK
+  {
+    unsigned long long h[4] = {}, z[4] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chol_clock), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_clock), z, sizeof z);
+    const double L = (double)std::max<unsigned long long>(h[3], 1);
+    fprintf(stderr, "[chol clock] %llu panel launches | us per launch (workgroup 0): load %.2f  chain %.2f  stores + rows %.2f\n", h[3], h[0] * 0.01 / L, h[1] * 0.01 / L, h[2] * 0.01 / L);
+  }
+#endif
 }
 
 // dense M (n x n, symmetric) += scatter of 6x6 blocks: entry (r, c) of block b goes to (row_idx[6b + r], col_idx[6b + c])
