@@ -154,9 +154,11 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
         pvlm_mvs::homography(nb.R[b0 + j], nb.t[b0 + j], nrm3, d, H);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          const int k = lane + 64 * m;
+          // lanes past the window's last texel repeat it (M = 1: 49 of 64 lanes carry a texel): same verdict, value unused — an
+          // `if (k < n)` here is an exec-mask save / restore around every piece of the chain
+          const int k = min(lane + 64 * m, n - 1);
           t1[j][m] = 0.f;
-          if (k < n) ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b0 + j], rows, cols, H, px, py, half_window, step, k, &t1[j][m]) && ok;
+          ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b0 + j], rows, cols, H, px, py, half_window, step, k, &t1[j][m]) && ok;
         }
       } else {
 #pragma unroll
@@ -168,15 +170,15 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
     const unsigned long long wk1 = FLOW_CLOCK_NOW();
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      const int k = lane + 64 * m;
-      if (k < n) sA[k] = make_float4(t1[0][m] * P.w[m], t1[1][m] * P.w[m], t1[2][m] * P.w[m], t1[3][m] * P.w[m]);
+      const int k = lane + 64 * m;                              // strips hold 64 M entries: the surplus lanes write slots the sums never read
+      sA[k] = make_float4(t1[0][m] * P.w[m], t1[1][m] * P.w[m], t1[2][m] * P.w[m], t1[3][m] * P.w[m]);
     }
     float sj[4];
     strip_seq_sum4(sA, n, lane, sj);                                     // sum += texels1[i] * weight[i]            :826-827
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
-      if (k < n) {
+      {
         float p1[4], p01[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { t1[j][m] -= sj[j]; p1[j] = t1[j][m] * t1[j][m] * P.w[m]; p01[j] = P.t0[m] * t1[j][m]; }
