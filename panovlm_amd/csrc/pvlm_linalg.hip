@@ -134,16 +134,27 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
   const unsigned long long ck0 = CHOL_NOW();
   const int t = threadIdx.x;
   if (t == 0) fail = 0;
-  for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) {
-    const int i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
-    a[i][j] = (i < kb && j <= i) ? M[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-    inv[i][j] = 0.0;
+  {
+    constexpr int kPer = PVLM_CHOL_NB * PVLM_CHOL_NB / 256;           // reads first (clamped addresses), LDS writes after: see k_chol_update_mfma
+    double av[kPer];
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int e = t + 256 * it, i = min(e / PVLM_CHOL_NB, kb - 1), j = min(e % PVLM_CHOL_NB, kb - 1);
+      av[it] = M[(size_t)(k0 + i) * n + k0 + j];
+    }
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int e = t + 256 * it, i = e / PVLM_CHOL_NB, j = e % PVLM_CHOL_NB;
+      a[i][j] = (i < kb && j <= i) ? av[it] : 0.0;
+      inv[i][j] = 0.0;
+    }
   }
   const int lr = t / PVLM_CHOL_NB, c = t % PVLM_CHOL_NB;
   int row = k0 + kb + blockIdx.x * 8 + lr;
   if (row_tiles) row = (int)(blockIdx.x >> 3) < n_row_tiles ? row_tiles[blockIdx.x >> 3] * 64 + (int)(blockIdx.x & 7) * 8 + lr : n;
   const bool live = row >= k0 + kb && row < n && c < kb;
-  As[lr][c] = live ? M[(size_t)row * n + k0 + c] : 0.0;
+  const double a_row = M[(size_t)min(max(row, 0), n - 1) * n + k0 + min(c, kb - 1)];
+  As[lr][c] = live ? a_row : 0.0;
   __syncthreads();
   const unsigned long long ck1 = CHOL_NOW();
   if (t < 64) {
@@ -317,10 +328,23 @@ __global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M
   int r0, c0;
   if (pairs) { const int2 pr = pairs[blockIdx.x]; r0 = pr.x * 64; c0 = pr.y * 64; }
   else { if (!chol_tile_of((int)blockIdx.x, tiles, part, &ti, &tj)) return; r0 = base + ti * 64; c0 = base + tj * 64; }
-  for (int e = threadIdx.x; e < 64 * PVLM_CHOL_NB; e += 256) {
-    const int i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
-    As[i][c] = (r0 + i >= base && r0 + i < n && c < kb) ? M[(size_t)(r0 + i) * n + k0 + c] : 0.0;
-    Bs[i][c] = (c0 + i >= base && c0 + i < n && c < kb) ? M[(size_t)(c0 + i) * n + k0 + c] : 0.0;
+  {
+    // the panel slices: every global read first, from clamped (always valid) addresses, then the LDS writes — `cond ? M[..] : 0` per element
+    // compiled into one load -> wait -> LDS write after the other (sixteen dependent round trips per thread)
+    constexpr int kPer = 64 * PVLM_CHOL_NB / 256;
+    double av[kPer], bv[kPer];
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int e = threadIdx.x + 256 * it, i = e / PVLM_CHOL_NB, c = min(e % PVLM_CHOL_NB, kb - 1);
+      av[it] = M[(size_t)min(max(r0 + i, 0), n - 1) * n + k0 + c];
+      bv[it] = M[(size_t)min(max(c0 + i, 0), n - 1) * n + k0 + c];
+    }
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int e = threadIdx.x + 256 * it, i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
+      As[i][c] = (r0 + i >= base && r0 + i < n && c < kb) ? av[it] : 0.0;
+      Bs[i][c] = (c0 + i >= base && c0 + i < n && c < kb) ? bv[it] : 0.0;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -334,13 +358,26 @@ __global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[16 * t + li][k + lk], acc[t], 0, 0, 0);
   }
+  // C -= acc: the 16 reads first, all in flight together, from clamped (always valid) addresses, then the guarded stores.  Written as
+  // `if (...) M[..] -= acc` the compiler emitted sixteen load -> wait -> subtract -> store sequences, each under its own exec mask:
+  // sixteen dependent memory round trips per workgroup — most of the kernel's 21 us average on the tile-sparse Floor system.
+  double cv[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = min(c0 + 16 * t + li, n - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(r0 + 16 * w + lk + 4 * r, n - 1);
+      cv[t][r] = M[(size_t)row * n + col];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int col = c0 + 16 * t + li;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = r0 + 16 * w + lk + 4 * r;
-      if (row < n && col <= row && col >= base) M[(size_t)row * n + col] -= acc[t][r];
+      if (row < n && col <= row && col >= base) M[(size_t)row * n + col] = cv[t][r] - acc[t][r];
     }
   }
 }
@@ -392,8 +429,13 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ M, 
   __syncthreads();
   const int j = blockIdx.x * 256 + t;
   if (j >= k0) return;
+  // all 32 rows of the block in flight together (rows past a short last block are clamped; their x is zero)
+  double m[PVLM_CHOL_NB];
+#pragma unroll
+  for (int c = 0; c < PVLM_CHOL_NB; ++c) m[c] = M[(size_t)min(k0 + c, n - 1) * n + j];
   double sacc = 0.0;
-  for (int c = 0; c < kb; ++c) sacc += M[(size_t)(k0 + c) * n + j] * x[c];
+#pragma unroll
+  for (int c = 0; c < PVLM_CHOL_NB; ++c) sacc += m[c] * x[c];
   yv[j] -= sacc;
 }
 
