@@ -142,6 +142,15 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
   if (d > 0) return -1.f;
   float best1 = 0.f, best2 = 0.f; int count = 0;
   float4* sA = lds; float4* sB1 = lds + PVLM_MVS_STRIP(M); float4* sB2 = lds + 2 * PVLM_MVS_STRIP(M);
+  // the unit rays of this lane's texels: one read per scoring (inside the loop over the neighbour images the compiler re-read them per image,
+  // each time a load the projection had to wait for).  Lanes past the window's last texel repeat it (M = 1: 49 of 64 lanes carry a texel):
+  // same verdict, value unused — an `if (k < n)` per piece of the chain is an exec-mask save / restore each time
+  float uv[M][3];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float* up = pvlm_mvs::texel_ray(unit, cols, px, py, half_window, step, min(lane + 64 * m, n - 1));
+    uv[m][0] = up[0]; uv[m][1] = up[1]; uv[m][2] = up[2];
+  }
   for (int b0 = 0; b0 < nb.n; b0 += 4) {                                 // four neighbour images per pass: one float4 per texel in LDS
     float t1[4][M];
     bool okj[4];
@@ -154,11 +163,8 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
         pvlm_mvs::homography(nb.R[b0 + j], nb.t[b0 + j], nrm3, d, H);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          // lanes past the window's last texel repeat it (M = 1: 49 of 64 lanes carry a texel): same verdict, value unused — an
-          // `if (k < n)` here is an exec-mask save / restore around every piece of the chain
-          const int k = min(lane + 64 * m, n - 1);
           t1[j][m] = 0.f;
-          ok = pvlm_mvs::neighbour_texel(unit, nb.gray[b0 + j], rows, cols, H, px, py, half_window, step, k, &t1[j][m]) && ok;
+          ok = pvlm_mvs::neighbour_texel_ray(uv[m], nb.gray[b0 + j], rows, cols, H, &t1[j][m]) && ok;
         }
       } else {
 #pragma unroll

@@ -122,6 +122,19 @@ PVLM_HD inline void homography(const float* R, const float* t, const float* norm
 
 // one texel of the neighbour patch: project the reference texel's unit ray through H, test frame.IsInside(x1, 1, 1),
 // sample bilinearly.  Returns false when the projection leaves the image (the whole neighbour is then skipped).
+// the same with the reference texel's unit ray already in hand (the wave scorer loads it once per scoring, not once per neighbour image)
+PVLM_HD inline bool neighbour_texel_ray(const float* uv, const unsigned char* nei_gray, int rows, int cols, const float* H, float* value) {
+  float X1[3];
+  for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += H[3 * r + c] * uv[c]; X1[r] = s; }
+  float x1[2];
+  cam_to_image(rows, cols, X1, x1);
+  if (!(x1[0] >= 1 && x1[1] >= 1 && x1[0] < cols - 1 && x1[1] < rows - 1)) return false;
+  const int lx = (int)x1[0], ly = (int)x1[1];
+  const float fx = x1[0] - lx, fy = x1[1] - ly, ax = 1.f - fx, ay = 1.f - fy;
+  const unsigned char* p = nei_gray + (size_t)ly * cols + lx;
+  *value = (p[0] * ax + p[1] * fx) * ay + (p[cols] * ax + p[cols + 1] * fx) * fy;
+  return true;
+}
 PVLM_HD inline bool neighbour_texel(const float* unit, const unsigned char* nei_gray, int rows, int cols, const float* H, int px, int py, int half_window,
                                     int step, int k, float* value) {
   int di, dj; texel_offset(half_window, step, k, &di, &dj);
