@@ -255,6 +255,9 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
 // the first of them goes through the insertion network (the compiler schedules a one-candidate loop as load - wait - use: the wave
 // then sits out one memory latency per candidate; a run is 3.3 candidates long on average, so four loads in flight cover most runs
 // with ONE latency).  Slots past the end of the run re-read its last candidate and are turned into +inf keys.
+#ifndef PVLM_K2_ANYSKIP
+#define PVLM_K2_ANYSKIP 1
+#endif
 #ifndef PVLM_K2_BATCH
 #define PVLM_K2_BATCH 1   // measured (profiles/r4_assoc_variants.txt): 1 / 2 / 4 / 8 -> 1327 / 1367 / 1466 / 2436 us per dispatch: the padded slots cost more network work than the latency they hide
 #endif
@@ -292,6 +295,11 @@ PVLM_HD void knn_scan_run(const CloudView& cv, int b, int e, float qx, float qy,
       if (k > 0) d2 = j + k < e ? d2 : u2f(0x7F800000u);  // past the end: never enters the list
 #ifdef PVLM_ASSOC_STATS_COUNT_PASS
       if ((k == 0 || j + k < e) && tk.would_enter(d2, (int)f2u(p[k].w))) ++stat_pass;
+#endif
+#if PVLM_K2_ANYSKIP && defined(PVLM_ASSOC_DEVICE) && defined(__HIP_DEVICE_COMPILE__)
+      // the 19-operation insertion only when the candidate beats the last key of SOME lane of the wave (one compare + a scalar branch;
+      // measured, profiles/r5_assoc_variants.txt: k_knn_pairs 1164 -> 1115 us on voxel targets, 5522 -> 4795 us on raw targets)
+      if (__builtin_amdgcn_ballot_w64(tk.would_enter(d2, (int)f2u(p[k].w))) == 0ull) continue;
 #endif
       tk.push(d2, (int)f2u(p[k].w));
       if (k == 0 || j + k < e) PVLM_ASSOC_STATS_CANDIDATE();

@@ -40,7 +40,7 @@ comp = (wl["queries"] + wl["targets"]) * 16
 res = {"workload": wl, "command": "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python tools/assoc_workload.py --scans %d (one pass per counter set)" % wl["scans"],
        "queries": wl["queries"], "compulsory_bytes_per_call": comp, "kernels": {}}
 for k in sorted(agg):
-    if not any(x in k for x in ("k_knn_pairs", "k_fit_pairs", "k_compact")):
+    if not any(x in k for x in ("k_knn_", "k_fit_pairs", "k_compact")):
         continue
     c = {n: v / calls for n, v in agg[k].items()}
     e = {"dispatches_per_call": {n: disp[k][n] / calls for n in disp[k]}, "per_call": c}
@@ -52,6 +52,10 @@ for k in sorted(agg):
     if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES", 0) > 0:
         e["valu_insts_per_query"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
         e["vmem_rd_insts_per_query"] = c.get("SQ_INSTS_VMEM_RD", 0.0) / c["SQ_WAVES"]
+        e["waves_per_call"] = c["SQ_WAVES"]
+    for extra in ("SQ_INSTS_SMEM", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+        if extra in c and c.get("SQ_WAVES", 0) > 0:
+            e[extra.lower() + "_per_wave"] = c[extra] / c["SQ_WAVES"]
     if "FETCH_SIZE" in c:
         e["fetch_bytes_raw"] = c["FETCH_SIZE"] * 1024; e["fetch_bytes_x2"] = 2 * c["FETCH_SIZE"] * 1024
         e["fetch_over_compulsory_raw"] = e["fetch_bytes_raw"] / comp; e["fetch_over_compulsory_x2"] = e["fetch_bytes_x2"] / comp
@@ -66,7 +70,7 @@ for k in sorted(agg):
             e["simd_valu_util_lower_bound"] = c["SQ_INSTS_VALU"] * 4.0 / (1024 * e["kernel_trace_ms_per_call"] * 1e-3 * 2.4e9)
     res["kernels"][k] = e
 for k in sorted(dur):
-    if k not in res["kernels"] and any(x in k for x in ("k_knn_pairs", "k_fit_pairs", "k_compact")):
+    if k not in res["kernels"] and any(x in k for x in ("k_knn_", "k_fit_pairs", "k_compact")):
         res["kernels"][k] = {"kernel_trace_ms_per_call": sum(dur[k]) / calls}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: {n: v for n, v in e.items() if n not in ("per_call", "dispatches_per_call")} for k, e in res["kernels"].items()}, indent=1))
