@@ -33,7 +33,8 @@ struct PairDesc {
   int nq;
   double Rr[9], tr[3], Rn[9], tn[3];  // R_wl / t_wl of ref and nei
   long long tmp_base;                 // first row of this pair in the batch temp arrays
-  int chunk_base;                     // first chunk counter of this pair
+  int chunk_base;                     // first chunk (256 queries) of this pair in the batch's chain
+  long long dst_row;                  // first row of the pair's segment in the batch's column block (a multiple of 16; the segment has room for nq rows)
 };
 
 // ---- K1 ---------------------------------------------------------------------------------------
@@ -98,6 +99,7 @@ struct GridDesc {
   const float* xyz; int n; int dense, nx, ny, nz; int T;
   float ox, oy, oz, inv_h, inv_hx;   // inv_hx: dense tables are xf times finer along x (nx counts the fine cells)
   unsigned long long* keys; int* count; int* start; int* cursor; int* slot; float4* sorted;
+  const float* tag; float4* pt4;     // pt4 (clouds with tags): (x, y, z, tag) per point in ORIGINAL order — what K3 gathers by neighbour index
 };
 struct GridBlock { int cloud, first; };   // 256 points of one cloud
 
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const GridDesc* __restrict
   if (i >= d.n) return;
   const int s = d.slot[i];
   const int pos = d.start[s] + atomicAdd(&d.cursor[s], 1);
-  d.sorted[pos] = make_float4(d.xyz[3 * i], d.xyz[3 * i + 1], d.xyz[3 * i + 2], __int_as_float(i));
+  const float x = d.xyz[3 * i], y = d.xyz[3 * i + 1], z = d.xyz[3 * i + 2];
+  d.sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+  if (d.pt4) d.pt4[i] = make_float4(x, y, z, d.tag[i]);
 }
 
 // ---- K2 / K3: per-query bodies in pvlm_assoc_core.h (TopK, knn_search, Fit10, world2local) --------------------------------
@@ -187,11 +191,6 @@ __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* 
 #define PVLM_K2_WAVES 8     // round 4, after the row-logic diet (76 VGPRs unconstrained): 6 / 7 / 8 waves -> 1313 / 1229 / 1188 us per dispatch (voxel), 6377 / 5974 / 5684 (raw):
                             // the search waits on dependent loads (cell table -> candidates), more resident waves hide more of it than the few spilled registers cost
 #endif
-#ifdef PVLM_K3_GLOBAL_LOADS        // measured variant (lost: 1273 vs 1245 us voxel, 1238 vs 1225 us raw; 223 instead of 195 VGPRs): K3's gathers as global saddr loads
-#define K3_LOADF(base, i) load_float(base, i)
-#else
-#define K3_LOADF(base, i) ((base)[i])
-#endif
 #ifndef PVLM_K3_WAVES
 #define PVLM_K3_WAVES 2     // 195 VGPRs; 3 waves = 168 VGPRs + 15 spilled doubles
 #endif
@@ -211,95 +210,151 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K2_WAV
   for (int k = 0; k < 10; ++k) nn_tmp[(size_t)k * tmp_rows + pd.tmp_base + q] = tk.index(k);
 }
 
-// K3 — class test, 10x3 plane fit, collinearity test, candidate record, accept flag and the
-// per-chunk accept counts for the ordered compaction.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAVES, 8))) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp,
-                                                   double* __restrict__ rec_tmp, unsigned char* __restrict__ flag_tmp,
-                                                   int* __restrict__ chunk_count, long long tmp_rows) {
-  const PairDesc& pd = pairs[blockIdx.y];
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= pd.nq) return;
-  bool accept = false;
-  if (q < pd.nq) {
-    const long long row = pd.tmp_base + q;
-    int id[10];
+// K3 — class test, collinearity test, 10x3 plane fit, and the accepted records written straight into the pair's segment of the residual set,
+// in query order (LidarFeatureAssociate.cpp:578-629 emits in query order).
+//
+// Ordered compaction inside the kernel.  A workgroup fits one chunk of 256 queries of one pair at a time; the row of an accepted query is
+//     segment start + accepted queries of the pair's earlier chunks + its rank inside the chunk.
+// The middle term comes from a chain over the pair's chunks (decoupled look-back): every chunk publishes its own count as soon as its fits are
+// done (one 8-byte word {state, count}, relaxed agent-scope atomics on both sides — the word is its own payload, no fence); the counts of the
+// chunks before it are summed back to the nearest one that already holds an inclusive prefix (the first wave reads 64 words per round trip),
+// and the chunk publishes its own inclusive prefix.  The last chunk of a pair leaves the pair's total for the host.
+// A workgroup must not WAIT for that sum with its registers allocated: fits take anything from a class test to a full QR, and at two
+// workgroups per CU a finished chunk idling behind a slow predecessor cost 40 % (1820 against 1296 us per dispatch without the chain).  So
+// the workgroups are persistent, take chunks from a ticket counter (the chunks a chunk depends on have always been taken), park the records
+// of the chunk just fitted in LDS (14 KB), fit the NEXT chunk, and only then place the parked one — by then its predecessors have long
+// published.
+// Round 4 wrote the records of EVERY query to scratch (56 B), copied the chunk counts to the host, sized the block there, uploaded the
+// destinations and compacted in a second kernel (k_compact: 282 us of the 2.7 ms per 16.7 M queries, HBM-bound on the round trip of the records);
+// now the segment of a pair has room for all of its queries (the set costs what the queries cost, not what was accepted: 7.5 instead of 5.6 GB
+// for the bench's 134 M queries) and the host only learns the per-pair totals.
+#define PVLM_CHAIN_AGG (1ull << 62)
+#define PVLM_CHAIN_INC (1ull << 63)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAVES, 8))) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp, long long tmp_rows,
+                                                   double* __restrict__ cols, long long n_dev, unsigned long long* __restrict__ chain, int* __restrict__ pair_count,
+                                                   int* __restrict__ ticket, int* __restrict__ qidx_out, int* __restrict__ nn_out, int chunks_x, int total) {
+  __shared__ int s_vid;
+  __shared__ int wc[4];
+  __shared__ long long s_prefix;
+  __shared__ double s_rec[7][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // the parked chunk: wave-uniform (pair, chunk, count) and per thread (accepted, rank inside the chunk)
+  int prev_pair = -1, prev_chunk = 0, prev_count = 0, prev_rank = 0;
+  bool prev_accept = false;
+  // rows of the parked chunk: look-back, inclusive prefix, records out of LDS
+  auto place = [&]() {
+    const PairDesc& pp = pairs[prev_pair];
+    if (wv == 0) {
+      unsigned long long* my = chain + pp.chunk_base + prev_chunk;
+      long long prefix = 0;
+      if (prev_chunk > 0) {
+        for (int base = prev_chunk - 1;; base -= 64) {
+          const int c = base - lane;
+          unsigned long long w = PVLM_CHAIN_INC;                 // before the pair's first chunk: an inclusive prefix of zero
+          if (c >= 0)
+            while (((w = __hip_atomic_load(chain + pp.chunk_base + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & (PVLM_CHAIN_AGG | PVLM_CHAIN_INC)) == 0ull) __builtin_amdgcn_s_sleep(1);
+          const unsigned long long inc = __ballot((w & PVLM_CHAIN_INC) != 0ull);   // never empty in the last window (c < 0 lanes)
+          const int first = inc ? __builtin_ctzll(inc) : 64;
+          long long v = lane <= first ? (long long)(w & 0xFFFFFFFFull) : 0ll;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
-    bool ok = id[9] >= 0;
-    if (ok) {
-      const float qtag = pd.q_tag[q];
-      double px[10], py[10], pz[10];
-      int same = 0;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) {
-        const int j = id[k];
-        same += (K3_LOADF(pd.ref.tag, j) == qtag);
-        double l[3];
-        world2local(pd.Rr, pd.tr, (double)K3_LOADF(pd.ref.xyz, 3 * j), (double)K3_LOADF(pd.ref.xyz, 3 * j + 1), (double)K3_LOADF(pd.ref.xyz, 3 * j + 2), l);
-        px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          prefix += v;
+          if (inc) break;
+        }
+        if (lane == 0) __hip_atomic_store(my, PVLM_CHAIN_INC | (unsigned long long)(prefix + prev_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      ok = (same == 10);  // :583-591
+      if (lane == 0) {
+        if ((prev_chunk + 1) * 256 >= pp.nq) pair_count[prev_pair] = (int)(prefix + prev_count);
+        s_prefix = prefix;
+      }
+    }
+    __syncthreads();
+    if (prev_accept) {
+      const long long d = pp.dst_row + s_prefix + prev_rank;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) cols[(size_t)c * n_dev + d] = s_rec[c][threadIdx.x];
+      if (qidx_out) {
+        const int q = prev_chunk * 256 + (int)threadIdx.x;
+        qidx_out[d] = q;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) nn_out[d * 10 + k] = nn_tmp[(size_t)k * tmp_rows + pp.tmp_base + q];
+      }
+    }
+    __syncthreads();   // s_rec and s_prefix are free again
+  };
+  // tickets are drawn one chunk ahead (thread 0 holds the next one while the chunk is fitted: the atomic's latency is off the path)
+  int next_vid = 0;
+  if (threadIdx.x == 0) next_vid = atomicAdd(ticket, 1);
+  for (;;) {
+    if (threadIdx.x == 0) { s_vid = next_vid; next_vid = atomicAdd(ticket, 1); }
+    __syncthreads();
+    const int vid = __builtin_amdgcn_readfirstlane(s_vid);
+    __syncthreads();   // s_vid is read before the next round overwrites it
+    if (vid >= total) break;
+    const int pair = vid / chunks_x, chunk = vid - pair * chunks_x;
+    const PairDesc& pd = pairs[pair];
+    if (chunk * 256 >= pd.nq) continue;
+    const int q = chunk * 256 + threadIdx.x;
+    bool accept = false;
+    double rec[7];
+    if (q < pd.nq) {
+      const long long row = pd.tmp_base + q;
+      int id[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
+      bool ok = id[9] >= 0;
       if (ok) {
-        double plane[4];
-        // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
-        // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
-        // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
-        // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
-        // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw — on 65 536-point targets K3 waits for its gathers at two
-        // waves per SIMD, not for the QR; profiles/r4_assoc_variants.txt.)
-        ok = !Fit10::is_line(px, py, pz, 3.0);
-        if (ok) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+        const float qtag = pd.q_tag[q];
+        double px[10], py[10], pz[10], Rt[3];
+        world2local_rt(pd.Rr, pd.tr, Rt);
+        int same = 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          const Point4 t = pd.ref.pt4[id[k]];          // (x, y, z, tag) of the neighbour: one 16-byte gather (round 4: four 4-byte ones)
+          same += (t.w == qtag);
+          double l[3];
+          world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
+          px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
+        }
+        ok = (same == 10);  // :583-591
         if (ok) {
-          double pl[3];
-          world2local(pd.Rn, pd.tn, (double)pd.q_xyz[3 * q], (double)pd.q_xyz[3 * q + 1], (double)pd.q_xyz[3 * q + 2], pl);
-          rec_tmp[0 * tmp_rows + row] = pl[0]; rec_tmp[1 * tmp_rows + row] = pl[1]; rec_tmp[2 * tmp_rows + row] = pl[2];
-          rec_tmp[3 * tmp_rows + row] = plane[0]; rec_tmp[4 * tmp_rows + row] = plane[1];
-          rec_tmp[5 * tmp_rows + row] = plane[2]; rec_tmp[6 * tmp_rows + row] = plane[3];
+          double plane[4];
+          // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
+          // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
+          // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
+          // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
+          // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw — on 65 536-point targets K3 waits for its gathers at two
+          // waves per SIMD, not for the QR; profiles/r4_assoc_variants.txt.)
+          ok = !Fit10::is_line(px, py, pz, 3.0);
+          if (ok) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+          if (ok) {
+            double pl[3];
+            world2local(pd.Rn, pd.tn, (double)pd.q_xyz[3 * q], (double)pd.q_xyz[3 * q + 1], (double)pd.q_xyz[3 * q + 2], pl);
+            rec[0] = pl[0]; rec[1] = pl[1]; rec[2] = pl[2]; rec[3] = plane[0]; rec[4] = plane[1]; rec[5] = plane[2]; rec[6] = plane[3];
+          }
         }
       }
+      accept = ok;
     }
-    flag_tmp[row] = ok ? 1 : 0;
-    accept = ok;
-  }
-  const unsigned long long bal = __ballot(accept);
-  __shared__ int wc[4];
-  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) chunk_count[pd.chunk_base + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
-}
-
-// ordered compaction: chunk (pair, c) writes its accepted rows at dst_dev_row[chunk] + rank of the batch's column
-// block (`cols`, column stride `n_dev` rows); qidx_out / nn_out (optional) are in the block's compact order.
-__global__ __launch_bounds__(256) void k_compact(const PairDesc* __restrict__ pairs, const unsigned char* __restrict__ flag_tmp,
-                                                 const double* __restrict__ rec_tmp, const int* __restrict__ nn_tmp, long long tmp_rows,
-                                                 const long long* __restrict__ dst_dev_row, const long long* __restrict__ dst_out_row,
-                                                 double* __restrict__ cols, long long n_dev, int* __restrict__ qidx_out,
-                                                 int* __restrict__ nn_out) {
-  const PairDesc& pd = pairs[blockIdx.y];
-  if (blockIdx.x * 256 >= pd.nq) return;
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  const long long row = pd.tmp_base + q;
-  const bool f = (q < pd.nq) && flag_tmp[row];
-  const unsigned long long bal = __ballot(f);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __shared__ int wc[4];
-  if (lane == 0) wc[wv] = __popcll(bal);
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wv; ++w) base += wc[w];
-  const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
-  if (f) {
-    const int ch = pd.chunk_base + blockIdx.x;
-    const long long d = dst_dev_row[ch] + rank;
+    const unsigned long long bal = __ballot(accept);
+    if (lane == 0) wc[wv] = __popcll(bal);
+    __syncthreads();
+    const int count = wc[0] + wc[1] + wc[2] + wc[3];
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wc[w];
+    const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+    // the chunk's own count is public at once: a first chunk's is its inclusive prefix
+    if (threadIdx.x == 0)
+      __hip_atomic_store(chain + pd.chunk_base + chunk, (chunk == 0 ? PVLM_CHAIN_INC : PVLM_CHAIN_AGG) | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev_pair >= 0) place();           // ends with a barrier: wc and s_rec are free
+    else __syncthreads();
+    if (accept) {
 #pragma unroll
-    for (int c = 0; c < 7; ++c) cols[(size_t)c * n_dev + d] = rec_tmp[(size_t)c * tmp_rows + row];
-    if (qidx_out) {
-      const long long o = dst_out_row[ch] + rank;
-      qidx_out[o] = q;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) nn_out[o * 10 + k] = nn_tmp[(size_t)k * tmp_rows + row];
+      for (int c = 0; c < 7; ++c) s_rec[c][threadIdx.x] = rec[c];
     }
+    prev_pair = pair; prev_chunk = chunk; prev_count = count; prev_rank = rank; prev_accept = accept;
   }
+  if (prev_pair >= 0) place();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,7 +394,7 @@ struct CloudPlan {
   int dense = 0, nx = 0, ny = 0, nz = 0, xf = 1;
   long long T = 0;
   // byte offsets: persistent slab (o_*) and build scratch (s_*)
-  size_t o_xyz = 0, o_tag = 0, o_count = 0, o_keys = 0, o_start = 0, o_sorted = 0, s_cursor = 0, s_slot = 0;
+  size_t o_xyz = 0, o_tag = 0, o_count = 0, o_keys = 0, o_start = 0, o_sorted = 0, o_pt4 = 0, s_cursor = 0, s_slot = 0;
 };
 
 // bounding box of a cloud and its first non-finite point (a NaN never updates a min / max, so every coordinate is tested): the one pass
@@ -406,7 +461,7 @@ static CloudView view_of(const pvlm_cloud& c);
 static CloudView view_of(const pvlm_cloud& c) {
   CloudView v;
   v.sorted = reinterpret_cast<const Point4*>(c.d_sorted); v.keys = c.d_keys; v.cell_start = c.d_cell_start; v.cell_count = c.d_cell_count;
-  v.xyz = c.d_xyz; v.tag = c.d_tag; v.n = c.n; v.mask = c.table_size - 1;
+  v.xyz = c.d_xyz; v.tag = c.d_tag; v.pt4 = reinterpret_cast<const Point4*>(c.d_pt4); v.n = c.n; v.mask = c.table_size - 1;
   v.dense = c.dense; v.nx = c.nx; v.ny = c.ny; v.nz = c.nz; v.xf = c.dense ? std::max(c.xf, 1) : 1;
   v.ox = c.origin[0]; v.oy = c.origin[1]; v.oz = c.origin[2]; v.h = c.cell; v.inv_h = c.cell > 0 ? 1.0f / c.cell : 0.f;
   return v;
@@ -422,14 +477,10 @@ static pvlm_status assoc_ws_ensure(pvlm_ctx* ctx, long long rows, int chunks, in
   pvlm_i_assoc_ws_free(ctx);
   pvlm_status st = PVLM_OK;
   for (int s = 0; s < 2 && !st; ++s) {
-    if (!st) st = pvlm_i_alloc(ctx, &w.d_rec[s], (size_t)rows * 7);
     if (!st) st = pvlm_i_alloc(ctx, &w.d_nn[s], (size_t)rows * 10);
-    if (!st) st = pvlm_i_alloc(ctx, &w.d_flag[s], (size_t)rows);
-    if (!st) st = pvlm_i_alloc(ctx, &w.d_cc[s], (size_t)chunks);
-    if (!st) st = pvlm_i_alloc(ctx, &w.d_dst[s], (size_t)chunks * 2);
+    if (!st) st = pvlm_i_alloc(ctx, &w.d_chain[s], (size_t)chunks + (size_t)pairs / 2 + 2);
     if (!st) st = pvlm_i_alloc_bytes(ctx, &w.d_desc[s], (size_t)pairs * sizeof(PairDesc));
-    if (!st && (hipHostMalloc((void**)&w.h_cc[s], (size_t)chunks * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc((void**)&w.h_dst[s], (size_t)chunks * 2 * sizeof(long long), hipHostMallocDefault) != hipSuccess ||
+    if (!st && (hipHostMalloc((void**)&w.h_count[s], (size_t)pairs * sizeof(int), hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc(&w.h_desc[s], (size_t)pairs * sizeof(PairDesc), hipHostMallocDefault) != hipSuccess ||
                 hipEventCreateWithFlags(&w.ev[s], hipEventDisableTiming) != hipSuccess)) {
       PVLM_SET_ERR(ctx, "association staging: pinned host allocation failed");
@@ -570,7 +621,7 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   const size_t count_bytes = slab - o_count0, o_keys0 = slab;
   each_cloud([&](CloudPlan& c) { if (c.grid && !c.dense) place(c.o_keys, slab, (size_t)c.T * 8); });
   const size_t keys_bytes = slab - o_keys0;
-  each_cloud([&](CloudPlan& c) { if (c.grid) { place(c.o_start, slab, (size_t)c.T * 4); place(c.o_sorted, slab, ((size_t)c.n + 1) * 16); } });   // + 1: the search may read (never use) one record past a run
+  each_cloud([&](CloudPlan& c) { if (c.grid) { place(c.o_start, slab, (size_t)c.T * 4); place(c.o_sorted, slab, ((size_t)c.n + 1) * 16); if (c.tag) place(c.o_pt4, slab, (size_t)c.n * 16); } });   // + 1: the search may read (never use) one record past a run
   each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_cursor, scratch, (size_t)c.T * 4); });
   const size_t cursor_bytes = scratch;
   each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_slot, scratch, (size_t)c.n * 4); });
@@ -622,6 +673,7 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
     D.keys = c.dense ? nullptr : (unsigned long long*)(d_slab + c.o_keys);
     D.count = (int*)(d_slab + c.o_count); D.start = (int*)(d_slab + c.o_start); D.sorted = (float4*)(d_slab + c.o_sorted);
     D.cursor = (int*)(d_scr + c.s_cursor); D.slot = (int*)(d_scr + c.s_slot);
+    D.tag = c.tag ? (const float*)(d_slab + c.o_tag) : nullptr; D.pt4 = c.tag ? (float4*)(d_slab + c.o_pt4) : nullptr;
     for (int f = 0; f < c.n; f += 256) hb.push_back(GridBlock{g, f});
     if (c.T <= GRID_SCAN_MAX) hs.push_back(g); else big.push_back({g, &c});
     ++g;
@@ -690,6 +742,7 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
     c.table_size = (int)p.T; c.dense = p.dense; c.nx = p.nx; c.ny = p.ny; c.nz = p.nz; c.xf = p.xf;
     c.d_keys = p.dense ? nullptr : (unsigned long long*)(d_slab + p.o_keys);
     c.d_cell_start = (int*)(d_slab + p.o_start); c.d_cell_count = (int*)(d_slab + p.o_count); c.d_sorted = (float4*)(d_slab + p.o_sorted);
+    c.d_pt4 = p.tag ? (float4*)(d_slab + p.o_pt4) : nullptr;
   };
   for (int k = 0; k < n_scans; ++k) {
     pvlm_scan* s = scans[(size_t)k]; const ScanPlan& P = plan[(size_t)k];
@@ -799,64 +852,67 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
   if (st) { pvlm_i_resset_free(ctx, rs); return st; }
   pvlm_assoc_ws& ws = ctx->assoc_ws;
 
+  // per batch: the column block is taken at ISSUE time with room for every query of the batch (segment of pair p: seg_rows(nq) rows at dst_row)
+  std::vector<long long> batch_R(batches.size(), 0);
+  for (size_t bi = 0; bi < batches.size(); ++bi) {
+    long long row = 0;
+    for (int p = batches[bi].p0; p < batches[bi].p1; ++p) { descs[p].dst_row = row; row += pvlm_i_seg_rows(descs[p].nq); }
+    batch_R[bi] = std::max<long long>(row, 16);
+  }
   auto issue = [&](int bi) -> pvlm_status {
     const Batch& b = batches[bi];
     const int s = bi & 1, nb = b.p1 - b.p0;
+    const long long R = batch_R[bi];
+    double* d_block = nullptr;
+    pvlm_status sa = pvlm_i_alloc(ctx, &d_block, (size_t)R * 7);
+    if (sa) return sa;
+    rs->col_blocks.push_back(d_block); rs->block_rows.push_back(R); rs->block_n.push_back(0);
+    rs->n_dev += R;
+    int32_t *d_q = nullptr, *d_n = nullptr;
+    if (keep_idx) {
+      if ((sa = pvlm_i_alloc(ctx, &d_q, (size_t)R))) return sa;
+      rs->d_qidx.push_back(d_q);
+      if ((sa = pvlm_i_alloc(ctx, &d_n, (size_t)R * 10))) return sa;
+      rs->d_nn.push_back(d_n);
+    }
     std::memcpy(ws.h_desc[s], &descs[b.p0], (size_t)nb * sizeof(PairDesc));
     PVLM_HIP(ctx, hipMemcpyAsync(ws.d_desc[s], ws.h_desc[s], (size_t)nb * sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream));
     const PairDesc* d_desc = static_cast<const PairDesc*>(ws.d_desc[s]);
+    // chain words of the batch's chunks, then the per-pair totals (ints), then the ticket: zeroed together
+    unsigned long long* d_chain = ws.d_chain[s];
+    int* d_count = reinterpret_cast<int*>(d_chain + b.chunks);
+    int* d_ticket = d_count + nb;
+    PVLM_HIP(ctx, hipMemsetAsync(d_chain, 0, (size_t)b.chunks * sizeof(unsigned long long) + ((size_t)nb + 1) * sizeof(int), ctx->stream));
     if (b.bmax > 0) {
       pvlm_prof_scope prof(ctx, 2);
       // (an LDS-staged variant of the search was built and measured in round 2: 35.0 vs 33.6 ms for 134 M queries — the
       // search is bound by instruction issue, not by memory latency; numbers in DESIGN.md, code removed in round 3)
       hipLaunchKernelGGL(k_knn_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
-      hipLaunchKernelGGL(k_fit_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.d_rec[s],
-                         ws.d_flag[s], ws.d_cc[s], ws.rows);
+      const int chunks_x = (b.bmax + 255) / 256;
+      const long long total = (long long)chunks_x * nb;
+      if (total > 0x7fffffffll) { PVLM_SET_ERR(ctx, "association batch too large"); return PVLM_ERR_ARG; }
+      static const int k3_blocks = [] { const char* e = getenv("PVLM_K3_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();   // persistent workgroups (two fit per CU)
+      hipLaunchKernelGGL(k_fit_pairs, dim3((unsigned)std::min<long long>(total, k3_blocks)), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.rows, d_block, R, d_chain,
+                         d_count, d_ticket, d_q, d_n, chunks_x, (int)total);
       PVLM_HIP(ctx, hipGetLastError());
     }
-    if (b.chunks > 0) PVLM_HIP(ctx, hipMemcpyAsync(ws.h_cc[s], ws.d_cc[s], (size_t)b.chunks * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PVLM_HIP(ctx, hipMemcpyAsync(ws.h_count[s], d_count, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PVLM_HIP(ctx, hipEventRecord(ws.ev[s], ctx->stream));
     return PVLM_OK;
   };
   auto finish = [&](int bi) -> pvlm_status {
     const Batch& b = batches[bi];
-    const int s = bi & 1, nb = b.p1 - b.p0;
+    const int s = bi & 1;
     PVLM_HIP(ctx, hipEventSynchronize(ws.ev[s]));
-    long long block_row = 0, block_n = 0;
+    long long block_n = 0;
     for (int p = b.p0; p < b.p1; ++p) {
-      const int nc = (descs[p].nq + 255) / 256;
+      const long long m = descs[p].nq > 0 ? ws.h_count[s][p - b.p0] : 0;
       rs->h_pair_block[p] = bi;
-      rs->h_seg_start[p] = block_row;
-      long long m = 0;
-      for (int c = 0; c < nc; ++c) {
-        const int ch = descs[p].chunk_base + c;
-        ws.h_dst[s][ch] = block_row + m;                 // row inside the block
-        ws.h_dst[s][b.chunks + ch] = block_n + m;        // compact row inside the block (debug arrays)
-        m += ws.h_cc[s][ch];
-      }
+      rs->h_seg_start[p] = descs[p].dst_row;
       rs->h_out_start[p + 1] = rs->h_out_start[p] + m;
-      block_row += pvlm_i_seg_rows(m);
       block_n += m;
     }
-    const long long R = std::max<long long>(block_row, 16);
-    double* d_block = nullptr;
-    pvlm_status sa = pvlm_i_alloc(ctx, &d_block, (size_t)R * 7);
-    if (sa) return sa;
-    rs->col_blocks.push_back(d_block); rs->block_rows.push_back(R); rs->block_n.push_back(block_n);
-    rs->n_dev += R;
-    int32_t *d_q = nullptr, *d_n = nullptr;
-    if (keep_idx) {
-      if ((sa = pvlm_i_alloc(ctx, &d_q, (size_t)std::max<long long>(block_n, 1)))) return sa;
-      rs->d_qidx.push_back(d_q);
-      if ((sa = pvlm_i_alloc(ctx, &d_n, (size_t)std::max<long long>(block_n, 1) * 10))) return sa;
-      rs->d_nn.push_back(d_n);
-    }
-    if (block_n > 0) {
-      PVLM_HIP(ctx, hipMemcpyAsync(ws.d_dst[s], ws.h_dst[s], (size_t)b.chunks * 2 * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_compact, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, static_cast<const PairDesc*>(ws.d_desc[s]), ws.d_flag[s],
-                         ws.d_rec[s], ws.d_nn[s], ws.rows, ws.d_dst[s], ws.d_dst[s] + b.chunks, d_block, R, d_q, d_n);
-      PVLM_HIP(ctx, hipGetLastError());
-    }
+    rs->block_n[(size_t)bi] = block_n;
     return PVLM_OK;
   };
   const int B = (int)batches.size();
@@ -879,16 +935,17 @@ pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, i
   if (rs->n > 0 && rs->d_qidx.empty()) { PVLM_SET_ERR(ctx, "indices were not kept: pass flag 0x100 to pvlm_assoc_point2plane"); return PVLM_ERR_STATE; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   if (rs->n == 0) return PVLM_OK;
-  int64_t o = 0;
-  for (size_t b = 0; b < rs->d_qidx.size(); ++b) {
-    const int64_t m = rs->block_n[b];
-    pvlm_status st = PVLM_OK;
-    if (qidx && m) st = pvlm_i_d2h(ctx, qidx + o, rs->d_qidx[b], (size_t)m * sizeof(int));
-    if (!st && nn && m) st = pvlm_i_d2h(ctx, nn + o * 10, rs->d_nn[b], (size_t)m * 10 * sizeof(int));
-    if (st) return st;
-    o += m;
+  // the debug arrays share the layout of the column blocks: the rows of pair p sit at its segment start
+  pvlm_status st = PVLM_OK;
+  for (int p = 0; p < rs->n_pairs && !st; ++p) {
+    const int64_t o = rs->h_out_start[(size_t)p], m = rs->h_out_start[(size_t)p + 1] - o, seg = rs->h_seg_start[(size_t)p];
+    const size_t b = (size_t)rs->h_pair_block[(size_t)p];
+    if (m <= 0) continue;
+    if (qidx) st = pvlm_i_d2h_q(ctx, qidx + o, rs->d_qidx[b] + seg, (size_t)m * sizeof(int));
+    if (!st && nn) st = pvlm_i_d2h_q(ctx, nn + o * 10, rs->d_nn[b] + seg * 10, (size_t)m * 10 * sizeof(int));
   }
-  return PVLM_OK;
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+  return st;
 }
 
 }  // extern "C"

@@ -39,6 +39,7 @@ struct CloudView {
   const int* cell_count;
   const float* xyz;  // original order, interleaved
   const float* tag;
+  const Point4* pt4; // original order: (x, y, z, tag) — clouds uploaded with tags
   int n, mask;
   int dense, nx, ny, nz;   // dense != 0: cells addressed directly as (iz*ny + iy)*nx + ix, no hashing
   int xf;                  // dense tables: cells are xf times finer along x (nx counts the FINE cells of a row); hashed tables: 1
@@ -631,6 +632,16 @@ PVLM_HD void world2local(const double* R, const double* t, double x, double y, d
     const double b = (R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];
     o[i] = a - b;
   }
+}
+
+// the same with the translation term R_wl^T t (identical for every point of a cloud) taken once: Rt[i] = (R[i] t0 + R[3+i] t1) + R[6+i] t2
+PVLM_HD void world2local_rt(const double* R, const double* t, double* Rt) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Rt[i] = (R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2];
+}
+PVLM_HD void world2local_pt(const double* R, const double* Rt, double x, double y, double z, double* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = ((R[i] * x + R[3 + i] * y) + R[6 + i] * z) - Rt[i];
 }
 
 }  // namespace pvlm_assoc

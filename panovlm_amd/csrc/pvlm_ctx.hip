@@ -238,10 +238,8 @@ pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes) 
 void pvlm_i_assoc_ws_free(pvlm_ctx* ctx) {
   pvlm_assoc_ws& w = ctx->assoc_ws;
   for (int s = 0; s < 2; ++s) {
-    pvlm_i_free(ctx, w.d_rec[s]); pvlm_i_free(ctx, w.d_nn[s]); pvlm_i_free(ctx, w.d_flag[s]); pvlm_i_free(ctx, w.d_cc[s]);
-    pvlm_i_free(ctx, w.d_dst[s]); pvlm_i_free(ctx, w.d_desc[s]);
-    if (w.h_cc[s]) (void)hipHostFree(w.h_cc[s]);
-    if (w.h_dst[s]) (void)hipHostFree(w.h_dst[s]);
+    pvlm_i_free(ctx, w.d_nn[s]); pvlm_i_free(ctx, w.d_chain[s]); pvlm_i_free(ctx, w.d_desc[s]);
+    if (w.h_count[s]) (void)hipHostFree(w.h_count[s]);
     if (w.h_desc[s]) (void)hipHostFree(w.h_desc[s]);
     if (w.ev[s]) (void)hipEventDestroy(w.ev[s]);
   }

@@ -39,14 +39,10 @@ struct pvlm_pool {
 // scratch of pvlm_assoc_point2plane that survives the call (two pipeline slots + pinned host staging)
 struct pvlm_assoc_ws {
   long long rows = 0; int chunks = 0, pairs = 0;  // capacity of one slot
-  double* d_rec[2] = {nullptr, nullptr};
-  int* d_nn[2] = {nullptr, nullptr};
-  unsigned char* d_flag[2] = {nullptr, nullptr};
-  int* d_cc[2] = {nullptr, nullptr};
-  long long* d_dst[2] = {nullptr, nullptr};       // 2 x chunks: device row, compact row
+  int* d_nn[2] = {nullptr, nullptr};              // 10 x rows: the neighbour table K2 hands to K3
+  unsigned long long* d_chain[2] = {nullptr, nullptr};   // chunks + pairs + 1 words: K3's look-back chain, the per-pair totals (as ints) behind it, the ticket
   void* d_desc[2] = {nullptr, nullptr};
-  int* h_cc[2] = {nullptr, nullptr};              // pinned
-  long long* h_dst[2] = {nullptr, nullptr};       // pinned
+  int* h_count[2] = {nullptr, nullptr};           // pinned: accepted rows per pair
   void* h_desc[2] = {nullptr, nullptr};           // pinned
   size_t desc_bytes = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -184,6 +180,7 @@ struct pvlm_cloud {
   int* d_cell_start = nullptr;   // table_size
   int* d_cell_count = nullptr;   // table_size
   float4* d_sorted = nullptr;    // n: (x,y,z, as_float(original index))
+  float4* d_pt4 = nullptr;       // n: (x,y,z,tag) in original order (clouds with tags)
   int* d_sorted_cell = nullptr;  // unused placeholder
 };
 

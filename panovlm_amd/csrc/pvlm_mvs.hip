@@ -83,7 +83,21 @@ static inline hipError_t mvs_up(pvlm_ctx* ctx, void* d, const void* h, size_t by
 static inline hipError_t mvs_down(pvlm_ctx* ctx, void* h, const void* d, size_t bytes) { return pvlm_i_d2h_q(ctx, h, d, bytes) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t mvs_sync(pvlm_ctx* ctx) { return pvlm_i_sync(ctx) == PVLM_OK ? hipSuccess : hipErrorUnknown; }
 
-struct pvlm_mvs_neighbours { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
+// neighbour images of one reference view: quad[b] = the 2x2-quad copy of grey image b (pvlm_mvs_core.h, QuadImage) — what every tap reads
+struct pvlm_mvs_neighbours {
+  const unsigned* quad[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric;
+  __host__ __device__ pvlm_mvs::QuadImage image(int b) const { return pvlm_mvs::QuadImage{quad[b]}; }
+};
+// quad copy of a grey image: word (x, y) = I(x,y) | I(x+1,y) << 8 | I(x,y+1) << 16 | I(x+1,y+1) << 24 (the last column / row repeat themselves: a
+// tap that is used never starts there — frame.IsInside(x1, 1, 1))
+__global__ __launch_bounds__(256) void k_mvs_quad(int rows, int cols, const unsigned char* __restrict__ gray, unsigned* __restrict__ quad) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  const int y = (int)(i / cols), x = (int)(i - (size_t)y * cols);
+  const int x1 = x + 1 < cols ? x + 1 : x, y1 = y + 1 < rows ? y + 1 : y;
+  quad[i] = (unsigned)gray[(size_t)y * cols + x] | ((unsigned)gray[(size_t)y * cols + x1] << 8) | ((unsigned)gray[(size_t)y1 * cols + x] << 16) |
+            ((unsigned)gray[(size_t)y1 * cols + x1] << 24);
+}
 
 // MEASURED VARIANT (-DPVLM_MVS_FLOW_CLOCK=1): where a pixel of K13q spends its time, summed over all workgroups by thread 0 with the
 // 100 MHz wall clock: [0] ticket + walk + patch preparation, [1] waiting for the two stamps, [2] the dependent chain, [3] store + stamp,
@@ -164,7 +178,7 @@ __device__ inline float wave_score(int rows, int cols, int half_window, int step
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           t1[j][m] = 0.f;
-          ok = pvlm_mvs::neighbour_texel_ray(uv[m], nb.gray[b0 + j], rows, cols, H, &t1[j][m]) && ok;
+          ok = pvlm_mvs::neighbour_texel_ray(uv[m], nb.image(b0 + j), rows, cols, H, &t1[j][m]) && ok;
         }
       } else {
 #pragma unroll
@@ -1248,7 +1262,9 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   const size_t npix = (size_t)rows * cols;
   unsigned char *d_img = nullptr, *d_const = nullptr; float *d_unit = nullptr, *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_ndepth = nullptr;
+  unsigned* d_quad = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_img, npix * (size_t)(n_neighbors + 1));
+  if (!st) st = pvlm_i_alloc(ctx, &d_quad, npix * (size_t)std::max(n_neighbors, 1));
   if (!st && nei_depth) st = pvlm_i_alloc(ctx, &d_ndepth, npix * (size_t)std::max(n_neighbors, 1));
   if (!st && depth_constant) st = pvlm_i_alloc(ctx, &d_const, npix);
   if (!st) st = pvlm_i_alloc(ctx, &d_unit, npix * 3);
@@ -1263,7 +1279,8 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
     for (int b = 0; b < n_neighbors && e == hipSuccess; ++b) {
       if (!nei_gray[b]) { e = hipErrorInvalidValue; break; }
       e = mvs_up(ctx, d_img + npix * (size_t)(b + 1), nei_gray[b], npix);
-      nb.gray[b] = d_img + npix * (size_t)(b + 1);
+      if (e == hipSuccess) hipLaunchKernelGGL(k_mvs_quad, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rows, cols, d_img + npix * (size_t)(b + 1), d_quad + npix * (size_t)b);
+      nb.quad[b] = d_quad + npix * (size_t)b;
       nb.depth[b] = nullptr;
       if (nei_depth && e == hipSuccess) {
         if (!nei_depth[b]) { e = hipErrorInvalidValue; break; }
@@ -1320,6 +1337,7 @@ static pvlm_status mvs_run(pvlm_ctx* ctx, const char* what, int rows, int cols, 
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "%s: %s", what, hipGetErrorString(e)); st = PVLM_ERR_HIP; }
   }
   mvs_sync(ctx);
+  pvlm_i_free(ctx, d_quad);
   pvlm_i_free(ctx, d_img); pvlm_i_free(ctx, d_unit); pvlm_i_free(ctx, d_depth); pvlm_i_free(ctx, d_normal); pvlm_i_free(ctx, d_conf); pvlm_i_free(ctx, d_ndepth); pvlm_i_free(ctx, d_const);
   return st;
 }
@@ -1563,6 +1581,7 @@ struct pvlm_mvs_views {
   int rows = 0, cols = 0, n = 0;
   size_t npix = 0;
   unsigned char* d_gray = nullptr;                      // n x npix
+  unsigned* d_quad = nullptr;                           // n x npix: the 2x2-quad copies the taps read (k_mvs_quad, rebuilt whenever a grey image is uploaded)
   float *d_depth = nullptr, *d_normal = nullptr, *d_conf = nullptr, *d_depth_filter = nullptr, *d_conf_filter = nullptr;   // n x npix (normal: x 3)
   float* d_unit = nullptr;                              // npix x 3 (PreComputeI2C)
   unsigned long long* d_key = nullptr;                  // 16 x npix splat keys (fusion filter scratch)
@@ -1590,6 +1609,7 @@ pvlm_status pvlm_mvs_views_destroy(pvlm_ctx* ctx, pvlm_mvs_views* v) {
   if (!v) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   mvs_sync(ctx);
+  pvlm_i_free(ctx, v->d_quad);
   pvlm_i_free(ctx, v->d_gray); pvlm_i_free(ctx, v->d_depth); pvlm_i_free(ctx, v->d_normal); pvlm_i_free(ctx, v->d_conf); pvlm_i_free(ctx, v->d_depth_filter); pvlm_i_free(ctx, v->d_conf_filter);
   pvlm_i_free(ctx, v->d_unit); pvlm_i_free(ctx, v->d_key); pvlm_i_free(ctx, v->d_const);
   delete v;
@@ -1604,6 +1624,7 @@ pvlm_status pvlm_mvs_views_create(pvlm_ctx* ctx, int rows, int cols, int n_views
   v->rows = rows; v->cols = cols; v->n = n_views; v->npix = (size_t)rows * cols;
   const size_t all = v->npix * (size_t)n_views;
   pvlm_status st = pvlm_i_alloc(ctx, &v->d_gray, all);
+  if (!st) st = pvlm_i_alloc(ctx, &v->d_quad, all);
   if (!st) st = pvlm_i_alloc(ctx, &v->d_depth, all);
   if (!st) st = pvlm_i_alloc(ctx, &v->d_normal, all * 3);
   if (!st) st = pvlm_i_alloc(ctx, &v->d_conf, all);
@@ -1615,6 +1636,7 @@ pvlm_status pvlm_mvs_views_create(pvlm_ctx* ctx, int rows, int cols, int n_views
   if (!st) {
     hipStream_t s = ctx->stream;
     hipError_t e = hipMemsetAsync(v->d_gray, 0, all, s);
+    if (e == hipSuccess) e = hipMemsetAsync(v->d_quad, 0, all * sizeof(unsigned), s);
     float* zero[5] = {v->d_depth, v->d_conf, v->d_depth_filter, v->d_conf_filter, v->d_normal};
     for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipMemsetAsync(zero[k], 0, all * sizeof(float) * (k == 4 ? 3 : 1), s);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_mvs_unit_table, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, s, rows, cols, v->d_unit); e = hipGetLastError(); }
@@ -1632,7 +1654,10 @@ pvlm_status pvlm_mvs_views_upload(pvlm_ctx* ctx, pvlm_mvs_views* v, int view, co
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   const size_t o = v->npix * (size_t)view;
   hipError_t e = hipSuccess;
-  if (gray) e = mvs_up(ctx, v->d_gray + o, gray, v->npix);
+  if (gray) {
+    e = mvs_up(ctx, v->d_gray + o, gray, v->npix);
+    if (e == hipSuccess) hipLaunchKernelGGL(k_mvs_quad, dim3((unsigned)((v->npix + 255) / 256)), dim3(256), 0, ctx->stream, v->rows, v->cols, v->d_gray + o, v->d_quad + o);
+  }
   if (e == hipSuccess && depth) e = mvs_up(ctx, v->d_depth + o, depth, v->npix * sizeof(float));
   if (e == hipSuccess && normal) e = mvs_up(ctx, v->d_normal + 3 * o, normal, v->npix * 3 * sizeof(float));
   if (e == hipSuccess && conf) e = mvs_up(ctx, v->d_conf + o, conf, v->npix * sizeof(float));
@@ -1669,7 +1694,7 @@ pvlm_status pvlm_mvs_views_snapshot_depth(pvlm_ctx* ctx, pvlm_mvs_views* v, int 
 static void views_neighbours(const pvlm_mvs_views* v, int n_neighbors, const int* nei, const float* R_nr, const float* t_nr, bool geometry, pvlm_mvs_neighbours& nb) {
   nb.n = n_neighbors; nb.geometric = geometry ? 1 : 0;
   for (int b = 0; b < n_neighbors; ++b) {
-    nb.gray[b] = v->d_gray + v->npix * (size_t)nei[b];
+    nb.quad[b] = v->d_quad + v->npix * (size_t)nei[b];
     nb.depth[b] = geometry ? v->d_depth_filter + v->npix * (size_t)nei[b] : nullptr;
     for (int k = 0; k < 9; ++k) nb.R[b][k] = R_nr[9 * b + k];
     for (int k = 0; k < 3; ++k) nb.t[b][k] = t_nr[3 * b + k];

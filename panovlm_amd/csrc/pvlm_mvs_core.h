@@ -120,10 +120,24 @@ PVLM_HD inline void homography(const float* R, const float* t, const float* norm
   for (int i = 0; i < 3; ++i) { const float ti = inv_d * t[i]; for (int j = 0; j < 3; ++j) H[3 * i + j] = R[3 * i + j] + ti * normal[j]; }
 }
 
+// The four grey values of a bilinear tap at pixel offset `at` (its top-left pixel).  From the image itself: four byte loads.  From its
+// 2x2-QUAD copy (QuadImage: one 32-bit word per pixel = I(x,y) | I(x+1,y) << 8 | I(x,y+1) << 16 | I(x+1,y+1) << 24, built once per neighbour
+// image on the device — 4 bytes per pixel, 66 MB for a 5.7K view): ONE dword load, the bytes unpacked by v_cvt_f32_ubyte0..3.  The taps of
+// the 49 texels of every scoring are the gathers the MVS kernels wait on; the same four values either way.
+struct Tap4 { unsigned char p00, p01, p10, p11; };
+struct QuadImage { const unsigned* q; };
+PVLM_HD inline Tap4 tap4(const unsigned char* gray, int cols, size_t at) { const unsigned char* p = gray + at; return Tap4{p[0], p[1], p[cols], p[cols + 1]}; }
+PVLM_HD inline Tap4 tap4(QuadImage img, int cols, size_t at) {
+  (void)cols;
+  const unsigned v = img.q[at];
+  return Tap4{(unsigned char)(v & 255u), (unsigned char)((v >> 8) & 255u), (unsigned char)((v >> 16) & 255u), (unsigned char)(v >> 24)};
+}
+
 // one texel of the neighbour patch: project the reference texel's unit ray through H, test frame.IsInside(x1, 1, 1),
 // sample bilinearly.  Returns false when the projection leaves the image (the whole neighbour is then skipped).
 // the same with the reference texel's unit ray already in hand (the wave scorer loads it once per scoring, not once per neighbour image)
-PVLM_HD inline bool neighbour_texel_ray(const float* uv, const unsigned char* nei_gray, int rows, int cols, const float* H, float* value) {
+template <class Img>
+PVLM_HD inline bool neighbour_texel_ray(const float* uv, Img nei_gray, int rows, int cols, const float* H, float* value) {
   float X1[3];
   for (int r = 0; r < 3; ++r) { float s = 0; for (int c = 0; c < 3; ++c) s += H[3 * r + c] * uv[c]; X1[r] = s; }
   float x1[2];
@@ -131,8 +145,8 @@ PVLM_HD inline bool neighbour_texel_ray(const float* uv, const unsigned char* ne
   if (!(x1[0] >= 1 && x1[1] >= 1 && x1[0] < cols - 1 && x1[1] < rows - 1)) return false;
   const int lx = (int)x1[0], ly = (int)x1[1];
   const float fx = x1[0] - lx, fy = x1[1] - ly, ax = 1.f - fx, ay = 1.f - fy;
-  const unsigned char* p = nei_gray + (size_t)ly * cols + lx;
-  *value = (p[0] * ax + p[1] * fx) * ay + (p[cols] * ax + p[cols + 1] * fx) * fy;
+  const Tap4 p = tap4(nei_gray, cols, (size_t)ly * cols + lx);
+  *value = (p.p00 * ax + p.p01 * fx) * ay + (p.p10 * ax + p.p11 * fx) * fy;
   return true;
 }
 PVLM_HD inline bool neighbour_texel(const float* unit, const unsigned char* nei_gray, int rows, int cols, const float* H, int px, int py, int half_window,
@@ -834,11 +848,9 @@ PVLM_HD inline TexelTap texel_tap(const float* uv, int rows, int cols, const flo
   t.at = (size_t)ly * cols + lx;
   return t;
 }
-struct TexelBytes { unsigned char p00, p01, p10, p11; };
-PVLM_HD inline TexelBytes tap_bytes(const unsigned char* gray, int cols, const TexelTap& t) {
-  const unsigned char* p = gray + t.at;
-  return TexelBytes{p[0], p[1], p[cols], p[cols + 1]};
-}
+typedef Tap4 TexelBytes;
+template <class Img>
+PVLM_HD inline TexelBytes tap_bytes(Img gray, int cols, const TexelTap& t) { return tap4(gray, cols, t.at); }
 PVLM_HD inline float tap_value(const TexelTap& t, const TexelBytes& b) {
   const float ax = 1.f - t.fx, ay = 1.f - t.fy;
   return (b.p00 * ax + b.p01 * t.fx) * ay + (b.p10 * ax + b.p11 * t.fx) * t.fy;
@@ -848,7 +860,7 @@ PVLM_HD inline const float* texel_ray(const float* unit, int cols, int px, int p
   return unit + 3 * ((size_t)(py - half_window + di) * cols + (px - half_window + dj));
 }
 
-// Views: gray[], depth[], R[][9], t[][3], n, geometric (pvlm_mvs_neighbours on the GPU)
+// Views: image(b) (the neighbour's grey image as tap4 takes it), depth[], R[][9], t[][3], n, geometric (pvlm_mvs_neighbours on the GPU)
 template <class Views>
 struct ColumnScorer : SerialMath, SerialFactors {
   int rows, cols, half_window, step, n, px, py;
@@ -858,7 +870,7 @@ struct ColumnScorer : SerialMath, SerialFactors {
     const size_t ws = P.w_stride; const int ts = P.t1_stride;
     float H[9];
     homography(nb->R[b], nb->t[b], nr, d, H);
-    const unsigned char* gray = nb->gray[b];
+    const auto gray = nb->image(b);
     // software pipeline over the window: the ray of texel k + 2, the taps of texel k + 1 and the weight of texel k + 1 are loaded
     // while texel k is interpolated — one thread has nothing else to hide its load latency with
     float uv[3];

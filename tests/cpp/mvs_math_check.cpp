@@ -201,7 +201,8 @@ extern "C" void chk_mvs_propagate(int rows, int cols, int half_window, int step,
 // k_mvs_propagate_lane): weight table and texel column with the strides the kernel uses ([texel][pixel of the pass], [texel][64]),
 // pixels visited backwards.
 namespace {
-struct HostViews { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric; };
+struct HostViews { const unsigned char* gray[16]; const float* depth[16]; float R[16][9]; float t[16][3]; int n; int geometric;
+                   const unsigned char* image(int b) const { return gray[b]; } };
 }
 extern "C" void chk_mvs_propagate_column(int rows, int cols, int half_window, int step, const unsigned char* ref_gray, int n_neighbors,
                                          const unsigned char* const* nei_gray, const float* R_nr, const float* t_nr, float* depth, float* normal, float* conf,
