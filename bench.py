@@ -18,6 +18,7 @@ Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
 (one rank per GPU).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -943,29 +944,39 @@ def panorama_block(ctx, pv, torch, dev, with_votes=True):
     lines = rng.uniform([0, 0, 0, 0], [cols, rows, cols, rows], size=(200, 4)).astype(np.float32)
     pairs = 454 * 3
     T = np.eye(4)
-    ctx.cam_lidar_votes_batch(rows, cols, [lines] * 8, [dscan] * 8, [T] * 8)       # code objects loaded, staging sized
+    ctx.cam_lidar_votes_batch_sparse(rows, cols, [lines] * 8, [dscan] * 8, [T] * 8)       # code objects loaded, staging sized
     ctx.profile_enable(True)
     t0 = time.perf_counter()
-    votes = ctx.cam_lidar_votes_batch(rows, cols, [lines] * pairs, [dscan] * pairs, [T] * pairs)
+    voff, nz_index, nz_count = ctx.cam_lidar_votes_batch_sparse(rows, cols, [lines] * pairs, [dscan] * pairs, [T] * pairs)
     wall = time.perf_counter() - t0
     k8_ms, k8_n = ctx.profile_read(3)
     ctx.profile_enable(False)
     tests_n = pairs * len(lines) * len(scan["corner_local"])
-    # K8's roof is instruction issue, not bytes (1500 points x 200 lines per pair stay in L2): static mix of k_cam_lidar_votes_batch up to and
-    # including the first angle test (llvm-objdump of csrc/pvlm_lines.hip, round 4): ~200 fp32 / integer VALU (4 cycles per wave64) + ~180 fp64
-    # VALU (8 cycles: fp64 is half rate on gfx950) per wave of 64 tests = 35 cycles per test and SIMD; 1024 SIMDs x 2.4 GHz
-    cycles_per_test = (200 * 4 + 180 * 8) / 64.0
-    roof = 1024 * 2.4e9 / cycles_per_test / 1e9
+    # K8 has no HBM term (1500 points x 200 lines per pair are re-read from L2): its roof is VALU issue.  One wave64 VALU instruction occupies its
+    # SIMD for 4 cycles (measured on these kernels, profiles/r5_assoc_variants.txt: 4.3-4.5 cycles per instruction at >= 90 % busy) -> 1024 SIMDs x
+    # 2.4 GHz / 4 = 614 G wave instructions per second at most; `valu_per_test` and `simd_valu_busy` come from the SQ counters of the kernel
+    # (rocprofv3 --pmc pass of this block: SQ_INSTS_VALU / tests, SQ_INSTS_VALU x 4 / (1024 x kernel time x 2.4 GHz)), not from its source.
+    pmc = {}
+    try:
+        src = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_k8.json")))[-1]
+        pmc = json.load(open(src)); pmc["source"] = "profiles/" + os.path.basename(src)
+    except Exception:
+        pmc = {"source": None}
+    kernel_ms = k8_ms / max(k8_n, 1)
+    roof = None
+    if pmc.get("valu_wave_insts_per_test"):
+        peak = 1024 * 2.4e9 / 4.0 / pmc["valu_wave_insts_per_test"] / 1e9
+        roof = {"bound": "VALU issue: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction", "valu_wave_insts_per_test": pmc["valu_wave_insts_per_test"],
+                "G_tests_per_s": peak, "frac": tests_n / max(k8_ms, 1e-9) / 1e6 / peak, "counters": pmc}
     out["cam_lidar_votes"] = {"pairs": pairs, "image_lines": len(lines), "corner_points": int(len(scan["corner_local"])), "segments": int(dscan.n_segments),
                               "point_line_tests": int(tests_n), "wall_s_incl_copies": wall, "G_tests_per_s_incl_copies": tests_n / wall / 1e9,
-                              "kernel_ms": k8_ms / max(k8_n, 1), "G_tests_per_s_kernel": tests_n / max(k8_ms, 1e-9) / 1e6,
-                              "roof": {"bound": "VALU issue (fp64 half rate); no HBM term: the pair's points and line table are re-read from L2",
-                                       "cycles_per_test_and_simd": cycles_per_test, "G_tests_per_s": roof,
-                                       "frac": tests_n / max(k8_ms, 1e-9) / 1e6 / roof,
-                                       "note": "tests that leave at the 15 m range test or have no segment cost less than the modelled path: the fraction can exceed 1 on easy inputs"},
+                              "c_abi_call_s": getattr(ctx, "last_call_s", None), "call_over_kernel": getattr(ctx, "last_call_s", 0.0) * 1e3 / max(k8_ms, 1e-9),
+                              "kernel_ms": kernel_ms, "G_tests_per_s_kernel": tests_n / max(k8_ms, 1e-9) / 1e6,
+                              "roof": roof,
                               "wall_over_kernel": wall * 1e3 / max(k8_ms, 1e-9),
-                              "wall_is": "host line tables (272 400 rows) + descriptors + 43 MB of vote blocks copied back + the Python lists of this tool",
-                              "votes_cast": int(sum(int(v.sum()) for v in votes))}
+                              "wall_is": "host line tables (272 400 rows, 16 host threads) + descriptors + the voting kernel + two small kernels that compact the "
+                                         "non-zero counters + their read-back (pvlm_cam_lidar_votes_batch_sparse); round 4 copied 43 MB of dense blocks back",
+                              "dense_counters": int(voff[-1]), "nonzero_counters": int(len(nz_index)), "votes_cast": int(nz_count.sum())}
     dscan.close()
     return out
 

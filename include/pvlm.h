@@ -528,6 +528,14 @@ pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int
                                        const float* lines, pvlm_scan* const* lidar_local, const double* T_cl_rowmajor16,
                                        int64_t* vote_offsets, int32_t* votes, int64_t capacity);
 
+/* The same launch with the votes returned SPARSE: a few per cent of the counters are non-zero (43 MB of dense blocks for the 1 362 pairs of a Room
+ * sequence).  vote_offsets as above (the dense layout the indices refer to); nz_index[k] = dense position of the k-th non-zero counter (ascending:
+ * pair by pair, line by line, segment by segment), nz_count[k] = its value; *n_nz = how many there are.  capacity = room in nz_index / nz_count:
+ * PVLM_ERR_CAPACITY when it is too small (*n_nz is set: call again). */
+pvlm_status pvlm_cam_lidar_votes_batch_sparse(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,
+                                              pvlm_scan* const* lidar_local, const double* T_cl_rowmajor16, int64_t* vote_offsets, int64_t* nz_index,
+                                              int32_t* nz_count, int64_t capacity, int64_t* n_nz);
+
 /* ---- LiDAR feature extraction, range-image stages ------------------------------------------------------- *
  * The per-point / per-ring stages in front of the association, for a BATCH of raw scans in one go (the reference runs them scan by
  * scan under `omp parallel for`, lidar_mapping/LidarOdometry.cpp:131-147):

@@ -7,6 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 POINT2PLANE_METER, POINT2PLANE_ANGLE, POINT2LINE_METER, POINT2LINE_ANGLE, PLANE2PLANE_GLOBAL, PLANE_IOU = range(6)
+ERR_CAPACITY = -5            # pvlm_status PVLM_ERR_CAPACITY
 FLAG_NORMALIZE_DISTANCE = 1
 LOSS_NONE, LOSS_HUBER = 0, 1
 PAIR_BLOCK = 121
@@ -22,7 +23,7 @@ ABI_SYMBOLS = [
     "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_upload_batch", "pvlm_scan_destroy",
     "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
-    "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch",
+    "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_cam_lidar_votes_batch", "pvlm_cam_lidar_votes_batch_sparse",
     "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate", "pvlm_mvs_propagate_sequential", "pvlm_mvs_views_estimate_sequential", "pvlm_mvs_views_estimate_sequential_batch", "pvlm_mvs_views_create", "pvlm_mvs_views_destroy", "pvlm_mvs_views_upload", "pvlm_mvs_views_download",
     "pvlm_mvs_views_snapshot_depth", "pvlm_mvs_views_estimate", "pvlm_mvs_views_filter_refine",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
@@ -402,6 +403,32 @@ class Context:
         votes = np.zeros(max(int(voff[-1]), 1), np.int32)
         self._check(self.lib.pvlm_cam_lidar_votes_batch(*args, _p(votes, C.c_int32), C.c_int64(len(votes))), "pvlm_cam_lidar_votes_batch")
         return [votes[voff[p]:voff[p + 1]].reshape(len(ls[p]), lidar_scans[p].n_segments) for p in range(n)]
+
+    def cam_lidar_votes_batch_sparse(self, rows, cols, lines_list, lidar_scans, T_cl_list):
+        """The same launch, the votes returned sparse: (vote_offsets [n + 1], nz_index, nz_count) — the non-zero counters of the dense
+        layout in ascending position (pvlm_cam_lidar_votes_batch_sparse)."""
+        n = len(lidar_scans)
+        assert len(lines_list) == n and len(T_cl_list) == n
+        ls = [_f32(l).reshape(-1, 4) for l in lines_list]
+        off = _i64(np.concatenate([[0], np.cumsum([len(l) for l in ls])]))
+        flat = _f32(np.concatenate(ls) if n and off[-1] else np.zeros((0, 4)))
+        T = _f64(np.array([np.asarray(t, np.float64).reshape(16) for t in T_cl_list]).reshape(-1))
+        hs = (C.c_void_p * max(n, 1))(*[s._h for s in lidar_scans])
+        voff = np.zeros(n + 1, np.int64)
+        nnz = C.c_int64(0)
+        cap = max(1, int(sum(len(l) for l in ls)) * 4)          # a line rarely collects votes for more than a few segments
+        import time as _time
+        while True:
+            idx = np.empty(cap, np.int64); cnt = np.empty(cap, np.int32)
+            t0 = _time.perf_counter()
+            rc = self.lib.pvlm_cam_lidar_votes_batch_sparse(self._h, C.c_int(n), C.c_int(rows), C.c_int(cols), _p(off, C.c_int64), _p(flat, C.c_float), hs,
+                                                             _p(T, C.c_double), _p(voff, C.c_int64), _p(idx, C.c_int64), _p(cnt, C.c_int32), C.c_int64(cap), C.byref(nnz))
+            self.last_call_s = _time.perf_counter() - t0      # the C ABI call alone (the lists above are this wrapper's)
+            if rc == ERR_CAPACITY and nnz.value > cap:
+                cap = int(nnz.value)
+                continue
+            self._check(rc, "pvlm_cam_lidar_votes_batch_sparse")
+            return voff, idx[:nnz.value], cnt[:nnz.value]
 
     # --- association -------------------------------------------------------------------------------
     def knn(self, scan, queries, k, max_dist, which=0):

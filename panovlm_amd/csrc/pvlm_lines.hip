@@ -3,13 +3,17 @@
 // loop of CameraLidarLineAssociate::AssociateByAngle (joint_optimization/
 // CameraLidarLineAssociate.cpp:394-426).  Compiled with -ffp-contract=off: every threshold test
 // must take the same branch as a non-FMA x86-64 build of the reference.
+#include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include "pvlm_internal.h"
+#include "pvlm_workers.h"
 #include "pvlm_exact_math.h"
 
 // ---- K4 -----------------------------------------------------------------------------------------
@@ -423,6 +427,41 @@ __global__ __launch_bounds__(256) void k_cam_lidar_votes_batch(int n_pairs, cons
   cam_vote_one(d->xyz, d->p2s_off, d->p2s_ids, i, li, line_tab + 8 * (d->tab_off + li), d->T, d->n_seg, angle_thr, votes + d->vote_off);
 }
 
+// Sparse read-back of a vote buffer: of the n_lines x n_segments counters of a pair a few per cent are non-zero (43 MB of dense blocks for
+// the 1 362 pairs of a Room sequence).  Tile = 4096 consecutive counters, 16 per thread: k_votes_count leaves the non-zeros per tile, the host
+// turns them into offsets, k_votes_emit writes (dense index, count) in dense order — the order the host walks the pairs in.
+#define PVLM_NZ_TILE 4096
+__global__ __launch_bounds__(256) void k_votes_count(long long n, const int* __restrict__ votes, int* __restrict__ tile_count) {
+  const long long base = (long long)blockIdx.x * PVLM_NZ_TILE + threadIdx.x * 16;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) c += (base + k < n && votes[base + k] != 0) ? 1 : 0;
+  __shared__ int s[256];
+  s[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(256) void k_votes_emit(long long n, const int* __restrict__ votes, const long long* __restrict__ tile_off, long long* __restrict__ nz_index,
+                                                    int* __restrict__ nz_count) {
+  const long long base = (long long)blockIdx.x * PVLM_NZ_TILE + threadIdx.x * 16;
+  int v[16], c = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { v[k] = base + k < n ? votes[base + k] : 0; c += v[k] != 0 ? 1 : 0; }
+  __shared__ int s[256];
+  s[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {            // inclusive scan of the per-thread counts
+    const int add = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += add;
+    __syncthreads();
+  }
+  long long o = tile_off[blockIdx.x] + s[threadIdx.x] - c;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) if (v[k] != 0) { nz_index[o] = base + k; nz_count[o] = v[k]; ++o; }
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 namespace {
 template <typename T> struct HostEq {
@@ -741,16 +780,37 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
   return PVLM_OK;
 }
 
-pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,
-                                       pvlm_scan* const* lidar_local, const double* T_cl, int64_t* vote_offsets, int32_t* votes, int64_t capacity) {
-  if (!ctx || n_pairs < 0 || !vote_offsets || rows <= 0 || cols <= 0 || (n_pairs > 0 && (!line_offsets || !lidar_local || !T_cl))) return PVLM_ERR_ARG;
-  std::vector<pvlm_cam_pair_desc> desc((size_t)n_pairs);
-  std::vector<long long> work_off((size_t)n_pairs + 1, 0);
-  long long nv = 0;
-  const long long n_lines_total = n_pairs > 0 ? line_offsets[n_pairs] : 0;
-  if (n_lines_total > 0 && !lines) return PVLM_ERR_ARG;
+// descriptors, work offsets and vote offsets of a batch of (frame, LiDAR) pairs; false: bad arguments
+// Line blocks with the same content get ONE set of table rows: every frame meets its three neighbouring scans with the same image lines
+// (AssociateLineMulti: 1 362 pairs, 454 distinct blocks).  Rewrites desc[p].tab_off to rows of the reduced table and returns the line ranges to build.
+static void cam_dedupe_lines(int n_pairs, const int64_t* line_offsets, const float* lines, std::vector<pvlm_cam_pair_desc>& desc,
+                             std::vector<std::pair<long long, long long>>& build /* (first line, count) */) {
+  std::unordered_map<unsigned long long, std::vector<int>> seen;     // content hash -> pairs that introduced a block with it
+  long long rows = 0;
+  build.clear();
+  std::vector<long long> first_row((size_t)n_pairs, 0);
   for (int p = 0; p < n_pairs; ++p) {
-    if (!lidar_local[p] || line_offsets[p + 1] < line_offsets[p]) return PVLM_ERR_ARG;
+    const long long a = line_offsets[p], n = line_offsets[p + 1] - a;
+    if (n <= 0) { desc[p].tab_off = 0; continue; }
+    const unsigned char* bytes = reinterpret_cast<const unsigned char*>(lines + 4 * a);
+    unsigned long long h = 1469598103934665603ull ^ (unsigned long long)n;
+    for (size_t k = 0; k < (size_t)n * 16; k += 8) { unsigned long long w; std::memcpy(&w, bytes + k, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
+    std::vector<int>& cand = seen[h];
+    int same = -1;
+    for (int q : cand)
+      if (line_offsets[q + 1] - line_offsets[q] == n && std::memcmp(lines + 4 * line_offsets[q], lines + 4 * a, (size_t)n * 16) == 0) { same = q; break; }
+    if (same >= 0) { first_row[(size_t)p] = first_row[(size_t)same]; }
+    else { cand.push_back(p); first_row[(size_t)p] = rows; build.emplace_back(a, n); rows += n; }
+    desc[p].tab_off = first_row[(size_t)p];
+  }
+}
+static bool cam_batch_plan(int n_pairs, const int64_t* line_offsets, pvlm_scan* const* lidar_local, const double* T_cl, std::vector<pvlm_cam_pair_desc>& desc,
+                           std::vector<long long>& work_off, int64_t* vote_offsets, long long* n_votes) {
+  desc.assign((size_t)n_pairs, pvlm_cam_pair_desc());
+  work_off.assign((size_t)n_pairs + 1, 0);
+  long long nv = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    if (!lidar_local[p] || line_offsets[p + 1] < line_offsets[p]) return false;
     pvlm_cam_pair_desc& d = desc[p];
     const pvlm_scan* l = lidar_local[p];
     d.xyz = l->corner.d_xyz; d.p2s_off = l->d_p2s_off; d.p2s_ids = l->d_p2s_ids;
@@ -763,18 +823,115 @@ pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int
     work_off[p + 1] = work_off[p] + (long long)d.n_pts * d.n_lines;
   }
   vote_offsets[n_pairs] = nv;
+  *n_votes = nv;
+  return true;
+}
+// the per-line constants of every image line of the batch: host fp64 (the libm the reference was built on), rows shared out over the host threads
+// (272 400 rows for a Room sequence: 13 ms on one thread)
+static void cam_line_tables(int rows, int cols, const float* lines, const std::vector<std::pair<long long, long long>>& build, std::vector<double>& tab) {
+  std::vector<long long> src;                       // table row -> line
+  for (const auto& b : build) for (long long k = 0; k < b.second; ++k) src.push_back(b.first + k);
+  const long long n_rows = (long long)src.size();
+  tab.resize((size_t)n_rows * 8);
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)(n_rows / 4096 + 1), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  std::atomic<long long> next{0};
+  auto work = [&]() {
+    for (long long b = next.fetch_add(1024); b < n_rows; b = next.fetch_add(1024))
+      for (long long r = b; r < std::min(n_rows, b + 1024); ++r) line_table_row(rows, cols, lines + 4 * src[(size_t)r], &tab[8 * (size_t)r]);
+  };
+  pvlm_run_workers(n_threads, work);
+}
+static void cam_launch(pvlm_ctx* c, int np, const pvlm_cam_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
+  pvlm_prof_scope prof(c, 3);
+  hipLaunchKernelGGL(k_cam_lidar_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl, 3.0 / 180.0 * M_PI, dv);
+}
+
+pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,
+                                       pvlm_scan* const* lidar_local, const double* T_cl, int64_t* vote_offsets, int32_t* votes, int64_t capacity) {
+  if (!ctx || n_pairs < 0 || !vote_offsets || rows <= 0 || cols <= 0 || (n_pairs > 0 && (!line_offsets || !lidar_local || !T_cl))) return PVLM_ERR_ARG;
+  std::vector<pvlm_cam_pair_desc> desc;
+  std::vector<long long> work_off;
+  long long nv = 0;
+  const long long n_lines_total = n_pairs > 0 ? line_offsets[n_pairs] : 0;
+  if (n_lines_total > 0 && !lines) return PVLM_ERR_ARG;
+  if (!cam_batch_plan(n_pairs, line_offsets, lidar_local, T_cl, desc, work_off, vote_offsets, &nv)) return PVLM_ERR_ARG;
   if (!votes) return PVLM_OK;
   if (capacity < nv) { PVLM_SET_ERR(ctx, "pvlm_cam_lidar_votes_batch: %lld votes do not fit the capacity %lld", nv, (long long)capacity); return PVLM_ERR_CAPACITY; }
   if (nv == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  std::vector<double> tab((size_t)n_lines_total * 8);
-  for (long long li = 0; li < n_lines_total; ++li) line_table_row(rows, cols, lines + 4 * li, &tab[8 * (size_t)li]);
-  return run_vote_batch(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes,
-      [](pvlm_ctx* c, int np, const pvlm_cam_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
-        pvlm_prof_scope prof(c, 3);
-        hipLaunchKernelGGL(k_cam_lidar_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl,
-                           3.0 / 180.0 * M_PI, dv);
-      });
+  std::vector<double> tab;
+  std::vector<std::pair<long long, long long>> build;
+  cam_dedupe_lines(n_pairs, line_offsets, lines, desc, build);
+  cam_line_tables(rows, cols, lines, build, tab);
+  return run_vote_batch(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes, cam_launch);
+}
+
+pvlm_status pvlm_cam_lidar_votes_batch_sparse(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,
+                                              pvlm_scan* const* lidar_local, const double* T_cl, int64_t* vote_offsets, int64_t* nz_index, int32_t* nz_count,
+                                              int64_t capacity, int64_t* n_nz) {
+  if (!ctx || n_pairs < 0 || !vote_offsets || !n_nz || capacity < 0 || (capacity > 0 && (!nz_index || !nz_count)) || rows <= 0 || cols <= 0 ||
+      (n_pairs > 0 && (!line_offsets || !lidar_local || !T_cl)))
+    return PVLM_ERR_ARG;
+  *n_nz = 0;
+  std::vector<pvlm_cam_pair_desc> desc;
+  std::vector<long long> work_off;
+  long long nv = 0;
+  const long long n_lines_total = n_pairs > 0 ? line_offsets[n_pairs] : 0;
+  if (n_lines_total > 0 && !lines) return PVLM_ERR_ARG;
+  if (!cam_batch_plan(n_pairs, line_offsets, lidar_local, T_cl, desc, work_off, vote_offsets, &nv)) return PVLM_ERR_ARG;
+  if (nv == 0 || work_off[n_pairs] == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  std::vector<double> tab;
+  std::vector<std::pair<long long, long long>> build;
+  cam_dedupe_lines(n_pairs, line_offsets, lines, desc, build);
+  cam_line_tables(rows, cols, lines, build, tab);
+  const long long tiles = (nv + PVLM_NZ_TILE - 1) / PVLM_NZ_TILE;
+  pvlm_cam_pair_desc* d_desc = nullptr; long long* d_work = nullptr; double* d_tab = nullptr; int* d_v = nullptr; int* d_tc = nullptr; long long* d_to = nullptr;
+  long long* d_ni = nullptr; int* d_nc = nullptr;
+  std::vector<int> tile_count((size_t)tiles);
+  std::vector<long long> tile_off((size_t)tiles);
+  pvlm_status st = pvlm_i_alloc(ctx, &d_desc, desc.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_work, work_off.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_tab, tab.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)nv);
+  if (!st) st = pvlm_i_alloc(ctx, &d_tc, (size_t)tiles);
+  if (!st) st = pvlm_i_alloc(ctx, &d_to, (size_t)tiles);
+  long long total = 0;
+  if (!st) {
+    st = pvlm_i_h2d_q(ctx, d_desc, desc.data(), desc.size() * sizeof(pvlm_cam_pair_desc));
+    if (!st) st = pvlm_i_h2d_q(ctx, d_work, work_off.data(), work_off.size() * sizeof(long long));
+    if (!st) st = pvlm_i_h2d_q(ctx, d_tab, tab.data(), tab.size() * sizeof(double));
+    hipError_t e = st ? hipSuccess : hipMemsetAsync(d_v, 0, (size_t)nv * sizeof(int), ctx->stream);
+    if (!st && e == hipSuccess) {
+      cam_launch(ctx, n_pairs, d_desc, d_work, work_off[n_pairs], d_tab, d_v);
+      hipLaunchKernelGGL(k_votes_count, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, nv, d_v, d_tc);
+      e = hipGetLastError();
+    }
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "batched votes: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (!st) st = pvlm_i_d2h_q(ctx, tile_count.data(), d_tc, (size_t)tiles * sizeof(int));
+    if (!st) st = pvlm_i_sync(ctx);
+    if (!st) {
+      for (long long t = 0; t < tiles; ++t) { tile_off[(size_t)t] = total; total += tile_count[(size_t)t]; }
+      *n_nz = total;
+      if (total > capacity) { PVLM_SET_ERR(ctx, "pvlm_cam_lidar_votes_batch_sparse: %lld non-zero votes do not fit the capacity %lld", total, (long long)capacity); st = PVLM_ERR_CAPACITY; }
+    }
+    if (!st && total > 0) {
+      st = pvlm_i_alloc(ctx, &d_ni, (size_t)total);
+      if (!st) st = pvlm_i_alloc(ctx, &d_nc, (size_t)total);
+      if (!st) st = pvlm_i_h2d_q(ctx, d_to, tile_off.data(), (size_t)tiles * sizeof(long long));
+      if (!st) {
+        hipLaunchKernelGGL(k_votes_emit, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, nv, d_v, d_to, d_ni, d_nc);
+        if (hipGetLastError() != hipSuccess) { PVLM_SET_ERR(ctx, "batched votes: emit launch failed"); st = PVLM_ERR_HIP; }
+      }
+      static_assert(sizeof(long long) == sizeof(int64_t), "index width");
+      if (!st) st = pvlm_i_d2h_q(ctx, nz_index, d_ni, (size_t)total * sizeof(int64_t));
+      if (!st) st = pvlm_i_d2h_q(ctx, nz_count, d_nc, (size_t)total * sizeof(int32_t));
+    }
+  }
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+  pvlm_i_free(ctx, d_desc); pvlm_i_free(ctx, d_work); pvlm_i_free(ctx, d_tab); pvlm_i_free(ctx, d_v); pvlm_i_free(ctx, d_tc); pvlm_i_free(ctx, d_to);
+  pvlm_i_free(ctx, d_ni); pvlm_i_free(ctx, d_nc);
+  return st;
 }
 
 pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm_scan* nei, float dist_threshold, int32_t* votes) {

@@ -100,6 +100,14 @@ def test_cam_lidar_votes(ctx, oracle):
         assert g.shape == (len(l), dscan.n_segments)
         if len(l):
             assert np.array_equal(g, ctx.cam_lidar_votes(rows, cols, l, dscan, Tj))
+    # sparse read-back of the same launch: the non-zero counters, in dense order
+    voff, nzi, nzc = ctx.cam_lidar_votes_batch_sparse(rows, cols, [j[0] for j in jobs], [dscan] * len(jobs), [j[1] for j in jobs])
+    dense = np.concatenate([g.reshape(-1) for g in got])
+    assert voff[-1] == len(dense) and np.array_equal(np.diff(voff), [g.size for g in got])
+    assert np.array_equal(nzi, np.flatnonzero(dense)) and np.array_equal(nzc, dense[dense != 0])
+    many = ctx.cam_lidar_votes_batch_sparse(rows, cols, [lines] * 40, [dscan] * 40, [T] * 40)       # more than one tile of counters
+    one = got[0].reshape(-1)
+    assert np.array_equal(many[1], np.concatenate([np.flatnonzero(one) + k * one.size for k in range(40)])) and np.array_equal(many[2], np.tile(one[one != 0], 40))
     dscan.close()
 
 
