@@ -2,6 +2,7 @@
 the REAL reference header (oracle/_ref, compiled from /root/reference/base/Math.h)."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -172,3 +173,39 @@ def test_refvec_container_round_trip(tmp_path):
         rv.write_pvv(os.path.join(str(tmp_path), fx + ".ref.pvv"),
                      {k: z[k] for k in z.files if rv._is_output(fx, k) and not rv.is_internal(fx, k)})
     assert rv.compare(str(tmp_path)) == 0
+
+
+def test_repin_kit_one_command(tmp_path):
+    """`make repin REFERENCE=...` (the one command of tools/repin/README.md) as a dry run: it must name the reference's own build, the dump tool,
+    the regeneration of the fixtures and the CPU suite; `refvec.py table` must cover every fixture; `regenerate` must rewrite exactly the
+    expected-output arrays (fed here with the fixtures' own expectations standing in for a reference run) and tag the files."""
+    import importlib.util, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "PanoVLM" / "base"
+    fake.mkdir(parents=True)
+    (fake / "CostFunction.h").write_text("// stand-in for the dry run\n")
+    out = subprocess.run(["make", "-n", "repin", "REFERENCE=" + str(tmp_path / "PanoVLM")], cwd=root, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    for needle in ("cmake -S \"%s\"" % (tmp_path / "PanoVLM"), "cmake -S tools/repin", "--target repin_regenerate", "refvec.py table", "pytest tests -q -m \"not gpu\""):
+        assert needle in out.stdout, (needle, out.stdout)
+    bad = subprocess.run(["make", "repin"], cwd=root, capture_output=True, text=True)
+    assert bad.returncode != 0 and "usage: make repin REFERENCE=" in bad.stdout
+    spec = importlib.util.spec_from_file_location("refvec", os.path.join(root, "tools", "refvec.py"))
+    rv = importlib.util.module_from_spec(spec); spec.loader.exec_module(rv)
+    assert set(rv.PINS) == set(rv.FIXTURES)
+    tab = subprocess.run([sys.executable, os.path.join(root, "tools", "refvec.py"), "table"], capture_output=True, text=True).stdout
+    for fx in rv.FIXTURES:
+        assert "`%s.npz`" % fx in tab
+    pvv = tmp_path / "pvv"; gold = tmp_path / "golden"
+    rv.export(str(pvv))
+    for fx in rv.FIXTURES:                      # a "reference run" that returns what the fixtures expect
+        z = np.load(os.path.join(rv.GOLDEN, fx + ".npz"))
+        rv.write_pvv(str(pvv / (fx + ".ref.pvv")), {k: z[k] for k in z.files if rv._is_output(fx, k) and not rv.is_internal(fx, k)})
+    assert rv.compare(str(pvv)) == 0
+    assert rv.regenerate(str(pvv), str(gold), "PanoVLM deadbeef") == 0
+    for fx in rv.FIXTURES:
+        a, b = np.load(os.path.join(rv.GOLDEN, fx + ".npz")), np.load(str(gold / (fx + ".npz")))
+        assert str(b["__pinned__"][0]) == "PanoVLM deadbeef"
+        assert set(a.files) | {"__pinned__"} == set(b.files)
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (fx, k)
