@@ -544,8 +544,11 @@ def main():
                                 ", RCCL all-reduce of %d doubles per step" % neq.size if world > 1 else ""),
                 "mode": "fused-normal-equations", "functor": args.functor, "targets": args.targets, "scans": F, "pairs": int(len(ref_all)),
                 "points_per_scan": 16 * args.cols, "residual_blocks": n_total, "robust_cost": cost},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "traffic_provenance": traffic_stamp,
+            "roofline": {"bound": "hbm", "frac": achieved / HBM_PEAK_GBPS,
+                         # the same kernel on SURVEY.md §8(d)'s LITERAL workload (every one of the 65 536 points a target: 94 % of the queries are
+                         # rejected by the reference's collinearity test, the surviving segments are short) — measured below in this same run
+                         "frac_literal_workload": (((extra_assoc or {}).get("raw_targets") or {}).get("fused") or {}).get("frac_of_hbm_peak"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "traffic_provenance": traffic_stamp,
                          "algorithmic_bytes_per_launch": n_local * bytes_per_eval,
                          "kernel": "k_eval_fused", "kernel_avg_ms": kern_ms / max(kern_n, 1), "launches": kern_n,
                          "bytes_per_eval": bytes_per_eval, "evals_per_launch": n_local,
@@ -553,9 +556,6 @@ def main():
                          "frac_of_64B_ceiling": (n_local / k_avg_s) / (HBM_PEAK_GBPS * 1e9 / 64),
                          "ceiling_M_evals_per_s_64B": HBM_PEAK_GBPS * 1e9 / 64 / 1e6,
                          "ceiling_M_evals_per_s_56B": HBM_PEAK_GBPS * 1e9 / 56 / 1e6,
-                         # the same kernel on SURVEY.md §8(d)'s LITERAL workload (every one of the 65 536 points a target: 94 % of the queries are
-                         # rejected by the reference's collinearity test, the surviving segments are short) — measured below in this same run
-                         "frac_literal_workload": (((extra_assoc or {}).get("raw_targets") or {}).get("fused") or {}).get("frac_of_hbm_peak"),
                          "literal_workload": "association.raw_targets.fused: %s" % ((((extra_assoc or {}).get("raw_targets") or {}).get("fused") or {}).get("what"))},
             "association": association_block(n_queries, n_targets, n_local, int(len(ref)), assoc_ms, assoc_n, t_assoc, t_assoc_first, assoc_ms_first,
                                              allocs_first, allocs_steady, t_res, reserve_bytes, ctx.mem_info(), extra_assoc),
@@ -608,7 +608,7 @@ def association_block(n_queries, n_targets, accepted, pairs, kernel_ms, launches
            "output_bytes": accepted * 56, "scratch_bytes_per_query": 97}
     # counter evidence for K2 / K3 (separate rocprofv3 --pmc passes of this command, summarised by tools/pmc_assoc.py)
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_assoc*.json"))):      # the latest round's summary wins
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_assoc_voxel*.json"))):      # the latest round's summary wins
         try:
             pm = json.load(open(f))
             # per-query figures: collected on the same generator at --scans 256 (134 M queries); they do not depend on the batch size
@@ -616,9 +616,45 @@ def association_block(n_queries, n_targets, accepted, pairs, kernel_ms, launches
                           "kernels": {k: {n: v for n, v in e.items() if n not in ("per_call", "dispatches_per_call")} for k, e in pm["kernels"].items()}}
         except Exception:
             pass
+    out["kernel"] = "k_knn_pairs + k_fit_pairs (the ordered compaction runs inside k_fit_pairs since round 5; round 4's kernel figure left k_compact, 282 us per 16.7 M queries, out)"
+    out["roof"] = association_roof(out.get("pmc"), out["M_queries_per_s_kernel"], "voxel")
     if extra:
         out.update(extra)
+        if isinstance(out.get("raw_targets"), dict):
+            raw_pmc = None
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_assoc_raw*.json"))):
+                try:
+                    pm = json.load(open(f)); raw_pmc = {"source": os.path.relpath(f, ROOT), "kernels": pm["kernels"]}
+                except Exception:
+                    pass
+            out["raw_targets"]["roof"] = association_roof(raw_pmc, out["raw_targets"].get("M_queries_per_s_kernel"), "raw")
     return out
+
+
+def association_roof(pmc, achieved_M_queries, which):
+    """Roof of the association kernels: VALU issue.  Hardware side: a SIMD issues one wave64 VALU instruction per 4 cycles (measured on these
+    kernels at > 90 % busy: 4.3-4.5 cycles, profiles/r5_assoc_variants.txt) -> 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave instructions per second.
+    Kernel side: the wave instructions per 64 queries the SQ counters report (SQ_INSTS_VALU / SQ_WAVES, separate --pmc pass of
+    tools/assoc_workload.py).  `frac` = achieved queries/s over the rate at which those instructions could issue; `lane_efficiency` (host
+    lockstep statistics of the same search, tools/assoc_lockstep.py) = the share of K2's insertion-network executions a lane needs for itself."""
+    issue = 1024 * 2.4e9 / 4.0
+    roof = {"bound": "VALU issue", "wave_insts_per_s_peak": issue, "cycles_per_wave_instruction": 4}
+    try:
+        ks = pmc["kernels"]
+        per_wave = sum(v["valu_insts_per_query"] for k, v in ks.items() if k.startswith(("k_knn", "k_fit", "k_compact")))
+        roof["valu_wave_insts_per_64_queries"] = {k: v["valu_insts_per_query"] for k, v in ks.items()}
+        roof["M_queries_per_s_at_full_issue"] = issue * 64 / per_wave / 1e6
+        roof["frac"] = achieved_M_queries / roof["M_queries_per_s_at_full_issue"] if achieved_M_queries else None
+        roof["counters_from"] = pmc.get("source")
+    except Exception:
+        roof["frac"] = None
+    try:
+        ls = json.load(open(os.path.join(ROOT, "profiles", "r5_assoc_lockstep.json")))[which]
+        roof["lane_efficiency"] = ls["lane_efficiency"]
+        roof["candidates_per_query"] = ls["candidates_per_query"]; roof["network_executions_per_query"] = ls["network_executions_per_query"]
+    except Exception:
+        roof["lane_efficiency"] = None
+    return roof
 
 
 def per_rank_projection(ctx, pv, torch, sharding, args, associate, make_step, ref_all, nei_all, F, ui, uj, dev, ms_full, k6_full_ms, neq_size):
@@ -807,6 +843,22 @@ def mvs_block(ctx, pv):
                                   for k, v in pmc.items() if "k_mvs_conf" in k or "k_mvs_propagate" in k}}
     except Exception:
         out["pmc"] = None
+    # counter-based roof: wave VALU instructions per pixel (SQ_INSTS_VALU of the pass above / pixels) against the rate a SIMD issues them at
+    # (one wave64 instruction per 4 cycles, 1024 SIMDs x 2.4 GHz); `frac` = achieved pixels/s over the pixels/s at full issue
+    try:
+        issue = 1024 * 2.4e9 / 4.0
+        roof = {"bound": "VALU issue", "wave_insts_per_s_peak": issue, "kernels": {}}
+        small = out.get("1440x720") or {}
+        for kname, block in (("k_mvs_conf_lane", "k11_scoring_pass"), ("k_mvs_propagate_lane", "k13_patchmatch_iteration")):
+            hit = [v for k, v in pmc.items() if kname in k and v.get("valu_wave_insts_per_unit")]
+            if hit and block in small:
+                per_pixel = hit[0]["valu_wave_insts_per_unit"]                         # wave instructions per pixel (a wave holds 64 pixels)
+                full = issue / per_pixel / 1e6
+                roof["kernels"][kname] = {"valu_wave_insts_per_pixel": per_pixel, "M_pixels_per_s_at_full_issue": full,
+                                          "achieved_M_pixels_per_s": small[block]["M_pixels_per_s"], "frac": small[block]["M_pixels_per_s"] / full}
+        out["roof"] = roof
+    except Exception:
+        out["roof"] = None
     return out
 
 
@@ -899,6 +951,12 @@ def features_block(ctx, pv, scans=454, cols=1800):
            "device_ms_per_batch": device_ms, "stage_ms": tm, "copies_ms": tm["upload"] + tm["download"],
            "points_decided_by_host_libm_sampled": int(resolved), "kept_of_reordered_scan0": [int(kept), int(reordered)],
            "what": "ReOrderVLP + Segmentation + adaptive curvature (sensors/Velodyne.cpp:371-526, :1438-1586, :623-657); bit-exact vs the oracle: tests/test_ring_gpu.py"}
+    # roof of the batch: the host link.  The boundary hands over host buffers and takes host arrays back: 16 B per raw point up, 20 B per point down
+    # (DESIGN.md section 2), at the link rate the `pcie` block of this line measures (55.7 GB/s on this pool, 63 GB/s spec)
+    link = 55.7e9
+    moved = out["points"] * 36
+    out["roof"] = {"bound": "host link (PCIe Gen5 x16)", "bytes_per_point": 36, "bytes_per_batch": moved, "GBps_assumed": link / 1e9,
+                   "ms_at_link_rate": moved / link * 1e3, "frac": (moved / link * 1e3) / wall, "device_ms_share": device_ms / wall}
     try:
         from oracle import oracle as orc
         t0 = time.perf_counter()

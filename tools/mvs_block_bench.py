@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import panovlm_amd as pv
 ctx = pv.Context(0)
-out = bench.mvs_block(ctx, pv)
-out.pop("pmc", None)
+if "--small" in sys.argv:          # 1440 x 720 only (counter passes: one pixel count per kernel)
+    out = {"1440x720": bench.mvs_one_size(ctx, 720, 1440)}
+else:
+    out = bench.mvs_block(ctx, pv)
+    out.pop("pmc", None)
 print(json.dumps(out))
