@@ -345,6 +345,13 @@ pvlm_status pvlm_line2line_votes(pvlm_ctx* ctx, const pvlm_scan* ref, const pvlm
 pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei,
                                        float dist_threshold, int64_t* vote_offsets, int32_t* votes, int64_t capacity);
 
+/* The batched votes reduced on the device to what FindAssociations (LidarFeatureAssociate.cpp:126-133) reads first: per neighbour segment (row of the
+ * pair's n_nei_segments x n_ref_segments block) the reference segment with the most votes — the first of equals — and that count.  Rows of pair p:
+ * [row_offsets[p], row_offsets[p + 1]) (a pair whose reference scan has no segment has none); n_pairs + 1 offsets.  best_col / best_count null =
+ * sizing call; PVLM_ERR_CAPACITY if capacity (entries) < row_offsets[n_pairs]. */
+pvlm_status pvlm_line2line_best_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, float dist_threshold,
+                                      int64_t* row_offsets, int32_t* best_col, int32_t* best_count, int64_t capacity);
+
 /* Residual blocks of the line-to-line term, built on the device (the body of the innermost loops of
  * AddLidarLineToLineResidual2, util/Optimization.cpp:404-434): match m says that segment match_nei_seg[m] of scan
  * nei[match_pair[m]] was associated with segment match_ref_seg[m] of scan ref[match_pair[m]] (AssociateLine2Line +

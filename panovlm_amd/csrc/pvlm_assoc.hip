@@ -543,7 +543,7 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
       if (d->n_surf_less_flat > 0 && d->n_surf_less_flat <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_surf_less_flat, d->surf_less_flat_xyz, boxes[(size_t)k * 3 + 1]);
       if (d->n_corner > 0 && d->n_corner <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_corner, d->corner_xyz, boxes[(size_t)k * 3 + 2]);
     };
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)n_scans / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), (size_t)n_scans / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     std::atomic<int> next{0};
     auto work = [&]() { for (int k = next++; k < n_scans; k = next++) box_of(k); };
     pvlm_run_workers(n_threads, work);

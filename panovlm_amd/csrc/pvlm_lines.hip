@@ -70,6 +70,22 @@ __global__ __launch_bounds__(256) void k_line_votes_batch(int n_pairs, const pvl
   for (int k = d.p2s_off[i]; k < d.p2s_off[i + 1]; ++k) atomicAdd(&votes[d.vote_off + (long long)d.p2s_ids[k] * d.n_ref + s], 1);
 }
 
+// First statement of FindAssociations (lidar_mapping/LidarFeatureAssociate.cpp:126-133) on the device: per neighbour segment (a row of the pair's
+// vote block) the reference segment with the most votes — the first of equals, as `if (v > max)` keeps it — and that count.  One thread per row;
+// what goes back to the host is 8 bytes per neighbour segment instead of the block (70 MB of blocks for the 11 k pairs of a Floor sequence).
+struct pvlm_row_desc { long long vote_off; int n_ref; };
+__global__ __launch_bounds__(256) void k_line_row_best(int n_pairs, const pvlm_row_desc* __restrict__ desc, const long long* __restrict__ row_off, long long rows,
+                                                       const int* __restrict__ votes, int* __restrict__ best_col, int* __restrict__ best_count) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows) return;
+  const int p = find_pair(row_off, n_pairs, g);
+  const pvlm_row_desc d = desc[p];
+  const int* v = votes + d.vote_off + (g - row_off[p]) * d.n_ref;
+  int col = 0, cnt = d.n_ref > 0 ? v[0] : 0;
+  for (int c = 1; c < d.n_ref; ++c) { const int x = v[c]; if (x > cnt) { cnt = x; col = c; } }
+  best_col[g] = col; best_count[g] = cnt;
+}
+
 // ---- K4b: residual rows of the line-to-line term ---------------------------------------------------------------
 // One workgroup per match (a neighbour segment associated with a reference segment): thread i turns point i of the
 // neighbour segment into the SoA row [World2Local_nei(p) | A | unit(A - B)] of the Point2Line functors
@@ -692,6 +708,76 @@ pvlm_status pvlm_line2line_votes_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* co
       });
 }
 
+pvlm_status pvlm_line2line_best_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, float dist_threshold,
+                                      int64_t* row_offsets, int32_t* best_col, int32_t* best_count, int64_t capacity) {
+  if (!ctx || n_pairs < 0 || !row_offsets || (n_pairs > 0 && (!ref || !nei)) || ((best_col == nullptr) != (best_count == nullptr))) return PVLM_ERR_ARG;
+  std::vector<pvlm_line_pair_desc> desc((size_t)n_pairs);
+  std::vector<pvlm_row_desc> rdesc((size_t)n_pairs);
+  std::vector<long long> work_off((size_t)n_pairs + 1, 0), row_off((size_t)n_pairs + 1, 0);
+  std::vector<double> lines;
+  std::unordered_map<const pvlm_scan*, long long> line_off_of;
+  long long nv = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    if (!ref[p] || !nei[p]) return PVLM_ERR_ARG;
+    pvlm_line_pair_desc& d = desc[p];
+    d.xyz = nei[p]->corner.d_xyz; d.p2s_off = nei[p]->d_p2s_off; d.p2s_ids = nei[p]->d_p2s_ids;
+    d.n_pts = nei[p]->n_segments > 0 ? nei[p]->corner.n : 0; d.n_ref = ref[p]->n_segments;
+    d.vote_off = nv; d.work_off = work_off[p];
+    if (best_col) {
+      auto it = line_off_of.find(ref[p]);
+      if (it == line_off_of.end()) {
+        it = line_off_of.emplace(ref[p], (long long)lines.size() / 6).first;
+        lines.resize(lines.size() + (size_t)ref[p]->n_segments * 6);
+        world_lines(ref[p], lines.data() + (size_t)it->second * 6);
+      }
+      d.line_off = it->second;
+    }
+    rdesc[p].vote_off = nv; rdesc[p].n_ref = d.n_ref;
+    row_offsets[p] = row_off[p];
+    row_off[p + 1] = row_off[p] + (d.n_ref > 0 ? nei[p]->n_segments : 0);     // a pair without reference segments has no rows (FindAssociations: nr > 0)
+    nv += (long long)nei[p]->n_segments * ref[p]->n_segments;
+    work_off[p + 1] = work_off[p] + (long long)d.n_pts * d.n_ref;
+  }
+  const long long rows = row_off[n_pairs];
+  row_offsets[n_pairs] = rows;
+  if (!best_col) return PVLM_OK;                    // sizing call
+  if (capacity < rows) { PVLM_SET_ERR(ctx, "pvlm_line2line_best_batch: %lld rows do not fit the capacity %lld", rows, (long long)capacity); return PVLM_ERR_CAPACITY; }
+  if (rows == 0) return PVLM_OK;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_line_pair_desc* d_desc = nullptr; pvlm_row_desc* d_rdesc = nullptr; long long *d_work = nullptr, *d_row = nullptr; double* d_lines = nullptr;
+  int *d_v = nullptr, *d_col = nullptr, *d_cnt = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_desc, desc.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_rdesc, rdesc.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_work, work_off.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_row, row_off.size());
+  if (!st) st = pvlm_i_alloc(ctx, &d_lines, std::max<size_t>(lines.size(), 1));
+  if (!st) st = pvlm_i_alloc(ctx, &d_v, (size_t)std::max<long long>(nv, 1));
+  if (!st) st = pvlm_i_alloc(ctx, &d_col, (size_t)rows);
+  if (!st) st = pvlm_i_alloc(ctx, &d_cnt, (size_t)rows);
+  if (!st) {
+    st = pvlm_i_h2d_q(ctx, d_desc, desc.data(), desc.size() * sizeof(pvlm_line_pair_desc));
+    if (!st) st = pvlm_i_h2d_q(ctx, d_rdesc, rdesc.data(), rdesc.size() * sizeof(pvlm_row_desc));
+    if (!st) st = pvlm_i_h2d_q(ctx, d_work, work_off.data(), work_off.size() * sizeof(long long));
+    if (!st) st = pvlm_i_h2d_q(ctx, d_row, row_off.data(), row_off.size() * sizeof(long long));
+    if (!st && !lines.empty()) st = pvlm_i_h2d_q(ctx, d_lines, lines.data(), lines.size() * sizeof(double));
+    hipError_t e = st ? hipSuccess : hipMemsetAsync(d_v, 0, (size_t)std::max<long long>(nv, 1) * sizeof(int), ctx->stream);
+    if (!st && e == hipSuccess) {
+      const long long tot = work_off[n_pairs];
+      if (tot > 0)
+        hipLaunchKernelGGL(k_line_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n_pairs, d_desc, d_work, tot, d_lines, (double)dist_threshold, d_v);
+      hipLaunchKernelGGL(k_line_row_best, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, n_pairs, d_rdesc, d_row, rows, d_v, d_col, d_cnt);
+      e = hipGetLastError();
+    }
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_line2line_best_batch: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (!st) st = pvlm_i_d2h_q(ctx, best_col, d_col, (size_t)rows * sizeof(int));
+    if (!st) st = pvlm_i_d2h_q(ctx, best_count, d_cnt, (size_t)rows * sizeof(int));
+  }
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+  pvlm_i_free(ctx, d_desc); pvlm_i_free(ctx, d_rdesc); pvlm_i_free(ctx, d_work); pvlm_i_free(ctx, d_row); pvlm_i_free(ctx, d_lines); pvlm_i_free(ctx, d_v);
+  pvlm_i_free(ctx, d_col); pvlm_i_free(ctx, d_cnt);
+  return st;
+}
+
 pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei, int n_matches, const int* match_pair,
                                      const int* match_nei_seg, const int* match_ref_seg, pvlm_functor kind, unsigned flags, double weight,
                                      pvlm_resset** out) {
@@ -833,7 +919,7 @@ static void cam_line_tables(int rows, int cols, const float* lines, const std::v
   for (const auto& b : build) for (long long k = 0; k < b.second; ++k) src.push_back(b.first + k);
   const long long n_rows = (long long)src.size();
   tab.resize((size_t)n_rows * 8);
-  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)(n_rows / 4096 + 1), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), (size_t)(n_rows / 4096 + 1), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   std::atomic<long long> next{0};
   auto work = [&]() {
     for (long long b = next.fetch_add(1024); b < n_rows; b = next.fetch_add(1024))

@@ -444,7 +444,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
           if (!std::isfinite(d[i].x) || !std::isfinite(d[i].y) || !std::isfinite(d[i].z)) { bad = B->scans[(size_t)s].pt0 + i; break; }
       }
     };
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)n_scans / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), (size_t)n_scans / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     pvlm_run_workers(n_threads, work);
     if (bad >= 0) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: non-finite coordinate (point %lld of the batch)", (long long)bad); return PVLM_ERR_ARG; }
   }

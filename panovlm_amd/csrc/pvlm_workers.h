@@ -1,5 +1,6 @@
 // Short-lived worker threads of a host-side pass (bounding boxes, staging copies, per-scan or per-pair loops).  Host only.
 #pragma once
+#include <cstdlib>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -24,4 +25,10 @@ inline void pvlm_run_workers(size_t n_threads, Work&& work) {
   guarded();
   for (std::thread& t : pool) t.join();
   if (failure) std::rethrow_exception(failure);
+}
+
+// upper limit of the worker threads of one host-side pass: 16 (a shared host rarely gives a short-lived pass more), PVLM_HOST_THREADS overrides
+inline size_t pvlm_thread_cap() {
+  static const size_t cap = [] { const char* e = std::getenv("PVLM_HOST_THREADS"); const long v = e ? std::atol(e) : 0; return v > 0 ? (size_t)v : (size_t)16; }();
+  return cap;
 }

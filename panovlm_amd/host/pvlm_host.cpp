@@ -317,7 +317,7 @@ void Velodyne::UploadBatch(const std::vector<const Velodyne*>& scans) {
   if (st.size() < todo.size()) st.resize(todo.size());
   std::vector<pvlm_scan_desc> descs(todo.size());
   {   // the flattening is per scan and independent: scan-parallel, like FindNeighbors
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, todo.size() / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), todo.size() / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     std::atomic<size_t> next{0};
     auto work = [&]() { for (size_t k = next++; k < todo.size(); k = next++) { st[k].Fill(*todo[k], todo[k]->R_wl_, todo[k]->t_wl_); descs[k] = st[k].d; } };
     pvlm_run_workers(n_threads, work);
@@ -398,7 +398,7 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
     }
     neighbors_all[i].swap(neighbors);
   };
-  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, lidars.size() / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), lidars.size() / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   std::atomic<size_t> next{0};
   auto work = [&]() { for (size_t i = next++; i < lidars.size(); i = next++) one(i); };
   pvlm_run_workers(n_threads, work);
@@ -463,13 +463,14 @@ std::vector<Line2Line> FindAssociations(const Velodyne& ref, const Velodyne& nei
                                         const std::vector<Vector6d>& nei_world, const std::vector<int>& line_matrix) {
   return FindAssociationsOn(ref, nei, ref_world, nei_world, line_matrix.data());
 }
-static std::vector<Line2Line> FindAssociationsOn(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
-                                                 const std::vector<Vector6d>& nei_world, const int* line_matrix) {
+// FindAssociations from its second statement on: (max_col, max_count) of every neighbour segment are given (best_col / best_count, one entry
+// per row of the vote block: the arg-max loop of :126-130, taken on the host by FindAssociationsOn or on the device by pvlm_line2line_best_batch)
+static std::vector<Line2Line> FindAssociationsBest(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
+                                                   const std::vector<Vector6d>& nei_world, const int* best_col, const int* best_count) {
   std::map<int, Line2Line> m;
   const int nr = (int)ref.edge_segmented.size(), nn = (int)nei.edge_segmented.size();
   for (int s = 0; s < nn && nr > 0; ++s) {
-    int max_col = 0, max_count = line_matrix[(size_t)s * nr];
-    for (int c = 1; c < nr; ++c) if (line_matrix[(size_t)s * nr + c] > max_count) { max_count = line_matrix[(size_t)s * nr + c]; max_col = c; }
+    const int max_col = best_col[s], max_count = best_count[s];
     if ((size_t)max_count < nei.edge_segmented[s].size() / 2) continue;
     if (PlaneAngle(&ref_world[max_col][3], &nei_world[s][3]) * 180.0 / M_PI > 7) continue;
     const Vector6d& loc = ref.segment_coeffs[max_col];
@@ -487,6 +488,17 @@ static std::vector<Line2Line> FindAssociationsOn(const Velodyne& ref, const Velo
   std::vector<Line2Line> out;
   for (auto& kv : m) out.push_back(kv.second);
   return out;
+}
+static std::vector<Line2Line> FindAssociationsOn(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
+                                                 const std::vector<Vector6d>& nei_world, const int* line_matrix) {
+  const int nr = (int)ref.edge_segmented.size(), nn = (int)nei.edge_segmented.size();
+  std::vector<int> col((size_t)std::max(nn, 1), 0), cnt((size_t)std::max(nn, 1), 0);
+  for (int s = 0; s < nn && nr > 0; ++s) {
+    int max_col = 0, max_count = line_matrix[(size_t)s * nr];
+    for (int c = 1; c < nr; ++c) if (line_matrix[(size_t)s * nr + c] > max_count) { max_count = line_matrix[(size_t)s * nr + c]; max_col = c; }
+    col[(size_t)s] = max_col; cnt[(size_t)s] = max_count;
+  }
+  return FindAssociationsBest(ref, nei, ref_world, nei_world, col.data(), cnt.data());
 }
 
 std::vector<Line2Line> AssociateLine2Line(const Velodyne& ref, const Velodyne& nei, const float dist_threshold, bool) {
@@ -682,29 +694,29 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
   }
   if (which.empty()) return out;
   Engine& e = Engine::Default();
-  std::vector<int64_t> voff(which.size() + 1, 0);
-  // kept between calls (every element of a vote block is written by the call: no clearing): a fresh 50 MB vector per call is 11 k page
-  // faults and a memset before the copy back even starts
-  static std::vector<int32_t> votes;
+  // the vote blocks stay on the device: what comes back is, per neighbour segment, the reference segment with the most votes and that count
+  // (pvlm_line2line_best_batch — the arg-max loop of FindAssociations; round 4 copied the blocks, 70 MB at Floor size, and scanned them here)
+  std::vector<int64_t> roff(which.size() + 1, 0);
+  std::vector<int32_t> best_col, best_count;
   {
-    StageTimer stage_timer_votes_("  (inside) line votes of all pairs on the GPU (launch + copy back)");
-    e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), nullptr, 0), "pvlm_line2line_votes_batch");
-    if (votes.size() < (size_t)std::max<int64_t>(voff.back(), 1)) votes.resize((size_t)std::max<int64_t>(voff.back(), 1));
-    e.Check(pvlm_line2line_votes_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, voff.data(), votes.data(), (int64_t)votes.size()),
-            "pvlm_line2line_votes_batch");
+    StageTimer stage_timer_votes_("  (inside) line votes of all pairs on the GPU (launch + row maxima back)");
+    e.Check(pvlm_line2line_best_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, roff.data(), nullptr, nullptr, 0), "pvlm_line2line_best_batch");
+    best_col.resize((size_t)std::max<int64_t>(roff.back(), 1)); best_count.resize(best_col.size());
+    e.Check(pvlm_line2line_best_batch(e.ctx(), (int)which.size(), refs.data(), neis.data(), dist_threshold, roff.data(), best_col.data(), best_count.data(),
+                                      (int64_t)best_col.size()), "pvlm_line2line_best_batch");
   }
-  StageTimer stage_timer_("  (inside) FindAssociations on the vote blocks (host)");
+  StageTimer stage_timer_("  (inside) FindAssociations on the row maxima (host)");
   std::map<const Velodyne*, std::vector<Vector6d>> world;      // TransformLines(segment_coeffs, pose): once per scan of the batch, not per pair
   for (size_t j = 0; j < which.size(); ++j)
     for (const Velodyne* v : {pairs[which[j]].first, pairs[which[j]].second})
       if (!world.count(v)) world.emplace(v, TransformLines(v->segment_coeffs, v->GetPose()));
-  // the pairs are independent (read-only scans and vote blocks, one output slot each): pair-parallel
-  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, which.size() / 256 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  // the pairs are independent (read-only scans and row tables, one output slot each): pair-parallel
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), which.size() / 256 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   std::atomic<size_t> next{0};
   auto work = [&]() {
     for (size_t j = next++; j < which.size(); j = next++) {
       const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
-      out[which[j]] = FindAssociationsOn(ref, nei, world.find(&ref)->second, world.find(&nei)->second, votes.data() + voff[j]);
+      out[which[j]] = FindAssociationsBest(ref, nei, world.find(&ref)->second, world.find(&nei)->second, best_col.data() + roff[j], best_count.data() + roff[j]);
     }
   };
   pvlm_run_workers(n_threads, work);
@@ -886,23 +898,43 @@ bool LidarLineMatch::GenerateTracks() {
   StageTimer stage_timer_("line tracks (associate + union-find)");
   std::vector<std::pair<size_t, size_t>> pairs;
   const std::vector<std::vector<int>> neighbors = FindNeighbors(lidars_, neighbor_size_);
+  const bool sharded = exchange_ && exchange_->active();
   std::vector<std::pair<const Velodyne*, const Velodyne*>> todo;   // the (ref, nei) arguments of AssociateLine2Line, :68
+  std::vector<size_t> todo_pair;                                   // position of todo[k] in `pairs` (sharded: this rank's pairs only)
   for (size_t i = 0; i < neighbors.size(); i++) {
     if (!lidars_[i].IsPoseValid()) continue;
     for (const int nei_id : neighbors[i]) {
       if (nei_id < 0 || nei_id >= (int)lidars_.size()) continue;
-      todo.push_back({&lidars_[nei_id], &lidars_[i]});
+      if (!sharded || (i >= first_ && i < last_)) { todo.push_back({&lidars_[nei_id], &lidars_[i]}); todo_pair.push_back(pairs.size()); }
       pairs.push_back({i, (size_t)nei_id});
     }
   }
   const std::vector<std::vector<Line2Line>> all_ass = AssociateLine2LineBatch(todo, 0.3f);   // one launch for the whole loop
   // feature_each_pair: the (neighbour segment, reference segment) matches of every pair as a std::set orders them (sorted, unique)
   typedef std::pair<uint32_t, uint32_t> Feature;      // (scan, segment)
-  std::vector<std::vector<Feature>> fpairs(all_ass.size());
+  std::vector<std::vector<Feature>> fpairs(pairs.size());
   for (size_t k = 0; k < all_ass.size(); ++k) {
-    std::vector<Feature>& fp = fpairs[k];
+    std::vector<Feature>& fp = fpairs[todo_pair[k]];
     for (const Line2Line& a : all_ass[k]) fp.push_back({(uint32_t)a.neighbor_line_idx, (uint32_t)a.ref_line_idx});
     std::sort(fp.begin(), fp.end()); fp.erase(std::unique(fp.begin(), fp.end()), fp.end());
+  }
+  if (sharded) {
+    // every rank holds the matches of its own pairs: counts per pair, then the matches themselves, summed over the ranks (each entry is
+    // written by exactly one rank) — the one primitive an Exchange has.  Segment ids are small integers: exact in a double.
+    StageTimer stage_timer_x_("  (inside) line tracks: matches of all ranks concatenated (2 all-reduces)");
+    std::vector<double> cnt(pairs.size(), 0.0);
+    for (size_t k = 0; k < pairs.size(); ++k) cnt[k] = (double)fpairs[k].size();
+    if (!cnt.empty()) exchange_->allreduce_sum(cnt.data(), cnt.size());
+    std::vector<size_t> off(pairs.size() + 1, 0);
+    for (size_t k = 0; k < pairs.size(); ++k) off[k + 1] = off[k] + (size_t)cnt[k];
+    std::vector<double> flat(std::max<size_t>(2 * off.back(), 1), 0.0);
+    for (size_t k = 0; k < pairs.size(); ++k)
+      for (size_t m = 0; m < fpairs[k].size(); ++m) { flat[2 * (off[k] + m)] = (double)fpairs[k][m].first; flat[2 * (off[k] + m) + 1] = (double)fpairs[k][m].second; }
+    exchange_->allreduce_sum(flat.data(), flat.size());
+    for (size_t k = 0; k < pairs.size(); ++k) {
+      fpairs[k].resize((size_t)cnt[k]);
+      for (size_t m = 0; m < fpairs[k].size(); ++m) fpairs[k][m] = {(uint32_t)flat[2 * (off[k] + m)], (uint32_t)flat[2 * (off[k] + m) + 1]};
+    }
   }
   // TrackBuilder(true).Build — util/Tracks.cpp:58-196 with its std::set / std::map containers replaced by sorted vectors and
   // dense tables: the same features in the same order (a set iterates in sorted order), the same unions in the same order
@@ -1902,7 +1934,7 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
     }
     std::vector<std::vector<std::pair<int, int>>> kept(pairs_todo.size());       // (neighbour line, reference line) per pair
     std::vector<size_t> kept_points(pairs_todo.size(), 0);
-    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, pairs_todo.size() / 256 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), pairs_todo.size() / 256 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     std::atomic<size_t> cursor{0};
     auto work = [&]() {
       for (size_t p = cursor++; p < pairs_todo.size(); p = cursor++) {
@@ -2075,6 +2107,7 @@ bool LidarOdometry::RefinePose(double& cost, int& steps, bool use_segment) {
     LidarLineMatch matcher(lidars);
     matcher.SetNeighborSize(4);
     matcher.SetMinTrackLength(3);
+    if (sharded) matcher.SetShard(&exchange_, my_range.first, my_range.second);
     matcher.GenerateTracks();
     AddLidarLineToLineResidual2(neighbors_all, lidars, aa_list, t_list, problem, matcher.GetTracks(), config.point_to_line_dis_threshold,
                                 config.angle_residual, config.normalize_distance, 1.0, range);

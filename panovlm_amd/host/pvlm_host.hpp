@@ -231,17 +231,24 @@ struct LineTrack {
   std::set<std::pair<uint32_t, uint32_t>> feature_pairs;  // {lidar id, line id}
   bool IsInside(const std::pair<uint32_t, uint32_t>& p) const { return feature_pairs.count(p) > 0; }
 };
+struct Exchange;
 class LidarLineMatch {
  public:
   explicit LidarLineMatch(const std::vector<Velodyne>& lidars) : lidars_(lidars) {}
   void SetNeighborSize(int n) { neighbor_size_ = n; }
   void SetMinTrackLength(int n) { min_track_length_ = n; }
+  // Sharded run: this rank associates the pairs of the scans [first, last) only — AssociateLine2Line of :68 is per pair —
+  // and the matches of all ranks are concatenated through the exchange (two small all-reduces: the match counts per pair, then the matches)
+  // before the union-find, which every rank runs on the complete list: the tracks are the same on every rank and equal to the one-process run's.
+  void SetShard(const Exchange* exchange, size_t first, size_t last) { exchange_ = exchange; first_ = first; last_ = last; }
   bool GenerateTracks();
   const std::vector<LineTrack>& GetTracks() const { return tracks_; }
  private:
   const std::vector<Velodyne>& lidars_;
   int neighbor_size_ = 4, min_track_length_ = 3;
   std::vector<LineTrack> tracks_;
+  const Exchange* exchange_ = nullptr;
+  size_t first_ = 0, last_ = 0;
 };
 
 // ---- the ceres:: surface the reference touches -----------------------------------------------------------

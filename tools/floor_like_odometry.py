@@ -64,6 +64,27 @@ def main():
         for l in single:
             if l.startswith("stage"):
                 print(_stage_line(l))
+        # what of the call shards by reference scan (every rank does 1 / N of it) and what every rank repeats: the stage table of the one-process run
+        st = {}
+        import re
+        for l in single:
+            m = re.match(r"stage (\S+) (.*) \[(\d+) calls\]$", l)
+            if m:
+                st[m.group(2).strip()] = float(m.group(1))
+        get = lambda frag: sum(v for k, v in st.items() if frag in k)
+        replicated = (get("solve (LM)") - get("solve: GPU linearisation + block assembly") - get("solve: first linearisation")      # the pose solve: every rank factorises the summed system
+                      + get("FindNeighbors (host)") + get("TrackBuilder: union-find")                                           # the scan graph and the union-find over ALL matches
+                      + get("scan clouds back to the local frame") + get("scan clouds to the world frame"))                    # every rank keeps every scan posed
+        listed = get("line tracks (associate") + get("line-to-line association + blocks") + get("point-to-plane association") + get("solve (LM)") + \
+            get("scan clouds back to the local frame") + get("scan clouds to the world frame") + get("feature extraction")
+        replicated += max(0.0, call1 - listed)                                                                                   # glue outside any stage timer: counted as serial
+        sharded = max(0.0, call1 - replicated)
+        print("of the %.3f s call: %.3f s (%.0f %%) in stages that shard by reference scan (association of points and lines incl. the scans they upload, "
+              "line-track association, block building, linearisation), %.3f s repeated by every rank (pose solve, FindNeighbors, union-find, re-posing, glue)"
+              % (call1, sharded, 100 * sharded / call1, replicated))
+        for N in (2, 4, 8):
+            print("   Amdahl projection of the CALL at %d GPUs: %.2f x  (the fused kernel alone projects %s: bench.py per_rank_projection)" %
+                  (N, call1 / (replicated + sharded / N), {2: "1.95 x", 4: "3.88 x", 8: "7.46 x"}[N]))
         e0 = np.mean([np.linalg.norm(scans[k]["t_wl"] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
         e1 = np.mean([np.linalg.norm(pos[k][9:] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
         print("mean translation error vs ground truth: %.4f m -> %.4f m" % (e0, e1))
