@@ -255,7 +255,11 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
  * M x = rhs solved in place (rhs host, n doubles).  blocks: n_blocks x 36 row-major; row_idx / col_idx: n_blocks x 6
  * scalar indices of the block's rows / columns (-1 = constant parameter, dropped).  mirror[b] != 0 (block between two
  * different poses) also adds the transposed block to the other triangle; a block of a pose with itself is given in full
- * with mirror = 0.  Repeated blocks add up. */
+ * with mirror = 0.  Repeated blocks add up.  A block between two DIFFERENT poses must be given with mirror != 0 (or in both
+ * triangles): from 1500 unknowns on the unknowns are reordered before the factorisation, which reads one triangle of the
+ * REORDERED matrix — a block given in one triangle only may land in the other one.  *info = 0 on success; k > 0 = the leading
+ * minor of order k of the matrix AS FACTORISED (reordered when pvlm_spd_last_plan reports a tile-sparse plan) is not positive
+ * definite: take it as "not positive definite", not as the index of an unknown. */
 pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror, const double* blocks,
                                   const double* scale, const double* diag_add, double* rhs, int* info);
 /* How the last pvlm_spd_solve_blocks structure of this context is factorised: *tile_sparse = 1 when the dense kernels skip the

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <iterator>
 #include <new>
+#include <cstring>
 #include <vector>
 
 #include "pvlm_internal.h"
@@ -595,6 +596,7 @@ struct SpdPlan {
   bool sparse = false;
   std::vector<int> new_of_old;                 // permutation of the unknowns
   std::vector<int> row_off, pair_off;          // steps + 1
+  std::vector<int> key_rows, key_cols, key_mirror;   // the structure the plan was built for: compared on every cache hit (a hash alone may collide)
   int* d_row_tiles = nullptr; int2* d_pairs = nullptr;
   double update_fraction = 1.0;                // tile updates / tile updates of the dense factorisation
 };
@@ -621,6 +623,7 @@ static pvlm_status spd_plan_build(pvlm_ctx* ctx, int n, int n_blocks, const int*
   static const int min_n = getenv("PVLM_SPD_SPARSE_MIN") ? atoi(getenv("PVLM_SPD_SPARSE_MIN")) : 1500;
   if (n < min_n || n_blocks == 0) return PVLM_OK;
   pvlm_spd::Symbolic S;
+  static_assert(64 % PVLM_CHOL_NB == 0, "a 64-row tile must span a whole number of block columns (pvlm_spd_plan.h marks the fill per tile)");
   pvlm_spd::plan_symbolic(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, &S);       // csrc/pvlm_spd_plan.h (host only, checked on the CPU)
   P->update_fraction = S.update_fraction;
   static const double max_fraction = getenv("PVLM_SPD_SPARSE_FRACTION") ? atof(getenv("PVLM_SPD_SPARSE_FRACTION")) : 0.6;
@@ -656,12 +659,20 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   std::vector<double> pscale, pdiag, prhs;
   try {
     const unsigned long long key = spd_hash(n, n_blocks, row_idx, col_idx, mirror);
-    if (!plan || plan->key != key || plan->n != n) {
+    // a hit needs the SAME index lists, not only the same 64-bit hash: with a colliding structure the tile lists of the old one would skip the new
+    // one's non-zeros and the solve would be wrong with info = 0 (three memcmp of ~100 KB at Floor size against a 10 ms solve)
+    const bool same = plan && plan->key == key && plan->n == n && plan->key_rows.size() == (size_t)n_blocks * 6 && plan->key_mirror.size() == (size_t)n_blocks &&
+                      std::memcmp(plan->key_rows.data(), row_idx, (size_t)n_blocks * 6 * sizeof(int)) == 0 &&
+                      std::memcmp(plan->key_cols.data(), col_idx, (size_t)n_blocks * 6 * sizeof(int)) == 0 &&
+                      std::memcmp(plan->key_mirror.data(), mirror, (size_t)n_blocks * sizeof(int)) == 0;
+    if (!same) {
       PVLM_TRY_SYNC(ctx);
       pvlm_i_trace("spd solve: before the plan");
       pvlm_i_spd_plan_release(ctx);
       plan = new SpdPlan();
       plan->key = key;
+      plan->key_rows.assign(row_idx, row_idx + (size_t)n_blocks * 6); plan->key_cols.assign(col_idx, col_idx + (size_t)n_blocks * 6);
+      plan->key_mirror.assign(mirror, mirror + n_blocks);
       ctx->spd_plan = plan;
       const pvlm_status pst = spd_plan_build(ctx, n, n_blocks, row_idx, col_idx, mirror, plan);
       if (pst) { pvlm_i_spd_plan_release(ctx); return pst; }

@@ -135,7 +135,8 @@ inline void plan_symbolic(int n, int n_blocks, const int* row_idx, const int* co
     for (size_t a = 0; a < R.size(); ++a)
       for (size_t c = 0; c <= a; ++c) {
         pairs.push_back(TilePair{R[a], R[c]});
-        for (int col = 2 * R[c]; col <= 2 * R[c] + 1; ++col) if (col > k && col < C) nz[(size_t)R[a] * C + col] = 1;
+        // the block columns a 64-row tile spans: 64 / NB of them (two at the library's NB = 32)
+        for (int col = (64 / NB) * R[c]; col < (64 / NB) * (R[c] + 1); ++col) if (col > k && col < C) nz[(size_t)R[a] * C + col] = 1;
       }
     P->row_off.push_back((int)row_tiles.size()); P->pair_off.push_back((int)pairs.size());
     const long long dt = (n - base + 63) / 64;

@@ -411,7 +411,28 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
   pvlm_ring_batch* batch = nullptr;
   {
     StageTimer stage_timer_("  (inside feature extraction) range-image stages of all scans on the GPU (pvlm_ring_extract_batch)");
-    e.Check(pvlm_ring_extract_batch(e.ctx(), (int)todo.size(), raw.data(), rings, horizon, segment ? 1 : 0, &batch), "pvlm_ring_extract_batch");
+    const pvlm_status rc = pvlm_ring_extract_batch(e.ctx(), (int)todo.size(), raw.data(), rings, horizon, segment ? 1 : 0, &batch);
+    if (rc == PVLM_ERR_ARG || rc == PVLM_ERR_CAPACITY || rc == PVLM_ERR_NOMEM) {
+      // The batch form is stricter than the reference: it refuses a batch with a non-finite coordinate (upstream such a point gets ring -1 and is
+      // skipped, sensors/Velodyne.cpp:439-445) and gives up beyond its bounds on undecided segmentation edges / memory.  Neither is a reason to fail
+      // EstimatePose: the scans go through the per-scan host path, which skips such points exactly as upstream does.
+      fprintf(stderr, "ExtractFeaturesBatch: %s — falling back to the host extraction for this batch\n", pvlm_last_error(e.ctx()));
+      std::atomic<size_t> next{0};
+      std::mutex lock; std::exception_ptr failure;
+      auto host_work = [&]() {
+        for (size_t j = next++; j < todo.size(); j = next++) {
+          try {
+            Velodyne& v = *scans[todo[j]];
+            v.ReOrderVLP();
+            v.ExtractFeatures(max_curvature, intersect_angle_threshold, method, segment);
+          } catch (...) { std::lock_guard<std::mutex> g(lock); if (!failure) failure = std::current_exception(); }
+        }
+      };
+      pvlm_run_workers((size_t)std::max(1, std::min(num_threads, (int)todo.size())), host_work);
+      if (failure) std::rethrow_exception(failure);
+      return;
+    }
+    e.Check(rc, "pvlm_ring_extract_batch");
   }
   struct Release { pvlm_ctx* c; pvlm_ring_batch* b; ~Release() { pvlm_ring_batch_destroy(c, b); } } release{e.ctx(), batch};
   if (traces) {                                   // the two images: device-resident, fetched for the parity tests only
