@@ -1,9 +1,9 @@
 #!/bin/bash
 # SQ counters of the association kernels on tools/assoc_workload.py (two passes of 8 SQ counters; no other trace domain beside --kernel-trace)
-#   TARGETS="voxel raw" K2_GROUP=16 tools/pmc_k2.sh  ->  gpurun_out/pmc_k2_<targets>.json
+#   TARGETS="voxel raw" tools/pmc_k2.sh  ->  gpurun_out/pmc_k2_<targets>.json
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_k2; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-[ -n "$K2_GROUP" ] && export PVLM_K2_GROUP=$K2_GROUP
+
 for TG in ${TARGETS:-voxel raw}; do
   SC=256; [ $TG = raw ] && SC=32
   W="python $R/tools/assoc_workload.py --scans $SC --targets $TG"
