@@ -314,7 +314,8 @@ void Velodyne::UploadBatch(const std::vector<const Velodyne*>& scans) {
   // the staging arrays outlive the call: the same scans come back at every outer iteration of EstimatePose, and filling vectors that keep
   // their capacity costs a third of filling fresh ones (no allocation, no first-touch page faults: 27 -> 9 ms for the 1593 scans of Floor)
   // (one set per calling thread: two LidarOdometry objects on two threads must not share it; released with the thread)
-  static thread_local std::vector<ScanStaging> st;
+  static thread_local std::vector<ScanStaging> st_of_this_thread;
+  std::vector<ScanStaging>& st = st_of_this_thread;      // the workers below fill the CALLING thread's set: a thread_local named inside their lambda would be their own (empty) one
   if (st.size() < todo.size()) st.resize(todo.size());
   std::vector<pvlm_scan_desc> descs(todo.size());
   {   // the flattening is per scan and independent: scan-parallel, like FindNeighbors
