@@ -6,8 +6,8 @@ Per kernel (k_knn_pairs, k_fit_pairs, k_compact): counters summed over the dispa
 (total / calls), normalised per query; derived figures:
   valu_issue_frac      = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES   (share of resident-wave cycles spent issuing VALU)
   wait_frac            = SQ_WAIT_ANY / SQ_WAVE_CYCLES
-  valu_insts_per_query = SQ_INSTS_VALU / SQ_WAVES   (SQ_INSTS_VALU counts wave instructions; one lane = one query, so an
-                         instruction issued by the wave is one instruction of each of its queries)
+  valu_insts_per_query = SQ_INSTS_VALU / (queries / 64)   (SQ_INSTS_VALU counts wave instructions; one lane = one query, so an
+                         instruction issued by a wave is one instruction of each of its 64 queries)
   fetch bytes          = FETCH_SIZE KiB x 1024 (raw) and x 2 (the guide's correction for 16 B/lane streams; K2's
                          candidate loads are 16 B/lane but divergent, so the truth lies between the two)
   compulsory ratio     = fetch bytes / ((Nq + Nt) x 16 B)
@@ -25,12 +25,13 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(int))
 dur = collections.defaultdict(list)
 for d in sys.argv[3:]:
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    import os
+    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:      # one run per directory: the newest
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k][r["Counter_Name"]] += 1
-    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    for f in sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1:]:
         if glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             continue        # durations under counter collection are not representative
         for r in csv.DictReader(open(f)):
@@ -50,8 +51,11 @@ for k in sorted(agg):
             if key in c:
                 e[name] = c[key] / c["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES", 0) > 0:
-        e["valu_insts_per_query"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
-        e["vmem_rd_insts_per_query"] = c.get("SQ_INSTS_VMEM_RD", 0.0) / c["SQ_WAVES"]
+        # per 64 queries (one wave's worth): k_knn_pairs runs one wave per 64 queries, the persistent k_fit_pairs does not — normalise by the queries
+        q64 = wl["queries"] / 64.0
+        e["valu_insts_per_query"] = c["SQ_INSTS_VALU"] / q64
+        e["vmem_rd_insts_per_query"] = c.get("SQ_INSTS_VMEM_RD", 0.0) / q64
+        e["waves_launched_per_call"] = c["SQ_WAVES"]
         e["waves_per_call"] = c["SQ_WAVES"]
     for extra in ("SQ_INSTS_SMEM", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
         if extra in c and c.get("SQ_WAVES", 0) > 0:
