@@ -43,7 +43,7 @@ cp $O/r5_pmc_k8.json $R/profiles/
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/mvs_trace -- python $R/tools/mvs_block_bench.py --small > $O/mvs_trace.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $O/mvs_pmc -- python $R/tools/mvs_block_bench.py --small > $O/mvs_pmc.log 2>&1
-cd $R && python tools/pmc_kernels.py $O/r5_pmc_mvs.json '{"k_mvs_propagate_flow": 1036800, "k_mvs_propagate_lane": 518400, "k_mvs_conf": 1036800}' $O/mvs_trace $O/mvs_pmc k_mvs_propagate k_mvs_conf > /dev/null
+cd $R && python tools/pmc_kernels.py $O/r5_pmc_mvs.json '{"k_mvs_propagate_flow": 1036800, "k_mvs_propagate_lane": 518400, "k_mvs_conf": 518400}' $O/mvs_trace $O/mvs_pmc k_mvs_propagate k_mvs_conf > /dev/null
 cp $O/r5_pmc_mvs.json $R/profiles/
 find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 # the default bench, then the same command under the kernel trace
