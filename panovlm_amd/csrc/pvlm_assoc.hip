@@ -33,7 +33,7 @@ struct PairDesc {
   int nq;
   double Rr[9], tr[3], Rn[9], tn[3];  // R_wl / t_wl of ref and nei
   long long tmp_base;                 // first row of this pair in the batch temp arrays
-  int chunk_base;                     // first chunk (256 queries) of this pair in the batch's chain
+  int chunk_base;                     // first chunk (PVLM_K3_CHUNK queries) of this pair in the batch's chain
   long long dst_row;                  // first row of the pair's segment in the batch's column block (a multiple of 16; the segment has room for nq rows)
 };
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K2_WAV
 // K3 — class test, collinearity test, 10x3 plane fit, and the accepted records written straight into the pair's segment of the residual set,
 // in query order (LidarFeatureAssociate.cpp:578-629 emits in query order).
 //
-// Ordered compaction inside the kernel.  A workgroup fits one chunk of 256 queries of one pair at a time; the row of an accepted query is
+// Ordered compaction inside the kernel.  A workgroup fits one chunk of 512 queries (two passes of 256) of one pair at a time; the row of an accepted query is
 //     segment start + accepted queries of the pair's earlier chunks + its rank inside the chunk.
 // The middle term comes from a chain over the pair's chunks (decoupled look-back): every chunk publishes its own count as soon as its fits are
 // done (one 8-byte word {state, count}, relaxed agent-scope atomics on both sides — the word is its own payload, no fence); the counts of the
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K2_WAV
 // A workgroup must not WAIT for that sum with its registers allocated: fits take anything from a class test to a full QR, and at two
 // workgroups per CU a finished chunk idling behind a slow predecessor cost 40 % (1820 against 1296 us per dispatch without the chain).  So
 // the workgroups are persistent, take chunks from a ticket counter (the chunks a chunk depends on have always been taken), park the records
-// of the chunk just fitted in LDS (14 KB), fit the NEXT chunk, and only then place the parked one — by then its predecessors have long
+// of the chunk just fitted in LDS (two buffers of 28 KB), fit the NEXT chunk, and only then place the parked one — by then its predecessors have long
 // published.
 // Round 4 wrote the records of EVERY query to scratch (56 B), copied the chunk counts to the host, sized the block there, uploaded the
 // destinations and compacted in a second kernel (k_compact: 282 us of the 2.7 ms per 16.7 M queries, HBM-bound on the round trip of the records);
@@ -230,17 +230,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K2_WAV
 // for the bench's 134 M queries) and the host only learns the per-pair totals.
 #define PVLM_CHAIN_AGG (1ull << 62)
 #define PVLM_CHAIN_INC (1ull << 63)
+#ifndef PVLM_K3_SUB
+#define PVLM_K3_SUB 2                          // a chunk = PVLM_K3_SUB x 256 queries: one ticket, one chain word, one look-back and two barriers per chunk
+#endif
+#define PVLM_K3_CHUNK (256 * PVLM_K3_SUB)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAVES, 8))) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp, long long tmp_rows,
                                                    double* __restrict__ cols, long long n_dev, unsigned long long* __restrict__ chain, int* __restrict__ pair_count,
                                                    int* __restrict__ ticket, int* __restrict__ qidx_out, int* __restrict__ nn_out, int chunks_x, int total) {
+  constexpr int SUB = PVLM_K3_SUB;
+  static_assert(SUB == 1 || SUB == 2, "the sub-chunk loop below keeps its per-pass results in slots 0 and SUB - 1");
   __shared__ int s_vid;
-  __shared__ int wc[4];
+  __shared__ int wc[SUB][4];
   __shared__ long long s_prefix;
-  __shared__ double s_rec[7][256];
+  __shared__ double s_rec[2][SUB][7][256];      // two buffers: the chunk being fitted and the parked one
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // the parked chunk: wave-uniform (pair, chunk, count) and per thread (accepted, rank inside the chunk)
-  int prev_pair = -1, prev_chunk = 0, prev_count = 0, prev_rank = 0;
-  bool prev_accept = false;
+  // the parked chunk: wave-uniform (pair, chunk, count, buffer) and per thread and sub-chunk (accepted, rank inside the chunk)
+  int prev_pair = -1, prev_chunk = 0, prev_count = 0, prev_buf = 0;
+  int prev_rank[SUB];
+  bool prev_accept[SUB];
+#pragma unroll
+  for (int u = 0; u < SUB; ++u) { prev_rank[u] = 0; prev_accept[u] = false; }
   // rows of the parked chunk: look-back, inclusive prefix, records out of LDS
   auto place = [&]() {
     const PairDesc& pp = pairs[prev_pair];
@@ -264,26 +273,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
         if (lane == 0) __hip_atomic_store(my, PVLM_CHAIN_INC | (unsigned long long)(prefix + prev_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (lane == 0) {
-        if ((prev_chunk + 1) * 256 >= pp.nq) pair_count[prev_pair] = (int)(prefix + prev_count);
+        if ((prev_chunk + 1) * PVLM_K3_CHUNK >= pp.nq) pair_count[prev_pair] = (int)(prefix + prev_count);
         s_prefix = prefix;
       }
     }
     __syncthreads();
-    if (prev_accept) {
-      const long long d = pp.dst_row + s_prefix + prev_rank;
 #pragma unroll
-      for (int c = 0; c < 7; ++c) cols[(size_t)c * n_dev + d] = s_rec[c][threadIdx.x];
-      if (qidx_out) {
-        const int q = prev_chunk * 256 + (int)threadIdx.x;
-        qidx_out[d] = q;
+    for (int u = 0; u < SUB; ++u) {
+      if (prev_accept[u]) {
+        const long long d = pp.dst_row + s_prefix + prev_rank[u];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) nn_out[d * 10 + k] = nn_tmp[(size_t)k * tmp_rows + pp.tmp_base + q];
+        for (int c = 0; c < 7; ++c) cols[(size_t)c * n_dev + d] = s_rec[prev_buf][u][c][threadIdx.x];
+        if (qidx_out) {
+          const int q = prev_chunk * PVLM_K3_CHUNK + u * 256 + (int)threadIdx.x;
+          qidx_out[d] = q;
+#pragma unroll
+          for (int k = 0; k < 10; ++k) nn_out[d * 10 + k] = nn_tmp[(size_t)k * tmp_rows + pp.tmp_base + q];
+        }
       }
     }
-    __syncthreads();   // s_rec and s_prefix are free again
+    __syncthreads();   // s_prefix is free again
   };
   // tickets are drawn one chunk ahead (thread 0 holds the next one while the chunk is fitted: the atomic's latency is off the path)
-  int next_vid = 0;
+  int next_vid = 0, buf = 0;
   if (threadIdx.x == 0) next_vid = atomicAdd(ticket, 1);
   for (;;) {
     if (threadIdx.x == 0) { s_vid = next_vid; next_vid = atomicAdd(ticket, 1); }
@@ -293,66 +305,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
     if (vid >= total) break;
     const int pair = vid / chunks_x, chunk = vid - pair * chunks_x;
     const PairDesc& pd = pairs[pair];
-    if (chunk * 256 >= pd.nq) continue;
-    const int q = chunk * 256 + threadIdx.x;
-    bool accept = false;
-    double rec[7];
-    if (q < pd.nq) {
-      const long long row = pd.tmp_base + q;
-      int id[10];
+    if (chunk * PVLM_K3_CHUNK >= pd.nq) continue;
+    bool accept[SUB];
+    unsigned long long bal[SUB];
+#pragma unroll 1
+    for (int u = 0; u < SUB; ++u) {
+      const int q = chunk * PVLM_K3_CHUNK + u * 256 + (int)threadIdx.x;
+      bool ok = false;
+      if (q < pd.nq) {
+        const long long row = pd.tmp_base + q;
+        int id[10];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
-      bool ok = id[9] >= 0;
-      if (ok) {
-        const float qtag = pd.q_tag[q];
-        double px[10], py[10], pz[10], Rt[3];
-        world2local_rt(pd.Rr, pd.tr, Rt);
-        int same = 0;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-          const Point4 t = pd.ref.pt4[id[k]];          // (x, y, z, tag) of the neighbour: one 16-byte gather (round 4: four 4-byte ones)
-          same += (t.w == qtag);
-          double l[3];
-          world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
-          px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
-        }
-        ok = (same == 10);  // :583-591
+        for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
+        ok = id[9] >= 0;
         if (ok) {
-          double plane[4];
-          // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
-          // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
-          // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
-          // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
-          // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw — on 65 536-point targets K3 waits for its gathers at two
-          // waves per SIMD, not for the QR; profiles/r4_assoc_variants.txt.)
-          ok = !Fit10::is_line(px, py, pz, 3.0);
-          if (ok) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+          const float qtag = pd.q_tag[q];
+          double px[10], py[10], pz[10], Rt[3];
+          world2local_rt(pd.Rr, pd.tr, Rt);
+          int same = 0;
+#pragma unroll
+          for (int k = 0; k < 10; ++k) {
+            const Point4 t = pd.ref.pt4[id[k]];          // (x, y, z, tag) of the neighbour: one 16-byte gather (round 4: four 4-byte ones)
+            same += (t.w == qtag);
+            double l[3];
+            world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
+            px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
+          }
+          ok = (same == 10);  // :583-591
           if (ok) {
-            double pl[3];
-            world2local(pd.Rn, pd.tn, (double)pd.q_xyz[3 * q], (double)pd.q_xyz[3 * q + 1], (double)pd.q_xyz[3 * q + 2], pl);
-            rec[0] = pl[0]; rec[1] = pl[1]; rec[2] = pl[2]; rec[3] = plane[0]; rec[4] = plane[1]; rec[5] = plane[2]; rec[6] = plane[3];
+            double plane[4];
+            // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
+            // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
+            // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
+            // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
+            // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw — on 65 536-point targets K3 waits for its gathers at two
+            // waves per SIMD, not for the QR; profiles/r4_assoc_variants.txt.)
+            ok = !Fit10::is_line(px, py, pz, 3.0);
+            if (ok) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+            if (ok) {
+              double pl[3];
+              world2local(pd.Rn, pd.tn, (double)pd.q_xyz[3 * q], (double)pd.q_xyz[3 * q + 1], (double)pd.q_xyz[3 * q + 2], pl);
+              double* r = &s_rec[buf][u][0][threadIdx.x];           // straight into this chunk's buffer (the parked chunk sits in the other one)
+              r[0 * 256] = pl[0]; r[1 * 256] = pl[1]; r[2 * 256] = pl[2]; r[3 * 256] = plane[0]; r[4 * 256] = plane[1]; r[5 * 256] = plane[2]; r[6 * 256] = plane[3];
+            }
           }
         }
       }
-      accept = ok;
+      if (u == 0) { accept[0] = ok; bal[0] = __ballot(ok); if (lane == 0) wc[0][wv] = __popcll(bal[0]); }
+      else { accept[SUB - 1] = ok; bal[SUB - 1] = __ballot(ok); if (lane == 0) wc[SUB - 1][wv] = __popcll(bal[SUB - 1]); }
     }
-    const unsigned long long bal = __ballot(accept);
-    if (lane == 0) wc[wv] = __popcll(bal);
     __syncthreads();
-    const int count = wc[0] + wc[1] + wc[2] + wc[3];
-    int base = 0;
-    for (int w = 0; w < wv; ++w) base += wc[w];
-    const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+    int count = 0, rank[SUB];
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) {
+      int base = count;
+      for (int w = 0; w < wv; ++w) base += wc[u][w];
+      rank[u] = base + __popcll(bal[u] & ((1ull << lane) - 1ull));
+      count += wc[u][0] + wc[u][1] + wc[u][2] + wc[u][3];
+    }
     // the chunk's own count is public at once: a first chunk's is its inclusive prefix
     if (threadIdx.x == 0)
       __hip_atomic_store(chain + pd.chunk_base + chunk, (chunk == 0 ? PVLM_CHAIN_INC : PVLM_CHAIN_AGG) | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev_pair >= 0) place();           // ends with a barrier: wc and s_rec are free
+    if (prev_pair >= 0) place();           // ends with a barrier: wc is free
     else __syncthreads();
-    if (accept) {
+    prev_pair = pair; prev_chunk = chunk; prev_count = count; prev_buf = buf;
 #pragma unroll
-      for (int c = 0; c < 7; ++c) s_rec[c][threadIdx.x] = rec[c];
-    }
-    prev_pair = pair; prev_chunk = chunk; prev_count = count; prev_rank = rank; prev_accept = accept;
+    for (int u = 0; u < SUB; ++u) { prev_rank[u] = rank[u]; prev_accept[u] = accept[u]; }
+    buf ^= 1;
   }
   if (prev_pair >= 0) place();
 }
@@ -840,7 +859,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
       descs[b.p1].tmp_base = b.rows;
       descs[b.p1].chunk_base = b.chunks;
       b.rows += descs[b.p1].nq;
-      b.chunks += (descs[b.p1].nq + 255) / 256;
+      b.chunks += (descs[b.p1].nq + PVLM_K3_CHUNK - 1) / PVLM_K3_CHUNK;
       b.bmax = std::max(b.bmax, descs[b.p1].nq);
       ++b.p1;
     }
@@ -888,7 +907,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
       // (an LDS-staged variant of the search was built and measured in round 2: 35.0 vs 33.6 ms for 134 M queries — the
       // search is bound by instruction issue, not by memory latency; numbers in DESIGN.md, code removed in round 3)
       hipLaunchKernelGGL(k_knn_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
-      const int chunks_x = (b.bmax + 255) / 256;
+      const int chunks_x = (b.bmax + PVLM_K3_CHUNK - 1) / PVLM_K3_CHUNK;
       const long long total = (long long)chunks_x * nb;
       if (total > 0x7fffffffll) { PVLM_SET_ERR(ctx, "association batch too large"); return PVLM_ERR_ARG; }
       static const int k3_blocks = [] { const char* e = getenv("PVLM_K3_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();   // persistent workgroups (two fit per CU)
