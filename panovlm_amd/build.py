@@ -1,9 +1,11 @@
 """Builds libpvlm.so (HIP kernels + C ABI, gfx950) in-tree with hipcc.  No JIT cache: the .so sits
 next to this file so that it travels to the GPU box with the repo snapshot."""
+import glob
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -112,16 +114,27 @@ HOST_DRIVER = os.path.join(HERE, "build", "pvlm_host_driver")
 def build_host(force=False):
     """libpvlm_host.so (C++ mirror of PanoVLM's interfaces above the C ABI) and its test driver."""
     build(force=False)
-    src = os.path.join(HERE, "host", "pvlm_host.cpp")
-    feat = os.path.join(HERE, "host", "pvlm_features.cpp")   # float threshold decisions of the feature extractor: no FMA contraction
-    lines = os.path.join(HERE, "host", "pvlm_lines.cpp")     # line branch of the extractor (EdgeToLine)
-    hdr = os.path.join(HERE, "host", "pvlm_host.hpp")
+    hdir = os.path.join(HERE, "host")
+    # one translation unit per mirrored reference file (pvlm_host_*.cpp), the feature extractor (pvlm_features.cpp, pvlm_lines.cpp) and the
+    # core (pvlm_host.cpp); -ffp-contract=off everywhere: the float threshold decisions of the extractor and the double chains of the
+    # solver must not pick up FMAs the oracle does not have
+    srcs = sorted(glob.glob(os.path.join(hdir, "*.cpp")))
+    hdrs = sorted(glob.glob(os.path.join(hdir, "*.hpp"))) + [os.path.join(HERE, "csrc", "pvlm_workers.h"), os.path.join(HERE, "..", "include", "pvlm.h")]
     drv = os.path.join(HERE, "..", "tests", "cpp", "pvlm_host_driver.cpp")
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    newest = max(os.path.getmtime(x) for x in (src, feat, lines, hdr, LIB))
-    if force or not os.path.exists(HOST_LIB) or os.path.getmtime(HOST_LIB) < newest:
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-ffp-contract=off", "-shared", src, feat, lines, "-o", HOST_LIB, "-L" + HERE, "-lpvlm", "-pthread",
-                               "-Wl,-rpath,$ORIGIN"])
+    odir = os.path.join(HERE, "build", "host")
+    os.makedirs(odir, exist_ok=True)
+    newest_hdr = max(os.path.getmtime(x) for x in hdrs)
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(odir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), newest_hdr):
+            jobs.append(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-ffp-contract=off", "-c", s, "-o", o])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(subprocess.check_call, jobs))
+    if jobs or not os.path.exists(HOST_LIB) or os.path.getmtime(HOST_LIB) < os.path.getmtime(LIB):
+        subprocess.check_call(["g++", "-shared", "-o", HOST_LIB] + objs + ["-L" + HERE, "-lpvlm", "-pthread", "-Wl,-rpath,$ORIGIN"])
     adapter = os.path.join(HERE, "..", "integration", "pvlm_ceres.hpp")
     if os.path.exists(drv) and (force or not os.path.exists(HOST_DRIVER) or
                                 os.path.getmtime(HOST_DRIVER) < max(os.path.getmtime(drv), os.path.getmtime(HOST_LIB), os.path.getmtime(adapter))):

@@ -4,6 +4,7 @@ feature extractor (through a sanitized build of the test driver), and the HIP ke
 host (tests/cpp/mvs_math_check.cpp) on odd-sized images.  Prints what the sanitizers flag; exits non-zero if anything.
 Run from the repo root:  python tools/sanitize_check.py"""
 import ctypes as C
+import glob
 import os
 import struct
 import subprocess
@@ -25,9 +26,9 @@ def main():
     flagged = 0
     with tempfile.TemporaryDirectory() as d:
         drv = os.path.join(d, "driver_asan")
-        subprocess.check_call(["g++"] + SAN + ["-ffp-contract=off", os.path.join(ROOT, "tests/cpp/pvlm_host_driver.cpp"), os.path.join(ROOT, "panovlm_amd/host/pvlm_host.cpp"),
-                               os.path.join(ROOT, "panovlm_amd/host/pvlm_features.cpp"), os.path.join(ROOT, "panovlm_amd/host/pvlm_lines.cpp"),
-                               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests/cpp/ceres_double"),
+        subprocess.check_call(["g++"] + SAN + ["-ffp-contract=off", os.path.join(ROOT, "tests/cpp/pvlm_host_driver.cpp")] +
+                              sorted(glob.glob(os.path.join(ROOT, "panovlm_amd/host/*.cpp"))) +
+                              [                               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests/cpp/ceres_double"),
                                "-o", drv, "-L" + os.path.join(ROOT, "panovlm_amd"), "-lpvlm", "-pthread",
                                "-Wl,-rpath," + os.path.join(ROOT, "panovlm_amd")])
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
