@@ -1039,12 +1039,32 @@ def panorama_block(ctx, pv, torch, dev, with_votes=True):
     return out
 
 
+def cpu_quota():
+    """CPUs this process may use on average: the cgroup's CFS quota (cpu.max: "<quota us> <period us>") when there is one, else None.  The GPU boxes of this
+    pool show 256 hardware threads and a quota of 16: more threads than that only run in bursts until the period's budget is spent, and then stall."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                return float(quota) / float(period)
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / p
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):
     """The CPU oracle (restated reference algorithm: Jet<12> AutoDiff through the reference's rotation
     chain, base/CostFunction.h) timed on this box's host cores on a bounded sample of the same batch:
     the residual blocks of the first pairs, all host threads (Ceres runs num_threads = 25 upstream)."""
     from oracle import oracle as orc
-    threads = orc.num_threads()
+    quota = cpu_quota()
+    threads = orc.num_threads() if not quota else max(1, min(orc.num_threads(), int(quota + 0.5)))     # threads beyond the cgroup's quota are throttled, not run
     npairs = min(len(ref), 64)
     small = ctx.assoc_point2plane([dscans[int(r)] for r in ref[:npairs]], [dscans[int(n)] for n in nei[:npairs]], args.tolerance, 1.0,
                                   kind=kind, flags=pv.FLAG_NORMALIZE_DISTANCE)
@@ -1053,7 +1073,7 @@ def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):
     rid = np.repeat(rr, np.diff(off)).astype(np.int32); nid = np.repeat(nn, np.diff(off)).astype(np.int32)
     orows = np.concatenate([rows, np.ones((rows.shape[0], 1))], axis=1)
     n = rows.shape[0]
-    orc.evaluate(kind, orows[:min(n, 50_000)], rid[:min(n, 50_000)], nid[:min(n, 50_000)], aa, t, normalize=True, jac=True)  # warm the thread pool
+    orc.evaluate(kind, orows[:min(n, 50_000)], rid[:min(n, 50_000)], nid[:min(n, 50_000)], aa, t, normalize=True, jac=True, threads=threads)  # warm the thread pool
     # three samples of cpu_seconds each, median reported with the spread: on a 128-thread box shared with the driver the figure moved by
     # 30 % between rounds on unchanged code (4.42 -> 3.18 M eval/s) — it is a noisy number and the line says so
     samples = []
@@ -1062,7 +1082,7 @@ def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):
         reps = 0
         t0 = time.perf_counter()
         while True:
-            orc.evaluate(kind, orows, rid, nid, aa, t, normalize=True, jac=True)
+            orc.evaluate(kind, orows, rid, nid, aa, t, normalize=True, jac=True, threads=threads)
             reps += 1
             dt = time.perf_counter() - t0
             if dt >= args.cpu_seconds:
@@ -1092,7 +1112,7 @@ def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):
         v_o0 = n0 * reps0 / dt2 / 1e6
     except Exception:
         pass
-    return {"value": samples[1], "unit": "M evals/s", "cores": threads, "kind": "port",
+    return {"value": samples[1], "unit": "M evals/s", "cores": threads, "kind": "port", "cpu_quota": quota, "hardware_threads": os.cpu_count(),
             "samples": samples, "spread": (samples[-1] - samples[0]) / max(samples[1], 1e-12), "noise_note": "median of 3 x %.0f s; min / max beside it" % args.cpu_seconds,
             "value_1thread": n1 * reps1 / dt1 / 1e6, "value_1thread_O0": v_o0,
             "sample": "%d residual blocks of the first %d pairs x %d repetitions; r + 1x12 J by Jet<12> AutoDiff (restated "

@@ -581,6 +581,10 @@ typedef struct pvlm_ring_result {
   const float* curvature;           /* cloudCurvature[i]; -1 where upstream leaves it unset                                      */
   const int* half_window;           /* left_neighbor[i] = i - half_window[i], right_neighbor[i] = i + half_window[i]; -1 = unset  */
   const float* range;               /* cloudDistance[i] = range_image(point_idx_to_image[i])  (:566-569)                         */
+  const int* sorted;                /* cloudSortInd: the six sectors of every ring (:707-723) ordered by curvature as ExtractEdgeFeatures2
+                                       :896 / ExtractPlaneFeatures2 :1110 sort them; index order outside the sectors                */
+  const unsigned char* sector_host; /* n_rings x 6: 1 = the sector holds equal curvatures (or a NaN, or > 2048 points): std::sort's
+                                       order of equal keys is the library's, `sorted` is the index order there and the caller sorts */
 } pvlm_ring_result;
 pvlm_status pvlm_ring_extract_batch(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* scans, int n_rings, int horizon_scans, int segment,
                                     pvlm_ring_batch** out);

@@ -899,7 +899,8 @@ class RawScanDesc(C.Structure):
 class RingResultDesc(C.Structure):
     _fields_ = [("n_raw", C.c_int), ("n_reordered", C.c_int), ("n_kept", C.c_int), ("resolved_points", C.c_int), ("resolved_edges", C.c_int), ("replayed", C.c_int),
                 ("ring_count_reordered", C.POINTER(C.c_int)), ("ring_count", C.POINTER(C.c_int)), ("source", C.POINTER(C.c_int)), ("ring_col", C.POINTER(C.c_int)),
-                ("curvature", C.POINTER(C.c_float)), ("half_window", C.POINTER(C.c_int)), ("range", C.POINTER(C.c_float))]
+                ("curvature", C.POINTER(C.c_float)), ("half_window", C.POINTER(C.c_int)), ("range", C.POINTER(C.c_float)), ("sorted", C.POINTER(C.c_int)),
+                ("sector_host", C.POINTER(C.c_ubyte))]
 
 
 class RingBatch:
@@ -941,7 +942,7 @@ class RingBatch:
         out = dict(n_raw=r.n_raw, n_reordered=r.n_reordered, n_kept=m, resolved_points=r.resolved_points, resolved_edges=r.resolved_edges, replayed=r.replayed,
                    ring_count_reordered=arr(r.ring_count_reordered, 64, np.int32), ring_count=arr(r.ring_count, 64, np.int32), source=arr(r.source, m, np.int32),
                    ring_col=arr(r.ring_col, m, np.int32), curvature=arr(r.curvature, m, np.float32), half_window=arr(r.half_window, m, np.int32),
-                   range=arr(r.range, m, np.float32))
+                   range=arr(r.range, m, np.float32), sorted=arr(r.sorted, m, np.int32), sector_host=arr(r.sector_host, self.n_rings * 6, np.uint8))
         return out
 
     def fetch(self, scan, state):
@@ -962,4 +963,5 @@ class RingBatch:
         return dict(n_reordered=res["n_reordered"], n_kept=res["n_kept"], cloud_reordered=c0, rc_reordered=rc0, range_image=image, image_to_point_reordered=i2p0,
                     ring_count_reordered=res["ring_count_reordered"], cloud_kept=c1, rc_kept=rc1, image_to_point_kept=i2p1, ring_count=res["ring_count"],
                     curvature=res["curvature"], half_window=res["half_window"], range=res["range"], source=res["source"], ring_col=res["ring_col"],
-                    resolved_points=res["resolved_points"], resolved_edges=res["resolved_edges"], replayed=res["replayed"])
+                    resolved_points=res["resolved_points"], resolved_edges=res["resolved_edges"], replayed=res["replayed"], sorted=res["sorted"],
+                    sector_host=res["sector_host"])

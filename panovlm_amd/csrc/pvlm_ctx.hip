@@ -317,7 +317,7 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   pvlm_i_assoc_ws_free(ctx);
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);
-  if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
+  for (int k = 0; k < ctx->ring_pool; ++k) (void)hipHostFree(ctx->h_ring[k]);
   pvlm_i_spd_plan_release(ctx);
   if (ctx->stage.base) (void)hipHostFree(ctx->stage.base);
   pvlm_i_free(ctx, ctx->d_aa); pvlm_i_free(ctx, ctx->d_t); pvlm_i_free(ctx, ctx->d_pose_tab); pvlm_i_free(ctx, ctx->d_ws); pvlm_i_free(ctx, ctx->d_neq_tmp);

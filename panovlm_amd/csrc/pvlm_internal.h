@@ -70,8 +70,10 @@ struct pvlm_ctx {
   double* d_neq_tmp = nullptr; size_t neq_tmp_count = 0;
   // pinned staging of pvlm_scan_upload[_batch] (grow-only)
   void* h_up = nullptr; size_t up_bytes = 0;
-  // pinned buffer a destroyed pvlm_ring_batch leaves behind for the next one (hipHostMalloc of a Room batch's 260 MB: 51 ms)
-  void* h_ring = nullptr; size_t ring_bytes = 0;
+  // pinned buffers destroyed pvlm_ring_batches leave behind for the next ones (hipHostMalloc of a Room batch's 260 MB: 51 ms).  Several: the host
+  // mirror runs a call's scans as a sequence of batches whose results stay alive until the call ends (the picks of one overlap the device stages of the next)
+  static constexpr int kRingPool = 16;
+  void* h_ring[kRingPool] = {}; size_t ring_bytes[kRingPool] = {}; int ring_pool = 0;
   // pinned staging arena of every other host <-> device copy (pvlm_i_h2d_q / pvlm_i_d2h_q / pvlm_i_sync)
   pvlm_stage stage;
   hipStream_t own_stream = nullptr;

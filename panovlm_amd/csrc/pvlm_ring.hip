@@ -18,6 +18,7 @@
 // build on this machine would call) before the dependent stage runs.  Comparisons between two azimuths (the +z-crossing
 // test, :447-461) are interval comparisons; a scan whose crossing cannot be certified gets exact azimuths for all its
 // points from the host and is replayed.  No decision is ever taken from an uncertified device value.
+#include "pvlm_stdsort.h"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(1024) void k_seg_compact(const RingScan* __restrict
 // twice; where upstream would read past the end of the cloud (undefined behaviour) the walk stops and the point has no curvature.
 __global__ __launch_bounds__(256) void k_curvature(const RingScan* __restrict__ scans, const PtBlock* __restrict__ blocks, const int* __restrict__ ring_count2,
                                                    const int* __restrict__ counts, const float4* __restrict__ cloud2, const float* __restrict__ range2,
-                                                   float* __restrict__ curvature, int* __restrict__ half_window) {
+                                                   float* __restrict__ curvature, int* __restrict__ half_window, int* __restrict__ order) {
   __shared__ int begin[kMaxRings + 1];
   const PtBlock b = blocks[blockIdx.x];
   const RingScan sc = scans[b.scan];
@@ -342,6 +343,119 @@ __global__ __launch_bounds__(256) void k_curvature(const RingScan* __restrict__ 
   float curv; int half;
   curvature_point(P, range2 + sc.pt0, n, begin[ring] + 5, begin[ring + 1] - 6, i, &curv, &half);
   curvature[sc.pt0 + i] = curv; half_window[sc.pt0 + i] = half;
+  order[sc.pt0 + i] = i;            // outside the sectors (and in sectors left to the host) the pick order is the index order
+}
+
+// ---- K23: the order the picks visit a sector in (:707-723 cut a ring into six sectors; ExtractEdgeFeatures2 :896 and ExtractPlaneFeatures2 :1110
+// walk each sector's points by curvature: std::sort of the index range with `curvature[a] < curvature[b]`).  One workgroup per sector: the keys
+// (order-preserving integer image of the float, point index) go through a bitonic network in LDS.  With distinct curvatures every correct sort
+// returns this permutation.  Where two curvatures of a sector are equal, the order of the equal elements is what libstdc++'s introsort leaves: the
+// first lane then runs that algorithm (pvlm_stdsort.h, pinned against the real std::sort by tests/test_stdsort_cpu.py and by
+// stdsort_selfcheck() below at the first call) on the sector's keys in LDS.  Left to the host (flag 1, index order): a sector with a NaN,
+// with more than kSectorMax points, or every tied sector when the self-check failed (`ties_on_device` == 0).
+constexpr int kSectorMax = 2048, kTieSmall = 512;
+__device__ inline unsigned curvature_key(float c) {
+  unsigned b = __float_as_uint(c);
+  if (c == 0.f) b = 0u;                                         // -0 == +0
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void k_sector_sort(const RingScan* __restrict__ scans, int rings, const int* __restrict__ ring_count2, const int* __restrict__ counts,
+                                                     const float* __restrict__ curvature, int ties_on_device, int* __restrict__ order,
+                                                     unsigned char* __restrict__ sector_host, int* __restrict__ tie_count, int4* __restrict__ tie_list, int tie_cap) {
+  __shared__ unsigned long long key[kSectorMax];
+  __shared__ int flagged;
+  const int s = blockIdx.y, ring = blockIdx.x / 6, j = blockIdx.x % 6, t = threadIdx.x;
+  const RingScan sc = scans[s];
+  const int n = counts[2 * s + 1];
+  int begin = 0;
+  for (int r = 0; r < ring; ++r) begin += ring_count2[(size_t)s * kMaxRings + r];
+  const int lo = begin + 5, hi = begin + ring_count2[(size_t)s * kMaxRings + ring] - 6, span = hi - lo;   // scanStartInd, scanEndInd (:520-522)
+  unsigned char* out_flag = sector_host + ((size_t)s * rings + ring) * 6 + j;
+  if (n == 0 || span < 6) { if (t == 0) *out_flag = 0; return; }                                          // the host never sorts such a ring
+  const int sp = lo + span * j / 6, ep = lo + span * (j + 1) / 6 - 1, m = ep - sp + 1;
+  if (m < 2) { if (t == 0) *out_flag = 0; return; }
+  if (m > kSectorMax) { if (t == 0) *out_flag = 1; return; }
+  int P = 2;
+  while (P < m) P <<= 1;
+  if (t == 0) flagged = 0;
+  __syncthreads();
+  const float* c = curvature + sc.pt0;
+  for (int k = t; k < P; k += 256) {
+    unsigned long long v = ~0ull;
+    if (k < m) {
+      const float x = c[sp + k];
+      if (x != x) flagged = 2;                                                                            // NaN: `<` is no order at all
+      v = ((unsigned long long)curvature_key(x) << 32) | (unsigned)(sp + k);
+    }
+    key[k] = v;
+  }
+  __syncthreads();
+  if (flagged == 2) { if (t == 0) *out_flag = 1; return; }
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int k = t; k < (P >> 1); k += 256) {
+        const int a = 2 * k - (k & (stride - 1)), b = a + stride;          // the k-th compare-exchange pair of this stage
+        const bool up = (a & size) == 0;
+        const unsigned long long x = key[a], y = key[b];
+        if ((x > y) == up) { key[a] = y; key[b] = x; }
+      }
+      __syncthreads();
+    }
+  for (int k = t; k + 1 < m; k += 256) if ((key[k] >> 32) == (key[k + 1] >> 32)) flagged = 1;
+  __syncthreads();
+  if (!flagged) {
+    for (int k = t; k < m; k += 256) order[sc.pt0 + sp + k] = (int)(unsigned)key[k];
+    if (t == 0) *out_flag = 0;
+    return;
+  }
+  // equal curvatures: the sector goes on the list of k_sector_ties (index order until then); without the self-check's blessing, to the host
+  if (t == 0) {
+    if (!ties_on_device) *out_flag = 1;
+    else { *out_flag = 0; const int at = atomicAdd(tie_count + (m > kTieSmall ? 1 : 0), 1); tie_list[(m > kTieSmall ? tie_cap : 0) + at] = make_int4(s, sp, m, (int)(out_flag - sector_host)); }
+  }
+}
+
+// std::sort's own steps (pvlm_stdsort.h) on the sectors k_sector_sort listed: one wave per sector, its first lane sorting packed (key, index) words in
+// LDS by key alone — the comparator std::sort was given looks at the curvature only, which is what makes the order of equal keys the algorithm's.
+template <int CAP>
+__global__ __launch_bounds__(64) void k_sector_ties(const RingScan* __restrict__ scans, const int4* __restrict__ list, const int* __restrict__ count,
+                                                    const float* __restrict__ curvature, int* __restrict__ order, unsigned char* __restrict__ sector_host) {
+  __shared__ unsigned long long e[CAP];
+  __shared__ int sane;
+  for (int item = blockIdx.x; item < *count; item += gridDim.x) {
+    const int4 it = list[item];
+    const int sp = it.y, m = it.z, t = threadIdx.x;
+    const long long pt0 = scans[it.x].pt0;
+    const float* c = curvature + pt0;
+    for (int k = t; k < m; k += 64) e[k] = ((unsigned long long)curvature_key(c[sp + k]) << 32) | (unsigned)(sp + k);
+    __syncthreads();
+    if (t == 0) sane = pvlm_stdsort::sort(e, m, [](unsigned long long x, unsigned long long y) { return (unsigned)(x >> 32) < (unsigned)(y >> 32); }) ? 1 : 0;
+    __syncthreads();
+    if (sane) for (int k = t; k < m; k += 64) order[pt0 + sp + k] = (int)(unsigned)e[k];
+    else if (t == 0) sector_host[it.w] = 1;                       // cannot happen with an order-preserving integer key; the host's std::sort then
+    __syncthreads();
+  }
+}
+
+// the restated introsort against the std::sort this library was built with, on tie-heavy keys: the condition for ordering tied sectors on the device
+static bool stdsort_selfcheck() {
+  static const bool ok = [] {
+    unsigned long long rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    for (int trial = 0; trial < 64; ++trial) {
+      const int n = 17 + (int)(next() % 1500);
+      const int levels = 1 + (int)(next() % (trial % 2 ? 8 : 200));
+      std::vector<float> key((size_t)n);
+      for (float& k : key) k = (float)(next() % (unsigned)levels) * 0.125f - 1.f;
+      std::vector<int> a((size_t)n), b((size_t)n);
+      for (int i = 0; i < n; ++i) a[(size_t)i] = b[(size_t)i] = i;
+      const float* kp = key.data();
+      std::sort(a.begin(), a.end(), [kp](int x, int y) { return kp[x] < kp[y]; });
+      if (!pvlm_stdsort::sort(b.data(), n, [kp](int x, int y) { return kp[x] < kp[y]; }) || a != b) return false;
+    }
+    return true;
+  }();
+  return ok;
 }
 
 }  // namespace
@@ -359,9 +473,10 @@ struct pvlm_ring_batch {
   RingScan* d_scans = nullptr;
   float4* d_cloud_scan = nullptr; int2* d_rc = nullptr; float* d_range_image = nullptr; int* d_image_to_point = nullptr;
   float4* d_cloud2 = nullptr; int* d_image_to_point2 = nullptr;
-  // pinned host results: kept state, 5 arrays of total_points
+  // pinned host results: kept state, 6 arrays of total_points + 6 sector flags per ring
   char* h_results = nullptr; size_t results_bytes = 0;
   const int* h_source = nullptr; const int* h_ring_col = nullptr; const float* h_curvature = nullptr; const int* h_half = nullptr; const float* h_range = nullptr;
+  const int* h_order = nullptr; const unsigned char* h_sector_host = nullptr;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -401,7 +516,8 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   int2* d_colpos = nullptr; int* d_ring_count = nullptr; int2* d_status = nullptr; PtBlock* d_blocks = nullptr; int* d_source = nullptr; int* d_winner = nullptr;
   unsigned char* d_edges = nullptr; EdgeQuery* d_queries = nullptr; int* d_parent = nullptr; int* d_root = nullptr; int* d_comp_size = nullptr;
   unsigned long long* d_row_mask = nullptr; int* d_source2 = nullptr; int* d_ring_col2 = nullptr; float* d_range2 = nullptr; int* d_ring_count2 = nullptr;
-  int* d_counts = nullptr; float* d_curv = nullptr; int* d_half = nullptr;
+  int* d_counts = nullptr; float* d_curv = nullptr; int* d_half = nullptr; int* d_order = nullptr; unsigned char* d_sector = nullptr; int4* d_ties = nullptr;
+  const size_t n_sectors = (size_t)n_scans * n_rings * 6;
   const int query_cap = 1 << 16;
   pvlm_status st = PVLM_OK;
 #define RING_GET(ptr, count) if (!st) st = tmp.get(&ptr, count)
@@ -413,15 +529,19 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   RING_GET(d_source, NP); RING_GET(d_winner, NC); RING_GET(d_edges, NC + 4); RING_GET(d_queries, (size_t)query_cap); RING_GET(d_parent, NC);
   RING_GET(d_root, NC); RING_GET(d_comp_size, NC); RING_GET(d_row_mask, NC); RING_GET(d_source2, NP); RING_GET(d_ring_col2, NP); RING_GET(d_range2, NP);
   RING_GET(d_ring_count2, (size_t)n_scans * kMaxRings); RING_GET(d_counts, (size_t)n_scans * 2); RING_GET(d_curv, NP); RING_GET(d_half, NP);
+  RING_GET(d_order, NP); RING_GET(d_sector, n_sectors); RING_GET(d_ties, 2 * n_sectors);
 #undef RING_GET
 #undef RING_KEEP
   if (st) return (st);
   pvlm_i_trace("ring: device memory");
-  // ---- pinned buffer: raw points on the way up (16 B / point), the five result arrays on the way down (20 B / point)
-  const size_t pinned = NP * 20 + 256;
-  if (ctx->h_ring && ctx->ring_bytes >= pinned) {
-    B->h_results = (char*)ctx->h_ring; B->results_bytes = ctx->ring_bytes;
-    ctx->h_ring = nullptr; ctx->ring_bytes = 0;
+  // ---- pinned buffer: raw points on the way up (16 B / point), the six result arrays (24 B / point) and the sector flags on the way down
+  const size_t pinned = NP * 24 + n_sectors + 256;
+  int fit = -1;                                    // the smallest pooled buffer that is large enough
+  for (int k = 0; k < ctx->ring_pool; ++k) if (ctx->ring_bytes[k] >= pinned && (fit < 0 || ctx->ring_bytes[k] < ctx->ring_bytes[fit])) fit = k;
+  if (fit >= 0) {
+    B->h_results = (char*)ctx->h_ring[fit]; B->results_bytes = ctx->ring_bytes[fit];
+    --ctx->ring_pool;
+    ctx->h_ring[fit] = ctx->h_ring[ctx->ring_pool]; ctx->ring_bytes[fit] = ctx->ring_bytes[ctx->ring_pool];
   } else if (hipHostMalloc((void**)&B->h_results, pinned, hipHostMallocDefault) == hipSuccess) {
     B->results_bytes = pinned;
   } else { B->h_results = nullptr; PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %zu bytes of pinned memory unavailable", pinned); return (PVLM_ERR_NOMEM); }
@@ -577,17 +697,25 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   // ---- K21 / K22
   hipLaunchKernelGGL(k_seg_compact, dim3((unsigned)n_scans), dim3(1024), 0, S, B->d_scans, n_rings, horizon, B->segment, d_ring_count, B->d_cloud_scan, d_source, B->d_rc,
                      B->d_range_image, d_root, d_comp_size, d_row_mask, B->d_cloud2, d_source2, d_ring_col2, d_range2, B->d_image_to_point2, d_ring_count2, d_counts);
-  hipLaunchKernelGGL(k_curvature, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, d_ring_count2, d_counts, B->d_cloud2, d_range2, d_curv, d_half);
+  hipLaunchKernelGGL(k_curvature, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, d_ring_count2, d_counts, B->d_cloud2, d_range2, d_curv, d_half, d_order);
+  hipLaunchKernelGGL(k_sector_sort, dim3((unsigned)(n_rings * 6), (unsigned)n_scans), dim3(256), 0, S, B->d_scans, n_rings, d_ring_count2, d_counts, d_curv, stdsort_selfcheck() ? 1 : 0, d_order, d_sector, d_counter + 2, d_ties, (int)n_sectors);
+  {
+    const unsigned waves = 256u * 16u;                                     // persistent: every wave walks the list with a grid stride
+    hipLaunchKernelGGL(k_sector_ties<kTieSmall>, dim3(waves), dim3(64), 0, S, B->d_scans, d_ties, d_counter + 2, d_curv, d_order, d_sector);
+    hipLaunchKernelGGL(k_sector_ties<kSectorMax>, dim3(waves / 4), dim3(64), 0, S, B->d_scans, d_ties + n_sectors, d_counter + 3, d_curv, d_order, d_sector);
+  }
   (void)hipEventRecord(ev[7], S);
   // ---- results
   char* h = B->h_results;
   B->h_source = (const int*)h; B->h_ring_col = (const int*)(h + NP * 4); B->h_curvature = (const float*)(h + NP * 8); B->h_half = (const int*)(h + NP * 12);
-  B->h_range = (const float*)(h + NP * 16);
+  B->h_range = (const float*)(h + NP * 16); B->h_order = (const int*)(h + NP * 20); B->h_sector_host = (const unsigned char*)(h + NP * 24);
   PVLM_HIP(ctx, hipMemcpyAsync(h, d_source2, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 4, d_ring_col2, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 8, d_curv, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 12, d_half, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16, d_range2, NP * 4, hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 20, d_order, NP * 4, hipMemcpyDeviceToHost, S));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 24, d_sector, n_sectors, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(B->counts.data(), d_counts, (size_t)n_scans * 2 * sizeof(int), hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(B->ring_count.data(), d_ring_count, (size_t)n_scans * kMaxRings * sizeof(int), hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(B->ring_count2.data(), d_ring_count2, (size_t)n_scans * kMaxRings * sizeof(int), hipMemcpyDeviceToHost, S));
@@ -610,12 +738,17 @@ pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* b) {
     pvlm_i_free(ctx, b->d_image_to_point); pvlm_i_free(ctx, b->d_cloud2); pvlm_i_free(ctx, b->d_image_to_point2);
   }
   if (b->h_results) {
-    if (ctx && b->results_bytes > ctx->ring_bytes) {      // the larger buffer stays with the context for the next batch
-      if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
-      ctx->h_ring = b->h_results; ctx->ring_bytes = b->results_bytes;
-    } else {
-      (void)hipHostFree(b->h_results);
+    void* gone = b->h_results;                             // the buffer stays with the context for the next batch; a full pool lets its smallest one go
+    if (ctx) {
+      size_t bytes = b->results_bytes;
+      if (ctx->ring_pool < pvlm_ctx::kRingPool) { ctx->h_ring[ctx->ring_pool] = gone; ctx->ring_bytes[ctx->ring_pool] = bytes; ++ctx->ring_pool; gone = nullptr; }
+      else {
+        int least = 0;
+        for (int k = 1; k < ctx->ring_pool; ++k) if (ctx->ring_bytes[k] < ctx->ring_bytes[least]) least = k;
+        if (ctx->ring_bytes[least] < bytes) { std::swap(ctx->h_ring[least], gone); ctx->ring_bytes[least] = bytes; }
+      }
     }
+    if (gone) (void)hipHostFree(gone);
   }
   delete b;
   return PVLM_OK;
@@ -665,6 +798,7 @@ pvlm_status pvlm_ring_batch_scan(const pvlm_ring_batch* b, int scan, pvlm_ring_r
   if (b->h_source) {
     r->source = b->h_source + sc.pt0; r->ring_col = b->h_ring_col + sc.pt0; r->curvature = b->h_curvature + sc.pt0; r->half_window = b->h_half + sc.pt0;
     r->range = b->h_range + sc.pt0;
+    r->sorted = b->h_order + sc.pt0; r->sector_host = b->h_sector_host + (size_t)scan * b->rings * 6;
   }
   return PVLM_OK;
 }

@@ -15,8 +15,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <numeric>
 #include <stdexcept>
@@ -110,6 +113,27 @@ struct StageTimer {   // wall clock of a host stage into pvlm::StageSeconds()
   const char* name; std::chrono::steady_clock::time_point t0;
   explicit StageTimer(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
   ~StageTimer() { AddStageSeconds(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+};
+
+// PVLM_FEATURE_PROFILE=1: thread-seconds of the host stages of ExtractFeaturesBatch on stderr (tools/feature_batch_bench.py)
+struct FeatureProfile {
+  std::atomic<long long> ns[8];
+  bool on;
+  FeatureProfile() : on(std::getenv("PVLM_FEATURE_PROFILE") != nullptr) { for (auto& v : ns) v = 0; }
+  void Report(const char* what, double wall_ms, double ring_ms, double producer_ms) {
+    static const char* name[8] = {"layout", "sector sort", "edge picks", "EdgeToLine", "plane picks", "voxel grid", "", ""};
+    fprintf(stderr, "feature_profile %s wall_ms %.2f ring_batch_events_ms %.2f producer_wall_ms %.2f thread_ms:", what, wall_ms, ring_ms, producer_ms);
+    for (int k = 0; k < 6; ++k) fprintf(stderr, " [%s] %.2f", name[k], 1e-6 * (double)ns[k].exchange(0));
+    fprintf(stderr, "\n");
+  }
+};
+FeatureProfile& Profile() { static FeatureProfile p; return p; }
+struct ProfileSpan {
+  int slot; std::chrono::steady_clock::time_point t0;
+  explicit ProfileSpan(int k) : slot(Profile().on ? k : -1) { if (slot >= 0) t0 = std::chrono::steady_clock::now(); }
+  void Next(int k) { Stop(); if (Profile().on) { slot = k; t0 = std::chrono::steady_clock::now(); } }
+  void Stop() { if (slot >= 0) Profile().ns[slot] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); slot = -1; }
+  ~ProfileSpan() { Stop(); }
 };
 
 // union-find over range-image cells
@@ -281,16 +305,20 @@ void Velodyne::ExtractFeatures(float max_curvature, float intersect_angle_thresh
       left[i] = a; right[i] = b;
     }
   }
-  PickFeatures(max_curvature, intersect_angle_threshold, curvature, range, left, right, trace, edge_to_line);
+  PickFeatures(max_curvature, intersect_angle_threshold, PickInputs{curvature.data(), range.data(), left.data(), right.data(), nullptr, nullptr, nullptr}, trace, edge_to_line);
 }
 
-void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold, std::vector<float>& curvature, const std::vector<float>& range, std::vector<int>& left,
-                            std::vector<int>& right, ExtractionTrace* trace, bool edge_to_line) {
+void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold, const PickInputs& in, ExtractionTrace* trace, bool edge_to_line) {
   const RingLayout& L = layout_;
   const int n = (int)cloud_scan.size();
   const PointCloud& P = cloud_scan;
+  const float* curvature = in.curvature;
+  const float* range = in.range;
+  auto left_of = [&](int i) { return in.left ? in.left[i] : (in.half_window[i] < 0 ? -1 : i - in.half_window[i]); };
+  auto right_of = [&](int i) { return in.right ? in.right[i] : (in.half_window[i] < 0 ? -1 : i + in.half_window[i]); };
   std::vector<int> state(n, POINT_NORMAL), order(n);
-  std::iota(order.begin(), order.end(), 0);
+  if (in.sorted) std::copy(in.sorted, in.sorted + n, order.begin());
+  else std::iota(order.begin(), order.end(), 0);
   // the six sectors of a ring (:707-723) — the same integer arithmetic everywhere below
   auto sector = [&](int ring, int j, int* sp, int* ep) {
     const int lo = L.scanStartInd[ring], span = L.scanEndInd[ring] - lo;
@@ -298,11 +326,15 @@ void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold
     *ep = lo + span * (j + 1) / 6 - 1;
   };
   auto usable = [&](int ring) { return L.scanEndInd[ring] - L.scanStartInd[ring] >= 6; };
+  ProfileSpan span(1);
   {
-    const float* c = curvature.data();
+    // sectors that arrive sorted (pvlm_ring_result::sorted: distinct curvatures, so the order is the one any sort returns) are taken as they are;
+    // the others — equal curvatures, whose order is libstdc++'s — are in index order and sorted here, as the per-scan path sorts all of them
+    const float* c = curvature;
     for (int ring = 0; ring < N_SCANS; ++ring) {
       if (!usable(ring)) continue;
       for (int j = 0; j < 6; ++j) {
+        if (in.sorted && !in.sector_host[ring * 6 + j]) continue;
         int sp, ep; sector(ring, j, &sp, &ep);
         std::sort(order.begin() + sp, order.begin() + ep + 1, [c](int x, int y) { return c[x] < c[y]; });
       }
@@ -323,6 +355,7 @@ void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold
 
   // ---- ExtractEdgeFeatures2 (:883-1000): per sector, from the largest curvature down, at most 3 sharp + 27 less sharp
   cornerSharp.clear(); cornerLessSharp.clear();
+  span.Next(2);
   for (int ring = 0; ring < N_SCANS; ++ring) {
     if (!usable(ring)) continue;
     for (int j = 0; j < 6; ++j) {
@@ -333,7 +366,7 @@ void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold
         if (state[ind] != POINT_NORMAL) continue;
         if (curvature[ind] > max_curvature || curvature[ind] < 0.1) continue;
         // incidence angle between the beam and the local surface direction (left - right window ends), degrees
-        const PointXYZI &a = P[ind], &l = P[left[ind]], &r = P[right[ind]];
+        const PointXYZI &a = P[ind], &l = P[left_of(ind)], &r = P[right_of(ind)];
         const float bx = l.x - r.x, by = l.y - r.y, bz = l.z - r.z;
         const float along = a.x * bx + (a.y * by + a.z * bz);
         const float blen = std::sqrt(bx * bx + (by * by + bz * bz));
@@ -352,7 +385,9 @@ void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold
     }
   }
   // ---- EdgeToLine (:752, :1269-1324): line segments from the edge points; does not touch the per-point state
+  span.Next(3);
   if (edge_to_line) EdgeToLine();
+  span.Next(4);
   // ---- ExtractPlaneFeatures2 (:1098-1189)
   surfFlat.clear(); surfLessFlat.clear();
   PointCloud ring_less_flat;
@@ -377,15 +412,20 @@ void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold
       for (int k = sp; k <= ep; ++k)      // note: k is a point index here, not a position in the sorted order (as upstream)
         if ((state[k] & POINT_NORMAL) > 0 && (state[k] & POINT_DISABLE) == 0 && curvature[k] < 0.3) ring_less_flat.push_back(P[k]);
     }
+    span.Next(5);
     VoxelGridAppend(ring_less_flat, 0.2f, (float)POINT_NORMAL, surfLessFlat);
+    span.Next(4);
   }
   PointCloud ground;
   for (int i = 0; i < n; ++i) if ((state[i] & POINT_GROUND) > 0) ground.push_back(P[i]);
+  span.Next(5);
   VoxelGridAppend(ground, 0.2f, (float)POINT_GROUND, surfLessFlat);
+  span.Stop();
   InvalidateDevice();
   if (trace) {
-    trace->curvature = std::move(curvature); trace->state = std::move(state); trace->sort_ind = std::move(order);
-    trace->left_neighbor = std::move(left); trace->right_neighbor = std::move(right);
+    trace->curvature.assign(curvature, curvature + n); trace->state = std::move(state); trace->sort_ind = std::move(order);
+    trace->left_neighbor.resize((size_t)n); trace->right_neighbor.resize((size_t)n);
+    for (int i = 0; i < n; ++i) { trace->left_neighbor[(size_t)i] = left_of(i); trace->right_neighbor[(size_t)i] = right_of(i); }
   }
 }
 
@@ -402,88 +442,115 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     todo.push_back(k);
   }
   if (todo.empty()) return;
+  const auto profile_t0 = std::chrono::steady_clock::now();
   const int rings = scans[todo[0]]->N_SCANS, horizon = scans[todo[0]]->horizon_scans;
   if (rings > 64) throw std::invalid_argument("ExtractFeatures: at most 64 rings");
   for (size_t k : todo) if (scans[k]->N_SCANS != rings || scans[k]->horizon_scans != horizon) throw std::invalid_argument("ExtractFeaturesBatch: the scans of a call share one range-image shape");
   std::vector<pvlm_raw_scan> raw(todo.size());
   for (size_t j = 0; j < todo.size(); ++j) { const PointCloud& c = scans[todo[j]]->cloud; raw[j] = pvlm_raw_scan{&c[0].x, (int)c.size(), (int)(sizeof(PointXYZI) / sizeof(float))}; }
   Engine& e = Engine::Default();
-  pvlm_ring_batch* batch = nullptr;
-  {
-    StageTimer stage_timer_("  (inside feature extraction) range-image stages of all scans on the GPU (pvlm_ring_extract_batch)");
-    const pvlm_status rc = pvlm_ring_extract_batch(e.ctx(), (int)todo.size(), raw.data(), rings, horizon, segment ? 1 : 0, &batch);
-    if (rc == PVLM_ERR_ARG || rc == PVLM_ERR_CAPACITY || rc == PVLM_ERR_NOMEM) {
-      // The batch form is stricter than the reference: it refuses a batch with a non-finite coordinate (upstream such a point gets ring -1 and is
-      // skipped, sensors/Velodyne.cpp:439-445) and gives up beyond its bounds on undecided segmentation edges / memory.  Neither is a reason to fail
-      // EstimatePose: the scans go through the per-scan host path, which skips such points exactly as upstream does.
-      fprintf(stderr, "ExtractFeaturesBatch: %s — falling back to the host extraction for this batch\n", pvlm_last_error(e.ctx()));
-      std::atomic<size_t> next{0};
-      std::mutex lock; std::exception_ptr failure;
-      auto host_work = [&]() {
-        for (size_t j = next++; j < todo.size(); j = next++) {
-          try {
-            Velodyne& v = *scans[todo[j]];
-            v.ReOrderVLP();
-            v.ExtractFeatures(max_curvature, intersect_angle_threshold, method, segment);
-          } catch (...) { std::lock_guard<std::mutex> g(lock); if (!failure) failure = std::current_exception(); }
+  // The scans go to the device as a sequence of batches: while the host threads pick the features of one batch, the next one is on the GPU (upload,
+  // K16-K23, download: PCIe-bound) under the one thread that talks to the context.  A batch lives until the call returns (the picks read its pinned arrays).
+  const size_t total = todo.size();
+  static const size_t n_parts = [] { const char* v = std::getenv("PVLM_FEATURE_PARTS"); const long k = v ? std::atol(v) : 0; return k > 0 ? (size_t)k : (size_t)2; }();
+  const size_t per_batch = total <= 48 ? total : std::max<size_t>(24, (total + n_parts - 1) / n_parts);
+  struct Part { pvlm_ring_batch* batch = nullptr; bool on_host = false; };
+  std::vector<Part> parts((total + per_batch - 1) / per_batch);
+  struct Release { pvlm_ctx* c; std::vector<Part>& p; ~Release() { for (Part& q : p) pvlm_ring_batch_destroy(c, q.batch); } } release{e.ctx(), parts};
+  std::mutex gate; std::condition_variable published_cv;
+  size_t published = 0;                        // scans (in `todo` order) whose batch is back from the device
+  bool production_failed = false;
+  double ring_ms = 0, producer_ms = 0;
+  auto produce = [&]() {
+    const auto produce_t0 = std::chrono::steady_clock::now();
+    StageTimer stage_timer_("  (inside feature extraction) range-image stages of all scans on the GPU (pvlm_ring_extract_batch), overlapped with the picks");
+    try {
+      for (size_t k = 0; k < parts.size(); ++k) {
+        const size_t first = k * per_batch, count = std::min(per_batch, total - first);
+        const pvlm_status rc = pvlm_ring_extract_batch(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, &parts[k].batch);
+        if (rc == PVLM_ERR_ARG || rc == PVLM_ERR_CAPACITY || rc == PVLM_ERR_NOMEM) {
+          // The batch form is stricter than the reference: it refuses a batch with a non-finite coordinate (upstream such a point gets ring -1 and is
+          // skipped, sensors/Velodyne.cpp:439-445) and gives up beyond its bounds on undecided segmentation edges / memory.  Neither is a reason to fail
+          // EstimatePose: these scans go through the per-scan host path, which skips such points exactly as upstream does.
+          fprintf(stderr, "ExtractFeaturesBatch: %s — falling back to the host extraction for %zu scans\n", pvlm_last_error(e.ctx()), count);
+          parts[k].on_host = true;
+        } else {
+          e.Check(rc, "pvlm_ring_extract_batch");
+          if (traces) {                             // the two images: device-resident, fetched for the parity tests only
+            for (size_t j = first; j < first + count; ++j) {
+              RingLayout& L = scans[todo[j]]->layout_;
+              L.range_image.assign((size_t)rings * horizon, 0.f); L.image_to_point_idx.assign((size_t)rings * horizon, -1);
+              e.Check(pvlm_ring_batch_fetch(e.ctx(), parts[k].batch, (int)(j - first), 1, nullptr, nullptr, L.range_image.data(), L.image_to_point_idx.data()), "pvlm_ring_batch_fetch");
+            }
+          }
+          double ms8[8] = {0};
+          if (pvlm_ring_batch_timing(parts[k].batch, ms8) == PVLM_OK) for (double v : ms8) ring_ms += v;
         }
-      };
-      pvlm_run_workers((size_t)std::max(1, std::min(num_threads, (int)todo.size())), host_work);
-      if (failure) std::rethrow_exception(failure);
+        { std::lock_guard<std::mutex> g(gate); published = first + count; }
+        published_cv.notify_all();
+      }
+      producer_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - produce_t0).count();
+    } catch (...) {
+      { std::lock_guard<std::mutex> g(gate); production_failed = true; }
+      published_cv.notify_all();
+      throw;
+    }
+  };
+  auto pick = [&](size_t j) {
+    Velodyne& v = *scans[todo[j]];
+    const Part& part = parts[j / per_batch];
+    if (part.on_host) {
+      v.ReOrderVLP();
+      v.ExtractFeatures(max_curvature, intersect_angle_threshold, method, segment, nullptr, edge_to_line);
       return;
     }
-    e.Check(rc, "pvlm_ring_extract_batch");
-  }
-  struct Release { pvlm_ctx* c; pvlm_ring_batch* b; ~Release() { pvlm_ring_batch_destroy(c, b); } } release{e.ctx(), batch};
-  if (traces) {                                   // the two images: device-resident, fetched for the parity tests only
-    for (size_t j = 0; j < todo.size(); ++j) {
-      RingLayout& L = scans[todo[j]]->layout_;
-      L.range_image.assign((size_t)rings * horizon, 0.f); L.image_to_point_idx.assign((size_t)rings * horizon, -1);
-      e.Check(pvlm_ring_batch_fetch(e.ctx(), batch, (int)j, 1, nullptr, nullptr, L.range_image.data(), L.image_to_point_idx.data()), "pvlm_ring_batch_fetch");
+    ProfileSpan span(0);
+    pvlm_ring_result r;
+    if (pvlm_ring_batch_scan(part.batch, (int)(j % per_batch), &r) != PVLM_OK) throw std::runtime_error("pvlm_ring_batch_scan failed");
+    RingLayout& L = v.layout_;
+    const std::vector<float> keep_image = std::move(L.range_image); const std::vector<int> keep_index = std::move(L.image_to_point_idx);
+    L = RingLayout();
+    L.range_image = keep_image; L.image_to_point_idx = keep_index;
+    L.scanStartInd.assign(rings, 0); L.scanEndInd.assign(rings, 0);
+    // < 10 % of the re-ordered points survive the segmentation: the scan is dropped (:551-556); the cloud is left as Segmentation left it
+    const int n = r.n_kept;
+    v.cloud_scan.resize((size_t)n);
+    L.point_idx_to_image.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      const PointXYZI& p = v.cloud[(size_t)r.source[i]];
+      const int ring = r.ring_col[i] >> 16;
+      v.cloud_scan[(size_t)i] = PointXYZI{p.x, p.y, p.z, (float)ring};
+      L.point_idx_to_image[(size_t)i] = std::pair<int, int>(ring, r.ring_col[i] & 0xFFFF);
     }
-  }
+    int begin = 0;
+    for (int q = 0; q < rings; ++q) { L.scanStartInd[q] = begin + 5; begin += r.ring_count[q]; L.scanEndInd[q] = begin - 6; }
+    if (n < r.n_reordered * 0.1) { fprintf(stderr, "LiDAR data %d has something wrong\n", v.id); v.valid = false; return; }
+    if (n == 0) return;
+    span.Stop();
+    v.PickFeatures(max_curvature, intersect_angle_threshold, PickInputs{r.curvature, r.range, nullptr, nullptr, r.half_window, r.sorted, r.sector_host},
+                   traces ? &(*traces)[todo[j]] : nullptr, edge_to_line);
+  };
   StageTimer stage_timer_picks_("  (inside feature extraction) picks, EdgeToLine, voxel grid (host, scan-parallel)");
   std::atomic<size_t> next{0};
+  std::atomic<bool> producer_taken{false};
   std::mutex failure_lock;
   std::exception_ptr failure;
   auto work = [&]() {
-    for (size_t j = next++; j < todo.size(); j = next++) {
-      try {
-        Velodyne& v = *scans[todo[j]];
-        pvlm_ring_result r;
-        if (pvlm_ring_batch_scan(batch, (int)j, &r) != PVLM_OK) throw std::runtime_error("pvlm_ring_batch_scan failed");
-        RingLayout& L = v.layout_;
-        const std::vector<float> keep_image = std::move(L.range_image); const std::vector<int> keep_index = std::move(L.image_to_point_idx);
-        L = RingLayout();
-        L.range_image = keep_image; L.image_to_point_idx = keep_index;
-        L.scanStartInd.assign(rings, 0); L.scanEndInd.assign(rings, 0);
-        // < 10 % of the re-ordered points survive the segmentation: the scan is dropped (:551-556); the cloud is left as Segmentation left it
-        const int n = r.n_kept;
-        v.cloud_scan.resize((size_t)n);
-        L.point_idx_to_image.resize((size_t)n);
-        for (int i = 0; i < n; ++i) {
-          const PointXYZI& p = v.cloud[(size_t)r.source[i]];
-          const int ring = r.ring_col[i] >> 16;
-          v.cloud_scan[(size_t)i] = PointXYZI{p.x, p.y, p.z, (float)ring};
-          L.point_idx_to_image[(size_t)i] = std::pair<int, int>(ring, r.ring_col[i] & 0xFFFF);
-        }
-        int begin = 0;
-        for (int q = 0; q < rings; ++q) { L.scanStartInd[q] = begin + 5; begin += r.ring_count[q]; L.scanEndInd[q] = begin - 6; }
-        if (n < r.n_reordered * 0.1) { fprintf(stderr, "LiDAR data %d has something wrong\n", v.id); v.valid = false; continue; }
-        if (n == 0) continue;
-        std::vector<float> curvature(r.curvature, r.curvature + n), range(r.range, r.range + n);
-        std::vector<int> left((size_t)n), right((size_t)n);
-        for (int i = 0; i < n; ++i) { const int h = r.half_window[i]; left[(size_t)i] = h < 0 ? -1 : i - h; right[(size_t)i] = h < 0 ? -1 : i + h; }
-        v.PickFeatures(max_curvature, intersect_angle_threshold, curvature, range, left, right, traces ? &(*traces)[todo[j]] : nullptr, edge_to_line);
-      } catch (...) {
-        std::lock_guard<std::mutex> g(failure_lock);
-        if (!failure) failure = std::current_exception();
+    if (!producer_taken.exchange(true)) produce();              // the first thread to arrive feeds the device, then picks like the others
+    for (size_t j = next++; j < total; j = next++) {
+      {
+        std::unique_lock<std::mutex> g(gate);
+        published_cv.wait(g, [&] { return published > j || production_failed; });
+        if (published <= j) return;
       }
+      try { pick(j); }
+      catch (...) { std::lock_guard<std::mutex> g(failure_lock); if (!failure) failure = std::current_exception(); }
     }
   };
-  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(num_threads, 1), todo.size(), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(num_threads, 1), total + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   pvlm_run_workers(n_threads, work);
   if (failure) std::rethrow_exception(failure);
+  if (Profile().on) Profile().Report("ExtractFeaturesBatch", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - profile_t0).count(), ring_ms, producer_ms);
 }
 
 }  // namespace pvlm

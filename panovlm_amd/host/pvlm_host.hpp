@@ -190,8 +190,12 @@ class Velodyne {
   RingLayout layout_;
   void Segmentation();                            // sensors/Velodyne.cpp:1438-1586
   // the second half of ExtractFeatures (:707-753, ExtractEdgeFeatures2, EdgeToLine, ExtractPlaneFeatures2) from the per-point arrays
-  void PickFeatures(float max_curvature, float intersect_angle_threshold, std::vector<float>& curvature, const std::vector<float>& range, std::vector<int>& left,
-                    std::vector<int>& right, ExtractionTrace* trace, bool edge_to_line);
+  // per-point arrays the picks read (cloud_scan.size() entries each; the caller keeps them alive).  Window ends: left / right, or — when both are
+  // null — index -+ half_window (-1 = no window).  sorted / sector_host: the sector orders of pvlm_ring_result, or null = sort every sector here.
+  struct PickInputs {
+    const float* curvature; const float* range; const int* left; const int* right; const int* half_window; const int* sorted; const unsigned char* sector_host;
+  };
+  void PickFeatures(float max_curvature, float intersect_angle_threshold, const PickInputs& in, ExtractionTrace* trace, bool edge_to_line);
   mutable pvlm_scan* dev_ = nullptr;
 };
 

@@ -111,7 +111,10 @@ struct Grower {
     std::vector<int> order = members;                     // the order the scatter sums see: members ascending, then accepted points as they come
     int a, b; double length;
     Extremes(P, order, &a, &b, &length);
-    Vector6d line = Fit(order, 3.0);
+    // upstream fits the current members first (tolerance 3) and uses that line only in the long-line branch below; the fit is made when that
+    // branch first asks for it — until a candidate is accepted, `order` without its last entry is still the member list the fit would have seen
+    Vector6d line{};
+    bool line_known = false;
     for (int j = 1; j < nn.k; ++j) {
       const int cand = nn.idx[(size_t)start * nn.k + j];
       if (stamp[(size_t)cand] == epoch) continue;
@@ -125,6 +128,7 @@ struct Grower {
         next = Fit(order, 5.0, 0.07);                     // short lines: every point within 7 cm
         if (AllZero(next)) { order.pop_back(); continue; }
       } else {
+        if (!line_known) { order.pop_back(); line = Fit(order, 3.0); order.push_back(cand); line_known = true; }
         next = Fit(order, 20.0);                          // long lines: much straighter, and the direction may not turn by more than 1 degree
         const double turn = DirectionAngle(&next[3], &line[3]) * 180.0 / M_PI;
         if (AllZero(next) || turn > 1) { order.pop_back(); continue; }
@@ -133,7 +137,7 @@ struct Grower {
       stamp[(size_t)cand] = epoch;
       members.insert(std::upper_bound(members.begin(), members.end(), cand), cand);
       length = reach;
-      line = next;
+      line = next; line_known = true;
     }
     return grown;
   }

@@ -53,7 +53,7 @@ def run(*args, timeout=600):
     out = subprocess.run(prefix + [driver()] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
     if out.returncode != 0:
         raise RuntimeError("driver failed (%d): %s" % (out.returncode, out.stderr[-2000:]))
-    if os.environ.get("PVLM_HOST_EVAL_TRACE"):
+    if os.environ.get("PVLM_HOST_EVAL_TRACE") or os.environ.get("PVLM_FEATURE_PROFILE"):
         import sys
         sys.stderr.write(out.stderr)
     return out.stdout.splitlines()

@@ -72,4 +72,32 @@ def assert_matches_oracle(oracle, raw, n_scans, horizon, segment, got):
         assert np.array_equal(np.where(half >= 0, idx - half, -1), after.left) and np.array_equal(np.where(half >= 0, idx + half, -1), after.right)
         cell_range = after.range_image[after.rc[:, 0], after.rc[:, 1]]
         assert np.array_equal(got["range"][:m].view(np.uint32), cell_range.view(np.uint32))
+    if m and "sorted" in got:
+        sector_order_check(got["sorted"][:m], got["sector_host"], after, n_scans)
     return before, after
+
+
+def sector_order_check(order, sector_host, after, n_scans):
+    """K23: every sector is in the oracle's order — the order ITS std::sort left, equal curvatures included (the device runs libstdc++'s introsort on a sector
+    with ties, csrc/pvlm_stdsort.h) — except a sector with a NaN or more than 2048 points, which is flagged and in index order like everything outside the
+    sectors.  Returns (sectors with equal curvatures, sectors left to the host)."""
+    expect = np.arange(len(order), dtype=np.int32)
+    tied = left = 0
+    for ring in range(n_scans):
+        lo, hi = int(after.scan_start[ring]), int(after.scan_end[ring])
+        span = hi - lo
+        for j in range(6):
+            flag = int(sector_host[ring * 6 + j])
+            if span < 6:
+                assert flag == 0
+                continue
+            sp, ep = lo + span * j // 6, lo + span * (j + 1) // 6 - 1
+            c = after.curvature[sp:ep + 1]
+            assert flag == (1 if (np.isnan(c).any() and len(c) > 1) or len(c) > 2048 else 0), (ring, j, flag)
+            tied += len(np.unique(np.where(c == 0, np.float32(0), c))) < len(c)
+            if flag:
+                left += 1
+            else:
+                expect[sp:ep + 1] = after.sort_ind[sp:ep + 1]
+    assert np.array_equal(order, expect)
+    return tied, left

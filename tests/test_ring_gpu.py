@@ -40,7 +40,9 @@ def test_batch_matches_oracle(ctx, oracle, key):
         assert np.array_equal(g["cloud_kept"][:, :3], raw[g["source"], :3])               # `source` indexes the raw scan
         assert np.array_equal(g["ring_col"] >> 16, g["rc_kept"][:, 0]) and np.array_equal(g["ring_col"] & 0xFFFF, g["rc_kept"][:, 1])
         listed += g["resolved_points"]
-        print("%s: %d points, %d decided by the host libm, %d edges, %d replays" % (rc.case_id(case), len(raw), g["resolved_points"], g["resolved_edges"], g["replayed"]))
+        print("%s: %d points, %d decided by the host libm, %d edges, %d replays, %d of %d sectors left to the host's std::sort" %
+              (rc.case_id(case), len(raw), g["resolved_points"], g["resolved_edges"], g["replayed"], int(g["sector_host"].sum()), 6 * n_scans))
+        assert int(g["sector_host"].sum()) == 0                                            # no NaN curvature, no sector beyond 2048 points in these cases
     for k, raw in enumerate(extra):
         rc.assert_matches_oracle(oracle, raw, n_scans, horizon, segment, batch.arrays(len(members) + k))
     print("stage ms:", {k: round(v, 3) for k, v in batch.timing().items()})
@@ -54,7 +56,7 @@ def test_batch_equals_scan_by_scan(ctx):
     for k, raw in enumerate(raws):
         alone = pv.RingBatch(ctx, [raw])
         a, b = together.arrays(k), alone.arrays(0)
-        for name in ("cloud_kept", "rc_kept", "curvature", "half_window", "range", "range_image", "image_to_point_kept", "source"):
+        for name in ("cloud_kept", "rc_kept", "curvature", "half_window", "range", "range_image", "image_to_point_kept", "source", "sorted", "sector_host"):
             assert np.array_equal(a[name], b[name], equal_nan=True), name
         alone.close()
     together.close()

@@ -10,5 +10,6 @@ for k in range(16):
 scans = [dict(base[k % 16], id=k) for k in range(n)]
 path = "/tmp/raw_%d.bin" % n
 host_io.write_raw_scans(path, scans)
-for l in host_io.run("featbench_gpu", path, 3, 1, 32): print(l)
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+for l in host_io.run("featbench_gpu", path, 3, 1, threads): print(l)
 for l in host_io.run("featbench", "/tmp/raw_16.bin" if os.path.exists("/tmp/raw_16.bin") else path, 1, 1): print(l)
