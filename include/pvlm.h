@@ -585,9 +585,23 @@ typedef struct pvlm_ring_result {
                                        :896 / ExtractPlaneFeatures2 :1110 sort them; index order outside the sectors                */
   const unsigned char* sector_host; /* n_rings x 6: 1 = the sector holds equal curvatures (or a NaN, or > 2048 points): std::sort's
                                        order of equal keys is the library's, `sorted` is the index order there and the caller sorts */
+  /* pvlm_ring_extract_batch_picks only (picks == 1): the picks of ExtractEdgeFeatures2 (:883-1000) / ExtractPlaneFeatures2 (:1098-1189) and the
+   * voxel grid of the less-flat points, ring by ring.  A scan with any ring_host[r] != 0 (incidence angle within libm distance of the threshold,
+   * a sector left to the host, a ring beyond the kernel's bounds) is to be picked by the caller from the arrays above.                          */
+  int picks;
+  float max_curvature, intersect_angle_threshold;   /* what the picks were made with                                                */
+  const unsigned char* state;       /* PointClassification bits of every kept point after both pick passes                         */
+  const int* corner;                /* n_rings x 181: count, then the edge picks in pick order: point | 0x80000000 when sharp       */
+  const int* flat;                  /* n_rings x 25: count, then the plane picks (surfFlat) in pick order                           */
+  const int* voxel_span;            /* n_rings x 2: first, count of the ring's surfLessFlat centroids in `voxels`                  */
+  const float* voxels;              /* x, y, z, class (1 = POINT_NORMAL) per centroid, ascending voxel order inside a ring          */
+  const unsigned char* ring_host;   /* n_rings flags                                                                               */
 } pvlm_ring_result;
 pvlm_status pvlm_ring_extract_batch(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* scans, int n_rings, int horizon_scans, int segment,
                                     pvlm_ring_batch** out);
+/* The same, plus K24: the feature picks and the voxel grid (max_curvature, intersect_angle_threshold: the arguments of Velodyne::ExtractFeatures). */
+pvlm_status pvlm_ring_extract_batch_picks(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* scans, int n_rings, int horizon_scans, int segment,
+                                          float max_curvature, float intersect_angle_threshold, pvlm_ring_batch** out);
 pvlm_status pvlm_ring_batch_scan(const pvlm_ring_batch* batch, int scan, pvlm_ring_result* result);
 /* The device-resident arrays of one scan (tests, visualisation).  state 0: after ReOrderVLP, 1: after Segmentation.  cloud_xyzi: n x 4
  * (intensity = ring), ring_col_pairs: n x 2, range_image / image_to_point: n_rings x horizon_scans (0 / -1 = empty).  NULL = skip. */
@@ -597,6 +611,9 @@ pvlm_status pvlm_ring_batch_fetch(pvlm_ctx* ctx, const pvlm_ring_batch* batch, i
  * [4] K19 edges + host libm  [5] K20 components  [6] K21 compaction + K22 curvature  [7] download. */
 pvlm_status pvlm_ring_batch_timing(const pvlm_ring_batch* batch, double* ms8);
 pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* batch);
+/* Tests: the device's restatement of std::sort (csrc/pvlm_stdsort.h, sort_wave) on caller-given keys, n <= 4096: order[k] = index of the k-th element
+ * as std::sort of the indices 0 .. n-1 by `keys[a] < keys[b]` leaves them — equal keys in libstdc++'s order.                                      */
+pvlm_status pvlm_ring_debug_sort(pvlm_ctx* ctx, const unsigned* keys, int n, int* order);
 
 #ifdef __cplusplus
 }

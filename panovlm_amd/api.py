@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -892,6 +892,14 @@ class Scan:
             pass
 
 
+def device_sort(ctx, keys):
+    """pvlm_ring_debug_sort: the permutation the device's std::sort restatement leaves for uint32 keys (tests)."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    order = np.zeros(len(keys), np.int32)
+    ctx._check(ctx.lib.pvlm_ring_debug_sort(ctx._h, _p(keys, C.c_uint), C.c_int(len(keys)), _p(order, C.c_int)), "pvlm_ring_debug_sort")
+    return order
+
+
 class RawScanDesc(C.Structure):
     _fields_ = [("xyzi", C.POINTER(C.c_float)), ("n", C.c_int), ("stride_floats", C.c_int)]
 
@@ -900,13 +908,16 @@ class RingResultDesc(C.Structure):
     _fields_ = [("n_raw", C.c_int), ("n_reordered", C.c_int), ("n_kept", C.c_int), ("resolved_points", C.c_int), ("resolved_edges", C.c_int), ("replayed", C.c_int),
                 ("ring_count_reordered", C.POINTER(C.c_int)), ("ring_count", C.POINTER(C.c_int)), ("source", C.POINTER(C.c_int)), ("ring_col", C.POINTER(C.c_int)),
                 ("curvature", C.POINTER(C.c_float)), ("half_window", C.POINTER(C.c_int)), ("range", C.POINTER(C.c_float)), ("sorted", C.POINTER(C.c_int)),
-                ("sector_host", C.POINTER(C.c_ubyte))]
+                ("sector_host", C.POINTER(C.c_ubyte)), ("picks", C.c_int), ("max_curvature", C.c_float), ("intersect_angle_threshold", C.c_float),
+                ("state", C.POINTER(C.c_ubyte)), ("corner", C.POINTER(C.c_int)), ("flat", C.POINTER(C.c_int)), ("voxel_span", C.POINTER(C.c_int)),
+                ("voxels", C.POINTER(C.c_float)), ("ring_host", C.POINTER(C.c_ubyte))]
 
 
 class RingBatch:
     """pvlm_ring_extract_batch: ReOrderVLP + Segmentation + adaptive curvature of a batch of raw scans (n x 4 float32 each) on the GPU."""
 
-    def __init__(self, ctx, raw_scans, n_rings=16, horizon=1800, segment=True):
+    def __init__(self, ctx, raw_scans, n_rings=16, horizon=1800, segment=True, picks=None):
+        """picks = (max_curvature, intersect_angle_threshold): also run K24 (feature picks + voxel grid) — see RingBatch.picks()."""
         self.ctx = ctx
         self._raw = [_f32(r).reshape(-1, 4) for r in raw_scans]
         self.n_rings, self.horizon = n_rings, horizon
@@ -914,8 +925,12 @@ class RingBatch:
         for k, r in enumerate(self._raw):
             descs[k].xyzi = _p(r, C.c_float); descs[k].n = len(r); descs[k].stride_floats = 4
         self._h = C.c_void_p()
-        ctx._check(ctx.lib.pvlm_ring_extract_batch(ctx._h, C.c_int(len(self._raw)), descs, C.c_int(n_rings), C.c_int(horizon), C.c_int(1 if segment else 0),
-                                                   C.byref(self._h)), "pvlm_ring_extract_batch")
+        if picks is None:
+            ctx._check(ctx.lib.pvlm_ring_extract_batch(ctx._h, C.c_int(len(self._raw)), descs, C.c_int(n_rings), C.c_int(horizon), C.c_int(1 if segment else 0),
+                                                       C.byref(self._h)), "pvlm_ring_extract_batch")
+        else:
+            ctx._check(ctx.lib.pvlm_ring_extract_batch_picks(ctx._h, C.c_int(len(self._raw)), descs, C.c_int(n_rings), C.c_int(horizon), C.c_int(1 if segment else 0),
+                                                             C.c_float(picks[0]), C.c_float(picks[1]), C.byref(self._h)), "pvlm_ring_extract_batch_picks")
 
     def close(self):
         if self._h and self.ctx._h:
@@ -944,6 +959,24 @@ class RingBatch:
                    ring_col=arr(r.ring_col, m, np.int32), curvature=arr(r.curvature, m, np.float32), half_window=arr(r.half_window, m, np.int32),
                    range=arr(r.range, m, np.float32), sorted=arr(r.sorted, m, np.int32), sector_host=arr(r.sector_host, self.n_rings * 6, np.uint8))
         return out
+
+    def picks(self, scan):
+        """K24's results for one scan: dict(ring_host (n_rings flags), state (per kept point), corner / sharp (edge picks in upstream's order and which of them are
+        sharp), flat (plane picks), less_flat (m x 4 centroids, ring by ring)) — or None when the batch was made without picks."""
+        r = RingResultDesc()
+        self.ctx._check(self.ctx.lib.pvlm_ring_batch_scan(self._h, C.c_int(scan), C.byref(r)), "pvlm_ring_batch_scan")
+        if not r.picks:
+            return None
+        R = self.n_rings
+        ring_host = np.ctypeslib.as_array(r.ring_host, shape=(R,)).copy()
+        state = np.ctypeslib.as_array(r.state, shape=(max(r.n_kept, 1),))[:r.n_kept].copy()
+        corner_t = np.ctypeslib.as_array(r.corner, shape=(R, 181)); flat_t = np.ctypeslib.as_array(r.flat, shape=(R, 25)); span = np.ctypeslib.as_array(r.voxel_span, shape=(R, 2))
+        corner = np.concatenate([corner_t[k, 1:1 + corner_t[k, 0]] for k in range(R)]) if R else np.zeros(0, np.int32)
+        flat = np.concatenate([flat_t[k, 1:1 + flat_t[k, 0]] for k in range(R)]) if R else np.zeros(0, np.int32)
+        less = [np.ctypeslib.as_array(C.cast(C.addressof(r.voxels.contents) + 16 * int(span[k, 0]), C.POINTER(C.c_float)), shape=(int(span[k, 1]), 4)).copy()
+                for k in range(R) if span[k, 1] > 0]
+        return dict(ring_host=ring_host, state=state, corner=(corner & 0x7FFFFFFF).astype(np.int32), sharp=(corner.view(np.uint32) >> 31).astype(bool),
+                    flat=flat.astype(np.int32), less_flat=np.concatenate(less) if less else np.zeros((0, 4), np.float32))
 
     def fetch(self, scan, state):
         """Device-resident arrays of one scan: state 0 after ReOrderVLP, 1 after Segmentation."""

@@ -18,7 +18,6 @@
 // build on this machine would call) before the dependent stage runs.  Comparisons between two azimuths (the +z-crossing
 // test, :447-461) are interval comparisons; a scan whose crossing cannot be certified gets exact azimuths for all its
 // points from the host and is replayed.  No decision is ever taken from an uncertified device value.
-#include "pvlm_stdsort.h"
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -30,6 +29,7 @@
 #include "pvlm_internal.h"
 #include "pvlm_workers.h"
 #include "pvlm_ring_core.h"
+#include "pvlm_ring_picks.h"
 
 using namespace pvlm_ring;
 
@@ -415,13 +415,16 @@ __global__ __launch_bounds__(256) void k_sector_sort(const RingScan* __restrict_
   }
 }
 
-// std::sort's own steps (pvlm_stdsort.h) on the sectors k_sector_sort listed: one wave per sector, its first lane sorting packed (key, index) words in
-// LDS by key alone — the comparator std::sort was given looks at the curvature only, which is what makes the order of equal keys the algorithm's.
+// std::sort's own steps (pvlm_stdsort.h) on the sectors k_sector_sort listed: one wave per sector, sorting packed (key, index) words in
+// LDS by key alone — the comparator std::sort was given looks at the curvature only, which is what makes the order of equal keys the algorithm's —
+// by the whole wave (pvlm_stdsort::sort_wave: long ranges partitioned by all lanes, short ones side by side on the lanes).
 template <int CAP>
 __global__ __launch_bounds__(64) void k_sector_ties(const RingScan* __restrict__ scans, const int4* __restrict__ list, const int* __restrict__ count,
                                                     const float* __restrict__ curvature, int* __restrict__ order, unsigned char* __restrict__ sector_host) {
   __shared__ unsigned long long e[CAP];
-  __shared__ int sane;
+  __shared__ unsigned queue[2 * pvlm_stdsort::kWaveQueue + pvlm_stdsort::kWideStack], cuts[(CAP + 31) / 32 + 1];
+  __shared__ unsigned short pos[2 * CAP];
+  __shared__ int ctr[4];
   for (int item = blockIdx.x; item < *count; item += gridDim.x) {
     const int4 it = list[item];
     const int sp = it.y, m = it.z, t = threadIdx.x;
@@ -429,12 +432,26 @@ __global__ __launch_bounds__(64) void k_sector_ties(const RingScan* __restrict__
     const float* c = curvature + pt0;
     for (int k = t; k < m; k += 64) e[k] = ((unsigned long long)curvature_key(c[sp + k]) << 32) | (unsigned)(sp + k);
     __syncthreads();
-    if (t == 0) sane = pvlm_stdsort::sort(e, m, [](unsigned long long x, unsigned long long y) { return (unsigned)(x >> 32) < (unsigned)(y >> 32); }) ? 1 : 0;
-    __syncthreads();
+    const bool sane = pvlm_stdsort::sort_wave(e, m, [](unsigned long long x, unsigned long long y) { return (unsigned)(x >> 32) < (unsigned)(y >> 32); }, queue, cuts, ctr,
+                                              pos, t);
     if (sane) for (int k = t; k < m; k += 64) order[pt0 + sp + k] = (int)(unsigned)e[k];
     else if (t == 0) sector_host[it.w] = 1;                       // cannot happen with an order-preserving integer key; the host's std::sort then
     __syncthreads();
   }
+}
+
+// pvlm_ring_debug_sort: sort_wave on caller-given integer keys (tests)
+__global__ __launch_bounds__(64) void k_debug_sort(const unsigned* __restrict__ keys, int n, int* __restrict__ order, int* __restrict__ sane_out) {
+  __shared__ unsigned long long e[4096];
+  __shared__ unsigned queue[2 * pvlm_stdsort::kWaveQueue + pvlm_stdsort::kWideStack], cuts[4096 / 32 + 1];
+  __shared__ unsigned short pos[2 * 4096];
+  __shared__ int ctr[4];
+  const int t = threadIdx.x;
+  for (int k = t; k < n; k += 64) e[k] = ((unsigned long long)keys[k] << 32) | (unsigned)k;
+  __syncthreads();
+  const bool sane = pvlm_stdsort::sort_wave(e, n, [](unsigned long long x, unsigned long long y) { return (unsigned)(x >> 32) < (unsigned)(y >> 32); }, queue, cuts, ctr, pos, t);
+  for (int k = t; k < n; k += 64) order[k] = (int)(unsigned)e[k];
+  if (t == 0) *sane_out = sane ? 1 : 0;
 }
 
 // the restated introsort against the std::sort this library was built with, on tie-heavy keys: the condition for ordering tied sectors on the device
@@ -477,6 +494,10 @@ struct pvlm_ring_batch {
   char* h_results = nullptr; size_t results_bytes = 0;
   const int* h_source = nullptr; const int* h_ring_col = nullptr; const float* h_curvature = nullptr; const int* h_half = nullptr; const float* h_range = nullptr;
   const int* h_order = nullptr; const unsigned char* h_sector_host = nullptr;
+  // K24 (picks != 0): states, per-ring pick lists, voxel centroids
+  int picks = 0; float max_curvature = 0, angle_threshold = 0;
+  const unsigned char* h_state = nullptr; const int* h_corner = nullptr; const int* h_flat = nullptr; const int* h_voxel_span = nullptr; const float* h_voxels = nullptr;
+  const unsigned char* h_ring_host = nullptr; int n_voxels = 0;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -489,7 +510,9 @@ struct RingScratch {
   template <typename T> pvlm_status get(T** d, size_t count) { const pvlm_status st = pvlm_i_alloc(ctx, d, count); if (!st) p.push_back(*d); return st; }
 };
 
-static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, long long total) {
+static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, long long total,
+                            int picks, float max_curvature, float angle_threshold) {
+  B->picks = picks ? 1 : 0; B->max_curvature = max_curvature; B->angle_threshold = angle_threshold;
   B->ctx = ctx; B->n_scans = n_scans; B->rings = n_rings; B->horizon = horizon; B->segment = segment ? 1 : 0;
   const int cells = n_rings * horizon;
   B->total_points = total; B->total_cells = (long long)n_scans * cells;
@@ -524,18 +547,27 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
 #define RING_KEEP(ptr, count) if (!st) st = pvlm_i_alloc(ctx, &ptr, count)
   RING_KEEP(B->d_scans, (size_t)n_scans); RING_KEEP(B->d_cloud_scan, NP); RING_KEEP(B->d_rc, NP); RING_KEEP(B->d_range_image, NC);
   RING_KEEP(B->d_image_to_point, NC); RING_KEEP(B->d_cloud2, NP); RING_KEEP(B->d_image_to_point2, NC);
-  RING_GET(d_raw, NP); RING_GET(d_rec, NS); RING_GET(d_listed, NP); RING_GET(d_counter, 4);
+  RING_GET(d_raw, NP); RING_GET(d_rec, NS); RING_GET(d_listed, NP); RING_GET(d_counter, 8);
   RING_GET(d_colpos, NS); RING_GET(d_ring_count, (size_t)n_scans * kMaxRings); RING_GET(d_status, (size_t)n_scans); RING_GET(d_blocks, blocks.size());
   RING_GET(d_source, NP); RING_GET(d_winner, NC); RING_GET(d_edges, NC + 4); RING_GET(d_queries, (size_t)query_cap); RING_GET(d_parent, NC);
   RING_GET(d_root, NC); RING_GET(d_comp_size, NC); RING_GET(d_row_mask, NC); RING_GET(d_source2, NP); RING_GET(d_ring_col2, NP); RING_GET(d_range2, NP);
   RING_GET(d_ring_count2, (size_t)n_scans * kMaxRings); RING_GET(d_counts, (size_t)n_scans * 2); RING_GET(d_curv, NP); RING_GET(d_half, NP);
   RING_GET(d_order, NP); RING_GET(d_sector, n_sectors); RING_GET(d_ties, 2 * n_sectors);
+  // K24: one centroid per four points is the batch's budget (a Room scan needs one per ten); rings beyond it go to the host like any undecided ring
+  const size_t n_ring_slots = (size_t)n_scans * n_rings, voxel_cap = NP / 4 + 64;
+  unsigned char* d_state = nullptr; int* d_corner = nullptr; int* d_flat = nullptr; int2* d_vspan = nullptr; float4* d_voxels = nullptr; unsigned char* d_ring_host = nullptr;
+  if (picks) {
+    RING_GET(d_state, NP); RING_GET(d_corner, n_ring_slots * (1 + kCornerSlots)); RING_GET(d_flat, n_ring_slots * (1 + kFlatSlots)); RING_GET(d_vspan, n_ring_slots);
+    RING_GET(d_voxels, voxel_cap); RING_GET(d_ring_host, n_ring_slots);
+  }
 #undef RING_GET
 #undef RING_KEEP
   if (st) return (st);
   pvlm_i_trace("ring: device memory");
   // ---- pinned buffer: raw points on the way up (16 B / point), the six result arrays (24 B / point) and the sector flags on the way down
-  const size_t pinned = NP * 24 + n_sectors + 256;
+  // with K24: + states (1 B / point), the per-ring lists and the centroids (16 B each, voxel_cap of them at most)
+  const size_t picks_fixed = picks ? NP + n_ring_slots * ((1 + kCornerSlots) * 4 + (1 + kFlatSlots) * 4 + 8 + 1) + 64 : 0;
+  const size_t pinned = NP * 24 + n_sectors + 256 + picks_fixed + (picks ? voxel_cap * 16 : 0);
   int fit = -1;                                    // the smallest pooled buffer that is large enough
   for (int k = 0; k < ctx->ring_pool; ++k) if (ctx->ring_bytes[k] >= pinned && (fit < 0 || ctx->ring_bytes[k] < ctx->ring_bytes[fit])) fit = k;
   if (fit >= 0) {
@@ -573,7 +605,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   PVLM_HIP(ctx, hipMemcpyAsync(d_raw, B->h_results, NP * 16, hipMemcpyHostToDevice, S));
   PVLM_HIP(ctx, hipMemcpyAsync(B->d_scans, B->scans.data(), (size_t)n_scans * sizeof(RingScan), hipMemcpyHostToDevice, S));
   PVLM_HIP(ctx, hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(PtBlock), hipMemcpyHostToDevice, S));
-  PVLM_HIP(ctx, hipMemsetAsync(d_counter, 0, 4 * sizeof(int), S));
+  PVLM_HIP(ctx, hipMemsetAsync(d_counter, 0, 8 * sizeof(int), S));
   PVLM_HIP(ctx, hipMemsetAsync(d_winner, 0xFF, NC * sizeof(int), S));
   PVLM_HIP(ctx, hipMemsetAsync(B->d_range_image, 0, NC * sizeof(float), S));
   PVLM_HIP(ctx, hipMemsetAsync(B->d_image_to_point, 0xFF, NC * sizeof(int), S));
@@ -704,6 +736,16 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     hipLaunchKernelGGL(k_sector_ties<kTieSmall>, dim3(waves), dim3(64), 0, S, B->d_scans, d_ties, d_counter + 2, d_curv, d_order, d_sector);
     hipLaunchKernelGGL(k_sector_ties<kSectorMax>, dim3(waves / 4), dim3(64), 0, S, B->d_scans, d_ties + n_sectors, d_counter + 3, d_curv, d_order, d_sector);
   }
+  int ring_cap = 0;
+  if (picks) {
+    ring_cap = std::min(horizon, 4096);                       // a ring holds one point per column; longer rings are refused by the kernel (-> host)
+    PickArrays A;
+    A.scans = B->d_scans; A.ring_count2 = d_ring_count2; A.counts = d_counts; A.cloud2 = B->d_cloud2; A.range2 = d_range2; A.curvature = d_curv; A.half_window = d_half;
+    A.order = d_order; A.sector_host = d_sector; A.state = d_state; A.corner = d_corner; A.flat = d_flat; A.voxel_span = d_vspan; A.voxels = d_voxels;
+    A.voxel_counter = d_counter + 4; A.voxel_cap = (int)voxel_cap; A.ring_host = d_ring_host;
+    const size_t lds = pick_lds_bytes(ring_cap);
+    hipLaunchKernelGGL(k_ring_picks, dim3((unsigned)n_rings, (unsigned)n_scans), dim3(64), lds, S, A, n_rings, ring_cap, max_curvature, angle_threshold);
+  }
   (void)hipEventRecord(ev[7], S);
   // ---- results
   char* h = B->h_results;
@@ -716,9 +758,26 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16, d_range2, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 20, d_order, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 24, d_sector, n_sectors, hipMemcpyDeviceToHost, S));
+  char* hp = h + NP * 24 + ((n_sectors + 63) / 64) * 64;       // K24's results behind the sector flags
+  int h_voxel_count = 0;
+  if (picks) {
+    char* q = hp;
+    B->h_state = (const unsigned char*)q; PVLM_HIP(ctx, hipMemcpyAsync(q, d_state, NP, hipMemcpyDeviceToHost, S)); q += (NP + 63) / 64 * 64;
+    B->h_corner = (const int*)q; PVLM_HIP(ctx, hipMemcpyAsync(q, d_corner, n_ring_slots * (1 + kCornerSlots) * 4, hipMemcpyDeviceToHost, S)); q += n_ring_slots * (1 + kCornerSlots) * 4;
+    B->h_flat = (const int*)q; PVLM_HIP(ctx, hipMemcpyAsync(q, d_flat, n_ring_slots * (1 + kFlatSlots) * 4, hipMemcpyDeviceToHost, S)); q += n_ring_slots * (1 + kFlatSlots) * 4;
+    B->h_voxel_span = (const int*)q; PVLM_HIP(ctx, hipMemcpyAsync(q, d_vspan, n_ring_slots * 8, hipMemcpyDeviceToHost, S)); q += n_ring_slots * 8;
+    B->h_ring_host = (const unsigned char*)q; PVLM_HIP(ctx, hipMemcpyAsync(q, d_ring_host, n_ring_slots, hipMemcpyDeviceToHost, S)); q += (n_ring_slots + 63) / 64 * 64;
+    B->h_voxels = (const float*)q;
+    PVLM_HIP(ctx, hipMemcpyAsync(&h_voxel_count, d_counter + 4, sizeof(int), hipMemcpyDeviceToHost, S));
+  }
   PVLM_HIP(ctx, hipMemcpyAsync(B->counts.data(), d_counts, (size_t)n_scans * 2 * sizeof(int), hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(B->ring_count.data(), d_ring_count, (size_t)n_scans * kMaxRings * sizeof(int), hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(B->ring_count2.data(), d_ring_count2, (size_t)n_scans * kMaxRings * sizeof(int), hipMemcpyDeviceToHost, S));
+  if (picks) {                                                  // the centroids: as many as the rings reserved (rings that overflowed the budget are flagged)
+    PVLM_HIP(ctx, hipStreamSynchronize(S));
+    B->n_voxels = (int)std::min<size_t>((size_t)std::max(h_voxel_count, 0), voxel_cap);
+    if (B->n_voxels > 0) PVLM_HIP(ctx, hipMemcpyAsync(const_cast<float*>(B->h_voxels), d_voxels, (size_t)B->n_voxels * 16, hipMemcpyDeviceToHost, S));
+  }
   (void)hipEventRecord(ev[8], S);
   PVLM_HIP(ctx, hipStreamSynchronize(S));
   pvlm_i_trace("ring: segmentation, curvature, download");
@@ -754,7 +813,17 @@ pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* b) {
   return PVLM_OK;
 }
 
+static pvlm_status ring_extract(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, int picks, float max_curvature,
+                                float angle_threshold, pvlm_ring_batch** out);
 pvlm_status pvlm_ring_extract_batch(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, pvlm_ring_batch** out) {
+  return ring_extract(ctx, n_scans, raw_scans, n_rings, horizon, segment, 0, 0.f, 0.f, out);
+}
+pvlm_status pvlm_ring_extract_batch_picks(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, float max_curvature,
+                                          float intersect_angle_threshold, pvlm_ring_batch** out) {
+  return ring_extract(ctx, n_scans, raw_scans, n_rings, horizon, segment, 1, max_curvature, intersect_angle_threshold, out);
+}
+static pvlm_status ring_extract(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, int picks, float max_curvature,
+                                float angle_threshold, pvlm_ring_batch** out) {
   if (!ctx || !out || n_scans < 0 || (n_scans > 0 && !raw_scans)) return PVLM_ERR_ARG;
   *out = nullptr;
   if ((n_rings != 16 && n_rings != 32 && n_rings != 64) || horizon <= 0 || horizon > 65535) {
@@ -773,7 +842,7 @@ pvlm_status pvlm_ring_extract_batch(pvlm_ctx* ctx, int n_scans, const pvlm_raw_s
   if (!B) return PVLM_ERR_NOMEM;
   pvlm_status st = PVLM_ERR_HIP;
   try {
-    st = ring_run(ctx, B, n_scans, raw_scans, n_rings, horizon, segment, total);
+    st = ring_run(ctx, B, n_scans, raw_scans, n_rings, horizon, segment, total, picks, max_curvature, angle_threshold);
   } catch (const std::bad_alloc&) {
     PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: out of host memory");
     st = PVLM_ERR_NOMEM;
@@ -800,6 +869,33 @@ pvlm_status pvlm_ring_batch_scan(const pvlm_ring_batch* b, int scan, pvlm_ring_r
     r->range = b->h_range + sc.pt0;
     r->sorted = b->h_order + sc.pt0; r->sector_host = b->h_sector_host + (size_t)scan * b->rings * 6;
   }
+  if (b->picks && b->h_state) {
+    const size_t slot0 = (size_t)scan * b->rings;
+    r->picks = 1; r->max_curvature = b->max_curvature; r->intersect_angle_threshold = b->angle_threshold;
+    r->state = b->h_state + sc.pt0; r->corner = b->h_corner + slot0 * (1 + kCornerSlots); r->flat = b->h_flat + slot0 * (1 + kFlatSlots);
+    r->voxel_span = b->h_voxel_span + slot0 * 2; r->voxels = b->h_voxels; r->ring_host = b->h_ring_host + slot0;
+  }
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_ring_debug_sort(pvlm_ctx* ctx, const unsigned* keys, int n, int* order) {
+  if (!ctx || !keys || !order || n < 1 || n > 4096) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  unsigned* d_keys = nullptr; int* d_order = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_keys, (size_t)n);
+  if (!st) st = pvlm_i_alloc(ctx, &d_order, (size_t)n + 1);
+  if (st) { pvlm_i_free(ctx, d_keys); return st; }
+  hipError_t e = hipMemcpyAsync(d_keys, keys, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+  int sane = 0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), 0, ctx->stream, d_keys, n, d_order, d_order + n);
+    e = hipMemcpyAsync(order, d_order, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&sane, d_order + n, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  pvlm_i_free(ctx, d_keys); pvlm_i_free(ctx, d_order);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_ring_debug_sort: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+  if (!sane) { PVLM_SET_ERR(ctx, "pvlm_ring_debug_sort: the sort refused the keys"); return PVLM_ERR_STATE; }
   return PVLM_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -429,6 +430,51 @@ void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold
   }
 }
 
+void Velodyne::AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, bool edge_to_line) {
+  const int n = (int)cloud_scan.size();
+  const PointCloud& P = cloud_scan;
+  ProfileSpan span(2);
+  cornerSharp.clear(); cornerLessSharp.clear();
+  for (int ring = 0; ring < N_SCANS; ++ring) {
+    const int* list = r.corner + (size_t)ring * 181;
+    for (int q = 0; q < list[0]; ++q) {
+      const int ind = list[1 + q] & 0x7FFFFFFF;
+      PointXYZI p = P[(size_t)ind];
+      p.intensity = ind;
+      if (list[1 + q] < 0) cornerSharp.push_back(p);
+      cornerLessSharp.push_back(p);
+    }
+  }
+  span.Next(3);
+  if (edge_to_line) EdgeToLine();
+  span.Next(4);
+  surfFlat.clear(); surfLessFlat.clear();
+  size_t centroids = 0;
+  for (int ring = 0; ring < N_SCANS; ++ring) centroids += (size_t)r.voxel_span[2 * ring + 1];
+  surfLessFlat.reserve(centroids);
+  for (int ring = 0; ring < N_SCANS; ++ring) {
+    const int* list = r.flat + (size_t)ring * 25;
+    for (int q = 0; q < list[0]; ++q) {
+      PointXYZI p = P[(size_t)list[1 + q]];
+      p.intensity = (float)(r.state[list[1 + q]] & (POINT_NORMAL | POINT_GROUND));       // the class the point had when it was picked (:1128)
+      surfFlat.push_back(p);
+    }
+    const float* v = r.voxels + 4 * (size_t)r.voxel_span[2 * ring];
+    for (int q = 0; q < r.voxel_span[2 * ring + 1]; ++q) surfLessFlat.push_back(PointXYZI{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+  }
+  span.Stop();
+  InvalidateDevice();
+  if (trace) {
+    trace->curvature.assign(r.curvature, r.curvature + n); trace->sort_ind.assign(r.sorted, r.sorted + n);
+    trace->state.resize((size_t)n); trace->left_neighbor.resize((size_t)n); trace->right_neighbor.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      trace->state[(size_t)i] = r.state[i];
+      const int h = r.half_window[i];
+      trace->left_neighbor[(size_t)i] = h < 0 ? -1 : i - h; trace->right_neighbor[(size_t)i] = h < 0 ? -1 : i + h;
+    }
+  }
+}
+
 // ---- the batch form: range-image stages on the GPU, picks on the host ---------------------------------------------------------
 void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float max_curvature, float intersect_angle_threshold, int method, bool segment, bool edge_to_line,
                                     int num_threads, std::vector<ExtractionTrace>* traces) {
@@ -454,6 +500,9 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
   const size_t total = todo.size();
   static const size_t n_parts = [] { const char* v = std::getenv("PVLM_FEATURE_PARTS"); const long k = v ? std::atol(v) : 0; return k > 0 ? (size_t)k : (size_t)2; }();
   const size_t per_batch = total <= 48 ? total : std::max<size_t>(24, (total + n_parts - 1) / n_parts);
+  // PVLM_FEATURE_PICKS=host: the picks and the voxel grid on the host threads (PickFeatures) instead of K24 — the A/B switch of tools/feature_batch_bench.py
+  static const bool device_picks = [] { const char* v = std::getenv("PVLM_FEATURE_PICKS"); return !(v && std::strcmp(v, "host") == 0); }();
+  std::atomic<long> scans_on_host{0};
   struct Part { pvlm_ring_batch* batch = nullptr; bool on_host = false; };
   std::vector<Part> parts((total + per_batch - 1) / per_batch);
   struct Release { pvlm_ctx* c; std::vector<Part>& p; ~Release() { for (Part& q : p) pvlm_ring_batch_destroy(c, q.batch); } } release{e.ctx(), parts};
@@ -467,7 +516,9 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     try {
       for (size_t k = 0; k < parts.size(); ++k) {
         const size_t first = k * per_batch, count = std::min(per_batch, total - first);
-        const pvlm_status rc = pvlm_ring_extract_batch(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, &parts[k].batch);
+        const pvlm_status rc = device_picks ? pvlm_ring_extract_batch_picks(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, max_curvature,
+                                                                            intersect_angle_threshold, &parts[k].batch)
+                                            : pvlm_ring_extract_batch(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, &parts[k].batch);
         if (rc == PVLM_ERR_ARG || rc == PVLM_ERR_CAPACITY || rc == PVLM_ERR_NOMEM) {
           // The batch form is stricter than the reference: it refuses a batch with a non-finite coordinate (upstream such a point gets ring -1 and is
           // skipped, sensors/Velodyne.cpp:439-445) and gives up beyond its bounds on undecided segmentation edges / memory.  Neither is a reason to fail
@@ -527,6 +578,10 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     if (n < r.n_reordered * 0.1) { fprintf(stderr, "LiDAR data %d has something wrong\n", v.id); v.valid = false; return; }
     if (n == 0) return;
     span.Stop();
+    bool decided = r.picks != 0;
+    for (int q = 0; decided && q < rings; ++q) decided = r.ring_host[q] == 0;
+    if (decided) { v.AssemblePicks(r, traces ? &(*traces)[todo[j]] : nullptr, edge_to_line); return; }
+    if (r.picks) ++scans_on_host;                  // a ring the device left undecided (incidence angle at the threshold, bounds): the whole scan is picked here
     v.PickFeatures(max_curvature, intersect_angle_threshold, PickInputs{r.curvature, r.range, nullptr, nullptr, r.half_window, r.sorted, r.sector_host},
                    traces ? &(*traces)[todo[j]] : nullptr, edge_to_line);
   };
@@ -550,6 +605,7 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
   const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(num_threads, 1), total + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   pvlm_run_workers(n_threads, work);
   if (failure) std::rethrow_exception(failure);
+  if (Profile().on) fprintf(stderr, "feature_profile scans picked on the host (a ring undecided on the device): %ld of %zu\n", scans_on_host.load(), total);
   if (Profile().on) Profile().Report("ExtractFeaturesBatch", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - profile_t0).count(), ring_ms, producer_ms);
 }
 

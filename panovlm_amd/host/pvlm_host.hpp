@@ -196,6 +196,8 @@ class Velodyne {
     const float* curvature; const float* range; const int* left; const int* right; const int* half_window; const int* sorted; const unsigned char* sector_host;
   };
   void PickFeatures(float max_curvature, float intersect_angle_threshold, const PickInputs& in, ExtractionTrace* trace, bool edge_to_line);
+  // the same from the picks the device made (pvlm_ring_extract_batch_picks, K24): the clouds are assembled ring by ring, EdgeToLine runs here
+  void AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, bool edge_to_line);
   mutable pvlm_scan* dev_ = nullptr;
 };
 

@@ -1,6 +1,6 @@
 // Host-compiled check of csrc/pvlm_stdsort.h: the restated introsort against the toolchain's own std::sort, element for element, on inputs
 // where the order of equal keys is the whole question.  Driven by tests/test_stdsort_cpu.py through ctypes.
-#define PVLM_HD
+#define PVLM_HD inline
 #define PVLM_STDSORT_STATS
 #include "../../panovlm_amd/csrc/pvlm_stdsort.h"
 
@@ -33,6 +33,21 @@ int chk_sort_pairs(const unsigned* cell, int n) {
   const bool sane = pvlm_stdsort::sort(b.data(), n, [](const Pair& x, const Pair& y) { return x.cell < y.cell; });
   if (!sane) return -1;
   for (int i = 0; i < n; ++i) if (a[(size_t)i].point != b[(size_t)i].point) return 1 + i;
+  return 0;
+}
+
+// the level-by-level form the device runs (lanes = a plain loop here), float keys as above; also -2 when it disagrees with the serial restatement
+int chk_sort_by_levels(const float* key, int n) {
+  if (n >= 8192) return 0;
+  std::vector<int> a((size_t)n), b((size_t)n);
+  std::iota(a.begin(), a.end(), 0); b = a;
+  std::sort(a.begin(), a.end(), [key](int x, int y) { return key[x] < key[y]; });
+  std::vector<unsigned> queue(2 * pvlm_stdsort::kWaveQueue), cuts((size_t)(n + 31) / 32 + 1);
+  int ctr[3];
+  auto lanes = [](int count, auto&& body) { for (int r = 0; r < count; ++r) body(r); };
+  const bool sane = pvlm_stdsort::sort_by_levels(b.data(), n, [key](int x, int y) { return key[x] < key[y]; }, queue.data(), cuts.data(), ctr, lanes);
+  if (!sane) return -1;
+  for (int i = 0; i < n; ++i) if (a[(size_t)i] != b[(size_t)i]) return 1 + i;
   return 0;
 }
 

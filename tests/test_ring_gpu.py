@@ -70,3 +70,75 @@ def test_errors(ctx):
     with pytest.raises(pv.PvlmError):
         pv.RingBatch(ctx, [raw, bad])
     pv.RingBatch(ctx, []).close()
+
+
+@pytest.mark.parametrize("key", sorted(_groups().keys()), ids=lambda k: "rings%d-cols%d-seg%d" % k)
+def test_picks_match_oracle(ctx, oracle, key):
+    """K24: the edge / plane picks (with their suppression chains), the point states and the voxel-grid centroids of every scan the device decides equal the oracle's
+    ExtractFeatures; a scan with a ring left to the host is counted, not compared (the host mirror's PickFeatures takes it: test_host_gpu.py)."""
+    n_scans, horizon, segment = key
+    members = _groups()[key]
+    batch = pv.RingBatch(ctx, [raw for _, raw in members], n_rings=n_scans, horizon=horizon, segment=segment, picks=(1000.0, 5.0))
+    decided = 0
+    for k, (case, raw) in enumerate(members):
+        after = oracle.ScanFeatures(raw, n_scans=n_scans, horizon=horizon, segment=segment, extract=True, max_curvature=1000.0, intersect_angle_threshold=5.0)
+        if not after.valid or len(after.cloud_scan) == 0:
+            continue
+        pk = batch.picks(k)
+        assert pk is not None
+        if pk["ring_host"].any():
+            print("%s: %d rings left to the host" % (rc.case_id(case), int(pk["ring_host"].sum())))
+            continue
+        decided += 1
+        cloud = after.cloud_scan
+        assert np.array_equal(pk["state"], after.state), rc.case_id(case)
+        assert np.array_equal(pk["corner"], after.cornerLessSharp[:, 3].astype(np.int32))
+        assert np.array_equal(cloud[pk["corner"], :3].view(np.uint32), after.cornerLessSharp[:, :3].view(np.uint32))
+        assert np.array_equal(pk["corner"][pk["sharp"]], after.cornerSharp[:, 3].astype(np.int32))
+        assert np.array_equal(cloud[pk["flat"], :3].view(np.uint32), after.surfFlat[:, :3].view(np.uint32)) and np.all(after.surfFlat[:, 3] == 1)
+        assert np.array_equal(pk["less_flat"].view(np.uint32), after.surfLessFlat.view(np.uint32)), rc.case_id(case)
+        print("%s: %d edge picks (%d sharp), %d flat, %d less-flat centroids" % (rc.case_id(case), len(pk["corner"]), int(pk["sharp"].sum()), len(pk["flat"]), len(pk["less_flat"])))
+    assert decided > 0 or all(not oracle.ScanFeatures(raw, n_scans=n_scans, horizon=horizon, segment=segment).valid for _, raw in members)
+    print("stage ms:", {k: round(v, 3) for k, v in batch.timing().items()})
+    batch.close()
+
+
+def test_device_sort_equals_std_sort(ctx, tmp_path):
+    """pvlm_stdsort::sort_wave (the form K23 / K24 run: long ranges partitioned by the whole wave, short ones side by side on the lanes, insertion leaf by leaf)
+    leaves the permutation of the real std::sort — taken from tests/cpp/stdsort_check.cpp, which sorts with the toolchain's std::sort — on keys that tie."""
+    import ctypes
+    import os
+    import subprocess
+    from panovlm_amd import api
+    so = str(tmp_path / "stdsort_check.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "stdsort_check.cpp")])
+    chk = ctypes.CDLL(so)
+    rng = np.random.default_rng(11)
+
+    def reference(keys):
+        f = np.ascontiguousarray(keys, np.float32)
+        out = np.zeros(len(f), np.int32)
+        assert chk.chk_sort_by_float(f.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(f), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) == 0
+        return out
+
+    cases = []
+    for trial in range(160):
+        n = int(rng.integers(1, 4097)) if trial % 4 else int(rng.integers(1, 40))
+        kind = trial % 5
+        if kind == 0:
+            keys = rng.permutation(n)                                        # distinct
+        elif kind == 1:
+            keys = rng.integers(0, max(2, n // int(rng.integers(2, 40)) + 1), n)   # voxel-like: many equal keys
+        elif kind == 2:
+            keys = np.sort(rng.integers(0, max(2, n // 8), n))               # nearly sorted runs
+        elif kind == 3:
+            keys = np.zeros(n, np.int64)                                     # all equal
+        else:
+            keys = np.minimum(np.arange(n), n - 1 - np.arange(n)) // 3       # organ pipe with ties
+        cases.append(keys)
+    killer = np.zeros(3000, np.int32)
+    chk.chk_killer_keys(3000, killer.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))   # drives the quicksort to its depth limit (heap-sorted ranges)
+    cases += [killer, killer // 3]
+    for keys in cases:
+        got = api.device_sort(ctx, keys)
+        assert np.array_equal(got, reference(keys)), (len(keys), keys[:8])

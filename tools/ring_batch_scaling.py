@@ -7,12 +7,12 @@ from panovlm_amd import synthetic as sy
 
 ctx = pv.Context()
 base = [sy.raw_vlp16_scan(k, clutter=40) for k in range(16)]
-for n in (454, 28, 57, 114, 227, 454):
+for n in ((454, 454) if "--picks" in sys.argv else (454, 28, 57, 114, 227, 454)):
     raws = [base[k % 16] for k in range(n)]
     best = None
     for rep in range(3):
         t0 = time.perf_counter()
-        b = pv.RingBatch(ctx, raws)
+        b = pv.RingBatch(ctx, raws, picks=(1000.0, 5.0) if "--picks" in sys.argv else None)
         wall = 1e3 * (time.perf_counter() - t0)
         t = b.timing()
         b.close()
