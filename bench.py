@@ -929,9 +929,9 @@ def mvs_batch_point(ctx, rows=720, cols=1440, views=64):
 
 
 def features_block(ctx, pv, scans=454, cols=1800):
-    """Range-image stages of the LiDAR feature extractor for a Room-sized batch (454 raw scans of 16 x 1800, firing order, ~28.5 k returns each)
-    in one pvlm_ring_extract_batch: HIP-event milliseconds per stage, wall per batch, and the oracle's statement-by-statement loop on one
-    host core beside it (ReOrderVLP alone, and ReOrderVLP + Segmentation + curvature + the picks)."""
+    """The LiDAR feature extractor of a Room-sized batch (454 raw scans of 16 x 1800, firing order, ~28.5 k returns each) in one
+    pvlm_ring_extract_batch_picks — range image, segmentation, curvature, the sector orders (K23), the edge / plane picks and the voxel grid (K24):
+    HIP-event milliseconds per stage, wall per batch, and the oracle's statement-by-statement loop on one host core beside it."""
     from panovlm_amd import synthetic as sy
     base = [sy.raw_vlp16_scan(k, cols=cols, clutter=40) for k in range(8)]
     raws = [base[k % len(base)] for k in range(scans)]
@@ -939,23 +939,30 @@ def features_block(ctx, pv, scans=454, cols=1800):
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
-        b = pv.RingBatch(ctx, raws, n_rings=16, horizon=cols, segment=True)
+        b = pv.RingBatch(ctx, raws, n_rings=16, horizon=cols, segment=True, picks=(1000.0, 5.0))
         wall = (time.perf_counter() - t0) * 1e3
         tm = b.timing()
         if best is None or wall < best[0]:
-            best = (wall, tm, sum(b.result(k)["resolved_points"] for k in range(0, scans, 16)), b.result(0)["n_kept"], b.result(0)["n_reordered"])
+            sample = [b.picks(k) for k in range(0, scans, 16)]
+            best = (wall, tm, sum(b.result(k)["resolved_points"] for k in range(0, scans, 16)), b.result(0)["n_kept"], b.result(0)["n_reordered"],
+                    sum(int(q["ring_host"].any()) for q in sample), len(sample), sum(len(q["less_flat"]) for q in sample) / len(sample),
+                    sum(len(q["corner"]) for q in sample) / len(sample))
         b.close()
-    wall, tm, resolved, kept, reordered = best
+    wall, tm, resolved, kept, reordered, undecided, sampled, centroids, corners = best
     device_ms = sum(v for k, v in tm.items() if k not in ("upload", "download"))
     out = {"scans": scans, "rings_x_columns": [16, cols], "points": int(sum(len(r) for r in raws)), "wall_ms_per_batch": wall, "ms_per_scan_wall": wall / scans,
            "device_ms_per_batch": device_ms, "stage_ms": tm, "copies_ms": tm["upload"] + tm["download"],
            "points_decided_by_host_libm_sampled": int(resolved), "kept_of_reordered_scan0": [int(kept), int(reordered)],
-           "what": "ReOrderVLP + Segmentation + adaptive curvature (sensors/Velodyne.cpp:371-526, :1438-1586, :623-657); bit-exact vs the oracle: tests/test_ring_gpu.py"}
-    # roof of the batch: the host link.  The boundary hands over host buffers and takes host arrays back: 16 B per raw point up, 20 B per point down
-    # (DESIGN.md section 2), at the link rate the `pcie` block of this line measures (55.7 GB/s on this pool, 63 GB/s spec)
+           "scans_with_a_ring_left_to_the_host_sampled": [int(undecided), int(sampled)], "edge_picks_per_scan": corners, "less_flat_centroids_per_scan": centroids,
+           "what": "ReOrderVLP + Segmentation + adaptive curvature + sector sort (std::sort's order of equal curvatures restated) + ExtractEdgeFeatures2 / "
+                   "ExtractPlaneFeatures2 picks + pcl::VoxelGrid of the less-flat points (sensors/Velodyne.cpp:371-526, :1438-1586, :623-657, :883-1000, :1098-1189); "
+                   "compact_curvature = K21 + K22 + K23 + K24; bit-exact vs the oracle: tests/test_ring_gpu.py.  EdgeToLine stays on the host "
+                   "(tools/feature_batch_bench.py times the whole ExtractFeaturesBatch)"}
+    # roof of the batch: the host link.  The boundary hands over host buffers and takes host arrays back: 16 B per raw point up; 24 B per point (five arrays +
+    # the sector order), 1 B of state and ~2 B of pick lists and centroids down, at the link rate the `pcie` block measures
     link = 55.7e9
-    moved = out["points"] * 36
-    out["roof"] = {"bound": "host link (PCIe Gen5 x16)", "bytes_per_point": 36, "bytes_per_batch": moved, "GBps_assumed": link / 1e9,
+    moved = out["points"] * 43
+    out["roof"] = {"bound": "host link (PCIe Gen5 x16)", "bytes_per_point": 43, "bytes_per_batch": moved, "GBps_assumed": link / 1e9,
                    "ms_at_link_rate": moved / link * 1e3, "frac": (moved / link * 1e3) / wall, "device_ms_share": device_ms / wall}
     try:
         from oracle import oracle as orc

@@ -1,8 +1,18 @@
-import os, sys, json
+"""Velodyne::ExtractFeaturesBatch (host mirror) over a Room-sized batch of raw VLP-16 scans: wall per call, thread-milliseconds of the host stages
+(PVLM_FEATURE_PROFILE) and the A/B switches of the call —
+    PVLM_FEATURE_PICKS=host   the picks and the voxel grid on the host threads (PickFeatures) instead of K24
+    PVLM_FEATURE_PARTS=k      the batch cut into k device batches whose GPU stages overlap the host work of the previous one (default 2)
+usage: feature_batch_bench.py [scans = 454] [threads = 32] [--ab]     (--ab: runs the four combinations)
+The boxes of this pool give a process 16 CPUs' worth of time per 100 ms (cgroup cpu.max) whatever nproc says: a 32-thread call of ~50 ms fits one period's
+budget, two calls back to back do not — the driver sleeps before each repetition, and thread_ms (CPU time actually spent) is the figure that transfers."""
+import os, sys
 sys.path.insert(0, "/root/repo")
 from panovlm_amd import synthetic as sy
 from tests import host_io
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 454
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if len(args) > 0 else 454
+threads = int(args[1]) if len(args) > 1 else 32
 base = []
 for k in range(16):
     R, t = sy.estimated_pose(k)
@@ -10,6 +20,14 @@ for k in range(16):
 scans = [dict(base[k % 16], id=k) for k in range(n)]
 path = "/tmp/raw_%d.bin" % n
 host_io.write_raw_scans(path, scans)
-threads = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-for l in host_io.run("featbench_gpu", path, 3, 1, threads): print(l)
+try:
+    print("cpu.max", open("/sys/fs/cgroup/cpu.max").read().strip(), "hardware threads", os.cpu_count())
+except Exception:
+    pass
+os.environ["PVLM_FEATURE_PROFILE"] = "1"
+combos = [("device", "2")] if "--ab" not in sys.argv else [("host", "1"), ("host", "2"), ("device", "1"), ("device", "2"), ("device", "4")]
+for picks, parts in combos:
+    os.environ["PVLM_FEATURE_PICKS"] = picks; os.environ["PVLM_FEATURE_PARTS"] = parts
+    print("== picks on the %s, %s device batch(es) per call, %d host threads" % (picks, parts, threads))
+    for l in host_io.run("featbench_gpu", path, 3, 1, threads): print(l)
 for l in host_io.run("featbench", "/tmp/raw_16.bin" if os.path.exists("/tmp/raw_16.bin") else path, 1, 1): print(l)
