@@ -59,7 +59,7 @@ timeout 300 python tools/k8_workload.py 2> /dev/null | tail -1 > $O/r5_k8_block.
 python tools/room_like_odometry.py --scans 454 --iters 3 --lines 1 --repeat 2 > $O/r5_room_like_lines454.txt 2>&1
 python tools/room_like_joint.py --frames 454 --points 150000 > $O/r5_room_like_joint454.txt 2>&1
 python tools/floor_like_odometry.py --scans 1593 --ranks 2,8 --iters 2 --repeat 5 > $O/r5_floor_like_1593.txt 2>&1
-python tools/feature_batch_bench.py 454 > $O/r5_feature_batch_454.txt 2>&1
+python tools/feature_batch_bench.py 454 32 --ab 2>&1 | cut -c1-300 > $O/r5_feature_batch_454.txt
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 du -sh $O
 head -c 400 $O/r5_bench_default.json
