@@ -33,6 +33,32 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+def cpu_quota():
+    """CPUs this process may use on average: the cgroup's CFS quota (cpu.max: "<quota us> <period us>") when there is one, else None.  The GPU boxes of this
+    pool show 256 hardware threads and a quota of 16: more threads than that only run in bursts until the period's budget is spent, and then stall."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                return float(quota) / float(period)
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / p
+    except Exception:
+        pass
+    return None
+
+
+def usable_cpus():
+    """Hardware threads, or the cgroup's CPU quota when that is smaller."""
+    n = os.cpu_count() or 8
+    q = cpu_quota()
+    return max(1, min(n, int(q + 0.5))) if q else n
+
+
 def _gen(args):
     from panovlm_amd import synthetic as sy
     k, cols, voxel = args
@@ -44,7 +70,7 @@ def _gen(args):
 def generate_scans(ids, cols, voxel):
     import multiprocessing as mp
     ids = list(ids)
-    procs = max(1, min(len(ids), (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 64))
+    procs = max(1, min(len(ids), usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), 64))
     if procs == 1:
         return {k: _gen((k, cols, voxel)) for k in ids}
     with mp.get_context("fork").Pool(procs) as pool:
@@ -110,7 +136,8 @@ def launch_ranks(n, shared_gpu):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    env.setdefault("PVLM_HOST_THREADS", str(max(2, min(16, usable_cpus() // n))))     # staging / table passes of libpvlm.so: the ranks share the node's CPU budget
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -1044,25 +1071,6 @@ def panorama_block(ctx, pv, torch, dev, with_votes=True):
                               "dense_counters": int(voff[-1]), "nonzero_counters": int(len(nz_index)), "votes_cast": int(nz_count.sum())}
     dscan.close()
     return out
-
-
-def cpu_quota():
-    """CPUs this process may use on average: the cgroup's CFS quota (cpu.max: "<quota us> <period us>") when there is one, else None.  The GPU boxes of this
-    pool show 256 hardware threads and a quota of 16: more threads than that only run in bursts until the period's budget is spent, and then stall."""
-    for path in ("/sys/fs/cgroup/cpu.max",):
-        try:
-            quota, period = open(path).read().split()[:2]
-            if quota != "max":
-                return float(quota) / float(period)
-        except Exception:
-            pass
-    try:
-        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        if q > 0:
-            return q / p
-    except Exception:
-        pass
-    return None
 
 
 def cpu_baseline(ctx, pv, dscans, ref, nei, aa, t, kind, args):

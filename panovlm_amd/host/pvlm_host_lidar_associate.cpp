@@ -228,8 +228,14 @@ bool FormLine(const double* pts, int n, double tolerance, double dis_threshold, 
         const double apq = A[p][q];
         if (apq == 0.0) continue;
         const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        // t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), cs = 1 / sqrt(t^2 + 1), sn = t cs — half of all rotations have |theta| > 2^27 (the
+        // last sweeps before the off-diagonal reaches zero), where the same IEEE results come without the square roots: theta^2 >= 2^54 absorbs
+        // the + 1, sqrt(fl(theta^2)) is |theta| again (binary round-to-nearest), so t = sign / (2 |theta|) <= 2^-28, t^2 + 1 rounds to 1 and
+        // cs = 1, sn = t.  Where theta^2 overflows the written expression gives t = sign / inf = +-0: kept as the general case.
+        const double at = std::fabs(theta);
+        double t, cs, sn;
+        if (at > 134217728.0 && at < 1.0e150) { t = (theta >= 0.0 ? 1.0 : -1.0) / (at + at); cs = 1.0; sn = t; }
+        else { t = (theta >= 0.0 ? 1.0 : -1.0) / (at + std::sqrt(theta * theta + 1.0)); cs = 1.0 / std::sqrt(t * t + 1.0); sn = t * cs; }
         const int r = 3 - p - q;
         A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.0;
         const double arp = A[r][p], arq = A[r][q];
