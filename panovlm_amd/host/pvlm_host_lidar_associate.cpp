@@ -30,22 +30,6 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
     owner.push_back((int)i);
   }
   const int nc = (int)owner.size();
-  // The lists are a function of (size, which scans have a pose / are valid, the float centres, neighbor_size).  One outer iteration of EstimatePose asks
-  // twice with the same poses — for the line tracks, then for the point-to-plane pairs: the second answer is the first (kept per calling thread).
-  struct Memo { std::vector<uint32_t> key; std::vector<std::vector<int>> lists; };
-  static thread_local Memo memo;
-  std::vector<uint32_t> key;
-  key.reserve(2 + lidars.size() * 4);
-  key.push_back((uint32_t)neighbor_size); key.push_back((uint32_t)lidars.size());
-  for (size_t i = 0; i < lidars.size(); i++) {
-    const bool posed = lidars[i].IsPoseValid();
-    key.push_back((posed ? 1u : 0u) | (lidars[i].valid ? 2u : 0u));
-    float c[3] = {0.f, 0.f, 0.f};
-    if (posed) { const Vector3d& t = lidars[i].GetTranslation(); c[0] = float(t[0]); c[1] = float(t[1]); c[2] = float(t[2]); }
-    uint32_t bits[3]; std::memcpy(bits, c, 12);
-    key.insert(key.end(), bits, bits + 3);
-  }
-  if (!memo.key.empty() && memo.key == key) return memo.lists;
   // every scan's list is independent of the others: scan-parallel (at Floor size — 1593 scans, all inside the 20 m radius of the
   // synthetic room — the serial loop was 0.1 s per call, four calls per EstimatePose)
   neighbors_all.assign(lidars.size(), std::vector<int>());
@@ -93,7 +77,6 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
   std::atomic<size_t> next{0};
   auto work = [&]() { for (size_t i = next++; i < lidars.size(); i = next++) one(i); };
   pvlm_run_workers(n_threads, work);
-  memo.key.swap(key); memo.lists = neighbors_all;
   return neighbors_all;
 }
 
