@@ -561,7 +561,7 @@ class CameraLidarOptimizer {
   bool JointOptimize();
   void SetStructure(const std::vector<PointTrack>& s) { structure = s; }
   const std::vector<PointTrack>& GetStructure() const { return structure; }
-  std::vector<std::vector<int>> NeighborEachFrame(const int neighbor_size, const bool temporal) const;   // :551-610 (temporal branch)
+  std::vector<std::vector<int>> NeighborEachFrame(const int neighbor_size, const bool temporal) const;   // :551-610
   LinePairs AssociateLineMulti(const int neighbor_size, const bool temporal = true);                      // :331-384
   int Optimize(const LinePairs& line_pairs, std::vector<PointTrack>& structure, const bool refine_camera_rotation, const bool refine_camera_trans,
                const bool refine_lidar_rotation, const bool refine_lidar_trans, const bool refine_structure, double& cost, int& steps);   // :387-548

@@ -245,12 +245,43 @@ std::vector<uint16_t> ProjectLidar2PanoramaDepth(const PointCloud& cloud, const 
 
 std::vector<std::vector<int>> CameraLidarOptimizer::NeighborEachFrame(const int neighbor_size, const bool temporal) const {
   std::vector<std::vector<int>> out(frames.size());
-  if (!temporal) throw std::runtime_error("NeighborEachFrame: only the temporal branch (the one JointOptimize uses) is mirrored");
-  for (int frame_id = 0; frame_id < (int)frames.size(); frame_id++) {
-    int start = std::max(0, frame_id - (neighbor_size / 2));
-    const int end = std::min((int)lidars.size(), start + neighbor_size);
-    start = std::max(0, end - neighbor_size);
-    for (int l = start; l < end; l++) out[frame_id].push_back(l);
+  if (temporal) {                                                       // :555-567
+    for (int frame_id = 0; frame_id < (int)frames.size(); frame_id++) {
+      int start = std::max(0, frame_id - (neighbor_size / 2));
+      const int end = std::min((int)lidars.size(), start + neighbor_size);
+      start = std::max(0, end - neighbor_size);
+      for (int l = start; l < end; l++) out[frame_id].push_back(l);
+    }
+    return out;
+  }
+  // :569-608 — the neighbor_size LiDAR scans whose centres are nearest to the camera centre (float32 centres, flann::L2_Simple order, equal
+  // distances by position like every k-NN of this mirror), then the scans before and after the frame's own index when they are not among them
+  std::vector<std::array<float, 3>> center;
+  std::vector<int> owner;
+  for (size_t i = 0; i < lidars.size(); i++) {
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    const Vector3d& t = lidars[i].GetTranslation();
+    center.push_back({float(t[0]), float(t[1]), float(t[2])});
+    owner.push_back((int)i);
+  }
+  std::vector<std::pair<float, int>> d(center.size());
+  for (int i = 0; i < (int)frames.size(); i++) {
+    if (!frames[i].IsPoseValid()) continue;
+    const Matrix4d T = frames[i].GetPose();
+    const float q[3] = {float(T[3]), float(T[7]), float(T[11])};
+    for (size_t j = 0; j < center.size(); ++j) {
+      const float dx = q[0] - center[j][0], dy = q[1] - center[j][1], dz = q[2] - center[j][2];
+      float s = 0.0f; s += dx * dx; s += dy * dy; s += dz * dz;
+      d[j] = {s, (int)j};
+    }
+    const size_t k = std::min<size_t>((size_t)std::max(neighbor_size, 0), d.size());
+    std::partial_sort(d.begin(), d.begin() + k, d.end());
+    std::vector<int> neighbors;
+    for (size_t j = 0; j < k; ++j) neighbors.push_back(owner[(size_t)d[j].second]);
+    const std::set<int> have(neighbors.begin(), neighbors.end());
+    if (have.count(i - 1) == 0 && i - 1 >= 0) neighbors.push_back(i - 1);
+    if (have.count(i + 1) == 0 && i + 1 < (int)lidars.size()) neighbors.push_back(i + 1);
+    out[(size_t)i] = neighbors;
   }
   return out;
 }

@@ -535,6 +535,16 @@ int main(int argc, char** argv) {
       PrintPoses(opt.GetLidars());
       PrintFrames(opt.GetFrames());
       for (const PointTrack& t : opt.GetStructure()) printf("point %u %.17g %.17g %.17g\n", t.id, t.point_3d[0], t.point_3d[1], t.point_3d[2]);
+    } else if (cmd == "frame_neighbors") {
+      // frame_neighbors <lidars.bin> <frames.bin> neighbor_size temporal : CameraLidarOptimizer::NeighborEachFrame, one line per frame
+      auto l = LoadScans(argv[2]);
+      std::ifstream f(argv[3], std::ios::binary);
+      Matrix4d T;
+      std::vector<Frame> frames = LoadFrames(f, &T);
+      Config cfg;
+      CameraLidarOptimizer opt(T, l, frames, cfg, atoi(argv[4]), 1);
+      const auto nb = opt.NeighborEachFrame(atoi(argv[4]), atoi(argv[5]) != 0);
+      for (const auto& list : nb) { printf("nb"); for (int v : list) printf(" %d", v); printf("\n"); }
     } else if (cmd == "bundle") {
       // bundle <frames.bin> <structure.bin> camera_w refine_structure max_iter : camera-only bundle adjustment
       // (AddCameraResidual + SetOptionsSfM + Solve, camera 0 constant) on the GPU with point elimination

@@ -401,3 +401,48 @@ def test_balanced_ranges_of_a_sharded_run():
             assert max(sums) <= tot / world + max(w)                 # no rank carries more than its share plus one scan
         else:
             assert [r[1:3] for r in rg] == [[len(w) * k // world, len(w) * (k + 1) // world] for k in range(world)]
+
+
+def test_frame_neighbors_spatial_and_temporal(tmp_path):
+    """CameraLidarOptimizer::NeighborEachFrame (joint_optimization/CameraLidarOptimizer.cpp:551-610): the temporal window JointOptimize uses, and the spatial
+    branch — the k scans whose centres are nearest to the camera centre (float32, first among equals), plus the scans before / after the frame's own index —
+    against a numpy restatement.  Scans marked invalid do not take part; a frame without a pose gets no list."""
+    rng = np.random.default_rng(4)
+    n = 23
+    t_l = np.cumsum(rng.normal(0, 0.6, (n, 3)), axis=0)
+    t_l[7] = t_l[3]                                                   # equal distances: position decides
+    scans = [dict(id=k, valid=0 if k in (5, 11) else 1, R_wl=np.eye(3), t_wl=t_l[k]) for k in range(n)]
+    frames = [dict(id=k, rows=64, cols=128, valid=0 if k == 9 else 1, R_wc=np.eye(3), t_wc=t_l[min(k, n - 1)] + rng.normal(0, 0.3, 3), lines=np.zeros((0, 4)))
+              for k in range(n + 2)]
+    lp, fp = str(tmp_path / "l.bin"), str(tmp_path / "f.bin")
+    host_io.write_scans(lp, scans)
+    host_io.write_frames(fp, np.eye(4), frames)
+
+    def lists(k, temporal):
+        out = [[int(v) for v in l.split()[1:]] for l in host_io.run("frame_neighbors", lp, fp, k, 1 if temporal else 0) if l.startswith("nb")]
+        assert len(out) == len(frames)
+        return out
+
+    for k in (3, 6, 40):
+        got = lists(k, True)
+        for f in range(len(frames)):
+            start = max(0, f - k // 2); end = min(n, start + k); start = max(0, end - k)
+            assert got[f] == list(range(start, end))
+        got = lists(k, False)
+        owner = [i for i in range(n) if scans[i]["valid"]]
+        c = np.asarray([t_l[i] for i in owner], np.float32)
+        for f, fr in enumerate(frames):
+            if not fr["valid"]:
+                assert got[f] == []
+                continue
+            d = c - np.asarray(fr["t_wc"], np.float32)
+            s = np.zeros(len(c), np.float32)
+            for a in range(3):
+                s = (s + d[:, a] * d[:, a]).astype(np.float32)
+            nearest = [owner[j] for j in np.argsort(s, kind="stable")[:k]]
+            want = list(nearest)
+            if f - 1 >= 0 and f - 1 not in nearest:
+                want.append(f - 1)
+            if f + 1 < n and f + 1 not in nearest:
+                want.append(f + 1)
+            assert got[f] == want, (k, f)

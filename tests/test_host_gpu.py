@@ -719,10 +719,13 @@ def test_host_visible_evaluation_matches_device_rows(oracle):
                                   dict(k=7, start_deg=180.0, dropout=0.9), dict(k=8, segment=False, max_curvature=5.0, angle_threshold=10.0),
                                   dict(k=9, cols=4096, clutter=40)],
                          ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_feature_extraction_with_gpu_stages_matches_oracle(oracle, case):
-    """Velodyne::ExtractFeaturesBatch — ring / column order, range image, Segmentation and curvature from the GPU
-    (pvlm_ring_extract_batch), picks + EdgeToLine + voxel grid on the host — leaves a scan exactly as the oracle's
+@pytest.mark.parametrize("picks", ["device", "host"])
+def test_feature_extraction_with_gpu_stages_matches_oracle(oracle, case, picks, monkeypatch):
+    """Velodyne::ExtractFeaturesBatch — ring / column order, range image, Segmentation, curvature, sector orders from the GPU
+    (pvlm_ring_extract_batch[_picks]); the picks and the voxel grid from K24 ("device": AssemblePicks) or on the host from the device's arrays
+    ("host": PickFeatures, the path a scan with an undecided ring takes); EdgeToLine on the host — leaves a scan exactly as the oracle's
     ReOrderVLP + ExtractFeatures do: every cloud, every per-point array, the line segments."""
+    monkeypatch.setenv("PVLM_FEATURE_PICKS", picks)
     c = dict(case); k = c.pop("k")
     ext = {n: c.pop(n) for n in ("segment", "max_curvature", "angle_threshold") if n in c}
     cols = c.get("cols", 1800)
