@@ -524,6 +524,10 @@ def main():
             features = features_block(ctx, pv)
         except Exception as e:  # reporting extra only
             features = {"error": str(e)[:200]}
+        try:
+            features["undistort"] = undistort_block(ctx, pv)
+        except Exception as e:
+            features["undistort"] = {"error": str(e)[:200]}
     mvs = None
     if rank == 0 and world == 1 and not args.no_mvs:
         try:
@@ -1001,6 +1005,43 @@ def features_block(ctx, pv, scans=454, cols=1800):
         for k in range(3):
             orc.ScanFeatures(raws[k], n_scans=16, horizon=cols, segment=True, extract=True)
         out["cpu_oracle_ms_per_scan_full_extraction"] = (time.perf_counter() - t0) / 3 * 1e3
+    except Exception as e:
+        out["cpu_oracle_error"] = str(e)[:120]
+    return out
+
+
+def undistort_block(ctx, pv, scans=454, cols=1800):
+    """Motion compensation of a Room-sized batch (pvlm_undistort_batch, K25: Velodyne::UndistortCloud of every scan of LidarOdometry::UndistortLidars in one call):
+    wall per call with the clouds on the host, as the boundary has them — 16 B up and 16 B down per point over the host link — and the oracle's per-point loop on
+    one host core beside it."""
+    from panovlm_amd import api, synthetic as sy
+    base = [sy.raw_vlp16_scan(k, cols=cols, clutter=40) for k in range(8)]
+    clouds = [base[k % len(base)] for k in range(scans)]
+    starts, ends = [], []
+    for k in range(scans):
+        R0, t0 = sy.estimated_pose(k % 16); R1, t1 = sy.estimated_pose(k % 16 + 1)
+        starts.append((R0, t0)); ends.append((R1, t1))
+    api.undistort_batch(ctx, clouds[:8], starts[:8], ends[:8])
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        api.undistort_batch(ctx, clouds, starts, ends)
+        w = (time.perf_counter() - t0) * 1e3
+        best = w if best is None or w < best else best
+    points = int(sum(len(c) for c in clouds))
+    link = 55.7e9
+    out = {"scans": scans, "points": points, "wall_ms_per_call": best, "M_points_per_s": points / best / 1e3,
+           "includes": "the Python wrapper's copy of every cloud (the C call works in place)",
+           "roof": {"bound": "host link (PCIe Gen5 x16), both directions in sequence", "bytes_per_point": 32, "ms_at_link_rate": points * 32 / link * 1e3,
+                    "frac": (points * 32 / link * 1e3) / best},
+           "what": "Velodyne::UndistortCloud (sensors/Velodyne.cpp:1642-1674) per point: slerp of the end-to-start rotation by i / n (two double sines), rotation, "
+                   "translation; bit-identical to the oracle on the test clouds (tests/test_undistort_gpu.py, tolerance 1e-6)"}
+    try:
+        from oracle import oracle as orc
+        t0 = time.perf_counter()
+        for k in range(3):
+            orc.undistort_cloud(clouds[k], *starts[k], *ends[k])
+        out["cpu_oracle_ms_per_scan"] = (time.perf_counter() - t0) / 3 * 1e3
     except Exception as e:
         out["cpu_oracle_error"] = str(e)[:120]
     return out

@@ -615,6 +615,21 @@ pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* batch);
  * as std::sort of the indices 0 .. n-1 by `keys[a] < keys[b]` leaves them — equal keys in libstdc++'s order.                                      */
 pvlm_status pvlm_ring_debug_sort(pvlm_ctx* ctx, const unsigned* keys, int n, int* order);
 
+/* ---- motion compensation of the sweeps (N5) ---------------------------------------------------------------------------------------------
+ * Velodyne::UndistortCloud(R_we, t_we) (sensors/Velodyne.cpp:1642-1674) for every scan of LidarOdometry::UndistortLidars
+ * (lidar_mapping/LidarOdometry.cpp:189-263) in one call: point i of n moves by the share i / n of the motion from the sweep's start pose (R_wl, t_wl)
+ * to its end pose (R_we, t_we) — rotation by Identity.slerp(i / n, q_se), translation (i / n) t_se.  xyzi: n points of stride_floats >= 4 floats
+ * (x, y, z first; pcl::PointXYZI: 8), updated in place; rotations row-major 3x3, world <- sensor.  The caller picks the end pose (next scan's pose
+ * through SlerpPose, ...) and clears the feature clouds as upstream does.                                                                    */
+typedef struct pvlm_undistort_scan {
+  float* xyzi;
+  int n;
+  int stride_floats;
+  const double* R_wl; const double* t_wl;
+  const double* R_we; const double* t_we;
+} pvlm_undistort_scan;
+pvlm_status pvlm_undistort_batch(pvlm_ctx* ctx, int n_scans, const pvlm_undistort_scan* scans);
+
 #ifdef __cplusplus
 }
 #endif

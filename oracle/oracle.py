@@ -596,3 +596,31 @@ def voxel_grid(cloud, leaf):
     n = lib().orc_voxel_grid(C.c_long(len(c)), _p(c, C.c_float), C.c_float(leaf), _p(out, C.c_float))
     return out[:n]
 
+
+def _pose12(R, t):
+    return np.concatenate([_f64(R).reshape(9), _f64(t).reshape(3)])
+
+
+def undistort_cloud(cloud, R_wl, t_wl, R_we, t_we, pose_valid=True):
+    """Velodyne::UndistortCloud (oracle/undistort.hpp): returns (done, cloud n x 4 float32)."""
+    c = _f32(cloud).reshape(-1, 4).copy()
+    a = _pose12(R_wl, t_wl); b = _pose12(R_we, t_we)
+    done = lib().orc_undistort_cloud(_p(c, C.c_float), C.c_long(len(c)), _p(a, C.c_double), C.c_int(1 if pose_valid else 0), _p(b, C.c_double))
+    return bool(done), c
+
+
+def slerp_pose(R1, t1, R2, t2, ratio):
+    """SlerpPose(pose_w1, pose_w2, ratio) of base/Geometry.hpp:572-583: returns (R, t)."""
+    out = np.zeros(12)
+    a = _pose12(R1, t1); b = _pose12(R2, t2)
+    lib().orc_slerp_pose(_p(a, C.c_double), _p(b, C.c_double), C.c_double(ratio), _p(out, C.c_double))
+    return out[:9].reshape(3, 3), out[9:]
+
+
+def sweep_end_pose(poses, pose_ok, ok, i, gap_time):
+    """The pose LidarOdometry::UndistortLidars hands to scan i's UndistortCloud, or None when the scan is left as it is.  poses: list of (R, t)."""
+    flat = np.concatenate([_pose12(R, t) for R, t in poses])
+    po = np.asarray(pose_ok, np.int8); o = np.asarray(ok, np.int8)
+    out = np.zeros(12)
+    got = lib().orc_sweep_end_pose(C.c_int(len(poses)), _p(flat, C.c_double), _p(po, C.c_char), _p(o, C.c_char), C.c_int(i), C.c_float(gap_time), _p(out, C.c_double))
+    return (out[:9].reshape(3, 3), out[9:]) if got else None

@@ -12,6 +12,7 @@
 #include "features.hpp"
 #include "lines.hpp"
 #include "mvs.hpp"
+#include "undistort.hpp"
 
 using namespace oracle;
 
@@ -470,6 +471,22 @@ long orc_voxel_grid(long n, const float* cloud, float leaf, float* out) {
   const std::vector<FPoint> o = VoxelGrid(c, leaf);
   for (size_t i = 0; i < o.size(); ++i) { out[4 * i] = o[i].x; out[4 * i + 1] = o[i].y; out[4 * i + 2] = o[i].z; out[4 * i + 3] = o[i].intensity; }
   return (long)o.size();
+}
+
+// ---- motion compensation (undistort.hpp).  Poses as 12 doubles: row-major R (9), t (3), world <- sensor.
+static oracle::undistort::Pose pose_of(const double* p) { oracle::undistort::Pose o; std::memcpy(o.R, p, 72); std::memcpy(o.t, p + 9, 24); return o; }
+static void pose_to(const oracle::undistort::Pose& o, double* p) { std::memcpy(p, o.R, 72); std::memcpy(p + 9, o.t, 24); }
+int orc_undistort_cloud(float* cloud, long n, const double* T_wl, int pose_valid, const double* T_we) {
+  return oracle::undistort::UndistortCloud(cloud, n, pose_of(T_wl), pose_valid != 0, pose_of(T_we)) ? 1 : 0;
+}
+void orc_slerp_pose(const double* T_w1, const double* T_w2, double ratio, double* out) { pose_to(oracle::undistort::SlerpPose(pose_of(T_w1), pose_of(T_w2), ratio), out); }
+int orc_sweep_end_pose(int n, const double* poses, const char* pose_ok, const char* ok, int i, float gap_time, double* out) {
+  std::vector<oracle::undistort::Pose> P((size_t)n);
+  for (int k = 0; k < n; ++k) P[(size_t)k] = pose_of(poses + 12 * (size_t)k);
+  oracle::undistort::Pose e;
+  if (!oracle::undistort::SweepEndPose(P, std::vector<char>(pose_ok, pose_ok + n), std::vector<char>(ok, ok + n), i, gap_time, &e)) return 0;
+  pose_to(e, out);
+  return 1;
 }
 
 }  // extern "C"

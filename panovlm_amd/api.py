@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -890,6 +890,26 @@ class Scan:
             self.close()
         except Exception:
             pass
+
+
+class UndistortScanDesc(C.Structure):
+    _fields_ = [("xyzi", C.POINTER(C.c_float)), ("n", C.c_int), ("stride_floats", C.c_int), ("R_wl", C.POINTER(C.c_double)), ("t_wl", C.POINTER(C.c_double)),
+                ("R_we", C.POINTER(C.c_double)), ("t_we", C.POINTER(C.c_double))]
+
+
+def undistort_batch(ctx, clouds, start_poses, end_poses):
+    """pvlm_undistort_batch: clouds — list of n x 4 float32 arrays; start_poses / end_poses — lists of (R 3x3, t 3), world <- sensor.  Returns the
+    motion-compensated copies (Velodyne::UndistortCloud)."""
+    out = [np.ascontiguousarray(c, np.float32).reshape(-1, 4).copy() for c in clouds]
+    keep = []
+    descs = (UndistortScanDesc * max(len(out), 1))()
+    for k, c in enumerate(out):
+        arrs = [_f64(start_poses[k][0]).reshape(9), _f64(start_poses[k][1]).reshape(3), _f64(end_poses[k][0]).reshape(9), _f64(end_poses[k][1]).reshape(3)]
+        keep.append(arrs)
+        descs[k].xyzi = _p(c, C.c_float); descs[k].n = len(c); descs[k].stride_floats = 4
+        descs[k].R_wl, descs[k].t_wl, descs[k].R_we, descs[k].t_we = (_p(a, C.c_double) for a in arrs)
+    ctx._check(ctx.lib.pvlm_undistort_batch(ctx._h, C.c_int(len(out)), descs), "pvlm_undistort_batch")
+    return out
 
 
 def device_sort(ctx, keys):

@@ -1,0 +1,104 @@
+// K25: Velodyne::UndistortCloud (sensors/Velodyne.cpp:1642-1674) for all scans of LidarOdometry::UndistortLidars (lidar_mapping/LidarOdometry.cpp:189-263)
+// in one launch: one thread per point, two double sines and a quaternion rotation each — 16 B in, 16 B out per point, bound by the host link when the clouds
+// live on the host (they do: the boundary is the reference's, host clouds in place), by HBM otherwise.  The per-sweep constants (quaternion of the end-to-start
+// rotation, its angle and sine) are computed once per scan on the host with the host's libm, exactly the values upstream recomputes for every point.
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "pvlm_internal.h"
+#include "pvlm_workers.h"
+#include "pvlm_undistort_core.h"
+
+namespace {
+
+struct SweepDesc { pvlm_undistort::Sweep w; long long pt0; int n; int pad; };
+
+__global__ __launch_bounds__(256) void k_undistort(const SweepDesc* __restrict__ sweeps, float4* __restrict__ pts) {
+  const SweepDesc d = sweeps[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= d.n) return;
+  float4 p = pts[d.pt0 + i];
+  const float in[3] = {p.x, p.y, p.z};
+  float out[3];
+  pvlm_undistort::undistort_point(d.w, i, d.n, in, out);
+  p.x = out[0]; p.y = out[1]; p.z = out[2];
+  pts[d.pt0 + i] = p;
+}
+
+}  // namespace
+
+extern "C" pvlm_status pvlm_undistort_batch(pvlm_ctx* ctx, int n_scans, const pvlm_undistort_scan* scans) {
+  if (!ctx || n_scans < 0 || (n_scans > 0 && !scans)) return PVLM_ERR_ARG;
+  long long total = 0;
+  int max_n = 0;
+  for (int s = 0; s < n_scans; ++s) {
+    const pvlm_undistort_scan& d = scans[s];
+    if (d.n < 0 || (d.n > 0 && !d.xyzi) || d.stride_floats < 4 || !d.R_wl || !d.t_wl || !d.R_we || !d.t_we) { PVLM_SET_ERR(ctx, "pvlm_undistort_batch: bad descriptor (scan %d)", s); return PVLM_ERR_ARG; }
+    total += d.n; max_n = d.n > max_n ? d.n : max_n;
+  }
+  if (total == 0) return PVLM_OK;
+  if (total >= (1ll << 31)) { PVLM_SET_ERR(ctx, "pvlm_undistort_batch: batch too large (split it)"); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if (ctx->capturing) { PVLM_SET_ERR(ctx, "pvlm_undistort_batch inside a graph capture"); return PVLM_ERR_STATE; }
+  try {
+    std::vector<SweepDesc> desc((size_t)n_scans);
+    long long pt0 = 0;
+    for (int s = 0; s < n_scans; ++s) {
+      desc[(size_t)s].w = pvlm_undistort::sweep_of(scans[s].R_wl, scans[s].t_wl, scans[s].R_we, scans[s].t_we);
+      desc[(size_t)s].pt0 = pt0; desc[(size_t)s].n = scans[s].n; desc[(size_t)s].pad = 0;
+      pt0 += scans[s].n;
+    }
+    // pinned staging: the ring batches' pool (the same scans pass through both in one EstimatePose / UndistortLidars / EstimatePose sequence)
+    const size_t bytes = (size_t)total * 16 + (size_t)n_scans * sizeof(SweepDesc) + 256;
+    char* h = nullptr; size_t h_bytes = 0;
+    int fit = -1;
+    for (int k = 0; k < ctx->ring_pool; ++k) if (ctx->ring_bytes[k] >= bytes && (fit < 0 || ctx->ring_bytes[k] < ctx->ring_bytes[fit])) fit = k;
+    if (fit >= 0) {
+      h = (char*)ctx->h_ring[fit]; h_bytes = ctx->ring_bytes[fit];
+      --ctx->ring_pool; ctx->h_ring[fit] = ctx->h_ring[ctx->ring_pool]; ctx->ring_bytes[fit] = ctx->ring_bytes[ctx->ring_pool];
+    } else if (hipHostMalloc((void**)&h, bytes, hipHostMallocDefault) == hipSuccess) h_bytes = bytes;
+    else { PVLM_SET_ERR(ctx, "pvlm_undistort_batch: %zu bytes of pinned memory unavailable", bytes); return PVLM_ERR_NOMEM; }
+    struct Back { pvlm_ctx* c; char* p; size_t b; ~Back() { if (c->ring_pool < pvlm_ctx::kRingPool) { c->h_ring[c->ring_pool] = p; c->ring_bytes[c->ring_pool] = b; ++c->ring_pool; } else (void)hipHostFree(p); } } back{ctx, h, h_bytes};
+    float4* hp = (float4*)h;
+    SweepDesc* hd = (SweepDesc*)(h + (((size_t)total * 16 + 255) & ~(size_t)255));
+    std::memcpy(hd, desc.data(), (size_t)n_scans * sizeof(SweepDesc));
+    auto each_scan = [&](auto&& body) {
+      const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), (size_t)n_scans / 16 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+      std::atomic<int> next{0};
+      auto work = [&]() { for (int s = next++; s < n_scans; s = next++) body(s); };
+      pvlm_run_workers(n_threads, work);
+    };
+    each_scan([&](int s) {
+      const pvlm_undistort_scan& d = scans[s];
+      float4* dst = hp + desc[(size_t)s].pt0;
+      if (d.stride_floats == 4) std::memcpy(dst, d.xyzi, (size_t)d.n * 16);
+      else for (int i = 0; i < d.n; ++i) { const float* p = d.xyzi + (size_t)i * d.stride_floats; dst[i] = make_float4(p[0], p[1], p[2], p[3]); }
+    });
+    float4* d_pts = nullptr; SweepDesc* d_desc = nullptr;
+    pvlm_status st = pvlm_i_alloc(ctx, &d_pts, (size_t)total);
+    if (!st) st = pvlm_i_alloc(ctx, &d_desc, (size_t)n_scans);
+    if (st) { pvlm_i_free(ctx, d_pts); return st; }
+    hipStream_t S = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d_pts, hp, (size_t)total * 16, hipMemcpyHostToDevice, S);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_desc, hd, (size_t)n_scans * sizeof(SweepDesc), hipMemcpyHostToDevice, S);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_undistort, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_scans), dim3(256), 0, S, d_desc, d_pts);
+      e = hipMemcpyAsync(hp, d_pts, (size_t)total * 16, hipMemcpyDeviceToHost, S);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(S);
+    pvlm_i_free(ctx, d_pts); pvlm_i_free(ctx, d_desc);
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_undistort_batch: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; }
+    each_scan([&](int s) {
+      const pvlm_undistort_scan& d = scans[s];
+      const float4* src = hp + desc[(size_t)s].pt0;
+      if (d.stride_floats == 4) std::memcpy(d.xyzi, src, (size_t)d.n * 16);
+      else for (int i = 0; i < d.n; ++i) { float* p = d.xyzi + (size_t)i * d.stride_floats; p[0] = src[i].x; p[1] = src[i].y; p[2] = src[i].z; }
+    });
+    return PVLM_OK;
+  } catch (const std::bad_alloc&) {
+    PVLM_SET_ERR(ctx, "pvlm_undistort_batch: out of host memory");
+    return PVLM_ERR_NOMEM;
+  }
+}

@@ -251,4 +251,44 @@ void Velodyne::UploadBatch(const std::vector<const Velodyne*>& scans) {
 }
 
 
+// ---- motion compensation (sensors/Velodyne.cpp:1635-1674) ------------------------------------------------------------------------------------
+void Velodyne::UndistortBatch(const std::vector<Velodyne*>& scans, const std::vector<Matrix4d>& T_we) {
+  if (scans.size() != T_we.size()) throw std::invalid_argument("UndistortBatch: one end pose per scan");
+  std::vector<pvlm_undistort_scan> descs;
+  std::vector<std::array<double, 24>> poses;          // R_wl, t_wl, R_we, t_we per scan (the descriptors point into it)
+  poses.reserve(scans.size());
+  std::vector<Velodyne*> done;
+  for (size_t k = 0; k < scans.size(); ++k) {
+    Velodyne* v = scans[k];
+    if (!v || !v->IsPoseValid()) continue;                                   // :1644-1645
+    if (v->cloud.empty()) v->LoadLidar(v->name);                             // :1650-1651
+    if (v->cloud.empty()) continue;
+    std::array<double, 24> p{};
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) { p[3 * r + c] = v->R_wl_[3 * r + c]; p[12 + 3 * r + c] = T_we[k][4 * r + c]; }
+      p[9 + r] = v->t_wl_[r]; p[21 + r] = T_we[k][4 * r + 3];
+    }
+    poses.push_back(p);
+    done.push_back(v);
+  }
+  if (done.empty()) return;
+  descs.resize(done.size());
+  for (size_t k = 0; k < done.size(); ++k)
+    descs[k] = pvlm_undistort_scan{&done[k]->cloud[0].x, (int)done[k]->cloud.size(), (int)(sizeof(PointXYZI) / sizeof(float)), &poses[k][0], &poses[k][9], &poses[k][12], &poses[k][21]};
+  Engine& e = Engine::Default();
+  e.Check(pvlm_undistort_batch(e.ctx(), (int)descs.size(), descs.data()), "pvlm_undistort_batch");
+  for (Velodyne* v : done) {                                                 // :1663-1667
+    v->cloud_scan.clear(); v->cornerLessSharp.clear(); v->cornerSharp.clear(); v->surfFlat.clear(); v->surfLessFlat.clear();
+    v->InvalidateDevice();
+  }
+}
+
+bool Velodyne::UndistortCloud(const Matrix4d& T_we) {
+  if (!IsPoseValid()) return false;
+  if (cloud.empty()) LoadLidar(name);
+  if (cloud.empty()) return false;
+  UndistortBatch({this}, {T_we});
+  return true;
+}
+
 }  // namespace pvlm

@@ -141,6 +141,10 @@ class Velodyne {
   // (removeClosedPointCloud, :148-172), swaps the axes to the camera convention (x, y, z) -> (x, -z, y) and marks the scan
   // invalid when fewer than 4000 points remain.  Returns false when the file cannot be read (the reference logs and returns).
   bool LoadLidar(std::string file_path = "");
+  // sensors/Velodyne.cpp:1635-1674: motion compensation of the raw cloud — point i of n moves by i / n of the way from this scan's pose to T_we (the pose
+  // at the sweep's end); the feature clouds are cleared as upstream clears them.  One scan: a batch of one; UndistortBatch: one device call for all.
+  bool UndistortCloud(const Matrix4d& T_we);
+  static void UndistortBatch(const std::vector<Velodyne*>& scans, const std::vector<Matrix4d>& T_we);
   // ReOrderVLP (sensors/Velodyne.cpp:371-526): firing order -> ring order, range image, ring/column of every point.
   void ReOrderVLP();
   // ExtractFeatures (sensors/Velodyne.cpp:531-760), method ADAPTIVE only (config/Room.txt:32), PLANAR BRANCH: optional
@@ -449,6 +453,9 @@ class LidarOdometry {
   // (the scans handed in already carry their feature clouds — SURVEY.md §8 A0 / "next" row N3).
   bool EstimatePose(const int max_iteration);
   bool RefinePose(double& cost, int& steps, bool use_segment);
+  // lidar_mapping/LidarOdometry.cpp:189-263 without the PCD export: every scan with a usable pose is motion-compensated with the pose that ends its sweep
+  // (the next usable scan's pose through SlerpPose; the last scan continues the motion of the one before), all scans in one device call
+  bool UndistortLidars(const float gap_time);
   const std::vector<Velodyne>& GetLidarData() const { return lidars; }
   std::vector<Matrix3d> GetGlobalRotation() const;
   std::vector<Vector3d> GetGlobalTranslation() const;
@@ -468,6 +475,9 @@ class LidarOdometry {
   Config config;
   Exchange exchange_;
 };
+
+// base/Geometry.hpp:572-583: the pose a fraction `ratio` of the way from pose_w1 to pose_w2 (rotation by slerp, translation of T_21 scaled)
+Matrix4d SlerpPose(const Matrix4d& pose_w1, const Matrix4d& pose_w2, double ratio);
 
 // ---- sensors/Equirectangular.h + joint_optimization/CameraLidarLineAssociate.h -------------------------------
 struct CameraLidarLinePair {

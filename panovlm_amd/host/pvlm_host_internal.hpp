@@ -3,6 +3,7 @@
 #pragma once
 #include "pvlm_host.hpp"
 #include "../csrc/pvlm_workers.h"
+#include "../csrc/pvlm_undistort_core.h"
 
 #include <algorithm>
 #include <atomic>

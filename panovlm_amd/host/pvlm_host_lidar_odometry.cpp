@@ -157,4 +157,68 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
 }
 
 
+// ---- base/Geometry.hpp:572-583, lidar_mapping/LidarOdometry.cpp:189-263 -----------------------------------------------------------------------
+namespace {
+struct Rigid { double R[9], t[3]; };
+Rigid RigidOf(const Matrix4d& T) { Rigid o; for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) o.R[3 * r + c] = T[4 * r + c]; o.t[r] = T[4 * r + 3]; } return o; }
+Matrix4d MatrixOf(const Rigid& p) { return {p.R[0], p.R[1], p.R[2], p.t[0], p.R[3], p.R[4], p.R[5], p.t[1], p.R[6], p.R[7], p.R[8], p.t[2], 0, 0, 0, 1}; }
+Rigid InverseOf(const Rigid& p) {       // a pose's inverse as (R^T, -R^T t); upstream's Matrix4d::inverse() of the same matrix agrees to the last bits
+  Rigid o;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o.R[3 * r + c] = p.R[3 * c + r];
+  for (int r = 0; r < 3; ++r) o.t[r] = -((o.R[3 * r] * p.t[0] + o.R[3 * r + 1] * p.t[1]) + o.R[3 * r + 2] * p.t[2]);
+  return o;
+}
+Rigid Compose(const Rigid& a, const Rigid& b) {
+  Rigid o;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) o.R[3 * r + c] = (a.R[3 * r] * b.R[c] + a.R[3 * r + 1] * b.R[3 + c]) + a.R[3 * r + 2] * b.R[6 + c];
+    o.t[r] = ((a.R[3 * r] * b.t[0] + a.R[3 * r + 1] * b.t[1]) + a.R[3 * r + 2] * b.t[2]) + a.t[r];
+  }
+  return o;
+}
+}  // namespace
+
+Matrix4d SlerpPose(const Matrix4d& pose_w1, const Matrix4d& pose_w2, double ratio) {
+  const Rigid w1 = RigidOf(pose_w1);
+  const Rigid T_21 = Compose(InverseOf(RigidOf(pose_w2)), w1);
+  const pvlm_undistort::Quat q_s1 = pvlm_undistort::slerp_at(pvlm_undistort::slerp_prepare(pvlm_undistort::quat_of_matrix(T_21.R)), ratio);
+  Rigid T_s1;
+  pvlm_undistort::matrix_of_quat(q_s1, T_s1.R);
+  for (int k = 0; k < 3; ++k) T_s1.t[k] = T_21.t[k] * ratio;
+  return MatrixOf(Compose(w1, InverseOf(T_s1)));
+}
+
+bool LidarOdometry::UndistortLidars(const float gap_time) {
+  StageTimer stage_timer_("motion compensation of the sweeps (UndistortLidars)");
+  const double lidar_duration = 0.1;
+  const int n = (int)lidars.size();
+  std::vector<Velodyne*> scans;
+  std::vector<Matrix4d> ends;
+  for (int i = 0; i < n; i++) {
+    // the pose of the sweep's last point: the next scan's pose — the next one that has a pose — interpolated back to the end of this sweep (:206-241;
+    // the conditions are upstream's as written: a neighbour is passed over only when it has neither a pose nor the valid flag, the backward search
+    // tests this scan's flag, and idx <= 0 gives up)
+    Matrix4d pose;
+    if (!lidars[i].IsPoseValid() || !lidars[i].valid) continue;
+    if (i < n - 1) {
+      int idx = i + 1;
+      while (idx < n && !lidars[idx].IsPoseValid() && !lidars[idx].valid) idx++;
+      if (idx >= n) continue;
+      pose = SlerpPose(lidars[i].GetPose(), lidars[idx].GetPose(), lidar_duration / ((idx - i) * (lidar_duration + gap_time)));
+    } else {
+      int idx = i - 1;
+      while (idx >= 0 && !lidars[idx].IsPoseValid() && !lidars[i].valid) idx--;
+      if (idx <= 0) continue;
+      // one scan period before this scan, mirrored to one period after it: the three poses are taken to move alike
+      pose = SlerpPose(lidars[idx].GetPose(), lidars[i].GetPose(), 1.0 - lidar_duration / ((idx - i) * (lidar_duration + gap_time)));
+      const Rigid cur = RigidOf(lidars[i].GetPose());
+      pose = MatrixOf(Compose(cur, Compose(InverseOf(cur), RigidOf(pose))));
+    }
+    scans.push_back(&lidars[i]);
+    ends.push_back(pose);
+  }
+  Velodyne::UndistortBatch(scans, ends);
+  return true;
+}
+
 }  // namespace pvlm

@@ -441,6 +441,39 @@ int main(int argc, char** argv) {
         printf("\n");
       }
       PrintPoses(odo.GetLidarData());
+    } else if (cmd == "undistort") {
+      // undistort <raw_scans.bin> gap_time out.bin [invalid ids ...] : LidarOdometry::UndistortLidars on raw scans with poses (a zero rotation = no pose;
+      // ids listed after out.bin get valid = false); out.bin: the clouds afterwards, scan by scan (n x 4 f32).  Prints the seconds of the call.
+      std::ifstream f(argv[2], std::ios::binary);
+      if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+      int32_t ns = 0; rd(f, &ns, 1);
+      std::vector<Velodyne> l(ns);
+      for (Velodyne& v : l) {
+        int32_t id = 0, n = 0; rd(f, &id, 1);
+        Matrix3d R; Vector3d t; rd(f, R.data(), 9); rd(f, t.data(), 3);
+        rd(f, &n, 1);
+        v.id = id; v.SetPose(R, t);
+        v.cloud.resize(n);
+        for (auto& p : v.cloud) rd(f, &p.x, 4);
+      }
+      for (int a = 5; a < argc; ++a) { const int id = atoi(argv[a]); if (id >= 0 && id < ns) l[id].valid = false; }
+      Config cfg;
+      LidarOdometry odo(l, cfg);
+      odo.UndistortLidars((float)atof(argv[3]));               // first call: code objects, pinned staging
+      const auto t0 = std::chrono::steady_clock::now();
+      LidarOdometry again(l, cfg);
+      again.UndistortLidars((float)atof(argv[3]));
+      printf("undistort_seconds %.6f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      std::ofstream o(argv[4], std::ios::binary);
+      for (const Velodyne& v : odo.GetLidarData()) o.write(reinterpret_cast<const char*>(v.cloud.data()), (std::streamsize)(v.cloud.size() * sizeof(PointXYZI)));
+    } else if (cmd == "slerp_pose") {
+      // slerp_pose ratio  + 24 doubles on stdin-like args: R1 (9) t1 (3) R2 (9) t2 (3) : pvlm::SlerpPose
+      const double ratio = atof(argv[2]);
+      double v[24]; for (int k = 0; k < 24; ++k) v[k] = atof(argv[3 + k]);
+      const Matrix4d T1 = {v[0], v[1], v[2], v[9], v[3], v[4], v[5], v[10], v[6], v[7], v[8], v[11], 0, 0, 0, 1};
+      const Matrix4d T2 = {v[12], v[13], v[14], v[21], v[15], v[16], v[17], v[22], v[18], v[19], v[20], v[23], 0, 0, 0, 1};
+      const Matrix4d T = SlerpPose(T1, T2, ratio);
+      printf("pose"); for (double x : T) printf(" %.17g", x); printf("\n");
     } else if (cmd == "featbench") {
       // featbench <raw_scans.bin> reps segment : host seconds per scan of ReOrderVLP + ExtractFeatures (no GPU involved)
       std::ifstream f(argv[2], std::ios::binary);
