@@ -78,6 +78,9 @@ pvlm_status pvlm_device_info(pvlm_ctx* ctx, int* cu_count, int64_t* hbm_bytes, c
  * held from the driver, bytes handed out, the high-water mark and the number of hipMalloc calls so far (a steady state
  * adds none).  Any pointer may be NULL.  PVLM_NO_POOL=1 in the environment bypasses the pool (debugging). */
 pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes);
+/* The pinned staging window of pvlm_scan_upload[_batch] (64 MB by default, PVLM_UPLOAD_STAGE_MB) is allocated by the first upload that needs it:
+ * hipHostMalloc + first touch of 64 MB cost 25 ms.  A host that knows it will upload reserves the window at start-up.                          */
+pvlm_status pvlm_reserve_staging(pvlm_ctx* ctx, int64_t bytes);
 pvlm_status pvlm_trim(pvlm_ctx* ctx);
 pvlm_status pvlm_mem_info(const pvlm_ctx* ctx, int64_t* reserved, int64_t* in_use, int64_t* peak, int64_t* device_allocs);
 /* HIP graph of a step: the calls issued between _begin and _end on this context (pvlm_set_poses_dev,

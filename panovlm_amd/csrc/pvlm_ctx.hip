@@ -368,6 +368,19 @@ pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes) {
   return PVLM_OK;
 }
 
+pvlm_status pvlm_reserve_staging(pvlm_ctx* ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  if ((size_t)bytes <= ctx->up_bytes) return PVLM_OK;
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+  ctx->h_up = nullptr; ctx->up_bytes = 0;
+  if (hipHostMalloc(&ctx->h_up, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_reserve_staging: %lld bytes of pinned memory unavailable", (long long)bytes); return PVLM_ERR_NOMEM; }
+  ctx->up_bytes = (size_t)bytes;
+  std::memset(ctx->h_up, 0, (size_t)bytes);         // first touch here, not inside the first upload
+  return PVLM_OK;
+}
+
 pvlm_status pvlm_trim(pvlm_ctx* ctx) {
   if (!ctx) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;

@@ -24,6 +24,10 @@ Engine::Engine(int device) {
   // on this driver — paid here instead of inside the first association / solve of the process)
   if (const char* mb = std::getenv("PVLM_HOST_RESERVE_MB"))
     if (std::atof(mb) > 0) Check(pvlm_reserve(ctx_, (size_t)(std::atof(mb) * 1048576.0)), "pvlm_reserve");
+  // PVLM_HOST_RESERVE_STAGING_MB: likewise the pinned staging window of the scan uploads (hipHostMalloc + first touch of its 64 MB: 25 ms inside the first
+  // association of the process otherwise)
+  if (const char* mb = std::getenv("PVLM_HOST_RESERVE_STAGING_MB"))
+    if (std::atof(mb) > 0) Check(pvlm_reserve_staging(ctx_, (int64_t)(std::atof(mb) * 1048576.0)), "pvlm_reserve_staging");
 }
 Engine::~Engine() { if (ctx_) pvlm_destroy(ctx_); }
 Engine& Engine::Default() {
