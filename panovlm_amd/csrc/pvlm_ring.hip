@@ -730,6 +730,17 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   hipLaunchKernelGGL(k_seg_compact, dim3((unsigned)n_scans), dim3(1024), 0, S, B->d_scans, n_rings, horizon, B->segment, d_ring_count, B->d_cloud_scan, d_source, B->d_rc,
                      B->d_range_image, d_root, d_comp_size, d_row_mask, B->d_cloud2, d_source2, d_ring_col2, d_range2, B->d_image_to_point2, d_ring_count2, d_counts);
   hipLaunchKernelGGL(k_curvature, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, d_ring_count2, d_counts, B->d_cloud2, d_range2, d_curv, d_half, d_order);
+  // the five per-point arrays are final here: they go down the link on a second stream while K23 / K24 run (20 of the 27 B per point)
+  char* h = B->h_results;
+  hipStream_t S2 = S;
+  if (!ctx->aux_stream && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->aux_stream = nullptr; }
+  if (ctx->aux_stream && hipEventRecord(ev[8], S) == hipSuccess && hipStreamWaitEvent(ctx->aux_stream, ev[8], 0) == hipSuccess) S2 = ctx->aux_stream;
+  struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{S2};        // before the scratch goes back to the pool, on every exit path
+  PVLM_HIP(ctx, hipMemcpyAsync(h, d_source2, NP * 4, hipMemcpyDeviceToHost, S2));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 4, d_ring_col2, NP * 4, hipMemcpyDeviceToHost, S2));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 8, d_curv, NP * 4, hipMemcpyDeviceToHost, S2));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 12, d_half, NP * 4, hipMemcpyDeviceToHost, S2));
+  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16, d_range2, NP * 4, hipMemcpyDeviceToHost, S2));
   hipLaunchKernelGGL(k_sector_sort, dim3((unsigned)(n_rings * 6), (unsigned)n_scans), dim3(256), 0, S, B->d_scans, n_rings, d_ring_count2, d_counts, d_curv, stdsort_selfcheck() ? 1 : 0, d_order, d_sector, d_counter + 2, d_ties, (int)n_sectors);
   {
     const unsigned waves = 256u * 16u;                                     // persistent: every wave walks the list with a grid stride
@@ -748,14 +759,8 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   }
   (void)hipEventRecord(ev[7], S);
   // ---- results
-  char* h = B->h_results;
   B->h_source = (const int*)h; B->h_ring_col = (const int*)(h + NP * 4); B->h_curvature = (const float*)(h + NP * 8); B->h_half = (const int*)(h + NP * 12);
   B->h_range = (const float*)(h + NP * 16); B->h_order = (const int*)(h + NP * 20); B->h_sector_host = (const unsigned char*)(h + NP * 24);
-  PVLM_HIP(ctx, hipMemcpyAsync(h, d_source2, NP * 4, hipMemcpyDeviceToHost, S));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 4, d_ring_col2, NP * 4, hipMemcpyDeviceToHost, S));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 8, d_curv, NP * 4, hipMemcpyDeviceToHost, S));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 12, d_half, NP * 4, hipMemcpyDeviceToHost, S));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16, d_range2, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 20, d_order, NP * 4, hipMemcpyDeviceToHost, S));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 24, d_sector, n_sectors, hipMemcpyDeviceToHost, S));
   char* hp = h + NP * 24 + ((n_sectors + 63) / 64) * 64;       // K24's results behind the sector flags
@@ -778,6 +783,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     B->n_voxels = (int)std::min<size_t>((size_t)std::max(h_voxel_count, 0), voxel_cap);
     if (B->n_voxels > 0) PVLM_HIP(ctx, hipMemcpyAsync(const_cast<float*>(B->h_voxels), d_voxels, (size_t)B->n_voxels * 16, hipMemcpyDeviceToHost, S));
   }
+  PVLM_HIP(ctx, hipStreamSynchronize(S2));
   (void)hipEventRecord(ev[8], S);
   PVLM_HIP(ctx, hipStreamSynchronize(S));
   pvlm_i_trace("ring: segmentation, curvature, download");

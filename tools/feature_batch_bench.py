@@ -2,7 +2,7 @@
 (PVLM_FEATURE_PROFILE) and the A/B switches of the call —
     PVLM_FEATURE_PICKS=host   the picks and the voxel grid on the host threads (PickFeatures) instead of K24
     PVLM_FEATURE_PARTS=k      the batch cut into k device batches whose GPU stages overlap the host work of the previous one (default 2)
-usage: feature_batch_bench.py [scans = 454] [threads = 32] [--ab]     (--ab: runs the four combinations)
+usage: feature_batch_bench.py [scans = 454] [threads = 32] [--ab | --parts=2,3,4]     (--ab: runs the combinations)
 The boxes of this pool give a process 16 CPUs' worth of time per 100 ms (cgroup cpu.max) whatever nproc says: a 32-thread call of ~50 ms fits one period's
 budget, two calls back to back do not — the driver sleeps before each repetition, and thread_ms (CPU time actually spent) is the figure that transfers."""
 import os, sys
@@ -26,6 +26,9 @@ except Exception:
     pass
 os.environ["PVLM_FEATURE_PROFILE"] = "1"
 combos = [("device", "2")] if "--ab" not in sys.argv else [("host", "1"), ("host", "2"), ("device", "1"), ("device", "2"), ("device", "4")]
+for a in sys.argv[1:]:
+    if a.startswith("--parts="):                      # --parts=2,3,4: the picks on the device with these numbers of device batches per call
+        combos = [("device", k) for k in a[8:].split(",")]
 for picks, parts in combos:
     os.environ["PVLM_FEATURE_PICKS"] = picks; os.environ["PVLM_FEATURE_PARTS"] = parts
     print("== picks on the %s, %s device batch(es) per call, %d host threads" % (picks, parts, threads))
