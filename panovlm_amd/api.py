@@ -897,10 +897,15 @@ class UndistortScanDesc(C.Structure):
                 ("R_we", C.POINTER(C.c_double)), ("t_we", C.POINTER(C.c_double))]
 
 
-def undistort_batch(ctx, clouds, start_poses, end_poses):
+def undistort_batch(ctx, clouds, start_poses, end_poses, inplace=False):
     """pvlm_undistort_batch: clouds — list of n x 4 float32 arrays; start_poses / end_poses — lists of (R 3x3, t 3), world <- sensor.  Returns the
-    motion-compensated copies (Velodyne::UndistortCloud)."""
-    out = [np.ascontiguousarray(c, np.float32).reshape(-1, 4).copy() for c in clouds]
+    motion-compensated copies (Velodyne::UndistortCloud); inplace=True: the arrays themselves (C-contiguous float32 n x 4) are updated, as the C call does."""
+    if inplace:
+        out = list(clouds)
+        for c in out:
+            assert c.dtype == np.float32 and c.flags["C_CONTIGUOUS"] and c.ndim == 2 and c.shape[1] == 4
+    else:
+        out = [np.ascontiguousarray(c, np.float32).reshape(-1, 4).copy() for c in clouds]
     keep = []
     descs = (UndistortScanDesc * max(len(out), 1))()
     for k, c in enumerate(out):
