@@ -240,10 +240,17 @@ PVLM_HD void knn_rows(const CloudView& cv, float qx, float qy, float qz, float m
             x0 = (part ? cx + r : cx - r) * xf; x1 = x0 + xf - 1;
           }
           x0 = x0 > xa ? x0 : xa; x1 = x1 < xb ? x1 : xb;
+#ifdef PVLM_K2_SHELL_BUDGET   // statistics experiment (tools/assoc_lockstep.py): the budget of a shell fixed when the shell is entered
+          if (x0 <= x1) { PVLM_ASSOC_STATS_ROW(); PVLM_ASSOC_STATS_ITER(r, dz, dy, part); visit(z, y, x0, x1); }
+#else
           if (x0 <= x1) { PVLM_ASSOC_STATS_ROW(); PVLM_ASSOC_STATS_ITER(r, dz, dy, part); visit(z, y, x0, x1); budget = tk.kth_or_threshold() * 1.00001f; }
+#endif
         }
       }
     }
+#ifdef PVLM_K2_SHELL_BUDGET
+    budget = tk.kth_or_threshold() * 1.00001f;
+#endif
     // every unsearched point lies outside the (2r+1)^3 block: farther than (inside + r) cells
     const float bound = (inside + (float)r) * cv.h - slack;
     if (tk.full() && bound > 0.f && tk.kth_or_threshold() < bound * bound) break;
