@@ -287,6 +287,13 @@ void Velodyne::UndistortBatch(const std::vector<Velodyne*>& scans, const std::ve
   }
 }
 
+void Velodyne::Reset() {
+  cloud_scan.clear(); cornerLessSharp.clear(); cornerSharp.clear(); surfLessFlat.clear(); surfFlat.clear();
+  edge_segmented.clear(); point_to_segment.clear(); segment_coeffs.clear(); end_points.clear(); cornerBeforeFilter.clear();
+  layout_ = RingLayout();
+  InvalidateDevice();
+}
+
 bool Velodyne::UndistortCloud(const Matrix4d& T_we) {
   if (!IsPoseValid()) return false;
   if (cloud.empty()) LoadLidar(name);

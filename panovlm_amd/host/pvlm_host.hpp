@@ -144,6 +144,7 @@ class Velodyne {
   // sensors/Velodyne.cpp:1635-1674: motion compensation of the raw cloud — point i of n moves by i / n of the way from this scan's pose to T_we (the pose
   // at the sweep's end); the feature clouds are cleared as upstream clears them.  One scan: a batch of one; UndistortBatch: one device call for all.
   bool UndistortCloud(const Matrix4d& T_we);
+  void Reset();                                   // sensors/Velodyne.cpp:1676-1720: everything but the raw cloud, the pose and the flags
   static void UndistortBatch(const std::vector<Velodyne*>& scans, const std::vector<Matrix4d>& T_we);
   // ReOrderVLP (sensors/Velodyne.cpp:371-526): firing order -> ring order, range image, ring/column of every point.
   void ReOrderVLP();
@@ -456,6 +457,10 @@ class LidarOdometry {
   // lidar_mapping/LidarOdometry.cpp:189-263 without the PCD export: every scan with a usable pose is motion-compensated with the pose that ends its sweep
   // (the next usable scan's pose through SlerpPose; the last scan continues the motion of the one before), all scans in one device call
   bool UndistortLidars(const float gap_time);
+  // lidar_mapping/LidarOdometry.cpp:306-: upstream reloads the raw scans from their files before the motion compensation (EstimatePose moved the clouds to the
+  // world frame and back in float, and may have dropped them); the in-memory form of that reload: scan k gets clouds[k] again
+  void ReloadClouds(const std::vector<PointCloud>& clouds);
+  void ResetAllLidars();                          // lidar_mapping/LidarOdometry.cpp:295-304 (the reload of an empty cloud is LoadLidar's business)
   const std::vector<Velodyne>& GetLidarData() const { return lidars; }
   std::vector<Matrix3d> GetGlobalRotation() const;
   std::vector<Vector3d> GetGlobalTranslation() const;

@@ -188,6 +188,18 @@ Matrix4d SlerpPose(const Matrix4d& pose_w1, const Matrix4d& pose_w2, double rati
   return MatrixOf(Compose(w1, InverseOf(T_s1)));
 }
 
+void LidarOdometry::ReloadClouds(const std::vector<PointCloud>& clouds) {
+  if (clouds.size() != lidars.size()) throw std::invalid_argument("ReloadClouds: one cloud per scan");
+  for (size_t k = 0; k < lidars.size(); ++k) lidars[k].cloud = clouds[k];
+}
+
+void LidarOdometry::ResetAllLidars() {
+  for (Velodyne& lidar : lidars) {
+    lidar.Reset();
+    if (lidar.cloud.empty() && lidar.IsPoseValid()) lidar.LoadLidar(lidar.name);
+  }
+}
+
 bool LidarOdometry::UndistortLidars(const float gap_time) {
   StageTimer stage_timer_("motion compensation of the sweeps (UndistortLidars)");
   const double lidar_duration = 0.1;

@@ -107,9 +107,9 @@ static void PrintFrames(const std::vector<Frame>& frames) {
   }
 }
 
-static void PrintPoses(const std::vector<Velodyne>& l) {
+static void PrintPoses(const std::vector<Velodyne>& l, const char* tag = "pose") {
   for (const Velodyne& v : l) {
-    printf("pose %d", v.id);
+    printf("%s %d", tag, v.id);
     for (double x : v.GetRotation()) printf(" %.17g", x);
     for (double x : v.GetTranslation()) printf(" %.17g", x);
     printf("\n");
@@ -432,8 +432,25 @@ int main(int argc, char** argv) {
       cfg.line_to_line_residual = with_lines; cfg.point_to_plane_residual = true;
       cfg.lidar_plane_tolerance = atof(argv[6]); cfg.point_to_plane_dis_threshold = atof(argv[7]);
       if (argc > 12) cfg.point_to_line_dis_threshold = atof(argv[12]);
+      if (argc > 13) { cfg.max_curvature = (float)atof(argv[8]); cfg.intersection_angle_threshold = (float)atof(argv[9]); cfg.lidar_segmentation = atoi(argv[10]) != 0; }
       LidarOdometry odo(l, cfg);
       odo.EstimatePose(atoi(argv[3]));
+      if (argc > 13) {
+        // second pass as main.cpp:415-432 runs it: motion compensation with the poses of the first pass (gap_time = argv[13]), everything but clouds and
+        // poses reset, EstimatePose again — which extracts the features of the compensated clouds itself (GPU batch)
+        for (auto& it : odo.log) printf("pass1 cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
+        PrintPoses(odo.GetLidarData(), "pass1pose");
+        odo.log.clear(); odo.shard_log.clear();
+        { std::vector<PointCloud> raw_again; for (const Velodyne& v : l) raw_again.push_back(v.cloud); odo.ReloadClouds(raw_again); }   // lidar_odometry.LoadLidars(config.lidar_path)
+        odo.UndistortLidars((float)atof(argv[13]));
+        auto sum_of = [](const PointCloud& c) { unsigned long long h = 1469598103934665603ull; for (const PointXYZI& p : c) { const float v[3] = {p.x, p.y, p.z}; unsigned w[3]; std::memcpy(w, v, 12); for (unsigned x : w) { h ^= x; h *= 1099511628211ull; } } return h; };
+        for (const Velodyne& v : odo.GetLidarData()) printf("compensated %d cloud_sum %llu\n", v.id, sum_of(v.cloud));
+        odo.ResetAllLidars();
+        odo.EstimatePose(atoi(argv[3]));
+        for (const Velodyne& v : odo.GetLidarData())
+          printf("features2 %d valid %d flat %zu less_flat %zu corner %zu segments %zu\n", v.id, v.valid ? 1 : 0, v.surfFlat.size(), v.surfLessFlat.size(), v.cornerLessSharp.size(),
+                 v.edge_segmented.size());
+      }
       for (auto& it : odo.log) printf("iter cost %.17g steps %d blocks %d\n", it.cost, it.steps, it.residual_blocks);
       for (auto& sl : odo.shard_log) {   // sharded runs: the partition of this outer iteration and the work behind it
         printf("shard refs %zu %zu local_blocks %d queries_per_rank", sl.first, sl.last, sl.local_blocks);

@@ -553,6 +553,58 @@ def test_raw_scans_to_refined_poses(oracle, tmp):
 
 
 
+def _fnv(xyz):
+    """FNV-1a over the 32-bit words of an n x 3 float32 array, as the driver's `features2` lines print it."""
+    h = 1469598103934665603
+    for w in np.ascontiguousarray(xyz, np.float32).view(np.uint32).reshape(-1).tolist():
+        h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_two_passes_with_motion_compensation(oracle, tmp):
+    """main.cpp:415-432: EstimatePose, UndistortLidars with the poses it found, ResetAllLidars, EstimatePose again — through the host mirror (K25 for the
+    clouds, the GPU feature batch incl. K23 / K24 inside the second EstimatePose, GPU association + normal equations) against the same chain on the oracle,
+    started from the poses the mirror's first pass printed: compensated clouds -> feature counts, residual-block counts, costs, poses."""
+    scans = []
+    for k in range(4):
+        R, t = sy.estimated_pose(k)
+        scans.append(dict(id=k, R_wl=R, t_wl=t, raw=sy.raw_vlp16_scan(k, clutter=30)))
+    path = os.path.join(tmp, "raw2.bin")
+    host_io.write_raw_scans(path, scans)
+    gap = 0.05
+    out = host_io.run("rawodometry", path, 2, 1, 1, 0.05, 1.0, 1000.0, 5.0, 1, 0, 0.3, gap)
+    pose1 = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pass1pose")}
+    feats2 = [l.split() for l in out if l.startswith("features2")]
+    comp = {int(l.split()[1]): int(l.split()[3]) for l in out if l.startswith("compensated")}
+    iters = [l.split() for l in out if l.startswith("iter")]
+    poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose ")}
+    assert len(pose1) == 4 and len(feats2) == 4 and len([l for l in out if l.startswith("pass1 ")]) == 2
+    first = [(pose1[k][:9].reshape(3, 3), pose1[k][9:]) for k in range(4)]
+    twin = []
+    moved = 0
+    for k, s in enumerate(scans):
+        end = oracle.sweep_end_pose(first, [1] * 4, [1] * 4, k, gap)
+        raw = s["raw"]
+        if end is not None:
+            done, raw = oracle.undistort_cloud(raw, *first[k], *end)
+            assert done
+            moved += int(not np.array_equal(raw, s["raw"]))
+        f = oracle.ScanFeatures(raw)
+        assert (int(feats2[k][5]), int(feats2[k][7])) == (len(f.surfFlat), len(f.surfLessFlat)), k
+        assert comp[k] == _fnv(raw[:, :3]), ("compensated cloud", k)
+        twin.append(dict(id=k, R_wl=first[k][0], t_wl=first[k][1], flat_local=f.surfFlat[:, :3], flat_tag=f.surfFlat[:, 3],
+                         less_local=f.surfLessFlat[:, :3], less_tag=f.surfLessFlat[:, 3]))
+    assert moved == 4
+    log = lm_twin.estimate_pose(oracle, twin, dict(angle=True, normalize=True, tol=0.05, thr=1.0), 2)
+    assert len(iters) == len(log)
+    for it, lg in zip(iters, log):
+        assert int(it[6]) == lg["blocks"] and lg["blocks"] > 500
+        assert abs(float(it[2]) - lg["final_cost"]) <= 1e-6 * lg["final_cost"]
+    for k, s in enumerate(twin):
+        R = poses[k][:9].reshape(3, 3); t = poses[k][9:]
+        assert np.abs(R - s["R_wl"]).max() <= 1e-6 and np.abs(t - s["t_wl"]).max() <= 1e-6 * max(1.0, np.abs(s["t_wl"]).max())
+
+
 def _parse_odometry(out):
     iters = [l.split() for l in out if l.startswith("iter")]
     poses = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:]]) for l in out if l.startswith("pose")}

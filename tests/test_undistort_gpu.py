@@ -90,5 +90,7 @@ def test_undistort_lidars_matches_oracle(oracle, tmp_path):
                 continue
             done, want = oracle.undistort_cloud(s["raw"], *poses[k], *end)
             assert done and _close(got, want), k
+            differ = int(np.sum(np.any(got.view(np.uint32) != want.view(np.uint32), axis=1)))
+            print("scan %d: %d of %d points differ from the oracle in some bit" % (k, differ, m))
             moved += 1
         assert at == len(blob) and moved == n_scans - 2
