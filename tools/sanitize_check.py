@@ -119,6 +119,21 @@ def bodies():
                     except AssertionError:
                         ok = False; print("ring bodies differ from the oracle:", name, threads, seg)
         print("range-image device bodies under the sanitizers equal to the oracle: %s" % ok)
+        # the std::sort restatement (csrc/pvlm_stdsort.h, serial and level-by-level forms) on tie-heavy, structured and depth-limit-forcing keys
+        so = os.path.join(d, "libstdsort_check_asan.so")
+        subprocess.check_call(["g++"] + SAN + ["-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests/cpp/stdsort_check.cpp")], env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
+        lib = C.CDLL(so)
+        ok = True
+        for trial in range(400):
+            n = int(rng.integers(0, 3000))
+            key = (rng.integers(0, max(2, n // int(rng.integers(1, 30)) + 1), n) if trial % 3 else np.arange(n) % 7).astype(np.float32)
+            ok = ok and lib.chk_sort_by_float(fp(key), n, None) == 0 and lib.chk_sort_by_levels(fp(key), n) == 0
+        killer = np.zeros(4000, np.int32)
+        lib.chk_killer_keys(4000, killer.ctypes.data_as(C.POINTER(C.c_int)))
+        for coarse in (1, 3):
+            key = (killer // coarse).astype(np.float32)
+            ok = ok and lib.chk_sort_by_float(fp(key), len(key), None) == 0 and lib.chk_sort_by_levels(fp(key), len(key)) == 0
+        print("std::sort restatement under the sanitizers equal to std::sort: %s" % ok)
     return 0
 
 
