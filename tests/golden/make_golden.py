@@ -243,13 +243,37 @@ def line_extraction():
                         p2s_ids=np.array([v for l in f.point_to_segment for v in l], np.int32))
 
 
+def undistort():
+    """Velodyne::UndistortCloud (sensors/Velodyne.cpp:1642-1674) of three small sweeps — a small motion, a vanishing one (slerp's linear branch) and a large one —
+    and SlerpPose (base/Geometry.hpp:572-583) at ratios inside and outside [0, 1]."""
+    rng = np.random.default_rng(77)
+    d = {}
+    for k, (angle, n) in enumerate(((0.03, 700), (1e-12, 64), (2.5, 300))):
+        cloud = np.concatenate([rng.normal(0, 7, (n, 3)), rng.integers(0, 16, (n, 1))], axis=1).astype(np.float32)
+        R_wl = synth.rodrigues(rng.normal(0, 1.0, 3)); t_wl = rng.normal(0, 5, 3)
+        R_we = R_wl @ synth.rodrigues(rng.normal(0, angle, 3)); t_we = t_wl + R_wl @ rng.normal(0, 0.2, 3)
+        done, out = orc.undistort_cloud(cloud, R_wl, t_wl, R_we, t_we)
+        assert done
+        d.update({"cloud%d" % k: cloud, "R_wl%d" % k: R_wl, "t_wl%d" % k: t_wl, "R_we%d" % k: R_we, "t_we%d" % k: t_we, "out%d" % k: out})
+    T1 = np.eye(4); T2 = np.eye(4)
+    T1[:3, :3] = synth.rodrigues(rng.normal(0, 0.8, 3)); T1[:3, 3] = rng.normal(0, 3, 3)
+    T2[:3, :3] = synth.rodrigues(rng.normal(0, 0.8, 3)); T2[:3, 3] = rng.normal(0, 3, 3)
+    ratios = np.array([0.0, 0.25, 0.6666666666666666, 1.0, 2.0, -0.5])
+    poses = np.zeros((len(ratios), 4, 4))
+    for i, r in enumerate(ratios):
+        R, t = orc.slerp_pose(T1[:3, :3], T1[:3, 3], T2[:3, :3], T2[:3, 3], float(r))
+        poses[i] = np.eye(4); poses[i, :3, :3] = R; poses[i, :3, 3] = t
+    d.update(cases=np.array(3), pose_w1=T1, pose_w2=T2, ratios=ratios, slerp=poses)
+    np.savez_compressed(os.path.join(OUT, "undistort.npz"), **d)
+
+
 if __name__ == "__main__":
     orc.build()
     if len(sys.argv) > 1:          # regenerate only the named fixtures: python tests/golden/make_golden.py line_extraction
         for name in sys.argv[1:]:
             globals()[name]()
         sys.exit(0)
-    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs(); mvs_cloud(); features(); line_extraction()
+    fast_atan2(); functors(); assoc(); equirect(); lines(); neighbors(); reproj(); depth(); mvs(); mvs_cloud(); features(); line_extraction(); undistort()
     tot = 0
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

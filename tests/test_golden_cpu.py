@@ -127,6 +127,17 @@ def test_depth_golden(oracle):
         assert np.array_equal(img, g["depth_size%d" % size]) and (img > 0).mean() > 0.02
 
 
+def test_undistort_golden(oracle):
+    """Velodyne::UndistortCloud and SlerpPose (oracle/undistort.hpp) against tests/golden/undistort.npz."""
+    g = load("undistort.npz")
+    for k in range(int(g["cases"])):
+        done, out = oracle.undistort_cloud(g["cloud%d" % k], g["R_wl%d" % k], g["t_wl%d" % k], g["R_we%d" % k], g["t_we%d" % k])
+        assert done and np.array_equal(out.view(np.uint32), g["out%d" % k].view(np.uint32)), k
+    for r, want in zip(g["ratios"], g["slerp"]):
+        R, t = oracle.slerp_pose(g["pose_w1"][:3, :3], g["pose_w1"][:3, 3], g["pose_w2"][:3, :3], g["pose_w2"][:3, 3], float(r))
+        assert np.array_equal(R, want[:3, :3]) and np.array_equal(t, want[:3, 3])
+
+
 def test_mvs_golden(oracle):
     g = load("mvs.npz")
     neis = [g["nei%d_gray" % k] for k in range(3)]; nd = [g["nei%d_depth" % k] for k in range(3)]

@@ -93,6 +93,19 @@ def test_depth_golden(ctx):
         assert np.array_equal(ctx.project_lidar_depth(int(g["rows"]), int(g["cols"]), g["xyz"], g["T_cl"], size), g["depth_size%d" % size])
 
 
+def test_undistort_golden(ctx):
+    """K25 (pvlm_undistort_batch) against tests/golden/undistort.npz: floating point through double sines, tolerance 1e-6 relative."""
+    from panovlm_amd import api
+    g = load("undistort.npz")
+    n = int(g["cases"])
+    got = api.undistort_batch(ctx, [g["cloud%d" % k] for k in range(n)], [(g["R_wl%d" % k], g["t_wl%d" % k]) for k in range(n)],
+                              [(g["R_we%d" % k], g["t_we%d" % k]) for k in range(n)])
+    for k in range(n):
+        want = g["out%d" % k]
+        scale = np.maximum(np.abs(want[:, :3]).max(axis=1, keepdims=True), 1.0)
+        assert np.all(np.abs(got[k][:, :3] - want[:, :3]) <= 1e-6 * scale) and np.array_equal(got[k][:, 3], want[:, 3]), k
+
+
 def test_mvs_golden(ctx):
     g = load("mvs.npz")
     neis = [g["nei%d_gray" % k] for k in range(3)]; nd = [g["nei%d_depth" % k] for k in range(3)]

@@ -466,6 +466,40 @@ void DumpLineExtraction(const std::string& dir) {
 
 }  // namespace
 
+// ---- Velodyne::UndistortCloud (sensors/Velodyne.cpp:1642-1674), SlerpPose (base/Geometry.hpp:572-583) --------------------------
+void DumpUndistort(const std::string& dir) {
+  const Bundle in = ReadBundle(dir + "/undistort.in.pvv");
+  if (in.empty()) return;
+  Bundle out;
+  const int cases = (int)in.at("cases").as_double(0);
+  auto mat3 = [&](const std::string& k) { Eigen::Matrix3d m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m(i, j) = in.at(k).f64()[3 * i + j]; return m; };
+  auto vec3 = [&](const std::string& k) { return Eigen::Vector3d(in.at(k).f64()[0], in.at(k).f64()[1], in.at(k).f64()[2]); };
+  for (int c = 0; c < cases; ++c) {
+    const std::string id = std::to_string(c);
+    const Array& raw = in.at("cloud" + id);
+    Velodyne v(16, 0, 1800);
+    for (size_t i = 0; i < raw.dims[0]; ++i) {
+      pcl::PointXYZI p; p.x = raw.f32()[4 * i]; p.y = raw.f32()[4 * i + 1]; p.z = raw.f32()[4 * i + 2]; p.intensity = raw.f32()[4 * i + 3];
+      v.cloud.push_back(p);
+    }
+    v.SetRotation(mat3("R_wl" + id)); v.SetTranslation(vec3("t_wl" + id));
+    v.UndistortCloud(mat3("R_we" + id), vec3("t_we" + id));
+    std::vector<float> o;
+    for (const auto& p : v.cloud.points) { o.push_back(p.x); o.push_back(p.y); o.push_back(p.z); o.push_back(p.intensity); }
+    out["out" + id] = MakeArray(0, {v.cloud.size(), 4}, o);
+  }
+  Eigen::Matrix4d T1, T2;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { T1(i, j) = in.at("pose_w1").f64()[4 * i + j]; T2(i, j) = in.at("pose_w2").f64()[4 * i + j]; }
+  const Array& ratios = in.at("ratios");
+  std::vector<double> poses;
+  for (size_t r = 0; r < ratios.dims[0]; ++r) {
+    const Eigen::Matrix4d T = SlerpPose<double>(T1, T2, ratios.f64()[r]);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) poses.push_back(T(i, j));
+  }
+  out["slerp"] = MakeArray(1, {ratios.dims[0], 4, 4}, poses);
+  WriteBundle(dir + "/undistort.ref.pvv", out);
+}
+
 int main(int argc, char** argv) {
   if (argc != 2) { std::fprintf(stderr, "usage: %s DIR   (DIR holds the *.in.pvv files of `python tools/refvec.py export DIR`)\n", argv[0]); return 2; }
   google::InitGoogleLogging(argv[0]);
@@ -480,5 +514,6 @@ int main(int argc, char** argv) {
   DumpDepth(dir);
   DumpFeatures(dir);
   DumpLineExtraction(dir);
+  DumpUndistort(dir);
   return 0;
 }

@@ -76,6 +76,8 @@ def _is_output(fixture, key):
         return key.startswith("depth_size")
     if fixture in ("features", "line_extraction"):
         return key not in ("raw", "horizon")
+    if fixture == "undistort":
+        return key.startswith("out") or key == "slerp"
     raise KeyError(fixture)
 
 
@@ -90,7 +92,7 @@ def is_internal(fixture, key):
     return key.endswith(INTERNAL) and fixture != "line_extraction"
 
 
-FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth", "features", "line_extraction")   # mvs.npz: the
+FIXTURES = ("functors", "assoc_point2plane", "equirect", "lines", "neighbors", "fast_atan2", "reproj", "depth", "features", "line_extraction", "undistort")   # mvs.npz: the
 # reference entry point (MVS::InitConfMap) is a private member driven by the whole MVS object — not exported here
 
 
@@ -142,6 +144,13 @@ def compare(out_dir):
             if exp.shape != got.shape:
                 print("%-20s %-18s SHAPE %s vs reference %s" % (fx, k, exp.shape, got.shape)); bad += 1
                 continue
+            if fx == "undistort" and exp.dtype == np.float32:
+                # double sines of two libms and, for a real build, Eigen's own quaternion kernels: north_star's floating-point tolerance, not bit equality
+                scale = np.maximum(np.abs(exp[:, :3]).max(axis=1, keepdims=True), 1.0)
+                ok = bool(np.all(np.abs(exp[:, :3] - got[:, :3]) <= 1e-6 * scale) and np.array_equal(exp[:, 3], got[:, 3]))
+                print("%-20s %-18s 1e-6 %s (%d of %d points bit-identical)" % (fx, k, "ok" if ok else "MISMATCH", int(np.sum(np.all(exp.view(np.uint32) == got.astype(np.float32).view(np.uint32), axis=1))), len(exp)))
+                bad += 0 if ok else 1
+                continue
             if exp.dtype.kind in "iu" and exp.dtype.itemsize == 2:      # .pvv has no 16-bit type: images travel as int32
                 ok = np.array_equal(exp.astype(np.int32), got.astype(np.int32)); how = "bit-exact"
             elif exp.dtype.kind in "iu" or exp.dtype == np.float32:
@@ -167,6 +176,8 @@ PINS = {
     "fast_atan2": ("A7", "FastAtan2<float>, FastAtan2<double> (base/Math.h:15-29) — ALREADY pinned in the development image (oracle/_ref)", "bit-exact"),
     "depth": ("N4 (depth prior)", "ProjectLidar2PanoramaDepth (util/Visualization.h:407-441)", "uint16 image bit-exact"),
     "features": ("N3", "Velodyne::ReOrderVLP + ExtractFeatures, ADAPTIVE (sensors/Velodyne.cpp:371-1189)", "clouds, picks bit-exact"),
+    "undistort": ("N5 (motion compensation; outside §8)", "Velodyne::UndistortCloud (sensors/Velodyne.cpp:1642-1674), SlerpPose (base/Geometry.hpp:572-583) — Eigen's Quaternion(Matrix3), "
+                  "slerp, q * v, Matrix4d::inverse", "points and poses 1e-6 relative (bit-identical count printed)"),
     "line_extraction": ("N3 (EdgeToLine, FuseLines)", "Velodyne::EdgeToLine / LidarLineExtraction (sensors/LidarLineExtraction.cpp:113-389)",
                         "segment membership exact; FuseLines coefficients RANSAC-tolerant (1 deg, 2 cm): PCL's seeded RANSAC vs the oracle's exhaustive 2-point consensus"),
 }
