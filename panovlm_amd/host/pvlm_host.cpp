@@ -242,6 +242,7 @@ void Velodyne::UploadBatch(const std::vector<const Velodyne*>& scans) {
   if (st.size() < todo.size()) st.resize(todo.size());
   std::vector<pvlm_scan_desc> descs(todo.size());
   {   // the flattening is per scan and independent: scan-parallel, like FindNeighbors
+    StageTimer stage_timer_fill_("  (inside the scan upload) host SoA staging of the scans (Fill)");
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), todo.size() / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     std::atomic<size_t> next{0};
     auto work = [&]() { for (size_t k = next++; k < todo.size(); k = next++) { st[k].Fill(*todo[k], todo[k]->R_wl_, todo[k]->t_wl_); descs[k] = st[k].d; } };
