@@ -261,7 +261,12 @@ __device__ inline int partition_wave(T* a, int first, int last, Less less, unsig
 // std::sort(a, a + n, less) by one wave: ranges longer than kWide are partitioned by the whole wave one after the other, the shorter ones side by side
 // on the lanes (sort_by_levels' loop), the final insertion pass runs leaf by leaf on the lanes.  n < 8192; all 64 lanes call with the same arguments.
 //   queue: 2 x kWaveQueue + kWideStack words;  cuts: (n + 31) / 32 + 1 words;  ctr: 4 ints;  pos: 2 x n unsigned shorts
-constexpr int kWide = 192, kWideStack = 64;
+// measured on the ring batch of 454 scans (K23 ties + K24, ms): kWide 192 / 128 / 96 / 64 / 48 / 32 / 24 / 16 -> 4.64 / 4.20 / 4.08 / 3.87 / 3.71 / 3.61 / 3.68 / 3.75 —
+// a partition by the whole wave costs a few LDS round trips whatever the range's length, one by a single lane a round trip per element
+#ifndef PVLM_STDSORT_WIDE
+#define PVLM_STDSORT_WIDE 32
+#endif
+constexpr int kWide = PVLM_STDSORT_WIDE, kWideStack = 64;
 template <class T, class Less>
 __device__ inline bool sort_wave(T* a, int n, Less less, unsigned* queue, unsigned* cuts, int* ctr, unsigned short* pos, int lane) {
   int lg = 0;
