@@ -51,10 +51,11 @@ NeighbourTable BuildNeighbourTable(const float* xyz, int stride, int n) {
   return t;
 }
 
-inline double Gap(const double* a, const double* b) {
+inline double Gap2(const double* a, const double* b) {        // the argument of Gap's square root
   const double x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
-  return std::sqrt(x * x + (y * y + z * z));
+  return x * x + (y * y + z * z);
 }
+inline double Gap(const double* a, const double* b) { return std::sqrt(Gap2(a, b)); }
 inline double PointToLine(const double* p, const double* l) {        // base/Geometry.hpp:198-211
   const double k = (l[3] * (p[0] - l[0]) + l[4] * (p[1] - l[1]) + l[5] * (p[2] - l[2])) / (l[3] * l[3] + l[4] * l[4] + l[5] * l[5]);
   const double q[3] = {k * l[3] + l[0], k * l[4] + l[1], k * l[5] + l[2]};
@@ -68,12 +69,17 @@ inline double DirectionAngle(const double* a, const double* b) {      // PlaneAn
 inline bool AllZero(const Vector6d& l) { for (double v : l) if (v != 0.0) return false; return true; }
 
 // the two points of `ids` (in the given order) that are farthest apart; first pair among equals (FurthestPoints, Eigen flavour)
+// (upstream compares the distances, g > length: the square root is monotone, so a pair whose SQUARED distance does not exceed the one behind the current
+// maximum cannot exceed it either — the root is only taken for the others, and the comparison of the roots still decides)
 void Extremes(const std::vector<double>& P, const std::vector<int>& ids, int* a, int* b, double* length) {
   *a = *b = -1; *length = -1;
+  double longest2 = -1;                                       // squared distance of the pair that holds *length
   for (size_t i = 0; i + 1 < ids.size(); ++i)
     for (size_t j = i + 1; j < ids.size(); ++j) {
-      const double g = Gap(&P[3 * (size_t)ids[i]], &P[3 * (size_t)ids[j]]);
-      if (g > *length) { *a = (int)i; *b = (int)j; *length = g; }
+      const double g2 = Gap2(&P[3 * (size_t)ids[i]], &P[3 * (size_t)ids[j]]);
+      if (!(g2 > longest2) && g2 == g2) continue;
+      const double g = std::sqrt(g2);
+      if (g > *length) { *a = (int)i; *b = (int)j; *length = g; longest2 = g2; }
     }
 }
 // FurthestPoints on a cloud (float squared distances, one square root): base/Geometry.hpp:619-645
@@ -94,6 +100,7 @@ struct Grower {
   std::vector<int> stamp;            // stamp[id] == epoch  <=>  id is a member of the segment being grown
   int epoch = 0;
   std::vector<double> buf;
+  std::vector<int> order_buf;        // Expand's working list (1 400 calls per scan: no allocation each)
 
   Grower(const std::vector<double>& p, const NeighbourTable& t) : P(p), nn(t), stamp(p.size() / 3, 0) {}
 
@@ -108,7 +115,8 @@ struct Grower {
   // ExpandLine: tries the (up to four) nearest neighbours of edge point `start`; members: ascending ids, updated in place
   bool Expand(int start, std::vector<int>& members) {
     bool grown = false;
-    std::vector<int> order = members;                     // the order the scatter sums see: members ascending, then accepted points as they come
+    std::vector<int>& order = order_buf;                  // the order the scatter sums see: members ascending, then accepted points as they come
+    order.assign(members.begin(), members.end());
     int a, b; double length;
     Extremes(P, order, &a, &b, &length);
     // upstream fits the current members first (tolerance 3) and uses that line only in the long-line branch below; the fit is made when that
@@ -120,8 +128,9 @@ struct Grower {
       if (stamp[(size_t)cand] == epoch) continue;
       if (nn.sqd[(size_t)start * nn.k + j] > (length / 2) * (length / 2)) break;
       order.push_back(cand);
-      double reach = -1;
-      for (int id : order) reach = std::max(reach, Gap(&P[3 * (size_t)id], &P[3 * (size_t)cand]));
+      double reach2 = -1;                                  // max of the distances = root of the max of the squares (monotone, correctly rounded)
+      for (int id : order) reach2 = std::max(reach2, Gap2(&P[3 * (size_t)id], &P[3 * (size_t)cand]));
+      double reach = reach2 < 0 ? -1 : std::sqrt(reach2);
       reach = std::max(reach, length);
       Vector6d next;
       if (reach < 2) {
