@@ -36,17 +36,21 @@ NeighbourTable BuildNeighbourTable(const float* xyz, int stride, int n) {
   NeighbourTable t;
   t.k = std::min(5, n);
   t.idx.resize((size_t)n * t.k); t.sqd.resize((size_t)n * t.k);
-  std::vector<std::pair<float, int>> d((size_t)n);
+  // the k smallest (d2, index) pairs in ascending order, kept in a k-entry list while the points stream by in index order (what a partial sort of all n
+  // pairs returns: equal distances by index, and a later index never displaces an equal earlier one)
   for (int q = 0; q < n; ++q) {
     const float qx = xyz[(size_t)q * stride], qy = xyz[(size_t)q * stride + 1], qz = xyz[(size_t)q * stride + 2];
+    float bd[5]; int bi[5]; int have = 0;
     for (int i = 0; i < n; ++i) {
       const float dx = qx - xyz[(size_t)i * stride], dy = qy - xyz[(size_t)i * stride + 1], dz = qz - xyz[(size_t)i * stride + 2];
       float s = 0.0f;
       s += dx * dx; s += dy * dy; s += dz * dz;                       // flann::L2_Simple order
-      d[(size_t)i] = {s, i};
+      if (have == t.k && !(s < bd[have - 1])) continue;
+      int at = have < t.k ? have++ : have - 1;
+      while (at > 0 && s < bd[at - 1]) { bd[at] = bd[at - 1]; bi[at] = bi[at - 1]; --at; }
+      bd[at] = s; bi[at] = i;
     }
-    std::partial_sort(d.begin(), d.begin() + t.k, d.end());
-    for (int j = 0; j < t.k; ++j) { t.idx[(size_t)q * t.k + j] = d[(size_t)j].second; t.sqd[(size_t)q * t.k + j] = d[(size_t)j].first; }
+    for (int j = 0; j < t.k; ++j) { t.idx[(size_t)q * t.k + j] = bi[j]; t.sqd[(size_t)q * t.k + j] = bd[j]; }
   }
   return t;
 }
@@ -158,7 +162,9 @@ std::vector<int> Consensus(const PointCloud& c, double threshold) {
   std::vector<double> q((size_t)n * 3);
   for (int i = 0; i < n; ++i) { q[3 * (size_t)i] = c[(size_t)i].x; q[3 * (size_t)i + 1] = c[(size_t)i].y; q[3 * (size_t)i + 2] = c[(size_t)i].z; }
   const double t2 = threshold * threshold;
-  auto count = [&](int i, int j, std::vector<int>* out) {
+  // inliers of the line through points i and j; `beat`: the count to exceed — the walk stops (returning 0) as soon as the points left cannot lift the count
+  // above it: only a count that exceeds the best so far is ever used
+  auto count = [&](int i, int j, std::vector<int>* out, int beat) {
     const double* o = &q[3 * (size_t)i];
     const double d[3] = {q[3 * (size_t)j] - o[0], q[3 * (size_t)j + 1] - o[1], q[3 * (size_t)j + 2] - o[2]};
     const double len2 = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
@@ -166,6 +172,7 @@ std::vector<int> Consensus(const PointCloud& c, double threshold) {
     const double bound = t2 * len2;
     int m = 0;
     for (int k = 0; k < n; ++k) {
+      if (m + (n - k) <= beat) return 0;
       const double x = q[3 * (size_t)k] - o[0], y = q[3 * (size_t)k + 1] - o[1], z = q[3 * (size_t)k + 2] - o[2];
       const double cx = y * d[2] - z * d[1], cy = z * d[0] - x * d[2], cz = x * d[1] - y * d[0];
       if ((cx * cx + cy * cy) + cz * cz < bound) { ++m; if (out) out->push_back(k); }
@@ -175,11 +182,11 @@ std::vector<int> Consensus(const PointCloud& c, double threshold) {
   int best = 0, bi = -1, bj = -1;
   for (int i = 0; i + 1 < n; ++i)
     for (int j = i + 1; j < n; ++j) {
-      const int m = count(i, j, nullptr);
+      const int m = count(i, j, nullptr, best);
       if (m > best) { best = m; bi = i; bj = j; }
     }
   std::vector<int> in;
-  if (bi >= 0) count(bi, bj, &in);
+  if (bi >= 0) count(bi, bj, &in, -1);
   return in;
 }
 
