@@ -552,7 +552,7 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     const Part& part = parts[j / per_batch];
     if (part.on_host) {
       v.ReOrderVLP();
-      v.ExtractFeatures(max_curvature, intersect_angle_threshold, method, segment, nullptr, edge_to_line);
+      v.ExtractFeatures(max_curvature, intersect_angle_threshold, method, segment, traces ? &(*traces)[todo[j]] : nullptr, edge_to_line);
       return;
     }
     ProfileSpan span(0);

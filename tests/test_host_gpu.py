@@ -553,6 +553,20 @@ def test_raw_scans_to_refined_poses(oracle, tmp):
 
 
 
+def test_feature_batch_takes_the_host_path_for_a_scan_the_device_refuses(oracle):
+    """A scan with a non-finite coordinate: the device batch refuses it (upstream gives such a point ring -1 and skips it), ExtractFeaturesBatch runs the per-scan
+    host path for that part of the call, and the result is the oracle's — clouds, per-point arrays and line segments."""
+    raw = sy.raw_vlp16_scan(3, clutter=20).copy()
+    raw[1234, 1] = np.nan; raw[20000, 0] = np.inf
+    o = oracle.ScanFeatures(raw, edge_to_line=True)
+    g = host_io.extract_features(raw, edge_to_line=True, on_gpu=True)
+    assert o.valid and g["valid"]
+    for name in ("cloud_scan", "cornerSharp", "cornerLessSharp", "surfFlat", "surfLessFlat", "rc", "scan_start", "scan_end", "curvature", "state", "sort_ind", "left", "right"):
+        a, b = getattr(o, name), g[name]
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), name
+    assert len(o.edge_segmented) == len(g["edge_segmented"]) and all(np.array_equal(a, b) for a, b in zip(o.edge_segmented, g["edge_segmented"]))
+
+
 def _fnv(xyz):
     """FNV-1a over the 32-bit words of an n x 3 float32 array, as the driver's `features2` lines print it."""
     h = 1469598103934665603
