@@ -475,7 +475,7 @@ void Velodyne::AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, 
   }
 }
 
-// ---- the batch form: range-image stages on the GPU, picks on the host ---------------------------------------------------------
+// ---- the batch form: range-image stages, sector orders, picks and voxel grid on the GPU; EdgeToLine on the host ---------------------------------------------------------
 void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float max_curvature, float intersect_angle_threshold, int method, bool segment, bool edge_to_line,
                                     int num_threads, std::vector<ExtractionTrace>* traces) {
   if (method != ADAPTIVE) throw std::invalid_argument("ExtractFeatures: only the ADAPTIVE method (config/Room.txt:32) is mirrored");

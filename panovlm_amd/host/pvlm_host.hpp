@@ -164,9 +164,11 @@ class Velodyne {
   // (pcl::SACSegmentation, :150-160) is replaced by the exhaustive 2-point maximum-consensus line (host/pvlm_lines.cpp).
   void EdgeToLine();
   // ReOrderVLP + ExtractFeatures for MANY scans: the per-point / per-ring stages (ring and column of every return, range image,
-  // Segmentation, adaptive-window curvature — sensors/Velodyne.cpp:371-526, :1438-1586, :623-657) run on the GPU for the whole
-  // batch (pvlm_ring_extract_batch, one launch per stage), the sort-dependent picks (ExtractEdgeFeatures2 / EdgeToLine /
-  // ExtractPlaneFeatures2 with pcl::VoxelGrid) on `num_threads` host threads from the arrays the device returns.  Every scan ends
+  // Segmentation, adaptive-window curvature — sensors/Velodyne.cpp:371-526, :1438-1586, :623-657), the sector orders, the picks of
+  // ExtractEdgeFeatures2 / ExtractPlaneFeatures2 and the pcl::VoxelGrid of the less-flat points (:883-1000, :1098-1189) run on the GPU
+  // (pvlm_ring_extract_batch_picks; a call's scans go as a few device batches that overlap the host work of the previous one), EdgeToLine
+  // and the assembly of the clouds on `num_threads` host threads.  A scan with a ring the device left undecided, and every scan of a
+  // batch the device refused (non-finite coordinate, capacity), takes the host's own picks / extraction.  Every scan ends
   // up exactly as ReOrderVLP() + ExtractFeatures(...) leave it (tests/test_host_gpu.py), except that Layout().range_image and
   // .image_to_point_idx are only filled when traces are asked for (nothing downstream reads them).  Scans that ReOrderVLP /
   // ExtractFeatures would leave alone (invalid, already re-ordered, no points) are skipped; all scans of a call share N_SCANS and

@@ -103,12 +103,12 @@ bool LidarOdometry::EstimatePose(const int max_iteration) {
   // Scans that arrive with their feature clouds (or without raw points) are left alone; upstream's ReOrderVLP /
   // ExtractFeatures return early for those as well (sensors/Velodyne.cpp:376-377, :542-543).
   {
-    StageTimer stage_timer_features_("feature extraction (range-image stages on the GPU, picks on the host)");
+    StageTimer stage_timer_features_("feature extraction (range image, picks and voxel grid on the GPU, EdgeToLine on the host)");
     // invalid scans first, on the calling thread: SetRotation / SetTranslation give the scan's device copy back to the engine's
     // context (InvalidateDevice -> pvlm_scan_destroy), whose pool is not thread-safe — never from the workers below
     for (Velodyne& l : lidars)
       if (!l.valid || !l.IsPoseValid()) { l.SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); l.SetTranslation({INFINITY, INFINITY, INFINITY}); }
-    // the scans that still need their features: range-image stages of all of them in one GPU batch, picks on config.num_threads
+    // the scans that still need their features: range-image stages, picks and voxel grid of all of them in GPU batches, EdgeToLine on config.num_threads
     // host threads (Velodyne::ExtractFeaturesBatch).  PVLM_HOST_FEATURES=1: everything on the host, scan by scan, as upstream does.
     std::vector<Velodyne*> need;
     for (Velodyne& l : lidars) {

@@ -90,7 +90,7 @@ def write_structure(path, frames, tracks):
 
 def extract_features(raw, n_scans=16, horizon=1800, max_curvature=1000.0, angle_threshold=5.0, segment=True, extract=True, edge_to_line=False, on_gpu=False):
     """Velodyne::ReOrderVLP (+ ExtractFeatures, optionally with EdgeToLine) of the host mirror on one raw scan (n x 4 float32)
-    through the test driver.  on_gpu: Velodyne::ExtractFeaturesBatch instead (range-image stages on the GPU, picks on the host).
+    through the test driver.  on_gpu: Velodyne::ExtractFeaturesBatch instead (range-image stages, picks and voxel grid on the GPU; PVLM_FEATURE_PICKS=host: picks on the host).
     Returns a dict with the same fields as oracle.ScanFeatures."""
     import tempfile
     with tempfile.TemporaryDirectory() as d:
