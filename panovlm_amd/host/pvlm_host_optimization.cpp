@@ -78,16 +78,30 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
   StageTimer stage_timer_("line-to-line association + blocks");
   const size_t i_lo = ref_range ? ref_range->first : 0, i_hi = ref_range ? std::min(ref_range->second, lidars.size()) : lidars.size();
   ceres_like::LossFunction* loss = new ceres_like::HuberLoss(angle_residual ? 2 * M_PI / 180.0 : 0.2);
-  // only looked up, never iterated (upstream: std::map, :369-377): key = lidar id << 32 | line id
-  std::unordered_map<unsigned long long, std::vector<uint32_t>> lines_to_track;
-  auto line_key = [](uint32_t lidar, uint32_t line) { return ((unsigned long long)lidar << 32) | line; };
+  // lines_to_track (upstream: std::map keyed by (lidar, line), :369-377) is only looked up, never iterated: here a table with one row per segment —
+  // scan s owns the rows seg_base[s] .. seg_base[s + 1] — listing the tracks the segment belongs to.  "Some track of the reference segment holds the
+  // neighbour's segment" (:387-395, LineTrack::IsInside: a std::set walk per candidate) is then "the two rows share a track id".
+  std::vector<size_t> seg_base(lidars.size() + 1, 0);
+  for (size_t q = 0; q < lidars.size(); ++q) seg_base[q + 1] = seg_base[q] + lidars[q].edge_segmented.size();
+  std::vector<uint32_t> row_start(seg_base.back() + 2, 0), row_tracks;
+  auto row_of = [&](uint32_t lidar, uint32_t line) -> long long {
+    if ((size_t)lidar >= lidars.size() || (size_t)line >= lidars[lidar].edge_segmented.size()) return -1;
+    return (long long)(seg_base[lidar] + line);
+  };
   {
     StageTimer stage_timer_l2t_("  (inside) line-to-line: lines_to_track map (host)");
-    size_t n_keys = 0;
-    for (const LineTrack& t : tracks) n_keys += t.feature_pairs.size();
-    lines_to_track.reserve(n_keys);
-    for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) lines_to_track[line_key(pr.first, pr.second)].push_back(t.id);
+    for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) { const long long r = row_of(pr.first, pr.second); if (r >= 0) ++row_start[(size_t)r + 2]; }
+    for (size_t r = 2; r < row_start.size(); ++r) row_start[r] += row_start[r - 1];            // row_start[r + 1] = first entry of row r, advanced while filling
+    row_tracks.resize(row_start.back());
+    for (const LineTrack& t : tracks) for (const auto& pr : t.feature_pairs) { const long long r = row_of(pr.first, pr.second); if (r >= 0) row_tracks[row_start[(size_t)r + 1]++] = t.id; }
   }
+  auto share_a_track = [&](long long a, long long b) {
+    if (a < 0 || b < 0) return false;
+    for (uint32_t x = row_start[(size_t)a]; x < row_start[(size_t)a + 1]; ++x)
+      for (uint32_t y = row_start[(size_t)b]; y < row_start[(size_t)b + 1]; ++y)
+        if (row_tracks[x] == row_tracks[y]) return true;
+    return false;
+  };
   size_t num = 0;
   // all AssociateLine2Line(lidars[i], lidars[n_idx], thr) calls of the loop below (:379) in one GPU launch
   std::vector<std::pair<const Velodyne*, const Velodyne*>> todo;
@@ -128,11 +142,7 @@ size_t AddLidarLineToLineResidual2(const std::vector<std::vector<int>>& neighbor
       for (size_t p = cursor++; p < pairs_todo.size(); p = cursor++) {
         const size_t i = pairs_todo[p].i; const int n_idx = pairs_todo[p].n_idx;
         for (const Line2Line& a : all_ass[next + p]) {
-          auto it = lines_to_track.find(line_key((uint32_t)i, (uint32_t)a.ref_line_idx));
-          if (it == lines_to_track.end()) continue;
-          bool valid = false;
-          for (uint32_t tid : it->second) if (tracks[tid].IsInside({(uint32_t)n_idx, (uint32_t)a.neighbor_line_idx})) { valid = true; break; }
-          if (!valid) continue;
+          if (!share_a_track(row_of((uint32_t)i, (uint32_t)a.ref_line_idx), row_of((uint32_t)n_idx, (uint32_t)a.neighbor_line_idx))) continue;
           const size_t pts = lidars[n_idx].edge_segmented[a.neighbor_line_idx].size();
           if (pts == 0) continue;
           kept[p].push_back({a.neighbor_line_idx, a.ref_line_idx});
