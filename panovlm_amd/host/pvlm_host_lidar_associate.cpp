@@ -131,7 +131,7 @@ std::vector<Line2Line> FindAssociations(const Velodyne& ref, const Velodyne& nei
 // per row of the vote block: the arg-max loop of :126-130, taken on the host by FindAssociationsOn or on the device by pvlm_line2line_best_batch)
 static std::vector<Line2Line> FindAssociationsBest(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
                                                    const std::vector<Vector6d>& nei_world, const int* best_col, const int* best_count) {
-  std::map<int, Line2Line> m;
+  std::vector<Line2Line> m;                      // one entry per reference segment, ordered by it at the end (upstream: a std::map keyed by the segment)
   const int nr = (int)ref.edge_segmented.size(), nn = (int)nei.edge_segmented.size();
   for (int s = 0; s < nn && nr > 0; ++s) {
     const int max_col = best_col[s], max_count = best_count[s];
@@ -141,17 +141,16 @@ static std::vector<Line2Line> FindAssociationsBest(const Velodyne& ref, const Ve
     Line2Line a;
     a.neighbor_line_idx = s; a.ref_line_idx = max_col;
     for (int c = 0; c < 3; ++c) { a.line_point1[c] = 0.1 * loc[3 + c] + loc[c]; a.line_point2[c] = -0.1 * loc[3 + c] + loc[c]; }
-    auto it = m.find(max_col);
-    if (it == m.end()) m.insert({max_col, a});
+    auto it = std::find_if(m.begin(), m.end(), [max_col](const Line2Line& x) { return x.ref_line_idx == max_col; });
+    if (it == m.end()) m.push_back(a);
     else {
-      const double d1 = PointToLineDistance3D(nei_world[it->second.neighbor_line_idx].data(), ref_world[max_col].data());
+      const double d1 = PointToLineDistance3D(nei_world[it->neighbor_line_idx].data(), ref_world[max_col].data());
       const double d2 = PointToLineDistance3D(nei_world[s].data(), ref_world[max_col].data());
-      if (d2 < d1) it->second = a;
+      if (d2 < d1) *it = a;
     }
   }
-  std::vector<Line2Line> out;
-  for (auto& kv : m) out.push_back(kv.second);
-  return out;
+  std::sort(m.begin(), m.end(), [](const Line2Line& x, const Line2Line& y) { return x.ref_line_idx < y.ref_line_idx; });   // keys are unique
+  return m;
 }
 static std::vector<Line2Line> FindAssociationsOn(const Velodyne& ref, const Velodyne& nei, const std::vector<Vector6d>& ref_world,
                                                  const std::vector<Vector6d>& nei_world, const int* line_matrix) {
@@ -401,11 +400,12 @@ std::vector<std::vector<Line2Line>> AssociateLine2LineBatch(const std::vector<st
   }
   // the pairs are independent (read-only scans and row tables, one output slot each): pair-parallel
   std::atomic<size_t> next{0};
-  auto work = [&]() {
-    for (size_t j = next++; j < which.size(); j = next++) {
-      const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
-      out[which[j]] = FindAssociationsBest(ref, nei, world[(size_t)slots[j].first], world[(size_t)slots[j].second], best_col.data() + roff[j], best_count.data() + roff[j]);
-    }
+  auto work = [&]() {                                   // 64 consecutive pairs per turn: the output slots of neighbouring pairs share cache lines
+    for (size_t j0 = next.fetch_add(64); j0 < which.size(); j0 = next.fetch_add(64))
+      for (size_t j = j0; j < std::min(j0 + 64, which.size()); ++j) {
+        const Velodyne& ref = *pairs[which[j]].first; const Velodyne& nei = *pairs[which[j]].second;
+        out[which[j]] = FindAssociationsBest(ref, nei, world[(size_t)slots[j].first], world[(size_t)slots[j].second], best_col.data() + roff[j], best_count.data() + roff[j]);
+      }
   };
   pvlm_run_workers(n_threads, work);
   return out;
