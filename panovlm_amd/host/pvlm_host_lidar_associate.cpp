@@ -38,35 +38,42 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
     if (lidars[i].IsPoseValid()) {
       const Vector3d& t = lidars[i].GetTranslation();
       const float q[3] = {float(t[0]), float(t[1]), float(t[2])};
-      std::vector<std::pair<float, int>> d(nc);
+      // (squared distance, position) pairs sorted as one 64-bit word each: the distances are sums of squares (never negative, a NaN centre is no valid
+      // pose), so their bit patterns order like the floats, and equal distances fall back to the position as the pair comparison did
+      std::vector<uint64_t> keys((size_t)nc);
       for (int j = 0; j < nc; ++j) {
         const float dx = q[0] - center[j][0], dy = q[1] - center[j][1], dz = q[2] - center[j][2];
         float s = 0.0f; s += dx * dx; s += dy * dy; s += dz * dz;
-        d[j] = {s, j};
+        uint32_t bits; std::memcpy(&bits, &s, 4);
+        keys[(size_t)j] = ((uint64_t)bits << 32) | (uint32_t)j;
       }
       // one sorted list serves both searches below: nearestKSearch (its first neighbor_size entries) and radiusSearch (its
       // prefix within 20 m, also ascending) — ties in pcl's order = position
-      std::sort(d.begin(), d.end());
+      std::sort(keys.begin(), keys.end());
+      std::vector<std::pair<float, int>> d((size_t)nc);
+      for (int j = 0; j < nc; ++j) { const uint32_t bits = (uint32_t)(keys[(size_t)j] >> 32); float s; std::memcpy(&s, &bits, 4); d[(size_t)j] = {s, (int)(uint32_t)keys[(size_t)j]}; }
       for (int j = 0; j < std::min(neighbor_size, nc); ++j) neighbors.push_back(d[j].second);
       if (!neighbors.empty()) neighbors.erase(neighbors.begin());  // the first one is the scan itself
       for (int& n : neighbors) n = owner[n];
-      std::set<int> nset(neighbors.begin(), neighbors.end());
+      // upstream's std::set of the chosen scans, as a sorted vector: "at least two members within loop_length of the candidate" looks at the members in
+      // [candidate - loop_length, candidate + loop_length], which are consecutive (the set was walked from its start for each of the ~1 600 candidates)
+      std::vector<int> nset(neighbors.begin(), neighbors.end());
+      std::sort(nset.begin(), nset.end());
+      nset.erase(std::unique(nset.begin(), nset.end()), nset.end());
+      auto has = [&nset](int v) { return std::binary_search(nset.begin(), nset.end(), v); };
       int ni = (int)i - 1;
       while (ni >= 0 && !lidars[ni].IsPoseValid()) ni--;
-      if (ni >= 0 && nset.count(ni) == 0) neighbors.push_back(ni);
+      if (ni >= 0 && !has(ni)) neighbors.push_back(ni);
       ni = (int)i + 1;
       while (ni < (int)lidars.size() && !lidars[ni].IsPoseValid()) ni++;
-      if (ni < (int)lidars.size() && nset.count(ni) == 0) neighbors.push_back(ni);
+      if (ni < (int)lidars.size() && !has(ni)) neighbors.push_back(ni);
       const float r2 = float(20.0 * 20.0);  // radiusSearch(20 m): FLANN keeps dist < r^2
       const int loop_length = 200;
       for (int j = 0; j < nc && d[j].first < r2; ++j) {
         const int n_idx = owner[d[j].second];
         int same_loop = 0;
-        for (int v : nset) {
-          if (std::abs(n_idx - v) <= loop_length) same_loop++;
-          if (same_loop >= 2) break;
-        }
-        if (same_loop < 2 && nset.count(n_idx) == 0) { neighbors.push_back(n_idx); nset.insert(n_idx); }
+        for (auto it = std::lower_bound(nset.begin(), nset.end(), n_idx - loop_length); it != nset.end() && *it <= n_idx + loop_length && same_loop < 2; ++it) same_loop++;
+        if (same_loop < 2 && !has(n_idx)) { neighbors.push_back(n_idx); nset.insert(std::upper_bound(nset.begin(), nset.end(), n_idx), n_idx); }
       }
     } else {
       for (int j = -neighbor_size / 2; j <= neighbor_size / 2; j++) neighbors.push_back((int)i - j);

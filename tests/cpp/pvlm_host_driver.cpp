@@ -124,6 +124,14 @@ int main(int argc, char** argv) {
       auto l = LoadScans(argv[2]);
       auto nb = FindNeighbors(l, atoi(argv[3]));
       for (size_t i = 0; i < nb.size(); ++i) { printf("nb %zu", i); for (int v : nb[i]) printf(" %d", v); printf("\n"); }
+    } else if (cmd == "neighborsbench") {
+      // neighborsbench <scans.bin> neighbor_size reps : milliseconds per FindNeighbors call (host only)
+      auto l = LoadScans(argv[2]);
+      const int reps = atoi(argv[4]);
+      size_t total = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int r = 0; r < reps; ++r) { auto nb = FindNeighbors(l, atoi(argv[3])); for (auto& v : nb) total += v.size(); }
+      printf("neighborsbench scans %zu ms_per_call %.3f entries %zu\n", l.size(), 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps, total / reps);
     } else if (cmd == "p2plane") {
       auto l = LoadScans(argv[2]);
       auto a = AssociatePoint2Plane(l[atoi(argv[3])], l[atoi(argv[4])], atof(argv[5]), (float)atof(argv[6]));
