@@ -315,6 +315,37 @@ pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* desc, pvlm_sca
 pvlm_status pvlm_scan_upload_batch(pvlm_ctx* ctx, int n_scans, const pvlm_scan_desc* descs, pvlm_scan** out);
 pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* scan);
 
+/* Velodyne::Transform2LidarWorld / Velodyne::Transform2Local (sensors/Velodyne.cpp:1773-1808, :1810-1848) on the RESIDENT clouds of n_scans
+ * scans, as LidarOdometry::RefinePose calls them around every solve (lidar_mapping/LidarOdometry.cpp:17-21, :100-110): scan k's float clouds
+ * (surfFlat, surfLessFlat, cornerLessSharp and the segments' points) are replaced IN PLACE by T_k applied the way
+ * pcl::transformPointCloud(cloud, cloud, Eigen::Matrix4d) applies it — per coordinate float(((m0 x + m1 y) + m2 z) + m3), the float point promoted
+ * to double — so the device's clouds equal the host's after any number of World <-> Local round trips, bit for bit, and nothing is uploaded again.
+ * T_rowmajor12: n_scans x 12 doubles, the upper 3 x 4 of T_k row-major ([R | t]; T_wl = [R_wl | t_wl] for Transform2LidarWorld,
+ * [R_wl^T | -R_wl^T t_wl] for Transform2Local).  rebuild_grids != 0: the voxel grids of the transformed clouds are rebuilt — bounding boxes
+ * reduced on the device, the same plan and tables an upload of the same floats gets; rebuild_grids == 0 leaves them stale (a scan on its way
+ * to the local frame is not searched): pvlm_knn / pvlm_assoc_point2plane on such a scan return PVLM_ERR_STATE until a call with
+ * rebuild_grids != 0.  The pose of a scan (R_wl, t_wl of its descriptor) is NOT touched: pvlm_scan_set_pose.  A scan may be listed once.
+ * On an error after the launch (a coordinate left the float range: PVLM_ERR_ARG) the clouds stay transformed and the grids stale: destroy
+ * the scans. */
+pvlm_status pvlm_scan_transform_batch(pvlm_ctx* ctx, int n_scans, pvlm_scan* const* scans, const double* T_rowmajor12, int rebuild_grids);
+/* Velodyne::SetRotation / SetTranslation (sensors/Velodyne.h:213-233) for a resident scan: replaces the pose the association and the line
+ * kernels read (R_wl 9 row-major, t_wl 3).  Host-side state only; the clouds are not moved. */
+pvlm_status pvlm_scan_set_pose(pvlm_ctx* ctx, pvlm_scan* scan, const double* R_wl, const double* t_wl);
+/* Tests / visualisation: the resident arrays of one cloud of a scan.  which: 0 surfFlat, 1 surfLessFlat, 2 cornerLessSharp, 3 the segments'
+ * points.  pvlm_scan_cloud_info: the cloud's size and (clouds 1, 2) the parameters of its voxel grid; pvlm_scan_cloud_fetch: xyz (n x 3), and of
+ * the grid cell_count / cell_start (table_size ints each), keys (table_size 64-bit words; hashed tables only) and the cell-sorted points
+ * (n x 4 floats: x, y, z, original index as int bits; the order INSIDE a cell is not deterministic).  NULL = skip. */
+typedef struct pvlm_grid_info {
+  int n;                       /* points                                                                   */
+  int has_grid, stale;         /* clouds 1, 2 with n > 0; stale: transformed without rebuild              */
+  int dense, nx, ny, nz, xf;   /* dense table: (iz ny + iy) nx + ix, cells xf times finer along x          */
+  int table_size;              /* dense: cells + 1; hashed: slots (power of two)                           */
+  float cell, origin[3];
+} pvlm_grid_info;
+pvlm_status pvlm_scan_cloud_info(const pvlm_scan* scan, int which, pvlm_grid_info* info);
+pvlm_status pvlm_scan_cloud_fetch(pvlm_ctx* ctx, const pvlm_scan* scan, int which, float* xyz, int* cell_count, int* cell_start,
+                                  unsigned long long* keys, float* sorted_xyzi);
+
 /* Exact k-nearest-neighbour search of `queries` (nq x 3 float, world frame) in the scan's
  * surfLessFlat cloud (which=0) or cornerLessSharp cloud (which=1): what
  * pcl::KdTreeFLANN<PointXYZI>::nearestKSearch returns at LidarFeatureAssociate.cpp:575 / :496 —

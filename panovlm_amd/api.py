@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -880,6 +880,48 @@ class Scan:
             out.append(o)
         return out
 
+    @staticmethod
+    def transform_batch(ctx, scans, T, rebuild_grids=True):
+        """pvlm_scan_transform_batch: scan k's resident float clouds are replaced by T[k] (3x4 or 4x4, [R | t]) applied as
+        pcl::transformPointCloud applies an Eigen::Matrix4d; rebuild_grids: the voxel grids follow."""
+        n = len(scans)
+        T12 = np.ascontiguousarray(np.stack([np.asarray(t, np.float64)[:3, :4] for t in T]).reshape(n, 12)) if n else np.zeros((0, 12))
+        handles = (C.c_void_p * max(n, 1))(*[s._h for s in scans])
+        ctx._check(ctx.lib.pvlm_scan_transform_batch(ctx._h, n, handles, _p(T12, C.c_double), 1 if rebuild_grids else 0), "pvlm_scan_transform_batch")
+
+    def set_pose(self, R_wl, t_wl):
+        R = _f64(R_wl).reshape(9); t = _f64(t_wl).reshape(3)
+        self.ctx._check(self.ctx.lib.pvlm_scan_set_pose(self.ctx._h, self._h, _p(R, C.c_double), _p(t, C.c_double)), "pvlm_scan_set_pose")
+
+    def cloud_info(self, which):
+        info = GridInfo()
+        self.ctx._check(self.ctx.lib.pvlm_scan_cloud_info(self._h, int(which), C.byref(info)), "pvlm_scan_cloud_info")
+        return info
+
+    def fetch_cloud(self, which, grid=False):
+        """The resident floats of cloud `which` (0 surfFlat, 1 surfLessFlat, 2 cornerLessSharp, 3 segment points) and, with grid=True, a
+        CANONICAL form of its voxel grid: the plan and the cell-sorted records ordered by (cell — dense: cell index, hashed: 64-bit key —, original
+        index): cell_key, index, points — independent of the slot / in-cell order the atomics of a build produce."""
+        info = self.cloud_info(which)
+        xyz = np.zeros((info.n, 3), np.float32)
+        if not grid or not info.has_grid:
+            self.ctx._check(self.ctx.lib.pvlm_scan_cloud_fetch(self.ctx._h, self._h, int(which), _p(xyz, C.c_float), None, None, None, None), "pvlm_scan_cloud_fetch")
+            return xyz if not grid else (xyz, None)
+        T = info.table_size
+        count = np.zeros(T, np.int32); start = np.zeros(T, np.int32); keys = np.zeros(T, np.uint64); srt = np.zeros((info.n, 4), np.float32)
+        self.ctx._check(self.ctx.lib.pvlm_scan_cloud_fetch(self.ctx._h, self._h, int(which), _p(xyz, C.c_float), _p(count, C.c_int), _p(start, C.c_int),
+                                                           _p(keys, C.c_uint64) if not info.dense else None, _p(srt, C.c_float)), "pvlm_scan_cloud_fetch")
+        plan = dict(n=info.n, dense=info.dense, nx=info.nx, ny=info.ny, nz=info.nz, xf=info.xf, table_size=T, cell=np.float32(info.cell).tobytes(),
+                    origin=np.asarray(list(info.origin), np.float32).tobytes(), stale=info.stale)
+        # per sorted position the key of its cell: the occupied slots in order of their start cover [0, n) without gaps
+        slots = np.nonzero(count)[0]
+        slots = slots[np.argsort(start[slots], kind="stable")]
+        assert int(count[slots].sum()) == info.n and np.array_equal(start[slots], np.concatenate([[0], np.cumsum(count[slots])[:-1]]))
+        cell_key = np.repeat(slots.astype(np.uint64) if info.dense else keys[slots], count[slots])
+        idx = srt[:, 3].view(np.int32)
+        order = np.lexsort((idx, cell_key))
+        return xyz, dict(plan=plan, cell_key=cell_key[order], index=idx[order].copy(), points=srt[order, :3].copy())
+
     def close(self):
         if self._h:
             self.ctx.lib.pvlm_scan_destroy(self.ctx._h, self._h)
@@ -890,6 +932,11 @@ class Scan:
             self.close()
         except Exception:
             pass
+
+
+class GridInfo(C.Structure):
+    _fields_ = [("n", C.c_int), ("has_grid", C.c_int), ("stale", C.c_int), ("dense", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("xf", C.c_int), ("table_size", C.c_int), ("cell", C.c_float), ("origin", C.c_float * 3)]
 
 
 class UndistortScanDesc(C.Structure):

@@ -173,6 +173,54 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const GridDesc* __restrict
   if (d.pt4) d.pt4[i] = make_float4(x, y, z, d.tag[i]);
 }
 
+// ---- K26: re-posing the resident float clouds (Velodyne::Transform2LidarWorld / Transform2Local, sensors/Velodyne.cpp:1773-1848) ------------------
+// pcl::transformPointCloud(cloud, cloud, Matrix4d) per point: every coordinate is float(((m0 x + m1 y) + m2 z) + m3) with the float point promoted to
+// double — the statement the host mirror (host/pvlm_host.cpp: TransformCloud) and the oracle use, unfused (-ffp-contract=off), so that the device's
+// clouds stay equal to the host's bit for bit through any number of World <-> Local round trips.  In place.  Clouds that carry a voxel grid also
+// reduce their bounding box (what cloud_box() computes on the host for an upload) and the first non-finite point: floats as order-preserving
+// 32-bit words, one atomic per wave and coordinate.
+struct XformCloud { float* xyz; int n; int scan; int box; int pad; };   // box: index of the cloud's 7-word box record, -1 = no grid
+struct XformBlock { int cloud, first; };                                // 256 points of one cloud
+__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static inline float ord2f(unsigned o) { const unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; std::memcpy(&f, &u, 4); return f; }
+__global__ __launch_bounds__(256) void k_scan_transform(const XformCloud* __restrict__ clouds, const XformBlock* __restrict__ blocks, const double* __restrict__ T12,
+                                                        unsigned* __restrict__ boxes) {
+  const XformBlock b = blocks[blockIdx.x];
+  const XformCloud c = clouds[b.cloud];
+  const double* m = T12 + 12 * (size_t)c.scan;
+  const int i = b.first + (int)threadIdx.x;
+  unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  int bad = 0x7FFFFFFF;
+  if (i < c.n) {
+    float* p = c.xyz + 3 * (size_t)i;
+    const double x = (double)p[0], y = (double)p[1], z = (double)p[2];
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = (float)(((m[4 * k] * x + m[4 * k + 1] * y) + m[4 * k + 2] * z) + m[4 * k + 3]);
+    p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+    if (c.box >= 0) {
+      if (!(isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]))) bad = i;
+      else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lo[k] = hi[k] = f2ord(o[k]);
+      }
+    }
+  }
+  if (c.box < 0) return;                       // uniform per workgroup
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], (unsigned)__shfl_xor((int)lo[k], off, 64)); hi[k] = max(hi[k], (unsigned)__shfl_xor((int)hi[k], off, 64)); }
+    bad = min(bad, __shfl_xor(bad, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned* bx = boxes + 7 * (size_t)c.box;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { if (lo[k] != 0xFFFFFFFFu) atomicMin(bx + k, lo[k]); if (hi[k] != 0u) atomicMax(bx + 3 + k, hi[k]); }
+    if (bad != 0x7FFFFFFF) atomicMin((int*)(bx + 6), bad);
+  }
+}
+
 // ---- K2 / K3: per-query bodies in pvlm_assoc_core.h (TopK, knn_search, Fit10, world2local) --------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_queries(CloudView cv, const float* __restrict__ q, int nq, float max_dist,
@@ -412,7 +460,7 @@ struct CloudPlan {
   float h = 0.f, origin[3] = {0, 0, 0};
   int dense = 0, nx = 0, ny = 0, nz = 0, xf = 1;
   long long T = 0;
-  // byte offsets: persistent slab (o_*) and build scratch (s_*)
+  // byte offsets: the points slab (o_xyz, o_tag), the grid slab (o_count .. o_pt4) and the build scratch (s_*)
   size_t o_xyz = 0, o_tag = 0, o_count = 0, o_keys = 0, o_start = 0, o_sorted = 0, o_pt4 = 0, s_cursor = 0, s_slot = 0;
 };
 
@@ -509,6 +557,113 @@ static pvlm_status assoc_ws_ensure(pvlm_ctx* ctx, long long rows, int chunks, in
   if (st) { pvlm_i_assoc_ws_free(ctx); return st; }
   w.rows = rows; w.chunks = chunks; w.pairs = pairs; w.desc_bytes = (size_t)pairs * sizeof(PairDesc);
   return PVLM_OK;
+}
+
+// ---- K1, host side: the voxel grids of a list of device-resident clouds — ONE slab, one table copy, three memsets, three launches (+ the long
+// tables), one synchronisation.  Shared by the upload (clouds just copied up) and by the re-pose (pvlm_scan_transform_batch: clouds transformed
+// in place, bounding boxes reduced on the device).  Grid slab: [descriptors | point blocks | short-table list | cell counts (zeroed) | hash keys
+// (0xFF) | cell starts, sorted points, pt4];  scratch: [cursors (zeroed) | cell / slot of every point].  The plans' o_count .. o_pt4 are offsets into
+// the slab returned in *out_slab (null when no cloud has a grid).
+struct GridJob { CloudPlan* plan; const float* d_xyz; const float* d_tag; };
+static pvlm_status grids_build(pvlm_ctx* ctx, const std::vector<GridJob>& jobs, char** out_slab) {
+  *out_slab = nullptr;
+  const int n_grids = (int)jobs.size();
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  auto place = [&](size_t& off, size_t& cursor, size_t bytes) { off = cursor; cursor = align(cursor + bytes); };
+  if (n_grids == 0) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: device error"); return PVLM_ERR_HIP; }
+    return PVLM_OK;
+  }
+  size_t n_blocks = 0, n_small = 0;
+  for (const GridJob& j : jobs) { n_blocks += ((size_t)j.plan->n + 255) / 256; n_small += j.plan->T <= GRID_SCAN_MAX; }
+  size_t slab = 0, scratch = 0, o_desc = 0, o_blocks = 0, o_small = 0;
+  place(o_desc, slab, (size_t)n_grids * sizeof(GridDesc));
+  place(o_blocks, slab, std::max<size_t>(n_blocks, 1) * sizeof(GridBlock));
+  place(o_small, slab, std::max<size_t>(n_small, 1) * sizeof(int));
+  const size_t tables_bytes = slab, o_count0 = slab;
+  for (const GridJob& j : jobs) place(j.plan->o_count, slab, (size_t)j.plan->T * 4);
+  const size_t count_bytes = slab - o_count0, o_keys0 = slab;
+  for (const GridJob& j : jobs) if (!j.plan->dense) place(j.plan->o_keys, slab, (size_t)j.plan->T * 8);
+  const size_t keys_bytes = slab - o_keys0;
+  for (const GridJob& j : jobs) {
+    CloudPlan& c = *j.plan;
+    place(c.o_start, slab, (size_t)c.T * 4);
+    place(c.o_sorted, slab, ((size_t)c.n + 1) * 16);          // + 1: the search may read (never use) one record past a run
+    if (j.d_tag) place(c.o_pt4, slab, (size_t)c.n * 16);
+  }
+  for (const GridJob& j : jobs) place(j.plan->s_cursor, scratch, (size_t)j.plan->T * 4);
+  const size_t cursor_bytes = scratch;
+  for (const GridJob& j : jobs) place(j.plan->s_slot, scratch, (size_t)j.plan->n * 4);
+  // pinned mirror of the tables (grow-only; idle here: every build ends with a synchronisation)
+  if (ctx->grid_bytes < tables_bytes) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build: device error"); return PVLM_ERR_HIP; }
+    if (ctx->h_grid) (void)hipHostFree(ctx->h_grid);
+    ctx->h_grid = nullptr; ctx->grid_bytes = 0;
+    const size_t want = tables_bytes + tables_bytes / 2;
+    if (hipHostMalloc(&ctx->h_grid, want, hipHostMallocDefault) != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build: %zu bytes of pinned staging unavailable", want); return PVLM_ERR_NOMEM; }
+    ctx->grid_bytes = want;
+  }
+  char* d_slab = nullptr; char* d_scr = nullptr;
+  pvlm_status st = pvlm_i_alloc_bytes(ctx, (void**)&d_slab, std::max<size_t>(slab, 256));
+  if (st) { (void)hipStreamSynchronize(ctx->stream); return st; }
+  if ((st = pvlm_i_alloc_bytes(ctx, (void**)&d_scr, std::max<size_t>(scratch, 256)))) { (void)hipStreamSynchronize(ctx->stream); pvlm_i_free(ctx, d_slab); return st; }
+  auto bail = [&](pvlm_status e) { (void)hipStreamSynchronize(ctx->stream); pvlm_i_free(ctx, d_slab); pvlm_i_free(ctx, d_scr); return e; };
+  char* h = (char*)ctx->h_grid;
+  GridDesc* hd = (GridDesc*)(h + o_desc); GridBlock* hb = (GridBlock*)(h + o_blocks); int* hs = (int*)(h + o_small);
+  std::vector<int> big;                                         // tables too long for one workgroup: scanned by launch_scan
+  size_t nb = 0; int ns = 0;
+  for (int g = 0; g < n_grids; ++g) {
+    const CloudPlan& c = *jobs[(size_t)g].plan;
+    GridDesc& D = hd[g];
+    D.xyz = jobs[(size_t)g].d_xyz; D.n = c.n; D.dense = c.dense; D.nx = c.nx; D.ny = c.ny; D.nz = c.nz; D.T = (int)c.T;
+    D.ox = c.origin[0]; D.oy = c.origin[1]; D.oz = c.origin[2]; D.inv_h = 1.0f / c.h; D.inv_hx = D.inv_h * (float)c.xf;
+    D.keys = c.dense ? nullptr : (unsigned long long*)(d_slab + c.o_keys);
+    D.count = (int*)(d_slab + c.o_count); D.start = (int*)(d_slab + c.o_start); D.sorted = (float4*)(d_slab + c.o_sorted);
+    D.cursor = (int*)(d_scr + c.s_cursor); D.slot = (int*)(d_scr + c.s_slot);
+    D.tag = jobs[(size_t)g].d_tag; D.pt4 = D.tag ? (float4*)(d_slab + c.o_pt4) : nullptr;
+    for (int f = 0; f < c.n; f += 256) hb[nb++] = GridBlock{g, f};
+    if (c.T <= GRID_SCAN_MAX) hs[ns++] = g; else big.push_back(g);
+  }
+  hipError_t e = hipMemcpyAsync(d_slab, h, tables_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && count_bytes) e = hipMemsetAsync(d_slab + o_count0, 0, count_bytes, ctx->stream);
+  if (e == hipSuccess && keys_bytes) e = hipMemsetAsync(d_slab + o_keys0, 0xFF, keys_bytes, ctx->stream);
+  if (e == hipSuccess && cursor_bytes) e = hipMemsetAsync(d_scr, 0, cursor_bytes, ctx->stream);
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build: copy / memset failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
+  DevScratch tiles_scratch(ctx);
+  if (nb) {
+    const GridDesc* dd = (const GridDesc*)(d_slab + o_desc); const GridBlock* db = (const GridBlock*)(d_slab + o_blocks);
+    hipLaunchKernelGGL(k_grid_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dd, db);
+    if (ns) hipLaunchKernelGGL(k_grid_scan, dim3((unsigned)ns), dim3(1024), 0, ctx->stream, dd, (const int*)(d_slab + o_small));
+    for (int g : big) {
+      const CloudPlan& c = *jobs[(size_t)g].plan;
+      int* d_tiles = nullptr;
+      if ((st = tiles_scratch.alloc(&d_tiles, (size_t)((c.T + SCAN_TILE - 1) / SCAN_TILE) + 1))) return bail(st);
+      launch_scan(ctx, (int)c.T, (const int*)(d_slab + c.o_count), (int*)(d_slab + c.o_start), d_tiles);
+    }
+    hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dd, db);
+    e = hipGetLastError();
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
+  }
+  pvlm_i_trace("grids_build: tables + kernels queued");
+  // the staging buffers are reused by the next call and the scratch goes back to the pool: wait once for the whole batch
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build: device error"); return bail(PVLM_ERR_HIP); }
+  pvlm_i_free(ctx, d_scr);
+  pvlm_i_trace("grids_build: synchronised");
+  *out_slab = d_slab;
+  return PVLM_OK;
+}
+// points a cloud's grid members into the grid slab its plan was laid out in
+static void grid_bind(pvlm_cloud& c, const CloudPlan& p, char* d_grid, bool has_tag) {
+  c.cell = p.h; for (int q = 0; q < 3; ++q) c.origin[q] = p.origin[q];
+  c.table_size = (int)p.T; c.dense = p.dense; c.nx = p.nx; c.ny = p.ny; c.nz = p.nz; c.xf = p.xf;
+  c.d_keys = p.dense ? nullptr : (unsigned long long*)(d_grid + p.o_keys);
+  c.d_cell_start = (int*)(d_grid + p.o_start); c.d_cell_count = (int*)(d_grid + p.o_count); c.d_sorted = (float4*)(d_grid + p.o_sorted);
+  c.d_pt4 = has_tag ? (float4*)(d_grid + p.o_pt4) : nullptr;
+  c.grid_stale = false;
+}
+static void slab_unref(pvlm_ctx* ctx, pvlm_scan_slab*& sl) {
+  if (sl && --sl->refs == 0) { pvlm_i_free(ctx, sl->base); delete sl; }
+  sl = nullptr;
 }
 
 extern "C" {
@@ -611,44 +766,27 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   }
   if (st) return fail(st);
   pvlm_i_trace("scan_upload_batch: plan (bbox, host tables)");
-  // ---- 2. layout.  Persistent slab: [uploaded arrays | build tables (descriptors, blocks) | cell counts (zeroed) |
-  //         hash keys (0xFF) | cell starts | sorted points];  scratch: [cursors (zeroed) | cell / slot of every point]
+  // ---- 2. layout.  Points slab (lives as long as the scans; pvlm_scan_transform_batch re-poses it in place): the uploaded arrays.  The voxel
+  //         grids go into a slab of their own (grids_build), replaced whenever the clouds are re-posed.
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t up = 0;
   auto place = [&](size_t& off, size_t& cursor, size_t bytes) { off = cursor; cursor = align(cursor + bytes); };
-  int n_grids = 0; size_t n_blocks = 0;
   auto each_cloud = [&](auto&& f) { for (ScanPlan& P : plan) { f(P.flat); f(P.less); f(P.corner); } };
   each_cloud([&](CloudPlan& c) {
     if (c.n <= 0) return;
     place(c.o_xyz, up, (size_t)c.n * 12);
     if (c.tag) place(c.o_tag, up, (size_t)c.n * 4);
-    if (c.grid) { ++n_grids; n_blocks += ((size_t)c.n + 255) / 256; }
   });
   for (int k = 0; k < n_scans; ++k) {
     ScanPlan& P = plan[(size_t)k];
     if (!scans[(size_t)k]->h_p2s_off.empty()) { place(P.o_p2s_off, up, scans[(size_t)k]->h_p2s_off.size() * 4); place(P.o_p2s_ids, up, std::max<size_t>(P.n_p2s_ids, 1) * 4); }
     if (!scans[(size_t)k]->h_seg_pt_off.empty()) place(P.o_seg_xyz, up, std::max<size_t>(P.n_seg_pts, 1) * 12);
   }
-  size_t o_desc = 0, o_blocks = 0, o_small = 0;
-  place(o_desc, up, std::max<size_t>((size_t)n_grids, 1) * sizeof(GridDesc));
-  place(o_blocks, up, std::max<size_t>(n_blocks, 1) * sizeof(GridBlock));
-  place(o_small, up, std::max<size_t>((size_t)n_grids, 1) * sizeof(int));
   const size_t up_bytes = up;
-  size_t slab = up_bytes, scratch = 0;
-  const size_t o_count0 = slab;
-  each_cloud([&](CloudPlan& c) { if (c.grid) place(c.o_count, slab, (size_t)c.T * 4); });
-  const size_t count_bytes = slab - o_count0, o_keys0 = slab;
-  each_cloud([&](CloudPlan& c) { if (c.grid && !c.dense) place(c.o_keys, slab, (size_t)c.T * 8); });
-  const size_t keys_bytes = slab - o_keys0;
-  each_cloud([&](CloudPlan& c) { if (c.grid) { place(c.o_start, slab, (size_t)c.T * 4); place(c.o_sorted, slab, ((size_t)c.n + 1) * 16); if (c.tag) place(c.o_pt4, slab, (size_t)c.n * 16); } });   // + 1: the search may read (never use) one record past a run
-  each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_cursor, scratch, (size_t)c.T * 4); });
-  const size_t cursor_bytes = scratch;
-  each_cloud([&](CloudPlan& c) { if (c.grid) place(c.s_slot, scratch, (size_t)c.n * 4); });
-  // ---- 3. allocate: slab + scratch from the pool, the staging mirror of the uploaded front (pinned, grow-only)
-  char* d_slab = nullptr; char* d_scr = nullptr;
-  if ((st = pvlm_i_alloc_bytes(ctx, (void**)&d_slab, std::max<size_t>(slab, 256)))) return fail(st);
-  if ((st = pvlm_i_alloc_bytes(ctx, (void**)&d_scr, std::max<size_t>(scratch, 256)))) { pvlm_i_free(ctx, d_slab); return fail(st); }
-  auto bail = [&](pvlm_status e) { hipStreamSynchronize(ctx->stream); pvlm_i_free(ctx, d_slab); pvlm_i_free(ctx, d_scr); return fail(e); };
+  // ---- 3. allocate: the slab from the pool, the staging mirror of the uploaded arrays (pinned, grow-only)
+  char* d_slab = nullptr;
+  if ((st = pvlm_i_alloc_bytes(ctx, (void**)&d_slab, std::max<size_t>(up_bytes, 256)))) return fail(st);
+  auto bail = [&](pvlm_status e) { hipStreamSynchronize(ctx->stream); pvlm_i_free(ctx, d_slab); return fail(e); };
   // staging window: the whole front when it fits, else PVLM_UPLOAD_STAGE_MB (default 64) at a time
   size_t window = (size_t)64 << 20;
   if (const char* env = getenv("PVLM_UPLOAD_STAGE_MB")) if (atof(env) > 0) window = (size_t)(atof(env) * 1048576.0);
@@ -664,7 +802,7 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   }
   char* h = (char*)ctx->h_up;
   pvlm_i_trace("scan_upload_batch: layout + allocations");
-  // ---- 4. the uploaded front as a list of (offset, source) segments, in ascending offset order
+  // ---- 4. the uploaded arrays as a list of (offset, source) segments, in ascending offset order
   struct Seg { size_t off; const void* src; size_t bytes; };
   std::vector<Seg> segs;
   each_cloud([&](CloudPlan& c) {
@@ -680,31 +818,10 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
     }
     if (!s->h_seg_pt_off.empty() && P.n_seg_pts) segs.push_back({P.o_seg_xyz, descs[k].seg_points_xyz, P.n_seg_pts * 12});
   }
-  std::vector<GridDesc> hd((size_t)n_grids); std::vector<GridBlock> hb; std::vector<int> hs;
-  hb.reserve(n_blocks);
-  int g = 0;
-  std::vector<std::pair<int, const CloudPlan*>> big;       // tables too long for one workgroup: scanned by launch_scan
-  each_cloud([&](CloudPlan& c) {
-    if (!c.grid) return;
-    GridDesc& D = hd[(size_t)g];
-    D.xyz = (const float*)(d_slab + c.o_xyz); D.n = c.n; D.dense = c.dense; D.nx = c.nx; D.ny = c.ny; D.nz = c.nz; D.T = (int)c.T;
-    D.ox = c.origin[0]; D.oy = c.origin[1]; D.oz = c.origin[2]; D.inv_h = 1.0f / c.h; D.inv_hx = D.inv_h * (float)c.xf;
-    D.keys = c.dense ? nullptr : (unsigned long long*)(d_slab + c.o_keys);
-    D.count = (int*)(d_slab + c.o_count); D.start = (int*)(d_slab + c.o_start); D.sorted = (float4*)(d_slab + c.o_sorted);
-    D.cursor = (int*)(d_scr + c.s_cursor); D.slot = (int*)(d_scr + c.s_slot);
-    D.tag = c.tag ? (const float*)(d_slab + c.o_tag) : nullptr; D.pt4 = c.tag ? (float4*)(d_slab + c.o_pt4) : nullptr;
-    for (int f = 0; f < c.n; f += 256) hb.push_back(GridBlock{g, f});
-    if (c.T <= GRID_SCAN_MAX) hs.push_back(g); else big.push_back({g, &c});
-    ++g;
-  });
-  const size_t nb = hb.size(); const int n_small = (int)hs.size();
-  if (n_grids) segs.push_back({o_desc, hd.data(), hd.size() * sizeof(GridDesc)});
-  if (nb) segs.push_back({o_blocks, hb.data(), nb * sizeof(GridBlock)});
-  if (n_small) segs.push_back({o_small, hs.data(), hs.size() * sizeof(int)});
-  // ---- 5. one copy, three memsets, three launches (+ the long tables), one synchronisation
+  // ---- 5. one copy (window by window), then the grids of the batch
   hipError_t e = hipSuccess;
   size_t first_seg = 0;
-  pvlm_i_trace("scan_upload_batch: segment + descriptor lists");
+  pvlm_i_trace("scan_upload_batch: segment lists");
   for (size_t lo = 0; lo < up_bytes && e == hipSuccess; lo += ctx->up_bytes) {
     const size_t hi = std::min(up_bytes, lo + ctx->up_bytes);
     if (lo > 0) e = hipStreamSynchronize(ctx->stream);            // the window is refilled: the previous copy must have left it
@@ -723,49 +840,28 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
     }
     if (e == hipSuccess) e = hipMemcpyAsync(d_slab + lo, h, hi - lo, hipMemcpyHostToDevice, ctx->stream);
   }
-  if (e == hipSuccess && count_bytes) e = hipMemsetAsync(d_slab + o_count0, 0, count_bytes, ctx->stream);
-  if (e == hipSuccess && keys_bytes) e = hipMemsetAsync(d_slab + o_keys0, 0xFF, keys_bytes, ctx->stream);
-  if (e == hipSuccess && cursor_bytes) e = hipMemsetAsync(d_scr, 0, cursor_bytes, ctx->stream);
-  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: copy / memset failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
-  DevScratch tiles_scratch(ctx);
-  if (nb) {
-    const GridDesc* dd = (const GridDesc*)(d_slab + o_desc); const GridBlock* db = (const GridBlock*)(d_slab + o_blocks);
-    hipLaunchKernelGGL(k_grid_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dd, db);
-    if (n_small) hipLaunchKernelGGL(k_grid_scan, dim3((unsigned)n_small), dim3(1024), 0, ctx->stream, dd, (const int*)(d_slab + o_small));
-    for (const auto& bg : big) {
-      const CloudPlan& c = *bg.second;
-      int* d_tiles = nullptr;
-      if ((st = tiles_scratch.alloc(&d_tiles, (size_t)((c.T + SCAN_TILE - 1) / SCAN_TILE) + 1))) return bail(st);
-      launch_scan(ctx, (int)c.T, (const int*)(d_slab + c.o_count), (int*)(d_slab + c.o_start), d_tiles);
-    }
-    hipLaunchKernelGGL(k_grid_scatter, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dd, db);
-    e = hipGetLastError();
-    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "voxel-grid build failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
-  }
-  pvlm_i_trace("scan_upload_batch: staged, copies + kernels queued");
-  // the staging buffer is reused by the next call and the scratch goes back to the pool: wait once for the whole batch
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: device error"); return bail(PVLM_ERR_HIP); }
-  pvlm_i_free(ctx, d_scr);
-  pvlm_i_trace("scan_upload_batch: synchronised");
-  // ---- 6. hand out the scans: views into the shared slab, released with the last of them
+  if (e != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: copy failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
+  std::vector<GridJob> jobs;
+  each_cloud([&](CloudPlan& c) { if (c.grid) jobs.push_back(GridJob{&c, (const float*)(d_slab + c.o_xyz), c.tag ? (const float*)(d_slab + c.o_tag) : nullptr}); });
+  pvlm_i_trace("scan_upload_batch: staged, copies queued");
+  char* d_grid = nullptr;
+  if ((st = grids_build(ctx, jobs, &d_grid))) { pvlm_i_free(ctx, d_slab); return fail(st); }      // synchronises: the staging window is free again
+  // ---- 6. hand out the scans: views into the two shared slabs, each released with the last of its scans
   pvlm_scan_slab* sl = new (std::nothrow) pvlm_scan_slab();
-  if (!sl) { pvlm_i_free(ctx, d_slab); return fail(PVLM_ERR_NOMEM); }
+  pvlm_scan_slab* gl = d_grid ? new (std::nothrow) pvlm_scan_slab() : nullptr;
+  if (!sl || (d_grid && !gl)) { delete sl; delete gl; pvlm_i_free(ctx, d_slab); pvlm_i_free(ctx, d_grid); return fail(PVLM_ERR_NOMEM); }
   sl->base = d_slab; sl->refs = n_scans;
+  if (gl) { gl->base = d_grid; gl->refs = n_scans; }
   auto bind = [&](pvlm_cloud& c, const CloudPlan& p) {
     c.n = std::max(p.n, 0);
     if (p.n <= 0) return;
     c.d_xyz = (float*)(d_slab + p.o_xyz);
     if (p.tag) c.d_tag = (float*)(d_slab + p.o_tag);
-    if (!p.grid) return;
-    c.cell = p.h; for (int q = 0; q < 3; ++q) c.origin[q] = p.origin[q];
-    c.table_size = (int)p.T; c.dense = p.dense; c.nx = p.nx; c.ny = p.ny; c.nz = p.nz; c.xf = p.xf;
-    c.d_keys = p.dense ? nullptr : (unsigned long long*)(d_slab + p.o_keys);
-    c.d_cell_start = (int*)(d_slab + p.o_start); c.d_cell_count = (int*)(d_slab + p.o_count); c.d_sorted = (float4*)(d_slab + p.o_sorted);
-    c.d_pt4 = p.tag ? (float4*)(d_slab + p.o_pt4) : nullptr;
+    if (p.grid) grid_bind(c, p, d_grid, p.tag != nullptr);
   };
   for (int k = 0; k < n_scans; ++k) {
     pvlm_scan* s = scans[(size_t)k]; const ScanPlan& P = plan[(size_t)k];
-    s->slab = sl;
+    s->slab = sl; s->grid_slab = gl;
     bind(s->flat, P.flat); bind(s->less, P.less); bind(s->corner, P.corner);
     if (!s->h_p2s_off.empty()) { s->d_p2s_off = (int*)(d_slab + P.o_p2s_off); s->d_p2s_ids = (int*)(d_slab + P.o_p2s_ids); }
     if (!s->h_seg_pt_off.empty()) s->d_seg_xyz = (float*)(d_slab + P.o_seg_xyz);
@@ -774,11 +870,147 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   return PVLM_OK;
 }
 
+pvlm_status pvlm_scan_set_pose(pvlm_ctx* ctx, pvlm_scan* s, const double* R_wl, const double* t_wl) {
+  if (!ctx || !s || !R_wl || !t_wl) return PVLM_ERR_ARG;
+  std::memcpy(s->R_wl, R_wl, sizeof(s->R_wl));
+  std::memcpy(s->t_wl, t_wl, sizeof(s->t_wl));
+  return PVLM_OK;
+}
+
+static pvlm_status scan_transform_batch_impl(pvlm_ctx* ctx, int n_scans, pvlm_scan* const* scans, const double* T12, int rebuild_grids);
+pvlm_status pvlm_scan_transform_batch(pvlm_ctx* ctx, int n_scans, pvlm_scan* const* scans, const double* T_rowmajor12, int rebuild_grids) {
+  try {
+    return scan_transform_batch_impl(ctx, n_scans, scans, T_rowmajor12, rebuild_grids);
+  } catch (const std::bad_alloc&) {
+    if (ctx) { (void)hipStreamSynchronize(ctx->stream); PVLM_SET_ERR(ctx, "pvlm_scan_transform_batch: out of host memory"); }
+    return PVLM_ERR_NOMEM;
+  } catch (...) {
+    if (ctx) { (void)hipStreamSynchronize(ctx->stream); PVLM_SET_ERR(ctx, "pvlm_scan_transform_batch: unexpected host exception"); }
+    return PVLM_ERR_HIP;
+  }
+}
+static pvlm_status scan_transform_batch_impl(pvlm_ctx* ctx, int n_scans, pvlm_scan* const* scans, const double* T12, int rebuild_grids) {
+  if (!ctx || n_scans < 0 || (n_scans > 0 && (!scans || !T12))) return PVLM_ERR_ARG;
+  if (n_scans == 0) return PVLM_OK;
+  for (int k = 0; k < n_scans; ++k) if (!scans[k]) { PVLM_SET_ERR(ctx, "pvlm_scan_transform_batch: null scan (%d of the batch)", k); return PVLM_ERR_ARG; }
+  for (int k = 0; k < 12 * n_scans; ++k) if (!std::isfinite(T12[k])) { PVLM_SET_ERR(ctx, "pvlm_scan_transform_batch: non-finite transform (scan %d of the batch)", k / 12); return PVLM_ERR_ARG; }
+  {   // a scan listed twice would be transformed twice
+    std::vector<const pvlm_scan*> seen(scans, scans + n_scans);
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) { PVLM_SET_ERR(ctx, "pvlm_scan_transform_batch: a scan is listed twice"); return PVLM_ERR_ARG; }
+  }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_i_trace("scan_transform_batch: enter");
+  // ---- 1. the clouds to move: flat, less, corner and the segments' points of every scan; less / corner carry a grid
+  std::vector<XformCloud> hc; std::vector<XformBlock> hb;
+  struct GridRef { pvlm_scan* scan; pvlm_cloud* cloud; };
+  std::vector<GridRef> grids;
+  for (int k = 0; k < n_scans; ++k) {
+    pvlm_scan* s = scans[k];
+    auto add = [&](float* xyz, int n, pvlm_cloud* grid_cloud) {
+      if (n <= 0 || !xyz) return;
+      int box = -1;
+      if (rebuild_grids && grid_cloud) { box = (int)grids.size(); grids.push_back(GridRef{s, grid_cloud}); }
+      const int ci = (int)hc.size();
+      hc.push_back(XformCloud{xyz, n, k, box, 0});
+      for (int f = 0; f < n; f += 256) hb.push_back(XformBlock{ci, f});
+    };
+    add(s->flat.d_xyz, s->flat.n, nullptr);
+    add(s->less.d_xyz, s->less.n, &s->less);
+    add(s->corner.d_xyz, s->corner.n, &s->corner);
+    if (s->d_seg_xyz && !s->h_seg_pt_off.empty()) add(s->d_seg_xyz, s->h_seg_pt_off.back(), nullptr);
+  }
+  if (hb.empty()) return PVLM_OK;
+  // ---- 2. tables up, one launch
+  DevScratch scratch(ctx);
+  XformCloud* d_clouds = nullptr; XformBlock* d_blocks = nullptr; double* d_T = nullptr; unsigned* d_boxes = nullptr;
+  pvlm_status st = scratch.alloc(&d_clouds, hc.size());
+  if (!st) st = scratch.alloc(&d_blocks, hb.size());
+  if (!st) st = scratch.alloc(&d_T, (size_t)n_scans * 12);
+  if (!st) st = scratch.alloc(&d_boxes, std::max<size_t>(grids.size(), 1) * 7);
+  if (!st) st = pvlm_i_h2d_q(ctx, d_clouds, hc.data(), hc.size() * sizeof(XformCloud));
+  if (!st) st = pvlm_i_h2d_q(ctx, d_blocks, hb.data(), hb.size() * sizeof(XformBlock));
+  if (!st) st = pvlm_i_h2d_q(ctx, d_T, T12, (size_t)n_scans * 12 * sizeof(double));
+  std::vector<unsigned> hbox(std::max<size_t>(grids.size(), 1) * 7);
+  for (size_t g = 0; g < grids.size(); ++g) { for (int q = 0; q < 3; ++q) { hbox[7 * g + q] = 0xFFFFFFFFu; hbox[7 * g + 3 + q] = 0u; } hbox[7 * g + 6] = 0x7FFFFFFFu; }
+  if (!st && !grids.empty()) st = pvlm_i_h2d_q(ctx, d_boxes, hbox.data(), grids.size() * 7 * sizeof(unsigned));
+  if (st) { (void)pvlm_i_sync(ctx); return st; }
+  hipLaunchKernelGGL(k_scan_transform, dim3((unsigned)hb.size()), dim3(256), 0, ctx->stream, d_clouds, d_blocks, d_T, d_boxes);
+  { const hipError_t e = hipGetLastError(); if (e != hipSuccess) { (void)pvlm_i_sync(ctx); PVLM_SET_ERR(ctx, "pvlm_scan_transform_batch: %s", hipGetErrorString(e)); return PVLM_ERR_HIP; } }
+  if (!rebuild_grids)
+    for (int k = 0; k < n_scans; ++k) { scans[k]->less.grid_stale = scans[k]->less.n > 0; scans[k]->corner.grid_stale = scans[k]->corner.n > 0; }
+  if (grids.empty()) { return pvlm_i_sync(ctx); }            // the scratch tables go back to the pool: stream-ordered, but the staged copies must have left the arena
+  // ---- 3. boxes back, the grid plans of an upload of the same floats, the grids
+  if ((st = pvlm_i_d2h_q(ctx, hbox.data(), d_boxes, grids.size() * 7 * sizeof(unsigned)))) { (void)pvlm_i_sync(ctx); return st; }
+  if ((st = pvlm_i_sync(ctx))) return st;
+  pvlm_i_trace("scan_transform_batch: transformed, boxes on the host");
+  std::vector<CloudPlan> plans(grids.size());
+  std::vector<GridJob> jobs; jobs.reserve(grids.size());
+  for (size_t g = 0; g < grids.size(); ++g) {
+    CloudBox box;
+    for (int q = 0; q < 3; ++q) { box.mn[q] = ord2f(hbox[7 * g + q]); box.mx[q] = ord2f(hbox[7 * g + 3 + q]); }
+    box.bad_point = hbox[7 * g + 6] == 0x7FFFFFFFu ? -1 : (int)hbox[7 * g + 6];
+    pvlm_cloud& c = *grids[g].cloud;
+    if ((st = cloud_plan(ctx, plans[g], c.n, nullptr, c.d_tag, true, &box))) return st;     // the clouds stay transformed: the caller destroys the scans
+    jobs.push_back(GridJob{&plans[g], c.d_xyz, c.d_tag});
+  }
+  char* d_grid = nullptr;
+  if ((st = grids_build(ctx, jobs, &d_grid))) return st;
+  pvlm_scan_slab* gl = new (std::nothrow) pvlm_scan_slab();
+  if (!gl) { pvlm_i_free(ctx, d_grid); return PVLM_ERR_NOMEM; }
+  gl->base = d_grid; gl->refs = 0;
+  for (size_t g = 0; g < grids.size(); ++g) grid_bind(*grids[g].cloud, plans[g], d_grid, grids[g].cloud->d_tag != nullptr);
+  for (int k = 0; k < n_scans; ++k) {
+    pvlm_scan* s = scans[k];
+    if (s->less.n <= 0 && s->corner.n <= 0) continue;         // no grid of this scan in the new slab
+    slab_unref(ctx, s->grid_slab);                            // the old tables: stream-ordered reuse, every kernel reading them has been queued
+    s->grid_slab = gl; ++gl->refs;
+  }
+  if (gl->refs == 0) { pvlm_i_free(ctx, d_grid); delete gl; }
+  return PVLM_OK;
+}
+
+static const pvlm_cloud* scan_cloud(const pvlm_scan* s, int which) { return which == 0 ? &s->flat : which == 1 ? &s->less : which == 2 ? &s->corner : nullptr; }
+pvlm_status pvlm_scan_cloud_info(const pvlm_scan* s, int which, pvlm_grid_info* info) {
+  if (!s || !info || which < 0 || which > 3) return PVLM_ERR_ARG;
+  std::memset(info, 0, sizeof(*info));
+  if (which == 3) { info->n = s->h_seg_pt_off.empty() || !s->d_seg_xyz ? 0 : s->h_seg_pt_off.back(); return PVLM_OK; }
+  const pvlm_cloud& c = *scan_cloud(s, which);
+  info->n = c.n;
+  info->has_grid = c.d_sorted != nullptr; info->stale = c.grid_stale;
+  if (info->has_grid) {
+    info->dense = c.dense; info->nx = c.nx; info->ny = c.ny; info->nz = c.nz; info->xf = c.xf; info->table_size = c.table_size; info->cell = c.cell;
+    for (int q = 0; q < 3; ++q) info->origin[q] = c.origin[q];
+  }
+  return PVLM_OK;
+}
+pvlm_status pvlm_scan_cloud_fetch(pvlm_ctx* ctx, const pvlm_scan* s, int which, float* xyz, int* cell_count, int* cell_start, unsigned long long* keys,
+                                  float* sorted_xyzi) {
+  if (!ctx || !s || which < 0 || which > 3) return PVLM_ERR_ARG;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_status st = PVLM_OK;
+  if (which == 3) {
+    const int n = s->h_seg_pt_off.empty() || !s->d_seg_xyz ? 0 : s->h_seg_pt_off.back();
+    if (xyz && n > 0) st = pvlm_i_d2h_q(ctx, xyz, s->d_seg_xyz, (size_t)n * 12);
+  } else {
+    const pvlm_cloud& c = *scan_cloud(s, which);
+    if (xyz && c.n > 0) st = pvlm_i_d2h_q(ctx, xyz, c.d_xyz, (size_t)c.n * 12);
+    if (c.d_sorted) {
+      if (!st && cell_count) st = pvlm_i_d2h_q(ctx, cell_count, c.d_cell_count, (size_t)c.table_size * 4);
+      if (!st && cell_start) st = pvlm_i_d2h_q(ctx, cell_start, c.d_cell_start, (size_t)c.table_size * 4);
+      if (!st && keys && c.d_keys) st = pvlm_i_d2h_q(ctx, keys, c.d_keys, (size_t)c.table_size * 8);
+      if (!st && sorted_xyzi) st = pvlm_i_d2h_q(ctx, sorted_xyzi, c.d_sorted, (size_t)c.n * 16);
+    }
+  }
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+  return st;
+}
+
 pvlm_status pvlm_scan_destroy(pvlm_ctx* ctx, pvlm_scan* s) {
   if (!ctx) return PVLM_ERR_ARG;
   if (!s) return PVLM_OK;
   hipSetDevice(ctx->device);
-  if (s->slab && --s->slab->refs == 0) { pvlm_i_free(ctx, s->slab->base); delete s->slab; }   // every array of the scan lives in the batch's slab
+  slab_unref(ctx, s->slab); slab_unref(ctx, s->grid_slab);   // every array of the scan lives in the two slabs its batch shares
   delete s;
   return PVLM_OK;
 }
@@ -790,6 +1022,7 @@ pvlm_status pvlm_knn(pvlm_ctx* ctx, const pvlm_scan* scan, int which, const floa
   if (nq == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   const pvlm_cloud& c = which == 0 ? scan->less : scan->corner;
+  if (c.grid_stale) { PVLM_SET_ERR(ctx, "pvlm_knn: the scan's clouds were transformed without rebuilding their grids (pvlm_scan_transform_batch with rebuild_grids = 0)"); return PVLM_ERR_STATE; }
   float* d_q = nullptr; int* d_idx = nullptr; float* d_sqd = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_q, (size_t)nq * 3);
   if (!st) st = pvlm_i_alloc(ctx, &d_idx, (size_t)nq * k);
@@ -826,6 +1059,8 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
   if (kind != PVLM_POINT2PLANE_ANGLE && kind != PVLM_POINT2PLANE_METER) { PVLM_SET_ERR(ctx, "kind must be a point-to-plane functor"); return PVLM_ERR_ARG; }
   if (!(dist_threshold > 0)) { PVLM_SET_ERR(ctx, "dist_threshold must be positive"); return PVLM_ERR_ARG; }
   for (int p = 0; p < n_pairs; ++p) if (!ref[p] || !nei[p]) { PVLM_SET_ERR(ctx, "null scan in pair %d", p); return PVLM_ERR_ARG; }
+  for (int p = 0; p < n_pairs; ++p)
+    if (ref[p]->less.grid_stale) { PVLM_SET_ERR(ctx, "pair %d: the reference scan's clouds were transformed without rebuilding their grids (pvlm_scan_transform_batch with rebuild_grids = 0)", p); return PVLM_ERR_STATE; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   const bool keep_idx = (flags & 0x100u) != 0;
 

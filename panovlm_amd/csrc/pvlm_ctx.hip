@@ -317,6 +317,7 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   pvlm_i_assoc_ws_free(ctx);
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+  if (ctx->h_grid) (void)hipHostFree(ctx->h_grid);
   for (int k = 0; k < ctx->ring_pool; ++k) (void)hipHostFree(ctx->h_ring[k]);
   pvlm_i_spd_plan_release(ctx);
   if (ctx->stage.base) (void)hipHostFree(ctx->stage.base);

@@ -70,6 +70,9 @@ struct pvlm_ctx {
   double* d_neq_tmp = nullptr; size_t neq_tmp_count = 0;
   // pinned staging of pvlm_scan_upload[_batch] (grow-only)
   void* h_up = nullptr; size_t up_bytes = 0;
+  // pinned staging of the voxel-grid build tables (descriptors, point blocks; grow-only): its own buffer, so that the tables of a build queued
+  // behind an upload's front copy do not have to wait for that copy to leave h_up
+  void* h_grid = nullptr; size_t grid_bytes = 0;
   // pinned buffers destroyed pvlm_ring_batches leave behind for the next ones (hipHostMalloc of a Room batch's 260 MB: 51 ms).  Several: the host
   // mirror runs a call's scans as a sequence of batches whose results stay alive until the call ends (the picks of one overlap the device stages of the next)
   static constexpr int kRingPool = 16;
@@ -184,13 +187,15 @@ struct pvlm_cloud {
   float4* d_sorted = nullptr;    // n: (x,y,z, as_float(original index))
   float4* d_pt4 = nullptr;       // n: (x,y,z,tag) in original order (clouds with tags)
   int* d_sorted_cell = nullptr;  // unused placeholder
+  bool grid_stale = false;       // the points were transformed in place without a rebuild of the grid (pvlm_scan_transform_batch, rebuild_grids = 0)
 };
 
-struct pvlm_scan_slab { void* base = nullptr; int refs = 0; };   // one device allocation shared by the scans of an upload batch
+struct pvlm_scan_slab { void* base = nullptr; int refs = 0; };   // one device allocation shared by the scans of an upload (or re-pose) batch
 
 struct pvlm_scan {
   int id = 0;
-  pvlm_scan_slab* slab = nullptr;
+  pvlm_scan_slab* slab = nullptr;        // the uploaded arrays: float clouds (transformed in place by pvlm_scan_transform_batch), tags, point_to_segment, segment points
+  pvlm_scan_slab* grid_slab = nullptr;   // the voxel grids built from them (cell tables, sorted points, pt4): replaced whenever the clouds are re-posed
   double R_wl[9];
   double t_wl[3];
   pvlm_cloud flat, less, corner;

@@ -110,51 +110,83 @@ static void TransformCloud(PointCloud& c, const Matrix3d& R, const Vector3d& t) 
     p.z = static_cast<float>(R[6] * x + R[7] * y + R[8] * z + t[2]);
   }
 }
-// the host half of Transform2LidarWorld / Transform2Local: no device call, so it may run on a worker thread
-static void TransformScanClouds(Velodyne& v, bool to_world, PointCloud& surfFlat, PointCloud& surfLessFlat, PointCloud& cornerLessSharp, PointCloud& cloud,
-                                std::vector<PointCloud>& edge_segmented, const Matrix3d& R_wl, const Vector3d& t_wl) {
-  (void)v;
-  Matrix3d R = R_wl; Vector3d t = t_wl;
+// the matrix of Transform2LidarWorld (T_wl) or Transform2Local (T_lw = [R_wl^T | -R_wl^T t_wl], sensors/Velodyne.cpp:1822-1826): host and device
+// copies of a scan are moved by the SAME twelve doubles
+static void TransformOf(const Matrix3d& R_wl, const Vector3d& t_wl, bool to_world, Matrix3d& R, Vector3d& t) {
+  R = R_wl; t = t_wl;
   if (!to_world) {
     R = {R_wl[0], R_wl[3], R_wl[6], R_wl[1], R_wl[4], R_wl[7], R_wl[2], R_wl[5], R_wl[8]};
     const Vector3d rt = MatVec(R, t_wl);
     t = {-rt[0], -rt[1], -rt[2]};
   }
+}
+// the host half of Transform2LidarWorld / Transform2Local: no device call, so it may run on a worker thread
+static void TransformScanClouds(bool to_world, PointCloud& surfFlat, PointCloud& surfLessFlat, PointCloud& cornerLessSharp, PointCloud& cloud,
+                                std::vector<PointCloud>& edge_segmented, const Matrix3d& R_wl, const Vector3d& t_wl) {
+  Matrix3d R; Vector3d t;
+  TransformOf(R_wl, t_wl, to_world, R, t);
   TransformCloud(surfFlat, R, t); TransformCloud(surfLessFlat, R, t); TransformCloud(cornerLessSharp, R, t);
   TransformCloud(cloud, R, t);
   for (PointCloud& s : edge_segmented) TransformCloud(s, R, t);
 }
+static bool ReuploadMode() { static const bool on = std::getenv("PVLM_HOST_REUPLOAD") != nullptr; return on; }
 void Velodyne::Transform2LidarWorld() {
   if (world_ || !IsPoseValid()) return;
-  TransformScanClouds(*this, true, surfFlat, surfLessFlat, cornerLessSharp, cloud, edge_segmented, R_wl_, t_wl_);
-  world_ = true;
-  InvalidateDevice();
+  TransformBatch({this}, true, 1);
 }
 void Velodyne::Transform2Local() {
   if (!world_ || !IsPoseValid()) return;
-  TransformScanClouds(*this, false, surfFlat, surfLessFlat, cornerLessSharp, cloud, edge_segmented, R_wl_, t_wl_);
-  world_ = false;
-  InvalidateDevice();
+  TransformBatch({this}, false, 1);
 }
 void Velodyne::TransformBatch(const std::vector<Velodyne*>& scans, bool to_world, int num_threads) {
-  StageTimer stage_timer_(to_world ? "scan clouds to the world frame (host, scan-parallel)" : "scan clouds back to the local frame (host, scan-parallel)");
+  StageTimer stage_timer_(to_world ? "scan clouds to the world frame (host clouds scan-parallel; resident device copies re-posed in place, K26)"
+                                   : "scan clouds back to the local frame (host clouds scan-parallel; resident device copies re-posed in place, K26)");
   std::vector<Velodyne*> todo;
   for (Velodyne* v : scans) if (v && v->IsPoseValid() && v->world_ != to_world) todo.push_back(v);
   if (todo.empty()) return;
-  for (Velodyne* v : todo) v->InvalidateDevice();           // calling thread
+  // the resident copies (calling thread: the engine's pool is not thread-safe): queued before the host workers start, collected after them
+  std::vector<pvlm_scan*> resident; std::vector<double> T12;
+  if (ReuploadMode()) { for (Velodyne* v : todo) v->InvalidateDevice(); }
+  else
+    for (Velodyne* v : todo) {
+      if (!v->dev_) continue;
+      Matrix3d R; Vector3d t;
+      TransformOf(v->R_wl_, v->t_wl_, to_world, R, t);
+      resident.push_back(v->dev_);
+      for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T12.push_back(R[3 * r + c]); T12.push_back(t[r]); }
+    }
   const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(num_threads, 1), todo.size() / 16 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   std::atomic<size_t> next{0};
   auto work = [&]() {
     for (size_t k = next++; k < todo.size(); k = next++) {
       Velodyne& v = *todo[k];
-      TransformScanClouds(v, to_world, v.surfFlat, v.surfLessFlat, v.cornerLessSharp, v.cloud, v.edge_segmented, v.R_wl_, v.t_wl_);
+      TransformScanClouds(to_world, v.surfFlat, v.surfLessFlat, v.cornerLessSharp, v.cloud, v.edge_segmented, v.R_wl_, v.t_wl_);
       v.world_ = to_world;
     }
   };
-  pvlm_run_workers(n_threads, work);
+  if (resident.empty()) { pvlm_run_workers(n_threads, work); return; }
+  // the device call is host-side work too (descriptor tables, the grid plans between its two synchronisations): it runs on the calling thread
+  // while the workers move the host's clouds
+  std::exception_ptr failure;
+  std::thread host_side([&]() { try { pvlm_run_workers(n_threads, work); } catch (...) { failure = std::current_exception(); } });
+  pvlm_status st;
+  {
+    StageTimer stage_timer_dev_("  (inside the re-posing) pvlm_scan_transform_batch");
+    Engine& e = Engine::Default();
+    st = pvlm_scan_transform_batch(e.ctx(), (int)resident.size(), resident.data(), T12.data(), to_world ? 1 : 0);
+  }
+  host_side.join();
+  if (failure) std::rethrow_exception(failure);
+  Engine::Default().Check(st, "pvlm_scan_transform_batch");
 }
 void Velodyne::InvalidateDevice() const {
   if (dev_) { pvlm_scan_destroy(Engine::Default().ctx(), dev_); dev_ = nullptr; }
+}
+void Velodyne::PoseChanged() const {
+  if (!dev_) return;
+  if (ReuploadMode()) { InvalidateDevice(); return; }
+  Engine& e = Engine::Default();
+  e.Check(pvlm_scan_set_pose(e.ctx(), dev_, R_wl_.data(), t_wl_.data()), "pvlm_scan_set_pose");
 }
 Velodyne::~Velodyne() { if (dev_) pvlm_scan_destroy(Engine::Default().ctx(), dev_); }
 Velodyne::Velodyne(const Velodyne& o)

@@ -123,11 +123,12 @@ class Velodyne {
   std::vector<Vector3d> end_points;      // 2 per segment, LiDAR-local
 
   Velodyne() { SetRotation({0, 0, 0, 0, 0, 0, 0, 0, 0}); SetTranslation({INFINITY, INFINITY, INFINITY}); }
-  // The pose setters and MarkWorld give the scan's device copy back to the engine's context (InvalidateDevice ->
-  // pvlm_scan_destroy), whose pool is not thread-safe: call them from the thread that owns the engine, never from workers.
-  void SetPose(const Matrix3d& R_wl, const Vector3d& t_wl) { R_wl_ = R_wl; t_wl_ = t_wl; InvalidateDevice(); }
-  void SetRotation(const Matrix3d& R_wl) { R_wl_ = R_wl; InvalidateDevice(); }
-  void SetTranslation(const Vector3d& t_wl) { t_wl_ = t_wl; InvalidateDevice(); }
+  // The pose setters hand the new pose to the scan's device copy (pvlm_scan_set_pose: the resident clouds stay where they are, like the host's);
+  // MarkWorld gives the device copy back to the engine's context (InvalidateDevice -> pvlm_scan_destroy), whose pool is not thread-safe: call
+  // them from the thread that owns the engine, never from workers.
+  void SetPose(const Matrix3d& R_wl, const Vector3d& t_wl) { R_wl_ = R_wl; t_wl_ = t_wl; PoseChanged(); }
+  void SetRotation(const Matrix3d& R_wl) { R_wl_ = R_wl; PoseChanged(); }
+  void SetTranslation(const Vector3d& t_wl) { t_wl_ = t_wl; PoseChanged(); }
   const Matrix3d& GetRotation() const { return R_wl_; }
   const Vector3d& GetTranslation() const { return t_wl_; }
   Matrix4d GetPose() const;
@@ -178,14 +179,18 @@ class Velodyne {
   const RingLayout& Layout() const { return layout_; }
   void Transform2LidarWorld();                    // :1773-1808  (float clouds, in place)
   void Transform2Local();                         // :1810-1848
-  // Every scan of the list to the world (local) frame — the loops of LidarOdometry.cpp:148-152 and :120-130 over all scans: the device
-  // copies are given back on the calling thread (the engine's pool is not thread-safe), the clouds transformed scan-parallel.
+  // Every scan of the list to the world (local) frame — the loops of LidarOdometry.cpp:148-152 and :120-130 over all scans: the host's clouds are
+  // transformed scan-parallel, the device copies of the resident scans IN PLACE by one pvlm_scan_transform_batch (K26: the same float arithmetic,
+  // the voxel grids rebuilt from device-side bounding boxes on the way to the world frame) — a scan is uploaded once per EstimatePose, not once per
+  // outer iteration.  PVLM_HOST_REUPLOAD=1: the device copies are dropped instead and uploaded again by the next association (the round-5 path;
+  // tests compare the two).
   static void TransformBatch(const std::vector<Velodyne*>& scans, bool to_world, int num_threads);
 
   // device mirror of the clouds (uploaded lazily by the association entry points)
   pvlm_scan* DeviceScan() const;
   static void UploadBatch(const std::vector<const Velodyne*>& scans);   // all of them that are not resident yet, in one pvlm_scan_upload_batch
   void InvalidateDevice() const;
+  void PoseChanged() const;                       // the device copy learns the pose the setters stored
   ~Velodyne();
   Velodyne(const Velodyne& o);
   Velodyne& operator=(const Velodyne& o);

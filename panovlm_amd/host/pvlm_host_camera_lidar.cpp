@@ -443,7 +443,11 @@ int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, std::vector<Poin
     RotationMatrixToAngleAxis(R_lw, &aa_lw[i]);
     const Vector3d rt = MatVec(R_lw, lidars[i].GetTranslation());
     t_lw[i] = {-rt[0], -rt[1], -rt[2]};
-    lidars[i].Transform2LidarWorld();
+  }
+  {   // lidars[i].Transform2LidarWorld() of every posed scan (CameraLidarOptimizer.cpp:409-417), the resident copies in one device call
+    std::vector<Velodyne*> posed;
+    for (Velodyne& l : lidars) if (l.IsPoseValid() && l.valid) posed.push_back(&l);
+    Velodyne::TransformBatch(posed, true, config.num_threads);
   }
   ceres_like::Problem problem;
   ceres_like::LossFunction* loss1 = new ceres_like::HuberLoss(3 * M_PI / 180.0);
@@ -491,9 +495,13 @@ int CameraLidarOptimizer::Optimize(const LinePairs& line_pairs, std::vector<Poin
     const Vector3d rt = MatVec(frames[i].R_wc, t_cw[i]);
     frames[i].t_wc = {-rt[0], -rt[1], -rt[2]};
   }
+  {
+    std::vector<Velodyne*> posed;
+    for (Velodyne& l : lidars) if (l.IsPoseValid() && l.IsInWorldCoordinate()) posed.push_back(&l);
+    Velodyne::TransformBatch(posed, false, config.num_threads);
+  }
   for (size_t i = 0; i < lidars.size(); i++) {
     if (!lidars[i].IsPoseValid()) continue;
-    if (lidars[i].IsInWorldCoordinate()) lidars[i].Transform2Local();
     Matrix3d R_lw;
     AngleAxisToRotationMatrix(aa_lw[i], &R_lw);
     const Matrix3d R_wl = {R_lw[0], R_lw[3], R_lw[6], R_lw[1], R_lw[4], R_lw[7], R_lw[2], R_lw[5], R_lw[8]};

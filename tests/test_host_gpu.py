@@ -2,6 +2,7 @@
 oracle: single cost functions, AssociatePoint2Plane / AssociateLine2Line, line tracks, FindNeighbors and
 the end-to-end LidarOdometry::EstimatePose loop against its CPU twin (tests/lm_twin.py)."""
 import os
+import re
 import tempfile
 
 import numpy as np
@@ -663,6 +664,45 @@ def test_sharded_estimate_pose_two_ranks_on_one_gpu(tmp):
         assert np.abs(po0[k] - pos[k]).max() <= 1e-9 * max(1.0, np.abs(pos[k]).max())
     # each rank really did only its share: the association stage of a rank saw half of the reference scans
     assert any(l.startswith("stage") and "exchange of the normal equations" in l for l in outs[0])
+
+
+def test_resident_reposing_equals_reupload(tmp, monkeypatch):
+    """K26 under the call surface: LidarOdometry::EstimatePose (three outer iterations, both LiDAR terms) and CameraLidarOptimizer::JointOptimize with the
+    scans' device copies re-posed in place (pvlm_scan_transform_batch inside Velodyne::TransformBatch — sensors/Velodyne.cpp:1773-1848 on the resident
+    clouds) against the same calls with every scan dropped and uploaded again at each outer iteration (PVLM_HOST_REUPLOAD=1, the round-5 path):
+    same costs, step counts, block counts and poses, bit for bit — and after the first iteration no scan upload at all."""
+    rng = np.random.default_rng(78)
+    scans = [_vlp(k, 256) for k in range(6)]
+    lines = _line_scans(rng, 6, pose_offset=0)
+    for s, l in zip(scans, lines):
+        for key in ("corner_local", "p2s", "seg_points", "seg_coeffs", "end_points"):
+            s[key] = l[key]
+    path = os.path.join(tmp, "repose.bin")
+    host_io.write_scans(path, scans, world=False)
+    args = ["odometry", path, 3, 1, 1, 1, 1, 0.05, 1.0, 0.3]
+    monkeypatch.delenv("PVLM_HOST_REUPLOAD", raising=False)
+    resident = host_io.run(*args)
+    monkeypatch.setenv("PVLM_HOST_REUPLOAD", "1")
+    reupload = host_io.run(*args)
+    monkeypatch.delenv("PVLM_HOST_REUPLOAD")
+    keep = lambda out: [l for l in out if l.startswith(("iter", "pose"))]
+    assert keep(resident) == keep(reupload) and len([l for l in resident if l.startswith("iter")]) >= 2
+    uploads = lambda out: [int(re.search(r"\[(\d+) calls\]", l).group(1)) for l in out if l.startswith("stage") and "scan upload: host SoA staging + pvlm_scan_upload" in l]
+    n_iter = len([l for l in resident if l.startswith("iter")])
+    assert uploads(resident) == [1] and uploads(reupload)[0] >= n_iter, (uploads(resident), uploads(reupload))
+    assert any(l.startswith("stage") and "pvlm_scan_transform_batch" in l for l in resident)
+    # the joint problem: scans uploaded in the LOCAL frame by AssociateLineMulti, to the world frame and back around every solve
+    rng = np.random.default_rng(77)
+    lidars, frames, T_cl = _joint_scene(rng, 3)
+    lpath, fpath = os.path.join(tmp, "jl2.bin"), os.path.join(tmp, "jf2.bin")
+    host_io.write_scans(lpath, lidars, world=False)
+    host_io.write_frames(fpath, T_cl, frames)
+    jargs = ["joint", lpath, fpath, 3, 2, 0, 1, 0.05, 1.0, 0.3, 1.0, 2.0]
+    resident = host_io.run(*jargs)
+    monkeypatch.setenv("PVLM_HOST_REUPLOAD", "1")
+    reupload = host_io.run(*jargs)
+    keep = lambda out: [l for l in out if l.startswith(("iter", "pose", "frame"))]
+    assert keep(resident) == keep(reupload) and len(keep(resident)) > 6
 
 
 def test_raw_scans_with_line_segments_to_refined_poses(oracle, tmp):
