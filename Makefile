@@ -27,6 +27,8 @@ repin:
 	cmake -S tools/repin -B "$(REPIN_BUILD)" -DPANOVLM_ROOT="$(REFERENCE)" -DPANOVLM_BUILD="$(REFERENCE_BUILD)"
 	cmake --build "$(REPIN_BUILD)" --target repin_regenerate -j $(JOBS)
 	$(PYTHON) tools/refvec.py table
+	@echo "std::sort order of equal keys: re-pinned against `$${CXX:-g++} --version | head -1` (tests/test_stdsort_cpu.py, compiled with that compiler)"
+	$(PYTHON) -m pytest tests/test_stdsort_cpu.py -q
 	$(PYTHON) -m pytest tests -q -m "not gpu"
 	@echo "re-pinned: commit tests/golden/*.npz and the table above (profiles/), replace 'parity unpinned' in DESIGN.md section 4 and oracle/*.hpp"
 	@echo "with a GPU: $(REPIN_BUILD)/ceres_adapter_check ceresadapter <scans.bin> 0.05 1.0   (integration/pvlm_ceres.hpp under the real Ceres)"

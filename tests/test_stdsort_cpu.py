@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def chk(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("stdsort") / "stdsort_check.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "cpp", "stdsort_check.cpp")])
+    # $CXX: `make repin` runs this file with the reference machine's compiler — the order of equal keys is that toolchain's libstdc++'s (tools/refvec.py table)
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "cpp", "stdsort_check.cpp")])
     lib = ctypes.CDLL(out)
     lib.chk_heap_sorted_ranges.restype = ctypes.c_longlong
     return lib

@@ -90,7 +90,7 @@ def main():
         e1 = np.mean([np.linalg.norm(pos[k][9:] - sy.true_pose(k)[1]) for k in range(1, a.scans)])
         print("mean translation error vs ground truth: %.4f m -> %.4f m" % (e0, e1))
         ok_all = True
-        for world in [int(w) for w in a.ranks.split(",") if w]:
+        for world in [int(w) for w in a.ranks.split(",") if w and int(w) > 1]:      # world 1 is the run above: a one-rank job has no shard log to compare
             xdir = os.path.join(d, "xchg%d" % world); os.makedirs(xdir, exist_ok=True)
             env = dict(os.environ, PVLM_HOST_RESERVE_MB=str(max(256, 1536 // world)))       # per-rank pool: 1/N of the one-process reservation
             t0 = time.perf_counter()

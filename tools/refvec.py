@@ -189,6 +189,25 @@ NOT_PINNED = {
 }
 
 
+# behaviours of THIRD-PARTY code the path depends on that no fixture of the reference's API isolates: what they are pinned against today and what `make repin`
+# re-runs on the reference machine
+THIRD_PARTY = {
+    "libstdc++ `std::sort`: the order it leaves EQUAL keys in (curvatures of a sector — sensors/Velodyne.cpp:896, :1110; voxel indices of pcl::VoxelGrid)": (
+        "N3 (picks, voxel grid)", "`csrc/pvlm_stdsort.h` (introsort restated, host + device) against the toolchain's own `std::sort`: `tests/cpp/stdsort_check.cpp`, "
+        "`tests/test_stdsort_cpu.py`, the load-time self-check and `pvlm_ring_debug_sort` on the GPU",
+        "pinned against THIS image's libstdc++ (%s); the reference's Dockerfile builds on Ubuntu 23 (GCC 12 / 13): `make repin` compiles `stdsort_check.cpp` with the "
+        "reference machine's `$(CXX)` and runs `tests/test_stdsort_cpu.py` against it — permutations element for element"),
+}
+
+
+def _toolchain():
+    import subprocess
+    try:
+        return subprocess.run([os.environ.get("CXX", "g++"), "--version"], capture_output=True, text=True).stdout.splitlines()[0].strip()
+    except Exception:
+        return "g++ not found"
+
+
 def table():
     print("| fixture (tests/golden) | pins SURVEY §8 row | reference entry point | judged |")
     print("|---|---|---|---|")
@@ -197,6 +216,8 @@ def table():
         print("| `%s.npz` | %s | %s | %s |" % (fx, rows, entry, how))
     for k, why in NOT_PINNED.items():
         print("| — | %s | not pinned by a fixture | %s |" % (k, why))
+    for k, (rows, what, how) in THIRD_PARTY.items():
+        print("| — (third party) | %s | %s — %s | %s |" % (rows, k, what, how % _toolchain()))
     return 0
 
 
