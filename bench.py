@@ -239,7 +239,11 @@ def main():
     reserve_bytes = min(reserve_bytes, int(info["hbm_bytes"] * 0.8))
     ctx.reserve(reserve_bytes)
     t_res = time.perf_counter() - t_res
-    dscans = {k: pv.Scan(ctx, s) for k, s in scans.items()}
+    # one pvlm_scan_upload_batch for the rank's scans (one slab, one set of grid-build launches), in slices that keep the staged front under 2 GB
+    dscans, keys_, per = {}, sorted(scans), max(1, (2 << 30) // (16 * args.cols * 40))
+    for a0 in range(0, len(keys_), per):
+        part = keys_[a0:a0 + per]
+        dscans.update(zip(part, pv.Scan.upload_batch(ctx, [scans[k] for k in part])))
     ctx.synchronize()
 
     def associate(rr, nn_, tol, ds=dscans):
@@ -408,6 +412,18 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    # the summed system at the INITIAL parameter point (the timed steps move the point by 1e-9 each and the pre-warm runs a clock-dependent number of
+    # them), as two numbers a one-rank run and an N-rank run of the same command must agree on (to the order of the sums)
+    d_t.copy_(torch.from_numpy(np.ascontiguousarray(t0)).to(dev))
+    ctx.set_poses_dev(F, d_aa.data_ptr(), d_t.data_ptr())
+    neq.accumulate_dev(rs, packed.data_ptr(), pv.LOSS_HUBER, loss_a, zero_first=True)
+    if world > 1:
+        if comm is not None:
+            comm.allreduce_sum_f64(packed.data_ptr(), neq.size)
+        else:
+            dist.all_reduce(packed)
+    torch.cuda.synchronize()
+    packed_sum, packed_l1 = float(packed.sum().item()), float(packed.abs().sum().item())
     cost = float(packed[-1].item())
     dog.disarm()
     # N > 1: the all-reduce of the packed blocks alone (barrier-bracketed, max over ranks) and the per-rank load table
@@ -594,7 +610,7 @@ def main():
                          "literal_workload": "association.raw_targets.fused: %s" % ((((extra_assoc or {}).get("raw_targets") or {}).get("fused") or {}).get("what"))},
             "association": association_block(n_queries, n_targets, n_local, int(len(ref)), assoc_ms, assoc_n, t_assoc, t_assoc_first, assoc_ms_first,
                                              allocs_first, allocs_steady, t_res, reserve_bytes, ctx.mem_info(), extra_assoc),
-            "step": {"graph": graph is not None, "comm": comm_mode, "allreduce_doubles": int(neq.size) if world > 1 else 0,
+            "step": {"graph": graph is not None, "comm": comm_mode, "packed_sum": packed_sum, "packed_l1": packed_l1, "allreduce_doubles": int(neq.size) if world > 1 else 0,
                      "comm_backend": None if world == 1 else ("gloo (PVLM_BENCH_SHARED_GPU: all ranks on one GPU, functional check, not a measurement)" if shared_gpu
                                                              else ("RCCL through torch.distributed (backend nccl)" if comm is None else "RCCL through pvlm_comm_*")),
                      "rccl_ranks": 0 if (world == 1 or shared_gpu) else world, "allreduce_us": allreduce_us,

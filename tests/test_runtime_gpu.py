@@ -304,3 +304,36 @@ def test_two_rccl_ranks_through_pvlm_comm():
             assert p.exitcode == 0
     want = np.arange(1000, dtype=np.float64) * 3
     assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+def test_bench_two_ranks_on_one_gpu_runs_the_multi_rank_branch_of_bench_py():
+    """Insurance for the day a multi-GPU node runs `bench.py --gpus N`: the N > 1 branch of TODAY's
+    bench.py — launcher, rendezvous, sharded association, the all-reduce inside the timed steps, the per-rank table, the image-space block —
+    executed as two ranks sharing this GPU (gloo stands in for RCCL, which refuses two ranks on one device).  The JSON line must carry the
+    multi-rank fields and the summed normal equations of the last step must equal the one-rank run's (1e-12: the order of the sums differs)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--scans", "64", "--cols", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-mvs", "--no-projection"]
+
+    def run(gpus, env_extra):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus)] + common, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    one = run(1, {})
+    two = run(2, {"PVLM_BENCH_SHARED_GPU": "1"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["value"] > 0 and two["steps"] == 3 and two["warmup"] == 1
+    st = two["step"]
+    assert st["allreduce_us"] is not None and st["allreduce_us"] > 0 and st["allreduce_doubles"] > 0 and st["comm"] == "torch" and "gloo" in st["comm_backend"]
+    assert len(st["per_rank"]) == 2 and sum(r["evals"] for r in st["per_rank"]) == two["config"]["residual_blocks"] == one["config"]["residual_blocks"]
+    assert all(r["pairs"] > 0 and r["fused_kernel_ms"] > 0 for r in st["per_rank"])
+    for k in ("packed_sum", "packed_l1"):
+        assert abs(st[k] - one["step"][k]) <= 1e-12 * abs(one["step"][k]), (k, st[k], one["step"][k])
+    assert abs(two["config"]["robust_cost"] - one["config"]["robust_cost"]) <= 1e-12 * one["config"]["robust_cost"]
+    assert two["image_space_all_ranks"]["ranks_measured"] == 2
+    assert two["roofline"]["kernel"] == "k_eval_fused" and two["scaling"] == "strong"
