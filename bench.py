@@ -31,6 +31,32 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+# The one table every `roof` object of this file is priced against (/opt/skills/guides/MI355X_MICROARCH.md; the link rate is the pcie block's measurement).
+PEAKS = {
+    "hbm_GBps": HBM_PEAK_GBPS,
+    # a SIMD issues one wave64 VALU instruction per 4 cycles — fp32, integer and v_min/max_f64 alike (measured at > 90 % busy: 4.3-4.5 cycles,
+    # profiles/r5_assoc_variants.txt section 1): 256 CUs x 4 SIMDs x 2.4 GHz / 4
+    "valu_wave_insts_per_s": 1024 * 2.4e9 / 4.0,
+    "host_link_GBps": 55.7,
+}
+
+
+def roof(bound, achieved, unit, issue_peak=None, algorithmic_peak=None, **extra):
+    """One shape for the side blocks' roofs.  Two fractions, kept apart on purpose:
+      issue_efficiency     achieved / the rate at which the kernel's OWN instruction stream (SQ_INSTS_VALU) could issue — how well the loop as written
+                           keeps the SIMDs busy; a bloated loop scores the same (what `frac` meant for these blocks up to round 5; `frac` is kept as its alias)
+      frac_of_algorithmic  achieved / the rate an implementation executing only the operations the PROBLEM needs would reach at full issue (the floor is
+                           stated beside it): distance from the problem, not from the loop."""
+    out = {"bound": bound, "achieved": achieved, "unit": unit}
+    if issue_peak:
+        out["at_full_issue_of_own_instructions"] = issue_peak
+        out["issue_efficiency"] = achieved / issue_peak if achieved is not None else None
+        out["frac"] = out["issue_efficiency"]
+    if algorithmic_peak:
+        out["at_full_issue_of_algorithmic_floor"] = algorithmic_peak
+        out["frac_of_algorithmic"] = achieved / algorithmic_peak if achieved is not None else None
+    out.update(extra)
+    return out
 
 
 def cpu_quota():
@@ -683,29 +709,40 @@ def association_block(n_queries, n_targets, accepted, pairs, kernel_ms, launches
 
 
 def association_roof(pmc, achieved_M_queries, which):
-    """Roof of the association kernels: VALU issue.  Hardware side: a SIMD issues one wave64 VALU instruction per 4 cycles (measured on these
-    kernels at > 90 % busy: 4.3-4.5 cycles, profiles/r5_assoc_variants.txt) -> 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave instructions per second.
-    Kernel side: the wave instructions per 64 queries the SQ counters report (SQ_INSTS_VALU / SQ_WAVES, separate --pmc pass of
-    tools/assoc_workload.py).  `frac` = achieved queries/s over the rate at which those instructions could issue; `lane_efficiency` (host
-    lockstep statistics of the same search, tools/assoc_lockstep.py) = the share of K2's insertion-network executions a lane needs for itself."""
-    issue = 1024 * 2.4e9 / 4.0
-    roof = {"bound": "VALU issue", "wave_insts_per_s_peak": issue, "cycles_per_wave_instruction": 4}
+    """Roof of the association kernels: VALU issue (PEAKS).  issue_efficiency prices the kernels' own instruction streams (SQ_INSTS_VALU per 64 queries,
+    a separate --pmc pass of tools/assoc_workload.py summarised by tools/pmc_assoc.py); frac_of_algorithmic prices a floor of the problem itself:
+      K2  every candidate the pruned search has to look at (host lockstep statistics of the same search, tools/assoc_lockstep.py: candidates_per_query) costs
+          3 subtractions + 3 multiplications + 2 additions (flann::L2_Simple, unfused) + 1 comparison against the 10th key = 9 operations; the ten that
+          end up in the list cost at least an insertion each (19 operations: the min / max network);
+      K3  per accepted-or-tested query: ten points to the reference scan's frame (10 x 3 x (3 mul + 2 add + 1 sub), unfused like upstream) = 180; the
+          collinearity decision = centroid + scatter matrix (10 x 15) + a closed-form 3x3 eigen screen (~100) = 250; the plane = normal equations
+          (10 x 9 fused multiply-adds) + a 3x3 solve (~60) + ten point-plane distances (10 x 4) = 190; the query's own point: 18.
+    `lane_efficiency` = the share of K2's insertion-network executions a lane needs for itself."""
+    issue = PEAKS["valu_wave_insts_per_s"]
+    own = None
+    extra = {"wave_insts_per_s_peak": issue, "cycles_per_wave_instruction": 4}
     try:
         ks = pmc["kernels"]
         per_wave = sum(v["valu_insts_per_query"] for k, v in ks.items() if k.startswith(("k_knn", "k_fit", "k_compact")))
-        roof["valu_wave_insts_per_64_queries"] = {k: v["valu_insts_per_query"] for k, v in ks.items()}
-        roof["M_queries_per_s_at_full_issue"] = issue * 64 / per_wave / 1e6
-        roof["frac"] = achieved_M_queries / roof["M_queries_per_s_at_full_issue"] if achieved_M_queries else None
-        roof["counters_from"] = pmc.get("source")
+        extra["valu_wave_insts_per_64_queries"] = {k: v["valu_insts_per_query"] for k, v in ks.items()}
+        extra["simd_busy_lower_bound"] = {k: v.get("simd_valu_util_lower_bound") for k, v in ks.items()}
+        own = issue * 64 / per_wave / 1e6
+        extra["counters_from"] = pmc.get("source")
     except Exception:
-        roof["frac"] = None
+        pass
+    floor = None
     try:
         ls = json.load(open(os.path.join(ROOT, "profiles", "r5_assoc_lockstep.json")))[which]
-        roof["lane_efficiency"] = ls["lane_efficiency"]
-        roof["candidates_per_query"] = ls["candidates_per_query"]; roof["network_executions_per_query"] = ls["network_executions_per_query"]
+        extra["lane_efficiency"] = ls["lane_efficiency"]
+        extra["candidates_per_query"] = ls["candidates_per_query"]; extra["network_executions_per_query"] = ls["network_executions_per_query"]
+        k2 = ls["candidates_per_query"] * 9 + 10 * 19
+        k3 = 180 + 250 + 190 + 18
+        extra["algorithmic_floor_valu_per_query"] = {"k_knn_pairs": k2, "k_fit_pairs": k3,
+                                                     "note": "K3's floor is per query that reaches the fits; with raw targets 94 % of the queries stop at the collinearity decision (180 + 250)"}
+        floor = issue * 64 / (k2 + k3) / 1e6
     except Exception:
-        roof["lane_efficiency"] = None
-    return roof
+        extra["lane_efficiency"] = None
+    return roof("VALU issue", achieved_M_queries, "M queries/s", own, floor, **extra)
 
 
 def per_rank_projection(ctx, pv, torch, sharding, args, associate, make_step, ref_all, nei_all, F, ui, uj, dev, ms_full, k6_full_ms, neq_size):
@@ -897,17 +934,23 @@ def mvs_block(ctx, pv):
     # counter-based roof: wave VALU instructions per pixel (SQ_INSTS_VALU of the pass above / pixels) against the rate a SIMD issues them at
     # (one wave64 instruction per 4 cycles, 1024 SIMDs x 2.4 GHz); `frac` = achieved pixels/s over the pixels/s at full issue
     try:
-        issue = 1024 * 2.4e9 / 4.0
-        roof = {"bound": "VALU issue", "wave_insts_per_s_peak": issue, "kernels": {}}
+        issue = PEAKS["valu_wave_insts_per_s"]
+        kernels = {}
         small = out.get("1440x720") or {}
+        # algorithmic floor per pixel (the operations the reference's ScorePixel / ProcessPixel prescribe, mvs/MVS.cpp:774-923, :721-772, counted from
+        # csrc/pvlm_mvs_core.h): a hypothesis = per neighbour view a homography (30) + 49 / step^2 taps (window 7, step 2: 16) of [projection with FastAtan2
+        # (~60 as float operations), 4 bilinear weights + blend (12), bilateral weight + 5 NCC sums (14)] + the NCC itself (25); K11 scores one hypothesis
+        # against two neighbours, K13 up to 4 propagated + 12 perturbed ones (config/Room.txt)
+        per_hyp_view = 30 + 16 * (60 + 12 + 14) + 25
+        floors = {"k_mvs_conf_lane": 2 * per_hyp_view + 40, "k_mvs_propagate_lane": 16 * 2 * per_hyp_view + 16 * 60}
         for kname, block in (("k_mvs_conf_lane", "k11_scoring_pass"), ("k_mvs_propagate_lane", "k13_patchmatch_iteration")):
             hit = [v for k, v in pmc.items() if kname in k and v.get("valu_wave_insts_per_unit")]
             if hit and block in small:
                 per_pixel = hit[0]["valu_wave_insts_per_unit"]                         # wave instructions per pixel (a wave holds 64 pixels)
-                full = issue / per_pixel / 1e6
-                roof["kernels"][kname] = {"valu_wave_insts_per_pixel": per_pixel, "M_pixels_per_s_at_full_issue": full,
-                                          "achieved_M_pixels_per_s": small[block]["M_pixels_per_s"], "frac": small[block]["M_pixels_per_s"] / full}
-        out["roof"] = roof
+                kernels[kname] = roof("VALU issue", small[block]["M_pixels_per_s"], "M pixels/s", issue / per_pixel / 1e6, issue / floors[kname] / 1e6,
+                                      valu_wave_insts_per_pixel=per_pixel, algorithmic_floor_valu_per_pixel=floors[kname])
+        roof_ = {"bound": "VALU issue", "wave_insts_per_s_peak": issue, "kernels": kernels}
+        out["roof"] = roof_
     except Exception:
         out["roof"] = None
     return out
@@ -1011,7 +1054,7 @@ def features_block(ctx, pv, scans=454, cols=1800):
                    "(tools/feature_batch_bench.py times the whole ExtractFeaturesBatch)"}
     # roof of the batch: the host link.  The boundary hands over host buffers and takes host arrays back: 16 B per raw point up; 24 B per point (five arrays +
     # the sector order), 1 B of state and ~2 B of pick lists and centroids down, at the link rate the `pcie` block measures
-    link = 55.7e9
+    link = PEAKS["host_link_GBps"] * 1e9
     moved = out["points"] * 43
     out["roof"] = {"bound": "host link (PCIe Gen5 x16)", "bytes_per_point": 43, "bytes_per_batch": moved, "GBps_assumed": link / 1e9,
                    "ms_at_link_rate": moved / link * 1e3, "frac": (moved / link * 1e3) / wall, "device_ms_share": device_ms / wall}
@@ -1083,7 +1126,7 @@ def undistort_block(ctx, pv, scans=454, cols=1800):
         w = (time.perf_counter() - t0) * 1e3
         best = w if best is None or w < best else best
     points = int(sum(len(c) for c in clouds))
-    link = 55.7e9
+    link = PEAKS["host_link_GBps"] * 1e9
     out = {"scans": scans, "points": points, "wall_ms_per_call": best, "M_points_per_s": points / best / 1e3,
            "includes": "descriptor marshalling of the Python wrapper, staging copies into / out of pinned memory (host threads), both link directions, the kernel",
            "roof": {"bound": "host link (PCIe Gen5 x16), both directions in sequence", "bytes_per_point": 32, "ms_at_link_rate": points * 32 / link * 1e3,
@@ -1150,16 +1193,21 @@ def panorama_block(ctx, pv, torch, dev, with_votes=True):
     except Exception:
         pmc = {"source": None}
     kernel_ms = k8_ms / max(k8_n, 1)
-    roof = None
+    roof_k8 = None
     if pmc.get("valu_wave_insts_per_test"):
-        peak = 1024 * 2.4e9 / 4.0 / pmc["valu_wave_insts_per_test"] / 1e9
-        roof = {"bound": "VALU issue: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction", "valu_wave_insts_per_test": pmc["valu_wave_insts_per_test"],
-                "G_tests_per_s": peak, "frac": tests_n / max(k8_ms, 1e-9) / 1e6 / peak, "counters": pmc}
+        peak = PEAKS["valu_wave_insts_per_s"] / pmc["valu_wave_insts_per_test"] / 1e9
+        # algorithmic floor of one (line, point) test (joint_optimization/CameraLidarLineAssociate.cpp:394-426): the transformed point is shared by the lines of a
+        # pair; per test two plane-side dot products (2 x 5), the range comparison and two angle comparisons against precomputed cosines (2 x 2) + the vote = ~16
+        # operations over the 64 lanes of a wave -> 0.25 wave instructions per test at one test per lane
+        floor_wave_insts_per_test = 16.0 / 64.0
+        roof_k8 = roof("VALU issue: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction", tests_n / max(k8_ms, 1e-9) / 1e6, "G tests/s", peak,
+                       PEAKS["valu_wave_insts_per_s"] / floor_wave_insts_per_test / 1e9, valu_wave_insts_per_test=pmc["valu_wave_insts_per_test"],
+                       algorithmic_floor_wave_insts_per_test=floor_wave_insts_per_test, G_tests_per_s=peak, counters=pmc)
     out["cam_lidar_votes"] = {"pairs": pairs, "image_lines": len(lines), "corner_points": int(len(scan["corner_local"])), "segments": int(dscan.n_segments),
                               "point_line_tests": int(tests_n), "wall_s_incl_copies": wall, "G_tests_per_s_incl_copies": tests_n / wall / 1e9,
                               "c_abi_call_s": getattr(ctx, "last_call_s", None), "call_over_kernel": getattr(ctx, "last_call_s", 0.0) * 1e3 / max(k8_ms, 1e-9),
                               "kernel_ms": kernel_ms, "G_tests_per_s_kernel": tests_n / max(k8_ms, 1e-9) / 1e6,
-                              "roof": roof,
+                              "roof": roof_k8,
                               "wall_over_kernel": wall * 1e3 / max(k8_ms, 1e-9),
                               "wall_is": "host line tables (272 400 rows, 16 host threads) + descriptors + the voting kernel + two small kernels that compact the "
                                          "non-zero counters + their read-back (pvlm_cam_lidar_votes_batch_sparse); round 4 copied 43 MB of dense blocks back",

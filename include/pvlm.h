@@ -364,6 +364,18 @@ pvlm_status pvlm_knn(pvlm_ctx* ctx, const pvlm_scan* scan, int which, const floa
 pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const* ref, pvlm_scan* const* nei,
                                    double plane_tolerance, float dist_threshold, pvlm_functor kind, unsigned flags,
                                    double weight, pvlm_resset** out);
+/* The plane of a correspondence (lidar_mapping/LidarFeatureAssociate.cpp:592-602: FormPlane, base/Geometry.hpp:345-373 — Eigen's column-pivoted
+ * Householder QR of the 10 x 3 system A n = -1) is computed in one of two ways:
+ *   default                      normal equations + an a-posteriori bound on the distance to the QR's solution (csrc/pvlm_assoc_core.h:
+ *                                form_plane_fast).  The reference's accept / reject decision is taken from it only when it holds for every solution
+ *                                inside the bound; otherwise — the largest point distance within ~1e-6 of plane_tolerance, an ill-conditioned
+ *                                neighbourhood — the QR runs for that query.  Same correspondences, same order; the stored plane is within 5e-7
+ *                                relative of the QR's by construction (1e-11 typically; the bar of the path is 1e-6).
+ *   PVLM_FLAG_ASSOC_EXACT_FIT    the QR for every query, operation by operation, unfused: records bit-identical to an x86-64 build of the
+ *                                reference (what the parity tests pin).  About 1.6 x the time of the plane-fit kernel.
+ * pvlm_assoc_point2plane_stats: how many queries of the set took the QR because the fast fit refused (0 in exact mode). */
+#define PVLM_FLAG_ASSOC_EXACT_FIT 0x200u
+pvlm_status pvlm_assoc_point2plane_stats(const pvlm_resset* rs, int64_t* exact_fits);
 /* Optional debug readback of the last pvlm_assoc_point2plane call: query index and the 10
  * neighbour indices of every accepted correspondence (n x 1, n x 10). */
 pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, int32_t* query_idx, int32_t* nn_idx);

@@ -9,6 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 POINT2PLANE_METER, POINT2PLANE_ANGLE, POINT2LINE_METER, POINT2LINE_ANGLE, PLANE2PLANE_GLOBAL, PLANE_IOU = range(6)
 ERR_CAPACITY = -5            # pvlm_status PVLM_ERR_CAPACITY
 FLAG_NORMALIZE_DISTANCE = 1
+FLAG_ASSOC_KEEP_INDICES = 0x100   # pvlm_assoc_point2plane: keep query / neighbour indices for pvlm_assoc_point2plane_debug
+FLAG_ASSOC_EXACT_FIT = 0x200      # pvlm_assoc_point2plane: the reference's QR for every query (bit-identical records)
 LOSS_NONE, LOSS_HUBER = 0, 1
 PAIR_BLOCK = 121
 STRIDE = {0: 7, 1: 7, 2: 9, 3: 9, 4: 10, 5: 12}
@@ -30,7 +32,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -638,6 +640,12 @@ class ResidualSet:
     def eval_force_host_async(self, f_host, tab_host):
         """[r | g(3)] rows (32 B per block, point functors) + pair tables into page-locked arrays (Context.host_alloc); complete after synchronize()."""
         self.ctx._check(self.ctx.lib.pvlm_eval_force_host_async(self.ctx._h, self._h, _p(f_host, C.c_double), _p(tab_host, C.c_double)), "pvlm_eval_force_host_async")
+
+    def assoc_exact_fits(self):
+        """Queries of the association whose plane came from the exact QR because the certified fast fit refused."""
+        n = C.c_int64(0)
+        self.ctx._check(self.ctx.lib.pvlm_assoc_point2plane_stats(self._h, C.byref(n)), "pvlm_assoc_point2plane_stats")
+        return int(n.value)
 
     def assoc_debug(self):
         q = np.empty(max(self.n, 1), np.int32); nn = np.empty((max(self.n, 1), 10), np.int32)

@@ -279,18 +279,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K2_WAV
 #define PVLM_CHAIN_AGG (1ull << 62)
 #define PVLM_CHAIN_INC (1ull << 63)
 #ifndef PVLM_K3_SUB
-#define PVLM_K3_SUB 2                          // a chunk = PVLM_K3_SUB x 256 queries: one ticket, one chain word, one look-back and two barriers per chunk
+#define PVLM_K3_SUB 2                          // exact kernel: a chunk = PVLM_K3_SUB x 256 queries: one ticket, one chain word, one look-back and two barriers per chunk
 #endif
-#define PVLM_K3_CHUNK (256 * PVLM_K3_SUB)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAVES, 8))) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp, long long tmp_rows,
+#ifndef PVLM_K3F_SUB
+#define PVLM_K3F_SUB 2                         // fast kernel: measured below
+#endif
+// EXACT = false (the default of pvlm_assoc_point2plane): the plane of a query comes from Fit10::form_plane_fast — normal equations + an a-posteriori bound, a
+// quarter of the QR's instructions and half of its registers — whenever that routine can certify the reference's accept / reject decision; the few
+// queries it refuses (the largest distance within ~1e-6 of the tolerance, ill-conditioned neighbourhoods) take the QR, counted in ticket[1].
+// EXACT = true (PVLM_FLAG_ASSOC_EXACT_FIT): the QR for every query — records bit-identical to a non-FMA x86-64 build of the reference.
+#ifndef PVLM_K3F_WAVES
+#define PVLM_K3F_WAVES 2
+#endif
+template <bool EXACT, int SUB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? PVLM_K3_WAVES : PVLM_K3F_WAVES, 8))) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp, long long tmp_rows,
                                                    double* __restrict__ cols, long long n_dev, unsigned long long* __restrict__ chain, int* __restrict__ pair_count,
                                                    int* __restrict__ ticket, int* __restrict__ qidx_out, int* __restrict__ nn_out, int chunks_x, int total) {
-  constexpr int SUB = PVLM_K3_SUB;
+  constexpr int PVLM_K3_CHUNK = 256 * SUB;
   static_assert(SUB == 1 || SUB == 2, "the sub-chunk loop below keeps its per-pass results in slots 0 and SUB - 1");
-  __shared__ int s_vid;
+  __shared__ int s_vid, s_vid2;
   __shared__ int wc[SUB][4];
   __shared__ long long s_prefix;
-  __shared__ double s_rec[2][SUB][7][256];      // two buffers: the chunk being fitted and the parked one
+  __shared__ double s_rec[2][SUB][4][256];      // two buffers: the plane coefficients of the chunk being fitted and of the parked one (the query's own
+                                                // local coordinates — three more doubles — are recomputed when the row is placed: 18 flops against 12 KB of LDS per buffer)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // the parked chunk: wave-uniform (pair, chunk, count, buffer) and per thread and sub-chunk (accepted, rank inside the chunk)
   int prev_pair = -1, prev_chunk = 0, prev_count = 0, prev_buf = 0;
@@ -330,10 +341,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
     for (int u = 0; u < SUB; ++u) {
       if (prev_accept[u]) {
         const long long d = pp.dst_row + s_prefix + prev_rank[u];
+        const int q = prev_chunk * PVLM_K3_CHUNK + u * 256 + (int)threadIdx.x;
+        double pl[3];
+        world2local(pp.Rn, pp.tn, (double)pp.q_xyz[3 * q], (double)pp.q_xyz[3 * q + 1], (double)pp.q_xyz[3 * q + 2], pl);
 #pragma unroll
-        for (int c = 0; c < 7; ++c) cols[(size_t)c * n_dev + d] = s_rec[prev_buf][u][c][threadIdx.x];
+        for (int c = 0; c < 3; ++c) cols[(size_t)c * n_dev + d] = pl[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cols[(size_t)(3 + c) * n_dev + d] = s_rec[prev_buf][u][c][threadIdx.x];
         if (qidx_out) {
-          const int q = prev_chunk * PVLM_K3_CHUNK + u * 256 + (int)threadIdx.x;
           qidx_out[d] = q;
 #pragma unroll
           for (int k = 0; k < 10; ++k) nn_out[d * 10 + k] = nn_tmp[(size_t)k * tmp_rows + pp.tmp_base + q];
@@ -342,67 +357,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
     }
     __syncthreads();   // s_prefix is free again
   };
-  // tickets are drawn one chunk ahead (thread 0 holds the next one while the chunk is fitted: the atomic's latency is off the path)
-  int next_vid = 0, buf = 0;
-  if (threadIdx.x == 0) next_vid = atomicAdd(ticket, 1);
+  int buf = 0;
+  int n_refused = 0;                         // queries of this thread the fast fit left to the QR: summed per wave when the workgroup retires
+  // ---- one query: the row of the neighbour table, the ten neighbours, the fits -------------------------------------------------------------------------
+  auto fit = [&](const PairDesc& pd, int q, int u) -> bool {
+    if (q >= pd.nq) return false;
+    const long long row = pd.tmp_base + q;
+    int id[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
+    if (id[9] < 0) return false;                                           // fewer than ten neighbours in reach (:577)
+    const float qtag = pd.q_tag[q];
+    double px[10], py[10], pz[10], Rt[3];
+    world2local_rt(pd.Rr, pd.tr, Rt);
+    int same = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const Point4 t = pd.ref.pt4[id[k]];                                  // (x, y, z, tag) of the neighbour: one 16-byte gather (round 4: four 4-byte ones)
+      same += (t.w == qtag);
+      double l[3];
+      world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
+      px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
+    }
+    if (same != 10) return false;  // :583-591
+    double plane[4];
+    // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
+    // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
+    // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
+    // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
+    // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw; profiles/r4_assoc_variants.txt.)
+    if (Fit10::is_line(px, py, pz, 3.0)) return false;
+    bool ok;
+    const int fast = EXACT ? -1 : Fit10::form_plane_fast(px, py, pz, plane_tol, plane);
+    if (fast >= 0) ok = fast != 0;
+    else if (EXACT) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+    else {
+      // the QR in place on the coordinate arrays, the ten points fetched again for the accept test: the fall-back does not set the
+      // register budget of the kernel (form_plane keeps 70 doubles alive)
+      double x[3];
+      Fit10::form_plane_solve(px, py, pz, x);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const Point4 t = pd.ref.pt4[id[k]];
+        double l[3];
+        world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
+        px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
+      }
+      ok = Fit10::form_plane_accept(x, px, py, pz, plane_tol, plane);
+      ++n_refused;
+    }
+    if (ok) {
+      double* r = &s_rec[buf][u][0][threadIdx.x];           // straight into this chunk's buffer (the parked chunk sits in the other one)
+      r[0 * 256] = plane[0]; r[1 * 256] = plane[1]; r[2 * 256] = plane[2]; r[3 * 256] = plane[3];
+    }
+    return ok;
+  };
+  // Tickets are drawn ahead by thread 0: the atomic's latency is off the path.  (A software pipeline over the queries — the ten gathers of query k + 1 and the
+  // table row of query k + 2 in flight while query k is fitted — was built for the fast kernel, which waits for those two dependent loads two thirds of its
+  // cycles (SQ_WAIT_ANY 0.66, SIMDs 45 % busy): 100 more live registers, spills inside the loop, 1261 against 931 us per dispatch.  Removed.)
+  int ahead = 0, cur_vid, nxt_vid;
+  if (threadIdx.x == 0) { s_vid = atomicAdd(ticket, 1); s_vid2 = atomicAdd(ticket, 1); ahead = atomicAdd(ticket, 1); }
+  __syncthreads();
+  cur_vid = __builtin_amdgcn_readfirstlane(s_vid); nxt_vid = __builtin_amdgcn_readfirstlane(s_vid2);
+  __syncthreads();
   for (;;) {
-    if (threadIdx.x == 0) { s_vid = next_vid; next_vid = atomicAdd(ticket, 1); }
-    __syncthreads();
-    const int vid = __builtin_amdgcn_readfirstlane(s_vid);
-    __syncthreads();   // s_vid is read before the next round overwrites it
-    if (vid >= total) break;
-    const int pair = vid / chunks_x, chunk = vid - pair * chunks_x;
+    if (cur_vid >= total) break;
+    const int pair = cur_vid / chunks_x, chunk = cur_vid - pair * chunks_x;
     const PairDesc& pd = pairs[pair];
-    if (chunk * PVLM_K3_CHUNK >= pd.nq) continue;
+    const bool live = chunk * PVLM_K3_CHUNK < pd.nq;        // the launch covers chunks_x chunks per pair: a short pair leaves empty ones behind
     bool accept[SUB];
     unsigned long long bal[SUB];
 #pragma unroll 1
     for (int u = 0; u < SUB; ++u) {
-      const int q = chunk * PVLM_K3_CHUNK + u * 256 + (int)threadIdx.x;
-      bool ok = false;
-      if (q < pd.nq) {
-        const long long row = pd.tmp_base + q;
-        int id[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
-        ok = id[9] >= 0;
-        if (ok) {
-          const float qtag = pd.q_tag[q];
-          double px[10], py[10], pz[10], Rt[3];
-          world2local_rt(pd.Rr, pd.tr, Rt);
-          int same = 0;
-#pragma unroll
-          for (int k = 0; k < 10; ++k) {
-            const Point4 t = pd.ref.pt4[id[k]];          // (x, y, z, tag) of the neighbour: one 16-byte gather (round 4: four 4-byte ones)
-            same += (t.w == qtag);
-            double l[3];
-            world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
-            px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
-          }
-          ok = (same == 10);  // :583-591
-          if (ok) {
-            double plane[4];
-            // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
-            // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
-            // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
-            // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
-            // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw — on 65 536-point targets K3 waits for its gathers at two
-            // waves per SIMD, not for the QR; profiles/r4_assoc_variants.txt.)
-            ok = !Fit10::is_line(px, py, pz, 3.0);
-            if (ok) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
-            if (ok) {
-              double pl[3];
-              world2local(pd.Rn, pd.tn, (double)pd.q_xyz[3 * q], (double)pd.q_xyz[3 * q + 1], (double)pd.q_xyz[3 * q + 2], pl);
-              double* r = &s_rec[buf][u][0][threadIdx.x];           // straight into this chunk's buffer (the parked chunk sits in the other one)
-              r[0 * 256] = pl[0]; r[1 * 256] = pl[1]; r[2 * 256] = pl[2]; r[3 * 256] = plane[0]; r[4 * 256] = plane[1]; r[5 * 256] = plane[2]; r[6 * 256] = plane[3];
-            }
-          }
-        }
-      }
+      const bool ok = live && fit(pd, chunk * PVLM_K3_CHUNK + u * 256 + (int)threadIdx.x, u);
       if (u == 0) { accept[0] = ok; bal[0] = __ballot(ok); if (lane == 0) wc[0][wv] = __popcll(bal[0]); }
       else { accept[SUB - 1] = ok; bal[SUB - 1] = __ballot(ok); if (lane == 0) wc[SUB - 1][wv] = __popcll(bal[SUB - 1]); }
     }
+    if (threadIdx.x == 0) { s_vid = ahead; ahead = atomicAdd(ticket, 1); }      // the chunk after the next one
     __syncthreads();
+    cur_vid = nxt_vid; nxt_vid = __builtin_amdgcn_readfirstlane(s_vid);
+    if (!live) { __syncthreads(); continue; }                                     // (s_vid is read before the next round overwrites it)
     int count = 0, rank[SUB];
 #pragma unroll
     for (int u = 0; u < SUB; ++u) {
@@ -414,7 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
     // the chunk's own count is public at once: a first chunk's is its inclusive prefix
     if (threadIdx.x == 0)
       __hip_atomic_store(chain + pd.chunk_base + chunk, (chunk == 0 ? PVLM_CHAIN_INC : PVLM_CHAIN_AGG) | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev_pair >= 0) place();           // ends with a barrier: wc is free
+    if (prev_pair >= 0) place();           // ends with a barrier: wc and s_vid are free
     else __syncthreads();
     prev_pair = pair; prev_chunk = chunk; prev_count = count; prev_buf = buf;
 #pragma unroll
@@ -422,6 +456,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K3_WAV
     buf ^= 1;
   }
   if (prev_pair >= 0) place();
+  if (!EXACT) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_refused += __shfl_xor(n_refused, off, 64);
+    if (lane == 0 && n_refused) atomicAdd(ticket + 1, n_refused);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,9 +584,9 @@ static pvlm_status assoc_ws_ensure(pvlm_ctx* ctx, long long rows, int chunks, in
   pvlm_status st = PVLM_OK;
   for (int s = 0; s < 2 && !st; ++s) {
     if (!st) st = pvlm_i_alloc(ctx, &w.d_nn[s], (size_t)rows * 10);
-    if (!st) st = pvlm_i_alloc(ctx, &w.d_chain[s], (size_t)chunks + (size_t)pairs / 2 + 2);
+    if (!st) st = pvlm_i_alloc(ctx, &w.d_chain[s], (size_t)chunks + (size_t)pairs / 2 + 3);
     if (!st) st = pvlm_i_alloc_bytes(ctx, &w.d_desc[s], (size_t)pairs * sizeof(PairDesc));
-    if (!st && (hipHostMalloc((void**)&w.h_count[s], (size_t)pairs * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+    if (!st && (hipHostMalloc((void**)&w.h_count[s], ((size_t)pairs + 2) * sizeof(int), hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc(&w.h_desc[s], (size_t)pairs * sizeof(PairDesc), hipHostMallocDefault) != hipSuccess ||
                 hipEventCreateWithFlags(&w.ev[s], hipEventDisableTiming) != hipSuccess)) {
       PVLM_SET_ERR(ctx, "association staging: pinned host allocation failed");
@@ -1063,6 +1102,8 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     if (ref[p]->less.grid_stale) { PVLM_SET_ERR(ctx, "pair %d: the reference scan's clouds were transformed without rebuilding their grids (pvlm_scan_transform_batch with rebuild_grids = 0)", p); return PVLM_ERR_STATE; }
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   const bool keep_idx = (flags & 0x100u) != 0;
+  static const bool force_exact = getenv("PVLM_ASSOC_EXACT_FIT") != nullptr;     // A/B runs of hosts that do not pass the flag
+  const bool exact_fit = (flags & PVLM_FLAG_ASSOC_EXACT_FIT) != 0 || force_exact;
 
   pvlm_resset* rs = new (std::nothrow) pvlm_resset();
   if (!rs) return PVLM_ERR_NOMEM;
@@ -1083,6 +1124,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     // a target cloud with fewer than 10 points can never satisfy the k = 10 search
     if (d.ref.n < 10) d.nq = 0;
   }
+  const int k3_chunk = 256 * (exact_fit ? PVLM_K3_SUB : PVLM_K3F_SUB);       // queries per chunk of the plane-fit kernel that will run
   long long budget_rows = 16ll << 20;
   if (const char* env = getenv("PVLM_ASSOC_BATCH_ROWS")) { const long long v = atoll(env); if (v > 0) budget_rows = v; }
   struct Batch { int p0, p1; long long rows; int chunks; int bmax; };
@@ -1094,7 +1136,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
       descs[b.p1].tmp_base = b.rows;
       descs[b.p1].chunk_base = b.chunks;
       b.rows += descs[b.p1].nq;
-      b.chunks += (descs[b.p1].nq + PVLM_K3_CHUNK - 1) / PVLM_K3_CHUNK;
+      b.chunks += (descs[b.p1].nq + k3_chunk - 1) / k3_chunk;
       b.bmax = std::max(b.bmax, descs[b.p1].nq);
       ++b.p1;
     }
@@ -1136,21 +1178,26 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     unsigned long long* d_chain = ws.d_chain[s];
     int* d_count = reinterpret_cast<int*>(d_chain + b.chunks);
     int* d_ticket = d_count + nb;
-    PVLM_HIP(ctx, hipMemsetAsync(d_chain, 0, (size_t)b.chunks * sizeof(unsigned long long) + ((size_t)nb + 1) * sizeof(int), ctx->stream));
+    PVLM_HIP(ctx, hipMemsetAsync(d_chain, 0, (size_t)b.chunks * sizeof(unsigned long long) + ((size_t)nb + 2) * sizeof(int), ctx->stream));   // + ticket, + the count of exact fits
     if (b.bmax > 0) {
       pvlm_prof_scope prof(ctx, 2);
       // (an LDS-staged variant of the search was built and measured in round 2: 35.0 vs 33.6 ms for 134 M queries — the
       // search is bound by instruction issue, not by memory latency; numbers in DESIGN.md, code removed in round 3)
       hipLaunchKernelGGL(k_knn_pairs, dim3((b.bmax + 255) / 256, nb), dim3(256), 0, ctx->stream, d_desc, dist_threshold, ws.d_nn[s], ws.rows);
-      const int chunks_x = (b.bmax + PVLM_K3_CHUNK - 1) / PVLM_K3_CHUNK;
+      const int chunks_x = (b.bmax + k3_chunk - 1) / k3_chunk;
       const long long total = (long long)chunks_x * nb;
       if (total > 0x7fffffffll) { PVLM_SET_ERR(ctx, "association batch too large"); return PVLM_ERR_ARG; }
       static const int k3_blocks = [] { const char* e = getenv("PVLM_K3_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();   // persistent workgroups (two fit per CU)
-      hipLaunchKernelGGL(k_fit_pairs, dim3((unsigned)std::min<long long>(total, k3_blocks)), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.rows, d_block, R, d_chain,
-                         d_count, d_ticket, d_q, d_n, chunks_x, (int)total);
+      static const int k3f_blocks = [] { const char* e = getenv("PVLM_K3F_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 256 * PVLM_K3F_WAVES; }();   // the fast kernel: PVLM_K3F_WAVES workgroups per CU
+      if (exact_fit)
+        hipLaunchKernelGGL((k_fit_pairs<true, PVLM_K3_SUB>), dim3((unsigned)std::min<long long>(total, k3_blocks)), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.rows, d_block, R, d_chain,
+                           d_count, d_ticket, d_q, d_n, chunks_x, (int)total);
+      else
+        hipLaunchKernelGGL((k_fit_pairs<false, PVLM_K3F_SUB>), dim3((unsigned)std::min<long long>(total, k3f_blocks)), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.rows, d_block, R, d_chain,
+                           d_count, d_ticket, d_q, d_n, chunks_x, (int)total);
       PVLM_HIP(ctx, hipGetLastError());
     }
-    PVLM_HIP(ctx, hipMemcpyAsync(ws.h_count[s], d_count, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PVLM_HIP(ctx, hipMemcpyAsync(ws.h_count[s], d_count, ((size_t)nb + 2) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));   // per-pair totals, the ticket, the exact fits
     PVLM_HIP(ctx, hipEventRecord(ws.ev[s], ctx->stream));
     return PVLM_OK;
   };
@@ -1167,6 +1214,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
       block_n += m;
     }
     rs->block_n[(size_t)bi] = block_n;
+    rs->assoc_exact_fits += ws.h_count[s][b.p1 - b.p0 + 1];
     return PVLM_OK;
   };
   const int B = (int)batches.size();
@@ -1181,6 +1229,12 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
   }
   if (st) { hipStreamSynchronize(ctx->stream); pvlm_i_resset_free(ctx, rs); return st; }
   *out = rs;
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_assoc_point2plane_stats(const pvlm_resset* rs, int64_t* exact_fits) {
+  if (!rs) return PVLM_ERR_ARG;
+  if (exact_fits) *exact_fits = rs->assoc_exact_fits;
   return PVLM_OK;
 }
 

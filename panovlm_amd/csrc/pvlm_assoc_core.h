@@ -429,9 +429,18 @@ struct Fit10 {
 
   // pts: 10 x 3 (px[10], py[10], pz[10]).  Returns plane_ok; plane = (n, d).
   static PVLM_HD bool form_plane(const double* px, const double* py, const double* pz, double tol, double* plane) {
-    double c0[10], c1[10], c2[10], b[10];
+    double c0[10], c1[10], c2[10], x[3];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { c0[i] = px[i]; c1[i] = py[i]; c2[i] = pz[i]; b[i] = -1.0; }
+    for (int i = 0; i < 10; ++i) { c0[i] = px[i]; c1[i] = py[i]; c2[i] = pz[i]; }
+    form_plane_solve(c0, c1, c2, x);
+    return form_plane_accept(x, px, py, pz, tol, plane);
+  }
+  // the two halves of form_plane for callers short of registers: the solve works IN PLACE on the three coordinate arrays (destroyed), the accept test
+  // wants the points again (the fast kernel's fall-back gathers them a second time instead of keeping 30 doubles alive across the factorisation)
+  static PVLM_HD void form_plane_solve(double* c0, double* c1, double* c2, double* x) {
+    double b[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) b[i] = -1.0;
     const double eps = DBL_EPSILON;
     double nU0, nU1, nU2, nD0, nD1, nD2;
     {
@@ -481,10 +490,13 @@ struct Fit10 {
     if (nonzero > 2) y2 = b[2] / c2[2];
     if (nonzero > 1) { double s = b[1]; if (nonzero > 2) s -= c2[1] * y2; y1 = s / c1[1]; }
     if (nonzero > 0) { double s = b[0]; if (nonzero > 1) s -= c1[0] * y1; if (nonzero > 2) s -= c2[0] * y2; y0 = s / c0[0]; }
-    double x[3] = {0.0, 0.0, 0.0};
+    x[0] = 0.0; x[1] = 0.0; x[2] = 0.0;
     if (nonzero > 0) { if (p0 == 0) x[0] = y0; else if (p0 == 1) x[1] = y0; else x[2] = y0; }
     if (nonzero > 1) { if (p1 == 0) x[0] = y1; else if (p1 == 1) x[1] = y1; else x[2] = y1; }
     if (nonzero > 2) { if (p2 == 0) x[0] = y2; else if (p2 == 1) x[1] = y2; else x[2] = y2; }
+  }
+  static PVLM_HD bool form_plane_accept(const double* xs, const double* px, const double* py, const double* pz, double tol, double* plane) {
+    double x[3] = {xs[0], xs[1], xs[2]};
     const double len = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     const double d = 1.0 / len;
     if (len * len > 0.0) { x[0] /= len; x[1] /= len; x[2] /= len; }
@@ -498,6 +510,79 @@ struct Fit10 {
     }
     plane[0] = ok ? x[0] : 0.0; plane[1] = ok ? x[1] : 0.0; plane[2] = ok ? x[2] : 0.0; plane[3] = ok ? d : 0.0;
     return ok;
+  }
+
+  // ---- certified fast fit ---------------------------------------------------------------------------------------------------------------
+  // form_plane() above restates Eigen's pivoted Householder QR operation by operation (~1 300 unfused fp64 instructions, 40 live doubles): it
+  // is what makes a record bit-identical to the reference's.  What the reference DECIDES with it is coarser: accept iff every point's distance
+  // |n.p_i + d| <= tol.  form_plane_fast() solves the same least-squares problem min ||A x + 1|| through the 3x3 normal equations (fused
+  // multiply-adds, Cramer + one refinement step), bounds how far ITS solution x and the QR's x_qr can lie apart, and answers only when the
+  // accept / reject decision is the same for every solution inside that bound:
+  //    1  accept (plane filled: unit normal, d), 0 reject, -1 undecided — the caller then runs form_plane(), whose answer stands.
+  //
+  // The bound E >= ||x - x_qr|| = E_fast + E_qr, both distances to x*, the exact minimiser for the given doubles (u = 2^-53, tr = trace A^T A,
+  // P = sqrt(tr) >= ||A||_2 >= max ||p_i||, r_i = x.p_i + 1):
+  //   * E_fast.  For any y, ||y - x*|| <= ||A^T (A y + 1)|| / lambda_min(A^T A).  rho = sum_i p_i r_i is evaluated with fused chains: each r_i
+  //     rounds by at most 3 u (||x|| ||p_i|| + 1) (Higham, Accuracy and Stability, ch. 3) and the ten-term sums by another g10 |p_ij| |r_i| each, so
+  //     ||rho_computed - rho|| <= 40 u P (P ||x|| + 1).                                  E_fast = (||rho|| + 40 u P (P ||x|| + 1)) / lambda_min.
+  //   * E_qr.  Column-pivoted Householder least squares is backward stable (ibid. Theorem 20.3): x_qr minimises ||(A + dA) y + 1 + db|| with
+  //     ||dA_j|| <= G ||a_j||, ||db|| <= G sqrt(10), G = c 30 u for a small integer c (c = 16 taken: G = 480 u), hence ||dA||_2 <= G P and, with
+  //     ||A||_2 >= P / sqrt(3), a relative perturbation eps <= sqrt(3) G < 1024 u of A and of the right-hand side.  Wedin's theorem (ibid. Theorem
+  //     20.1), k = kappa_2(A) <= P / sqrt(lambda_min), k eps <= 1e-2:
+  //         ||x_qr - x*|| <= k eps / (1 - k eps) (2 ||x*|| + (k + 1) ||r*|| / ||A||_2),   ||r*|| <= ||(r_i)|| (x* minimises the residual).
+  //   * lambda_min(A^T A) >= det / e2 for a symmetric positive definite 3x3 matrix, e2 = the sum of its principal 2x2 minors (e2 >= lambda_max
+  //     lambda_mid).  The computed cofactors give det and e2 with a relative error below 10 u tr^3 / det, and the sums M differ from A^T A by at
+  //     most g10 tr in norm; the routine refuses (-1) unless tr^3 <= 5e13 det — both effects are then below 6e-2 — and uses HALF of det / e2.
+  //   Distances: f(y) = max_i |y.p_i + 1| / ||y||.  With e = E / ||x|| (<= 2.5e-7 or the routine refuses: the stored record stays within 5e-7 relative of the QR's):  |f(x_qr) - f(x)| <= (4/3) e (P + f(x)), and the two evaluations
+  //   themselves round by less than 16 u (P + 1/||x||) together (the reference normalises x by three divisions and adds d = 1 / len: 8 u (P + d);
+  //   the fused chain here: 3 u).
+  // tests/test_assoc_core_cpu.py drives this against form_plane() on 2 10^6 neighbourhoods (near and far, random, bisected onto the threshold,
+  // degenerate) and against a __float128 solve: no decided case may differ, ||x - x_qr|| must stay below E and each distance below its share.
+  static PVLM_HD int form_plane_fast(const double* px, const double* py, const double* pz, double tol, double* plane, double* diag = nullptr) {
+    const double U = 1.1102230246251565e-16;
+    double m00 = 0.0, m01 = 0.0, m02 = 0.0, m11 = 0.0, m12 = 0.0, m22 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      m00 = fma(px[i], px[i], m00); m01 = fma(px[i], py[i], m01); m02 = fma(px[i], pz[i], m02);
+      m11 = fma(py[i], py[i], m11); m12 = fma(py[i], pz[i], m12); m22 = fma(pz[i], pz[i], m22);
+      s0 += px[i]; s1 += py[i]; s2 += pz[i];
+    }
+    const double c00 = fma(m11, m22, -(m12 * m12)), c01 = fma(m12, m02, -(m01 * m22)), c02 = fma(m01, m12, -(m11 * m02));
+    const double c11 = fma(m00, m22, -(m02 * m02)), c12 = fma(m01, m02, -(m00 * m12)), c22 = fma(m00, m11, -(m01 * m01));
+    const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
+    const double tr = (m00 + m11) + m22, e2 = (c00 + c11) + c22;
+    if (!(tol > 0.0 && det > 0.0 && e2 > 0.0 && tr < 1e100 && (tr * tr) * tr <= 5e13 * det)) return -1;   // also NaN / inf
+    const double inv = 1.0 / det;
+    double x0 = -(fma(c00, s0, fma(c01, s1, c02 * s2))) * inv, x1 = -(fma(c01, s0, fma(c11, s1, c12 * s2))) * inv, x2 = -(fma(c02, s0, fma(c12, s1, c22 * s2))) * inv;
+    {   // one refinement step on the computed system
+      const double r0 = fma(m00, x0, fma(m01, x1, fma(m02, x2, s0))), r1 = fma(m01, x0, fma(m11, x1, fma(m12, x2, s1))), r2 = fma(m02, x0, fma(m12, x1, fma(m22, x2, s2)));
+      x0 = fma(-(fma(c00, r0, fma(c01, r1, c02 * r2))), inv, x0); x1 = fma(-(fma(c01, r0, fma(c11, r1, c12 * r2))), inv, x1); x2 = fma(-(fma(c02, r0, fma(c12, r1, c22 * r2))), inv, x2);
+    }
+    const double nn = fma(x0, x0, fma(x1, x1, x2 * x2));
+    if (!(nn > 1e-200 && nn < 1e200)) return -1;
+    // residuals r_i, their largest magnitude, their sum of squares and rho = A^T r in one pass
+    double fmx = 0.0, R2 = 0.0, h0 = 0.0, h1 = 0.0, h2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const double r = fma(x0, px[i], fma(x1, py[i], fma(x2, pz[i], 1.0)));
+      fmx = fmax(fmx, fabs(r)); R2 = fma(r, r, R2);
+      h0 = fma(px[i], r, h0); h1 = fma(py[i], r, h1); h2 = fma(pz[i], r, h2);
+    }
+    const double len = sqrt(nn), rn = 1.0 / len, P = sqrt(tr);
+    const double L = (2.0 * e2) * inv;                                        // >= 1 / lambda_min
+    const double k = P * sqrt(L), keps = k * (1024.0 * U);
+    if (!(keps <= 1e-2)) return -1;
+    const double E_fast = (sqrt(fma(h0, h0, fma(h1, h1, h2 * h2))) + (40.0 * U) * P * fma(P, len, 1.0)) * L;
+    const double E_qr = (1.0102 * keps) * fma(2.02, len, (k + 1.0) * sqrt(3.0 * R2 / tr) * 1.0001);
+    const double E = E_fast + E_qr;
+    const double e = E * rn;
+    if (!(e <= 2.5e-7)) return -1;                                            // the accepted RECORD (x / ||x||, 1 / ||x||) is then within 5e-7 relative of the QR's (the bar is 1e-6); also keeps ||x*|| <= 1.01 ||x|| as E_qr assumed
+    const double f = fmx * rn;
+    const double B = (4.0 / 3.0) * e * (P + f) + (16.0 * U) * (P + rn);
+    if (diag) { diag[0] = x0; diag[1] = x1; diag[2] = x2; diag[3] = E; diag[4] = f; diag[5] = B; diag[6] = E_fast; diag[7] = E_qr; }
+    if (f + B <= tol) { plane[0] = x0 * rn; plane[1] = x1 * rn; plane[2] = x2 * rn; plane[3] = rn; return 1; }
+    if (f - B > tol) { plane[0] = 0.0; plane[1] = 0.0; plane[2] = 0.0; plane[3] = 0.0; return 0; }
+    return -1;
   }
 
   // Closed-form screen of the collinearity decision.  The eigenvalues of the symmetric 3x3 scatter matrix by the trigonometric

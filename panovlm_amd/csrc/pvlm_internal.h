@@ -154,6 +154,7 @@ struct pvlm_resset {
   std::vector<int32_t*> d_qidx;  // rows of the block
   std::vector<int32_t*> d_nn;    // rows x 10
   std::vector<int64_t> block_n;  // accepted rows of the block
+  int64_t assoc_exact_fits = 0;  // queries of the association whose plane came from the exact QR because the certified fast fit refused (0 with PVLM_FLAG_ASSOC_EXACT_FIT)
 };
 
 struct pvlm_neq {

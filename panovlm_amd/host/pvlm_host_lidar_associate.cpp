@@ -96,7 +96,9 @@ std::vector<Point2Plane> AssociatePoint2Plane(const Velodyne& ref, const Velodyn
   Engine& e = Engine::Default();
   pvlm_scan* r = ref.DeviceScan(); pvlm_scan* n = nei.DeviceScan();
   pvlm_resset* rs = nullptr;
-  e.Check(pvlm_assoc_point2plane(e.ctx(), 1, &r, &n, plane_tolerance, dist_threshold, PVLM_POINT2PLANE_METER, 0, 1.0, &rs), "pvlm_assoc_point2plane");
+  // the one-pair form hands the records to the caller, as the reference's function does: the reference's own QR for every query
+  // (PVLM_FLAG_ASSOC_EXACT_FIT — records bit-identical to the reference's); the adders, whose records stay on the device, use the certified fast fit
+  e.Check(pvlm_assoc_point2plane(e.ctx(), 1, &r, &n, plane_tolerance, dist_threshold, PVLM_POINT2PLANE_METER, PVLM_FLAG_ASSOC_EXACT_FIT, 1.0, &rs), "pvlm_assoc_point2plane");
   int64_t m = 0;
   pvlm_resset_info(rs, &m, nullptr, nullptr, nullptr);
   std::vector<double> rows((size_t)std::max<int64_t>(m, 1) * 7);

@@ -173,4 +173,48 @@ long long chk_line_sweeps(const double* pts, int m, double line_tol, int screen,
   return total;
 }
 
+// the certified fast fit (Fit10::form_plane_fast) against the exact path on m 10-point sets.  Per set, out8 = [decision of the fast fit (1 / 0 / -1),
+// decision of form_plane, E (its bound on ||x - x_qr||), ||x - x_qr|| measured, ||x - x_ref|| and ||x_qr - x_ref|| against a __float128 solve of the
+// normal equations (only when quad != 0; else 0), B (its bound on the distance), |max distance of the fast fit - max distance the exact path evaluates|].
+// With quad, out8[2] / out8[6] are replaced by the two shares E_fast / E_qr of the bound.  Returns the number of sets where a DECIDED fast answer differs from form_plane's (must be 0).
+long long chk_fit_fast(const double* pts, int m, double tol, int quad, double* out8, double* plane_fast) {
+  long long wrong = 0;
+  for (int s = 0; s < m; ++s) {
+    double px[10], py[10], pz[10];
+    for (int i = 0; i < 10; ++i) { px[i] = pts[(size_t)s * 30 + 3 * i]; py[i] = pts[(size_t)s * 30 + 3 * i + 1]; pz[i] = pts[(size_t)s * 30 + 3 * i + 2]; }
+    double* o = out8 + 8 * (size_t)s;
+    for (int k = 0; k < 8; ++k) o[k] = 0.0;
+    double pf[4] = {0, 0, 0, 0}, pe[4], pall[4], diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int fast = Fit10::form_plane_fast(px, py, pz, tol, pf, diag);
+    const bool exact = Fit10::form_plane(px, py, pz, tol, pe);
+    o[0] = fast; o[1] = exact ? 1 : 0;
+    if (plane_fast) for (int k = 0; k < 4; ++k) plane_fast[4 * (size_t)s + k] = fast == 1 ? pf[k] : pe[k];
+    if (fast >= 0 && fast != (exact ? 1 : 0)) ++wrong;
+    if (fast < 0 && diag[3] == 0.0) continue;                               // refused before a solution existed
+    Fit10::form_plane(px, py, pz, 1e300, pall);                             // the QR's plane whatever the tolerance: x_qr = n / d
+    if (!(pall[3] > 0.0)) continue;
+    const double xq[3] = {pall[0] / pall[3], pall[1] / pall[3], pall[2] / pall[3]};
+    o[2] = diag[3];
+    o[3] = std::sqrt((diag[0] - xq[0]) * (diag[0] - xq[0]) + (diag[1] - xq[1]) * (diag[1] - xq[1]) + (diag[2] - xq[2]) * (diag[2] - xq[2]));
+    double dmax = 0.0;
+    for (int i = 0; i < 10; ++i) dmax = std::max(dmax, std::fabs((pall[0] * px[i] + pall[1] * py[i]) + pall[2] * pz[i] + pall[3]));
+    o[6] = diag[5]; o[7] = std::fabs(diag[4] - dmax);
+    if (quad) {
+      __float128 M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, sv[3] = {0, 0, 0};
+      for (int i = 0; i < 10; ++i) {
+        const __float128 p[3] = {px[i], py[i], pz[i]};
+        for (int a = 0; a < 3; ++a) { sv[a] += p[a]; for (int b = 0; b < 3; ++b) M[a][b] += p[a] * p[b]; }
+      }
+      const __float128 c00 = M[1][1] * M[2][2] - M[1][2] * M[1][2], c01 = M[1][2] * M[0][2] - M[0][1] * M[2][2], c02 = M[0][1] * M[1][2] - M[1][1] * M[0][2];
+      const __float128 c11 = M[0][0] * M[2][2] - M[0][2] * M[0][2], c12 = M[0][1] * M[0][2] - M[0][0] * M[1][2], c22 = M[0][0] * M[1][1] - M[0][1] * M[0][1];
+      const __float128 det = M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02;
+      const __float128 xr[3] = {-(c00 * sv[0] + c01 * sv[1] + c02 * sv[2]) / det, -(c01 * sv[0] + c11 * sv[1] + c12 * sv[2]) / det, -(c02 * sv[0] + c12 * sv[1] + c22 * sv[2]) / det};
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < 3; ++k) { const double d1 = (double)((__float128)diag[k] - xr[k]), d2 = (double)((__float128)xq[k] - xr[k]); a += d1 * d1; b += d2 * d2; }
+      o[4] = std::sqrt(a); o[5] = std::sqrt(b); o[2] = diag[6]; o[6] = diag[7];
+    }
+  }
+  return wrong;
+}
+
 }  // extern "C"

@@ -23,6 +23,7 @@ def chk(tmp_path_factory):
     lib = ctypes.CDLL(out)
     lib.chk_knn.restype = ctypes.c_int
     lib.chk_line_sweeps.restype = ctypes.c_longlong
+    lib.chk_fit_fast.restype = ctypes.c_longlong
     return lib
 
 
@@ -216,3 +217,103 @@ def test_closed_form_screen_accuracy_and_fallback_band(chk):
     assert np.array_equal(dec[decided] == 1, margin[decided] > 0)          # never wrong
     assert np.all(np.abs(margin[~decided]) < 1.1e-5)                        # undecided only inside the guard band ...
     assert np.all(decided[np.abs(margin) > 1.1e-5])                         # ... and always decided outside it
+
+
+def _fit_fast(lib, pts, tol, quad=False):
+    pts = np.ascontiguousarray(pts, np.float64)
+    out = np.zeros((len(pts), 8)); plane = np.zeros((len(pts), 4))
+    wrong = lib.chk_fit_fast(_p(pts, ctypes.c_double), len(pts), ctypes.c_double(tol), 1 if quad else 0, _p(out, ctypes.c_double), _p(plane, ctypes.c_double))
+    return wrong, out, plane
+
+
+def _planar_sets(rng, m, tol, near_threshold=False, far=False):
+    """Neighbourhoods like the association sees them: a patch of spread 0.1-0.6 m at 1-40 m (far: up to 300 m) from the sensor, out-of-plane noise
+    drawn so that the largest distance lands anywhere from well inside to well outside the tolerance (near_threshold: within 1e-6 relative of it)."""
+    c = rng.normal(size=(m, 3)); c /= np.linalg.norm(c, axis=1, keepdims=True)
+    c *= rng.uniform(1.0, 300.0 if far else 40.0, size=(m, 1))
+    B = np.linalg.qr(rng.normal(size=(m, 3, 3)))[0]
+    spread = rng.uniform(0.1, 0.6, size=(m, 1, 1)) * np.array([1.0, 1.0, 0.0]) * rng.uniform(0.6, 1.0, size=(m, 1, 3))
+    local = rng.normal(size=(m, 10, 3)) * spread
+    noise = rng.normal(size=(m, 10)) * tol * rng.uniform(0.0, 1.2, size=(m, 1))
+    if near_threshold:       # scale the noise so that the exact fit's largest distance sits within ~1e-7 .. 1e-12 of the tolerance
+        noise = rng.normal(size=(m, 10)) * tol * 0.4
+    local[:, :, 2] = noise
+    return c[:, None, :] + np.einsum("mij,mkj->mik", local, B)
+
+
+def test_certified_fast_fit_takes_the_exact_fits_decisions(chk):
+    """Fit10::form_plane_fast (normal equations + an a-posteriori bound; the default of K3) against Fit10::form_plane (the reference's pivoted
+    Householder QR restated; base/Geometry.hpp:345-373, lidar_mapping/LidarFeatureAssociate.cpp:592-602): wherever the fast fit answers, the answer is
+    the exact path's; it answers almost always; the distance between the two solutions stays under the bound E it computed; the accepted planes agree
+    to 5e-7 relative by construction, 1e-11 typically (that is the record the residual set stores; the bar of the path is 1e-6)."""
+    rng = np.random.default_rng(31)
+    total = decided = 0
+    worst_ratio = 0.0
+    for tol in (0.05, 0.01):
+        for far in (False, True):
+            pts = _planar_sets(rng, 400_000, tol, far=far)
+            wrong, out, plane = _fit_fast(chk, pts, tol)
+            assert wrong == 0
+            have = out[:, 2] > 0
+            assert np.all(out[have, 3] <= out[have, 2]), "||x - x_qr|| above the bound E"
+            assert np.all(out[have, 7] <= out[have, 6] + 1e-300), "distance bound B violated"
+            worst_ratio = max(worst_ratio, float((out[have, 3] / out[have, 2]).max()))
+            dec = out[:, 0] >= 0
+            if not far:                                                                # beyond 40 m at grazing incidence the systems are refused (condition cap): correct, just not fast
+                total += len(pts); decided += int(dec.sum())
+            acc = out[:, 0] == 1
+            assert 0.15 < acc.mean() < 0.95 and (out[:, 0] == 0).mean() > 0.03        # both answers exercised
+            # accepted records: unit normal + d against the exact path's, relative to the record's size
+            _, exact_plane, _ = _fits(chk, pts[acc][:50_000], tol, 3.0)
+            rel = np.abs(plane[acc][:50_000] - exact_plane) / np.maximum(1.0, np.abs(exact_plane).max(axis=1, keepdims=True))
+            assert rel.max() <= 5e-7 and np.median(rel.max(axis=1)) <= 1e-11, (rel.max(), np.median(rel.max(axis=1)))   # guaranteed (e <= 2.5e-7) / typical
+    assert decided >= 0.98 * total, (decided, total)                               # up to 40 m at random incidence; indoor ranges: > 0.9999 (bench.py reports the rate)
+    assert worst_ratio < 0.2, worst_ratio                                          # the bound has room (it is built from worst-case constants)
+    # the sets of the collinearity / degeneracy tests: lines, blobs, exactly coplanar lattices (rank-deficient systems are refused, never decided wrongly)
+    pts = _point_sets(rng, 60_000)
+    for tol in (0.05, 0.01):
+        wrong, out, _ = _fit_fast(chk, pts, tol)
+        assert wrong == 0
+        have = out[:, 2] > 0
+        assert np.all(out[have, 3] <= out[have, 2])
+
+
+def test_certified_fast_fit_near_the_tolerance_and_against_quad_precision(chk):
+    """Largest distance within a hair of the tolerance: the fast fit must refuse (or be right).  And both solutions against a __float128 solve of the
+    normal equations: each lies within the share of the bound the derivation gives it."""
+    rng = np.random.default_rng(32)
+    tol = 0.05
+    base = _planar_sets(rng, 20_000, tol, near_threshold=True)
+    # bisect a scale of the out-of-plane component (about the centroid plane of the exact fit) so that the exact path flips between accept and reject
+    sets = []
+    for P in base[:3000]:
+        c = P.mean(0)
+        _, _, Vt = np.linalg.svd(P - c)
+        n = Vt[2]
+        h = (P - c) @ n
+        lo, hi = 0.0, 8.0
+        flat = P - np.outer(h, n)
+        f = lambda a: _fits(chk, (flat + np.outer(h * a, n))[None], tol, 3.0)[0][0]
+        if not f(lo) or f(hi):
+            continue
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            if f(mid):
+                lo = mid
+            else:
+                hi = mid
+        for a in (lo, hi, lo * (1 - 1e-12), hi * (1 + 1e-12), lo * (1 - 1e-9), hi * (1 + 1e-9), lo * (1 - 1e-6), hi * (1 + 1e-6), lo * (1 - 1e-3), hi * (1 + 1e-3)):
+            sets.append(flat + np.outer(h * a, n))
+    sets = np.array(sets)
+    assert len(sets) > 10000
+    wrong, out, _ = _fit_fast(chk, sets, tol)
+    assert wrong == 0
+    undecided = (out[:, 0] < 0).reshape(-1, 10).mean(0)
+    assert undecided[0] > 0.99 and undecided[1] > 0.99 and undecided[6] < 0.7 and undecided[8] < 0.03, undecided   # at the flip: refused; 1e-6 away: half answered again; 1e-3 away: answered
+    # quad-precision reference
+    pts = _planar_sets(rng, 30_000, tol, far=True)
+    wrong, out, _ = _fit_fast(chk, pts, tol, quad=True)
+    assert wrong == 0
+    have = out[:, 2] > 0
+    assert np.all(out[have, 4] <= out[have, 2]) and np.all(out[have, 5] <= out[have, 6]), "a distance to the exact minimiser exceeds its share of the bound"
+    assert (out[have, 4] / out[have, 2]).max() < 0.2 and (out[have, 5] / out[have, 6]).max() < 0.05       # with room: the shares are built from worst-case constants

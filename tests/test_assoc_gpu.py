@@ -1,6 +1,9 @@
 """GPU parity of the association kernels (voxel-hash k-NN, plane fit + accept tests, ordered
 compaction, line votes) against the CPU oracle through the C ABI.  Bar: correspondence indices
-bit-exact; fp64 records bit-exact too (same arithmetic, no FMA contraction in these kernels)."""
+bit-exact in both modes of the plane fit; fp64 records bit-exact with PVLM_FLAG_ASSOC_EXACT_FIT (the
+reference's QR restated, no FMA contraction), and within 1e-6 relative in the default mode, where the
+plane comes from the certified fast fit (csrc/pvlm_assoc_core.h: form_plane_fast — its bound keeps the
+record within 5e-7 of the QR's; observed ~1e-11) and only the accept / reject DECISION is the QR's."""
 import numpy as np
 import pytest
 
@@ -9,6 +12,15 @@ from tests import synth
 
 pytestmark = pytest.mark.gpu
 KEEP = 0x100
+EXACT = 0x200
+
+
+def same_planes(got, want, exact):
+    """rows[:, 3:7] of a residual set against the oracle's planes: bit for bit in exact mode, 1e-6 of the record's size otherwise (observed 1e-11)."""
+    if exact:
+        return np.array_equal(got, want, equal_nan=True)
+    scale = np.maximum(1.0, np.abs(want).max(axis=1, keepdims=True)) if len(want) else 1.0
+    return bool(np.all(np.abs(got - want) <= 1e-6 * scale))
 
 
 @pytest.fixture(scope="module")
@@ -54,10 +66,16 @@ def test_knn_vlp_geometry_and_ties(ctx, oracle):
 
 
 def _compare_assoc(ctx, oracle, scans, pairs, tol, thr):
+    return [_compare_assoc_mode(ctx, oracle, scans, pairs, tol, thr, exact) for exact in (True, False)][0]
+
+
+def _compare_assoc_mode(ctx, oracle, scans, pairs, tol, thr, exact):
     import panovlm_amd as pv
     dev = {k: pv.Scan(ctx, s) for k, s in scans.items()}
     rs = ctx.assoc_point2plane([dev[r] for r, _ in pairs], [dev[n] for _, n in pairs], tol, thr,
-                               kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE | KEEP)
+                               kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE | KEEP | (EXACT if exact else 0))
+    assert exact or rs.assoc_exact_fits() <= 0.02 * max(rs.n, 50), (rs.assoc_exact_fits(), rs.n)      # the fast fit answers almost always
+    assert not exact or rs.assoc_exact_fits() == 0
     off, ref, nei, rows = rs.download()
     qidx, nn = rs.assoc_debug()
     assert list(ref) == [scans[r]["id"] for r, _ in pairs] and list(nei) == [scans[n]["id"] for _, n in pairs]
@@ -69,7 +87,7 @@ def _compare_assoc(ctx, oracle, scans, pairs, tol, thr):
         assert np.array_equal(qidx[s:e], o["qidx"])
         assert np.array_equal(nn[s:e], o["nn"])
         assert np.array_equal(rows[s:e, 0:3], o["point"]), np.abs(rows[s:e, 0:3] - o["point"]).max()
-        assert np.array_equal(rows[s:e, 3:7], o["plane"]), np.abs(rows[s:e, 3:7] - o["plane"]).max()
+        assert same_planes(rows[s:e, 3:7], o["plane"], exact), np.abs(rows[s:e, 3:7] - o["plane"]).max()
         total += e - s
     assert rs.n == total
     rs.close()

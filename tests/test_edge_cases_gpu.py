@@ -91,13 +91,16 @@ def test_association_with_coincident_and_collinear_targets(ctx, oracle):
     qs = np.concatenate([b["flat_xyz"], tg[:5] + np.float32(0.001), line[10:20].astype(np.float32) + np.float32(0.002)])
     b["flat_xyz"] = qs; b["flat_tag"] = np.ones(len(qs), np.float32)
     da, db = pv.Scan(ctx, a), pv.Scan(ctx, b)
-    rs = ctx.assoc_point2plane([da], [db], 0.05, 1.0, flags=0x101)
-    off, _, _, rows = rs.download()
-    qidx, nn = rs.assoc_debug()
+    from tests.test_assoc_gpu import same_planes
     o = oracle.assoc_point2plane(a, b, 0.05, 1.0)
-    assert np.array_equal(qidx, o["qidx"]) and np.array_equal(nn, o["nn"])
-    assert np.array_equal(rows[:, :3], o["point"]) and np.array_equal(rows[:, 3:], o["plane"], equal_nan=True)
-    assert np.all(np.isfinite(rows))
+    for exact in (True, False):           # the reference's QR for every query / the certified fast fit (which must refuse the rank-deficient systems)
+        rs = ctx.assoc_point2plane([da], [db], 0.05, 1.0, flags=0x101 | (0x200 if exact else 0))
+        off, _, _, rows = rs.download()
+        qidx, nn = rs.assoc_debug()
+        assert np.array_equal(qidx, o["qidx"]) and np.array_equal(nn, o["nn"])
+        assert np.array_equal(rows[:, :3], o["point"]) and same_planes(rows[:, 3:], o["plane"], exact)
+        assert np.all(np.isfinite(rows))
+        rs.close()
 
 
 def test_votes_with_empty_inputs(ctx):

@@ -49,8 +49,11 @@ def test_property_checker_on_the_oracle(oracle):
 
 
 @pytest.mark.gpu
-def test_full_size_association_and_evaluation(oracle):
+@pytest.mark.parametrize("exact", [True, False], ids=["exact_qr", "certified_fast_fit"])
+def test_full_size_association_and_evaluation(oracle, exact):
     import panovlm_amd as pv
+    from tests.test_assoc_gpu import same_planes
+    mode = 0x200 if exact else 0
     ctx = pv.Context(0)
     rng = np.random.default_rng(4)
     scans = {k: sy.make_scan(k, cols=4096) for k in (0, 1)}
@@ -59,7 +62,7 @@ def test_full_size_association_and_evaluation(oracle):
     pairs = [(0, 1), (1, 0)]
     for tol in (0.05, 0.01):                                                                    # Room and Floor tolerances
         rs = ctx.assoc_point2plane([dev[r] for r, _ in pairs], [dev[n] for _, n in pairs], tol, 1.0, kind=pv.POINT2PLANE_ANGLE,
-                                   flags=pv.FLAG_NORMALIZE_DISTANCE | KEEP)
+                                   flags=pv.FLAG_NORMALIZE_DISTANCE | KEEP | mode)
         off, ref, nei, rows = rs.download()
         qidx, nn = rs.assoc_debug()
         for p, (r, n) in enumerate(pairs):
@@ -82,12 +85,12 @@ def test_full_size_association_and_evaluation(oracle):
     sub = dict(scans[1]); sub["id"] = 5
     sub["flat_xyz"] = scans[1]["flat_xyz"][::32]; sub["flat_tag"] = scans[1]["flat_tag"][::32]
     dsub = pv.Scan(ctx, sub)
-    rs = ctx.assoc_point2plane([dev[0]], [dsub], 0.05, 1.0, kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE | KEEP)
+    rs = ctx.assoc_point2plane([dev[0]], [dsub], 0.05, 1.0, kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE | KEEP | mode)
     _, _, _, rows = rs.download()
     q, nn = rs.assoc_debug()
     o = oracle.assoc_point2plane(scans[0], sub, 0.05, 1.0)
     assert len(o["qidx"]) > 100 and np.array_equal(q, o["qidx"]) and np.array_equal(nn, o["nn"])
-    assert np.array_equal(rows[:, 0:3], o["point"]) and np.array_equal(rows[:, 3:7], o["plane"])
+    assert np.array_equal(rows[:, 0:3], o["point"]) and same_planes(rows[:, 3:7], o["plane"], exact)
     off, fq, fnn, frows = full
     sel = np.nonzero(fq[off[0]:off[1]] % 32 == 0)[0]
     assert np.array_equal(fq[off[0]:off[1]][sel] // 32, q) and np.array_equal(fnn[off[0]:off[1]][sel], nn)

@@ -38,13 +38,15 @@ def test_assoc_point2plane_golden(ctx):
     import panovlm_amd as pv
     g = load("assoc_point2plane.npz")
     dev = {k: pv.Scan(ctx, _scan(g, k)) for k in (0, 1, 2)}
+    from tests.test_assoc_gpu import same_planes
     for i, (r, n, tol, thr) in enumerate(g["cases"]):
-        rs = ctx.assoc_point2plane([dev[int(r)]], [dev[int(n)]], float(tol), float(thr), flags=0x101)
-        off, ref, nei, rows = rs.download()
-        qidx, nn = rs.assoc_debug()
-        assert np.array_equal(qidx, g["c%d_qidx" % i]) and np.array_equal(nn, g["c%d_nn" % i])
-        assert np.array_equal(rows[:, :3], g["c%d_point" % i]) and np.array_equal(rows[:, 3:], g["c%d_plane" % i])
-        rs.close()
+        for exact in (True, False):        # PVLM_FLAG_ASSOC_EXACT_FIT: bit for bit; default (certified fast fit): same correspondences, planes to 1e-6
+            rs = ctx.assoc_point2plane([dev[int(r)]], [dev[int(n)]], float(tol), float(thr), flags=0x101 | (0x200 if exact else 0))
+            off, ref, nei, rows = rs.download()
+            qidx, nn = rs.assoc_debug()
+            assert np.array_equal(qidx, g["c%d_qidx" % i]) and np.array_equal(nn, g["c%d_nn" % i])
+            assert np.array_equal(rows[:, :3], g["c%d_point" % i]) and same_planes(rows[:, 3:], g["c%d_plane" % i], exact)
+            rs.close()
 
 
 def test_equirect_golden(ctx):

@@ -16,7 +16,7 @@ for tg in ${TARGETS:-voxel raw}; do
     python - "$f" $tg $v@$sc >> $out <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-pick = lambda n: next((float(r["AverageNs"]) / 1e3 for r in rows if r["Name"].startswith(n)), float("nan"))
+pick = lambda n: next((float(r["AverageNs"]) / 1e3 for r in rows if n in r["Name"]), float("nan"))
 print("%-6s %-14s knn_us %9.1f fit_us %9.1f compact_us %8.1f" % (sys.argv[2], sys.argv[3], pick("k_knn_pairs"), pick("k_fit_pairs"), pick("k_compact")))
 PY
    done

@@ -20,25 +20,28 @@ def main():
     ap.add_argument("--targets", choices=["voxel", "raw"], default="voxel")
     ap.add_argument("--tolerance", type=float, default=0.05)
     ap.add_argument("--calls", type=int, default=3)
+    ap.add_argument("--exact", action="store_true", help="PVLM_FLAG_ASSOC_EXACT_FIT: the reference's QR for every query")
     a = ap.parse_args()
     from panovlm_amd import synthetic as sy
     ref, nei = sy.pair_list(a.scans, a.neighbors)
     scans = bench.generate_scans(range(a.scans), a.cols, 0.2 if a.targets == "voxel" else 0.0)
     import panovlm_amd as pv
     ctx = pv.Context(0)
-    ds = {k: pv.Scan(ctx, s) for k, s in scans.items()}
+    keys = sorted(scans)
+    ds = dict(zip(keys, pv.Scan.upload_batch(ctx, [scans[k] for k in keys])))
     nq = int(sum(len(scans[int(n)]["flat_xyz"]) for n in nei)); nt = int(sum(len(scans[int(r)]["less_xyz"]) for r in ref))
     walls, acc = [], 0
     for _ in range(a.calls):
         ctx.synchronize()
         t0 = time.perf_counter()
         rs = ctx.assoc_point2plane([ds[int(r)] for r in ref], [ds[int(n)] for n in nei], a.tolerance, 1.0, kind=pv.POINT2PLANE_ANGLE,
-                                   flags=pv.FLAG_NORMALIZE_DISTANCE)
+                                   flags=pv.FLAG_NORMALIZE_DISTANCE | (pv.FLAG_ASSOC_EXACT_FIT if a.exact else 0))
         ctx.synchronize()
         walls.append(time.perf_counter() - t0)
         acc = rs.n
+        exact_fits = rs.assoc_exact_fits()
         rs.close()
-    print(json.dumps({"scans": a.scans, "pairs": int(len(ref)), "queries": nq, "targets": nt, "accepted": int(acc), "calls": a.calls, "targets_kind": a.targets,
+    print(json.dumps({"scans": a.scans, "pairs": int(len(ref)), "queries": nq, "targets": nt, "accepted": int(acc), "calls": a.calls, "targets_kind": a.targets, "exact_mode": bool(a.exact), "queries_refused_by_the_fast_fit": exact_fits,
                       "wall_s": walls}))
 
 
