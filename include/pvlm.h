@@ -270,6 +270,13 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
  * SPARSE_SCHUR for 50 < lidars <= 2000, util/Optimization.cpp:641-658), *update_fraction = its tile updates / those of the dense
  * factorisation.  Systems under 1500 unknowns, or whose fraction exceeds 0.6, keep the natural order and the dense kernels. */
 pvlm_status pvlm_spd_plan_info(const pvlm_ctx* ctx, int* tile_sparse, double* update_fraction);
+/* The schedule of that factorisation.  From 1500 unknowns on the pose graph is ordered by NESTED DISSECTION (recursive bisection by breadth-first level sets; the
+ * halves first, the separator last; every group aligned to a 64-row tile by identity rows) and the block columns are factorised LEVEL by level: the columns of a level
+ * do not depend on each other — one launch factorises them all, one launch applies their trailing updates (a workgroup per target tile, sources added in list order:
+ * bit-reproducible), the triangular solves run level by level too.  *levels = dependent steps (0: the column-by-column factorisation is in use — small systems,
+ * PVLM_SPD_LEVELS=0, or a graph whose schedule is not shorter than two thirds of its block columns), *block_columns = block columns of the (padded) system,
+ * *padded_rows = its rows.  The reference leaves this to Ceres' SPARSE_SCHUR (util/Optimization.cpp:638-666).  Any pointer may be NULL. */
+pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_columns, int* padded_rows);
 
 /* ---- multi-GPU exchange (RCCL over xGMI) -------------------------------------------------------- *
  * The reference is single-process (OpenMP only); sharding scan pairs across GPUs introduces exactly one

@@ -87,9 +87,12 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, int 
   const bool live = row < n && c < kb;
   As[lr][c] = live ? M[(size_t)row * n + k0 + c] : 0.0;
   __syncthreads();
-  double x = 0.0;
-  for (int d = 0; d <= c; ++d) x += As[lr][d] * inv[c][d];
-  if (live) M[(size_t)row * n + k0 + c] = x;
+#pragma unroll
+  for (int sub = 0; sub < SUBS; ++sub) {
+    double x = 0.0;
+    for (int d = 0; d <= c; ++d) x += As[8 * sub + lr][d] * inv[c][d];
+    if (lives[sub]) M[(size_t)rows[sub] * n + k0 + c] = x;
+  }
 }
 #endif  // PVLM_MEASURED_VARIANTS
 
@@ -124,12 +127,15 @@ __device__ __forceinline__ double bcast_f64(double v, int src_lane) {     // v o
 // subtracts L[j, k] y_k from the rows below (k_chol_fwd_rows): the 171 k_fwd_step launches of round 1 disappear.
 // row_tiles != nullptr (the tile-sparse factorisation below): workgroup g handles rows 8 (g & 7) .. + 8 of the 64-row tile
 // row_tiles[g >> 3] — only the tiles that hold a nonzero of this block column — instead of the g-th group of 8 rows below the block.
-__global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M, int n, int k0, int kb, double* __restrict__ Linv, int* __restrict__ info,
-                                                         int* __restrict__ fail_out, const double* __restrict__ fwd_b, double* __restrict__ fwd_y,
-                                                         const int* __restrict__ row_tiles, int n_row_tiles) {
+// SUBS: groups of 8 panel rows a workgroup multiplies by the inverse (1: eight rows — the fewest rows behind the chain, right for a handful of workgroups; 8: a whole
+// 64-row tile — an eighth of the workgroups, each of which repeats the 32-pivot chain: a level of forty leaf columns has 13 000 eight-row groups)
+template <int SUBS>
+__device__ __forceinline__ void chol_diag_panel_body(double* __restrict__ M, int n, int k0, int kb, double* __restrict__ Linv, int* __restrict__ info,
+                                                     int* __restrict__ fail_out, const double* __restrict__ fwd_b, double* __restrict__ fwd_y,
+                                                     const int* __restrict__ row_tiles, int n_row_tiles, const unsigned wg) {
   __shared__ double a[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
   __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
-  __shared__ double As[8][PVLM_CHOL_NB + 1];
+  __shared__ double As[8 * SUBS][PVLM_CHOL_NB + 1];
   __shared__ int fail;
   if (*info != 0) return;
   const unsigned long long ck0 = CHOL_NOW();
@@ -151,11 +157,20 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
     }
   }
   const int lr = t / PVLM_CHOL_NB, c = t % PVLM_CHOL_NB;
-  int row = k0 + kb + blockIdx.x * 8 + lr;
-  if (row_tiles) row = (int)(blockIdx.x >> 3) < n_row_tiles ? row_tiles[blockIdx.x >> 3] * 64 + (int)(blockIdx.x & 7) * 8 + lr : n;
-  const bool live = row >= k0 + kb && row < n && c < kb;
-  const double a_row = M[(size_t)min(max(row, 0), n - 1) * n + k0 + min(c, kb - 1)];
-  As[lr][c] = live ? a_row : 0.0;
+  int rows[SUBS]; bool lives[SUBS];
+  {
+    double a_row[SUBS];
+#pragma unroll
+    for (int sub = 0; sub < SUBS; ++sub) {
+      const unsigned unit = wg * SUBS + sub;                 // which group of 8 rows
+      int row = k0 + kb + unit * 8 + lr;
+      if (row_tiles) row = (int)(unit >> 3) < n_row_tiles ? row_tiles[unit >> 3] * 64 + (int)(unit & 7) * 8 + lr : n;
+      rows[sub] = row; lives[sub] = row >= k0 + kb && row < n && c < kb;
+      a_row[sub] = M[(size_t)min(max(row, 0), n - 1) * n + k0 + min(c, kb - 1)];
+    }
+#pragma unroll
+    for (int sub = 0; sub < SUBS; ++sub) As[8 * sub + lr][c] = lives[sub] ? a_row[sub] : 0.0;
+  }
   __syncthreads();
   const unsigned long long ck1 = CHOL_NOW();
   if (t < 64) {
@@ -220,8 +235,8 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
   }
   __syncthreads();
   const unsigned long long ck2 = CHOL_NOW();
-  if (fail) { if (t == 0 && blockIdx.x == 0) { *fail_out = k0 + fail; } return; }
-  if (blockIdx.x == 0) {
+  if (fail) { if (t == 0 && wg == 0) { *fail_out = k0 + fail; } return; }
+  if (wg == 0) {
     double* Lk = Linv + (size_t)(k0 / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
     for (int e = t; e < PVLM_CHOL_NB * PVLM_CHOL_NB; e += 256) Lk[e] = inv[e / PVLM_CHOL_NB][e % PVLM_CHOL_NB];
     if (fwd_b && t < kb) {
@@ -230,10 +245,28 @@ __global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M,
       fwd_y[k0 + t] = sacc;
     }
   }
-  double x = 0.0;
-  for (int d = 0; d <= c; ++d) x += As[lr][d] * inv[c][d];
-  if (live) M[(size_t)row * n + k0 + c] = x;
+#pragma unroll
+  for (int sub = 0; sub < SUBS; ++sub) {
+    double x = 0.0;
+    for (int d = 0; d <= c; ++d) x += As[8 * sub + lr][d] * inv[c][d];
+    if (lives[sub]) M[(size_t)rows[sub] * n + k0 + c] = x;
+  }
   CHOL_ADD(0, ck1 - ck0); CHOL_ADD(1, ck2 - ck1); CHOL_ADD(2, CHOL_NOW() - ck2); CHOL_ADD(3, 1);
+}
+
+__global__ __launch_bounds__(256) void k_chol_diag_panel(double* __restrict__ M, int n, int k0, int kb, double* __restrict__ Linv, int* __restrict__ info,
+                                                         int* __restrict__ fail_out, const double* __restrict__ fwd_b, double* __restrict__ fwd_y,
+                                                         const int* __restrict__ row_tiles, int n_row_tiles) {
+  chol_diag_panel_body<1>(M, n, k0, kb, Linv, info, fail_out, fwd_b, fwd_y, row_tiles, n_row_tiles, blockIdx.x);
+}
+// Level schedule (csrc/pvlm_spd_plan.h: plan_levels): every block column of a level in ONE launch — workgroup g works for block column groups[g].x as its
+// groups[g].y-th workgroup.  A failed pivot is recorded by the first workgroup of its column (several columns may fail: any of them is a valid report).
+template <int SUBS>
+__global__ __launch_bounds__(256) void k_nd_panel(double* __restrict__ M, int n, double* __restrict__ Linv, int* __restrict__ info, const double* __restrict__ fwd_b,
+                                                  double* __restrict__ fwd_y, const int2* __restrict__ groups, const int* __restrict__ row_off, const int* __restrict__ row_tiles) {
+  const int2 g = groups[blockIdx.x];
+  const int k0 = g.x * PVLM_CHOL_NB;
+  chol_diag_panel_body<SUBS>(M, n, k0, min(PVLM_CHOL_NB, n - k0), Linv, info, info, fwd_b, fwd_y, row_tiles + row_off[g.x], row_off[g.x + 1] - row_off[g.x], (unsigned)g.y);
 }
 
 // Which 64 x 64 tile (ti >= tj) of the trailing lower triangle a workgroup updates.  part 0: all tiles, linear id -> lower
@@ -380,6 +413,141 @@ __global__ __launch_bounds__(256) void k_chol_update_mfma(double* __restrict__ M
       const int row = r0 + 16 * w + lk + 4 * r;
       if (row < n && col <= row && col >= base) M[(size_t)row * n + col] = cv[t][r] - acc[t][r];
     }
+  }
+}
+
+// Trailing updates of ONE LEVEL of the schedule, target-centric: workgroup g owns the tile pair targets[g] and subtracts the rank-32 products of every
+// source block column of the level that reaches it, in list order, from registers — one read-modify-write of the tile whatever the number of sources, no two
+// workgroups on the same tile, no atomics: the factor is bit-reproducible.  Workgroups past the tile list do the same for 64 rows of the right-hand side
+// (the forward substitution rides along: y of a level's columns comes out of its panel launch).
+struct NdTarget { int ti, tj, src_off, n_src, col_min, pad; };
+struct NdRowTarget { int tile, src_off, n_src, pad; };
+__global__ __launch_bounds__(256) void k_nd_update(double* __restrict__ M, int n, const int* __restrict__ info, const NdTarget* __restrict__ targets, int n_targets,
+                                                   const int* __restrict__ sources, const NdRowTarget* __restrict__ row_targets, const int* __restrict__ row_sources,
+                                                   double* __restrict__ fwd_b, const double* __restrict__ fwd_y) {
+  __shared__ double As[64][PVLM_CHOL_NB + 1];
+  __shared__ double Bs[64][PVLM_CHOL_NB + 1];
+  if (*info != 0) return;
+  if ((int)blockIdx.x >= n_targets) {
+    // b[rows of the tile] -= L[rows, block column k] y_k for the sources of the row tile: four threads per row, eight columns each, in source order
+    const NdRowTarget rt = row_targets[(int)blockIdx.x - n_targets];
+    double* ys = &As[0][0];
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3, row = rt.tile * 64 + r;
+    double acc = 0.0;
+    for (int q = 0; q < rt.n_src; ++q) {
+      const int k0 = row_sources[rt.src_off + q] * PVLM_CHOL_NB, kb = min(PVLM_CHOL_NB, n - k0);
+      __syncthreads();
+      if (threadIdx.x < PVLM_CHOL_NB) ys[threadIdx.x] = (int)threadIdx.x < kb ? fwd_y[k0 + threadIdx.x] : 0.0;
+      __syncthreads();
+      if (row < n && row >= k0 + kb) {
+        const double* m = M + (size_t)row * n + k0 + 8 * part;
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sacc += (8 * part + c < kb ? m[c] : 0.0) * ys[8 * part + c];
+        acc += sacc;
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+    if (part == 0 && row < n) fwd_b[row] -= acc;
+    return;
+  }
+  const NdTarget tg = targets[blockIdx.x];
+  const int r0 = tg.ti * 64, c0 = tg.tj * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  pvlm_d4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < tg.n_src; ++q) {
+    const int k0 = sources[tg.src_off + q] * PVLM_CHOL_NB, kb = min(PVLM_CHOL_NB, n - k0), base = k0 + kb;
+    constexpr int kPer = 64 * PVLM_CHOL_NB / 256;
+    double av[kPer], bv[kPer];
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int e = threadIdx.x + 256 * it, i = e / PVLM_CHOL_NB, c = min(e % PVLM_CHOL_NB, kb - 1);
+      av[it] = M[(size_t)min(r0 + i, n - 1) * n + k0 + c];
+      bv[it] = M[(size_t)min(c0 + i, n - 1) * n + k0 + c];
+    }
+    if (q) __syncthreads();                                   // the previous source's slices have been consumed
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int e = threadIdx.x + 256 * it, i = e / PVLM_CHOL_NB, c = e % PVLM_CHOL_NB;
+      As[i][c] = (r0 + i >= base && r0 + i < n && c < kb) ? av[it] : 0.0;
+      Bs[i][c] = (c0 + i >= base && c0 + i < n && c < kb) ? bv[it] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PVLM_CHOL_NB; k += 4) {
+      const double a = As[16 * w + li][k + lk];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[16 * t + li][k + lk], acc[t], 0, 0, 0);
+    }
+  }
+  double cv[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = min(c0 + 16 * t + li, n - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(r0 + 16 * w + lk + 4 * r, n - 1);
+      cv[t][r] = M[(size_t)row * n + col];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = c0 + 16 * t + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 16 * w + lk + 4 * r;
+      if (row < n && col <= row && col >= tg.col_min) M[(size_t)row * n + col] = cv[t][r] - acc[t][r];
+    }
+  }
+}
+
+// Backward substitution of ONE LEVEL (levels in descending order): workgroup g solves block column cols[g] in gather form —
+//   x_k = L_kk^-T (y_k - sum over the rows i of the column's panel tiles of L[i, k]^T x_i);
+// every such row belongs to a block column of a higher level, whose x is final.  1024 threads: thread (rg, c) takes rows rg and rg + 32 of every tile for column
+// c, eight tiles' loads in flight together (a leaf column has a hundred tiles below it — its own group and every separator above: eight rows per round trip took 35 us
+// per level).  (Measured and removed: a workgroup per chunk of eight tiles with the last one to arrive adding the chunks up in order — the fences and the counter cost
+// the 8 us the shorter loop saves: 1.83 against 1.75 ms for the 108 levels of the Floor system.)
+__global__ __launch_bounds__(1024) void k_nd_bwd(const double* __restrict__ M, int n, const double* __restrict__ Linv, double* __restrict__ b, const double* __restrict__ yv,
+                                                 const int* __restrict__ info, const int* __restrict__ cols, const int* __restrict__ row_off, const int* __restrict__ row_tiles) {
+  __shared__ double part[32][PVLM_CHOL_NB + 1];
+  __shared__ double inv[PVLM_CHOL_NB][PVLM_CHOL_NB + 1];
+  __shared__ double v[PVLM_CHOL_NB];
+  if (*info != 0) return;
+  const int kc = cols[blockIdx.x], k0 = kc * PVLM_CHOL_NB, kb = min(PVLM_CHOL_NB, n - k0), base = k0 + kb;
+  const int t = threadIdx.x, c = t % PVLM_CHOL_NB, rg = t / PVLM_CHOL_NB;
+  const double* Lk = Linv + (size_t)kc * PVLM_CHOL_NB * PVLM_CHOL_NB;
+  inv[t / PVLM_CHOL_NB][t % PVLM_CHOL_NB] = Lk[t];
+  double acc = 0.0;
+  const int* rt = row_tiles + row_off[kc]; const int nrt = row_off[kc + 1] - row_off[kc];
+  const int cc = k0 + min(c, kb - 1);
+  for (int a = 0; a < nrt; a += 8) {
+    double m[16], xr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int ai = a + (q >> 1);
+      const int row = ai < nrt ? rt[ai] * 64 + rg + 32 * (q & 1) : n, rc = min(row, n - 1);
+      m[q] = M[(size_t)rc * n + cc];
+      xr[q] = (row >= base && row < n) ? b[rc] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += m[q] * xr[q];
+  }
+  part[rg][c] = c < kb ? acc : 0.0;
+  __syncthreads();
+  if (t < PVLM_CHOL_NB) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) sacc += part[q][t];
+    v[t] = t < kb ? yv[k0 + t] - sacc : 0.0;
+  }
+  __syncthreads();
+  if (t < kb) {
+    double sacc = 0.0;
+    for (int d = t; d < PVLM_CHOL_NB; ++d) sacc += inv[d][t] * v[d];
+    b[k0 + t] = sacc;
   }
 }
 
@@ -549,6 +717,11 @@ static void chol_factor_solve(pvlm_ctx* ctx, int n, double* d_M, double* d_B, in
 #endif
 }
 
+// The same factorisation and the two triangular solves by the level schedule: per level ONE panel launch (every block column of the level) and ONE update
+// launch (every tile the level's columns reach + the right-hand side rows), then the backward substitution level by level in descending order.
+struct SpdPlan;
+static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* d_b, double* d_Linv, double* d_y, int* d_info, const SpdPlan* P);
+
 // dense M (n x n, symmetric) += scatter of 6x6 blocks: entry (r, c) of block b goes to (row_idx[6b + r], col_idx[6b + c])
 // scaled by scale[i] * scale[j]; blocks flagged `mirror` (two different poses) are also added to the other triangle.
 __global__ void k_scatter_blocks(int n, int n_blocks, const int* __restrict__ row_idx, const int* __restrict__ col_idx, const int* __restrict__ mirror,
@@ -599,6 +772,12 @@ struct SpdPlan {
   std::vector<int> key_rows, key_cols, key_mirror;   // the structure the plan was built for: compared on every cache hit (a hash alone may collide)
   int* d_row_tiles = nullptr; int2* d_pairs = nullptr;
   double update_fraction = 1.0;                // tile updates / tile updates of the dense factorisation
+  // level schedule (nested dissection, pvlm_spd::plan_levels): the system is padded to n_pad rows (groups aligned to 64-row tiles, dummy rows = identity)
+  bool levels = false;
+  int n_pad = 0, n_levels = 0;
+  std::vector<int> col_off, pwg_off, pwt_off, upd_off, fwd_off;       // levels + 1 each (host)
+  int* d_cols = nullptr; int* d_row_off = nullptr; int2* d_pwg = nullptr; int2* d_pwt = nullptr; NdTarget* d_targets = nullptr; int* d_sources = nullptr;
+  NdRowTarget* d_ftargets = nullptr; int* d_fsources = nullptr;
 };
 
 static unsigned long long spd_hash(int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror) {
@@ -611,6 +790,8 @@ static unsigned long long spd_hash(int n, int n_blocks, const int* row_idx, cons
 static void spd_plan_free(pvlm_ctx* ctx, SpdPlan* p) {
   if (!p) return;
   pvlm_i_free(ctx, p->d_row_tiles); pvlm_i_free(ctx, p->d_pairs);
+  pvlm_i_free(ctx, p->d_cols); pvlm_i_free(ctx, p->d_row_off); pvlm_i_free(ctx, p->d_pwg); pvlm_i_free(ctx, p->d_pwt); pvlm_i_free(ctx, p->d_targets); pvlm_i_free(ctx, p->d_sources);
+  pvlm_i_free(ctx, p->d_ftargets); pvlm_i_free(ctx, p->d_fsources);
   delete p;
 }
 void pvlm_i_spd_plan_release(pvlm_ctx* ctx) { spd_plan_free(ctx, static_cast<SpdPlan*>(ctx->spd_plan)); ctx->spd_plan = nullptr; }
@@ -622,8 +803,41 @@ static pvlm_status spd_plan_build(pvlm_ctx* ctx, int n, int n_blocks, const int*
   for (int i = 0; i < n; ++i) P->new_of_old[(size_t)i] = i;
   static const int min_n = getenv("PVLM_SPD_SPARSE_MIN") ? atoi(getenv("PVLM_SPD_SPARSE_MIN")) : 1500;
   if (n < min_n || n_blocks == 0) return PVLM_OK;
-  pvlm_spd::Symbolic S;
   static_assert(64 % PVLM_CHOL_NB == 0, "a 64-row tile must span a whole number of block columns (pvlm_spd_plan.h marks the fill per tile)");
+  static_assert(sizeof(pvlm_spd::Target) == sizeof(NdTarget) && sizeof(pvlm_spd::RowTarget) == sizeof(NdRowTarget) && sizeof(pvlm_spd::PanelGroup) == sizeof(int2), "level lists are uploaded as they are");
+  // nested dissection + level schedule (PVLM_SPD_LEVELS=0: the round-5 plan — minimum degree, one block column after the other)
+  static const bool want_levels = !(getenv("PVLM_SPD_LEVELS") && atoi(getenv("PVLM_SPD_LEVELS")) == 0);
+  if (want_levels) {
+    static const int leaf = getenv("PVLM_SPD_LEAF") ? std::max(1, atoi(getenv("PVLM_SPD_LEAF"))) : 42;      // nodes per undissected group (42 poses = 252 rows = 4 tiles)
+    pvlm_spd::LevelPlan L;
+    pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, leaf, &L);
+    static const double max_pad = getenv("PVLM_SPD_MAX_PAD") ? atof(getenv("PVLM_SPD_MAX_PAD")) : 1.6;
+    // adopted when it shortens the chain of dependent launches by a third at least and the padding stays bounded
+    if (L.ordered && L.levels * 3 <= L.cols_total * 2 + 2 && (double)L.n_pad <= max_pad * (double)n + 256.0) {
+      pvlm_status st = PVLM_OK;
+      auto up = [&](void** d, const void* src, size_t bytes) {
+        if (st) return;
+        st = pvlm_i_alloc_bytes(ctx, d, std::max<size_t>(bytes, 256));
+        if (!st && bytes) st = pvlm_i_h2d_q(ctx, *d, src, bytes);
+      };
+      up((void**)&P->d_cols, L.cols.data(), L.cols.size() * sizeof(int));
+      up((void**)&P->d_row_off, L.row_off.data(), L.row_off.size() * sizeof(int));
+      up((void**)&P->d_row_tiles, L.row_tiles.data(), L.row_tiles.size() * sizeof(int));
+      up((void**)&P->d_pwg, L.pwg.data(), L.pwg.size() * sizeof(int2));
+      up((void**)&P->d_pwt, L.pwt.data(), L.pwt.size() * sizeof(int2));
+      up((void**)&P->d_targets, L.targets.data(), L.targets.size() * sizeof(NdTarget));
+      up((void**)&P->d_sources, L.sources.data(), L.sources.size() * sizeof(int));
+      up((void**)&P->d_ftargets, L.ftargets.data(), L.ftargets.size() * sizeof(NdRowTarget));
+      up((void**)&P->d_fsources, L.fsources.data(), L.fsources.size() * sizeof(int));
+      if (!st) st = pvlm_i_sync(ctx);
+      if (st) return st;
+      P->new_of_old.swap(L.new_of_old); P->col_off.swap(L.col_off); P->pwg_off.swap(L.pwg_off); P->pwt_off.swap(L.pwt_off); P->upd_off.swap(L.upd_off); P->fwd_off.swap(L.fwd_off);
+      P->n_pad = L.n_pad; P->n_levels = L.levels; P->update_fraction = L.update_fraction;
+      P->levels = true; P->sparse = true;
+      return PVLM_OK;
+    }
+  }
+  pvlm_spd::Symbolic S;
   pvlm_spd::plan_symbolic(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, &S);       // csrc/pvlm_spd_plan.h (host only, checked on the CPU)
   P->update_fraction = S.update_fraction;
   static const double max_fraction = getenv("PVLM_SPD_SPARSE_FRACTION") ? atof(getenv("PVLM_SPD_SPARSE_FRACTION")) : 0.6;
@@ -638,6 +852,30 @@ static pvlm_status spd_plan_build(pvlm_ctx* ctx, int n, int n_blocks, const int*
   P->new_of_old.swap(S.new_of_old); P->row_off.swap(S.row_off); P->pair_off.swap(S.pair_off);
   P->sparse = true;
   return PVLM_OK;
+}
+
+static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* d_b, double* d_Linv, double* d_y, int* d_info, const SpdPlan* P) {
+  hipStream_t s = ctx->stream;
+  for (int l = 0; l < P->n_levels; ++l) {
+    const int npw = P->pwg_off[(size_t)l + 1] - P->pwg_off[(size_t)l], ntg = P->upd_off[(size_t)l + 1] - P->upd_off[(size_t)l], nft = P->fwd_off[(size_t)l + 1] - P->fwd_off[(size_t)l];
+    // eight-row workgroups while they fit the device in about one round (256 CUs x 8 resident workgroups), whole tiles beyond
+    const int npt = P->pwt_off[(size_t)l + 1] - P->pwt_off[(size_t)l];
+    if (npw > 3072)
+      hipLaunchKernelGGL(k_nd_panel<8>, dim3((unsigned)npt), dim3(256), 0, s, d_M, n, d_Linv, d_info, (const double*)d_b, d_y, (const int2*)P->d_pwt + P->pwt_off[(size_t)l],
+                         (const int*)P->d_row_off, (const int*)P->d_row_tiles);
+    else if (npw > 0)
+      hipLaunchKernelGGL(k_nd_panel<1>, dim3((unsigned)npw), dim3(256), 0, s, d_M, n, d_Linv, d_info, (const double*)d_b, d_y, (const int2*)P->d_pwg + P->pwg_off[(size_t)l],
+                         (const int*)P->d_row_off, (const int*)P->d_row_tiles);
+    if (ntg + nft > 0)
+      hipLaunchKernelGGL(k_nd_update, dim3((unsigned)(ntg + nft)), dim3(256), 0, s, d_M, n, (const int*)d_info, (const NdTarget*)P->d_targets + P->upd_off[(size_t)l], ntg,
+                         (const int*)P->d_sources, (const NdRowTarget*)P->d_ftargets + P->fwd_off[(size_t)l], (const int*)P->d_fsources, d_b, (const double*)d_y);
+  }
+  for (int l = P->n_levels - 1; l >= 0; --l) {
+    const int nc = P->col_off[(size_t)l + 1] - P->col_off[(size_t)l];
+    if (nc > 0)
+      hipLaunchKernelGGL(k_nd_bwd, dim3((unsigned)nc), dim3(1024), 0, s, (const double*)d_M, n, (const double*)d_Linv, d_b, (const double*)d_y, (const int*)d_info,
+                         (const int*)P->d_cols + P->col_off[(size_t)l], (const int*)P->d_row_off, (const int*)P->d_row_tiles);
+  }
 }
 
 extern "C" {
@@ -682,7 +920,9 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
       const std::vector<int>& nw = plan->new_of_old;
       prow.resize((size_t)n_blocks * 6); pcol.resize((size_t)n_blocks * 6);
       for (size_t k = 0; k < prow.size(); ++k) { prow[k] = row_idx[k] >= 0 && row_idx[k] < n ? nw[(size_t)row_idx[k]] : -1; pcol[k] = col_idx[k] >= 0 && col_idx[k] < n ? nw[(size_t)col_idx[k]] : -1; }
-      pscale.resize((size_t)n); pdiag.resize((size_t)n); prhs.resize((size_t)n);
+      // the level plan pads the system: dummy rows are identity rows (scale 1, diagonal 1, right-hand side 0 -> solution 0)
+      const size_t np = plan->levels ? (size_t)plan->n_pad : (size_t)n;
+      pscale.assign(np, 1.0); pdiag.assign(np, 1.0); prhs.assign(np, 0.0);
       for (int i = 0; i < n; ++i) { const size_t q = (size_t)nw[(size_t)i]; pscale[q] = scale[i]; pdiag[q] = diag_add[i]; prhs[q] = rhs[i]; }
       row_idx = prow.data(); col_idx = pcol.data(); scale = pscale.data(); diag_add = pdiag.data();
     }
@@ -691,6 +931,8 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     return PVLM_ERR_NOMEM;
   }
   double* rhs_io = plan->sparse ? prhs.data() : rhs;
+  const int n_user = n;
+  if (plan->levels) n = plan->n_pad;                     // from here on the device works on the padded system
   SpdTileLists lists{plan->d_row_tiles, plan->d_pairs, plan->row_off.data(), plan->pair_off.data()};
   const size_t linv_count = (size_t)((n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB) * PVLM_CHOL_NB * PVLM_CHOL_NB;
   const size_t need = pad256((size_t)n * n * 8) + pad256((size_t)n_blocks * 36 * 8) + 3 * pad256((size_t)n_blocks * 6 * 4) + 4 * pad256((size_t)n * 8) +
@@ -724,7 +966,8 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     }
     if (e == hipSuccess && !st) e = hipMemsetAsync(d_info, 0, sizeof(int), s);
     if (e == hipSuccess && !st) {
-      chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_Linv, d_y, d_info, plan->sparse ? &lists : nullptr);
+      if (plan->levels) chol_factor_solve_levels(ctx, n, d_M, d_rhs, d_Linv, d_y, d_info, plan);
+      else chol_factor_solve(ctx, n, d_M, d_rhs, 1, d_Linv, d_y, d_info, plan->sparse ? &lists : nullptr);
       e = hipGetLastError();
     }
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
@@ -732,12 +975,22 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     if (!st) st = pvlm_i_d2h_q(ctx, rhs_io, d_rhs, (size_t)n * sizeof(double));
     { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
     pvlm_i_trace("spd solve: factorised and solved");
-    if (!st && plan->sparse) for (int i = 0; i < n; ++i) rhs[i] = prhs[(size_t)plan->new_of_old[(size_t)i]];
+    if (!st && plan->sparse) for (int i = 0; i < n_user; ++i) rhs[i] = prhs[(size_t)plan->new_of_old[(size_t)i]];
     *info_out = info;
   } else {
     hipStreamSynchronize(ctx->stream);
   }
   return st;
+}
+
+pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_columns, int* padded_rows) {
+  if (!ctx) return PVLM_ERR_ARG;
+  const SpdPlan* p = static_cast<const SpdPlan*>(ctx->spd_plan);
+  const bool lv = p && p->levels;
+  if (levels) *levels = lv ? p->n_levels : 0;
+  if (block_columns) *block_columns = lv ? p->n_pad / PVLM_CHOL_NB : (p ? (p->n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB : 0);
+  if (padded_rows) *padded_rows = lv ? p->n_pad : (p ? p->n : 0);
+  return PVLM_OK;
 }
 
 pvlm_status pvlm_spd_plan_info(const pvlm_ctx* ctx, int* tile_sparse, double* update_fraction) {

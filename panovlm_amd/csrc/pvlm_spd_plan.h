@@ -8,6 +8,8 @@
 //   3. per block column the list of its row tiles (panel) and of the tile pairs its rank-NB update touches.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
+#include <utility>
 #include <vector>
 
 namespace pvlm_spd {
@@ -143,6 +145,217 @@ inline void plan_symbolic(int n, int n_blocks, const int* row_idx, const int* co
     dense_pairs += dt * (dt + 1) / 2;
   }
   P->update_fraction = dense_pairs ? (double)pairs.size() / (double)dense_pairs : 1.0;
+}
+
+
+// ---- nested dissection + level schedule (round 6) -----------------------------------------------------------------------------------------------
+// plan_symbolic above orders by minimum degree and factorises block column after block column: on the Floor pose graph (1 593 poses, every pose tied to
+// ~20 others all along the trajectory — the scans of a room seen again and again) its 299 block columns form a dependency chain of 293 (every 64-row
+// tile drags its neighbours along), 35 us each.  plan_levels orders by NESTED DISSECTION of the pose graph — recursive bisection by a breadth-first level
+// set from a pseudo-peripheral node (George's automatic nested dissection); the two halves first, the separator last — aligns every group (leaf or
+// separator) to a 64-row tile with dummy unknowns (identity rows), so that no tile couples two groups that have nothing to do with each other, and
+// then SCHEDULES: the level of a block column = 1 + the highest level among the block columns whose update reaches it.  Block columns of one level are
+// factorised in one launch, their trailing updates are applied in one launch in which a workgroup owns a TARGET tile and adds up every source column of the
+// level in list order (deterministic: no two workgroups write the same tile, no atomics), the triangular solves run level by level too.  Floor graph:
+// 110 levels instead of 293 dependent steps.
+struct Target { int ti, tj, src_off, n_src, col_min, pad; };   // tile pair (ti >= tj, absolute 64-row tiles) <- sources[src_off .. + n_src) (block columns); columns below
+                                                               // col_min are not written: the panel of a source column that lies inside the target's own column tile
+struct RowTarget { int tile, src_off, n_src, pad; };    // rows of a 64-row tile of the right-hand side <- sources
+struct PanelGroup { int col, local; };                  // workgroup -> (block column, its local workgroup index)
+struct LevelPlan {
+  int n_pad = 0, levels = 0, cols_total = 0;
+  std::vector<int> new_of_old;                          // unknown -> row of the padded system
+  std::vector<int> col_off, cols;                       // levels + 1; block columns in level order
+  std::vector<int> row_off, row_tiles;                  // per block column (cols_total + 1): the 64-row tiles of its panel
+  std::vector<int> pwg_off; std::vector<PanelGroup> pwg;  // levels + 1; the panel launch of a level: a workgroup per 8 rows of a column's panel tiles ...
+  std::vector<int> pwt_off; std::vector<PanelGroup> pwt;  // ... or per whole 64-row tile (wide levels)
+  std::vector<int> upd_off; std::vector<Target> targets; std::vector<int> sources;
+  std::vector<int> fwd_off; std::vector<RowTarget> ftargets; std::vector<int> fsources;
+  long long tile_updates = 0;
+  double update_fraction = 1.0;
+  bool ordered = false;
+};
+
+inline void plan_levels(int n, int n_blocks, const int* row_idx, const int* col_idx, int NB, int leaf_nodes, LevelPlan* P) {
+  *P = LevelPlan();
+  P->new_of_old.assign((size_t)std::max(n, 0), 0);
+  if (n <= 0) return;
+  // ---- nodes and their graph: as in plan_symbolic
+  std::vector<int> uf((size_t)n);
+  for (int i = 0; i < n; ++i) uf[(size_t)i] = i;
+  auto find = [&](int a) { while (uf[(size_t)a] != a) { uf[(size_t)a] = uf[(size_t)uf[(size_t)a]]; a = uf[(size_t)a]; } return a; };
+  auto side = [&](const int* idx) { int first = -1; for (int r = 0; r < 6; ++r) { const int i = idx[r]; if (i < 0 || i >= n) continue; if (first < 0) first = find(i); else { const int q = find(i); if (q != first) uf[(size_t)std::max(q, first)] = std::min(q, first), first = std::min(q, first); } } return first; };
+  for (int b = 0; b < n_blocks; ++b) { side(row_idx + 6 * b); side(col_idx + 6 * b); }
+  std::vector<int> node_of((size_t)n, -1);
+  std::vector<std::vector<int>> members;
+  for (int i = 0; i < n; ++i) { const int r = find(i); if (node_of[(size_t)r] < 0) { node_of[(size_t)r] = (int)members.size(); members.emplace_back(); } node_of[(size_t)i] = node_of[(size_t)r]; members[(size_t)node_of[(size_t)i]].push_back(i); }
+  const int N = (int)members.size();
+  std::vector<std::vector<int>> adj((size_t)N);
+  for (int b = 0; b < n_blocks; ++b) {
+    int a = -1, c = -1;
+    for (int r = 0; r < 6 && a < 0; ++r) if (row_idx[6 * b + r] >= 0 && row_idx[6 * b + r] < n) a = node_of[(size_t)row_idx[6 * b + r]];
+    for (int r = 0; r < 6 && c < 0; ++r) if (col_idx[6 * b + r] >= 0 && col_idx[6 * b + r] < n) c = node_of[(size_t)col_idx[6 * b + r]];
+    if (a >= 0 && c >= 0 && a != c) { adj[(size_t)a].push_back(c); adj[(size_t)c].push_back(a); }
+  }
+  for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  // ---- nested dissection: groups in elimination order.  `tag[v]` = id of the subset v currently belongs to (a subset is a list of nodes + its tag)
+  std::vector<std::vector<int>> groups;
+  {
+    std::vector<int> tag((size_t)N, 0), lev((size_t)N, -1), queue;
+    int next_tag = 1;
+    // breadth-first levels of `start` inside the subset `t`; returns the visit order in `queue`
+    auto bfs = [&](int start, int t) {
+      queue.clear(); queue.push_back(start); lev[(size_t)start] = 0;
+      for (size_t h = 0; h < queue.size(); ++h) { const int u = queue[h]; for (int w : adj[(size_t)u]) if (tag[(size_t)w] == t && lev[(size_t)w] < 0) { lev[(size_t)w] = lev[(size_t)u] + 1; queue.push_back(w); } }
+    };
+    struct Work { std::vector<int> nodes; int t; bool emit_after; };     // emit_after: a separator, emitted as a group when it comes off the stack
+    std::vector<Work> stack;
+    { Work w; w.nodes.resize((size_t)N); for (int v = 0; v < N; ++v) w.nodes[(size_t)v] = v; w.t = 0; w.emit_after = false; stack.push_back(std::move(w)); }
+    while (!stack.empty()) {
+      Work w = std::move(stack.back()); stack.pop_back();
+      if (w.emit_after) { groups.push_back(std::move(w.nodes)); continue; }
+      if (w.nodes.empty()) continue;
+      if ((int)w.nodes.size() <= std::max(leaf_nodes, 1)) { groups.push_back(std::move(w.nodes)); continue; }
+      const int t = w.t;
+      for (int v : w.nodes) lev[(size_t)v] = -1;
+      // connected components of the subset: several -> two bins, no separator
+      bfs(w.nodes[0], t);
+      if (queue.size() < w.nodes.size()) {
+        std::vector<std::vector<int>> comps; comps.push_back(queue);
+        for (int v : w.nodes) if (lev[(size_t)v] < 0) { bfs(v, t); comps.push_back(queue); }
+        std::sort(comps.begin(), comps.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() != b.size() ? a.size() > b.size() : a[0] < b[0]; });
+        Work A, B; A.t = next_tag++; B.t = next_tag++; A.emit_after = B.emit_after = false;
+        for (auto& c : comps) { Work& dst = A.nodes.size() <= B.nodes.size() ? A : B; for (int v : c) { tag[(size_t)v] = dst.t; dst.nodes.push_back(v); } }
+        stack.push_back(std::move(B)); stack.push_back(std::move(A));      // A is dissected (and emitted) first
+        continue;
+      }
+      // pseudo-peripheral start: the farthest node of the farthest node ... (three rounds)
+      int start = w.nodes[0];
+      for (int round = 0; round < 3; ++round) {
+        for (int v : w.nodes) lev[(size_t)v] = -1;
+        bfs(start, t);
+        int far = start;
+        for (int v : queue) if (lev[(size_t)v] > lev[(size_t)far] || (lev[(size_t)v] == lev[(size_t)far] && adj[(size_t)v].size() < adj[(size_t)far].size())) far = v;
+        if (far == start) break;
+        start = far;
+      }
+      for (int v : w.nodes) lev[(size_t)v] = -1;
+      bfs(start, t);
+      int depth = 0;
+      for (int v : w.nodes) depth = std::max(depth, lev[(size_t)v]);
+      if (depth < 2) { groups.push_back(std::move(w.nodes)); continue; }   // (nearly) a clique: one dense group
+      std::vector<int> count((size_t)depth + 1, 0);
+      for (int v : w.nodes) ++count[(size_t)lev[(size_t)v]];
+      long long best_cost = -1; int best = 1; int below = count[0];
+      for (int l = 1; l < depth; ++l) {
+        const int above = (int)w.nodes.size() - below - count[(size_t)l];
+        const long long cost = std::llabs((long long)below - above) + 2ll * count[(size_t)l];
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = l; }
+        below += count[(size_t)l];
+      }
+      Work A, B, S; A.t = next_tag++; B.t = next_tag++; S.t = -1; A.emit_after = B.emit_after = false; S.emit_after = true;
+      for (int v : w.nodes) if (lev[(size_t)v] > best) { tag[(size_t)v] = B.t; B.nodes.push_back(v); }
+      for (int v : w.nodes) {
+        if (lev[(size_t)v] < best) { tag[(size_t)v] = A.t; A.nodes.push_back(v); }
+        else if (lev[(size_t)v] == best) {
+          bool touches_b = false;                                           // a separator node without a neighbour on the far side belongs to the near side
+          for (int q : adj[(size_t)v]) if (tag[(size_t)q] == B.t) { touches_b = true; break; }
+          if (touches_b) { tag[(size_t)v] = -1; S.nodes.push_back(v); } else { tag[(size_t)v] = A.t; A.nodes.push_back(v); }
+        }
+      }
+      stack.push_back(std::move(S)); stack.push_back(std::move(B)); stack.push_back(std::move(A));
+    }
+  }
+  // ---- rows of the padded system: every group starts on a 64-row tile
+  int n_pad = 0;
+  for (auto& g : groups) {
+    std::sort(g.begin(), g.end());
+    for (int v : g) for (int i : members[(size_t)v]) P->new_of_old[(size_t)i] = n_pad++;
+    n_pad = (n_pad + 63) / 64 * 64;
+  }
+  P->n_pad = n_pad;
+  // ---- symbolic factorisation on (64-row tile) x (NB-column block column) cells of the padded system, with the level of every block column
+  const int C = n_pad / NB, T = n_pad / 64, per_tile = 64 / NB;
+  P->cols_total = C;
+  std::vector<unsigned char> nz((size_t)T * C, 0);
+  for (int c = 0; c < C; ++c) nz[(size_t)(c / per_tile) * C + c] = 1;           // the diagonal (dummy rows are identity rows)
+  for (int b = 0; b < n_blocks; ++b)
+    for (int r = 0; r < 6; ++r) {
+      const int io = row_idx[6 * b + r];
+      if (io < 0 || io >= n) continue;
+      const int i = P->new_of_old[(size_t)io];
+      for (int c = 0; c < 6; ++c) {
+        const int jo = col_idx[6 * b + c];
+        if (jo < 0 || jo >= n) continue;
+        const int j = P->new_of_old[(size_t)jo];
+        const int lo = std::min(i, j), hi = std::max(i, j);
+        nz[(size_t)(hi / 64) * C + lo / NB] = 1;
+      }
+    }
+  std::vector<int> level((size_t)C, 0);
+  P->row_off.assign(1, 0);
+  std::vector<int> R;
+  long long dense_pairs = 0;
+  for (int k = 0; k < C; ++k) {
+    const int base = (k + 1) * NB, t0 = base / 64;
+    R.clear();
+    for (int t = t0; t < T && base < n_pad; ++t) if (nz[(size_t)t * C + k] && (t + 1) * 64 > base) R.push_back(t);
+    for (int t : R) P->row_tiles.push_back(t);
+    P->row_off.push_back((int)P->row_tiles.size());
+    for (size_t a = 0; a < R.size(); ++a)
+      for (size_t c = 0; c <= a; ++c)
+        for (int col = per_tile * R[c]; col < per_tile * (R[c] + 1); ++col) if (col > k && col < C) nz[(size_t)R[a] * C + col] = 1;
+    for (int t : R) for (int col = per_tile * t; col < per_tile * (t + 1); ++col) if (col > k && col < C) level[(size_t)col] = std::max(level[(size_t)col], level[(size_t)k] + 1);
+    P->tile_updates += (long long)R.size() * ((long long)R.size() + 1) / 2;
+    const long long dt = (n_pad - base + 63) / 64;
+    dense_pairs += dt * (dt + 1) / 2;
+  }
+  P->update_fraction = dense_pairs ? (double)P->tile_updates / (double)dense_pairs : 1.0;
+  // ---- the schedule
+  int L = 0;
+  for (int k = 0; k < C; ++k) L = std::max(L, level[(size_t)k] + 1);
+  P->levels = L;
+  P->col_off.assign((size_t)L + 1, 0);
+  for (int k = 0; k < C; ++k) ++P->col_off[(size_t)level[(size_t)k] + 1];
+  for (int l = 0; l < L; ++l) P->col_off[(size_t)l + 1] += P->col_off[(size_t)l];
+  P->cols.assign((size_t)C, 0);
+  { std::vector<int> cur(P->col_off.begin(), P->col_off.end() - 1); for (int k = 0; k < C; ++k) P->cols[(size_t)cur[(size_t)level[(size_t)k]]++] = k; }
+  P->pwg_off.assign(1, 0); P->pwt_off.assign(1, 0); P->upd_off.assign(1, 0); P->fwd_off.assign(1, 0);
+  std::vector<std::pair<long long, int>> hits;      // (target key, source column) of one level
+  std::vector<std::pair<int, int>> rhits;           // (row tile, source column)
+  for (int l = 0; l < L; ++l) {
+    hits.clear(); rhits.clear();
+    for (int q = P->col_off[(size_t)l]; q < P->col_off[(size_t)l + 1]; ++q) {
+      const int k = P->cols[(size_t)q];
+      const int* rt = P->row_tiles.data() + P->row_off[(size_t)k]; const int nrt = P->row_off[(size_t)k + 1] - P->row_off[(size_t)k];
+      for (int g = 0; g < std::max(1, nrt * 8); ++g) P->pwg.push_back(PanelGroup{k, g});
+      for (int g = 0; g < std::max(1, nrt); ++g) P->pwt.push_back(PanelGroup{k, g});
+      for (int a = 0; a < nrt; ++a) {
+        rhits.push_back({rt[a], k});
+        for (int c = 0; c <= a; ++c) hits.push_back({(long long)rt[a] * T + rt[c], k});
+      }
+    }
+    std::sort(hits.begin(), hits.end()); std::sort(rhits.begin(), rhits.end());
+    for (size_t h = 0; h < hits.size();) {
+      size_t e = h;
+      while (e < hits.size() && hits[e].first == hits[h].first) ++e;
+      const int tj = (int)(hits[h].first % T);
+      int col_min = 0;
+      for (size_t q = h; q < e; ++q) if (hits[q].second / per_tile == tj) col_min = std::max(col_min, (hits[q].second + 1) * NB);
+      P->targets.push_back(Target{(int)(hits[h].first / T), tj, (int)P->sources.size(), (int)(e - h), col_min, 0});
+      for (size_t q = h; q < e; ++q) P->sources.push_back(hits[q].second);
+      h = e;
+    }
+    for (size_t h = 0; h < rhits.size();) {
+      size_t e = h;
+      while (e < rhits.size() && rhits[e].first == rhits[h].first) ++e;
+      P->ftargets.push_back(RowTarget{rhits[h].first, (int)P->fsources.size(), (int)(e - h), 0});
+      for (size_t q = h; q < e; ++q) P->fsources.push_back(rhits[q].second);
+      h = e;
+    }
+    P->pwg_off.push_back((int)P->pwg.size()); P->pwt_off.push_back((int)P->pwt.size()); P->upd_off.push_back((int)P->targets.size()); P->fwd_off.push_back((int)P->ftargets.size());
+  }
+  P->ordered = true;
 }
 
 }  // namespace pvlm_spd

@@ -21,4 +21,23 @@ int chk_spd_plan(int n, int n_blocks, const int* row_idx, const int* col_idx, in
   return S.ordered ? 1 : 0;
 }
 
+// the level plan (nested dissection + schedule, pvlm_spd::plan_levels).  First call with null outputs: sizes[0..9] = n_pad, levels, block columns, row tiles, panel
+// groups, targets, sources, row targets, row sources, tile updates.  Second call fills the arrays (targets: 6 ints each, row targets: 4, panel groups: 2).
+int chk_spd_levels(int n, int n_blocks, const int* row_idx, const int* col_idx, int nb, int leaf, long long* sizes, double* update_fraction, int* new_of_old, int* col_off,
+                   int* cols, int* row_off, int* row_tiles, int* pwg_off, int* pwg, int* upd_off, int* targets, int* sources, int* fwd_off, int* ftargets, int* fsources) {
+  pvlm_spd::LevelPlan P;
+  pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, nb, leaf, &P);
+  const long long sz[10] = {P.n_pad, P.levels, P.cols_total, (long long)P.row_tiles.size(), (long long)P.pwg.size(), (long long)P.targets.size(), (long long)P.sources.size(),
+                            (long long)P.ftargets.size(), (long long)P.fsources.size(), P.tile_updates};
+  for (int k = 0; k < 10; ++k) sizes[k] = sz[k];
+  *update_fraction = P.update_fraction;
+  auto put = [](int* dst, const void* src, size_t bytes) { if (dst && bytes) std::memcpy(dst, src, bytes); };
+  put(new_of_old, P.new_of_old.data(), P.new_of_old.size() * 4); put(col_off, P.col_off.data(), P.col_off.size() * 4); put(cols, P.cols.data(), P.cols.size() * 4);
+  put(row_off, P.row_off.data(), P.row_off.size() * 4); put(row_tiles, P.row_tiles.data(), P.row_tiles.size() * 4);
+  put(pwg_off, P.pwg_off.data(), P.pwg_off.size() * 4); put(pwg, P.pwg.data(), P.pwg.size() * sizeof(pvlm_spd::PanelGroup));
+  put(upd_off, P.upd_off.data(), P.upd_off.size() * 4); put(targets, P.targets.data(), P.targets.size() * sizeof(pvlm_spd::Target)); put(sources, P.sources.data(), P.sources.size() * 4);
+  put(fwd_off, P.fwd_off.data(), P.fwd_off.size() * 4); put(ftargets, P.ftargets.data(), P.ftargets.size() * sizeof(pvlm_spd::RowTarget)); put(fsources, P.fsources.data(), P.fsources.size() * 4);
+  return P.ordered ? 1 : 0;
+}
+
 }  // extern "C"

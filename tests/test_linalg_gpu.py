@@ -138,3 +138,56 @@ def test_solve_with_gpu_cholesky_matches_twin(oracle, tmp_path, monkeypatch):
     assert int(summ[8]) == res["successful"] and int(summ[10]) == res["unsuccessful"]
     assert np.abs(cams[:, :3] - aa).max() <= 1e-6 and np.abs(cams[:, 3:] - t).max() <= 1e-6
     assert np.abs(pts - X).max() <= 1e-6 * max(1.0, np.abs(X).max())
+
+
+def _proximity_pairs(rng, P, degree):
+    xy = rng.uniform(0, 1, size=(P, 2))
+    d = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)
+    pairs, seen = [(p, p) for p in range(P)], set()
+    for p in range(P):
+        for q in np.argsort(d[p])[1:degree + 1]:
+            e = (min(p, int(q)), max(p, int(q)))
+            if e not in seen:
+                seen.add(e); pairs.append(e)
+    return pairs
+
+
+@pytest.mark.parametrize("shape,P", [("proximity", 700), ("chain_with_loops", 600)])
+def test_nested_dissection_level_schedule(shape, P):
+    """pvlm_spd_solve_blocks from 1500 unknowns on: nested dissection of the pose graph + the level schedule (csrc/pvlm_spd_plan.h: plan_levels; kernels k_nd_panel /
+    k_nd_update / k_nd_bwd) — the graph FindNeighbors builds on a trajectory that keeps coming back to the same rooms (every pose tied to its nearest ones) and a
+    temporal chain with loop closures.  Same solution as a dense solve and as the column-by-column plan of round 5 (PVLM_SPD_LEVELS=0, in a child process); far fewer
+    dependent steps than block columns; two solves give the same bits (a workgroup per target tile, no atomics); a matrix that is not positive definite is reported.
+    Upstream this is Ceres' SPARSE_SCHUR (util/Optimization.cpp:638-666)."""
+    import panovlm_amd as pv
+    rng = np.random.default_rng(P)
+    if shape == "proximity":
+        pairs = _proximity_pairs(rng, P, 9)
+    else:
+        pairs = [(p, p) for p in range(P)] + [(p, q) for p in range(P) for q in range(p + 1, min(p + 4, P))] + \
+                [(int(a), int(b)) for a, b in zip(rng.integers(0, P, 60), rng.integers(0, P, 60)) if a < b]
+    n, rows, cols, mirror, blocks, scale, diag, rhs, M = _block_system(rng, P, pairs, constant={(0, 0), (0, 1), (9, 1)})
+    assert n >= 1500
+    ctx = pv.Context(0)
+    x, info = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    plan = ctx.spd_plan()
+    want = np.linalg.solve(M, rhs)
+    assert info == 0 and np.allclose(x, want, rtol=1e-9, atol=1e-12)
+    assert plan["tile_sparse"] and 0 < plan["levels"] <= 0.67 * plan["block_columns"] and plan["padded_rows"] % 64 == 0 and plan["padded_rows"] >= n, plan
+    x2, _ = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert np.array_equal(x, x2)
+    diag_bad = diag.copy(); diag_bad[n // 3] = -1e6
+    _, info_bad = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag_bad, rhs)
+    assert info_bad != 0
+    ctx.close()
+    # the round-5 plan on the same system, in a child process (the switch is read once per process)
+    import pickle, subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        pickle.dump((n, rows, cols, mirror, blocks, scale, diag, rhs), open(os.path.join(d, "sys.pkl"), "wb"))
+        code = ("import pickle, sys, numpy as np; sys.path.insert(0, %r); import panovlm_amd as pv; a = pickle.load(open(%r, 'rb')); ctx = pv.Context(0); "
+                "x, info = ctx.spd_solve_blocks(*a); p = ctx.spd_plan(); pickle.dump((x, info, p), open(%r, 'wb'))") % (host_io.ROOT, os.path.join(d, "sys.pkl"), os.path.join(d, "out.pkl"))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVLM_SPD_LEVELS="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        x_old, info_old, plan_old = pickle.load(open(os.path.join(d, "out.pkl"), "rb"))
+    assert info_old == 0 and plan_old["levels"] == 0
+    assert np.abs(x - x_old).max() <= 1e-11 * max(1.0, np.abs(x_old).max())

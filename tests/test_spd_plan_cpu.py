@@ -109,3 +109,118 @@ def test_degenerate_structures(chk):
     rows = np.array([0, 1, 2, 3, 4, 5, -1, -1, -1, -1, -1, -1], np.int32); cols = np.array([0, 1, 2, 3, 4, 5, -1, -1, -1, -1, -1, -1], np.int32)
     pl = plan(chk, 9, rows, cols)
     assert sorted(pl["perm"].tolist()) == list(range(9))
+
+
+# ---- nested dissection + level schedule (pvlm_spd::plan_levels) ----------------------------------------------------------------------------------
+def levels_plan(lib, n, rows, cols, leaf=8):
+    rows = np.ascontiguousarray(rows, np.int32); cols = np.ascontiguousarray(cols, np.int32)
+    sizes = np.zeros(10, np.int64); frac = ctypes.c_double()
+    args = (n, len(rows) // 6, _p(rows, ctypes.c_int), _p(cols, ctypes.c_int), NB, leaf, _p(sizes, ctypes.c_longlong), ctypes.byref(frac))
+    lib.chk_spd_levels(*args, *([None] * 13))
+    n_pad, L, C, nrt, npw, ntg, nsrc, nft, nfs, _ = [int(v) for v in sizes]
+    A = dict(new_of_old=np.zeros(n, np.int32), col_off=np.zeros(L + 1, np.int32), cols=np.zeros(C, np.int32), row_off=np.zeros(C + 1, np.int32), row_tiles=np.zeros(max(nrt, 1), np.int32),
+             pwg_off=np.zeros(L + 1, np.int32), pwg=np.zeros((max(npw, 1), 2), np.int32), upd_off=np.zeros(L + 1, np.int32), targets=np.zeros((max(ntg, 1), 6), np.int32),
+             sources=np.zeros(max(nsrc, 1), np.int32), fwd_off=np.zeros(L + 1, np.int32), ftargets=np.zeros((max(nft, 1), 4), np.int32), fsources=np.zeros(max(nfs, 1), np.int32))
+    order = ("new_of_old", "col_off", "cols", "row_off", "row_tiles", "pwg_off", "pwg", "upd_off", "targets", "sources", "fwd_off", "ftargets", "fsources")
+    ok = lib.chk_spd_levels(*args, *[_p(A[k], ctypes.c_int) for k in order])
+    A.update(n_pad=n_pad, levels=L, block_cols=C, tile_updates=int(sizes[9]), fraction=frac.value, ordered=bool(ok))
+    return A
+
+
+def solve_by_levels(P, M, rhs):
+    """The arithmetic of chol_factor_solve_levels (csrc/pvlm_linalg.hip) in numpy, with EXACTLY the plan's lists and the launch structure of the device: every
+    launch reads a snapshot of what the launches before it left (a job that needed a result of its own launch would read stale data here, as it would race there),
+    touches only the tiles the lists name, masks as the kernels mask."""
+    n = len(rhs); n_pad = P["n_pad"]; nw = P["new_of_old"]
+    A = np.eye(n_pad); b = np.zeros(n_pad)
+    A[np.ix_(nw, nw)] = M; b[nw] = rhs
+    A = np.tril(A)
+    Linv = {}; y = np.zeros(n_pad)
+    for l in range(P["levels"]):
+        snap = A.copy(); bsnap = b.copy()
+        seen = set()
+        for k, g in P["pwg"][P["pwg_off"][l]:P["pwg_off"][l + 1]]:
+            k0, base = k * NB, (k + 1) * NB
+            rt = P["row_tiles"][P["row_off"][k]:P["row_off"][k + 1]]
+            assert g < max(1, 8 * len(rt))
+            if k not in seen:
+                seen.add(k)
+                D = snap[k0:base, k0:base]; D = np.tril(D) + np.tril(D, -1).T
+                Lkk = np.linalg.cholesky(D); Linv[k] = np.linalg.inv(Lkk)
+                y[k0:base] = Linv[k] @ bsnap[k0:base]
+            if len(rt):
+                r0 = rt[g // 8] * TILE + (g % 8) * 8
+                rows = np.arange(r0, r0 + 8); rows = rows[(rows >= base) & (rows < n_pad)]
+                A[np.ix_(rows, np.arange(k0, base))] = snap[np.ix_(rows, np.arange(k0, base))] @ Linv[k].T
+        assert seen == set(P["cols"][P["col_off"][l]:P["col_off"][l + 1]].tolist())
+        snap = A.copy()
+        written = set()
+        for ti, tj, so, ns, col_min, _ in P["targets"][P["upd_off"][l]:P["upd_off"][l + 1]]:
+            assert (ti, tj) not in written and ti >= tj
+            written.add((ti, tj))
+            r = np.arange(ti * TILE, (ti + 1) * TILE); c = np.arange(tj * TILE, (tj + 1) * TILE)
+            acc = np.zeros((TILE, TILE))
+            for k in P["sources"][so:so + ns]:
+                k0, base = k * NB, (k + 1) * NB
+                a = snap[np.ix_(r, np.arange(k0, base))] * (r >= base)[:, None]
+                bb = snap[np.ix_(c, np.arange(k0, base))] * (c >= base)[:, None]
+                acc += a @ bb.T
+            mask = (c[None, :] <= r[:, None]) & (c[None, :] >= col_min)
+            A[np.ix_(r, c)] = np.where(mask, snap[np.ix_(r, c)] - acc, snap[np.ix_(r, c)])
+        for tile, so, ns, _ in P["ftargets"][P["fwd_off"][l]:P["fwd_off"][l + 1]]:
+            r = np.arange(tile * TILE, (tile + 1) * TILE)
+            for k in P["fsources"][so:so + ns]:
+                k0, base = k * NB, (k + 1) * NB
+                b[r] -= (snap[np.ix_(r, np.arange(k0, base))] @ y[k0:base]) * (r >= base)
+    x = b.copy()
+    for l in range(P["levels"] - 1, -1, -1):
+        xs = x.copy()
+        for k in P["cols"][P["col_off"][l]:P["col_off"][l + 1]]:
+            k0, base = k * NB, (k + 1) * NB
+            v = y[k0:base].copy()
+            for t in P["row_tiles"][P["row_off"][k]:P["row_off"][k + 1]]:
+                r = np.arange(t * TILE, (t + 1) * TILE)
+                v -= A[np.ix_(r, np.arange(k0, base))].T @ (xs[r] * (r >= base))
+            x[k0:base] = Linv[k].T @ v
+    return x[nw], A
+
+
+def proximity_pairs(rng, P, degree):
+    """Poses scattered over a floor, every pose tied to its `degree` nearest ones (what FindNeighbors produces on a trajectory that revisits a room), + self blocks."""
+    xy = rng.uniform(0, 1, size=(P, 2))
+    d = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)
+    pairs = [(p, p) for p in range(P)]
+    seen = set()
+    for p in range(P):
+        for q in np.argsort(d[p])[1:degree + 1]:
+            e = (min(p, int(q)), max(p, int(q)))
+            if e not in seen:
+                seen.add(e); pairs.append(e)
+    return pairs
+
+
+@pytest.mark.parametrize("shape", ["chain", "chain_with_loops", "proximity", "two_components", "tiny"])
+def test_level_schedule_solves_the_system_with_its_own_lists(chk, shape):
+    chk.chk_spd_levels.restype = ctypes.c_int
+    rng = np.random.default_rng(11)
+    if shape == "chain":
+        P = 90; pairs = [(p, p) for p in range(P)] + [(p, q) for p in range(P) for q in range(p + 1, min(P, p + 4))]
+    elif shape == "chain_with_loops":
+        P = 120; pairs = [(p, p) for p in range(P)] + [(p, q) for p in range(P) for q in range(p + 1, min(P, p + 3))] + [(3, 97), (10, 60), (11, 61), (40, 118)]
+    elif shape == "proximity":
+        P = 260; pairs = proximity_pairs(rng, P, 7)
+    elif shape == "two_components":
+        P = 80; pairs = [(p, p) for p in range(P)] + [(p, p + 1) for p in range(39)] + [(p, p + 1) for p in range(40, 79)] + [(p, p + 2) for p in range(40, 78)]
+    else:
+        P = 3; pairs = [(0, 0), (1, 1), (2, 2), (0, 1)]
+    n, rows, cols, M = system(rng, P, pairs, constant={(0, 0), (0, 1)})
+    plan_ = levels_plan(chk, n, rows, cols, leaf=6)
+    assert plan_["ordered"] and plan_["n_pad"] % TILE == 0 and plan_["n_pad"] >= n
+    assert len(set(plan_["new_of_old"].tolist())) == n and plan_["new_of_old"].max() < plan_["n_pad"]
+    assert sorted(plan_["cols"].tolist()) == list(range(plan_["block_cols"]))
+    rhs = rng.normal(size=n)
+    x, _ = solve_by_levels(plan_, M, rhs)
+    want = np.linalg.solve(M, rhs)
+    assert np.abs(x - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    if shape in ("chain", "proximity", "chain_with_loops"):
+        assert plan_["levels"] < 0.75 * plan_["block_cols"], (plan_["levels"], plan_["block_cols"])      # the schedule is shorter than the column-by-column chain
