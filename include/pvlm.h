@@ -311,6 +311,10 @@ typedef struct {
   const double* end_points;     /* 2x3 per segment, LiDAR-local                                   */
   const float* seg_points_xyz;  /* optional: the points of edge_segmented[0], [1], ... one after the other (sum of
                                    segment_size x 3 floats, WORLD frame like the clouds) — needed by pvlm_line2line_residuals */
+  int point_stride_floats;      /* distance in floats between consecutive points of surf_flat_xyz / surf_less_flat_xyz / corner_xyz AND between
+                                   consecutive entries of the two tag arrays.  0 (or 3 for the xyz arrays): packed, as documented above.  4: the arrays point
+                                   INTO pcl::PointXYZI-style records {x, y, z, intensity} (xyz = &cloud[0].x, tag = &cloud[0].intensity): the upload gathers them
+                                   itself and the caller flattens nothing.  seg_points_xyz is always packed.                                                  */
 } pvlm_scan_desc;
 
 pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* desc, pvlm_scan** out);

@@ -822,7 +822,7 @@ class ScanDesc(C.Structure):
         ("p2s_offsets", C.POINTER(C.c_int)), ("p2s_ids", C.POINTER(C.c_int)),
         ("n_segments", C.c_int), ("segment_size", C.POINTER(C.c_int)),
         ("segment_coeffs", C.POINTER(C.c_double)), ("end_points", C.POINTER(C.c_double)),
-        ("seg_points_xyz", C.POINTER(C.c_float)),
+        ("seg_points_xyz", C.POINTER(C.c_float)), ("point_stride_floats", C.c_int),
     ]
 
 
@@ -863,6 +863,16 @@ class Scan:
             assert len(seg_xyz) == int(seg_size.sum())
         d.seg_points_xyz = _p(seg_xyz, C.c_float) if seg_xyz is not None and len(seg_xyz) else None
         keep = (R, t, flat, flat_tag, less, less_tag, corner, off, ids, seg_size, seg_coeffs, end_points, seg_xyz)
+        if g("point_records", False):
+            # the clouds handed over as pcl::PointXYZI-style records {x, y, z, intensity} (point_stride_floats = 4): xyz and tag point INTO one n x 4 array per cloud
+            rec = [np.ascontiguousarray(np.concatenate([xyz, tag[:, None]], axis=1), np.float32) if len(xyz) else np.zeros((0, 4), np.float32)
+                   for xyz, tag in ((flat, flat_tag), (less, less_tag), (corner, np.zeros(len(corner), np.float32)))]
+            at = lambda a, k: C.cast(a.ctypes.data + 4 * k, C.POINTER(C.c_float)) if len(a) else None
+            d.point_stride_floats = 4
+            d.surf_flat_xyz, d.surf_flat_tag = at(rec[0], 0), at(rec[0], 3)
+            d.surf_less_flat_xyz, d.surf_less_flat_tag = at(rec[1], 0), at(rec[1], 3)
+            d.corner_xyz = at(rec[2], 0)
+            keep = keep + tuple(rec)
         return d, keep
 
     def _adopt(self, ctx, d, handle):

@@ -495,6 +495,7 @@ struct DevScratch {
 struct CloudPlan {
   int n = 0;
   const float* xyz = nullptr; const float* tag = nullptr;
+  int xyz_stride = 3, tag_stride = 1;            // floats between consecutive points / tags of the CALLER's arrays (pvlm_scan_desc::point_stride_floats)
   bool grid = false;
   float h = 0.f, origin[3] = {0, 0, 0};
   int dense = 0, nx = 0, ny = 0, nz = 0, xf = 1;
@@ -506,12 +507,12 @@ struct CloudPlan {
 // bounding box of a cloud and its first non-finite point (a NaN never updates a min / max, so every coordinate is tested): the one pass
 // over the points that planning needs — taken for all clouds of a batch side by side (pvlm_scan_upload_batch), reported serially
 struct CloudBox { float mn[3], mx[3]; int bad_point; };
-static void cloud_box(int n, const float* xyz, CloudBox& b) {
+static void cloud_box(int n, const float* xyz, CloudBox& b, int stride = 3) {
   for (int k = 0; k < 3; ++k) { b.mn[k] = FLT_MAX; b.mx[k] = -FLT_MAX; }
   b.bad_point = -1;
   for (int i = 0; i < n; ++i)
     for (int k = 0; k < 3; ++k) {
-      const float v = xyz[3 * i + k];
+      const float v = xyz[(size_t)stride * i + k];
       if (!std::isfinite(v)) { b.bad_point = i; return; }
       if (v < b.mn[k]) b.mn[k] = v;
       if (v > b.mx[k]) b.mx[k] = v;
@@ -734,7 +735,7 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
     if (!d->R_wl || !d->t_wl || d->n_surf_flat < 0 || d->n_surf_less_flat < 0 || d->n_corner < 0 || d->n_segments < 0 ||
         (d->n_surf_flat > 0 && (!d->surf_flat_xyz || !d->surf_flat_tag)) ||
         (d->n_surf_less_flat > 0 && (!d->surf_less_flat_xyz || !d->surf_less_flat_tag)) || (d->n_corner > 0 && !d->corner_xyz) ||
-        (d->n_segments > 0 && (!d->segment_size || !d->segment_coeffs))) {
+        (d->n_segments > 0 && (!d->segment_size || !d->segment_coeffs)) || d->point_stride_floats < 0 || (d->point_stride_floats > 0 && d->point_stride_floats < 3)) {
       PVLM_SET_ERR(ctx, "pvlm_scan_upload: inconsistent descriptor (scan %d of the batch)", k);
       return PVLM_ERR_ARG;
     }
@@ -752,9 +753,10 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   {
     auto box_of = [&](int k) {
       const pvlm_scan_desc* d = &descs[k];
-      if (d->n_surf_flat > 0 && d->n_surf_flat <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_surf_flat, d->surf_flat_xyz, boxes[(size_t)k * 3]);
-      if (d->n_surf_less_flat > 0 && d->n_surf_less_flat <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_surf_less_flat, d->surf_less_flat_xyz, boxes[(size_t)k * 3 + 1]);
-      if (d->n_corner > 0 && d->n_corner <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_corner, d->corner_xyz, boxes[(size_t)k * 3 + 2]);
+      const int ps = d->point_stride_floats > 0 ? d->point_stride_floats : 3;
+      if (d->n_surf_flat > 0 && d->n_surf_flat <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_surf_flat, d->surf_flat_xyz, boxes[(size_t)k * 3], ps);
+      if (d->n_surf_less_flat > 0 && d->n_surf_less_flat <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_surf_less_flat, d->surf_less_flat_xyz, boxes[(size_t)k * 3 + 1], ps);
+      if (d->n_corner > 0 && d->n_corner <= PVLM_MAX_CLOUD_POINTS) cloud_box(d->n_corner, d->corner_xyz, boxes[(size_t)k * 3 + 2], ps);
     };
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), (size_t)n_scans / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     std::atomic<int> next{0};
@@ -774,6 +776,9 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
     if (!st) st = cloud_plan(ctx, P.less, d->n_surf_less_flat, d->surf_less_flat_xyz, d->surf_less_flat_tag, true, &boxes[(size_t)k * 3 + 1]);
     if (!st) st = cloud_plan(ctx, P.corner, d->n_corner, d->corner_xyz, nullptr, true, &boxes[(size_t)k * 3 + 2]);
     if (st) break;
+    if (d->point_stride_floats > 3) {
+      for (CloudPlan* c : {&P.flat, &P.less, &P.corner}) { c->xyz_stride = d->point_stride_floats; c->tag_stride = d->point_stride_floats; }
+    }
     if (d->n_corner > 0) {
       if (d->p2s_offsets) {
         s->h_p2s_off.assign(d->p2s_offsets, d->p2s_offsets + d->n_corner + 1);
@@ -842,12 +847,13 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   char* h = (char*)ctx->h_up;
   pvlm_i_trace("scan_upload_batch: layout + allocations");
   // ---- 4. the uploaded arrays as a list of (offset, source) segments, in ascending offset order
-  struct Seg { size_t off; const void* src; size_t bytes; };
+  struct Seg { size_t off; const void* src; size_t bytes; size_t elem = 0, stride = 0; };   // elem != 0: `bytes / elem` records of `elem` bytes, `stride` bytes apart at the source
   std::vector<Seg> segs;
   each_cloud([&](CloudPlan& c) {
     if (c.n <= 0) return;
-    segs.push_back({c.o_xyz, c.xyz, (size_t)c.n * 12});
-    if (c.tag) segs.push_back({c.o_tag, c.tag, (size_t)c.n * 4});
+    if (c.xyz_stride == 3) segs.push_back({c.o_xyz, c.xyz, (size_t)c.n * 12});
+    else segs.push_back({c.o_xyz, c.xyz, (size_t)c.n * 12, 12, (size_t)c.xyz_stride * 4});
+    if (c.tag) { if (c.tag_stride == 1) segs.push_back({c.o_tag, c.tag, (size_t)c.n * 4}); else segs.push_back({c.o_tag, c.tag, (size_t)c.n * 4, 4, (size_t)c.tag_stride * 4}); }
   });
   for (int k = 0; k < n_scans; ++k) {
     ScanPlan& P = plan[(size_t)k]; pvlm_scan* s = scans[(size_t)k];
@@ -869,7 +875,15 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
     while (last_seg < segs.size() && segs[last_seg].off < hi) ++last_seg;
     auto stage = [&](size_t q) {
       const size_t a = std::max(segs[q].off, lo), b = std::min(segs[q].off + segs[q].bytes, hi);
-      if (b > a) std::memcpy(h + (a - lo), (const char*)segs[q].src + (a - segs[q].off), b - a);
+      if (b <= a) return;
+      if (!segs[q].elem) { std::memcpy(h + (a - lo), (const char*)segs[q].src + (a - segs[q].off), b - a); return; }
+      // strided records (pcl::PointXYZI-style arrays): gathered record by record; a window boundary may fall inside a record
+      const size_t el = segs[q].elem, sd = segs[q].stride;
+      for (size_t p = a; p < b;) {
+        const size_t rel = p - segs[q].off, rec = rel / el, in = rel - rec * el, take = std::min(el - in, b - p);
+        std::memcpy(h + (p - lo), (const char*)segs[q].src + rec * sd + in, take);
+        p += take;
+      }
     };
     {   // the segments land in disjoint ranges of the pinned window: copied side by side (one core moves ~10 GB/s, the window is up to 64 MB)
       const size_t n_threads = (hi - lo) < ((size_t)8 << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)8, (last_seg - first_seg) / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));

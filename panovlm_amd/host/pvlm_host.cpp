@@ -206,16 +206,14 @@ Velodyne& Velodyne::operator=(const Velodyne& o) {
 // Host-side flattening of one scan's members into the arrays a pvlm_scan_desc points at.
 namespace {
 struct ScanStaging {
-  std::vector<float> fx, ft, lx, lt, cx, seg_xyz;
+  std::vector<float> seg_xyz;
   std::vector<int> off, ids, seg_size;
   std::vector<double> coeffs, ends;
   pvlm_scan_desc d;
   void Fill(const Velodyne& v, const Matrix3d& R_wl, const Vector3d& t_wl) {
-    auto flat = [](const PointCloud& c, std::vector<float>& xyz, std::vector<float>* tag) {
-      xyz.resize(c.size() * 3); if (tag) tag->resize(c.size());
-      for (size_t i = 0; i < c.size(); ++i) { xyz[3 * i] = c[i].x; xyz[3 * i + 1] = c[i].y; xyz[3 * i + 2] = c[i].z; if (tag) (*tag)[i] = c[i].intensity; }
-    };
-    flat(v.surfFlat, fx, &ft); flat(v.surfLessFlat, lx, &lt); flat(v.cornerLessSharp, cx, nullptr);
+    // the three clouds are handed over where they lie: point_stride_floats = 4 lets the upload gather x, y, z and the intensity out of the PointXYZI records
+    // itself (round 5 flattened them into six scratch vectors first: 28 ms of first-touch page faults for the 1593 scans of Floor)
+    static_assert(sizeof(PointXYZI) == 4 * sizeof(float), "PointXYZI is handed to pvlm_scan_upload with point_stride_floats = 4");
     off.assign(v.cornerLessSharp.size() + 1, 0); ids.clear(); seg_size.resize(v.edge_segmented.size());
     for (size_t i = 0; i < v.cornerLessSharp.size(); ++i) {
       if (i < v.point_to_segment.size()) for (int s : v.point_to_segment[i]) ids.push_back(s);
@@ -230,9 +228,11 @@ struct ScanStaging {
     if (ids.empty()) ids.push_back(0);
     std::memset(&d, 0, sizeof(d));
     d.id = v.id; d.R_wl = R_wl.data(); d.t_wl = t_wl.data();
-    d.n_surf_flat = (int)v.surfFlat.size(); d.surf_flat_xyz = fx.data(); d.surf_flat_tag = ft.data();
-    d.n_surf_less_flat = (int)v.surfLessFlat.size(); d.surf_less_flat_xyz = lx.data(); d.surf_less_flat_tag = lt.data();
-    d.n_corner = (int)v.cornerLessSharp.size(); d.corner_xyz = cx.data(); d.p2s_offsets = off.data(); d.p2s_ids = ids.data();
+    d.point_stride_floats = 4;
+    d.n_surf_flat = (int)v.surfFlat.size(); if (d.n_surf_flat) { d.surf_flat_xyz = &v.surfFlat[0].x; d.surf_flat_tag = &v.surfFlat[0].intensity; }
+    d.n_surf_less_flat = (int)v.surfLessFlat.size(); if (d.n_surf_less_flat) { d.surf_less_flat_xyz = &v.surfLessFlat[0].x; d.surf_less_flat_tag = &v.surfLessFlat[0].intensity; }
+    d.n_corner = (int)v.cornerLessSharp.size(); if (d.n_corner) d.corner_xyz = &v.cornerLessSharp[0].x;
+    d.p2s_offsets = off.data(); d.p2s_ids = ids.data();
     d.n_segments = (int)std::min(v.edge_segmented.size(), v.segment_coeffs.size()); d.segment_size = seg_size.data();
     d.segment_coeffs = coeffs.data(); d.end_points = ends.data();
     // the segments' own point lists (edge_segmented), for the device-built line-to-line blocks

@@ -189,3 +189,36 @@ def test_argument_and_state_errors(ctx):
         pv.Scan.transform_batch(ctx, dev, [huge, I])
     for d in dev:
         d.close()
+
+
+def test_upload_from_point_records_equals_packed_upload(ctx):
+    """pvlm_scan_desc::point_stride_floats = 4 — the clouds handed over as pcl::PointXYZI records where they lie (what the host mirror does since round 6: no flattening
+    pass) — builds the same resident scan as the packed arrays: floats, tags (through the association: class test), grids."""
+    import panovlm_amd as pv
+    rng = np.random.default_rng(9)
+    scans = []
+    for k in range(5):
+        s = _posed(_local_scan(rng, k, 256, 4, big_extent=(k == 3)), _T(*sy.estimated_pose(k)), sy.estimated_pose(k))
+        s["less_tag"] = np.where(rng.uniform(size=len(s["less_xyz"])) < 0.1, 16.0, 1.0).astype(np.float32)
+        s["flat_tag"] = np.where(rng.uniform(size=len(s["flat_xyz"])) < 0.3, 16.0, 1.0).astype(np.float32)
+        scans.append(s)
+    packed = pv.Scan.upload_batch(ctx, scans)
+    records = pv.Scan.upload_batch(ctx, [dict(s, point_records=True) for s in scans])
+    for a, b in zip(packed, records):
+        for which in range(4):
+            if which in (1, 2):
+                xa, ga = a.fetch_cloud(which, grid=True); xb, gb = b.fetch_cloud(which, grid=True)
+                _same_grid(ga, gb)
+            else:
+                xa, xb = a.fetch_cloud(which), b.fetch_cloud(which)
+            assert xa.tobytes() == xb.tobytes()
+    pairs = [(0, 1), (1, 2), (3, 4), (4, 0)]
+    out = []
+    for dev in (packed, records):
+        rs = ctx.assoc_point2plane([dev[r] for r, _ in pairs], [dev[q] for _, q in pairs], 0.05, 1.0, flags=pv.FLAG_NORMALIZE_DISTANCE | 0x100)
+        off, _, _, rows = rs.download(); qidx, nn = rs.assoc_debug()
+        out.append((off.tobytes(), rows.tobytes(), qidx.tobytes(), nn.tobytes())); assert rs.n > 500
+        rs.close()
+    assert out[0] == out[1]
+    for d in packed + records:
+        d.close()
