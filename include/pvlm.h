@@ -33,7 +33,9 @@ typedef enum {
   PVLM_ERR_HIP = -2,      /* HIP runtime error (no device, launch failure, ...)           */
   PVLM_ERR_NOMEM = -3,    /* host or device allocation failed                             */
   PVLM_ERR_STATE = -4,    /* call order violated (e.g. evaluate before pvlm_set_poses)    */
-  PVLM_ERR_CAPACITY = -5  /* caller-provided output buffer too small                      */
+  PVLM_ERR_CAPACITY = -5, /* caller-provided output buffer too small                      */
+  PVLM_ERR_REFUSED = -6   /* the input is valid for the reference but outside what this entry point handles (pvlm_ring_extract_batch: a non-finite
+                             coordinate, more undecided segmentation edges than its tables hold): the caller takes its own path for it; nothing else failed */
 } pvlm_status;
 
 /* Residual functors — base/CostFunction.h.  All are 1 residual x 4 parameter blocks of 3

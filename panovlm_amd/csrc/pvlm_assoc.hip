@@ -463,6 +463,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? PVL
   }
 }
 
+// A sparse column block made dense: the accepted rows of every pair copied into a block that holds only them (segment p: rows [dst[p], dst[p] + count[p])).
+// With raw scans as targets 94 % of the queries are rejected: the block of a batch reserves a row per QUERY (the ordered placement needs no sizing round trip)
+// and would keep sixteen times the memory it uses for as long as the residual set lives.
+struct CompactSeg { long long src, dst; int count, pad; };
+__global__ __launch_bounds__(256) void k_compact_block(const CompactSeg* __restrict__ segs, const double* __restrict__ src, long long src_rows, double* __restrict__ dst, long long dst_rows) {
+  const CompactSeg sg = segs[blockIdx.y];
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < sg.count; r += gridDim.x * 256)
+#pragma unroll
+    for (int c = 0; c < 7; ++c) dst[(size_t)c * dst_rows + sg.dst + r] = src[(size_t)c * src_rows + sg.src + r];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1138,6 +1149,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     // a target cloud with fewer than 10 points can never satisfy the k = 10 search
     if (d.ref.n < 10) d.nq = 0;
   }
+  static const long long compact_min_bytes = getenv("PVLM_ASSOC_COMPACT_MIN_MB") ? (long long)(atof(getenv("PVLM_ASSOC_COMPACT_MIN_MB")) * 1048576.0) : (64ll << 20);
   const int k3_chunk = 256 * (exact_fit ? PVLM_K3_SUB : PVLM_K3F_SUB);       // queries per chunk of the plane-fit kernel that will run
   long long budget_rows = 16ll << 20;
   if (const char* env = getenv("PVLM_ASSOC_BATCH_ROWS")) { const long long v = atoll(env); if (v > 0) budget_rows = v; }
@@ -1229,6 +1241,29 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     }
     rs->block_n[(size_t)bi] = block_n;
     rs->assoc_exact_fits += ws.h_count[s][b.p1 - b.p0 + 1];
+    // a block that is mostly empty is replaced by a dense one (queued behind the kernels that filled it; the next batch is already running)
+    const long long R = batch_R[(size_t)bi];
+    if (!keep_idx && R * 56 >= compact_min_bytes && block_n * 2 < R) {
+      std::vector<CompactSeg> segs((size_t)(b.p1 - b.p0));
+      long long row = 0, longest = 0;
+      for (int p = b.p0; p < b.p1; ++p) {
+        const long long m = rs->h_out_start[(size_t)p + 1] - rs->h_out_start[(size_t)p];
+        segs[(size_t)(p - b.p0)] = CompactSeg{descs[(size_t)p].dst_row, row, (int)m, 0};
+        rs->h_seg_start[(size_t)p] = row;
+        row += pvlm_i_seg_rows(m); longest = std::max(longest, m);
+      }
+      const long long R2 = std::max<long long>(row, 16);
+      double* d_new = nullptr; CompactSeg* d_segs = nullptr;
+      pvlm_status sc = pvlm_i_alloc(ctx, &d_new, (size_t)R2 * 7);
+      if (!sc) sc = pvlm_i_alloc(ctx, &d_segs, segs.size());
+      if (!sc) sc = pvlm_i_h2d_q(ctx, d_segs, segs.data(), segs.size() * sizeof(CompactSeg));
+      if (sc) { pvlm_i_free(ctx, d_new); pvlm_i_free(ctx, d_segs); return sc; }
+      hipLaunchKernelGGL(k_compact_block, dim3((unsigned)std::max<long long>(1, std::min<long long>((longest + 255) / 256, 64)), (unsigned)segs.size()), dim3(256), 0, ctx->stream,
+                         (const CompactSeg*)d_segs, (const double*)rs->col_blocks[(size_t)bi], R, d_new, R2);
+      PVLM_HIP(ctx, hipGetLastError());
+      pvlm_i_free(ctx, rs->col_blocks[(size_t)bi]); pvlm_i_free(ctx, d_segs);     // stream-ordered: reused only by work queued after the copy
+      rs->col_blocks[(size_t)bi] = d_new; rs->block_rows[(size_t)bi] = R2; rs->n_dev += R2 - R;
+    }
     return PVLM_OK;
   };
   const int B = (int)batches.size();

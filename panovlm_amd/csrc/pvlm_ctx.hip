@@ -557,7 +557,10 @@ pvlm_status pvlm_i_resset_free(pvlm_ctx* ctx, pvlm_resset* rs) {
 pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs) {
   const int P = rs->n_pairs;
   rs->serial = ++ctx->resset_serial;
-  int64_t total = rs->n_dev;
+  // the rows the evaluation kernels will read: the accepted rows of every segment, padded — not n_dev, which for a set made by the association is the
+  // CAPACITY of its column blocks (every query has a slot)
+  int64_t total = 0;
+  for (int p = 0; p < P; ++p) total += pvlm_i_seg_rows(rs->h_out_start[(size_t)p + 1] - rs->h_out_start[(size_t)p]);
   int64_t chunk = ((total / 4096 + 511) / 512) * 512;
   chunk = std::max<int64_t>(512, std::min<int64_t>(16384, chunk));
   // Sets of many short segments (Room / Floor odometry: thousands of pairs of a few hundred blocks) are evaluated with a wave

@@ -598,7 +598,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     };
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({pvlm_thread_cap(), (size_t)n_scans / 32 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
     pvlm_run_workers(n_threads, work);
-    if (bad >= 0) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: non-finite coordinate (point %lld of the batch)", (long long)bad); return PVLM_ERR_ARG; }
+    if (bad >= 0) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: non-finite coordinate (point %lld of the batch)", (long long)bad); return PVLM_ERR_REFUSED; }
   }
   pvlm_i_trace("ring: staging copy");
   (void)hipEventRecord(ev[0], S);
@@ -699,7 +699,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     hipLaunchKernelGGL(k_seg_edges, cell_grid, dim3(256), 0, S, B->d_scans, n_rings, horizon, B->d_range_image, sin_x, cos_x, sin_y, cos_y, theta, d_edges, d_counter + 1, d_queries, query_cap);
     PVLM_HIP(ctx, hipMemcpyAsync(h_counter + 1, d_counter + 1, sizeof(int), hipMemcpyDeviceToHost, S));
     PVLM_HIP(ctx, hipStreamSynchronize(S));
-    if (h_counter[1] > query_cap) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %d undecided segmentation edges (capacity %d)", h_counter[1], query_cap); return (PVLM_ERR_CAPACITY); }
+    if (h_counter[1] > query_cap) { PVLM_SET_ERR(ctx, "pvlm_ring_extract_batch: %d undecided segmentation edges (capacity %d)", h_counter[1], query_cap); return (PVLM_ERR_REFUSED); }
     if (h_counter[1] > 0) {
       std::vector<EdgeQuery> q((size_t)h_counter[1]);
       PVLM_HIP(ctx, hipMemcpy(q.data(), d_queries, q.size() * sizeof(EdgeQuery), hipMemcpyDeviceToHost));
@@ -730,6 +730,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   hipLaunchKernelGGL(k_seg_compact, dim3((unsigned)n_scans), dim3(1024), 0, S, B->d_scans, n_rings, horizon, B->segment, d_ring_count, B->d_cloud_scan, d_source, B->d_rc,
                      B->d_range_image, d_root, d_comp_size, d_row_mask, B->d_cloud2, d_source2, d_ring_col2, d_range2, B->d_image_to_point2, d_ring_count2, d_counts);
   hipLaunchKernelGGL(k_curvature, dim3((unsigned)blocks.size()), dim3(256), 0, S, B->d_scans, d_blocks, d_ring_count2, d_counts, B->d_cloud2, d_range2, d_curv, d_half, d_order);
+  PVLM_HIP(ctx, hipGetLastError());       // a rejected launch must fail the batch: the arrays below would be copied down uninitialised (the caller's host path takes over)
   // the five per-point arrays are final here: they go down the link on a second stream while K23 / K24 run (20 of the 27 B per point)
   char* h = B->h_results;
   hipStream_t S2 = S;
@@ -746,6 +747,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     const unsigned waves = 256u * 16u;                                     // persistent: every wave walks the list with a grid stride
     hipLaunchKernelGGL(k_sector_ties<kTieSmall>, dim3(waves), dim3(64), 0, S, B->d_scans, d_ties, d_counter + 2, d_curv, d_order, d_sector);
     hipLaunchKernelGGL(k_sector_ties<kSectorMax>, dim3(waves / 4), dim3(64), 0, S, B->d_scans, d_ties + n_sectors, d_counter + 3, d_curv, d_order, d_sector);
+    PVLM_HIP(ctx, hipGetLastError());     // K23: sector orders / flags of a launch that did not run are pool garbage
   }
   int ring_cap = 0;
   if (picks) {
@@ -756,6 +758,7 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     A.voxel_counter = d_counter + 4; A.voxel_cap = (int)voxel_cap; A.ring_host = d_ring_host;
     const size_t lds = pick_lds_bytes(ring_cap);
     hipLaunchKernelGGL(k_ring_picks, dim3((unsigned)n_rings, (unsigned)n_scans), dim3(64), lds, S, A, n_rings, ring_cap, max_curvature, angle_threshold);
+    PVLM_HIP(ctx, hipGetLastError());     // K24 (dynamic LDS up to ~56 KB): ring_host / pick lists of a rejected launch must not reach AssemblePicks
   }
   (void)hipEventRecord(ev[7], S);
   // ---- results

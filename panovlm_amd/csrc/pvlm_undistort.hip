@@ -84,8 +84,13 @@ extern "C" pvlm_status pvlm_undistort_batch(pvlm_ctx* ctx, int n_scans, const pv
     hipError_t e = hipMemcpyAsync(d_pts, hp, (size_t)total * 16, hipMemcpyHostToDevice, S);
     if (e == hipSuccess) e = hipMemcpyAsync(d_desc, hd, (size_t)n_scans * sizeof(SweepDesc), hipMemcpyHostToDevice, S);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_undistort, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_scans), dim3(256), 0, S, d_desc, d_pts);
-      e = hipMemcpyAsync(hp, d_pts, (size_t)total * 16, hipMemcpyDeviceToHost, S);
+      // gridDim.y holds at most 65 535 scans: larger batches go in slices of the descriptor table (a launch that fails must not pass for a run that moved nothing)
+      for (int s0 = 0; s0 < n_scans && e == hipSuccess; s0 += 65535) {
+        const int ns = std::min(65535, n_scans - s0);
+        hipLaunchKernelGGL(k_undistort, dim3((unsigned)((max_n + 255) / 256), (unsigned)ns), dim3(256), 0, S, (const SweepDesc*)d_desc + s0, d_pts);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(hp, d_pts, (size_t)total * 16, hipMemcpyDeviceToHost, S);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(S);
     pvlm_i_free(ctx, d_pts); pvlm_i_free(ctx, d_desc);

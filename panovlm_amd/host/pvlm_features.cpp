@@ -488,6 +488,9 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     todo.push_back(k);
   }
   if (todo.empty()) return;
+  // the device copies of the scans that are about to change, given back HERE, on the thread that owns the engine: the workers below call InvalidateDevice() too
+  // (PickFeatures, AssemblePicks, EdgeToLine), concurrently with the producer's use of the same context — with nothing left to give back those calls are no-ops
+  for (size_t k : todo) scans[k]->InvalidateDevice();
   const auto profile_t0 = std::chrono::steady_clock::now();
   const int rings = scans[todo[0]]->N_SCANS, horizon = scans[todo[0]]->horizon_scans;
   if (rings > 64) throw std::invalid_argument("ExtractFeatures: at most 64 rings");
@@ -502,7 +505,7 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
   const size_t per_batch = total <= 48 ? total : std::max<size_t>(24, (total + n_parts - 1) / n_parts);
   // PVLM_FEATURE_PICKS=host: the picks and the voxel grid on the host threads (PickFeatures) instead of K24 — the A/B switch of tools/feature_batch_bench.py
   static const bool device_picks = [] { const char* v = std::getenv("PVLM_FEATURE_PICKS"); return !(v && std::strcmp(v, "host") == 0); }();
-  std::atomic<long> scans_on_host{0};
+  std::atomic<long> scans_on_host{0}, scans_refused{0};
   struct Part { pvlm_ring_batch* batch = nullptr; bool on_host = false; };
   std::vector<Part> parts((total + per_batch - 1) / per_batch);
   struct Release { pvlm_ctx* c; std::vector<Part>& p; ~Release() { for (Part& q : p) pvlm_ring_batch_destroy(c, q.batch); } } release{e.ctx(), parts};
@@ -519,11 +522,13 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
         const pvlm_status rc = device_picks ? pvlm_ring_extract_batch_picks(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, max_curvature,
                                                                             intersect_angle_threshold, &parts[k].batch)
                                             : pvlm_ring_extract_batch(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, &parts[k].batch);
-        if (rc == PVLM_ERR_ARG || rc == PVLM_ERR_CAPACITY || rc == PVLM_ERR_NOMEM) {
+        if (rc == PVLM_ERR_REFUSED) {
           // The batch form is stricter than the reference: it refuses a batch with a non-finite coordinate (upstream such a point gets ring -1 and is
-          // skipped, sensors/Velodyne.cpp:439-445) and gives up beyond its bounds on undecided segmentation edges / memory.  Neither is a reason to fail
-          // EstimatePose: these scans go through the per-scan host path, which skips such points exactly as upstream does.
-          fprintf(stderr, "ExtractFeaturesBatch: %s — falling back to the host extraction for %zu scans\n", pvlm_last_error(e.ctx()), count);
+          // skipped, sensors/Velodyne.cpp:439-445) and gives up beyond its bounds on undecided segmentation edges.  Neither is a reason to fail
+          // EstimatePose: these scans go through the per-scan host path, which skips such points exactly as upstream does.  Every OTHER error (a bad argument,
+          // memory, a failed launch) is an error and propagates: a silent fall-back would turn it into a large unexplained slowdown.
+          fprintf(stderr, "ExtractFeaturesBatch: %s — the per-scan host extraction takes these %zu scans\n", pvlm_last_error(e.ctx()), count);
+          scans_refused += (long)count;
           parts[k].on_host = true;
         } else {
           e.Check(rc, "pvlm_ring_extract_batch");
@@ -605,7 +610,8 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
   const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::max(num_threads, 1), total + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
   pvlm_run_workers(n_threads, work);
   if (failure) std::rethrow_exception(failure);
-  if (Profile().on) fprintf(stderr, "feature_profile scans picked on the host (a ring undecided on the device): %ld of %zu\n", scans_on_host.load(), total);
+  if (scans_refused.load()) AddStageSeconds("  (inside feature extraction) scans of batches the device refused, extracted scan by scan on the host [count in calls]", 0.0);
+  if (Profile().on) fprintf(stderr, "feature_profile scans picked on the host (a ring undecided on the device): %ld of %zu; scans of refused batches: %ld\n", scans_on_host.load(), total, scans_refused.load());
   if (Profile().on) Profile().Report("ExtractFeaturesBatch", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - profile_t0).count(), ring_ms, producer_ms);
 }
 

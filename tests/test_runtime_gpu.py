@@ -337,3 +337,35 @@ def test_bench_two_ranks_on_one_gpu_runs_the_multi_rank_branch_of_bench_py():
     assert abs(two["config"]["robust_cost"] - one["config"]["robust_cost"]) <= 1e-12 * one["config"]["robust_cost"]
     assert two["image_space_all_ranks"]["ranks_measured"] == 2
     assert two["roofline"]["kernel"] == "k_eval_fused" and two["scaling"] == "strong"
+
+
+def test_sparse_association_blocks_are_made_dense():
+    """Raw scans as targets at full resolution: nine queries in ten are rejected by the reference's collinearity test (here, at a quarter of the resolution, a short
+    search radius does the rejecting), yet every query has a row reserved in the batch's column block
+    (the ordered placement inside k_fit_pairs needs no sizing round trip).  A block that ends up less than half full is replaced by a dense copy (k_compact_block;
+    from 64 MB on by default, forced here): the residual set keeps the memory it uses, and evaluates to the same bits."""
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "import panovlm_amd as pv\nfrom panovlm_amd import synthetic as sy\n"
+        "F = 4; scans = {k: sy.make_scan(k, cols=1024) for k in range(F)}\n"
+        "ref, nei = sy.pair_list(F, 2)\n"
+        "ctx = pv.Context(0); dev = {k: pv.Scan(ctx, s) for k, s in scans.items()}\n"
+        "m0 = ctx.mem_info()['in_use']\n"
+        "rs = ctx.assoc_point2plane([dev[int(r)] for r in ref], [dev[int(n)] for n in nei], 0.05, 0.12, kind=pv.POINT2PLANE_ANGLE, flags=pv.FLAG_NORMALIZE_DISTANCE)\n"
+        "ctx.synchronize(); held = ctx.mem_info()['in_use'] - m0\n"
+        "off, r, n, rows = rs.download()\n"
+        "aa = np.zeros((F, 3)); t = np.zeros((F, 3)); ctx.set_poses(aa, t)\n"
+        "res, J = rs.eval(jac=True); blocks = rs.pair_blocks(pv.LOSS_HUBER, 0.03)\n"
+        "queries = sum(len(scans[int(k)]['flat_xyz']) for k in nei)\n"
+        "np.savez(sys.argv[1], off=off, rows=rows, res=res, J=J, blocks=blocks, held=held, queries=queries)\n" % ROOT)
+    out = {}
+    for tag, mb in (("dense", "0"), ("reserved", "1000000")):
+        path = "/tmp/pvlm_compact_%s_%d.npz" % (tag, os.getpid())
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, PVLM_ASSOC_COMPACT_MIN_MB=mb), timeout=600)
+        out[tag] = dict(np.load(path))
+        os.remove(path)
+    for k in ("off", "rows", "res", "J", "blocks"):
+        assert np.array_equal(out["dense"][k], out["reserved"][k]), k
+    n, q = int(out["dense"]["off"][-1]), int(out["dense"]["queries"])
+    assert 0 < n < 0.45 * q, (n, q)                                               # most queries were rejected
+    assert out["reserved"]["held"] >= q * 56 and out["dense"]["held"] <= out["reserved"]["held"] - 0.4 * q * 56, (out["dense"]["held"], out["reserved"]["held"], q)
