@@ -1033,7 +1033,7 @@ def features_block(ctx, pv, scans=454, cols=1800):
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
-        b = pv.RingBatch(ctx, raws, n_rings=16, horizon=cols, segment=True, picks=(1000.0, 5.0))
+        b = pv.RingBatch(ctx, raws, n_rings=16, horizon=cols, segment=True, picks=(1000.0, 5.0), keep_arrays=False)      # what the C++ host mirror asks for
         wall = (time.perf_counter() - t0) * 1e3
         tm = b.timing()
         if best is None or wall < best[0]:
@@ -1052,11 +1052,13 @@ def features_block(ctx, pv, scans=454, cols=1800):
                    "ExtractPlaneFeatures2 picks + pcl::VoxelGrid of the less-flat points (sensors/Velodyne.cpp:371-526, :1438-1586, :623-657, :883-1000, :1098-1189); "
                    "compact_curvature = K21 + K22 + K23 + K24; bit-exact vs the oracle: tests/test_ring_gpu.py.  EdgeToLine stays on the host "
                    "(tools/feature_batch_bench.py times the whole ExtractFeaturesBatch)"}
-    # roof of the batch: the host link.  The boundary hands over host buffers and takes host arrays back: 16 B per raw point up; 24 B per point (five arrays +
-    # the sector order), 1 B of state and ~2 B of pick lists and centroids down, at the link rate the `pcie` block measures
+    # roof of the batch: the host link.  The boundary hands over host buffers and takes host arrays back: 16 B per raw point up; down — since round 6 — source index +
+    # (ring, column) of every kept point (8 B), 1 B of state and ~2 B of pick lists and centroids; the other five per-point arrays (16 B: curvature, window, range,
+    # sector order) only for the scans with a ring K24 left to the host (round 5: always, 43 B per point in all)
     link = PEAKS["host_link_GBps"] * 1e9
-    moved = out["points"] * 43
-    out["roof"] = {"bound": "host link (PCIe Gen5 x16)", "bytes_per_point": 43, "bytes_per_batch": moved, "GBps_assumed": link / 1e9,
+    bytes_per_point = 16 + 8 + 1 + 2 + 16.0 * undecided / max(sampled, 1)
+    moved = out["points"] * bytes_per_point
+    out["roof"] = {"bound": "host link (PCIe Gen5 x16)", "bytes_per_point": bytes_per_point, "bytes_per_point_round5": 43, "bytes_per_batch": moved, "GBps_assumed": link / 1e9,
                    "ms_at_link_rate": moved / link * 1e3, "frac": (moved / link * 1e3) / wall, "device_ms_share": device_ms / wall}
     try:
         from oracle import oracle as orc

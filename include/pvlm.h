@@ -658,7 +658,9 @@ typedef struct pvlm_ring_result {
 } pvlm_ring_result;
 pvlm_status pvlm_ring_extract_batch(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* scans, int n_rings, int horizon_scans, int segment,
                                     pvlm_ring_batch** out);
-/* The same, plus K24: the feature picks and the voxel grid (max_curvature, intersect_angle_threshold: the arguments of Velodyne::ExtractFeatures). */
+/* The same, plus K24: the feature picks and the voxel grid (max_curvature, intersect_angle_threshold: the arguments of Velodyne::ExtractFeatures).  With the picks made
+ * on the device the five per-point arrays curvature / half_window / range / sorted / sector_host (16 of the 27 B per point of the download) are delivered only for the
+ * scans that have a ring left to the host (ring_host != 0) — they are NULL for the others — unless bit 1 of `segment` is set (segment = 2 | run_segmentation: always). */
 pvlm_status pvlm_ring_extract_batch_picks(pvlm_ctx* ctx, int n_scans, const pvlm_raw_scan* scans, int n_rings, int horizon_scans, int segment,
                                           float max_curvature, float intersect_angle_threshold, pvlm_ring_batch** out);
 pvlm_status pvlm_ring_batch_scan(const pvlm_ring_batch* batch, int scan, pvlm_ring_result* result);

@@ -1014,8 +1014,9 @@ class RingResultDesc(C.Structure):
 class RingBatch:
     """pvlm_ring_extract_batch: ReOrderVLP + Segmentation + adaptive curvature of a batch of raw scans (n x 4 float32 each) on the GPU."""
 
-    def __init__(self, ctx, raw_scans, n_rings=16, horizon=1800, segment=True, picks=None):
-        """picks = (max_curvature, intersect_angle_threshold): also run K24 (feature picks + voxel grid) — see RingBatch.picks()."""
+    def __init__(self, ctx, raw_scans, n_rings=16, horizon=1800, segment=True, picks=None, keep_arrays=True):
+        """picks = (max_curvature, intersect_angle_threshold): also run K24 (feature picks + voxel grid) — see RingBatch.picks().  keep_arrays=False (with picks): the
+        per-point arrays curvature / half_window / range / sorted come down only for scans with a ring left to the host, as the C++ host mirror asks for them."""
         self.ctx = ctx
         self._raw = [_f32(r).reshape(-1, 4) for r in raw_scans]
         self.n_rings, self.horizon = n_rings, horizon
@@ -1027,7 +1028,7 @@ class RingBatch:
             ctx._check(ctx.lib.pvlm_ring_extract_batch(ctx._h, C.c_int(len(self._raw)), descs, C.c_int(n_rings), C.c_int(horizon), C.c_int(1 if segment else 0),
                                                        C.byref(self._h)), "pvlm_ring_extract_batch")
         else:
-            ctx._check(ctx.lib.pvlm_ring_extract_batch_picks(ctx._h, C.c_int(len(self._raw)), descs, C.c_int(n_rings), C.c_int(horizon), C.c_int(1 if segment else 0),
+            ctx._check(ctx.lib.pvlm_ring_extract_batch_picks(ctx._h, C.c_int(len(self._raw)), descs, C.c_int(n_rings), C.c_int(horizon), C.c_int((1 if segment else 0) | (2 if keep_arrays else 0)),
                                                              C.c_float(picks[0]), C.c_float(picks[1]), C.byref(self._h)), "pvlm_ring_extract_batch_picks")
 
     def close(self):
@@ -1051,7 +1052,7 @@ class RingBatch:
         r = RingResultDesc()
         self.ctx._check(self.ctx.lib.pvlm_ring_batch_scan(self._h, C.c_int(scan), C.byref(r)), "pvlm_ring_batch_scan")
         m = r.n_kept
-        arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n > 0 else np.zeros(0, dt)
+        arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n > 0 and ptr else np.zeros(0, dt)
         out = dict(n_raw=r.n_raw, n_reordered=r.n_reordered, n_kept=m, resolved_points=r.resolved_points, resolved_edges=r.resolved_edges, replayed=r.replayed,
                    ring_count_reordered=arr(r.ring_count_reordered, 64, np.int32), ring_count=arr(r.ring_count, 64, np.int32), source=arr(r.source, m, np.int32),
                    ring_col=arr(r.ring_col, m, np.int32), curvature=arr(r.curvature, m, np.float32), half_window=arr(r.half_window, m, np.int32),

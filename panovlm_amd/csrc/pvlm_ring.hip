@@ -494,6 +494,8 @@ struct pvlm_ring_batch {
   char* h_results = nullptr; size_t results_bytes = 0;
   const int* h_source = nullptr; const int* h_ring_col = nullptr; const float* h_curvature = nullptr; const int* h_half = nullptr; const float* h_range = nullptr;
   const int* h_order = nullptr; const unsigned char* h_sector_host = nullptr;
+  bool lazy_arrays = false;                       // picks on the device: curvature / window / range / order / sector flags came down only for the scans the host has to pick
+  std::vector<unsigned char> has_arrays;          // per scan
   // K24 (picks != 0): states, per-ring pick lists, voxel centroids
   int picks = 0; float max_curvature = 0, angle_threshold = 0;
   const unsigned char* h_state = nullptr; const int* h_corner = nullptr; const int* h_flat = nullptr; const int* h_voxel_span = nullptr; const float* h_voxels = nullptr;
@@ -513,7 +515,9 @@ struct RingScratch {
 static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, const pvlm_raw_scan* raw_scans, int n_rings, int horizon, int segment, long long total,
                             int picks, float max_curvature, float angle_threshold) {
   B->picks = picks ? 1 : 0; B->max_curvature = max_curvature; B->angle_threshold = angle_threshold;
-  B->ctx = ctx; B->n_scans = n_scans; B->rings = n_rings; B->horizon = horizon; B->segment = segment ? 1 : 0;
+  B->ctx = ctx; B->n_scans = n_scans; B->rings = n_rings; B->horizon = horizon; B->segment = (segment & 1) ? 1 : 0;
+  B->lazy_arrays = picks != 0 && (segment & 2) == 0;       // bit 1 of `segment`: always deliver the per-point arrays (parity tests, traces)
+  B->has_arrays.assign((size_t)n_scans, B->lazy_arrays ? 0 : 1);
   const int cells = n_rings * horizon;
   B->total_points = total; B->total_cells = (long long)n_scans * cells;
   B->scans.resize((size_t)n_scans); B->counts.assign((size_t)n_scans * 2, 0);
@@ -739,9 +743,11 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{S2};        // before the scratch goes back to the pool, on every exit path
   PVLM_HIP(ctx, hipMemcpyAsync(h, d_source2, NP * 4, hipMemcpyDeviceToHost, S2));
   PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 4, d_ring_col2, NP * 4, hipMemcpyDeviceToHost, S2));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 8, d_curv, NP * 4, hipMemcpyDeviceToHost, S2));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 12, d_half, NP * 4, hipMemcpyDeviceToHost, S2));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16, d_range2, NP * 4, hipMemcpyDeviceToHost, S2));
+  if (!B->lazy_arrays) {
+    PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 8, d_curv, NP * 4, hipMemcpyDeviceToHost, S2));
+    PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 12, d_half, NP * 4, hipMemcpyDeviceToHost, S2));
+    PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16, d_range2, NP * 4, hipMemcpyDeviceToHost, S2));
+  }
   hipLaunchKernelGGL(k_sector_sort, dim3((unsigned)(n_rings * 6), (unsigned)n_scans), dim3(256), 0, S, B->d_scans, n_rings, d_ring_count2, d_counts, d_curv, stdsort_selfcheck() ? 1 : 0, d_order, d_sector, d_counter + 2, d_ties, (int)n_sectors);
   {
     const unsigned waves = 256u * 16u;                                     // persistent: every wave walks the list with a grid stride
@@ -764,8 +770,10 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
   // ---- results
   B->h_source = (const int*)h; B->h_ring_col = (const int*)(h + NP * 4); B->h_curvature = (const float*)(h + NP * 8); B->h_half = (const int*)(h + NP * 12);
   B->h_range = (const float*)(h + NP * 16); B->h_order = (const int*)(h + NP * 20); B->h_sector_host = (const unsigned char*)(h + NP * 24);
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 20, d_order, NP * 4, hipMemcpyDeviceToHost, S));
-  PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 24, d_sector, n_sectors, hipMemcpyDeviceToHost, S));
+  if (!B->lazy_arrays) {
+    PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 20, d_order, NP * 4, hipMemcpyDeviceToHost, S));
+    PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 24, d_sector, n_sectors, hipMemcpyDeviceToHost, S));
+  }
   char* hp = h + NP * 24 + ((n_sectors + 63) / 64) * 64;       // K24's results behind the sector flags
   int h_voxel_count = 0;
   if (picks) {
@@ -785,6 +793,24 @@ static pvlm_status ring_run(pvlm_ctx* ctx, pvlm_ring_batch* B, int n_scans, cons
     PVLM_HIP(ctx, hipStreamSynchronize(S));
     B->n_voxels = (int)std::min<size_t>((size_t)std::max(h_voxel_count, 0), voxel_cap);
     if (B->n_voxels > 0) PVLM_HIP(ctx, hipMemcpyAsync(const_cast<float*>(B->h_voxels), d_voxels, (size_t)B->n_voxels * 16, hipMemcpyDeviceToHost, S));
+    if (B->lazy_arrays) {
+      // the ring flags are on the host (the synchronisation above): the five per-point arrays — 16 of the 27 B per point of round 5's download — come down only
+      // for the scans with a ring K24 left to the host (incidence angle at the libm threshold, a sector with ties beyond the kernel's bounds: 0-6 % of the scans)
+      for (int sc = 0; sc < n_scans; ++sc) {
+        bool undecided = false;
+        for (int q = 0; q < n_rings && !undecided; ++q) undecided = B->h_ring_host[(size_t)sc * n_rings + q] != 0;
+        if (!undecided) continue;
+        const size_t p0 = (size_t)B->scans[(size_t)sc].pt0, np = (size_t)B->scans[(size_t)sc].n;
+        if (np) {
+          PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 8 + p0 * 4, d_curv + p0, np * 4, hipMemcpyDeviceToHost, S));
+          PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 12 + p0 * 4, d_half + p0, np * 4, hipMemcpyDeviceToHost, S));
+          PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 16 + p0 * 4, d_range2 + p0, np * 4, hipMemcpyDeviceToHost, S));
+          PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 20 + p0 * 4, d_order + p0, np * 4, hipMemcpyDeviceToHost, S));
+        }
+        PVLM_HIP(ctx, hipMemcpyAsync(h + NP * 24 + (size_t)sc * n_rings * 6, d_sector + (size_t)sc * n_rings * 6, (size_t)n_rings * 6, hipMemcpyDeviceToHost, S));
+        B->has_arrays[(size_t)sc] = 1;
+      }
+    }
   }
   PVLM_HIP(ctx, hipStreamSynchronize(S2));
   (void)hipEventRecord(ev[8], S);
@@ -874,9 +900,11 @@ pvlm_status pvlm_ring_batch_scan(const pvlm_ring_batch* b, int scan, pvlm_ring_r
   r->ring_count_reordered = b->ring_count.data() + (size_t)scan * kMaxRings;
   r->ring_count = b->ring_count2.data() + (size_t)scan * kMaxRings;
   if (b->h_source) {
-    r->source = b->h_source + sc.pt0; r->ring_col = b->h_ring_col + sc.pt0; r->curvature = b->h_curvature + sc.pt0; r->half_window = b->h_half + sc.pt0;
-    r->range = b->h_range + sc.pt0;
-    r->sorted = b->h_order + sc.pt0; r->sector_host = b->h_sector_host + (size_t)scan * b->rings * 6;
+    r->source = b->h_source + sc.pt0; r->ring_col = b->h_ring_col + sc.pt0;
+    if (b->has_arrays[(size_t)scan]) {
+      r->curvature = b->h_curvature + sc.pt0; r->half_window = b->h_half + sc.pt0; r->range = b->h_range + sc.pt0;
+      r->sorted = b->h_order + sc.pt0; r->sector_host = b->h_sector_host + (size_t)scan * b->rings * 6;
+    }
   }
   if (b->picks && b->h_state) {
     const size_t slot0 = (size_t)scan * b->rings;

@@ -519,7 +519,8 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     try {
       for (size_t k = 0; k < parts.size(); ++k) {
         const size_t first = k * per_batch, count = std::min(per_batch, total - first);
-        const pvlm_status rc = device_picks ? pvlm_ring_extract_batch_picks(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, max_curvature,
+        // traces (parity tests) read curvature / windows / order of every scan: bit 1 of `segment` keeps the per-point arrays in the download
+        const pvlm_status rc = device_picks ? pvlm_ring_extract_batch_picks(e.ctx(), (int)count, raw.data() + first, rings, horizon, (segment ? 1 : 0) | (traces ? 2 : 0), max_curvature,
                                                                             intersect_angle_threshold, &parts[k].batch)
                                             : pvlm_ring_extract_batch(e.ctx(), (int)count, raw.data() + first, rings, horizon, segment ? 1 : 0, &parts[k].batch);
         if (rc == PVLM_ERR_REFUSED) {
