@@ -389,6 +389,10 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
  * pvlm_assoc_point2plane_stats: how many queries of the set took the QR because the fast fit refused (0 in exact mode). */
 #define PVLM_FLAG_ASSOC_EXACT_FIT 0x200u
 pvlm_status pvlm_assoc_point2plane_stats(const pvlm_resset* rs, int64_t* exact_fits);
+/* The same + how the call was run: its batches (column blocks) and how many of them ran the exact plane-fit kernel.  In the default mode the first batch is a
+ * probe of about a million queries (PVLM_ASSOC_PROBE_ROWS): when the fast fit refuses more than 2 % of its queries — neighbourhoods the normal equations cannot
+ * handle, e.g. raw scans as targets — the other batches run the QR kernel directly, which is then the faster one.  Decided from the data alone. */
+pvlm_status pvlm_assoc_point2plane_stats2(const pvlm_resset* rs, int64_t* exact_fits, int* batches, int* exact_kernel_batches);
 /* Optional debug readback of the last pvlm_assoc_point2plane call: query index and the 10
  * neighbour indices of every accepted correspondence (n x 1, n x 10). */
 pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, int32_t* query_idx, int32_t* nn_idx);

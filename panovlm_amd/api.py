@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -654,6 +654,11 @@ class ResidualSet:
         n = C.c_int64(0)
         self.ctx._check(self.ctx.lib.pvlm_assoc_point2plane_stats(self._h, C.byref(n)), "pvlm_assoc_point2plane_stats")
         return int(n.value)
+
+    def assoc_stats(self):
+        n, b, e = C.c_int64(0), C.c_int(0), C.c_int(0)
+        self.ctx._check(self.ctx.lib.pvlm_assoc_point2plane_stats2(self._h, C.byref(n), C.byref(b), C.byref(e)), "pvlm_assoc_point2plane_stats2")
+        return dict(exact_fits=int(n.value), batches=b.value, exact_kernel_batches=e.value)
 
     def assoc_debug(self):
         q = np.empty(max(self.n, 1), np.int32); nn = np.empty((max(self.n, 1), 10), np.int32)

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVLM_K2_WAV
 // queries it refuses (the largest distance within ~1e-6 of the tolerance, ill-conditioned neighbourhoods) take the QR, counted in ticket[1].
 // EXACT = true (PVLM_FLAG_ASSOC_EXACT_FIT): the QR for every query — records bit-identical to a non-FMA x86-64 build of the reference.
 #ifndef PVLM_K3F_WAVES
-#define PVLM_K3F_WAVES 2
+#define PVLM_K3F_WAVES 3
 #endif
 template <bool EXACT, int SUB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? PVLM_K3_WAVES : PVLM_K3F_WAVES, 8))) void k_fit_pairs(const PairDesc* __restrict__ pairs, double plane_tol, const int* __restrict__ nn_tmp, long long tmp_rows,
@@ -368,43 +368,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT ? PVL
     for (int k = 0; k < 10; ++k) id[k] = nn_tmp[(size_t)k * tmp_rows + row];
     if (id[9] < 0) return false;                                           // fewer than ten neighbours in reach (:577)
     const float qtag = pd.q_tag[q];
-    double px[10], py[10], pz[10], Rt[3];
+    double Rt[3], plane[4];
     world2local_rt(pd.Rr, pd.tr, Rt);
-    int same = 0;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const Point4 t = pd.ref.pt4[id[k]];                                  // (x, y, z, tag) of the neighbour: one 16-byte gather (round 4: four 4-byte ones)
-      same += (t.w == qtag);
-      double l[3];
-      world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
-      px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
-    }
-    if (same != 10) return false;  // :583-591
-    double plane[4];
-    // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
-    // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
-    // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
-    // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
-    // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw; profiles/r4_assoc_variants.txt.)
-    if (Fit10::is_line(px, py, pz, 3.0)) return false;
     bool ok;
-    const int fast = EXACT ? -1 : Fit10::form_plane_fast(px, py, pz, plane_tol, plane);
-    if (fast >= 0) ok = fast != 0;
-    else if (EXACT) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
-    else {
-      // the QR in place on the coordinate arrays, the ten points fetched again for the accept test: the fall-back does not set the
-      // register budget of the kernel (form_plane keeps 70 doubles alive)
-      double x[3];
-      Fit10::form_plane_solve(px, py, pz, x);
+    bool decided = false;
+    if (!EXACT) {
+      // The fast kernel keeps no point: it gathers the ten neighbours TWICE (the second time out of the cache) — first into the raw second moments, from which the
+      // collinearity screen and the normal-equation solve come, then into the residuals of that solve, from which the certified accept / reject decision comes
+      // (Fit10::FastFit).  Sixty registers less than the arrays: twice the resident waves for a kernel that waited for its gathers two thirds of its cycles.  Whatever the
+      // moments cannot decide — the screen inside its guard band, an ill-conditioned system, a largest distance within ~1e-6 of the tolerance — takes the exact path below.
+      Fit10::FastFit F;
+      int same = 0;
 #pragma unroll
       for (int k = 0; k < 10; ++k) {
-        const Point4 t = pd.ref.pt4[id[k]];
+        const Point4 t = pd.ref.pt4[id[k]];                                // (x, y, z, tag) of the neighbour: one 16-byte gather
+        same += (t.w == qtag);
+        double l[3];
+        world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
+        F.add(l[0], l[1], l[2]);
+      }
+      if (same != 10) return false;  // :583-591
+      const int line = F.collinear(3.0);
+      if (line == 1) return false;   // :592-596: collinear neighbourhoods are rejected
+      if (line == 0 && F.solve(plane_tol)) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          const Point4 t = pd.ref.pt4[id[k]];
+          double l[3];
+          world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
+          F.residual(l[0], l[1], l[2]);
+        }
+        const int fast = F.decide(plane_tol, plane);
+        if (fast >= 0) { ok = fast != 0; decided = true; }
+      }
+      if (!decided) ++n_refused;
+    }
+    if (!decided) {
+      // the reference's own arithmetic: the ten points in the reference scan's frame, FormLine's eigen decision, the pivoted Householder QR
+      double px[10], py[10], pz[10];
+      int same = 0;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const Point4 t = pd.ref.pt4[id[k]];                                // (x, y, z, tag) of the neighbour: one 16-byte gather (round 4: four 4-byte ones)
+        same += (t.w == qtag);
         double l[3];
         world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
         px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
       }
-      ok = Fit10::form_plane_accept(x, px, py, pz, plane_tol, plane);
-      ++n_refused;
+      if (same != 10) return false;  // :583-591
+      // :592-596 accepts when the plane fits AND the ten points are not collinear.  Both tests are side-effect free, so the
+      // cheap one runs first: the scatter matrix + closed-form screen is ~250 flops, the 10x3 pivoted QR ~2 000 instructions,
+      // and with raw scans as targets 94 % of the queries die at the collinearity test (ten neighbours along one ring).
+      // A wave whose lanes are all collinear never enters the QR.  (Re-packing the survivors of a workgroup so that whole waves skip the QR
+      // was built and measured: slower, 1394 vs 1322 us voxel, 1599 vs 1316 us raw; profiles/r4_assoc_variants.txt.)
+      if (Fit10::is_line(px, py, pz, 3.0)) return false;
+      if (EXACT) ok = Fit10::form_plane(px, py, pz, plane_tol, plane);
+      else {
+        // the QR in place on the coordinate arrays, the ten points fetched again for the accept test: the fall-back does not set the
+        // register budget of the kernel (form_plane keeps 70 doubles alive)
+        double x[3];
+        Fit10::form_plane_solve(px, py, pz, x);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          const Point4 t = pd.ref.pt4[id[k]];
+          double l[3];
+          world2local_pt(pd.Rr, Rt, (double)t.x, (double)t.y, (double)t.z, l);
+          px[k] = l[0]; py[k] = l[1]; pz[k] = l[2];
+        }
+        ok = Fit10::form_plane_accept(x, px, py, pz, plane_tol, plane);
+      }
     }
     if (ok) {
       double* r = &s_rec[buf][u][0][threadIdx.x];           // straight into this chunk's buffer (the parked chunk sits in the other one)
@@ -1156,9 +1188,16 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
   struct Batch { int p0, p1; long long rows; int chunks; int bmax; };
   std::vector<Batch> batches;
   long long cap_rows = 0; int cap_chunks = 0, cap_pairs = 0;
+  // Fast mode: the FIRST batch is a probe of about a million queries.  Its share of queries the fast fit had to leave to the QR decides the kernel of the other
+  // batches: a cloud whose neighbourhoods the normal equations cannot handle (raw scans as targets: ten neighbours along one ring, planes through the sensor) pays
+  // for the fast attempt AND the QR — there the exact kernel is the faster one (1.2 against 1.5-2.3 ms per 16.7 M queries).  Decided from the data alone: the same
+  // call gives the same set.
+  static const long long probe_rows = getenv("PVLM_ASSOC_PROBE_ROWS") ? atoll(getenv("PVLM_ASSOC_PROBE_ROWS")) : (1ll << 20);
+  const bool probing = !exact_fit && probe_rows > 0 && PVLM_K3_SUB == PVLM_K3F_SUB;      // (both kernels lay their chunks out alike: the choice is per batch)
   for (int p = 0; p < n_pairs;) {
     Batch b{p, p, 0, 0, 0};
-    while (b.p1 < n_pairs && (b.p1 == b.p0 || (b.rows + descs[b.p1].nq <= budget_rows && b.p1 - b.p0 < 32768))) {
+    const long long budget = (probing && batches.empty()) ? std::min(budget_rows, probe_rows) : budget_rows;
+    while (b.p1 < n_pairs && (b.p1 == b.p0 || (b.rows + descs[b.p1].nq <= budget && b.p1 - b.p0 < 32768))) {
       descs[b.p1].tmp_base = b.rows;
       descs[b.p1].chunk_base = b.chunks;
       b.rows += descs[b.p1].nq;
@@ -1174,6 +1213,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
   if (st) { pvlm_i_resset_free(ctx, rs); return st; }
   pvlm_assoc_ws& ws = ctx->assoc_ws;
 
+  bool batch_exact = exact_fit;                      // which plane-fit kernel the batches issued from now on run
   // per batch: the column block is taken at ISSUE time with room for every query of the batch (segment of pair p: seg_rows(nq) rows at dst_row)
   std::vector<long long> batch_R(batches.size(), 0);
   for (size_t bi = 0; bi < batches.size(); ++bi) {
@@ -1215,7 +1255,7 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
       if (total > 0x7fffffffll) { PVLM_SET_ERR(ctx, "association batch too large"); return PVLM_ERR_ARG; }
       static const int k3_blocks = [] { const char* e = getenv("PVLM_K3_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();   // persistent workgroups (two fit per CU)
       static const int k3f_blocks = [] { const char* e = getenv("PVLM_K3F_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 256 * PVLM_K3F_WAVES; }();   // the fast kernel: PVLM_K3F_WAVES workgroups per CU
-      if (exact_fit)
+      if (batch_exact)
         hipLaunchKernelGGL((k_fit_pairs<true, PVLM_K3_SUB>), dim3((unsigned)std::min<long long>(total, k3_blocks)), dim3(256), 0, ctx->stream, d_desc, plane_tolerance, ws.d_nn[s], ws.rows, d_block, R, d_chain,
                            d_count, d_ticket, d_q, d_n, chunks_x, (int)total);
       else
@@ -1267,11 +1307,17 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
     return PVLM_OK;
   };
   const int B = (int)batches.size();
+  int finished = 0;                                  // batches [0, finished) are accounted for
   for (int bi = 0; bi < B && !st; ++bi) {
     st = issue(bi);
-    if (!st && bi >= 1) st = finish(bi - 1);
+    if (!st && bi == 0 && probing && B > 1) {        // the probe: waited for at once (a few hundred microseconds with the GPU idle, once per call)
+      st = finish(0); finished = 1;
+      if (!st && batches[0].rows > 0 && (double)rs->assoc_exact_fits > 0.02 * (double)batches[0].rows) batch_exact = true;
+    }
+    if (!st && bi >= 1 && finished < bi) { st = finish(bi - 1); finished = bi; }
   }
-  if (!st && B > 0) st = finish(B - 1);
+  if (!st && finished < B) st = finish(B - 1);
+  rs->assoc_exact_kernel_batches = batch_exact && !exact_fit ? B - 1 : (exact_fit ? B : 0);
   if (!st) {
     rs->n = rs->h_out_start[n_pairs];
     st = pvlm_i_resset_finalize(ctx, rs);   // uploads the segment table + work list; the call's one full synchronisation
@@ -1284,6 +1330,13 @@ pvlm_status pvlm_assoc_point2plane(pvlm_ctx* ctx, int n_pairs, pvlm_scan* const*
 pvlm_status pvlm_assoc_point2plane_stats(const pvlm_resset* rs, int64_t* exact_fits) {
   if (!rs) return PVLM_ERR_ARG;
   if (exact_fits) *exact_fits = rs->assoc_exact_fits;
+  return PVLM_OK;
+}
+pvlm_status pvlm_assoc_point2plane_stats2(const pvlm_resset* rs, int64_t* exact_fits, int* batches, int* exact_kernel_batches) {
+  if (!rs) return PVLM_ERR_ARG;
+  if (exact_fits) *exact_fits = rs->assoc_exact_fits;
+  if (batches) *batches = (int)rs->col_blocks.size();
+  if (exact_kernel_batches) *exact_kernel_batches = rs->assoc_exact_kernel_batches;
   return PVLM_OK;
 }
 

@@ -538,51 +538,79 @@ struct Fit10 {
   //   the fused chain here: 3 u).
   // tests/test_assoc_core_cpu.py drives this against form_plane() on 2 10^6 neighbourhoods (near and far, random, bisected onto the threshold,
   // degenerate) and against a __float128 solve: no decided case may differ, ||x - x_qr|| must stay below E and each distance below its share.
-  static PVLM_HD int form_plane_fast(const double* px, const double* py, const double* pz, double tol, double* plane, double* diag = nullptr) {
-    const double U = 1.1102230246251565e-16;
+  // The same routine in STREAMING form, for a caller that does not keep the ten points (the fast kernel gathers them twice instead — 60 registers less, twice the
+  // resident waves): add() every point, solve(), residual() every point again in the same order, decide().  collinear() answers the reference's collinearity test
+  // (is_line) from the same moments through line_screen(): the scatter matrix S = M - s s^T / 10 derived from the sums differs from the one the reference
+  // accumulates about the centroid by less than 8 u tr entrywise (the cancellation is against tr, the sums' size), handed to the screen as `slack`; -1 = undecided.
+  struct FastFit {
     double m00 = 0.0, m01 = 0.0, m02 = 0.0, m11 = 0.0, m12 = 0.0, m22 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      m00 = fma(px[i], px[i], m00); m01 = fma(px[i], py[i], m01); m02 = fma(px[i], pz[i], m02);
-      m11 = fma(py[i], py[i], m11); m12 = fma(py[i], pz[i], m12); m22 = fma(pz[i], pz[i], m22);
-      s0 += px[i]; s1 += py[i]; s2 += pz[i];
-    }
-    const double c00 = fma(m11, m22, -(m12 * m12)), c01 = fma(m12, m02, -(m01 * m22)), c02 = fma(m01, m12, -(m11 * m02));
-    const double c11 = fma(m00, m22, -(m02 * m02)), c12 = fma(m01, m02, -(m00 * m12)), c22 = fma(m00, m11, -(m01 * m01));
-    const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
-    const double tr = (m00 + m11) + m22, e2 = (c00 + c11) + c22;
-    if (!(tol > 0.0 && det > 0.0 && e2 > 0.0 && tr < 1e100 && (tr * tr) * tr <= 5e13 * det)) return -1;   // also NaN / inf
-    const double inv = 1.0 / det;
-    double x0 = -(fma(c00, s0, fma(c01, s1, c02 * s2))) * inv, x1 = -(fma(c01, s0, fma(c11, s1, c12 * s2))) * inv, x2 = -(fma(c02, s0, fma(c12, s1, c22 * s2))) * inv;
-    {   // one refinement step on the computed system
-      const double r0 = fma(m00, x0, fma(m01, x1, fma(m02, x2, s0))), r1 = fma(m01, x0, fma(m11, x1, fma(m12, x2, s1))), r2 = fma(m02, x0, fma(m12, x1, fma(m22, x2, s2)));
-      x0 = fma(-(fma(c00, r0, fma(c01, r1, c02 * r2))), inv, x0); x1 = fma(-(fma(c01, r0, fma(c11, r1, c12 * r2))), inv, x1); x2 = fma(-(fma(c02, r0, fma(c12, r1, c22 * r2))), inv, x2);
-    }
-    const double nn = fma(x0, x0, fma(x1, x1, x2 * x2));
-    if (!(nn > 1e-200 && nn < 1e200)) return -1;
-    // residuals r_i, their largest magnitude, their sum of squares and rho = A^T r in one pass
+    double x0, x1, x2, tr, e2, inv, nn;
     double fmx = 0.0, R2 = 0.0, h0 = 0.0, h1 = 0.0, h2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const double r = fma(x0, px[i], fma(x1, py[i], fma(x2, pz[i], 1.0)));
-      fmx = fmax(fmx, fabs(r)); R2 = fma(r, r, R2);
-      h0 = fma(px[i], r, h0); h1 = fma(py[i], r, h1); h2 = fma(pz[i], r, h2);
+    PVLM_HD void add(double x, double y, double z) {
+      m00 = fma(x, x, m00); m01 = fma(x, y, m01); m02 = fma(x, z, m02);
+      m11 = fma(y, y, m11); m12 = fma(y, z, m12); m22 = fma(z, z, m22);
+      s0 += x; s1 += y; s2 += z;
     }
-    const double len = sqrt(nn), rn = 1.0 / len, P = sqrt(tr);
-    const double L = (2.0 * e2) * inv;                                        // >= 1 / lambda_min
-    const double k = P * sqrt(L), keps = k * (1024.0 * U);
-    if (!(keps <= 1e-2)) return -1;
-    const double E_fast = (sqrt(fma(h0, h0, fma(h1, h1, h2 * h2))) + (40.0 * U) * P * fma(P, len, 1.0)) * L;
-    const double E_qr = (1.0102 * keps) * fma(2.02, len, (k + 1.0) * sqrt(3.0 * R2 / tr) * 1.0001);
-    const double E = E_fast + E_qr;
-    const double e = E * rn;
-    if (!(e <= 2.5e-7)) return -1;                                            // the accepted RECORD (x / ||x||, 1 / ||x||) is then within 5e-7 relative of the QR's (the bar is 1e-6); also keeps ||x*|| <= 1.01 ||x|| as E_qr assumed
-    const double f = fmx * rn;
-    const double B = (4.0 / 3.0) * e * (P + f) + (16.0 * U) * (P + rn);
-    if (diag) { diag[0] = x0; diag[1] = x1; diag[2] = x2; diag[3] = E; diag[4] = f; diag[5] = B; diag[6] = E_fast; diag[7] = E_qr; }
-    if (f + B <= tol) { plane[0] = x0 * rn; plane[1] = x1 * rn; plane[2] = x2 * rn; plane[3] = rn; return 1; }
-    if (f - B > tol) { plane[0] = 0.0; plane[1] = 0.0; plane[2] = 0.0; plane[3] = 0.0; return 0; }
-    return -1;
+    PVLM_HD int collinear(double tol) const {
+      const double U = 1.1102230246251565e-16;
+      const double a00 = fma(-0.1 * s0, s0, m00), a01 = fma(-0.1 * s0, s1, m01), a02 = fma(-0.1 * s0, s2, m02);
+      const double a11 = fma(-0.1 * s1, s1, m11), a12 = fma(-0.1 * s1, s2, m12), a22 = fma(-0.1 * s2, s2, m22);
+      return line_screen(a00, a01, a02, a11, a12, a22, tol, nullptr, (8.0 * U) * ((m00 + m11) + m22));
+    }
+    PVLM_HD bool solve(double tol) {
+      const double c00 = fma(m11, m22, -(m12 * m12)), c01 = fma(m12, m02, -(m01 * m22)), c02 = fma(m01, m12, -(m11 * m02));
+      const double c11 = fma(m00, m22, -(m02 * m02)), c12 = fma(m01, m02, -(m00 * m12)), c22 = fma(m00, m11, -(m01 * m01));
+      const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
+      tr = (m00 + m11) + m22; e2 = (c00 + c11) + c22;
+      if (!(tol > 0.0 && det > 0.0 && e2 > 0.0 && tr < 1e100 && (tr * tr) * tr <= 5e13 * det)) return false;   // also NaN / inf
+      inv = 1.0 / det;
+      x0 = -(fma(c00, s0, fma(c01, s1, c02 * s2))) * inv; x1 = -(fma(c01, s0, fma(c11, s1, c12 * s2))) * inv; x2 = -(fma(c02, s0, fma(c12, s1, c22 * s2))) * inv;
+      {   // one refinement step on the computed system
+        const double r0 = fma(m00, x0, fma(m01, x1, fma(m02, x2, s0))), r1 = fma(m01, x0, fma(m11, x1, fma(m12, x2, s1))), r2 = fma(m02, x0, fma(m12, x1, fma(m22, x2, s2)));
+        x0 = fma(-(fma(c00, r0, fma(c01, r1, c02 * r2))), inv, x0); x1 = fma(-(fma(c01, r0, fma(c11, r1, c12 * r2))), inv, x1); x2 = fma(-(fma(c02, r0, fma(c12, r1, c22 * r2))), inv, x2);
+      }
+      nn = fma(x0, x0, fma(x1, x1, x2 * x2));
+      return nn > 1e-200 && nn < 1e200;
+    }
+    PVLM_HD void residual(double x, double y, double z) {      // r_i, their largest magnitude, their sum of squares and rho = A^T r
+      const double r = fma(x0, x, fma(x1, y, fma(x2, z, 1.0)));
+      fmx = fmax(fmx, fabs(r)); R2 = fma(r, r, R2);
+      h0 = fma(x, r, h0); h1 = fma(y, r, h1); h2 = fma(z, r, h2);
+    }
+    PVLM_HD int decide(double tol, double* plane, double* diag = nullptr) const {
+      const double U = 1.1102230246251565e-16;
+      const double len = sqrt(nn), rn = 1.0 / len, P = sqrt(tr);
+      const double L = (2.0 * e2) * inv;                                        // >= 1 / lambda_min
+      const double k = P * sqrt(L), keps = k * (1024.0 * U);
+      if (!(keps <= 1e-2)) return -1;
+      const double E_fast = (sqrt(fma(h0, h0, fma(h1, h1, h2 * h2))) + (40.0 * U) * P * fma(P, len, 1.0)) * L;
+      const double E_qr = (1.0102 * keps) * fma(2.02, len, (k + 1.0) * sqrt(3.0 * R2 / tr) * 1.0001);
+      const double E = E_fast + E_qr;
+      const double e = E * rn;
+      if (!(e <= 2.5e-7)) return -1;                                            // the accepted RECORD (x / ||x||, 1 / ||x||) is then within 5e-7 relative of the QR's (the bar is 1e-6); also keeps ||x*|| <= 1.01 ||x|| as E_qr assumed
+      const double f = fmx * rn;
+      const double B = (4.0 / 3.0) * e * (P + f) + (16.0 * U) * (P + rn);
+      if (diag) { diag[0] = x0; diag[1] = x1; diag[2] = x2; diag[3] = E; diag[4] = f; diag[5] = B; diag[6] = E_fast; diag[7] = E_qr; }
+      if (f + B <= tol) { plane[0] = x0 * rn; plane[1] = x1 * rn; plane[2] = x2 * rn; plane[3] = rn; return 1; }
+      if (f - B > tol) { plane[0] = 0.0; plane[1] = 0.0; plane[2] = 0.0; plane[3] = 0.0; return 0; }
+      return -1;
+    }
+  };
+  static PVLM_HD int form_plane_fast(const double* px, const double* py, const double* pz, double tol, double* plane, double* diag = nullptr) {
+    FastFit F;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) F.add(px[i], py[i], pz[i]);
+    if (!F.solve(tol)) return -1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) F.residual(px[i], py[i], pz[i]);
+    return F.decide(tol, plane, diag);
+  }
+  // the collinearity decision from the moments alone (streaming form): 1 line, 0 no line, -1 undecided — the array form for the CPU tests
+  static PVLM_HD int is_line_fast(const double* px, const double* py, const double* pz, double tol) {
+    FastFit F;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) F.add(px[i], py[i], pz[i]);
+    return F.collinear(tol);
   }
 
   // Closed-form screen of the collinearity decision.  The eigenvalues of the symmetric 3x3 scatter matrix by the trigonometric
@@ -594,7 +622,9 @@ struct Fit10 {
   // the exact one (measured against LAPACK over 10^6 matrices in tests/test_assoc_core_cpu.py: <= 2e-8 l3), while the converged
   // Jacobi loop of the reference restatement is within 1e-13.  The screen answers only when l3 - tol l2 clears a guard of
   // 1e-5 (l3 + tol |l2|) — 160 times its error — and returns -1 otherwise: then, and only then, the exact loop runs.
-  static PVLM_HD int line_screen(double a00, double a01, double a02, double a11, double a12, double a22, double tol, double* eig = nullptr) {
+  // `slack`: an absolute bound on how far the eigenvalues of the matrix handed in may lie from those of the matrix the reference forms (0 when it IS that matrix;
+  // the streaming fit below hands in the scatter matrix derived from the raw second moments): added to the guard on both sides.
+  static PVLM_HD int line_screen(double a00, double a01, double a02, double a11, double a12, double a22, double tol, double* eig = nullptr, double slack = 0.0) {
     const double q = ((a00 + a11) + a22) * (1.0 / 3.0);
     const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
     const double p1 = (a01 * a01 + a02 * a02) + a12 * a12;
@@ -620,7 +650,7 @@ struct Fit10 {
     const double l1 = q + 2.0 * p * (-0.5 * c - 0.86602540378443864676 * sn);
     const double l2 = (3.0 * q - l1) - l3;
     if (eig) { eig[0] = l1; eig[1] = l2; eig[2] = l3; }
-    const double margin = l3 - tol * l2, guard = 1e-5 * (fabs(l3) + fabs(tol * l2));
+    const double margin = l3 - tol * l2, guard = 1e-5 * (fabs(l3) + fabs(tol * l2)) + slack * (1.0 + fabs(tol));
     if (margin > guard) return 1;
     if (margin < -guard) return 0;
     return -1;

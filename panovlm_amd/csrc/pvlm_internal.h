@@ -154,6 +154,7 @@ struct pvlm_resset {
   std::vector<int32_t*> d_qidx;  // rows of the block
   std::vector<int32_t*> d_nn;    // rows x 10
   std::vector<int64_t> block_n;  // accepted rows of the block
+  int assoc_exact_kernel_batches = 0;   // batches of the association that ran the exact plane-fit kernel (all of them with PVLM_FLAG_ASSOC_EXACT_FIT; all but the probe when the probe's refusal rate said so)
   int64_t assoc_exact_fits = 0;  // queries of the association whose plane came from the exact QR because the certified fast fit refused (0 with PVLM_FLAG_ASSOC_EXACT_FIT)
 };
 

@@ -173,6 +173,20 @@ long long chk_line_sweeps(const double* pts, int m, double line_tol, int screen,
   return total;
 }
 
+// the collinearity decision from the raw moments (Fit10::is_line_fast, the streaming kernel's form) next to the reference's (is_line): decided[s] = 1 / 0 / -1,
+// exact[s] = 1 / 0.  Returns the number of decided sets that differ (must be 0).
+long long chk_is_line_fast(const double* pts, int m, double tol, int* decided, int* exact) {
+  long long wrong = 0;
+  for (int s = 0; s < m; ++s) {
+    double px[10], py[10], pz[10];
+    for (int i = 0; i < 10; ++i) { px[i] = pts[(size_t)s * 30 + 3 * i]; py[i] = pts[(size_t)s * 30 + 3 * i + 1]; pz[i] = pts[(size_t)s * 30 + 3 * i + 2]; }
+    decided[s] = Fit10::is_line_fast(px, py, pz, tol);
+    exact[s] = Fit10::is_line(px, py, pz, tol) ? 1 : 0;
+    if (decided[s] >= 0 && decided[s] != exact[s]) ++wrong;
+  }
+  return wrong;
+}
+
 // the certified fast fit (Fit10::form_plane_fast) against the exact path on m 10-point sets.  Per set, out8 = [decision of the fast fit (1 / 0 / -1),
 // decision of form_plane, E (its bound on ||x - x_qr||), ||x - x_qr|| measured, ||x - x_ref|| and ||x_qr - x_ref|| against a __float128 solve of the
 // normal equations (only when quad != 0; else 0), B (its bound on the distance), |max distance of the fast fit - max distance the exact path evaluates|].

@@ -24,6 +24,7 @@ def chk(tmp_path_factory):
     lib.chk_knn.restype = ctypes.c_int
     lib.chk_line_sweeps.restype = ctypes.c_longlong
     lib.chk_fit_fast.restype = ctypes.c_longlong
+    lib.chk_is_line_fast.restype = ctypes.c_longlong
     return lib
 
 
@@ -317,3 +318,28 @@ def test_certified_fast_fit_near_the_tolerance_and_against_quad_precision(chk):
     have = out[:, 2] > 0
     assert np.all(out[have, 4] <= out[have, 2]) and np.all(out[have, 5] <= out[have, 6]), "a distance to the exact minimiser exceeds its share of the bound"
     assert (out[have, 4] / out[have, 2]).max() < 0.2 and (out[have, 5] / out[have, 6]).max() < 0.05       # with room: the shares are built from worst-case constants
+
+
+def test_collinearity_from_the_moments_takes_the_exact_decision(chk):
+    """Fit10::is_line_fast — the closed-form screen on the scatter matrix derived from the raw second moments (M - s s^T / 10), what the streaming form of the fast
+    kernel evaluates without keeping the ten points — against Fit10::is_line (the reference's FormLine decision, base/Geometry.hpp:220-260): every decided case
+    equal, undecided ones rare, near and far from the sensor (the derivation cancels against the distance)."""
+    rng = np.random.default_rng(41)
+    for scale, shift in ((1.0, 0.0), (1.0, 300.0), (0.02, 50.0)):
+        pts = _point_sets(rng, 60_000) * scale + shift
+        for tol in (3.0,):
+            dec = np.zeros(len(pts), np.int32); exact = np.zeros(len(pts), np.int32)
+            wrong = chk.chk_is_line_fast(_p(np.ascontiguousarray(pts), ctypes.c_double), len(pts), ctypes.c_double(tol), _p(dec, ctypes.c_int), _p(exact, ctypes.c_int))
+            assert wrong == 0
+            assert (dec < 0).mean() < (0.25 if scale < 1 else 0.2), (scale, shift, (dec < 0).mean())     # the lattice sets (a sixth) are exactly degenerate: refused
+            assert 0.1 < exact.mean() < 0.9
+    # the thin band around the threshold: refused or right
+    sets = []
+    for _ in range(4000):
+        a = rng.uniform(0.05, 0.5)
+        B = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        s_ = np.array([a, a / np.sqrt(3.0) * (1 + rng.normal() * 1e-6), rng.uniform(0, 0.01)])
+        sets.append(rng.uniform(-20, 20, size=3) + (rng.normal(size=(10, 3)) * s_) @ B.T)
+    sets = np.array(sets)
+    dec = np.zeros(len(sets), np.int32); exact = np.zeros(len(sets), np.int32)
+    assert chk.chk_is_line_fast(_p(np.ascontiguousarray(sets), ctypes.c_double), len(sets), ctypes.c_double(3.0), _p(dec, ctypes.c_int), _p(exact, ctypes.c_int)) == 0

@@ -39,9 +39,9 @@ def main():
         ctx.synchronize()
         walls.append(time.perf_counter() - t0)
         acc = rs.n
-        exact_fits = rs.assoc_exact_fits()
+        exact_fits = rs.assoc_exact_fits(); stats = rs.assoc_stats()
         rs.close()
-    print(json.dumps({"scans": a.scans, "pairs": int(len(ref)), "queries": nq, "targets": nt, "accepted": int(acc), "calls": a.calls, "targets_kind": a.targets, "exact_mode": bool(a.exact), "queries_refused_by_the_fast_fit": exact_fits,
+    print(json.dumps({"scans": a.scans, "pairs": int(len(ref)), "queries": nq, "targets": nt, "accepted": int(acc), "calls": a.calls, "targets_kind": a.targets, "exact_mode": bool(a.exact), "queries_refused_by_the_fast_fit": exact_fits, "batches": stats["batches"], "batches_on_the_exact_kernel": stats["exact_kernel_batches"],
                       "wall_s": walls}))
 
 
