@@ -937,12 +937,14 @@ def mvs_block(ctx, pv):
         issue = PEAKS["valu_wave_insts_per_s"]
         kernels = {}
         small = out.get("1440x720") or {}
-        # algorithmic floor per pixel (the operations the reference's ScorePixel / ProcessPixel prescribe, mvs/MVS.cpp:774-923, :721-772, counted from
-        # csrc/pvlm_mvs_core.h): a hypothesis = per neighbour view a homography (30) + 49 / step^2 taps (window 7, step 2: 16) of [projection with FastAtan2
-        # (~60 as float operations), 4 bilinear weights + blend (12), bilateral weight + 5 NCC sums (14)] + the NCC itself (25); K11 scores one hypothesis
-        # against two neighbours, K13 up to 4 propagated + 12 perturbed ones (config/Room.txt)
-        per_hyp_view = 30 + 16 * (60 + 12 + 14) + 25
-        floors = {"k_mvs_conf_lane": 2 * per_hyp_view + 40, "k_mvs_propagate_lane": 16 * 2 * per_hyp_view + 16 * 60}
+        # algorithmic floor per pixel, in the counters' unit (wave instructions per pixel = operations of one pixel's lane / 64), counted from the per-pixel program the
+        # reference prescribes (ScorePixel / ProcessPixel, mvs/MVS.cpp:774-923, :721-772; csrc/pvlm_mvs_core.h) — an estimate good to a few tens of per cent:
+        # a hypothesis scored against one neighbour view = the plane-induced homography (30) + 49 taps (window 7 x 7, step 1: this block's configuration) of
+        # [projection of the tap into the neighbour panorama with FastAtan2 (~60 as single-precision operations), four bilinear weights + blend (12), bilateral weight
+        # + the five NCC sums (14)] + the NCC itself (25); K11 scores one hypothesis per pixel against two neighbours, a K13 iteration up to 4 propagated + 12
+        # perturbed ones (config/Room.txt)
+        per_hyp_view = 30 + 49 * (60 + 12 + 14) + 25
+        floors = {"k_mvs_conf_lane": (2 * per_hyp_view + 40) / 64.0, "k_mvs_propagate_lane": (16 * 2 * per_hyp_view + 16 * 60) / 64.0}
         for kname, block in (("k_mvs_conf_lane", "k11_scoring_pass"), ("k_mvs_propagate_lane", "k13_patchmatch_iteration")):
             hit = [v for k, v in pmc.items() if kname in k and v.get("valu_wave_insts_per_unit")]
             if hit and block in small:
