@@ -267,6 +267,14 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
  * definite: take it as "not positive definite", not as the index of an unknown. */
 pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror, const double* blocks,
                                   const double* scale, const double* diag_add, double* rhs, int* info);
+/* Makes the plan of a structure AHEAD of the solve that needs it: the host half (ordering, symbolic factorisation, schedule lists: ~10 ms for a Floor-sized
+ * pose graph) starts on a thread of its own and the call returns at once; the lists are copied.  The next pvlm_spd_solve_blocks whose n / row_idx / col_idx /
+ * mirror are EXACTLY these takes the plan (waiting for the thread if it is still at work); with any other structure the prefetch is dropped and the plan is made
+ * inside the solve as without this call — a hint, never a change of result.  The host mirror's LM driver calls it on entry to a Solve, so that the plan is made
+ * beside the upload of the residual sets and the first linearisation (upstream: inside ceres::Solve's preprocessing, util/Optimization.cpp:638-666).
+ * pvlm_spd_plan_prefetch_hits: how many solves of this context took a prefetched plan. */
+pvlm_status pvlm_spd_plan_prefetch(pvlm_ctx* ctx, int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror);
+pvlm_status pvlm_spd_plan_prefetch_hits(const pvlm_ctx* ctx, long long* hits);
 /* How the last pvlm_spd_solve_blocks structure of this context is factorised: *tile_sparse = 1 when the dense kernels skip the
  * structurally zero 64-row tiles (ordering of the pose graph by minimum degree + elimination-tree postorder; the reference selects
  * SPARSE_SCHUR for 50 < lidars <= 2000, util/Optimization.cpp:641-658), *update_fraction = its tile updates / those of the dense

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -275,6 +275,16 @@ class Context:
                                                    _p(blocks, C.c_double), _p(_f64(scale), C.c_double), _p(_f64(diag_add), C.c_double),
                                                    _p(x, C.c_double), C.byref(info)), "pvlm_spd_solve_blocks")
         return x, info.value
+
+    def spd_plan_prefetch(self, n, row_idx, col_idx, mirror):
+        """pvlm_spd_plan_prefetch: the host half of the plan of this structure starts on a thread of the library; the next spd_solve_blocks with exactly these lists takes it."""
+        row_idx = _i32(row_idx).reshape(-1, 6); col_idx = _i32(col_idx).reshape(-1, 6); mirror = _i32(mirror)
+        self._check(self.lib.pvlm_spd_plan_prefetch(self._h, C.c_int(n), C.c_int(len(mirror)), _p(row_idx, C.c_int), _p(col_idx, C.c_int), _p(mirror, C.c_int)), "pvlm_spd_plan_prefetch")
+
+    def spd_plan_prefetch_hits(self):
+        h = C.c_longlong()
+        self._check(self.lib.pvlm_spd_plan_prefetch_hits(self._h, C.byref(h)), "pvlm_spd_plan_prefetch_hits")
+        return h.value
 
     def spd_plan(self):
         """How the last spd_solve_blocks structure is factorised: tile_sparse, update_fraction (pvlm_spd_plan_info) and the schedule (pvlm_spd_plan_schedule):

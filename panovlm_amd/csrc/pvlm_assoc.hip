@@ -920,13 +920,29 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
       const size_t a = std::max(segs[q].off, lo), b = std::min(segs[q].off + segs[q].bytes, hi);
       if (b <= a) return;
       if (!segs[q].elem) { std::memcpy(h + (a - lo), (const char*)segs[q].src + (a - segs[q].off), b - a); return; }
-      // strided records (pcl::PointXYZI-style arrays): gathered record by record; a window boundary may fall inside a record
+      // strided records (pcl::PointXYZI-style arrays): a window boundary may fall inside a record — the (at most two) cut records byte by byte, the whole
+      // records between them in a loop of fixed-size copies without a division per record (round 6: 24 -> 6 ms of a Floor-sized upload were this gather)
       const size_t el = segs[q].elem, sd = segs[q].stride;
-      for (size_t p = a; p < b;) {
-        const size_t rel = p - segs[q].off, rec = rel / el, in = rel - rec * el, take = std::min(el - in, b - p);
-        std::memcpy(h + (p - lo), (const char*)segs[q].src + rec * sd + in, take);
-        p += take;
-      }
+      const char* src = (const char*)segs[q].src;
+      size_t p = a;
+      auto partial = [&](size_t upto) {
+        while (p < upto) {
+          const size_t rel = p - segs[q].off, rec = rel / el, in = rel - rec * el, take = std::min(el - in, upto - p);
+          std::memcpy(h + (p - lo), src + rec * sd + in, take);
+          p += take;
+        }
+      };
+      const size_t first_whole = segs[q].off + ((a - segs[q].off + el - 1) / el) * el;      // first record boundary at or after a
+      if (first_whole >= b) { partial(b); return; }
+      partial(first_whole);
+      const size_t n_whole = (b - first_whole) / el;
+      const char* sp = src + ((first_whole - segs[q].off) / el) * sd;
+      char* dp = h + (first_whole - lo);
+      if (el == 12) for (size_t r = 0; r < n_whole; ++r, sp += sd, dp += 12) std::memcpy(dp, sp, 12);
+      else if (el == 4) for (size_t r = 0; r < n_whole; ++r, sp += sd, dp += 4) std::memcpy(dp, sp, 4);
+      else for (size_t r = 0; r < n_whole; ++r, sp += sd, dp += el) std::memcpy(dp, sp, el);
+      p = first_whole + n_whole * el;
+      partial(b);
     };
     {   // the segments land in disjoint ranges of the pinned window: copied side by side (one core moves ~10 GB/s, the window is up to 64 MB)
       const size_t n_threads = (hi - lo) < ((size_t)8 << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)8, (last_seg - first_seg) / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));

@@ -97,6 +97,8 @@ struct pvlm_ctx {
   void* d_ws = nullptr;
   size_t ws_bytes = 0;
   void* spd_plan = nullptr;           // tile-sparse plan of the last pvlm_spd_solve_blocks structure (csrc/pvlm_linalg.hip), freed by pvlm_i_spd_plan_release
+  void* spd_prefetch = nullptr;       // plan being made ahead on a host thread (pvlm_spd_plan_prefetch), joined and freed by pvlm_i_spd_plan_release
+  long long spd_prefetch_hits = 0;    // solves that took their plan from a prefetch
   // per-kernel profiling (pvlm_profile_*): pending (start, stop) event pairs per kernel class
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[4];

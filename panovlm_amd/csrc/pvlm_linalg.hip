@@ -9,7 +9,10 @@
 #include <cstdlib>
 #include <iterator>
 #include <new>
+#include <chrono>
 #include <cstring>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "pvlm_internal.h"
@@ -787,6 +790,53 @@ static unsigned long long spd_hash(int n, int n_blocks, const int* row_idx, cons
   return h;
 }
 
+// The HOST half of a plan: ordering + symbolic factorisation + schedule lists (csrc/pvlm_spd_plan.h), no device call — what pvlm_spd_plan_prefetch runs on a thread of
+// its own while the caller's GPU work (structures, first linearisation of a Solve) goes on.  kind: 0 = natural order + dense kernels, 1 = level schedule, 2 = round-5 plan.
+struct SpdHostPlan {
+  int kind = 0;
+  double update_fraction = 1.0;
+  pvlm_spd::LevelPlan L;
+  pvlm_spd::Symbolic S;
+};
+static void spd_plan_host(int n, int n_blocks, const int* row_idx, const int* col_idx, SpdHostPlan* H) {
+  H->kind = 0; H->update_fraction = 1.0;
+  static const int min_n = getenv("PVLM_SPD_SPARSE_MIN") ? atoi(getenv("PVLM_SPD_SPARSE_MIN")) : 1500;
+  if (n < min_n || n_blocks == 0) return;
+  static_assert(64 % PVLM_CHOL_NB == 0, "a 64-row tile must span a whole number of block columns (pvlm_spd_plan.h marks the fill per tile)");
+  // nested dissection + level schedule (PVLM_SPD_LEVELS=0: the round-5 plan — minimum degree, one block column after the other)
+  static const bool want_levels = !(getenv("PVLM_SPD_LEVELS") && atoi(getenv("PVLM_SPD_LEVELS")) == 0);
+  if (want_levels) {
+    static const int leaf = getenv("PVLM_SPD_LEAF") ? std::max(1, atoi(getenv("PVLM_SPD_LEAF"))) : 42;      // nodes per undissected group (42 poses = 252 rows = 4 tiles)
+    pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, leaf, &H->L);
+    static const double max_pad = getenv("PVLM_SPD_MAX_PAD") ? atof(getenv("PVLM_SPD_MAX_PAD")) : 1.6;
+    // adopted when it shortens the chain of dependent launches by a third at least and the padding stays bounded
+    if (H->L.ordered && H->L.levels * 3 <= H->L.cols_total * 2 + 2 && (double)H->L.n_pad <= max_pad * (double)n + 256.0) { H->kind = 1; H->update_fraction = H->L.update_fraction; return; }
+    H->L = pvlm_spd::LevelPlan();
+  }
+  pvlm_spd::plan_symbolic(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, &H->S);       // csrc/pvlm_spd_plan.h (host only, checked on the CPU)
+  H->update_fraction = H->S.update_fraction;
+  static const double max_fraction = getenv("PVLM_SPD_SPARSE_FRACTION") ? atof(getenv("PVLM_SPD_SPARSE_FRACTION")) : 0.6;
+  if (H->S.ordered && H->S.update_fraction <= max_fraction) H->kind = 2;             // else: not sparse enough to pay for the irregular tile lists
+}
+
+// A plan being made ahead of the solve that will need it (pvlm_spd_plan_prefetch): the structure it is for (compared entry by entry when a solve misses the
+// cache) and the thread that computes its host half.  One per context; a newer prefetch or the context's end joins the thread.
+struct SpdPrefetch {
+  int n = 0, n_blocks = 0;
+  std::vector<int> rows, cols, mirror;
+  SpdHostPlan host;
+  bool failed = false;
+  double worker_ms = 0.0;             // how long the host half took on its thread (PVLM_TRACE)
+  std::thread worker;
+};
+static void spd_prefetch_drop(pvlm_ctx* ctx) {
+  SpdPrefetch* f = static_cast<SpdPrefetch*>(ctx->spd_prefetch);
+  if (!f) return;
+  if (f->worker.joinable()) f->worker.join();
+  delete f;
+  ctx->spd_prefetch = nullptr;
+}
+
 static void spd_plan_free(pvlm_ctx* ctx, SpdPlan* p) {
   if (!p) return;
   pvlm_i_free(ctx, p->d_row_tiles); pvlm_i_free(ctx, p->d_pairs);
@@ -794,59 +844,46 @@ static void spd_plan_free(pvlm_ctx* ctx, SpdPlan* p) {
   pvlm_i_free(ctx, p->d_ftargets); pvlm_i_free(ctx, p->d_fsources);
   delete p;
 }
-void pvlm_i_spd_plan_release(pvlm_ctx* ctx) { spd_plan_free(ctx, static_cast<SpdPlan*>(ctx->spd_plan)); ctx->spd_plan = nullptr; }
+void pvlm_i_spd_plan_release(pvlm_ctx* ctx) { spd_prefetch_drop(ctx); spd_plan_free(ctx, static_cast<SpdPlan*>(ctx->spd_plan)); ctx->spd_plan = nullptr; }
 
-static pvlm_status spd_plan_build(pvlm_ctx* ctx, int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror, SpdPlan* P) {
-  (void)mirror;
+// The DEVICE half: the lists of a host plan uploaded, the host plan's vectors moved into *P.
+static pvlm_status spd_plan_adopt(pvlm_ctx* ctx, int n, SpdHostPlan& H, SpdPlan* P) {
   P->n = n; P->sparse = false;
-  P->new_of_old.resize((size_t)n);
-  for (int i = 0; i < n; ++i) P->new_of_old[(size_t)i] = i;
-  static const int min_n = getenv("PVLM_SPD_SPARSE_MIN") ? atoi(getenv("PVLM_SPD_SPARSE_MIN")) : 1500;
-  if (n < min_n || n_blocks == 0) return PVLM_OK;
-  static_assert(64 % PVLM_CHOL_NB == 0, "a 64-row tile must span a whole number of block columns (pvlm_spd_plan.h marks the fill per tile)");
-  static_assert(sizeof(pvlm_spd::Target) == sizeof(NdTarget) && sizeof(pvlm_spd::RowTarget) == sizeof(NdRowTarget) && sizeof(pvlm_spd::PanelGroup) == sizeof(int2), "level lists are uploaded as they are");
-  // nested dissection + level schedule (PVLM_SPD_LEVELS=0: the round-5 plan — minimum degree, one block column after the other)
-  static const bool want_levels = !(getenv("PVLM_SPD_LEVELS") && atoi(getenv("PVLM_SPD_LEVELS")) == 0);
-  if (want_levels) {
-    static const int leaf = getenv("PVLM_SPD_LEAF") ? std::max(1, atoi(getenv("PVLM_SPD_LEAF"))) : 42;      // nodes per undissected group (42 poses = 252 rows = 4 tiles)
-    pvlm_spd::LevelPlan L;
-    pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, leaf, &L);
-    static const double max_pad = getenv("PVLM_SPD_MAX_PAD") ? atof(getenv("PVLM_SPD_MAX_PAD")) : 1.6;
-    // adopted when it shortens the chain of dependent launches by a third at least and the padding stays bounded
-    if (L.ordered && L.levels * 3 <= L.cols_total * 2 + 2 && (double)L.n_pad <= max_pad * (double)n + 256.0) {
-      pvlm_status st = PVLM_OK;
-      auto up = [&](void** d, const void* src, size_t bytes) {
-        if (st) return;
-        st = pvlm_i_alloc_bytes(ctx, d, std::max<size_t>(bytes, 256));
-        if (!st && bytes) st = pvlm_i_h2d_q(ctx, *d, src, bytes);
-      };
-      up((void**)&P->d_cols, L.cols.data(), L.cols.size() * sizeof(int));
-      up((void**)&P->d_row_off, L.row_off.data(), L.row_off.size() * sizeof(int));
-      up((void**)&P->d_row_tiles, L.row_tiles.data(), L.row_tiles.size() * sizeof(int));
-      up((void**)&P->d_pwg, L.pwg.data(), L.pwg.size() * sizeof(int2));
-      up((void**)&P->d_pwt, L.pwt.data(), L.pwt.size() * sizeof(int2));
-      up((void**)&P->d_targets, L.targets.data(), L.targets.size() * sizeof(NdTarget));
-      up((void**)&P->d_sources, L.sources.data(), L.sources.size() * sizeof(int));
-      up((void**)&P->d_ftargets, L.ftargets.data(), L.ftargets.size() * sizeof(NdRowTarget));
-      up((void**)&P->d_fsources, L.fsources.data(), L.fsources.size() * sizeof(int));
-      if (!st) st = pvlm_i_sync(ctx);
-      if (st) return st;
-      P->new_of_old.swap(L.new_of_old); P->col_off.swap(L.col_off); P->pwg_off.swap(L.pwg_off); P->pwt_off.swap(L.pwt_off); P->upd_off.swap(L.upd_off); P->fwd_off.swap(L.fwd_off);
-      P->n_pad = L.n_pad; P->n_levels = L.levels; P->update_fraction = L.update_fraction;
-      P->levels = true; P->sparse = true;
-      return PVLM_OK;
-    }
+  P->update_fraction = H.update_fraction;
+  if (H.kind == 0) {
+    P->new_of_old.resize((size_t)n);
+    for (int i = 0; i < n; ++i) P->new_of_old[(size_t)i] = i;
+    return PVLM_OK;
   }
-  pvlm_spd::Symbolic S;
-  pvlm_spd::plan_symbolic(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, &S);       // csrc/pvlm_spd_plan.h (host only, checked on the CPU)
-  P->update_fraction = S.update_fraction;
-  static const double max_fraction = getenv("PVLM_SPD_SPARSE_FRACTION") ? atof(getenv("PVLM_SPD_SPARSE_FRACTION")) : 0.6;
-  if (!S.ordered || S.update_fraction > max_fraction) return PVLM_OK;     // not sparse enough to pay for the irregular tile lists: natural order, dense kernels
+  static_assert(sizeof(pvlm_spd::Target) == sizeof(NdTarget) && sizeof(pvlm_spd::RowTarget) == sizeof(NdRowTarget) && sizeof(pvlm_spd::PanelGroup) == sizeof(int2), "level lists are uploaded as they are");
   static_assert(sizeof(pvlm_spd::TilePair) == sizeof(int2), "tile pairs are uploaded as int2");
-  pvlm_status st = pvlm_i_alloc(ctx, &P->d_row_tiles, std::max<size_t>(S.row_tiles.size(), 1));
-  if (!st) st = pvlm_i_alloc(ctx, &P->d_pairs, std::max<size_t>(S.pairs.size(), 1));
-  if (!st && !S.row_tiles.empty()) st = pvlm_i_h2d_q(ctx, P->d_row_tiles, S.row_tiles.data(), S.row_tiles.size() * sizeof(int));
-  if (!st && !S.pairs.empty()) st = pvlm_i_h2d_q(ctx, P->d_pairs, S.pairs.data(), S.pairs.size() * sizeof(int2));
+  pvlm_status st = PVLM_OK;
+  auto up = [&](void** d, const void* src, size_t bytes) {
+    if (st) return;
+    st = pvlm_i_alloc_bytes(ctx, d, std::max<size_t>(bytes, 256));
+    if (!st && bytes) st = pvlm_i_h2d_q(ctx, *d, src, bytes);
+  };
+  if (H.kind == 1) {
+    pvlm_spd::LevelPlan& L = H.L;
+    up((void**)&P->d_cols, L.cols.data(), L.cols.size() * sizeof(int));
+    up((void**)&P->d_row_off, L.row_off.data(), L.row_off.size() * sizeof(int));
+    up((void**)&P->d_row_tiles, L.row_tiles.data(), L.row_tiles.size() * sizeof(int));
+    up((void**)&P->d_pwg, L.pwg.data(), L.pwg.size() * sizeof(int2));
+    up((void**)&P->d_pwt, L.pwt.data(), L.pwt.size() * sizeof(int2));
+    up((void**)&P->d_targets, L.targets.data(), L.targets.size() * sizeof(NdTarget));
+    up((void**)&P->d_sources, L.sources.data(), L.sources.size() * sizeof(int));
+    up((void**)&P->d_ftargets, L.ftargets.data(), L.ftargets.size() * sizeof(NdRowTarget));
+    up((void**)&P->d_fsources, L.fsources.data(), L.fsources.size() * sizeof(int));
+    if (!st) st = pvlm_i_sync(ctx);
+    if (st) return st;
+    P->new_of_old.swap(L.new_of_old); P->col_off.swap(L.col_off); P->pwg_off.swap(L.pwg_off); P->pwt_off.swap(L.pwt_off); P->upd_off.swap(L.upd_off); P->fwd_off.swap(L.fwd_off);
+    P->n_pad = L.n_pad; P->n_levels = L.levels;
+    P->levels = true; P->sparse = true;
+    return PVLM_OK;
+  }
+  pvlm_spd::Symbolic& S = H.S;
+  up((void**)&P->d_row_tiles, S.row_tiles.data(), S.row_tiles.size() * sizeof(int));
+  up((void**)&P->d_pairs, S.pairs.data(), S.pairs.size() * sizeof(int2));
   if (!st) st = pvlm_i_sync(ctx);
   if (st) return st;
   P->new_of_old.swap(S.new_of_old); P->row_off.swap(S.row_off); P->pair_off.swap(S.pair_off);
@@ -906,13 +943,36 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     if (!same) {
       PVLM_TRY_SYNC(ctx);
       pvlm_i_trace("spd solve: before the plan");
-      pvlm_i_spd_plan_release(ctx);
+      spd_plan_free(ctx, static_cast<SpdPlan*>(ctx->spd_plan)); ctx->spd_plan = nullptr;      // the old plan only: a prefetch in flight is looked at below
       plan = new SpdPlan();
       plan->key = key;
       plan->key_rows.assign(row_idx, row_idx + (size_t)n_blocks * 6); plan->key_cols.assign(col_idx, col_idx + (size_t)n_blocks * 6);
       plan->key_mirror.assign(mirror, mirror + n_blocks);
       ctx->spd_plan = plan;
-      const pvlm_status pst = spd_plan_build(ctx, n, n_blocks, row_idx, col_idx, mirror, plan);
+      // the host half: taken from pvlm_spd_plan_prefetch when that was given exactly these lists (it has been running beside the caller's GPU work), else made now
+      SpdPrefetch* pre = static_cast<SpdPrefetch*>(ctx->spd_prefetch);
+      bool taken = false;
+      pvlm_status pst = PVLM_OK;
+      if (pre) {
+        const auto tj = std::chrono::steady_clock::now();
+        if (pre->worker.joinable()) pre->worker.join();
+        if (getenv("PVLM_TRACE")) {
+          char msg[128];
+          snprintf(msg, sizeof msg, "spd plan prefetch: thread %.2f ms, joined after %.2f ms", pre->worker_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count());
+          pvlm_i_trace(msg);
+        }
+        if (!pre->failed && pre->n == n && pre->n_blocks == n_blocks && pre->rows == plan->key_rows && pre->cols == plan->key_cols && pre->mirror == plan->key_mirror) {
+          pst = spd_plan_adopt(ctx, n, pre->host, plan);
+          taken = true;
+        }
+        spd_prefetch_drop(ctx);
+      }
+      ctx->spd_prefetch_hits += taken ? 1 : 0;
+      if (!taken) {
+        SpdHostPlan host;
+        spd_plan_host(n, n_blocks, row_idx, col_idx, &host);
+        pst = spd_plan_adopt(ctx, n, host, plan);
+      }
       if (pst) { pvlm_i_spd_plan_release(ctx); return pst; }
       if (getenv("PVLM_TRACE")) { char msg[96]; snprintf(msg, sizeof msg, "spd plan built: %s, update fraction %.3f, n %d, blocks %d", plan->sparse ? "tile-sparse" : "dense", plan->update_fraction, n, n_blocks); pvlm_i_trace(msg); }
     }
@@ -981,6 +1041,43 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     hipStreamSynchronize(ctx->stream);
   }
   return st;
+}
+
+// Starts the host half of the plan for this structure on a thread of its own and returns at once; the next pvlm_spd_solve_blocks with EXACTLY these lists takes it
+// (any other structure: the prefetch is dropped and the plan made as before).  The lists are copied.  No device work here.
+pvlm_status pvlm_spd_plan_prefetch(pvlm_ctx* ctx, int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror) {
+  if (!ctx || n < 0 || n_blocks < 0 || (n_blocks > 0 && (!row_idx || !col_idx || !mirror))) return PVLM_ERR_ARG;
+  spd_prefetch_drop(ctx);
+  // a structure the context already holds a plan for needs none
+  const SpdPlan* have = static_cast<const SpdPlan*>(ctx->spd_plan);
+  try {
+    if (have && have->n == n && have->key_mirror.size() == (size_t)n_blocks && have->key_rows.size() == (size_t)n_blocks * 6 &&
+        (n_blocks == 0 || (std::memcmp(have->key_rows.data(), row_idx, (size_t)n_blocks * 6 * sizeof(int)) == 0 && std::memcmp(have->key_cols.data(), col_idx, (size_t)n_blocks * 6 * sizeof(int)) == 0 &&
+                           std::memcmp(have->key_mirror.data(), mirror, (size_t)n_blocks * sizeof(int)) == 0)))
+      return PVLM_OK;
+    SpdPrefetch* f = new SpdPrefetch();
+    ctx->spd_prefetch = f;
+    f->n = n; f->n_blocks = n_blocks;
+    if (n_blocks > 0) { f->rows.assign(row_idx, row_idx + (size_t)n_blocks * 6); f->cols.assign(col_idx, col_idx + (size_t)n_blocks * 6); f->mirror.assign(mirror, mirror + n_blocks); }
+    f->worker = std::thread([f]() {
+      const auto t0 = std::chrono::steady_clock::now();
+      try { spd_plan_host(f->n, f->n_blocks, f->rows.data(), f->cols.data(), &f->host); }
+      catch (...) { f->failed = true; }
+      f->worker_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();                       // out of memory on the thread: the solve makes its plan itself (and reports what it meets)
+    });
+  } catch (const std::bad_alloc&) {
+    spd_prefetch_drop(ctx);
+    PVLM_SET_ERR(ctx, "pvlm_spd_plan_prefetch: out of host memory");
+    return PVLM_ERR_NOMEM;
+  } catch (const std::system_error&) {                         // no thread to be had: not an error of the caller's, the solve plans for itself
+    spd_prefetch_drop(ctx);
+  }
+  return PVLM_OK;
+}
+pvlm_status pvlm_spd_plan_prefetch_hits(const pvlm_ctx* ctx, long long* hits) {
+  if (!ctx || !hits) return PVLM_ERR_ARG;
+  *hits = ctx->spd_prefetch_hits;
+  return PVLM_OK;
 }
 
 pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_columns, int* padded_rows) {

@@ -845,13 +845,16 @@ pvlm_status pvlm_line2line_residuals(pvlm_ctx* ctx, int n_pairs, pvlm_scan* cons
   pvlm_status st = pvlm_i_alloc(ctx, &d_block, (size_t)R_rows * 9);
   if (st) { pvlm_i_resset_free(ctx, rs); return st; }
   rs->col_blocks.push_back(d_block); rs->block_rows.push_back(R_rows);
+  pvlm_i_trace("line2line_residuals: column block allocated");
   pvlm_match_desc* d_md = nullptr; pvlm_match_pose* d_po = nullptr;
   if (n_matches > 0) {
     st = pvlm_i_alloc(ctx, &d_md, md.size());
     if (!st) st = pvlm_i_alloc(ctx, &d_po, poses.size());
     if (!st) {
+      pvlm_i_trace("line2line_residuals: tables allocated");
       st = pvlm_i_h2d_q(ctx, d_md, md.data(), md.size() * sizeof(pvlm_match_desc));
       if (!st) st = pvlm_i_h2d_q(ctx, d_po, poses.data(), poses.size() * sizeof(pvlm_match_pose));
+      if (getenv("PVLM_TRACE")) { char msg[96]; snprintf(msg, sizeof msg, "line2line_residuals: %d matches, %lld rows: copies queued", n_matches, R_rows); pvlm_i_trace(msg); }
       hipError_t e = hipSuccess;
       if (!st) { hipLaunchKernelGGL(k_line_rows, dim3((unsigned)n_matches), dim3(64), 0, ctx->stream, d_md, d_po, d_block, R_rows); e = hipGetLastError(); }
       if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_line2line_residuals: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }

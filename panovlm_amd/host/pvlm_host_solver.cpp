@@ -303,6 +303,40 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   // indices: pvlm_resset_set_pose_ids, once), so that a linearisation needs one pose table and the groups' blocks are summed on the
   // device into one packed buffer [diag NP x 36 | off U x 36 | g NP x 6 | cost] over the union (ui < uj) of their pose pairs.
   StageTimer* stage_timer_setup_ = new StageTimer("solve: residual-set upload + structures");
+  const char* gpu_min_env = std::getenv("PVLM_GPU_CHOLESKY_MIN");
+  const int gpu_chol_min = gpu_min_env ? std::atoi(gpu_min_env) : 1500;
+  // The plan of the pose solve (ordering + schedule of pvlm_spd_solve_blocks: ~10 ms of host work at Floor size) is asked for as soon as the block structure is
+  // known and made on a thread of the library beside what follows — set uploads, structures, the first linearisation — instead of inside the first Cholesky of the
+  // Solve.  A hint: pvlm_spd_solve_blocks compares the lists it is given with the prefetched ones and plans for itself when they differ.
+  auto prefetch_plan = [&](const BlockKeys& keys, const std::vector<int>& block_off, int n_free) {
+    if (n_free < gpu_chol_min || std::getenv("PVLM_NO_PLAN_PREFETCH")) return;
+    std::vector<int> rows, cols, mirror;
+    rows.reserve(keys.size() * 6); cols.reserve(keys.size() * 6); mirror.reserve(keys.size());
+    auto at = [&](int pose, int r) { const int b = r < 3 ? I.poses[(size_t)pose].first : I.poses[(size_t)pose].second; return block_off[(size_t)b] < 0 ? -1 : block_off[(size_t)b] + (r % 3); };
+    for (const auto& key : keys) {
+      for (int r = 0; r < 6; ++r) { rows.push_back(at(key.first, r)); cols.push_back(at(key.second, r)); }
+      mirror.push_back(key.first != key.second ? 1 : 0);
+    }
+    e.Check(pvlm_spd_plan_prefetch(e.ctx(), n_free, (int)mirror.size(), rows.data(), cols.data(), mirror.data()), "pvlm_spd_plan_prefetch");
+  };
+  bool any_bundle = false;
+  for (auto& b : I.bundles) if (!b.obs_pose.empty()) any_bundle = true;
+  if (!xch && !any_bundle) {
+    // one process, four-block groups only: the key list is [every pose with itself | the union of the groups' pose pairs, sorted] and every block is free unless
+    // constant — the same lists the code below arrives at (it stays the authority)
+    std::set<std::pair<int, int>> up;
+    for (auto& g : I.groups) for (size_t p = 0; p < g.ref.size(); ++p) up.insert({std::min(g.ref[p], g.nei[p]), std::max(g.ref[p], g.nei[p])});
+    std::vector<int> off(I.blocks.size(), -1);
+    int nf = 0;
+    for (int p = 0; p < NP; ++p)
+      for (int b : {I.poses[(size_t)p].first, I.poses[(size_t)p].second})
+        if (!I.constant[(size_t)b] && off[(size_t)b] < 0) { off[(size_t)b] = nf; nf += 3; }
+    BlockKeys early;
+    early.reserve((size_t)NP + up.size());
+    for (int p = 0; p < NP; ++p) early.push_back({p, p});
+    for (auto& u : up) early.push_back(u);
+    prefetch_plan(early, off, nf);
+  }
   std::vector<int> gui, guj;
   {
     std::set<std::pair<int, int>> up;
@@ -428,6 +462,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     slot_of_packed.assign((size_t)NP + (size_t)U, -1);
     for (int p = 0; p < NP; ++p) if (used[(size_t)p]) slot_of_packed[(size_t)p] = slot_of(p, p);
     for (int u = 0; u < U; ++u) slot_of_packed[(size_t)NP + (size_t)u] = slot_of(gui[(size_t)u], guj[(size_t)u]);
+    if (!have_bundles) prefetch_plan(*keys, block_off, n_free);        // sharded: the structure is known after the exchange of the key lists; the first linearisation is still ahead
   } else {
     keys->reserve((size_t)NP + (size_t)U);
     for (int p = 0; p < NP; ++p) keys->push_back({p, p});
@@ -661,8 +696,7 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
   };
   // Large reduced systems (Room / Floor sized joint problems: thousands of unknowns) are assembled, factorised and solved
   // on the GPU (pvlm_spd_solve_blocks: blocked Cholesky kernels); small ones by the host skyline Cholesky.
-  const char* gpu_min_env = std::getenv("PVLM_GPU_CHOLESKY_MIN");
-  const bool gpu_chol = n_free >= (gpu_min_env ? std::atoi(gpu_min_env) : 1500);
+  const bool gpu_chol = n_free >= gpu_chol_min;
   // v^T (D H D) v over a block list, without forming the matrix
   auto quad_form = [&](const auto& H, const std::vector<double>& v) {
     double q = 0.0;
@@ -709,8 +743,12 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
       if (have_bundles) push(R.H);
       delete stage_timer_push_;
       int info = 0;
+      long long hits_before = 0, hits_after = 0;
+      pvlm_spd_plan_prefetch_hits(e.ctx(), &hits_before);
       e.Check(pvlm_spd_solve_blocks(e.ctx(), n_free, (int)mirror.size(), rows.data(), cols.data(), mirror.data(), blocks.data(), scale.data(), damp.data(),
                                     dy.data(), &info), "pvlm_spd_solve_blocks");
+      pvlm_spd_plan_prefetch_hits(e.ctx(), &hits_after);
+      if (hits_after > hits_before) { StageTimer stage_timer_hit_("  (inside the GPU Cholesky stage) plan taken from the prefetch started on entry to the Solve (count)"); }
       step_ok = info == 0;
     } else {
       S0.Init(build_first(A, R));

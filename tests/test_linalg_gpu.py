@@ -191,3 +191,43 @@ def test_nested_dissection_level_schedule(shape, P):
         x_old, info_old, plan_old = pickle.load(open(os.path.join(d, "out.pkl"), "rb"))
     assert info_old == 0 and plan_old["levels"] == 0
     assert np.abs(x - x_old).max() <= 1e-11 * max(1.0, np.abs(x_old).max())
+
+
+def test_plan_prefetch_is_a_hint_never_a_change_of_result():
+    """pvlm_spd_plan_prefetch: the host half of the plan made on a thread of the library ahead of the solve.  Same lists: the solve takes it (hit counted) and returns the
+    bits of a solve that planned for itself; other lists: the prefetch is dropped, the solve plans for itself; a second prefetch replaces the first; a context may end
+    with a prefetch in flight."""
+    import panovlm_amd as pv
+    rng = np.random.default_rng(23)
+    F = 330
+    pairs = [(p, p) for p in range(F)] + [(p, q) for p in range(F) for q in range(p + 1, min(F, p + 4))] + [(5, 300), (40, 222)]
+    n = 6 * (F - 1)
+    off = np.arange(-6, n).reshape(F, 6); off[0] = -1
+    rows = np.array([off[a] for a, b in pairs], np.int32); cols = np.array([off[b] for a, b in pairs], np.int32)
+    mirror = np.array([int(a != b) for a, b in pairs], np.int32)
+    blocks = np.empty((len(pairs), 36))
+    for k, (a, b) in enumerate(pairs):
+        if a == b:
+            J = rng.normal(size=(9, 6)); blocks[k] = (J.T @ J + 30 * np.eye(6)).reshape(-1)
+        else:
+            blocks[k] = (rng.normal(size=(6, 6)) * 0.2).reshape(-1)
+    scale = np.full(n, 0.3); diag = np.full(n, 1.0); rhs = rng.normal(size=n)
+    a = pv.Context(0)
+    want, info = a.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert info == 0 and a.spd_plan()["tile_sparse"] and a.spd_plan_prefetch_hits() == 0
+    b = pv.Context(0)
+    b.spd_plan_prefetch(n, rows, cols, mirror)
+    got, info = b.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert info == 0 and b.spd_plan_prefetch_hits() == 1 and np.array_equal(got, want)
+    assert b.spd_plan() == a.spd_plan()
+    b.spd_plan_prefetch(n, rows, cols, mirror)                     # the context holds this plan already: nothing is started, nothing is taken
+    got, _ = b.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert b.spd_plan_prefetch_hits() == 1 and np.array_equal(got, want)
+    # another structure prefetched (the loop closures left out): dropped by the solve, which plans for itself
+    c = pv.Context(0)
+    c.spd_plan_prefetch(n, rows[:-2], cols[:-2], mirror[:-2])
+    got, info = c.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert info == 0 and c.spd_plan_prefetch_hits() == 0 and np.array_equal(got, want)
+    c.spd_plan_prefetch(n, rows[:-2], cols[:-2], mirror[:-2])      # replaced by the next one before any solve ...
+    c.spd_plan_prefetch(n, rows[:-1], cols[:-1], mirror[:-1])      # ... and this one is still in flight when the context ends
+    del c

@@ -4,6 +4,8 @@ reference's World <-> Local round trips bit for bit (pcl::transformPointCloud ar
 rebuilt from device-side bounding boxes equal the grids an upload of the same floats builds (plan, cell membership, stored records), and the
 association on re-posed scans equals the association on freshly uploaded ones — over three outer iterations, at small, Room (454) and Floor
 (1593) batch sizes.  Bar: bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -222,3 +224,36 @@ def test_upload_from_point_records_equals_packed_upload(ctx):
     assert out[0] == out[1]
     for d in packed + records:
         d.close()
+
+
+def test_upload_from_point_records_with_a_staging_window_that_cuts_records(tmp_path):
+    """The same equality when the pinned staging window is far smaller than the upload and not a multiple of a record (PVLM_UPLOAD_STAGE_MB: window boundaries fall
+    inside 12-byte coordinate records — the gather copies the cut records byte by byte and the whole ones in a fixed-size loop).  In a process of its own: the window
+    size is read per upload, the context's pinned buffer is grow-only."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, panovlm_amd as pv
+        from panovlm_amd import synthetic as sy
+        from tests.test_repose_gpu import _posed, _local_scan, _T
+        rng = np.random.default_rng(9)
+        scans = []
+        for k in range(6):
+            s = _posed(_local_scan(rng, k, 256, 4), _T(*sy.estimated_pose(k)), sy.estimated_pose(k))
+            s["less_tag"] = np.where(rng.uniform(size=len(s["less_xyz"])) < 0.1, 16.0, 1.0).astype(np.float32)
+            s["flat_tag"] = np.where(rng.uniform(size=len(s["flat_xyz"])) < 0.3, 16.0, 1.0).astype(np.float32)
+            scans.append(s)
+        ctx = pv.Context(0)
+        packed = pv.Scan.upload_batch(ctx, scans)
+        records = pv.Scan.upload_batch(ctx, [dict(s, point_records=True) for s in scans])
+        n = 0
+        for a, b in zip(packed, records):
+            for which in range(4):
+                xa, xb = a.fetch_cloud(which), b.fetch_cloud(which)
+                assert xa.tobytes() == xb.tobytes(), which
+                n += xa.size
+        print("same", n)
+    """)
+    env = dict(os.environ, PVLM_UPLOAD_STAGE_MB="0.004", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # 4 KiB windows
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("same") and int(out.stdout.split()[1]) > 10000
