@@ -688,6 +688,37 @@ pvlm_status pvlm_ring_batch_destroy(pvlm_ctx* ctx, pvlm_ring_batch* batch);
  * as std::sort of the indices 0 .. n-1 by `keys[a] < keys[b]` leaves them — equal keys in libstdc++'s order.                                      */
 pvlm_status pvlm_ring_debug_sort(pvlm_ctx* ctx, const unsigned* keys, int n, int* order);
 
+/* ---- growth of the line segments of a batch of scans (N3, K27) -----------------------------------------------------------------------------
+ * The growth phase of ExtractLineFeatures / ExpandLine (sensors/LidarLineExtraction.cpp:296-389, :10-70; called by Velodyne::EdgeToLine,
+ * sensors/Velodyne.cpp:1269-1324) for every scan of a batch.  The segment grown from edge point i with its neighbours (a, b), 1 <= a < b <= 4 among its four nearest
+ * edge points, never looks at what other segments took — only upstream's walk over the start points does (a point an earlier segment took is skipped) — so the
+ * device grows the tasks of the next start points side by side and replays the walk over them (csrc/pvlm_linegrow.hip).  clouds[s]: the edge points of scan s
+ * (cornerLessSharp before the filter), n <= 65535, stride_floats >= 3 floats between points (pcl::PointXYZI: 4).
+ * pvlm_line_grow_scan: the segments upstream's walk keeps for one scan, in its order (start point ascending, then the combinations (1,2) (1,3) (1,4) (2,3) (2,4)
+ * (3,4)): seg_task[q] = 6 i + combination, members[seg_offset[q] .. seg_offset[q + 1]) = ascending point ids of segment q (>= 5), coeffs[6 q ..] =
+ * FormLine(members, 1.0) (zeros when that fit refuses: kept, as upstream keeps it).  status != 0: a segment of this scan outgrew the kernel's lists (2: more than 64
+ * members, or more than 8192 edge points) or met a turn angle the host's acos has to decide (3) — the scan is to be grown by the caller.  PVLM_ERR_REFUSED: the
+ * batch's segment pool was exhausted (nothing is returned; grow on the host).  The result lives in host memory until pvlm_line_grow_destroy. */
+typedef struct pvlm_edge_cloud { const float* xyz; int n; int stride_floats; } pvlm_edge_cloud;
+typedef struct pvlm_line_grow pvlm_line_grow;
+typedef struct pvlm_line_grow_result {
+  int status, n_points, n_segments;
+  const int* seg_task;
+  const int* seg_offset;            /* n_segments + 1 entries, offsets into `members` */
+  const int* members;
+  const double* coeffs;
+  double kernel_ms;                 /* HIP-event time of the batch's two kernels */
+  long long tasks_run;              /* (start point, neighbour pair) tasks the batch grew, the speculative ones included */
+} pvlm_line_grow_result;
+pvlm_status pvlm_line_grow_batch(pvlm_ctx* ctx, int n_scans, const pvlm_edge_cloud* clouds, pvlm_line_grow** out);
+/* The same in two halves: _begin copies the clouds, queues the batch on a stream of its own (ordered behind what the context's stream holds at that moment) and returns
+ * without waiting — the caller's next calls on this context (the range-image stages of the next device batch, say) run beside it; _finish waits and brings the
+ * segments down.  One batch in flight per context (PVLM_ERR_STATE otherwise); pvlm_line_grow_scan serves finished batches only. */
+pvlm_status pvlm_line_grow_begin(pvlm_ctx* ctx, int n_scans, const pvlm_edge_cloud* clouds, pvlm_line_grow** out);
+pvlm_status pvlm_line_grow_finish(pvlm_ctx* ctx, pvlm_line_grow* grow);
+pvlm_status pvlm_line_grow_scan(const pvlm_line_grow* grow, int scan, pvlm_line_grow_result* result);
+pvlm_status pvlm_line_grow_destroy(pvlm_ctx* ctx, pvlm_line_grow* grow);
+
 /* ---- motion compensation of the sweeps (N5) ---------------------------------------------------------------------------------------------
  * Velodyne::UndistortCloud(R_we, t_we) (sensors/Velodyne.cpp:1642-1674) for every scan of LidarOdometry::UndistortLidars
  * (lidar_mapping/LidarOdometry.cpp:189-263) in one call: point i of n moves by the share i / n of the motion from the sweep's start pose (R_wl, t_wl)

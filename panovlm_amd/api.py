@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_line_grow_batch", "pvlm_line_grow_begin", "pvlm_line_grow_finish", "pvlm_line_grow_scan", "pvlm_line_grow_destroy", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -275,6 +275,43 @@ class Context:
                                                    _p(blocks, C.c_double), _p(_f64(scale), C.c_double), _p(_f64(diag_add), C.c_double),
                                                    _p(x, C.c_double), C.byref(info)), "pvlm_spd_solve_blocks")
         return x, info.value
+
+    def line_grow_batch(self, clouds, two_halves=False):
+        """pvlm_line_grow_batch (K27): the line segments upstream's walk keeps for every edge cloud (n x >= 3 float32 each).  Returns one dict per cloud:
+        status, seg_task, seg_offset, members, coeffs (n_segments x 6); the last call's kernel_ms / tasks_run under those keys of the first dict.
+        two_halves: through pvlm_line_grow_begin / _finish."""
+        class _Cloud(C.Structure):
+            _fields_ = [("xyz", C.POINTER(C.c_float)), ("n", C.c_int), ("stride_floats", C.c_int)]
+
+        class _Result(C.Structure):
+            _fields_ = [("status", C.c_int), ("n_points", C.c_int), ("n_segments", C.c_int), ("seg_task", C.POINTER(C.c_int)), ("seg_offset", C.POINTER(C.c_int)),
+                        ("members", C.POINTER(C.c_int)), ("coeffs", C.POINTER(C.c_double)), ("kernel_ms", C.c_double), ("tasks_run", C.c_longlong)]
+        arrs = [np.ascontiguousarray(c, np.float32).reshape(len(c), -1) if len(c) else np.zeros((0, 3), np.float32) for c in clouds]
+        descs = (_Cloud * max(len(arrs), 1))()
+        for k, a in enumerate(arrs):
+            descs[k].xyz = a.ctypes.data_as(C.POINTER(C.c_float)); descs[k].n = len(a); descs[k].stride_floats = a.shape[1] if len(a) else 3
+        h = C.c_void_p()
+        if two_halves:
+            self._check(self.lib.pvlm_line_grow_begin(self._h, C.c_int(len(arrs)), descs, C.byref(h)), "pvlm_line_grow_begin")
+            st = self.lib.pvlm_line_grow_finish(self._h, h)
+            if st:
+                self.lib.pvlm_line_grow_destroy(self._h, h)
+                self._check(st, "pvlm_line_grow_finish")
+        else:
+            self._check(self.lib.pvlm_line_grow_batch(self._h, C.c_int(len(arrs)), descs, C.byref(h)), "pvlm_line_grow_batch")
+        out = []
+        try:
+            for k in range(len(arrs)):
+                r = _Result()
+                self._check(self.lib.pvlm_line_grow_scan(h, C.c_int(k), C.byref(r)), "pvlm_line_grow_scan")
+                ns = r.n_segments
+                off = np.ctypeslib.as_array(r.seg_offset, (ns + 1,)).copy() if ns else np.zeros(1, np.int32)
+                mem = np.ctypeslib.as_array(r.members, (int(off[-1]),))[int(off[0]):].copy() if ns else np.zeros(0, np.int32)
+                out.append(dict(status=r.status, seg_task=np.ctypeslib.as_array(r.seg_task, (ns,)).copy() if ns else np.zeros(0, np.int32), seg_offset=off - off[0], members=mem,
+                                coeffs=np.ctypeslib.as_array(r.coeffs, (ns, 6)).copy() if ns else np.zeros((0, 6)), kernel_ms=r.kernel_ms, tasks_run=r.tasks_run))
+        finally:
+            self.lib.pvlm_line_grow_destroy(self._h, h)
+        return out
 
     def spd_plan_prefetch(self, n, row_idx, col_idx, mirror):
         """pvlm_spd_plan_prefetch: the host half of the plan of this structure starts on a thread of the library; the next spd_solve_blocks with exactly these lists takes it."""

@@ -315,6 +315,7 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   if (!ctx) return PVLM_ERR_ARG;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->grow_stream) hipStreamSynchronize(ctx->grow_stream);      // a line growth begun and never finished: its kernels end before its blocks go
   pvlm_i_assoc_ws_free(ctx);
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);
   if (ctx->h_grid) (void)hipHostFree(ctx->h_grid);
@@ -327,6 +328,10 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   for (int w = 0; w < 4; ++w) for (auto& pr : ctx->prof_pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
   if (ctx->aux_stream) { hipStreamSynchronize(ctx->aux_stream); hipStreamDestroy(ctx->aux_stream); }
+  if (ctx->grow_stream) { hipStreamSynchronize(ctx->grow_stream); hipStreamDestroy(ctx->grow_stream); }
+  for (hipEvent_t e : ctx->grow_ev) if (e) hipEventDestroy(e);
+  if (ctx->h_grow_in) (void)hipHostFree(ctx->h_grow_in);
+  if (ctx->h_grow_out) (void)hipHostFree(ctx->h_grow_out);
   for (hipEvent_t e : ctx->aux_ev) if (e) hipEventDestroy(e);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;

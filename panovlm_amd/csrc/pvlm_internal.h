@@ -82,6 +82,13 @@ struct pvlm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t aux_stream = nullptr;   // second stream of the look-ahead Cholesky (K10), created on first use
   hipEvent_t aux_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // K27 (pvlm_line_grow_begin / _finish): its own stream — the line growth of one device batch of scans runs beside the range-image stages of the next —, three
+  // events (ordering behind the main stream, kernel timing) and two grow-only pinned buffers (inputs; counters, statuses and the kept segments coming back)
+  hipStream_t grow_stream = nullptr;
+  hipEvent_t grow_ev[3] = {nullptr, nullptr, nullptr};
+  void* h_grow_in = nullptr; size_t grow_in_bytes = 0;
+  void* h_grow_out = nullptr; size_t grow_out_bytes = 0;
+  bool grow_in_flight = false;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;

@@ -430,7 +430,7 @@ void Velodyne::PickFeatures(float max_curvature, float intersect_angle_threshold
   }
 }
 
-void Velodyne::AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, bool edge_to_line) {
+void Velodyne::AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, bool edge_to_line, const pvlm_line_grow_result* grown) {
   const int n = (int)cloud_scan.size();
   const PointCloud& P = cloud_scan;
   ProfileSpan span(2);
@@ -446,7 +446,7 @@ void Velodyne::AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, 
     }
   }
   span.Next(3);
-  if (edge_to_line) EdgeToLine();
+  if (edge_to_line) EdgeToLine(grown);
   span.Next(4);
   surfFlat.clear(); surfLessFlat.clear();
   size_t centroids = 0;
@@ -505,12 +505,19 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
   const size_t per_batch = total <= 48 ? total : std::max<size_t>(24, (total + n_parts - 1) / n_parts);
   // PVLM_FEATURE_PICKS=host: the picks and the voxel grid on the host threads (PickFeatures) instead of K24 — the A/B switch of tools/feature_batch_bench.py
   static const bool device_picks = [] { const char* v = std::getenv("PVLM_FEATURE_PICKS"); return !(v && std::strcmp(v, "host") == 0); }();
-  std::atomic<long> scans_on_host{0}, scans_refused{0};
-  struct Part { pvlm_ring_batch* batch = nullptr; bool on_host = false; };
+  std::atomic<long> scans_on_host{0}, scans_refused{0}, scans_grown_on_host{0};
+  // grow: the line segments of the part's scans grown ahead on the GPU (K27, pvlm_line_grow_batch) from the edge picks the device made; grow_slot[j]: the scan's
+  // position in that batch, -1 = none (picks left to the host, scan dropped, no edge points).  PVLM_EDGE_GROW=host: all growth on the host threads (round 5).
+  struct Part { pvlm_ring_batch* batch = nullptr; bool on_host = false; pvlm_line_grow* grow = nullptr; std::vector<int> grow_slot; };
   std::vector<Part> parts((total + per_batch - 1) / per_batch);
-  struct Release { pvlm_ctx* c; std::vector<Part>& p; ~Release() { for (Part& q : p) pvlm_ring_batch_destroy(c, q.batch); } } release{e.ctx(), parts};
+  struct Release { pvlm_ctx* c; std::vector<Part>& p; ~Release() { for (Part& q : p) { pvlm_ring_batch_destroy(c, q.batch); pvlm_line_grow_destroy(c, q.grow); } } } release{e.ctx(), parts};
+  static const bool device_grow = [] { const char* v = std::getenv("PVLM_EDGE_GROW"); return !(v && (std::strcmp(v, "host") == 0 || std::strcmp(v, "tasks") == 0)); }();
+  double grow_ms = 0, grow_kernel_ms = 0; long long grow_tasks = 0;
   std::mutex gate; std::condition_variable published_cv;
   size_t published = 0;                        // scans (in `todo` order) whose batch is back from the device
+  size_t grown_parts = 0;                      // parts whose line growth is back (or that have none)
+  std::vector<size_t> deferred;                // scans assembled before their part's growth was back: their EdgeToLine is still to run
+  size_t assembled = 0;                        // scans whose first pass is over
   bool production_failed = false;
   double ring_ms = 0, producer_ms = 0;
   auto produce = [&]() {
@@ -543,8 +550,55 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
           double ms8[8] = {0};
           if (pvlm_ring_batch_timing(parts[k].batch, ms8) == PVLM_OK) for (double v : ms8) ring_ms += v;
         }
+        // the part's scans are the workers' from here on; the growth of the PREVIOUS part (it ran beside this part's range-image stages) comes back now, this
+        // part's growth starts and runs beside the next part's stages
         { std::lock_guard<std::mutex> g(gate); published = first + count; }
         published_cv.notify_all();
+        auto finish_growth = [&](size_t q) {
+          Part& pq = parts[q];
+          if (pq.grow) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const pvlm_status gs = pvlm_line_grow_finish(e.ctx(), pq.grow);
+            if (gs == PVLM_ERR_REFUSED) { fprintf(stderr, "ExtractFeaturesBatch: %s — the host threads grow the lines of these scans\n", pvlm_last_error(e.ctx())); pvlm_line_grow_destroy(e.ctx(), pq.grow); pq.grow = nullptr; }
+            else e.Check(gs, "pvlm_line_grow_finish");
+            pvlm_line_grow_result g0;
+            if (pq.grow && pvlm_line_grow_scan(pq.grow, 0, &g0) == PVLM_OK) { grow_kernel_ms += g0.kernel_ms; grow_tasks += g0.tasks_run; }
+            grow_ms += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          }
+          { std::lock_guard<std::mutex> g(gate); grown_parts = q + 1; }
+          published_cv.notify_all();
+        };
+        if (k > 0) finish_growth(k - 1);
+        if (!parts[k].on_host && edge_to_line && device_picks && device_grow) {
+          // the edge points of every scan whose picks the device made, as AssemblePicks will lay them out (ring by ring, pick order), grown in one batch
+          const auto grow_t0 = std::chrono::steady_clock::now();
+          Part& part = parts[k];
+          part.grow_slot.assign(count, -1);
+          std::vector<std::vector<float>> edge(count);
+          std::vector<pvlm_edge_cloud> clouds;
+          for (size_t j = first; j < first + count; ++j) {
+            pvlm_ring_result r;
+            if (pvlm_ring_batch_scan(part.batch, (int)(j - first), &r) != PVLM_OK || !r.picks) continue;
+            bool decided = r.n_kept > 0 && !(r.n_kept < r.n_reordered * 0.1);
+            for (int q = 0; decided && q < rings; ++q) decided = r.ring_host[q] == 0;
+            if (!decided) continue;
+            const PointCloud& raw_cloud = scans[todo[j]]->cloud;
+            std::vector<float>& xyz = edge[j - first];
+            for (int ring = 0; ring < rings; ++ring) {
+              const int* list = r.corner + (size_t)ring * 181;
+              for (int q = 0; q < list[0]; ++q) {
+                const PointXYZI& p = raw_cloud[(size_t)r.source[list[1 + q] & 0x7FFFFFFF]];
+                xyz.push_back(p.x); xyz.push_back(p.y); xyz.push_back(p.z);
+              }
+            }
+            if (xyz.empty() || xyz.size() / 3 > 65535) continue;
+            part.grow_slot[j - first] = (int)clouds.size();
+            clouds.push_back(pvlm_edge_cloud{xyz.data(), (int)(xyz.size() / 3), 3});
+          }
+          if (!clouds.empty()) e.Check(pvlm_line_grow_begin(e.ctx(), (int)clouds.size(), clouds.data(), &part.grow), "pvlm_line_grow_begin");      // copies the clouds
+          grow_ms += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - grow_t0).count();
+        }
+        if (k + 1 == parts.size()) finish_growth(k);
       }
       producer_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - produce_t0).count();
     } catch (...) {
@@ -553,13 +607,24 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
       throw;
     }
   };
-  auto pick = [&](size_t j) {
+  // the lines of a scan whose clouds are assembled, from its part's growth (back by now)
+  auto lines = [&](size_t j) {
+    Velodyne& v = *scans[todo[j]];
+    const Part& part = parts[j / per_batch];
+    pvlm_line_grow_result grown; const pvlm_line_grow_result* pre = nullptr;
+    const int slot = part.grow && !part.grow_slot.empty() ? part.grow_slot[j % per_batch] : -1;
+    if (slot >= 0 && pvlm_line_grow_scan(part.grow, slot, &grown) == PVLM_OK) { pre = &grown; if (grown.status != 0) ++scans_grown_on_host; }
+    ProfileSpan span(3);
+    v.EdgeToLine(pre);
+  };
+  // first pass over a scan; returns true when its EdgeToLine waits for the part's growth (`lines` runs it)
+  auto pick = [&](size_t j) -> bool {
     Velodyne& v = *scans[todo[j]];
     const Part& part = parts[j / per_batch];
     if (part.on_host) {
       v.ReOrderVLP();
       v.ExtractFeatures(max_curvature, intersect_angle_threshold, method, segment, traces ? &(*traces)[todo[j]] : nullptr, edge_to_line);
-      return;
+      return false;
     }
     ProfileSpan span(0);
     pvlm_ring_result r;
@@ -581,15 +646,22 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
     }
     int begin = 0;
     for (int q = 0; q < rings; ++q) { L.scanStartInd[q] = begin + 5; begin += r.ring_count[q]; L.scanEndInd[q] = begin - 6; }
-    if (n < r.n_reordered * 0.1) { fprintf(stderr, "LiDAR data %d has something wrong\n", v.id); v.valid = false; return; }
-    if (n == 0) return;
+    if (n < r.n_reordered * 0.1) { fprintf(stderr, "LiDAR data %d has something wrong\n", v.id); v.valid = false; return false; }
+    if (n == 0) return false;
     span.Stop();
     bool decided = r.picks != 0;
     for (int q = 0; decided && q < rings; ++q) decided = r.ring_host[q] == 0;
-    if (decided) { v.AssemblePicks(r, traces ? &(*traces)[todo[j]] : nullptr, edge_to_line); return; }
+    if (decided) {
+      // the clouds now; the lines when the part's growth is back (K27 runs beside the next part's range-image stages) — EdgeToLine touches neither the per-point
+      // state nor the planar clouds, so the order of the two does not matter
+      const bool defer = edge_to_line && device_grow;
+      v.AssemblePicks(r, traces ? &(*traces)[todo[j]] : nullptr, edge_to_line && !defer, nullptr);
+      return defer;
+    }
     if (r.picks) ++scans_on_host;                  // a ring the device left undecided (incidence angle at the threshold, bounds): the whole scan is picked here
     v.PickFeatures(max_curvature, intersect_angle_threshold, PickInputs{r.curvature, r.range, nullptr, nullptr, r.half_window, r.sorted, r.sector_host},
                    traces ? &(*traces)[todo[j]] : nullptr, edge_to_line);
+    return false;
   };
   StageTimer stage_timer_picks_("  (inside feature extraction) picks, EdgeToLine, voxel grid (host, scan-parallel)");
   std::atomic<size_t> next{0};
@@ -602,9 +674,38 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
       {
         std::unique_lock<std::mutex> g(gate);
         published_cv.wait(g, [&] { return published > j || production_failed; });
-        if (published <= j) return;
+        if (published <= j) break;
       }
-      try { pick(j); }
+      bool wants_lines = false;
+      try { wants_lines = pick(j); }
+      catch (...) { std::lock_guard<std::mutex> g(failure_lock); if (!failure) failure = std::current_exception(); }
+      bool now = false;
+      {
+        std::lock_guard<std::mutex> g(gate);
+        ++assembled;
+        if (wants_lines) { now = grown_parts > j / per_batch; if (!now) deferred.push_back(j); }
+      }
+      published_cv.notify_all();
+      if (now) {
+        try { lines(j); }
+        catch (...) { std::lock_guard<std::mutex> g(failure_lock); if (!failure) failure = std::current_exception(); }
+      }
+    }
+    // the scans whose growth was not back when their clouds were done
+    for (;;) {
+      size_t j = 0; bool have = false;
+      {
+        std::unique_lock<std::mutex> g(gate);
+        published_cv.wait(g, [&] {
+          if (production_failed) return true;
+          for (size_t q : deferred) if (grown_parts > q / per_batch) return true;
+          return deferred.empty() && assembled >= total;
+        });
+        if (production_failed) return;
+        for (size_t q = 0; q < deferred.size(); ++q) if (grown_parts > deferred[q] / per_batch) { j = deferred[q]; deferred[q] = deferred.back(); deferred.pop_back(); have = true; break; }
+        if (!have) return;                                       // nothing deferred and every scan assembled
+      }
+      try { lines(j); }
       catch (...) { std::lock_guard<std::mutex> g(failure_lock); if (!failure) failure = std::current_exception(); }
     }
   };
@@ -613,6 +714,7 @@ void Velodyne::ExtractFeaturesBatch(const std::vector<Velodyne*>& scans, float m
   if (failure) std::rethrow_exception(failure);
   if (scans_refused.load()) AddStageSeconds("  (inside feature extraction) scans of batches the device refused, extracted scan by scan on the host [count in calls]", 0.0);
   if (Profile().on) fprintf(stderr, "feature_profile scans picked on the host (a ring undecided on the device): %ld of %zu; scans of refused batches: %ld\n", scans_on_host.load(), total, scans_refused.load());
+  if (Profile().on) fprintf(stderr, "feature_profile line growth on the GPU (K27): %.2f ms on the producer (kernels %.2f ms, %lld tasks); scans the device handed back to the host growth: %ld\n", grow_ms, grow_kernel_ms, grow_tasks, scans_grown_on_host.load());
   if (Profile().on) Profile().Report("ExtractFeaturesBatch", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - profile_t0).count(), ring_ms, producer_ms);
 }
 

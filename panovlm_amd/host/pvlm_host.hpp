@@ -163,7 +163,11 @@ class Velodyne {
   // segments grown from the edge points -> edge_segmented / segment_coeffs / end_points / point_to_segment, cornerLessSharp
   // and cornerSharp filtered down to the members of segments.  Upstream's RANSAC line fit of a fused group
   // (pcl::SACSegmentation, :150-160) is replaced by the exhaustive 2-point maximum-consensus line (host/pvlm_lines.cpp).
-  void EdgeToLine();
+  // grown: the growth phase done ahead for this scan's edge points by K27 (pvlm_line_grow_batch: every (start point, neighbour pair) task of the scan grown on the
+  // GPU) — the walk over the start points, the fusion and the filters run here on its segments.  Null (or a result the device gave back, status != 0): the growth
+  // runs here too, segment after segment as upstream.  PVLM_EDGE_GROW=tasks: the host itself grows every task through the kernel's code (csrc/pvlm_linegrow_core.h)
+  // and replays the walk — the CPU check of the task formulation (tests/test_lines_cpu.py).
+  void EdgeToLine(const pvlm_line_grow_result* grown = nullptr);
   // ReOrderVLP + ExtractFeatures for MANY scans: the per-point / per-ring stages (ring and column of every return, range image,
   // Segmentation, adaptive-window curvature — sensors/Velodyne.cpp:371-526, :1438-1586, :623-657), the sector orders, the picks of
   // ExtractEdgeFeatures2 / ExtractPlaneFeatures2 and the pcl::VoxelGrid of the less-flat points (:883-1000, :1098-1189) run on the GPU
@@ -209,7 +213,7 @@ class Velodyne {
   };
   void PickFeatures(float max_curvature, float intersect_angle_threshold, const PickInputs& in, ExtractionTrace* trace, bool edge_to_line);
   // the same from the picks the device made (pvlm_ring_extract_batch_picks, K24): the clouds are assembled ring by ring, EdgeToLine runs here
-  void AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, bool edge_to_line);
+  void AssemblePicks(const pvlm_ring_result& r, ExtractionTrace* trace, bool edge_to_line, const pvlm_line_grow_result* grown = nullptr);
   mutable pvlm_scan* dev_ = nullptr;
 };
 

@@ -19,9 +19,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 
 #include "pvlm_host.hpp"
+#include "../csrc/pvlm_linegrow_core.h"
 
 namespace pvlm {
 namespace {
@@ -272,13 +275,67 @@ void Fuse(Segments& S) {
 
 }  // namespace
 
-void Velodyne::EdgeToLine() {
+// plain-array lists of a task grown on the host through the kernel's code
+struct HostLists {
+  int mm[pvlm_linegrow::kMaxMembers + 1], oo[pvlm_linegrow::kMaxMembers + 1];
+  int& m(int k) { return mm[k]; }
+  int& o(int k) { return oo[k]; }
+};
+
+void Velodyne::EdgeToLine(const pvlm_line_grow_result* grown) {
   edge_segmented.clear(); segment_coeffs.clear(); end_points.clear(); point_to_segment.clear();
   cornerBeforeFilter = cornerLessSharp;
   const PointCloud& E = cornerBeforeFilter;
   const int n = (int)E.size();
   Segments S;
-  if (n > 0) {
+  if (grown && (grown->status != 0 || grown->n_points != n)) grown = nullptr;      // the device handed the scan back: grown here
+  static const bool host_tasks = [] { const char* v = std::getenv("PVLM_EDGE_GROW"); return v && std::strcmp(v, "tasks") == 0; }();
+  // the segments of every (start point, neighbour pair) task, in task order: from K27, or (PVLM_EDGE_GROW=tasks) grown here by the kernel's code
+  pvlm_line_grow_result host_result{};
+  std::vector<int> h_task, h_off, h_members; std::vector<double> h_coeffs;
+  if (n > 0 && !grown && host_tasks) {
+    namespace lg = pvlm_linegrow;
+    const int k = std::min(lg::kK, n);
+    std::vector<int> idx((size_t)n * lg::kK, -1); std::vector<float> sqd((size_t)n * lg::kK, 0.f);
+    for (int q = 0; q < n; ++q) lg::neighbours_of(&E[0].x, 4, n, q, k, &idx[(size_t)q * lg::kK], &sqd[(size_t)q * lg::kK]);
+    const lg::Cloud C{&E[0].x, 4, n, k, idx.data(), sqd.data()};
+    static const lg::Turn turn = lg::turn_thresholds();
+    h_off.push_back(0);
+    bool ok = true;
+    for (int t = 0; t < n * lg::kCombos && ok; ++t) {
+      int a, b; lg::combo(t % lg::kCombos, &a, &b);
+      HostLists w; int count = 0; double coeff[6];
+      const int st = lg::grow_task(C, turn, t / lg::kCombos, a, b, w, &count, coeff);
+      if (st == lg::kOverflow || st == lg::kUndecided) ok = false;
+      if (st != lg::kSegment) continue;
+      h_task.push_back(t);
+      h_members.insert(h_members.end(), w.mm, w.mm + count);
+      h_off.push_back((int)h_members.size());
+      h_coeffs.insert(h_coeffs.end(), coeff, coeff + 6);
+    }
+    if (ok) {
+      host_result.status = 0; host_result.n_points = n; host_result.n_segments = (int)h_task.size();
+      host_result.seg_task = h_task.data(); host_result.seg_offset = h_off.data(); host_result.members = h_members.data(); host_result.coeffs = h_coeffs.data();
+      grown = &host_result;
+    }
+  }
+  if (n > 0 && grown) {
+    // upstream's walk over the start points (LidarLineExtraction.cpp:300-389) on finished segments: a point an earlier segment took is skipped with all its tasks
+    std::vector<char> visited((size_t)n, 0);
+    int q = 0;
+    for (int i = 0; i < n; ++i) {
+      while (q < grown->n_segments && grown->seg_task[q] < i * pvlm_linegrow::kCombos) ++q;
+      if (visited[(size_t)i]) continue;
+      visited[(size_t)i] = 1;
+      for (; q < grown->n_segments && grown->seg_task[q] < (i + 1) * pvlm_linegrow::kCombos; ++q) {
+        PointCloud cloud;
+        for (int k = grown->seg_offset[q]; k < grown->seg_offset[q + 1]; ++k) { const int id = grown->members[k]; visited[(size_t)id] = 1; cloud.push_back(E[(size_t)id]); }
+        S.points.push_back(std::move(cloud));
+        Vector6d c; for (int k = 0; k < 6; ++k) c[(size_t)k] = grown->coeffs[6 * (size_t)q + (size_t)k];
+        S.coeffs.push_back(c);
+      }
+    }
+  } else if (n > 0) {
     std::vector<double> P((size_t)n * 3);
     for (int i = 0; i < n; ++i) { P[3 * (size_t)i] = E[(size_t)i].x; P[3 * (size_t)i + 1] = E[(size_t)i].y; P[3 * (size_t)i + 2] = E[(size_t)i].z; }
     const NeighbourTable nn = BuildNeighbourTable(&E[0].x, 4, n);
@@ -314,6 +371,8 @@ void Velodyne::EdgeToLine() {
           }
         }
     }
+  }
+  if (n > 0) {
     Fuse(S);
     // FilterLineByScan: the points of a line come from >= 3 rings and from at least half as many rings as it has points
     Segments kept;

@@ -49,6 +49,20 @@ def test_host_mirror_equals_oracle(oracle, k, kw):
     assert np.array_equal(p.cornerLessSharp, o.cornerBeforeFilter)
 
 
+@pytest.mark.parametrize("k,kw", SCANS)
+def test_task_formulation_of_the_growth_equals_oracle(oracle, monkeypatch, k, kw):
+    """K27's formulation on the CPU: every (start point, neighbour pair) grown as an independent task by the kernel's own code (csrc/pvlm_linegrow_core.h, compiled
+    for the host: PVLM_EDGE_GROW=tasks), then upstream's walk over the start points replayed on the finished segments — the same segments, coefficients and filtered
+    clouds as the oracle's segment-after-segment growth, bit for bit (incl. the 1-degree turn test decided on the cosine against thresholds taken from this
+    machine's acos)."""
+    monkeypatch.setenv("PVLM_EDGE_GROW", "tasks")
+    raw = sy.raw_vlp16_scan(k, cols=1800, **kw)
+    o = oracle.ScanFeatures(raw, edge_to_line=True)
+    h = host_io.extract_features(raw, edge_to_line=True)
+    assert len(o.edge_segmented) >= 5
+    _same(o, h)
+
+
 def test_degenerate_inputs(oracle):
     """No edge points, fewer edge points than neighbours, a scan without any structure: empty segment lists on both sides."""
     rng = np.random.default_rng(5)
