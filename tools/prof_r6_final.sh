@@ -75,7 +75,13 @@ PY
   python tools/floor_like_odometry.py --scans 1593 --ranks 2,8 --iters 2 --repeat 5 > $O/r6_floor_like_1593.txt 2>&1
   PVLM_HOST_REUPLOAD=1 python tools/floor_like_odometry.py --scans 1593 --ranks 1 --iters 2 --repeat 3 > $O/r6_floor_like_1593_reupload.txt 2>&1
   PVLM_SPD_LEVELS=0 python tools/floor_like_odometry.py --scans 1593 --ranks 1 --iters 2 --repeat 3 > $O/r6_floor_like_1593_column_by_column.txt 2>&1
-  python tools/feature_batch_bench.py 454 32 --ab 2>&1 | cut -c1-300 > $O/r6_feature_batch_454.txt
+  PVLM_NO_PLAN_PREFETCH=1 python tools/floor_like_odometry.py --scans 1593 --ranks 1 --iters 2 --repeat 5 > $O/r6_floor_like_1593_no_plan_prefetch.txt 2>&1
+  python tools/feature_batch_bench.py 454 32 --ab 2>&1 | cut -c1-330 > $O/r6_feature_batch_454.txt
+  # K27 (line growth of the feature batch): kernel statistics of one bench run
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k27_trace -- python $R/tools/feature_batch_bench.py 454 32 > $O/k27_under_rocprof.log 2>&1
+  cp $(find $O/k27_trace -name "*kernel_stats.csv" | head -1) $O/r6_feature_batch_kernel_stats.csv
+  cd $R
   find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 fi
 du -sh $O
