@@ -1052,8 +1052,8 @@ def features_block(ctx, pv, scans=454, cols=1800):
            "scans_with_a_ring_left_to_the_host_sampled": [int(undecided), int(sampled)], "edge_picks_per_scan": corners, "less_flat_centroids_per_scan": centroids,
            "what": "ReOrderVLP + Segmentation + adaptive curvature + sector sort (std::sort's order of equal curvatures restated) + ExtractEdgeFeatures2 / "
                    "ExtractPlaneFeatures2 picks + pcl::VoxelGrid of the less-flat points (sensors/Velodyne.cpp:371-526, :1438-1586, :623-657, :883-1000, :1098-1189); "
-                   "compact_curvature = K21 + K22 + K23 + K24; bit-exact vs the oracle: tests/test_ring_gpu.py.  EdgeToLine stays on the host "
-                   "(tools/feature_batch_bench.py times the whole ExtractFeaturesBatch)"}
+                   "compact_curvature = K21 + K22 + K23 + K24; bit-exact vs the oracle: tests/test_ring_gpu.py.  The line branch (EdgeToLine: growth on the GPU, K27; fusion and "
+                   "filters on the host) is in extract_features_batch below"}
     # roof of the batch: the host link.  The boundary hands over host buffers and takes host arrays back: 16 B per raw point up; down — since round 6 — source index +
     # (ring, column) of every kept point (8 B), 1 B of state and ~2 B of pick lists and centroids; the other five per-point arrays (16 B: curvature, window, range,
     # sector order) only for the scans with a ring K24 left to the host (round 5: always, 43 B per point in all)
@@ -1079,7 +1079,7 @@ def features_block(ctx, pv, scans=454, cols=1800):
 
 def extract_features_batch_block(scans=454, threads=32):
     """The whole Velodyne::ExtractFeaturesBatch of the host mirror (libpvlm_host.so through its test driver, its own process and context): the device batch
-    above + EdgeToLine and the assembly of the clouds on host threads, for a Room-sized batch of raw scans.  Wall of the best of three calls (each starts
+    above + the line branch (growth on the GPU, K27; fusion and filters on the host) and the assembly of the clouds on host threads, for a Room-sized batch of raw scans.  Wall of the best of three calls (each starts
     after a pause: the boxes of this pool cap a process at 16 CPUs per 100 ms) and the thread-milliseconds of the host stages."""
     import re
     import subprocess
@@ -1103,11 +1103,21 @@ def extract_features_batch_block(scans=454, threads=32):
     if prof:
         for name, ms in re.findall(r"\[([^\]]+)\] ([0-9.]+)", prof[-1]):
             stages[name] = float(ms)
+    grow = {}
+    k27 = [l for l in r.stderr.splitlines() if l.startswith("feature_profile line growth on the GPU (K27)")]
+    if k27:
+        m = re.search(r"([0-9.]+) ms on the producer \(kernels ([0-9.]+) ms, ([0-9]+) tasks\); scans the device handed back to the host growth: ([0-9]+)", k27[-1])
+        if m:
+            grow = {"producer_ms": float(m.group(1)), "kernel_ms": float(m.group(2)), "tasks": int(m.group(3)), "scans_handed_back_to_the_host": int(m.group(4)),
+                    "what": "K27 (pvlm_line_grow_begin / _finish): every (start point, neighbour pair) of ExtractLineFeatures grown as a task of its own, a lane each, in rounds "
+                            "of speculative start points with upstream's walk replayed on the device; the growth of device batch k runs beside the range-image stages of "
+                            "batch k + 1.  Round 5 grew on the host threads: EdgeToLine 574 thread-ms per call"}
     return {"scans": scans, "host_threads": threads, "wall_ms_per_call": min(walls[1:] or walls), "wall_ms_all_calls": walls, "host_thread_ms_last_call": stages,
-            "cpu_quota": cpu_quota(),
+            "line_growth_on_the_gpu": grow, "cpu_quota": cpu_quota(),
             "what": "Velodyne::ExtractFeaturesBatch (raw scans -> cloud_scan, cornerSharp / cornerLessSharp, surfFlat / surfLessFlat, line segments): range image, "
-                    "sector orders, picks, voxel grid on the GPU in two overlapped device batches, EdgeToLine on the host; first call includes code-object loading "
-                    "and pinned allocations.  Round 4: 69.7 ms.  Every output equal to the oracle: tests/test_host_gpu.py"}
+                    "sector orders, picks, voxel grid and the growth of the line segments on the GPU in two overlapped device batches; the fusion and the filters of the "
+                    "line branch and the assembly of the clouds on the host threads; first call includes code-object loading and pinned allocations.  Round 4: 69.7 ms, "
+                    "round 5: 33.9 ms with 574 host thread-ms of EdgeToLine.  Every output equal to the oracle: tests/test_host_gpu.py, tests/test_linegrow_gpu.py"}
 
 
 def undistort_block(ctx, pv, scans=454, cols=1800):
