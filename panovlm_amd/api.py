@@ -526,6 +526,20 @@ class Context:
         return [votes[voff[p]:voff[p + 1]].reshape(neis[p].n_segments, refs[p].n_segments) for p in range(n)]
 
 
+    def line2line_best_batch(self, refs, neis, dist_threshold):
+        """pvlm_line2line_best_batch: per pair and neighbour segment (a row of the vote block) the reference segment with the most votes — the first of equals — and
+        that count.  Returns (row_offsets, best_col, best_count); a pair without reference segments has no rows."""
+        n = len(refs)
+        assert len(neis) == n
+        hr = (C.c_void_p * max(n, 1))(*[s._h for s in refs]); hn = (C.c_void_p * max(n, 1))(*[s._h for s in neis])
+        roff = np.zeros(n + 1, np.int64)
+        self._check(self.lib.pvlm_line2line_best_batch(self._h, C.c_int(n), hr, hn, C.c_float(dist_threshold), _p(roff, C.c_int64), None, None, C.c_int64(0)), "pvlm_line2line_best_batch")
+        col = np.zeros(max(int(roff[-1]), 1), np.int32); cnt = np.zeros_like(col)
+        self._check(self.lib.pvlm_line2line_best_batch(self._h, C.c_int(n), hr, hn, C.c_float(dist_threshold), _p(roff, C.c_int64), _p(col, C.c_int32), _p(cnt, C.c_int32),
+                                                       C.c_int64(len(col))), "pvlm_line2line_best_batch")
+        return roff, col[:int(roff[-1])], cnt[:int(roff[-1])]
+
+
 class MvsViews:
     """Resident set of equally sized MVS views (pvlm_mvs_views_*): maps stay on the GPU between the scoring pass, the
     PatchMatch sweeps and the fusion filter."""

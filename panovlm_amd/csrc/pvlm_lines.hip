@@ -70,6 +70,50 @@ __global__ __launch_bounds__(256) void k_line_votes_batch(int n_pairs, const pvl
   for (int k = d.p2s_off[i]; k < d.p2s_off[i + 1]; ++k) atomicAdd(&votes[d.vote_off + (long long)d.p2s_ids[k] * d.n_ref + s], 1);
 }
 
+// The same votes with a thread per (pair, neighbour corner point) that walks the pair's reference segments (round 6; pvlm_line2line_best_batch).  The thread-per-test
+// form above pays per TEST for what belongs to the point or to the pair: a 15-step bisection through the pair offsets (dependent loads), a 64-bit division for
+// (point, segment), the 64-byte descriptor, the point's coordinates and segment list — and a square root the decision does not need: sqrt is monotone and correctly
+// rounded, so dist > thr  <=>  q > T with T = the largest double whose root is still <= thr, found once on the host (q: the squared distance, as upstream sums it).
+// The division inside PointToLineDistance3D stays (its quotient enters q).  334 M tests of a Floor-sized call: 4.5 -> 1.x ms.  Same vote blocks, bit for bit.
+__global__ __launch_bounds__(256) void k_line_votes_points(int n_pairs, const pvlm_line_pair_desc* __restrict__ desc, const long long* __restrict__ pt_off, long long total,
+                                                           const double* __restrict__ lines, double T, int* __restrict__ votes) {
+  __shared__ int s_p0;
+  const long long g0 = (long long)blockIdx.x * 256;
+  if (threadIdx.x == 0) s_p0 = find_pair(pt_off, n_pairs, g0 < total ? g0 : total - 1);
+  __syncthreads();
+  const long long g = g0 + threadIdx.x;
+  if (g >= total) return;
+  int p = s_p0;
+  while (p + 1 < n_pairs && pt_off[p + 1] <= g) ++p;
+  const pvlm_line_pair_desc* d = desc + p;
+  const int i = (int)(g - pt_off[p]);
+  const int* p2s_off = d->p2s_off;
+  const int k0 = p2s_off[i], k1 = p2s_off[i + 1];
+  if (k0 == k1) return;                                            // a point of no segment votes for nothing
+  const float* xyz = d->xyz;
+  const double px = (double)xyz[3 * i], py = (double)xyz[3 * i + 1], pz = (double)xyz[3 * i + 2];
+  const int n_ref = d->n_ref;
+  const double* l = lines + 6 * d->line_off;
+  int* v = votes + d->vote_off;
+  const int* p2s_ids = d->p2s_ids;
+  for (int s = 0; s < n_ref; ++s, l += 6) {
+    const double x0 = l[0], y0 = l[1], z0 = l[2], nx = l[3], ny = l[4], nz = l[5];
+    const double k = (nx * (px - x0) + ny * (py - y0) + nz * (pz - z0)) / (nx * nx + ny * ny + nz * nz);
+    const double qx = k * nx + x0, qy = k * ny + y0, qz = k * nz + z0;
+    const double q = (qx - px) * (qx - px) + (qy - py) * (qy - py) + (qz - pz) * (qz - pz);
+    if (q > T) continue;
+    for (int kk = k0; kk < k1; ++kk) atomicAdd(&v[(long long)p2s_ids[kk] * n_ref + s], 1);
+  }
+}
+// the largest double whose (correctly rounded) square root does not exceed thr
+static double sqrt_threshold(double thr) {
+  if (!(thr >= 0.0)) return -1.0;                                  // dist > thr for every dist >= 0 (and q > -1 for every q >= 0); NaN thr: dist > NaN is false, handled by the caller
+  double x = thr * thr;
+  while (std::sqrt(x) > thr) x = std::nextafter(x, 0.0);
+  while (std::sqrt(std::nextafter(x, INFINITY)) <= thr && std::isfinite(x)) x = std::nextafter(x, INFINITY);
+  return x;
+}
+
 // First statement of FindAssociations (lidar_mapping/LidarFeatureAssociate.cpp:126-133) on the device: per neighbour segment (a row of the pair's
 // vote block) the reference segment with the most votes — the first of equals, as `if (v > max)` keeps it — and that count.  One thread per row;
 // what goes back to the host is 8 bytes per neighbour segment instead of the block (70 MB of blocks for the 11 k pairs of a Floor sequence).
@@ -713,10 +757,11 @@ pvlm_status pvlm_line2line_best_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* con
   if (!ctx || n_pairs < 0 || !row_offsets || (n_pairs > 0 && (!ref || !nei)) || ((best_col == nullptr) != (best_count == nullptr))) return PVLM_ERR_ARG;
   std::vector<pvlm_line_pair_desc> desc((size_t)n_pairs);
   std::vector<pvlm_row_desc> rdesc((size_t)n_pairs);
-  std::vector<long long> work_off((size_t)n_pairs + 1, 0), row_off((size_t)n_pairs + 1, 0);
+  std::vector<long long> work_off((size_t)n_pairs + 1, 0), row_off((size_t)n_pairs + 1, 0), pt_off((size_t)n_pairs + 1, 0);
   std::vector<double> lines;
   std::unordered_map<const pvlm_scan*, long long> line_off_of;
   long long nv = 0;
+  if (best_col) pvlm_i_trace("line2line_best_batch: enter");
   for (int p = 0; p < n_pairs; ++p) {
     if (!ref[p] || !nei[p]) return PVLM_ERR_ARG;
     pvlm_line_pair_desc& d = desc[p];
@@ -737,6 +782,7 @@ pvlm_status pvlm_line2line_best_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* con
     row_off[p + 1] = row_off[p] + (d.n_ref > 0 ? nei[p]->n_segments : 0);     // a pair without reference segments has no rows (FindAssociations: nr > 0)
     nv += (long long)nei[p]->n_segments * ref[p]->n_segments;
     work_off[p + 1] = work_off[p] + (long long)d.n_pts * d.n_ref;
+    pt_off[p + 1] = pt_off[p] + (d.n_ref > 0 ? d.n_pts : 0);
   }
   const long long rows = row_off[n_pairs];
   row_offsets[n_pairs] = rows;
@@ -744,6 +790,7 @@ pvlm_status pvlm_line2line_best_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* con
   if (capacity < rows) { PVLM_SET_ERR(ctx, "pvlm_line2line_best_batch: %lld rows do not fit the capacity %lld", rows, (long long)capacity); return PVLM_ERR_CAPACITY; }
   if (rows == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  pvlm_i_trace("line2line_best_batch: tables built on the host");
   pvlm_line_pair_desc* d_desc = nullptr; pvlm_row_desc* d_rdesc = nullptr; long long *d_work = nullptr, *d_row = nullptr; double* d_lines = nullptr;
   int *d_v = nullptr, *d_col = nullptr, *d_cnt = nullptr;
   pvlm_status st = pvlm_i_alloc(ctx, &d_desc, desc.size());
@@ -757,22 +804,31 @@ pvlm_status pvlm_line2line_best_batch(pvlm_ctx* ctx, int n_pairs, pvlm_scan* con
   if (!st) {
     st = pvlm_i_h2d_q(ctx, d_desc, desc.data(), desc.size() * sizeof(pvlm_line_pair_desc));
     if (!st) st = pvlm_i_h2d_q(ctx, d_rdesc, rdesc.data(), rdesc.size() * sizeof(pvlm_row_desc));
-    if (!st) st = pvlm_i_h2d_q(ctx, d_work, work_off.data(), work_off.size() * sizeof(long long));
+    // PVLM_LINE_VOTES=tests: the thread-per-test kernel of rounds 2-5 (A/B; the same vote blocks)
+    static const bool per_test = getenv("PVLM_LINE_VOTES") && std::strcmp(getenv("PVLM_LINE_VOTES"), "tests") == 0;
+    const double thr = (double)dist_threshold;
+    const bool by_points = !per_test && thr == thr;                 // a NaN threshold: dist > NaN is false for every test — the old kernel says so by itself
+    if (!st) st = pvlm_i_h2d_q(ctx, d_work, by_points ? pt_off.data() : work_off.data(), work_off.size() * sizeof(long long));
     if (!st) st = pvlm_i_h2d_q(ctx, d_row, row_off.data(), row_off.size() * sizeof(long long));
     if (!st && !lines.empty()) st = pvlm_i_h2d_q(ctx, d_lines, lines.data(), lines.size() * sizeof(double));
     hipError_t e = st ? hipSuccess : hipMemsetAsync(d_v, 0, (size_t)std::max<long long>(nv, 1) * sizeof(int), ctx->stream);
     if (!st && e == hipSuccess) {
-      const long long tot = work_off[n_pairs];
-      if (tot > 0)
+      const long long tot = work_off[n_pairs], pts = pt_off[n_pairs];
+      if (by_points) {
+        if (pts > 0)
+          hipLaunchKernelGGL(k_line_votes_points, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, ctx->stream, n_pairs, d_desc, d_work, pts, d_lines, sqrt_threshold(thr), d_v);
+      } else if (tot > 0)
         hipLaunchKernelGGL(k_line_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n_pairs, d_desc, d_work, tot, d_lines, (double)dist_threshold, d_v);
       hipLaunchKernelGGL(k_line_row_best, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, n_pairs, d_rdesc, d_row, rows, d_v, d_col, d_cnt);
       e = hipGetLastError();
     }
     if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_line2line_best_batch: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (getenv("PVLM_TRACE")) { char msg[128]; snprintf(msg, sizeof msg, "line2line_best_batch: %d pairs, %lld votes, %lld tests, %lld rows: queued", n_pairs, nv, work_off[n_pairs], rows); pvlm_i_trace(msg); }
     if (!st) st = pvlm_i_d2h_q(ctx, best_col, d_col, (size_t)rows * sizeof(int));
     if (!st) st = pvlm_i_d2h_q(ctx, best_count, d_cnt, (size_t)rows * sizeof(int));
   }
   { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+  pvlm_i_trace("line2line_best_batch: synchronised");
   pvlm_i_free(ctx, d_desc); pvlm_i_free(ctx, d_rdesc); pvlm_i_free(ctx, d_work); pvlm_i_free(ctx, d_row); pvlm_i_free(ctx, d_lines); pvlm_i_free(ctx, d_v);
   pvlm_i_free(ctx, d_col); pvlm_i_free(ctx, d_cnt);
   return st;

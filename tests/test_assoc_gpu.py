@@ -168,6 +168,20 @@ def test_line2line_votes(ctx, oracle):
     for r, n, g in zip(refs, neis, got):
         assert g.shape == (n.n_segments, r.n_segments) and np.array_equal(g, ctx.line2line_votes(r, n, 0.3))
     assert ctx.line2line_votes_batch([], [], 0.3) == []
+    # the row maxima of the blocks (pvlm_line2line_best_batch; since round 6 its votes come from the thread-per-point kernel, which decides dist > thr on the squared
+    # distance against the largest double whose root does not exceed thr): the arg-max of the blocks above, first of equals, for thresholds on both sides of the data
+    for thr in (0.3, 0.05, 0.4, 0.0, 2.5, float("inf")):
+        blocks = ctx.line2line_votes_batch(refs, neis, thr)
+        roff, col, cnt = ctx.line2line_best_batch(refs, neis, thr)
+        at = 0
+        for p, (r, nb, g) in enumerate(zip(refs, neis, blocks)):
+            assert roff[p] == at
+            if r.n_segments == 0:
+                continue
+            for row in range(nb.n_segments):
+                assert col[at] == int(np.argmax(g[row])) and cnt[at] == int(g[row].max()), (thr, p, row)
+                at += 1
+        assert roff[-1] == at
     da.close(); db.close(); de.close()
 
 
