@@ -1204,12 +1204,15 @@ def panorama_block(ctx, pv, torch, dev, with_votes=True):
     try:
         src = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_k8.json")))[-1]
         pmc = json.load(open(src)); pmc["source"] = "profiles/" + os.path.basename(src)
+        if pmc.get("kernel") != "k_cam_lidar_votes_points":       # counters of the thread-per-test kernel of rounds 2-5: not this kernel's instruction stream
+            pmc = {"source": pmc["source"], "note": "counters of another kernel (%s): no roof derived from them" % pmc.get("kernel")}
     except Exception:
         pmc = {"source": None}
     kernel_ms = k8_ms / max(k8_n, 1)
     roof_k8 = None
     if pmc.get("valu_wave_insts_per_test"):
         peak = PEAKS["valu_wave_insts_per_s"] / pmc["valu_wave_insts_per_test"] / 1e9
+        # (the kernel since round 6: a thread per point walking the pair's lines, k_cam_lidar_votes_points)
         # algorithmic floor of one (line, point) test (joint_optimization/CameraLidarLineAssociate.cpp:394-426): the transformed point is shared by the lines of a
         # pair; per test two plane-side dot products (2 x 5), the range comparison and two angle comparisons against precomputed cosines (2 x 2) + the vote = ~16
         # operations over the 64 lanes of a wave -> 0.25 wave instructions per test at one test per lane

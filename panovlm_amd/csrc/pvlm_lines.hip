@@ -452,6 +452,7 @@ struct pvlm_cam_pair_desc {
   long long vote_off;   // first vote of the pair (n_lines x n_seg block)
   long long work_off;
   double T[12];         // T_cl rows 0..2
+  long long pt_off;     // prefix sum of n_pts (k_cam_lidar_votes_points: a thread per point)
 };
 
 __device__ __forceinline__ void cam_vote_one(const float* __restrict__ xyz_local, const int* __restrict__ p2s_off, const int* __restrict__ p2s_ids,
@@ -485,6 +486,85 @@ __global__ __launch_bounds__(256) void k_cam_lidar_votes_batch(int n_pairs, cons
   const long long l = g - d->work_off;
   const int li = (int)(l / d->n_pts), i = (int)(l - (long long)li * d->n_pts);
   cam_vote_one(d->xyz, d->p2s_off, d->p2s_ids, i, li, line_tab + 8 * (d->tab_off + li), d->T, d->n_seg, angle_thr, votes + d->vote_off);
+}
+
+// K8 with a thread per (pair, corner point) that walks the pair's image lines (round 6).  The thread-per-test form above pays per TEST for what belongs to the point:
+// the bisection through the pair offsets, a 64-bit division, the pair's 3 x 4 transform and the transformed point itself — and takes two arc cosines, two divisions
+// and four square roots to compare two angles with thresholds.  Here the point is transformed once, and an angle is compared with its threshold on squared
+// quantities: angle(a, b) >= t  <=>  a.b / (|a| |b|) <= cos t for 0 < t < pi, decided as sign and (a.b)^2 against cos^2 t |a|^2 |b|^2 whenever the two sides
+// differ by more than 10^-11 of their sum (the rounding of either side is ~10^-15); inside that band, for thresholds within 0.8 degrees of 0 or pi (where acos
+// amplifies the rounding of its argument) and for non-finite input the reference's own chain — VectorAngle3D with its roots, quotient and acos — decides, as in the
+// form above.  cos(scope + threshold) of every table row comes from k_cam_line_cos (NaN outside (0, pi): the exact chain).  Same vote blocks.
+__device__ __forceinline__ int angle_ge_fast(double d, double A2, double B2, double ct) {      // 1: angle >= t, 0: angle < t, -1: undecided
+  if (!(fabs(ct) <= 0.9999)) return -1;
+  const double S = A2 * B2;
+  if (!(S > 0.0) || !(S < 1.0e300) || !(fabs(d) < 1.0e150)) return -1;
+  const double lhs = d * d, rhs = ct * ct * S;
+  if (fabs(lhs - rhs) <= 1.0e-11 * (lhs + rhs)) return -1;
+  if (ct >= 0.0) return d <= 0.0 ? 1 : (lhs < rhs ? 1 : 0);
+  return d >= 0.0 ? 0 : (lhs > rhs ? 1 : 0);
+}
+__global__ __launch_bounds__(256) void k_cam_line_cos(long long n_rows, const double* __restrict__ line_tab, double angle_thr, double* __restrict__ cs) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const double t = line_tab[8 * r + 7] + angle_thr;
+  cs[r] = (t > 0.0 && t < 3.14159265358979323846) ? cos(t) : __longlong_as_double(0x7ff8000000000000ll);
+}
+__device__ __forceinline__ int find_cam_pair(const pvlm_cam_pair_desc* __restrict__ desc, int n_pairs, long long g) {
+  int lo = 0, hi = n_pairs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].pt_off <= g) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void k_cam_lidar_votes_points(int n_pairs, const pvlm_cam_pair_desc* __restrict__ desc, long long total_pts,
+                                                                const double* __restrict__ line_tab, const double* __restrict__ line_cos, double angle_thr, double cos_thr,
+                                                                int* __restrict__ votes) {
+  __shared__ int s_p0;
+  const long long g0 = (long long)blockIdx.x * 256;
+  if (threadIdx.x == 0) s_p0 = find_cam_pair(desc, n_pairs, g0 < total_pts ? g0 : total_pts - 1);
+  __syncthreads();
+  const long long g = g0 + threadIdx.x;
+  if (g >= total_pts) return;
+  int pr = s_p0;
+  while (pr + 1 < n_pairs && desc[pr + 1].pt_off <= g) ++pr;
+  const pvlm_cam_pair_desc* d = desc + pr;
+  const int i = (int)(g - d->pt_off);
+  const int* p2s_off = d->p2s_off;
+  const int k0 = p2s_off[i], k1 = p2s_off[i + 1];
+  if (k0 == k1) return;
+  const float* xyz = d->xyz;
+  const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  const float range = x * x + y * y + z * z;
+  if (range > 15 * 15) return;
+  double p[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    p[r] = (double)(float)(d->T[r * 4] * (double)x + d->T[r * 4 + 1] * (double)y + d->T[r * 4 + 2] * (double)z + d->T[r * 4 + 3]);
+  const double A2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+  const int n_lines = d->n_lines, n_seg = d->n_seg;
+  const double* L = line_tab + 8 * d->tab_off;
+  const double* cs = line_cos + d->tab_off;
+  int* v = votes + d->vote_off;
+  const int* p2s_ids = d->p2s_ids;
+  for (int li = 0; li < n_lines; ++li, L += 8) {
+    const double l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
+    const double dis = fabs(l0 * p[0] + l1 * p[1] + l2 * p[2] + l3);
+    double pp[3] = {p[0] - dis * l0, p[1] - dis * l1, p[2] - dis * l2};
+    if (fabs(l0 * pp[0] + l1 * pp[1] + l2 * pp[2] + l3) > 1e-4) {
+      pp[0] = p[0] + dis * l0; pp[1] = p[1] + dis * l1; pp[2] = p[2] + dis * l2;
+    }
+    const double B2 = pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2];
+    int r1 = angle_ge_fast(p[0] * pp[0] + p[1] * pp[1] + p[2] * pp[2], A2, B2, cos_thr);
+    if (r1 < 0) r1 = vangle(p, pp) >= angle_thr ? 1 : 0;
+    if (r1) continue;                                                  // :419
+    const double q0 = L[4], q1 = L[5], q2 = L[6];
+    int r2 = angle_ge_fast(q0 * pp[0] + q1 * pp[1] + q2 * pp[2], q0 * q0 + q1 * q1 + q2 * q2, B2, cs[li]);
+    if (r2 < 0) r2 = vangle(L + 4, pp) >= L[7] + angle_thr ? 1 : 0;
+    if (r2) continue;                                                  // :422
+    for (int k = k0; k < k1; ++k) atomicAdd(&v[(size_t)li * n_seg + p2s_ids[k]], 1);
+  }
 }
 
 // Sparse read-back of a vote buffer: of the n_lines x n_segments counters of a pair a few per cent are non-zero (43 MB of dense blocks for
@@ -987,6 +1067,7 @@ static bool cam_batch_plan(int n_pairs, const int64_t* line_offsets, pvlm_scan* 
     d.n_lines = (int)(line_offsets[p + 1] - line_offsets[p]); d.n_seg = l->n_segments;
     d.n_pts = (d.n_seg > 0 && d.n_lines > 0) ? l->corner.n : 0;
     d.tab_off = line_offsets[p]; d.vote_off = nv; d.work_off = work_off[p];
+    d.pt_off = p == 0 ? 0 : desc[(size_t)p - 1].pt_off + desc[(size_t)p - 1].n_pts;
     for (int k = 0; k < 12; ++k) d.T[k] = T_cl[(size_t)p * 16 + k];
     vote_offsets[p] = nv;
     nv += (long long)d.n_lines * d.n_seg;
@@ -1011,9 +1092,28 @@ static void cam_line_tables(int rows, int cols, const float* lines, const std::v
   };
   pvlm_run_workers(n_threads, work);
 }
-static void cam_launch(pvlm_ctx* c, int np, const pvlm_cam_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) {
-  pvlm_prof_scope prof(c, 3);
-  hipLaunchKernelGGL(k_cam_lidar_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl, 3.0 / 180.0 * M_PI, dv);
+// n_rows: rows of the (de-duplicated) line table; total_pts: corner points of all pairs.  PVLM_CAM_VOTES=tests: the thread-per-test kernel of rounds 2-5 (A/B).
+struct CamLaunch {
+  long long n_rows = 0, total_pts = 0;
+  void operator()(pvlm_ctx* c, int np, const pvlm_cam_pair_desc* dd, const long long* dw, long long tot, const double* dl, int* dv) const {
+    pvlm_prof_scope prof(c, 3);
+    const double thr = 3.0 / 180.0 * M_PI;
+    const char* mode = getenv("PVLM_CAM_VOTES");
+    double* d_cos = nullptr;
+    if (!(mode && std::strcmp(mode, "tests") == 0) && total_pts > 0 && n_rows > 0 && pvlm_i_alloc(c, &d_cos, (size_t)n_rows) == PVLM_OK) {
+      hipLaunchKernelGGL(k_cam_line_cos, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, n_rows, dl, thr, d_cos);
+      hipLaunchKernelGGL(k_cam_lidar_votes_points, dim3((unsigned)((total_pts + 255) / 256)), dim3(256), 0, c->stream, np, dd, total_pts, dl, (const double*)d_cos, thr, std::cos(thr), dv);
+      pvlm_i_free(c, d_cos);                                           // stream-ordered pool: whoever gets the block next runs behind these launches
+      return;
+    }
+    hipLaunchKernelGGL(k_cam_lidar_votes_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, np, dd, dw, tot, dl, thr, dv);
+  }
+};
+static CamLaunch cam_launcher(const std::vector<pvlm_cam_pair_desc>& desc, const std::vector<double>& tab) {
+  CamLaunch l;
+  l.n_rows = (long long)(tab.size() / 8);
+  l.total_pts = desc.empty() ? 0 : desc.back().pt_off + desc.back().n_pts;
+  return l;
 }
 
 pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,
@@ -1033,7 +1133,7 @@ pvlm_status pvlm_cam_lidar_votes_batch(pvlm_ctx* ctx, int n_pairs, int rows, int
   std::vector<std::pair<long long, long long>> build;
   cam_dedupe_lines(n_pairs, line_offsets, lines, desc, build);
   cam_line_tables(rows, cols, lines, build, tab);
-  return run_vote_batch(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes, cam_launch);
+  return run_vote_batch(ctx, desc, work_off, work_off[n_pairs], tab, nv, votes, cam_launcher(desc, tab));
 }
 
 pvlm_status pvlm_cam_lidar_votes_batch_sparse(pvlm_ctx* ctx, int n_pairs, int rows, int cols, const int64_t* line_offsets, const float* lines,
@@ -1073,7 +1173,7 @@ pvlm_status pvlm_cam_lidar_votes_batch_sparse(pvlm_ctx* ctx, int n_pairs, int ro
     if (!st) st = pvlm_i_h2d_q(ctx, d_tab, tab.data(), tab.size() * sizeof(double));
     hipError_t e = st ? hipSuccess : hipMemsetAsync(d_v, 0, (size_t)nv * sizeof(int), ctx->stream);
     if (!st && e == hipSuccess) {
-      cam_launch(ctx, n_pairs, d_desc, d_work, work_off[n_pairs], d_tab, d_v);
+      cam_launcher(desc, tab)(ctx, n_pairs, d_desc, d_work, work_off[n_pairs], d_tab, d_v);
       hipLaunchKernelGGL(k_votes_count, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, nv, d_v, d_tc);
       e = hipGetLastError();
     }

@@ -100,6 +100,22 @@ def test_cam_lidar_votes(ctx, oracle):
         assert g.shape == (len(l), dscan.n_segments)
         if len(l):
             assert np.array_equal(g, ctx.cam_lidar_votes(rows, cols, l, dscan, Tj))
+    # the thread-per-point kernel of the batch (round 6: angles compared on squared cosines, the reference's acos chain only inside a 10^-11 band) against the
+    # thread-per-test kernel (PVLM_CAM_VOTES=tests: roots, quotient and acos for every test) over many calibrations: the same blocks
+    import os
+    many_jobs = []
+    for k in range(48):
+        Tk = np.eye(4); Tk[:3, :3] = synth.rodrigues(np.deg2rad(rng.uniform(-4, 4, size=3))); Tk[:3, 3] = rng.uniform(-0.2, 0.2, size=3)
+        many_jobs.append((lines[rng.permutation(len(lines))[:rng.integers(1, len(lines) + 1)]], Tk))
+    new_kernel = ctx.cam_lidar_votes_batch(rows, cols, [j[0] for j in many_jobs], [dscan] * len(many_jobs), [j[1] for j in many_jobs])
+    os.environ["PVLM_CAM_VOTES"] = "tests"
+    try:
+        old_kernel = ctx.cam_lidar_votes_batch(rows, cols, [j[0] for j in many_jobs], [dscan] * len(many_jobs), [j[1] for j in many_jobs])
+    finally:
+        del os.environ["PVLM_CAM_VOTES"]
+    assert sum(int(g.sum()) for g in new_kernel) > 500
+    for a_, b_ in zip(new_kernel, old_kernel):
+        assert np.array_equal(a_, b_)
     # sparse read-back of the same launch: the non-zero counters, in dense order
     voff, nzi, nzc = ctx.cam_lidar_votes_batch_sparse(rows, cols, [j[0] for j in jobs], [dscan] * len(jobs), [j[1] for j in jobs])
     dense = np.concatenate([g.reshape(-1) for g in got])

@@ -46,12 +46,13 @@ else
   cd /tmp && export TMPDIR=/tmp
   timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/k8_trace -- python $R/tools/k8_workload.py > $O/k8_trace.log 2>&1
   timeout 300 rocprofv3 --pmc $SQ --output-format csv -d $O/k8_pmc -- python $R/tools/k8_workload.py > $O/k8_pmc.log 2>&1
-  cd $R && python tools/pmc_kernels.py $O/k8_kernels.json '{"k_cam_lidar_votes_batch": 420040800}' $O/k8_trace $O/k8_pmc k_cam_lidar_votes_batch > /dev/null
+  cd $R && python tools/pmc_kernels.py $O/k8_kernels.json '{"k_cam_lidar_votes_points": 420040800}' $O/k8_trace $O/k8_pmc k_cam_lidar_votes_points > /dev/null
   python - $O/k8_kernels.json $O/r6_pmc_k8.json <<'PY'
 import json, sys
-k = [v for n, v in json.load(open(sys.argv[1])).items() if "k_cam_lidar_votes_batch" in n][0]
-out = {"kernel": "k_cam_lidar_votes_batch", "command": "rocprofv3 --pmc <SQ set> -- python tools/k8_workload.py (1 362 pairs + an 8-pair warm-up launch)",
-       "valu_insts_per_wave": k["valu_insts_per_wave"], "valu_wave_insts_per_test": k["valu_insts_per_wave"] / 64.0,
+k = [v for n, v in json.load(open(sys.argv[1])).items() if "k_cam_lidar_votes_points" in n][0]
+out = {"kernel": "k_cam_lidar_votes_points", "command": "rocprofv3 --pmc <SQ set> -- python tools/k8_workload.py (1 362 pairs + an 8-pair warm-up launch)",
+       "valu_insts_per_wave": k["valu_insts_per_wave"], "valu_wave_insts_per_test": k["valu_insts_per_wave"] / (64.0 * 200.0),   # a lane = a point walking the pair's 200 lines
+       "tests_per_wave": 12800,
        "valu_issue_frac": k.get("valu_issue_frac"), "wait_frac": k.get("wait_frac"), "vmem_rd_insts_per_wave": k.get("vmem_rd_insts_per_wave")}
 json.dump(out, open(sys.argv[2], "w"), indent=1); print(out)
 PY
