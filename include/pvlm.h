@@ -287,6 +287,12 @@ pvlm_status pvlm_spd_plan_info(const pvlm_ctx* ctx, int* tile_sparse, double* up
  * PVLM_SPD_LEVELS=0, or a graph whose schedule is not shorter than two thirds of its block columns), *block_columns = block columns of the (padded) system,
  * *padded_rows = its rows.  The reference leaves this to Ceres' SPARSE_SCHUR (util/Optimization.cpp:638-666).  Any pointer may be NULL. */
 pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_columns, int* padded_rows);
+/* The dense TAIL of that schedule.  The last group of the dissection (the top separator) is dense once everything below it is eliminated and every one of its block
+ * columns is a level of its own; from eight such columns on they are factorised by ONE launch instead (a tile Cholesky in 64 x 64 tiles whose workgroups hand the
+ * finished tiles to each other inside the launch; forward substitution inside it, backward substitution in a second launch).  *tail_block_columns = the block columns
+ * done that way (0: none — PVLM_SPD_TAIL=0, no level schedule, or a short separator), *launched_levels = the levels that still run launch by launch.  Bit-reproducible
+ * like the levels; last-bit differences against PVLM_SPD_TAIL=0 (another order of the same sums).  Any pointer may be NULL. */
+pvlm_status pvlm_spd_plan_tail(const pvlm_ctx* ctx, int* tail_block_columns, int* launched_levels);
 
 /* ---- multi-GPU exchange (RCCL over xGMI) -------------------------------------------------------- *
  * The reference is single-process (OpenMP only); sharding scan pairs across GPUs introduces exactly one

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_line_grow_batch", "pvlm_line_grow_begin", "pvlm_line_grow_finish", "pvlm_line_grow_scan", "pvlm_line_grow_destroy", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_tail", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_line_grow_batch", "pvlm_line_grow_begin", "pvlm_line_grow_finish", "pvlm_line_grow_scan", "pvlm_line_grow_destroy", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -329,7 +329,10 @@ class Context:
         ts, lv, bc, pr = C.c_int(), C.c_int(), C.c_int(), C.c_int(); fr = C.c_double()
         self._check(self.lib.pvlm_spd_plan_info(self._h, C.byref(ts), C.byref(fr)), "pvlm_spd_plan_info")
         self._check(self.lib.pvlm_spd_plan_schedule(self._h, C.byref(lv), C.byref(bc), C.byref(pr)), "pvlm_spd_plan_schedule")
-        return dict(tile_sparse=bool(ts.value), update_fraction=fr.value, levels=lv.value, block_columns=bc.value, padded_rows=pr.value)
+        tc, ll = C.c_int(), C.c_int()
+        self._check(self.lib.pvlm_spd_plan_tail(self._h, C.byref(tc), C.byref(ll)), "pvlm_spd_plan_tail")
+        return dict(tile_sparse=bool(ts.value), update_fraction=fr.value, levels=lv.value, block_columns=bc.value, padded_rows=pr.value, tail_block_columns=tc.value,
+                    launched_levels=ll.value)
 
     def mvs_init_conf_map(self, ref_gray, nei_grays, R_nr, t_nr, depth, normal, half_window=3, step=1, conf=None, nei_depths=None):
         """MVS::InitPatchMap + InitConfMap(use_geometry=False) on the GPU: returns (conf, depth, normal) copies."""

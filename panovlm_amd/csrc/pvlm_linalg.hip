@@ -554,6 +554,345 @@ __global__ __launch_bounds__(1024) void k_nd_bwd(const double* __restrict__ M, i
   }
 }
 
+// ---- the dense tail of a level schedule: ONE launch for the top separator ---------------------------------------------------------------------
+// The last group of a nested dissection (the top separator: 247 poses = 1 482 rows of the Floor graph) is dense once everything below it has been
+// eliminated, and every one of its block columns is a level of its own: 46 of the 108 levels, 46 x (panel + update + backward) launches that each wait for the
+// one before (2.1 of the 6.3 ms of kernel time of a solve, profiles/r6_spd_levels_kernel_stats.csv).  k_nd_tail factorises that trailing block as a TILE
+// Cholesky in one launch: a workgroup per 64 x 64 tile (i, j), handed out by a ticket in column-major order (so the lowest unfinished tile always runs — no
+// residency assumption); it subtracts L(i,k) L(j,k)^T for k < j as the tiles of the row panels are PUBLISHED, then
+//   i == j: factorises the 64 x 64 block (two passes of the 32-pivot register chain of chol_diag_panel_body with the rank-32 update between them), inverts it,
+//           publishes the inverse, and forms y_j = L_jj^-1 (b_j - sum_k L(j,k) y_k) — the forward substitution rides along;
+//   i >  j: waits for that inverse, multiplies, publishes L(i,j).
+// The dependent chain is 64 pivots + two hand-offs per 64 columns instead of six launches.  Hand-offs follow cdna_hip_programming.md Guideline 16: payload stored
+// write-through by agent-scope stores, every storing wave drains, ONE lane stores the flag; consumers poll the flag relaxed and read the payload with agent-scope loads.
+// Every sum has a fixed order: the factor is bit-reproducible.  k_nd_tail_bwd is the backward substitution of the same block, a workgroup per tile column.
+typedef __attribute__((address_space(1))) unsigned pvlm_gu32;
+typedef __attribute__((address_space(1))) unsigned long long pvlm_gu64;
+__device__ __forceinline__ double tail_ld(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((pvlm_gu64*)(unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void tail_st(double* p, double v) {
+  __hip_atomic_store((pvlm_gu64*)(unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// thread 0 of the workgroup: waits until *flag != 0; false when the solve has failed elsewhere (info != 0) or nothing came for seconds (info := -1)
+__device__ __forceinline__ bool tail_wait(unsigned* flag, int* info) {
+  unsigned spins = 0;
+  while (__hip_atomic_load((pvlm_gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63u) == 0u) {
+      if (__hip_atomic_load((pvlm_gu32*)(unsigned*)info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if (spins > (1u << 21)) { __hip_atomic_store((pvlm_gu32*)(unsigned*)info, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    }
+  }
+  return true;
+}
+// every storing wave has drained its stores (the caller's __syncthreads() follows the drain); ONE lane raises the flag
+__device__ __forceinline__ void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void tail_raise(unsigned* flag) { __hip_atomic_store((pvlm_gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static size_t tail_flag_words(int T) { return (size_t)2 + (size_t)T * T + 3 * (size_t)T; }
+#define PVLM_TAIL_LD 65     // row stride (doubles) of the 64 x 64 tiles in LDS
+// flags: [0] ticket, [1] ticket of the backward launch, [2 + i * T + j] tile (i, j) published, then T words each: inverse of column j, y_j, x_j
+__global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
+                                                 const double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk) {
+  // clk != nullptr (PVLM_SPD_TAIL_CLOCK=1): 100 MHz wall-clock stamps of the dependent chain, twelve per tile column — the diagonal tile: [0] ticket taken, [1] last
+  // dependency seen, [2] products done, [3] tile in LDS, [4] factor + inverse done, [5] inverse published, [8] first 32 pivots, [9] rank-32 update, [10] last 32
+  // pivots; the tile below it: [6] inverse seen, [7] tile published
+  __shared__ double lds[2 * 64 * PVLM_TAIL_LD];                        // the k loop: As | Bs (64 x 65 each); afterwards As is the tile itself
+  __shared__ double Is[64 * PVLM_TAIL_LD];                             // the inverse of the diagonal block
+  __shared__ double ys[64], vs[64];
+  __shared__ int s_id, s_ok, s_fail;
+  double (*As)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(lds);
+  double (*Bs)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(lds + 64 * PVLM_TAIL_LD);
+  double (*Cs)[PVLM_TAIL_LD] = As;
+  double (*Iv)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(Is);
+  unsigned* tile_flag = flags + 2; unsigned* inv_flag = tile_flag + T * T; unsigned* y_flag = inv_flag + T;
+  const int n_tiles = T * (T + 1) / 2;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 15, lk = lane >> 4;
+  if (*info != 0) return;                                            // a level below has failed
+  for (;;) {
+    __syncthreads();
+    if (t == 0) { s_id = (int)atomicAdd(flags, 1u); s_fail = 0; }
+    __syncthreads();
+    int id = s_id;
+    if (id >= n_tiles) return;
+    int j = 0;
+    while (id >= T - j) { id -= T - j; ++j; }                        // column-major: column j holds the tiles i = j .. T - 1
+    const int i = j + id;
+    const bool diag = i == j;
+    const size_t row_i = (size_t)(r0 + 64 * i), row_j = (size_t)(r0 + 64 * j);
+    const bool stamp = clk && t == 0;
+    if (stamp && diag) clk[12 * j + 0] = wall_clock64();
+    pvlm_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+    double bacc = 0.0;                                               // diagonal tiles, threads 0..63: (sum_k L(j,k) y_k)[t]
+    for (int k = 0; k < j; ++k) {
+      if (t == 0) {
+        bool ok = tail_wait(tile_flag + i * T + k, info);
+        if (ok && !diag) ok = tail_wait(tile_flag + j * T + k, info);
+        if (ok && diag) ok = tail_wait(y_flag + k, info);
+        s_ok = ok ? 1 : 0;
+        if (stamp && diag && k == j - 1) clk[12 * j + 1] = wall_clock64();
+      }
+      __syncthreads();
+      if (!s_ok) return;
+      if (diag && t < 64) ys[t] = tail_ld(yv + r0 + 64 * k + t);
+      {
+        // both tiles whole (64 x 64 each), every load of the step in flight together: the last step of a diagonal tile is on the chain of dependent steps
+        double av[16], bv[16];
+        const size_t col = (size_t)(r0 + 64 * k);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int e = t + 256 * it, r = e >> 6, c = e & 63;
+          av[it] = tail_ld(M + (row_i + r) * n + col + c);
+          if (!diag) bv[it] = tail_ld(M + (row_j + r) * n + col + c);
+        }
+        __syncthreads();                                             // the previous tiles have been consumed (and ys is complete)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int e = t + 256 * it, r = e >> 6, c = e & 63;
+          As[r][c] = av[it];
+          if (!diag) Bs[r][c] = bv[it];
+        }
+        __syncthreads();
+        double (*Bp)[PVLM_TAIL_LD] = diag ? As : Bs;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk += 4) {
+          const double a = As[16 * w + li][kk + lk];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bp[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+        }
+        if (diag && t < 64) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int c = 0; c < 64; ++c) sacc += As[t][c] * ys[c];
+          bacc += sacc;
+        }
+      }
+    }
+    // the tile's own values (written by the launches before this one, or zero) minus the products
+    if (stamp && diag) clk[12 * j + 2] = wall_clock64();
+    double cv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[q][r] = M[(row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li];
+    __syncthreads();                                                 // the last slices have been consumed: lds becomes the tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * w + lk + 4 * r, cc = 16 * q + li;
+        Cs[rr][cc] = (!diag || cc <= rr) ? cv[q][r] - acc[q][r] : 0.0;
+      }
+    if (!diag) {
+      if (t == 0) s_ok = tail_wait(inv_flag + j, info) ? 1 : 0;
+      if (stamp && i == j + 1) clk[12 * j + 6] = wall_clock64();
+      __syncthreads();
+      if (!s_ok) return;
+      double iv[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) iv[it] = tail_ld(inv64 + (size_t)j * 4096 + t + 256 * it);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) { const int e = t + 256 * it; Iv[e >> 6][e & 63] = iv[it]; }
+      __syncthreads();
+      // X = C L_jj^-T: X[r][c] = sum_d C[r][d] inv[c][d]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 64; kk += 4) {
+        const double a = Cs[16 * w + li][kk + lk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Iv[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tail_st(M + (row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li, acc[q][r]);
+      tail_drain();
+      __syncthreads();
+      if (t == 0) tail_raise(tile_flag + i * T + j);
+      if (stamp && i == j + 1) clk[12 * j + 7] = wall_clock64();
+      continue;
+    }
+    // ---- the diagonal tile: Cs (lower triangle, zeros above) -> L and L^-1, 32 columns at a time
+    __syncthreads();
+    if (stamp) clk[12 * j + 3] = wall_clock64();
+#pragma unroll 1
+    for (int blk = 0; blk < 2; ++blk) {
+      if (t < 64) {
+        // lane l keeps row l (blk 0: rows 0..63 — the lanes 32..63 come out as L21, the rows below the block) resp. row 32 + (l & 31) (blk 1) of the
+        // 32 columns of this pass in registers; pivots and column entries cross lanes by v_readlane (see chol_diag_panel_body)
+        const int i32 = t & (PVLM_CHOL_NB - 1);
+        const int row = blk == 0 ? t : PVLM_CHOL_NB + i32;
+        double r[PVLM_CHOL_NB], x[PVLM_CHOL_NB], rdiag[PVLM_CHOL_NB];
+#pragma unroll
+        for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) { r[cc] = Cs[row][PVLM_CHOL_NB * blk + cc]; x[cc] = 0.0; rdiag[cc] = 0.0; }
+        int bad = 0;
+        // kb = 32, but not to the compiler: the branch per step keeps the steps apart — without it the scheduler hoists the 992 v_readlane of the inverse ahead of their
+        // sums, runs out of scalar registers and spills them to vector lanes (916 v_writelane, 1 374 s_nop: 25 us per pass instead of 9)
+        int kb = PVLM_CHOL_NB;
+        asm volatile("" : "+s"(kb));
+#pragma unroll
+        for (int jj = 0; jj < PVLM_CHOL_NB; ++jj) {
+          if (jj < kb && !bad) {
+            const double d = bcast_f64(r[jj], jj);
+            if (!(d > 0.0)) bad = jj + 1;
+            else {
+              double y = __builtin_amdgcn_rsq(d);
+              y = y * (1.5 - 0.5 * d * y * y);
+              y = y * (1.5 - 0.5 * d * y * y);
+              y = y * (1.5 - 0.5 * d * y * y);
+              rdiag[jj] = y;
+              const double lij = r[jj] * y;
+#pragma unroll
+              for (int cc = jj + 1; cc < PVLM_CHOL_NB; ++cc) r[cc] -= lij * bcast_f64(lij, cc);
+              r[jj] = lij;
+            }
+          }
+        }
+        if (bad) { if (t == 0) s_fail = PVLM_CHOL_NB * blk + bad; }
+        else {
+#pragma unroll
+          for (int q = 0; q < PVLM_CHOL_NB; ++q) {
+            if (q < kb) {
+              double sacc = 0.0;
+#pragma unroll
+              for (int k2 = 0; k2 < q; ++k2) sacc += bcast_f64(r[k2], q) * x[k2];
+              const double rq = rdiag[q];
+              x[q] = q == i32 ? rq : (q > i32 ? -sacc * rq : 0.0);
+            }
+          }
+          // L back into the tile (blk 0: rows 0..63 of the left half; blk 1: rows 32..63 of the right half), the inverse of the 32 x 32 block into Iv's diagonal blocks
+          if (blk == 0 || t < PVLM_CHOL_NB) {
+#pragma unroll
+            for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) Cs[row][PVLM_CHOL_NB * blk + cc] = (blk == 0 ? (t >= PVLM_CHOL_NB || cc <= t) : cc <= i32) ? r[cc] : 0.0;
+          }
+          if (t < PVLM_CHOL_NB) {
+#pragma unroll
+            for (int q = 0; q < PVLM_CHOL_NB; ++q) Iv[PVLM_CHOL_NB * blk + q][PVLM_CHOL_NB * blk + i32] = x[q];
+          }
+        }
+      }
+      __syncthreads();
+      if (stamp) clk[12 * j + 8 + 2 * blk] = wall_clock64();
+      if (s_fail) break;
+      if (blk == 0) {
+        // A22 -= L21 L21^T (lower triangle): a 16 x 16 block per wave on the matrix core
+        const int bm = w >> 1, bn = w & 1;
+        pvlm_d4 c4 = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < PVLM_CHOL_NB; kk += 4)
+          c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cs[PVLM_CHOL_NB + 16 * bm + li][kk + lk], Cs[PVLM_CHOL_NB + 16 * bn + li][kk + lk], c4, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * bm + lk + 4 * r, bcol = 16 * bn + li;
+          if (bcol <= a) Cs[PVLM_CHOL_NB + a][PVLM_CHOL_NB + bcol] -= c4[r];
+        }
+        __syncthreads();
+        if (stamp) clk[12 * j + 9] = wall_clock64();
+      }
+    }
+    if (s_fail) { if (t == 0) atomicCAS(info, 0, r0 + 64 * j + s_fail); return; }
+    {
+      // inv21 = -inv22 (L21 inv11), a 16 x 16 block per wave on the matrix core: tmp = L21 inv11 into the upper right quarter of Cs (free: zeros above the diagonal),
+      // then the product into Iv's lower left quarter.  (As loops of 32 over LDS per thread the two products took 9.7 us of the 34 of a diagonal tile.)
+      const int bm = w >> 1, bn = w & 1;
+      pvlm_d4 c4 = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < PVLM_CHOL_NB; kk += 4)
+        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cs[PVLM_CHOL_NB + 16 * bm + li][kk + lk], Iv[kk + lk][16 * bn + li], c4, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[16 * bm + lk + 4 * r][PVLM_CHOL_NB + 16 * bn + li] = c4[r];
+      __syncthreads();
+      c4 = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < PVLM_CHOL_NB; kk += 4)
+        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[PVLM_CHOL_NB + 16 * bm + li][PVLM_CHOL_NB + kk + lk], Cs[kk + lk][PVLM_CHOL_NB + 16 * bn + li], c4, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { Iv[PVLM_CHOL_NB + 16 * bm + lk + 4 * r][16 * bn + li] = -c4[r]; Iv[16 * bm + lk + 4 * r][PVLM_CHOL_NB + 16 * bn + li] = 0.0; }
+      // the upper triangles of the two diagonal blocks of Iv: lane c of the chain wrote x[q] = 0 for q < c — complete
+      __syncthreads();
+    }
+    if (stamp) clk[12 * j + 4] = wall_clock64();
+    // publish the inverse
+#pragma unroll
+    for (int it = 0; it < 16; ++it) { const int e = t + 256 * it; tail_st(inv64 + (size_t)j * 4096 + e, Iv[e >> 6][e & 63]); }
+    tail_drain();
+    __syncthreads();
+    if (t == 0) tail_raise(inv_flag + j);
+    if (stamp) clk[12 * j + 5] = wall_clock64();
+    // y_j = L_jj^-1 (b_j - sum_k L(j,k) y_k)
+    if (t < 64) vs[t] = b[r0 + 64 * j + t] - bacc;
+    __syncthreads();
+    if (t < 64) {
+      double sacc = 0.0;
+      for (int d = 0; d <= t; ++d) sacc += Iv[t][d] * vs[d];
+      tail_st(yv + r0 + 64 * j + t, sacc);
+    }
+    tail_drain();
+    __syncthreads();
+    if (t == 0) tail_raise(y_flag + j);
+  }
+}
+
+// Backward substitution of the tail: x_j = L_jj^-T (y_j - sum_{i > j} L(i,j)^T x_i), a workgroup per tile column (ticket order: j descending), the tile of the next
+// i on its way while the workgroup waits for x_i.  x goes into b (where k_nd_bwd of the levels below gathers it).
+__global__ __launch_bounds__(256) void k_nd_tail_bwd(const double* __restrict__ M, int n, int r0, int T, const double* __restrict__ inv64, unsigned* __restrict__ flags,
+                                                     int* __restrict__ info, double* __restrict__ b, const double* __restrict__ yv) {
+  __shared__ double Is[64 * PVLM_TAIL_LD];
+  __shared__ double xs[64], part[4][64], vs[64];
+  __shared__ int s_id, s_ok;
+  double (*Iv)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(Is);
+  unsigned* x_flag = flags + 2 + T * T + 2 * T;
+  const int t = threadIdx.x, c = t & 63, rg = t >> 6;
+  if (*info != 0) return;
+  if (t == 0) s_id = (int)atomicAdd(flags + 1, 1u);
+  __syncthreads();
+  if (s_id >= T) return;
+  const int j = T - 1 - s_id;
+  const size_t col_j = (size_t)(r0 + 64 * j);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) { const int e = t + 256 * it; Iv[e >> 6][e & 63] = inv64[(size_t)j * 4096 + e]; }
+  double acc = 0.0;
+  double m[16], mn[16];
+  if (j < T - 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mn[q] = M[((size_t)(r0 + 64 * (T - 1)) + 16 * rg + q) * n + col_j + c];
+  }
+  for (int i = T - 1; i > j; --i) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m[q] = mn[q];
+    if (i - 1 > j) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) mn[q] = M[((size_t)(r0 + 64 * (i - 1)) + 16 * rg + q) * n + col_j + c];
+    }
+    if (t == 0) s_ok = tail_wait(x_flag + i, info) ? 1 : 0;
+    __syncthreads();
+    if (!s_ok) return;
+    if (t < 64) xs[t] = tail_ld(b + r0 + 64 * i + t);
+    __syncthreads();
+    double sacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sacc += m[q] * xs[16 * rg + q];
+    acc += sacc;
+    __syncthreads();                                                 // xs is read: the next round may overwrite it
+  }
+  part[rg][c] = acc;
+  __syncthreads();
+  if (t < 64) vs[t] = yv[col_j + t] - (((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]);
+  __syncthreads();
+  if (t < 64) {
+    double sacc = 0.0;
+    for (int d = t; d < 64; ++d) sacc += Iv[d][t] * vs[d];
+    tail_st(b + col_j + t, sacc);
+  }
+  tail_drain();
+  __syncthreads();
+  if (t == 0) tail_raise(x_flag + j);
+}
+
 // ---- triangular solves with the factor (single right-hand side), one launch per block column ------------------------
 // forward step k: y_k = Linv_k b_k (every workgroup recomputes the 32-vector, workgroup 0 stores it in yv), then
 // b[i] -= L[i, k] . y_k for the rows below.  yv is a separate vector so that no workgroup reads what another one writes.
@@ -781,6 +1120,9 @@ struct SpdPlan {
   std::vector<int> col_off, pwg_off, pwt_off, upd_off, fwd_off;       // levels + 1 each (host)
   int* d_cols = nullptr; int* d_row_off = nullptr; int2* d_pwg = nullptr; int2* d_pwt = nullptr; NdTarget* d_targets = nullptr; int* d_sources = nullptr;
   NdRowTarget* d_ftargets = nullptr; int* d_fsources = nullptr;
+  // the dense tail (k_nd_tail): levels n_main .. n_levels - 1 = the rows tail_r0 .. n_pad - 1 (tail_T 64-row tiles); 0 tiles: every level by its launches
+  int n_main = 0, tail_r0 = 0, tail_T = 0;
+  double* d_tail_inv = nullptr; unsigned* d_tail_flags = nullptr;
 };
 
 static unsigned long long spd_hash(int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror) {
@@ -842,6 +1184,7 @@ static void spd_plan_free(pvlm_ctx* ctx, SpdPlan* p) {
   pvlm_i_free(ctx, p->d_row_tiles); pvlm_i_free(ctx, p->d_pairs);
   pvlm_i_free(ctx, p->d_cols); pvlm_i_free(ctx, p->d_row_off); pvlm_i_free(ctx, p->d_pwg); pvlm_i_free(ctx, p->d_pwt); pvlm_i_free(ctx, p->d_targets); pvlm_i_free(ctx, p->d_sources);
   pvlm_i_free(ctx, p->d_ftargets); pvlm_i_free(ctx, p->d_fsources);
+  pvlm_i_free(ctx, p->d_tail_inv); pvlm_i_free(ctx, p->d_tail_flags);
   delete p;
 }
 void pvlm_i_spd_plan_release(pvlm_ctx* ctx) { spd_prefetch_drop(ctx); spd_plan_free(ctx, static_cast<SpdPlan*>(ctx->spd_plan)); ctx->spd_plan = nullptr; }
@@ -879,6 +1222,17 @@ static pvlm_status spd_plan_adopt(pvlm_ctx* ctx, int n, SpdHostPlan& H, SpdPlan*
     P->new_of_old.swap(L.new_of_old); P->col_off.swap(L.col_off); P->pwg_off.swap(L.pwg_off); P->pwt_off.swap(L.pwt_off); P->upd_off.swap(L.upd_off); P->fwd_off.swap(L.fwd_off);
     P->n_pad = L.n_pad; P->n_levels = L.levels;
     P->levels = true; P->sparse = true;
+    P->n_main = L.levels; P->tail_T = 0;
+    static const bool want_tail = !(getenv("PVLM_SPD_TAIL") && atoi(getenv("PVLM_SPD_TAIL")) == 0);
+    if (want_tail && L.tail_col0 < L.cols_total) {
+      const int r0 = L.tail_col0 * PVLM_CHOL_NB, T = (L.n_pad - r0) / 64;
+      if (T >= 2 && T <= 1024 && r0 % 64 == 0) {
+        st = pvlm_i_alloc_bytes(ctx, (void**)&P->d_tail_inv, (size_t)T * 4096 * sizeof(double));
+        if (!st) st = pvlm_i_alloc_bytes(ctx, (void**)&P->d_tail_flags, tail_flag_words(T) * sizeof(unsigned));
+        if (st) return st;
+        P->n_main = L.main_levels; P->tail_r0 = r0; P->tail_T = T;
+      }
+    }
     return PVLM_OK;
   }
   pvlm_spd::Symbolic& S = H.S;
@@ -893,7 +1247,9 @@ static pvlm_status spd_plan_adopt(pvlm_ctx* ctx, int n, SpdHostPlan& H, SpdPlan*
 
 static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* d_b, double* d_Linv, double* d_y, int* d_info, const SpdPlan* P) {
   hipStream_t s = ctx->stream;
-  for (int l = 0; l < P->n_levels; ++l) {
+  const int n_main = P->tail_T > 0 ? P->n_main : P->n_levels;
+  if (P->tail_T > 0) (void)hipMemsetAsync(P->d_tail_flags, 0, tail_flag_words(P->tail_T) * sizeof(unsigned), s);     // ahead of the levels: not between two dependent launches
+  for (int l = 0; l < n_main; ++l) {
     const int npw = P->pwg_off[(size_t)l + 1] - P->pwg_off[(size_t)l], ntg = P->upd_off[(size_t)l + 1] - P->upd_off[(size_t)l], nft = P->fwd_off[(size_t)l + 1] - P->fwd_off[(size_t)l];
     // eight-row workgroups while they fit the device in about one round (256 CUs x 8 resident workgroups), whole tiles beyond
     const int npt = P->pwt_off[(size_t)l + 1] - P->pwt_off[(size_t)l];
@@ -907,7 +1263,29 @@ static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* 
       hipLaunchKernelGGL(k_nd_update, dim3((unsigned)(ntg + nft)), dim3(256), 0, s, d_M, n, (const int*)d_info, (const NdTarget*)P->d_targets + P->upd_off[(size_t)l], ntg,
                          (const int*)P->d_sources, (const NdRowTarget*)P->d_ftargets + P->fwd_off[(size_t)l], (const int*)P->d_fsources, d_b, (const double*)d_y);
   }
-  for (int l = P->n_levels - 1; l >= 0; --l) {
+  if (P->tail_T > 0) {
+    const int T = P->tail_T, n_tiles = T * (T + 1) / 2;
+    static const bool want_clock = getenv("PVLM_SPD_TAIL_CLOCK") && atoi(getenv("PVLM_SPD_TAIL_CLOCK")) != 0;
+    unsigned long long* d_clk = nullptr;
+    if (want_clock && pvlm_i_alloc_bytes(ctx, (void**)&d_clk, (size_t)T * 12 * sizeof(unsigned long long)) != PVLM_OK) d_clk = nullptr;
+    if (d_clk) (void)hipMemsetAsync(d_clk, 0, (size_t)T * 12 * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_nd_tail, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), 0, s, d_M, n, P->tail_r0, T, P->d_tail_inv, P->d_tail_flags, d_info, (const double*)d_b, d_y, d_clk);
+    hipLaunchKernelGGL(k_nd_tail_bwd, dim3((unsigned)T), dim3(256), 0, s, (const double*)d_M, n, P->tail_r0, T, (const double*)P->d_tail_inv, P->d_tail_flags, d_info, d_b, (const double*)d_y);
+    if (d_clk) {
+      std::vector<unsigned long long> c((size_t)T * 12);
+      if (hipMemcpyAsync(c.data(), d_clk, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+        const unsigned long long t0 = c[0];
+        fprintf(stderr, "k_nd_tail clocks (us from the first ticket): col | ticket dep-seen products tile-in-LDS factored published | below: inverse-seen published\n");
+        for (int j = 0; j < T; ++j) {
+          fprintf(stderr, "%3d |", j);
+          for (int q = 0; q < 12; ++q) { const unsigned long long v = c[(size_t)12 * j + q]; if (q == 6) fprintf(stderr, " |"); if (v) fprintf(stderr, " %8.2f", (double)(long long)(v - t0) * 0.01); else fprintf(stderr, "        -"); }
+          fprintf(stderr, "\n");
+        }
+      }
+      pvlm_i_free(ctx, d_clk);
+    }
+  }
+  for (int l = n_main - 1; l >= 0; --l) {
     const int nc = P->col_off[(size_t)l + 1] - P->col_off[(size_t)l];
     if (nc > 0)
       hipLaunchKernelGGL(k_nd_bwd, dim3((unsigned)nc), dim3(1024), 0, s, (const double*)d_M, n, (const double*)d_Linv, d_b, (const double*)d_y, (const int*)d_info,
@@ -1087,6 +1465,15 @@ pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_
   if (levels) *levels = lv ? p->n_levels : 0;
   if (block_columns) *block_columns = lv ? p->n_pad / PVLM_CHOL_NB : (p ? (p->n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB : 0);
   if (padded_rows) *padded_rows = lv ? p->n_pad : (p ? p->n : 0);
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_spd_plan_tail(const pvlm_ctx* ctx, int* tail_block_columns, int* launched_levels) {
+  if (!ctx) return PVLM_ERR_ARG;
+  const SpdPlan* p = static_cast<const SpdPlan*>(ctx->spd_plan);
+  const bool lv = p && p->levels, tl = lv && p->tail_T > 0;
+  if (tail_block_columns) *tail_block_columns = tl ? p->tail_T * (64 / PVLM_CHOL_NB) : 0;
+  if (launched_levels) *launched_levels = tl ? p->n_main : (lv ? p->n_levels : 0);
   return PVLM_OK;
 }
 

@@ -178,7 +178,21 @@ struct LevelPlan {
   long long tile_updates = 0;
   double update_fraction = 1.0;
   bool ordered = false;
+  // the dense tail (k_nd_tail): the levels main_levels .. levels - 1 hold exactly the block columns tail_col0 .. cols_total - 1, one per level in ascending order,
+  // tail_col0 on a 64-row tile — the top separator, factorised by one launch instead of level by level.  No tail: tail_col0 = cols_total, main_levels = levels.
+  int tail_col0 = 0, main_levels = 0;
 };
+
+// The longest run of one-column levels at the end of a schedule whose columns are the last ones of the matrix in ascending order, cut to a 64-row tile boundary
+// (per_tile = block columns per 64-row tile); fewer than min_cols columns: no tail.
+inline void plan_tail(const std::vector<int>& col_off, const std::vector<int>& cols, int cols_total, int per_tile, int min_cols, int* tail_col0, int* main_levels) {
+  const int L = (int)col_off.size() - 1;
+  int l = L, c = cols_total;
+  while (l > 0 && col_off[(size_t)l] - col_off[(size_t)l - 1] == 1 && cols[(size_t)col_off[(size_t)l - 1]] == c - 1) { --l; --c; }
+  while (c < cols_total && c % per_tile != 0) { ++c; ++l; }
+  if (cols_total - c < min_cols) { c = cols_total; l = L; }
+  *tail_col0 = c; *main_levels = l;
+}
 
 inline void plan_levels(int n, int n_blocks, const int* row_idx, const int* col_idx, int NB, int leaf_nodes, LevelPlan* P) {
 #ifdef PVLM_PLAN_PROFILE
@@ -378,6 +392,7 @@ inline void plan_levels(int n, int n_blocks, const int* row_idx, const int* col_
     P->pwg_off.push_back((int)P->pwg.size()); P->pwt_off.push_back((int)P->pwt.size()); P->upd_off.push_back((int)P->targets.size()); P->fwd_off.push_back((int)P->ftargets.size());
   }
   mark("schedule lists");
+  plan_tail(P->col_off, P->cols, C, per_tile, 8, &P->tail_col0, &P->main_levels);
   P->ordered = true;
 }
 

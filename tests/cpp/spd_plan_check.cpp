@@ -40,4 +40,13 @@ int chk_spd_levels(int n, int n_blocks, const int* row_idx, const int* col_idx, 
   return P.ordered ? 1 : 0;
 }
 
+// the dense tail of a level plan (pvlm_spd::plan_tail with the given minimum number of columns; plan_levels itself asks for 8): out[0] = tail_col0, out[1] = main_levels,
+// out[2] / out[3] = what plan_levels stored
+void chk_spd_tail(int n, int n_blocks, const int* row_idx, const int* col_idx, int nb, int leaf, int min_cols, int* out) {
+  pvlm_spd::LevelPlan P;
+  pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, nb, leaf, &P);
+  pvlm_spd::plan_tail(P.col_off, P.cols, P.cols_total, 64 / nb, min_cols, &out[0], &out[1]);
+  out[2] = P.tail_col0; out[3] = P.main_levels;
+}
+
 }  // extern "C"

@@ -193,6 +193,49 @@ def test_nested_dissection_level_schedule(shape, P):
     assert np.abs(x - x_old).max() <= 1e-11 * max(1.0, np.abs(x_old).max())
 
 
+@pytest.mark.parametrize("P,degree", [(700, 9), (1100, 14)])
+def test_dense_tail_of_the_level_schedule(P, degree):
+    """k_nd_tail / k_nd_tail_bwd: the top separator of the dissection — dense, a level per block column — factorised by ONE launch (tile Cholesky, workgroups handing
+    tiles to each other inside the launch) and back-substituted by a second.  Same solution as numpy and as the launch-per-level path (PVLM_SPD_TAIL=0, child process);
+    repeated solves give the same bits whatever the order the workgroups ran in; a pivot that fails INSIDE the tail (the last unknowns of the order) is reported and
+    nobody hangs waiting for its tile."""
+    import panovlm_amd as pv
+    rng = np.random.default_rng(P + degree)
+    pairs = _proximity_pairs(rng, P, degree)
+    n, rows, cols, mirror, blocks, scale, diag, rhs, M = _block_system(rng, P, pairs, constant={(0, 0), (0, 1), (9, 1)})
+    ctx = pv.Context(0)
+    x, info = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    plan = ctx.spd_plan()
+    assert plan["levels"] > 0 and plan["tail_block_columns"] >= 8 and plan["tail_block_columns"] % 2 == 0, plan
+    assert plan["launched_levels"] + plan["tail_block_columns"] == plan["levels"], plan
+    want = np.linalg.solve(M, rhs)
+    assert info == 0 and np.allclose(x, want, rtol=1e-9, atol=1e-12)
+    for _ in range(5):
+        x2, info2 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+        assert info2 == 0 and np.array_equal(x, x2)
+    # not positive definite in every unknown in turn would take long: the last pose of every tenth of the order, which includes the tail's
+    hit_tail = 0
+    for q in range(0, n, max(1, n // 12)):
+        diag_bad = diag.copy(); diag_bad[q] = -1e7
+        _, info_bad = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag_bad, rhs)
+        assert info_bad != 0, q
+        hit_tail += int(info_bad > plan["padded_rows"] - 32 * plan["tail_block_columns"])
+    assert hit_tail >= 1, "none of the broken diagonals fell into the tail: choose other unknowns"
+    x3, info3 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)      # and the context is as good as before
+    assert info3 == 0 and np.array_equal(x, x3)
+    ctx.close()
+    import pickle, subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        pickle.dump((n, rows, cols, mirror, blocks, scale, diag, rhs), open(os.path.join(d, "sys.pkl"), "wb"))
+        code = ("import pickle, sys, numpy as np; sys.path.insert(0, %r); import panovlm_amd as pv; a = pickle.load(open(%r, 'rb')); ctx = pv.Context(0); "
+                "x, info = ctx.spd_solve_blocks(*a); p = ctx.spd_plan(); pickle.dump((x, info, p), open(%r, 'wb'))") % (host_io.ROOT, os.path.join(d, "sys.pkl"), os.path.join(d, "out.pkl"))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVLM_SPD_TAIL="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        x_lv, info_lv, plan_lv = pickle.load(open(os.path.join(d, "out.pkl"), "rb"))
+    assert info_lv == 0 and plan_lv["tail_block_columns"] == 0 and plan_lv["launched_levels"] == plan_lv["levels"] == plan["levels"]
+    assert np.abs(x - x_lv).max() <= 1e-11 * max(1.0, np.abs(x_lv).max())
+
+
 def test_plan_prefetch_is_a_hint_never_a_change_of_result():
     """pvlm_spd_plan_prefetch: the host half of the plan made on a thread of the library ahead of the solve.  Same lists: the solve takes it (hit counted) and returns the
     bits of a solve that planned for itself; other lists: the prefetch is dropped, the solve plans for itself; a second prefetch replaces the first; a context may end

@@ -127,7 +127,7 @@ def levels_plan(lib, n, rows, cols, leaf=8):
     return A
 
 
-def solve_by_levels(P, M, rhs):
+def solve_by_levels(P, M, rhs, tail=None):
     """The arithmetic of chol_factor_solve_levels (csrc/pvlm_linalg.hip) in numpy, with EXACTLY the plan's lists and the launch structure of the device: every
     launch reads a snapshot of what the launches before it left (a job that needed a result of its own launch would read stale data here, as it would race there),
     touches only the tiles the lists name, masks as the kernels mask."""
@@ -136,7 +136,8 @@ def solve_by_levels(P, M, rhs):
     A[np.ix_(nw, nw)] = M; b[nw] = rhs
     A = np.tril(A)
     Linv = {}; y = np.zeros(n_pad)
-    for l in range(P["levels"]):
+    n_main = P["levels"] if tail is None else tail[1]
+    for l in range(n_main):
         snap = A.copy(); bsnap = b.copy()
         seen = set()
         for k, g in P["pwg"][P["pwg_off"][l]:P["pwg_off"][l + 1]]:
@@ -173,7 +174,33 @@ def solve_by_levels(P, M, rhs):
                 k0, base = k * NB, (k + 1) * NB
                 b[r] -= (snap[np.ix_(r, np.arange(k0, base))] @ y[k0:base]) * (r >= base)
     x = b.copy()
-    for l in range(P["levels"] - 1, -1, -1):
+    if tail is not None:
+        # k_nd_tail / k_nd_tail_bwd: the rows from the tail's first column on are ONE dense block — tile Cholesky in 64 x 64 tiles, column by column, the forward
+        # substitution with it, then the backward substitution by tile columns in descending order
+        r0 = tail[0] * NB; T = (n_pad - r0) // TILE
+        assert r0 % TILE == 0 and T >= 1
+        inv = {}
+        sl = lambda q: slice(r0 + q * TILE, r0 + (q + 1) * TILE)
+        for j in range(T):
+            for i in range(j, T):
+                C = A[sl(i), sl(j)].copy()
+                for k in range(j):
+                    C -= A[sl(i), sl(k)] @ A[sl(j), sl(k)].T
+                if i == j:
+                    C = np.tril(C) + np.tril(C, -1).T
+                    inv[j] = np.linalg.inv(np.linalg.cholesky(C))
+                    acc = np.zeros(TILE)
+                    for k in range(j):
+                        acc += A[sl(j), sl(k)] @ y[sl(k)]
+                    y[sl(j)] = inv[j] @ (b[sl(j)] - acc)
+                else:
+                    A[sl(i), sl(j)] = C @ inv[j].T
+        for j in range(T - 1, -1, -1):
+            v = y[sl(j)].copy()
+            for i in range(T - 1, j, -1):
+                v -= A[sl(i), sl(j)].T @ x[sl(i)]
+            x[sl(j)] = inv[j].T @ v
+    for l in range(n_main - 1, -1, -1):
         xs = x.copy()
         for k in P["cols"][P["col_off"][l]:P["col_off"][l + 1]]:
             k0, base = k * NB, (k + 1) * NB
@@ -224,3 +251,22 @@ def test_level_schedule_solves_the_system_with_its_own_lists(chk, shape):
     assert np.abs(x - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
     if shape in ("chain", "proximity", "chain_with_loops"):
         assert plan_["levels"] < 0.75 * plan_["block_cols"], (plan_["levels"], plan_["block_cols"])      # the schedule is shorter than the column-by-column chain
+    # the dense tail (pvlm_spd::plan_tail): the last levels hold one column each, the last columns of the matrix in ascending order from a 64-row tile on; the
+    # same system solved with those levels replaced by the tile Cholesky of the trailing block
+    out = np.zeros(4, np.int32)
+    r32 = np.ascontiguousarray(rows, np.int32); c32 = np.ascontiguousarray(cols, np.int32)
+    chk.chk_spd_tail(n, len(r32) // 6, _p(r32, ctypes.c_int), _p(c32, ctypes.c_int), NB, 6, 2, _p(out, ctypes.c_int))
+    col0, n_main = int(out[0]), int(out[1])
+    C_, L_ = plan_["block_cols"], plan_["levels"]
+    assert 0 <= col0 <= C_ and (C_ - col0) == (L_ - n_main)
+    if out[2] < C_:
+        assert C_ - out[2] >= 8 and out[2] >= col0                   # what plan_levels keeps: the same run, from eight columns on
+    if col0 < C_:
+        assert col0 % (TILE // NB) == 0
+        for q, l in enumerate(range(n_main, L_)):
+            assert plan_["cols"][plan_["col_off"][l]:plan_["col_off"][l + 1]].tolist() == [col0 + q]
+        assert all(plan_["cols"][q] < col0 for q in range(plan_["col_off"][n_main]))
+        x_t, _ = solve_by_levels(plan_, M, rhs, tail=(col0, n_main))
+        assert np.abs(x_t - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    if shape in ("proximity", "chain_with_loops"):
+        assert col0 < C_, "a separator of several block columns at the top of the dissection"
