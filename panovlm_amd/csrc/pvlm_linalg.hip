@@ -593,8 +593,14 @@ __device__ __forceinline__ void tail_raise(unsigned* flag) { __hip_atomic_store(
 static size_t tail_flag_words(int T) { return (size_t)2 + (size_t)T * T + 3 * (size_t)T; }
 #define PVLM_TAIL_LD 65     // row stride (doubles) of the 64 x 64 tiles in LDS
 // flags: [0] ticket, [1] ticket of the backward launch, [2 + i * T + j] tile (i, j) published, then T words each: inverse of column j, y_j, x_j
-__global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
-                                                 const double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk) {
+// LISTS (k_nd_flow): the WHOLE factorisation in this form — the tiles are the tasks of pvlm_spd::plan_flow (tile row, tile column, sources = the earlier tile columns
+// that hold both tiles, with the tasks that publish them), r0 = 0, T = tile columns of the padded system; tile flags are indexed by task.
+struct NdFlowTask { int I, J, src_off, n_src; };
+struct NdFlowSource { int K, task_a, task_b, pad; };
+template <bool LISTS>
+__device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
+                                             const double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk,
+                                             const NdFlowTask* __restrict__ tasks, const NdFlowSource* __restrict__ sources, int n_tasks) {
   // clk != nullptr (PVLM_SPD_TAIL_CLOCK=1): 100 MHz wall-clock stamps of the dependent chain, twelve per tile column — the diagonal tile: [0] ticket taken, [1] last
   // dependency seen, [2] products done, [3] tile in LDS, [4] factor + inverse done, [5] inverse published, [8] first 32 pivots, [9] rank-32 update, [10] last 32
   // pivots; the tile below it: [6] inverse seen, [7] tile published
@@ -606,8 +612,8 @@ __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, 
   double (*Bs)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(lds + 64 * PVLM_TAIL_LD);
   double (*Cs)[PVLM_TAIL_LD] = As;
   double (*Iv)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(Is);
-  unsigned* tile_flag = flags + 2; unsigned* inv_flag = tile_flag + T * T; unsigned* y_flag = inv_flag + T;
-  const int n_tiles = T * (T + 1) / 2;
+  unsigned* tile_flag = flags + 2; unsigned* inv_flag = tile_flag + (LISTS ? n_tasks : T * T); unsigned* y_flag = inv_flag + T;
+  const int n_tiles = LISTS ? n_tasks : T * (T + 1) / 2;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 15, lk = lane >> 4;
   if (*info != 0) return;                                            // a level below has failed
   for (;;) {
@@ -616,9 +622,14 @@ __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, 
     __syncthreads();
     int id = s_id;
     if (id >= n_tiles) return;
-    int j = 0;
-    while (id >= T - j) { id -= T - j; ++j; }                        // column-major: column j holds the tiles i = j .. T - 1
-    const int i = j + id;
+    int i, j, n_src, src_off = 0;
+    if (LISTS) { const NdFlowTask tk = tasks[id]; i = tk.I; j = tk.J; n_src = tk.n_src; src_off = tk.src_off; }
+    else {
+      j = 0;
+      while (id >= T - j) { id -= T - j; ++j; }                      // column-major: column j holds the tiles i = j .. T - 1
+      i = j + id; n_src = j;
+    }
+    const int my_flag = LISTS ? s_id : i * T + j;
     const bool diag = i == j;
     const size_t row_i = (size_t)(r0 + 64 * i), row_j = (size_t)(r0 + 64 * j);
     const bool stamp = clk && t == 0;
@@ -627,13 +638,15 @@ __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
     double bacc = 0.0;                                               // diagonal tiles, threads 0..63: (sum_k L(j,k) y_k)[t]
-    for (int k = 0; k < j; ++k) {
+    for (int q_src = 0; q_src < n_src; ++q_src) {
+      int k = q_src, flag_a = i * T + q_src, flag_b = j * T + q_src;
+      if (LISTS) { const NdFlowSource sr = sources[src_off + q_src]; k = sr.K; flag_a = sr.task_a; flag_b = sr.task_b; }
       if (t == 0) {
-        bool ok = tail_wait(tile_flag + i * T + k, info);
-        if (ok && !diag) ok = tail_wait(tile_flag + j * T + k, info);
+        bool ok = tail_wait(tile_flag + flag_a, info);
+        if (ok && !diag) ok = tail_wait(tile_flag + flag_b, info);
         if (ok && diag) ok = tail_wait(y_flag + k, info);
         s_ok = ok ? 1 : 0;
-        if (stamp && diag && k == j - 1) clk[12 * j + 1] = wall_clock64();
+        if (stamp && diag && q_src == n_src - 1) clk[12 * j + 1] = wall_clock64();
       }
       __syncthreads();
       if (!s_ok) return;
@@ -712,7 +725,7 @@ __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, 
         for (int r = 0; r < 4; ++r) tail_st(M + (row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li, acc[q][r]);
       tail_drain();
       __syncthreads();
-      if (t == 0) tail_raise(tile_flag + i * T + j);
+      if (t == 0) tail_raise(tile_flag + my_flag);
       if (stamp && i == j + 1) clk[12 * j + 7] = wall_clock64();
       continue;
     }
@@ -836,37 +849,55 @@ __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, 
     if (t == 0) tail_raise(y_flag + j);
   }
 }
+__global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
+                                                 const double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk) {
+  nd_tile_flow<false>(M, n, r0, T, inv64, flags, info, b, yv, clk, nullptr, nullptr, 0);
+}
+__global__ __launch_bounds__(256) void k_nd_flow(double* __restrict__ M, int n, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
+                                                 const double* __restrict__ b, double* __restrict__ yv, const NdFlowTask* __restrict__ tasks,
+                                                 const NdFlowSource* __restrict__ sources, int n_tasks) {
+  nd_tile_flow<true>(M, n, 0, T, inv64, flags, info, b, yv, nullptr, tasks, sources, n_tasks);
+}
 
 // Backward substitution of the tail: x_j = L_jj^-T (y_j - sum_{i > j} L(i,j)^T x_i), a workgroup per tile column (ticket order: j descending), the tile of the next
 // i on its way while the workgroup waits for x_i.  x goes into b (where k_nd_bwd of the levels below gathers it).
-__global__ __launch_bounds__(256) void k_nd_tail_bwd(const double* __restrict__ M, int n, int r0, int T, const double* __restrict__ inv64, unsigned* __restrict__ flags,
-                                                     int* __restrict__ info, double* __restrict__ b, const double* __restrict__ yv) {
+template <bool LISTS>
+__device__ __forceinline__ void nd_tile_bwd(const double* __restrict__ M, int n, int r0, int T, const double* __restrict__ inv64, unsigned* __restrict__ flags, int n_tile_flags,
+                                            int* __restrict__ info, double* __restrict__ b, const double* __restrict__ yv, const int* __restrict__ col_order,
+                                            const int* __restrict__ below_off, const int* __restrict__ below) {
   __shared__ double Is[64 * PVLM_TAIL_LD];
   __shared__ double xs[64], part[4][64], vs[64];
   __shared__ int s_id, s_ok;
   double (*Iv)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(Is);
-  unsigned* x_flag = flags + 2 + T * T + 2 * T;
+  unsigned* x_flag = flags + 2 + n_tile_flags + 2 * T;
   const int t = threadIdx.x, c = t & 63, rg = t >> 6;
   if (*info != 0) return;
   if (t == 0) s_id = (int)atomicAdd(flags + 1, 1u);
   __syncthreads();
   if (s_id >= T) return;
-  const int j = T - 1 - s_id;
+  const int j = LISTS ? col_order[T - 1 - s_id] : T - 1 - s_id;
+  // the tile rows below the diagonal, walked from the last to the first: rows[q], q = n_below - 1 .. 0
+  const int* rows = LISTS ? below + below_off[j] : nullptr;
+  const int n_below = LISTS ? below_off[j + 1] - below_off[j] : T - 1 - j;
+  auto row_at = [&](int q) { return LISTS ? rows[q] : j + 1 + q; };
   const size_t col_j = (size_t)(r0 + 64 * j);
 #pragma unroll
   for (int it = 0; it < 16; ++it) { const int e = t + 256 * it; Iv[e >> 6][e & 63] = inv64[(size_t)j * 4096 + e]; }
   double acc = 0.0;
   double m[16], mn[16];
-  if (j < T - 1) {
+  if (n_below > 0) {
+    const int i0 = row_at(n_below - 1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) mn[q] = M[((size_t)(r0 + 64 * (T - 1)) + 16 * rg + q) * n + col_j + c];
+    for (int q = 0; q < 16; ++q) mn[q] = M[((size_t)(r0 + 64 * i0) + 16 * rg + q) * n + col_j + c];
   }
-  for (int i = T - 1; i > j; --i) {
+  for (int qi = n_below - 1; qi >= 0; --qi) {
+    const int i = row_at(qi);
 #pragma unroll
     for (int q = 0; q < 16; ++q) m[q] = mn[q];
-    if (i - 1 > j) {
+    if (qi > 0) {
+      const int i1 = row_at(qi - 1);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) mn[q] = M[((size_t)(r0 + 64 * (i - 1)) + 16 * rg + q) * n + col_j + c];
+      for (int q = 0; q < 16; ++q) mn[q] = M[((size_t)(r0 + 64 * i1) + 16 * rg + q) * n + col_j + c];
     }
     if (t == 0) s_ok = tail_wait(x_flag + i, info) ? 1 : 0;
     __syncthreads();
@@ -891,6 +922,16 @@ __global__ __launch_bounds__(256) void k_nd_tail_bwd(const double* __restrict__ 
   tail_drain();
   __syncthreads();
   if (t == 0) tail_raise(x_flag + j);
+}
+__global__ __launch_bounds__(256) void k_nd_tail_bwd(const double* __restrict__ M, int n, int r0, int T, const double* __restrict__ inv64, unsigned* __restrict__ flags,
+                                                     int* __restrict__ info, double* __restrict__ b, const double* __restrict__ yv) {
+  nd_tile_bwd<false>(M, n, r0, T, inv64, flags, T * T, info, b, yv, nullptr, nullptr, nullptr);
+}
+// the whole backward substitution (k_nd_flow's factor): tile columns in the reverse of the task order, the tile rows of a column from its list
+__global__ __launch_bounds__(256) void k_nd_flow_bwd(const double* __restrict__ M, int n, int T, const double* __restrict__ inv64, unsigned* __restrict__ flags, int n_tasks,
+                                                     int* __restrict__ info, double* __restrict__ b, const double* __restrict__ yv, const int* __restrict__ col_order,
+                                                     const int* __restrict__ below_off, const int* __restrict__ below) {
+  nd_tile_bwd<true>(M, n, 0, T, inv64, flags, n_tasks, info, b, yv, col_order, below_off, below);
 }
 
 // ---- triangular solves with the factor (single right-hand side), one launch per block column ------------------------
@@ -1123,6 +1164,9 @@ struct SpdPlan {
   // the dense tail (k_nd_tail): levels n_main .. n_levels - 1 = the rows tail_r0 .. n_pad - 1 (tail_T 64-row tiles); 0 tiles: every level by its launches
   int n_main = 0, tail_r0 = 0, tail_T = 0;
   double* d_tail_inv = nullptr; unsigned* d_tail_flags = nullptr;
+  // the whole factorisation as the tasks of one launch (k_nd_flow / k_nd_flow_bwd, pvlm_spd::plan_flow); flow_T = 0: levels (+ tail)
+  int flow_T = 0, flow_tasks = 0, flow_depth = 0;
+  NdFlowTask* d_flow_tasks = nullptr; NdFlowSource* d_flow_sources = nullptr; int* d_flow_cols = nullptr; int* d_flow_below_off = nullptr; int* d_flow_below = nullptr;
 };
 
 static unsigned long long spd_hash(int n, int n_blocks, const int* row_idx, const int* col_idx, const int* mirror) {
@@ -1185,6 +1229,7 @@ static void spd_plan_free(pvlm_ctx* ctx, SpdPlan* p) {
   pvlm_i_free(ctx, p->d_cols); pvlm_i_free(ctx, p->d_row_off); pvlm_i_free(ctx, p->d_pwg); pvlm_i_free(ctx, p->d_pwt); pvlm_i_free(ctx, p->d_targets); pvlm_i_free(ctx, p->d_sources);
   pvlm_i_free(ctx, p->d_ftargets); pvlm_i_free(ctx, p->d_fsources);
   pvlm_i_free(ctx, p->d_tail_inv); pvlm_i_free(ctx, p->d_tail_flags);
+  pvlm_i_free(ctx, p->d_flow_tasks); pvlm_i_free(ctx, p->d_flow_sources); pvlm_i_free(ctx, p->d_flow_cols); pvlm_i_free(ctx, p->d_flow_below_off); pvlm_i_free(ctx, p->d_flow_below);
   delete p;
 }
 void pvlm_i_spd_plan_release(pvlm_ctx* ctx) { spd_prefetch_drop(ctx); spd_plan_free(ctx, static_cast<SpdPlan*>(ctx->spd_plan)); ctx->spd_plan = nullptr; }
@@ -1223,6 +1268,23 @@ static pvlm_status spd_plan_adopt(pvlm_ctx* ctx, int n, SpdHostPlan& H, SpdPlan*
     P->n_pad = L.n_pad; P->n_levels = L.levels;
     P->levels = true; P->sparse = true;
     P->n_main = L.levels; P->tail_T = 0;
+    // one launch for the whole factorisation (PVLM_SPD_FLOW=0: the level launches, with the dense tail below)
+    static const bool want_flow = !(getenv("PVLM_SPD_FLOW") && atoi(getenv("PVLM_SPD_FLOW")) == 0);
+    static_assert(sizeof(pvlm_spd::FlowTask) == sizeof(NdFlowTask) && sizeof(pvlm_spd::FlowSource) == sizeof(NdFlowSource), "flow lists are uploaded as they are");
+    if (want_flow && L.flow.ready && L.flow.tile_cols >= 2 && L.flow.tile_cols <= 4096) {
+      const pvlm_spd::FlowPlan& F = L.flow;
+      up((void**)&P->d_flow_tasks, F.tasks.data(), F.tasks.size() * sizeof(NdFlowTask));
+      up((void**)&P->d_flow_sources, F.sources.data(), F.sources.size() * sizeof(NdFlowSource));
+      up((void**)&P->d_flow_cols, F.col_order.data(), F.col_order.size() * sizeof(int));
+      up((void**)&P->d_flow_below_off, F.below_off.data(), F.below_off.size() * sizeof(int));
+      up((void**)&P->d_flow_below, F.below.data(), F.below.size() * sizeof(int));
+      if (!st) st = pvlm_i_alloc_bytes(ctx, (void**)&P->d_tail_inv, (size_t)F.tile_cols * 4096 * sizeof(double));
+      if (!st) st = pvlm_i_alloc_bytes(ctx, (void**)&P->d_tail_flags, ((size_t)2 + F.tasks.size() + 3 * (size_t)F.tile_cols) * sizeof(unsigned));
+      if (!st) st = pvlm_i_sync(ctx);
+      if (st) return st;
+      P->flow_T = F.tile_cols; P->flow_tasks = (int)F.tasks.size(); P->flow_depth = F.depth;
+      return PVLM_OK;
+    }
     static const bool want_tail = !(getenv("PVLM_SPD_TAIL") && atoi(getenv("PVLM_SPD_TAIL")) == 0);
     if (want_tail && L.tail_col0 < L.cols_total) {
       const int r0 = L.tail_col0 * PVLM_CHOL_NB, T = (L.n_pad - r0) / 64;
@@ -1247,6 +1309,15 @@ static pvlm_status spd_plan_adopt(pvlm_ctx* ctx, int n, SpdHostPlan& H, SpdPlan*
 
 static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* d_b, double* d_Linv, double* d_y, int* d_info, const SpdPlan* P) {
   hipStream_t s = ctx->stream;
+  if (P->flow_T > 0) {
+    const int T = P->flow_T;
+    (void)hipMemsetAsync(P->d_tail_flags, 0, ((size_t)2 + (size_t)P->flow_tasks + 3 * (size_t)T) * sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_nd_flow, dim3((unsigned)std::min(P->flow_tasks, 1024)), dim3(256), 0, s, d_M, n, T, P->d_tail_inv, P->d_tail_flags, d_info, (const double*)d_b, d_y,
+                       (const NdFlowTask*)P->d_flow_tasks, (const NdFlowSource*)P->d_flow_sources, P->flow_tasks);
+    hipLaunchKernelGGL(k_nd_flow_bwd, dim3((unsigned)T), dim3(256), 0, s, (const double*)d_M, n, T, (const double*)P->d_tail_inv, P->d_tail_flags, P->flow_tasks, d_info, d_b,
+                       (const double*)d_y, (const int*)P->d_flow_cols, (const int*)P->d_flow_below_off, (const int*)P->d_flow_below);
+    return;
+  }
   const int n_main = P->tail_T > 0 ? P->n_main : P->n_levels;
   if (P->tail_T > 0) (void)hipMemsetAsync(P->d_tail_flags, 0, tail_flag_words(P->tail_T) * sizeof(unsigned), s);     // ahead of the levels: not between two dependent launches
   for (int l = 0; l < n_main; ++l) {
@@ -1471,9 +1542,9 @@ pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_
 pvlm_status pvlm_spd_plan_tail(const pvlm_ctx* ctx, int* tail_block_columns, int* launched_levels) {
   if (!ctx) return PVLM_ERR_ARG;
   const SpdPlan* p = static_cast<const SpdPlan*>(ctx->spd_plan);
-  const bool lv = p && p->levels, tl = lv && p->tail_T > 0;
-  if (tail_block_columns) *tail_block_columns = tl ? p->tail_T * (64 / PVLM_CHOL_NB) : 0;
-  if (launched_levels) *launched_levels = tl ? p->n_main : (lv ? p->n_levels : 0);
+  const bool lv = p && p->levels, tl = lv && p->tail_T > 0, fl = lv && p->flow_T > 0;
+  if (tail_block_columns) *tail_block_columns = fl ? p->flow_T * (64 / PVLM_CHOL_NB) : tl ? p->tail_T * (64 / PVLM_CHOL_NB) : 0;
+  if (launched_levels) *launched_levels = fl ? 0 : tl ? p->n_main : (lv ? p->n_levels : 0);
   return PVLM_OK;
 }
 

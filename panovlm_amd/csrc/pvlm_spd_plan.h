@@ -152,6 +152,80 @@ inline void plan_symbolic(int n, int n_blocks, const int* row_idx, const int* co
 }
 
 
+// ---- the factorisation as ONE launch (k_nd_flow): tasks handed from workgroup to workgroup inside the launch --------------------------------------------------------
+// The level schedule still costs three dependent launches per level (46 levels + the tail on the Floor graph, ~90 us each: 4.2 of the 6.2 ms of a solve), and a level is
+// as slow as its slowest launch ramp although most of its tiles were ready long before.  plan_flow restates the same symbolic factorisation at 64 x 64 TILE granularity
+// as a list of TASKS: task (I, J) = tile row I of tile column J; it subtracts L(I,K) L(J,K)^T for every earlier tile column K that holds both tiles (its sources, in
+// ascending elimination order), then factorises (I == J) or multiplies by the inverse of the diagonal tile (I > J).  Tasks are ordered by the dependency depth of
+// their column, then column, diagonal first — every task depends only on tasks before it, so workgroups that take tasks in this order by a ticket can always finish
+// the lowest unfinished one (no residency assumption).  The backward substitution walks the columns in reverse order.
+struct FlowTask { int I, J, src_off, n_src; };
+struct FlowSource { int K, task_a, task_b, pad; };           // tile column K; the tasks that publish L(I,K) and L(J,K)
+struct FlowPlan {
+  int tile_cols = 0, depth = 0;                               // 64-wide tile columns; dependent tile columns on the longest chain
+  std::vector<FlowTask> tasks;
+  std::vector<FlowSource> sources;
+  std::vector<int> col_order;                                 // tile columns in task order
+  std::vector<int> below_off, below;                          // per tile column (tile_cols + 1, indexed by COLUMN): its tile rows below the diagonal, ascending
+  bool ready = false;
+};
+
+// row_off / row_tiles: the panel tiles of every NB-column block column, as plan_levels leaves them (tiles that reach below the block, the block's own tile included
+// for the first half of a tile column)
+inline void plan_flow(int n_pad, int NB, const std::vector<int>& row_off, const std::vector<int>& row_tiles, FlowPlan* F) {
+  *F = FlowPlan();
+  const int per_tile = 64 / NB, TC = n_pad / 64;
+  if (TC <= 0 || n_pad % 64 != 0 || (int)row_off.size() != TC * per_tile + 1) return;
+  F->tile_cols = TC;
+  F->below_off.assign(1, 0);
+  std::vector<unsigned char> mark((size_t)TC, 0);
+  for (int J = 0; J < TC; ++J) {
+    const size_t first = F->below.size();
+    for (int k = per_tile * J; k < per_tile * (J + 1); ++k)
+      for (int q = row_off[(size_t)k]; q < row_off[(size_t)k + 1]; ++q) { const int t = row_tiles[(size_t)q]; if (t > J && t < TC && !mark[(size_t)t]) { mark[(size_t)t] = 1; F->below.push_back(t); } }
+    std::sort(F->below.begin() + (long)first, F->below.end());
+    for (size_t q = first; q < F->below.size(); ++q) mark[(size_t)F->below[q]] = 0;
+    F->below_off.push_back((int)F->below.size());
+  }
+  // dependency depth of the tile columns, their order
+  std::vector<int> lev((size_t)TC, 0);
+  for (int K = 0; K < TC; ++K) for (int q = F->below_off[(size_t)K]; q < F->below_off[(size_t)K + 1]; ++q) { int& l = lev[(size_t)F->below[(size_t)q]]; l = std::max(l, lev[(size_t)K] + 1); }
+  F->col_order.resize((size_t)TC);
+  for (int J = 0; J < TC; ++J) { F->col_order[(size_t)J] = J; F->depth = std::max(F->depth, lev[(size_t)J] + 1); }
+  std::stable_sort(F->col_order.begin(), F->col_order.end(), [&](int a, int b) { return lev[(size_t)a] < lev[(size_t)b]; });
+  // tasks, column by column in that order; first task of column J = its diagonal tile
+  std::vector<int> first_task((size_t)TC, 0);
+  for (int J : F->col_order) {
+    first_task[(size_t)J] = (int)F->tasks.size();
+    F->tasks.push_back(FlowTask{J, J, 0, 0});
+    for (int q = F->below_off[(size_t)J]; q < F->below_off[(size_t)J + 1]; ++q) F->tasks.push_back(FlowTask{F->below[(size_t)q], J, 0, 0});
+  }
+  // task of tile (I, J): position of I in the column's list (binary search)
+  auto task_of = [&](int I, int J) {
+    if (I == J) return first_task[(size_t)J];
+    const int* b = F->below.data() + F->below_off[(size_t)J]; const int* e = F->below.data() + F->below_off[(size_t)J + 1];
+    const int* it = std::lower_bound(b, e, I);
+    return (it != e && *it == I) ? first_task[(size_t)J] + 1 + (int)(it - b) : -1;
+  };
+  // sources: two passes over the columns in ascending order (count, fill) — ascending K inside every task
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) { int off = 0; for (FlowTask& t : F->tasks) { t.src_off = off; off += t.n_src; t.n_src = 0; } F->sources.assign((size_t)off, FlowSource{0, 0, 0, 0}); }
+    for (int K = 0; K < TC; ++K) {
+      const int* b = F->below.data() + F->below_off[(size_t)K]; const int nb = F->below_off[(size_t)K + 1] - F->below_off[(size_t)K];
+      for (int c = 0; c < nb; ++c)
+        for (int a = c; a < nb; ++a) {
+          const int id = task_of(b[a], b[c]);
+          if (id < 0) return;                                   // a fill the symbolic factorisation did not mark: not ready (never seen; checked by the CPU test)
+          FlowTask& t = F->tasks[(size_t)id];
+          if (pass == 1) F->sources[(size_t)(t.src_off + t.n_src)] = FlowSource{K, first_task[(size_t)K] + 1 + a, first_task[(size_t)K] + 1 + c, 0};
+          ++t.n_src;
+        }
+    }
+  }
+  F->ready = true;
+}
+
+
 // ---- nested dissection + level schedule (round 6) -----------------------------------------------------------------------------------------------
 // plan_symbolic above orders by minimum degree and factorises block column after block column: on the Floor pose graph (1 593 poses, every pose tied to
 // ~20 others all along the trajectory — the scans of a room seen again and again) its 299 block columns form a dependency chain of 293 (every 64-row
@@ -181,6 +255,7 @@ struct LevelPlan {
   // the dense tail (k_nd_tail): the levels main_levels .. levels - 1 hold exactly the block columns tail_col0 .. cols_total - 1, one per level in ascending order,
   // tail_col0 on a 64-row tile — the top separator, factorised by one launch instead of level by level.  No tail: tail_col0 = cols_total, main_levels = levels.
   int tail_col0 = 0, main_levels = 0;
+  FlowPlan flow;                                        // the same factorisation as tasks of one launch (plan_flow)
 };
 
 // The longest run of one-column levels at the end of a schedule whose columns are the last ones of the matrix in ascending order, cut to a 64-row tile boundary
@@ -393,6 +468,8 @@ inline void plan_levels(int n, int n_blocks, const int* row_idx, const int* col_
   }
   mark("schedule lists");
   plan_tail(P->col_off, P->cols, C, per_tile, 8, &P->tail_col0, &P->main_levels);
+  plan_flow(n_pad, NB, P->row_off, P->row_tiles, &P->flow);
+  mark("flow tasks");
   P->ordered = true;
 }
 

@@ -193,12 +193,25 @@ def test_nested_dissection_level_schedule(shape, P):
     assert np.abs(x - x_old).max() <= 1e-11 * max(1.0, np.abs(x_old).max())
 
 
+def _solve_in_child(args, env):
+    import pickle, subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        pickle.dump(args, open(os.path.join(d, "sys.pkl"), "wb"))
+        code = ("import pickle, sys, numpy as np; sys.path.insert(0, %r); import panovlm_amd as pv; a = pickle.load(open(%r, 'rb')); ctx = pv.Context(0); "
+                "x, info = ctx.spd_solve_blocks(*a); x2, _ = ctx.spd_solve_blocks(*a); p = ctx.spd_plan(); pickle.dump((x, info, p, bool(np.array_equal(x, x2))), open(%r, 'wb'))") % (
+                    host_io.ROOT, os.path.join(d, "sys.pkl"), os.path.join(d, "out.pkl"))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return pickle.load(open(os.path.join(d, "out.pkl"), "rb"))
+
+
 @pytest.mark.parametrize("P,degree", [(700, 9), (1100, 14)])
-def test_dense_tail_of_the_level_schedule(P, degree):
-    """k_nd_tail / k_nd_tail_bwd: the top separator of the dissection — dense, a level per block column — factorised by ONE launch (tile Cholesky, workgroups handing
-    tiles to each other inside the launch) and back-substituted by a second.  Same solution as numpy and as the launch-per-level path (PVLM_SPD_TAIL=0, child process);
-    repeated solves give the same bits whatever the order the workgroups ran in; a pivot that fails INSIDE the tail (the last unknowns of the order) is reported and
-    nobody hangs waiting for its tile."""
+def test_factorisation_in_one_launch_and_the_dense_tail(P, degree):
+    """k_nd_flow / k_nd_flow_bwd (the default from 1500 unknowns on): the whole tile-sparse factorisation as the tasks of ONE launch (pvlm_spd::plan_flow — a task per
+    tile of the factor, workgroups take them in dependency order by a ticket and hand finished tiles to each other inside the launch), the backward substitution as a
+    second.  PVLM_SPD_FLOW=0: the level launches with the dense TAIL (k_nd_tail: the top separator, a level per block column, in one launch); PVLM_SPD_TAIL=0 as well:
+    every level by its launches.  Same solution from all three and numpy; repeated solves give the same bits whatever order the workgroups ran in; a pivot that fails
+    anywhere — the last unknowns of the order, inside the tail, included — is reported and nobody hangs waiting for its tile."""
     import panovlm_amd as pv
     rng = np.random.default_rng(P + degree)
     pairs = _proximity_pairs(rng, P, degree)
@@ -206,34 +219,34 @@ def test_dense_tail_of_the_level_schedule(P, degree):
     ctx = pv.Context(0)
     x, info = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
     plan = ctx.spd_plan()
-    assert plan["levels"] > 0 and plan["tail_block_columns"] >= 8 and plan["tail_block_columns"] % 2 == 0, plan
-    assert plan["launched_levels"] + plan["tail_block_columns"] == plan["levels"], plan
+    assert plan["levels"] > 0 and plan["tail_block_columns"] == plan["block_columns"] and plan["launched_levels"] == 0, plan
     want = np.linalg.solve(M, rhs)
     assert info == 0 and np.allclose(x, want, rtol=1e-9, atol=1e-12)
     for _ in range(5):
         x2, info2 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
         assert info2 == 0 and np.array_equal(x, x2)
-    # not positive definite in every unknown in turn would take long: the last pose of every tenth of the order, which includes the tail's
-    hit_tail = 0
-    for q in range(0, n, max(1, n // 12)):
+    last = 0
+    for q in list(range(0, n, max(1, n // 12))) + [n - 1]:
         diag_bad = diag.copy(); diag_bad[q] = -1e7
         _, info_bad = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag_bad, rhs)
         assert info_bad != 0, q
-        hit_tail += int(info_bad > plan["padded_rows"] - 32 * plan["tail_block_columns"])
-    assert hit_tail >= 1, "none of the broken diagonals fell into the tail: choose other unknowns"
+        last = max(last, info_bad)
+    assert last > plan["padded_rows"] // 2, "none of the broken diagonals fell into the second half of the order"
     x3, info3 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)      # and the context is as good as before
     assert info3 == 0 and np.array_equal(x, x3)
     ctx.close()
-    import pickle, subprocess, sys, tempfile
-    with tempfile.TemporaryDirectory() as d:
-        pickle.dump((n, rows, cols, mirror, blocks, scale, diag, rhs), open(os.path.join(d, "sys.pkl"), "wb"))
-        code = ("import pickle, sys, numpy as np; sys.path.insert(0, %r); import panovlm_amd as pv; a = pickle.load(open(%r, 'rb')); ctx = pv.Context(0); "
-                "x, info = ctx.spd_solve_blocks(*a); p = ctx.spd_plan(); pickle.dump((x, info, p), open(%r, 'wb'))") % (host_io.ROOT, os.path.join(d, "sys.pkl"), os.path.join(d, "out.pkl"))
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVLM_SPD_TAIL="0"), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        x_lv, info_lv, plan_lv = pickle.load(open(os.path.join(d, "out.pkl"), "rb"))
-    assert info_lv == 0 and plan_lv["tail_block_columns"] == 0 and plan_lv["launched_levels"] == plan_lv["levels"] == plan["levels"]
-    assert np.abs(x - x_lv).max() <= 1e-11 * max(1.0, np.abs(x_lv).max())
+    args = (n, rows, cols, mirror, blocks, scale, diag, rhs)
+    x_t, info_t, plan_t, same_t = _solve_in_child(args, {"PVLM_SPD_FLOW": "0"})
+    assert info_t == 0 and same_t and plan_t["tail_block_columns"] >= 8 and plan_t["tail_block_columns"] % 2 == 0, plan_t
+    assert plan_t["launched_levels"] + plan_t["tail_block_columns"] == plan_t["levels"] == plan["levels"], plan_t
+    x_l, info_l, plan_l, same_l = _solve_in_child(args, {"PVLM_SPD_FLOW": "0", "PVLM_SPD_TAIL": "0"})
+    assert info_l == 0 and same_l and plan_l["tail_block_columns"] == 0 and plan_l["launched_levels"] == plan_l["levels"] == plan["levels"]
+    scale_x = max(1.0, np.abs(x_l).max())
+    assert np.abs(x - x_l).max() <= 1e-11 * scale_x and np.abs(x_t - x_l).max() <= 1e-11 * scale_x
+    # a broken diagonal inside the tail, on the path with the tail
+    diag_bad = diag.copy(); diag_bad[n - 1] = -1e7
+    _, info_bt, _, _ = _solve_in_child((n, rows, cols, mirror, blocks, scale, diag_bad, rhs), {"PVLM_SPD_FLOW": "0"})
+    assert info_bt != 0
 
 
 def test_plan_prefetch_is_a_hint_never_a_change_of_result():

@@ -212,6 +212,64 @@ def solve_by_levels(P, M, rhs, tail=None):
     return x[nw], A
 
 
+def flow_plan(lib, n, rows, cols, leaf=8):
+    rows = np.ascontiguousarray(rows, np.int32); cols = np.ascontiguousarray(cols, np.int32)
+    sizes = np.zeros(5, np.int64)
+    args = (n, len(rows) // 6, _p(rows, ctypes.c_int), _p(cols, ctypes.c_int), NB, leaf, _p(sizes, ctypes.c_longlong))
+    lib.chk_spd_flow.restype = ctypes.c_int
+    lib.chk_spd_flow(*args, None, None, None, None, None)
+    TC, nt, ns, nb, depth = [int(v) for v in sizes]
+    F = dict(tasks=np.zeros((max(nt, 1), 4), np.int32), sources=np.zeros((max(ns, 1), 4), np.int32), col_order=np.zeros(max(TC, 1), np.int32), below_off=np.zeros(TC + 1, np.int32),
+             below=np.zeros(max(nb, 1), np.int32))
+    ok = lib.chk_spd_flow(*args, *[_p(F[k], ctypes.c_int) for k in ("tasks", "sources", "col_order", "below_off", "below")])
+    F.update(tile_cols=TC, n_tasks=nt, n_sources=ns, depth=depth, ready=bool(ok))
+    return F
+
+
+def solve_by_flow(P, F, M, rhs):
+    """The arithmetic of k_nd_flow / k_nd_flow_bwd (csrc/pvlm_linalg.hip) in numpy with EXACTLY the task lists: tasks run in list order and may only read tiles that an
+    EARLIER task has published (a list that named a later task would deadlock the launch: asserted), sources are added in list order, nothing outside the lists is touched."""
+    n_pad = P["n_pad"]; nw = P["new_of_old"]
+    A = np.eye(n_pad); b = np.zeros(n_pad)
+    A[np.ix_(nw, nw)] = M; b[nw] = rhs
+    A = np.tril(A)
+    sl = lambda q: slice(q * TILE, (q + 1) * TILE)
+    published = np.zeros(F["n_tasks"], bool); inv = {}; y = np.zeros(n_pad)
+    diag_done = set()
+    for tid in range(F["n_tasks"]):
+        I, J, so, ns = [int(v) for v in F["tasks"][tid]]
+        assert I >= J
+        C = A[sl(I), sl(J)].copy()
+        acc_y = np.zeros(TILE)
+        last_K = -1
+        for K, ta, tb, _ in F["sources"][so:so + ns]:
+            assert K > last_K and ta < tid and tb < tid and published[ta] and published[tb], (tid, K)
+            assert tuple(F["tasks"][ta][:2]) == (I, K) and tuple(F["tasks"][tb][:2]) == (J, K)
+            last_K = K
+            C -= A[sl(I), sl(K)] @ A[sl(J), sl(K)].T
+            if I == J:
+                assert K in diag_done
+                acc_y += A[sl(J), sl(K)] @ y[sl(K)]
+        if I == J:
+            C = np.tril(C) + np.tril(C, -1).T
+            inv[J] = np.linalg.inv(np.linalg.cholesky(C))
+            y[sl(J)] = inv[J] @ (b[sl(J)] - acc_y)
+            diag_done.add(J)
+        else:
+            assert J in diag_done
+            A[sl(I), sl(J)] = C @ inv[J].T
+        published[tid] = True
+    x = np.zeros(n_pad); solved = set()
+    for J in F["col_order"][::-1]:
+        v = y[sl(J)].copy()
+        for I in F["below"][F["below_off"][J]:F["below_off"][J + 1]][::-1]:
+            assert I in solved and I > J
+            v -= A[sl(I), sl(J)].T @ x[sl(I)]
+        x[sl(J)] = inv[J].T @ v
+        solved.add(int(J))
+    return x[nw], A
+
+
 def proximity_pairs(rng, P, degree):
     """Poses scattered over a floor, every pose tied to its `degree` nearest ones (what FindNeighbors produces on a trajectory that revisits a room), + self blocks."""
     xy = rng.uniform(0, 1, size=(P, 2))
@@ -270,3 +328,19 @@ def test_level_schedule_solves_the_system_with_its_own_lists(chk, shape):
         assert np.abs(x_t - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
     if shape in ("proximity", "chain_with_loops"):
         assert col0 < C_, "a separator of several block columns at the top of the dissection"
+    # the same factorisation as tasks of ONE launch (pvlm_spd::plan_flow): every tile of the factor a task, tasks in an order in which each depends only on earlier ones
+    F = flow_plan(chk, n, rows, cols, leaf=6)
+    assert F["ready"] and F["tile_cols"] == plan_["n_pad"] // TILE and sorted(F["col_order"].tolist()) == list(range(F["tile_cols"]))
+    assert F["depth"] <= F["tile_cols"] and F["n_tasks"] >= F["tile_cols"]
+    x_f, A_f = solve_by_flow(plan_, F, M, rhs)
+    assert np.abs(x_f - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    # every nonzero tile of a numeric factor of the permuted, padded matrix is a task
+    nw_ = plan_["new_of_old"]; Ap = np.eye(plan_["n_pad"]); Ap[np.ix_(nw_, nw_)] = M
+    Lnum = np.linalg.cholesky(Ap)
+    have = {(int(t[0]), int(t[1])) for t in F["tasks"][:F["n_tasks"]]}
+    T_ = plan_["n_pad"] // TILE
+    for I in range(T_):
+        for J in range(I + 1):
+            if np.abs(Lnum[I * TILE:(I + 1) * TILE, J * TILE:(J + 1) * TILE]).max() > 1e-13: assert (I, J) in have, (I, J)
+    if shape in ("chain", "proximity", "chain_with_loops"):
+        assert F["depth"] < 0.75 * F["tile_cols"], (F["depth"], F["tile_cols"])
