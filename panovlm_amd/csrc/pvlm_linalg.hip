@@ -595,11 +595,11 @@ static size_t tail_flag_words(int T) { return (size_t)2 + (size_t)T * T + 3 * (s
 // flags: [0] ticket, [1] ticket of the backward launch, [2 + i * T + j] tile (i, j) published, then T words each: inverse of column j, y_j, x_j
 // LISTS (k_nd_flow): the WHOLE factorisation in this form — the tiles are the tasks of pvlm_spd::plan_flow (tile row, tile column, sources = the earlier tile columns
 // that hold both tiles, with the tasks that publish them), r0 = 0, T = tile columns of the padded system; tile flags are indexed by task.
-struct NdFlowTask { int I, J, src_off, n_src; };
+struct NdFlowTask { int I, J, src_off, n_src, prev, final_, pad0, pad1; };   // pvlm_spd::FlowTask
 struct NdFlowSource { int K, task_a, task_b, pad; };
 template <bool LISTS>
 __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
-                                             const double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk,
+                                             double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk,
                                              const NdFlowTask* __restrict__ tasks, const NdFlowSource* __restrict__ sources, int n_tasks) {
   // clk != nullptr (PVLM_SPD_TAIL_CLOCK=1): 100 MHz wall-clock stamps of the dependent chain, twelve per tile column — the diagonal tile: [0] ticket taken, [1] last
   // dependency seen, [2] products done, [3] tile in LDS, [4] factor + inverse done, [5] inverse published, [8] first 32 pivots, [9] rank-32 update, [10] last 32
@@ -622,8 +622,9 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
     __syncthreads();
     int id = s_id;
     if (id >= n_tiles) return;
-    int i, j, n_src, src_off = 0;
-    if (LISTS) { const NdFlowTask tk = tasks[id]; i = tk.I; j = tk.J; n_src = tk.n_src; src_off = tk.src_off; }
+    int i, j, n_src, src_off = 0, prev = -1;
+    bool final_task = true;
+    if (LISTS) { const NdFlowTask tk = tasks[id]; i = tk.I; j = tk.J; n_src = tk.n_src; src_off = tk.src_off; prev = tk.prev; final_task = tk.final_ != 0; }
     else {
       j = 0;
       while (id >= T - j) { id -= T - j; ++j; }                      // column-major: column j holds the tiles i = j .. T - 1
@@ -633,7 +634,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
     const bool diag = i == j;
     const size_t row_i = (size_t)(r0 + 64 * i), row_j = (size_t)(r0 + 64 * j);
     const bool stamp = clk && t == 0;
-    if (stamp && diag) clk[12 * j + 0] = wall_clock64();
+    if (stamp && diag && final_task) clk[12 * j + 0] = wall_clock64();
     pvlm_d4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
@@ -646,7 +647,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
         if (ok && !diag) ok = tail_wait(tile_flag + flag_b, info);
         if (ok && diag) ok = tail_wait(y_flag + k, info);
         s_ok = ok ? 1 : 0;
-        if (stamp && diag && q_src == n_src - 1) clk[12 * j + 1] = wall_clock64();
+        if (stamp && diag && final_task && q_src == n_src - 1) clk[12 * j + 1] = wall_clock64();
       }
       __syncthreads();
       if (!s_ok) return;
@@ -685,12 +686,37 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
       }
     }
     // the tile's own values (written by the launches before this one, or zero) minus the products
-    if (stamp && diag) clk[12 * j + 2] = wall_clock64();
+    if (stamp && diag && final_task) clk[12 * j + 2] = wall_clock64();
     double cv[4][4];
+    if (LISTS) {
+      // the tile may hold the partial sums of a chunk task (another workgroup, this launch): wait for the last of them, read through the agent-scope path
+      if (prev >= 0) {
+        if (t == 0) s_ok = tail_wait(tile_flag + prev, info) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) return;
+      }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cv[q][r] = M[(row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li];
+        for (int r = 0; r < 4; ++r) cv[q][r] = tail_ld(M + (row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li);
+      if (!final_task) {
+        // a chunk: the tile in memory minus this chunk's products (and b_j minus its share of the forward substitution), published for the next task of the tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tail_st(M + (row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li, cv[q][r] - acc[q][r]);
+        if (diag && t < 64) tail_st(b + r0 + 64 * j + t, tail_ld(b + r0 + 64 * j + t) - bacc);
+        tail_drain();
+        __syncthreads();
+        if (t == 0) tail_raise(tile_flag + my_flag);
+        continue;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[q][r] = M[(row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li];
+    }
     __syncthreads();                                                 // the last slices have been consumed: lds becomes the tile
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -701,7 +727,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
       }
     if (!diag) {
       if (t == 0) s_ok = tail_wait(inv_flag + j, info) ? 1 : 0;
-      if (stamp && i == j + 1) clk[12 * j + 6] = wall_clock64();
+      if (stamp && (LISTS ? (s_id > 0 && tasks[s_id - 1].I == j && tasks[s_id - 1].J == j) : i == j + 1)) clk[12 * j + 6] = wall_clock64();
       __syncthreads();
       if (!s_ok) return;
       double iv[16];
@@ -726,7 +752,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
       tail_drain();
       __syncthreads();
       if (t == 0) tail_raise(tile_flag + my_flag);
-      if (stamp && i == j + 1) clk[12 * j + 7] = wall_clock64();
+      if (stamp && (LISTS ? (s_id > 0 && tasks[s_id - 1].I == j && tasks[s_id - 1].J == j) : i == j + 1)) clk[12 * j + 7] = wall_clock64();
       continue;
     }
     // ---- the diagonal tile: Cs (lower triangle, zeros above) -> L and L^-1, 32 columns at a time
@@ -837,7 +863,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
     if (t == 0) tail_raise(inv_flag + j);
     if (stamp) clk[12 * j + 5] = wall_clock64();
     // y_j = L_jj^-1 (b_j - sum_k L(j,k) y_k)
-    if (t < 64) vs[t] = b[r0 + 64 * j + t] - bacc;
+    if (t < 64) vs[t] = (LISTS ? tail_ld(b + r0 + 64 * j + t) : b[r0 + 64 * j + t]) - bacc;
     __syncthreads();
     if (t < 64) {
       double sacc = 0.0;
@@ -850,13 +876,13 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
   }
 }
 __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
-                                                 const double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk) {
+                                                 double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk) {
   nd_tile_flow<false>(M, n, r0, T, inv64, flags, info, b, yv, clk, nullptr, nullptr, 0);
 }
 __global__ __launch_bounds__(256) void k_nd_flow(double* __restrict__ M, int n, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
-                                                 const double* __restrict__ b, double* __restrict__ yv, const NdFlowTask* __restrict__ tasks,
-                                                 const NdFlowSource* __restrict__ sources, int n_tasks) {
-  nd_tile_flow<true>(M, n, 0, T, inv64, flags, info, b, yv, nullptr, tasks, sources, n_tasks);
+                                                 double* __restrict__ b, double* __restrict__ yv, const NdFlowTask* __restrict__ tasks,
+                                                 const NdFlowSource* __restrict__ sources, int n_tasks, unsigned long long* __restrict__ clk) {
+  nd_tile_flow<true>(M, n, 0, T, inv64, flags, info, b, yv, clk, tasks, sources, n_tasks);
 }
 
 // Backward substitution of the tail: x_j = L_jj^-T (y_j - sum_{i > j} L(i,j)^T x_i), a workgroup per tile column (ticket order: j descending), the tile of the next
@@ -1312,8 +1338,26 @@ static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* 
   if (P->flow_T > 0) {
     const int T = P->flow_T;
     (void)hipMemsetAsync(P->d_tail_flags, 0, ((size_t)2 + (size_t)P->flow_tasks + 3 * (size_t)T) * sizeof(unsigned), s);
-    hipLaunchKernelGGL(k_nd_flow, dim3((unsigned)std::min(P->flow_tasks, 1024)), dim3(256), 0, s, d_M, n, T, P->d_tail_inv, P->d_tail_flags, d_info, (const double*)d_b, d_y,
-                       (const NdFlowTask*)P->d_flow_tasks, (const NdFlowSource*)P->d_flow_sources, P->flow_tasks);
+    static const bool want_clock = getenv("PVLM_SPD_TAIL_CLOCK") && atoi(getenv("PVLM_SPD_TAIL_CLOCK")) != 0;
+    unsigned long long* d_clk = nullptr;
+    if (want_clock && pvlm_i_alloc_bytes(ctx, (void**)&d_clk, (size_t)T * 12 * sizeof(unsigned long long)) != PVLM_OK) d_clk = nullptr;
+    if (d_clk) (void)hipMemsetAsync(d_clk, 0, (size_t)T * 12 * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_nd_flow, dim3((unsigned)std::min(P->flow_tasks, 1024)), dim3(256), 0, s, d_M, n, T, P->d_tail_inv, P->d_tail_flags, d_info, d_b, d_y,
+                       (const NdFlowTask*)P->d_flow_tasks, (const NdFlowSource*)P->d_flow_sources, P->flow_tasks, d_clk);
+    if (d_clk) {
+      std::vector<unsigned long long> c((size_t)T * 12);
+      if (hipMemcpyAsync(c.data(), d_clk, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+        unsigned long long t0 = ~0ull;
+        for (int j = 0; j < T; ++j) if (c[(size_t)12 * j]) t0 = std::min(t0, c[(size_t)12 * j]);
+        fprintf(stderr, "k_nd_flow clocks (us from the first ticket): tile column | ticket dep-seen products tile-in-LDS factored published | first tile below: inverse-seen published | 32 pivots, update, 32 pivots\n");
+        for (int j = 0; j < T; ++j) {
+          fprintf(stderr, "%3d |", j);
+          for (int q = 0; q < 12; ++q) { const unsigned long long v = c[(size_t)12 * j + q]; if (q == 6) fprintf(stderr, " |"); if (v) fprintf(stderr, " %8.2f", (double)(long long)(v - t0) * 0.01); else fprintf(stderr, "        -"); }
+          fprintf(stderr, "\n");
+        }
+      }
+      pvlm_i_free(ctx, d_clk);
+    }
     hipLaunchKernelGGL(k_nd_flow_bwd, dim3((unsigned)T), dim3(256), 0, s, (const double*)d_M, n, T, (const double*)P->d_tail_inv, P->d_tail_flags, P->flow_tasks, d_info, d_b,
                        (const double*)d_y, (const int*)P->d_flow_cols, (const int*)P->d_flow_below_off, (const int*)P->d_flow_below);
     return;
@@ -1340,7 +1384,7 @@ static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* 
     unsigned long long* d_clk = nullptr;
     if (want_clock && pvlm_i_alloc_bytes(ctx, (void**)&d_clk, (size_t)T * 12 * sizeof(unsigned long long)) != PVLM_OK) d_clk = nullptr;
     if (d_clk) (void)hipMemsetAsync(d_clk, 0, (size_t)T * 12 * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(k_nd_tail, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), 0, s, d_M, n, P->tail_r0, T, P->d_tail_inv, P->d_tail_flags, d_info, (const double*)d_b, d_y, d_clk);
+    hipLaunchKernelGGL(k_nd_tail, dim3((unsigned)std::min(n_tiles, 512)), dim3(256), 0, s, d_M, n, P->tail_r0, T, P->d_tail_inv, P->d_tail_flags, d_info, d_b, d_y, d_clk);
     hipLaunchKernelGGL(k_nd_tail_bwd, dim3((unsigned)T), dim3(256), 0, s, (const double*)d_M, n, P->tail_r0, T, (const double*)P->d_tail_inv, P->d_tail_flags, d_info, d_b, (const double*)d_y);
     if (d_clk) {
       std::vector<unsigned long long> c((size_t)T * 12);

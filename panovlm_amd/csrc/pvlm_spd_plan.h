@@ -159,10 +159,11 @@ inline void plan_symbolic(int n, int n_blocks, const int* row_idx, const int* co
 // ascending elimination order), then factorises (I == J) or multiplies by the inverse of the diagonal tile (I > J).  Tasks are ordered by the dependency depth of
 // their column, then column, diagonal first — every task depends only on tasks before it, so workgroups that take tasks in this order by a ticket can always finish
 // the lowest unfinished one (no residency assumption).  The backward substitution walks the columns in reverse order.
-struct FlowTask { int I, J, src_off, n_src; };
+struct FlowTask { int I, J, src_off, n_src, prev, final_, pad0, pad1; };   // prev: the task that must have published this tile before it is read (-1: none);
+                                                                            // final_ = 0: a CHUNK — it only subtracts its sources from the tile in memory
 struct FlowSource { int K, task_a, task_b, pad; };           // tile column K; the tasks that publish L(I,K) and L(J,K)
 struct FlowPlan {
-  int tile_cols = 0, depth = 0;                               // 64-wide tile columns; dependent tile columns on the longest chain
+  int tile_cols = 0, depth = 0, finals = 0;                   // 64-wide tile columns; dependent tile columns on the longest chain; tasks that finish a tile
   std::vector<FlowTask> tasks;
   std::vector<FlowSource> sources;
   std::vector<int> col_order;                                 // tile columns in task order
@@ -171,8 +172,13 @@ struct FlowPlan {
 };
 
 // row_off / row_tiles: the panel tiles of every NB-column block column, as plan_levels leaves them (tiles that reach below the block, the block's own tile included
-// for the first half of a tile column)
-inline void plan_flow(int n_pad, int NB, const std::vector<int>& row_off, const std::vector<int>& row_tiles, FlowPlan* F) {
+// for the first half of a tile column).  chunk: sources per chunk task (0: no chunks).
+// CHUNKS.  A tile of the top separator has a source in nearly every column below it (138 on the Floor graph): one task adding them up one after the other is 0.4 ms of
+// serial work that starts when the task gets its ticket — late, tickets go in dependency order — and the tile column that needs it waits (measured: 170 us between
+// a column's inverse and the first dependency of the next).  So the sources of a tile that are published two or more levels before the tile's own column are split off
+// into chunk tasks of `chunk` sources, each placed right after the level that publishes its last source: they run while the launch has idle workgroups, subtract their
+// products from the tile IN MEMORY (one after the other: chunk c waits for chunk c - 1), and the final task is left with the sources of the level just before it.
+inline void plan_flow(int n_pad, int NB, const std::vector<int>& row_off, const std::vector<int>& row_tiles, int chunk, FlowPlan* F) {
   *F = FlowPlan();
   const int per_tile = 64 / NB, TC = n_pad / 64;
   if (TC <= 0 || n_pad % 64 != 0 || (int)row_off.size() != TC * per_tile + 1) return;
@@ -193,38 +199,87 @@ inline void plan_flow(int n_pad, int NB, const std::vector<int>& row_off, const 
   F->col_order.resize((size_t)TC);
   for (int J = 0; J < TC; ++J) { F->col_order[(size_t)J] = J; F->depth = std::max(F->depth, lev[(size_t)J] + 1); }
   std::stable_sort(F->col_order.begin(), F->col_order.end(), [&](int a, int b) { return lev[(size_t)a] < lev[(size_t)b]; });
-  // tasks, column by column in that order; first task of column J = its diagonal tile
-  std::vector<int> first_task((size_t)TC, 0);
+  // the tiles ("finals": the tasks that finish a tile), column by column in that order; first tile of column J = its diagonal tile
+  struct Tile { int I, J, src_off, n_src, n_chunks, task; };
+  std::vector<Tile> tiles;
+  std::vector<int> first_tile((size_t)TC, 0);
   for (int J : F->col_order) {
-    first_task[(size_t)J] = (int)F->tasks.size();
-    F->tasks.push_back(FlowTask{J, J, 0, 0});
-    for (int q = F->below_off[(size_t)J]; q < F->below_off[(size_t)J + 1]; ++q) F->tasks.push_back(FlowTask{F->below[(size_t)q], J, 0, 0});
+    first_tile[(size_t)J] = (int)tiles.size();
+    tiles.push_back(Tile{J, J, 0, 0, 0, -1});
+    for (int q = F->below_off[(size_t)J]; q < F->below_off[(size_t)J + 1]; ++q) tiles.push_back(Tile{F->below[(size_t)q], J, 0, 0, 0, -1});
   }
-  // task of tile (I, J): position of I in the column's list (binary search)
-  auto task_of = [&](int I, int J) {
-    if (I == J) return first_task[(size_t)J];
+  F->finals = (int)tiles.size();
+  auto tile_of = [&](int I, int J) {
+    if (I == J) return first_tile[(size_t)J];
     const int* b = F->below.data() + F->below_off[(size_t)J]; const int* e = F->below.data() + F->below_off[(size_t)J + 1];
     const int* it = std::lower_bound(b, e, I);
-    return (it != e && *it == I) ? first_task[(size_t)J] + 1 + (int)(it - b) : -1;
+    return (it != e && *it == I) ? first_tile[(size_t)J] + 1 + (int)(it - b) : -1;
   };
-  // sources: two passes over the columns in ascending order (count, fill) — ascending K inside every task
+  // sources per tile as (K, tile of (I,K), tile of (J,K)): two passes over the columns IN TASK ORDER (count, fill) — inside a tile ascending (level, column) of K
+  struct Src { int K, ta, tb; };
+  std::vector<Src> srcs;
   for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1) { int off = 0; for (FlowTask& t : F->tasks) { t.src_off = off; off += t.n_src; t.n_src = 0; } F->sources.assign((size_t)off, FlowSource{0, 0, 0, 0}); }
-    for (int K = 0; K < TC; ++K) {
+    if (pass == 1) { int off = 0; for (Tile& t : tiles) { t.src_off = off; off += t.n_src; t.n_src = 0; } srcs.assign((size_t)off, Src{0, 0, 0}); }
+    for (int K : F->col_order) {
       const int* b = F->below.data() + F->below_off[(size_t)K]; const int nb = F->below_off[(size_t)K + 1] - F->below_off[(size_t)K];
       for (int c = 0; c < nb; ++c)
         for (int a = c; a < nb; ++a) {
-          const int id = task_of(b[a], b[c]);
+          const int id = tile_of(b[a], b[c]);
           if (id < 0) return;                                   // a fill the symbolic factorisation did not mark: not ready (never seen; checked by the CPU test)
-          FlowTask& t = F->tasks[(size_t)id];
-          if (pass == 1) F->sources[(size_t)(t.src_off + t.n_src)] = FlowSource{K, first_task[(size_t)K] + 1 + a, first_task[(size_t)K] + 1 + c, 0};
+          Tile& t = tiles[(size_t)id];
+          if (pass == 1) srcs[(size_t)(t.src_off + t.n_src)] = Src{K, first_tile[(size_t)K] + 1 + a, first_tile[(size_t)K] + 1 + c};
           ++t.n_src;
         }
     }
   }
+  // chunks: the sources published two levels or more before the tile's column, `chunk` at a time (the last chunk takes the remainder when it is short)
+  struct Chunk { int tile, first, count, ready_level; };
+  std::vector<std::vector<Chunk>> chunks_at((size_t)F->depth);
+  for (size_t f = 0; f < tiles.size(); ++f) {
+    Tile& t = tiles[f];
+    int early = 0;
+    while (chunk > 0 && early < t.n_src && lev[(size_t)srcs[(size_t)(t.src_off + early)].K] + 2 <= lev[(size_t)t.J]) ++early;
+    if (chunk <= 0 || early < std::max(4, chunk / 2)) continue;
+    const int nc = (early + chunk - 1) / chunk;
+    for (int c = 0; c < nc; ++c) {
+      const int first = (int)((long long)early * c / nc), last = (int)((long long)early * (c + 1) / nc);
+      chunks_at[(size_t)lev[(size_t)srcs[(size_t)(t.src_off + last - 1)].K]].push_back(Chunk{(int)f, first, last - first, 0});
+    }
+    t.n_chunks = nc;
+  }
+  // task order: level by level — the tiles of the level's columns, then the chunks whose last source that level publishes
+  std::vector<int> last_task_of_tile(tiles.size(), -1);          // the latest chunk of the tile emitted so far
+  std::vector<int> chunk_first(tiles.size(), 0);                // sources of the tile already given to chunks
+  size_t tile_cursor = 0;
+  struct Pending { int task, tile, first, count; };
+  std::vector<Pending> emit;
+  for (int l = 0; l < F->depth; ++l) {
+    while (tile_cursor < tiles.size() && lev[(size_t)tiles[tile_cursor].J] == l) {
+      Tile& t = tiles[tile_cursor];
+      t.task = (int)F->tasks.size();
+      F->tasks.push_back(FlowTask{t.I, t.J, 0, t.n_src - chunk_first[tile_cursor], last_task_of_tile[tile_cursor], 1, 0, 0});
+      emit.push_back(Pending{t.task, (int)tile_cursor, chunk_first[tile_cursor], t.n_src - chunk_first[tile_cursor]});
+      ++tile_cursor;
+    }
+    for (const Chunk& c : chunks_at[(size_t)l]) {
+      const Tile& t = tiles[(size_t)c.tile];
+      const int id = (int)F->tasks.size();
+      F->tasks.push_back(FlowTask{t.I, t.J, 0, c.count, last_task_of_tile[(size_t)c.tile], 0, 0, 0});
+      emit.push_back(Pending{id, c.tile, c.first, c.count});
+      last_task_of_tile[(size_t)c.tile] = id;
+      chunk_first[(size_t)c.tile] = c.first + c.count;
+    }
+  }
+  if (tile_cursor != tiles.size()) return;
+  int off = 0;
+  for (const Pending& e : emit) {
+    FlowTask& t = F->tasks[(size_t)e.task];
+    t.src_off = off;
+    for (int q = 0; q < e.count; ++q) { const Src& sr = srcs[(size_t)(tiles[(size_t)e.tile].src_off + e.first + q)]; F->sources.push_back(FlowSource{sr.K, tiles[(size_t)sr.ta].task, tiles[(size_t)sr.tb].task, 0}); }
+    off += e.count;
+  }
   F->ready = true;
 }
-
 
 // ---- nested dissection + level schedule (round 6) -----------------------------------------------------------------------------------------------
 // plan_symbolic above orders by minimum degree and factorises block column after block column: on the Floor pose graph (1 593 poses, every pose tied to
@@ -269,7 +324,7 @@ inline void plan_tail(const std::vector<int>& col_off, const std::vector<int>& c
   *tail_col0 = c; *main_levels = l;
 }
 
-inline void plan_levels(int n, int n_blocks, const int* row_idx, const int* col_idx, int NB, int leaf_nodes, LevelPlan* P) {
+inline void plan_levels(int n, int n_blocks, const int* row_idx, const int* col_idx, int NB, int leaf_nodes, LevelPlan* P, int flow_chunk = 12) {
 #ifdef PVLM_PLAN_PROFILE
   auto T0 = std::chrono::steady_clock::now(); auto mark = [&](const char* w) { auto t = std::chrono::steady_clock::now(); printf("%-28s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0).count()); T0 = t; };
 #else
@@ -468,7 +523,7 @@ inline void plan_levels(int n, int n_blocks, const int* row_idx, const int* col_
   }
   mark("schedule lists");
   plan_tail(P->col_off, P->cols, C, per_tile, 8, &P->tail_col0, &P->main_levels);
-  plan_flow(n_pad, NB, P->row_off, P->row_tiles, &P->flow);
+  plan_flow(n_pad, NB, P->row_off, P->row_tiles, flow_chunk, &P->flow);
   mark("flow tasks");
   P->ordered = true;
 }

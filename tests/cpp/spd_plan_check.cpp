@@ -50,12 +50,12 @@ void chk_spd_tail(int n, int n_blocks, const int* row_idx, const int* col_idx, i
 }
 
 // the one-launch form of the level plan (pvlm_spd::plan_flow).  First call with null outputs: sizes[0..4] = tile columns, tasks, sources, below entries, depth; second call
-// fills tasks (4 ints each), sources (4 ints each), col_order, below_off, below.  Returns 1 when the flow plan is ready.
+// fills tasks (8 ints each: I, J, src_off, n_src, prev, final, 0, 0), sources (4 ints each), col_order, below_off, below; sizes[5] = finals.  Returns 1 when the flow plan is ready.
 int chk_spd_flow(int n, int n_blocks, const int* row_idx, const int* col_idx, int nb, int leaf, long long* sizes, int* tasks, int* sources, int* col_order, int* below_off, int* below) {
   pvlm_spd::LevelPlan P;
   pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, nb, leaf, &P);
   const pvlm_spd::FlowPlan& F = P.flow;
-  sizes[0] = F.tile_cols; sizes[1] = (long long)F.tasks.size(); sizes[2] = (long long)F.sources.size(); sizes[3] = (long long)F.below.size(); sizes[4] = F.depth;
+  sizes[0] = F.tile_cols; sizes[1] = (long long)F.tasks.size(); sizes[2] = (long long)F.sources.size(); sizes[3] = (long long)F.below.size(); sizes[4] = F.depth; sizes[5] = F.finals;
   auto put = [](int* dst, const void* src, size_t bytes) { if (dst && bytes) std::memcpy(dst, src, bytes); };
   put(tasks, F.tasks.data(), F.tasks.size() * sizeof(pvlm_spd::FlowTask)); put(sources, F.sources.data(), F.sources.size() * sizeof(pvlm_spd::FlowSource));
   put(col_order, F.col_order.data(), F.col_order.size() * 4); put(below_off, F.below_off.data(), F.below_off.size() * 4); put(below, F.below.data(), F.below.size() * 4);

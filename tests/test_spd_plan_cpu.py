@@ -214,12 +214,12 @@ def solve_by_levels(P, M, rhs, tail=None):
 
 def flow_plan(lib, n, rows, cols, leaf=8):
     rows = np.ascontiguousarray(rows, np.int32); cols = np.ascontiguousarray(cols, np.int32)
-    sizes = np.zeros(5, np.int64)
+    sizes = np.zeros(6, np.int64)
     args = (n, len(rows) // 6, _p(rows, ctypes.c_int), _p(cols, ctypes.c_int), NB, leaf, _p(sizes, ctypes.c_longlong))
     lib.chk_spd_flow.restype = ctypes.c_int
     lib.chk_spd_flow(*args, None, None, None, None, None)
-    TC, nt, ns, nb, depth = [int(v) for v in sizes]
-    F = dict(tasks=np.zeros((max(nt, 1), 4), np.int32), sources=np.zeros((max(ns, 1), 4), np.int32), col_order=np.zeros(max(TC, 1), np.int32), below_off=np.zeros(TC + 1, np.int32),
+    TC, nt, ns, nb, depth, finals = [int(v) for v in sizes]
+    F = dict(finals=finals, tasks=np.zeros((max(nt, 1), 8), np.int32), sources=np.zeros((max(ns, 1), 4), np.int32), col_order=np.zeros(max(TC, 1), np.int32), below_off=np.zeros(TC + 1, np.int32),
              below=np.zeros(max(nb, 1), np.int32))
     ok = lib.chk_spd_flow(*args, *[_p(F[k], ctypes.c_int) for k in ("tasks", "sources", "col_order", "below_off", "below")])
     F.update(tile_cols=TC, n_tasks=nt, n_sources=ns, depth=depth, ready=bool(ok))
@@ -235,30 +235,36 @@ def solve_by_flow(P, F, M, rhs):
     A = np.tril(A)
     sl = lambda q: slice(q * TILE, (q + 1) * TILE)
     published = np.zeros(F["n_tasks"], bool); inv = {}; y = np.zeros(n_pad)
-    diag_done = set()
+    diag_done = set(); final_of = {}
     for tid in range(F["n_tasks"]):
-        I, J, so, ns = [int(v) for v in F["tasks"][tid]]
+        I, J, so, ns, prev, final = [int(v) for v in F["tasks"][tid][:6]]
         assert I >= J
-        C = A[sl(I), sl(J)].copy()
-        acc_y = np.zeros(TILE)
-        last_K = -1
+        if prev >= 0:                                             # the chunk before this task has left its partial sums in the tile
+            assert prev < tid and published[prev] and tuple(F["tasks"][prev][:2]) == (I, J) and F["tasks"][prev][5] == 0
+        acc = np.zeros((TILE, TILE)); acc_y = np.zeros(TILE)
         for K, ta, tb, _ in F["sources"][so:so + ns]:
-            assert K > last_K and ta < tid and tb < tid and published[ta] and published[tb], (tid, K)
-            assert tuple(F["tasks"][ta][:2]) == (I, K) and tuple(F["tasks"][tb][:2]) == (J, K)
-            last_K = K
-            C -= A[sl(I), sl(K)] @ A[sl(J), sl(K)].T
+            assert ta < tid and tb < tid and published[ta] and published[tb], (tid, K)
+            assert tuple(F["tasks"][ta][:2]) == (I, K) and tuple(F["tasks"][tb][:2]) == (J, K) and F["tasks"][ta][5] == 1 and F["tasks"][tb][5] == 1
+            acc += A[sl(I), sl(K)] @ A[sl(J), sl(K)].T
             if I == J:
                 assert K in diag_done
                 acc_y += A[sl(J), sl(K)] @ y[sl(K)]
-        if I == J:
+        C = A[sl(I), sl(J)] - acc
+        if not final:
+            A[sl(I), sl(J)] = C
+            if I == J: b[sl(J)] -= acc_y
+        elif I == J:
+            assert (I, J) not in final_of
             C = np.tril(C) + np.tril(C, -1).T
             inv[J] = np.linalg.inv(np.linalg.cholesky(C))
             y[sl(J)] = inv[J] @ (b[sl(J)] - acc_y)
             diag_done.add(J)
         else:
-            assert J in diag_done
+            assert J in diag_done and (I, J) not in final_of
             A[sl(I), sl(J)] = C @ inv[J].T
+        if final: final_of[(I, J)] = tid
         published[tid] = True
+    assert len(final_of) == F["finals"]
     x = np.zeros(n_pad); solved = set()
     for J in F["col_order"][::-1]:
         v = y[sl(J)].copy()
@@ -331,13 +337,15 @@ def test_level_schedule_solves_the_system_with_its_own_lists(chk, shape):
     # the same factorisation as tasks of ONE launch (pvlm_spd::plan_flow): every tile of the factor a task, tasks in an order in which each depends only on earlier ones
     F = flow_plan(chk, n, rows, cols, leaf=6)
     assert F["ready"] and F["tile_cols"] == plan_["n_pad"] // TILE and sorted(F["col_order"].tolist()) == list(range(F["tile_cols"]))
-    assert F["depth"] <= F["tile_cols"] and F["n_tasks"] >= F["tile_cols"]
+    assert F["depth"] <= F["tile_cols"] and F["n_tasks"] >= F["finals"] >= F["tile_cols"]
+    if shape == "proximity": assert F["n_tasks"] > F["finals"], "a graph with a top separator has tiles with early sources: chunk tasks"
+
     x_f, A_f = solve_by_flow(plan_, F, M, rhs)
     assert np.abs(x_f - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
     # every nonzero tile of a numeric factor of the permuted, padded matrix is a task
     nw_ = plan_["new_of_old"]; Ap = np.eye(plan_["n_pad"]); Ap[np.ix_(nw_, nw_)] = M
     Lnum = np.linalg.cholesky(Ap)
-    have = {(int(t[0]), int(t[1])) for t in F["tasks"][:F["n_tasks"]]}
+    have = {(int(t[0]), int(t[1])) for t in F["tasks"][:F["n_tasks"]] if t[5] == 1}
     T_ = plan_["n_pad"] // TILE
     for I in range(T_):
         for J in range(I + 1):
