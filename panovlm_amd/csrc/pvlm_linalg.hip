@@ -591,6 +591,18 @@ __device__ __forceinline__ void tail_drain() { asm volatile("s_waitcnt vmcnt(0)"
 __device__ __forceinline__ void tail_raise(unsigned* flag) { __hip_atomic_store((pvlm_gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 static size_t tail_flag_words(int T) { return (size_t)2 + (size_t)T * T + 3 * (size_t)T; }
+// lane q of every row of 16 lanes, for all lanes of that row (DPP row_newbcast: one v_mov_b64_dpp)
+template <int Q> __device__ __forceinline__ double row_bcast_f64_c(double v) {
+  return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + Q, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double row_bcast_f64(double v, int q) {      // q: a constant after unrolling
+  switch (q) {
+    case 0: return row_bcast_f64_c<0>(v); case 1: return row_bcast_f64_c<1>(v); case 2: return row_bcast_f64_c<2>(v); case 3: return row_bcast_f64_c<3>(v);
+    case 4: return row_bcast_f64_c<4>(v); case 5: return row_bcast_f64_c<5>(v); case 6: return row_bcast_f64_c<6>(v); case 7: return row_bcast_f64_c<7>(v);
+    case 8: return row_bcast_f64_c<8>(v); case 9: return row_bcast_f64_c<9>(v); case 10: return row_bcast_f64_c<10>(v); case 11: return row_bcast_f64_c<11>(v);
+    case 12: return row_bcast_f64_c<12>(v); case 13: return row_bcast_f64_c<13>(v); case 14: return row_bcast_f64_c<14>(v); default: return row_bcast_f64_c<15>(v);
+  }
+}
 #define PVLM_TAIL_LD 65     // row stride (doubles) of the 64 x 64 tiles in LDS
 // flags: [0] ticket, [1] ticket of the backward launch, [2 + i * T + j] tile (i, j) published, then T words each: inverse of column j, y_j, x_j
 // LISTS (k_nd_flow): the WHOLE factorisation in this form — the tiles are the tasks of pvlm_spd::plan_flow (tile row, tile column, sources = the earlier tile columns
@@ -606,7 +618,8 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
   // pivots; the tile below it: [6] inverse seen, [7] tile published
   __shared__ double lds[2 * 64 * PVLM_TAIL_LD];                        // the k loop: As | Bs (64 x 65 each); afterwards As is the tile itself
   __shared__ double Is[64 * PVLM_TAIL_LD];                             // the inverse of the diagonal block
-  __shared__ double ys[64], vs[64];
+  __shared__ double ys[64], vs[64], rds[64];
+  __shared__ double Ts[2][16][17];
   __shared__ int s_id, s_ok, s_fail;
   double (*As)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(lds);
   double (*Bs)[PVLM_TAIL_LD] = reinterpret_cast<double (*)[PVLM_TAIL_LD]>(lds + 64 * PVLM_TAIL_LD);
@@ -765,12 +778,12 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
         // 32 columns of this pass in registers; pivots and column entries cross lanes by v_readlane (see chol_diag_panel_body)
         const int i32 = t & (PVLM_CHOL_NB - 1);
         const int row = blk == 0 ? t : PVLM_CHOL_NB + i32;
-        double r[PVLM_CHOL_NB], x[PVLM_CHOL_NB], rdiag[PVLM_CHOL_NB];
+        double r[PVLM_CHOL_NB];
 #pragma unroll
-        for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) { r[cc] = Cs[row][PVLM_CHOL_NB * blk + cc]; x[cc] = 0.0; rdiag[cc] = 0.0; }
+        for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) r[cc] = Cs[row][PVLM_CHOL_NB * blk + cc];
         int bad = 0;
-        // kb = 32, but not to the compiler: the branch per step keeps the steps apart — without it the scheduler hoists the 992 v_readlane of the inverse ahead of their
-        // sums, runs out of scalar registers and spills them to vector lanes (916 v_writelane, 1 374 s_nop: 25 us per pass instead of 9)
+        // kb = 32, but not to the compiler: the branch per step keeps the steps apart (without it the scheduler hoists the v_readlane of later steps ahead of their
+        // sums, runs out of scalar registers and spills them to vector lanes: 25 us per pass instead of 9 when the inverse was still computed here)
         int kb = PVLM_CHOL_NB;
         asm volatile("" : "+s"(kb));
 #pragma unroll
@@ -783,7 +796,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
               y = y * (1.5 - 0.5 * d * y * y);
               y = y * (1.5 - 0.5 * d * y * y);
               y = y * (1.5 - 0.5 * d * y * y);
-              rdiag[jj] = y;
+              if (t == 0) rds[PVLM_CHOL_NB * blk + jj] = y;     // 1 / l_jj for the inverse below
               const double lij = r[jj] * y;
 #pragma unroll
               for (int cc = jj + 1; cc < PVLM_CHOL_NB; ++cc) r[cc] -= lij * bcast_f64(lij, cc);
@@ -792,26 +805,10 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
           }
         }
         if (bad) { if (t == 0) s_fail = PVLM_CHOL_NB * blk + bad; }
-        else {
+        else if (blk == 0 || t < PVLM_CHOL_NB) {
+          // L back into the tile (blk 0: rows 0..63 of the left half; blk 1: rows 32..63 of the right half)
 #pragma unroll
-          for (int q = 0; q < PVLM_CHOL_NB; ++q) {
-            if (q < kb) {
-              double sacc = 0.0;
-#pragma unroll
-              for (int k2 = 0; k2 < q; ++k2) sacc += bcast_f64(r[k2], q) * x[k2];
-              const double rq = rdiag[q];
-              x[q] = q == i32 ? rq : (q > i32 ? -sacc * rq : 0.0);
-            }
-          }
-          // L back into the tile (blk 0: rows 0..63 of the left half; blk 1: rows 32..63 of the right half), the inverse of the 32 x 32 block into Iv's diagonal blocks
-          if (blk == 0 || t < PVLM_CHOL_NB) {
-#pragma unroll
-            for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) Cs[row][PVLM_CHOL_NB * blk + cc] = (blk == 0 ? (t >= PVLM_CHOL_NB || cc <= t) : cc <= i32) ? r[cc] : 0.0;
-          }
-          if (t < PVLM_CHOL_NB) {
-#pragma unroll
-            for (int q = 0; q < PVLM_CHOL_NB; ++q) Iv[PVLM_CHOL_NB * blk + q][PVLM_CHOL_NB * blk + i32] = x[q];
-          }
+          for (int cc = 0; cc < PVLM_CHOL_NB; ++cc) Cs[row][PVLM_CHOL_NB * blk + cc] = (blk == 0 ? (t >= PVLM_CHOL_NB || cc <= t) : cc <= i32) ? r[cc] : 0.0;
         }
       }
       __syncthreads();
@@ -834,6 +831,46 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
       }
     }
     if (s_fail) { if (t == 0) atomicCAS(info, 0, r0 + 64 * j + s_fail); return; }
+    // ---- L^-1 of the 64 x 64 tile from L (in Cs), by halves: the four 16 x 16 diagonal blocks at once in ONE wave — lane 16 g + c solves L_g x = e_c, the entries of
+    // L_g reach the sixteen lanes of their group by DPP row_newbcast (one v_mov_b64_dpp per term where the 32-wide inverse of the pivot chain needed two v_readlane
+    // and could do one block at a time: 2 x 4.8 us of a diagonal tile's 24) —, then the blocks below them by products on the matrix core, 16 -> 32 -> 64.
+    if (t < 64) {
+      const int g16 = 16 * (t >> 4), c = t & 15;
+      double lrow[16], x[16];
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) lrow[k2] = Cs[g16 + c][g16 + k2];        // row c of the group's block (zeros above the diagonal)
+      const double rd_own = rds[g16 + c];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < q; ++k2) sacc += row_bcast_f64(lrow[k2], q) * x[k2];   // x[k2] = 0 for k2 < c
+        const double rq = row_bcast_f64(rd_own, q);
+        x[q] = q == c ? rq : (q > c ? -sacc * rq : 0.0);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Iv[g16 + q][g16 + c] = x[q];
+    }
+    __syncthreads();
+    if (w < 2) {
+      // inside each 32 x 32 diagonal block h = w: X21 = -X22 (L21 X11), all 16 x 16
+      const int h0 = PVLM_CHOL_NB * w;
+      pvlm_d4 c4 = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cs[h0 + 16 + li][h0 + kk + lk], Iv[h0 + kk + lk][h0 + li], c4, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[w][lk + 4 * r][li] = c4[r];
+    }
+    __syncthreads();
+    if (w < 2) {
+      const int h0 = PVLM_CHOL_NB * w;
+      pvlm_d4 c4 = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[h0 + 16 + li][h0 + 16 + kk + lk], Ts[w][kk + lk][li], c4, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { Iv[h0 + 16 + lk + 4 * r][h0 + li] = -c4[r]; Iv[h0 + lk + 4 * r][h0 + 16 + li] = 0.0; }
+    }
+    __syncthreads();
     {
       // inv21 = -inv22 (L21 inv11), a 16 x 16 block per wave on the matrix core: tmp = L21 inv11 into the upper right quarter of Cs (free: zeros above the diagonal),
       // then the product into Iv's lower left quarter.  (As loops of 32 over LDS per thread the two products took 9.7 us of the 34 of a diagonal tile.)
@@ -851,7 +888,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
         c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[PVLM_CHOL_NB + 16 * bm + li][PVLM_CHOL_NB + kk + lk], Cs[kk + lk][PVLM_CHOL_NB + 16 * bn + li], c4, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) { Iv[PVLM_CHOL_NB + 16 * bm + lk + 4 * r][16 * bn + li] = -c4[r]; Iv[16 * bm + lk + 4 * r][PVLM_CHOL_NB + 16 * bn + li] = 0.0; }
-      // the upper triangles of the two diagonal blocks of Iv: lane c of the chain wrote x[q] = 0 for q < c — complete
+      // the upper triangles of the 16 x 16 diagonal blocks of Iv: lane c wrote x[q] = 0 for q < c — complete
       __syncthreads();
     }
     if (stamp) clk[12 * j + 4] = wall_clock64();
