@@ -1202,6 +1202,18 @@ static pvlm_status ws_reserve(pvlm_ctx* ctx, size_t bytes) {
 }
 static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// Only the tiles the one-launch factorisation reads have to start from zero — the tiles of its task list, 170 MB of the 1.16 GB of the padded Floor matrix (the
+// assembly also adds mirrored blocks into tiles above the diagonal, which nobody reads).  A workgroup per task; chunk tasks name a tile a second time and return.
+__global__ __launch_bounds__(256) void k_zero_flow_tiles(double* __restrict__ M, int n, const NdFlowTask* __restrict__ tasks) {
+  const NdFlowTask tk = tasks[blockIdx.x];
+  if (!tk.final_) return;
+  double2* row0 = reinterpret_cast<double2*>(M + (size_t)(64 * tk.I) * n + 64 * tk.J);
+  const int r = threadIdx.x >> 2, c = threadIdx.x & 3;                  // 64 rows x 4 threads, 8 double2 each (n is a multiple of 64: 16-byte aligned)
+  double2* p = row0 + (size_t)r * (n / 2) + c;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) p[4 * q] = make_double2(0.0, 0.0);
+}
+
 // ---- tile-sparse plan of pvlm_spd_solve_blocks ------------------------------------------------------------------------------------
 // The reduced pose system of a Floor-sized run (1593 scans, 9558 unknowns) is block-sparse: 15 neighbours per scan.  Factorised as a
 // dense matrix it cost 39.6 ms per LM step and 46 % of the whole EstimatePose call (profiles/r3_floor_like_1593.txt); the reference
@@ -1537,7 +1549,9 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   int* d_info = ws.take<int>(1);
   if (!st) {
     hipStream_t s = ctx->stream;
-    hipError_t e = hipMemsetAsync(d_M, 0, (size_t)n * n * sizeof(double), s);
+    hipError_t e = hipSuccess;
+    if (plan->levels && plan->flow_T > 0) hipLaunchKernelGGL(k_zero_flow_tiles, dim3((unsigned)plan->flow_tasks), dim3(256), 0, s, d_M, n, (const NdFlowTask*)plan->d_flow_tasks);
+    else e = hipMemsetAsync(d_M, 0, (size_t)n * n * sizeof(double), s);
     // through the pinned arena (1.3 MB of blocks at Room scale, once per LM step: a pageable copy locks the caller's pages)
     if (e == hipSuccess && n_blocks) {
       st = pvlm_i_h2d_q(ctx, d_blocks, blocks, (size_t)n_blocks * 36 * sizeof(double));
