@@ -652,15 +652,24 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = (pvlm_d4){0.0, 0.0, 0.0, 0.0};
     double bacc = 0.0;                                               // diagonal tiles, threads 0..63: (sum_k L(j,k) y_k)[t]
+    // thread 0 looks at the flags of source q + 1 while source q is loaded and multiplied (two dependent round trips of ~1 us per source otherwise — a third of a
+    // source step, and the launch is throughput-bound for its first half); a flag seen raised is final, one not yet raised is waited for as before
+    unsigned seen_a = 0u, seen_b = 0u;
     for (int q_src = 0; q_src < n_src; ++q_src) {
       int k = q_src, flag_a = i * T + q_src, flag_b = j * T + q_src;
       if (LISTS) { const NdFlowSource sr = sources[src_off + q_src]; k = sr.K; flag_a = sr.task_a; flag_b = sr.task_b; }
       if (t == 0) {
-        bool ok = tail_wait(tile_flag + flag_a, info);
-        if (ok && !diag) ok = tail_wait(tile_flag + flag_b, info);
-        if (ok && diag) ok = tail_wait(y_flag + k, info);
+        bool ok = seen_a != 0u || tail_wait(tile_flag + flag_a, info);
+        if (ok && seen_b == 0u) ok = tail_wait(diag ? y_flag + k : tile_flag + flag_b, info);
         s_ok = ok ? 1 : 0;
         if (stamp && diag && final_task && q_src == n_src - 1) clk[12 * j + 1] = wall_clock64();
+        seen_a = seen_b = 0u;
+        if (ok && q_src + 1 < n_src) {
+          int k1 = q_src + 1, fa1 = i * T + q_src + 1, fb1 = j * T + q_src + 1;
+          if (LISTS) { const NdFlowSource s1 = sources[src_off + q_src + 1]; k1 = s1.K; fa1 = s1.task_a; fb1 = s1.task_b; }
+          seen_a = __hip_atomic_load((pvlm_gu32*)(tile_flag + fa1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          seen_b = __hip_atomic_load((pvlm_gu32*)(diag ? y_flag + k1 : tile_flag + fb1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       __syncthreads();
       if (!s_ok) return;
