@@ -293,6 +293,16 @@ pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_
  * done that way (0: none — PVLM_SPD_TAIL=0, no level schedule, or a short separator), *launched_levels = the levels that still run launch by launch.  Bit-reproducible
  * like the levels; last-bit differences against PVLM_SPD_TAIL=0 (another order of the same sums).  Any pointer may be NULL. */
 pvlm_status pvlm_spd_plan_tail(const pvlm_ctx* ctx, int* tail_block_columns, int* launched_levels);
+/* ONE LAUNCH for the whole tile-sparse factorisation (the default with a level schedule): every 64 x 64 tile of the factor is a task (its sources = the earlier tile
+ * columns that hold both tiles; the sources of a tile that exist two levels ahead of it are split off into chunk tasks that subtract them from the tile in memory as
+ * soon as they exist), tasks are ordered by dependency depth, workgroups take them by a ticket and hand finished tiles to each other inside the launch (payload stored
+ * write-through, one flag per task); the forward substitution rides along and the backward substitution is a second launch over the tile columns.  Floor system: 278
+ * dependent launches -> 2, 7.1 -> 3.4 ms per solve.  pvlm_spd_plan_tail then reports every block column as done inside one launch (launched_levels 0).
+ * The workgroups of such a launch WAIT for each other, which presumes that the launch gets the GPU's workgroup slots: processes that share one GPU should switch it off
+ * (enable = 0: level launches + the dense tail; enable < 0: no change, query only).  A solve whose launch does not get through within 2 s is redone with the level
+ * launches by itself, the context keeps them from then on, and *fallbacks (may be NULL) counts such solves.  Both forms are bit-reproducible; they differ from each
+ * other in the last bits (another order of the same sums) — ranks that must agree bit for bit use the same form. */
+pvlm_status pvlm_spd_one_launch(pvlm_ctx* ctx, int enable, long long* fallbacks);
 
 /* ---- multi-GPU exchange (RCCL over xGMI) -------------------------------------------------------- *
  * The reference is single-process (OpenMP only); sharding scan pairs across GPUs introduces exactly one

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
     "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
-    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_tail", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_line_grow_batch", "pvlm_line_grow_begin", "pvlm_line_grow_finish", "pvlm_line_grow_scan", "pvlm_line_grow_destroy", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
+    "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_tail", "pvlm_spd_one_launch", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_line_grow_batch", "pvlm_line_grow_begin", "pvlm_line_grow_finish", "pvlm_line_grow_scan", "pvlm_line_grow_destroy", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
 
 
@@ -322,6 +322,13 @@ class Context:
         h = C.c_longlong()
         self._check(self.lib.pvlm_spd_plan_prefetch_hits(self._h, C.byref(h)), "pvlm_spd_plan_prefetch_hits")
         return h.value
+
+    def spd_one_launch(self, enable=None):
+        """pvlm_spd_one_launch: enable / disable the one-launch form of the tile-sparse factorisation (None: query only); returns the number of solves this context has
+        redone with the level launches."""
+        fb = C.c_longlong()
+        self._check(self.lib.pvlm_spd_one_launch(self._h, C.c_int(-1 if enable is None else int(bool(enable))), C.byref(fb)), "pvlm_spd_one_launch")
+        return fb.value
 
     def spd_plan(self):
         """How the last spd_solve_blocks structure is factorised: tile_sparse, update_fraction (pvlm_spd_plan_info) and the schedule (pvlm_spd_plan_schedule):

@@ -910,17 +910,31 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
   hipError_t e = hipSuccess;
   size_t first_seg = 0;
   pvlm_i_trace("scan_upload_batch: segment lists");
+  // a window goes down in PIECES (PVLM_UPLOAD_PIECE_MB, default 8): the copy of a piece is queued as soon as the host threads have staged it and runs while they stage
+  // the next one (staging at ~14 GB/s of host copy bandwidth and the link at ~55 GB/s used to take turns: 15 + 8 ms of a Floor-sized upload)
+  size_t piece = (size_t)8 << 20;
+  if (const char* env = getenv("PVLM_UPLOAD_PIECE_MB")) if (atof(env) > 0) piece = (size_t)(atof(env) * 1048576.0);
+  piece = align(std::max<size_t>(piece, 4096));
   for (size_t lo = 0; lo < up_bytes && e == hipSuccess; lo += ctx->up_bytes) {
     const size_t hi = std::min(up_bytes, lo + ctx->up_bytes);
-    if (lo > 0) e = hipStreamSynchronize(ctx->stream);            // the window is refilled: the previous copy must have left it
-    while (first_seg < segs.size() && segs[first_seg].off + segs[first_seg].bytes <= lo) ++first_seg;
-    size_t last_seg = first_seg;
-    while (last_seg < segs.size() && segs[last_seg].off < hi) ++last_seg;
-    auto stage = [&](size_t q) {
-      const size_t a = std::max(segs[q].off, lo), b = std::min(segs[q].off + segs[q].bytes, hi);
+    if (lo > 0) e = hipStreamSynchronize(ctx->stream);            // the window is refilled: the previous copies must have left it
+    // the pieces of this window and, per piece, the segments that reach into it
+    struct Piece { size_t pa, pb, first, last, item0; };
+    std::vector<Piece> pieces;
+    size_t n_items = 0;
+    for (size_t pa = lo; pa < hi; pa += piece) {
+      const size_t pb = std::min(hi, pa + piece);
+      while (first_seg < segs.size() && segs[first_seg].off + segs[first_seg].bytes <= pa) ++first_seg;
+      size_t last_seg = first_seg;
+      while (last_seg < segs.size() && segs[last_seg].off < pb) ++last_seg;
+      pieces.push_back(Piece{pa, pb, first_seg, last_seg, n_items});
+      n_items += last_seg - first_seg;
+    }
+    auto stage = [&](size_t q, size_t pa, size_t pb) {
+      const size_t a = std::max(segs[q].off, pa), b = std::min(segs[q].off + segs[q].bytes, pb);
       if (b <= a) return;
       if (!segs[q].elem) { std::memcpy(h + (a - lo), (const char*)segs[q].src + (a - segs[q].off), b - a); return; }
-      // strided records (pcl::PointXYZI-style arrays): a window boundary may fall inside a record — the (at most two) cut records byte by byte, the whole
+      // strided records (pcl::PointXYZI-style arrays): a piece boundary may fall inside a record — the (at most two) cut records byte by byte, the whole
       // records between them in a loop of fixed-size copies without a division per record (round 6: 24 -> 6 ms of a Floor-sized upload were this gather)
       const size_t el = segs[q].elem, sd = segs[q].stride;
       const char* src = (const char*)segs[q].src;
@@ -944,13 +958,39 @@ static pvlm_status scan_upload_batch_impl(pvlm_ctx* ctx, int n_scans, const pvlm
       p = first_whole + n_whole * el;
       partial(b);
     };
-    {   // the segments land in disjoint ranges of the pinned window: copied side by side (one core moves ~10 GB/s, the window is up to 64 MB)
-      const size_t n_threads = (hi - lo) < ((size_t)8 << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)8, (last_seg - first_seg) / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
-      std::atomic<size_t> next{first_seg};
-      auto work = [&]() { for (size_t q = next++; q < last_seg; q = next++) stage(q); };
-      pvlm_run_workers(n_threads, work);
+    const size_t n_threads = (hi - lo) < ((size_t)8 << 20) ? 1 : std::max<size_t>(1, std::min<size_t>({(size_t)8, n_items / 64 + 1, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    if (n_threads == 1) {
+      for (const Piece& pc : pieces) {
+        for (size_t q = pc.first; q < pc.last; ++q) stage(q, pc.pa, pc.pb);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_slab + pc.pa, h + (pc.pa - lo), pc.pb - pc.pa, hipMemcpyHostToDevice, ctx->stream);
+      }
+    } else {
+      // ONE set of threads for the window: they take (piece, segment) items in order from a counter; the calling thread queues the copy of a piece when its last item
+      // is done (the segments land in disjoint ranges of the pinned window; one core moves ~10 GB/s)
+      std::vector<std::atomic<size_t>> done(pieces.size());
+      for (auto& d : done) d.store(0, std::memory_order_relaxed);
+      std::atomic<size_t> next{0};
+      std::atomic<bool> failed{false};
+      auto work = [&]() {
+        size_t pi = 0;
+        for (size_t it = next++; it < n_items; it = next++) {
+          while (pi + 1 < pieces.size() && pieces[pi + 1].item0 <= it) ++pi;
+          const Piece& pc = pieces[pi];
+          try { stage(pc.first + (it - pc.item0), pc.pa, pc.pb); } catch (...) { failed.store(true); }
+          done[pi].fetch_add(1, std::memory_order_release);
+        }
+      };
+      std::vector<std::thread> pool;
+      try { pool.reserve(n_threads); for (size_t t = 0; t < n_threads; ++t) pool.emplace_back(work); } catch (...) {}
+      if (pool.empty()) work();                                   // no thread to be had: the calling thread stages everything
+      for (size_t pi = 0; pi < pieces.size(); ++pi) {
+        const Piece& pc = pieces[pi];
+        while (done[pi].load(std::memory_order_acquire) < pc.last - pc.first) std::this_thread::yield();
+        if (e == hipSuccess) e = hipMemcpyAsync(d_slab + pc.pa, h + (pc.pa - lo), pc.pb - pc.pa, hipMemcpyHostToDevice, ctx->stream);
+      }
+      for (std::thread& t : pool) t.join();
+      if (failed.load() && e == hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: staging failed"); return bail(PVLM_ERR_HIP); }
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_slab + lo, h, hi - lo, hipMemcpyHostToDevice, ctx->stream);
   }
   if (e != hipSuccess) { PVLM_SET_ERR(ctx, "scan upload: copy failed: %s", hipGetErrorString(e)); return bail(PVLM_ERR_HIP); }
   std::vector<GridJob> jobs;

@@ -574,14 +574,34 @@ __device__ __forceinline__ double tail_ld(const double* p) {
 __device__ __forceinline__ void tail_st(double* p, double v) {
   __hip_atomic_store((pvlm_gu64*)(unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// thread 0 of the workgroup: waits until *flag != 0; false when the solve has failed elsewhere (info != 0) or nothing came for seconds (info := -1)
-__device__ __forceinline__ bool tail_wait(unsigned* flag, int* info) {
+// thread 0 of the workgroup: waits until *flag != 0; false when the solve has failed elsewhere (info != 0) or nothing came for 2 s of wall clock (info := -1: the host redoes the solve with the level launches).
+// A launch that has the GPU to itself waits for milliseconds at most (the work of the tasks before this one).  With 8 processes factorising on ONE GPU at the same
+// time about 1 solve in 300 did run into the limit on some boxes of the pool and on others never (limits of 1 s and of 20 s alike: a task that had its ticket never
+// published; not reproduced with one process) — workgroups that wait hold the compute units the ones that work need, and the one-launch form is not meant for a
+// shared GPU: pvlm_spd_one_launch(ctx, 0) selects the level launches, and a solve that meets the limit is redone with them by itself.
+// Long waits back off (s_sleep up to ~3 us) so that the workgroups that wait leave the memory system to the ones that work.
+__device__ unsigned g_wg_state[1024 * 2];     // debug: per workgroup of k_nd_flow {task, phase | source index << 8}
+#define WG_STATE(task, phase) do { if (LISTS && threadIdx.x == 0 && blockIdx.x < 1024) { g_wg_state[2 * blockIdx.x] = (unsigned)(task); g_wg_state[2 * blockIdx.x + 1] = (unsigned)(phase); } } while (0)
+__device__ unsigned g_tail_timeout[8];        // the first wait of a process that ran into the limit: [0] marker, [1] site, [2] own task / ticket, [3] awaited flag word, [4..5] the two ticket counters, [6] workgroup
+__device__ __forceinline__ bool tail_wait(unsigned* flag, int* info, const unsigned* flags = nullptr, int site = 0, int own = 0) {
   unsigned spins = 0;
+  unsigned long long t0 = 0;
   while (__hip_atomic_load((pvlm_gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-    __builtin_amdgcn_s_sleep(1);
+    if (spins < 256u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(127);
     if ((++spins & 63u) == 0u) {
       if (__hip_atomic_load((pvlm_gu32*)(unsigned*)info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-      if (spins > (1u << 21)) { __hip_atomic_store((pvlm_gu32*)(unsigned*)info, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+      const unsigned long long now = wall_clock64();              // 100 MHz
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > 200000000ull) {
+        if (flags && atomicCAS(&g_tail_timeout[0], 0u, 1u) == 0u) {
+          g_tail_timeout[1] = (unsigned)site; g_tail_timeout[2] = (unsigned)own; g_tail_timeout[3] = (unsigned)(flag - flags);
+          g_tail_timeout[4] = __hip_atomic_load((pvlm_gu32*)flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g_tail_timeout[5] = __hip_atomic_load((pvlm_gu32*)(flags + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g_tail_timeout[6] = blockIdx.x;
+        }
+        __hip_atomic_store((pvlm_gu32*)(unsigned*)info, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
     }
   }
   return true;
@@ -644,6 +664,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
       i = j + id; n_src = j;
     }
     const int my_flag = LISTS ? s_id : i * T + j;
+    WG_STATE(s_id, 1);
     const bool diag = i == j;
     const size_t row_i = (size_t)(r0 + 64 * i), row_j = (size_t)(r0 + 64 * j);
     const bool stamp = clk && t == 0;
@@ -658,9 +679,10 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
     for (int q_src = 0; q_src < n_src; ++q_src) {
       int k = q_src, flag_a = i * T + q_src, flag_b = j * T + q_src;
       if (LISTS) { const NdFlowSource sr = sources[src_off + q_src]; k = sr.K; flag_a = sr.task_a; flag_b = sr.task_b; }
+      WG_STATE(s_id, 1 | (q_src << 8));
       if (t == 0) {
-        bool ok = seen_a != 0u || tail_wait(tile_flag + flag_a, info);
-        if (ok && seen_b == 0u) ok = tail_wait(diag ? y_flag + k : tile_flag + flag_b, info);
+        bool ok = seen_a != 0u || tail_wait(tile_flag + flag_a, info, flags, 1, s_id);
+        if (ok && seen_b == 0u) ok = tail_wait(diag ? y_flag + k : tile_flag + flag_b, info, flags, diag ? 2 : 3, s_id);
         s_ok = ok ? 1 : 0;
         if (stamp && diag && final_task && q_src == n_src - 1) clk[12 * j + 1] = wall_clock64();
         seen_a = seen_b = 0u;
@@ -712,8 +734,9 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
     double cv[4][4];
     if (LISTS) {
       // the tile may hold the partial sums of a chunk task (another workgroup, this launch): wait for the last of them, read through the agent-scope path
+      WG_STATE(s_id, 2);
       if (prev >= 0) {
-        if (t == 0) s_ok = tail_wait(tile_flag + prev, info) ? 1 : 0;
+        if (t == 0) s_ok = tail_wait(tile_flag + prev, info, flags, 4, s_id) ? 1 : 0;
         __syncthreads();
         if (!s_ok) return;
       }
@@ -721,6 +744,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cv[q][r] = tail_ld(M + (row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li);
+      WG_STATE(s_id, 3);
       if (!final_task) {
         // a chunk: the tile in memory minus this chunk's products (and b_j minus its share of the forward substitution), published for the next task of the tile
 #pragma unroll
@@ -748,7 +772,8 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
         Cs[rr][cc] = (!diag || cc <= rr) ? cv[q][r] - acc[q][r] : 0.0;
       }
     if (!diag) {
-      if (t == 0) s_ok = tail_wait(inv_flag + j, info) ? 1 : 0;
+      WG_STATE(s_id, 4);
+      if (t == 0) s_ok = tail_wait(inv_flag + j, info, flags, 5, s_id) ? 1 : 0;
       if (stamp && (LISTS ? (s_id > 0 && tasks[s_id - 1].I == j && tasks[s_id - 1].J == j) : i == j + 1)) clk[12 * j + 6] = wall_clock64();
       __syncthreads();
       if (!s_ok) return;
@@ -774,10 +799,12 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
       tail_drain();
       __syncthreads();
       if (t == 0) tail_raise(tile_flag + my_flag);
+      WG_STATE(s_id, 9);
       if (stamp && (LISTS ? (s_id > 0 && tasks[s_id - 1].I == j && tasks[s_id - 1].J == j) : i == j + 1)) clk[12 * j + 7] = wall_clock64();
       continue;
     }
     // ---- the diagonal tile: Cs (lower triangle, zeros above) -> L and L^-1, 32 columns at a time
+    WG_STATE(s_id, 6);
     __syncthreads();
     if (stamp) clk[12 * j + 3] = wall_clock64();
 #pragma unroll 1
@@ -919,6 +946,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
     tail_drain();
     __syncthreads();
     if (t == 0) tail_raise(y_flag + j);
+    WG_STATE(s_id, 10);
   }
 }
 __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
@@ -971,7 +999,7 @@ __device__ __forceinline__ void nd_tile_bwd(const double* __restrict__ M, int n,
 #pragma unroll
       for (int q = 0; q < 16; ++q) mn[q] = M[((size_t)(r0 + 64 * i1) + 16 * rg + q) * n + col_j + c];
     }
-    if (t == 0) s_ok = tail_wait(x_flag + i, info) ? 1 : 0;
+    if (t == 0) s_ok = tail_wait(x_flag + i, info, flags, 6, s_id) ? 1 : 0;
     __syncthreads();
     if (!s_ok) return;
     if (t < 64) xs[t] = tail_ld(b + r0 + 64 * i + t);
@@ -1250,6 +1278,7 @@ struct SpdPlan {
   double* d_tail_inv = nullptr; unsigned* d_tail_flags = nullptr;
   // the whole factorisation as the tasks of one launch (k_nd_flow / k_nd_flow_bwd, pvlm_spd::plan_flow); flow_T = 0: levels (+ tail)
   int flow_T = 0, flow_tasks = 0, flow_depth = 0;
+  bool flow_possible = false;                       // the host plan had a task list (whether or not this plan uses it: pvlm_spd_one_launch)
   NdFlowTask* d_flow_tasks = nullptr; NdFlowSource* d_flow_sources = nullptr; int* d_flow_cols = nullptr; int* d_flow_below_off = nullptr; int* d_flow_below = nullptr;
 };
 
@@ -1354,8 +1383,9 @@ static pvlm_status spd_plan_adopt(pvlm_ctx* ctx, int n, SpdHostPlan& H, SpdPlan*
     P->n_main = L.levels; P->tail_T = 0;
     // one launch for the whole factorisation (PVLM_SPD_FLOW=0: the level launches, with the dense tail below)
     static const bool want_flow = !(getenv("PVLM_SPD_FLOW") && atoi(getenv("PVLM_SPD_FLOW")) == 0);
+    P->flow_possible = want_flow && L.flow.ready && L.flow.tile_cols >= 2 && L.flow.tile_cols <= 4096;
     static_assert(sizeof(pvlm_spd::FlowTask) == sizeof(NdFlowTask) && sizeof(pvlm_spd::FlowSource) == sizeof(NdFlowSource), "flow lists are uploaded as they are");
-    if (want_flow && L.flow.ready && L.flow.tile_cols >= 2 && L.flow.tile_cols <= 4096) {
+    if (want_flow && ctx->spd_one_launch && L.flow.ready && L.flow.tile_cols >= 2 && L.flow.tile_cols <= 4096) {
       const pvlm_spd::FlowPlan& F = L.flow;
       up((void**)&P->d_flow_tasks, F.tasks.data(), F.tasks.size() * sizeof(NdFlowTask));
       up((void**)&P->d_flow_sources, F.sources.data(), F.sources.size() * sizeof(NdFlowSource));
@@ -1479,6 +1509,7 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
   *info_out = 0;
   if (n == 0) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const int* const user_rows = row_idx; const int* const user_cols = col_idx; const double* const user_scale = scale; const double* const user_diag = diag_add;
   // the plan of this structure (ordering + tile lists), built once and reused while the index lists stay the same
   SpdPlan* plan = static_cast<SpdPlan*>(ctx->spd_plan);
   std::vector<int> prow, pcol;
@@ -1487,7 +1518,7 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     const unsigned long long key = spd_hash(n, n_blocks, row_idx, col_idx, mirror);
     // a hit needs the SAME index lists, not only the same 64-bit hash: with a colliding structure the tile lists of the old one would skip the new
     // one's non-zeros and the solve would be wrong with info = 0 (three memcmp of ~100 KB at Floor size against a 10 ms solve)
-    const bool same = plan && plan->key == key && plan->n == n && plan->key_rows.size() == (size_t)n_blocks * 6 && plan->key_mirror.size() == (size_t)n_blocks &&
+    const bool same = plan && plan->key == key && plan->n == n && (!plan->levels || (plan->flow_T > 0) == (ctx->spd_one_launch != 0 && plan->flow_possible)) && plan->key_rows.size() == (size_t)n_blocks * 6 && plan->key_mirror.size() == (size_t)n_blocks &&
                       std::memcmp(plan->key_rows.data(), row_idx, (size_t)n_blocks * 6 * sizeof(int)) == 0 &&
                       std::memcmp(plan->key_cols.data(), col_idx, (size_t)n_blocks * 6 * sizeof(int)) == 0 &&
                       std::memcmp(plan->key_mirror.data(), mirror, (size_t)n_blocks * sizeof(int)) == 0;
@@ -1587,6 +1618,36 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     if (!st) st = pvlm_i_d2h_q(ctx, &info, d_info, sizeof(int));
     if (!st) st = pvlm_i_d2h_q(ctx, rhs_io, d_rhs, (size_t)n * sizeof(double));
     { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+    if (!st && info == -1) {                       // a wait inside the one-launch factorisation ran into its limit: say where (the step is reported as failed)
+      unsigned w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_tail_timeout), sizeof w) == hipSuccess)
+      {
+        fprintf(stderr, "pvlm_spd_solve_blocks: a wait of the one-launch factorisation ran into its limit (site %u, task / ticket %u, flag word %u of %d tasks + 3 x %d, tickets %u / %u, workgroup %u)\n",
+                w[1], w[2], w[3], plan->flow_tasks, plan->flow_T, w[4], w[5], w[6]);
+        std::vector<unsigned> wg(2048, 0);
+        if (getenv("PVLM_SPD_FLOW_DEBUG") && hipMemcpyFromSymbol(wg.data(), HIP_SYMBOL(g_wg_state), wg.size() * 4) == hipSuccess) {
+          std::vector<NdFlowTask> tk((size_t)plan->flow_tasks);
+          (void)hipMemcpy(tk.data(), plan->d_flow_tasks, tk.size() * sizeof(NdFlowTask), hipMemcpyDeviceToHost);
+          std::vector<unsigned> fl((size_t)2 + tk.size() + 3 * (size_t)plan->flow_T);
+          (void)hipMemcpy(fl.data(), plan->d_tail_flags, fl.size() * 4, hipMemcpyDeviceToHost);
+          for (int g = 0; g < 1024; ++g) {
+            const unsigned task = wg[2 * g], ph = wg[2 * g + 1];
+            if ((ph & 255u) >= 9u || task >= tk.size()) continue;
+            const NdFlowTask& q = tk[task];
+            fprintf(stderr, "  wg %4d task %6u (I %3d J %3d n_src %3d prev %6d final %d) phase %u source %u | own flag %u prev flag %d inv flag %u\n", g, task, q.I, q.J, q.n_src, q.prev, q.final_,
+                    ph & 255u, ph >> 8, fl[2 + task], q.prev >= 0 ? (int)fl[2 + (size_t)q.prev] : -1, fl[2 + tk.size() + (size_t)q.J]);
+          }
+        }
+      }
+      else (void)hipGetLastError();
+    }
+    if (!st && info == -1 && plan->levels && plan->flow_T > 0) {
+      // Not a property of the matrix: the launch did not get through (see tail_wait).  This context factorises by level launches from here on and this solve is
+      // redone with them — same inputs (the caller's right-hand side has not been touched yet), a deterministic result again.
+      ctx->spd_one_launch = 0; ctx->spd_fallbacks += 1;
+      fprintf(stderr, "pvlm_spd_solve_blocks: redone with the level launches; this context keeps them (pvlm_spd_one_launch)\n");
+      return pvlm_spd_solve_blocks(ctx, n_user, n_blocks, user_rows, user_cols, mirror, blocks, user_scale, user_diag, rhs, info_out);
+    }
     pvlm_i_trace("spd solve: factorised and solved");
     if (!st && plan->sparse) for (int i = 0; i < n_user; ++i) rhs[i] = prhs[(size_t)plan->new_of_old[(size_t)i]];
     *info_out = info;
@@ -1640,6 +1701,13 @@ pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_
   if (levels) *levels = lv ? p->n_levels : 0;
   if (block_columns) *block_columns = lv ? p->n_pad / PVLM_CHOL_NB : (p ? (p->n + PVLM_CHOL_NB - 1) / PVLM_CHOL_NB : 0);
   if (padded_rows) *padded_rows = lv ? p->n_pad : (p ? p->n : 0);
+  return PVLM_OK;
+}
+
+pvlm_status pvlm_spd_one_launch(pvlm_ctx* ctx, int enable, long long* fallbacks) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (enable >= 0) ctx->spd_one_launch = enable ? 1 : 0;
+  if (fallbacks) *fallbacks = ctx->spd_fallbacks;
   return PVLM_OK;
 }
 

@@ -720,6 +720,8 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     });
     return q;
   };
+  std::vector<int> chol_rows, chol_cols, chol_mirror; std::vector<double> chol_blocks;     // block lists of the GPU Cholesky (see below)
+  unsigned long long chol_key_hash = 0;
   while (iter < opt.max_num_iterations) {
     ++iter;
     if (!R_valid) { bundle_reduce(x, radius, false, R); R_valid = true; }
@@ -738,16 +740,40 @@ void Solve(const Solver::Options& opt, Problem* problem, Solver::Summary* summar
     if (gpu_chol) {
       StageTimer stage_timer_chol_("solve: GPU Cholesky");
       StageTimer* stage_timer_push_ = new StageTimer("  (inside the GPU Cholesky stage) host block list");
-      std::vector<int> rows, cols, mirror; std::vector<double> blocks;
+      // the index lists depend on the structure only: made by the first step of the Solve, checked (block count) and reused by the others — only the values move
+      std::vector<int>& rows = chol_rows; std::vector<int>& cols = chol_cols; std::vector<int>& mirror = chol_mirror; std::vector<double>& blocks = chol_blocks;
+      size_t n_pushed = 0;
+      unsigned long long key_hash = 1469598103934665603ull;          // of the block keys in push order: the reused lists must belong to exactly this sequence
+      const bool have_lists = !mirror.empty();
+      blocks.clear();
       auto push = [&](const auto& H) {
         ForEachBlock(H, [&](const std::pair<int, int>& key, const double* blk) {
-          for (int r = 0; r < 6; ++r) { rows.push_back(idx(key.first, r)); cols.push_back(idx(key.second, r)); }
-          mirror.push_back(key.first != key.second ? 1 : 0);
+          if (!have_lists) {
+            for (int r = 0; r < 6; ++r) { rows.push_back(idx(key.first, r)); cols.push_back(idx(key.second, r)); }
+            mirror.push_back(key.first != key.second ? 1 : 0);
+          }
           blocks.insert(blocks.end(), blk, blk + 36);
+          key_hash = (key_hash ^ (unsigned long long)(unsigned)key.first) * 1099511628211ull;
+          key_hash = (key_hash ^ (unsigned long long)(unsigned)key.second) * 1099511628211ull;
+          ++n_pushed;
         });
       };
       push(A);
       if (have_bundles) push(R.H);
+      if (!have_lists) chol_key_hash = key_hash;
+      if (have_lists && (n_pushed != mirror.size() || key_hash != chol_key_hash)) {               // never seen (the structure of a Solve is fixed); rebuilt rather than trusted
+        rows.clear(); cols.clear(); mirror.clear(); blocks.clear(); n_pushed = 0;
+        auto push_all = [&](const auto& H) {
+          ForEachBlock(H, [&](const std::pair<int, int>& key, const double* blk) {
+            for (int r = 0; r < 6; ++r) { rows.push_back(idx(key.first, r)); cols.push_back(idx(key.second, r)); }
+            mirror.push_back(key.first != key.second ? 1 : 0);
+            blocks.insert(blocks.end(), blk, blk + 36);
+          });
+        };
+        push_all(A);
+        if (have_bundles) push_all(R.H);
+        chol_key_hash = key_hash;
+      }
       delete stage_timer_push_;
       int info = 0;
       long long hits_before = 0, hits_after = 0;
@@ -909,6 +935,10 @@ std::pair<size_t, size_t> Exchange::BalancedRange(const std::vector<double>& wei
 
 Exchange MakeFileExchange(int world, int rank, const std::string& dir) {
   auto seq = std::make_shared<long>(0);
+  // The ranks of a file exchange are processes on ONE machine that usually share ONE GPU (the functional check of the sharded path where no second GPU exists): the
+  // pose solve by level launches for them — the one-launch form's workgroups wait for each other and want the GPU's workgroup slots to themselves (pvlm_spd_one_launch),
+  // and every rank has to take the same form for the ranks to agree bit for bit.  One process per GPU (MakeRcclExchange) keeps the default.
+  if (world > 1) { Engine& en = Engine::Default(); en.Check(pvlm_spd_one_launch(en.ctx(), 0, nullptr), "pvlm_spd_one_launch"); }
   Exchange x; x.world = world; x.rank = rank;
   x.allreduce_sum = [world, rank, dir, seq](double* buf, size_t count) {
     const long s = (*seq)++;
@@ -928,7 +958,11 @@ Exchange MakeFileExchange(int world, int rank, const std::string& dir) {
       for (int spin = 0; spin < 1200000 && !(f = fopen(name(s, r).c_str(), "rb")); ++spin) std::this_thread::sleep_for(std::chrono::microseconds(100));
       if (!f) throw std::runtime_error("file exchange: rank " + std::to_string(r) + " never arrived at exchange " + std::to_string(s));
       uint64_t n = 0;
-      if (fread(&n, sizeof(n), 1, f) != 1 || n != count || fread(part.data(), sizeof(double), count, f) != count) { fclose(f); throw std::runtime_error("file exchange: size mismatch between ranks"); }
+      if (fread(&n, sizeof(n), 1, f) != 1 || n != count || fread(part.data(), sizeof(double), count, f) != count) {
+        fclose(f);
+        throw std::runtime_error("file exchange: size mismatch between ranks (exchange " + std::to_string(s) + ": rank " + std::to_string(r) + " wrote " + std::to_string((unsigned long long)n) +
+                                 " doubles, rank " + std::to_string(rank) + " expects " + std::to_string((unsigned long long)count) + ")");
+      }
       fclose(f);
       for (size_t i = 0; i < count; ++i) sum[i] += part[i];
     }

@@ -234,6 +234,16 @@ def test_factorisation_in_one_launch_and_the_dense_tail(P, degree):
     assert last > plan["padded_rows"] // 2, "none of the broken diagonals fell into the second half of the order"
     x3, info3 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)      # and the context is as good as before
     assert info3 == 0 and np.array_equal(x, x3)
+    # pvlm_spd_one_launch: the switch of a context (what ranks sharing a GPU use); the plan of the same structure is made again for the other form; no solve here had
+    # to be redone
+    assert ctx.spd_one_launch(False) == 0
+    x4, info4 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    plan4 = ctx.spd_plan()
+    assert info4 == 0 and plan4["launched_levels"] > 0 and plan4["launched_levels"] + plan4["tail_block_columns"] == plan4["levels"], plan4
+    assert np.abs(x4 - x).max() <= 1e-11 * max(1.0, np.abs(x).max())
+    assert ctx.spd_one_launch(True) == 0
+    x5, info5 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert info5 == 0 and np.array_equal(x5, x) and ctx.spd_plan()["launched_levels"] == 0
     ctx.close()
     args = (n, rows, cols, mirror, blocks, scale, diag, rhs)
     x_t, info_t, plan_t, same_t = _solve_in_child(args, {"PVLM_SPD_FLOW": "0"})
