@@ -67,7 +67,14 @@ PY
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/spd_trace -- python $R/tools/spd_levels_bench.py --reps 5 > $O/spd_under_rocprof.log 2>&1
   cp $(find $O/spd_trace -name "*kernel_stats.csv" | head -1) $O/r6_spd_levels_kernel_stats.csv
   cd $R
-  { python tools/spd_levels_bench.py --reps 7 | tail -1; PVLM_SPD_LEVELS=0 python tools/spd_levels_bench.py --reps 7 | tail -1; } > $O/r6_spd_levels.txt 2>&1
+  # the one-launch factorisation (default), the level launches with the dense tail, the level launches alone, the column-by-column plan of round 5
+  { python tools/spd_levels_bench.py --reps 9 | tail -1; PVLM_SPD_FLOW=0 python tools/spd_levels_bench.py --reps 9 | tail -1; PVLM_SPD_FLOW=0 PVLM_SPD_TAIL=0 python tools/spd_levels_bench.py --reps 9 | tail -1;
+    PVLM_SPD_LEVELS=0 python tools/spd_levels_bench.py --reps 7 | tail -1; } > $O/r6_spd_levels.txt 2>&1
+  PVLM_SPD_TAIL_CLOCK=1 python tools/spd_levels_bench.py --reps 1 2> $O/r6_spd_flow_clocks.txt > /dev/null
+  cd /tmp
+  PVLM_SPD_FLOW=0 PVLM_SPD_TAIL=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/spd_trace_levels -- python $R/tools/spd_levels_bench.py --reps 5 > $O/spd_levels_under_rocprof.log 2>&1
+  cp $(find $O/spd_trace_levels -name "*kernel_stats.csv" | head -1) $O/r6_spd_level_launches_kernel_stats.csv
+  cd $R
   timeout 600 python tools/mvs_block_bench.py 2> /dev/null | tail -1 > $O/r6_mvs_block.json
   timeout 300 python tools/k8_workload.py 2> /dev/null | tail -1 > $O/r6_k8_block.json
   # scale runs
@@ -76,6 +83,7 @@ PY
   python tools/floor_like_odometry.py --scans 1593 --ranks 2,8 --iters 2 --repeat 5 > $O/r6_floor_like_1593.txt 2>&1
   PVLM_HOST_REUPLOAD=1 python tools/floor_like_odometry.py --scans 1593 --ranks 1 --iters 2 --repeat 3 > $O/r6_floor_like_1593_reupload.txt 2>&1
   PVLM_SPD_LEVELS=0 python tools/floor_like_odometry.py --scans 1593 --ranks 1 --iters 2 --repeat 3 > $O/r6_floor_like_1593_column_by_column.txt 2>&1
+  PVLM_SPD_FLOW=0 PVLM_SPD_TAIL=0 python tools/floor_like_odometry.py --scans 1593 --ranks 1 --iters 2 --repeat 5 > $O/r6_floor_like_1593_level_launches.txt 2>&1
   PVLM_NO_PLAN_PREFETCH=1 python tools/floor_like_odometry.py --scans 1593 --ranks 1 --iters 2 --repeat 5 > $O/r6_floor_like_1593_no_plan_prefetch.txt 2>&1
   python tools/feature_batch_bench.py 454 32 --ab 2>&1 | cut -c1-330 > $O/r6_feature_batch_454.txt
   # K27 (line growth of the feature batch): kernel statistics of one bench run
