@@ -574,6 +574,12 @@ def main():
             features["extract_features_batch"] = extract_features_batch_block()
         except Exception as e:
             features["extract_features_batch"] = {"error": str(e)[:200]}
+    pose_solve = None
+    if rank == 0 and world == 1 and not args.no_mvs:
+        try:
+            pose_solve = pose_solve_block(ctx)
+        except Exception as e:  # reporting extra only
+            pose_solve = {"error": str(e)[:200]}
     mvs = None
     if rank == 0 and world == 1 and not args.no_mvs:
         try:
@@ -649,6 +655,7 @@ def main():
             "panorama": pano,
             "mvs": mvs,
             "features": features,
+            "pose_solve": pose_solve,
             "image_space_all_ranks": image_space,
             "setup": {"scan_generation_s": t_gen, "scans_generated": len(needed)},
         }
@@ -901,6 +908,43 @@ def pcie_block(ctx, pv, associate, ref, nei, args):
     for a in (h_r, h_J, h_w, h_t, h_f):
         ctx.host_free(a)
     return out
+
+
+def pose_solve_block(ctx, scans=1593, reps=9):
+    """K10: the reduced pose system of a Floor-sized EstimatePose (1593 poses, the proximity graph of tools/spd_floor_bench.py: 9 552 unknowns, 17 361 blocks) solved
+    by pvlm_spd_solve_blocks — assembly on the device, nested-dissection factorisation as the tasks of ONE launch, both substitutions.  Wall per solve (median), with
+    the plan cached as it is from the second LM step of a Solve on.  Upstream this is inside ceres::Solve (SPARSE_SCHUR, util/Optimization.cpp:638-666)."""
+    from tools.spd_floor_bench import neighbours
+    rng = np.random.default_rng(3)
+    pairs = set()
+    for i, nb in enumerate(neighbours(scans)):
+        for j in nb:
+            if i != j:
+                pairs.add((min(i, j), max(i, j)))
+    pairs = [(p, p) for p in range(scans)] + sorted(pairs)
+    n = 6 * (scans - 1)
+    off = np.arange(-6, n).reshape(scans, 6); off[0] = -1
+    rows = np.array([off[pa] for pa, pb in pairs], np.int32); cols = np.array([off[pb] for pa, pb in pairs], np.int32)
+    mirror = np.array([int(pa != pb) for pa, pb in pairs], np.int32)
+    blocks = np.empty((len(pairs), 36))
+    for k, (pa, pb) in enumerate(pairs):
+        if pa == pb:
+            J = rng.normal(size=(9, 6)); blocks[k] = (J.T @ J + 30 * np.eye(6)).reshape(-1)
+        else:
+            blocks[k] = (rng.normal(size=(6, 6)) * 0.2).reshape(-1)
+    scale = np.full(n, 0.2); diag = np.full(n, 1.0); rhs = rng.normal(size=n)
+    t0 = time.perf_counter()
+    x, info = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    first = time.perf_counter() - t0
+    walls = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        x, info = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+        walls.append(time.perf_counter() - t0)
+    plan = ctx.spd_plan()
+    return {"poses": scans, "unknowns": n, "blocks": len(pairs), "ms_per_solve": float(np.median(walls) * 1e3), "ms_first_call_with_plan": first * 1e3, "info": int(info),
+            "plan": plan, "form": "one launch (k_nd_flow + k_nd_flow_bwd)" if plan.get("launched_levels") == 0 and plan.get("levels", 0) > 0 else "level launches",
+            "solves_redone_with_level_launches": int(ctx.spd_one_launch()), "ms_per_solve_earlier": {"round 5, column by column": 11.2, "level launches": 7.1}}
 
 
 def mvs_block(ctx, pv):

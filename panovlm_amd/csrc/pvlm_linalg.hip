@@ -627,6 +627,13 @@ __device__ __forceinline__ double row_bcast_f64(double v, int q) {      // q: a 
 // flags: [0] ticket, [1] ticket of the backward launch, [2 + i * T + j] tile (i, j) published, then T words each: inverse of column j, y_j, x_j
 // LISTS (k_nd_flow): the WHOLE factorisation in this form — the tiles are the tasks of pvlm_spd::plan_flow (tile row, tile column, sources = the earlier tile columns
 // that hold both tiles, with the tasks that publish them), r0 = 0, T = tile columns of the padded system; tile flags are indexed by task.
+// Two workgroups of the one-launch factorisation per CU: the inverse of a diagonal tile lives where the second source tile was (72 KB of LDS instead of 105) and the
+// register budget is that of __launch_bounds__(256, 2) (256 registers, 68 bytes of scratch).  The first half of the launch is bound by the traffic of its source tiles
+// and twice the workgroups keep twice the loads in flight: 3.52 -> 3.28 ms per Floor solve.  -DPVLM_FLOW_OCC2=0 (python -m panovlm_amd.build --variant occ1
+// -DPVLM_FLOW_OCC2=0) is the one-workgroup form, kept for the A/B.
+#ifndef PVLM_FLOW_OCC2
+#define PVLM_FLOW_OCC2 1
+#endif
 struct NdFlowTask { int I, J, src_off, n_src, prev, final_, pad0, pad1; };   // pvlm_spd::FlowTask
 struct NdFlowSource { int K, task_a, task_b, pad; };
 template <bool LISTS>
@@ -637,7 +644,11 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
   // dependency seen, [2] products done, [3] tile in LDS, [4] factor + inverse done, [5] inverse published, [8] first 32 pivots, [9] rank-32 update, [10] last 32
   // pivots; the tile below it: [6] inverse seen, [7] tile published
   __shared__ double lds[2 * 64 * PVLM_TAIL_LD];                        // the k loop: As | Bs (64 x 65 each); afterwards As is the tile itself
+#if PVLM_FLOW_OCC2
+  double* Is = lds + 64 * PVLM_TAIL_LD;                                // the inverse of the diagonal block where Bs was (free after the source loop): 72 KB, two workgroups per CU
+#else
   __shared__ double Is[64 * PVLM_TAIL_LD];                             // the inverse of the diagonal block
+#endif
   __shared__ double ys[64], vs[64], rds[64];
   __shared__ double Ts[2][16][17];
   __shared__ int s_id, s_ok, s_fail;
@@ -953,7 +964,12 @@ __global__ __launch_bounds__(256) void k_nd_tail(double* __restrict__ M, int n, 
                                                  double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk) {
   nd_tile_flow<false>(M, n, r0, T, inv64, flags, info, b, yv, clk, nullptr, nullptr, 0);
 }
-__global__ __launch_bounds__(256) void k_nd_flow(double* __restrict__ M, int n, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
+#if PVLM_FLOW_OCC2
+__global__ __launch_bounds__(256, 2) void k_nd_flow(
+#else
+__global__ __launch_bounds__(256) void k_nd_flow(
+#endif
+                                                 double* __restrict__ M, int n, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
                                                  double* __restrict__ b, double* __restrict__ yv, const NdFlowTask* __restrict__ tasks,
                                                  const NdFlowSource* __restrict__ sources, int n_tasks, unsigned long long* __restrict__ clk) {
   nd_tile_flow<true>(M, n, 0, T, inv64, flags, info, b, yv, clk, tasks, sources, n_tasks);
