@@ -1295,6 +1295,8 @@ struct SpdPlan {
   // the whole factorisation as the tasks of one launch (k_nd_flow / k_nd_flow_bwd, pvlm_spd::plan_flow); flow_T = 0: levels (+ tail)
   int flow_T = 0, flow_tasks = 0, flow_depth = 0;
   bool flow_possible = false;                       // the host plan had a task list (whether or not this plan uses it: pvlm_spd_one_launch)
+  // the permuted index lists of the structure on the device, made by the first solve with this plan: the LM steps of a Solve change the values only
+  int* d_idx_rows = nullptr; int* d_idx_cols = nullptr; int* d_idx_mirror = nullptr; bool idx_on_device = false;
   NdFlowTask* d_flow_tasks = nullptr; NdFlowSource* d_flow_sources = nullptr; int* d_flow_cols = nullptr; int* d_flow_below_off = nullptr; int* d_flow_below = nullptr;
 };
 
@@ -1358,6 +1360,7 @@ static void spd_plan_free(pvlm_ctx* ctx, SpdPlan* p) {
   pvlm_i_free(ctx, p->d_cols); pvlm_i_free(ctx, p->d_row_off); pvlm_i_free(ctx, p->d_pwg); pvlm_i_free(ctx, p->d_pwt); pvlm_i_free(ctx, p->d_targets); pvlm_i_free(ctx, p->d_sources);
   pvlm_i_free(ctx, p->d_ftargets); pvlm_i_free(ctx, p->d_fsources);
   pvlm_i_free(ctx, p->d_tail_inv); pvlm_i_free(ctx, p->d_tail_flags);
+  pvlm_i_free(ctx, p->d_idx_rows); pvlm_i_free(ctx, p->d_idx_cols); pvlm_i_free(ctx, p->d_idx_mirror);
   pvlm_i_free(ctx, p->d_flow_tasks); pvlm_i_free(ctx, p->d_flow_sources); pvlm_i_free(ctx, p->d_flow_cols); pvlm_i_free(ctx, p->d_flow_below_off); pvlm_i_free(ctx, p->d_flow_below);
   delete p;
 }
@@ -1576,13 +1579,16 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     }
     if (plan->sparse) {
       const std::vector<int>& nw = plan->new_of_old;
-      prow.resize((size_t)n_blocks * 6); pcol.resize((size_t)n_blocks * 6);
-      for (size_t k = 0; k < prow.size(); ++k) { prow[k] = row_idx[k] >= 0 && row_idx[k] < n ? nw[(size_t)row_idx[k]] : -1; pcol[k] = col_idx[k] >= 0 && col_idx[k] < n ? nw[(size_t)col_idx[k]] : -1; }
+      if (!plan->idx_on_device) {
+        prow.resize((size_t)n_blocks * 6); pcol.resize((size_t)n_blocks * 6);
+        for (size_t k = 0; k < prow.size(); ++k) { prow[k] = row_idx[k] >= 0 && row_idx[k] < n ? nw[(size_t)row_idx[k]] : -1; pcol[k] = col_idx[k] >= 0 && col_idx[k] < n ? nw[(size_t)col_idx[k]] : -1; }
+      }
       // the level plan pads the system: dummy rows are identity rows (scale 1, diagonal 1, right-hand side 0 -> solution 0)
       const size_t np = plan->levels ? (size_t)plan->n_pad : (size_t)n;
       pscale.assign(np, 1.0); pdiag.assign(np, 1.0); prhs.assign(np, 0.0);
       for (int i = 0; i < n; ++i) { const size_t q = (size_t)nw[(size_t)i]; pscale[q] = scale[i]; pdiag[q] = diag_add[i]; prhs[q] = rhs[i]; }
-      row_idx = prow.data(); col_idx = pcol.data(); scale = pscale.data(); diag_add = pdiag.data();
+      if (!plan->idx_on_device) { row_idx = prow.data(); col_idx = pcol.data(); }
+      scale = pscale.data(); diag_add = pdiag.data();
     }
   } catch (const std::bad_alloc&) {
     PVLM_SET_ERR(ctx, "pvlm_spd_solve_blocks: out of host memory");
@@ -1611,9 +1617,22 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     // through the pinned arena (1.3 MB of blocks at Room scale, once per LM step: a pageable copy locks the caller's pages)
     if (e == hipSuccess && n_blocks) {
       st = pvlm_i_h2d_q(ctx, d_blocks, blocks, (size_t)n_blocks * 36 * sizeof(double));
-      if (!st) st = pvlm_i_h2d_q(ctx, d_row, row_idx, (size_t)n_blocks * 6 * sizeof(int));
-      if (!st) st = pvlm_i_h2d_q(ctx, d_col, col_idx, (size_t)n_blocks * 6 * sizeof(int));
-      if (!st) st = pvlm_i_h2d_q(ctx, d_mir, mirror, (size_t)n_blocks * sizeof(int));
+      if (plan->sparse && !plan->idx_on_device && !st) {
+        // the (permuted) index lists of this structure stay on the device with the plan: later solves send the values only
+        st = pvlm_i_alloc(ctx, &plan->d_idx_rows, (size_t)n_blocks * 6);
+        if (!st) st = pvlm_i_alloc(ctx, &plan->d_idx_cols, (size_t)n_blocks * 6);
+        if (!st) st = pvlm_i_alloc(ctx, &plan->d_idx_mirror, (size_t)n_blocks);
+        if (!st) st = pvlm_i_h2d_q(ctx, plan->d_idx_rows, row_idx, (size_t)n_blocks * 6 * sizeof(int));
+        if (!st) st = pvlm_i_h2d_q(ctx, plan->d_idx_cols, col_idx, (size_t)n_blocks * 6 * sizeof(int));
+        if (!st) st = pvlm_i_h2d_q(ctx, plan->d_idx_mirror, mirror, (size_t)n_blocks * sizeof(int));
+        if (!st) plan->idx_on_device = true;
+      }
+      if (plan->idx_on_device) { d_row = plan->d_idx_rows; d_col = plan->d_idx_cols; d_mir = plan->d_idx_mirror; }
+      else {
+        if (!st) st = pvlm_i_h2d_q(ctx, d_row, row_idx, (size_t)n_blocks * 6 * sizeof(int));
+        if (!st) st = pvlm_i_h2d_q(ctx, d_col, col_idx, (size_t)n_blocks * 6 * sizeof(int));
+        if (!st) st = pvlm_i_h2d_q(ctx, d_mir, mirror, (size_t)n_blocks * sizeof(int));
+      }
     }
     if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_scale, scale, (size_t)n * sizeof(double));
     if (e == hipSuccess && !st) st = pvlm_i_h2d_q(ctx, d_diag, diag_add, (size_t)n * sizeof(double));
