@@ -290,14 +290,15 @@ pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_
 /* The dense TAIL of that schedule.  The last group of the dissection (the top separator) is dense once everything below it is eliminated and every one of its block
  * columns is a level of its own; from eight such columns on they are factorised by ONE launch instead (a tile Cholesky in 64 x 64 tiles whose workgroups hand the
  * finished tiles to each other inside the launch; forward substitution inside it, backward substitution in a second launch).  *tail_block_columns = the block columns
- * done that way (0: none — PVLM_SPD_TAIL=0, no level schedule, or a short separator), *launched_levels = the levels that still run launch by launch.  Bit-reproducible
- * like the levels; last-bit differences against PVLM_SPD_TAIL=0 (another order of the same sums).  Any pointer may be NULL. */
+ * done that way (0: none — PVLM_SPD_TAIL=0, no level schedule, or a short separator), *launched_levels = the levels that still run launch by launch.  With the
+ * one-launch form of the whole factorisation (pvlm_spd_one_launch, the default) EVERY block column is done inside one launch: *tail_block_columns = all of them,
+ * *launched_levels = 0.  Bit-reproducible like the levels; last-bit differences against PVLM_SPD_TAIL=0 (another order of the same sums).  Any pointer may be NULL. */
 pvlm_status pvlm_spd_plan_tail(const pvlm_ctx* ctx, int* tail_block_columns, int* launched_levels);
 /* ONE LAUNCH for the whole tile-sparse factorisation (the default with a level schedule): every 64 x 64 tile of the factor is a task (its sources = the earlier tile
  * columns that hold both tiles; the sources of a tile that exist two levels ahead of it are split off into chunk tasks that subtract them from the tile in memory as
  * soon as they exist), tasks are ordered by dependency depth, workgroups take them by a ticket and hand finished tiles to each other inside the launch (payload stored
  * write-through, one flag per task); the forward substitution rides along and the backward substitution is a second launch over the tile columns.  Floor system: 278
- * dependent launches -> 2, 7.1 -> 3.4 ms per solve.  pvlm_spd_plan_tail then reports every block column as done inside one launch (launched_levels 0).
+ * dependent launches -> 2, 6.9 -> 3.15 ms per solve.  pvlm_spd_plan_tail then reports every block column as done inside one launch (launched_levels 0).
  * The workgroups of such a launch WAIT for each other, which presumes that the launch gets the GPU's workgroup slots: processes that share one GPU should switch it off
  * (enable = 0: level launches + the dense tail; enable < 0: no change, query only).  A solve whose launch does not get through within 2 s is redone with the level
  * launches by itself, the context keeps them from then on, and *fallbacks (may be NULL) counts such solves.  Both forms are bit-reproducible; they differ from each
