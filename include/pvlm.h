@@ -302,7 +302,9 @@ pvlm_status pvlm_spd_plan_tail(const pvlm_ctx* ctx, int* tail_block_columns, int
  * The workgroups of such a launch WAIT for each other, which presumes that the launch gets the GPU's workgroup slots: processes that share one GPU should switch it off
  * (enable = 0: level launches + the dense tail; enable < 0: no change, query only).  A solve whose launch does not get through within 2 s is redone with the level
  * launches by itself, the context keeps them from then on, and *fallbacks (may be NULL) counts such solves.  Both forms are bit-reproducible; they differ from each
- * other in the last bits (another order of the same sums) — ranks that must agree bit for bit use the same form. */
+ * other in the last bits (another order of the same sums) — ranks that must agree bit for bit use the same form.
+ * Test hook: enable = 2 + k makes task k of the one launch withhold its tile (what a launch that does not get through looks like): the next solve runs into the limit
+ * and exercises the recovery; tests/test_linalg_gpu.py. */
 pvlm_status pvlm_spd_one_launch(pvlm_ctx* ctx, int enable, long long* fallbacks);
 
 /* ---- multi-GPU exchange (RCCL over xGMI) -------------------------------------------------------- *

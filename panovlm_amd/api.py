@@ -327,7 +327,8 @@ class Context:
         """pvlm_spd_one_launch: enable / disable the one-launch form of the tile-sparse factorisation (None: query only); returns the number of solves this context has
         redone with the level launches."""
         fb = C.c_longlong()
-        self._check(self.lib.pvlm_spd_one_launch(self._h, C.c_int(-1 if enable is None else int(bool(enable))), C.byref(fb)), "pvlm_spd_one_launch")
+        self._check(self.lib.pvlm_spd_one_launch(self._h, C.c_int(-1 if enable is None else (int(enable) if isinstance(enable, int) and not isinstance(enable, bool) else int(bool(enable)))), C.byref(fb)),
+                    "pvlm_spd_one_launch")
         return fb.value
 
     def spd_plan(self):

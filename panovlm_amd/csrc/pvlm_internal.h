@@ -107,6 +107,7 @@ struct pvlm_ctx {
   void* spd_prefetch = nullptr;       // plan being made ahead on a host thread (pvlm_spd_plan_prefetch), joined and freed by pvlm_i_spd_plan_release
   long long spd_prefetch_hits = 0;    // solves that took their plan from a prefetch
   int spd_one_launch = 1;             // pvlm_spd_one_launch: 1 = the tile-sparse factorisation as ONE launch whose workgroups wait for each other (k_nd_flow), 0 = level launches
+  int spd_withhold_task = -1;         // test hook (pvlm_spd_one_launch(ctx, 2 + task, ..)): this task of the one launch never publishes its tile — the recovery path's test
   long long spd_fallbacks = 0;        // solves redone with the level launches because a wait inside the one launch ran into its limit (a GPU shared with other processes)
   // per-kernel profiling (pvlm_profile_*): pending (start, stop) event pairs per kernel class
   bool profiling = false;

@@ -639,7 +639,7 @@ struct NdFlowSource { int K, task_a, task_b, pad; };
 template <bool LISTS>
 __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int r0, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
                                              double* __restrict__ b, double* __restrict__ yv, unsigned long long* __restrict__ clk,
-                                             const NdFlowTask* __restrict__ tasks, const NdFlowSource* __restrict__ sources, int n_tasks) {
+                                             const NdFlowTask* __restrict__ tasks, const NdFlowSource* __restrict__ sources, int n_tasks, int withhold = -1) {
   // clk != nullptr (PVLM_SPD_TAIL_CLOCK=1): 100 MHz wall-clock stamps of the dependent chain, twelve per tile column — the diagonal tile: [0] ticket taken, [1] last
   // dependency seen, [2] products done, [3] tile in LDS, [4] factor + inverse done, [5] inverse published, [8] first 32 pivots, [9] rank-32 update, [10] last 32
   // pivots; the tile below it: [6] inverse seen, [7] tile published
@@ -765,7 +765,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
         if (diag && t < 64) tail_st(b + r0 + 64 * j + t, tail_ld(b + r0 + 64 * j + t) - bacc);
         tail_drain();
         __syncthreads();
-        if (t == 0) tail_raise(tile_flag + my_flag);
+        if (t == 0 && !(LISTS && s_id == withhold)) tail_raise(tile_flag + my_flag);
         continue;
       }
     } else {
@@ -809,7 +809,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
         for (int r = 0; r < 4; ++r) tail_st(M + (row_i + 16 * w + lk + 4 * r) * n + row_j + 16 * q + li, acc[q][r]);
       tail_drain();
       __syncthreads();
-      if (t == 0) tail_raise(tile_flag + my_flag);
+      if (t == 0 && !(LISTS && s_id == withhold)) tail_raise(tile_flag + my_flag);       // withhold: the test of the recovery path — this task never publishes
       WG_STATE(s_id, 9);
       if (stamp && (LISTS ? (s_id > 0 && tasks[s_id - 1].I == j && tasks[s_id - 1].J == j) : i == j + 1)) clk[12 * j + 7] = wall_clock64();
       continue;
@@ -944,7 +944,7 @@ __device__ __forceinline__ void nd_tile_flow(double* __restrict__ M, int n, int 
     for (int it = 0; it < 16; ++it) { const int e = t + 256 * it; tail_st(inv64 + (size_t)j * 4096 + e, Iv[e >> 6][e & 63]); }
     tail_drain();
     __syncthreads();
-    if (t == 0) tail_raise(inv_flag + j);
+    if (t == 0 && !(LISTS && s_id == withhold)) tail_raise(inv_flag + j);
     if (stamp) clk[12 * j + 5] = wall_clock64();
     // y_j = L_jj^-1 (b_j - sum_k L(j,k) y_k)
     if (t < 64) vs[t] = (LISTS ? tail_ld(b + r0 + 64 * j + t) : b[r0 + 64 * j + t]) - bacc;
@@ -971,8 +971,8 @@ __global__ __launch_bounds__(256) void k_nd_flow(
 #endif
                                                  double* __restrict__ M, int n, int T, double* __restrict__ inv64, unsigned* __restrict__ flags, int* __restrict__ info,
                                                  double* __restrict__ b, double* __restrict__ yv, const NdFlowTask* __restrict__ tasks,
-                                                 const NdFlowSource* __restrict__ sources, int n_tasks, unsigned long long* __restrict__ clk) {
-  nd_tile_flow<true>(M, n, 0, T, inv64, flags, info, b, yv, clk, tasks, sources, n_tasks);
+                                                 const NdFlowSource* __restrict__ sources, int n_tasks, unsigned long long* __restrict__ clk, int withhold) {
+  nd_tile_flow<true>(M, n, 0, T, inv64, flags, info, b, yv, clk, tasks, sources, n_tasks, withhold);
 }
 
 // Backward substitution of the tail: x_j = L_jj^-T (y_j - sum_{i > j} L(i,j)^T x_i), a workgroup per tile column (ticket order: j descending), the tile of the next
@@ -1450,7 +1450,7 @@ static void chol_factor_solve_levels(pvlm_ctx* ctx, int n, double* d_M, double* 
     if (want_clock && pvlm_i_alloc_bytes(ctx, (void**)&d_clk, (size_t)T * 12 * sizeof(unsigned long long)) != PVLM_OK) d_clk = nullptr;
     if (d_clk) (void)hipMemsetAsync(d_clk, 0, (size_t)T * 12 * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(k_nd_flow, dim3((unsigned)std::min(P->flow_tasks, 1024)), dim3(256), 0, s, d_M, n, T, P->d_tail_inv, P->d_tail_flags, d_info, d_b, d_y,
-                       (const NdFlowTask*)P->d_flow_tasks, (const NdFlowSource*)P->d_flow_sources, P->flow_tasks, d_clk);
+                       (const NdFlowTask*)P->d_flow_tasks, (const NdFlowSource*)P->d_flow_sources, P->flow_tasks, d_clk, ctx->spd_withhold_task);
     if (d_clk) {
       std::vector<unsigned long long> c((size_t)T * 12);
       if (hipMemcpyAsync(c.data(), d_clk, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
@@ -1742,6 +1742,7 @@ pvlm_status pvlm_spd_plan_schedule(const pvlm_ctx* ctx, int* levels, int* block_
 pvlm_status pvlm_spd_one_launch(pvlm_ctx* ctx, int enable, long long* fallbacks) {
   if (!ctx) return PVLM_ERR_ARG;
   if (enable >= 0) ctx->spd_one_launch = enable ? 1 : 0;
+  ctx->spd_withhold_task = enable >= 2 ? enable - 2 : -1;          // test hook: enable = 2 + task makes that task of the next one-launch solves withhold its tile
   if (fallbacks) *fallbacks = ctx->spd_fallbacks;
   return PVLM_OK;
 }

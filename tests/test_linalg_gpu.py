@@ -259,6 +259,36 @@ def test_factorisation_in_one_launch_and_the_dense_tail(P, degree):
     assert info_bt != 0
 
 
+def test_a_one_launch_solve_that_does_not_get_through_is_redone_with_the_level_launches():
+    """The recovery path of the one-launch factorisation: a task that never publishes its tile (the test hook of pvlm_spd_one_launch — what starvation on a GPU shared
+    by many processes looks like) makes every workgroup that needs it run into the 2 s limit; the library then redoes the SAME solve with the level launches, keeps
+    them for the context and counts the event.  The caller sees a correct solution and info 0."""
+    import time
+    import panovlm_amd as pv
+    rng = np.random.default_rng(77)
+    P = 700
+    pairs = _proximity_pairs(rng, P, 9)
+    n, rows, cols, mirror, blocks, scale, diag, rhs, M = _block_system(rng, P, pairs, constant={(0, 0), (0, 1)})
+    ctx = pv.Context(0)
+    x_flow, info = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert info == 0 and ctx.spd_plan()["launched_levels"] == 0 and ctx.spd_one_launch() == 0
+    ctx.spd_one_launch(2 + 40)                        # task 40: a tile of a leaf column that others need
+    t0 = time.perf_counter()
+    x, info = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    waited = time.perf_counter() - t0
+    plan = ctx.spd_plan()
+    assert info == 0 and ctx.spd_one_launch() == 1 and plan["launched_levels"] > 0, (info, plan)
+    assert 1.5 < waited < 30.0, waited
+    want = np.linalg.solve(M, rhs)
+    assert np.allclose(x, want, rtol=1e-9, atol=1e-12) and np.abs(x - x_flow).max() <= 1e-11 * max(1.0, np.abs(x_flow).max())
+    x2, info2 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)            # the context stays with the level launches
+    assert info2 == 0 and np.array_equal(x, x2) and ctx.spd_one_launch() == 1
+    assert ctx.spd_one_launch(True) == 1                                                      # and back, by hand
+    x3, info3 = ctx.spd_solve_blocks(n, rows, cols, mirror, blocks, scale, diag, rhs)
+    assert info3 == 0 and np.array_equal(x3, x_flow) and ctx.spd_plan()["launched_levels"] == 0
+    ctx.close()
+
+
 def test_plan_prefetch_is_a_hint_never_a_change_of_result():
     """pvlm_spd_plan_prefetch: the host half of the plan made on a thread of the library ahead of the solve.  Same lists: the solve takes it (hit counted) and returns the
     bits of a solve that planned for itself; other lists: the prefetch is dropped, the solve plans for itself; a second prefetch replaces the first; a context may end
