@@ -81,8 +81,13 @@ pvlm_status pvlm_device_info(pvlm_ctx* ctx, int* cu_count, int64_t* hbm_bytes, c
  * adds none).  Any pointer may be NULL.  PVLM_NO_POOL=1 in the environment bypasses the pool (debugging). */
 pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes);
 /* The pinned staging window of pvlm_scan_upload[_batch] (64 MB by default, PVLM_UPLOAD_STAGE_MB) is allocated by the first upload that needs it:
- * hipHostMalloc + first touch of 64 MB cost 25 ms.  A host that knows it will upload reserves the window at start-up.                          */
+ * hipHostMalloc + first touch of 64 MB cost 25 ms.  A host that knows it will upload reserves the window at start-up.  The same call allocates the
+ * 32 MB pinned arena every other small host <-> device copy of the context goes through (8 ms inside whichever call needs it first otherwise).      */
 pvlm_status pvlm_reserve_staging(pvlm_ctx* ctx, int64_t bytes);
+/* Loads the code objects of the library's kernels now (one empty launch per translation unit + a synchronisation).  HIP loads a code object at the first launch of
+ * one of its kernels — 5-20 ms each, ~60 ms for all of them — which otherwise lands inside the first call that needs it (the first EstimatePose of a process).  Like
+ * pvlm_reserve / pvlm_reserve_staging: once per context, after pvlm_create; never needed for correctness. */
+pvlm_status pvlm_preload(pvlm_ctx* ctx);
 pvlm_status pvlm_trim(pvlm_ctx* ctx);
 pvlm_status pvlm_mem_info(const pvlm_ctx* ctx, int64_t* reserved, int64_t* in_use, int64_t* peak, int64_t* device_allocs);
 /* HIP graph of a step: the calls issued between _begin and _end on this context (pvlm_set_poses_dev,
@@ -394,6 +399,15 @@ pvlm_status pvlm_scan_cloud_fetch(pvlm_ctx* ctx, const pvlm_scan* scan, int whic
  * max_dist get idx = -1 / sqd = +inf in the missing slots.  k <= 16. */
 pvlm_status pvlm_knn(pvlm_ctx* ctx, const pvlm_scan* scan, int which, const float* queries, int nq, int k,
                      float max_dist, int32_t* idx, float* sqd);
+
+/* The searches of FindNeighbors (lidar_mapping/LidarFeatureAssociate.cpp:19-111) for ALL scans at once.  Upstream builds a pcl::KdTreeFLANN over the scan centres
+ * (float32 PointXYZI) and asks, per scan, for nearestKSearch(neighbor_size) and radiusSearch(20 m) — both return ascending L2_Simple distances, ties in index order.
+ * Here: row i of the result = the positions j of all centres ordered by the 64-bit key (bits of the float32 squared distance ((dx*dx)+dy*dy)+dz*dz from centre i)
+ * << 32 | j, ascending — the first k entries of a row are the k nearest (the scan itself first), the entries whose distance lies below a squared radius are the radius
+ * search (the caller recomputes the distance of an entry it looks at: three multiply-adds).  One workgroup per row (distances + a bitonic sort in LDS).
+ * xyz: n x 3 floats (host); order: n x n positions (uint16, host, the caller's).  n <= 4096 (PVLM_ERR_CAPACITY beyond: the caller keeps its own search).  The set
+ * logic of FindNeighbors (loop closures, temporal neighbours) stays with the caller: it walks sorted rows. */
+pvlm_status pvlm_centre_orders(pvlm_ctx* ctx, int n, const float* xyz, uint16_t* order);
 
 /* AssociatePoint2Plane(ref, nei, plane_tolerance, dist_threshold) of
  * lidar_mapping/LidarFeatureAssociate.cpp:550-630 for a BATCH of ordered scan pairs

@@ -23,14 +23,14 @@ ABI_SYMBOLS = [
     "pvlm_eval_dev", "pvlm_eval_pair_blocks", "pvlm_eval_pair_blocks_dev", "pvlm_neq_create", "pvlm_neq_destroy",
     "pvlm_neq_size", "pvlm_neq_accumulate_dev", "pvlm_neq_accumulate", "pvlm_neq_accumulate_async", "pvlm_neq_accumulate_sets", "pvlm_resset_set_pose_ids", "pvlm_comm_unique_id", "pvlm_comm_create",
     "pvlm_comm_destroy", "pvlm_allreduce_sum_f64", "pvlm_scan_upload", "pvlm_scan_upload_batch", "pvlm_scan_destroy",
-    "pvlm_knn", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
+    "pvlm_knn", "pvlm_centre_orders", "pvlm_assoc_point2plane", "pvlm_assoc_point2plane_debug", "pvlm_line2line_votes",
     "pvlm_cam_to_image_f32", "pvlm_cam_to_image_f64", "pvlm_image_to_cam_f32", "pvlm_image_to_cam_f64",
     "pvlm_cam_lidar_votes", "pvlm_line2line_votes_batch", "pvlm_line2line_best_batch", "pvlm_cam_lidar_votes_batch", "pvlm_cam_lidar_votes_batch_sparse",
     "pvlm_cam_to_image_f32_dev", "pvlm_image_to_cam_f32_dev", "pvlm_project_lidar_depth", "pvlm_spd_solve", "pvlm_spd_solve_blocks", "pvlm_mvs_init_conf_map", "pvlm_mvs_filter_depth", "pvlm_mvs_filter_depth_refine", "pvlm_mvs_propagate", "pvlm_mvs_propagate_sequential", "pvlm_mvs_views_estimate_sequential", "pvlm_mvs_views_estimate_sequential_batch", "pvlm_mvs_views_create", "pvlm_mvs_views_destroy", "pvlm_mvs_views_upload", "pvlm_mvs_views_download",
     "pvlm_mvs_views_snapshot_depth", "pvlm_mvs_views_estimate", "pvlm_mvs_views_filter_refine",
     "pvlm_ba_create", "pvlm_ba_destroy", "pvlm_ba_structure", "pvlm_ba_packed_size", "pvlm_ba_get_points", "pvlm_ba_set_points", "pvlm_ba_set_constant",
     "pvlm_ba_eval", "pvlm_ba_reduce", "pvlm_ba_step", "pvlm_ba_cost", "pvlm_ba_accept",
-    "pvlm_reserve", "pvlm_reserve_staging", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
+    "pvlm_reserve", "pvlm_reserve_staging", "pvlm_preload", "pvlm_trim", "pvlm_mem_info", "pvlm_graph_begin", "pvlm_graph_end", "pvlm_graph_launch", "pvlm_graph_destroy",
     "pvlm_allreduce_sum_f64_host", "pvlm_host_alloc", "pvlm_host_free", "pvlm_eval_host_async", "pvlm_eval_wrench_host_async", "pvlm_eval_force_host_async", "pvlm_line2line_residuals", "pvlm_mvs_init_depth_normal", "pvlm_mvs_remove_small_segments", "pvlm_mvs_depth_to_cloud", "pvlm_mvs_views_depth_to_cloud",
     "pvlm_spd_plan_info", "pvlm_spd_plan_schedule", "pvlm_spd_plan_tail", "pvlm_spd_one_launch", "pvlm_spd_plan_prefetch", "pvlm_spd_plan_prefetch_hits", "pvlm_line_grow_batch", "pvlm_line_grow_begin", "pvlm_line_grow_finish", "pvlm_line_grow_scan", "pvlm_line_grow_destroy", "pvlm_ring_extract_batch", "pvlm_ring_extract_batch_picks", "pvlm_ring_debug_sort", "pvlm_undistort_batch", "pvlm_assoc_point2plane_stats", "pvlm_assoc_point2plane_stats2", "pvlm_scan_transform_batch", "pvlm_scan_set_pose", "pvlm_scan_cloud_info", "pvlm_scan_cloud_fetch", "pvlm_ring_batch_scan", "pvlm_ring_batch_fetch", "pvlm_ring_batch_timing", "pvlm_ring_batch_destroy",
 ]
@@ -322,6 +322,13 @@ class Context:
         h = C.c_longlong()
         self._check(self.lib.pvlm_spd_plan_prefetch_hits(self._h, C.byref(h)), "pvlm_spd_plan_prefetch_hits")
         return h.value
+
+    def centre_orders(self, xyz):
+        """pvlm_centre_orders: for every centre the positions of all centres ordered by (float squared distance, position) — (n, n) uint16."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3); n = len(xyz)
+        out = np.zeros((n, n), np.uint16)
+        self._check(self.lib.pvlm_centre_orders(self._h, C.c_int(n), _p(xyz, C.c_float), _p(out, C.c_uint16)), "pvlm_centre_orders")
+        return out
 
     def spd_one_launch(self, enable=None):
         """pvlm_spd_one_launch: enable / disable the one-launch form of the tile-sparse factorisation (None: query only); returns the number of solves this context has

@@ -749,7 +749,66 @@ static void slab_unref(pvlm_ctx* ctx, pvlm_scan_slab*& sl) {
   sl = nullptr;
 }
 
+// K28 — the searches of FindNeighbors for all scans: row i = the centres ordered by (float squared distance from centre i, position).  A workgroup per row: the keys of
+// the row in LDS (P = the next power of two >= n, the tail padded with ~0), a bitonic sort (P / 2 compare-exchanges per step, log2 P (log2 P + 1) / 2 steps), the
+// positions of the first n keys out (2 bytes each: 5 MB for the 1593 scans of Floor where the keys themselves are 20 — the caller recomputes a distance it needs).  The distance is the reference's float chain without contraction: ((dx*dx) + dy*dy) + dz*dz.
+template <int P>
+__global__ __launch_bounds__(1024) void k_centre_orders(int n, const float* __restrict__ xyz, unsigned short* __restrict__ order_out) {
+  __shared__ unsigned long long key[P];
+  const int i = blockIdx.x, t = threadIdx.x;
+  const float qx = xyz[3 * i], qy = xyz[3 * i + 1], qz = xyz[3 * i + 2];
+  for (int j = t; j < P; j += 1024) {
+    unsigned long long k = ~0ull;
+    if (j < n) {
+      const float dx = __fsub_rn(qx, xyz[3 * j]), dy = __fsub_rn(qy, xyz[3 * j + 1]), dz = __fsub_rn(qz, xyz[3 * j + 2]);
+      float s2 = __fmul_rn(dx, dx);
+      s2 = __fadd_rn(s2, __fmul_rn(dy, dy));
+      s2 = __fadd_rn(s2, __fmul_rn(dz, dz));
+      k = ((unsigned long long)__float_as_uint(s2) << 32) | (unsigned)j;
+    }
+    key[j] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int p = t; p < P / 2; p += 1024) {
+        const int lo = 2 * p - (p & (stride - 1));          // the lower partner of the p-th pair of this step
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = key[lo], b = key[hi];
+        if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int j = t; j < n; j += 1024) order_out[(size_t)i * n + j] = (unsigned short)(key[j] & 0xffffu);     // the positions in key order: 2 bytes each (n <= 4096)
+}
+
 extern "C" {
+
+pvlm_status pvlm_centre_orders(pvlm_ctx* ctx, int n, const float* xyz, uint16_t* order) {
+  if (!ctx || n < 0 || (n > 0 && (!xyz || !order))) return PVLM_ERR_ARG;
+  if (n == 0) return PVLM_OK;
+  if (n > 4096) { PVLM_SET_ERR(ctx, "pvlm_centre_orders: %d centres (at most 4096)", n); return PVLM_ERR_CAPACITY; }
+  for (int j = 0; j < 3 * n; ++j) if (!(xyz[j] == xyz[j]) || std::isinf(xyz[j])) { PVLM_SET_ERR(ctx, "pvlm_centre_orders: a centre is not finite"); return PVLM_ERR_ARG; }
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  const size_t bytes = (size_t)n * n * sizeof(unsigned short);
+  float* d_xyz = nullptr; unsigned short* d_keys = nullptr;
+  pvlm_status st = pvlm_i_alloc(ctx, &d_xyz, (size_t)3 * n);
+  if (!st) st = pvlm_i_alloc(ctx, &d_keys, (size_t)n * n);
+  if (!st) st = pvlm_i_h2d_q(ctx, d_xyz, xyz, (size_t)3 * n * sizeof(float));
+  if (!st) {
+    int P = 64; while (P < n) P <<= 1;
+    if (P <= 1024) hipLaunchKernelGGL(k_centre_orders<1024>, dim3((unsigned)n), dim3(1024), 0, ctx->stream, n, (const float*)d_xyz, d_keys);
+    else if (P == 2048) hipLaunchKernelGGL(k_centre_orders<2048>, dim3((unsigned)n), dim3(1024), 0, ctx->stream, n, (const float*)d_xyz, d_keys);
+    else hipLaunchKernelGGL(k_centre_orders<4096>, dim3((unsigned)n), dim3(1024), 0, ctx->stream, n, (const float*)d_xyz, d_keys);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { PVLM_SET_ERR(ctx, "pvlm_centre_orders: %s", hipGetErrorString(e)); st = PVLM_ERR_HIP; }
+    if (!st) st = pvlm_i_d2h_q(ctx, order, d_keys, bytes);        // through the context's pinned arena: no buffer of its own to allocate (hipHostMalloc of 5 MB: 10 ms)
+  }
+  { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
+  pvlm_i_free(ctx, d_xyz); pvlm_i_free(ctx, d_keys);
+  return st;
+}
 
 pvlm_status pvlm_scan_upload(pvlm_ctx* ctx, const pvlm_scan_desc* d, pvlm_scan** out) { return pvlm_scan_upload_batch(ctx, 1, d, out); }
 
@@ -1415,3 +1474,8 @@ pvlm_status pvlm_assoc_point2plane_debug(pvlm_ctx* ctx, const pvlm_resset* rs, i
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_assoc() {}
+void pvlm_i_preload_assoc(hipStream_t s) { hipLaunchKernelGGL(k_preload_assoc, dim3(1), dim3(1), 0, s); }

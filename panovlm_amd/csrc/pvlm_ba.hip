@@ -485,3 +485,8 @@ pvlm_status pvlm_ba_accept(pvlm_ctx* ctx, pvlm_baset* set) {
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_ba() {}
+void pvlm_i_preload_ba(hipStream_t s) { hipLaunchKernelGGL(k_preload_ba, dim3(1), dim3(1), 0, s); }

@@ -374,9 +374,34 @@ pvlm_status pvlm_reserve(pvlm_ctx* ctx, int64_t bytes) {
   return PVLM_OK;
 }
 
+__global__ void k_preload_ctx() {}
+pvlm_status pvlm_preload(pvlm_ctx* ctx) {
+  if (!ctx) return PVLM_ERR_ARG;
+  if (ctx->capturing) return PVLM_ERR_STATE;
+  if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  hipLaunchKernelGGL(k_preload_ctx, dim3(1), dim3(1), 0, ctx->stream);
+  pvlm_i_preload_assoc(ctx->stream);
+  pvlm_i_preload_ba(ctx->stream);
+  pvlm_i_preload_eval(ctx->stream);
+  pvlm_i_preload_linalg(ctx->stream);
+  pvlm_i_preload_linegrow(ctx->stream);
+  pvlm_i_preload_lines(ctx->stream);
+  pvlm_i_preload_mvs(ctx->stream);
+  pvlm_i_preload_ring(ctx->stream);
+  pvlm_i_preload_undistort(ctx->stream);
+  PVLM_HIP(ctx, hipGetLastError());
+  PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PVLM_OK;
+}
+
 pvlm_status pvlm_reserve_staging(pvlm_ctx* ctx, int64_t bytes) {
   if (!ctx || bytes < 0) return PVLM_ERR_ARG;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
+  // the arena of the small copies as well (32 MB of pinned memory, allocated at its first use otherwise: 8 ms inside whichever call comes first)
+  if (bytes > 0 && !ctx->stage.base && !ctx->capturing) {
+    if (hipHostMalloc((void**)&ctx->stage.base, kStageBytes, hipHostMallocDefault) == hipSuccess) { ctx->stage.size = kStageBytes; std::memset(ctx->stage.base, 0, kStageBytes); }
+    else { ctx->stage.base = nullptr; (void)hipGetLastError(); }          // stage_take tries again (and has its own fall-back)
+  }
   if ((size_t)bytes <= ctx->up_bytes) return PVLM_OK;
   PVLM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);

@@ -964,3 +964,8 @@ pvlm_status pvlm_neq_accumulate_sets(pvlm_ctx* ctx, int n, pvlm_neq* const* neq,
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_eval() {}
+void pvlm_i_preload_eval(hipStream_t s) { hipLaunchKernelGGL(k_preload_eval, dim3(1), dim3(1), 0, s); }

@@ -270,6 +270,15 @@ pvlm_status pvlm_i_h2d(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 pvlm_status pvlm_i_d2h(pvlm_ctx* ctx, void* dst, const void* src, size_t bytes);
 void pvlm_i_assoc_ws_free(pvlm_ctx* ctx);
 void pvlm_i_spd_plan_release(pvlm_ctx* ctx);
+void pvlm_i_preload_assoc(hipStream_t s);
+void pvlm_i_preload_ba(hipStream_t s);
+void pvlm_i_preload_eval(hipStream_t s);
+void pvlm_i_preload_linalg(hipStream_t s);
+void pvlm_i_preload_linegrow(hipStream_t s);
+void pvlm_i_preload_lines(hipStream_t s);
+void pvlm_i_preload_mvs(hipStream_t s);
+void pvlm_i_preload_ring(hipStream_t s);
+void pvlm_i_preload_undistort(hipStream_t s);
 // builds work list + scratch for a resset whose segment table is final (h_* mirrors filled)
 pvlm_status pvlm_i_resset_finalize(pvlm_ctx* ctx, pvlm_resset* rs);
 pvlm_status pvlm_i_resset_free(pvlm_ctx* ctx, pvlm_resset* rs);

@@ -1800,3 +1800,8 @@ pvlm_status pvlm_spd_solve(pvlm_ctx* ctx, int n, int nrhs, const double* A, doub
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_linalg() {}
+void pvlm_i_preload_linalg(hipStream_t s) { hipLaunchKernelGGL(k_preload_linalg, dim3(1), dim3(1), 0, s); }

@@ -363,3 +363,8 @@ pvlm_status pvlm_line_grow_destroy(pvlm_ctx* ctx, pvlm_line_grow* g) {
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_linegrow() {}
+void pvlm_i_preload_linegrow(hipStream_t s) { hipLaunchKernelGGL(k_preload_linegrow, dim3(1), dim3(1), 0, s); }

@@ -1269,3 +1269,8 @@ pvlm_status pvlm_cam_lidar_votes(pvlm_ctx* ctx, int rows, int cols, const float*
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_lines() {}
+void pvlm_i_preload_lines(hipStream_t s) { hipLaunchKernelGGL(k_preload_lines, dim3(1), dim3(1), 0, s); }

@@ -1898,3 +1898,8 @@ pvlm_status pvlm_mvs_views_filter_refine(pvlm_ctx* ctx, pvlm_mvs_views* v, int r
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_mvs() {}
+void pvlm_i_preload_mvs(hipStream_t s) { hipLaunchKernelGGL(k_preload_mvs, dim3(1), dim3(1), 0, s); }

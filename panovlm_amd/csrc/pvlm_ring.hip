@@ -961,3 +961,8 @@ pvlm_status pvlm_ring_batch_fetch(pvlm_ctx* ctx, const pvlm_ring_batch* b, int s
 }
 
 }  // extern "C"
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_ring() {}
+void pvlm_i_preload_ring(hipStream_t s) { hipLaunchKernelGGL(k_preload_ring, dim3(1), dim3(1), 0, s); }

@@ -107,3 +107,8 @@ extern "C" pvlm_status pvlm_undistort_batch(pvlm_ctx* ctx, int n_scans, const pv
     return PVLM_ERR_NOMEM;
   }
 }
+
+// pvlm_preload: HIP loads the code object of a translation unit at the first launch of one of its kernels (15 ms for the larger ones) — an empty launch from here
+// moves that out of the first call that needs this file's kernels
+__global__ void k_preload_undistort() {}
+void pvlm_i_preload_undistort(hipStream_t s) { hipLaunchKernelGGL(k_preload_undistort, dim3(1), dim3(1), 0, s); }

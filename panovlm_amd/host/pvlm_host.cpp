@@ -28,6 +28,10 @@ Engine::Engine(int device) {
   // association of the process otherwise)
   if (const char* mb = std::getenv("PVLM_HOST_RESERVE_STAGING_MB"))
     if (std::atof(mb) > 0) Check(pvlm_reserve_staging(ctx_, (int64_t)(std::atof(mb) * 1048576.0)), "pvlm_reserve_staging");
+  // PVLM_HOST_PRELOAD=1: likewise the code objects of the library's kernels (HIP loads one at the first launch of a kernel of its file: ~60 ms spread over the first
+  // EstimatePose of the process otherwise)
+  if (const char* on = std::getenv("PVLM_HOST_PRELOAD"))
+    if (std::atoi(on) > 0) Check(pvlm_preload(ctx_), "pvlm_preload");
 }
 Engine::~Engine() { if (ctx_) pvlm_destroy(ctx_); }
 Engine& Engine::Default() {

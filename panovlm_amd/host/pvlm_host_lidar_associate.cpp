@@ -30,6 +30,26 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
     owner.push_back((int)i);
   }
   const int nc = (int)owner.size();
+  // The distances and their order — the two searches of every scan — on the GPU for all scans at once (K28, pvlm_centre_orders: a row of sorted (distance, position)
+  // keys per centre, the same keys the loop below builds and sorts) when the queries are the centres themselves: every scan with a valid pose is a valid scan, as
+  // EstimatePose leaves them.  Fewer than PVLM_NEIGHBORS_GPU_MIN scans, more than 4096 or a pose that is valid on an invalid scan: the host's own distance loop and sort.
+  const uint16_t* rows = nullptr;
+  std::vector<uint16_t> row_store;
+  std::vector<int> position((size_t)lidars.size(), -1);
+  {
+    // from PVLM_NEIGHBORS_GPU_MIN scans on (default 2048): the host's sort of 1593 keys per scan on 16 threads takes as long as the launch, its copies and the
+    // first-use costs they meet in a fresh process (Floor: 5.9 against 6.1 ms per call); the host's share grows with n^2 log n (37 ms at 4000 scans), the launch's does not
+    static const int gpu_min = [] { const char* v = std::getenv("PVLM_NEIGHBORS_GPU_MIN"); return v ? std::atoi(v) : 2048; }();
+    bool same_sets = nc >= gpu_min && nc > 0;
+    for (size_t i = 0; i < lidars.size() && same_sets; ++i) if (lidars[i].IsPoseValid() && !lidars[i].valid) same_sets = false;
+    for (int j = 0; j < nc; ++j) position[(size_t)owner[(size_t)j]] = j;
+    if (same_sets) {
+      Engine& e = Engine::Default();
+      row_store.resize((size_t)nc * (size_t)nc);
+      const pvlm_status st = pvlm_centre_orders(e.ctx(), nc, &center[0][0], row_store.data());
+      if (st != PVLM_ERR_CAPACITY) { e.Check(st, "pvlm_centre_orders"); rows = row_store.data(); }
+    }
+  }
   // every scan's list is independent of the others: scan-parallel (at Floor size — 1593 scans, all inside the 20 m radius of the
   // synthetic room — the serial loop was 0.1 s per call, four calls per EstimatePose)
   neighbors_all.assign(lidars.size(), std::vector<int>());
@@ -40,18 +60,31 @@ std::vector<std::vector<int>> FindNeighbors(const std::vector<Velodyne>& lidars,
       const float q[3] = {float(t[0]), float(t[1]), float(t[2])};
       // (squared distance, position) pairs sorted as one 64-bit word each: the distances are sums of squares (never negative, a NaN centre is no valid
       // pose), so their bit patterns order like the floats, and equal distances fall back to the position as the pair comparison did
-      std::vector<uint64_t> keys((size_t)nc);
-      for (int j = 0; j < nc; ++j) {
-        const float dx = q[0] - center[j][0], dy = q[1] - center[j][1], dz = q[2] - center[j][2];
-        float s = 0.0f; s += dx * dx; s += dy * dy; s += dz * dz;
-        uint32_t bits; std::memcpy(&bits, &s, 4);
-        keys[(size_t)j] = ((uint64_t)bits << 32) | (uint32_t)j;
+      std::vector<uint64_t> own_keys;
+      const uint16_t* order = rows ? rows + (size_t)position[i] * (size_t)nc : nullptr;
+      if (!order) {
+        own_keys.resize((size_t)nc);
+        for (int j = 0; j < nc; ++j) {
+          const float dx = q[0] - center[j][0], dy = q[1] - center[j][1], dz = q[2] - center[j][2];
+          float s = 0.0f; s += dx * dx; s += dy * dy; s += dz * dz;
+          uint32_t bits; std::memcpy(&bits, &s, 4);
+          own_keys[(size_t)j] = ((uint64_t)bits << 32) | (uint32_t)j;
+        }
+        // one sorted list serves both searches below: nearestKSearch (its first neighbor_size entries) and radiusSearch (its
+        // prefix within 20 m, also ascending) — ties in pcl's order = position
+        std::sort(own_keys.begin(), own_keys.end());
       }
-      // one sorted list serves both searches below: nearestKSearch (its first neighbor_size entries) and radiusSearch (its
-      // prefix within 20 m, also ascending) — ties in pcl's order = position
-      std::sort(keys.begin(), keys.end());
       std::vector<std::pair<float, int>> d((size_t)nc);
-      for (int j = 0; j < nc; ++j) { const uint32_t bits = (uint32_t)(keys[(size_t)j] >> 32); float s; std::memcpy(&s, &bits, 4); d[(size_t)j] = {s, (int)(uint32_t)keys[(size_t)j]}; }
+      if (order) {
+        // the device's row holds the positions in key order; the distance of an entry by the same float chain as above
+        for (int j = 0; j < nc; ++j) {
+          const int c = (int)order[(size_t)j];
+          const float dx = q[0] - center[(size_t)c][0], dy = q[1] - center[(size_t)c][1], dz = q[2] - center[(size_t)c][2];
+          float s = 0.0f; s += dx * dx; s += dy * dy; s += dz * dz;
+          d[(size_t)j] = {s, c};
+        }
+      } else
+        for (int j = 0; j < nc; ++j) { const uint32_t bits = (uint32_t)(own_keys[(size_t)j] >> 32); float s; std::memcpy(&s, &bits, 4); d[(size_t)j] = {s, (int)(uint32_t)own_keys[(size_t)j]}; }
       for (int j = 0; j < std::min(neighbor_size, nc); ++j) neighbors.push_back(d[j].second);
       if (!neighbors.empty()) neighbors.erase(neighbors.begin());  // the first one is the scan itself
       for (int& n : neighbors) n = owner[n];

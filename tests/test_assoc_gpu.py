@@ -288,3 +288,31 @@ def test_knn_results_larger_than_the_staging_arena(ctx, oracle):
     ib, db = ctx.knn(scan, big, 10, 1.0)
     assert np.array_equal(ib[:len(q)], idx) and np.array_equal(ib[len(q):], idx) and np.array_equal(db[:len(q)], sqd)
     scan.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 37, 1024, 1593, 2500])
+def test_centre_orders_are_the_sorted_distance_keys_of_find_neighbors(n):
+    """K28 pvlm_centre_orders — the two searches of FindNeighbors (lidar_mapping/LidarFeatureAssociate.cpp:19-111: nearestKSearch + radiusSearch over the scan centres)
+    for all scans at once: row i = the positions j ordered by the key (bits of the float32 squared distance ((dx*dx)+dy*dy)+dz*dz from centre i) << 32 | j.  Bit-exact against the
+    same float chain in numpy, ties (coincident centres) in index order; the row's first key is the scan itself."""
+    import panovlm_amd as pv
+    rng = np.random.default_rng(n)
+    xyz = rng.uniform(-15, 15, size=(n, 3)).astype(np.float32)
+    if n > 40:
+        xyz[7] = xyz[3]; xyz[n - 1] = xyz[3]          # coincident centres: equal distances, the position decides
+    ctx = pv.Context(0)
+    keys = ctx.centre_orders(xyz)
+    assert keys.shape == (n, n) and keys.dtype == np.uint16
+    for i in sorted(set([0, 3 % n, 7 % n, n // 2, n - 1])):
+        d = xyz[i][None, :] - xyz
+        s = (d[:, 0] * d[:, 0]).astype(np.float32)
+        s = (s + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+        s = (s + (d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+        want = np.sort((s.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64))
+        assert np.array_equal(keys[i], (want & np.uint64(0xffff)).astype(np.uint16)), i
+        assert s[int(keys[i][0])] == 0                                    # distance zero first ...
+    again = ctx.centre_orders(xyz)
+    assert np.array_equal(keys, again)
+    with pytest.raises(Exception):
+        ctx.centre_orders(np.zeros((5000, 3), np.float32))                # beyond the kernel's bound: the caller keeps its own search
+    ctx.close()

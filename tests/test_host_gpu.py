@@ -64,6 +64,32 @@ def test_find_neighbors_and_point2plane(oracle, tmp):
         assert np.array_equal(got[:, :3], o["point"]) and np.array_equal(got[:, 3:], o["plane"])
 
 
+def test_find_neighbors_with_the_searches_on_the_gpu(oracle, tmp, monkeypatch):
+    """FindNeighbors with its two searches (nearestKSearch + radiusSearch over the scan centres) on the GPU (K28, pvlm_centre_orders: what the mirror does from
+    PVLM_NEIGHBORS_GPU_MIN scans on) against the host's own distance loop and sort and against the oracle: the same lists, for 6 and for 4 neighbours, with scans far
+    apart (radius search cut off), scans on top of each other (equal distances: the position decides) and loop closures."""
+    rng = np.random.default_rng(5)
+    scans = []
+    for k in range(260):
+        s = _vlp(k % 7, 64)
+        t = np.array([0.1 * k, 3.0 * np.sin(0.04 * k), 0.02 * k]) if k < 225 else np.array([0.1 * (k - 224) + 0.01, 3.0 * np.sin(0.04 * (k - 224)), 0.0])   # the last 35 revisit the start, more than loop_length = 200 scans later
+        if k in (11, 12): t = np.array([4.0, 1.0, 0.5])                   # coincident centres
+        if k == 40: t = np.array([500.0, 0.0, 0.0])                       # out of every radius
+        s = dict(s, id=k, t_wl=t.astype(np.float64))
+        scans.append(s)
+    path = os.path.join(tmp, "scans_nb.bin")
+    host_io.write_scans(path, scans)
+    poses = np.array([np.concatenate([s["R_wl"].reshape(-1), s["t_wl"]]) for s in scans])
+    for k in (6, 4):
+        want = oracle.find_neighbors(poses, np.ones(len(scans), np.int32), k)
+        monkeypatch.setenv("PVLM_NEIGHBORS_GPU_MIN", "1")
+        on_gpu = [[int(v) for v in l.split()[2:]] for l in host_io.run("neighbors", path, k)]
+        monkeypatch.setenv("PVLM_NEIGHBORS_GPU_MIN", "100000")
+        on_host = [[int(v) for v in l.split()[2:]] for l in host_io.run("neighbors", path, k)]
+        assert on_gpu == on_host == want
+        assert any(abs(v - i) > 200 for i, l in enumerate(want) for v in l), "no loop closure in the test trajectory"
+
+
 def _line_scans(rng, n, pose_offset=2):
     lines = synth.random_world_lines(rng, 10)
     out = []

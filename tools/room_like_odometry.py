@@ -66,6 +66,7 @@ def main():
         host_io.write_scans(path, scans, world=False)
         os.environ.setdefault("PVLM_HOST_RESERVE_MB", "1536")       # the engine's pool, sized once at context creation
         os.environ.setdefault("PVLM_HOST_RESERVE_STAGING_MB", "64")  # ... and the pinned staging window of the scan uploads
+        os.environ.setdefault("PVLM_HOST_PRELOAD", "1")             # ... and the code objects of the kernels (pvlm_preload)
         t0 = time.perf_counter()
         out = host_io.run("odometry", path, a.iters, 1, 1, 1 if a.lines else 0, 1, 0.05, 1.0, 0.3, timeout=3000)
         wall = time.perf_counter() - t0
