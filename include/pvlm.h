@@ -303,7 +303,7 @@ pvlm_status pvlm_spd_plan_tail(const pvlm_ctx* ctx, int* tail_block_columns, int
  * columns that hold both tiles; the sources of a tile that exist two levels ahead of it are split off into chunk tasks that subtract them from the tile in memory as
  * soon as they exist), tasks are ordered by dependency depth, workgroups take them by a ticket and hand finished tiles to each other inside the launch (payload stored
  * write-through, one flag per task); the forward substitution rides along and the backward substitution is a second launch over the tile columns.  Floor system: 278
- * dependent launches -> 2, 6.9 -> 3.15 ms per solve.  pvlm_spd_plan_tail then reports every block column as done inside one launch (launched_levels 0).
+ * dependent launches -> 2, 6.9 -> 3.2 ms per solve.  pvlm_spd_plan_tail then reports every block column as done inside one launch (launched_levels 0).
  * The workgroups of such a launch WAIT for each other, which presumes that the launch gets the GPU's workgroup slots: processes that share one GPU should switch it off
  * (enable = 0: level launches + the dense tail; enable < 0: no change, query only).  A solve whose launch does not get through within 2 s is redone with the level
  * launches by itself, the context keeps them from then on, and *fallbacks (may be NULL) counts such solves.  Both forms are bit-reproducible; they differ from each
