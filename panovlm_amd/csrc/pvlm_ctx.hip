@@ -318,6 +318,7 @@ pvlm_status pvlm_destroy(pvlm_ctx* ctx) {
   if (ctx->grow_stream) hipStreamSynchronize(ctx->grow_stream);      // a line growth begun and never finished: its kernels end before its blocks go
   pvlm_i_assoc_ws_free(ctx);
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+  if (ctx->host_spare) (void)hipHostFree(ctx->host_spare);
   if (ctx->h_grid) (void)hipHostFree(ctx->h_grid);
   for (int k = 0; k < ctx->ring_pool; ++k) (void)hipHostFree(ctx->h_ring[k]);
   pvlm_i_spd_plan_release(ctx);

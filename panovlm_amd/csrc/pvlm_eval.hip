@@ -809,7 +809,18 @@ pvlm_status pvlm_host_alloc(pvlm_ctx* ctx, int64_t bytes, void** out) {
   if (!ctx || !out || bytes < 0) return PVLM_ERR_ARG;
   *out = nullptr;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
-  PVLM_HIP(ctx, hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault));
+  const size_t want = (size_t)std::max<int64_t>(bytes, 1);
+  try {
+    if (ctx->host_spare && ctx->host_spare_bytes >= want && ctx->host_spare_bytes <= 2 * want + 4096) {       // the block the last pvlm_host_free left behind
+      *out = ctx->host_spare;
+      ctx->host_live.push_back({ctx->host_spare, ctx->host_spare_bytes});
+      ctx->host_spare = nullptr; ctx->host_spare_bytes = 0;
+      return PVLM_OK;
+    }
+    ctx->host_live.reserve(ctx->host_live.size() + 1);
+  } catch (const std::bad_alloc&) { return PVLM_ERR_NOMEM; }
+  PVLM_HIP(ctx, hipHostMalloc(out, want, hipHostMallocDefault));
+  ctx->host_live.push_back({*out, want});
   return PVLM_OK;
 }
 
@@ -818,6 +829,14 @@ pvlm_status pvlm_host_free(pvlm_ctx* ctx, void* p) {
   if (!p) return PVLM_OK;
   if (pvlm_i_bind(ctx)) return PVLM_ERR_HIP;
   PVLM_TRY_SYNC(ctx);
+  size_t bytes = 0;
+  for (size_t k = 0; k < ctx->host_live.size(); ++k)
+    if (ctx->host_live[k].first == p) { bytes = ctx->host_live[k].second; ctx->host_live[k] = ctx->host_live.back(); ctx->host_live.pop_back(); break; }
+  if (bytes > 0 && bytes <= ((size_t)64 << 20)) {                  // kept for the next allocation of about this size; the previous spare goes
+    if (ctx->host_spare) PVLM_HIP(ctx, hipHostFree(ctx->host_spare));
+    ctx->host_spare = p; ctx->host_spare_bytes = bytes;
+    return PVLM_OK;
+  }
   PVLM_HIP(ctx, hipHostFree(p));
   return PVLM_OK;
 }

@@ -106,6 +106,9 @@ struct pvlm_ctx {
   void* spd_plan = nullptr;           // tile-sparse plan of the last pvlm_spd_solve_blocks structure (csrc/pvlm_linalg.hip), freed by pvlm_i_spd_plan_release
   void* spd_prefetch = nullptr;       // plan being made ahead on a host thread (pvlm_spd_plan_prefetch), joined and freed by pvlm_i_spd_plan_release
   long long spd_prefetch_hits = 0;    // solves that took their plan from a prefetch
+  // pvlm_host_alloc / pvlm_host_free: the sizes of the live blocks and ONE freed block kept for the next allocation (the LM driver takes a pinned landing buffer of the
+  // same size per Solve: hipHostMalloc + hipHostFree of it cost 2-3 ms each time)
+  std::vector<std::pair<void*, size_t>> host_live; void* host_spare = nullptr; size_t host_spare_bytes = 0;
   int spd_one_launch = 1;             // pvlm_spd_one_launch: 1 = the tile-sparse factorisation as ONE launch whose workgroups wait for each other (k_nd_flow), 0 = level launches
   int spd_withhold_task = -1;         // test hook (pvlm_spd_one_launch(ctx, 2 + task, ..)): this task of the one launch never publishes its tile — the recovery path's test
   long long spd_fallbacks = 0;        // solves redone with the level launches because a wait inside the one launch ran into its limit (a GPU shared with other processes)
