@@ -1324,7 +1324,8 @@ static void spd_plan_host(int n, int n_blocks, const int* row_idx, const int* co
   static const bool want_levels = !(getenv("PVLM_SPD_LEVELS") && atoi(getenv("PVLM_SPD_LEVELS")) == 0);
   if (want_levels) {
     static const int leaf = getenv("PVLM_SPD_LEAF") ? std::max(1, atoi(getenv("PVLM_SPD_LEAF"))) : 42;      // nodes per undissected group (42 poses = 252 rows = 4 tiles)
-    pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, leaf, &H->L);
+    static const int flow_chunk = getenv("PVLM_SPD_FLOW_CHUNK") ? std::max(0, atoi(getenv("PVLM_SPD_FLOW_CHUNK"))) : 12;      // sources per chunk task of the one launch (0: no chunks)
+    pvlm_spd::plan_levels(n, n_blocks, row_idx, col_idx, PVLM_CHOL_NB, leaf, &H->L, flow_chunk);
     static const double max_pad = getenv("PVLM_SPD_MAX_PAD") ? atof(getenv("PVLM_SPD_MAX_PAD")) : 1.6;
     // adopted when it shortens the chain of dependent launches by a third at least and the padding stays bounded
     if (H->L.ordered && H->L.levels * 3 <= H->L.cols_total * 2 + 2 && (double)H->L.n_pad <= max_pad * (double)n + 256.0) { H->kind = 1; H->update_fraction = H->L.update_fraction; return; }
