@@ -1656,7 +1656,10 @@ pvlm_status pvlm_spd_solve_blocks(pvlm_ctx* ctx, int n, int n_blocks, const int*
     { const pvlm_status s2 = pvlm_i_sync(ctx); if (!st) st = s2; }
     if (!st && info == -1) {                       // a wait inside the one-launch factorisation ran into its limit: say where (the step is reported as failed)
       unsigned w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_tail_timeout), sizeof w) == hipSuccess)
+      const unsigned zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bool got = hipMemcpyFromSymbol(w, HIP_SYMBOL(g_tail_timeout), sizeof w) == hipSuccess;
+      if (got) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_timeout), zero8, sizeof zero8);        // the next event records its own site
+      if (got)
       {
         fprintf(stderr, "pvlm_spd_solve_blocks: a wait of the one-launch factorisation ran into its limit (site %u, task / ticket %u, flag word %u of %d tasks + 3 x %d, tickets %u / %u, workgroup %u)\n",
                 w[1], w[2], w[3], plan->flow_tasks, plan->flow_T, w[4], w[5], w[6]);
